@@ -1,0 +1,7 @@
+import os, sys, pytest
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "needs_ref: needs oracle/_ref/*.so (the compiled reference)")

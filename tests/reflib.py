@@ -1,0 +1,32 @@
+"""tests/reflib.py — loaders for the checker libraries (TEST INFRASTRUCTURE).
+
+ref_fx()    : unmodified reference, fixed-point build (oracle/_ref/libopus_ref_fx.so)
+ref_expose(): wrappers reaching reference statics (oracle/_ref/libref_expose_fx.so)
+oracle()    : this repo's plain-C restatement (oracle/libcelt_oracle.so)
+"""
+import ctypes, os, functools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def _load(rel, mode=ctypes.RTLD_LOCAL):
+    p = os.path.join(ROOT, rel)
+    if not os.path.exists(p):
+        return None
+    return ctypes.CDLL(p, mode=mode)
+
+@functools.lru_cache(None)
+def ref_fx():
+    # RTLD_GLOBAL so libref_expose_fx.so (linked against it) resolves to the same copy
+    return _load("oracle/_ref/libopus_ref_fx.so", ctypes.RTLD_GLOBAL)
+
+@functools.lru_cache(None)
+def ref_fl():
+    return _load("oracle/_ref/libopus_ref_fl.so")
+
+@functools.lru_cache(None)
+def ref_expose():
+    ref_fx()
+    return _load("oracle/_ref/libref_expose_fx.so")
+
+@functools.lru_cache(None)
+def oracle():
+    return _load("oracle/libcelt_oracle.so")

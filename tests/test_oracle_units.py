@@ -1,0 +1,162 @@
+"""CPU: the plain-C restatement (oracle/) pinned against the compiled, unmodified reference
+(oracle/_ref, fixed-point build) function by function.  Bit-exact or fail."""
+import ctypes, numpy as np, pytest
+from reflib import ref_fx, ref_expose, oracle
+
+pytestmark = pytest.mark.skipif(ref_expose() is None or oracle() is None, reason="oracle/_ref or oracle lib not built")
+I = ctypes.c_int32
+def P(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+def _cmp(rf, of, gen, n, restype=I):
+    rf.restype = restype; of.restype = restype
+    for _ in range(n):
+        a = gen()
+        assert rf(*a) == of(*a), (a, rf(*a), of(*a))
+
+def test_mathops_exported():
+    R, O = ref_fx(), oracle(); rng = np.random.default_rng(0); N = 5000
+    _cmp(R.celt_rcp, O.oc_rcp, lambda: (int(rng.integers(1, 2**31 - 1)),), N)
+    _cmp(R.celt_sqrt, O.oc_sqrt, lambda: (int(rng.integers(0, 2**31 - 1)),), N)
+    _cmp(R.celt_sqrt32, O.oc_sqrt32, lambda: (int(rng.integers(0, 2**31 - 1)),), N)
+    _cmp(R.celt_rsqrt_norm, O.oc_rsqrt_norm, lambda: (int(rng.integers(16384, 65536)),), N, ctypes.c_int16)
+    _cmp(R.celt_rsqrt_norm32, O.oc_rsqrt_norm32, lambda: (int(rng.integers(2**29, 2**31 - 1)),), N)
+    _cmp(R.celt_cos_norm, O.oc_cos_norm, lambda: (int(rng.integers(-2**20, 2**20)),), N, ctypes.c_int16)
+    _cmp(R.celt_cos_norm32, O.oc_cos_norm32, lambda: (int(rng.integers(-2**30, 2**30 + 1)),), N)
+    _cmp(R.celt_rcp_norm32, O.oc_rcp_norm32, lambda: (int(rng.integers(2**30, 2**31 - 1)),), N)
+    _cmp(R.frac_div32, O.oc_frac_div32, lambda: (int(rng.integers(-2**30, 2**30)), int(rng.integers(1, 2**31 - 1))), N)
+    _cmp(R.isqrt32, O.oc_isqrt32, lambda: (int(rng.integers(1, 2**32 - 1)),), N, ctypes.c_uint32)
+
+def test_mathops_inline():
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(1); N = 5000
+    _cmp(X.ref_log2, O.oc_log2, lambda: (int(rng.integers(0, 2**31 - 1)),), N, ctypes.c_int16)
+    _cmp(X.ref_exp2, O.oc_exp2, lambda: (int(rng.integers(-20000, 16000)),), N)
+    _cmp(X.ref_exp2_db, O.oc_exp2_db, lambda: (int(rng.integers(-2**29, 2**28)),), N)
+    _cmp(X.ref_exp2_db_frac, O.oc_exp2_db_frac, lambda: (int(rng.integers(0, 2**24)),), N)
+    _cmp(X.ref_log2_db, O.oc_log2_db, lambda: (int(rng.integers(0, 2**31 - 1)),), N)
+    _cmp(X.ref_atan2p_norm, O.oc_atan2p_norm, lambda: (int(rng.integers(0, 2**30)), int(rng.integers(1, 2**30))), N)
+
+@pytest.mark.parametrize("shift,stride", [(0, 1), (3, 8), (1, 1), (2, 4), (3, 1)])
+def test_mdct_bit_exact(shift, stride):
+    """clt_mdct_forward_c / clt_mdct_backward_c (celt/mdct.c:122,:268) on random fixed-point input."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(shift * 10 + stride)
+    N2 = 960 >> shift
+    for _ in range(25):
+        amp = 2 ** int(rng.integers(4, 28))
+        x = rng.integers(-amp, amp, size=N2 + 120).astype(np.int32)
+        o1 = np.zeros(1920, np.int32); o2 = np.zeros(1920, np.int32)
+        xa, xb = x.copy(), x.copy()
+        X.ref_mdct_forward(P(xa), P(o1), shift, stride); O.oc_mdct_forward(P(xb), P(o2), shift, stride)
+        assert np.array_equal(o1, o2)
+        spec = rng.integers(-amp, amp, size=960).astype(np.int32)
+        y1 = rng.integers(-1000, 1000, size=N2 + 120).astype(np.int32); y2 = y1.copy()
+        s1, s2 = spec.copy(), spec.copy()
+        X.ref_mdct_backward(P(s1), P(y1), shift, stride); O.oc_mdct_backward(P(s2), P(y2), shift, stride)
+        assert np.array_equal(y1, y2)
+
+def test_mdct_snr_vs_naive():
+    """Same bound as the reference's celt/tests/test_unit_mdct.c:67-72: SNR >= 60 dB against the direct O(N^2) MDCT."""
+    O = oracle(); rng = np.random.default_rng(5)
+    for shift in (0, 3):
+        N = 1920 >> shift; N2 = N // 2
+        x = rng.integers(-2**24, 2**24, size=N).astype(np.int32)
+        # forward MDCT takes N2+overlap samples: the window is applied only on the 120-sample edges;
+        # emulate test_unit_mdct by feeding a length-N frame laid out as [overlap/2 zeros | ... ]
+        inp = np.zeros(N2 + 120, np.int32)
+        inp[:] = x[:N2 + 120]
+        out = np.zeros(N2, np.int32)
+        O.oc_mdct_forward(P(inp.copy()), P(out), shift, 1)
+        # direct transform of the windowed, folded signal
+        w = np.sin(.5 * np.pi * np.sin(.5 * np.pi * (np.arange(120) + .5) / 120) ** 2)
+        full = np.zeros(N)
+        off = (N2 - 120) // 2
+        seg = inp.astype(np.float64).copy()
+        seg[:120] *= w; seg[-120:] *= w[::-1]
+        full[off:off + N2 + 120] = seg
+        n = np.arange(N); k = np.arange(N2)
+        ref = (full[None, :] * np.cos(2 * np.pi * (n[None, :] + .5 + .25 * N) * (k[:, None] + .5) / N)).sum(1) / (N / 4)
+        err = ref - out
+        snr = 10 * np.log10((ref**2).sum() / (err**2).sum())
+        assert snr > 60, snr
+
+def test_range_coder_scripts():
+    """ec_encode/ec_enc_bit_logp/ec_enc_icdf/ec_enc_uint/ec_enc_bits/ec_laplace_encode/ec_encode_bin +
+    ec_tell_frac after every symbol + ec_enc_done (celt/entenc.c, celt/laplace.c:51, celt/entcode.c:69)."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(2)
+    for t in range(150):
+        n = int(rng.integers(1, 400)); ops = np.zeros((n, 4), np.int32)
+        for i in range(n):
+            k = int(rng.integers(0, 7)); ops[i, 0] = k
+            if k == 0:
+                ft = int(rng.integers(2, 60000)); fl = int(rng.integers(0, ft)); fh = int(rng.integers(fl + 1, ft + 1)); ops[i, 1:] = [fl, fh, ft]
+            elif k == 1: ops[i, 1:] = [int(rng.integers(0, 2)), int(rng.integers(1, 16)), 0]
+            elif k == 2: ops[i, 1] = int(rng.integers(0, 4))
+            elif k == 3:
+                ft = int(rng.integers(2, 2**31 - 1)); ops[i, 1:] = [int(rng.integers(0, ft)), ft, 0]
+            elif k == 4:
+                b = int(rng.integers(1, 25)); ops[i, 1:] = [int(rng.integers(0, 2**b)), b, 0]
+            elif k == 5: ops[i, 1:] = [int(rng.integers(-40, 40)), int(rng.integers(1000, 20000)), int(rng.integers(100, 11456))]
+            else:
+                bits = int(rng.integers(1, 16)); ft = 1 << bits; fl = int(rng.integers(0, ft)); fh = int(rng.integers(fl + 1, ft + 1)); ops[i, 1:] = [fl, fh, bits]
+        nb = int(rng.integers(10, 1276))
+        b1 = np.zeros(1276, np.uint8); b2 = np.zeros(1276, np.uint8); t1 = np.zeros(n, np.uint32); t2 = np.zeros(n, np.uint32)
+        r1 = X.ref_ec_script(P(ops), n, P(b1), nb, P(t1)); r2 = O.oc_hook_ec_script(P(ops), n, P(b2), nb, P(t2))
+        assert r1 == r2 and np.array_equal(b1, b2) and np.array_equal(t1, t2)
+
+def test_pulse_cache_and_caps():
+    X, O = ref_expose(), oracle()
+    for LM in range(4):
+        for band in range(21):
+            for bits in range(0, 1500, 7):
+                assert X.ref_bits2pulses(band, LM, bits) == O.oc_bits2pulses(band, LM, bits)
+            for p in range(0, 41):
+                q = X.ref_bits2pulses(band, LM, 4000)
+                if p <= q: assert X.ref_pulses2bits(band, LM, p) == O.oc_pulses2bits(band, LM, p)
+        for C in (1, 2):
+            c1 = np.zeros(21, np.int32); c2 = np.zeros(21, np.int32)
+            X.ref_init_caps(P(c1), LM, C); O.oc_init_caps(P(c2), LM, C)
+            assert np.array_equal(c1, c2)
+
+def test_compute_allocation():
+    """clt_compute_allocation (celt/rate.c:535) incl. skip / intensity / dual-stereo signalling."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(3)
+    for t in range(400):
+        C = int(rng.integers(1, 3)); LM = int(rng.integers(0, 4)); start = 0 if rng.random() < .8 else 17
+        end = int(rng.choice([13, 17, 19, 21])); 
+        if end <= start: end = 21
+        cap = np.zeros(21, np.int32); X.ref_init_caps(P(cap), LM, C)
+        offsets = np.zeros(21, np.int32)
+        for j in range(start, end):
+            if rng.random() < .2: offsets[j] = int(rng.integers(0, 4)) * (C * (8 << LM)) 
+        trim = int(rng.integers(0, 11)); total = int(rng.integers(0, 1275 * 64))
+        intensity0 = int(rng.integers(start, end + 1)); ds0 = int(rng.integers(0, 2))
+        prev = int(rng.integers(0, 22)); sbw = int(rng.integers(0, 21))
+        res = []
+        for lib, fn in ((X, X.ref_compute_allocation), (O, O.oc_hook_compute_allocation)):
+            inten = I(intensity0); ds = I(ds0); bal = I(0); rngv = ctypes.c_uint32(0)
+            pulses = np.zeros(21, np.int32); ebits = np.zeros(21, np.int32); fp = np.zeros(21, np.int32); buf = np.zeros(1276, np.uint8)
+            cb = fn(start, end, P(offsets), P(cap), trim, ctypes.byref(inten), ctypes.byref(ds), total, ctypes.byref(bal),
+                    P(pulses), P(ebits), P(fp), C, LM, P(buf), 1275, prev, sbw, ctypes.byref(rngv))
+            res.append((cb, inten.value, ds.value, bal.value, rngv.value, pulses[start:end].tolist(), ebits[start:end].tolist(), fp[start:end].tolist(), buf.tobytes()))
+        assert res[0] == res[1], (t, res[0][:5], res[1][:5])
+
+def test_energy_quant():
+    """amp2Log2 + quant_coarse_energy (two-pass intra/inter with rollback) + fine + finalise (celt/quant_bands.c)."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(4)
+    for t in range(300):
+        C = int(rng.integers(1, 3)); LM = int(rng.integers(0, 4)); start = 0; end = int(rng.choice([13, 17, 19, 21]))
+        bandE = (2.0 ** rng.uniform(0, 28, size=42)).astype(np.int64).astype(np.int32)
+        l1 = np.zeros(42, np.int32); l2 = np.zeros(42, np.int32)
+        X.ref_amp2log2(end, end, P(bandE), P(l1), C); O.oc_amp2log2(end, end, P(bandE), P(l2), C)
+        assert np.array_equal(l1, l2)
+        old0 = (rng.normal(0, 3, size=42) * (1 << 24)).astype(np.int32)
+        nbytes = int(rng.integers(8, 400)); budget = nbytes * 8
+        fq = rng.integers(0, 5, size=21).astype(np.int32); fpz = rng.integers(0, 2, size=21).astype(np.int32)
+        force_intra = int(rng.random() < .1); two_pass = int(rng.random() < .7); dI0 = int(rng.integers(0, 200)); loss = int(rng.integers(0, 30))
+        res = []
+        for fn in (X.ref_quant_energy, O.oc_hook_quant_energy):
+            old = old0.copy(); err = np.zeros(42, np.int32); dI = I(dI0); rngv = ctypes.c_uint32(0); buf = np.zeros(1276, np.uint8)
+            fn(start, end, end, P(l1), P(old), budget, P(err), C, LM, nbytes, force_intra, ctypes.byref(dI), two_pass, loss, 0,
+               P(fq), P(fpz), int(rng.integers(0, 1)) + 10, P(buf), nbytes, ctypes.byref(rngv))
+            valid = np.r_[np.arange(start, end), 21 + np.arange(start, end)][: (end - start) * C]  # error[] past `end` is never written
+            res.append((old.tolist(), err[valid].tolist(), dI.value, rngv.value, buf.tobytes()))
+        assert res[0] == res[1], t
