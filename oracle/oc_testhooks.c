@@ -44,3 +44,34 @@ int oc_hook_ec_script(const int *ops, int nops, u8 *buf, int nbytes, u32 *tells)
    oc_ec_enc_done(&enc);
    return enc.error ? -1 : (int)enc.offs;
 }
+
+int oc_hook_band_pipeline(const i32 *freq, int C, int LM, int shortBlocks, int spread, int dual_stereo, int intensity,
+      int *tf_res, int nbytes, int complexity, int alloc_trim, u32 *seed, int disable_inv, int end,
+      i32 *X_out, i32 *bandE_out, u8 *collapse_masks, u8 *buf, u32 *rng_out, int *pulses_out)
+{
+   int Mm = 1 << LM, N = Mm * 120;
+   i32 X[2 * 960], bandE[42], balance;
+   int cap[21], offsets[21] = {0}, pulses[21], fine_quant[21], fine_priority[21];
+   oc_ec enc; oc_ec_enc_init(&enc, buf, nbytes);
+   oc_compute_band_energies(freq, bandE, end, C, LM);
+   oc_normalise_bands(freq, X, bandE, end, C, Mm);
+   oc_init_caps(cap, LM, C);
+   i32 bits = ((i32)nbytes * 8 << BITRES) - (i32)oc_ec_tell_frac(&enc) - 1;
+   int codedBands = oc_compute_allocation(0, end, offsets, cap, alloc_trim, &intensity, &dual_stereo, bits, &balance,
+         pulses, fine_quant, fine_priority, C, LM, &enc, 1, 0, end - 1);
+   oc_quant_all_bands(1, 0, end, X, C == 2 ? X + N : 0, collapse_masks, bandE, pulses, shortBlocks, spread, dual_stereo,
+         intensity, tf_res, nbytes * (8 << BITRES), balance, &enc, LM, codedBands, seed, complexity, disable_inv);
+   *rng_out = enc.rng;
+   oc_ec_enc_done(&enc);
+   memcpy(X_out, X, sizeof(i32) * C * N);
+   memcpy(bandE_out, bandE, sizeof(bandE));
+   memcpy(pulses_out, pulses, sizeof(pulses));
+   return codedBands;
+}
+unsigned oc_hook_alg_quant(i32 *X, int N, int K, int spread, int B, i32 gain, int resynth, u8 *buf, u32 *rng_out)
+{
+   oc_ec enc; oc_ec_enc_init(&enc, buf, 1275);
+   unsigned cm = oc_alg_quant(X, N, K, spread, B, &enc, gain, resynth);
+   *rng_out = enc.rng; oc_ec_enc_done(&enc);
+   return cm;
+}

@@ -76,3 +76,39 @@ int ref_ec_script(const int *ops, int nops, unsigned char *buf, int nbytes, opus
    ec_enc_done(&enc);
    return enc.error ? -1 : (int)enc.offs;
 }
+
+/* band pipeline: energies -> normalise -> allocation -> quant_all_bands(encode) with a private encoder */
+int ref_band_pipeline(const opus_int32 *freq, int C, int LM, int shortBlocks, int spread, int dual_stereo, int intensity,
+      int *tf_res, int nbytes, int complexity, int alloc_trim, opus_uint32 *seed, int disable_inv, int end,
+      opus_int32 *X_out, opus_int32 *bandE_out, unsigned char *collapse_masks, unsigned char *buf, opus_uint32 *rng_out,
+      int *pulses_out)
+{
+   const CELTMode *m = M();
+   int Mm = 1 << LM, N = Mm * 120;
+   opus_int32 X[2 * 960];
+   opus_int32 bandE[42];
+   int cap[21], offsets[21] = {0}, pulses[21], fine_quant[21], fine_priority[21];
+   opus_int32 balance;
+   ec_enc enc; ec_enc_init(&enc, buf, nbytes);
+   compute_band_energies(m, freq, bandE, end, C, LM, 0);
+   normalise_bands(m, freq, X, bandE, end, C, Mm);
+   init_caps(m, cap, LM, C);
+   opus_int32 bits = ((opus_int32)nbytes * 8 << BITRES) - (opus_int32)ec_tell_frac(&enc) - 1;
+   int codedBands = clt_compute_allocation(m, 0, end, offsets, cap, alloc_trim, &intensity, &dual_stereo, bits, &balance,
+         pulses, fine_quant, fine_priority, C, LM, &enc, 1, 0, end - 1);
+   quant_all_bands(1, m, 0, end, X, C == 2 ? X + N : NULL, collapse_masks, bandE, pulses, shortBlocks, spread, dual_stereo,
+         intensity, tf_res, nbytes * (8 << BITRES), balance, &enc, LM, codedBands, seed, complexity, 0, disable_inv);
+   *rng_out = enc.rng;
+   ec_enc_done(&enc);
+   memcpy(X_out, X, sizeof(opus_int32) * C * N);
+   memcpy(bandE_out, bandE, sizeof(bandE));
+   memcpy(pulses_out, pulses, sizeof(pulses));
+   return codedBands;
+}
+unsigned ref_alg_quant(opus_int32 *X, int N, int K, int spread, int B, opus_int32 gain, int resynth, unsigned char *buf, opus_uint32 *rng_out)
+{
+   ec_enc enc; ec_enc_init(&enc, buf, 1275);
+   unsigned cm = alg_quant(X, N, K, spread, B, &enc, gain, resynth, 0);
+   *rng_out = enc.rng; ec_enc_done(&enc);
+   return cm;
+}

@@ -160,3 +160,141 @@ def test_energy_quant():
             valid = np.r_[np.arange(start, end), 21 + np.arange(start, end)][: (end - start) * C]  # error[] past `end` is never written
             res.append((old.tolist(), err[valid].tolist(), dI.value, rngv.value, buf.tobytes()))
         assert res[0] == res[1], t
+
+def _music(rng, n, C=2, amp=8000.0, f0=None):
+    t = np.arange(n) / 48000.0
+    f0 = f0 or rng.uniform(80, 800)
+    s = sum(np.sin(2 * np.pi * f0 * k * t + rng.uniform(0, 6)) / k for k in range(1, 8))
+    x = np.stack([s * amp * rng.uniform(.3, 1) + rng.normal(0, amp * .02, n) for _ in range(C)], 1)
+    return x
+
+def test_pitch_chain():
+    """pitch_downsample / pitch_search / remove_doubling (celt/pitch.c:140,:307,:454) on harmonic + noise input."""
+    R, O = ref_fx(), oracle(); rng = np.random.default_rng(6)
+    R.remove_doubling.restype = ctypes.c_int16; O.oc_remove_doubling.restype = ctypes.c_int16
+    for t in range(60):
+        C = int(rng.integers(1, 3)); N = 960
+        amp = float(2 ** rng.uniform(2, 14.5))
+        sig = (_music(rng, 1024 + N, C, amp) * 4096).astype(np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+        if t % 7 == 0: sig[:] = 0
+        chans = [np.ascontiguousarray(sig[:, c]) for c in range(C)]
+        ptrs = (ctypes.c_void_p * 2)(*[c.ctypes.data for c in chans], *([None] * (2 - C)))
+        n_lp = (1024 + N) >> 1
+        lp1 = np.zeros(n_lp, np.int16); lp2 = np.zeros(n_lp, np.int16)
+        R.pitch_downsample(ptrs, P(lp1), n_lp, C, 2, 0); O.oc_pitch_downsample(ptrs, P(lp2), n_lp, C, 2)
+        assert np.array_equal(lp1, lp2), t
+        p1 = I(0); p2 = I(0)
+        R.pitch_search(P(lp1[512:]), P(lp1), N, 1024 - 3 * 15, ctypes.byref(p1), 0)
+        O.oc_pitch_search(P(lp2[512:]), P(lp2), N, 1024 - 3 * 15, ctypes.byref(p2))
+        assert p1.value == p2.value, t
+        T1 = I(1024 - p1.value); T2 = I(1024 - p2.value)
+        prev_period = int(rng.integers(15, 1023)); prev_gain = int(rng.integers(0, 26000))
+        g1 = R.remove_doubling(P(lp1), 1024, 15, N, ctypes.byref(T1), prev_period, prev_gain, 0)
+        g2 = O.oc_remove_doubling(P(lp2), 1024, 15, N, ctypes.byref(T2), prev_period, prev_gain)
+        assert (g1, T1.value) == (g2, T2.value), t
+
+def test_comb_filter():
+    """comb_filter + comb_filter_const (celt/celt.c:238,:166), incl. overlap cross-fade and saturation."""
+    R, O = ref_fx(), oracle(); rng = np.random.default_rng(7)
+    X = ref_expose()
+    win = np.array([int(v) for v in open(__import__('os').path.join(__import__('os').path.dirname(__file__), '..', 'oracle', 'oc_tables.h')).read().split('oc_window[120] = {')[1].split('}')[0].replace('\n', '').split(',') if v.strip()], np.int16)
+    for t in range(200):
+        N = int(rng.choice([120, 240, 480, 960])); 
+        amp = 2 ** int(rng.integers(10, 30))
+        x = rng.integers(-amp, amp, size=1024 + 2 + N + 4).astype(np.int32)
+        T0 = int(rng.integers(15, 1023)); T1 = int(rng.integers(15, 1023)) if rng.random() < .7 else T0
+        g0 = int(rng.integers(0, 26000)) if rng.random() < .8 else 0
+        g1 = int(rng.integers(0, 26000)) if rng.random() < .8 else 0
+        if rng.random() < .2: g1 = g0
+        ts0 = int(rng.integers(0, 3)); ts1 = int(rng.integers(0, 3)) if rng.random() < .5 else ts0
+        ov = int(rng.choice([0, 120]))
+        y1 = np.zeros(N, np.int32); y2 = np.zeros(N, np.int32)
+        xa = x.copy(); xb = x.copy()
+        base = 1026
+        R.comb_filter(P(y1), ctypes.c_void_p(xa.ctypes.data + 4 * base), T0, T1, N, g0, g1, ts0, ts1, P(win), ov, 0)
+        O.oc_comb_filter(P(y2), ctypes.c_void_p(xb.ctypes.data + 4 * base), T0, T1, N, g0, g1, ts0, ts1, ov)
+        assert np.array_equal(y1, y2), t
+
+def test_lpc_autocorr():
+    R, O = ref_fx(), oracle(); rng = np.random.default_rng(8)
+    for t in range(200):
+        n = int(rng.choice([240, 512, 992, 1080])); lag = int(rng.choice([4, 24]))
+        amp = 2 ** int(rng.integers(1, 15))
+        x = (rng.normal(0, amp / 3, n)).clip(-32768, 32767).astype(np.int16)
+        a1 = np.zeros(lag + 1, np.int32); a2 = np.zeros(lag + 1, np.int32)
+        s1 = R._celt_autocorr(P(x), P(a1), None, 0, lag, n, 0); s2 = O.oc_autocorr(P(x), P(a2), None, 0, lag, n)
+        assert s1 == s2 and np.array_equal(a1, a2), t
+        l1 = np.zeros(lag, np.int16); l2 = np.zeros(lag, np.int16)
+        R._celt_lpc(P(l1), P(a1), lag); O.oc_celt_lpc(P(l2), P(a2), lag)
+        assert np.array_equal(l1, l2), t
+
+def test_alg_quant():
+    """exp_rotation + op_pvq_search + icwrs/encode_pulses + normalise_residual (celt/vq.c:552) on unit-norm vectors."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(9)
+    sizes = [2, 3, 4, 6, 8, 9, 11, 12, 16, 18, 22, 24, 32, 36, 44, 48, 64, 72, 88, 96, 144, 176]
+    for t in range(1500):
+        N = int(rng.choice(sizes))
+        v = rng.normal(0, 1, N) * (rng.random(N) < rng.uniform(.1, 1))
+        if not v.any(): v[0] = 1
+        v = v / np.sqrt((v**2).sum())
+        x = np.round(v * (1 << 24)).astype(np.int32)
+        # largest K with V(N,K) < 2^32 (bounded by 128)
+        O.oc_pvq_v.restype = ctypes.c_uint32
+        K = int(rng.integers(1, 129))
+        while K > 1:
+            try_rows = min(N, K + 1)
+            if try_rows <= 14 or N <= 14:
+                lo, hi = min(N, K + 1), max(N, K + 1)
+                ok = (lo < 6 and hi <= 176) or (lo == 6 and hi <= 96) or (lo == 7 and hi <= 54) or (lo == 8 and hi <= 37) or (lo == 9 and hi <= 28) or (lo == 10 and hi <= 24) or (lo == 11 and hi <= 19) or (lo == 12 and hi <= 18) or (lo == 13 and hi <= 16) or (lo == 14 and hi <= 14)
+                if ok: break
+            K -= 1
+        spread = int(rng.integers(0, 4)); B = int(rng.choice([1, 2, 4, 8])); 
+        if N % B: B = 1
+        gain = int(rng.integers(1 << 28, (1 << 31) - 1)); resynth = int(rng.integers(0, 2))
+        x1, x2 = x.copy(), x.copy(); b1 = np.zeros(1275, np.uint8); b2 = np.zeros(1275, np.uint8); r1 = ctypes.c_uint32(); r2 = ctypes.c_uint32()
+        c1 = X.ref_alg_quant(P(x1), N, K, spread, B, gain, resynth, P(b1), ctypes.byref(r1))
+        c2 = O.oc_hook_alg_quant(P(x2), N, K, spread, B, gain, resynth, P(b2), ctypes.byref(r2))
+        assert c1 == c2 and r1.value == r2.value and np.array_equal(b1, b2), (t, N, K)
+        if resynth: assert np.array_equal(x1, x2), (t, N, K)
+
+def _rand_spectrum(rng, C, LM):
+    N = 120 << LM
+    tilt = np.exp(-np.arange(N) / (N * rng.uniform(.05, 1.0)))
+    f = rng.normal(0, 1, (C, N)) * tilt * 2.0 ** rng.uniform(8, 26)
+    if C == 2:
+        mix = rng.uniform(0, 1)
+        f[1] = mix * f[0] + (1 - mix) * f[1] * rng.uniform(.01, 1)
+    if rng.random() < .1: f[:, N // 2:] = 0
+    return np.clip(f, -2**30, 2**30).astype(np.int32).reshape(-1)
+
+@pytest.mark.parametrize("C", [1, 2])
+def test_band_pipeline(C):
+    """compute_band_energies + normalise_bands + clt_compute_allocation + quant_all_bands (encode), incl. stereo
+    theta-RDO at complexity>=8, dual stereo, short blocks, tf changes (celt/bands.c:1589)."""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(10 + C)
+    for t in range(250):
+        LM = int(rng.integers(0, 4)); N = 120 << LM
+        freq = _rand_spectrum(rng, C, LM)
+        shortBlocks = int(rng.random() < .3) * (1 << LM) if LM > 0 else 0
+        spread = int(rng.integers(0, 4)); dual = int(rng.random() < .2) if C == 2 else 0
+        end = int(rng.choice([13, 17, 19, 21, 21, 21]))
+        intensity = int(rng.integers(0, end + 1)) if C == 2 else 0
+        isT = 1 if shortBlocks else 0
+        tf_table = [[0, -1, 0, -1, 0, -1, 0, -1], [0, -1, 0, -2, 1, 0, 1, -1], [0, -2, 0, -3, 2, 0, 1, -1], [0, -2, 0, -3, 3, 0, 1, -1]]
+        tf_select = int(rng.integers(0, 2))
+        tf_res = np.array([tf_table[LM][4 * isT + 2 * tf_select + int(rng.integers(0, 2))] for _ in range(21)], np.int32)
+        nbytes = int(rng.integers(10, 640)); complexity = int(rng.choice([5, 10])); trim = int(rng.integers(0, 11))
+        disable_inv = int(rng.random() < .2)
+        res = []
+        for fn in (X.ref_band_pipeline, O.oc_hook_band_pipeline):
+            Xo = np.zeros(C * N, np.int32); bE = np.zeros(42, np.int32); cmk = np.zeros(42, np.uint8); buf = np.zeros(1276, np.uint8)
+            rv = ctypes.c_uint32(); seed = ctypes.c_uint32(12345 + t); pul = np.zeros(21, np.int32); tfr = tf_res.copy()
+            cb = fn(P(freq), C, LM, shortBlocks, spread, dual, intensity, P(tfr), nbytes, complexity, trim, ctypes.byref(seed), disable_inv, end,
+                    P(Xo), P(bE), P(cmk), P(buf), ctypes.byref(rv), P(pul))
+            theta_rdo = C == 2 and not dual and complexity >= 8
+            eBm = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100]) << LM
+            for c in range(C): Xo[c * N + eBm[end]:(c + 1) * N] = 0      # bins past the last coded band are never written
+            res.append((cb, rv.value, seed.value, bE[:end].tolist(), bE[21:21 + end].tolist() if C == 2 else [], pul[:end].tolist(), cmk[:C * end].tolist(), buf.tobytes(),
+                        Xo.tolist() if theta_rdo else []))
+        for k in range(len(res[0])):
+            assert res[0][k] == res[1][k], (t, k, LM, C, shortBlocks, complexity)
