@@ -1,0 +1,337 @@
+/* celt_enc_frame.h — one (stream, frame) on one wavefront: HBM state -> LDS -> packet bytes -> HBM.
+ * Follows src/opus_encoder.c:1182 opus_encode_native / :1855 opus_encode_frame_native (CELT-only branch) and
+ * celt/celt_encoder.c:1726 celt_encode_with_ec step for step; see the per-phase headers for the parallel mapping.
+ * HBM traffic per frame: PCM in (frame*channels*2 B) + state in/out (2 x ~10 KB, coalesced dwords) + packet out. */
+#ifndef OPUS_AMD_CELT_ENC_FRAME_H
+#define OPUS_AMD_CELT_ENC_FRAME_H
+
+#ifndef K_DUMP
+#define K_DUMP(tag, ptr, nbytes)
+#define K_DUMPI(tag, v)
+#endif
+
+WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+      u8 *out, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   WV_LDS EcCtx *e = &L->ec;
+   WV_LDS u8 *buf = L->packet + 1;
+   const int lane = wv_lane();
+   const int overlap = OA_OVERLAP;
+
+   /* ---- load persistent state (coalesced) ---- */
+   {
+      const i32 *g = (const i32 *)&gs->st.s;
+      WV_LDS i32 *d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->oldLogE[i] = gs->st.oldLogE[i]; L->oldLogE2[i] = gs->st.oldLogE2[i]; L->energyError[i] = gs->st.energyError[i]; }
+      FOR_LANES(i, 2 * OA_OVERLAP) L->in_mem[i] = gs->st.in_mem[i];
+      const int CC = gs->cfg.channels;
+      for (int c = 0; c < CC; c++) { FOR_LANES(i, OA_MAX_PERIOD) L->A.pre[c][i] = gs->st.prefilter_mem[c * OA_MAX_PERIOD + i]; }
+   }
+   wv_sync();
+   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
+   wv_sync();
+   if (sh->plc_frame) {
+      LANE0 { out[0] = L->packet[0]; *len_out = 1; *rng_out = 0; gs->st.s.rangeFinal = 0; }
+      return;
+   }
+   const int CC = sh->CC, C = sh->C;
+
+   /* ---- Opus layer: dc_reject (+ optional stereo width fade) into int16 staging ---- */
+   dc_reject_lanes(L, pcm, frame_size, CC);
+   wv_sync();
+   if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
+   {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973) */
+      const WV_LDS i16 *p = L->Cc.pcm16;
+      const int Nf = frame_size;
+      i32 a = 0, b = 0;
+      FOR_LANES(i, CC * (Nf - overlap)) a = imax(a, iabs((i32)p[i]));
+      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)p[CC * (Nf - overlap) + i]));
+      a = wv_max(a); b = wv_max(b);
+      LANE0 { sh->r[0] = a; sh->r[1] = b; }
+   }
+   wv_sync();
+   LANE0 celt_prologue(L);
+   wv_sync();
+   if (sh->skip_celt) {
+      /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
+      LANE0 { out[0] = (u8)sh->toc; out[1] = 0; *len_out = 2; *rng_out = 0; st->rangeFinal = 0; }
+      return;
+   }
+   const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
+
+   /* ---- pre-emphasis (FIR on the input) ---- */
+   for (int c = 0; c < CC; c++) {
+      const WV_LDS i16 *p = L->Cc.pcm16;
+      WV_LDS i32 *inp = L->B.in[c];
+      i32 mem = st->preemph_memE[c];
+      FOR_LANES(i, N) {
+         i32 x = shl32((i32)p[CC * i + c], SIG_SHIFT);
+         i32 m = i == 0 ? mem : mult16_32_q15(27853, shl32((i32)p[CC * (i - 1) + c], SIG_SHIFT));
+         inp[overlap + i] = x - m;
+      }
+      FOR_LANES(i, overlap) inp[i] = L->A.pre[c][OA_MAX_PERIOD - overlap + i];
+   }
+   wv_sync();
+   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->Cc.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
+   wv_sync();
+   for (int c = 0; c < CC; c++) K_DUMP("in_pre", L->B.in[c], (N + overlap) * 4);
+
+   /* ---- tone / transient analysis ---- */
+   tone_detect_wave(L);
+   wv_sync();
+   K_DUMPI("tone_freq", (i16)sh->tone_freq); K_DUMPI("toneishness", sh->toneishness);
+   LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
+   wv_sync();
+   if (sh->complexity >= 1) transient_analysis_wave(L, 0);
+   wv_sync();
+   K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
+   LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
+   wv_sync();
+
+   /* ---- pitch pre-filter ---- */
+   {
+      int enabled = (sh->nbAvailableBytes > 12 * C) && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
+      run_prefilter_wave(L, enabled);
+      /* persistent tails: filtered overlap -> in_mem, unfiltered history -> prefilter_mem (HBM) */
+      for (int c = 0; c < CC; c++) {
+         FOR_LANES(i, overlap) L->in_mem[c * overlap + i] = L->B.in[c][N + i];
+         FOR_LANES(i, OA_MAX_PERIOD) gs->st.prefilter_mem[c * OA_MAX_PERIOD + i] = L->A.pre[c][N + i];
+      }
+      wv_sync();
+      LANE0 {
+         int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
+         sh->pitch_change = 0;
+         if ((gain1 > QC16(.4f, 15) || (i16)st->prefilter_gain > QC16(.4f, 15)) && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period)) sh->pitch_change = 1;
+         if (sh->pf_on == 0) {
+            if (sh->tell + 16 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, 0, 1);
+         } else {
+            int octave;
+            k_ec_enc_bit_logp(EC_PASS, 1, 1);
+            pitch_index += 1;
+            octave = ec_ilog(pitch_index) - 5;
+            k_ec_enc_uint(EC_PASS, octave, 6);
+            k_ec_enc_bits(EC_PASS, pitch_index - (16 << octave), 4 + octave);
+            pitch_index -= 1;
+            k_ec_enc_bits(EC_PASS, sh->qg, 3);
+            k_ec_enc_icdf(EC_PASS, sh->prefilter_tapset, k_tapset_icdf, 2);
+         }
+         if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) { if (sh->isTransient) sh->shortBlocks = M; }
+         else { sh->isTransient = 0; sh->transient_got_disabled = 1; }
+         sh->secondMdct = sh->shortBlocks && sh->complexity >= 8;
+      }
+      wv_sync();
+      K_DUMPI("pf_on", sh->pf_on); K_DUMPI("pitch_index", sh->pitch_index); K_DUMPI("gain1", (i16)sh->gain1); K_DUMPI("qg", sh->qg);
+      for (int c = 0; c < CC; c++) K_DUMP("in_pf", L->B.in[c], (N + overlap) * 4);
+   }
+
+   /* ---- MDCT + band energies ---- */
+   if (sh->secondMdct) {
+      compute_mdcts_wave(L, 0);
+      band_energies_wave(L, L->bandLogE2);
+      FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
+      wv_sync();
+   }
+   compute_mdcts_wave(L, sh->shortBlocks);
+   band_energies_wave(L, L->bandLogE);
+   K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
+   LANE0 {
+      temporal_vbr_l0(L);
+      if (!sh->secondMdct) for (int i = 0; i < C * NBE; i++) L->bandLogE2[i] = L->bandLogE[i];
+      sh->do_patch = 0;
+      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5)
+         sh->do_patch = patch_transient_decision_l0(L);
+   }
+   wv_sync();
+   if (sh->do_patch) {
+      LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
+      wv_sync();
+      compute_mdcts_wave(L, sh->shortBlocks);
+      band_energies_wave(L, L->bandLogE);
+      FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
+      LANE0 sh->tf_estimate = QC16(.2f, 14);
+      wv_sync();
+   }
+   LANE0 { if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); }
+   normalise_bands_wave(L);
+   K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->A.s.X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
+
+   /* ---- allocation analyses ---- */
+   LANE0 {
+      sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && sh->complexity >= 2 && sh->toneishness < QC32(.98f, 29);
+      dynalloc_analysis_l0(L);
+   }
+   wv_sync();
+   K_DUMPI("maxDepth", sh->maxDepth); K_DUMPI("tot_boost", sh->tot_boost); K_DUMP("offsets", L->offsets, 84); K_DUMP("importance", L->importance, 84); K_DUMP("spread_weight", L->spread_weight, 84);
+   if (sh->enable_tf_analysis) tf_analysis_wave(L, imax(80, 20480 / sh->effectiveBytes + 2));
+   else { LANE0 { for (int i = 0; i < end; i++) L->tf_res[i] = sh->isTransient; sh->tf_select = 0; } wv_sync(); }
+   FOR_LANES(w, C * NBE) {
+      int c = w / NBE, i = w - c * NBE;
+      if (i >= start && i < end && iabs(sub32(L->bandLogE[i + c * NBE], L->oldBandE[i + c * NBE])) < GC(2.f))
+         L->bandLogE[i + c * NBE] -= mult16_32_q15(QC16(0.25f, 15), L->energyError[i + c * NBE]);
+   }
+   wv_sync();
+   LANE0 {
+      k_quant_coarse_energy(L->scr, L->bytes_save, L->ecsave, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
+            C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, 0);
+      tf_encode_l0(L);
+      sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
+   }
+   wv_sync();
+   K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", e->rng); K_DUMPI("tell_tf", k_ec_tell_frac(EC_PASS));
+   if (sh->r[2]) {
+      if (sh->shortBlocks || sh->complexity < 3 || sh->nbAvailableBytes < 10 * C) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : 2; wv_sync(); }
+      else spreading_decision_wave(L, sh->pf_on && !sh->shortBlocks);
+      LANE0 k_ec_enc_icdf(EC_PASS, st->spread_decision, k_spread_icdf, 5);
+   } else { LANE0 st->spread_decision = 2; }
+   wv_sync();
+   K_DUMPI("spread", st->spread_decision); K_DUMPI("tapset", st->tapset_decision);
+   LANE0 {
+      k_init_caps(L->cap, LM, C);
+      int dynalloc_logp = 6;
+      i32 total_bits = sh->total_bits << BITRES, total_boost = 0, tell = k_ec_tell_frac(EC_PASS);
+      for (int i = start; i < end; i++) {
+         int width = C * (ct_eBands[i + 1] - ct_eBands[i]) << LM;
+         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
+         int dynalloc_loop_logp = dynalloc_logp, boost = 0, j;
+         for (j = 0; tell + (dynalloc_loop_logp << BITRES) < total_bits - total_boost && boost < L->cap[i]; j++) {
+            int flag = j < L->offsets[i];
+            k_ec_enc_bit_logp(EC_PASS, flag, dynalloc_loop_logp);
+            tell = k_ec_tell_frac(EC_PASS);
+            if (!flag) break;
+            boost += quanta;
+            total_boost += quanta;
+            dynalloc_loop_logp = 1;
+         }
+         if (j) dynalloc_logp = imax(2, dynalloc_logp - 1);
+         L->offsets[i] = boost;
+      }
+      sh->total_boost = total_boost;
+      sh->r[3] = tell;
+   }
+   wv_sync();
+   {
+      int ds = 0;
+      if (C == 2 && LM != 0) ds = stereo_analysis_wave(L);
+      LANE0 {
+         sh->dual_stereo = ds;
+         if (C == 2) {
+            const i16 intensity_thresholds[21] = {1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 36, 44, 50, 56, 62, 67, 72, 79, 88, 106, 134};
+            const i16 intensity_histeresis[21] = {1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3, 4, 5, 6, 8, 8};
+            st->intensity = hysteresis_decision((i16)(sh->equiv_rate / 1000), intensity_thresholds, intensity_histeresis, 21, st->intensity);
+            st->intensity = imin(end, imax(start, st->intensity));
+         }
+         sh->alloc_trim = 5;
+         sh->r[4] = sh->r[3] + (6 << BITRES) <= (sh->total_bits << BITRES) - sh->total_boost;
+      }
+      wv_sync();
+   }
+   if (sh->r[4]) {
+      alloc_trim_analysis_wave(L);
+      LANE0 k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7);
+      wv_sync();
+   }
+   K_DUMPI("alloc_trim", sh->alloc_trim); K_DUMPI("dual_stereo", sh->dual_stereo); K_DUMPI("intensity", st->intensity); K_DUMP("offsets2", L->offsets, 84); K_DUMPI("rng_trim", e->rng);
+
+   /* ---- VBR target, bit allocation, fine energy (lane 0) ---- */
+   LANE0 {
+      i32 tell = k_ec_tell_frac(EC_PASS), total_boost = sh->total_boost, vbr_rate = sh->vbr_rate;
+      int nbCompressedBytes = sh->nbCompressedBytes, nbAvailableBytes, silence = sh->silence;
+      i32 min_allowed = ((tell + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3)) + 2;
+      if (vbr_rate > 0) {
+         i16 alpha;
+         i32 delta, target, base_target;
+         int lm_diff = 3 - LM;
+         nbCompressedBytes = imin(nbCompressedBytes, 1275 >> (3 - LM));
+         base_target = vbr_rate - ((40 * C + 20) << BITRES);
+         if (sh->constrained_vbr) base_target += (st->vbr_offset >> lm_diff);
+         target = compute_vbr_l0(L, base_target);
+         target = target + tell;
+         nbAvailableBytes = (target + (1 << (BITRES + 2))) >> (BITRES + 3);
+         nbAvailableBytes = imax(min_allowed, nbAvailableBytes);
+         nbAvailableBytes = imin(nbCompressedBytes, nbAvailableBytes);
+         delta = target - vbr_rate;
+         target = nbAvailableBytes << (BITRES + 3);
+         if (silence) { nbAvailableBytes = 2; target = 2 * 8 << BITRES; delta = 0; }
+         if (st->vbr_count < 970) { st->vbr_count++; alpha = (i16)fx_rcp(shl32((i32)(st->vbr_count + 20), 16)); }
+         else alpha = QC16(.001f, 15);
+         if (sh->constrained_vbr) st->vbr_reservoir += target - vbr_rate;
+         if (sh->constrained_vbr) {
+            st->vbr_drift += (i32)mult16_32_q15(alpha, (delta * (1 << lm_diff)) - st->vbr_offset - st->vbr_drift);
+            st->vbr_offset = -st->vbr_drift;
+         }
+         if (sh->constrained_vbr && st->vbr_reservoir < 0) {
+            int adjust = (-st->vbr_reservoir) / (8 << BITRES);
+            nbAvailableBytes += silence ? 0 : adjust;
+            st->vbr_reservoir = 0;
+         }
+         nbCompressedBytes = imin(nbCompressedBytes, nbAvailableBytes);
+         k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+      }
+      sh->nbCompressedBytes = nbCompressedBytes;
+      i32 bits = (((i32)nbCompressedBytes * 8) << BITRES) - (i32)k_ec_tell_frac(EC_PASS) - 1;
+      int anti_collapse_rsv = sh->isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
+      bits -= anti_collapse_rsv;
+      sh->anti_collapse_rsv = anti_collapse_rsv;
+      int signalBandwidth = end - 1;
+      sh->codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, sh->alloc_trim, &st->intensity, &sh->dual_stereo, bits, &sh->balance,
+            L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 1, st->lastCodedBands, signalBandwidth);
+      if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, sh->codedBands));
+      else st->lastCodedBands = sh->codedBands;
+      k_quant_fine_energy(start, end, L->oldBandE, L->error, 0, L->fine_quant, EC_PASS, C);
+      for (int i = 0; i < NBE * CC; i++) L->energyError[i] = 0;
+   }
+   wv_sync();
+   K_DUMPI("nbCompressedBytes", sh->nbCompressedBytes); K_DUMPI("codedBands", sh->codedBands); K_DUMPI("balance", sh->balance); K_DUMP("pulses", L->pulses, 84); K_DUMP("fine_quant", L->fine_quant, 84); K_DUMP("fine_priority", L->fine_priority, 84); K_DUMPI("rng_fine", e->rng);
+
+   /* ---- PVQ residual ---- */
+   quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
+         sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv);
+   K_DUMPI("rng_pvq", e->rng); K_DUMP("collapse", L->collapse_masks, 42);
+
+   /* ---- finalise (lane 0) ---- */
+   LANE0 {
+      const int nbCompressedBytes = sh->nbCompressedBytes, isTransient = sh->isTransient, silence = sh->silence;
+      if (sh->anti_collapse_rsv > 0) k_ec_enc_bits(EC_PASS, st->consec_transient < 2, 1);
+      k_quant_energy_finalise(start, end, L->oldBandE, L->error, L->fine_quant, L->fine_priority, nbCompressedBytes * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
+      for (int c = 0; c < C; c++)
+         for (int i = start; i < end; i++) L->energyError[i + c * NBE] = imax(-GC(0.5f), imin(GC(0.5f), L->error[i + c * NBE]));
+      if (silence) for (int i = 0; i < C * NBE; i++) L->oldBandE[i] = -GC(28.f);
+      st->prefilter_period = sh->pitch_index;
+      st->prefilter_gain = (i16)sh->gain1;
+      st->prefilter_tapset = sh->prefilter_tapset;
+      if (CC == 2 && C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[NBE + i] = L->oldBandE[i];
+      if (!isTransient) {
+         for (int i = 0; i < CC * NBE; i++) { L->oldLogE2[i] = L->oldLogE[i]; L->oldLogE[i] = L->oldBandE[i]; }
+      } else for (int i = 0; i < CC * NBE; i++) L->oldLogE[i] = imin(L->oldLogE[i], L->oldBandE[i]);
+      for (int c = 0; c < CC; c++) {
+         for (int i = 0; i < start; i++) { L->oldBandE[c * NBE + i] = 0; L->oldLogE[c * NBE + i] = L->oldLogE2[c * NBE + i] = -GC(28.f); }
+         for (int i = end; i < NBE; i++) { L->oldBandE[c * NBE + i] = 0; L->oldLogE[c * NBE + i] = L->oldLogE2[c * NBE + i] = -GC(28.f); }
+      }
+      if (isTransient || sh->transient_got_disabled) st->consec_transient++;
+      else st->consec_transient = 0;
+      st->rng = e->rng;
+      k_ec_enc_done(EC_PASS);
+      int ret = e->error ? -3 : nbCompressedBytes;
+      st->rangeFinal = st->rng;
+      L->packet[0] |= (u8)sh->toc;
+      if (ret >= 0 && k_ec_tell(EC_PASS) > (sh->max_data_bytes - 1) * 8) { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
+      sh->ret = ret < 0 ? ret : ret + 1;
+   }
+   wv_sync();
+
+   /* ---- store packet + state (coalesced) ---- */
+   {
+      const int nbytes = sh->ret;
+      if (nbytes > 0) { FOR_LANES(i, nbytes) out[i] = L->packet[i]; }
+      LANE0 { *len_out = nbytes; *rng_out = st->rangeFinal; }
+      i32 *g = (i32 *)&gs->st.s;
+      const WV_LDS i32 *d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
+      FOR_LANES(i, 2 * NBE) { gs->st.oldBandE[i] = L->oldBandE[i]; gs->st.oldLogE[i] = L->oldLogE[i]; gs->st.oldLogE2[i] = L->oldLogE2[i]; gs->st.energyError[i] = L->energyError[i]; }
+      FOR_LANES(i, 2 * OA_OVERLAP) gs->st.in_mem[i] = L->in_mem[i];
+   }
+}
+#endif

@@ -1,0 +1,388 @@
+/* celt_enc_front.h — Opus-layer front end and CELT time-domain analysis, wave-parallel where the math allows.
+ *
+ *   opus_layer_decide   lane 0    src/opus_encoder.c:1182-1700 (the decisions left when the application pins CELT-only)
+ *   dc_reject           lane/ch   src/opus_encoder.c:479 (1st-order recursion with rounding: serial per channel)
+ *   stereo_fade         parallel  src/opus_encoder.c:548
+ *   celt_prologue       lane 0    celt/celt_encoder.c:1902-2008 (rate/VBR bounds, silence flag)
+ *   preemphasis         parallel  celt/celt_encoder.c:557 (an FIR on the input: y[i] = x[i] - .85 x[i-1])
+ *   tone_detect         reductions + scalar tail   celt/celt_encoder.c:1272-1403
+ *   transient_analysis  lane/ch recursions + parallel normalisation   celt/celt_encoder.c:267
+ *   run_prefilter       parallel xcorr / comb FIR, lane-0 decisions   celt/celt_encoder.c:1405, celt/pitch.c, celt/celt.c:166-312
+ */
+#ifndef OPUS_AMD_CELT_ENC_FRONT_H
+#define OPUS_AMD_CELT_ENC_FRONT_H
+
+/* lane-0 serial section, fenced on both sides: other lanes neither race ahead of its inputs nor read its
+ * outputs early (on the GPU the fences are LDS waits; the CPU emulator needs them for fiber ordering) */
+#define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
+#define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
+
+#define OA_AUTO (-1000)
+#define OA_BITRATE_MAX (-1)
+#define OA_BW_NB 1101
+#define OA_BW_MB 1102
+#define OA_BW_WB 1103
+#define OA_BW_SWB 1104
+#define OA_BW_FB 1105
+
+WV_DEV i32 bits_to_bitrate(i32 bits, i32 Fs, i32 frame_size) { return bits * (6 * Fs / frame_size) / 6; }
+WV_DEV i32 bitrate_to_bits(i32 bitrate, i32 Fs, i32 frame_size) { return bitrate * 6 / (6 * Fs / frame_size); }
+WV_DEV i32 compute_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int celt_mode_known, int complexity)
+{
+   i32 equiv = bitrate;
+   if (frame_rate > 50) equiv -= (40 * channels + 20) * (frame_rate - 50);
+   if (!vbr) equiv -= equiv / 12;
+   equiv = equiv * (90 + complexity) / 100;
+   if (celt_mode_known) { if (complexity < 5) equiv = equiv * 9 / 10; }
+   return equiv;
+}
+WV_DEV u8 gen_toc_celt(int framerate, int bandwidth, int channels)
+{
+   int period = 0;
+   while (framerate < 400) { framerate <<= 1; period++; }
+   int tmp = bandwidth - OA_BW_MB;
+   if (tmp < 0) tmp = 0;
+   return (u8)(0x80 | (tmp << 5) | (period << 3) | ((channels == 2) << 2));
+}
+
+/* lane 0: everything opus_encode_native / opus_encode_frame_native decide before the CELT call. */
+WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int frame_size, int out_data_bytes)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   const int Fs = 48000, voice_est = 48;
+   int channels = cfg->channels;
+   i32 max_data_bytes = imin(1276 * 6, out_data_bytes);
+   st->rangeFinal = 0;
+   sh->plc_frame = 0; sh->ret = 0; sh->skip_celt = 0;
+   sh->CC = channels; sh->frame_size = frame_size;
+   i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
+   i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
+   int frame_rate = Fs / frame_size;
+   if (max_data_bytes < 3 || bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || bitrate_bps < 2400))) {
+      int bw = st->bandwidth == 0 ? OA_BW_NB : st->bandwidth;
+      if (bw == OA_BW_MB) bw = OA_BW_NB;
+      L->packet[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      sh->plc_frame = 1; sh->ret = 1;
+      return;
+   }
+   i32 equiv_rate = compute_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity);
+   if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
+   else if (channels == 2) {
+      i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
+      if (st->stream_channels == 2) thr -= 1000; else thr += 1000;
+      st->stream_channels = (equiv_rate > thr) ? 2 : 1;
+   } else st->stream_channels = channels;
+   equiv_rate = compute_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 1, cfg->complexity);
+   {
+      const i32 voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000};
+      const i32 music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};
+      int bandwidth = OA_BW_FB;
+      do {
+         int k = 2 * (bandwidth - OA_BW_MB);
+         int threshold = music_bw[k] + ((voice_est * voice_est * (voice_bw[k] - music_bw[k])) >> 14);
+         int hysteresis = music_bw[k + 1] + ((voice_est * voice_est * (voice_bw[k + 1] - music_bw[k + 1])) >> 14);
+         if (!st->first) { if (st->auto_bandwidth >= bandwidth) threshold -= hysteresis; else threshold += hysteresis; }
+         if (equiv_rate >= threshold) break;
+      } while (--bandwidth > OA_BW_NB);
+      if (bandwidth == OA_BW_MB) bandwidth = OA_BW_WB;
+      st->bandwidth = st->auto_bandwidth = bandwidth;
+   }
+   if (st->bandwidth > cfg->max_bandwidth) st->bandwidth = cfg->max_bandwidth;
+   if (cfg->user_bandwidth != OA_AUTO) st->bandwidth = cfg->user_bandwidth;
+   if (st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
+   int curr_bandwidth = st->bandwidth;
+   sh->curr_bandwidth = curr_bandwidth;
+   sh->lsb_depth = imin(16, cfg->lsb_depth);
+   sh->orig_max_data_bytes = max_data_bytes;
+   sh->max_data_bytes = imin(max_data_bytes, 1276);
+   int endband = 21;
+   if (curr_bandwidth == OA_BW_NB) endband = 13;
+   else if (curr_bandwidth == OA_BW_MB || curr_bandwidth == OA_BW_WB) endband = 17;
+   else if (curr_bandwidth == OA_BW_SWB) endband = 19;
+   sh->start = 0; sh->end = endband; sh->effEnd = endband;
+   sh->C = st->stream_channels;
+   sh->complexity = cfg->complexity; sh->disable_inv = cfg->disable_inv; sh->disable_pf = 0; sh->force_intra = 0; sh->loss_rate = cfg->packet_loss_perc;
+   sh->vbr = cfg->use_vbr; sh->constrained_vbr = cfg->vbr_constraint;
+   sh->bitrate = -1;
+   if (cfg->use_vbr && bitrate_bps > 500) sh->bitrate = imin(bitrate_bps, 750000 * channels);
+   i32 stereoWidth_Q14;
+   if (equiv_rate > 32000) stereoWidth_Q14 = 16384;
+   else if (equiv_rate < 16000) stereoWidth_Q14 = 0;
+   else stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - equiv_rate) / (equiv_rate - 14000);
+   sh->do_stereo_fade = 0;
+   if (channels == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || stereoWidth_Q14 < (1 << 14))) {
+      i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)stereoWidth_Q14;
+      g1 = g1 == 16384 ? Q15ONE : shl16(g1, 1);
+      g2 = g2 == 16384 ? Q15ONE : shl16(g2, 1);
+      sh->do_stereo_fade = 1; sh->fade_g1 = g1; sh->fade_g2 = g2;
+      st->hybrid_stereo_width_Q14 = stereoWidth_Q14;
+   }
+   sh->toc = gen_toc_celt(frame_rate, curr_bandwidth, st->stream_channels);
+   st->prev_mode = 1002;
+   st->first = 0;
+}
+
+/* dc_reject: lanes 0..CC-1 each run one channel's recursion; global int16 PCM in, LDS int16 out (interleaved). */
+WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int channels)
+{
+   int c = wv_lane();
+   if (c < channels) {
+      const int shift = celt_ilog2(48000 / (3 * 4));
+      i32 mem = L->st.hp_mem[2 * c];
+      WV_LDS i16 *out = L->Cc.pcm16;
+      for (int i = 0; i < len; i++) {
+         i32 x = saturate((i32)pcm[channels * i + c], (1 << 16) - 1);
+         x = shl32(x, 14);
+         i32 y = x - mem;
+         mem = mem + pshr32(x - mem, shift);
+         out[channels * i + c] = (i16)saturate(pshr32(y, 14), 32767);
+      }
+      L->st.hp_mem[2 * c] = mem;
+   }
+}
+WV_DEV void stereo_fade_lanes(WV_LDS FrameLds *L, int frame_size)
+{
+   WV_LDS i16 *io = L->Cc.pcm16;
+   i16 g1 = (i16)(Q15ONE - L->sh.fade_g1), g2 = (i16)(Q15ONE - L->sh.fade_g2);
+   FOR_LANES(i, frame_size) {
+      i16 g = g2;
+      if (i < OA_OVERLAP) {
+         i16 w = ct_window[i];
+         w = (i16)mult16_16_q15(w, w);
+         g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15);
+      }
+      i32 diff = half32((i32)io[2 * i] - (i32)io[2 * i + 1]);
+      diff = mult16_16_q15(g, diff);
+      io[2 * i] = (i16)(io[2 * i] - diff);
+      io[2 * i + 1] = (i16)(io[2 * i + 1] + diff);
+   }
+}
+
+/* celt_encode_with_ec prologue (lane 0): byte budget, VBR bounds, silence flag (celt_encoder.c:1858-2008). */
+WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   WV_LDS EcCtx *e = &L->ec;
+   WV_LDS u8 *buf = L->packet + 1;
+   const int Fs = 48000, frame_size = sh->frame_size;
+   int LM;
+   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
+   sh->LM = LM; sh->M = 1 << LM; sh->N = 120 << LM;
+   /* opus_encode_frame_native: ec_enc_init(data+1, orig_max-1), shrink to max_data_bytes-1 */
+   k_ec_enc_init(EC_PASS, sh->orig_max_data_bytes - 1);
+   int nbCompressedBytes = sh->max_data_bytes - 1;
+   k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+   L->packet[0] = 0;
+   if (k_ec_tell(EC_PASS) > 8 * nbCompressedBytes) { sh->skip_celt = 1; return; }
+   int C = sh->C;
+   i32 tell = k_ec_tell(EC_PASS), tell0_frac = k_ec_tell_frac(EC_PASS);
+   int nbFilledBytes = (tell + 4) >> 3, effectiveBytes, nbAvailableBytes;
+   i32 vbr_rate;
+   nbCompressedBytes = imin(nbCompressedBytes, 1275);
+   if (sh->vbr && sh->bitrate != -1) {
+      vbr_rate = bitrate_to_bits(sh->bitrate, Fs, frame_size) << BITRES;
+      effectiveBytes = vbr_rate >> (3 + BITRES);
+   } else {
+      vbr_rate = 0;
+      i32 tmp = sh->bitrate * frame_size;
+      if (tell > 1) tmp += tell * Fs;
+      if (sh->bitrate != -1) {
+         nbCompressedBytes = imax(2, imin(nbCompressedBytes, (tmp + 4 * Fs) / (8 * Fs)));
+         k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+      }
+      effectiveBytes = nbCompressedBytes - nbFilledBytes;
+   }
+   nbAvailableBytes = nbCompressedBytes - nbFilledBytes;
+   i32 equiv_rate = ((i32)nbCompressedBytes * 8 * 50 << (3 - LM)) - (40 * C + 20) * ((400 >> LM) - 50);
+   if (sh->bitrate != -1) equiv_rate = imin(equiv_rate, sh->bitrate - (40 * C + 20) * ((400 >> LM) - 50));
+   if (vbr_rate > 0 && sh->constrained_vbr) {
+      i32 vbr_bound = vbr_rate;
+      i32 max_allowed = imin(imax(tell == 1 ? 2 : 0, (vbr_rate + vbr_bound - st->vbr_reservoir) >> (BITRES + 3)), nbAvailableBytes);
+      if (max_allowed < nbAvailableBytes) {
+         nbCompressedBytes = nbFilledBytes + max_allowed;
+         nbAvailableBytes = max_allowed;
+         k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+      }
+   }
+   i32 total_bits = nbCompressedBytes * 8;
+   /* sample_max pieces were reduced by the wave into r[0] (head) and r[1] (overlap tail) */
+   i32 sample_max = imax(st->overlap_max, sh->r[0]);
+   st->overlap_max = sh->r[1];
+   sample_max = imax(sample_max, st->overlap_max);
+   int silence = (sample_max == 0);
+   if (tell == 1) k_ec_enc_bit_logp(EC_PASS, silence, 15);
+   else silence = 0;
+   if (silence) {
+      if (vbr_rate > 0) {
+         effectiveBytes = nbCompressedBytes = imin(nbCompressedBytes, nbFilledBytes + 2);
+         total_bits = nbCompressedBytes * 8;
+         nbAvailableBytes = 2;
+         k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+      }
+      tell = nbCompressedBytes * 8;
+      e->nbits_total += tell - k_ec_tell(EC_PASS);
+   }
+   sh->nbCompressedBytes = nbCompressedBytes; sh->nbFilledBytes = nbFilledBytes; sh->nbAvailableBytes = nbAvailableBytes;
+   sh->effectiveBytes = effectiveBytes; sh->vbr_rate = vbr_rate; sh->total_bits = total_bits; sh->equiv_rate = equiv_rate;
+   sh->tell = tell; sh->tell0_frac = tell0_frac; sh->silence = silence; sh->sample_max = sample_max;
+}
+
+/* tone detector (celt_encoder.c:1272-1403).  x16 built in parallel, correlations by wave reductions
+ * (plain int32 sums are order-free), 2x2 solve redundantly on every lane (pure scalar code). */
+WV_DEV int acos_approx(i32 x)
+{
+   int flip = x < 0;
+   x = iabs(x);
+   i16 x14 = (i16)(x >> 15);
+   i32 tmp = (762 * x14 >> 14) - 3308;
+   tmp = (tmp * x14 >> 14) + 25726;
+   tmp = tmp * fx_sqrt(imax(0, (1 << 30) - (x << 1))) >> 16;
+   if (flip) tmp = 25736 - tmp;
+   return tmp;
+}
+WV_DEV int tone_lpc_wave(const WV_LDS i16 *x, int len, int delay, i32 *lpc)
+{
+   i32 r00 = 0, r01 = 0, r02 = 0, e1 = 0, e2 = 0, e3 = 0;
+   FOR_LANES(i, len - 2 * delay) {
+      r00 += mult16_16(x[i], x[i]);
+      r01 += mult16_16(x[i], x[i + delay]);
+      r02 += mult16_16(x[i], x[i + 2 * delay]);
+   }
+   FOR_LANES(i, delay) {
+      e1 += mult16_16(x[len + i - 2 * delay], x[len + i - 2 * delay]) - mult16_16(x[i], x[i]);
+      e2 += mult16_16(x[len + i - delay], x[len + i - delay]) - mult16_16(x[i + delay], x[i + delay]);
+      e3 += mult16_16(x[len + i - 2 * delay], x[len + i - delay]) - mult16_16(x[i], x[i + delay]);
+   }
+   r00 = wv_sum(r00); r01 = wv_sum(r01); r02 = wv_sum(r02); e1 = wv_sum(e1); e2 = wv_sum(e2); e3 = wv_sum(e3);
+   i32 r11 = r00 + e1, r22 = r11 + e2, r12 = r01 + e3;
+   {
+      i32 R00 = r00 + r22, R01 = r01 + r12, R11 = 2 * r11, R02 = 2 * r02, R12 = r12 + r01;
+      r00 = R00; r01 = R01; r11 = R11; r02 = R02; r12 = R12;
+   }
+   i32 den = mult32_32_q31(r00, r11) - mult32_32_q31(r01, r01);
+   if (den <= (mult32_32_q31(r00, r11) >> 10)) return 1;
+   i32 num1 = mult32_32_q31(r02, r11) - mult32_32_q31(r01, r12);
+   if (num1 >= den) lpc[1] = QC32(1.f, 29);
+   else if (num1 <= -den) lpc[1] = -QC32(1.f, 29);
+   else lpc[1] = fx_frac_div32_q29(num1, den);
+   i32 num0 = mult32_32_q31(r00, r12) - mult32_32_q31(r02, r01);
+   if (half32(num0) >= den) lpc[0] = QC32(1.999999f, 29);
+   else if (half32(num0) <= -den) lpc[0] = -QC32(1.999999f, 29);
+   else lpc[0] = fx_frac_div32_q29(num0, den);
+   return 0;
+}
+WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L)
+{
+   const int CC = L->sh.CC, N = L->sh.N + OA_OVERLAP;
+   WV_LDS i16 *x = L->Cc.x16[0];
+   const WV_LDS i32 *in0 = L->B.in[0], *in1 = L->B.in[1];
+   i32 ac0 = 0;
+   FOR_LANES(i, N) {
+      i16 v = CC == 2 ? (i16)pshr32(add32(in0[i] >> 1, in1[i] >> 1), SIG_SHIFT + 2) : (i16)pshr32(in0[i], SIG_SHIFT + 2);
+      x[i] = v;
+      ac0 += mult16_16(v, v) >> 10;
+   }
+   ac0 = add32(N, wv_sum(ac0));
+   int shift = 5 - (28 - celt_ilog2(ac0)) / 2;
+   wv_sync();
+   if (shift > 0) { FOR_LANES(i, N) x[i] = (i16)pshr32(x[i], shift); }
+   wv_sync();
+   i32 lpc[2] = {0, 0};
+   int delay = 1;
+   int fail = tone_lpc_wave(x, N, delay, lpc);
+   while (delay <= 48000 / 3000 && (fail || (lpc[0] > QC32(1.f, 29) && lpc[1] < 0))) {
+      delay *= 2;
+      fail = tone_lpc_wave(x, N, delay, lpc);
+   }
+   i32 toneishness; i16 freq;
+   if (!fail && mult32_32_q31(lpc[0], lpc[0]) + mult32_32_q31(QC32(3.999999, 29), lpc[1]) < 0) {
+      toneishness = -lpc[1];
+      freq = (i16)((acos_approx(lpc[0] >> 1) + delay / 2) / delay);
+   } else { freq = -1; toneishness = 0; }
+   wv_sync();
+   LANE0 { L->sh.tone_freq = freq; L->sh.toneishness = toneishness; }
+}
+
+/* transient_analysis (celt_encoder.c:267): the HP filter and the forward/backward masking followers are
+ * recursions with rounding -> one lane per channel runs them; ranges/normalisation use wave reductions. */
+WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, int allow_weak_transients)
+{
+   const u8 inv_table[128] = {
+      255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18, 17, 16, 16, 15, 15, 14, 13, 13, 12, 12,
+      12, 12, 11, 11, 11, 10, 10, 10, 9, 9, 9, 9, 9, 9, 8, 8, 8, 8, 8, 7, 7, 7, 7, 7, 7, 6, 6, 6, 6, 6, 6, 6,
+      6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+      4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2};
+   const int C = L->sh.CC, len = L->sh.N + OA_OVERLAP, len2 = len / 2, lane = wv_lane();
+   const int forward_shift = allow_weak_transients ? 5 : 4;
+   i32 mx = 0;
+   FOR_LANES(i, len) { mx = imax(mx, iabs(L->B.in[0][i])); if (C == 2) mx = imax(mx, iabs(L->B.in[1][i])); }
+   mx = wv_max(mx);                       /* celt_maxabs32 over both channels (|INT32_MIN| cannot occur: SIG range) */
+   const int in_shift = imax(0, celt_ilog2(1 + mx) - 14);
+   wv_sync();
+   if (lane < C) {
+      WV_LDS i16 *tmp = L->Cc.x16[lane];
+      const WV_LDS i32 *in = L->B.in[lane];
+      i32 mem0 = 0, mem1 = 0;
+      for (int i = 0; i < len; i++) {
+         i32 x = in[i] >> in_shift;
+         i32 y = add32(mem0, x);
+         mem0 = mem1 + y - shl32(x, 1);
+         mem1 = x - (y >> 1);
+         tmp[i] = sround16(y, 2);
+      }
+      for (int i = 0; i < 12; i++) tmp[i] = 0;
+   }
+   wv_sync();
+   /* per-channel normalisation to max range */
+   i32 m0 = 0, m1 = 0;
+   FOR_LANES(i, len) { m0 = imax(m0, iabs((i32)L->Cc.x16[0][i])); if (C == 2) m1 = imax(m1, iabs((i32)L->Cc.x16[1][i])); }
+   m0 = wv_max(m0); m1 = wv_max(m1);
+   {
+      int s0 = 14 - celt_ilog2(imax(1, m0)), s1 = 14 - celt_ilog2(imax(1, m1));
+      FOR_LANES(i, len) {
+         if (s0 != 0) L->Cc.x16[0][i] = shl16(L->Cc.x16[0][i], s0);
+         if (C == 2 && s1 != 0) L->Cc.x16[1][i] = shl16(L->Cc.x16[1][i], s1);
+      }
+   }
+   wv_sync();
+   i32 unmask_c = 0;
+   if (lane < C) {
+      WV_LDS i16 *tmp = L->Cc.x16[lane];
+      i32 mean = 0, mem0 = 0, norm;
+      i16 maxE = 0;
+      for (int i = 0; i < len2; i++) {
+         i32 x2 = pshr32(mult16_16(tmp[2 * i], tmp[2 * i]) + mult16_16(tmp[2 * i + 1], tmp[2 * i + 1]), 4);
+         mean += pshr32(x2, 12);
+         mem0 = mem0 + pshr32(x2 - mem0, forward_shift);
+         tmp[i] = (i16)pshr32(mem0, 12);
+      }
+      mem0 = 0;
+      for (int i = len2 - 1; i >= 0; i--) {
+         mem0 = mem0 + pshr32(shl32(tmp[i], 4) - mem0, 3);
+         tmp[i] = (i16)pshr32(mem0, 4);
+         maxE = (i16)imax(maxE, tmp[i]);
+      }
+      mean = mult16_16(fx_sqrt(mean), fx_sqrt(mult16_16(maxE, len2 >> 1)));
+      norm = shl32((i32)len2, 6 + 14) / add32(EPSILON, mean >> 1);
+      i32 unmask = 0;
+      for (int i = 12; i < len2 - 5; i += 4) {
+         int id = imax(0, imin(127, mult16_32_q15(tmp[i] + EPSILON, norm)));
+         unmask += inv_table[id];
+      }
+      unmask_c = 64 * unmask * 4 / (6 * (len2 - 17));
+   }
+   i32 u0 = wv_bcast(unmask_c, 0), u1 = wv_bcast(unmask_c, 1);
+   i32 mask_metric = 0; int tf_chan = L->sh.tf_chan;
+   if (u0 > mask_metric) { tf_chan = 0; mask_metric = u0; }
+   if (C == 2 && u1 > mask_metric) { tf_chan = 1; mask_metric = u1; }
+   int is_transient = mask_metric > 200, weak = 0;
+   if (L->sh.toneishness > QC32(.98f, 29) && (i16)L->sh.tone_freq < QC16(0.026f, 13)) { is_transient = 0; mask_metric = 0; }
+   if (allow_weak_transients && is_transient && mask_metric < 600) { is_transient = 0; weak = 1; }
+   i16 tf_max = (i16)imax(0, fx_sqrt(27 * mask_metric) - 42);
+   i16 tf_estimate = (i16)fx_sqrt(imax(0, shl32(mult16_16(QC16(0.0069, 14), imin(163, tf_max)), 14) - QC32(0.139, 28)));
+   wv_sync();
+   LANE0 { L->sh.isTransient = is_transient; L->sh.weak_transient = weak; L->sh.tf_estimate = tf_estimate; L->sh.tf_chan = tf_chan; }
+}
+#endif

@@ -1,0 +1,448 @@
+/* celt_enc_pitch.h — pitch pre-filter of the CELT encoder on one wavefront.
+ * Reference: celt/celt_encoder.c:1405 run_prefilter, celt/pitch.c:45 find_best_pitch, :103 celt_fir5,
+ * :140 pitch_downsample, :230 celt_pitch_xcorr, :307 pitch_search, :418 compute_pitch_gain, :454 remove_doubling,
+ * celt/celt_lpc.c:37 _celt_lpc, :284 _celt_autocorr, celt/celt.c:166/:238 comb filter.
+ * Every multi-tap sum is a mod-2^32 sum of individually rounded terms, so lanes may add in any order
+ * (SURVEY.md appendix A "reduction-order rule"); decisions stay on uniform scalar code. */
+#ifndef OPUS_AMD_CELT_ENC_PITCH_H
+#define OPUS_AMD_CELT_ENC_PITCH_H
+
+WV_DEV i32 wave_inner16(const WV_LDS i16 *x, const WV_LDS i16 *y, int N)
+{
+   i32 s = 0;
+   FOR_LANES(i, N) s = mac16_16(s, x[i], y[i]);
+   return wv_sum(s);
+}
+WV_DEV void wave_dual_inner16(const WV_LDS i16 *x, const WV_LDS i16 *y1, const WV_LDS i16 *y2, int N, i32 *xy1, i32 *xy2)
+{
+   i32 a = 0, b = 0;
+   FOR_LANES(i, N) { a = mac16_16(a, x[i], y1[i]); b = mac16_16(b, x[i], y2[i]); }
+   *xy1 = wv_sum(a); *xy2 = wv_sum(b);
+}
+
+/* _celt_lpc for order 4 on uniform registers (celt_lpc.c:37) */
+WV_DEV void celt_lpc4(i16 *_lpc, const i32 *ac)
+{
+   const int p = 4;
+   i32 lpc[4] = {0, 0, 0, 0}, r, error = ac[0];
+   if (ac[0] != 0) {
+      for (int i = 0; i < p; i++) {
+         i64 acc = 0;
+         for (int j = 0; j < i; j++) acc += (i64)lpc[j] * (i64)ac[i - j];
+         i32 rr = (i32)(acc >> 31);
+         rr += ac[i + 1] >> 6;
+         r = neg32(fx_frac_div32(shl32(rr, 6), error));
+         lpc[i] = r >> 6;
+         for (int j = 0; j < (i + 1) >> 1; j++) {
+            i32 t1 = lpc[j], t2 = lpc[i - 1 - j];
+            lpc[j] = t1 + mult32_32_q31(r, t2);
+            lpc[i - 1 - j] = t2 + mult32_32_q31(r, t1);
+         }
+         error = error - mult32_32_q31(mult32_32_q31(r, r), error);
+         if (error <= (ac[0] >> 10)) break;
+      }
+   }
+   int iter, idx = 0;
+   for (iter = 0; iter < 10; iter++) {
+      i32 maxabs = 0;
+      for (int i = 0; i < p; i++) { i32 a = iabs(lpc[i]); if (a > maxabs) { maxabs = a; idx = i; } }
+      maxabs = pshr32(maxabs, 13);
+      if (maxabs > 32767) {
+         maxabs = imin(maxabs, 163838);
+         i32 chirp = QC32(0.999, 16) - shl32(maxabs - 32767, 14) / ((maxabs * (idx + 1)) >> 2);
+         i32 chirp_m1 = chirp - 65536;
+         for (int i = 0; i < p - 1; i++) {
+            lpc[i] = mult32_32_q16(chirp, lpc[i]);
+            chirp += pshr32(chirp * chirp_m1, 16);
+         }
+         lpc[p - 1] = mult32_32_q16(chirp, lpc[p - 1]);
+      } else break;
+   }
+   if (iter == 10) { _lpc[0] = 4096; _lpc[1] = _lpc[2] = _lpc[3] = 0; }
+   else for (int i = 0; i < p; i++) _lpc[i] = extract16(pshr32(lpc[i], 13));
+}
+
+/* pitch_downsample (factor 2): pre[c] -> Cc.p.pitch_buf[len], len = (1024+N)>>1 */
+WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, int len, int C)
+{
+   const WV_LDS i32 *x0 = L->A.pre[0], *x1 = L->A.pre[1];
+   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->Cc.p.xcorr;       /* raw low-passed signal (kept for the final FIR) */
+   WV_LDS i16 *xx = L->Cc.p.pitch_buf;                    /* scaled copy for the autocorrelation, then the result */
+   i32 maxabs = 0;
+   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(x0[i])); if (C == 2) maxabs = imax(maxabs, iabs(x1[i])); }
+   maxabs = wv_max(maxabs);
+   if (maxabs < 1) maxabs = 1;
+   int shift = celt_ilog2(maxabs) - 10;
+   if (shift < 0) shift = 0;
+   if (C == 2) shift++;
+   FOR_LANES(i, len) {
+      i16 v;
+      if (i == 0) v = (i16)((x0[1] >> (shift + 2)) + (x0[0] >> (shift + 1)));
+      else v = (i16)((x0[2 * i - 1] >> (shift + 2)) + (x0[2 * i + 1] >> (shift + 2)) + (x0[2 * i] >> (shift + 1)));
+      if (C == 2) {
+         if (i == 0) v = (i16)(v + (x1[1] >> (shift + 2)) + (x1[0] >> (shift + 1)));
+         else v = (i16)(v + (x1[2 * i - 1] >> (shift + 2)) + (x1[2 * i + 1] >> (shift + 2)) + (x1[2 * i] >> (shift + 1)));
+      }
+      x_lp[i] = v;
+   }
+   wv_sync();
+   /* _celt_autocorr(x_lp, ac, NULL, 0, 4, len) */
+   i32 ac[5];
+   {
+      const int n = len, lag = 4, fastN = n - lag;
+      int ac0_shift = celt_ilog2(n + (n >> 4));
+      i32 a0 = 0;
+      FOR_LANES(i, n) a0 += mult16_16(x_lp[i], x_lp[i]) >> ac0_shift;
+      i32 ac0 = add32(1 + (n << 7), wv_sum(a0));
+      ac0 += ac0 >> 7;
+      int sh = celt_ilog2(ac0) - 30 + ac0_shift + 1;
+      sh = sh / 2;
+      const WV_LDS i16 *xptr = x_lp;
+      if (sh > 0) {
+         FOR_LANES(i, n) xx[i] = (i16)pshr32(x_lp[i], sh);
+         xptr = xx;
+         wv_sync();
+      } else sh = 0;
+      for (int k = 0; k <= lag; k++) {
+         i32 s = 0;
+         FOR_LANES(i, fastN) s = mac16_16(s, xptr[i], xptr[i + k]);
+         for (int i = k + fastN + wv_lane(); i < n; i += WV_WIDTH) s = mac16_16(s, xptr[i], xptr[i - k]);
+         ac[k] = wv_sum(s);
+      }
+      sh = 2 * sh;
+      if (sh <= 0) ac[0] += shl32(1, -sh);
+      if (ac[0] < 268435456) {
+         int s2 = 29 - ec_ilog(ac[0]);
+         for (int i = 0; i <= lag; i++) ac[i] = shl32(ac[i], s2);
+      } else if (ac[0] >= 536870912) {
+         int s2 = 1;
+         if (ac[0] >= 1073741824) s2++;
+         for (int i = 0; i <= lag; i++) ac[i] = ac[i] >> s2;
+      }
+   }
+   ac[0] += ac[0] >> 13;
+   for (int i = 1; i <= 4; i++) ac[i] -= mult16_32_q15(2 * i * i, ac[i]);
+   i16 lpc[4], lpc2[5], tmp = Q15ONE, c1 = QC16(.8f, 15);
+   celt_lpc4(lpc, ac);
+   for (int i = 0; i < 4; i++) { tmp = (i16)mult16_16_q15(QC16(.9f, 15), tmp); lpc[i] = (i16)mult16_16_q15(lpc[i], tmp); }
+   lpc2[0] = (i16)(lpc[0] + QC16(.8f, SIG_SHIFT));
+   lpc2[1] = (i16)(lpc[1] + mult16_16_q15(c1, lpc[0]));
+   lpc2[2] = (i16)(lpc[2] + mult16_16_q15(c1, lpc[1]));
+   lpc2[3] = (i16)(lpc[3] + mult16_16_q15(c1, lpc[2]));
+   lpc2[4] = (i16)mult16_16_q15(c1, lpc[3]);
+   wv_sync();
+   /* celt_fir5: a pure FIR on the raw signal -> every output independently */
+   FOR_LANES(i, len) {
+      i32 sum = shl32((i32)x_lp[i], SIG_SHIFT);
+      for (int k = 0; k < 5; k++) { int j = i - 1 - k; i32 m = j >= 0 ? x_lp[j] : 0; sum = mac16_16(sum, lpc2[k], m); }
+      xx[i] = round16(sum, SIG_SHIFT);
+   }
+   wv_sync();
+}
+
+/* find_best_pitch (pitch.c:45): a running-energy recursion with a clamp -> lane 0 */
+WV_DEV void find_best_pitch_l0(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int len, int max_pitch, int *best_pitch, int yshift, i32 maxcorr)
+{
+   i32 Syy = 1;
+   i16 best_num[2] = {-1, -1};
+   i32 best_den[2] = {0, 0};
+   int xshift = celt_ilog2(maxcorr) - 14;
+   best_pitch[0] = 0; best_pitch[1] = 1;
+   for (int j = 0; j < len; j++) Syy = add32(Syy, mult16_16(y[j], y[j]) >> yshift);
+   for (int i = 0; i < max_pitch; i++) {
+      if (xcorr[i] > 0) {
+         i16 xcorr16 = extract16(vshr32(xcorr[i], xshift));
+         i16 num = (i16)mult16_16_q15(xcorr16, xcorr16);
+         if (mult16_32_q15(num, best_den[1]) > mult16_32_q15(best_num[1], Syy)) {
+            if (mult16_32_q15(num, best_den[0]) > mult16_32_q15(best_num[0], Syy)) {
+               best_num[1] = best_num[0]; best_den[1] = best_den[0]; best_pitch[1] = best_pitch[0];
+               best_num[0] = num; best_den[0] = Syy; best_pitch[0] = i;
+            } else { best_num[1] = num; best_den[1] = Syy; best_pitch[1] = i; }
+         }
+      }
+      Syy += (mult16_16(y[i + len], y[i + len]) >> yshift) - (mult16_16(y[i], y[i]) >> yshift);
+      Syy = imax(1, Syy);
+   }
+}
+
+/* pitch_search (pitch.c:307); returns the pitch lag in every lane */
+WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
+{
+   const WV_LDS i16 *y = L->Cc.p.pitch_buf, *x_lp = L->Cc.p.pitch_buf + (OA_MAX_PERIOD >> 1);
+   WV_LDS i16 *x_lp4 = L->Cc.p.x_lp4, *y_lp4 = L->Cc.p.y_lp4;
+   WV_LDS i32 *xcorr = L->Cc.p.xcorr;
+   const int lag = len + max_pitch;
+   i32 xmax = 0, ymax = 0;
+   FOR_LANES(j, len >> 2) { i16 v = x_lp[2 * j]; x_lp4[j] = v; xmax = imax(xmax, iabs((i32)v)); }
+   FOR_LANES(j, lag >> 2) { i16 v = y[2 * j]; y_lp4[j] = v; ymax = imax(ymax, iabs((i32)v)); }
+   xmax = wv_max(xmax); ymax = wv_max(ymax);
+   int shift = celt_ilog2(imax(1, imax(xmax, ymax))) - 14 + celt_ilog2(len) / 2;
+   wv_sync();
+   if (shift > 0) {
+      FOR_LANES(j, len >> 2) x_lp4[j] = x_lp4[j] >> shift;
+      FOR_LANES(j, lag >> 2) y_lp4[j] = y_lp4[j] >> shift;
+      shift *= 2;
+      wv_sync();
+   } else shift = 0;
+   /* coarse search, 4x decimated: one lag per lane */
+   i32 maxcorr = 1;
+   FOR_LANES(i, max_pitch >> 2) {
+      i32 s = 0;
+      for (int j = 0; j < len >> 2; j++) s = mac16_16(s, x_lp4[j], y_lp4[i + j]);
+      xcorr[i] = s;
+      maxcorr = imax(maxcorr, s);
+   }
+   maxcorr = wv_max(maxcorr);
+   wv_sync();
+   LANE0 {
+      int bp[2];
+      find_best_pitch_l0(xcorr, y_lp4, len >> 2, max_pitch >> 2, bp, 0, maxcorr);
+      L->sh.r[0] = bp[0]; L->sh.r[1] = bp[1];
+   }
+   wv_sync();
+   int bp0 = L->sh.r[0], bp1 = L->sh.r[1];
+   wv_sync();
+   /* finer search, 2x decimated, around the two candidates */
+   maxcorr = 1;
+   FOR_LANES(i, max_pitch >> 1) xcorr[i] = 0;
+   wv_sync();
+   for (int i = 0; i < max_pitch >> 1; i++) {
+      if (iabs(i - 2 * bp0) > 2 && iabs(i - 2 * bp1) > 2) continue;
+      i32 s = 0;
+      FOR_LANES(j, len >> 1) s += mult16_16(x_lp[j], y[i + j]) >> shift;
+      s = wv_sum(s);
+      LANE0 xcorr[i] = imax(-1, s);
+      maxcorr = imax(maxcorr, s);
+   }
+   wv_sync();
+   LANE0 {
+      int bp[2] = {bp0, bp1};
+      find_best_pitch_l0(xcorr, y, len >> 1, max_pitch >> 1, bp, shift + 1, maxcorr);
+      int offset = 0;
+      if (bp[0] > 0 && bp[0] < (max_pitch >> 1) - 1) {
+         i32 a = xcorr[bp[0] - 1], b = xcorr[bp[0]], c = xcorr[bp[0] + 1];
+         if ((c - a) > mult16_32_q15(QC16(.7f, 15), b - a)) offset = 1;
+         else if ((a - c) > mult16_32_q15(QC16(.7f, 15), b - c)) offset = -1;
+      }
+      L->sh.r[0] = 2 * bp[0] - offset;
+   }
+   wv_sync();
+   int pitch = L->sh.r[0];
+   wv_sync();
+   return pitch;
+}
+
+WV_DEV i16 pitch_gain_fx(i32 xy, i32 xx, i32 yy)
+{
+   if (xy == 0 || xx == 0 || yy == 0) return 0;
+   int sx = celt_ilog2(xx) - 14, sy = celt_ilog2(yy) - 14, shift = sx + sy;
+   i32 x2y2 = mult16_16(vshr32(xx, sx), vshr32(yy, sy)) >> 14;
+   if (shift & 1) {
+      if (x2y2 < 32768) { x2y2 <<= 1; shift--; }
+      else { x2y2 >>= 1; shift++; }
+   }
+   i16 den = fx_rsqrt_norm(x2y2);
+   i32 g = mult16_32_q15(den, xy);
+   g = vshr32(g, (shift >> 1) - 1);
+   return extract16(imax(-Q15ONE, imin(g, Q15ONE)));
+}
+
+/* remove_doubling (pitch.c:454); all lanes return the same (gain, *T0_) */
+WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperiod, int N, int *T0_, int prev_period, i16 prev_gain)
+{
+   const int second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+   int T, T0, offset, minperiod0 = minperiod;
+   i16 g, g0, pg;
+   i32 xy, xx, yy, xy2, best_xy, best_yy;
+   WV_LDS i32 *yy_lookup = L->Cc.p.yy_lookup;
+   maxperiod /= 2; minperiod /= 2; *T0_ /= 2; prev_period /= 2; N /= 2;
+   const WV_LDS i16 *x = L->Cc.p.pitch_buf + maxperiod;
+   if (*T0_ >= maxperiod) *T0_ = maxperiod - 1;
+   T = T0 = *T0_;
+   wave_dual_inner16(x, x, x - T0, N, &xx, &xy);
+   {  /* yy_lookup[i] = max(0, xx + sum_{j<=i} (x[-j]^2 - x[N-j]^2)) : chunked prefix sum, 8 lags per lane */
+      i32 loc[8], s = 0;
+      int base = 1 + 8 * wv_lane();
+      for (int t = 0; t < 8; t++) {
+         int j = base + t;
+         if (j <= maxperiod) s = s + mult16_16(x[-j], x[-j]) - mult16_16(x[N - j], x[N - j]);
+         loc[t] = s;
+      }
+      i32 excl = wv_scan_incl(s) - s;
+      for (int t = 0; t < 8; t++) { int j = base + t; if (j <= maxperiod) yy_lookup[j] = imax(0, xx + excl + loc[t]); }
+      LANE0 yy_lookup[0] = xx;
+   }
+   wv_sync();
+   yy = yy_lookup[T0];
+   best_xy = xy; best_yy = yy;
+   g = g0 = pitch_gain_fx(xy, xx, yy);
+   for (int k = 2; k <= 15; k++) {
+      int T1, T1b;
+      i16 g1, cont, thresh;
+      T1 = (u32)(2 * T0 + k) / (u32)(2 * k);
+      if (T1 < minperiod) break;
+      if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+      else T1b = (u32)(2 * second_check[k] * T0 + k) / (u32)(2 * k);
+      wave_dual_inner16(x, x - T1, x - T1b, N, &xy, &xy2);
+      xy = half32(xy + xy2);
+      yy = half32(yy_lookup[T1] + yy_lookup[T1b]);
+      g1 = pitch_gain_fx(xy, xx, yy);
+      if (iabs(T1 - prev_period) <= 1) cont = prev_gain;
+      else if (iabs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = prev_gain >> 1;
+      else cont = 0;
+      thresh = (i16)imax(QC16(.3f, 15), mult16_16_q15(QC16(.7f, 15), g0) - cont);
+      if (T1 < 3 * minperiod) thresh = (i16)imax(QC16(.4f, 15), mult16_16_q15(QC16(.85f, 15), g0) - cont);
+      else if (T1 < 2 * minperiod) thresh = (i16)imax(QC16(.5f, 15), mult16_16_q15(QC16(.9f, 15), g0) - cont);
+      if (g1 > thresh) { best_xy = xy; best_yy = yy; T = T1; g = g1; }
+   }
+   if (T < minperiod * 2) {
+      int T1 = T * 5 / 8, T2 = T * 6 / 8;
+      wave_dual_inner16(x, x - T1, x - T2, N, &xy, &xy2);
+      i16 g1 = pitch_gain_fx(xy, xx, yy_lookup[T1]), g2 = pitch_gain_fx(xy2, xx, yy_lookup[T2]);
+      if (g1 >= g || g2 >= g) g = 0;
+   }
+   best_xy = imax(0, best_xy);
+   if (best_yy <= best_xy) pg = Q15ONE;
+   else pg = (i16)(fx_frac_div32(best_xy, best_yy + 1) >> 16);
+   i32 xc[3];
+   for (int k = 0; k < 3; k++) xc[k] = wave_inner16(x, x - (T + k - 1), N);
+   if ((xc[2] - xc[0]) > mult16_32_q15(QC16(.7f, 15), xc[1] - xc[0])) offset = 1;
+   else if ((xc[0] - xc[2]) > mult16_32_q15(QC16(.7f, 15), xc[1] - xc[2])) offset = -1;
+   else offset = 0;
+   if (pg > g) pg = g;
+   *T0_ = 2 * T + offset;
+   if (*T0_ < minperiod0) *T0_ = minperiod0;
+   return pg;
+}
+
+/* comb_filter (celt.c:238) out of place: y[i] from the *unfiltered* x (pre), so all outputs are independent */
+WV_DEV void comb_filter_wave(WV_LDS i32 *y, const WV_LDS i32 *x, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
+{
+   const i16 gains[3][3] = {
+      {QC16(0.3066406250f, 15), QC16(0.2170410156f, 15), QC16(0.1296386719f, 15)},
+      {QC16(0.4638671875f, 15), QC16(0.2680664062f, 15), QC16(0.f, 15)},
+      {QC16(0.7998046875f, 15), QC16(0.1000976562f, 15), QC16(0.f, 15)}};
+   if (g0 == 0 && g1 == 0) { FOR_LANES(i, N) y[i] = x[i]; return; }
+   T0 = imax(T0, OA_MIN_PERIOD);
+   T1 = imax(T1, OA_MIN_PERIOD);
+   i16 g00 = (i16)mult_coef_taps(g0, gains[tapset0][0]), g01 = (i16)mult_coef_taps(g0, gains[tapset0][1]), g02 = (i16)mult_coef_taps(g0, gains[tapset0][2]);
+   i16 g10 = (i16)mult_coef_taps(g1, gains[tapset1][0]), g11 = (i16)mult_coef_taps(g1, gains[tapset1][1]), g12 = (i16)mult_coef_taps(g1, gains[tapset1][2]);
+   if (g0 == g1 && T0 == T1 && tapset0 == tapset1) overlap = 0;
+   FOR_LANES(i, N) {
+      i32 v;
+      if (i < overlap) {
+         i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
+         v = x[i];
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), x[i - T0]));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(x[i - T0 + 1], x[i - T0 - 1])));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(x[i - T0 + 2], x[i - T0 - 2])));
+         v = add32(v, mult_coef_32(mult_coef(f, g10), x[i - T1]));
+         v = add32(v, mult_coef_32(mult_coef(f, g11), add32(x[i - T1 + 1], x[i - T1 - 1])));
+         v = add32(v, mult_coef_32(mult_coef(f, g12), add32(x[i - T1 + 2], x[i - T1 - 2])));
+         v = saturate(sub32(v, 3), SIG_SAT);
+      } else if (g1 == 0) {
+         v = x[i];
+      } else {
+         v = add32(add32(add32(x[i], mult_coef_32(g10, x[i - T1])), mult_coef_32(g11, add32(x[i - T1 + 1], x[i - T1 - 1]))),
+               mult_coef_32(g12, add32(x[i - T1 + 2], x[i - T1 - 2])));
+         v = saturate(sub32(v, 1), SIG_SAT);
+      }
+      y[i] = v;
+   }
+}
+
+/* run_prefilter (celt_encoder.c:1405).  A.pre[c][0..1024) already holds prefilter_mem; B.in[c][overlap..) the new input. */
+WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   const int CC = sh->CC, N = sh->N, overlap = OA_OVERLAP, max_period = OA_MAX_PERIOD, min_period = OA_MIN_PERIOD;
+   const int prefilter_tapset = st->tapset_decision;
+   int pitch_index, pf_on, qg;
+   i16 gain1, pf_threshold;
+   for (int c = 0; c < CC; c++) { FOR_LANES(i, N) L->A.pre[c][max_period + i] = L->B.in[c][overlap + i]; }
+   wv_sync();
+   i16 tone_freq = (i16)sh->tone_freq;
+   if (enabled && sh->toneishness > QC32(.99f, 29)) {
+      int multiple = 1;
+      if (tone_freq >= QC16(3.1416f, 13)) tone_freq = (i16)(QC16(3.141593f, 13) - tone_freq);
+      while (tone_freq >= multiple * QC16(0.39f, 13)) multiple++;
+      if (tone_freq > QC16(0.006148f, 13)) pitch_index = imin((51472 * multiple + tone_freq / 2) / tone_freq, OA_MAX_PERIOD - 2);
+      else pitch_index = OA_MIN_PERIOD;
+      gain1 = QC16(.75f, 15);
+   } else if (enabled && sh->complexity >= 5) {
+      pitch_downsample_wave(L, (max_period + N) >> 1, CC);
+      pitch_index = pitch_search_wave(L, N, max_period - 3 * min_period);
+      pitch_index = max_period - pitch_index;
+      gain1 = remove_doubling_wave(L, max_period, min_period, N, &pitch_index, st->prefilter_period, (i16)st->prefilter_gain);
+      if (pitch_index > max_period - 2) pitch_index = max_period - 2;
+      gain1 = (i16)mult16_16_q15(QC16(.7f, 15), gain1);
+      if (sh->loss_rate > 2) gain1 = (i16)(gain1 >> 1);
+      if (sh->loss_rate > 4) gain1 = (i16)(gain1 >> 1);
+      if (sh->loss_rate > 8) gain1 = 0;
+   } else { gain1 = 0; pitch_index = OA_MIN_PERIOD; }
+   const i16 old_gain = (i16)st->prefilter_gain;
+   pf_threshold = QC16(.2f, 15);
+   if (iabs(pitch_index - st->prefilter_period) * 10 > pitch_index) {
+      pf_threshold += QC16(.2f, 15);
+      if ((i16)sh->tf_estimate > QC16(.98f, 14)) gain1 = 0;
+   }
+   if (sh->nbAvailableBytes < 25) pf_threshold += QC16(.1f, 15);
+   if (sh->nbAvailableBytes < 35) pf_threshold += QC16(.1f, 15);
+   if (old_gain > QC16(.4f, 15)) pf_threshold -= QC16(.1f, 15);
+   if (old_gain > QC16(.55f, 15)) pf_threshold -= QC16(.1f, 15);
+   pf_threshold = (i16)imax(pf_threshold, QC16(.2f, 15));
+   if (gain1 < pf_threshold) { gain1 = 0; pf_on = 0; qg = 0; }
+   else {
+      if (iabs(gain1 - old_gain) < QC16(.1f, 15)) gain1 = old_gain;
+      qg = ((gain1 + 1536) >> 10) / 3 - 1;
+      qg = imax(0, imin(7, qg));
+      gain1 = (i16)(QC16(0.09375f, 15) * (qg + 1));
+      pf_on = 1;
+   }
+   const int old_period = imax(st->prefilter_period, OA_MIN_PERIOD), old_tapset = st->prefilter_tapset;
+   i32 before[2] = {0, 0}, after[2] = {0, 0};
+   wv_sync();
+   /* in[c][0..overlap) <- in_mem: last frame's *filtered* tail (celt_encoder.c:1546) */
+   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) L->B.in[c][i] = L->in_mem[c * overlap + i]; }
+   for (int c = 0; c < CC; c++) {
+      WV_LDS i32 *in = L->B.in[c];
+      i32 b = 0;
+      FOR_LANES(i, N) b += iabs(in[overlap + i] >> 12);
+      before[c] = wv_sum(b);
+   }
+   wv_sync();
+   for (int c = 0; c < CC; c++)
+      comb_filter_wave(L->B.in[c] + overlap, L->A.pre[c] + max_period, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
+   wv_sync();
+   for (int c = 0; c < CC; c++) {
+      i32 a = 0;
+      FOR_LANES(i, N) a += iabs(L->B.in[c][overlap + i] >> 12);
+      after[c] = wv_sum(a);
+   }
+   int cancel_pitch = 0;
+   if (CC == 2) {
+      i16 thresh[2];
+      thresh[0] = (i16)(mult16_32_q15(mult16_16_q15(QC16(.25f, 15), gain1), before[0]) + mult16_32_q15(QC16(.01f, 15), before[1]));
+      thresh[1] = (i16)(mult16_32_q15(mult16_16_q15(QC16(.25f, 15), gain1), before[1]) + mult16_32_q15(QC16(.01f, 15), before[0]));
+      if (after[0] - before[0] > thresh[0] || after[1] - before[1] > thresh[1]) cancel_pitch = 1;
+      if (before[0] - after[0] < thresh[0] && before[1] - after[1] < thresh[1]) cancel_pitch = 1;
+   } else if (after[0] > before[0]) cancel_pitch = 1;
+   if (cancel_pitch) {
+      wv_sync();
+      for (int c = 0; c < CC; c++) {
+         FOR_LANES(i, N) L->B.in[c][overlap + i] = L->A.pre[c][max_period + i];
+      }
+      wv_sync();
+      for (int c = 0; c < CC; c++)
+         comb_filter_wave(L->B.in[c] + overlap, L->A.pre[c] + max_period, old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
+      gain1 = 0; pf_on = 0; qg = 0;
+   }
+   wv_sync();
+   LANE0 {
+      st->prefilter_period = old_period;
+      sh->pf_on = pf_on; sh->pitch_index = pitch_index; sh->gain1 = gain1; sh->qg = qg; sh->prefilter_tapset = prefilter_tapset;
+   }
+   wv_sync();
+}
+#endif

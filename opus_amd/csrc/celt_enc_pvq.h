@@ -1,0 +1,818 @@
+/* celt_enc_pvq.h — PVQ band quantisation on one wavefront (encoder side, with the resynthesis the stereo theta-RDO needs).
+ * Reference: celt/bands.c (:379 intensity_stereo, :405 stereo_split, :418 stereo_merge, :574/:600 hadamard, :623 haar1,
+ * :638 compute_qn, :700 compute_theta, :930 quant_band_n1, :973 quant_partition, :1248 quant_band, :1387 quant_band_stereo,
+ * :1589 quant_all_bands), celt/vq.c (:75 exp_rotation1, :104 exp_rotation, :150 normalise_residual, :183 extract_collapse_mask,
+ * :205 op_pvq_search_c, :552 alg_quant, :695 renormalise_vector, :724 stereo_itheta), celt/cwrs.c:444 icwrs.
+ *
+ * Control flow (budget-driven, band after band) is executed uniformly by all 64 lanes; range-coder calls run on lane 0;
+ * vector work over the N<=176 coefficients of a band is lane-strided with exact wave reductions:
+ *   - greedy pulse search: every lane scores its coefficients, one cross-lane arg-max per pulse (exact 16x16 cross products,
+ *     lowest index wins ties = the reference's scan order);
+ *   - codeword index (icwrs): suffix sums of |y| by a wave scan, then all U(N-j,k) lookups in parallel, summed mod 2^32. */
+#ifndef OPUS_AMD_CELT_ENC_PVQ_H
+#define OPUS_AMD_CELT_ENC_PVQ_H
+#ifndef K_DUMP
+#define K_DUMP(tag, ptr, nbytes)
+#define K_DUMPI(tag, v)
+#endif
+
+struct BandCtx {
+   int resynth, i, intensity, spread, tf_change;
+   i32 remaining_bits;
+   u32 seed;
+   int theta_round, disable_inv, avoid_split_noise;
+};
+struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
+
+#define PVQ_EC &L->ec, (L->packet + 1)
+
+WV_DEV u32 lcg_rand(u32 seed) { return 1664525u * seed + 1013904223u; }
+WV_DEV int bitexact_cos(int x_)
+{
+   i16 x = (i16)x_;
+   i32 tmp = (4096 + ((i32)x * x)) >> 13;
+   i16 x2 = (i16)tmp;
+   x2 = (i16)((32767 - x2) + frac_mul16(x2, (-7651 + frac_mul16(x2, (8277 + frac_mul16(-626, x2))))));
+   return (i16)(1 + x2);
+}
+WV_DEV int bitexact_log2tan(int isin, int icos)
+{
+   int lc = ec_ilog(icos), ls = ec_ilog(isin);
+   icos <<= 15 - lc;
+   isin <<= 15 - ls;
+   return (ls - lc) * (1 << 11) + frac_mul16(isin, frac_mul16(isin, -2597) + 7932) - frac_mul16(icos, frac_mul16(icos, -2597) + 7932);
+}
+WV_DEV u32 pvq_u(int n, int k)
+{
+   int lo = n < k ? n : k, hi = n < k ? k : n;
+   return ct_pvq_u_data[ct_pvq_u_row[lo] + hi];
+}
+
+WV_DEV void haar1_wave(WV_LDS i32 *X, int N0, int stride)
+{
+   N0 >>= 1;
+   FOR_LANES(p, N0 * stride) {
+      int i = p / N0, j = p - i * N0;
+      i32 t1 = mult32_32_q31(QC32(.70710678f, 31), X[stride * 2 * j + i]);
+      i32 t2 = mult32_32_q31(QC32(.70710678f, 31), X[stride * (2 * j + 1) + i]);
+      X[stride * 2 * j + i] = add32(t1, t2);
+      X[stride * (2 * j + 1) + i] = sub32(t1, t2);
+   }
+   wv_sync();
+}
+WV_TABLE int k_ordery_table[30] = {1, 0, 3, 0, 2, 1, 7, 0, 4, 3, 6, 1, 5, 2, 15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10, 5};
+WV_DEV void deinterleave_hadamard_wave(WV_LDS i32 *X, WV_LDS i32 *tmp, int N0, int stride, int hadamard)
+{
+   int N = N0 * stride;
+   FOR_LANES(p, N) {
+      int i = p / N0, j = p - i * N0;
+      int dst = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
+      tmp[dst] = X[j * stride + i];
+   }
+   wv_sync();
+   FOR_LANES(p, N) X[p] = tmp[p];
+   wv_sync();
+}
+WV_DEV void interleave_hadamard_wave(WV_LDS i32 *X, WV_LDS i32 *tmp, int N0, int stride, int hadamard)
+{
+   int N = N0 * stride;
+   FOR_LANES(p, N) {
+      int i = p / N0, j = p - i * N0;
+      int src = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
+      tmp[j * stride + i] = X[src];
+   }
+   wv_sync();
+   FOR_LANES(p, N) X[p] = tmp[p];
+   wv_sync();
+}
+WV_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)
+{
+   const i16 exp2_table8[8] = {16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048};
+   int qn, qb, N2 = 2 * N - 1;
+   if (stereo && N == 2) N2--;
+   qb = (b + N2 * offset) / N2;
+   qb = imin(b - pulse_cap - (4 << BITRES), qb);
+   qb = imin(8 << BITRES, qb);
+   if (qb < (1 << BITRES >> 1)) qn = 1;
+   else {
+      qn = exp2_table8[qb & 0x7] >> (14 - (qb >> BITRES));
+      qn = (qn + 1) >> 1 << 1;
+   }
+   return qn;
+}
+WV_DEV void compute_channel_weights(i32 Ex, i32 Ey, i16 w[2])
+{
+   i32 minE = imin(Ex, Ey);
+   Ex = add32(Ex, minE / 3);
+   Ey = add32(Ey, minE / 3);
+   int shift = celt_ilog2(EPSILON + imax(Ex, Ey)) - 14;
+   w[0] = (i16)vshr32(Ex, shift);
+   w[1] = (i16)vshr32(Ey, shift);
+}
+WV_DEV void intensity_stereo_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, const WV_LDS i32 *Y, int bandID, int N)
+{
+   const WV_LDS i32 *bandE = L->bandE;
+   int i = bandID;
+   int shift = celt_zlog2(imax(bandE[i], bandE[i + NBE])) - 13;
+   i16 left = (i16)vshr32(bandE[i], shift), right = (i16)vshr32(bandE[i + NBE], shift);
+   i16 norm = (i16)(EPSILON + fx_sqrt(EPSILON + mult16_16(left, left) + mult16_16(right, right)));
+   left = (i16)imin(left, norm - 1);
+   right = (i16)imin(right, norm - 1);
+   i16 a1 = (i16)(shl32((i32)left, 15) / norm), a2 = (i16)(shl32((i32)right, 15) / norm);
+   FOR_LANES(j, N) X[j] = add32(mult16_32_q15(a1, X[j]), mult16_32_q15(a2, Y[j]));
+   wv_sync();
+}
+WV_DEV void stereo_split_wave(WV_LDS i32 *X, WV_LDS i32 *Y, int N)
+{
+   FOR_LANES(j, N) {
+      i32 l = mult32_32_q31(QC32(.70710678f, 31), X[j]);
+      i32 r = mult32_32_q31(QC32(.70710678f, 31), Y[j]);
+      X[j] = add32(l, r);
+      Y[j] = sub32(r, l);
+   }
+   wv_sync();
+}
+WV_DEV void stereo_merge_wave(WV_LDS i32 *X, WV_LDS i32 *Y, i32 mid, int N)
+{
+   i32 xp = inner_prod_norm_shift_w(Y, X, N), side = inner_prod_norm_shift_w(Y, Y, N);
+   xp = mult32_32_q31(mid, xp);
+   i32 El = (mult32_32_q31(mid, mid) >> 3) + side - 2 * xp;
+   i32 Er = (mult32_32_q31(mid, mid) >> 3) + side + 2 * xp;
+   if (Er < QC32(6e-4f, 28) || El < QC32(6e-4f, 28)) { FOR_LANES(j, N) Y[j] = X[j]; wv_sync(); return; }
+   int kl = celt_ilog2(El) >> 1, kr = celt_ilog2(Er) >> 1;
+   i32 t = vshr32(El, (kl << 1) - 29);
+   i32 lgain = fx_rsqrt_norm32(t);
+   t = vshr32(Er, (kr << 1) - 29);
+   i32 rgain = fx_rsqrt_norm32(t);
+   if (kl < 7) kl = 7;
+   if (kr < 7) kr = 7;
+   FOR_LANES(j, N) {
+      i32 l = mult32_32_q31(mid, X[j]), r = Y[j];
+      X[j] = vshr32(mult32_32_q31(lgain, sub32(l, r)), kl - 15);
+      Y[j] = vshr32(mult32_32_q31(rgain, add32(l, r)), kr - 15);
+   }
+   wv_sync();
+}
+WV_DEV i32 stereo_itheta_wave(const WV_LDS i32 *X, const WV_LDS i32 *Y, int stereo, int N)
+{
+   i32 Emid = 0, Eside = 0;
+   if (stereo) {
+      FOR_LANES(i, N) {
+         i32 m = pshr32(add32(X[i], Y[i]), NORM_SHIFT - 13);
+         i32 s = pshr32(sub32(X[i], Y[i]), NORM_SHIFT - 13);
+         Emid = mac16_16(Emid, m, m);
+         Eside = mac16_16(Eside, s, s);
+      }
+      Emid = wv_sum(Emid); Eside = wv_sum(Eside);
+   } else {
+      Emid = inner_prod_norm_shift_w(X, X, N);
+      Eside = inner_prod_norm_shift_w(Y, Y, N);
+   }
+   i32 mid = fx_sqrt32(Emid), side = fx_sqrt32(Eside);
+   return fx_atan2p_norm(side, mid);
+}
+
+/* exp_rotation (vq.c:104): the rotation chain along a block is a recursion with rounding -> one lane per block */
+WV_DEV void exp_rotation1_l(WV_LDS i32 *X, int len, int stride, i16 c, i16 s)
+{
+   i16 ms = (i16)(-s);
+   for (int i = 0; i < len; i++) X[i] = pshr32(X[i], NORM_SHIFT - 14);
+   WV_LDS i32 *Xptr = X;
+   for (int i = 0; i < len - stride; i++) {
+      i32 x1 = Xptr[0], x2 = Xptr[stride];
+      Xptr[stride] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
+      *Xptr++ = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
+   }
+   Xptr = &X[len - 2 * stride - 1];
+   for (int i = len - 2 * stride - 1; i >= 0; i--) {
+      i32 x1 = Xptr[0], x2 = Xptr[stride];
+      Xptr[stride] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
+      *Xptr-- = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
+   }
+   for (int i = 0; i < len; i++) X[i] = shl32(X[i], NORM_SHIFT - 14);
+}
+WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K, int spread)
+{
+   const int SPREAD_FACTOR[3] = {15, 10, 5};
+   int stride2 = 0;
+   if (2 * K >= len || spread == 0) return;
+   int factor = SPREAD_FACTOR[spread - 1];
+   i16 gain = (i16)fx_div(mult16_16(Q15ONE, len), (i32)(len + factor * K));
+   i16 theta = (i16)(mult16_16_q15(gain, gain) >> 1);
+   i16 c = fx_cos_norm(theta);
+   i16 s = fx_cos_norm(sub16(Q15ONE, theta));
+   if (len >= 8 * stride) {
+      stride2 = 1;
+      while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
+   }
+   len = (u32)len / (u32)stride;
+   int i = wv_lane();
+   if (i < stride) {
+      if (dir < 0) {
+         if (stride2) exp_rotation1_l(X + i * len, len, stride2, s, c);
+         exp_rotation1_l(X + i * len, len, 1, c, s);
+      } else {
+         exp_rotation1_l(X + i * len, len, 1, c, (i16)-s);
+         if (stride2) exp_rotation1_l(X + i * len, len, stride2, s, (i16)-c);
+      }
+   }
+   wv_sync();
+}
+
+/* op_pvq_search (vq.c:205).  Returns yy in every lane; iy[] in LDS. */
+WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
+{
+   WV_LDS i32 *iy = L->A.s.pvq.iy, *y = L->A.s.pvq.ysearch;
+   const int lane = wv_lane();
+   {
+      int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
+      shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
+      K_DUMPI("dbg_shift", shift);
+      if (shift > 0) { FOR_LANES(j, N) X[j] = pshr32(X[j], shift); }
+   }
+   u32 signbits[3] = {0, 0, 0};
+   { int t = 0; for (int j = lane; j < N; j += WV_WIDTH, t++) { i32 v = X[j]; signbits[t] = v < 0; X[j] = iabs(v); iy[j] = 0; y[j] = 0; } }
+   wv_sync();
+   i32 xy = 0; i16 yy = 0;
+   int pulsesLeft = K;
+   if (K > (N >> 1)) {
+      i32 s = 0;
+      FOR_LANES(j, N) s += X[j];
+      i32 sum = wv_sum(s);
+      if (sum <= K) {
+         wv_sync();
+         FOR_LANES(j, N) X[j] = j == 0 ? QC16(1.f, 14) : 0;
+         sum = QC16(1.f, 14);
+         wv_sync();
+      }
+      i16 rcp = extract16(mult16_32_q16(K, fx_rcp(sum)));
+      K_DUMPI("dbg_sum", sum); K_DUMPI("dbg_rcp", rcp);
+      i32 yyp = 0, xyp = 0, used = 0;
+      FOR_LANES(j, N) {
+         i32 q = mult16_16_q15(X[j], rcp);
+         iy[j] = q;
+         yyp = mac16_16(yyp, q, q);
+         xyp = mac16_16(xyp, X[j], q);
+         y[j] = 2 * q;
+         used += q;
+      }
+      yy = (i16)wv_sum(yyp);
+      xy = wv_sum(xyp);
+      pulsesLeft -= wv_sum(used);
+      wv_sync();
+   }
+   K_DUMPI("dbg_pulsesLeft", pulsesLeft); K_DUMPI("dbg_yy", yy); K_DUMPI("dbg_xy", xy);
+   if (pulsesLeft > N + 3) {
+      i16 tmp = (i16)pulsesLeft;
+      yy = (i16)mac16_16(yy, tmp, tmp);
+      yy = (i16)mac16_16(yy, tmp, y[0]);
+      wv_sync();
+      LANE0 iy[0] += pulsesLeft;
+      pulsesLeft = 0;
+      wv_sync();
+   }
+   for (int i = 0; i < pulsesLeft; i++) {
+      int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
+      yy = add16(yy, 1);
+      i32 best_num = -1, best_den = 1, best_id = 0x7fffffff;
+      for (int j = lane; j < N; j += WV_WIDTH) {
+         i16 Rxy = extract16(add32(xy, X[j]) >> rshift);
+         i16 Ryy = add16(yy, y[j]);
+         Rxy = (i16)mult16_16_q15(Rxy, Rxy);
+         if (best_num < 0 || mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = j; }
+      }
+      wv_argmax_ratio(best_num, best_den, best_id);
+      xy = add32(xy, X[best_id]);
+      yy = add16(yy, y[best_id]);
+      wv_sync();
+      LANE0 { y[best_id] += 2; iy[best_id]++; }
+      wv_sync();
+   }
+   { int t = 0; for (int j = lane; j < N; j += WV_WIDTH, t++) { i32 sg = (i32)signbits[t]; iy[j] = (iy[j] ^ -sg) + sg; } }
+   wv_sync();
+   return yy;
+}
+
+/* encode_pulses (cwrs.c:444-465): index = (y[n-1]<0) + sum_j U(n-j, k_{j+1}) + [y_j<0] U(n-j, k_j+1), k_j = sum_{i>=j}|y_i| */
+WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
+{
+   const WV_LDS i32 *y = L->A.s.pvq.iy;
+   const int lane = wv_lane(), j0 = 3 * lane;
+   i32 a[3], tot = 0;
+   for (int t = 0; t < 3; t++) { int j = j0 + t; a[t] = j < N ? iabs(y[j]) : 0; tot += a[t]; }
+   i32 incl = wv_scan_incl(tot);
+   i32 k = K - incl;                     /* sum over lanes above this one = suffix beyond the chunk */
+   u32 idx = 0;
+   for (int t = 2; t >= 0; t--) {
+      int j = j0 + t;
+      if (j < N) {
+         if (j == N - 1) { idx += y[j] < 0; k = a[t]; }
+         else {
+            idx += pvq_u(N - j, k);
+            k += a[t];
+            if (y[j] < 0) idx += pvq_u(N - j, k + 1);
+         }
+      }
+   }
+   idx = wv_sumu(idx);
+   LANE0 k_ec_enc_uint(PVQ_EC, idx, pvq_u(N, K) + pvq_u(N, K + 1));
+   wv_sync();
+}
+
+/* alg_quant (vq.c:552) */
+WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
+{
+   WV_LDS i32 *iy = L->A.s.pvq.iy;
+   K_DUMP("pvqX", X, N * 4);
+   exp_rotation_wave(X, N, 1, B, K, spread);
+   i32 yy = op_pvq_search_wave(L, X, K, N);
+   unsigned cm = 1;
+   if (B > 1) {
+      int N0 = (u32)N / (u32)B;
+      u32 m = 0;
+      FOR_LANES(j, N) if (iy[j] != 0) m |= 1u << (j / N0);
+      cm = wv_or(m);
+   }
+   K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K);
+   encode_pulses_wave(L, N, K);
+   if (resynth) {
+      int k = celt_ilog2(yy) >> 1;
+      i32 t = vshr32(yy, 2 * (k - 7) - 15);
+      i32 g = mult32_32_q31(fx_rsqrt_norm32(t), gain);
+      FOR_LANES(i, N) X[i] = vshr32(mult16_32_q15(iy[i], g), k + 15 - NORM_SHIFT);
+      wv_sync();
+      exp_rotation_wave(X, N, -1, B, K, spread);
+   }
+   return cm;
+}
+WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
+{
+   i32 e = 0;
+   FOR_LANES(i, N) { i32 v = pshr32(X[i], NORM_SHIFT - 14); e = add32(e, (i32)((u32)v * (u32)v)); }
+   i32 E = add32(EPSILON, wv_sum(e));
+   int k = celt_ilog2(E) >> 1;
+   i32 t = vshr32(E, 2 * (k - 7));
+   i16 g = (i16)mult32_32_q31(fx_rsqrt_norm(t), gain);
+   FOR_LANES(i, N) { i32 v = pshr32(X[i], NORM_SHIFT - 14); X[i] = shl32((i32)extract16(pshr32(mult16_16(g, v), k + 15 - 14)), NORM_SHIFT - 14); }
+   wv_sync();
+}
+
+WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int *b, int B, int B0,
+      int LM, int stereo, int *fill)
+{
+   int qn, itheta = 0, delta, imid, iside, qalloc, pulse_cap, offset, inv = 0;
+   const int i = ctx->i, intensity = ctx->intensity;
+   pulse_cap = ct_logN[i] + LM * (1 << BITRES);
+   offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
+   qn = compute_qn(N, *b, offset, pulse_cap, stereo);
+   if (stereo && i >= intensity) qn = 1;
+   itheta = stereo_itheta_wave(X, Y, stereo, N) >> 16;
+   wv_sync();
+   i32 tell = k_ec_tell_frac(PVQ_EC);
+   wv_sync();
+   if (qn != 1) {
+      if (!stereo || ctx->theta_round == 0) {
+         itheta = (itheta * (i32)qn + 8192) >> 14;
+         if (!stereo && ctx->avoid_split_noise && itheta > 0 && itheta < qn) {
+            int unquantized = (u32)((i32)itheta * 16384) / (u32)qn;
+            imid = bitexact_cos((i16)unquantized);
+            iside = bitexact_cos((i16)(16384 - unquantized));
+            delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
+            if (delta > *b) itheta = qn;
+            else if (delta < -*b) itheta = 0;
+         }
+      } else {
+         int bias = itheta > 8192 ? 32767 / qn : -32767 / qn;
+         int down = imin(qn - 1, imax(0, (itheta * (i32)qn + bias) >> 14));
+         itheta = ctx->theta_round < 0 ? down : down + 1;
+      }
+      LANE0 {
+         if (stereo && N > 2) {
+            int p0 = 3, x = itheta, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
+            k_ec_encode(PVQ_EC, x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
+         } else if (B0 > 1 || stereo) {
+            k_ec_enc_uint(PVQ_EC, itheta, qn + 1);
+         } else {
+            int ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
+            int fs = itheta <= (qn >> 1) ? itheta + 1 : qn + 1 - itheta;
+            int fl = itheta <= (qn >> 1) ? itheta * (itheta + 1) >> 1 : ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
+            k_ec_encode(PVQ_EC, fl, fl + fs, ft);
+         }
+      }
+      itheta = (u32)((i32)itheta * 16384) / (u32)qn;
+      if (stereo) {
+         if (itheta == 0) intensity_stereo_wave(L, X, Y, i, N);
+         else stereo_split_wave(X, Y, N);
+      }
+   } else if (stereo) {
+      inv = itheta > 8192 && !ctx->disable_inv;
+      if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
+      intensity_stereo_wave(L, X, Y, i, N);
+      if (*b > 2 << BITRES && ctx->remaining_bits > 2 << BITRES) {
+         LANE0 k_ec_enc_bit_logp(PVQ_EC, inv, 2);
+      } else inv = 0;
+      if (ctx->disable_inv) inv = 0;
+      itheta = 0;
+   }
+   wv_sync();
+   qalloc = k_ec_tell_frac(PVQ_EC) - tell;
+   *b -= qalloc;
+   if (itheta == 0) { imid = 32767; iside = 0; *fill &= (1 << B) - 1; delta = -16384; }
+   else if (itheta == 16384) { imid = 0; iside = 32767; *fill &= ((1 << B) - 1) << B; delta = 16384; }
+   else {
+      imid = bitexact_cos((i16)itheta);
+      iside = bitexact_cos((i16)(16384 - itheta));
+      delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
+   }
+   K_DUMPI("itheta", itheta); K_DUMPI("qn", qn);
+   sctx->inv = inv; sctx->imid = imid; sctx->iside = iside; sctx->delta = delta; sctx->itheta = itheta; sctx->qalloc = qalloc;
+}
+
+WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, WV_LDS i32 *Y, WV_LDS i32 *lowband_out)
+{
+   WV_LDS i32 *x = X;
+   int stereo = Y != 0;
+   wv_sync();
+   for (int c = 0; c < 1 + stereo; c++) {
+      int sign = 0;
+      if (ctx->remaining_bits >= 1 << BITRES) {
+         sign = x[0] < 0;
+         LANE0 k_ec_enc_bits(PVQ_EC, sign, 1);
+         ctx->remaining_bits -= 1 << BITRES;
+      }
+      if (ctx->resynth) { wv_sync(); LANE0 x[0] = sign ? -(1 << NORM_SHIFT) : (1 << NORM_SHIFT); wv_sync(); }
+      x = Y;
+   }
+   wv_sync();
+   if (lowband_out) { LANE0 lowband_out[0] = X[0] >> 4; }
+   wv_sync();
+   return 1;
+}
+
+template <int DEPTH>
+WV_DEVN unsigned quant_partition_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM, i32 gain, int fill)
+{
+   int B0 = B;
+   const int i = ctx->i, spread = ctx->spread;
+   unsigned cm = 0;
+   const u8 *cache = ct_cache_bits + ct_cache_index[(LM + 1) * NBE + i];
+   bool split = LM != -1 && b > cache[cache[0]] + 12 && N > 2;
+   if constexpr (DEPTH < 4) {
+      if (split) {
+         int mbits, sbits, delta, itheta, qalloc;
+         SplitCtx sctx;
+         WV_LDS i32 *next_lowband2 = 0, *Y;
+         i32 rebalance, mid, side;
+         N >>= 1;
+         Y = X + N;
+         LM -= 1;
+         if (B == 1) fill = (fill & 1) | (fill << 1);
+         B = (B + 1) >> 1;
+         compute_theta_wave(L, ctx, &sctx, X, Y, N, &b, B, B0, LM, 0, &fill);
+         delta = sctx.delta; itheta = sctx.itheta; qalloc = sctx.qalloc;
+         mid = shl32((i32)sctx.imid, 16);
+         side = shl32((i32)sctx.iside, 16);
+         if (B0 > 1 && (itheta & 0x3fff)) {
+            if (itheta > 8192) delta -= delta >> (4 - LM);
+            else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
+         }
+         mbits = imax(0, imin(b, (b - delta) / 2));
+         sbits = b - mbits;
+         ctx->remaining_bits -= qalloc;
+         if (lowband) next_lowband2 = lowband + N;
+         rebalance = ctx->remaining_bits;
+         if (mbits >= sbits) {
+            cm = quant_partition_wave<DEPTH + 1>(L, ctx, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
+            rebalance = mbits - (rebalance - ctx->remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+            cm |= quant_partition_wave<DEPTH + 1>(L, ctx, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B) << (B0 >> 1);
+         } else {
+            cm = quant_partition_wave<DEPTH + 1>(L, ctx, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B) << (B0 >> 1);
+            rebalance = sbits - (rebalance - ctx->remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+            cm |= quant_partition_wave<DEPTH + 1>(L, ctx, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
+         }
+         return cm;
+      }
+   }
+   {
+      int q = k_bits2pulses(i, LM, b);
+      int curr_bits = k_pulses2bits(i, LM, q);
+      ctx->remaining_bits -= curr_bits;
+      while (ctx->remaining_bits < 0 && q > 0) {
+         ctx->remaining_bits += curr_bits;
+         q--;
+         curr_bits = k_pulses2bits(i, LM, q);
+         ctx->remaining_bits -= curr_bits;
+      }
+      if (q != 0) {
+         int K = k_get_pulses(q);
+         cm = alg_quant_wave(L, X, N, K, spread, B, gain, ctx->resynth);
+      } else if (ctx->resynth) {
+         unsigned cm_mask = (unsigned)(1UL << B) - 1;
+         fill &= cm_mask;
+         if (!fill) { FOR_LANES(j, N) X[j] = 0; wv_sync(); }
+         else {
+            wv_sync();
+            u32 seed = ctx->seed;
+            if (lowband == 0) {
+               LANE0 { u32 s = seed; for (int j = 0; j < N; j++) { s = lcg_rand(s); X[j] = shl32((i32)((i32)s >> 20), NORM_SHIFT - 14); } }
+               cm = cm_mask;
+            } else {
+               LANE0 {
+                  u32 s = seed;
+                  for (int j = 0; j < N; j++) {
+                     s = lcg_rand(s);
+                     i16 tmp = QC16(1.0f / 256, NORM_SHIFT - 4);
+                     tmp = (s) & 0x8000 ? tmp : -tmp;
+                     X[j] = lowband[j] + tmp;
+                  }
+               }
+               cm = fill;
+            }
+            for (int j = 0; j < N; j++) seed = lcg_rand(seed);      /* every lane advances its private copy identically */
+            ctx->seed = seed;
+            wv_sync();
+            renormalise_vector_wave(X, N, gain);
+         }
+      }
+   }
+   return cm;
+}
+
+WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
+      WV_LDS i32 *lowband_out, i32 gain, WV_LDS i32 *lowband_scratch, int fill)
+{
+   const u8 bit_interleave_table[16] = {0, 1, 1, 1, 2, 3, 3, 3, 2, 3, 3, 3, 2, 3, 3, 3};
+   const u8 bit_deinterleave_table[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F, 0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
+   int N0 = N, N_B = N, N_B0, B0 = B, time_divide = 0, recombine = 0, longBlocks, k;
+   unsigned cm = 0;
+   int tf_change = ctx->tf_change;
+   WV_LDS i32 *hada = L->A.s.pvq.hada_tmp;
+   longBlocks = B0 == 1;
+   N_B = (u32)N_B / (u32)B;
+   if (N == 1) return quant_band_n1_wave(L, ctx, X, 0, lowband_out);
+   if (tf_change > 0) recombine = tf_change;
+   if (lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
+      wv_sync();
+      FOR_LANES(j, N) lowband_scratch[j] = lowband[j];
+      wv_sync();
+      lowband = lowband_scratch;
+   }
+   for (k = 0; k < recombine; k++) {
+      haar1_wave(X, N >> k, 1 << k);
+      if (lowband) haar1_wave(lowband, N >> k, 1 << k);
+      fill = bit_interleave_table[fill & 0xF] | bit_interleave_table[fill >> 4] << 2;
+   }
+   B >>= recombine;
+   N_B <<= recombine;
+   while ((N_B & 1) == 0 && tf_change < 0) {
+      haar1_wave(X, N_B, B);
+      if (lowband) haar1_wave(lowband, N_B, B);
+      fill |= fill << B;
+      B <<= 1;
+      N_B >>= 1;
+      time_divide++;
+      tf_change++;
+   }
+   B0 = B;
+   N_B0 = N_B;
+   if (B0 > 1) {
+      deinterleave_hadamard_wave(X, hada, N_B >> recombine, B0 << recombine, longBlocks);
+      if (lowband) deinterleave_hadamard_wave(lowband, hada, N_B >> recombine, B0 << recombine, longBlocks);
+   }
+   cm = quant_partition_wave<0>(L, ctx, X, N, b, B, lowband, LM, gain, fill);
+   if (ctx->resynth) {
+      if (B0 > 1) interleave_hadamard_wave(X, hada, N_B >> recombine, B0 << recombine, longBlocks);
+      N_B = N_B0;
+      B = B0;
+      for (k = 0; k < time_divide; k++) {
+         B >>= 1;
+         N_B <<= 1;
+         cm |= cm >> B;
+         haar1_wave(X, N_B, B);
+      }
+      for (k = 0; k < recombine; k++) {
+         cm = bit_deinterleave_table[cm];
+         haar1_wave(X, N0 >> k, 1 << k);
+      }
+      B <<= recombine;
+      if (lowband_out) {
+         i16 n = (i16)fx_sqrt(shl32((i32)N0, 22));
+         wv_sync();
+         FOR_LANES(j, N0) lowband_out[j] = mult16_32_q15(n, X[j]);
+         wv_sync();
+      }
+      cm &= (1 << B) - 1;
+   }
+   return cm;
+}
+
+WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, WV_LDS i32 *lowband_out, WV_LDS i32 *lowband_scratch, int fill)
+{
+   int inv = 0, mbits, sbits, delta, itheta, qalloc, orig_fill;
+   i32 mid = 0, side = 0;
+   unsigned cm = 0;
+   SplitCtx sctx;
+   if (N == 1) return quant_band_n1_wave(L, ctx, X, Y, lowband_out);
+   orig_fill = fill;
+   if (L->bandE[ctx->i] < 2 || L->bandE[NBE + ctx->i] < 2) {
+      wv_sync();
+      if (L->bandE[ctx->i] > L->bandE[NBE + ctx->i]) { FOR_LANES(j, N) Y[j] = X[j]; }
+      else { FOR_LANES(j, N) X[j] = Y[j]; }
+      wv_sync();
+   }
+   compute_theta_wave(L, ctx, &sctx, X, Y, N, &b, B, B, LM, 1, &fill);
+   inv = sctx.inv; delta = sctx.delta; itheta = sctx.itheta; qalloc = sctx.qalloc;
+   mid = shl32((i32)sctx.imid, 16);
+   side = shl32((i32)sctx.iside, 16);
+   if (N == 2) {
+      int c, sign = 0;
+      WV_LDS i32 *x2, *y2;
+      mbits = b;
+      sbits = 0;
+      if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
+      mbits -= sbits;
+      c = itheta > 8192;
+      ctx->remaining_bits -= qalloc + sbits;
+      x2 = c ? Y : X;
+      y2 = c ? X : Y;
+      wv_sync();
+      if (sbits) {
+         sign = mult32_32_q31(x2[0], y2[1]) - mult32_32_q31(x2[1], y2[0]) < 0;
+         LANE0 k_ec_enc_bits(PVQ_EC, sign, 1);
+      }
+      sign = 1 - 2 * sign;
+      cm = quant_band_wave(L, ctx, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);
+      wv_sync();
+      LANE0 { y2[0] = -sign * x2[1]; y2[1] = sign * x2[0]; }
+      wv_sync();
+      if (ctx->resynth) {
+         LANE0 {
+            i32 tmp;
+            X[0] = mult32_32_q31(mid, X[0]);
+            X[1] = mult32_32_q31(mid, X[1]);
+            Y[0] = mult32_32_q31(side, Y[0]);
+            Y[1] = mult32_32_q31(side, Y[1]);
+            tmp = X[0]; X[0] = sub32(tmp, Y[0]); Y[0] = add32(tmp, Y[0]);
+            tmp = X[1]; X[1] = sub32(tmp, Y[1]); Y[1] = add32(tmp, Y[1]);
+         }
+         wv_sync();
+      }
+   } else {
+      i32 rebalance;
+      mbits = imax(0, imin(b, (b - delta) / 2));
+      sbits = b - mbits;
+      ctx->remaining_bits -= qalloc;
+      rebalance = ctx->remaining_bits;
+      if (mbits >= sbits) {
+         cm = quant_band_wave(L, ctx, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
+         rebalance = mbits - (rebalance - ctx->remaining_bits);
+         if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+         cm |= quant_band_wave(L, ctx, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
+      } else {
+         cm = quant_band_wave(L, ctx, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
+         rebalance = sbits - (rebalance - ctx->remaining_bits);
+         if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+         cm |= quant_band_wave(L, ctx, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
+      }
+   }
+   if (ctx->resynth) {
+      if (N != 2) stereo_merge_wave(X, Y, mid, N);
+      if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
+   }
+   return cm;
+}
+
+WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int spread, int dual_stereo, int intensity, i32 total_bits, i32 balance,
+      int codedBands, int complexity, int disable_inv)
+{
+   const int start = L->sh.start, end = L->sh.end, LM = L->sh.LM, C = L->sh.C, Nfull = L->sh.N;
+   WV_LDS i32 *X_ = L->A.s.X, *Y_ = C == 2 ? L->A.s.X + Nfull : 0;
+   WV_LDS PvqScratch *P = &L->A.s.pvq;
+   WV_LDS i32 *norm = L->B.s.norm, *norm2 = L->B.s.norm + 800;
+   WV_LDS u8 *collapse_masks = L->collapse_masks;
+   const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
+   i32 remaining_bits;
+   int M = 1 << LM, B = shortBlocks ? M : 1, lowband_offset = 0, update_lowband = 1;
+   int norm_offset = M * ct_eBands[start];
+   int theta_rdo = Y_ != 0 && !dual_stereo && complexity >= 8;
+   int resynth = theta_rdo;
+   WV_LDS i32 *lowband_scratch = P->lowband_scratch;
+   BandCtx ctx;
+   ctx.intensity = intensity; ctx.seed = L->st.rng; ctx.spread = spread; ctx.disable_inv = disable_inv; ctx.resynth = resynth;
+   ctx.theta_round = 0; ctx.avoid_split_noise = B > 1; ctx.i = 0; ctx.tf_change = 0; ctx.remaining_bits = 0;
+   for (int i = start; i < end; i++) {
+      i32 tell, curr_balance;
+      int b, N, effective_lowband = -1, tf_change = 0, last;
+      WV_LDS i32 *X, *Y;
+      unsigned x_cm, y_cm;
+      ctx.i = i;
+      last = (i == end - 1);
+      X = X_ + M * ct_eBands[i];
+      Y = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
+      N = M * ct_eBands[i + 1] - M * ct_eBands[i];
+      wv_sync();
+      tell = k_ec_tell_frac(PVQ_EC);
+      if (i != start) balance -= tell;
+      remaining_bits = total_bits - tell - 1;
+      ctx.remaining_bits = remaining_bits;
+      if (i <= codedBands - 1) {
+         curr_balance = balance / imin(3, codedBands - i);
+         b = imax(0, imin(16383, imin(remaining_bits + 1, pulses[i] + curr_balance)));
+      } else b = 0;
+      if (resynth && (M * ct_eBands[i] - N >= M * ct_eBands[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
+         lowband_offset = i;
+      tf_change = tf_res[i];
+      ctx.tf_change = tf_change;
+      if (last && !theta_rdo) lowband_scratch = 0;
+      if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
+         int fold_start, fold_end, fold_i;
+         effective_lowband = imax(0, M * ct_eBands[lowband_offset] - norm_offset - N);
+         fold_start = lowband_offset;
+         while (M * ct_eBands[--fold_start] > effective_lowband + norm_offset);
+         fold_end = lowband_offset - 1;
+         while (++fold_end < i && M * ct_eBands[fold_end] < effective_lowband + norm_offset + N);
+         x_cm = y_cm = 0;
+         fold_i = fold_start;
+         do {
+            x_cm |= collapse_masks[fold_i * C + 0];
+            y_cm |= collapse_masks[fold_i * C + C - 1];
+         } while (++fold_i < fold_end);
+      } else x_cm = y_cm = (1 << B) - 1;
+      if (dual_stereo && i == intensity) {
+         dual_stereo = 0;
+         if (resynth) { wv_sync(); FOR_LANES(j, M * ct_eBands[i] - norm_offset) norm[j] = half32(norm[j] + norm2[j]); wv_sync(); }
+      }
+      WV_LDS i32 *lb = effective_lowband != -1 ? norm + effective_lowband : 0;
+      WV_LDS i32 *lb2 = effective_lowband != -1 ? norm2 + effective_lowband : 0;
+      WV_LDS i32 *lbo = last ? 0 : norm + M * ct_eBands[i] - norm_offset;
+      WV_LDS i32 *lbo2 = last ? 0 : norm2 + M * ct_eBands[i] - norm_offset;
+      if (dual_stereo) {
+         x_cm = quant_band_wave(L, &ctx, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
+         y_cm = quant_band_wave(L, &ctx, Y, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
+      } else {
+         if (Y != 0) {
+            if (theta_rdo && i < intensity) {
+               BandCtx ctx_save, ctx_save2;
+               i32 dist0, dist1;
+               unsigned cm, cm2;
+               i16 w[2];
+               compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
+               cm = x_cm | y_cm;
+               wv_sync();
+               LANE0 ec_copy(&L->ecsave[0], &L->ec);
+               ctx_save = ctx;
+               FOR_LANES(j, N) { P->X_save[j] = X[j]; P->Y_save[j] = Y[j]; }
+               wv_sync();
+               ctx.theta_round = -1;
+               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               wv_sync();
+               dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(P->X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(P->Y_save, Y, N));
+               cm2 = x_cm;
+               LANE0 ec_copy(&L->ecsave[1], &L->ec);
+               ctx_save2 = ctx;
+               FOR_LANES(j, N) { P->X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
+               const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
+               WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
+               const int save_bytes = nend_bytes - nstart_bytes;
+               FOR_LANES(j, save_bytes) L->bytes_save[j] = bytes_buf[j];
+               wv_sync();
+               LANE0 ec_copy(&L->ec, &L->ecsave[0]);
+               ctx = ctx_save;
+               FOR_LANES(j, N) { X[j] = P->X_save[j]; Y[j] = P->Y_save[j]; }
+               wv_sync();
+               ctx.theta_round = 1;
+               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               wv_sync();
+               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_w(P->X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(P->Y_save, Y, N));
+               if (dist0 >= dist1) {
+                  x_cm = cm2;
+                  wv_sync();
+                  LANE0 ec_copy(&L->ec, &L->ecsave[1]);
+                  ctx = ctx_save2;
+                  FOR_LANES(j, N) { X[j] = P->X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
+                  FOR_LANES(j, save_bytes) bytes_buf[j] = L->bytes_save[j];
+                  wv_sync();
+               }
+            } else {
+               ctx.theta_round = 0;
+               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, x_cm | y_cm);
+            }
+         } else {
+            x_cm = quant_band_wave(L, &ctx, X, N, b, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm | y_cm);
+         }
+         y_cm = x_cm;
+      }
+      wv_sync();
+      LANE0 { collapse_masks[i * C + 0] = (u8)x_cm; collapse_masks[i * C + C - 1] = (u8)y_cm; }
+      balance += pulses[i] + tell;
+      update_lowband = b > (N << BITRES);
+      ctx.avoid_split_noise = 0;
+   }
+   wv_sync();
+   LANE0 L->st.rng = ctx.seed;
+   wv_sync();
+}
+#endif

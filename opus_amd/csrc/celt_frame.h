@@ -1,0 +1,56 @@
+/* celt_frame.h — data layout of the batched encoder.
+ *
+ * HBM: one OaStream per independent stream, contiguous (stream-major), so the 64 lanes of the wave that owns
+ * the stream load/store its state with fully coalesced dword accesses.  Fields mirror what must persist
+ * between frame-steps in the reference: OpusEncoder (src/opus_encoder.c:76-146, the CELT-only subset) and
+ * OpusCustomEncoder (celt/celt_encoder.c:63-142) incl. in_mem / prefilter_mem / oldBandE.. arrays.
+ * LDS: one FrameLds per wave; big regions are phase-aliased (pre -> spectrum, input -> folding memory). */
+#ifndef OPUS_AMD_CELT_FRAME_H
+#define OPUS_AMD_CELT_FRAME_H
+#include <stdint.h>
+
+#define OA_NB_EBANDS 21
+#define OA_OVERLAP 120
+#define OA_MAX_PERIOD 1024
+#define OA_MIN_PERIOD 15
+#define OA_MAX_FRAME 960
+#define OA_MAX_PACKET 1276
+
+/* per-stream configuration (set through the ctl interface; may differ between streams of a batch) */
+struct OaEncConfig {
+   int32_t channels;            /* 1 or 2 */
+   int32_t application;         /* OPUS_APPLICATION_RESTRICTED_LOWDELAY (2051) / RESTRICTED_CELT (2053) */
+   int32_t user_bitrate_bps;    /* OPUS_AUTO (-1000), OPUS_BITRATE_MAX (-1) or bits/s */
+   int32_t use_vbr, vbr_constraint, complexity;
+   int32_t force_channels, user_bandwidth, max_bandwidth, lsb_depth, disable_inv, packet_loss_perc;
+   int32_t reserved[4];
+};
+
+/* per-stream persistent state: scalars (kept in LDS while a frame is being encoded) ... */
+struct OaEncScalars {
+   /* Opus layer */
+   int32_t stream_channels, bandwidth, auto_bandwidth, first, prev_mode, hybrid_stereo_width_Q14;
+   int32_t hp_mem[4];
+   uint32_t rangeFinal;
+   /* CELT layer (reset region of the reference) */
+   uint32_t rng;
+   int32_t spread_decision, delayedIntra, tonal_average, lastCodedBands, hf_average, tapset_decision;
+   int32_t prefilter_period, prefilter_gain, prefilter_tapset, consec_transient;
+   int32_t preemph_memE[2];
+   int32_t vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max, stereo_saving, intensity, spec_avg;
+   int32_t pad0[4];
+};
+/* ... and arrays */
+struct OaEncState {
+   OaEncScalars s;
+   int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], energyError[2 * OA_NB_EBANDS];
+   int32_t in_mem[2 * OA_OVERLAP];
+   int32_t prefilter_mem[2 * OA_MAX_PERIOD];
+};
+
+struct OaStream {
+   OaEncConfig cfg;
+   OaEncState st;
+};
+
+#endif

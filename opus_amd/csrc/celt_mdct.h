@@ -1,0 +1,201 @@
+/* celt_mdct.h — wave-parallel forward MDCT (N = 1920 >> shift) on LDS data.
+ * Arithmetic is the reference's fixed-point transform bit for bit: fold/window + pre-rotation
+ * (celt/mdct.c:122-266), mixed-radix FFT with per-stage down-shifts (celt/kiss_fft.c:52-312, :538-611;
+ * radix order 480:{4,2,4,3,5} 240:{4,4,3,5} 120:{4,2,3,5} 60:{4,3,5} as processed), post-rotation.
+ * Mapping: one lane per butterfly; the N/4-point complex FFT lives in LDS (3,840 B for 480 points);
+ * for transient frames the 8 short transforms of a channel run side by side in the same buffer.
+ * The butterfly network is order-fixed (per-stage shifts), only the butterflies *within* a stage run in
+ * parallel, which is exact because they touch disjoint elements. */
+#ifndef OPUS_AMD_CELT_MDCT_H
+#define OPUS_AMD_CELT_MDCT_H
+
+struct cpx32 { i32 r, i; };
+#define SMUL(a, b) mult16_32_q15((b), (a))
+#define SMUL2(a, b) mult16_32_q16((b), (a))
+WV_DEV cpx32 c_mul(cpx32 a, int twr, int twi) { cpx32 m; m.r = sub32(SMUL(a.r, twr), SMUL(a.i, twi)); m.i = add32(SMUL(a.r, twi), SMUL(a.i, twr)); return m; }
+WV_DEV cpx32 c_add(cpx32 a, cpx32 b) { cpx32 c; c.r = add32(a.r, b.r); c.i = add32(a.i, b.i); return c; }
+WV_DEV cpx32 c_sub(cpx32 a, cpx32 b) { cpx32 c; c.r = sub32(a.r, b.r); c.i = sub32(a.i, b.i); return c; }
+WV_DEV i32 fft_shift_val(i32 x, int s) { return s == 0 ? x : (s == 1 ? (x >> 1) : pshr32(x, s)); }
+WV_DEV cpx32 c_ld(const WV_LDS i32 *d, int idx, int s) { cpx32 c; c.r = fft_shift_val(d[2 * idx], s); c.i = fft_shift_val(d[2 * idx + 1], s); return c; }
+WV_DEV void c_st(WV_LDS i32 *d, int idx, cpx32 c) { d[2 * idx] = c.r; d[2 * idx + 1] = c.i; }
+#define TWR(k) ((int)ct_fft_twiddles[2 * (k)])
+#define TWI(k) ((int)ct_fft_twiddles[2 * (k) + 1])
+
+/* one FFT stage over nblk side-by-side transforms of nfft points each.
+ * p radix, m butterfly span, ngrp groups, mm group pitch, tws twiddle stride;
+ * total[b] = down-shift budget of block b before this stage, step = max shift of this radix. */
+WV_DEV void fft_stage(WV_LDS i32 *data, int nblk, int nfft, int p, int m, int ngrp, int mm, int tws,
+      const WV_LDS int *remaining, int step)
+{
+   int per = nfft / p;                 /* butterflies per transform in this stage */
+   int tot = per * nblk;
+   for (int w = wv_lane(); w < tot; w += WV_WIDTH) {
+      int blk = w / per, q = w - blk * per;
+      int rem = remaining[blk];
+      int s = rem < step ? rem : step;
+      WV_LDS i32 *F = data + 2 * blk * nfft;
+      if (p == 2) {                    /* m == 4: radix-2 that follows a radix-4 (kiss_fft.c:52) */
+         int g = q >> 2, j = q & 3;
+         int a = g * 8 + j, b = a + 4;
+         cpx32 x = c_ld(F, a, s), y = c_ld(F, b, s), t;
+         const int tw = 23170;
+         if (j == 0) t = y;
+         else if (j == 1) { t.r = SMUL(add32(y.r, y.i), tw); t.i = SMUL(sub32(y.i, y.r), tw); }
+         else if (j == 2) { t.r = y.i; t.i = neg32(y.r); }
+         else { t.r = SMUL(sub32(y.i, y.r), tw); t.i = SMUL(neg32(add32(y.i, y.r)), tw); }
+         c_st(F, b, c_sub(x, t));
+         c_st(F, a, c_add(x, t));
+      } else if (p == 4) {
+         int g = q / m, j = q - g * m;
+         int b0 = g * mm + j;
+         cpx32 f0 = c_ld(F, b0, s), f1 = c_ld(F, b0 + m, s), f2 = c_ld(F, b0 + 2 * m, s), f3 = c_ld(F, b0 + 3 * m, s);
+         if (m == 1) {                 /* twiddle-free first stage (kiss_fft.c:117) */
+            cpx32 s0 = c_sub(f0, f2);
+            f0 = c_add(f0, f2);
+            cpx32 s1 = c_add(f1, f3);
+            f2 = c_sub(f0, s1);
+            f0 = c_add(f0, s1);
+            s1 = c_sub(f1, f3);
+            f1.r = add32(s0.r, s1.i); f1.i = sub32(s0.i, s1.r);
+            f3.r = sub32(s0.r, s1.i); f3.i = add32(s0.i, s1.r);
+         } else {
+            cpx32 s0 = c_mul(f1, TWR(j * tws), TWI(j * tws));
+            cpx32 s1 = c_mul(f2, TWR(j * tws * 2), TWI(j * tws * 2));
+            cpx32 s2 = c_mul(f3, TWR(j * tws * 3), TWI(j * tws * 3));
+            cpx32 s5 = c_sub(f0, s1);
+            f0 = c_add(f0, s1);
+            cpx32 s3 = c_add(s0, s2), s4 = c_sub(s0, s2);
+            f2 = c_sub(f0, s3);
+            f0 = c_add(f0, s3);
+            f1.r = add32(s5.r, s4.i); f1.i = sub32(s5.i, s4.r);
+            f3.r = sub32(s5.r, s4.i); f3.i = add32(s5.i, s4.r);
+         }
+         c_st(F, b0, f0); c_st(F, b0 + m, f1); c_st(F, b0 + 2 * m, f2); c_st(F, b0 + 3 * m, f3);
+      } else if (p == 3) {
+         const int epi3i = -28378;
+         int g = q / m, j = q - g * m;
+         int b0 = g * mm + j;
+         cpx32 f0 = c_ld(F, b0, s), f1 = c_ld(F, b0 + m, s), f2 = c_ld(F, b0 + 2 * m, s);
+         cpx32 s1 = c_mul(f1, TWR(j * tws), TWI(j * tws));
+         cpx32 s2 = c_mul(f2, TWR(j * tws * 2), TWI(j * tws * 2));
+         cpx32 s3 = c_add(s1, s2), s0 = c_sub(s1, s2);
+         f1.r = sub32(f0.r, s3.r >> 1);
+         f1.i = sub32(f0.i, s3.i >> 1);
+         s0.r = SMUL(s0.r, epi3i); s0.i = SMUL(s0.i, epi3i);
+         f0 = c_add(f0, s3);
+         f2.r = add32(f1.r, s0.i);
+         f2.i = sub32(f1.i, s0.r);
+         f1.r = sub32(f1.r, s0.i);
+         f1.i = add32(f1.i, s0.r);
+         c_st(F, b0, f0); c_st(F, b0 + m, f1); c_st(F, b0 + 2 * m, f2);
+      } else {                         /* p == 5 */
+         const int yar = 10126, yai = -31164, ybr = -26510, ybi = -19261;
+         int g = q / m, u = q - g * m;
+         int b0 = g * mm + u;
+         cpx32 s0 = c_ld(F, b0, s);
+         cpx32 s1 = c_mul(c_ld(F, b0 + m, s), TWR(u * tws), TWI(u * tws));
+         cpx32 s2 = c_mul(c_ld(F, b0 + 2 * m, s), TWR(2 * u * tws), TWI(2 * u * tws));
+         cpx32 s3 = c_mul(c_ld(F, b0 + 3 * m, s), TWR(3 * u * tws), TWI(3 * u * tws));
+         cpx32 s4 = c_mul(c_ld(F, b0 + 4 * m, s), TWR(4 * u * tws), TWI(4 * u * tws));
+         cpx32 s7 = c_add(s1, s4), s10 = c_sub(s1, s4), s8 = c_add(s2, s3), s9 = c_sub(s2, s3);
+         cpx32 o0, s5, s6, s11, s12;
+         o0.r = add32(s0.r, add32(s7.r, s8.r));
+         o0.i = add32(s0.i, add32(s7.i, s8.i));
+         s5.r = add32(s0.r, add32(SMUL(s7.r, yar), SMUL(s8.r, ybr)));
+         s5.i = add32(s0.i, add32(SMUL(s7.i, yar), SMUL(s8.i, ybr)));
+         s6.r = add32(SMUL(s10.i, yai), SMUL(s9.i, ybi));
+         s6.i = neg32(add32(SMUL(s10.r, yai), SMUL(s9.r, ybi)));
+         s11.r = add32(s0.r, add32(SMUL(s7.r, ybr), SMUL(s8.r, yar)));
+         s11.i = add32(s0.i, add32(SMUL(s7.i, ybr), SMUL(s8.i, yar)));
+         s12.r = sub32(SMUL(s9.i, yai), SMUL(s10.i, ybi));
+         s12.i = sub32(SMUL(s10.r, ybi), SMUL(s9.r, yai));
+         c_st(F, b0, o0);
+         c_st(F, b0 + m, c_sub(s5, s6));
+         c_st(F, b0 + 4 * m, c_add(s5, s6));
+         c_st(F, b0 + 2 * m, c_add(s11, s12));
+         c_st(F, b0 + 3 * m, c_sub(s11, s12));
+      }
+   }
+}
+
+/* opus_fft_impl over nblk transforms (kiss_fft.c:562).  remaining[b] holds block b's down-shift budget
+ * and is updated; whatever is left after the last stage is returned to the caller through remaining[]. */
+WV_DEV void fft_forward(WV_LDS i32 *data, int idx, int nblk, WV_LDS int *remaining)
+{
+   const int16_t *factors = ct_fft_factors + 16 * idx;
+   int nfft = ct_fft_misc[4 * idx], stshift = ct_fft_misc[4 * idx + 3];
+   int shift = stshift > 0 ? stshift : 0;
+   int fstride[9], L = 0, m, m2, p;
+   fstride[0] = 1;
+   do { p = factors[2 * L]; m = factors[2 * L + 1]; fstride[L + 1] = fstride[L] * p; L++; } while (m != 1);
+   m = factors[2 * L - 1];
+   for (int i = L - 1; i >= 0; i--) {
+      m2 = i != 0 ? factors[2 * i - 1] : 1;
+      p = factors[2 * i];
+      int step = p == 2 ? 1 : (p == 5 ? 3 : 2);
+      fft_stage(data, nblk, nfft, p, m, fstride[i], m2, fstride[i] << shift, remaining, step);
+      wv_sync();
+      if (wv_lane() < nblk) { int r = remaining[wv_lane()]; remaining[wv_lane()] = r - (r < step ? r : step); }
+      wv_sync();
+      m = m2;
+   }
+}
+
+/* Forward MDCTs of one channel: B transforms of N2 = (960>>shift) output bins each, input block b starts at
+ * in + b*N2 (N2+overlap samples), output bin k of block b goes to out[b + k*B] (interleaved, stride B).
+ * fbuf: >= B*N2 words of LDS scratch (complex FFT storage), aux: >= 2*8 ints. */
+WV_DEV void mdct_forward_blocks(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int B, WV_LDS i32 *fbuf, WV_LDS int *aux)
+{
+   const int N = 1920 >> shift, N2 = N >> 1, N4 = N >> 2, overlap = OA_OVERLAP;
+   const int trig_off = shift == 0 ? 0 : (shift == 1 ? 960 : (shift == 2 ? 1440 : 1680));
+   const int16_t *trig = ct_mdct_trig + trig_off;
+   const int16_t *bitrev = ct_fft_bitrev + ct_fft_bitrev_off[shift];
+   const int scale = ct_fft_misc[4 * shift + 1], scale_shift = ct_fft_misc[4 * shift + 2] - 1;
+   WV_LDS int *headroom = aux, *remaining = aux + 8;
+   const int lane = wv_lane();
+   for (int b = 0; b < B; b++) {
+      const WV_LDS i32 *x = in + b * N2;
+      WV_LDS i32 *f2 = fbuf + 2 * b * N4;
+      i32 maxval = 1;
+      for (int i = lane; i < N4; i += WV_WIDTH) {
+         i32 re, im;
+         const WV_LDS i32 *xp1 = x + (overlap >> 1) + 2 * i, *xp2 = x + N2 - 1 + (overlap >> 1) - 2 * i;
+         if (i < ((overlap + 3) >> 2)) {
+            int w1 = ct_window[(overlap >> 1) + 2 * i], w2 = ct_window[(overlap >> 1) - 1 - 2 * i];
+            re = add32(SMUL(xp1[N2], w2), SMUL(*xp2, w1));
+            im = sub32(SMUL(*xp1, w1), SMUL(xp2[-N2], w2));
+         } else if (i < N4 - ((overlap + 3) >> 2)) {
+            re = *xp2; im = *xp1;
+         } else {
+            int k = i - (N4 - ((overlap + 3) >> 2));
+            int w1 = ct_window[2 * k], w2 = ct_window[overlap - 1 - 2 * k];
+            re = add32(neg32(SMUL(xp1[-N2], w1)), SMUL(*xp2, w2));
+            im = add32(SMUL(*xp1, w2), SMUL(xp2[N2], w1));
+         }
+         int t0 = trig[i], t1 = trig[N4 + i];
+         i32 yr = sub32(SMUL(re, t0), SMUL(im, t1));
+         i32 yi = add32(SMUL(im, t0), SMUL(re, t1));
+         yr = SMUL2(yr, scale); yi = SMUL2(yi, scale);
+         maxval = imax(maxval, imax(iabs(yr), iabs(yi)));
+         int rv = bitrev[i];
+         f2[2 * rv] = yr; f2[2 * rv + 1] = yi;
+      }
+      maxval = wv_max(maxval);
+      int hr = imax(0, imin(scale_shift, 28 - celt_ilog2(maxval)));
+      if (lane == 0) { headroom[b] = hr; remaining[b] = scale_shift - hr; }
+   }
+   wv_sync();
+   fft_forward(fbuf, shift, B, remaining);
+   for (int w = lane; w < B * N4; w += WV_WIDTH) {
+      int b = w / N4, i = w - b * N4;
+      int hr = headroom[b], left = remaining[b];
+      cpx32 fp = c_ld(fbuf + 2 * b * N4, i, left);
+      int t0 = trig[i], t1 = trig[N4 + i];
+      i32 yr = pshr32(sub32(SMUL(fp.i, t1), SMUL(fp.r, t0)), hr);
+      i32 yi = pshr32(add32(SMUL(fp.r, t1), SMUL(fp.i, t0)), hr);
+      out[b + B * (2 * i)] = yr;
+      out[b + B * (N2 - 1 - 2 * i)] = yi;
+   }
+   wv_sync();
+}
+#endif

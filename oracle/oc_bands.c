@@ -6,6 +6,7 @@
  * :1387 quant_band_stereo, :1575 special_hybrid_folding, :1589 quant_all_bands (incl. theta-RDO). */
 #include "oc_celt.h"
 #include <stdlib.h>
+extern void (*oc_dump_hook)(const char *tag, const void *p, int nbytes);
 
 i32 oc_inner_prod_norm_shift(const i32 *x, const i32 *y, int len);
 
@@ -300,6 +301,7 @@ static void compute_theta(band_ctx *ctx, split_ctx *sctx, i32 *X, i32 *Y, int N,
       iside = oc_bitexact_cos((i16)(16384 - itheta));
       delta = frac_mul16((N - 1) << 7, oc_bitexact_log2tan(iside, imid));
    }
+   if (oc_dump_hook) { i32 a_ = itheta, b_ = qn; oc_dump_hook("itheta", &a_, 4); oc_dump_hook("qn", &b_, 4); }
    sctx->inv = inv; sctx->imid = imid; sctx->iside = iside; sctx->delta = delta; sctx->itheta = itheta; sctx->qalloc = qalloc;
 }
 

@@ -9,6 +9,11 @@
 #include "oc_celt_enc.h"
 #include <stdlib.h>
 
+/* test-only tracing of intermediate values (used to localise kernel-vs-oracle divergences) */
+void (*oc_dump_hook)(const char *tag, const void *p, int nbytes) = 0;
+#define OC_DUMP(tag, p, n) do { if (oc_dump_hook) oc_dump_hook(tag, p, n); } while (0)
+#define OC_DUMPI(tag, v) do { i32 v_ = (i32)(v); OC_DUMP(tag, &v_, 4); } while (0)
+
 i32 oc_inner_prod_norm_shift(const i32 *x, const i32 *y, int len);
 
 static const u8 trim_icdf[11] = {126, 124, 119, 109, 87, 41, 19, 9, 4, 2, 0};
@@ -675,17 +680,22 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
       memcpy(in + c * (N + overlap), &prefilter_mem[(1 + c) * COMBFILTER_MAXPERIOD - overlap], overlap * sizeof(i32));
    }
    tone_freq = tone_detect(in, CC, N + overlap, &toneishness, Fs);
+   for (int c = 0; c < CC; c++) OC_DUMP("in_pre", in + c * (N + overlap), (N + overlap) * 4);
+   OC_DUMPI("tone_freq", tone_freq); OC_DUMPI("toneishness", toneishness);
    if (st->complexity >= 1 && !st->lfe) {
       int allow_weak_transients = hybrid && effectiveBytes < 15 && st->silk_signalType != 2;
       isTransient = transient_analysis(in, N + overlap, CC, &tf_estimate, &tf_chan, allow_weak_transients, &weak_transient, tone_freq, toneishness);
    }
    toneishness = imin(toneishness, QC32(1.f, 29) - shl32(tf_estimate, 15));
+   OC_DUMPI("isTransient", isTransient); OC_DUMPI("tf_estimate", tf_estimate); OC_DUMPI("tf_chan", tf_chan);
    {
       int enabled, qg;
       enabled = ((st->lfe && nbAvailableBytes > 3) || nbAvailableBytes > 12 * C) && !hybrid && !silence && tell + 16 <= total_bits && !st->disable_pf;
       prefilter_tapset = st->tapset_decision;
       pf_on = run_prefilter(st, in, prefilter_mem, CC, N, prefilter_tapset, &pitch_index, &gain1, &qg, enabled, st->complexity, tf_estimate,
             nbAvailableBytes, tone_freq, toneishness);
+      OC_DUMPI("pf_on", pf_on); OC_DUMPI("pitch_index", pitch_index); OC_DUMPI("gain1", gain1); OC_DUMPI("qg", qg);
+      for (int c = 0; c < CC; c++) OC_DUMP("in_pf", in + c * (N + overlap), (N + overlap) * 4);
       if ((gain1 > QC16(.4f, 15) || st->prefilter_gain > QC16(.4f, 15))
             && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period))
          pitch_change = 1;
@@ -718,6 +728,7 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
    oc_compute_band_energies(freq, bandE, effEnd, C, LM);
    if (st->lfe) for (int i = 2; i < end; i++) { bandE[i] = imin(bandE[i], mult16_32_q15(QC16(1e-4f, 15), bandE[0])); bandE[i] = imax(bandE[i], EPSILON); }
    oc_amp2log2(effEnd, end, bandE, bandLogE, C);
+   OC_DUMPI("shortBlocks", shortBlocks); OC_DUMP("freq", freq, C * N * 4); OC_DUMP("bandE", bandE, 42 * 4); OC_DUMP("bandLogE", bandLogE, 42 * 4);
    memset(surround_dynalloc, 0, sizeof(surround_dynalloc));
    if (!st->lfe) {
       i32 follow = -QC32(10.0f, DB_SHIFT - 5), frame_avg = 0, offset = shortBlocks ? half32(shl32(LM, DB_SHIFT - 5)) : 0;
@@ -745,9 +756,11 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
    }
    if (LM > 0 && oc_ec_tell(enc) + 3 <= total_bits) oc_ec_enc_bit_logp(enc, isTransient, 3);
    oc_normalise_bands(freq, X, bandE, effEnd, C, M);
+   OC_DUMPI("isTransient2", isTransient); OC_DUMP("bandLogE2", bandLogE2, 42 * 4); for (int c = 0; c < C; c++) OC_DUMP("X", X + c * N, M * eBands[effEnd] * 4); OC_DUMPI("temporal_vbr", temporal_vbr);
    enable_tf_analysis = effectiveBytes >= 15 * C && !hybrid && st->complexity >= 2 && !st->lfe && toneishness < QC32(.98f, 29);
    maxDepth = dynalloc_analysis(bandLogE, bandLogE2, oldBandE, start, end, C, offsets, st->lsb_depth, isTransient, st->vbr, st->constrained_vbr,
          LM, effectiveBytes, &tot_boost, st->lfe, surround_dynalloc, importance, spread_weight, tone_freq, toneishness);
+   OC_DUMPI("maxDepth", maxDepth); OC_DUMPI("tot_boost", tot_boost); OC_DUMP("offsets", offsets, 84); OC_DUMP("importance", importance, 84); OC_DUMP("spread_weight", spread_weight, 84);
    if (enable_tf_analysis) {
       int lambda = imax(80, 20480 / effectiveBytes + 2);
       tf_select = tf_analysis(effEnd, isTransient, tf_res, lambda, X, N, LM, tf_estimate, tf_chan, importance);
@@ -769,6 +782,7 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
    oc_quant_coarse_energy(start, end, effEnd, bandLogE, oldBandE, total_bits, error, enc, C, LM, nbAvailableBytes, st->force_intra,
          &st->delayedIntra, st->complexity >= 4, st->loss_rate, st->lfe);
    tf_encode(start, end, isTransient, tf_res, LM, tf_select, enc);
+   OC_DUMP("tf_res", tf_res, 84); OC_DUMP("oldBandE_c", oldBandE, 168); OC_DUMP("error_c", error, 168); OC_DUMPI("rng_tf", enc->rng); OC_DUMPI("tell_tf", oc_ec_tell_frac(enc));
    if (oc_ec_tell(enc) + 4 <= total_bits) {
       if (st->lfe) { st->tapset_decision = 0; st->spread_decision = SPREAD_NORMAL; }
       else if (hybrid) {
@@ -785,6 +799,7 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
    } else st->spread_decision = SPREAD_NORMAL;
    if (st->lfe) offsets[0] = imin(8, effectiveBytes / 3);
    oc_init_caps(cap, LM, C);
+   OC_DUMPI("spread", st->spread_decision); OC_DUMPI("tapset", st->tapset_decision);
    dynalloc_logp = 6;
    total_bits <<= BITRES;
    total_boost = 0;
@@ -820,6 +835,7 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
       tell = oc_ec_tell_frac(enc);
    }
    min_allowed = ((tell + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3)) + 2;
+   OC_DUMPI("alloc_trim", alloc_trim); OC_DUMPI("dual_stereo", dual_stereo); OC_DUMPI("intensity", st->intensity); OC_DUMP("offsets2", offsets, 84); OC_DUMPI("rng_trim", enc->rng);
    if (hybrid) min_allowed = imax(min_allowed, (tell0_frac + (37 << BITRES) + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3));
    if (vbr_rate > 0) {
       i16 alpha;
@@ -871,10 +887,12 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
    if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, codedBands));
    else st->lastCodedBands = codedBands;
    oc_quant_fine_energy(start, end, oldBandE, error, 0, fine_quant, enc, C);
+   OC_DUMPI("nbCompressedBytes", nbCompressedBytes); OC_DUMPI("codedBands", codedBands); OC_DUMPI("balance", balance); OC_DUMP("pulses", pulses, 84); OC_DUMP("fine_quant", fine_quant, 84); OC_DUMP("fine_priority", fine_priority, 84); OC_DUMPI("rng_fine", enc->rng);
    memset(energyError, 0, nbEBands * CC * sizeof(i32));
    oc_quant_all_bands(1, start, end, X, C == 2 ? X + N : 0, collapse_masks, bandE, pulses, shortBlocks, st->spread_decision, dual_stereo,
          st->intensity, tf_res, nbCompressedBytes * (8 << BITRES) - anti_collapse_rsv, balance, enc, LM, codedBands, &st->rng,
          st->complexity, st->disable_inv);
+   OC_DUMPI("rng_pvq", enc->rng); OC_DUMP("collapse", collapse_masks, 42);
    if (anti_collapse_rsv > 0) {
       anti_collapse_on = st->consec_transient < 2;
       oc_ec_enc_bits(enc, anti_collapse_on, 1);

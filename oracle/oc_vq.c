@@ -4,6 +4,7 @@
  * :695-756 (renormalise_vector, stereo_itheta).  celt_norm is int32 Q24 (NORM_SHIFT 24). */
 #include "oc_celt.h"
 #include <stdlib.h>
+extern void (*oc_dump_hook)(const char *tag, const void *p, int nbytes);
 
 static void norm_scaleup(i32 *X, int N, int shift) { if (shift <= 0) return; for (int i = 0; i < N; i++) X[i] = shl32(X[i], shift); }
 static void norm_scaledown(i32 *X, int N, int shift) { if (shift <= 0) return; for (int i = 0; i < N; i++) X[i] = pshr32(X[i], shift); }
@@ -154,9 +155,11 @@ i32 oc_op_pvq_search(i32 *X, int *iy, int K, int N)
 unsigned oc_alg_quant(i32 *X, int N, int K, int spread, int B, oc_ec *enc, i32 gain, int resynth)
 {
    int iy[176 + 3];
+   if (oc_dump_hook) oc_dump_hook("pvqX", X, N * 4);
    oc_exp_rotation(X, N, 1, B, K, spread);
    i32 yy = oc_op_pvq_search(X, iy, K, N);
    unsigned cm = extract_collapse_mask(iy, N, B);
+   if (oc_dump_hook) { i32 k_ = K; oc_dump_hook("iy", iy, N * 4); oc_dump_hook("pvqK", &k_, 4); }
    oc_encode_pulses(iy, N, K, enc);
    if (resynth) {
       normalise_residual(iy, X, N, yy, gain);

@@ -1,0 +1,32 @@
+/* tests/emu/emu_encoder.cpp — TEST INFRASTRUCTURE: runs the *kernel body source* (opus_amd/csrc/celt_enc_*.h) on the
+ * CPU wave emulator so it can be debugged and diffed against the oracle in a GPU-less container.  Exposes a dump hook
+ * for intermediate values.  Never part of the product library. */
+#include "wave_emu.h"
+#include <vector>
+#include <string>
+typedef void (*dump_fn)(const char *tag, const void *p, int nbytes);
+static dump_fn g_dump = nullptr;
+extern "C" void emu_set_dump(dump_fn f) { g_dump = f; }
+#define K_DUMP(tag, ptr, nbytes) do { if (g_dump && wv_lane() == 0) g_dump(tag, (const void *)(ptr), nbytes); } while (0)
+#define K_DUMPI(tag, v) do { int32_t v__ = (int32_t)(v); if (g_dump && wv_lane() == 0) g_dump(tag, &v__, 4); } while (0)
+#include "celt_enc_all.h"
+
+struct Job { FrameLds *L; OaStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int32_t *len; uint32_t *rng; };
+static void job_entry(void *p)
+{
+   Job *j = (Job *)p;
+   oa_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->len, j->rng);
+}
+extern "C" int emu_sizeof_stream() { return (int)sizeof(OaStream); }
+extern "C" int emu_sizeof_lds() { return (int)sizeof(FrameLds); }
+extern "C" void emu_encode_batch(OaStream *streams, const int16_t *pcm, int S, int frame_size, int max_bytes,
+      uint8_t *out, int stride, int32_t *lens, uint32_t *rngs)
+{
+   for (int s = 0; s < S; s++) {
+      FrameLds *L = (FrameLds *)aligned_alloc(64, (sizeof(FrameLds) + 63) & ~63);
+      memset(L, 0xA5, sizeof(FrameLds));          /* LDS is uninitialised on the GPU: make stale reads loud */
+      Job j = {L, streams + s, pcm + (size_t)s * frame_size * streams[s].cfg.channels, frame_size, max_bytes, out + (size_t)s * stride, lens + s, rngs + s};
+      emu_run_wave(job_entry, &j);
+      free(L);
+   }
+}

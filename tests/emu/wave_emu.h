@@ -1,0 +1,86 @@
+/* tests/emu/wave_emu.h — TEST INFRASTRUCTURE.  A CPU stand-in for opus_amd/csrc/wave.h so the *same* kernel
+ * body source can be exercised in this GPU-less container (gdb, dumps, bit-exact diffs against the oracle)
+ * before it is sent to a real MI355X.  64 fibers = 64 lanes; every wave primitive is a rendezvous of all
+ * lanes; a lane that skips a collective is reported (divergence on the GPU would hang or read garbage).
+ * The product never includes this file. */
+#ifndef WAVE_EMU_H
+#define WAVE_EMU_H
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <execinfo.h>
+static inline void emu_die() { void *bt[32]; int n = backtrace(bt, 32); backtrace_symbols_fd(bt, n, 2); abort(); }
+
+#define WV_DEV  static inline
+#define WV_DEVN static
+#define WV_LDS
+#define WV_TABLE static const
+#define WV_WIDTH 64
+
+struct EmuFiber { void *sp; char *stack; int done; long nsync; long nx; };
+struct EmuWave {
+   EmuFiber f[64];
+   void *main_sp;
+   int cur;
+   int64_t xch[2][64][4];
+   unsigned char kind_ring[4096];      /* lane 0's op kind per rendezvous, to catch lanes meeting at different primitives */
+   void (*entry)(void *);
+   void *arg;
+};
+extern thread_local EmuWave *emu_cur;
+extern "C" void emu_switch(void **save_sp, void *new_sp);
+void emu_run_wave(void (*entry)(void *), void *arg);
+
+WV_DEV int wv_lane() { return emu_cur->cur; }
+static inline void emu_rendezvous(int kind = 0)
+{
+   EmuWave *w = emu_cur;
+   int me = w->cur, nxt = (me + 1) & 63;
+   w->f[me].nsync++;
+   if (me == 0) w->kind_ring[w->f[0].nsync & 4095] = (unsigned char)kind;
+   else if (w->kind_ring[w->f[me].nsync & 4095] != kind) {
+      fprintf(stderr, "wave_emu: lane %d meets lane 0 at rendezvous %ld with a different primitive (%d vs %d): divergent control flow\n", me, w->f[me].nsync, kind, w->kind_ring[w->f[me].nsync & 4095]); emu_die();
+   }
+   if (w->f[nxt].done) { fprintf(stderr, "wave_emu: lane %d reached a collective but lane %d already exited (divergence)\n", me, nxt); abort(); }
+   w->cur = nxt;
+   emu_switch(&w->f[me].sp, w->f[nxt].sp);
+   int prv = (me + 63) & 63;
+   long expect = w->f[me].nsync + (me == 0 ? 0 : 1);          /* the previous lane is parked at the next rendezvous */
+   if (!(w->f[prv].nsync == expect || (w->f[prv].done && w->f[prv].nsync == w->f[me].nsync))) {
+      fprintf(stderr, "wave_emu: divergent collectives: lane %d at %ld, lane %d at %ld\n", me, w->f[me].nsync, prv, w->f[prv].nsync); abort();
+   }
+}
+WV_DEV void wv_sync() { emu_rendezvous(); }
+/* publish (a,b,c,d) for this lane, rendezvous, return this op's table [64][4] */
+static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0))[4]
+{
+   EmuWave *w = emu_cur;
+   int me = w->cur;
+   int p = (int)(w->f[me].nx++ & 1);
+   w->xch[p][me][0] = a; w->xch[p][me][1] = b; w->xch[p][me][2] = c; w->xch[p][me][3] = d;
+   emu_rendezvous(1);
+   return w->xch[p];
+}
+WV_DEV int32_t wv_shfl(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src & 63][0]; }
+WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
+WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
+WV_DEV uint32_t wv_sumu(uint32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return s; }
+WV_DEV int64_t wv_sum64(int64_t v) { auto t = emu_xchg(v); uint64_t s = 0; for (int i = 0; i < 64; i++) s += (uint64_t)t[i][0]; return (int64_t)s; }
+WV_DEV int32_t wv_max(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[0][0]; for (int i = 1; i < 64; i++) if ((int32_t)t[i][0] > m) m = (int32_t)t[i][0]; return m; }
+WV_DEV int32_t wv_min(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[0][0]; for (int i = 1; i < 64; i++) if ((int32_t)t[i][0] < m) m = (int32_t)t[i][0]; return m; }
+WV_DEV uint32_t wv_or(uint32_t v) { auto t = emu_xchg(v); uint32_t m = 0; for (int i = 0; i < 64; i++) m |= (uint32_t)t[i][0]; return m; }
+WV_DEV uint64_t wv_ballot(int pred) { auto t = emu_xchg(pred != 0); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(t[i][0] != 0) << i; return m; }
+WV_DEV int32_t wv_scan_incl(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; int me = emu_cur->cur; for (int i = 0; i <= me; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
+WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
+{
+   auto t = emu_xchg(num, den, idx);
+   int32_t bn = (int32_t)t[0][0], bd = (int32_t)t[0][1], bi = (int32_t)t[0][2];
+   for (int i = 1; i < 64; i++) {
+      int32_t n2 = (int32_t)t[i][0], d2 = (int32_t)t[i][1], i2 = (int32_t)t[i][2];
+      int32_t lhs = (int32_t)(int16_t)bd * (int32_t)(int16_t)n2, rhs = (int32_t)(int16_t)d2 * (int32_t)(int16_t)bn;
+      if (lhs > rhs || (lhs == rhs && i2 < bi)) { bn = n2; bd = d2; bi = i2; }
+   }
+   num = bn; den = bd; idx = bi;
+}
+#endif
