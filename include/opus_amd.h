@@ -1,0 +1,123 @@
+/* opus_amd.h — C ABI of the MI355X-native batched Opus encode path (drop-in boundary).
+ *
+ * Two layers, both plain C (no torch / HIP types in the signatures):
+ *
+ * 1. The classic libopus encoder entry points, same names, argument meaning and error codes as the reference
+ *    (reference/include/opus.h: opus_encoder_get_size :174, opus_encoder_create :212, opus_encoder_init :235,
+ *    opus_encode :266, opus_encoder_destroy :355, opus_encoder_ctl :367; error codes opus_defines.h:46-60).
+ *    The OpusEncoder blob is flat host memory holding the complete canonical state (memcpy-able, no device
+ *    handles: opus.h:108-109); every opus_encode() runs the frame on the GPU as a batch of one.
+ *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only path), Fs = 48000,
+ *    one 2.5/5/10/20 ms frame per call, VBR/CVBR.  Anything else returns OPUS_UNIMPLEMENTED.
+ *
+ * 2. The batch API (additive): S independent streams stepped together, one wavefront per
+ *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.
+ *
+ * Results are bit-identical to the reference fixed-point build (FIXED_POINT, DISABLE_FLOAT_API): same packet
+ * bytes and OPUS_GET_FINAL_RANGE. */
+#ifndef OPUS_AMD_H
+#define OPUS_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUS_AMD_EXPORT __attribute__((visibility("default")))
+
+/* error codes: reference/include/opus_defines.h:46-60 */
+#define OPUS_OK 0
+#define OPUS_BAD_ARG -1
+#define OPUS_BUFFER_TOO_SMALL -2
+#define OPUS_INTERNAL_ERROR -3
+#define OPUS_INVALID_PACKET -4
+#define OPUS_UNIMPLEMENTED -5
+#define OPUS_INVALID_STATE -6
+#define OPUS_ALLOC_FAIL -7
+/* applications / special values: opus_defines.h:205-232 */
+#define OPUS_AUTO -1000
+#define OPUS_BITRATE_MAX -1
+#define OPUS_APPLICATION_VOIP 2048
+#define OPUS_APPLICATION_AUDIO 2049
+#define OPUS_APPLICATION_RESTRICTED_LOWDELAY 2051
+#define OPUS_APPLICATION_RESTRICTED_SILK 2052
+#define OPUS_APPLICATION_RESTRICTED_CELT 2053
+#define OPUS_BANDWIDTH_NARROWBAND 1101
+#define OPUS_BANDWIDTH_MEDIUMBAND 1102
+#define OPUS_BANDWIDTH_WIDEBAND 1103
+#define OPUS_BANDWIDTH_SUPERWIDEBAND 1104
+#define OPUS_BANDWIDTH_FULLBAND 1105
+/* CTL request numbers: opus_defines.h:130-181 */
+#define OPUS_SET_APPLICATION_REQUEST 4000
+#define OPUS_GET_APPLICATION_REQUEST 4001
+#define OPUS_SET_BITRATE_REQUEST 4002
+#define OPUS_GET_BITRATE_REQUEST 4003
+#define OPUS_SET_MAX_BANDWIDTH_REQUEST 4004
+#define OPUS_GET_MAX_BANDWIDTH_REQUEST 4005
+#define OPUS_SET_VBR_REQUEST 4006
+#define OPUS_GET_VBR_REQUEST 4007
+#define OPUS_SET_BANDWIDTH_REQUEST 4008
+#define OPUS_GET_BANDWIDTH_REQUEST 4009
+#define OPUS_SET_COMPLEXITY_REQUEST 4010
+#define OPUS_GET_COMPLEXITY_REQUEST 4011
+#define OPUS_SET_VBR_CONSTRAINT_REQUEST 4020
+#define OPUS_GET_VBR_CONSTRAINT_REQUEST 4021
+#define OPUS_SET_FORCE_CHANNELS_REQUEST 4022
+#define OPUS_GET_FORCE_CHANNELS_REQUEST 4023
+#define OPUS_RESET_STATE 4028
+#define OPUS_GET_SAMPLE_RATE_REQUEST 4029
+#define OPUS_GET_FINAL_RANGE_REQUEST 4031
+#define OPUS_SET_LSB_DEPTH_REQUEST 4036
+#define OPUS_GET_LSB_DEPTH_REQUEST 4037
+#define OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST 4046
+#define OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST 4047
+
+typedef int16_t opus_int16;
+typedef int32_t opus_int32;
+typedef uint32_t opus_uint32;
+typedef struct OpusEncoder OpusEncoder;
+
+/* ---- classic API (replaces reference/src/opus_encoder.c:194,:204,:547?,:2671,:2772,:3350) ---- */
+OPUS_AMD_EXPORT int opus_encoder_get_size(int channels);
+OPUS_AMD_EXPORT OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, int *error);
+OPUS_AMD_EXPORT int opus_encoder_init(OpusEncoder *st, opus_int32 Fs, int channels, int application);
+OPUS_AMD_EXPORT opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT int opus_encoder_ctl(OpusEncoder *st, int request, ...);
+OPUS_AMD_EXPORT void opus_encoder_destroy(OpusEncoder *st);
+OPUS_AMD_EXPORT const char *opus_strerror(int error);
+OPUS_AMD_EXPORT const char *opus_get_version_string(void);
+
+/* ---- batch API ---- */
+typedef struct OpusGpuEncBatch OpusGpuEncBatch;
+
+OPUS_AMD_EXPORT int opusgpu_device_count(void);
+/* S streams with a common initial configuration on HIP device `device`. */
+OPUS_AMD_EXPORT OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int application, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b);
+OPUS_AMD_EXPORT opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b);
+/* set-type CTL on one stream (stream >= 0) or on all (stream == -1); same request numbers / validation as opus_encoder_ctl */
+OPUS_AMD_EXPORT int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, opus_int32 value);
+OPUS_AMD_EXPORT int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, opus_int32 *value);
+/* One frame-step for every stream.  pcm: [S][frame_size*channels] int16 interleaved; out: [S][out_stride] bytes;
+ * lens[s] = packet length or negative error; final_range[s] = OPUS_GET_FINAL_RANGE.  Host pointers. */
+OPUS_AMD_EXPORT int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
+/* Same, with every buffer already resident in this device's HBM; asynchronous on `hip_stream` (NULL = the batch's stream). */
+OPUS_AMD_EXPORT int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_enc_batch_sync(OpusGpuEncBatch *b);
+/* `steps` back-to-back frame-steps on device buffers ([steps][S][frame*channels] PCM), timed with HIP events on the
+ * launch stream; returns elapsed milliseconds in *ms (kernel time only, inputs resident). */
+OPUS_AMD_EXPORT int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, int steps, float *ms);
+/* memcpy contract: a stream's complete state as a flat blob (same layout as the classic OpusEncoder payload) */
+OPUS_AMD_EXPORT int opusgpu_enc_state_size(void);
+OPUS_AMD_EXPORT int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *blob);
+OPUS_AMD_EXPORT int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const void *blob);
+OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);
+/* introspection for the roofline report */
+OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

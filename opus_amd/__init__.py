@@ -1,0 +1,147 @@
+"""opus_amd — MI355X-native batched Opus (CELT-only) encoder behind the libopus C ABI.
+
+Host side: a thin ctypes mirror of the reference's encoder interface (`opus_encoder_create / opus_encode /
+opus_encoder_ctl`, reference/include/opus.h:174-367) plus the additive batch API of include/opus_amd.h.
+All compute happens in the hand-written HIP kernels of opus_amd/csrc (one wavefront per stream-frame);
+there is NO CPU fallback: if the shared library or a GPU is missing, construction raises.
+
+PyTorch is only plumbing here (device buffers, streams, torch.distributed for the multi-GPU gather).
+"""
+import ctypes, os, subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libopus_amd.so")
+
+OPUS_OK, OPUS_BAD_ARG, OPUS_BUFFER_TOO_SMALL, OPUS_INTERNAL_ERROR = 0, -1, -2, -3
+OPUS_INVALID_PACKET, OPUS_UNIMPLEMENTED, OPUS_INVALID_STATE, OPUS_ALLOC_FAIL = -4, -5, -6, -7
+OPUS_AUTO, OPUS_BITRATE_MAX = -1000, -1
+OPUS_APPLICATION_VOIP, OPUS_APPLICATION_AUDIO, OPUS_APPLICATION_RESTRICTED_LOWDELAY = 2048, 2049, 2051
+OPUS_APPLICATION_RESTRICTED_SILK, OPUS_APPLICATION_RESTRICTED_CELT = 2052, 2053
+OPUS_SET_BITRATE_REQUEST, OPUS_GET_BITRATE_REQUEST = 4002, 4003
+OPUS_SET_MAX_BANDWIDTH_REQUEST, OPUS_SET_VBR_REQUEST, OPUS_SET_BANDWIDTH_REQUEST, OPUS_GET_BANDWIDTH_REQUEST = 4004, 4006, 4008, 4009
+OPUS_SET_COMPLEXITY_REQUEST, OPUS_GET_COMPLEXITY_REQUEST = 4010, 4011
+OPUS_SET_VBR_CONSTRAINT_REQUEST, OPUS_SET_FORCE_CHANNELS_REQUEST, OPUS_RESET_STATE = 4020, 4022, 4028
+OPUS_GET_FINAL_RANGE_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST = 4031, 4036, 4046
+
+SOURCES = [os.path.join(_HERE, "csrc", "opus_amd.hip")]
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    hdrs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [os.path.join(_ROOT, "include", "opus_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in hdrs):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "csrc"),
+           "-I" + os.path.join(_ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
+    if verbose: print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+_lib = None
+def lib():
+    """The C-ABI library; raises if it is missing (the product path never falls back to the CPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("opus_amd: %s is not built — run opus_amd.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, u32p, i32p = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)
+        L.opus_encoder_create.restype = vp; L.opus_encoder_create.argtypes = [i32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opus_encoder_init.argtypes = [vp, i32, ctypes.c_int, ctypes.c_int]
+        L.opus_encode.restype = i32; L.opus_encode.argtypes = [vp, vp, ctypes.c_int, vp, i32]
+        L.opus_encoder_destroy.argtypes = [vp]; L.opus_encoder_destroy.restype = None
+        L.opus_strerror.restype = ctypes.c_char_p; L.opus_get_version_string.restype = ctypes.c_char_p
+        L.opusgpu_enc_batch_create.restype = vp; L.opusgpu_enc_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
+        L.opusgpu_enc_batch_ctl.argtypes = [vp, i32, ctypes.c_int, i32]
+        L.opusgpu_enc_batch_get.argtypes = [vp, i32, ctypes.c_int, i32p]
+        L.opusgpu_encode_batch.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp]
+        L.opusgpu_encode_batch_dev.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp, vp]
+        L.opusgpu_time_encode_dev.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, i32, vp]
+        L.opusgpu_enc_batch_sync.argtypes = [vp]; L.opusgpu_enc_batch_reset.argtypes = [vp]
+        _lib = L
+    return _lib
+
+class OpusError(Exception):
+    def __init__(self, code): super().__init__("%s (%d)" % (lib().opus_strerror(code).decode(), code)); self.code = code
+
+class OpusEncoder:
+    """Mirror of the reference encoder object: OpusEncoder(Fs, channels, application); .encode(pcm_int16, frame_size);
+    .ctl(request, value) / .get(request).  Each encode runs on the GPU as a batch of one."""
+    def __init__(self, Fs, channels, application):
+        err = ctypes.c_int()
+        self._L = lib()
+        self._st = self._L.opus_encoder_create(Fs, channels, application, ctypes.byref(err))
+        if not self._st: raise OpusError(err.value)
+        self.channels = channels
+        self._out = (ctypes.c_ubyte * 1500)()
+        self._L.opus_encoder_ctl.restype = ctypes.c_int
+    def ctl(self, request, value=0):
+        self._L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32]
+        r = self._L.opus_encoder_ctl(self._st, request, value)
+        if r != OPUS_OK: raise OpusError(r)
+    def get(self, request):
+        v = ctypes.c_int32()
+        self._L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        r = self._L.opus_encoder_ctl(self._st, request, ctypes.byref(v))
+        if r != OPUS_OK: raise OpusError(r)
+        return v.value
+    def encode(self, pcm, frame_size, max_data_bytes=1276):
+        import numpy as np
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        n = self._L.opus_encode(self._st, pcm.ctypes.data, frame_size, self._out, max_data_bytes)
+        if n < 0: raise OpusError(n)
+        return bytes(self._out[:n])
+    def final_range(self): return self.get(OPUS_GET_FINAL_RANGE_REQUEST) & 0xffffffff
+    def __del__(self):
+        if getattr(self, "_st", None): self._L.opus_encoder_destroy(self._st); self._st = None
+
+class EncoderBatch:
+    """S independent streams stepped together on one GPU (include/opus_amd.h batch API)."""
+    def __init__(self, nstreams, channels=2, application=OPUS_APPLICATION_RESTRICTED_LOWDELAY, Fs=48000, device=0):
+        err = ctypes.c_int()
+        self._L = lib()
+        self._b = self._L.opusgpu_enc_batch_create(nstreams, Fs, channels, application, device, ctypes.byref(err))
+        if not self._b: raise OpusError(err.value)
+        self.S, self.channels, self.device = nstreams, channels, device
+    def ctl(self, request, value=0, stream=-1):
+        r = self._L.opusgpu_enc_batch_ctl(self._b, stream, request, value)
+        if r != OPUS_OK: raise OpusError(r)
+    def get(self, request, stream):
+        v = ctypes.c_int32()
+        r = self._L.opusgpu_enc_batch_get(self._b, stream, request, ctypes.byref(v))
+        if r != OPUS_OK: raise OpusError(r)
+        return v.value
+    def encode(self, pcm, frame_size, max_data_bytes=1276):
+        """pcm: int16 array [S, frame_size*channels] (host).  Returns (list of packet bytes, final ranges)."""
+        import numpy as np
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        assert pcm.size == self.S * frame_size * self.channels
+        out = np.zeros((self.S, 1280), np.uint8); lens = np.zeros(self.S, np.int32); rng = np.zeros(self.S, np.uint32)
+        r = self._L.opusgpu_encode_batch(self._b, pcm.ctypes.data, frame_size, out.ctypes.data, 1280, max_data_bytes, lens.ctypes.data, rng.ctypes.data)
+        if r != OPUS_OK: raise OpusError(r)
+        return [bytes(out[s, :max(int(lens[s]), 0)]) for s in range(self.S)], lens, rng
+    def encode_dev(self, d_pcm_ptr, frame_size, d_out_ptr, out_stride, d_lens_ptr, d_rng_ptr, max_data_bytes=1276, hip_stream=None):
+        r = self._L.opusgpu_encode_batch_dev(self._b, d_pcm_ptr, frame_size, d_out_ptr, out_stride, max_data_bytes, d_lens_ptr, d_rng_ptr, hip_stream)
+        if r != OPUS_OK: raise OpusError(r)
+    def time_encode_dev(self, d_pcm_ptr, frame_size, d_out_ptr, out_stride, d_lens_ptr, d_rng_ptr, steps, max_data_bytes=1276):
+        ms = ctypes.c_float()
+        r = self._L.opusgpu_time_encode_dev(self._b, d_pcm_ptr, frame_size, d_out_ptr, out_stride, max_data_bytes, d_lens_ptr, d_rng_ptr, steps, ctypes.byref(ms))
+        if r != OPUS_OK: raise OpusError(r)
+        return ms.value
+    def export_state(self, stream):
+        buf = ctypes.create_string_buffer(self._L.opusgpu_enc_state_size())
+        r = self._L.opusgpu_enc_batch_export_state(self._b, stream, buf)
+        if r != OPUS_OK: raise OpusError(r)
+        return buf.raw
+    def import_state(self, stream, blob):
+        r = self._L.opusgpu_enc_batch_import_state(self._b, stream, blob)
+        if r != OPUS_OK: raise OpusError(r)
+    def reset(self):
+        r = self._L.opusgpu_enc_batch_reset(self._b)
+        if r != OPUS_OK: raise OpusError(r)
+    def sync(self): self._L.opusgpu_enc_batch_sync(self._b)
+    def close(self):
+        if getattr(self, "_b", None): self._L.opusgpu_enc_batch_destroy(self._b); self._b = None
+    def __del__(self): self.close()

@@ -135,6 +135,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       wv_sync();
    }
    compute_mdcts_wave(L, sh->shortBlocks);
+   if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    band_energies_wave(L, L->bandLogE);
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
    LANE0 {

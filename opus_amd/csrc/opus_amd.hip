@@ -1,0 +1,330 @@
+/* opus_amd.hip — kernels + C ABI of the batched Opus (CELT-only) encoder for gfx950.
+ * One 64-lane wavefront (= one workgroup) per (stream, frame); see celt_enc_*.h for the body. */
+#include "wave.h"
+#include "celt_enc_all.h"
+#include "../../include/opus_amd.h"
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+
+extern "C" __global__ void __launch_bounds__(64)
+oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
+   const int s = blockIdx.x;
+   if (s >= nstreams) return;
+   OaStream *gs = streams + s;
+   const int ch = gs->cfg.channels;
+   oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, lens + s, rngs + s);
+}
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "opus_amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return OPUS_INTERNAL_ERROR; } } while (0)
+
+/* ---------------- host-side state initialisation / ctl (mirrors opus_encoder_init :204 and opus_encoder_ctl :2772) ---------------- */
+static int oa_init_stream(OaStream *st, opus_int32 Fs, int channels, int application)
+{
+   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2) ||
+       (application != OPUS_APPLICATION_VOIP && application != OPUS_APPLICATION_AUDIO && application != OPUS_APPLICATION_RESTRICTED_LOWDELAY &&
+        application != OPUS_APPLICATION_RESTRICTED_SILK && application != OPUS_APPLICATION_RESTRICTED_CELT))
+      return OPUS_BAD_ARG;
+   if (Fs != 48000 || (application != OPUS_APPLICATION_RESTRICTED_LOWDELAY && application != OPUS_APPLICATION_RESTRICTED_CELT))
+      return OPUS_UNIMPLEMENTED;
+   memset(st, 0, sizeof(*st));
+   st->cfg.channels = channels; st->cfg.application = application; st->cfg.user_bitrate_bps = OPUS_AUTO;
+   st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = OPUS_AUTO;
+   st->cfg.user_bandwidth = OPUS_AUTO; st->cfg.max_bandwidth = OPUS_BANDWIDTH_FULLBAND; st->cfg.lsb_depth = 24;
+   st->st.s.stream_channels = channels; st->st.s.bandwidth = OPUS_BANDWIDTH_FULLBAND; st->st.s.first = 1; st->st.s.hybrid_stereo_width_Q14 = 1 << 14;
+   st->st.s.spread_decision = 2; st->st.s.delayedIntra = 1; st->st.s.tonal_average = 256;
+   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->st.oldLogE[i] = st->st.oldLogE2[i] = -(28 << 24);
+   return OPUS_OK;
+}
+static void oa_reset_stream(OaStream *st)
+{
+   OaEncConfig cfg = st->cfg;
+   oa_init_stream(st, 48000, cfg.channels, cfg.application);
+   st->cfg = cfg;
+}
+static int oa_ctl_set(OaStream *st, int request, opus_int32 value)
+{
+   switch (request) {
+   case OPUS_SET_BITRATE_REQUEST:
+      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) {
+         if (value <= 0) return OPUS_BAD_ARG;
+         else if (value <= 500) value = 500;
+         else if (value > (opus_int32)750000 * st->cfg.channels) value = (opus_int32)750000 * st->cfg.channels;
+      }
+      st->cfg.user_bitrate_bps = value; return OPUS_OK;
+   case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; st->cfg.complexity = value; return OPUS_OK;
+   case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.use_vbr = value; return OPUS_OK;
+   case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.vbr_constraint = value; return OPUS_OK;
+   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > st->cfg.channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; st->cfg.force_channels = value; return OPUS_OK;
+   case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; st->cfg.user_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; st->cfg.max_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; st->cfg.lsb_depth = value; return OPUS_OK;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.disable_inv = value; return OPUS_OK;
+   case OPUS_RESET_STATE: oa_reset_stream(st); return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+static int oa_ctl_get(const OaStream *st, int request, opus_int32 *value)
+{
+   if (!value) return OPUS_BAD_ARG;
+   switch (request) {
+   case OPUS_GET_APPLICATION_REQUEST: *value = st->cfg.application; return OPUS_OK;
+   case OPUS_GET_BITRATE_REQUEST: {
+      opus_int32 fs = 960, mb = 1276, maxb = mb * 8 * (6 * 48000 / fs) / 6;
+      opus_int32 ub = st->cfg.user_bitrate_bps == OPUS_AUTO ? 60 * 48000 / fs + 48000 * st->cfg.channels : (st->cfg.user_bitrate_bps == OPUS_BITRATE_MAX ? 1500000 : st->cfg.user_bitrate_bps);
+      *value = ub < maxb ? ub : maxb; return OPUS_OK; }
+   case OPUS_GET_COMPLEXITY_REQUEST: *value = st->cfg.complexity; return OPUS_OK;
+   case OPUS_GET_VBR_REQUEST: *value = st->cfg.use_vbr; return OPUS_OK;
+   case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = st->cfg.vbr_constraint; return OPUS_OK;
+   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = st->cfg.force_channels; return OPUS_OK;
+   case OPUS_GET_BANDWIDTH_REQUEST: *value = st->st.s.bandwidth; return OPUS_OK;
+   case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = st->cfg.max_bandwidth; return OPUS_OK;
+   case OPUS_GET_LSB_DEPTH_REQUEST: *value = st->cfg.lsb_depth; return OPUS_OK;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: *value = st->cfg.disable_inv; return OPUS_OK;
+   case OPUS_GET_SAMPLE_RATE_REQUEST: *value = 48000; return OPUS_OK;
+   case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)st->st.s.rangeFinal; return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+static int oa_frame_size_ok(int frame_size) { return frame_size == 120 || frame_size == 240 || frame_size == 480 || frame_size == 960; }
+
+/* ---------------- batch object ---------------- */
+struct OpusGpuEncBatch {
+   int device;
+   opus_int32 S;
+   int channels;
+   hipStream_t stream;
+   OaStream *d_streams;
+   std::vector<OaStream> h_streams;     /* host mirror of the configuration (state is authoritative on device) */
+   bool cfg_dirty;
+   /* staging for the host-pointer entry */
+   opus_int16 *d_pcm; size_t pcm_cap;
+   unsigned char *d_out; size_t out_cap;
+   opus_int32 *d_lens; opus_uint32 *d_rng;
+};
+
+extern "C" {
+
+int opusgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
+int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
+opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
+
+OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int application, int device, int *error)
+{
+   int err = OPUS_OK;
+   OpusGpuEncBatch *b = nullptr;
+   OaStream proto;
+   if (nstreams <= 0) err = OPUS_BAD_ARG;
+   if (err == OPUS_OK) err = oa_init_stream(&proto, Fs, channels, application);
+   if (err == OPUS_OK) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+         fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev);
+         err = OPUS_INTERNAL_ERROR;
+      }
+   }
+   if (err == OPUS_OK) {
+      b = new OpusGpuEncBatch();
+      b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = false;
+      b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
+      b->h_streams.assign(nstreams, proto);
+      bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
+                hipMalloc((void **)&b->d_streams, sizeof(OaStream) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
+                hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FrameLds)) == hipSuccess;
+      if (!ok) { opusgpu_enc_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
+   }
+   if (error) *error = err;
+   return b;
+}
+void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
+{
+   if (!b) return;
+   (void)hipSetDevice(b->device);
+   if (b->stream) (void)hipStreamSynchronize(b->stream);
+   if (b->d_streams) (void)hipFree(b->d_streams);
+   if (b->d_pcm) (void)hipFree(b->d_pcm);
+   if (b->d_out) (void)hipFree(b->d_out);
+   if (b->d_lens) (void)hipFree(b->d_lens);
+   if (b->d_rng) (void)hipFree(b->d_rng);
+   if (b->stream) (void)hipStreamDestroy(b->stream);
+   delete b;
+}
+/* configuration lives in the first bytes of each OaStream; ctl edits the host mirror and pushes only cfg (or the whole stream on RESET) */
+int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, opus_int32 value)
+{
+   if (!b || stream < -1 || stream >= b->S) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   for (opus_int32 s = lo; s < hi; s++) {
+      int r = oa_ctl_set(&b->h_streams[s], request, value);
+      if (r != OPUS_OK) return r;
+      if (request == OPUS_RESET_STATE) HIPCHECK(hipMemcpy(b->d_streams + s, &b->h_streams[s], sizeof(OaStream), hipMemcpyHostToDevice));
+      else HIPCHECK(hipMemcpy(&b->d_streams[s].cfg, &b->h_streams[s].cfg, sizeof(OaEncConfig), hipMemcpyHostToDevice));
+   }
+   return OPUS_OK;
+}
+int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, opus_int32 *value)
+{
+   if (!b || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   OaStream tmp = b->h_streams[stream];
+   HIPCHECK(hipMemcpy(&tmp.st.s, &b->d_streams[stream].st.s, sizeof(OaEncScalars), hipMemcpyDeviceToHost));
+   return oa_ctl_get(&tmp, request, value);
+}
+int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *blob)
+{
+   if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(blob, b->d_streams + stream, sizeof(OaStream), hipMemcpyDeviceToHost));
+   return OPUS_OK;
+}
+int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const void *blob)
+{
+   if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   const OaStream *src = (const OaStream *)blob;
+   if (src->cfg.channels != b->channels) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   b->h_streams[stream] = *src;
+   HIPCHECK(hipMemcpy(b->d_streams + stream, src, sizeof(OaStream), hipMemcpyHostToDevice));
+   return OPUS_OK;
+}
+int opusgpu_enc_batch_reset(OpusGpuEncBatch *b) { return opusgpu_enc_batch_ctl(b, -1, OPUS_RESET_STATE, 0); }
+int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
+
+int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
+{
+   if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
+   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   if (max_data_bytes <= 0) return OPUS_BAD_ARG;
+   if (out_stride < (max_data_bytes < 1276 ? max_data_bytes : 1276)) return OPUS_BUFFER_TOO_SMALL;
+   HIPCHECK(hipSetDevice(b->device));
+   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds), s,
+         b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, int steps, float *ms)
+{
+   if (!b || !ms || steps <= 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipEvent_t e0, e1;
+   HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+   HIPCHECK(hipEventRecord(e0, b->stream));
+   size_t step_elems = (size_t)b->S * frame_size * b->channels;
+   for (int k = 0; k < steps; k++) {
+      int r = opusgpu_encode_batch_dev(b, d_pcm + (size_t)k * step_elems, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, nullptr);
+      if (r != OPUS_OK) return r;
+   }
+   HIPCHECK(hipEventRecord(e1, b->stream));
+   HIPCHECK(hipEventSynchronize(e1));
+   HIPCHECK(hipEventElapsedTime(ms, e0, e1));
+   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   return OPUS_OK;
+}
+int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
+{
+   if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
+   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   size_t npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->S * out_stride;
+   if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
+   if (nout > b->out_cap) { if (b->d_out) (void)hipFree(b->d_out); HIPCHECK(hipMalloc((void **)&b->d_out, nout)); b->out_cap = nout; }
+   HIPCHECK(hipMemcpyAsync(b->d_pcm, pcm, npcm, hipMemcpyHostToDevice, b->stream));
+   int r = opusgpu_encode_batch_dev(b, b->d_pcm, frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpyAsync(out, b->d_out, nout, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipMemcpyAsync(lens, b->d_lens, sizeof(opus_int32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   return OPUS_OK;
+}
+
+/* ---------------- classic libopus encoder API on top of a process-wide batch-of-one ---------------- */
+#define OA_MAGIC 0x4f41454eu /* "OAEN" */
+struct OpusEncoder { uint32_t magic; uint32_t pad[3]; OaStream s; };
+static std::mutex g_classic_mu;
+static OpusGpuEncBatch *g_classic[2] = {nullptr, nullptr};    /* per channel count */
+
+int opus_encoder_get_size(int channels) { if (channels < 1 || channels > 2) return 0; return (int)sizeof(OpusEncoder); }
+int opus_encoder_init(OpusEncoder *st, opus_int32 Fs, int channels, int application)
+{
+   if (!st) return OPUS_BAD_ARG;
+   OaStream tmp;
+   int r = oa_init_stream(&tmp, Fs, channels, application);
+   if (r != OPUS_OK) return r;
+   memset(st, 0, sizeof(*st));
+   st->magic = OA_MAGIC; st->s = tmp;
+   return OPUS_OK;
+}
+OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, int *error)
+{
+   OpusEncoder *st = (OpusEncoder *)malloc(sizeof(OpusEncoder));
+   if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return nullptr; }
+   int r = opus_encoder_init(st, Fs, channels, application);
+   if (error) *error = r;
+   if (r != OPUS_OK) { free(st); return nullptr; }
+   return st;
+}
+void opus_encoder_destroy(OpusEncoder *st) { free(st); }
+opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   if (!st || st->magic != OA_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
+   if (max_data_bytes <= 0) return OPUS_BAD_ARG;
+   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   std::lock_guard<std::mutex> lock(g_classic_mu);
+   const int ci = st->s.cfg.channels - 1;
+   if (!g_classic[ci]) {
+      int err;
+      g_classic[ci] = opusgpu_enc_batch_create(1, 48000, st->s.cfg.channels, st->s.cfg.application, 0, &err);
+      if (!g_classic[ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   }
+   OpusGpuEncBatch *b = g_classic[ci];
+   unsigned char buf[1280];
+   opus_int32 len = 0; opus_uint32 rng = 0;
+   opus_int32 cap = max_data_bytes < 1276 ? max_data_bytes : 1276;
+   int r = opusgpu_enc_batch_import_state(b, 0, &st->s);
+   if (r == OPUS_OK) r = opusgpu_encode_batch(b, pcm, frame_size, buf, 1280, max_data_bytes, &len, &rng);
+   if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, &st->s);
+   if (r != OPUS_OK) return r;
+   if (len > 0) memcpy(data, buf, (size_t)(len < cap ? len : cap));
+   return len;
+}
+int opus_encoder_ctl(OpusEncoder *st, int request, ...)
+{
+   if (!st || st->magic != OA_MAGIC) return OPUS_BAD_ARG;
+   va_list ap;
+   va_start(ap, request);
+   int ret;
+   if (request == OPUS_RESET_STATE) ret = oa_ctl_set(&st->s, request, 0);
+   else if (request & 1) { opus_int32 *p = va_arg(ap, opus_int32 *); ret = oa_ctl_get(&st->s, request, p); }   /* GET requests are odd */
+   else { opus_int32 v = va_arg(ap, opus_int32); ret = oa_ctl_set(&st->s, request, v); }
+   va_end(ap);
+   return ret;
+}
+const char *opus_strerror(int error)
+{
+   static const char *const s[8] = {"success", "invalid argument", "buffer too small", "internal error", "corrupted stream", "request not implemented", "invalid state", "memory allocation failed"};
+   if (error > 0 || error < -7) return "unknown error";
+   return s[-error];
+}
+const char *opus_get_version_string(void) { return "opus-amd 0.1 (gfx950, fixed-point bit-exact CELT encoder)"; }
+
+} /* extern "C" */

