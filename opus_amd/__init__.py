@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [os.path.join(_ROOT, "include", "opus_amd.h")]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in hdrs):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(_HERE, "csrc"),
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-I" + os.path.join(_HERE, "csrc"),
            "-I" + os.path.join(_ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
     if verbose: print(" ".join(cmd))
     subprocess.check_call(cmd)

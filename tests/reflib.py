@@ -15,8 +15,9 @@ def _load(rel, mode=ctypes.RTLD_LOCAL):
 
 @functools.lru_cache(None)
 def ref_fx():
-    # RTLD_GLOBAL so libref_expose_fx.so (linked against it) resolves to the same copy
-    return _load("oracle/_ref/libopus_ref_fx.so", ctypes.RTLD_GLOBAL)
+    # RTLD_LOCAL: the reference exports the same opus_* names as the product library; they must never interpose.
+    # libref_expose_fx.so is linked against this file (rpath $ORIGIN), so the loader shares the one copy.
+    return _load("oracle/_ref/libopus_ref_fx.so")
 
 @functools.lru_cache(None)
 def ref_fl():
