@@ -5,13 +5,24 @@
 #ifndef OPUS_AMD_CELT_EC_H
 #define OPUS_AMD_CELT_EC_H
 struct EcCtx { u32 storage, end_offs, end_window; i32 nend_bits, nbits_total; u32 offs, rng, val, ext; i32 rem, error; };
-#define EC_ARGS WV_LDS EcCtx *e, WV_LDS u8 *buf
+/* The coder state is worked on in registers (a private EcCtx) inside lane-0 sections and parked in LDS between them:
+ * EC_BEGIN loads the 11 words with back-to-back ds_reads, EC_END stores them; every symbol in between is pure VALU
+ * plus the byte stores into the LDS packet. */
+#define EC_ARGS EcCtx *e, WV_LDS u8 *buf
 #define EC_PASS e, buf
-WV_DEV void ec_copy(WV_LDS EcCtx *d, const WV_LDS EcCtx *s)
+WV_DEV void ec_ld(EcCtx *d, const WV_LDS EcCtx *s)
 {
-   WV_LDS u32 *dd = (WV_LDS u32 *)d; const WV_LDS u32 *ss = (const WV_LDS u32 *)s;
-   for (int i = 0; i < (int)(sizeof(EcCtx) / 4); i++) dd[i] = ss[i];
+   d->storage = s->storage; d->end_offs = s->end_offs; d->end_window = s->end_window; d->nend_bits = s->nend_bits; d->nbits_total = s->nbits_total;
+   d->offs = s->offs; d->rng = s->rng; d->val = s->val; d->ext = s->ext; d->rem = s->rem; d->error = s->error;
 }
+WV_DEV void ec_st(WV_LDS EcCtx *d, const EcCtx *s)
+{
+   d->storage = s->storage; d->end_offs = s->end_offs; d->end_window = s->end_window; d->nend_bits = s->nend_bits; d->nbits_total = s->nbits_total;
+   d->offs = s->offs; d->rng = s->rng; d->val = s->val; d->ext = s->ext; d->rem = s->rem; d->error = s->error;
+}
+WV_DEV void ec_cp_lds(WV_LDS EcCtx *d, const WV_LDS EcCtx *s) { EcCtx t; ec_ld(&t, s); ec_st(d, &t); }
+#define EC_BEGIN EcCtx ec_; ec_ld(&ec_, &L->ec); EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1
+#define EC_END ec_st(&L->ec, &ec_)
 #define SYM_BITS 8
 #define SYM_MAX 255u
 #define CODE_SHIFT 23
@@ -43,7 +54,7 @@ WV_DEV void ec_carry_out(EC_ARGS, int c)
       e->rem = c & SYM_MAX;
    } else e->ext++;
 }
-WV_DEVN void ec_renorm(EC_ARGS)
+WV_DEV void ec_renorm(EC_ARGS)
 {
    while (e->rng <= CODE_BOT) {
       ec_carry_out(EC_PASS, (int)(e->val >> CODE_SHIFT));
@@ -58,13 +69,24 @@ WV_DEV void k_ec_enc_init(EC_ARGS, u32 size)
    e->nbits_total = 33; e->offs = 0; e->rng = CODE_TOP; e->rem = -1; e->val = 0; e->ext = 0;
    e->storage = size; e->error = 0;
 }
-WV_DEV int k_ec_tell(EC_ARGS) { return e->nbits_total - ec_ilog(e->rng); }
+WV_DEV int k_ec_tell(const EcCtx *e, WV_LDS u8 *buf) { (void)buf; return e->nbits_total - ec_ilog(e->rng); }
 WV_DEV u32 k_ec_tell_frac(EC_ARGS)
 {
    const unsigned correction[8] = {35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535};
    u32 nbits = (u32)e->nbits_total << BITRES;
    int l = ec_ilog(e->rng);
    u32 r = e->rng >> (l - 16);
+   unsigned b = (r >> 12) - 8;
+   b += r > correction[b];
+   l = (l << 3) + b;
+   return nbits - l;
+}
+WV_DEV u32 ec_tell_frac_lds(const WV_LDS EcCtx *e)
+{
+   const unsigned correction[8] = {35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535};
+   u32 rng = e->rng, nbits = (u32)e->nbits_total << BITRES;
+   int l = ec_ilog(rng);
+   u32 r = rng >> (l - 16);
    unsigned b = (r >> 12) - 8;
    b += r > correction[b];
    l = (l << 3) + b;

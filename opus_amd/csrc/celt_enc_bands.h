@@ -324,9 +324,8 @@ WV_DEVN void tf_analysis_wave(WV_LDS FrameLds *L, int lambda)
 }
 
 /* lane 0: tf_encode (celt_encoder.c:823) */
-WV_DEV void tf_encode_l0(WV_LDS FrameLds *L)
+WV_DEV void tf_encode_l0(WV_LDS FrameLds *L, EC_ARGS)
 {
-   WV_LDS EcCtx *e = &L->ec; WV_LDS u8 *buf = L->packet + 1;
    const int start = L->sh.start, end = L->sh.end, isTransient = L->sh.isTransient, LM = L->sh.LM;
    int tf_select = L->sh.tf_select;
    WV_LDS i32 *tf_res = L->tf_res;

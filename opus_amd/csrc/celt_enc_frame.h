@@ -9,16 +9,21 @@
 #define K_DUMP(tag, ptr, nbytes)
 #define K_DUMPI(tag, v)
 #endif
+/* profiling build only (-DOA_PHASE_TIMERS): per-phase shader-clock accounting, see opus_amd.hip */
+#ifndef K_PHASE
+#define K_PHASE(id)
+#endif
 
 WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
       u8 *out, i32 *len_out, u32 *rng_out)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   WV_LDS EcCtx *e = &L->ec;
-   WV_LDS u8 *buf = L->packet + 1;
    const int lane = wv_lane();
    const int overlap = OA_OVERLAP;
+#ifdef OA_PHASE_TIMERS
+   unsigned long long oa_phase_t0 = 0;
+#endif
 
    /* ---- load persistent state (coalesced) ---- */
    {
@@ -39,6 +44,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    const int CC = sh->CC, C = sh->C;
 
+   K_PHASE(0);
    /* ---- Opus layer: dc_reject (+ optional stereo width fade) into int16 staging ---- */
    dc_reject_lanes(L, pcm, frame_size, CC);
    wv_sync();
@@ -62,6 +68,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
 
+   K_PHASE(1);
    /* ---- pre-emphasis (FIR on the input) ---- */
    for (int c = 0; c < CC; c++) {
       const WV_LDS i16 *p = L->Cc.pcm16;
@@ -79,18 +86,21 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    wv_sync();
    for (int c = 0; c < CC; c++) K_DUMP("in_pre", L->B.in[c], (N + overlap) * 4);
 
+   K_PHASE(2);
    /* ---- tone / transient analysis ---- */
    tone_detect_wave(L);
    wv_sync();
    K_DUMPI("tone_freq", (i16)sh->tone_freq); K_DUMPI("toneishness", sh->toneishness);
    LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
    wv_sync();
+   K_PHASE(3);
    if (sh->complexity >= 1) transient_analysis_wave(L, 0);
    wv_sync();
    K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
    LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
    wv_sync();
 
+   K_PHASE(4);
    /* ---- pitch pre-filter ---- */
    {
       int enabled = (sh->nbAvailableBytes > 12 * C) && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
@@ -102,6 +112,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       }
       wv_sync();
       LANE0 {
+         EC_BEGIN;
          int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
          sh->pitch_change = 0;
          if ((gain1 > QC16(.4f, 15) || (i16)st->prefilter_gain > QC16(.4f, 15)) && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period)) sh->pitch_change = 1;
@@ -121,12 +132,14 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
          if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) { if (sh->isTransient) sh->shortBlocks = M; }
          else { sh->isTransient = 0; sh->transient_got_disabled = 1; }
          sh->secondMdct = sh->shortBlocks && sh->complexity >= 8;
+         EC_END;
       }
       wv_sync();
       K_DUMPI("pf_on", sh->pf_on); K_DUMPI("pitch_index", sh->pitch_index); K_DUMPI("gain1", (i16)sh->gain1); K_DUMPI("qg", sh->qg);
       for (int c = 0; c < CC; c++) K_DUMP("in_pf", L->B.in[c], (N + overlap) * 4);
    }
 
+   K_PHASE(5);
    /* ---- MDCT + band energies ---- */
    if (sh->secondMdct) {
       compute_mdcts_wave(L, 0);
@@ -138,12 +151,15 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    band_energies_wave(L, L->bandLogE);
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
+   K_PHASE(6);
    LANE0 {
+      EC_BEGIN;
       temporal_vbr_l0(L);
       if (!sh->secondMdct) for (int i = 0; i < C * NBE; i++) L->bandLogE2[i] = L->bandLogE[i];
       sh->do_patch = 0;
       if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5)
          sh->do_patch = patch_transient_decision_l0(L);
+      EC_END;
    }
    wv_sync();
    if (sh->do_patch) {
@@ -155,10 +171,11 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
    }
-   LANE0 { if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); }
+   LANE0 { EC_BEGIN; if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); EC_END; }
    normalise_bands_wave(L);
    K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->A.s.X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
 
+   K_PHASE(7);
    /* ---- allocation analyses ---- */
    LANE0 {
       sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && sh->complexity >= 2 && sh->toneishness < QC32(.98f, 29);
@@ -166,6 +183,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    wv_sync();
    K_DUMPI("maxDepth", sh->maxDepth); K_DUMPI("tot_boost", sh->tot_boost); K_DUMP("offsets", L->offsets, 84); K_DUMP("importance", L->importance, 84); K_DUMP("spread_weight", L->spread_weight, 84);
+   K_PHASE(8);
    if (sh->enable_tf_analysis) tf_analysis_wave(L, imax(80, 20480 / sh->effectiveBytes + 2));
    else { LANE0 { for (int i = 0; i < end; i++) L->tf_res[i] = sh->isTransient; sh->tf_select = 0; } wv_sync(); }
    FOR_LANES(w, C * NBE) {
@@ -174,22 +192,27 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
          L->bandLogE[i + c * NBE] -= mult16_32_q15(QC16(0.25f, 15), L->energyError[i + c * NBE]);
    }
    wv_sync();
+   K_PHASE(9);
    LANE0 {
-      k_quant_coarse_energy(L->scr, L->bytes_save, L->ecsave, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
+      EC_BEGIN;
+      k_quant_coarse_energy(L->scr, L->bytes_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
             C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, 0);
-      tf_encode_l0(L);
+      tf_encode_l0(L, EC_PASS);
       sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
+      EC_END;
    }
    wv_sync();
-   K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", e->rng); K_DUMPI("tell_tf", k_ec_tell_frac(EC_PASS));
+   K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", L->ec.rng); K_DUMPI("tell_tf", ec_tell_frac_lds(&L->ec));
+   K_PHASE(10);
    if (sh->r[2]) {
       if (sh->shortBlocks || sh->complexity < 3 || sh->nbAvailableBytes < 10 * C) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : 2; wv_sync(); }
       else spreading_decision_wave(L, sh->pf_on && !sh->shortBlocks);
-      LANE0 k_ec_enc_icdf(EC_PASS, st->spread_decision, k_spread_icdf, 5);
+      LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, st->spread_decision, k_spread_icdf, 5); EC_END; }
    } else { LANE0 st->spread_decision = 2; }
    wv_sync();
    K_DUMPI("spread", st->spread_decision); K_DUMPI("tapset", st->tapset_decision);
    LANE0 {
+      EC_BEGIN;
       k_init_caps(L->cap, LM, C);
       int dynalloc_logp = 6;
       i32 total_bits = sh->total_bits << BITRES, total_boost = 0, tell = k_ec_tell_frac(EC_PASS);
@@ -211,6 +234,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       }
       sh->total_boost = total_boost;
       sh->r[3] = tell;
+      EC_END;
    }
    wv_sync();
    {
@@ -231,13 +255,15 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    if (sh->r[4]) {
       alloc_trim_analysis_wave(L);
-      LANE0 k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7);
+      LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7); EC_END; }
       wv_sync();
    }
-   K_DUMPI("alloc_trim", sh->alloc_trim); K_DUMPI("dual_stereo", sh->dual_stereo); K_DUMPI("intensity", st->intensity); K_DUMP("offsets2", L->offsets, 84); K_DUMPI("rng_trim", e->rng);
+   K_DUMPI("alloc_trim", sh->alloc_trim); K_DUMPI("dual_stereo", sh->dual_stereo); K_DUMPI("intensity", st->intensity); K_DUMP("offsets2", L->offsets, 84); K_DUMPI("rng_trim", L->ec.rng);
 
+   K_PHASE(11);
    /* ---- VBR target, bit allocation, fine energy (lane 0) ---- */
    LANE0 {
+      EC_BEGIN;
       i32 tell = k_ec_tell_frac(EC_PASS), total_boost = sh->total_boost, vbr_rate = sh->vbr_rate;
       int nbCompressedBytes = sh->nbCompressedBytes, nbAvailableBytes, silence = sh->silence;
       i32 min_allowed = ((tell + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3)) + 2;
@@ -283,17 +309,21 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       else st->lastCodedBands = sh->codedBands;
       k_quant_fine_energy(start, end, L->oldBandE, L->error, 0, L->fine_quant, EC_PASS, C);
       for (int i = 0; i < NBE * CC; i++) L->energyError[i] = 0;
+      EC_END;
    }
    wv_sync();
-   K_DUMPI("nbCompressedBytes", sh->nbCompressedBytes); K_DUMPI("codedBands", sh->codedBands); K_DUMPI("balance", sh->balance); K_DUMP("pulses", L->pulses, 84); K_DUMP("fine_quant", L->fine_quant, 84); K_DUMP("fine_priority", L->fine_priority, 84); K_DUMPI("rng_fine", e->rng);
+   K_DUMPI("nbCompressedBytes", sh->nbCompressedBytes); K_DUMPI("codedBands", sh->codedBands); K_DUMPI("balance", sh->balance); K_DUMP("pulses", L->pulses, 84); K_DUMP("fine_quant", L->fine_quant, 84); K_DUMP("fine_priority", L->fine_priority, 84); K_DUMPI("rng_fine", L->ec.rng);
 
+   K_PHASE(12);
    /* ---- PVQ residual ---- */
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
          sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv);
-   K_DUMPI("rng_pvq", e->rng); K_DUMP("collapse", L->collapse_masks, 42);
+   K_DUMPI("rng_pvq", L->ec.rng); K_DUMP("collapse", L->collapse_masks, 42);
 
+   K_PHASE(13);
    /* ---- finalise (lane 0) ---- */
    LANE0 {
+      EC_BEGIN;
       const int nbCompressedBytes = sh->nbCompressedBytes, isTransient = sh->isTransient, silence = sh->silence;
       if (sh->anti_collapse_rsv > 0) k_ec_enc_bits(EC_PASS, st->consec_transient < 2, 1);
       k_quant_energy_finalise(start, end, L->oldBandE, L->error, L->fine_quant, L->fine_priority, nbCompressedBytes * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
@@ -320,9 +350,11 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       L->packet[0] |= (u8)sh->toc;
       if (ret >= 0 && k_ec_tell(EC_PASS) > (sh->max_data_bytes - 1) * 8) { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
       sh->ret = ret < 0 ? ret : ret + 1;
+      EC_END;
    }
    wv_sync();
 
+   K_PHASE(14);
    /* ---- store packet + state (coalesced) ---- */
    {
       const int nbytes = sh->ret;
@@ -334,5 +366,6 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       FOR_LANES(i, 2 * NBE) { gs->st.oldBandE[i] = L->oldBandE[i]; gs->st.oldLogE[i] = L->oldLogE[i]; gs->st.oldLogE2[i] = L->oldLogE2[i]; gs->st.energyError[i] = L->energyError[i]; }
       FOR_LANES(i, 2 * OA_OVERLAP) gs->st.in_mem[i] = L->in_mem[i];
    }
+   K_PHASE(15);
 }
 #endif

@@ -164,8 +164,7 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   WV_LDS EcCtx *e = &L->ec;
-   WV_LDS u8 *buf = L->packet + 1;
+   EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
    const int Fs = 48000, frame_size = sh->frame_size;
    int LM;
    for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
@@ -175,7 +174,7 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
    int nbCompressedBytes = sh->max_data_bytes - 1;
    k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
    L->packet[0] = 0;
-   if (k_ec_tell(EC_PASS) > 8 * nbCompressedBytes) { sh->skip_celt = 1; return; }
+   if (k_ec_tell(EC_PASS) > 8 * nbCompressedBytes) { sh->skip_celt = 1; EC_END; return; }
    int C = sh->C;
    i32 tell = k_ec_tell(EC_PASS), tell0_frac = k_ec_tell_frac(EC_PASS);
    int nbFilledBytes = (tell + 4) >> 3, effectiveBytes, nbAvailableBytes;
@@ -227,6 +226,7 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
    sh->nbCompressedBytes = nbCompressedBytes; sh->nbFilledBytes = nbFilledBytes; sh->nbAvailableBytes = nbAvailableBytes;
    sh->effectiveBytes = effectiveBytes; sh->vbr_rate = vbr_rate; sh->total_bits = total_bits; sh->equiv_rate = equiv_rate;
    sh->tell = tell; sh->tell0_frac = tell0_frac; sh->silence = silence; sh->sample_max = sample_max;
+   EC_END;
 }
 
 /* tone detector (celt_encoder.c:1272-1403).  x16 built in parallel, correlations by wave reductions

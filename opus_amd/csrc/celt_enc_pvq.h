@@ -15,6 +15,10 @@
 #define K_DUMP(tag, ptr, nbytes)
 #define K_DUMPI(tag, v)
 #endif
+#ifndef K_TIC
+#define K_TIC()
+#define K_TOC(bucket)
+#endif
 
 struct BandCtx {
    int resynth, i, intensity, spread, tf_change;
@@ -24,7 +28,6 @@ struct BandCtx {
 };
 struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
 
-#define PVQ_EC &L->ec, (L->packet + 1)
 
 WV_DEV u32 lcg_rand(u32 seed) { return 1664525u * seed + 1013904223u; }
 WV_DEV int bitexact_cos(int x_)
@@ -45,7 +48,7 @@ WV_DEV int bitexact_log2tan(int isin, int icos)
 WV_DEV u32 pvq_u(int n, int k)
 {
    int lo = n < k ? n : k, hi = n < k ? k : n;
-   return ct_pvq_u_data[ct_pvq_u_row[lo] + hi];
+   return ct_pvq_u_flat[lo * 177 + hi];
 }
 
 WV_DEV void haar1_wave(WV_LDS i32 *X, int N0, int stride)
@@ -172,11 +175,33 @@ WV_DEV i32 stereo_itheta_wave(const WV_LDS i32 *X, const WV_LDS i32 *Y, int ster
    return fx_atan2p_norm(side, mid);
 }
 
-/* exp_rotation (vq.c:104): the rotation chain along a block is a recursion with rounding -> one lane per block */
+/* exp_rotation (vq.c:104).  The down/up scaling is elementwise (done by the whole wave, once); each rotation pass
+ * is a recurrence with rounding along a block -> one lane per block, the running element carried in a register so the
+ * chain latency is ALU-only (the second operand is an independent, prefetchable LDS read). */
 WV_DEV void exp_rotation1_l(WV_LDS i32 *X, int len, int stride, i16 c, i16 s)
 {
    i16 ms = (i16)(-s);
-   for (int i = 0; i < len; i++) X[i] = pshr32(X[i], NORM_SHIFT - 14);
+   if (stride == 1) {
+      i32 x1 = X[0];
+      for (int i = 0; i < len - 1; i++) {
+         i32 x2 = X[i + 1];
+         i32 n2 = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
+         X[i] = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
+         x1 = n2;
+      }
+      X[len - 1] = x1;
+      /* backward pass: pairs (i, i+1) for i = len-3 .. 0; x2 of step i is the x1-result of step i+1 */
+      if (len >= 3) {
+         i32 x2 = X[len - 2];
+         for (int i = len - 3; i >= 0; i--) {
+            i32 x1b = X[i];
+            X[i + 1] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1b), 15));
+            x2 = extract16(pshr32(mac16_16(mult16_16(c, x1b), ms, x2), 15));
+         }
+         X[0] = x2;
+      }
+      return;
+   }
    WV_LDS i32 *Xptr = X;
    for (int i = 0; i < len - stride; i++) {
       i32 x1 = Xptr[0], x2 = Xptr[stride];
@@ -189,14 +214,12 @@ WV_DEV void exp_rotation1_l(WV_LDS i32 *X, int len, int stride, i16 c, i16 s)
       Xptr[stride] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
       *Xptr-- = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
    }
-   for (int i = 0; i < len; i++) X[i] = shl32(X[i], NORM_SHIFT - 14);
 }
 WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K, int spread)
 {
-   const int SPREAD_FACTOR[3] = {15, 10, 5};
    int stride2 = 0;
    if (2 * K >= len || spread == 0) return;
-   int factor = SPREAD_FACTOR[spread - 1];
+   int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
    i16 gain = (i16)fx_div(mult16_16(Q15ONE, len), (i32)(len + factor * K));
    i16 theta = (i16)(mult16_16_q15(gain, gain) >> 1);
    i16 c = fx_cos_norm(theta);
@@ -205,6 +228,9 @@ WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K
       stride2 = 1;
       while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
    }
+   const int total = len;
+   FOR_LANES(j, total) X[j] = pshr32(X[j], NORM_SHIFT - 14);      /* norm_scaledown once (up/down between passes cancels exactly) */
+   wv_sync();
    len = (u32)len / (u32)stride;
    int i = wv_lane();
    if (i < stride) {
@@ -217,106 +243,104 @@ WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K
       }
    }
    wv_sync();
+   FOR_LANES(j, total) X[j] = shl32(X[j], NORM_SHIFT - 14);
+   wv_sync();
 }
 
-/* op_pvq_search (vq.c:205).  Returns yy in every lane; iy[] in LDS. */
+/* op_pvq_search (vq.c:205).  Each lane keeps its (up to three) coefficients |X|, 2*y and iy in registers; one
+ * cross-lane arg-max per pulse on the DPP network; the winner's |X| and y are fetched with v_readlane.  Returns yy in
+ * every lane; iy[] (signed) is written to LDS once at the end. */
 WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
 {
-   WV_LDS i32 *iy = L->A.s.pvq.iy, *y = L->A.s.pvq.ysearch;
+   WV_LDS i32 *iy = L->A.s.pvq.iy;
    const int lane = wv_lane();
-   {
-      int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
-      shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
-      K_DUMPI("dbg_shift", shift);
-      if (shift > 0) { FOR_LANES(j, N) X[j] = pshr32(X[j], shift); }
-   }
-   u32 signbits[3] = {0, 0, 0};
-   { int t = 0; for (int j = lane; j < N; j += WV_WIDTH, t++) { i32 v = X[j]; signbits[t] = v < 0; X[j] = iabs(v); iy[j] = 0; y[j] = 0; } }
-   wv_sync();
+   int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
+   shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
+   i32 x0 = 0, x1 = 0, x2 = 0, y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;
+   const bool v0 = lane < N, v1 = lane + 64 < N, v2 = lane + 128 < N;
+   if (v0) x0 = pshr32(X[lane], shift);
+   if (v1) x1 = pshr32(X[lane + 64], shift);
+   if (v2) x2 = pshr32(X[lane + 128], shift);
+   const i32 s0 = x0 < 0, s1 = x1 < 0, s2 = x2 < 0;
+   x0 = iabs(x0); x1 = iabs(x1); x2 = iabs(x2);
    i32 xy = 0; i16 yy = 0;
    int pulsesLeft = K;
    if (K > (N >> 1)) {
-      i32 s = 0;
-      FOR_LANES(j, N) s += X[j];
-      i32 sum = wv_sum(s);
+      i32 sum = wv_sum(x0 + x1 + x2);
       if (sum <= K) {
-         wv_sync();
-         FOR_LANES(j, N) X[j] = j == 0 ? QC16(1.f, 14) : 0;
+         x0 = lane == 0 ? QC16(1.f, 14) : 0; x1 = 0; x2 = 0;
          sum = QC16(1.f, 14);
-         wv_sync();
       }
       i16 rcp = extract16(mult16_32_q16(K, fx_rcp(sum)));
-      K_DUMPI("dbg_sum", sum); K_DUMPI("dbg_rcp", rcp);
-      i32 yyp = 0, xyp = 0, used = 0;
-      FOR_LANES(j, N) {
-         i32 q = mult16_16_q15(X[j], rcp);
-         iy[j] = q;
-         yyp = mac16_16(yyp, q, q);
-         xyp = mac16_16(xyp, X[j], q);
-         y[j] = 2 * q;
-         used += q;
-      }
+      q0 = mult16_16_q15(x0, rcp); q1 = mult16_16_q15(x1, rcp); q2 = mult16_16_q15(x2, rcp);
+      i32 yyp = mac16_16(mac16_16(mult16_16(q0, q0), q1, q1), q2, q2);
+      i32 xyp = mac16_16(mac16_16(mult16_16(x0, q0), x1, q1), x2, q2);
+      y0 = 2 * q0; y1 = 2 * q1; y2 = 2 * q2;
       yy = (i16)wv_sum(yyp);
       xy = wv_sum(xyp);
-      pulsesLeft -= wv_sum(used);
-      wv_sync();
+      pulsesLeft -= wv_sum(q0 + q1 + q2);
    }
-   K_DUMPI("dbg_pulsesLeft", pulsesLeft); K_DUMPI("dbg_yy", yy); K_DUMPI("dbg_xy", xy);
    if (pulsesLeft > N + 3) {
       i16 tmp = (i16)pulsesLeft;
+      i32 yfirst = wv_bcast(y0, 0);
       yy = (i16)mac16_16(yy, tmp, tmp);
-      yy = (i16)mac16_16(yy, tmp, y[0]);
-      wv_sync();
-      LANE0 iy[0] += pulsesLeft;
+      yy = (i16)mac16_16(yy, tmp, yfirst);
+      if (lane == 0) q0 += pulsesLeft;
       pulsesLeft = 0;
-      wv_sync();
    }
    for (int i = 0; i < pulsesLeft; i++) {
       int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
       yy = add16(yy, 1);
       i32 best_num = -1, best_den = 1, best_id = 0x7fffffff;
-      for (int j = lane; j < N; j += WV_WIDTH) {
-         i16 Rxy = extract16(add32(xy, X[j]) >> rshift);
-         i16 Ryy = add16(yy, y[j]);
-         Rxy = (i16)mult16_16_q15(Rxy, Rxy);
-         if (best_num < 0 || mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = j; }
+      if (v0) {
+         i16 Rxy = extract16(add32(xy, x0) >> rshift); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
+         best_den = add16(yy, y0); best_num = Rxy; best_id = lane;
+      }
+      if (v1) {
+         i16 Rxy = extract16(add32(xy, x1) >> rshift); i16 Ryy = add16(yy, y1); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
+         if (mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 64; }
+      }
+      if (v2) {
+         i16 Rxy = extract16(add32(xy, x2) >> rshift); i16 Ryy = add16(yy, y2); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
+         if (mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 128; }
       }
       wv_argmax_ratio(best_num, best_den, best_id);
-      xy = add32(xy, X[best_id]);
-      yy = add16(yy, y[best_id]);
-      wv_sync();
-      LANE0 { y[best_id] += 2; iy[best_id]++; }
-      wv_sync();
+      const int owner = best_id & 63, slot = best_id >> 6;
+      i32 xs = slot == 0 ? x0 : (slot == 1 ? x1 : x2), ys = slot == 0 ? y0 : (slot == 1 ? y1 : y2);
+      xy = add32(xy, wv_bcast(xs, owner));
+      yy = add16(yy, wv_bcast(ys, owner));
+      if (lane == owner) {
+         if (slot == 0) { y0 += 2; q0++; } else if (slot == 1) { y1 += 2; q1++; } else { y2 += 2; q2++; }
+      }
    }
-   { int t = 0; for (int j = lane; j < N; j += WV_WIDTH, t++) { i32 sg = (i32)signbits[t]; iy[j] = (iy[j] ^ -sg) + sg; } }
+   if (v0) iy[lane] = (q0 ^ -s0) + s0;
+   if (v1) iy[lane + 64] = (q1 ^ -s1) + s1;
+   if (v2) iy[lane + 128] = (q2 ^ -s2) + s2;
    wv_sync();
    return yy;
 }
 
-/* encode_pulses (cwrs.c:444-465): index = (y[n-1]<0) + sum_j U(n-j, k_{j+1}) + [y_j<0] U(n-j, k_j+1), k_j = sum_{i>=j}|y_i| */
+/* encode_pulses (cwrs.c:444-465): index = (y[n-1]<0) + sum_j U(n-j, k_{j+1}) + [y_j<0] U(n-j, k_j+1), k_j = sum_{i>=j}|y_i|.
+ * Suffix sums of |y| come from a wave scan; every table read is then independent (issued back to back). */
 WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
 {
    const WV_LDS i32 *y = L->A.s.pvq.iy;
    const int lane = wv_lane(), j0 = 3 * lane;
-   i32 a[3], tot = 0;
-   for (int t = 0; t < 3; t++) { int j = j0 + t; a[t] = j < N ? iabs(y[j]) : 0; tot += a[t]; }
+   i32 yv[3], a[3], tot = 0;
+   for (int t = 0; t < 3; t++) { int j = j0 + t; yv[t] = j < N ? y[j] : 0; a[t] = iabs(yv[t]); tot += a[t]; }
    i32 incl = wv_scan_incl(tot);
-   i32 k = K - incl;                     /* sum over lanes above this one = suffix beyond the chunk */
+   i32 kafter[3];                         /* k_{j+1}: pulses strictly after element j */
+   kafter[2] = K - incl; kafter[1] = kafter[2] + a[2]; kafter[0] = kafter[1] + a[1];
    u32 idx = 0;
-   for (int t = 2; t >= 0; t--) {
+   for (int t = 0; t < 3; t++) {
       int j = j0 + t;
-      if (j < N) {
-         if (j == N - 1) { idx += y[j] < 0; k = a[t]; }
-         else {
-            idx += pvq_u(N - j, k);
-            k += a[t];
-            if (y[j] < 0) idx += pvq_u(N - j, k + 1);
-         }
-      }
+      if (j < N - 1) {
+         idx += pvq_u(N - j, kafter[t]);
+         if (yv[t] < 0) idx += pvq_u(N - j, kafter[t] + a[t] + 1);
+      } else if (j == N - 1) idx += yv[t] < 0;
    }
    idx = wv_sumu(idx);
-   LANE0 k_ec_enc_uint(PVQ_EC, idx, pvq_u(N, K) + pvq_u(N, K + 1));
-   wv_sync();
+   LANE0 { EC_BEGIN; k_ec_enc_uint(EC_PASS, idx, pvq_u(N, K) + pvq_u(N, K + 1)); EC_END; }
 }
 
 /* alg_quant (vq.c:552) */
@@ -324,8 +348,11 @@ WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K,
 {
    WV_LDS i32 *iy = L->A.s.pvq.iy;
    K_DUMP("pvqX", X, N * 4);
+   K_TIC();
    exp_rotation_wave(X, N, 1, B, K, spread);
+   K_TOC(16);
    i32 yy = op_pvq_search_wave(L, X, K, N);
+   K_TOC(17);
    unsigned cm = 1;
    if (B > 1) {
       int N0 = (u32)N / (u32)B;
@@ -335,6 +362,7 @@ WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K,
    }
    K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K);
    encode_pulses_wave(L, N, K);
+   K_TOC(18);
    if (resynth) {
       int k = celt_ilog2(yy) >> 1;
       i32 t = vshr32(yy, 2 * (k - 7) - 15);
@@ -343,6 +371,7 @@ WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K,
       wv_sync();
       exp_rotation_wave(X, N, -1, B, K, spread);
    }
+   K_TOC(19);
    return cm;
 }
 WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
@@ -368,7 +397,7 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
    if (stereo && i >= intensity) qn = 1;
    itheta = stereo_itheta_wave(X, Y, stereo, N) >> 16;
    wv_sync();
-   i32 tell = k_ec_tell_frac(PVQ_EC);
+   i32 tell = ec_tell_frac_lds(&L->ec);
    wv_sync();
    if (qn != 1) {
       if (!stereo || ctx->theta_round == 0) {
@@ -387,17 +416,19 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
          itheta = ctx->theta_round < 0 ? down : down + 1;
       }
       LANE0 {
+         EC_BEGIN;
          if (stereo && N > 2) {
             int p0 = 3, x = itheta, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
-            k_ec_encode(PVQ_EC, x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
+            k_ec_encode(EC_PASS, x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
          } else if (B0 > 1 || stereo) {
-            k_ec_enc_uint(PVQ_EC, itheta, qn + 1);
+            k_ec_enc_uint(EC_PASS, itheta, qn + 1);
          } else {
             int ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
             int fs = itheta <= (qn >> 1) ? itheta + 1 : qn + 1 - itheta;
             int fl = itheta <= (qn >> 1) ? itheta * (itheta + 1) >> 1 : ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
-            k_ec_encode(PVQ_EC, fl, fl + fs, ft);
+            k_ec_encode(EC_PASS, fl, fl + fs, ft);
          }
+         EC_END;
       }
       itheta = (u32)((i32)itheta * 16384) / (u32)qn;
       if (stereo) {
@@ -409,13 +440,13 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
       if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
       intensity_stereo_wave(L, X, Y, i, N);
       if (*b > 2 << BITRES && ctx->remaining_bits > 2 << BITRES) {
-         LANE0 k_ec_enc_bit_logp(PVQ_EC, inv, 2);
+         LANE0 { EC_BEGIN; k_ec_enc_bit_logp(EC_PASS, inv, 2); EC_END; }
       } else inv = 0;
       if (ctx->disable_inv) inv = 0;
       itheta = 0;
    }
    wv_sync();
-   qalloc = k_ec_tell_frac(PVQ_EC) - tell;
+   qalloc = ec_tell_frac_lds(&L->ec) - tell;
    *b -= qalloc;
    if (itheta == 0) { imid = 32767; iside = 0; *fill &= (1 << B) - 1; delta = -16384; }
    else if (itheta == 16384) { imid = 0; iside = 32767; *fill &= ((1 << B) - 1) << B; delta = 16384; }
@@ -437,7 +468,7 @@ WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 
       int sign = 0;
       if (ctx->remaining_bits >= 1 << BITRES) {
          sign = x[0] < 0;
-         LANE0 k_ec_enc_bits(PVQ_EC, sign, 1);
+         LANE0 { EC_BEGIN; k_ec_enc_bits(EC_PASS, sign, 1); EC_END; }
          ctx->remaining_bits -= 1 << BITRES;
       }
       if (ctx->resynth) { wv_sync(); LANE0 x[0] = sign ? -(1 << NORM_SHIFT) : (1 << NORM_SHIFT); wv_sync(); }
@@ -641,7 +672,7 @@ WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS
       wv_sync();
       if (sbits) {
          sign = mult32_32_q31(x2[0], y2[1]) - mult32_32_q31(x2[1], y2[0]) < 0;
-         LANE0 k_ec_enc_bits(PVQ_EC, sign, 1);
+         LANE0 { EC_BEGIN; k_ec_enc_bits(EC_PASS, sign, 1); EC_END; }
       }
       sign = 1 - 2 * sign;
       cm = quant_band_wave(L, ctx, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);
@@ -714,7 +745,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       Y = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
       N = M * ct_eBands[i + 1] - M * ct_eBands[i];
       wv_sync();
-      tell = k_ec_tell_frac(PVQ_EC);
+      tell = ec_tell_frac_lds(&L->ec);
       if (i != start) balance -= tell;
       remaining_bits = total_bits - tell - 1;
       ctx.remaining_bits = remaining_bits;
@@ -762,7 +793,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
                cm = x_cm | y_cm;
                wv_sync();
-               LANE0 ec_copy(&L->ecsave[0], &L->ec);
+               LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
                ctx_save = ctx;
                FOR_LANES(j, N) { P->X_save[j] = X[j]; P->Y_save[j] = Y[j]; }
                wv_sync();
@@ -771,7 +802,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                wv_sync();
                dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(P->X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(P->Y_save, Y, N));
                cm2 = x_cm;
-               LANE0 ec_copy(&L->ecsave[1], &L->ec);
+               LANE0 ec_cp_lds(&L->ecsave[1], &L->ec);
                ctx_save2 = ctx;
                FOR_LANES(j, N) { P->X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
                const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
@@ -779,7 +810,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                const int save_bytes = nend_bytes - nstart_bytes;
                FOR_LANES(j, save_bytes) L->bytes_save[j] = bytes_buf[j];
                wv_sync();
-               LANE0 ec_copy(&L->ec, &L->ecsave[0]);
+               LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
                ctx = ctx_save;
                FOR_LANES(j, N) { X[j] = P->X_save[j]; Y[j] = P->Y_save[j]; }
                wv_sync();
@@ -790,7 +821,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                if (dist0 >= dist1) {
                   x_cm = cm2;
                   wv_sync();
-                  LANE0 ec_copy(&L->ec, &L->ecsave[1]);
+                  LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
                   ctx = ctx_save2;
                   FOR_LANES(j, N) { X[j] = P->X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
                   FOR_LANES(j, save_bytes) bytes_buf[j] = L->bytes_save[j];

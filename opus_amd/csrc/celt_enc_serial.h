@@ -56,7 +56,7 @@ WV_TABLE i16 k_pred_coef[4] = {29440, 26112, 21248, 16384};
 WV_TABLE i16 k_beta_coef[4] = {30147, 22282, 12124, 6554};
 WV_TABLE u8 k_small_energy_icdf[3] = {2, 1, 0};
 
-WV_DEVN int coarse_impl(int start, int end, const WV_LDS i32 *eBands, WV_LDS i32 *oldEBands, i32 budget, i32 tell,
+WV_DEV int coarse_impl(int start, int end, const WV_LDS i32 *eBands, WV_LDS i32 *oldEBands, i32 budget, i32 tell,
       const u8 *prob_model, WV_LDS i32 *error, EC_ARGS, int C, int LM, int intra, i32 max_decay, int lfe)
 {
    int badness = 0;
@@ -105,7 +105,7 @@ WV_DEVN int coarse_impl(int start, int end, const WV_LDS i32 *eBands, WV_LDS i32
    }
    return lfe ? 0 : badness;
 }
-WV_DEVN void k_quant_coarse_energy(WV_LDS i32 *scr, WV_LDS u8 *intra_bits, WV_LDS EcCtx *ecsave, int start, int end, int effEnd, const WV_LDS i32 *eBands, WV_LDS i32 *oldEBands, u32 budget,
+WV_DEV void k_quant_coarse_energy(WV_LDS i32 *scr, WV_LDS u8 *intra_bits, int start, int end, int effEnd, const WV_LDS i32 *eBands, WV_LDS i32 *oldEBands, u32 budget,
       WV_LDS i32 *error, EC_ARGS, int C, int LM, int nbAvailableBytes, int force_intra, WV_LDS i32 *delayedIntra,
       int two_pass, int loss_rate, int lfe)
 {
@@ -119,22 +119,23 @@ WV_DEVN void k_quant_coarse_energy(WV_LDS i32 *scr, WV_LDS u8 *intra_bits, WV_LD
    i32 max_decay = GC(16.f);
    if (end - start > 10) max_decay = shl32(imin(max_decay >> (DB_SHIFT - 3), nbAvailableBytes), DB_SHIFT - 3);
    if (lfe) max_decay = GC(3.f);
-   ec_copy(&ecsave[0], e);   /* enc_start */
+   EcCtx ecsave[2];
+   ecsave[0] = *e;   /* enc_start */
    for (int i_ = 0; i_ < C * OA_NB_EBANDS; i_++) oldEBands_intra[i_] = oldEBands[i_];
    if (two_pass || intra)
       badness1 = coarse_impl(start, end, eBands, oldEBands_intra, budget, tell, ct_e_prob_model[LM][1],
             error_intra, EC_PASS, C, LM, 1, max_decay, lfe);
    if (!intra) {
       i32 tell_intra = k_ec_tell_frac(EC_PASS);
-      ec_copy(&ecsave[1], e);   /* enc_intra */
+      ecsave[1] = *e;   /* enc_intra */
       u32 nstart = ecsave[0].offs, nintra = ecsave[1].offs;
       WV_LDS u8 *intra_buf = buf + nstart;
       for (u32 i_ = 0; i_ < nintra - nstart; i_++) intra_bits[i_] = intra_buf[i_];
-      ec_copy(e, &ecsave[0]);
+      *e = ecsave[0];
       int badness2 = coarse_impl(start, end, eBands, oldEBands, budget, tell, ct_e_prob_model[LM][intra],
             error, EC_PASS, C, LM, 0, max_decay, lfe);
       if (two_pass && (badness1 < badness2 || (badness1 == badness2 && ((i32)k_ec_tell_frac(EC_PASS)) + intra_bias > tell_intra))) {
-         ec_copy(e, &ecsave[1]);
+         *e = ecsave[1];
          for (u32 i_ = 0; i_ < nintra - nstart; i_++) intra_buf[i_] = intra_bits[i_];
          for (int i_ = 0; i_ < C * OA_NB_EBANDS; i_++) oldEBands[i_] = oldEBands_intra[i_];
          for (int i_ = 0; i_ < C * OA_NB_EBANDS; i_++) error[i_] = error_intra[i_];
@@ -147,7 +148,7 @@ WV_DEVN void k_quant_coarse_energy(WV_LDS i32 *scr, WV_LDS u8 *intra_bits, WV_LD
    if (intra) *delayedIntra = new_distortion;
    else *delayedIntra = add32(mult16_32_q15(mult16_16_q15(k_pred_coef[LM], k_pred_coef[LM]), *delayedIntra), new_distortion);
 }
-WV_DEVN void k_quant_fine_energy(int start, int end, WV_LDS i32 *oldEBands, WV_LDS i32 *error, const WV_LDS int *prev_quant,
+WV_DEV void k_quant_fine_energy(int start, int end, WV_LDS i32 *oldEBands, WV_LDS i32 *error, const WV_LDS int *prev_quant,
       const WV_LDS int *extra_quant, EC_ARGS, int C)
 {
    for (int i = start; i < end; i++) {
@@ -167,7 +168,7 @@ WV_DEVN void k_quant_fine_energy(int start, int end, WV_LDS i32 *oldEBands, WV_L
       }
    }
 }
-WV_DEVN void k_quant_energy_finalise(int start, int end, WV_LDS i32 *oldEBands, WV_LDS i32 *error, const WV_LDS int *fine_quant,
+WV_DEV void k_quant_energy_finalise(int start, int end, WV_LDS i32 *oldEBands, WV_LDS i32 *error, const WV_LDS int *fine_quant,
       const WV_LDS int *fine_priority, int bits_left, EC_ARGS, int C)
 {
    for (int prio = 0; prio < 2; prio++)
@@ -212,7 +213,7 @@ WV_DEV void k_init_caps(WV_LDS int *cap, int LM, int C)
       cap[i] = (ct_cache_caps[OA_NB_EBANDS * (2 * LM + C - 1) + i] + 64) * C * N >> 2;
    }
 }
-WV_DEVN int interp_bits2pulses(int start, int end, int skip_start, const WV_LDS int *bits1, const WV_LDS int *bits2,
+WV_DEV int interp_bits2pulses(int start, int end, int skip_start, const WV_LDS int *bits1, const WV_LDS int *bits2,
       const WV_LDS int *thresh, const WV_LDS int *cap, i32 total, WV_LDS i32 *_balance, int skip_rsv, WV_LDS int *intensity,
       int intensity_rsv, WV_LDS int *dual_stereo, int dual_stereo_rsv, WV_LDS int *bits, WV_LDS int *ebits, WV_LDS int *fine_priority,
       int C, int LM, EC_ARGS, int encode, int prev, int signalBandwidth)
@@ -335,7 +336,7 @@ WV_DEVN int interp_bits2pulses(int start, int end, int skip_start, const WV_LDS 
    }
    return codedBands;
 }
-WV_DEVN int k_compute_allocation(WV_LDS i32 *scr, int start, int end, const WV_LDS int *offsets, const WV_LDS int *cap, int alloc_trim,
+WV_DEV int k_compute_allocation(WV_LDS i32 *scr, int start, int end, const WV_LDS int *offsets, const WV_LDS int *cap, int alloc_trim,
       WV_LDS int *intensity, WV_LDS int *dual_stereo, i32 total, WV_LDS i32 *balance, WV_LDS int *pulses, WV_LDS int *ebits,
       WV_LDS int *fine_priority, int C, int LM, EC_ARGS, int encode, int prev, int signalBandwidth)
 {

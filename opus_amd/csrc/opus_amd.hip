@@ -1,6 +1,13 @@
 /* opus_amd.hip — kernels + C ABI of the batched Opus (CELT-only) encoder for gfx950.
  * One 64-lane wavefront (= one workgroup) per (stream, frame); see celt_enc_*.h for the body. */
 #include "wave.h"
+#ifdef OA_PHASE_TIMERS
+/* profiling variant: accumulate shader-clock ticks per encoder phase (lane 0 of every wave) */
+__device__ unsigned long long oa_phase_ticks[20];
+#define K_TIC() unsigned long long tic_ = clock64()
+#define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - tic_); tic_ = t_; } } while (0)
+#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) atomicAdd(&oa_phase_ticks[(id) - 1], t_ - oa_phase_t0); oa_phase_t0 = t_; } } while (0)
+#endif
 #include "celt_enc_all.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
@@ -325,6 +332,15 @@ const char *opus_strerror(int error)
    if (error > 0 || error < -7) return "unknown error";
    return s[-error];
 }
+#ifdef OA_PHASE_TIMERS
+OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset)
+{
+   HIPCHECK(hipDeviceSynchronize());
+   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 20));
+   if (reset) { unsigned long long z[20] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
+   return OPUS_OK;
+}
+#endif
 const char *opus_get_version_string(void) { return "opus-amd 0.1 (gfx950, fixed-point bit-exact CELT encoder)"; }
 
 } /* extern "C" */

@@ -22,20 +22,60 @@ WV_DEV int wv_lane() { return (int)threadIdx.x; }
 WV_DEV void wv_sync() { __syncthreads(); }
 
 WV_DEV int32_t wv_shfl(int32_t v, int src) { return __shfl(v, src, 64); }
-WV_DEV int32_t wv_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
-WV_DEV int32_t wv_sum(int32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
-WV_DEV uint32_t wv_sumu(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64); return v; }
+/* src must be wave-uniform */
+WV_DEV int32_t wv_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+
+/* Wave-wide reductions on the DPP cross-lane network (no LDS round trips, unlike ds_bpermute shuffles):
+ * quad_perm swaps -> row rotations (every lane of a 16-lane row holds the row result) -> row_bcast:15 / row_bcast:31
+ * carry the partial results up the rows; lane 63 ends with the wave result, v_readlane broadcasts it. */
+#define WV_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
+#define WV_DPP_QP_1032 0xB1
+#define WV_DPP_QP_2301 0x4E
+#define WV_DPP_ROW_ROR4 0x124
+#define WV_DPP_ROW_ROR8 0x128
+#define WV_DPP_BCAST15 0x142
+#define WV_DPP_BCAST31 0x143
+WV_DEV int32_t wv_sum(int32_t v)
+{
+   v += WV_DPP(0, v, WV_DPP_QP_1032, 0xf);
+   v += WV_DPP(0, v, WV_DPP_QP_2301, 0xf);
+   v += WV_DPP(0, v, WV_DPP_ROW_ROR4, 0xf);
+   v += WV_DPP(0, v, WV_DPP_ROW_ROR8, 0xf);
+   v += WV_DPP(0, v, WV_DPP_BCAST15, 0xa);
+   v += WV_DPP(0, v, WV_DPP_BCAST31, 0xc);
+   return __builtin_amdgcn_readlane(v, 63);
+}
+WV_DEV uint32_t wv_sumu(uint32_t v) { return (uint32_t)wv_sum((int32_t)v); }
 WV_DEV int64_t wv_sum64(int64_t v)
 {
-   for (int o = 32; o > 0; o >>= 1) {
-      int lo = __shfl_xor((int)(uint32_t)v, o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
-      v += (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-   }
-   return v;
+   /* two independent 32-bit lanes of work; carries are rebuilt exactly by summing 16-bit quarters */
+   uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+   uint32_t a = wv_sumu(lo & 0xffff), b = wv_sumu(lo >> 16), c = wv_sumu(hi & 0xffff), d = wv_sumu(hi >> 16);
+   uint64_t r = (uint64_t)a + ((uint64_t)b << 16) + ((uint64_t)c << 32) + ((uint64_t)d << 48);
+   return (int64_t)r;
 }
-WV_DEV int32_t wv_max(int32_t v) { for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
-WV_DEV int32_t wv_min(int32_t v) { for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
-WV_DEV uint32_t wv_or(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 64); return v; }
+WV_DEV int32_t wv_max(int32_t v)
+{
+   int32_t t;
+   t = WV_DPP(v, v, WV_DPP_QP_1032, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_QP_2301, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_ROW_ROR4, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_ROW_ROR8, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_BCAST15, 0xa); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_BCAST31, 0xc); v = t > v ? t : v;
+   return __builtin_amdgcn_readlane(v, 63);
+}
+WV_DEV int32_t wv_min(int32_t v) { return -wv_max(-v); }   /* callers never pass INT32_MIN */
+WV_DEV uint32_t wv_or(uint32_t v)
+{
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_QP_1032, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_QP_2301, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_ROW_ROR4, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_ROW_ROR8, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_BCAST15, 0xa);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_BCAST31, 0xc);
+   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 WV_DEV uint64_t wv_ballot(int pred) { return __ballot(pred); }
 /* inclusive prefix sum over lanes */
 WV_DEV int32_t wv_scan_incl(int32_t v)
@@ -45,14 +85,20 @@ WV_DEV int32_t wv_scan_incl(int32_t v)
    return v;
 }
 /* PVQ greedy-search arg-max: maximise num/den (den > 0, exact 16x16 cross products), lowest index wins ties.
- * Every lane receives the winning (num, den, idx). */
+ * Every lane receives the winning (num, den, idx).  The order is total, so the DPP tree may combine in any shape. */
+#define WV_ARGMAX_STEP(ctrl, rmask) do { \
+      int32_t n2 = WV_DPP(num, num, ctrl, rmask), d2 = WV_DPP(den, den, ctrl, rmask), i2 = WV_DPP(idx, idx, ctrl, rmask); \
+      int32_t lhs = (int32_t)(int16_t)den * (int32_t)(int16_t)n2, rhs = (int32_t)(int16_t)d2 * (int32_t)(int16_t)num; \
+      bool take = lhs > rhs || (lhs == rhs && i2 < idx); \
+      num = take ? n2 : num; den = take ? d2 : den; idx = take ? i2 : idx; } while (0)
 WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
 {
-   for (int o = 32; o > 0; o >>= 1) {
-      int32_t n2 = __shfl_xor(num, o, 64), d2 = __shfl_xor(den, o, 64), i2 = __shfl_xor(idx, o, 64);
-      int32_t lhs = (int32_t)(int16_t)den * (int32_t)(int16_t)n2, rhs = (int32_t)(int16_t)d2 * (int32_t)(int16_t)num;
-      bool take = lhs > rhs || (lhs == rhs && i2 < idx);
-      if (take) { num = n2; den = d2; idx = i2; }
-   }
+   WV_ARGMAX_STEP(WV_DPP_QP_1032, 0xf);
+   WV_ARGMAX_STEP(WV_DPP_QP_2301, 0xf);
+   WV_ARGMAX_STEP(WV_DPP_ROW_ROR4, 0xf);
+   WV_ARGMAX_STEP(WV_DPP_ROW_ROR8, 0xf);
+   WV_ARGMAX_STEP(WV_DPP_BCAST15, 0xa);
+   WV_ARGMAX_STEP(WV_DPP_BCAST31, 0xc);
+   num = __builtin_amdgcn_readlane(num, 63); den = __builtin_amdgcn_readlane(den, 63); idx = __builtin_amdgcn_readlane(idx, 63);
 }
 #endif

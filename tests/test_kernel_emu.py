@@ -11,9 +11,13 @@ def _build():
     so = os.path.join(ROOT, "tests/emu/libemu_encoder.so")
     srcs = [os.path.join(ROOT, "tests/emu", f) for f in ("emu_encoder.cpp", "wave_emu.cpp")]
     hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "opus_amd/csrc")) if f.endswith(".h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs + hdrs):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-rdynamic", "-I" + os.path.join(ROOT, "tests/emu"),
-                               "-I" + os.path.join(ROOT, "opus_amd/csrc")] + srcs + ["-o", so])
+    import fcntl
+    with open(so + ".lock", "w") as lk:                     # pytest-xdist workers must not race the rebuild
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs + hdrs):
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-rdynamic", "-I" + os.path.join(ROOT, "tests/emu"),
+                                   "-I" + os.path.join(ROOT, "opus_amd/csrc")] + srcs + ["-o", so + ".tmp"])
+            os.replace(so + ".tmp", so)
     return ctypes.CDLL(so)
 
 pytestmark = pytest.mark.skipif(oracle() is None, reason="oracle lib not built")
