@@ -30,10 +30,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       const i32 *g = (const i32 *)&gs->st.s;
       WV_LDS i32 *d = (WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->oldLogE[i] = gs->st.oldLogE[i]; L->oldLogE2[i] = gs->st.oldLogE2[i]; L->energyError[i] = gs->st.energyError[i]; }
-      FOR_LANES(i, 2 * OA_OVERLAP) L->in_mem[i] = gs->st.in_mem[i];
-      const int CC = gs->cfg.channels;
-      for (int c = 0; c < CC; c++) { FOR_LANES(i, OA_MAX_PERIOD) L->A.pre[c][i] = gs->st.prefilter_mem[c * OA_MAX_PERIOD + i]; }
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
    }
    wv_sync();
    LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
@@ -50,7 +47,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    wv_sync();
    if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
    {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973) */
-      const WV_LDS i16 *p = L->Cc.pcm16;
+      const WV_LDS i16 *p = L->A.pcm16;
       const int Nf = frame_size;
       i32 a = 0, b = 0;
       FOR_LANES(i, CC * (Nf - overlap)) a = imax(a, iabs((i32)p[i]));
@@ -71,7 +68,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(1);
    /* ---- pre-emphasis (FIR on the input) ---- */
    for (int c = 0; c < CC; c++) {
-      const WV_LDS i16 *p = L->Cc.pcm16;
+      const WV_LDS i16 *p = L->A.pcm16;
       WV_LDS i32 *inp = L->B.in[c];
       i32 mem = st->preemph_memE[c];
       FOR_LANES(i, N) {
@@ -79,10 +76,11 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
          i32 m = i == 0 ? mem : mult16_32_q15(27853, shl32((i32)p[CC * (i - 1) + c], SIG_SHIFT));
          inp[overlap + i] = x - m;
       }
-      FOR_LANES(i, overlap) inp[i] = L->A.pre[c][OA_MAX_PERIOD - overlap + i];
+      FOR_LANES(i, overlap) inp[i] = gs->st.prefilter_mem[c * OA_MAX_PERIOD + OA_MAX_PERIOD - overlap + i];
    }
    wv_sync();
-   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->Cc.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
+   const i32 preemph_mem0[2] = {st->preemph_memE[0], st->preemph_memE[1]};     /* needed to recompute sample 0 later */
+   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
    wv_sync();
    for (int c = 0; c < CC; c++) K_DUMP("in_pre", L->B.in[c], (N + overlap) * 4);
 
@@ -104,13 +102,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    /* ---- pitch pre-filter ---- */
    {
       int enabled = (sh->nbAvailableBytes > 12 * C) && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
-      run_prefilter_wave(L, enabled);
-      /* persistent tails: filtered overlap -> in_mem, unfiltered history -> prefilter_mem (HBM) */
-      for (int c = 0; c < CC; c++) {
-         FOR_LANES(i, overlap) L->in_mem[c * overlap + i] = L->B.in[c][N + i];
-         FOR_LANES(i, OA_MAX_PERIOD) gs->st.prefilter_mem[c * OA_MAX_PERIOD + i] = L->A.pre[c][N + i];
-      }
-      wv_sync();
+      run_prefilter_wave(L, &gs->st, preemph_mem0, enabled);
       LANE0 {
          EC_BEGIN;
          int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
@@ -195,7 +187,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(9);
    LANE0 {
       EC_BEGIN;
-      k_quant_coarse_energy(L->scr, L->bytes_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
+      k_quant_coarse_energy(L->scr, L->B.s.bytes_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
             C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, 0);
       tf_encode_l0(L, EC_PASS);
       sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
@@ -334,12 +326,9 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       st->prefilter_gain = (i16)sh->gain1;
       st->prefilter_tapset = sh->prefilter_tapset;
       if (CC == 2 && C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[NBE + i] = L->oldBandE[i];
-      if (!isTransient) {
-         for (int i = 0; i < CC * NBE; i++) { L->oldLogE2[i] = L->oldLogE[i]; L->oldLogE[i] = L->oldBandE[i]; }
-      } else for (int i = 0; i < CC * NBE; i++) L->oldLogE[i] = imin(L->oldLogE[i], L->oldBandE[i]);
       for (int c = 0; c < CC; c++) {
-         for (int i = 0; i < start; i++) { L->oldBandE[c * NBE + i] = 0; L->oldLogE[c * NBE + i] = L->oldLogE2[c * NBE + i] = -GC(28.f); }
-         for (int i = end; i < NBE; i++) { L->oldBandE[c * NBE + i] = 0; L->oldLogE[c * NBE + i] = L->oldLogE2[c * NBE + i] = -GC(28.f); }
+         for (int i = 0; i < start; i++) L->oldBandE[c * NBE + i] = 0;
+         for (int i = end; i < NBE; i++) L->oldBandE[c * NBE + i] = 0;
       }
       if (isTransient || sh->transient_got_disabled) st->consec_transient++;
       else st->consec_transient = 0;
@@ -363,8 +352,19 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       i32 *g = (i32 *)&gs->st.s;
       const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
-      FOR_LANES(i, 2 * NBE) { gs->st.oldBandE[i] = L->oldBandE[i]; gs->st.oldLogE[i] = L->oldLogE[i]; gs->st.oldLogE2[i] = L->oldLogE2[i]; gs->st.energyError[i] = L->energyError[i]; }
-      FOR_LANES(i, 2 * OA_OVERLAP) gs->st.in_mem[i] = L->in_mem[i];
+      /* oldLogE / oldLogE2 (celt_encoder.c:2783-2803) are only ever updated here: do it straight on the HBM state.
+       * oldBandE in LDS still holds the pre-"start/end clearing" values for [start,end) and 0 outside, as the reference has at this point. */
+      const int isTr = sh->isTransient, nb = sh->CC * NBE;
+      FOR_LANES(i, 2 * NBE) {
+         if (i < nb) {
+            int bi = i % NBE;
+            i32 ob = L->oldBandE[i], l1 = gs->st.oldLogE[i], l2 = gs->st.oldLogE2[i];
+            if (!isTr) { l2 = l1; l1 = ob; } else l1 = imin(l1, ob);
+            if (bi < sh->start || bi >= sh->end) { l1 = l2 = -GC(28.f); }
+            gs->st.oldLogE[i] = l1; gs->st.oldLogE2[i] = l2;
+         }
+         gs->st.oldBandE[i] = L->oldBandE[i]; gs->st.energyError[i] = L->energyError[i];
+      }
    }
    K_PHASE(15);
 }

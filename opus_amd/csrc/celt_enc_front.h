@@ -130,7 +130,7 @@ WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int cha
    if (c < channels) {
       const int shift = celt_ilog2(48000 / (3 * 4));
       i32 mem = L->st.hp_mem[2 * c];
-      WV_LDS i16 *out = L->Cc.pcm16;
+      WV_LDS i16 *out = L->A.pcm16;
       for (int i = 0; i < len; i++) {
          i32 x = saturate((i32)pcm[channels * i + c], (1 << 16) - 1);
          x = shl32(x, 14);
@@ -143,7 +143,7 @@ WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int cha
 }
 WV_DEV void stereo_fade_lanes(WV_LDS FrameLds *L, int frame_size)
 {
-   WV_LDS i16 *io = L->Cc.pcm16;
+   WV_LDS i16 *io = L->A.pcm16;
    i16 g1 = (i16)(Q15ONE - L->sh.fade_g1), g2 = (i16)(Q15ONE - L->sh.fade_g2);
    FOR_LANES(i, frame_size) {
       i16 g = g2;

@@ -7,6 +7,19 @@
 #ifndef OPUS_AMD_CELT_ENC_PITCH_H
 #define OPUS_AMD_CELT_ENC_PITCH_H
 
+/* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
+ * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
+ * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
+struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; };
+WV_DEV i32 pre_at(const PreSrc &p, int j)
+{
+   if (j < OA_MAX_PERIOD) return p.hist[j];
+   int i = j - OA_MAX_PERIOD;
+   i32 x = shl32((i32)p.pcm[p.CC * i + p.c], SIG_SHIFT);
+   i32 m = i == 0 ? p.mem0 : mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * (i - 1) + p.c], SIG_SHIFT));
+   return x - m;
+}
+
 WV_DEV i32 wave_inner16(const WV_LDS i16 *x, const WV_LDS i16 *y, int N)
 {
    i32 s = 0;
@@ -63,13 +76,12 @@ WV_DEV void celt_lpc4(i16 *_lpc, const i32 *ac)
 }
 
 /* pitch_downsample (factor 2): pre[c] -> Cc.p.pitch_buf[len], len = (1024+N)>>1 */
-WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, int len, int C)
+WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int len, int C)
 {
-   const WV_LDS i32 *x0 = L->A.pre[0], *x1 = L->A.pre[1];
-   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->Cc.p.xcorr;       /* raw low-passed signal (kept for the final FIR) */
+   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->Cc.p.u.xcorr;       /* raw low-passed signal (kept for the final FIR) */
    WV_LDS i16 *xx = L->Cc.p.pitch_buf;                    /* scaled copy for the autocorrelation, then the result */
    i32 maxabs = 0;
-   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(x0[i])); if (C == 2) maxabs = imax(maxabs, iabs(x1[i])); }
+   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(pre_at(p0, i))); if (C == 2) maxabs = imax(maxabs, iabs(pre_at(p1, i))); }
    maxabs = wv_max(maxabs);
    if (maxabs < 1) maxabs = 1;
    int shift = celt_ilog2(maxabs) - 10;
@@ -77,11 +89,11 @@ WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, int len, int C)
    if (C == 2) shift++;
    FOR_LANES(i, len) {
       i16 v;
-      if (i == 0) v = (i16)((x0[1] >> (shift + 2)) + (x0[0] >> (shift + 1)));
-      else v = (i16)((x0[2 * i - 1] >> (shift + 2)) + (x0[2 * i + 1] >> (shift + 2)) + (x0[2 * i] >> (shift + 1)));
+      if (i == 0) v = (i16)((pre_at(p0, 1) >> (shift + 2)) + (pre_at(p0, 0) >> (shift + 1)));
+      else v = (i16)((pre_at(p0, 2 * i - 1) >> (shift + 2)) + (pre_at(p0, 2 * i + 1) >> (shift + 2)) + (pre_at(p0, 2 * i) >> (shift + 1)));
       if (C == 2) {
-         if (i == 0) v = (i16)(v + (x1[1] >> (shift + 2)) + (x1[0] >> (shift + 1)));
-         else v = (i16)(v + (x1[2 * i - 1] >> (shift + 2)) + (x1[2 * i + 1] >> (shift + 2)) + (x1[2 * i] >> (shift + 1)));
+         if (i == 0) v = (i16)(v + (pre_at(p1, 1) >> (shift + 2)) + (pre_at(p1, 0) >> (shift + 1)));
+         else v = (i16)(v + (pre_at(p1, 2 * i - 1) >> (shift + 2)) + (pre_at(p1, 2 * i + 1) >> (shift + 2)) + (pre_at(p1, 2 * i) >> (shift + 1)));
       }
       x_lp[i] = v;
    }
@@ -170,7 +182,7 @@ WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
 {
    const WV_LDS i16 *y = L->Cc.p.pitch_buf, *x_lp = L->Cc.p.pitch_buf + (OA_MAX_PERIOD >> 1);
    WV_LDS i16 *x_lp4 = L->Cc.p.x_lp4, *y_lp4 = L->Cc.p.y_lp4;
-   WV_LDS i32 *xcorr = L->Cc.p.xcorr;
+   WV_LDS i32 *xcorr = L->Cc.p.u.xcorr;
    const int lag = len + max_pitch;
    i32 xmax = 0, ymax = 0;
    FOR_LANES(j, len >> 2) { i16 v = x_lp[2 * j]; x_lp4[j] = v; xmax = imax(xmax, iabs((i32)v)); }
@@ -254,7 +266,7 @@ WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperio
    int T, T0, offset, minperiod0 = minperiod;
    i16 g, g0, pg;
    i32 xy, xx, yy, xy2, best_xy, best_yy;
-   WV_LDS i32 *yy_lookup = L->Cc.p.yy_lookup;
+   WV_LDS i32 *yy_lookup = L->Cc.p.u.yy_lookup;
    maxperiod /= 2; minperiod /= 2; *T0_ /= 2; prev_period /= 2; N /= 2;
    const WV_LDS i16 *x = L->Cc.p.pitch_buf + maxperiod;
    if (*T0_ >= maxperiod) *T0_ = maxperiod - 1;
@@ -315,14 +327,16 @@ WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperio
    return pg;
 }
 
-/* comb_filter (celt.c:238) out of place: y[i] from the *unfiltered* x (pre), so all outputs are independent */
-WV_DEV void comb_filter_wave(WV_LDS i32 *y, const WV_LDS i32 *x, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
+/* comb_filter (celt.c:238) out of place: y[i] from the *unfiltered* signal (PreSrc, index 0 = first new sample), so all
+ * outputs are independent */
+WV_DEV void comb_filter_wave(WV_LDS i32 *y, const PreSrc &p, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
 {
    const i16 gains[3][3] = {
       {QC16(0.3066406250f, 15), QC16(0.2170410156f, 15), QC16(0.1296386719f, 15)},
       {QC16(0.4638671875f, 15), QC16(0.2680664062f, 15), QC16(0.f, 15)},
       {QC16(0.7998046875f, 15), QC16(0.1000976562f, 15), QC16(0.f, 15)}};
-   if (g0 == 0 && g1 == 0) { FOR_LANES(i, N) y[i] = x[i]; return; }
+#define XA(k) pre_at(p, OA_MAX_PERIOD + (k))
+   if (g0 == 0 && g1 == 0) { FOR_LANES(i, N) y[i] = XA(i); return; }
    T0 = imax(T0, OA_MIN_PERIOD);
    T1 = imax(T1, OA_MIN_PERIOD);
    i16 g00 = (i16)mult_coef_taps(g0, gains[tapset0][0]), g01 = (i16)mult_coef_taps(g0, gains[tapset0][1]), g02 = (i16)mult_coef_taps(g0, gains[tapset0][2]);
@@ -332,27 +346,29 @@ WV_DEV void comb_filter_wave(WV_LDS i32 *y, const WV_LDS i32 *x, int T0, int T1,
       i32 v;
       if (i < overlap) {
          i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
-         v = x[i];
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), x[i - T0]));
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(x[i - T0 + 1], x[i - T0 - 1])));
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(x[i - T0 + 2], x[i - T0 - 2])));
-         v = add32(v, mult_coef_32(mult_coef(f, g10), x[i - T1]));
-         v = add32(v, mult_coef_32(mult_coef(f, g11), add32(x[i - T1 + 1], x[i - T1 - 1])));
-         v = add32(v, mult_coef_32(mult_coef(f, g12), add32(x[i - T1 + 2], x[i - T1 - 2])));
+         v = XA(i);
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), XA(i - T0)));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(XA(i - T0 + 1), XA(i - T0 - 1))));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(XA(i - T0 + 2), XA(i - T0 - 2))));
+         v = add32(v, mult_coef_32(mult_coef(f, g10), XA(i - T1)));
+         v = add32(v, mult_coef_32(mult_coef(f, g11), add32(XA(i - T1 + 1), XA(i - T1 - 1))));
+         v = add32(v, mult_coef_32(mult_coef(f, g12), add32(XA(i - T1 + 2), XA(i - T1 - 2))));
          v = saturate(sub32(v, 3), SIG_SAT);
       } else if (g1 == 0) {
-         v = x[i];
+         v = XA(i);
       } else {
-         v = add32(add32(add32(x[i], mult_coef_32(g10, x[i - T1])), mult_coef_32(g11, add32(x[i - T1 + 1], x[i - T1 - 1]))),
-               mult_coef_32(g12, add32(x[i - T1 + 2], x[i - T1 - 2])));
+         v = add32(add32(add32(XA(i), mult_coef_32(g10, XA(i - T1))), mult_coef_32(g11, add32(XA(i - T1 + 1), XA(i - T1 - 1)))),
+               mult_coef_32(g12, add32(XA(i - T1 + 2), XA(i - T1 - 2))));
          v = saturate(sub32(v, 1), SIG_SAT);
       }
       y[i] = v;
    }
+#undef XA
 }
 
-/* run_prefilter (celt_encoder.c:1405).  A.pre[c][0..1024) already holds prefilter_mem; B.in[c][overlap..) the new input. */
-WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
+/* run_prefilter (celt_encoder.c:1405).  B.in[c][overlap..) holds the new (unfiltered) input on entry, the filtered one on exit;
+ * in_mem / prefilter_mem are read from and written back to the stream's HBM state here. */
+WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *mem0, int enabled)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -360,8 +376,8 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
    const int prefilter_tapset = st->tapset_decision;
    int pitch_index, pf_on, qg;
    i16 gain1, pf_threshold;
-   for (int c = 0; c < CC; c++) { FOR_LANES(i, N) L->A.pre[c][max_period + i] = L->B.in[c][overlap + i]; }
-   wv_sync();
+   PreSrc ps[2];
+   for (int c = 0; c < 2; c++) { ps[c].hist = gst->prefilter_mem + c * OA_MAX_PERIOD; ps[c].pcm = L->A.pcm16; ps[c].CC = CC; ps[c].c = c; ps[c].mem0 = mem0[c]; }
    i16 tone_freq = (i16)sh->tone_freq;
    if (enabled && sh->toneishness > QC32(.99f, 29)) {
       int multiple = 1;
@@ -371,7 +387,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
       else pitch_index = OA_MIN_PERIOD;
       gain1 = QC16(.75f, 15);
    } else if (enabled && sh->complexity >= 5) {
-      pitch_downsample_wave(L, (max_period + N) >> 1, CC);
+      pitch_downsample_wave(L, ps[0], ps[1], (max_period + N) >> 1, CC);
       pitch_index = pitch_search_wave(L, N, max_period - 3 * min_period);
       pitch_index = max_period - pitch_index;
       gain1 = remove_doubling_wave(L, max_period, min_period, N, &pitch_index, st->prefilter_period, (i16)st->prefilter_gain);
@@ -404,7 +420,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
    i32 before[2] = {0, 0}, after[2] = {0, 0};
    wv_sync();
    /* in[c][0..overlap) <- in_mem: last frame's *filtered* tail (celt_encoder.c:1546) */
-   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) L->B.in[c][i] = L->in_mem[c * overlap + i]; }
+   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) L->B.in[c][i] = gst->in_mem[c * overlap + i]; }
    for (int c = 0; c < CC; c++) {
       WV_LDS i32 *in = L->B.in[c];
       i32 b = 0;
@@ -413,7 +429,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
    }
    wv_sync();
    for (int c = 0; c < CC; c++)
-      comb_filter_wave(L->B.in[c] + overlap, L->A.pre[c] + max_period, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
+      comb_filter_wave(L->B.in[c] + overlap, ps[c], old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
    wv_sync();
    for (int c = 0; c < CC; c++) {
       i32 a = 0;
@@ -431,14 +447,24 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, int enabled)
    if (cancel_pitch) {
       wv_sync();
       for (int c = 0; c < CC; c++) {
-         FOR_LANES(i, N) L->B.in[c][overlap + i] = L->A.pre[c][max_period + i];
+         FOR_LANES(i, N) L->B.in[c][overlap + i] = pre_at(ps[c], max_period + i);
       }
       wv_sync();
       for (int c = 0; c < CC; c++)
-         comb_filter_wave(L->B.in[c] + overlap, L->A.pre[c] + max_period, old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
+         comb_filter_wave(L->B.in[c] + overlap, ps[c], old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
       gain1 = 0; pf_on = 0; qg = 0;
    }
    wv_sync();
+   /* persistent tails: filtered overlap -> in_mem; unfiltered [history | new][N .. N+1024) -> prefilter_mem.
+    * Every lane first gathers its 16 values (the shift may overlap source and destination), then stores. */
+   for (int c = 0; c < CC; c++) {
+      FOR_LANES(i, overlap) gst->in_mem[c * overlap + i] = L->B.in[c][N + i];
+      i32 keep[OA_MAX_PERIOD / WV_WIDTH];
+      for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) keep[t] = pre_at(ps[c], N + wv_lane() + t * WV_WIDTH);
+      wv_sync();
+      for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) gst->prefilter_mem[c * OA_MAX_PERIOD + wv_lane() + t * WV_WIDTH] = keep[t];
+      wv_sync();
+   }
    LANE0 {
       st->prefilter_period = old_period;
       sh->pf_on = pf_on; sh->pitch_index = pitch_index; sh->gain1 = gain1; sh->qg = qg; sh->prefilter_tapset = prefilter_tapset;

@@ -252,7 +252,7 @@ WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K
  * every lane; iy[] (signed) is written to LDS once at the end. */
 WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
 {
-   WV_LDS i32 *iy = L->A.s.pvq.iy;
+   WV_LDS i32 *iy = L->Cc.pvq.iy;
    const int lane = wv_lane();
    int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
    shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
@@ -324,7 +324,7 @@ WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
  * Suffix sums of |y| come from a wave scan; every table read is then independent (issued back to back). */
 WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
 {
-   const WV_LDS i32 *y = L->A.s.pvq.iy;
+   const WV_LDS i32 *y = L->Cc.pvq.iy;
    const int lane = wv_lane(), j0 = 3 * lane;
    i32 yv[3], a[3], tot = 0;
    for (int t = 0; t < 3; t++) { int j = j0 + t; yv[t] = j < N ? y[j] : 0; a[t] = iabs(yv[t]); tot += a[t]; }
@@ -346,7 +346,7 @@ WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
 /* alg_quant (vq.c:552) */
 WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
 {
-   WV_LDS i32 *iy = L->A.s.pvq.iy;
+   WV_LDS i32 *iy = L->Cc.pvq.iy;
    K_DUMP("pvqX", X, N * 4);
    K_TIC();
    exp_rotation_wave(X, N, 1, B, K, spread);
@@ -579,7 +579,7 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
    int N0 = N, N_B = N, N_B0, B0 = B, time_divide = 0, recombine = 0, longBlocks, k;
    unsigned cm = 0;
    int tf_change = ctx->tf_change;
-   WV_LDS i32 *hada = L->A.s.pvq.hada_tmp;
+   WV_LDS i32 *hada = L->Cc.pvq.hada_tmp;
    longBlocks = B0 == 1;
    N_B = (u32)N_B / (u32)B;
    if (N == 1) return quant_band_n1_wave(L, ctx, X, 0, lowband_out);
@@ -721,7 +721,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
 {
    const int start = L->sh.start, end = L->sh.end, LM = L->sh.LM, C = L->sh.C, Nfull = L->sh.N;
    WV_LDS i32 *X_ = L->A.s.X, *Y_ = C == 2 ? L->A.s.X + Nfull : 0;
-   WV_LDS PvqScratch *P = &L->A.s.pvq;
+   WV_LDS PvqScratch *P = &L->Cc.pvq;
    WV_LDS i32 *norm = L->B.s.norm, *norm2 = L->B.s.norm + 800;
    WV_LDS u8 *collapse_masks = L->collapse_masks;
    const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
@@ -808,7 +808,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
                WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
                const int save_bytes = nend_bytes - nstart_bytes;
-               FOR_LANES(j, save_bytes) L->bytes_save[j] = bytes_buf[j];
+               FOR_LANES(j, save_bytes) L->B.s.bytes_save[j] = bytes_buf[j];
                wv_sync();
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
                ctx = ctx_save;
@@ -824,7 +824,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                   LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
                   ctx = ctx_save2;
                   FOR_LANES(j, N) { X[j] = P->X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
-                  FOR_LANES(j, save_bytes) bytes_buf[j] = L->bytes_save[j];
+                  FOR_LANES(j, save_bytes) bytes_buf[j] = L->B.s.bytes_save[j];
                   wv_sync();
                }
             } else {

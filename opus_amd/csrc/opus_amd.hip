@@ -2,11 +2,13 @@
  * One 64-lane wavefront (= one workgroup) per (stream, frame); see celt_enc_*.h for the body. */
 #include "wave.h"
 #ifdef OA_PHASE_TIMERS
-/* profiling variant: accumulate shader-clock ticks per encoder phase (lane 0 of every wave) */
-__device__ unsigned long long oa_phase_ticks[20];
+/* profiling variant: shader-clock ticks per encoder phase, accumulated per wave in LDS (lane 0) and added to the
+ * global totals once per frame */
+__device__ unsigned long long oa_phase_ticks[24];
 #define K_TIC() unsigned long long tic_ = clock64()
-#define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - tic_); tic_ = t_; } } while (0)
-#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) atomicAdd(&oa_phase_ticks[(id) - 1], t_ - oa_phase_t0); oa_phase_t0 = t_; } } while (0)
+#define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); L->prof[b] += (u32)(t_ - tic_); tic_ = t_; } } while (0)
+#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) L->prof[(id) - 1] = (u32)(t_ - oa_phase_t0); else for (int z_ = 0; z_ < 24; z_++) L->prof[z_] = 0; oa_phase_t0 = t_; \
+      if ((id) == 15) for (int z_ = 0; z_ < 24; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
 #endif
 #include "celt_enc_all.h"
 #include "../../include/opus_amd.h"
@@ -17,7 +19,7 @@ __device__ unsigned long long oa_phase_ticks[20];
 #include <mutex>
 #include <vector>
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,7 +149,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
                 hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess &&
-                hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FrameLds)) == hipSuccess;
+                hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       if (!ok) { opusgpu_enc_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
    }
    if (error) *error = err;
@@ -221,7 +223,8 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    if (out_stride < (max_data_bytes < 1276 ? max_data_bytes : 1276)) return OPUS_BUFFER_TOO_SMALL;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
-   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds), s,
+   static const size_t lds_pad = getenv("OPUS_AMD_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_LDS_PAD")) : 0;   /* occupancy experiments only */
+   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds) + lds_pad, s,
          b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
@@ -336,8 +339,8 @@ const char *opus_strerror(int error)
 OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset)
 {
    HIPCHECK(hipDeviceSynchronize());
-   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 20));
-   if (reset) { unsigned long long z[20] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
+   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 24));
+   if (reset) { unsigned long long z[24] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
    return OPUS_OK;
 }
 #endif

@@ -17,7 +17,7 @@ def main():
     b.ctl(opus_amd.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(opus_amd.OPUS_SET_COMPLEXITY_REQUEST, 10)
     sig = [signals.music(8, seed=s) if s % 4 else signals.noise_bursts(8, seed=s) for s in range(64)]
     L = opus_amd.lib()
-    ticks = (ctypes.c_ulonglong * 20)()
+    ticks = (ctypes.c_ulonglong * 24)()
     for i in range(8):
         pcm = np.stack([sig[s % 64][i * 960:(i + 1) * 960].reshape(-1) for s in range(S)])
         if i == 3: L.opusgpu_debug_phase_ticks(ticks, 1)
