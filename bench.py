@@ -96,14 +96,13 @@ def main():
     b = opus_amd.EncoderBatch(S, channels=CH, application=opus_amd.OPUS_APPLICATION_RESTRICTED_LOWDELAY, device=local)
     b.ctl(opus_amd.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(opus_amd.OPUS_SET_COMPLEXITY_REQUEST, 10)
     stream = torch.cuda.current_stream(dev)
-    gather_len = [torch.empty_like(lens) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_out = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from opus_amd.shard import PacketGather
+    gather = PacketGather(S * world, 1280, dev, dst=0) if world > 1 else None
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), 1280, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
         if world > 1:   # the only exchange of the path: final gather of the packets (RCCL over xGMI)
-            dist.gather(lens, gather_len, dst=0)
-            dist.gather(out, gather_out, dst=0)
+            gather.launch(lens, rng, out)
 
     for t in range(W): step(t)
     torch.cuda.synchronize(dev)
@@ -116,8 +115,7 @@ def main():
         b.encode_dev(pcm[W + k].data_ptr(), FR, out.data_ptr(), 1280, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.gather(lens, gather_len, dst=0)
-            dist.gather(out, gather_out, dst=0)
+            gather.launch(lens, rng, out)
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)

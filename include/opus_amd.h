@@ -3,8 +3,8 @@
  * Two layers, both plain C (no torch / HIP types in the signatures):
  *
  * 1. The classic libopus encoder entry points, same names, argument meaning and error codes as the reference
- *    (reference/include/opus.h: opus_encoder_get_size :174, opus_encoder_create :212, opus_encoder_init :235,
- *    opus_encode :266, opus_encoder_destroy :355, opus_encoder_ctl :367; error codes opus_defines.h:46-60).
+ *    (reference/include/opus.h: opus_encoder_get_size :174, opus_encoder_create :211, opus_encoder_init :231,
+ *    opus_encode :266, opus_encoder_destroy :354, opus_encoder_ctl :367; error codes opus_defines.h:46-60).
  *    The OpusEncoder blob is flat host memory holding the complete canonical state (memcpy-able, no device
  *    handles: opus.h:108-109); every opus_encode() runs the frame on the GPU as a batch of one.
  *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only path), Fs = 48000,
@@ -76,7 +76,8 @@ typedef int32_t opus_int32;
 typedef uint32_t opus_uint32;
 typedef struct OpusEncoder OpusEncoder;
 
-/* ---- classic API (replaces reference/src/opus_encoder.c:194,:204,:547?,:2671,:2772,:3350) ---- */
+/* ---- classic API (replaces reference/src/opus_encoder.c:194 get_size, :204 init, :622 create, :2671 opus_encode, :2772 ctl, :3362 destroy;
+ * celt/celt.c:342 opus_strerror, :360 opus_get_version_string) ---- */
 OPUS_AMD_EXPORT int opus_encoder_get_size(int channels);
 OPUS_AMD_EXPORT OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, int *error);
 OPUS_AMD_EXPORT int opus_encoder_init(OpusEncoder *st, opus_int32 Fs, int channels, int application);
