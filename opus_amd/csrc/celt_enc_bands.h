@@ -26,14 +26,14 @@ WV_DEV i32 inner_prod_norm_shift_w(const WV_LDS i32 *x, const WV_LDS i32 *y, int
 }
 
 /* compute_mdcts (celt_encoder.c:511): per channel, B interleaved transforms; freq lands in A.s.X */
-WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, int shortBlocks)
+WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks)
 {
    const int C = L->sh.C, CC = L->sh.CC, LM = L->sh.LM;
    int B, N, shift;
    if (shortBlocks) { B = shortBlocks; N = 120; shift = 3; }
    else { B = 1; N = 120 << LM; shift = 3 - LM; }
    for (int c = 0; c < CC; c++)
-      mdct_forward_blocks(L->B.in[c], L->A.s.X + c * N * B, shift, B, L->Cc.fft, L->aux);
+      mdct_forward_blocks(gst->in_mem + c * OA_OVERLAP, L->BC.in[c], L->A.s.X + c * N * B, shift, B, L->aux);
    if (CC == 2 && C == 1) {
       WV_LDS i32 *out = L->A.s.X;
       FOR_LANES(i, B * N) out[i] = add32(out[i] >> 1, out[B * N + i] >> 1);
@@ -264,8 +264,8 @@ WV_DEVN void tf_analysis_wave(WV_LDS FrameLds *L, int lambda)
    const int len = sh->effEnd, isTransient = sh->isTransient, LM = sh->LM, N0 = sh->N, tf_chan = sh->tf_chan;
    const i16 tf_estimate = (i16)sh->tf_estimate;
    WV_LDS i32 *metric = L->scr, *path0 = L->scr + 21, *path1 = L->scr + 42;
-   WV_LDS i32 *tmpA = L->B.s.norm;          /* 800 words: private per-band segments (folding memory not live yet) */
-   WV_LDS i32 *tmpB = L->B.s.norm + 800;    /* second copy for the "-1" trial */
+   WV_LDS i32 *tmpA = L->BC.tf;             /* 800 words: private per-band segments (folding memory not live yet) */
+   WV_LDS i32 *tmpB = L->BC.tf + 800;    /* second copy for the "-1" trial */
    const WV_LDS i32 *X = L->A.s.X;
    i16 bias = (i16)mult16_16_q14(QC16(.04f, 15), imax(-QC16(.25f, 14), QC16(.5f, 14) - tf_estimate));
    FOR_LANES(i, len) {

@@ -66,33 +66,23 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
 
    K_PHASE(1);
-   /* ---- pre-emphasis (FIR on the input) ---- */
-   for (int c = 0; c < CC; c++) {
-      const WV_LDS i16 *p = L->A.pcm16;
-      WV_LDS i32 *inp = L->B.in[c];
-      i32 mem = st->preemph_memE[c];
-      FOR_LANES(i, N) {
-         i32 x = shl32((i32)p[CC * i + c], SIG_SHIFT);
-         i32 m = i == 0 ? mem : mult16_32_q15(27853, shl32((i32)p[CC * (i - 1) + c], SIG_SHIFT));
-         inp[overlap + i] = x - m;
-      }
-      FOR_LANES(i, overlap) inp[i] = gs->st.prefilter_mem[c * OA_MAX_PERIOD + OA_MAX_PERIOD - overlap + i];
-   }
+   /* ---- pre-emphasis (celt_encoder.c:557) is not materialised: pre_at() recomputes it from the int16 staging buffer ---- */
+   PreSrc ps0, ps1;
+   ps0.hist = gs->st.prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0];
+   ps1.hist = gs->st.prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1];
    wv_sync();
-   const i32 preemph_mem0[2] = {st->preemph_memE[0], st->preemph_memE[1]};     /* needed to recompute sample 0 later */
    LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
    wv_sync();
-   for (int c = 0; c < CC; c++) K_DUMP("in_pre", L->B.in[c], (N + overlap) * 4);
 
    K_PHASE(2);
    /* ---- tone / transient analysis ---- */
-   tone_detect_wave(L);
+   tone_detect_wave(L, ps0, ps1);
    wv_sync();
    K_DUMPI("tone_freq", (i16)sh->tone_freq); K_DUMPI("toneishness", sh->toneishness);
    LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
    wv_sync();
    K_PHASE(3);
-   if (sh->complexity >= 1) transient_analysis_wave(L, 0);
+   if (sh->complexity >= 1) transient_analysis_wave(L, ps0, ps1, 0);
    wv_sync();
    K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
    LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
@@ -102,7 +92,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    /* ---- pitch pre-filter ---- */
    {
       int enabled = (sh->nbAvailableBytes > 12 * C) && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
-      run_prefilter_wave(L, &gs->st, preemph_mem0, enabled);
+      run_prefilter_wave(L, &gs->st, ps0, ps1, enabled);
       LANE0 {
          EC_BEGIN;
          int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
@@ -128,18 +118,17 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       }
       wv_sync();
       K_DUMPI("pf_on", sh->pf_on); K_DUMPI("pitch_index", sh->pitch_index); K_DUMPI("gain1", (i16)sh->gain1); K_DUMPI("qg", sh->qg);
-      for (int c = 0; c < CC; c++) K_DUMP("in_pf", L->B.in[c], (N + overlap) * 4);
    }
 
    K_PHASE(5);
    /* ---- MDCT + band energies ---- */
    if (sh->secondMdct) {
-      compute_mdcts_wave(L, 0);
+      compute_mdcts_wave(L, &gs->st, 0);
       band_energies_wave(L, L->bandLogE2);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       wv_sync();
    }
-   compute_mdcts_wave(L, sh->shortBlocks);
+   compute_mdcts_wave(L, &gs->st, sh->shortBlocks);
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    band_energies_wave(L, L->bandLogE);
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
@@ -157,12 +146,13 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    if (sh->do_patch) {
       LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
       wv_sync();
-      compute_mdcts_wave(L, sh->shortBlocks);
+      compute_mdcts_wave(L, &gs->st, sh->shortBlocks);
       band_energies_wave(L, L->bandLogE);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
    }
+   store_in_mem_wave(L, &gs->st);          /* last MDCT done: the overlap memory may now be replaced; BC is free from here */
    LANE0 { EC_BEGIN; if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); EC_END; }
    normalise_bands_wave(L);
    K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->A.s.X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
@@ -187,7 +177,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(9);
    LANE0 {
       EC_BEGIN;
-      k_quant_coarse_energy(L->scr, L->B.s.bytes_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
+      k_quant_coarse_energy(L->scr, L->BC.coarse_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
             C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, 0);
       tf_encode_l0(L, EC_PASS);
       sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
@@ -309,7 +299,8 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(12);
    /* ---- PVQ residual ---- */
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
-         sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv);
+         sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv,
+         out /* the stream's still-unwritten output slot doubles as the theta-RDO byte journal */);
    K_DUMPI("rng_pvq", L->ec.rng); K_DUMP("collapse", L->collapse_masks, 42);
 
    K_PHASE(13);

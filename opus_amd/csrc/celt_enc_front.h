@@ -229,6 +229,19 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
    EC_END;
 }
 
+/* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
+ * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
+ * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
+struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; };
+WV_DEV i32 pre_at(const PreSrc &p, int j)
+{
+   if (j < OA_MAX_PERIOD) return p.hist[j];
+   int i = j - OA_MAX_PERIOD;
+   i32 x = shl32((i32)p.pcm[p.CC * i + p.c], SIG_SHIFT);
+   i32 m = i == 0 ? p.mem0 : mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * (i - 1) + p.c], SIG_SHIFT));
+   return x - m;
+}
+
 /* tone detector (celt_encoder.c:1272-1403).  x16 built in parallel, correlations by wave reductions
  * (plain int32 sums are order-free), 2x2 solve redundantly on every lane (pure scalar code). */
 WV_DEV int acos_approx(i32 x)
@@ -273,14 +286,15 @@ WV_DEV int tone_lpc_wave(const WV_LDS i16 *x, int len, int delay, i32 *lpc)
    else lpc[0] = fx_frac_div32_q29(num0, den);
    return 0;
 }
-WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L)
+WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1)
 {
    const int CC = L->sh.CC, N = L->sh.N + OA_OVERLAP;
-   WV_LDS i16 *x = L->Cc.x16[0];
-   const WV_LDS i32 *in0 = L->B.in[0], *in1 = L->B.in[1];
+   WV_LDS i16 *x = L->BC.x16[0];
+   const int j0 = OA_MAX_PERIOD - OA_OVERLAP;      /* in[c][i] == pre[c][1024 - overlap + i] */
    i32 ac0 = 0;
    FOR_LANES(i, N) {
-      i16 v = CC == 2 ? (i16)pshr32(add32(in0[i] >> 1, in1[i] >> 1), SIG_SHIFT + 2) : (i16)pshr32(in0[i], SIG_SHIFT + 2);
+      i32 a0 = pre_at(p0, j0 + i);
+      i16 v = CC == 2 ? (i16)pshr32(add32(a0 >> 1, pre_at(p1, j0 + i) >> 1), SIG_SHIFT + 2) : (i16)pshr32(a0, SIG_SHIFT + 2);
       x[i] = v;
       ac0 += mult16_16(v, v) >> 10;
    }
@@ -307,7 +321,7 @@ WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L)
 
 /* transient_analysis (celt_encoder.c:267): the HP filter and the forward/backward masking followers are
  * recursions with rounding -> one lane per channel runs them; ranges/normalisation use wave reductions. */
-WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, int allow_weak_transients)
+WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int allow_weak_transients)
 {
    const u8 inv_table[128] = {
       255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18, 17, 16, 16, 15, 15, 14, 13, 13, 12, 12,
@@ -316,17 +330,20 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, int allow_weak_transien
       4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2};
    const int C = L->sh.CC, len = L->sh.N + OA_OVERLAP, len2 = len / 2, lane = wv_lane();
    const int forward_shift = allow_weak_transients ? 5 : 4;
+   const int j0 = OA_MAX_PERIOD - OA_OVERLAP;      /* in[c][i] == pre[c][1024 - overlap + i] */
    i32 mx = 0;
-   FOR_LANES(i, len) { mx = imax(mx, iabs(L->B.in[0][i])); if (C == 2) mx = imax(mx, iabs(L->B.in[1][i])); }
+   FOR_LANES(i, len) { mx = imax(mx, iabs(pre_at(p0, j0 + i))); if (C == 2) mx = imax(mx, iabs(pre_at(p1, j0 + i))); }
    mx = wv_max(mx);                       /* celt_maxabs32 over both channels (|INT32_MIN| cannot occur: SIG range) */
    const int in_shift = imax(0, celt_ilog2(1 + mx) - 14);
    wv_sync();
+   /* the shifted input fits 16 bits (|x| < 2^15 by construction of in_shift): stage it in place of the filter output */
+   FOR_LANES(i, len) { L->BC.x16[0][i] = (i16)(pre_at(p0, j0 + i) >> in_shift); if (C == 2) L->BC.x16[1][i] = (i16)(pre_at(p1, j0 + i) >> in_shift); }
+   wv_sync();
    if (lane < C) {
-      WV_LDS i16 *tmp = L->Cc.x16[lane];
-      const WV_LDS i32 *in = L->B.in[lane];
+      WV_LDS i16 *tmp = L->BC.x16[lane];
       i32 mem0 = 0, mem1 = 0;
       for (int i = 0; i < len; i++) {
-         i32 x = in[i] >> in_shift;
+         i32 x = tmp[i];
          i32 y = add32(mem0, x);
          mem0 = mem1 + y - shl32(x, 1);
          mem1 = x - (y >> 1);
@@ -337,19 +354,19 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, int allow_weak_transien
    wv_sync();
    /* per-channel normalisation to max range */
    i32 m0 = 0, m1 = 0;
-   FOR_LANES(i, len) { m0 = imax(m0, iabs((i32)L->Cc.x16[0][i])); if (C == 2) m1 = imax(m1, iabs((i32)L->Cc.x16[1][i])); }
+   FOR_LANES(i, len) { m0 = imax(m0, iabs((i32)L->BC.x16[0][i])); if (C == 2) m1 = imax(m1, iabs((i32)L->BC.x16[1][i])); }
    m0 = wv_max(m0); m1 = wv_max(m1);
    {
       int s0 = 14 - celt_ilog2(imax(1, m0)), s1 = 14 - celt_ilog2(imax(1, m1));
       FOR_LANES(i, len) {
-         if (s0 != 0) L->Cc.x16[0][i] = shl16(L->Cc.x16[0][i], s0);
-         if (C == 2 && s1 != 0) L->Cc.x16[1][i] = shl16(L->Cc.x16[1][i], s1);
+         if (s0 != 0) L->BC.x16[0][i] = shl16(L->BC.x16[0][i], s0);
+         if (C == 2 && s1 != 0) L->BC.x16[1][i] = shl16(L->BC.x16[1][i], s1);
       }
    }
    wv_sync();
    i32 unmask_c = 0;
    if (lane < C) {
-      WV_LDS i16 *tmp = L->Cc.x16[lane];
+      WV_LDS i16 *tmp = L->BC.x16[lane];
       i32 mean = 0, mem0 = 0, norm;
       i16 maxE = 0;
       for (int i = 0; i < len2; i++) {

@@ -1,13 +1,14 @@
 /* celt_enc_lds.h — per-wavefront LDS working set of the CELT frame encoder (one wave = one stream-frame).
  *
- * Big regions are phase-aliased:
- *   A (7,680 B)  dc-rejected int16 PCM (the unfiltered pre-emphasised signal is recomputed from it on the fly)
- *                                                      -> from the MDCT on: spectrum freq/X[2][960]
- *   B (8,640 B)  in[2][960+120] (pre-emphasised, comb-filtered input)   -> afterwards: folding memory norm[2][800],
- *                                                      tf_analysis scratch, theta-RDO byte snapshot
- *   C (5,664 B)  tone/transient int16 buffers | pitch buffers | FFT storage | PVQ save slots
- * The 2x1024-sample pitch history (prefilter_mem) is NOT copied to LDS: it is read from the stream's HBM state where
- * needed (coalesced) and rewritten in place.  Total ~26 KB/wave -> 6 waves per CU (160 KB LDS), 2 per SIMD with <=256 VGPRs. */
+ * Two big phase-aliased regions:
+ *   A  (7,680 B)  dc-rejected int16 PCM (the unfiltered pre-emphasised signal is recomputed from it on the fly)
+ *                 -> from the MDCT on: spectrum freq/X[2][960]; the FFT runs in place in its channel's half
+ *   BC (7,840 B)  tone/transient int16 buffers | pitch buffers | comb-filtered input in[2][960] (until the last MDCT)
+ *                 | tf_analysis / coarse-energy rollback scratch | PVQ: folding memory norm[624] (+ norm2 for
+ *                 dual stereo, or the theta-RDO save slots: the two are mutually exclusive) + band scratch
+ * Not in LDS: the 2x1024-sample pitch history and the 2x120 overlap memory (read from the stream's HBM record where
+ * needed, rewritten in place) and the theta-RDO byte journal (per-stream HBM scratch).
+ * Total < 20,480 B/wave -> 8 waves per CU (160 KB LDS) = 2 per SIMD, the VGPR limit. */
 #ifndef OPUS_AMD_CELT_ENC_LDS_H
 #define OPUS_AMD_CELT_ENC_LDS_H
 
@@ -27,10 +28,10 @@ struct FrameShared {
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 
-struct PvqScratch {                  /* region C during the PVQ phase */
-   i32 lowband_scratch[176], X_save[176], Y_save[176], X_save2[176], Y_save2[176], norm_save2[176], hada_tmp[176];
-   i32 iy[176 + 8];
+struct PvqScratch {                  /* band scratch during the PVQ phase */
+   i32 lowband_scratch[176], iy[176 + 8], Y_save2[176], norm_save2[176];
 };
+#define OA_NORM_LEN 624              /* 8 * eBands[20]: folding memory never extends into the last band */
 
 struct FrameLds {
    EcCtx ec;
@@ -42,22 +43,26 @@ struct FrameLds {
    i32 offsets[NBE], importance[NBE], spread_weight[NBE], tf_res[NBE], pulses[NBE], fine_quant[NBE], fine_priority[NBE], cap[NBE];
    i32 scr[6 * NBE];                  /* lane-0 scratch (allocation vectors, dynalloc followers, two-pass energies) */
    i32 aux[32];                       /* MDCT headroom/shift bookkeeping, reductions hand-off */
-   u32 prof[24];                      /* shader-clock buckets, only written by the -DOA_PHASE_TIMERS profiling build */
+#ifdef OA_PHASE_TIMERS
+   u32 prof[26];                      /* shader-clock buckets of the profiling build */
+#endif
    u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* packet[0] = TOC, range coder buffer = packet+1 */
    union {                            /* A: int16 input until the MDCT, then the spectrum */
       i16 pcm16[2 * OA_MAX_FRAME];                                     /* dc-rejected input, interleaved */
       struct { i32 X[2 * OA_MAX_FRAME]; } s;
    } A;
-   union {                            /* B: filtered time signal until the MDCT, then folding memory / rollback bytes */
-      i32 in[2][OA_MAX_FRAME + OA_OVERLAP];
-      struct { i32 norm[2 * 800]; u8 bytes_save[OA_MAX_PACKET + 4]; } s;
-   } B;
-   union {                            /* C: phase scratch */
+   union {                            /* BC: phase scratch */
       i16 x16[2][OA_MAX_FRAME + OA_OVERLAP + 8];                        /* tone detector / transient detector */
       struct { i16 pitch_buf[992 + 8]; i16 x_lp4[240 + 8]; i16 y_lp4[496 + 8]; union { i32 xcorr[488 + 8]; i32 yy_lookup[514 + 6]; } u; } p;
-      i32 fft[OA_MAX_FRAME];                                           /* N/4 complex points x blocks */
-      PvqScratch pvq;
-   } Cc;
+      i32 in[2][OA_MAX_FRAME];                                         /* comb-filtered new input (the 120-sample head is in_mem in HBM) */
+      i32 tf[2 * 800];                                                 /* tf_analysis trial buffers */
+      u8 coarse_save[OA_MAX_PACKET + 4];                               /* two-pass coarse energy rollback */
+      struct {
+         i32 norm[OA_NORM_LEN];
+         union { i32 norm2[OA_NORM_LEN]; struct { i32 X_save[176], Y_save[176], X_save2[176]; } r; } u;
+         PvqScratch pvq;
+      } q;
+   } BC;
 };
 #endif

@@ -7,19 +7,6 @@
 #ifndef OPUS_AMD_CELT_ENC_PITCH_H
 #define OPUS_AMD_CELT_ENC_PITCH_H
 
-/* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
- * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
- * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
-struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; };
-WV_DEV i32 pre_at(const PreSrc &p, int j)
-{
-   if (j < OA_MAX_PERIOD) return p.hist[j];
-   int i = j - OA_MAX_PERIOD;
-   i32 x = shl32((i32)p.pcm[p.CC * i + p.c], SIG_SHIFT);
-   i32 m = i == 0 ? p.mem0 : mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * (i - 1) + p.c], SIG_SHIFT));
-   return x - m;
-}
-
 WV_DEV i32 wave_inner16(const WV_LDS i16 *x, const WV_LDS i16 *y, int N)
 {
    i32 s = 0;
@@ -78,8 +65,8 @@ WV_DEV void celt_lpc4(i16 *_lpc, const i32 *ac)
 /* pitch_downsample (factor 2): pre[c] -> Cc.p.pitch_buf[len], len = (1024+N)>>1 */
 WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int len, int C)
 {
-   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->Cc.p.u.xcorr;       /* raw low-passed signal (kept for the final FIR) */
-   WV_LDS i16 *xx = L->Cc.p.pitch_buf;                    /* scaled copy for the autocorrelation, then the result */
+   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->BC.p.u.xcorr;       /* raw low-passed signal (kept for the final FIR) */
+   WV_LDS i16 *xx = L->BC.p.pitch_buf;                    /* scaled copy for the autocorrelation, then the result */
    i32 maxabs = 0;
    FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(pre_at(p0, i))); if (C == 2) maxabs = imax(maxabs, iabs(pre_at(p1, i))); }
    maxabs = wv_max(maxabs);
@@ -180,9 +167,9 @@ WV_DEV void find_best_pitch_l0(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int
 /* pitch_search (pitch.c:307); returns the pitch lag in every lane */
 WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
 {
-   const WV_LDS i16 *y = L->Cc.p.pitch_buf, *x_lp = L->Cc.p.pitch_buf + (OA_MAX_PERIOD >> 1);
-   WV_LDS i16 *x_lp4 = L->Cc.p.x_lp4, *y_lp4 = L->Cc.p.y_lp4;
-   WV_LDS i32 *xcorr = L->Cc.p.u.xcorr;
+   const WV_LDS i16 *y = L->BC.p.pitch_buf, *x_lp = L->BC.p.pitch_buf + (OA_MAX_PERIOD >> 1);
+   WV_LDS i16 *x_lp4 = L->BC.p.x_lp4, *y_lp4 = L->BC.p.y_lp4;
+   WV_LDS i32 *xcorr = L->BC.p.u.xcorr;
    const int lag = len + max_pitch;
    i32 xmax = 0, ymax = 0;
    FOR_LANES(j, len >> 2) { i16 v = x_lp[2 * j]; x_lp4[j] = v; xmax = imax(xmax, iabs((i32)v)); }
@@ -266,9 +253,9 @@ WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperio
    int T, T0, offset, minperiod0 = minperiod;
    i16 g, g0, pg;
    i32 xy, xx, yy, xy2, best_xy, best_yy;
-   WV_LDS i32 *yy_lookup = L->Cc.p.u.yy_lookup;
+   WV_LDS i32 *yy_lookup = L->BC.p.u.yy_lookup;
    maxperiod /= 2; minperiod /= 2; *T0_ /= 2; prev_period /= 2; N /= 2;
-   const WV_LDS i16 *x = L->Cc.p.pitch_buf + maxperiod;
+   const WV_LDS i16 *x = L->BC.p.pitch_buf + maxperiod;
    if (*T0_ >= maxperiod) *T0_ = maxperiod - 1;
    T = T0 = *T0_;
    wave_dual_inner16(x, x, x - T0, N, &xx, &xy);
@@ -366,9 +353,9 @@ WV_DEV void comb_filter_wave(WV_LDS i32 *y, const PreSrc &p, int T0, int T1, int
 #undef XA
 }
 
-/* run_prefilter (celt_encoder.c:1405).  B.in[c][overlap..) holds the new (unfiltered) input on entry, the filtered one on exit;
- * in_mem / prefilter_mem are read from and written back to the stream's HBM state here. */
-WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *mem0, int enabled)
+/* run_prefilter (celt_encoder.c:1405).  Writes the comb-filtered new input to BC.in[c][0..N) (its 120-sample head stays
+ * in_mem in HBM until the last MDCT of the frame has consumed it: store_in_mem_wave); rewrites prefilter_mem in HBM. */
+WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSrc &ps0, const PreSrc &ps1, int enabled)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -376,8 +363,6 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *
    const int prefilter_tapset = st->tapset_decision;
    int pitch_index, pf_on, qg;
    i16 gain1, pf_threshold;
-   PreSrc ps[2];
-   for (int c = 0; c < 2; c++) { ps[c].hist = gst->prefilter_mem + c * OA_MAX_PERIOD; ps[c].pcm = L->A.pcm16; ps[c].CC = CC; ps[c].c = c; ps[c].mem0 = mem0[c]; }
    i16 tone_freq = (i16)sh->tone_freq;
    if (enabled && sh->toneishness > QC32(.99f, 29)) {
       int multiple = 1;
@@ -387,7 +372,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *
       else pitch_index = OA_MIN_PERIOD;
       gain1 = QC16(.75f, 15);
    } else if (enabled && sh->complexity >= 5) {
-      pitch_downsample_wave(L, ps[0], ps[1], (max_period + N) >> 1, CC);
+      pitch_downsample_wave(L, ps0, ps1, (max_period + N) >> 1, CC);
       pitch_index = pitch_search_wave(L, N, max_period - 3 * min_period);
       pitch_index = max_period - pitch_index;
       gain1 = remove_doubling_wave(L, max_period, min_period, N, &pitch_index, st->prefilter_period, (i16)st->prefilter_gain);
@@ -419,21 +404,20 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *
    const int old_period = imax(st->prefilter_period, OA_MIN_PERIOD), old_tapset = st->prefilter_tapset;
    i32 before[2] = {0, 0}, after[2] = {0, 0};
    wv_sync();
-   /* in[c][0..overlap) <- in_mem: last frame's *filtered* tail (celt_encoder.c:1546) */
-   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) L->B.in[c][i] = gst->in_mem[c * overlap + i]; }
+   /* (the head in[c][0..overlap) is in_mem, last frame's *filtered* tail, celt_encoder.c:1546: it stays in HBM) */
    for (int c = 0; c < CC; c++) {
-      WV_LDS i32 *in = L->B.in[c];
+      const PreSrc &ps = c ? ps1 : ps0;
       i32 b = 0;
-      FOR_LANES(i, N) b += iabs(in[overlap + i] >> 12);
+      FOR_LANES(i, N) b += iabs(pre_at(ps, max_period + i) >> 12);
       before[c] = wv_sum(b);
    }
-   wv_sync();
+   wv_sync();                    /* the pitch buffers (aliased with in[]) are dead from here */
    for (int c = 0; c < CC; c++)
-      comb_filter_wave(L->B.in[c] + overlap, ps[c], old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
+      comb_filter_wave(L->BC.in[c], c ? ps1 : ps0, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
    wv_sync();
    for (int c = 0; c < CC; c++) {
       i32 a = 0;
-      FOR_LANES(i, N) a += iabs(L->B.in[c][overlap + i] >> 12);
+      FOR_LANES(i, N) a += iabs(L->BC.in[c][i] >> 12);
       after[c] = wv_sum(a);
    }
    int cancel_pitch = 0;
@@ -447,20 +431,21 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *
    if (cancel_pitch) {
       wv_sync();
       for (int c = 0; c < CC; c++) {
-         FOR_LANES(i, N) L->B.in[c][overlap + i] = pre_at(ps[c], max_period + i);
+         const PreSrc &ps = c ? ps1 : ps0;
+         FOR_LANES(i, N) L->BC.in[c][i] = pre_at(ps, max_period + i);
       }
       wv_sync();
       for (int c = 0; c < CC; c++)
-         comb_filter_wave(L->B.in[c] + overlap, ps[c], old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
+         comb_filter_wave(L->BC.in[c], c ? ps1 : ps0, old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
       gain1 = 0; pf_on = 0; qg = 0;
    }
    wv_sync();
-   /* persistent tails: filtered overlap -> in_mem; unfiltered [history | new][N .. N+1024) -> prefilter_mem.
+   /* persistent history: unfiltered [history | new][N .. N+1024) -> prefilter_mem.
     * Every lane first gathers its 16 values (the shift may overlap source and destination), then stores. */
    for (int c = 0; c < CC; c++) {
-      FOR_LANES(i, overlap) gst->in_mem[c * overlap + i] = L->B.in[c][N + i];
+      const PreSrc &ps = c ? ps1 : ps0;
       i32 keep[OA_MAX_PERIOD / WV_WIDTH];
-      for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) keep[t] = pre_at(ps[c], N + wv_lane() + t * WV_WIDTH);
+      for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) keep[t] = pre_at(ps, N + wv_lane() + t * WV_WIDTH);
       wv_sync();
       for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) gst->prefilter_mem[c * OA_MAX_PERIOD + wv_lane() + t * WV_WIDTH] = keep[t];
       wv_sync();
@@ -469,6 +454,15 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const i32 *
       st->prefilter_period = old_period;
       sh->pf_on = pf_on; sh->pitch_index = pitch_index; sh->gain1 = gain1; sh->qg = qg; sh->prefilter_tapset = prefilter_tapset;
    }
+   wv_sync();
+}
+
+/* in_mem <- the filtered tail in[c][N-overlap .. N) (celt_encoder.c:1556); called once the last MDCT of the frame has
+ * consumed the old head */
+WV_DEV void store_in_mem_wave(WV_LDS FrameLds *L, OaEncState *gst)
+{
+   const int CC = L->sh.CC, N = L->sh.N, overlap = OA_OVERLAP;
+   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) gst->in_mem[c * overlap + i] = L->BC.in[c][N - overlap + i]; }
    wv_sync();
 }
 #endif

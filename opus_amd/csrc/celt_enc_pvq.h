@@ -64,28 +64,39 @@ WV_DEV void haar1_wave(WV_LDS i32 *X, int N0, int stride)
    wv_sync();
 }
 WV_TABLE int k_ordery_table[30] = {1, 0, 3, 0, 2, 1, 7, 0, 4, 3, 6, 1, 5, 2, 15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10, 5};
-WV_DEV void deinterleave_hadamard_wave(WV_LDS i32 *X, WV_LDS i32 *tmp, int N0, int stride, int hadamard)
+/* (de)interleave_hadamard (bands.c:574/:600): a permutation of N0*stride <= 176 words, done in place through registers
+ * (every lane gathers its <= 3 elements, barrier, scatter) */
+WV_DEV void deinterleave_hadamard_wave(WV_LDS i32 *X, int N0, int stride, int hadamard)
 {
-   int N = N0 * stride;
-   FOR_LANES(p, N) {
-      int i = p / N0, j = p - i * N0;
-      int dst = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
-      tmp[dst] = X[j * stride + i];
+   const int N = N0 * stride;
+   i32 v[3]; int dst[3];
+   for (int t = 0; t < 3; t++) {
+      int p = wv_lane() + t * WV_WIDTH;
+      if (p < N) {
+         int i = p / N0, j = p - i * N0;
+         dst[t] = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
+         v[t] = X[j * stride + i];
+      }
    }
    wv_sync();
-   FOR_LANES(p, N) X[p] = tmp[p];
+   for (int t = 0; t < 3; t++) { int p = wv_lane() + t * WV_WIDTH; if (p < N) X[dst[t]] = v[t]; }
    wv_sync();
 }
-WV_DEV void interleave_hadamard_wave(WV_LDS i32 *X, WV_LDS i32 *tmp, int N0, int stride, int hadamard)
+WV_DEV void interleave_hadamard_wave(WV_LDS i32 *X, int N0, int stride, int hadamard)
 {
-   int N = N0 * stride;
-   FOR_LANES(p, N) {
-      int i = p / N0, j = p - i * N0;
-      int src = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
-      tmp[j * stride + i] = X[src];
+   const int N = N0 * stride;
+   i32 v[3]; int dst[3];
+   for (int t = 0; t < 3; t++) {
+      int p = wv_lane() + t * WV_WIDTH;
+      if (p < N) {
+         int i = p / N0, j = p - i * N0;
+         int src = hadamard ? k_ordery_table[stride - 2 + i] * N0 + j : i * N0 + j;
+         dst[t] = j * stride + i;
+         v[t] = X[src];
+      }
    }
    wv_sync();
-   FOR_LANES(p, N) X[p] = tmp[p];
+   for (int t = 0; t < 3; t++) { int p = wv_lane() + t * WV_WIDTH; if (p < N) X[dst[t]] = v[t]; }
    wv_sync();
 }
 WV_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)
@@ -252,7 +263,7 @@ WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K
  * every lane; iy[] (signed) is written to LDS once at the end. */
 WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
 {
-   WV_LDS i32 *iy = L->Cc.pvq.iy;
+   WV_LDS i32 *iy = L->BC.q.pvq.iy;
    const int lane = wv_lane();
    int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
    shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
@@ -324,7 +335,7 @@ WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
  * Suffix sums of |y| come from a wave scan; every table read is then independent (issued back to back). */
 WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
 {
-   const WV_LDS i32 *y = L->Cc.pvq.iy;
+   const WV_LDS i32 *y = L->BC.q.pvq.iy;
    const int lane = wv_lane(), j0 = 3 * lane;
    i32 yv[3], a[3], tot = 0;
    for (int t = 0; t < 3; t++) { int j = j0 + t; yv[t] = j < N ? y[j] : 0; a[t] = iabs(yv[t]); tot += a[t]; }
@@ -346,7 +357,7 @@ WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
 /* alg_quant (vq.c:552) */
 WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
 {
-   WV_LDS i32 *iy = L->Cc.pvq.iy;
+   WV_LDS i32 *iy = L->BC.q.pvq.iy;
    K_DUMP("pvqX", X, N * 4);
    K_TIC();
    exp_rotation_wave(X, N, 1, B, K, spread);
@@ -391,6 +402,7 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
 {
    int qn, itheta = 0, delta, imid, iside, qalloc, pulse_cap, offset, inv = 0;
    const int i = ctx->i, intensity = ctx->intensity;
+   K_TIC();
    pulse_cap = ct_logN[i] + LM * (1 << BITRES);
    offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
    qn = compute_qn(N, *b, offset, pulse_cap, stereo);
@@ -456,6 +468,7 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
       delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
    }
    K_DUMPI("itheta", itheta); K_DUMPI("qn", qn);
+   K_TOC(20);
    sctx->inv = inv; sctx->imid = imid; sctx->iside = iside; sctx->delta = delta; sctx->itheta = itheta; sctx->qalloc = qalloc;
 }
 
@@ -579,10 +592,10 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
    int N0 = N, N_B = N, N_B0, B0 = B, time_divide = 0, recombine = 0, longBlocks, k;
    unsigned cm = 0;
    int tf_change = ctx->tf_change;
-   WV_LDS i32 *hada = L->Cc.pvq.hada_tmp;
    longBlocks = B0 == 1;
    N_B = (u32)N_B / (u32)B;
    if (N == 1) return quant_band_n1_wave(L, ctx, X, 0, lowband_out);
+   K_TIC();
    if (tf_change > 0) recombine = tf_change;
    if (lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
       wv_sync();
@@ -609,12 +622,14 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
    B0 = B;
    N_B0 = N_B;
    if (B0 > 1) {
-      deinterleave_hadamard_wave(X, hada, N_B >> recombine, B0 << recombine, longBlocks);
-      if (lowband) deinterleave_hadamard_wave(lowband, hada, N_B >> recombine, B0 << recombine, longBlocks);
+      deinterleave_hadamard_wave(X, N_B >> recombine, B0 << recombine, longBlocks);
+      if (lowband) deinterleave_hadamard_wave(lowband, N_B >> recombine, B0 << recombine, longBlocks);
    }
+   K_TOC(22);
    cm = quant_partition_wave<0>(L, ctx, X, N, b, B, lowband, LM, gain, fill);
+   K_TOC(24);
    if (ctx->resynth) {
-      if (B0 > 1) interleave_hadamard_wave(X, hada, N_B >> recombine, B0 << recombine, longBlocks);
+      if (B0 > 1) interleave_hadamard_wave(X, N_B >> recombine, B0 << recombine, longBlocks);
       N_B = N_B0;
       B = B0;
       for (k = 0; k < time_divide; k++) {
@@ -636,6 +651,7 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
       }
       cm &= (1 << B) - 1;
    }
+   K_TOC(22);
    return cm;
 }
 
@@ -710,19 +726,22 @@ WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS
       }
    }
    if (ctx->resynth) {
+      K_TIC();
       if (N != 2) stereo_merge_wave(X, Y, mid, N);
       if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
+      K_TOC(23);
    }
    return cm;
 }
 
 WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int spread, int dual_stereo, int intensity, i32 total_bits, i32 balance,
-      int codedBands, int complexity, int disable_inv)
+      int codedBands, int complexity, int disable_inv, u8 *journal)
 {
    const int start = L->sh.start, end = L->sh.end, LM = L->sh.LM, C = L->sh.C, Nfull = L->sh.N;
    WV_LDS i32 *X_ = L->A.s.X, *Y_ = C == 2 ? L->A.s.X + Nfull : 0;
-   WV_LDS PvqScratch *P = &L->Cc.pvq;
-   WV_LDS i32 *norm = L->B.s.norm, *norm2 = L->B.s.norm + 800;
+   WV_LDS PvqScratch *P = &L->BC.q.pvq;
+   WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.u.norm2;     /* norm2 (dual stereo) aliases the theta-RDO slots: never both */
+   WV_LDS i32 *X_save = L->BC.q.u.r.X_save, *Y_save = L->BC.q.u.r.Y_save, *X_save2 = L->BC.q.u.r.X_save2;
    WV_LDS u8 *collapse_masks = L->collapse_masks;
    const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
    i32 remaining_bits;
@@ -792,41 +811,47 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                i16 w[2];
                compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
                cm = x_cm | y_cm;
+               K_TIC();
                wv_sync();
                LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
                ctx_save = ctx;
-               FOR_LANES(j, N) { P->X_save[j] = X[j]; P->Y_save[j] = Y[j]; }
+               FOR_LANES(j, N) { X_save[j] = X[j]; Y_save[j] = Y[j]; }
                wv_sync();
                ctx.theta_round = -1;
+               K_TOC(21);
                x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               K_TOC(24);
                wv_sync();
-               dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(P->X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(P->Y_save, Y, N));
+               dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
                cm2 = x_cm;
                LANE0 ec_cp_lds(&L->ecsave[1], &L->ec);
                ctx_save2 = ctx;
-               FOR_LANES(j, N) { P->X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
+               FOR_LANES(j, N) { X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
                const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
                WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
                const int save_bytes = nend_bytes - nstart_bytes;
-               FOR_LANES(j, save_bytes) L->B.s.bytes_save[j] = bytes_buf[j];
+               FOR_LANES(j, save_bytes) journal[j] = bytes_buf[j];         /* trial-1 byte journal -> per-stream HBM scratch */
                wv_sync();
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
                ctx = ctx_save;
-               FOR_LANES(j, N) { X[j] = P->X_save[j]; Y[j] = P->Y_save[j]; }
+               FOR_LANES(j, N) { X[j] = X_save[j]; Y[j] = Y_save[j]; }
                wv_sync();
                ctx.theta_round = 1;
+               K_TOC(21);
                x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               K_TOC(24);
                wv_sync();
-               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_w(P->X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(P->Y_save, Y, N));
+               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
                if (dist0 >= dist1) {
                   x_cm = cm2;
                   wv_sync();
                   LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
                   ctx = ctx_save2;
-                  FOR_LANES(j, N) { X[j] = P->X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
-                  FOR_LANES(j, save_bytes) bytes_buf[j] = L->B.s.bytes_save[j];
+                  FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
+                  FOR_LANES(j, save_bytes) bytes_buf[j] = journal[j];
                   wv_sync();
                }
+               K_TOC(21);
             } else {
                ctx.theta_round = 0;
                x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, x_cm | y_cm);

@@ -2,7 +2,7 @@
  * Arithmetic is the reference's fixed-point transform bit for bit: fold/window + pre-rotation
  * (celt/mdct.c:122-266), mixed-radix FFT with per-stage down-shifts (celt/kiss_fft.c:52-312, :538-611;
  * radix order 480:{4,2,4,3,5} 240:{4,4,3,5} 120:{4,2,3,5} 60:{4,3,5} as processed), post-rotation.
- * Mapping: one lane per butterfly; the N/4-point complex FFT lives in LDS (3,840 B for 480 points);
+ * Mapping: one lane per butterfly; the N/4-point complex FFT runs in place in the channel's output half;
  * for transient frames the 8 short transforms of a channel run side by side in the same buffer.
  * The butterfly network is order-fixed (per-stage shifts), only the butterflies *within* a stage run in
  * parallel, which is exact because they touch disjoint elements. */
@@ -141,10 +141,12 @@ WV_DEV void fft_forward(WV_LDS i32 *data, int idx, int nblk, WV_LDS int *remaini
    }
 }
 
-/* Forward MDCTs of one channel: B transforms of N2 = (960>>shift) output bins each, input block b starts at
- * in + b*N2 (N2+overlap samples), output bin k of block b goes to out[b + k*B] (interleaved, stride B).
- * fbuf: >= B*N2 words of LDS scratch (complex FFT storage), aux: >= 2*8 ints. */
-WV_DEV void mdct_forward_blocks(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int B, WV_LDS i32 *fbuf, WV_LDS int *aux)
+/* Forward MDCTs of one channel: B transforms of N2 = (960>>shift) output bins each.  The channel's time signal is
+ * [head | body]: the first `overlap` samples (last frame's filtered tail, in_mem) come from HBM, the rest from LDS;
+ * input block b starts at sample b*N2 (N2+overlap samples); output bin k of block b goes to out[b + k*B] (interleaved,
+ * stride B).  The complex FFT runs IN PLACE in out[] (B*N2 words); the post-rotation gathers every result into
+ * registers before the first scattered store.  aux: >= 2*8 ints. */
+WV_DEV void mdct_forward_blocks(const i32 *head, const WV_LDS i32 *body, WV_LDS i32 *out, int shift, int B, WV_LDS int *aux)
 {
    const int N = 1920 >> shift, N2 = N >> 1, N4 = N >> 2, overlap = OA_OVERLAP;
    const int trig_off = shift == 0 ? 0 : (shift == 1 ? 960 : (shift == 2 ? 1440 : 1680));
@@ -152,25 +154,27 @@ WV_DEV void mdct_forward_blocks(const WV_LDS i32 *in, WV_LDS i32 *out, int shift
    const int16_t *bitrev = ct_fft_bitrev + ct_fft_bitrev_off[shift];
    const int scale = ct_fft_misc[4 * shift + 1], scale_shift = ct_fft_misc[4 * shift + 2] - 1;
    WV_LDS int *headroom = aux, *remaining = aux + 8;
+   WV_LDS i32 *fbuf = out;
    const int lane = wv_lane();
+#define XIN(t) ((t) < overlap ? head[(t)] : body[(t) - overlap])
    for (int b = 0; b < B; b++) {
-      const WV_LDS i32 *x = in + b * N2;
+      const int x0 = b * N2;
       WV_LDS i32 *f2 = fbuf + 2 * b * N4;
       i32 maxval = 1;
       for (int i = lane; i < N4; i += WV_WIDTH) {
          i32 re, im;
-         const WV_LDS i32 *xp1 = x + (overlap >> 1) + 2 * i, *xp2 = x + N2 - 1 + (overlap >> 1) - 2 * i;
+         const int p1 = x0 + (overlap >> 1) + 2 * i, p2 = x0 + N2 - 1 + (overlap >> 1) - 2 * i;
          if (i < ((overlap + 3) >> 2)) {
             int w1 = ct_window[(overlap >> 1) + 2 * i], w2 = ct_window[(overlap >> 1) - 1 - 2 * i];
-            re = add32(SMUL(xp1[N2], w2), SMUL(*xp2, w1));
-            im = sub32(SMUL(*xp1, w1), SMUL(xp2[-N2], w2));
+            re = add32(SMUL(XIN(p1 + N2), w2), SMUL(XIN(p2), w1));
+            im = sub32(SMUL(XIN(p1), w1), SMUL(XIN(p2 - N2), w2));
          } else if (i < N4 - ((overlap + 3) >> 2)) {
-            re = *xp2; im = *xp1;
+            re = XIN(p2); im = XIN(p1);
          } else {
             int k = i - (N4 - ((overlap + 3) >> 2));
             int w1 = ct_window[2 * k], w2 = ct_window[overlap - 1 - 2 * k];
-            re = add32(neg32(SMUL(xp1[-N2], w1)), SMUL(*xp2, w2));
-            im = add32(SMUL(*xp1, w2), SMUL(xp2[N2], w1));
+            re = add32(neg32(SMUL(XIN(p1 - N2), w1)), SMUL(XIN(p2), w2));
+            im = add32(SMUL(XIN(p1), w2), SMUL(XIN(p2 + N2), w1));
          }
          int t0 = trig[i], t1 = trig[N4 + i];
          i32 yr = sub32(SMUL(re, t0), SMUL(im, t1));
@@ -184,17 +188,31 @@ WV_DEV void mdct_forward_blocks(const WV_LDS i32 *in, WV_LDS i32 *out, int shift
       int hr = imax(0, imin(scale_shift, 28 - celt_ilog2(maxval)));
       if (lane == 0) { headroom[b] = hr; remaining[b] = scale_shift - hr; }
    }
+#undef XIN
    wv_sync();
    fft_forward(fbuf, shift, B, remaining);
-   for (int w = lane; w < B * N4; w += WV_WIDTH) {
-      int b = w / N4, i = w - b * N4;
-      int hr = headroom[b], left = remaining[b];
-      cpx32 fp = c_ld(fbuf + 2 * b * N4, i, left);
-      int t0 = trig[i], t1 = trig[N4 + i];
-      i32 yr = pshr32(sub32(SMUL(fp.i, t1), SMUL(fp.r, t0)), hr);
-      i32 yi = pshr32(add32(SMUL(fp.r, t1), SMUL(fp.i, t0)), hr);
-      out[b + B * (2 * i)] = yr;
-      out[b + B * (N2 - 1 - 2 * i)] = yi;
+   {  /* post-rotation, in place: B*N4 <= 480 complex points -> at most 8 per lane held in registers across the barrier */
+      i32 vr[8], vi[8];
+      for (int t = 0; t < 8; t++) {
+         int w = lane + t * WV_WIDTH;
+         if (w < B * N4) {
+            int b = w / N4, i = w - b * N4;
+            int hr = headroom[b], left = remaining[b];
+            cpx32 fp = c_ld(fbuf + 2 * b * N4, i, left);
+            int t0 = trig[i], t1 = trig[N4 + i];
+            vr[t] = pshr32(sub32(SMUL(fp.i, t1), SMUL(fp.r, t0)), hr);
+            vi[t] = pshr32(add32(SMUL(fp.r, t1), SMUL(fp.i, t0)), hr);
+         }
+      }
+      wv_sync();
+      for (int t = 0; t < 8; t++) {
+         int w = lane + t * WV_WIDTH;
+         if (w < B * N4) {
+            int b = w / N4, i = w - b * N4;
+            out[b + B * (2 * i)] = vr[t];
+            out[b + B * (N2 - 1 - 2 * i)] = vi[t];
+         }
+      }
    }
    wv_sync();
 }

@@ -680,7 +680,6 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
       memcpy(in + c * (N + overlap), &prefilter_mem[(1 + c) * COMBFILTER_MAXPERIOD - overlap], overlap * sizeof(i32));
    }
    tone_freq = tone_detect(in, CC, N + overlap, &toneishness, Fs);
-   for (int c = 0; c < CC; c++) OC_DUMP("in_pre", in + c * (N + overlap), (N + overlap) * 4);
    OC_DUMPI("tone_freq", tone_freq); OC_DUMPI("toneishness", toneishness);
    if (st->complexity >= 1 && !st->lfe) {
       int allow_weak_transients = hybrid && effectiveBytes < 15 && st->silk_signalType != 2;
@@ -695,7 +694,6 @@ int oc_celt_encode_with_ec(oc_celt_enc *st, const i16 *pcm, int frame_size, u8 *
       pf_on = run_prefilter(st, in, prefilter_mem, CC, N, prefilter_tapset, &pitch_index, &gain1, &qg, enabled, st->complexity, tf_estimate,
             nbAvailableBytes, tone_freq, toneishness);
       OC_DUMPI("pf_on", pf_on); OC_DUMPI("pitch_index", pitch_index); OC_DUMPI("gain1", gain1); OC_DUMPI("qg", qg);
-      for (int c = 0; c < CC; c++) OC_DUMP("in_pf", in + c * (N + overlap), (N + overlap) * 4);
       if ((gain1 > QC16(.4f, 15) || st->prefilter_gain > QC16(.4f, 15))
             && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period))
          pitch_change = 1;
