@@ -186,204 +186,243 @@ WV_DEV i32 stereo_itheta_wave(const WV_LDS i32 *X, const WV_LDS i32 *Y, int ster
    return fx_atan2p_norm(side, mid);
 }
 
-/* exp_rotation (vq.c:104).  The down/up scaling is elementwise (done by the whole wave, once); each rotation pass
- * is a recurrence with rounding along a block -> one lane per block, the running element carried in a register so the
- * chain latency is ALU-only (the second operand is an independent, prefetchable LDS read). */
-WV_DEV void exp_rotation1_l(WV_LDS i32 *X, int len, int stride, i16 c, i16 s)
+/* ---- register-resident band vector: element e lives in register e>>6, lane e&63 (NR = 1 for N <= 64, else 3) ---- */
+template <int NR> WV_DEV i32 rv_get(const i32 (&v)[NR], int e)                 /* e uniform -> scalar result */
 {
-   i16 ms = (i16)(-s);
-   if (stride == 1) {
-      i32 x1 = X[0];
-      for (int i = 0; i < len - 1; i++) {
-         i32 x2 = X[i + 1];
-         i32 n2 = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
-         X[i] = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
-         x1 = n2;
-      }
-      X[len - 1] = x1;
-      /* backward pass: pairs (i, i+1) for i = len-3 .. 0; x2 of step i is the x1-result of step i+1 */
-      if (len >= 3) {
-         i32 x2 = X[len - 2];
-         for (int i = len - 3; i >= 0; i--) {
-            i32 x1b = X[i];
-            X[i + 1] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1b), 15));
-            x2 = extract16(pshr32(mac16_16(mult16_16(c, x1b), ms, x2), 15));
-         }
-         X[0] = x2;
-      }
-      return;
-   }
-   WV_LDS i32 *Xptr = X;
-   for (int i = 0; i < len - stride; i++) {
-      i32 x1 = Xptr[0], x2 = Xptr[stride];
-      Xptr[stride] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
-      *Xptr++ = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
-   }
-   Xptr = &X[len - 2 * stride - 1];
-   for (int i = len - 2 * stride - 1; i >= 0; i--) {
-      i32 x1 = Xptr[0], x2 = Xptr[stride];
-      Xptr[stride] = extract16(pshr32(mac16_16(mult16_16(c, x2), s, x1), 15));
-      *Xptr-- = extract16(pshr32(mac16_16(mult16_16(c, x1), ms, x2), 15));
+   if (NR == 1 || e < 64) return wv_bcast(v[0], e);
+   if (NR == 2 || e < 128) return wv_bcast(v[NR > 1 ? 1 : 0], e - 64);
+   return wv_bcast(v[NR > 2 ? 2 : 0], e - 128);
+}
+template <int NR> WV_DEV void rv_set(i32 (&v)[NR], int e, i32 val)            /* e, val uniform */
+{
+   if (NR == 1 || e < 64) v[0] = wv_writelane(val, e, v[0]);
+   else if (NR == 2 || e < 128) v[NR > 1 ? 1 : 0] = wv_writelane(val, e - 64, v[NR > 1 ? 1 : 0]);
+   else v[NR > 2 ? 2 : 0] = wv_writelane(val, e - 128, v[NR > 2 ? 2 : 0]);
+}
+template <int NR> WV_DEV void rv_shift_down(const i32 (&v)[NR], int d, i32 (&o)[NR])     /* o[e] = v[e + d], 0 < d < 64 */
+{
+   const int src = wv_lane() + d, wrap = src >= 64;
+   for (int t = 0; t < NR; t++) {
+      i32 a = wv_shfl(v[t], src & 63), b = t + 1 < NR ? wv_shfl(v[t + 1 < NR ? t + 1 : t], src & 63) : 0;
+      o[t] = wrap ? b : a;
    }
 }
-WV_DEV void exp_rotation_wave(WV_LDS i32 *X, int len, int dir, int stride, int K, int spread)
+template <int NR> WV_DEV void rv_shift_up(const i32 (&v)[NR], int d, i32 (&o)[NR])       /* o[e] = v[e - d], 0 < d < 64 */
+{
+   const int src = wv_lane() - d, wrap = src < 0;
+   for (int t = 0; t < NR; t++) {
+      i32 a = wv_shfl(v[t], src & 63), b = t > 0 ? wv_shfl(v[t > 0 ? t - 1 : 0], src & 63) : 0;
+      o[t] = wrap ? b : a;
+   }
+}
+
+/* exp_rotation1 (vq.c:75) on every block of the band at once.  Each pass is a recurrence with rounding, so the chain
+ * itself is serial -- but only the chain: the products with the not-yet-touched operand and all the "other" outputs are
+ * elementwise.  The chain runs on the SCALAR unit (v_readlane -> s_mul/s_add/s_ashr/s_sext -> v_writelane), one chain per
+ * (block, residue mod d), leaving the vector ALU to the other wave of the SIMD. */
+template <int NR> WV_DEV void rot_pass(i32 (&v)[NR], int nblk, int len, int d, i32 c_, i32 s_)
+{
+   const i32 c = (i16)c_, s = (i16)s_;
+   const int lane = wv_lane();
+   int pos[NR];
+   for (int t = 0; t < NR; t++) { int e = lane + 64 * t; pos[t] = nblk == 1 ? e : e - (int)((u32)e / (u32)len) * len; }
+   if (len - d > 0) {            /* forward: for i in [0, len-d): (X[i], X[i+d]) <- (c X[i] - s X[i+d], c X[i+d] + s X[i]) */
+      i32 xs[NR], A[NR], Bv[NR], cv[NR], nv[NR];
+      rv_shift_down(v, d, xs);
+      for (int t = 0; t < NR; t++) { A[t] = add32(mult16_16(c, xs[t]), 16384); Bv[t] = mult16_16(s, xs[t]); cv[t] = v[t]; nv[t] = v[t]; }
+      for (int blk = 0; blk < nblk; blk++) {
+         const int base = blk * len;
+         for (int r = 0; r < d && r < len - d; r++) {
+            i32 x1 = rv_get(v, base + r);
+            int i = r;
+            for (; i < len - d; i += d) {
+               rv_set(cv, base + i, x1);
+               x1 = (i32)(i16)(add32(rv_get(A, base + i), s * x1) >> 15);
+            }
+            rv_set(nv, base + i, x1);
+         }
+      }
+      for (int t = 0; t < NR; t++) {
+         i32 o = (i32)(i16)(add32(sub32(mult16_16(c, cv[t]), Bv[t]), 16384) >> 15);
+         v[t] = pos[t] < len - d ? o : nv[t];
+      }
+   }
+   if (len - 2 * d - 1 >= 0) {   /* backward: for i = len-2d-1 .. 0, same butterfly */
+      i32 Cv[NR], Sv[NR], yv[NR], hv[NR], o[NR], ou[NR];
+      for (int t = 0; t < NR; t++) { Cv[t] = add32(mult16_16(c, v[t]), 16384); Sv[t] = mult16_16(s, v[t]); yv[t] = 0; hv[t] = v[t]; }
+      const int top = len - 2 * d - 1;
+      for (int blk = 0; blk < nblk; blk++) {
+         const int base = blk * len;
+         for (int i0 = top; i0 > top - d && i0 >= 0; i0--) {
+            i32 y = rv_get(v, base + i0 + d);
+            int i = i0;
+            for (; i >= 0; i -= d) {
+               rv_set(yv, base + i, y);
+               y = (i32)(i16)(sub32(rv_get(Cv, base + i), s * y) >> 15);
+            }
+            rv_set(hv, base + i + d, y);
+         }
+      }
+      for (int t = 0; t < NR; t++) o[t] = (i32)(i16)(add32(add32(mult16_16(c, yv[t]), Sv[t]), 16384) >> 15);
+      rv_shift_up(o, d, ou);
+      for (int t = 0; t < NR; t++) v[t] = (pos[t] >= d && pos[t] <= len - d - 1) ? ou[t] : hv[t];
+   }
+}
+/* exp_rotation (vq.c:104) on the register-resident band */
+template <int NR> WV_DEV void exp_rotation_regs(i32 (&v)[NR], int len, int dir, int stride, int K, int spread)
 {
    int stride2 = 0;
    if (2 * K >= len || spread == 0) return;
    int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
    i16 gain = (i16)fx_div(mult16_16(Q15ONE, len), (i32)(len + factor * K));
    i16 theta = (i16)(mult16_16_q15(gain, gain) >> 1);
-   i16 c = fx_cos_norm(theta);
-   i16 s = fx_cos_norm(sub16(Q15ONE, theta));
+   i32 c = wv_uni(fx_cos_norm(theta));
+   i32 s = wv_uni(fx_cos_norm(sub16(Q15ONE, theta)));
    if (len >= 8 * stride) {
       stride2 = 1;
       while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
    }
-   const int total = len;
-   FOR_LANES(j, total) X[j] = pshr32(X[j], NORM_SHIFT - 14);      /* norm_scaledown once (up/down between passes cancels exactly) */
-   wv_sync();
+   for (int t = 0; t < NR; t++) v[t] = pshr32(v[t], NORM_SHIFT - 14);       /* norm_scaledown once (up/down between passes cancels exactly) */
    len = (u32)len / (u32)stride;
-   int i = wv_lane();
-   if (i < stride) {
-      if (dir < 0) {
-         if (stride2) exp_rotation1_l(X + i * len, len, stride2, s, c);
-         exp_rotation1_l(X + i * len, len, 1, c, s);
-      } else {
-         exp_rotation1_l(X + i * len, len, 1, c, (i16)-s);
-         if (stride2) exp_rotation1_l(X + i * len, len, stride2, s, (i16)-c);
-      }
+   if (dir < 0) {
+      if (stride2) rot_pass(v, stride, len, stride2, s, c);
+      rot_pass(v, stride, len, 1, c, s);
+   } else {
+      rot_pass(v, stride, len, 1, c, -s);
+      if (stride2) rot_pass(v, stride, len, stride2, s, -c);
    }
-   wv_sync();
-   FOR_LANES(j, total) X[j] = shl32(X[j], NORM_SHIFT - 14);
-   wv_sync();
+   for (int t = 0; t < NR; t++) v[t] = shl32(v[t], NORM_SHIFT - 14);
 }
 
-/* op_pvq_search (vq.c:205).  Each lane keeps its (up to three) coefficients |X|, 2*y and iy in registers; one
- * cross-lane arg-max per pulse on the DPP network; the winner's |X| and y are fetched with v_readlane.  Returns yy in
- * every lane; iy[] (signed) is written to LDS once at the end. */
-WV_DEVN i32 op_pvq_search_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int K, int N)
+/* op_pvq_search (vq.c:205) on the register-resident band: x[] in, signed pulse vector q[] out; returns yy.  One
+ * cross-lane arg-max per pulse on the DPP network; the winner's |X| and y are fetched with v_readlane. */
+template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int K, int N)
 {
-   WV_LDS i32 *iy = L->BC.q.pvq.iy;
    const int lane = wv_lane();
-   int shift = (celt_ilog2(1 + inner_prod_norm_shift_w(X, X, N)) + 1) / 2;
+   i64 e2 = 0;
+   for (int t = 0; t < NR; t++) e2 += x[t] * (i64)x[t];
+   int shift = (celt_ilog2(1 + (i32)(wv_sum64(e2) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
    shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
-   i32 x0 = 0, x1 = 0, x2 = 0, y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;
-   const bool v0 = lane < N, v1 = lane + 64 < N, v2 = lane + 128 < N;
-   if (v0) x0 = pshr32(X[lane], shift);
-   if (v1) x1 = pshr32(X[lane + 64], shift);
-   if (v2) x2 = pshr32(X[lane + 128], shift);
-   const i32 s0 = x0 < 0, s1 = x1 < 0, s2 = x2 < 0;
-   x0 = iabs(x0); x1 = iabs(x1); x2 = iabs(x2);
+   bool vld[NR]; i32 sg[NR], y[NR];
+   i32 xsum = 0;
+   for (int t = 0; t < NR; t++) {
+      vld[t] = lane + 64 * t < N;
+      i32 xv = vld[t] ? pshr32(x[t], shift) : 0;
+      sg[t] = xv < 0; x[t] = iabs(xv); y[t] = 0; q[t] = 0; xsum += x[t];
+   }
    i32 xy = 0; i16 yy = 0;
    int pulsesLeft = K;
    if (K > (N >> 1)) {
-      i32 sum = wv_sum(x0 + x1 + x2);
+      i32 sum = wv_sum(xsum);
       if (sum <= K) {
-         x0 = lane == 0 ? QC16(1.f, 14) : 0; x1 = 0; x2 = 0;
+         for (int t = 0; t < NR; t++) x[t] = 0;
+         if (lane == 0) x[0] = QC16(1.f, 14);
          sum = QC16(1.f, 14);
       }
       i16 rcp = extract16(mult16_32_q16(K, fx_rcp(sum)));
-      q0 = mult16_16_q15(x0, rcp); q1 = mult16_16_q15(x1, rcp); q2 = mult16_16_q15(x2, rcp);
-      i32 yyp = mac16_16(mac16_16(mult16_16(q0, q0), q1, q1), q2, q2);
-      i32 xyp = mac16_16(mac16_16(mult16_16(x0, q0), x1, q1), x2, q2);
-      y0 = 2 * q0; y1 = 2 * q1; y2 = 2 * q2;
+      i32 yyp = 0, xyp = 0, qs = 0;
+      for (int t = 0; t < NR; t++) {
+         q[t] = mult16_16_q15(x[t], rcp);
+         yyp = mac16_16(yyp, q[t], q[t]); xyp = mac16_16(xyp, x[t], q[t]); y[t] = 2 * q[t]; qs += q[t];
+      }
       yy = (i16)wv_sum(yyp);
       xy = wv_sum(xyp);
-      pulsesLeft -= wv_sum(q0 + q1 + q2);
+      pulsesLeft -= wv_sum(qs);
    }
    if (pulsesLeft > N + 3) {
       i16 tmp = (i16)pulsesLeft;
-      i32 yfirst = wv_bcast(y0, 0);
+      i32 yfirst = wv_bcast(y[0], 0);
       yy = (i16)mac16_16(yy, tmp, tmp);
       yy = (i16)mac16_16(yy, tmp, yfirst);
-      if (lane == 0) q0 += pulsesLeft;
+      if (lane == 0) q[0] += pulsesLeft;
       pulsesLeft = 0;
    }
    for (int i = 0; i < pulsesLeft; i++) {
       int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
       yy = add16(yy, 1);
       i32 best_num = -1, best_den = 1, best_id = 0x7fffffff;
-      if (v0) {
-         i16 Rxy = extract16(add32(xy, x0) >> rshift); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
-         best_den = add16(yy, y0); best_num = Rxy; best_id = lane;
-      }
-      if (v1) {
-         i16 Rxy = extract16(add32(xy, x1) >> rshift); i16 Ryy = add16(yy, y1); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
-         if (mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 64; }
-      }
-      if (v2) {
-         i16 Rxy = extract16(add32(xy, x2) >> rshift); i16 Ryy = add16(yy, y2); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
-         if (mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 128; }
+      for (int t = 0; t < NR; t++) {
+         if (vld[t]) {
+            i16 Rxy = extract16(add32(xy, x[t]) >> rshift); i16 Ryy = add16(yy, y[t]); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
+            if (t == 0 || mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 64 * t; }
+         }
       }
       wv_argmax_ratio(best_num, best_den, best_id);
       const int owner = best_id & 63, slot = best_id >> 6;
-      i32 xs = slot == 0 ? x0 : (slot == 1 ? x1 : x2), ys = slot == 0 ? y0 : (slot == 1 ? y1 : y2);
+      i32 xs = x[0], ys = y[0];
+      for (int t = 1; t < NR; t++) if (slot == t) { xs = x[t]; ys = y[t]; }
       xy = add32(xy, wv_bcast(xs, owner));
       yy = add16(yy, wv_bcast(ys, owner));
-      if (lane == owner) {
-         if (slot == 0) { y0 += 2; q0++; } else if (slot == 1) { y1 += 2; q1++; } else { y2 += 2; q2++; }
-      }
+      if (lane == owner) { for (int t = 0; t < NR; t++) if (slot == t) { y[t] += 2; q[t]++; } }
    }
-   if (v0) iy[lane] = (q0 ^ -s0) + s0;
-   if (v1) iy[lane + 64] = (q1 ^ -s1) + s1;
-   if (v2) iy[lane + 128] = (q2 ^ -s2) + s2;
-   wv_sync();
+   for (int t = 0; t < NR; t++) q[t] = (q[t] ^ -sg[t]) + sg[t];
    return yy;
 }
 
 /* encode_pulses (cwrs.c:444-465): index = (y[n-1]<0) + sum_j U(n-j, k_{j+1}) + [y_j<0] U(n-j, k_j+1), k_j = sum_{i>=j}|y_i|.
- * Suffix sums of |y| come from a wave scan; every table read is then independent (issued back to back). */
-WV_DEV void encode_pulses_wave(WV_LDS FrameLds *L, int N, int K)
+ * Suffix sums of |y| come from a wave scan per register; every table read is then independent (issued back to back). */
+template <int NR> WV_DEV void encode_pulses_regs(WV_LDS FrameLds *L, const i32 (&yv)[NR], int N, int K)
 {
-   const WV_LDS i32 *y = L->BC.q.pvq.iy;
-   const int lane = wv_lane(), j0 = 3 * lane;
-   i32 yv[3], a[3], tot = 0;
-   for (int t = 0; t < 3; t++) { int j = j0 + t; yv[t] = j < N ? y[j] : 0; a[t] = iabs(yv[t]); tot += a[t]; }
-   i32 incl = wv_scan_incl(tot);
-   i32 kafter[3];                         /* k_{j+1}: pulses strictly after element j */
-   kafter[2] = K - incl; kafter[1] = kafter[2] + a[2]; kafter[0] = kafter[1] + a[1];
+   const int lane = wv_lane();
+   i32 a[NR], incl[NR], tot[NR];
+   for (int t = 0; t < NR; t++) { a[t] = iabs(yv[t]); incl[t] = wv_scan_incl(a[t]); tot[t] = wv_bcast(incl[t], 63); }
    u32 idx = 0;
-   for (int t = 0; t < 3; t++) {
-      int j = j0 + t;
+   i32 above = 0;                           /* pulses in higher registers */
+   for (int t = NR - 1; t >= 0; t--) {
+      const int j = lane + 64 * t;
+      const i32 kafter = above + tot[t] - incl[t];      /* k_{j+1}: pulses strictly after element j */
       if (j < N - 1) {
-         idx += pvq_u(N - j, kafter[t]);
-         if (yv[t] < 0) idx += pvq_u(N - j, kafter[t] + a[t] + 1);
+         idx += pvq_u(N - j, kafter);
+         if (yv[t] < 0) idx += pvq_u(N - j, kafter + a[t] + 1);
       } else if (j == N - 1) idx += yv[t] < 0;
+      above += tot[t];
    }
    idx = wv_sumu(idx);
    LANE0 { EC_BEGIN; k_ec_enc_uint(EC_PASS, idx, pvq_u(N, K) + pvq_u(N, K + 1)); EC_END; }
 }
 
-/* alg_quant (vq.c:552) */
-WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
+/* alg_quant (vq.c:552): load the band once, rotate / search / index / resynthesise in registers, store once */
+template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
 {
-   WV_LDS i32 *iy = L->BC.q.pvq.iy;
+   const int lane = wv_lane();
+   i32 v[NR], q[NR];
    K_DUMP("pvqX", X, N * 4);
    K_TIC();
-   exp_rotation_wave(X, N, 1, B, K, spread);
+   for (int t = 0; t < NR; t++) v[t] = lane + 64 * t < N ? X[lane + 64 * t] : 0;
+   exp_rotation_regs(v, N, 1, B, K, spread);
    K_TOC(16);
-   i32 yy = op_pvq_search_wave(L, X, K, N);
+   i32 yy = op_pvq_search_regs(v, q, K, N);
    K_TOC(17);
    unsigned cm = 1;
    if (B > 1) {
       int N0 = (u32)N / (u32)B;
       u32 m = 0;
-      FOR_LANES(j, N) if (iy[j] != 0) m |= 1u << (j / N0);
+      for (int t = 0; t < NR; t++) if (q[t] != 0) m |= 1u << ((u32)(lane + 64 * t) / (u32)N0);
       cm = wv_or(m);
    }
-   K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K);
-   encode_pulses_wave(L, N, K);
+#ifdef K_DUMP_ENABLED
+   { WV_LDS i32 *iy = L->BC.q.pvq.iy; wv_sync(); for (int t = 0; t < NR; t++) if (lane + 64 * t < N) iy[lane + 64 * t] = q[t]; wv_sync(); K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K); }
+#endif
+   encode_pulses_regs(L, q, N, K);
    K_TOC(18);
    if (resynth) {
       int k = celt_ilog2(yy) >> 1;
-      i32 t = vshr32(yy, 2 * (k - 7) - 15);
-      i32 g = mult32_32_q31(fx_rsqrt_norm32(t), gain);
-      FOR_LANES(i, N) X[i] = vshr32(mult16_32_q15(iy[i], g), k + 15 - NORM_SHIFT);
+      i32 t_ = vshr32(yy, 2 * (k - 7) - 15);
+      i32 g = mult32_32_q31(fx_rsqrt_norm32(t_), gain);
+      for (int t = 0; t < NR; t++) v[t] = vshr32(mult16_32_q15(q[t], g), k + 15 - NORM_SHIFT);
+      exp_rotation_regs(v, N, -1, B, K, spread);
       wv_sync();
-      exp_rotation_wave(X, N, -1, B, K, spread);
+      for (int t = 0; t < NR; t++) if (lane + 64 * t < N) X[lane + 64 * t] = v[t];
+      wv_sync();
    }
    K_TOC(19);
    return cm;
+}
+WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
+{
+   N = wv_uni(N); K = wv_uni(K); spread = wv_uni(spread); B = wv_uni(B); gain = wv_uni(gain); resynth = wv_uni(resynth);
+   if (N <= 64) return alg_quant_regs<1>(L, X, N, K, spread, B, gain, resynth);
+   return alg_quant_regs<3>(L, X, N, K, spread, B, gain, resynth);
 }
 WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
 {

@@ -24,6 +24,16 @@ WV_DEV void wv_sync() { __syncthreads(); }
 WV_DEV int32_t wv_shfl(int32_t v, int src) { return __shfl(v, src, 64); }
 /* src must be wave-uniform */
 WV_DEV int32_t wv_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+/* v is the same in every lane: move it to a scalar register so that control flow and address math derived from it run
+ * on the scalar unit (arguments of non-inlined device functions arrive in VGPRs and would otherwise stay there) */
+WV_DEV int32_t wv_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+/* old with lane `lane` replaced by the (uniform) value val */
+WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
+{
+   /* no clang builtin for llvm.amdgcn.writelane in this toolchain; a VOP3 may read one SGPR only, so the lane select goes through M0 */
+   asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+   return old;
+}
 
 /* Wave-wide reductions on the DPP cross-lane network (no LDS round trips, unlike ds_bpermute shuffles):
  * quad_perm swaps -> row rotations (every lane of a 16-lane row holds the row result) -> row_bcast:15 / row_bcast:31

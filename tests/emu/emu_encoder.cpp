@@ -9,6 +9,7 @@ static dump_fn g_dump = nullptr;
 extern "C" void emu_set_dump(dump_fn f) { g_dump = f; }
 #define K_DUMP(tag, ptr, nbytes) do { if (g_dump && wv_lane() == 0) g_dump(tag, (const void *)(ptr), nbytes); } while (0)
 #define K_DUMPI(tag, v) do { int32_t v__ = (int32_t)(v); if (g_dump && wv_lane() == 0) g_dump(tag, &v__, 4); } while (0)
+#define K_DUMP_ENABLED 1
 #include "celt_enc_all.h"
 
 struct Job { FrameLds *L; OaStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int32_t *len; uint32_t *rng; };

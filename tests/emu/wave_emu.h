@@ -64,6 +64,8 @@ static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_
 }
 WV_DEV int32_t wv_shfl(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src & 63][0]; }
 WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
+WV_DEV int32_t wv_uni(int32_t v) { return v; }
+WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return emu_cur->cur == lane ? val : old; }
 WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
 WV_DEV uint32_t wv_sumu(uint32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return s; }
 WV_DEV int64_t wv_sum64(int64_t v) { auto t = emu_xchg(v); uint64_t s = 0; for (int i = 0; i < 64; i++) s += (uint64_t)t[i][0]; return (int64_t)s; }
