@@ -20,13 +20,7 @@
 #define K_TOC(bucket)
 #endif
 
-struct BandCtx {
-   int resynth, i, intensity, spread, tf_change;
-   i32 remaining_bits;
-   u32 seed;
-   int theta_round, disable_inv, avoid_split_noise;
-};
-struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
+struct BandCfg { int resynth, i, intensity, spread, tf_change, theta_round, disable_inv, avoid_split_noise; };
 
 
 WV_DEV u32 lcg_rand(u32 seed) { return 1664525u * seed + 1013904223u; }
@@ -436,35 +430,72 @@ WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
    wv_sync();
 }
 
-WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int *b, int B, int B0,
-      int LM, int stereo, int *fill)
+/* ---- band recursion ----------------------------------------------------------------------------------------------
+ * Everything the recursion carries is wave-uniform.  It travels BY VALUE (registers), never through pointers to private
+ * memory (that would be scratch = HBM-latency accesses on the critical path): BandCfg is the read-only part of the
+ * reference's band_ctx (bands.c:664), remaining_bits / seed are threaded through arguments and vector returns. */
+typedef i32 i32x4 __attribute__((vector_size(16)));
+typedef i32 i32x8 __attribute__((vector_size(32)));
+WV_DEV i32x4 ret3(unsigned cm, i32 rem, u32 seed) { i32x4 r = {(i32)cm, rem, (i32)seed, 0}; return r; }
+WV_DEV BandCfg cfg_uni(BandCfg c)
 {
+   c.resynth = wv_uni(c.resynth); c.i = wv_uni(c.i); c.intensity = wv_uni(c.intensity); c.spread = wv_uni(c.spread); c.tf_change = wv_uni(c.tf_change);
+   c.theta_round = wv_uni(c.theta_round); c.disable_inv = wv_uni(c.disable_inv); c.avoid_split_noise = wv_uni(c.avoid_split_noise);
+   return c;
+}
+
+/* one row of the pulse cache (rate.h:48-66 get_pulses/bits2pulses/pulses2bits): cache[0..40] for (LM, band) held one entry per
+ * lane, so the bisection and every later lookup are v_readlane's instead of dependent byte loads from memory */
+WV_DEV i32 cache_row_load(int band, int LM)
+{
+   const int off = ct_cache_index[(LM + 1) * OA_NB_EBANDS + band];
+   return (i32)ct_cache_bits[off + imin(wv_lane(), 40)];
+}
+WV_DEV int row_bits2pulses(i32 row, int bits)
+{
+   int lo = 0, hi = wv_bcast(row, 0);
+   bits--;
+   for (int i = 0; i < LOG_MAX_PSEUDO; i++) {
+      int mid = (lo + hi + 1) >> 1;
+      if (wv_bcast(row, mid) >= bits) hi = mid; else lo = mid;
+   }
+   if (bits - (lo == 0 ? -1 : wv_bcast(row, lo)) <= wv_bcast(row, hi) - bits) return lo;
+   return hi;
+}
+WV_DEV int row_pulses2bits(i32 row, int pulses) { return pulses == 0 ? 0 : wv_bcast(row, pulses) + 1; }
+
+/* compute_theta (bands.c:700).  Returns {inv, imid, iside, delta, itheta, qalloc, b, fill}. */
+WV_DEVN i32x8 compute_theta_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B, int B0,
+      int LM, int stereo, int fill)
+{
+   cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B); B0 = wv_uni(B0); LM = wv_uni(LM);
+   stereo = wv_uni(stereo); fill = wv_uni(fill);
    int qn, itheta = 0, delta, imid, iside, qalloc, pulse_cap, offset, inv = 0;
-   const int i = ctx->i, intensity = ctx->intensity;
+   const int i = cfg.i, intensity = cfg.intensity;
    K_TIC();
    pulse_cap = ct_logN[i] + LM * (1 << BITRES);
    offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
-   qn = compute_qn(N, *b, offset, pulse_cap, stereo);
+   qn = compute_qn(N, b, offset, pulse_cap, stereo);
    if (stereo && i >= intensity) qn = 1;
    itheta = stereo_itheta_wave(X, Y, stereo, N) >> 16;
    wv_sync();
    i32 tell = ec_tell_frac_lds(&L->ec);
    wv_sync();
    if (qn != 1) {
-      if (!stereo || ctx->theta_round == 0) {
+      if (!stereo || cfg.theta_round == 0) {
          itheta = (itheta * (i32)qn + 8192) >> 14;
-         if (!stereo && ctx->avoid_split_noise && itheta > 0 && itheta < qn) {
+         if (!stereo && cfg.avoid_split_noise && itheta > 0 && itheta < qn) {
             int unquantized = (u32)((i32)itheta * 16384) / (u32)qn;
             imid = bitexact_cos((i16)unquantized);
             iside = bitexact_cos((i16)(16384 - unquantized));
             delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
-            if (delta > *b) itheta = qn;
-            else if (delta < -*b) itheta = 0;
+            if (delta > b) itheta = qn;
+            else if (delta < -b) itheta = 0;
          }
       } else {
          int bias = itheta > 8192 ? 32767 / qn : -32767 / qn;
          int down = imin(qn - 1, imax(0, (itheta * (i32)qn + bias) >> 14));
-         itheta = ctx->theta_round < 0 ? down : down + 1;
+         itheta = cfg.theta_round < 0 ? down : down + 1;
       }
       LANE0 {
          EC_BEGIN;
@@ -487,20 +518,20 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
          else stereo_split_wave(X, Y, N);
       }
    } else if (stereo) {
-      inv = itheta > 8192 && !ctx->disable_inv;
+      inv = itheta > 8192 && !cfg.disable_inv;
       if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
       intensity_stereo_wave(L, X, Y, i, N);
-      if (*b > 2 << BITRES && ctx->remaining_bits > 2 << BITRES) {
+      if (b > 2 << BITRES && remaining_bits > 2 << BITRES) {
          LANE0 { EC_BEGIN; k_ec_enc_bit_logp(EC_PASS, inv, 2); EC_END; }
       } else inv = 0;
-      if (ctx->disable_inv) inv = 0;
+      if (cfg.disable_inv) inv = 0;
       itheta = 0;
    }
    wv_sync();
    qalloc = ec_tell_frac_lds(&L->ec) - tell;
-   *b -= qalloc;
-   if (itheta == 0) { imid = 32767; iside = 0; *fill &= (1 << B) - 1; delta = -16384; }
-   else if (itheta == 16384) { imid = 0; iside = 32767; *fill &= ((1 << B) - 1) << B; delta = 16384; }
+   b -= qalloc;
+   if (itheta == 0) { imid = 32767; iside = 0; fill &= (1 << B) - 1; delta = -16384; }
+   else if (itheta == 16384) { imid = 0; iside = 32767; fill &= ((1 << B) - 1) << B; delta = 16384; }
    else {
       imid = bitexact_cos((i16)itheta);
       iside = bitexact_cos((i16)(16384 - itheta));
@@ -508,22 +539,23 @@ WV_DEVN void compute_theta_wave(WV_LDS FrameLds *L, BandCtx *ctx, SplitCtx *sctx
    }
    K_DUMPI("itheta", itheta); K_DUMPI("qn", qn);
    K_TOC(20);
-   sctx->inv = inv; sctx->imid = imid; sctx->iside = iside; sctx->delta = delta; sctx->itheta = itheta; sctx->qalloc = qalloc;
+   i32x8 r = {inv, imid, iside, delta, itheta, qalloc, b, fill};
+   return r;
 }
 
-WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, WV_LDS i32 *Y, WV_LDS i32 *lowband_out)
+WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, const BandCfg &cfg, i32 &remaining_bits, WV_LDS i32 *X, WV_LDS i32 *Y, WV_LDS i32 *lowband_out)
 {
    WV_LDS i32 *x = X;
    int stereo = Y != 0;
    wv_sync();
    for (int c = 0; c < 1 + stereo; c++) {
       int sign = 0;
-      if (ctx->remaining_bits >= 1 << BITRES) {
+      if (remaining_bits >= 1 << BITRES) {
          sign = x[0] < 0;
          LANE0 { EC_BEGIN; k_ec_enc_bits(EC_PASS, sign, 1); EC_END; }
-         ctx->remaining_bits -= 1 << BITRES;
+         remaining_bits -= 1 << BITRES;
       }
-      if (ctx->resynth) { wv_sync(); LANE0 x[0] = sign ? -(1 << NORM_SHIFT) : (1 << NORM_SHIFT); wv_sync(); }
+      if (cfg.resynth) { wv_sync(); LANE0 x[0] = sign ? -(1 << NORM_SHIFT) : (1 << NORM_SHIFT); wv_sync(); }
       x = Y;
    }
    wv_sync();
@@ -532,18 +564,21 @@ WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 
    return 1;
 }
 
+/* quant_partition (bands.c:973).  Returns {collapse mask, remaining_bits, seed}. */
 template <int DEPTH>
-WV_DEVN unsigned quant_partition_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM, i32 gain, int fill)
+WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, i32 gain, int fill)
 {
+   cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
+   LM = wv_uni(LM); gain = wv_uni(gain); fill = wv_uni(fill);
    int B0 = B;
-   const int i = ctx->i, spread = ctx->spread;
+   const int i = cfg.i, spread = cfg.spread;
    unsigned cm = 0;
-   const u8 *cache = ct_cache_bits + ct_cache_index[(LM + 1) * NBE + i];
-   bool split = LM != -1 && b > cache[cache[0]] + 12 && N > 2;
+   const i32 row = cache_row_load(i, LM);
+   bool split = LM != -1 && b > wv_bcast(row, wv_bcast(row, 0)) + 12 && N > 2;
    if constexpr (DEPTH < 4) {
       if (split) {
          int mbits, sbits, delta, itheta, qalloc;
-         SplitCtx sctx;
          WV_LDS i32 *next_lowband2 = 0, *Y;
          i32 rebalance, mid, side;
          N >>= 1;
@@ -551,53 +586,57 @@ WV_DEVN unsigned quant_partition_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i
          LM -= 1;
          if (B == 1) fill = (fill & 1) | (fill << 1);
          B = (B + 1) >> 1;
-         compute_theta_wave(L, ctx, &sctx, X, Y, N, &b, B, B0, LM, 0, &fill);
-         delta = sctx.delta; itheta = sctx.itheta; qalloc = sctx.qalloc;
-         mid = shl32((i32)sctx.imid, 16);
-         side = shl32((i32)sctx.iside, 16);
+         const i32x8 th = compute_theta_wave(L, cfg, remaining_bits, X, Y, N, b, B, B0, LM, 0, fill);
+         delta = wv_uni(th[3]); itheta = wv_uni(th[4]); qalloc = wv_uni(th[5]); b = wv_uni(th[6]); fill = wv_uni(th[7]);
+         mid = shl32((i32)wv_uni(th[1]), 16);
+         side = shl32((i32)wv_uni(th[2]), 16);
          if (B0 > 1 && (itheta & 0x3fff)) {
             if (itheta > 8192) delta -= delta >> (4 - LM);
             else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
          }
          mbits = imax(0, imin(b, (b - delta) / 2));
          sbits = b - mbits;
-         ctx->remaining_bits -= qalloc;
+         remaining_bits -= qalloc;
          if (lowband) next_lowband2 = lowband + N;
-         rebalance = ctx->remaining_bits;
+         rebalance = remaining_bits;
+         i32x4 r;
          if (mbits >= sbits) {
-            cm = quant_partition_wave<DEPTH + 1>(L, ctx, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
-            rebalance = mbits - (rebalance - ctx->remaining_bits);
+            r = quant_partition_wave<DEPTH + 1>(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
+            cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+            rebalance = mbits - (rebalance - remaining_bits);
             if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            cm |= quant_partition_wave<DEPTH + 1>(L, ctx, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B) << (B0 >> 1);
+            r = quant_partition_wave<DEPTH + 1>(L, cfg, remaining_bits, seed, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B);
+            cm |= (unsigned)wv_uni(r[0]) << (B0 >> 1); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
          } else {
-            cm = quant_partition_wave<DEPTH + 1>(L, ctx, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B) << (B0 >> 1);
-            rebalance = sbits - (rebalance - ctx->remaining_bits);
+            r = quant_partition_wave<DEPTH + 1>(L, cfg, remaining_bits, seed, Y, N, sbits, B, next_lowband2, LM, mult32_32_q31(gain, side), fill >> B);
+            cm = (unsigned)wv_uni(r[0]) << (B0 >> 1); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+            rebalance = sbits - (rebalance - remaining_bits);
             if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-            cm |= quant_partition_wave<DEPTH + 1>(L, ctx, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
+            r = quant_partition_wave<DEPTH + 1>(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, mult32_32_q31(gain, mid), fill);
+            cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
          }
-         return cm;
+         return ret3(cm, remaining_bits, seed);
       }
    }
    {
-      int q = k_bits2pulses(i, LM, b);
-      int curr_bits = k_pulses2bits(i, LM, q);
-      ctx->remaining_bits -= curr_bits;
-      while (ctx->remaining_bits < 0 && q > 0) {
-         ctx->remaining_bits += curr_bits;
+      int q = row_bits2pulses(row, b);
+      int curr_bits = row_pulses2bits(row, q);
+      remaining_bits -= curr_bits;
+      while (remaining_bits < 0 && q > 0) {
+         remaining_bits += curr_bits;
          q--;
-         curr_bits = k_pulses2bits(i, LM, q);
-         ctx->remaining_bits -= curr_bits;
+         curr_bits = row_pulses2bits(row, q);
+         remaining_bits -= curr_bits;
       }
       if (q != 0) {
          int K = k_get_pulses(q);
-         cm = alg_quant_wave(L, X, N, K, spread, B, gain, ctx->resynth);
-      } else if (ctx->resynth) {
+         cm = alg_quant_wave(L, X, N, K, spread, B, gain, cfg.resynth);
+      } else if (cfg.resynth) {
          unsigned cm_mask = (unsigned)(1UL << B) - 1;
          fill &= cm_mask;
          if (!fill) { FOR_LANES(j, N) X[j] = 0; wv_sync(); }
          else {
             wv_sync();
-            u32 seed = ctx->seed;
             if (lowband == 0) {
                LANE0 { u32 s = seed; for (int j = 0; j < N; j++) { s = lcg_rand(s); X[j] = shl32((i32)((i32)s >> 20), NORM_SHIFT - 14); } }
                cm = cm_mask;
@@ -613,27 +652,29 @@ WV_DEVN unsigned quant_partition_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i
                }
                cm = fill;
             }
-            for (int j = 0; j < N; j++) seed = lcg_rand(seed);      /* every lane advances its private copy identically */
-            ctx->seed = seed;
+            for (int j = 0; j < N; j++) seed = lcg_rand(seed);      /* uniform: the same N steps the lane-0 loop took */
             wv_sync();
             renormalise_vector_wave(X, N, gain);
          }
       }
    }
-   return cm;
+   return ret3(cm, remaining_bits, seed);
 }
 
-WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
+/* quant_band (bands.c:1248).  Returns {collapse mask, remaining_bits, seed}. */
+WV_DEVN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
       WV_LDS i32 *lowband_out, i32 gain, WV_LDS i32 *lowband_scratch, int fill)
 {
+   cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
+   LM = wv_uni(LM); gain = wv_uni(gain); fill = wv_uni(fill);
    const u8 bit_interleave_table[16] = {0, 1, 1, 1, 2, 3, 3, 3, 2, 3, 3, 3, 2, 3, 3, 3};
    const u8 bit_deinterleave_table[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F, 0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
    int N0 = N, N_B = N, N_B0, B0 = B, time_divide = 0, recombine = 0, longBlocks, k;
    unsigned cm = 0;
-   int tf_change = ctx->tf_change;
+   int tf_change = cfg.tf_change;
    longBlocks = B0 == 1;
    N_B = (u32)N_B / (u32)B;
-   if (N == 1) return quant_band_n1_wave(L, ctx, X, 0, lowband_out);
+   if (N == 1) { cm = quant_band_n1_wave(L, cfg, remaining_bits, X, 0, lowband_out); return ret3(cm, remaining_bits, seed); }
    K_TIC();
    if (tf_change > 0) recombine = tf_change;
    if (lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
@@ -665,9 +706,12 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
       if (lowband) deinterleave_hadamard_wave(lowband, N_B >> recombine, B0 << recombine, longBlocks);
    }
    K_TOC(22);
-   cm = quant_partition_wave<0>(L, ctx, X, N, b, B, lowband, LM, gain, fill);
+   {
+      const i32x4 r = quant_partition_wave<0>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
+      cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+   }
    K_TOC(24);
-   if (ctx->resynth) {
+   if (cfg.resynth) {
       if (B0 > 1) interleave_hadamard_wave(X, N_B >> recombine, B0 << recombine, longBlocks);
       N_B = N_B0;
       B = B0;
@@ -691,28 +735,33 @@ WV_DEVN unsigned quant_band_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X
       cm &= (1 << B) - 1;
    }
    K_TOC(22);
-   return cm;
+   return ret3(cm, remaining_bits, seed);
 }
 
-WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B, WV_LDS i32 *lowband,
-      int LM, WV_LDS i32 *lowband_out, WV_LDS i32 *lowband_scratch, int fill)
+/* quant_band_stereo (bands.c:1387).  Returns {collapse mask, remaining_bits, seed}. */
+WV_DEVN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B,
+      WV_LDS i32 *lowband, int LM, WV_LDS i32 *lowband_out, WV_LDS i32 *lowband_scratch, int fill)
 {
+   cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
+   LM = wv_uni(LM); fill = wv_uni(fill);
    int inv = 0, mbits, sbits, delta, itheta, qalloc, orig_fill;
    i32 mid = 0, side = 0;
    unsigned cm = 0;
-   SplitCtx sctx;
-   if (N == 1) return quant_band_n1_wave(L, ctx, X, Y, lowband_out);
+   i32x4 r;
+   if (N == 1) { cm = quant_band_n1_wave(L, cfg, remaining_bits, X, Y, lowband_out); return ret3(cm, remaining_bits, seed); }
    orig_fill = fill;
-   if (L->bandE[ctx->i] < 2 || L->bandE[NBE + ctx->i] < 2) {
+   if (L->bandE[cfg.i] < 2 || L->bandE[NBE + cfg.i] < 2) {
       wv_sync();
-      if (L->bandE[ctx->i] > L->bandE[NBE + ctx->i]) { FOR_LANES(j, N) Y[j] = X[j]; }
+      if (L->bandE[cfg.i] > L->bandE[NBE + cfg.i]) { FOR_LANES(j, N) Y[j] = X[j]; }
       else { FOR_LANES(j, N) X[j] = Y[j]; }
       wv_sync();
    }
-   compute_theta_wave(L, ctx, &sctx, X, Y, N, &b, B, B, LM, 1, &fill);
-   inv = sctx.inv; delta = sctx.delta; itheta = sctx.itheta; qalloc = sctx.qalloc;
-   mid = shl32((i32)sctx.imid, 16);
-   side = shl32((i32)sctx.iside, 16);
+   {
+      const i32x8 th = compute_theta_wave(L, cfg, remaining_bits, X, Y, N, b, B, B, LM, 1, fill);
+      inv = wv_uni(th[0]); delta = wv_uni(th[3]); itheta = wv_uni(th[4]); qalloc = wv_uni(th[5]); b = wv_uni(th[6]); fill = wv_uni(th[7]);
+      mid = shl32((i32)wv_uni(th[1]), 16);
+      side = shl32((i32)wv_uni(th[2]), 16);
+   }
    if (N == 2) {
       int c, sign = 0;
       WV_LDS i32 *x2, *y2;
@@ -721,7 +770,7 @@ WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS
       if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
       mbits -= sbits;
       c = itheta > 8192;
-      ctx->remaining_bits -= qalloc + sbits;
+      remaining_bits -= qalloc + sbits;
       x2 = c ? Y : X;
       y2 = c ? X : Y;
       wv_sync();
@@ -730,11 +779,12 @@ WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS
          LANE0 { EC_BEGIN; k_ec_enc_bits(EC_PASS, sign, 1); EC_END; }
       }
       sign = 1 - 2 * sign;
-      cm = quant_band_wave(L, ctx, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);
+      r = quant_band_wave(L, cfg, remaining_bits, seed, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);
+      cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       wv_sync();
       LANE0 { y2[0] = -sign * x2[1]; y2[1] = sign * x2[0]; }
       wv_sync();
-      if (ctx->resynth) {
+      if (cfg.resynth) {
          LANE0 {
             i32 tmp;
             X[0] = mult32_32_q31(mid, X[0]);
@@ -750,33 +800,40 @@ WV_DEVN unsigned quant_band_stereo_wave(WV_LDS FrameLds *L, BandCtx *ctx, WV_LDS
       i32 rebalance;
       mbits = imax(0, imin(b, (b - delta) / 2));
       sbits = b - mbits;
-      ctx->remaining_bits -= qalloc;
-      rebalance = ctx->remaining_bits;
+      remaining_bits -= qalloc;
+      rebalance = remaining_bits;
       if (mbits >= sbits) {
-         cm = quant_band_wave(L, ctx, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
-         rebalance = mbits - (rebalance - ctx->remaining_bits);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
+         cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+         rebalance = mbits - (rebalance - remaining_bits);
          if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-         cm |= quant_band_wave(L, ctx, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
+         cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       } else {
-         cm = quant_band_wave(L, ctx, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
-         rebalance = sbits - (rebalance - ctx->remaining_bits);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
+         cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+         rebalance = sbits - (rebalance - remaining_bits);
          if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-         cm |= quant_band_wave(L, ctx, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
+         cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       }
    }
-   if (ctx->resynth) {
+   if (cfg.resynth) {
       K_TIC();
       if (N != 2) stereo_merge_wave(X, Y, mid, N);
       if (inv) { FOR_LANES(j, N) Y[j] = neg32(Y[j]); wv_sync(); }
       K_TOC(23);
    }
-   return cm;
+   return ret3(cm, remaining_bits, seed);
 }
 
+/* quant_all_bands (bands.c:1589), encoder side */
 WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int spread, int dual_stereo, int intensity, i32 total_bits, i32 balance,
       int codedBands, int complexity, int disable_inv, u8 *journal)
 {
-   const int start = L->sh.start, end = L->sh.end, LM = L->sh.LM, C = L->sh.C, Nfull = L->sh.N;
+   shortBlocks = wv_uni(shortBlocks); spread = wv_uni(spread); dual_stereo = wv_uni(dual_stereo); intensity = wv_uni(intensity); total_bits = wv_uni(total_bits);
+   balance = wv_uni(balance); codedBands = wv_uni(codedBands); complexity = wv_uni(complexity); disable_inv = wv_uni(disable_inv);
+   const int start = wv_uni(L->sh.start), end = wv_uni(L->sh.end), LM = wv_uni(L->sh.LM), C = wv_uni(L->sh.C), Nfull = wv_uni(L->sh.N);
    WV_LDS i32 *X_ = L->A.s.X, *Y_ = C == 2 ? L->A.s.X + Nfull : 0;
    WV_LDS PvqScratch *P = &L->BC.q.pvq;
    WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.u.norm2;     /* norm2 (dual stereo) aliases the theta-RDO slots: never both */
@@ -789,32 +846,33 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
    int theta_rdo = Y_ != 0 && !dual_stereo && complexity >= 8;
    int resynth = theta_rdo;
    WV_LDS i32 *lowband_scratch = P->lowband_scratch;
-   BandCtx ctx;
-   ctx.intensity = intensity; ctx.seed = L->st.rng; ctx.spread = spread; ctx.disable_inv = disable_inv; ctx.resynth = resynth;
-   ctx.theta_round = 0; ctx.avoid_split_noise = B > 1; ctx.i = 0; ctx.tf_change = 0; ctx.remaining_bits = 0;
+   BandCfg cfg;
+   u32 seed = (u32)wv_uni((i32)L->st.rng);
+   i32x4 r;
+   cfg.intensity = intensity; cfg.spread = spread; cfg.disable_inv = disable_inv; cfg.resynth = resynth;
+   cfg.theta_round = 0; cfg.avoid_split_noise = B > 1; cfg.i = 0; cfg.tf_change = 0;
    for (int i = start; i < end; i++) {
       i32 tell, curr_balance;
       int b, N, effective_lowband = -1, tf_change = 0, last;
       WV_LDS i32 *X, *Y;
       unsigned x_cm, y_cm;
-      ctx.i = i;
+      cfg.i = i;
       last = (i == end - 1);
       X = X_ + M * ct_eBands[i];
       Y = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
       N = M * ct_eBands[i + 1] - M * ct_eBands[i];
       wv_sync();
-      tell = ec_tell_frac_lds(&L->ec);
+      tell = wv_uni(ec_tell_frac_lds(&L->ec));
       if (i != start) balance -= tell;
       remaining_bits = total_bits - tell - 1;
-      ctx.remaining_bits = remaining_bits;
       if (i <= codedBands - 1) {
          curr_balance = balance / imin(3, codedBands - i);
-         b = imax(0, imin(16383, imin(remaining_bits + 1, pulses[i] + curr_balance)));
+         b = imax(0, imin(16383, imin(remaining_bits + 1, wv_uni(pulses[i]) + curr_balance)));
       } else b = 0;
       if (resynth && (M * ct_eBands[i] - N >= M * ct_eBands[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
          lowband_offset = i;
-      tf_change = tf_res[i];
-      ctx.tf_change = tf_change;
+      tf_change = wv_uni(tf_res[i]);
+      cfg.tf_change = tf_change;
       if (last && !theta_rdo) lowband_scratch = 0;
       if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
          int fold_start, fold_end, fold_i;
@@ -829,6 +887,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
             x_cm |= collapse_masks[fold_i * C + 0];
             y_cm |= collapse_masks[fold_i * C + C - 1];
          } while (++fold_i < fold_end);
+         x_cm = (unsigned)wv_uni((i32)x_cm); y_cm = (unsigned)wv_uni((i32)y_cm);
       } else x_cm = y_cm = (1 << B) - 1;
       if (dual_stereo && i == intensity) {
          dual_stereo = 0;
@@ -839,13 +898,15 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       WV_LDS i32 *lbo = last ? 0 : norm + M * ct_eBands[i] - norm_offset;
       WV_LDS i32 *lbo2 = last ? 0 : norm2 + M * ct_eBands[i] - norm_offset;
       if (dual_stereo) {
-         x_cm = quant_band_wave(L, &ctx, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
-         y_cm = quant_band_wave(L, &ctx, Y, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
+         x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
+         y_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       } else {
          if (Y != 0) {
             if (theta_rdo && i < intensity) {
-               BandCtx ctx_save, ctx_save2;
-               i32 dist0, dist1;
+               i32 dist0, dist1, rem1;
+               u32 seed1;
                unsigned cm, cm2;
                i16 w[2];
                compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
@@ -853,18 +914,16 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                K_TIC();
                wv_sync();
                LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
-               ctx_save = ctx;
                FOR_LANES(j, N) { X_save[j] = X[j]; Y_save[j] = Y[j]; }
                wv_sync();
-               ctx.theta_round = -1;
+               cfg.theta_round = -1;
                K_TOC(21);
-               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               cm2 = (unsigned)wv_uni(r[0]); rem1 = wv_uni(r[1]); seed1 = (u32)wv_uni(r[2]);
                K_TOC(24);
                wv_sync();
                dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
-               cm2 = x_cm;
                LANE0 ec_cp_lds(&L->ecsave[1], &L->ec);
-               ctx_save2 = ctx;
                FOR_LANES(j, N) { X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
                const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
                WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
@@ -872,42 +931,43 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                FOR_LANES(j, save_bytes) journal[j] = bytes_buf[j];         /* trial-1 byte journal -> per-stream HBM scratch */
                wv_sync();
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
-               ctx = ctx_save;
                FOR_LANES(j, N) { X[j] = X_save[j]; Y[j] = Y_save[j]; }
                wv_sync();
-               ctx.theta_round = 1;
+               cfg.theta_round = 1;
                K_TOC(21);
-               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
+               x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
                K_TOC(24);
                wv_sync();
                dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
                if (dist0 >= dist1) {
-                  x_cm = cm2;
+                  x_cm = cm2; remaining_bits = rem1; seed = seed1;
                   wv_sync();
                   LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
-                  ctx = ctx_save2;
                   FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
                   FOR_LANES(j, save_bytes) bytes_buf[j] = journal[j];
                   wv_sync();
                }
                K_TOC(21);
             } else {
-               ctx.theta_round = 0;
-               x_cm = quant_band_stereo_wave(L, &ctx, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, x_cm | y_cm);
+               cfg.theta_round = 0;
+               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, x_cm | y_cm);
+               x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
             }
          } else {
-            x_cm = quant_band_wave(L, &ctx, X, N, b, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm | y_cm);
+            r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm | y_cm);
+            x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
          }
          y_cm = x_cm;
       }
       wv_sync();
       LANE0 { collapse_masks[i * C + 0] = (u8)x_cm; collapse_masks[i * C + C - 1] = (u8)y_cm; }
-      balance += pulses[i] + tell;
+      balance += wv_uni(pulses[i]) + tell;
       update_lowband = b > (N << BITRES);
-      ctx.avoid_split_noise = 0;
+      cfg.avoid_split_noise = 0;
    }
    wv_sync();
-   LANE0 L->st.rng = ctx.seed;
+   LANE0 L->st.rng = seed;
    wv_sync();
 }
 #endif
