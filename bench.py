@@ -132,6 +132,12 @@ def main():
         state_bytes = ctypes.CDLL(opus_amd.LIB_PATH).opusgpu_enc_state_size()
         alg_bytes = S * (FR * CH * 2 + mean_len + 4 + 4 + 2 * state_bytes)       # per launch: PCM in + packet/len/range out + state in and out
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 calibration + WRITE_SIZE), scaled to this launch
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = int(pt["hbm_bytes_per_frame"] * S)
+        except Exception:
+            pass
         res = {
             "metric": "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -139,7 +145,7 @@ def main():
             "config": {"workload": "CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10, bit-exact fixed-point",
                        "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok,
                        "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather in timed region" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                          "kernel": "oa_encode_kernel", "kernel_ms": round(kern_ms, 3), "algorithmic_bytes_per_frame": round(alg_bytes / S, 1),
                          "note": "latency/issue-bound integer codec path: HBM fraction is small by construction (SURVEY.md 8d)"},
         }

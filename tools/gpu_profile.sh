@@ -22,3 +22,10 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 cd "$REPO" && timeout 300 python tools/phase_profile.py 8192 > "$OUT/phase_ticks.txt" 2>&1
 ls -la "$OUT"
+# counter calibration on a known byte count in the encoder's access width (4 B/lane)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 120 rocprofv3 --pmc $c -f csv -d /tmp/cal_${TAG}_$c -- "$REPO/tools/pmc_calibrate" > "$OUT/calib_$c.log" 2>&1
+  find /tmp/cal_${TAG}_$c -name '*counter_collection.csv' -exec cp {} "$OUT/calib_$c.csv" \;
+done
+ls -la "$OUT"
