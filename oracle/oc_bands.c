@@ -265,14 +265,34 @@ static void compute_theta(band_ctx *ctx, split_ctx *sctx, i32 *X, i32 *Y, int N,
       if (stereo && N > 2) {
          int p0 = 3, x = itheta, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
          if (encode) oc_ec_encode(ec, x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
+         else {
+            int fs = oc_ec_decode(ec, ft);
+            if (fs < (x0 + 1) * p0) x = fs / p0;
+            else x = x0 + 1 + (fs - (x0 + 1) * p0);
+            oc_ec_dec_update(ec, x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
+            itheta = x;
+         }
       } else if (B0 > 1 || stereo) {
          if (encode) oc_ec_enc_uint(ec, itheta, qn + 1);
+         else itheta = oc_ec_dec_uint(ec, qn + 1);
       } else {
          int fs, ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
          if (encode) {
             fs = itheta <= (qn >> 1) ? itheta + 1 : qn + 1 - itheta;
             int fl = itheta <= (qn >> 1) ? itheta * (itheta + 1) >> 1 : ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
             oc_ec_encode(ec, fl, fl + fs, ft);
+         } else {                        /* triangular pdf (bands.c:822) */
+            int fl = 0, fm = oc_ec_decode(ec, ft);
+            if (fm < ((qn >> 1) * ((qn >> 1) + 1) >> 1)) {
+               itheta = (oc_isqrt32(8 * (u32)fm + 1) - 1) >> 1;
+               fs = itheta + 1;
+               fl = itheta * (itheta + 1) >> 1;
+            } else {
+               itheta = (2 * (qn + 1) - oc_isqrt32(8 * (u32)(ft - fm - 1) + 1)) >> 1;
+               fs = qn + 1 - itheta;
+               fl = ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
+            }
+            oc_ec_dec_update(ec, fl, fl + fs, ft);
          }
       }
       itheta = (u32)((i32)itheta * 16384) / (u32)qn;
@@ -288,6 +308,7 @@ static void compute_theta(band_ctx *ctx, split_ctx *sctx, i32 *X, i32 *Y, int N,
       }
       if (*b > 2 << BITRES && ctx->remaining_bits > 2 << BITRES) {
          if (encode) oc_ec_enc_bit_logp(ec, inv, 2);
+         else inv = oc_ec_dec_bit_logp(ec, 2);
       } else inv = 0;
       if (ctx->disable_inv) inv = 0;
       itheta = 0;
@@ -313,6 +334,7 @@ static unsigned quant_band_n1(band_ctx *ctx, i32 *X, i32 *Y, i32 *lowband_out)
       int sign = 0;
       if (ctx->remaining_bits >= 1 << BITRES) {
          if (ctx->encode) { sign = x[0] < 0; oc_ec_enc_bits(ctx->ec, sign, 1); }
+         else sign = oc_ec_dec_bits(ctx->ec, 1);
          ctx->remaining_bits -= 1 << BITRES;
       }
       if (ctx->resynth) x[0] = sign ? -(1 << NORM_SHIFT) : (1 << NORM_SHIFT);
@@ -375,6 +397,7 @@ static unsigned quant_partition(band_ctx *ctx, i32 *X, int N, int b, int B, i32 
       if (q != 0) {
          int K = oc_get_pulses(q);
          if (ctx->encode) cm = oc_alg_quant(X, N, K, spread, B, ctx->ec, gain, ctx->resynth);
+         else cm = oc_alg_unquant(X, N, K, spread, B, ctx->ec, gain);
       } else if (ctx->resynth) {
          unsigned cm_mask = (unsigned)(1UL << B) - 1;
          fill &= cm_mask;
@@ -500,7 +523,7 @@ static unsigned quant_band_stereo(band_ctx *ctx, i32 *X, i32 *Y, int N, int b, i
          if (encode) {
             sign = mult32_32_q31(x2[0], y2[1]) - mult32_32_q31(x2[1], y2[0]) < 0;
             oc_ec_enc_bits(ec, sign, 1);
-         }
+         } else sign = oc_ec_dec_bits(ec, 1);
       }
       sign = 1 - 2 * sign;
       cm = quant_band(ctx, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);

@@ -63,9 +63,22 @@ void oc_ec_enc_uint(oc_ec *e, u32 fl, u32 ft);
 void oc_ec_enc_patch_initial_bits(oc_ec *e, unsigned val, unsigned nbits);
 void oc_ec_enc_shrink(oc_ec *e, u32 size);
 void oc_ec_enc_done(oc_ec *e);
+/* range decoder (oc_rangedec.c) */
+void oc_ec_dec_init(oc_ec *d, const u8 *buf, u32 storage);
+unsigned oc_ec_decode(oc_ec *d, unsigned ft);
+unsigned oc_ec_decode_bin(oc_ec *d, unsigned bits);
+void oc_ec_dec_update(oc_ec *d, unsigned fl, unsigned fh, unsigned ft);
+int  oc_ec_dec_bit_logp(oc_ec *d, unsigned logp);
+int  oc_ec_dec_icdf(oc_ec *d, const u8 *icdf, unsigned ftb);
+u32  oc_ec_dec_bits(oc_ec *d, unsigned bits);
+u32  oc_ec_dec_uint(oc_ec *d, u32 ft);
 
 /* ---- energy quantisation (oc_energy.c) ---- */
 void oc_laplace_encode(oc_ec *enc, int *value, unsigned fs, int decay);
+int  oc_laplace_decode(oc_ec *dec, unsigned fs, int decay);
+void oc_unquant_coarse_energy(int start, int end, i32 *oldEBands, int intra, oc_ec *dec, int C, int LM);
+void oc_unquant_fine_energy(int start, int end, i32 *oldEBands, const int *extra_quant, oc_ec *dec, int C);
+void oc_unquant_energy_finalise(int start, int end, i32 *oldEBands, const int *fine_quant, const int *fine_priority, int bits_left, oc_ec *dec, int C);
 void oc_amp2log2(int effEnd, int end, const i32 *bandE, i32 *bandLogE, int C);
 void oc_quant_coarse_energy(int start, int end, int effEnd, const i32 *eBands, i32 *oldEBands, u32 budget,
       i32 *error, oc_ec *enc, int C, int LM, int nbAvailableBytes, int force_intra, i32 *delayedIntra,
@@ -78,6 +91,7 @@ void oc_quant_energy_finalise(int start, int end, i32 *oldEBands, i32 *error, co
 /* ---- PVQ index coding (oc_cwrs.c) ---- */
 u32  oc_pvq_v(int n, int k);
 void oc_encode_pulses(const int *y, int n, int k, oc_ec *enc);
+i32  oc_decode_pulses(int *y, int n, int k, oc_ec *dec);
 
 /* ---- bit allocation (oc_rate.c) ---- */
 int oc_bits2pulses(int band, int LM, int bits);
@@ -108,6 +122,7 @@ void oc_exp_rotation(i32 *X, int len, int dir, int stride, int K, int spread);
 i32  oc_op_pvq_search(i32 *X, int *iy, int K, int N);
 unsigned oc_alg_quant(i32 *X, int N, int K, int spread, int B, oc_ec *enc, i32 gain, int resynth);
 void oc_renormalise_vector(i32 *X, int N, i32 gain);
+unsigned oc_alg_unquant(i32 *X, int N, int K, int spread, int B, oc_ec *dec, i32 gain);
 i32  oc_stereo_itheta(const i32 *X, const i32 *Y, int stereo, int N);
 void oc_compute_band_energies(const i32 *X, i32 *bandE, int end, int C, int LM);
 void oc_normalise_bands(const i32 *freq, i32 *X, const i32 *bandE, int end, int C, int M);

@@ -203,3 +203,91 @@ void oc_quant_energy_finalise(int start, int end, i32 *oldEBands, i32 *error, co
          }
       }
 }
+
+/* ---------------- decoder side ---------------- */
+/* ec_laplace_decode, laplace.c:94 */
+int oc_laplace_decode(oc_ec *dec, unsigned fs, int decay)
+{
+   int val = 0;
+   unsigned fl = 0, fm = oc_ec_decode_bin(dec, 15);
+   if (fm >= fs) {
+      val++;
+      fl = fs;
+      fs = laplace_freq1(fs, decay) + 1;
+      while (fs > 1 && fm >= fl + 2 * fs) {
+         fs *= 2;
+         fl += fs;
+         fs = ((fs - 2 * 1) * (i32)decay) >> 15;
+         fs += 1;
+         val++;
+      }
+      if (fs <= 1) {
+         int di = (fm - fl) >> (0 + 1);
+         val += di;
+         fl += 2 * di * 1;
+      }
+      if (fm < fl + fs) val = -val;
+      else fl += fs;
+   }
+   oc_ec_dec_update(dec, fl, imin(fl + fs, 32768), 32768);
+   return val;
+}
+/* unquant_coarse_energy, quant_bands.c:431 */
+void oc_unquant_coarse_energy(int start, int end, i32 *oldEBands, int intra, oc_ec *dec, int C, int LM)
+{
+   const u8 *prob_model = oc_e_prob_model[LM][intra];
+   long long prev[2] = {0, 0};
+   i16 coef, beta;
+   if (intra) { coef = 0; beta = beta_intra; }
+   else { beta = beta_coef[LM]; coef = pred_coef[LM]; }
+   i32 budget = dec->storage * 8;
+   for (int i = start; i < end; i++) {
+      for (int c = 0; c < C; c++) {
+         int qi;
+         i32 tell = oc_ec_tell(dec);
+         if (budget - tell >= 15) {
+            int pi = 2 * imin(i, 20);
+            qi = oc_laplace_decode(dec, prob_model[pi] << 7, prob_model[pi + 1] << 6);
+         } else if (budget - tell >= 2) {
+            qi = oc_ec_dec_icdf(dec, small_energy_icdf, 2);
+            qi = (qi >> 1) ^ -(qi & 1);
+         } else if (budget - tell >= 1) qi = -oc_ec_dec_bit_logp(dec, 1);
+         else qi = -1;
+         i32 q = shl32(qi, DB_SHIFT);
+         oldEBands[i + c * NB_EBANDS] = imax(-GC(9.f), oldEBands[i + c * NB_EBANDS]);
+         i32 tmp = (i32)(mult16_32_q15(coef, oldEBands[i + c * NB_EBANDS]) + prev[c] + q);
+         tmp = imin(GC(28.f), imax(-GC(28.f), tmp));
+         oldEBands[i + c * NB_EBANDS] = tmp;
+         prev[c] = prev[c] + q - mult16_32_q15(beta, q);
+      }
+   }
+}
+/* unquant_fine_energy, quant_bands.c:496 (prev_quant == NULL: first and only refinement stage without QEXT) */
+void oc_unquant_fine_energy(int start, int end, i32 *oldEBands, const int *extra_quant, oc_ec *dec, int C)
+{
+   for (int i = start; i < end; i++) {
+      int extra = extra_quant[i];
+      if (extra <= 0) continue;
+      if (oc_ec_tell(dec) + C * extra > (i32)dec->storage * 8) continue;
+      for (int c = 0; c < C; c++) {
+         int q2 = oc_ec_dec_bits(dec, extra);
+         i32 offset = sub32(vshr32(2 * q2 + 1, extra - DB_SHIFT + 1), GC(.5f));
+         oldEBands[i + c * NB_EBANDS] += offset;
+      }
+   }
+}
+/* unquant_energy_finalise, quant_bands.c:525 */
+void oc_unquant_energy_finalise(int start, int end, i32 *oldEBands, const int *fine_quant, const int *fine_priority, int bits_left, oc_ec *dec, int C)
+{
+   for (int prio = 0; prio < 2; prio++) {
+      for (int i = start; i < end && bits_left >= C; i++) {
+         if (fine_quant[i] >= MAX_FINE_BITS || fine_priority[i] != prio) continue;
+         for (int c = 0; c < C; c++) {
+            int q2 = oc_ec_dec_bits(dec, 1);
+            i32 offset = (shl32(q2, DB_SHIFT) - GC(.5f)) >> (fine_quant[i] + 1);
+            oldEBands[i + c * NB_EBANDS] += offset;
+            bits_left--;
+         }
+      }
+   }
+}

@@ -82,10 +82,7 @@ static int interp_bits2pulses(int start, int end, int skip_start, const int *bit
                break;
             }
             oc_ec_enc_bit_logp(ec, 0, 1);
-         } else {
-            /* decoder side not restated yet */
-            break;
-         }
+         } else if (oc_ec_dec_bit_logp(ec, 1)) break;
          psum += 1 << BITRES;
          band_bits -= 1 << BITRES;
       }
@@ -99,11 +96,12 @@ static int interp_bits2pulses(int start, int end, int skip_start, const int *bit
       if (encode) {
          *intensity = imin(*intensity, codedBands);
          oc_ec_enc_uint(ec, *intensity - start, codedBands + 1 - start);
-      }
+      } else *intensity = start + oc_ec_dec_uint(ec, codedBands + 1 - start);
    } else *intensity = 0;
    if (*intensity <= start) { total += dual_stereo_rsv; dual_stereo_rsv = 0; }
    if (dual_stereo_rsv > 0) {
       if (encode) oc_ec_enc_bit_logp(ec, *dual_stereo, 1);
+      else *dual_stereo = oc_ec_dec_bit_logp(ec, 1);
    } else *dual_stereo = 0;
 
    left = total - psum;

@@ -168,6 +168,16 @@ unsigned oc_alg_quant(i32 *X, int N, int K, int spread, int B, oc_ec *enc, i32 g
    return cm;
 }
 
+/* alg_unquant, vq.c:621 (non-QEXT path) */
+unsigned oc_alg_unquant(i32 *X, int N, int K, int spread, int B, oc_ec *dec, i32 gain)
+{
+   int iy[176 + 3];
+   i32 Ryy = oc_decode_pulses(iy, N, K, dec);
+   normalise_residual(iy, X, N, Ryy, gain);
+   oc_exp_rotation(X, N, -1, B, K, spread);
+   return extract_collapse_mask(iy, N, B);
+}
+
 /* renormalise_vector, vq.c:695 */
 void oc_renormalise_vector(i32 *X, int N, i32 gain)
 {
