@@ -1,0 +1,503 @@
+/* celt_dec_frame.h — CELT frame decoder + Opus packet layer for CELT-only packets, one wavefront per stream.
+ * Reference: src/opus.c:203/:224 (packet parse), src/opus_decoder.c:271/:716 (opus_decode_frame / _native, CELT-only branch),
+ * celt/celt_decoder.c:1104 (celt_decode_with_ec), :413 (celt_synthesis), :318 (deemphasis), celt/mdct.c:268
+ * (clt_mdct_backward), celt/celt.c:238 (comb_filter, in place = recursive).  Not built: PLC / FEC / DTX (len <= 1 frames,
+ * data == NULL), SILK and hybrid packets, mode transitions -> OPUS_UNIMPLEMENTED per stream. */
+#ifndef OPUS_AMD_CELT_DEC_FRAME_H
+#define OPUS_AMD_CELT_DEC_FRAME_H
+
+#define OA_ERR_BAD_ARG (-1)
+#define OA_ERR_BUFFER_TOO_SMALL (-2)
+#define OA_ERR_INTERNAL (-3)
+#define OA_ERR_INVALID_PACKET (-4)
+#define OA_ERR_UNIMPLEMENTED (-5)
+
+/* ---- inverse MDCT of one block (mdct.c:268): in = N2 bins at `stride` (LDS), out = N2 + overlap samples, TDAC into out[0..overlap) ---- */
+WV_DEVN void mdct_backward_wave(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int stride, WV_LDS int *aux)
+{
+   shift = wv_uni(shift); stride = wv_uni(stride);
+   const int N = 1920 >> shift, N2 = N >> 1, N4 = N >> 2, overlap = OA_OVERLAP;
+   const int trig_off = shift == 0 ? 0 : (shift == 1 ? 960 : (shift == 2 ? 1440 : 1680));
+   const int16_t *trig = ct_mdct_trig + trig_off;
+   const int16_t *bitrev = ct_fft_bitrev + ct_fft_bitrev_off[shift];
+   const int lane = wv_lane();
+   int pre_shift, post_shift, fft_shift;
+   {
+      i32 mx = 0, sm = 0;
+      FOR_LANES(i, N2) { i32 v = in[i * stride]; mx = imax(mx, iabs(v)); sm = add32(sm, iabs(v >> 11)); }
+      i32 maxval = wv_max(mx), sumval = add32(N2, wv_sum(sm));
+      pre_shift = imax(0, 29 - celt_zlog2(1 + maxval));
+      post_shift = imax(0, 19 - celt_ilog2(iabs(sumval)));
+      post_shift = imin(post_shift, pre_shift);
+      fft_shift = pre_shift - post_shift;
+   }
+   WV_LDS i32 *yp = out + (overlap >> 1);
+   wv_sync();
+   FOR_LANES(i, N4) {
+      int rev = bitrev[i];
+      i32 x1 = shl32(in[2 * i * stride], pre_shift), x2 = shl32(in[stride * (N2 - 1 - 2 * i)], pre_shift);
+      i32 yr = add32(SMUL(x2, trig[i]), SMUL(x1, trig[N4 + i]));
+      i32 yi = sub32(SMUL(x1, trig[i]), SMUL(x2, trig[N4 + i]));
+      yp[2 * rev + 1] = yr; yp[2 * rev] = yi;
+   }
+   if (lane == 0) aux[8] = fft_shift;            /* remaining[0]: down-shift budget of the single block */
+   wv_sync();
+   fft_forward(yp, shift, 1, aux + 8);
+   const int left = aux[8];
+   {  /* post-rotation in place: pair (i, N4-1-i); every lane reads its four words before writing them */
+      const int half = (N4 + 1) >> 1;
+      for (int i0 = 0; i0 < half; i0 += WV_WIDTH) {
+         int i = i0 + lane;
+         i32 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+         if (i < half) {
+            WV_LDS i32 *yp0 = yp + 2 * i, *yp1 = yp + N2 - 2 - 2 * i;
+            i32 re = fft_shift_val(yp0[1], left), im = fft_shift_val(yp0[0], left);
+            int t0 = trig[i], t1 = trig[N4 + i];
+            a0 = pshr32(add32(SMUL(re, t0), SMUL(im, t1)), post_shift);          /* -> yp0[0] */
+            b1 = pshr32(sub32(SMUL(re, t1), SMUL(im, t0)), post_shift);          /* -> yp1[1] */
+            re = fft_shift_val(yp1[1], left); im = fft_shift_val(yp1[0], left);
+            t0 = trig[N4 - i - 1]; t1 = trig[N2 - i - 1];
+            b0 = pshr32(add32(SMUL(re, t0), SMUL(im, t1)), post_shift);          /* -> yp1[0] */
+            a1 = pshr32(sub32(SMUL(re, t1), SMUL(im, t0)), post_shift);          /* -> yp0[1] */
+         }
+         wv_sync();
+         if (i < half) {
+            WV_LDS i32 *yp0 = yp + 2 * i, *yp1 = yp + N2 - 2 - 2 * i;
+            yp0[0] = a0; yp1[1] = b1; yp1[0] = b0; yp0[1] = a1;
+         }
+         wv_sync();
+      }
+   }
+   FOR_LANES(i, overlap / 2) {     /* mirror on both sides for TDAC */
+      i32 x1 = out[overlap - 1 - i], x2 = out[i];
+      int w1 = ct_window[i], w2 = ct_window[overlap - 1 - i];
+      out[i] = sub32(SMUL(x2, w2), SMUL(x1, w1));
+      out[overlap - 1 - i] = add32(SMUL(x2, w1), SMUL(x1, w2));
+   }
+   wv_sync();
+}
+
+/* the synthesis signal of channel c, frame-relative index j: j >= 0 -> this frame (LDS), j < 0 -> history ring (HBM) */
+struct SynSrc { const WV_LDS i32 *cur; const i32 *hist; int head; };
+WV_DEV i32 syn_at(const SynSrc &s, int j) { return j >= 0 ? s.cur[j] : s.hist[(s.head + j) & (OA_DEC_HISTORY - 1)]; }
+
+/* comb_filter (celt.c:238) in place on y[off .. off+N): the decoder's post-filter is recursive (taps read already-filtered
+ * samples), so it is run in chunks no longer than min(T0,T1)-2 samples: inside a chunk every tap points before the chunk. */
+WV_DEVN void comb_filter_inplace_wave(WV_LDS i32 *cur, const i32 *hist, int head, int off, int T0, int T1, int N, i32 g0_, i32 g1_, int tapset0, int tapset1, int overlap)
+{
+   T0 = wv_uni(T0); T1 = wv_uni(T1); N = wv_uni(N); off = wv_uni(off); tapset0 = wv_uni(tapset0); tapset1 = wv_uni(tapset1); overlap = wv_uni(overlap);
+   const i16 g0 = (i16)wv_uni(g0_), g1 = (i16)wv_uni(g1_);
+   const i16 gains[3][3] = {
+      {QC16(0.3066406250f, 15), QC16(0.2170410156f, 15), QC16(0.1296386719f, 15)},
+      {QC16(0.4638671875f, 15), QC16(0.2680664062f, 15), QC16(0.f, 15)},
+      {QC16(0.7998046875f, 15), QC16(0.1000976562f, 15), QC16(0.f, 15)}};
+   if (g0 == 0 && g1 == 0) return;
+   T0 = imax(T0, OA_MIN_PERIOD);
+   T1 = imax(T1, OA_MIN_PERIOD);
+   const i16 g00 = (i16)mult_coef_taps(g0, gains[tapset0][0]), g01 = (i16)mult_coef_taps(g0, gains[tapset0][1]), g02 = (i16)mult_coef_taps(g0, gains[tapset0][2]);
+   const i16 g10 = (i16)mult_coef_taps(g1, gains[tapset1][0]), g11 = (i16)mult_coef_taps(g1, gains[tapset1][1]), g12 = (i16)mult_coef_taps(g1, gains[tapset1][2]);
+   if (g0 == g1 && T0 == T1 && tapset0 == tapset1) overlap = 0;
+   SynSrc s; s.cur = cur; s.hist = hist; s.head = head;
+#define XA(k) syn_at(s, off + (k))
+   const int chunk = imin(WV_WIDTH, imin(T0, T1) - 2);
+   const int ov = imin(overlap, N);
+   wv_sync();
+   for (int c0 = 0; c0 < ov; c0 += chunk) {                  /* cross-fade from (T0, g0, tapset0) to (T1, g1, tapset1) */
+      const int i = c0 + wv_lane();
+      const bool act = wv_lane() < chunk && i < ov;
+      i32 v = 0;
+      if (act) {
+         i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
+         v = XA(i);
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), XA(i - T0)));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(XA(i - T0 + 1), XA(i - T0 - 1))));
+         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(XA(i - T0 + 2), XA(i - T0 - 2))));
+         v = add32(v, mult_coef_32(mult_coef(f, g10), XA(i - T1)));
+         v = add32(v, mult_coef_32(mult_coef(f, g11), add32(XA(i - T1 + 1), XA(i - T1 - 1))));
+         v = add32(v, mult_coef_32(mult_coef(f, g12), add32(XA(i - T1 + 2), XA(i - T1 - 2))));
+         v = saturate(sub32(v, 3), SIG_SAT);
+      }
+      wv_sync();
+      if (act) cur[off + i] = v;
+      wv_sync();
+   }
+   if (g1 != 0) {                                            /* constant filter on the rest (comb_filter_const, celt.c:205) */
+      for (int c0 = ov; c0 < N; c0 += chunk) {
+         const int i = c0 + wv_lane();
+         const bool act = wv_lane() < chunk && i < N;
+         i32 v = 0;
+         if (act) {
+            v = add32(add32(add32(XA(i), mult_coef_32(g10, XA(i - T1))), mult_coef_32(g11, add32(XA(i - T1 + 1), XA(i - T1 - 1)))),
+                  mult_coef_32(g12, add32(XA(i - T1 + 2), XA(i - T1 - 2))));
+            v = saturate(sub32(v, 1), SIG_SAT);
+         }
+         wv_sync();
+         if (act) cur[off + i] = v;
+         wv_sync();
+      }
+   }
+#undef XA
+}
+
+/* ---- one CELT frame (celt_decoder.c:1104, data present).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
+WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out)
+{
+   WV_LDS DecShared *sh = &L->sh;
+   WV_LDS OaDecScalars *st = &L->st;
+   const int overlap = OA_OVERLAP;
+   const int lane = wv_lane();
+   len = wv_uni(len); frame_size = wv_uni(frame_size);
+   int LM;
+   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
+   if (LM > 3) return OA_ERR_BAD_ARG;
+   if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
+   if (len <= 1) return OA_ERR_UNIMPLEMENTED;                     /* celt_decode_lost */
+   const int M = 1 << LM, N = M * 120;
+   const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
+   const int effEnd = imin(end, NBE);
+   wv_sync();
+   LANE0 {
+      EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
+      sh->CC = CC; sh->C = C; sh->LM = LM; sh->M = M; sh->N = N; sh->start = start; sh->end = end; sh->effEnd = effEnd; sh->len = len;
+      if (st->loss_duration == 0) st->skip_plc = 0;
+      k_ec_dec_init(EC_PASS, len);
+      if (C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[i] = imax(L->oldBandE[i], L->oldBandE[NBE + i]);
+      i32 total_bits = len * 8, tell = k_ec_tell(EC_PASS);
+      int silence;
+      if (tell >= total_bits) silence = 1;
+      else if (tell == 1) silence = k_ec_dec_bit_logp(EC_PASS, 15);
+      else silence = 0;
+      if (silence) { tell = len * 8; e->nbits_total += tell - k_ec_tell(EC_PASS); }
+      int postfilter_gain = 0, postfilter_pitch = 0, postfilter_tapset = 0;
+      if (start == 0 && tell + 16 <= total_bits) {
+         if (k_ec_dec_bit_logp(EC_PASS, 1)) {
+            int qg, octave = k_ec_dec_uint(EC_PASS, 6);
+            postfilter_pitch = (16 << octave) + k_ec_dec_bits(EC_PASS, 4 + octave) - 1;
+            qg = k_ec_dec_bits(EC_PASS, 3);
+            if (k_ec_tell(EC_PASS) + 2 <= total_bits) postfilter_tapset = k_ec_dec_icdf(EC_PASS, k_tapset_icdf, 2);
+            postfilter_gain = (i16)(QC16(.09375f, 15) * (qg + 1));
+         }
+         tell = k_ec_tell(EC_PASS);
+      }
+      int isTransient = 0;
+      if (LM > 0 && tell + 3 <= total_bits) { isTransient = k_ec_dec_bit_logp(EC_PASS, 3); tell = k_ec_tell(EC_PASS); }
+      const int shortBlocks = isTransient ? M : 0;
+      const int intra_ener = tell + 3 <= total_bits ? k_ec_dec_bit_logp(EC_PASS, 3) : 0;
+      k_unquant_coarse_energy(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM);
+      k_tf_decode(start, end, isTransient, L->tf_res, LM, EC_PASS);
+      tell = k_ec_tell(EC_PASS);
+      int spread_decision = 2;
+      if (tell + 4 <= total_bits) spread_decision = k_ec_dec_icdf(EC_PASS, k_spread_icdf, 5);
+      k_init_caps(L->cap, LM, C);
+      int dynalloc_logp = 6;
+      total_bits <<= BITRES;
+      tell = k_ec_tell_frac(EC_PASS);
+      for (int i = start; i < end; i++) {
+         int width = C * (ct_eBands[i + 1] - ct_eBands[i]) << LM;
+         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
+         int dynalloc_loop_logp = dynalloc_logp, boost = 0;
+         while (tell + (dynalloc_loop_logp << BITRES) < total_bits && boost < L->cap[i]) {
+            int flag = k_ec_dec_bit_logp(EC_PASS, dynalloc_loop_logp);
+            tell = k_ec_tell_frac(EC_PASS);
+            if (!flag) break;
+            boost += quanta;
+            total_bits -= quanta;
+            dynalloc_loop_logp = 1;
+         }
+         L->offsets[i] = boost;
+         if (boost > 0) dynalloc_logp = imax(2, dynalloc_logp - 1);
+      }
+      const int alloc_trim = tell + (6 << BITRES) <= total_bits ? k_ec_dec_icdf(EC_PASS, k_trim_icdf, 7) : 5;
+      i32 bits = (((i32)len * 8) << BITRES) - (i32)k_ec_tell_frac(EC_PASS) - 1;
+      const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
+      bits -= anti_collapse_rsv;
+      int intensity = 0, dual_stereo = 0;
+      i32 balance = 0;
+      const int codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, alloc_trim, &intensity, &dual_stereo, bits, &balance,
+            L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 0, 0, 0);
+      k_unquant_fine_energy(start, end, L->oldBandE, L->fine_quant, EC_PASS, C);
+      sh->silence = silence; sh->postfilter_pitch = postfilter_pitch; sh->postfilter_gain = postfilter_gain; sh->postfilter_tapset = postfilter_tapset;
+      sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision; sh->intensity = intensity; sh->dual_stereo = dual_stereo;
+      sh->anti_collapse_rsv = anti_collapse_rsv; sh->codedBands = codedBands; sh->balance = balance;
+      sh->pvq_total_bits = len * (8 << BITRES) - anti_collapse_rsv;
+      ec_st(&L->ec, &ec_);
+   }
+   wv_sync();
+   /* X starts at zero (the reference's bands below start / above end are never written) */
+   FOR_LANES(i, C * N) L->A.X[i] = 0;
+   wv_sync();
+   dec_quant_all_bands_wave(L, sh->shortBlocks, sh->spread, sh->dual_stereo, sh->intensity, sh->pvq_total_bits, sh->balance, sh->codedBands, st->disable_inv);
+   LANE0 {
+      EC_BEGIN;
+      int anti_collapse_on = 0;
+      if (sh->anti_collapse_rsv > 0) anti_collapse_on = k_ec_dec_bits(EC_PASS, 1);
+      k_unquant_energy_finalise(start, end, L->oldBandE, L->fine_quant, L->fine_priority, len * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
+      sh->anti_collapse_on = anti_collapse_on;
+      EC_END;
+   }
+   wv_sync();
+   if (sh->anti_collapse_on) anti_collapse_wave(L, LM, C, N, start, end);
+   const int silence = wv_uni(sh->silence), isTransient = wv_uni(sh->isTransient);
+   if (silence) { wv_sync(); FOR_LANES(i, C * NBE) L->oldBandE[i] = -GC(28.f); wv_sync(); }
+   K_DUMP("dec_X", L->A.X, C * N * 4); K_DUMP("dec_oldBandE", L->oldBandE, 2 * NBE * 4);
+
+   /* ---- celt_synthesis (celt_decoder.c:413): denormalise in place, IMDCT per block into syn[c] (head = last frame's overlap tail) ---- */
+   {
+      int B, NB, shift;
+      if (isTransient) { B = M; NB = 120; shift = 3; }
+      else { B = 1; NB = 120 << LM; shift = 3 - LM; }
+      for (int c = 0; c < CC; c++) {
+         FOR_LANES(i, overlap) L->BC.syn[c][i] = gs->overlap_mem[c * overlap + i];
+         FOR_LANES(i, N) L->BC.syn[c][overlap + i] = 0;
+      }
+      wv_sync();
+      WV_LDS i32 *freq = L->A.X;
+      if (CC == 2 && C == 1) {
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence);
+         FOR_LANES(i, N) freq[N + i] = freq[i];        /* the IMDCT consumes its input: keep a copy for the second channel */
+         wv_sync();
+         for (int b = 0; b < B; b++) mdct_backward_wave(freq + N + b, L->BC.syn[0] + NB * b, shift, B, L->aux);
+         for (int b = 0; b < B; b++) mdct_backward_wave(freq + b, L->BC.syn[1] + NB * b, shift, B, L->aux);
+      } else if (CC == 1 && C == 2) {
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence);
+         denormalise_bands_wave(freq + N, L->oldBandE + NBE, L->scr, start, effEnd, M, silence);
+         FOR_LANES(i, N) freq[i] = add32(half32(freq[i]), half32(freq[N + i]));
+         wv_sync();
+         for (int b = 0; b < B; b++) mdct_backward_wave(freq + b, L->BC.syn[0] + NB * b, shift, B, L->aux);
+      } else {
+         for (int c = 0; c < CC; c++) {
+            denormalise_bands_wave(freq + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, M, silence);
+            for (int b = 0; b < B; b++) mdct_backward_wave(freq + c * N + b, L->BC.syn[c] + NB * b, shift, B, L->aux);
+         }
+      }
+      for (int c = 0; c < CC; c++) { FOR_LANES(i, N) L->BC.syn[c][i] = saturate(L->BC.syn[c][i], SIG_SAT); }
+      wv_sync();
+   }
+   for (int c = 0; c < CC; c++) K_DUMP("dec_syn", L->BC.syn[c], N * 4);
+
+   /* ---- pitch post-filter (celt_decoder.c:1536-1553), in place and recursive ---- */
+   {
+      const int head = wv_uni(st->hist_head);
+      LANE0 { st->postfilter_period = imax(st->postfilter_period, OA_MIN_PERIOD); st->postfilter_period_old = imax(st->postfilter_period_old, OA_MIN_PERIOD); }
+      wv_sync();
+      for (int c = 0; c < CC; c++) {
+         const i32 *hist = gs->hist + c * OA_DEC_HISTORY;
+         comb_filter_inplace_wave(L->BC.syn[c], hist, head, 0, st->postfilter_period_old, st->postfilter_period, 120, st->postfilter_gain_old, st->postfilter_gain,
+               st->postfilter_tapset_old, st->postfilter_tapset, overlap);
+         if (LM != 0)
+            comb_filter_inplace_wave(L->BC.syn[c], hist, head, 120, st->postfilter_period, sh->postfilter_pitch, N - 120, st->postfilter_gain, sh->postfilter_gain,
+                  st->postfilter_tapset, sh->postfilter_tapset, overlap);
+      }
+      wv_sync();
+   }
+   /* ---- state update (celt_decoder.c:1555-1607) ---- */
+   LANE0 {
+      st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset;
+      st->postfilter_period = sh->postfilter_pitch; st->postfilter_gain = sh->postfilter_gain; st->postfilter_tapset = sh->postfilter_tapset;
+      if (LM != 0) { st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset; }
+   }
+   wv_sync();
+   if (C == 1) { FOR_LANES(i, NBE) L->oldBandE[NBE + i] = L->oldBandE[i]; wv_sync(); }
+   {
+      const i32 max_background_increase = imin(160, wv_uni(st->loss_duration) + M) * GC(0.001f);
+      FOR_LANES(i, 2 * NBE) {
+         const int bi = i % NBE;
+         i32 ob = L->oldBandE[i], l1 = L->oldLogE[i], l2 = L->oldLogE2[i];
+         if (!isTransient) { l2 = l1; l1 = ob; } else l1 = imin(l1, ob);
+         L->backgroundLogE[i] = imin(L->backgroundLogE[i] + max_background_increase, ob);
+         if (bi < start || bi >= end) { ob = 0; l1 = l2 = -GC(28.f); }
+         L->oldBandE[i] = ob; L->oldLogE[i] = l1; L->oldLogE2[i] = l2;
+      }
+   }
+   wv_sync();
+   /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; int16 staged in region A ---- */
+   if (lane < CC) {
+      i32 m = st->preemph_memD[lane];
+      const WV_LDS i32 *x = L->BC.syn[lane];
+      WV_LDS i16 *y = L->A.pcm16;
+      for (int j = 0; j < N; j++) {
+         i32 tmp = saturate(x[j] + m, SIG_SAT);
+         m = mult16_32_q15(27853, tmp);
+         y[j * CC + lane] = sig2word16(tmp);
+      }
+      st->preemph_memD[lane] = m;
+   }
+   wv_sync();
+   FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
+   /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
+   {
+      const int head = wv_uni(st->hist_head);
+      for (int c = 0; c < CC; c++) {
+         FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = L->BC.syn[c][i];
+         FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = L->BC.syn[c][N + i];
+      }
+   }
+   wv_sync();
+   int ret = frame_size;
+   LANE0 {
+      st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
+      st->rng = L->ec.rng;
+      st->loss_duration = 0; st->plc_duration = 0; st->last_frame_type = 1; st->prefilter_and_fold = 0;
+      i32 used = L->ec.nbits_total - ec_ilog(L->ec.rng);
+      sh->r[1] = used > 8 * len ? OA_ERR_INTERNAL : frame_size;
+      if (L->ec.error) st->error = 1;
+   }
+   wv_sync();
+   ret = wv_uni(sh->r[1]);
+   return ret;
+}
+
+/* ---- Opus packet layer: opus_decode_native (opus_decoder.c:716) for CELT-only packets ---- */
+WV_DEV int oa_samples_per_frame(int toc, i32 Fs)
+{
+   int audiosize;
+   if (toc & 0x80) { audiosize = ((toc >> 3) & 0x3); audiosize = (Fs << audiosize) / 400; }
+   else if ((toc & 0x60) == 0x60) audiosize = (toc & 0x08) ? Fs / 50 : Fs / 100;
+   else { audiosize = ((toc >> 3) & 0x3); audiosize = audiosize == 3 ? Fs * 60 / 1000 : (Fs << audiosize) / 100; }
+   return audiosize;
+}
+WV_DEV int oa_parse_size(const u8 *data, i32 len, i32 *size)
+{
+   if (len < 1) { *size = -1; return -1; }
+   else if (data[0] < 252) { *size = data[0]; return 1; }
+   else if (len < 2) { *size = -1; return -1; }
+   else { *size = 4 * data[1] + data[0]; return 2; }
+}
+/* opus_packet_parse_impl (opus.c:224, not self-delimited); lane 0.  Fills sh->size[], returns count or < 0; *payload_offset */
+WV_DEV int oa_packet_parse(const u8 *data, i32 len, WV_LDS i32 *size, int *payload_offset)
+{
+   int i, bytes, count, framesize;
+   u8 ch, toc;
+   i32 last_size, sz;
+   const u8 *data0 = data;
+   if (len < 0) return OA_ERR_BAD_ARG;
+   if (len == 0) return OA_ERR_INVALID_PACKET;
+   framesize = oa_samples_per_frame(data[0], 48000);
+   toc = *data++;
+   len--;
+   last_size = len;
+   switch (toc & 0x3) {
+   case 0: count = 1; break;
+   case 1:
+      count = 2;
+      if (len & 0x1) return OA_ERR_INVALID_PACKET;
+      last_size = len / 2;
+      size[0] = last_size;
+      break;
+   case 2:
+      count = 2;
+      bytes = oa_parse_size(data, len, &sz); size[0] = sz;
+      len -= bytes;
+      if (sz < 0 || sz > len) return OA_ERR_INVALID_PACKET;
+      data += bytes;
+      last_size = len - sz;
+      break;
+   default:
+      if (len < 1) return OA_ERR_INVALID_PACKET;
+      ch = *data++;
+      count = ch & 0x3F;
+      if (count <= 0 || framesize * (i32)count > 5760) return OA_ERR_INVALID_PACKET;
+      len--;
+      if (ch & 0x40) {
+         int p;
+         do {
+            int tmp;
+            if (len <= 0) return OA_ERR_INVALID_PACKET;
+            p = *data++;
+            len--;
+            tmp = p == 255 ? 254 : p;
+            len -= tmp;
+         } while (p == 255);
+      }
+      if (len < 0) return OA_ERR_INVALID_PACKET;
+      if (ch & 0x80) {
+         last_size = len;
+         for (i = 0; i < count - 1; i++) {
+            bytes = oa_parse_size(data, len, &sz); size[i] = sz;
+            len -= bytes;
+            if (sz < 0 || sz > len) return OA_ERR_INVALID_PACKET;
+            data += bytes;
+            last_size -= bytes + sz;
+         }
+         if (last_size < 0) return OA_ERR_INVALID_PACKET;
+      } else {
+         last_size = len / count;
+         if (last_size * count != len) return OA_ERR_INVALID_PACKET;
+         for (i = 0; i < count - 1; i++) size[i] = last_size;
+      }
+      break;
+   }
+   if (last_size > 1275) return OA_ERR_INVALID_PACKET;
+   size[count - 1] = last_size;
+   *payload_offset = (int)(data - data0);
+   return count;
+}
+
+/* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
+WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
+{
+   WV_LDS DecShared *sh = &L->sh;
+   WV_LDS OaDecScalars *st = &L->st;
+   {
+      const i32 *g = (const i32 *)&gs->s;
+      WV_LDS i32 *d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaDecScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->oldBandE[i]; L->oldLogE[i] = gs->oldLogE[i]; L->oldLogE2[i] = gs->oldLogE2[i]; L->backgroundLogE[i] = gs->backgroundLogE[i]; }
+   }
+   wv_sync();
+   LANE0 {
+      int ret = 0, offset = 0;
+      sh->count = 0; sh->nb_samples = 0;
+      if (frame_size <= 0) ret = OA_ERR_BAD_ARG;
+      else if (len == 0 || data == 0) ret = frame_size % 120 != 0 ? OA_ERR_BAD_ARG : OA_ERR_UNIMPLEMENTED;      /* PLC */
+      else if (len < 0) ret = OA_ERR_BAD_ARG;
+      else {
+         const int toc = data[0];
+         const int packet_mode = (toc & 0x80) ? 1002 : ((toc & 0x60) == 0x60 ? 1001 : 1000);
+         int packet_bandwidth;
+         if (toc & 0x80) { packet_bandwidth = 1102 + ((toc >> 5) & 0x3); if (packet_bandwidth == 1102) packet_bandwidth = 1101; }
+         else if ((toc & 0x60) == 0x60) packet_bandwidth = (toc & 0x10) ? 1105 : 1104;
+         else packet_bandwidth = 1101 + ((toc >> 5) & 0x3);
+         const int packet_frame_size = oa_samples_per_frame(toc, 48000);
+         const int count = oa_packet_parse(data, len, sh->size, &offset);
+         if (count < 0) ret = count;
+         else if (packet_mode != 1002) ret = OA_ERR_UNIMPLEMENTED;                  /* SILK / hybrid */
+         else if (st->prev_mode > 0 && st->prev_mode != 1002) ret = OA_ERR_UNIMPLEMENTED;
+         else if (count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
+         else {
+            st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
+            int endband = 21;
+            switch (packet_bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
+            st->end = endband; st->start = 0;
+            sh->count = count; sh->packet_frame_size = packet_frame_size; sh->frame_bytes_off = offset;
+         }
+      }
+      sh->ret = ret;
+   }
+   wv_sync();
+   int ret = wv_uni(sh->ret);
+   const int count = wv_uni(sh->count), pfs = wv_uni(sh->packet_frame_size), CC = wv_uni(st->channels);
+   int off = wv_uni(sh->frame_bytes_off), nb = 0;
+   for (int f = 0; f < count && ret >= 0; f++) {
+      const int flen = wv_uni(sh->size[f]);
+      wv_sync();
+      FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
+      wv_sync();
+      int r = celt_decode_frame_wave(L, gs, flen, pfs, pcm_out + (size_t)nb * CC);
+      if (r < 0) ret = r;
+      else nb += r;
+      off += flen;
+      LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1002; st->prev_redundancy = 0; }
+      wv_sync();
+   }
+   if (ret >= 0) { ret = nb; LANE0 st->last_packet_duration = nb; wv_sync(); }
+   /* ---- store state ---- */
+   {
+      i32 *g = (i32 *)&gs->s;
+      const WV_LDS i32 *d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaDecScalars) / 4)) g[i] = d[i];
+      FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
+   }
+   LANE0 { *nsamples_out = ret; *rng_out = st->rangeFinal; }
+}
+#endif

@@ -6,6 +6,7 @@
 #include "celt_tables.h"
 #include "celt_frame.h"
 #include "celt_ec.h"
+#include "celt_ecdec.h"
 #include "celt_enc_lds.h"
 #include "celt_enc_serial.h"
 #include "celt_mdct.h"

@@ -261,10 +261,7 @@ WV_DEV int interp_bits2pulses(int start, int end, int skip_start, const WV_LDS i
                break;
             }
             k_ec_enc_bit_logp(EC_PASS, 0, 1);
-         } else {
-            /* decoder side not restated yet */
-            break;
-         }
+         } else if (k_ec_dec_bit_logp(EC_PASS, 1)) break;
          psum += 1 << BITRES;
          band_bits -= 1 << BITRES;
       }
@@ -278,11 +275,12 @@ WV_DEV int interp_bits2pulses(int start, int end, int skip_start, const WV_LDS i
       if (encode) {
          *intensity = imin(*intensity, codedBands);
          k_ec_enc_uint(EC_PASS, *intensity - start, codedBands + 1 - start);
-      }
+      } else *intensity = start + k_ec_dec_uint(EC_PASS, codedBands + 1 - start);
    } else *intensity = 0;
    if (*intensity <= start) { total += dual_stereo_rsv; dual_stereo_rsv = 0; }
    if (dual_stereo_rsv > 0) {
       if (encode) k_ec_enc_bit_logp(EC_PASS, *dual_stereo, 1);
+      else *dual_stereo = k_ec_dec_bit_logp(EC_PASS, 1);
    } else *dual_stereo = 0;
 
    left = total - psum;

@@ -53,4 +53,27 @@ struct OaStream {
    OaEncState st;
 };
 
+
+/* ---- decoder: per-stream persistent state (reference OpusDecoder src/opus_decoder.c:65-94, CELT-only subset, and
+ * OpusCustomDecoder celt/celt_decoder.c:87-139).  The reference's linear decode_mem[ch][2048+120] (shifted by N every frame)
+ * is kept as a 2048-sample ring per channel (hist, oldest sample at hist_head) plus the 120-sample IMDCT overlap tail, so a
+ * frame-step appends N samples instead of moving 2x1208. */
+#define OA_DEC_HISTORY 2048
+struct OaDecScalars {
+   int32_t channels, stream_channels, bandwidth, mode, prev_mode, frame_size, prev_redundancy, last_packet_duration;
+   uint32_t rangeFinal;
+   int32_t start, end, disable_inv;
+   uint32_t rng;
+   int32_t error, last_pitch_index, loss_duration, plc_duration, last_frame_type, skip_plc;
+   int32_t postfilter_period, postfilter_period_old, postfilter_gain, postfilter_gain_old, postfilter_tapset, postfilter_tapset_old, prefilter_and_fold;
+   int32_t preemph_memD[2];
+   int32_t hist_head;
+   int32_t pad0[3];
+};
+struct OaDecStream {
+   OaDecScalars s;
+   int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], backgroundLogE[2 * OA_NB_EBANDS];
+   int32_t overlap_mem[2 * OA_OVERLAP];
+   int32_t hist[2 * OA_DEC_HISTORY];
+};
 #endif

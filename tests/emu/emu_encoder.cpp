@@ -11,6 +11,7 @@ extern "C" void emu_set_dump(dump_fn f) { g_dump = f; }
 #define K_DUMPI(tag, v) do { int32_t v__ = (int32_t)(v); if (g_dump && wv_lane() == 0) g_dump(tag, &v__, 4); } while (0)
 #define K_DUMP_ENABLED 1
 #include "celt_enc_all.h"
+#include "celt_dec_all.h"
 
 struct Job { FrameLds *L; OaStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int32_t *len; uint32_t *rng; };
 static void job_entry(void *p)
@@ -28,6 +29,27 @@ extern "C" void emu_encode_batch(OaStream *streams, const int16_t *pcm, int S, i
       memset(L, 0xA5, sizeof(FrameLds));          /* LDS is uninitialised on the GPU: make stale reads loud */
       Job j = {L, streams + s, pcm + (size_t)s * frame_size * streams[s].cfg.channels, frame_size, max_bytes, out + (size_t)s * stride, lens + s, rngs + s};
       emu_run_wave(job_entry, &j);
+      free(L);
+   }
+}
+
+/* ---- decoder ---- */
+struct DJob { DecLds *L; OaDecStream *gs; const uint8_t *data; int len, frame_size; int16_t *pcm; int32_t *ns; uint32_t *rng; };
+static void djob_entry(void *p)
+{
+   DJob *j = (DJob *)p;
+   oa_decode_packet(j->L, j->gs, j->data, j->len, j->frame_size, j->pcm, j->ns, j->rng);
+}
+extern "C" int emu_sizeof_dec_stream() { return (int)sizeof(OaDecStream); }
+extern "C" int emu_sizeof_dec_lds() { return (int)sizeof(DecLds); }
+extern "C" void emu_decode_batch(OaDecStream *streams, const uint8_t *data, int stride, const int32_t *lens, int S, int frame_size,
+      int16_t *pcm, int pcm_stride, int32_t *ns, uint32_t *rngs)
+{
+   for (int s = 0; s < S; s++) {
+      DecLds *L = (DecLds *)aligned_alloc(64, (sizeof(DecLds) + 63) & ~63);
+      memset(L, 0xA5, sizeof(DecLds));
+      DJob j = {L, streams + s, data + (size_t)s * stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, ns + s, rngs + s};
+      emu_run_wave(djob_entry, &j);
       free(L);
    }
 }
