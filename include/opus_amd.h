@@ -118,6 +118,43 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);
 /* introspection for the roofline report */
 OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
 
+
+/* ================= decoder: CELT-only Opus packets, 48 kHz output =================
+ * Classic API — same names, arguments and error codes as reference/include/opus.h: opus_decoder_get_size :460,
+ * opus_decoder_create :477, opus_decoder_init :494, opus_decode :516, opus_decoder_ctl :586, opus_decoder_destroy :591
+ * (definitions replaced: reference/src/opus_decoder.c:121, :186, :135, :890, :1033, :1246).  The OpusDecoder blob is flat
+ * host memory with the complete state (memcpy-able).  Scope this round: CELT-only packets (any frame count / size the
+ * TOC allows), mono/stereo streams into mono/stereo output.  SILK / hybrid packets, packet-loss concealment
+ * (data == NULL or len == 0), FEC and Fs != 48000 return OPUS_UNIMPLEMENTED. */
+typedef struct OpusDecoder OpusDecoder;
+OPUS_AMD_EXPORT int opus_decoder_get_size(int channels);
+OPUS_AMD_EXPORT OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error);
+OPUS_AMD_EXPORT int opus_decoder_init(OpusDecoder *st, opus_int32 Fs, int channels);
+OPUS_AMD_EXPORT int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_decoder_ctl(OpusDecoder *st, int request, ...);
+OPUS_AMD_EXPORT void opus_decoder_destroy(OpusDecoder *st);
+
+/* Batch decoder: S independent streams, one wavefront per stream per call; state (incl. the 2x2048-sample synthesis history)
+ * stays in HBM.  packets: [S][packet_stride] bytes (one Opus packet per stream, lens[s] bytes used); pcm: [S][frame_size*channels]
+ * int16 interleaved (frame_size = capacity per channel, <= 5760); nsamples[s] = samples per channel decoded or a negative
+ * OPUS_* code for that stream; final_range[s] = OPUS_GET_FINAL_RANGE. */
+typedef struct OpusGpuDecBatch OpusGpuDecBatch;
+OPUS_AMD_EXPORT OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b);
+OPUS_AMD_EXPORT opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b);
+OPUS_AMD_EXPORT int opusgpu_decode_batch(OpusGpuDecBatch *b, const unsigned char *packets, opus_int32 packet_stride, const opus_int32 *lens,
+      opus_int16 *pcm, int frame_size, opus_int32 *nsamples, opus_uint32 *final_range);
+OPUS_AMD_EXPORT int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, opus_int32 packet_stride, const opus_int32 *d_lens,
+      opus_int16 *d_pcm, int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, opus_int32 packet_stride, const opus_int32 *d_lens,
+      opus_int16 *d_pcm, int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, int steps, float *ms);
+OPUS_AMD_EXPORT int opusgpu_dec_batch_sync(OpusGpuDecBatch *b);
+OPUS_AMD_EXPORT int opusgpu_dec_batch_reset(OpusGpuDecBatch *b);
+OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
+OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);
+OPUS_AMD_EXPORT int opusgpu_dec_batch_import_state(OpusGpuDecBatch *b, opus_int32 stream, const void *blob);
+OPUS_AMD_EXPORT int opusgpu_dec_kernel_lds_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,17 @@ def lib():
         L.opusgpu_time_encode_dev.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, i32, vp]
         L.opusgpu_enc_batch_sync.argtypes = [vp]; L.opusgpu_enc_batch_reset.argtypes = [vp]
+        # decoder
+        L.opus_decoder_create.restype = vp; L.opus_decoder_create.argtypes = [i32, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opus_decoder_destroy.argtypes = [vp]
+        L.opus_decode.argtypes = [vp, ctypes.c_char_p, i32, vp, ctypes.c_int, ctypes.c_int]
+        L.opusgpu_dec_batch_create.restype = vp; L.opusgpu_dec_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opusgpu_dec_batch_destroy.argtypes = [vp]
+        L.opusgpu_decode_batch.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp]
+        L.opusgpu_decode_batch_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, vp]
+        L.opusgpu_time_decode_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.opusgpu_dec_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_dec_batch_import_state.argtypes = [vp, i32, vp]
+        L.opusgpu_dec_batch_sync.argtypes = [vp]; L.opusgpu_dec_batch_reset.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -144,4 +155,68 @@ class EncoderBatch:
     def sync(self): self._L.opusgpu_enc_batch_sync(self._b)
     def close(self):
         if getattr(self, "_b", None): self._L.opusgpu_enc_batch_destroy(self._b); self._b = None
+    def __del__(self): self.close()
+
+
+class OpusDecoder:
+    """Mirror of the reference decoder object: OpusDecoder(Fs, channels); .decode(packet, frame_size) -> int16 [n, channels].
+    CELT-only packets; each decode runs on the GPU as a batch of one."""
+    def __init__(self, Fs, channels):
+        err = ctypes.c_int()
+        self._L = lib()
+        self._st = self._L.opus_decoder_create(Fs, channels, ctypes.byref(err))
+        if not self._st: raise OpusError(err.value)
+        self.channels = channels
+    def decode(self, packet, frame_size=5760, decode_fec=0):
+        import numpy as np
+        pcm = np.zeros((frame_size, self.channels), np.int16)
+        n = self._L.opus_decode(self._st, packet, len(packet) if packet is not None else 0, pcm.ctypes.data, frame_size, decode_fec)
+        if n < 0: raise OpusError(n)
+        return pcm[:n].copy()
+    def final_range(self):
+        v = ctypes.c_uint32()
+        self._L.opus_decoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        r = self._L.opus_decoder_ctl(self._st, OPUS_GET_FINAL_RANGE_REQUEST, ctypes.byref(v))
+        if r != OPUS_OK: raise OpusError(r)
+        return v.value
+    def __del__(self):
+        if getattr(self, "_st", None): self._L.opus_decoder_destroy(self._st); self._st = None
+
+class DecoderBatch:
+    """S independent streams decoded together on one GPU (include/opus_amd.h batch decoder API)."""
+    def __init__(self, nstreams, channels=2, Fs=48000, device=0):
+        err = ctypes.c_int()
+        self._L = lib()
+        self._b = self._L.opusgpu_dec_batch_create(nstreams, Fs, channels, device, ctypes.byref(err))
+        if not self._b: raise OpusError(err.value)
+        self.S, self.channels, self.device = nstreams, channels, device
+    def decode(self, packets, frame_size=960):
+        """packets: list of S bytes objects.  Returns (pcm int16 [S, frame_size, channels], nsamples [S], final ranges [S])."""
+        import numpy as np
+        assert len(packets) == self.S
+        stride = (max(len(p) for p in packets) + 8 + 3) & ~3
+        buf = np.zeros((self.S, stride), np.uint8)
+        lens = np.array([len(p) for p in packets], np.int32)
+        for s, p in enumerate(packets): buf[s, :len(p)] = np.frombuffer(p, np.uint8)
+        pcm = np.zeros((self.S, frame_size, self.channels), np.int16); ns = np.zeros(self.S, np.int32); rng = np.zeros(self.S, np.uint32)
+        r = self._L.opusgpu_decode_batch(self._b, buf.ctypes.data, stride, lens.ctypes.data, pcm.ctypes.data, frame_size, ns.ctypes.data, rng.ctypes.data)
+        if r != OPUS_OK: raise OpusError(r)
+        return pcm, ns, rng
+    def decode_dev(self, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream=None):
+        r = self._L.opusgpu_decode_batch_dev(self._b, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream)
+        if r != OPUS_OK: raise OpusError(r)
+    def export_state(self, stream):
+        buf = ctypes.create_string_buffer(self._L.opusgpu_dec_state_size())
+        r = self._L.opusgpu_dec_batch_export_state(self._b, stream, buf)
+        if r != OPUS_OK: raise OpusError(r)
+        return buf.raw
+    def import_state(self, stream, blob):
+        r = self._L.opusgpu_dec_batch_import_state(self._b, stream, blob)
+        if r != OPUS_OK: raise OpusError(r)
+    def reset(self):
+        r = self._L.opusgpu_dec_batch_reset(self._b)
+        if r != OPUS_OK: raise OpusError(r)
+    def sync(self): self._L.opusgpu_dec_batch_sync(self._b)
+    def close(self):
+        if getattr(self, "_b", None): self._L.opusgpu_dec_batch_destroy(self._b); self._b = None
     def __del__(self): self.close()

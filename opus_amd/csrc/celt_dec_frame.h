@@ -211,14 +211,13 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       i32 bits = (((i32)len * 8) << BITRES) - (i32)k_ec_tell_frac(EC_PASS) - 1;
       const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
       bits -= anti_collapse_rsv;
-      int intensity = 0, dual_stereo = 0;
-      i32 balance = 0;
-      const int codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, alloc_trim, &intensity, &dual_stereo, bits, &balance,
+      sh->intensity = 0; sh->dual_stereo = 0; sh->balance = 0;
+      const int codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, alloc_trim, &sh->intensity, &sh->dual_stereo, bits, &sh->balance,
             L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 0, 0, 0);
       k_unquant_fine_energy(start, end, L->oldBandE, L->fine_quant, EC_PASS, C);
       sh->silence = silence; sh->postfilter_pitch = postfilter_pitch; sh->postfilter_gain = postfilter_gain; sh->postfilter_tapset = postfilter_tapset;
-      sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision; sh->intensity = intensity; sh->dual_stereo = dual_stereo;
-      sh->anti_collapse_rsv = anti_collapse_rsv; sh->codedBands = codedBands; sh->balance = balance;
+      sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision;
+      sh->anti_collapse_rsv = anti_collapse_rsv; sh->codedBands = codedBands;
       sh->pvq_total_bits = len * (8 << BITRES) - anti_collapse_rsv;
       ec_st(&L->ec, &ec_);
    }

@@ -11,6 +11,7 @@ __device__ unsigned long long oa_phase_ticks[26];
       if ((id) == 15) for (int z_ = 0; z_ < 26; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
 #endif
 #include "celt_enc_all.h"
+#include "celt_dec_all.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
 #include <stdlib.h>
@@ -29,6 +30,16 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data
    OaStream *gs = streams + s;
    const int ch = gs->cfg.channels;
    oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, lens + s, rngs + s);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   const int s = blockIdx.x;
+   if (s >= nstreams) return;
+   oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s);
 }
 
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "opus_amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return OPUS_INTERNAL_ERROR; } } while (0)
@@ -345,6 +356,234 @@ OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset
    return OPUS_OK;
 }
 #endif
-const char *opus_get_version_string(void) { return "opus-amd 0.1 (gfx950, fixed-point bit-exact CELT encoder)"; }
+
+/* ================= decoder (CELT-only packets at 48 kHz) ================= */
+static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
+{
+   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
+   if (Fs != 48000) return OPUS_UNIMPLEMENTED;
+   memset(st, 0, sizeof(*st));
+   st->s.channels = st->s.stream_channels = channels;
+   st->s.frame_size = Fs / 400;                                  /* opus_decoder_init :164 */
+   st->s.start = 0; st->s.end = OA_NB_EBANDS; st->s.disable_inv = channels == 1;   /* celt_decoder_init :244-264 */
+   st->s.skip_plc = 1;
+   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->oldLogE[i] = st->oldLogE2[i] = -(28 << 24);
+   return OPUS_OK;
+}
+struct OpusGpuDecBatch {
+   int device; opus_int32 S; int channels; hipStream_t stream;
+   OaDecStream *d_streams;
+   unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
+};
+int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
+int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
+opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
+void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
+{
+   if (!b) return;
+   (void)hipSetDevice(b->device);
+   if (b->stream) (void)hipStreamSynchronize(b->stream);
+   if (b->d_streams) (void)hipFree(b->d_streams);
+   if (b->d_pkt) (void)hipFree(b->d_pkt);
+   if (b->d_pcm) (void)hipFree(b->d_pcm);
+   if (b->d_lens) (void)hipFree(b->d_lens);
+   if (b->d_ns) (void)hipFree(b->d_ns);
+   if (b->d_rng) (void)hipFree(b->d_rng);
+   if (b->stream) (void)hipStreamDestroy(b->stream);
+   delete b;
+}
+OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int device, int *error)
+{
+   int err = OPUS_OK;
+   OpusGpuDecBatch *b = nullptr;
+   OaDecStream *proto = new OaDecStream;
+   if (nstreams <= 0) err = OPUS_BAD_ARG;
+   if (err == OPUS_OK) err = oa_dec_init_stream(proto, Fs, channels);
+   if (err == OPUS_OK) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+         fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev);
+         err = OPUS_INTERNAL_ERROR;
+      }
+   }
+   if (err == OPUS_OK) {
+      b = new OpusGpuDecBatch();
+      b->device = device; b->S = nstreams; b->channels = channels; b->stream = nullptr; b->d_streams = nullptr;
+      b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
+      std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
+      bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
+                hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      for (opus_int32 s0 = 0; ok && s0 < nstreams; s0 += 256) {
+         opus_int32 n = nstreams - s0 < 256 ? nstreams - s0 : 256;
+         ok = hipMemcpy(b->d_streams + s0, init.data(), sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+      }
+      if (!ok) { opusgpu_dec_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
+   }
+   delete proto;
+   if (error) *error = err;
+   return b;
+}
+int opusgpu_dec_batch_sync(OpusGpuDecBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
+int opusgpu_dec_batch_reset(OpusGpuDecBatch *b)
+{
+   if (!b) return OPUS_BAD_ARG;
+   OaDecStream *proto = new OaDecStream;
+   oa_dec_init_stream(proto, 48000, b->channels);
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   std::vector<OaDecStream> init((size_t)(b->S < 256 ? b->S : 256), *proto);
+   delete proto;
+   for (opus_int32 s0 = 0; s0 < b->S; s0 += 256) {
+      opus_int32 n = b->S - s0 < 256 ? b->S - s0 : 256;
+      HIPCHECK(hipMemcpy(b->d_streams + s0, init.data(), sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice));
+   }
+   return OPUS_OK;
+}
+int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob)
+{
+   if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(blob, b->d_streams + stream, sizeof(OaDecStream), hipMemcpyDeviceToHost));
+   return OPUS_OK;
+}
+int opusgpu_dec_batch_import_state(OpusGpuDecBatch *b, opus_int32 stream, const void *blob)
+{
+   if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   if (((const OaDecStream *)blob)->s.channels != b->channels) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(b->d_streams + stream, blob, sizeof(OaDecStream), hipMemcpyHostToDevice));
+   return OPUS_OK;
+}
+int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, opus_int32 packet_stride, const opus_int32 *d_lens, opus_int16 *d_pcm,
+      int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, void *hip_stream)
+{
+   if (!b || !d_packets || !d_lens || !d_pcm || !d_nsamples || !d_final_range || packet_stride <= 0) return OPUS_BAD_ARG;
+   if (frame_size <= 0 || frame_size > 5760) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(DecLds), s,
+         b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
+         (u32 *)d_final_range, (int)b->S);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_decode_batch(OpusGpuDecBatch *b, const unsigned char *packets, opus_int32 packet_stride, const opus_int32 *lens, opus_int16 *pcm,
+      int frame_size, opus_int32 *nsamples, opus_uint32 *final_range)
+{
+   if (!b || !packets || !lens || !pcm || !nsamples || packet_stride <= 0) return OPUS_BAD_ARG;
+   if (frame_size <= 0 || frame_size > 5760) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   size_t npkt = (size_t)b->S * packet_stride, npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16);
+   if (npkt > b->pkt_cap) { if (b->d_pkt) (void)hipFree(b->d_pkt); HIPCHECK(hipMalloc((void **)&b->d_pkt, npkt)); b->pkt_cap = npkt; }
+   if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
+   HIPCHECK(hipMemcpyAsync(b->d_pkt, packets, npkt, hipMemcpyHostToDevice, b->stream));
+   HIPCHECK(hipMemcpyAsync(b->d_lens, lens, sizeof(opus_int32) * (size_t)b->S, hipMemcpyHostToDevice, b->stream));
+   HIPCHECK(hipMemsetAsync(b->d_pcm, 0, npcm, b->stream));
+   int r = opusgpu_decode_batch_dev(b, b->d_pkt, packet_stride, b->d_lens, b->d_pcm, frame_size, b->d_ns, b->d_rng, nullptr);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpyAsync(pcm, b->d_pcm, npcm, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipMemcpyAsync(nsamples, b->d_ns, sizeof(opus_int32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   return OPUS_OK;
+}
+int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, opus_int32 packet_stride, const opus_int32 *d_lens, opus_int16 *d_pcm,
+      int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, int steps, float *ms)
+{
+   if (!b || !ms || steps <= 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipEvent_t e0, e1;
+   HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+   HIPCHECK(hipEventRecord(e0, b->stream));
+   for (int k = 0; k < steps; k++) {
+      int r = opusgpu_decode_batch_dev(b, d_packets + (size_t)k * b->S * packet_stride, packet_stride, d_lens + (size_t)k * b->S, d_pcm, frame_size, d_nsamples, d_final_range, nullptr);
+      if (r != OPUS_OK) return r;
+   }
+   HIPCHECK(hipEventRecord(e1, b->stream));
+   HIPCHECK(hipEventSynchronize(e1));
+   HIPCHECK(hipEventElapsedTime(ms, e0, e1));
+   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   return OPUS_OK;
+}
+
+/* ---- classic decoder API: flat host blob, batch of one per call (reference src/opus_decoder.c:121 get_size, :135 init, :186 create,
+ *      :890 opus_decode, :1033 ctl, :1246 destroy) ---- */
+#define OA_DEC_MAGIC 0x4f414443u
+struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 pad[2]; OaDecStream s; };
+static std::mutex g_classic_dec_mu;
+static OpusGpuDecBatch *g_classic_dec[2] = {nullptr, nullptr};
+int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
+int opus_decoder_init(OpusDecoder *st, opus_int32 Fs, int channels)
+{
+   if (!st) return OPUS_BAD_ARG;
+   OaDecStream *tmp = new OaDecStream;
+   int r = oa_dec_init_stream(tmp, Fs, channels);
+   if (r == OPUS_OK) { memset(st, 0, sizeof(*st)); st->magic = OA_DEC_MAGIC; st->Fs = Fs; st->s = *tmp; }
+   delete tmp;
+   return r;
+}
+OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error)
+{
+   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) { if (error) *error = OPUS_BAD_ARG; return nullptr; }
+   OpusDecoder *st = (OpusDecoder *)malloc(sizeof(OpusDecoder));
+   if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return nullptr; }
+   int r = opus_decoder_init(st, Fs, channels);
+   if (error) *error = r;
+   if (r != OPUS_OK) { free(st); return nullptr; }
+   return st;
+}
+void opus_decoder_destroy(OpusDecoder *st) { free(st); }
+int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec)
+{
+   if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
+   if (frame_size <= 0 || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG;
+   if ((decode_fec || len == 0 || data == nullptr) && frame_size % (st->Fs / 400) != 0) return OPUS_BAD_ARG;
+   if (len == 0 || data == nullptr || decode_fec) return OPUS_UNIMPLEMENTED;      /* PLC / FEC */
+   if (len < 0) return OPUS_BAD_ARG;
+   if (frame_size > 5760) frame_size = 5760;
+   std::lock_guard<std::mutex> lock(g_classic_dec_mu);
+   const int ci = st->s.s.channels - 1;
+   if (!g_classic_dec[ci]) {
+      int err;
+      g_classic_dec[ci] = opusgpu_dec_batch_create(1, 48000, st->s.s.channels, 0, &err);
+      if (!g_classic_dec[ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   }
+   OpusGpuDecBatch *b = g_classic_dec[ci];
+   std::vector<unsigned char> pkt((size_t)len + 8, 0);
+   memcpy(pkt.data(), data, (size_t)len);
+   std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
+   opus_int32 n = 0, l = len; opus_uint32 rng = 0;
+   int r = opusgpu_dec_batch_import_state(b, 0, &st->s);
+   if (r == OPUS_OK) r = opusgpu_decode_batch(b, pkt.data(), (opus_int32)pkt.size(), &l, out.data(), frame_size, &n, &rng);
+   if (r == OPUS_OK) r = opusgpu_dec_batch_export_state(b, 0, &st->s);
+   if (r != OPUS_OK) return r;
+   if (n > 0) memcpy(pcm, out.data(), (size_t)n * st->s.s.channels * sizeof(opus_int16));
+   return n;
+}
+int opus_decoder_ctl(OpusDecoder *st, int request, ...)
+{
+   if (!st || st->magic != OA_DEC_MAGIC) return OPUS_BAD_ARG;
+   va_list ap;
+   va_start(ap, request);
+   int ret = OPUS_OK;
+   switch (request) {
+   case OPUS_RESET_STATE: { OaDecStream *tmp = new OaDecStream; oa_dec_init_stream(tmp, st->Fs, st->s.s.channels); st->s = *tmp; delete tmp; } break;
+   case OPUS_GET_FINAL_RANGE_REQUEST: { opus_uint32 *p = va_arg(ap, opus_uint32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.rangeFinal; } break;
+   case OPUS_GET_SAMPLE_RATE_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->Fs; } break;
+   case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.bandwidth; } break;
+   case 4039 /* OPUS_GET_LAST_PACKET_DURATION */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.last_packet_duration; } break;
+   case 4033 /* OPUS_GET_PITCH */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.postfilter_period; } break;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else st->s.s.disable_inv = v; } break;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.disable_inv; } break;
+   default: ret = OPUS_UNIMPLEMENTED;
+   }
+   va_end(ap);
+   return ret;
+}
+const char *opus_get_version_string(void) { return "opus-amd 0.2 (gfx950, fixed-point bit-exact CELT encoder + decoder)"; }
 
 } /* extern "C" */
