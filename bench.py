@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode", action="store_true", help="also time the HIP decoder on the packets just produced (extra JSON field, not the headline metric)")
     a = ap.parse_args()
     import torch, torch.distributed as dist
     import opus_amd, signals
@@ -124,6 +125,31 @@ def main():
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1: dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    dec = None
+    if a.decode and world == 1:
+        # decoder leg: re-encode the K timed frames keeping every packet, then decode them with the state carried (device-resident throughout)
+        b.reset()
+        outs = torch.zeros((K + W, S, 1280), dtype=torch.uint8, device=dev); lns = torch.zeros((K + W, S), dtype=torch.int32, device=dev)
+        for t in range(K + W):
+            b.encode_dev(pcm[t].data_ptr(), FR, outs[t].data_ptr(), 1280, lns[t].data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
+        d = opus_amd.DecoderBatch(S, channels=CH, device=local)
+        dpcm = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((S,), dtype=torch.int32, device=dev)
+        for t in range(W): d.decode_dev(outs[t].data_ptr(), 1280, lns[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for t in range(W, W + K): d.decode_dev(outs[t].data_ptr(), 1280, lns[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        dms = e0.elapsed_time(e1) / K
+        dstate = ctypes.CDLL(opus_amd.LIB_PATH).opusgpu_dec_state_size()
+        mean_l = float(lns[W:].float().mean().item())
+        # algorithmic bytes/frame: packet in + PCM out + state touched: scalars/energies (in+out) + overlap (in+out) + N new history samples out (+ history taps read by the post-filter, <= 2*1030 words, not counted)
+        dalg = mean_l + FR * CH * 2 + 2 * (128 + 4 * 168 + 960) + FR * CH * 4
+        dec = {"metric": "decoded frames/s (48 kHz stereo, 20 ms CELT packets)", "value": round(S / (dms * 1e-3), 1), "kernel": "oa_decode_kernel", "kernel_ms": round(dms, 3),
+               "all_frames_ok": bool((dns == FR).all().item()), "state_bytes": dstate, "algorithmic_bytes_per_frame": round(dalg, 1),
+               "roofline": {"bound": "hbm", "achieved": round(S * dalg / (dms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(S * dalg / (dms * 1e-3) / 1e9 / 8000.0, 5)}}
+        d.close()
     lens_h = lens.cpu().numpy()
     ok = bool((lens_h > 2).all())
     mean_len = float(lens_h.mean())
@@ -149,6 +175,7 @@ def main():
                          "kernel": "oa_encode_kernel", "kernel_ms": round(kern_ms, 3), "algorithmic_bytes_per_frame": round(alg_bytes / S, 1),
                          "note": "latency/issue-bound integer codec path: HBM fraction is small by construction (SURVEY.md 8d)"},
         }
+        if dec is not None: res["decode"] = dec
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
