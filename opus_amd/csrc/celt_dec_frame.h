@@ -314,10 +314,14 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       i32 m = st->preemph_memD[lane];
       const WV_LDS i32 *x = L->BC.syn[lane];
       WV_LDS i16 *y = L->A.pcm16;
-      for (int j = 0; j < N; j++) {
-         i32 tmp = saturate(x[j] + m, SIG_SAT);
-         m = mult16_32_q15(27853, tmp);
-         y[j * CC + lane] = sig2word16(tmp);
+      for (int j0 = 0; j0 < N; j0 += 8) {                /* eight reads in flight per trip; only the (add, saturate, multiply) chain is serial */
+         i32 t[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
+#pragma unroll
+         for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
+#pragma unroll
+         for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
       }
       st->preemph_memD[lane] = m;
    }

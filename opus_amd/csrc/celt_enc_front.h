@@ -123,20 +123,30 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    st->first = 0;
 }
 
-/* dc_reject: lanes 0..CC-1 each run one channel's recursion; global int16 PCM in, LDS int16 out (interleaved). */
+/* dc_reject (opus_encoder.c:479): the raw int16 PCM is staged into LDS with coalesced loads, then lanes 0..CC-1 each run one
+ * channel's one-pole recursion in place, eight samples per trip so the LDS reads of a trip are issued back to back and
+ * only the 3-operation chain (mem) is serial. */
 WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int channels)
 {
+   WV_LDS i16 *io = L->A.pcm16;
+   FOR_LANES(i, len * channels) io[i] = pcm[i];
+   wv_sync();
    int c = wv_lane();
    if (c < channels) {
       const int shift = celt_ilog2(48000 / (3 * 4));
       i32 mem = L->st.hp_mem[2 * c];
-      WV_LDS i16 *out = L->A.pcm16;
-      for (int i = 0; i < len; i++) {
-         i32 x = saturate((i32)pcm[channels * i + c], (1 << 16) - 1);
-         x = shl32(x, 14);
-         i32 y = x - mem;
-         mem = mem + pshr32(x - mem, shift);
-         out[channels * i + c] = (i16)saturate(pshr32(y, 14), 32767);
+      for (int i0 = 0; i0 < len; i0 += 8) {           /* len is a multiple of 120 */
+         i32 x[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) x[k] = shl32(saturate((i32)io[channels * (i0 + k) + c], (1 << 16) - 1), 14);
+#pragma unroll
+         for (int k = 0; k < 8; k++) {
+            i32 y = x[k] - mem;
+            mem = mem + pshr32(y, shift);
+            x[k] = saturate(pshr32(y, 14), 32767);
+         }
+#pragma unroll
+         for (int k = 0; k < 8; k++) io[channels * (i0 + k) + c] = (i16)x[k];
       }
       L->st.hp_mem[2 * c] = mem;
    }
@@ -342,12 +352,19 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
    if (lane < C) {
       WV_LDS i16 *tmp = L->BC.x16[lane];
       i32 mem0 = 0, mem1 = 0;
-      for (int i = 0; i < len; i++) {
-         i32 x = tmp[i];
-         i32 y = add32(mem0, x);
-         mem0 = mem1 + y - shl32(x, 1);
-         mem1 = x - (y >> 1);
-         tmp[i] = sround16(y, 2);
+      for (int i0 = 0; i0 < len; i0 += 8) {            /* len = N + 120 is a multiple of 8; eight reads in flight per trip */
+         i32 x[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) x[k] = tmp[i0 + k];
+#pragma unroll
+         for (int k = 0; k < 8; k++) {
+            i32 y = add32(mem0, x[k]);
+            mem0 = mem1 + y - shl32(x[k], 1);
+            mem1 = x[k] - (y >> 1);
+            x[k] = sround16(y, 2);
+         }
+#pragma unroll
+         for (int k = 0; k < 8; k++) tmp[i0 + k] = (i16)x[k];
       }
       for (int i = 0; i < 12; i++) tmp[i] = 0;
    }
@@ -369,17 +386,28 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
       WV_LDS i16 *tmp = L->BC.x16[lane];
       i32 mean = 0, mem0 = 0, norm;
       i16 maxE = 0;
-      for (int i = 0; i < len2; i++) {
-         i32 x2 = pshr32(mult16_16(tmp[2 * i], tmp[2 * i]) + mult16_16(tmp[2 * i + 1], tmp[2 * i + 1]), 4);
-         mean += pshr32(x2, 12);
-         mem0 = mem0 + pshr32(x2 - mem0, forward_shift);
-         tmp[i] = (i16)pshr32(mem0, 12);
+      for (int i0 = 0; i0 < len2; i0 += 4) {           /* len2 is a multiple of 4; the energies are chain-independent */
+         i32 x2[4];
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            i32 a = tmp[2 * (i0 + k)], b = tmp[2 * (i0 + k) + 1];
+            x2[k] = pshr32(mult16_16(a, a) + mult16_16(b, b), 4);
+            mean += pshr32(x2[k], 12);
+         }
+#pragma unroll
+         for (int k = 0; k < 4; k++) { mem0 = mem0 + pshr32(x2[k] - mem0, forward_shift); x2[k] = pshr32(mem0, 12); }
+#pragma unroll
+         for (int k = 0; k < 4; k++) tmp[i0 + k] = (i16)x2[k];
       }
       mem0 = 0;
-      for (int i = len2 - 1; i >= 0; i--) {
-         mem0 = mem0 + pshr32(shl32(tmp[i], 4) - mem0, 3);
-         tmp[i] = (i16)pshr32(mem0, 4);
-         maxE = (i16)imax(maxE, tmp[i]);
+      for (int i0 = len2 - 4; i0 >= 0; i0 -= 4) {
+         i32 t[4];
+#pragma unroll
+         for (int k = 0; k < 4; k++) t[k] = shl32(tmp[i0 + k], 4);
+#pragma unroll
+         for (int k = 3; k >= 0; k--) { mem0 = mem0 + pshr32(t[k] - mem0, 3); t[k] = (i16)pshr32(mem0, 4); maxE = (i16)imax(maxE, t[k]); }
+#pragma unroll
+         for (int k = 0; k < 4; k++) tmp[i0 + k] = (i16)t[k];
       }
       mean = mult16_16(fx_sqrt(mean), fx_sqrt(mult16_16(maxE, len2 >> 1)));
       norm = shl32((i32)len2, 6 + 14) / add32(EPSILON, mean >> 1);
