@@ -13,6 +13,10 @@
 #define OPUS_AMD_CELT_ENC_LDS_H
 
 #define NBE OA_NB_EBANDS
+#ifndef K_TIC            /* shader-clock section timers exist only in the -DOA_PHASE_TIMERS profiling build */
+#define K_TIC()
+#define K_TOC(bucket)
+#endif
 
 struct FrameShared {
    /* frame constants derived by the Opus layer / CELT prologue */
@@ -44,7 +48,7 @@ struct FrameLds {
    i32 scr[6 * NBE];                  /* lane-0 scratch (allocation vectors, dynalloc followers, two-pass energies) */
    i32 aux[32];                       /* MDCT headroom/shift bookkeeping, reductions hand-off */
 #ifdef OA_PHASE_TIMERS
-   u32 prof[26];                      /* shader-clock buckets of the profiling build */
+   u32 prof[34];                      /* shader-clock buckets of the profiling build */
 #endif
    u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* packet[0] = TOC, range coder buffer = packet+1 */

@@ -372,10 +372,14 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       else pitch_index = OA_MIN_PERIOD;
       gain1 = QC16(.75f, 15);
    } else if (enabled && sh->complexity >= 5) {
+      K_TIC();
       pitch_downsample_wave(L, ps0, ps1, (max_period + N) >> 1, CC);
+      K_TOC(25);
       pitch_index = pitch_search_wave(L, N, max_period - 3 * min_period);
+      K_TOC(26);
       pitch_index = max_period - pitch_index;
       gain1 = remove_doubling_wave(L, max_period, min_period, N, &pitch_index, st->prefilter_period, (i16)st->prefilter_gain);
+      K_TOC(27);
       if (pitch_index > max_period - 2) pitch_index = max_period - 2;
       gain1 = (i16)mult16_16_q15(QC16(.7f, 15), gain1);
       if (sh->loss_rate > 2) gain1 = (i16)(gain1 >> 1);
@@ -403,6 +407,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
    }
    const int old_period = imax(st->prefilter_period, OA_MIN_PERIOD), old_tapset = st->prefilter_tapset;
    i32 before[2] = {0, 0}, after[2] = {0, 0};
+   K_TIC();
    wv_sync();
    /* (the head in[c][0..overlap) is in_mem, last frame's *filtered* tail, celt_encoder.c:1546: it stays in HBM) */
    for (int c = 0; c < CC; c++) {
@@ -440,6 +445,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       gain1 = 0; pf_on = 0; qg = 0;
    }
    wv_sync();
+   K_TOC(28);
    /* persistent history: unfiltered [history | new][N .. N+1024) -> prefilter_mem.
     * Every lane first gathers its 16 values (the shift may overlap source and destination), then stores. */
    for (int c = 0; c < CC; c++) {
@@ -450,6 +456,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       for (int t = 0; t < OA_MAX_PERIOD / WV_WIDTH; t++) gst->prefilter_mem[c * OA_MAX_PERIOD + wv_lane() + t * WV_WIDTH] = keep[t];
       wv_sync();
    }
+   K_TOC(29);
    LANE0 {
       st->prefilter_period = old_period;
       sh->pf_on = pf_on; sh->pitch_index = pitch_index; sh->gain1 = gain1; sh->qg = qg; sh->prefilter_tapset = prefilter_tapset;

@@ -331,18 +331,34 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
       if (lane == 0) q[0] += pulsesLeft;
       pulsesLeft = 0;
    }
+   const int nl = NR == 1 ? N : 64;
    for (int i = 0; i < pulsesLeft; i++) {
       int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
       yy = add16(yy, 1);
-      i32 best_num = -1, best_den = 1, best_id = 0x7fffffff;
+      /* per-lane best over its (<= NR) candidates; ties inside a lane go to the lower slot = lower index */
+      u32 num[NR], den[NR];
+      u32 bn = 0, bd = 1;
       for (int t = 0; t < NR; t++) {
+         num[t] = 0; den[t] = 1;
          if (vld[t]) {
             i16 Rxy = extract16(add32(xy, x[t]) >> rshift); i16 Ryy = add16(yy, y[t]); Rxy = (i16)mult16_16_q15(Rxy, Rxy);
-            if (t == 0 || mult16_16(best_den, Rxy) > mult16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = lane + 64 * t; }
+            num[t] = (u32)Rxy; den[t] = (u32)Ryy;
+            if (t == 0 || bd * num[t] > den[t] * bn) { bn = num[t]; bd = den[t]; }
          }
       }
-      wv_argmax_ratio(best_num, best_den, best_id);
-      const int owner = best_id & 63, slot = best_id >> 6;
+      int owner, slot = 0;
+      if (NR == 1) owner = wv_argmax_ratio_packed(bn, bd, vld[0], nl);
+      else {
+         /* global index order is (slot, lane): find the maximal ratio first, then the lowest slot that attains it, then the lowest lane */
+         const int any = wv_argmax_ratio_packed(bn, bd, vld[0], 64);
+         const u32 gn = (u32)wv_bcast((i32)bn, any), gd = (u32)wv_bcast((i32)bd, any);
+         owner = any;
+         for (int t = 0; t < NR; t++) {
+            const bool hit = vld[t] && den[t] * gn == gd * num[t];
+            const unsigned long long m = wv_ballot(hit);
+            if (m) { owner = (int)__builtin_ctzll(m); slot = t; break; }
+         }
+      }
       i32 xs = x[0], ys = y[0];
       for (int t = 1; t < NR; t++) if (slot == t) { xs = x[t]; ys = y[t]; }
       xy = add32(xy, wv_bcast(xs, owner));

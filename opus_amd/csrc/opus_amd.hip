@@ -4,11 +4,11 @@
 #ifdef OA_PHASE_TIMERS
 /* profiling variant: shader-clock ticks per encoder phase, accumulated per wave in LDS (lane 0) and added to the
  * global totals once per frame */
-__device__ unsigned long long oa_phase_ticks[26];
+__device__ unsigned long long oa_phase_ticks[34];
 #define K_TIC() unsigned long long tic_ = clock64()
 #define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); L->prof[b] += (u32)(t_ - tic_); tic_ = t_; } } while (0)
-#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) L->prof[(id) - 1] = (u32)(t_ - oa_phase_t0); else for (int z_ = 0; z_ < 26; z_++) L->prof[z_] = 0; oa_phase_t0 = t_; \
-      if ((id) == 15) for (int z_ = 0; z_ < 26; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
+#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) L->prof[(id) - 1] = (u32)(t_ - oa_phase_t0); else for (int z_ = 0; z_ < 34; z_++) L->prof[z_] = 0; oa_phase_t0 = t_; \
+      if ((id) == 15) for (int z_ = 0; z_ < 34; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
 #endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
@@ -351,8 +351,8 @@ const char *opus_strerror(int error)
 OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset)
 {
    HIPCHECK(hipDeviceSynchronize());
-   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 26));
-   if (reset) { unsigned long long z[26] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
+   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 34));
+   if (reset) { unsigned long long z[34] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
    return OPUS_OK;
 }
 #endif

@@ -111,4 +111,31 @@ WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
    WV_ARGMAX_STEP(WV_DPP_BCAST31, 0xc);
    num = __builtin_amdgcn_readlane(num, 63); den = __builtin_amdgcn_readlane(den, 63); idx = __builtin_amdgcn_readlane(idx, 63);
 }
+/* Same arg-max with (num, den) packed in one register (den in the high half, both 15-bit unsigned) and WITHOUT carrying the index:
+ * the DPP tree finds a maximal ratio, every lane then tests itself against it by exact cross-multiplication and the lowest
+ * matching lane (s_ff1 of the ballot) is the winner -- half the cross-lane traffic and no index tie-break per stage.
+ * `valid` lanes only may win; invalid lanes must pass num = 0, den = 1.  nlanes (uniform) bounds the occupied lanes so that short
+ * bands skip the cross-row stages.  Returns the winning lane. */
+#define WV_ARGMAXP_STEP(ctrl, rmask) do { \
+      uint32_t o = (uint32_t)WV_DPP((int)pk, (int)pk, ctrl, rmask); \
+      uint32_t lhs = (pk >> 16) * (o & 0xffffu), rhs = (o >> 16) * (pk & 0xffffu); \
+      pk = lhs > rhs ? o : pk; } while (0)
+WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nlanes)
+{
+   uint32_t pk = den << 16 | num;
+   const uint32_t mine = pk;
+   WV_ARGMAXP_STEP(WV_DPP_QP_1032, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_QP_2301, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_ROW_ROR4, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_ROW_ROR8, 0xf);
+   uint32_t best;
+   if (nlanes <= 16) best = (uint32_t)__builtin_amdgcn_readlane((int)pk, 0);
+   else {
+      WV_ARGMAXP_STEP(WV_DPP_BCAST15, 0xa);
+      if (nlanes <= 32) best = (uint32_t)__builtin_amdgcn_readlane((int)pk, 31);
+      else { WV_ARGMAXP_STEP(WV_DPP_BCAST31, 0xc); best = (uint32_t)__builtin_amdgcn_readlane((int)pk, 63); }
+   }
+   const bool hit = valid && (mine >> 16) * (best & 0xffffu) == (best >> 16) * (mine & 0xffffu);
+   return (int)__builtin_ctzll(__ballot(hit));
+}
 #endif

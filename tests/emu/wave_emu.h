@@ -74,6 +74,18 @@ WV_DEV int32_t wv_min(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[
 WV_DEV uint32_t wv_or(uint32_t v) { auto t = emu_xchg(v); uint32_t m = 0; for (int i = 0; i < 64; i++) m |= (uint32_t)t[i][0]; return m; }
 WV_DEV uint64_t wv_ballot(int pred) { auto t = emu_xchg(pred != 0); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(t[i][0] != 0) << i; return m; }
 WV_DEV int32_t wv_scan_incl(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; int me = emu_cur->cur; for (int i = 0; i <= me; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
+WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nlanes)
+{
+   /* same contract as the DPP version: maximal num/den by exact cross-multiplication among valid lanes, lowest lane wins ties */
+   auto t = emu_xchg(num, den, valid ? 1 : 0);
+   (void)nlanes;
+   int best = -1;
+   for (int i = 0; i < 64; i++) {
+      if (!t[i][2]) continue;
+      if (best < 0 || (uint64_t)t[best][1] * (uint64_t)t[i][0] > (uint64_t)t[i][1] * (uint64_t)t[best][0]) best = i;
+   }
+   return best;
+}
 WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
 {
    auto t = emu_xchg(num, den, idx);
