@@ -8,7 +8,8 @@
  *    The OpusEncoder blob is flat host memory holding the complete canonical state (memcpy-able, no device
  *    handles: opus.h:108-109); every opus_encode() runs the frame on the GPU as a batch of one.
  *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only path), Fs = 48000,
- *    one 2.5/5/10/20 ms frame per call, VBR/CVBR.  Anything else returns OPUS_UNIMPLEMENTED.
+ *    one 2.5/5/10/20 ms frame per call, VBR / constrained VBR / hard CBR (with code-3 padding).  Anything else returns
+ *    OPUS_UNIMPLEMENTED.
  *
  * 2. The batch API (additive): S independent streams stepped together, one wavefront per
  *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.

@@ -14,8 +14,34 @@
 #define K_PHASE(id)
 #endif
 
+/* Final coalesced packet store.  nbytes of L->packet, or -- hard CBR (pad_to != 0) -- the same frame re-framed as a code-3
+ * packet padded with zeros to exactly pad_to bytes: opus_packet_pad (src/repacketizer.c:346, out_range_impl :112 with pad = 1)
+ * for a single-frame packet: [toc|3][0x01|0x40][255 x n][rest][frame][zeros]. */
+WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to, int out_cap)
+{
+   if (nbytes <= 0) return nbytes;
+   if (pad_to == 0 || nbytes == pad_to) {
+      if (nbytes > out_cap) return -2;
+      FOR_LANES(i, nbytes) out[i] = L->packet[i];
+      return nbytes;
+   }
+   if (nbytes > pad_to) return -3;
+   if (pad_to > out_cap) return -2;
+   const int L0 = nbytes - 1, pad_amount = pad_to - (L0 + 2);
+   const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = 2 + (pad_amount > 0 ? nb_255s + 1 : 0);
+   FOR_LANES(i, pad_to) {
+      u8 v = 0;
+      if (i == 0) v = (u8)((L->packet[0] & 0xFC) | 0x3);
+      else if (i == 1) v = (u8)(1 | (pad_amount != 0 ? 0x40 : 0));
+      else if (i < hdr) v = i < hdr - 1 ? 255 : (u8)(pad_amount - 255 * nb_255s - 1);
+      else if (i < hdr + L0) v = L->packet[1 + i - hdr];
+      out[i] = v;
+   }
+   return pad_to;
+}
+
 WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, i32 *len_out, u32 *rng_out)
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -36,7 +62,8 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
    wv_sync();
    if (sh->plc_frame) {
-      LANE0 { out[0] = L->packet[0]; *len_out = 1; *rng_out = 0; gs->st.s.rangeFinal = 0; }
+      const int n = emit_packet_wave(L, out, 1, sh->pad_to, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; gs->st.s.rangeFinal = 0; }
       return;
    }
    const int CC = sh->CC, C = sh->C;
@@ -60,7 +87,10 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    wv_sync();
    if (sh->skip_celt) {
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
-      LANE0 { out[0] = (u8)sh->toc; out[1] = 0; *len_out = 2; *rng_out = 0; st->rangeFinal = 0; }
+      LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; }
+      wv_sync();
+      const int n = emit_packet_wave(L, out, 2, sh->pad_to, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; st->rangeFinal = 0; }
       return;
    }
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
@@ -337,8 +367,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(14);
    /* ---- store packet + state (coalesced) ---- */
    {
-      const int nbytes = sh->ret;
-      if (nbytes > 0) { FOR_LANES(i, nbytes) out[i] = L->packet[i]; }
+      const int nbytes = emit_packet_wave(L, out, sh->ret, sh->pad_to, out_cap);
       LANE0 { *len_out = nbytes; *rng_out = st->rangeFinal; }
       i32 *g = (i32 *)&gs->st.s;
       const WV_LDS i32 *d = (const WV_LDS i32 *)st;

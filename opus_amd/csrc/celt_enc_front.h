@@ -59,10 +59,26 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
    i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
    int frame_rate = Fs / frame_size;
+   sh->pad_to = 0;
+   if (!cfg->use_vbr) {          /* hard CBR: src/opus_encoder.c:1328-1334; the packet is padded to max_data_bytes at the end (:2646) */
+      i32 cbr_bytes = imin((bitrate_to_bits(bitrate_bps, Fs, frame_size) + 4) / 8, max_data_bytes);
+      bitrate_bps = bits_to_bitrate(cbr_bytes * 8, Fs, frame_size);
+      max_data_bytes = imax(1, cbr_bytes);
+      sh->pad_to = max_data_bytes;
+   }
    if (max_data_bytes < 3 || bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || bitrate_bps < 2400))) {
+      /* st->mode is still its initial MODE_HYBRID until the first coded frame (opus_encoder_init :319), CELT-only afterwards */
+      int tocmode = st->prev_mode == 0 ? 1001 : 1002;
       int bw = st->bandwidth == 0 ? OA_BW_NB : st->bandwidth;
-      if (bw == OA_BW_MB) bw = OA_BW_NB;
-      L->packet[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      if (frame_rate > 100) tocmode = 1002;
+      if (tocmode == 1002 && bw == OA_BW_MB) bw = OA_BW_NB;
+      else if (tocmode == 1001 && bw <= OA_BW_SWB) bw = OA_BW_SWB;
+      if (tocmode == 1002) L->packet[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      else {
+         int period = 0, fr = frame_rate;
+         while (fr < 400) { fr <<= 1; period++; }
+         L->packet[0] = (u8)(0x60 | ((bw - OA_BW_SWB) << 4) | ((period - 2) << 3) | ((st->stream_channels == 2) << 2));
+      }
       sh->plc_frame = 1; sh->ret = 1;
       return;
    }

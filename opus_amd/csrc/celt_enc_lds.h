@@ -23,7 +23,7 @@ struct FrameShared {
    i32 CC, C, LM, M, N, start, end, effEnd, complexity, lsb_depth, vbr, constrained_vbr, disable_inv, disable_pf, force_intra, loss_rate;
    i32 bitrate, curr_bandwidth, toc, max_data_bytes, orig_max_data_bytes, frame_size, do_stereo_fade, fade_g1, fade_g2;
    i32 nbCompressedBytes, nbFilledBytes, nbAvailableBytes, effectiveBytes, vbr_rate, total_bits, equiv_rate, tell, tell0_frac;
-   i32 silence, sample_max, skip_celt, ret, plc_frame;
+   i32 silence, sample_max, skip_celt, ret, plc_frame, pad_to;
    /* analysis results */
    i32 tone_freq, toneishness, isTransient, tf_estimate, tf_chan, weak_transient, shortBlocks, transient_got_disabled, secondMdct;
    i32 pf_on, pitch_index, gain1, qg, prefilter_tapset, pitch_change, pf_enabled, cancel_pitch;

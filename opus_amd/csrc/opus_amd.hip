@@ -29,7 +29,7 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data
    if (s >= nstreams) return;
    OaStream *gs = streams + s;
    const int ch = gs->cfg.channels;
-   oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, lens + s, rngs + s);
+   oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s);
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2)

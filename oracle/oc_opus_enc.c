@@ -109,6 +109,31 @@ static const i32 mono_music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2
 static const i32 stereo_voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000};
 static const i32 stereo_music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};
 
+/* opus_packet_pad (src/repacketizer.c:346 -> opus_repacketizer_out_range_impl :112 with pad = 1) for the only shape this encoder
+ * emits: a code-0 packet [toc][len-1 frame bytes] becomes the code-3 packet [toc|3][0x01 or 0x41][padding length][frame][zeros]. */
+static int packet_pad1(u8 *data, int len, int new_len)
+{
+   if (len < 1) return -1;
+   if (len == new_len) return 0;
+   if (len > new_len) return -1;
+   int L0 = len - 1, tot = L0 + 2;
+   if (tot > new_len) return -2;
+   int pad_amount = new_len - tot, hdr = 2;
+   u8 tmp[1500];
+   memcpy(tmp, data + 1, L0);
+   data[0] = (data[0] & 0xFC) | 0x3;
+   data[1] = 1;
+   if (pad_amount != 0) {
+      int nb_255s = (pad_amount - 1) / 255;
+      data[1] |= 0x40;
+      for (int i = 0; i < nb_255s; i++) data[hdr++] = 255;
+      data[hdr++] = (u8)(pad_amount - 255 * nb_255s - 1);
+   }
+   memcpy(data + hdr, tmp, L0);
+   for (int i = hdr + L0; i < new_len; i++) data[i] = 0;
+   return 0;
+}
+
 int oc_opus_encode(oc_opus_enc *st, const i16 *pcm, int frame_size, u8 *data, int out_data_bytes)
 {
    i16 pcm_buf[2 * 960];
@@ -119,15 +144,30 @@ int oc_opus_encode(oc_opus_enc *st, const i16 *pcm, int frame_size, u8 *data, in
    max_data_bytes = imin(1276 * 6, out_data_bytes);
    st->rangeFinal = 0;
    if (frame_size <= 0 || max_data_bytes <= 0) return -1;
-   if (st->packet_loss_perc != 0 || !st->use_vbr) return -5;   /* loss-aware equiv_rate / CBR padding: not restated */
+   if (st->packet_loss_perc != 0) return -5;   /* loss-aware equiv_rate: not restated */
    st->bitrate_bps = imin(st->user_bitrate_bps == OC_AUTO ? 60 * Fs / frame_size + Fs * st->channels :
          st->user_bitrate_bps == OC_BITRATE_MAX ? 1500000 : st->user_bitrate_bps, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
    frame_rate = Fs / frame_size;
+   if (!st->use_vbr) {          /* hard CBR: src/opus_encoder.c:1328-1334 */
+      i32 cbr_bytes = imin((bitrate_to_bits(st->bitrate_bps, Fs, frame_size) + 4) / 8, max_data_bytes);
+      st->bitrate_bps = bits_to_bitrate(cbr_bytes * 8, Fs, frame_size);
+      max_data_bytes = imax(1, cbr_bytes);
+   }
    if (max_data_bytes < 3 || st->bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || st->bitrate_bps < 2400))) {
-      /* "PLC frame": TOC only (src/opus_encoder.c:1340-1406) */
+      /* "PLC frame": TOC only (src/opus_encoder.c:1340-1406).  st->mode is still its initial MODE_HYBRID until the first coded frame
+       * (opus_encoder_init :319), CELT-only afterwards; 2.5 ms frames are always CELT. */
+      int tocmode = st->prev_mode == 0 ? 1001 : 1002;
       int bw = st->bandwidth == 0 ? OC_BANDWIDTH_NARROWBAND : st->bandwidth;
-      if (bw == OC_BANDWIDTH_MEDIUMBAND) bw = OC_BANDWIDTH_NARROWBAND;
-      data[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      if (frame_rate > 100) tocmode = 1002;
+      if (tocmode == 1002 && bw == OC_BANDWIDTH_MEDIUMBAND) bw = OC_BANDWIDTH_NARROWBAND;
+      else if (tocmode == 1001 && bw <= OC_BANDWIDTH_SUPERWIDEBAND) bw = OC_BANDWIDTH_SUPERWIDEBAND;
+      if (tocmode == 1002) data[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      else {
+         int period = 0, fr = frame_rate;
+         while (fr < 400) { fr <<= 1; period++; }
+         data[0] = (u8)(0x60 | ((bw - OC_BANDWIDTH_SUPERWIDEBAND) << 4) | ((period - 2) << 3) | ((st->stream_channels == 2) << 2));
+      }
+      if (!st->use_vbr) { max_data_bytes = imax(max_data_bytes, 1); return packet_pad1(data, 1, max_data_bytes) == 0 ? max_data_bytes : -3; }
       return 1;
    }
    max_rate = bits_to_bitrate(max_data_bytes * 8, Fs, frame_size);
@@ -223,5 +263,9 @@ int oc_opus_encode(oc_opus_enc *st, const i16 *pcm, int frame_size, u8 *data, in
       st->rangeFinal = 0;
    }
    ret += 1;
+   if (!st->use_vbr) {          /* apply_padding, src/opus_encoder.c:2602/:2646 */
+      if (packet_pad1(data, ret, orig_max_data_bytes) != 0) return -3;
+      ret = orig_max_data_bytes;
+   }
    return ret;
 }

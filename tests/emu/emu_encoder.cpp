@@ -17,7 +17,7 @@ struct Job { FrameLds *L; OaStream *gs; const int16_t *pcm; int frame_size, max_
 static void job_entry(void *p)
 {
    Job *j = (Job *)p;
-   oa_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->len, j->rng);
+   oa_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, 1 << 20, j->len, j->rng);
 }
 extern "C" int emu_sizeof_stream() { return (int)sizeof(OaStream); }
 extern "C" int emu_sizeof_lds() { return (int)sizeof(FrameLds); }

@@ -102,6 +102,27 @@ def test_gpu_classic_api_and_state_contract():
         assert a[0] == pk[1] and a[2] == int(rng[1])
     b.close()
 
+@pytest.mark.parametrize("channels,bitrate,frame", [(2, 128000, 960), (2, 64000, 480), (1, 32000, 960), (2, 6000, 960), (1, 500, 960), (2, 510000, 960)])
+def test_gpu_hard_cbr(channels, bitrate, frame):
+    """OPUS_SET_VBR(0): constant packet size, code-3 padding where the coder comes up short, TOC-only packets below the useful minimum"""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    S = 6
+    b = oa.EncoderBatch(S, channels=channels)
+    b.ctl(oa.OPUS_SET_BITRATE_REQUEST, bitrate); b.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 10); b.ctl(oa.OPUS_SET_VBR_REQUEST, 0)
+    chk = [OracleEnc(channels, bitrate=bitrate, complexity=10, vbr=0) for _ in range(S)]
+    sigs = [signals.music(10, channels=channels, seed=300 + s) for s in range(S)]
+    sizes = set()
+    for i in range(10 * 960 // frame):
+        pcm = np.stack([np.ascontiguousarray(sigs[s][i * frame:(i + 1) * frame]).reshape(-1) for s in range(S)])
+        pk, lens, rng = b.encode(pcm, frame)
+        for s in range(S):
+            a = chk[s].encode(np.ascontiguousarray(sigs[s][i * frame:(i + 1) * frame]), frame)
+            assert (a[0], a[1], a[2]) == (pk[s], int(lens[s]), int(rng[s])), (i, s, a[1], int(lens[s]))
+            sizes.add(int(lens[s]))
+    assert len(sizes) == 1
+    b.close()
+
 def test_gpu_full_size_properties():
     """BASELINE size (65,536 streams): size-independent properties — identical inputs give identical packets on every
     wavefront; a sampled subset matches the oracle; every packet decodes with matching final range is checked on the subset

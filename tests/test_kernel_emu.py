@@ -57,3 +57,8 @@ def test_emu_ctls():
     _run(2, signals.music(24, seed=4), 960, 24, bitrate=96000, complexity=10, force_channels=1)
     _run(2, signals.music(24, seed=5), 960, 24, bitrate=64000, complexity=10, user_bandwidth=1103)
     _run(2, signals.music(24, seed=6), 960, 24, bitrate=64000, complexity=10, max_bandwidth=1104, disable_inv=1)
+
+
+@pytest.mark.parametrize("channels,bitrate,frame", [(2, 128000, 960), (2, 64000, 480), (1, 32000, 960), (2, 6000, 960), (1, 500, 960)])
+def test_emu_hard_cbr(channels, bitrate, frame):
+    _run(channels, signals.music(8, channels=channels, seed=31), frame, 8 * 960 // frame, bitrate=bitrate, complexity=10, use_vbr=0)

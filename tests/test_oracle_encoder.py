@@ -32,7 +32,7 @@ class OracleEnc:
         O = self.O = oracle()
         self.buf = ctypes.create_string_buffer(O.oc_opus_enc_size())
         assert O.oc_opus_enc_init(self.buf, 48000, channels, application) == 0
-        what = dict(bitrate=0, complexity=1, vbr=2, vbr_constraint=3, force_channels=4, bandwidth=5, user_bandwidth=5, max_bandwidth=6, lsb_depth=7, phase_inv_disabled=8, disable_inv=8)
+        what = dict(bitrate=0, complexity=1, vbr=2, use_vbr=2, vbr_constraint=3, force_channels=4, bandwidth=5, user_bandwidth=5, max_bandwidth=6, lsb_depth=7, phase_inv_disabled=8, disable_inv=8)
         for k, v in ctl.items(): assert O.oc_opus_enc_set(self.buf, what[k], v) == 0
         self.out = (ctypes.c_ubyte * 1500)()
         O.oc_opus_enc_final_range.restype = ctypes.c_uint32
@@ -72,3 +72,18 @@ def test_unconstrained_vbr_and_ctls():
     _run(2, signals.music(80, seed=4), 960, 80, bitrate=96000, complexity=10, force_channels=1)
     _run(2, signals.music(80, seed=5), 960, 80, bitrate=64000, complexity=10, bandwidth=1103)
     _run(2, signals.music(80, seed=6), 960, 80, bitrate=64000, complexity=10, max_bandwidth=1104, phase_inv_disabled=1)
+
+
+@pytest.mark.parametrize("channels,bitrate,frame,maxb", [(2, 128000, 960, 1276), (2, 64000, 480, 1276), (1, 32000, 960, 1276), (2, 510000, 960, 1276),
+                                                         (2, 96000, 960, 200), (2, 6000, 960, 1276), (2, 256000, 120, 1276), (1, 500, 960, 1276)])
+def test_hard_cbr(channels, bitrate, frame, maxb):
+    """OPUS_SET_VBR(0): cbr_bytes budget (opus_encoder.c:1328), CELT CBR allocation, code-3 padding of short / TOC-only packets"""
+    sig = signals.music(12, channels=channels, seed=31)
+    r = RefEnc(channels, bitrate=bitrate, complexity=10, vbr=0); o = OracleEnc(channels, bitrate=bitrate, complexity=10, vbr=0)
+    sizes = set()
+    for i in range(12 * 960 // frame):
+        pcm = np.ascontiguousarray(sig[i * frame:(i + 1) * frame])
+        a = r.encode(pcm, frame, maxb); b = o.encode(pcm, frame, maxb)
+        assert a == b, (i, a[1], b[1], hex(a[2]), hex(b[2]))
+        sizes.add(a[1])
+    assert len(sizes) == 1            # constant bitrate: every packet has the same size
