@@ -156,6 +156,29 @@ OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int3
 OPUS_AMD_EXPORT int opusgpu_dec_batch_import_state(OpusGpuDecBatch *b, opus_int32 stream, const void *blob);
 OPUS_AMD_EXPORT int opusgpu_dec_kernel_lds_bytes(void);
 
+/* ================= packet toolkit (host-side; reference/include/opus.h:713-788 and :953-1167) =================
+ * Same names, arguments and results as the reference (src/opus.c:203-399, src/opus_decoder.c:1252-1340, src/repacketizer.c).
+ * Extension payloads carried in code-3 padding are not interpreted (dropped on re-assembly). */
+typedef struct OpusRepacketizer OpusRepacketizer;
+OPUS_AMD_EXPORT int opus_packet_parse(const unsigned char *data, opus_int32 len, unsigned char *out_toc, const unsigned char *frames[48], opus_int16 size[48], int *payload_offset);
+OPUS_AMD_EXPORT int opus_packet_get_bandwidth(const unsigned char *data);
+OPUS_AMD_EXPORT int opus_packet_get_samples_per_frame(const unsigned char *data, opus_int32 Fs);
+OPUS_AMD_EXPORT int opus_packet_get_nb_channels(const unsigned char *data);
+OPUS_AMD_EXPORT int opus_packet_get_nb_frames(const unsigned char packet[], opus_int32 len);
+OPUS_AMD_EXPORT int opus_packet_get_nb_samples(const unsigned char packet[], opus_int32 len, opus_int32 Fs);
+OPUS_AMD_EXPORT int opus_repacketizer_get_size(void);
+OPUS_AMD_EXPORT OpusRepacketizer *opus_repacketizer_init(OpusRepacketizer *rp);
+OPUS_AMD_EXPORT OpusRepacketizer *opus_repacketizer_create(void);
+OPUS_AMD_EXPORT void opus_repacketizer_destroy(OpusRepacketizer *rp);
+OPUS_AMD_EXPORT int opus_repacketizer_cat(OpusRepacketizer *rp, const unsigned char *data, opus_int32 len);
+OPUS_AMD_EXPORT opus_int32 opus_repacketizer_out_range(OpusRepacketizer *rp, int begin, int end, unsigned char *data, opus_int32 maxlen);
+OPUS_AMD_EXPORT int opus_repacketizer_get_nb_frames(OpusRepacketizer *rp);
+OPUS_AMD_EXPORT opus_int32 opus_repacketizer_out(OpusRepacketizer *rp, unsigned char *data, opus_int32 maxlen);
+OPUS_AMD_EXPORT int opus_packet_pad(unsigned char *data, opus_int32 len, opus_int32 new_len);
+OPUS_AMD_EXPORT opus_int32 opus_packet_unpad(unsigned char *data, opus_int32 len);
+OPUS_AMD_EXPORT int opus_multistream_packet_pad(unsigned char *data, opus_int32 len, opus_int32 new_len, int nb_streams);
+OPUS_AMD_EXPORT opus_int32 opus_multistream_packet_unpad(unsigned char *data, opus_int32 len, int nb_streams);
+
 #ifdef __cplusplus
 }
 #endif

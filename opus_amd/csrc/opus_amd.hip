@@ -42,6 +42,8 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
    oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s);
 }
 
+#include "opus_packet_host.h"
+
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "opus_amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return OPUS_INTERNAL_ERROR; } } while (0)
 
 /* ---------------- host-side state initialisation / ctl (mirrors opus_encoder_init :204 and opus_encoder_ctl :2772) ---------------- */
