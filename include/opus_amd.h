@@ -179,6 +179,29 @@ OPUS_AMD_EXPORT opus_int32 opus_packet_unpad(unsigned char *data, opus_int32 len
 OPUS_AMD_EXPORT int opus_multistream_packet_pad(unsigned char *data, opus_int32 len, opus_int32 new_len, int nb_streams);
 OPUS_AMD_EXPORT opus_int32 opus_multistream_packet_unpad(unsigned char *data, opus_int32 len, int nb_streams);
 
+/* ================= multistream (reference/include/opus_multistream.h:203-726) =================
+ * One multistream frame = its streams stepped together by the batch kernels (one launch per group: coupled, mono).  Same names,
+ * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: CELT-only applications at 48 kHz, frames <= 20 ms,
+ * mapping families 0, 2 (ambisonics) and 255, family 1 up to two channels; int16 entry points.  Family-1 surround (> 2 channels,
+ * needs the masking analysis), float / 24-bit entry points, PLC and FEC return OPUS_UNIMPLEMENTED. */
+typedef struct OpusMSEncoder OpusMSEncoder;
+typedef struct OpusMSDecoder OpusMSDecoder;
+OPUS_AMD_EXPORT opus_int32 opus_multistream_encoder_get_size(int streams, int coupled_streams);
+OPUS_AMD_EXPORT opus_int32 opus_multistream_surround_encoder_get_size(int channels, int mapping_family);
+OPUS_AMD_EXPORT OpusMSEncoder *opus_multistream_encoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application, int *error);
+OPUS_AMD_EXPORT OpusMSEncoder *opus_multistream_surround_encoder_create(opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application, int *error);
+OPUS_AMD_EXPORT int opus_multistream_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application);
+OPUS_AMD_EXPORT int opus_multistream_surround_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application);
+OPUS_AMD_EXPORT int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT void opus_multistream_encoder_destroy(OpusMSEncoder *st);
+OPUS_AMD_EXPORT int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...);
+OPUS_AMD_EXPORT opus_int32 opus_multistream_decoder_get_size(int streams, int coupled_streams);
+OPUS_AMD_EXPORT OpusMSDecoder *opus_multistream_decoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int *error);
+OPUS_AMD_EXPORT int opus_multistream_decoder_init(OpusMSDecoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping);
+OPUS_AMD_EXPORT int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...);
+OPUS_AMD_EXPORT void opus_multistream_decoder_destroy(OpusMSDecoder *st);
+
 #ifdef __cplusplus
 }
 #endif

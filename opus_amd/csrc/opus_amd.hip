@@ -586,6 +586,9 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
    va_end(ap);
    return ret;
 }
+} /* extern "C" */
+#include "opus_ms_host.h"
+extern "C" {
 const char *opus_get_version_string(void) { return "opus-amd 0.2 (gfx950, fixed-point bit-exact CELT encoder + decoder)"; }
 
 } /* extern "C" */

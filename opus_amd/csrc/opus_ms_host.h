@@ -1,0 +1,492 @@
+/* opus_ms_host.h — libopus multistream API (reference include/opus_multistream.h, src/opus_multistream.c,
+ * src/opus_multistream_encoder.c, src/opus_multistream_decoder.c) on top of the batch kernels: the streams of one multistream
+ * frame are independent CELT encodes / decodes, so ONE launch per group (coupled streams, mono streams) does a whole frame of up to
+ * 255 channels.  Host code only orchestrates: layout, rate allocation, channel (de)interleaving, self-delimited packing.
+ * Scope: CELT-only applications (restricted-lowdelay / restricted-celt) at 48 kHz, frames <= 20 ms, mapping families 0, 2, 255 and
+ * family 1 up to two channels (the surround masking analysis of family 1 with > 2 channels is not built -> OPUS_UNIMPLEMENTED). */
+#ifndef OPUS_AMD_MS_HOST_H
+#define OPUS_AMD_MS_HOST_H
+#include <map>
+
+struct OaLayout { int nb_channels, nb_streams, nb_coupled_streams; unsigned char mapping[256]; };
+static int oa_validate_layout(const OaLayout *l)                       /* opus_multistream.c:40 */
+{
+   int max_channel = l->nb_streams + l->nb_coupled_streams;
+   if (max_channel > 255) return 0;
+   for (int i = 0; i < l->nb_channels; i++) if (l->mapping[i] >= max_channel && l->mapping[i] != 255) return 0;
+   return 1;
+}
+static int oa_get_left(const OaLayout *l, int s, int prev) { for (int i = prev < 0 ? 0 : prev + 1; i < l->nb_channels; i++) if (l->mapping[i] == s * 2) return i; return -1; }
+static int oa_get_right(const OaLayout *l, int s, int prev) { for (int i = prev < 0 ? 0 : prev + 1; i < l->nb_channels; i++) if (l->mapping[i] == s * 2 + 1) return i; return -1; }
+static int oa_get_mono(const OaLayout *l, int s, int prev) { for (int i = prev < 0 ? 0 : prev + 1; i < l->nb_channels; i++) if (l->mapping[i] == s + l->nb_coupled_streams) return i; return -1; }
+static int oa_validate_encoder_layout(const OaLayout *l)               /* opus_multistream_encoder.c:133 */
+{
+   for (int s = 0; s < l->nb_streams; s++) {
+      if (s < l->nb_coupled_streams) { if (oa_get_left(l, s, -1) == -1 || oa_get_right(l, s, -1) == -1) return 0; }
+      else if (oa_get_mono(l, s, -1) == -1) return 0;
+   }
+   return 1;
+}
+static unsigned oa_isqrt32(opus_uint32 v) { unsigned g = 0, b = 0x8000; while (b) { unsigned t = g | b; if ((opus_uint32)t * t <= v) g = t; b >>= 1; } return g; }
+static int oa_validate_ambisonics(int nb_channels, int *nb_streams, int *nb_coupled)   /* opus_multistream_encoder.c:110 */
+{
+   if (nb_channels < 1 || nb_channels > 227) return 0;
+   int order_plus_one = (int)oa_isqrt32((opus_uint32)nb_channels), acn = order_plus_one * order_plus_one, nd = nb_channels - acn;
+   if (nd != 0 && nd != 2) return 0;
+   if (nb_streams) *nb_streams = acn + (nd != 0);
+   if (nb_coupled) *nb_coupled = nd != 0;
+   return 1;
+}
+
+/* process-wide batches, one per (stream count, channels) */
+static std::mutex g_ms_mu;
+static std::map<long, OpusGpuEncBatch *> g_ms_enc;
+static std::map<long, OpusGpuDecBatch *> g_ms_dec;
+static OpusGpuEncBatch *oa_ms_enc_batch(int n, int channels, int application, int *err)
+{
+   long key = (long)n * 4 + channels;
+   auto it = g_ms_enc.find(key);
+   if (it != g_ms_enc.end()) return it->second;
+   OpusGpuEncBatch *b = opusgpu_enc_batch_create(n, 48000, channels, application, 0, err);
+   if (b) g_ms_enc[key] = b;
+   return b;
+}
+static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, int *err)
+{
+   long key = (long)n * 4 + channels;
+   auto it = g_ms_dec.find(key);
+   if (it != g_ms_dec.end()) return it->second;
+   OpusGpuDecBatch *b = opusgpu_dec_batch_create(n, 48000, channels, 0, err);
+   if (b) g_ms_dec[key] = b;
+   return b;
+}
+
+#define OA_MS_MAGIC 0x4f414d53u
+enum { OA_MAP_NONE = 0, OA_MAP_SURROUND = 1, OA_MAP_AMBISONICS = 2 };
+struct OpusMSEncoder {
+   opus_uint32 magic; opus_int32 Fs, application, bitrate_bps, mapping_type, lfe_stream;
+   OaLayout layout;
+   opus_int32 pad[2];
+   OaStream streams[1];            /* nb_streams records: coupled streams first, then mono (flat, memcpy-able) */
+};
+struct OpusMSDecoder {
+   opus_uint32 magic; opus_int32 Fs;
+   OaLayout layout;
+   opus_int32 pad[2];
+   OaDecStream streams[1];
+};
+#define OA_MS_FRAME_TMP (6 * 1275 + 12)
+
+extern "C" {
+opus_int32 opus_multistream_encoder_get_size(int nb_streams, int nb_coupled_streams)
+{
+   if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;
+   return (opus_int32)(sizeof(OpusMSEncoder) + (size_t)(nb_streams - 1) * sizeof(OaStream));
+}
+static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application, int mapping_type, int lfe_stream)
+{
+   if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams || streams + coupled_streams > channels)
+      return OPUS_BAD_ARG;
+   OaStream probe;
+   int r = oa_init_stream(&probe, Fs, 2, application);
+   if (r != OPUS_OK) return r;
+   if (mapping_type == OA_MAP_SURROUND) return OPUS_UNIMPLEMENTED;
+   memset(st, 0, sizeof(OpusMSEncoder) - sizeof(OaStream));
+   st->magic = OA_MS_MAGIC; st->Fs = Fs; st->application = application; st->bitrate_bps = OPUS_AUTO; st->mapping_type = mapping_type; st->lfe_stream = lfe_stream;
+   st->layout.nb_channels = channels; st->layout.nb_streams = streams; st->layout.nb_coupled_streams = coupled_streams;
+   for (int i = 0; i < channels; i++) st->layout.mapping[i] = mapping[i];
+   if (!oa_validate_layout(&st->layout) || !oa_validate_encoder_layout(&st->layout)) return OPUS_BAD_ARG;
+   if (mapping_type == OA_MAP_AMBISONICS && !oa_validate_ambisonics(channels, NULL, NULL)) return OPUS_BAD_ARG;
+   for (int s = 0; s < streams; s++) {
+      r = oa_init_stream(&st->streams[s], Fs, s < coupled_streams ? 2 : 1, application);
+      if (r != OPUS_OK) return r;
+   }
+   return OPUS_OK;
+}
+int opus_multistream_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application)
+{
+   if (!st || !mapping) return OPUS_BAD_ARG;
+   return oa_ms_encoder_init_impl(st, Fs, channels, streams, coupled_streams, mapping, application, OA_MAP_NONE, -1);
+}
+OpusMSEncoder *opus_multistream_encoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application, int *error)
+{
+   if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams || streams + coupled_streams > channels || !mapping) {
+      if (error) *error = OPUS_BAD_ARG;
+      return NULL;
+   }
+   OpusMSEncoder *st = (OpusMSEncoder *)malloc((size_t)opus_multistream_encoder_get_size(streams, coupled_streams));
+   if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return NULL; }
+   int r = opus_multistream_encoder_init(st, Fs, channels, streams, coupled_streams, mapping, application);
+   if (error) *error = r;
+   if (r != OPUS_OK) { free(st); return NULL; }
+   return st;
+}
+static int oa_surround_layout(int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int *mapping_type)
+{
+   if (channels > 255 || channels < 1) return OPUS_BAD_ARG;
+   if (mapping_family == 0) {
+      if (channels == 1) { *streams = 1; *coupled_streams = 0; mapping[0] = 0; }
+      else if (channels == 2) { *streams = 1; *coupled_streams = 1; mapping[0] = 0; mapping[1] = 1; }
+      else return OPUS_UNIMPLEMENTED;
+   } else if (mapping_family == 1 && channels <= 8 && channels >= 1) {
+      if (channels == 1) { *streams = 1; *coupled_streams = 0; mapping[0] = 0; }
+      else if (channels == 2) { *streams = 1; *coupled_streams = 1; mapping[0] = 0; mapping[1] = 1; }
+      else return OPUS_UNIMPLEMENTED;       /* vorbis layouts with surround masking analysis: not built */
+   } else if (mapping_family == 255) {
+      *streams = channels; *coupled_streams = 0;
+      for (int i = 0; i < channels; i++) mapping[i] = (unsigned char)i;
+   } else if (mapping_family == 2) {
+      if (!oa_validate_ambisonics(channels, streams, coupled_streams)) return OPUS_BAD_ARG;
+      for (int i = 0; i < (*streams - *coupled_streams); i++) mapping[i] = (unsigned char)(i + (*coupled_streams * 2));
+      for (int i = 0; i < *coupled_streams * 2; i++) mapping[i + (*streams - *coupled_streams)] = (unsigned char)i;
+   } else return OPUS_UNIMPLEMENTED;
+   *mapping_type = mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE;
+   return OPUS_OK;
+}
+opus_int32 opus_multistream_surround_encoder_get_size(int channels, int mapping_family)
+{
+   int streams, coupled, mt; unsigned char mapping[256];
+   if (oa_surround_layout(channels, mapping_family, &streams, &coupled, mapping, &mt) != OPUS_OK) return 0;
+   return opus_multistream_encoder_get_size(streams, coupled);
+}
+int opus_multistream_surround_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application)
+{
+   int mt;
+   if (!st || !streams || !coupled_streams || !mapping) return OPUS_BAD_ARG;
+   int r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt);
+   if (r != OPUS_OK) return r;
+   return oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, -1);
+}
+OpusMSEncoder *opus_multistream_surround_encoder_create(opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application, int *error)
+{
+   int mt, r;
+   if (!streams || !coupled_streams || !mapping) { if (error) *error = OPUS_BAD_ARG; return NULL; }
+   r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt);
+   if (r != OPUS_OK) { if (error) *error = r; return NULL; }
+   OpusMSEncoder *st = (OpusMSEncoder *)malloc((size_t)opus_multistream_encoder_get_size(*streams, *coupled_streams));
+   if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return NULL; }
+   r = oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, -1);
+   if (error) *error = r;
+   if (r != OPUS_OK) { free(st); return NULL; }
+   return st;
+}
+void opus_multistream_encoder_destroy(OpusMSEncoder *st) { free(st); }
+
+/* surround_rate_allocation / ambisonics_rate_allocation / rate_allocation, opus_multistream_encoder.c:702-832 */
+static opus_int32 oa_ms_rate_allocation(const OpusMSEncoder *st, opus_int32 *rate, int frame_size)
+{
+   const opus_int32 Fs = st->Fs;
+   const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams;
+   if (st->mapping_type == OA_MAP_AMBISONICS) {
+      opus_int32 total_rate;
+      const int nb_channels = ns + nc;
+      if (st->bitrate_bps == OPUS_AUTO) total_rate = (nc + ns) * (Fs + 60 * Fs / frame_size) + ns * (opus_int32)15000;
+      else if (st->bitrate_bps == OPUS_BITRATE_MAX) total_rate = nb_channels * 750000;
+      else total_rate = st->bitrate_bps;
+      for (int i = 0; i < ns; i++) rate[i] = total_rate / ns;
+   } else {
+      const int nb_lfe = st->lfe_stream != -1, nb_uncoupled = ns - nc - nb_lfe, nb_normal = 2 * nc + nb_uncoupled;
+      opus_int32 channel_offset = 40 * (50 > Fs / frame_size ? 50 : Fs / frame_size), bitrate;
+      if (st->bitrate_bps == OPUS_AUTO) bitrate = nb_normal * (channel_offset + Fs + 10000) + 8000 * nb_lfe;
+      else if (st->bitrate_bps == OPUS_BITRATE_MAX) bitrate = nb_normal * 750000 + nb_lfe * 128000;
+      else bitrate = st->bitrate_bps;
+      int lfe_offset = (bitrate / 20 < 3000 ? bitrate / 20 : 3000) + 15 * (50 > Fs / frame_size ? 50 : Fs / frame_size);
+      int stream_offset = (bitrate - channel_offset * nb_normal - lfe_offset * nb_lfe) / nb_normal / 2;
+      stream_offset = stream_offset < 0 ? 0 : (stream_offset > 20000 ? 20000 : stream_offset);
+      const int coupled_ratio = 512, lfe_ratio = 32;
+      int total = (nb_uncoupled << 8) + coupled_ratio * nc + nb_lfe * lfe_ratio;
+      opus_int32 channel_rate = (opus_int32)(256 * (long long)(bitrate - lfe_offset * nb_lfe - stream_offset * (nc + nb_uncoupled) - channel_offset * nb_normal) / total);
+      for (int i = 0; i < ns; i++) {
+         opus_int32 r;
+         if (i < nc) { r = stream_offset + (channel_rate * coupled_ratio >> 8); rate[i] = 2 * channel_offset + (r > 0 ? r : 0); }
+         else if (i != st->lfe_stream) { r = stream_offset + channel_rate; rate[i] = channel_offset + (r > 0 ? r : 0); }
+         else { r = lfe_offset + (channel_rate * lfe_ratio >> 8); rate[i] = r > 0 ? r : 0; }
+      }
+   }
+   opus_int32 rate_sum = 0;
+   for (int i = 0; i < ns; i++) { if (rate[i] < 500) rate[i] = 500; rate_sum += rate[i]; }
+   return rate_sum;
+}
+
+/* encode n streams of one group (all `ch`-channel) in one launch; states are loaded from / stored back to the flat blob */
+static int oa_ms_encode_group(OaStream *states, int n, int ch, int application, const opus_int16 *pcm, int frame_size, opus_int32 max_data_bytes,
+      unsigned char *out /* [n][1280] */, opus_int32 *lens, opus_uint32 *rngs)
+{
+   int err = OPUS_OK;
+   OpusGpuEncBatch *b = oa_ms_enc_batch(n, ch, application, &err);
+   if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(b->d_streams, states, sizeof(OaStream) * (size_t)n, hipMemcpyHostToDevice));
+   int r = opusgpu_encode_batch(b, pcm, frame_size, out, 1280, max_data_bytes, lens, rngs);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpy(states, b->d_streams, sizeof(OaStream) * (size_t)n, hipMemcpyDeviceToHost));
+   return OPUS_OK;
+}
+
+/* opus_multistream_encode_native, opus_multistream_encoder.c:841 (int16 input) */
+int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   if (!st || st->magic != OA_MS_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
+   const opus_int32 Fs = st->Fs;
+   const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
+   if (frame_size < Fs / 400) return OPUS_BAD_ARG;
+   if (400 * frame_size != Fs && 200 * frame_size != Fs && 100 * frame_size != Fs && 50 * frame_size != Fs) {
+      if (25 * frame_size == Fs || 50 * frame_size == 3 * Fs || 50 * frame_size == 4 * Fs || 50 * frame_size == 5 * Fs || 50 * frame_size == 6 * Fs) return OPUS_UNIMPLEMENTED;
+      return OPUS_BAD_ARG;
+   }
+   const int vbr = st->streams[0].cfg.use_vbr;
+   opus_int32 smallest_packet = ns * 2 - 1;
+   if (Fs / frame_size == 10) smallest_packet += ns;
+   if (max_data_bytes < smallest_packet) return OPUS_BUFFER_TOO_SMALL;
+   std::lock_guard<std::mutex> lock(g_ms_mu);
+   std::vector<opus_int32> bitrates((size_t)ns);
+   opus_int32 rate_sum = oa_ms_rate_allocation(st, bitrates.data(), frame_size);
+   if (!vbr) {
+      if (st->bitrate_bps == OPUS_AUTO) { opus_int32 m = (rate_sum * 6 / (6 * Fs / frame_size) + 4) / 8; if (m < max_data_bytes) max_data_bytes = m; }
+      else if (st->bitrate_bps != OPUS_BITRATE_MAX) {
+         opus_int32 m = (st->bitrate_bps * 6 / (6 * Fs / frame_size) + 4) / 8;
+         if (m < smallest_packet) m = smallest_packet;
+         if (m < max_data_bytes) max_data_bytes = m;
+      }
+   }
+   for (int s = 0; s < ns; s++) st->streams[s].cfg.user_bitrate_bps = bitrates[s];
+   /* channel de-interleave into the two groups */
+   std::vector<opus_int16> pc((size_t)nc * frame_size * 2 + 2), pm((size_t)nm * frame_size + 1);
+   for (int s = 0; s < nc; s++) {
+      int l = oa_get_left(&st->layout, s, -1), r = oa_get_right(&st->layout, s, -1);
+      opus_int16 *d = pc.data() + (size_t)s * frame_size * 2;
+      for (int i = 0; i < frame_size; i++) { d[2 * i] = pcm[(size_t)i * nch + l]; d[2 * i + 1] = pcm[(size_t)i * nch + r]; }
+   }
+   for (int s = 0; s < nm; s++) {
+      int c = oa_get_mono(&st->layout, nc + s, -1);
+      opus_int16 *d = pm.data() + (size_t)s * frame_size;
+      for (int i = 0; i < frame_size; i++) d[i] = pcm[(size_t)i * nch + c];
+   }
+   std::vector<unsigned char> pk((size_t)ns * 1280);
+   std::vector<opus_int32> lens((size_t)ns);
+   std::vector<opus_uint32> rngs((size_t)ns);
+   /* The byte budget handed to stream s is max_data_bytes minus what the previous streams used (:1016-1026).  When the caller's buffer is so
+    * generous that every stream would be offered at least the encoder's own cap, the budgets are identical and all streams of a group go in
+    * ONE launch; otherwise (tight buffer, or hard CBR where the last stream absorbs the remainder) the streams are stepped in order. */
+   const long long worst = (long long)(ns - 1) * (1275 + 1 + 2) + OA_MS_FRAME_TMP + 2 * ns + 8;
+   const bool parallel = vbr && max_data_bytes >= worst;
+   int r = OPUS_OK;
+   opus_int32 tot_size = 0;
+   unsigned char *out = data;
+   if (parallel) {
+      if (nc) r = oa_ms_encode_group(st->streams, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), lens.data(), rngs.data());
+      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * 1280, lens.data() + nc, rngs.data() + nc);
+      if (r != OPUS_OK) return r;
+   }
+   for (int s = 0; s < ns; s++) {
+      OpusRepacketizer rp;
+      opus_repacketizer_init(&rp);
+      if (!parallel) {
+         opus_int32 curr_max = max_data_bytes - tot_size;
+         int resv = 2 * (ns - s - 1) - 1;
+         curr_max -= resv > 0 ? resv : 0;
+         if (Fs / frame_size == 10) curr_max -= ns - s - 1;
+         if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
+         if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
+         if (!vbr && s == ns - 1) st->streams[s].cfg.user_bitrate_bps = curr_max * 8 * (6 * Fs / frame_size) / 6;
+         if (curr_max <= 0) return OPUS_BUFFER_TOO_SMALL;
+         if (s < nc) r = oa_ms_encode_group(st->streams + s, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
+         else r = oa_ms_encode_group(st->streams + s, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
+         if (r != OPUS_OK) return r;
+      }
+      if (lens[s] < 0) return lens[s];
+      if (opus_repacketizer_cat(&rp, pk.data() + (size_t)s * 1280, lens[s]) != OPUS_OK) return OPUS_INTERNAL_ERROR;
+      opus_int32 len = oa_repacketizer_out_range_impl(&rp, 0, opus_repacketizer_get_nb_frames(&rp), out, max_data_bytes - tot_size, s != ns - 1, !vbr && s == ns - 1);
+      if (len < 0) return len;
+      out += len;
+      tot_size += len;
+   }
+   return tot_size;
+}
+int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
+{
+   if (!st || st->magic != OA_MS_MAGIC) return OPUS_BAD_ARG;
+   va_list ap;
+   va_start(ap, request);
+   int ret = OPUS_OK;
+   const int ns = st->layout.nb_streams;
+   switch (request) {
+   case OPUS_SET_BITRATE_REQUEST: {
+      opus_int32 value = va_arg(ap, opus_int32);
+      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) {
+         if (value <= 0) { ret = OPUS_BAD_ARG; break; }
+         opus_int32 lo = 500 * st->layout.nb_channels, hi = 750000 * st->layout.nb_channels;
+         value = value < lo ? lo : (value > hi ? hi : value);
+      }
+      st->bitrate_bps = value;
+   } break;
+   case OPUS_GET_BITRATE_REQUEST: {
+      opus_int32 *value = va_arg(ap, opus_int32 *);
+      if (!value) { ret = OPUS_BAD_ARG; break; }
+      *value = 0;
+      for (int s = 0; s < ns; s++) { opus_int32 r = 0; oa_ctl_get(&st->streams[s], request, &r); *value += r; }
+   } break;
+   case OPUS_GET_FINAL_RANGE_REQUEST: {
+      opus_uint32 *value = va_arg(ap, opus_uint32 *);
+      if (!value) { ret = OPUS_BAD_ARG; break; }
+      *value = 0;
+      for (int s = 0; s < ns; s++) *value ^= st->streams[s].st.s.rangeFinal;
+   } break;
+   case OPUS_RESET_STATE:
+      for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = oa_ctl_set(&st->streams[s], request, 0);
+      break;
+   default:
+      if (request & 1) {           /* GET: answered by the first stream (opus_multistream_encoder.c:1196-1219) */
+         opus_int32 *value = va_arg(ap, opus_int32 *);
+         if (!value) ret = OPUS_BAD_ARG; else ret = oa_ctl_get(&st->streams[0], request, value);
+      } else {                     /* SET: applied to every stream (:1245-1278) */
+         opus_int32 value = va_arg(ap, opus_int32);
+         for (int s = 0; s < ns; s++) { ret = oa_ctl_set(&st->streams[s], request, value); if (ret != OPUS_OK) break; }
+      }
+   }
+   va_end(ap);
+   return ret;
+}
+
+/* ---------------- multistream decoder ---------------- */
+opus_int32 opus_multistream_decoder_get_size(int nb_streams, int nb_coupled_streams)
+{
+   if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;
+   return (opus_int32)(sizeof(OpusMSDecoder) + (size_t)(nb_streams - 1) * sizeof(OaDecStream));
+}
+int opus_multistream_decoder_init(OpusMSDecoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping)
+{
+   if (!st || !mapping) return OPUS_BAD_ARG;
+   if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams) return OPUS_BAD_ARG;
+   OaDecStream *probe = new OaDecStream;
+   int r = oa_dec_init_stream(probe, Fs, 2);
+   delete probe;
+   if (r != OPUS_OK) return r;
+   memset(st, 0, sizeof(OpusMSDecoder) - sizeof(OaDecStream));
+   st->magic = OA_MS_MAGIC; st->Fs = Fs;
+   st->layout.nb_channels = channels; st->layout.nb_streams = streams; st->layout.nb_coupled_streams = coupled_streams;
+   for (int i = 0; i < channels; i++) st->layout.mapping[i] = mapping[i];
+   if (!oa_validate_layout(&st->layout)) return OPUS_BAD_ARG;
+   for (int s = 0; s < streams; s++) { r = oa_dec_init_stream(&st->streams[s], Fs, s < coupled_streams ? 2 : 1); if (r != OPUS_OK) return r; }
+   return OPUS_OK;
+}
+OpusMSDecoder *opus_multistream_decoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int *error)
+{
+   if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams || !mapping) {
+      if (error) *error = OPUS_BAD_ARG;
+      return NULL;
+   }
+   OpusMSDecoder *st = (OpusMSDecoder *)malloc((size_t)opus_multistream_decoder_get_size(streams, coupled_streams));
+   if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return NULL; }
+   int r = opus_multistream_decoder_init(st, Fs, channels, streams, coupled_streams, mapping);
+   if (error) *error = r;
+   if (r != OPUS_OK) { free(st); return NULL; }
+   return st;
+}
+void opus_multistream_decoder_destroy(OpusMSDecoder *st) { free(st); }
+
+static int oa_ms_decode_group(OaDecStream *states, int n, int ch, const unsigned char *pk, int stride, const opus_int32 *lens, opus_int16 *pcm, int frame_size,
+      opus_int32 *ns_out, opus_uint32 *rngs)
+{
+   int err = OPUS_OK;
+   OpusGpuDecBatch *b = oa_ms_dec_batch(n, ch, &err);
+   if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(b->d_streams, states, sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice));
+   int r = opusgpu_decode_batch(b, pk, stride, lens, pcm, frame_size, ns_out, rngs);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpy(states, b->d_streams, sizeof(OaDecStream) * (size_t)n, hipMemcpyDeviceToHost));
+   return OPUS_OK;
+}
+/* opus_multistream_decode_native, opus_multistream_decoder.c:178 (int16 output) */
+int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec)
+{
+   if (!st || st->magic != OA_MS_MAGIC || !pcm) return OPUS_BAD_ARG;
+   if (frame_size <= 0) return OPUS_BAD_ARG;
+   const opus_int32 Fs = st->Fs;
+   const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
+   if (frame_size > Fs / 25 * 3) frame_size = Fs / 25 * 3;
+   if (len < 0) return OPUS_BAD_ARG;
+   if (len == 0 || data == NULL || decode_fec) return OPUS_UNIMPLEMENTED;           /* PLC / FEC */
+   if (len < 2 * ns - 1) return OPUS_INVALID_PACKET;
+   /* opus_multistream_packet_validate (:149) + re-framing of every stream's self-delimited packet as a plain packet for the batch decoder */
+   const int stride = 1280 * 6 + 16;
+   std::vector<unsigned char> pk((size_t)ns * stride, 0);
+   std::vector<opus_int32> lens((size_t)ns);
+   int samples = 0;
+   {
+      const unsigned char *p = data; opus_int32 left = len;
+      for (int s = 0; s < ns; s++) {
+         unsigned char toc; opus_int16 size[48]; opus_int32 packet_offset;
+         if (left <= 0) return OPUS_INVALID_PACKET;
+         int count = oa_packet_parse_impl(p, left, s != ns - 1, &toc, NULL, size, NULL, &packet_offset);
+         if (count < 0) return count;
+         int tmp_samples = opus_packet_get_nb_samples(p, packet_offset, Fs);
+         if (s != 0 && samples != tmp_samples) return OPUS_INVALID_PACKET;
+         samples = tmp_samples;
+         OpusRepacketizer rp;
+         opus_repacketizer_init(&rp);
+         int r = oa_repacketizer_cat_impl(&rp, p, packet_offset, s != ns - 1);
+         if (r != OPUS_OK) return r;
+         opus_int32 l = oa_repacketizer_out_range_impl(&rp, 0, rp.nb_frames, pk.data() + (size_t)s * stride, stride, 0, 0);
+         if (l < 0) return l;
+         lens[s] = l;
+         p += packet_offset; left -= packet_offset;
+      }
+   }
+   if (samples < 0) return samples;
+   if (samples > frame_size) return OPUS_BUFFER_TOO_SMALL;
+   std::lock_guard<std::mutex> lock(g_ms_mu);
+   std::vector<opus_int16> oc((size_t)nc * frame_size * 2 + 2), om((size_t)nm * frame_size + 1);
+   std::vector<opus_int32> nso((size_t)ns);
+   std::vector<opus_uint32> rngs((size_t)ns);
+   int r = OPUS_OK;
+   if (nc) r = oa_ms_decode_group(st->streams, nc, 2, pk.data(), stride, lens.data(), oc.data(), frame_size, nso.data(), rngs.data());
+   if (r == OPUS_OK && nm) r = oa_ms_decode_group(st->streams + nc, nm, 1, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, om.data(), frame_size, nso.data() + nc, rngs.data() + nc);
+   if (r != OPUS_OK) return r;
+   int out_n = 0;
+   for (int s = 0; s < ns; s++) { if (nso[s] <= 0) return nso[s] == 0 ? OPUS_INTERNAL_ERROR : nso[s]; out_n = nso[s]; }
+   for (int s = 0; s < ns; s++) {
+      if (s < nc) {
+         const opus_int16 *b = oc.data() + (size_t)s * frame_size * 2;
+         for (int prev = -1, chan; (chan = oa_get_left(&st->layout, s, prev)) != -1; prev = chan) for (int i = 0; i < out_n; i++) pcm[(size_t)i * nch + chan] = b[2 * i];
+         for (int prev = -1, chan; (chan = oa_get_right(&st->layout, s, prev)) != -1; prev = chan) for (int i = 0; i < out_n; i++) pcm[(size_t)i * nch + chan] = b[2 * i + 1];
+      } else {
+         const opus_int16 *b = om.data() + (size_t)(s - nc) * frame_size;
+         for (int prev = -1, chan; (chan = oa_get_mono(&st->layout, s, prev)) != -1; prev = chan) for (int i = 0; i < out_n; i++) pcm[(size_t)i * nch + chan] = b[i];
+      }
+   }
+   for (int c = 0; c < nch; c++) if (st->layout.mapping[c] == 255) for (int i = 0; i < out_n; i++) pcm[(size_t)i * nch + c] = 0;
+   return out_n;
+}
+int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...)
+{
+   if (!st || st->magic != OA_MS_MAGIC) return OPUS_BAD_ARG;
+   va_list ap;
+   va_start(ap, request);
+   int ret = OPUS_OK;
+   const int ns = st->layout.nb_streams;
+   switch (request) {
+   case OPUS_GET_FINAL_RANGE_REQUEST: {
+      opus_uint32 *value = va_arg(ap, opus_uint32 *);
+      if (!value) { ret = OPUS_BAD_ARG; break; }
+      *value = 0;
+      for (int s = 0; s < ns; s++) *value ^= st->streams[s].s.rangeFinal;
+   } break;
+   case OPUS_GET_SAMPLE_RATE_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->Fs; } break;
+   case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.bandwidth; } break;
+   case 4039 /* OPUS_GET_LAST_PACKET_DURATION */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.last_packet_duration; } break;
+   case OPUS_RESET_STATE:
+      for (int s = 0; s < ns; s++) oa_dec_init_stream(&st->streams[s], st->Fs, s < st->layout.nb_coupled_streams ? 2 : 1);
+      break;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else for (int s = 0; s < ns; s++) st->streams[s].s.disable_inv = v; } break;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.disable_inv; } break;
+   default: ret = OPUS_UNIMPLEMENTED;
+   }
+   va_end(ap);
+   return ret;
+}
+} /* extern "C" */
+#endif
