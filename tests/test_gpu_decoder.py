@@ -169,3 +169,25 @@ def test_gpu_full_size_encode_decode_roundtrip():
             a = od[s].decode(pk[s])
             assert a[0] == 960 and a[2] == int(drng[s]) and np.array_equal(a[1], pcm[s])
     eb.close(); db.close()
+
+def test_gpu_dec_corrupted_packets():
+    """bit flips, truncations, overwritten and random payloads: same PCM, sample count / error code and final range as the oracle on every
+    stream, with the (now garbage-driven) state carried from packet to packet; neighbours in the batch are unaffected"""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    from test_oracle_decoder import OracleDec, _mutations
+    rng = np.random.default_rng(31)
+    S = 24
+    e = OracleEnc(2, bitrate=96000, complexity=5)
+    chk = [OracleDec(2) for _ in range(S)]
+    b = oa.DecoderBatch(S, channels=2)
+    sig = signals.music(30, seed=32)
+    for i in range(30):
+        pkt = e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)[0]
+        pk = _mutations(pkt, rng, S - 1) + [pkt]
+        pcm, ns, rngs = b.decode(pk, 960)
+        for s in range(S):
+            a = chk[s].decode(pk[s])
+            assert a[0] == int(ns[s]), (i, s, a[0], int(ns[s]), pk[s][:4].hex())
+            if a[0] > 0: assert a[2] == int(rngs[s]) and np.array_equal(a[1], pcm[s, :a[0]]), (i, s)
+    b.close()

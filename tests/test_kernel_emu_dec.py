@@ -61,3 +61,16 @@ def test_emu_dec_channel_mismatch_and_bandwidths():
     _run(2, 1, signals.music(8, seed=6), 960, 8, bitrate=96000, complexity=10)
     for bw in (1101, 1103, 1104):
         _run(2, 2, signals.music(6, seed=8), 960, 6, bitrate=64000, complexity=10, bandwidth=bw)
+
+def test_emu_dec_corrupted_packets():
+    """garbage in, the reference's garbage out: corrupted packets decode to exactly what the oracle (== reference) produces, state carried"""
+    from test_oracle_decoder import _mutations
+    rng = np.random.default_rng(21)
+    e = OracleEnc(2, bitrate=96000, complexity=5); o = OracleDec(2); k = EmuDec(2)
+    sig = signals.music(16, seed=22)
+    for i in range(16):
+        pkt = e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)[0]
+        for q in _mutations(pkt, rng, 3) + [pkt]:
+            a = o.decode(q); b = k.decode(q)
+            assert a[0] == b[0], (i, a[0], b[0], q[:4].hex())
+            if a[0] > 0: assert a[2] == b[2] and np.array_equal(a[1], b[1]), (i, q[:4].hex())

@@ -110,3 +110,35 @@ def test_dec_error_codes():
     e = RefEnc(2, bitrate=64000)
     pkt, n, _ = e.encode(np.ascontiguousarray(signals.music(1, seed=1)[:960]), 960)
     assert r.decode(pkt, 480)[0] == o.decode(pkt, 480)[0] == -2          # OPUS_BUFFER_TOO_SMALL
+
+def _mutations(pk, rng, n):
+    """corrupted variants of a real packet: bit flips, truncation, byte overwrite, random tail; the TOC stays CELT-only"""
+    out = []
+    for _ in range(n):
+        b = bytearray(pk)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                i = int(rng.integers(1, len(b))); b[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            b = b[:max(3, int(rng.integers(2, len(b))))]
+        elif kind == 2:
+            i = int(rng.integers(1, len(b))); j = min(len(b), i + int(rng.integers(1, 12)))
+            b[i:j] = bytes(rng.integers(0, 256, j - i, dtype=np.uint8))
+        else:
+            b = bytearray(b[:1]) + bytes(rng.integers(0, 256, int(rng.integers(2, 300)), dtype=np.uint8))
+        b[0] = (b[0] & 0xfc) | 0x80                      # keep it a single-frame CELT-only packet
+        out.append(bytes(b))
+    return out
+
+def test_dec_corrupted_packets_match_reference():
+    """the decoder is deterministic on ANY bytes: corrupted packets must decode to the same PCM / final range as the reference does"""
+    rng = np.random.default_rng(11)
+    e = RefEnc(2, bitrate=96000, complexity=5); r = RefDec(2); o = OracleDec(2)
+    sig = signals.music(40, seed=12)
+    for i in range(40):
+        pkt, n, _ = e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)
+        for q in _mutations(pkt, rng, 6) + [pkt]:
+            a = r.decode(q); b = o.decode(q)
+            assert a[0] == b[0], (i, a[0], b[0], q[:4].hex())
+            if a[0] > 0: assert a[2] == b[2] and np.array_equal(a[1], b[1]), (i, q[:4].hex())
