@@ -1,9 +1,11 @@
 /* oc_celt_dec.c — CELT frame decoder, oracle restatement (fixed-point, non-QEXT, non-custom) of
  * celt/celt_decoder.c: celt_decoder_init :224/:244, OPUS_RESET_STATE :1794, deemphasis :318, celt_synthesis :413,
- * tf_decode :513, celt_decode_with_ec_dred :1104 (normal-frame path; PLC = celt_decode_lost is NOT restated);
+ * tf_decode :513, celt_plc_pitch_search :552, prefilter_and_fold :576, celt_decode_lost :679 (noise and pitch PLC; no deep PLC),
+ * celt_decode_with_ec_dred :1104; celt/celt_lpc.c: celt_fir :140, celt_iir :186;
  * celt/bands.c: denormalise_bands :187, anti_collapse :259.  TEST INFRASTRUCTURE, never shipped. */
 #include "oc_celt_dec.h"
 #include <string.h>
+#include <stdlib.h>
 
 extern void (*oc_dump_hook)(const char *tag, const void *p, int nbytes);
 #define OC_DUMP(tag, p, n) do { if (oc_dump_hook) oc_dump_hook(tag, p, n); } while (0)
@@ -161,6 +163,181 @@ static void deemphasis(i32 *in[], i16 *pcm, int N, int C, i32 *mem)
    }
 }
 
+#define PLC_PITCH_LAG_MAX 720
+#define PLC_PITCH_LAG_MIN 100
+#define MAX_PERIOD 1024
+#define LPC_ORDER 24
+#define FRAME_NONE 0
+#define FRAME_NORMAL 1
+#define FRAME_PLC_NOISE 2
+#define FRAME_PLC_PERIODIC 4
+
+/* celt_plc_pitch_search, celt_decoder.c:552 */
+static int plc_pitch_search(i32 *decode_mem[2], int C)
+{
+   i16 lp_pitch_buf[OC_DECODE_BUFFER_SIZE >> 1];
+   int pitch_index;
+   oc_pitch_downsample(decode_mem, lp_pitch_buf, OC_DECODE_BUFFER_SIZE >> 1, C, 2);
+   oc_pitch_search(lp_pitch_buf + (PLC_PITCH_LAG_MAX >> 1), lp_pitch_buf, OC_DECODE_BUFFER_SIZE - PLC_PITCH_LAG_MAX, PLC_PITCH_LAG_MAX - PLC_PITCH_LAG_MIN, &pitch_index);
+   return PLC_PITCH_LAG_MAX - pitch_index;
+}
+/* prefilter_and_fold, celt_decoder.c:576 */
+static void prefilter_and_fold(oc_celt_dec *st, int N)
+{
+   const int overlap = OVERLAP;
+   i32 etmp[OVERLAP];
+   for (int c = 0; c < st->channels; c++) {
+      i32 *dm = st->decode_mem[c];
+      oc_comb_filter(etmp, dm + OC_DECODE_BUFFER_SIZE - N, st->postfilter_period_old, st->postfilter_period, overlap, (i16)-st->postfilter_gain_old, (i16)-st->postfilter_gain,
+            st->postfilter_tapset_old, st->postfilter_tapset, 0);
+      for (int i = 0; i < overlap / 2; i++)
+         dm[OC_DECODE_BUFFER_SIZE - N + i] = mult16_32_q15(oc_window[i], etmp[overlap - 1 - i]) + mult16_32_q15(oc_window[overlap - i - 1], etmp[i]);
+   }
+}
+/* celt_fir_c, celt_lpc.c:140: y[i] = round(x[i] + sum num[m-1] x[i-m]); x must have ord samples of history before it */
+static void celt_fir(const i16 *x, const i16 *num, i16 *y, int N, int ord)
+{
+   for (int i = 0; i < N; i++) {
+      i32 sum = shl32((i32)x[i], SIG_SHIFT);
+      for (int j = 0; j < ord; j++) sum = mac16_16(sum, num[ord - 1 - j], x[i + j - ord]);
+      y[i] = sround16(sum, SIG_SHIFT);
+   }
+}
+/* celt_iir, celt_lpc.c:186: the feedback taps see the outputs rounded (and saturated) to 16 bits */
+static void celt_iir(const i32 *x, const i16 *den, i32 *y, int N, int ord, i16 *mem)
+{
+   i16 hist[LPC_ORDER];                  /* hist[m-1] = out16[i-m] */
+   for (int j = 0; j < ord; j++) hist[j] = mem[j];
+   for (int i = 0; i < N; i++) {
+      i32 sum = x[i];
+      for (int j = 0; j < ord; j++) sum -= mult16_16(den[j], hist[j]);
+      for (int j = ord - 1; j >= 1; j--) hist[j] = hist[j - 1];
+      hist[0] = sround16(sum, SIG_SHIFT);
+      y[i] = sum;
+   }
+   for (int i = 0; i < ord; i++) mem[i] = (i16)y[N - i - 1];
+}
+
+/* celt_decode_lost, celt_decoder.c:679 */
+static void celt_decode_lost(oc_celt_dec *st, int N, int LM)
+{
+   const int C = st->channels, overlap = OVERLAP, start = st->start;
+   i32 *decode_mem[2], *out_syn[2];
+   i32 *oldBandE = st->oldBandE, *backgroundLogE = st->backgroundLogE;
+   int loss_duration = st->loss_duration, curr_frame_type = FRAME_PLC_PERIODIC;
+   for (int c = 0; c < C; c++) { decode_mem[c] = st->decode_mem[c]; out_syn[c] = decode_mem[c] + OC_DECODE_BUFFER_SIZE - N; }
+   if (st->plc_duration >= 40 || start != 0 || st->skip_plc) curr_frame_type = FRAME_PLC_NOISE;
+   if (curr_frame_type == FRAME_PLC_NOISE) {
+      i32 X[2 * 960];
+      const int end = st->end, effEnd = imax(start, imin(end, NB_EBANDS));
+      u32 seed;
+      for (int c = 0; c < C; c++) memmove(decode_mem[c], decode_mem[c] + N, (OC_DECODE_BUFFER_SIZE - N + overlap) * sizeof(i32));
+      if (st->prefilter_and_fold) prefilter_and_fold(st, N);
+      i32 decay = loss_duration == 0 ? GC(1.5f) : GC(.5f);
+      for (int c = 0; c < C; c++) for (int i = start; i < end; i++) oldBandE[c * NB_EBANDS + i] = imax(backgroundLogE[c * NB_EBANDS + i], oldBandE[c * NB_EBANDS + i] - decay);
+      seed = st->rng;
+      memset(X, 0, sizeof(X));
+      for (int c = 0; c < C; c++) {
+         for (int i = start; i < effEnd; i++) {
+            int boffs = N * c + (oc_eBands[i] << LM), blen = (oc_eBands[i + 1] - oc_eBands[i]) << LM;
+            for (int j = 0; j < blen; j++) { seed = 1664525u * seed + 1013904223u; X[boffs + j] = shl32((i32)((i32)seed >> 20), NORM_SHIFT - 14); }
+            oc_renormalise_vector(X + boffs, blen, Q31ONE);
+         }
+      }
+      st->rng = seed;
+      celt_synthesis(X, out_syn, oldBandE, start, effEnd, C, C, 0, LM, 0);
+      for (int c = 0; c < C; c++) {
+         st->postfilter_period = imax(st->postfilter_period, COMBFILTER_MINPERIOD);
+         st->postfilter_period_old = imax(st->postfilter_period_old, COMBFILTER_MINPERIOD);
+         oc_comb_filter(out_syn[c], out_syn[c], st->postfilter_period_old, st->postfilter_period, 120, st->postfilter_gain_old, st->postfilter_gain,
+               st->postfilter_tapset_old, st->postfilter_tapset, overlap);
+         if (LM != 0)
+            oc_comb_filter(out_syn[c] + 120, out_syn[c] + 120, st->postfilter_period, st->postfilter_period, N - 120, st->postfilter_gain, st->postfilter_gain,
+                  st->postfilter_tapset, st->postfilter_tapset, overlap);
+      }
+      st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset;
+      st->prefilter_and_fold = 0;
+      st->skip_plc = 1;
+   } else {
+      i16 _exc[MAX_PERIOD + LPC_ORDER], fir_tmp[MAX_PERIOD], *exc = _exc + LPC_ORDER;
+      i16 fade = Q15ONE;
+      int pitch_index, exc_length;
+      if (st->last_frame_type != FRAME_PLC_PERIODIC) st->last_pitch_index = pitch_index = plc_pitch_search(decode_mem, C);
+      else { pitch_index = st->last_pitch_index; fade = QC16(.8f, 15); }
+      exc_length = imin(2 * pitch_index, MAX_PERIOD);
+      for (int c = 0; c < C; c++) {
+         i16 decay, attenuation, *lpc = st->lpc + c * LPC_ORDER;
+         i32 S1 = 0, *buf = decode_mem[c];
+         int extrapolation_offset, extrapolation_len, i, j;
+         for (i = 0; i < MAX_PERIOD + LPC_ORDER; i++) exc[i - LPC_ORDER] = sround16(buf[OC_DECODE_BUFFER_SIZE - MAX_PERIOD - LPC_ORDER + i], SIG_SHIFT);
+         if (st->last_frame_type != FRAME_PLC_PERIODIC) {
+            i32 ac[LPC_ORDER + 1];
+            oc_autocorr(exc, ac, oc_window, overlap, LPC_ORDER, MAX_PERIOD);
+            ac[0] += ac[0] >> 13;
+            for (i = 1; i <= LPC_ORDER; i++) ac[i] -= mult16_32_q15(2 * i * i, ac[i]);
+            oc_celt_lpc(lpc, ac, LPC_ORDER);
+            while (1) {
+               i16 tmp = Q15ONE;
+               i32 sum = QC16(1., SIG_SHIFT);
+               for (i = 0; i < LPC_ORDER; i++) sum += abs(lpc[i]);
+               if (sum < 65535) break;
+               for (i = 0; i < LPC_ORDER; i++) { tmp = (i16)mult16_16_q15(QC16(.99f, 15), tmp); lpc[i] = (i16)mult16_16_q15(lpc[i], tmp); }
+            }
+         }
+         celt_fir(exc + MAX_PERIOD - exc_length, lpc, fir_tmp, exc_length, LPC_ORDER);
+         memcpy(exc + MAX_PERIOD - exc_length, fir_tmp, exc_length * sizeof(i16));
+         {
+            i32 E1 = 1, E2 = 1, mx = 0;
+            for (i = 0; i < exc_length; i++) mx = imax(mx, abs(exc[MAX_PERIOD - exc_length + i]));
+            int shift = imax(0, 2 * celt_zlog2(mx) - 20);
+            int decay_length = exc_length >> 1;
+            for (i = 0; i < decay_length; i++) {
+               i16 e = exc[MAX_PERIOD - decay_length + i];
+               E1 += mult16_16(e, e) >> shift;
+               e = exc[MAX_PERIOD - 2 * decay_length + i];
+               E2 += mult16_16(e, e) >> shift;
+            }
+            E1 = imin(E1, E2);
+            decay = (i16)oc_sqrt(oc_frac_div32(E1 >> 1, E2));
+         }
+         memmove(buf, buf + N, (OC_DECODE_BUFFER_SIZE - N) * sizeof(i32));
+         extrapolation_offset = MAX_PERIOD - pitch_index;
+         extrapolation_len = N + overlap;
+         attenuation = (i16)mult16_16_q15(fade, decay);
+         for (i = j = 0; i < extrapolation_len; i++, j++) {
+            i16 tmp;
+            if (j >= pitch_index) { j -= pitch_index; attenuation = (i16)mult16_16_q15(attenuation, decay); }
+            buf[OC_DECODE_BUFFER_SIZE - N + i] = shl32((i32)(i16)mult16_16_q15(attenuation, exc[extrapolation_offset + j]), SIG_SHIFT);
+            tmp = sround16(buf[OC_DECODE_BUFFER_SIZE - MAX_PERIOD - N + extrapolation_offset + j], SIG_SHIFT);
+            S1 += mult16_16(tmp, tmp) >> 11;
+         }
+         {
+            i16 lpc_mem[LPC_ORDER];
+            for (i = 0; i < LPC_ORDER; i++) lpc_mem[i] = sround16(buf[OC_DECODE_BUFFER_SIZE - N - 1 - i], SIG_SHIFT);
+            celt_iir(buf + OC_DECODE_BUFFER_SIZE - N, lpc, buf + OC_DECODE_BUFFER_SIZE - N, extrapolation_len, LPC_ORDER, lpc_mem);
+            for (i = 0; i < extrapolation_len; i++) buf[OC_DECODE_BUFFER_SIZE - N + i] = saturate(buf[OC_DECODE_BUFFER_SIZE - N + i], SIG_SAT);
+         }
+         {
+            i32 S2 = 0;
+            for (i = 0; i < extrapolation_len; i++) { i16 tmp = sround16(buf[OC_DECODE_BUFFER_SIZE - N + i], SIG_SHIFT); S2 += mult16_16(tmp, tmp) >> 11; }
+            if (!(S1 > (S2 >> 2))) { for (i = 0; i < extrapolation_len; i++) buf[OC_DECODE_BUFFER_SIZE - N + i] = 0; }
+            else if (S1 < S2) {
+               i16 ratio = (i16)oc_sqrt(oc_frac_div32((S1 >> 1) + 1, S2 + 1));
+               for (i = 0; i < overlap; i++) {
+                  i16 tmp_g = (i16)(Q15ONE - mult16_16_q15(oc_window[i], Q15ONE - ratio));
+                  buf[OC_DECODE_BUFFER_SIZE - N + i] = mult16_32_q15(tmp_g, buf[OC_DECODE_BUFFER_SIZE - N + i]);
+               }
+               for (i = overlap; i < extrapolation_len; i++) buf[OC_DECODE_BUFFER_SIZE - N + i] = mult16_32_q15(ratio, buf[OC_DECODE_BUFFER_SIZE - N + i]);
+            }
+         }
+      }
+      st->prefilter_and_fold = 1;
+   }
+   st->loss_duration = imin(10000, loss_duration + (1 << LM));
+   st->plc_duration = imin(10000, st->plc_duration + (1 << LM));
+   st->last_frame_type = curr_frame_type;
+}
+
 /* celt_decode_with_ec_dred, celt_decoder.c:1104 — normal frames only */
 int oc_celt_decode_with_ec(oc_celt_dec *st, const u8 *data, int len, i16 *pcm, int frame_size, oc_ec *dec)
 {
@@ -183,7 +360,11 @@ int oc_celt_decode_with_ec(oc_celt_dec *st, const u8 *data, int len, i16 *pcm, i
    N = M * 120;
    for (c = 0; c < CC; c++) { decode_mem[c] = st->decode_mem[c]; out_syn[c] = decode_mem[c] + OC_DECODE_BUFFER_SIZE - N; }
    effEnd = imin(end, NB_EBANDS);
-   if (data == 0 || len <= 1) return -5;                      /* celt_decode_lost: not restated */
+   if (data == 0 || len <= 1) {
+      celt_decode_lost(st, N, LM);
+      deemphasis(out_syn, pcm, N, CC, st->preemph_memD);
+      return frame_size;
+   }
    if (st->loss_duration == 0) st->skip_plc = 0;
    if (dec == 0) { oc_ec_dec_init(&_dec, data, len); dec = &_dec; }
    if (C == 1) for (i = 0; i < NB_EBANDS; i++) oldBandE[i] = imax(oldBandE[i], oldBandE[NB_EBANDS + i]);
@@ -208,7 +389,24 @@ int oc_celt_decode_with_ec(oc_celt_dec *st, const u8 *data, int len, i16 *pcm, i
    else isTransient = 0;
    shortBlocks = isTransient ? M : 0;
    intra_ener = tell + 3 <= total_bits ? oc_ec_dec_bit_logp(dec, 3) : 0;
-   /* (loss_duration != 0 energy-safety branch :1387 unreachable without PLC) */
+   if (!intra_ener && st->loss_duration != 0) {            /* energy prediction safety after a loss, celt_decoder.c:1387 */
+      for (c = 0; c < 2; c++) {
+         i32 safety = 0;
+         int missing = imin(10, st->loss_duration >> LM);
+         if (LM == 0) safety = GC(1.5f);
+         else if (LM == 1) safety = GC(.5f);
+         for (i = start; i < end; i++) {
+            if (oldBandE[c * NB_EBANDS + i] < imax(oldLogE[c * NB_EBANDS + i], oldLogE2[c * NB_EBANDS + i])) {
+               i32 E0 = oldBandE[c * NB_EBANDS + i], E1 = oldLogE[c * NB_EBANDS + i], E2 = oldLogE2[c * NB_EBANDS + i];
+               i32 slope = imax(E1 - E0, half32(E2 - E0));
+               slope = imin(slope, GC(2.f));
+               E0 -= imax(0, (1 + missing) * slope);
+               oldBandE[c * NB_EBANDS + i] = imax(-GC(20.f), E0);
+            } else oldBandE[c * NB_EBANDS + i] = imin(imin(oldBandE[c * NB_EBANDS + i], oldLogE[c * NB_EBANDS + i]), oldLogE2[c * NB_EBANDS + i]);
+            oldBandE[c * NB_EBANDS + i] -= safety;
+         }
+      }
+   }
    oc_unquant_coarse_energy(start, end, oldBandE, intra_ener, dec, C, LM);
    tf_decode(start, end, isTransient, tf_res, LM, dec);
    tell = oc_ec_tell(dec);
@@ -249,7 +447,7 @@ int oc_celt_decode_with_ec(oc_celt_dec *st, const u8 *data, int len, i16 *pcm, i
    if (anti_collapse_on) anti_collapse(X, collapse_masks, LM, C, N, start, end, oldBandE, oldLogE, oldLogE2, pulses, st->rng);
    if (silence) for (i = 0; i < C * NB_EBANDS; i++) oldBandE[i] = -GC(28.f);
    OC_DUMP("dec_X", X, C * N * 4); OC_DUMP("dec_oldBandE", oldBandE, 2 * NB_EBANDS * 4);
-   /* (prefilter_and_fold :576 only follows a concealed frame) */
+   if (st->prefilter_and_fold) prefilter_and_fold(st, N);
    celt_synthesis(X, out_syn, oldBandE, start, effEnd, C, CC, isTransient, LM, silence);
    for (c = 0; c < CC; c++) OC_DUMP("dec_syn", out_syn[c], N * 4);
    for (c = 0; c < CC; c++) {

@@ -15,6 +15,7 @@ typedef struct {
    i32 preemph_memD[2];
    i32 decode_mem[2][OC_DECODE_BUFFER_SIZE + OVERLAP];
    i32 oldBandE[2 * NB_EBANDS], oldLogE[2 * NB_EBANDS], oldLogE2[2 * NB_EBANDS], backgroundLogE[2 * NB_EBANDS];
+   i16 lpc[2 * 24];
 } oc_celt_dec;
 void oc_celt_dec_init(oc_celt_dec *st, int channels);
 void oc_celt_dec_reset(oc_celt_dec *st);
@@ -27,7 +28,8 @@ typedef struct {
 } oc_opus_dec;
 int oc_opus_dec_size(void);
 int oc_opus_dec_init(oc_opus_dec *st, int Fs, int channels);
-/* returns samples per channel or a negative OPUS_* code; -5 (UNIMPLEMENTED-like) for SILK/hybrid packets, PLC (data == NULL / len <= 1 frames) and FEC */
+/* returns samples per channel or a negative OPUS_* code; -5 (UNIMPLEMENTED-like) for SILK/hybrid packets and FEC; data == NULL / len == 0 and
+ * frames of <= 1 byte run the CELT packet-loss concealment */
 int oc_opus_decode(oc_opus_dec *st, const u8 *data, int len, i16 *pcm, int frame_size, int decode_fec);
 u32 oc_opus_dec_final_range(const oc_opus_dec *st);
 int oc_opus_packet_parse(const u8 *data, int len, u8 *out_toc, i16 size[48], int *payload_offset);

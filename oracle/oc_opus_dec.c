@@ -110,17 +110,38 @@ int oc_opus_packet_parse(const u8 *data, int len, u8 *out_toc, i16 size[48], int
    return count;
 }
 
-/* opus_decode_frame, opus_decoder.c:271: CELT-only, data present, no mode transition */
+/* opus_decode_frame, opus_decoder.c:271: CELT-only; data == NULL (or a frame of <= 1 byte) runs the concealment */
 static int decode_frame(oc_opus_dec *st, const u8 *data, i32 len, i16 *pcm, int frame_size)
 {
-   const int F20 = st->Fs / 50, F2_5 = F20 >> 3;
+   const int F20 = st->Fs / 50, F10 = F20 >> 1, F5 = F10 >> 1, F2_5 = F5 >> 1;
    oc_ec dec;
+   int audiosize, mode;
    if (frame_size < F2_5) return -2;
    frame_size = imin(frame_size, st->Fs / 25 * 3);
-   if (len <= 1) return -5;                                   /* PLC / DTX */
-   int audiosize = st->frame_size;
-   oc_ec_dec_init(&dec, data, len);
-   if (st->prev_mode > 0 && st->prev_mode != MODE_CELT_ONLY) return -5;    /* transitions need SILK */
+   if (len <= 1) { data = 0; frame_size = imin(frame_size, st->frame_size); }
+   if (data != 0) {
+      audiosize = st->frame_size;
+      mode = st->mode;
+      oc_ec_dec_init(&dec, data, len);
+   } else {
+      audiosize = frame_size;
+      mode = st->prev_redundancy ? MODE_CELT_ONLY : st->prev_mode;
+      if (mode == 0) { for (int i = 0; i < audiosize * st->channels; i++) pcm[i] = 0; return audiosize; }
+      if (audiosize > F20) {
+         do {
+            int ret = decode_frame(st, 0, 0, pcm, imin(audiosize, F20));
+            if (ret < 0) return ret;
+            pcm += ret * st->channels;
+            audiosize -= ret;
+         } while (audiosize > 0);
+         return frame_size;
+      } else if (audiosize < F20) {
+         if (audiosize > F10) audiosize = F10;
+         else if (mode != MODE_SILK_ONLY && audiosize > F5 && audiosize < F10) audiosize = F5;
+      }
+   }
+   if (mode != MODE_CELT_ONLY) return -5;
+   if (data != 0 && st->prev_mode > 0 && st->prev_mode != MODE_CELT_ONLY) return -5;    /* transitions need SILK */
    if (audiosize > frame_size) return -1;
    frame_size = audiosize;
    if (st->bandwidth) {
@@ -135,10 +156,11 @@ static int decode_frame(oc_opus_dec *st, const u8 *data, i32 len, i16 *pcm, int 
    }
    st->celt.stream_channels = st->stream_channels;
    st->celt.start = 0;
-   int celt_ret = oc_celt_decode_with_ec(&st->celt, data, len, pcm, imin(F20, frame_size), &dec);
+   int celt_ret = oc_celt_decode_with_ec(&st->celt, data, len, pcm, imin(F20, frame_size), data ? &dec : 0);
    st->rangeFinal = st->celt.rng;
-   st->prev_mode = MODE_CELT_ONLY;
+   st->prev_mode = mode;
    st->prev_redundancy = 0;
+   if (len <= 1) st->rangeFinal = 0;
    return celt_ret < 0 ? celt_ret : audiosize;
 }
 
@@ -151,7 +173,16 @@ int oc_opus_decode(oc_opus_dec *st, const u8 *data, int len, i16 *pcm, int frame
    if (frame_size <= 0) return -1;
    if (decode_fec < 0 || decode_fec > 1) return -1;
    if ((decode_fec || len == 0 || data == 0) && frame_size % (st->Fs / 400) != 0) return -1;
-   if (len == 0 || data == 0) return -5;                      /* PLC */
+   if (len == 0 || data == 0) {                               /* packet loss: conceal frame_size samples */
+      int pcm_count = 0;
+      do {
+         int ret = decode_frame(st, 0, 0, pcm + pcm_count * st->channels, frame_size - pcm_count);
+         if (ret < 0) return ret;
+         pcm_count += ret;
+      } while (pcm_count < frame_size);
+      st->last_packet_duration = pcm_count;
+      return pcm_count;
+   }
    if (len < 0) return -1;
    if (decode_fec) return -5;
    int packet_mode = (data[0] & 0x80) ? MODE_CELT_ONLY : ((data[0] & 0x60) == 0x60 ? MODE_HYBRID : MODE_SILK_ONLY);

@@ -142,3 +142,32 @@ def test_dec_corrupted_packets_match_reference():
             a = r.decode(q); b = o.decode(q)
             assert a[0] == b[0], (i, a[0], b[0], q[:4].hex())
             if a[0] > 0: assert a[2] == b[2] and np.array_equal(a[1], b[1]), (i, q[:4].hex())
+
+def _decode_loss(dec, L_decode, frame):
+    pcm = np.zeros((frame, dec.ch), np.int16)
+    n = L_decode(None, 0, pcm.ctypes.data, frame, 0)
+    return n, pcm[:max(n, 0)].copy()
+
+@pytest.mark.parametrize("channels,bitrate,frame,pattern", [
+    (2, 96000, 960, "single"), (2, 96000, 960, "burst"), (1, 32000, 960, "burst"), (2, 64000, 480, "random"), (2, 128000, 240, "random"),
+    (2, 128000, 120, "burst"), (2, 48000, 960, "long"), (1, 64000, 480, "start")])
+def test_dec_packet_loss_concealment(channels, bitrate, frame, pattern):
+    """opus_decode(NULL): pitch-based PLC, its fade, the switch to noise PLC after 40+ lost 2.5 ms units, recovery frames (prefilter_and_fold,
+    energy safety) — PCM identical to the reference; state carried across losses."""
+    rng = np.random.default_rng(41)
+    n = min(60 * 960 // frame, 160)
+    sig = signals.music(n * frame // 960 + 1, channels=channels, seed=42)
+    e = RefEnc(channels, bitrate=bitrate, complexity=5); r = RefDec(channels); o = OracleDec(channels)
+    lost = {"single": {10, 20, 30}, "burst": set(range(8, 14)) | set(range(30, 33)), "random": set(np.nonzero(rng.random(n) < 0.2)[0].tolist()),
+            "long": set(range(6, 40)), "start": {0, 1, 5}}[pattern]
+    for i in range(n):
+        pkt, m, erng = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)
+        if i in lost:
+            pa = np.zeros((frame, channels), np.int16); pb = np.zeros((frame, channels), np.int16)
+            na = r.L.opus_decode(r.st, None, 0, pa.ctypes.data, frame, 0)
+            nb = o.O.oc_opus_decode(o.buf, None, 0, pb.ctypes.data, frame, 0)
+            assert na == nb == frame, (i, na, nb)
+            assert np.array_equal(pa, pb), (i, "lost", np.argwhere(pa != pb)[:4])
+        else:
+            a = r.decode(pkt); b = o.decode(pkt)
+            assert a[0] == b[0] == frame and a[2] == b[2] and np.array_equal(a[1], b[1]), (i, "recv", np.argwhere(a[1] != b[1])[:4])
