@@ -125,8 +125,8 @@ OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
  * opus_decoder_create :477, opus_decoder_init :494, opus_decode :516, opus_decoder_ctl :586, opus_decoder_destroy :591
  * (definitions replaced: reference/src/opus_decoder.c:121, :186, :135, :890, :1033, :1246).  The OpusDecoder blob is flat
  * host memory with the complete state (memcpy-able).  Scope this round: CELT-only packets (any frame count / size the
- * TOC allows), mono/stereo streams into mono/stereo output.  SILK / hybrid packets, packet-loss concealment
- * (data == NULL or len == 0), FEC and Fs != 48000 return OPUS_UNIMPLEMENTED. */
+ * TOC allows), mono/stereo streams into mono/stereo output, packet-loss concealment (data == NULL or len == 0, and decode_fec = 1,
+ * which for CELT-only streams conceals as well).  SILK / hybrid packets and Fs != 48000 return OPUS_UNIMPLEMENTED. */
 typedef struct OpusDecoder OpusDecoder;
 OPUS_AMD_EXPORT int opus_decoder_get_size(int channels);
 OPUS_AMD_EXPORT OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error);
@@ -137,7 +137,8 @@ OPUS_AMD_EXPORT void opus_decoder_destroy(OpusDecoder *st);
 
 /* Batch decoder: S independent streams, one wavefront per stream per call; state (incl. the 2x2048-sample synthesis history)
  * stays in HBM.  packets: [S][packet_stride] bytes (one Opus packet per stream, lens[s] bytes used); pcm: [S][frame_size*channels]
- * int16 interleaved (frame_size = capacity per channel, <= 5760); nsamples[s] = samples per channel decoded or a negative
+ * int16 interleaved (frame_size = capacity per channel, <= 5760); lens[s] == 0 marks a lost packet: that stream conceals frame_size
+ * samples; nsamples[s] = samples per channel decoded or a negative
  * OPUS_* code for that stream; final_range[s] = OPUS_GET_FINAL_RANGE. */
 typedef struct OpusGpuDecBatch OpusGpuDecBatch;
 OPUS_AMD_EXPORT OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int device, int *error);
@@ -183,7 +184,7 @@ OPUS_AMD_EXPORT opus_int32 opus_multistream_packet_unpad(unsigned char *data, op
  * One multistream frame = its streams stepped together by the batch kernels (one launch per group: coupled, mono).  Same names,
  * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: CELT-only applications at 48 kHz, frames <= 20 ms,
  * mapping families 0, 2 (ambisonics) and 255, family 1 up to two channels; int16 entry points.  Family-1 surround (> 2 channels,
- * needs the masking analysis), float / 24-bit entry points, PLC and FEC return OPUS_UNIMPLEMENTED. */
+ * needs the masking analysis) and float / 24-bit entry points return OPUS_UNIMPLEMENTED. */
 typedef struct OpusMSEncoder OpusMSEncoder;
 typedef struct OpusMSDecoder OpusMSDecoder;
 OPUS_AMD_EXPORT opus_int32 opus_multistream_encoder_get_size(int streams, int coupled_streams);

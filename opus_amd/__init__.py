@@ -170,7 +170,7 @@ class OpusDecoder:
     def decode(self, packet, frame_size=5760, decode_fec=0):
         import numpy as np
         pcm = np.zeros((frame_size, self.channels), np.int16)
-        n = self._L.opus_decode(self._st, packet, len(packet) if packet is not None else 0, pcm.ctypes.data, frame_size, decode_fec)
+        n = self._L.opus_decode(self._st, packet, len(packet) if packet else 0, pcm.ctypes.data, frame_size, decode_fec)
         if n < 0: raise OpusError(n)
         return pcm[:n].copy()
     def final_range(self):
@@ -191,9 +191,11 @@ class DecoderBatch:
         if not self._b: raise OpusError(err.value)
         self.S, self.channels, self.device = nstreams, channels, device
     def decode(self, packets, frame_size=960):
-        """packets: list of S bytes objects.  Returns (pcm int16 [S, frame_size, channels], nsamples [S], final ranges [S])."""
+        """packets: list of S bytes objects (b"" or None = lost packet: conceal frame_size samples).  Returns (pcm int16 [S, frame_size, channels],
+        nsamples [S], final ranges [S])."""
         import numpy as np
         assert len(packets) == self.S
+        packets = [p or b"" for p in packets]
         stride = (max(len(p) for p in packets) + 8 + 3) & ~3
         buf = np.zeros((self.S, stride), np.uint8)
         lens = np.array([len(p) for p in packets], np.int32)

@@ -139,7 +139,47 @@ WV_DEVN void comb_filter_inplace_wave(WV_LDS i32 *cur, const i32 *hist, int head
 #undef XA
 }
 
-/* ---- one CELT frame (celt_decoder.c:1104, data present).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
+/* common tail of a decoded or concealed frame: de-emphasis -> int16 PCM, history ring += N samples, overlap tail kept */
+WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int CC, i16 *pcm_out)
+{
+   WV_LDS OaDecScalars *st = &L->st;
+   const int overlap = OA_OVERLAP, lane = wv_lane();
+   N = wv_uni(N); CC = wv_uni(CC);
+   wv_sync();
+   /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; int16 staged in region A ---- */
+   if (lane < CC) {
+      i32 m = st->preemph_memD[lane];
+      const WV_LDS i32 *x = L->BC.syn[lane];
+      WV_LDS i16 *y = L->A.pcm16;
+      for (int j0 = 0; j0 < N; j0 += 8) {                /* eight reads in flight per trip; only the (add, saturate, multiply) chain is serial */
+         i32 t[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
+#pragma unroll
+         for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
+#pragma unroll
+         for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
+      }
+      st->preemph_memD[lane] = m;
+   }
+   wv_sync();
+   FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
+   /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
+   {
+      const int head = wv_uni(st->hist_head);
+      for (int c = 0; c < CC; c++) {
+         FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = L->BC.syn[c][i];
+         FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = L->BC.syn[c][N + i];
+      }
+   }
+   wv_sync();
+   LANE0 st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
+   wv_sync();
+}
+
+#include "celt_dec_plc.h"
+
+/* ---- one CELT frame (celt_decoder.c:1104).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
 WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out)
 {
    WV_LDS DecShared *sh = &L->sh;
@@ -151,9 +191,13 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
    if (LM > 3) return OA_ERR_BAD_ARG;
    if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
-   if (len <= 1) return OA_ERR_UNIMPLEMENTED;                     /* celt_decode_lost */
    const int M = 1 << LM, N = M * 120;
    const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
+   if (len <= 1) {                                                /* lost / DTX frame: conceal (celt_decoder.c:1306) */
+      celt_decode_lost_wave(L, gs, N, LM);
+      celt_emit_frame_wave(L, gs, N, CC, pcm_out);
+      return frame_size;
+   }
    const int effEnd = imin(end, NBE);
    wv_sync();
    LANE0 {
@@ -183,6 +227,24 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       if (LM > 0 && tell + 3 <= total_bits) { isTransient = k_ec_dec_bit_logp(EC_PASS, 3); tell = k_ec_tell(EC_PASS); }
       const int shortBlocks = isTransient ? M : 0;
       const int intra_ener = tell + 3 <= total_bits ? k_ec_dec_bit_logp(EC_PASS, 3) : 0;
+      if (!intra_ener && st->loss_duration != 0) {          /* energy prediction safety after a loss (celt_decoder.c:1387) */
+         for (int c = 0; c < 2; c++) {
+            i32 safety = 0;
+            int missing = imin(10, st->loss_duration >> LM);
+            if (LM == 0) safety = GC(1.5f);
+            else if (LM == 1) safety = GC(.5f);
+            for (int i = start; i < end; i++) {
+               i32 E0 = L->oldBandE[c * NBE + i], E1 = L->oldLogE[c * NBE + i], E2 = L->oldLogE2[c * NBE + i];
+               if (E0 < imax(E1, E2)) {
+                  i32 slope = imax(E1 - E0, half32(E2 - E0));
+                  slope = imin(slope, GC(2.f));
+                  E0 -= imax(0, (1 + missing) * slope);
+                  E0 = imax(-GC(20.f), E0);
+               } else E0 = imin(imin(E0, E1), E2);
+               L->oldBandE[c * NBE + i] = E0 - safety;
+            }
+         }
+      }
       k_unquant_coarse_energy(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM);
       k_tf_decode(start, end, isTransient, L->tf_res, LM, EC_PASS);
       tell = k_ec_tell(EC_PASS);
@@ -250,6 +312,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
          FOR_LANES(i, N) L->BC.syn[c][overlap + i] = 0;
       }
       wv_sync();
+      if (wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, CC);
       WV_LDS i32 *freq = L->A.X;
       if (CC == 2 && C == 1) {
          denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence);
@@ -309,36 +372,9 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       }
    }
    wv_sync();
-   /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; int16 staged in region A ---- */
-   if (lane < CC) {
-      i32 m = st->preemph_memD[lane];
-      const WV_LDS i32 *x = L->BC.syn[lane];
-      WV_LDS i16 *y = L->A.pcm16;
-      for (int j0 = 0; j0 < N; j0 += 8) {                /* eight reads in flight per trip; only the (add, saturate, multiply) chain is serial */
-         i32 t[8];
-#pragma unroll
-         for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
-#pragma unroll
-         for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
-#pragma unroll
-         for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
-      }
-      st->preemph_memD[lane] = m;
-   }
-   wv_sync();
-   FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
-   /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
-   {
-      const int head = wv_uni(st->hist_head);
-      for (int c = 0; c < CC; c++) {
-         FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = L->BC.syn[c][i];
-         FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = L->BC.syn[c][N + i];
-      }
-   }
-   wv_sync();
+   celt_emit_frame_wave(L, gs, N, CC, pcm_out);
    int ret = frame_size;
    LANE0 {
-      st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
       st->rng = L->ec.rng;
       st->loss_duration = 0; st->plc_duration = 0; st->last_frame_type = 1; st->prefilter_and_fold = 0;
       i32 used = L->ec.nbits_total - ec_ilog(L->ec.rng);
@@ -436,6 +472,42 @@ WV_DEV int oa_packet_parse(const u8 *data, i32 len, WV_LDS i32 *size, int *paylo
    return count;
 }
 
+/* opus_decode_frame(data = NULL) (opus_decoder.c:316-366): conceal up to frame_size samples with the last mode; returns samples produced */
+WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i16 *pcm_out, int CC)
+{
+   WV_LDS OaDecScalars *st = &L->st;
+   frame_size = wv_uni(frame_size);
+   const int F20 = 960, F10 = 480, F5 = 240, F2_5 = 120;
+   if (frame_size < F2_5) return OA_ERR_BUFFER_TOO_SMALL;
+   const int mode = wv_uni(st->prev_redundancy) ? 1002 : wv_uni(st->prev_mode);
+   if (mode == 0) {                     /* nothing decoded yet: zeros */
+      FOR_LANES(i, frame_size * CC) pcm_out[i] = 0;
+      LANE0 st->rangeFinal = 0;
+      wv_sync();
+      return frame_size;
+   }
+   if (mode != 1002) return OA_ERR_UNIMPLEMENTED;
+   int done = 0;
+   while (done < frame_size) {
+      int audiosize = frame_size - done;
+      if (audiosize > F20) audiosize = F20;
+      else if (audiosize < F20) {
+         if (audiosize > F10) audiosize = F10;
+         else if (audiosize > F5 && audiosize < F10) audiosize = F5;
+      }
+      if (audiosize != F20 && audiosize != F10 && audiosize != F5 && audiosize != F2_5) return OA_ERR_BAD_ARG;
+      LANE0 { st->start = 0; st->stream_channels = st->stream_channels; }
+      wv_sync();
+      int r = celt_decode_frame_wave(L, gs, 0, audiosize, pcm_out + (size_t)done * CC);
+      if (r < 0) return r;
+      done += r;
+      LANE0 { st->rangeFinal = 0; st->prev_mode = mode; st->prev_redundancy = 0; }
+      wv_sync();
+      if (frame_size - done > 0 && frame_size <= F20) break;      /* a single call conceals one legal frame size; the caller loops */
+   }
+   return done;
+}
+
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
 WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
 {
@@ -452,7 +524,7 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
       int ret = 0, offset = 0;
       sh->count = 0; sh->nb_samples = 0;
       if (frame_size <= 0) ret = OA_ERR_BAD_ARG;
-      else if (len == 0 || data == 0) ret = frame_size % 120 != 0 ? OA_ERR_BAD_ARG : OA_ERR_UNIMPLEMENTED;      /* PLC */
+      else if (len == 0 || data == 0) { ret = frame_size % 120 != 0 ? OA_ERR_BAD_ARG : 0; sh->count = -1; }        /* packet loss: conceal frame_size samples */
       else if (len < 0) ret = OA_ERR_BAD_ARG;
       else {
          const int toc = data[0];
@@ -483,15 +555,27 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
    int off = wv_uni(sh->frame_bytes_off), nb = 0;
    for (int f = 0; f < count && ret >= 0; f++) {
       const int flen = wv_uni(sh->size[f]);
-      wv_sync();
-      FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
-      wv_sync();
-      int r = celt_decode_frame_wave(L, gs, flen, pfs, pcm_out + (size_t)nb * CC);
+      int r;
+      if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
+         r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
+      } else {
+         wv_sync();
+         FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
+         wv_sync();
+         r = celt_decode_frame_wave(L, gs, flen, pfs, pcm_out + (size_t)nb * CC);
+         LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1002; st->prev_redundancy = 0; }
+         wv_sync();
+      }
       if (r < 0) ret = r;
       else nb += r;
       off += flen;
-      LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1002; st->prev_redundancy = 0; }
-      wv_sync();
+   }
+   if (count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
+      while (nb < frame_size) {
+         int r = oa_conceal_wave(L, gs, frame_size - nb, pcm_out + (size_t)nb * CC, CC);
+         if (r < 0) { ret = r; break; }
+         nb += r;
+      }
    }
    if (ret >= 0) { ret = nb; LANE0 st->last_packet_duration = nb; wv_sync(); }
    /* ---- store state ---- */

@@ -62,13 +62,15 @@ WV_DEV void celt_lpc4(i16 *_lpc, const i32 *ac)
    else for (int i = 0; i < p; i++) _lpc[i] = extract16(pshr32(lpc[i], 13));
 }
 
-/* pitch_downsample (factor 2): pre[c] -> Cc.p.pitch_buf[len], len = (1024+N)>>1 */
-WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int len, int C)
+/* pitch_downsample (pitch.c:140, factor 2) of one or two channels given by sample accessors (src_at): x_lp = raw low-passed signal
+ * (scratch, len words), xx = scaled copy for the autocorrelation and then the result (len words).  Shared by the encoder's
+ * pre-filter (source: recomputed pre-emphasis) and the decoder's loss concealment (source: synthesis history ring). */
+WV_DEV i32 src_at(const PreSrc &p, int j) { return pre_at(p, j); }
+template <class Src>
+WV_DEVN void pitch_downsample_src(WV_LDS i16 *x_lp, WV_LDS i16 *xx, const Src &p0, const Src &p1, int len, int C)
 {
-   WV_LDS i16 *x_lp = (WV_LDS i16 *)L->BC.p.u.xcorr;       /* raw low-passed signal (kept for the final FIR) */
-   WV_LDS i16 *xx = L->BC.p.pitch_buf;                    /* scaled copy for the autocorrelation, then the result */
    i32 maxabs = 0;
-   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(pre_at(p0, i))); if (C == 2) maxabs = imax(maxabs, iabs(pre_at(p1, i))); }
+   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(src_at(p0, i))); if (C == 2) maxabs = imax(maxabs, iabs(src_at(p1, i))); }
    maxabs = wv_max(maxabs);
    if (maxabs < 1) maxabs = 1;
    int shift = celt_ilog2(maxabs) - 10;
@@ -76,11 +78,11 @@ WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const P
    if (C == 2) shift++;
    FOR_LANES(i, len) {
       i16 v;
-      if (i == 0) v = (i16)((pre_at(p0, 1) >> (shift + 2)) + (pre_at(p0, 0) >> (shift + 1)));
-      else v = (i16)((pre_at(p0, 2 * i - 1) >> (shift + 2)) + (pre_at(p0, 2 * i + 1) >> (shift + 2)) + (pre_at(p0, 2 * i) >> (shift + 1)));
+      if (i == 0) v = (i16)((src_at(p0, 1) >> (shift + 2)) + (src_at(p0, 0) >> (shift + 1)));
+      else v = (i16)((src_at(p0, 2 * i - 1) >> (shift + 2)) + (src_at(p0, 2 * i + 1) >> (shift + 2)) + (src_at(p0, 2 * i) >> (shift + 1)));
       if (C == 2) {
-         if (i == 0) v = (i16)(v + (pre_at(p1, 1) >> (shift + 2)) + (pre_at(p1, 0) >> (shift + 1)));
-         else v = (i16)(v + (pre_at(p1, 2 * i - 1) >> (shift + 2)) + (pre_at(p1, 2 * i + 1) >> (shift + 2)) + (pre_at(p1, 2 * i) >> (shift + 1)));
+         if (i == 0) v = (i16)(v + (src_at(p1, 1) >> (shift + 2)) + (src_at(p1, 0) >> (shift + 1)));
+         else v = (i16)(v + (src_at(p1, 2 * i - 1) >> (shift + 2)) + (src_at(p1, 2 * i + 1) >> (shift + 2)) + (src_at(p1, 2 * i) >> (shift + 1)));
       }
       x_lp[i] = v;
    }
@@ -139,6 +141,11 @@ WV_DEVN void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const P
    wv_sync();
 }
 
+WV_DEV void pitch_downsample_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int len, int C)
+{
+   pitch_downsample_src((WV_LDS i16 *)L->BC.p.u.xcorr, L->BC.p.pitch_buf, p0, p1, len, C);
+}
+
 /* find_best_pitch (pitch.c:45): a running-energy recursion with a clamp -> lane 0 */
 WV_DEV void find_best_pitch_l0(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int len, int max_pitch, int *best_pitch, int yshift, i32 maxcorr)
 {
@@ -165,11 +172,8 @@ WV_DEV void find_best_pitch_l0(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int
 }
 
 /* pitch_search (pitch.c:307); returns the pitch lag in every lane */
-WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
+WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LDS i16 *x_lp4, WV_LDS i16 *y_lp4, WV_LDS i32 *xcorr, WV_LDS i32 *hand, int len, int max_pitch)
 {
-   const WV_LDS i16 *y = L->BC.p.pitch_buf, *x_lp = L->BC.p.pitch_buf + (OA_MAX_PERIOD >> 1);
-   WV_LDS i16 *x_lp4 = L->BC.p.x_lp4, *y_lp4 = L->BC.p.y_lp4;
-   WV_LDS i32 *xcorr = L->BC.p.u.xcorr;
    const int lag = len + max_pitch;
    i32 xmax = 0, ymax = 0;
    FOR_LANES(j, len >> 2) { i16 v = x_lp[2 * j]; x_lp4[j] = v; xmax = imax(xmax, iabs((i32)v)); }
@@ -196,10 +200,10 @@ WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
    LANE0 {
       int bp[2];
       find_best_pitch_l0(xcorr, y_lp4, len >> 2, max_pitch >> 2, bp, 0, maxcorr);
-      L->sh.r[0] = bp[0]; L->sh.r[1] = bp[1];
+      hand[0] = bp[0]; hand[1] = bp[1];
    }
    wv_sync();
-   int bp0 = L->sh.r[0], bp1 = L->sh.r[1];
+   int bp0 = hand[0], bp1 = hand[1];
    wv_sync();
    /* finer search, 2x decimated, around the two candidates */
    maxcorr = 1;
@@ -223,12 +227,17 @@ WV_DEVN int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
          if ((c - a) > mult16_32_q15(QC16(.7f, 15), b - a)) offset = 1;
          else if ((a - c) > mult16_32_q15(QC16(.7f, 15), b - c)) offset = -1;
       }
-      L->sh.r[0] = 2 * bp[0] - offset;
+      hand[0] = 2 * bp[0] - offset;
    }
    wv_sync();
-   int pitch = L->sh.r[0];
+   int pitch = hand[0];
    wv_sync();
    return pitch;
+}
+
+WV_DEV int pitch_search_wave(WV_LDS FrameLds *L, int len, int max_pitch)
+{
+   return pitch_search_bufs(L->BC.p.pitch_buf + (OA_MAX_PERIOD >> 1), L->BC.p.pitch_buf, L->BC.p.x_lp4, L->BC.p.y_lp4, L->BC.p.u.xcorr, L->sh.r, len, max_pitch);
 }
 
 WV_DEV i16 pitch_gain_fx(i32 xy, i32 xx, i32 yy)

@@ -74,6 +74,7 @@ struct OaDecStream {
    OaDecScalars s;
    int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], backgroundLogE[2 * OA_NB_EBANDS];
    int32_t overlap_mem[2 * OA_OVERLAP];
+   int32_t plc_lpc[2 * 24];                /* concealment LPC (int16 values), celt_decoder.c:722 */
    int32_t hist[2 * OA_DEC_HISTORY];
 };
 #endif

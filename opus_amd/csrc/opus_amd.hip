@@ -544,8 +544,8 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
    if (frame_size <= 0 || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG;
    if ((decode_fec || len == 0 || data == nullptr) && frame_size % (st->Fs / 400) != 0) return OPUS_BAD_ARG;
-   if (len == 0 || data == nullptr || decode_fec) return OPUS_UNIMPLEMENTED;      /* PLC / FEC */
    if (len < 0) return OPUS_BAD_ARG;
+   if (data == nullptr || decode_fec) len = 0;      /* packet loss; CELT-only streams carry no in-band FEC, so decode_fec conceals too (opus_decoder.c:805) */
    if (frame_size > 5760) frame_size = 5760;
    std::lock_guard<std::mutex> lock(g_classic_dec_mu);
    const int ci = st->s.s.channels - 1;
@@ -556,7 +556,7 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    }
    OpusGpuDecBatch *b = g_classic_dec[ci];
    std::vector<unsigned char> pkt((size_t)len + 8, 0);
-   memcpy(pkt.data(), data, (size_t)len);
+   if (len > 0) memcpy(pkt.data(), data, (size_t)len);
    std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
    opus_int32 n = 0, l = len; opus_uint32 rng = 0;
    int r = opusgpu_dec_batch_import_state(b, 0, &st->s);

@@ -409,14 +409,16 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
    const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
    if (frame_size > Fs / 25 * 3) frame_size = Fs / 25 * 3;
    if (len < 0) return OPUS_BAD_ARG;
-   if (len == 0 || data == NULL || decode_fec) return OPUS_UNIMPLEMENTED;           /* PLC / FEC */
-   if (len < 2 * ns - 1) return OPUS_INVALID_PACKET;
+   const bool lost = len == 0 || data == NULL || decode_fec;                        /* every stream conceals frame_size samples */
+   if (lost && frame_size % (Fs / 400) != 0) return OPUS_BAD_ARG;
+   if (!lost && len < 2 * ns - 1) return OPUS_INVALID_PACKET;
    /* opus_multistream_packet_validate (:149) + re-framing of every stream's self-delimited packet as a plain packet for the batch decoder */
    const int stride = 1280 * 6 + 16;
    std::vector<unsigned char> pk((size_t)ns * stride, 0);
    std::vector<opus_int32> lens((size_t)ns);
    int samples = 0;
-   {
+   if (lost) { for (int s = 0; s < ns; s++) lens[s] = 0; }
+   else {
       const unsigned char *p = data; opus_int32 left = len;
       for (int s = 0; s < ns; s++) {
          unsigned char toc; opus_int16 size[48]; opus_int32 packet_offset;

@@ -35,6 +35,9 @@ WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
    return old;
 }
 
+/* lane i receives v of lane i-1, lane 0 receives `fill` (DPP wave_shr:1: one instruction, no LDS) */
+WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+
 /* Wave-wide reductions on the DPP cross-lane network (no LDS round trips, unlike ds_bpermute shuffles):
  * quad_perm swaps -> row rotations (every lane of a 16-lane row holds the row result) -> row_bcast:15 / row_bcast:31
  * carry the partial results up the rows; lane 63 ends with the wave result, v_readlane broadcasts it. */

@@ -191,3 +191,58 @@ def test_gpu_dec_corrupted_packets():
             assert a[0] == int(ns[s]), (i, s, a[0], int(ns[s]), pk[s][:4].hex())
             if a[0] > 0: assert a[2] == int(rngs[s]) and np.array_equal(a[1], pcm[s, :a[0]]), (i, s)
     b.close()
+
+@pytest.mark.parametrize("channels,bitrate,frame,pattern", [
+    (2, 96000, 960, "single"), (2, 96000, 960, "burst"), (1, 32000, 960, "burst"), (2, 64000, 480, "random"), (2, 128000, 240, "random"),
+    (2, 128000, 120, "burst"), (2, 48000, 960, "long"), (1, 64000, 480, "start")])
+def test_gpu_dec_packet_loss(channels, bitrate, frame, pattern):
+    """lost packets (lens[s] = 0) per stream: pitch PLC, fade, noise PLC after long bursts, recovery frames — identical to the oracle (== reference);
+    every stream of the batch has its own loss pattern"""
+    oa = _oa()
+    from test_oracle_encoder import OracleEnc
+    from test_oracle_decoder import OracleDec
+    rng = np.random.default_rng(41)
+    S = 8
+    n = min(40 * 960 // frame, 100)
+    sig = signals.music(n * frame // 960 + 1, channels=channels, seed=42)
+    e = OracleEnc(channels, bitrate=bitrate, complexity=5)
+    base = {"single": {10, 20, 30}, "burst": set(range(8, 14)) | set(range(30, 33)), "random": set(np.nonzero(rng.random(n) < 0.2)[0].tolist()),
+            "long": set(range(6, 40)), "start": {0, 1, 5}}[pattern]
+    lost = [{(i + 3 * s) % n for i in base} if s else base for s in range(S)]
+    chk = [OracleDec(channels) for _ in range(S)]
+    b = oa.DecoderBatch(S, channels=channels)
+    for i in range(n):
+        pkt = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)[0]
+        pk = [b"" if i in lost[s] else pkt for s in range(S)]
+        pcm, ns, rngs = b.decode(pk, frame)
+        for s in range(S):
+            if i in lost[s]:
+                pb = np.zeros((frame, channels), np.int16)
+                nb = chk[s].O.oc_opus_decode(chk[s].buf, None, 0, pb.ctypes.data, frame, 0)
+                assert nb == int(ns[s]) == frame and int(rngs[s]) == 0 and np.array_equal(pb, pcm[s]), (i, s, "lost")
+            else:
+                a = chk[s].decode(pkt)
+                assert a[0] == int(ns[s]) == frame and a[2] == int(rngs[s]) and np.array_equal(a[1], pcm[s]), (i, s, "recv")
+    b.close()
+
+@pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")
+def test_gpu_dec_classic_loss_api_vs_reference():
+    """opus_decode(st, NULL, 0, ...) and decode_fec = 1 through the classic entry point, against the compiled reference"""
+    oa = _oa()
+    from test_oracle_encoder import RefEnc
+    from test_oracle_decoder import RefDec
+    L = oa.lib()
+    L.opus_decode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    e = RefEnc(2, bitrate=64000, complexity=5); r = RefDec(2); d = oa.OpusDecoder(48000, 2)
+    sig = signals.music(30, seed=51)
+    for i in range(30):
+        pkt = e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)[0]
+        pa = np.zeros((960, 2), np.int16); pb = np.zeros((960, 2), np.int16)
+        if i % 7 == 3:
+            na = r.L.opus_decode(r.st, None, 0, pa.ctypes.data, 960, 0); nb = L.opus_decode(d._st, None, 0, pb.ctypes.data, 960, 0)
+        elif i % 7 == 5:
+            na = r.L.opus_decode(r.st, pkt, len(pkt), pa.ctypes.data, 960, 1); nb = L.opus_decode(d._st, pkt, len(pkt), pb.ctypes.data, 960, 1)
+        else:
+            na = r.L.opus_decode(r.st, pkt, len(pkt), pa.ctypes.data, 960, 0); nb = L.opus_decode(d._st, pkt, len(pkt), pb.ctypes.data, 960, 0)
+        assert na == nb == 960 and np.array_equal(pa, pb), (i, na, nb)
+    assert L.opus_decode(d._st, None, 0, pb.ctypes.data, 961, 0) == r.L.opus_decode(r.st, None, 0, pa.ctypes.data, 961, 0) == -1

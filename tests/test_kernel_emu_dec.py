@@ -74,3 +74,26 @@ def test_emu_dec_corrupted_packets():
             a = o.decode(q); b = k.decode(q)
             assert a[0] == b[0], (i, a[0], b[0], q[:4].hex())
             if a[0] > 0: assert a[2] == b[2] and np.array_equal(a[1], b[1]), (i, q[:4].hex())
+
+@pytest.mark.parametrize("channels,bitrate,frame,pattern", [
+    (2, 96000, 960, "single"), (2, 96000, 960, "burst"), (1, 32000, 960, "burst"), (2, 64000, 480, "random"), (2, 128000, 240, "random"),
+    (2, 128000, 120, "burst"), (2, 48000, 960, "long"), (1, 64000, 480, "start")])
+def test_emu_dec_packet_loss(channels, bitrate, frame, pattern):
+    """lost packets (len 0): pitch PLC, fade, noise PLC after long losses, recovery (prefilter_and_fold, energy safety) == oracle == reference"""
+    rng = np.random.default_rng(41)
+    n = min(40 * 960 // frame, 100)
+    sig = signals.music(n * frame // 960 + 1, channels=channels, seed=42)
+    e = OracleEnc(channels, bitrate=bitrate, complexity=5); o = OracleDec(channels); k = EmuDec(channels)
+    lost = {"single": {10, 20, 30}, "burst": set(range(8, 14)) | set(range(30, 33)), "random": set(np.nonzero(rng.random(n) < 0.2)[0].tolist()),
+            "long": set(range(6, 40)), "start": {0, 1, 5}}[pattern]
+    for i in range(n):
+        pkt = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)[0]
+        if i in lost:
+            pb = np.zeros((frame, channels), np.int16)
+            nb = o.O.oc_opus_decode(o.buf, None, 0, pb.ctypes.data, frame, 0)
+            a = k.decode(b"", frame)
+            assert nb == a[0] == frame, (i, nb, a[0])
+            assert np.array_equal(pb, a[1]), (i, "lost", np.argwhere(pb != a[1])[:4])
+        else:
+            a = o.decode(pkt); b = k.decode(pkt)
+            assert a[0] == b[0] == frame and a[2] == b[2] and np.array_equal(a[1], b[1]), (i, "recv", np.argwhere(a[1] != b[1])[:4])
