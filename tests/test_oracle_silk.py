@@ -1,0 +1,80 @@
+"""CPU: the plain-C restatement of the SILK building blocks (oracle/oc_silk_*.c) pinned against the compiled, unmodified
+reference (silk_NSQ_c, silk_NSQ_del_dec_c, silk_LPC_analysis_filter, DIV32/INVERSE32_varQ).  Bit-exact or fail."""
+import ctypes, numpy as np, pytest
+from reflib import ref_expose, oracle
+from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame, make_input
+
+pytestmark = pytest.mark.skipif(ref_expose() is None or oracle() is None, reason="oracle/_ref or oracle lib not built")
+def P(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+def test_varq_division():
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(0)
+    for f in (X.ref_silk_div32_varQ, X.ref_silk_inverse32_varQ, O.oc_silk_div32_varQ, O.oc_silk_inverse32_varQ): f.restype = ctypes.c_int32
+    for _ in range(20000):
+        a = int(rng.integers(-2**31 + 1, 2**31 - 1)); b = int(2 ** rng.uniform(0, 31)) * int(rng.choice([-1, 1])) or 1
+        q = int(rng.integers(0, 32))
+        assert X.ref_silk_div32_varQ(a, b, q) == O.oc_silk_div32_varQ(a, b, q), (a, b, q)
+        q = int(rng.integers(1, 48))
+        assert X.ref_silk_inverse32_varQ(b, q) == O.oc_silk_inverse32_varQ(b, q), (b, q)
+
+def test_lpc_analysis_filter():
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(1)
+    for it in range(300):
+        d = int(rng.choice([6, 8, 10, 12, 16])); n = int(rng.integers(d, 700))
+        x = rng.integers(-32768, 32768, n).astype(np.int16)
+        B = rng.integers(-32768 if it % 3 == 0 else -4096, 32768 if it % 3 == 0 else 4096, d).astype(np.int16)   # 1/3 of the cases wrap and saturate
+        o1 = np.full(n, 77, np.int16); o2 = o1.copy()
+        X.ref_silk_lpc_analysis_filter(P(o1), P(x), P(B), n, d); O.oc_silk_lpc_analysis_filter(P(o2), P(x), P(B), n, d)
+        assert np.array_equal(o1, o2)
+
+def run_ref(cfg, dd, st, fr, x):
+    X = ref_expose()
+    pulses = np.zeros(len(x), np.int8)
+    ind = np.array([fr["signalType"], fr["quantOffsetType"], fr["NLSFInterpCoef_Q2"], fr["Seed"]], np.int8)
+    hs, ti, lf, ga, pl = (np.ascontiguousarray(fr[k]) for k in ("HarmShapeGain_Q14", "Tilt_Q14", "LF_shp_Q14", "Gains_Q16", "pitchL"))
+    pc, lt, ar = (np.ascontiguousarray(fr[k]) for k in ("PredCoef_Q12", "LTPCoef_Q14", "AR_Q13"))
+    X.ref_silk_nsq(P(cfg), int(dd), P(st), P(ind), P(x), P(pulses), P(pc), P(lt), P(ar), P(hs), P(ti), P(lf), P(ga), P(pl),
+                   int(fr["Lambda_Q10"]), int(fr["LTP_scale_Q14"]))
+    return pulses, int(ind[3])
+
+def run_oracle(cfg, dd, st, fr, x):
+    O = oracle()
+    pulses = np.zeros(len(x), np.int8)
+    f = np.array([fr], dtype=NSQ_FRAME)
+    (O.oc_silk_nsq_del_dec if dd else O.oc_silk_nsq)(P(cfg), P(st), P(f), P(x), P(pulses))
+    return pulses, int(f[0]["Seed"])
+
+def state_equal(a, b, cfg):
+    """every persistent word; sLPC_Q14[16:] is per-call scratch in the reference (only [0:16] carries over)"""
+    for name in NSQ_STATE.names:
+        x, y = a[name][0], b[name][0]
+        if name == "sLPC_Q14": x, y = x[:16], y[:16]
+        if name in ("xq", "sLTP_shp_Q14"): x, y = x[:20 * int(cfg[0])], y[:20 * int(cfg[0])]   # [ltp_mem:] is dead after the memmove
+        if name == "rand_seed": continue       # silk_NSQ_del_dec_c never touches it; silk_NSQ_c leaves the running dither there, checked below
+        if not np.array_equal(x, y): return name
+    return None
+
+CASES = [(16, 4, 24, 1, False, False), (16, 4, 16, 1, False, False), (8, 4, 12, 1, False, False), (12, 2, 14, 1, False, False),
+         (16, 4, 24, 4, True, True), (16, 4, 24, 2, True, True), (16, 4, 16, 3, True, True), (16, 2, 24, 4, True, True),
+         (8, 4, 12, 4, True, True), (12, 4, 14, 2, False, True), (16, 4, 20, 1, True, True)]
+
+@pytest.mark.needs_ref
+@pytest.mark.parametrize("fs,nb,shaping,states,warp,dd", CASES)
+def test_nsq_matches_reference(fs, nb, shaping, states, warp, dd):
+    cfg = make_cfg(fs, nb, shaping, states, warp)
+    rng = np.random.default_rng(fs * 1000 + nb * 100 + shaping + states + dd)
+    for stream in range(6):
+        s_ref, s_or = fresh_state(), fresh_state()
+        nz = 0
+        for frame in range(8):
+            fr = make_frame(rng, cfg)
+            x = make_input(rng, cfg, fr["Gains_Q16"])
+            p1, seed1 = run_ref(cfg, dd, s_ref, fr, x)
+            p2, seed2 = run_oracle(cfg, dd, s_or, fr, x)
+            assert np.array_equal(p1, p2), (stream, frame, np.nonzero(p1 != p2)[0][:8])
+            assert seed1 == seed2
+            bad = state_equal(s_ref, s_or, cfg)
+            assert bad is None, (stream, frame, bad)
+            if not dd: assert s_ref["rand_seed"][0] == s_or["rand_seed"][0]
+            nz += int(np.count_nonzero(p1))
+        assert nz > 100                       # the synthetic inputs do exercise the quantiser
