@@ -10,6 +10,7 @@ typedef int32_t  i32;
 typedef int64_t  i64;
 typedef uint32_t u32;
 typedef uint8_t  u8;
+typedef int8_t   i8;
 #define SIG_SHIFT 12
 #define SIG_SAT 536870911
 #define NORM_SHIFT 24

@@ -1,0 +1,46 @@
+/* tests/emu/emu_silk.cpp — TEST INFRASTRUCTURE: runs the SILK quantiser kernel bodies (opus_amd/csrc/silk_nsq*.h) on the CPU
+ * wave emulator, 64 fibers per tile, so the exact device source is checked against the oracle without a GPU. */
+#include "wave_emu.h"
+#include "fx.h"
+#include "silk_nsq.h"
+#include "silk_nsq_dd.h"
+#include "silk_host.h"
+
+struct NsqJob { OaNsqCfg cfg; int32_t *tile; const OaNsqFrame *frames; const int16_t *x16; int8_t *pulses; int8_t *seed_out; int first, n; };
+static void nsq_entry(void *arg)
+{
+   NsqJob *j = (NsqJob *)arg;
+   int lane = wv_lane(), sidx = j->first + lane; bool act = sidx < j->n; if (!act) sidx = j->first;
+   const int frame = j->cfg.nb_subfr * 5 * j->cfg.fs_kHz;
+   NsqMem m = nsq_mem(j->tile, 64, lane, 20 * j->cfg.fs_kHz + frame);
+   silk_nsq_lane(j->cfg, m, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, act);
+}
+extern "C" long emu_nsq_tile_words(int T) { return (long)oa_nsq_tile_words(T); }
+extern "C" void emu_nsq_import(int32_t *tile, int T, int t, const OaNsqRefState *r, const OaNsqCfg *cfg) { oa_nsq_import(tile, T, t, r, cfg); }
+extern "C" void emu_nsq_export(const int32_t *tile, int T, int t, OaNsqRefState *r, const OaNsqCfg *cfg) { oa_nsq_export(tile, T, t, r, cfg); }
+extern "C" void emu_silk_nsq(const OaNsqCfg *cfg, int32_t *tiles, const OaNsqFrame *frames, const int16_t *x16, int8_t *pulses, int n)
+{
+   const long tw = (long)oa_nsq_tile_words(64);
+   for (int first = 0, tl = 0; first < n; first += 64, tl++) {
+      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, nullptr, first, n };
+      emu_run_wave(nsq_entry, &j);
+   }
+}
+
+static void nsq_dd_entry(void *arg)
+{
+   NsqJob *j = (NsqJob *)arg;
+   int lane = wv_lane(), sidx = j->first + (lane >> 2); bool act = sidx < j->n; if (!act) sidx = j->first;
+   const int frame = j->cfg.nb_subfr * 5 * j->cfg.fs_kHz;
+   NsqMem m = nsq_mem(j->tile, 16, lane >> 2, 20 * j->cfg.fs_kHz + frame);
+   int32_t *ring = j->tile + (oa_nsq_tile_words(16) - 5 * OA_SILK_DD * 64);
+   silk_nsq_dd_wave(j->cfg, m, ring, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, j->seed_out + sidx, act);
+}
+extern "C" void emu_silk_nsq_dd(const OaNsqCfg *cfg, int32_t *tiles, const OaNsqFrame *frames, const int16_t *x16, int8_t *pulses, int8_t *seed_out, int n)
+{
+   const long tw = (long)oa_nsq_tile_words(16);
+   for (int first = 0, tl = 0; first < n; first += 16, tl++) {
+      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, seed_out, first, n };
+      emu_run_wave(nsq_dd_entry, &j);
+   }
+}

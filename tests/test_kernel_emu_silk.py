@@ -1,0 +1,78 @@
+"""CPU: the SILK quantiser kernel bodies (opus_amd/csrc/silk_nsq*.h — the exact device source) run on the 64-fiber wave emulator
+and compared word-for-word with the oracle restatement (which tests/test_oracle_silk.py pins to the compiled reference)."""
+import ctypes, os, subprocess, numpy as np, pytest
+from reflib import oracle, ROOT
+from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame, make_input
+
+def _build():
+    so = os.path.join(ROOT, "tests/emu/libemu_silk.so")
+    srcs = [os.path.join(ROOT, "tests/emu", f) for f in ("emu_silk.cpp", "wave_emu.cpp")]
+    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
+    hdrs = [h for h in hdrs if os.path.exists(h)]
+    import fcntl
+    with open(so + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs + hdrs):
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-rdynamic", "-I" + os.path.join(ROOT, "tests/emu"),
+                                   "-I" + os.path.join(ROOT, "opus_amd/csrc")] + srcs + ["-o", so + ".tmp"])
+            os.replace(so + ".tmp", so)
+    return ctypes.CDLL(so)
+
+pytestmark = pytest.mark.skipif(oracle() is None, reason="oracle lib not built")
+def P(a): return a.ctypes.data_as(ctypes.c_void_p)
+PERSISTENT = ["xq", "sLTP_shp_Q14", "sLPC_Q14", "sAR2_Q14", "sLF_AR_shp_Q14", "sDiff_shp_Q14", "lagPrev", "prev_gain_Q16"]
+
+def compare_states(a, b, cfg, with_seed):
+    mem = 20 * int(cfg[0])
+    for name in PERSISTENT + (["rand_seed"] if with_seed else []):
+        x, y = a[name], b[name]
+        if name == "sLPC_Q14": x, y = x[:, :16], y[:, :16]
+        if name in ("xq", "sLTP_shp_Q14"): x, y = x[:, :mem], y[:, :mem]
+        assert np.array_equal(x, y), name
+
+def drive(E, cfg, dd, n, frames, seed, T):
+    """n streams x `frames` frames through the emulator and the oracle; states imported from the oracle's layout at start and
+    exported after every frame."""
+    O = oracle(); rng = np.random.default_rng(seed)
+    L = int(cfg[1]) * 5 * int(cfg[0])
+    tw = E.emu_nsq_tile_words(T); ntiles = (n + T - 1) // T
+    tiles = np.zeros(ntiles * tw, np.int32)
+    st_or = fresh_state(n)
+    # start from a non-trivial state: one oracle frame first
+    for warm in range(1):
+        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
+        for s in range(n):
+            p = np.zeros(L, np.int8)
+            (O.oc_silk_nsq_del_dec if dd else O.oc_silk_nsq)(P(cfg), P(st_or[s:s + 1]), P(fr[s:s + 1]), P(x[s]), P(p))
+    for s in range(n):
+        E.emu_nsq_import(P(tiles[(s // T) * tw:]), T, s % T, P(st_or[s:s + 1]), P(cfg))
+    for f in range(frames):
+        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
+        p_or = np.zeros((n, L), np.int8); fr_or = fr.copy()
+        for s in range(n):
+            (O.oc_silk_nsq_del_dec if dd else O.oc_silk_nsq)(P(cfg), P(st_or[s:s + 1]), P(fr_or[s:s + 1]), P(x[s]), P(p_or[s]))
+        p_em = np.full((n, L), 99, np.int8); seeds = np.full(n, 99, np.int8)
+        if dd: E.emu_silk_nsq_dd(P(cfg), P(tiles), P(fr), P(x), P(p_em), P(seeds), n)
+        else: E.emu_silk_nsq(P(cfg), P(tiles), P(fr), P(x), P(p_em), n)
+        bad = np.nonzero((p_em != p_or).any(axis=1))[0]
+        assert len(bad) == 0, (f, bad[:8], [np.nonzero(p_em[b] != p_or[b])[0][:4] for b in bad[:4]])
+        if dd: assert np.array_equal(seeds, fr_or["Seed"])
+        st_em = np.zeros(n, dtype=NSQ_STATE)
+        for s in range(n):
+            E.emu_nsq_export(P(tiles[(s // T) * tw:]), T, s % T, P(st_em[s:s + 1]), P(cfg))
+        compare_states(st_em, st_or, cfg, with_seed=not dd)
+
+@pytest.mark.parametrize("fs,nb,shaping", [(16, 4, 24), (16, 4, 16), (8, 4, 12), (12, 2, 14), (16, 2, 20)])
+def test_emu_nsq(fs, nb, shaping):
+    E = _build()
+    cfg = make_cfg(fs, nb, shaping, 1, False)
+    drive(E, cfg, False, n=70, frames=3, seed=fs + nb + shaping, T=64)
+
+@pytest.mark.parametrize("fs,nb,shaping,states,warp", [(16, 4, 24, 4, True), (16, 4, 24, 2, True), (16, 4, 16, 3, True), (16, 2, 24, 4, True),
+                                                        (8, 4, 12, 4, True), (12, 4, 14, 2, False), (16, 4, 20, 1, True)])
+def test_emu_nsq_del_dec(fs, nb, shaping, states, warp):
+    E = _build()
+    cfg = make_cfg(fs, nb, shaping, states, warp)
+    drive(E, cfg, True, n=21, frames=3, seed=fs + nb + shaping + states, T=16)
