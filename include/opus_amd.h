@@ -73,6 +73,7 @@ extern "C" {
 #define OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST 4047
 
 typedef int16_t opus_int16;
+typedef int8_t opus_int8;
 typedef int32_t opus_int32;
 typedef uint32_t opus_uint32;
 typedef struct OpusEncoder OpusEncoder;
@@ -202,6 +203,41 @@ OPUS_AMD_EXPORT int opus_multistream_decoder_init(OpusMSDecoder *st, opus_int32 
 OPUS_AMD_EXPORT int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec);
 OPUS_AMD_EXPORT int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...);
 OPUS_AMD_EXPORT void opus_multistream_decoder_destroy(OpusMSDecoder *st);
+
+/* ================= SILK building blocks (reference/silk/NSQ.c, NSQ_del_dec.c, LPC_analysis_filter.c) =================
+ * The noise-shaping quantiser for N independent SILK channels, one frame per call.  This is the reference's own RTCD cut
+ * (SILK_NSQ_IMPL / SILK_NSQ_DEL_DEC_IMPL, silk/x86/x86_silk_map.c:47-179, prototypes silk/main.h:236-272) lifted to a batch:
+ *   OpusGpuNsqConfig = the six silk_encoder_state fields the quantisers read (silk/structs.h:167-207); frame_length =
+ *                      nb_subfr * 5 * fs_kHz, ltp_mem_length = 20 * fs_kHz as set by silk_setup_fs (silk/control_codec.c:225-246)
+ *   OpusGpuNsqFrame  = the argument list of silk_NSQ_c / silk_NSQ_del_dec_c (silk/NSQ.c:76-93, silk/NSQ_del_dec.c:114-131) incl. the
+ *                      four SideInfoIndices fields they read (silk/structs.h:129-141)
+ *   state blob       = silk_nsq_state, byte for byte (silk/structs.h:56-69, 4,352 B); import/export only — between calls the
+ *                      states live in HBM in a tile-transposed layout
+ * Dispatch as in the reference: delayed decision iff nStatesDelayedDecision > 1 || warping_Q16 > 0 (silk/float/wrappers_FLP.c:163).
+ * Output: pulses[n][frame_length] exactly as the reference writes them; seed_out[i] = psIndices->Seed after the call. */
+typedef struct OpusGpuNsqBatch OpusGpuNsqBatch;
+typedef struct { opus_int32 fs_kHz, nb_subfr, predictLPCOrder, shapingLPCOrder, nStatesDelayedDecision, warping_Q16; } OpusGpuNsqConfig;
+typedef struct {
+   signed char signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed;
+   opus_int16 PredCoef_Q12[2 * 16];
+   opus_int16 LTPCoef_Q14[5 * 4];
+   opus_int16 AR_Q13[4 * 24];
+   opus_int32 HarmShapeGain_Q14[4], Tilt_Q14[4], LF_shp_Q14[4], Gains_Q16[4], pitchL[4];
+   opus_int32 Lambda_Q10, LTP_scale_Q14;
+} OpusGpuNsqFrame;
+OPUS_AMD_EXPORT OpusGpuNsqBatch *opusgpu_nsq_batch_create(opus_int32 nstreams, const OpusGpuNsqConfig *config, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_nsq_batch_destroy(OpusGpuNsqBatch *b);
+OPUS_AMD_EXPORT opus_int32 opusgpu_nsq_batch_streams(const OpusGpuNsqBatch *b);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_frame_length(const OpusGpuNsqBatch *b);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_reset(OpusGpuNsqBatch *b);                       /* silk/control_codec.c:247-258 */
+OPUS_AMD_EXPORT int opusgpu_nsq_state_size(void);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_import_state(OpusGpuNsqBatch *b, opus_int32 stream, const void *silk_nsq_state);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_export_state(OpusGpuNsqBatch *b, opus_int32 stream, void *silk_nsq_state);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_run(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *frames, const opus_int16 *x16, opus_int8 *pulses, opus_int8 *seed_out);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_run_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, const opus_int16 *d_x16, opus_int8 *d_pulses,
+      opus_int8 *d_seed_out, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_nsq_batch_sync(OpusGpuNsqBatch *b);
+OPUS_AMD_EXPORT int opusgpu_nsq_time_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, const opus_int16 *d_x16, opus_int8 *d_pulses, int steps, float *ms);
 
 #ifdef __cplusplus
 }

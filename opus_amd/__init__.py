@@ -71,6 +71,14 @@ def lib():
         L.opusgpu_time_decode_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.opusgpu_dec_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_dec_batch_import_state.argtypes = [vp, i32, vp]
         L.opusgpu_dec_batch_sync.argtypes = [vp]; L.opusgpu_dec_batch_reset.argtypes = [vp]
+        # SILK building blocks
+        L.opusgpu_nsq_batch_create.restype = vp; L.opusgpu_nsq_batch_create.argtypes = [i32, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opusgpu_nsq_batch_destroy.argtypes = [vp]; L.opusgpu_nsq_batch_destroy.restype = None
+        L.opusgpu_nsq_batch_reset.argtypes = [vp]; L.opusgpu_nsq_batch_sync.argtypes = [vp]
+        L.opusgpu_nsq_batch_import_state.argtypes = [vp, i32, vp]; L.opusgpu_nsq_batch_export_state.argtypes = [vp, i32, vp]
+        L.opusgpu_nsq_batch_run.argtypes = [vp, vp, vp, vp, vp]
+        L.opusgpu_nsq_batch_run_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.opusgpu_nsq_time_dev.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib
 
@@ -221,4 +229,50 @@ class DecoderBatch:
     def sync(self): self._L.opusgpu_dec_batch_sync(self._b)
     def close(self):
         if getattr(self, "_b", None): self._L.opusgpu_dec_batch_destroy(self._b); self._b = None
+    def __del__(self): self.close()
+
+
+class NsqBatch:
+    """N independent SILK channels' noise-shaping quantisers on one GPU (include/opus_amd.h opusgpu_nsq_*; reference silk/NSQ.c:76,
+    silk/NSQ_del_dec.c:114).  cfg = (fs_kHz, nb_subfr, predictLPCOrder, shapingLPCOrder, nStatesDelayedDecision, warping_Q16)."""
+    def __init__(self, nstreams, cfg, device=0):
+        import numpy as np
+        err = ctypes.c_int()
+        self._L = lib()
+        self.cfg = np.ascontiguousarray(cfg, dtype=np.int32)
+        self._b = self._L.opusgpu_nsq_batch_create(nstreams, self.cfg.ctypes.data, device, ctypes.byref(err))
+        if not self._b: raise OpusError(err.value)
+        self.n, self.device = nstreams, device
+        self.frame_length = int(self.cfg[1]) * 5 * int(self.cfg[0])
+    def run(self, frames, x16):
+        """frames: structured array [n] laid out as OpusGpuNsqFrame (388 B); x16: int16 [n, frame_length].  Returns (pulses int8 [n, frame_length], seed int8 [n])."""
+        import numpy as np
+        assert frames.shape == (self.n,) and frames.dtype.itemsize == 388 and x16.shape == (self.n, self.frame_length) and x16.dtype == np.int16
+        frames = np.ascontiguousarray(frames); x16 = np.ascontiguousarray(x16)
+        pulses = np.zeros((self.n, self.frame_length), np.int8); seed = np.zeros(self.n, np.int8)
+        r = self._L.opusgpu_nsq_batch_run(self._b, frames.ctypes.data, x16.ctypes.data, pulses.ctypes.data, seed.ctypes.data)
+        if r != OPUS_OK: raise OpusError(r)
+        return pulses, seed
+    def run_dev(self, d_frames_ptr, d_x16_ptr, d_pulses_ptr, d_seed_ptr=None, hip_stream=None):
+        r = self._L.opusgpu_nsq_batch_run_dev(self._b, d_frames_ptr, d_x16_ptr, d_pulses_ptr, d_seed_ptr, hip_stream)
+        if r != OPUS_OK: raise OpusError(r)
+    def time_dev(self, d_frames_ptr, d_x16_ptr, d_pulses_ptr, steps):
+        ms = ctypes.c_float()
+        r = self._L.opusgpu_nsq_time_dev(self._b, d_frames_ptr, d_x16_ptr, d_pulses_ptr, steps, ctypes.byref(ms))
+        if r != OPUS_OK: raise OpusError(r)
+        return ms.value
+    def export_state(self, stream):
+        buf = ctypes.create_string_buffer(self._L.opusgpu_nsq_state_size())
+        r = self._L.opusgpu_nsq_batch_export_state(self._b, stream, buf)
+        if r != OPUS_OK: raise OpusError(r)
+        return buf.raw
+    def import_state(self, stream, blob):
+        r = self._L.opusgpu_nsq_batch_import_state(self._b, stream, bytes(blob))
+        if r != OPUS_OK: raise OpusError(r)
+    def reset(self):
+        r = self._L.opusgpu_nsq_batch_reset(self._b)
+        if r != OPUS_OK: raise OpusError(r)
+    def sync(self): self._L.opusgpu_nsq_batch_sync(self._b)
+    def close(self):
+        if getattr(self, "_b", None): self._L.opusgpu_nsq_batch_destroy(self._b); self._b = None
     def __del__(self): self.close()

@@ -1,0 +1,187 @@
+/* silk_batch.h — kernels and C-ABI of the batched SILK building blocks (included by opus_amd.hip).
+ *
+ * opusgpu_nsq_batch_*: N independent SILK channels' noise-shaping quantiser states resident in HBM (tile-SoA, silk_frame.h); one
+ * call quantises one frame of every stream.  The per-stream inputs are the reference's own argument list (OpusGpuNsqFrame = the
+ * parameters of silk_NSQ_c, silk/NSQ.c:76-93), dispatch follows the reference (delayed decision iff nStatesDelayedDecision > 1 ||
+ * warping_Q16 > 0, silk/fixed/encode_frame_FIX.c / silk/float/wrappers_FLP.c:163-169). */
+#ifndef OPUS_AMD_SILK_BATCH_H
+#define OPUS_AMD_SILK_BATCH_H
+#include "silk_nsq.h"
+#include "silk_nsq_dd.h"
+#include "silk_host.h"
+
+__global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
+{
+   const int lane = (int)threadIdx.x, first = (int)blockIdx.x * 64;
+   int sidx = first + lane; const bool act = sidx < n; if (!act) sidx = first;
+   const int frame = cfg.nb_subfr * 5 * cfg.fs_kHz;
+   NsqMem m = nsq_mem(tiles + (size_t)blockIdx.x * tile_words, 64, lane, 20 * cfg.fs_kHz + frame);
+   silk_nsq_lane(cfg, m, &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, act);
+}
+
+__global__ __launch_bounds__(64) void oa_silk_nsq_dd_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, i8 *seed_out, int n)
+{
+   const int lane = (int)threadIdx.x, first = (int)blockIdx.x * 16;
+   int sidx = first + (lane >> 2); const bool act = sidx < n; if (!act) sidx = first;
+   const int frame = cfg.nb_subfr * 5 * cfg.fs_kHz;
+   i32 *tile = tiles + (size_t)blockIdx.x * tile_words;
+   NsqMem m = nsq_mem(tile, 16, lane >> 2, 20 * cfg.fs_kHz + frame);
+   silk_nsq_dd_wave(cfg, m, tile + (tile_words - 5 * OA_SILK_DD * 64), &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, seed_out + sidx, act);
+}
+
+struct OpusGpuNsqBatch {
+   int device; opus_int32 n; OaNsqCfg cfg; int T; long tile_words; opus_int32 ntiles; bool dd; hipStream_t stream;
+   i32 *d_tiles; OaNsqFrame *d_frames; opus_int16 *d_x16; opus_int8 *d_pulses, *d_seed;
+};
+
+static int oa_nsq_cfg_ok(const OaNsqCfg &c)
+{
+   if (c.fs_kHz != 8 && c.fs_kHz != 12 && c.fs_kHz != 16) return 0;
+   if (c.nb_subfr != 2 && c.nb_subfr != 4) return 0;
+   if (c.predictLPCOrder != 10 && c.predictLPCOrder != 16) return 0;
+   if (c.shapingLPCOrder < 2 || c.shapingLPCOrder > 24 || (c.shapingLPCOrder & 1)) return 0;
+   if (c.nStatesDelayedDecision < 1 || c.nStatesDelayedDecision > 4) return 0;
+   if (c.warping_Q16 < 0 || c.warping_Q16 > 32767) return 0;
+   return 1;
+}
+int opusgpu_nsq_state_size(void) { return (int)sizeof(OaNsqRefState); }
+opus_int32 opusgpu_nsq_batch_streams(const OpusGpuNsqBatch *b) { return b ? b->n : 0; }
+int opusgpu_nsq_batch_frame_length(const OpusGpuNsqBatch *b) { return b ? b->cfg.nb_subfr * 5 * b->cfg.fs_kHz : 0; }
+void opusgpu_nsq_batch_destroy(OpusGpuNsqBatch *b)
+{
+   if (!b) return;
+   (void)hipSetDevice(b->device);
+   if (b->stream) (void)hipStreamSynchronize(b->stream);
+   if (b->d_tiles) (void)hipFree(b->d_tiles);
+   if (b->d_frames) (void)hipFree(b->d_frames);
+   if (b->d_x16) (void)hipFree(b->d_x16);
+   if (b->d_pulses) (void)hipFree(b->d_pulses);
+   if (b->d_seed) (void)hipFree(b->d_seed);
+   if (b->stream) (void)hipStreamDestroy(b->stream);
+   delete b;
+}
+/* all streams to the encoder's reset state (silk/control_codec.c:247-258: zeroed, lagPrev = 100, prev_gain_Q16 = 65536) */
+int opusgpu_nsq_batch_reset(OpusGpuNsqBatch *b)
+{
+   if (!b) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   std::vector<i32> img((size_t)b->tile_words, 0);
+   OaNsqRefState r; memset(&r, 0, sizeof r); r.lagPrev = 100; r.prev_gain_Q16 = 65536;
+   for (int t = 0; t < b->T; t++) oa_nsq_import(img.data(), b->T, t, &r, &b->cfg);
+   for (opus_int32 tl = 0; tl < b->ntiles; tl++)
+      HIPCHECK(hipMemcpyAsync(b->d_tiles + (size_t)tl * b->tile_words, img.data(), sizeof(i32) * (size_t)b->tile_words, hipMemcpyHostToDevice, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   return OPUS_OK;
+}
+OpusGpuNsqBatch *opusgpu_nsq_batch_create(opus_int32 nstreams, const OpusGpuNsqConfig *config, int device, int *error)
+{
+   int err = OPUS_OK;
+   OpusGpuNsqBatch *b = nullptr;
+   OaNsqCfg c; memset(&c, 0, sizeof c);
+   if (nstreams <= 0 || !config) err = OPUS_BAD_ARG;
+   else { memcpy(&c, config, sizeof c); if (!oa_nsq_cfg_ok(c)) err = OPUS_BAD_ARG; }
+   if (err == OPUS_OK) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+         fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev);
+         err = OPUS_INTERNAL_ERROR;
+      }
+   }
+   if (err == OPUS_OK) {
+      b = new OpusGpuNsqBatch();
+      memset(b, 0, sizeof *b);
+      b->device = device; b->n = nstreams; b->cfg = c;
+      b->dd = c.nStatesDelayedDecision > 1 || c.warping_Q16 > 0;
+      b->T = b->dd ? 16 : 64; b->tile_words = (long)oa_nsq_tile_words(b->T); b->ntiles = (nstreams + b->T - 1) / b->T;
+      const size_t frame = (size_t)c.nb_subfr * 5 * c.fs_kHz;
+      bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
+                hipMalloc((void **)&b->d_tiles, sizeof(i32) * (size_t)b->tile_words * b->ntiles) == hipSuccess &&
+                hipMalloc((void **)&b->d_frames, sizeof(OaNsqFrame) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_x16, sizeof(opus_int16) * frame * nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_pulses, frame * nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_seed, (size_t)nstreams) == hipSuccess;
+      if (ok) ok = opusgpu_nsq_batch_reset(b) == OPUS_OK;
+      if (!ok) { opusgpu_nsq_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
+   }
+   if (error) *error = err;
+   return b;
+}
+static int oa_nsq_tile_rw(OpusGpuNsqBatch *b, opus_int32 i, const void *in, void *out)
+{
+   if (!b || i < 0 || i >= b->n || (!in && !out)) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   std::vector<i32> img((size_t)b->tile_words);
+   i32 *d = b->d_tiles + (size_t)(i / b->T) * b->tile_words;
+   HIPCHECK(hipMemcpy(img.data(), d, sizeof(i32) * (size_t)b->tile_words, hipMemcpyDeviceToHost));
+   if (out) oa_nsq_export(img.data(), b->T, i % b->T, (OaNsqRefState *)out, &b->cfg);
+   if (in) { oa_nsq_import(img.data(), b->T, i % b->T, (const OaNsqRefState *)in, &b->cfg); HIPCHECK(hipMemcpy(d, img.data(), sizeof(i32) * (size_t)b->tile_words, hipMemcpyHostToDevice)); }
+   return OPUS_OK;
+}
+/* NOTE: import re-bases the stream's history ring to row 0; the other streams of the tile are untouched only if they share that
+ * base, which they do whenever every stream of a batch has run the same number of frames (the only way to run them). */
+int opusgpu_nsq_batch_import_state(OpusGpuNsqBatch *b, opus_int32 i, const void *silk_nsq_state)
+{
+   if (!b || i < 0 || i >= b->n || !silk_nsq_state) return OPUS_BAD_ARG;
+   /* bring the whole tile to base 0 first so that mixed bases never exist inside a tile */
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   std::vector<i32> img((size_t)b->tile_words), img2((size_t)b->tile_words, 0);
+   i32 *d = b->d_tiles + (size_t)(i / b->T) * b->tile_words;
+   HIPCHECK(hipMemcpy(img.data(), d, sizeof(i32) * (size_t)b->tile_words, hipMemcpyDeviceToHost));
+   OaNsqRefState r;
+   for (int t = 0; t < b->T; t++) {
+      if (t == i % b->T) { oa_nsq_import(img2.data(), b->T, t, (const OaNsqRefState *)silk_nsq_state, &b->cfg); continue; }
+      oa_nsq_export(img.data(), b->T, t, &r, &b->cfg); oa_nsq_import(img2.data(), b->T, t, &r, &b->cfg);
+   }
+   HIPCHECK(hipMemcpy(d, img2.data(), sizeof(i32) * (size_t)b->tile_words, hipMemcpyHostToDevice));
+   return OPUS_OK;
+}
+int opusgpu_nsq_batch_export_state(OpusGpuNsqBatch *b, opus_int32 i, void *silk_nsq_state) { return oa_nsq_tile_rw(b, i, nullptr, silk_nsq_state); }
+
+int opusgpu_nsq_batch_run_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, const opus_int16 *d_x16, opus_int8 *d_pulses, opus_int8 *d_seed_out, void *hip_stream)
+{
+   if (!b || !d_frames || !d_x16 || !d_pulses) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+   if (b->dd) hipLaunchKernelGGL(oa_silk_nsq_dd_kernel, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames,
+                                 (const i16 *)d_x16, (i8 *)d_pulses, (i8 *)(d_seed_out ? d_seed_out : b->d_seed), (int)b->n);
+   else hipLaunchKernelGGL(oa_silk_nsq_kernel, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames,
+                           (const i16 *)d_x16, (i8 *)d_pulses, (int)b->n);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_nsq_batch_sync(OpusGpuNsqBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
+/* host-buffer convenience: frames[n], x16[n][frame_length] -> pulses[n][frame_length]; seed_out[n] (may be NULL) receives the Seed index the
+ * delayed-decision winner started from (psIndices->Seed, NSQ_del_dec.c:286); for the plain quantiser it echoes frames[i].Seed */
+int opusgpu_nsq_batch_run(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *frames, const opus_int16 *x16, opus_int8 *pulses, opus_int8 *seed_out)
+{
+   if (!b || !frames || !x16 || !pulses) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   const size_t frame = (size_t)b->cfg.nb_subfr * 5 * b->cfg.fs_kHz, n = (size_t)b->n;
+   HIPCHECK(hipMemcpyAsync(b->d_frames, frames, sizeof(OaNsqFrame) * n, hipMemcpyHostToDevice, b->stream));
+   HIPCHECK(hipMemcpyAsync(b->d_x16, x16, sizeof(opus_int16) * frame * n, hipMemcpyHostToDevice, b->stream));
+   int r = opusgpu_nsq_batch_run_dev(b, (const OpusGpuNsqFrame *)b->d_frames, b->d_x16, b->d_pulses, b->d_seed, nullptr);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpyAsync(pulses, b->d_pulses, frame * n, hipMemcpyDeviceToHost, b->stream));
+   if (seed_out && b->dd) HIPCHECK(hipMemcpyAsync(seed_out, b->d_seed, n, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   if (seed_out && !b->dd) for (size_t i = 0; i < n; i++) seed_out[i] = frames[i].Seed;
+   return OPUS_OK;
+}
+/* average launch duration of `steps` back-to-back frames on the batch's stream (HIP events), inputs already resident */
+int opusgpu_nsq_time_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, const opus_int16 *d_x16, opus_int8 *d_pulses, int steps, float *ms)
+{
+   if (!b || !ms || steps <= 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipEvent_t e0, e1;
+   HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+   HIPCHECK(hipEventRecord(e0, b->stream));
+   for (int k = 0; k < steps; k++) { int r = opusgpu_nsq_batch_run_dev(b, d_frames, d_x16, d_pulses, nullptr, nullptr); if (r != OPUS_OK) return r; }
+   HIPCHECK(hipEventRecord(e1, b->stream));
+   HIPCHECK(hipEventSynchronize(e1));
+   HIPCHECK(hipEventElapsedTime(ms, e0, e1));
+   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+   return OPUS_OK;
+}
+#endif

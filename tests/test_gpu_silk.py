@@ -1,0 +1,84 @@
+"""GPU: the batched SILK noise-shaping quantisers through the C ABI (opusgpu_nsq_*) against the oracle restatement (itself pinned to the
+compiled reference's silk_NSQ_c / silk_NSQ_del_dec_c by tests/test_oracle_silk.py) and, where oracle/_ref is present, against the
+compiled reference directly.  Bit-exact pulses, Seed and every persistent state word."""
+import ctypes, numpy as np, pytest
+from reflib import oracle, ref_expose
+from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame, make_input
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(oracle() is None, reason="oracle lib not built")]
+def P(a): return a.ctypes.data_as(ctypes.c_void_p)
+PERSISTENT = ["xq", "sLTP_shp_Q14", "sLPC_Q14", "sAR2_Q14", "sLF_AR_shp_Q14", "sDiff_shp_Q14", "lagPrev", "prev_gain_Q16"]
+
+def oracle_frame(cfg, dd, st, fr, x):
+    O = oracle(); n, L = x.shape
+    p = np.zeros((n, L), np.int8); fr = fr.copy()
+    for s in range(n):
+        (O.oc_silk_nsq_del_dec if dd else O.oc_silk_nsq)(P(cfg), P(st[s:s + 1]), P(fr[s:s + 1]), P(x[s]), P(p[s]))
+    return p, fr["Seed"].copy()
+
+def states_of(b, n):
+    st = np.zeros(n, dtype=NSQ_STATE)
+    for s in range(n): st[s:s + 1] = np.frombuffer(b.export_state(s), dtype=NSQ_STATE)
+    return st
+
+def check_states(a, b, cfg, with_seed):
+    mem = 20 * int(cfg[0])
+    for name in PERSISTENT + (["rand_seed"] if with_seed else []):
+        x, y = a[name], b[name]
+        if name == "sLPC_Q14": x, y = x[:, :16], y[:, :16]
+        if name in ("xq", "sLTP_shp_Q14"): x, y = x[:, :mem], y[:, :mem]
+        assert np.array_equal(x, y), name
+
+CASES = [(16, 4, 24, 1, False), (16, 4, 16, 1, False), (8, 4, 12, 1, False), (12, 2, 14, 1, False),
+         (16, 4, 24, 4, True), (16, 4, 24, 2, True), (16, 4, 16, 3, True), (16, 2, 24, 4, True), (8, 4, 12, 4, True), (12, 4, 14, 2, False), (16, 4, 20, 1, True)]
+
+@pytest.mark.parametrize("fs,nb,shaping,states,warp", CASES)
+def test_gpu_nsq_matches_oracle(fs, nb, shaping, states, warp):
+    import opus_amd
+    cfg = make_cfg(fs, nb, shaping, states, warp); dd = states > 1 or warp
+    n = 150 if not dd else 70                        # > 2 tiles incl. a ragged tail
+    rng = np.random.default_rng(fs * 7 + nb + shaping + states)
+    b = opus_amd.NsqBatch(n, cfg)
+    st = fresh_state(n)
+    for f in range(4):
+        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
+        p_or, seed_or = oracle_frame(cfg, dd, st, fr, x)
+        p_gpu, seed_gpu = b.run(fr, x)
+        bad = np.nonzero((p_gpu != p_or).any(axis=1))[0]
+        assert len(bad) == 0, (f, bad[:8])
+        assert np.array_equal(seed_gpu, seed_or)
+        if f in (0, 3): check_states(states_of(b, n), st, cfg, with_seed=not dd)
+    b.close()
+
+def test_gpu_nsq_import_export_and_reference():
+    """state migration: run 2 frames on the compiled reference, import its silk_nsq_state into the batch, continue on the GPU and on the
+    reference side by side (the memcpy contract of the boundary)."""
+    X = ref_expose()
+    if X is None: pytest.skip("oracle/_ref not built")
+    import opus_amd
+    from test_oracle_silk import run_ref
+    cfg = make_cfg(16, 4, 24, 4, True); n = 20; rng = np.random.default_rng(99)
+    st = fresh_state(n)
+    b = opus_amd.NsqBatch(n, cfg)
+    for f in range(4):
+        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
+        if f == 2:
+            for s in range(n): b.import_state(s, st[s:s + 1].tobytes())
+        p_ref = np.zeros_like(x, dtype=np.int8); seeds = np.zeros(n, np.int8)
+        for s in range(n):
+            p_ref[s], seeds[s] = run_ref(cfg, True, st[s:s + 1], fr[s], x[s])
+        if f >= 2:
+            p_gpu, seed_gpu = b.run(fr, x)
+            assert np.array_equal(p_gpu, p_ref) and np.array_equal(seed_gpu, seeds)
+    check_states(states_of(b, n), st, cfg, with_seed=False)
+    b.close()
+
+def test_gpu_nsq_bad_args():
+    import opus_amd
+    with pytest.raises(opus_amd.OpusError): opus_amd.NsqBatch(4, make_cfg(24, 4, 24, 4, True))      # fs_kHz out of range
+    with pytest.raises(opus_amd.OpusError): opus_amd.NsqBatch(0, make_cfg())
+    b = opus_amd.NsqBatch(3, make_cfg())
+    with pytest.raises(opus_amd.OpusError): b.export_state(3)
+    b.close()
