@@ -588,8 +588,8 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 }
 } /* extern "C" */
 #include "opus_ms_host.h"
-extern "C" {
 #include "silk_batch.h"
+extern "C" {
 const char *opus_get_version_string(void) { return "opus-amd 0.2 (gfx950, fixed-point bit-exact CELT encoder + decoder)"; }
 
 } /* extern "C" */

@@ -10,25 +10,26 @@
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
 
-__global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
+template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
 {
    const int lane = (int)threadIdx.x, first = (int)blockIdx.x * 64;
    int sidx = first + lane; const bool act = sidx < n; if (!act) sidx = first;
    const int frame = cfg.nb_subfr * 5 * cfg.fs_kHz;
    NsqMem m = nsq_mem(tiles + (size_t)blockIdx.x * tile_words, 64, lane, 20 * cfg.fs_kHz + frame);
-   silk_nsq_lane(cfg, m, &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, act);
+   silk_nsq_lane<SS>(cfg, m, &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, act);
 }
 
-__global__ __launch_bounds__(64) void oa_silk_nsq_dd_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, i8 *seed_out, int n)
+template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_dd_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, i8 *seed_out, int n)
 {
    const int lane = (int)threadIdx.x, first = (int)blockIdx.x * 16;
    int sidx = first + (lane >> 2); const bool act = sidx < n; if (!act) sidx = first;
    const int frame = cfg.nb_subfr * 5 * cfg.fs_kHz;
    i32 *tile = tiles + (size_t)blockIdx.x * tile_words;
    NsqMem m = nsq_mem(tile, 16, lane >> 2, 20 * cfg.fs_kHz + frame);
-   silk_nsq_dd_wave(cfg, m, tile + (tile_words - 5 * OA_SILK_DD * 64), &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, seed_out + sidx, act);
+   silk_nsq_dd_wave<SS>(cfg, m, tile + (tile_words - 5 * OA_SILK_DD * 64), &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, seed_out + sidx, act);
 }
 
+extern "C" {
 struct OpusGpuNsqBatch {
    int device; opus_int32 n; OaNsqCfg cfg; int T; long tile_words; opus_int32 ntiles; bool dd; hipStream_t stream;
    i32 *d_tiles; OaNsqFrame *d_frames; opus_int16 *d_x16; opus_int8 *d_pulses, *d_seed;
@@ -144,10 +145,17 @@ int opusgpu_nsq_batch_run_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frame
    if (!b || !d_frames || !d_x16 || !d_pulses) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
-   if (b->dd) hipLaunchKernelGGL(oa_silk_nsq_dd_kernel, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames,
-                                 (const i16 *)d_x16, (i8 *)d_pulses, (i8 *)(d_seed_out ? d_seed_out : b->d_seed), (int)b->n);
-   else hipLaunchKernelGGL(oa_silk_nsq_kernel, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames,
-                           (const i16 *)d_x16, (i8 *)d_pulses, (int)b->n);
+   /* the shaping orders the reference's complexity table uses (silk/control_codec.c:320-385) get compile-time-specialised tap loops */
+#define OA_NSQ_LAUNCH(SS) do { \
+      if (b->dd) hipLaunchKernelGGL(oa_silk_nsq_dd_kernel<SS>, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames, \
+                                    (const i16 *)d_x16, (i8 *)d_pulses, (i8 *)(d_seed_out ? d_seed_out : b->d_seed), (int)b->n); \
+      else hipLaunchKernelGGL(oa_silk_nsq_kernel<SS>, dim3((unsigned)b->ntiles), dim3(64), 0, s, b->cfg, b->d_tiles, b->tile_words, (const OaNsqFrame *)d_frames, \
+                              (const i16 *)d_x16, (i8 *)d_pulses, (int)b->n); } while (0)
+   switch (b->cfg.shapingLPCOrder) {
+   case 12: OA_NSQ_LAUNCH(12); break;  case 14: OA_NSQ_LAUNCH(14); break;  case 16: OA_NSQ_LAUNCH(16); break;
+   case 20: OA_NSQ_LAUNCH(20); break;  case 24: OA_NSQ_LAUNCH(24); break;  default: OA_NSQ_LAUNCH(0);
+   }
+#undef OA_NSQ_LAUNCH
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -184,4 +192,5 @@ int opusgpu_nsq_time_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, co
    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
    return OPUS_OK;
 }
+} /* extern "C" */
 #endif

@@ -146,9 +146,9 @@ WV_DEV void nsq_levels(i32 r_Q10, int offset_Q10, int Lambda_Q10, i32 &q1_Q10, i
 }
 
 /* One frame of one stream on one lane.  `fr`, `x16`, `pulses` point at this lane's stream (AoS, exactly the caller's arrays). */
-WV_DEV void silk_nsq_lane(const OaNsqCfg cfg, NsqMem m, const OaNsqFrame *fr, const i16 *x16, i8 *pulses, bool store)
+template <int SS> WV_DEV void silk_nsq_lane(const OaNsqCfg cfg, NsqMem m, const OaNsqFrame *fr, const i16 *x16, i8 *pulses, bool store)
 {
-   const int T = m.T, L = 5 * cfg.fs_kHz, mem = 20 * cfg.fs_kHz, frame = cfg.nb_subfr * L, P = cfg.predictLPCOrder, S = cfg.shapingLPCOrder;
+   const int T = m.T, L = 5 * cfg.fs_kHz, mem = 20 * cfg.fs_kHz, frame = cfg.nb_subfr * L, P = cfg.predictLPCOrder, S = SS ? SS : cfg.shapingLPCOrder;
    i32 s[16], ar2[24];                                 /* s[j] = sLPC at lag j; ar2 = AR-shaping delay line */
    for (int j = 0; j < 16; j++) s[j] = m.scal[(OA_NSQ_S_LPC + 15 - j) * T];
    for (int j = 0; j < 24; j++) ar2[j] = m.scal[(OA_NSQ_S_AR2 + j) * T];
@@ -207,11 +207,20 @@ WV_DEV void silk_nsq_lane(const OaNsqCfg cfg, NsqMem m, const OaNsqFrame *fr, co
       if (voiced) for (int j = 1; j < 5; j++) pl[j - 1] = m.q15[(pl0 - j) * T];
       if (lag > 0) { sh[0] = m.shp[nm_row(m, sh0 - 1)]; sh[1] = m.shp[nm_row(m, sh0 - 2)]; }
       i32 last_shp = m.shp[nm_row(m, shp_idx - 1)];
+      /* software pipeline: sample i+1's loads are issued at the top of sample i, before sample i's stores (in-order vm counter);
+       * the taps of i+1 were written at i+3-lag or earlier, so this is safe for lag > 3 (else they are re-read) */
+      i32 nPl = voiced ? m.q15[pl0 * T] : 0, nSh = lag > 0 ? m.shp[nm_row(m, sh0)] : 0, nX = x16[k * L];
       for (int i = 0; i < L; i++) {
-         /* issue the two lag-addressed history loads first: nothing below needs them for ~200 instructions */
-         if (voiced) { for (int j = 4; j > 0; j--) pl[j] = pl[j - 1]; pl[0] = m.q15[(pl0 + i) * T]; }
-         if (lag > 0) { sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = m.shp[nm_row(m, sh0 + i)]; }
-         const i32 x_sc_Q10 = mult16_32_q16(x16[k * L + i], inv_gain_Q26);
+         if (lag <= 3) { if (voiced) nPl = m.q15[(pl0 + i) * T]; if (lag > 0) nSh = m.shp[nm_row(m, sh0 + i)]; }
+         if (voiced) { for (int j = 4; j > 0; j--) pl[j] = pl[j - 1]; pl[0] = nPl; }
+         if (lag > 0) { sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = nSh; }
+         const i32 x_sc_Q10 = mult16_32_q16(nX, inv_gain_Q26);
+         {
+            const int i1 = i + 1 < L ? i + 1 : i;
+            if (voiced) nPl = m.q15[(pl0 + i1) * T];
+            if (lag > 0) nSh = m.shp[nm_row(m, sh0 + i1)];
+            nX = x16[k * L + i1];
+         }
          seed = sk_rand(seed);
 
          i32 LPC_pred_Q10 = P >> 1;

@@ -33,10 +33,10 @@ WV_DEV int dd_argmax4(i32 v0, i32 v1, i32 v2, i32 v3, int K)
 { int w = 0; i32 m = v0; if (K > 1 && v1 > m) { m = v1; w = 1; } if (K > 2 && v2 > m) { m = v2; w = 2; } if (K > 3 && v3 > m) { m = v3; w = 3; } return w; }
 
 /* One frame of 16 streams on one wave.  fr/x16/pulses/seed_out point at this quad's stream; `store` masks the tail tile. */
-WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNsqFrame *fr, const i16 *x16, i8 *pulses, i8 *seed_out, bool store)
+template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNsqFrame *fr, const i16 *x16, i8 *pulses, i8 *seed_out, bool store)
 {
    const int lane = wv_lane(), kk = lane & 3, qb = lane & ~3;
-   const int T = m.T, L = 5 * cfg.fs_kHz, mem = 20 * cfg.fs_kHz, frame = cfg.nb_subfr * L, P = cfg.predictLPCOrder, S = cfg.shapingLPCOrder;
+   const int T = m.T, L = 5 * cfg.fs_kHz, mem = 20 * cfg.fs_kHz, frame = cfg.nb_subfr * L, P = cfg.predictLPCOrder, S = SS ? SS : cfg.shapingLPCOrder;   /* SS != 0: shaping order known at compile time */
    const int K = cfg.nStatesDelayedDecision;
    const i32 warp_s = shl32((i16)cfg.warping_Q16, 16);
 
@@ -81,7 +81,7 @@ WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNs
 
       if (k == 2) {
          /* mid-frame predictor switch (NSQ_del_dec.c:199-229): commit everything pending from the winner, demote the others */
-         const i32 r0 = wv_shfl(RD, qb), r1 = wv_shfl(RD, qb + 1), r2 = wv_shfl(RD, qb + 2), r3 = wv_shfl(RD, qb + 3);
+         const i32 r0 = wv_quad_bcast<0>(RD), r1 = wv_quad_bcast<1>(RD), r2 = wv_quad_bcast<2>(RD), r3 = wv_quad_bcast<3>(RD);
          const int w = dd_argmin4(r0, r1, r2, r3, K);
          DdAnc aw; aw.w0 = (u32)wv_shfl((i32)anc.w0, qb + w); aw.w1 = (u32)wv_shfl((i32)anc.w1, qb + w); aw.w2 = (u32)wv_shfl((i32)anc.w2, qb + w);
          for (int age = OA_SILK_DD - 1; age >= 0; age--) {
@@ -145,15 +145,34 @@ WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNs
       const int pl0 = ltp_idx - lag + OA_SILK_LTP_ORDER / 2, sh0 = shp_idx - lag + 1;
       if (voiced) for (int j = 1; j < 5; j++) pl[j - 1] = m.q15[(pl0 - j) * T];
       if (lag > 0) { sh[0] = m.shp[nm_row(m, sh0 - 1)]; sh[1] = m.shp[nm_row(m, sh0 - 2)]; }
+      /* Software pipeline: everything sample i+1 reads from memory is requested at the top of sample i, i.e. BEFORE sample i's stores
+       * in program order (the vm counter is in-order, so a load issued after a store cannot be waited on without also waiting for the
+       * store's write acknowledge).  Hazards: the ring row committed at i+1 was written at i+1-D (needs D >= 2, else re-read); the
+       * LTP tap for i+1 is the entry committed at i exactly when D == lag-3 (then it is forwarded from the register, vPred). */
+      int pn = p == 0 ? OA_SILK_DD - 1 : p - 1, lastn = (pn + D) % OA_SILK_DD;
+      i32 nRand = DD_RING(ring, DD_RAND, lastn, lane), nQ = DD_RING(ring, DD_Q, lastn, lane), nXq = DD_RING(ring, DD_XQ, lastn, lane);
+      i32 nPred = DD_RING(ring, DD_PRED, lastn, lane), nShape = DD_RING(ring, DD_SHAPE, lastn, lane);
+      i32 nPl = voiced ? m.q15[pl0 * T] : 0, nSh = lag > 0 ? m.shp[nm_row(m, sh0)] : 0, nX = x16[k * L];
       for (int i = 0; i < L; i++) {
-         p = p == 0 ? OA_SILK_DD - 1 : p - 1;
-         const int last = (p + D) % OA_SILK_DD;
-         /* loads first: the ring row being committed this sample and the two lag-addressed history taps */
-         const i32 rRand = DD_RING(ring, DD_RAND, last, lane), rQ = DD_RING(ring, DD_Q, last, lane), rXq = DD_RING(ring, DD_XQ, last, lane);
-         const i32 rPred = DD_RING(ring, DD_PRED, last, lane), rShape = DD_RING(ring, DD_SHAPE, last, lane);
-         if (voiced) { for (int j = 4; j > 0; j--) pl[j] = pl[j - 1]; pl[0] = m.q15[(pl0 + i) * T]; }
-         if (lag > 0) { sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = m.shp[nm_row(m, sh0 + i)]; }
-         const i32 x_Q10 = mult16_32_q16(x16[k * L + i], inv_gain_Q26);
+         p = pn;
+         const int last = lastn;
+         if (D < 2) {                                                /* (never with the encoder's pitch range; kept for imported states) */
+            nRand = DD_RING(ring, DD_RAND, last, lane); nQ = DD_RING(ring, DD_Q, last, lane); nXq = DD_RING(ring, DD_XQ, last, lane);
+            nPred = DD_RING(ring, DD_PRED, last, lane); nShape = DD_RING(ring, DD_SHAPE, last, lane);
+         }
+         const i32 rRand = nRand, rQ = nQ, rXq = nXq, rPred = nPred, rShape = nShape;
+         if (voiced) { for (int j = 4; j > 0; j--) pl[j] = pl[j - 1]; pl[0] = nPl; }
+         if (lag > 0) { sh[2] = sh[1]; sh[1] = sh[0]; sh[0] = nSh; }
+         const i32 x_Q10 = mult16_32_q16(nX, inv_gain_Q26);
+         {
+            const int i1 = i + 1 < L ? i + 1 : i;
+            pn = p == 0 ? OA_SILK_DD - 1 : p - 1; lastn = (pn + D) % OA_SILK_DD;
+            nRand = DD_RING(ring, DD_RAND, lastn, lane); nQ = DD_RING(ring, DD_Q, lastn, lane); nXq = DD_RING(ring, DD_XQ, lastn, lane);
+            nPred = DD_RING(ring, DD_PRED, lastn, lane); nShape = DD_RING(ring, DD_SHAPE, lastn, lane);
+            if (voiced) nPl = m.q15[(pl0 + i1) * T];
+            if (lag > 0) nSh = m.shp[nm_row(m, sh0 + i1)];
+            nX = x16[k * L + i1];
+         }
 
          /* per-survivor part */
          Seed = sk_rand(Seed);
@@ -212,14 +231,14 @@ WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNs
          }
 
          /* ---- K-way decisions inside the quad ---- */
-         i32 g0 = wv_shfl(cRD[0], qb), g1 = wv_shfl(cRD[0], qb + 1), g2 = wv_shfl(cRD[0], qb + 2), g3 = wv_shfl(cRD[0], qb + 3);
+         i32 g0 = wv_quad_bcast<0>(cRD[0]), g1 = wv_quad_bcast<1>(cRD[0]), g2 = wv_quad_bcast<2>(cRD[0]), g3 = wv_quad_bcast<3>(cRD[0]);
          const int winner = dd_argmin4(g0, g1, g2, g3, K);
          const int mysrc = qb + dd_anc_at(anc, D - 1);                    /* column holding my path's entry of the sample being committed */
          const i32 myrand = wv_shfl(rRand, mysrc);
          const i32 wrand = wv_shfl(myrand, qb + winner);
          if (myrand != wrand) { cRD[0] += DD_PENALTY; cRD[1] += DD_PENALTY; }
-         g0 = wv_shfl(cRD[0], qb); g1 = wv_shfl(cRD[0], qb + 1); g2 = wv_shfl(cRD[0], qb + 2); g3 = wv_shfl(cRD[0], qb + 3);
-         const i32 h0 = wv_shfl(cRD[1], qb), h1 = wv_shfl(cRD[1], qb + 1), h2 = wv_shfl(cRD[1], qb + 2), h3 = wv_shfl(cRD[1], qb + 3);
+         g0 = wv_quad_bcast<0>(cRD[0]); g1 = wv_quad_bcast<1>(cRD[0]); g2 = wv_quad_bcast<2>(cRD[0]); g3 = wv_quad_bcast<3>(cRD[0]);
+         const i32 h0 = wv_quad_bcast<0>(cRD[1]), h1 = wv_quad_bcast<1>(cRD[1]), h2 = wv_quad_bcast<2>(cRD[1]), h3 = wv_quad_bcast<3>(cRD[1]);
          const int worst = dd_argmax4(g0, g1, g2, g3, K), best2 = dd_argmin4(h0, h1, h2, h3, K);
          const i32 rdmax = worst == 0 ? g0 : worst == 1 ? g1 : worst == 2 ? g2 : g3, rdmin2 = best2 == 0 ? h0 : best2 == 1 ? h1 : best2 == 2 ? h2 : h3;
          const bool take = rdmin2 < rdmax && kk == worst;                 /* this lane's survivor is replaced by best2's second choice */
@@ -233,6 +252,7 @@ WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNs
             m.xq[nm_row(m, mem + k * L + i - D)] = (i16)sk_sat16(sk_rround(sk_mulww(vXq, i >= D ? Gain_Q10 : prevGain_Q10), 8));
             m.shp[nm_row(m, shp_idx - D)] = vShape;
             m.q15[(ltp_idx - D) * T] = vPred;
+            if (D == lag - OA_SILK_LTP_ORDER / 2 - 1) nPl = vPred;           /* the tap sample i+1 needs is the one just committed */
          }
          shp_idx++; ltp_idx++;
 
@@ -263,7 +283,7 @@ WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNs
    }
    /* final flush from the winner (NSQ_del_dec.c:275-306) */
    {
-      const i32 r0 = wv_shfl(RD, qb), r1 = wv_shfl(RD, qb + 1), r2 = wv_shfl(RD, qb + 2), r3 = wv_shfl(RD, qb + 3);
+      const i32 r0 = wv_quad_bcast<0>(RD), r1 = wv_quad_bcast<1>(RD), r2 = wv_quad_bcast<2>(RD), r3 = wv_quad_bcast<3>(RD);
       const int w = dd_argmin4(r0, r1, r2, r3, K), from = qb + w;
       DdAnc aw; aw.w0 = (u32)wv_shfl((i32)anc.w0, from); aw.w1 = (u32)wv_shfl((i32)anc.w1, from); aw.w2 = (u32)wv_shfl((i32)anc.w2, from);
       const i32 Gain_Q10 = fr->Gains_Q16[cfg.nb_subfr - 1] >> 6;

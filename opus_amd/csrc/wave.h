@@ -36,6 +36,8 @@ WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
 }
 
 /* lane i receives v of lane i-1, lane 0 receives `fill` (DPP wave_shr:1: one instruction, no LDS) */
+/* value of lane J (0..3) of the caller's quad, in all four lanes: one DPP quad_perm move, no LDS crossbar */
+template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 
 /* Wave-wide reductions on the DPP cross-lane network (no LDS round trips, unlike ds_bpermute shuffles):

@@ -6,14 +6,18 @@
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
 
-struct NsqJob { OaNsqCfg cfg; int32_t *tile; const OaNsqFrame *frames; const int16_t *x16; int8_t *pulses; int8_t *seed_out; int first, n; };
+static int g_generic = 0;
+extern "C" void emu_nsq_force_generic(int g) { g_generic = g; }   /* run the runtime-order instantiation even for specialised orders */
+struct NsqJob { OaNsqCfg cfg; int32_t *tile; const OaNsqFrame *frames; const int16_t *x16; int8_t *pulses; int8_t *seed_out; int first, n; int generic; };
 static void nsq_entry(void *arg)
 {
    NsqJob *j = (NsqJob *)arg;
    int lane = wv_lane(), sidx = j->first + lane; bool act = sidx < j->n; if (!act) sidx = j->first;
    const int frame = j->cfg.nb_subfr * 5 * j->cfg.fs_kHz;
    NsqMem m = nsq_mem(j->tile, 64, lane, 20 * j->cfg.fs_kHz + frame);
-   silk_nsq_lane(j->cfg, m, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, act);
+#define CALL(SS) silk_nsq_lane<SS>(j->cfg, m, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, act)
+   switch (j->generic ? 0 : j->cfg.shapingLPCOrder) { case 12: CALL(12); break; case 14: CALL(14); break; case 16: CALL(16); break; case 20: CALL(20); break; case 24: CALL(24); break; default: CALL(0); }
+#undef CALL
 }
 extern "C" long emu_nsq_tile_words(int T) { return (long)oa_nsq_tile_words(T); }
 extern "C" void emu_nsq_import(int32_t *tile, int T, int t, const OaNsqRefState *r, const OaNsqCfg *cfg) { oa_nsq_import(tile, T, t, r, cfg); }
@@ -22,7 +26,7 @@ extern "C" void emu_silk_nsq(const OaNsqCfg *cfg, int32_t *tiles, const OaNsqFra
 {
    const long tw = (long)oa_nsq_tile_words(64);
    for (int first = 0, tl = 0; first < n; first += 64, tl++) {
-      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, nullptr, first, n };
+      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, nullptr, first, n, g_generic };
       emu_run_wave(nsq_entry, &j);
    }
 }
@@ -34,13 +38,15 @@ static void nsq_dd_entry(void *arg)
    const int frame = j->cfg.nb_subfr * 5 * j->cfg.fs_kHz;
    NsqMem m = nsq_mem(j->tile, 16, lane >> 2, 20 * j->cfg.fs_kHz + frame);
    int32_t *ring = j->tile + (oa_nsq_tile_words(16) - 5 * OA_SILK_DD * 64);
-   silk_nsq_dd_wave(j->cfg, m, ring, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, j->seed_out + sidx, act);
+#define CALL(SS) silk_nsq_dd_wave<SS>(j->cfg, m, ring, &j->frames[sidx], j->x16 + (size_t)sidx * frame, j->pulses + (size_t)sidx * frame, j->seed_out + sidx, act)
+   switch (j->generic ? 0 : j->cfg.shapingLPCOrder) { case 12: CALL(12); break; case 14: CALL(14); break; case 16: CALL(16); break; case 20: CALL(20); break; case 24: CALL(24); break; default: CALL(0); }
+#undef CALL
 }
 extern "C" void emu_silk_nsq_dd(const OaNsqCfg *cfg, int32_t *tiles, const OaNsqFrame *frames, const int16_t *x16, int8_t *pulses, int8_t *seed_out, int n)
 {
    const long tw = (long)oa_nsq_tile_words(16);
    for (int first = 0, tl = 0; first < n; first += 16, tl++) {
-      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, seed_out, first, n };
+      NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, seed_out, first, n, g_generic };
       emu_run_wave(nsq_dd_entry, &j);
    }
 }

@@ -63,6 +63,7 @@ static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_
    return w->xch[p];
 }
 WV_DEV int32_t wv_shfl(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src & 63][0]; }
+template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[(emu_cur->cur & ~3) | J][0]; }
 WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
 WV_DEV int32_t wv_uni(int32_t v) { return v; }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = emu_cur->cur; return me == 0 ? fill : (int32_t)t[me - 1][0]; }

@@ -29,7 +29,7 @@ def _stable(rng, order, scale, q):
     a *= scale / max(1e-9, np.abs(a).sum())
     return np.round(a * (1 << q)).astype(np.int16)
 
-def make_frame(rng, cfg, voiced=None, interp=None):
+def make_frame(rng, cfg, voiced=None, interp=None, max_lag_ms=18):
     fs, nb, P, S = int(cfg[0]), int(cfg[1]), int(cfg[2]), int(cfg[3])
     f = np.zeros(1, dtype=NSQ_FRAME)[0]
     voiced = bool(rng.integers(0, 2)) if voiced is None else voiced
@@ -42,7 +42,7 @@ def make_frame(rng, cfg, voiced=None, interp=None):
     pc[:P] = _stable(rng, P, 0.9, 12); pc[16:16 + P] = _stable(rng, P, 0.9, 12)
     f["PredCoef_Q12"] = pc
     ar = np.zeros(96, np.int16); ltp = np.zeros(20, np.int16)
-    lag0 = int(rng.integers(2 * fs, 18 * fs + 1))
+    lag0 = int(rng.integers(2 * fs, int(max_lag_ms * fs) + 1))
     for k in range(nb):
         ar[k * 24:k * 24 + S] = _stable(rng, S, 0.8, 13)
         if voiced:

@@ -30,7 +30,7 @@ def compare_states(a, b, cfg, with_seed):
         if name in ("xq", "sLTP_shp_Q14"): x, y = x[:, :mem], y[:, :mem]
         assert np.array_equal(x, y), name
 
-def drive(E, cfg, dd, n, frames, seed, T):
+def drive(E, cfg, dd, n, frames, seed, T, **fkw):
     """n streams x `frames` frames through the emulator and the oracle; states imported from the oracle's layout at start and
     exported after every frame."""
     O = oracle(); rng = np.random.default_rng(seed)
@@ -40,7 +40,7 @@ def drive(E, cfg, dd, n, frames, seed, T):
     st_or = fresh_state(n)
     # start from a non-trivial state: one oracle frame first
     for warm in range(1):
-        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        fr = np.array([make_frame(rng, cfg, **fkw) for _ in range(n)], dtype=NSQ_FRAME)
         x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
         for s in range(n):
             p = np.zeros(L, np.int8)
@@ -48,7 +48,7 @@ def drive(E, cfg, dd, n, frames, seed, T):
     for s in range(n):
         E.emu_nsq_import(P(tiles[(s // T) * tw:]), T, s % T, P(st_or[s:s + 1]), P(cfg))
     for f in range(frames):
-        fr = np.array([make_frame(rng, cfg) for _ in range(n)], dtype=NSQ_FRAME)
+        fr = np.array([make_frame(rng, cfg, **fkw) for _ in range(n)], dtype=NSQ_FRAME)
         x = np.stack([make_input(rng, cfg, fr[s]["Gains_Q16"]) for s in range(n)])
         p_or = np.zeros((n, L), np.int8); fr_or = fr.copy()
         for s in range(n):
@@ -76,3 +76,22 @@ def test_emu_nsq_del_dec(fs, nb, shaping, states, warp):
     E = _build()
     cfg = make_cfg(fs, nb, shaping, states, warp)
     drive(E, cfg, True, n=21, frames=3, seed=fs + nb + shaping + states, T=16)
+
+def test_emu_generic_order_instantiation():
+    """the runtime-shaping-order instantiation (orders outside the complexity table) on orders that normally take a specialised one"""
+    E = _build()
+    E.emu_nsq_force_generic(1)
+    try:
+        drive(E, make_cfg(16, 4, 24, 4, True), True, n=17, frames=2, seed=5, T=16)
+        drive(E, make_cfg(16, 4, 16, 1, False), False, n=65, frames=2, seed=6, T=64)
+        drive(E, make_cfg(16, 4, 18, 3, True), True, n=17, frames=2, seed=7, T=16)
+    finally:
+        E.emu_nsq_force_generic(0)
+
+def test_emu_short_lags_forwarding():
+    """pitch lags of 2..2.6 ms: decisionDelay == lag-3, the case where the LTP tap of sample i+1 is the entry committed at sample i
+    (register forwarding in the software-pipelined loop)"""
+    E = _build()
+    drive(E, make_cfg(16, 4, 24, 4, True), True, n=18, frames=3, seed=11, T=16, voiced=True, max_lag_ms=2.6)
+    drive(E, make_cfg(8, 4, 12, 3, True), True, n=18, frames=3, seed=12, T=16, voiced=True, max_lag_ms=2.6)
+    drive(E, make_cfg(16, 4, 16, 1, False), False, n=66, frames=2, seed=13, T=64, voiced=True, max_lag_ms=2.6)
