@@ -239,6 +239,13 @@ OPUS_AMD_EXPORT int opusgpu_nsq_batch_run_dev(OpusGpuNsqBatch *b, const OpusGpuN
 OPUS_AMD_EXPORT int opusgpu_nsq_batch_sync(OpusGpuNsqBatch *b);
 OPUS_AMD_EXPORT int opusgpu_nsq_time_dev(OpusGpuNsqBatch *b, const OpusGpuNsqFrame *d_frames, const opus_int16 *d_x16, opus_int8 *d_pulses, int steps, float *ms);
 
+/* silk_LPC_analysis_filter (silk/LPC_analysis_filter.c:49, prototype silk/SigProc_FIX.h:113-120) for n independent signals:
+ * in[n][len], B[n][d] (Q12), out[n][len]; 6 <= d <= 16 even, d <= len <= 1024 (the reference's asserts :65-67).  One wave per signal,
+ * signal and coefficients staged in LDS; the _dev form takes device pointers and a hipStream_t (NULL = default stream). */
+OPUS_AMD_EXPORT int opusgpu_silk_lpc_analysis_filter_batch(int device, opus_int32 n, opus_int16 *out, const opus_int16 *in, const opus_int16 *B, opus_int32 len, opus_int32 d);
+OPUS_AMD_EXPORT int opusgpu_silk_lpc_analysis_filter_batch_dev(int device, opus_int32 n, opus_int16 *d_out, const opus_int16 *d_in, const opus_int16 *d_B, opus_int32 len,
+      opus_int32 d, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,8 @@ def lib():
         L.opusgpu_nsq_batch_run.argtypes = [vp, vp, vp, vp, vp]
         L.opusgpu_nsq_batch_run_dev.argtypes = [vp, vp, vp, vp, vp, vp]
         L.opusgpu_nsq_time_dev.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.opusgpu_silk_lpc_analysis_filter_batch.argtypes = [ctypes.c_int, i32, vp, vp, vp, i32, i32]
+        L.opusgpu_silk_lpc_analysis_filter_batch_dev.argtypes = [ctypes.c_int, i32, vp, vp, vp, i32, i32, vp]
         _lib = L
     return _lib
 
@@ -276,3 +278,14 @@ class NsqBatch:
     def close(self):
         if getattr(self, "_b", None): self._L.opusgpu_nsq_batch_destroy(self._b); self._b = None
     def __del__(self): self.close()
+
+
+def silk_lpc_analysis_filter(x, B, device=0):
+    """silk_LPC_analysis_filter (silk/LPC_analysis_filter.c:49) for n signals: x int16 [n, len], B int16 [n, d] (Q12) -> int16 [n, len]."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.int16); B = np.ascontiguousarray(B, dtype=np.int16)
+    assert x.ndim == 2 and B.ndim == 2 and x.shape[0] == B.shape[0]
+    out = np.zeros_like(x)
+    r = lib().opusgpu_silk_lpc_analysis_filter_batch(device, x.shape[0], out.ctypes.data, x.ctypes.data, B.ctypes.data, x.shape[1], B.shape[1])
+    if r != OPUS_OK: raise OpusError(r)
+    return out

@@ -9,6 +9,7 @@
 #include "silk_nsq.h"
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
+#include "silk_lpc.h"
 
 template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
 {
@@ -29,7 +30,42 @@ template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_dd_kernel(Oa
    silk_nsq_dd_wave<SS>(cfg, m, tile + (tile_words - 5 * OA_SILK_DD * 64), &frames[sidx], x16 + (size_t)sidx * frame, pulses + (size_t)sidx * frame, seed_out + sidx, act);
 }
 
+__global__ __launch_bounds__(64) void oa_silk_lpc_analysis_kernel(i16 *out, const i16 *in, const i16 *B, int len, int d)
+{
+   __shared__ LpcLds lds;
+   const size_t s = blockIdx.x;
+   silk_lpc_analysis_filter_wave((WV_LDS LpcLds *)&lds, out + s * (size_t)len, in + s * (size_t)len, B + s * (size_t)d, len, d);
+}
+
 extern "C" {
+/* ---- silk_LPC_analysis_filter for n independent signals of one length and order (silk/LPC_analysis_filter.c:49) ---- */
+int opusgpu_silk_lpc_analysis_filter_batch_dev(int device, opus_int32 n, opus_int16 *d_out, const opus_int16 *d_in, const opus_int16 *d_B, opus_int32 len, opus_int32 d, void *hip_stream)
+{
+   if (n <= 0 || !d_out || !d_in || !d_B || d < 6 || d > OA_LPC_MAX_ORDER || (d & 1) || len < d || len > OA_LPC_MAX_LEN) return OPUS_BAD_ARG;   /* the reference's asserts (:65-67) */
+   HIPCHECK(hipSetDevice(device));
+   hipLaunchKernelGGL(oa_silk_lpc_analysis_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)hip_stream, (i16 *)d_out, (const i16 *)d_in, (const i16 *)d_B, (int)len, (int)d);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_silk_lpc_analysis_filter_batch(int device, opus_int32 n, opus_int16 *out, const opus_int16 *in, const opus_int16 *B, opus_int32 len, opus_int32 d)
+{
+   if (n <= 0 || !out || !in || !B) return OPUS_BAD_ARG;
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev); return OPUS_INTERNAL_ERROR; }
+   HIPCHECK(hipSetDevice(device));
+   opus_int16 *d_in = nullptr, *d_out = nullptr, *d_B = nullptr;
+   const size_t sig = sizeof(opus_int16) * (size_t)n * (size_t)len, cb = sizeof(opus_int16) * (size_t)n * (size_t)d;
+   int r = OPUS_OK;
+   if (hipMalloc((void **)&d_in, sig) != hipSuccess || hipMalloc((void **)&d_out, sig) != hipSuccess || hipMalloc((void **)&d_B, cb) != hipSuccess) r = OPUS_ALLOC_FAIL;
+   if (r == OPUS_OK && (hipMemcpy(d_in, in, sig, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_B, B, cb, hipMemcpyHostToDevice) != hipSuccess)) r = OPUS_INTERNAL_ERROR;
+   if (r == OPUS_OK) r = opusgpu_silk_lpc_analysis_filter_batch_dev(device, n, d_out, d_in, d_B, len, d, nullptr);
+   if (r == OPUS_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_out, sig, hipMemcpyDeviceToHost) != hipSuccess)) r = OPUS_INTERNAL_ERROR;
+   if (d_in) (void)hipFree(d_in);
+   if (d_out) (void)hipFree(d_out);
+   if (d_B) (void)hipFree(d_B);
+   return r;
+}
+
 struct OpusGpuNsqBatch {
    int device; opus_int32 n; OaNsqCfg cfg; int T; long tile_words; opus_int32 ntiles; bool dd; hipStream_t stream;
    i32 *d_tiles; OaNsqFrame *d_frames; opus_int16 *d_x16; opus_int8 *d_pulses, *d_seed;

@@ -76,4 +76,16 @@ typedef struct {                        /* one frame's quantiser inputs = the ar
 void oc_silk_lpc_analysis_filter(s16 *out, const s16 *in, const s16 *B, s32 len, s32 d);     /* silk/LPC_analysis_filter.c:49 */
 void oc_silk_nsq(const OcSilkNsqCfg *cfg, OcSilkNsqState *st, OcSilkNsqFrame *fr, const s16 *x16, s8 *pulses);          /* silk/NSQ.c:76 */
 void oc_silk_nsq_del_dec(const OcSilkNsqCfg *cfg, OcSilkNsqState *st, OcSilkNsqFrame *fr, const s16 *x16, s8 *pulses);  /* silk/NSQ_del_dec.c:114 */
+
+/* ---- resampler (silk/resampler_structs.h:38-52; the coefficient pointer is replaced by a table id) ---- */
+enum { OC_RS_FN_COPY = 0, OC_RS_FN_UP2 = 1, OC_RS_FN_IIR_FIR = 2, OC_RS_FN_DOWN_FIR = 3 };          /* resampler.c:72-75 */
+enum { OC_RS_NONE = 0, OC_RS_3_4, OC_RS_2_3, OC_RS_1_2, OC_RS_1_3, OC_RS_1_4, OC_RS_1_6 };
+typedef struct {
+   s32 sIIR[6];
+   union { s32 i32[36]; s16 i16[36]; } sFIR;
+   s16 delayBuf[96];
+   s32 resampler_function, batchSize, invRatio_Q16, FIR_Order, FIR_Fracs, Fs_in_kHz, Fs_out_kHz, inputDelay, coefs_id;
+} OcSilkResampler;
+int oc_silk_resampler_init(OcSilkResampler *S, s32 Fs_Hz_in, s32 Fs_Hz_out, int forEnc);         /* silk/resampler.c:79  */
+int oc_silk_resampler(OcSilkResampler *S, s16 *out, const s16 *in, s32 inLen);                    /* silk/resampler.c:183 */
 #endif

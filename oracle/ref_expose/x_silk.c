@@ -32,3 +32,7 @@ void ref_silk_lpc_analysis_filter(opus_int16 *out, const opus_int16 *in, const o
 { silk_LPC_analysis_filter(out, in, B, len, d, 0); }
 opus_int32 ref_silk_div32_varQ(opus_int32 a, opus_int32 b, int q) { return silk_DIV32_varQ(a, b, q); }
 opus_int32 ref_silk_inverse32_varQ(opus_int32 b, int q) { return silk_INVERSE32_varQ(b, q); }
+#include "resampler_structs.h"
+int ref_silk_resampler_state_size(void) { return (int)sizeof(silk_resampler_state_struct); }
+int ref_silk_resampler_init(void *S, opus_int32 in, opus_int32 out, int forEnc) { return silk_resampler_init((silk_resampler_state_struct *)S, in, out, forEnc); }
+int ref_silk_resampler(void *S, opus_int16 *out, const opus_int16 *in, opus_int32 inLen) { return silk_resampler((silk_resampler_state_struct *)S, out, in, inLen); }

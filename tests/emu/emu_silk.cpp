@@ -5,6 +5,7 @@
 #include "silk_nsq.h"
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
+#include "silk_lpc.h"
 
 static int g_generic = 0;
 extern "C" void emu_nsq_force_generic(int g) { g_generic = g; }   /* run the runtime-order instantiation even for specialised orders */
@@ -49,4 +50,11 @@ extern "C" void emu_silk_nsq_dd(const OaNsqCfg *cfg, int32_t *tiles, const OaNsq
       NsqJob j = { *cfg, tiles + tl * tw, frames, x16, pulses, seed_out, first, n, g_generic };
       emu_run_wave(nsq_dd_entry, &j);
    }
+}
+
+struct LpcJob { LpcLds lds; int16_t *out; const int16_t *in, *B; int len, d; };
+static void lpc_entry(void *arg) { LpcJob *j = (LpcJob *)arg; silk_lpc_analysis_filter_wave(&j->lds, j->out, j->in, j->B, j->len, j->d); }
+extern "C" void emu_silk_lpc_analysis_filter(int n, int16_t *out, const int16_t *in, const int16_t *B, int len, int d)
+{
+   for (int s = 0; s < n; s++) { LpcJob *j = new LpcJob; j->out = out + (size_t)s * len; j->in = in + (size_t)s * len; j->B = B + (size_t)s * d; j->len = len; j->d = d; emu_run_wave(lpc_entry, j); delete j; }
 }

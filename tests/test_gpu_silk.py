@@ -82,3 +82,26 @@ def test_gpu_nsq_bad_args():
     b = opus_amd.NsqBatch(3, make_cfg())
     with pytest.raises(opus_amd.OpusError): b.export_state(3)
     b.close()
+
+@pytest.mark.parametrize("d,length", [(16, 672), (10, 336), (16, 16), (6, 7), (12, 1024), (8, 333)])
+def test_gpu_lpc_analysis_filter(d, length):
+    import opus_amd
+    O = oracle(); rng = np.random.default_rng(d * 1000 + length); n = 300
+    x = rng.integers(-32768, 32768, (n, length)).astype(np.int16)
+    B = rng.integers(-4096, 4096, (n, d)).astype(np.int16); B[::7] = rng.integers(-32768, 32768, (len(B[::7]), d))     # every 7th wraps and saturates
+    got = opus_amd.silk_lpc_analysis_filter(x, B)
+    want = np.zeros_like(x)
+    for s in range(n): O.oc_silk_lpc_analysis_filter(P(want[s]), P(x[s]), P(B[s]), length, d)
+    assert np.array_equal(got, want)
+    X = ref_expose()
+    if X is not None:
+        ref = np.zeros_like(x[:20])
+        for s in range(20): X.ref_silk_lpc_analysis_filter(P(ref[s]), P(x[s]), P(B[s]), length, d)
+        assert np.array_equal(got[:20], ref)
+
+def test_gpu_lpc_analysis_filter_bad_args():
+    import opus_amd
+    x = np.zeros((2, 100), np.int16)
+    for d in (4, 7, 18):
+        with pytest.raises(opus_amd.OpusError): opus_amd.silk_lpc_analysis_filter(x, np.zeros((2, d), np.int16))
+    with pytest.raises(opus_amd.OpusError): opus_amd.silk_lpc_analysis_filter(np.zeros((2, 2000), np.int16), np.zeros((2, 16), np.int16))

@@ -7,7 +7,7 @@ from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame,
 def _build():
     so = os.path.join(ROOT, "tests/emu/libemu_silk.so")
     srcs = [os.path.join(ROOT, "tests/emu", f) for f in ("emu_silk.cpp", "wave_emu.cpp")]
-    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
+    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_lpc.h", "silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
     hdrs = [h for h in hdrs if os.path.exists(h)]
     import fcntl
     with open(so + ".lock", "w") as lk:
@@ -95,3 +95,13 @@ def test_emu_short_lags_forwarding():
     drive(E, make_cfg(16, 4, 24, 4, True), True, n=18, frames=3, seed=11, T=16, voiced=True, max_lag_ms=2.6)
     drive(E, make_cfg(8, 4, 12, 3, True), True, n=18, frames=3, seed=12, T=16, voiced=True, max_lag_ms=2.6)
     drive(E, make_cfg(16, 4, 16, 1, False), False, n=66, frames=2, seed=13, T=64, voiced=True, max_lag_ms=2.6)
+
+@pytest.mark.parametrize("d,length", [(16, 672), (10, 336), (16, 16), (6, 7), (12, 1024), (8, 333)])
+def test_emu_lpc_analysis_filter(d, length):
+    E = _build(); O = oracle(); rng = np.random.default_rng(d * 1000 + length); n = 5
+    x = rng.integers(-32768, 32768, (n, length)).astype(np.int16)
+    B = rng.integers(-4096, 4096, (n, d)).astype(np.int16); B[0] = rng.integers(-32768, 32768, d)          # signal 0 wraps and saturates
+    got = np.full((n, length), 77, np.int16); want = got.copy()
+    E.emu_silk_lpc_analysis_filter(n, P(got), P(x), P(B), length, d)
+    for s in range(n): O.oc_silk_lpc_analysis_filter(P(want[s]), P(x[s]), P(B[s]), length, d)
+    assert np.array_equal(got, want)

@@ -78,3 +78,34 @@ def test_nsq_matches_reference(fs, nb, shaping, states, warp, dd):
             if not dd: assert s_ref["rand_seed"][0] == s_or["rand_seed"][0]
             nz += int(np.count_nonzero(p1))
         assert nz > 100                       # the synthetic inputs do exercise the quantiser
+
+RS_STATE = np.dtype([("sIIR", "<i4", 6), ("sFIR", "<i4", 36), ("delayBuf", "<i2", 96), ("resampler_function", "<i4"), ("batchSize", "<i4"),
+                     ("invRatio_Q16", "<i4"), ("FIR_Order", "<i4"), ("FIR_Fracs", "<i4"), ("Fs_in_kHz", "<i4"), ("Fs_out_kHz", "<i4"),
+                     ("inputDelay", "<i4"), ("coefs_id", "<i4")], align=True)
+RATES = [8000, 12000, 16000, 24000, 48000]
+RS_PAIRS = [(i, o, 1) for i in RATES for o in (8000, 12000, 16000)] + [(i, o, 0) for i in (8000, 12000, 16000) for o in RATES]
+RS_FIELDS = ["resampler_function", "batchSize", "invRatio_Q16", "FIR_Order", "FIR_Fracs", "Fs_in_kHz", "Fs_out_kHz", "inputDelay"]
+
+@pytest.mark.needs_ref
+@pytest.mark.parametrize("fs_in,fs_out,for_enc", RS_PAIRS)
+def test_resampler_matches_reference(fs_in, fs_out, for_enc):
+    """silk_resampler_init + silk_resampler (silk/resampler.c:79,:183) over consecutive calls of mixed lengths"""
+    X, O = ref_expose(), oracle(); rng = np.random.default_rng(fs_in // 1000 * 100 + fs_out // 1000 + for_enc)
+    ref = np.zeros(X.ref_silk_resampler_state_size(), np.uint8); st = np.zeros(1, dtype=RS_STATE)
+    assert X.ref_silk_resampler_init(P(ref), fs_in, fs_out, for_enc) == 0 and O.oc_silk_resampler_init(P(st), fs_in, fs_out, for_enc) == 0
+    ki, ko = fs_in // 1000, fs_out // 1000
+    for call in range(12):
+        ms = int(rng.choice([1, 2, 5, 10, 20]))
+        amp = 32767 if call % 4 == 3 else 8000                   # every fourth call saturates
+        x = np.clip(np.round(rng.standard_normal(ki * ms) * amp), -32768, 32767).astype(np.int16)
+        o1 = np.full(ko * ms, 77, np.int16); o2 = o1.copy()
+        X.ref_silk_resampler(P(ref), P(o1), P(x), len(x)); O.oc_silk_resampler(P(st), P(o2), P(x), len(x))
+        assert np.array_equal(o1, o2), (call, ms)
+        assert bytes(ref[:360]) == st.tobytes()[:360], call      # sIIR, sFIR, delayBuf: identical layout in both structs
+    for i, k in enumerate(RS_FIELDS):
+        assert int(np.frombuffer(bytes(ref[360 + 4 * i:364 + 4 * i]), np.int32)[0]) == int(st[k][0]), k
+
+def test_resampler_rejects_unsupported_rates():
+    O = oracle(); st = np.zeros(1, dtype=RS_STATE)
+    assert O.oc_silk_resampler_init(P(st), 44100, 16000, 1) == -1 and O.oc_silk_resampler_init(P(st), 48000, 24000, 1) == -1
+    assert O.oc_silk_resampler_init(P(st), 24000, 48000, 0) == -1
