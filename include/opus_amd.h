@@ -246,6 +246,24 @@ OPUS_AMD_EXPORT int opusgpu_silk_lpc_analysis_filter_batch(int device, opus_int3
 OPUS_AMD_EXPORT int opusgpu_silk_lpc_analysis_filter_batch_dev(int device, opus_int32 n, opus_int16 *d_out, const opus_int16 *d_in, const opus_int16 *d_B, opus_int32 len,
       opus_int32 d, void *hip_stream);
 
+/* silk_resampler (silk/resampler.c:79 silk_resampler_init, :183 silk_resampler; prototypes silk/SigProc_FIX.h:59-75) for n independent
+ * channels of one rate pair.  create() validates the pair exactly like silk_resampler_init (forEnc=1: {8,12,16,24,48} kHz -> {8,12,16} kHz;
+ * forEnc=0: {8,12,16} kHz -> {8,12,16,24,48} kHz; the ratios of resampler.c:135-166) and fails with OPUS_BAD_ARG otherwise.
+ * run(): in[n][inLen] -> out[n][inLen * Fs_out / Fs_in], inLen a whole number of milliseconds >= 1 ms (the reference asserts >= 1 ms).
+ * The state blob is silk_resampler_state_struct field for field (silk/resampler_structs.h:38-52) with the Coefs pointer replaced by a
+ * table id; it can only be imported into a batch of the same rate pair. */
+typedef struct OpusGpuResamplerBatch OpusGpuResamplerBatch;
+OPUS_AMD_EXPORT OpusGpuResamplerBatch *opusgpu_resampler_batch_create(opus_int32 nchannels, opus_int32 Fs_Hz_in, opus_int32 Fs_Hz_out, int forEnc, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_resampler_batch_destroy(OpusGpuResamplerBatch *b);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_reset(OpusGpuResamplerBatch *b);
+OPUS_AMD_EXPORT opus_int32 opusgpu_resampler_batch_out_len(const OpusGpuResamplerBatch *b, opus_int32 inLen);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_run(OpusGpuResamplerBatch *b, opus_int16 *out, const opus_int16 *in, opus_int32 inLen);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_run_dev(OpusGpuResamplerBatch *b, opus_int16 *d_out, const opus_int16 *d_in, opus_int32 inLen, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_sync(OpusGpuResamplerBatch *b);
+OPUS_AMD_EXPORT int opusgpu_resampler_state_size(void);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_export_state(OpusGpuResamplerBatch *b, opus_int32 channel, void *state);
+OPUS_AMD_EXPORT int opusgpu_resampler_batch_import_state(OpusGpuResamplerBatch *b, opus_int32 channel, const void *state);
+
 #ifdef __cplusplus
 }
 #endif

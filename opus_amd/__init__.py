@@ -81,6 +81,12 @@ def lib():
         L.opusgpu_nsq_time_dev.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.opusgpu_silk_lpc_analysis_filter_batch.argtypes = [ctypes.c_int, i32, vp, vp, vp, i32, i32]
         L.opusgpu_silk_lpc_analysis_filter_batch_dev.argtypes = [ctypes.c_int, i32, vp, vp, vp, i32, i32, vp]
+        L.opusgpu_resampler_batch_create.restype = vp; L.opusgpu_resampler_batch_create.argtypes = [i32, i32, i32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opusgpu_resampler_batch_destroy.argtypes = [vp]; L.opusgpu_resampler_batch_destroy.restype = None
+        L.opusgpu_resampler_batch_reset.argtypes = [vp]; L.opusgpu_resampler_batch_sync.argtypes = [vp]
+        L.opusgpu_resampler_batch_out_len.argtypes = [vp, i32]
+        L.opusgpu_resampler_batch_run.argtypes = [vp, vp, vp, i32]; L.opusgpu_resampler_batch_run_dev.argtypes = [vp, vp, vp, i32, vp]
+        L.opusgpu_resampler_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_resampler_batch_import_state.argtypes = [vp, i32, vp]
         _lib = L
     return _lib
 
@@ -289,3 +295,41 @@ def silk_lpc_analysis_filter(x, B, device=0):
     r = lib().opusgpu_silk_lpc_analysis_filter_batch(device, x.shape[0], out.ctypes.data, x.ctypes.data, B.ctypes.data, x.shape[1], B.shape[1])
     if r != OPUS_OK: raise OpusError(r)
     return out
+
+
+class ResamplerBatch:
+    """n independent channels of one SILK rate pair (include/opus_amd.h opusgpu_resampler_*; reference silk/resampler.c:79,:183)."""
+    def __init__(self, nchannels, Fs_in, Fs_out, for_enc=1, device=0):
+        err = ctypes.c_int()
+        self._L = lib()
+        self._b = self._L.opusgpu_resampler_batch_create(nchannels, Fs_in, Fs_out, for_enc, device, ctypes.byref(err))
+        if not self._b: raise OpusError(err.value)
+        self.n, self.Fs_in, self.Fs_out = nchannels, Fs_in, Fs_out
+    def run(self, x):
+        """x int16 [n, inLen] (whole milliseconds) -> int16 [n, inLen * Fs_out / Fs_in]"""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.int16); assert x.ndim == 2 and x.shape[0] == self.n
+        ol = self._L.opusgpu_resampler_batch_out_len(self._b, x.shape[1])
+        if ol < 0: raise OpusError(ol)
+        out = np.zeros((self.n, ol), np.int16)
+        r = self._L.opusgpu_resampler_batch_run(self._b, out.ctypes.data, x.ctypes.data, x.shape[1])
+        if r != OPUS_OK: raise OpusError(r)
+        return out
+    def run_dev(self, d_out_ptr, d_in_ptr, in_len, hip_stream=None):
+        r = self._L.opusgpu_resampler_batch_run_dev(self._b, d_out_ptr, d_in_ptr, in_len, hip_stream)
+        if r != OPUS_OK: raise OpusError(r)
+    def export_state(self, channel):
+        buf = ctypes.create_string_buffer(self._L.opusgpu_resampler_state_size())
+        r = self._L.opusgpu_resampler_batch_export_state(self._b, channel, buf)
+        if r != OPUS_OK: raise OpusError(r)
+        return buf.raw
+    def import_state(self, channel, blob):
+        r = self._L.opusgpu_resampler_batch_import_state(self._b, channel, bytes(blob))
+        if r != OPUS_OK: raise OpusError(r)
+    def reset(self):
+        r = self._L.opusgpu_resampler_batch_reset(self._b)
+        if r != OPUS_OK: raise OpusError(r)
+    def sync(self): self._L.opusgpu_resampler_batch_sync(self._b)
+    def close(self):
+        if getattr(self, "_b", None): self._L.opusgpu_resampler_batch_destroy(self._b); self._b = None
+    def __del__(self): self.close()

@@ -10,6 +10,7 @@
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
 #include "silk_lpc.h"
+#include "silk_resampler.h"
 
 template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
 {
@@ -37,7 +38,143 @@ __global__ __launch_bounds__(64) void oa_silk_lpc_analysis_kernel(i16 *out, cons
    silk_lpc_analysis_filter_wave((WV_LDS LpcLds *)&lds, out + s * (size_t)len, in + s * (size_t)len, B + s * (size_t)d, len, d);
 }
 
+__global__ __launch_bounds__(64) void oa_silk_resampler_kernel(OaResamplerCfg cfg, i32 *state, int n, const i16 *in, int inLen, i16 *out, int outLen)
+{
+   __shared__ ResamplerLds lds;
+   const int ch = (int)blockIdx.x * 64 + (int)threadIdx.x;
+   if (ch >= n) return;                              /* no cross-lane operation anywhere in this kernel */
+   silk_resampler_lane(cfg, (WV_LDS ResamplerLds *)&lds, state + ch, n, in + (size_t)ch * inLen, inLen, out + (size_t)ch * outLen);
+}
+
+/* silk_resampler_init (silk/resampler.c:79-178): delay-compensation matrices :52-67, method selection, rounded-up Q16 ratio */
+static int oa_resampler_init_cfg(OaResamplerCfg *S, opus_int32 Fs_in, opus_int32 Fs_out, int forEnc)
+{
+   static const signed char dEnc[6][3] = { { 6, 0, 3 }, { 0, 7, 3 }, { 0, 1, 10 }, { 0, 2, 6 }, { 18, 10, 12 }, { 0, 0, 44 } };
+   static const signed char dDec[3][6] = { { 4, 0, 2, 0, 0, 0 }, { 0, 9, 4, 7, 4, 4 }, { 0, 3, 12, 7, 7, 7 } };
+   auto rid = [](opus_int32 R) { int v = ((((R >> 12) - (R > 16000)) >> (R > 24000)) - 1); return v < 5 ? v : 5; };
+   memset(S, 0, sizeof *S);
+   const bool in3 = Fs_in == 8000 || Fs_in == 12000 || Fs_in == 16000, out3 = Fs_out == 8000 || Fs_out == 12000 || Fs_out == 16000;
+   if (forEnc) { if (!(in3 || Fs_in == 24000 || Fs_in == 48000) || !out3) return -1; S->inputDelay = dEnc[rid(Fs_in)][rid(Fs_out)]; }
+   else { if (!in3 || !(out3 || Fs_out == 24000 || Fs_out == 48000)) return -1; S->inputDelay = dDec[rid(Fs_in)][rid(Fs_out)]; }
+   S->Fs_in_kHz = Fs_in / 1000; S->Fs_out_kHz = Fs_out / 1000; S->batchSize = S->Fs_in_kHz * 10;
+   int up2x = 0;
+   if (Fs_out > Fs_in) { if (Fs_out == 2 * Fs_in) S->resampler_function = OA_RS_FN_UP2; else { S->resampler_function = OA_RS_FN_IIR_FIR; up2x = 1; } }
+   else if (Fs_out < Fs_in) {
+      S->resampler_function = OA_RS_FN_DOWN_FIR;
+      if (Fs_out * 4 == Fs_in * 3)      { S->FIR_Fracs = 3; S->FIR_Order = 18; S->coefs_id = OA_RS_3_4; }
+      else if (Fs_out * 3 == Fs_in * 2) { S->FIR_Fracs = 2; S->FIR_Order = 18; S->coefs_id = OA_RS_2_3; }
+      else if (Fs_out * 2 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 24; S->coefs_id = OA_RS_1_2; }
+      else if (Fs_out * 3 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_3; }
+      else if (Fs_out * 4 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_4; }
+      else if (Fs_out * 6 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_6; }
+      else return -1;
+   } else S->resampler_function = OA_RS_FN_COPY;
+   S->invRatio_Q16 = ((Fs_in << (14 + up2x)) / Fs_out) << 2;
+   while ((opus_int32)(((int64_t)S->invRatio_Q16 * Fs_out) >> 16) < (Fs_in << up2x)) S->invRatio_Q16++;
+   return 0;
+}
+
 extern "C" {
+/* ---- silk_resampler for n independent channels of one rate pair (silk/resampler.c:79 init, :183 run) ---- */
+struct OpusGpuResamplerBatch { int device; opus_int32 n; OaResamplerCfg cfg; hipStream_t stream; i32 *d_state; opus_int16 *d_in, *d_out; size_t in_cap, out_cap; };
+int opusgpu_resampler_state_size(void) { return (int)sizeof(OaResamplerState); }
+void opusgpu_resampler_batch_destroy(OpusGpuResamplerBatch *b)
+{
+   if (!b) return;
+   (void)hipSetDevice(b->device);
+   if (b->stream) (void)hipStreamSynchronize(b->stream);
+   if (b->d_state) (void)hipFree(b->d_state);
+   if (b->d_in) (void)hipFree(b->d_in);
+   if (b->d_out) (void)hipFree(b->d_out);
+   if (b->stream) (void)hipStreamDestroy(b->stream);
+   delete b;
+}
+int opusgpu_resampler_batch_reset(OpusGpuResamplerBatch *b)
+{
+   if (!b) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipMemsetAsync(b->d_state, 0, sizeof(i32) * OA_RS_ROWS * (size_t)b->n, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   return OPUS_OK;
+}
+OpusGpuResamplerBatch *opusgpu_resampler_batch_create(opus_int32 nchannels, opus_int32 Fs_Hz_in, opus_int32 Fs_Hz_out, int forEnc, int device, int *error)
+{
+   int err = OPUS_OK; OpusGpuResamplerBatch *b = nullptr; OaResamplerCfg c;
+   if (nchannels <= 0 || oa_resampler_init_cfg(&c, Fs_Hz_in, Fs_Hz_out, forEnc) != 0) err = OPUS_BAD_ARG;
+   if (err == OPUS_OK) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+         fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev);
+         err = OPUS_INTERNAL_ERROR;
+      }
+   }
+   if (err == OPUS_OK) {
+      b = new OpusGpuResamplerBatch(); memset(b, 0, sizeof *b);
+      b->device = device; b->n = nchannels; b->cfg = c;
+      bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
+                hipMalloc((void **)&b->d_state, sizeof(i32) * OA_RS_ROWS * (size_t)nchannels) == hipSuccess && opusgpu_resampler_batch_reset(b) == OPUS_OK;
+      if (!ok) { opusgpu_resampler_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
+   }
+   if (error) *error = err;
+   return b;
+}
+opus_int32 opusgpu_resampler_batch_out_len(const OpusGpuResamplerBatch *b, opus_int32 inLen)
+{ return (!b || inLen < b->cfg.Fs_in_kHz || inLen % b->cfg.Fs_in_kHz) ? OPUS_BAD_ARG : inLen / b->cfg.Fs_in_kHz * b->cfg.Fs_out_kHz; }
+int opusgpu_resampler_batch_run_dev(OpusGpuResamplerBatch *b, opus_int16 *d_out, const opus_int16 *d_in, opus_int32 inLen, void *hip_stream)
+{
+   if (!b || !d_out || !d_in) return OPUS_BAD_ARG;
+   const opus_int32 outLen = opusgpu_resampler_batch_out_len(b, inLen);           /* whole milliseconds, >= 1 ms (silk/resampler.c:193) */
+   if (outLen < 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   hipLaunchKernelGGL(oa_silk_resampler_kernel, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, hip_stream ? (hipStream_t)hip_stream : b->stream, b->cfg, b->d_state, (int)b->n,
+                      (const i16 *)d_in, (int)inLen, (i16 *)d_out, (int)outLen);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_resampler_batch_sync(OpusGpuResamplerBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
+int opusgpu_resampler_batch_run(OpusGpuResamplerBatch *b, opus_int16 *out, const opus_int16 *in, opus_int32 inLen)
+{
+   if (!b || !out || !in) return OPUS_BAD_ARG;
+   const opus_int32 outLen = opusgpu_resampler_batch_out_len(b, inLen);
+   if (outLen < 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   const size_t ib = sizeof(opus_int16) * (size_t)b->n * inLen, ob = sizeof(opus_int16) * (size_t)b->n * outLen;
+   if (ib > b->in_cap) { if (b->d_in) (void)hipFree(b->d_in); b->d_in = nullptr; b->in_cap = 0; if (hipMalloc((void **)&b->d_in, ib) != hipSuccess) return OPUS_ALLOC_FAIL; b->in_cap = ib; }
+   if (ob > b->out_cap) { if (b->d_out) (void)hipFree(b->d_out); b->d_out = nullptr; b->out_cap = 0; if (hipMalloc((void **)&b->d_out, ob) != hipSuccess) return OPUS_ALLOC_FAIL; b->out_cap = ob; }
+   HIPCHECK(hipMemcpyAsync(b->d_in, in, ib, hipMemcpyHostToDevice, b->stream));
+   int r = opusgpu_resampler_batch_run_dev(b, b->d_out, b->d_in, inLen, nullptr);
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpyAsync(out, b->d_out, ob, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   return OPUS_OK;
+}
+static int oa_resampler_state_rw(OpusGpuResamplerBatch *b, opus_int32 i, const OaResamplerState *in, OaResamplerState *out)
+{
+   if (!b || i < 0 || i >= b->n) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   i32 rows[OA_RS_ROWS];
+   const bool fir16 = b->cfg.resampler_function == OA_RS_FN_IIR_FIR;
+   if (out) {
+      HIPCHECK(hipMemcpy2D(rows, sizeof(i32), b->d_state + i, sizeof(i32) * (size_t)b->n, sizeof(i32), OA_RS_ROWS, hipMemcpyDeviceToHost));
+      memset(out, 0, sizeof *out);
+      for (int j = 0; j < 6; j++) out->sIIR[j] = rows[OA_RS_ROW_IIR + j];
+      for (int j = 0; j < 36; j++) { if (fir16) { if (j < 8) out->sFIR.w16[j] = (i16)rows[OA_RS_ROW_FIR + j]; } else out->sFIR.w32[j] = rows[OA_RS_ROW_FIR + j]; }
+      for (int j = 0; j < 48; j++) out->delayBuf[j] = (i16)rows[OA_RS_ROW_DELAY + j];
+      out->cfg = b->cfg;
+   }
+   if (in) {
+      if (memcmp(&in->cfg, &b->cfg, sizeof(OaResamplerCfg)) != 0) return OPUS_BAD_ARG;       /* a state only fits a batch of its own rate pair */
+      for (int j = 0; j < 6; j++) rows[OA_RS_ROW_IIR + j] = in->sIIR[j];
+      for (int j = 0; j < 36; j++) rows[OA_RS_ROW_FIR + j] = fir16 ? (j < 8 ? in->sFIR.w16[j] : 0) : in->sFIR.w32[j];
+      for (int j = 0; j < 48; j++) rows[OA_RS_ROW_DELAY + j] = in->delayBuf[j];
+      HIPCHECK(hipMemcpy2D(b->d_state + i, sizeof(i32) * (size_t)b->n, rows, sizeof(i32), sizeof(i32), OA_RS_ROWS, hipMemcpyHostToDevice));
+   }
+   return OPUS_OK;
+}
+int opusgpu_resampler_batch_export_state(OpusGpuResamplerBatch *b, opus_int32 channel, void *state) { return state ? oa_resampler_state_rw(b, channel, nullptr, (OaResamplerState *)state) : OPUS_BAD_ARG; }
+int opusgpu_resampler_batch_import_state(OpusGpuResamplerBatch *b, opus_int32 channel, const void *state) { return state ? oa_resampler_state_rw(b, channel, (const OaResamplerState *)state, nullptr) : OPUS_BAD_ARG; }
+
 /* ---- silk_LPC_analysis_filter for n independent signals of one length and order (silk/LPC_analysis_filter.c:49) ---- */
 int opusgpu_silk_lpc_analysis_filter_batch_dev(int device, opus_int32 n, opus_int16 *d_out, const opus_int16 *d_in, const opus_int16 *d_B, opus_int32 len, opus_int32 d, void *hip_stream)
 {

@@ -6,6 +6,7 @@
 #include "silk_nsq_dd.h"
 #include "silk_host.h"
 #include "silk_lpc.h"
+#include "silk_resampler.h"
 
 static int g_generic = 0;
 extern "C" void emu_nsq_force_generic(int g) { g_generic = g; }   /* run the runtime-order instantiation even for specialised orders */
@@ -57,4 +58,16 @@ static void lpc_entry(void *arg) { LpcJob *j = (LpcJob *)arg; silk_lpc_analysis_
 extern "C" void emu_silk_lpc_analysis_filter(int n, int16_t *out, const int16_t *in, const int16_t *B, int len, int d)
 {
    for (int s = 0; s < n; s++) { LpcJob *j = new LpcJob; j->out = out + (size_t)s * len; j->in = in + (size_t)s * len; j->B = B + (size_t)s * d; j->len = len; j->d = d; emu_run_wave(lpc_entry, j); delete j; }
+}
+
+struct RsJob { ResamplerLds lds; OaResamplerCfg cfg; int32_t *state; int n, first; const int16_t *in; int inLen; int16_t *out; int outLen; };
+static void rs_entry(void *arg)
+{
+   RsJob *j = (RsJob *)arg; int ch = j->first + wv_lane(); if (ch >= j->n) return;
+   silk_resampler_lane(j->cfg, &j->lds, j->state + ch, j->n, j->in + (size_t)ch * j->inLen, j->inLen, j->out + (size_t)ch * j->outLen);
+}
+/* state: [OA_RS_ROWS][n] int32 rows exactly as the device keeps them; cfg: the nine OaResamplerCfg words */
+extern "C" void emu_silk_resampler(const OaResamplerCfg *cfg, int32_t *state, int n, const int16_t *in, int inLen, int16_t *out, int outLen)
+{
+   for (int first = 0; first < n; first += 64) { RsJob *j = new RsJob; j->cfg = *cfg; j->state = state; j->n = n; j->first = first; j->in = in; j->inLen = inLen; j->out = out; j->outLen = outLen; emu_run_wave(rs_entry, j); delete j; }
 }

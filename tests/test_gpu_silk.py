@@ -105,3 +105,43 @@ def test_gpu_lpc_analysis_filter_bad_args():
     for d in (4, 7, 18):
         with pytest.raises(opus_amd.OpusError): opus_amd.silk_lpc_analysis_filter(x, np.zeros((2, d), np.int16))
     with pytest.raises(opus_amd.OpusError): opus_amd.silk_lpc_analysis_filter(np.zeros((2, 2000), np.int16), np.zeros((2, 16), np.int16))
+
+from test_oracle_silk import RS_STATE, RS_PAIRS
+
+@pytest.mark.parametrize("fs_in,fs_out,for_enc", RS_PAIRS)
+def test_gpu_resampler(fs_in, fs_out, for_enc):
+    """opusgpu_resampler_* against the oracle (pinned to silk_resampler by tests/test_oracle_silk.py) over consecutive calls, then the state
+    blob against the oracle's (same field order)"""
+    import opus_amd
+    O = oracle(); rng = np.random.default_rng(fs_in // 1000 * 100 + fs_out // 1000 + for_enc); n = 200
+    st = np.zeros(n, dtype=RS_STATE)
+    for s in range(n): assert O.oc_silk_resampler_init(P(st[s:s + 1]), fs_in, fs_out, for_enc) == 0
+    b = opus_amd.ResamplerBatch(n, fs_in, fs_out, for_enc)
+    ki, ko = fs_in // 1000, fs_out // 1000
+    for call in range(5):
+        ms = int(rng.choice([1, 2, 10, 20])) if call else 20
+        x = np.clip(np.round(rng.standard_normal((n, ki * ms)) * (30000 if call == 3 else 8000)), -32768, 32767).astype(np.int16)
+        want = np.zeros((n, ko * ms), np.int16)
+        for s in range(n): O.oc_silk_resampler(P(st[s:s + 1]), P(want[s]), P(x[s]), ki * ms)
+        assert np.array_equal(b.run(x), want), call
+    for s in (0, 63, 64, n - 1):
+        blob = np.frombuffer(b.export_state(s), dtype=RS_STATE)[0]
+        nfir = st[s]["FIR_Order"] if st[s]["resampler_function"] == 3 else 2 if st[s]["resampler_function"] == 2 else 0      # words of FIR tail in use (8 int16 = 4 words... compared as int16 below)
+        assert np.array_equal(blob["sIIR"], st[s]["sIIR"])
+        if st[s]["resampler_function"] == 3: assert np.array_equal(blob["sFIR"][:nfir], st[s]["sFIR"][:nfir])
+        if st[s]["resampler_function"] == 2: assert np.array_equal(blob["sFIR"].view(np.int16)[:8], st[s]["sFIR"].view(np.int16)[:8])
+        d = int(st[s]["inputDelay"]); assert np.array_equal(blob["delayBuf"][:d], st[s]["delayBuf"][:d])
+    # migrate channel 0's state into channel 1 and check both then produce the same output for the same input
+    b.import_state(1, b.export_state(0))
+    x = np.clip(np.round(rng.standard_normal((n, ki * 10)) * 8000), -32768, 32767).astype(np.int16); x[1] = x[0]
+    y = b.run(x); assert np.array_equal(y[0], y[1])
+    b.close()
+
+def test_gpu_resampler_bad_args():
+    import opus_amd
+    with pytest.raises(opus_amd.OpusError): opus_amd.ResamplerBatch(4, 44100, 16000, 1)
+    with pytest.raises(opus_amd.OpusError): opus_amd.ResamplerBatch(4, 48000, 24000, 1)
+    b = opus_amd.ResamplerBatch(4, 48000, 16000, 1)
+    with pytest.raises(opus_amd.OpusError): b.run(np.zeros((4, 50), np.int16))          # not a whole number of milliseconds
+    with pytest.raises(opus_amd.OpusError): b.run(np.zeros((4, 24), np.int16))          # < 1 ms
+    b.close()

@@ -7,7 +7,7 @@ from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame,
 def _build():
     so = os.path.join(ROOT, "tests/emu/libemu_silk.so")
     srcs = [os.path.join(ROOT, "tests/emu", f) for f in ("emu_silk.cpp", "wave_emu.cpp")]
-    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_lpc.h", "silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
+    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_lpc.h", "silk_resampler.h", "silk_tables.h", "silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
     hdrs = [h for h in hdrs if os.path.exists(h)]
     import fcntl
     with open(so + ".lock", "w") as lk:
@@ -105,3 +105,27 @@ def test_emu_lpc_analysis_filter(d, length):
     E.emu_silk_lpc_analysis_filter(n, P(got), P(x), P(B), length, d)
     for s in range(n): O.oc_silk_lpc_analysis_filter(P(want[s]), P(x[s]), P(B[s]), length, d)
     assert np.array_equal(got, want)
+
+from test_oracle_silk import RS_STATE, RS_PAIRS
+RS_CFG = ["resampler_function", "batchSize", "invRatio_Q16", "FIR_Order", "FIR_Fracs", "Fs_in_kHz", "Fs_out_kHz", "inputDelay", "coefs_id"]
+
+@pytest.mark.parametrize("fs_in,fs_out,for_enc", RS_PAIRS)
+def test_emu_resampler(fs_in, fs_out, for_enc):
+    """the lane-per-channel streaming resampler against the oracle over consecutive calls, incl. the carried filter state"""
+    E = _build(); O = oracle(); rng = np.random.default_rng(fs_in // 1000 * 100 + fs_out // 1000 + for_enc); n = 67
+    st = np.zeros(n, dtype=RS_STATE)
+    for s in range(n): assert O.oc_silk_resampler_init(P(st[s:s + 1]), fs_in, fs_out, for_enc) == 0
+    cfg = np.array([st[0][k] for k in RS_CFG], np.int32)
+    rows = np.zeros((90, n), np.int32)
+    ki, ko = fs_in // 1000, fs_out // 1000
+    for call in range(5):
+        ms = int(rng.choice([1, 2, 10, 20])) if call else 20
+        x = np.clip(np.round(rng.standard_normal((n, ki * ms)) * (30000 if call == 3 else 8000)), -32768, 32767).astype(np.int16)
+        want = np.zeros((n, ko * ms), np.int16); got = np.full((n, ko * ms), 77, np.int16)
+        for s in range(n): O.oc_silk_resampler(P(st[s:s + 1]), P(want[s]), P(x[s]), ki * ms)
+        E.emu_silk_resampler(P(cfg), P(rows), n, P(x), ki * ms, P(got), ko * ms)
+        assert np.array_equal(got, want), call
+        assert np.array_equal(rows[0:6].T, st["sIIR"])
+        if cfg[0] == 3: assert np.array_equal(rows[6:6 + cfg[3]].T, st["sFIR"][:, :cfg[3]])
+        if cfg[0] == 2: assert np.array_equal(rows[6:14].T.astype(np.int16), st["sFIR"].view(np.int16).reshape(n, 72)[:, :8])
+        assert np.array_equal(rows[42:42 + cfg[7]].T.astype(np.int16), st["delayBuf"][:, :cfg[7]])
