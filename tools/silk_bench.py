@@ -11,8 +11,10 @@ def main():
     ap.add_argument("--streams", type=int, default=65536); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--states", type=int, default=4); ap.add_argument("--plain", action="store_true", help="plain NSQ (1 state, no warping)")
     ap.add_argument("--cpu-frames", type=int, default=4000)
+    ap.add_argument("--kernel", default="nsq", choices=["nsq", "resampler", "lpc"])
     a = ap.parse_args()
     import torch, opus_amd
+    if a.kernel != "nsq": return hbm_kernels(a, torch, opus_amd)
     from silk_inputs import NSQ_FRAME, make_cfg, make_frame, make_input, fresh_state
     cfg = make_cfg(16, 4, 24, 1 if a.plain else a.states, not a.plain)
     dd = not a.plain
@@ -49,6 +51,53 @@ def main():
         # subtract the ctypes marshalling overhead measured with a no-op-sized call? keep it simple: report as is, it is ~15 us/call
         out["cpu_baseline"] = {"value": a.cpu_frames / dt, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "%d frames, silk_NSQ%s_c via ctypes (incl. ~10 us/call marshalling)" % (a.cpu_frames, "_del_dec" if dd else "")}
         out["speedup_vs_1core"] = fps / (a.cpu_frames / dt)
+    print(json.dumps(out))
+
+def hbm_kernels(a, torch, opus_amd):
+    """the two HBM-bound SILK kernels: resampler 48 -> 16 kHz (20 ms per channel per step) and the order-16 LPC analysis filter over the
+    672-sample pitch-analysis buffer (silk/fixed/find_pitch_lags_FIX.c); achieved GB/s = algorithmic bytes / HIP-event time."""
+    import ctypes
+    from reflib import ref_expose, oracle
+    n = a.streams; dev = torch.device("cuda:0"); rng = np.random.default_rng(2)
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.kernel == "resampler":
+        x = torch.from_numpy(rng.integers(-20000, 20000, (n, 960)).astype(np.int16)).to(dev); y = torch.zeros((n, 320), dtype=torch.int16, device=dev)
+        b = opus_amd.ResamplerBatch(n, 48000, 16000, 1)
+        for _ in range(a.warmup): b.run_dev(y.data_ptr(), x.data_ptr(), 960, stream)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(a.steps): b.run_dev(y.data_ptr(), x.data_ptr(), 960, stream)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps; bytes_per = 960 * 2 + 320 * 2 + 2 * 90 * 4
+        out = {"kernel": "silk_resampler 48k->16k", "channels": n, "ms_per_step": ms, "frames_per_s": n / (ms * 1e-3), "bytes_per_frame": bytes_per,
+               "achieved_GBps": n * bytes_per / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000}
+        X = ref_expose()
+        if X is not None and a.cpu_frames > 0:
+            st = np.zeros(X.ref_silk_resampler_state_size(), np.uint8); X.ref_silk_resampler_init(st.ctypes.data_as(ctypes.c_void_p), 48000, 16000, 1)
+            xi = rng.integers(-20000, 20000, 960).astype(np.int16); yo = np.zeros(320, np.int16)
+            t0 = time.perf_counter()
+            for _ in range(a.cpu_frames): X.ref_silk_resampler(st.ctypes.data_as(ctypes.c_void_p), yo.ctypes.data_as(ctypes.c_void_p), xi.ctypes.data_as(ctypes.c_void_p), 960)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": a.cpu_frames / dt, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "%d x silk_resampler(960 samples) via ctypes" % a.cpu_frames}
+    else:
+        L, d = 672, 16
+        x = torch.from_numpy(rng.integers(-20000, 20000, (n, L)).astype(np.int16)).to(dev); y = torch.zeros((n, L), dtype=torch.int16, device=dev)
+        B = torch.from_numpy(rng.integers(-3000, 3000, (n, d)).astype(np.int16)).to(dev)
+        Lb = opus_amd.lib()
+        for _ in range(a.warmup): Lb.opusgpu_silk_lpc_analysis_filter_batch_dev(0, n, y.data_ptr(), x.data_ptr(), B.data_ptr(), L, d, stream)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(a.steps): Lb.opusgpu_silk_lpc_analysis_filter_batch_dev(0, n, y.data_ptr(), x.data_ptr(), B.data_ptr(), L, d, stream)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps; bytes_per = 4 * L + 2 * d
+        out = {"kernel": "silk_lpc_analysis_filter len=672 d=16", "signals": n, "ms_per_step": ms, "signals_per_s": n / (ms * 1e-3), "bytes_per_signal": bytes_per,
+               "achieved_GBps": n * bytes_per / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000}
+        X = ref_expose()
+        if X is not None and a.cpu_frames > 0:
+            xi = rng.integers(-20000, 20000, L).astype(np.int16); yo = np.zeros(L, np.int16); Bi = rng.integers(-3000, 3000, d).astype(np.int16)
+            t0 = time.perf_counter()
+            for _ in range(a.cpu_frames): X.ref_silk_lpc_analysis_filter(yo.ctypes.data_as(ctypes.c_void_p), xi.ctypes.data_as(ctypes.c_void_p), Bi.ctypes.data_as(ctypes.c_void_p), L, d)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": a.cpu_frames / dt, "unit": "signals/s", "cores": 1, "kind": "reference", "sample": "%d x silk_LPC_analysis_filter(672, 16) via ctypes" % a.cpu_frames}
     print(json.dumps(out))
 
 if __name__ == "__main__":
