@@ -88,4 +88,12 @@ typedef struct {
 } OcSilkResampler;
 int oc_silk_resampler_init(OcSilkResampler *S, s32 Fs_Hz_in, s32 Fs_Hz_out, int forEnc);         /* silk/resampler.c:79  */
 int oc_silk_resampler(OcSilkResampler *S, s16 *out, const s16 *in, s32 inLen);                    /* silk/resampler.c:183 */
+
+/* ---- pitch estimator (silk/fixed/pitch_analysis_core_FIX.c:82); returns 0 voiced / 1 unvoiced ---- */
+void oc_silk_sum_sqr_shift(s32 *energy, int *shift, const s16 *x, int len);
+void oc_silk_resampler_down2(s32 *S, s16 *out, const s16 *in, s32 inLen);
+void oc_silk_resampler_down2_3(s32 *S, s16 *out, const s16 *in, s32 inLen);
+s32 oc_silk_lin2log(s32 inLin);
+int oc_silk_pitch_analysis_core(const s16 *frame, s32 *pitch_out, s16 *lagIndex, s8 *contourIndex, s32 *LTPCorr_Q15, s32 prevLag,
+                                s32 search_thres1_Q16, s32 search_thres2_Q13, int Fs_kHz, int complexity, int nb_subfr);
 #endif

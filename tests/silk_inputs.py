@@ -68,3 +68,20 @@ def make_input(rng, cfg, gains):
         amp = min(30000.0, gains[k] / 65536.0 * rng.uniform(0.5, 6.0))
         x[k * L:(k + 1) * L] = np.clip(np.round(rng.standard_normal(L) * amp), -32768, 32767).astype(np.int16)
     return x
+
+def make_pitch_frame(rng, fs_kHz, nb_subfr, kind=None):
+    """an LPC-residual-like analysis buffer of (20 + 5*nb_subfr) ms: a jittered pulse train + noise (voiced), noise (unvoiced), or silence"""
+    n = (20 + 5 * nb_subfr) * fs_kHz
+    kind = kind or rng.choice(["voiced", "voiced", "voiced", "weak", "noise", "loud", "silence", "tiny"])
+    if kind == "silence": return np.zeros(n, np.int16), kind
+    x = rng.standard_normal(n) * 200.0
+    if kind in ("voiced", "weak", "loud", "tiny"):
+        lag = rng.uniform(2.2, 17.5) * fs_kHz; drift = rng.uniform(-0.004, 0.004)
+        t = rng.uniform(0, lag); amp = 3000.0 if kind != "weak" else 500.0
+        shape = rng.standard_normal(6) * np.array([1, .7, .5, .3, .2, .1])
+        while t < n - 8:
+            i = int(t); x[i:i + 6] += amp * shape * rng.uniform(0.8, 1.2)
+            lag *= (1 + drift); t += lag
+    if kind == "loud": x *= 12.0
+    if kind == "tiny": x *= 0.01
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16), kind

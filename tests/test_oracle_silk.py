@@ -109,3 +109,49 @@ def test_resampler_rejects_unsupported_rates():
     O = oracle(); st = np.zeros(1, dtype=RS_STATE)
     assert O.oc_silk_resampler_init(P(st), 44100, 16000, 1) == -1 and O.oc_silk_resampler_init(P(st), 48000, 24000, 1) == -1
     assert O.oc_silk_resampler_init(P(st), 24000, 48000, 0) == -1
+
+from silk_inputs import make_pitch_frame
+def _pitch_both(x, prev_lag, ltpcorr, t1, t2, fs, cx, nb):
+    from reflib import ref_fx
+    R, O = ref_fx(), oracle()
+    out = []
+    for fn, extra in ((R.silk_pitch_analysis_core, (0,)), (O.oc_silk_pitch_analysis_core, ())):
+        pitch = np.full(4, -7, np.int32); li = np.zeros(1, np.int16); ci = np.zeros(1, np.int8); lc = np.array([ltpcorr], np.int32)
+        fn.restype = ctypes.c_int
+        v = fn(P(x), P(pitch), P(li), P(ci), P(lc), int(prev_lag), int(t1), int(t2), fs, cx, nb, *extra)
+        out.append((v, pitch[:nb].tolist(), int(li[0]), int(ci[0]), int(lc[0])))
+    return out
+
+@pytest.mark.needs_ref
+@pytest.mark.parametrize("fs,nb", [(16, 4), (12, 4), (8, 4), (16, 2), (12, 2), (8, 2)])
+def test_pitch_analysis_matches_reference(fs, nb):
+    """silk_pitch_analysis_core (silk/fixed/pitch_analysis_core_FIX.c:82): voicing decision, lags, lagIndex, contourIndex, LTPCorr"""
+    rng = np.random.default_rng(fs * 10 + nb); voiced = 0
+    for it in range(160):
+        x, kind = make_pitch_frame(rng, fs, nb)
+        cx = int(rng.integers(0, 3)); prev = int(rng.choice([0, 0, rng.integers(2 * fs, 18 * fs)])); ltp = int(rng.integers(0, 30000))
+        t1 = int(rng.uniform(0.6, 0.85) * 65536); t2 = int(rng.uniform(0.1, 0.6) * 8192)
+        a, b = _pitch_both(x, prev, ltp, t1, t2, fs, cx, nb)
+        assert a == b, (it, kind, cx, prev, a, b)
+        voiced += a[0] == 0
+    assert voiced > 25              # the synthetic frames do reach stages 2 and 3
+
+@pytest.mark.needs_ref
+def test_pitch_helpers_match_reference():
+    from reflib import ref_fx
+    R, O = ref_fx(), oracle(); rng = np.random.default_rng(5)
+    R.silk_lin2log.restype = ctypes.c_int32; O.oc_silk_lin2log.restype = ctypes.c_int32
+    for v in list(range(1, 600)) + [int(2 ** rng.uniform(0, 31)) for _ in range(2000)]:
+        assert R.silk_lin2log(v) == O.oc_silk_lin2log(v), v
+    for it in range(100):
+        n = int(rng.integers(2, 700)); x = (rng.standard_normal(n) * 2 ** rng.uniform(0, 15)).clip(-32768, 32767).astype(np.int16)
+        e1, s1, e2, s2 = ctypes.c_int32(), ctypes.c_int(), ctypes.c_int32(), ctypes.c_int()
+        R.silk_sum_sqr_shift(ctypes.byref(e1), ctypes.byref(s1), P(x), n); O.oc_silk_sum_sqr_shift(ctypes.byref(e2), ctypes.byref(s2), P(x), n)
+        assert (e1.value, s1.value) == (e2.value, s2.value)
+        for fn_r, fn_o, nst, olen in ((R.silk_resampler_down2, O.oc_silk_resampler_down2, 2, n // 2), (R.silk_resampler_down2_3, O.oc_silk_resampler_down2_3, 6, 2 * (n // 3))):
+            m = n - n % 6
+            if m < 6: continue
+            sa = rng.integers(-1000, 1000, 6).astype(np.int32); sb = sa.copy()
+            oa = np.zeros(m, np.int16); ob = oa.copy()
+            fn_r(P(sa), P(oa), P(x), m); fn_o(P(sb), P(ob), P(x), m)
+            assert np.array_equal(oa, ob) and np.array_equal(sa[:nst], sb[:nst])
