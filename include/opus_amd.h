@@ -264,6 +264,18 @@ OPUS_AMD_EXPORT int opusgpu_resampler_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_resampler_batch_export_state(OpusGpuResamplerBatch *b, opus_int32 channel, void *state);
 OPUS_AMD_EXPORT int opusgpu_resampler_batch_import_state(OpusGpuResamplerBatch *b, opus_int32 channel, const void *state);
 
+/* silk_pitch_analysis_core (silk/fixed/pitch_analysis_core_FIX.c:82, prototype silk/SigProc_FIX.h:296-309) for n independent analysis
+ * buffers: frames[n][(20 + 5*nb_subfr) * Fs_kHz] (the LPC residual the caller's find_pitch_lags step produced, e.g. with
+ * opusgpu_silk_lpc_analysis_filter_batch), Fs_kHz in {8,12,16}, complexity 0..2 (SILK_PE_*_COMPLEX), nb_subfr in {2,4}.
+ * OpusGpuPitchIn = the per-frame scalar arguments (prevLag, *LTPCorr_Q15 on entry, the two thresholds); OpusGpuPitchOut = everything the
+ * reference writes back: pitch_out[4], *LTPCorr_Q15, *lagIndex, *contourIndex and its return value (0 voiced / 1 unvoiced). */
+typedef struct { opus_int32 prevLag, LTPCorr_Q15, search_thres1_Q16, search_thres2_Q13; } OpusGpuPitchIn;
+typedef struct { opus_int32 pitch[4]; opus_int32 LTPCorr_Q15; opus_int16 lagIndex; signed char contourIndex; signed char unvoiced; } OpusGpuPitchOut;
+OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch(int device, opus_int32 n, const opus_int16 *frames, const OpusGpuPitchIn *in, OpusGpuPitchOut *out,
+      int Fs_kHz, int complexity, int nb_subfr);
+OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32 n, const opus_int16 *d_frames, const OpusGpuPitchIn *d_in, OpusGpuPitchOut *d_out,
+      int Fs_kHz, int complexity, int nb_subfr, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

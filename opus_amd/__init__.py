@@ -87,6 +87,8 @@ def lib():
         L.opusgpu_resampler_batch_out_len.argtypes = [vp, i32]
         L.opusgpu_resampler_batch_run.argtypes = [vp, vp, vp, i32]; L.opusgpu_resampler_batch_run_dev.argtypes = [vp, vp, vp, i32, vp]
         L.opusgpu_resampler_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_resampler_batch_import_state.argtypes = [vp, i32, vp]
+        L.opusgpu_silk_pitch_analysis_batch.argtypes = [ctypes.c_int, i32, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.opusgpu_silk_pitch_analysis_batch_dev.argtypes = [ctypes.c_int, i32, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         _lib = L
     return _lib
 
@@ -333,3 +335,16 @@ class ResamplerBatch:
     def close(self):
         if getattr(self, "_b", None): self._L.opusgpu_resampler_batch_destroy(self._b); self._b = None
     def __del__(self): self.close()
+
+
+def silk_pitch_analysis(frames, params, Fs_kHz, complexity, nb_subfr, device=0):
+    """silk_pitch_analysis_core (silk/fixed/pitch_analysis_core_FIX.c:82) for n buffers: frames int16 [n, (20+5*nb_subfr)*Fs_kHz]; params: structured
+    array [n] laid out as OpusGpuPitchIn (4 x int32).  Returns a structured array [n] laid out as OpusGpuPitchOut (28 bytes)."""
+    import numpy as np
+    frames = np.ascontiguousarray(frames, dtype=np.int16); params = np.ascontiguousarray(params)
+    n = frames.shape[0]
+    assert frames.shape == (n, (20 + 5 * nb_subfr) * Fs_kHz) and params.shape == (n,) and params.dtype.itemsize == 16
+    out = np.zeros(n, np.dtype([("pitch", "<i4", 4), ("LTPCorr_Q15", "<i4"), ("lagIndex", "<i2"), ("contourIndex", "i1"), ("unvoiced", "i1")], align=True))
+    r = lib().opusgpu_silk_pitch_analysis_batch(device, n, frames.ctypes.data, params.ctypes.data, out.ctypes.data, Fs_kHz, complexity, nb_subfr)
+    if r != OPUS_OK: raise OpusError(r)
+    return out

@@ -9,6 +9,7 @@ typedef int16_t  i16;
 typedef int32_t  i32;
 typedef int64_t  i64;
 typedef uint32_t u32;
+typedef uint64_t u64;
 typedef uint8_t  u8;
 typedef int8_t   i8;
 #define SIG_SHIFT 12

@@ -11,6 +11,7 @@
 #include "silk_host.h"
 #include "silk_lpc.h"
 #include "silk_resampler.h"
+#include "silk_pitch.h"
 
 template <int SS> __global__ __launch_bounds__(64) void oa_silk_nsq_kernel(OaNsqCfg cfg, i32 *tiles, long tile_words, const OaNsqFrame *frames, const i16 *x16, i8 *pulses, int n)
 {
@@ -74,7 +75,44 @@ static int oa_resampler_init_cfg(OaResamplerCfg *S, opus_int32 Fs_in, opus_int32
    return 0;
 }
 
+__global__ __launch_bounds__(64) void oa_silk_pitch_kernel(OaPitchCfg cfg, const i16 *frames, int flen, const OaPitchIn *in, OaPitchOut *out)
+{
+   __shared__ PitchLds lds;
+   const size_t s = blockIdx.x;
+   silk_pitch_analysis_wave(cfg, (WV_LDS PitchLds *)&lds, frames + s * (size_t)flen, in + s, out + s);
+}
+
 extern "C" {
+/* ---- silk_pitch_analysis_core for n independent analysis buffers (silk/fixed/pitch_analysis_core_FIX.c:82) ---- */
+int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32 n, const opus_int16 *d_frames, const OpusGpuPitchIn *d_in, OpusGpuPitchOut *d_out,
+      int Fs_kHz, int complexity, int nb_subfr, void *hip_stream)
+{
+   if (n <= 0 || !d_frames || !d_in || !d_out || (Fs_kHz != 8 && Fs_kHz != 12 && Fs_kHz != 16) || complexity < 0 || complexity > 2 || (nb_subfr != 2 && nb_subfr != 4)) return OPUS_BAD_ARG;   /* the reference's asserts (:131-135) */
+   HIPCHECK(hipSetDevice(device));
+   OaPitchCfg c = { Fs_kHz, complexity, nb_subfr };
+   hipLaunchKernelGGL(oa_silk_pitch_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)hip_stream, c, (const i16 *)d_frames, (20 + 5 * nb_subfr) * Fs_kHz, (const OaPitchIn *)d_in, (OaPitchOut *)d_out);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+int opusgpu_silk_pitch_analysis_batch(int device, opus_int32 n, const opus_int16 *frames, const OpusGpuPitchIn *in, OpusGpuPitchOut *out, int Fs_kHz, int complexity, int nb_subfr)
+{
+   if (n <= 0 || !frames || !in || !out || (Fs_kHz != 8 && Fs_kHz != 12 && Fs_kHz != 16) || (nb_subfr != 2 && nb_subfr != 4)) return OPUS_BAD_ARG;
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { fprintf(stderr, "opus_amd: no usable HIP device (requested %d of %d) — this library has no CPU fallback\n", device, ndev); return OPUS_INTERNAL_ERROR; }
+   HIPCHECK(hipSetDevice(device));
+   const size_t fb = sizeof(opus_int16) * (size_t)n * (size_t)((20 + 5 * nb_subfr) * Fs_kHz);
+   opus_int16 *d_f = nullptr; OpusGpuPitchIn *d_i = nullptr; OpusGpuPitchOut *d_o = nullptr;
+   int r = OPUS_OK;
+   if (hipMalloc((void **)&d_f, fb) != hipSuccess || hipMalloc((void **)&d_i, sizeof(OpusGpuPitchIn) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_o, sizeof(OpusGpuPitchOut) * (size_t)n) != hipSuccess) r = OPUS_ALLOC_FAIL;
+   if (r == OPUS_OK && (hipMemcpy(d_f, frames, fb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_i, in, sizeof(OpusGpuPitchIn) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)) r = OPUS_INTERNAL_ERROR;
+   if (r == OPUS_OK) r = opusgpu_silk_pitch_analysis_batch_dev(device, n, d_f, d_i, d_o, Fs_kHz, complexity, nb_subfr, nullptr);
+   if (r == OPUS_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_o, sizeof(OpusGpuPitchOut) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)) r = OPUS_INTERNAL_ERROR;
+   if (d_f) (void)hipFree(d_f);
+   if (d_i) (void)hipFree(d_i);
+   if (d_o) (void)hipFree(d_o);
+   return r;
+}
+
 /* ---- silk_resampler for n independent channels of one rate pair (silk/resampler.c:79 init, :183 run) ---- */
 struct OpusGpuResamplerBatch { int device; opus_int32 n; OaResamplerCfg cfg; hipStream_t stream; i32 *d_state; opus_int16 *d_in, *d_out; size_t in_cap, out_cap; };
 int opusgpu_resampler_state_size(void) { return (int)sizeof(OaResamplerState); }

@@ -7,6 +7,7 @@
 #include "silk_host.h"
 #include "silk_lpc.h"
 #include "silk_resampler.h"
+#include "silk_pitch.h"
 
 static int g_generic = 0;
 extern "C" void emu_nsq_force_generic(int g) { g_generic = g; }   /* run the runtime-order instantiation even for specialised orders */
@@ -70,4 +71,12 @@ static void rs_entry(void *arg)
 extern "C" void emu_silk_resampler(const OaResamplerCfg *cfg, int32_t *state, int n, const int16_t *in, int inLen, int16_t *out, int outLen)
 {
    for (int first = 0; first < n; first += 64) { RsJob *j = new RsJob; j->cfg = *cfg; j->state = state; j->n = n; j->first = first; j->in = in; j->inLen = inLen; j->out = out; j->outLen = outLen; emu_run_wave(rs_entry, j); delete j; }
+}
+
+struct PeJob { PitchLds lds; OaPitchCfg cfg; const int16_t *frame; const OaPitchIn *in; OaPitchOut *out; };
+static void pe_entry(void *arg) { PeJob *j = (PeJob *)arg; silk_pitch_analysis_wave(j->cfg, &j->lds, j->frame, j->in, j->out); }
+extern "C" void emu_silk_pitch(int n, const int16_t *frames, const OaPitchIn *in, OaPitchOut *out, int Fs_kHz, int complexity, int nb_subfr)
+{
+   const int flen = (20 + 5 * nb_subfr) * Fs_kHz;
+   for (int s = 0; s < n; s++) { PeJob *j = new PeJob; j->cfg = { Fs_kHz, complexity, nb_subfr }; j->frame = frames + (size_t)s * flen; j->in = in + s; j->out = out + s; emu_run_wave(pe_entry, j); delete j; }
 }

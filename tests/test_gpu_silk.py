@@ -145,3 +145,23 @@ def test_gpu_resampler_bad_args():
     with pytest.raises(opus_amd.OpusError): b.run(np.zeros((4, 50), np.int16))          # not a whole number of milliseconds
     with pytest.raises(opus_amd.OpusError): b.run(np.zeros((4, 24), np.int16))          # < 1 ms
     b.close()
+
+from test_kernel_emu_silk import pitch_case, pitch_oracle
+
+@pytest.mark.parametrize("fs,nb,cx", [(16, 4, 2), (16, 4, 0), (12, 4, 1), (8, 4, 2), (8, 4, 0), (16, 2, 2), (12, 2, 0), (8, 2, 1)])
+def test_gpu_pitch_analysis(fs, nb, cx):
+    """opusgpu_silk_pitch_analysis_batch against the oracle (pinned to silk_pitch_analysis_core by tests/test_oracle_silk.py): voicing, the four
+    lags, lagIndex, contourIndex, LTPCorr — byte-identical output records"""
+    import opus_amd
+    rng = np.random.default_rng(fs * 100 + nb * 10 + cx + 1); n = 400
+    x, pin = pitch_case(rng, fs, nb, n)
+    want = pitch_oracle(x, pin, fs, cx, nb)
+    got = opus_amd.silk_pitch_analysis(x, pin, fs, cx, nb)
+    bad = [s for s in range(n) if got[s].tobytes() != want[s].tobytes()]
+    assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+    assert (want["unvoiced"] == 0).sum() > 60
+
+def test_gpu_pitch_analysis_bad_args():
+    import opus_amd
+    pin = np.zeros(2, np.dtype([("a", "<i4", 4)]))
+    with pytest.raises(opus_amd.OpusError): opus_amd.lib() and opus_amd.silk_pitch_analysis(np.zeros((2, 40 * 16), np.int16), pin, 16, 3, 4)

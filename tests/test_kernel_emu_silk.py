@@ -7,7 +7,7 @@ from silk_inputs import NSQ_STATE, NSQ_FRAME, make_cfg, fresh_state, make_frame,
 def _build():
     so = os.path.join(ROOT, "tests/emu/libemu_silk.so")
     srcs = [os.path.join(ROOT, "tests/emu", f) for f in ("emu_silk.cpp", "wave_emu.cpp")]
-    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_lpc.h", "silk_resampler.h", "silk_tables.h", "silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
+    hdrs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in ("silk_lpc.h", "silk_pitch.h", "silk_resampler.h", "silk_tables.h", "silk_nsq.h", "silk_nsq_dd.h", "silk_frame.h", "silk_host.h", "fx.h")] + [os.path.join(ROOT, "tests/emu/wave_emu.h")]
     hdrs = [h for h in hdrs if os.path.exists(h)]
     import fcntl
     with open(so + ".lock", "w") as lk:
@@ -129,3 +129,35 @@ def test_emu_resampler(fs_in, fs_out, for_enc):
         if cfg[0] == 3: assert np.array_equal(rows[6:6 + cfg[3]].T, st["sFIR"][:, :cfg[3]])
         if cfg[0] == 2: assert np.array_equal(rows[6:14].T.astype(np.int16), st["sFIR"].view(np.int16).reshape(n, 72)[:, :8])
         assert np.array_equal(rows[42:42 + cfg[7]].T.astype(np.int16), st["delayBuf"][:, :cfg[7]])
+
+from silk_inputs import make_pitch_frame
+PE_IN = np.dtype([("prevLag", "<i4"), ("LTPCorr_Q15", "<i4"), ("search_thres1_Q16", "<i4"), ("search_thres2_Q13", "<i4")])
+PE_OUT = np.dtype([("pitch", "<i4", 4), ("LTPCorr_Q15", "<i4"), ("lagIndex", "<i2"), ("contourIndex", "i1"), ("unvoiced", "i1")], align=True)
+
+def pitch_case(rng, fs, nb, n):
+    flen = (20 + 5 * nb) * fs
+    x = np.zeros((n, flen), np.int16); pin = np.zeros(n, PE_IN)
+    for s in range(n):
+        x[s], _ = make_pitch_frame(rng, fs, nb)
+        pin[s] = (int(rng.choice([0, 0, rng.integers(2 * fs, 18 * fs)])), int(rng.integers(0, 30000)), int(rng.uniform(0.6, 0.85) * 65536), int(rng.uniform(0.1, 0.6) * 8192))
+    return x, pin
+
+def pitch_oracle(x, pin, fs, cx, nb):
+    O = oracle(); n = len(x); out = np.zeros(n, PE_OUT)
+    O.oc_silk_pitch_analysis_core.restype = ctypes.c_int
+    for s in range(n):
+        pitch = np.zeros(4, np.int32); li = np.zeros(1, np.int16); ci = np.zeros(1, np.int8); lc = np.array([pin[s]["LTPCorr_Q15"]], np.int32)
+        v = O.oc_silk_pitch_analysis_core(P(x[s]), P(pitch), P(li), P(ci), P(lc), int(pin[s]["prevLag"]), int(pin[s]["search_thres1_Q16"]), int(pin[s]["search_thres2_Q13"]), fs, cx, nb)
+        out[s] = (pitch, lc[0], li[0], ci[0], v)
+    return out
+
+@pytest.mark.parametrize("fs,nb,cx", [(16, 4, 2), (16, 4, 0), (12, 4, 1), (8, 4, 2), (8, 4, 0), (16, 2, 2), (12, 2, 0), (8, 2, 1)])
+def test_emu_pitch_analysis(fs, nb, cx):
+    E = _build(); rng = np.random.default_rng(fs * 100 + nb * 10 + cx); n = 60
+    x, pin = pitch_case(rng, fs, nb, n)
+    want = pitch_oracle(x, pin, fs, cx, nb)
+    got = np.zeros(n, PE_OUT)
+    E.emu_silk_pitch(n, P(x), P(pin), P(got), fs, cx, nb)
+    bad = [s for s in range(n) if got[s].tobytes() != want[s].tobytes()]
+    assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+    assert (want["unvoiced"] == 0).sum() > 8

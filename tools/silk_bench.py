@@ -11,7 +11,7 @@ def main():
     ap.add_argument("--streams", type=int, default=65536); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--states", type=int, default=4); ap.add_argument("--plain", action="store_true", help="plain NSQ (1 state, no warping)")
     ap.add_argument("--cpu-frames", type=int, default=4000)
-    ap.add_argument("--kernel", default="nsq", choices=["nsq", "resampler", "lpc"])
+    ap.add_argument("--kernel", default="nsq", choices=["nsq", "resampler", "lpc", "pitch"])
     a = ap.parse_args()
     import torch, opus_amd
     if a.kernel != "nsq": return hbm_kernels(a, torch, opus_amd)
@@ -61,7 +61,34 @@ def hbm_kernels(a, torch, opus_amd):
     n = a.streams; dev = torch.device("cuda:0"); rng = np.random.default_rng(2)
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if a.kernel == "resampler":
+    if a.kernel == "pitch":
+        from silk_inputs import make_pitch_frame
+        from test_kernel_emu_silk import PE_IN, PE_OUT
+        U = 256; xu = np.stack([make_pitch_frame(rng, 16, 4, "voiced" if i % 4 else "noise")[0] for i in range(U)])
+        x = torch.from_numpy(xu[np.arange(n) % U]).to(dev)
+        pin = np.zeros(n, PE_IN); pin["search_thres1_Q16"] = int(0.7 * 65536); pin["search_thres2_Q13"] = int(0.3 * 8192); pin["prevLag"] = 120; pin["LTPCorr_Q15"] = 16000
+        d_in = torch.from_numpy(pin.view(np.uint8).reshape(n, -1).copy()).to(dev); d_out = torch.zeros((n, 28), dtype=torch.uint8, device=dev)
+        Lb = opus_amd.lib()
+        for _ in range(a.warmup): Lb.opusgpu_silk_pitch_analysis_batch_dev(0, n, x.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 16, 2, 4, stream)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(a.steps): Lb.opusgpu_silk_pitch_analysis_batch_dev(0, n, x.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 16, 2, 4, stream)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps; bytes_per = 640 * 2 + 16 + 28
+        voiced = int((np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=PE_OUT)["unvoiced"] == 0).sum())
+        out = {"kernel": "silk_pitch_analysis_core 16 kHz, 20 ms, complexity 2", "frames": n, "voiced": voiced, "ms_per_step": ms, "frames_per_s": n / (ms * 1e-3), "bytes_per_frame": bytes_per,
+               "achieved_GBps": n * bytes_per / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000}
+        from reflib import ref_fx
+        R = ref_fx()
+        if R is not None and a.cpu_frames > 0:
+            pitch = np.zeros(4, np.int32); li = np.zeros(1, np.int16); ci = np.zeros(1, np.int8)
+            vp = lambda z: z.ctypes.data_as(ctypes.c_void_p)
+            t0 = time.perf_counter()
+            for k in range(a.cpu_frames):
+                lc = np.array([16000], np.int32)
+                R.silk_pitch_analysis_core(vp(xu[k % U]), vp(pitch), vp(li), vp(ci), vp(lc), 120, int(0.7 * 65536), int(0.3 * 8192), 16, 2, 4, 0)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": a.cpu_frames / dt, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "%d x silk_pitch_analysis_core via ctypes" % a.cpu_frames}
+    elif a.kernel == "resampler":
         x = torch.from_numpy(rng.integers(-20000, 20000, (n, 960)).astype(np.int16)).to(dev); y = torch.zeros((n, 320), dtype=torch.int16, device=dev)
         b = opus_amd.ResamplerBatch(n, 48000, 16000, 1)
         for _ in range(a.warmup): b.run_dev(y.data_ptr(), x.data_ptr(), 960, stream)
