@@ -339,7 +339,7 @@ class ResamplerBatch:
 
 def silk_pitch_analysis(frames, params, Fs_kHz, complexity, nb_subfr, device=0):
     """silk_pitch_analysis_core (silk/fixed/pitch_analysis_core_FIX.c:82) for n buffers: frames int16 [n, (20+5*nb_subfr)*Fs_kHz]; params: structured
-    array [n] laid out as OpusGpuPitchIn (4 x int32).  Returns a structured array [n] laid out as OpusGpuPitchOut (28 bytes)."""
+    array [n] laid out as OpusGpuPitchIn (4 x int32).  Returns a structured array [n] laid out as OpusGpuPitchOut (24 bytes)."""
     import numpy as np
     frames = np.ascontiguousarray(frames, dtype=np.int16); params = np.ascontiguousarray(params)
     n = frames.shape[0]

@@ -67,13 +67,13 @@ def hbm_kernels(a, torch, opus_amd):
         U = 256; xu = np.stack([make_pitch_frame(rng, 16, 4, "voiced" if i % 4 else "noise")[0] for i in range(U)])
         x = torch.from_numpy(xu[np.arange(n) % U]).to(dev)
         pin = np.zeros(n, PE_IN); pin["search_thres1_Q16"] = int(0.7 * 65536); pin["search_thres2_Q13"] = int(0.3 * 8192); pin["prevLag"] = 120; pin["LTPCorr_Q15"] = 16000
-        d_in = torch.from_numpy(pin.view(np.uint8).reshape(n, -1).copy()).to(dev); d_out = torch.zeros((n, 28), dtype=torch.uint8, device=dev)
+        d_in = torch.from_numpy(pin.view(np.uint8).reshape(n, -1).copy()).to(dev); d_out = torch.zeros((n, 24), dtype=torch.uint8, device=dev)
         Lb = opus_amd.lib()
         for _ in range(a.warmup): Lb.opusgpu_silk_pitch_analysis_batch_dev(0, n, x.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 16, 2, 4, stream)
         torch.cuda.synchronize(); e0.record()
         for _ in range(a.steps): Lb.opusgpu_silk_pitch_analysis_batch_dev(0, n, x.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 16, 2, 4, stream)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.steps; bytes_per = 640 * 2 + 16 + 28
+        ms = e0.elapsed_time(e1) / a.steps; bytes_per = 640 * 2 + 16 + 24
         voiced = int((np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=PE_OUT)["unvoiced"] == 0).sum())
         out = {"kernel": "silk_pitch_analysis_core 16 kHz, 20 ms, complexity 2", "frames": n, "voiced": voiced, "ms_per_step": ms, "frames_per_s": n / (ms * 1e-3), "bytes_per_frame": bytes_per,
                "achieved_GBps": n * bytes_per / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000}
