@@ -44,35 +44,7 @@ __global__ __launch_bounds__(64) void oa_silk_resampler_kernel(OaResamplerCfg cf
    __shared__ ResamplerLds lds;
    const int ch = (int)blockIdx.x * 64 + (int)threadIdx.x;
    if (ch >= n) return;                              /* no cross-lane operation anywhere in this kernel */
-   silk_resampler_lane(cfg, (WV_LDS ResamplerLds *)&lds, state + ch, n, in + (size_t)ch * inLen, inLen, out + (size_t)ch * outLen);
-}
-
-/* silk_resampler_init (silk/resampler.c:79-178): delay-compensation matrices :52-67, method selection, rounded-up Q16 ratio */
-static int oa_resampler_init_cfg(OaResamplerCfg *S, opus_int32 Fs_in, opus_int32 Fs_out, int forEnc)
-{
-   static const signed char dEnc[6][3] = { { 6, 0, 3 }, { 0, 7, 3 }, { 0, 1, 10 }, { 0, 2, 6 }, { 18, 10, 12 }, { 0, 0, 44 } };
-   static const signed char dDec[3][6] = { { 4, 0, 2, 0, 0, 0 }, { 0, 9, 4, 7, 4, 4 }, { 0, 3, 12, 7, 7, 7 } };
-   auto rid = [](opus_int32 R) { int v = ((((R >> 12) - (R > 16000)) >> (R > 24000)) - 1); return v < 5 ? v : 5; };
-   memset(S, 0, sizeof *S);
-   const bool in3 = Fs_in == 8000 || Fs_in == 12000 || Fs_in == 16000, out3 = Fs_out == 8000 || Fs_out == 12000 || Fs_out == 16000;
-   if (forEnc) { if (!(in3 || Fs_in == 24000 || Fs_in == 48000) || !out3) return -1; S->inputDelay = dEnc[rid(Fs_in)][rid(Fs_out)]; }
-   else { if (!in3 || !(out3 || Fs_out == 24000 || Fs_out == 48000)) return -1; S->inputDelay = dDec[rid(Fs_in)][rid(Fs_out)]; }
-   S->Fs_in_kHz = Fs_in / 1000; S->Fs_out_kHz = Fs_out / 1000; S->batchSize = S->Fs_in_kHz * 10;
-   int up2x = 0;
-   if (Fs_out > Fs_in) { if (Fs_out == 2 * Fs_in) S->resampler_function = OA_RS_FN_UP2; else { S->resampler_function = OA_RS_FN_IIR_FIR; up2x = 1; } }
-   else if (Fs_out < Fs_in) {
-      S->resampler_function = OA_RS_FN_DOWN_FIR;
-      if (Fs_out * 4 == Fs_in * 3)      { S->FIR_Fracs = 3; S->FIR_Order = 18; S->coefs_id = OA_RS_3_4; }
-      else if (Fs_out * 3 == Fs_in * 2) { S->FIR_Fracs = 2; S->FIR_Order = 18; S->coefs_id = OA_RS_2_3; }
-      else if (Fs_out * 2 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 24; S->coefs_id = OA_RS_1_2; }
-      else if (Fs_out * 3 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_3; }
-      else if (Fs_out * 4 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_4; }
-      else if (Fs_out * 6 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_6; }
-      else return -1;
-   } else S->resampler_function = OA_RS_FN_COPY;
-   S->invRatio_Q16 = ((Fs_in << (14 + up2x)) / Fs_out) << 2;
-   while ((opus_int32)(((int64_t)S->invRatio_Q16 * Fs_out) >> 16) < (Fs_in << up2x)) S->invRatio_Q16++;
-   return 0;
+   silk_resampler_lane(cfg, (WV_LDS ResamplerLds *)&lds, state + ch, n, in + (size_t)ch * inLen, inLen, out + (size_t)ch * outLen, (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void oa_silk_pitch_kernel(OaPitchCfg cfg, const i16 *frames, int flen, const OaPitchIn *in, OaPitchOut *out)
@@ -138,7 +110,7 @@ int opusgpu_resampler_batch_reset(OpusGpuResamplerBatch *b)
 OpusGpuResamplerBatch *opusgpu_resampler_batch_create(opus_int32 nchannels, opus_int32 Fs_Hz_in, opus_int32 Fs_Hz_out, int forEnc, int device, int *error)
 {
    int err = OPUS_OK; OpusGpuResamplerBatch *b = nullptr; OaResamplerCfg c;
-   if (nchannels <= 0 || oa_resampler_init_cfg(&c, Fs_Hz_in, Fs_Hz_out, forEnc) != 0) err = OPUS_BAD_ARG;
+   if (nchannels <= 0 || rs_init_cfg(&c, Fs_Hz_in, Fs_Hz_out, forEnc) != 0) err = OPUS_BAD_ARG;
    if (err == OPUS_OK) {
       int ndev = 0;
       if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {

@@ -1,0 +1,535 @@
+/* silk_dec.h — the SILK decoder (lane-0 serial code of the stream's wave), rows a22/a34 of SURVEY §8.
+ *
+ * What it computes, with the reference function each block follows:
+ *   sd_decode_indices     silk_decode_indices       silk/decode_indices.c:35      side information (gains, NLSF path, pitch, LTP, seed)
+ *   sd_decode_pulses      silk_decode_pulses        silk/decode_pulses.c:37       shell-coded excitation (silk/shell_coder.c:118, code_signs.c:74)
+ *   sd_decode_parameters  silk_decode_parameters    silk/decode_parameters.c:35   gains (gain_quant.c:100, log2lin.c:36), NLSF (NLSF_decode.c:62,
+ *                                                                                 NLSF_unpack.c:35, NLSF_stabilize.c:50) -> LPC (NLSF2A.c:66, LPC_fit.c:35,
+ *                                                                                 LPC_inv_pred_gain.c:45/:122, bwexpander_32.c:35), pitch lags (decode_pitch.c:38)
+ *   sd_decode_core        silk_decode_core          silk/decode_core.c:38         excitation -> LTP synthesis -> LPC synthesis
+ *   sd_decode_frame       silk_decode_frame         silk/decode_frame.c:43
+ *   sd_set_fs / sd_reset  silk_decoder_set_fs / silk_reset_decoder   silk/decoder_set_fs.c:35, silk/init_decoder.c:43
+ *   sd_stereo_*           silk_stereo_decode_pred / _mid_only / silk_stereo_MS_to_LR   silk/stereo_decode_pred.c:35,:66, silk/stereo_MS_to_LR.c:35
+ *   silk_decode_l0        silk_Decode               silk/dec_API.c:142            per-packet frame/channel sequencing, LBRR skipping, resampling to the API rate
+ * Everything is a serial chain per stream (one range decoder, recursive synthesis filters), so it runs on lane 0 of the wave that owns the
+ * stream, in the same kernel as the CELT decoder whose LDS regions it borrows between CELT frames.  Packet loss concealment / comfort noise
+ * (silk/PLC.c, silk/CNG.c) are not built yet: a lost SILK frame reports OPUS_UNIMPLEMENTED. */
+#ifndef OPUS_AMD_SILK_DEC_H
+#define OPUS_AMD_SILK_DEC_H
+#include "silk_tables.h"
+
+#define SD_CODE_INDEPENDENTLY 0
+#define SD_CODE_INDEPENDENTLY_NO_LTP_SCALING 1
+#define SD_CODE_CONDITIONALLY 2
+#define SD_TYPE_NO_VOICE 0
+#define SD_TYPE_VOICED 2
+#define SD_FLAG_DECODE_NORMAL 0
+#define SD_FLAG_PACKET_LOST 1
+#define SD_FLAG_DECODE_LBRR 2
+
+struct SdCtrl { i32 pitchL[4]; i32 Gains_Q16[4]; i16 PredCoef_Q12[2][16]; i16 LTPCoef_Q14[20]; i32 LTP_scale_Q14; };
+struct SdNlsfCb { int nVectors, order, qstep; const u8 *cb1_nlsf, *cb1_icdf, *pred, *ec_sel, *ec_icdf; const i16 *wght, *deltamin; };
+WV_DEV SdNlsfCb sd_nlsf_cb(int LPC_order)
+{
+   SdNlsfCb c;
+   if (LPC_order == 16) { c.nVectors = 32; c.order = 16; c.qstep = SK_NLSF_WB_QSTEP_Q16; c.cb1_nlsf = sk_nlsf_wb_cb1_nlsf_q8; c.cb1_icdf = sk_nlsf_wb_cb1_icdf; c.pred = sk_nlsf_wb_pred_q8;
+                         c.ec_sel = sk_nlsf_wb_ec_sel; c.ec_icdf = sk_nlsf_wb_ec_icdf; c.wght = sk_nlsf_wb_cb1_wght_q9; c.deltamin = sk_nlsf_wb_deltamin_q15; }
+   else { c.nVectors = 32; c.order = 10; c.qstep = SK_NLSF_NB_MB_QSTEP_Q16; c.cb1_nlsf = sk_nlsf_nb_mb_cb1_nlsf_q8; c.cb1_icdf = sk_nlsf_nb_mb_cb1_icdf; c.pred = sk_nlsf_nb_mb_pred_q8;
+          c.ec_sel = sk_nlsf_nb_mb_ec_sel; c.ec_icdf = sk_nlsf_nb_mb_ec_icdf; c.wght = sk_nlsf_nb_mb_cb1_wght_q9; c.deltamin = sk_nlsf_nb_mb_deltamin_q15; }
+   return c;
+}
+WV_DEV void sd_nlsf_unpack(i32 *ec_ix, i32 *pred_Q8, const SdNlsfCb &cb, int CB1_index)            /* NLSF_unpack.c:35 */
+{
+   const u8 *sel = &cb.ec_sel[CB1_index * cb.order / 2];
+   for (int i = 0; i < cb.order; i += 2) {
+      const int entry = *sel++;
+      ec_ix[i] = ((entry >> 1) & 7) * 9;
+      pred_Q8[i] = cb.pred[i + (entry & 1) * (cb.order - 1)];
+      ec_ix[i + 1] = ((entry >> 5) & 7) * 9;
+      pred_Q8[i + 1] = cb.pred[i + ((entry >> 4) & 1) * (cb.order - 1) + 1];
+   }
+}
+
+WV_DEV const u8 *sd_pitch_contour_icdf(int fs_kHz, int nb_subfr)
+{ return fs_kHz == 8 ? (nb_subfr == 4 ? sk_pitch_contour_nb_icdf : sk_pitch_contour_10ms_nb_icdf) : (nb_subfr == 4 ? sk_pitch_contour_icdf : sk_pitch_contour_10ms_icdf); }
+WV_DEV const u8 *sd_pitch_low_bits_icdf(int fs_kHz) { return fs_kHz == 16 ? sk_uniform8_icdf : fs_kHz == 12 ? sk_uniform6_icdf : sk_uniform4_icdf; }
+
+WV_DEV void sd_decode_indices(EC_ARGS, OaSilkChannel *ch, int FrameIndex, int decode_LBRR, int condCoding)
+{
+   OaSilkIndices *ix = &ch->indices;
+   int Ix;
+   if (decode_LBRR || ch->VAD_flags[FrameIndex]) Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_vad_icdf, 8) + 2;
+   else Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_no_vad_icdf, 8);
+   ix->signalType = (i8)(Ix >> 1); ix->quantOffsetType = (i8)(Ix & 1);
+   if (condCoding == SD_CODE_CONDITIONALLY) ix->GainsIndices[0] = (i8)k_ec_dec_icdf(EC_PASS, sk_delta_gain_icdf, 8);
+   else { ix->GainsIndices[0] = (i8)(k_ec_dec_icdf(EC_PASS, &sk_gain_icdf[ix->signalType * 8], 8) << 3); ix->GainsIndices[0] += (i8)k_ec_dec_icdf(EC_PASS, sk_uniform8_icdf, 8); }
+   for (int i = 1; i < ch->nb_subfr; i++) ix->GainsIndices[i] = (i8)k_ec_dec_icdf(EC_PASS, sk_delta_gain_icdf, 8);
+   const SdNlsfCb cb = sd_nlsf_cb(ch->LPC_order);
+   ix->NLSFIndices[0] = (i8)k_ec_dec_icdf(EC_PASS, &cb.cb1_icdf[(ix->signalType >> 1) * cb.nVectors], 8);
+   i32 ec_ix[16], pred_Q8[16];
+   sd_nlsf_unpack(ec_ix, pred_Q8, cb, ix->NLSFIndices[0]);
+   for (int i = 0; i < cb.order; i++) {
+      Ix = k_ec_dec_icdf(EC_PASS, &cb.ec_icdf[ec_ix[i]], 8);
+      if (Ix == 0) Ix -= k_ec_dec_icdf(EC_PASS, sk_nlsf_ext_icdf, 8);
+      else if (Ix == 8) Ix += k_ec_dec_icdf(EC_PASS, sk_nlsf_ext_icdf, 8);
+      ix->NLSFIndices[i + 1] = (i8)(Ix - 4);
+   }
+   ix->NLSFInterpCoef_Q2 = ch->nb_subfr == 4 ? (i8)k_ec_dec_icdf(EC_PASS, sk_nlsf_interpolation_factor_icdf, 8) : (i8)4;
+   if (ix->signalType == SD_TYPE_VOICED) {
+      int absolute = 1;
+      if (condCoding == SD_CODE_CONDITIONALLY && ch->ec_prevSignalType == SD_TYPE_VOICED) {
+         int delta = (i16)k_ec_dec_icdf(EC_PASS, sk_pitch_delta_icdf, 8);
+         if (delta > 0) { ix->lagIndex = (i16)(ch->ec_prevLagIndex + delta - 9); absolute = 0; }
+      }
+      if (absolute) {
+         ix->lagIndex = (i16)((i16)k_ec_dec_icdf(EC_PASS, sk_pitch_lag_icdf, 8) * (ch->fs_kHz >> 1));
+         ix->lagIndex += (i16)k_ec_dec_icdf(EC_PASS, sd_pitch_low_bits_icdf(ch->fs_kHz), 8);
+      }
+      ch->ec_prevLagIndex = ix->lagIndex;
+      ix->contourIndex = (i8)k_ec_dec_icdf(EC_PASS, sd_pitch_contour_icdf(ch->fs_kHz, ch->nb_subfr), 8);
+      ix->PERIndex = (i8)k_ec_dec_icdf(EC_PASS, sk_ltp_per_index_icdf, 8);
+      const u8 *gicdf = &sk_ltp_gain_icdf[ix->PERIndex == 0 ? 0 : ix->PERIndex == 1 ? 8 : 24];
+      for (int k = 0; k < ch->nb_subfr; k++) ix->LTPIndex[k] = (i8)k_ec_dec_icdf(EC_PASS, gicdf, 8);
+      ix->LTP_scaleIndex = condCoding == SD_CODE_INDEPENDENTLY ? (i8)k_ec_dec_icdf(EC_PASS, sk_ltpscale_icdf, 8) : (i8)0;
+   }
+   ch->ec_prevSignalType = ix->signalType;
+   ix->Seed = (i8)k_ec_dec_icdf(EC_PASS, sk_uniform4_icdf, 8);
+}
+
+WV_DEV void sd_split(WV_LDS i16 *c1, WV_LDS i16 *c2, EC_ARGS, int p, const u8 *table)                 /* shell_coder.c:63 */
+{
+   if (p > 0) { c1[0] = (i16)k_ec_dec_icdf(EC_PASS, &table[sk_shell_code_table_offsets[p]], 8); c2[0] = (i16)(p - c1[0]); }
+   else { c1[0] = 0; c2[0] = 0; }
+}
+WV_DEV void sd_shell_decoder(WV_LDS i16 *p0, EC_ARGS, int pulses4, WV_LDS i16 *tmp)                   /* shell_coder.c:118; tmp: 14 words */
+{
+   WV_LDS i16 *p3 = tmp, *p2 = tmp + 2, *p1 = tmp + 6;
+   sd_split(&p3[0], &p3[1], EC_PASS, pulses4, sk_shell_code_table3);
+   sd_split(&p2[0], &p2[1], EC_PASS, p3[0], sk_shell_code_table2);
+   sd_split(&p1[0], &p1[1], EC_PASS, p2[0], sk_shell_code_table1);
+   sd_split(&p0[0], &p0[1], EC_PASS, p1[0], sk_shell_code_table0);
+   sd_split(&p0[2], &p0[3], EC_PASS, p1[1], sk_shell_code_table0);
+   sd_split(&p1[2], &p1[3], EC_PASS, p2[1], sk_shell_code_table1);
+   sd_split(&p0[4], &p0[5], EC_PASS, p1[2], sk_shell_code_table0);
+   sd_split(&p0[6], &p0[7], EC_PASS, p1[3], sk_shell_code_table0);
+   sd_split(&p2[2], &p2[3], EC_PASS, p3[1], sk_shell_code_table2);
+   sd_split(&p1[4], &p1[5], EC_PASS, p2[2], sk_shell_code_table1);
+   sd_split(&p0[8], &p0[9], EC_PASS, p1[4], sk_shell_code_table0);
+   sd_split(&p0[10], &p0[11], EC_PASS, p1[5], sk_shell_code_table0);
+   sd_split(&p1[6], &p1[7], EC_PASS, p2[3], sk_shell_code_table1);
+   sd_split(&p0[12], &p0[13], EC_PASS, p1[6], sk_shell_code_table0);
+   sd_split(&p0[14], &p0[15], EC_PASS, p1[7], sk_shell_code_table0);
+}
+WV_DEV void sd_decode_pulses(EC_ARGS, WV_LDS i16 *pulses, int signalType, int quantOffsetType, int frame_length, WV_LDS i16 *tmp)
+{
+   i32 sum_pulses[20], nLshifts[20];
+   const int RateLevelIndex = k_ec_dec_icdf(EC_PASS, &sk_rate_levels_icdf[(signalType >> 1) * 9], 8);
+   int iter = frame_length >> 4;
+   if (iter * 16 < frame_length) iter++;                                                              /* 10 ms at 12 kHz */
+   const u8 *cdf = &sk_pulses_per_block_icdf[RateLevelIndex * 18];
+   for (int i = 0; i < iter; i++) {
+      nLshifts[i] = 0;
+      sum_pulses[i] = k_ec_dec_icdf(EC_PASS, cdf, 8);
+      while (sum_pulses[i] == 17) { nLshifts[i]++; sum_pulses[i] = k_ec_dec_icdf(EC_PASS, &sk_pulses_per_block_icdf[9 * 18] + (nLshifts[i] == 10), 8); }
+   }
+   for (int i = 0; i < iter; i++) {
+      if (sum_pulses[i] > 0) sd_shell_decoder(&pulses[i * 16], EC_PASS, sum_pulses[i], tmp);
+      else for (int k = 0; k < 16; k++) pulses[i * 16 + k] = 0;
+   }
+   for (int i = 0; i < iter; i++) {
+      if (nLshifts[i] > 0) {
+         const int nLS = nLshifts[i];
+         for (int k = 0; k < 16; k++) {
+            int abs_q = pulses[i * 16 + k];
+            for (int j = 0; j < nLS; j++) abs_q = (abs_q << 1) + k_ec_dec_icdf(EC_PASS, sk_lsb_icdf, 8);
+            pulses[i * 16 + k] = (i16)abs_q;
+         }
+         sum_pulses[i] |= nLS << 5;
+      }
+   }
+   /* signs (code_signs.c:74) */
+   const u8 *icdf_ptr = &sk_sign_icdf[7 * (quantOffsetType + (signalType << 1))];
+   const int nblk = (frame_length + 8) >> 4;
+   for (int i = 0; i < nblk; i++) {
+      const int p = sum_pulses[i];
+      if (p > 0) {
+         u8 icdf[2]; icdf[0] = icdf_ptr[imin(p & 0x1F, 6)]; icdf[1] = 0;
+         for (int j = 0; j < 16; j++) if (pulses[i * 16 + j] > 0) pulses[i * 16 + j] = (i16)(pulses[i * 16 + j] * ((k_ec_dec_icdf(EC_PASS, icdf, 8) << 1) - 1));
+      }
+   }
+}
+
+WV_DEV i32 sd_log2lin(i32 inLog_Q7)                                                                    /* log2lin.c:36 */
+{
+   if (inLog_Q7 < 0) return 0;
+   if (inLog_Q7 >= 3967) return 2147483647;
+   i32 out = (i32)1 << (inLog_Q7 >> 7);
+   const i32 frac = inLog_Q7 & 0x7F, t = sk_mlawb(frac, sk_mulbb(frac, 128 - frac), -174);
+   if (inLog_Q7 < 2048) out = out + ((out * t) >> 7); else out = out + (out >> 7) * t;
+   return out;
+}
+WV_DEV void sd_bwexpander_32(i32 *ar, int d, i32 chirp_Q16)                                           /* bwexpander_32.c:35 */
+{
+   const i32 cm1 = chirp_Q16 - 65536;
+   for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
+   ar[d - 1] = sk_mulww(chirp_Q16, ar[d - 1]);
+}
+WV_DEV void sd_bwexpander(i16 *ar, int d, i32 chirp_Q16)                                              /* bwexpander.c:35 */
+{
+   const i32 cm1 = chirp_Q16 - 65536;
+   for (int i = 0; i < d - 1; i++) { ar[i] = (i16)sk_rround(chirp_Q16 * ar[i], 16); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
+   ar[d - 1] = (i16)sk_rround(chirp_Q16 * ar[d - 1], 16);
+}
+WV_DEV i32 sd_rround64(i64 a, int s) { return (i32)(s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1); }
+WV_DEV i64 sd_rround64w(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; }
+/* LPC_inv_pred_gain.c:45 (QA = 24): 0 = unstable, else inverse prediction gain Q30 */
+WV_DEV i32 sd_lpc_inverse_pred_gain(const i16 *A_Q12, int order)
+{
+   i32 A[16]; i32 DC = 0;
+   for (int k = 0; k < order; k++) { DC += A_Q12[k]; A[k] = shl32(A_Q12[k], 12); }
+   if (DC >= 4096) return 0;
+   const i32 A_LIMIT = 16773022;                                                                      /* SILK_FIX_CONST(0.99975, 24) */
+   const i32 MIN_INVGAIN = 107374;                                                                    /* SILK_FIX_CONST(1/1e4, 30) */
+   i32 invGain_Q30 = (i32)1 << 30;
+   int k;
+   for (k = order - 1; k > 0; k--) {
+      if (A[k] > A_LIMIT || A[k] < -A_LIMIT) return 0;
+      const i32 rc_Q31 = -shl32(A[k], 31 - 24);
+      const i32 rc_mult1_Q30 = ((i32)1 << 30) - sk_mulhi(rc_Q31, rc_Q31);
+      invGain_Q30 = shl32(sk_mulhi(invGain_Q30, rc_mult1_Q30), 2);
+      if (invGain_Q30 < MIN_INVGAIN) return 0;
+      const int mult2Q = 32 - sk_clz(rc_mult1_Q30 > 0 ? rc_mult1_Q30 : -rc_mult1_Q30);
+      const i32 rc_mult2 = sk_inverse32_varQ(rc_mult1_Q30, mult2Q + 30);
+      for (int n = 0; n < (k + 1) >> 1; n++) {
+         const i32 tmp1 = A[n], tmp2 = A[k - n - 1];
+         i64 t64 = sd_rround64w((i64)sk_sub_sat(tmp1, sd_rround64((i64)tmp2 * rc_Q31, 31)) * rc_mult2, mult2Q);
+         if (t64 > 2147483647LL || t64 < -2147483648LL) return 0;
+         A[n] = (i32)t64;
+         t64 = sd_rround64w((i64)sk_sub_sat(tmp2, sd_rround64((i64)tmp1 * rc_Q31, 31)) * rc_mult2, mult2Q);
+         if (t64 > 2147483647LL || t64 < -2147483648LL) return 0;
+         A[k - n - 1] = (i32)t64;
+      }
+   }
+   if (A[k] > A_LIMIT || A[k] < -A_LIMIT) return 0;
+   const i32 rc_Q31 = -shl32(A[0], 31 - 24);
+   const i32 rc_mult1_Q30 = ((i32)1 << 30) - sk_mulhi(rc_Q31, rc_Q31);
+   invGain_Q30 = shl32(sk_mulhi(invGain_Q30, rc_mult1_Q30), 2);
+   if (invGain_Q30 < MIN_INVGAIN) return 0;
+   return invGain_Q30;
+}
+/* NLSF2A.c:66: NLSF (Q15) -> monic LPC coefficients Q12 via the two symmetric polynomials, then range fit and stability loop */
+WV_DEV void sd_nlsf2a_poly(i32 *out, const i32 *cLSF, int dd)
+{
+   out[0] = (i32)1 << 16; out[1] = -cLSF[0];
+   for (int k = 1; k < dd; k++) {
+      const i32 ftmp = cLSF[2 * k];
+      out[k + 1] = shl32(out[k - 1], 1) - sd_rround64((i64)ftmp * out[k], 16);
+      for (int n = k; n > 1; n--) out[n] += out[n - 2] - sd_rround64((i64)ftmp * out[n - 1], 16);
+      out[1] -= ftmp;
+   }
+}
+WV_TABLE u8 k_sd_ordering16[16] = { 0, 15, 8, 7, 4, 11, 12, 3, 2, 13, 10, 5, 6, 9, 14, 1 };
+WV_TABLE u8 k_sd_ordering10[10] = { 0, 9, 6, 3, 4, 5, 8, 1, 2, 7 };
+WV_DEV void sd_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d)
+{
+   const u8 *ordering = d == 16 ? k_sd_ordering16 : k_sd_ordering10;
+   i32 cosq[16], P[9], Q[9], a32[16];
+   for (int k = 0; k < d; k++) {
+      const i32 f_int = NLSF[k] >> 8, f_frac = NLSF[k] - (f_int << 8);
+      const i32 cos_val = sk_lsf_cos_tab_q12[f_int], delta = sk_lsf_cos_tab_q12[f_int + 1] - cos_val;
+      cosq[ordering[k]] = sk_rround(shl32(cos_val, 8) + delta * f_frac, 4);
+   }
+   const int dd = d >> 1;
+   sd_nlsf2a_poly(P, &cosq[0], dd);
+   sd_nlsf2a_poly(Q, &cosq[1], dd);
+   for (int k = 0; k < dd; k++) { const i32 Pt = P[k + 1] + P[k], Qt = Q[k + 1] - Q[k]; a32[k] = -Qt - Pt; a32[d - k - 1] = Qt - Pt; }
+   /* silk_LPC_fit(a_Q12, a32, 12, 17, d)  (LPC_fit.c:35) */
+   {
+      int i, idx = 0;
+      for (i = 0; i < 10; i++) {
+         i32 maxabs = 0;
+         for (int k = 0; k < d; k++) { const i32 av = a32[k] > 0 ? a32[k] : -a32[k]; if (av > maxabs) { maxabs = av; idx = k; } }
+         maxabs = sk_rround(maxabs, 5);
+         if (maxabs > 32767) {
+            maxabs = imin(maxabs, 163838);
+            const i32 chirp_Q16 = 65470 - shl32(maxabs - 32767, 14) / ((maxabs * (idx + 1)) >> 2);           /* SILK_FIX_CONST(0.999, 16) */
+            sd_bwexpander_32(a32, d, chirp_Q16);
+         } else break;
+      }
+      if (i == 10) for (int k = 0; k < d; k++) { a_Q12[k] = (i16)sk_sat16(sk_rround(a32[k], 5)); a32[k] = shl32(a_Q12[k], 5); }
+      else for (int k = 0; k < d; k++) a_Q12[k] = (i16)sk_rround(a32[k], 5);
+   }
+   for (int i = 0; sd_lpc_inverse_pred_gain(a_Q12, d) == 0 && i < 16; i++) {                                /* MAX_LPC_STABILIZE_ITERATIONS */
+      sd_bwexpander_32(a32, d, 65536 - shl32(2, i));
+      for (int k = 0; k < d; k++) a_Q12[k] = (i16)sk_rround(a32[k], 5);
+   }
+}
+WV_DEV void sd_nlsf_stabilize(i16 *NLSF, const i16 *NDeltaMin, int L)                                       /* NLSF_stabilize.c:50 */
+{
+   for (int loops = 0; loops < 20; loops++) {
+      i32 min_diff = NLSF[0] - NDeltaMin[0]; int I = 0;
+      for (int i = 1; i <= L - 1; i++) { const i32 diff = NLSF[i] - (NLSF[i - 1] + NDeltaMin[i]); if (diff < min_diff) { min_diff = diff; I = i; } }
+      { const i32 diff = (1 << 15) - (NLSF[L - 1] + NDeltaMin[L]); if (diff < min_diff) { min_diff = diff; I = L; } }
+      if (min_diff >= 0) return;
+      if (I == 0) NLSF[0] = NDeltaMin[0];
+      else if (I == L) NLSF[L - 1] = (i16)((1 << 15) - NDeltaMin[L]);
+      else {
+         i32 min_center = 0, max_center = 1 << 15;
+         for (int k = 0; k < I; k++) min_center += NDeltaMin[k];
+         min_center += NDeltaMin[I] >> 1;
+         for (int k = L; k > I; k--) max_center -= NDeltaMin[k];
+         max_center -= NDeltaMin[I] >> 1;
+         i32 c = sk_rround((i32)NLSF[I - 1] + (i32)NLSF[I], 1);
+         /* silk_LIMIT_32 tolerates min > max */
+         if (min_center > max_center) c = c > min_center ? min_center : c < max_center ? max_center : c;
+         else c = c > max_center ? max_center : c < min_center ? min_center : c;
+         NLSF[I - 1] = (i16)((i16)c - (NDeltaMin[I] >> 1));
+         NLSF[I] = (i16)(NLSF[I - 1] + NDeltaMin[I]);
+      }
+   }
+   /* fall-back: sort and clamp (NLSF_stabilize.c:120-141) */
+   for (int i = 1; i < L; i++) { const i16 v = NLSF[i]; int j = i - 1; for (; j >= 0 && v < NLSF[j]; j--) NLSF[j + 1] = NLSF[j]; NLSF[j + 1] = v; }
+   NLSF[0] = (i16)imax(NLSF[0], NDeltaMin[0]);
+   for (int i = 1; i < L; i++) NLSF[i] = (i16)imax(NLSF[i], sk_sat16((i32)NLSF[i - 1] + NDeltaMin[i]));
+   NLSF[L - 1] = (i16)imin(NLSF[L - 1], (1 << 15) - NDeltaMin[L]);
+   for (int i = L - 2; i >= 0; i--) NLSF[i] = (i16)imin(NLSF[i], NLSF[i + 1] - NDeltaMin[i + 1]);
+}
+WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const i8 *NLSFIndices, const SdNlsfCb &cb)                      /* NLSF_decode.c:62 */
+{
+   i32 ec_ix[16], pred_Q8[16]; i32 res_Q10[16];
+   sd_nlsf_unpack(ec_ix, pred_Q8, cb, NLSFIndices[0]);
+   i32 out_Q10 = 0;
+   for (int i = cb.order - 1; i >= 0; i--) {
+      const i32 pred_Q10 = sk_mulbb(out_Q10, pred_Q8[i]) >> 8;
+      out_Q10 = shl32(NLSFIndices[1 + i], 10);
+      if (out_Q10 > 0) out_Q10 -= 102; else if (out_Q10 < 0) out_Q10 += 102;                               /* SILK_FIX_CONST(0.1, 10) */
+      out_Q10 = sk_mlawb(pred_Q10, out_Q10, cb.qstep);
+      res_Q10[i] = (i16)out_Q10;
+      out_Q10 = (i16)out_Q10;
+   }
+   const u8 *el = &cb.cb1_nlsf[NLSFIndices[0] * cb.order]; const i16 *w = &cb.wght[NLSFIndices[0] * cb.order];
+   for (int i = 0; i < cb.order; i++) {
+      const i32 t = shl32(res_Q10[i], 14) / w[i] + shl32((i16)el[i], 7);
+      pNLSF_Q15[i] = (i16)(t < 0 ? 0 : t > 32767 ? 32767 : t);
+   }
+   sd_nlsf_stabilize(pNLSF_Q15, cb.deltamin, cb.order);
+}
+WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, i32 *pitch_lags, int Fs_kHz, int nb_subfr)     /* decode_pitch.c:38 */
+{
+   const i8 *cb; int cbk_size;
+   if (Fs_kHz == 8) { if (nb_subfr == 4) { cb = sk_cb_lags_stage2; cbk_size = 11; } else { cb = sk_cb_lags_stage2_10ms; cbk_size = 3; } }
+   else { if (nb_subfr == 4) { cb = sk_cb_lags_stage3; cbk_size = 34; } else { cb = sk_cb_lags_stage3_10ms; cbk_size = 12; } }
+   const int min_lag = 2 * Fs_kHz, max_lag = 18 * Fs_kHz, lag = min_lag + lagIndex;
+   for (int k = 0; k < nb_subfr; k++) { int p = lag + cb[k * cbk_size + contourIndex]; pitch_lags[k] = p < min_lag ? min_lag : p > max_lag ? max_lag : p; }
+}
+
+WV_DEV void sd_decode_parameters(OaSilkChannel *ch, SdCtrl *c, int condCoding)                              /* decode_parameters.c:35 */
+{
+   OaSilkIndices *ix = &ch->indices;
+   /* gains (gain_quant.c:100): OFFSET = 2090, INV_SCALE_Q16 = 1907825 */
+   for (int k = 0; k < ch->nb_subfr; k++) {
+      int prev = ch->LastGainIndex;
+      if (k == 0 && condCoding != SD_CODE_CONDITIONALLY) prev = imax(ix->GainsIndices[k], prev - 16);
+      else {
+         const int ind_tmp = ix->GainsIndices[k] - 4, thr = 2 * 36 - 64 + prev;
+         if (ind_tmp > thr) prev += (ind_tmp << 1) - thr; else prev += ind_tmp;
+      }
+      prev = prev < 0 ? 0 : prev > 63 ? 63 : prev;
+      ch->LastGainIndex = prev;
+      c->Gains_Q16[k] = sd_log2lin(imin(sk_mulwb(1907825, prev) + 2090, 3967));
+   }
+   const SdNlsfCb cb = sd_nlsf_cb(ch->LPC_order);
+   i16 pNLSF[16], pNLSF0[16];
+   sd_nlsf_decode(pNLSF, ix->NLSFIndices, cb);
+   sd_nlsf2a(c->PredCoef_Q12[1], pNLSF, ch->LPC_order);
+   if (ch->first_frame_after_reset == 1) ix->NLSFInterpCoef_Q2 = 4;
+   if (ix->NLSFInterpCoef_Q2 < 4) {
+      for (int i = 0; i < ch->LPC_order; i++) pNLSF0[i] = (i16)(ch->prevNLSF_Q15[i] + ((ix->NLSFInterpCoef_Q2 * (pNLSF[i] - ch->prevNLSF_Q15[i])) >> 2));
+      sd_nlsf2a(c->PredCoef_Q12[0], pNLSF0, ch->LPC_order);
+   } else for (int i = 0; i < ch->LPC_order; i++) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+   for (int i = 0; i < ch->LPC_order; i++) ch->prevNLSF_Q15[i] = pNLSF[i];
+   if (ch->lossCnt) { sd_bwexpander(c->PredCoef_Q12[0], ch->LPC_order, 63570); sd_bwexpander(c->PredCoef_Q12[1], ch->LPC_order, 63570); }   /* BWE_AFTER_LOSS_Q16 */
+   if (ix->signalType == SD_TYPE_VOICED) {
+      sd_decode_pitch(ix->lagIndex, ix->contourIndex, c->pitchL, ch->fs_kHz, ch->nb_subfr);
+      const i8 *cbk = &sk_ltp_vq_q7[ix->PERIndex == 0 ? 0 : ix->PERIndex == 1 ? 40 : 120];
+      for (int k = 0; k < ch->nb_subfr; k++) for (int i = 0; i < 5; i++) c->LTPCoef_Q14[k * 5 + i] = (i16)shl32(cbk[ix->LTPIndex[k] * 5 + i], 7);
+      c->LTP_scale_Q14 = sk_ltpscales_table_q14[ix->LTP_scaleIndex];
+   } else {
+      for (int k = 0; k < ch->nb_subfr; k++) c->pitchL[k] = 0;
+      for (int i = 0; i < 5 * ch->nb_subfr; i++) c->LTPCoef_Q14[i] = 0;
+      ix->PERIndex = 0; c->LTP_scale_Q14 = 0;
+   }
+}
+
+struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; };
+
+WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)               /* decode_core.c:38 */
+{
+   const OaSilkIndices *ix = &ch->indices;
+   const int L = ch->subfr_length, mem = ch->ltp_mem_length, P = ch->LPC_order;
+   const i32 offset_Q10 = k_silk_quant_offsets_Q10[(ix->signalType >> 1) * 2 + ix->quantOffsetType];
+   const int interp_flag = ix->NLSFInterpCoef_Q2 < 4;
+   i32 rand_seed = ix->Seed;
+   for (int i = 0; i < ch->frame_length; i++) {
+      rand_seed = sk_rand(rand_seed);
+      i32 e = shl32(S.pulses[i], 14);
+      if (e > 0) e -= 80 << 4; else if (e < 0) e += 80 << 4;
+      e += offset_Q10 << 4;
+      if (rand_seed < 0) e = -e;
+      ch->exc_Q14[i] = e;
+      rand_seed = add32(rand_seed, S.pulses[i]);
+   }
+   for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = ch->sLPC_Q14_buf[i];
+   const i32 *pexc = ch->exc_Q14;
+   WV_LDS i16 *pxq = xq;
+   int sLTP_buf_idx = mem, lag = 0;
+   for (int k = 0; k < ch->nb_subfr; k++) {
+      const i16 *A_Q12 = c->PredCoef_Q12[k >> 1];
+      i16 *B_Q14 = &c->LTPCoef_Q14[k * 5];
+      int signalType = ix->signalType;
+      const i32 Gain_Q10 = c->Gains_Q16[k] >> 6;
+      i32 inv_gain_Q31 = sk_inverse32_varQ(c->Gains_Q16[k], 47);
+      i32 gain_adj_Q16 = (i32)1 << 16;
+      if (c->Gains_Q16[k] != ch->prev_gain_Q16) {
+         gain_adj_Q16 = sk_div32_varQ(ch->prev_gain_Q16, c->Gains_Q16[k], 16);
+         for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = sk_mulww(gain_adj_Q16, S.sLPC_Q14[i]);
+      }
+      ch->prev_gain_Q16 = c->Gains_Q16[k];
+      if (ch->lossCnt && ch->prevSignalType == SD_TYPE_VOICED && ix->signalType != SD_TYPE_VOICED && k < 2) {
+         for (int i = 0; i < 5; i++) B_Q14[i] = 0;
+         B_Q14[2] = 4096;
+         signalType = SD_TYPE_VOICED;
+         c->pitchL[k] = ch->lagPrev;
+      }
+      if (signalType == SD_TYPE_VOICED) {
+         lag = c->pitchL[k];
+         if (k == 0 || (k == 2 && interp_flag)) {
+            const int start_idx = mem - lag - P - 2;
+            if (k == 2) for (int i = 0; i < 2 * L; i++) ch->outBuf[mem + i] = xq[i];
+            /* silk_LPC_analysis_filter(&sLTP[start_idx], &outBuf[start_idx + k*L], A_Q12, mem - start_idx, P) */
+            for (int n = 0; n < mem - start_idx; n++) {
+               i32 o = 0;
+               if (n >= P) {
+                  const i16 *in = &ch->outBuf[start_idx + k * L + n];
+                  i32 pred = 0;
+                  for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
+                  o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
+               }
+               S.sLTP[start_idx + n] = (i16)o;
+            }
+            if (k == 0) inv_gain_Q31 = shl32(sk_mulwb(inv_gain_Q31, c->LTP_scale_Q14), 2);
+            for (int i = 0; i < lag + 2; i++) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulwb(inv_gain_Q31, S.sLTP[mem - i - 1]);
+         } else if (gain_adj_Q16 != (i32)1 << 16) {
+            for (int i = 0; i < lag + 2; i++) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulww(gain_adj_Q16, S.sLTP_Q15[sLTP_buf_idx - i - 1]);
+         }
+      }
+      const i32 *pres;
+      if (signalType == SD_TYPE_VOICED) {
+         for (int i = 0; i < L; i++) {
+            const WV_LDS i32 *pl = &S.sLTP_Q15[sLTP_buf_idx - lag + 2];
+            i32 LTP_pred_Q13 = 2;
+            for (int j = 0; j < 5; j++) LTP_pred_Q13 = sk_mlawb(LTP_pred_Q13, pl[-j], B_Q14[j]);
+            const i32 r = pexc[i] + shl32(LTP_pred_Q13, 1);
+            S.res_Q14[i] = r;
+            S.sLTP_Q15[sLTP_buf_idx] = shl32(r, 1);
+            sLTP_buf_idx++;
+         }
+         pres = 0;
+      } else pres = pexc;
+      for (int i = 0; i < L; i++) {
+         i32 LPC_pred_Q10 = P >> 1;
+         for (int j = 0; j < P; j++) LPC_pred_Q10 = sk_mlawb(LPC_pred_Q10, S.sLPC_Q14[16 + i - 1 - j], A_Q12[j]);
+         const i32 r = pres ? pres[i] : S.res_Q14[i];
+         const i32 v = sk_add_sat(r, sk_shl_sat(LPC_pred_Q10, 4));
+         S.sLPC_Q14[16 + i] = v;
+         pxq[i] = (i16)sk_sat16(sk_rround(sk_mulww(v, Gain_Q10), 8));
+      }
+      for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = S.sLPC_Q14[L + i];
+      pexc += L; pxq += L;
+   }
+   for (int i = 0; i < 16; i++) ch->sLPC_Q14_buf[i] = S.sLPC_Q14[i];
+}
+
+WV_DEV void sd_reset(OaSilkChannel *ch)                                                                    /* init_decoder.c:43 (whole state) */
+{
+   i32 *w = (i32 *)ch;
+   for (int i = 0; i < (int)(sizeof(OaSilkChannel) / 4); i++) w[i] = 0;
+   ch->first_frame_after_reset = 1;
+   ch->prev_gain_Q16 = 65536;
+}
+/* silk_decoder_set_fs (decoder_set_fs.c:35); returns nonzero when the resampler has to be re-initialised by the caller */
+WV_DEV int sd_set_fs(OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
+{
+   int reinit = 0;
+   ch->subfr_length = 5 * fs_kHz;
+   const int frame_length = ch->nb_subfr * ch->subfr_length;
+   if (ch->fs_kHz != fs_kHz || ch->fs_API_hz != fs_API_Hz) { reinit = 1; ch->fs_API_hz = fs_API_Hz; }
+   if (ch->fs_kHz != fs_kHz || frame_length != ch->frame_length) {
+      if (ch->fs_kHz != fs_kHz) {
+         ch->ltp_mem_length = 20 * fs_kHz;
+         ch->LPC_order = (fs_kHz == 8 || fs_kHz == 12) ? 10 : 16;
+         ch->first_frame_after_reset = 1;
+         ch->lagPrev = 100; ch->LastGainIndex = 10; ch->prevSignalType = SD_TYPE_NO_VOICE;
+         for (int i = 0; i < 480; i++) ch->outBuf[i] = 0;
+         for (int i = 0; i < 16; i++) ch->sLPC_Q14_buf[i] = 0;
+      }
+      ch->fs_kHz = fs_kHz; ch->frame_length = frame_length;
+   }
+   return reinit;
+}
+
+/* silk_decode_frame (decode_frame.c:43), normal / LBRR frames only */
+WV_DEV int sd_decode_frame(OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int lostFlag, int condCoding, const SdScratch &S)
+{
+   const int L = ch->frame_length;
+   SdCtrl ctrl; ctrl.LTP_scale_Q14 = 0;
+   if (lostFlag == SD_FLAG_DECODE_NORMAL || (lostFlag == SD_FLAG_DECODE_LBRR && ch->LBRR_flags[ch->nFramesDecoded] == 1)) {
+      sd_decode_indices(EC_PASS, ch, ch->nFramesDecoded, lostFlag, condCoding);
+      sd_decode_pulses(EC_PASS, S.pulses, ch->indices.signalType, ch->indices.quantOffsetType, L, S.tmp);
+      sd_decode_parameters(ch, &ctrl, condCoding);
+      sd_decode_core(ch, &ctrl, pOut, S);
+      const int mv = ch->ltp_mem_length - L;
+      for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
+      for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
+      ch->lossCnt = 0;
+      ch->prevSignalType = ch->indices.signalType;
+      ch->first_frame_after_reset = 0;
+   } else return OA_ERR_UNIMPLEMENTED;                                                                       /* concealment: not built yet */
+   ch->lagPrev = ctrl.pitchL[ch->nb_subfr - 1];
+   return L;
+}
+
+WV_DEV void sd_stereo_decode_pred(EC_ARGS, i32 *pred_Q13)                                                   /* stereo_decode_pred.c:35 */
+{
+   int ixs[2][3];
+   int n = k_ec_dec_icdf(EC_PASS, sk_stereo_pred_joint_icdf, 8);
+   ixs[0][2] = n / 5; ixs[1][2] = n - 5 * ixs[0][2];
+   for (n = 0; n < 2; n++) { ixs[n][0] = k_ec_dec_icdf(EC_PASS, sk_uniform3_icdf, 8); ixs[n][1] = k_ec_dec_icdf(EC_PASS, sk_uniform5_icdf, 8); }
+   for (n = 0; n < 2; n++) {
+      ixs[n][0] += 3 * ixs[n][2];
+      const i32 low = sk_stereo_pred_quant_q13[ixs[n][0]];
+      const i32 step = sk_mulwb(sk_stereo_pred_quant_q13[ixs[n][0] + 1] - low, 6554);                        /* SILK_FIX_CONST(0.5 / 5, 16) */
+      pred_Q13[n] = sk_mlabb(low, step, 2 * ixs[n][1] + 1);
+   }
+   pred_Q13[0] -= pred_Q13[1];
+}
+WV_DEV void sd_stereo_ms_to_lr(OaSilkDec *sd, WV_LDS i16 *x1, WV_LDS i16 *x2, const i32 *pred_Q13, int fs_kHz, int frame_length)   /* stereo_MS_to_LR.c:35 */
+{
+   for (int i = 0; i < 2; i++) { x1[i] = sd->sMid[i]; x2[i] = sd->sSide[i]; sd->sMid[i] = x1[frame_length + i]; sd->sSide[i] = x2[frame_length + i]; }
+   i32 pred0 = sd->pred_prev_Q13[0], pred1 = sd->pred_prev_Q13[1];
+   const i32 denom_Q16 = ((i32)1 << 16) / (8 * fs_kHz);
+   const i32 delta0 = sk_rround(sk_mulbb(pred_Q13[0] - sd->pred_prev_Q13[0], denom_Q16), 16), delta1 = sk_rround(sk_mulbb(pred_Q13[1] - sd->pred_prev_Q13[1], denom_Q16), 16);
+   for (int n = 0; n < frame_length; n++) {
+      if (n < 8 * fs_kHz) { pred0 += delta0; pred1 += delta1; } else { pred0 = pred_Q13[0]; pred1 = pred_Q13[1]; }
+      i32 sum = shl32((i32)x1[n] + (i32)x1[n + 2] + shl32(x1[n + 1], 1), 9);
+      sum = sk_mlawb(shl32((i32)x2[n + 1], 8), sum, pred0);
+      sum = sk_mlawb(sum, shl32((i32)x1[n + 1], 11), pred1);
+      x2[n + 1] = (i16)sk_sat16(sk_rround(sum, 8));
+   }
+   sd->pred_prev_Q13[0] = pred_Q13[0]; sd->pred_prev_Q13[1] = pred_Q13[1];
+   for (int n = 0; n < frame_length; n++) {
+      const i32 s = x1[n + 1] + (i32)x2[n + 1], d = x1[n + 1] - (i32)x2[n + 1];
+      x1[n + 1] = (i16)sk_sat16(s); x2[n + 1] = (i16)sk_sat16(d);
+   }
+}
+#endif

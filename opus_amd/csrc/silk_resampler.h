@@ -22,7 +22,37 @@ struct OaResamplerState { i32 sIIR[6]; union { i32 w32[36]; i16 w16[36]; } sFIR;
 /* device state rows ([row][nchannels]): 0..5 sIIR, 6..41 FIR tail (one value per row), 42..89 delay line */
 enum { OA_RS_ROW_IIR = 0, OA_RS_ROW_FIR = 6, OA_RS_ROW_DELAY = 42, OA_RS_ROWS = 90 };
 #define OA_RS_RING 64
-struct ResamplerLds { i32 ring[OA_RS_RING][WV_WIDTH]; };
+template <int W> struct ResamplerLdsT { i32 ring[OA_RS_RING][W]; };    /* W = 64: one column per lane (batch kernel); W = 1: a single channel on lane 0 (decoder) */
+typedef ResamplerLdsT<WV_WIDTH> ResamplerLds;
+
+/* silk_resampler_init (silk/resampler.c:79-178): delay-compensation matrices :52-67, method selection, rounded-up Q16 ratio */
+WV_HD int rs_init_cfg(OaResamplerCfg *S, i32 Fs_in, i32 Fs_out, int forEnc)
+{
+   const signed char dEnc[6][3] = { { 6, 0, 3 }, { 0, 7, 3 }, { 0, 1, 10 }, { 0, 2, 6 }, { 18, 10, 12 }, { 0, 0, 44 } };
+   const signed char dDec[3][6] = { { 4, 0, 2, 0, 0, 0 }, { 0, 9, 4, 7, 4, 4 }, { 0, 3, 12, 7, 7, 7 } };
+   int ri = ((((Fs_in >> 12) - (Fs_in > 16000)) >> (Fs_in > 24000)) - 1), ro = ((((Fs_out >> 12) - (Fs_out > 16000)) >> (Fs_out > 24000)) - 1);
+   if (ri > 5) ri = 5; if (ro > 5) ro = 5;
+   S->resampler_function = 0; S->batchSize = 0; S->invRatio_Q16 = 0; S->FIR_Order = 0; S->FIR_Fracs = 0; S->Fs_in_kHz = 0; S->Fs_out_kHz = 0; S->inputDelay = 0; S->coefs_id = 0;
+   const bool in3 = Fs_in == 8000 || Fs_in == 12000 || Fs_in == 16000, out3 = Fs_out == 8000 || Fs_out == 12000 || Fs_out == 16000;
+   if (forEnc) { if (!(in3 || Fs_in == 24000 || Fs_in == 48000) || !out3) return -1; S->inputDelay = dEnc[ri][ro]; }
+   else { if (!in3 || !(out3 || Fs_out == 24000 || Fs_out == 48000)) return -1; S->inputDelay = dDec[ri][ro]; }
+   S->Fs_in_kHz = Fs_in / 1000; S->Fs_out_kHz = Fs_out / 1000; S->batchSize = S->Fs_in_kHz * 10;
+   int up2x = 0;
+   if (Fs_out > Fs_in) { if (Fs_out == 2 * Fs_in) S->resampler_function = OA_RS_FN_UP2; else { S->resampler_function = OA_RS_FN_IIR_FIR; up2x = 1; } }
+   else if (Fs_out < Fs_in) {
+      S->resampler_function = OA_RS_FN_DOWN_FIR;
+      if (Fs_out * 4 == Fs_in * 3)      { S->FIR_Fracs = 3; S->FIR_Order = 18; S->coefs_id = OA_RS_3_4; }
+      else if (Fs_out * 3 == Fs_in * 2) { S->FIR_Fracs = 2; S->FIR_Order = 18; S->coefs_id = OA_RS_2_3; }
+      else if (Fs_out * 2 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 24; S->coefs_id = OA_RS_1_2; }
+      else if (Fs_out * 3 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_3; }
+      else if (Fs_out * 4 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_4; }
+      else if (Fs_out * 6 == Fs_in)     { S->FIR_Fracs = 1; S->FIR_Order = 36; S->coefs_id = OA_RS_1_6; }
+      else return -1;
+   } else S->resampler_function = OA_RS_FN_COPY;
+   S->invRatio_Q16 = ((Fs_in << (14 + up2x)) / Fs_out) << 2;
+   while ((i32)(((i64)S->invRatio_Q16 * Fs_out) >> 16) < (Fs_in << up2x)) S->invRatio_Q16++;
+   return 0;
+}
 
 WV_DEV const i16 *rs_coefs(int id)
 {
@@ -37,13 +67,13 @@ struct RsLane {                      /* per-lane registers */
    i32 iir[6];
    int rb;                           /* ring slot of logical FIR-buffer index 0 of the current batch (wave-uniform) */
 };
-#define RS_RING(L, slot) (L)->ring[(slot) & (OA_RS_RING - 1)][lane]
+#define RS_RING(L, slot) (L)->ring[(slot) & (OA_RS_RING - 1)][col]
 
 /* the reference's "source" for one run: sample k of the segment */
-struct RsDelaySrc { const i32 *d; int nd; int stride; const i16 *in; };            /* the delay line (state rows) followed by new input */
-struct RsPlainSrc { const i16 *in; };
-WV_DEV i32 rs_at(const RsDelaySrc &s, int k) { return k < s.nd ? s.d[k * s.stride] : (i32)s.in[k - s.nd]; }
-WV_DEV i32 rs_at(const RsPlainSrc &s, int k) { return (i32)s.in[k]; }
+template <class InP> struct RsDelaySrc { const i32 *d; int nd; int stride; InP in; };   /* the delay line (state rows) followed by new input */
+template <class InP> struct RsPlainSrc { InP in; };
+template <class InP> WV_DEV i32 rs_at(const RsDelaySrc<InP> &s, int k) { return k < s.nd ? s.d[k * s.stride] : (i32)s.in[k - s.nd]; }
+template <class InP> WV_DEV i32 rs_at(const RsPlainSrc<InP> &s, int k) { return (i32)s.in[k]; }
 
 WV_DEV void rs_up2_step(i32 *S, i32 in32, i32 &even, i32 &odd)                    /* resampler_private_up2_HQ.c:60-108 */
 {
@@ -61,9 +91,8 @@ WV_DEV void rs_up2_step(i32 *S, i32 in32, i32 &even, i32 &odd)                  
 }
 
 /* One segment (one call of the reference's per-function routine): `len` input samples x[0..len) -> out, returns outputs written. */
-template <class In> WV_DEV int rs_segment(const OaResamplerCfg c, WV_LDS ResamplerLds *L, RsLane &r, In x, int len, i16 *out)
+template <class RL, class In, class Out> WV_DEV int rs_segment(const OaResamplerCfg c, WV_LDS RL *L, RsLane &r, In x, int len, Out out, const int col)
 {
-   const int lane = wv_lane();
    int no = 0;
    if (c.resampler_function == OA_RS_FN_COPY) { for (int k = 0; k < len; k++) out[k] = (i16)rs_at(x, k); return len; }
    if (c.resampler_function == OA_RS_FN_UP2) {
@@ -125,19 +154,17 @@ template <class In> WV_DEV int rs_segment(const OaResamplerCfg c, WV_LDS Resampl
 
 
 /* One call of silk_resampler for this lane's channel.  st = &state[channel] (row stride n), in/out = the channel's buffers. */
-WV_DEV void silk_resampler_lane(const OaResamplerCfg c, WV_LDS ResamplerLds *L, i32 *st, int n, const i16 *in, int inLen, i16 *out)
+template <class RL, class InP, class Out> WV_DEV void silk_resampler_lane(const OaResamplerCfg c, WV_LDS RL *L, i32 *st, int n, InP in, int inLen, Out out, const int col)
 {
-   const int lane = wv_lane();
    RsLane r; r.rb = 0;
    for (int j = 0; j < 6; j++) r.iir[j] = st[(OA_RS_ROW_IIR + j) * n];
    const int ord = c.resampler_function == OA_RS_FN_DOWN_FIR ? c.FIR_Order : c.resampler_function == OA_RS_FN_IIR_FIR ? 8 : 0;
    for (int j = 0; j < ord; j++) RS_RING(L, j) = st[(OA_RS_ROW_FIR + j) * n];
    const int nNew = c.Fs_in_kHz - c.inputDelay;
-   i16 *o = out;
-   RsDelaySrc s1 = { st + OA_RS_ROW_DELAY * n, c.inputDelay, n, in };
-   int w = rs_segment(c, L, r, s1, c.Fs_in_kHz, o);
-   RsPlainSrc s2 = { in + nNew };
-   rs_segment(c, L, r, s2, inLen - c.Fs_in_kHz, o + w);
+   RsDelaySrc<InP> s1 = { st + OA_RS_ROW_DELAY * n, c.inputDelay, n, in };
+   int w = rs_segment(c, L, r, s1, c.Fs_in_kHz, out, col);
+   RsPlainSrc<InP> s2 = { in + nNew };
+   rs_segment(c, L, r, s2, inLen - c.Fs_in_kHz, out + w, col);
    for (int j = 0; j < 6; j++) st[(OA_RS_ROW_IIR + j) * n] = r.iir[j];
    for (int j = 0; j < ord; j++) st[(OA_RS_ROW_FIR + j) * n] = RS_RING(L, r.rb + j);
    for (int j = 0; j < c.inputDelay; j++) st[(OA_RS_ROW_DELAY + j) * n] = in[inLen - c.inputDelay + j];

@@ -65,7 +65,7 @@ struct RsJob { ResamplerLds lds; OaResamplerCfg cfg; int32_t *state; int n, firs
 static void rs_entry(void *arg)
 {
    RsJob *j = (RsJob *)arg; int ch = j->first + wv_lane(); if (ch >= j->n) return;
-   silk_resampler_lane(j->cfg, &j->lds, j->state + ch, j->n, j->in + (size_t)ch * j->inLen, j->inLen, j->out + (size_t)ch * j->outLen);
+   silk_resampler_lane(j->cfg, &j->lds, j->state + ch, j->n, j->in + (size_t)ch * j->inLen, j->inLen, j->out + (size_t)ch * j->outLen, wv_lane());
 }
 /* state: [OA_RS_ROWS][n] int32 rows exactly as the device keeps them; cfg: the nine OaResamplerCfg words */
 extern "C" void emu_silk_resampler(const OaResamplerCfg *cfg, int32_t *state, int n, const int16_t *in, int inLen, int16_t *out, int outLen)
