@@ -11,6 +11,9 @@
 #define OA_ERR_INTERNAL (-3)
 #define OA_ERR_INVALID_PACKET (-4)
 #define OA_ERR_UNIMPLEMENTED (-5)
+#include "silk_nsq.h"          /* SILK fixed-point primitives */
+#include "silk_resampler.h"
+#include "silk_dec_api.h"      /* SILK decoder (lane-0 serial), shares this kernel's wave, range decoder and LDS */
 
 /* ---- inverse MDCT of one block (mdct.c:268): in = N2 bins at `stride` (LDS), out = N2 + overlap samples, TDAC into out[0..overlap) ---- */
 WV_DEVN void mdct_backward_wave(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int stride, WV_LDS int *aux)
@@ -536,8 +539,8 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
          const int packet_frame_size = oa_samples_per_frame(toc, 48000);
          const int count = oa_packet_parse(data, len, sh->size, &offset);
          if (count < 0) ret = count;
-         else if (packet_mode != 1002) ret = OA_ERR_UNIMPLEMENTED;                  /* SILK / hybrid */
-         else if (st->prev_mode > 0 && st->prev_mode != 1002) ret = OA_ERR_UNIMPLEMENTED;
+         else if (packet_mode == 1001) ret = OA_ERR_UNIMPLEMENTED;                  /* hybrid: not built yet */
+         else if (st->prev_mode > 0 && st->prev_mode != packet_mode) ret = OA_ERR_UNIMPLEMENTED;   /* SILK <-> CELT mode transitions: not built yet */
          else if (count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
          else {
             st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
@@ -556,7 +559,35 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
    for (int f = 0; f < count && ret >= 0; f++) {
       const int flen = wv_uni(sh->size[f]);
       int r;
-      if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
+      if (wv_uni(st->mode) == 1000) {
+         /* ---- SILK-only frame (opus_decode_frame, src/opus_decoder.c:404-497 and :606-622) ---- */
+         if (flen <= 1) r = OA_ERR_UNIMPLEMENTED;                                  /* SILK concealment / DTX: not built yet */
+         else {
+            wv_sync();
+            FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
+            wv_sync();
+            LANE0 {
+               EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
+               k_ec_dec_init(&ec, buf, (u32)flen);
+               WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
+               SdDecControl dc;
+               dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
+               dc.internalSampleRate = st->bandwidth == 1101 ? 8000 : st->bandwidth == 1102 ? 12000 : 16000;
+               dc.payloadSize_ms = imax(10, 1000 * pfs / 48000);
+               int decoded = 0, rr = 0;
+               do {
+                  const int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
+                  if (n < 0) { rr = n; break; }
+                  for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm_out[(size_t)(nb + decoded + i) * CC + c] = SB->rs_out[c][i];
+                  decoded += n;
+               } while (decoded < pfs);
+               if (rr == 0 && k_ec_tell(&ec, buf) + 17 <= 8 * flen) rr = OA_ERR_UNIMPLEMENTED;   /* a 5 ms CELT redundancy frame follows (:499-526): not built yet */
+               if (rr == 0) { st->rangeFinal = ec.rng; st->prev_mode = 1000; st->prev_redundancy = 0; rr = decoded; }
+               sh->r[0] = rr;
+            }
+            r = wv_uni(sh->r[0]);
+         }
+      } else if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
          r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
       } else {
          wv_sync();
@@ -570,6 +601,7 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
       else nb += r;
       off += flen;
    }
+   if (count == -1 && ret >= 0 && wv_uni(st->prev_mode) == 1000) ret = OA_ERR_UNIMPLEMENTED;   /* SILK concealment: not built yet */
    if (count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
       while (nb < frame_size) {
          int r = oa_conceal_wave(L, gs, frame_size - nb, pcm_out + (size_t)nb * CC, CC);

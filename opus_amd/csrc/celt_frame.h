@@ -70,11 +70,46 @@ struct OaDecScalars {
    int32_t hist_head;
    int32_t pad0[3];
 };
+/* ---- SILK decoder state (reference silk_decoder_state silk/structs.h:236-286, silk_decoder / stereo_dec_state silk/main.h, silk/structs.h:121-127),
+ * flat: table pointers of the reference (NLSF codebook, iCDFs) are re-derived from fs_kHz / nb_subfr, the resampler is its nine configuration
+ * words + the 90 state rows of silk_resampler.h ---- */
+struct OaSilkIndices { int8_t GainsIndices[4], LTPIndex[4], NLSFIndices[17]; int8_t contourIndex, signalType, quantOffsetType, NLSFInterpCoef_Q2, PERIndex, LTP_scaleIndex, Seed; int16_t lagIndex; int16_t pad; };
+struct OaSilkChannel {
+   int32_t prev_gain_Q16;
+   int32_t exc_Q14[320];
+   int32_t sLPC_Q14_buf[16];
+   int32_t lagPrev, LastGainIndex, fs_kHz, fs_API_hz, nb_subfr, frame_length, subfr_length, ltp_mem_length, LPC_order;
+   int32_t first_frame_after_reset, nFramesDecoded, nFramesPerPacket, ec_prevSignalType, ec_prevLagIndex;
+   int32_t VAD_flags[3], LBRR_flag, LBRR_flags[3];
+   int32_t lossCnt, prevSignalType;
+   int32_t rs_cfg[9], rs_rows[90];
+   int16_t outBuf[480], prevNLSF_Q15[16];
+   OaSilkIndices indices;
+};
+struct OaSilkDec {
+   OaSilkChannel ch[2];
+   int32_t pred_prev_Q13[2];
+   int16_t sMid[2], sSide[2];
+   int32_t nChannelsAPI, nChannelsInternal, prev_decode_only_middle, pad;
+};
 struct OaDecStream {
    OaDecScalars s;
    int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], backgroundLogE[2 * OA_NB_EBANDS];
    int32_t overlap_mem[2 * OA_OVERLAP];
    int32_t plc_lpc[2 * 24];                /* concealment LPC (int16 values), celt_decoder.c:722 */
    int32_t hist[2 * OA_DEC_HISTORY];
+   OaSilkDec silk;
 };
+/* reset values shared by the host library and the emulator harness (opus_decoder_init src/opus_decoder.c:135-184, celt_decoder_init
+ * celt/celt_decoder.c:244-264, silk_InitDecoder silk/dec_API.c:107) */
+static inline void oa_dec_stream_reset(OaDecStream *st, int channels)
+{
+   char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
+   st->s.channels = st->s.stream_channels = channels;
+   st->s.frame_size = 48000 / 400;
+   st->s.start = 0; st->s.end = OA_NB_EBANDS; st->s.disable_inv = channels == 1;
+   st->s.skip_plc = 1;
+   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->oldLogE[i] = st->oldLogE2[i] = -(28 << 24);
+   for (int c = 0; c < 2; c++) { st->silk.ch[c].first_frame_after_reset = 1; st->silk.ch[c].prev_gain_Q16 = 65536; }
+}
 #endif

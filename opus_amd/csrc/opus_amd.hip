@@ -364,12 +364,7 @@ static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
 {
    if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
    if (Fs != 48000) return OPUS_UNIMPLEMENTED;
-   memset(st, 0, sizeof(*st));
-   st->s.channels = st->s.stream_channels = channels;
-   st->s.frame_size = Fs / 400;                                  /* opus_decoder_init :164 */
-   st->s.start = 0; st->s.end = OA_NB_EBANDS; st->s.disable_inv = channels == 1;   /* celt_decoder_init :244-264 */
-   st->s.skip_plc = 1;
-   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->oldLogE[i] = st->oldLogE2[i] = -(28 << 24);
+   oa_dec_stream_reset(st, channels);
    return OPUS_OK;
 }
 struct OpusGpuDecBatch {

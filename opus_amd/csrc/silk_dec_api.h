@@ -1,0 +1,138 @@
+/* silk_dec_api.h — silk_Decode (silk/dec_API.c:142-470) on lane 0 of the stream's wave, and the LDS scratch it borrows from the CELT decoder.
+ * One call decodes one 10/20 ms SILK frame of every internal channel, converts mid/side to left/right and resamples to the API rate into
+ * L's staging area; the caller (oa_decode_packet) copies the staged PCM out with all lanes. */
+#ifndef OPUS_AMD_SILK_DEC_API_H
+#define OPUS_AMD_SILK_DEC_API_H
+#include "silk_dec.h"
+
+/* scratch overlaid on the CELT decoder's phase regions (free while SILK runs): A (7,680 B) and BC (8,640 B) */
+struct SilkLdsA { i32 sLTP_Q15[640]; i32 res_Q14[80]; i32 sLPC_Q14[96]; i16 sLTP[320]; i16 pulses[336]; i16 tmp[16]; i16 xq[2][324]; };
+struct SilkLdsB { i16 rs_out[2][960]; ResamplerLdsT<1> ring; };
+struct SdDecControl { i32 nChannelsAPI, nChannelsInternal, API_sampleRate, internalSampleRate, payloadSize_ms; };
+
+WV_DEV void sd_resample(OaSilkChannel *ch, WV_LDS SilkLdsB *B, WV_LDS i16 *out, WV_LDS i16 *in, int inLen)
+{
+   OaResamplerCfg c;
+   c.resampler_function = ch->rs_cfg[0]; c.batchSize = ch->rs_cfg[1]; c.invRatio_Q16 = ch->rs_cfg[2]; c.FIR_Order = ch->rs_cfg[3]; c.FIR_Fracs = ch->rs_cfg[4];
+   c.Fs_in_kHz = ch->rs_cfg[5]; c.Fs_out_kHz = ch->rs_cfg[6]; c.inputDelay = ch->rs_cfg[7]; c.coefs_id = ch->rs_cfg[8];
+   silk_resampler_lane(c, &B->ring, ch->rs_rows, 1, in, inLen, out, 0);
+}
+WV_DEV void sd_resampler_init(OaSilkChannel *ch, i32 Fs_in, i32 Fs_out)
+{
+   OaResamplerCfg c;
+   rs_init_cfg(&c, Fs_in, Fs_out, 0);
+   ch->rs_cfg[0] = c.resampler_function; ch->rs_cfg[1] = c.batchSize; ch->rs_cfg[2] = c.invRatio_Q16; ch->rs_cfg[3] = c.FIR_Order; ch->rs_cfg[4] = c.FIR_Fracs;
+   ch->rs_cfg[5] = c.Fs_in_kHz; ch->rs_cfg[6] = c.Fs_out_kHz; ch->rs_cfg[7] = c.inputDelay; ch->rs_cfg[8] = c.coefs_id;
+   for (int i = 0; i < 90; i++) ch->rs_rows[i] = 0;
+}
+
+/* returns the number of samples per channel staged in B->rs_out (at the API rate), or a negative OA_ERR_* */
+WV_DEVN int silk_decode_l0(OaSilkDec *sd, const SdDecControl &dc, int lostFlag, int newPacketFlag, EC_ARGS, WV_LDS SilkLdsA *A, WV_LDS SilkLdsB *B)
+{
+   OaSilkChannel *cs = sd->ch;
+   int decode_only_middle = 0;
+   i32 MS_pred_Q13[2] = { 0, 0 };
+   SdScratch S; S.sLTP_Q15 = A->sLTP_Q15; S.res_Q14 = A->res_Q14; S.sLPC_Q14 = A->sLPC_Q14; S.sLTP = A->sLTP; S.pulses = A->pulses; S.tmp = A->tmp;
+
+   if (newPacketFlag) for (int n = 0; n < dc.nChannelsInternal; n++) cs[n].nFramesDecoded = 0;
+   if (dc.nChannelsInternal > sd->nChannelsInternal) sd_reset(&cs[1]);                                   /* mono -> stereo: init the side channel (:186) */
+   const int stereo_to_mono = dc.nChannelsInternal == 1 && sd->nChannelsInternal == 2 && dc.internalSampleRate == 1000 * cs[0].fs_kHz;
+   if (cs[0].nFramesDecoded == 0) {
+      for (int n = 0; n < dc.nChannelsInternal; n++) {
+         if (dc.payloadSize_ms == 0 || dc.payloadSize_ms == 10) { cs[n].nFramesPerPacket = 1; cs[n].nb_subfr = 2; }
+         else if (dc.payloadSize_ms == 20) { cs[n].nFramesPerPacket = 1; cs[n].nb_subfr = 4; }
+         else if (dc.payloadSize_ms == 40) { cs[n].nFramesPerPacket = 2; cs[n].nb_subfr = 4; }
+         else if (dc.payloadSize_ms == 60) { cs[n].nFramesPerPacket = 3; cs[n].nb_subfr = 4; }
+         else return OA_ERR_INTERNAL;
+         const int fs_kHz_dec = (dc.internalSampleRate >> 10) + 1;
+         if (fs_kHz_dec != 8 && fs_kHz_dec != 12 && fs_kHz_dec != 16) return OA_ERR_INTERNAL;
+         if (sd_set_fs(&cs[n], fs_kHz_dec, dc.API_sampleRate)) sd_resampler_init(&cs[n], fs_kHz_dec * 1000, dc.API_sampleRate);
+      }
+   }
+   if (dc.nChannelsAPI == 2 && dc.nChannelsInternal == 2 && (sd->nChannelsAPI == 1 || sd->nChannelsInternal == 1)) {
+      sd->pred_prev_Q13[0] = sd->pred_prev_Q13[1] = 0; sd->sSide[0] = sd->sSide[1] = 0;
+      for (int i = 0; i < 9; i++) cs[1].rs_cfg[i] = cs[0].rs_cfg[i];
+      for (int i = 0; i < 90; i++) cs[1].rs_rows[i] = cs[0].rs_rows[i];
+   }
+   sd->nChannelsAPI = dc.nChannelsAPI; sd->nChannelsInternal = dc.nChannelsInternal;
+
+   if (lostFlag != SD_FLAG_PACKET_LOST && cs[0].nFramesDecoded == 0) {
+      /* VAD and LBRR flags, then skip over any LBRR payload (:233-290) */
+      for (int n = 0; n < dc.nChannelsInternal; n++) {
+         for (int i = 0; i < cs[n].nFramesPerPacket; i++) cs[n].VAD_flags[i] = k_ec_dec_bit_logp(EC_PASS, 1);
+         cs[n].LBRR_flag = k_ec_dec_bit_logp(EC_PASS, 1);
+      }
+      for (int n = 0; n < dc.nChannelsInternal; n++) {
+         cs[n].LBRR_flags[0] = cs[n].LBRR_flags[1] = cs[n].LBRR_flags[2] = 0;
+         if (cs[n].LBRR_flag) {
+            if (cs[n].nFramesPerPacket == 1) cs[n].LBRR_flags[0] = 1;
+            else {
+               const int sym = k_ec_dec_icdf(EC_PASS, &sk_lbrr_flags_icdf[cs[n].nFramesPerPacket == 2 ? 0 : 3], 8) + 1;
+               for (int i = 0; i < cs[n].nFramesPerPacket; i++) cs[n].LBRR_flags[i] = (sym >> i) & 1;
+            }
+         }
+      }
+      if (lostFlag == SD_FLAG_DECODE_NORMAL) {
+         for (int i = 0; i < cs[0].nFramesPerPacket; i++) {
+            for (int n = 0; n < dc.nChannelsInternal; n++) {
+               if (cs[n].LBRR_flags[i]) {
+                  if (dc.nChannelsInternal == 2 && n == 0) {
+                     sd_stereo_decode_pred(EC_PASS, MS_pred_Q13);
+                     if (cs[1].LBRR_flags[i] == 0) decode_only_middle = k_ec_dec_icdf(EC_PASS, sk_stereo_only_code_mid_icdf, 8);
+                  }
+                  const int condCoding = (i > 0 && cs[n].LBRR_flags[i - 1]) ? SD_CODE_CONDITIONALLY : SD_CODE_INDEPENDENTLY;
+                  sd_decode_indices(EC_PASS, &cs[n], i, 1, condCoding);
+                  sd_decode_pulses(EC_PASS, S.pulses, cs[n].indices.signalType, cs[n].indices.quantOffsetType, cs[n].frame_length, S.tmp);
+               }
+            }
+         }
+      }
+   }
+   if (dc.nChannelsInternal == 2) {
+      if (lostFlag == SD_FLAG_DECODE_NORMAL || (lostFlag == SD_FLAG_DECODE_LBRR && cs[0].LBRR_flags[cs[0].nFramesDecoded] == 1)) {
+         sd_stereo_decode_pred(EC_PASS, MS_pred_Q13);
+         if ((lostFlag == SD_FLAG_DECODE_NORMAL && cs[1].VAD_flags[cs[0].nFramesDecoded] == 0) ||
+             (lostFlag == SD_FLAG_DECODE_LBRR && cs[1].LBRR_flags[cs[0].nFramesDecoded] == 0)) decode_only_middle = k_ec_dec_icdf(EC_PASS, sk_stereo_only_code_mid_icdf, 8);
+         else decode_only_middle = 0;
+      } else { MS_pred_Q13[0] = sd->pred_prev_Q13[0]; MS_pred_Q13[1] = sd->pred_prev_Q13[1]; }
+   }
+   if (dc.nChannelsInternal == 2 && decode_only_middle == 0 && sd->prev_decode_only_middle == 1) {
+      for (int i = 0; i < 480; i++) cs[1].outBuf[i] = 0;
+      for (int i = 0; i < 16; i++) cs[1].sLPC_Q14_buf[i] = 0;
+      cs[1].lagPrev = 100; cs[1].LastGainIndex = 10; cs[1].prevSignalType = SD_TYPE_NO_VOICE; cs[1].first_frame_after_reset = 1;
+   }
+   int has_side;
+   if (lostFlag == SD_FLAG_DECODE_NORMAL) has_side = !decode_only_middle;
+   else has_side = !sd->prev_decode_only_middle || (dc.nChannelsInternal == 2 && lostFlag == SD_FLAG_DECODE_LBRR && cs[1].LBRR_flags[cs[1].nFramesDecoded] == 1);
+
+   int nSamplesOutDec = cs[0].frame_length;
+   for (int n = 0; n < dc.nChannelsInternal; n++) {
+      if (n == 0 || has_side) {
+         const int FrameIndex = cs[0].nFramesDecoded - n;
+         int condCoding;
+         if (FrameIndex <= 0) condCoding = SD_CODE_INDEPENDENTLY;
+         else if (lostFlag == SD_FLAG_DECODE_LBRR) condCoding = cs[n].LBRR_flags[FrameIndex - 1] ? SD_CODE_CONDITIONALLY : SD_CODE_INDEPENDENTLY;
+         else if (n > 0 && sd->prev_decode_only_middle) condCoding = SD_CODE_INDEPENDENTLY_NO_LTP_SCALING;
+         else condCoding = SD_CODE_CONDITIONALLY;
+         const int r = sd_decode_frame(&cs[n], EC_PASS, &A->xq[n][2], lostFlag, condCoding, S);
+         if (r < 0) return r;
+         nSamplesOutDec = r;
+      } else for (int i = 0; i < nSamplesOutDec; i++) A->xq[n][2 + i] = 0;
+      cs[n].nFramesDecoded++;
+   }
+   if (dc.nChannelsAPI == 2 && dc.nChannelsInternal == 2) sd_stereo_ms_to_lr(sd, A->xq[0], A->xq[1], MS_pred_Q13, cs[0].fs_kHz, nSamplesOutDec);
+   else { for (int i = 0; i < 2; i++) { A->xq[0][i] = sd->sMid[i]; sd->sMid[i] = A->xq[0][nSamplesOutDec + i]; } }
+
+   const int nOut = (nSamplesOutDec * dc.API_sampleRate) / (cs[0].fs_kHz * 1000);
+   const int nres = imin(dc.nChannelsAPI, dc.nChannelsInternal);
+   for (int n = 0; n < nres; n++) sd_resample(&cs[n], B, B->rs_out[n], &A->xq[n][1], nSamplesOutDec);
+   if (dc.nChannelsAPI == 2 && dc.nChannelsInternal == 1) {
+      if (stereo_to_mono) sd_resample(&cs[1], B, B->rs_out[1], &A->xq[0][1], nSamplesOutDec);
+      else for (int i = 0; i < nOut; i++) B->rs_out[1][i] = B->rs_out[0][i];
+   }
+   /* (prevPitchLag export for the CELT PLC hand-over, :451-458, is not needed until SILK concealment exists) */
+   if (lostFlag == SD_FLAG_PACKET_LOST) { for (int i = 0; i < sd->nChannelsInternal; i++) sd->ch[i].LastGainIndex = 10; }
+   else sd->prev_decode_only_middle = decode_only_middle;
+   return nOut;
+}
+#endif

@@ -41,6 +41,7 @@ static void djob_entry(void *p)
    oa_decode_packet(j->L, j->gs, j->data, j->len, j->frame_size, j->pcm, j->ns, j->rng);
 }
 extern "C" int emu_sizeof_dec_stream() { return (int)sizeof(OaDecStream); }
+extern "C" void emu_dec_stream_reset(OaDecStream *st, int channels) { oa_dec_stream_reset(st, channels); }
 extern "C" int emu_sizeof_dec_lds() { return (int)sizeof(DecLds); }
 extern "C" void emu_decode_batch(OaDecStream *streams, const uint8_t *data, int stride, const int32_t *lens, int S, int frame_size,
       int16_t *pcm, int pcm_stride, int32_t *ns, uint32_t *rngs)

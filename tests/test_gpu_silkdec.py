@@ -1,0 +1,48 @@
+"""GPU: SILK-only packets from the compiled reference encoder through the C ABI (classic opus_decode and the batch decoder) against the compiled
+reference decoder: identical PCM and OPUS_GET_FINAL_RANGE, state carried across packets."""
+import numpy as np, pytest
+from reflib import ref_fx
+from test_oracle_encoder import RefEnc
+from test_oracle_decoder import RefDec
+from test_kernel_emu_silkdec import speechy
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ref_fx() is None, reason="oracle/_ref not built")]
+
+def _packets(enc_ch, frame, nframes, seed, **ctl):
+    sig = speechy(nframes, enc_ch, seed, frame)
+    e = RefEnc(enc_ch, application=2048, force_mode=1000, **ctl)
+    out = []
+    for i in range(nframes):
+        pkt, n, erng = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)
+        assert n > 1 and (pkt[0] >> 7) == 0
+        out.append((pkt, erng))
+    return out
+
+@pytest.mark.parametrize("enc_ch,dec_ch,bw,bitrate,frame", [(1, 1, 1103, 24000, 960), (1, 1, 1102, 16000, 960), (1, 1, 1101, 10000, 960), (1, 1, 1103, 20000, 480),
+                                                          (1, 1, 1103, 20000, 1920), (1, 1, 1103, 20000, 2880), (2, 2, 1103, 40000, 960), (2, 2, 1101, 20000, 960),
+                                                          (1, 2, 1103, 20000, 960), (2, 1, 1103, 36000, 960)])
+def test_gpu_silk_classic_decode(enc_ch, dec_ch, bw, bitrate, frame):
+    import opus_amd
+    pk = _packets(enc_ch, frame, 20, bw + bitrate + frame, bitrate=bitrate, bandwidth=bw)
+    r = RefDec(dec_ch); d = opus_amd.OpusDecoder(48000, dec_ch)
+    for i, (pkt, erng) in enumerate(pk):
+        a = r.decode(pkt); pcm = d.decode(pkt, 5760)
+        assert a[0] == frame == pcm.shape[0], (i, a[0], pcm.shape)
+        assert d.final_range() == a[2] == erng, i
+        assert np.array_equal(pcm.reshape(-1, dec_ch), a[1]), i
+
+def test_gpu_silk_batch_decode_many_streams():
+    """2,048 streams in one launch: 8 distinct SILK streams tiled; every replica must equal the reference decode of its source"""
+    import opus_amd
+    S = 2048; U = 8; nframes = 6
+    pks = [_packets(1, 960, nframes, 100 + u, bitrate=14000 + 2000 * u, bandwidth=[1101, 1102, 1103][u % 3]) for u in range(U)]
+    refs = [RefDec(1) for _ in range(U)]
+    b = opus_amd.DecoderBatch(S, channels=1)
+    for f in range(nframes):
+        pcm, ns, rng = b.decode([pks[s % U][f][0] for s in range(S)], 960)
+        for u in range(U):
+            a = refs[u].decode(pks[u][f][0])
+            sel = np.arange(u, S, U)
+            assert (ns[sel] == 960).all() and (rng[sel] == a[2]).all(), (f, u)
+            assert (pcm[sel, :, 0] == a[1][:, 0]).all(), (f, u)
+    b.close()

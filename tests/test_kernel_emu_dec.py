@@ -10,13 +10,8 @@ from reflib import oracle
 pytestmark = pytest.mark.skipif(oracle() is None, reason="oracle lib not built")
 
 def new_dec_stream(E, channels):
-    n = E.emu_sizeof_dec_stream() // 4
-    s = np.zeros(n, np.int32)
-    # OaDecScalars: channels, stream_channels, bandwidth, mode, prev_mode, frame_size, prev_redundancy, last_packet_duration, rangeFinal,
-    # start, end, disable_inv, rng, error, last_pitch_index, loss_duration, plc_duration, last_frame_type, skip_plc, ...
-    s[0] = channels; s[1] = channels; s[5] = 120; s[9] = 0; s[10] = 21; s[11] = 1 if channels == 1 else 0; s[18] = 1
-    arr = 32
-    s[arr + 42: arr + 42 + 84] = -(28 << 24)          # oldLogE, oldLogE2
+    s = np.zeros(E.emu_sizeof_dec_stream() // 4, np.int32)
+    E.emu_dec_stream_reset(s.ctypes.data_as(ctypes.c_void_p), channels)       # the library's own reset (celt_frame.h: oa_dec_stream_reset)
     return s
 
 class EmuDec:

@@ -16,7 +16,7 @@ class RefEnc:
         err = ctypes.c_int()
         self.st = L.opus_encoder_create(48000, channels, application, ctypes.byref(err))
         assert err.value == 0
-        req = dict(bitrate=4002, complexity=4010, vbr=4006, vbr_constraint=4020, force_channels=4022, bandwidth=4008, max_bandwidth=4004, lsb_depth=4036, phase_inv_disabled=4046)
+        req = dict(bitrate=4002, complexity=4010, vbr=4006, vbr_constraint=4020, force_channels=4022, bandwidth=4008, max_bandwidth=4004, lsb_depth=4036, phase_inv_disabled=4046, force_mode=11002, signal=4024, inband_fec=4012, packet_loss=4014, dtx=4016)
         for k, v in ctl.items(): assert L.opus_encoder_ctl(self.st, req[k], v) == 0
         self.out = (ctypes.c_ubyte * 1500)()
     def encode(self, pcm, frame, maxb=1276):
