@@ -409,6 +409,12 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
       } else b = 0;
       if ((M * ct_eBands[i] - N >= M * ct_eBands[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
          lowband_offset = i;
+      if (i == start + 1) {            /* special_hybrid_folding (bands.c:1575, RFC 8251 section 9): the second band never has to fold from the LCG; copies nothing when start == 0 */
+         const int n1 = M * (ct_eBands[start + 1] - ct_eBands[start]), n2 = M * (ct_eBands[start + 2] - ct_eBands[start + 1]);
+         wv_sync();
+         FOR_LANES(j, n2 - n1) { norm[n1 + j] = norm[2 * n1 - n2 + j]; if (dual_stereo) norm2[n1 + j] = norm2[2 * n1 - n2 + j]; }
+         wv_sync();
+      }
       tf_change = wv_uni(tf_res[i]);
       cfg.tf_change = tf_change;
       if (last) lowband_scratch = 0;

@@ -143,7 +143,7 @@ WV_DEVN void comb_filter_inplace_wave(WV_LDS i32 *cur, const i32 *hist, int head
 }
 
 /* common tail of a decoded or concealed frame: de-emphasis -> int16 PCM, history ring += N samples, overlap tail kept */
-WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int CC, i16 *pcm_out)
+WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int CC, i16 *pcm_out, int accum = 0)
 {
    WV_LDS OaDecScalars *st = &L->st;
    const int overlap = OA_OVERLAP, lane = wv_lane();
@@ -166,7 +166,9 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
       st->preemph_memD[lane] = m;
    }
    wv_sync();
-   FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
+   accum = wv_uni(accum);
+   if (accum) { FOR_LANES(i, N * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }   /* ADD_RES, celt/arch.h:172 */
+   else FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
    /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
    {
       const int head = wv_uni(st->hist_head);
@@ -183,7 +185,8 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
 #include "celt_dec_plc.h"
 
 /* ---- one CELT frame (celt_decoder.c:1104).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
-WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out)
+/* ec_cont: continue the range decoder parked in L->ec_silk (hybrid frames) instead of starting one; accum: add onto pcm_out (celt_decoder.c:1104 `dec`, `accum`) */
+WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int ec_cont = 0, int accum = 0)
 {
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
@@ -198,7 +201,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
    if (len <= 1) {                                                /* lost / DTX frame: conceal (celt_decoder.c:1306) */
       celt_decode_lost_wave(L, gs, N, LM);
-      celt_emit_frame_wave(L, gs, N, CC, pcm_out);
+      celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
       return frame_size;
    }
    const int effEnd = imin(end, NBE);
@@ -207,7 +210,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
       sh->CC = CC; sh->C = C; sh->LM = LM; sh->M = M; sh->N = N; sh->start = start; sh->end = end; sh->effEnd = effEnd; sh->len = len;
       if (st->loss_duration == 0) st->skip_plc = 0;
-      k_ec_dec_init(EC_PASS, len);
+      if (ec_cont) { ec_ld(e, &L->ec_silk); e->storage = (u32)len; } else k_ec_dec_init(EC_PASS, len);
       if (C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[i] = imax(L->oldBandE[i], L->oldBandE[NBE + i]);
       i32 total_bits = len * 8, tell = k_ec_tell(EC_PASS);
       int silence;
@@ -375,7 +378,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       }
    }
    wv_sync();
-   celt_emit_frame_wave(L, gs, N, CC, pcm_out);
+   celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
    int ret = frame_size;
    LANE0 {
       st->rng = L->ec.rng;
@@ -511,6 +514,163 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
    return done;
 }
 
+
+/* OPUS_RESET_STATE of the CELT decoder (celt_decoder.c:1794-1814): everything from `rng` on, then the -28 dB energy floors */
+WV_DEVN void celt_reset_wave(WV_LDS DecLds *L, OaDecStream *gs)
+{
+   WV_LDS OaDecScalars *st = &L->st;
+   wv_sync();
+   LANE0 {
+      st->rng = 0; st->error = 0; st->last_pitch_index = 0; st->loss_duration = 0; st->plc_duration = 0; st->last_frame_type = 0; st->skip_plc = 1;
+      st->postfilter_period = st->postfilter_period_old = st->postfilter_gain = st->postfilter_gain_old = st->postfilter_tapset = st->postfilter_tapset_old = 0;
+      st->prefilter_and_fold = 0; st->preemph_memD[0] = st->preemph_memD[1] = 0; st->hist_head = 0;
+   }
+   FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = 0; L->backgroundLogE[i] = 0; L->oldLogE[i] = L->oldLogE2[i] = -(28 << 24); }
+   FOR_LANES(i, 2 * OA_DEC_HISTORY) gs->hist[i] = 0;
+   FOR_LANES(i, 2 * OA_OVERLAP) gs->overlap_mem[i] = 0;
+   FOR_LANES(i, 2 * 24) gs->plc_lpc[i] = 0;
+   wv_sync();
+}
+
+/* smooth_fade (src/opus_decoder.c:234-253): cross-fade over `overlap` samples with the squared CELT window */
+WV_DEV void oa_smooth_fade_wave(const i16 *in1, const i16 *in2, i16 *out, int overlap, int CC)
+{
+   FOR_LANES(it, overlap * CC) {
+      const int i = it / CC;
+      i32 w = ct_window[i]; w = mult16_16_q15(w, w);
+      out[it] = (i16)((mult16_16(w, in2[it]) + mult16_16(Q15ONE - w, in1[it])) >> 15);
+   }
+}
+
+/* One Opus frame with payload (opus_decode_frame, src/opus_decoder.c:271-714, data != NULL): SILK part, redundancy, CELT part, mode transitions.
+ * `data` = the frame's bytes in HBM, len >= 2.  Returns the frame size or a negative OA_ERR_*. */
+WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC)
+{
+   WV_LDS DecShared *sh = &L->sh;
+   WV_LDS OaDecScalars *st = &L->st;
+   const int F20 = 960, F5 = 240, F2_5 = 120;
+   const int mode = wv_uni(st->mode), bandwidth = wv_uni(st->bandwidth), prev_mode = wv_uni(st->prev_mode), prev_red = wv_uni(st->prev_redundancy);
+   const int frame_size = audiosize;
+   int transition = 0, redundancy = 0, celt_to_silk = 0, redundancy_bytes = 0;
+   u32 redundant_rng = 0;
+   const int celt_accum = mode != 1002;
+   if (prev_mode > 0 && ((mode == 1002 && prev_mode != 1002 && !prev_red) || (mode != 1002 && prev_mode == 1002))) transition = 1;
+   if (transition && mode == 1002) return OA_ERR_UNIMPLEMENTED;                 /* needs SILK concealment for the 5 ms cross-fade source: not built yet */
+
+   wv_sync();
+   FOR_LANES(i, len) L->packet[1 + i] = data[i];
+   wv_sync();
+   if (mode != 1002) {
+      /* ---- SILK part (:404-497) ---- */
+      LANE0 {
+         EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
+         k_ec_dec_init(&ec, buf, (u32)len);
+         WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
+         if (prev_mode == 1002) {                                               /* silk_ResetDecoder (silk/dec_API.c:91) */
+            sd_reset(&gs->silk.ch[0]); sd_reset(&gs->silk.ch[1]);
+            gs->silk.pred_prev_Q13[0] = gs->silk.pred_prev_Q13[1] = 0; gs->silk.sMid[0] = gs->silk.sMid[1] = gs->silk.sSide[0] = gs->silk.sSide[1] = 0;
+            gs->silk.prev_decode_only_middle = 0;
+         }
+         SdDecControl dc;
+         dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
+         dc.internalSampleRate = mode == 1001 ? 16000 : bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000;
+         dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+         int decoded = 0, rr = 0;
+         do {
+            const int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
+            if (n < 0) { rr = n; break; }
+            for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
+            decoded += n;
+         } while (decoded < frame_size);
+         /* ---- redundancy signalling (:499-526) ---- */
+         int red = 0, c2s = 0, rbytes = 0, newlen = len;
+         if (rr == 0 && k_ec_tell(&ec, buf) + 17 + 20 * (mode == 1001) <= 8 * len) {
+            red = mode == 1001 ? k_ec_dec_bit_logp(&ec, buf, 12) : 1;
+            if (red) {
+               c2s = k_ec_dec_bit_logp(&ec, buf, 1);
+               rbytes = mode == 1001 ? (int)k_ec_dec_uint(&ec, buf, 256) + 2 : len - ((k_ec_tell(&ec, buf) + 7) >> 3);
+               newlen = len - rbytes;
+               if (newlen * 8 < k_ec_tell(&ec, buf)) { newlen = 0; rbytes = 0; red = 0; }
+               ec.storage -= (u32)rbytes;
+            }
+         }
+         ec_st(&L->ec_silk, &ec);
+         sh->r[0] = rr; sh->r[1] = red; sh->r[2] = c2s; sh->r[3] = rbytes; sh->r[4] = newlen;
+      }
+      const int rr = wv_uni(sh->r[0]);
+      if (rr < 0) return rr;
+      redundancy = wv_uni(sh->r[1]); celt_to_silk = wv_uni(sh->r[2]); redundancy_bytes = wv_uni(sh->r[3]); len = wv_uni(sh->r[4]);
+   }
+   const int start_band = mode != 1002 ? 17 : 0;
+   if (redundancy) transition = 0;
+   if (transition && mode != 1002) {                                            /* CELT -> SILK/hybrid: 5 ms of CELT concealment as the fade source (:534-539) */
+      const int r = oa_conceal_wave(L, gs, imin(F5, audiosize), gs->trans, CC);
+      if (r < 0) return r;
+      wv_sync();
+      FOR_LANES(i, len + redundancy_bytes) L->packet[1 + i] = data[i];           /* (concealment does not touch the packet buffer; reloaded for clarity of state) */
+      wv_sync();
+   }
+   {
+      int endband = 21;
+      switch (bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
+      LANE0 { st->end = endband; }
+   }
+   if (redundancy && celt_to_silk) {                                            /* 5 ms redundant CELT frame ahead of the SILK audio (:571-583) */
+      wv_sync();
+      FOR_LANES(i, redundancy_bytes) L->packet[1 + i] = data[len + i];
+      LANE0 st->start = 0;
+      const int r = celt_decode_frame_wave(L, gs, redundancy_bytes, F5, gs->red, 0, 0);
+      if (r < 0) return r;
+      redundant_rng = (u32)wv_uni((i32)st->rng);
+      wv_sync();
+      FOR_LANES(i, len) L->packet[1 + i] = data[i];
+      wv_sync();
+   }
+   LANE0 st->start = start_band;
+   if (mode != 1000) {
+      const int celt_frame_size = imin(F20, frame_size);
+      if (mode != prev_mode && prev_mode > 0 && !prev_red) celt_reset_wave(L, gs);
+      const int r = celt_decode_frame_wave(L, gs, len, celt_frame_size, pcm, mode == 1001, celt_accum);
+      if (r < 0) return r;
+      LANE0 st->rangeFinal = st->rng;
+   } else {
+      if (prev_mode == 1001 && !(redundancy && celt_to_silk && prev_red)) {     /* hybrid -> SILK: let the CELT MDCT fade out on a silence frame (:606-615) */
+         wv_sync();
+         LANE0 { L->packet[1] = 0xFF; L->packet[2] = 0xFF; st->start = 0; }
+         const int r = celt_decode_frame_wave(L, gs, 2, F2_5, pcm, 0, celt_accum);
+         if (r < 0) return r;
+      }
+      LANE0 st->rangeFinal = L->ec_silk.rng;
+   }
+   wv_sync();
+   if (redundancy && !celt_to_silk) {                                           /* 5 ms redundant CELT frame after the SILK audio (:624-633) */
+      celt_reset_wave(L, gs);
+      FOR_LANES(i, redundancy_bytes) L->packet[1 + i] = data[len + i];
+      LANE0 st->start = 0;
+      const int r = celt_decode_frame_wave(L, gs, redundancy_bytes, F5, gs->red, 0, 0);
+      if (r < 0) return r;
+      redundant_rng = (u32)wv_uni((i32)st->rng);
+      wv_sync();
+      oa_smooth_fade_wave(pcm + (size_t)CC * (frame_size - F2_5), gs->red + CC * F2_5, pcm + (size_t)CC * (frame_size - F2_5), F2_5, CC);
+   }
+   if (redundancy && celt_to_silk && (prev_mode != 1000 || prev_red)) {
+      wv_sync();
+      FOR_LANES(i, F2_5 * CC) pcm[i] = gs->red[i];
+      oa_smooth_fade_wave(gs->red + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC);
+   }
+   if (transition) {
+      wv_sync();
+      if (audiosize >= F5) {
+         FOR_LANES(i, F2_5 * CC) pcm[i] = gs->trans[i];
+         oa_smooth_fade_wave(gs->trans + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC);
+      } else oa_smooth_fade_wave(gs->trans, pcm, pcm, F2_5, CC);
+   }
+   wv_sync();
+   LANE0 { st->rangeFinal ^= redundant_rng; st->prev_mode = mode; st->prev_redundancy = redundancy && !celt_to_silk; }
+   wv_sync();
+   return audiosize;
+}
+
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
 WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
 {
@@ -539,8 +699,6 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
          const int packet_frame_size = oa_samples_per_frame(toc, 48000);
          const int count = oa_packet_parse(data, len, sh->size, &offset);
          if (count < 0) ret = count;
-         else if (packet_mode == 1001) ret = OA_ERR_UNIMPLEMENTED;                  /* hybrid: not built yet */
-         else if (st->prev_mode > 0 && st->prev_mode != packet_mode) ret = OA_ERR_UNIMPLEMENTED;   /* SILK <-> CELT mode transitions: not built yet */
          else if (count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
          else {
             st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
@@ -559,43 +717,10 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
    for (int f = 0; f < count && ret >= 0; f++) {
       const int flen = wv_uni(sh->size[f]);
       int r;
-      if (wv_uni(st->mode) == 1000) {
-         /* ---- SILK-only frame (opus_decode_frame, src/opus_decoder.c:404-497 and :606-622) ---- */
-         if (flen <= 1) r = OA_ERR_UNIMPLEMENTED;                                  /* SILK concealment / DTX: not built yet */
-         else {
-            wv_sync();
-            FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
-            wv_sync();
-            LANE0 {
-               EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
-               k_ec_dec_init(&ec, buf, (u32)flen);
-               WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
-               SdDecControl dc;
-               dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
-               dc.internalSampleRate = st->bandwidth == 1101 ? 8000 : st->bandwidth == 1102 ? 12000 : 16000;
-               dc.payloadSize_ms = imax(10, 1000 * pfs / 48000);
-               int decoded = 0, rr = 0;
-               do {
-                  const int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
-                  if (n < 0) { rr = n; break; }
-                  for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm_out[(size_t)(nb + decoded + i) * CC + c] = SB->rs_out[c][i];
-                  decoded += n;
-               } while (decoded < pfs);
-               if (rr == 0 && k_ec_tell(&ec, buf) + 17 <= 8 * flen) rr = OA_ERR_UNIMPLEMENTED;   /* a 5 ms CELT redundancy frame follows (:499-526): not built yet */
-               if (rr == 0) { st->rangeFinal = ec.rng; st->prev_mode = 1000; st->prev_redundancy = 0; rr = decoded; }
-               sh->r[0] = rr;
-            }
-            r = wv_uni(sh->r[0]);
-         }
-      } else if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
+      if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
          r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
       } else {
-         wv_sync();
-         FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
-         wv_sync();
-         r = celt_decode_frame_wave(L, gs, flen, pfs, pcm_out + (size_t)nb * CC);
-         LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1002; st->prev_redundancy = 0; }
-         wv_sync();
+         r = oa_decode_frame_wave(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
       }
       if (r < 0) ret = r;
       else nb += r;

@@ -16,6 +16,7 @@ struct DecShared {
 };
 struct DecLds {
    EcCtx ec;
+   EcCtx ec_silk;                     /* the range decoder after the SILK part of a hybrid frame (the CELT part continues from it) */
    DecShared sh;
    OaDecScalars st;
    i32 oldBandE[2 * NBE], oldLogE[2 * NBE], oldLogE2[2 * NBE], backgroundLogE[2 * NBE];

@@ -99,6 +99,7 @@ struct OaDecStream {
    int32_t plc_lpc[2 * 24];                /* concealment LPC (int16 values), celt_decoder.c:722 */
    int32_t hist[2 * OA_DEC_HISTORY];
    OaSilkDec silk;
+   int16_t trans[2 * 240], red[2 * 240];   /* call-local: 5 ms mode-transition and redundancy audio (src/opus_decoder.c:285-291) */
 };
 /* reset values shared by the host library and the emulator harness (opus_decoder_init src/opus_decoder.c:135-184, celt_decoder_init
  * celt/celt_decoder.c:244-264, silk_InitDecoder silk/dec_API.c:107) */

@@ -46,3 +46,35 @@ def test_gpu_silk_batch_decode_many_streams():
             assert (ns[sel] == 960).all() and (rng[sel] == a[2]).all(), (f, u)
             assert (pcm[sel, :, 0] == a[1][:, 0]).all(), (f, u)
     b.close()
+
+def _mode_stream(enc_ch, frame, nframes, seed, schedule, **ctl):
+    sig = speechy(nframes, enc_ch, seed, frame)
+    e = RefEnc(enc_ch, application=2048, **ctl)
+    req = dict(bitrate=4002, bandwidth=4008, max_bandwidth=4004, force_mode=11002, force_channels=4022)
+    out = []
+    for i in range(nframes):
+        if i in schedule:
+            for kk, v in schedule[i].items(): assert e.L.opus_encoder_ctl(e.st, req[kk], v) == 0
+        pkt, n, erng = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)
+        assert n > 1
+        out.append((pkt, erng))
+    return out
+
+@pytest.mark.parametrize("ch,frame,bitrate,schedule", [
+    (1, 960, 32000, {0: dict(force_mode=1001, bandwidth=1105)}),
+    (2, 960, 48000, {0: dict(force_mode=1001, bandwidth=1104)}),
+    (1, 480, 28000, {0: dict(force_mode=1001, bandwidth=1105)}),
+    (1, 960, 28000, {0: dict(force_mode=1000, bandwidth=1103), 6: dict(force_mode=1001, bandwidth=1105), 12: dict(force_mode=1000, bandwidth=1103), 18: dict(force_mode=1001, bandwidth=1104)}),
+    (2, 960, 44000, {0: dict(force_mode=1000, bandwidth=1103), 6: dict(force_mode=1001, bandwidth=1105), 12: dict(force_mode=1000, bandwidth=1102)}),
+    (1, 960, 32000, {0: dict(force_mode=1002), 8: dict(force_mode=1000, bandwidth=1103)}),
+    (2, 960, 48000, {0: dict(force_mode=1002), 8: dict(force_mode=1001, bandwidth=1105)})])
+def test_gpu_hybrid_and_mode_switching(ch, frame, bitrate, schedule):
+    """hybrid packets, SILK<->hybrid switches (CELT reset / silence-frame fade), CELT -> SILK/hybrid switches (redundancy frames, concealment cross-fade)"""
+    import opus_amd
+    pk = _mode_stream(ch, frame, 24, ch * 1000 + bitrate, schedule, bitrate=bitrate)
+    r = RefDec(ch); d = opus_amd.OpusDecoder(48000, ch)
+    for i, (pkt, erng) in enumerate(pk):
+        a = r.decode(pkt); pcm = d.decode(pkt, 5760)
+        assert a[0] == frame == pcm.shape[0], (i, a[0], pcm.shape)
+        assert d.final_range() == a[2] == erng, i
+        assert np.array_equal(pcm.reshape(-1, ch), a[1]), i

@@ -58,3 +58,39 @@ def test_emu_silk_stereo(bw, bitrate):
 def test_emu_silk_channel_mismatch():
     _run(1, 2, 960, 12, seed=5, bitrate=20000, bandwidth=1103)       # mono stream, stereo output
     _run(2, 1, 960, 12, seed=6, bitrate=36000, bandwidth=1103)       # stereo stream, mono output
+
+def _run_any(enc_ch, dec_ch, frame, nframes, seed=0, application=2048, schedule=None, expect_modes=None, **ctl):
+    """reference encoder with its own mode decisions (or a per-frame ctl schedule) -> reference decoder vs the emulated kernel"""
+    sig = speechy(nframes, enc_ch, seed, frame)
+    e = RefEnc(enc_ch, application=application, **ctl); r = RefDec(dec_ch); k = EmuDec(dec_ch)
+    req = dict(bitrate=4002, bandwidth=4008, max_bandwidth=4004, force_mode=11002, force_channels=4022)
+    modes = []
+    for i in range(nframes):
+        if schedule and i in schedule:
+            for kk, v in schedule[i].items(): assert e.L.opus_encoder_ctl(e.st, req[kk], v) == 0
+        pkt, n, erng = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)
+        assert n > 1, (i, n)
+        modes.append("C" if pkt[0] & 0x80 else "H" if (pkt[0] & 0x60) == 0x60 else "S")
+        a = r.decode(pkt); b = k.decode(pkt)
+        assert a[0] == b[0] == frame, (i, modes[-1], a[0], b[0])
+        assert a[2] == b[2] == erng, (i, modes[-1], hex(a[2]), hex(b[2]), hex(erng), "".join(modes))
+        assert np.array_equal(a[1], b[1]), (i, modes[-1], "".join(modes), np.nonzero(a[1] != b[1])[0][:6])
+    if expect_modes: assert set(modes) >= set(expect_modes), "".join(modes)
+    return "".join(modes)
+
+@pytest.mark.parametrize("ch,bitrate,bw,frame", [(1, 32000, 1105, 960), (1, 24000, 1104, 960), (2, 48000, 1105, 960), (1, 28000, 1105, 480), (2, 40000, 1104, 480)])
+def test_emu_hybrid(ch, bitrate, bw, frame):
+    _run_any(ch, ch, frame, 24, seed=ch + bitrate, force_mode=1001, bitrate=bitrate, bandwidth=bw, expect_modes="H")
+
+def test_emu_silk_hybrid_switching():
+    """bandwidth moves between WB (SILK-only) and FB (hybrid) inside one stream: the CELT layer is reset / faded on a silence frame"""
+    sched = {0: dict(force_mode=1000, bandwidth=1103), 6: dict(force_mode=1001, bandwidth=1105), 12: dict(force_mode=1000, bandwidth=1103), 18: dict(force_mode=1001, bandwidth=1104)}
+    _run_any(1, 1, 960, 24, seed=9, bitrate=28000, schedule=sched, expect_modes="SH")
+    _run_any(2, 2, 960, 24, seed=10, bitrate=44000, schedule=sched, expect_modes="SH")
+
+def test_emu_celt_to_silk_transitions():
+    """CELT-only -> SILK/hybrid switches: redundancy frames and CELT-concealment cross-fades (the opposite direction needs SILK concealment)"""
+    sched = {0: dict(force_mode=1002), 8: dict(force_mode=1000, bandwidth=1103)}
+    _run_any(1, 1, 960, 16, seed=11, bitrate=32000, schedule=sched, expect_modes="CS")
+    sched = {0: dict(force_mode=1002), 8: dict(force_mode=1001, bandwidth=1105)}
+    _run_any(2, 2, 960, 16, seed=12, bitrate=48000, schedule=sched, expect_modes="CH")
