@@ -99,10 +99,12 @@ def test_gpu_dec_multiframe_packets_and_errors():
     e = RefEnc(2, bitrate=64000); r = RefDec(2)
     good = e.encode(np.ascontiguousarray(signals.music(1, seed=1)[:960]), 960)[0]
     b = oa.DecoderBatch(4, channels=2)
-    pcm, ns, rng = b.decode([good, b"\xfd\x01", b"\x08" + b"\0" * 20, good], 960)        # ok, invalid code-1 (odd length), SILK-only TOC, ok
+    pcm, ns, rng = b.decode([good, b"\xfd\x01", b"\x08" + b"\0" * 20, good], 960)        # ok, invalid code-1 (odd length), a (garbage) SILK-only packet, ok
     a = r.decode(good)
     assert int(ns[0]) == int(ns[3]) == 960 and np.array_equal(pcm[0], a[1]) and np.array_equal(pcm[3], a[1])
-    assert int(ns[1]) == -4 and int(ns[2]) == -5
+    assert int(ns[1]) == -4
+    a2 = RefDec(2).decode(b"\x08" + b"\0" * 20)                                          # a SILK-only packet decodes since the SILK decoder exists
+    assert int(ns[2]) == a2[0] == 960 and np.array_equal(pcm[2], a2[1]) and int(rng[2]) == a2[2]
     pcm, ns, rng = b.decode([good] * 4, 480)
     assert all(int(x) == -2 for x in ns)                                                 # OPUS_BUFFER_TOO_SMALL
     b.close()
