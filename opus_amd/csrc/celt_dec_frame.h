@@ -492,28 +492,53 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
       wv_sync();
       return frame_size;
    }
-   if (mode != 1002) return OA_ERR_UNIMPLEMENTED;
    int done = 0;
    while (done < frame_size) {
       int audiosize = frame_size - done;
       if (audiosize > F20) audiosize = F20;
       else if (audiosize < F20) {
          if (audiosize > F10) audiosize = F10;
-         else if (audiosize > F5 && audiosize < F10) audiosize = F5;
+         else if (mode != 1000 && audiosize > F5 && audiosize < F10) audiosize = F5;
       }
-      if (audiosize != F20 && audiosize != F10 && audiosize != F5 && audiosize != F2_5) return OA_ERR_BAD_ARG;
-      LANE0 { st->start = 0; st->stream_channels = st->stream_channels; }
+      if (mode == 1002 && audiosize != F20 && audiosize != F10 && audiosize != F5 && audiosize != F2_5) return OA_ERR_BAD_ARG;
+      i16 *pcm = pcm_out + (size_t)done * CC;
+      if (mode != 1002) {
+         /* SILK concealment (src/opus_decoder.c:404-497 with data == NULL): the decoder control of the last good frame persists */
+         wv_sync();
+         LANE0 {
+            EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
+            ec.storage = 0; ec.end_offs = 0; ec.end_window = 0; ec.nend_bits = 0; ec.nbits_total = 0; ec.offs = 0; ec.rng = 0; ec.val = 0; ec.ext = 0; ec.rem = 0; ec.error = 0;
+            WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
+            SdDecControl dc;
+            dc.nChannelsAPI = CC; dc.nChannelsInternal = gs->silk.lastChannelsInternal; dc.API_sampleRate = 48000;
+            dc.internalSampleRate = gs->silk.lastInternalRate; dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+            int decoded = 0;
+            do {
+               int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_PACKET_LOST, decoded == 0, &ec, buf, SA, SB);
+               if (n < 0) {                                                        /* "PLC failure should not be fatal" (:466-471) */
+                  n = audiosize;
+                  for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) SB->rs_out[c][i] = 0;
+               }
+               const int m = imin(n, audiosize - decoded);                        /* a 10 ms SILK frame may be longer than what is asked for (pcm_too_small, :411-420) */
+               for (int c = 0; c < CC; c++) for (int i = 0; i < m; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
+               decoded += n;
+            } while (decoded < audiosize);
+         }
+         wv_sync();
+      }
+      LANE0 { st->start = mode != 1002 ? 17 : 0; }
       wv_sync();
-      int r = celt_decode_frame_wave(L, gs, 0, audiosize, pcm_out + (size_t)done * CC);
-      if (r < 0) return r;
-      done += r;
+      if (mode != 1000) {
+         int r = celt_decode_frame_wave(L, gs, 0, imin(F20, audiosize), pcm, 0, mode != 1002);
+         if (r < 0) return r;
+      }
+      done += audiosize;
       LANE0 { st->rangeFinal = 0; st->prev_mode = mode; st->prev_redundancy = 0; }
       wv_sync();
       if (frame_size - done > 0 && frame_size <= F20) break;      /* a single call conceals one legal frame size; the caller loops */
    }
    return done;
 }
-
 
 /* OPUS_RESET_STATE of the CELT decoder (celt_decoder.c:1794-1814): everything from `rng` on, then the -28 dB energy floors */
 WV_DEVN void celt_reset_wave(WV_LDS DecLds *L, OaDecStream *gs)
@@ -555,7 +580,11 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    u32 redundant_rng = 0;
    const int celt_accum = mode != 1002;
    if (prev_mode > 0 && ((mode == 1002 && prev_mode != 1002 && !prev_red) || (mode != 1002 && prev_mode == 1002))) transition = 1;
-   if (transition && mode == 1002) return OA_ERR_UNIMPLEMENTED;                 /* needs SILK concealment for the 5 ms cross-fade source: not built yet */
+   if (transition && mode == 1002) {                                            /* SILK/hybrid -> CELT without redundancy: 5 ms of concealment in the old mode as the fade source (:388-393) */
+      const int r = oa_conceal_wave(L, gs, imin(F5, audiosize), gs->trans, CC);
+      if (r < 0) return r;
+      LANE0 { st->mode = mode; st->start = 0; }
+   }
 
    wv_sync();
    FOR_LANES(i, len) L->packet[1 + i] = data[i];
@@ -575,6 +604,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
          dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
          dc.internalSampleRate = mode == 1001 ? 16000 : bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000;
          dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+         gs->silk.lastInternalRate = dc.internalSampleRate; gs->silk.lastChannelsInternal = dc.nChannelsInternal;
          int decoded = 0, rr = 0;
          do {
             const int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
@@ -726,7 +756,6 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
       else nb += r;
       off += flen;
    }
-   if (count == -1 && ret >= 0 && wv_uni(st->prev_mode) == 1000) ret = OA_ERR_UNIMPLEMENTED;   /* SILK concealment: not built yet */
    if (count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
       while (nb < frame_size) {
          int r = oa_conceal_wave(L, gs, frame_size - nb, pcm_out + (size_t)nb * CC, CC);

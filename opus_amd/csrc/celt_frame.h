@@ -83,14 +83,19 @@ struct OaSilkChannel {
    int32_t VAD_flags[3], LBRR_flag, LBRR_flags[3];
    int32_t lossCnt, prevSignalType;
    int32_t rs_cfg[9], rs_rows[90];
-   int16_t outBuf[480], prevNLSF_Q15[16];
+   /* concealment (silk_PLC_struct, silk/structs.h:254-271) and comfort noise (silk_CNG_struct :274-281) */
+   int32_t plc_pitchL_Q8, plc_last_frame_lost, plc_rand_seed, plc_conc_energy, plc_conc_energy_shift, plc_prevGain_Q16[2], plc_fs_kHz, plc_nb_subfr, plc_subfr_length;
+   int32_t plc_randScale_Q14, plc_prevLTP_scale_Q14;
+   int32_t cng_exc_buf_Q14[320], cng_synth_state[16], cng_smth_Gain_Q16, cng_rand_seed, cng_fs_kHz;
+   int16_t outBuf[480], prevNLSF_Q15[16], plc_LTPCoef_Q14[6], plc_prevLPC_Q12[16], cng_smth_NLSF_Q15[16];
    OaSilkIndices indices;
 };
 struct OaSilkDec {
    OaSilkChannel ch[2];
    int32_t pred_prev_Q13[2];
    int16_t sMid[2], sSide[2];
-   int32_t nChannelsAPI, nChannelsInternal, prev_decode_only_middle, pad;
+   int32_t nChannelsAPI, nChannelsInternal, prev_decode_only_middle;
+   int32_t lastInternalRate, lastChannelsInternal, pad;   /* the DecControl fields that persist for concealment (src/opus_decoder.c:424-441) */
 };
 struct OaDecStream {
    OaDecScalars s;
@@ -111,6 +116,11 @@ static inline void oa_dec_stream_reset(OaDecStream *st, int channels)
    st->s.start = 0; st->s.end = OA_NB_EBANDS; st->s.disable_inv = channels == 1;
    st->s.skip_plc = 1;
    for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->oldLogE[i] = st->oldLogE2[i] = -(28 << 24);
-   for (int c = 0; c < 2; c++) { st->silk.ch[c].first_frame_after_reset = 1; st->silk.ch[c].prev_gain_Q16 = 65536; }
+   for (int c = 0; c < 2; c++) {                                  /* silk_reset_decoder + silk_CNG_Reset + silk_PLC_Reset (silk/init_decoder.c:43, CNG.c:58, PLC.c:65) */
+      OaSilkChannel *ch = &st->silk.ch[c];
+      ch->first_frame_after_reset = 1; ch->prev_gain_Q16 = 65536;
+      ch->cng_rand_seed = 3176576; ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2;
+   }
+   st->silk.lastInternalRate = 0; st->silk.lastChannelsInternal = 0;
 }
 #endif

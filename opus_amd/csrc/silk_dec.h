@@ -13,7 +13,7 @@
  *   silk_decode_l0        silk_Decode               silk/dec_API.c:142            per-packet frame/channel sequencing, LBRR skipping, resampling to the API rate
  * Everything is a serial chain per stream (one range decoder, recursive synthesis filters), so it runs on lane 0 of the wave that owns the
  * stream, in the same kernel as the CELT decoder whose LDS regions it borrows between CELT frames.  Packet loss concealment / comfort noise
- * (silk/PLC.c, silk/CNG.c) are not built yet: a lost SILK frame reports OPUS_UNIMPLEMENTED. */
+ * (silk/PLC.c:77-493 silk_PLC / _update / _conceal / _glue_frames, silk/CNG.c:79 silk_CNG) are sd_plc*, sd_cng. */
 #ifndef OPUS_AMD_SILK_DEC_H
 #define OPUS_AMD_SILK_DEC_H
 #include "silk_tables.h"
@@ -456,6 +456,8 @@ WV_DEV void sd_reset(OaSilkChannel *ch)                                         
    for (int i = 0; i < (int)(sizeof(OaSilkChannel) / 4); i++) w[i] = 0;
    ch->first_frame_after_reset = 1;
    ch->prev_gain_Q16 = 65536;
+   ch->cng_smth_Gain_Q16 = 0; ch->cng_rand_seed = 3176576;                                                  /* silk_CNG_Reset with LPC_order == 0 (CNG.c:58) */
+   ch->plc_pitchL_Q8 = 0; ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2;   /* silk_PLC_Reset (PLC.c:65) */
 }
 /* silk_decoder_set_fs (decoder_set_fs.c:35); returns nonzero when the resampler has to be re-initialised by the caller */
 WV_DEV int sd_set_fs(OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
@@ -478,7 +480,239 @@ WV_DEV int sd_set_fs(OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
    return reinit;
 }
 
-/* silk_decode_frame (decode_frame.c:43), normal / LBRR frames only */
+
+/* ---- packet loss concealment and comfort noise (silk/PLC.c, silk/CNG.c) ---- */
+WV_DEV void sd_sum_sqr_shift(i32 *energy, int *shift, const WV_LDS i16 *x, int len)                         /* sum_sqr_shift.c:36 */
+{
+   int shft = 31 - sk_clz(len);
+   i32 nrg = len;
+   for (int pass = 0; pass < 2; pass++) {
+      int i;
+      if (pass) { shft = imax(0, shft + 3 - sk_clz(nrg)); nrg = 0; }
+      for (i = 0; i < len - 1; i += 2) { const u32 t = (u32)((i32)x[i] * x[i]) + (u32)((i32)x[i + 1] * x[i + 1]); nrg = (i32)((u32)nrg + (t >> shft)); }
+      if (i < len) { const u32 t = (u32)((i32)x[i] * x[i]); nrg = (i32)((u32)nrg + (t >> shft)); }
+   }
+   *shift = shft; *energy = nrg;
+}
+WV_DEV i32 sd_sqrt_approx(i32 x)                                                                            /* Inlines.h:67 */
+{
+   if (x <= 0) return 0;
+   const int lz = sk_clz(x), rot = 24 - lz;
+   const u32 u = (u32)x;
+   const i32 frac_Q7 = (i32)((rot == 0 ? u : rot < 0 ? ((u << -rot) | (u >> (32 + rot))) : ((u << (32 - rot)) | (u >> rot))) & 0x7f);
+   i32 y = (lz & 1) ? 32768 : 46214;
+   y >>= lz >> 1;
+   return sk_mlawb(y, y, sk_mulbb(213, frac_Q7));
+}
+WV_DEV void sd_plc_reset(OaSilkChannel *ch)                                                                 /* PLC.c:65 */
+{ ch->plc_pitchL_Q8 = shl32(ch->frame_length, 7); ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2; }
+WV_DEV void sd_plc_update(OaSilkChannel *ch, const SdCtrl *c)                                               /* PLC.c:107 */
+{
+   ch->prevSignalType = ch->indices.signalType;
+   i32 LTP_Gain_Q14 = 0;
+   if (ch->indices.signalType == SD_TYPE_VOICED) {
+      for (int j = 0; j * ch->subfr_length < c->pitchL[ch->nb_subfr - 1]; j++) {
+         if (j == ch->nb_subfr) break;
+         i32 t = 0;
+         for (int i = 0; i < 5; i++) t += c->LTPCoef_Q14[(ch->nb_subfr - 1 - j) * 5 + i];
+         if (t > LTP_Gain_Q14) {
+            LTP_Gain_Q14 = t;
+            for (int i = 0; i < 5; i++) ch->plc_LTPCoef_Q14[i] = c->LTPCoef_Q14[(ch->nb_subfr - 1 - j) * 5 + i];
+            ch->plc_pitchL_Q8 = shl32(c->pitchL[ch->nb_subfr - 1 - j], 8);
+         }
+      }
+      for (int i = 0; i < 5; i++) ch->plc_LTPCoef_Q14[i] = 0;
+      ch->plc_LTPCoef_Q14[2] = (i16)LTP_Gain_Q14;
+      if (LTP_Gain_Q14 < 11469) {
+         const i32 scale_Q10 = shl32(11469, 10) / imax(LTP_Gain_Q14, 1);
+         for (int i = 0; i < 5; i++) ch->plc_LTPCoef_Q14[i] = (i16)(sk_mulbb(ch->plc_LTPCoef_Q14[i], scale_Q10) >> 10);
+      } else if (LTP_Gain_Q14 > 15565) {
+         const i32 scale_Q14 = shl32(15565, 14) / imax(LTP_Gain_Q14, 1);
+         for (int i = 0; i < 5; i++) ch->plc_LTPCoef_Q14[i] = (i16)(sk_mulbb(ch->plc_LTPCoef_Q14[i], scale_Q14) >> 14);
+      }
+   } else {
+      ch->plc_pitchL_Q8 = shl32(sk_mulbb(ch->fs_kHz, 18), 8);
+      for (int i = 0; i < 5; i++) ch->plc_LTPCoef_Q14[i] = 0;
+   }
+   for (int i = 0; i < ch->LPC_order; i++) ch->plc_prevLPC_Q12[i] = c->PredCoef_Q12[1][i];
+   ch->plc_prevLTP_scale_Q14 = (i16)c->LTP_scale_Q14;
+   ch->plc_prevGain_Q16[0] = c->Gains_Q16[ch->nb_subfr - 2]; ch->plc_prevGain_Q16[1] = c->Gains_Q16[ch->nb_subfr - 1];
+   ch->plc_subfr_length = ch->subfr_length; ch->plc_nb_subfr = ch->nb_subfr;
+}
+WV_DEV void sd_plc_conceal(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, const SdScratch &S)             /* PLC.c:198 */
+{
+   const int mem = ch->ltp_mem_length, L = ch->subfr_length, P = ch->LPC_order;
+   WV_LDS i32 *sLTP_Q14 = S.sLTP_Q15;
+   i32 prevGain_Q10[2] = { ch->plc_prevGain_Q16[0] >> 6, ch->plc_prevGain_Q16[1] >> 6 };
+   if (ch->first_frame_after_reset) for (int i = 0; i < 16; i++) ch->plc_prevLPC_Q12[i] = 0;
+   /* energies of the last two subframes of the previous excitation decide where the noise is drawn from (PLC.c:172-196) */
+   i32 energy1, energy2; int shift1, shift2;
+   {
+      WV_LDS i16 *eb = S.pulses;
+      for (int k = 0; k < 2; k++) for (int i = 0; i < L; i++) eb[k * L + i] = (i16)sk_sat16(sk_mulww(ch->exc_Q14[i + (k + ch->nb_subfr - 2) * L], prevGain_Q10[k]) >> 8);
+      sd_sum_sqr_shift(&energy1, &shift1, eb, L); sd_sum_sqr_shift(&energy2, &shift2, eb + L, L);
+   }
+   const i32 *rand_ptr;
+   if ((energy1 >> shift2) < (energy2 >> shift1)) rand_ptr = &ch->exc_Q14[imax(0, (ch->plc_nb_subfr - 1) * ch->plc_subfr_length - 128)];
+   else rand_ptr = &ch->exc_Q14[imax(0, ch->plc_nb_subfr * ch->plc_subfr_length - 128)];
+   i16 *B_Q14 = ch->plc_LTPCoef_Q14;
+   i16 rand_scale_Q14 = (i16)ch->plc_randScale_Q14;
+   const int att = imin(1, ch->lossCnt);
+   const i32 harm_Gain_Q15 = att ? 31130 : 32440;
+   i32 rand_Gain_Q15 = ch->prevSignalType == SD_TYPE_VOICED ? (att ? 26214 : 31130) : (att ? 29491 : 32440);
+   sd_bwexpander(ch->plc_prevLPC_Q12, P, 64881);                                                          /* SILK_FIX_CONST(0.99, 16) */
+   i16 A_Q12[16];
+   for (int i = 0; i < 16; i++) A_Q12[i] = i < P ? ch->plc_prevLPC_Q12[i] : (i16)0;
+   if (ch->lossCnt == 0) {
+      rand_scale_Q14 = 1 << 14;
+      if (ch->prevSignalType == SD_TYPE_VOICED) {
+         for (int i = 0; i < 5; i++) rand_scale_Q14 = (i16)(rand_scale_Q14 - B_Q14[i]);
+         rand_scale_Q14 = (i16)imax(3277, rand_scale_Q14);
+         rand_scale_Q14 = (i16)(sk_mulbb(rand_scale_Q14, ch->plc_prevLTP_scale_Q14) >> 14);
+      } else {
+         const i32 invGain_Q30 = sd_lpc_inverse_pred_gain(ch->plc_prevLPC_Q12, P);
+         i32 down_scale_Q30 = imin(((i32)1 << 30) >> 3, invGain_Q30);
+         down_scale_Q30 = imax(((i32)1 << 30) >> 8, down_scale_Q30);
+         down_scale_Q30 = shl32(down_scale_Q30, 3);
+         rand_Gain_Q15 = sk_mulwb(down_scale_Q30, rand_Gain_Q15) >> 14;
+      }
+   }
+   i32 rand_seed = ch->plc_rand_seed;
+   int lag = sk_rround(ch->plc_pitchL_Q8, 8);
+   int sLTP_buf_idx = mem;
+   int idx = mem - lag - P - 2;
+   for (int n = 0; n < mem - idx; n++) {                                                                  /* silk_LPC_analysis_filter(&sLTP[idx], &outBuf[idx], A_Q12, mem - idx, P) */
+      i32 o = 0;
+      if (n >= P) {
+         const i16 *in = &ch->outBuf[idx + n];
+         i32 pred = 0;
+         for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
+         o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
+      }
+      S.sLTP[idx + n] = (i16)o;
+   }
+   i32 inv_gain_Q30 = sk_inverse32_varQ(ch->plc_prevGain_Q16[1], 46);
+   inv_gain_Q30 = imin(inv_gain_Q30, 2147483647 >> 1);
+   for (int i = idx + P; i < mem; i++) sLTP_Q14[i] = sk_mulwb(inv_gain_Q30, S.sLTP[i]);
+   for (int k = 0; k < ch->nb_subfr; k++) {
+      for (int i = 0; i < L; i++) {
+         const WV_LDS i32 *pl = &sLTP_Q14[sLTP_buf_idx - lag + 2];
+         i32 LTP_pred_Q12 = 2;
+         for (int j = 0; j < 5; j++) LTP_pred_Q12 = sk_mlawb(LTP_pred_Q12, pl[-j], B_Q14[j]);
+         rand_seed = sk_rand(rand_seed);
+         const int ri = (rand_seed >> 25) & 127;
+         sLTP_Q14[sLTP_buf_idx] = shl32(sk_mlawb(LTP_pred_Q12, rand_ptr[ri], rand_scale_Q14), 2);
+         sLTP_buf_idx++;
+      }
+      for (int j = 0; j < 5; j++) B_Q14[j] = (i16)(sk_mulbb(harm_Gain_Q15, B_Q14[j]) >> 15);
+      rand_scale_Q14 = (i16)(sk_mulbb(rand_scale_Q14, rand_Gain_Q15) >> 15);
+      ch->plc_pitchL_Q8 = sk_mlawb(ch->plc_pitchL_Q8, ch->plc_pitchL_Q8, 655);
+      ch->plc_pitchL_Q8 = imin(ch->plc_pitchL_Q8, shl32(sk_mulbb(18, ch->fs_kHz), 8));
+      lag = sk_rround(ch->plc_pitchL_Q8, 8);
+   }
+   WV_LDS i32 *sLPC = &sLTP_Q14[mem - 16];
+   for (int i = 0; i < 16; i++) sLPC[i] = ch->sLPC_Q14_buf[i];
+   for (int i = 0; i < ch->frame_length; i++) {
+      i32 LPC_pred_Q10 = P >> 1;
+      for (int j = 0; j < P; j++) LPC_pred_Q10 = sk_mlawb(LPC_pred_Q10, sLPC[16 + i - 1 - j], A_Q12[j]);
+      sLPC[16 + i] = sk_add_sat(sLPC[16 + i], sk_shl_sat(LPC_pred_Q10, 4));
+      frame[i] = (i16)sk_sat16(sk_sat16(sk_rround(sk_mulww(sLPC[16 + i], prevGain_Q10[1]), 8)));
+   }
+   for (int i = 0; i < 16; i++) ch->sLPC_Q14_buf[i] = sLPC[ch->frame_length + i];
+   ch->plc_rand_seed = rand_seed;
+   ch->plc_randScale_Q14 = rand_scale_Q14;
+   for (int i = 0; i < 4; i++) c->pitchL[i] = lag;
+}
+WV_DEV void sd_plc(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, int lost, const SdScratch &S)           /* PLC.c:77 */
+{
+   if (ch->fs_kHz != ch->plc_fs_kHz) { sd_plc_reset(ch); ch->plc_fs_kHz = ch->fs_kHz; }
+   if (lost) { sd_plc_conceal(ch, c, frame, S); ch->lossCnt++; }
+   else sd_plc_update(ch, c);
+}
+WV_DEV void sd_plc_glue_frames(OaSilkChannel *ch, WV_LDS i16 *frame, int length)                            /* PLC.c:441 */
+{
+   if (ch->lossCnt) {
+      int sh; sd_sum_sqr_shift(&ch->plc_conc_energy, &sh, frame, length); ch->plc_conc_energy_shift = sh;
+      ch->plc_last_frame_lost = 1;
+   } else {
+      if (ch->plc_last_frame_lost) {
+         i32 energy; int energy_shift;
+         sd_sum_sqr_shift(&energy, &energy_shift, frame, length);
+         if (energy_shift > ch->plc_conc_energy_shift) ch->plc_conc_energy = ch->plc_conc_energy >> (energy_shift - ch->plc_conc_energy_shift);
+         else if (energy_shift < ch->plc_conc_energy_shift) energy = energy >> (ch->plc_conc_energy_shift - energy_shift);
+         if (energy > ch->plc_conc_energy) {
+            int LZ = sk_clz(ch->plc_conc_energy) - 1;
+            ch->plc_conc_energy = shl32(ch->plc_conc_energy, LZ);
+            energy = energy >> imax(24 - LZ, 0);
+            const i32 frac_Q24 = ch->plc_conc_energy / imax(energy, 1);
+            i32 gain_Q16 = shl32(sd_sqrt_approx(frac_Q24), 4);
+            i32 slope_Q16 = (((i32)1 << 16) - gain_Q16) / length;
+            slope_Q16 = shl32(slope_Q16, 2);
+            for (int i = 0; i < length; i++) {
+               frame[i] = (i16)sk_mulwb(gain_Q16, frame[i]);
+               gain_Q16 += slope_Q16;
+               if (gain_Q16 > (i32)1 << 16) break;
+            }
+         }
+      }
+      ch->plc_last_frame_lost = 0;
+   }
+}
+WV_DEV void sd_cng_reset(OaSilkChannel *ch)                                                                 /* CNG.c:58 */
+{
+   const i32 step = 32767 / (ch->LPC_order + 1);
+   i32 acc = 0;
+   for (int i = 0; i < ch->LPC_order; i++) { acc += step; ch->cng_smth_NLSF_Q15[i] = (i16)acc; }
+   ch->cng_smth_Gain_Q16 = 0; ch->cng_rand_seed = 3176576;
+}
+WV_DEV void sd_cng(OaSilkChannel *ch, const SdCtrl *c, WV_LDS i16 *frame, int length, const SdScratch &S)   /* CNG.c:79 */
+{
+   if (ch->fs_kHz != ch->cng_fs_kHz) { sd_cng_reset(ch); ch->cng_fs_kHz = ch->fs_kHz; }
+   if (ch->lossCnt == 0 && ch->prevSignalType == SD_TYPE_NO_VOICE) {
+      for (int i = 0; i < ch->LPC_order; i++) ch->cng_smth_NLSF_Q15[i] = (i16)(ch->cng_smth_NLSF_Q15[i] + sk_mulwb((i32)ch->prevNLSF_Q15[i] - (i32)ch->cng_smth_NLSF_Q15[i], 16348));
+      i32 max_Gain_Q16 = 0; int subfr = 0;
+      for (int i = 0; i < ch->nb_subfr; i++) if (c->Gains_Q16[i] > max_Gain_Q16) { max_Gain_Q16 = c->Gains_Q16[i]; subfr = i; }
+      for (int i = (ch->nb_subfr - 1) * ch->subfr_length - 1; i >= 0; i--) ch->cng_exc_buf_Q14[ch->subfr_length + i] = ch->cng_exc_buf_Q14[i];
+      for (int i = 0; i < ch->subfr_length; i++) ch->cng_exc_buf_Q14[i] = ch->exc_Q14[subfr * ch->subfr_length + i];
+      for (int i = 0; i < ch->nb_subfr; i++) {
+         ch->cng_smth_Gain_Q16 += sk_mulwb(c->Gains_Q16[i] - ch->cng_smth_Gain_Q16, 4634);
+         if (sk_mulww(ch->cng_smth_Gain_Q16, 46396) > c->Gains_Q16[i]) ch->cng_smth_Gain_Q16 = c->Gains_Q16[i];
+      }
+   }
+   if (ch->lossCnt) {
+      WV_LDS i32 *sig = S.sLTP_Q15;
+      i32 gain_Q16 = sk_mulww(ch->plc_randScale_Q14, ch->plc_prevGain_Q16[1]);
+      if (gain_Q16 >= (1 << 21) || ch->cng_smth_Gain_Q16 > (1 << 23)) {
+         gain_Q16 = (gain_Q16 >> 16) * (gain_Q16 >> 16);
+         gain_Q16 = (ch->cng_smth_Gain_Q16 >> 16) * (ch->cng_smth_Gain_Q16 >> 16) - shl32(gain_Q16, 5);
+         gain_Q16 = shl32(sd_sqrt_approx(gain_Q16), 16);
+      } else {
+         gain_Q16 = sk_mulww(gain_Q16, gain_Q16);
+         gain_Q16 = sk_mulww(ch->cng_smth_Gain_Q16, ch->cng_smth_Gain_Q16) - shl32(gain_Q16, 5);
+         gain_Q16 = shl32(sd_sqrt_approx(gain_Q16), 8);
+      }
+      const i32 gain_Q10 = gain_Q16 >> 6;
+      {  /* silk_CNG_exc (CNG.c:36) */
+         int exc_mask = 255; while (exc_mask > length) exc_mask >>= 1;
+         i32 seed = ch->cng_rand_seed;
+         for (int i = 0; i < length; i++) { seed = sk_rand(seed); sig[16 + i] = ch->cng_exc_buf_Q14[(seed >> 24) & exc_mask]; }
+         ch->cng_rand_seed = seed;
+      }
+      i16 A_Q12[16];
+      for (int i = 0; i < 16; i++) A_Q12[i] = 0;
+      sd_nlsf2a(A_Q12, ch->cng_smth_NLSF_Q15, ch->LPC_order);
+      for (int i = 0; i < 16; i++) sig[i] = ch->cng_synth_state[i];
+      for (int i = 0; i < length; i++) {
+         i32 LPC_pred_Q10 = ch->LPC_order >> 1;
+         for (int j = 0; j < ch->LPC_order; j++) LPC_pred_Q10 = sk_mlawb(LPC_pred_Q10, sig[16 + i - 1 - j], A_Q12[j]);
+         sig[16 + i] = sk_add_sat(sig[16 + i], sk_shl_sat(LPC_pred_Q10, 4));
+         frame[i] = (i16)sk_sat16((i32)frame[i] + sk_sat16(sk_rround(sk_mulww(sig[16 + i], gain_Q10), 8)));
+      }
+      for (int i = 0; i < 16; i++) ch->cng_synth_state[i] = sig[length + i];
+   } else for (int i = 0; i < ch->LPC_order; i++) ch->cng_synth_state[i] = 0;
+}
+
+/* silk_decode_frame (decode_frame.c:43) */
 WV_DEV int sd_decode_frame(OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int lostFlag, int condCoding, const SdScratch &S)
 {
    const int L = ch->frame_length;
@@ -491,10 +725,18 @@ WV_DEV int sd_decode_frame(OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int los
       const int mv = ch->ltp_mem_length - L;
       for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
       for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
+      sd_plc(ch, &ctrl, pOut, 0, S);
       ch->lossCnt = 0;
       ch->prevSignalType = ch->indices.signalType;
       ch->first_frame_after_reset = 0;
-   } else return OA_ERR_UNIMPLEMENTED;                                                                       /* concealment: not built yet */
+   } else {
+      sd_plc(ch, &ctrl, pOut, 1, S);
+      const int mv = ch->ltp_mem_length - L;
+      for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
+      for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
+   }
+   sd_cng(ch, &ctrl, pOut, L, S);
+   sd_plc_glue_frames(ch, pOut, L);
    ch->lagPrev = ctrl.pitchL[ch->nb_subfr - 1];
    return L;
 }

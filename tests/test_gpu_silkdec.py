@@ -78,3 +78,30 @@ def test_gpu_hybrid_and_mode_switching(ch, frame, bitrate, schedule):
         assert a[0] == frame == pcm.shape[0], (i, a[0], pcm.shape)
         assert d.final_range() == a[2] == erng, i
         assert np.array_equal(pcm.reshape(-1, ch), a[1]), i
+
+@pytest.mark.parametrize("ch,mode,bw,bitrate,frame", [(1, 1000, 1103, 20000, 960), (2, 1000, 1103, 36000, 960), (1, 1001, 1105, 32000, 960), (2, 1001, 1104, 44000, 960),
+                                                    (1, 1000, 1102, 16000, 480), (1, 1000, 1101, 12000, 1920)])
+def test_gpu_silk_packet_loss(ch, mode, bw, bitrate, frame):
+    """lost packets in SILK-only and hybrid streams: SILK concealment + comfort noise (+ CELT noise concealment above 8 kHz), recovery glue"""
+    import opus_amd
+    pk = _mode_stream(ch, frame, 30, mode + bw + frame, {0: dict(force_mode=mode, bandwidth=bw)}, bitrate=bitrate)
+    lose = {3, 7, 8, 9, 14, 15, 16, 17, 18, 19, 20, 24}
+    r = RefDec(ch); d = opus_amd.OpusDecoder(48000, ch)
+    for i, (pkt, erng) in enumerate(pk):
+        if i in lose: pkt = b""
+        a = r.decode(pkt, frame); pcm = d.decode(pkt if pkt else None, frame)
+        assert a[0] == frame == pcm.shape[0], (i, a[0], pcm.shape)
+        assert d.final_range() == a[2], i
+        assert np.array_equal(pcm.reshape(-1, ch), a[1]), (i, i in lose)
+
+def test_gpu_all_mode_transitions_with_loss():
+    import opus_amd
+    sched = {0: dict(force_mode=1000, bandwidth=1103), 8: dict(force_mode=1002, bandwidth=1105), 16: dict(force_mode=1001, bandwidth=1105), 24: dict(force_mode=1002)}
+    for ch, lose in ((1, set()), (2, set()), (1, {7, 8, 15, 16, 23, 24, 25})):
+        pk = _mode_stream(ch, 960, 32, 50 + ch, sched, bitrate=36000 * ch)
+        r = RefDec(ch); d = opus_amd.OpusDecoder(48000, ch)
+        for i, (pkt, erng) in enumerate(pk):
+            if i in lose: pkt = b""
+            a = r.decode(pkt, 960); pcm = d.decode(pkt if pkt else None, 960)
+            assert a[0] == 960 == pcm.shape[0] and d.final_range() == a[2], (ch, i)
+            assert np.array_equal(pcm.reshape(-1, ch), a[1]), (ch, i, i in lose)

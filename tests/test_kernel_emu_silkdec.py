@@ -94,3 +94,31 @@ def test_emu_celt_to_silk_transitions():
     _run_any(1, 1, 960, 16, seed=11, bitrate=32000, schedule=sched, expect_modes="CS")
     sched = {0: dict(force_mode=1002), 8: dict(force_mode=1001, bandwidth=1105)}
     _run_any(2, 2, 960, 16, seed=12, bitrate=48000, schedule=sched, expect_modes="CH")
+
+def _run_loss(ch, frame, nframes, seed, lose, schedule=None, **ctl):
+    """packets listed in `lose` never reach the decoders (opus_decode(NULL, 0, frame)): SILK / hybrid concealment, comfort noise, the energy glue
+    on recovery, and concealment-driven mode transitions must match the reference sample for sample"""
+    sig = speechy(nframes, ch, seed, frame)
+    e = RefEnc(ch, application=2048, **ctl); r = RefDec(ch); k = EmuDec(ch)
+    req = dict(bitrate=4002, bandwidth=4008, max_bandwidth=4004, force_mode=11002)
+    for i in range(nframes):
+        if schedule and i in schedule:
+            for kk, v in schedule[i].items(): assert e.L.opus_encoder_ctl(e.st, req[kk], v) == 0
+        pkt, n, erng = e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)
+        if i in lose: pkt = b""
+        a = r.decode(pkt, frame); b = k.decode(pkt, frame)
+        assert a[0] == b[0] == frame, (i, a[0], b[0])
+        assert a[2] == b[2], (i, hex(a[2]), hex(b[2]))
+        assert np.array_equal(a[1], b[1]), (i, i in lose, np.nonzero(a[1] != b[1])[0][:6])
+
+@pytest.mark.parametrize("ch,mode,bw,bitrate,frame", [(1, 1000, 1103, 20000, 960), (1, 1000, 1101, 10000, 960), (2, 1000, 1103, 36000, 960), (1, 1001, 1105, 32000, 960),
+                                                    (2, 1001, 1104, 44000, 960), (1, 1000, 1102, 16000, 480), (1, 1001, 1105, 30000, 480), (1, 1000, 1103, 20000, 1920)])
+def test_emu_silk_packet_loss(ch, mode, bw, bitrate, frame):
+    lose = {3, 7, 8, 9, 14, 15, 16, 17, 18, 19, 20, 24}
+    _run_loss(ch, frame, 30, seed=mode + bw + frame, lose=lose, force_mode=mode, bandwidth=bw, bitrate=bitrate)
+
+def test_emu_silk_to_celt_transition_and_loss_across_modes():
+    sched = {0: dict(force_mode=1000, bandwidth=1103), 8: dict(force_mode=1002, bandwidth=1105), 16: dict(force_mode=1001, bandwidth=1105), 24: dict(force_mode=1002)}
+    _run_any(1, 1, 960, 32, seed=21, bitrate=36000, schedule=sched, expect_modes="SCH")
+    _run_any(2, 2, 960, 32, seed=22, bitrate=56000, schedule=sched, expect_modes="SCH")
+    _run_loss(1, 960, 32, seed=23, lose={7, 8, 15, 16, 23, 24, 25}, schedule=sched, bitrate=36000)     # the packets around every switch are lost
