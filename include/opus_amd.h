@@ -121,13 +121,14 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);
 OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
 
 
-/* ================= decoder: CELT-only Opus packets, 48 kHz output =================
+/* ================= decoder: every Opus packet mode (CELT-only, SILK-only, hybrid), 48 kHz output =================
  * Classic API — same names, arguments and error codes as reference/include/opus.h: opus_decoder_get_size :460,
  * opus_decoder_create :477, opus_decoder_init :494, opus_decode :516, opus_decoder_ctl :586, opus_decoder_destroy :591
  * (definitions replaced: reference/src/opus_decoder.c:121, :186, :135, :890, :1033, :1246).  The OpusDecoder blob is flat
- * host memory with the complete state (memcpy-able).  Scope this round: CELT-only packets (any frame count / size the
- * TOC allows), mono/stereo streams into mono/stereo output, packet-loss concealment (data == NULL or len == 0, and decode_fec = 1,
- * which for CELT-only streams conceals as well).  SILK / hybrid packets and Fs != 48000 return OPUS_UNIMPLEMENTED. */
+ * host memory with the complete state (memcpy-able).  Scope: CELT-only, SILK-only (NB/MB/WB, 10-60 ms) and hybrid packets, any frame count /
+ * size the TOC allows, mono/stereo streams into mono/stereo output, mode transitions in every direction incl. the 5 ms CELT redundancy frames,
+ * packet-loss concealment in every mode (data == NULL or len == 0: CELT pitch/noise PLC, SILK PLC + comfort noise, hybrid = both) and DTX frames.
+ * decode_fec = 1 conceals instead of decoding the LBRR copy (legal, lower quality).  Fs != 48000 returns OPUS_UNIMPLEMENTED. */
 typedef struct OpusDecoder OpusDecoder;
 OPUS_AMD_EXPORT int opus_decoder_get_size(int channels);
 OPUS_AMD_EXPORT OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error);

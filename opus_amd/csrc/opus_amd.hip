@@ -585,6 +585,6 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 #include "opus_ms_host.h"
 #include "silk_batch.h"
 extern "C" {
-const char *opus_get_version_string(void) { return "opus-amd 0.2 (gfx950, fixed-point bit-exact CELT encoder + decoder)"; }
+const char *opus_get_version_string(void) { return "opus-amd 0.3 (gfx950, fixed-point bit-exact CELT encoder, full Opus decoder, SILK operator kernels)"; }
 
 } /* extern "C" */
