@@ -14,6 +14,8 @@
 #include "silk_nsq.h"          /* SILK fixed-point primitives */
 #include "silk_resampler.h"
 #include "silk_dec_api.h"      /* SILK decoder (lane-0 serial), shares this kernel's wave, range decoder and LDS */
+static_assert(sizeof(SilkLdsAll) <= sizeof(((DecLds *)0)->A) + sizeof(((DecLds *)0)->BC), "SILK scratch + staged state must fit the CELT decoder's phase regions");
+static_assert(OA_SILK_HOT_BYTES % 4 == 0 && sizeof(OaSilkChannel) % 4 == 0, "SILK state is copied as dwords");
 
 /* ---- inverse MDCT of one block (mdct.c:268): in = N2 bins at `stride` (LDS), out = N2 + overlap samples, TDAC into out[0..overlap) ---- */
 WV_DEVN void mdct_backward_wave(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int stride, WV_LDS int *aux)
@@ -504,17 +506,21 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
       i16 *pcm = pcm_out + (size_t)done * CC;
       if (mode != 1002) {
          /* SILK concealment (src/opus_decoder.c:404-497 with data == NULL): the decoder control of the last good frame persists */
+         WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->A;
+         wv_sync();
+         FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];           /* SILK state -> LDS, coalesced */
          wv_sync();
          LANE0 {
+            OaSilkDec *sdh = (OaSilkDec *)(i32 *)SL->hot;
             EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
             ec.storage = 0; ec.end_offs = 0; ec.end_window = 0; ec.nend_bits = 0; ec.nbits_total = 0; ec.offs = 0; ec.rng = 0; ec.val = 0; ec.ext = 0; ec.rem = 0; ec.error = 0;
-            WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
+            WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
             SdDecControl dc;
-            dc.nChannelsAPI = CC; dc.nChannelsInternal = gs->silk.lastChannelsInternal; dc.API_sampleRate = 48000;
-            dc.internalSampleRate = gs->silk.lastInternalRate; dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+            dc.nChannelsAPI = CC; dc.nChannelsInternal = sdh->lastChannelsInternal; dc.API_sampleRate = 48000;
+            dc.internalSampleRate = sdh->lastInternalRate; dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
             int decoded = 0;
             do {
-               int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_PACKET_LOST, decoded == 0, &ec, buf, SA, SB);
+               int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_PACKET_LOST, decoded == 0, &ec, buf, SA, SB);
                if (n < 0) {                                                        /* "PLC failure should not be fatal" (:466-471) */
                   n = audiosize;
                   for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) SB->rs_out[c][i] = 0;
@@ -524,6 +530,8 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
                decoded += n;
             } while (decoded < audiosize);
          }
+         wv_sync();
+         FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) ((i32 *)&gs->silk)[i] = SL->hot[i];
          wv_sync();
       }
       LANE0 { st->start = mode != 1002 ? 17 : 0; }
@@ -591,23 +599,27 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    wv_sync();
    if (mode != 1002) {
       /* ---- SILK part (:404-497) ---- */
+      WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->A;
+      FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];              /* SILK state -> LDS, coalesced */
+      wv_sync();
       LANE0 {
+         OaSilkDec *sdh = (OaSilkDec *)(i32 *)SL->hot;
          EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
          k_ec_dec_init(&ec, buf, (u32)len);
-         WV_LDS SilkLdsA *SA = (WV_LDS SilkLdsA *)&L->A; WV_LDS SilkLdsB *SB = (WV_LDS SilkLdsB *)&L->BC;
+         WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
          if (prev_mode == 1002) {                                               /* silk_ResetDecoder (silk/dec_API.c:91) */
-            sd_reset(&gs->silk.ch[0]); sd_reset(&gs->silk.ch[1]);
-            gs->silk.pred_prev_Q13[0] = gs->silk.pred_prev_Q13[1] = 0; gs->silk.sMid[0] = gs->silk.sMid[1] = gs->silk.sSide[0] = gs->silk.sSide[1] = 0;
-            gs->silk.prev_decode_only_middle = 0;
+            sd_reset(&sdh->ch[0]); sd_reset(&sdh->ch[1]);
+            sdh->pred_prev_Q13[0] = sdh->pred_prev_Q13[1] = 0; sdh->sMid[0] = sdh->sMid[1] = sdh->sSide[0] = sdh->sSide[1] = 0;
+            sdh->prev_decode_only_middle = 0;
          }
          SdDecControl dc;
          dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
          dc.internalSampleRate = mode == 1001 ? 16000 : bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000;
          dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
-         gs->silk.lastInternalRate = dc.internalSampleRate; gs->silk.lastChannelsInternal = dc.nChannelsInternal;
+         sdh->lastInternalRate = dc.internalSampleRate; sdh->lastChannelsInternal = dc.nChannelsInternal;
          int decoded = 0, rr = 0;
          do {
-            const int n = silk_decode_l0(&gs->silk, dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
+            const int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
             if (n < 0) { rr = n; break; }
             for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
             decoded += n;
@@ -627,6 +639,8 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
          ec_st(&L->ec_silk, &ec);
          sh->r[0] = rr; sh->r[1] = red; sh->r[2] = c2s; sh->r[3] = rbytes; sh->r[4] = newlen;
       }
+      FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) ((i32 *)&gs->silk)[i] = SL->hot[i];
+      wv_sync();
       const int rr = wv_uni(sh->r[0]);
       if (rr < 0) return rr;
       redundancy = wv_uni(sh->r[1]); celt_to_silk = wv_uni(sh->r[2]); redundancy_bytes = wv_uni(sh->r[3]); len = wv_uni(sh->r[4]);

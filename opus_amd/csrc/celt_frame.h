@@ -86,7 +86,7 @@ struct OaSilkChannel {
    /* concealment (silk_PLC_struct, silk/structs.h:254-271) and comfort noise (silk_CNG_struct :274-281) */
    int32_t plc_pitchL_Q8, plc_last_frame_lost, plc_rand_seed, plc_conc_energy, plc_conc_energy_shift, plc_prevGain_Q16[2], plc_fs_kHz, plc_nb_subfr, plc_subfr_length;
    int32_t plc_randScale_Q14, plc_prevLTP_scale_Q14;
-   int32_t cng_exc_buf_Q14[320], cng_synth_state[16], cng_smth_Gain_Q16, cng_rand_seed, cng_fs_kHz;
+   int32_t cng_synth_state[16], cng_smth_Gain_Q16, cng_rand_seed, cng_fs_kHz;   /* (CNG_exc_buf_Q14 is cold and lives at the end of OaSilkDec) */
    int16_t outBuf[480], prevNLSF_Q15[16], plc_LTPCoef_Q14[6], plc_prevLPC_Q12[16], cng_smth_NLSF_Q15[16];
    OaSilkIndices indices;
 };
@@ -96,7 +96,10 @@ struct OaSilkDec {
    int16_t sMid[2], sSide[2];
    int32_t nChannelsAPI, nChannelsInternal, prev_decode_only_middle;
    int32_t lastInternalRate, lastChannelsInternal, pad;   /* the DecControl fields that persist for concealment (src/opus_decoder.c:424-441) */
+   /* ---- everything above is staged in LDS while the SILK layer runs (OA_SILK_HOT_BYTES); below: cold, stays in HBM ---- */
+   int32_t cng_exc_buf_Q14[2][320];
 };
+#define OA_SILK_HOT_BYTES (sizeof(OaSilkDec) - 2 * 320 * sizeof(int32_t))
 struct OaDecStream {
    OaDecScalars s;
    int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], backgroundLogE[2 * OA_NB_EBANDS];

@@ -361,7 +361,7 @@ WV_DEV void sd_decode_parameters(OaSilkChannel *ch, SdCtrl *c, int condCoding)  
    }
 }
 
-struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; };
+struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; i32 *cng_exc; /* this channel's CNG excitation buffer (HBM) */ };
 
 WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)               /* decode_core.c:38 */
 {
@@ -672,8 +672,8 @@ WV_DEV void sd_cng(OaSilkChannel *ch, const SdCtrl *c, WV_LDS i16 *frame, int le
       for (int i = 0; i < ch->LPC_order; i++) ch->cng_smth_NLSF_Q15[i] = (i16)(ch->cng_smth_NLSF_Q15[i] + sk_mulwb((i32)ch->prevNLSF_Q15[i] - (i32)ch->cng_smth_NLSF_Q15[i], 16348));
       i32 max_Gain_Q16 = 0; int subfr = 0;
       for (int i = 0; i < ch->nb_subfr; i++) if (c->Gains_Q16[i] > max_Gain_Q16) { max_Gain_Q16 = c->Gains_Q16[i]; subfr = i; }
-      for (int i = (ch->nb_subfr - 1) * ch->subfr_length - 1; i >= 0; i--) ch->cng_exc_buf_Q14[ch->subfr_length + i] = ch->cng_exc_buf_Q14[i];
-      for (int i = 0; i < ch->subfr_length; i++) ch->cng_exc_buf_Q14[i] = ch->exc_Q14[subfr * ch->subfr_length + i];
+      for (int i = (ch->nb_subfr - 1) * ch->subfr_length - 1; i >= 0; i--) S.cng_exc[ch->subfr_length + i] = S.cng_exc[i];
+      for (int i = 0; i < ch->subfr_length; i++) S.cng_exc[i] = ch->exc_Q14[subfr * ch->subfr_length + i];
       for (int i = 0; i < ch->nb_subfr; i++) {
          ch->cng_smth_Gain_Q16 += sk_mulwb(c->Gains_Q16[i] - ch->cng_smth_Gain_Q16, 4634);
          if (sk_mulww(ch->cng_smth_Gain_Q16, 46396) > c->Gains_Q16[i]) ch->cng_smth_Gain_Q16 = c->Gains_Q16[i];
@@ -695,7 +695,7 @@ WV_DEV void sd_cng(OaSilkChannel *ch, const SdCtrl *c, WV_LDS i16 *frame, int le
       {  /* silk_CNG_exc (CNG.c:36) */
          int exc_mask = 255; while (exc_mask > length) exc_mask >>= 1;
          i32 seed = ch->cng_rand_seed;
-         for (int i = 0; i < length; i++) { seed = sk_rand(seed); sig[16 + i] = ch->cng_exc_buf_Q14[(seed >> 24) & exc_mask]; }
+         for (int i = 0; i < length; i++) { seed = sk_rand(seed); sig[16 + i] = S.cng_exc[(seed >> 24) & exc_mask]; }
          ch->cng_rand_seed = seed;
       }
       i16 A_Q12[16];

@@ -5,9 +5,12 @@
 #define OPUS_AMD_SILK_DEC_API_H
 #include "silk_dec.h"
 
-/* scratch overlaid on the CELT decoder's phase regions (free while SILK runs): A (7,680 B) and BC (8,640 B) */
+/* scratch overlaid on the CELT decoder's phase regions (free while SILK runs): A (7,680 B) and BC (8,640 B), contiguous = 16,320 B:
+ * 5,904 B synthesis scratch + 4,096 B resampler staging + the hot part of the stream's SILK state (both channels, 6,168 B) so that the lane-0
+ * code never waits on HBM (its first version kept the state in HBM: 1.2 ms per frame, two orders of magnitude behind one CPU core) */
 struct SilkLdsA { i32 sLTP_Q15[640]; i32 res_Q14[80]; i32 sLPC_Q14[96]; i16 sLTP[320]; i16 pulses[336]; i16 tmp[16]; i16 xq[2][324]; };
 struct SilkLdsB { i16 rs_out[2][960]; ResamplerLdsT<1> ring; };
+struct SilkLdsAll { SilkLdsA a; SilkLdsB b; i32 hot[(OA_SILK_HOT_BYTES + 3) / 4]; };
 struct SdDecControl { i32 nChannelsAPI, nChannelsInternal, API_sampleRate, internalSampleRate, payloadSize_ms; };
 
 WV_DEV void sd_resample(OaSilkChannel *ch, WV_LDS SilkLdsB *B, WV_LDS i16 *out, WV_LDS i16 *in, int inLen)
@@ -27,12 +30,13 @@ WV_DEV void sd_resampler_init(OaSilkChannel *ch, i32 Fs_in, i32 Fs_out)
 }
 
 /* returns the number of samples per channel staged in B->rs_out (at the API rate), or a negative OA_ERR_* */
-WV_DEVN int silk_decode_l0(OaSilkDec *sd, const SdDecControl &dc, int lostFlag, int newPacketFlag, EC_ARGS, WV_LDS SilkLdsA *A, WV_LDS SilkLdsB *B)
+/* sd: the (LDS-staged) hot state; cng_exc: &OaSilkDec::cng_exc_buf_Q14[0][0] in HBM */
+WV_DEVN int silk_decode_l0(OaSilkDec *sd, i32 *cng_exc, const SdDecControl &dc, int lostFlag, int newPacketFlag, EC_ARGS, WV_LDS SilkLdsA *A, WV_LDS SilkLdsB *B)
 {
    OaSilkChannel *cs = sd->ch;
    int decode_only_middle = 0;
    i32 MS_pred_Q13[2] = { 0, 0 };
-   SdScratch S; S.sLTP_Q15 = A->sLTP_Q15; S.res_Q14 = A->res_Q14; S.sLPC_Q14 = A->sLPC_Q14; S.sLTP = A->sLTP; S.pulses = A->pulses; S.tmp = A->tmp;
+   SdScratch S; S.cng_exc = cng_exc; S.sLTP_Q15 = A->sLTP_Q15; S.res_Q14 = A->res_Q14; S.sLPC_Q14 = A->sLPC_Q14; S.sLTP = A->sLTP; S.pulses = A->pulses; S.tmp = A->tmp;
 
    if (newPacketFlag) for (int n = 0; n < dc.nChannelsInternal; n++) cs[n].nFramesDecoded = 0;
    if (dc.nChannelsInternal > sd->nChannelsInternal) sd_reset(&cs[1]);                                   /* mono -> stereo: init the side channel (:186) */
@@ -114,6 +118,7 @@ WV_DEVN int silk_decode_l0(OaSilkDec *sd, const SdDecControl &dc, int lostFlag, 
          else if (lostFlag == SD_FLAG_DECODE_LBRR) condCoding = cs[n].LBRR_flags[FrameIndex - 1] ? SD_CODE_CONDITIONALLY : SD_CODE_INDEPENDENTLY;
          else if (n > 0 && sd->prev_decode_only_middle) condCoding = SD_CODE_INDEPENDENTLY_NO_LTP_SCALING;
          else condCoding = SD_CODE_CONDITIONALLY;
+         S.cng_exc = cng_exc + n * 320;
          const int r = sd_decode_frame(&cs[n], EC_PASS, &A->xq[n][2], lostFlag, condCoding, S);
          if (r < 0) return r;
          nSamplesOutDec = r;

@@ -11,7 +11,7 @@ def main():
     ap.add_argument("--streams", type=int, default=65536); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--states", type=int, default=4); ap.add_argument("--plain", action="store_true", help="plain NSQ (1 state, no warping)")
     ap.add_argument("--cpu-frames", type=int, default=4000)
-    ap.add_argument("--kernel", default="nsq", choices=["nsq", "resampler", "lpc", "pitch"])
+    ap.add_argument("--kernel", default="nsq", choices=["nsq", "resampler", "lpc", "pitch", "decode"])
     a = ap.parse_args()
     import torch, opus_amd
     if a.kernel != "nsq": return hbm_kernels(a, torch, opus_amd)
@@ -61,6 +61,43 @@ def hbm_kernels(a, torch, opus_amd):
     n = a.streams; dev = torch.device("cuda:0"); rng = np.random.default_rng(2)
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.kernel == "decode":
+        # SILK-only (WB, 20 ms, mono) and hybrid (FB, 20 ms, mono) packets from the compiled reference encoder, U distinct streams tiled over the batch
+        from test_kernel_emu_silkdec import speechy
+        from test_oracle_encoder import RefEnc
+        from test_oracle_decoder import RefDec
+        out = {"kernel": "oa_decode_kernel on SILK-only / hybrid packets", "streams": n}
+        for name, mode, bw, br in (("silk_wb", 1000, 1103, 20000), ("hybrid_fb", 1001, 1105, 32000)):
+            U = 16; F = a.steps + a.warmup
+            pk = []
+            for u in range(U):
+                sig = speechy(F, 1, 300 + u, 960); e = RefEnc(1, application=2048, force_mode=mode, bandwidth=bw, bitrate=br)
+                pk.append([e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)[0] for i in range(F)])
+            stride = 256
+            buf = np.zeros((F, U, stride), np.uint8); lens = np.zeros((F, U), np.int32)
+            for f in range(F):
+                for u in range(U): buf[f, u, :len(pk[u][f])] = np.frombuffer(pk[u][f], np.uint8); lens[f, u] = len(pk[u][f])
+            idx = np.arange(n) % U
+            d_buf = [torch.from_numpy(buf[f][idx]).to(dev) for f in range(F)]; d_len = [torch.from_numpy(lens[f][idx]).to(dev) for f in range(F)]
+            d_pcm = torch.zeros((n, 960), dtype=torch.int16, device=dev); d_ns = torch.zeros(n, dtype=torch.int32, device=dev); d_rng = torch.zeros(n, dtype=torch.int32, device=dev)
+            b = opus_amd.DecoderBatch(n, channels=1)
+            for f in range(a.warmup): b.decode_dev(d_buf[f].data_ptr(), stride, d_len[f].data_ptr(), d_pcm.data_ptr(), 960, d_ns.data_ptr(), d_rng.data_ptr(), stream)
+            torch.cuda.synchronize(); e0.record()
+            for f in range(a.warmup, F): b.decode_dev(d_buf[f].data_ptr(), stride, d_len[f].data_ptr(), d_pcm.data_ptr(), 960, d_ns.data_ptr(), d_rng.data_ptr(), stream)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.steps
+            ok = bool((d_ns.cpu().numpy() == 960).all())
+            # spot check of the last step against the compiled reference decoder
+            r = RefDec(1); ref = None
+            for f in range(F): ref = r.decode(pk[0][f])
+            same = bool(np.array_equal(d_pcm[0].cpu().numpy(), ref[1][:, 0]))
+            out[name] = {"ms_per_step": ms, "frames_per_s": n / (ms * 1e-3), "all_frames_ok": ok, "matches_reference": same, "mean_packet_bytes": float(lens.mean())}
+            if a.cpu_frames > 0:
+                r = RefDec(1); t0 = time.perf_counter(); k = 0
+                while k < a.cpu_frames: r.decode(pk[0][k % F]); k += 1
+                out[name]["cpu_baseline"] = {"value": a.cpu_frames / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "%d x opus_decode via ctypes" % a.cpu_frames}
+            b.close()
+        print(json.dumps(out)); return
     if a.kernel == "pitch":
         from silk_inputs import make_pitch_frame
         from test_kernel_emu_silk import PE_IN, PE_OUT
