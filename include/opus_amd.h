@@ -128,12 +128,14 @@ OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
  * host memory with the complete state (memcpy-able).  Scope: CELT-only, SILK-only (NB/MB/WB, 10-60 ms) and hybrid packets, any frame count /
  * size the TOC allows, mono/stereo streams into mono/stereo output, mode transitions in every direction incl. the 5 ms CELT redundancy frames,
  * packet-loss concealment in every mode (data == NULL or len == 0: CELT pitch/noise PLC, SILK PLC + comfort noise, hybrid = both) and DTX frames.
- * decode_fec = 1 conceals instead of decoding the LBRR copy (legal, lower quality).  Fs != 48000 returns OPUS_UNIMPLEMENTED. */
+ * decode_fec = 1 decodes the in-band FEC (LBRR) copy (src/opus_decoder.c:786-824), concealing where there is none.  Fs != 48000 returns OPUS_UNIMPLEMENTED. */
 typedef struct OpusDecoder OpusDecoder;
 OPUS_AMD_EXPORT int opus_decoder_get_size(int channels);
 OPUS_AMD_EXPORT OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error);
 OPUS_AMD_EXPORT int opus_decoder_init(OpusDecoder *st, opus_int32 Fs, int channels);
 OPUS_AMD_EXPORT int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec);
+/* reference include/opus.h:541 (the API opus_demo decodes with, src/opus_demo.c:1145): 24-bit samples in int32, here int16 resolution << 8 like the reference's int16-resolution build */
+OPUS_AMD_EXPORT int opus_decode24(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec);
 OPUS_AMD_EXPORT int opus_decoder_ctl(OpusDecoder *st, int request, ...);
 OPUS_AMD_EXPORT void opus_decoder_destroy(OpusDecoder *st);
 
@@ -153,6 +155,7 @@ OPUS_AMD_EXPORT int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned 
 OPUS_AMD_EXPORT int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, opus_int32 packet_stride, const opus_int32 *d_lens,
       opus_int16 *d_pcm, int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, int steps, float *ms);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_sync(OpusGpuDecBatch *b);
+OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec);   /* decode_fec of the following decode calls (include/opus.h:516) */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_reset(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);

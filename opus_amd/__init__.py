@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in hdrs):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-I" + os.path.join(_HERE, "csrc"),
-           "-I" + os.path.join(_ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
+           "-I" + os.path.join(_ROOT, "include")] + os.environ.get("OPUS_AMD_EXTRA_CFLAGS", "").split() + SOURCES + ["-o", LIB_PATH]   # (extra flags: profiling experiments only)
     if verbose: print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB_PATH

@@ -577,8 +577,9 @@ WV_DEV void oa_smooth_fade_wave(const i16 *in1, const i16 *in2, i16 *out, int ov
 
 /* One Opus frame with payload (opus_decode_frame, src/opus_decoder.c:271-714, data != NULL): SILK part, redundancy, CELT part, mode transitions.
  * `data` = the frame's bytes in HBM, len >= 2.  Returns the frame size or a negative OA_ERR_*. */
-WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC)
+WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0)
 {
+   decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
    const int F20 = 960, F5 = 240, F2_5 = 120;
@@ -619,14 +620,14 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
          sdh->lastInternalRate = dc.internalSampleRate; sdh->lastChannelsInternal = dc.nChannelsInternal;
          int decoded = 0, rr = 0;
          do {
-            const int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
+            const int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, decode_fec ? SD_FLAG_DECODE_LBRR : SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
             if (n < 0) { rr = n; break; }
             for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
             decoded += n;
          } while (decoded < frame_size);
          /* ---- redundancy signalling (:499-526) ---- */
          int red = 0, c2s = 0, rbytes = 0, newlen = len;
-         if (rr == 0 && k_ec_tell(&ec, buf) + 17 + 20 * (mode == 1001) <= 8 * len) {
+         if (rr == 0 && !decode_fec && k_ec_tell(&ec, buf) + 17 + 20 * (mode == 1001) <= 8 * len) {
             red = mode == 1001 ? k_ec_dec_bit_logp(&ec, buf, 12) : 1;
             if (red) {
                c2s = k_ec_dec_bit_logp(&ec, buf, 1);
@@ -674,7 +675,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    if (mode != 1000) {
       const int celt_frame_size = imin(F20, frame_size);
       if (mode != prev_mode && prev_mode > 0 && !prev_red) celt_reset_wave(L, gs);
-      const int r = celt_decode_frame_wave(L, gs, len, celt_frame_size, pcm, mode == 1001, celt_accum);
+      const int r = celt_decode_frame_wave(L, gs, decode_fec ? 0 : len, celt_frame_size, pcm, mode == 1001, celt_accum);   /* decode_fec: the CELT layer is concealed (:598) */
       if (r < 0) return r;
       LANE0 st->rangeFinal = st->rng;
    } else {
@@ -716,8 +717,9 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
 }
 
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
-WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
+WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
 {
+   decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
    {
@@ -729,7 +731,7 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
    wv_sync();
    LANE0 {
       int ret = 0, offset = 0;
-      sh->count = 0; sh->nb_samples = 0;
+      sh->count = 0; sh->nb_samples = 0; sh->r[5] = 0;
       if (frame_size <= 0) ret = OA_ERR_BAD_ARG;
       else if (len == 0 || data == 0) { ret = frame_size % 120 != 0 ? OA_ERR_BAD_ARG : 0; sh->count = -1; }        /* packet loss: conceal frame_size samples */
       else if (len < 0) ret = OA_ERR_BAD_ARG;
@@ -743,8 +745,10 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
          const int packet_frame_size = oa_samples_per_frame(toc, 48000);
          const int count = oa_packet_parse(data, len, sh->size, &offset);
          if (count < 0) ret = count;
-         else if (count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
+         else if (decode_fec && (frame_size < packet_frame_size || packet_mode == 1002 || st->mode == 1002)) sh->count = -1;   /* no usable LBRR: conceal (src/opus_decoder.c:791-797) */
+         else if (!decode_fec && count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
          else {
+            if (decode_fec) sh->r[5] = 1;
             st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
             int endband = 21;
             switch (packet_bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
@@ -758,7 +762,22 @@ WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data,
    int ret = wv_uni(sh->ret);
    const int count = wv_uni(sh->count), pfs = wv_uni(sh->packet_frame_size), CC = wv_uni(st->channels);
    int off = wv_uni(sh->frame_bytes_off), nb = 0;
-   for (int f = 0; f < count && ret >= 0; f++) {
+   const int fec = wv_uni(sh->r[5]);
+   if (fec && ret >= 0) {
+      /* in-band FEC (src/opus_decoder.c:798-824): conceal everything before the last packet_frame_size samples, then decode the LBRR copy of
+       * the first frame in this packet into them */
+      const int duration_copy = wv_uni(st->last_packet_duration);
+      while (nb < frame_size - pfs) {
+         const int r = oa_conceal_wave(L, gs, frame_size - pfs - nb, pcm_out + (size_t)nb * CC, CC);
+         if (r < 0) { ret = r; LANE0 st->last_packet_duration = duration_copy; wv_sync(); break; }
+         nb += r;
+      }
+      if (ret >= 0) {
+         const int r = oa_decode_frame_wave(L, gs, data + off, wv_uni(sh->size[0]), pfs, pcm_out + (size_t)nb * CC, CC, 1);
+         if (r < 0) ret = r; else nb = frame_size;
+      }
+   }
+   for (int f = 0; f < count && ret >= 0 && !fec; f++) {
       const int flen = wv_uni(sh->size[f]);
       int r;
       if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */

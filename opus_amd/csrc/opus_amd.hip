@@ -33,13 +33,13 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams)
+oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
    const int s = blockIdx.x;
    if (s >= nstreams) return;
-   oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s);
+   oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
 }
 
 #include "opus_packet_host.h"
@@ -368,11 +368,14 @@ static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
    return OPUS_OK;
 }
 struct OpusGpuDecBatch {
-   int device; opus_int32 S; int channels; hipStream_t stream;
+   int device; opus_int32 S; int channels; int decode_fec; hipStream_t stream;
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
+/* decode_fec of the following calls (opus_decode's last argument, include/opus.h:516): 1 = decode the in-band FEC (LBRR) copy the packets carry for
+ * the frame BEFORE them, concealing where there is none */
+int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec) { if (!b || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG; b->decode_fec = decode_fec; return OPUS_OK; }
 int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
 opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
 void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
@@ -405,7 +408,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuDecBatch();
-      b->device = device; b->S = nstreams; b->channels = channels; b->stream = nullptr; b->d_streams = nullptr;
+      b->device = device; b->S = nstreams; b->channels = channels; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -464,7 +467,7 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-         (u32 *)d_final_range, (int)b->S);
+         (u32 *)d_final_range, (int)b->S, b->decode_fec);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -540,7 +543,8 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (frame_size <= 0 || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG;
    if ((decode_fec || len == 0 || data == nullptr) && frame_size % (st->Fs / 400) != 0) return OPUS_BAD_ARG;
    if (len < 0) return OPUS_BAD_ARG;
-   if (data == nullptr || decode_fec) len = 0;      /* packet loss; CELT-only streams carry no in-band FEC, so decode_fec conceals too (opus_decoder.c:805) */
+   if (data == nullptr) len = 0;                    /* packet loss */
+   if (len == 0) decode_fec = 0;
    if (frame_size > 5760) frame_size = 5760;
    std::lock_guard<std::mutex> lock(g_classic_dec_mu);
    const int ci = st->s.s.channels - 1;
@@ -555,11 +559,26 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
    opus_int32 n = 0, l = len; opus_uint32 rng = 0;
    int r = opusgpu_dec_batch_import_state(b, 0, &st->s);
+   b->decode_fec = decode_fec;
    if (r == OPUS_OK) r = opusgpu_decode_batch(b, pkt.data(), (opus_int32)pkt.size(), &l, out.data(), frame_size, &n, &rng);
    if (r == OPUS_OK) r = opusgpu_dec_batch_export_state(b, 0, &st->s);
    if (r != OPUS_OK) return r;
    if (n > 0) memcpy(pcm, out.data(), (size_t)n * st->s.s.channels * sizeof(opus_int16));
    return n;
+}
+/* opus_decode24 (reference include/opus.h:541, src/opus_decoder.c:947-980, the int16-resolution build): decode, then RES2INT24 = << 8 */
+int opus_decode24(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec)
+{
+   if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
+   if (frame_size <= 0) return OPUS_BAD_ARG;
+   if (data != nullptr && len > 0 && !decode_fec) {
+      const int nb = opus_packet_get_nb_samples(data, len, st->Fs);
+      if (nb > 0) frame_size = frame_size < nb ? frame_size : nb; else return OPUS_INVALID_PACKET;
+   }
+   std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
+   const int ret = opus_decode(st, data, len, out.data(), frame_size, decode_fec);
+   for (int i = 0; i < ret * st->s.s.channels; i++) pcm[i] = (opus_int32)out[i] * 256;
+   return ret;
 }
 int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 {

@@ -720,8 +720,12 @@ WV_DEV int sd_decode_frame(OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int los
    if (lostFlag == SD_FLAG_DECODE_NORMAL || (lostFlag == SD_FLAG_DECODE_LBRR && ch->LBRR_flags[ch->nFramesDecoded] == 1)) {
       sd_decode_indices(EC_PASS, ch, ch->nFramesDecoded, lostFlag, condCoding);
       sd_decode_pulses(EC_PASS, S.pulses, ch->indices.signalType, ch->indices.quantOffsetType, L, S.tmp);
+#ifndef SD_PROF_SKIP_PARAMS
       sd_decode_parameters(ch, &ctrl, condCoding);
+#endif
+#ifndef SD_PROF_SKIP_CORE          /* (profiling experiment switch, never defined in the product build) */
       sd_decode_core(ch, &ctrl, pOut, S);
+#endif
       const int mv = ch->ltp_mem_length - L;
       for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
       for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];

@@ -130,7 +130,9 @@ WV_DEVN int silk_decode_l0(OaSilkDec *sd, i32 *cng_exc, const SdDecControl &dc, 
 
    const int nOut = (nSamplesOutDec * dc.API_sampleRate) / (cs[0].fs_kHz * 1000);
    const int nres = imin(dc.nChannelsAPI, dc.nChannelsInternal);
+#ifndef SD_PROF_SKIP_RESAMPLE      /* (profiling experiment switch, never defined in the product build) */
    for (int n = 0; n < nres; n++) sd_resample(&cs[n], B, B->rs_out[n], &A->xq[n][1], nSamplesOutDec);
+#endif
    if (dc.nChannelsAPI == 2 && dc.nChannelsInternal == 1) {
       if (stereo_to_mono) sd_resample(&cs[1], B, B->rs_out[1], &A->xq[0][1], nSamplesOutDec);
       else for (int i = 0; i < nOut; i++) B->rs_out[1][i] = B->rs_out[0][i];

@@ -34,11 +34,13 @@ extern "C" void emu_encode_batch(OaStream *streams, const int16_t *pcm, int S, i
 }
 
 /* ---- decoder ---- */
+static int g_decode_fec = 0;
+extern "C" void emu_set_decode_fec(int v) { g_decode_fec = v; }
 struct DJob { DecLds *L; OaDecStream *gs; const uint8_t *data; int len, frame_size; int16_t *pcm; int32_t *ns; uint32_t *rng; };
 static void djob_entry(void *p)
 {
    DJob *j = (DJob *)p;
-   oa_decode_packet(j->L, j->gs, j->data, j->len, j->frame_size, j->pcm, j->ns, j->rng);
+   oa_decode_packet(j->L, j->gs, j->data, j->len, j->frame_size, j->pcm, j->ns, j->rng, g_decode_fec);
 }
 extern "C" int emu_sizeof_dec_stream() { return (int)sizeof(OaDecStream); }
 extern "C" void emu_dec_stream_reset(OaDecStream *st, int channels) { oa_dec_stream_reset(st, channels); }

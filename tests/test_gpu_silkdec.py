@@ -105,3 +105,35 @@ def test_gpu_all_mode_transitions_with_loss():
             a = r.decode(pkt, 960); pcm = d.decode(pkt if pkt else None, 960)
             assert a[0] == 960 == pcm.shape[0] and d.final_range() == a[2], (ch, i)
             assert np.array_equal(pcm.reshape(-1, ch), a[1]), (ch, i, i in lose)
+
+def test_gpu_decode24_matches_reference():
+    """opus_decode24 (the entry point opus_demo uses) on a hybrid stream, next to the reference's opus_decode24"""
+    import ctypes, opus_amd
+    L = opus_amd.lib(); R = ref_fx()
+    pk = _mode_stream(2, 960, 10, 77, {0: dict(force_mode=1001, bandwidth=1105)}, bitrate=48000)
+    err = ctypes.c_int()
+    R.opus_decoder_create.restype = ctypes.c_void_p; R.opus_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    rd = R.opus_decoder_create(48000, 2, ctypes.byref(err)); d = opus_amd.OpusDecoder(48000, 2)
+    R.opus_decode24.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.opus_decode24.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for i, (pkt, _) in enumerate(pk):
+        a = np.zeros((5760, 2), np.int32); b = np.zeros((5760, 2), np.int32)
+        na = R.opus_decode24(rd, pkt, len(pkt), a.ctypes.data, 5760, 0); nb = L.opus_decode24(d._st, pkt, len(pkt), b.ctypes.data, 5760, 0)
+        assert na == nb == 960 and np.array_equal(a[:na], b[:nb]), i
+
+@pytest.mark.parametrize("ch,mode,bw,bitrate,frame", [(1, 1000, 1103, 24000, 960), (2, 1000, 1103, 40000, 960), (1, 1001, 1105, 36000, 960), (1, 1000, 1101, 14000, 1920)])
+def test_gpu_inband_fec(ch, mode, bw, bitrate, frame):
+    """lost packets recovered from the LBRR copy in the next packet (opus_decode(next, decode_fec = 1)), as a jitter buffer drives the reference"""
+    import opus_amd
+    sig = speechy(26, ch, mode + bw + frame + ch, frame)
+    e = RefEnc(ch, application=2048, inband_fec=1, packet_loss=25, force_mode=mode, bandwidth=bw, bitrate=bitrate)
+    pk = [e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)[0] for i in range(26)]
+    lose = {3, 7, 8, 12, 16, 17, 18, 22}
+    r = RefDec(ch); d = opus_amd.OpusDecoder(48000, ch)
+    for i in range(26):
+        if i in lose:
+            if i + 1 < 26 and (i + 1) not in lose: a = r.decode(pk[i + 1], frame, fec=1); pcm = d.decode(pk[i + 1], frame, 1)
+            else: a = r.decode(b"", frame); pcm = d.decode(None, frame)
+        else: a = r.decode(pk[i], frame); pcm = d.decode(pk[i], frame)
+        assert a[0] == frame == pcm.shape[0] and d.final_range() == a[2], i
+        assert np.array_equal(pcm.reshape(-1, ch), a[1]), (i, i in lose)

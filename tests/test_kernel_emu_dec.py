@@ -17,8 +17,9 @@ def new_dec_stream(E, channels):
 class EmuDec:
     def __init__(self, channels):
         self.E = _build(); self.ch = channels; self.st = new_dec_stream(self.E, channels)
-    def decode(self, pkt, max_frame=5760):
+    def decode(self, pkt, max_frame=5760, fec=0):
         P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.E.emu_set_decode_fec(int(fec))
         data = np.frombuffer(pkt + b"\0" * 8, np.uint8).copy()
         lens = np.array([len(pkt)], np.int32); ns = np.zeros(1, np.int32); rg = np.zeros(1, np.uint32)
         pcm = np.zeros((max_frame, self.ch), np.int16)

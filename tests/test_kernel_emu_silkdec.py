@@ -122,3 +122,38 @@ def test_emu_silk_to_celt_transition_and_loss_across_modes():
     _run_any(1, 1, 960, 32, seed=21, bitrate=36000, schedule=sched, expect_modes="SCH")
     _run_any(2, 2, 960, 32, seed=22, bitrate=56000, schedule=sched, expect_modes="SCH")
     _run_loss(1, 960, 32, seed=23, lose={7, 8, 15, 16, 23, 24, 25}, schedule=sched, bitrate=36000)     # the packets around every switch are lost
+
+def _run_fec(ch, frame, nframes, seed, lose, **ctl):
+    """in-band FEC: every lost packet is recovered from the LBRR copy carried by the NEXT packet (opus_decode(next, decode_fec=1) then
+    opus_decode(next, decode_fec=0)), exactly as a jitter buffer drives the reference (src/opus_demo.c:1107-1160)"""
+    sig = speechy(nframes, ch, seed, frame)
+    e = RefEnc(ch, application=2048, inband_fec=1, packet_loss=25, **ctl); r = RefDec(ch); k = EmuDec(ch)
+    pk = [e.encode(np.ascontiguousarray(sig[i * frame:(i + 1) * frame]), frame)[0] for i in range(nframes)]
+    used_lbrr = 0
+    for i in range(nframes):
+        if i in lose:
+            if i + 1 < nframes and (i + 1) not in lose:
+                a = r.decode(pk[i + 1], frame, fec=1); b = k.decode(pk[i + 1], frame, fec=1); used_lbrr += 1
+            else:
+                a = r.decode(b"", frame); b = k.decode(b"", frame)
+        else:
+            a = r.decode(pk[i], frame); b = k.decode(pk[i], frame)
+        assert a[0] == b[0] == frame, (i, a[0], b[0])
+        assert a[2] == b[2], (i, hex(a[2]), hex(b[2]))
+        assert np.array_equal(a[1], b[1]), (i, i in lose, np.nonzero(a[1] != b[1])[0][:6])
+    assert used_lbrr > 0
+
+@pytest.mark.parametrize("ch,mode,bw,bitrate,frame", [(1, 1000, 1103, 24000, 960), (2, 1000, 1103, 40000, 960), (1, 1001, 1105, 36000, 960), (1, 1000, 1101, 14000, 1920),
+                                                    (1, 1000, 1103, 24000, 480)])
+def test_emu_inband_fec(ch, mode, bw, bitrate, frame):
+    _run_fec(ch, frame, 26, seed=mode + bw + frame + ch, lose={3, 7, 8, 12, 16, 17, 18, 22}, force_mode=mode, bandwidth=bw, bitrate=bitrate)
+
+def test_emu_fec_request_on_celt_packets_conceals():
+    """decode_fec on CELT-only packets (no LBRR exists) = concealment (src/opus_decoder.c:791-797)"""
+    sig = speechy(10, 1, 3, 960)
+    e = RefEnc(1, application=2051, bitrate=48000); r = RefDec(1); k = EmuDec(1)
+    for i in range(10):
+        pkt = e.encode(np.ascontiguousarray(sig[i * 960:(i + 1) * 960]), 960)[0]
+        fec = i in (4, 7)
+        a = r.decode(pkt, 960, fec=fec); b = k.decode(pkt, 960, fec=fec)
+        assert a[0] == b[0] == 960 and a[2] == b[2] and np.array_equal(a[1], b[1]), i

@@ -19,9 +19,9 @@ class RefDec:
         self.st = L.opus_decoder_create(48000, channels, ctypes.byref(err))
         assert err.value == 0
         self.ch = channels
-    def decode(self, pkt, max_frame=5760):
+    def decode(self, pkt, max_frame=5760, fec=0):
         pcm = np.zeros((max_frame, self.ch), np.int16)
-        n = self.L.opus_decode(self.st, pkt, len(pkt), pcm.ctypes.data, max_frame, 0)
+        n = self.L.opus_decode(self.st, pkt, len(pkt), pcm.ctypes.data, max_frame, int(fec))
         rng = ctypes.c_uint32()
         self.L.opus_decoder_ctl(self.st, 4031, ctypes.byref(rng))
         return n, pcm[:max(n, 0)].copy(), rng.value
