@@ -132,3 +132,36 @@ def test_ms_errors():
         assert L.opus_multistream_decode(d, b"\xf8", 1, o.ctypes.data, 960, 0) == -4                                                     # shorter than 2*streams-1
         assert L.opus_multistream_decode(d, b"\xf8\x01\x00\xf0\x00", 5, o.ctypes.data, 960, 0) == -4                                    # streams with different durations
         L.opus_multistream_decoder_destroy(d)
+
+def test_gpu_multistream_decode_silk_and_hybrid_streams():
+    """a multistream packet whose elementary streams are SILK-only / hybrid (voip application of the reference encoder): the multistream decoder runs the
+    same kernels per stream group, so every packet mode decodes"""
+    import ctypes, opus_amd
+    from reflib import ref_fx
+    from test_kernel_emu_silkdec import speechy
+    R = ref_fx(); L = opus_amd.lib()
+    ch, streams, coupled = 3, 2, 1
+    mapping = (ctypes.c_ubyte * 3)(0, 1, 2)
+    err = ctypes.c_int()
+    R.opus_multistream_encoder_create.restype = ctypes.c_void_p; R.opus_multistream_decoder_create.restype = ctypes.c_void_p
+    L.opus_multistream_decoder_create.restype = ctypes.c_void_p
+    R.opus_multistream_encoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    for Lx in (R, L): Lx.opus_multistream_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    enc = R.opus_multistream_encoder_create(48000, ch, streams, coupled, mapping, 2048, ctypes.byref(err)); assert err.value == 0
+    R.opus_multistream_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    assert R.opus_multistream_encoder_ctl(enc, 4002, 60000) == 0
+    rd = R.opus_multistream_decoder_create(48000, ch, streams, coupled, mapping, ctypes.byref(err)); assert err.value == 0
+    gd = L.opus_multistream_decoder_create(48000, ch, streams, coupled, mapping, ctypes.byref(err)); assert err.value == 0 and gd
+    for Lx in (R, L): Lx.opus_multistream_decode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    R.opus_multistream_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    sig = np.concatenate([speechy(12, 2, 5), speechy(12, 1, 6)], axis=1).astype(np.int16)
+    out = (ctypes.c_ubyte * 4000)(); modes = set()
+    for i in range(12):
+        n = R.opus_multistream_encode(enc, np.ascontiguousarray(sig[i * 960:(i + 1) * 960]).ctypes.data, 960, out, 4000)
+        assert n > 0
+        pkt = bytes(out[:n]); modes.add(pkt[0] >> 7)
+        a = np.zeros((960, ch), np.int16); b = np.zeros((960, ch), np.int16)
+        na = R.opus_multistream_decode(rd, pkt, n, a.ctypes.data, 960, 0); nb = L.opus_multistream_decode(gd, pkt, n, b.ctypes.data, 960, 0)
+        assert na == nb == 960, (i, na, nb)
+        assert np.array_equal(a, b), i
+    assert 0 in modes                       # SILK or hybrid TOCs were really in there
