@@ -511,7 +511,7 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
          FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];           /* SILK state -> LDS, coalesced */
          wv_sync();
          LANE0 {
-            OaSilkDec *sdh = (OaSilkDec *)(i32 *)SL->hot;
+            WV_LDS OaSilkDec *sdh = (WV_LDS OaSilkDec *)SL->hot;
             EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
             ec.storage = 0; ec.end_offs = 0; ec.end_window = 0; ec.nend_bits = 0; ec.nbits_total = 0; ec.offs = 0; ec.rng = 0; ec.val = 0; ec.ext = 0; ec.rem = 0; ec.error = 0;
             WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
@@ -604,7 +604,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
       FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];              /* SILK state -> LDS, coalesced */
       wv_sync();
       LANE0 {
-         OaSilkDec *sdh = (OaSilkDec *)(i32 *)SL->hot;
+         WV_LDS OaSilkDec *sdh = (WV_LDS OaSilkDec *)SL->hot;
          EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
          k_ec_dec_init(&ec, buf, (u32)len);
          WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;

@@ -54,9 +54,9 @@ WV_DEV const u8 *sd_pitch_contour_icdf(int fs_kHz, int nb_subfr)
 { return fs_kHz == 8 ? (nb_subfr == 4 ? sk_pitch_contour_nb_icdf : sk_pitch_contour_10ms_nb_icdf) : (nb_subfr == 4 ? sk_pitch_contour_icdf : sk_pitch_contour_10ms_icdf); }
 WV_DEV const u8 *sd_pitch_low_bits_icdf(int fs_kHz) { return fs_kHz == 16 ? sk_uniform8_icdf : fs_kHz == 12 ? sk_uniform6_icdf : sk_uniform4_icdf; }
 
-WV_DEV void sd_decode_indices(EC_ARGS, OaSilkChannel *ch, int FrameIndex, int decode_LBRR, int condCoding)
+WV_DEV void sd_decode_indices(EC_ARGS, WV_LDS OaSilkChannel *ch, int FrameIndex, int decode_LBRR, int condCoding)
 {
-   OaSilkIndices *ix = &ch->indices;
+   WV_LDS OaSilkIndices *ix = &ch->indices;
    int Ix;
    if (decode_LBRR || ch->VAD_flags[FrameIndex]) Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_vad_icdf, 8) + 2;
    else Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_no_vad_icdf, 8);
@@ -174,7 +174,7 @@ WV_DEV void sd_bwexpander_32(i32 *ar, int d, i32 chirp_Q16)                     
    for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
    ar[d - 1] = sk_mulww(chirp_Q16, ar[d - 1]);
 }
-WV_DEV void sd_bwexpander(i16 *ar, int d, i32 chirp_Q16)                                              /* bwexpander.c:35 */
+WV_DEV void sd_bwexpander(WV_LDS i16 *ar, int d, i32 chirp_Q16)                                              /* bwexpander.c:35 */
 {
    const i32 cm1 = chirp_Q16 - 65536;
    for (int i = 0; i < d - 1; i++) { ar[i] = (i16)sk_rround(chirp_Q16 * ar[i], 16); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
@@ -183,7 +183,7 @@ WV_DEV void sd_bwexpander(i16 *ar, int d, i32 chirp_Q16)                        
 WV_DEV i32 sd_rround64(i64 a, int s) { return (i32)(s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1); }
 WV_DEV i64 sd_rround64w(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; }
 /* LPC_inv_pred_gain.c:45 (QA = 24): 0 = unstable, else inverse prediction gain Q30 */
-WV_DEV i32 sd_lpc_inverse_pred_gain(const i16 *A_Q12, int order)
+template <class PA> WV_DEV i32 sd_lpc_inverse_pred_gain(PA A_Q12, int order)
 {
    i32 A[16]; i32 DC = 0;
    for (int k = 0; k < order; k++) { DC += A_Q12[k]; A[k] = shl32(A_Q12[k], 12); }
@@ -230,7 +230,7 @@ WV_DEV void sd_nlsf2a_poly(i32 *out, const i32 *cLSF, int dd)
 }
 WV_TABLE u8 k_sd_ordering16[16] = { 0, 15, 8, 7, 4, 11, 12, 3, 2, 13, 10, 5, 6, 9, 14, 1 };
 WV_TABLE u8 k_sd_ordering10[10] = { 0, 9, 6, 3, 4, 5, 8, 1, 2, 7 };
-WV_DEV void sd_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d)
+template <class PA, class PN> WV_DEV void sd_nlsf2a(PA a_Q12, PN NLSF, int d)
 {
    const u8 *ordering = d == 16 ? k_sd_ordering16 : k_sd_ordering10;
    i32 cosq[16], P[9], Q[9], a32[16];
@@ -294,7 +294,7 @@ WV_DEV void sd_nlsf_stabilize(i16 *NLSF, const i16 *NDeltaMin, int L)           
    NLSF[L - 1] = (i16)imin(NLSF[L - 1], (1 << 15) - NDeltaMin[L]);
    for (int i = L - 2; i >= 0; i--) NLSF[i] = (i16)imin(NLSF[i], NLSF[i + 1] - NDeltaMin[i + 1]);
 }
-WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const i8 *NLSFIndices, const SdNlsfCb &cb)                      /* NLSF_decode.c:62 */
+WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const WV_LDS i8 *NLSFIndices, const SdNlsfCb &cb)                      /* NLSF_decode.c:62 */
 {
    i32 ec_ix[16], pred_Q8[16]; i32 res_Q10[16];
    sd_nlsf_unpack(ec_ix, pred_Q8, cb, NLSFIndices[0]);
@@ -314,7 +314,7 @@ WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const i8 *NLSFIndices, const SdNlsfCb
    }
    sd_nlsf_stabilize(pNLSF_Q15, cb.deltamin, cb.order);
 }
-WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, i32 *pitch_lags, int Fs_kHz, int nb_subfr)     /* decode_pitch.c:38 */
+WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, WV_LDS i32 *pitch_lags, int Fs_kHz, int nb_subfr)     /* decode_pitch.c:38 */
 {
    const i8 *cb; int cbk_size;
    if (Fs_kHz == 8) { if (nb_subfr == 4) { cb = sk_cb_lags_stage2; cbk_size = 11; } else { cb = sk_cb_lags_stage2_10ms; cbk_size = 3; } }
@@ -323,9 +323,9 @@ WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, i32 *pitch_lags, int
    for (int k = 0; k < nb_subfr; k++) { int p = lag + cb[k * cbk_size + contourIndex]; pitch_lags[k] = p < min_lag ? min_lag : p > max_lag ? max_lag : p; }
 }
 
-WV_DEV void sd_decode_parameters(OaSilkChannel *ch, SdCtrl *c, int condCoding)                              /* decode_parameters.c:35 */
+WV_DEV void sd_decode_parameters(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, int condCoding)                              /* decode_parameters.c:35 */
 {
-   OaSilkIndices *ix = &ch->indices;
+   WV_LDS OaSilkIndices *ix = &ch->indices;
    /* gains (gain_quant.c:100): OFFSET = 2090, INV_SCALE_Q16 = 1907825 */
    for (int k = 0; k < ch->nb_subfr; k++) {
       int prev = ch->LastGainIndex;
@@ -361,11 +361,11 @@ WV_DEV void sd_decode_parameters(OaSilkChannel *ch, SdCtrl *c, int condCoding)  
    }
 }
 
-struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; i32 *cng_exc; /* this channel's CNG excitation buffer (HBM) */ };
+struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; WV_LDS SdCtrl *ctrl; i32 *cng_exc; /* this channel's CNG excitation buffer (HBM) */ };
 
-WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)               /* decode_core.c:38 */
+WV_DEV void sd_decode_core(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)               /* decode_core.c:38 */
 {
-   const OaSilkIndices *ix = &ch->indices;
+   const WV_LDS OaSilkIndices *ix = &ch->indices;
    const int L = ch->subfr_length, mem = ch->ltp_mem_length, P = ch->LPC_order;
    const i32 offset_Q10 = k_silk_quant_offsets_Q10[(ix->signalType >> 1) * 2 + ix->quantOffsetType];
    const int interp_flag = ix->NLSFInterpCoef_Q2 < 4;
@@ -380,12 +380,12 @@ WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const S
       rand_seed = add32(rand_seed, S.pulses[i]);
    }
    for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = ch->sLPC_Q14_buf[i];
-   const i32 *pexc = ch->exc_Q14;
+   const WV_LDS i32 *pexc = ch->exc_Q14;
    WV_LDS i16 *pxq = xq;
    int sLTP_buf_idx = mem, lag = 0;
    for (int k = 0; k < ch->nb_subfr; k++) {
-      const i16 *A_Q12 = c->PredCoef_Q12[k >> 1];
-      i16 *B_Q14 = &c->LTPCoef_Q14[k * 5];
+      const WV_LDS i16 *A_Q12 = c->PredCoef_Q12[k >> 1];
+      WV_LDS i16 *B_Q14 = &c->LTPCoef_Q14[k * 5];
       int signalType = ix->signalType;
       const i32 Gain_Q10 = c->Gains_Q16[k] >> 6;
       i32 inv_gain_Q31 = sk_inverse32_varQ(c->Gains_Q16[k], 47);
@@ -410,7 +410,7 @@ WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const S
             for (int n = 0; n < mem - start_idx; n++) {
                i32 o = 0;
                if (n >= P) {
-                  const i16 *in = &ch->outBuf[start_idx + k * L + n];
+                  const WV_LDS i16 *in = &ch->outBuf[start_idx + k * L + n];
                   i32 pred = 0;
                   for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
                   o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
@@ -423,7 +423,7 @@ WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const S
             for (int i = 0; i < lag + 2; i++) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulww(gain_adj_Q16, S.sLTP_Q15[sLTP_buf_idx - i - 1]);
          }
       }
-      const i32 *pres;
+      const WV_LDS i32 *pres;
       if (signalType == SD_TYPE_VOICED) {
          for (int i = 0; i < L; i++) {
             const WV_LDS i32 *pl = &S.sLTP_Q15[sLTP_buf_idx - lag + 2];
@@ -450,9 +450,9 @@ WV_DEV void sd_decode_core(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *xq, const S
    for (int i = 0; i < 16; i++) ch->sLPC_Q14_buf[i] = S.sLPC_Q14[i];
 }
 
-WV_DEV void sd_reset(OaSilkChannel *ch)                                                                    /* init_decoder.c:43 (whole state) */
+WV_DEV void sd_reset(WV_LDS OaSilkChannel *ch)                                                                    /* init_decoder.c:43 (whole state) */
 {
-   i32 *w = (i32 *)ch;
+   WV_LDS i32 *w = (WV_LDS i32 *)ch;
    for (int i = 0; i < (int)(sizeof(OaSilkChannel) / 4); i++) w[i] = 0;
    ch->first_frame_after_reset = 1;
    ch->prev_gain_Q16 = 65536;
@@ -460,7 +460,7 @@ WV_DEV void sd_reset(OaSilkChannel *ch)                                         
    ch->plc_pitchL_Q8 = 0; ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2;   /* silk_PLC_Reset (PLC.c:65) */
 }
 /* silk_decoder_set_fs (decoder_set_fs.c:35); returns nonzero when the resampler has to be re-initialised by the caller */
-WV_DEV int sd_set_fs(OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
+WV_DEV int sd_set_fs(WV_LDS OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
 {
    int reinit = 0;
    ch->subfr_length = 5 * fs_kHz;
@@ -504,9 +504,9 @@ WV_DEV i32 sd_sqrt_approx(i32 x)                                                
    y >>= lz >> 1;
    return sk_mlawb(y, y, sk_mulbb(213, frac_Q7));
 }
-WV_DEV void sd_plc_reset(OaSilkChannel *ch)                                                                 /* PLC.c:65 */
+WV_DEV void sd_plc_reset(WV_LDS OaSilkChannel *ch)                                                                 /* PLC.c:65 */
 { ch->plc_pitchL_Q8 = shl32(ch->frame_length, 7); ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2; }
-WV_DEV void sd_plc_update(OaSilkChannel *ch, const SdCtrl *c)                                               /* PLC.c:107 */
+WV_DEV void sd_plc_update(WV_LDS OaSilkChannel *ch, const WV_LDS SdCtrl *c)                                               /* PLC.c:107 */
 {
    ch->prevSignalType = ch->indices.signalType;
    i32 LTP_Gain_Q14 = 0;
@@ -539,7 +539,7 @@ WV_DEV void sd_plc_update(OaSilkChannel *ch, const SdCtrl *c)                   
    ch->plc_prevGain_Q16[0] = c->Gains_Q16[ch->nb_subfr - 2]; ch->plc_prevGain_Q16[1] = c->Gains_Q16[ch->nb_subfr - 1];
    ch->plc_subfr_length = ch->subfr_length; ch->plc_nb_subfr = ch->nb_subfr;
 }
-WV_DEV void sd_plc_conceal(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, const SdScratch &S)             /* PLC.c:198 */
+WV_DEV void sd_plc_conceal(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *frame, const SdScratch &S)             /* PLC.c:198 */
 {
    const int mem = ch->ltp_mem_length, L = ch->subfr_length, P = ch->LPC_order;
    WV_LDS i32 *sLTP_Q14 = S.sLTP_Q15;
@@ -552,10 +552,10 @@ WV_DEV void sd_plc_conceal(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, cons
       for (int k = 0; k < 2; k++) for (int i = 0; i < L; i++) eb[k * L + i] = (i16)sk_sat16(sk_mulww(ch->exc_Q14[i + (k + ch->nb_subfr - 2) * L], prevGain_Q10[k]) >> 8);
       sd_sum_sqr_shift(&energy1, &shift1, eb, L); sd_sum_sqr_shift(&energy2, &shift2, eb + L, L);
    }
-   const i32 *rand_ptr;
+   const WV_LDS i32 *rand_ptr;
    if ((energy1 >> shift2) < (energy2 >> shift1)) rand_ptr = &ch->exc_Q14[imax(0, (ch->plc_nb_subfr - 1) * ch->plc_subfr_length - 128)];
    else rand_ptr = &ch->exc_Q14[imax(0, ch->plc_nb_subfr * ch->plc_subfr_length - 128)];
-   i16 *B_Q14 = ch->plc_LTPCoef_Q14;
+   WV_LDS i16 *B_Q14 = ch->plc_LTPCoef_Q14;
    i16 rand_scale_Q14 = (i16)ch->plc_randScale_Q14;
    const int att = imin(1, ch->lossCnt);
    const i32 harm_Gain_Q15 = att ? 31130 : 32440;
@@ -584,7 +584,7 @@ WV_DEV void sd_plc_conceal(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, cons
    for (int n = 0; n < mem - idx; n++) {                                                                  /* silk_LPC_analysis_filter(&sLTP[idx], &outBuf[idx], A_Q12, mem - idx, P) */
       i32 o = 0;
       if (n >= P) {
-         const i16 *in = &ch->outBuf[idx + n];
+         const WV_LDS i16 *in = &ch->outBuf[idx + n];
          i32 pred = 0;
          for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
          o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
@@ -623,16 +623,16 @@ WV_DEV void sd_plc_conceal(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, cons
    ch->plc_randScale_Q14 = rand_scale_Q14;
    for (int i = 0; i < 4; i++) c->pitchL[i] = lag;
 }
-WV_DEV void sd_plc(OaSilkChannel *ch, SdCtrl *c, WV_LDS i16 *frame, int lost, const SdScratch &S)           /* PLC.c:77 */
+WV_DEV void sd_plc(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *frame, int lost, const SdScratch &S)           /* PLC.c:77 */
 {
    if (ch->fs_kHz != ch->plc_fs_kHz) { sd_plc_reset(ch); ch->plc_fs_kHz = ch->fs_kHz; }
    if (lost) { sd_plc_conceal(ch, c, frame, S); ch->lossCnt++; }
    else sd_plc_update(ch, c);
 }
-WV_DEV void sd_plc_glue_frames(OaSilkChannel *ch, WV_LDS i16 *frame, int length)                            /* PLC.c:441 */
+WV_DEV void sd_plc_glue_frames(WV_LDS OaSilkChannel *ch, WV_LDS i16 *frame, int length)                            /* PLC.c:441 */
 {
    if (ch->lossCnt) {
-      int sh; sd_sum_sqr_shift(&ch->plc_conc_energy, &sh, frame, length); ch->plc_conc_energy_shift = sh;
+      i32 en; int sh; sd_sum_sqr_shift(&en, &sh, frame, length); ch->plc_conc_energy = en; ch->plc_conc_energy_shift = sh;
       ch->plc_last_frame_lost = 1;
    } else {
       if (ch->plc_last_frame_lost) {
@@ -658,14 +658,14 @@ WV_DEV void sd_plc_glue_frames(OaSilkChannel *ch, WV_LDS i16 *frame, int length)
       ch->plc_last_frame_lost = 0;
    }
 }
-WV_DEV void sd_cng_reset(OaSilkChannel *ch)                                                                 /* CNG.c:58 */
+WV_DEV void sd_cng_reset(WV_LDS OaSilkChannel *ch)                                                                 /* CNG.c:58 */
 {
    const i32 step = 32767 / (ch->LPC_order + 1);
    i32 acc = 0;
    for (int i = 0; i < ch->LPC_order; i++) { acc += step; ch->cng_smth_NLSF_Q15[i] = (i16)acc; }
    ch->cng_smth_Gain_Q16 = 0; ch->cng_rand_seed = 3176576;
 }
-WV_DEV void sd_cng(OaSilkChannel *ch, const SdCtrl *c, WV_LDS i16 *frame, int length, const SdScratch &S)   /* CNG.c:79 */
+WV_DEV void sd_cng(WV_LDS OaSilkChannel *ch, const WV_LDS SdCtrl *c, WV_LDS i16 *frame, int length, const SdScratch &S)   /* CNG.c:79 */
 {
    if (ch->fs_kHz != ch->cng_fs_kHz) { sd_cng_reset(ch); ch->cng_fs_kHz = ch->fs_kHz; }
    if (ch->lossCnt == 0 && ch->prevSignalType == SD_TYPE_NO_VOICE) {
@@ -713,35 +713,35 @@ WV_DEV void sd_cng(OaSilkChannel *ch, const SdCtrl *c, WV_LDS i16 *frame, int le
 }
 
 /* silk_decode_frame (decode_frame.c:43) */
-WV_DEV int sd_decode_frame(OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int lostFlag, int condCoding, const SdScratch &S)
+WV_DEV int sd_decode_frame(WV_LDS OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int lostFlag, int condCoding, const SdScratch &S)
 {
    const int L = ch->frame_length;
-   SdCtrl ctrl; ctrl.LTP_scale_Q14 = 0;
+   WV_LDS SdCtrl *ctrl = S.ctrl; ctrl->LTP_scale_Q14 = 0;
    if (lostFlag == SD_FLAG_DECODE_NORMAL || (lostFlag == SD_FLAG_DECODE_LBRR && ch->LBRR_flags[ch->nFramesDecoded] == 1)) {
       sd_decode_indices(EC_PASS, ch, ch->nFramesDecoded, lostFlag, condCoding);
       sd_decode_pulses(EC_PASS, S.pulses, ch->indices.signalType, ch->indices.quantOffsetType, L, S.tmp);
 #ifndef SD_PROF_SKIP_PARAMS
-      sd_decode_parameters(ch, &ctrl, condCoding);
+      sd_decode_parameters(ch, ctrl, condCoding);
 #endif
 #ifndef SD_PROF_SKIP_CORE          /* (profiling experiment switch, never defined in the product build) */
-      sd_decode_core(ch, &ctrl, pOut, S);
+      sd_decode_core(ch, ctrl, pOut, S);
 #endif
       const int mv = ch->ltp_mem_length - L;
       for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
       for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
-      sd_plc(ch, &ctrl, pOut, 0, S);
+      sd_plc(ch, ctrl, pOut, 0, S);
       ch->lossCnt = 0;
       ch->prevSignalType = ch->indices.signalType;
       ch->first_frame_after_reset = 0;
    } else {
-      sd_plc(ch, &ctrl, pOut, 1, S);
+      sd_plc(ch, ctrl, pOut, 1, S);
       const int mv = ch->ltp_mem_length - L;
       for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
       for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
    }
-   sd_cng(ch, &ctrl, pOut, L, S);
+   sd_cng(ch, ctrl, pOut, L, S);
    sd_plc_glue_frames(ch, pOut, L);
-   ch->lagPrev = ctrl.pitchL[ch->nb_subfr - 1];
+   ch->lagPrev = ctrl->pitchL[ch->nb_subfr - 1];
    return L;
 }
 
@@ -759,7 +759,7 @@ WV_DEV void sd_stereo_decode_pred(EC_ARGS, i32 *pred_Q13)                       
    }
    pred_Q13[0] -= pred_Q13[1];
 }
-WV_DEV void sd_stereo_ms_to_lr(OaSilkDec *sd, WV_LDS i16 *x1, WV_LDS i16 *x2, const i32 *pred_Q13, int fs_kHz, int frame_length)   /* stereo_MS_to_LR.c:35 */
+WV_DEV void sd_stereo_ms_to_lr(WV_LDS OaSilkDec *sd, WV_LDS i16 *x1, WV_LDS i16 *x2, const i32 *pred_Q13, int fs_kHz, int frame_length)   /* stereo_MS_to_LR.c:35 */
 {
    for (int i = 0; i < 2; i++) { x1[i] = sd->sMid[i]; x2[i] = sd->sSide[i]; sd->sMid[i] = x1[frame_length + i]; sd->sSide[i] = x2[frame_length + i]; }
    i32 pred0 = sd->pred_prev_Q13[0], pred1 = sd->pred_prev_Q13[1];

@@ -8,19 +8,20 @@
 /* scratch overlaid on the CELT decoder's phase regions (free while SILK runs): A (7,680 B) and BC (8,640 B), contiguous = 16,320 B:
  * 5,904 B synthesis scratch + 4,096 B resampler staging + the hot part of the stream's SILK state (both channels, 6,168 B) so that the lane-0
  * code never waits on HBM (its first version kept the state in HBM: 1.2 ms per frame, two orders of magnitude behind one CPU core) */
-struct SilkLdsA { i32 sLTP_Q15[640]; i32 res_Q14[80]; i32 sLPC_Q14[96]; i16 sLTP[320]; i16 pulses[336]; i16 tmp[16]; i16 xq[2][324]; };
+struct SilkLdsA { i32 sLTP_Q15[640]; i32 res_Q14[80]; i32 sLPC_Q14[96]; union { i16 pulses[336]; i16 sLTP[320]; } u;   /* pulses are dead once the excitation exists */
+                  i16 tmp[16]; i16 xq[2][324]; SdCtrl ctrl; };
 struct SilkLdsB { i16 rs_out[2][960]; ResamplerLdsT<1> ring; };
 struct SilkLdsAll { SilkLdsA a; SilkLdsB b; i32 hot[(OA_SILK_HOT_BYTES + 3) / 4]; };
 struct SdDecControl { i32 nChannelsAPI, nChannelsInternal, API_sampleRate, internalSampleRate, payloadSize_ms; };
 
-WV_DEV void sd_resample(OaSilkChannel *ch, WV_LDS SilkLdsB *B, WV_LDS i16 *out, WV_LDS i16 *in, int inLen)
+WV_DEV void sd_resample(WV_LDS OaSilkChannel *ch, WV_LDS SilkLdsB *B, WV_LDS i16 *out, WV_LDS i16 *in, int inLen)
 {
    OaResamplerCfg c;
    c.resampler_function = ch->rs_cfg[0]; c.batchSize = ch->rs_cfg[1]; c.invRatio_Q16 = ch->rs_cfg[2]; c.FIR_Order = ch->rs_cfg[3]; c.FIR_Fracs = ch->rs_cfg[4];
    c.Fs_in_kHz = ch->rs_cfg[5]; c.Fs_out_kHz = ch->rs_cfg[6]; c.inputDelay = ch->rs_cfg[7]; c.coefs_id = ch->rs_cfg[8];
    silk_resampler_lane(c, &B->ring, ch->rs_rows, 1, in, inLen, out, 0);
 }
-WV_DEV void sd_resampler_init(OaSilkChannel *ch, i32 Fs_in, i32 Fs_out)
+WV_DEV void sd_resampler_init(WV_LDS OaSilkChannel *ch, i32 Fs_in, i32 Fs_out)
 {
    OaResamplerCfg c;
    rs_init_cfg(&c, Fs_in, Fs_out, 0);
@@ -31,12 +32,12 @@ WV_DEV void sd_resampler_init(OaSilkChannel *ch, i32 Fs_in, i32 Fs_out)
 
 /* returns the number of samples per channel staged in B->rs_out (at the API rate), or a negative OA_ERR_* */
 /* sd: the (LDS-staged) hot state; cng_exc: &OaSilkDec::cng_exc_buf_Q14[0][0] in HBM */
-WV_DEVN int silk_decode_l0(OaSilkDec *sd, i32 *cng_exc, const SdDecControl &dc, int lostFlag, int newPacketFlag, EC_ARGS, WV_LDS SilkLdsA *A, WV_LDS SilkLdsB *B)
+WV_DEVN int silk_decode_l0(WV_LDS OaSilkDec *sd, i32 *cng_exc, const SdDecControl &dc, int lostFlag, int newPacketFlag, EC_ARGS, WV_LDS SilkLdsA *A, WV_LDS SilkLdsB *B)
 {
-   OaSilkChannel *cs = sd->ch;
+   WV_LDS OaSilkChannel *cs = sd->ch;
    int decode_only_middle = 0;
    i32 MS_pred_Q13[2] = { 0, 0 };
-   SdScratch S; S.cng_exc = cng_exc; S.sLTP_Q15 = A->sLTP_Q15; S.res_Q14 = A->res_Q14; S.sLPC_Q14 = A->sLPC_Q14; S.sLTP = A->sLTP; S.pulses = A->pulses; S.tmp = A->tmp;
+   SdScratch S; S.cng_exc = cng_exc; S.sLTP_Q15 = A->sLTP_Q15; S.res_Q14 = A->res_Q14; S.sLPC_Q14 = A->sLPC_Q14; S.sLTP = A->u.sLTP; S.pulses = A->u.pulses; S.tmp = A->tmp; S.ctrl = &A->ctrl;
 
    if (newPacketFlag) for (int n = 0; n < dc.nChannelsInternal; n++) cs[n].nFramesDecoded = 0;
    if (dc.nChannelsInternal > sd->nChannelsInternal) sd_reset(&cs[1]);                                   /* mono -> stereo: init the side channel (:186) */

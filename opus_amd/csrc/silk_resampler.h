@@ -70,9 +70,9 @@ struct RsLane {                      /* per-lane registers */
 #define RS_RING(L, slot) (L)->ring[(slot) & (OA_RS_RING - 1)][col]
 
 /* the reference's "source" for one run: sample k of the segment */
-template <class InP> struct RsDelaySrc { const i32 *d; int nd; int stride; InP in; };   /* the delay line (state rows) followed by new input */
+template <class DP, class InP> struct RsDelaySrc { DP d; int nd; int stride; InP in; };   /* the delay line (state rows) followed by new input */
 template <class InP> struct RsPlainSrc { InP in; };
-template <class InP> WV_DEV i32 rs_at(const RsDelaySrc<InP> &s, int k) { return k < s.nd ? s.d[k * s.stride] : (i32)s.in[k - s.nd]; }
+template <class DP, class InP> WV_DEV i32 rs_at(const RsDelaySrc<DP, InP> &s, int k) { return k < s.nd ? s.d[k * s.stride] : (i32)s.in[k - s.nd]; }
 template <class InP> WV_DEV i32 rs_at(const RsPlainSrc<InP> &s, int k) { return (i32)s.in[k]; }
 
 WV_DEV void rs_up2_step(i32 *S, i32 in32, i32 &even, i32 &odd)                    /* resampler_private_up2_HQ.c:60-108 */
@@ -154,14 +154,14 @@ template <class RL, class In, class Out> WV_DEV int rs_segment(const OaResampler
 
 
 /* One call of silk_resampler for this lane's channel.  st = &state[channel] (row stride n), in/out = the channel's buffers. */
-template <class RL, class InP, class Out> WV_DEV void silk_resampler_lane(const OaResamplerCfg c, WV_LDS RL *L, i32 *st, int n, InP in, int inLen, Out out, const int col)
+template <class RL, class StP, class InP, class Out> WV_DEV void silk_resampler_lane(const OaResamplerCfg c, WV_LDS RL *L, StP st, int n, InP in, int inLen, Out out, const int col)
 {
    RsLane r; r.rb = 0;
    for (int j = 0; j < 6; j++) r.iir[j] = st[(OA_RS_ROW_IIR + j) * n];
    const int ord = c.resampler_function == OA_RS_FN_DOWN_FIR ? c.FIR_Order : c.resampler_function == OA_RS_FN_IIR_FIR ? 8 : 0;
    for (int j = 0; j < ord; j++) RS_RING(L, j) = st[(OA_RS_ROW_FIR + j) * n];
    const int nNew = c.Fs_in_kHz - c.inputDelay;
-   RsDelaySrc<InP> s1 = { st + OA_RS_ROW_DELAY * n, c.inputDelay, n, in };
+   RsDelaySrc<StP, InP> s1 = { st + OA_RS_ROW_DELAY * n, c.inputDelay, n, in };
    int w = rs_segment(c, L, r, s1, c.Fs_in_kHz, out, col);
    RsPlainSrc<InP> s2 = { in + nNew };
    rs_segment(c, L, r, s2, inLen - c.Fs_in_kHz, out + w, col);
