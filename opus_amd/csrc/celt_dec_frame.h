@@ -510,23 +510,29 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
          wv_sync();
          FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];           /* SILK state -> LDS, coalesced */
          wv_sync();
-         LANE0 {
+         {
             WV_LDS OaSilkDec *sdh = (WV_LDS OaSilkDec *)SL->hot;
-            EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
-            ec.storage = 0; ec.end_offs = 0; ec.end_window = 0; ec.nend_bits = 0; ec.nbits_total = 0; ec.offs = 0; ec.rng = 0; ec.val = 0; ec.ext = 0; ec.rem = 0; ec.error = 0;
+            WV_LDS u8 *buf = L->packet + 1;
+            LANE0 {
+               EcCtx ec;
+               ec.storage = 0; ec.end_offs = 0; ec.end_window = 0; ec.nend_bits = 0; ec.nbits_total = 0; ec.offs = 0; ec.rng = 0; ec.val = 0; ec.ext = 0; ec.rem = 0; ec.error = 0;
+               ec_st(&L->ec_silk, &ec);
+            }
             WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
             SdDecControl dc;
-            dc.nChannelsAPI = CC; dc.nChannelsInternal = sdh->lastChannelsInternal; dc.API_sampleRate = 48000;
-            dc.internalSampleRate = sdh->lastInternalRate; dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+            dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(sdh->lastChannelsInternal); dc.API_sampleRate = 48000;
+            dc.internalSampleRate = wv_uni(sdh->lastInternalRate); dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
             int decoded = 0;
             do {
-               int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_PACKET_LOST, decoded == 0, &ec, buf, SA, SB);
+               int n = silk_decode_wave(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_PACKET_LOST, decoded == 0, &L->ec_silk, buf, SA, SB, L->sh.r);
+               wv_sync();
                if (n < 0) {                                                        /* "PLC failure should not be fatal" (:466-471) */
                   n = audiosize;
-                  for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) SB->rs_out[c][i] = 0;
+                  for (int c = 0; c < CC; c++) FOR_LANES(i, n) SB->rs_out[c][i] = 0;
+                  wv_sync();
                }
                const int m = imin(n, audiosize - decoded);                        /* a 10 ms SILK frame may be longer than what is asked for (pcm_too_small, :411-420) */
-               for (int c = 0; c < CC; c++) for (int i = 0; i < m; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
+               FOR_LANES(it, m * CC) { const int i = it / CC, c = it - i * CC; pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i]; }
                decoded += n;
             } while (decoded < audiosize);
          }
@@ -603,42 +609,50 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
       WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->A;
       FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];              /* SILK state -> LDS, coalesced */
       wv_sync();
-      LANE0 {
+      {
          WV_LDS OaSilkDec *sdh = (WV_LDS OaSilkDec *)SL->hot;
-         EcCtx ec; WV_LDS u8 *buf = L->packet + 1;
-         k_ec_dec_init(&ec, buf, (u32)len);
+         WV_LDS u8 *buf = L->packet + 1;
          WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
-         if (prev_mode == 1002) {                                               /* silk_ResetDecoder (silk/dec_API.c:91) */
-            sd_reset(&sdh->ch[0]); sd_reset(&sdh->ch[1]);
-            sdh->pred_prev_Q13[0] = sdh->pred_prev_Q13[1] = 0; sdh->sMid[0] = sdh->sMid[1] = sdh->sSide[0] = sdh->sSide[1] = 0;
-            sdh->prev_decode_only_middle = 0;
-         }
          SdDecControl dc;
-         dc.nChannelsAPI = CC; dc.nChannelsInternal = st->stream_channels; dc.API_sampleRate = 48000;
+         dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(st->stream_channels); dc.API_sampleRate = 48000;
          dc.internalSampleRate = mode == 1001 ? 16000 : bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000;
          dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
-         sdh->lastInternalRate = dc.internalSampleRate; sdh->lastChannelsInternal = dc.nChannelsInternal;
+         LANE0 {
+            EcCtx ec;
+            k_ec_dec_init(&ec, buf, (u32)len);
+            ec_st(&L->ec_silk, &ec);
+            if (prev_mode == 1002) {                                            /* silk_ResetDecoder (silk/dec_API.c:91) */
+               sd_reset(&sdh->ch[0]); sd_reset(&sdh->ch[1]);
+               sdh->pred_prev_Q13[0] = sdh->pred_prev_Q13[1] = 0; sdh->sMid[0] = sdh->sMid[1] = sdh->sSide[0] = sdh->sSide[1] = 0;
+               sdh->prev_decode_only_middle = 0;
+            }
+            sdh->lastInternalRate = dc.internalSampleRate; sdh->lastChannelsInternal = dc.nChannelsInternal;
+         }
          int decoded = 0, rr = 0;
          do {
-            const int n = silk_decode_l0(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, decode_fec ? SD_FLAG_DECODE_LBRR : SD_FLAG_DECODE_NORMAL, decoded == 0, &ec, buf, SA, SB);
+            const int n = silk_decode_wave(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, decode_fec ? SD_FLAG_DECODE_LBRR : SD_FLAG_DECODE_NORMAL, decoded == 0, &L->ec_silk, buf, SA, SB, sh->r);
+            wv_sync();
             if (n < 0) { rr = n; break; }
-            for (int c = 0; c < CC; c++) for (int i = 0; i < n; i++) pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i];
+            FOR_LANES(it, n * CC) { const int i = it / CC, c = it - i * CC; pcm[(size_t)(decoded + i) * CC + c] = SB->rs_out[c][i]; }
             decoded += n;
          } while (decoded < frame_size);
-         /* ---- redundancy signalling (:499-526) ---- */
-         int red = 0, c2s = 0, rbytes = 0, newlen = len;
-         if (rr == 0 && !decode_fec && k_ec_tell(&ec, buf) + 17 + 20 * (mode == 1001) <= 8 * len) {
-            red = mode == 1001 ? k_ec_dec_bit_logp(&ec, buf, 12) : 1;
-            if (red) {
-               c2s = k_ec_dec_bit_logp(&ec, buf, 1);
-               rbytes = mode == 1001 ? (int)k_ec_dec_uint(&ec, buf, 256) + 2 : len - ((k_ec_tell(&ec, buf) + 7) >> 3);
-               newlen = len - rbytes;
-               if (newlen * 8 < k_ec_tell(&ec, buf)) { newlen = 0; rbytes = 0; red = 0; }
-               ec.storage -= (u32)rbytes;
+         LANE0 {
+            /* ---- redundancy signalling (:499-526) ---- */
+            EcCtx ec; ec_ld(&ec, &L->ec_silk);
+            int red = 0, c2s = 0, rbytes = 0, newlen = len;
+            if (rr == 0 && !decode_fec && k_ec_tell(&ec, buf) + 17 + 20 * (mode == 1001) <= 8 * len) {
+               red = mode == 1001 ? k_ec_dec_bit_logp(&ec, buf, 12) : 1;
+               if (red) {
+                  c2s = k_ec_dec_bit_logp(&ec, buf, 1);
+                  rbytes = mode == 1001 ? (int)k_ec_dec_uint(&ec, buf, 256) + 2 : len - ((k_ec_tell(&ec, buf) + 7) >> 3);
+                  newlen = len - rbytes;
+                  if (newlen * 8 < k_ec_tell(&ec, buf)) { newlen = 0; rbytes = 0; red = 0; }
+                  ec.storage -= (u32)rbytes;
+               }
             }
+            ec_st(&L->ec_silk, &ec);
+            sh->r[0] = rr; sh->r[1] = red; sh->r[2] = c2s; sh->r[3] = rbytes; sh->r[4] = newlen;
          }
-         ec_st(&L->ec_silk, &ec);
-         sh->r[0] = rr; sh->r[1] = red; sh->r[2] = c2s; sh->r[3] = rbytes; sh->r[4] = newlen;
       }
       FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) ((i32 *)&gs->silk)[i] = SL->hot[i];
       wv_sync();

@@ -10,9 +10,9 @@
  *   sd_decode_frame       silk_decode_frame         silk/decode_frame.c:43
  *   sd_set_fs / sd_reset  silk_decoder_set_fs / silk_reset_decoder   silk/decoder_set_fs.c:35, silk/init_decoder.c:43
  *   sd_stereo_*           silk_stereo_decode_pred / _mid_only / silk_stereo_MS_to_LR   silk/stereo_decode_pred.c:35,:66, silk/stereo_MS_to_LR.c:35
- *   silk_decode_l0        silk_Decode               silk/dec_API.c:142            per-packet frame/channel sequencing, LBRR skipping, resampling to the API rate
- * Everything is a serial chain per stream (one range decoder, recursive synthesis filters), so it runs on lane 0 of the wave that owns the
- * stream, in the same kernel as the CELT decoder whose LDS regions it borrows between CELT frames.  Packet loss concealment / comfort noise
+ *   silk_decode_wave      silk_Decode               silk/dec_API.c:142            per-packet frame/channel sequencing, LBRR skipping, resampling to the API rate (silk_dec_api.h)
+ * Entropy and parameter decoding are serial chains per stream and run as lane-0 sections of the wave that owns the stream; the synthesis filters
+ * (sd_decode_core_wave) and the resampler use the whole wave.  Same kernel as the CELT decoder, whose LDS regions are borrowed between CELT frames.  Packet loss concealment / comfort noise
  * (silk/PLC.c:77-493 silk_PLC / _update / _conceal / _glue_frames, silk/CNG.c:79 silk_CNG) are sd_plc*, sd_cng. */
 #ifndef OPUS_AMD_SILK_DEC_H
 #define OPUS_AMD_SILK_DEC_H
@@ -712,20 +712,141 @@ WV_DEV void sd_cng(WV_LDS OaSilkChannel *ch, const WV_LDS SdCtrl *c, WV_LDS i16 
    } else for (int i = 0; i < ch->LPC_order; i++) ch->cng_synth_state[i] = 0;
 }
 
-/* silk_decode_frame (decode_frame.c:43) */
-WV_DEV int sd_decode_frame(WV_LDS OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, int lostFlag, int condCoding, const SdScratch &S)
+/* ---- silk_decode_core, wave-wide (decode_core.c:38).  Same arithmetic as sd_decode_core above (kept as the readable serial statement of the
+ * algorithm and used by nothing else), spread over the 64 lanes:
+ *   excitation    the dither seed is an affine recurrence s <- a*s + c + pulse[i]; affine maps compose associatively, so each lane composes its
+ *                 5 samples, a 6-step scan over the lanes gives every lane its starting seed, and the lane replays its 5 samples
+ *   re-whitening  an FIR: one output per lane
+ *   LTP synthesis a recurrence with delay lag-2 >= 14: chunks of min(64, lag-2) samples, one per lane
+ *   LPC synthesis a true 16-tap recursion: lane j holds tap j and the sample of lag j+1; per sample one multiply per lane, a DPP sum over the wave,
+ *                 and a one-lane shift of the delay line (wv_shift_up1) */
+WV_DEV void sd_decode_core_wave(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)
 {
-   const int L = ch->frame_length;
-   WV_LDS SdCtrl *ctrl = S.ctrl; ctrl->LTP_scale_Q14 = 0;
+   const int lane = wv_lane();
+   const WV_LDS OaSilkIndices *ix = &ch->indices;
+   const int L = ch->subfr_length, mem = ch->ltp_mem_length, P = ch->LPC_order, FL = ch->frame_length;
+   const i32 offset_Q10 = k_silk_quant_offsets_Q10[(ix->signalType >> 1) * 2 + ix->quantOffsetType];
+   const int interp_flag = ix->NLSFInterpCoef_Q2 < 4;
+   /* ---- excitation ---- */
+   {
+      const int B = 5, i0 = lane * B;
+      u32 Am = 1, Cm = 0;                                                   /* this lane's block as one affine map x -> Am*x + Cm */
+      for (int t = 0; t < B; t++) { const int i = i0 + t; if (i < FL) { Am = Am * 196314165u; Cm = Cm * 196314165u + 907633515u + (u32)(i32)S.pulses[i]; } }
+      u32 Ai = Am, Ci = Cm;                                                 /* inclusive scan: (Ai, Ci) = composition of blocks 0..lane */
+      for (int d = 1; d < WV_WIDTH; d <<= 1) {
+         const u32 Ap = (u32)wv_shfl((i32)Ai, lane - d), Cp = (u32)wv_shfl((i32)Ci, lane - d);
+         if (lane >= d) { Ci = Ai * Cp + Ci; Ai = Ai * Ap; }
+      }
+      const u32 Ae = (u32)wv_shfl((i32)Ai, lane - 1), Ce = (u32)wv_shfl((i32)Ci, lane - 1);
+      i32 seed = lane == 0 ? (i32)ix->Seed : (i32)(Ae * (u32)(i32)ix->Seed + Ce);
+      for (int t = 0; t < B; t++) {
+         const int i = i0 + t;
+         if (i < FL) {
+            seed = sk_rand(seed);
+            i32 e = shl32(S.pulses[i], 14);
+            if (e > 0) e -= 80 << 4; else if (e < 0) e += 80 << 4;
+            e += offset_Q10 << 4;
+            if (seed < 0) e = -e;
+            ch->exc_Q14[i] = e;
+            seed = add32(seed, S.pulses[i]);
+         }
+      }
+   }
+   wv_sync();
+   i32 st = lane < 16 ? ch->sLPC_Q14_buf[15 - lane] : 0;                     /* lane j: the synthesis output of lag j+1 */
+   int sLTP_buf_idx = mem, lag = 0;
+   i32 prev_gain = ch->prev_gain_Q16;
+   for (int k = 0; k < ch->nb_subfr; k++) {
+      const WV_LDS i16 *A_Q12 = c->PredCoef_Q12[k >> 1];
+      WV_LDS i16 *B_Q14 = &c->LTPCoef_Q14[k * 5];
+      int signalType = ix->signalType;
+      const i32 Gain_Q16 = c->Gains_Q16[k], Gain_Q10 = Gain_Q16 >> 6;
+      i32 inv_gain_Q31 = sk_inverse32_varQ(Gain_Q16, 47);
+      i32 gain_adj_Q16 = (i32)1 << 16;
+      if (Gain_Q16 != prev_gain) { gain_adj_Q16 = sk_div32_varQ(prev_gain, Gain_Q16, 16); st = sk_mulww(gain_adj_Q16, st); }
+      prev_gain = Gain_Q16;
+      if (ch->lossCnt && ch->prevSignalType == SD_TYPE_VOICED && ix->signalType != SD_TYPE_VOICED && k < 2) {
+         wv_sync();
+         if (lane < 5) B_Q14[lane] = lane == 2 ? (i16)4096 : (i16)0;
+         if (lane == 0) c->pitchL[k] = ch->lagPrev;
+         signalType = SD_TYPE_VOICED;
+         wv_sync();
+      }
+      const WV_LDS i32 *pexc = ch->exc_Q14 + k * L;
+      if (signalType == SD_TYPE_VOICED) {
+         lag = c->pitchL[k];
+         if (k == 0 || (k == 2 && interp_flag)) {
+            const int start_idx = mem - lag - P - 2;
+            if (k == 2) { for (int i = lane; i < 2 * L; i += WV_WIDTH) ch->outBuf[mem + i] = xq[i]; wv_sync(); }
+            for (int n = lane; n < mem - start_idx; n += WV_WIDTH) {
+               i32 o = 0;
+               if (n >= P) {
+                  const WV_LDS i16 *in = &ch->outBuf[start_idx + k * L + n];
+                  i32 pred = 0;
+                  for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
+                  o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
+               }
+               S.sLTP[start_idx + n] = (i16)o;
+            }
+            wv_sync();
+            if (k == 0) inv_gain_Q31 = shl32(sk_mulwb(inv_gain_Q31, c->LTP_scale_Q14), 2);
+            for (int i = lane; i < lag + 2; i += WV_WIDTH) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulwb(inv_gain_Q31, S.sLTP[mem - i - 1]);
+         } else if (gain_adj_Q16 != (i32)1 << 16) {
+            for (int i = lane; i < lag + 2; i += WV_WIDTH) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulww(gain_adj_Q16, S.sLTP_Q15[sLTP_buf_idx - i - 1]);
+         }
+         wv_sync();
+         /* LTP synthesis in chunks no longer than the recursion delay */
+         const int chunk = imin(WV_WIDTH, lag - 2);
+         i32 b0 = B_Q14[0], b1 = B_Q14[1], b2 = B_Q14[2], b3 = B_Q14[3], b4 = B_Q14[4];
+         for (int i0 = 0; i0 < L; i0 += chunk) {
+            const int i = i0 + lane;
+            if (lane < chunk && i < L) {
+               const WV_LDS i32 *pl = &S.sLTP_Q15[sLTP_buf_idx + i - lag + 2];
+               i32 p = 2;
+               p = sk_mlawb(p, pl[0], b0); p = sk_mlawb(p, pl[-1], b1); p = sk_mlawb(p, pl[-2], b2); p = sk_mlawb(p, pl[-3], b3); p = sk_mlawb(p, pl[-4], b4);
+               const i32 r = pexc[i] + shl32(p, 1);
+               S.res_Q14[i] = r;
+               S.sLTP_Q15[sLTP_buf_idx + i] = shl32(r, 1);
+            }
+            wv_sync();
+         }
+         sLTP_buf_idx += L;
+      }
+      /* LPC synthesis: lane j = tap j */
+      {
+         const i32 a = lane < P ? (i32)A_Q12[lane] : 0;
+         const WV_LDS i32 *res = signalType == SD_TYPE_VOICED ? S.res_Q14 : pexc;
+         for (int i = 0; i < L; i++) {
+            const i32 pred = add32(P >> 1, wv_sum(lane < P ? sk_mulwb(st, a) : 0));
+            const i32 v = sk_add_sat(res[i], sk_shl_sat(pred, 4));
+            st = wv_shift_up1(st, v);
+            if (lane == 0) xq[k * L + i] = (i16)sk_sat16(sk_rround(sk_mulww(v, Gain_Q10), 8));
+         }
+      }
+      wv_sync();
+   }
+   if (lane < 16) ch->sLPC_Q14_buf[15 - lane] = st;
+   if (lane == 0) ch->prev_gain_Q16 = prev_gain;
+   wv_sync();
+}
+
+/* silk_decode_frame (decode_frame.c:43) in three steps: entropy + parameters (lane 0), synthesis (wave), bookkeeping (lane 0) */
+WV_DEV int sd_decode_frame_front(WV_LDS OaSilkChannel *ch, EC_ARGS, int lostFlag, int condCoding, const SdScratch &S)      /* 1 = decode, 0 = conceal */
+{
+   S.ctrl->LTP_scale_Q14 = 0;
    if (lostFlag == SD_FLAG_DECODE_NORMAL || (lostFlag == SD_FLAG_DECODE_LBRR && ch->LBRR_flags[ch->nFramesDecoded] == 1)) {
       sd_decode_indices(EC_PASS, ch, ch->nFramesDecoded, lostFlag, condCoding);
-      sd_decode_pulses(EC_PASS, S.pulses, ch->indices.signalType, ch->indices.quantOffsetType, L, S.tmp);
-#ifndef SD_PROF_SKIP_PARAMS
-      sd_decode_parameters(ch, ctrl, condCoding);
-#endif
-#ifndef SD_PROF_SKIP_CORE          /* (profiling experiment switch, never defined in the product build) */
-      sd_decode_core(ch, ctrl, pOut, S);
-#endif
+      sd_decode_pulses(EC_PASS, S.pulses, ch->indices.signalType, ch->indices.quantOffsetType, ch->frame_length, S.tmp);
+      sd_decode_parameters(ch, S.ctrl, condCoding);
+      return 1;
+   }
+   return 0;
+}
+WV_DEV void sd_decode_frame_back(WV_LDS OaSilkChannel *ch, WV_LDS i16 *pOut, int decoded, const SdScratch &S)
+{
+   const int L = ch->frame_length;
+   WV_LDS SdCtrl *ctrl = S.ctrl;
+   if (decoded) {
       const int mv = ch->ltp_mem_length - L;
       for (int i = 0; i < mv; i++) ch->outBuf[i] = ch->outBuf[L + i];
       for (int i = 0; i < L; i++) ch->outBuf[mv + i] = pOut[i];
@@ -742,7 +863,6 @@ WV_DEV int sd_decode_frame(WV_LDS OaSilkChannel *ch, EC_ARGS, WV_LDS i16 *pOut, 
    sd_cng(ch, ctrl, pOut, L, S);
    sd_plc_glue_frames(ch, pOut, L);
    ch->lagPrev = ctrl->pitchL[ch->nb_subfr - 1];
-   return L;
 }
 
 WV_DEV void sd_stereo_decode_pred(EC_ARGS, i32 *pred_Q13)                                                   /* stereo_decode_pred.c:35 */
