@@ -1,0 +1,528 @@
+/* silk_enc_analysis.h — SILK encoder analysis stages (row a20 of SURVEY §8): noise shaping, LTP and LPC analysis.
+ *
+ *   se_warped_autocorr_l0        silk_warped_autocorrelation_FIX_c   silk/fixed/warped_autocorrelation_FIX.c:40
+ *   se_schur64 / se_k2a_Q16      silk_schur64 / silk_k2a_Q16         silk/fixed/schur64_FIX.c:36, k2a_Q16_FIX.c:36
+ *   se_noise_shape_analysis      silk_noise_shape_analysis_FIX       silk/fixed/noise_shape_analysis_FIX.c:147 (warped_gain :38, limit_warped_coefs :59)
+ *   se_burg_modified_l0          silk_burg_modified_c                silk/fixed/burg_modified_FIX.c:46
+ *   se_find_ltp_l0               silk_find_LTP_FIX                   silk/fixed/find_LTP_FIX.c:36 (corrMatrix_FIX.c:40,:83)
+ *   se_quant_ltp_gains_l0        silk_quant_LTP_gains, silk_VQ_WMat_EC_c   silk/quant_LTP_gains.c:35, silk/VQ_WMat_EC.c:35
+ *   se_ltp_scale_ctrl            silk_LTP_scale_ctrl_FIX             silk/fixed/LTP_scale_ctrl_FIX.c:36
+ *   se_ltp_analysis_filter_wave  silk_LTP_analysis_filter_FIX        silk/fixed/LTP_analysis_filter_FIX.c:36
+ *   se_residual_energy           silk_residual_energy_FIX            silk/fixed/residual_energy_FIX.c:37
+ *   se_find_lpc                  silk_find_LPC_FIX                   silk/fixed/find_LPC_FIX.c:38
+ *   se_find_pred_coefs           silk_find_pred_coefs_FIX            silk/fixed/find_pred_coefs_FIX.c:36 */
+#ifndef OPUS_AMD_SILK_ENC_ANALYSIS_H
+#define OPUS_AMD_SILK_ENC_ANALYSIS_H
+
+WV_DEV int se_clz64(i64 in) { const i32 up = (i32)(in >> 32); return up == 0 ? 32 + sk_clz((i32)in) : sk_clz(up); }
+WV_DEV i32 se_add_lshift32(i32 a, i32 b, int s) { return add32(a, shl32(b, s)); }
+WV_DEV void se_bwexpander_32(i32 *ar, int d, i32 chirp_Q16)                                    /* bwexpander_32.c:37 */
+{
+   const i32 cm1 = chirp_Q16 - 65536;
+   for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
+   ar[d - 1] = sk_mulww(chirp_Q16, ar[d - 1]);
+}
+/* silk_LPC_fit (silk/LPC_fit.c:35) */
+template <class PO> WV_DEV void se_lpc_fit(PO a_QOUT, i32 *a_QIN, int QOUT, int QIN, int d)
+{
+   int i, idx = 0;
+   for (i = 0; i < 10; i++) {
+      i32 maxabs = 0;
+      for (int k = 0; k < d; k++) { const i32 av = iabs(a_QIN[k]); if (av > maxabs) { maxabs = av; idx = k; } }
+      maxabs = sk_rround(maxabs, QIN - QOUT);
+      if (maxabs > 32767) {
+         maxabs = imin(maxabs, 163838);
+         const i32 chirp_Q16 = SE_FIX(0.999, 16) - shl32(maxabs - 32767, 14) / ((maxabs * (idx + 1)) >> 2);
+         se_bwexpander_32(a_QIN, d, chirp_Q16);
+      } else break;
+   }
+   if (i == 10) for (int k = 0; k < d; k++) { a_QOUT[k] = (i16)sk_sat16(sk_rround(a_QIN[k], QIN - QOUT)); a_QIN[k] = shl32((i32)a_QOUT[k], QIN - QOUT); }
+   else for (int k = 0; k < d; k++) a_QOUT[k] = (i16)sk_rround(a_QIN[k], QIN - QOUT);
+}
+
+/* corr: [order + 1]; returns scale.  QC = 10, QS = 13 (silk/fixed/main_FIX.h:49-50) */
+WV_DEV int se_warped_autocorr_l0(i32 *corr, const WV_LDS i16 *input, int warping_Q16, int length, int order)
+{
+   i32 state_QS[SE_MAX_SHAPE_ORDER + 1]; i64 corr_QC[SE_MAX_SHAPE_ORDER + 1];
+   for (int i = 0; i <= order; i++) { state_QS[i] = 0; corr_QC[i] = 0; }
+   for (int n = 0; n < length; n++) {
+      i32 tmp1_QS = shl32((i32)input[n], 13), tmp2_QS;
+      for (int i = 0; i < order; i += 2) {
+         tmp2_QS = sk_mlawb(state_QS[i], state_QS[i + 1] - tmp1_QS, warping_Q16);
+         state_QS[i] = tmp1_QS;
+         corr_QC[i] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 13 - 10);
+         tmp1_QS = sk_mlawb(state_QS[i + 1], state_QS[i + 2] - tmp2_QS, warping_Q16);
+         state_QS[i + 1] = tmp2_QS;
+         corr_QC[i + 1] += ((i64)tmp2_QS * state_QS[0]) >> (2 * 13 - 10);
+      }
+      state_QS[order] = tmp1_QS;
+      corr_QC[order] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 13 - 10);
+   }
+   int lsh = se_clz64(corr_QC[0]) - 35;
+   lsh = se_limit(lsh, -12 - 10, 30 - 10);
+   if (lsh >= 0) for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] << lsh);
+   else for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] >> -lsh);
+   return -(10 + lsh);
+}
+WV_DEV i32 se_schur64(i32 *rc_Q16, const i32 *c, int order)
+{
+   i32 C[SE_MAX_SHAPE_ORDER + 1][2];
+   int k;
+   if (c[0] <= 0) { for (k = 0; k < order; k++) rc_Q16[k] = 0; return 0; }
+   for (k = 0; k <= order; k++) C[k][0] = C[k][1] = c[k];
+   for (k = 0; k < order; k++) {
+      if (iabs(C[k + 1][0]) >= C[0][1]) { rc_Q16[k] = C[k + 1][0] > 0 ? -SE_FIX(.99f, 16) : SE_FIX(.99f, 16); k++; break; }
+      const i32 rc_tmp_Q31 = sk_div32_varQ(-C[k + 1][0], C[0][1], 31);
+      rc_Q16[k] = sk_rround(rc_tmp_Q31, 15);
+      for (int n = 0; n < order - k; n++) {
+         const i32 t1 = C[n + k + 1][0], t2 = C[n][1];
+         C[n + k + 1][0] = t1 + sk_mulhi(shl32(t2, 1), rc_tmp_Q31);
+         C[n][1] = t2 + sk_mulhi(shl32(t1, 1), rc_tmp_Q31);
+      }
+   }
+   for (; k < order; k++) rc_Q16[k] = 0;
+   return imax(1, C[0][1]);
+}
+WV_DEV void se_k2a_Q16(i32 *A_Q24, const i32 *rc_Q16, int order)
+{
+   for (int k = 0; k < order; k++) {
+      const i32 rc = rc_Q16[k];
+      for (int n = 0; n < (k + 1) >> 1; n++) { const i32 t1 = A_Q24[n], t2 = A_Q24[k - n - 1]; A_Q24[n] = sk_mlaww(t1, t2, rc); A_Q24[k - n - 1] = sk_mlaww(t2, t1, rc); }
+      A_Q24[k] = -shl32(rc, 8);
+   }
+}
+WV_DEV i32 se_warped_gain(const i32 *coefs_Q24, int lambda_Q16, int order)
+{
+   lambda_Q16 = -lambda_Q16;
+   i32 gain_Q24 = coefs_Q24[order - 1];
+   for (int i = order - 2; i >= 0; i--) gain_Q24 = sk_mlawb(coefs_Q24[i], gain_Q24, lambda_Q16);
+   gain_Q24 = sk_mlawb(SE_FIX(1.0, 24), gain_Q24, -lambda_Q16);
+   return sk_inverse32_varQ(gain_Q24, 40);
+}
+WV_DEV void se_limit_warped_coefs(i32 *coefs_Q24, int lambda_Q16, i32 limit_Q24, int order)
+{
+   int ind = 0;
+   lambda_Q16 = -lambda_Q16;
+   for (int i = order - 1; i > 0; i--) coefs_Q24[i - 1] = sk_mlawb(coefs_Q24[i - 1], coefs_Q24[i], lambda_Q16);
+   lambda_Q16 = -lambda_Q16;
+   i32 nom_Q16 = sk_mlawb(SE_FIX(1.0, 16), -(i32)lambda_Q16, lambda_Q16), den_Q24 = sk_mlawb(SE_FIX(1.0, 24), coefs_Q24[0], lambda_Q16);
+   i32 gain_Q16 = sk_div32_varQ(nom_Q16, den_Q24, 24);
+   for (int i = 0; i < order; i++) coefs_Q24[i] = sk_mulww(gain_Q16, coefs_Q24[i]);
+   const i32 limit_Q20 = limit_Q24 >> 4;
+   for (int iter = 0; iter < 10; iter++) {
+      i32 maxabs_Q24 = -1;
+      for (int i = 0; i < order; i++) { const i32 t = iabs(coefs_Q24[i]); if (t > maxabs_Q24) { maxabs_Q24 = t; ind = i; } }
+      const i32 maxabs_Q20 = maxabs_Q24 >> 4;
+      if (maxabs_Q20 <= limit_Q20) return;
+      for (int i = 1; i < order; i++) coefs_Q24[i - 1] = sk_mlawb(coefs_Q24[i - 1], coefs_Q24[i], lambda_Q16);
+      gain_Q16 = sk_inverse32_varQ(gain_Q16, 32);
+      for (int i = 0; i < order; i++) coefs_Q24[i] = sk_mulww(gain_Q16, coefs_Q24[i]);
+      const i32 chirp_Q16 = SE_FIX(0.99, 16) - sk_div32_varQ(sk_mulwb(maxabs_Q20 - limit_Q20, sk_mlabb(SE_FIX(0.8, 10), SE_FIX(0.1, 10), iter)), maxabs_Q20 * (ind + 1), 22);
+      se_bwexpander_32(coefs_Q24, order, chirp_Q16);
+      lambda_Q16 = -lambda_Q16;
+      for (int i = order - 1; i > 0; i--) coefs_Q24[i - 1] = sk_mlawb(coefs_Q24[i - 1], coefs_Q24[i], lambda_Q16);
+      lambda_Q16 = -lambda_Q16;
+      nom_Q16 = sk_mlawb(SE_FIX(1.0, 16), -(i32)lambda_Q16, lambda_Q16); den_Q24 = sk_mlawb(SE_FIX(1.0, 24), coefs_Q24[0], lambda_Q16);
+      gain_Q16 = sk_div32_varQ(nom_Q16, den_Q24, 24);
+      for (int i = 0; i < order; i++) coefs_Q24[i] = sk_mulww(gain_Q16, coefs_Q24[i]);
+   }
+}
+
+/* pitch_res = res_pitch_frame, x = x_frame; xw: i16[240] windowed signal, xx: i16[240], w32: i32[28] */
+WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32)
+{
+   const WV_LDS i16 *x_ptr = x - c->la_shape;
+   const int order = c->shapingLPCOrder, swl = c->shapeWinLength;
+   LANE0 {
+      i32 SNR_adj_dB_Q7 = c->SNR_dB_Q7;
+      ctl->input_quality_Q14 = ((i32)c->input_quality_bands_Q15[0] + c->input_quality_bands_Q15[1]) >> 2;
+      ctl->coding_quality_Q14 = se_sigm_Q15(sk_rround(SNR_adj_dB_Q7 - SE_FIX(20.0, 7), 4)) >> 1;
+      if (c->useCBR == 0) {
+         i32 b_Q8 = SE_FIX(1.0, 8) - c->speech_activity_Q8;
+         b_Q8 = sk_mulwb(shl32(b_Q8, 8), b_Q8);
+         SNR_adj_dB_Q7 = sk_mlawb(SNR_adj_dB_Q7, sk_mulbb(SE_FIX(-2.0f, 7) >> (4 + 1), b_Q8), sk_mulwb(SE_FIX(1.0, 14) + ctl->input_quality_Q14, ctl->coding_quality_Q14));
+      }
+      if (c->indices.signalType == SE_TYPE_VOICED) SNR_adj_dB_Q7 = sk_mlawb(SNR_adj_dB_Q7, SE_FIX(2.0f, 8), c->LTPCorr_Q15);
+      else SNR_adj_dB_Q7 = sk_mlawb(SNR_adj_dB_Q7, sk_mlawb(SE_FIX(6.0, 9), -SE_FIX(0.4, 18), c->SNR_dB_Q7), SE_FIX(1.0, 14) - ctl->input_quality_Q14);
+      if (c->indices.signalType == SE_TYPE_VOICED) c->indices.quantOffsetType = 0;
+      else {
+         const int nSamples = shl32(c->fs_kHz, 1), nSegs = sk_mulbb(5, c->nb_subfr) / 2;
+         i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
+         const WV_LDS i16 *p = pitch_res;
+         for (int k = 0; k < nSegs; k++) {
+            i32 nrg; int scale;
+            sd_sum_sqr_shift(&nrg, &scale, p, nSamples);
+            nrg += nSamples >> scale;
+            const i32 log_energy_Q7 = se_lin2log(nrg);
+            if (k > 0) energy_variation_Q7 += iabs(log_energy_Q7 - log_energy_prev_Q7);
+            log_energy_prev_Q7 = log_energy_Q7;
+            p += nSamples;
+         }
+         c->indices.quantOffsetType = energy_variation_Q7 > SE_FIX(0.6f, 7) * (nSegs - 1) ? 0 : 1;
+      }
+      w32[26] = SNR_adj_dB_Q7;
+   }
+   i32 strength_Q16 = sk_mulwb(ctl->predGain_Q16, SE_FIX(1e-3f, 16));
+   const i32 BWExp_Q16 = sk_div32_varQ(SE_FIX(0.94f, 16), sk_mlaww(SE_FIX(1.0, 16), strength_Q16, strength_Q16), 16);
+   const int warping_Q16 = c->warping_Q16 > 0 ? sk_mlawb(c->warping_Q16, (i32)ctl->coding_quality_Q14, SE_FIX(0.01, 18)) : 0;
+   for (int k = 0; k < c->nb_subfr; k++) {
+      const int flat_part = c->fs_kHz * 3, slope_part = (swl - flat_part) >> 1;
+      LANE0 {
+         se_apply_sine_window(xw, x_ptr, 1, slope_part);
+         for (int i = 0; i < flat_part; i++) xw[slope_part + i] = x_ptr[slope_part + i];
+         se_apply_sine_window(xw + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
+      }
+      x_ptr += c->subfr_length;
+      int scale = 0;
+      if (c->warping_Q16 <= 0) scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
+      LANE0 {
+         i32 auto_corr[SE_MAX_SHAPE_ORDER + 1], refl_coef_Q16[SE_MAX_SHAPE_ORDER], AR_Q24[SE_MAX_SHAPE_ORDER];
+         if (c->warping_Q16 > 0) scale = se_warped_autocorr_l0(auto_corr, xw, warping_Q16, swl, order);
+         else for (int i = 0; i <= order; i++) auto_corr[i] = w32[i];
+         auto_corr[0] = add32(auto_corr[0], imax(sk_mulwb(auto_corr[0] >> 4, SE_FIX(3e-5f, 20)), 1));
+         i32 nrg = se_schur64(refl_coef_Q16, auto_corr, order);
+         se_k2a_Q16(AR_Q24, refl_coef_Q16, order);
+         int Qnrg = -scale;
+         if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
+         const i32 tmp32 = se_sqrt_approx(nrg);
+         Qnrg >>= 1;
+         i32 g = sk_shl_sat(tmp32, 16 - Qnrg);
+         if (c->warping_Q16 > 0) {
+            const i32 gain_mult_Q16 = se_warped_gain(AR_Q24, warping_Q16, order);
+            if (g < SE_FIX(0.25, 16)) g = sk_mulww(g, gain_mult_Q16);
+            else { g = sk_mulww(sk_rround(g, 1), gain_mult_Q16); g = g >= (2147483647 >> 1) ? 2147483647 : shl32(g, 1); }
+         }
+         ctl->Gains_Q16[k] = g;
+         se_bwexpander_32(AR_Q24, order, BWExp_Q16);
+         if (c->warping_Q16 > 0) {
+            se_limit_warped_coefs(AR_Q24, warping_Q16, SE_FIX(3.999, 24), order);
+            for (int i = 0; i < order; i++) ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER + i] = (i16)sk_sat16(sk_rround(AR_Q24[i], 11));
+         } else se_lpc_fit(&ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER], AR_Q24, 13, 24, order);
+      }
+   }
+   LANE0 {
+      const i32 SNR_adj_dB_Q7 = w32[26];
+      const i32 gain_mult_Q16 = se_log2lin(-sk_mlawb(-SE_FIX(16.0, 7), SNR_adj_dB_Q7, SE_FIX(0.16, 16)));
+      const i32 gain_add_Q16 = se_log2lin(sk_mlawb(SE_FIX(16.0, 7), SE_FIX(2, 7), SE_FIX(0.16, 16)));
+      for (int k = 0; k < c->nb_subfr; k++) { ctl->Gains_Q16[k] = sk_mulww(ctl->Gains_Q16[k], gain_mult_Q16); ctl->Gains_Q16[k] = se_add_pos_sat(ctl->Gains_Q16[k], gain_add_Q16); }
+      strength_Q16 = SE_FIX(4.0f, 4) * sk_mlawb(SE_FIX(1.0, 12), SE_FIX(0.5f, 13), c->input_quality_bands_Q15[0] - SE_FIX(1.0, 15));
+      strength_Q16 = (strength_Q16 * c->speech_activity_Q8) >> 8;
+      i32 Tilt_Q16, HarmShapeGain_Q16;
+      if (c->indices.signalType == SE_TYPE_VOICED) {
+         const int fs_kHz_inv = SE_FIX(0.2, 14) / c->fs_kHz;
+         for (int k = 0; k < c->nb_subfr; k++) {
+            const int b_Q14 = fs_kHz_inv + SE_FIX(3.0, 14) / ctl->pitchL[k];
+            ctl->LF_shp_Q14[k] = shl32(SE_FIX(1.0, 14) - b_Q14 - sk_mulwb(strength_Q16, b_Q14), 16);
+            ctl->LF_shp_Q14[k] |= (uint16_t)(b_Q14 - SE_FIX(1.0, 14));
+         }
+         Tilt_Q16 = -SE_FIX(0.25f, 16) - sk_mulwb(SE_FIX(1.0, 16) - SE_FIX(0.25f, 16), sk_mulwb(SE_FIX(0.35f, 24), c->speech_activity_Q8));
+      } else {
+         const int b_Q14 = 21299 / c->fs_kHz;
+         ctl->LF_shp_Q14[0] = shl32(SE_FIX(1.0, 14) - b_Q14 - sk_mulwb(strength_Q16, sk_mulwb(SE_FIX(0.6, 16), b_Q14)), 16);
+         ctl->LF_shp_Q14[0] |= (uint16_t)(b_Q14 - SE_FIX(1.0, 14));
+         for (int k = 1; k < c->nb_subfr; k++) ctl->LF_shp_Q14[k] = ctl->LF_shp_Q14[0];
+         Tilt_Q16 = -SE_FIX(0.25f, 16);
+      }
+      if (c->indices.signalType == SE_TYPE_VOICED) {
+         HarmShapeGain_Q16 = sk_mlawb(SE_FIX(0.3f, 16), SE_FIX(1.0, 16) - sk_mulwb(SE_FIX(1.0, 18) - shl32(ctl->coding_quality_Q14, 4), ctl->input_quality_Q14), SE_FIX(0.2f, 16));
+         HarmShapeGain_Q16 = sk_mulwb(shl32(HarmShapeGain_Q16, 1), se_sqrt_approx(shl32(c->LTPCorr_Q15, 15)));
+      } else HarmShapeGain_Q16 = 0;
+      for (int k = 0; k < 4; k++) {
+         c->HarmShapeGain_smth_Q16 = sk_mlawb(c->HarmShapeGain_smth_Q16, HarmShapeGain_Q16 - c->HarmShapeGain_smth_Q16, SE_FIX(0.4f, 16));
+         c->Tilt_smth_Q16 = sk_mlawb(c->Tilt_smth_Q16, Tilt_Q16 - c->Tilt_smth_Q16, SE_FIX(0.4f, 16));
+         ctl->HarmShapeGain_Q14[k] = sk_rround(c->HarmShapeGain_smth_Q16, 2);
+         ctl->Tilt_Q14[k] = sk_rround(c->Tilt_smth_Q16, 2);
+      }
+   }
+}
+
+/* ---- silk_burg_modified_c.  QA 25, N_BITS_HEAD_ROOM 3, MIN_RSHIFTS -16, MAX_RSHIFTS 7 ---- */
+WV_DEV i64 se_inner_prod16(const WV_LDS i16 *a, const WV_LDS i16 *b, int len) { i64 s = 0; for (int i = 0; i < len; i++) s += (i32)a[i] * (i32)b[i]; return s; }
+WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q, i32 *A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D)
+{
+   const int QA = 25;
+   i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
+   int k, n, s, lz, rshifts, reached_max_gain;
+   i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
+   const i64 C0_64 = se_inner_prod16(x, x, subfr_length * nb_subfr);
+   lz = se_clz64(C0_64);
+   rshifts = 32 + 1 + 3 - lz;
+   if (rshifts > 32 - QA) rshifts = 32 - QA;
+   if (rshifts < -16) rshifts = -16;
+   if (rshifts > 0) C0 = (i32)(C0_64 >> rshifts); else C0 = shl32((i32)C0_64, -rshifts);
+   CAb[0] = CAf[0] = C0 + sk_mulhi(SE_FIX(1e-5f, 32), C0) + 1;
+   for (k = 0; k < 16; k++) C_first_row[k] = 0;
+   for (s = 0; s < nb_subfr; s++) {
+      const WV_LDS i16 *x_ptr = x + s * subfr_length;
+      for (n = 1; n < D + 1; n++) {
+         const i64 ip = se_inner_prod16(x_ptr, x_ptr + n, subfr_length - n);
+         if (rshifts > 0) C_first_row[n - 1] += (i32)(ip >> rshifts); else C_first_row[n - 1] = add32(C_first_row[n - 1], shl32((i32)ip, -rshifts));
+      }
+   }
+   for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
+   CAb[0] = CAf[0] = C0 + sk_mulhi(SE_FIX(1e-5f, 32), C0) + 1;
+   invGain_Q30 = (i32)1 << 30;
+   reached_max_gain = 0;
+   for (n = 0; n < D; n++) {
+      if (rshifts > -2) {
+         for (s = 0; s < nb_subfr; s++) {
+            const WV_LDS i16 *x_ptr = x + s * subfr_length;
+            x1 = -shl32((i32)x_ptr[n], 16 - rshifts); x2 = -shl32((i32)x_ptr[subfr_length - n - 1], 16 - rshifts);
+            tmp1 = shl32((i32)x_ptr[n], QA - 16); tmp2 = shl32((i32)x_ptr[subfr_length - n - 1], QA - 16);
+            for (k = 0; k < n; k++) {
+               C_first_row[k] = sk_mlawb(C_first_row[k], x1, x_ptr[n - k - 1]);
+               C_last_row[k] = sk_mlawb(C_last_row[k], x2, x_ptr[subfr_length - n + k]);
+               Atmp_QA = Af_QA[k];
+               tmp1 = sk_mlawb(tmp1, Atmp_QA, x_ptr[n - k - 1]);
+               tmp2 = sk_mlawb(tmp2, Atmp_QA, x_ptr[subfr_length - n + k]);
+            }
+            tmp1 = shl32(-tmp1, 32 - QA - rshifts); tmp2 = shl32(-tmp2, 32 - QA - rshifts);
+            for (k = 0; k <= n; k++) { CAf[k] = sk_mlawb(CAf[k], tmp1, x_ptr[n - k]); CAb[k] = sk_mlawb(CAb[k], tmp2, x_ptr[subfr_length - n + k - 1]); }
+         }
+      } else {
+         for (s = 0; s < nb_subfr; s++) {
+            const WV_LDS i16 *x_ptr = x + s * subfr_length;
+            x1 = -shl32((i32)x_ptr[n], -rshifts); x2 = -shl32((i32)x_ptr[subfr_length - n - 1], -rshifts);
+            tmp1 = shl32((i32)x_ptr[n], 17); tmp2 = shl32((i32)x_ptr[subfr_length - n - 1], 17);
+            for (k = 0; k < n; k++) {
+               C_first_row[k] = add32(C_first_row[k], (i32)((u32)x1 * (u32)(i32)x_ptr[n - k - 1]));
+               C_last_row[k] = add32(C_last_row[k], (i32)((u32)x2 * (u32)(i32)x_ptr[subfr_length - n + k]));
+               Atmp1 = sk_rround(Af_QA[k], QA - 17);
+               tmp1 = add32(tmp1, (i32)((u32)(i32)x_ptr[n - k - 1] * (u32)Atmp1));
+               tmp2 = add32(tmp2, (i32)((u32)(i32)x_ptr[subfr_length - n + k] * (u32)Atmp1));
+            }
+            tmp1 = neg32(tmp1); tmp2 = neg32(tmp2);
+            for (k = 0; k <= n; k++) {
+               CAf[k] = sk_mlaww(CAf[k], tmp1, shl32((i32)x_ptr[n - k], -rshifts - 1));
+               CAb[k] = sk_mlaww(CAb[k], tmp2, shl32((i32)x_ptr[subfr_length - n + k - 1], -rshifts - 1));
+            }
+         }
+      }
+      tmp1 = C_first_row[n]; tmp2 = C_last_row[n]; num = 0; nrg = add32(CAb[0], CAf[0]);
+      for (k = 0; k < n; k++) {
+         Atmp_QA = Af_QA[k];
+         lz = sk_clz(iabs(Atmp_QA)) - 1;
+         lz = imin(32 - QA, lz);
+         Atmp1 = shl32(Atmp_QA, lz);
+         tmp1 = se_add_lshift32(tmp1, sk_mulhi(C_last_row[n - k - 1], Atmp1), 32 - QA - lz);
+         tmp2 = se_add_lshift32(tmp2, sk_mulhi(C_first_row[n - k - 1], Atmp1), 32 - QA - lz);
+         num = se_add_lshift32(num, sk_mulhi(CAb[n - k], Atmp1), 32 - QA - lz);
+         nrg = se_add_lshift32(nrg, sk_mulhi(add32(CAb[k + 1], CAf[k + 1]), Atmp1), 32 - QA - lz);
+      }
+      CAf[n + 1] = tmp1; CAb[n + 1] = tmp2;
+      num = add32(num, tmp2);
+      num = shl32(neg32(num), 1);
+      if (iabs(num) < nrg) rc_Q31 = sk_div32_varQ(num, nrg, 31); else rc_Q31 = num > 0 ? 2147483647 : (i32)(-2147483647 - 1);
+      tmp1 = ((i32)1 << 30) - sk_mulhi(rc_Q31, rc_Q31);
+      tmp1 = shl32(sk_mulhi(invGain_Q30, tmp1), 2);
+      if (tmp1 <= minInvGain_Q30) {
+         tmp2 = ((i32)1 << 30) - sk_div32_varQ(minInvGain_Q30, invGain_Q30, 30);
+         rc_Q31 = se_sqrt_approx(tmp2);
+         if (rc_Q31 > 0) { rc_Q31 = (rc_Q31 + tmp2 / rc_Q31) >> 1; rc_Q31 = shl32(rc_Q31, 16); if (num < 0) rc_Q31 = -rc_Q31; }
+         invGain_Q30 = minInvGain_Q30;
+         reached_max_gain = 1;
+      } else invGain_Q30 = tmp1;
+      for (k = 0; k < (n + 1) >> 1; k++) {
+         tmp1 = Af_QA[k]; tmp2 = Af_QA[n - k - 1];
+         Af_QA[k] = se_add_lshift32(tmp1, sk_mulhi(tmp2, rc_Q31), 1);
+         Af_QA[n - k - 1] = se_add_lshift32(tmp2, sk_mulhi(tmp1, rc_Q31), 1);
+      }
+      Af_QA[n] = rc_Q31 >> (31 - QA);
+      if (reached_max_gain) { for (k = n + 1; k < D; k++) Af_QA[k] = 0; break; }
+      for (k = 0; k <= n + 1; k++) {
+         tmp1 = CAf[k]; tmp2 = CAb[n - k + 1];
+         CAf[k] = se_add_lshift32(tmp1, sk_mulhi(tmp2, rc_Q31), 1);
+         CAb[n - k + 1] = se_add_lshift32(tmp2, sk_mulhi(tmp1, rc_Q31), 1);
+      }
+   }
+   if (reached_max_gain) {
+      for (k = 0; k < D; k++) A_Q16[k] = -sk_rround(Af_QA[k], QA - 16);
+      for (s = 0; s < nb_subfr; s++) {
+         const WV_LDS i16 *x_ptr = x + s * subfr_length;
+         const i64 ip = se_inner_prod16(x_ptr, x_ptr, D);
+         if (rshifts > 0) C0 -= (i32)(ip >> rshifts); else C0 = sub32(C0, shl32((i32)ip, -rshifts));
+      }
+      *res_nrg = shl32(sk_mulhi(invGain_Q30, C0), 2);
+      *res_nrg_Q = -rshifts;
+   } else {
+      nrg = CAf[0]; tmp1 = (i32)1 << 16;
+      for (k = 0; k < D; k++) {
+         Atmp1 = sk_rround(Af_QA[k], QA - 16);
+         nrg = sk_mlaww(nrg, CAf[k + 1], Atmp1);
+         tmp1 = sk_mlaww(tmp1, Atmp1, Atmp1);
+         A_Q16[k] = -Atmp1;
+      }
+      *res_nrg = sk_mlaww(nrg, sk_mulhi(SE_FIX(1e-5f, 32), C0), -tmp1);
+      *res_nrg_Q = -rshifts;
+   }
+}
+
+/* ---- silk_find_LTP_FIX with silk_corrMatrix_FIX / silk_corrVector_FIX.  XX: i32[nb*25], xX: i32[nb*5] ---- */
+WV_DEV void se_find_ltp_l0(WV_LDS i32 *XX, WV_LDS i32 *xX, const WV_LDS i16 *r_ptr, const WV_LDS i32 *lag, int subfr_length, int nb_subfr)
+{
+   const int order = 5, L = subfr_length;
+   for (int k = 0; k < nb_subfr; k++) {
+      const WV_LDS i16 *lag_ptr = r_ptr - (lag[k] + 5 / 2);
+      i32 xx, nrg; int xx_shifts, XX_shifts, xX_shifts;
+      sd_sum_sqr_shift(&xx, &xx_shifts, r_ptr, L + order);
+      {  /* corrMatrix */
+         const WV_LDS i16 *xm = lag_ptr;
+         sd_sum_sqr_shift(&nrg, &XX_shifts, xm, L + order - 1);
+         const int rs = XX_shifts;
+         i32 energy = nrg;
+         for (int i = 0; i < order - 1; i++) energy -= sk_mulbb(xm[i], xm[i]) >> rs;
+         XX[0] = energy;
+         const WV_LDS i16 *ptr1 = &xm[order - 1];
+         for (int j = 1; j < order; j++) {
+            energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr1[L - j]) >> rs);
+            energy = add32(energy, sk_mulbb(ptr1[-j], ptr1[-j]) >> rs);
+            XX[j * order + j] = energy;
+         }
+         const WV_LDS i16 *ptr2 = &xm[order - 2];
+         for (int lg = 1; lg < order; lg++) {
+            energy = 0;
+            if (rs > 0) for (int i = 0; i < L; i++) energy += sk_mulbb(ptr1[i], ptr2[i]) >> rs;
+            else for (int i = 0; i < L; i++) energy = sk_mlabb(energy, ptr1[i], ptr2[i]);
+            XX[lg * order] = energy; XX[lg] = energy;
+            for (int j = 1; j < order - lg; j++) {
+               if (rs > 0) { energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr2[L - j]) >> rs); energy = add32(energy, sk_mulbb(ptr1[-j], ptr2[-j]) >> rs); }
+               else { energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr2[L - j])); energy = sk_mlabb(energy, ptr1[-j], ptr2[-j]); }
+               XX[(lg + j) * order + j] = energy; XX[j * order + lg + j] = energy;
+            }
+            ptr2--;
+         }
+      }
+      const int extra_shifts = xx_shifts - XX_shifts;
+      if (extra_shifts > 0) { xX_shifts = xx_shifts; for (int i = 0; i < 25; i++) XX[i] >>= extra_shifts; nrg >>= extra_shifts; }
+      else if (extra_shifts < 0) { xX_shifts = XX_shifts; xx >>= -extra_shifts; }
+      else xX_shifts = xx_shifts;
+      {  /* corrVector */
+         const WV_LDS i16 *ptr1 = &lag_ptr[order - 1];
+         for (int lg = 0; lg < order; lg++) {
+            i32 ip = 0;
+            if (xX_shifts > 0) for (int i = 0; i < L; i++) ip = add32(ip, sk_mulbb(ptr1[i], r_ptr[i]) >> xX_shifts);
+            else for (int i = 0; i < L; i++) ip = sk_mlabb(ip, ptr1[i], r_ptr[i]);
+            xX[lg] = ip;
+            ptr1--;
+         }
+      }
+      i32 temp = sk_mlawb(1, nrg, SE_FIX(0.03f, 16));
+      temp = imax(temp, xx);
+      for (int i = 0; i < 25; i++) XX[i] = (i32)(((i64)XX[i] << 17) / temp);
+      for (int i = 0; i < 5; i++) xX[i] = (i32)(((i64)xX[i] << 17) / temp);
+      r_ptr += subfr_length; XX += 25; xX += 5;
+   }
+}
+
+/* ---- silk_quant_LTP_gains + silk_VQ_WMat_EC_c ---- */
+WV_DEV void se_quant_ltp_gains_l0(WV_LDS i16 *B_Q14, WV_LDS i8 *cbk_index, WV_LDS i8 *periodicity_index, WV_LDS i32 *sum_log_gain_Q7, WV_LDS i32 *pred_gain_dB_Q7,
+      const WV_LDS i32 *XX_Q17, const WV_LDS i32 *xX_Q17, int subfr_len, int nb_subfr)
+{
+   const int cb_off[3] = {0, 8, 24};
+   i8 temp_idx[4];
+   i32 min_rate_dist_Q7 = 2147483647, best_sum_log_gain_Q7 = 0, res_nrg_Q15 = 0;
+   int gain_Q7 = 0;
+   for (int k = 0; k < 3; k++) {
+      const i32 gain_safety = SE_FIX(0.4, 7);
+      const u8 *cl_Q5 = &se_ltp_gain_bits_q5[cb_off[k]], *cb_gain_Q7 = &se_ltp_vq_gain_q7[cb_off[k]];
+      const i8 *cb_Q7 = &sk_ltp_vq_q7[cb_off[k] * 5];
+      const int cbk_size = 8 << k;
+      const WV_LDS i32 *XX = XX_Q17, *xX = xX_Q17;
+      i32 rate_dist_Q7 = 0, sum_log_gain_tmp_Q7 = *sum_log_gain_Q7;
+      res_nrg_Q15 = 0;
+      for (int j = 0; j < nb_subfr; j++) {
+         const i32 max_gain_Q7 = se_log2lin((SE_FIX(250.0f / 6.0, 7) - sum_log_gain_tmp_Q7) + SE_FIX(7, 7)) - gain_safety;
+         /* VQ_WMat_EC */
+         i32 neg_xX_Q24[5], rate_dist_sub = 2147483647, res_nrg_sub = 2147483647;
+         for (int i = 0; i < 5; i++) neg_xX_Q24[i] = -shl32(xX[i], 7);
+         temp_idx[j] = 0;
+         const i8 *row = cb_Q7;
+         for (int v = 0; v < cbk_size; v++) {
+            const int gain_tmp_Q7 = cb_gain_Q7[v];
+            i32 sum1_Q15 = SE_FIX(1.001, 15), sum2_Q24;
+            const i32 penalty = shl32(imax(sub32(gain_tmp_Q7, max_gain_Q7), 0), 11);
+            sum2_Q24 = neg_xX_Q24[0] + XX[1] * row[1]; sum2_Q24 += XX[2] * row[2]; sum2_Q24 += XX[3] * row[3]; sum2_Q24 += XX[4] * row[4];
+            sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[0] * row[0]; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, row[0]);
+            sum2_Q24 = neg_xX_Q24[1] + XX[7] * row[2]; sum2_Q24 += XX[8] * row[3]; sum2_Q24 += XX[9] * row[4];
+            sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[6] * row[1]; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, row[1]);
+            sum2_Q24 = neg_xX_Q24[2] + XX[13] * row[3]; sum2_Q24 += XX[14] * row[4];
+            sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[12] * row[2]; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, row[2]);
+            sum2_Q24 = neg_xX_Q24[3] + XX[19] * row[4];
+            sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[18] * row[3]; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, row[3]);
+            sum2_Q24 = shl32(neg_xX_Q24[4], 1); sum2_Q24 += XX[24] * row[4]; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, row[4]);
+            if (sum1_Q15 >= 0) {
+               const i32 bits_res_Q8 = sk_mulbb(subfr_len, se_lin2log(sum1_Q15 + penalty) - (15 << 7));
+               const i32 bits_tot_Q8 = se_add_lshift32(bits_res_Q8, cl_Q5[v], 3 - 1);
+               if (bits_tot_Q8 <= rate_dist_sub) { rate_dist_sub = bits_tot_Q8; res_nrg_sub = sum1_Q15 + penalty; temp_idx[j] = (i8)v; gain_Q7 = gain_tmp_Q7; }
+            }
+            row += 5;
+         }
+         res_nrg_Q15 = se_add_pos_sat(res_nrg_Q15, res_nrg_sub);
+         rate_dist_Q7 = se_add_pos_sat(rate_dist_Q7, rate_dist_sub);
+         sum_log_gain_tmp_Q7 = imax(0, sum_log_gain_tmp_Q7 + se_lin2log(gain_safety + gain_Q7) - SE_FIX(7, 7));
+         XX += 25; xX += 5;
+      }
+      if (rate_dist_Q7 <= min_rate_dist_Q7) {
+         min_rate_dist_Q7 = rate_dist_Q7; *periodicity_index = (i8)k;
+         for (int j = 0; j < nb_subfr; j++) cbk_index[j] = temp_idx[j];
+         best_sum_log_gain_Q7 = sum_log_gain_tmp_Q7;
+      }
+   }
+   const i8 *cb = &sk_ltp_vq_q7[cb_off[*periodicity_index] * 5];
+   for (int j = 0; j < nb_subfr; j++) for (int k = 0; k < 5; k++) B_Q14[j * 5 + k] = (i16)shl32(cb[cbk_index[j] * 5 + k], 7);
+   res_nrg_Q15 = nb_subfr == 2 ? res_nrg_Q15 >> 1 : res_nrg_Q15 >> 2;
+   *sum_log_gain_Q7 = best_sum_log_gain_Q7;
+   *pred_gain_dB_Q7 = sk_mulbb(-3, se_lin2log(res_nrg_Q15) - (15 << 7));
+}
+
+WV_DEV void se_ltp_scale_ctrl(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int condCoding)
+{
+   if (condCoding == SE_CODE_INDEPENDENTLY) {
+      int round_loss = c->PacketLoss_perc * c->nFramesPerPacket;
+      if (c->LBRR_flag) round_loss = 2 + sk_mulbb(round_loss, round_loss) / 100;
+      c->indices.LTP_scaleIndex = (i8)(sk_mulbb(ctl->LTPredCodGain_Q7, round_loss) > se_log2lin(128 * 7 + 2900 - c->SNR_dB_Q7));
+      c->indices.LTP_scaleIndex += (i8)(sk_mulbb(ctl->LTPredCodGain_Q7, round_loss) > se_log2lin(128 * 7 + 3900 - c->SNR_dB_Q7));
+   } else c->indices.LTP_scaleIndex = 0;
+   ctl->LTP_scale_Q14 = sk_ltpscales_table_q14[c->indices.LTP_scaleIndex];
+}
+
+/* every output sample is independent: lanes */
+WV_DEV void se_ltp_analysis_filter_wave(WV_LDS i16 *LTP_res, const WV_LDS i16 *x, const WV_LDS i16 *LTPCoef_Q14, const WV_LDS i32 *pitchL, const WV_LDS i32 *invGains_Q16, int subfr_length, int nb_subfr, int pre_length)
+{
+   for (int k = 0; k < nb_subfr; k++) {
+      const WV_LDS i16 *x_ptr = x + k * subfr_length, *x_lag = x_ptr - pitchL[k];
+      WV_LDS i16 *out = LTP_res + k * (subfr_length + pre_length);
+      const i32 b0 = LTPCoef_Q14[k * 5], b1 = LTPCoef_Q14[k * 5 + 1], b2 = LTPCoef_Q14[k * 5 + 2], b3 = LTPCoef_Q14[k * 5 + 3], b4 = LTPCoef_Q14[k * 5 + 4], ig = invGains_Q16[k];
+      FOR_LANES(i, subfr_length + pre_length) {
+         i32 e = sk_mulbb(x_lag[i + 2], b0);
+         e = sk_mlabb(e, x_lag[i + 1], b1); e = sk_mlabb(e, x_lag[i], b2); e = sk_mlabb(e, x_lag[i - 1], b3); e = sk_mlabb(e, x_lag[i - 2], b4);
+         e = sk_rround(e, 14);
+         const i32 r = sk_sat16((i32)x_ptr[i] - e);
+         out[i] = (i16)sk_mulwb(ig, r);
+      }
+   }
+}
+
+/* LPC_res: i16[2 * (16 + 80)] */
+WV_DEV void se_residual_energy_wave(WV_LDS i32 *nrgs, WV_LDS i32 *nrgsQ, const WV_LDS i16 *x, const WV_LDS i16 *a_Q12 /* [2][16] */, const WV_LDS i32 *gains, int subfr_length, int nb_subfr, int LPC_order, WV_LDS i16 *LPC_res)
+{
+   const int offset = LPC_order + subfr_length;
+   const WV_LDS i16 *x_ptr = x;
+   for (int i = 0; i < nb_subfr >> 1; i++) {
+      se_lpc_analysis_filter_wave(LPC_res, x_ptr, a_Q12 + i * 16, 2 * offset, LPC_order);
+      LANE0 {
+         for (int j = 0; j < 2; j++) { i32 e; int rshift; sd_sum_sqr_shift(&e, &rshift, LPC_res + LPC_order + j * offset, subfr_length); nrgs[i * 2 + j] = e; nrgsQ[i * 2 + j] = -rshift; }
+      }
+      x_ptr += 2 * offset;
+   }
+   LANE0 {
+      for (int i = 0; i < nb_subfr; i++) {
+         const int lz1 = sk_clz(nrgs[i]) - 1, lz2 = sk_clz(gains[i]) - 1;
+         i32 t = shl32(gains[i], lz2);
+         t = sk_mulhi(t, t);
+         nrgs[i] = sk_mulhi(t, shl32(nrgs[i], lz1));
+         nrgsQ[i] += lz1 + 2 * lz2 - 32 - 32;
+      }
+   }
+}
+#endif

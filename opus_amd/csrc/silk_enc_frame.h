@@ -1,0 +1,655 @@
+/* silk_enc_frame.h — SILK encoder: entropy coding, stereo front end, frame driver with the rate-control loop, and silk_Encode
+ * (rows a16, a22 encoder half, a18 stereo of SURVEY §8).
+ *
+ *   se_encode_indices     silk_encode_indices     silk/encode_indices.c:35
+ *   se_encode_pulses      silk_encode_pulses, silk_shell_encoder, silk_encode_signs   silk/encode_pulses.c:60, shell_coder.c:78, code_signs.c:41
+ *   se_stereo_*           silk_stereo_LR_to_MS / _find_predictor / _quant_pred / _encode_pred   silk/stereo_LR_to_MS.c:35, stereo_find_predictor.c:35, stereo_quant_pred.c:35, stereo_encode_pred.c:35
+ *   se_encode_frame_wave  silk_encode_frame_FIX   silk/fixed/encode_frame_FIX.c:85
+ *   silk_encode_wave      silk_Encode             silk/enc_API.c:150
+ * Not built: LBRR (in-band FEC) side streams, DTX, prefill (they are driven by Opus-layer options outside this round's path; control words that ask
+ * for them make the frame fail loudly through the stream's error word). */
+#ifndef OPUS_AMD_SILK_ENC_FRAME_H
+#define OPUS_AMD_SILK_ENC_FRAME_H
+
+/* ---- LDS working set ---- */
+struct SeAnaLds {                                      /* analysis phases */
+   i16 res_pitch[32 + 320 + 320 + 8];
+   i16 Wsig[384 + 8], xx[384 + 8];
+   i32 w32[32];
+   i16 A_Q12s[16];
+   union {
+      PitchLds pitch;
+      struct { i16 LPC_in_pre[4 * 16 + 320]; i32 XX[120]; i16 LPC_res[2 * 96]; SeLpcWork W; } p;
+   } u;
+};
+struct SeQuantLds {                                    /* quantiser + rate loop */
+   SeNsqLds N;
+   OaSilkNsqState nsq_copy[2];
+   u8 ec_buf_copy[1276];
+   EcCtx ec_copy, ec_copy2;
+};
+struct SeStereoLds { i16 side[322 + 6], LP_mid[320], HP_mid[320], LP_side[320], HP_side[320]; };
+struct SilkEncLds {
+   OaSilkEnc st;                                       /* persistent state, staged */
+   SeEncCtrl ctl;
+   SeRsLds rs;
+   i32 tmp_rs[99 + 1];
+   i32 r[16];                                          /* lane-0 hand-off words */
+   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; } u;
+};
+
+/* ---- silk_encode_indices (encode_LBRR = 0) ---- */
+WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, EC_ARGS, int condCoding)
+{
+   const WV_LDS OaSilkEncIndices *ix = &c->indices;
+   const int typeOffset = 2 * ix->signalType + ix->quantOffsetType;
+   if (typeOffset >= 2) k_ec_enc_icdf(EC_PASS, typeOffset - 2, sk_type_offset_vad_icdf, 8); else k_ec_enc_icdf(EC_PASS, typeOffset, sk_type_offset_no_vad_icdf, 8);
+   if (condCoding == SE_CODE_CONDITIONALLY) k_ec_enc_icdf(EC_PASS, ix->GainsIndices[0], sk_delta_gain_icdf, 8);
+   else { k_ec_enc_icdf(EC_PASS, ix->GainsIndices[0] >> 3, &sk_gain_icdf[ix->signalType * 8], 8); k_ec_enc_icdf(EC_PASS, ix->GainsIndices[0] & 7, sk_uniform8_icdf, 8); }
+   for (int i = 1; i < c->nb_subfr; i++) k_ec_enc_icdf(EC_PASS, ix->GainsIndices[i], sk_delta_gain_icdf, 8);
+   const SdNlsfCb cb = sd_nlsf_cb(c->predictLPCOrder);
+   k_ec_enc_icdf(EC_PASS, ix->NLSFIndices[0], &cb.cb1_icdf[(ix->signalType >> 1) * cb.nVectors], 8);
+   i32 ec_ix[16], pred_Q8[16];
+   sd_nlsf_unpack(ec_ix, pred_Q8, cb, ix->NLSFIndices[0]);
+   for (int i = 0; i < cb.order; i++) {
+      const int v = ix->NLSFIndices[i + 1];
+      if (v >= 4) { k_ec_enc_icdf(EC_PASS, 8, &cb.ec_icdf[ec_ix[i]], 8); k_ec_enc_icdf(EC_PASS, v - 4, sk_nlsf_ext_icdf, 8); }
+      else if (v <= -4) { k_ec_enc_icdf(EC_PASS, 0, &cb.ec_icdf[ec_ix[i]], 8); k_ec_enc_icdf(EC_PASS, -v - 4, sk_nlsf_ext_icdf, 8); }
+      else k_ec_enc_icdf(EC_PASS, v + 4, &cb.ec_icdf[ec_ix[i]], 8);
+   }
+   if (c->nb_subfr == 4) k_ec_enc_icdf(EC_PASS, ix->NLSFInterpCoef_Q2, sk_nlsf_interpolation_factor_icdf, 8);
+   if (ix->signalType == SE_TYPE_VOICED) {
+      int encode_absolute_lagIndex = 1;
+      if (condCoding == SE_CODE_CONDITIONALLY && c->ec_prevSignalType == SE_TYPE_VOICED) {
+         int delta_lagIndex = ix->lagIndex - c->ec_prevLagIndex;
+         if (delta_lagIndex < -8 || delta_lagIndex > 11) delta_lagIndex = 0; else { delta_lagIndex += 9; encode_absolute_lagIndex = 0; }
+         k_ec_enc_icdf(EC_PASS, delta_lagIndex, sk_pitch_delta_icdf, 8);
+      }
+      if (encode_absolute_lagIndex) {
+         const i32 hi = ix->lagIndex / (c->fs_kHz >> 1), lo = ix->lagIndex - sk_mulbb(hi, c->fs_kHz >> 1);
+         k_ec_enc_icdf(EC_PASS, hi, sk_pitch_lag_icdf, 8);
+         k_ec_enc_icdf(EC_PASS, lo, sd_pitch_low_bits_icdf(c->fs_kHz), 8);
+      }
+      c->ec_prevLagIndex = ix->lagIndex;
+      k_ec_enc_icdf(EC_PASS, ix->contourIndex, sd_pitch_contour_icdf(c->fs_kHz, c->nb_subfr), 8);
+      k_ec_enc_icdf(EC_PASS, ix->PERIndex, sk_ltp_per_index_icdf, 8);
+      const u8 *gicdf = &sk_ltp_gain_icdf[ix->PERIndex == 0 ? 0 : ix->PERIndex == 1 ? 8 : 24];
+      for (int k = 0; k < c->nb_subfr; k++) k_ec_enc_icdf(EC_PASS, ix->LTPIndex[k], gicdf, 8);
+      if (condCoding == SE_CODE_INDEPENDENTLY) k_ec_enc_icdf(EC_PASS, ix->LTP_scaleIndex, sk_ltpscale_icdf, 8);
+   }
+   c->ec_prevSignalType = ix->signalType;
+   k_ec_enc_icdf(EC_PASS, ix->Seed, sk_uniform4_icdf, 8);
+}
+
+/* ---- silk_encode_pulses ---- */
+WV_DEV int se_combine_and_check(int *out, const int *in, int max_pulses, int len) { for (int k = 0; k < len; k++) { const int s = in[2 * k] + in[2 * k + 1]; if (s > max_pulses) return 1; out[k] = s; } return 0; }
+WV_DEV void se_encode_split(EC_ARGS, int p_child1, int p, const u8 *tab) { if (p > 0) k_ec_enc_icdf(EC_PASS, p_child1, &tab[sk_shell_code_table_offsets[p]], 8); }
+WV_DEV void se_shell_encoder(EC_ARGS, const int *p0)
+{
+   int p1[8], p2[4], p3[2], p4[1];
+   for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
+   for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
+   for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
+   p4[0] = p3[0] + p3[1];
+   se_encode_split(EC_PASS, p3[0], p4[0], sk_shell_code_table3);
+   se_encode_split(EC_PASS, p2[0], p3[0], sk_shell_code_table2);
+   se_encode_split(EC_PASS, p1[0], p2[0], sk_shell_code_table1);
+   se_encode_split(EC_PASS, p0[0], p1[0], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p0[2], p1[1], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p1[2], p2[1], sk_shell_code_table1);
+   se_encode_split(EC_PASS, p0[4], p1[2], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p0[6], p1[3], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p2[2], p3[1], sk_shell_code_table2);
+   se_encode_split(EC_PASS, p1[4], p2[2], sk_shell_code_table1);
+   se_encode_split(EC_PASS, p0[8], p1[4], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p0[10], p1[5], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p1[6], p2[3], sk_shell_code_table1);
+   se_encode_split(EC_PASS, p0[12], p1[6], sk_shell_code_table0);
+   se_encode_split(EC_PASS, p0[14], p1[7], sk_shell_code_table0);
+}
+WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LDS i8 *pulses, int frame_length)
+{
+   const int max_pulses_table[4] = {8, 10, 12, 16};
+   int iter = frame_length >> 4;
+   if (iter * 16 < frame_length) { iter++; for (int i = 0; i < 16; i++) pulses[frame_length + i] = 0; }
+   int sum_pulses[20], nRshifts[20], pulses_comb[8];
+   for (int i = 0; i < 8; i++) pulses_comb[i] = 0;
+   for (int i = 0; i < iter; i++) {
+      int ap[16];
+      for (int k = 0; k < 16; k++) ap[k] = iabs((i32)pulses[i * 16 + k]);
+      nRshifts[i] = 0;
+      while (1) {
+         int scale_down = se_combine_and_check(pulses_comb, ap, max_pulses_table[0], 8);
+         scale_down += se_combine_and_check(pulses_comb, pulses_comb, max_pulses_table[1], 4);
+         scale_down += se_combine_and_check(pulses_comb, pulses_comb, max_pulses_table[2], 2);
+         scale_down += se_combine_and_check(&sum_pulses[i], pulses_comb, max_pulses_table[3], 1);
+         if (scale_down) { nRshifts[i]++; for (int k = 0; k < 16; k++) ap[k] >>= 1; } else break;
+      }
+   }
+   i32 minSumBits_Q5 = 2147483647; int RateLevelIndex = 0;
+   for (int k = 0; k < 9; k++) {
+      const u8 *nBits = &se_pulses_per_block_bits_q5[k * 18];
+      i32 sumBits_Q5 = se_rate_levels_bits_q5[(signalType >> 1) * 9 + k];
+      for (int i = 0; i < iter; i++) sumBits_Q5 += nRshifts[i] > 0 ? nBits[16 + 1] : nBits[sum_pulses[i]];
+      if (sumBits_Q5 < minSumBits_Q5) { minSumBits_Q5 = sumBits_Q5; RateLevelIndex = k; }
+   }
+   k_ec_enc_icdf(EC_PASS, RateLevelIndex, &sk_rate_levels_icdf[(signalType >> 1) * 9], 8);
+   const u8 *cdf = &sk_pulses_per_block_icdf[RateLevelIndex * 18];
+   for (int i = 0; i < iter; i++) {
+      if (nRshifts[i] == 0) k_ec_enc_icdf(EC_PASS, sum_pulses[i], cdf, 8);
+      else {
+         k_ec_enc_icdf(EC_PASS, 16 + 1, cdf, 8);
+         for (int k = 0; k < nRshifts[i] - 1; k++) k_ec_enc_icdf(EC_PASS, 16 + 1, &sk_pulses_per_block_icdf[9 * 18], 8);
+         k_ec_enc_icdf(EC_PASS, sum_pulses[i], &sk_pulses_per_block_icdf[9 * 18], 8);
+      }
+   }
+   for (int i = 0; i < iter; i++) {
+      if (sum_pulses[i] > 0) { int ap[16]; for (int k = 0; k < 16; k++) ap[k] = iabs((i32)pulses[i * 16 + k]) >> nRshifts[i]; se_shell_encoder(EC_PASS, ap); }
+   }
+   for (int i = 0; i < iter; i++) {
+      if (nRshifts[i] > 0) {
+         const int nLS = nRshifts[i] - 1;
+         for (int k = 0; k < 16; k++) {
+            const i32 abs_q = (i8)iabs((i32)pulses[i * 16 + k]);
+            for (int j = nLS; j > 0; j--) k_ec_enc_icdf(EC_PASS, (abs_q >> j) & 1, sk_lsb_icdf, 8);
+            k_ec_enc_icdf(EC_PASS, abs_q & 1, sk_lsb_icdf, 8);
+         }
+      }
+   }
+   {  /* silk_encode_signs */
+      u8 icdf[2]; icdf[1] = 0;
+      const u8 *icdf_ptr = &sk_sign_icdf[sk_mulbb(7, quantOffsetType + shl32(signalType, 1))];
+      const int n = (frame_length + 8) >> 4;
+      for (int i = 0; i < n; i++) {
+         const int p = sum_pulses[i];
+         if (p > 0) {
+            icdf[0] = icdf_ptr[imin(p & 0x1F, 6)];
+            for (int j = 0; j < 16; j++) { const int q = pulses[i * 16 + j]; if (q != 0) k_ec_enc_icdf(EC_PASS, (q >> 15) + 1, icdf, 8); }
+         }
+      }
+   }
+}
+
+/* ---- stereo ---- */
+WV_DEV i32 se_stereo_find_predictor(i32 *ratio_Q14, const WV_LDS i16 *x, const WV_LDS i16 *y, WV_LDS i32 *mid_res_amp_Q0, int length, int smooth_coef_Q16)
+{
+   int scale, scale1, scale2; i32 nrgx, nrgy;
+   sd_sum_sqr_shift(&nrgx, &scale1, x, length);
+   sd_sum_sqr_shift(&nrgy, &scale2, y, length);
+   scale = imax(scale1, scale2);
+   scale = scale + (scale & 1);
+   nrgy >>= scale - scale2; nrgx >>= scale - scale1;
+   nrgx = imax(nrgx, 1);
+   i32 corr = 0;
+   for (int i = 0; i < length; i++) corr = corr + (sk_mulbb(x[i], y[i]) >> scale);
+   i32 pred_Q13 = sk_div32_varQ(corr, nrgx, 13);
+   pred_Q13 = se_limit(pred_Q13, -(1 << 14), 1 << 14);
+   const i32 pred2_Q10 = sk_mulwb(pred_Q13, pred_Q13);
+   smooth_coef_Q16 = imax(smooth_coef_Q16, iabs(pred2_Q10));
+   scale >>= 1;
+   mid_res_amp_Q0[0] = sk_mlawb(mid_res_amp_Q0[0], shl32(se_sqrt_approx(nrgx), scale) - mid_res_amp_Q0[0], smooth_coef_Q16);
+   nrgy = sub32(nrgy, shl32(sk_mulwb(corr, pred_Q13), 3 + 1));
+   nrgy = add32(nrgy, shl32(sk_mulwb(nrgx, pred2_Q10), 6));
+   mid_res_amp_Q0[1] = sk_mlawb(mid_res_amp_Q0[1], shl32(se_sqrt_approx(nrgy), scale) - mid_res_amp_Q0[1], smooth_coef_Q16);
+   *ratio_Q14 = sk_div32_varQ(mid_res_amp_Q0[1], imax(mid_res_amp_Q0[0], 1), 14);
+   *ratio_Q14 = se_limit(*ratio_Q14, 0, 32767);
+   return pred_Q13;
+}
+WV_DEV void se_stereo_quant_pred(i32 *pred_Q13, WV_LDS i8 *ix /* [2][3] */)
+{
+   i32 quant_pred_Q13 = 0;
+   for (int n = 0; n < 2; n++) {
+      i32 err_min_Q13 = 2147483647; int done = 0;
+      for (int i = 0; i < 15 && !done; i++) {
+         const i32 low_Q13 = sk_stereo_pred_quant_q13[i], step_Q13 = sk_mulwb(sk_stereo_pred_quant_q13[i + 1] - low_Q13, SE_FIX(0.5 / 5, 16));
+         for (int j = 0; j < 5; j++) {
+            const i32 lvl_Q13 = sk_mlabb(low_Q13, step_Q13, 2 * j + 1), err_Q13 = iabs(pred_Q13[n] - lvl_Q13);
+            if (err_Q13 < err_min_Q13) { err_min_Q13 = err_Q13; quant_pred_Q13 = lvl_Q13; ix[n * 3 + 0] = (i8)i; ix[n * 3 + 1] = (i8)j; } else { done = 1; break; }
+         }
+      }
+      ix[n * 3 + 2] = (i8)(ix[n * 3 + 0] / 3);
+      ix[n * 3 + 0] = (i8)(ix[n * 3 + 0] - ix[n * 3 + 2] * 3);
+      pred_Q13[n] = quant_pred_Q13;
+   }
+   pred_Q13[0] -= pred_Q13[1];
+}
+WV_DEV void se_stereo_encode_pred(EC_ARGS, const WV_LDS i8 *ix)
+{
+   k_ec_enc_icdf(EC_PASS, 5 * ix[2] + ix[3 + 2], sk_stereo_pred_joint_icdf, 8);
+   for (int n = 0; n < 2; n++) { k_ec_enc_icdf(EC_PASS, ix[n * 3 + 0], sk_uniform3_icdf, 8); k_ec_enc_icdf(EC_PASS, ix[n * 3 + 1], sk_uniform5_icdf, 8); }
+}
+/* x1 = &inputBuf0[2], x2 = &inputBuf1[2]; lane 0 */
+WV_DEV void se_stereo_lr_to_ms_l0(WV_LDS OaSilkEncStereo *state, WV_LDS i16 *x1, WV_LDS i16 *x2, WV_LDS i8 *ix, WV_LDS i8 *mid_only_flag, i32 *mid_side_rates_bps, i32 total_rate_bps,
+      int prev_speech_act_Q8, int toMono, int fs_kHz, int frame_length, WV_LDS SeStereoLds *T)
+{
+   WV_LDS i16 *mid = &x1[-2], *side = T->side;
+   i32 sum, diff, pred_Q13[2], LP_ratio_Q14, HP_ratio_Q14, width_Q14;
+   for (int n = 0; n < frame_length + 2; n++) {
+      sum = x1[n - 2] + (i32)x2[n - 2]; diff = x1[n - 2] - (i32)x2[n - 2];
+      mid[n] = (i16)sk_rround(sum, 1); side[n] = (i16)sk_sat16(sk_rround(diff, 1));
+   }
+   mid[0] = state->sMid[0]; mid[1] = state->sMid[1]; side[0] = state->sSide[0]; side[1] = state->sSide[1];
+   state->sMid[0] = mid[frame_length]; state->sMid[1] = mid[frame_length + 1]; state->sSide[0] = side[frame_length]; state->sSide[1] = side[frame_length + 1];
+   for (int n = 0; n < frame_length; n++) {
+      sum = sk_rround(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 2); T->LP_mid[n] = (i16)sum; T->HP_mid[n] = (i16)(mid[n + 1] - sum);
+      sum = sk_rround(add32(side[n] + (i32)side[n + 2], shl32(side[n + 1], 1)), 2); T->LP_side[n] = (i16)sum; T->HP_side[n] = (i16)(side[n + 1] - sum);
+   }
+   const int is10msFrame = frame_length == 10 * fs_kHz;
+   i32 smooth_coef_Q16 = is10msFrame ? SE_FIX(0.01 / 2, 16) : SE_FIX(0.01, 16);
+   smooth_coef_Q16 = sk_mulwb(sk_mulbb(prev_speech_act_Q8, prev_speech_act_Q8), smooth_coef_Q16);
+   pred_Q13[0] = se_stereo_find_predictor(&LP_ratio_Q14, T->LP_mid, T->LP_side, &state->mid_side_amp_Q0[0], frame_length, smooth_coef_Q16);
+   pred_Q13[1] = se_stereo_find_predictor(&HP_ratio_Q14, T->HP_mid, T->HP_side, &state->mid_side_amp_Q0[2], frame_length, smooth_coef_Q16);
+   i32 frac_Q16 = sk_mlabb(HP_ratio_Q14, LP_ratio_Q14, 3);
+   frac_Q16 = imin(frac_Q16, SE_FIX(1, 16));
+   total_rate_bps -= is10msFrame ? 1200 : 600;
+   if (total_rate_bps < 1) total_rate_bps = 1;
+   const i32 min_mid_rate_bps = sk_mlabb(2000, fs_kHz, 600), frac_3_Q16 = 3 * frac_Q16;
+   mid_side_rates_bps[0] = sk_div32_varQ(total_rate_bps, SE_FIX(8 + 5, 16) + frac_3_Q16, 16 + 3);
+   if (mid_side_rates_bps[0] < min_mid_rate_bps) {
+      mid_side_rates_bps[0] = min_mid_rate_bps; mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0];
+      width_Q14 = sk_div32_varQ(shl32(mid_side_rates_bps[1], 1) - min_mid_rate_bps, sk_mulwb(SE_FIX(1, 16) + frac_3_Q16, min_mid_rate_bps), 14 + 2);
+      width_Q14 = se_limit(width_Q14, 0, SE_FIX(1, 14));
+   } else { mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0]; width_Q14 = SE_FIX(1, 14); }
+   state->smth_width_Q14 = (i16)sk_mlawb(state->smth_width_Q14, width_Q14 - state->smth_width_Q14, smooth_coef_Q16);
+   *mid_only_flag = 0;
+   if (toMono) { width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; se_stereo_quant_pred(pred_Q13, ix); }
+   else if (state->width_prev_Q14 == 0 && (8 * total_rate_bps < 13 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.05, 14))) {
+      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+      se_stereo_quant_pred(pred_Q13, ix);
+      width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; mid_side_rates_bps[0] = total_rate_bps; mid_side_rates_bps[1] = 0; *mid_only_flag = 1;
+   } else if (state->width_prev_Q14 != 0 && (8 * total_rate_bps < 11 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.02, 14))) {
+      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+      se_stereo_quant_pred(pred_Q13, ix);
+      width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0;
+   } else if (state->smth_width_Q14 > SE_FIX(0.95, 14)) { se_stereo_quant_pred(pred_Q13, ix); width_Q14 = SE_FIX(1, 14); }
+   else {
+      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+      se_stereo_quant_pred(pred_Q13, ix);
+      width_Q14 = state->smth_width_Q14;
+   }
+   if (*mid_only_flag == 1) {
+      state->silent_side_len += frame_length - 8 * fs_kHz;
+      if (state->silent_side_len < 5 * fs_kHz) *mid_only_flag = 0; else state->silent_side_len = 10000;
+   } else state->silent_side_len = 0;
+   if (*mid_only_flag == 0 && mid_side_rates_bps[1] < 1) { mid_side_rates_bps[1] = 1; mid_side_rates_bps[0] = imax(1, total_rate_bps - mid_side_rates_bps[1]); }
+   i32 pred0_Q13 = -state->pred_prev_Q13[0], pred1_Q13 = -state->pred_prev_Q13[1], w_Q24 = shl32(state->width_prev_Q14, 10);
+   const int denom_Q16 = ((i32)1 << 16) / (8 * fs_kHz);
+   const i32 delta0_Q13 = -sk_rround(sk_mulbb(pred_Q13[0] - state->pred_prev_Q13[0], denom_Q16), 16), delta1_Q13 = -sk_rround(sk_mulbb(pred_Q13[1] - state->pred_prev_Q13[1], denom_Q16), 16);
+   const i32 deltaw_Q24 = shl32(sk_mulwb(width_Q14 - state->width_prev_Q14, denom_Q16), 10);
+   for (int n = 0; n < 8 * fs_kHz; n++) {
+      pred0_Q13 += delta0_Q13; pred1_Q13 += delta1_Q13; w_Q24 += deltaw_Q24;
+      sum = shl32(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 9);
+      sum = sk_mlawb(sk_mulwb(w_Q24, side[n + 1]), sum, pred0_Q13);
+      sum = sk_mlawb(sum, shl32((i32)mid[n + 1], 11), pred1_Q13);
+      x2[n - 1] = (i16)sk_sat16(sk_rround(sum, 8));
+   }
+   pred0_Q13 = -pred_Q13[0]; pred1_Q13 = -pred_Q13[1]; w_Q24 = shl32(width_Q14, 10);
+   for (int n = 8 * fs_kHz; n < frame_length; n++) {
+      sum = shl32(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 9);
+      sum = sk_mlawb(sk_mulwb(w_Q24, side[n + 1]), sum, pred0_Q13);
+      sum = sk_mlawb(sum, shl32((i32)mid[n + 1], 11), pred1_Q13);
+      x2[n - 1] = (i16)sk_sat16(sk_rround(sum, 8));
+   }
+   state->pred_prev_Q13[0] = (i16)pred_Q13[0]; state->pred_prev_Q13[1] = (i16)pred_Q13[1]; state->width_prev_Q14 = (i16)width_Q14;
+}
+
+/* ---- stage taps of the emulator build (same word layout as oracle/ref_expose/x_silk_enc.c) ---- */
+#ifdef K_DUMP_ENABLED
+WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
+{
+   i32 w[330]; int n = 0;
+   if (which == 0) {
+      w[n++] = c->speech_activity_Q8; w[n++] = c->input_tilt_Q15; for (int i = 0; i < 4; i++) w[n++] = c->input_quality_bands_Q15[i];
+      w[n++] = c->SNR_dB_Q7;
+      for (int i = 0; i < 4; i++) w[n++] = ctl->pitchL[i];
+      w[n++] = c->indices.lagIndex; w[n++] = c->indices.contourIndex; w[n++] = c->indices.signalType; w[n++] = c->LTPCorr_Q15; w[n++] = ctl->predGain_Q16;
+      K_DUMP("pitch", w, 4 * n);
+   } else if (which == 1) {
+      for (int i = 0; i < 4; i++) w[n++] = ctl->Gains_Q16[i];
+      for (int i = 0; i < 96; i++) w[n++] = ctl->AR_Q13[i];
+      for (int i = 0; i < 4; i++) w[n++] = ctl->LF_shp_Q14[i];
+      for (int i = 0; i < 4; i++) w[n++] = ctl->Tilt_Q14[i];
+      for (int i = 0; i < 4; i++) w[n++] = ctl->HarmShapeGain_Q14[i];
+      w[n++] = c->indices.quantOffsetType; w[n++] = ctl->input_quality_Q14; w[n++] = ctl->coding_quality_Q14;
+      K_DUMP("shape", w, 4 * n);
+   } else if (which == 2) {
+      for (int i = 0; i < 32; i++) w[n++] = ctl->PredCoef_Q12[i >> 4][i & 15];
+      for (int i = 0; i < 20; i++) w[n++] = ctl->LTPCoef_Q14[i];
+      w[n++] = ctl->LTP_scale_Q14;
+      for (int i = 0; i < 17; i++) w[n++] = c->indices.NLSFIndices[i];
+      w[n++] = c->indices.NLSFInterpCoef_Q2;
+      for (int i = 0; i < 4; i++) w[n++] = c->indices.LTPIndex[i];
+      w[n++] = c->indices.PERIndex;
+      for (int i = 0; i < 4; i++) w[n++] = ctl->ResNrg[i];
+      for (int i = 0; i < 4; i++) w[n++] = ctl->ResNrgQ[i];
+      w[n++] = ctl->LTPredCodGain_Q7;
+      K_DUMP("pred", w, 4 * n);
+   } else if (which == 3) {
+      for (int i = 0; i < 4; i++) w[n++] = ctl->Gains_Q16[i];
+      for (int i = 0; i < 4; i++) w[n++] = c->indices.GainsIndices[i];
+      w[n++] = ctl->Lambda_Q10; w[n++] = c->indices.quantOffsetType; w[n++] = c->LastGainIndex;
+      K_DUMP("gains", w, 4 * n);
+   } else {
+      w[n++] = c->indices.Seed;
+      for (int i = 0; i < c->frame_length; i++) w[n++] = c->pulses[i];
+      K_DUMP("nsq", w, 4 * n);
+   }
+}
+#define SE_TAP(which) do { wv_sync(); if (wv_lane() == 0) se_tap(c, ctl, which); wv_sync(); } while (0)
+#else
+#define SE_TAP(which)
+#endif
+
+/* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
+WV_DEV void se_copy_words_wave(WV_LDS i32 *d, const WV_LDS i32 *s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
+WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR)
+{
+   WV_LDS SeEncCtrl *ctl = &S->ctl;
+   WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+   const int bits_margin = useCBR ? 5 : maxBits / 4;
+   const int NSQW = (int)(sizeof(OaSilkNsqState) / 4);
+   LANE0 {
+      c->indices.Seed = (i8)(c->frameCounter++ & 3);
+      se_lp_variable_cutoff(c, c->inputBuf + 1, c->frame_length);
+   }
+   FOR_LANES(i, c->frame_length) x_frame[5 * c->fs_kHz + i] = c->inputBuf[1 + i];
+   wv_sync();
+   if (!c->prefillFlag) {
+      WV_LDS SeAnaLds *A = &S->u.a;
+      WV_LDS i16 *res_pitch = A->res_pitch, *res_pitch_frame = res_pitch + c->ltp_mem_length;
+      se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->Wsig, A->xx, A->w32, A->A_Q12s, &A->u.pitch);
+      wv_sync();
+      SE_TAP(0);
+      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->Wsig, A->xx, A->w32);
+      wv_sync();
+      SE_TAP(1);
+      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.XX, A->u.p.LPC_res);
+      SE_TAP(2);
+      LANE0 se_process_gains_l0(c, ctl, condCoding);
+      SE_TAP(3);
+      /* (silk_LBRR_encode_FIX: LBRR_enabled is never set on this path) */
+      WV_LDS SeQuantLds *Q = &S->u.q;
+      const int maxIter = 6;
+      int gainMult_Q8 = SE_FIX(1, 8), found_lower = 0, found_upper = 0;
+      i32 gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr), gainsID_lower = -1, gainsID_upper = -1;
+      i32 nBits = 0, nBits_lower = 0, nBits_upper = 0, gainMult_lower = 0, gainMult_upper = 0;
+      int LastGainIndex_copy2 = 0;
+      int gain_lock[4] = {0, 0, 0, 0}; i16 best_gain_mult[4] = {0, 0, 0, 0}; int best_sum[4] = {0, 0, 0, 0};
+      ec_cp_lds(&Q->ec_copy, ecl);
+      se_copy_words_wave((WV_LDS i32 *)&Q->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+      const int seed_copy = c->indices.Seed, ec_prevLagIndex_copy = c->ec_prevLagIndex, ec_prevSignalType_copy = c->ec_prevSignalType;
+      for (int iter = 0; ; iter++) {
+         if (gainsID == gainsID_lower) nBits = nBits_lower;
+         else if (gainsID == gainsID_upper) nBits = nBits_upper;
+         else {
+            if (iter > 0) {
+               wv_sync();
+               LANE0 { ec_cp_lds(ecl, &Q->ec_copy); c->indices.Seed = (i8)seed_copy; c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy; }
+               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const WV_LDS i32 *)&Q->nsq_copy[0], NSQW);
+            }
+            if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+            else se_nsq_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+            wv_sync();
+            SE_TAP(4);
+            LANE0 {
+               if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
+               EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+               se_encode_indices(c, EC_PASS, condCoding);
+               se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
+               int nb = k_ec_tell(EC_PASS);
+               if (iter == maxIter && !found_lower && nb > maxBits) {
+                  ec_ld(&ec_, &Q->ec_copy2);
+                  c->LastGainIndex = ctl->lastGainIndexPrev;
+                  for (int i = 0; i < c->nb_subfr; i++) c->indices.GainsIndices[i] = 4;
+                  if (condCoding != SE_CODE_CONDITIONALLY) c->indices.GainsIndices[0] = (i8)ctl->lastGainIndexPrev;
+                  c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
+                  for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
+                  se_encode_indices(c, EC_PASS, condCoding);
+                  se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
+                  nb = k_ec_tell(EC_PASS);
+               }
+               ec_st(ecl, &ec_);
+               S->r[1] = nb;
+            }
+            nBits = S->r[1];
+            if (useCBR == 0 && iter == 0 && nBits <= maxBits) break;
+         }
+         if (iter == maxIter) {
+            if (found_lower && (gainsID == gainsID_lower || nBits > maxBits)) {
+               wv_sync();
+               LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = Q->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
+               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const WV_LDS i32 *)&Q->nsq_copy[1], NSQW);
+            }
+            break;
+         }
+         if (nBits > maxBits) {
+            if (found_lower == 0 && iter >= 2) { LANE0 ctl->Lambda_Q10 = ctl->Lambda_Q10 + (ctl->Lambda_Q10 >> 1); found_upper = 0; gainsID_upper = -1; }
+            else { found_upper = 1; nBits_upper = nBits; gainMult_upper = gainMult_Q8; gainsID_upper = gainsID; }
+         } else if (nBits < maxBits - bits_margin) {
+            found_lower = 1; nBits_lower = nBits; gainMult_lower = gainMult_Q8;
+            if (gainsID != gainsID_lower) {
+               gainsID_lower = gainsID;
+               wv_sync();
+               LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) Q->ec_buf_copy[i] = buf[i]; }
+               se_copy_words_wave((WV_LDS i32 *)&Q->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
+               LastGainIndex_copy2 = c->LastGainIndex;
+            }
+         } else break;
+         if (!found_lower && nBits > maxBits) {
+            for (int i = 0; i < c->nb_subfr; i++) {
+               int sum = 0;
+               for (int j = i * c->subfr_length; j < (i + 1) * c->subfr_length; j++) sum += iabs((i32)c->pulses[j]);
+               if (iter == 0 || (sum < best_sum[i] && !gain_lock[i])) { best_sum[i] = sum; best_gain_mult[i] = (i16)gainMult_Q8; } else gain_lock[i] = 1;
+            }
+         }
+         if ((found_lower & found_upper) == 0) {
+            if (nBits > maxBits) gainMult_Q8 = imin(1024, gainMult_Q8 * 3 / 2); else gainMult_Q8 = imax(64, gainMult_Q8 * 4 / 5);
+            gainMult_Q8 = (i16)gainMult_Q8;
+         } else {
+            gainMult_Q8 = gainMult_lower + ((gainMult_upper - gainMult_lower) * (maxBits - nBits_lower)) / (nBits_upper - nBits_lower);
+            gainMult_Q8 = (i16)gainMult_Q8;
+            if (gainMult_Q8 > gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2));
+            else if (gainMult_Q8 < gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2));
+         }
+         wv_sync();
+         LANE0 {
+            for (int i = 0; i < c->nb_subfr; i++) { const i16 tmp = gain_lock[i] ? best_gain_mult[i] : (i16)gainMult_Q8; ctl->Gains_Q16[i] = sk_shl_sat(sk_mulwb(ctl->GainsUnq_Q16[i], tmp), 8); }
+            c->LastGainIndex = ctl->lastGainIndexPrev;
+            se_gains_quant(c->indices.GainsIndices, ctl->Gains_Q16, &c->LastGainIndex, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
+         }
+         gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr);
+      }
+   }
+   /* input buffer shift (:381): overlapping move through registers */
+   {
+      const int n = c->ltp_mem_length + 5 * c->fs_kHz, fl = c->frame_length;
+      for (int b = 0; b < n; b += WV_WIDTH) { const int i = b + wv_lane(); i16 v = 0; if (i < n) v = c->x_buf[fl + i]; wv_sync(); if (i < n) c->x_buf[i] = v; wv_sync(); }
+   }
+   LANE0 {
+      if (c->prefillFlag) S->r[0] = 0;
+      else {
+         c->prevLag = ctl->pitchL[c->nb_subfr - 1]; c->prevSignalType = c->indices.signalType; c->first_frame_after_reset = 0;
+         S->r[0] = ((ecl->nbits_total - ec_ilog(ecl->rng)) + 7) >> 3;
+      }
+   }
+}
+
+/* ---- silk_Encode.  pcm: the Opus layer's int16 staging of this call's input (interleaved, nChannelsAPI), nSamplesIn per channel.
+ * Returns 0 or a negative error; *nBytesOut through S->r[0].  One SILK frame per call for 10/20 ms payloads, 2-3 frames for 40/60 ms. ---- */
+struct SePcmSrc {
+   const WV_LDS i16 *p; int stride, off, mix;
+   WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
+   WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
+};
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const WV_LDS i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   int nBytesOut = 0;
+   if (ec->useInBandFEC && ec->LBRR_coded) return -100;                       /* LBRR not built */
+   LANE0 {
+      if (ec->reducedDependency) for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].first_frame_after_reset = 1;
+      for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].nFramesEncoded = 0;
+      ec->switchReady = 0;
+      if (ec->nChannelsInternal > E->nChannelsInternal) {
+         se_init_channel(c1);
+         E->st.pred_prev_Q13[0] = E->st.pred_prev_Q13[1] = 0; E->st.sSide[0] = E->st.sSide[1] = 0;
+         E->st.mid_side_amp_Q0[0] = 0; E->st.mid_side_amp_Q0[1] = 1; E->st.mid_side_amp_Q0[2] = 0; E->st.mid_side_amp_Q0[3] = 1;
+         E->st.width_prev_Q14 = 0; E->st.smth_width_Q14 = SE_FIX(1, 14);
+         if (E->nChannelsAPI == 2) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; }
+      }
+   }
+   const int transition = ec->payloadSize_ms != c0->PacketSize_ms || E->nChannelsInternal != ec->nChannelsInternal;
+   LANE0 { E->nChannelsAPI = ec->nChannelsAPI; E->nChannelsInternal = ec->nChannelsInternal; }
+   const int nBlocksOf10ms = (100 * nSamplesIn) / ec->API_sampleRate;
+   const int tot_blocks = nBlocksOf10ms > 1 ? nBlocksOf10ms >> 1 : 1;
+   int curr_block = 0;
+   if (nBlocksOf10ms * ec->API_sampleRate != 100 * nSamplesIn || nSamplesIn < 0) return -101;
+   if (1000 * (i32)nSamplesIn > ec->payloadSize_ms * ec->API_sampleRate) return -101;
+   LANE0 {
+      i32 mb = ec->maxBits, sr = ec->switchReady;
+      for (int n = 0; n < ec->nChannelsInternal; n++) {
+         const int force_fs_kHz = n == 1 ? c0->fs_kHz : 0;
+         se_control_encoder(&E->ch[n], ec, E->allowBandwidthSwitch, n, force_fs_kHz, &S->rs, S->u.rs_tmp, S->tmp_rs);
+         if (E->ch[n].first_frame_after_reset || transition) for (int i = 0; i < c0->nFramesPerPacket; i++) E->ch[n].LBRR_flags[i] = 0;
+         E->ch[n].inDTX = E->ch[n].useDTX;
+      }
+      S->r[2] = ec->maxBits; S->r[3] = ec->switchReady; (void)mb; (void)sr;
+   }
+   ec->maxBits = S->r[2]; ec->switchReady = S->r[3];                           /* se_control_audio_bw may have changed them on lane 0 */
+   const int nSamplesToBufferMax = 10 * nBlocksOf10ms * c0->fs_kHz;
+   while (1) {
+      int nSamplesToBuffer = imin(c0->frame_length - c0->inputBufIx, nSamplesToBufferMax);
+      const int nSamplesFromInput = (nSamplesToBuffer * c0->API_fs_Hz) / (c0->fs_kHz * 1000);
+      LANE0 {
+         if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
+            const int id = c0->nFramesEncoded;
+            if (E->nPrevChannelsInternal == 1 && id == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; }
+            SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
+            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], s0, nSamplesFromInput);
+            c0->inputBufIx += nSamplesToBuffer;
+            const int n1 = imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz);
+            se_resample_l0(c1->rs_cfg, c1->rs_rows, &S->rs, &c1->inputBuf[c1->inputBufIx + 2], s1, nSamplesFromInput);
+            c1->inputBufIx += n1;
+         } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
+            SePcmSrc sm = {pcm, 2, 0, 1};
+            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], sm, nSamplesFromInput);
+            if (E->nPrevChannelsInternal == 2 && c0->nFramesEncoded == 0) {
+               se_resample_l0(c1->rs_cfg, c1->rs_rows, &S->rs, &c1->inputBuf[c1->inputBufIx + 2], sm, nSamplesFromInput);
+               for (int n = 0; n < c0->frame_length; n++) c0->inputBuf[c0->inputBufIx + n + 2] = (i16)((c0->inputBuf[c0->inputBufIx + n + 2] + c1->inputBuf[c1->inputBufIx + n + 2]) >> 1);
+            }
+            c0->inputBufIx += nSamplesToBuffer;
+         } else {
+            SePcmSrc s0 = {pcm, 1, 0, 0};
+            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], s0, nSamplesFromInput);
+            c0->inputBufIx += nSamplesToBuffer;
+         }
+         E->allowBandwidthSwitch = 0;
+      }
+      pcm += nSamplesFromInput * ec->nChannelsAPI;
+      nSamplesIn -= nSamplesFromInput;
+      if (c0->inputBufIx < c0->frame_length) break;
+      /* ---- enough data: encode one frame ---- */
+      i32 MStargetRates_bps[2] = {0, 0}, TargetRate_bps;
+      LANE0 {
+         EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+         int curr_nBitsUsedLBRR = 0;
+         if (c0->nFramesEncoded == 0) {
+            u8 iCDF[2] = {0, 0};
+            iCDF[0] = (u8)(256 - (256 >> ((c0->nFramesPerPacket + 1) * ec->nChannelsInternal)));
+            k_ec_enc_icdf(EC_PASS, 0, iCDF, 8);
+            curr_nBitsUsedLBRR = k_ec_tell(EC_PASS);
+            for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].LBRR_flag = 0; for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0; }
+            curr_nBitsUsedLBRR = k_ec_tell(EC_PASS) - curr_nBitsUsedLBRR;
+         }
+         se_hp_variable_cutoff(c0);
+         i32 nBits = (ec->bitRate * ec->payloadSize_ms) / 1000;
+         if (curr_nBitsUsedLBRR < 10) E->nBitsUsedLBRR = 0; else if (E->nBitsUsedLBRR < 10) E->nBitsUsedLBRR = curr_nBitsUsedLBRR; else E->nBitsUsedLBRR = (E->nBitsUsedLBRR + curr_nBitsUsedLBRR) / 2;
+         nBits -= E->nBitsUsedLBRR;
+         nBits = nBits / c0->nFramesPerPacket;
+         i32 T = ec->payloadSize_ms == 10 ? sk_mulbb(nBits, 100) : sk_mulbb(nBits, 50);
+         T -= (E->nBitsExceeded * 1000) / 500;
+         if (c0->nFramesEncoded > 0) { const i32 bitsBalance = k_ec_tell(EC_PASS) - E->nBitsUsedLBRR - nBits * c0->nFramesEncoded; T -= (bitsBalance * 1000) / 500; }
+         T = se_limit(T, ec->bitRate, 5000);
+         S->r[4] = T;
+         if (ec->nChannelsInternal == 2) {
+            i32 ms[2];
+            se_stereo_lr_to_ms_l0(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], ms, T, c0->speech_activity_Q8,
+                  ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
+            S->r[5] = ms[0]; S->r[6] = ms[1];
+            if (E->st.mid_only_flags[c0->nFramesEncoded] == 0) {
+               if (E->prev_decode_only_middle == 1) {
+                  c1->LastGainIndex = 0; c1->HarmShapeGain_smth_Q16 = 0; c1->Tilt_smth_Q16 = 0;
+                  se_nsq_reset(&c1->nsq);
+                  for (int i = 0; i < 16; i++) c1->prev_NLSFq_Q15[i] = 0;
+                  c1->lp_In_LP_State[0] = c1->lp_In_LP_State[1] = 0;
+                  c1->prevLag = 100; c1->nsq.lagPrev = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->nsq.prev_gain_Q16 = 65536; c1->first_frame_after_reset = 1;
+               }
+               se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
+            } else c1->VAD_flags[c0->nFramesEncoded] = 0;
+            se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
+            if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
+         } else {
+            c0->inputBuf[0] = E->st.sMid[0]; c0->inputBuf[1] = E->st.sMid[1];
+            E->st.sMid[0] = c0->inputBuf[c0->frame_length]; E->st.sMid[1] = c0->inputBuf[c0->frame_length + 1];
+         }
+         se_vad_l0(c0, c0->inputBuf + 1, S->u.vadX, activity);
+         ec_st(ecl, &ec_);
+      }
+      TargetRate_bps = S->r[4]; MStargetRates_bps[0] = S->r[5]; MStargetRates_bps[1] = S->r[6];
+      for (int n = 0; n < ec->nChannelsInternal; n++) {
+         int maxBits = ec->maxBits;
+         if (tot_blocks == 2 && curr_block == 0) maxBits = maxBits * 3 / 5;
+         else if (tot_blocks == 3) { if (curr_block == 0) maxBits = maxBits * 2 / 5; else if (curr_block == 1) maxBits = maxBits * 3 / 4; }
+         int useCBR = ec->useCBR && curr_block == tot_blocks - 1;
+         i32 channelRate_bps;
+         if (ec->nChannelsInternal == 1) channelRate_bps = TargetRate_bps;
+         else { channelRate_bps = MStargetRates_bps[n]; if (n == 0 && MStargetRates_bps[1] > 0) { useCBR = 0; maxBits -= ec->maxBits / (tot_blocks * 2); } }
+         if (channelRate_bps > 0) {
+            LANE0 se_control_snr(&E->ch[n], channelRate_bps);
+            int condCoding;
+            if (c0->nFramesEncoded - n <= 0) condCoding = SE_CODE_INDEPENDENTLY;
+            else if (n > 0 && E->prev_decode_only_middle) condCoding = SE_CODE_INDEPENDENTLY_NO_LTP_SCALING;
+            else condCoding = SE_CODE_CONDITIONALLY;
+            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR);
+            nBytesOut = S->r[0];
+         }
+         wv_sync();
+         LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
+      }
+      LANE0 {
+         E->prev_decode_only_middle = E->st.mid_only_flags[c0->nFramesEncoded - 1];
+         if (nBytesOut > 0 && c0->nFramesEncoded == c0->nFramesPerPacket) {
+            int flags = 0;
+            for (int n = 0; n < ec->nChannelsInternal; n++) {
+               for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) { flags <<= 1; flags |= E->ch[n].VAD_flags[i]; }
+               flags <<= 1; flags |= E->ch[n].LBRR_flag;
+            }
+            EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+            k_ec_enc_patch_initial_bits(EC_PASS, flags, (c0->nFramesPerPacket + 1) * ec->nChannelsInternal);
+            ec_st(ecl, &ec_);
+            int nb = nBytesOut;
+            if (c0->inDTX && (ec->nChannelsInternal == 1 || c1->inDTX)) nb = 0;
+            E->nBitsExceeded += nb * 8;
+            E->nBitsExceeded -= (ec->bitRate * ec->payloadSize_ms) / 1000;
+            E->nBitsExceeded = se_limit(E->nBitsExceeded, 0, 10000);
+            const int thr = sk_mlawb(SE_FIX(0.05f, 8), SE_FIX((1 - 0.05f) / 5000, 16 + 8), E->timeSinceSwitchAllowed_ms);
+            if (c0->speech_activity_Q8 < thr) { E->allowBandwidthSwitch = 1; E->timeSinceSwitchAllowed_ms = 0; } else { E->allowBandwidthSwitch = 0; E->timeSinceSwitchAllowed_ms += ec->payloadSize_ms; }
+            S->r[0] = nb;
+         }
+      }
+      nBytesOut = S->r[0];
+      if (nSamplesIn == 0) break;
+      curr_block++;
+   }
+   LANE0 E->nPrevChannelsInternal = ec->nChannelsInternal;
+   ec->allowBandwidthSwitch = E->allowBandwidthSwitch;
+   ec->inWBmodeWithoutVariableLP = c0->fs_kHz == 16 && c0->lp_mode == 0;
+   ec->internalSampleRate = sk_mulbb(c0->fs_kHz, 1000);
+   ec->stereoWidth_Q14 = ec->toMono ? 0 : E->st.smth_width_Q14;
+   ec->signalType = c0->indices.signalType;
+   ec->offset = se_quantization_offsets_q10[(c0->indices.signalType >> 1) * 2 + c0->indices.quantOffsetType];
+   S->r[0] = nBytesOut;
+   return 0;
+}
+#endif

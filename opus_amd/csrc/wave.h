@@ -13,6 +13,7 @@
 
 #define WV_DEV  __device__ __forceinline__
 #define WV_DEVN __device__ __noinline__
+#define WV_MEM  __device__ __forceinline__          /* member functions */
 #define WV_HD   __host__ __device__ inline          /* small pure helpers shared with host code */
 #define WV_LDS  __attribute__((address_space(3)))
 #define WV_TABLE __device__ const

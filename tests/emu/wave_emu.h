@@ -14,6 +14,7 @@ static inline void emu_die() { void *bt[32]; int n = backtrace(bt, 32); backtrac
 
 #define WV_DEV  static inline
 #define WV_DEVN static
+#define WV_MEM  inline
 #define WV_HD   static inline
 #define WV_LDS
 #define WV_TABLE static const
