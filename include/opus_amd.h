@@ -60,15 +60,29 @@ extern "C" {
 #define OPUS_GET_BANDWIDTH_REQUEST 4009
 #define OPUS_SET_COMPLEXITY_REQUEST 4010
 #define OPUS_GET_COMPLEXITY_REQUEST 4011
+#define OPUS_SET_INBAND_FEC_REQUEST 4012
+#define OPUS_GET_INBAND_FEC_REQUEST 4013
+#define OPUS_SET_PACKET_LOSS_PERC_REQUEST 4014
+#define OPUS_GET_PACKET_LOSS_PERC_REQUEST 4015
+#define OPUS_SET_DTX_REQUEST 4016
+#define OPUS_GET_DTX_REQUEST 4017
 #define OPUS_SET_VBR_CONSTRAINT_REQUEST 4020
 #define OPUS_GET_VBR_CONSTRAINT_REQUEST 4021
 #define OPUS_SET_FORCE_CHANNELS_REQUEST 4022
 #define OPUS_GET_FORCE_CHANNELS_REQUEST 4023
+#define OPUS_SET_SIGNAL_REQUEST 4024
+#define OPUS_GET_SIGNAL_REQUEST 4025
 #define OPUS_RESET_STATE 4028
 #define OPUS_GET_SAMPLE_RATE_REQUEST 4029
 #define OPUS_GET_FINAL_RANGE_REQUEST 4031
 #define OPUS_SET_LSB_DEPTH_REQUEST 4036
 #define OPUS_GET_LSB_DEPTH_REQUEST 4037
+#define OPUS_SET_FORCE_MODE_REQUEST 11002              /* src/opus_private.h:173 (what opus_demo and the tests use to pin SILK-only / hybrid) */
+#define OPUS_SIGNAL_VOICE 3001
+#define OPUS_SIGNAL_MUSIC 3002
+#define OPUS_MODE_SILK_ONLY 1000
+#define OPUS_MODE_HYBRID 1001
+#define OPUS_MODE_CELT_ONLY 1002
 #define OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST 4046
 #define OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST 4047
 

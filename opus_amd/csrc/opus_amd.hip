@@ -12,6 +12,7 @@ __device__ unsigned long long oa_phase_ticks[34];
 #endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
+#include "silk_enc_all.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
 #include <stdlib.h>
@@ -40,6 +41,19 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
    const int s = blockIdx.x;
    if (s >= nstreams) return;
    oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
+}
+
+/* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream, SILK state staged in LDS */
+extern "C" __global__ void __launch_bounds__(64, 1)
+oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i16 *pcm_hp, i32 *lens, u32 *rngs, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   const int s = blockIdx.x;
+   if (s >= nstreams) return;
+   OaShStream *gs = streams + s;
+   const size_t off = (size_t)s * frame_size * gs->cfg.channels;
+   oa_sh_encode_frame(L, gs, pcm + off, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, pcm_hp + off, lens + s, rngs + s);
 }
 
 #include "opus_packet_host.h"
@@ -116,8 +130,80 @@ static int oa_ctl_get(const OaStream *st, int request, opus_int32 *value)
 }
 static int oa_frame_size_ok(int frame_size) { return frame_size == 120 || frame_size == 240 || frame_size == 480 || frame_size == 960; }
 
+/* ---------------- the SILK-capable stream record (applications VOIP / AUDIO / RESTRICTED_SILK) ---------------- */
+static int oa_app_is_sh(int application) { return application == OPUS_APPLICATION_VOIP || application == OPUS_APPLICATION_AUDIO || application == OPUS_APPLICATION_RESTRICTED_SILK; }
+static int sh_init_stream(OaShStream *st, opus_int32 Fs, int channels, int application)
+{
+   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2) || !oa_app_is_sh(application)) return OPUS_BAD_ARG;
+   oa_sh_stream_init(st, Fs, channels, application);
+   return OPUS_OK;
+}
+static int sh_ctl_set(OaShStream *st, int request, opus_int32 value)
+{
+   OaShConfig *c = &st->cfg;
+   switch (request) {
+   case OPUS_SET_BITRATE_REQUEST:
+      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) { if (value <= 0) return OPUS_BAD_ARG; else if (value <= 500) value = 500; else if (value > (opus_int32)750000 * c->channels) value = (opus_int32)750000 * c->channels; }
+      c->user_bitrate_bps = value; return OPUS_OK;
+   case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; c->complexity = value; return OPUS_OK;
+   case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_vbr = value; return OPUS_OK;
+   case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->vbr_constraint = value; return OPUS_OK;
+   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > c->channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->force_channels = value; return OPUS_OK;
+   case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; c->max_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; c->lsb_depth = value; return OPUS_OK;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->disable_inv = value; return OPUS_OK;
+   case OPUS_SET_FORCE_MODE_REQUEST: if ((value < OPUS_MODE_SILK_ONLY || value > OPUS_MODE_CELT_ONLY) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_forced_mode = value; return OPUS_OK;
+   case OPUS_SET_SIGNAL_REQUEST: if (value != OPUS_AUTO && value != OPUS_SIGNAL_VOICE && value != OPUS_SIGNAL_MUSIC) return OPUS_BAD_ARG; c->signal_type = value; return OPUS_OK;
+   case OPUS_SET_PACKET_LOSS_PERC_REQUEST: if (value < 0 || value > 100) return OPUS_BAD_ARG; c->packet_loss_perc = value; return OPUS_OK;
+   case OPUS_SET_INBAND_FEC_REQUEST: if (value < 0 || value > 2) return OPUS_BAD_ARG; c->use_inband_fec = value; return OPUS_OK;     /* refused at encode time when it would produce LBRR */
+   case OPUS_SET_DTX_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_dtx = value; return OPUS_OK;
+   case OPUS_RESET_STATE: oa_sh_stream_reset(st, c->Fs, c->channels, c->application); return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+static int sh_ctl_get(const OaShStream *st, int request, opus_int32 *value)
+{
+   if (!value) return OPUS_BAD_ARG;
+   const OaShConfig *c = &st->cfg;
+   switch (request) {
+   case OPUS_GET_APPLICATION_REQUEST: *value = c->application; return OPUS_OK;
+   case OPUS_GET_BITRATE_REQUEST: {
+      const opus_int32 fs = st->s.prev_framesize ? st->s.prev_framesize : c->Fs / 400, maxb = 1276 * 8 * (6 * c->Fs / fs) / 6;
+      const opus_int32 ub = c->user_bitrate_bps == OPUS_AUTO ? 60 * c->Fs / fs + c->Fs * c->channels : (c->user_bitrate_bps == OPUS_BITRATE_MAX ? 1500000 : c->user_bitrate_bps);
+      *value = ub < maxb ? ub : maxb; return OPUS_OK; }
+   case OPUS_GET_COMPLEXITY_REQUEST: *value = c->complexity; return OPUS_OK;
+   case OPUS_GET_VBR_REQUEST: *value = c->use_vbr; return OPUS_OK;
+   case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = c->vbr_constraint; return OPUS_OK;
+   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = c->force_channels; return OPUS_OK;
+   case OPUS_GET_BANDWIDTH_REQUEST: *value = st->s.bandwidth; return OPUS_OK;
+   case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = c->max_bandwidth; return OPUS_OK;
+   case OPUS_GET_LSB_DEPTH_REQUEST: *value = c->lsb_depth; return OPUS_OK;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: *value = c->disable_inv; return OPUS_OK;
+   case OPUS_GET_SIGNAL_REQUEST: *value = c->signal_type; return OPUS_OK;
+   case OPUS_GET_PACKET_LOSS_PERC_REQUEST: *value = c->packet_loss_perc; return OPUS_OK;
+   case OPUS_GET_INBAND_FEC_REQUEST: *value = c->use_inband_fec; return OPUS_OK;
+   case OPUS_GET_DTX_REQUEST: *value = c->use_dtx; return OPUS_OK;
+   case OPUS_GET_SAMPLE_RATE_REQUEST: *value = c->Fs; return OPUS_OK;
+   case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)st->s.rangeFinal; return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+/* frame sizes of the SILK layer: 10, 20, 40, 60 ms (2.5 / 5 ms need CELT; 80-120 ms are repacketised multi-frame packets) */
+static int sh_frame_size_code(opus_int32 Fs, int frame_size)
+{
+   if (frame_size == Fs / 100 || frame_size == Fs / 50 || frame_size == Fs / 25 || frame_size == 3 * Fs / 50) return OPUS_OK;
+   if (frame_size == Fs / 400 || frame_size == Fs / 200 || frame_size == 4 * Fs / 50 || frame_size == 5 * Fs / 50 || frame_size == 6 * Fs / 50) return OPUS_UNIMPLEMENTED;
+   return OPUS_BAD_ARG;
+}
+
 /* ---------------- batch object ---------------- */
 struct OpusGpuEncBatch {
+   int kind;                            /* 0: CELT-only kernel (OaStream), 1: SILK-capable kernel (OaShStream) */
+   opus_int32 Fs;
+   OaShStream *d_sh;
+   std::vector<OaShStream> h_sh;
+   opus_int16 *d_pcm_hp; size_t hp_cap; /* per-stream scratch of the high-passed input (kind 1) */
    int device;
    opus_int32 S;
    int channels;
@@ -135,6 +221,8 @@ extern "C" {
 
 int opusgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
+int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
+int opusgpu_sh_kernel_lds_bytes(void) { return (int)sizeof(ShLds); }
 int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
 opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
 
@@ -143,8 +231,10 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    int err = OPUS_OK;
    OpusGpuEncBatch *b = nullptr;
    OaStream proto;
+   const int kind = oa_app_is_sh(application);
+   OaShStream *shproto = kind ? new OaShStream : nullptr;
    if (nstreams <= 0) err = OPUS_BAD_ARG;
-   if (err == OPUS_OK) err = oa_init_stream(&proto, Fs, channels, application);
+   if (err == OPUS_OK) err = kind ? sh_init_stream(shproto, Fs, channels, application) : oa_init_stream(&proto, Fs, channels, application);
    if (err == OPUS_OK) {
       int ndev = 0;
       if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -155,16 +245,22 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = false;
+      b->kind = kind; b->Fs = Fs; b->d_sh = nullptr; b->d_pcm_hp = nullptr; b->hp_cap = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
-      b->h_streams.assign(nstreams, proto);
+      if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
-                hipMalloc((void **)&b->d_streams, sizeof(OaStream) * (size_t)nstreams) == hipSuccess &&
+                (kind ? hipMalloc((void **)&b->d_sh, sizeof(OaShStream) * (size_t)nstreams) == hipSuccess &&
+                        hipMemcpy(b->d_sh, b->h_sh.data(), sizeof(OaShStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipFuncSetAttribute((const void *)oa_sh_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                      : true) &&
+                hipMalloc((void **)&b->d_streams, sizeof(OaStream) * (size_t)(kind ? 1 : nstreams)) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess &&
+                (kind || hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess) &&
                 hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       if (!ok) { opusgpu_enc_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
    }
+   delete shproto;
    if (error) *error = err;
    return b;
 }
@@ -174,6 +270,8 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    (void)hipSetDevice(b->device);
    if (b->stream) (void)hipStreamSynchronize(b->stream);
    if (b->d_streams) (void)hipFree(b->d_streams);
+   if (b->d_sh) (void)hipFree(b->d_sh);
+   if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_pcm) (void)hipFree(b->d_pcm);
    if (b->d_out) (void)hipFree(b->d_out);
    if (b->d_lens) (void)hipFree(b->d_lens);
@@ -188,6 +286,12 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   if (b->kind) {
+      for (opus_int32 s = lo; s < hi; s++) { int r = sh_ctl_set(&b->h_sh[s], request, value); if (r != OPUS_OK) return r; }
+      if (request == OPUS_RESET_STATE) HIPCHECK(hipMemcpy(b->d_sh + lo, &b->h_sh[lo], sizeof(OaShStream) * (size_t)(hi - lo), hipMemcpyHostToDevice));
+      else HIPCHECK(hipMemcpy2D(&b->d_sh[lo].cfg, sizeof(OaShStream), &b->h_sh[lo].cfg, sizeof(OaShStream), sizeof(OaShConfig), (size_t)(hi - lo), hipMemcpyHostToDevice));
+      return OPUS_OK;
+   }
    for (opus_int32 s = lo; s < hi; s++) {
       int r = oa_ctl_set(&b->h_streams[s], request, value);
       if (r != OPUS_OK) return r;
@@ -202,6 +306,13 @@ int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    if (!b || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
+   if (b->kind) {
+      OaShStream *t = new OaShStream(b->h_sh[stream]);
+      hipError_t e_ = hipMemcpy(&t->s, &b->d_sh[stream].s, sizeof(OaShScalars), hipMemcpyDeviceToHost);
+      const int r = e_ == hipSuccess ? sh_ctl_get(t, request, value) : OPUS_INTERNAL_ERROR;
+      delete t;
+      return r;
+   }
    OaStream tmp = b->h_streams[stream];
    HIPCHECK(hipMemcpy(&tmp.st.s, &b->d_streams[stream].st.s, sizeof(OaEncScalars), hipMemcpyDeviceToHost));
    return oa_ctl_get(&tmp, request, value);
@@ -211,12 +322,22 @@ int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *
    if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   HIPCHECK(hipMemcpy(blob, b->d_streams + stream, sizeof(OaStream), hipMemcpyDeviceToHost));
+   if (b->kind) HIPCHECK(hipMemcpy(blob, b->d_sh + stream, sizeof(OaShStream), hipMemcpyDeviceToHost));
+   else HIPCHECK(hipMemcpy(blob, b->d_streams + stream, sizeof(OaStream), hipMemcpyDeviceToHost));
    return OPUS_OK;
 }
 int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const void *blob)
 {
    if (!b || !blob || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
+   if (b->kind) {
+      const OaShStream *src = (const OaShStream *)blob;
+      if (src->cfg.channels != b->channels || src->cfg.Fs != b->Fs) return OPUS_BAD_ARG;
+      HIPCHECK(hipSetDevice(b->device));
+      HIPCHECK(hipStreamSynchronize(b->stream));
+      b->h_sh[stream] = *src;
+      HIPCHECK(hipMemcpy(b->d_sh + stream, src, sizeof(OaShStream), hipMemcpyHostToDevice));
+      return OPUS_OK;
+   }
    const OaStream *src = (const OaStream *)blob;
    if (src->cfg.channels != b->channels) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
@@ -232,11 +353,20 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
-   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   if (b->kind) { const int fr = sh_frame_size_code(b->Fs, frame_size); if (fr != OPUS_OK) return fr; }
+   else if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
    if (out_stride < (max_data_bytes < 1276 ? max_data_bytes : 1276)) return OPUS_BUFFER_TOO_SMALL;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+   if (b->kind) {
+      const size_t need = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16);
+      if (need > b->hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->hp_cap = need; }
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(ShLds), s,
+            b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i16 *)b->d_pcm_hp, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+      HIPCHECK(hipGetLastError());
+      return OPUS_OK;
+   }
    static const size_t lds_pad = getenv("OPUS_AMD_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_LDS_PAD")) : 0;   /* occupancy experiments only */
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds) + lds_pad, s,
          b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
@@ -266,7 +396,8 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
 {
    if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
-   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   if (b->kind) { const int fr = sh_frame_size_code(b->Fs, frame_size); if (fr != OPUS_OK) return fr; }
+   else if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    size_t npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->S * out_stride;
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
@@ -283,19 +414,27 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
 
 /* ---------------- classic libopus encoder API on top of a process-wide batch-of-one ---------------- */
 #define OA_MAGIC 0x4f41454eu /* "OAEN" */
-struct OpusEncoder { uint32_t magic; uint32_t pad[3]; OaStream s; };
+struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pad[2]; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
 static std::mutex g_classic_mu;
-static OpusGpuEncBatch *g_classic[2] = {nullptr, nullptr};    /* per channel count */
+static OpusGpuEncBatch *g_classic[2] = {nullptr, nullptr};    /* CELT-only kernel, per channel count */
+static OpusGpuEncBatch *g_classic_sh[5][2];                   /* SILK-capable kernel, per API rate and channel count */
+static int oa_fs_index(opus_int32 Fs) { return Fs == 8000 ? 0 : Fs == 12000 ? 1 : Fs == 16000 ? 2 : Fs == 24000 ? 3 : 4; }
 
 int opus_encoder_get_size(int channels) { if (channels < 1 || channels > 2) return 0; return (int)sizeof(OpusEncoder); }
 int opus_encoder_init(OpusEncoder *st, opus_int32 Fs, int channels, int application)
 {
    if (!st) return OPUS_BAD_ARG;
+   if (oa_app_is_sh(application)) {
+      if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
+      memset(st, 0, sizeof(*st));
+      st->magic = OA_MAGIC; st->kind = 1;
+      return sh_init_stream(&st->sh, Fs, channels, application);
+   }
    OaStream tmp;
    int r = oa_init_stream(&tmp, Fs, channels, application);
    if (r != OPUS_OK) return r;
    memset(st, 0, sizeof(*st));
-   st->magic = OA_MAGIC; st->s = tmp;
+   st->magic = OA_MAGIC; st->kind = 0; st->s = tmp;
    return OPUS_OK;
 }
 OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, int *error)
@@ -312,21 +451,27 @@ opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, u
 {
    if (!st || st->magic != OA_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
-   if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
    std::lock_guard<std::mutex> lock(g_classic_mu);
-   const int ci = st->s.cfg.channels - 1;
-   if (!g_classic[ci]) {
-      int err;
-      g_classic[ci] = opusgpu_enc_batch_create(1, 48000, st->s.cfg.channels, st->s.cfg.application, 0, &err);
-      if (!g_classic[ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   OpusGpuEncBatch **slot;
+   int channels; opus_int32 Fs; int application;
+   if (st->kind) { channels = st->sh.cfg.channels; Fs = st->sh.cfg.Fs; application = st->sh.cfg.application; slot = &g_classic_sh[oa_fs_index(Fs)][channels - 1]; const int fr = sh_frame_size_code(Fs, frame_size); if (fr != OPUS_OK) return fr; }
+   else {
+      channels = st->s.cfg.channels; Fs = 48000; application = st->s.cfg.application; slot = &g_classic[channels - 1];
+      if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
    }
-   OpusGpuEncBatch *b = g_classic[ci];
+   if (!*slot) {
+      int err;
+      *slot = opusgpu_enc_batch_create(1, Fs, channels, application, 0, &err);
+      if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   }
+   OpusGpuEncBatch *b = *slot;
    unsigned char buf[1280];
    opus_int32 len = 0; opus_uint32 rng = 0;
    opus_int32 cap = max_data_bytes < 1276 ? max_data_bytes : 1276;
-   int r = opusgpu_enc_batch_import_state(b, 0, &st->s);
+   void *blob = st->kind ? (void *)&st->sh : (void *)&st->s;
+   int r = opusgpu_enc_batch_import_state(b, 0, blob);
    if (r == OPUS_OK) r = opusgpu_encode_batch(b, pcm, frame_size, buf, 1280, max_data_bytes, &len, &rng);
-   if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, &st->s);
+   if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, blob);
    if (r != OPUS_OK) return r;
    if (len > 0) memcpy(data, buf, (size_t)(len < cap ? len : cap));
    return len;
@@ -337,9 +482,9 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    va_list ap;
    va_start(ap, request);
    int ret;
-   if (request == OPUS_RESET_STATE) ret = oa_ctl_set(&st->s, request, 0);
-   else if (request & 1) { opus_int32 *p = va_arg(ap, opus_int32 *); ret = oa_ctl_get(&st->s, request, p); }   /* GET requests are odd */
-   else { opus_int32 v = va_arg(ap, opus_int32); ret = oa_ctl_set(&st->s, request, v); }
+   if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
+   else if (request & 1) { opus_int32 *p = va_arg(ap, opus_int32 *); ret = st->kind ? sh_ctl_get(&st->sh, request, p) : oa_ctl_get(&st->s, request, p); }   /* GET requests are odd */
+   else { opus_int32 v = va_arg(ap, opus_int32); ret = st->kind ? sh_ctl_set(&st->sh, request, v) : oa_ctl_set(&st->s, request, v); }
    va_end(ap);
    return ret;
 }

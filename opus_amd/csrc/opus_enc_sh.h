@@ -1,0 +1,336 @@
+/* opus_enc_sh.h — one (stream, frame) of the SILK-capable Opus encoder on one wavefront: HBM state -> LDS -> packet bytes -> HBM.
+ *
+ * Follows src/opus_encoder.c:1182 opus_encode_native (rate, channel, mode and bandwidth decisions :1310-1700) and :1855 opus_encode_frame_native
+ * (high-pass :1958-1992, SILK control block :2024-2160, SILK call :2181, TOC / range finalisation :2310-2560, CBR padding :2646) for the SILK-only
+ * mode, i.e. applications VOIP, AUDIO and RESTRICTED_SILK at API rates 8-48 kHz, mono/stereo, 10-60 ms frames.  What this round's path does not
+ * build is refused loudly through the stream's error word and a negative length: hybrid / CELT-only outcomes of the mode decision, mode and
+ * bandwidth transitions that need a CELT redundancy frame, in-band FEC, DTX, frames above 60 ms (repacketised multi-frame packets). */
+#ifndef OPUS_AMD_OPUS_ENC_SH_H
+#define OPUS_AMD_OPUS_ENC_SH_H
+#include "opus_sh_state.h"
+
+#define OA_MODE_SILK_ONLY 1000
+#define OA_MODE_HYBRID 1001
+#define OA_MODE_CELT_ONLY 1002
+#define OA_APP_VOIP 2048
+#define OA_APP_AUDIO 2049
+#define OA_APP_RESTRICTED_SILK 2052
+#define OA_SIGNAL_VOICE 3001
+#define OA_SIGNAL_MUSIC 3002
+#define OA_ERR_UNIMPLEMENTED (-5)
+#define OA_ERR_INTERNAL (-3)
+#define OA_ERR_BUFFER_TOO_SMALL (-2)
+
+struct ShShared {
+   i32 frame_size, max_data_bytes, orig_max_data_bytes, pad_to, plc_frame, ret, err, toc, is_silence, sample_max;
+   i32 bitrate_bps, equiv_rate, curr_bandwidth, activity, cutoff_Hz, use_hp_cutoff, bits_target, nBytes, silk_ret;
+   i32 r[8];
+};
+struct ShLds {
+   SilkEncLds S;
+   EcCtx ec;
+   ShShared sh;
+   OaShScalars st;
+   OaShConfig cfg;
+   u8 packet[OA_MAX_PACKET + 4];
+};
+#define SH_STAGE_SAMPLES 1920
+
+WV_DEV i32 sh_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int mode, int complexity, int loss)      /* compute_equiv_rate :780 */
+{
+   i32 equiv = bitrate;
+   if (frame_rate > 50) equiv -= (40 * channels + 20) * (frame_rate - 50);
+   if (!vbr) equiv -= equiv / 12;
+   equiv = equiv * (90 + complexity) / 100;
+   if (mode == OA_MODE_SILK_ONLY || mode == OA_MODE_HYBRID) { if (complexity < 2) equiv = equiv * 4 / 5; equiv -= equiv * loss / (6 * loss + 10); }
+   else if (mode == OA_MODE_CELT_ONLY) { if (complexity < 5) equiv = equiv * 9 / 10; }
+   else equiv -= equiv * loss / (12 * loss + 20);
+   return equiv;
+}
+WV_DEV u8 sh_gen_toc(int mode, int framerate, int bandwidth, int channels)                                            /* gen_toc :330 */
+{
+   int period = 0; u8 toc;
+   while (framerate < 400) { framerate <<= 1; period++; }
+   if (mode == OA_MODE_SILK_ONLY) toc = (u8)(((bandwidth - OA_BW_NB) << 5) | ((period - 2) << 3));
+   else if (mode == OA_MODE_CELT_ONLY) { int tmp = bandwidth - OA_BW_MB; if (tmp < 0) tmp = 0; toc = (u8)(0x80 | (tmp << 5) | (period << 3)); }
+   else toc = (u8)(0x60 | ((bandwidth - OA_BW_SWB) << 4) | ((period - 2) << 3));
+   return (u8)(toc | ((channels == 2) << 2));
+}
+
+/* lane 0: opus_encode_native's decisions (:1310-1700) */
+WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st; const WV_LDS OaShConfig *cfg = &L->cfg;
+   const int Fs = cfg->Fs, channels = cfg->channels;
+   i32 max_data_bytes = imin(1276 * 6, out_data_bytes);
+   st->rangeFinal = 0;
+   sh->plc_frame = 0; sh->ret = 0; sh->err = 0; sh->pad_to = 0; sh->frame_size = frame_size;
+   if (max_data_bytes == 1 && Fs == frame_size * 10) { sh->err = OA_ERR_BUFFER_TOO_SMALL; return; }
+   const i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
+   i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
+   int frame_rate = Fs / frame_size;
+   if (!cfg->use_vbr) {
+      const i32 cbr_bytes = imin((bitrate_to_bits(bitrate_bps, Fs, frame_size) + 4) / 8, max_data_bytes);
+      bitrate_bps = bits_to_bitrate(cbr_bytes * 8, Fs, frame_size);
+      max_data_bytes = imax(1, cbr_bytes);
+      sh->pad_to = max_data_bytes;
+   }
+   if (max_data_bytes < 3 || bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || bitrate_bps < 2400))) {
+      /* 'PLC' frame (:1345-1410) */
+      int tocmode = st->mode, bw = st->bandwidth == 0 ? OA_BW_NB : st->bandwidth, packet_code = 0, num_multiframes = 0;
+      if (tocmode == 0) tocmode = OA_MODE_SILK_ONLY;
+      if (frame_rate > 100) tocmode = OA_MODE_CELT_ONLY;
+      if (frame_rate == 25 && tocmode != OA_MODE_SILK_ONLY) { frame_rate = 50; packet_code = 1; }
+      if (frame_rate <= 16) {
+         if (out_data_bytes == 1 || (tocmode == OA_MODE_SILK_ONLY && frame_rate != 10)) { tocmode = OA_MODE_SILK_ONLY; packet_code = frame_rate <= 12; frame_rate = frame_rate == 12 ? 25 : 16; }
+         else { num_multiframes = 50 / frame_rate; frame_rate = 50; packet_code = 3; }
+      }
+      if (tocmode == OA_MODE_SILK_ONLY && bw > OA_BW_WB) bw = OA_BW_WB;
+      else if (tocmode == OA_MODE_CELT_ONLY && bw == OA_BW_MB) bw = OA_BW_NB;
+      else if (tocmode == OA_MODE_HYBRID && bw <= OA_BW_SWB) bw = OA_BW_SWB;
+      L->packet[0] = (u8)(sh_gen_toc(tocmode, frame_rate, bw, st->stream_channels) | packet_code);
+      if (packet_code == 3) L->packet[1] = (u8)num_multiframes;
+      sh->plc_frame = 1; sh->ret = packet_code <= 1 ? 1 : 2;
+      return;
+   }
+   const i32 max_rate = bits_to_bitrate(max_data_bytes * 8, Fs, frame_size);
+   const int loss = cfg->packet_loss_perc;
+   i32 equiv_rate = sh_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
+   int voice_est;
+   if (cfg->signal_type == OA_SIGNAL_VOICE) voice_est = 127; else if (cfg->signal_type == OA_SIGNAL_MUSIC) voice_est = 0;
+   else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;                 /* voice_ratio is -1 without the float analysis */
+   if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
+   else if (channels == 2) {
+      i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
+      if (st->stream_channels == 2) thr -= 1000; else thr += 1000;
+      st->stream_channels = equiv_rate > thr ? 2 : 1;
+   } else st->stream_channels = channels;
+   equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
+   if (cfg->use_dtx && !sh->is_silence) { sh->err = OA_ERR_UNIMPLEMENTED; return; }              /* SILK DTX */
+   /* mode (:1487-1560) */
+   if (cfg->application == OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_SILK_ONLY;
+   else if (cfg->user_forced_mode == OA_AUTO) {
+      if (channels == 2 && cfg->force_channels != 1) { sh->err = OA_ERR_UNIMPLEMENTED; return; }  /* needs compute_stereo_width (next round) */
+      const i32 stereo_width = 0;
+      const i32 mode_voice = (i32)(mult16_32_q15(Q15ONE - stereo_width, 64000) + mult16_32_q15(stereo_width, 44000));
+      const i32 mode_music = (i32)(mult16_32_q15(Q15ONE - stereo_width, 10000) + mult16_32_q15(stereo_width, 10000));
+      i32 threshold = mode_music + ((voice_est * voice_est * (mode_voice - mode_music)) >> 14);
+      if (cfg->application == OA_APP_VOIP) threshold += 8000;
+      if (st->prev_mode == OA_MODE_CELT_ONLY) threshold -= 4000; else if (st->prev_mode > 0) threshold += 4000;
+      st->mode = equiv_rate >= threshold ? OA_MODE_CELT_ONLY : OA_MODE_SILK_ONLY;
+      if (max_data_bytes < bitrate_to_bits(frame_rate > 50 ? 9000 : 6000, Fs, frame_size) / 8) st->mode = OA_MODE_CELT_ONLY;
+   } else st->mode = cfg->user_forced_mode;
+   if (st->mode != OA_MODE_CELT_ONLY && frame_size < Fs / 100) st->mode = OA_MODE_CELT_ONLY;
+   if (st->mode == OA_MODE_CELT_ONLY || st->prev_mode == OA_MODE_CELT_ONLY) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
+   if (st->stream_channels == 1 && st->prev_channels == 2 && st->sm_toMono == 0) { st->sm_toMono = 1; st->stream_channels = 2; } else st->sm_toMono = 0;
+   equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, st->mode, cfg->complexity, loss);
+   /* bandwidth (:1600-1700) */
+   if (st->first || st->sm_allowBandwidthSwitch) {
+      const i32 voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000}, music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};
+      int bandwidth = OA_BW_FB;
+      do {
+         const int k = 2 * (bandwidth - OA_BW_MB);
+         int threshold = music_bw[k] + ((voice_est * voice_est * (voice_bw[k] - music_bw[k])) >> 14);
+         const int hysteresis = music_bw[k + 1] + ((voice_est * voice_est * (voice_bw[k + 1] - music_bw[k + 1])) >> 14);
+         if (!st->first) { if (st->auto_bandwidth >= bandwidth) threshold -= hysteresis; else threshold += hysteresis; }
+         if (equiv_rate >= threshold) break;
+      } while (--bandwidth > OA_BW_NB);
+      if (bandwidth == OA_BW_MB) bandwidth = OA_BW_WB;
+      st->bandwidth = st->auto_bandwidth = bandwidth;
+      if (!st->first && !st->sm_inWBmodeWithoutVariableLP && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
+   }
+   if (st->bandwidth > cfg->max_bandwidth) st->bandwidth = cfg->max_bandwidth;
+   if (cfg->user_bandwidth != OA_AUTO) st->bandwidth = cfg->user_bandwidth;
+   if (max_rate < 15000) st->bandwidth = imin(st->bandwidth, OA_BW_WB);
+   if (Fs <= 24000 && st->bandwidth > OA_BW_SWB) st->bandwidth = OA_BW_SWB;
+   if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
+   if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
+   if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
+   if (cfg->use_inband_fec && loss > 0) { sh->err = OA_ERR_UNIMPLEMENTED; return; }               /* decide_fec :739 -> LBRR */
+   st->sm_LBRR_coded = 0;
+   int curr_bandwidth = st->bandwidth;
+   if (cfg->application == OA_APP_RESTRICTED_SILK && curr_bandwidth > OA_BW_WB) st->bandwidth = curr_bandwidth = OA_BW_WB;
+   if (st->mode == OA_MODE_SILK_ONLY && curr_bandwidth > OA_BW_WB) st->mode = OA_MODE_HYBRID;
+   if (st->mode == OA_MODE_HYBRID && curr_bandwidth <= OA_BW_WB) st->mode = OA_MODE_SILK_ONLY;
+   if (st->mode != OA_MODE_SILK_ONLY) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                  /* hybrid: next */
+   if (frame_size > 3 * Fs / 50) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                       /* 80/100/120 ms: repacketised multi-frame packets */
+   if (st->silk_bw_switch) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                             /* bandwidth switch with CELT redundancy */
+   sh->bitrate_bps = bitrate_bps; sh->equiv_rate = equiv_rate; sh->curr_bandwidth = curr_bandwidth;
+   sh->orig_max_data_bytes = max_data_bytes; sh->max_data_bytes = imin(max_data_bytes, 1276);
+   /* opus_encode_frame_native prologue */
+   sh->activity = sh->is_silence ? 0 : SE_VAD_NO_DECISION;
+   sh->bits_target = imin(8 * sh->max_data_bytes, bitrate_to_bits(bitrate_bps, Fs, frame_size)) - 8;
+   st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, L->S.st.ch[0].variable_HP_smth1_Q15 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
+   sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
+   sh->use_hp_cutoff = cfg->application == OA_APP_VOIP;
+}
+
+/* hp_cutoff (:441, VOIP) or dc_reject (:479) over one chunk staged in LDS: lane c runs channel c's recursion */
+WV_DEV void sh_highpass_chunk(WV_LDS ShLds *L, WV_LDS i16 *io, int len, int channels, const i32 *B_Q28, const i32 *A_Q28)
+{
+   const int c = wv_lane();
+   if (c < channels) {
+      if (L->sh.use_hp_cutoff) {
+         const i32 A0_L = (-A_Q28[0]) & 0x3FFF, A0_U = (-A_Q28[0]) >> 14, A1_L = (-A_Q28[1]) & 0x3FFF, A1_U = (-A_Q28[1]) >> 14;
+         i32 S0 = L->st.hp_mem[2 * c], S1 = L->st.hp_mem[2 * c + 1];
+         for (int k = 0; k < len; k++) {
+            const i32 inval = io[k * channels + c];
+            const i32 out32_Q14 = shl32(sk_mlawb(S0, B_Q28[0], inval), 2);
+            S0 = S1 + sk_rround(sk_mulwb(out32_Q14, A0_L), 14); S0 = sk_mlawb(S0, out32_Q14, A0_U); S0 = sk_mlawb(S0, B_Q28[1], inval);
+            S1 = sk_rround(sk_mulwb(out32_Q14, A1_L), 14); S1 = sk_mlawb(S1, out32_Q14, A1_U); S1 = sk_mlawb(S1, B_Q28[2], inval);
+            io[k * channels + c] = (i16)sk_sat16((out32_Q14 + (1 << 14) - 1) >> 14);
+         }
+         L->st.hp_mem[2 * c] = S0; L->st.hp_mem[2 * c + 1] = S1;
+      } else {
+         const int shift = celt_ilog2(L->cfg.Fs / (3 * 4));
+         i32 mem = L->st.hp_mem[2 * c];
+         for (int k = 0; k < len; k++) {
+            const i32 x = shl32(saturate((i32)io[k * channels + c], (1 << 16) - 1), 14), y = x - mem;
+            mem = mem + pshr32(y, shift);
+            io[k * channels + c] = (i16)saturate(pshr32(y, 14), 32767);
+         }
+         L->st.hp_mem[2 * c] = mem;
+      }
+   }
+}
+
+/* packet bytes (nbytes at pk, pk[0] = TOC) -> out, or the same frame re-framed as a code-3 packet padded to pad_to bytes (opus_packet_pad, src/repacketizer.c:346) */
+WV_DEV int sh_emit_packet(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, int out_cap)
+{
+   if (nbytes <= 0) return nbytes;
+   if (pad_to == 0 || nbytes == pad_to) { if (nbytes > out_cap) return OA_ERR_BUFFER_TOO_SMALL; FOR_LANES(i, nbytes) out[i] = pk[i]; return nbytes; }
+   if (nbytes > pad_to) return OA_ERR_INTERNAL;
+   if (pad_to > out_cap) return OA_ERR_BUFFER_TOO_SMALL;
+   const int L0 = nbytes - 1, pad_amount = pad_to - (L0 + 2);
+   const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = 2 + (pad_amount > 0 ? nb_255s + 1 : 0);
+   FOR_LANES(i, pad_to) {
+      u8 v = 0;
+      if (i == 0) v = (u8)((pk[0] & 0xFC) | 0x3);
+      else if (i == 1) v = (u8)(1 | (pad_amount != 0 ? 0x40 : 0));
+      else if (i < hdr) v = i < hdr - 1 ? 255 : (u8)(pad_amount - 255 * nb_255s - 1);
+      else if (i < hdr + L0) v = pk[1 + i - hdr];
+      out[i] = v;
+   }
+   return pad_to;
+}
+
+WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   /* ---- load configuration, Opus-layer scalars and the SILK encoder state (coalesced) ---- */
+   {
+      const i32 *g = (const i32 *)&gs->cfg; WV_LDS i32 *d = (WV_LDS i32 *)&L->cfg;
+      FOR_LANES(i, (int)(sizeof(OaShConfig) / 4)) d[i] = g[i];
+      g = (const i32 *)&gs->s; d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) d[i] = g[i];
+      g = (const i32 *)&gs->silk; d = (WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) d[i] = g[i];
+   }
+   wv_sync();
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   {  /* is_digital_silence (:1060, fixed point: all samples zero) */
+      i32 m = 0;
+      FOR_LANES(i, frame_size * CC) m = imax(m, iabs((i32)pcm[i]));
+      m = wv_max(m);
+      LANE0 { sh->sample_max = m; sh->is_silence = m == 0; }
+   }
+   LANE0 sh_layer_decide(L, frame_size, max_data_bytes);
+   if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
+   if (sh->plc_frame) {
+      const int n = sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; gs->s.rangeFinal = 0; }
+      return;
+   }
+   /* ---- high-pass into the per-stream HBM scratch, staged through LDS in chunks ---- */
+   {
+      i32 B_Q28[3] = {0, 0, 0}, A_Q28[2] = {0, 0};
+      if (sh->use_hp_cutoff) {
+         const i32 Fc_Q19 = sk_mulbb(SE_FIX(1.5 * 3.14159 / 1000, 19), sh->cutoff_Hz) / (Fs / 1000);
+         const i32 r_Q28 = SE_FIX(1.0, 28) - SE_FIX(0.92, 9) * Fc_Q19;
+         B_Q28[0] = r_Q28; B_Q28[1] = shl32(-r_Q28, 1); B_Q28[2] = r_Q28;
+         const i32 r_Q22 = r_Q28 >> 6;
+         A_Q28[0] = sk_mulww(r_Q22, sk_mulww(Fc_Q19, Fc_Q19) - SE_FIX(2.0, 22));
+         A_Q28[1] = sk_mulww(r_Q22, r_Q22);
+      }
+      WV_LDS i16 *stage = L->S.u.pcm_stage;
+      const int chunk = SH_STAGE_SAMPLES / CC;
+      for (int i0 = 0; i0 < frame_size; i0 += chunk) {
+         const int n = imin(chunk, frame_size - i0);
+         wv_sync();
+         FOR_LANES(i, n * CC) stage[i] = pcm[i0 * CC + i];
+         wv_sync();
+         sh_highpass_chunk(L, stage, n, CC, B_Q28, A_Q28);
+         wv_sync();
+         FOR_LANES(i, n * CC) pcm_hp[i0 * CC + i] = stage[i];
+      }
+      wv_sync();
+   }
+   /* ---- SILK (:2024-2200) ---- */
+   SeControl sc;
+   {
+      const int mode = st->mode, curr_bandwidth = sh->curr_bandwidth, frame_rate = Fs / frame_size;
+      sc.nChannelsAPI = CC; sc.nChannelsInternal = st->stream_channels; sc.API_sampleRate = Fs;
+      sc.bitRate = bits_to_bitrate(sh->bits_target, Fs, frame_size);
+      sc.payloadSize_ms = 1000 * frame_size / Fs;
+      sc.desiredInternalSampleRate = curr_bandwidth == OA_BW_NB ? 8000 : curr_bandwidth == OA_BW_MB ? 12000 : 16000;
+      sc.minInternalSampleRate = mode == OA_MODE_HYBRID ? 16000 : 8000;
+      sc.maxInternalSampleRate = 16000;
+      if (mode == OA_MODE_SILK_ONLY) {
+         i32 effective_max_rate = bits_to_bitrate(sh->max_data_bytes * 8, Fs, frame_size);
+         if (frame_rate > 50) effective_max_rate = effective_max_rate * 2 / 3;
+         if (effective_max_rate < 8000) { sc.maxInternalSampleRate = 12000; sc.desiredInternalSampleRate = imin(12000, sc.desiredInternalSampleRate); }
+         if (effective_max_rate < 7000) { sc.maxInternalSampleRate = 8000; sc.desiredInternalSampleRate = imin(8000, sc.desiredInternalSampleRate); }
+      }
+      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = 0; sc.useDTX = 0;
+      sc.useCBR = !L->cfg.use_vbr;
+      sc.maxBits = (sh->max_data_bytes - 1) * 8;
+      sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = 0;
+      sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
+   }
+   LANE0 { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(sh->orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
+   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity);
+   wv_sync();
+   if (sret) { LANE0 { *len_out = sret == -100 ? OA_ERR_UNIMPLEMENTED : OA_ERR_INTERNAL; *rng_out = 0; gs->s.error = sret; } return; }
+   /* ---- finalise (:2190-2560) ---- */
+   LANE0 {
+      int curr_bandwidth = sh->curr_bandwidth;
+      if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB;
+      st->sm_allowBandwidthSwitch = sc.allowBandwidthSwitch; st->sm_inWBmodeWithoutVariableLP = sc.inWBmodeWithoutVariableLP; st->sm_switchReady = sc.switchReady;
+      st->sm_opusCanSwitch = sc.switchReady;                                          /* (!nonfinal_frame: single-packet calls only) */
+      const int nBytes = L->S.r[0];
+      int ret;
+      if (nBytes == 0) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); ret = 1; }
+      else {
+         if (st->sm_opusCanSwitch) {
+            if (L->cfg.application != OA_APP_RESTRICTED_SILK) st->error = OA_ERR_UNIMPLEMENTED;          /* the next frame would need a redundant CELT frame */
+            st->silk_bw_switch = L->cfg.application != OA_APP_RESTRICTED_SILK;
+         }
+         /* stereo width bookkeeping (:2365-2400; the fade itself only touches the CELT input) */
+         if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
+         else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
+         if (CC == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
+         EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+         const int tell = k_ec_tell(EC_PASS);
+         ret = (tell + 7) >> 3;
+         st->rangeFinal = e->rng;
+         k_ec_enc_done(EC_PASS);
+         L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
+         if (tell > (sh->max_data_bytes - 1) * 8) {
+            if (sh->max_data_bytes < 2) ret = OA_ERR_BUFFER_TOO_SMALL; else { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
+         } else while (ret > 2 && L->packet[ret] == 0) ret--;                         /* trailing zeros are implied in SILK-only packets (:2540) */
+         if (ret >= 0) ret += 1;
+      }
+      st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
+      sh->ret = ret;
+   }
+   /* ---- store packet + state (coalesced) ---- */
+   {
+      const int nbytes = sh->ret < 0 ? sh->ret : sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);
+      LANE0 { *len_out = nbytes; *rng_out = st->rangeFinal; }
+      i32 *g = (i32 *)&gs->s; const WV_LDS i32 *d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
+      g = (i32 *)&gs->silk; d = (const WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) g[i] = d[i];
+   }
+}
+#endif

@@ -1,0 +1,55 @@
+/* opus_sh_state.h — per-stream record of the SILK / hybrid capable Opus encoder ("sh" kernel), flat and memcpy-able.
+ * Mirrors the persistent part of OpusEncoder (src/opus_encoder.c:76-146) for the applications that can run the SILK layer (VOIP, AUDIO,
+ * RESTRICTED_SILK), the silk_EncControlStruct fields that persist between calls (silk/control.h:42-120), the SILK encoder (silk_enc_state.h) and
+ * — for hybrid — the CELT encoder state of celt_frame.h. */
+#ifndef OPUS_AMD_OPUS_SH_STATE_H
+#define OPUS_AMD_OPUS_SH_STATE_H
+#include "celt_frame.h"
+#include "silk_enc_state.h"
+
+struct OaShConfig {
+   int32_t Fs, channels, application, user_bitrate_bps, use_vbr, vbr_constraint, complexity, force_channels;
+   int32_t user_bandwidth, max_bandwidth, lsb_depth, disable_inv, packet_loss_perc, user_forced_mode, signal_type, use_inband_fec;
+   int32_t use_dtx, reserved[7];
+};
+struct OaShScalars {
+   int32_t stream_channels, bandwidth, auto_bandwidth, first, mode, prev_mode, prev_channels, prev_framesize;
+   int32_t hybrid_stereo_width_Q14, variable_HP_smth2_Q15, prev_HB_gain, hp_mem[4];
+   uint32_t rangeFinal;
+   int32_t silk_bw_switch, error;
+   /* silk_mode fields that persist between calls */
+   int32_t sm_toMono, sm_opusCanSwitch, sm_allowBandwidthSwitch, sm_inWBmodeWithoutVariableLP, sm_stereoWidth_Q14, sm_LBRR_coded, sm_switchReady;
+   /* compute_stereo_width state (StereoWidthState, src/opus_encoder.c:62-68) */
+   int32_t wm_XX, wm_XY, wm_YY, wm_smoothed_width, wm_max_follower;
+   int32_t pad0[6];
+};
+#define OA_SH_MAX_DELAY 480                              /* encoder_buffer = Fs / 100 samples per channel */
+struct OaShStream {
+   OaShConfig cfg;
+   OaShScalars s;
+   OaSilkEnc silk;
+   OaEncState celt;                                      /* hybrid only */
+   int16_t delay_buffer[2 * OA_SH_MAX_DELAY];            /* hybrid only */
+};
+/* opus_encoder_init (src/opus_encoder.c:204-330) */
+static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)
+{
+   OaShConfig keep = st->cfg;
+   char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
+   st->cfg = keep;
+   st->cfg.Fs = Fs; st->cfg.channels = channels; st->cfg.application = application;
+   st->s.stream_channels = channels; st->s.first = 1; st->s.mode = 1001; st->s.bandwidth = 1105;
+   st->s.hybrid_stereo_width_Q14 = 1 << 14; st->s.prev_HB_gain = 32767;
+   st->s.variable_HP_smth2_Q15 = 193536;                 /* silk_LSHIFT(silk_lin2log(VARIABLE_HP_MIN_CUTOFF_HZ), 8) = 756 << 8 */
+   oa_silk_enc_reset(&st->silk);
+   st->celt.s.spread_decision = 2; st->celt.s.delayedIntra = 1; st->celt.s.tonal_average = 256;
+   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->celt.oldLogE[i] = st->celt.oldLogE2[i] = -(28 << 24);
+}
+static inline void oa_sh_stream_init(OaShStream *st, int32_t Fs, int channels, int application)
+{
+   char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
+   st->cfg.user_bitrate_bps = -1000; st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = -1000;
+   st->cfg.user_bandwidth = -1000; st->cfg.max_bandwidth = 1105; st->cfg.lsb_depth = 24; st->cfg.user_forced_mode = -1000; st->cfg.signal_type = -1000;
+   oa_sh_stream_reset(st, Fs, channels, application);
+}
+#endif

@@ -8,4 +8,5 @@
 #include "silk_enc_quant.h"
 #include "silk_enc_nsq.h"
 #include "silk_enc_frame.h"
+#include "opus_enc_sh.h"
 #endif

@@ -35,7 +35,7 @@ struct SilkEncLds {
    SeRsLds rs;
    i32 tmp_rs[99 + 1];
    i32 r[16];                                          /* lane-0 hand-off words */
-   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; } u;
+   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; } u;
 };
 
 /* ---- silk_encode_indices (encode_LBRR = 0) ---- */
@@ -477,11 +477,11 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
 /* ---- silk_Encode.  pcm: the Opus layer's int16 staging of this call's input (interleaved, nChannelsAPI), nSamplesIn per channel.
  * Returns 0 or a negative error; *nBytesOut through S->r[0].  One SILK frame per call for 10/20 ms payloads, 2-3 frames for 40/60 ms. ---- */
 struct SePcmSrc {
-   const WV_LDS i16 *p; int stride, off, mix;
+   const i16 *p; int stride, off, mix;                                       /* the Opus layer's high-passed input (HBM scratch) */
    WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
    WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
 };
-WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const WV_LDS i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity)
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity)
 {
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];

@@ -51,3 +51,20 @@ extern "C" int emu_silk_encode(OaSilkEnc *st, int32_t *ctl, const int16_t *pcm, 
    free(S);
    return j.ret;
 }
+
+/* ---- the whole Opus-layer frame (opus_enc_sh.h) ---- */
+struct ShJob { ShLds *L; OaShStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int out_cap; int16_t *pcm_hp; int32_t *len; uint32_t *rng; };
+static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->len, j->rng); }
+extern "C" int emu_sh_stream_size() { return (int)sizeof(OaShStream); }
+extern "C" int emu_sh_lds_size() { return (int)sizeof(ShLds); }
+extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int application) { oa_sh_stream_init(st, Fs, channels, application); }
+extern "C" void emu_sh_set_cfg(OaShStream *st, int word, int value) { ((int32_t *)&st->cfg)[word] = value; }
+extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size, int max_bytes, uint8_t *out, int out_cap, int32_t *len, uint32_t *rng)
+{
+   ShLds *L = (ShLds *)aligned_alloc(64, (sizeof(ShLds) + 63) & ~63);
+   memset(L, 0xA5, sizeof(ShLds));
+   int16_t *hp = (int16_t *)malloc(sizeof(int16_t) * (size_t)frame_size * 2 + 64);
+   ShJob j = {L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
+   emu_run_wave(shjob, &j);
+   free(hp); free(L);
+}
