@@ -128,6 +128,9 @@ OPUS_AMD_EXPORT int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, int steps, float *ms);
 /* memcpy contract: a stream's complete state as a flat blob (same layout as the classic OpusEncoder payload) */
 OPUS_AMD_EXPORT int opusgpu_enc_state_size(void);
+/* record size / LDS per wave of the SILK-capable encoder (batches created with OPUS_APPLICATION_VOIP / _AUDIO / _RESTRICTED_SILK; src/opus_encoder.c:76-146 + silk/fixed/structs_FIX.h:108) */
+OPUS_AMD_EXPORT int opusgpu_enc_sh_state_size(void);
+OPUS_AMD_EXPORT int opusgpu_sh_kernel_lds_bytes(void);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *blob);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const void *blob);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);

@@ -12,6 +12,12 @@ __device__ unsigned long long oa_phase_ticks[34];
 #endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
+#ifdef OA_PHASE_TIMERS
+/* SILK-capable kernel: shader-clock ticks between SE_PHASE marks (lane 0), summed over all waves */
+__device__ unsigned long long oa_sh_phase_ticks[24];
+#define SE_PHASE(S_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)(S_)->r[15])); (S_)->r[15] = (i32)t_; } } while (0)
+#define SE_PHASE_START(S_) do { if (threadIdx.x == 0) (S_)->r[15] = (i32)(u32)clock64(); } while (0)
+#endif
 #include "silk_enc_all.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
@@ -44,7 +50,7 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 }
 
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream, SILK state staged in LDS */
-extern "C" __global__ void __launch_bounds__(64, 1)
+extern "C" __global__ void __launch_bounds__(64, 2)
 oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i16 *pcm_hp, i32 *lens, u32 *rngs, int nstreams)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,8 +58,10 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max
    const int s = blockIdx.x;
    if (s >= nstreams) return;
    OaShStream *gs = streams + s;
-   const size_t off = (size_t)s * frame_size * gs->cfg.channels;
-   oa_sh_encode_frame(L, gs, pcm + off, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, pcm_hp + off, lens + s, rngs + s);
+   const int ch = gs->cfg.channels;
+   char *scr = (char *)pcm_hp + (size_t)s * SH_SCRATCH_BYTES(frame_size, ch);
+   oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
+         (SeRateScratch *)(scr + SH_SCRATCH_BYTES(frame_size, ch) - sizeof(SeRateScratch)), lens + s, rngs + s);
 }
 
 #include "opus_packet_host.h"
@@ -222,7 +230,7 @@ extern "C" {
 int opusgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
 int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
-int opusgpu_sh_kernel_lds_bytes(void) { return (int)sizeof(ShLds); }
+int opusgpu_sh_kernel_lds_bytes(void) { return (int)SH_LDS_BYTES(1); }
 int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
 opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
 
@@ -360,9 +368,9 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    if (b->kind) {
-      const size_t need = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16);
+      const size_t need = (size_t)b->S * SH_SCRATCH_BYTES(frame_size, b->channels);
       if (need > b->hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->hp_cap = need; }
-      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(ShLds), s,
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), SH_LDS_BYTES(b->channels), s,
             b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i16 *)b->d_pcm_hp, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
@@ -495,6 +503,13 @@ const char *opus_strerror(int error)
    return s[-error];
 }
 #ifdef OA_PHASE_TIMERS
+OPUS_AMD_EXPORT int opusgpu_debug_sh_phase_ticks(unsigned long long *out, int reset)
+{
+   HIPCHECK(hipDeviceSynchronize());
+   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_sh_phase_ticks), sizeof(unsigned long long) * 24));
+   if (reset) { unsigned long long z[24] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_sh_phase_ticks), z, sizeof(z))); }
+   return OPUS_OK;
+}
 OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset)
 {
    HIPCHECK(hipDeviceSynchronize());

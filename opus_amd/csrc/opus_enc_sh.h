@@ -27,13 +27,16 @@ struct ShShared {
    i32 r[8];
 };
 struct ShLds {
-   SilkEncLds S;
    EcCtx ec;
    ShShared sh;
    OaShScalars st;
    OaShConfig cfg;
    u8 packet[OA_MAX_PACKET + 4];
+   SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
+#define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
+/* per-stream HBM scratch: the high-passed input of the call followed by the rate-loop snapshots */
+#define SH_SCRATCH_BYTES(frame_size, channels) (((size_t)(frame_size) * (channels) * 2 + 63) / 64 * 64 + sizeof(SeRateScratch))
 #define SH_STAGE_SAMPLES 1920
 
 WV_DEV i32 sh_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int mode, int complexity, int loss)      /* compute_equiv_rate :780 */
@@ -214,9 +217,10 @@ WV_DEV int sh_emit_packet(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, 
    return pad_to;
 }
 
-WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, i32 *len_out, u32 *rng_out)
+WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   SE_PHASE_START(&L->S);
    /* ---- load configuration, Opus-layer scalars and the SILK encoder state (coalesced) ---- */
    {
       const i32 *g = (const i32 *)&gs->cfg; WV_LDS i32 *d = (WV_LDS i32 *)&L->cfg;
@@ -224,9 +228,10 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       g = (const i32 *)&gs->s; d = (WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) d[i] = g[i];
       g = (const i32 *)&gs->silk; d = (WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) d[i] = g[i];
+      FOR_LANES(i, SE_STATE_WORDS(gs->cfg.channels)) d[i] = g[i];
    }
    wv_sync();
+   SE_PHASE(&L->S, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    {  /* is_digital_silence (:1060, fixed point: all samples zero) */
       i32 m = 0;
@@ -265,6 +270,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       }
       wv_sync();
    }
+   SE_PHASE(&L->S, 1);
    /* ---- SILK (:2024-2200) ---- */
    SeControl sc;
    {
@@ -288,9 +294,10 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
    }
    LANE0 { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(sh->orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
-   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity);
+   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G);
    wv_sync();
    if (sret) { LANE0 { *len_out = sret == -100 ? OA_ERR_UNIMPLEMENTED : OA_ERR_INTERNAL; *rng_out = 0; gs->s.error = sret; } return; }
+   SE_PHASE(&L->S, 9);
    /* ---- finalise (:2190-2560) ---- */
    LANE0 {
       int curr_bandwidth = sh->curr_bandwidth;
@@ -330,7 +337,8 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       i32 *g = (i32 *)&gs->s; const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
       g = (i32 *)&gs->silk; d = (const WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) g[i] = d[i];
+      FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
    }
+   SE_PHASE(&L->S, 10);
 }
 #endif

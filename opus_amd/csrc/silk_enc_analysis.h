@@ -16,14 +16,14 @@
 
 WV_DEV int se_clz64(i64 in) { const i32 up = (i32)(in >> 32); return up == 0 ? 32 + sk_clz((i32)in) : sk_clz(up); }
 WV_DEV i32 se_add_lshift32(i32 a, i32 b, int s) { return add32(a, shl32(b, s)); }
-WV_DEV void se_bwexpander_32(i32 *ar, int d, i32 chirp_Q16)                                    /* bwexpander_32.c:37 */
+template <class PA> WV_DEV void se_bwexpander_32(PA ar, int d, i32 chirp_Q16)                                    /* bwexpander_32.c:37 */
 {
    const i32 cm1 = chirp_Q16 - 65536;
    for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
    ar[d - 1] = sk_mulww(chirp_Q16, ar[d - 1]);
 }
 /* silk_LPC_fit (silk/LPC_fit.c:35) */
-template <class PO> WV_DEV void se_lpc_fit(PO a_QOUT, i32 *a_QIN, int QOUT, int QIN, int d)
+template <class PO, class PI> WV_DEV void se_lpc_fit(PO a_QOUT, PI a_QIN, int QOUT, int QIN, int d)
 {
    int i, idx = 0;
    for (i = 0; i < 10; i++) {
@@ -40,33 +40,36 @@ template <class PO> WV_DEV void se_lpc_fit(PO a_QOUT, i32 *a_QIN, int QOUT, int 
    else for (int k = 0; k < d; k++) a_QOUT[k] = (i16)sk_rround(a_QIN[k], QIN - QOUT);
 }
 
-/* corr: [order + 1]; returns scale.  QC = 10, QS = 13 (silk/fixed/main_FIX.h:49-50) */
-WV_DEV int se_warped_autocorr_l0(i32 *corr, const WV_LDS i16 *input, int warping_Q16, int length, int order)
+/* silk_warped_autocorrelation_FIX_c as a systolic chain: lane i owns stage i of the warped allpass ladder and runs i samples behind lane 0, so one
+ * wave step advances every stage (length + order steps instead of length x order).  in_{i}(n) = in_{i-1}(n-1) + SMLAWB(in_i(n-1) - in_{i-1}(n), w) is
+ * exactly the reference's tmp1/tmp2 recursion; every corr[i] accumulates its 64-bit products in the reference's sample order.  QC = 10, QS = 13
+ * (silk/fixed/main_FIX.h:49-50).  corr: [order + 2] in LDS, corr[order + 1] receives the scale. */
+WV_DEV int se_warped_autocorr_wave(WV_LDS i32 *corr, const WV_LDS i16 *input, int warping_Q16, int length, int order)
 {
-   i32 state_QS[SE_MAX_SHAPE_ORDER + 1]; i64 corr_QC[SE_MAX_SHAPE_ORDER + 1];
-   for (int i = 0; i <= order; i++) { state_QS[i] = 0; corr_QC[i] = 0; }
-   for (int n = 0; n < length; n++) {
-      i32 tmp1_QS = shl32((i32)input[n], 13), tmp2_QS;
-      for (int i = 0; i < order; i += 2) {
-         tmp2_QS = sk_mlawb(state_QS[i], state_QS[i + 1] - tmp1_QS, warping_Q16);
-         state_QS[i] = tmp1_QS;
-         corr_QC[i] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 13 - 10);
-         tmp1_QS = sk_mlawb(state_QS[i + 1], state_QS[i + 2] - tmp2_QS, warping_Q16);
-         state_QS[i + 1] = tmp2_QS;
-         corr_QC[i + 1] += ((i64)tmp2_QS * state_QS[0]) >> (2 * 13 - 10);
+   const int lane = wv_lane();
+   i32 cur = 0, prev_stage_prev = 0, my = 0;
+   i64 acc = 0;
+   for (int t = 0; t < length + order; t++) {
+      const i32 from_prev = wv_shift_up1(my, 0);
+      const int m = t - lane;
+      if (lane <= order && m >= 0 && m < length) {
+         const i32 x13 = shl32((i32)input[m], 13);
+         const i32 v = lane == 0 ? x13 : add32(prev_stage_prev, sk_mulwb(sub32(cur, from_prev), warping_Q16));
+         prev_stage_prev = from_prev; cur = v; my = v;
+         acc += ((i64)v * (i64)x13) >> (2 * 13 - 10);
       }
-      state_QS[order] = tmp1_QS;
-      corr_QC[order] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 13 - 10);
    }
-   int lsh = se_clz64(corr_QC[0]) - 35;
+   const i32 hi0 = wv_bcast((i32)(acc >> 32), 0), lo0 = wv_bcast((i32)acc, 0);
+   int lsh = se_clz64((i64)(((u64)(u32)hi0 << 32) | (u32)lo0)) - 35;
    lsh = se_limit(lsh, -12 - 10, 30 - 10);
-   if (lsh >= 0) for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] << lsh);
-   else for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] >> -lsh);
+   wv_sync();
+   if (lane <= order) corr[lane] = lsh >= 0 ? (i32)(acc << lsh) : (i32)(acc >> -lsh);
+   wv_sync();
    return -(10 + lsh);
 }
-WV_DEV i32 se_schur64(i32 *rc_Q16, const i32 *c, int order)
+/* C: [order + 1][2] words of LDS */
+template <class PR, class PC> WV_DEV i32 se_schur64(PR rc_Q16, PC c, int order, WV_LDS i32 (*C)[2])
 {
-   i32 C[SE_MAX_SHAPE_ORDER + 1][2];
    int k;
    if (c[0] <= 0) { for (k = 0; k < order; k++) rc_Q16[k] = 0; return 0; }
    for (k = 0; k <= order; k++) C[k][0] = C[k][1] = c[k];
@@ -83,7 +86,7 @@ WV_DEV i32 se_schur64(i32 *rc_Q16, const i32 *c, int order)
    for (; k < order; k++) rc_Q16[k] = 0;
    return imax(1, C[0][1]);
 }
-WV_DEV void se_k2a_Q16(i32 *A_Q24, const i32 *rc_Q16, int order)
+template <class PA, class PR> WV_DEV void se_k2a_Q16(PA A_Q24, PR rc_Q16, int order)
 {
    for (int k = 0; k < order; k++) {
       const i32 rc = rc_Q16[k];
@@ -91,7 +94,7 @@ WV_DEV void se_k2a_Q16(i32 *A_Q24, const i32 *rc_Q16, int order)
       A_Q24[k] = -shl32(rc, 8);
    }
 }
-WV_DEV i32 se_warped_gain(const i32 *coefs_Q24, int lambda_Q16, int order)
+template <class PA> WV_DEV i32 se_warped_gain(PA coefs_Q24, int lambda_Q16, int order)
 {
    lambda_Q16 = -lambda_Q16;
    i32 gain_Q24 = coefs_Q24[order - 1];
@@ -99,7 +102,7 @@ WV_DEV i32 se_warped_gain(const i32 *coefs_Q24, int lambda_Q16, int order)
    gain_Q24 = sk_mlawb(SE_FIX(1.0, 24), gain_Q24, -lambda_Q16);
    return sk_inverse32_varQ(gain_Q24, 40);
 }
-WV_DEV void se_limit_warped_coefs(i32 *coefs_Q24, int lambda_Q16, i32 limit_Q24, int order)
+template <class PA> WV_DEV void se_limit_warped_coefs(PA coefs_Q24, int lambda_Q16, i32 limit_Q24, int order)
 {
    int ind = 0;
    lambda_Q16 = -lambda_Q16;
@@ -128,8 +131,9 @@ WV_DEV void se_limit_warped_coefs(i32 *coefs_Q24, int lambda_Q16, i32 limit_Q24,
    }
 }
 
-/* pitch_res = res_pitch_frame, x = x_frame; xw: i16[240] windowed signal, xx: i16[240], w32: i32[28] */
-WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32)
+/* pitch_res = res_pitch_frame, x = x_frame; xw: i16[240] windowed signal, xx: i16[240], w32: i32[28] (auto-correlation, [26] = SNR hand-off) */
+/* stk: 100 words of lane-0 working arrays in LDS */
+WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32, WV_LDS i32 *stk)
 {
    const WV_LDS i16 *x_ptr = x - c->la_shape;
    const int order = c->shapingLPCOrder, swl = c->shapeWinLength;
@@ -173,14 +177,15 @@ WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEn
          se_apply_sine_window(xw + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
       }
       x_ptr += c->subfr_length;
-      int scale = 0;
-      if (c->warping_Q16 <= 0) scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
+      int scale;
+      wv_sync();
+      if (c->warping_Q16 > 0) scale = se_warped_autocorr_wave(w32, xw, warping_Q16, swl, order);
+      else scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
       LANE0 {
-         i32 auto_corr[SE_MAX_SHAPE_ORDER + 1], refl_coef_Q16[SE_MAX_SHAPE_ORDER], AR_Q24[SE_MAX_SHAPE_ORDER];
-         if (c->warping_Q16 > 0) scale = se_warped_autocorr_l0(auto_corr, xw, warping_Q16, swl, order);
-         else for (int i = 0; i <= order; i++) auto_corr[i] = w32[i];
+         WV_LDS i32 *auto_corr = w32, *refl_coef_Q16 = stk, *AR_Q24 = stk + 24;
+         WV_LDS i32 (*Cs)[2] = (WV_LDS i32 (*)[2])(stk + 48);
          auto_corr[0] = add32(auto_corr[0], imax(sk_mulwb(auto_corr[0] >> 4, SE_FIX(3e-5f, 20)), 1));
-         i32 nrg = se_schur64(refl_coef_Q16, auto_corr, order);
+         i32 nrg = se_schur64(refl_coef_Q16, auto_corr, order, Cs);
          se_k2a_Q16(AR_Q24, refl_coef_Q16, order);
          int Qnrg = -scale;
          if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
@@ -238,10 +243,11 @@ WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEn
 
 /* ---- silk_burg_modified_c.  QA 25, N_BITS_HEAD_ROOM 3, MIN_RSHIFTS -16, MAX_RSHIFTS 7 ---- */
 WV_DEV i64 se_inner_prod16(const WV_LDS i16 *a, const WV_LDS i16 *b, int len) { i64 s = 0; for (int i = 0; i < len; i++) s += (i32)a[i] * (i32)b[i]; return s; }
-WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q, i32 *A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D)
+/* stk: 84 words of LDS for the five working rows */
+template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q, PA A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D, WV_LDS i32 *stk)
 {
    const int QA = 25;
-   i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
+   WV_LDS i32 *C_first_row = stk, *C_last_row = stk + 16, *Af_QA = stk + 32, *CAf = stk + 48, *CAb = stk + 66;
    int k, n, s, lz, rshifts, reached_max_gain;
    i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
    const i64 C0_64 = se_inner_prod16(x, x, subfr_length * nb_subfr);

@@ -24,19 +24,22 @@ struct SeAnaLds {                                      /* analysis phases */
 };
 struct SeQuantLds {                                    /* quantiser + rate loop */
    SeNsqLds N;
-   OaSilkNsqState nsq_copy[2];
-   u8 ec_buf_copy[1276];
    EcCtx ec_copy, ec_copy2;
 };
+/* rate-control loop snapshots (silk/fixed/encode_frame_FIX.c:108-118 sNSQ_copy[2], ec_buf_copy): per-stream HBM scratch, touched once per frame in VBR */
+struct SeRateScratch { OaSilkNsqState nsq_copy[2]; u8 ec_buf_copy[1280]; };
 struct SeStereoLds { i16 side[322 + 6], LP_mid[320], HP_mid[320], LP_side[320], HP_side[320]; };
 struct SilkEncLds {
-   OaSilkEnc st;                                       /* persistent state, staged */
    SeEncCtrl ctl;
    SeRsLds rs;
    i32 tmp_rs[99 + 1];
    i32 r[16];                                          /* lane-0 hand-off words */
+   i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM) */
    union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; } u;
+   OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.ch[1] */
 };
+#define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
+#define SE_STATE_WORDS(channels) ((int)((sizeof(OaSilkEnc) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0)) / 4))
 
 /* ---- silk_encode_indices (encode_LBRR = 0) ---- */
 WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, EC_ARGS, int condCoding)
@@ -341,13 +344,14 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
 #endif
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
-WV_DEV void se_copy_words_wave(WV_LDS i32 *d, const WV_LDS i32 *s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
-WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR)
+template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
+WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G)
 {
    WV_LDS SeEncCtrl *ctl = &S->ctl;
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
    const int bits_margin = useCBR ? 5 : maxBits / 4;
    const int NSQW = (int)(sizeof(OaSilkNsqState) / 4);
+   SE_PHASE(S, 2);
    LANE0 {
       c->indices.Seed = (i8)(c->frameCounter++ & 3);
       se_lp_variable_cutoff(c, c->inputBuf + 1, c->frame_length);
@@ -360,13 +364,17 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
       se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->Wsig, A->xx, A->w32, A->A_Q12s, &A->u.pitch);
       wv_sync();
       SE_TAP(0);
-      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->Wsig, A->xx, A->w32);
+      SE_PHASE(S, 3);
+      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->Wsig, A->xx, A->w32, S->stk);
       wv_sync();
       SE_TAP(1);
+      SE_PHASE(S, 4);
       se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.XX, A->u.p.LPC_res);
       SE_TAP(2);
+      SE_PHASE(S, 5);
       LANE0 se_process_gains_l0(c, ctl, condCoding);
       SE_TAP(3);
+      SE_PHASE(S, 6);
       /* (silk_LBRR_encode_FIX: LBRR_enabled is never set on this path) */
       WV_LDS SeQuantLds *Q = &S->u.q;
       const int maxIter = 6;
@@ -376,7 +384,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
       int LastGainIndex_copy2 = 0;
       int gain_lock[4] = {0, 0, 0, 0}; i16 best_gain_mult[4] = {0, 0, 0, 0}; int best_sum[4] = {0, 0, 0, 0};
       ec_cp_lds(&Q->ec_copy, ecl);
-      se_copy_words_wave((WV_LDS i32 *)&Q->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+      se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
       const int seed_copy = c->indices.Seed, ec_prevLagIndex_copy = c->ec_prevLagIndex, ec_prevSignalType_copy = c->ec_prevSignalType;
       for (int iter = 0; ; iter++) {
          if (gainsID == gainsID_lower) nBits = nBits_lower;
@@ -385,12 +393,13 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
             if (iter > 0) {
                wv_sync();
                LANE0 { ec_cp_lds(ecl, &Q->ec_copy); c->indices.Seed = (i8)seed_copy; c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy; }
-               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const WV_LDS i32 *)&Q->nsq_copy[0], NSQW);
+               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
             }
             if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
             else se_nsq_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
             wv_sync();
             SE_TAP(4);
+            SE_PHASE(S, 7);
             LANE0 {
                if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
                EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
@@ -411,14 +420,15 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
                ec_st(ecl, &ec_);
                S->r[1] = nb;
             }
+            SE_PHASE(S, 8);
             nBits = S->r[1];
             if (useCBR == 0 && iter == 0 && nBits <= maxBits) break;
          }
          if (iter == maxIter) {
             if (found_lower && (gainsID == gainsID_lower || nBits > maxBits)) {
                wv_sync();
-               LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = Q->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
-               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const WV_LDS i32 *)&Q->nsq_copy[1], NSQW);
+               LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = G->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
+               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[1], NSQW);
             }
             break;
          }
@@ -430,8 +440,8 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
             if (gainsID != gainsID_lower) {
                gainsID_lower = gainsID;
                wv_sync();
-               LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) Q->ec_buf_copy[i] = buf[i]; }
-               se_copy_words_wave((WV_LDS i32 *)&Q->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
+               LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) G->ec_buf_copy[i] = buf[i]; }
+               se_copy_words_wave((i32 *)&G->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
                LastGainIndex_copy2 = c->LastGainIndex;
             }
          } else break;
@@ -481,7 +491,7 @@ struct SePcmSrc {
    WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
    WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
 };
-WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity)
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G)
 {
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
@@ -611,7 +621,7 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
             if (c0->nFramesEncoded - n <= 0) condCoding = SE_CODE_INDEPENDENTLY;
             else if (n > 0 && E->prev_decode_only_middle) condCoding = SE_CODE_INDEPENDENTLY_NO_LTP_SCALING;
             else condCoding = SE_CODE_CONDITIONALLY;
-            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR);
+            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR, G);
             nBytesOut = S->r[0];
          }
          wv_sync();

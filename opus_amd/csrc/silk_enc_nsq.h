@@ -316,15 +316,23 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
          smpl_buf_idx = (smpl_buf_idx + SE_DD - 1) % SE_DD;
          const int last = (smpl_buf_idx + decisionDelay) % SE_DD;
          /* every lane evaluates the K-way decisions from the shared candidates (K <= 4) */
+         /* (running minima / maxima in scalars and fully unrolled loops: an array indexed by `winner` would be placed in scratch memory) */
          int winner = 0;
-         i32 rd0[4], rd1c[4];
-         for (int q = 0; q < K; q++) { rd0[q] = N->cand[q][0].RD_Q10; rd1c[q] = N->cand[q][1].RD_Q10; }
-         for (int q = 1; q < K; q++) if (rd0[q] < rd0[winner]) winner = q;
+         i32 win_rd = N->cand[0][0].RD_Q10;
+#pragma unroll
+         for (int q = 1; q < 4; q++) if (q < K) { const i32 v = N->cand[q][0].RD_Q10; if (v < win_rd) { win_rd = v; winner = q; } }
          const i32 wrand = N->sv[winner].RandState[last];
-         for (int q = 0; q < K; q++) if (N->sv[q].RandState[last] != wrand) { rd0[q] += 2147483647 >> 4; rd1c[q] += 2147483647 >> 4; }
          int worst = 0, best2 = 0;
-         for (int q = 1; q < K; q++) { if (rd0[q] > rd0[worst]) worst = q; if (rd1c[q] < rd1c[best2]) best2 = q; }
-         const int replace = rd1c[best2] < rd0[worst];
+         i32 worst_rd = 0, best2_rd = 0, my_rd0 = 0;
+#pragma unroll
+         for (int q = 0; q < 4; q++) if (q < K) {
+            const i32 pen = N->sv[q].RandState[last] != wrand ? (2147483647 >> 4) : 0;
+            const i32 a0 = N->cand[q][0].RD_Q10 + pen, a1 = N->cand[q][1].RD_Q10 + pen;
+            if (q == 0 || a0 > worst_rd) { worst_rd = a0; worst = q; }
+            if (q == 0 || a1 < best2_rd) { best2_rd = a1; best2 = q; }
+            if (q == lane) my_rd0 = a0;
+         }
+         const int replace = best2_rd < worst_rd;
          /* commit the sample decisionDelay back from the winner (read before any survivor is overwritten) */
          if (lane == 0 && (subfr > 0 || i >= decisionDelay)) {
             const WV_LDS SeSurvivor *w = &N->sv[winner];
@@ -347,7 +355,7 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
                const int repl = replace && lane == worst;
                const WV_LDS SeCand *src = repl ? &N->cand[best2][1] : &N->cand[lane][0];
                cv.Q_Q10 = src->Q_Q10; cv.xq_Q14 = src->xq_Q14; cv.LF_AR_Q14 = src->LF_AR_Q14; cv.Diff_Q14 = src->Diff_Q14; cv.sLTP_shp_Q14 = src->sLTP_shp_Q14; cv.LPC_exc_Q14 = src->LPC_exc_Q14;
-               cv.RD_Q10 = repl ? rd1c[best2] : rd0[lane];
+               cv.RD_Q10 = repl ? best2_rd : my_rd0;
             }
             s->LF_AR_Q14 = cv.LF_AR_Q14; s->Diff_Q14 = cv.Diff_Q14;
             s->sLPC_Q14[16 + i] = cv.xq_Q14;
@@ -358,7 +366,7 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
          }
          LANE0 N->delayedGain_Q10[smpl_buf_idx] = Gain_Q10;
       }
-      if (lane < K) { WV_LDS SeSurvivor *s = &N->sv[lane]; i32 t[16]; for (int i = 0; i < 16; i++) t[i] = s->sLPC_Q14[L + i]; for (int i = 0; i < 16; i++) s->sLPC_Q14[i] = t[i]; }
+      if (lane < K) { WV_LDS SeSurvivor *s = &N->sv[lane]; for (int i = 0; i < 16; i++) s->sLPC_Q14[i] = s->sLPC_Q14[L + i]; }   /* L >= 40 > 16: no overlap */
       LANE0 { st->sLTP_shp_buf_idx = shp_buf_idx; st->sLTP_buf_idx = ltp_buf_idx; }
       subfr++;
    }

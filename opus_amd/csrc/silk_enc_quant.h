@@ -15,14 +15,14 @@
 
 WV_DEV void se_a2nlsf_trans_poly(i32 *p, int dd) { for (int k = 2; k <= dd; k++) { for (int n = dd; n > k; n--) p[n - 2] -= p[n]; p[k - 2] -= shl32(p[k], 1); } }
 WV_DEV i32 se_a2nlsf_eval_poly(const i32 *p, i32 x, int dd) { i32 y32 = p[dd]; const i32 x_Q16 = shl32(x, 4); for (int n = dd - 1; n >= 0; n--) y32 = sk_mlaww(p[n], y32, x_Q16); return y32; }
-WV_DEV void se_a2nlsf_init(const i32 *a_Q16, i32 *P, i32 *Q, int dd)
+template <class PA> WV_DEV void se_a2nlsf_init(PA a_Q16, i32 *P, i32 *Q, int dd)
 {
    P[dd] = 1 << 16; Q[dd] = 1 << 16;
    for (int k = 0; k < dd; k++) { P[k] = -a_Q16[dd - k - 1] - a_Q16[dd + k]; Q[k] = -a_Q16[dd - k - 1] + a_Q16[dd + k]; }
    for (int k = dd; k > 0; k--) { P[k - 1] -= P[k]; Q[k - 1] += Q[k]; }
    se_a2nlsf_trans_poly(P, dd); se_a2nlsf_trans_poly(Q, dd);
 }
-WV_DEV void se_a2nlsf(i16 *NLSF, i32 *a_Q16, int d)
+template <class PA> WV_DEV void se_a2nlsf(i16 *NLSF, PA a_Q16, int d)
 {
    i32 P[9], Q[9];
    const int dd = d >> 1;
@@ -85,32 +85,37 @@ WV_DEV void se_insertion_sort_increasing(i32 *a, int *idx, int L, int K)
    for (i = K; i < L; i++) { const i32 v = a[i]; if (v < a[K - 1]) { for (j = K - 2; j >= 0 && v < a[j]; j--) { a[j + 1] = a[j]; idx[j + 1] = idx[j]; } a[j + 1] = v; idx[j + 1] = i; } }
 }
 
-WV_DEV i32 se_nlsf_del_dec_quant(i8 *indices, const i16 *x_Q10, const i16 *w_Q5, const i32 *pred_coef_Q8, const i32 *ec_ix, const u8 *ec_rates_Q5, int quant_step_size_Q16, i16 inv_quant_step_size_Q6, i32 mu_Q20, int order)
+/* per-survivor working set of the NLSF trellis search, in LDS (run-time indexed private arrays would be scratch memory = HBM round trips) */
+struct SeNlsfLane {
+   i32 ec_ix[16], pred_Q8[16], RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4], ind_sort[4];
+   i16 res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
+   i8 ind[4][16], ti[16];
+};
+struct SeNlsfTabs { i32 out0[20], out1[20]; };
+WV_DEV void se_nlsf_out_tabs(WV_LDS SeNlsfTabs *T, int i /* 0..19 */, int quant_step_size_Q16)                 /* NLSF_del_dec_quant.c:66-87 */
+{
+   const int v = i - 10, adj = SE_FIX(0.1, 10);
+   i16 out0 = (i16)shl32(v, 10), out1 = (i16)(out0 + 1024);
+   if (v > 0) { out0 = (i16)(out0 - adj); out1 = (i16)(out1 - adj); } else if (v == 0) out1 = (i16)(out1 - adj); else if (v == -1) out0 = (i16)(out0 + adj); else { out0 = (i16)(out0 + adj); out1 = (i16)(out1 + adj); }
+   T->out0[i] = sk_mulbb(out0, quant_step_size_Q16) >> 16; T->out1[i] = sk_mulbb(out1, quant_step_size_Q16) >> 16;
+}
+WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *T, const u8 *ec_rates_Q5, i16 inv_quant_step_size_Q6, i32 mu_Q20, int order)
 {
    const int NS = 4, AMP = 4, EXT = 10;
    int i, j, nStates, ind_tmp, ind_min_max, ind_max_min;
-   int ind_sort[4]; i8 ind[4][16]; i16 prev_out_Q10[8]; i32 RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4];
-   int out0_tab[20], out1_tab[20];
-   for (i = -EXT; i <= EXT - 1; i++) {
-      i16 out0 = (i16)shl32(i, 10), out1 = (i16)(out0 + 1024);
-      const int adj = SE_FIX(0.1, 10);
-      if (i > 0) { out0 = (i16)(out0 - adj); out1 = (i16)(out1 - adj); } else if (i == 0) out1 = (i16)(out1 - adj); else if (i == -1) out0 = (i16)(out0 + adj); else { out0 = (i16)(out0 + adj); out1 = (i16)(out1 + adj); }
-      out0_tab[i + EXT] = sk_mulbb(out0, quant_step_size_Q16) >> 16;
-      out1_tab[i + EXT] = sk_mulbb(out1, quant_step_size_Q16) >> 16;
-   }
-   nStates = 1; RD_Q25[0] = 0; prev_out_Q10[0] = 0;
+   nStates = 1; w->RD_Q25[0] = 0; w->prev_out_Q10[0] = 0;
    for (i = order - 1; i >= 0; i--) {
-      const u8 *rates_Q5 = &ec_rates_Q5[ec_ix[i]];
-      const int in_Q10 = x_Q10[i];
+      const u8 *rates_Q5 = &ec_rates_Q5[w->ec_ix[i]];
+      const int in_Q10 = w->res_Q10[i], wi = w->W_adj_Q5[i], pc = (i16)w->pred_Q8[i];
       for (j = 0; j < nStates; j++) {
-         const int pred_Q10 = sk_mulbb((i16)pred_coef_Q8[i], prev_out_Q10[j]) >> 8;
+         const int pred_Q10 = sk_mulbb(pc, w->prev_out_Q10[j]) >> 8;
          const int res_Q10 = (i16)(in_Q10 - pred_Q10);
          ind_tmp = sk_mulbb(inv_quant_step_size_Q6, res_Q10) >> 16;
          ind_tmp = se_limit(ind_tmp, -EXT, EXT - 1);
-         ind[j][i] = (i8)ind_tmp;
-         i16 out0 = (i16)out0_tab[ind_tmp + EXT], out1 = (i16)out1_tab[ind_tmp + EXT];
+         w->ind[j][i] = (i8)ind_tmp;
+         i16 out0 = (i16)T->out0[ind_tmp + EXT], out1 = (i16)T->out1[ind_tmp + EXT];
          out0 = (i16)(out0 + pred_Q10); out1 = (i16)(out1 + pred_Q10);
-         prev_out_Q10[j] = out0; prev_out_Q10[j + nStates] = out1;
+         w->prev_out_Q10[j] = out0; w->prev_out_Q10[j + nStates] = out1;
          int rate0_Q5, rate1_Q5;
          if (ind_tmp + 1 >= AMP) {
             if (ind_tmp + 1 == AMP) { rate0_Q5 = rates_Q5[ind_tmp + AMP]; rate1_Q5 = 280; }
@@ -119,52 +124,54 @@ WV_DEV i32 se_nlsf_del_dec_quant(i8 *indices, const i16 *x_Q10, const i16 *w_Q5,
             if (ind_tmp == -AMP) { rate0_Q5 = 280; rate1_Q5 = rates_Q5[ind_tmp + 1 + AMP]; }
             else { rate0_Q5 = sk_mlabb(280 - 43 * AMP, -43, ind_tmp); rate1_Q5 = (i16)(rate0_Q5 - 43); }
          } else { rate0_Q5 = rates_Q5[ind_tmp + AMP]; rate1_Q5 = rates_Q5[ind_tmp + 1 + AMP]; }
-         const i32 RD_tmp = RD_Q25[j];
+         const i32 RD_tmp = w->RD_Q25[j];
          int diff = (i16)(in_Q10 - out0);
-         RD_Q25[j] = sk_mlabb(add32(RD_tmp, (i32)((u32)sk_mulbb(diff, diff) * (u32)(i32)w_Q5[i])), mu_Q20, rate0_Q5);
+         w->RD_Q25[j] = sk_mlabb(add32(RD_tmp, (i32)((u32)sk_mulbb(diff, diff) * (u32)(i32)wi)), mu_Q20, rate0_Q5);
          diff = (i16)(in_Q10 - out1);
-         RD_Q25[j + nStates] = sk_mlabb(add32(RD_tmp, (i32)((u32)sk_mulbb(diff, diff) * (u32)(i32)w_Q5[i])), mu_Q20, rate1_Q5);
+         w->RD_Q25[j + nStates] = sk_mlabb(add32(RD_tmp, (i32)((u32)sk_mulbb(diff, diff) * (u32)(i32)wi)), mu_Q20, rate1_Q5);
       }
       if (nStates <= NS / 2) {
-         for (j = 0; j < nStates; j++) ind[j + nStates][i] = (i8)(ind[j][i] + 1);
+         for (j = 0; j < nStates; j++) w->ind[j + nStates][i] = (i8)(w->ind[j][i] + 1);
          nStates <<= 1;
-         for (j = nStates; j < NS; j++) ind[j][i] = ind[j - nStates][i];
+         for (j = nStates; j < NS; j++) w->ind[j][i] = w->ind[j - nStates][i];
       } else {
          for (j = 0; j < NS; j++) {
-            if (RD_Q25[j] > RD_Q25[j + NS]) {
-               RD_max_Q25[j] = RD_Q25[j]; RD_min_Q25[j] = RD_Q25[j + NS]; RD_Q25[j] = RD_min_Q25[j]; RD_Q25[j + NS] = RD_max_Q25[j];
-               const i16 t = prev_out_Q10[j]; prev_out_Q10[j] = prev_out_Q10[j + NS]; prev_out_Q10[j + NS] = t;
-               ind_sort[j] = j + NS;
-            } else { RD_min_Q25[j] = RD_Q25[j]; RD_max_Q25[j] = RD_Q25[j + NS]; ind_sort[j] = j; }
+            if (w->RD_Q25[j] > w->RD_Q25[j + NS]) {
+               w->RD_max_Q25[j] = w->RD_Q25[j]; w->RD_min_Q25[j] = w->RD_Q25[j + NS]; w->RD_Q25[j] = w->RD_min_Q25[j]; w->RD_Q25[j + NS] = w->RD_max_Q25[j];
+               const i16 t = w->prev_out_Q10[j]; w->prev_out_Q10[j] = w->prev_out_Q10[j + NS]; w->prev_out_Q10[j + NS] = t;
+               w->ind_sort[j] = j + NS;
+            } else { w->RD_min_Q25[j] = w->RD_Q25[j]; w->RD_max_Q25[j] = w->RD_Q25[j + NS]; w->ind_sort[j] = j; }
          }
          while (1) {
             i32 min_max = 2147483647, max_min = 0;
             ind_min_max = 0; ind_max_min = 0;
-            for (j = 0; j < NS; j++) { if (min_max > RD_max_Q25[j]) { min_max = RD_max_Q25[j]; ind_min_max = j; } if (max_min < RD_min_Q25[j]) { max_min = RD_min_Q25[j]; ind_max_min = j; } }
+            for (j = 0; j < NS; j++) { if (min_max > w->RD_max_Q25[j]) { min_max = w->RD_max_Q25[j]; ind_min_max = j; } if (max_min < w->RD_min_Q25[j]) { max_min = w->RD_min_Q25[j]; ind_max_min = j; } }
             if (min_max >= max_min) break;
-            ind_sort[ind_max_min] = ind_sort[ind_min_max] ^ NS;
-            RD_Q25[ind_max_min] = RD_Q25[ind_min_max + NS];
-            prev_out_Q10[ind_max_min] = prev_out_Q10[ind_min_max + NS];
-            RD_min_Q25[ind_max_min] = 0; RD_max_Q25[ind_min_max] = 2147483647;
-            for (int q = 0; q < 16; q++) ind[ind_max_min][q] = ind[ind_min_max][q];
+            w->ind_sort[ind_max_min] = w->ind_sort[ind_min_max] ^ NS;
+            w->RD_Q25[ind_max_min] = w->RD_Q25[ind_min_max + NS];
+            w->prev_out_Q10[ind_max_min] = w->prev_out_Q10[ind_min_max + NS];
+            w->RD_min_Q25[ind_max_min] = 0; w->RD_max_Q25[ind_min_max] = 2147483647;
+            for (int q = 0; q < 16; q++) w->ind[ind_max_min][q] = w->ind[ind_min_max][q];
          }
-         for (j = 0; j < NS; j++) ind[j][i] = (i8)(ind[j][i] + (ind_sort[j] >> 2));
+         for (j = 0; j < NS; j++) w->ind[j][i] = (i8)(w->ind[j][i] + (w->ind_sort[j] >> 2));
       }
    }
    ind_tmp = 0;
    i32 min_Q25 = 2147483647;
-   for (j = 0; j < 2 * NS; j++) if (min_Q25 > RD_Q25[j]) { min_Q25 = RD_Q25[j]; ind_tmp = j; }
-   for (j = 0; j < order; j++) indices[j] = ind[ind_tmp & (NS - 1)][j];
-   indices[0] = (i8)(indices[0] + (ind_tmp >> 2));
+   for (j = 0; j < 2 * NS; j++) if (min_Q25 > w->RD_Q25[j]) { min_Q25 = w->RD_Q25[j]; ind_tmp = j; }
+   for (j = 0; j < order; j++) w->ti[j] = w->ind[ind_tmp & (NS - 1)][j];
+   w->ti[0] = (i8)(w->ti[0] + (ind_tmp >> 2));
    return min_Q25;
 }
 
 /* scratch of the LPC / NLSF stages (LDS) */
 struct SeLpcWork {
-   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8];
+   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8], stk[100];
    i16 NLSF_Q15[16], NLSF0_Q15[16], a_tmp_Q12[16], pW[16];
    i32 err_Q24[32], RD_Q25[16], surv[16];
    i8 tempIndices2[16 * 16];
+   SeNlsfTabs tabs;
+   SeNlsfLane lane[16];
 };
 
 /* NLSFIndices, pNLSF_Q15 (in/out) live in LDS; lanes = survivors */
@@ -195,23 +202,32 @@ WV_DEV void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, i
       se_insertion_sort_increasing(e, idx, cb.nVectors, nSurvivors);
       for (int s = 0; s < nSurvivors; s++) W->surv[s] = idx[s];
    }
+   FOR_LANES(i, 20) se_nlsf_out_tabs(&W->tabs, i, cb.qstep);
+   wv_sync();
    FOR_LANES(s, nSurvivors) {
       const int ind1 = W->surv[s];
       const u8 *pCB = &cb.cb1_nlsf[ind1 * order]; const i16 *pWg = &cb.wght[ind1 * order];
-      i16 res_Q10[16], W_adj_Q5[16]; i32 ec_ix[16], pred_Q8[16]; i8 ti[16];
+      WV_LDS SeNlsfLane *w = &W->lane[s];
       for (int i = 0; i < order; i++) {
          const i16 tmp = (i16)shl32((i16)pCB[i], 7);
          const i32 W_tmp_Q9 = pWg[i];
-         res_Q10[i] = (i16)(sk_mulbb(pNLSF_Q15[i] - tmp, W_tmp_Q9) >> 14);
-         W_adj_Q5[i] = (i16)sk_div32_varQ((i32)pW_Q2[i], sk_mulbb(W_tmp_Q9, W_tmp_Q9), 21);
+         w->res_Q10[i] = (i16)(sk_mulbb(pNLSF_Q15[i] - tmp, W_tmp_Q9) >> 14);
+         w->W_adj_Q5[i] = (i16)sk_div32_varQ((i32)pW_Q2[i], sk_mulbb(W_tmp_Q9, W_tmp_Q9), 21);
       }
-      sd_nlsf_unpack(ec_ix, pred_Q8, cb, ind1);
-      i32 RD = se_nlsf_del_dec_quant(ti, res_Q10, W_adj_Q5, pred_Q8, ec_ix, ec_rates_Q5, cb.qstep, inv_qstep_Q6, NLSF_mu_Q20, order);
+      {  /* silk_NLSF_unpack (NLSF_unpack.c:35) into the lane's workspace */
+         const u8 *sel = &cb.ec_sel[ind1 * order / 2];
+         for (int i = 0; i < order; i += 2) {
+            const int entry = *sel++;
+            w->ec_ix[i] = ((entry >> 1) & 7) * 9; w->pred_Q8[i] = cb.pred[i + (entry & 1) * (order - 1)];
+            w->ec_ix[i + 1] = ((entry >> 5) & 7) * 9; w->pred_Q8[i + 1] = cb.pred[i + ((entry >> 4) & 1) * (order - 1) + 1];
+         }
+      }
+      const i32 RD = se_nlsf_del_dec_quant(w, &W->tabs, ec_rates_Q5, inv_qstep_Q6, NLSF_mu_Q20, order);
       const u8 *icdf = &cb.cb1_icdf[(signalType >> 1) * cb.nVectors];
       const int prob_Q8 = ind1 == 0 ? 256 - icdf[ind1] : icdf[ind1 - 1] - icdf[ind1];
       const int bits_q7 = (8 << 7) - se_lin2log(prob_Q8);
       W->RD_Q25[s] = sk_mlabb(RD, bits_q7, NLSF_mu_Q20 >> 2);
-      for (int i = 0; i < 16; i++) W->tempIndices2[s * 16 + i] = i < order ? ti[i] : 0;
+      for (int i = 0; i < 16; i++) W->tempIndices2[s * 16 + i] = i < order ? w->ti[i] : 0;
    }
    LANE0 {
       int best = 0; i32 bv = W->RD_Q25[0];
@@ -260,13 +276,13 @@ WV_DEV void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, co
    const int order = c->predictLPCOrder, subfr_length = c->subfr_length + order;
    const int interp = c->useInterpolatedNLSFs && !c->first_frame_after_reset && c->nb_subfr == 4;
    LANE0 {
-      i32 a[16], res_nrg; int res_nrg_Q;
+      i32 res_nrg; int res_nrg_Q;
       c->indices.NLSFInterpCoef_Q2 = 4;
-      se_burg_modified_l0(&res_nrg, &res_nrg_Q, a, x, minInvGain_Q30, subfr_length, c->nb_subfr, order);
-      for (int i = 0; i < order; i++) W->a_Q16[i] = a[i];
+      se_burg_modified_l0(&res_nrg, &res_nrg_Q, W->a_Q16, x, minInvGain_Q30, subfr_length, c->nb_subfr, order, W->stk);
       if (interp) {
-         i32 at[16], res_tmp_nrg; int res_tmp_nrg_Q;
-         se_burg_modified_l0(&res_tmp_nrg, &res_tmp_nrg_Q, at, x + 2 * subfr_length, minInvGain_Q30, subfr_length, 2, order);
+         i32 res_tmp_nrg; int res_tmp_nrg_Q;
+         WV_LDS i32 *at = W->a_tmp_Q16;
+         se_burg_modified_l0(&res_tmp_nrg, &res_tmp_nrg_Q, at, x + 2 * subfr_length, minInvGain_Q30, subfr_length, 2, order, W->stk);
          const int shift = res_tmp_nrg_Q - res_nrg_Q;
          if (shift >= 0) { if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift); }
          else { res_nrg = (res_nrg >> -shift) - res_tmp_nrg; res_nrg_Q = res_tmp_nrg_Q; }
@@ -303,9 +319,8 @@ WV_DEV void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, co
    }
    LANE0 {
       if (c->indices.NLSFInterpCoef_Q2 == 4) {
-         i32 a[16]; i16 n[16];
-         for (int i = 0; i < order; i++) a[i] = W->a_Q16[i];
-         se_a2nlsf(n, a, order);
+         i16 n[16];
+         se_a2nlsf(n, W->a_Q16, order);
          for (int i = 0; i < order; i++) W->NLSF_Q15[i] = n[i];
       }
    }

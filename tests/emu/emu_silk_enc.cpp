@@ -11,7 +11,7 @@ extern "C" void emu_set_dump(dump_fn f) { g_dump = f; }
 #include "celt_dec_all.h"
 #include "silk_enc_all.h"
 
-struct EJob { SilkEncLds *S; OaSilkEnc *gs; int32_t *ctl; const int16_t *pcm; int nSamples; uint8_t *out; int out_cap; int32_t *res; int activity; int ret; };
+struct EJob { SeRateScratch *G; SilkEncLds *S; OaSilkEnc *gs; int32_t *ctl; const int16_t *pcm; int nSamples; uint8_t *out; int out_cap; int32_t *res; int activity; int ret; };
 static void ejob(void *p)
 {
    EJob *j = (EJob *)p;
@@ -24,7 +24,7 @@ static void ejob(void *p)
    /* the packet buffer and coder context stand where the Opus layer keeps them */
    static thread_local EcCtx ecl; static thread_local uint8_t buf[1280]; static thread_local int16_t pcm16[2 * 2880];
    LANE0 { EcCtx e_; EcCtx *e = &e_; uint8_t *b = buf; (void)b; k_ec_enc_init(e, buf, (u32)j->out_cap); ec_st(&ecl, e); for (int i = 0; i < j->nSamples * c.nChannelsAPI; i++) pcm16[i] = j->pcm[i]; }
-   const int ret = silk_encode_wave(S, &c, pcm16, j->nSamples, &ecl, buf, j->activity);
+   const int ret = silk_encode_wave(S, &c, pcm16, j->nSamples, &ecl, buf, j->activity, j->G);
    wv_sync();
    LANE0 {
       j->ret = ret;
@@ -46,15 +46,16 @@ extern "C" int emu_silk_encode(OaSilkEnc *st, int32_t *ctl, const int16_t *pcm, 
 {
    SilkEncLds *S = (SilkEncLds *)aligned_alloc(64, (sizeof(SilkEncLds) + 63) & ~63);
    memset(S, 0xA5, sizeof(SilkEncLds));
-   EJob j = {S, st, ctl, pcm, nSamples, out, out_cap, res, activity, 0};
+   SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
+   EJob j = {G, S, st, ctl, pcm, nSamples, out, out_cap, res, activity, 0};
    emu_run_wave(ejob, &j);
-   free(S);
+   free(S); free(G);
    return j.ret;
 }
 
 /* ---- the whole Opus-layer frame (opus_enc_sh.h) ---- */
-struct ShJob { ShLds *L; OaShStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int out_cap; int16_t *pcm_hp; int32_t *len; uint32_t *rng; };
-static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->len, j->rng); }
+struct ShJob { SeRateScratch *G; ShLds *L; OaShStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int out_cap; int16_t *pcm_hp; int32_t *len; uint32_t *rng; };
+static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->G, j->len, j->rng); }
 extern "C" int emu_sh_stream_size() { return (int)sizeof(OaShStream); }
 extern "C" int emu_sh_lds_size() { return (int)sizeof(ShLds); }
 extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int application) { oa_sh_stream_init(st, Fs, channels, application); }
@@ -64,7 +65,8 @@ extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size
    ShLds *L = (ShLds *)aligned_alloc(64, (sizeof(ShLds) + 63) & ~63);
    memset(L, 0xA5, sizeof(ShLds));
    int16_t *hp = (int16_t *)malloc(sizeof(int16_t) * (size_t)frame_size * 2 + 64);
-   ShJob j = {L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
+   SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
+   ShJob j = {G, L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
    emu_run_wave(shjob, &j);
-   free(hp); free(L);
+   free(hp); free(L); free(G);
 }

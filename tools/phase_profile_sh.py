@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""tools/phase_profile_sh.py — build the -DOA_PHASE_TIMERS variant and print the shader-clock share of every stage of the SILK-capable encoder kernel
+(lane 0 of every wave) on the config-3 workload.  Profiling aid only; the product library has no timers."""
+import ctypes, os, subprocess, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+PH = ["load state", "silence+decide+highpass", "silk_Encode front (control, resample, VAD)", "find_pitch_lags", "noise_shape_analysis", "find_pred_coefs", "process_gains", "NSQ", "encode indices+pulses",
+      "silk_Encode tail", "finalise+store"]
+def main():
+    so = os.path.join(ROOT, "opus_amd/libopus_amd_prof.so")
+    hd = os.path.join(ROOT, "opus_amd/csrc")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(hd, f)) for f in os.listdir(hd)):
+      subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DOA_PHASE_TIMERS",
+                           "-I" + os.path.join(ROOT, "opus_amd/csrc"), "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "opus_amd/csrc/opus_amd.hip"), "-o", so])
+    import opus_amd
+    from silk_enc_bench import speech
+    opus_amd.LIB_PATH = so
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    cx = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    b = opus_amd.EncoderBatch(S, channels=1, application=2048, Fs=16000)
+    for req, v in ((11002, 1000), (4008, 1103), (4002, 24000), (4010, cx)): b.ctl(req, v)
+    sig = [speech(16000, 8 * 320, 100 + s) for s in range(64)]
+    L = opus_amd.lib()
+    ticks = (ctypes.c_ulonglong * 24)()
+    for i in range(8):
+        pcm = np.stack([sig[s % 64][i * 320:(i + 1) * 320] for s in range(S)])
+        if i == 3: L.opusgpu_debug_sh_phase_ticks(ticks, 1)
+        b.encode(pcm, 320)
+    L.opusgpu_debug_sh_phase_ticks(ticks, 0)
+    t = np.array(list(ticks)[:11], dtype=np.float64); tot = t.sum()
+    print("oa_sh_encode_kernel, complexity %d: stage shares over %d frames (shader clock ticks per frame: %.0f)" % (cx, 5 * S, tot / (5 * S)))
+    for n, v in zip(PH, t): print("  %-44s %6.2f %%  %9.0f ticks/frame" % (n, 100 * v / tot, v / (5 * S)))
+if __name__ == "__main__": main()
