@@ -40,66 +40,24 @@ WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to,
    return pad_to;
 }
 
-WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+/* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
+ * constants of the prologue in L->sh, the int16 input staged in L->A.pcm16 and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
+ * HYB = the hybrid branches of the reference (start band 17: no pitch pre-filter, no tf_analysis, weak transients, its own VBR target, :2030-2470). */
+template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int lane = wv_lane();
-   const int overlap = OA_OVERLAP;
+   const int CC = sh->CC, C = sh->C;
 #ifdef OA_PHASE_TIMERS
    unsigned long long oa_phase_t0 = 0;
 #endif
-
-   /* ---- load persistent state (coalesced) ---- */
-   {
-      const i32 *g = (const i32 *)&gs->st.s;
-      WV_LDS i32 *d = (WV_LDS i32 *)st;
-      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
-   }
-   wv_sync();
-   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
-   wv_sync();
-   if (sh->plc_frame) {
-      const int n = emit_packet_wave(L, out, 1, sh->pad_to, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; gs->st.s.rangeFinal = 0; }
-      return;
-   }
-   const int CC = sh->CC, C = sh->C;
-
-   K_PHASE(0);
-   /* ---- Opus layer: dc_reject (+ optional stereo width fade) into int16 staging ---- */
-   dc_reject_lanes(L, pcm, frame_size, CC);
-   wv_sync();
-   if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
-   {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973) */
-      const WV_LDS i16 *p = L->A.pcm16;
-      const int Nf = frame_size;
-      i32 a = 0, b = 0;
-      FOR_LANES(i, CC * (Nf - overlap)) a = imax(a, iabs((i32)p[i]));
-      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)p[CC * (Nf - overlap) + i]));
-      a = wv_max(a); b = wv_max(b);
-      LANE0 { sh->r[0] = a; sh->r[1] = b; }
-   }
-   wv_sync();
-   LANE0 celt_prologue(L);
-   wv_sync();
-   if (sh->skip_celt) {
-      /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
-      LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; }
-      wv_sync();
-      const int n = emit_packet_wave(L, out, 2, sh->pad_to, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; st->rangeFinal = 0; }
-      return;
-   }
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
 
    K_PHASE(1);
    /* ---- pre-emphasis (celt_encoder.c:557) is not materialised: pre_at() recomputes it from the int16 staging buffer ---- */
    PreSrc ps0, ps1;
-   ps0.hist = gs->st.prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0];
-   ps1.hist = gs->st.prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1];
+   ps0.hist = gst->prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0];
+   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1];
    wv_sync();
    LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
    wv_sync();
@@ -112,7 +70,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
    wv_sync();
    K_PHASE(3);
-   if (sh->complexity >= 1) transient_analysis_wave(L, ps0, ps1, 0);
+   if (sh->complexity >= 1) transient_analysis_wave(L, ps0, ps1, HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2);
    wv_sync();
    K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
    LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
@@ -121,15 +79,15 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(4);
    /* ---- pitch pre-filter ---- */
    {
-      int enabled = (sh->nbAvailableBytes > 12 * C) && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
-      run_prefilter_wave(L, &gs->st, ps0, ps1, enabled);
+      int enabled = (sh->nbAvailableBytes > 12 * C) && !HYB && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
+      run_prefilter_wave(L, gst, ps0, ps1, enabled);
       LANE0 {
          EC_BEGIN;
          int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
          sh->pitch_change = 0;
          if ((gain1 > QC16(.4f, 15) || (i16)st->prefilter_gain > QC16(.4f, 15)) && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period)) sh->pitch_change = 1;
          if (sh->pf_on == 0) {
-            if (sh->tell + 16 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, 0, 1);
+            if (!HYB && sh->tell + 16 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, 0, 1);
          } else {
             int octave;
             k_ec_enc_bit_logp(EC_PASS, 1, 1);
@@ -153,12 +111,12 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(5);
    /* ---- MDCT + band energies ---- */
    if (sh->secondMdct) {
-      compute_mdcts_wave(L, &gs->st, 0);
+      compute_mdcts_wave(L, gst, 0);
       band_energies_wave(L, L->bandLogE2);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       wv_sync();
    }
-   compute_mdcts_wave(L, &gs->st, sh->shortBlocks);
+   compute_mdcts_wave(L, gst, sh->shortBlocks);
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    band_energies_wave(L, L->bandLogE);
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
@@ -168,7 +126,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       temporal_vbr_l0(L);
       if (!sh->secondMdct) for (int i = 0; i < C * NBE; i++) L->bandLogE2[i] = L->bandLogE[i];
       sh->do_patch = 0;
-      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5)
+      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5 && !HYB)
          sh->do_patch = patch_transient_decision_l0(L);
       EC_END;
    }
@@ -176,13 +134,13 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    if (sh->do_patch) {
       LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
       wv_sync();
-      compute_mdcts_wave(L, &gs->st, sh->shortBlocks);
+      compute_mdcts_wave(L, gst, sh->shortBlocks);
       band_energies_wave(L, L->bandLogE);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
    }
-   store_in_mem_wave(L, &gs->st);          /* last MDCT done: the overlap memory may now be replaced; BC is free from here */
+   store_in_mem_wave(L, gst);          /* last MDCT done: the overlap memory may now be replaced; BC is free from here */
    LANE0 { EC_BEGIN; if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); EC_END; }
    normalise_bands_wave(L);
    K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->A.s.X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
@@ -190,14 +148,21 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_PHASE(7);
    /* ---- allocation analyses ---- */
    LANE0 {
-      sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && sh->complexity >= 2 && sh->toneishness < QC32(.98f, 29);
+      sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && !HYB && sh->complexity >= 2 && sh->toneishness < QC32(.98f, 29);
       dynalloc_analysis_l0(L);
    }
    wv_sync();
    K_DUMPI("maxDepth", sh->maxDepth); K_DUMPI("tot_boost", sh->tot_boost); K_DUMP("offsets", L->offsets, 84); K_DUMP("importance", L->importance, 84); K_DUMP("spread_weight", L->spread_weight, 84);
    K_PHASE(8);
    if (sh->enable_tf_analysis) tf_analysis_wave(L, imax(80, 20480 / sh->effectiveBytes + 2));
-   else { LANE0 { for (int i = 0; i < end; i++) L->tf_res[i] = sh->isTransient; sh->tf_select = 0; } wv_sync(); }
+   else {
+      LANE0 {
+         if (HYB && sh->weak_transient) { for (int i = 0; i < end; i++) L->tf_res[i] = 1; sh->tf_select = 0; }                                   /* celt_encoder.c:2262 */
+         else if (HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2) { for (int i = 0; i < end; i++) L->tf_res[i] = 0; sh->tf_select = sh->isTransient; }
+         else { for (int i = 0; i < end; i++) L->tf_res[i] = sh->isTransient; sh->tf_select = 0; }
+      }
+      wv_sync();
+   }
    FOR_LANES(w, C * NBE) {
       int c = w / NBE, i = w - c * NBE;
       if (i >= start && i < end && iabs(sub32(L->bandLogE[i + c * NBE], L->oldBandE[i + c * NBE])) < GC(2.f))
@@ -205,6 +170,16 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    wv_sync();
    K_PHASE(9);
+#ifdef K_DUMP_ENABLED
+   LANE0 {   /* same words as oracle/ref_expose/x_opus_enc_tap.c tap_coarse */
+      i32 w[12 + 84]; int n = 0;
+      w[n++] = start; w[n++] = end; w[n++] = C; w[n++] = LM; w[n++] = sh->total_bits; w[n++] = sh->nbAvailableBytes; w[n++] = sh->force_intra; w[n++] = st->delayedIntra; w[n++] = sh->complexity >= 4;
+      w[n++] = L->ec.nbits_total - ec_ilog(L->ec.rng); w[n++] = (i32)L->ec.rng; w[n++] = 0;
+      for (int i = 0; i < 42; i++) w[n++] = i < C * 21 ? L->bandLogE[i] : 0;
+      for (int i = 0; i < 42; i++) w[n++] = i < C * 21 ? L->oldBandE[i] : 0;
+      K_DUMP("coarse_in", w, 4 * n);
+   }
+#endif
    LANE0 {
       EC_BEGIN;
       k_quant_coarse_energy(L->scr, L->BC.coarse_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
@@ -217,7 +192,8 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", L->ec.rng); K_DUMPI("tell_tf", ec_tell_frac_lds(&L->ec));
    K_PHASE(10);
    if (sh->r[2]) {
-      if (sh->shortBlocks || sh->complexity < 3 || sh->nbAvailableBytes < 10 * C) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : 2; wv_sync(); }
+      if (HYB) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : sh->isTransient ? 2 : 3; wv_sync(); }                                      /* :2309 SPREAD_NONE / NORMAL / AGGRESSIVE */
+      else if (sh->shortBlocks || sh->complexity < 3 || sh->nbAvailableBytes < 10 * C) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : 2; wv_sync(); }
       else spreading_decision_wave(L, sh->pf_on && !sh->shortBlocks);
       LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, st->spread_decision, k_spread_icdf, 5); EC_END; }
    } else { LANE0 st->spread_decision = 2; }
@@ -266,7 +242,8 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       wv_sync();
    }
    if (sh->r[4]) {
-      alloc_trim_analysis_wave(L);
+      if (HYB) { LANE0 { st->stereo_saving = 0; sh->alloc_trim = 5; } }                        /* start > 0 (celt_encoder.c:2401) */
+      else alloc_trim_analysis_wave(L);
       LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7); EC_END; }
       wv_sync();
    }
@@ -279,14 +256,22 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       i32 tell = k_ec_tell_frac(EC_PASS), total_boost = sh->total_boost, vbr_rate = sh->vbr_rate;
       int nbCompressedBytes = sh->nbCompressedBytes, nbAvailableBytes, silence = sh->silence;
       i32 min_allowed = ((tell + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3)) + 2;
+      if (HYB) min_allowed = imax(min_allowed, (sh->tell0_frac + (37 << BITRES) + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3));   /* room to signal a redundant frame (:2433) */
       if (vbr_rate > 0) {
          i16 alpha;
          i32 delta, target, base_target;
          int lm_diff = 3 - LM;
          nbCompressedBytes = imin(nbCompressedBytes, 1275 >> (3 - LM));
-         base_target = vbr_rate - ((40 * C + 20) << BITRES);
+         base_target = HYB ? imax(0, vbr_rate - ((9 * C + 4) << BITRES)) : vbr_rate - ((40 * C + 20) << BITRES);
          if (sh->constrained_vbr) base_target += (st->vbr_offset >> lm_diff);
-         target = compute_vbr_l0(L, base_target);
+         if (!HYB) target = compute_vbr_l0(L, base_target);
+         else {                                                                                       /* :2463-2475 */
+            target = base_target;
+            if (sh->silk_offset < 100) target += 12 << BITRES >> (3 - LM);
+            if (sh->silk_offset > 100) target -= 18 << BITRES >> (3 - LM);
+            target += (i32)mult16_16_q14((i16)sh->tf_estimate - QC16(.25f, 14), (50 << BITRES));
+            if ((i16)sh->tf_estimate > QC16(.7f, 14)) target = imax(target, 50 << BITRES);
+         }
          target = target + tell;
          nbAvailableBytes = (target + (1 << (BITRES + 2))) >> (BITRES + 3);
          nbAvailableBytes = imax(min_allowed, nbAvailableBytes);
@@ -315,6 +300,15 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       bits -= anti_collapse_rsv;
       sh->anti_collapse_rsv = anti_collapse_rsv;
       int signalBandwidth = end - 1;
+#ifdef K_DUMP_ENABLED
+      {  /* tap_alloc */
+         i32 w[12 + 42]; int n = 0;
+         w[n++] = start; w[n++] = end; w[n++] = sh->alloc_trim; w[n++] = st->intensity; w[n++] = sh->dual_stereo; w[n++] = bits; w[n++] = C; w[n++] = LM; w[n++] = k_ec_tell(EC_PASS); w[n++] = (i32)e->rng; w[n++] = st->lastCodedBands; w[n++] = signalBandwidth;
+         for (int i = 0; i < 21; i++) w[n++] = L->offsets[i];
+         for (int i = 0; i < 21; i++) w[n++] = L->cap[i];
+         K_DUMP("alloc_in", w, 4 * n);
+      }
+#endif
       sh->codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, sh->alloc_trim, &st->intensity, &sh->dual_stereo, bits, &sh->balance,
             L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 1, st->lastCodedBands, signalBandwidth);
       if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, sh->codedBands));
@@ -330,7 +324,7 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    /* ---- PVQ residual ---- */
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
          sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv,
-         out /* the stream's still-unwritten output slot doubles as the theta-RDO byte journal */);
+         journal /* the stream's still-unwritten output slot doubles as the theta-RDO byte journal */);
    K_DUMPI("rng_pvq", L->ec.rng); K_DUMP("collapse", L->collapse_masks, 42);
 
    K_PHASE(13);
@@ -364,6 +358,79 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
    }
    wv_sync();
 
+   /* ---- CELT array state (coalesced) ---- */
+   {
+      /* oldLogE / oldLogE2 (celt_encoder.c:2783-2803) are only ever updated here: do it straight on the HBM state.
+       * oldBandE in LDS still holds the pre-"start/end clearing" values for [start,end) and 0 outside, as the reference has at this point. */
+      const int isTr = sh->isTransient, nb = sh->CC * NBE;
+      FOR_LANES(i, 2 * NBE) {
+         if (i < nb) {
+            int bi = i % NBE;
+            i32 ob = L->oldBandE[i], l1 = gst->oldLogE[i], l2 = gst->oldLogE2[i];
+            if (!isTr) { l2 = l1; l1 = ob; } else l1 = imin(l1, ob);
+            if (bi < sh->start || bi >= sh->end) { l1 = l2 = -GC(28.f); }
+            gst->oldLogE[i] = l1; gst->oldLogE2[i] = l2;
+         }
+         gst->oldBandE[i] = L->oldBandE[i]; gst->energyError[i] = L->energyError[i];
+      }
+   }
+}
+
+WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   const int lane = wv_lane();
+   const int overlap = OA_OVERLAP;
+#ifdef OA_PHASE_TIMERS
+   unsigned long long oa_phase_t0 = 0;
+#endif
+
+   /* ---- load persistent state (coalesced) ---- */
+   {
+      const i32 *g = (const i32 *)&gs->st.s;
+      WV_LDS i32 *d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
+   }
+   wv_sync();
+   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
+   wv_sync();
+   if (sh->plc_frame) {
+      const int n = emit_packet_wave(L, out, 1, sh->pad_to, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; gs->st.s.rangeFinal = 0; }
+      return;
+   }
+   const int CC = sh->CC;
+
+   K_PHASE(0);
+   /* ---- Opus layer: dc_reject (+ optional stereo width fade) into int16 staging ---- */
+   dc_reject_lanes(L, pcm, frame_size, CC);
+   wv_sync();
+   if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
+   {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973) */
+      const WV_LDS i16 *p = L->A.pcm16;
+      const int Nf = frame_size;
+      i32 a = 0, b = 0;
+      FOR_LANES(i, CC * (Nf - overlap)) a = imax(a, iabs((i32)p[i]));
+      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)p[CC * (Nf - overlap) + i]));
+      a = wv_max(a); b = wv_max(b);
+      LANE0 { sh->r[0] = a; sh->r[1] = b; }
+   }
+   wv_sync();
+   LANE0 celt_prologue(L);
+   wv_sync();
+   if (sh->skip_celt) {
+      /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
+      LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; }
+      wv_sync();
+      const int n = emit_packet_wave(L, out, 2, sh->pad_to, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; st->rangeFinal = 0; }
+      return;
+   }
+   celt_encode_core<false>(L, &gs->st, out);
+
    K_PHASE(14);
    /* ---- store packet + state (coalesced) ---- */
    {
@@ -372,19 +439,6 @@ WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, i
       i32 *g = (i32 *)&gs->st.s;
       const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
-      /* oldLogE / oldLogE2 (celt_encoder.c:2783-2803) are only ever updated here: do it straight on the HBM state.
-       * oldBandE in LDS still holds the pre-"start/end clearing" values for [start,end) and 0 outside, as the reference has at this point. */
-      const int isTr = sh->isTransient, nb = sh->CC * NBE;
-      FOR_LANES(i, 2 * NBE) {
-         if (i < nb) {
-            int bi = i % NBE;
-            i32 ob = L->oldBandE[i], l1 = gs->st.oldLogE[i], l2 = gs->st.oldLogE2[i];
-            if (!isTr) { l2 = l1; l1 = ob; } else l1 = imin(l1, ob);
-            if (bi < sh->start || bi >= sh->end) { l1 = l2 = -GC(28.f); }
-            gs->st.oldLogE[i] = l1; gs->st.oldLogE2[i] = l2;
-         }
-         gs->st.oldBandE[i] = L->oldBandE[i]; gs->st.energyError[i] = L->energyError[i];
-      }
    }
    K_PHASE(15);
 }

@@ -186,7 +186,8 @@ WV_DEV void stereo_fade_lanes(WV_LDS FrameLds *L, int frame_size)
 }
 
 /* celt_encode_with_ec prologue (lane 0): byte budget, VBR bounds, silence flag (celt_encoder.c:1858-2008). */
-WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
+/* hyb_bytes > 0: hybrid frame, the coder continues after the SILK layer inside a buffer already shrunk to hyb_bytes (src/opus_encoder.c:2446, celt_encoder.c:1858) */
+WV_DEVN void celt_prologue(WV_LDS FrameLds *L, int hyb_bytes = 0)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -196,9 +197,13 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L)
    for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
    sh->LM = LM; sh->M = 1 << LM; sh->N = 120 << LM;
    /* opus_encode_frame_native: ec_enc_init(data+1, orig_max-1), shrink to max_data_bytes-1 */
-   k_ec_enc_init(EC_PASS, sh->orig_max_data_bytes - 1);
-   int nbCompressedBytes = sh->max_data_bytes - 1;
-   k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+   int nbCompressedBytes;
+   if (hyb_bytes > 0) { ec_ld(e, &L->ec); nbCompressedBytes = hyb_bytes; }
+   else {
+      k_ec_enc_init(EC_PASS, sh->orig_max_data_bytes - 1);
+      nbCompressedBytes = sh->max_data_bytes - 1;
+      k_ec_enc_shrink(EC_PASS, nbCompressedBytes);
+   }
    L->packet[0] = 0;
    if (k_ec_tell(EC_PASS) > 8 * nbCompressedBytes) { sh->skip_celt = 1; EC_END; return; }
    int C = sh->C;

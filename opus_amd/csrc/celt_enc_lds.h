@@ -29,6 +29,7 @@ struct FrameShared {
    i32 pf_on, pitch_index, gain1, qg, prefilter_tapset, pitch_change, pf_enabled, cancel_pitch;
    i32 maxDepth, tot_boost, temporal_vbr, tf_select, enable_tf_analysis, do_patch;
    i32 alloc_trim, dual_stereo, total_boost, anti_collapse_rsv, anti_collapse_on, codedBands, balance, bits, signalBandwidth, pvq_total_bits;
+   i32 silk_signalType, silk_offset;   /* hybrid: SILKInfo of the frame (celt/celt.h SILKInfo, src/opus_encoder.c:2486) */
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 

@@ -24,6 +24,7 @@
 struct ShShared {
    i32 frame_size, max_data_bytes, orig_max_data_bytes, pad_to, plc_frame, ret, err, toc, is_silence, sample_max;
    i32 bitrate_bps, equiv_rate, curr_bandwidth, activity, cutoff_Hz, use_hp_cutoff, bits_target, nBytes, silk_ret;
+   i32 silk_bitRate, HB_gain, nb_compr_bytes, silk_signalType, silk_offset;
    i32 r[8];
 };
 struct ShLds {
@@ -155,7 +156,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    if (cfg->application == OA_APP_RESTRICTED_SILK && curr_bandwidth > OA_BW_WB) st->bandwidth = curr_bandwidth = OA_BW_WB;
    if (st->mode == OA_MODE_SILK_ONLY && curr_bandwidth > OA_BW_WB) st->mode = OA_MODE_HYBRID;
    if (st->mode == OA_MODE_HYBRID && curr_bandwidth <= OA_BW_WB) st->mode = OA_MODE_SILK_ONLY;
-   if (st->mode != OA_MODE_SILK_ONLY) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                  /* hybrid: next */
+   if (st->mode == OA_MODE_HYBRID && (Fs != 48000 || frame_size > Fs / 50 || (st->prev_mode > 0 && st->prev_mode != OA_MODE_HYBRID))) { sh->err = OA_ERR_UNIMPLEMENTED; return; }   /* CELT layer: 48 kHz, <= 20 ms; SILK -> hybrid needs the CELT prefill */
    if (frame_size > 3 * Fs / 50) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                       /* 80/100/120 ms: repacketised multi-frame packets */
    if (st->silk_bw_switch) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                             /* bandwidth switch with CELT redundancy */
    sh->bitrate_bps = bitrate_bps; sh->equiv_rate = equiv_rate; sh->curr_bandwidth = curr_bandwidth;
@@ -217,6 +218,106 @@ WV_DEV int sh_emit_packet(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, 
    return pad_to;
 }
 
+/* compute_silk_rate_for_hybrid (src/opus_encoder.c:656) */
+WV_DEV i32 sh_silk_rate_for_hybrid(i32 rate, int bandwidth, int frame20ms, int vbr, int fec, int channels)
+{
+   const i32 rate_table[7][5] = {{0, 0, 0, 0, 0}, {12000, 10000, 10000, 11000, 11000}, {16000, 13500, 13500, 15000, 15000}, {20000, 16000, 16000, 18000, 18000},
+                                 {24000, 18000, 18000, 21000, 21000}, {32000, 22000, 22000, 28000, 28000}, {64000, 38000, 38000, 50000, 50000}};
+   rate /= channels;
+   const int entry = 1 + frame20ms + 2 * fec, N = 7;
+   int i; i32 silk_rate;
+   for (i = 1; i < N; i++) if (rate_table[i][0] > rate) break;
+   if (i == N) { silk_rate = rate_table[i - 1][entry]; silk_rate += (rate - rate_table[i - 1][0]) / 2; }
+   else { const i32 lo = rate_table[i - 1][entry], hi = rate_table[i][entry], x0 = rate_table[i - 1][0], x1 = rate_table[i][0]; silk_rate = (lo * (x1 - rate) + hi * (rate - x0)) / (x1 - x0); }
+   if (!vbr) silk_rate += 100;
+   if (bandwidth == OA_BW_SWB) silk_rate += 300;
+   silk_rate *= channels;
+   if (channels == 2 && rate >= 12000) silk_rate -= 1000;
+   return silk_rate;
+}
+
+/* The CELT layer of a hybrid frame (src/opus_encoder.c:2452-2600): bands 17.. on the coder the SILK layer leaves behind.  The SILK state has served its
+ * purpose: it goes back to HBM and the CELT encoder's LDS working set takes its place.  CELT input = the delay-compensated high-passed signal
+ * (delay_buffer tail + this call's frame), faded towards the high-band gain and the stereo width decided above. */
+WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm_hp, int frame_size, u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   {  /* SILK state and Opus-layer scalars back to HBM (coalesced) */
+      i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+   }
+   wv_sync();
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameShared *fs = &F->sh;
+   {
+      const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = gs->celt.oldBandE[i]; F->energyError[i] = gs->celt.energyError[i]; }
+      FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i];
+   }
+   LANE0 {
+      ec_cp_lds(&F->ec, &L->ec);
+      const int curr_bandwidth = sh->curr_bandwidth, endband = curr_bandwidth == OA_BW_SWB ? 19 : 21;
+      fs->CC = CC; fs->C = st->stream_channels; fs->frame_size = frame_size; fs->start = 17; fs->end = endband; fs->effEnd = endband;
+      fs->complexity = L->cfg.complexity; fs->lsb_depth = imin(16, L->cfg.lsb_depth); fs->disable_inv = L->cfg.disable_inv; fs->disable_pf = 0; fs->force_intra = 0; fs->loss_rate = L->cfg.packet_loss_perc;
+      fs->vbr = L->cfg.use_vbr; fs->constrained_vbr = 0;
+      fs->bitrate = -1;
+      if (L->cfg.use_vbr) { const i32 cb = sh->bitrate_bps - sh->silk_bitRate; if (cb > 500) fs->bitrate = imin(cb, 750000 * CC); }     /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
+      fs->curr_bandwidth = curr_bandwidth; fs->max_data_bytes = sh->max_data_bytes; fs->orig_max_data_bytes = sh->orig_max_data_bytes; fs->pad_to = sh->pad_to;
+      fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0;
+      fs->toc = sh_gen_toc(OA_MODE_HYBRID, Fs / frame_size, curr_bandwidth, st->stream_channels);
+      fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
+      fs->do_stereo_fade = sh->r[0]; fs->fade_g1 = sh->r[1]; fs->fade_g2 = sh->r[2];
+   }
+   /* ---- CELT input: [delay tail | new frame], then the delay line moves on (:1950, :2340-2353) ---- */
+   const int total_buffer = Fs / 250, encoder_buffer = Fs / 100;
+   {
+      WV_LDS i16 *io = F->A.pcm16;
+      FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
+      wv_sync();
+      FOR_LANES(i, encoder_buffer * CC) gs->delay_buffer[i] = pcm_hp[(frame_size - encoder_buffer) * CC + i];
+      const i16 g1 = (i16)st->prev_HB_gain, g2 = (i16)sh->HB_gain;
+      if (g1 < Q15ONE || g2 < Q15ONE) {                                               /* gain_fade (:581) */
+         FOR_LANES(i, frame_size * CC) {
+            const int n = i / CC; i16 g = g2;
+            if (n < OA_OVERLAP) { i16 w = ct_window[n]; w = (i16)mult16_16_q15(w, w); g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15); }
+            io[i] = (i16)mult16_16_q15(g, io[i]);
+         }
+      }
+      wv_sync();
+      LANE0 st->prev_HB_gain = sh->HB_gain;
+      if (fs->do_stereo_fade) { stereo_fade_lanes(F, frame_size); wv_sync(); }
+      const int overlap = OA_OVERLAP;
+      i32 a = 0, b = 0;
+      FOR_LANES(i, CC * (frame_size - overlap)) a = imax(a, iabs((i32)io[i]));
+      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)io[CC * (frame_size - overlap) + i]));
+      a = wv_max(a); b = wv_max(b);
+      LANE0 { fs->r[0] = a; fs->r[1] = b; }
+   }
+   wv_sync();
+   LANE0 celt_prologue(F, sh->nb_compr_bytes);
+#ifdef SH_DEBUG
+   LANE0 printf("hyb: toc %d pk0 %d nb_compr %d tell %d skip %d bitrate %d vbr %d C %d end %d\n", fs->toc, F->packet[0], sh->nb_compr_bytes, fs->tell, fs->skip_celt, fs->bitrate, fs->vbr, fs->C, fs->end);
+#endif
+   wv_sync();
+   if (fs->skip_celt) { LANE0 { F->packet[0] = (u8)fs->toc; F->packet[1] = 0; F->st.rangeFinal = 0; fs->ret = 2; } wv_sync(); }
+   else celt_encode_core<true>(F, &gs->celt, out);
+   wv_sync();
+#ifdef SH_DEBUG
+   LANE0 printf("hyb end: toc %d pk0 %d ret %d rng %u\n", fs->toc, F->packet[0], fs->ret, F->st.rangeFinal);
+#endif
+   {
+      const int nbytes = emit_packet_wave(F, out, fs->ret, fs->pad_to, out_cap);
+      LANE0 { *len_out = nbytes; *rng_out = F->st.rangeFinal; st->rangeFinal = F->st.rangeFinal; }
+      wv_sync();
+      i32 *g = (i32 *)&gs->celt.s; const WV_LDS i32 *d = (const WV_LDS i32 *)&F->st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
+      g = (i32 *)&gs->s; d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
+   }
+}
+
 WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
@@ -276,7 +377,14 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
    {
       const int mode = st->mode, curr_bandwidth = sh->curr_bandwidth, frame_rate = Fs / frame_size;
       sc.nChannelsAPI = CC; sc.nChannelsInternal = st->stream_channels; sc.API_sampleRate = Fs;
-      sc.bitRate = bits_to_bitrate(sh->bits_target, Fs, frame_size);
+      const i32 total_bitRate = bits_to_bitrate(sh->bits_target, Fs, frame_size);
+      sc.bitRate = total_bitRate;
+      sh->HB_gain = Q15ONE;
+      if (mode == OA_MODE_HYBRID) {                                                  /* :2034-2046 */
+         sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, 0, st->stream_channels);
+         sh->HB_gain = Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1);        /* celt_exp2 takes an opus_val16: the rate difference is truncated as in the reference */
+      }
+      sh->silk_bitRate = sc.bitRate;
       sc.payloadSize_ms = 1000 * frame_size / Fs;
       sc.desiredInternalSampleRate = curr_bandwidth == OA_BW_NB ? 8000 : curr_bandwidth == OA_BW_MB ? 12000 : 16000;
       sc.minInternalSampleRate = mode == OA_MODE_HYBRID ? 16000 : 8000;
@@ -290,6 +398,10 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = 0; sc.useDTX = 0;
       sc.useCBR = !L->cfg.use_vbr;
       sc.maxBits = (sh->max_data_bytes - 1) * 8;
+      if (mode == OA_MODE_HYBRID) {                                                  /* :2136-2160 */
+         if (sc.useCBR) { const i16 other_bits = (i16)imax(0, sc.maxBits - sc.bitRate * frame_size / Fs); sc.maxBits = imax(0, sc.maxBits - other_bits * 3 / 4); sc.useCBR = 0; }
+         else { const i32 maxBitRate = sh_silk_rate_for_hybrid(sc.maxBits * Fs / frame_size, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, 0, st->stream_channels); sc.maxBits = bitrate_to_bits(maxBitRate, Fs, frame_size); }
+      }
       sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = 0;
       sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
    }
@@ -301,7 +413,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
    /* ---- finalise (:2190-2560) ---- */
    LANE0 {
       int curr_bandwidth = sh->curr_bandwidth;
-      if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB;
+      if (st->mode == OA_MODE_SILK_ONLY) { if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB; }
       st->sm_allowBandwidthSwitch = sc.allowBandwidthSwitch; st->sm_inWBmodeWithoutVariableLP = sc.inWBmodeWithoutVariableLP; st->sm_switchReady = sc.switchReady;
       st->sm_opusCanSwitch = sc.switchReady;                                          /* (!nonfinal_frame: single-packet calls only) */
       const int nBytes = L->S.r[0];
@@ -313,9 +425,26 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
             st->silk_bw_switch = L->cfg.application != OA_APP_RESTRICTED_SILK;
          }
          /* stereo width bookkeeping (:2365-2400; the fade itself only touches the CELT input) */
-         if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
-         else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
-         if (CC == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
+         st->sm_stereoWidth_Q14 = sc.stereoWidth_Q14;
+         if (st->mode != OA_MODE_HYBRID || st->stream_channels == 1) {
+            if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
+            else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
+         }
+         sh->r[0] = 0;
+         if (CC == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) {
+            i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)st->sm_stereoWidth_Q14;
+            sh->r[0] = 1; sh->r[1] = g1 == 16384 ? Q15ONE : shl16(g1, 1); sh->r[2] = g2 == 16384 ? Q15ONE : shl16(g2, 1);
+            st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
+         }
+         if (st->mode == OA_MODE_HYBRID) {                                            /* :2402-2450: the redundancy flag, then the CELT layer takes the coder over */
+            EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+            if (k_ec_tell(EC_PASS) + 17 + 20 <= 8 * (sh->max_data_bytes - 1)) k_ec_enc_bit_logp(EC_PASS, 0, 12);
+            sh->nb_compr_bytes = sh->max_data_bytes - 1;
+            k_ec_enc_shrink(EC_PASS, (u32)sh->nb_compr_bytes);
+            ec_st(&L->ec, e);
+            sh->curr_bandwidth = curr_bandwidth; sh->silk_signalType = sc.signalType; sh->silk_offset = sc.offset;
+            sh->ret = -1000;                                                          /* continue in sh_hybrid_celt_wave */
+         } else {
          EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
          const int tell = k_ec_tell(EC_PASS);
          ret = (tell + 7) >> 3;
@@ -326,10 +455,13 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
             if (sh->max_data_bytes < 2) ret = OA_ERR_BUFFER_TOO_SMALL; else { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
          } else while (ret > 2 && L->packet[ret] == 0) ret--;                         /* trailing zeros are implied in SILK-only packets (:2540) */
          if (ret >= 0) ret += 1;
+         sh->ret = ret;
+         }
       }
+      if (nBytes == 0) sh->ret = ret;
       st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
-      sh->ret = ret;
    }
+   if (sh->ret == -1000) { sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); return; }
    /* ---- store packet + state (coalesced) ---- */
    {
       const int nbytes = sh->ret < 0 ? sh->ret : sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);

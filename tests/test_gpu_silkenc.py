@@ -74,6 +74,22 @@ def test_gpu_silk_complexities(cx): check(4, 25, force_mode=1000, bitrate=20000,
 ])
 def test_gpu_silk_matrix(Fs, ch, app, ms, ctl): check(4, 25 if ms <= 20 else 10, Fs=Fs, ch=ch, app=app, ms=ms, **ctl)
 
+@pytest.mark.parametrize("Fs,ch,app,ms,ctl", [
+    (48000, 2, 2049, 20, dict(force_mode=1001, bandwidth=1105, bitrate=128000, complexity=10)),   # BASELINE config 4: hybrid audio 48 kHz stereo 20 ms VBR 128 kb/s
+    (48000, 1, 2049, 20, dict(force_mode=1001, bandwidth=1105, bitrate=48000)),
+    (48000, 1, 2048, 20, dict(force_mode=1001, bandwidth=1104, bitrate=32000)),                   # super-wideband
+    (48000, 2, 2049, 20, dict(force_mode=1001, bandwidth=1105, bitrate=64000, vbr=0)),            # hybrid CBR
+    (48000, 1, 2049, 10, dict(force_mode=1001, bandwidth=1105, bitrate=40000)),
+    (48000, 2, 2049, 20, dict(force_mode=1001, bandwidth=1104, bitrate=24000)),
+    (48000, 1, 2048, 20, dict(bitrate=28000)),                                                    # hybrid by the encoder's own mode / bandwidth decision
+    (48000, 2, 2049, 20, dict(force_mode=1001, bandwidth=1105, bitrate=96000, complexity=3)),
+])
+def test_gpu_hybrid_matrix(Fs, ch, app, ms, ctl): check(4, 25, Fs=Fs, ch=ch, app=app, ms=ms, **ctl)
+
+def test_gpu_config4_hybrid_long():
+    """BASELINE config 4 shape over 60 frame-steps, 16 streams"""
+    check(16, 60, Fs=48000, ch=2, app=2049, force_mode=1001, bandwidth=1105, bitrate=128000, complexity=10)
+
 def test_gpu_silk_small_buffer():
     """max_data_bytes below the VBR demand: the rate-control loop (gain search, pulses cleared as a last resort) must take the reference's path"""
     check(4, 25, max_bytes=40, force_mode=1000, bitrate=32000)
@@ -81,7 +97,7 @@ def test_gpu_silk_small_buffer():
 
 def test_gpu_silk_unbuilt_paths_fail_loudly():
     import opus_amd as oa
-    b = oa.EncoderBatch(2, channels=1, application=2049, Fs=48000)              # AUDIO 48 kHz fullband at the default rate decides CELT-only / hybrid: not built
+    b = oa.EncoderBatch(2, channels=1, application=2049, Fs=48000)              # AUDIO 48 kHz at the default rate decides CELT-only inside the SILK-capable kernel: not built
     pk, lens, rng = b.encode(np.zeros((2, 960), np.int16) + 100, 960)
     assert all(int(l) == oa.OPUS_UNIMPLEMENTED for l in lens)
     b.close()
