@@ -171,7 +171,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    wv_sync();
    K_PHASE(9);
 #ifdef K_DUMP_ENABLED
-   LANE0 {   /* same words as oracle/ref_expose/x_opus_enc_tap.c tap_coarse */
+   LANE0 {   /* same words as the tapped reference shim of the tests */
       i32 w[12 + 84]; int n = 0;
       w[n++] = start; w[n++] = end; w[n++] = C; w[n++] = LM; w[n++] = sh->total_bits; w[n++] = sh->nbAvailableBytes; w[n++] = sh->force_intra; w[n++] = st->delayedIntra; w[n++] = sh->complexity >= 4;
       w[n++] = L->ec.nbits_total - ec_ilog(L->ec.rng); w[n++] = (i32)L->ec.rng; w[n++] = 0;

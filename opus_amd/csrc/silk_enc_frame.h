@@ -296,7 +296,7 @@ WV_DEV void se_stereo_lr_to_ms_l0(WV_LDS OaSilkEncStereo *state, WV_LDS i16 *x1,
    state->pred_prev_Q13[0] = (i16)pred_Q13[0]; state->pred_prev_Q13[1] = (i16)pred_Q13[1]; state->width_prev_Q14 = (i16)width_Q14;
 }
 
-/* ---- stage taps of the emulator build (same word layout as oracle/ref_expose/x_silk_enc.c) ---- */
+/* ---- stage taps of the emulator build (same word layout as the tapped reference shim of the tests) ---- */
 #ifdef K_DUMP_ENABLED
 WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
 {

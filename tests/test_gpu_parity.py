@@ -85,7 +85,7 @@ def test_gpu_classic_api_and_state_contract():
         pcm = np.ascontiguousarray(sig[i * 960:(i + 1) * 960])
         a = o.encode(pcm, 960); p = e.encode(pcm, 960)
         assert a[0] == p and a[2] == e.final_range()
-    with pytest.raises(oa.OpusError): oa.OpusEncoder(48000, 2, oa.OPUS_APPLICATION_AUDIO)        # OPUS_UNIMPLEMENTED this round
+    assert oa.OpusEncoder(48000, 2, oa.OPUS_APPLICATION_AUDIO) is not None                       # the SILK-capable encoder (tests/test_gpu_silkenc.py)
     with pytest.raises(oa.OpusError): oa.OpusEncoder(44100, 2, oa.OPUS_APPLICATION_RESTRICTED_LOWDELAY)  # OPUS_BAD_ARG like the reference
     with pytest.raises(oa.OpusError): e.ctl(oa.OPUS_SET_COMPLEXITY_REQUEST, 11)
     # state migrates between batch slots through a flat blob

@@ -21,14 +21,14 @@ def speech(fs, secs, ch, seed):
 
 class RefOpusEnc:
     def __init__(self, Fs, ch, app, **ctl):
-        self.R = ref_fx(); self.R.opus_encoder_create.restype = ctypes.c_void_p
+        self.R = ref_fx(); self.R.opus_encoder_create.restype = ctypes.c_void_p; self.R.opus_encoder_ctl.argtypes = None; self.R.opus_encode.argtypes = None; R.opus_encoder_ctl.argtypes = None; R.opus_encode.argtypes = None   # (other tests set prototypes on the shared handle)
         err = ctypes.c_int(0)
         self.enc = ctypes.c_void_p(self.R.opus_encoder_create(Fs, ch, app, ctypes.byref(err))); assert err.value == 0
         for k, v in ctl.items(): assert self.R.opus_encoder_ctl(self.enc, REQ[k], ctypes.c_int(v)) == 0
     def encode(self, x, n, max_bytes=1276):
         o = np.zeros(1500, np.uint8)
         l = self.R.opus_encode(self.enc, x.ctypes.data_as(ctypes.c_void_p), n, o.ctypes.data_as(ctypes.c_void_p), max_bytes)
-        r = ctypes.c_uint32(0); self.R.opus_encoder_ctl(self.enc, 4031, ctypes.byref(r))
+        self.R.opus_encoder_ctl.argtypes = None; self.R.opus_encode.argtypes = None; r = ctypes.c_uint32(0); self.R.opus_encoder_ctl(self.enc, 4031, ctypes.byref(r))
         return bytes(o[:max(l, 0)]), l, r.value
     def __del__(self):
         try: self.R.opus_encoder_destroy(self.enc)
