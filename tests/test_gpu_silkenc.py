@@ -21,7 +21,7 @@ def speech(fs, secs, ch, seed):
 
 class RefOpusEnc:
     def __init__(self, Fs, ch, app, **ctl):
-        self.R = ref_fx(); self.R.opus_encoder_create.restype = ctypes.c_void_p; self.R.opus_encoder_ctl.argtypes = None; self.R.opus_encode.argtypes = None; R.opus_encoder_ctl.argtypes = None; R.opus_encode.argtypes = None   # (other tests set prototypes on the shared handle)
+        self.R = ref_fx(); self.R.opus_encoder_create.restype = ctypes.c_void_p; self.R.opus_encoder_ctl.argtypes = None; self.R.opus_encode.argtypes = None   # (other tests set prototypes on the shared handle)
         err = ctypes.c_int(0)
         self.enc = ctypes.c_void_p(self.R.opus_encoder_create(Fs, ch, app, ctypes.byref(err))); assert err.value == 0
         for k, v in ctl.items(): assert self.R.opus_encoder_ctl(self.enc, REQ[k], ctypes.c_int(v)) == 0

@@ -20,19 +20,24 @@ def main():
     ap.add_argument("--streams", type=int, default=65536); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--complexity", type=int, default=10); ap.add_argument("--bitrate", type=int, default=24000); ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--fs", type=int, default=16000); ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--mode", choices=["silk", "hybrid"], default="silk", help="hybrid = BASELINE config 4: AUDIO 48 kHz stereo, forced hybrid fullband, 128 kb/s VBR")
     a = ap.parse_args()
+    if a.mode == "hybrid": a.fs, a.channels = 48000, 2; a.bitrate = 128000 if a.bitrate == 24000 else a.bitrate
     import torch, opus_amd
     from reflib import ref_fl, ref_fx
     dev = torch.device("cuda:0")
     S, K, W, Fs, ch = a.streams, a.steps, a.warmup, a.fs, a.channels
     n = Fs // 50
     U = 256
-    base = np.stack([speech(Fs, (W + K) * n * ch, 100 + u) for u in range(U)])                       # [U, steps*n*ch]
+    app = 2049 if a.mode == "hybrid" else 2048
+    ctls = ((11002, 1001), (4008, 1105), (4002, a.bitrate), (4010, a.complexity)) if a.mode == "hybrid" else ((11002, 1000), (4008, 1103), (4002, a.bitrate), (4010, a.complexity))
+    if ch == 1: base = np.stack([speech(Fs, (W + K) * n, 100 + u) for u in range(U)])                  # [U, steps*n*ch]
+    else: base = np.stack([np.stack([speech(Fs, (W + K) * n, 100 + u), speech(Fs, (W + K) * n, 900 + u)], 1).reshape(-1) for u in range(U)])
     d_base = torch.from_numpy(base).to(dev).view(U, W + K, n * ch)
     idx = torch.arange(S, device=dev) % U
     d_pcm = d_base[idx].permute(1, 0, 2).contiguous()                                                # [step][S][n*ch]
-    b = opus_amd.EncoderBatch(S, channels=ch, application=2048, Fs=Fs)
-    for req, v in ((11002, 1000), (4008, 1103), (4002, a.bitrate), (4010, a.complexity)): b.ctl(req, v)
+    b = opus_amd.EncoderBatch(S, channels=ch, application=app, Fs=Fs)
+    for req, v in ctls: b.ctl(req, v)
     d_out = torch.zeros((S, 1280), dtype=torch.uint8, device=dev); d_len = torch.zeros(S, dtype=torch.int32, device=dev); d_rng = torch.zeros(S, dtype=torch.int32, device=dev)
     step_elems = S * n * ch
     b.time_encode_dev(d_pcm.data_ptr(), n, d_out.data_ptr(), 1280, d_len.data_ptr(), d_rng.data_ptr(), W)
@@ -41,9 +46,10 @@ def main():
     lens = d_len.cpu().numpy(); rng = d_rng.cpu().numpy().view(np.uint32); out = d_out.cpu().numpy()
     ok = bool((lens > 0).all())
     L = opus_amd.lib()
-    state_bytes = 4 * 24 + 4 * 44 + L.opusgpu_enc_sh_state_size() * 0 + 14732                          # cfg + scalars + OaSilkEnc, in and (scalars + SILK) out
-    bytes_per = n * ch * 2 + float(lens.mean()) + 8 + 2 * state_bytes
-    res = {"metric": "encoded frames/s (SILK-only, %d kHz %s, 20 ms, complexity %d)" % (Fs // 1000, "mono" if ch == 1 else "stereo", a.complexity), "kernel": "oa_sh_encode_kernel",
+    silk_state = 14732 if ch == 2 else 14732 - 7344                                                      # OaSilkEnc (mono batches move one channel)
+    state_bytes = 4 * 24 + 4 * 44 + silk_state + (10032 + 1920 if a.mode == "hybrid" else 0)            # cfg + scalars + SILK (+ CELT state and delay line), in and out
+    bytes_per = n * ch * 2 * (3 if True else 1) + float(lens.mean()) + 8 + 2 * state_bytes               # PCM in + high-passed copy out and in again + packet + state in/out
+    res = {"metric": "encoded frames/s (%s, %d kHz %s, 20 ms, complexity %d)" % ("hybrid" if a.mode == "hybrid" else "SILK-only", Fs // 1000, "mono" if ch == 1 else "stereo", a.complexity), "kernel": "oa_sh_encode_kernel",
            "streams": S, "steps": K, "warmup": W, "ms_per_step": ms, "value": S / (ms * 1e-3), "unit": "frames/s", "all_frames_ok": ok, "mean_packet_bytes": float(lens.mean()),
            "lds_bytes_per_wave": L.opusgpu_sh_kernel_lds_bytes(),
            "roofline": {"bound": "hbm", "achieved": S * bytes_per / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": S * bytes_per / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
@@ -53,8 +59,8 @@ def main():
         if R is None: continue
         R.opus_encoder_create.restype = ctypes.c_void_p
         err = ctypes.c_int(0)
-        enc = ctypes.c_void_p(R.opus_encoder_create(Fs, ch, 2048, ctypes.byref(err)))
-        for req, v in ((11002, 1000), (4008, 1103), (4002, a.bitrate), (4010, a.complexity)): R.opus_encoder_ctl(enc, req, ctypes.c_int(v))
+        enc = ctypes.c_void_p(R.opus_encoder_create(Fs, ch, app, ctypes.byref(err)))
+        for req, v in ctls: R.opus_encoder_ctl(enc, req, ctypes.c_int(v))
         o = np.zeros(1500, np.uint8)
         if name == "fx":
             last = None
