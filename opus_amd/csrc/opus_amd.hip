@@ -201,6 +201,7 @@ static int sh_ctl_get(const OaShStream *st, int request, opus_int32 *value)
 static int sh_frame_size_code(opus_int32 Fs, int frame_size)
 {
    if (frame_size == Fs / 100 || frame_size == Fs / 50 || frame_size == Fs / 25 || frame_size == 3 * Fs / 50) return OPUS_OK;
+   if ((frame_size == Fs / 400 || frame_size == Fs / 200) && Fs == 48000) return OPUS_OK;                /* CELT-only frames */
    if (frame_size == Fs / 400 || frame_size == Fs / 200 || frame_size == 4 * Fs / 50 || frame_size == 5 * Fs / 50 || frame_size == 6 * Fs / 50) return OPUS_UNIMPLEMENTED;
    return OPUS_BAD_ARG;
 }

@@ -24,7 +24,7 @@
 struct ShShared {
    i32 frame_size, max_data_bytes, orig_max_data_bytes, pad_to, plc_frame, ret, err, toc, is_silence, sample_max;
    i32 bitrate_bps, equiv_rate, curr_bandwidth, activity, cutoff_Hz, use_hp_cutoff, bits_target, nBytes, silk_ret;
-   i32 silk_bitRate, HB_gain, nb_compr_bytes, silk_signalType, silk_offset;
+   i32 silk_bitRate, HB_gain, nb_compr_bytes, silk_signalType, silk_offset, stereo_width;
    i32 r[8];
 };
 struct ShLds {
@@ -59,6 +59,39 @@ WV_DEV u8 sh_gen_toc(int mode, int framerate, int bandwidth, int channels)      
    else if (mode == OA_MODE_CELT_ONLY) { int tmp = bandwidth - OA_BW_MB; if (tmp < 0) tmp = 0; toc = (u8)(0x80 | (tmp << 5) | (period << 3)); }
    else toc = (u8)(0x60 | ((bandwidth - OA_BW_SWB) << 4) | ((period - 2) << 3));
    return (u8)(toc | ((channels == 2) << 2));
+}
+
+/* compute_stereo_width (src/opus_encoder.c:854): inter-channel correlation / loudness-difference tracker on the raw input; the three energy sums are plain
+ * int32 sums of per-group terms (order-free) and are reduced over the wave, the smoothing recursion runs on lane 0.  Result in sh->stereo_width. */
+WV_DEV void sh_compute_stereo_width_wave(WV_LDS ShLds *L, const i16 *pcm, int frame_size)
+{
+   WV_LDS OaShScalars *st = &L->st;
+   const int shift = celt_ilog2(frame_size) - 2;
+   i32 xx = 0, xy = 0, yy = 0;
+   FOR_LANES(g, frame_size / 4) {
+      i32 pxx = 0, pxy = 0, pyy = 0;
+      for (int k = 0; k < 4; k++) { const i32 x = pcm[2 * (4 * g + k)], y = pcm[2 * (4 * g + k) + 1]; pxx += mult16_16(x, x) >> 2; pxy += mult16_16(x, y) >> 2; pyy += mult16_16(y, y) >> 2; }
+      xx += pxx >> shift; xy += pxy >> shift; yy += pyy >> shift;
+   }
+   xx = wv_sum(xx); xy = wv_sum(xy); yy = wv_sum(yy);
+   LANE0 {
+      const int frame_rate = L->cfg.Fs / frame_size;
+      const i16 short_alpha = (i16)(mult16_16(25, Q15ONE) / imax(50, frame_rate));
+      st->wm_XX += mult16_32_q15(short_alpha, xx - st->wm_XX);
+      st->wm_XY = mult16_32_q15(Q15ONE - short_alpha, st->wm_XY) + mult16_32_q15(short_alpha, xy);
+      st->wm_YY += mult16_32_q15(short_alpha, yy - st->wm_YY);
+      st->wm_XX = imax(0, st->wm_XX); st->wm_XY = imax(0, st->wm_XY); st->wm_YY = imax(0, st->wm_YY);
+      if (imax(st->wm_XX, st->wm_YY) > QC16(8e-4f, 18)) {
+         const i16 sqrt_xx = (i16)fx_sqrt(st->wm_XX), sqrt_yy = (i16)fx_sqrt(st->wm_YY), qrrt_xx = (i16)fx_sqrt(sqrt_xx), qrrt_yy = (i16)fx_sqrt(sqrt_yy);
+         st->wm_XY = imin(st->wm_XY, sqrt_xx * sqrt_yy);
+         const i16 corr = (i16)(fx_frac_div32(st->wm_XY, EPSILON + mult16_16(sqrt_xx, sqrt_yy)) >> 16);
+         const i16 ldiff = (i16)(mult16_16(Q15ONE, iabs((i16)(qrrt_xx - qrrt_yy))) / (EPSILON + qrrt_xx + qrrt_yy));
+         const i16 width = (i16)mult16_16_q15(imin(Q15ONE, fx_sqrt(QC32(1.f, 30) - mult16_16(corr, corr))), ldiff);
+         st->wm_smoothed_width = (i16)(st->wm_smoothed_width + (width - st->wm_smoothed_width) / frame_rate);
+         st->wm_max_follower = (i16)imax(st->wm_max_follower - QC16(.02f, 15) / frame_rate, st->wm_smoothed_width);
+      }
+      L->sh.stereo_width = (i16)imin(Q15ONE, mult16_16(20, st->wm_max_follower));
+   }
 }
 
 /* lane 0: opus_encode_native's decisions (:1310-1700) */
@@ -114,8 +147,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    /* mode (:1487-1560) */
    if (cfg->application == OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_SILK_ONLY;
    else if (cfg->user_forced_mode == OA_AUTO) {
-      if (channels == 2 && cfg->force_channels != 1) { sh->err = OA_ERR_UNIMPLEMENTED; return; }  /* needs compute_stereo_width (next round) */
-      const i32 stereo_width = 0;
+      const i32 stereo_width = sh->stereo_width;
       const i32 mode_voice = (i32)(mult16_32_q15(Q15ONE - stereo_width, 64000) + mult16_32_q15(stereo_width, 44000));
       const i32 mode_music = (i32)(mult16_32_q15(Q15ONE - stereo_width, 10000) + mult16_32_q15(stereo_width, 10000));
       i32 threshold = mode_music + ((voice_est * voice_est * (mode_voice - mode_music)) >> 14);
@@ -125,11 +157,13 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       if (max_data_bytes < bitrate_to_bits(frame_rate > 50 ? 9000 : 6000, Fs, frame_size) / 8) st->mode = OA_MODE_CELT_ONLY;
    } else st->mode = cfg->user_forced_mode;
    if (st->mode != OA_MODE_CELT_ONLY && frame_size < Fs / 100) st->mode = OA_MODE_CELT_ONLY;
-   if (st->mode == OA_MODE_CELT_ONLY || st->prev_mode == OA_MODE_CELT_ONLY) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
+   /* a SILK/hybrid <-> CELT-only switch needs a redundant CELT frame and a SILK prefill (:1568-1590, :2478-2590): not built; CELT below 48 kHz neither */
+   if ((st->mode == OA_MODE_CELT_ONLY) != (st->prev_mode == OA_MODE_CELT_ONLY) && st->prev_mode > 0) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
+   if (st->mode == OA_MODE_CELT_ONLY && (Fs != 48000 || frame_size > Fs / 50)) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
    if (st->stream_channels == 1 && st->prev_channels == 2 && st->sm_toMono == 0) { st->sm_toMono = 1; st->stream_channels = 2; } else st->sm_toMono = 0;
    equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, st->mode, cfg->complexity, loss);
    /* bandwidth (:1600-1700) */
-   if (st->first || st->sm_allowBandwidthSwitch) {
+   if (st->mode == OA_MODE_CELT_ONLY || st->first || st->sm_allowBandwidthSwitch) {
       const i32 voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000}, music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};
       int bandwidth = OA_BW_FB;
       do {
@@ -141,17 +175,18 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       } while (--bandwidth > OA_BW_NB);
       if (bandwidth == OA_BW_MB) bandwidth = OA_BW_WB;
       st->bandwidth = st->auto_bandwidth = bandwidth;
-      if (!st->first && !st->sm_inWBmodeWithoutVariableLP && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
+      if (!st->first && st->mode != OA_MODE_CELT_ONLY && !st->sm_inWBmodeWithoutVariableLP && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
    }
    if (st->bandwidth > cfg->max_bandwidth) st->bandwidth = cfg->max_bandwidth;
    if (cfg->user_bandwidth != OA_AUTO) st->bandwidth = cfg->user_bandwidth;
-   if (max_rate < 15000) st->bandwidth = imin(st->bandwidth, OA_BW_WB);
+   if (st->mode != OA_MODE_CELT_ONLY && max_rate < 15000) st->bandwidth = imin(st->bandwidth, OA_BW_WB);
    if (Fs <= 24000 && st->bandwidth > OA_BW_SWB) st->bandwidth = OA_BW_SWB;
    if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
    if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
    if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
    if (cfg->use_inband_fec && loss > 0) { sh->err = OA_ERR_UNIMPLEMENTED; return; }               /* decide_fec :739 -> LBRR */
    st->sm_LBRR_coded = 0;
+   if (st->mode == OA_MODE_CELT_ONLY && st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
    int curr_bandwidth = st->bandwidth;
    if (cfg->application == OA_APP_RESTRICTED_SILK && curr_bandwidth > OA_BW_WB) st->bandwidth = curr_bandwidth = OA_BW_WB;
    if (st->mode == OA_MODE_SILK_ONLY && curr_bandwidth > OA_BW_WB) st->mode = OA_MODE_HYBRID;
@@ -164,7 +199,8 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    /* opus_encode_frame_native prologue */
    sh->activity = sh->is_silence ? 0 : SE_VAD_NO_DECISION;
    sh->bits_target = imin(8 * sh->max_data_bytes, bitrate_to_bits(bitrate_bps, Fs, frame_size)) - 8;
-   st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, L->S.st.ch[0].variable_HP_smth1_Q15 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
+   const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
+   st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
    sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
    sh->use_hp_cutoff = cfg->application == OA_APP_VOIP;
 }
@@ -236,14 +272,33 @@ WV_DEV i32 sh_silk_rate_for_hybrid(i32 rate, int bandwidth, int frame20ms, int v
    return silk_rate;
 }
 
+/* stereo-width decision and the fade gains of the CELT input (:2365-2400), then the per-call bookkeeping (:2596-2600); silk_width = the width SILK reported */
+WV_DEV void sh_width_and_bookkeeping_l0(WV_LDS ShLds *L, int frame_size, i32 silk_width)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   st->sm_stereoWidth_Q14 = silk_width;
+   if (st->mode != OA_MODE_HYBRID || st->stream_channels == 1) {
+      if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
+      else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
+   }
+   sh->r[0] = 0;
+   if (L->cfg.channels == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) {
+      i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)st->sm_stereoWidth_Q14;
+      sh->r[0] = 1; sh->r[1] = g1 == 16384 ? Q15ONE : shl16(g1, 1); sh->r[2] = g2 == 16384 ? Q15ONE : shl16(g2, 1);
+      st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
+   }
+   st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
+}
+
 /* The CELT layer of a hybrid frame (src/opus_encoder.c:2452-2600): bands 17.. on the coder the SILK layer leaves behind.  The SILK state has served its
  * purpose: it goes back to HBM and the CELT encoder's LDS working set takes its place.  CELT input = the delay-compensated high-passed signal
  * (delay_buffer tail + this call's frame), faded towards the high-band gain and the stereo width decided above. */
 WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm_hp, int frame_size, u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
 {
+   const int hyb = L->st.mode == OA_MODE_HYBRID;                                       /* else CELT-only inside an AUDIO / VOIP encoder (:2452-2560 with start band 0) */
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
-   {  /* SILK state and Opus-layer scalars back to HBM (coalesced) */
+   if (hyb) {  /* SILK state back to HBM (coalesced); a CELT-only frame leaves it untouched */
       i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
       FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
    }
@@ -257,16 +312,16 @@ WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm
       FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i];
    }
    LANE0 {
-      ec_cp_lds(&F->ec, &L->ec);
-      const int curr_bandwidth = sh->curr_bandwidth, endband = curr_bandwidth == OA_BW_SWB ? 19 : 21;
-      fs->CC = CC; fs->C = st->stream_channels; fs->frame_size = frame_size; fs->start = 17; fs->end = endband; fs->effEnd = endband;
+      if (hyb) ec_cp_lds(&F->ec, &L->ec);
+      const int curr_bandwidth = sh->curr_bandwidth, endband = curr_bandwidth == OA_BW_NB ? 13 : curr_bandwidth <= OA_BW_WB ? 17 : curr_bandwidth == OA_BW_SWB ? 19 : 21;
+      fs->CC = CC; fs->C = st->stream_channels; fs->frame_size = frame_size; fs->start = hyb ? 17 : 0; fs->end = endband; fs->effEnd = endband;
       fs->complexity = L->cfg.complexity; fs->lsb_depth = imin(16, L->cfg.lsb_depth); fs->disable_inv = L->cfg.disable_inv; fs->disable_pf = 0; fs->force_intra = 0; fs->loss_rate = L->cfg.packet_loss_perc;
-      fs->vbr = L->cfg.use_vbr; fs->constrained_vbr = 0;
+      fs->vbr = L->cfg.use_vbr; fs->constrained_vbr = hyb ? 0 : L->cfg.vbr_constraint;
       fs->bitrate = -1;
-      if (L->cfg.use_vbr) { const i32 cb = sh->bitrate_bps - sh->silk_bitRate; if (cb > 500) fs->bitrate = imin(cb, 750000 * CC); }     /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
+      if (L->cfg.use_vbr) { const i32 cb = hyb ? sh->bitrate_bps - sh->silk_bitRate : sh->bitrate_bps; if (cb > 500) fs->bitrate = imin(cb, 750000 * CC); }     /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
       fs->curr_bandwidth = curr_bandwidth; fs->max_data_bytes = sh->max_data_bytes; fs->orig_max_data_bytes = sh->orig_max_data_bytes; fs->pad_to = sh->pad_to;
       fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0;
-      fs->toc = sh_gen_toc(OA_MODE_HYBRID, Fs / frame_size, curr_bandwidth, st->stream_channels);
+      fs->toc = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
       fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
       fs->do_stereo_fade = sh->r[0]; fs->fade_g1 = sh->r[1]; fs->fade_g2 = sh->r[2];
    }
@@ -296,13 +351,14 @@ WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm
       LANE0 { fs->r[0] = a; fs->r[1] = b; }
    }
    wv_sync();
-   LANE0 celt_prologue(F, sh->nb_compr_bytes);
+   LANE0 celt_prologue(F, hyb ? sh->nb_compr_bytes : 0);
 #ifdef SH_DEBUG
    LANE0 printf("hyb: toc %d pk0 %d nb_compr %d tell %d skip %d bitrate %d vbr %d C %d end %d\n", fs->toc, F->packet[0], sh->nb_compr_bytes, fs->tell, fs->skip_celt, fs->bitrate, fs->vbr, fs->C, fs->end);
 #endif
    wv_sync();
    if (fs->skip_celt) { LANE0 { F->packet[0] = (u8)fs->toc; F->packet[1] = 0; F->st.rangeFinal = 0; fs->ret = 2; } wv_sync(); }
-   else celt_encode_core<true>(F, &gs->celt, out);
+   else if (hyb) celt_encode_core<true>(F, &gs->celt, out);
+   else celt_encode_core<false>(F, &gs->celt, out);
    wv_sync();
 #ifdef SH_DEBUG
    LANE0 printf("hyb end: toc %d pk0 %d ret %d rng %u\n", fs->toc, F->packet[0], fs->ret, F->st.rangeFinal);
@@ -340,6 +396,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       m = wv_max(m);
       LANE0 { sh->sample_max = m; sh->is_silence = m == 0; }
    }
+   if (CC == 2 && L->cfg.force_channels != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
    LANE0 sh_layer_decide(L, frame_size, max_data_bytes);
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
@@ -372,6 +429,11 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       wv_sync();
    }
    SE_PHASE(&L->S, 1);
+   if (st->mode == OA_MODE_CELT_ONLY) {
+      LANE0 { sh->HB_gain = Q15ONE; sh_width_and_bookkeeping_l0(L, frame_size, 0); }
+      sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out);
+      return;
+   }
    /* ---- SILK (:2024-2200) ---- */
    SeControl sc;
    {
@@ -424,18 +486,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
             if (L->cfg.application != OA_APP_RESTRICTED_SILK) st->error = OA_ERR_UNIMPLEMENTED;          /* the next frame would need a redundant CELT frame */
             st->silk_bw_switch = L->cfg.application != OA_APP_RESTRICTED_SILK;
          }
-         /* stereo width bookkeeping (:2365-2400; the fade itself only touches the CELT input) */
-         st->sm_stereoWidth_Q14 = sc.stereoWidth_Q14;
-         if (st->mode != OA_MODE_HYBRID || st->stream_channels == 1) {
-            if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
-            else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
-         }
-         sh->r[0] = 0;
-         if (CC == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) {
-            i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)st->sm_stereoWidth_Q14;
-            sh->r[0] = 1; sh->r[1] = g1 == 16384 ? Q15ONE : shl16(g1, 1); sh->r[2] = g2 == 16384 ? Q15ONE : shl16(g2, 1);
-            st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
-         }
+         sh_width_and_bookkeeping_l0(L, frame_size, sc.stereoWidth_Q14);
          if (st->mode == OA_MODE_HYBRID) {                                            /* :2402-2450: the redundancy flag, then the CELT layer takes the coder over */
             EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
             if (k_ec_tell(EC_PASS) + 17 + 20 <= 8 * (sh->max_data_bytes - 1)) k_ec_enc_bit_logp(EC_PASS, 0, 12);
@@ -458,8 +509,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
          sh->ret = ret;
          }
       }
-      if (nBytes == 0) sh->ret = ret;
-      st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
+      if (nBytes == 0) { sh->ret = ret; st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0; }
    }
    if (sh->ret == -1000) { sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); return; }
    /* ---- store packet + state (coalesced) ---- */

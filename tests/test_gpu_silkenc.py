@@ -39,7 +39,7 @@ def check(S, frames, Fs=16000, ch=1, app=2048, ms=20, max_bytes=1276, **ctl):
     b = oa.EncoderBatch(S, channels=ch, application=app, Fs=Fs)
     for k, v in ctl.items(): b.ctl(REQ[k], v)
     refs = [RefOpusEnc(Fs, ch, app, **ctl) for _ in range(S)]
-    n = Fs * ms // 1000
+    n = int(Fs * ms) // 1000
     sigs = [speech(Fs, frames * ms / 1000 + 0.1, ch, 10 + s) for s in range(S)]
     for f in range(frames):
         pcm = np.stack([np.ascontiguousarray(sigs[s][f * n:(f + 1) * n]).reshape(-1) for s in range(S)])
@@ -95,11 +95,28 @@ def test_gpu_silk_small_buffer():
     check(4, 25, max_bytes=40, force_mode=1000, bitrate=32000)
     check(2, 15, max_bytes=25, force_mode=1000, bitrate=24000)
 
+@pytest.mark.parametrize("Fs,ch,app,ms,ctl", [
+    (48000, 1, 2049, 20, dict()),                                                                 # AUDIO default: CELT-only by the encoder's own decision
+    (48000, 2, 2049, 20, dict()),                                                                 # stereo, automatic mode (compute_stereo_width)
+    (48000, 2, 2049, 20, dict(force_mode=1002, bitrate=96000, complexity=10)),
+    (48000, 1, 2048, 10, dict(force_mode=1002, bitrate=32000)),
+    (48000, 2, 2049, 5, dict(bitrate=96000)), (48000, 1, 2049, 2.5, dict(bitrate=64000)),
+    (48000, 2, 2048, 20, dict(bitrate=40000)), (16000, 2, 2048, 20, dict(bitrate=24000)),
+])
+def test_gpu_celt_only_and_auto_modes_in_audio_voip(Fs, ch, app, ms, ctl): check(4, 25, Fs=Fs, ch=ch, app=app, ms=ms, **ctl)
+
 def test_gpu_silk_unbuilt_paths_fail_loudly():
     import opus_amd as oa
-    b = oa.EncoderBatch(2, channels=1, application=2049, Fs=48000)              # AUDIO 48 kHz at the default rate decides CELT-only inside the SILK-capable kernel: not built
-    pk, lens, rng = b.encode(np.zeros((2, 960), np.int16) + 100, 960)
+    b = oa.EncoderBatch(2, channels=1, application=2049, Fs=24000)              # CELT below 48 kHz is not built: AUDIO 24 kHz at the default rate decides CELT-only
+    pk, lens, rng = b.encode(np.zeros((2, 480), np.int16) + 100, 480)
     assert all(int(l) == oa.OPUS_UNIMPLEMENTED for l in lens)
+    b.close()
+    b = oa.EncoderBatch(1, channels=1, application=2048, Fs=48000)              # a SILK -> CELT-only switch mid-stream needs the redundancy frame: not built
+    b.ctl(11002, 1000); b.ctl(4002, 20000)
+    x = (np.random.default_rng(1).normal(0, 3000, (1, 960))).astype(np.int16)
+    pk, lens, rng = b.encode(x, 960); assert int(lens[0]) > 0
+    b.ctl(11002, 1002)
+    pk, lens, rng = b.encode(x, 960); assert int(lens[0]) == oa.OPUS_UNIMPLEMENTED
     b.close()
     with pytest.raises(oa.OpusError): oa.EncoderBatch(1, channels=1, application=2048, Fs=44100)
 

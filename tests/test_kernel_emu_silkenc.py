@@ -51,7 +51,7 @@ def run_opus(nframes, Fs=16000, ch=1, app=2048, ms=20, seed=1, max_bytes=1276, *
     st = np.zeros(E.emu_sh_stream_size() + 64, np.uint8); E.emu_sh_stream_init(P(st), Fs, ch, app)
     for k, v in kw.items():
         assert R.opus_encoder_ctl(enc, REQ[k], ctypes.c_int(v)) == 0; E.emu_sh_set_cfg(P(st), CFG.index(k), v)
-    n = Fs * ms // 1000
+    n = int(Fs * ms) // 1000
     pcm = signal(Fs, nframes * ms / 1000 + 0.1, ch, seed)
     for f in range(nframes):
         x = pcm[f * n * ch:(f + 1) * n * ch].copy()
@@ -82,3 +82,20 @@ def test_emu_opus_silk_only(kw):
     dict(Fs=48000, ch=2, app=2049, user_forced_mode=1001, user_bandwidth=1104, user_bitrate_bps=24000),
     dict(Fs=48000, ch=1, app=2048, user_bitrate_bps=28000)])
 def test_emu_opus_hybrid(kw): run_opus(12, **dict(kw))
+
+@pytest.mark.parametrize("kw", [
+    dict(Fs=48000, ch=1, app=2049),                                                                              # AUDIO default: the encoder's own decision is CELT-only
+    dict(Fs=48000, ch=2, app=2049, user_forced_mode=1002, user_bitrate_bps=96000, complexity=10),
+    dict(Fs=48000, ch=1, app=2048, ms=10, user_forced_mode=1002, user_bitrate_bps=32000),                       # VOIP: hp_cutoff in front of CELT
+    dict(Fs=48000, ch=2, app=2049, ms=5, user_bitrate_bps=96000), dict(Fs=48000, ch=1, app=2049, ms=2.5, user_bitrate_bps=64000),
+    dict(Fs=48000, ch=1, app=2049, user_forced_mode=1002, use_vbr=0, user_bitrate_bps=48000),
+    dict(Fs=48000, ch=2, app=2048, user_forced_mode=1002, user_bitrate_bps=24000)])
+def test_emu_opus_celt_only_in_audio_voip(kw):
+    """CELT-only frames of an AUDIO / VOIP encoder: delay compensation (4 ms), the application's high-pass, the same CELT core"""
+    run_opus(14, **dict(kw))
+
+@pytest.mark.parametrize("kw", [
+    dict(Fs=48000, ch=2, app=2049), dict(Fs=16000, ch=2, app=2048, user_bitrate_bps=24000), dict(Fs=48000, ch=2, app=2048, user_bitrate_bps=40000), dict(Fs=48000, ch=2, app=2049, user_bitrate_bps=36000)])
+def test_emu_opus_stereo_automatic_mode(kw):
+    """stereo input with the mode left to the encoder: compute_stereo_width feeds the SILK/CELT threshold"""
+    run_opus(30, **dict(kw))
