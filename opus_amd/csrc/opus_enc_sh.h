@@ -331,7 +331,15 @@ WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm
       WV_LDS i16 *io = F->A.pcm16;
       FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
       wv_sync();
-      FOR_LANES(i, encoder_buffer * CC) gs->delay_buffer[i] = pcm_hp[(frame_size - encoder_buffer) * CC + i];
+      /* new delay line = the last encoder_buffer samples of [old line | this frame]; ascending in place through registers, one 64-lane trip at a time */
+      for (int b0 = 0; b0 < encoder_buffer * CC; b0 += WV_WIDTH) {
+         const int i = b0 + wv_lane(), j = i + frame_size * CC;
+         i16 v = 0;
+         if (i < encoder_buffer * CC) v = j < encoder_buffer * CC ? gs->delay_buffer[j] : pcm_hp[j - encoder_buffer * CC];
+         wv_sync();
+         if (i < encoder_buffer * CC) gs->delay_buffer[i] = v;
+         wv_sync();
+      }
       const i16 g1 = (i16)st->prev_HB_gain, g2 = (i16)sh->HB_gain;
       if (g1 < Q15ONE || g2 < Q15ONE) {                                               /* gain_fade (:581) */
          FOR_LANES(i, frame_size * CC) {
