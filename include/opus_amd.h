@@ -7,9 +7,12 @@
  *    opus_encode :266, opus_encoder_destroy :354, opus_encoder_ctl :367; error codes opus_defines.h:46-60).
  *    The OpusEncoder blob is flat host memory holding the complete canonical state (memcpy-able, no device
  *    handles: opus.h:108-109); every opus_encode() runs the frame on the GPU as a batch of one.
- *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only path), Fs = 48000,
- *    one 2.5/5/10/20 ms frame per call, VBR / constrained VBR / hard CBR (with code-3 padding).  Anything else returns
- *    OPUS_UNIMPLEMENTED.
+ *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only kernel, Fs = 48000, 2.5-20 ms) and
+ *    OPUS_APPLICATION_VOIP / AUDIO / RESTRICTED_SILK (the SILK-capable kernel: SILK-only frames at Fs 8-48 kHz, 10-60 ms; hybrid and
+ *    CELT-only frames at 48 kHz; mode / bandwidth / channel decisions as the reference's opus_encode_native, src/opus_encoder.c:1310-1700,
+ *    or pinned with OPUS_SET_FORCE_MODE); VBR / constrained VBR / hard CBR (code-3 padding).  What is not built (mode switches that need a
+ *    redundancy frame, in-band FEC / DTX encode, frames above 60 ms, CELT below 48 kHz) returns OPUS_UNIMPLEMENTED -- from the encode call,
+ *    per stream, when the decision arises.
  *
  * 2. The batch API (additive): S independent streams stepped together, one wavefront per
  *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.
