@@ -462,7 +462,7 @@ struct SeEncCtrl {
 };
 
 /* ---- silk_find_pitch_lags_FIX.  res: i16[la_pitch + frame + ltp_mem]; x = x_frame - ltp_mem; Wsig: i16[384] window scratch; xx: i16[384]; w32: i32[20] ---- */
-WV_DEV void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, WV_LDS i16 *res, const WV_LDS i16 *x, WV_LDS i16 *Wsig, WV_LDS i16 *xx, WV_LDS i32 *w32,
+WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, WV_LDS i16 *res, const WV_LDS i16 *x, WV_LDS i16 *Wsig, WV_LDS i16 *xx, WV_LDS i32 *w32,
       WV_LDS i16 *A_Q12s, WV_LDS PitchLds *PL)
 {
    const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length, wl = c->pitch_LPC_win_length, la = c->la_pitch, order = c->pitchEstimationLPCOrder;

@@ -133,7 +133,7 @@ template <class PA> WV_DEV void se_limit_warped_coefs(PA coefs_Q24, int lambda_Q
 
 /* pitch_res = res_pitch_frame, x = x_frame; xw: i16[240] windowed signal, xx: i16[240], w32: i32[28] (auto-correlation, [26] = SNR hand-off) */
 /* stk: 100 words of lane-0 working arrays in LDS */
-WV_DEV void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32, WV_LDS i32 *stk)
+WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32, WV_LDS i32 *stk)
 {
    const WV_LDS i16 *x_ptr = x - c->la_shape;
    const int order = c->shapingLPCOrder, swl = c->shapeWinLength;

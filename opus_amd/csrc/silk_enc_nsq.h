@@ -10,7 +10,7 @@
 
 #define SE_DD 40
 #define SE_QLA 80                                                                   /* QUANT_LEVEL_ADJUST_Q10 */
-struct SeSurvivor { i32 sLPC_Q14[80 + 16]; i32 RandState[SE_DD], Q_Q10[SE_DD], Xq_Q14[SE_DD], Pred_Q15[SE_DD], Shape_Q14[SE_DD]; i32 sAR2_Q14[24]; i32 LF_AR_Q14, Diff_Q14, Seed, SeedInit, RD_Q10; };
+struct SeSurvivor { i32 RandState[SE_DD], Q_Q10[SE_DD], Xq_Q14[SE_DD], Pred_Q15[SE_DD], Shape_Q14[SE_DD]; i32 SeedInit, RD_Q10, pad[2]; };   /* the LDS part of a survivor: rings of undecided samples */
 struct SeCand { i32 Q_Q10, RD_Q10, xq_Q14, LF_AR_Q14, Diff_Q14, sLTP_shp_Q14, LPC_exc_Q14, pad; };
 struct SeNsqLds {
    i32 sLTP_Q15[2 * SE_MAX_FRAME];
@@ -123,7 +123,7 @@ WV_DEV void se_nsq_subframe_l0(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState
 WV_DEV i32 se_harm_packed(i32 h) { return (h >> 2) | (i32)((u32)(h >> 1) << 16); }
 
 /* indices->Seed is read (and, for delayed decision, rewritten); pulses: frame_length */
-WV_DEV void se_nsq_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState *st, WV_LDS OaSilkEncIndices *ix, WV_LDS SeNsqLds *N, const WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *x16, WV_LDS i8 *pulses)
+WV_DEVN void se_nsq_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState *st, WV_LDS OaSilkEncIndices *ix, WV_LDS SeNsqLds *N, const WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *x16, WV_LDS i8 *pulses)
 {
    const int L = c->subfr_length, mem = c->ltp_mem_length, frame = c->frame_length, P = c->predictLPCOrder, signalType = ix->signalType;
    const int offset_Q10 = se_quantization_offsets_q10[(signalType >> 1) * 2 + ix->quantOffsetType];
@@ -171,7 +171,11 @@ WV_DEV void se_dd_flush_l0(WV_LDS OaSilkNsqState *st, const WV_LDS SeSurvivor *w
       st->sLTP_shp_Q14[st->sLTP_shp_buf_idx - decisionDelay + i] = w->Shape_Q14[last];
    }
 }
-WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState *st, WV_LDS OaSilkEncIndices *ix, WV_LDS SeNsqLds *N, const WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *x16, WV_LDS i8 *pulses)
+/* Register-resident version: survivor k on lane k keeps its 16-sample LPC window, its <= 24 shaping-filter memories and both coefficient sets in VGPRs
+ * (fixed-size arrays indexed only by unrolled constants; taps beyond the order carry zero coefficients / are predicated off), so a sample costs no LDS
+ * round trip for the filters.  The five 40-deep rings of undecided samples stay in LDS.  A survivor replacement moves the 40 filter words of the better
+ * lane with v_readlane and the rings with a 64-lane copy. */
+WV_DEVN void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState *st, WV_LDS OaSilkEncIndices *ix, WV_LDS SeNsqLds *N, const WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *x16, WV_LDS i8 *pulses)
 {
    const int lane = wv_lane();
    const int L = c->subfr_length, mem = c->ltp_mem_length, frame = c->frame_length, P = c->predictLPCOrder, S = c->shapingLPCOrder, K = c->nStatesDelayedDecision, signalType = ix->signalType;
@@ -179,17 +183,21 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
    const int offset_Q10 = se_quantization_offsets_q10[(signalType >> 1) * 2 + ix->quantOffsetType];
    const int interp = ix->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
    const int Lambda_Q10 = ctl->Lambda_Q10;
+   const bool act = lane < K;
    int lag = st->lagPrev;
-   {  /* survivor init (:143-160) */
-      WV_LDS i32 *w = (WV_LDS i32 *)N->sv;
-      FOR_LANES(i, (int)(sizeof(N->sv) / 4)) w[i] = 0;
+   /* survivor state (:143-160): filters in registers, rings in LDS */
+   i32 w[16], sar[24];                                     /* w[j] = sLPC_Q14[newest - j] */
+   i32 LF_AR = st->sLF_AR_shp_Q14, Diff = st->sDiff_shp_Q14, Seed = (lane + ix->Seed) & 3, RD = 0;
+   const i32 SeedInit = Seed;
+#pragma unroll
+   for (int j = 0; j < 16; j++) w[j] = st->sLPC_Q14[15 - j];
+#pragma unroll
+   for (int j = 0; j < 24; j++) sar[j] = st->sAR2_Q14[j];
+   {
+      WV_LDS i32 *z = (WV_LDS i32 *)N->sv;
+      FOR_LANES(i, (int)(sizeof(N->sv) / 4)) z[i] = 0;
       wv_sync();
-      if (lane < K) {
-         WV_LDS SeSurvivor *s = &N->sv[lane];
-         s->Seed = (lane + ix->Seed) & 3; s->SeedInit = s->Seed; s->LF_AR_Q14 = st->sLF_AR_shp_Q14; s->Diff_Q14 = st->sDiff_shp_Q14; s->Shape_Q14[0] = st->sLTP_shp_Q14[mem - 1];
-         for (int i = 0; i < 16; i++) s->sLPC_Q14[i] = st->sLPC_Q14[i];
-         for (int i = 0; i < 24; i++) s->sAR2_Q14[i] = st->sAR2_Q14[i];
-      }
+      if (act) { N->sv[lane].Shape_Q14[0] = st->sLTP_shp_Q14[mem - 1]; N->sv[lane].SeedInit = SeedInit; }
       wv_sync();
    }
    int smpl_buf_idx = 0, decisionDelay = imin(SE_DD, L);
@@ -208,11 +216,12 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
          lag = ctl->pitchL[k];
          if ((k & (3 - (interp << 1))) == 0) {
             if (k == 2) {
-               LANE0 {
-                  const int w = se_dd_best(N->sv, K);
-                  for (int i = 0; i < K; i++) if (i != w) N->sv[i].RD_Q10 += 2147483647 >> 4;
-                  se_dd_flush_l0(st, &N->sv[w], smpl_buf_idx, decisionDelay, pls, pxq, ctl->Gains_Q16[1], 14);
-               }
+               wv_sync();
+               if (act) N->sv[lane].RD_Q10 = RD;
+               wv_sync();
+               const int wn = se_dd_best(N->sv, K);
+               if (act && lane != wn) RD += 2147483647 >> 4;
+               LANE0 se_dd_flush_l0(st, &N->sv[wn], smpl_buf_idx, decisionDelay, pls, pxq, ctl->Gains_Q16[1], 14);
                subfr = 0;
             }
             const int start = mem - lag - P - 5 / 2;
@@ -237,53 +246,67 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
             const i32 adj = sk_div32_varQ(prev_gain, gain, 16);
             FOR_LANES(j, mem) st->sLTP_shp_Q14[shp_idx - mem + j] = sk_mulww(adj, st->sLTP_shp_Q14[shp_idx - mem + j]);
             if (signalType == SE_TYPE_VOICED && !rewhite) { const int i0 = sLTP_buf_idx - lag - 5 / 2; FOR_LANES(j, sLTP_buf_idx - decisionDelay - i0) N->sLTP_Q15[i0 + j] = sk_mulww(adj, N->sLTP_Q15[i0 + j]); }
-            if (lane < K) {
-               WV_LDS SeSurvivor *s = &N->sv[lane];
-               s->LF_AR_Q14 = sk_mulww(adj, s->LF_AR_Q14); s->Diff_Q14 = sk_mulww(adj, s->Diff_Q14);
-               for (int i = 0; i < 16; i++) s->sLPC_Q14[i] = sk_mulww(adj, s->sLPC_Q14[i]);
-               for (int i = 0; i < 24; i++) s->sAR2_Q14[i] = sk_mulww(adj, s->sAR2_Q14[i]);
-               for (int i = 0; i < SE_DD; i++) { s->Pred_Q15[i] = sk_mulww(adj, s->Pred_Q15[i]); s->Shape_Q14[i] = sk_mulww(adj, s->Shape_Q14[i]); }
-            }
+            LF_AR = sk_mulww(adj, LF_AR); Diff = sk_mulww(adj, Diff);
+#pragma unroll
+            for (int j = 0; j < 16; j++) w[j] = sk_mulww(adj, w[j]);
+#pragma unroll
+            for (int j = 0; j < 24; j++) sar[j] = sk_mulww(adj, sar[j]);
+            if (act) { WV_LDS SeSurvivor *s = &N->sv[lane]; for (int i = 0; i < SE_DD; i++) { s->Pred_Q15[i] = sk_mulww(adj, s->Pred_Q15[i]); s->Shape_Q14[i] = sk_mulww(adj, s->Shape_Q14[i]); } }
             LANE0 st->prev_gain_Q16 = gain;
          }
          wv_sync();
       }
+      /* coefficient sets of the subframe in registers; zero beyond the order */
+      i32 ca[16], cs[24];
+#pragma unroll
+      for (int j = 0; j < 16; j++) ca[j] = j < P ? (i32)a_Q12[j] : 0;
+#pragma unroll
+      for (int j = 0; j < 24; j++) cs[j] = j < S ? (i32)AR_shp_Q13[j] : 0;
+      const i32 b0 = b_Q14[0], b1 = b_Q14[1], b2 = b_Q14[2], b3 = b_Q14[3], b4 = b_Q14[4];
       /* sample loop (:315-644) */
       const i32 Gain_Q10 = Gain_Q16 >> 6;
       int shp_lag = st->sLTP_shp_buf_idx - lag + 1, pred_lag = st->sLTP_buf_idx - lag + 5 / 2;
       int shp_buf_idx = st->sLTP_shp_buf_idx, ltp_buf_idx = st->sLTP_buf_idx;
       for (int i = 0; i < L; i++) {
-         if (lane < K) {
+         SeCand c0, c1;
+         c0.Q_Q10 = c0.RD_Q10 = c0.xq_Q14 = c0.LF_AR_Q14 = c0.Diff_Q14 = c0.sLTP_shp_Q14 = c0.LPC_exc_Q14 = 0; c1 = c0;
+         if (act) {
             i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
-            if (signalType == SE_TYPE_VOICED) { LTP_pred_Q14 = 2; for (int j = 0; j < 5; j++) LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - j], b_Q14[j]); LTP_pred_Q14 = shl32(LTP_pred_Q14, 1); }
+            if (signalType == SE_TYPE_VOICED) {
+               LTP_pred_Q14 = 2;
+               LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag], b0); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 1], b1); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 2], b2);
+               LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 3], b3); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 4], b4);
+               LTP_pred_Q14 = shl32(LTP_pred_Q14, 1);
+            }
             if (lag > 0) {
                n_LTP_Q14 = sk_mulwb(sk_add_sat(st->sLTP_shp_Q14[shp_lag], st->sLTP_shp_Q14[shp_lag - 2]), HarmPacked_Q14);
                n_LTP_Q14 = sk_mlawt(n_LTP_Q14, st->sLTP_shp_Q14[shp_lag - 1], HarmPacked_Q14);
                n_LTP_Q14 = LTP_pred_Q14 - shl32(n_LTP_Q14, 2);
             }
-            WV_LDS SeSurvivor *s = &N->sv[lane];
-            WV_LDS SeCand *cd = N->cand[lane];
-            const i32 Seed = sk_rand(s->Seed);
-            s->Seed = Seed;
-            const WV_LDS i32 *lpc = &s->sLPC_Q14[16 - 1 + i];
+            Seed = sk_rand(Seed);
             i32 LPC_pred_Q14 = P >> 1;
-            for (int j = 0; j < P; j++) LPC_pred_Q14 = sk_mlawb(LPC_pred_Q14, lpc[-j], a_Q12[j]);
+#pragma unroll
+            for (int j = 0; j < 16; j++) LPC_pred_Q14 = sk_mlawb(LPC_pred_Q14, w[j], ca[j]);
             LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
             i32 n_AR_Q14 = S >> 1;
             {
-               i32 in = sk_mlawb(s->Diff_Q14, s->sAR2_Q14[0], warp);
-               for (int j = 0; j < S; j++) {
-                  const i32 out = j + 1 < S ? sk_mlawb(s->sAR2_Q14[j], sub32(s->sAR2_Q14[j + 1], in), warp) : 0;
-                  s->sAR2_Q14[j] = in;
-                  n_AR_Q14 = sk_mlawb(n_AR_Q14, in, AR_shp_Q13[j]);
-                  in = out;
+               i32 in = sk_mlawb(Diff, sar[0], warp);
+#pragma unroll
+               for (int j = 0; j < 24; j++) {
+                  if (j < S) {
+                     const i32 nxt = j + 1 < 24 ? sar[j + 1 < 24 ? j + 1 : 23] : 0;
+                     const i32 out = j + 1 < S ? sk_mlawb(sar[j], sub32(nxt, in), warp) : 0;
+                     sar[j] = in;
+                     n_AR_Q14 = sk_mlawb(n_AR_Q14, in, cs[j]);
+                     in = out;
+                  }
                }
             }
             n_AR_Q14 = shl32(n_AR_Q14, 1);
-            n_AR_Q14 = sk_mlawb(n_AR_Q14, s->LF_AR_Q14, Tilt_Q14);
+            n_AR_Q14 = sk_mlawb(n_AR_Q14, LF_AR, Tilt_Q14);
             n_AR_Q14 = shl32(n_AR_Q14, 2);
-            i32 n_LF_Q14 = sk_mulwb(s->Shape_Q14[smpl_buf_idx], LF_shp_Q14);
-            n_LF_Q14 = sk_mlawt(n_LF_Q14, s->LF_AR_Q14, LF_shp_Q14);
+            i32 n_LF_Q14 = sk_mulwb(N->sv[lane].Shape_Q14[smpl_buf_idx], LF_shp_Q14);
+            n_LF_Q14 = sk_mlawt(n_LF_Q14, LF_AR, LF_shp_Q14);
             n_LF_Q14 = shl32(n_LF_Q14, 2);
             i32 t1 = sk_add_sat(n_AR_Q14, n_LF_Q14);
             const i32 t2 = add32(n_LTP_Q14, LPC_pred_Q14);
@@ -296,94 +319,110 @@ WV_DEV void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqStat
             i32 q1_Q10, q2_Q10, rd1, rd2;
             se_nsq_levels(r_Q10, offset_Q10, Lambda_Q10, q1_Q10, q2_Q10, rd1, rd2);
             rd1 >>= 10; rd2 >>= 10;
-            const int first_is_q1 = rd1 < rd2;
-            const i32 RD0 = s->RD_Q10;
-            for (int b = 0; b < 2; b++) {
-               const i32 Q = (b == 0) == (first_is_q1 != 0) ? q1_Q10 : q2_Q10;
-               cd[b].Q_Q10 = Q; cd[b].RD_Q10 = RD0 + ((b == 0) == (first_is_q1 != 0) ? rd1 : rd2);
-               i32 exc_Q14 = shl32(Q, 4);
-               if (Seed < 0) exc_Q14 = -exc_Q14;
-               const i32 LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14, xq_Q14 = add32(LPC_exc_Q14, LPC_pred_Q14);
-               cd[b].Diff_Q14 = sub32(xq_Q14, shl32(x_Q10, 4));
-               const i32 sLF = sub32(cd[b].Diff_Q14, n_AR_Q14);
-               cd[b].sLTP_shp_Q14 = sk_sub_sat(sLF, n_LF_Q14);
-               cd[b].LF_AR_Q14 = sLF; cd[b].LPC_exc_Q14 = LPC_exc_Q14; cd[b].xq_Q14 = xq_Q14;
+            const bool first_is_q1 = rd1 < rd2;
+            c0.Q_Q10 = first_is_q1 ? q1_Q10 : q2_Q10; c0.RD_Q10 = RD + (first_is_q1 ? rd1 : rd2);
+            c1.Q_Q10 = first_is_q1 ? q2_Q10 : q1_Q10; c1.RD_Q10 = RD + (first_is_q1 ? rd2 : rd1);
+            {
+               i32 exc_Q14 = shl32(c0.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
+               c0.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c0.xq_Q14 = add32(c0.LPC_exc_Q14, LPC_pred_Q14); c0.Diff_Q14 = sub32(c0.xq_Q14, shl32(x_Q10, 4));
+               c0.LF_AR_Q14 = sub32(c0.Diff_Q14, n_AR_Q14); c0.sLTP_shp_Q14 = sk_sub_sat(c0.LF_AR_Q14, n_LF_Q14);
+               exc_Q14 = shl32(c1.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
+               c1.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c1.xq_Q14 = add32(c1.LPC_exc_Q14, LPC_pred_Q14); c1.Diff_Q14 = sub32(c1.xq_Q14, shl32(x_Q10, 4));
+               c1.LF_AR_Q14 = sub32(c1.Diff_Q14, n_AR_Q14); c1.sLTP_shp_Q14 = sk_sub_sat(c1.LF_AR_Q14, n_LF_Q14);
             }
+            N->cand[lane][0].RD_Q10 = c0.RD_Q10; N->cand[lane][1].RD_Q10 = c1.RD_Q10;
          }
          if (signalType == SE_TYPE_VOICED) pred_lag++;
          if (lag > 0) shp_lag++;
          wv_sync();
          smpl_buf_idx = (smpl_buf_idx + SE_DD - 1) % SE_DD;
          const int last = (smpl_buf_idx + decisionDelay) % SE_DD;
-         /* every lane evaluates the K-way decisions from the shared candidates (K <= 4) */
-         /* (running minima / maxima in scalars and fully unrolled loops: an array indexed by `winner` would be placed in scratch memory) */
+         /* every lane evaluates the K-way decisions from the shared costs (running minima in scalars, loops unrolled) */
          int winner = 0;
          i32 win_rd = N->cand[0][0].RD_Q10;
 #pragma unroll
          for (int q = 1; q < 4; q++) if (q < K) { const i32 v = N->cand[q][0].RD_Q10; if (v < win_rd) { win_rd = v; winner = q; } }
          const i32 wrand = N->sv[winner].RandState[last];
          int worst = 0, best2 = 0;
-         i32 worst_rd = 0, best2_rd = 0, my_rd0 = 0;
+         i32 worst_rd = 0, best2_rd = 0, my_pen = 0;
 #pragma unroll
          for (int q = 0; q < 4; q++) if (q < K) {
             const i32 pen = N->sv[q].RandState[last] != wrand ? (2147483647 >> 4) : 0;
             const i32 a0 = N->cand[q][0].RD_Q10 + pen, a1 = N->cand[q][1].RD_Q10 + pen;
             if (q == 0 || a0 > worst_rd) { worst_rd = a0; worst = q; }
             if (q == 0 || a1 < best2_rd) { best2_rd = a1; best2 = q; }
-            if (q == lane) my_rd0 = a0;
+            if (q == lane) my_pen = pen;
          }
          const int replace = best2_rd < worst_rd;
-         /* commit the sample decisionDelay back from the winner (read before any survivor is overwritten) */
-         if (lane == 0 && (subfr > 0 || i >= decisionDelay)) {
-            const WV_LDS SeSurvivor *w = &N->sv[winner];
-            pls[i - decisionDelay] = (i8)sk_rround(w->Q_Q10[last], 10);
-            pxq[i - decisionDelay] = (i16)sk_sat16(sk_rround(sk_mulww(w->Xq_Q14[last], N->delayedGain_Q10[last]), 8));
-            st->sLTP_shp_Q14[shp_buf_idx - decisionDelay] = w->Shape_Q14[last];
-            N->sLTP_Q15[ltp_buf_idx - decisionDelay] = w->Pred_Q15[last];
+         if (lane == 0 && (subfr > 0 || i >= decisionDelay)) {                        /* commit the sample decisionDelay back from the winner, before any ring is overwritten */
+            const WV_LDS SeSurvivor *wv_ = &N->sv[winner];
+            pls[i - decisionDelay] = (i8)sk_rround(wv_->Q_Q10[last], 10);
+            pxq[i - decisionDelay] = (i16)sk_sat16(sk_rround(sk_mulww(wv_->Xq_Q14[last], N->delayedGain_Q10[last]), 8));
+            st->sLTP_shp_Q14[shp_buf_idx - decisionDelay] = wv_->Shape_Q14[last];
+            N->sLTP_Q15[ltp_buf_idx - decisionDelay] = wv_->Pred_Q15[last];
          }
          shp_buf_idx++; ltp_buf_idx++;
          wv_sync();
+         /* the candidate this survivor continues with: its own first choice, or -- for the replaced survivor -- the second choice of the best one */
+         i32 nQ = c0.Q_Q10, nRD = c0.RD_Q10 + my_pen, nxq = c0.xq_Q14, nLF = c0.LF_AR_Q14, nDiff = c0.Diff_Q14, nShp = c0.sLTP_shp_Q14, nExc = c0.LPC_exc_Q14;
          if (replace) {
+            const bool me = lane == worst;
+            i32 t;
+            t = wv_bcast(c1.Q_Q10, best2); if (me) nQ = t;
+            t = wv_bcast(c1.xq_Q14, best2); if (me) nxq = t;
+            t = wv_bcast(c1.LF_AR_Q14, best2); if (me) nLF = t;
+            t = wv_bcast(c1.Diff_Q14, best2); if (me) nDiff = t;
+            t = wv_bcast(c1.sLTP_shp_Q14, best2); if (me) nShp = t;
+            t = wv_bcast(c1.LPC_exc_Q14, best2); if (me) nExc = t;
+            t = wv_bcast(Seed, best2); if (me) Seed = t;
+            if (me) nRD = best2_rd;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { t = wv_bcast(w[j], best2); if (me) w[j] = t; }
+#pragma unroll
+            for (int j = 0; j < 24; j++) { t = wv_bcast(sar[j], best2); if (me) sar[j] = t; }
+            /* rings + SeedInit through LDS (64-lane copy) */
             WV_LDS i32 *d = (WV_LDS i32 *)&N->sv[worst]; const WV_LDS i32 *sr = (const WV_LDS i32 *)&N->sv[best2];
-            for (int q = i + lane; q < (int)(sizeof(SeSurvivor) / 4); q += WV_WIDTH) d[q] = sr[q];
+            for (int q = lane; q < (int)(sizeof(SeSurvivor) / 4); q += WV_WIDTH) d[q] = sr[q];
          }
          wv_sync();
-         if (lane < K) {
+         if (act) {
             WV_LDS SeSurvivor *s = &N->sv[lane];
-            SeCand cv;
-            {  /* the survivor-mismatch penalty stays in the candidate's cost (the reference adds it in place, :560-567): rd0 / rd1c hold the adjusted costs */
-               const int repl = replace && lane == worst;
-               const WV_LDS SeCand *src = repl ? &N->cand[best2][1] : &N->cand[lane][0];
-               cv.Q_Q10 = src->Q_Q10; cv.xq_Q14 = src->xq_Q14; cv.LF_AR_Q14 = src->LF_AR_Q14; cv.Diff_Q14 = src->Diff_Q14; cv.sLTP_shp_Q14 = src->sLTP_shp_Q14; cv.LPC_exc_Q14 = src->LPC_exc_Q14;
-               cv.RD_Q10 = repl ? best2_rd : my_rd0;
-            }
-            s->LF_AR_Q14 = cv.LF_AR_Q14; s->Diff_Q14 = cv.Diff_Q14;
-            s->sLPC_Q14[16 + i] = cv.xq_Q14;
-            s->Xq_Q14[smpl_buf_idx] = cv.xq_Q14; s->Q_Q10[smpl_buf_idx] = cv.Q_Q10; s->Pred_Q15[smpl_buf_idx] = shl32(cv.LPC_exc_Q14, 1); s->Shape_Q14[smpl_buf_idx] = cv.sLTP_shp_Q14;
-            s->Seed = add32(s->Seed, sk_rround(cv.Q_Q10, 10));
-            s->RandState[smpl_buf_idx] = s->Seed;
-            s->RD_Q10 = cv.RD_Q10;
+            LF_AR = nLF; Diff = nDiff;
+#pragma unroll
+            for (int j = 15; j > 0; j--) w[j] = w[j - 1];
+            w[0] = nxq;
+            s->Xq_Q14[smpl_buf_idx] = nxq; s->Q_Q10[smpl_buf_idx] = nQ; s->Pred_Q15[smpl_buf_idx] = shl32(nExc, 1); s->Shape_Q14[smpl_buf_idx] = nShp;
+            Seed = add32(Seed, sk_rround(nQ, 10));
+            s->RandState[smpl_buf_idx] = Seed;
+            RD = nRD;
          }
          LANE0 N->delayedGain_Q10[smpl_buf_idx] = Gain_Q10;
       }
-      if (lane < K) { WV_LDS SeSurvivor *s = &N->sv[lane]; for (int i = 0; i < 16; i++) s->sLPC_Q14[i] = s->sLPC_Q14[L + i]; }   /* L >= 40 > 16: no overlap */
       LANE0 { st->sLTP_shp_buf_idx = shp_buf_idx; st->sLTP_buf_idx = ltp_buf_idx; }
       subfr++;
    }
+   wv_sync();
+   if (act) N->sv[lane].RD_Q10 = RD;
+   wv_sync();
+   const int wn = se_dd_best(N->sv, K);
    LANE0 {
-      const int w = se_dd_best(N->sv, K);
-      ix->Seed = (i8)N->sv[w].SeedInit;
-      se_dd_flush_l0(st, &N->sv[w], smpl_buf_idx, decisionDelay, pulses + c->nb_subfr * L, &st->xq[mem + c->nb_subfr * L], ctl->Gains_Q16[c->nb_subfr - 1] >> 6, 8);
-      for (int i = 0; i < 16; i++) st->sLPC_Q14[i] = N->sv[w].sLPC_Q14[i];          /* (already moved to the front above) */
-      for (int i = 0; i < 24; i++) st->sAR2_Q14[i] = N->sv[w].sAR2_Q14[i];
-      st->sLF_AR_shp_Q14 = N->sv[w].LF_AR_Q14; st->sDiff_shp_Q14 = N->sv[w].Diff_Q14;
+      ix->Seed = (i8)N->sv[wn].SeedInit;
+      se_dd_flush_l0(st, &N->sv[wn], smpl_buf_idx, decisionDelay, pulses + c->nb_subfr * L, &st->xq[mem + c->nb_subfr * L], ctl->Gains_Q16[c->nb_subfr - 1] >> 6, 8);
       st->lagPrev = ctl->pitchL[c->nb_subfr - 1];
    }
+   if (lane == wn) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) st->sLPC_Q14[15 - j] = w[j];
+#pragma unroll
+      for (int j = 0; j < 24; j++) st->sAR2_Q14[j] = sar[j];
+      st->sLF_AR_shp_Q14 = LF_AR; st->sDiff_shp_Q14 = Diff;
+   }
+   wv_sync();
    for (int b = 0; b < mem; b += WV_WIDTH) {
-      const int i = b + wv_lane(); i16 a = 0; i32 s = 0;
-      if (i < mem) { a = st->xq[frame + i]; s = st->sLTP_shp_Q14[frame + i]; }
+      const int i = b + wv_lane(); i16 a = 0; i32 sv_ = 0;
+      if (i < mem) { a = st->xq[frame + i]; sv_ = st->sLTP_shp_Q14[frame + i]; }
       wv_sync();
-      if (i < mem) { st->xq[i] = a; st->sLTP_shp_Q14[i] = s; }
+      if (i < mem) { st->xq[i] = a; st->sLTP_shp_Q14[i] = sv_; }
       wv_sync();
    }
 }

@@ -175,7 +175,7 @@ struct SeLpcWork {
 };
 
 /* NLSFIndices, pNLSF_Q15 (in/out) live in LDS; lanes = survivors */
-WV_DEV void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, int order, const WV_LDS i16 *pW_Q2, int NLSF_mu_Q20, int nSurvivors, int signalType, WV_LDS SeLpcWork *W)
+WV_DEVN void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, int order, const WV_LDS i16 *pW_Q2, int NLSF_mu_Q20, int nSurvivors, int signalType, WV_LDS SeLpcWork *W)
 {
    const SdNlsfCb cb = sd_nlsf_cb(order);
    const u8 *ec_rates_Q5 = order == 16 ? se_nlsf_wb_ec_rates_q5 : se_nlsf_nb_mb_ec_rates_q5;
@@ -271,7 +271,7 @@ WV_DEV void se_process_nlsfs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS i16 *PredCo
 }
 
 /* x = LPC_in_pre; LPC_res: i16[2 * 96] */
-WV_DEV void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res)
+WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res)
 {
    const int order = c->predictLPCOrder, subfr_length = c->subfr_length + order;
    const int interp = c->useInterpolatedNLSFs && !c->first_frame_after_reset && c->nb_subfr == 4;
@@ -327,7 +327,7 @@ WV_DEV void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, co
 }
 
 /* res_pitch = res_pitch_frame, x = x_frame.  LPC_in_pre: i16[4 * 16 + 320]; XX: i32[100 + 20]; LPC_res: i16[192] */
-WV_DEV void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
+WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
       WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res)
 {
    const int order = c->predictLPCOrder, nb = c->nb_subfr, sl = c->subfr_length;
