@@ -17,6 +17,7 @@ __device__ unsigned long long oa_phase_ticks[34];
 __device__ unsigned long long oa_sh_phase_ticks[24];
 #define SE_PHASE(S_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)(S_)->r[15])); (S_)->r[15] = (i32)t_; } } while (0)
 #define SE_PHASE_START(S_) do { if (threadIdx.x == 0) (S_)->r[15] = (i32)(u32)clock64(); } while (0)
+#define SE_TICK(tk_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)*(tk_))); *(tk_) = (i32)t_; } } while (0)
 #endif
 #include "silk_enc_all.h"
 #include "../../include/opus_amd.h"

@@ -168,7 +168,7 @@ WV_DEV i32 sd_log2lin(i32 inLog_Q7)                                             
    if (inLog_Q7 < 2048) out = out + ((out * t) >> 7); else out = out + (out >> 7) * t;
    return out;
 }
-WV_DEV void sd_bwexpander_32(i32 *ar, int d, i32 chirp_Q16)                                           /* bwexpander_32.c:35 */
+template <class PA> WV_DEV void sd_bwexpander_32(PA ar, int d, i32 chirp_Q16)                                           /* bwexpander_32.c:35 */
 {
    const i32 cm1 = chirp_Q16 - 65536;
    for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
@@ -183,9 +183,10 @@ WV_DEV void sd_bwexpander(WV_LDS i16 *ar, int d, i32 chirp_Q16)                 
 WV_DEV i32 sd_rround64(i64 a, int s) { return (i32)(s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1); }
 WV_DEV i64 sd_rround64w(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; }
 /* LPC_inv_pred_gain.c:45 (QA = 24): 0 = unstable, else inverse prediction gain Q30 */
-template <class PA> WV_DEV i32 sd_lpc_inverse_pred_gain(PA A_Q12, int order)
+/* A: 16 words of working storage (LDS for lane-0 callers that care about latency: a run-time indexed private array lives in scratch memory) */
+template <class PA, class PW> WV_DEV i32 sd_lpc_inverse_pred_gain_w(PA A_Q12, int order, PW A)
 {
-   i32 A[16]; i32 DC = 0;
+   i32 DC = 0;
    for (int k = 0; k < order; k++) { DC += A_Q12[k]; A[k] = shl32(A_Q12[k], 12); }
    if (DC >= 4096) return 0;
    const i32 A_LIMIT = 16773022;                                                                      /* SILK_FIX_CONST(0.99975, 24) */
@@ -217,8 +218,9 @@ template <class PA> WV_DEV i32 sd_lpc_inverse_pred_gain(PA A_Q12, int order)
    if (invGain_Q30 < MIN_INVGAIN) return 0;
    return invGain_Q30;
 }
+template <class PA> WV_DEV i32 sd_lpc_inverse_pred_gain(PA A_Q12, int order) { i32 A[16]; return sd_lpc_inverse_pred_gain_w(A_Q12, order, A); }
 /* NLSF2A.c:66: NLSF (Q15) -> monic LPC coefficients Q12 via the two symmetric polynomials, then range fit and stability loop */
-WV_DEV void sd_nlsf2a_poly(i32 *out, const i32 *cLSF, int dd)
+template <class PO, class PC> WV_DEV void sd_nlsf2a_poly(PO out, PC cLSF, int dd)
 {
    out[0] = (i32)1 << 16; out[1] = -cLSF[0];
    for (int k = 1; k < dd; k++) {
@@ -230,10 +232,11 @@ WV_DEV void sd_nlsf2a_poly(i32 *out, const i32 *cLSF, int dd)
 }
 WV_TABLE u8 k_sd_ordering16[16] = { 0, 15, 8, 7, 4, 11, 12, 3, 2, 13, 10, 5, 6, 9, 14, 1 };
 WV_TABLE u8 k_sd_ordering10[10] = { 0, 9, 6, 3, 4, 5, 8, 1, 2, 7 };
-template <class PA, class PN> WV_DEV void sd_nlsf2a(PA a_Q12, PN NLSF, int d)
+/* wk: 66 words of working storage (cosq 16, P 9, Q 9, a32 16, inverse-gain work 16) */
+template <class PA, class PN, class PW> WV_DEV void sd_nlsf2a_w(PA a_Q12, PN NLSF, int d, PW wk)
 {
    const u8 *ordering = d == 16 ? k_sd_ordering16 : k_sd_ordering10;
-   i32 cosq[16], P[9], Q[9], a32[16];
+   PW cosq = wk, P = wk + 16, Q = wk + 25, a32 = wk + 34, ipg = wk + 50;
    for (int k = 0; k < d; k++) {
       const i32 f_int = NLSF[k] >> 8, f_frac = NLSF[k] - (f_int << 8);
       const i32 cos_val = sk_lsf_cos_tab_q12[f_int], delta = sk_lsf_cos_tab_q12[f_int + 1] - cos_val;
@@ -259,11 +262,12 @@ template <class PA, class PN> WV_DEV void sd_nlsf2a(PA a_Q12, PN NLSF, int d)
       if (i == 10) for (int k = 0; k < d; k++) { a_Q12[k] = (i16)sk_sat16(sk_rround(a32[k], 5)); a32[k] = shl32(a_Q12[k], 5); }
       else for (int k = 0; k < d; k++) a_Q12[k] = (i16)sk_rround(a32[k], 5);
    }
-   for (int i = 0; sd_lpc_inverse_pred_gain(a_Q12, d) == 0 && i < 16; i++) {                                /* MAX_LPC_STABILIZE_ITERATIONS */
+   for (int i = 0; sd_lpc_inverse_pred_gain_w(a_Q12, d, ipg) == 0 && i < 16; i++) {                         /* MAX_LPC_STABILIZE_ITERATIONS */
       sd_bwexpander_32(a32, d, 65536 - shl32(2, i));
       for (int k = 0; k < d; k++) a_Q12[k] = (i16)sk_rround(a32[k], 5);
    }
 }
+template <class PA, class PN> WV_DEV void sd_nlsf2a(PA a_Q12, PN NLSF, int d) { i32 wk[66]; sd_nlsf2a_w(a_Q12, NLSF, d, wk); }
 WV_DEV void sd_nlsf_stabilize(i16 *NLSF, const i16 *NDeltaMin, int L)                                       /* NLSF_stabilize.c:50 */
 {
    for (int loops = 0; loops < 20; loops++) {

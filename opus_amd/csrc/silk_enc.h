@@ -21,6 +21,7 @@
 #ifndef SE_PHASE            /* shader-clock marks exist only in the -DOA_PHASE_TIMERS profiling build */
 #define SE_PHASE(S_, id)
 #define SE_PHASE_START(S_)
+#define SE_TICK(tk_, id)
 #endif
 #define SE_FIX(C, Q) ((i32)((C) * ((i64)1 << (Q)) + 0.5))          /* SILK_FIX_CONST (silk/SigProc_FIX.h:574): the literal keeps the reference's type */
 #define SE_TYPE_NO_VOICE 0

@@ -363,6 +363,117 @@ template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q
    }
 }
 
+/* silk_burg_modified_c on the whole wave.  Every inner loop of the reference is a sum of individually rounded terms added with wrap-around, so the terms are
+ * computed one per lane -- lane = (subframe s = lane / 16, tap k = lane % 16) -- and summed in any order; only the order recursion n = 0..D-1 is serial.
+ * out[0] = res_nrg, out[1] = res_nrg_Q; stk: 84 + 4 * 64 + 8 words of LDS. */
+WV_DEVN void se_burg_modified_wave(WV_LDS i32 *out, WV_LDS i32 *A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D, WV_LDS i32 *stk)
+{
+   const int QA = 25;
+   const int lane = wv_lane(), s = lane >> 4, k = lane & 15;
+   const bool sact = s < nb_subfr;
+   WV_LDS i32 *C_first_row = stk, *C_last_row = stk + 16, *Af_QA = stk + 32, *CAf = stk + 48, *CAb = stk + 66, *T0 = stk + 84, *T1 = T0 + 64, *T2 = T1 + 64, *T3 = T2 + 64, *TS = T3 + 64;
+   const WV_LDS i16 *xs = x + (sact ? s : 0) * subfr_length;
+   i64 part = 0;
+   FOR_LANES(i, subfr_length * nb_subfr) part += (i32)x[i] * (i32)x[i];
+   const i64 C0_64 = wv_sum64(part);
+   int rshifts = 32 + 1 + 3 - se_clz64(C0_64);
+   if (rshifts > 32 - QA) rshifts = 32 - QA;
+   if (rshifts < -16) rshifts = -16;
+   i32 C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
+   {  /* first row of the correlation matrix: lane (s, n - 1) */
+      i32 term = 0;
+      if (sact && k < D) { const i64 ip = se_inner_prod16(xs, xs + k + 1, subfr_length - k - 1); term = rshifts > 0 ? (i32)(ip >> rshifts) : shl32((i32)ip, -rshifts); }
+      T0[lane] = term;
+      wv_sync();
+      if (lane < 16) { i32 v = 0; for (int q = 0; q < nb_subfr; q++) v = add32(v, T0[q * 16 + lane]); C_first_row[lane] = lane < D ? v : 0; C_last_row[lane] = lane < D ? v : 0; Af_QA[lane] = 0; }
+      if (lane == 0) { CAb[0] = CAf[0] = C0 + sk_mulhi(SE_FIX(1e-5f, 32), C0) + 1; }
+      wv_sync();
+   }
+   i32 invGain_Q30 = (i32)1 << 30;
+   int reached_max_gain = 0, n;
+   for (n = 0; n < D; n++) {
+      /* ---- update the rows and C * Af, C * flipud(Af): terms per (s, k) ---- */
+      i32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      const i32 xn = sact ? (i32)xs[n] : 0, xe = sact ? (i32)xs[subfr_length - n - 1] : 0;
+      if (sact && k < n) {
+         const i32 xa = xs[n - k - 1], xb = xs[subfr_length - n + k], Atmp = Af_QA[k];
+         if (rshifts > -2) { t0 = sk_mulwb(-shl32(xn, 16 - rshifts), xa); t1 = sk_mulwb(-shl32(xe, 16 - rshifts), xb); t2 = sk_mulwb(Atmp, xa); t3 = sk_mulwb(Atmp, xb); }
+         else { const i32 A1 = sk_rround(Atmp, QA - 17); t0 = (i32)((u32)(-shl32(xn, -rshifts)) * (u32)xa); t1 = (i32)((u32)(-shl32(xe, -rshifts)) * (u32)xb); t2 = (i32)((u32)xa * (u32)A1); t3 = (i32)((u32)xb * (u32)A1); }
+      }
+      T0[lane] = t0; T1[lane] = t1; T2[lane] = t2; T3[lane] = t3;
+      wv_sync();
+      if (lane < 16 && lane < n) { i32 a0 = C_first_row[lane], a1 = C_last_row[lane]; for (int q = 0; q < nb_subfr; q++) { a0 = add32(a0, T0[q * 16 + lane]); a1 = add32(a1, T1[q * 16 + lane]); } C_first_row[lane] = a0; C_last_row[lane] = a1; }
+      if (sact && k == 0) {                                                       /* tmp1 / tmp2 of subframe s */
+         i32 tmp1, tmp2;
+         if (rshifts > -2) { tmp1 = shl32(xn, QA - 16); tmp2 = shl32(xe, QA - 16); } else { tmp1 = shl32(xn, 17); tmp2 = shl32(xe, 17); }
+         for (int q = 0; q < n; q++) { tmp1 = add32(tmp1, T2[s * 16 + q]); tmp2 = add32(tmp2, T3[s * 16 + q]); }
+         if (rshifts > -2) { tmp1 = shl32(neg32(tmp1), 32 - QA - rshifts); tmp2 = shl32(neg32(tmp2), 32 - QA - rshifts); } else { tmp1 = neg32(tmp1); tmp2 = neg32(tmp2); }
+         TS[2 * s] = tmp1; TS[2 * s + 1] = tmp2;
+      }
+      wv_sync();
+      t0 = 0; t1 = 0;
+      if (sact && k <= n) {
+         const i32 tmp1 = TS[2 * s], tmp2 = TS[2 * s + 1], xa = xs[n - k], xb = xs[subfr_length - n + k - 1];
+         if (rshifts > -2) { t0 = sk_mulwb(tmp1, xa); t1 = sk_mulwb(tmp2, xb); }
+         else { t0 = sk_mulww(tmp1, shl32(xa, -rshifts - 1)); t1 = sk_mulww(tmp2, shl32(xb, -rshifts - 1)); }
+      }
+      T0[lane] = t0; T1[lane] = t1;
+      wv_sync();
+      if (lane < 16 && lane <= n) { i32 a0 = CAf[lane], a1 = CAb[lane]; for (int q = 0; q < nb_subfr; q++) { a0 = add32(a0, T0[q * 16 + lane]); a1 = add32(a1, T1[q * 16 + lane]); } CAf[lane] = a0; CAb[lane] = a1; }
+      wv_sync();
+      /* ---- nominator / denominator of the reflection coefficient: lanes over k < n ---- */
+      i32 p1 = 0, p2 = 0, pn = 0, pg = 0;
+      if (lane < n) {
+         const i32 Atmp_QA = Af_QA[lane];
+         int lz = sk_clz(iabs(Atmp_QA)) - 1; lz = imin(32 - QA, lz);
+         const i32 Atmp1 = shl32(Atmp_QA, lz); const int sh = 32 - QA - lz;
+         p1 = shl32(sk_mulhi(C_last_row[n - lane - 1], Atmp1), sh); p2 = shl32(sk_mulhi(C_first_row[n - lane - 1], Atmp1), sh);
+         pn = shl32(sk_mulhi(CAb[n - lane], Atmp1), sh); pg = shl32(sk_mulhi(add32(CAb[lane + 1], CAf[lane + 1]), Atmp1), sh);
+      }
+      i32 tmp1 = add32(C_first_row[n], wv_sum(p1)), tmp2 = add32(C_last_row[n], wv_sum(p2)), num = wv_sum(pn), nrg = add32(add32(CAb[0], CAf[0]), wv_sum(pg));
+      wv_sync();
+      if (lane == 0) { CAf[n + 1] = tmp1; CAb[n + 1] = tmp2; }
+      num = add32(num, tmp2);
+      num = shl32(neg32(num), 1);
+      i32 rc_Q31;
+      if (iabs(num) < nrg) rc_Q31 = sk_div32_varQ(num, nrg, 31); else rc_Q31 = num > 0 ? 2147483647 : (i32)(-2147483647 - 1);
+      tmp1 = ((i32)1 << 30) - sk_mulhi(rc_Q31, rc_Q31);
+      tmp1 = shl32(sk_mulhi(invGain_Q30, tmp1), 2);
+      if (tmp1 <= minInvGain_Q30) {
+         tmp2 = ((i32)1 << 30) - sk_div32_varQ(minInvGain_Q30, invGain_Q30, 30);
+         rc_Q31 = se_sqrt_approx(tmp2);
+         if (rc_Q31 > 0) { rc_Q31 = (rc_Q31 + tmp2 / rc_Q31) >> 1; rc_Q31 = shl32(rc_Q31, 16); if (num < 0) rc_Q31 = -rc_Q31; }
+         invGain_Q30 = minInvGain_Q30;
+         reached_max_gain = 1;
+      } else invGain_Q30 = tmp1;
+      wv_sync();
+      if (lane < ((n + 1) >> 1)) { const i32 a = Af_QA[lane], b = Af_QA[n - lane - 1]; Af_QA[lane] = se_add_lshift32(a, sk_mulhi(b, rc_Q31), 1); Af_QA[n - lane - 1] = se_add_lshift32(b, sk_mulhi(a, rc_Q31), 1); }
+      wv_sync();
+      if (lane == 0) Af_QA[n] = rc_Q31 >> (31 - QA);
+      if (reached_max_gain) { if (lane > n && lane < D) Af_QA[lane] = 0; wv_sync(); break; }
+      if (lane <= n + 1) { const i32 a = CAf[lane], b = CAb[n - lane + 1]; T0[lane] = se_add_lshift32(a, sk_mulhi(b, rc_Q31), 1); T1[lane] = se_add_lshift32(b, sk_mulhi(a, rc_Q31), 1); }
+      wv_sync();
+      if (lane <= n + 1) { CAf[lane] = T0[lane]; CAb[n - lane + 1] = T1[lane]; }
+      wv_sync();
+   }
+   LANE0 {
+      if (reached_max_gain) {
+         for (int q = 0; q < D; q++) A_Q16[q] = -sk_rround(Af_QA[q], QA - 16);
+         for (int q = 0; q < nb_subfr; q++) {
+            const WV_LDS i16 *xp = x + q * subfr_length;
+            const i64 ip = se_inner_prod16(xp, xp, D);
+            if (rshifts > 0) C0 -= (i32)(ip >> rshifts); else C0 = sub32(C0, shl32((i32)ip, -rshifts));
+         }
+         out[0] = shl32(sk_mulhi(invGain_Q30, C0), 2);
+      } else {
+         i32 nrg = CAf[0], tmp1 = (i32)1 << 16;
+         for (int q = 0; q < D; q++) { const i32 Atmp1 = sk_rround(Af_QA[q], QA - 16); nrg = sk_mlaww(nrg, CAf[q + 1], Atmp1); tmp1 = sk_mlaww(tmp1, Atmp1, Atmp1); A_Q16[q] = -Atmp1; }
+         out[0] = sk_mlaww(nrg, sk_mulhi(SE_FIX(1e-5f, 32), C0), -tmp1);
+      }
+      out[1] = -rshifts;
+   }
+}
+
 /* ---- silk_find_LTP_FIX with silk_corrMatrix_FIX / silk_corrVector_FIX.  XX: i32[nb*25], xX: i32[nb*5] ---- */
 WV_DEV void se_find_ltp_l0(WV_LDS i32 *XX, WV_LDS i32 *xX, const WV_LDS i16 *r_ptr, const WV_LDS i32 *lag, int subfr_length, int nb_subfr)
 {

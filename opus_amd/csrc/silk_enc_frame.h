@@ -369,7 +369,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
       wv_sync();
       SE_TAP(1);
       SE_PHASE(S, 4);
-      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.XX, A->u.p.LPC_res);
+      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.XX, A->u.p.LPC_res, &S->r[15]);
       SE_TAP(2);
       SE_PHASE(S, 5);
       LANE0 se_process_gains_l0(c, ctl, condCoding);

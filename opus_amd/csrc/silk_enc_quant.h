@@ -13,57 +13,78 @@
 #ifndef OPUS_AMD_SILK_ENC_QUANT_H
 #define OPUS_AMD_SILK_ENC_QUANT_H
 
-WV_DEV void se_a2nlsf_trans_poly(i32 *p, int dd) { for (int k = 2; k <= dd; k++) { for (int n = dd; n > k; n--) p[n - 2] -= p[n]; p[k - 2] -= shl32(p[k], 1); } }
-WV_DEV i32 se_a2nlsf_eval_poly(const i32 *p, i32 x, int dd) { i32 y32 = p[dd]; const i32 x_Q16 = shl32(x, 4); for (int n = dd - 1; n >= 0; n--) y32 = sk_mlaww(p[n], y32, x_Q16); return y32; }
-template <class PA> WV_DEV void se_a2nlsf_init(PA a_Q16, i32 *P, i32 *Q, int dd)
+/* silk_A2NLSF (silk/A2NLSF.c:127) on the wave.  The two polynomials live in registers of every lane (fixed-size arrays, unrolled loops, DD = d / 2 known at
+ * compile time); their values at the 129 table points are independent -> lanes evaluate the grid into LDS, lane 0 then runs the reference's root scan on the
+ * table and only the 3-step bisections evaluate the polynomial again.  Y: 2 x 132 words of LDS; a_Q16 (LDS) is bandwidth-expanded in the rare retry path. */
+template <int DD> WV_DEV void se_a2nlsf_poly_init(const WV_LDS i32 *a_Q16, i32 *P, i32 *Q)
 {
-   P[dd] = 1 << 16; Q[dd] = 1 << 16;
-   for (int k = 0; k < dd; k++) { P[k] = -a_Q16[dd - k - 1] - a_Q16[dd + k]; Q[k] = -a_Q16[dd - k - 1] + a_Q16[dd + k]; }
-   for (int k = dd; k > 0; k--) { P[k - 1] -= P[k]; Q[k - 1] += Q[k]; }
-   se_a2nlsf_trans_poly(P, dd); se_a2nlsf_trans_poly(Q, dd);
-}
-template <class PA> WV_DEV void se_a2nlsf(i16 *NLSF, PA a_Q16, int d)
-{
-   i32 P[9], Q[9];
-   const int dd = d >> 1;
-   se_a2nlsf_init(a_Q16, P, Q, dd);
-   const i32 *p = P;
-   i32 xlo = sk_lsf_cos_tab_q12[0], ylo = se_a2nlsf_eval_poly(p, xlo, dd), xhi, yhi, thr = 0;
-   int root_ix, k = 1, i = 0;
-   if (ylo < 0) { NLSF[0] = 0; p = Q; ylo = se_a2nlsf_eval_poly(p, xlo, dd); root_ix = 1; } else root_ix = 0;
-   while (1) {
-      xhi = sk_lsf_cos_tab_q12[k];
-      yhi = se_a2nlsf_eval_poly(p, xhi, dd);
-      if ((ylo <= 0 && yhi >= thr) || (ylo >= 0 && yhi <= -thr)) {
-         thr = yhi == 0 ? 1 : 0;
-         int ffrac = -256;
-         for (int m = 0; m < 3; m++) {
-            const i32 xmid = sk_rround(xlo + xhi, 1), ymid = se_a2nlsf_eval_poly(p, xmid, dd);
-            if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) { xhi = xmid; yhi = ymid; }
-            else { xlo = xmid; ylo = ymid; ffrac = ffrac + (128 >> m); }
-         }
-         if (iabs(ylo) < 65536) { const i32 den = ylo - yhi, nom = shl32(ylo, 8 - 3) + (den >> 1); if (den != 0) ffrac += nom / den; }
-         else ffrac += ylo / ((ylo - yhi) >> (8 - 3));
-         NLSF[root_ix] = (i16)imin(shl32((i32)k, 8) + ffrac, 32767);
-         root_ix++;
-         if (root_ix >= d) break;
-         p = (root_ix & 1) ? Q : P;
-         xlo = sk_lsf_cos_tab_q12[k - 1];
-         ylo = shl32(1 - (root_ix & 2), 12);
-      } else {
-         k++; xlo = xhi; ylo = yhi; thr = 0;
-         if (k > 128) {
-            i++;
-            if (i > 16) { NLSF[0] = (i16)((1 << 15) / (d + 1)); for (k = 1; k < d; k++) NLSF[k] = (i16)(NLSF[k - 1] + NLSF[0]); return; }
-            se_bwexpander_32(a_Q16, d, 65536 - shl32(1, i));
-            se_a2nlsf_init(a_Q16, P, Q, dd);
-            p = P; xlo = sk_lsf_cos_tab_q12[0]; ylo = se_a2nlsf_eval_poly(p, xlo, dd);
-            if (ylo < 0) { NLSF[0] = 0; p = Q; ylo = se_a2nlsf_eval_poly(p, xlo, dd); root_ix = 1; } else root_ix = 0;
-            k = 1;
-         }
-      }
+#pragma unroll
+   for (int k = 0; k < DD; k++) { P[k] = -a_Q16[DD - k - 1] - a_Q16[DD + k]; Q[k] = -a_Q16[DD - k - 1] + a_Q16[DD + k]; }
+   P[DD] = 1 << 16; Q[DD] = 1 << 16;
+#pragma unroll
+   for (int k = DD; k > 0; k--) { P[k - 1] -= P[k]; Q[k - 1] += Q[k]; }
+#pragma unroll
+   for (int k = 2; k <= DD; k++) {
+#pragma unroll
+      for (int n = DD; n > k; n--) { P[n - 2] -= P[n]; Q[n - 2] -= Q[n]; }
+      P[k - 2] -= shl32(P[k], 1); Q[k - 2] -= shl32(Q[k], 1);
    }
 }
+template <int DD> WV_DEV i32 se_a2nlsf_eval(const i32 *P, const i32 *Q, bool useQ, i32 x)
+{
+   i32 y32 = useQ ? Q[DD] : P[DD]; const i32 x_Q16 = shl32(x, 4);
+#pragma unroll
+   for (int n = DD - 1; n >= 0; n--) y32 = sk_mlaww(useQ ? Q[n] : P[n], y32, x_Q16);
+   return y32;
+}
+template <int DD> WV_DEV void se_a2nlsf_wave_t(WV_LDS i16 *NLSF, WV_LDS i32 *a_Q16, WV_LDS i32 *Y)
+{
+   const int d = 2 * DD;
+   for (int attempt = 0; ; attempt++) {
+      i32 P[DD + 1], Q[DD + 1];
+      se_a2nlsf_poly_init<DD>(a_Q16, P, Q);
+      FOR_LANES(i, 2 * 129) { const bool q = i >= 129; const int k = q ? i - 129 : i; Y[q * 132 + k] = se_a2nlsf_eval<DD>(P, Q, q, sk_lsf_cos_tab_q12[k]); }
+      wv_sync();
+      LANE0 {
+         bool useQ = false;
+         i32 xlo = sk_lsf_cos_tab_q12[0], ylo = Y[0], xhi, yhi, thr = 0;
+         int root_ix, k = 1, done = 0;
+         if (ylo < 0) { NLSF[0] = 0; useQ = true; ylo = Y[132]; root_ix = 1; } else root_ix = 0;
+         while (1) {
+            xhi = sk_lsf_cos_tab_q12[k];
+            yhi = Y[useQ * 132 + k];
+            if ((ylo <= 0 && yhi >= thr) || (ylo >= 0 && yhi <= -thr)) {
+               thr = yhi == 0 ? 1 : 0;
+               int ffrac = -256;
+               for (int m = 0; m < 3; m++) {
+                  const i32 xmid = sk_rround(xlo + xhi, 1), ymid = se_a2nlsf_eval<DD>(P, Q, useQ, xmid);
+                  if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) { xhi = xmid; yhi = ymid; } else { xlo = xmid; ylo = ymid; ffrac = ffrac + (128 >> m); }
+               }
+               if (iabs(ylo) < 65536) { const i32 den = ylo - yhi, nom = shl32(ylo, 8 - 3) + (den >> 1); if (den != 0) ffrac += nom / den; }
+               else ffrac += ylo / ((ylo - yhi) >> (8 - 3));
+               NLSF[root_ix] = (i16)imin(shl32((i32)k, 8) + ffrac, 32767);
+               root_ix++;
+               if (root_ix >= d) { done = 1; break; }
+               useQ = (root_ix & 1) != 0;
+               xlo = sk_lsf_cos_tab_q12[k - 1];
+               ylo = shl32(1 - (root_ix & 2), 12);
+            } else {
+               k++; xlo = xhi; ylo = yhi; thr = 0;
+               if (k > 128) {                                                      /* no full set of roots: bandwidth-expand and search again (:227) */
+                  if (attempt + 1 > 16) { NLSF[0] = (i16)((1 << 15) / (d + 1)); for (k = 1; k < d; k++) NLSF[k] = (i16)(NLSF[k - 1] + NLSF[0]); done = 1; }
+                  else se_bwexpander_32(a_Q16, d, 65536 - shl32(1, attempt + 1));
+                  break;
+               }
+            }
+         }
+         Y[131] = done;
+      }
+      if (Y[131]) break;
+      wv_sync();
+   }
+   wv_sync();
+}
+WV_DEV void se_a2nlsf_wave(WV_LDS i16 *NLSF, WV_LDS i32 *a_Q16, int d, WV_LDS i32 *Y) { if (d == 16) se_a2nlsf_wave_t<8>(NLSF, a_Q16, Y); else se_a2nlsf_wave_t<5>(NLSF, a_Q16, Y); }
 WV_DEV void se_interpolate(i16 *xi, const WV_LDS i16 *x0, const i16 *x1, int ifact_Q2, int d) { for (int i = 0; i < d; i++) xi[i] = (i16)(x0[i] + (sk_mulbb(x1[i] - x0[i], ifact_Q2) >> 2)); }
 WV_DEV void se_nlsf_vq_weights(i16 *pW, const i16 *pN, int D)
 {
@@ -166,9 +187,10 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *
 
 /* scratch of the LPC / NLSF stages (LDS) */
 struct SeLpcWork {
-   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8], stk[100];
+   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8], stk[84 + 4 * 64 + 8];
    i16 NLSF_Q15[16], NLSF0_Q15[16], a_tmp_Q12[16], pW[16];
    i32 err_Q24[32], RD_Q25[16], surv[16];
+   i32 Y[2 * 132], wk[66];
    i8 tempIndices2[16 * 16];
    SeNlsfTabs tabs;
    SeNlsfLane lane[16];
@@ -261,45 +283,40 @@ WV_DEV void se_process_nlsfs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS i16 *PredCo
    }
    se_nlsf_encode_wave(c->indices.NLSFIndices, W->NLSF_Q15, order, W->pW, NLSF_mu_Q20, c->NLSF_MSVQ_Survivors, c->indices.signalType, W);
    LANE0 {
-      i16 n[16], n0[16], a[16];
-      for (int i = 0; i < order; i++) n[i] = W->NLSF_Q15[i];
-      sd_nlsf2a(a, n, order);
-      for (int i = 0; i < order; i++) PredCoef_Q12[16 + i] = a[i];
-      if (doInterpolate) { se_interpolate(n0, c->prev_NLSFq_Q15, n, c->indices.NLSFInterpCoef_Q2, order); sd_nlsf2a(a, n0, order); }
-      for (int i = 0; i < order; i++) PredCoef_Q12[i] = a[i];
+      sd_nlsf2a_w(PredCoef_Q12 + 16, W->NLSF_Q15, order, W->wk);
+      if (doInterpolate) {
+         for (int i = 0; i < order; i++) W->NLSF0_Q15[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], c->indices.NLSFInterpCoef_Q2) >> 2));
+         sd_nlsf2a_w(PredCoef_Q12, W->NLSF0_Q15, order, W->wk);
+      } else for (int i = 0; i < order; i++) PredCoef_Q12[i] = PredCoef_Q12[16 + i];
    }
 }
 
 /* x = LPC_in_pre; LPC_res: i16[2 * 96] */
-WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res)
+WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
 {
    const int order = c->predictLPCOrder, subfr_length = c->subfr_length + order;
    const int interp = c->useInterpolatedNLSFs && !c->first_frame_after_reset && c->nb_subfr == 4;
+   se_burg_modified_wave(&W->r[0], W->a_Q16, x, minInvGain_Q30, subfr_length, c->nb_subfr, order, W->stk);
+   if (interp) se_burg_modified_wave(&W->r[2], W->a_tmp_Q16, x + 2 * subfr_length, minInvGain_Q30, subfr_length, 2, order, W->stk);
    LANE0 {
-      i32 res_nrg; int res_nrg_Q;
+      i32 res_nrg = W->r[0]; int res_nrg_Q = W->r[1];
       c->indices.NLSFInterpCoef_Q2 = 4;
-      se_burg_modified_l0(&res_nrg, &res_nrg_Q, W->a_Q16, x, minInvGain_Q30, subfr_length, c->nb_subfr, order, W->stk);
       if (interp) {
-         i32 res_tmp_nrg; int res_tmp_nrg_Q;
+         const i32 res_tmp_nrg = W->r[2]; const int res_tmp_nrg_Q = W->r[3];
          WV_LDS i32 *at = W->a_tmp_Q16;
-         se_burg_modified_l0(&res_tmp_nrg, &res_tmp_nrg_Q, at, x + 2 * subfr_length, minInvGain_Q30, subfr_length, 2, order, W->stk);
          const int shift = res_tmp_nrg_Q - res_nrg_Q;
          if (shift >= 0) { if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift); }
          else { res_nrg = (res_nrg >> -shift) - res_tmp_nrg; res_nrg_Q = res_tmp_nrg_Q; }
-         i16 n[16];
-         se_a2nlsf(n, at, order);
-         for (int i = 0; i < order; i++) W->NLSF_Q15[i] = n[i];
       }
       W->r[0] = res_nrg; W->r[1] = res_nrg_Q;
    }
+   if (interp) se_a2nlsf_wave(W->NLSF_Q15, W->a_tmp_Q16, order, W->Y);
+   SE_TICK(tk, 12);                                                              /* Burg (x2) + A2NLSF of the second half */
    if (interp) {
       for (int k = 3; k >= 0; k--) {
          LANE0 {
-            i16 n[16], n0[16], a[16];
-            for (int i = 0; i < order; i++) n[i] = W->NLSF_Q15[i];
-            se_interpolate(n0, c->prev_NLSFq_Q15, n, k, order);
-            sd_nlsf2a(a, n0, order);
-            for (int i = 0; i < order; i++) W->a_tmp_Q12[i] = a[i];
+            for (int i = 0; i < order; i++) W->NLSF0_Q15[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], k) >> 2));   /* silk_interpolate */
+            sd_nlsf2a_w(W->a_tmp_Q12, W->NLSF0_Q15, order, W->wk);
          }
          se_lpc_analysis_filter_wave(LPC_res, x, W->a_tmp_Q12, 2 * subfr_length, order);
          LANE0 {
@@ -317,18 +334,13 @@ WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, c
          }
       }
    }
-   LANE0 {
-      if (c->indices.NLSFInterpCoef_Q2 == 4) {
-         i16 n[16];
-         se_a2nlsf(n, W->a_Q16, order);
-         for (int i = 0; i < order; i++) W->NLSF_Q15[i] = n[i];
-      }
-   }
+   SE_TICK(tk, 13);                                                              /* interpolation search */
+   if (c->indices.NLSFInterpCoef_Q2 == 4) se_a2nlsf_wave(W->NLSF_Q15, W->a_Q16, order, W->Y);
 }
 
 /* res_pitch = res_pitch_frame, x = x_frame.  LPC_in_pre: i16[4 * 16 + 320]; XX: i32[100 + 20]; LPC_res: i16[192] */
 WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
-      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res)
+      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
 {
    const int order = c->predictLPCOrder, nb = c->nb_subfr, sl = c->subfr_length;
    LANE0 {
@@ -356,14 +368,17 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       LANE0 { for (int i = 0; i < nb * 5; i++) ctl->LTPCoef_Q14[i] = 0; ctl->LTPredCodGain_Q7 = 0; c->sum_log_gain_Q7 = 0; ctl->LTP_scale_Q14 = 0; }
    }
    wv_sync();
+   SE_TICK(tk, 11);                                                              /* LTP analysis */
    i32 minInvGain_Q30;
    if (c->first_frame_after_reset) minInvGain_Q30 = SE_FIX(1.0f / 1e2f, 30);
    else {
       minInvGain_Q30 = se_log2lin(sk_mlawb(16 << 7, (i32)ctl->LTPredCodGain_Q7, SE_FIX(1.0 / 3, 16)));
       minInvGain_Q30 = sk_div32_varQ(minInvGain_Q30, sk_mulww(SE_FIX(1e4f, 0), sk_mlawb(SE_FIX(0.25, 18), SE_FIX(0.75, 18), ctl->coding_quality_Q14)), 14);
    }
-   se_find_lpc_wave(c, W, LPC_in_pre, minInvGain_Q30, LPC_res);
+   se_find_lpc_wave(c, W, LPC_in_pre, minInvGain_Q30, LPC_res, tk);
+   SE_TICK(tk, 14);                                                              /* final A2NLSF */
    se_process_nlsfs_wave(c, &ctl->PredCoef_Q12[0][0], W);
+   SE_TICK(tk, 15);                                                              /* NLSF quantiser + NLSF2A */
    se_residual_energy_wave(ctl->ResNrg, ctl->ResNrgQ, LPC_in_pre, &ctl->PredCoef_Q12[0][0], W->local_gains, sl, nb, order, LPC_res);
    LANE0 { for (int i = 0; i < 16; i++) c->prev_NLSFq_Q15[i] = i < order ? W->NLSF_Q15[i] : (i16)0; }
 }

@@ -17,11 +17,11 @@ def signal(fs, secs, ch, seed):
         outs.append(s)
     return np.clip(np.stack(outs, 1).reshape(-1), -32768, 32767).astype(np.int16)
 
-def run_silk(nframes, ch=1, chi=None, fs=16000, ms=20, seed=1, **kw):
+def run_silk(nframes, ch=1, chi=None, fs=16000, ms=20, seed=1, gain=1.0, **kw):
     from silkenc_harness import Pair, make_ctl, compare
     chi = chi or ch
     p = Pair(ch)
-    pcm = signal(fs, nframes * ms / 1000 + 0.1, ch, seed)
+    pcm = (signal(fs, nframes * ms / 1000 + 0.1, ch, seed) * gain).astype(np.int16)
     n = fs * ms // 1000 * ch
     ctl = make_ctl(nChannelsAPI=ch, nChannelsInternal=chi, API_sampleRate=fs, payloadSize_ms=ms, **kw)
     for f in range(nframes):
@@ -31,6 +31,10 @@ def run_silk(nframes, ch=1, chi=None, fs=16000, ms=20, seed=1, **kw):
 
 @pytest.mark.parametrize("cx", [0, 1, 2, 5, 8, 10])
 def test_emu_silk_encode_complexities(cx): run_silk(14, complexity=cx)
+@pytest.mark.parametrize("gain", [0.0, 0.0004, 0.003, 0.02, 5.0])
+def test_emu_silk_encode_levels(gain):
+    """digital silence, a few LSBs (the low-level branches of the Burg recursion and the correlation scalings), and clipping input"""
+    run_silk(14, gain=gain); run_silk(8, gain=gain, ch=2, bitRate=36000, complexity=4)
 @pytest.mark.parametrize("kw", [
     dict(desiredInternalSampleRate=8000, maxInternalSampleRate=8000, bitRate=12000), dict(desiredInternalSampleRate=12000, maxInternalSampleRate=12000, bitRate=16000),
     dict(ms=10), dict(fs=48000), dict(useCBR=1, maxBits=60 * 8), dict(maxBits=40 * 8, bitRate=32000), dict(ch=2, bitRate=40000), dict(ch=2, fs=48000, bitRate=36000, complexity=5),
