@@ -18,7 +18,6 @@ struct SeNsqLds {
    i32 sLPC[80 + 16];                                                                /* silk_NSQ_c working LPC state */
    i16 sLTP[2 * SE_MAX_FRAME];
    SeSurvivor sv[4];
-   SeCand cand[4][2];
 };
 
 /* 2-level quantisation of one residual sample (NSQ.c:268-321 / NSQ_del_dec.c:440-493): candidates and their rate terms */
@@ -175,6 +174,22 @@ WV_DEV void se_dd_flush_l0(WV_LDS OaSilkNsqState *st, const WV_LDS SeSurvivor *w
  * (fixed-size arrays indexed only by unrolled constants; taps beyond the order carry zero coefficients / are predicated off), so a sample costs no LDS
  * round trip for the filters.  The five 40-deep rings of undecided samples stay in LDS.  A survivor replacement moves the 40 filter words of the better
  * lane with v_readlane and the rings with a 64-lane copy. */
+/* survivor J of the quad hands its second-choice candidate and its filter state to the replaced survivor (:566-575): DPP quad broadcasts, no LDS */
+template <int J> WV_DEV void se_dd_take(bool me, const SeCand &c1, i32 &nQ, i32 &nxq, i32 &nLF, i32 &nDiff, i32 &nShp, i32 &nExc, i32 &Seed, i32 *w, i32 *sar)
+{
+   i32 t;
+   t = wv_quad_bcast<J>(c1.Q_Q10); nQ = me ? t : nQ;
+   t = wv_quad_bcast<J>(c1.xq_Q14); nxq = me ? t : nxq;
+   t = wv_quad_bcast<J>(c1.LF_AR_Q14); nLF = me ? t : nLF;
+   t = wv_quad_bcast<J>(c1.Diff_Q14); nDiff = me ? t : nDiff;
+   t = wv_quad_bcast<J>(c1.sLTP_shp_Q14); nShp = me ? t : nShp;
+   t = wv_quad_bcast<J>(c1.LPC_exc_Q14); nExc = me ? t : nExc;
+   t = wv_quad_bcast<J>(Seed); Seed = me ? t : Seed;
+#pragma unroll
+   for (int j = 0; j < 16; j++) { t = wv_quad_bcast<J>(w[j]); w[j] = me ? t : w[j]; }
+#pragma unroll
+   for (int j = 0; j < 24; j++) { t = wv_quad_bcast<J>(sar[j]); sar[j] = me ? t : sar[j]; }
+}
 WV_DEVN void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqState *st, WV_LDS OaSilkEncIndices *ix, WV_LDS SeNsqLds *N, const WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *x16, WV_LDS i8 *pulses)
 {
    const int lane = wv_lane();
@@ -256,148 +271,143 @@ WV_DEVN void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqSta
          }
          wv_sync();
       }
-      /* coefficient sets of the subframe in registers; zero beyond the order */
+      /* coefficient sets of the subframe in registers; zero beyond the order (unconditional loads: the arrays are 16 / 24 wide) */
       i32 ca[16], cs[24];
 #pragma unroll
-      for (int j = 0; j < 16; j++) ca[j] = j < P ? (i32)a_Q12[j] : 0;
+      for (int j = 0; j < 16; j++) { const i32 v = a_Q12[j]; ca[j] = j < P ? v : 0; }
 #pragma unroll
-      for (int j = 0; j < 24; j++) cs[j] = j < S ? (i32)AR_shp_Q13[j] : 0;
+      for (int j = 0; j < 24; j++) { const i32 v = AR_shp_Q13[j]; cs[j] = j < S ? v : 0; }
       const i32 b0 = b_Q14[0], b1 = b_Q14[1], b2 = b_Q14[2], b3 = b_Q14[3], b4 = b_Q14[4];
-      /* sample loop (:315-644) */
+      /* sample loop (:315-644).  Every lane runs the arithmetic (lanes >= K on survivor 0's data, results unused); stores are guarded. */
       const i32 Gain_Q10 = Gain_Q16 >> 6;
       int shp_lag = st->sLTP_shp_buf_idx - lag + 1, pred_lag = st->sLTP_buf_idx - lag + 5 / 2;
       int shp_buf_idx = st->sLTP_shp_buf_idx, ltp_buf_idx = st->sLTP_buf_idx;
+      WV_LDS SeSurvivor *const sv = &N->sv[act ? lane : 0];
+      const bool voiced = signalType == SE_TYPE_VOICED;
       for (int i = 0; i < L; i++) {
-         SeCand c0, c1;
-         c0.Q_Q10 = c0.RD_Q10 = c0.xq_Q14 = c0.LF_AR_Q14 = c0.Diff_Q14 = c0.sLTP_shp_Q14 = c0.LPC_exc_Q14 = 0; c1 = c0;
-         if (act) {
-            i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
-            if (signalType == SE_TYPE_VOICED) {
-               LTP_pred_Q14 = 2;
-               LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag], b0); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 1], b1); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 2], b2);
-               LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 3], b3); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 4], b4);
-               LTP_pred_Q14 = shl32(LTP_pred_Q14, 1);
-            }
-            if (lag > 0) {
-               n_LTP_Q14 = sk_mulwb(sk_add_sat(st->sLTP_shp_Q14[shp_lag], st->sLTP_shp_Q14[shp_lag - 2]), HarmPacked_Q14);
-               n_LTP_Q14 = sk_mlawt(n_LTP_Q14, st->sLTP_shp_Q14[shp_lag - 1], HarmPacked_Q14);
-               n_LTP_Q14 = LTP_pred_Q14 - shl32(n_LTP_Q14, 2);
-            }
-            Seed = sk_rand(Seed);
-            i32 LPC_pred_Q14 = P >> 1;
-#pragma unroll
-            for (int j = 0; j < 16; j++) LPC_pred_Q14 = sk_mlawb(LPC_pred_Q14, w[j], ca[j]);
-            LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
-            i32 n_AR_Q14 = S >> 1;
-            {
-               i32 in = sk_mlawb(Diff, sar[0], warp);
-#pragma unroll
-               for (int j = 0; j < 24; j++) {
-                  if (j < S) {
-                     const i32 nxt = j + 1 < 24 ? sar[j + 1 < 24 ? j + 1 : 23] : 0;
-                     const i32 out = j + 1 < S ? sk_mlawb(sar[j], sub32(nxt, in), warp) : 0;
-                     sar[j] = in;
-                     n_AR_Q14 = sk_mlawb(n_AR_Q14, in, cs[j]);
-                     in = out;
-                  }
-               }
-            }
-            n_AR_Q14 = shl32(n_AR_Q14, 1);
-            n_AR_Q14 = sk_mlawb(n_AR_Q14, LF_AR, Tilt_Q14);
-            n_AR_Q14 = shl32(n_AR_Q14, 2);
-            i32 n_LF_Q14 = sk_mulwb(N->sv[lane].Shape_Q14[smpl_buf_idx], LF_shp_Q14);
-            n_LF_Q14 = sk_mlawt(n_LF_Q14, LF_AR, LF_shp_Q14);
-            n_LF_Q14 = shl32(n_LF_Q14, 2);
-            i32 t1 = sk_add_sat(n_AR_Q14, n_LF_Q14);
-            const i32 t2 = add32(n_LTP_Q14, LPC_pred_Q14);
-            t1 = sk_sub_sat(t2, t1);
-            t1 = sk_rround(t1, 4);
-            const i32 x_Q10 = N->x_sc_Q10[i];
-            i32 r_Q10 = x_Q10 - t1;
-            if (Seed < 0) r_Q10 = neg32(r_Q10);
-            r_Q10 = se_limit(r_Q10, -(31 << 10), 30 << 10);
-            i32 q1_Q10, q2_Q10, rd1, rd2;
-            se_nsq_levels(r_Q10, offset_Q10, Lambda_Q10, q1_Q10, q2_Q10, rd1, rd2);
-            rd1 >>= 10; rd2 >>= 10;
-            const bool first_is_q1 = rd1 < rd2;
-            c0.Q_Q10 = first_is_q1 ? q1_Q10 : q2_Q10; c0.RD_Q10 = RD + (first_is_q1 ? rd1 : rd2);
-            c1.Q_Q10 = first_is_q1 ? q2_Q10 : q1_Q10; c1.RD_Q10 = RD + (first_is_q1 ? rd2 : rd1);
-            {
-               i32 exc_Q14 = shl32(c0.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
-               c0.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c0.xq_Q14 = add32(c0.LPC_exc_Q14, LPC_pred_Q14); c0.Diff_Q14 = sub32(c0.xq_Q14, shl32(x_Q10, 4));
-               c0.LF_AR_Q14 = sub32(c0.Diff_Q14, n_AR_Q14); c0.sLTP_shp_Q14 = sk_sub_sat(c0.LF_AR_Q14, n_LF_Q14);
-               exc_Q14 = shl32(c1.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
-               c1.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c1.xq_Q14 = add32(c1.LPC_exc_Q14, LPC_pred_Q14); c1.Diff_Q14 = sub32(c1.xq_Q14, shl32(x_Q10, 4));
-               c1.LF_AR_Q14 = sub32(c1.Diff_Q14, n_AR_Q14); c1.sLTP_shp_Q14 = sk_sub_sat(c1.LF_AR_Q14, n_LF_Q14);
-            }
-            N->cand[lane][0].RD_Q10 = c0.RD_Q10; N->cand[lane][1].RD_Q10 = c1.RD_Q10;
-         }
-         if (signalType == SE_TYPE_VOICED) pred_lag++;
-         if (lag > 0) shp_lag++;
-         wv_sync();
+         const int old_idx = smpl_buf_idx;
          smpl_buf_idx = (smpl_buf_idx + SE_DD - 1) % SE_DD;
          const int last = (smpl_buf_idx + decisionDelay) % SE_DD;
-         /* every lane evaluates the K-way decisions from the shared costs (running minima in scalars, loops unrolled) */
-         int winner = 0;
-         i32 win_rd = N->cand[0][0].RD_Q10;
+         /* the ring entries this sample may commit, read ahead of the arithmetic that hides their latency */
+         const i32 l_rand = sv->RandState[last], l_Q = sv->Q_Q10[last], l_Xq = sv->Xq_Q14[last], l_Shape = sv->Shape_Q14[last], l_Pred = sv->Pred_Q15[last], l_gain = N->delayedGain_Q10[last];
+         const i32 x_Q10 = N->x_sc_Q10[i];
+         i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
+         if (voiced) {
+            LTP_pred_Q14 = 2;
+            LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag], b0); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 1], b1); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 2], b2);
+            LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 3], b3); LTP_pred_Q14 = sk_mlawb(LTP_pred_Q14, N->sLTP_Q15[pred_lag - 4], b4);
+            LTP_pred_Q14 = shl32(LTP_pred_Q14, 1);
+            pred_lag++;
+         }
+         if (lag > 0) {
+            n_LTP_Q14 = sk_mulwb(sk_add_sat(st->sLTP_shp_Q14[shp_lag], st->sLTP_shp_Q14[shp_lag - 2]), HarmPacked_Q14);
+            n_LTP_Q14 = sk_mlawt(n_LTP_Q14, st->sLTP_shp_Q14[shp_lag - 1], HarmPacked_Q14);
+            n_LTP_Q14 = LTP_pred_Q14 - shl32(n_LTP_Q14, 2);
+            shp_lag++;
+         }
+         Seed = sk_rand(Seed);
+         i32 LPC_pred_Q14 = P >> 1;
 #pragma unroll
-         for (int q = 1; q < 4; q++) if (q < K) { const i32 v = N->cand[q][0].RD_Q10; if (v < win_rd) { win_rd = v; winner = q; } }
-         const i32 wrand = N->sv[winner].RandState[last];
-         int worst = 0, best2 = 0;
+         for (int j = 0; j < 16; j++) LPC_pred_Q14 = sk_mlawb(LPC_pred_Q14, w[j], ca[j]);
+         LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
+         i32 n_AR_Q14 = S >> 1;
+         {  /* warped all-pass ladder: stage j consumes the output of stage j - 1 (:392-413); orders 12 / 14 / 16 / 24 (control_codec.c complexity table) */
+            i32 in = sk_mlawb(Diff, sar[0], warp);
+#define SE_AR_STAGE(j) { const i32 nxt = (j) + 1 < 24 ? sar[(j) + 1 < 24 ? (j) + 1 : 23] : 0; const i32 out = sk_mlawb(sar[j], sub32(nxt, in), warp); sar[j] = in; n_AR_Q14 = sk_mlawb(n_AR_Q14, in, cs[j]); in = out; }
+#pragma unroll
+            for (int j = 0; j < 12; j++) SE_AR_STAGE(j)
+            if (S > 12) { SE_AR_STAGE(12) SE_AR_STAGE(13) }
+            if (S > 14) { SE_AR_STAGE(14) SE_AR_STAGE(15) }
+            if (S > 16) {
+#pragma unroll
+               for (int j = 16; j < 24; j++) SE_AR_STAGE(j)
+            }
+#undef SE_AR_STAGE
+         }
+         n_AR_Q14 = shl32(n_AR_Q14, 1);
+         n_AR_Q14 = sk_mlawb(n_AR_Q14, LF_AR, Tilt_Q14);
+         n_AR_Q14 = shl32(n_AR_Q14, 2);
+         i32 n_LF_Q14 = sk_mulwb(sv->Shape_Q14[old_idx], LF_shp_Q14);
+         n_LF_Q14 = sk_mlawt(n_LF_Q14, LF_AR, LF_shp_Q14);
+         n_LF_Q14 = shl32(n_LF_Q14, 2);
+         i32 t1 = sk_add_sat(n_AR_Q14, n_LF_Q14);
+         const i32 t2 = add32(n_LTP_Q14, LPC_pred_Q14);
+         t1 = sk_sub_sat(t2, t1);
+         t1 = sk_rround(t1, 4);
+         i32 r_Q10 = x_Q10 - t1;
+         if (Seed < 0) r_Q10 = neg32(r_Q10);
+         r_Q10 = se_limit(r_Q10, -(31 << 10), 30 << 10);
+         i32 q1_Q10, q2_Q10, rd1, rd2;
+         se_nsq_levels(r_Q10, offset_Q10, Lambda_Q10, q1_Q10, q2_Q10, rd1, rd2);
+         rd1 >>= 10; rd2 >>= 10;
+         const bool first_is_q1 = rd1 < rd2;
+         SeCand c0, c1;
+         c0.Q_Q10 = first_is_q1 ? q1_Q10 : q2_Q10; c0.RD_Q10 = RD + (first_is_q1 ? rd1 : rd2);
+         c1.Q_Q10 = first_is_q1 ? q2_Q10 : q1_Q10; c1.RD_Q10 = RD + (first_is_q1 ? rd2 : rd1);
+         {
+            i32 exc_Q14 = shl32(c0.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
+            c0.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c0.xq_Q14 = add32(c0.LPC_exc_Q14, LPC_pred_Q14); c0.Diff_Q14 = sub32(c0.xq_Q14, shl32(x_Q10, 4));
+            c0.LF_AR_Q14 = sub32(c0.Diff_Q14, n_AR_Q14); c0.sLTP_shp_Q14 = sk_sub_sat(c0.LF_AR_Q14, n_LF_Q14);
+            exc_Q14 = shl32(c1.Q_Q10, 4); if (Seed < 0) exc_Q14 = -exc_Q14;
+            c1.LPC_exc_Q14 = exc_Q14 + LTP_pred_Q14; c1.xq_Q14 = add32(c1.LPC_exc_Q14, LPC_pred_Q14); c1.Diff_Q14 = sub32(c1.xq_Q14, shl32(x_Q10, 4));
+            c1.LF_AR_Q14 = sub32(c1.Diff_Q14, n_AR_Q14); c1.sLTP_shp_Q14 = sk_sub_sat(c1.LF_AR_Q14, n_LF_Q14);
+         }
+         /* the K-way decisions (:530-590) on the scalar unit: costs and random states of lanes 0..K-1 read with constant lane selects */
+         int winner = 0, worst = 0, best2 = 0;
          i32 worst_rd = 0, best2_rd = 0, my_pen = 0;
+         {
+            i32 r0[4], r1[4], rs[4];
+#define SE_DD_GET(q) r0[q] = wv_lane_const<q>(c0.RD_Q10); r1[q] = wv_lane_const<q>(c1.RD_Q10); rs[q] = wv_lane_const<q>(l_rand);
+            SE_DD_GET(0) SE_DD_GET(1) SE_DD_GET(2) SE_DD_GET(3)
+#undef SE_DD_GET
+            i32 win_rd = r0[0], wrand = rs[0];
 #pragma unroll
-         for (int q = 0; q < 4; q++) if (q < K) {
-            const i32 pen = N->sv[q].RandState[last] != wrand ? (2147483647 >> 4) : 0;
-            const i32 a0 = N->cand[q][0].RD_Q10 + pen, a1 = N->cand[q][1].RD_Q10 + pen;
-            if (q == 0 || a0 > worst_rd) { worst_rd = a0; worst = q; }
-            if (q == 0 || a1 < best2_rd) { best2_rd = a1; best2 = q; }
-            if (q == lane) my_pen = pen;
+            for (int q = 1; q < 4; q++) if (q < K && r0[q] < win_rd) { win_rd = r0[q]; winner = q; wrand = rs[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (q < K) {
+               const i32 pen = rs[q] != wrand ? (2147483647 >> 4) : 0;
+               const i32 a0 = r0[q] + pen, a1 = r1[q] + pen;
+               if (q == 0 || a0 > worst_rd) { worst_rd = a0; worst = q; }
+               if (q == 0 || a1 < best2_rd) { best2_rd = a1; best2 = q; }
+               if (q == lane) my_pen = pen;
+            }
          }
          const int replace = best2_rd < worst_rd;
-         if (lane == 0 && (subfr > 0 || i >= decisionDelay)) {                        /* commit the sample decisionDelay back from the winner, before any ring is overwritten */
-            const WV_LDS SeSurvivor *wv_ = &N->sv[winner];
-            pls[i - decisionDelay] = (i8)sk_rround(wv_->Q_Q10[last], 10);
-            pxq[i - decisionDelay] = (i16)sk_sat16(sk_rround(sk_mulww(wv_->Xq_Q14[last], N->delayedGain_Q10[last]), 8));
-            st->sLTP_shp_Q14[shp_buf_idx - decisionDelay] = wv_->Shape_Q14[last];
-            N->sLTP_Q15[ltp_buf_idx - decisionDelay] = wv_->Pred_Q15[last];
+         if (lane == winner && (subfr > 0 || i >= decisionDelay)) {                   /* commit the sample decisionDelay back from the winner (its ring entries were read above, before any ring is overwritten) */
+            pls[i - decisionDelay] = (i8)sk_rround(l_Q, 10);
+            pxq[i - decisionDelay] = (i16)sk_sat16(sk_rround(sk_mulww(l_Xq, l_gain), 8));
+            st->sLTP_shp_Q14[shp_buf_idx - decisionDelay] = l_Shape;
+            N->sLTP_Q15[ltp_buf_idx - decisionDelay] = l_Pred;
          }
          shp_buf_idx++; ltp_buf_idx++;
-         wv_sync();
          /* the candidate this survivor continues with: its own first choice, or -- for the replaced survivor -- the second choice of the best one */
          i32 nQ = c0.Q_Q10, nRD = c0.RD_Q10 + my_pen, nxq = c0.xq_Q14, nLF = c0.LF_AR_Q14, nDiff = c0.Diff_Q14, nShp = c0.sLTP_shp_Q14, nExc = c0.LPC_exc_Q14;
          if (replace) {
             const bool me = lane == worst;
-            i32 t;
-            t = wv_bcast(c1.Q_Q10, best2); if (me) nQ = t;
-            t = wv_bcast(c1.xq_Q14, best2); if (me) nxq = t;
-            t = wv_bcast(c1.LF_AR_Q14, best2); if (me) nLF = t;
-            t = wv_bcast(c1.Diff_Q14, best2); if (me) nDiff = t;
-            t = wv_bcast(c1.sLTP_shp_Q14, best2); if (me) nShp = t;
-            t = wv_bcast(c1.LPC_exc_Q14, best2); if (me) nExc = t;
-            t = wv_bcast(Seed, best2); if (me) Seed = t;
             if (me) nRD = best2_rd;
-#pragma unroll
-            for (int j = 0; j < 16; j++) { t = wv_bcast(w[j], best2); if (me) w[j] = t; }
-#pragma unroll
-            for (int j = 0; j < 24; j++) { t = wv_bcast(sar[j], best2); if (me) sar[j] = t; }
+            switch (best2) {
+            case 0: se_dd_take<0>(me, c1, nQ, nxq, nLF, nDiff, nShp, nExc, Seed, w, sar); break;
+            case 1: se_dd_take<1>(me, c1, nQ, nxq, nLF, nDiff, nShp, nExc, Seed, w, sar); break;
+            case 2: se_dd_take<2>(me, c1, nQ, nxq, nLF, nDiff, nShp, nExc, Seed, w, sar); break;
+            default: se_dd_take<3>(me, c1, nQ, nxq, nLF, nDiff, nShp, nExc, Seed, w, sar); break;
+            }
             /* rings + SeedInit through LDS (64-lane copy) */
+            wv_order();
             WV_LDS i32 *d = (WV_LDS i32 *)&N->sv[worst]; const WV_LDS i32 *sr = (const WV_LDS i32 *)&N->sv[best2];
             for (int q = lane; q < (int)(sizeof(SeSurvivor) / 4); q += WV_WIDTH) d[q] = sr[q];
          }
-         wv_sync();
-         if (act) {
-            WV_LDS SeSurvivor *s = &N->sv[lane];
-            LF_AR = nLF; Diff = nDiff;
+         wv_order();
+         LF_AR = nLF; Diff = nDiff;
 #pragma unroll
-            for (int j = 15; j > 0; j--) w[j] = w[j - 1];
-            w[0] = nxq;
-            s->Xq_Q14[smpl_buf_idx] = nxq; s->Q_Q10[smpl_buf_idx] = nQ; s->Pred_Q15[smpl_buf_idx] = shl32(nExc, 1); s->Shape_Q14[smpl_buf_idx] = nShp;
-            Seed = add32(Seed, sk_rround(nQ, 10));
-            s->RandState[smpl_buf_idx] = Seed;
-            RD = nRD;
-         }
-         LANE0 N->delayedGain_Q10[smpl_buf_idx] = Gain_Q10;
+         for (int j = 15; j > 0; j--) w[j] = w[j - 1];
+         w[0] = nxq;
+         Seed = add32(Seed, sk_rround(nQ, 10));
+         RD = nRD;
+         if (act) { sv->Xq_Q14[smpl_buf_idx] = nxq; sv->Q_Q10[smpl_buf_idx] = nQ; sv->Pred_Q15[smpl_buf_idx] = shl32(nExc, 1); sv->Shape_Q14[smpl_buf_idx] = nShp; sv->RandState[smpl_buf_idx] = Seed; }
+         if (lane == 0) N->delayedGain_Q10[smpl_buf_idx] = Gain_Q10;
+         wv_order();
       }
+      wv_sync();
       LANE0 { st->sLTP_shp_buf_idx = shp_buf_idx; st->sLTP_buf_idx = ltp_buf_idx; }
       subfr++;
    }

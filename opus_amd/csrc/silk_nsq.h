@@ -16,10 +16,12 @@
 #include "silk_frame.h"
 
 /* ---- SILK fixed-point primitives (silk/macros.h:40-122, silk/SigProc_FIX.h:447-584, OPUS_FAST_INT64 forms) ---- */
+/* 32 x 16 -> top 32 of 48 bits.  a * b16 >> 16 == a * (b16 << 16) >> 32: one v_mul_hi_i32 (the shift of a loop-invariant coefficient hoists) instead of the
+ * mul_lo + mul_hi + alignbit a 64-bit product costs */
 WV_DEV i32 sk_mulhi(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 32); }
-WV_DEV i32 sk_mulwb(i32 a, i32 b) { return (i32)(((i64)a * (i16)b) >> 16); }          /* silk_SMULWB */
+WV_DEV i32 sk_mulwb(i32 a, i32 b) { return sk_mulhi(a, (i32)((u32)b << 16)); }                 /* silk_SMULWB */
 WV_DEV i32 sk_mlawb(i32 c, i32 a, i32 b) { return add32(c, sk_mulwb(a, b)); }          /* silk_SMLAWB */
-WV_DEV i32 sk_mulwt(i32 a, i32 b) { return (i32)(((i64)a * (b >> 16)) >> 16); }        /* silk_SMULWT */
+WV_DEV i32 sk_mulwt(i32 a, i32 b) { return sk_mulhi(a, (i32)((u32)b & 0xffff0000u)); }        /* silk_SMULWT */
 WV_DEV i32 sk_mlawt(i32 c, i32 a, i32 b) { return add32(c, sk_mulwt(a, b)); }
 WV_DEV i32 sk_mulww(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 16); }           /* silk_SMULWW */
 WV_DEV i32 sk_mlaww(i32 c, i32 a, i32 b) { return add32(c, sk_mulww(a, b)); }

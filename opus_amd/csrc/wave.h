@@ -22,6 +22,9 @@
 WV_DEV int wv_lane() { return (int)threadIdx.x; }
 /* orders LDS traffic between lanes of the wave (block == wave) */
 WV_DEV void wv_sync() { __syncthreads(); }
+/* compiler-level ordering of LDS traffic between lanes, no wait: the LDS pipeline executes one wave's ds_* instructions in issue order, so a later read by
+ * any lane sees an earlier write by any other lane.  (wv_sync additionally waits for every outstanding LDS operation, which also drains prefetches.) */
+WV_DEV void wv_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 WV_DEV int32_t wv_shfl(int32_t v, int src) { return __shfl(v, src, 64); }
 /* src must be wave-uniform */
@@ -39,6 +42,8 @@ WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
 
 /* lane i receives v of lane i-1, lane 0 receives `fill` (DPP wave_shr:1: one instruction, no LDS) */
 /* value of lane J (0..3) of the caller's quad, in all four lanes: one DPP quad_perm move, no LDS crossbar */
+/* value of lane Q as a wave-uniform scalar (v_readlane_b32 with a constant lane select: the result lives in an SGPR) */
+template <int Q> WV_DEV int32_t wv_lane_const(int32_t v) { return __builtin_amdgcn_readlane(v, Q); }
 template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 

@@ -54,6 +54,7 @@ static inline void emu_rendezvous(int kind = 0)
    }
 }
 WV_DEV void wv_sync() { emu_rendezvous(); }
+WV_DEV void wv_order() { emu_rendezvous(); }
 /* publish (a,b,c,d) for this lane, rendezvous, return this op's table [64][4] */
 static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0))[4]
 {
@@ -65,6 +66,7 @@ static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_
    return w->xch[p];
 }
 WV_DEV int32_t wv_shfl(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src & 63][0]; }
+template <int Q> WV_DEV int32_t wv_lane_const(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[Q][0]; }
 template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[(emu_cur->cur & ~3) | J][0]; }
 WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
 WV_DEV int32_t wv_uni(int32_t v) { return v; }
