@@ -18,6 +18,8 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #define SE_PHASE(S_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)(S_)->r[15])); (S_)->r[15] = (i32)t_; } } while (0)
 #define SE_PHASE_START(S_) do { if (threadIdx.x == 0) (S_)->r[15] = (i32)(u32)clock64(); } while (0)
 #define SE_TICK(tk_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)*(tk_))); *(tk_) = (i32)t_; } } while (0)
+#define SE_CLK_BEGIN() const u32 clk0_ = (u32)clock64()
+#define SE_CLK_END(id) do { if (threadIdx.x == 0) atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)((u32)clock64() - clk0_)); } while (0)
 #endif
 #include "silk_enc_all.h"
 #include "../../include/opus_amd.h"
@@ -233,6 +235,8 @@ int opusgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSucc
 int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
 int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
 int opusgpu_sh_kernel_lds_bytes(void) { return (int)SH_LDS_BYTES(1); }
+/* dynamic LDS of one wave: the SILK working set, or -- when the batch can reach the CELT layer (48 kHz) -- at least the CELT frame arena that aliases it */
+static size_t sh_lds_bytes(int channels, int Fs) { size_t n = SH_LDS_BYTES(channels); const size_t celt = offsetof(ShLds, S) + sizeof(FrameLds); if (Fs == 48000 && celt > n) n = celt; return n; }
 int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
 opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
 
@@ -372,7 +376,7 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    if (b->kind) {
       const size_t need = (size_t)b->S * SH_SCRATCH_BYTES(frame_size, b->channels);
       if (need > b->hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->hp_cap = need; }
-      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), SH_LDS_BYTES(b->channels), s,
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sh_lds_bytes(b->channels, b->Fs), s,
             b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i16 *)b->d_pcm_hp, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;

@@ -519,7 +519,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       }
       if (nBytes == 0) { sh->ret = ret; st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0; }
    }
-   if (sh->ret == -1000) { sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); return; }
+   if (sh->ret == -1000) { SE_CLK_BEGIN(); sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); SE_CLK_END(16); return; }
    /* ---- store packet + state (coalesced) ---- */
    {
       const int nbytes = sh->ret < 0 ? sh->ret : sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);

@@ -20,6 +20,8 @@
 
 #ifndef SE_PHASE            /* shader-clock marks exist only in the -DOA_PHASE_TIMERS profiling build */
 #define SE_PHASE(S_, id)
+#define SE_CLK_BEGIN()
+#define SE_CLK_END(id)
 #define SE_PHASE_START(S_)
 #define SE_TICK(tk_, id)
 #endif

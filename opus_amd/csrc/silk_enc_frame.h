@@ -14,12 +14,11 @@
 /* ---- LDS working set ---- */
 struct SeAnaLds {                                      /* analysis phases */
    i16 res_pitch[32 + 320 + 320 + 8];
-   i16 Wsig[384 + 8], xx[384 + 8];
    i32 w32[32];
    i16 A_Q12s[16];
    union {
-      PitchLds pitch;
-      struct { i16 LPC_in_pre[4 * 16 + 320]; i32 XX[120]; i16 LPC_res[2 * 96]; SeLpcWork W; } p;
+      struct { i16 Wsig[384 + 8], xx[384 + 8]; PitchLds pitch; } a;     /* pitch analysis, noise shaping analysis */
+      struct { i16 LPC_in_pre[4 * 16 + 320]; SeLpcWork W; } p;           /* prediction coefficients */
    } u;
 };
 struct SeQuantLds {                                    /* quantiser + rate loop */
@@ -361,15 +360,15 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
    if (!c->prefillFlag) {
       WV_LDS SeAnaLds *A = &S->u.a;
       WV_LDS i16 *res_pitch = A->res_pitch, *res_pitch_frame = res_pitch + c->ltp_mem_length;
-      se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->Wsig, A->xx, A->w32, A->A_Q12s, &A->u.pitch);
+      se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->u.a.Wsig, A->u.a.xx, A->w32, A->A_Q12s, &A->u.a.pitch);
       wv_sync();
       SE_TAP(0);
       SE_PHASE(S, 3);
-      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->Wsig, A->xx, A->w32, S->stk);
+      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->u.a.Wsig, A->u.a.xx, A->w32, S->stk);
       wv_sync();
       SE_TAP(1);
       SE_PHASE(S, 4);
-      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.XX, A->u.p.LPC_res, &S->r[15]);
+      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15]);
       SE_TAP(2);
       SE_PHASE(S, 5);
       LANE0 se_process_gains_l0(c, ctl, condCoding);

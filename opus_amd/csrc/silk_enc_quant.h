@@ -108,8 +108,8 @@ WV_DEV void se_insertion_sort_increasing(i32 *a, int *idx, int L, int K)
 
 /* per-survivor working set of the NLSF trellis search, in LDS (run-time indexed private arrays would be scratch memory = HBM round trips) */
 struct SeNlsfLane {
-   i32 ec_ix[16], pred_Q8[16], RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4], ind_sort[4];
-   i16 res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
+   i32 RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4], ind_sort[4];
+   i16 ec_ix[16], pred_Q8[16], res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
    i8 ind[4][16], ti[16];
 };
 struct SeNlsfTabs { i32 out0[20], out1[20]; };
@@ -187,13 +187,16 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *
 
 /* scratch of the LPC / NLSF stages (LDS) */
 struct SeLpcWork {
-   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8], stk[84 + 4 * 64 + 8];
+   i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8];
    i16 NLSF_Q15[16], NLSF0_Q15[16], a_tmp_Q12[16], pW[16];
-   i32 err_Q24[32], RD_Q25[16], surv[16];
-   i32 Y[2 * 132], wk[66];
-   i8 tempIndices2[16 * 16];
-   SeNlsfTabs tabs;
-   SeNlsfLane lane[16];
+   i32 wk[66];
+   union {                                                     /* one stage at a time: LTP correlations -> Burg -> A2NLSF grid -> interpolation residual -> NLSF quantiser -> residual energies */
+      i32 XX[120];
+      i32 stk[84 + 4 * 64 + 8];
+      i32 Y[2 * 132];
+      i16 LPC_res[2 * 96];
+      struct { i32 err_Q24[32], RD_Q25[16], surv[16]; i8 tempIndices2[16 * 16]; SeNlsfTabs tabs; SeNlsfLane lane[16]; };
+   };
 };
 
 /* NLSFIndices, pNLSF_Q15 (in/out) live in LDS; lanes = survivors */
