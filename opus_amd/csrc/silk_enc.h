@@ -104,6 +104,77 @@ WV_DEV void se_resampler_init(WV_LDS i32 *cfgw, WV_LDS i32 *rows, i32 Fs_in, i32
 template <class InP> WV_DEV void se_resample_l0(WV_LDS i32 *cfgw, WV_LDS i32 *rows, WV_LDS SeRsLds *R, WV_LDS i16 *out, InP in, int inLen)
 { silk_resampler_lane(se_rs_cfg(cfgw), R, rows, 1, in, inLen, out, 0); }
 
+/* silk_resampler (silk/resampler.c:183) for the encoder's input direction (API rate >= internal rate: copy or silk_resampler_private_down_FIR,
+ * resampler_private_down_FIR.c:144) with the whole wave.  Per <= 10 ms batch: all lanes stage the input (coalesced reads of the Opus layer's HBM
+ * scratch) into the FIR buffer, lane 0 runs the second-order AR prefilter in place (a rounding recursion, serial by nature; loads batched four ahead),
+ * then one lane per output sample evaluates the FIR.  The reference's logical input is delayBuf ++ in, cut into a 1 ms and a (inLen - 1 ms) call whose
+ * batches restart the fractional index at 0.  Rb: i32[36 + 480 + 4] of LDS.  Any other method falls back to the single-lane routine. */
+template <class InP> WV_DEV void se_resample_wave(WV_LDS i32 *cfgw, WV_LDS i32 *rows, WV_LDS SeRsLds *R, WV_LDS i32 *Rb, WV_LDS i16 *out, InP in, int inLen)
+{
+   const OaResamplerCfg c = se_rs_cfg(cfgw);
+   const int nd = c.inputDelay, lane = wv_lane();
+   wv_sync();
+   if (c.resampler_function == OA_RS_FN_COPY) {
+      FOR_LANES(k, inLen) out[k] = k < nd ? (i16)rows[OA_RS_ROW_DELAY + k] : (i16)in[k - nd];
+      wv_sync();
+      FOR_LANES(j, nd) rows[OA_RS_ROW_DELAY + j] = in[inLen - nd + j];
+      wv_sync();
+      return;
+   }
+   if (c.resampler_function != OA_RS_FN_DOWN_FIR) { LANE0 silk_resampler_lane(c, R, rows, 1, in, inLen, out, 0); return; }
+   const int ord = c.FIR_Order;
+   const i16 *C = rs_coefs(c.coefs_id), *F = C + 2;
+   const i32 C0 = C[0], C1 = C[1], inv = c.invRatio_Q16;
+   i32 iir0 = rows[OA_RS_ROW_IIR], iir1 = rows[OA_RS_ROW_IIR + 1];
+   FOR_LANES(j, ord) Rb[j] = rows[OA_RS_ROW_FIR + j];
+   int pos = 0, no = 0;
+   for (int seg = 0; seg < 2; seg++) {
+      const int len = seg == 0 ? c.Fs_in_kHz : inLen - c.Fs_in_kHz;
+      for (int done = 0; done < len;) {
+         const int nIn = imin(len - done, c.batchSize);
+         FOR_LANES(k, nIn) { const int q = pos + k; Rb[ord + k] = q < nd ? rows[OA_RS_ROW_DELAY + q] : (i32)in[q - nd]; }
+         wv_sync();
+         if (lane == 0) {                                                            /* silk_resampler_private_AR2 (resampler_private_AR2.c:36) */
+            WV_LDS i32 *x = Rb + ord;
+            int k = 0;
+            for (; k + 4 <= nIn; k += 4) {
+               const i32 s0 = x[k], s1 = x[k + 1], s2 = x[k + 2], s3 = x[k + 3];
+               i32 o;
+               o = iir0 + shl32(s0, 8); x[k] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s1, 8); x[k + 1] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s2, 8); x[k + 2] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s3, 8); x[k + 3] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+            }
+            for (; k < nIn; k++) { i32 o = iir0 + shl32(x[k], 8); x[k] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1); }
+         }
+         wv_sync();
+         const int nOut = (int)((((i64)nIn << 16) + inv - 1) / inv);                   /* index_Q16 = 0, inv, 2 inv, ... < nIn << 16 */
+         FOR_LANES(j, nOut) {
+            const i32 idx = j * inv; const int b = idx >> 16;
+            i32 a;
+            if (ord == 18) {                                                          /* resampler_private_down_FIR.c:56-86 */
+               const int ph = sk_mulwb(idx & 0xFFFF, c.FIR_Fracs);
+               const i16 *c0 = &F[9 * ph], *c1 = &F[9 * (c.FIR_Fracs - 1 - ph)];
+               a = sk_mulwb(Rb[b], c0[0]);
+               for (int t = 1; t < 9; t++) a = sk_mlawb(a, Rb[b + t], c0[t]);
+               for (int t = 0; t < 9; t++) a = sk_mlawb(a, Rb[b + 17 - t], c1[t]);
+            } else {                                                                  /* :88-141, symmetric 24 / 36 taps */
+               a = sk_mulwb(Rb[b] + Rb[b + ord - 1], F[0]);
+               for (int t = 1; t < ord / 2; t++) a = sk_mlawb(a, Rb[b + t] + Rb[b + ord - 1 - t], F[t]);
+            }
+            out[no + j] = (i16)sk_sat16(sk_rround(a, 6));
+         }
+         wv_sync();
+         { const i32 t = lane < ord ? Rb[nIn + lane] : 0; wv_sync(); if (lane < ord) Rb[lane] = t; wv_sync(); }   /* the tail becomes the head of the next batch */
+         no += nOut; pos += nIn; done += nIn;
+      }
+   }
+   LANE0 { rows[OA_RS_ROW_IIR] = iir0; rows[OA_RS_ROW_IIR + 1] = iir1; }
+   FOR_LANES(j, ord) rows[OA_RS_ROW_FIR + j] = Rb[j];
+   FOR_LANES(j, nd) rows[OA_RS_ROW_DELAY + j] = in[inLen - nd + j];
+   wv_sync();
+}
+
 /* ---- silk_setup_resamplers (control_codec.c:134): on a change of internal rate the buffered signal is carried over by resampling it up to the API
  * rate and down again.  tmp: i16[(2 * 20 + 5) * 48] scratch ---- */
 WV_DEV void se_setup_resamplers(WV_LDS OaSilkEncChannel *c, int fs_kHz, WV_LDS SeRsLds *R, WV_LDS i16 *tmp, WV_LDS i32 *tmp_rs)

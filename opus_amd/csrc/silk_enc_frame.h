@@ -34,7 +34,7 @@ struct SilkEncLds {
    i32 tmp_rs[99 + 1];
    i32 r[16];                                          /* lane-0 hand-off words */
    i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM) */
-   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; } u;
+   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; } u;
    OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.ch[1] */
 };
 #define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
@@ -530,30 +530,30 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
    while (1) {
       int nSamplesToBuffer = imin(c0->frame_length - c0->inputBufIx, nSamplesToBufferMax);
       const int nSamplesFromInput = (nSamplesToBuffer * c0->API_fs_Hz) / (c0->fs_kHz * 1000);
-      LANE0 {
+      {  /* resample this call's input to the internal rate, buffer it (enc_API.c:283-340) */
+         const int ix0 = c0->inputBufIx;
          if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
-            const int id = c0->nFramesEncoded;
-            if (E->nPrevChannelsInternal == 1 && id == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; }
+            const int ix1 = c1->inputBufIx;
+            LANE0 { if (E->nPrevChannelsInternal == 1 && c0->nFramesEncoded == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; } }
             SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
-            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], s0, nSamplesFromInput);
-            c0->inputBufIx += nSamplesToBuffer;
-            const int n1 = imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz);
-            se_resample_l0(c1->rs_cfg, c1->rs_rows, &S->rs, &c1->inputBuf[c1->inputBufIx + 2], s1, nSamplesFromInput);
-            c1->inputBufIx += n1;
+            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
+            se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], s1, nSamplesFromInput);
+            LANE0 { c0->inputBufIx += nSamplesToBuffer; c1->inputBufIx += imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz); }
          } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
             SePcmSrc sm = {pcm, 2, 0, 1};
-            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], sm, nSamplesFromInput);
+            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], sm, nSamplesFromInput);
             if (E->nPrevChannelsInternal == 2 && c0->nFramesEncoded == 0) {
-               se_resample_l0(c1->rs_cfg, c1->rs_rows, &S->rs, &c1->inputBuf[c1->inputBufIx + 2], sm, nSamplesFromInput);
-               for (int n = 0; n < c0->frame_length; n++) c0->inputBuf[c0->inputBufIx + n + 2] = (i16)((c0->inputBuf[c0->inputBufIx + n + 2] + c1->inputBuf[c1->inputBufIx + n + 2]) >> 1);
+               const int ix1 = c1->inputBufIx;
+               se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], sm, nSamplesFromInput);
+               FOR_LANES(n, c0->frame_length) c0->inputBuf[ix0 + n + 2] = (i16)((c0->inputBuf[ix0 + n + 2] + c1->inputBuf[ix1 + n + 2]) >> 1);
             }
-            c0->inputBufIx += nSamplesToBuffer;
+            LANE0 c0->inputBufIx += nSamplesToBuffer;
          } else {
             SePcmSrc s0 = {pcm, 1, 0, 0};
-            se_resample_l0(c0->rs_cfg, c0->rs_rows, &S->rs, &c0->inputBuf[c0->inputBufIx + 2], s0, nSamplesFromInput);
-            c0->inputBufIx += nSamplesToBuffer;
+            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
+            LANE0 c0->inputBufIx += nSamplesToBuffer;
          }
-         E->allowBandwidthSwitch = 0;
+         LANE0 E->allowBandwidthSwitch = 0;
       }
       pcm += nSamplesFromInput * ec->nChannelsAPI;
       nSamplesIn -= nSamplesFromInput;

@@ -36,6 +36,13 @@ def test_emu_silk_encode_levels(gain):
     """digital silence, a few LSBs (the low-level branches of the Burg recursion and the correlation scalings), and clipping input"""
     run_silk(14, gain=gain); run_silk(8, gain=gain, ch=2, bitRate=36000, complexity=4)
 @pytest.mark.parametrize("kw", [
+    dict(fs=24000), dict(fs=24000, desiredInternalSampleRate=12000, maxInternalSampleRate=12000, bitRate=16000), dict(fs=24000, desiredInternalSampleRate=8000, maxInternalSampleRate=8000, bitRate=12000),
+    dict(fs=48000, desiredInternalSampleRate=12000, maxInternalSampleRate=12000, bitRate=16000), dict(fs=48000, ch=2, desiredInternalSampleRate=8000, maxInternalSampleRate=8000, bitRate=20000),
+    dict(fs=12000, bitRate=16000), dict(fs=12000, desiredInternalSampleRate=8000, maxInternalSampleRate=8000, bitRate=12000), dict(fs=8000, bitRate=12000), dict(fs=48000, ms=10)])
+def test_emu_silk_encode_resampler_ratios(kw):
+    """every input-resampler method the encoder can select: copy, 1/2, 2/3, 3/4 (18-tap interpolated), 1/3, 1/4, 1/6 (symmetric 24 / 36 taps)"""
+    run_silk(8, **dict(kw))
+@pytest.mark.parametrize("kw", [
     dict(desiredInternalSampleRate=8000, maxInternalSampleRate=8000, bitRate=12000), dict(desiredInternalSampleRate=12000, maxInternalSampleRate=12000, bitRate=16000),
     dict(ms=10), dict(fs=48000), dict(useCBR=1, maxBits=60 * 8), dict(maxBits=40 * 8, bitRate=32000), dict(ch=2, bitRate=40000), dict(ch=2, fs=48000, bitRate=36000, complexity=5),
     dict(ch=2, chi=1), dict(ms=40), dict(ms=60, ch=2, bitRate=30000), dict(bitRate=6000, desiredInternalSampleRate=8000, maxInternalSampleRate=8000)])
