@@ -2,7 +2,8 @@
  * src/opus_multistream_encoder.c, src/opus_multistream_decoder.c) on top of the batch kernels: the streams of one multistream
  * frame are independent CELT encodes / decodes, so ONE launch per group (coupled streams, mono streams) does a whole frame of up to
  * 255 channels.  Host code only orchestrates: layout, rate allocation, channel (de)interleaving, self-delimited packing.
- * Scope: CELT-only applications (restricted-lowdelay / restricted-celt) at 48 kHz, frames <= 20 ms, mapping families 0, 2, 255 and
+ * Scope: every application (the CELT-only ones run the CELT kernel, VOIP / AUDIO / RESTRICTED_SILK the SILK-capable kernel with the mode decisions
+ * that kernel builds), mapping families 0, 2, 255 and
  * family 1 up to two channels (the surround masking analysis of family 1 with > 2 channels is not built -> OPUS_UNIMPLEMENTED). */
 #ifndef OPUS_AMD_MS_HOST_H
 #define OPUS_AMD_MS_HOST_H
@@ -42,12 +43,12 @@ static int oa_validate_ambisonics(int nb_channels, int *nb_streams, int *nb_coup
 static std::mutex g_ms_mu;
 static std::map<long, OpusGpuEncBatch *> g_ms_enc;
 static std::map<long, OpusGpuDecBatch *> g_ms_dec;
-static OpusGpuEncBatch *oa_ms_enc_batch(int n, int channels, int application, int *err)
+static OpusGpuEncBatch *oa_ms_enc_batch(int n, int channels, int application, opus_int32 Fs, int *err)
 {
-   long key = (long)n * 4 + channels;
+   long key = (((long)n * 4 + channels) * 64 + Fs / 1000) * 2 + oa_app_is_sh(application);
    auto it = g_ms_enc.find(key);
    if (it != g_ms_enc.end()) return it->second;
-   OpusGpuEncBatch *b = opusgpu_enc_batch_create(n, 48000, channels, application, 0, err);
+   OpusGpuEncBatch *b = opusgpu_enc_batch_create(n, Fs, channels, application, 0, err);
    if (b) g_ms_enc[key] = b;
    return b;
 }
@@ -63,12 +64,18 @@ static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, int *err)
 
 #define OA_MS_MAGIC 0x4f414d53u
 enum { OA_MAP_NONE = 0, OA_MAP_SURROUND = 1, OA_MAP_AMBISONICS = 2 };
+/* one elementary encoder: the CELT-only record or the SILK-capable one, by application (opus_multistream_encoder_get_size does not know the
+ * application, so every record has room for either) */
+union OaMsRec { OaStream c; OaShStream sh; };
 struct OpusMSEncoder {
    opus_uint32 magic; opus_int32 Fs, application, bitrate_bps, mapping_type, lfe_stream;
    OaLayout layout;
-   opus_int32 pad[2];
-   OaStream streams[1];            /* nb_streams records: coupled streams first, then mono (flat, memcpy-able) */
+   opus_int32 kind, pad;           /* kind 1: records are OaShStream */
+   OaMsRec streams[1];             /* nb_streams records: coupled streams first, then mono (flat, memcpy-able) */
 };
+static int oa_ms_rec_init(OaMsRec *r, int kind, opus_int32 Fs, int ch, int application) { return kind ? sh_init_stream(&r->sh, Fs, ch, application) : oa_init_stream(&r->c, Fs, ch, application); }
+static int oa_ms_rec_set(OaMsRec *r, int kind, int request, opus_int32 v) { return kind ? sh_ctl_set(&r->sh, request, v) : oa_ctl_set(&r->c, request, v); }
+static int oa_ms_rec_get(const OaMsRec *r, int kind, int request, opus_int32 *v) { return kind ? sh_ctl_get(&r->sh, request, v) : oa_ctl_get(&r->c, request, v); }
 struct OpusMSDecoder {
    opus_uint32 magic; opus_int32 Fs;
    OaLayout layout;
@@ -81,24 +88,26 @@ extern "C" {
 opus_int32 opus_multistream_encoder_get_size(int nb_streams, int nb_coupled_streams)
 {
    if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;
-   return (opus_int32)(sizeof(OpusMSEncoder) + (size_t)(nb_streams - 1) * sizeof(OaStream));
+   return (opus_int32)(sizeof(OpusMSEncoder) + (size_t)(nb_streams - 1) * sizeof(OaMsRec));
 }
 static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application, int mapping_type, int lfe_stream)
 {
    if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams || streams + coupled_streams > channels)
       return OPUS_BAD_ARG;
-   OaStream probe;
-   int r = oa_init_stream(&probe, Fs, 2, application);
+   const int kind = oa_app_is_sh(application);
+   int r;
+   { OaMsRec *probe = new OaMsRec; r = oa_ms_rec_init(probe, kind, Fs, 2, application); delete probe; }
    if (r != OPUS_OK) return r;
    if (mapping_type == OA_MAP_SURROUND) return OPUS_UNIMPLEMENTED;
-   memset(st, 0, sizeof(OpusMSEncoder) - sizeof(OaStream));
+   memset(st, 0, sizeof(OpusMSEncoder) - sizeof(OaMsRec));
+   st->kind = kind;
    st->magic = OA_MS_MAGIC; st->Fs = Fs; st->application = application; st->bitrate_bps = OPUS_AUTO; st->mapping_type = mapping_type; st->lfe_stream = lfe_stream;
    st->layout.nb_channels = channels; st->layout.nb_streams = streams; st->layout.nb_coupled_streams = coupled_streams;
    for (int i = 0; i < channels; i++) st->layout.mapping[i] = mapping[i];
    if (!oa_validate_layout(&st->layout) || !oa_validate_encoder_layout(&st->layout)) return OPUS_BAD_ARG;
    if (mapping_type == OA_MAP_AMBISONICS && !oa_validate_ambisonics(channels, NULL, NULL)) return OPUS_BAD_ARG;
    for (int s = 0; s < streams; s++) {
-      r = oa_init_stream(&st->streams[s], Fs, s < coupled_streams ? 2 : 1, application);
+      r = oa_ms_rec_init(&st->streams[s], kind, Fs, s < coupled_streams ? 2 : 1, application);
       if (r != OPUS_OK) return r;
    }
    return OPUS_OK;
@@ -209,18 +218,20 @@ static opus_int32 oa_ms_rate_allocation(const OpusMSEncoder *st, opus_int32 *rat
 }
 
 /* encode n streams of one group (all `ch`-channel) in one launch; states are loaded from / stored back to the flat blob */
-static int oa_ms_encode_group(OaStream *states, int n, int ch, int application, const opus_int16 *pcm, int frame_size, opus_int32 max_data_bytes,
+static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, int ch, int application, const opus_int16 *pcm, int frame_size, opus_int32 max_data_bytes,
       unsigned char *out /* [n][1280] */, opus_int32 *lens, opus_uint32 *rngs)
 {
    int err = OPUS_OK;
-   OpusGpuEncBatch *b = oa_ms_enc_batch(n, ch, application, &err);
+   OpusGpuEncBatch *b = oa_ms_enc_batch(n, ch, application, Fs, &err);
    if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   HIPCHECK(hipMemcpy(b->d_streams, states, sizeof(OaStream) * (size_t)n, hipMemcpyHostToDevice));
+   if (kind) HIPCHECK(hipMemcpy2D(b->d_sh, sizeof(OaShStream), &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), (size_t)n, hipMemcpyHostToDevice));
+   else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].c, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
    int r = opusgpu_encode_batch(b, pcm, frame_size, out, 1280, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
-   HIPCHECK(hipMemcpy(states, b->d_streams, sizeof(OaStream) * (size_t)n, hipMemcpyDeviceToHost));
+   if (kind) HIPCHECK(hipMemcpy2D(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), sizeof(OaShStream), (size_t)n, hipMemcpyDeviceToHost));
+   else HIPCHECK(hipMemcpy2D(&states[0].c, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), sizeof(OaStream), (size_t)n, hipMemcpyDeviceToHost));
    return OPUS_OK;
 }
 
@@ -235,7 +246,8 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
       if (25 * frame_size == Fs || 50 * frame_size == 3 * Fs || 50 * frame_size == 4 * Fs || 50 * frame_size == 5 * Fs || 50 * frame_size == 6 * Fs) return OPUS_UNIMPLEMENTED;
       return OPUS_BAD_ARG;
    }
-   const int vbr = st->streams[0].cfg.use_vbr;
+   const int kind = st->kind;
+   const int vbr = kind ? st->streams[0].sh.cfg.use_vbr : st->streams[0].c.cfg.use_vbr;
    opus_int32 smallest_packet = ns * 2 - 1;
    if (Fs / frame_size == 10) smallest_packet += ns;
    if (max_data_bytes < smallest_packet) return OPUS_BUFFER_TOO_SMALL;
@@ -250,7 +262,10 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
          if (m < max_data_bytes) max_data_bytes = m;
       }
    }
-   for (int s = 0; s < ns; s++) st->streams[s].cfg.user_bitrate_bps = bitrates[s];
+   for (int s = 0; s < ns; s++) {
+      if (kind) { st->streams[s].sh.cfg.user_bitrate_bps = bitrates[s]; if (st->mapping_type == OA_MAP_AMBISONICS) st->streams[s].sh.cfg.user_forced_mode = 1002; /* MODE_CELT_ONLY (:981) */ }
+      else st->streams[s].c.cfg.user_bitrate_bps = bitrates[s];
+   }
    /* channel de-interleave into the two groups */
    std::vector<opus_int16> pc((size_t)nc * frame_size * 2 + 2), pm((size_t)nm * frame_size + 1);
    for (int s = 0; s < nc; s++) {
@@ -275,8 +290,8 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
    opus_int32 tot_size = 0;
    unsigned char *out = data;
    if (parallel) {
-      if (nc) r = oa_ms_encode_group(st->streams, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), lens.data(), rngs.data());
-      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * 1280, lens.data() + nc, rngs.data() + nc);
+      if (nc) r = oa_ms_encode_group(st->streams, kind, Fs, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), lens.data(), rngs.data());
+      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, kind, Fs, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * 1280, lens.data() + nc, rngs.data() + nc);
       if (r != OPUS_OK) return r;
    }
    for (int s = 0; s < ns; s++) {
@@ -289,10 +304,10 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
          if (Fs / frame_size == 10) curr_max -= ns - s - 1;
          if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
          if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
-         if (!vbr && s == ns - 1) st->streams[s].cfg.user_bitrate_bps = curr_max * 8 * (6 * Fs / frame_size) / 6;
+         if (!vbr && s == ns - 1) { const opus_int32 br = curr_max * 8 * (6 * Fs / frame_size) / 6; if (kind) st->streams[s].sh.cfg.user_bitrate_bps = br; else st->streams[s].c.cfg.user_bitrate_bps = br; }
          if (curr_max <= 0) return OPUS_BUFFER_TOO_SMALL;
-         if (s < nc) r = oa_ms_encode_group(st->streams + s, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
-         else r = oa_ms_encode_group(st->streams + s, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
+         if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
+         else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
          if (r != OPUS_OK) return r;
       }
       if (lens[s] < 0) return lens[s];
@@ -325,24 +340,24 @@ int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
       opus_int32 *value = va_arg(ap, opus_int32 *);
       if (!value) { ret = OPUS_BAD_ARG; break; }
       *value = 0;
-      for (int s = 0; s < ns; s++) { opus_int32 r = 0; oa_ctl_get(&st->streams[s], request, &r); *value += r; }
+      for (int s = 0; s < ns; s++) { opus_int32 r = 0; oa_ms_rec_get(&st->streams[s], st->kind, request, &r); *value += r; }
    } break;
    case OPUS_GET_FINAL_RANGE_REQUEST: {
       opus_uint32 *value = va_arg(ap, opus_uint32 *);
       if (!value) { ret = OPUS_BAD_ARG; break; }
       *value = 0;
-      for (int s = 0; s < ns; s++) *value ^= st->streams[s].st.s.rangeFinal;
+      for (int s = 0; s < ns; s++) *value ^= st->kind ? st->streams[s].sh.s.rangeFinal : st->streams[s].c.st.s.rangeFinal;
    } break;
    case OPUS_RESET_STATE:
-      for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = oa_ctl_set(&st->streams[s], request, 0);
+      for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = oa_ms_rec_set(&st->streams[s], st->kind, request, 0);
       break;
    default:
       if (request & 1) {           /* GET: answered by the first stream (opus_multistream_encoder.c:1196-1219) */
          opus_int32 *value = va_arg(ap, opus_int32 *);
-         if (!value) ret = OPUS_BAD_ARG; else ret = oa_ctl_get(&st->streams[0], request, value);
+         if (!value) ret = OPUS_BAD_ARG; else ret = oa_ms_rec_get(&st->streams[0], st->kind, request, value);
       } else {                     /* SET: applied to every stream (:1245-1278) */
          opus_int32 value = va_arg(ap, opus_int32);
-         for (int s = 0; s < ns; s++) { ret = oa_ctl_set(&st->streams[s], request, value); if (ret != OPUS_OK) break; }
+         for (int s = 0; s < ns; s++) { ret = oa_ms_rec_set(&st->streams[s], st->kind, request, value); if (ret != OPUS_OK) break; }
       }
    }
    va_end(ap);

@@ -53,6 +53,7 @@ def _run(mk_enc, dec_layout, channels, frame, nframes, maxb, ctls=(), seed=1):
         assert d and err.value == 0
         decs.append(d)
     sig = _sig(channels, nframes * frame // 960 + 1, seed)
+    tocs = set()
     for i in range(nframes):
         pcm = np.ascontiguousarray(sig[i * frame:(i + 1) * frame])
         outs = []
@@ -63,6 +64,7 @@ def _run(mk_enc, dec_layout, channels, frame, nframes, maxb, ctls=(), seed=1):
         assert outs[0] == outs[1], (i, outs[0][0], outs[1][0], outs[0][2], outs[1][2])
         if outs[0][0] <= 0: continue
         pkt = outs[1][1]
+        tocs.add(pkt[0] >> 3)
         dres = []
         for L, d in zip((A, R), decs):
             o = np.full((frame, out_ch), 7, np.int16)
@@ -71,20 +73,21 @@ def _run(mk_enc, dec_layout, channels, frame, nframes, maxb, ctls=(), seed=1):
         assert dres[0][0] == dres[1][0] == frame and dres[0][2] == dres[1][2] == outs[0][2], (i, dres[0][0], dres[1][0])
         assert np.array_equal(dres[0][1], dres[1][1]), (i, np.argwhere(dres[0][1] != dres[1][1])[:4])
     for L, e, d in zip((A, R), encs, decs): L.opus_multistream_encoder_destroy(e); L.opus_multistream_decoder_destroy(d)
+    return tocs                                                                      # TOC configurations of the first elementary stream
 
-def _explicit(channels, streams, coupled, mapping):
+def _explicit(channels, streams, coupled, mapping, app=2051):
     def mk(L):
         err = ctypes.c_int()
-        e = L.opus_multistream_encoder_create(48000, channels, streams, coupled, bytes(mapping), 2051, ctypes.byref(err))
+        e = L.opus_multistream_encoder_create(48000, channels, streams, coupled, bytes(mapping), app, ctypes.byref(err))
         assert e and err.value == 0, err.value
         return e
     return mk
 
-def _family(channels, family):
+def _family(channels, family, app=2051):
     info = {}
     def mk(L):
         err = ctypes.c_int(); s = ctypes.c_int(); c = ctypes.c_int(); m = (ctypes.c_ubyte * 256)()
-        e = L.opus_multistream_surround_encoder_create(48000, channels, family, ctypes.byref(s), ctypes.byref(c), m, 2051, ctypes.byref(err))
+        e = L.opus_multistream_surround_encoder_create(48000, channels, family, ctypes.byref(s), ctypes.byref(c), m, app, ctypes.byref(err))
         assert e and err.value == 0, err.value
         got = (s.value, c.value, list(m[:channels]))
         assert info.setdefault("layout", got) == got
@@ -107,6 +110,23 @@ def test_ms_mapping_families(channels, family):
     probe = mk(R); R.opus_multistream_encoder_destroy(probe)
     s, c, m = info["layout"]
     _run(mk, (s, c, m, channels), channels, 960, 4 if channels > 64 else 8, 255 * 1300 + 9000)
+
+@pytest.mark.parametrize("channels,family,app", [(255, 255, 2049), (6, 255, 2049), (9, 2, 2049), (2, 1, 2049), (3, 255, 2048)])
+def test_ms_general_applications(channels, family, app):
+    """BASELINE config 5 as specified (255 mono streams, OPUS_APPLICATION_AUDIO) and the other non-restricted applications: the elementary encoders are
+    the SILK-capable records, every stream makes the reference's own mode decision (CELT-only at these rates; ambisonics forces it)"""
+    mk, info = _family(channels, family, app)
+    A, R = _libs()
+    probe = mk(R); R.opus_multistream_encoder_destroy(probe)
+    s, c, m = info["layout"]
+    _run(mk, (s, c, m, channels), channels, 960, 4 if channels > 64 else 8, 255 * 1300 + 9000)
+
+def test_ms_voip_low_rate_streams_are_silk():
+    """two mono + one coupled stream at speech rates: the elementary encoders choose SILK-only / hybrid"""
+    mapping = [0, 1, 2, 3]
+    t1 = _run(_explicit(4, 3, 1, mapping, app=2048), (3, 1, mapping, 4), 4, 960, 10, 40000, ctls=[(4002, 72000), (4010, 6)])
+    t2 = _run(_explicit(2, 2, 0, [0, 1], app=2049), (2, 0, [0, 1], 2), 2, 960, 10, 40000, ctls=[(4002, 24000), (4024, 3001)])      # AUDIO, signal hint voice
+    assert min(t1) < 16 and min(t2) < 16, (t1, t2)                                    # configurations 0-11 SILK-only, 12-15 hybrid
 
 def test_ms_tight_buffer_and_cbr_go_stream_by_stream():
     mapping = [0, 1, 2, 3]
