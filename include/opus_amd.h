@@ -69,6 +69,7 @@ extern "C" {
 #define OPUS_GET_PACKET_LOSS_PERC_REQUEST 4015
 #define OPUS_SET_DTX_REQUEST 4016
 #define OPUS_GET_DTX_REQUEST 4017
+#define OPUS_GET_IN_DTX_REQUEST 4049
 #define OPUS_SET_VBR_CONSTRAINT_REQUEST 4020
 #define OPUS_GET_VBR_CONSTRAINT_REQUEST 4021
 #define OPUS_SET_FORCE_CHANNELS_REQUEST 4022

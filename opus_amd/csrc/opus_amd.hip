@@ -197,6 +197,13 @@ static int sh_ctl_get(const OaShStream *st, int request, opus_int32 *value)
    case OPUS_GET_DTX_REQUEST: *value = c->use_dtx; return OPUS_OK;
    case OPUS_GET_SAMPLE_RATE_REQUEST: *value = c->Fs; return OPUS_OK;
    case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)st->s.rangeFinal; return OPUS_OK;
+   case OPUS_GET_IN_DTX_REQUEST:                                                    /* src/opus_encoder.c:3299-3322 */
+      if (st->s.sm_useDTX && (st->s.prev_mode == OA_MODE_SILK_ONLY || st->s.prev_mode == OA_MODE_HYBRID)) {
+         *value = st->silk.ch[0].noSpeechCounter >= 10;
+         if (*value == 1 && st->silk.nChannelsInternal == 2 && st->silk.prev_decode_only_middle == 0) *value = st->silk.ch[1].noSpeechCounter >= 10;
+      } else if (c->use_dtx) *value = st->s.nb_no_activity_ms_Q1 >= 10 * 20 * 2;
+      else *value = 0;
+      return OPUS_OK;
    default: return OPUS_UNIMPLEMENTED;
    }
 }
@@ -322,7 +329,8 @@ int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipStreamSynchronize(b->stream));
    if (b->kind) {
       OaShStream *t = new OaShStream(b->h_sh[stream]);
-      hipError_t e_ = hipMemcpy(&t->s, &b->d_sh[stream].s, sizeof(OaShScalars), hipMemcpyDeviceToHost);
+      hipError_t e_ = request == OPUS_GET_IN_DTX_REQUEST ? hipMemcpy(t, &b->d_sh[stream], sizeof(OaShStream), hipMemcpyDeviceToHost)      /* needs the SILK channel counters */
+                                                         : hipMemcpy(&t->s, &b->d_sh[stream].s, sizeof(OaShScalars), hipMemcpyDeviceToHost);
       const int r = e_ == hipSuccess ? sh_ctl_get(t, request, value) : OPUS_INTERNAL_ERROR;
       delete t;
       return r;

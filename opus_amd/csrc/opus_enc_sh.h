@@ -143,7 +143,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       st->stream_channels = equiv_rate > thr ? 2 : 1;
    } else st->stream_channels = channels;
    equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
-   if (cfg->use_dtx && !sh->is_silence) { sh->err = OA_ERR_UNIMPLEMENTED; return; }              /* SILK DTX */
+   st->sm_useDTX = cfg->use_dtx && !sh->is_silence;                                               /* :1463: SILK's own DTX; digital silence takes the generalised one */
    /* mode (:1487-1560) */
    if (cfg->application == OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_SILK_ONLY;
    else if (cfg->user_forced_mode == OA_AUTO) {
@@ -154,6 +154,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       if (cfg->application == OA_APP_VOIP) threshold += 8000;
       if (st->prev_mode == OA_MODE_CELT_ONLY) threshold -= 4000; else if (st->prev_mode > 0) threshold += 4000;
       st->mode = equiv_rate >= threshold ? OA_MODE_CELT_ONLY : OA_MODE_SILK_ONLY;
+      if (st->sm_useDTX && voice_est > 100) st->mode = OA_MODE_SILK_ONLY;                          /* :1521 */
       if (max_data_bytes < bitrate_to_bits(frame_rate > 50 ? 9000 : 6000, Fs, frame_size) / 8) st->mode = OA_MODE_CELT_ONLY;
    } else st->mode = cfg->user_forced_mode;
    if (st->mode != OA_MODE_CELT_ONLY && frame_size < Fs / 100) st->mode = OA_MODE_CELT_ONLY;
@@ -273,6 +274,22 @@ WV_DEV i32 sh_silk_rate_for_hybrid(i32 rate, int bandwidth, int frame20ms, int v
 }
 
 /* stereo-width decision and the fade gains of the CELT input (:2365-2400), then the per-call bookkeeping (:2596-2600); silk_width = the width SILK reported */
+/* the generalised DTX decision at the end of opus_encode_frame_native (:2565-2576, decide_dtx_mode :1115): without the float analysis it only ever sees
+ * digital silence (SILK's own DTX covers the rest); after 200 ms of it the packet is the TOC byte alone, at most 400 ms in a row */
+WV_DEV int sh_generalised_dtx_l0(WV_LDS ShLds *L, int frame_size, int Fs)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   if (L->cfg.use_dtx && !st->sm_useDTX) {
+      int dtx = 0;
+      if (!sh->activity) {
+         st->nb_no_activity_ms_Q1 += 2 * 1000 * frame_size / Fs;
+         if (st->nb_no_activity_ms_Q1 > 10 * 20 * 2) { if (st->nb_no_activity_ms_Q1 <= (10 + 20) * 20 * 2) dtx = 1; else st->nb_no_activity_ms_Q1 = 10 * 20 * 2; }
+      } else st->nb_no_activity_ms_Q1 = 0;
+      return dtx;
+   }
+   st->nb_no_activity_ms_Q1 = 0;
+   return 0;
+}
 WV_DEV void sh_width_and_bookkeeping_l0(WV_LDS ShLds *L, int frame_size, i32 silk_width)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
@@ -372,6 +389,7 @@ WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm
    LANE0 printf("hyb end: toc %d pk0 %d ret %d rng %u\n", fs->toc, F->packet[0], fs->ret, F->st.rangeFinal);
 #endif
    {
+      LANE0 { if (fs->ret >= 0 && sh_generalised_dtx_l0(L, frame_size, Fs)) { F->st.rangeFinal = 0; F->packet[0] = (u8)fs->toc; fs->ret = 1; fs->pad_to = 0; } }
       const int nbytes = emit_packet_wave(F, out, fs->ret, fs->pad_to, out_cap);
       LANE0 { *len_out = nbytes; *rng_out = F->st.rangeFinal; st->rangeFinal = F->st.rangeFinal; }
       wv_sync();
@@ -465,7 +483,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
          if (effective_max_rate < 8000) { sc.maxInternalSampleRate = 12000; sc.desiredInternalSampleRate = imin(12000, sc.desiredInternalSampleRate); }
          if (effective_max_rate < 7000) { sc.maxInternalSampleRate = 8000; sc.desiredInternalSampleRate = imin(8000, sc.desiredInternalSampleRate); }
       }
-      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = 0; sc.useDTX = 0;
+      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = 0; sc.useDTX = st->sm_useDTX;
       sc.useCBR = !L->cfg.use_vbr;
       sc.maxBits = (sh->max_data_bytes - 1) * 8;
       if (mode == OA_MODE_HYBRID) {                                                  /* :2136-2160 */
@@ -488,7 +506,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       st->sm_opusCanSwitch = sc.switchReady;                                          /* (!nonfinal_frame: single-packet calls only) */
       const int nBytes = L->S.r[0];
       int ret;
-      if (nBytes == 0) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); ret = 1; }
+      if (nBytes == 0) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); ret = 1; sh->pad_to = 0; }   /* SILK DTX (:2242): straight out, no bookkeeping */
       else {
          if (st->sm_opusCanSwitch) {
             if (L->cfg.application != OA_APP_RESTRICTED_SILK) st->error = OA_ERR_UNIMPLEMENTED;          /* the next frame would need a redundant CELT frame */
@@ -517,7 +535,8 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
          sh->ret = ret;
          }
       }
-      if (nBytes == 0) { sh->ret = ret; st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0; }
+      if (nBytes == 0) sh->ret = ret;
+      else if (sh->ret >= 0 && sh_generalised_dtx_l0(L, frame_size, Fs)) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); sh->ret = 1; sh->pad_to = 0; }
    }
    if (sh->ret == -1000) { SE_CLK_BEGIN(); sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); SE_CLK_END(16); return; }
    /* ---- store packet + state (coalesced) ---- */

@@ -21,7 +21,8 @@ struct OaShScalars {
    int32_t sm_toMono, sm_opusCanSwitch, sm_allowBandwidthSwitch, sm_inWBmodeWithoutVariableLP, sm_stereoWidth_Q14, sm_LBRR_coded, sm_switchReady;
    /* compute_stereo_width state (StereoWidthState, src/opus_encoder.c:62-68) */
    int32_t wm_XX, wm_XY, wm_YY, wm_smoothed_width, wm_max_follower;
-   int32_t pad0[6];
+   int32_t nb_no_activity_ms_Q1, sm_useDTX;             /* generalised DTX counter (decide_dtx_mode, src/opus_encoder.c:1115); silk_mode.useDTX of the last frame */
+   int32_t pad0[4];
 };
 #define OA_SH_MAX_DELAY 480                              /* encoder_buffer = Fs / 100 samples per channel */
 struct OaShStream {

@@ -5,7 +5,7 @@ import ctypes, numpy as np, pytest
 from reflib import ref_fx
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")]
-REQ = dict(bitrate=4002, vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, bandwidth=4008, max_bandwidth=4004, force_mode=11002, signal=4024)
+REQ = dict(bitrate=4002, vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, bandwidth=4008, max_bandwidth=4004, force_mode=11002, signal=4024, dtx=4016)
 
 def speech(fs, secs, ch, seed):
     """SURVEY §8d config-3 signal: glottal-like harmonic source with vibrato, gated, over noise; one seed per stream"""
@@ -34,20 +34,27 @@ class RefOpusEnc:
         try: self.R.opus_encoder_destroy(self.enc)
         except Exception: pass
 
-def check(S, frames, Fs=16000, ch=1, app=2048, ms=20, max_bytes=1276, **ctl):
+def check(S, frames, Fs=16000, ch=1, app=2048, ms=20, max_bytes=1276, shape=None, **ctl):
     import opus_amd as oa
     b = oa.EncoderBatch(S, channels=ch, application=app, Fs=Fs)
     for k, v in ctl.items(): b.ctl(REQ[k], v)
     refs = [RefOpusEnc(Fs, ch, app, **ctl) for _ in range(S)]
     n = int(Fs * ms) // 1000
     sigs = [speech(Fs, frames * ms / 1000 + 0.1, ch, 10 + s) for s in range(S)]
+    if shape is not None: sigs = [shape(s, x, n) for s, x in enumerate(sigs)]
+    all_lens = []
     for f in range(frames):
         pcm = np.stack([np.ascontiguousarray(sigs[s][f * n:(f + 1) * n]).reshape(-1) for s in range(S)])
         pk, lens, rng = b.encode(pcm, n, max_bytes)
         for s in range(S):
             a = refs[s].encode(np.ascontiguousarray(sigs[s][f * n:(f + 1) * n]), n, max_bytes)
             assert (a[0], a[1], a[2]) == (pk[s], int(lens[s]), int(rng[s])), (f, s, a[1], int(lens[s]), hex(a[2]), hex(int(rng[s])))
+        all_lens.append([int(l) for l in lens])
+        if ctl.get("dtx"):
+            for s in range(S):
+                v = ctypes.c_int(-1); refs[s].R.opus_encoder_ctl(refs[s].enc, 4049, ctypes.byref(v)); assert b.get(4049, s) == v.value, (f, s, v.value)     # OPUS_GET_IN_DTX
     b.close()
+    return all_lens
 
 def test_gpu_config3_silk_voip_16k():
     """BASELINE config 3: VOIP 16 kHz mono, forced SILK-only, wideband, 20 ms, complexity 10, 24 kb/s VBR; 24 streams x 50 frame-steps"""
@@ -104,6 +111,18 @@ def test_gpu_silk_small_buffer():
     (48000, 2, 2048, 20, dict(bitrate=40000)), (16000, 2, 2048, 20, dict(bitrate=24000)),
 ])
 def test_gpu_celt_only_and_auto_modes_in_audio_voip(Fs, ch, app, ms, ctl): check(4, 25, Fs=Fs, ch=ch, app=app, ms=ms, **ctl)
+
+@pytest.mark.parametrize("Fs,ch,app,ctl", [
+    (16000, 1, 2048, dict(force_mode=1000, bitrate=20000)), (48000, 2, 2048, dict(bitrate=28000)),
+    (48000, 1, 2049, dict(force_mode=1001, bandwidth=1105, bitrate=40000)), (48000, 2, 2049, dict(bitrate=96000))])
+def test_gpu_dtx(Fs, ch, app, ctl):
+    """OPUS_SET_DTX: a noise-floor pause (SILK's own DTX) and a digital-silence pause (the generalised decision); TOC-only packets and OPUS_GET_IN_DTX must agree"""
+    def shape(s, x, n):
+        x = x.copy()
+        x[4 * n:26 * n] = ((np.arange(22 * n * ch).reshape(-1, ch) * 7919 % 5) - 2) if s % 2 == 0 else 0
+        return x
+    lens = check(4, 30, Fs=Fs, ch=ch, app=app, shape=shape, dtx=1, **ctl)
+    assert any(l[1] == 1 for l in lens[10:26])                                   # the digital-silence streams do go quiet
 
 def test_gpu_silk_unbuilt_paths_fail_loudly():
     import opus_amd as oa

@@ -52,8 +52,8 @@ def test_emu_silk_encode_matrix(kw):
 
 CFG = ["Fs", "channels", "application", "user_bitrate_bps", "use_vbr", "vbr_constraint", "complexity", "force_channels", "user_bandwidth", "max_bandwidth", "lsb_depth", "disable_inv",
        "packet_loss_perc", "user_forced_mode", "signal_type", "use_inband_fec", "use_dtx"]
-REQ = dict(user_bitrate_bps=4002, use_vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, user_bandwidth=4008, max_bandwidth=4004, user_forced_mode=11002, signal_type=4024, packet_loss_perc=4014)
-def run_opus(nframes, Fs=16000, ch=1, app=2048, ms=20, seed=1, max_bytes=1276, **kw):
+REQ = dict(user_bitrate_bps=4002, use_vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, user_bandwidth=4008, max_bandwidth=4004, user_forced_mode=11002, signal_type=4024, packet_loss_perc=4014, use_dtx=4016)
+def run_opus(nframes, Fs=16000, ch=1, app=2048, ms=20, seed=1, max_bytes=1276, shape=None, **kw):
     from silkenc_harness import build_emu, P
     E = build_emu(); R = ref_fx()
     R.opus_encoder_create.restype = ctypes.c_void_p; R.opus_encoder_ctl.argtypes = None; R.opus_encode.argtypes = None   # (other tests set prototypes on the shared handle)
@@ -64,14 +64,18 @@ def run_opus(nframes, Fs=16000, ch=1, app=2048, ms=20, seed=1, max_bytes=1276, *
         assert R.opus_encoder_ctl(enc, REQ[k], ctypes.c_int(v)) == 0; E.emu_sh_set_cfg(P(st), CFG.index(k), v)
     n = int(Fs * ms) // 1000
     pcm = signal(Fs, nframes * ms / 1000 + 0.1, ch, seed)
+    lens = []
     for f in range(nframes):
         x = pcm[f * n * ch:(f + 1) * n * ch].copy()
+        if shape is not None: x = shape(f, x)
         o0 = np.zeros(1500, np.uint8); l0 = R.opus_encode(enc, P(x), n, P(o0), max_bytes)
+        lens.append(l0)
         R.opus_encoder_ctl.argtypes = None; r0 = ctypes.c_uint32(0); R.opus_encoder_ctl(enc, 4031, ctypes.byref(r0))
         o1 = np.zeros(1500, np.uint8); l1 = np.zeros(1, np.int32); r1 = np.zeros(1, np.uint32)
         E.emu_sh_encode(P(st), P(x), n, max_bytes, P(o1), 1500, P(l1), P(r1))
         assert l0 == l1[0] and r0.value == r1[0] and np.array_equal(o0[:max(l0, 0)], o1[:max(l0, 0)]), (f, l0, int(l1[0]), r0.value, int(r1[0]))
     R.opus_encoder_destroy(enc)
+    return lens
 
 @pytest.mark.parametrize("kw", [
     dict(user_forced_mode=1000, user_bitrate_bps=24000, complexity=10),                                         # BASELINE config 3
@@ -110,3 +114,23 @@ def test_emu_opus_celt_only_in_audio_voip(kw):
 def test_emu_opus_stereo_automatic_mode(kw):
     """stereo input with the mode left to the encoder: compute_stereo_width feeds the SILK/CELT threshold"""
     run_opus(30, **dict(kw))
+
+
+def _pause(lo, hi, level):
+    """frames lo..hi-1 replaced by a +-level LSB dither (level 0: digital silence)"""
+    def f(i, x):
+        if lo <= i < hi: return ((np.arange(x.size) * 7919 % (2 * level + 1)) - level).astype(np.int16) if level else np.zeros_like(x)
+        return x
+    return f
+@pytest.mark.parametrize("kw", [
+    dict(user_forced_mode=1000, user_bitrate_bps=20000),                                   # SILK's own DTX on a noise floor; the generalised one on digital silence
+    dict(Fs=48000, ch=2, app=2048, user_bitrate_bps=28000),
+    dict(Fs=48000, ch=1, app=2049, user_forced_mode=1001, user_bandwidth=1105, user_bitrate_bps=40000),
+    dict(Fs=48000, ch=1, app=2049, user_bitrate_bps=64000)])                                # CELT-only inside AUDIO: only digital silence goes quiet
+def test_emu_opus_dtx(kw):
+    """OPUS_SET_DTX: SILK DTX (no-speech counter, empty payload -> TOC-only packets, src/opus_encoder.c:2242) and the generalised decision on digital
+    silence (:2565); packets must agree byte for byte including the 1-byte ones"""
+    kw = dict(kw)
+    for level in (2, 0):
+        lens = run_opus(34, use_dtx=1, shape=_pause(4, 30, level), seed=3, **kw)
+        if level == 0 or kw.get("user_forced_mode", 0) in (1000, 1001): assert 1 in lens[10:30], lens
