@@ -154,6 +154,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       if (cfg->application == OA_APP_VOIP) threshold += 8000;
       if (st->prev_mode == OA_MODE_CELT_ONLY) threshold -= 4000; else if (st->prev_mode > 0) threshold += 4000;
       st->mode = equiv_rate >= threshold ? OA_MODE_CELT_ONLY : OA_MODE_SILK_ONLY;
+      if (cfg->use_inband_fec && loss > ((128 - voice_est) >> 4) && (cfg->use_inband_fec != 2 || voice_est > 25)) st->mode = OA_MODE_SILK_ONLY;   /* :1517 */
       if (st->sm_useDTX && voice_est > 100) st->mode = OA_MODE_SILK_ONLY;                          /* :1521 */
       if (max_data_bytes < bitrate_to_bits(frame_rate > 50 ? 9000 : 6000, Fs, frame_size) / 8) st->mode = OA_MODE_CELT_ONLY;
    } else st->mode = cfg->user_forced_mode;
@@ -185,8 +186,24 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
    if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
    if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
-   if (cfg->use_inband_fec && loss > 0) { sh->err = OA_ERR_UNIMPLEMENTED; return; }               /* decide_fec :739 -> LBRR */
-   st->sm_LBRR_coded = 0;
+   {  /* decide_fec (:940): enough rate for the LBRR side stream at this bandwidth?  With > 5 % loss the bandwidth comes down until there is. */
+      int fec = 0;
+      if (cfg->use_inband_fec && loss != 0 && st->mode != OA_MODE_CELT_ONLY) {
+         const i32 thr_tab[10] = {12000, 1000, 14000, 1000, 16000, 1000, 20000, 1000, 22000, 1000};
+         const int orig_bandwidth = st->bandwidth;
+         for (;;) {
+            i32 thr = thr_tab[2 * (st->bandwidth - OA_BW_NB)]; const i32 hyst = thr_tab[2 * (st->bandwidth - OA_BW_NB) + 1];
+            if (st->sm_LBRR_coded == 1) thr -= hyst;
+            if (st->sm_LBRR_coded == 0) thr += hyst;
+            thr = sk_mulwb(thr * (125 - imin(loss, 25)), SE_FIX(0.01, 16));
+            if (equiv_rate > thr) { fec = 1; break; }
+            else if (loss <= 5) break;
+            else if (st->bandwidth > OA_BW_NB) st->bandwidth--;
+            else { st->bandwidth = orig_bandwidth; break; }
+         }
+      }
+      st->sm_LBRR_coded = fec;
+   }
    if (st->mode == OA_MODE_CELT_ONLY && st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
    int curr_bandwidth = st->bandwidth;
    if (cfg->application == OA_APP_RESTRICTED_SILK && curr_bandwidth > OA_BW_WB) st->bandwidth = curr_bandwidth = OA_BW_WB;
@@ -469,7 +486,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       sc.bitRate = total_bitRate;
       sh->HB_gain = Q15ONE;
       if (mode == OA_MODE_HYBRID) {                                                  /* :2034-2046 */
-         sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, 0, st->stream_channels);
+         sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels);
          sh->HB_gain = Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1);        /* celt_exp2 takes an opus_val16: the rate difference is truncated as in the reference */
       }
       sh->silk_bitRate = sc.bitRate;
@@ -483,18 +500,18 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
          if (effective_max_rate < 8000) { sc.maxInternalSampleRate = 12000; sc.desiredInternalSampleRate = imin(12000, sc.desiredInternalSampleRate); }
          if (effective_max_rate < 7000) { sc.maxInternalSampleRate = 8000; sc.desiredInternalSampleRate = imin(8000, sc.desiredInternalSampleRate); }
       }
-      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = 0; sc.useDTX = st->sm_useDTX;
+      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = st->sm_LBRR_coded; sc.useDTX = st->sm_useDTX;
       sc.useCBR = !L->cfg.use_vbr;
       sc.maxBits = (sh->max_data_bytes - 1) * 8;
       if (mode == OA_MODE_HYBRID) {                                                  /* :2136-2160 */
          if (sc.useCBR) { const i16 other_bits = (i16)imax(0, sc.maxBits - sc.bitRate * frame_size / Fs); sc.maxBits = imax(0, sc.maxBits - other_bits * 3 / 4); sc.useCBR = 0; }
-         else { const i32 maxBitRate = sh_silk_rate_for_hybrid(sc.maxBits * Fs / frame_size, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, 0, st->stream_channels); sc.maxBits = bitrate_to_bits(maxBitRate, Fs, frame_size); }
+         else { const i32 maxBitRate = sh_silk_rate_for_hybrid(sc.maxBits * Fs / frame_size, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels); sc.maxBits = bitrate_to_bits(maxBitRate, Fs, frame_size); }
       }
       sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = 0;
       sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
    }
    LANE0 { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(sh->orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
-   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G);
+   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
    wv_sync();
    if (sret) { LANE0 { *len_out = sret == -100 ? OA_ERR_UNIMPLEMENTED : OA_ERR_INTERNAL; *rng_out = 0; gs->s.error = sret; } return; }
    SE_PHASE(&L->S, 9);
@@ -512,6 +529,8 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
             if (L->cfg.application != OA_APP_RESTRICTED_SILK) st->error = OA_ERR_UNIMPLEMENTED;          /* the next frame would need a redundant CELT frame */
             st->silk_bw_switch = L->cfg.application != OA_APP_RESTRICTED_SILK;
          }
+         if (st->silk_bw_switch) { sh->ret = OA_ERR_UNIMPLEMENTED; }                 /* this very frame would carry the redundant CELT frame (:2251-2262) */
+         else {
          sh_width_and_bookkeeping_l0(L, frame_size, sc.stereoWidth_Q14);
          if (st->mode == OA_MODE_HYBRID) {                                            /* :2402-2450: the redundancy flag, then the CELT layer takes the coder over */
             EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
@@ -533,6 +552,7 @@ WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
          } else while (ret > 2 && L->packet[ret] == 0) ret--;                         /* trailing zeros are implied in SILK-only packets (:2540) */
          if (ret >= 0) ret += 1;
          sh->ret = ret;
+         }
          }
       }
       if (nBytes == 0) sh->ret = ret;

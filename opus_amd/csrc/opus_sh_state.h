@@ -31,6 +31,7 @@ struct OaShStream {
    OaSilkEnc silk;
    OaEncState celt;                                      /* hybrid only */
    int16_t delay_buffer[2 * OA_SH_MAX_DELAY];            /* hybrid only */
+   OaSilkLbrr lbrr;                                      /* in-band FEC only */
 };
 /* opus_encoder_init (src/opus_encoder.c:204-330) */
 static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)

@@ -6,7 +6,7 @@
  *   se_stereo_*           silk_stereo_LR_to_MS / _find_predictor / _quant_pred / _encode_pred   silk/stereo_LR_to_MS.c:35, stereo_find_predictor.c:35, stereo_quant_pred.c:35, stereo_encode_pred.c:35
  *   se_encode_frame_wave  silk_encode_frame_FIX   silk/fixed/encode_frame_FIX.c:85
  *   silk_encode_wave      silk_Encode             silk/enc_API.c:150
- * Not built: LBRR (in-band FEC) side streams, DTX, prefill (they are driven by Opus-layer options outside this round's path; control words that ask
+ * Not built: prefill (they are driven by Opus-layer options outside this round's path; control words that ask
  * for them make the frame fail loudly through the stream's error word). */
 #ifndef OPUS_AMD_SILK_ENC_FRAME_H
 #define OPUS_AMD_SILK_ENC_FRAME_H
@@ -24,6 +24,7 @@ struct SeAnaLds {                                      /* analysis phases */
 struct SeQuantLds {                                    /* quantiser + rate loop */
    SeNsqLds N;
    EcCtx ec_copy, ec_copy2;
+   OaSilkEncIndices ix_lbrr; i8 pulses_lbrr[320];      /* silk_LBRR_encode_FIX output before it goes to the HBM store */
 };
 /* rate-control loop snapshots (silk/fixed/encode_frame_FIX.c:108-118 sNSQ_copy[2], ec_buf_copy): per-stream HBM scratch, touched once per frame in VBR */
 struct SeRateScratch { OaSilkNsqState nsq_copy[2]; u8 ec_buf_copy[1280]; };
@@ -34,16 +35,15 @@ struct SilkEncLds {
    i32 tmp_rs[99 + 1];
    i32 r[16];                                          /* lane-0 hand-off words */
    i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM) */
-   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; } u;
+   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; OaSilkLbrr lbrr; } u;
    OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.ch[1] */
 };
 #define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
 #define SE_STATE_WORDS(channels) ((int)((sizeof(OaSilkEnc) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0)) / 4))
 
-/* ---- silk_encode_indices (encode_LBRR = 0) ---- */
-WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, EC_ARGS, int condCoding)
+/* ---- silk_encode_indices; ix = the frame's own index set, or an LBRR one (encode_LBRR: the type offset is then always >= 2) ---- */
+WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, const WV_LDS OaSilkEncIndices *ix, EC_ARGS, int condCoding)
 {
-   const WV_LDS OaSilkEncIndices *ix = &c->indices;
    const int typeOffset = 2 * ix->signalType + ix->quantOffsetType;
    if (typeOffset >= 2) k_ec_enc_icdf(EC_PASS, typeOffset - 2, sk_type_offset_vad_icdf, 8); else k_ec_enc_icdf(EC_PASS, typeOffset, sk_type_offset_no_vad_icdf, 8);
    if (condCoding == SE_CODE_CONDITIONALLY) k_ec_enc_icdf(EC_PASS, ix->GainsIndices[0], sk_delta_gain_icdf, 8);
@@ -344,7 +344,7 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
 template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
-WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G)
+WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
 {
    WV_LDS SeEncCtrl *ctl = &S->ctl;
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
@@ -374,8 +374,35 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
       LANE0 se_process_gains_l0(c, ctl, condCoding);
       SE_TAP(3);
       SE_PHASE(S, 6);
-      /* (silk_LBRR_encode_FIX: LBRR_enabled is never set on this path) */
       WV_LDS SeQuantLds *Q = &S->u.q;
+      if (c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8)) {
+         /* silk_LBRR_encode_FIX (:392): the same frame once more with raised gains -- the noise-shaping quantiser runs on the live state, which comes
+          * back from its HBM snapshot afterwards; indices and pulses go to the stream's HBM store for the next packet */
+         const int fi = c->nFramesEncoded, chn = c->channelNb;
+         i32 TempGains_Q16[4];
+         for (int k = 0; k < 4; k++) TempGains_Q16[k] = ctl->Gains_Q16[k];
+         se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+         LANE0 {
+            c->LBRR_flags[fi] = 1;
+            { WV_LDS i32 *d = (WV_LDS i32 *)&Q->ix_lbrr; const WV_LDS i32 *sr = (const WV_LDS i32 *)&c->indices; for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) d[k] = sr[k]; }
+            if (fi == 0 || c->LBRR_flags[fi - 1] == 0) {
+               c->LBRRprevLastGainIndex = c->LastGainIndex;
+               Q->ix_lbrr.GainsIndices[0] = (i8)imin(Q->ix_lbrr.GainsIndices[0] + c->LBRR_GainIncreases, 64 - 1);
+            }
+            i32 g[4]; i8 gi[4]; int prev = c->LBRRprevLastGainIndex;
+            for (int k = 0; k < 4; k++) gi[k] = Q->ix_lbrr.GainsIndices[k];
+            se_gains_dequant(g, gi, &prev, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
+            for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = g[k];
+            c->LBRRprevLastGainIndex = prev;
+         }
+         if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+         else se_nsq_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+         wv_sync();
+         FOR_LANES(i, c->frame_length) lb->pulses[chn][fi][i] = Q->pulses_lbrr[i];
+         { const WV_LDS i32 *src = (const WV_LDS i32 *)&Q->ix_lbrr; i32 *dst = (i32 *)&lb->indices[chn][fi]; FOR_LANES(i, (int)(sizeof(OaSilkEncIndices) / 4)) dst[i] = src[i]; }
+         se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
+         LANE0 { for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = TempGains_Q16[k]; }
+      }
       const int maxIter = 6;
       int gainMult_Q8 = SE_FIX(1, 8), found_lower = 0, found_upper = 0;
       i32 gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr), gainsID_lower = -1, gainsID_upper = -1;
@@ -402,7 +429,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
             LANE0 {
                if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
                EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
-               se_encode_indices(c, EC_PASS, condCoding);
+               se_encode_indices(c, &c->indices, EC_PASS, condCoding);
                se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
                int nb = k_ec_tell(EC_PASS);
                if (iter == maxIter && !found_lower && nb > maxBits) {
@@ -412,7 +439,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
                   if (condCoding != SE_CODE_CONDITIONALLY) c->indices.GainsIndices[0] = (i8)ctl->lastGainIndexPrev;
                   c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
                   for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
-                  se_encode_indices(c, EC_PASS, condCoding);
+                  se_encode_indices(c, &c->indices, EC_PASS, condCoding);
                   se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
                   nb = k_ec_tell(EC_PASS);
                }
@@ -490,12 +517,11 @@ struct SePcmSrc {
    WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
    WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
 };
-WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G)
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb)
 {
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    int nBytesOut = 0;
-   if (ec->useInBandFEC && ec->LBRR_coded) return -100;                       /* LBRR not built */
    LANE0 {
       if (ec->reducedDependency) for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].first_frame_after_reset = 1;
       for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].nFramesEncoded = 0;
@@ -560,6 +586,11 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
       if (c0->inputBufIx < c0->frame_length) break;
       /* ---- enough data: encode one frame ---- */
       i32 MStargetRates_bps[2] = {0, 0}, TargetRate_bps;
+      if (c0->nFramesEncoded == 0) {                                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
+         int any = 0;
+         for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) any |= E->ch[n].LBRR_flags[i];
+         if (any) { WV_LDS i32 *d = (WV_LDS i32 *)&S->u.lbrr; const i32 *g = (const i32 *)lb; wv_sync(); FOR_LANES(i, (int)(sizeof(OaSilkLbrr) / 4)) d[i] = g[i]; wv_sync(); }
+      }
       LANE0 {
          EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
          int curr_nBitsUsedLBRR = 0;
@@ -568,7 +599,22 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
             iCDF[0] = (u8)(256 - (256 >> ((c0->nFramesPerPacket + 1) * ec->nChannelsInternal)));
             k_ec_enc_icdf(EC_PASS, 0, iCDF, 8);
             curr_nBitsUsedLBRR = k_ec_tell(EC_PASS);
-            for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].LBRR_flag = 0; for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0; }
+            for (int n = 0; n < ec->nChannelsInternal; n++) {                        /* LBRR flags (enc_API.c:364-374) */
+               int sym = 0;
+               for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) sym |= E->ch[n].LBRR_flags[i] << i;
+               E->ch[n].LBRR_flag = sym > 0;
+               if (sym && E->ch[n].nFramesPerPacket > 1) k_ec_enc_icdf(EC_PASS, sym - 1, &sk_lbrr_flags_icdf[E->ch[n].nFramesPerPacket == 2 ? 0 : 3], 8);
+            }
+            for (int i = 0; i < c0->nFramesPerPacket; i++) for (int n = 0; n < ec->nChannelsInternal; n++) if (E->ch[n].LBRR_flags[i]) {      /* indices and excitation (:376-400) */
+               if (ec->nChannelsInternal == 2 && n == 0) {
+                  se_stereo_encode_pred(EC_PASS, &E->st.predIx[i][0][0]);
+                  if (c1->LBRR_flags[i] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[i], sk_stereo_only_code_mid_icdf, 8);
+               }
+               const int cc = i > 0 && E->ch[n].LBRR_flags[i - 1] ? SE_CODE_CONDITIONALLY : SE_CODE_INDEPENDENTLY;
+               se_encode_indices(&E->ch[n], &S->u.lbrr.indices[n][i], EC_PASS, cc);
+               se_encode_pulses(EC_PASS, S->u.lbrr.indices[n][i].signalType, S->u.lbrr.indices[n][i].quantOffsetType, S->u.lbrr.pulses[n][i], E->ch[n].frame_length);
+            }
+            for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0;
             curr_nBitsUsedLBRR = k_ec_tell(EC_PASS) - curr_nBitsUsedLBRR;
          }
          se_hp_variable_cutoff(c0);
@@ -620,7 +666,7 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
             if (c0->nFramesEncoded - n <= 0) condCoding = SE_CODE_INDEPENDENTLY;
             else if (n > 0 && E->prev_decode_only_middle) condCoding = SE_CODE_INDEPENDENTLY_NO_LTP_SCALING;
             else condCoding = SE_CODE_CONDITIONALLY;
-            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR, G);
+            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR, G, lb);
             nBytesOut = S->r[0];
          }
          wv_sync();

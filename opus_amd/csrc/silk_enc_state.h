@@ -62,6 +62,9 @@ struct OaSilkEnc {                             /* silk_encoder */
 };
 
 /* silk_EncControlStruct (silk/control.h:42-120): what the Opus layer hands to silk_Encode and reads back */
+/* in-band FEC side stream of the packet being built (silk_encoder_state indices_LBRR / pulses_LBRR, silk/structs.h:200-203): written once per frame,
+ * read once at the start of the next packet -> lives in HBM only, never staged into the wave's LDS */
+struct OaSilkLbrr { int8_t pulses[2][3][320]; OaSilkEncIndices indices[2][3]; };
 struct SeControl {
    int32_t nChannelsAPI, nChannelsInternal, API_sampleRate, maxInternalSampleRate, minInternalSampleRate, desiredInternalSampleRate, payloadSize_ms, bitRate;
    int32_t packetLossPercentage, complexity, useInBandFEC, LBRR_coded, useDTX, useCBR, maxBits, toMono, opusCanSwitch, reducedDependency;

@@ -24,7 +24,8 @@ static void ejob(void *p)
    /* the packet buffer and coder context stand where the Opus layer keeps them */
    static thread_local EcCtx ecl; static thread_local uint8_t buf[1280]; static thread_local int16_t pcm16[2 * 2880];
    LANE0 { EcCtx e_; EcCtx *e = &e_; uint8_t *b = buf; (void)b; k_ec_enc_init(e, buf, (u32)j->out_cap); ec_st(&ecl, e); for (int i = 0; i < j->nSamples * c.nChannelsAPI; i++) pcm16[i] = j->pcm[i]; }
-   const int ret = silk_encode_wave(S, &c, pcm16, j->nSamples, &ecl, buf, j->activity, j->G);
+   static OaSilkLbrr lbrr_store;                                                   /* SILK-level harness: one encoder at a time */
+   const int ret = silk_encode_wave(S, &c, pcm16, j->nSamples, &ecl, buf, j->activity, j->G, &lbrr_store);
    wv_sync();
    LANE0 {
       j->ret = ret;

@@ -5,7 +5,7 @@ import ctypes, numpy as np, pytest
 from reflib import ref_fx
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")]
-REQ = dict(bitrate=4002, vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, bandwidth=4008, max_bandwidth=4004, force_mode=11002, signal=4024, dtx=4016)
+REQ = dict(bitrate=4002, vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, bandwidth=4008, max_bandwidth=4004, force_mode=11002, signal=4024, dtx=4016, fec=4012, loss=4014)
 
 def speech(fs, secs, ch, seed):
     """SURVEY §8d config-3 signal: glottal-like harmonic source with vibrato, gated, over noise; one seed per stream"""
@@ -123,6 +123,15 @@ def test_gpu_dtx(Fs, ch, app, ctl):
         return x
     lens = check(4, 30, Fs=Fs, ch=ch, app=app, shape=shape, dtx=1, **ctl)
     assert any(l[1] == 1 for l in lens[10:26])                                   # the digital-silence streams do go quiet
+
+@pytest.mark.parametrize("Fs,ch,app,ms,ctl", [
+    (16000, 1, 2048, 20, dict(force_mode=1000, bitrate=24000, loss=10, complexity=10)), (16000, 1, 2048, 20, dict(bitrate=26000, loss=20)),
+    (48000, 2, 2048, 20, dict(bitrate=40000, loss=15)), (48000, 1, 2048, 20, dict(force_mode=1001, bandwidth=1104, bitrate=32000, loss=8)),
+    (16000, 1, 2048, 40, dict(force_mode=1000, bitrate=24000, loss=12)), (16000, 2, 2048, 60, dict(force_mode=1000, bitrate=36000, loss=30)),
+    (48000, 2, 2049, 20, dict(force_mode=1001, bandwidth=1105, bitrate=96000, loss=10, complexity=10))])
+def test_gpu_inband_fec(Fs, ch, app, ms, ctl):
+    """OPUS_SET_INBAND_FEC with packet loss: decide_fec, the LBRR re-quantisation (silk_LBRR_encode_FIX) and its coding at the head of the next packet"""
+    check(4, 20 if ms <= 20 else 8, Fs=Fs, ch=ch, app=app, ms=ms, fec=1, **ctl)
 
 def test_gpu_silk_unbuilt_paths_fail_loudly():
     import opus_amd as oa

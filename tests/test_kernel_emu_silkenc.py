@@ -52,7 +52,7 @@ def test_emu_silk_encode_matrix(kw):
 
 CFG = ["Fs", "channels", "application", "user_bitrate_bps", "use_vbr", "vbr_constraint", "complexity", "force_channels", "user_bandwidth", "max_bandwidth", "lsb_depth", "disable_inv",
        "packet_loss_perc", "user_forced_mode", "signal_type", "use_inband_fec", "use_dtx"]
-REQ = dict(user_bitrate_bps=4002, use_vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, user_bandwidth=4008, max_bandwidth=4004, user_forced_mode=11002, signal_type=4024, packet_loss_perc=4014, use_dtx=4016)
+REQ = dict(user_bitrate_bps=4002, use_vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, user_bandwidth=4008, max_bandwidth=4004, user_forced_mode=11002, signal_type=4024, packet_loss_perc=4014, use_dtx=4016, use_inband_fec=4012)
 def run_opus(nframes, Fs=16000, ch=1, app=2048, ms=20, seed=1, max_bytes=1276, shape=None, **kw):
     from silkenc_harness import build_emu, P
     E = build_emu(); R = ref_fx()
@@ -134,3 +134,16 @@ def test_emu_opus_dtx(kw):
     for level in (2, 0):
         lens = run_opus(34, use_dtx=1, shape=_pause(4, 30, level), seed=3, **kw)
         if level == 0 or kw.get("user_forced_mode", 0) in (1000, 1001): assert 1 in lens[10:30], lens
+
+
+@pytest.mark.parametrize("kw", [
+    dict(user_forced_mode=1000, user_bitrate_bps=24000, packet_loss_perc=10),
+    dict(user_bitrate_bps=20000, packet_loss_perc=20, complexity=10),
+    dict(Fs=48000, ch=2, app=2048, user_bitrate_bps=40000, packet_loss_perc=15),
+    dict(Fs=48000, ch=1, app=2048, user_bitrate_bps=32000, packet_loss_perc=8, user_bandwidth=1104, user_forced_mode=1001),
+    dict(ms=40, user_forced_mode=1000, user_bitrate_bps=24000, packet_loss_perc=12), dict(ms=60, ch=2, user_forced_mode=1000, user_bitrate_bps=36000, packet_loss_perc=30),
+    dict(user_forced_mode=1000, user_bitrate_bps=12000, packet_loss_perc=3), dict(user_forced_mode=1000, user_bitrate_bps=16000, packet_loss_perc=25, complexity=1)])
+def test_emu_opus_inband_fec(kw):
+    """OPUS_SET_INBAND_FEC + packet loss: decide_fec, the LBRR re-quantisation of every active frame and its coding at the head of the next packet"""
+    kw = dict(kw); ms = kw.get("ms", 20)
+    run_opus(16 if ms <= 20 else 8, use_inband_fec=1, seed=5, **kw)
