@@ -445,6 +445,20 @@ WV_DEV void se_apply_sine_window(WV_LDS i16 *px_win, const WV_LDS i16 *px, int w
       S1 = sk_mulwb(S0, c_Q16) + shl32(S0, 1) - S1; S1 = imin(S1, (i32)1 << 16);
    }
 }
+/* the multipliers of silk_apply_sine_window (a rounding recursion that depends on the length only): m[k] with px_win[k] = SMULWB(m[k], px[k]) */
+WV_DEV void se_sine_window_table(WV_LDS i32 *m, int win_type, int length)
+{
+   const i16 freq_table_Q16[27] = {12111, 9804, 8235, 7100, 6239, 5565, 5022, 4575, 4202, 3885, 3612, 3375, 3167, 2984, 2820, 2674, 2542, 2422, 2313, 2214, 2123, 2038, 1961, 1889, 1822, 1760, 1702};
+   const int f_Q16 = freq_table_Q16[(length >> 2) - 4], c_Q16 = sk_mulwb((i32)f_Q16, -f_Q16);
+   i32 S0, S1;
+   if (win_type == 1) { S0 = 0; S1 = f_Q16 + (length >> 3); } else { S0 = (i32)1 << 16; S1 = ((i32)1 << 16) + (c_Q16 >> 1) + (length >> 4); }
+   for (int k = 0; k < length; k += 4) {
+      m[k] = (S0 + S1) >> 1; m[k + 1] = S1;
+      S0 = sk_mulwb(S1, c_Q16) + shl32(S1, 1) - S0 + 1; S0 = imin(S0, (i32)1 << 16);
+      m[k + 2] = (S0 + S1) >> 1; m[k + 3] = S0;
+      S1 = sk_mulwb(S0, c_Q16) + shl32(S0, 1) - S1; S1 = imin(S1, (i32)1 << 16);
+   }
+}
 /* silk_autocorr (silk/fixed/autocorr_FIX.c:36) = _celt_autocorr (celt/celt_lpc.c:284) without window; xx: i16[n] scratch; all lanes.
  * ac[k] = sum_{i>=k} xs[i] xs[i-k] mod 2^32 is order-free, so lane = lag. */
 WV_DEV int se_autocorr_wave(WV_LDS i32 *ac, const WV_LDS i16 *x, int n, int count, WV_LDS i16 *xx)
@@ -504,6 +518,41 @@ WV_DEV void se_k2a(i32 *A_Q24, const i16 *rc_Q15, int order)
       A_Q24[k] = -shl32((i32)rc_Q15[k], 9);
    }
 }
+/* silk_schur / silk_k2a with one lane per correlation pair / coefficient (same layout as se_schur64_wave / se_k2a_Q16_wave); rc: LDS i32[order] */
+WV_DEV i32 se_schur_wave(WV_LDS i32 *rc_Q15, const WV_LDS i32 *c, int order)
+{
+   const int lane = wv_lane();
+   const int lz = sk_clz(c[0]);
+   i32 a = lane < order ? c[lane + 1] : 0, b = lane <= order ? c[lane] : 0;
+   if (lz < 2) { a >>= 1; b >>= 1; } else if (lz > 2) { a = shl32(a, lz - 2); b = shl32(b, lz - 2); }
+   wv_sync();
+   int k;
+   for (k = 0; k < order; k++) {
+      const i32 a0 = wv_lane_const<0>(a), b0 = wv_lane_const<0>(b);
+      if (iabs(a0) >= b0) { if (lane == 0) rc_Q15[k] = a0 > 0 ? -SE_FIX(.99f, 15) : SE_FIX(.99f, 15); k++; break; }
+      const i32 rc_tmp = sk_sat16(-(a0 / imax(b0 >> 15, 1)));
+      if (lane == 0) rc_Q15[k] = rc_tmp;
+      const i32 na = sk_mlawb(a, shl32(b, 1), rc_tmp), nb = sk_mlawb(b, shl32(a, 1), rc_tmp);
+      if (lane < order - k) { a = na; b = nb; }
+      a = wv_shift_down1(a, 0);
+   }
+   if (lane >= k && lane < order) rc_Q15[lane] = 0;
+   const i32 nrg = imax(1, wv_lane_const<0>(b));
+   wv_sync();
+   return nrg;
+}
+WV_DEV i32 se_k2a_wave(const WV_LDS i32 *rc_Q15, int order)                    /* returns A_Q24[lane] */
+{
+   const int lane = wv_lane();
+   i32 a = 0;
+   for (int k = 0; k < order; k++) {
+      const i32 rc = rc_Q15[k];
+      const i32 other = wv_shfl(a, (k - 1 - lane) & 63);
+      if (lane < k) a = sk_mlawb(a, shl32(other, 1), rc);
+      if (lane == k) a = -shl32(rc, 9);
+   }
+   return a;
+}
 /* silk_bwexpander (silk/bwexpander.c:35) on a plain array */
 template <class P> WV_DEV void se_bwexpander(P ar, int d, i32 chirp_Q16)
 {
@@ -540,23 +589,22 @@ WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       WV_LDS i16 *A_Q12s, WV_LDS PitchLds *PL)
 {
    const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length, wl = c->pitch_LPC_win_length, la = c->la_pitch, order = c->pitchEstimationLPCOrder;
-   LANE0 {
+   {
       const WV_LDS i16 *x_ptr = x + buf_len - wl;
-      se_apply_sine_window(Wsig, x_ptr, 1, la);
-      for (int i = 0; i < wl - 2 * la; i++) Wsig[la + i] = x_ptr[la + i];
-      se_apply_sine_window(Wsig + wl - la, x_ptr + wl - la, 2, la);
+      LANE0 { se_apply_sine_window(Wsig, x_ptr, 1, la); se_apply_sine_window(Wsig + wl - la, x_ptr + wl - la, 2, la); }
+      FOR_LANES(i, wl - 2 * la) Wsig[la + i] = x_ptr[la + i];
+      wv_sync();
    }
    se_autocorr_wave(w32, Wsig, wl, order + 1, xx);
-   LANE0 {
-      i16 rc_Q15[16]; i32 A_Q24[16];
-      w32[0] = sk_mlawb(w32[0], w32[0], SE_FIX(1e-3f, 16)) + 1;
-      const i32 res_nrg = se_schur(rc_Q15, w32, order);
-      ctl->predGain_Q16 = sk_div32_varQ(w32[0], imax(res_nrg, 1), 16);
-      se_k2a(A_Q24, rc_Q15, order);
-      i16 A_Q12[16];
-      for (int i = 0; i < order; i++) A_Q12[i] = (i16)sk_sat16(A_Q24[i] >> 12);
-      se_bwexpander(A_Q12, order, SE_FIX(0.99f, 16));
-      for (int i = 0; i < order; i++) A_Q12s[i] = A_Q12[i];
+   LANE0 w32[0] = sk_mlawb(w32[0], w32[0], SE_FIX(1e-3f, 16)) + 1;
+   {
+      WV_LDS i32 *rc = PL->d_srch;                                               /* free until the pitch core runs */
+      const i32 res_nrg = se_schur_wave(rc, w32, order);
+      LANE0 ctl->predGain_Q16 = sk_div32_varQ(w32[0], imax(res_nrg, 1), 16);
+      const i32 a24 = se_k2a_wave(rc, order);
+      if (wv_lane() < order) A_Q12s[wv_lane()] = (i16)sk_sat16(a24 >> 12);
+      wv_sync();
+      LANE0 se_bwexpander(A_Q12s, order, SE_FIX(0.99f, 16));
    }
    se_lpc_analysis_filter_wave(res, x, A_Q12s, buf_len, order);
    wv_sync();

@@ -94,6 +94,44 @@ template <class PA, class PR> WV_DEV void se_k2a_Q16(PA A_Q24, PR rc_Q16, int or
       A_Q24[k] = -shl32(rc, 8);
    }
 }
+/* silk_schur64 (silk/fixed/schur64_FIX.c:35) with one lane per correlation pair: lane n keeps C[n + k + 1][0] and C[n][1]; the updates of one order are
+ * independent across n, the upper row slides down one lane per order (DPP), the reflection coefficient comes from lane 0's pair.  rc_Q16: LDS [order]. */
+WV_DEV i32 se_schur64_wave(WV_LDS i32 *rc_Q16, const WV_LDS i32 *c, int order)
+{
+   const int lane = wv_lane();
+   if (c[0] <= 0) { wv_sync(); FOR_LANES(k, order) rc_Q16[k] = 0; wv_sync(); return 0; }
+   i32 a = lane < order ? c[lane + 1] : 0, b = lane <= order ? c[lane] : 0;
+   wv_sync();
+   int k;
+   for (k = 0; k < order; k++) {
+      const i32 a0 = wv_lane_const<0>(a), b0 = wv_lane_const<0>(b);
+      if (iabs(a0) >= b0) { if (lane == 0) rc_Q16[k] = a0 > 0 ? -SE_FIX(.99f, 16) : SE_FIX(.99f, 16); k++; break; }
+      const i32 rc_tmp_Q31 = sk_div32_varQ(-a0, b0, 31);
+      if (lane == 0) rc_Q16[k] = sk_rround(rc_tmp_Q31, 15);
+      const i32 na = a + sk_mulhi(shl32(b, 1), rc_tmp_Q31), nb = b + sk_mulhi(shl32(a, 1), rc_tmp_Q31);
+      if (lane < order - k) { a = na; b = nb; }
+      a = wv_shift_down1(a, 0);
+   }
+   if (lane >= k && lane < order) rc_Q16[lane] = 0;
+   const i32 nrg = imax(1, wv_lane_const<0>(b));
+   wv_sync();
+   return nrg;
+}
+/* silk_k2a_Q16 (silk/k2a_Q16.c:35), lane n = coefficient n: step k pairs n with k - 1 - n (both read the old values), A_Q24: LDS [order] */
+WV_DEV void se_k2a_Q16_wave(WV_LDS i32 *A_Q24, const WV_LDS i32 *rc_Q16, int order)
+{
+   const int lane = wv_lane();
+   i32 a = 0;
+   for (int k = 0; k < order; k++) {
+      const i32 rc = rc_Q16[k];
+      const i32 other = wv_shfl(a, (k - 1 - lane) & 63);
+      if (lane < k) a = sk_mlaww(a, other, rc);
+      if (lane == k) a = -shl32(rc, 8);
+   }
+   wv_sync();
+   if (lane < order) A_Q24[lane] = a;
+   wv_sync();
+}
 template <class PA> WV_DEV i32 se_warped_gain(PA coefs_Q24, int lambda_Q16, int order)
 {
    lambda_Q16 = -lambda_Q16;
@@ -171,7 +209,15 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
    const int warping_Q16 = c->warping_Q16 > 0 ? sk_mlawb(c->warping_Q16, (i32)ctl->coding_quality_Q14, SE_FIX(0.01, 18)) : 0;
    for (int k = 0; k < c->nb_subfr; k++) {
       const int flat_part = c->fs_kHz * 3, slope_part = (swl - flat_part) >> 1;
-      LANE0 {
+      if (c->warping_Q16 > 0) {                                                        /* xx is free on the warped path: it holds the two window slopes, worked out once (lanes 0 and 1) */
+         WV_LDS i32 *wtab = (WV_LDS i32 *)xx;
+         if (k == 0) { if (wv_lane() < 2) se_sine_window_table(wtab + wv_lane() * slope_part, wv_lane() + 1, slope_part); wv_sync(); }
+         FOR_LANES(i, swl) {
+            i32 v = x_ptr[i];
+            if (i < slope_part) v = sk_mulwb(wtab[i], v); else if (i >= slope_part + flat_part) v = sk_mulwb(wtab[i - flat_part], v);
+            xw[i] = (i16)v;
+         }
+      } else LANE0 {
          se_apply_sine_window(xw, x_ptr, 1, slope_part);
          for (int i = 0; i < flat_part; i++) xw[slope_part + i] = x_ptr[slope_part + i];
          se_apply_sine_window(xw + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
@@ -181,12 +227,12 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
       wv_sync();
       if (c->warping_Q16 > 0) scale = se_warped_autocorr_wave(w32, xw, warping_Q16, swl, order);
       else scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
+      LANE0 w32[0] = add32(w32[0], imax(sk_mulwb(w32[0] >> 4, SE_FIX(3e-5f, 20)), 1));
+      const i32 nrg_w = se_schur64_wave(stk, w32, order);
+      se_k2a_Q16_wave(stk + 24, stk, order);
       LANE0 {
          WV_LDS i32 *auto_corr = w32, *refl_coef_Q16 = stk, *AR_Q24 = stk + 24;
-         WV_LDS i32 (*Cs)[2] = (WV_LDS i32 (*)[2])(stk + 48);
-         auto_corr[0] = add32(auto_corr[0], imax(sk_mulwb(auto_corr[0] >> 4, SE_FIX(3e-5f, 20)), 1));
-         i32 nrg = se_schur64(refl_coef_Q16, auto_corr, order, Cs);
-         se_k2a_Q16(AR_Q24, refl_coef_Q16, order);
+         i32 nrg = nrg_w; (void)auto_corr; (void)refl_coef_Q16;
          int Qnrg = -scale;
          if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
          const i32 tmp32 = se_sqrt_approx(nrg);

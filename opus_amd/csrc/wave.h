@@ -46,6 +46,8 @@ WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
 template <int Q> WV_DEV int32_t wv_lane_const(int32_t v) { return __builtin_amdgcn_readlane(v, Q); }
 template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+/* lane i receives v of lane i+1, lane 63 receives `fill` (DPP wave_shl:1) */
+WV_DEV int32_t wv_shift_down1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 
 /* Wave-wide reductions on the DPP cross-lane network (no LDS round trips, unlike ds_bpermute shuffles):
  * quad_perm swaps -> row rotations (every lane of a 16-lane row holds the row result) -> row_bcast:15 / row_bcast:31

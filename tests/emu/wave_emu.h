@@ -70,6 +70,7 @@ template <int Q> WV_DEV int32_t wv_lane_const(int32_t v) { auto t = emu_xchg(v);
 template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[(emu_cur->cur & ~3) | J][0]; }
 WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
 WV_DEV int32_t wv_uni(int32_t v) { return v; }
+WV_DEV int32_t wv_shift_down1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = emu_cur->cur; return me == 63 ? fill : (int32_t)t[me + 1][0]; }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = emu_cur->cur; return me == 0 ? fill : (int32_t)t[me - 1][0]; }
 WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return emu_cur->cur == lane ? val : old; }
 WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
