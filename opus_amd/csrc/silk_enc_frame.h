@@ -84,13 +84,21 @@ WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, const WV_LDS OaSilkEnc
 }
 
 /* ---- silk_encode_pulses ---- */
-WV_DEV int se_combine_and_check(int *out, const int *in, int max_pulses, int len) { for (int k = 0; k < len; k++) { const int s = in[2 * k] + in[2 * k + 1]; if (s > max_pulses) return 1; out[k] = s; } return 0; }
+/* {sk_sign_icdf[i], 0}: the two-entry iCDFs silk_encode_signs builds on its stack, tabulated (a private array handed to the range coder would live in scratch memory) */
+WV_TABLE uint8_t se_sign_icdf_pairs[84] = { 254, 0, 49, 0, 67, 0, 77, 0, 82, 0, 93, 0, 99, 0, 198, 0, 11, 0, 18, 0, 24, 0, 31, 0, 36, 0, 45, 0, 255, 0, 46, 0, 66, 0, 78, 0, 87, 0, 94, 0, 104, 0, 208, 0, 14, 0, 21, 0, 32, 0, 42, 0, 51, 0, 66, 0, 255, 0, 94, 0, 104, 0, 109, 0, 112, 0, 115, 0, 118, 0, 248, 0, 53, 0, 69, 0, 80, 0, 88, 0, 95, 0, 102, 0 };
+/* fixed-size, fully unrolled: the small arrays stay in registers */
+template <int LEN> WV_DEV int se_combine_and_check(int *out, const int *in, int max_pulses) { int over = 0;
+#pragma unroll
+   for (int k = 0; k < LEN; k++) { const int s = in[2 * k] + in[2 * k + 1]; over |= s > max_pulses; out[k] = s; } return over; }
 WV_DEV void se_encode_split(EC_ARGS, int p_child1, int p, const u8 *tab) { if (p > 0) k_ec_enc_icdf(EC_PASS, p_child1, &tab[sk_shell_code_table_offsets[p]], 8); }
 WV_DEV void se_shell_encoder(EC_ARGS, const int *p0)
 {
    int p1[8], p2[4], p3[2], p4[1];
+#pragma unroll
    for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
+#pragma unroll
    for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
+#pragma unroll
    for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
    p4[0] = p3[0] + p3[1];
    se_encode_split(EC_PASS, p3[0], p4[0], sk_shell_code_table3);
@@ -109,24 +117,31 @@ WV_DEV void se_shell_encoder(EC_ARGS, const int *p0)
    se_encode_split(EC_PASS, p0[12], p1[6], sk_shell_code_table0);
    se_encode_split(EC_PASS, p0[14], p1[7], sk_shell_code_table0);
 }
-WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LDS i8 *pulses, int frame_length)
+/* wk: 40 words of LDS (per-block sums and shift counts: run-time indexed) */
+WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LDS i8 *pulses, int frame_length, WV_LDS i32 *wk)
 {
    const int max_pulses_table[4] = {8, 10, 12, 16};
    int iter = frame_length >> 4;
    if (iter * 16 < frame_length) { iter++; for (int i = 0; i < 16; i++) pulses[frame_length + i] = 0; }
-   int sum_pulses[20], nRshifts[20], pulses_comb[8];
-   for (int i = 0; i < 8; i++) pulses_comb[i] = 0;
+   WV_LDS i32 *sum_pulses = wk, *nRshifts = wk + 20;
    for (int i = 0; i < iter; i++) {
       int ap[16];
+#pragma unroll
       for (int k = 0; k < 16; k++) ap[k] = iabs((i32)pulses[i * 16 + k]);
-      nRshifts[i] = 0;
+      int sh = 0, sum = 0;
       while (1) {
-         int scale_down = se_combine_and_check(pulses_comb, ap, max_pulses_table[0], 8);
-         scale_down += se_combine_and_check(pulses_comb, pulses_comb, max_pulses_table[1], 4);
-         scale_down += se_combine_and_check(pulses_comb, pulses_comb, max_pulses_table[2], 2);
-         scale_down += se_combine_and_check(&sum_pulses[i], pulses_comb, max_pulses_table[3], 1);
-         if (scale_down) { nRshifts[i]++; for (int k = 0; k < 16; k++) ap[k] >>= 1; } else break;
+         /* (the reference leaves a partially written level behind when a check fails and overwrites it on the next pass: only the final pass matters) */
+         int c8[8], c4[4], c2[2], c1[1];
+         int scale_down = se_combine_and_check<8>(c8, ap, max_pulses_table[0]);
+         scale_down += se_combine_and_check<4>(c4, c8, max_pulses_table[1]);
+         scale_down += se_combine_and_check<2>(c2, c4, max_pulses_table[2]);
+         scale_down += se_combine_and_check<1>(c1, c2, max_pulses_table[3]);
+         sum = c1[0];
+         if (scale_down) { sh++;
+#pragma unroll
+            for (int k = 0; k < 16; k++) ap[k] >>= 1; } else break;
       }
+      sum_pulses[i] = sum; nRshifts[i] = sh;
    }
    i32 minSumBits_Q5 = 2147483647; int RateLevelIndex = 0;
    for (int k = 0; k < 9; k++) {
@@ -146,7 +161,10 @@ WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LD
       }
    }
    for (int i = 0; i < iter; i++) {
-      if (sum_pulses[i] > 0) { int ap[16]; for (int k = 0; k < 16; k++) ap[k] = iabs((i32)pulses[i * 16 + k]) >> nRshifts[i]; se_shell_encoder(EC_PASS, ap); }
+      if (sum_pulses[i] > 0) { int ap[16]; const int sh = nRshifts[i];
+#pragma unroll
+         for (int k = 0; k < 16; k++) ap[k] = iabs((i32)pulses[i * 16 + k]) >> sh;
+         se_shell_encoder(EC_PASS, ap); }
    }
    for (int i = 0; i < iter; i++) {
       if (nRshifts[i] > 0) {
@@ -159,13 +177,12 @@ WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LD
       }
    }
    {  /* silk_encode_signs */
-      u8 icdf[2]; icdf[1] = 0;
-      const u8 *icdf_ptr = &sk_sign_icdf[sk_mulbb(7, quantOffsetType + shl32(signalType, 1))];
+      const int base = sk_mulbb(7, quantOffsetType + shl32(signalType, 1));
       const int n = (frame_length + 8) >> 4;
       for (int i = 0; i < n; i++) {
          const int p = sum_pulses[i];
          if (p > 0) {
-            icdf[0] = icdf_ptr[imin(p & 0x1F, 6)];
+            const u8 *icdf = &se_sign_icdf_pairs[2 * (base + imin(p & 0x1F, 6))];
             for (int j = 0; j < 16; j++) { const int q = pulses[i * 16 + j]; if (q != 0) k_ec_enc_icdf(EC_PASS, (q >> 15) + 1, icdf, 8); }
          }
       }
@@ -344,7 +361,7 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
 template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
-WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
+WV_DEVN void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
 {
    WV_LDS SeEncCtrl *ctl = &S->ctl;
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
@@ -430,7 +447,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
                if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
                EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
                se_encode_indices(c, &c->indices, EC_PASS, condCoding);
-               se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
+               se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
                int nb = k_ec_tell(EC_PASS);
                if (iter == maxIter && !found_lower && nb > maxBits) {
                   ec_ld(&ec_, &Q->ec_copy2);
@@ -440,7 +457,7 @@ WV_DEV void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *
                   c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
                   for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
                   se_encode_indices(c, &c->indices, EC_PASS, condCoding);
-                  se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length);
+                  se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
                   nb = k_ec_tell(EC_PASS);
                }
                ec_st(ecl, &ec_);
@@ -612,7 +629,7 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
                }
                const int cc = i > 0 && E->ch[n].LBRR_flags[i - 1] ? SE_CODE_CONDITIONALLY : SE_CODE_INDEPENDENTLY;
                se_encode_indices(&E->ch[n], &S->u.lbrr.indices[n][i], EC_PASS, cc);
-               se_encode_pulses(EC_PASS, S->u.lbrr.indices[n][i].signalType, S->u.lbrr.indices[n][i].quantOffsetType, S->u.lbrr.pulses[n][i], E->ch[n].frame_length);
+               se_encode_pulses(EC_PASS, S->u.lbrr.indices[n][i].signalType, S->u.lbrr.indices[n][i].quantOffsetType, S->u.lbrr.pulses[n][i], E->ch[n].frame_length, S->stk);
             }
             for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0;
             curr_nBitsUsedLBRR = k_ec_tell(EC_PASS) - curr_nBitsUsedLBRR;
