@@ -221,11 +221,11 @@ WV_DEVN void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, 
       }
       W->err_Q24[v] = sum;
    }
-   LANE0 {
-      i32 e[32]; int idx[16];
-      for (int i = 0; i < cb.nVectors; i++) e[i] = W->err_Q24[i];
-      se_insertion_sort_increasing(e, idx, cb.nVectors, nSurvivors);
-      for (int s = 0; s < nSurvivors; s++) W->surv[s] = idx[s];
+   wv_sync();
+   FOR_LANES(v, cb.nVectors) {                                                                    /* silk_insertion_sort_increasing (stable, first K): every vector finds its own rank */
+      const i32 ev = W->err_Q24[v]; int rank = 0;
+      for (int u = 0; u < cb.nVectors; u++) { const i32 eu = W->err_Q24[u]; rank += eu < ev || (eu == ev && u < v); }
+      if (rank < nSurvivors) W->surv[rank] = v;
    }
    FOR_LANES(i, 20) se_nlsf_out_tabs(&W->tabs, i, cb.qstep);
    wv_sync();
