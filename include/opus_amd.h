@@ -10,9 +10,10 @@
  *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only kernel, Fs = 48000, 2.5-20 ms) and
  *    OPUS_APPLICATION_VOIP / AUDIO / RESTRICTED_SILK (the SILK-capable kernel: SILK-only frames at Fs 8-48 kHz, 10-60 ms; hybrid and
  *    CELT-only frames at 48 kHz; mode / bandwidth / channel decisions as the reference's opus_encode_native, src/opus_encoder.c:1310-1700,
- *    or pinned with OPUS_SET_FORCE_MODE); VBR / constrained VBR / hard CBR (code-3 padding).  What is not built (mode switches that need a
- *    redundancy frame, in-band FEC / DTX encode, frames above 60 ms, CELT below 48 kHz) returns OPUS_UNIMPLEMENTED -- from the encode call,
- *    per stream, when the decision arises.
+ *    or pinned with OPUS_SET_FORCE_MODE); VBR / constrained VBR / hard CBR (code-3 padding); OPUS_SET_DTX (SILK's own DTX and the generalised
+ *    decision, OPUS_GET_IN_DTX) and OPUS_SET_INBAND_FEC + OPUS_SET_PACKET_LOSS_PERC (decide_fec, LBRR).  What is not built (mode or SILK-bandwidth
+ *    switches that need a CELT redundancy frame, frames above 60 ms, CELT below 48 kHz) returns OPUS_UNIMPLEMENTED -- from the encode call,
+ *    per stream, on the very frame where the decision arises (no packet is ever emitted without the redundancy it would need).
  *
  * 2. The batch API (additive): S independent streams stepped together, one wavefront per
  *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.
@@ -208,8 +209,9 @@ OPUS_AMD_EXPORT opus_int32 opus_multistream_packet_unpad(unsigned char *data, op
 
 /* ================= multistream (reference/include/opus_multistream.h:203-726) =================
  * One multistream frame = its streams stepped together by the batch kernels (one launch per group: coupled, mono).  Same names,
- * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: CELT-only applications at 48 kHz, frames <= 20 ms,
- * mapping families 0, 2 (ambisonics) and 255, family 1 up to two channels; int16 entry points.  Family-1 surround (> 2 channels,
+ * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: every application (the elementary encoders are the CELT-only or the
+ * SILK-capable stream records, with the scope stated above for each), frames <= 20 ms, mapping families 0, 2 (ambisonics) and 255, family 1
+ * up to two channels; int16 entry points.  Family-1 surround (> 2 channels,
  * needs the masking analysis) and float / 24-bit entry points return OPUS_UNIMPLEMENTED. */
 typedef struct OpusMSEncoder OpusMSEncoder;
 typedef struct OpusMSDecoder OpusMSDecoder;

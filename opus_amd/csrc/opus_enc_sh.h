@@ -2,9 +2,10 @@
  *
  * Follows src/opus_encoder.c:1182 opus_encode_native (rate, channel, mode and bandwidth decisions :1310-1700) and :1855 opus_encode_frame_native
  * (high-pass :1958-1992, SILK control block :2024-2160, SILK call :2181, TOC / range finalisation :2310-2560, CBR padding :2646) for the SILK-only
- * mode, i.e. applications VOIP, AUDIO and RESTRICTED_SILK at API rates 8-48 kHz, mono/stereo, 10-60 ms frames.  What this round's path does not
- * build is refused loudly through the stream's error word and a negative length: hybrid / CELT-only outcomes of the mode decision, mode and
- * bandwidth transitions that need a CELT redundancy frame, in-band FEC, DTX, frames above 60 ms (repacketised multi-frame packets). */
+ * mode (API rates 8-48 kHz, mono/stereo, 10-60 ms frames) and for hybrid and CELT-only frames at 48 kHz (:2402-2600, sh_hybrid_celt_wave), i.e. applications
+ * VOIP, AUDIO and RESTRICTED_SILK; DTX (:1463, :2242, :2565, decide_dtx_mode :1115) and in-band FEC (decide_fec :940).  What is not built is refused loudly
+ * (negative length, on the frame where it arises): mode and SILK-bandwidth transitions that need a CELT redundancy frame or a SILK prefill, CELT below
+ * 48 kHz, frames above 60 ms (repacketised multi-frame packets). */
 #ifndef OPUS_AMD_OPUS_ENC_SH_H
 #define OPUS_AMD_OPUS_ENC_SH_H
 #include "opus_sh_state.h"

@@ -6,8 +6,9 @@
  *   se_stereo_*           silk_stereo_LR_to_MS / _find_predictor / _quant_pred / _encode_pred   silk/stereo_LR_to_MS.c:35, stereo_find_predictor.c:35, stereo_quant_pred.c:35, stereo_encode_pred.c:35
  *   se_encode_frame_wave  silk_encode_frame_FIX   silk/fixed/encode_frame_FIX.c:85
  *   silk_encode_wave      silk_Encode             silk/enc_API.c:150
- * Not built: prefill (they are driven by Opus-layer options outside this round's path; control words that ask
- * for them make the frame fail loudly through the stream's error word). */
+ * In-band FEC: silk_LBRR_encode_FIX (encode_frame_FIX.c:392) inside se_encode_frame_wave, the LBRR store in HBM (OaSilkLbrr), coded at the head of the
+ * next packet (enc_API.c:355-406).  DTX: the no-speech counter / inDTX logic of silk_encode_do_VAD_FIX and the empty payload of enc_API.c:560.
+ * Not built: prefill (only a CELT -> SILK mode switch asks for it; that switch fails loudly at the Opus layer). */
 #ifndef OPUS_AMD_SILK_ENC_FRAME_H
 #define OPUS_AMD_SILK_ENC_FRAME_H
 
