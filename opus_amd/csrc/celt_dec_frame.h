@@ -731,7 +731,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
 }
 
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
-WV_DEVN void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
+WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
 {
    decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;

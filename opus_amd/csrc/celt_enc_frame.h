@@ -376,7 +376,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    }
 }
 
-WV_DEVN void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
       u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
 {
    WV_LDS FrameShared *sh = &L->sh;

@@ -418,7 +418,7 @@ WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm
    }
 }
 
-WV_DEVN void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
+WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    SE_PHASE_START(&L->S);
