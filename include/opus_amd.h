@@ -231,6 +231,58 @@ OPUS_AMD_EXPORT int opus_multistream_decode(OpusMSDecoder *st, const unsigned ch
 OPUS_AMD_EXPORT int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...);
 OPUS_AMD_EXPORT void opus_multistream_decoder_destroy(OpusMSDecoder *st);
 
+/* ================= the rest of the reference's exported surface (include/opus.h, opus_multistream.h, opus_projection.h) =================
+ * Same names, arguments and error codes.  The arithmetic of this library is the reference's int16-resolution fixed-point build, so the 24-bit and float
+ * entry points convert at the boundary exactly as that build does (celt/arch.h:167-173: INT24TORES = SAT16(PSHR32(x, 8)), FLOAT2RES = FLOAT2INT16,
+ * RES2INT24 = x << 8, RES2FLOAT = x / 32768).  DRED is not built: its entry points answer like a reference compiled without ENABLE_DRED. */
+OPUS_AMD_EXPORT opus_int32 opus_encode24(OpusEncoder *st, const opus_int32 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);      /* opus.h:302 */
+OPUS_AMD_EXPORT opus_int32 opus_encode_float(OpusEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);      /* opus.h:343 */
+OPUS_AMD_EXPORT int opus_decode_float(OpusDecoder *st, const unsigned char *data, opus_int32 len, float *pcm, int frame_size, int decode_fec);        /* opus.h:566 */
+OPUS_AMD_EXPORT int opus_decoder_get_nb_samples(const OpusDecoder *dec, const unsigned char packet[], opus_int32 len);                                /* opus.h:788 */
+OPUS_AMD_EXPORT int opus_packet_has_lbrr(const unsigned char packet[], opus_int32 len);                                                               /* opus.h:778 */
+OPUS_AMD_EXPORT void opus_pcm_soft_clip(float *pcm, int frame_size, int channels, float *softclip_mem);                                               /* opus.h:800 */
+OPUS_AMD_EXPORT int opus_multistream_encode24(OpusMSEncoder *st, const opus_int32 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT int opus_multistream_encode_float(OpusMSEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT int opus_multistream_decode24(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_multistream_decode_float(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, float *pcm, int frame_size, int decode_fec);
+typedef struct OpusDREDDecoder OpusDREDDecoder;
+typedef struct OpusDRED OpusDRED;
+OPUS_AMD_EXPORT int opus_dred_decoder_get_size(void);
+OPUS_AMD_EXPORT OpusDREDDecoder *opus_dred_decoder_create(int *error);
+OPUS_AMD_EXPORT int opus_dred_decoder_init(OpusDREDDecoder *dec);
+OPUS_AMD_EXPORT void opus_dred_decoder_destroy(OpusDREDDecoder *dec);
+OPUS_AMD_EXPORT int opus_dred_decoder_ctl(OpusDREDDecoder *dred_dec, int request, ...);
+OPUS_AMD_EXPORT int opus_dred_get_size(void);
+OPUS_AMD_EXPORT OpusDRED *opus_dred_alloc(int *error);
+OPUS_AMD_EXPORT void opus_dred_free(OpusDRED *dec);
+OPUS_AMD_EXPORT int opus_dred_parse(OpusDREDDecoder *dred_dec, OpusDRED *dred, const unsigned char *data, opus_int32 len, opus_int32 max_dred_samples, opus_int32 sampling_rate, int *dred_end, int defer_processing);
+OPUS_AMD_EXPORT int opus_dred_process(OpusDREDDecoder *dred_dec, const OpusDRED *src, OpusDRED *dst);
+OPUS_AMD_EXPORT int opus_decoder_dred_decode(OpusDecoder *st, const OpusDRED *dred, opus_int32 dred_offset, opus_int16 *pcm, opus_int32 frame_size);
+OPUS_AMD_EXPORT int opus_decoder_dred_decode24(OpusDecoder *st, const OpusDRED *dred, opus_int32 dred_offset, opus_int32 *pcm, opus_int32 frame_size);
+OPUS_AMD_EXPORT int opus_decoder_dred_decode_float(OpusDecoder *st, const OpusDRED *dred, opus_int32 dred_offset, float *pcm, opus_int32 frame_size);
+
+/* ================= projection (ambisonics, reference/include/opus_projection.h:123-632) =================
+ * A mixing matrix in front of a multistream encoder / a demixing matrix behind a multistream decoder (src/opus_projection_encoder.c,
+ * src/opus_projection_decoder.c, src/mapping_matrix.c), mapping family 3, orders 1-5 (+ optional non-diegetic stereo pair). */
+typedef struct OpusProjectionEncoder OpusProjectionEncoder;
+typedef struct OpusProjectionDecoder OpusProjectionDecoder;
+OPUS_AMD_EXPORT opus_int32 opus_projection_ambisonics_encoder_get_size(int channels, int mapping_family);
+OPUS_AMD_EXPORT OpusProjectionEncoder *opus_projection_ambisonics_encoder_create(opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, int application, int *error);
+OPUS_AMD_EXPORT int opus_projection_ambisonics_encoder_init(OpusProjectionEncoder *st, opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, int application);
+OPUS_AMD_EXPORT int opus_projection_encode(OpusProjectionEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT int opus_projection_encode24(OpusProjectionEncoder *st, const opus_int32 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT int opus_projection_encode_float(OpusProjectionEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes);
+OPUS_AMD_EXPORT void opus_projection_encoder_destroy(OpusProjectionEncoder *st);
+OPUS_AMD_EXPORT int opus_projection_encoder_ctl(OpusProjectionEncoder *st, int request, ...);
+OPUS_AMD_EXPORT opus_int32 opus_projection_decoder_get_size(int channels, int streams, int coupled_streams);
+OPUS_AMD_EXPORT OpusProjectionDecoder *opus_projection_decoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, unsigned char *demixing_matrix, opus_int32 demixing_matrix_size, int *error);
+OPUS_AMD_EXPORT int opus_projection_decoder_init(OpusProjectionDecoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, unsigned char *demixing_matrix, opus_int32 demixing_matrix_size);
+OPUS_AMD_EXPORT int opus_projection_decode(OpusProjectionDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_projection_decode24(OpusProjectionDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_projection_decode_float(OpusProjectionDecoder *st, const unsigned char *data, opus_int32 len, float *pcm, int frame_size, int decode_fec);
+OPUS_AMD_EXPORT int opus_projection_decoder_ctl(OpusProjectionDecoder *st, int request, ...);
+OPUS_AMD_EXPORT void opus_projection_decoder_destroy(OpusProjectionDecoder *st);
+
 /* ================= SILK building blocks (reference/silk/NSQ.c, NSQ_del_dec.c, LPC_analysis_filter.c) =================
  * The noise-shaping quantiser for N independent SILK channels, one frame per call.  This is the reference's own RTCD cut
  * (SILK_NSQ_IMPL / SILK_NSQ_DEL_DEC_IMPL, silk/x86/x86_silk_map.c:47-179, prototypes silk/main.h:236-272) lifted to a batch:

@@ -23,7 +23,10 @@ struct OaEncConfig {
    int32_t user_bitrate_bps;    /* OPUS_AUTO (-1000), OPUS_BITRATE_MAX (-1) or bits/s */
    int32_t use_vbr, vbr_constraint, complexity;
    int32_t force_channels, user_bandwidth, max_bandwidth, lsb_depth, disable_inv, packet_loss_perc;
-   int32_t reserved[4];
+   int32_t variable_duration;   /* OPUS_SET_EXPERT_FRAME_DURATION (0 = not set = OPUS_FRAMESIZE_ARG) */
+   int32_t input_depth;         /* sample depth of the entry point of this call: 16 (opus_encode) or 24 (opus_encode24 / _float); 0 = 16 */
+   int32_t lfe;                 /* OPUS_SET_LFE (multistream surround) */
+   int32_t prediction_disabled; /* OPUS_SET_PREDICTION_DISABLED */
 };
 
 /* per-stream persistent state: scalars (kept in LDS while a frame is being encoded) ... */
@@ -51,6 +54,12 @@ struct OaEncState {
 struct OaStream {
    OaEncConfig cfg;
    OaEncState st;
+   /* tail (added after the arrays so that the offsets above stay put) */
+   int32_t Fs;                  /* API rate: 48000 (0 = 48000), 24000, 16000, 12000, 8000 (CELT zero-stuffs up to 48 kHz, celt_encoder.c:255,:557) */
+   int32_t use_dtx, nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize, energy_mask_on;
+   int32_t signal_type, use_inband_fec, user_forced_mode, voice_ratio;   /* accepted and read back like the reference does; they do not change CELT-only coding */
+   int32_t tail_pad[5];
+   int32_t energy_mask[2 * OA_NB_EBANDS];   /* surround masking of this stream (OPUS_SET_ENERGY_MASK; copied in by the multistream layer each frame) */
 };
 
 
@@ -68,7 +77,8 @@ struct OaDecScalars {
    int32_t postfilter_period, postfilter_period_old, postfilter_gain, postfilter_gain_old, postfilter_tapset, postfilter_tapset_old, prefilter_and_fold;
    int32_t preemph_memD[2];
    int32_t hist_head;
-   int32_t pad0[3];
+   int32_t Fs;                  /* API (output) rate: 48000 (0 = 48000), 24000, 16000, 12000, 8000 */
+   int32_t pad0[2];
 };
 /* ---- SILK decoder state (reference silk_decoder_state silk/structs.h:236-286, silk_decoder / stereo_dec_state silk/main.h, silk/structs.h:121-127),
  * flat: table pointers of the reference (NLSF codebook, iCDFs) are re-derived from fs_kHz / nb_subfr, the resampler is its nine configuration

@@ -24,6 +24,7 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #include "silk_enc_all.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -71,155 +72,25 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max
 
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "opus_amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return OPUS_INTERNAL_ERROR; } } while (0)
 
-/* ---------------- host-side state initialisation / ctl (mirrors opus_encoder_init :204 and opus_encoder_ctl :2772) ---------------- */
-static int oa_init_stream(OaStream *st, opus_int32 Fs, int channels, int application)
+#include "opus_enc_host.h"
+/* frame sizes an encode call accepts: 2.5, 5, 10, 20, 40, 60, 80, 100, 120 ms at the API rate (frame_size_select :845; the SILK-only application starts at 10 ms) */
+/* bytes of the per-stream output slot a call needs: the packet itself, and for calls above 20 ms (repacketised multi-frame packets, src/opus_encoder.c:1698-1838)
+ * the 48-byte staging head-room of oa_multiframe_* (opus_multiframe.h) */
+static opus_int32 oa_enc_out_stride_needed(opus_int32 Fs, int frame_size, opus_int32 max_data_bytes)
 {
-   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2) ||
-       (application != OPUS_APPLICATION_VOIP && application != OPUS_APPLICATION_AUDIO && application != OPUS_APPLICATION_RESTRICTED_LOWDELAY &&
-        application != OPUS_APPLICATION_RESTRICTED_SILK && application != OPUS_APPLICATION_RESTRICTED_CELT))
-      return OPUS_BAD_ARG;
-   if (Fs != 48000 || (application != OPUS_APPLICATION_RESTRICTED_LOWDELAY && application != OPUS_APPLICATION_RESTRICTED_CELT))
-      return OPUS_UNIMPLEMENTED;
-   memset(st, 0, sizeof(*st));
-   st->cfg.channels = channels; st->cfg.application = application; st->cfg.user_bitrate_bps = OPUS_AUTO;
-   st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = OPUS_AUTO;
-   st->cfg.user_bandwidth = OPUS_AUTO; st->cfg.max_bandwidth = OPUS_BANDWIDTH_FULLBAND; st->cfg.lsb_depth = 24;
-   st->st.s.stream_channels = channels; st->st.s.bandwidth = OPUS_BANDWIDTH_FULLBAND; st->st.s.first = 1; st->st.s.hybrid_stereo_width_Q14 = 1 << 14;
-   st->st.s.spread_decision = 2; st->st.s.delayedIntra = 1; st->st.s.tonal_average = 256;
-   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->st.oldLogE[i] = st->st.oldLogE2[i] = -(28 << 24);
-   return OPUS_OK;
+   const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;
+   const opus_int32 cap = 1276 * nf, m = max_data_bytes < cap ? max_data_bytes : cap;
+   return nf > 1 ? m + 48 : m;
 }
-static void oa_reset_stream(OaStream *st)
+static int oa_enc_frame_size_code(opus_int32 Fs, int application, int frame_size)
 {
-   OaEncConfig cfg = st->cfg;
-   oa_init_stream(st, 48000, cfg.channels, cfg.application);
-   st->cfg = cfg;
-}
-static int oa_ctl_set(OaStream *st, int request, opus_int32 value)
-{
-   switch (request) {
-   case OPUS_SET_BITRATE_REQUEST:
-      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) {
-         if (value <= 0) return OPUS_BAD_ARG;
-         else if (value <= 500) value = 500;
-         else if (value > (opus_int32)750000 * st->cfg.channels) value = (opus_int32)750000 * st->cfg.channels;
-      }
-      st->cfg.user_bitrate_bps = value; return OPUS_OK;
-   case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; st->cfg.complexity = value; return OPUS_OK;
-   case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.use_vbr = value; return OPUS_OK;
-   case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.vbr_constraint = value; return OPUS_OK;
-   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > st->cfg.channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; st->cfg.force_channels = value; return OPUS_OK;
-   case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; st->cfg.user_bandwidth = value; return OPUS_OK;
-   case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; st->cfg.max_bandwidth = value; return OPUS_OK;
-   case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; st->cfg.lsb_depth = value; return OPUS_OK;
-   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; st->cfg.disable_inv = value; return OPUS_OK;
-   case OPUS_RESET_STATE: oa_reset_stream(st); return OPUS_OK;
-   default: return OPUS_UNIMPLEMENTED;
-   }
-}
-static int oa_ctl_get(const OaStream *st, int request, opus_int32 *value)
-{
-   if (!value) return OPUS_BAD_ARG;
-   switch (request) {
-   case OPUS_GET_APPLICATION_REQUEST: *value = st->cfg.application; return OPUS_OK;
-   case OPUS_GET_BITRATE_REQUEST: {
-      opus_int32 fs = 960, mb = 1276, maxb = mb * 8 * (6 * 48000 / fs) / 6;
-      opus_int32 ub = st->cfg.user_bitrate_bps == OPUS_AUTO ? 60 * 48000 / fs + 48000 * st->cfg.channels : (st->cfg.user_bitrate_bps == OPUS_BITRATE_MAX ? 1500000 : st->cfg.user_bitrate_bps);
-      *value = ub < maxb ? ub : maxb; return OPUS_OK; }
-   case OPUS_GET_COMPLEXITY_REQUEST: *value = st->cfg.complexity; return OPUS_OK;
-   case OPUS_GET_VBR_REQUEST: *value = st->cfg.use_vbr; return OPUS_OK;
-   case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = st->cfg.vbr_constraint; return OPUS_OK;
-   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = st->cfg.force_channels; return OPUS_OK;
-   case OPUS_GET_BANDWIDTH_REQUEST: *value = st->st.s.bandwidth; return OPUS_OK;
-   case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = st->cfg.max_bandwidth; return OPUS_OK;
-   case OPUS_GET_LSB_DEPTH_REQUEST: *value = st->cfg.lsb_depth; return OPUS_OK;
-   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: *value = st->cfg.disable_inv; return OPUS_OK;
-   case OPUS_GET_SAMPLE_RATE_REQUEST: *value = 48000; return OPUS_OK;
-   case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)st->st.s.rangeFinal; return OPUS_OK;
-   default: return OPUS_UNIMPLEMENTED;
-   }
-}
-static int oa_frame_size_ok(int frame_size) { return frame_size == 120 || frame_size == 240 || frame_size == 480 || frame_size == 960; }
-
-/* ---------------- the SILK-capable stream record (applications VOIP / AUDIO / RESTRICTED_SILK) ---------------- */
-static int oa_app_is_sh(int application) { return application == OPUS_APPLICATION_VOIP || application == OPUS_APPLICATION_AUDIO || application == OPUS_APPLICATION_RESTRICTED_SILK; }
-static int sh_init_stream(OaShStream *st, opus_int32 Fs, int channels, int application)
-{
-   if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2) || !oa_app_is_sh(application)) return OPUS_BAD_ARG;
-   oa_sh_stream_init(st, Fs, channels, application);
-   return OPUS_OK;
-}
-static int sh_ctl_set(OaShStream *st, int request, opus_int32 value)
-{
-   OaShConfig *c = &st->cfg;
-   switch (request) {
-   case OPUS_SET_BITRATE_REQUEST:
-      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) { if (value <= 0) return OPUS_BAD_ARG; else if (value <= 500) value = 500; else if (value > (opus_int32)750000 * c->channels) value = (opus_int32)750000 * c->channels; }
-      c->user_bitrate_bps = value; return OPUS_OK;
-   case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; c->complexity = value; return OPUS_OK;
-   case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_vbr = value; return OPUS_OK;
-   case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->vbr_constraint = value; return OPUS_OK;
-   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > c->channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->force_channels = value; return OPUS_OK;
-   case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_bandwidth = value; return OPUS_OK;
-   case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; c->max_bandwidth = value; return OPUS_OK;
-   case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; c->lsb_depth = value; return OPUS_OK;
-   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->disable_inv = value; return OPUS_OK;
-   case OPUS_SET_FORCE_MODE_REQUEST: if ((value < OPUS_MODE_SILK_ONLY || value > OPUS_MODE_CELT_ONLY) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_forced_mode = value; return OPUS_OK;
-   case OPUS_SET_SIGNAL_REQUEST: if (value != OPUS_AUTO && value != OPUS_SIGNAL_VOICE && value != OPUS_SIGNAL_MUSIC) return OPUS_BAD_ARG; c->signal_type = value; return OPUS_OK;
-   case OPUS_SET_PACKET_LOSS_PERC_REQUEST: if (value < 0 || value > 100) return OPUS_BAD_ARG; c->packet_loss_perc = value; return OPUS_OK;
-   case OPUS_SET_INBAND_FEC_REQUEST: if (value < 0 || value > 2) return OPUS_BAD_ARG; c->use_inband_fec = value; return OPUS_OK;     /* refused at encode time when it would produce LBRR */
-   case OPUS_SET_DTX_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_dtx = value; return OPUS_OK;
-   case OPUS_RESET_STATE: oa_sh_stream_reset(st, c->Fs, c->channels, c->application); return OPUS_OK;
-   default: return OPUS_UNIMPLEMENTED;
-   }
-}
-static int sh_ctl_get(const OaShStream *st, int request, opus_int32 *value)
-{
-   if (!value) return OPUS_BAD_ARG;
-   const OaShConfig *c = &st->cfg;
-   switch (request) {
-   case OPUS_GET_APPLICATION_REQUEST: *value = c->application; return OPUS_OK;
-   case OPUS_GET_BITRATE_REQUEST: {
-      const opus_int32 fs = st->s.prev_framesize ? st->s.prev_framesize : c->Fs / 400, maxb = 1276 * 8 * (6 * c->Fs / fs) / 6;
-      const opus_int32 ub = c->user_bitrate_bps == OPUS_AUTO ? 60 * c->Fs / fs + c->Fs * c->channels : (c->user_bitrate_bps == OPUS_BITRATE_MAX ? 1500000 : c->user_bitrate_bps);
-      *value = ub < maxb ? ub : maxb; return OPUS_OK; }
-   case OPUS_GET_COMPLEXITY_REQUEST: *value = c->complexity; return OPUS_OK;
-   case OPUS_GET_VBR_REQUEST: *value = c->use_vbr; return OPUS_OK;
-   case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = c->vbr_constraint; return OPUS_OK;
-   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = c->force_channels; return OPUS_OK;
-   case OPUS_GET_BANDWIDTH_REQUEST: *value = st->s.bandwidth; return OPUS_OK;
-   case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = c->max_bandwidth; return OPUS_OK;
-   case OPUS_GET_LSB_DEPTH_REQUEST: *value = c->lsb_depth; return OPUS_OK;
-   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: *value = c->disable_inv; return OPUS_OK;
-   case OPUS_GET_SIGNAL_REQUEST: *value = c->signal_type; return OPUS_OK;
-   case OPUS_GET_PACKET_LOSS_PERC_REQUEST: *value = c->packet_loss_perc; return OPUS_OK;
-   case OPUS_GET_INBAND_FEC_REQUEST: *value = c->use_inband_fec; return OPUS_OK;
-   case OPUS_GET_DTX_REQUEST: *value = c->use_dtx; return OPUS_OK;
-   case OPUS_GET_SAMPLE_RATE_REQUEST: *value = c->Fs; return OPUS_OK;
-   case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)st->s.rangeFinal; return OPUS_OK;
-   case OPUS_GET_IN_DTX_REQUEST:                                                    /* src/opus_encoder.c:3299-3322 */
-      if (st->s.sm_useDTX && (st->s.prev_mode == OA_MODE_SILK_ONLY || st->s.prev_mode == OA_MODE_HYBRID)) {
-         *value = st->silk.ch[0].noSpeechCounter >= 10;
-         if (*value == 1 && st->silk.nChannelsInternal == 2 && st->silk.prev_decode_only_middle == 0) *value = st->silk.ch[1].noSpeechCounter >= 10;
-      } else if (c->use_dtx) *value = st->s.nb_no_activity_ms_Q1 >= 10 * 20 * 2;
-      else *value = 0;
-      return OPUS_OK;
-   default: return OPUS_UNIMPLEMENTED;
-   }
-}
-/* frame sizes of the SILK layer: 10, 20, 40, 60 ms (2.5 / 5 ms need CELT; 80-120 ms are repacketised multi-frame packets) */
-static int sh_frame_size_code(opus_int32 Fs, int frame_size)
-{
-   if (frame_size == Fs / 100 || frame_size == Fs / 50 || frame_size == Fs / 25 || frame_size == 3 * Fs / 50) return OPUS_OK;
-   if ((frame_size == Fs / 400 || frame_size == Fs / 200) && Fs == 48000) return OPUS_OK;                /* CELT-only frames */
-   if (frame_size == Fs / 400 || frame_size == Fs / 200 || frame_size == 4 * Fs / 50 || frame_size == 5 * Fs / 50 || frame_size == 6 * Fs / 50) return OPUS_UNIMPLEMENTED;
-   return OPUS_BAD_ARG;
+   return oa_frame_size_select(application, frame_size, OPUS_FRAMESIZE_ARG, Fs) == frame_size ? OPUS_OK : OPUS_BAD_ARG;
 }
 
 /* ---------------- batch object ---------------- */
 struct OpusGpuEncBatch {
    int kind;                            /* 0: CELT-only kernel (OaStream), 1: SILK-capable kernel (OaShStream) */
-   opus_int32 Fs;
+   opus_int32 Fs; int application;
    OaShStream *d_sh;
    std::vector<OaShStream> h_sh;
    opus_int16 *d_pcm_hp; size_t hp_cap; /* per-stream scratch of the high-passed input (kind 1) */
@@ -266,7 +137,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = false;
-      b->kind = kind; b->Fs = Fs; b->d_sh = nullptr; b->d_pcm_hp = nullptr; b->hp_cap = 0;
+      b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_pcm_hp = nullptr; b->hp_cap = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -375,10 +246,9 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
-   if (b->kind) { const int fr = sh_frame_size_code(b->Fs, frame_size); if (fr != OPUS_OK) return fr; }
-   else if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
-   if (out_stride < (max_data_bytes < 1276 ? max_data_bytes : 1276)) return OPUS_BUFFER_TOO_SMALL;
+   if (out_stride < oa_enc_out_stride_needed(b->Fs, frame_size, max_data_bytes)) return OPUS_BUFFER_TOO_SMALL;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    if (b->kind) {
@@ -418,8 +288,7 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
 {
    if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
-   if (b->kind) { const int fr = sh_frame_size_code(b->Fs, frame_size); if (fr != OPUS_OK) return fr; }
-   else if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    HIPCHECK(hipSetDevice(b->device));
    size_t npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->S * out_stride;
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
@@ -438,29 +307,21 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
 #define OA_MAGIC 0x4f41454eu /* "OAEN" */
 struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pad[2]; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
 static std::mutex g_classic_mu;
-static OpusGpuEncBatch *g_classic[2] = {nullptr, nullptr};    /* CELT-only kernel, per channel count */
-static OpusGpuEncBatch *g_classic_sh[5][2];                   /* SILK-capable kernel, per API rate and channel count */
+static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][API rate][channels - 1] */
 static int oa_fs_index(opus_int32 Fs) { return Fs == 8000 ? 0 : Fs == 12000 ? 1 : Fs == 16000 ? 2 : Fs == 24000 ? 3 : 4; }
 
 int opus_encoder_get_size(int channels) { if (channels < 1 || channels > 2) return 0; return (int)sizeof(OpusEncoder); }
 int opus_encoder_init(OpusEncoder *st, opus_int32 Fs, int channels, int application)
 {
    if (!st) return OPUS_BAD_ARG;
-   if (oa_app_is_sh(application)) {
-      if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
-      memset(st, 0, sizeof(*st));
-      st->magic = OA_MAGIC; st->kind = 1;
-      return sh_init_stream(&st->sh, Fs, channels, application);
-   }
-   OaStream tmp;
-   int r = oa_init_stream(&tmp, Fs, channels, application);
-   if (r != OPUS_OK) return r;
+   if (!oa_fs_ok(Fs) || (channels != 1 && channels != 2) || !oa_app_ok(application)) return OPUS_BAD_ARG;
    memset(st, 0, sizeof(*st));
-   st->magic = OA_MAGIC; st->kind = 0; st->s = tmp;
-   return OPUS_OK;
+   st->magic = OA_MAGIC; st->kind = (uint32_t)oa_app_is_sh(application);
+   return st->kind ? sh_init_stream(&st->sh, Fs, channels, application) : oa_init_stream(&st->s, Fs, channels, application);
 }
 OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, int *error)
 {
+   if (!oa_fs_ok(Fs) || (channels != 1 && channels != 2) || !oa_app_ok(application)) { if (error) *error = OPUS_BAD_ARG; return nullptr; }
    OpusEncoder *st = (OpusEncoder *)malloc(sizeof(OpusEncoder));
    if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return nullptr; }
    int r = opus_encoder_init(st, Fs, channels, application);
@@ -469,34 +330,65 @@ OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, i
    return st;
 }
 void opus_encoder_destroy(OpusEncoder *st) { free(st); }
-opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+/* one frame of one classic encoder: the record goes to the device, the kernel runs a batch of one, the record comes back.  depth = the sample depth
+ * of the entry point (opus_encode 16, opus_encode24 / _float 24: the lsb_depth argument of opus_encode_native, src/opus_encoder.c:2667,:2722) */
+static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth)
 {
    if (!st || st->magic != OA_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
-   if (max_data_bytes <= 0) return OPUS_BAD_ARG;
+   const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels, application = st->kind ? st->sh.cfg.application : st->s.cfg.application;
+   const opus_int32 Fs = st->kind ? st->sh.cfg.Fs : st->s.Fs;
+   const int frame_size = (int)oa_frame_size_select(application, analysis_frame_size, st->kind ? st->sh.cfg.variable_duration : st->s.cfg.variable_duration, Fs);
+   if (frame_size <= 0 || max_data_bytes <= 0) return OPUS_BAD_ARG;
    std::lock_guard<std::mutex> lock(g_classic_mu);
-   OpusGpuEncBatch **slot;
-   int channels; opus_int32 Fs; int application;
-   if (st->kind) { channels = st->sh.cfg.channels; Fs = st->sh.cfg.Fs; application = st->sh.cfg.application; slot = &g_classic_sh[oa_fs_index(Fs)][channels - 1]; const int fr = sh_frame_size_code(Fs, frame_size); if (fr != OPUS_OK) return fr; }
-   else {
-      channels = st->s.cfg.channels; Fs = 48000; application = st->s.cfg.application; slot = &g_classic[channels - 1];
-      if (!oa_frame_size_ok(frame_size)) return frame_size > 960 && frame_size % 120 == 0 && frame_size <= 5760 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
-   }
+   OpusGpuEncBatch **slot = &g_classic[st->kind][oa_fs_index(Fs)][channels - 1];
    if (!*slot) {
       int err;
-      *slot = opusgpu_enc_batch_create(1, Fs, channels, application, 0, &err);
+      *slot = opusgpu_enc_batch_create(1, Fs, channels, st->kind ? OPUS_APPLICATION_AUDIO : OPUS_APPLICATION_RESTRICTED_LOWDELAY, 0, &err);
       if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
    OpusGpuEncBatch *b = *slot;
-   unsigned char buf[1280];
+   b->application = application;
+   if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
+   const opus_int32 stride = oa_enc_out_stride_needed(Fs, frame_size, max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6) + 8;
+   std::vector<unsigned char> buf((size_t)(stride < 1288 ? 1288 : stride));
    opus_int32 len = 0; opus_uint32 rng = 0;
-   opus_int32 cap = max_data_bytes < 1276 ? max_data_bytes : 1276;
    void *blob = st->kind ? (void *)&st->sh : (void *)&st->s;
    int r = opusgpu_enc_batch_import_state(b, 0, blob);
-   if (r == OPUS_OK) r = opusgpu_encode_batch(b, pcm, frame_size, buf, 1280, max_data_bytes, &len, &rng);
+   if (r == OPUS_OK) r = opusgpu_encode_batch(b, pcm, frame_size, buf.data(), (opus_int32)buf.size(), max_data_bytes, &len, &rng);
    if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, blob);
    if (r != OPUS_OK) return r;
-   if (len > 0) memcpy(data, buf, (size_t)(len < cap ? len : cap));
+   if (len > 0) memcpy(data, buf.data(), (size_t)(len < max_data_bytes ? len : max_data_bytes));
    return len;
+}
+opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   return oa_classic_encode(st, pcm, frame_size, data, max_data_bytes, 16);
+}
+/* int16-resolution build of the reference (FIXED_POINT without ENABLE_RES24): the 24-bit and float inputs are rounded to int16 first
+ * (INT24TORES = SAT16(PSHR32(a, 8)), FLOAT2RES = FLOAT2INT16; celt/arch.h:171-173, src/opus_encoder.c:2703-2722, :2745-2765) */
+static inline opus_int16 oa_sat16(opus_int32 x) { return (opus_int16)(x > 32767 ? 32767 : x < -32768 ? -32768 : x); }
+static inline opus_int16 oa_float2int16(float x)
+{
+   x = x * 32768.f;
+   x = x > -32768.f ? x : -32768.f;
+   x = x < 32767.f ? x : 32767.f;
+   return (opus_int16)lrintf(x);
+}
+opus_int32 opus_encode24(OpusEncoder *st, const opus_int32 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   if (!st || st->magic != OA_MAGIC || !pcm || frame_size <= 0 || frame_size > 5760 * 2) return OPUS_BAD_ARG;
+   const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels;
+   std::vector<opus_int16> in((size_t)frame_size * channels);
+   for (size_t i = 0; i < in.size(); i++) in[i] = oa_sat16((pcm[i] + 128) >> 8);
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24);
+}
+opus_int32 opus_encode_float(OpusEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   if (!st || st->magic != OA_MAGIC || !pcm || frame_size <= 0 || frame_size > 5760 * 2) return OPUS_BAD_ARG;
+   const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels;
+   std::vector<opus_int16> in((size_t)frame_size * channels);
+   for (size_t i = 0; i < in.size(); i++) in[i] = oa_float2int16(pcm[i]);
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24);
 }
 int opus_encoder_ctl(OpusEncoder *st, int request, ...)
 {
@@ -505,6 +397,38 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    va_start(ap, request);
    int ret;
    if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
+   else if (request == OPUS_SET_ENERGY_MASK_REQUEST) {                                  /* internal (src/opus_private.h): multistream surround masking, 21 values per channel or NULL */
+      const opus_int32 *m = va_arg(ap, const opus_int32 *);
+      opus_int32 *dst = st->kind ? st->sh.energy_mask : st->s.energy_mask;
+      const int n = 21 * (st->kind ? st->sh.cfg.channels : st->s.cfg.channels);
+      if (m) memcpy(dst, m, sizeof(opus_int32) * (size_t)n);
+      if (st->kind) st->sh.cfg.energy_mask_on = m != nullptr; else st->s.energy_mask_on = m != nullptr;
+      ret = OPUS_OK;
+   }
+   else if (request == OPUS_SET_APPLICATION_REQUEST) {
+      const opus_int32 v = va_arg(ap, opus_int32);
+      ret = st->kind ? sh_ctl_set(&st->sh, request, v) : oa_ctl_set(&st->s, request, v);
+      if (ret == OPUS_UNIMPLEMENTED) {                                                  /* legal before the first frame, but the new application lives in the other record type: convert */
+         OpusEncoder *o = (OpusEncoder *)malloc(sizeof(OpusEncoder));
+         if (!o) ret = OPUS_ALLOC_FAIL;
+         else {
+            memcpy(o, st, sizeof(*o));
+            ret = opus_encoder_init(st, o->kind ? o->sh.cfg.Fs : o->s.Fs, o->kind ? o->sh.cfg.channels : o->s.cfg.channels, v);
+            static const int carry[] = {OPUS_SET_BITRATE_REQUEST, OPUS_SET_COMPLEXITY_REQUEST, OPUS_SET_VBR_REQUEST, OPUS_SET_VBR_CONSTRAINT_REQUEST, OPUS_SET_FORCE_CHANNELS_REQUEST,
+               OPUS_SET_BANDWIDTH_REQUEST, OPUS_SET_MAX_BANDWIDTH_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST, OPUS_SET_FORCE_MODE_REQUEST, OPUS_SET_SIGNAL_REQUEST,
+               OPUS_SET_PACKET_LOSS_PERC_REQUEST, OPUS_SET_INBAND_FEC_REQUEST, OPUS_SET_DTX_REQUEST, OPUS_SET_VOICE_RATIO_REQUEST, OPUS_SET_EXPERT_FRAME_DURATION_REQUEST, OPUS_SET_PREDICTION_DISABLED_REQUEST};
+            for (size_t i = 0; ret == OPUS_OK && i < sizeof(carry) / sizeof(carry[0]); i++) {
+               opus_int32 cur = 0;
+               if (carry[i] == OPUS_SET_BITRATE_REQUEST) cur = o->kind ? o->sh.cfg.user_bitrate_bps : o->s.cfg.user_bitrate_bps;
+               else if (carry[i] == OPUS_SET_BANDWIDTH_REQUEST) cur = o->kind ? o->sh.cfg.user_bandwidth : o->s.cfg.user_bandwidth;
+               else if (carry[i] == OPUS_SET_FORCE_MODE_REQUEST) cur = o->kind ? o->sh.cfg.user_forced_mode : o->s.user_forced_mode;
+               else if ((o->kind ? sh_ctl_get(&o->sh, carry[i] + 1, &cur) : oa_ctl_get(&o->s, carry[i] + 1, &cur)) != OPUS_OK) continue;
+               (void)(st->kind ? sh_ctl_set(&st->sh, carry[i], cur) : oa_ctl_set(&st->s, carry[i], cur));
+            }
+            free(o);
+         }
+      }
+   }
    else if (request & 1) { opus_int32 *p = va_arg(ap, opus_int32 *); ret = st->kind ? sh_ctl_get(&st->sh, request, p) : oa_ctl_get(&st->s, request, p); }   /* GET requests are odd */
    else { opus_int32 v = va_arg(ap, opus_int32); ret = st->kind ? sh_ctl_set(&st->sh, request, v) : oa_ctl_set(&st->s, request, v); }
    va_end(ap);
@@ -537,12 +461,12 @@ OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset
 static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
 {
    if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
-   if (Fs != 48000) return OPUS_UNIMPLEMENTED;
    oa_dec_stream_reset(st, channels);
+   st->s.Fs = Fs;
    return OPUS_OK;
 }
 struct OpusGpuDecBatch {
-   int device; opus_int32 S; int channels; int decode_fec; hipStream_t stream;
+   int device; opus_int32 S; int channels; opus_int32 Fs; int decode_fec; hipStream_t stream;
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
 };
@@ -582,7 +506,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuDecBatch();
-      b->device = device; b->S = nstreams; b->channels = channels; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
+      b->device = device; b->S = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -606,7 +530,7 @@ int opusgpu_dec_batch_reset(OpusGpuDecBatch *b)
 {
    if (!b) return OPUS_BAD_ARG;
    OaDecStream *proto = new OaDecStream;
-   oa_dec_init_stream(proto, 48000, b->channels);
+   oa_dec_init_stream(proto, b->Fs, b->channels);
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    std::vector<OaDecStream> init((size_t)(b->S < 256 ? b->S : 256), *proto);
@@ -687,9 +611,11 @@ int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, 
 /* ---- classic decoder API: flat host blob, batch of one per call (reference src/opus_decoder.c:121 get_size, :135 init, :186 create,
  *      :890 opus_decode, :1033 ctl, :1246 destroy) ---- */
 #define OA_DEC_MAGIC 0x4f414443u
-struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 pad[2]; OaDecStream s; };
+#define OPUS_SET_GAIN_REQUEST 4034
+#define OPUS_GET_GAIN_REQUEST 4045
+struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 decode_gain; opus_int32 pad[1]; OaDecStream s; };
 static std::mutex g_classic_dec_mu;
-static OpusGpuDecBatch *g_classic_dec[2] = {nullptr, nullptr};
+static OpusGpuDecBatch *g_classic_dec[5][2];
 int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
 int opus_decoder_init(OpusDecoder *st, opus_int32 Fs, int channels)
 {
@@ -711,6 +637,27 @@ OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error)
    return st;
 }
 void opus_decoder_destroy(OpusDecoder *st) { free(st); }
+/* OPUS_SET_GAIN (src/opus_decoder.c:700-712): gain = celt_exp2(6.48814081e-4 * decode_gain) in Q16-ish fixed point, applied with saturation */
+static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
+{
+   /* celt_exp2(MULT16_16_P15(QCONST16(6.48814081e-4f, 25), decode_gain)) with the reference's fixed-point celt_exp2 (celt/mathops.h) */
+   const opus_int32 x = ((opus_int32)21771 * (opus_int16)decode_gain + 16384) >> 15;   /* QCONST16(6.48814081e-4, 25) = 21771; result Q10 */
+   opus_int32 gain;
+   {  /* celt_exp2(x), x in Q10 -> Q16 */
+      const int integer = x >> 10;
+      if (integer > 14) gain = 0x7f000000;
+      else if (integer < -15) gain = 0;
+      else {
+         const opus_int32 fr = (opus_int32)(opus_int16)(x - (integer << 10)) << 4;      /* celt_exp2_frac, Q14 */
+         opus_int32 f = 16383 + (((opus_int32)(opus_int16)fr * (22804 + (((opus_int32)(opus_int16)fr * (14819 + ((10204 * (opus_int32)(opus_int16)fr) >> 15))) >> 15))) >> 15);
+         gain = integer + 2 >= 0 ? f << (integer + 2) : f >> (-2 - integer);                 /* VSHR32(frac, -integer-2) */
+      }
+   }
+   for (int i = 0; i < n; i++) {
+      const opus_int32 y = (opus_int32)(((long long)(opus_int16)pcm[i] * gain + 32768) >> 16);   /* MULT16_32_P16 */
+      pcm[i] = (opus_int16)(y > 32767 ? 32767 : y < -32767 ? -32767 : y);
+   }
+}
 int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec)
 {
    if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
@@ -719,15 +666,16 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (len < 0) return OPUS_BAD_ARG;
    if (data == nullptr) len = 0;                    /* packet loss */
    if (len == 0) decode_fec = 0;
-   if (frame_size > 5760) frame_size = 5760;
+   const int cap = st->Fs / 25 * 3;                 /* 120 ms */
+   if (frame_size > cap) frame_size = cap;
    std::lock_guard<std::mutex> lock(g_classic_dec_mu);
-   const int ci = st->s.s.channels - 1;
-   if (!g_classic_dec[ci]) {
+   const int ci = st->s.s.channels - 1, fi = oa_fs_index(st->Fs);
+   if (!g_classic_dec[fi][ci]) {
       int err;
-      g_classic_dec[ci] = opusgpu_dec_batch_create(1, 48000, st->s.s.channels, 0, &err);
-      if (!g_classic_dec[ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+      g_classic_dec[fi][ci] = opusgpu_dec_batch_create(1, st->Fs, st->s.s.channels, 0, &err);
+      if (!g_classic_dec[fi][ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
-   OpusGpuDecBatch *b = g_classic_dec[ci];
+   OpusGpuDecBatch *b = g_classic_dec[fi][ci];
    std::vector<unsigned char> pkt((size_t)len + 8, 0);
    if (len > 0) memcpy(pkt.data(), data, (size_t)len);
    std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
@@ -737,23 +685,41 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (r == OPUS_OK) r = opusgpu_decode_batch(b, pkt.data(), (opus_int32)pkt.size(), &l, out.data(), frame_size, &n, &rng);
    if (r == OPUS_OK) r = opusgpu_dec_batch_export_state(b, 0, &st->s);
    if (r != OPUS_OK) return r;
-   if (n > 0) memcpy(pcm, out.data(), (size_t)n * st->s.s.channels * sizeof(opus_int16));
+   if (n > 0) { if (st->decode_gain) oa_apply_decode_gain(out.data(), n * st->s.s.channels, st->decode_gain); memcpy(pcm, out.data(), (size_t)n * st->s.s.channels * sizeof(opus_int16)); }
    return n;
 }
-/* opus_decode24 (reference include/opus.h:541, src/opus_decoder.c:947-980, the int16-resolution build): decode, then RES2INT24 = << 8 */
-int opus_decode24(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec)
+/* opus_decode24 / opus_decode_float (reference include/opus.h:541,:566; src/opus_decoder.c:947-1030, the int16-resolution build): the frame size is
+ * first limited to what the packet holds (so the temporary is no larger than needed), then decode, then RES2INT24 = << 8 / RES2FLOAT = * 1/32768 */
+static int oa_decode_limit(OpusDecoder *st, const unsigned char *data, opus_int32 len, int frame_size, int decode_fec)
 {
-   if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
    if (frame_size <= 0) return OPUS_BAD_ARG;
    if (data != nullptr && len > 0 && !decode_fec) {
       const int nb = opus_packet_get_nb_samples(data, len, st->Fs);
       if (nb > 0) frame_size = frame_size < nb ? frame_size : nb; else return OPUS_INVALID_PACKET;
    }
+   return frame_size;
+}
+int opus_decode24(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec)
+{
+   if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
+   frame_size = oa_decode_limit(st, data, len, frame_size, decode_fec);
+   if (frame_size < 0) return frame_size;
    std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
    const int ret = opus_decode(st, data, len, out.data(), frame_size, decode_fec);
    for (int i = 0; i < ret * st->s.s.channels; i++) pcm[i] = (opus_int32)out[i] * 256;
    return ret;
 }
+int opus_decode_float(OpusDecoder *st, const unsigned char *data, opus_int32 len, float *pcm, int frame_size, int decode_fec)
+{
+   if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
+   frame_size = oa_decode_limit(st, data, len, frame_size, decode_fec);
+   if (frame_size < 0) return frame_size;
+   std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
+   const int ret = opus_decode(st, data, len, out.data(), frame_size, decode_fec);
+   for (int i = 0; i < ret * st->s.s.channels; i++) pcm[i] = (1.f / 32768.f) * out[i];
+   return ret;
+}
+int opus_decoder_get_nb_samples(const OpusDecoder *dec, const unsigned char packet[], opus_int32 len) { return opus_packet_get_nb_samples(packet, len, dec->Fs); }
 int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 {
    if (!st || st->magic != OA_DEC_MAGIC) return OPUS_BAD_ARG;
@@ -761,12 +727,21 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
    va_start(ap, request);
    int ret = OPUS_OK;
    switch (request) {
-   case OPUS_RESET_STATE: { OaDecStream *tmp = new OaDecStream; oa_dec_init_stream(tmp, st->Fs, st->s.s.channels); st->s = *tmp; delete tmp; } break;
+   case OPUS_RESET_STATE: { OaDecStream *tmp = new OaDecStream; oa_dec_init_stream(tmp, st->Fs, st->s.s.channels); tmp->s.disable_inv = st->s.s.disable_inv; st->s = *tmp; delete tmp; } break;
    case OPUS_GET_FINAL_RANGE_REQUEST: { opus_uint32 *p = va_arg(ap, opus_uint32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.rangeFinal; } break;
    case OPUS_GET_SAMPLE_RATE_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->Fs; } break;
    case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.bandwidth; } break;
    case 4039 /* OPUS_GET_LAST_PACKET_DURATION */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.last_packet_duration; } break;
-   case 4033 /* OPUS_GET_PITCH */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.postfilter_period; } break;
+   case 4033 /* OPUS_GET_PITCH (:1090): the CELT post-filter period, or the SILK lag scaled to 48 kHz */: {
+      opus_int32 *p = va_arg(ap, opus_int32 *);
+      if (!p) ret = OPUS_BAD_ARG;
+      else if (st->s.s.prev_mode == 1002) *p = st->s.s.postfilter_period;
+      else *p = st->s.silk.ch[0].prevSignalType == 2 ? st->s.silk.ch[0].lagPrev * 48 / (st->s.silk.ch[0].fs_kHz ? st->s.silk.ch[0].fs_kHz : 16) : 0;
+   } break;
+   case OPUS_SET_GAIN_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < -32768 || v > 32767) ret = OPUS_BAD_ARG; else st->decode_gain = v; } break;
+   case OPUS_GET_GAIN_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->decode_gain; } break;
+   case OPUS_SET_COMPLEXITY_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 10) ret = OPUS_BAD_ARG; else st->pad[0] = v; } break;   /* decoder complexity only gates the DNN options (:1041) */
+   case OPUS_GET_COMPLEXITY_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->pad[0]; } break;
    case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else st->s.s.disable_inv = v; } break;
    case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.disable_inv; } break;
    default: ret = OPUS_UNIMPLEMENTED;
@@ -776,6 +751,8 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 }
 } /* extern "C" */
 #include "opus_ms_host.h"
+#include "opus_api_host.h"
+#include "opus_projection_host.h"
 #include "silk_batch.h"
 extern "C" {
 const char *opus_get_version_string(void) { return "opus-amd 0.3 (gfx950, fixed-point bit-exact CELT encoder, full Opus decoder, SILK operator kernels)"; }

@@ -1,0 +1,181 @@
+/* opus_enc_host.h — host side of the classic encoder API: record initialisation, the CTL surface and the opus_encode* entry points.
+ * Same names, argument meaning and error codes as the reference: opus_encoder_get_size src/opus_encoder.c:194, _init :204, _create :622,
+ * opus_encode :2662, opus_encode24 :2697, opus_encode_float :2735, opus_encoder_ctl :2772 (every request of :2785-3345), _destroy :3362,
+ * frame_size_select :827, user_bitrate_to_bitrate :804.  An OpusEncoder is flat host memory (memcpy-able, include/opus.h:108): a header and one of
+ * the two stream records — OaStream for the CELT-only applications (RESTRICTED_LOWDELAY / RESTRICTED_CELT, the lean kernel) or OaShStream for
+ * VOIP / AUDIO / RESTRICTED_SILK.  The CTL code is one template over both record types. */
+#ifndef OPUS_AMD_ENC_HOST_H
+#define OPUS_AMD_ENC_HOST_H
+
+#define OPUS_SET_VOICE_RATIO_REQUEST 11018
+#define OPUS_GET_VOICE_RATIO_REQUEST 11019
+#define OPUS_SET_LFE_REQUEST 10024
+#define OPUS_SET_ENERGY_MASK_REQUEST 10026
+#define OPUS_GET_LOOKAHEAD_REQUEST 4027
+#define OPUS_SET_EXPERT_FRAME_DURATION_REQUEST 4040
+#define OPUS_GET_EXPERT_FRAME_DURATION_REQUEST 4041
+#define OPUS_SET_PREDICTION_DISABLED_REQUEST 4042
+#define OPUS_GET_PREDICTION_DISABLED_REQUEST 4043
+#define OPUS_FRAMESIZE_ARG 5000
+#define OPUS_FRAMESIZE_2_5_MS 5001
+#define OPUS_FRAMESIZE_40_MS 5005
+#define OPUS_FRAMESIZE_120_MS 5009
+
+static int oa_app_is_sh(int application) { return application == OPUS_APPLICATION_VOIP || application == OPUS_APPLICATION_AUDIO || application == OPUS_APPLICATION_RESTRICTED_SILK; }
+static int oa_fs_ok(opus_int32 Fs) { return Fs == 48000 || Fs == 24000 || Fs == 16000 || Fs == 12000 || Fs == 8000; }
+static int oa_app_ok(int a) { return a == OPUS_APPLICATION_VOIP || a == OPUS_APPLICATION_AUDIO || a == OPUS_APPLICATION_RESTRICTED_LOWDELAY || a == OPUS_APPLICATION_RESTRICTED_SILK || a == OPUS_APPLICATION_RESTRICTED_CELT; }
+
+/* ---- field access that differs between the two records ---- */
+static inline opus_int32 &oa_fs(OaStream *r) { return r->Fs; }                       static inline opus_int32 &oa_fs(OaShStream *r) { return r->cfg.Fs; }
+static inline opus_int32 &oa_use_dtx(OaStream *r) { return r->use_dtx; }             static inline opus_int32 &oa_use_dtx(OaShStream *r) { return r->cfg.use_dtx; }
+static inline opus_int32 &oa_signal(OaStream *r) { return r->signal_type; }          static inline opus_int32 &oa_signal(OaShStream *r) { return r->cfg.signal_type; }
+static inline opus_int32 &oa_fec(OaStream *r) { return r->use_inband_fec; }          static inline opus_int32 &oa_fec(OaShStream *r) { return r->cfg.use_inband_fec; }
+static inline opus_int32 &oa_forced_mode(OaStream *r) { return r->user_forced_mode; } static inline opus_int32 &oa_forced_mode(OaShStream *r) { return r->cfg.user_forced_mode; }
+static inline opus_int32 &oa_voice_ratio(OaStream *r) { return r->voice_ratio; }     static inline opus_int32 &oa_voice_ratio(OaShStream *r) { return r->cfg.voice_ratio; }
+static inline opus_int32 &oa_mask_on(OaStream *r) { return r->energy_mask_on; }      static inline opus_int32 &oa_mask_on(OaShStream *r) { return r->cfg.energy_mask_on; }
+static inline opus_int32 oa_prev_framesize(const OaStream *r) { return r->prev_framesize; }   static inline opus_int32 oa_prev_framesize(const OaShStream *r) { return r->s.prev_framesize; }
+static inline opus_int32 oa_bandwidth(const OaStream *r) { return r->st.s.bandwidth; }        static inline opus_int32 oa_bandwidth(const OaShStream *r) { return r->s.bandwidth; }
+static inline opus_uint32 oa_range(const OaStream *r) { return r->st.s.rangeFinal; }          static inline opus_uint32 oa_range(const OaShStream *r) { return r->s.rangeFinal; }
+static inline int oa_first(const OaStream *r) { return r->st.s.first; }                       static inline int oa_first(const OaShStream *r) { return r->s.first; }
+static inline opus_int32 oa_dtx_counter(const OaStream *r) { return r->nb_no_activity_ms_Q1; } static inline opus_int32 oa_dtx_counter(const OaShStream *r) { return r->s.nb_no_activity_ms_Q1; }
+
+/* ---- init / reset (opus_encoder_init :204-330, OPUS_RESET_STATE :3200-3232) ---- */
+static void oa_stream_reset_state(OaStream *st)
+{
+   OaEncConfig cfg = st->cfg;
+   const opus_int32 Fs = st->Fs, dtx = st->use_dtx, sig = st->signal_type, fec = st->use_inband_fec, fm = st->user_forced_mode, vr = st->voice_ratio;
+   memset(st, 0, sizeof(*st));
+   st->cfg = cfg; st->Fs = Fs; st->use_dtx = dtx; st->signal_type = sig; st->use_inband_fec = fec; st->user_forced_mode = fm; st->voice_ratio = vr;
+   st->st.s.stream_channels = cfg.channels; st->st.s.bandwidth = OPUS_BANDWIDTH_FULLBAND; st->st.s.first = 1; st->st.s.hybrid_stereo_width_Q14 = 1 << 14;
+   st->st.s.spread_decision = 2; st->st.s.delayedIntra = 1; st->st.s.tonal_average = 256;
+   for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->st.oldLogE[i] = st->st.oldLogE2[i] = -(28 << 24);
+}
+static int oa_init_stream(OaStream *st, opus_int32 Fs, int channels, int application)
+{
+   if (!oa_fs_ok(Fs) || (channels != 1 && channels != 2) || !oa_app_ok(application)) return OPUS_BAD_ARG;
+   if (oa_app_is_sh(application)) return OPUS_BAD_ARG;
+   memset(st, 0, sizeof(*st));
+   st->cfg.channels = channels; st->cfg.application = application; st->cfg.user_bitrate_bps = OPUS_AUTO;
+   st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = OPUS_AUTO;
+   st->cfg.user_bandwidth = OPUS_AUTO; st->cfg.max_bandwidth = OPUS_BANDWIDTH_FULLBAND; st->cfg.lsb_depth = 24; st->cfg.variable_duration = OPUS_FRAMESIZE_ARG;
+   st->Fs = Fs; st->signal_type = OPUS_AUTO; st->user_forced_mode = OPUS_AUTO; st->voice_ratio = -1;
+   oa_stream_reset_state(st);
+   return OPUS_OK;
+}
+static int sh_init_stream(OaShStream *st, opus_int32 Fs, int channels, int application)
+{
+   if (!oa_fs_ok(Fs) || (channels != 1 && channels != 2) || !oa_app_is_sh(application)) return OPUS_BAD_ARG;
+   oa_sh_stream_init(st, Fs, channels, application);
+   st->cfg.variable_duration = OPUS_FRAMESIZE_ARG; st->cfg.voice_ratio = -1;
+   return OPUS_OK;
+}
+static void oa_reset_rec(OaStream *r) { oa_stream_reset_state(r); }
+static void oa_reset_rec(OaShStream *r) { oa_sh_stream_reset(r, r->cfg.Fs, r->cfg.channels, r->cfg.application); }
+
+/* frame_size_select (:827) */
+static opus_int32 oa_frame_size_select(int application, opus_int32 frame_size, int variable_duration, opus_int32 Fs)
+{
+   opus_int32 n;
+   if (frame_size < Fs / 400) return -1;
+   if (variable_duration == OPUS_FRAMESIZE_ARG || variable_duration == 0) n = frame_size;
+   else if (variable_duration >= OPUS_FRAMESIZE_2_5_MS && variable_duration <= OPUS_FRAMESIZE_120_MS)
+      n = variable_duration <= OPUS_FRAMESIZE_40_MS ? (Fs / 400) << (variable_duration - OPUS_FRAMESIZE_2_5_MS) : (variable_duration - OPUS_FRAMESIZE_2_5_MS - 2) * Fs / 50;
+   else return -1;
+   if (n > frame_size) return -1;
+   if (400 * n != Fs && 200 * n != Fs && 100 * n != Fs && 50 * n != Fs && 25 * n != Fs && 50 * n != 3 * Fs && 50 * n != 4 * Fs && 50 * n != 5 * Fs && 50 * n != 6 * Fs) return -1;
+   if (application == OPUS_APPLICATION_RESTRICTED_SILK && n < Fs / 100) return -1;
+   return n;
+}
+
+/* ---- CTLs ---- */
+template <class R> static int oa_rec_set(R *r, int request, opus_int32 value)
+{
+   auto *c = &r->cfg;
+   switch (request) {
+   case OPUS_SET_APPLICATION_REQUEST:          /* only VOIP / AUDIO / RESTRICTED_LOWDELAY, never on the restricted applications, not after the first frame (:2785-2803);
+                                                  a change that needs the other record type is done by the caller (opus_encoder_ctl) */
+      if (c->application == OPUS_APPLICATION_RESTRICTED_SILK || c->application == OPUS_APPLICATION_RESTRICTED_CELT) return OPUS_BAD_ARG;
+      if ((value != OPUS_APPLICATION_VOIP && value != OPUS_APPLICATION_AUDIO && value != OPUS_APPLICATION_RESTRICTED_LOWDELAY) || (!oa_first(r) && c->application != value)) return OPUS_BAD_ARG;
+      if (oa_app_is_sh(value) != oa_app_is_sh(c->application)) return OPUS_UNIMPLEMENTED;
+      c->application = value; return OPUS_OK;
+   case OPUS_SET_BITRATE_REQUEST:
+      if (value != OPUS_AUTO && value != OPUS_BITRATE_MAX) { if (value <= 0) return OPUS_BAD_ARG; else if (value <= 500) value = 500; else if (value > (opus_int32)750000 * c->channels) value = (opus_int32)750000 * c->channels; }
+      c->user_bitrate_bps = value; return OPUS_OK;
+   case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; c->complexity = value; return OPUS_OK;
+   case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_vbr = value; return OPUS_OK;
+   case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->vbr_constraint = value; return OPUS_OK;
+   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > c->channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->force_channels = value; return OPUS_OK;
+   case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; c->max_bandwidth = value; return OPUS_OK;
+   case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; c->lsb_depth = value; return OPUS_OK;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; if (c->application != OPUS_APPLICATION_RESTRICTED_SILK) c->disable_inv = value; return OPUS_OK;
+   case OPUS_SET_FORCE_MODE_REQUEST: if ((value < OPUS_MODE_SILK_ONLY || value > OPUS_MODE_CELT_ONLY) && value != OPUS_AUTO) return OPUS_BAD_ARG; oa_forced_mode(r) = value; return OPUS_OK;
+   case OPUS_SET_SIGNAL_REQUEST: if (value != OPUS_AUTO && value != OPUS_SIGNAL_VOICE && value != OPUS_SIGNAL_MUSIC) return OPUS_BAD_ARG; oa_signal(r) = value; return OPUS_OK;
+   case OPUS_SET_PACKET_LOSS_PERC_REQUEST: if (value < 0 || value > 100) return OPUS_BAD_ARG; c->packet_loss_perc = value; return OPUS_OK;
+   case OPUS_SET_INBAND_FEC_REQUEST: if (value < 0 || value > 2) return OPUS_BAD_ARG; oa_fec(r) = value; return OPUS_OK;
+   case OPUS_SET_DTX_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; oa_use_dtx(r) = value; return OPUS_OK;
+   case OPUS_SET_VOICE_RATIO_REQUEST: if (value < -1 || value > 100) return OPUS_BAD_ARG; oa_voice_ratio(r) = value; return OPUS_OK;
+   case OPUS_SET_EXPERT_FRAME_DURATION_REQUEST: if (value < OPUS_FRAMESIZE_ARG || value > OPUS_FRAMESIZE_120_MS) return OPUS_BAD_ARG; c->variable_duration = value; return OPUS_OK;
+   case OPUS_SET_PREDICTION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->prediction_disabled = value; return OPUS_OK;
+   case OPUS_SET_LFE_REQUEST: c->lfe = value; return OPUS_OK;
+   case OPUS_RESET_STATE: oa_reset_rec(r); return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+/* user_bitrate_to_bitrate (:804) */
+template <class R> static opus_int32 oa_user_bitrate(R *r, opus_int32 frame_size, opus_int32 max_data_bytes)
+{
+   const opus_int32 Fs = oa_fs(r);
+   if (!frame_size) frame_size = Fs / 400;
+   const opus_int32 maxb = max_data_bytes * 8 * (6 * Fs / frame_size) / 6, u = r->cfg.user_bitrate_bps;
+   const opus_int32 ub = u == OPUS_AUTO ? 60 * Fs / frame_size + Fs * r->cfg.channels : (u == OPUS_BITRATE_MAX ? 1500000 : u);
+   return ub < maxb ? ub : maxb;
+}
+static int oa_in_dtx(OaStream *r) { return r->use_dtx ? r->nb_no_activity_ms_Q1 >= 10 * 20 * 2 : 0; }
+static int oa_in_dtx(OaShStream *st)                                                 /* :3299-3322 */
+{
+   if (st->s.sm_useDTX && (st->s.prev_mode == OA_MODE_SILK_ONLY || st->s.prev_mode == OA_MODE_HYBRID)) {
+      int v = st->silk.ch[0].noSpeechCounter >= 10;
+      if (v == 1 && st->silk.nChannelsInternal == 2 && st->silk.prev_decode_only_middle == 0) v = st->silk.ch[1].noSpeechCounter >= 10;
+      return v;
+   }
+   return st->cfg.use_dtx ? st->s.nb_no_activity_ms_Q1 >= 10 * 20 * 2 : 0;
+}
+template <class R> static int oa_rec_get(R *r, int request, opus_int32 *value)
+{
+   if (!value) return OPUS_BAD_ARG;
+   auto *c = &r->cfg;
+   switch (request) {
+   case OPUS_GET_APPLICATION_REQUEST: *value = c->application; return OPUS_OK;
+   case OPUS_GET_BITRATE_REQUEST: *value = oa_user_bitrate(r, oa_prev_framesize(r), 1276); return OPUS_OK;
+   case OPUS_GET_COMPLEXITY_REQUEST: *value = c->complexity; return OPUS_OK;
+   case OPUS_GET_VBR_REQUEST: *value = c->use_vbr; return OPUS_OK;
+   case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = c->vbr_constraint; return OPUS_OK;
+   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = c->force_channels; return OPUS_OK;
+   case OPUS_GET_BANDWIDTH_REQUEST: *value = oa_bandwidth(r); return OPUS_OK;
+   case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = c->max_bandwidth; return OPUS_OK;
+   case OPUS_GET_LSB_DEPTH_REQUEST: *value = c->lsb_depth; return OPUS_OK;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: *value = c->application == OPUS_APPLICATION_RESTRICTED_SILK ? 0 : c->disable_inv; return OPUS_OK;
+   case OPUS_GET_SIGNAL_REQUEST: *value = oa_signal(r); return OPUS_OK;
+   case OPUS_GET_PACKET_LOSS_PERC_REQUEST: *value = c->packet_loss_perc; return OPUS_OK;
+   case OPUS_GET_INBAND_FEC_REQUEST: *value = oa_fec(r); return OPUS_OK;
+   case OPUS_GET_DTX_REQUEST: *value = oa_use_dtx(r); return OPUS_OK;
+   case OPUS_GET_VOICE_RATIO_REQUEST: *value = oa_voice_ratio(r); return OPUS_OK;
+   case OPUS_GET_EXPERT_FRAME_DURATION_REQUEST: *value = c->variable_duration ? c->variable_duration : OPUS_FRAMESIZE_ARG; return OPUS_OK;
+   case OPUS_GET_PREDICTION_DISABLED_REQUEST: *value = c->prediction_disabled; return OPUS_OK;
+   case OPUS_GET_SAMPLE_RATE_REQUEST: *value = oa_fs(r); return OPUS_OK;
+   case OPUS_GET_LOOKAHEAD_REQUEST:                                                    /* Fs/400 (+ the 4 ms delay compensation outside the low-delay applications, :3050) */
+      *value = oa_fs(r) / 400;
+      if (c->application != OPUS_APPLICATION_RESTRICTED_LOWDELAY && c->application != OPUS_APPLICATION_RESTRICTED_CELT) *value += oa_fs(r) / 250;
+      return OPUS_OK;
+   case OPUS_GET_FINAL_RANGE_REQUEST: *value = (opus_int32)oa_range(r); return OPUS_OK;
+   case OPUS_GET_IN_DTX_REQUEST: *value = oa_in_dtx(r); return OPUS_OK;
+   default: return OPUS_UNIMPLEMENTED;
+   }
+}
+/* names kept for the batch / multistream code */
+static int oa_ctl_set(OaStream *st, int request, opus_int32 value) { return oa_rec_set(st, request, value); }
+static int oa_ctl_get(const OaStream *st, int request, opus_int32 *value) { return oa_rec_get(const_cast<OaStream *>(st), request, value); }
+static int sh_ctl_set(OaShStream *st, int request, opus_int32 value) { return oa_rec_set(st, request, value); }
+static int sh_ctl_get(const OaShStream *st, int request, opus_int32 *value) { return oa_rec_get(const_cast<OaShStream *>(st), request, value); }
+#endif

@@ -52,12 +52,12 @@ static OpusGpuEncBatch *oa_ms_enc_batch(int n, int channels, int application, op
    if (b) g_ms_enc[key] = b;
    return b;
 }
-static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, int *err)
+static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, opus_int32 Fs, int *err)
 {
-   long key = (long)n * 4 + channels;
+   long key = ((long)n * 4 + channels) * 64 + Fs / 1000;
    auto it = g_ms_dec.find(key);
    if (it != g_ms_dec.end()) return it->second;
-   OpusGpuDecBatch *b = opusgpu_dec_batch_create(n, 48000, channels, 0, err);
+   OpusGpuDecBatch *b = opusgpu_dec_batch_create(n, Fs, channels, 0, err);
    if (b) g_ms_dec[key] = b;
    return b;
 }
@@ -66,21 +66,21 @@ static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, int *err)
 enum { OA_MAP_NONE = 0, OA_MAP_SURROUND = 1, OA_MAP_AMBISONICS = 2 };
 /* one elementary encoder: the CELT-only record or the SILK-capable one, by application (opus_multistream_encoder_get_size does not know the
  * application, so every record has room for either) */
-union OaMsRec { OaStream c; OaShStream sh; };
+typedef OpusEncoder OaMsRec;                 /* a complete classic encoder object: OPUS_MULTISTREAM_GET_ENCODER_STATE hands it out (opus_multistream.h:74) */
 struct OpusMSEncoder {
    opus_uint32 magic; opus_int32 Fs, application, bitrate_bps, mapping_type, lfe_stream;
    OaLayout layout;
    opus_int32 kind, pad;           /* kind 1: records are OaShStream */
    OaMsRec streams[1];             /* nb_streams records: coupled streams first, then mono (flat, memcpy-able) */
 };
-static int oa_ms_rec_init(OaMsRec *r, int kind, opus_int32 Fs, int ch, int application) { return kind ? sh_init_stream(&r->sh, Fs, ch, application) : oa_init_stream(&r->c, Fs, ch, application); }
-static int oa_ms_rec_set(OaMsRec *r, int kind, int request, opus_int32 v) { return kind ? sh_ctl_set(&r->sh, request, v) : oa_ctl_set(&r->c, request, v); }
-static int oa_ms_rec_get(const OaMsRec *r, int kind, int request, opus_int32 *v) { return kind ? sh_ctl_get(&r->sh, request, v) : oa_ctl_get(&r->c, request, v); }
+static int oa_ms_rec_init(OaMsRec *r, int kind, opus_int32 Fs, int ch, int application) { (void)kind; return opus_encoder_init(r, Fs, ch, application); }
+static int oa_ms_rec_set(OaMsRec *r, int kind, int request, opus_int32 v) { return kind ? sh_ctl_set(&r->sh, request, v) : oa_ctl_set(&r->s, request, v); }
+static int oa_ms_rec_get(const OaMsRec *r, int kind, int request, opus_int32 *v) { return kind ? sh_ctl_get(&r->sh, request, v) : oa_ctl_get(&r->s, request, v); }
 struct OpusMSDecoder {
    opus_uint32 magic; opus_int32 Fs;
    OaLayout layout;
    opus_int32 pad[2];
-   OaDecStream streams[1];
+   OpusDecoder streams[1];      /* complete classic decoder objects: OPUS_MULTISTREAM_GET_DECODER_STATE hands them out */
 };
 #define OA_MS_FRAME_TMP (6 * 1275 + 12)
 
@@ -227,27 +227,25 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    if (kind) HIPCHECK(hipMemcpy2D(b->d_sh, sizeof(OaShStream), &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), (size_t)n, hipMemcpyHostToDevice));
-   else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].c, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
+   else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].s, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
    int r = opusgpu_encode_batch(b, pcm, frame_size, out, 1280, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
    if (kind) HIPCHECK(hipMemcpy2D(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), sizeof(OaShStream), (size_t)n, hipMemcpyDeviceToHost));
-   else HIPCHECK(hipMemcpy2D(&states[0].c, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), sizeof(OaStream), (size_t)n, hipMemcpyDeviceToHost));
+   else HIPCHECK(hipMemcpy2D(&states[0].s, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), sizeof(OaStream), (size_t)n, hipMemcpyDeviceToHost));
    return OPUS_OK;
 }
 
-/* opus_multistream_encode_native, opus_multistream_encoder.c:841 (int16 input) */
-int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+/* opus_multistream_encode_native, opus_multistream_encoder.c:841 (int16 samples; depth = 16 or 24: the lsb_depth of the entry point) */
+static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth)
 {
    if (!st || st->magic != OA_MS_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
    const opus_int32 Fs = st->Fs;
    const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
-   if (frame_size < Fs / 400) return OPUS_BAD_ARG;
-   if (400 * frame_size != Fs && 200 * frame_size != Fs && 100 * frame_size != Fs && 50 * frame_size != Fs) {
-      if (25 * frame_size == Fs || 50 * frame_size == 3 * Fs || 50 * frame_size == 4 * Fs || 50 * frame_size == 5 * Fs || 50 * frame_size == 6 * Fs) return OPUS_UNIMPLEMENTED;
-      return OPUS_BAD_ARG;
-   }
    const int kind = st->kind;
-   const int vbr = kind ? st->streams[0].sh.cfg.use_vbr : st->streams[0].c.cfg.use_vbr;
+   const int frame_size = (int)oa_frame_size_select(st->application, analysis_frame_size, kind ? st->streams[0].sh.cfg.variable_duration : st->streams[0].s.cfg.variable_duration, Fs);
+   if (frame_size <= 0) return OPUS_BAD_ARG;
+   for (int s = 0; s < ns; s++) { if (kind) st->streams[s].sh.cfg.input_depth = depth; else st->streams[s].s.cfg.input_depth = depth; }
+   const int vbr = kind ? st->streams[0].sh.cfg.use_vbr : st->streams[0].s.cfg.use_vbr;
    opus_int32 smallest_packet = ns * 2 - 1;
    if (Fs / frame_size == 10) smallest_packet += ns;
    if (max_data_bytes < smallest_packet) return OPUS_BUFFER_TOO_SMALL;
@@ -264,7 +262,7 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
    }
    for (int s = 0; s < ns; s++) {
       if (kind) { st->streams[s].sh.cfg.user_bitrate_bps = bitrates[s]; if (st->mapping_type == OA_MAP_AMBISONICS) st->streams[s].sh.cfg.user_forced_mode = 1002; /* MODE_CELT_ONLY (:981) */ }
-      else st->streams[s].c.cfg.user_bitrate_bps = bitrates[s];
+      else st->streams[s].s.cfg.user_bitrate_bps = bitrates[s];
    }
    /* channel de-interleave into the two groups */
    std::vector<opus_int16> pc((size_t)nc * frame_size * 2 + 2), pm((size_t)nm * frame_size + 1);
@@ -304,7 +302,7 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
          if (Fs / frame_size == 10) curr_max -= ns - s - 1;
          if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
          if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
-         if (!vbr && s == ns - 1) { const opus_int32 br = curr_max * 8 * (6 * Fs / frame_size) / 6; if (kind) st->streams[s].sh.cfg.user_bitrate_bps = br; else st->streams[s].c.cfg.user_bitrate_bps = br; }
+         if (!vbr && s == ns - 1) { const opus_int32 br = curr_max * 8 * (6 * Fs / frame_size) / 6; if (kind) st->streams[s].sh.cfg.user_bitrate_bps = br; else st->streams[s].s.cfg.user_bitrate_bps = br; }
          if (curr_max <= 0) return OPUS_BUFFER_TOO_SMALL;
          if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
          else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
@@ -319,11 +317,13 @@ int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_
    }
    return tot_size;
 }
-int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
+int opus_multistream_encode(OpusMSEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
+{
+   return oa_ms_encode_native(st, pcm, frame_size, data, max_data_bytes, 16);
+}
+static int oa_ms_encoder_ctl_va(OpusMSEncoder *st, int request, va_list ap)
 {
    if (!st || st->magic != OA_MS_MAGIC) return OPUS_BAD_ARG;
-   va_list ap;
-   va_start(ap, request);
    int ret = OPUS_OK;
    const int ns = st->layout.nb_streams;
    switch (request) {
@@ -346,11 +346,17 @@ int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
       opus_uint32 *value = va_arg(ap, opus_uint32 *);
       if (!value) { ret = OPUS_BAD_ARG; break; }
       *value = 0;
-      for (int s = 0; s < ns; s++) *value ^= st->kind ? st->streams[s].sh.s.rangeFinal : st->streams[s].c.st.s.rangeFinal;
+      for (int s = 0; s < ns; s++) *value ^= st->kind ? st->streams[s].sh.s.rangeFinal : st->streams[s].s.st.s.rangeFinal;
    } break;
    case OPUS_RESET_STATE:
       for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = oa_ms_rec_set(&st->streams[s], st->kind, request, 0);
       break;
+   case 5120 /* OPUS_MULTISTREAM_GET_ENCODER_STATE (opus_multistream.h:74) */: {
+      const opus_int32 id = va_arg(ap, opus_int32);
+      OpusEncoder **value = va_arg(ap, OpusEncoder **);
+      if (id < 0 || id >= ns || !value) { ret = OPUS_BAD_ARG; break; }
+      *value = &st->streams[id];
+   } break;
    default:
       if (request & 1) {           /* GET: answered by the first stream (opus_multistream_encoder.c:1196-1219) */
          opus_int32 *value = va_arg(ap, opus_int32 *);
@@ -360,6 +366,13 @@ int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
          for (int s = 0; s < ns; s++) { ret = oa_ms_rec_set(&st->streams[s], st->kind, request, value); if (ret != OPUS_OK) break; }
       }
    }
+   return ret;
+}
+int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
+{
+   va_list ap;
+   va_start(ap, request);
+   const int ret = oa_ms_encoder_ctl_va(st, request, ap);
    va_end(ap);
    return ret;
 }
@@ -368,7 +381,7 @@ int opus_multistream_encoder_ctl(OpusMSEncoder *st, int request, ...)
 opus_int32 opus_multistream_decoder_get_size(int nb_streams, int nb_coupled_streams)
 {
    if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;
-   return (opus_int32)(sizeof(OpusMSDecoder) + (size_t)(nb_streams - 1) * sizeof(OaDecStream));
+   return (opus_int32)(sizeof(OpusMSDecoder) + (size_t)(nb_streams - 1) * sizeof(OpusDecoder));
 }
 int opus_multistream_decoder_init(OpusMSDecoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping)
 {
@@ -378,12 +391,12 @@ int opus_multistream_decoder_init(OpusMSDecoder *st, opus_int32 Fs, int channels
    int r = oa_dec_init_stream(probe, Fs, 2);
    delete probe;
    if (r != OPUS_OK) return r;
-   memset(st, 0, sizeof(OpusMSDecoder) - sizeof(OaDecStream));
+   memset(st, 0, sizeof(OpusMSDecoder) - sizeof(OpusDecoder));
    st->magic = OA_MS_MAGIC; st->Fs = Fs;
    st->layout.nb_channels = channels; st->layout.nb_streams = streams; st->layout.nb_coupled_streams = coupled_streams;
    for (int i = 0; i < channels; i++) st->layout.mapping[i] = mapping[i];
    if (!oa_validate_layout(&st->layout)) return OPUS_BAD_ARG;
-   for (int s = 0; s < streams; s++) { r = oa_dec_init_stream(&st->streams[s], Fs, s < coupled_streams ? 2 : 1); if (r != OPUS_OK) return r; }
+   for (int s = 0; s < streams; s++) { r = opus_decoder_init(&st->streams[s], Fs, s < coupled_streams ? 2 : 1); if (r != OPUS_OK) return r; }
    return OPUS_OK;
 }
 OpusMSDecoder *opus_multistream_decoder_create(opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int *error)
@@ -401,18 +414,19 @@ OpusMSDecoder *opus_multistream_decoder_create(opus_int32 Fs, int channels, int 
 }
 void opus_multistream_decoder_destroy(OpusMSDecoder *st) { free(st); }
 
-static int oa_ms_decode_group(OaDecStream *states, int n, int ch, const unsigned char *pk, int stride, const opus_int32 *lens, opus_int16 *pcm, int frame_size,
-      opus_int32 *ns_out, opus_uint32 *rngs)
+static int oa_ms_decode_group(OpusDecoder *states, int n, int ch, const unsigned char *pk, int stride, const opus_int32 *lens, opus_int16 *pcm, int frame_size,
+      opus_int32 *ns_out, opus_uint32 *rngs, int decode_fec)
 {
    int err = OPUS_OK;
-   OpusGpuDecBatch *b = oa_ms_dec_batch(n, ch, &err);
+   OpusGpuDecBatch *b = oa_ms_dec_batch(n, ch, states[0].Fs, &err);
+   if (b) b->decode_fec = decode_fec;
    if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   HIPCHECK(hipMemcpy(b->d_streams, states, sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice));
+   HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaDecStream), &states[0].s, sizeof(OpusDecoder), sizeof(OaDecStream), (size_t)n, hipMemcpyHostToDevice));
    int r = opusgpu_decode_batch(b, pk, stride, lens, pcm, frame_size, ns_out, rngs);
    if (r != OPUS_OK) return r;
-   HIPCHECK(hipMemcpy(states, b->d_streams, sizeof(OaDecStream) * (size_t)n, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy2D(&states[0].s, sizeof(OpusDecoder), b->d_streams, sizeof(OaDecStream), sizeof(OaDecStream), (size_t)n, hipMemcpyDeviceToHost));
    return OPUS_OK;
 }
 /* opus_multistream_decode_native, opus_multistream_decoder.c:178 (int16 output) */
@@ -424,8 +438,9 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
    const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
    if (frame_size > Fs / 25 * 3) frame_size = Fs / 25 * 3;
    if (len < 0) return OPUS_BAD_ARG;
-   const bool lost = len == 0 || data == NULL || decode_fec;                        /* every stream conceals frame_size samples */
-   if (lost && frame_size % (Fs / 400) != 0) return OPUS_BAD_ARG;
+   const bool lost = len == 0 || data == NULL;                                      /* every stream conceals frame_size samples */
+   const int fec = lost ? 0 : (decode_fec != 0);                                     /* in-band FEC: each stream decodes the LBRR copy its sub-packet carries (src/opus_multistream_decoder.c:245) */
+   if ((lost || fec) && frame_size % (Fs / 400) != 0) return OPUS_BAD_ARG;
    if (!lost && len < 2 * ns - 1) return OPUS_INVALID_PACKET;
    /* opus_multistream_packet_validate (:149) + re-framing of every stream's self-delimited packet as a plain packet for the batch decoder */
    const int stride = 1280 * 6 + 16;
@@ -454,14 +469,14 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
       }
    }
    if (samples < 0) return samples;
-   if (samples > frame_size) return OPUS_BUFFER_TOO_SMALL;
+   if (!fec && samples > frame_size) return OPUS_BUFFER_TOO_SMALL;
    std::lock_guard<std::mutex> lock(g_ms_mu);
    std::vector<opus_int16> oc((size_t)nc * frame_size * 2 + 2), om((size_t)nm * frame_size + 1);
    std::vector<opus_int32> nso((size_t)ns);
    std::vector<opus_uint32> rngs((size_t)ns);
    int r = OPUS_OK;
-   if (nc) r = oa_ms_decode_group(st->streams, nc, 2, pk.data(), stride, lens.data(), oc.data(), frame_size, nso.data(), rngs.data());
-   if (r == OPUS_OK && nm) r = oa_ms_decode_group(st->streams + nc, nm, 1, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, om.data(), frame_size, nso.data() + nc, rngs.data() + nc);
+   if (nc) r = oa_ms_decode_group(st->streams, nc, 2, pk.data(), stride, lens.data(), oc.data(), frame_size, nso.data(), rngs.data(), fec);
+   if (r == OPUS_OK && nm) r = oa_ms_decode_group(st->streams + nc, nm, 1, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, om.data(), frame_size, nso.data() + nc, rngs.data() + nc, fec);
    if (r != OPUS_OK) return r;
    int out_n = 0;
    for (int s = 0; s < ns; s++) { if (nso[s] <= 0) return nso[s] == 0 ? OPUS_INTERNAL_ERROR : nso[s]; out_n = nso[s]; }
@@ -478,11 +493,9 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
    for (int c = 0; c < nch; c++) if (st->layout.mapping[c] == 255) for (int i = 0; i < out_n; i++) pcm[(size_t)i * nch + c] = 0;
    return out_n;
 }
-int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...)
+static int oa_ms_decoder_ctl_va(OpusMSDecoder *st, int request, va_list ap)
 {
    if (!st || st->magic != OA_MS_MAGIC) return OPUS_BAD_ARG;
-   va_list ap;
-   va_start(ap, request);
    int ret = OPUS_OK;
    const int ns = st->layout.nb_streams;
    switch (request) {
@@ -490,18 +503,34 @@ int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...)
       opus_uint32 *value = va_arg(ap, opus_uint32 *);
       if (!value) { ret = OPUS_BAD_ARG; break; }
       *value = 0;
-      for (int s = 0; s < ns; s++) *value ^= st->streams[s].s.rangeFinal;
+      for (int s = 0; s < ns; s++) *value ^= st->streams[s].s.s.rangeFinal;
    } break;
+   case 5122 /* OPUS_MULTISTREAM_GET_DECODER_STATE (opus_multistream.h:82) */: {
+      const opus_int32 id = va_arg(ap, opus_int32);
+      OpusDecoder **value = va_arg(ap, OpusDecoder **);
+      if (id < 0 || id >= ns || !value) { ret = OPUS_BAD_ARG; break; }
+      *value = &st->streams[id];
+   } break;
+   case OPUS_SET_GAIN_REQUEST: { const opus_int32 v = va_arg(ap, opus_int32); for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = opus_decoder_ctl(&st->streams[s], request, v); } break;
+   case OPUS_GET_GAIN_REQUEST: case OPUS_GET_COMPLEXITY_REQUEST: case 4033: { opus_int32 *p = va_arg(ap, opus_int32 *); ret = opus_decoder_ctl(&st->streams[0], request, p); } break;
+   case OPUS_SET_COMPLEXITY_REQUEST: { const opus_int32 v = va_arg(ap, opus_int32); for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = opus_decoder_ctl(&st->streams[s], request, v); } break;
    case OPUS_GET_SAMPLE_RATE_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->Fs; } break;
-   case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.bandwidth; } break;
-   case 4039 /* OPUS_GET_LAST_PACKET_DURATION */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.last_packet_duration; } break;
+   case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.s.bandwidth; } break;
+   case 4039 /* OPUS_GET_LAST_PACKET_DURATION */: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.s.last_packet_duration; } break;
    case OPUS_RESET_STATE:
-      for (int s = 0; s < ns; s++) oa_dec_init_stream(&st->streams[s], st->Fs, s < st->layout.nb_coupled_streams ? 2 : 1);
+      for (int s = 0; s < ns; s++) opus_decoder_ctl(&st->streams[s], OPUS_RESET_STATE);
       break;
-   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else for (int s = 0; s < ns; s++) st->streams[s].s.disable_inv = v; } break;
-   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.disable_inv; } break;
+   case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else for (int s = 0; s < ns; s++) st->streams[s].s.s.disable_inv = v; } break;
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.s.disable_inv; } break;
    default: ret = OPUS_UNIMPLEMENTED;
    }
+   return ret;
+}
+int opus_multistream_decoder_ctl(OpusMSDecoder *st, int request, ...)
+{
+   va_list ap;
+   va_start(ap, request);
+   const int ret = oa_ms_decoder_ctl_va(st, request, ap);
    va_end(ap);
    return ret;
 }

@@ -10,7 +10,7 @@
 struct OaShConfig {
    int32_t Fs, channels, application, user_bitrate_bps, use_vbr, vbr_constraint, complexity, force_channels;
    int32_t user_bandwidth, max_bandwidth, lsb_depth, disable_inv, packet_loss_perc, user_forced_mode, signal_type, use_inband_fec;
-   int32_t use_dtx, reserved[7];
+   int32_t use_dtx, variable_duration, input_depth, lfe, prediction_disabled, voice_ratio, energy_mask_on, reserved[1];
 };
 struct OaShScalars {
    int32_t stream_channels, bandwidth, auto_bandwidth, first, mode, prev_mode, prev_channels, prev_framesize;
@@ -22,7 +22,9 @@ struct OaShScalars {
    /* compute_stereo_width state (StereoWidthState, src/opus_encoder.c:62-68) */
    int32_t wm_XX, wm_XY, wm_YY, wm_smoothed_width, wm_max_follower;
    int32_t nb_no_activity_ms_Q1, sm_useDTX;             /* generalised DTX counter (decide_dtx_mode, src/opus_encoder.c:1115); silk_mode.useDTX of the last frame */
-   int32_t pad0[4];
+   int32_t peak_signal_energy;                          /* src/opus_encoder.c:1310-1320 (activity decision of CELT-only frames, :1926) */
+   int32_t nonfinal_frame;                              /* inside a repacketised multi-frame packet (:1779) */
+   int32_t pad0[2];
 };
 #define OA_SH_MAX_DELAY 480                              /* encoder_buffer = Fs / 100 samples per channel */
 struct OaShStream {
@@ -32,6 +34,7 @@ struct OaShStream {
    OaEncState celt;                                      /* hybrid only */
    int16_t delay_buffer[2 * OA_SH_MAX_DELAY];            /* hybrid only */
    OaSilkLbrr lbrr;                                      /* in-band FEC only */
+   int32_t energy_mask[2 * OA_NB_EBANDS];                /* surround masking (OPUS_SET_ENERGY_MASK; copied in by the multistream layer each frame) */
 };
 /* opus_encoder_init (src/opus_encoder.c:204-330) */
 static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)

@@ -1,0 +1,71 @@
+/* tests/emu/hip_stub.h — TEST INFRASTRUCTURE.  Just enough of the HIP runtime API for opus_amd/csrc/opus_amd.hip (host side + kernels) to be
+ * compiled by g++ on top of the CPU wave emulator (wave_emu.h): "device" memory is host memory, a kernel launch runs the kernel function once per
+ * workgroup on 64 fibers.  This is how the reference's own C test programs are linked against the complete C ABI in the GPU-less container
+ * (tests/hostemu.py).  The product never includes this file and has no CPU path. */
+#ifndef HIP_STUB_H
+#define HIP_STUB_H
+#include "wave_emu.h"
+#include <functional>
+#include <chrono>
+#include <mutex>
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+typedef struct EmuStream_ *hipStream_t;
+typedef struct EmuEvent_ { std::chrono::steady_clock::time_point t; } *hipEvent_t;
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __noinline__
+#define __launch_bounds__(...)
+#define __shared__ thread_local
+#define HIP_SYMBOL(x) x
+
+extern thread_local __attribute__((aligned(64))) char smem[];
+extern thread_local unsigned emu_block_x;
+struct EmuIdx { unsigned x, y, z; };
+static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)emu_cur->cur, 0, 0}; return i; }
+static inline EmuIdx emu_bidx() { EmuIdx i = {emu_block_x, 0, 0}; return i; }
+#define threadIdx (emu_tidx())
+#define blockIdx (emu_bidx())
+
+static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); if (*p) memset(*p, 0xA5, n); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind)
+{ for (size_t i = 0; i < h; i++) memmove((char *)d + i * dp, (const char *)s + i * sp, w); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
+template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent_; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
+
+static void emu_launch_tramp(void *p) { (*(std::function<void()> *)p)(); }
+static inline void emu_launch(dim3 grid, std::function<void()> body)
+{
+   for (unsigned b = 0; b < grid.x; b++) {
+      emu_block_x = b;
+      memset(smem, 0xA5, 65536);                         /* LDS is uninitialised on the GPU: make stale reads loud */
+      emu_run_wave(emu_launch_tramp, &body);
+   }
+}
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu_launch((grid), [&]() { kern(__VA_ARGS__); })
+#endif
