@@ -512,10 +512,11 @@ WV_DEVN void anti_collapse_wave(WV_LDS DecLds *L, int LM, int C, int size, int s
 }
 
 /* denormalise_bands (bands.c:187), in place on one channel of X (downsample == 1): one lane per coefficient */
-WV_DEV void denormalise_bands_wave(WV_LDS i32 *XF, const WV_LDS i32 *bandLogE, WV_LDS i32 *gains /* 2*21 ints */, int start, int end, int M, int silence)
+WV_DEV void denormalise_bands_wave(WV_LDS i32 *XF, const WV_LDS i32 *bandLogE, WV_LDS i32 *gains /* 2*21 ints */, int start, int end, int M, int silence, int downsample = 1)
 {
    const int N = M * 120;
    int bound = M * ct_eBands[end];
+   if (downsample != 1) bound = imin(bound, N / downsample);          /* nothing above the output Nyquist (bands.c:199) */
    if (silence) { bound = 0; start = end = 0; }
    wv_sync();
    FOR_LANES(i, NBE) {

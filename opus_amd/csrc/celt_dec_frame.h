@@ -6,6 +6,9 @@
 #ifndef OPUS_AMD_CELT_DEC_FRAME_H
 #define OPUS_AMD_CELT_DEC_FRAME_H
 
+/* API (output) rate of a decoder record and the CELT down-sampling factor it implies (celt_decoder.c:235 resampling_factor) */
+WV_DEV int oa_dec_fs(const WV_LDS OaDecScalars *st) { const int f = wv_uni(st->Fs); return f ? f : 48000; }
+WV_DEV int oa_dec_downsample(const WV_LDS OaDecScalars *st) { return 48000 / oa_dec_fs(st); }
 #define OA_ERR_BAD_ARG (-1)
 #define OA_ERR_BUFFER_TOO_SMALL (-2)
 #define OA_ERR_INTERNAL (-3)
@@ -150,6 +153,7 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
    WV_LDS OaDecScalars *st = &L->st;
    const int overlap = OA_OVERLAP, lane = wv_lane();
    N = wv_uni(N); CC = wv_uni(CC);
+   const int ds = oa_dec_downsample(st), Nd = N / ds;               /* API rates below 48 kHz keep every ds-th de-emphasised sample (celt_decoder.c:361-404) */
    wv_sync();
    /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; int16 staged in region A ---- */
    if (lane < CC) {
@@ -162,14 +166,22 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
          for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
 #pragma unroll
          for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
+         if (ds == 1) {
 #pragma unroll
-         for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
+            for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
+         } else {
+            for (int k = 0; k < 8; k++) if ((j0 + k) % ds == 0) y[((j0 + k) / ds) * CC + lane] = sig2word16(t[k]);
+         }
       }
       st->preemph_memD[lane] = m;
    }
    wv_sync();
    accum = wv_uni(accum);
-   if (accum) { FOR_LANES(i, N * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }   /* ADD_RES, celt/arch.h:172 */
+   if (ds != 1) {
+      if (accum) { FOR_LANES(i, Nd * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }
+      else FOR_LANES(i, Nd * CC) pcm_out[i] = L->A.pcm16[i];
+   }
+   else if (accum) { FOR_LANES(i, N * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }   /* ADD_RES, celt/arch.h:172 */
    else FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
    /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
    {
@@ -195,8 +207,9 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    const int overlap = OA_OVERLAP;
    const int lane = wv_lane();
    len = wv_uni(len); frame_size = wv_uni(frame_size);
+   const int downsample = oa_dec_downsample(st);                        /* frame_size is in API-rate samples; the codec runs at 48 kHz (celt_decoder.c:1185) */
    int LM;
-   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
+   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size * downsample) break;
    if (LM > 3) return OA_ERR_BAD_ARG;
    if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
    const int M = 1 << LM, N = M * 120;
@@ -323,20 +336,20 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       if (wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, CC);
       WV_LDS i32 *freq = L->A.X;
       if (CC == 2 && C == 1) {
-         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence);
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
          FOR_LANES(i, N) freq[N + i] = freq[i];        /* the IMDCT consumes its input: keep a copy for the second channel */
          wv_sync();
          for (int b = 0; b < B; b++) mdct_backward_wave(freq + N + b, L->BC.syn[0] + NB * b, shift, B, L->aux);
          for (int b = 0; b < B; b++) mdct_backward_wave(freq + b, L->BC.syn[1] + NB * b, shift, B, L->aux);
       } else if (CC == 1 && C == 2) {
-         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence);
-         denormalise_bands_wave(freq + N, L->oldBandE + NBE, L->scr, start, effEnd, M, silence);
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
+         denormalise_bands_wave(freq + N, L->oldBandE + NBE, L->scr, start, effEnd, M, silence, downsample);
          FOR_LANES(i, N) freq[i] = add32(half32(freq[i]), half32(freq[N + i]));
          wv_sync();
          for (int b = 0; b < B; b++) mdct_backward_wave(freq + b, L->BC.syn[0] + NB * b, shift, B, L->aux);
       } else {
          for (int c = 0; c < CC; c++) {
-            denormalise_bands_wave(freq + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, M, silence);
+            denormalise_bands_wave(freq + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, M, silence, downsample);
             for (int b = 0; b < B; b++) mdct_backward_wave(freq + c * N + b, L->BC.syn[c] + NB * b, shift, B, L->aux);
          }
       }
@@ -485,7 +498,8 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
 {
    WV_LDS OaDecScalars *st = &L->st;
    frame_size = wv_uni(frame_size);
-   const int F20 = 960, F10 = 480, F5 = 240, F2_5 = 120;
+   const int Fs = oa_dec_fs(st);
+   const int F20 = Fs / 50, F10 = Fs / 100, F5 = Fs / 200, F2_5 = Fs / 400;
    if (frame_size < F2_5) return OA_ERR_BUFFER_TOO_SMALL;
    const int mode = wv_uni(st->prev_redundancy) ? 1002 : wv_uni(st->prev_mode);
    if (mode == 0) {                     /* nothing decoded yet: zeros */
@@ -520,8 +534,8 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
             }
             WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
             SdDecControl dc;
-            dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(sdh->lastChannelsInternal); dc.API_sampleRate = 48000;
-            dc.internalSampleRate = wv_uni(sdh->lastInternalRate); dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+            dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(sdh->lastChannelsInternal); dc.API_sampleRate = Fs;
+            dc.internalSampleRate = wv_uni(sdh->lastInternalRate); dc.payloadSize_ms = imax(10, 1000 * audiosize / Fs);
             int decoded = 0;
             do {
                int n = silk_decode_wave(sdh, &gs->silk.cng_exc_buf_Q14[0][0], dc, SD_FLAG_PACKET_LOST, decoded == 0, &L->ec_silk, buf, SA, SB, L->sh.r);
@@ -572,11 +586,11 @@ WV_DEVN void celt_reset_wave(WV_LDS DecLds *L, OaDecStream *gs)
 }
 
 /* smooth_fade (src/opus_decoder.c:234-253): cross-fade over `overlap` samples with the squared CELT window */
-WV_DEV void oa_smooth_fade_wave(const i16 *in1, const i16 *in2, i16 *out, int overlap, int CC)
+WV_DEV void oa_smooth_fade_wave(const i16 *in1, const i16 *in2, i16 *out, int overlap, int CC, int inc = 1)
 {
    FOR_LANES(it, overlap * CC) {
       const int i = it / CC;
-      i32 w = ct_window[i]; w = mult16_16_q15(w, w);
+      i32 w = ct_window[i * inc]; w = mult16_16_q15(w, w);
       out[it] = (i16)((mult16_16(w, in2[it]) + mult16_16(Q15ONE - w, in1[it])) >> 15);
    }
 }
@@ -588,7 +602,8 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
-   const int F20 = 960, F5 = 240, F2_5 = 120;
+   const int Fs = oa_dec_fs(st), finc = 48000 / Fs;
+   const int F20 = Fs / 50, F5 = Fs / 200, F2_5 = Fs / 400;
    const int mode = wv_uni(st->mode), bandwidth = wv_uni(st->bandwidth), prev_mode = wv_uni(st->prev_mode), prev_red = wv_uni(st->prev_redundancy);
    const int frame_size = audiosize;
    int transition = 0, redundancy = 0, celt_to_silk = 0, redundancy_bytes = 0;
@@ -614,9 +629,9 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
          WV_LDS u8 *buf = L->packet + 1;
          WV_LDS SilkLdsA *SA = &SL->a; WV_LDS SilkLdsB *SB = &SL->b;
          SdDecControl dc;
-         dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(st->stream_channels); dc.API_sampleRate = 48000;
+         dc.nChannelsAPI = CC; dc.nChannelsInternal = wv_uni(st->stream_channels); dc.API_sampleRate = Fs;
          dc.internalSampleRate = mode == 1001 ? 16000 : bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000;
-         dc.payloadSize_ms = imax(10, 1000 * audiosize / 48000);
+         dc.payloadSize_ms = imax(10, 1000 * audiosize / Fs);
          LANE0 {
             EcCtx ec;
             k_ec_dec_init(&ec, buf, (u32)len);
@@ -710,19 +725,19 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
       if (r < 0) return r;
       redundant_rng = (u32)wv_uni((i32)st->rng);
       wv_sync();
-      oa_smooth_fade_wave(pcm + (size_t)CC * (frame_size - F2_5), gs->red + CC * F2_5, pcm + (size_t)CC * (frame_size - F2_5), F2_5, CC);
+      oa_smooth_fade_wave(pcm + (size_t)CC * (frame_size - F2_5), gs->red + CC * F2_5, pcm + (size_t)CC * (frame_size - F2_5), F2_5, CC, finc);
    }
    if (redundancy && celt_to_silk && (prev_mode != 1000 || prev_red)) {
       wv_sync();
       FOR_LANES(i, F2_5 * CC) pcm[i] = gs->red[i];
-      oa_smooth_fade_wave(gs->red + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC);
+      oa_smooth_fade_wave(gs->red + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC, finc);
    }
    if (transition) {
       wv_sync();
       if (audiosize >= F5) {
          FOR_LANES(i, F2_5 * CC) pcm[i] = gs->trans[i];
-         oa_smooth_fade_wave(gs->trans + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC);
-      } else oa_smooth_fade_wave(gs->trans, pcm, pcm, F2_5, CC);
+         oa_smooth_fade_wave(gs->trans + CC * F2_5, pcm + CC * F2_5, pcm + CC * F2_5, F2_5, CC, finc);
+      } else oa_smooth_fade_wave(gs->trans, pcm, pcm, F2_5, CC, finc);
    }
    wv_sync();
    LANE0 { st->rangeFinal ^= redundant_rng; st->prev_mode = mode; st->prev_redundancy = redundancy && !celt_to_silk; }
@@ -747,7 +762,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
       int ret = 0, offset = 0;
       sh->count = 0; sh->nb_samples = 0; sh->r[5] = 0;
       if (frame_size <= 0) ret = OA_ERR_BAD_ARG;
-      else if (len == 0 || data == 0) { ret = frame_size % 120 != 0 ? OA_ERR_BAD_ARG : 0; sh->count = -1; }        /* packet loss: conceal frame_size samples */
+      else if (len == 0 || data == 0) { ret = frame_size % (oa_dec_fs(st) / 400) != 0 ? OA_ERR_BAD_ARG : 0; sh->count = -1; }        /* packet loss: conceal frame_size samples */
       else if (len < 0) ret = OA_ERR_BAD_ARG;
       else {
          const int toc = data[0];
@@ -756,7 +771,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
          if (toc & 0x80) { packet_bandwidth = 1102 + ((toc >> 5) & 0x3); if (packet_bandwidth == 1102) packet_bandwidth = 1101; }
          else if ((toc & 0x60) == 0x60) packet_bandwidth = (toc & 0x10) ? 1105 : 1104;
          else packet_bandwidth = 1101 + ((toc >> 5) & 0x3);
-         const int packet_frame_size = oa_samples_per_frame(toc, 48000);
+         const int packet_frame_size = oa_samples_per_frame(toc, oa_dec_fs(st));
          const int count = oa_packet_parse(data, len, sh->size, &offset);
          if (count < 0) ret = count;
          else if (decode_fec && (frame_size < packet_frame_size || packet_mode == 1002 || st->mode == 1002)) sh->count = -1;   /* no usable LBRR: conceal (src/opus_decoder.c:791-797) */
@@ -782,7 +797,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
        * the first frame in this packet into them */
       const int duration_copy = wv_uni(st->last_packet_duration);
       while (nb < frame_size - pfs) {
-         const int r = oa_conceal_wave(L, gs, frame_size - pfs - nb, pcm_out + (size_t)nb * CC, CC);
+         const int r = oa_conceal_wave(L, gs, imin(frame_size - pfs - nb, wv_uni(st->frame_size)), pcm_out + (size_t)nb * CC, CC);   /* never more than the last TOC's frame size at a time (:316-322) */
          if (r < 0) { ret = r; LANE0 st->last_packet_duration = duration_copy; wv_sync(); break; }
          nb += r;
       }
@@ -805,7 +820,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
    }
    if (count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
       while (nb < frame_size) {
-         int r = oa_conceal_wave(L, gs, frame_size - nb, pcm_out + (size_t)nb * CC, CC);
+         int r = oa_conceal_wave(L, gs, imin(frame_size - nb, wv_uni(st->frame_size)), pcm_out + (size_t)nb * CC, CC);   /* never more than the last TOC's frame size at a time (src/opus_decoder.c:316-322) */
          if (r < 0) { ret = r; break; }
          nb += r;
       }

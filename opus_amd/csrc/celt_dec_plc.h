@@ -156,7 +156,7 @@ WV_DEVN void celt_decode_lost_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int
       wv_sync();
       /* celt_synthesis(X, out_syn, oldBandE, start, effEnd, C, C, isTransient = 0, LM, silence = 0) */
       for (int c = 0; c < C; c++) {
-         denormalise_bands_wave(L->A.X + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, 1 << LM, 0);
+         denormalise_bands_wave(L->A.X + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, 1 << LM, 0, oa_dec_downsample(&L->st));
          mdct_backward_wave(L->A.X + c * N, L->BC.syn[c], 3 - LM, 1, L->aux);
       }
       for (int c = 0; c < C; c++) { FOR_LANES(i, N) L->BC.syn[c][i] = saturate(L->BC.syn[c][i], SIG_SAT); }

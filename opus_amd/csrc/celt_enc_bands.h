@@ -39,6 +39,11 @@ WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int s
       FOR_LANES(i, B * N) out[i] = add32(out[i] >> 1, out[B * N + i] >> 1);
       wv_sync();
    }
+   if (L->sh.upsample > 1) {           /* zero-stuffed input: restore the level below the input's Nyquist, nothing above it (celt_encoder.c:544-554) */
+      const int up = L->sh.upsample, bound = B * N / up;
+      for (int c = 0; c < C; c++) { WV_LDS i32 *out = L->A.s.X + c * B * N; FOR_LANES(i, B * N) out[i] = i < bound ? out[i] * up : 0; }
+      wv_sync();
+   }
 }
 
 /* compute_band_energies + amp2Log2: one lane per (band, channel) */

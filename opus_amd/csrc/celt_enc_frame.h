@@ -56,10 +56,11 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_PHASE(1);
    /* ---- pre-emphasis (celt_encoder.c:557) is not materialised: pre_at() recomputes it from the int16 staging buffer ---- */
    PreSrc ps0, ps1;
-   ps0.hist = gst->prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0];
-   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1];
+   const int up = sh->upsample > 1 ? wv_uni(sh->upsample) : 1;
+   ps0.hist = gst->prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0]; ps0.up = up;
+   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1]; ps1.up = up;
    wv_sync();
-   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }
+   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = up > 1 ? 0 : mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }   /* the last zero-stuffed sample is 0 */
    wv_sync();
 
    K_PHASE(2);
@@ -269,6 +270,9 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
             target = base_target;
             if (sh->silk_offset < 100) target += 12 << BITRES >> (3 - LM);
             if (sh->silk_offset > 100) target -= 18 << BITRES >> (3 - LM);
+#ifdef OA_DBG_VBR
+            fprintf(stderr, "EMU q14 %d | vbr_rate %d tell %d off %d nbc %d boost %d min_allowed %d LM %d base %d\n", (int)((i16)sh->tf_estimate - QC16(.25f, 14)), vbr_rate, tell, sh->silk_offset, nbCompressedBytes, total_boost, min_allowed, LM, base_target);
+#endif
             target += (i32)mult16_16_q14((i16)sh->tf_estimate - QC16(.25f, 14), (50 << BITRES));
             if ((i16)sh->tf_estimate > QC16(.7f, 14)) target = imax(target, 50 << BITRES);
          }
@@ -351,9 +355,12 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       k_ec_enc_done(EC_PASS);
       int ret = e->error ? -3 : nbCompressedBytes;
       st->rangeFinal = st->rng;
-      L->packet[0] |= (u8)sh->toc;
-      if (ret >= 0 && k_ec_tell(EC_PASS) > (sh->max_data_bytes - 1) * 8) { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
-      sh->ret = ret < 0 ? ret : ret + 1;
+      if (sh->raw_frame) sh->ret = ret;                                               /* celt_encode_with_ec's own return value: the Opus layer of the caller takes it from here */
+      else {
+         L->packet[0] |= (u8)sh->toc;
+         if (ret >= 0 && k_ec_tell(EC_PASS) > (sh->max_data_bytes - 1) * 8) { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
+         sh->ret = ret < 0 ? ret : ret + 1;
+      }
       EC_END;
    }
    wv_sync();

@@ -192,7 +192,7 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L, int hyb_bytes = 0)
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
    EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
-   const int Fs = 48000, frame_size = sh->frame_size;
+   const int Fs = 48000, frame_size = sh->frame_size * (sh->upsample > 1 ? sh->upsample : 1);      /* the coder runs at 48 kHz (celt_encoder.c:1838) */
    int LM;
    for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size) break;
    sh->LM = LM; sh->M = 1 << LM; sh->N = 120 << LM;
@@ -263,11 +263,17 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L, int hyb_bytes = 0)
 /* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
  * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
  * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
-struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; };
+struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; int up; };
 WV_DEV i32 pre_at(const PreSrc &p, int j)
 {
    if (j < OA_MAX_PERIOD) return p.hist[j];
    int i = j - OA_MAX_PERIOD;
+   if (p.up > 1) {                     /* API rate below 48 kHz: sample i of the zero-stuffed signal is pcm[i / up] when up divides i, else 0 (celt_encoder.c:583-612) */
+      const int q = i / p.up, r = i - q * p.up;
+      const i32 x = r == 0 ? shl32((i32)p.pcm[p.CC * q + p.c], SIG_SHIFT) : 0;
+      const i32 m = i == 0 ? p.mem0 : (r == 1 ? mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * q + p.c], SIG_SHIFT)) : 0);
+      return x - m;
+   }
    i32 x = shl32((i32)p.pcm[p.CC * i + p.c], SIG_SHIFT);
    i32 m = i == 0 ? p.mem0 : mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * (i - 1) + p.c], SIG_SHIFT));
    return x - m;

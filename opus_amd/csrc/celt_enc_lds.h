@@ -30,6 +30,8 @@ struct FrameShared {
    i32 maxDepth, tot_boost, temporal_vbr, tf_select, enable_tf_analysis, do_patch;
    i32 alloc_trim, dual_stereo, total_boost, anti_collapse_rsv, anti_collapse_on, codedBands, balance, bits, signalBandwidth, pvq_total_bits;
    i32 silk_signalType, silk_offset;   /* hybrid: SILKInfo of the frame (celt/celt.h SILKInfo, src/opus_encoder.c:2486) */
+   i32 upsample;                       /* 48000 / API rate: the input is zero-stuffed up to 48 kHz (celt_encoder.c:255, :557, :544); 0 = 1 */
+   i32 raw_frame;                      /* plain celt_encode_with_ec (redundancy / prefill frames): no TOC, no Opus-layer finalisation */
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 

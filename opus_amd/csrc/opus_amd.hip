@@ -100,7 +100,8 @@ struct OpusGpuEncBatch {
    hipStream_t stream;
    OaStream *d_streams;
    std::vector<OaStream> h_streams;     /* host mirror of the configuration (state is authoritative on device) */
-   bool cfg_dirty;
+   bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
+   int all_silk_pinned;
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
    unsigned char *d_out; size_t out_cap;
@@ -114,7 +115,7 @@ int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
 int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
 int opusgpu_sh_kernel_lds_bytes(void) { return (int)SH_LDS_BYTES(1); }
 /* dynamic LDS of one wave: the SILK working set, or -- when the batch can reach the CELT layer (48 kHz) -- at least the CELT frame arena that aliases it */
-static size_t sh_lds_bytes(int channels, int Fs) { size_t n = SH_LDS_BYTES(channels); const size_t celt = offsetof(ShLds, S) + sizeof(FrameLds); if (Fs == 48000 && celt > n) n = celt; return n; }
+static size_t sh_lds_bytes(int channels, int silk_only) { size_t n = SH_LDS_BYTES(channels); const size_t celt = offsetof(ShLds, S) + sizeof(FrameLds); if (!silk_only && celt > n) n = celt; return n; }
 int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
 opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
 
@@ -136,7 +137,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = false;
+      b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_pcm_hp = nullptr; b->hp_cap = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
@@ -179,6 +180,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
    if (b->kind) {
+      b->cfg_dirty = true;
       for (opus_int32 s = lo; s < hi; s++) { int r = sh_ctl_set(&b->h_sh[s], request, value); if (r != OPUS_OK) return r; }
       if (request == OPUS_RESET_STATE) HIPCHECK(hipMemcpy(b->d_sh + lo, &b->h_sh[lo], sizeof(OaShStream) * (size_t)(hi - lo), hipMemcpyHostToDevice));
       else HIPCHECK(hipMemcpy2D(&b->d_sh[lo].cfg, sizeof(OaShStream), &b->h_sh[lo].cfg, sizeof(OaShStream), sizeof(OaShConfig), (size_t)(hi - lo), hipMemcpyHostToDevice));
@@ -227,7 +229,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
       if (src->cfg.channels != b->channels || src->cfg.Fs != b->Fs) return OPUS_BAD_ARG;
       HIPCHECK(hipSetDevice(b->device));
       HIPCHECK(hipStreamSynchronize(b->stream));
-      b->h_sh[stream] = *src;
+      b->h_sh[stream] = *src; b->cfg_dirty = true;
       HIPCHECK(hipMemcpy(b->d_sh + stream, src, sizeof(OaShStream), hipMemcpyHostToDevice));
       return OPUS_OK;
    }
@@ -254,7 +256,18 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    if (b->kind) {
       const size_t need = (size_t)b->S * SH_SCRATCH_BYTES(frame_size, b->channels);
       if (need > b->hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->hp_cap = need; }
-      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sh_lds_bytes(b->channels, b->Fs), s,
+      /* a launch whose streams are all pinned to the SILK layer (RESTRICTED_SILK, or OPUS_SET_FORCE_MODE(SILK_ONLY) with >= 10 ms frames at <= wideband) never enters the
+       * CELT arena and gets the smaller LDS footprint (one more wave per CU) */
+      if (b->cfg_dirty) {
+         int pinned = 1;
+         for (opus_int32 i = 0; pinned && i < b->S; i++) {
+            const OaShConfig &c = b->h_sh[i].cfg;
+            pinned = c.application == OPUS_APPLICATION_RESTRICTED_SILK || (c.user_forced_mode == OPUS_MODE_SILK_ONLY && !c.lfe && (b->Fs <= 16000 || (c.user_bandwidth != OPUS_AUTO && c.user_bandwidth <= OPUS_BANDWIDTH_WIDEBAND) || c.max_bandwidth <= OPUS_BANDWIDTH_WIDEBAND));
+         }
+         b->all_silk_pinned = pinned; b->cfg_dirty = false;
+      }
+      const int silk_only = b->all_silk_pinned && frame_size >= b->Fs / 100;
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sh_lds_bytes(b->channels, silk_only), s,
             b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i16 *)b->d_pcm_hp, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
@@ -462,7 +475,7 @@ static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
 {
    if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2)) return OPUS_BAD_ARG;
    oa_dec_stream_reset(st, channels);
-   st->s.Fs = Fs;
+   st->s.Fs = Fs; st->s.frame_size = Fs / 400;
    return OPUS_OK;
 }
 struct OpusGpuDecBatch {
@@ -663,8 +676,8 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
    if (frame_size <= 0 || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG;
    if ((decode_fec || len == 0 || data == nullptr) && frame_size % (st->Fs / 400) != 0) return OPUS_BAD_ARG;
+   if (data == nullptr) len = 0;                    /* packet loss (takes precedence over a negative length, src/opus_decoder.c:738-750) */
    if (len < 0) return OPUS_BAD_ARG;
-   if (data == nullptr) len = 0;                    /* packet loss */
    if (len == 0) decode_fec = 0;
    const int cap = st->Fs / 25 * 3;                 /* 120 ms */
    if (frame_size > cap) frame_size = cap;

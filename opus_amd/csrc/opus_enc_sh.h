@@ -1,14 +1,19 @@
-/* opus_enc_sh.h — one (stream, frame) of the SILK-capable Opus encoder on one wavefront: HBM state -> LDS -> packet bytes -> HBM.
+/* opus_enc_sh.h — one encode call of one stream of the SILK-capable Opus encoder on one wavefront: HBM state -> LDS -> packet bytes -> HBM.
  *
- * Follows src/opus_encoder.c:1182 opus_encode_native (rate, channel, mode and bandwidth decisions :1310-1700) and :1855 opus_encode_frame_native
- * (high-pass :1958-1992, SILK control block :2024-2160, SILK call :2181, TOC / range finalisation :2310-2560, CBR padding :2646) for the SILK-only
- * mode (API rates 8-48 kHz, mono/stereo, 10-60 ms frames) and for hybrid and CELT-only frames at 48 kHz (:2402-2600, sh_hybrid_celt_wave), i.e. applications
- * VOIP, AUDIO and RESTRICTED_SILK; DTX (:1463, :2242, :2565, decide_dtx_mode :1115) and in-band FEC (decide_fec :940).  What is not built is refused loudly
- * (negative length, on the frame where it arises): mode and SILK-bandwidth transitions that need a CELT redundancy frame or a SILK prefill, CELT below
- * 48 kHz, frames above 60 ms (repacketised multi-frame packets). */
+ * Follows src/opus_encoder.c:1182 opus_encode_native (the call: rate, channel, mode, redundancy / prefill and bandwidth decisions :1310-1696, the split of calls
+ * above 20 ms (60 ms in SILK-only) into frames that are re-framed as one packet :1698-1838) and :1855 opus_encode_frame_native (one coded frame: activity :1911-1930,
+ * SILK bandwidth-switch redundancy :1933-1940, high-pass :1969-2009, SILK control block and call :2043-2261 with the prefill :2191-2209, CELT control :2264-2295,
+ * delay line / gain and stereo fades :2297-2349, redundancy signalling :2351-2383, the 5 ms redundant CELT frames :2427-2442 / :2514-2545 and the 2.5 ms CELT
+ * prefill :2478-2486, TOC / range / bookkeeping :2549-2562, DTX :2565-2576, CBR padding :2646) for the applications VOIP, AUDIO and RESTRICTED_SILK at every API
+ * rate (8-48 kHz), mono / stereo, 2.5-120 ms.  Mode switches in every direction (SILK / hybrid <-> CELT-only with the redundant frame on the right side of the
+ * switch, SILK bandwidth switches), in-band FEC, both DTX flavours.
+ *
+ * LDS protocol: the packet being built lives in L->packet (ShLds); the SILK working set and the CELT frame arena alias each other in L->S, so a frame that needs
+ * the CELT coder first sends the SILK state back to HBM (sh_enter_celt) and the next frame of the same call brings it back (sh_reload_silk). */
 #ifndef OPUS_AMD_OPUS_ENC_SH_H
 #define OPUS_AMD_OPUS_ENC_SH_H
 #include "opus_sh_state.h"
+#include "opus_multiframe.h"
 
 #define OA_MODE_SILK_ONLY 1000
 #define OA_MODE_HYBRID 1001
@@ -23,9 +28,15 @@
 #define OA_ERR_BUFFER_TOO_SMALL (-2)
 
 struct ShShared {
-   i32 frame_size, max_data_bytes, orig_max_data_bytes, pad_to, plc_frame, ret, err, toc, is_silence, sample_max;
-   i32 bitrate_bps, equiv_rate, curr_bandwidth, activity, cutoff_Hz, use_hp_cutoff, bits_target, nBytes, silk_ret;
-   i32 silk_bitRate, HB_gain, nb_compr_bytes, silk_signalType, silk_offset, stereo_width;
+   /* the call (opus_encode_native) */
+   i32 frame_size, max_data_bytes, plc_frame, ret, err, is_silence, sample_max, stereo_width;
+   i32 bitrate_bps, equiv_rate, redundancy, celt_to_silk, to_celt, prefill, cbr_bytes, lsb_depth;
+   i32 nb_frames, enc_frame_size, repacketize_len, max_len_sum;
+   /* the frame (opus_encode_frame_native) */
+   i32 f_size, f_max_data_bytes, f_orig_max_data_bytes, f_redundancy, f_celt_to_silk, f_prefill, f_to_celt, f_silence;
+   i32 curr_bandwidth, activity, cutoff_Hz, use_hp_cutoff, bits_target, redundancy_bytes, nb_compr_bytes, silk_bitRate, HB_gain;
+   i32 silk_signalType, silk_offset, redundant_rng, start_band, celt_ret, silk_in_lds, tell_frac0;
+   i32 do_gain_fade, do_stereo_fade, fade_g1, fade_g2, hb_g1, hb_g2, need_celt_prefill;
    i32 r[8];
 };
 struct ShLds {
@@ -33,12 +44,15 @@ struct ShLds {
    ShShared sh;
    OaShScalars st;
    OaShConfig cfg;
+   MfLds mf;
    u8 packet[OA_MAX_PACKET + 4];
    SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
 #define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
-/* per-stream HBM scratch: the high-passed input of the call followed by the rate-loop snapshots */
-#define SH_SCRATCH_BYTES(frame_size, channels) (((size_t)(frame_size) * (channels) * 2 + 63) / 64 * 64 + sizeof(SeRateScratch))
+/* per-stream HBM scratch: the high-passed input of the frame, the faded CELT input of the frame (only written when a frame needs more than one CELT pass),
+ * the 2.5 ms CELT prefill, then the rate-loop snapshots */
+#define SH_PCM_BYTES(frame_size, channels) (((size_t)(frame_size) * (channels) * 2 + 63) / 64 * 64)
+#define SH_SCRATCH_BYTES(frame_size, channels) (2 * SH_PCM_BYTES(frame_size, channels) + 512 + sizeof(SeRateScratch))
 #define SH_STAGE_SAMPLES 1920
 
 WV_DEV i32 sh_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int mode, int complexity, int loss)      /* compute_equiv_rate :780 */
@@ -60,6 +74,18 @@ WV_DEV u8 sh_gen_toc(int mode, int framerate, int bandwidth, int channels)      
    else if (mode == OA_MODE_CELT_ONLY) { int tmp = bandwidth - OA_BW_MB; if (tmp < 0) tmp = 0; toc = (u8)(0x80 | (tmp << 5) | (period << 3)); }
    else toc = (u8)(0x60 | ((bandwidth - OA_BW_SWB) << 4) | ((period - 2) << 3));
    return (u8)(toc | ((channels == 2) << 2));
+}
+/* compute_redundancy_bytes :1142 */
+WV_DEV int sh_redundancy_bytes(i32 max_data_bytes, i32 bitrate_bps, int frame_rate, int channels)
+{
+   const int base_bits = 40 * channels + 20;
+   i32 redundancy_rate = bitrate_bps + base_bits * (200 - frame_rate);
+   redundancy_rate = 3 * redundancy_rate / 2;
+   int redundancy_bytes = redundancy_rate / 1600;
+   const i32 available_bits = max_data_bytes * 8 - 2 * base_bits;
+   const int cap = (available_bits * 240 / (240 + 48000 / frame_rate) + base_bits) / 8;
+   redundancy_bytes = imin(redundancy_bytes, cap);
+   return redundancy_bytes > 4 + 8 * channels ? imin(257, redundancy_bytes) : 0;
 }
 
 /* compute_stereo_width (src/opus_encoder.c:854): inter-channel correlation / loudness-difference tracker on the raw input; the three energy sums are plain
@@ -94,15 +120,35 @@ WV_DEV void sh_compute_stereo_width_wave(WV_LDS ShLds *L, const i16 *pcm, int fr
       L->sh.stereo_width = (i16)imin(Q15ONE, mult16_16(20, st->wm_max_follower));
    }
 }
+/* celt_maxabs16 of n int16 samples in HBM */
+WV_DEV i32 sh_maxabs_wave(const i16 *pcm, int n)
+{
+   i32 m = 0;
+   FOR_LANES(i, n) m = imax(m, iabs((i32)pcm[i]));
+   return wv_max(m);
+}
+/* compute_frame_energy (:1080): a plain int32 sum of down-shifted squares (order-free), normalised by the length */
+WV_DEV i32 sh_frame_energy_wave(const i16 *pcm, int len)
+{
+   const i32 sample_max = sh_maxabs_wave(pcm, len);
+   const int shift = imax(0, (celt_ilog2(1 + sample_max) << 1) + celt_ilog2(len) - 28);
+   i32 e = 0;
+   FOR_LANES(i, len) e += mult16_16(pcm[i], pcm[i]) >> shift;
+   e = wv_sum(e);
+   e /= len;
+   return shl32(e, shift);
+}
 
-/* lane 0: opus_encode_native's decisions (:1310-1700) */
+/* lane 0: opus_encode_native's decisions for the call (:1325-1696) */
 WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st; const WV_LDS OaShConfig *cfg = &L->cfg;
    const int Fs = cfg->Fs, channels = cfg->channels;
    i32 max_data_bytes = imin(1276 * 6, out_data_bytes);
    st->rangeFinal = 0;
-   sh->plc_frame = 0; sh->ret = 0; sh->err = 0; sh->pad_to = 0; sh->frame_size = frame_size;
+   sh->plc_frame = 0; sh->ret = 0; sh->err = 0; sh->frame_size = frame_size; sh->cbr_bytes = -1;
+   sh->redundancy = 0; sh->celt_to_silk = 0; sh->to_celt = 0; sh->prefill = 0; sh->nb_frames = 1; sh->enc_frame_size = frame_size;
+   sh->lsb_depth = imin(cfg->input_depth ? cfg->input_depth : 16, cfg->lsb_depth);
    if (max_data_bytes == 1 && Fs == frame_size * 10) { sh->err = OA_ERR_BUFFER_TOO_SMALL; return; }
    const i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
    i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
@@ -111,7 +157,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       const i32 cbr_bytes = imin((bitrate_to_bits(bitrate_bps, Fs, frame_size) + 4) / 8, max_data_bytes);
       bitrate_bps = bits_to_bitrate(cbr_bytes * 8, Fs, frame_size);
       max_data_bytes = imax(1, cbr_bytes);
-      sh->pad_to = max_data_bytes;
+      sh->cbr_bytes = cbr_bytes;
    }
    if (max_data_bytes < 3 || bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || bitrate_bps < 2400))) {
       /* 'PLC' frame (:1345-1410) */
@@ -129,6 +175,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       L->packet[0] = (u8)(sh_gen_toc(tocmode, frame_rate, bw, st->stream_channels) | packet_code);
       if (packet_code == 3) L->packet[1] = (u8)num_multiframes;
       sh->plc_frame = 1; sh->ret = packet_code <= 1 ? 1 : 2;
+      sh->max_data_bytes = imax(max_data_bytes, sh->ret);
       return;
    }
    const i32 max_rate = bits_to_bitrate(max_data_bytes * 8, Fs, frame_size);
@@ -136,7 +183,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    i32 equiv_rate = sh_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
    int voice_est;
    if (cfg->signal_type == OA_SIGNAL_VOICE) voice_est = 127; else if (cfg->signal_type == OA_SIGNAL_MUSIC) voice_est = 0;
-   else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;                 /* voice_ratio is -1 without the float analysis */
+   else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;                 /* voice_ratio is -1 without the float analysis (:1307) */
    if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
    else if (channels == 2) {
       i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
@@ -145,7 +192,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    } else st->stream_channels = channels;
    equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
    st->sm_useDTX = cfg->use_dtx && !sh->is_silence;                                               /* :1463: SILK's own DTX; digital silence takes the generalised one */
-   /* mode (:1487-1560) */
+   /* mode (:1466-1539) */
    if (cfg->application == OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_SILK_ONLY;
    else if (cfg->user_forced_mode == OA_AUTO) {
       const i32 stereo_width = sh->stereo_width;
@@ -160,12 +207,21 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       if (max_data_bytes < bitrate_to_bits(frame_rate > 50 ? 9000 : 6000, Fs, frame_size) / 8) st->mode = OA_MODE_CELT_ONLY;
    } else st->mode = cfg->user_forced_mode;
    if (st->mode != OA_MODE_CELT_ONLY && frame_size < Fs / 100) st->mode = OA_MODE_CELT_ONLY;
-   /* a SILK/hybrid <-> CELT-only switch needs a redundant CELT frame and a SILK prefill (:1568-1590, :2478-2590): not built; CELT below 48 kHz neither */
-   if ((st->mode == OA_MODE_CELT_ONLY) != (st->prev_mode == OA_MODE_CELT_ONLY) && st->prev_mode > 0) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
-   if (st->mode == OA_MODE_CELT_ONLY && (Fs != 48000 || frame_size > Fs / 50)) { sh->err = OA_ERR_UNIMPLEMENTED; return; }
-   if (st->stream_channels == 1 && st->prev_channels == 2 && st->sm_toMono == 0) { st->sm_toMono = 1; st->stream_channels = 2; } else st->sm_toMono = 0;
+   if (cfg->lfe && cfg->application != OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_CELT_ONLY;
+   /* a switch between the SILK-based modes and CELT-only carries a 5 ms redundant CELT frame on the SILK side of it (:1541-1558) */
+   if (st->prev_mode > 0 && ((st->mode != OA_MODE_CELT_ONLY) != (st->prev_mode != OA_MODE_CELT_ONLY))) {
+      sh->redundancy = 1;
+      sh->celt_to_silk = st->mode != OA_MODE_CELT_ONLY;
+      if (!sh->celt_to_silk) {
+         if (frame_size >= Fs / 100) { st->mode = st->prev_mode; sh->to_celt = 1; }            /* this call is still coded in the old mode, the redundant frame follows it */
+         else sh->redundancy = 0;
+      }
+   }
+   if (st->stream_channels == 1 && st->prev_channels == 2 && st->sm_toMono == 0 && st->mode != OA_MODE_CELT_ONLY && st->prev_mode != OA_MODE_CELT_ONLY) { st->sm_toMono = 1; st->stream_channels = 2; }
+   else st->sm_toMono = 0;
    equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, st->mode, cfg->complexity, loss);
-   /* bandwidth (:1600-1700) */
+   if (st->mode != OA_MODE_CELT_ONLY && st->prev_mode == OA_MODE_CELT_ONLY) sh->prefill = 1;      /* + silk_InitEncoder, done by the wave right after this section (:1576-1581) */
+   /* bandwidth (:1583-1696) */
    if (st->mode == OA_MODE_CELT_ONLY || st->first || st->sm_allowBandwidthSwitch) {
       const i32 voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000}, music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};
       int bandwidth = OA_BW_FB;
@@ -206,22 +262,22 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       st->sm_LBRR_coded = fec;
    }
    if (st->mode == OA_MODE_CELT_ONLY && st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
+   if (cfg->lfe) st->bandwidth = OA_BW_NB;
    int curr_bandwidth = st->bandwidth;
    if (cfg->application == OA_APP_RESTRICTED_SILK && curr_bandwidth > OA_BW_WB) st->bandwidth = curr_bandwidth = OA_BW_WB;
    if (st->mode == OA_MODE_SILK_ONLY && curr_bandwidth > OA_BW_WB) st->mode = OA_MODE_HYBRID;
    if (st->mode == OA_MODE_HYBRID && curr_bandwidth <= OA_BW_WB) st->mode = OA_MODE_SILK_ONLY;
-   if (st->mode == OA_MODE_HYBRID && (Fs != 48000 || frame_size > Fs / 50 || (st->prev_mode > 0 && st->prev_mode != OA_MODE_HYBRID))) { sh->err = OA_ERR_UNIMPLEMENTED; return; }   /* CELT layer: 48 kHz, <= 20 ms; SILK -> hybrid needs the CELT prefill */
-   if (frame_size > 3 * Fs / 50) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                       /* 80/100/120 ms: repacketised multi-frame packets */
-   if (st->silk_bw_switch) { sh->err = OA_ERR_UNIMPLEMENTED; return; }                             /* bandwidth switch with CELT redundancy */
-   sh->bitrate_bps = bitrate_bps; sh->equiv_rate = equiv_rate; sh->curr_bandwidth = curr_bandwidth;
-   sh->orig_max_data_bytes = max_data_bytes; sh->max_data_bytes = imin(max_data_bytes, 1276);
-   /* opus_encode_frame_native prologue */
-   sh->activity = sh->is_silence ? 0 : SE_VAD_NO_DECISION;
-   sh->bits_target = imin(8 * sh->max_data_bytes, bitrate_to_bits(bitrate_bps, Fs, frame_size)) - 8;
-   const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
-   st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
-   sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
-   sh->use_hp_cutoff = cfg->application == OA_APP_VOIP;
+   sh->bitrate_bps = bitrate_bps; sh->equiv_rate = equiv_rate; sh->max_data_bytes = max_data_bytes;
+   /* more than one coded frame? (:1698-1755) */
+   if ((frame_size > Fs / 50 && st->mode != OA_MODE_SILK_ONLY) || frame_size > 3 * Fs / 50) {
+      int enc_frame_size;
+      if (st->mode == OA_MODE_SILK_ONLY) enc_frame_size = frame_size == 2 * Fs / 25 ? Fs / 25 : frame_size == 3 * Fs / 25 ? 3 * Fs / 50 : Fs / 50;
+      else enc_frame_size = Fs / 50;
+      const int nb_frames = frame_size / enc_frame_size, max_header_bytes = nb_frames == 2 ? 3 : 2 + (nb_frames - 1) * 2;
+      sh->repacketize_len = (cfg->use_vbr || cfg->user_bitrate_bps == OA_BITRATE_MAX) ? out_data_bytes : imin(sh->cbr_bytes, out_data_bytes);
+      sh->max_len_sum = nb_frames + sh->repacketize_len - max_header_bytes;
+      sh->nb_frames = nb_frames; sh->enc_frame_size = enc_frame_size;
+   }
 }
 
 /* hp_cutoff (:441, VOIP) or dc_reject (:479) over one chunk staged in LDS: lane c runs channel c's recursion */
@@ -260,14 +316,19 @@ WV_DEV int sh_emit_packet(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, 
    if (pad_to == 0 || nbytes == pad_to) { if (nbytes > out_cap) return OA_ERR_BUFFER_TOO_SMALL; FOR_LANES(i, nbytes) out[i] = pk[i]; return nbytes; }
    if (nbytes > pad_to) return OA_ERR_INTERNAL;
    if (pad_to > out_cap) return OA_ERR_BUFFER_TOO_SMALL;
-   const int L0 = nbytes - 1, pad_amount = pad_to - (L0 + 2);
-   const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = 2 + (pad_amount > 0 ? nb_255s + 1 : 0);
+   /* the frame(s) of the packet as it stands: code 0 (everything after the TOC) -- or the code-1/3 'PLC' packets of sh_layer_decide, which carry no payload */
+   const int code = pk[0] & 3;
+   const int count = code == 0 ? 1 : code == 3 ? (pk[1] & 0x3F) : 2, L0 = code == 0 ? nbytes - 1 : 0, src0 = code == 0 ? 1 : nbytes;
+   int hdr0 = 2, vbr = 0;
+   (void)vbr;
+   const int pad_amount = pad_to - (hdr0 + count * L0);
+   const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = hdr0 + (pad_amount > 0 ? nb_255s + 1 : 0);
    FOR_LANES(i, pad_to) {
       u8 v = 0;
       if (i == 0) v = (u8)((pk[0] & 0xFC) | 0x3);
-      else if (i == 1) v = (u8)(1 | (pad_amount != 0 ? 0x40 : 0));
+      else if (i == 1) v = (u8)(count | (pad_amount != 0 ? 0x40 : 0));
       else if (i < hdr) v = i < hdr - 1 ? 255 : (u8)(pad_amount - 255 * nb_255s - 1);
-      else if (i < hdr + L0) v = pk[1 + i - hdr];
+      else if (i < hdr + L0) v = pk[src0 + i - hdr];
       out[i] = v;
    }
    return pad_to;
@@ -291,9 +352,7 @@ WV_DEV i32 sh_silk_rate_for_hybrid(i32 rate, int bandwidth, int frame20ms, int v
    return silk_rate;
 }
 
-/* stereo-width decision and the fade gains of the CELT input (:2365-2400), then the per-call bookkeeping (:2596-2600); silk_width = the width SILK reported */
-/* the generalised DTX decision at the end of opus_encode_frame_native (:2565-2576, decide_dtx_mode :1115): without the float analysis it only ever sees
- * digital silence (SILK's own DTX covers the rest); after 200 ms of it the packet is the TOC byte alone, at most 400 ms in a row */
+/* the generalised DTX decision at the end of opus_encode_frame_native (:2565-2576, decide_dtx_mode :1115); 1 = send the TOC byte alone */
 WV_DEV int sh_generalised_dtx_l0(WV_LDS ShLds *L, int frame_size, int Fs)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
@@ -308,147 +367,178 @@ WV_DEV int sh_generalised_dtx_l0(WV_LDS ShLds *L, int frame_size, int Fs)
    st->nb_no_activity_ms_Q1 = 0;
    return 0;
 }
-WV_DEV void sh_width_and_bookkeeping_l0(WV_LDS ShLds *L, int frame_size, i32 silk_width)
-{
-   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   st->sm_stereoWidth_Q14 = silk_width;
-   if (st->mode != OA_MODE_HYBRID || st->stream_channels == 1) {
-      if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
-      else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
-   }
-   sh->r[0] = 0;
-   if (L->cfg.channels == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) {
-      i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)st->sm_stereoWidth_Q14;
-      sh->r[0] = 1; sh->r[1] = g1 == 16384 ? Q15ONE : shl16(g1, 1); sh->r[2] = g2 == 16384 ? Q15ONE : shl16(g2, 1);
-      st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
-   }
-   st->prev_mode = st->mode; st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
-}
 
-/* The CELT layer of a hybrid frame (src/opus_encoder.c:2452-2600): bands 17.. on the coder the SILK layer leaves behind.  The SILK state has served its
- * purpose: it goes back to HBM and the CELT encoder's LDS working set takes its place.  CELT input = the delay-compensated high-passed signal
- * (delay_buffer tail + this call's frame), faded towards the high-band gain and the stereo width decided above. */
-WV_DEVN void sh_hybrid_celt_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm_hp, int frame_size, u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+/* ---- SILK <-> CELT arena ---- */
+WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                               /* SILK state back to HBM (coalesced) if it is in LDS; CELT scalars in */
 {
-   const int hyb = L->st.mode == OA_MODE_HYBRID;                                       /* else CELT-only inside an AUDIO / VOIP encoder (:2452-2560 with start band 0) */
-   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
-   if (hyb) {  /* SILK state back to HBM (coalesced); a CELT-only frame leaves it untouched */
+   const int CC = L->cfg.channels;
+   wv_sync();
+   if (wv_uni(L->sh.silk_in_lds)) {
       i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
       FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+      wv_sync();
+      LANE0 L->sh.silk_in_lds = 0;
    }
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
+   FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
+   FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = gs->celt.oldBandE[i]; F->energyError[i] = gs->celt.energyError[i]; }
    wv_sync();
+}
+WV_DEV void sh_leave_celt(WV_LDS ShLds *L, OaShStream *gs)
+{
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   wv_sync();
+   i32 *g = (i32 *)&gs->celt.s; const WV_LDS i32 *d = (const WV_LDS i32 *)&F->st;
+   FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
+   wv_sync();
+}
+WV_DEV void sh_reload_silk(WV_LDS ShLds *L, const OaShStream *gs)
+{
+   if (wv_uni(L->sh.silk_in_lds)) return;
+   wv_sync();
+   const i32 *g = (const i32 *)&gs->silk; WV_LDS i32 *d = (WV_LDS i32 *)&L->S.st;
+   FOR_LANES(i, SE_STATE_WORDS(L->cfg.channels)) d[i] = g[i];
+   wv_sync();
+   LANE0 L->sh.silk_in_lds = 1;
+}
+/* OPUS_RESET_STATE of the CELT encoder (celt_encoder.c:2972-2992) on the state in HBM + the scalars in the arena; configuration-like words survive */
+WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
+{
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   wv_sync();
+   LANE0 {
+      WV_LDS OaEncScalars *c = &F->st;
+      const i32 dpf = c->pad0[0], fi = c->pad0[1];
+      WV_LDS i32 *w = (WV_LDS i32 *)c; for (int i = 0; i < (int)(sizeof(OaEncScalars) / 4); i++) w[i] = 0;
+      c->pad0[0] = dpf; c->pad0[1] = fi;
+      c->spread_decision = 2; c->delayedIntra = 1; c->tonal_average = 256;
+      L->sh.silk_signalType = 0; L->sh.silk_offset = 0;                                  /* SILKInfo sits in the reset region too: the CELT passes after a reset see zeros until the next frame sets it */
+   }
+   FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = 0; F->energyError[i] = 0; gs->celt.oldBandE[i] = 0; gs->celt.energyError[i] = 0; gs->celt.oldLogE[i] = gs->celt.oldLogE2[i] = -(28 << 24); }
+   FOR_LANES(i, 2 * OA_OVERLAP) gs->celt.in_mem[i] = 0;
+   FOR_LANES(i, 2 * OA_MAX_PERIOD) gs->celt.prefilter_mem[i] = 0;
+   wv_sync();
+}
+/* the persistent CELT_SET_PREDICTION state (celt_encoder.c:2893: disable_pf = value <= 1, force_intra = value == 0) lives in two spare scalar words */
+#define SH_CELT_DISABLE_PF(F) ((F)->st.pad0[0])
+#define SH_CELT_FORCE_INTRA(F) ((F)->st.pad0[1])
+
+/* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in F->A.pcm16).
+ *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in L->packet (hybrid), or starting it (CELT-only frame)
+ *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
+struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
+WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
    WV_LDS FrameShared *fs = &F->sh;
-   {
-      const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
-      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-      FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = gs->celt.oldBandE[i]; F->energyError[i] = gs->celt.energyError[i]; }
-      FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i];
-   }
-   LANE0 {
-      if (hyb) ec_cp_lds(&F->ec, &L->ec);
-      const int curr_bandwidth = sh->curr_bandwidth, endband = curr_bandwidth == OA_BW_NB ? 13 : curr_bandwidth <= OA_BW_WB ? 17 : curr_bandwidth == OA_BW_SWB ? 19 : 21;
-      fs->CC = CC; fs->C = st->stream_channels; fs->frame_size = frame_size; fs->start = hyb ? 17 : 0; fs->end = endband; fs->effEnd = endband;
-      fs->complexity = L->cfg.complexity; fs->lsb_depth = imin(16, L->cfg.lsb_depth); fs->disable_inv = L->cfg.disable_inv; fs->disable_pf = 0; fs->force_intra = 0; fs->loss_rate = L->cfg.packet_loss_perc;
-      fs->vbr = L->cfg.use_vbr; fs->constrained_vbr = hyb ? 0 : L->cfg.vbr_constraint;
-      fs->bitrate = -1;
-      if (L->cfg.use_vbr) { const i32 cb = hyb ? sh->bitrate_bps - sh->silk_bitRate : sh->bitrate_bps; if (cb > 500) fs->bitrate = imin(cb, 750000 * CC); }     /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
-      fs->curr_bandwidth = curr_bandwidth; fs->max_data_bytes = sh->max_data_bytes; fs->orig_max_data_bytes = sh->orig_max_data_bytes; fs->pad_to = sh->pad_to;
-      fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0;
-      fs->toc = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
-      fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
-      fs->do_stereo_fade = sh->r[0]; fs->fade_g1 = sh->r[1]; fs->fade_g2 = sh->r[2];
-   }
-   /* ---- CELT input: [delay tail | new frame], then the delay line moves on (:1950, :2340-2353) ---- */
-   const int total_buffer = Fs / 250, encoder_buffer = Fs / 100;
-   {
-      WV_LDS i16 *io = F->A.pcm16;
-      FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
-      wv_sync();
-      /* new delay line = the last encoder_buffer samples of [old line | this frame]; ascending in place through registers, one 64-lane trip at a time */
-      for (int b0 = 0; b0 < encoder_buffer * CC; b0 += WV_WIDTH) {
-         const int i = b0 + wv_lane(), j = i + frame_size * CC;
-         i16 v = 0;
-         if (i < encoder_buffer * CC) v = j < encoder_buffer * CC ? gs->delay_buffer[j] : pcm_hp[j - encoder_buffer * CC];
-         wv_sync();
-         if (i < encoder_buffer * CC) gs->delay_buffer[i] = v;
-         wv_sync();
-      }
-      const i16 g1 = (i16)st->prev_HB_gain, g2 = (i16)sh->HB_gain;
-      if (g1 < Q15ONE || g2 < Q15ONE) {                                               /* gain_fade (:581) */
-         FOR_LANES(i, frame_size * CC) {
-            const int n = i / CC; i16 g = g2;
-            if (n < OA_OVERLAP) { i16 w = ct_window[n]; w = (i16)mult16_16_q15(w, w); g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15); }
-            io[i] = (i16)mult16_16_q15(g, io[i]);
-         }
-      }
-      wv_sync();
-      LANE0 st->prev_HB_gain = sh->HB_gain;
-      if (fs->do_stereo_fade) { stereo_fade_lanes(F, frame_size); wv_sync(); }
-      const int overlap = OA_OVERLAP;
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs, up = 48000 / Fs;
+   wv_sync();
+   if (src) { FOR_LANES(i, nsamp * CC) F->A.pcm16[i] = src[i]; }
+   if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i]; }
+   wv_sync();
+   {  /* celt_maxabs over the head and the overlap tail of the input (celt_encoder.c:1970-1973), at the API rate */
+      const WV_LDS i16 *p = F->A.pcm16;
+      const int ov = OA_OVERLAP / up;
       i32 a = 0, b = 0;
-      FOR_LANES(i, CC * (frame_size - overlap)) a = imax(a, iabs((i32)io[i]));
-      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)io[CC * (frame_size - overlap) + i]));
+      FOR_LANES(i, CC * (nsamp - ov)) a = imax(a, iabs((i32)p[i]));
+      FOR_LANES(i, CC * ov) b = imax(b, iabs((i32)p[CC * (nsamp - ov) + i]));
       a = wv_max(a); b = wv_max(b);
       LANE0 { fs->r[0] = a; fs->r[1] = b; }
    }
+   LANE0 {
+      if (ctl.cont) ec_cp_lds(&F->ec, &L->ec);
+      const int curr_bandwidth = sh->curr_bandwidth, endband = curr_bandwidth == OA_BW_NB ? 13 : curr_bandwidth <= OA_BW_WB ? 17 : curr_bandwidth == OA_BW_SWB ? 19 : 21;
+      fs->CC = CC; fs->C = st->stream_channels; fs->frame_size = nsamp; fs->upsample = up; fs->raw_frame = 1;        /* this Opus layer does its own finalisation */
+      fs->start = ctl.start; fs->end = endband; fs->effEnd = endband;
+      fs->complexity = L->cfg.complexity; fs->lsb_depth = sh->lsb_depth; fs->disable_inv = L->cfg.disable_inv; fs->loss_rate = L->cfg.packet_loss_perc;
+      fs->disable_pf = SH_CELT_DISABLE_PF(F); fs->force_intra = SH_CELT_FORCE_INTRA(F);
+      fs->vbr = ctl.vbr; fs->constrained_vbr = ctl.constrained_vbr; fs->bitrate = ctl.bitrate;
+      fs->curr_bandwidth = curr_bandwidth;
+      fs->max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_max_data_bytes; fs->orig_max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_orig_max_data_bytes; fs->pad_to = 0;
+      fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0; fs->toc = 0;
+      fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
+      fs->do_stereo_fade = 0;
+   }
    wv_sync();
-   LANE0 celt_prologue(F, hyb ? sh->nb_compr_bytes : 0);
-#ifdef SH_DEBUG
-   LANE0 printf("hyb: toc %d pk0 %d nb_compr %d tell %d skip %d bitrate %d vbr %d C %d end %d\n", fs->toc, F->packet[0], sh->nb_compr_bytes, fs->tell, fs->skip_celt, fs->bitrate, fs->vbr, fs->C, fs->end);
-#endif
+   LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
    wv_sync();
-   if (fs->skip_celt) { LANE0 { F->packet[0] = (u8)fs->toc; F->packet[1] = 0; F->st.rangeFinal = 0; fs->ret = 2; } wv_sync(); }
-   else if (hyb) celt_encode_core<true>(F, &gs->celt, out);
-   else celt_encode_core<false>(F, &gs->celt, out);
+   if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
+   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
+   else celt_encode_core<false>(F, &gs->celt, journal);
    wv_sync();
-#ifdef SH_DEBUG
-   LANE0 printf("hyb end: toc %d pk0 %d ret %d rng %u\n", fs->toc, F->packet[0], fs->ret, F->st.rangeFinal);
-#endif
-   {
-      LANE0 { if (fs->ret >= 0 && sh_generalised_dtx_l0(L, frame_size, Fs)) { F->st.rangeFinal = 0; F->packet[0] = (u8)fs->toc; fs->ret = 1; fs->pad_to = 0; } }
-      const int nbytes = emit_packet_wave(F, out, fs->ret, fs->pad_to, out_cap);
-      LANE0 { *len_out = nbytes; *rng_out = F->st.rangeFinal; st->rangeFinal = F->st.rangeFinal; }
-      wv_sync();
-      i32 *g = (i32 *)&gs->celt.s; const WV_LDS i32 *d = (const WV_LDS i32 *)&F->st;
-      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
-      g = (i32 *)&gs->s; d = (const WV_LDS i32 *)st;
-      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
+   LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = fs->ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
+   wv_sync();
+}
+
+/* gain_fade (:581) / stereo_fade (:548) on `n` frames of CC interleaved int16 in LDS; the cross-fade covers overlap = 120 * Fs / 48000 samples, window read with stride inc */
+WV_DEV void sh_gain_fade_lds(WV_LDS i16 *io, int n, int CC, i16 g1, i16 g2, int Fs)
+{
+   const int inc = 48000 / Fs, overlap = OA_OVERLAP / inc;
+   FOR_LANES(i, n * CC) {
+      const int k = i / CC; i16 g = g2;
+      if (k < overlap) { i16 w = ct_window[k * inc]; w = (i16)mult16_16_q15(w, w); g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15); }
+      io[i] = (i16)mult16_16_q15(g, io[i]);
+   }
+}
+WV_DEV void sh_stereo_fade_lds(WV_LDS i16 *io, int n, i16 g1_, i16 g2_, int Fs)
+{
+   const int inc = 48000 / Fs, overlap = OA_OVERLAP / inc;
+   const i16 g1 = (i16)(Q15ONE - g1_), g2 = (i16)(Q15ONE - g2_);
+   FOR_LANES(i, n) {
+      i16 g = g2;
+      if (i < overlap) { i16 w = ct_window[i * inc]; w = (i16)mult16_16_q15(w, w); g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15); }
+      i32 diff = half32((i32)io[2 * i] - (i32)io[2 * i + 1]);
+      diff = mult16_16_q15(g, diff);
+      io[2 * i] = (i16)(io[2 * i] - diff);
+      io[2 * i + 1] = (i16)(io[2 * i + 1] + diff);
    }
 }
 
-WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
+/* One coded frame: opus_encode_frame_native (:1855).  pcm = this frame's input, frame_size samples per channel; the packet ends up in L->packet, its length (before
+ * CBR padding) is returned and st / the HBM state are updated.  pcm_hp / pcm_celt / pre = per-stream HBM scratch. */
+WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill,
+      SeRateScratch *G, u8 *journal)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   SE_PHASE_START(&L->S);
-   /* ---- load configuration, Opus-layer scalars and the SILK encoder state (coalesced) ---- */
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs, application = L->cfg.application;
+   const int delay_compensation = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, total_buffer = delay_compensation, encoder_buffer = Fs / 100;
+   const int frame_rate = Fs / frame_size;
+   frame_size = wv_uni(frame_size); orig_max_data_bytes = wv_uni(orig_max_data_bytes);
+   /* ---- activity (:1911-1930) ---- */
    {
-      const i32 *g = (const i32 *)&gs->cfg; WV_LDS i32 *d = (WV_LDS i32 *)&L->cfg;
-      FOR_LANES(i, (int)(sizeof(OaShConfig) / 4)) d[i] = g[i];
-      g = (const i32 *)&gs->s; d = (WV_LDS i32 *)st;
-      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) d[i] = g[i];
-      g = (const i32 *)&gs->silk; d = (WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(gs->cfg.channels)) d[i] = g[i];
+      i32 noise_energy = 0;
+      const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;
+      if (!wv_uni(sh->f_silence) && celt_only) noise_energy = sh_frame_energy_wave(pcm, frame_size * CC);
+      LANE0 {
+         sh->activity = SE_VAD_NO_DECISION;
+         if (sh->f_silence) sh->activity = 0;
+         else if (celt_only) sh->activity = (i64)st->peak_signal_energy < 316 * (i64)half32(noise_energy);
+      }
    }
-   wv_sync();
-   SE_PHASE(&L->S, 0);
-   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
-   {  /* is_digital_silence (:1060, fixed point: all samples zero) */
-      i32 m = 0;
-      FOR_LANES(i, frame_size * CC) m = imax(m, iabs((i32)pcm[i]));
-      m = wv_max(m);
-      LANE0 { sh->sample_max = m; sh->is_silence = m == 0; }
+   LANE0 {
+      int redundancy = sh->f_redundancy, celt_to_silk = sh->f_celt_to_silk, prefill = sh->f_prefill;
+      const int max_data_bytes = imin(orig_max_data_bytes, 1276);
+      st->rangeFinal = 0;
+      if (st->silk_bw_switch) { redundancy = 1; celt_to_silk = 1; st->silk_bw_switch = 0; prefill = 2; }      /* first frame at a new SILK bandwidth (:1933) */
+      if (st->mode == OA_MODE_CELT_ONLY) redundancy = 0;
+      int redundancy_bytes = 0;
+      if (redundancy) { redundancy_bytes = sh_redundancy_bytes(max_data_bytes, sh->bitrate_bps, frame_rate, st->stream_channels); if (redundancy_bytes == 0) redundancy = 0; }
+      if (application == OA_APP_RESTRICTED_SILK) { redundancy = 0; redundancy_bytes = 0; }
+      sh->f_redundancy = redundancy; sh->f_celt_to_silk = celt_to_silk; sh->f_prefill = prefill; sh->redundancy_bytes = redundancy_bytes;
+      sh->f_max_data_bytes = max_data_bytes; sh->f_orig_max_data_bytes = orig_max_data_bytes;
+      sh->bits_target = imin(8 * (max_data_bytes - redundancy_bytes), bitrate_to_bits(sh->bitrate_bps, Fs, frame_size)) - 8;
+      sh->curr_bandwidth = st->bandwidth;
+      sh->redundant_rng = 0; sh->f_size = frame_size; sh->r[3] = 0;                  /* r[3]: the result is a bare TOC that is never padded (DTX) */
+      { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
+      const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
+      st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
+      sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
+      sh->use_hp_cutoff = application == OA_APP_VOIP;
    }
-   if (CC == 2 && L->cfg.force_channels != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
-   LANE0 sh_layer_decide(L, frame_size, max_data_bytes);
-   if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
-   if (sh->plc_frame) {
-      const int n = sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; gs->s.rangeFinal = 0; }
-      return;
-   }
-   /* ---- high-pass into the per-stream HBM scratch, staged through LDS in chunks ---- */
+   /* ---- high-pass into the per-stream HBM scratch, staged through LDS in chunks (:1980-2009) ---- */
    {
       i32 B_Q28[3] = {0, 0, 0}, A_Q28[2] = {0, 0};
       if (sh->use_hp_cutoff) {
@@ -473,101 +563,381 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       wv_sync();
    }
    SE_PHASE(&L->S, 1);
-   if (st->mode == OA_MODE_CELT_ONLY) {
-      LANE0 { sh->HB_gain = Q15ONE; sh_width_and_bookkeeping_l0(L, frame_size, 0); }
-      sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out);
-      return;
-   }
-   /* ---- SILK (:2024-2200) ---- */
+   const int mode = wv_uni(st->mode);
    SeControl sc;
-   {
-      const int mode = st->mode, curr_bandwidth = sh->curr_bandwidth, frame_rate = Fs / frame_size;
-      sc.nChannelsAPI = CC; sc.nChannelsInternal = st->stream_channels; sc.API_sampleRate = Fs;
-      const i32 total_bitRate = bits_to_bitrate(sh->bits_target, Fs, frame_size);
-      sc.bitRate = total_bitRate;
-      sh->HB_gain = Q15ONE;
-      if (mode == OA_MODE_HYBRID) {                                                  /* :2034-2046 */
-         sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels);
-         sh->HB_gain = Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1);        /* celt_exp2 takes an opus_val16: the rate difference is truncated as in the reference */
-      }
-      sh->silk_bitRate = sc.bitRate;
-      sc.payloadSize_ms = 1000 * frame_size / Fs;
-      sc.desiredInternalSampleRate = curr_bandwidth == OA_BW_NB ? 8000 : curr_bandwidth == OA_BW_MB ? 12000 : 16000;
-      sc.minInternalSampleRate = mode == OA_MODE_HYBRID ? 16000 : 8000;
-      sc.maxInternalSampleRate = 16000;
-      if (mode == OA_MODE_SILK_ONLY) {
-         i32 effective_max_rate = bits_to_bitrate(sh->max_data_bytes * 8, Fs, frame_size);
-         if (frame_rate > 50) effective_max_rate = effective_max_rate * 2 / 3;
-         if (effective_max_rate < 8000) { sc.maxInternalSampleRate = 12000; sc.desiredInternalSampleRate = imin(12000, sc.desiredInternalSampleRate); }
-         if (effective_max_rate < 7000) { sc.maxInternalSampleRate = 8000; sc.desiredInternalSampleRate = imin(8000, sc.desiredInternalSampleRate); }
-      }
-      sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec; sc.LBRR_coded = st->sm_LBRR_coded; sc.useDTX = st->sm_useDTX;
-      sc.useCBR = !L->cfg.use_vbr;
-      sc.maxBits = (sh->max_data_bytes - 1) * 8;
-      if (mode == OA_MODE_HYBRID) {                                                  /* :2136-2160 */
-         if (sc.useCBR) { const i16 other_bits = (i16)imax(0, sc.maxBits - sc.bitRate * frame_size / Fs); sc.maxBits = imax(0, sc.maxBits - other_bits * 3 / 4); sc.useCBR = 0; }
-         else { const i32 maxBitRate = sh_silk_rate_for_hybrid(sc.maxBits * Fs / frame_size, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels); sc.maxBits = bitrate_to_bits(maxBitRate, Fs, frame_size); }
-      }
-      sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = 0;
-      sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
-   }
-   LANE0 { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(sh->orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
-   const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
-   wv_sync();
-   if (sret) { LANE0 { *len_out = sret == -100 ? OA_ERR_UNIMPLEMENTED : OA_ERR_INTERNAL; *rng_out = 0; gs->s.error = sret; } return; }
-   SE_PHASE(&L->S, 9);
-   /* ---- finalise (:2190-2560) ---- */
-   LANE0 {
-      int curr_bandwidth = sh->curr_bandwidth;
-      if (st->mode == OA_MODE_SILK_ONLY) { if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB; }
-      st->sm_allowBandwidthSwitch = sc.allowBandwidthSwitch; st->sm_inWBmodeWithoutVariableLP = sc.inWBmodeWithoutVariableLP; st->sm_switchReady = sc.switchReady;
-      st->sm_opusCanSwitch = sc.switchReady;                                          /* (!nonfinal_frame: single-packet calls only) */
-      const int nBytes = L->S.r[0];
-      int ret;
-      if (nBytes == 0) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); ret = 1; sh->pad_to = 0; }   /* SILK DTX (:2242): straight out, no bookkeeping */
-      else {
-         if (st->sm_opusCanSwitch) {
-            if (L->cfg.application != OA_APP_RESTRICTED_SILK) st->error = OA_ERR_UNIMPLEMENTED;          /* the next frame would need a redundant CELT frame */
-            st->silk_bw_switch = L->cfg.application != OA_APP_RESTRICTED_SILK;
+   int silk_nBytes = 1;
+   if (mode != OA_MODE_CELT_ONLY) {
+      /* ---- SILK (:2043-2261) ---- */
+      {
+         const int curr_bandwidth = sh->curr_bandwidth, redundancy = sh->f_redundancy, redundancy_bytes = sh->redundancy_bytes;
+         sc.nChannelsAPI = CC; sc.nChannelsInternal = st->stream_channels; sc.API_sampleRate = Fs;
+         const i32 total_bitRate = bits_to_bitrate(sh->bits_target, Fs, frame_size);
+         sc.bitRate = total_bitRate;
+         i32 HB_gain = Q15ONE;
+         if (mode == OA_MODE_HYBRID) {                                                  /* :2052-2062 */
+            sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels);
+            if (!L->cfg.energy_mask_on) HB_gain = Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1);   /* celt_exp2 takes an opus_val16: the rate difference is truncated as in the reference */
          }
-         if (st->silk_bw_switch) { sh->ret = OA_ERR_UNIMPLEMENTED; }                 /* this very frame would carry the redundant CELT frame (:2251-2262) */
-         else {
-         sh_width_and_bookkeeping_l0(L, frame_size, sc.stereoWidth_Q14);
-         if (st->mode == OA_MODE_HYBRID) {                                            /* :2402-2450: the redundancy flag, then the CELT layer takes the coder over */
-            EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
-            if (k_ec_tell(EC_PASS) + 17 + 20 <= 8 * (sh->max_data_bytes - 1)) k_ec_enc_bit_logp(EC_PASS, 0, 12);
-            sh->nb_compr_bytes = sh->max_data_bytes - 1;
-            k_ec_enc_shrink(EC_PASS, (u32)sh->nb_compr_bytes);
-            ec_st(&L->ec, e);
-            sh->curr_bandwidth = curr_bandwidth; sh->silk_signalType = sc.signalType; sh->silk_offset = sc.offset;
-            sh->ret = -1000;                                                          /* continue in sh_hybrid_celt_wave */
-         } else {
-         EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
-         const int tell = k_ec_tell(EC_PASS);
-         ret = (tell + 7) >> 3;
+         LANE0 { sh->HB_gain = HB_gain; }
+         if (L->cfg.energy_mask_on && L->cfg.use_vbr && !L->cfg.lfe) {                 /* surround masking for SILK (:2069-2108) */
+            i32 mask_sum = 0;
+            int end = 17; i16 srate = 16000;
+            if (st->bandwidth == OA_BW_NB) { end = 13; srate = 8000; } else if (st->bandwidth == OA_BW_MB) { end = 15; srate = 12000; }
+            for (int c = 0; c < CC; c++) for (int i = 0; i < end; i++) {
+               i32 mask = imax(imin(gs->energy_mask[21 * c + i], GC(.5f)), -GC(2.0f));
+               if (mask > 0) mask = half32(mask);
+               mask_sum += mask;
+            }
+            i32 masking_depth = mask_sum / end * CC;
+            masking_depth += GC(.2f);
+            i32 rate_offset = (i32)pshr32(mult16_16(srate, (i16)(masking_depth >> (DB_SHIFT - 10))), 10);
+            rate_offset = imax(rate_offset, -2 * sc.bitRate / 3);
+            if (st->bandwidth == OA_BW_SWB || st->bandwidth == OA_BW_FB) sc.bitRate += 3 * rate_offset / 5; else sc.bitRate += rate_offset;
+         }
+         LANE0 { sh->silk_bitRate = sc.bitRate; }
+         sc.payloadSize_ms = 1000 * frame_size / Fs;
+         sc.desiredInternalSampleRate = curr_bandwidth == OA_BW_NB ? 8000 : curr_bandwidth == OA_BW_MB ? 12000 : 16000;
+         sc.minInternalSampleRate = mode == OA_MODE_HYBRID ? 16000 : 8000;
+         sc.maxInternalSampleRate = 16000;
+         if (mode == OA_MODE_SILK_ONLY) {
+            i32 effective_max_rate = bits_to_bitrate(sh->f_max_data_bytes * 8, Fs, frame_size);
+            if (frame_rate > 50) effective_max_rate = effective_max_rate * 2 / 3;
+            if (effective_max_rate < 8000) { sc.maxInternalSampleRate = 12000; sc.desiredInternalSampleRate = imin(12000, sc.desiredInternalSampleRate); }
+            if (effective_max_rate < 7000) { sc.maxInternalSampleRate = 8000; sc.desiredInternalSampleRate = imin(8000, sc.desiredInternalSampleRate); }
+         }
+         sc.packetLossPercentage = L->cfg.packet_loss_perc; sc.complexity = L->cfg.complexity; sc.useInBandFEC = L->cfg.use_inband_fec != 0; sc.LBRR_coded = st->sm_LBRR_coded; sc.useDTX = st->sm_useDTX;
+         sc.useCBR = !L->cfg.use_vbr;
+         sc.maxBits = (sh->f_max_data_bytes - 1) * 8;
+         if (redundancy && redundancy_bytes >= 2) { sc.maxBits -= redundancy_bytes * 8 + 1; if (mode == OA_MODE_HYBRID) sc.maxBits -= 20; }     /* :2156 */
+         if (sc.useCBR) {
+            if (mode == OA_MODE_HYBRID) { const i16 other_bits = (i16)imax(0, sc.maxBits - sc.bitRate * frame_size / Fs); sc.maxBits = imax(0, sc.maxBits - other_bits * 3 / 4); sc.useCBR = 0; }
+         } else if (mode == OA_MODE_HYBRID) {
+            const i32 maxBitRate = sh_silk_rate_for_hybrid(sc.maxBits * Fs / frame_size, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels);
+            sc.maxBits = bitrate_to_bits(maxBitRate, Fs, frame_size);
+         }
+         sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = L->cfg.prediction_disabled;
+         sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
+      }
+      if (wv_uni(sh->f_prefill) && application != OA_APP_RESTRICTED_SILK) {
+         /* smooth onset for the SILK prefill (:2191-2209): fade the delay line in over 2.5 ms, silence before it, feed its 10 ms to SILK with nothing coded */
+         const int prefill_offset = CC * (encoder_buffer - delay_compensation - Fs / 400), n4 = Fs / 400;
+         WV_LDS i16 *stage = L->S.u.pcm_stage;
+         wv_sync();
+         FOR_LANES(i, n4 * CC) stage[i] = gs->delay_buffer[prefill_offset + i];
+         wv_sync();
+         sh_gain_fade_lds(stage, n4, CC, 0, Q15ONE, Fs);
+         wv_sync();
+         FOR_LANES(i, n4 * CC) gs->delay_buffer[prefill_offset + i] = stage[i];
+         FOR_LANES(i, prefill_offset) gs->delay_buffer[i] = 0;
+         wv_sync();
+         const int pr = silk_encode_wave(&L->S, &sc, gs->delay_buffer, encoder_buffer, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr, wv_uni(sh->f_prefill));
+         wv_sync();
+         if (pr) { LANE0 { gs->s.error = pr; } return OA_ERR_INTERNAL; }
+         sc.opusCanSwitch = 0;                                                              /* no second switch in the real call */
+      }
+      const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
+      wv_sync();
+      if (sret) { LANE0 { gs->s.error = sret; } return OA_ERR_INTERNAL; }
+      SE_PHASE(&L->S, 9);
+      silk_nBytes = wv_uni(L->S.r[0]);
+      LANE0 {
+         int curr_bandwidth = sh->curr_bandwidth;
+         if (st->mode == OA_MODE_SILK_ONLY) { if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB; }
+         sh->curr_bandwidth = curr_bandwidth;
+         st->sm_allowBandwidthSwitch = sc.allowBandwidthSwitch; st->sm_inWBmodeWithoutVariableLP = sc.inWBmodeWithoutVariableLP; st->sm_switchReady = sc.switchReady;
+         st->sm_opusCanSwitch = sc.switchReady && !st->nonfinal_frame;
+         st->sm_stereoWidth_Q14 = sc.stereoWidth_Q14;
+         sh->silk_signalType = sc.signalType; sh->silk_offset = sc.offset;
+         if (sh->activity == SE_VAD_NO_DECISION) sh->activity = sc.signalType != SE_TYPE_NO_VOICE;
+         if (silk_nBytes != 0 && st->sm_opusCanSwitch) {                                 /* SILK is ready to change its bandwidth: announce it with a redundant frame (:2251-2260) */
+            if (application != OA_APP_RESTRICTED_SILK) {
+               sh->redundancy_bytes = sh_redundancy_bytes(sh->f_max_data_bytes, sh->bitrate_bps, frame_rate, st->stream_channels);
+               sh->f_redundancy = sh->redundancy_bytes != 0;
+            }
+            sh->f_celt_to_silk = 0;
+            st->silk_bw_switch = 1;
+         }
+      }
+      if (silk_nBytes == 0) {                                                             /* SILK DTX (:2242): the TOC alone, no bookkeeping */
+         LANE0 { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, sh->curr_bandwidth, st->stream_channels); sh->r[3] = 1; }
+         wv_sync();
+         return 1;
+      }
+   } else { LANE0 sh->HB_gain = Q15ONE; }
+   wv_sync();
+   /* ---- CELT control, delay line, fades (:2264-2349) ---- */
+   const int need_celt = mode != OA_MODE_SILK_ONLY || wv_uni(sh->f_redundancy);
+   const int celt_prefill = mode != OA_MODE_SILK_ONLY && mode != wv_uni(st->prev_mode) && wv_uni(st->prev_mode) > 0;
+   if (celt_prefill) {                                                                    /* tmp_prefill: the 2.5 ms ahead of the delay-compensated input (:2298-2302) */
+      const int n4 = Fs / 400;
+      FOR_LANES(i, n4 * CC) tmp_prefill[i] = gs->delay_buffer[(encoder_buffer - total_buffer - n4) * CC + i];
+      wv_sync();
+   }
+   if (need_celt) sh_enter_celt(L, gs);
+   LANE0 {
+      if (mode != OA_MODE_SILK_ONLY) { SH_CELT_DISABLE_PF(F) = 0; SH_CELT_FORCE_INTRA(F) = 0; if (L->cfg.prediction_disabled) { SH_CELT_DISABLE_PF(F) = 1; SH_CELT_FORCE_INTRA(F) = 1; } }   /* CELT_SET_PREDICTION(2 or 0) :2288-2295 */
+      /* stereo width (:2320-2328) and fade gains */
+      if (st->mode != OA_MODE_HYBRID || st->stream_channels == 1) {
+         if (sh->equiv_rate > 32000) st->sm_stereoWidth_Q14 = 16384; else if (sh->equiv_rate < 16000) st->sm_stereoWidth_Q14 = 0;
+         else st->sm_stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - sh->equiv_rate) / (sh->equiv_rate - 14000);
+      }
+      sh->do_gain_fade = (st->prev_HB_gain < Q15ONE || sh->HB_gain < Q15ONE) && application != OA_APP_RESTRICTED_SILK;
+      sh->hb_g1 = st->prev_HB_gain; sh->hb_g2 = sh->HB_gain;
+      st->prev_HB_gain = sh->HB_gain;
+      sh->do_stereo_fade = 0;
+      if (!L->cfg.energy_mask_on && CC == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || st->sm_stereoWidth_Q14 < (1 << 14))) {
+         i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)st->sm_stereoWidth_Q14;
+         sh->do_stereo_fade = application != OA_APP_RESTRICTED_SILK; sh->fade_g1 = g1 == 16384 ? Q15ONE : shl16(g1, 1); sh->fade_g2 = g2 == 16384 ? Q15ONE : shl16(g2, 1);
+         st->hybrid_stereo_width_Q14 = st->sm_stereoWidth_Q14;
+      }
+   }
+   /* pcm_buf = [delay tail | this frame] -> the CELT staging area (only when a CELT pass will read it), then the delay line moves on (:2304-2312) */
+   if (need_celt) {
+      WV_LDS i16 *io = F->A.pcm16;
+      FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
+      wv_sync();
+   }
+   if (application != OA_APP_RESTRICTED_SILK) {
+      /* new delay line = the last encoder_buffer samples of [old line | this frame]; ascending in place through registers, one 64-lane trip at a time */
+      for (int b0 = 0; b0 < encoder_buffer * CC; b0 += WV_WIDTH) {
+         const int i = b0 + wv_lane(), j = i + frame_size * CC;
+         i16 v = 0;
+         if (i < encoder_buffer * CC) v = j < encoder_buffer * CC ? gs->delay_buffer[j] : pcm_hp[j - encoder_buffer * CC];
+         wv_sync();
+         if (i < encoder_buffer * CC) gs->delay_buffer[i] = v;
+         wv_sync();
+      }
+   }
+   if (need_celt) {
+      WV_LDS i16 *io = F->A.pcm16;
+      if (sh->do_gain_fade) { sh_gain_fade_lds(io, frame_size, CC, (i16)sh->hb_g1, (i16)sh->hb_g2, Fs); wv_sync(); }
+      if (sh->do_stereo_fade) { sh_stereo_fade_lds(io, frame_size, (i16)sh->fade_g1, (i16)sh->fade_g2, Fs); wv_sync(); }
+      /* more than one CELT pass reads pcm_buf: keep it in the HBM scratch */
+      if (wv_uni(sh->f_redundancy) || celt_prefill) { FOR_LANES(i, frame_size * CC) pcm_celt[i] = io[i]; wv_sync(); }
+   }
+   /* ---- redundancy signalling, end of the SILK layer (:2351-2414) ---- */
+   LANE0 {
+      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+      int redundancy = sh->f_redundancy, redundancy_bytes = sh->redundancy_bytes;
+      const int max_data_bytes = sh->f_max_data_bytes;
+      if (st->mode != OA_MODE_CELT_ONLY && k_ec_tell(EC_PASS) + 17 + 20 * (st->mode == OA_MODE_HYBRID) <= 8 * (max_data_bytes - 1)) {
+         if (st->mode == OA_MODE_HYBRID) k_ec_enc_bit_logp(EC_PASS, redundancy, 12);
+         if (redundancy) {
+            int max_redundancy;
+            k_ec_enc_bit_logp(EC_PASS, sh->f_celt_to_silk, 1);
+            if (st->mode == OA_MODE_HYBRID) max_redundancy = (max_data_bytes - 1) - ((k_ec_tell(EC_PASS) + 8 + 3 + 7) >> 3);
+            else max_redundancy = (max_data_bytes - 1) - ((k_ec_tell(EC_PASS) + 7) >> 3);
+            redundancy_bytes = imin(max_redundancy, redundancy_bytes);
+            redundancy_bytes = imin(257, imax(2, redundancy_bytes));
+            if (st->mode == OA_MODE_HYBRID) k_ec_enc_uint(EC_PASS, redundancy_bytes - 2, 256);
+         }
+      } else redundancy = 0;
+      if (!redundancy) { st->silk_bw_switch = 0; redundancy_bytes = 0; }
+      sh->start_band = st->mode != OA_MODE_CELT_ONLY ? 17 : 0;
+      if (st->mode == OA_MODE_SILK_ONLY) {
+         sh->ret = (k_ec_tell(EC_PASS) + 7) >> 3;
+         sh->r[7] = k_ec_tell(EC_PASS);
          st->rangeFinal = e->rng;
          k_ec_enc_done(EC_PASS);
-         L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
-         if (tell > (sh->max_data_bytes - 1) * 8) {
-            if (sh->max_data_bytes < 2) ret = OA_ERR_BUFFER_TOO_SMALL; else { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
-         } else while (ret > 2 && L->packet[ret] == 0) ret--;                         /* trailing zeros are implied in SILK-only packets (:2540) */
-         if (ret >= 0) ret += 1;
-         sh->ret = ret;
-         }
+         sh->nb_compr_bytes = sh->ret;
+      } else {
+         sh->nb_compr_bytes = (max_data_bytes - 1) - redundancy_bytes;
+         if (st->mode == OA_MODE_HYBRID) k_ec_enc_shrink(EC_PASS, (u32)sh->nb_compr_bytes);   /* (a CELT-only frame starts its coder in the prologue, shrunk there) */
+         sh->r[7] = k_ec_tell(EC_PASS);
+      }
+      ec_st(&L->ec, e);
+      sh->f_redundancy = redundancy; sh->redundancy_bytes = redundancy_bytes;
+   }
+   const int redundancy = wv_uni(sh->f_redundancy), celt_to_silk = wv_uni(sh->f_celt_to_silk), redundancy_bytes = wv_uni(sh->redundancy_bytes);
+   const int n2 = Fs / 200, n4 = Fs / 400;
+   /* ---- 5 ms redundant CELT frame ahead of the SILK / hybrid audio (CELT -> SILK, :2427-2442) ---- */
+   if (redundancy && celt_to_silk) {
+      ShCeltCtl c; c.start = 0; c.vbr = 0; c.constrained_vbr = 0; c.nbytes = redundancy_bytes; c.raw = 1; c.cont = 0; c.bitrate = -1;
+      sh_celt_run(L, gs, pcm_celt, n2, c, journal);
+      if (wv_uni(sh->celt_ret) < 0) return OA_ERR_INTERNAL;
+      wv_sync();
+      FOR_LANES(i, redundancy_bytes) L->packet[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
+      LANE0 sh->redundant_rng = F->st.rangeFinal;
+      sh_celt_reset_wave(L, gs);
+   }
+   /* ---- the CELT layer of the frame (:2447-2512) ---- */
+   if (mode != OA_MODE_SILK_ONLY) {
+      const int hyb = mode == OA_MODE_HYBRID;
+      ShCeltCtl c; c.start = hyb ? 17 : 0; c.vbr = L->cfg.use_vbr; c.constrained_vbr = hyb ? 0 : L->cfg.vbr_constraint; c.nbytes = 0; c.raw = 0; c.cont = hyb; c.bitrate = -1;
+      if (L->cfg.use_vbr) { const i32 cb = hyb ? sh->bitrate_bps - sh->silk_bitRate : sh->bitrate_bps; if (cb > 500) c.bitrate = imin(cb, 750000 * CC); }    /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
+      if (celt_prefill) {                                                                 /* mode change: restart CELT on the 2.5 ms before the frame, then no inter-frame prediction (:2478-2486) */
+         sh_celt_reset_wave(L, gs);
+         ShCeltCtl p = c; p.raw = 1; p.nbytes = 2; p.cont = 0;
+         sh_celt_run(L, gs, tmp_prefill, n4, p, journal);
+         LANE0 { SH_CELT_DISABLE_PF(F) = 1; SH_CELT_FORCE_INTRA(F) = 1; }
+      }
+      int ran = 0;
+      if (wv_uni(sh->r[7]) <= 8 * wv_uni(sh->nb_compr_bytes)) {                            /* otherwise the budget is gone already and the frame ends up a "PLC frame" (:2487) */
+         const int reload = wv_uni(sh->f_redundancy) || celt_prefill;
+         sh_celt_run(L, gs, reload ? pcm_celt : (const i16 *)0, frame_size, c, journal);
+         const int cret = wv_uni(sh->celt_ret);
+         if (cret != -1000 && cret < 0) return OA_ERR_INTERNAL;
+         if (cret >= 0) {
+            ran = 1;
+            LANE0 sh->ret = cret;
+            wv_sync();
+            FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)L->packet)[i] = ((const WV_LDS i32 *)F->packet)[i];    /* the frame's bytes return to the packet buffer */
+            wv_sync();
+            if (redundancy && celt_to_silk && hyb && wv_uni(sh->nb_compr_bytes) != cret) {      /* the redundant frame follows the bytes CELT really used (:2503-2507) */
+               const int from = wv_uni(sh->nb_compr_bytes);
+               for (int b0 = 0; b0 < redundancy_bytes; b0 += WV_WIDTH) {
+                  const int i = b0 + wv_lane(); u8 v = 0;
+                  if (i < redundancy_bytes) v = L->packet[1 + from + i];
+                  wv_sync();
+                  if (i < redundancy_bytes) L->packet[1 + cret + i] = v;
+                  wv_sync();
+               }
+               LANE0 sh->nb_compr_bytes = cret + redundancy_bytes;
+            }
          }
       }
-      if (nBytes == 0) sh->ret = ret;
-      else if (sh->ret >= 0 && sh_generalised_dtx_l0(L, frame_size, Fs)) { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels); sh->ret = 1; sh->pad_to = 0; }
+      LANE0 { if (ran) st->rangeFinal = F->st.rangeFinal; else { sh->ret = 0; sh->r[4] = sh->r[7]; st->rangeFinal = F->st.rng; } }   /* OPUS_GET_FINAL_RANGE of the CELT encoder (:2509) */
+      wv_sync();
    }
-   if (sh->ret == -1000) { SE_CLK_BEGIN(); sh_hybrid_celt_wave(L, gs, pcm_hp, frame_size, out, out_cap, len_out, rng_out); SE_CLK_END(16); return; }
-   /* ---- store packet + state (coalesced) ---- */
+   /* ---- 5 ms redundant CELT frame after the SILK / hybrid audio (SILK -> CELT, :2514-2545) ---- */
+   if (redundancy && !celt_to_silk) {
+      sh_celt_reset_wave(L, gs);
+      LANE0 { SH_CELT_DISABLE_PF(F) = 1; SH_CELT_FORCE_INTRA(F) = 1; if (st->mode == OA_MODE_HYBRID) sh->nb_compr_bytes = sh->ret; }      /* hybrid: the packet shrinks to what the coder used */
+      ShCeltCtl c; c.start = 0; c.vbr = 0; c.constrained_vbr = 0; c.nbytes = 2; c.raw = 1; c.cont = 0; c.bitrate = -1;
+      sh_celt_run(L, gs, pcm_celt + CC * (frame_size - n2 - n4), n4, c, journal);
+      c.nbytes = redundancy_bytes;
+      sh_celt_run(L, gs, pcm_celt + CC * (frame_size - n2), n2, c, journal);
+      if (wv_uni(sh->celt_ret) < 0) return OA_ERR_INTERNAL;
+      wv_sync();
+      FOR_LANES(i, redundancy_bytes) L->packet[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
+      LANE0 sh->redundant_rng = F->st.rangeFinal;
+      wv_sync();
+   }
+   if (need_celt) sh_leave_celt(L, gs);
+   /* ---- TOC, bookkeeping, DTX, busted budget (:2549-2601) ---- */
+   LANE0 {
+      const int curr_bandwidth = sh->curr_bandwidth;
+      L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
+      st->rangeFinal ^= (u32)sh->redundant_rng;
+      st->prev_mode = sh->f_to_celt ? OA_MODE_CELT_ONLY : st->mode;
+      st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
+      int ret = sh->ret;
+      if (sh_generalised_dtx_l0(L, frame_size, Fs)) { st->rangeFinal = 0; ret = 1; sh->r[3] = 1; }
+      else {
+         const int busted = (st->mode == OA_MODE_SILK_ONLY ? sh->r[7] : sh->r[4]) > (sh->f_max_data_bytes - 1) * 8;
+         if (busted) {
+            if (sh->f_max_data_bytes < 2) ret = OA_ERR_BUFFER_TOO_SMALL;
+            else { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
+         } else if (st->mode == OA_MODE_SILK_ONLY && !sh->f_redundancy) while (ret > 2 && L->packet[ret] == 0) ret--;     /* trailing zeros are implied in SILK-only packets (:2590) */
+         if (ret >= 0) ret += 1 + sh->redundancy_bytes;
+      }
+      sh->ret = ret;
+   }
+   wv_sync();
+   return wv_uni(sh->ret);
+}
+
+/* silk_InitEncoder (silk/enc_API.c:82) on the state staged in LDS: everything, both channels */
+WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
+{
+   const int CC = L->cfg.channels;
+   wv_sync();
+   WV_LDS i32 *w = (WV_LDS i32 *)&L->S.st;
+   FOR_LANES(i, SE_STATE_WORDS(CC)) w[i] = 0;
+   wv_sync();
+   LANE0 {
+      WV_LDS OaSilkEnc *E = &L->S.st;
+      se_init_channel(&E->ch[0]); if (CC == 2) se_init_channel(&E->ch[1]);
+      E->nChannelsAPI = 1; E->nChannelsInternal = 1;
+   }
+}
+
+WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   SE_PHASE_START(&L->S);
+   /* ---- load configuration, Opus-layer scalars and the SILK encoder state (coalesced) ---- */
    {
-      const int nbytes = sh->ret < 0 ? sh->ret : sh_emit_packet(L->packet, out, sh->ret, sh->pad_to, out_cap);
-      LANE0 { *len_out = nbytes; *rng_out = st->rangeFinal; }
+      const i32 *g = (const i32 *)&gs->cfg; WV_LDS i32 *d = (WV_LDS i32 *)&L->cfg;
+      FOR_LANES(i, (int)(sizeof(OaShConfig) / 4)) d[i] = g[i];
+      g = (const i32 *)&gs->s; d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) d[i] = g[i];
+      g = (const i32 *)&gs->silk; d = (WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, SE_STATE_WORDS(gs->cfg.channels)) d[i] = g[i];
+   }
+   wv_sync();
+   LANE0 sh->silk_in_lds = 1;
+   SE_PHASE(&L->S, 0);
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
+   {  /* is_digital_silence (:1060, fixed point: all samples zero); peak signal energy tracker (:1310-1320) */
+      const i32 m = sh_maxabs_wave(pcm, frame_size * CC);
+      i32 en = 0;
+      if (m != 0) en = sh_frame_energy_wave(pcm, frame_size * CC);
+      LANE0 { sh->sample_max = m; sh->is_silence = m == 0; if (m != 0) st->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), st->peak_signal_energy), en); }
+   }
+   if (CC == 2 && L->cfg.force_channels != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
+   LANE0 sh_layer_decide(L, frame_size, max_data_bytes);
+   if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
+   if (sh->plc_frame) {
+      const int n = sh_emit_packet(L->packet, out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);
+      LANE0 { *len_out = n; *rng_out = 0; gs->s.rangeFinal = 0; }
+      return;
+   }
+   if (wv_uni(sh->prefill)) sh_silk_init_wave(L);                                      /* CELT -> SILK: the SILK encoder starts over (:1576-1581) */
+   int result;
+   if (wv_uni(sh->nb_frames) == 1) {
+      LANE0 { sh->f_redundancy = sh->redundancy; sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_to_celt = sh->to_celt; sh->f_silence = sh->is_silence; st->nonfinal_frame = 0; }
+      const int ret = sh_encode_frame_native(L, gs, pcm, frame_size, wv_uni(sh->max_data_bytes), pcm_hp, pcm_celt, tmp_prefill, G, out);
+      /* apply_padding (:2646): hard CBR pads every packet, except the bare TOC of a DTX frame, to the byte budget */
+      const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
+      result = ret < 0 ? ret : sh_emit_packet(L->packet, out, ret, pad_to, out_cap);
+   } else {
+      /* ---- several coded frames, one packet (:1757-1838) ---- */
+      const int nb_frames = wv_uni(sh->nb_frames), enc_frame_size = wv_uni(sh->enc_frame_size), max_len_sum = wv_uni(sh->max_len_sum), repacketize_len = wv_uni(sh->repacketize_len);
+      const int bak_to_mono = wv_uni(st->sm_toMono), saved_force_channels = wv_uni(L->cfg.force_channels);
+      LANE0 { if (bak_to_mono) L->cfg.force_channels = 1; else st->prev_channels = st->stream_channels; L->mf.n = nb_frames; }
+      int tot_size = 0, dtx_count = 0, err = 0, staged = 0;
+      if (OA_MF_HEADROOM + imin(max_len_sum, 1276 * nb_frames) > out_cap) err = OA_ERR_BUFFER_TOO_SMALL;     /* staging + theta-RDO journal need the slot the host promised */
+      for (int i = 0; i < nb_frames && !err; i++) {
+         const i16 *fp = pcm + (size_t)i * CC * enc_frame_size;
+         const i32 fm = sh_maxabs_wave(fp, enc_frame_size * CC);
+         int curr_max = imin(bitrate_to_bits(wv_uni(sh->bitrate_bps), Fs, enc_frame_size) / 8, max_len_sum / nb_frames);
+         curr_max = imin(max_len_sum - tot_size, curr_max);
+         LANE0 {
+            st->sm_toMono = 0; st->nonfinal_frame = i < nb_frames - 1;
+            const int frame_to_celt = sh->to_celt && i == nb_frames - 1;
+            sh->f_to_celt = frame_to_celt; sh->f_redundancy = sh->redundancy && (frame_to_celt || (!sh->to_celt && i == 0));
+            sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_silence = fm == 0;
+         }
+         sh_reload_silk(L, gs);
+         const int tmp_len = sh_encode_frame_native(L, gs, fp, enc_frame_size, curr_max, pcm_hp, pcm_celt, tmp_prefill, G, out + OA_MF_HEADROOM + staged);
+         if (tmp_len < 0) { err = OA_ERR_INTERNAL; break; }
+         if (tmp_len == 1) dtx_count++;
+         wv_sync();
+         if (i > 0 && ((wv_uni(L->mf.toc) ^ L->packet[0]) & 0xFC)) { err = OA_ERR_INTERNAL; break; }   /* opus_repacketizer_cat refuses frames of another configuration */
+         LANE0 { if (i == 0) L->mf.toc = L->packet[0]; L->mf.len[i] = tmp_len - 1; }
+         FOR_LANES(k, tmp_len - 1) out[OA_MF_HEADROOM + staged + k] = L->packet[1 + k];
+         wv_sync();
+         staged += tmp_len - 1; tot_size += tmp_len;
+      }
+      LANE0 { st->sm_toMono = bak_to_mono; L->cfg.force_channels = saved_force_channels; }
+      wv_sync();
+      if (err) result = err;
+      else {
+         result = oa_multiframe_assemble_wave(&L->mf, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames);
+         if (result < 0) result = OA_ERR_INTERNAL;
+      }
+   }
+   /* ---- store lengths + state (coalesced) ---- */
+   {
+      LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
       i32 *g = (i32 *)&gs->s; const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
-      g = (i32 *)&gs->silk; d = (const WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+      if (wv_uni(sh->silk_in_lds)) {
+         g = (i32 *)&gs->silk; d = (const WV_LDS i32 *)&L->S.st;
+         FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+      }
    }
    SE_PHASE(&L->S, 10);
 }

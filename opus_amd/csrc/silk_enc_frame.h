@@ -8,7 +8,8 @@
  *   silk_encode_wave      silk_Encode             silk/enc_API.c:150
  * In-band FEC: silk_LBRR_encode_FIX (encode_frame_FIX.c:392) inside se_encode_frame_wave, the LBRR store in HBM (OaSilkLbrr), coded at the head of the
  * next packet (enc_API.c:355-406).  DTX: the no-speech counter / inDTX logic of silk_encode_do_VAD_FIX and the empty payload of enc_API.c:560.
- * Not built: prefill (only a CELT -> SILK mode switch asks for it; that switch fails loudly at the Opus layer). */
+ * Prefill (prefillFlag 1: after a CELT -> SILK switch, 2: at a SILK bandwidth switch; enc_API.c:210-240, :563-571): the encoder is reset, 10 ms of input fill its
+ * buffers at complexity 0 and nothing is coded. */
 #ifndef OPUS_AMD_SILK_ENC_FRAME_H
 #define OPUS_AMD_SILK_ENC_FRAME_H
 
@@ -535,8 +536,9 @@ struct SePcmSrc {
    WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
    WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
 };
-WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb)
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb, int prefillFlag = 0)
 {
+   prefillFlag = wv_uni(prefillFlag);
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    int nBytesOut = 0;
@@ -557,8 +559,24 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
    const int nBlocksOf10ms = (100 * nSamplesIn) / ec->API_sampleRate;
    const int tot_blocks = nBlocksOf10ms > 1 ? nBlocksOf10ms >> 1 : 1;
    int curr_block = 0;
-   if (nBlocksOf10ms * ec->API_sampleRate != 100 * nSamplesIn || nSamplesIn < 0) return -101;
-   if (1000 * (i32)nSamplesIn > ec->payloadSize_ms * ec->API_sampleRate) return -101;
+   int tmp_payloadSize_ms = 0, tmp_complexity = 0;
+   if (prefillFlag) {
+      if (nBlocksOf10ms != 1) return -101;
+      LANE0 {
+         i32 lp[5];
+         if (prefillFlag == 2) { lp[0] = c0->lp_In_LP_State[0]; lp[1] = c0->lp_In_LP_State[1]; lp[2] = c0->lp_transition_frame_no; lp[3] = c0->lp_mode; lp[4] = c0->fs_kHz; }   /* saved_fs_kHz = the rate in use */
+         for (int n = 0; n < ec->nChannelsInternal; n++) {
+            se_init_channel(&E->ch[n]);
+            if (prefillFlag == 2) { E->ch[n].lp_In_LP_State[0] = lp[0]; E->ch[n].lp_In_LP_State[1] = lp[1]; E->ch[n].lp_transition_frame_no = lp[2]; E->ch[n].lp_mode = lp[3]; E->ch[n].lp_saved_fs_kHz = lp[4]; }
+         }
+      }
+      tmp_payloadSize_ms = ec->payloadSize_ms; ec->payloadSize_ms = 10;
+      tmp_complexity = ec->complexity; ec->complexity = 0;
+      LANE0 { for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].controlled_since_last_payload = 0; E->ch[n].prefillFlag = 1; } }
+   } else {
+      if (nBlocksOf10ms * ec->API_sampleRate != 100 * nSamplesIn || nSamplesIn < 0) return -101;
+      if (1000 * (i32)nSamplesIn > ec->payloadSize_ms * ec->API_sampleRate) return -101;
+   }
    LANE0 {
       i32 mb = ec->maxBits, sr = ec->switchReady;
       for (int n = 0; n < ec->nChannelsInternal; n++) {
@@ -604,7 +622,7 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
       if (c0->inputBufIx < c0->frame_length) break;
       /* ---- enough data: encode one frame ---- */
       i32 MStargetRates_bps[2] = {0, 0}, TargetRate_bps;
-      if (c0->nFramesEncoded == 0) {                                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
+      if (c0->nFramesEncoded == 0 && !prefillFlag) {                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
          int any = 0;
          for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) any |= E->ch[n].LBRR_flags[i];
          if (any) { WV_LDS i32 *d = (WV_LDS i32 *)&S->u.lbrr; const i32 *g = (const i32 *)lb; wv_sync(); FOR_LANES(i, (int)(sizeof(OaSilkLbrr) / 4)) d[i] = g[i]; wv_sync(); }
@@ -612,7 +630,7 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
       LANE0 {
          EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
          int curr_nBitsUsedLBRR = 0;
-         if (c0->nFramesEncoded == 0) {
+         if (c0->nFramesEncoded == 0 && !prefillFlag) {
             u8 iCDF[2] = {0, 0};
             iCDF[0] = (u8)(256 - (256 >> ((c0->nFramesPerPacket + 1) * ec->nChannelsInternal)));
             k_ec_enc_icdf(EC_PASS, 0, iCDF, 8);
@@ -637,8 +655,10 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
          }
          se_hp_variable_cutoff(c0);
          i32 nBits = (ec->bitRate * ec->payloadSize_ms) / 1000;
-         if (curr_nBitsUsedLBRR < 10) E->nBitsUsedLBRR = 0; else if (E->nBitsUsedLBRR < 10) E->nBitsUsedLBRR = curr_nBitsUsedLBRR; else E->nBitsUsedLBRR = (E->nBitsUsedLBRR + curr_nBitsUsedLBRR) / 2;
-         nBits -= E->nBitsUsedLBRR;
+         if (!prefillFlag) {
+            if (curr_nBitsUsedLBRR < 10) E->nBitsUsedLBRR = 0; else if (E->nBitsUsedLBRR < 10) E->nBitsUsedLBRR = curr_nBitsUsedLBRR; else E->nBitsUsedLBRR = (E->nBitsUsedLBRR + curr_nBitsUsedLBRR) / 2;
+            nBits -= E->nBitsUsedLBRR;
+         }
          nBits = nBits / c0->nFramesPerPacket;
          i32 T = ec->payloadSize_ms == 10 ? sk_mulbb(nBits, 100) : sk_mulbb(nBits, 50);
          T -= (E->nBitsExceeded * 1000) / 500;
@@ -660,8 +680,10 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
                }
                se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
             } else c1->VAD_flags[c0->nFramesEncoded] = 0;
-            se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
-            if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
+            if (!prefillFlag) {
+               se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
+               if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
+            }
          } else {
             c0->inputBuf[0] = E->st.sMid[0]; c0->inputBuf[1] = E->st.sMid[1];
             E->st.sMid[0] = c0->inputBuf[c0->frame_length]; E->st.sMid[1] = c0->inputBuf[c0->frame_length + 1];
@@ -698,9 +720,11 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
                for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) { flags <<= 1; flags |= E->ch[n].VAD_flags[i]; }
                flags <<= 1; flags |= E->ch[n].LBRR_flag;
             }
-            EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
-            k_ec_enc_patch_initial_bits(EC_PASS, flags, (c0->nFramesPerPacket + 1) * ec->nChannelsInternal);
-            ec_st(ecl, &ec_);
+            if (!prefillFlag) {
+               EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+               k_ec_enc_patch_initial_bits(EC_PASS, flags, (c0->nFramesPerPacket + 1) * ec->nChannelsInternal);
+               ec_st(ecl, &ec_);
+            }
             int nb = nBytesOut;
             if (c0->inDTX && (ec->nChannelsInternal == 1 || c1->inDTX)) nb = 0;
             E->nBitsExceeded += nb * 8;
@@ -720,6 +744,10 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
    ec->inWBmodeWithoutVariableLP = c0->fs_kHz == 16 && c0->lp_mode == 0;
    ec->internalSampleRate = sk_mulbb(c0->fs_kHz, 1000);
    ec->stereoWidth_Q14 = ec->toMono ? 0 : E->st.smth_width_Q14;
+   if (prefillFlag) {
+      ec->payloadSize_ms = tmp_payloadSize_ms; ec->complexity = tmp_complexity;
+      LANE0 { for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].controlled_since_last_payload = 0; E->ch[n].prefillFlag = 0; } }
+   }
    ec->signalType = c0->indices.signalType;
    ec->offset = se_quantization_offsets_q10[(c0->indices.signalType >> 1) * 2 + c0->indices.quantOffsetType];
    S->r[0] = nBytesOut;

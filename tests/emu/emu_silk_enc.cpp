@@ -65,7 +65,7 @@ extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size
 {
    ShLds *L = (ShLds *)aligned_alloc(64, (sizeof(ShLds) + 63) & ~63);
    memset(L, 0xA5, sizeof(ShLds));
-   int16_t *hp = (int16_t *)malloc(sizeof(int16_t) * (size_t)frame_size * 2 + 64);
+   int16_t *hp = (int16_t *)malloc(2 * SH_PCM_BYTES(frame_size, 2) + 512);          /* high-passed frame | faded CELT input | 2.5 ms CELT prefill */
    SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
    ShJob j = {G, L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
    emu_run_wave(shjob, &j);

@@ -1,0 +1,52 @@
+"""CPU: the classic decoder API of the product's C ABI on the wave emulator at every API rate (8-48 kHz) against the compiled reference decoder:
+CELT down-sampling in the de-emphasis (celt/celt_decoder.c:318), SILK resampling to the API rate, hybrid, losses, mode switches."""
+import numpy as np, pytest
+import capi, signals
+from reflib import ref_fx
+from test_kernel_emu_silkdec import speechy
+pytestmark = pytest.mark.skipif(ref_fx() is None, reason="oracle/_ref not built")
+WHICH = "emu"
+
+def _stream(app, ch, frame, nframes, schedule=None, seed=0, **ctl):
+    """packets of the reference encoder at 48 kHz"""
+    sig = speechy(nframes, ch, seed, frame) if app != 2051 else signals.music(nframes, frame, ch, seed)
+    e = capi.Enc("ref", 48000, ch, app, **ctl)
+    pk = []
+    for i in range(nframes):
+        if schedule and i in schedule:
+            for k, v in schedule[i].items(): assert e.set(k, v) == 0
+        p, n, rng = e.encode(sig[i * frame:(i + 1) * frame], frame)
+        assert n > 0
+        pk.append(p)
+    return pk
+
+def _compare(pk, Fs, dec_ch, lose=()):
+    a = capi.Dec("ref", Fs, dec_ch); b = capi.Dec(WHICH, Fs, dec_ch)
+    for i, p in enumerate(pk):
+        nsamp = (len(p) and 1) and None
+        if i in lose:
+            n = Fs // 50
+            x = a.decode(b"", n); y = b.decode(b"", n)
+        else:
+            x = a.decode(p); y = b.decode(p)
+        assert x[0] == y[0], (Fs, i, x[0], y[0])
+        assert x[2] == y[2], (Fs, i, hex(x[2]), hex(y[2]))
+        assert np.array_equal(x[1], y[1]), (Fs, i, p[0] >> 3, np.nonzero(x[1] != y[1])[0][:6])
+
+@pytest.mark.parametrize("Fs", [8000, 12000, 16000, 24000])
+def test_celt_rates(Fs):
+    _compare(_stream(2051, 2, 960, 8, bitrate=96000), Fs, 2)
+    _compare(_stream(2051, 1, 480, 8, bitrate=48000), Fs, 1, lose=(3,))
+    _compare(_stream(2051, 2, 120, 12, bitrate=64000, seed=3), Fs, 1)
+
+@pytest.mark.parametrize("Fs", [8000, 12000, 16000, 24000])
+def test_silk_rates(Fs):
+    _compare(_stream(2048, 1, 960, 8, bitrate=20000, force_mode=1000, bandwidth=1103), Fs, 1)
+    _compare(_stream(2048, 2, 960, 8, bitrate=32000, force_mode=1000, bandwidth=1101, seed=2), Fs, 2, lose=(4,))
+    _compare(_stream(2048, 1, 1920, 5, bitrate=16000, force_mode=1000, bandwidth=1102, seed=4), Fs, 2)
+
+@pytest.mark.parametrize("Fs", [8000, 16000, 24000])
+def test_hybrid_and_switches(Fs):
+    _compare(_stream(2049, 2, 960, 8, bitrate=64000, force_mode=1001, bandwidth=1105), Fs, 2, lose=(5,))
+    sched = {3: dict(force_mode=1002), 6: dict(force_mode=1000, bandwidth=1103), 9: dict(force_mode=1001, bandwidth=1104)}
+    _compare(_stream(2049, 1, 960, 12, schedule=sched, bitrate=40000, force_mode=1001, bandwidth=1105, seed=7), Fs, 1)
