@@ -14,31 +14,30 @@
 #define K_PHASE(id)
 #endif
 
-/* Final coalesced packet store.  nbytes of L->packet, or -- hard CBR (pad_to != 0) -- the same frame re-framed as a code-3
- * packet padded with zeros to exactly pad_to bytes: opus_packet_pad (src/repacketizer.c:346, out_range_impl :112 with pad = 1)
- * for a single-frame packet: [toc|3][0x01|0x40][255 x n][rest][frame][zeros]. */
-WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to, int out_cap)
+/* Final coalesced packet store.  nbytes at pk (pk[0] = TOC), or -- hard CBR (pad_to != 0) -- the same packet re-framed as a code-3 packet padded with zeros to exactly
+ * pad_to bytes: opus_packet_pad (src/repacketizer.c:346, out_range_impl :112 with pad = 1).  The input is either a single-frame packet (code 0) or one of the
+ * payload-less 'PLC' packets of the Opus layer (code 1: two empty frames, code 3: M empty frames): [toc|3][M|0x40][255 x n][rest][frame][zeros]. */
+WV_DEV int oa_emit_packet_wave(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, int out_cap)
 {
    if (nbytes <= 0) return nbytes;
-   if (pad_to == 0 || nbytes == pad_to) {
-      if (nbytes > out_cap) return -2;
-      FOR_LANES(i, nbytes) out[i] = L->packet[i];
-      return nbytes;
-   }
+   if (pad_to == 0 || nbytes == pad_to) { if (nbytes > out_cap) return -2; FOR_LANES(i, nbytes) out[i] = pk[i]; return nbytes; }
    if (nbytes > pad_to) return -3;
    if (pad_to > out_cap) return -2;
-   const int L0 = nbytes - 1, pad_amount = pad_to - (L0 + 2);
+   const int code = pk[0] & 3;
+   const int count = code == 0 ? 1 : code == 3 ? (pk[1] & 0x3F) : 2, L0 = code == 0 ? nbytes - 1 : 0, src0 = code == 0 ? 1 : nbytes;
+   const int pad_amount = pad_to - (2 + count * L0);
    const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = 2 + (pad_amount > 0 ? nb_255s + 1 : 0);
    FOR_LANES(i, pad_to) {
       u8 v = 0;
-      if (i == 0) v = (u8)((L->packet[0] & 0xFC) | 0x3);
-      else if (i == 1) v = (u8)(1 | (pad_amount != 0 ? 0x40 : 0));
+      if (i == 0) v = (u8)((pk[0] & 0xFC) | 0x3);
+      else if (i == 1) v = (u8)(count | (pad_amount != 0 ? 0x40 : 0));
       else if (i < hdr) v = i < hdr - 1 ? 255 : (u8)(pad_amount - 255 * nb_255s - 1);
-      else if (i < hdr + L0) v = L->packet[1 + i - hdr];
+      else if (i < hdr + L0) v = pk[src0 + i - hdr];
       out[i] = v;
    }
    return pad_to;
 }
+WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to, int out_cap) { return oa_emit_packet_wave(L->packet, out, nbytes, pad_to, out_cap); }
 
 /* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
  * constants of the prologue in L->sh, the int16 input staged in L->A.pcm16 and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
@@ -383,45 +382,49 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    }
 }
 
-WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+/* celt_maxabs16 / compute_frame_energy (src/opus_encoder.c:1080) of n int16 samples in HBM: plain int32 sums, order-free */
+WV_DEV i32 oa_maxabs_wave(const i16 *pcm, int n) { i32 m = 0; FOR_LANES(i, n) m = imax(m, iabs((i32)pcm[i])); return wv_max(m); }
+WV_DEV i32 oa_frame_energy_wave(const i16 *pcm, int len, i32 sample_max)
+{
+   const int shift = imax(0, (celt_ilog2(1 + sample_max) << 1) + celt_ilog2(len) - 28);
+   i32 e = 0;
+   FOR_LANES(i, len) e += mult16_16(pcm[i], pcm[i]) >> shift;
+   e = wv_sum(e);
+   e /= len;
+   return shl32(e, shift);
+}
+
+/* One coded frame of a CELT-only application: opus_encode_frame_native (src/opus_encoder.c:1855) with mode == MODE_CELT_ONLY and no delay compensation.
+ * The packet ends up in L->packet; returns its length before CBR padding (1 = DTX / bare TOC), or a negative OPUS_* code. */
+WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int lane = wv_lane();
-   const int overlap = OA_OVERLAP;
+   const int overlap = OA_OVERLAP, CC = sh->CC;
 #ifdef OA_PHASE_TIMERS
    unsigned long long oa_phase_t0 = 0;
 #endif
-
-   /* ---- load persistent state (coalesced) ---- */
-   {
-      const i32 *g = (const i32 *)&gs->st.s;
-      WV_LDS i32 *d = (WV_LDS i32 *)st;
-      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
+   {  /* activity for the generalised DTX (:1911-1930): digital silence, else the frame's energy against the tracked peak */
+      int activity = 1;
+      if (wv_uni(sh->use_dtx)) {
+         const i32 m = oa_maxabs_wave(pcm, frame_size * CC);
+         if (m == 0) activity = 0;
+         else { const i32 noise_energy = oa_frame_energy_wave(pcm, frame_size * CC, m); activity = (i64)wv_uni(sh->peak_signal_energy) < 316 * (i64)half32(noise_energy); }
+      }
+      LANE0 { sh->activity = activity; opus_layer_frame(L, &gs->cfg, frame_size, orig_max_data_bytes); }
    }
    wv_sync();
-   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
-   wv_sync();
-   if (sh->plc_frame) {
-      const int n = emit_packet_wave(L, out, 1, sh->pad_to, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; gs->st.s.rangeFinal = 0; }
-      return;
-   }
-   const int CC = sh->CC;
-
    K_PHASE(0);
    /* ---- Opus layer: dc_reject (+ optional stereo width fade) into int16 staging ---- */
    dc_reject_lanes(L, pcm, frame_size, CC);
    wv_sync();
    if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
-   {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973) */
+   {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973), at the API rate */
       const WV_LDS i16 *p = L->A.pcm16;
-      const int Nf = frame_size;
+      const int Nf = frame_size, ov = overlap / (sh->upsample > 1 ? sh->upsample : 1);
       i32 a = 0, b = 0;
-      FOR_LANES(i, CC * (Nf - overlap)) a = imax(a, iabs((i32)p[i]));
-      FOR_LANES(i, CC * overlap) b = imax(b, iabs((i32)p[CC * (Nf - overlap) + i]));
+      FOR_LANES(i, CC * (Nf - ov)) a = imax(a, iabs((i32)p[i]));
+      FOR_LANES(i, CC * ov) b = imax(b, iabs((i32)p[CC * (Nf - ov) + i]));
       a = wv_max(a); b = wv_max(b);
       LANE0 { sh->r[0] = a; sh->r[1] = b; }
    }
@@ -430,19 +433,85 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
    wv_sync();
    if (sh->skip_celt) {
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
-      LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; }
+      LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; st->rangeFinal = 0; sh->ret = 2; }
       wv_sync();
-      const int n = emit_packet_wave(L, out, 2, sh->pad_to, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; st->rangeFinal = 0; }
-      return;
-   }
-   celt_encode_core<false>(L, &gs->st, out);
-
+   } else celt_encode_core<false>(L, &gs->st, journal);
    K_PHASE(14);
-   /* ---- store packet + state (coalesced) ---- */
+   LANE0 {   /* the generalised DTX decision (:2565-2576, decide_dtx_mode :1115): after 200 ms without activity the packet is the TOC alone, at most 400 ms in a row */
+      if (sh->use_dtx && sh->ret >= 0) {
+         int dtx = 0;
+         if (!sh->activity) {
+            sh->nb_no_activity_ms_Q1 += 2 * 1000 * frame_size / sh->Fs;
+            if (sh->nb_no_activity_ms_Q1 > 10 * 20 * 2) { if (sh->nb_no_activity_ms_Q1 <= (10 + 20) * 20 * 2) dtx = 1; else sh->nb_no_activity_ms_Q1 = 10 * 20 * 2; }
+         } else sh->nb_no_activity_ms_Q1 = 0;
+         if (dtx) { st->rangeFinal = 0; L->packet[0] = (u8)sh->toc; sh->ret = 1; sh->no_pad = 1; }
+      } else if (!sh->use_dtx) sh->nb_no_activity_ms_Q1 = 0;
+   }
+   wv_sync();
+   return wv_uni(sh->ret);
+}
+
+WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   /* ---- load persistent state (coalesced) ---- */
    {
-      const int nbytes = emit_packet_wave(L, out, sh->ret, sh->pad_to, out_cap);
-      LANE0 { *len_out = nbytes; *rng_out = st->rangeFinal; }
+      const i32 *g = (const i32 *)&gs->st.s;
+      WV_LDS i32 *d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
+   }
+   wv_sync();
+   const int CC = gs->cfg.channels;
+   LANE0 {
+      sh->Fs = gs->Fs ? gs->Fs : 48000; sh->use_dtx = gs->use_dtx; sh->nb_no_activity_ms_Q1 = gs->nb_no_activity_ms_Q1; sh->peak_signal_energy = gs->peak_signal_energy;
+      sh->prev_framesize = gs->prev_framesize; sh->lfe = gs->cfg.lfe; sh->energy_mask_on = gs->energy_mask_on;
+   }
+   if (wv_uni(sh->use_dtx)) {                                                            /* peak signal energy tracker (:1310-1320); only the DTX decision reads it */
+      const i32 m = oa_maxabs_wave(pcm, frame_size * CC);
+      if (m != 0) { const i32 en = oa_frame_energy_wave(pcm, frame_size * CC, m); LANE0 sh->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), sh->peak_signal_energy), en); }
+   }
+   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
+   wv_sync();
+   int result;
+   if (sh->plc_frame) {
+      result = sh->plc_frame == 2 ? wv_uni(sh->ret) : emit_packet_wave(L, out, sh->ret, gs->cfg.use_vbr ? 0 : sh->call_max_data_bytes, out_cap);
+      LANE0 st->rangeFinal = 0;
+   } else if (wv_uni(sh->nb_frames) == 1) {
+      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out);
+      const int pad_to = (!gs->cfg.use_vbr && ret > 0 && !wv_uni(sh->no_pad)) ? wv_uni(sh->call_max_data_bytes) : 0;      /* apply_padding (:2646) */
+      result = ret < 0 ? ret : emit_packet_wave(L, out, ret, pad_to, out_cap);
+   } else {
+      /* ---- 40-120 ms: 20 ms frames staged in the output slot, then framed as one packet (:1757-1838, opus_multiframe.h) ---- */
+      const int nb_frames = wv_uni(sh->nb_frames), efs = wv_uni(sh->enc_frame_size), max_len_sum = wv_uni(sh->max_len_sum), repacketize_len = wv_uni(sh->repacketize_len);
+      const int Fs = wv_uni(sh->Fs);
+      int tot_size = 0, dtx_count = 0, err = 0, staged = 0;
+      LANE0 L->mf.n = nb_frames;
+      if (OA_MF_HEADROOM + imin(max_len_sum, 1276 * nb_frames) > out_cap) err = -2;
+      for (int i = 0; i < nb_frames && !err; i++) {
+         int curr_max = imin(bitrate_to_bits(wv_uni(sh->call_bitrate), Fs, efs) / 8, max_len_sum / nb_frames);
+         curr_max = imin(max_len_sum - tot_size, curr_max);
+         const int tmp_len = oa_celt_frame_native(L, gs, pcm + (size_t)i * CC * efs, efs, curr_max, out + OA_MF_HEADROOM + staged);
+         if (tmp_len < 0) { err = -3; break; }
+         if (tmp_len == 1) dtx_count++;
+         wv_sync();
+         if (i > 0 && ((wv_uni(L->mf.toc) ^ L->packet[0]) & 0xFC)) { err = -3; break; }
+         LANE0 { if (i == 0) L->mf.toc = L->packet[0]; L->mf.len[i] = tmp_len - 1; }
+         FOR_LANES(k, tmp_len - 1) out[OA_MF_HEADROOM + staged + k] = L->packet[1 + k];
+         wv_sync();
+         staged += tmp_len - 1; tot_size += tmp_len;
+      }
+      if (err) result = err;
+      else { result = oa_multiframe_assemble_wave(&L->mf, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames); if (result < 0) result = -3; }
+   }
+   /* ---- store lengths + state (coalesced) ---- */
+   {
+      LANE0 {
+         *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal;
+         gs->nb_no_activity_ms_Q1 = sh->nb_no_activity_ms_Q1; gs->peak_signal_energy = sh->peak_signal_energy; if (!sh->plc_frame) gs->prev_framesize = sh->prev_framesize;
+      }
       i32 *g = (i32 *)&gs->st.s;
       const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];

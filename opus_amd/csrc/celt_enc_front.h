@@ -14,8 +14,10 @@
 
 /* lane-0 serial section, fenced on both sides: other lanes neither race ahead of its inputs nor read its
  * outputs early (on the GPU the fences are LDS waits; the CPU emulator needs them for fiber ordering) */
+#ifndef LANE0
 #define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
+#endif
 
 #define OA_AUTO (-1000)
 #define OA_BITRATE_MAX (-1)
@@ -45,41 +47,53 @@ WV_DEV u8 gen_toc_celt(int framerate, int bandwidth, int channels)
    return (u8)(0x80 | (tmp << 5) | (period << 3) | ((channels == 2) << 2));
 }
 
-/* lane 0: everything opus_encode_native / opus_encode_frame_native decide before the CELT call. */
+/* lane 0: the call-level decisions of opus_encode_native (src/opus_encoder.c:1325-1755) that are left when the application pins CELT-only
+ * (RESTRICTED_LOWDELAY / RESTRICTED_CELT): rate, 'PLC' frames, channels, bandwidth, the split of calls above 20 ms into 20 ms frames. */
 WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int frame_size, int out_data_bytes)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int Fs = 48000, voice_est = 48;
+   const int Fs = sh->Fs, voice_est = 48;
    int channels = cfg->channels;
    i32 max_data_bytes = imin(1276 * 6, out_data_bytes);
    st->rangeFinal = 0;
-   sh->plc_frame = 0; sh->ret = 0; sh->skip_celt = 0;
-   sh->CC = channels; sh->frame_size = frame_size;
+   sh->plc_frame = 0; sh->ret = 0; sh->skip_celt = 0; sh->cbr_bytes = -1; sh->nb_frames = 1; sh->enc_frame_size = frame_size;
+   sh->CC = channels; sh->upsample = 48000 / Fs; sh->raw_frame = 0;
+   sh->lsb_depth = imin(cfg->input_depth ? cfg->input_depth : 16, cfg->lsb_depth);
+   if (max_data_bytes == 1 && Fs == frame_size * 10) { sh->plc_frame = 2; sh->ret = -2; return; }           /* cannot code 100 ms in one byte: OPUS_BUFFER_TOO_SMALL (:1231) */
    i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
    i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
    int frame_rate = Fs / frame_size;
-   sh->pad_to = 0;
    if (!cfg->use_vbr) {          /* hard CBR: src/opus_encoder.c:1328-1334; the packet is padded to max_data_bytes at the end (:2646) */
       i32 cbr_bytes = imin((bitrate_to_bits(bitrate_bps, Fs, frame_size) + 4) / 8, max_data_bytes);
       bitrate_bps = bits_to_bitrate(cbr_bytes * 8, Fs, frame_size);
       max_data_bytes = imax(1, cbr_bytes);
-      sh->pad_to = max_data_bytes;
+      sh->cbr_bytes = cbr_bytes;
    }
+   sh->call_max_data_bytes = max_data_bytes;
    if (max_data_bytes < 3 || bitrate_bps < 3 * frame_rate * 8 || (frame_rate < 50 && (max_data_bytes * (i32)frame_rate < 300 || bitrate_bps < 2400))) {
-      /* st->mode is still its initial MODE_HYBRID until the first coded frame (opus_encoder_init :319), CELT-only afterwards */
-      int tocmode = st->prev_mode == 0 ? 1001 : 1002;
+      /* 'PLC' frame (:1345-1405).  st->mode is still its initial MODE_HYBRID until the first coded frame (opus_encoder_init :319), CELT-only afterwards */
+      int tocmode = st->prev_mode == 0 ? 1001 : 1002, packet_code = 0, num_multiframes = 0;
       int bw = st->bandwidth == 0 ? OA_BW_NB : st->bandwidth;
       if (frame_rate > 100) tocmode = 1002;
-      if (tocmode == 1002 && bw == OA_BW_MB) bw = OA_BW_NB;
-      else if (tocmode == 1001 && bw <= OA_BW_SWB) bw = OA_BW_SWB;
-      if (tocmode == 1002) L->packet[0] = gen_toc_celt(frame_rate, bw, st->stream_channels);
-      else {
-         int period = 0, fr = frame_rate;
-         while (fr < 400) { fr <<= 1; period++; }
-         L->packet[0] = (u8)(0x60 | ((bw - OA_BW_SWB) << 4) | ((period - 2) << 3) | ((st->stream_channels == 2) << 2));
+      if (frame_rate == 25) { frame_rate = 50; packet_code = 1; }
+      if (frame_rate <= 16) {
+         if (out_data_bytes == 1) { tocmode = 1000; packet_code = frame_rate <= 12; frame_rate = frame_rate == 12 ? 25 : 16; }
+         else { num_multiframes = 50 / frame_rate; frame_rate = 50; packet_code = 3; }
       }
-      sh->plc_frame = 1; sh->ret = 1;
+      if (tocmode == 1000 && bw > OA_BW_WB) bw = OA_BW_WB;
+      else if (tocmode == 1002 && bw == OA_BW_MB) bw = OA_BW_NB;
+      else if (tocmode == 1001 && bw <= OA_BW_SWB) bw = OA_BW_SWB;
+      int period = 0, fr = frame_rate;
+      while (fr < 400) { fr <<= 1; period++; }
+      u8 toc;
+      if (tocmode == 1002) toc = gen_toc_celt(frame_rate, bw, st->stream_channels);
+      else if (tocmode == 1000) toc = (u8)(((bw - OA_BW_NB) << 5) | ((period - 2) << 3) | ((st->stream_channels == 2) << 2));
+      else toc = (u8)(0x60 | ((bw - OA_BW_SWB) << 4) | ((period - 2) << 3) | ((st->stream_channels == 2) << 2));
+      L->packet[0] = (u8)(toc | packet_code);
+      if (packet_code == 3) L->packet[1] = (u8)num_multiframes;
+      sh->plc_frame = 1; sh->ret = packet_code <= 1 ? 1 : 2;
+      sh->call_max_data_bytes = imax(max_data_bytes, sh->ret);
       return;
    }
    i32 equiv_rate = compute_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity);
@@ -106,19 +120,41 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    }
    if (st->bandwidth > cfg->max_bandwidth) st->bandwidth = cfg->max_bandwidth;
    if (cfg->user_bandwidth != OA_AUTO) st->bandwidth = cfg->user_bandwidth;
+   if (Fs <= 24000 && st->bandwidth > OA_BW_SWB) st->bandwidth = OA_BW_SWB;                          /* nothing above the input's Nyquist rate (:1641-1650) */
+   if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
+   if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
+   if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
    if (st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
-   int curr_bandwidth = st->bandwidth;
-   sh->curr_bandwidth = curr_bandwidth;
-   sh->lsb_depth = imin(16, cfg->lsb_depth);
-   sh->orig_max_data_bytes = max_data_bytes;
-   sh->max_data_bytes = imin(max_data_bytes, 1276);
+   if (cfg->lfe) st->bandwidth = OA_BW_NB;
+   sh->curr_bandwidth = st->bandwidth;
+   sh->call_bitrate = bitrate_bps; sh->call_equiv_rate = equiv_rate;
+   if (frame_size > Fs / 50) {                                                                        /* 40-120 ms: 20 ms frames, one packet (:1698-1755) */
+      const int nb_frames = frame_size / (Fs / 50), max_header_bytes = nb_frames == 2 ? 3 : 2 + (nb_frames - 1) * 2;
+      sh->repacketize_len = (cfg->use_vbr || cfg->user_bitrate_bps == OA_BITRATE_MAX) ? out_data_bytes : imin(sh->cbr_bytes, out_data_bytes);
+      sh->max_len_sum = nb_frames + sh->repacketize_len - max_header_bytes;
+      sh->nb_frames = nb_frames; sh->enc_frame_size = Fs / 50;
+   }
+}
+/* lane 0: opus_encode_frame_native's set-up for one coded frame of a CELT-only application (:1893-1909, :2264-2295, :2320-2349, :2447-2464) */
+WV_DEVN void opus_layer_frame(WV_LDS FrameLds *L, const OaEncConfig *cfg, int frame_size, int orig_max_data_bytes)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   const int channels = cfg->channels, curr_bandwidth = sh->curr_bandwidth, frame_rate = sh->Fs / frame_size;
+   const i32 bitrate_bps = sh->call_bitrate, equiv_rate = sh->call_equiv_rate;
+   st->rangeFinal = 0;
+   sh->frame_size = frame_size; sh->skip_celt = 0; sh->ret = 0; sh->no_pad = 0;
+   sh->orig_max_data_bytes = orig_max_data_bytes;
+   sh->max_data_bytes = imin(orig_max_data_bytes, 1276);
+   sh->pad_to = 0;
    int endband = 21;
    if (curr_bandwidth == OA_BW_NB) endband = 13;
    else if (curr_bandwidth == OA_BW_MB || curr_bandwidth == OA_BW_WB) endband = 17;
    else if (curr_bandwidth == OA_BW_SWB) endband = 19;
    sh->start = 0; sh->end = endband; sh->effEnd = endband;
    sh->C = st->stream_channels;
-   sh->complexity = cfg->complexity; sh->disable_inv = cfg->disable_inv; sh->disable_pf = 0; sh->force_intra = 0; sh->loss_rate = cfg->packet_loss_perc;
+   sh->complexity = cfg->complexity; sh->disable_inv = cfg->disable_inv; sh->loss_rate = cfg->packet_loss_perc;
+   sh->disable_pf = cfg->prediction_disabled; sh->force_intra = cfg->prediction_disabled;            /* CELT_SET_PREDICTION(reducedDependency ? 0 : 2), :2288-2295 */
    sh->vbr = cfg->use_vbr; sh->constrained_vbr = cfg->vbr_constraint;
    sh->bitrate = -1;
    if (cfg->use_vbr && bitrate_bps > 500) sh->bitrate = imin(bitrate_bps, 750000 * channels);
@@ -127,7 +163,7 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    else if (equiv_rate < 16000) stereoWidth_Q14 = 0;
    else stereoWidth_Q14 = 16384 - 2048 * (i32)(32000 - equiv_rate) / (equiv_rate - 14000);
    sh->do_stereo_fade = 0;
-   if (channels == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || stereoWidth_Q14 < (1 << 14))) {
+   if (!sh->energy_mask_on && channels == 2 && (st->hybrid_stereo_width_Q14 < (1 << 14) || stereoWidth_Q14 < (1 << 14))) {
       i16 g1 = (i16)st->hybrid_stereo_width_Q14, g2 = (i16)stereoWidth_Q14;
       g1 = g1 == 16384 ? Q15ONE : shl16(g1, 1);
       g2 = g2 == 16384 ? Q15ONE : shl16(g2, 1);
@@ -137,6 +173,7 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    sh->toc = gen_toc_celt(frame_rate, curr_bandwidth, st->stream_channels);
    st->prev_mode = 1002;
    st->first = 0;
+   sh->prev_framesize = frame_size;
 }
 
 /* dc_reject (opus_encoder.c:479): the raw int16 PCM is staged into LDS with coalesced loads, then lanes 0..CC-1 each run one
@@ -149,9 +186,10 @@ WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int cha
    wv_sync();
    int c = wv_lane();
    if (c < channels) {
-      const int shift = celt_ilog2(48000 / (3 * 4));
+      const int shift = celt_ilog2(L->sh.Fs / (3 * 4));
       i32 mem = L->st.hp_mem[2 * c];
-      for (int i0 = 0; i0 < len; i0 += 8) {           /* len is a multiple of 120 */
+      int i0 = 0;
+      for (; i0 + 8 <= len; i0 += 8) {
          i32 x[8];
 #pragma unroll
          for (int k = 0; k < 8; k++) x[k] = shl32(saturate((i32)io[channels * (i0 + k) + c], (1 << 16) - 1), 14);
@@ -164,17 +202,24 @@ WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int cha
 #pragma unroll
          for (int k = 0; k < 8; k++) io[channels * (i0 + k) + c] = (i16)x[k];
       }
+      for (; i0 < len; i0++) {                         /* (2.5 ms at 8 / 12 / 24 kHz is not a multiple of 8 samples) */
+         const i32 x = shl32(saturate((i32)io[channels * i0 + c], (1 << 16) - 1), 14), y = x - mem;
+         mem = mem + pshr32(y, shift);
+         io[channels * i0 + c] = (i16)saturate(pshr32(y, 14), 32767);
+      }
       L->st.hp_mem[2 * c] = mem;
    }
 }
+/* stereo_fade (:548): the cross-fade covers overlap = 120 * Fs / 48000 samples, the window is read with stride 48000 / Fs */
 WV_DEV void stereo_fade_lanes(WV_LDS FrameLds *L, int frame_size)
 {
    WV_LDS i16 *io = L->A.pcm16;
+   const int inc = L->sh.upsample > 1 ? L->sh.upsample : 1, overlap = OA_OVERLAP / inc;
    i16 g1 = (i16)(Q15ONE - L->sh.fade_g1), g2 = (i16)(Q15ONE - L->sh.fade_g2);
    FOR_LANES(i, frame_size) {
       i16 g = g2;
-      if (i < OA_OVERLAP) {
-         i16 w = ct_window[i];
+      if (i < overlap) {
+         i16 w = ct_window[i * inc];
          w = (i16)mult16_16_q15(w, w);
          g = (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15);
       }

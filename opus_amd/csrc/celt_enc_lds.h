@@ -13,6 +13,7 @@
 #define OPUS_AMD_CELT_ENC_LDS_H
 
 #define NBE OA_NB_EBANDS
+#include "opus_multiframe.h"
 #ifndef K_TIC            /* shader-clock section timers exist only in the -DOA_PHASE_TIMERS profiling build */
 #define K_TIC()
 #define K_TOC(bucket)
@@ -32,6 +33,9 @@ struct FrameShared {
    i32 silk_signalType, silk_offset;   /* hybrid: SILKInfo of the frame (celt/celt.h SILKInfo, src/opus_encoder.c:2486) */
    i32 upsample;                       /* 48000 / API rate: the input is zero-stuffed up to 48 kHz (celt_encoder.c:255, :557, :544); 0 = 1 */
    i32 raw_frame;                      /* plain celt_encode_with_ec (redundancy / prefill frames): no TOC, no Opus-layer finalisation */
+   /* the call (opus_encode_native) of the CELT-only applications */
+   i32 Fs, call_bitrate, call_max_data_bytes, call_equiv_rate, cbr_bytes, nb_frames, enc_frame_size, repacketize_len, max_len_sum, is_silence, activity, no_pad;
+   i32 use_dtx, nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize, lfe, energy_mask_on;        /* the tail of the stream record, staged */
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 
@@ -42,6 +46,7 @@ struct PvqScratch {                  /* band scratch during the PVQ phase */
 
 struct FrameLds {
    EcCtx ec;
+   MfLds mf;                          /* multi-frame packet assembly (opus_multiframe.h) */
    EcCtx ecsave[2];
    FrameShared sh;
    OaEncScalars st;

@@ -210,6 +210,7 @@ int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    }
    OaStream tmp = b->h_streams[stream];
    HIPCHECK(hipMemcpy(&tmp.st.s, &b->d_streams[stream].st.s, sizeof(OaEncScalars), hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(&tmp.nb_no_activity_ms_Q1, &b->d_streams[stream].nb_no_activity_ms_Q1, 3 * sizeof(opus_int32), hipMemcpyDeviceToHost));   /* DTX counter, peak energy, prev_framesize */
    return oa_ctl_get(&tmp, request, value);
 }
 int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *blob)

@@ -309,30 +309,7 @@ WV_DEV void sh_highpass_chunk(WV_LDS ShLds *L, WV_LDS i16 *io, int len, int chan
    }
 }
 
-/* packet bytes (nbytes at pk, pk[0] = TOC) -> out, or the same frame re-framed as a code-3 packet padded to pad_to bytes (opus_packet_pad, src/repacketizer.c:346) */
-WV_DEV int sh_emit_packet(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad_to, int out_cap)
-{
-   if (nbytes <= 0) return nbytes;
-   if (pad_to == 0 || nbytes == pad_to) { if (nbytes > out_cap) return OA_ERR_BUFFER_TOO_SMALL; FOR_LANES(i, nbytes) out[i] = pk[i]; return nbytes; }
-   if (nbytes > pad_to) return OA_ERR_INTERNAL;
-   if (pad_to > out_cap) return OA_ERR_BUFFER_TOO_SMALL;
-   /* the frame(s) of the packet as it stands: code 0 (everything after the TOC) -- or the code-1/3 'PLC' packets of sh_layer_decide, which carry no payload */
-   const int code = pk[0] & 3;
-   const int count = code == 0 ? 1 : code == 3 ? (pk[1] & 0x3F) : 2, L0 = code == 0 ? nbytes - 1 : 0, src0 = code == 0 ? 1 : nbytes;
-   int hdr0 = 2, vbr = 0;
-   (void)vbr;
-   const int pad_amount = pad_to - (hdr0 + count * L0);
-   const int nb_255s = pad_amount > 0 ? (pad_amount - 1) / 255 : 0, hdr = hdr0 + (pad_amount > 0 ? nb_255s + 1 : 0);
-   FOR_LANES(i, pad_to) {
-      u8 v = 0;
-      if (i == 0) v = (u8)((pk[0] & 0xFC) | 0x3);
-      else if (i == 1) v = (u8)(count | (pad_amount != 0 ? 0x40 : 0));
-      else if (i < hdr) v = i < hdr - 1 ? 255 : (u8)(pad_amount - 255 * nb_255s - 1);
-      else if (i < hdr + L0) v = pk[src0 + i - hdr];
-      out[i] = v;
-   }
-   return pad_to;
-}
+#define sh_emit_packet oa_emit_packet_wave            /* celt_enc_frame.h: plain store, or the code-3 re-framing of hard CBR */
 
 /* compute_silk_rate_for_hybrid (src/opus_encoder.c:656) */
 WV_DEV i32 sh_silk_rate_for_hybrid(i32 rate, int bandwidth, int frame20ms, int vbr, int fec, int channels)
@@ -576,7 +553,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
          i32 HB_gain = Q15ONE;
          if (mode == OA_MODE_HYBRID) {                                                  /* :2052-2062 */
             sc.bitRate = sh_silk_rate_for_hybrid(total_bitRate, curr_bandwidth, Fs == 50 * frame_size, L->cfg.use_vbr, st->sm_LBRR_coded, st->stream_channels);
-            if (!L->cfg.energy_mask_on) HB_gain = Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1);   /* celt_exp2 takes an opus_val16: the rate difference is truncated as in the reference */
+            if (!L->cfg.energy_mask_on) HB_gain = (i16)(Q15ONE - (fx_exp2((i16)(-(total_bitRate - sc.bitRate))) >> 1));   /* celt_exp2 takes an opus_val16 and HB_gain is one: both truncations as in the reference */
          }
          LANE0 { sh->HB_gain = HB_gain; }
          if (L->cfg.energy_mask_on && L->cfg.use_vbr && !L->cfg.lfe) {                 /* surround masking for SILK (:2069-2108) */

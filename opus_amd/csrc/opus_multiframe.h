@@ -6,6 +6,10 @@
 #ifndef OPUS_AMD_MULTIFRAME_H
 #define OPUS_AMD_MULTIFRAME_H
 
+#ifndef LANE0
+#define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
+#define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
+#endif
 #define OA_MF_MAX_FRAMES 6
 #define OA_MF_HEADROOM 48            /* >= the largest header: 2 + 31 padding length bytes for 7.6 KB + 2 x 5 frame lengths */
 

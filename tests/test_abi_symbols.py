@@ -48,11 +48,10 @@ def test_create_argument_errors(lib):
     err = ctypes.c_int(7)
     lib.opus_encoder_create.restype = ctypes.c_void_p
     lib.opus_encoder_destroy.argtypes = [ctypes.c_void_p]
-    for Fs, ch, app, want in [(44100, 2, 2051, -1), (48000, 3, 2051, -1), (48000, 2, 1234, -1), (44100, 1, 2048, -1),
-                              (16000, 1, 2051, -5)]:                            # unsupported but valid (CELT-only below 48 kHz) -> OPUS_UNIMPLEMENTED
+    for Fs, ch, app, want in [(44100, 2, 2051, -1), (48000, 3, 2051, -1), (48000, 2, 1234, -1), (44100, 1, 2048, -1)]:
         p = lib.opus_encoder_create(Fs, ch, app, ctypes.byref(err))
         assert p is None and err.value == want, (Fs, ch, app, err.value)
-    for Fs, ch, app in [(48000, 2, 2049), (16000, 1, 2048), (8000, 1, 2052)]:  # the SILK-capable encoder: AUDIO / VOIP / RESTRICTED_SILK at any API rate
+    for Fs, ch, app in [(48000, 2, 2049), (16000, 1, 2048), (8000, 1, 2052), (16000, 1, 2051), (24000, 2, 2053)]:  # the SILK-capable encoder: AUDIO / VOIP / RESTRICTED_SILK at any API rate
         p = lib.opus_encoder_create(Fs, ch, app, ctypes.byref(err))
         assert p and err.value == 0
         v = ctypes.c_int32(0)
