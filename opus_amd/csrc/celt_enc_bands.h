@@ -150,7 +150,7 @@ WV_DEV i32 median_of_3(const WV_LDS i32 *x)
    return t0;
 }
 
-/* lane 0: dynalloc_analysis (celt_encoder.c:1049); surround masking is out of scope (energy_mask == NULL) */
+/* lane 0: dynalloc_analysis (celt_encoder.c:1049) */
 WV_DEVN void dynalloc_analysis_l0(WV_LDS FrameLds *L)
 {
    WV_LDS FrameShared *sh = &L->sh;
@@ -177,7 +177,7 @@ WV_DEVN void dynalloc_analysis_l0(WV_LDS FrameLds *L)
          spread_weight[i] = 32 >> shift;
       }
    }
-   if (effectiveBytes >= (30 + 5 * LM)) {
+   if (effectiveBytes >= (30 + 5 * LM) && !sh->lfe) {
       int last = 0;
       for (int c = 0; c < C; c++) {
          i32 offset, tmp;
@@ -206,7 +206,7 @@ WV_DEVN void dynalloc_analysis_l0(WV_LDS FrameLds *L)
             follower[i] = half32(imax(0, bandLogE[i] - follower[i]) + imax(0, bandLogE[NBE + i] - follower[NBE + i]));
          }
       } else for (int i = start; i < end; i++) follower[i] = imax(0, bandLogE[i] - follower[i]);
-      for (int i = start; i < end; i++) follower[i] = imax(follower[i], 0);   /* surround_dynalloc == 0 */
+      for (int i = start; i < end; i++) follower[i] = imax(follower[i], L->surround_dynalloc[i]);
       for (int i = start; i < end; i++) importance[i] = pshr32(13 * fx_exp2_db(imin(follower[i], GC(4.f))), 16);
       if ((!vbr || constrained_vbr) && !isTransient) for (int i = start; i < end; i++) follower[i] = half32(follower[i]);
       for (int i = start; i < end; i++) {
@@ -474,6 +474,7 @@ WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
          for (int i = 0; i < end - 1; i++) diff += (bandLogE[i + c * NBE] >> 5) * (i32)(2 + 2 * i - end);
       diff /= C * (end - 1);
       trim = (i16)(trim - imax(-QC16(2.f, 8), imin(QC16(2.f, 8), ((diff + QC32(1.f, DB_SHIFT - 5)) >> (DB_SHIFT - 13)) / 6)));
+      trim = (i16)(trim - (sh->surround_trim >> (DB_SHIFT - 8)));
       trim = (i16)(trim - 2 * ((i16)sh->tf_estimate >> (14 - 8)));
       int trim_index = pshr32(trim, 8);
       sh->alloc_trim = imax(0, imin(10, trim_index));
@@ -481,7 +482,7 @@ WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
    wv_sync();
 }
 
-/* lane 0: compute_vbr (celt_encoder.c:1605), no surround mask */
+/* lane 0: compute_vbr (celt_encoder.c:1605) */
 WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target)
 {
    WV_LDS FrameShared *sh = &L->sh;
@@ -505,14 +506,19 @@ WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target)
    target += sh->tot_boost - (19 << LM);
    i16 tf_calibration = QC16(0.044f, 14);
    target += (i32)shl32(mult16_32_q15(tf_estimate - tf_calibration, target), 1);
+   const int has_surround_mask = sh->energy_mask_on, lfe = sh->lfe;
+   if (has_surround_mask && !lfe) {
+      const i32 surround_target = target + (i32)(mult16_16((i16)(sh->surround_masking >> (DB_SHIFT - 10)), coded_bins << BITRES) >> 10);
+      target = imax(target / 4, surround_target);
+   }
    {
       int bins = ct_eBands[NBE - 2] << LM;
       i32 floor_depth = (i32)(mult16_32_q15((C * bins << BITRES), maxDepth) >> (DB_SHIFT - 15));
       floor_depth = imax(floor_depth, target >> 2);
       target = imin(target, floor_depth);
    }
-   if (constrained_vbr) target = base_target + (i32)mult16_32_q15(QC16(0.67f, 15), target - base_target);
-   if (tf_estimate < QC16(.2f, 14)) {
+   if ((!has_surround_mask || lfe) && constrained_vbr) target = base_target + (i32)mult16_32_q15(QC16(0.67f, 15), target - base_target);
+   if (!has_surround_mask && tf_estimate < QC16(.2f, 14)) {
       i16 amount = (i16)mult16_16_q15(QC16(.0000031f, 30), imax(0, imin(32000, 96000 - bitrate)));
       i16 tvbr_factor = (i16)(mult16_16(temporal_vbr >> (DB_SHIFT - 10), amount) >> 10);
       target += (i32)mult16_32_q15(tvbr_factor, target);

@@ -42,7 +42,7 @@ WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to,
 /* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
  * constants of the prologue in L->sh, the int16 input staged in L->A.pcm16 and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
  * HYB = the hybrid branches of the reference (start band 17: no pitch pre-filter, no tf_analysis, weak transients, its own VBR target, :2030-2470). */
-template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal)
+template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -70,7 +70,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
    wv_sync();
    K_PHASE(3);
-   if (sh->complexity >= 1) transient_analysis_wave(L, ps0, ps1, HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2);
+   if (sh->complexity >= 1 && !sh->lfe) transient_analysis_wave(L, ps0, ps1, HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2);
    wv_sync();
    K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
    LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
@@ -79,7 +79,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_PHASE(4);
    /* ---- pitch pre-filter ---- */
    {
-      int enabled = (sh->nbAvailableBytes > 12 * C) && !HYB && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
+      int enabled = ((sh->lfe && sh->nbAvailableBytes > 3) || sh->nbAvailableBytes > 12 * C) && !HYB && !sh->silence && sh->tell + 16 <= sh->total_bits && !sh->disable_pf;
       run_prefilter_wave(L, gst, ps0, ps1, enabled);
       LANE0 {
          EC_BEGIN;
@@ -120,13 +120,59 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    band_energies_wave(L, L->bandLogE);
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
+   if (sh->lfe) {                    /* LFE: nothing but the first two bands carries energy (celt_encoder.c:2099-2107) */
+      LANE0 {
+         for (int c = 0; c < C; c++) for (int i = 2; i < end; i++) {
+            i32 E = imin(L->bandE[i + c * NBE], mult16_32_q15(QC16(1e-4f, 15), L->bandE[c * NBE])); E = imax(E, EPSILON);
+            L->bandE[i + c * NBE] = E;
+            if (i < sh->effEnd) L->bandLogE[i + c * NBE] = fx_log2_db(E) - shl32((i32)ct_eMeans[i], DB_SHIFT - 4) + GC(2.f);
+         }
+      }
+   }
+   LANE0 {                             /* how much masking takes place between surround channels (celt_encoder.c:2109-2186) */
+      for (int i = 0; i < NBE; i++) L->surround_dynalloc[i] = 0;
+      sh->surround_masking = 0; sh->surround_trim = 0;
+      if (!HYB && sh->energy_mask_on && energy_mask && !sh->lfe) {
+         i32 mask_avg = 0, diff = 0; int count = 0, midband, count_dynalloc = 0;
+         const int mask_end = imax(2, st->lastCodedBands);
+         for (int c = 0; c < C; c++) for (int i = 0; i < mask_end; i++) {
+            i32 mask = imax(imin(energy_mask[NBE * c + i], GC(.25f)), -GC(2.0f));
+            if (mask > 0) mask = half32(mask);
+            const i16 mask16 = (i16)(mask >> (DB_SHIFT - 10));
+            mask_avg += mult16_16(mask16, ct_eBands[i + 1] - ct_eBands[i]);
+            count += ct_eBands[i + 1] - ct_eBands[i];
+            diff += mult16_16(mask16, 1 + 2 * i - mask_end);
+         }
+         mask_avg = shl32(mask_avg / (i16)count, DB_SHIFT - 10);
+         mask_avg += GC(.2f);
+         diff = shl32(diff * 6 / (C * (mask_end - 1) * (mask_end + 1) * mask_end), DB_SHIFT - 10);
+         diff = half32(diff);
+         diff = imax(imin(diff, GC(.031f)), -GC(.031f));
+         for (midband = 0; ct_eBands[midband + 1] < ct_eBands[mask_end] / 2; midband++);
+         for (int i = 0; i < mask_end; i++) {
+            const i32 lin = mask_avg + diff * (i - midband);
+            i32 unmask = C == 2 ? imax(energy_mask[i], energy_mask[NBE + i]) : energy_mask[i];
+            unmask = imin(unmask, GC(.0f));
+            unmask -= lin;
+            if (unmask > GC(.25f)) { L->surround_dynalloc[i] = unmask - GC(.25f); count_dynalloc++; }
+         }
+         if (count_dynalloc >= 3) {
+            mask_avg += GC(.25f);
+            if (mask_avg > 0) { mask_avg = 0; diff = 0; for (int i = 0; i < mask_end; i++) L->surround_dynalloc[i] = 0; }
+            else for (int i = 0; i < mask_end; i++) L->surround_dynalloc[i] = imax(0, L->surround_dynalloc[i] - GC(.25f));
+         }
+         mask_avg += GC(.2f);
+         sh->surround_trim = 64 * diff;
+         sh->surround_masking = mask_avg;
+      }
+   }
    K_PHASE(6);
    LANE0 {
       EC_BEGIN;
-      temporal_vbr_l0(L);
+      if (!sh->lfe) temporal_vbr_l0(L); else sh->temporal_vbr = 0;
       if (!sh->secondMdct) for (int i = 0; i < C * NBE; i++) L->bandLogE2[i] = L->bandLogE[i];
       sh->do_patch = 0;
-      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5 && !HYB)
+      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5 && !sh->lfe && !HYB)
          sh->do_patch = patch_transient_decision_l0(L);
       EC_END;
    }
@@ -148,7 +194,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_PHASE(7);
    /* ---- allocation analyses ---- */
    LANE0 {
-      sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && !HYB && sh->complexity >= 2 && sh->toneishness < QC32(.98f, 29);
+      sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && !HYB && sh->complexity >= 2 && !sh->lfe && sh->toneishness < QC32(.98f, 29);
       dynalloc_analysis_l0(L);
    }
    wv_sync();
@@ -183,7 +229,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    LANE0 {
       EC_BEGIN;
       k_quant_coarse_energy(L->scr, L->BC.coarse_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
-            C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, 0);
+            C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, sh->lfe);
       tf_encode_l0(L, EC_PASS);
       sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
       EC_END;
@@ -192,7 +238,8 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", L->ec.rng); K_DUMPI("tell_tf", ec_tell_frac_lds(&L->ec));
    K_PHASE(10);
    if (sh->r[2]) {
-      if (HYB) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : sh->isTransient ? 2 : 3; wv_sync(); }                                      /* :2309 SPREAD_NONE / NORMAL / AGGRESSIVE */
+      if (sh->lfe) { LANE0 { st->tapset_decision = 0; st->spread_decision = 2; } wv_sync(); }                                                  /* :2305 */
+      else if (HYB) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : sh->isTransient ? 2 : 3; wv_sync(); }                                      /* :2309 SPREAD_NONE / NORMAL / AGGRESSIVE */
       else if (sh->shortBlocks || sh->complexity < 3 || sh->nbAvailableBytes < 10 * C) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : 2; wv_sync(); }
       else spreading_decision_wave(L, sh->pf_on && !sh->shortBlocks);
       LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, st->spread_decision, k_spread_icdf, 5); EC_END; }
@@ -201,6 +248,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_DUMPI("spread", st->spread_decision); K_DUMPI("tapset", st->tapset_decision);
    LANE0 {
       EC_BEGIN;
+      if (sh->lfe) L->offsets[0] = imin(8, sh->effectiveBytes / 3);                      /* for LFE everything interesting is in the first band (:2352) */
       k_init_caps(L->cap, LM, C);
       int dynalloc_logp = 6;
       i32 total_bits = sh->total_bits << BITRES, total_boost = 0, tell = k_ec_tell_frac(EC_PASS);
@@ -242,7 +290,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       wv_sync();
    }
    if (sh->r[4]) {
-      if (HYB) { LANE0 { st->stereo_saving = 0; sh->alloc_trim = 5; } }                        /* start > 0 (celt_encoder.c:2401) */
+      if (HYB || sh->lfe) { LANE0 { st->stereo_saving = 0; sh->alloc_trim = 5; } }             /* start > 0 || lfe (celt_encoder.c:2412) */
       else alloc_trim_analysis_wave(L);
       LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7); EC_END; }
       wv_sync();
@@ -303,6 +351,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       bits -= anti_collapse_rsv;
       sh->anti_collapse_rsv = anti_collapse_rsv;
       int signalBandwidth = end - 1;
+      if (sh->lfe) signalBandwidth = 1;
 #ifdef K_DUMP_ENABLED
       {  /* tap_alloc */
          i32 w[12 + 42]; int n = 0;
@@ -435,7 +484,7 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
       LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; st->rangeFinal = 0; sh->ret = 2; }
       wv_sync();
-   } else celt_encode_core<false>(L, &gs->st, journal);
+   } else celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask);
    K_PHASE(14);
    LANE0 {   /* the generalised DTX decision (:2565-2576, decide_dtx_mode :1115): after 200 ms without activity the packet is the TOC alone, at most 400 ms in a row */
       if (sh->use_dtx && sh->ret >= 0) {

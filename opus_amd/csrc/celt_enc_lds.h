@@ -36,6 +36,7 @@ struct FrameShared {
    /* the call (opus_encode_native) of the CELT-only applications */
    i32 Fs, call_bitrate, call_max_data_bytes, call_equiv_rate, cbr_bytes, nb_frames, enc_frame_size, repacketize_len, max_len_sum, is_silence, activity, no_pad;
    i32 use_dtx, nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize, lfe, energy_mask_on;        /* the tail of the stream record, staged */
+   i32 surround_masking, surround_trim;   /* what the surround masks of the multistream layer contribute to the VBR target / the allocation trim (celt_encoder.c:2112-2186) */
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 
@@ -53,6 +54,7 @@ struct FrameLds {
    i32 bandE[2 * NBE], bandLogE[2 * NBE], bandLogE2[2 * NBE], error[2 * NBE];
    i32 oldBandE[2 * NBE], energyError[2 * NBE];
    i32 offsets[NBE], importance[NBE], spread_weight[NBE], tf_res[NBE], pulses[NBE], fine_quant[NBE], fine_priority[NBE], cap[NBE];
+   i32 surround_dynalloc[NBE];
    i32 scr[6 * NBE];                  /* lane-0 scratch (allocation vectors, dynalloc followers, two-pass energies) */
    i32 aux[32];                       /* MDCT headroom/shift bookkeeping, reductions hand-off */
 #ifdef OA_PHASE_TIMERS

@@ -22,6 +22,7 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #define SE_CLK_END(id) do { if (threadIdx.x == 0) atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)((u32)clock64() - clk0_)); } while (0)
 #endif
 #include "silk_enc_all.h"
+#include "opus_surround.h"
 #include "../../include/opus_amd.h"
 #include <stdarg.h>
 #include <math.h>
@@ -66,6 +67,14 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max
    char *scr = (char *)pcm_hp + (size_t)s * SH_SCRATCH_BYTES(frame_size, ch);
    oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
          (SeRateScratch *)(scr + SH_SCRATCH_BYTES(frame_size, ch) - sizeof(SeRateScratch)), lens + s, rngs + s);
+}
+
+/* masking analysis of the surround multistream encoder: one wave per input channel (opus_surround.h) */
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_surround_kernel(const i16 *pcm, int len, int channels, int Fs, i32 *mem, i32 *preemph_mem, i32 *bandLogE)
+{
+   __shared__ SurroundLds lds;
+   oa_surround_channel_wave((WV_LDS SurroundLds *)&lds, pcm, len, channels, (int)blockIdx.x, Fs, mem, preemph_mem, bandLogE);
 }
 
 #include "opus_packet_host.h"

@@ -436,14 +436,14 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
       fs->max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_max_data_bytes; fs->orig_max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_orig_max_data_bytes; fs->pad_to = 0;
       fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0; fs->toc = 0;
       fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
-      fs->do_stereo_fade = 0;
+      fs->do_stereo_fade = 0; fs->lfe = L->cfg.lfe; fs->energy_mask_on = L->cfg.energy_mask_on; fs->Fs = Fs;
    }
    wv_sync();
    LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
    wv_sync();
    if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
-   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
-   else celt_encode_core<false>(F, &gs->celt, journal);
+   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
+   else celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask);
    wv_sync();
    LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = fs->ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
    wv_sync();

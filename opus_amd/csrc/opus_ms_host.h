@@ -8,6 +8,7 @@
 #ifndef OPUS_AMD_MS_HOST_H
 #define OPUS_AMD_MS_HOST_H
 #include <map>
+#include "opus_surround_host.h"
 
 struct OaLayout { int nb_channels, nb_streams, nb_coupled_streams; unsigned char mapping[256]; };
 static int oa_validate_layout(const OaLayout *l)                       /* opus_multistream.c:40 */
@@ -90,6 +91,9 @@ opus_int32 opus_multistream_encoder_get_size(int nb_streams, int nb_coupled_stre
    if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;
    return (opus_int32)(sizeof(OpusMSEncoder) + (size_t)(nb_streams - 1) * sizeof(OaMsRec));
 }
+/* surround encoders carry the masking analysis state behind the stream records: pre-emphasis memory [channels], window memory [channels][120] (:96-108) */
+static opus_int32 *oa_ms_preemph_mem(OpusMSEncoder *st) { return (opus_int32 *)(void *)((char *)st + opus_multistream_encoder_get_size(st->layout.nb_streams, st->layout.nb_coupled_streams)); }
+static opus_int32 *oa_ms_window_mem(OpusMSEncoder *st) { return oa_ms_preemph_mem(st) + st->layout.nb_channels; }
 static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application, int mapping_type, int lfe_stream)
 {
    if (channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 || streams > 255 - coupled_streams || streams + coupled_streams > channels)
@@ -98,7 +102,6 @@ static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channel
    int r;
    { OaMsRec *probe = new OaMsRec; r = oa_ms_rec_init(probe, kind, Fs, 2, application); delete probe; }
    if (r != OPUS_OK) return r;
-   if (mapping_type == OA_MAP_SURROUND) return OPUS_UNIMPLEMENTED;
    memset(st, 0, sizeof(OpusMSEncoder) - sizeof(OaMsRec));
    st->kind = kind;
    st->magic = OA_MS_MAGIC; st->Fs = Fs; st->application = application; st->bitrate_bps = OPUS_AUTO; st->mapping_type = mapping_type; st->lfe_stream = lfe_stream;
@@ -109,7 +112,9 @@ static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channel
    for (int s = 0; s < streams; s++) {
       r = oa_ms_rec_init(&st->streams[s], kind, Fs, s < coupled_streams ? 2 : 1, application);
       if (r != OPUS_OK) return r;
+      if (s == lfe_stream) oa_ms_rec_set(&st->streams[s], kind, OPUS_SET_LFE_REQUEST, 1);
    }
+   if (mapping_type == OA_MAP_SURROUND) memset(oa_ms_preemph_mem(st), 0, sizeof(opus_int32) * (size_t)channels * (120 + 1));
    return OPUS_OK;
 }
 int opus_multistream_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int application)
@@ -130,17 +135,21 @@ OpusMSEncoder *opus_multistream_encoder_create(opus_int32 Fs, int channels, int 
    if (r != OPUS_OK) { free(st); return NULL; }
    return st;
 }
-static int oa_surround_layout(int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int *mapping_type)
+static int oa_surround_layout(int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int *mapping_type, int *lfe_stream = nullptr)
 {
+   if (lfe_stream) *lfe_stream = -1;
    if (channels > 255 || channels < 1) return OPUS_BAD_ARG;
    if (mapping_family == 0) {
       if (channels == 1) { *streams = 1; *coupled_streams = 0; mapping[0] = 0; }
       else if (channels == 2) { *streams = 1; *coupled_streams = 1; mapping[0] = 0; mapping[1] = 1; }
       else return OPUS_UNIMPLEMENTED;
    } else if (mapping_family == 1 && channels <= 8 && channels >= 1) {
-      if (channels == 1) { *streams = 1; *coupled_streams = 0; mapping[0] = 0; }
-      else if (channels == 2) { *streams = 1; *coupled_streams = 1; mapping[0] = 0; mapping[1] = 1; }
-      else return OPUS_UNIMPLEMENTED;       /* vorbis layouts with surround masking analysis: not built */
+      /* the Vorbis channel orders as (streams, coupled streams, mapping) (RFC 7845 §5.1.1.2; src/opus_multistream_encoder.c:53-62) */
+      static const struct { unsigned char ns, nc, map[8]; } vorbis[8] = {{1, 0, {0}}, {1, 1, {0, 1}}, {2, 1, {0, 2, 1}}, {2, 2, {0, 1, 2, 3}}, {3, 2, {0, 4, 1, 2, 3}},
+         {4, 2, {0, 4, 1, 2, 3, 5}}, {4, 3, {0, 4, 1, 2, 3, 5, 6}}, {5, 3, {0, 6, 1, 2, 3, 4, 5, 7}}};
+      *streams = vorbis[channels - 1].ns; *coupled_streams = vorbis[channels - 1].nc;
+      for (int i = 0; i < channels; i++) mapping[i] = vorbis[channels - 1].map[i];
+      if (lfe_stream && channels >= 6) *lfe_stream = *streams - 1;
    } else if (mapping_family == 255) {
       *streams = channels; *coupled_streams = 0;
       for (int i = 0; i < channels; i++) mapping[i] = (unsigned char)i;
@@ -149,32 +158,32 @@ static int oa_surround_layout(int channels, int mapping_family, int *streams, in
       for (int i = 0; i < (*streams - *coupled_streams); i++) mapping[i] = (unsigned char)(i + (*coupled_streams * 2));
       for (int i = 0; i < *coupled_streams * 2; i++) mapping[i + (*streams - *coupled_streams)] = (unsigned char)i;
    } else return OPUS_UNIMPLEMENTED;
-   *mapping_type = mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE;
+   *mapping_type = mapping_family == 2 ? OA_MAP_AMBISONICS : (mapping_family == 1 && channels > 2) ? OA_MAP_SURROUND : OA_MAP_NONE;
    return OPUS_OK;
 }
 opus_int32 opus_multistream_surround_encoder_get_size(int channels, int mapping_family)
 {
    int streams, coupled, mt; unsigned char mapping[256];
    if (oa_surround_layout(channels, mapping_family, &streams, &coupled, mapping, &mt) != OPUS_OK) return 0;
-   return opus_multistream_encoder_get_size(streams, coupled);
+   return opus_multistream_encoder_get_size(streams, coupled) + (channels > 2 ? channels * (120 + 1) * (opus_int32)sizeof(opus_int32) : 0);
 }
 int opus_multistream_surround_encoder_init(OpusMSEncoder *st, opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application)
 {
-   int mt;
+   int mt, lfe;
    if (!st || !streams || !coupled_streams || !mapping) return OPUS_BAD_ARG;
-   int r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt);
+   int r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt, &lfe);
    if (r != OPUS_OK) return r;
-   return oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, -1);
+   return oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, lfe);
 }
 OpusMSEncoder *opus_multistream_surround_encoder_create(opus_int32 Fs, int channels, int mapping_family, int *streams, int *coupled_streams, unsigned char *mapping, int application, int *error)
 {
-   int mt, r;
+   int mt, r, lfe;
    if (!streams || !coupled_streams || !mapping) { if (error) *error = OPUS_BAD_ARG; return NULL; }
-   r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt);
+   r = oa_surround_layout(channels, mapping_family, streams, coupled_streams, mapping, &mt, &lfe);
    if (r != OPUS_OK) { if (error) *error = r; return NULL; }
-   OpusMSEncoder *st = (OpusMSEncoder *)malloc((size_t)opus_multistream_encoder_get_size(*streams, *coupled_streams));
+   OpusMSEncoder *st = (OpusMSEncoder *)malloc((size_t)opus_multistream_surround_encoder_get_size(channels, mapping_family));
    if (!st) { if (error) *error = OPUS_ALLOC_FAIL; return NULL; }
-   r = oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, -1);
+   r = oa_ms_encoder_init_impl(st, Fs, channels, *streams, *coupled_streams, mapping, application, mt, lfe);
    if (error) *error = r;
    if (r != OPUS_OK) { free(st); return NULL; }
    return st;
@@ -219,7 +228,7 @@ static opus_int32 oa_ms_rate_allocation(const OpusMSEncoder *st, opus_int32 *rat
 
 /* encode n streams of one group (all `ch`-channel) in one launch; states are loaded from / stored back to the flat blob */
 static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, int ch, int application, const opus_int16 *pcm, int frame_size, opus_int32 max_data_bytes,
-      unsigned char *out /* [n][1280] */, opus_int32 *lens, opus_uint32 *rngs)
+      unsigned char *out /* [n][stride] */, opus_int32 stride, opus_int32 *lens, opus_uint32 *rngs)
 {
    int err = OPUS_OK;
    OpusGpuEncBatch *b = oa_ms_enc_batch(n, ch, application, Fs, &err);
@@ -228,7 +237,7 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    HIPCHECK(hipStreamSynchronize(b->stream));
    if (kind) HIPCHECK(hipMemcpy2D(b->d_sh, sizeof(OaShStream), &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), (size_t)n, hipMemcpyHostToDevice));
    else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].s, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
-   int r = opusgpu_encode_batch(b, pcm, frame_size, out, 1280, max_data_bytes, lens, rngs);
+   int r = opusgpu_encode_batch(b, pcm, frame_size, out, stride, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
    if (kind) HIPCHECK(hipMemcpy2D(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), sizeof(OaShStream), (size_t)n, hipMemcpyDeviceToHost));
    else HIPCHECK(hipMemcpy2D(&states[0].s, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), sizeof(OaStream), (size_t)n, hipMemcpyDeviceToHost));
@@ -260,9 +269,25 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
          if (m < max_data_bytes) max_data_bytes = m;
       }
    }
+   /* the masking analysis of the surround layouts (:912-915): per-channel signal-to-mask ratios, handed to each elementary encoder as its energy mask (:1014) */
+   std::vector<opus_int32> bandSMR((size_t)21 * nch);
+   const bool surround = st->mapping_type == OA_MAP_SURROUND && st->application != OPUS_APPLICATION_RESTRICTED_SILK;
+   if (surround) { const int r0 = oa_surround_analysis(pcm, frame_size, nch, Fs, oa_ms_window_mem(st), oa_ms_preemph_mem(st), bandSMR.data()); if (r0 != OPUS_OK) return r0; }
    for (int s = 0; s < ns; s++) {
-      if (kind) { st->streams[s].sh.cfg.user_bitrate_bps = bitrates[s]; if (st->mapping_type == OA_MAP_AMBISONICS) st->streams[s].sh.cfg.user_forced_mode = 1002; /* MODE_CELT_ONLY (:981) */ }
-      else st->streams[s].s.cfg.user_bitrate_bps = bitrates[s];
+      OaMsRec *rec = &st->streams[s];
+      oa_ms_rec_set(rec, kind, OPUS_SET_BITRATE_REQUEST, bitrates[s]);
+      if (st->mapping_type == OA_MAP_SURROUND) {                                          /* :965-985 */
+         opus_int32 equiv_rate = st->bitrate_bps;
+         if (frame_size * 50 < Fs) equiv_rate -= 60 * (Fs / frame_size - 50) * nch;
+         oa_ms_rec_set(rec, kind, OPUS_SET_BANDWIDTH_REQUEST, equiv_rate > 10000 * nch ? OPUS_BANDWIDTH_FULLBAND : equiv_rate > 7000 * nch ? OPUS_BANDWIDTH_SUPERWIDEBAND : equiv_rate > 5000 * nch ? OPUS_BANDWIDTH_WIDEBAND : OPUS_BANDWIDTH_NARROWBAND);
+         if (s < nc) { oa_ms_rec_set(rec, kind, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY); oa_ms_rec_set(rec, kind, OPUS_SET_FORCE_CHANNELS_REQUEST, 2); }   /* keep the spatial image: stereo CELT on coupled streams */
+      } else if (st->mapping_type == OA_MAP_AMBISONICS) oa_ms_rec_set(rec, kind, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY);
+      if (surround) {
+         opus_int32 *mask = kind ? rec->sh.energy_mask : rec->s.energy_mask;
+         if (s < nc) { const int l = oa_get_left(&st->layout, s, -1), r = oa_get_right(&st->layout, s, -1); for (int i = 0; i < 21; i++) { mask[i] = bandSMR[21 * l + i]; mask[21 + i] = bandSMR[21 * r + i]; } }
+         else { const int c = oa_get_mono(&st->layout, s, -1); for (int i = 0; i < 21; i++) mask[i] = bandSMR[21 * c + i]; }
+         if (kind) rec->sh.cfg.energy_mask_on = 1; else rec->s.energy_mask_on = 1;
+      }
    }
    /* channel de-interleave into the two groups */
    std::vector<opus_int16> pc((size_t)nc * frame_size * 2 + 2), pm((size_t)nm * frame_size + 1);
@@ -276,20 +301,22 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
       opus_int16 *d = pm.data() + (size_t)s * frame_size;
       for (int i = 0; i < frame_size; i++) d[i] = pcm[(size_t)i * nch + c];
    }
-   std::vector<unsigned char> pk((size_t)ns * 1280);
+   const opus_int32 stride = (oa_enc_out_stride_needed(Fs, frame_size, 1276 * 6) + 15) & ~15;     /* multi-frame calls stage their frames in the output slot */
+   std::vector<unsigned char> pk((size_t)ns * stride);
    std::vector<opus_int32> lens((size_t)ns);
    std::vector<opus_uint32> rngs((size_t)ns);
    /* The byte budget handed to stream s is max_data_bytes minus what the previous streams used (:1016-1026).  When the caller's buffer is so
     * generous that every stream would be offered at least the encoder's own cap, the budgets are identical and all streams of a group go in
     * ONE launch; otherwise (tight buffer, or hard CBR where the last stream absorbs the remainder) the streams are stepped in order. */
-   const long long worst = (long long)(ns - 1) * (1275 + 1 + 2) + OA_MS_FRAME_TMP + 2 * ns + 8;
+   const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;                      /* coded frames a stream may put into its packet */
+   const long long worst = (long long)(ns - 1) * (1276 * nf + 3) + OA_MS_FRAME_TMP + 3 * ns + 8;
    const bool parallel = vbr && max_data_bytes >= worst;
    int r = OPUS_OK;
    opus_int32 tot_size = 0;
    unsigned char *out = data;
    if (parallel) {
-      if (nc) r = oa_ms_encode_group(st->streams, kind, Fs, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), lens.data(), rngs.data());
-      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, kind, Fs, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * 1280, lens.data() + nc, rngs.data() + nc);
+      if (nc) r = oa_ms_encode_group(st->streams, kind, Fs, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), stride, lens.data(), rngs.data());
+      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, kind, Fs, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, rngs.data() + nc);
       if (r != OPUS_OK) return r;
    }
    for (int s = 0; s < ns; s++) {
@@ -302,14 +329,14 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
          if (Fs / frame_size == 10) curr_max -= ns - s - 1;
          if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
          if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
-         if (!vbr && s == ns - 1) { const opus_int32 br = curr_max * 8 * (6 * Fs / frame_size) / 6; if (kind) st->streams[s].sh.cfg.user_bitrate_bps = br; else st->streams[s].s.cfg.user_bitrate_bps = br; }
+         if (!vbr && s == ns - 1) (void)oa_ms_rec_set(&st->streams[s], kind, OPUS_SET_BITRATE_REQUEST, curr_max * 8 * (6 * Fs / frame_size) / 6);
          if (curr_max <= 0) return OPUS_BUFFER_TOO_SMALL;
-         if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
-         else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * 1280, &lens[s], &rngs[s]);
+         if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s]);
+         else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s]);
          if (r != OPUS_OK) return r;
       }
       if (lens[s] < 0) return lens[s];
-      if (opus_repacketizer_cat(&rp, pk.data() + (size_t)s * 1280, lens[s]) != OPUS_OK) return OPUS_INTERNAL_ERROR;
+      if (opus_repacketizer_cat(&rp, pk.data() + (size_t)s * stride, lens[s]) != OPUS_OK) return OPUS_INTERNAL_ERROR;
       opus_int32 len = oa_repacketizer_out_range_impl(&rp, 0, opus_repacketizer_get_nb_frames(&rp), out, max_data_bytes - tot_size, s != ns - 1, !vbr && s == ns - 1);
       if (len < 0) return len;
       out += len;
