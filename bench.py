@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — encoded frames/s of the batched CELT-only Opus encoder on N MI355X (one process per GPU).
+"""bench.py — encoded frames/s of the batched Opus encoder on N MI355X (one process per GPU).
 
-Workload = BASELINE.json configs[1]: CELT-only encode, OPUS_APPLICATION_RESTRICTED_LOWDELAY, 48 kHz stereo, 20 ms frames,
-128 kb/s CVBR, complexity 10, 65,536 independent streams per GPU; a "step" = one 20 ms frame-step of every stream
-(65,536 frames per GPU), state carried in HBM between steps, PCM resident in HBM before the timed region.
-Streams shard across ranks with no data-path collective; the only exchange is the final gather of (length, payload)
-to rank 0 over RCCL, included in the timed region when N > 1 (weak scaling: per-GPU work fixed).
+Headline workload (default, --config 2) = BASELINE.json configs[1]: CELT-only encode, OPUS_APPLICATION_RESTRICTED_LOWDELAY, 48 kHz stereo, 20 ms
+frames, 128 kb/s CVBR, complexity 10, 65,536 independent streams per GPU; a "step" = one 20 ms frame-step of every stream (65,536 frames per GPU), state
+carried in HBM between steps, PCM resident in HBM before the timed region.  --config 3 (SILK-only VOIP 16 kHz mono 24 kb/s), 4 (hybrid AUDIO 48 kHz stereo
+128 kb/s VBR, the 8-GPU configuration of BASELINE.json: 65,536 streams per GPU) and 5 (multistream: 257 encoders x 255 mono AUDIO streams, one batch) run the
+other BASELINE configurations through the same harness.  At N = 1 the default run also times configs 3 and 4 briefly and reports them in "configs".
+Streams shard across ranks with no data-path collective; the only exchange is the final gather of the compacted packets to rank 0 over RCCL, included in the
+timed region when N > 1 (weak scaling: per-GPU work fixed).
 
-Prints ONE JSON line (rank 0): metric/value + "roofline" (HBM-bound, algorithmic bytes / measured kernel time) and
-"cpu_baseline" (the compiled reference on one host core, bounded sample).
+Prints ONE JSON line (rank 0): metric/value + "roofline" (HBM-bound: algorithmic bytes / kernel time measured live with HIP events on the launch stream; peak = the
+8 TB/s of the guide, peak_measured = a device-to-device copy timed in this run) and "cpu_baseline" (the compiled reference on one pinned host core, on the PCM of
+stream 0 copied back from the GPU batch; plus an all-cores figure and the host's core count / CPU model).
 """
 import argparse, ctypes, json, os, sys, time
 import numpy as np
@@ -16,73 +19,118 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-def cpu_baseline(seconds=12.0):
-    """Reference libopus (default float build, RTCD/AVX2) on ONE host core, same encoder settings, same kind of signal."""
+CONFIGS = {
+    2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
+            ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
+    3: dict(name="SILK-only encode, VOIP, 16 kHz mono, 20 ms, wideband, VBR 24 kb/s, complexity 10", app=2048, Fs=16000, ch=1, kernel="oa_sh_encode_kernel",
+            ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded frames/s (SILK-only, 16 kHz mono, 20 ms, complexity 10)"),
+    4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_encode_kernel",
+            ctls=((11002, 1001), (4008, 1105), (4006, 1), (4002, 128000), (4010, 10)), metric="encoded frames/s (hybrid, 48 kHz stereo, 20 ms, complexity 10)"),
+    5: dict(name="multistream, 255 mono AUDIO streams per encoder (mapping family 255), 48 kHz, 20 ms, 64 kb/s per stream, complexity 10; 257 encoders = 65,535 elementary streams",
+            app=2049, Fs=48000, ch=1, kernel="oa_sh_encode_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
+}
+
+def synth(cfg, T, n_pool, rank):
+    """pool of distinct signals [n_pool, (T+2)*frame*ch] int16 at the config's rate"""
     import signals
-    path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fl.so")
-    kind = "reference"
-    sig = signals.music(500, seed=0)
-    if os.path.exists(path):
-        L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
-        L.opus_encoder_create.restype = ctypes.c_void_p
-        L.opus_encoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
-        L.opus_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-        L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        err = ctypes.c_int()
-        st = L.opus_encoder_create(48000, 2, 2051, ctypes.byref(err))
-        L.opus_encoder_ctl(st, 4002, 128000); L.opus_encoder_ctl(st, 4010, 10)
-        out = (ctypes.c_ubyte * 1500)()
-        enc = lambda ptr: L.opus_encode(st, ptr, 960, out, 1276)
-    else:   # the compiled reference did not travel: time our plain-C port instead
-        from test_oracle_encoder import OracleEnc
-        kind = "port"
-        o = OracleEnc(2, bitrate=128000, complexity=10)
-        enc = lambda ptr: o.O.oc_opus_encode(o.buf, ptr, 960, o.out, 1276)
-    try: os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    Fs, ch, fr = cfg["Fs"], cfg["ch"], cfg["Fs"] // 50
+    if Fs == 48000:
+        return np.stack([(signals.music(T + 2, channels=ch, seed=1000 * rank + p) if p % 4 else signals.noise_bursts(T + 2, channels=ch, seed=1000 * rank + p)).reshape(-1) for p in range(n_pool)])
+    rng = np.random.default_rng(77 + rank)
+    out = []
+    for p in range(n_pool):                                    # glottal-like harmonic source, gated, with noise (SURVEY.md 8d config 3)
+        n = (T + 2) * fr; t = np.arange(n) / Fs
+        f0 = 120 + 30 * np.sin(2 * np.pi * 0.7 * t + p) + (p % 7) * 9
+        ph = 2 * np.pi * np.cumsum(f0) / Fs
+        s = sum(np.sin(k * ph) / k for k in range(1, 25)) * (np.sin(2 * np.pi * 1.5 * t + p) > -0.3) * 6000 + rng.normal(0, 120, n)
+        s = np.clip(s, -32768, 32767).astype(np.int16)
+        out.append(np.repeat(s[:, None], ch, 1).reshape(-1) if ch > 1 else s)
+    return np.stack(out)
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"): model = line.split(":", 1)[1].strip(); break
     except Exception: pass
-    base = sig.ctypes.data
+    try: ncpu = len(os.sched_getaffinity(0))
+    except Exception: ncpu = os.cpu_count() or 1
+    return model, ncpu
+
+def _cpu_worker(args):
+    """encode `frames` (list of int16 arrays) in a loop for `seconds` with the compiled reference; returns frames/s of this worker"""
+    path, cfg, pcm, seconds, pin = args
+    if pin is not None:
+        try: os.sched_setaffinity(0, {pin})
+        except Exception: pass
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    L.opus_encoder_create.restype = ctypes.c_void_p
+    L.opus_encoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.opus_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    err = ctypes.c_int()
+    st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
+    for req, v in cfg["ctls"]: L.opus_encoder_ctl(st, req, v)
+    out = (ctypes.c_ubyte * 1500)()
+    fr = cfg["Fs"] // 50; nfr = pcm.shape[0]
+    base = pcm.ctypes.data; stride = pcm.strides[0]
     n = 0; t0 = time.perf_counter()
     while True:
-        for i in range(500):
-            enc(base + i * 960 * 2 * 2)
-        n += 500
+        for i in range(nfr): L.opus_encode(st, base + i * stride, fr, out, 1276)
+        n += nfr
         if time.perf_counter() - t0 > seconds: break
-    dt = time.perf_counter() - t0
+    return n / (time.perf_counter() - t0)
+
+def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
+    """Reference libopus (default float build, RTCD/AVX2) on ONE pinned host core over the frames of stream 0 copied back from the GPU batch; then one
+    worker per host core for the all-cores figure."""
+    path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fl.so")
+    model, ncpu = host_info()
+    if not os.path.exists(path):
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libopus_ref_fl.so did not travel", "host_nproc": ncpu, "cpu_model": model}
+    pcm0 = np.ascontiguousarray(pcm0)
+    try: first = sorted(os.sched_getaffinity(0))[0]
+    except Exception: first = None
+    one = _cpu_worker((path, cfg, pcm0, seconds, first))
+    allc = None
+    if all_cores_seconds > 0 and ncpu > 1:
+        try:
+            import multiprocessing as mp
+            cpus = sorted(os.sched_getaffinity(0))
+            with mp.get_context("spawn").Pool(len(cpus)) as pool:            # (never fork a process that holds a HIP context)
+                allc = float(sum(pool.map(_cpu_worker, [(path, cfg, pcm0, all_cores_seconds, c) for c in cpus])))
+        except Exception:
+            allc = None
     try: os.sched_setaffinity(0, set(range(os.cpu_count())))
     except Exception: pass
-    return {"value": round(n / dt, 1), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "%d consecutive 20 ms frames of one synthetic stereo stream (same settings), %.1f s, 1 thread pinned" % (n, dt)}
+    return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": "stream 0 of the GPU batch (its %d frames copied back, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD" % (pcm0.shape[0], seconds),
+            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": ncpu if allc is not None else None}
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode", action="store_true", help="also time the HIP decoder on the packets just produced (extra JSON field, not the headline metric)")
-    a = ap.parse_args()
+def copy_bandwidth(dev):
+    """device-to-device copy, GB/s of traffic (read + write)"""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev); b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a); torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record();
+    for _ in range(4): b.copy_(a)
+    e1.record(); torch.cuda.synchronize(dev)
+    return 4 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=True, frames_per_launch=0):
+    """times K frame-steps of BASELINE config `cid` on this rank; returns a result dict (rank-local figures; the caller reduces dt over ranks)"""
     import torch, torch.distributed as dist
-    import opus_amd, signals
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr); sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible — the product path has no CPU fallback", file=sys.stderr); sys.exit(3)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    S, K, W, FR, CH = a.streams, a.steps, a.warmup, 960, 2
-    T = K + W
-    # ---- synthetic input, resident in HBM: a pool of 256 distinct signals, every stream = pool member with its own time offset and gain
+    import opus_amd
+    cfg = CONFIGS[cid]
+    Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; T = K + W
     P = 256
-    pool = np.stack([(signals.music(T + 2, seed=1000 * rank + p) if p % 4 else signals.noise_bursts(T + 2, seed=1000 * rank + p)).reshape(-1) for p in range(P)])
-    pool_d = torch.from_numpy(pool).to(dev)                                  # [P, (T+2)*1920] int16
+    pool = synth(cfg, T, P, rank)
+    pool_d = torch.from_numpy(pool).to(dev)
     g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
     pid = torch.randint(0, P, (S,), generator=g).to(dev)
-    off = (torch.randint(0, 960, (S,), generator=g) * CH).to(dev)           # sample-aligned start offset (both channels)
+    off = (torch.randint(0, FR, (S,), generator=g) * CH).to(dev)
     gain = (0.5 + 0.5 * torch.rand((S,), generator=g)).to(dev)
     pcm = torch.empty((T, S, FR * CH), dtype=torch.int16, device=dev)
     ar = torch.arange(FR * CH, device=dev)
@@ -91,19 +139,20 @@ def main():
         x = pool_d[pid[:, None], idx].to(torch.float32) * gain[:, None]
         pcm[t] = x.round().clamp(-32768, 32767).to(torch.int16)
     del pool_d
-    out = torch.zeros((S, 1280), dtype=torch.uint8, device=dev)
+    STRIDE = 1280
+    out = torch.zeros((S, STRIDE), dtype=torch.uint8, device=dev)
     lens = torch.zeros((S,), dtype=torch.int32, device=dev)
     rng = torch.zeros((S,), dtype=torch.int32, device=dev)
-    b = opus_amd.EncoderBatch(S, channels=CH, application=opus_amd.OPUS_APPLICATION_RESTRICTED_LOWDELAY, device=local)
-    b.ctl(opus_amd.OPUS_SET_BITRATE_REQUEST, 128000); b.ctl(opus_amd.OPUS_SET_COMPLEXITY_REQUEST, 10)
+    b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
+    for req, v in cfg["ctls"]: b.ctl(req, v)
+    if cid == 5:                                               # per-stream rates of the 255-channel multistream layout (rate_allocation, src/opus_multistream_encoder.c:702): equal shares
+        pass
     stream = torch.cuda.current_stream(dev)
-    from opus_amd.shard import PacketGather
-    gather = PacketGather(S * world, 1280, dev, dst=0) if world > 1 else None
+    gather = gather_cls(S * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls) else None
 
     def step(t):
-        b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), 1280, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
-        if world > 1:   # the only exchange of the path: final gather of the packets (RCCL over xGMI)
-            gather.launch(lens, rng, out)
+        b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
+        if gather is not None: gather.launch(lens, rng, out)       # the only exchange of the path: final gather of the packets (RCCL over xGMI)
 
     for t in range(W): step(t)
     torch.cuda.synchronize(dev)
@@ -113,74 +162,120 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         ev[k][0].record(stream)
-        b.encode_dev(pcm[W + k].data_ptr(), FR, out.data_ptr(), 1280, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
+        b.encode_dev(pcm[W + k].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
         ev[k][1].record(stream)
-        if world > 1:
-            gather.launch(lens, rng, out)
+        if gather is not None: gather.launch(lens, rng, out)
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1: dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    dec = None
-    if a.decode and world == 1:
-        # decoder leg: re-encode the K timed frames keeping every packet, then decode them with the state carried (device-resident throughout)
-        b.reset()
-        outs = torch.zeros((K + W, S, 1280), dtype=torch.uint8, device=dev); lns = torch.zeros((K + W, S), dtype=torch.int32, device=dev)
-        for t in range(K + W):
-            b.encode_dev(pcm[t].data_ptr(), FR, outs[t].data_ptr(), 1280, lns[t].data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
-        d = opus_amd.DecoderBatch(S, channels=CH, device=local)
-        dpcm = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((S,), dtype=torch.int32, device=dev)
-        for t in range(W): d.decode_dev(outs[t].data_ptr(), 1280, lns[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
-        torch.cuda.synchronize(dev)
+    lens_h = lens.cpu().numpy()
+    ok = bool((lens_h > 0).all())
+    mean_len = float(lens_h.mean())
+    L = opus_amd.lib()
+    L.opusgpu_enc_moved_state_bytes.restype = ctypes.c_int
+    state_moved = L.opusgpu_enc_moved_state_bytes(cfg["app"], CH, 1 if cid == 4 else 0)          # state bytes read + written per frame-step
+    alg = FR * CH * 2 + mean_len + 8 + state_moved
+    res = {"config_id": cid, "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"], "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
+           "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved}
+    if frames_per_launch and world == 1:
+        # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "T = 50 consecutive steps"
+        Tn = min(frames_per_launch, T)
+        outs = torch.zeros((Tn, S, STRIDE), dtype=torch.uint8, device=dev); lns = torch.zeros((Tn, S), dtype=torch.int32, device=dev); rgs = torch.zeros((Tn, S), dtype=torch.int32, device=dev)
+        L.opusgpu_encode_batch_dev_frames.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for t in range(W, W + K): d.decode_dev(outs[t].data_ptr(), 1280, lns[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        dms = e0.elapsed_time(e1) / K
-        dstate = ctypes.CDLL(opus_amd.LIB_PATH).opusgpu_dec_state_size()
-        mean_l = float(lns[W:].float().mean().item())
-        # algorithmic bytes/frame: packet in + PCM out + state touched: scalars/energies (in+out) + overlap (in+out) + N new history samples out (+ history taps read by the post-filter, <= 2*1030 words, not counted)
-        dalg = mean_l + FR * CH * 2 + 2 * (128 + 4 * 168 + 960) + FR * CH * 4
-        dec = {"metric": "decoded frames/s (48 kHz stereo, 20 ms CELT packets)", "value": round(S / (dms * 1e-3), 1), "kernel": "oa_decode_kernel", "kernel_ms": round(dms, 3),
-               "all_frames_ok": bool((dns == FR).all().item()), "state_bytes": dstate, "algorithmic_bytes_per_frame": round(dalg, 1),
-               "roofline": {"bound": "hbm", "achieved": round(S * dalg / (dms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(S * dalg / (dms * 1e-3) / 1e9 / 8000.0, 5)}}
-        d.close()
-    lens_h = lens.cpu().numpy()
-    ok = bool((lens_h > 2).all())
-    mean_len = float(lens_h.mean())
+        r = L.opusgpu_encode_batch_dev_frames(b._b, pcm.data_ptr(), FR, Tn, outs.data_ptr(), STRIDE, 1276, lns.data_ptr(), rgs.data_ptr(), stream.cuda_stream)
+        e1.record(stream); torch.cuda.synchronize(dev)
+        if r == 0: res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1)}
+    if with_cpu:
+        res["pcm0"] = pcm[:, 0, :].cpu().numpy().reshape(T, FR * CH)
+    b.close()
+    del pcm, out
+    torch.cuda.empty_cache()
+    return res
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default 65,536; config 5: 257 x 255)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="also time T consecutive frame-steps in one launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the short config 3 / 4 legs")
+    a = ap.parse_args()
+    import torch, torch.distributed as dist
+    import opus_amd
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print("bench.py: launch with torch.distributed.run for --gpus > 1", file=sys.stderr); sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible — the product path has no CPU fallback", file=sys.stderr); sys.exit(3)
+    # test hook (tests/test_gpu_bench_ranks.py): OPUS_AMD_BENCH_BACKEND=gloo runs the N > 1 code path with every rank on GPU 0 and the exchange staged through host
+    # memory, so that the sharded bench is executed end to end on a 1-GPU box; the driver's multi-GPU runs use RCCL ("nccl"), one GPU per rank
+    backend = os.environ.get("OPUS_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl": local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl": dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else: dist.init_process_group(backend, rank=rank, world_size=world)
+    from opus_amd.shard import PacketGather
+    S = a.streams or (257 * 255 if a.config == 5 else 65536)
+    K, W = a.steps, a.warmup
+    main_res = run_config(a.config, S, K, W, dev, local, rank, world, gather_cls=PacketGather, with_cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline),
+                          frames_per_launch=a.frames_per_launch)
+    tt = torch.tensor([main_res["dt"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        if backend != "nccl": tt = tt.cpu()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    extras = []
+    if world == 1 and a.config == 2 and not a.no_extra_configs:
+        for cid in (3, 4):
+            extras.append(run_config(cid, S, max(3, K // 2), 2, dev, local, rank, world, with_cpu=not a.no_cpu_baseline))
     if rank == 0:
+        peak_meas = round(copy_bandwidth(dev), 1) if world == 1 else None
+        def roof(r, Sn):
+            ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
+            traffic = None
+            try:
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")))
+                traffic = int(pt["config_%d" % r["config_id"]]["hbm_bytes_per_frame"] * Sn)
+            except Exception: pass
+            return {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
+                    "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),
+                    "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"],
+                    "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)"}
         frames = S * world * K
-        state_bytes = ctypes.CDLL(opus_amd.LIB_PATH).opusgpu_enc_state_size()
-        alg_bytes = S * (FR * CH * 2 + mean_len + 4 + 4 + 2 * state_bytes)       # per launch: PCM in + packet/len/range out + state in and out
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 calibration + WRITE_SIZE), scaled to this launch
-        try:
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = int(pt["hbm_bytes_per_frame"] * S)
-        except Exception:
-            pass
         res = {
-            "metric": "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
+            "metric": CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": "CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10, bit-exact fixed-point",
-                       "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok,
-                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather in timed region" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                         "kernel": "oa_encode_kernel", "kernel_ms": round(kern_ms, 3), "algorithmic_bytes_per_frame": round(alg_bytes / S, 1),
-                         "note": "latency/issue-bound integer codec path: HBM fraction is small by construction (SURVEY.md 8d)"},
+            "config": {"workload": CONFIGS[a.config]["name"] + ", bit-exact fixed-point", "baseline_config": a.config,
+                       "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
+                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather of the compacted packets in the timed region" if world > 1 else "")},
+            "roofline": roof(main_res, S),
         }
-        if dec is not None: res["decode"] = dec
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
-            res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+        if "frames_per_launch" in main_res: res["frames_per_launch"] = main_res["frames_per_launch"]
+        if "pcm0" in main_res:
+            res["cpu_baseline"] = cpu_baseline(CONFIGS[a.config], main_res["pcm0"])
+            if res["cpu_baseline"]["value"]: res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+        if extras:
+            res["configs"] = {}
+            for r in extras:
+                Kx = max(3, K // 2)
+                e = {"workload": r["workload"], "metric": r["metric"], "value": round(S * Kx / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
+                     "mean_packet_bytes": r["mean_packet_bytes"], "all_packets_valid": r["all_packets_valid"], "roofline": roof(r, S)}
+                if "pcm0" in r:
+                    e["cpu_baseline"] = cpu_baseline(CONFIGS[r["config_id"]], r["pcm0"], seconds=5.0, all_cores_seconds=0)
+                    if e["cpu_baseline"]["value"]: e["speedup_vs_cpu_1core"] = round(e["value"] / e["cpu_baseline"]["value"], 2)
+                res["configs"]["config_%d" % r["config_id"]] = e
         print(json.dumps(res))
-    b.close()
     if world > 1: dist.destroy_process_group()
 
 if __name__ == "__main__":

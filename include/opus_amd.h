@@ -131,6 +131,14 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_sync(OpusGpuEncBatch *b);
  * launch stream; returns elapsed milliseconds in *ms (kernel time only, inputs resident). */
 OPUS_AMD_EXPORT int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, int steps, float *ms);
+/* T consecutive frame-steps of every stream in ONE launch (CELT-only applications): d_pcm [T][S][frame_size*channels], d_out [T][S][out_stride], d_lens / d_final_range [T][S] */
+OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_frames(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, int T, unsigned char *d_out, opus_int32 out_stride,
+      opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
+/* final-gather compaction (opus_amd/shard.py): packet s = d_lens[s] bytes of its slot -> d_packed[d_offsets[s] ...]; d_offsets = exclusive prefix sum of the lengths (int64) */
+OPUS_AMD_EXPORT int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed,
+      opus_int32 n, void *hip_stream);
+/* state bytes one frame-step reads plus writes (roofline accounting): application, channels, hybrid frame? */
+OPUS_AMD_EXPORT int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid);
 /* memcpy contract: a stream's complete state as a flat blob (same layout as the classic OpusEncoder payload) */
 OPUS_AMD_EXPORT int opusgpu_enc_state_size(void);
 /* record size / LDS per wave of the SILK-capable encoder (batches created with OPUS_APPLICATION_VOIP / _AUDIO / _RESTRICTED_SILK; src/opus_encoder.c:76-146 + silk/fixed/structs_FIX.h:108) */

@@ -63,6 +63,8 @@ def lib():
         L.opusgpu_time_encode_dev.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, i32, vp]
         L.opusgpu_enc_batch_sync.argtypes = [vp]; L.opusgpu_enc_batch_reset.argtypes = [vp]
+        L.opusgpu_pack_packets_dev.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+        L.opusgpu_enc_moved_state_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         # decoder
         L.opus_decoder_create.restype = vp; L.opus_decoder_create.argtypes = [i32, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.opus_decoder_destroy.argtypes = [vp]
@@ -136,7 +138,11 @@ class EncoderBatch:
         self._L = lib()
         self._b = self._L.opusgpu_enc_batch_create(nstreams, Fs, channels, application, device, ctypes.byref(err))
         if not self._b: raise OpusError(err.value)
-        self.S, self.channels, self.device = nstreams, channels, device
+        self.S, self.channels, self.device, self.Fs = nstreams, channels, device, Fs
+        # record kind: the SILK-capable applications (VOIP / AUDIO / RESTRICTED_SILK) use the larger OaShStream record
+        self.kind = 1 if application in (OPUS_APPLICATION_VOIP, OPUS_APPLICATION_AUDIO, OPUS_APPLICATION_RESTRICTED_SILK) else 0
+        self._L.opusgpu_enc_sh_state_size.restype = ctypes.c_int
+        self.state_size = self._L.opusgpu_enc_sh_state_size() if self.kind else self._L.opusgpu_enc_state_size()
     def ctl(self, request, value=0, stream=-1):
         r = self._L.opusgpu_enc_batch_ctl(self._b, stream, request, value)
         if r != OPUS_OK: raise OpusError(r)
@@ -150,8 +156,10 @@ class EncoderBatch:
         import numpy as np
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         assert pcm.size == self.S * frame_size * self.channels
-        out = np.zeros((self.S, 1280), np.uint8); lens = np.zeros(self.S, np.int32); rng = np.zeros(self.S, np.uint32)
-        r = self._L.opusgpu_encode_batch(self._b, pcm.ctypes.data, frame_size, out.ctypes.data, 1280, max_data_bytes, lens.ctypes.data, rng.ctypes.data)
+        nf = max(1, -(-frame_size * 50 // self.Fs)) if frame_size > self.Fs // 50 else 1       # calls above 20 ms may come back as multi-frame packets
+        stride = 1280 if nf == 1 else ((min(max_data_bytes, 1276 * nf) + 48 + 15) // 16) * 16
+        out = np.zeros((self.S, stride), np.uint8); lens = np.zeros(self.S, np.int32); rng = np.zeros(self.S, np.uint32)
+        r = self._L.opusgpu_encode_batch(self._b, pcm.ctypes.data, frame_size, out.ctypes.data, stride, max_data_bytes, lens.ctypes.data, rng.ctypes.data)
         if r != OPUS_OK: raise OpusError(r)
         return [bytes(out[s, :max(int(lens[s]), 0)]) for s in range(self.S)], lens, rng
     def encode_dev(self, d_pcm_ptr, frame_size, d_out_ptr, out_stride, d_lens_ptr, d_rng_ptr, max_data_bytes=1276, hip_stream=None):
@@ -163,11 +171,12 @@ class EncoderBatch:
         if r != OPUS_OK: raise OpusError(r)
         return ms.value
     def export_state(self, stream):
-        buf = ctypes.create_string_buffer(self._L.opusgpu_enc_state_size())
+        buf = ctypes.create_string_buffer(self.state_size)
         r = self._L.opusgpu_enc_batch_export_state(self._b, stream, buf)
         if r != OPUS_OK: raise OpusError(r)
         return buf.raw
     def import_state(self, stream, blob):
+        if len(blob) != self.state_size: raise ValueError("state blob of %d bytes, this batch's records are %d bytes" % (len(blob), self.state_size))
         r = self._L.opusgpu_enc_batch_import_state(self._b, stream, blob)
         if r != OPUS_OK: raise OpusError(r)
     def reset(self):

@@ -51,6 +51,7 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
    const int s = blockIdx.x;
    if (s >= nstreams) return;
+   if (lens[s] > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } return; }       /* a length beyond the stream's slot would read the neighbour's packet */
    oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
 }
 
@@ -75,6 +76,33 @@ oa_surround_kernel(const i16 *pcm, int len, int channels, int Fs, i32 *mem, i32 
 {
    __shared__ SurroundLds lds;
    oa_surround_channel_wave((WV_LDS SurroundLds *)&lds, pcm, len, channels, (int)blockIdx.x, Fs, mem, preemph_mem, bandLogE);
+}
+
+/* final-gather compaction: packet s (lens[s] bytes of its out slot) -> packed[offs[s] ...], one wave per packet */
+extern "C" __global__ void __launch_bounds__(64)
+oa_pack_kernel(const u8 *out, int stride, const i32 *lens, const long long *offs, u8 *packed, int n)
+{
+   const int s = blockIdx.x;
+   if (s >= n) return;
+   const int len = lens[s];
+   const u8 *src = out + (size_t)s * stride; u8 *dst = packed + offs[s];
+   for (int i = threadIdx.x; i < len; i += 64) dst[i] = src[i];
+}
+/* T consecutive frame-steps of every stream in one launch: the wave keeps its stream for T frames (pcm [T][S][frame*ch], out [T][S][stride], lens / rngs [T][S]) */
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
+   const int s = blockIdx.x;
+   if (s >= nstreams) return;
+   OaStream *gs = streams + s;
+   const int ch = gs->cfg.channels;
+   for (int t = 0; t < T; t++) {
+      const size_t row = (size_t)t * nstreams + s;
+      oa_encode_frame(L, gs, pcm + row * frame_size * ch, frame_size, max_data_bytes, out + row * out_stride, out_stride, lens + row, rngs + row);
+      __syncthreads();
+   }
 }
 
 #include "opus_packet_host.h"
@@ -288,6 +316,38 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
+int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed, opus_int32 n, void *hip_stream)
+{
+   if (!d_out || !d_lens || !d_offsets || !d_packed || n <= 0 || stride <= 0) return OPUS_BAD_ARG;
+   hipLaunchKernelGGL(oa_pack_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)hip_stream, (const u8 *)d_out, (int)stride, (const i32 *)d_lens, d_offsets, (u8 *)d_packed, (int)n);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+/* state bytes a frame-step reads plus writes (for the roofline's algorithmic traffic): the CELT-only record moves its scalars, the four energy arrays, the overlap and the
+ * pitch history; the SILK-capable record moves configuration, scalars and the SILK state of the coded channels, plus -- hybrid -- the CELT state and the delay line */
+int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid)
+{
+   if (!oa_app_is_sh(application)) return 2 * (int)(sizeof(OaEncScalars) + sizeof(int32_t) * (4 * channels * OA_NB_EBANDS + channels * OA_OVERLAP + channels * OA_MAX_PERIOD));
+   int n = (int)(sizeof(OaShConfig) + 2 * sizeof(OaShScalars)) + 2 * 4 * SE_STATE_WORDS(channels);
+   if (hybrid) n += 2 * (int)(sizeof(OaEncScalars) + sizeof(int32_t) * (4 * channels * OA_NB_EBANDS + channels * OA_OVERLAP + channels * OA_MAX_PERIOD)) + 2 * 2 * channels * OA_SH_MAX_DELAY;
+   return n;
+}
+int opusgpu_encode_batch_dev_frames(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, int T, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
+      opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
+{
+   if (!b || !d_pcm || !d_out || !d_lens || !d_final_range || T <= 0) return OPUS_BAD_ARG;
+   if (b->kind) return OPUS_UNIMPLEMENTED;                                            /* the CELT-only kernel (the headline configuration) */
+   { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
+   if (max_data_bytes <= 0) return OPUS_BAD_ARG;
+   if (out_stride < oa_enc_out_stride_needed(b->Fs, frame_size, max_data_bytes)) return OPUS_BUFFER_TOO_SMALL;
+   HIPCHECK(hipSetDevice(b->device));
+   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+   HIPCHECK(hipFuncSetAttribute((const void *)oa_encode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+   hipLaunchKernelGGL(oa_encode_frames_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds), s,
+         b->d_streams, (const i16 *)d_pcm, frame_size, T, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
 int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, int steps, float *ms)
 {
@@ -299,7 +359,7 @@ int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fra
    size_t step_elems = (size_t)b->S * frame_size * b->channels;
    for (int k = 0; k < steps; k++) {
       int r = opusgpu_encode_batch_dev(b, d_pcm + (size_t)k * step_elems, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, nullptr);
-      if (r != OPUS_OK) return r;
+      if (r != OPUS_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return r; }
    }
    HIPCHECK(hipEventRecord(e1, b->stream));
    HIPCHECK(hipEventSynchronize(e1));
@@ -622,7 +682,7 @@ int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, 
    HIPCHECK(hipEventRecord(e0, b->stream));
    for (int k = 0; k < steps; k++) {
       int r = opusgpu_decode_batch_dev(b, d_packets + (size_t)k * b->S * packet_stride, packet_stride, d_lens + (size_t)k * b->S, d_pcm, frame_size, d_nsamples, d_final_range, nullptr);
-      if (r != OPUS_OK) return r;
+      if (r != OPUS_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return r; }
    }
    HIPCHECK(hipEventRecord(e1, b->stream));
    HIPCHECK(hipEventSynchronize(e1));

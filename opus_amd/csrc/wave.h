@@ -35,8 +35,10 @@ WV_DEV int32_t wv_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 /* old with lane `lane` replaced by the (uniform) value val */
 WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old)
 {
-   /* no clang builtin for llvm.amdgcn.writelane in this toolchain; a VOP3 may read one SGPR only, so the lane select goes through M0 */
-   asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+   /* no clang builtin for llvm.amdgcn.writelane in this toolchain; a VOP3 may read one SGPR only, so the lane select goes through M0.  M0 cannot be named
+    * in a clobber list (reserved register), so the sequence saves and restores it itself */
+   int32_t m0_save;
+   asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(old), "=&s"(m0_save) : "s"(val), "s"(lane));
    return old;
 }
 

@@ -31,6 +31,7 @@ extern thread_local unsigned emu_block_x;
 struct EmuIdx { unsigned x, y, z; };
 static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)emu_cur->cur, 0, 0}; return i; }
 static inline EmuIdx emu_bidx() { EmuIdx i = {emu_block_x, 0, 0}; return i; }
+static inline void __syncthreads() { emu_rendezvous(); }
 #define threadIdx (emu_tidx())
 #define blockIdx (emu_bidx())
 
