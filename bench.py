@@ -89,23 +89,22 @@ def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
     if not os.path.exists(path):
         return {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libopus_ref_fl.so did not travel", "host_nproc": ncpu, "cpu_model": model}
     pcm0 = np.ascontiguousarray(pcm0)
-    try: first = sorted(os.sched_getaffinity(0))[0]
-    except Exception: first = None
+    try: cpus = sorted(os.sched_getaffinity(0)); first = cpus[0]
+    except Exception: cpus = list(range(ncpu)); first = None
     one = _cpu_worker((path, cfg, pcm0, seconds, first))
+    try: os.sched_setaffinity(0, set(cpus))                                 # the single-core leg pinned this process: undo before spawning the pool
+    except Exception: pass
     allc = None
     if all_cores_seconds > 0 and ncpu > 1:
         try:
             import multiprocessing as mp
-            cpus = sorted(os.sched_getaffinity(0))
             with mp.get_context("spawn").Pool(len(cpus)) as pool:            # (never fork a process that holds a HIP context)
                 allc = float(sum(pool.map(_cpu_worker, [(path, cfg, pcm0, all_cores_seconds, c) for c in cpus])))
         except Exception:
             allc = None
-    try: os.sched_setaffinity(0, set(range(os.cpu_count())))
-    except Exception: pass
     return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
             "sample": "stream 0 of the GPU batch (its %d frames copied back, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD" % (pcm0.shape[0], seconds),
-            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": ncpu if allc is not None else None}
+            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None}
 
 def copy_bandwidth(dev):
     """device-to-device copy, GB/s of traffic (read + write)"""

@@ -47,9 +47,6 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
    const int CC = sh->CC, C = sh->C;
-#ifdef OA_PHASE_TIMERS
-   unsigned long long oa_phase_t0 = 0;
-#endif
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
 
    K_PHASE(1);
@@ -450,9 +447,6 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
    const int overlap = OA_OVERLAP, CC = sh->CC;
-#ifdef OA_PHASE_TIMERS
-   unsigned long long oa_phase_t0 = 0;
-#endif
    {  /* activity for the generalised DTX (:1911-1930): digital silence, else the frame's energy against the tracked peak */
       int activity = 1;
       if (wv_uni(sh->use_dtx)) {

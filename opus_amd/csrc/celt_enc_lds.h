@@ -58,7 +58,7 @@ struct FrameLds {
    i32 scr[6 * NBE];                  /* lane-0 scratch (allocation vectors, dynalloc followers, two-pass energies) */
    i32 aux[32];                       /* MDCT headroom/shift bookkeeping, reductions hand-off */
 #ifdef OA_PHASE_TIMERS
-   u32 prof[34];                      /* shader-clock buckets of the profiling build */
+   u32 prof[34], prof_t0;             /* shader-clock buckets of the profiling build, start of the open phase */
 #endif
    u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* packet[0] = TOC, range coder buffer = packet+1 */

@@ -7,7 +7,7 @@
 __device__ unsigned long long oa_phase_ticks[34];
 #define K_TIC() unsigned long long tic_ = clock64()
 #define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); L->prof[b] += (u32)(t_ - tic_); tic_ = t_; } } while (0)
-#define K_PHASE(id) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((id) > 0) L->prof[(id) - 1] = (u32)(t_ - oa_phase_t0); else for (int z_ = 0; z_ < 34; z_++) L->prof[z_] = 0; oa_phase_t0 = t_; \
+#define K_PHASE(id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); if ((id) > 0) L->prof[(id) - 1] = t_ - L->prof_t0; else for (int z_ = 0; z_ < 34; z_++) L->prof[z_] = 0; L->prof_t0 = t_; \
       if ((id) == 15) for (int z_ = 0; z_ < 34; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
 #endif
 #include "celt_enc_all.h"
@@ -32,7 +32,10 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #include <mutex>
 #include <vector>
 
-extern "C" __global__ void __launch_bounds__(64, 2)
+#ifndef OA_ENC_WAVES_PER_EU
+#define OA_ENC_WAVES_PER_EU 2
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
 oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -133,18 +133,25 @@ def test_gpu_inband_fec(Fs, ch, app, ms, ctl):
     """OPUS_SET_INBAND_FEC with packet loss: decide_fec, the LBRR re-quantisation (silk_LBRR_encode_FIX) and its coding at the head of the next packet"""
     check(4, 20 if ms <= 20 else 8, Fs=Fs, ch=ch, app=app, ms=ms, fec=1, **ctl)
 
-def test_gpu_silk_unbuilt_paths_fail_loudly():
+def test_gpu_formerly_unbuilt_paths_match_the_reference():
+    """round 1 refused CELT below 48 kHz and a SILK -> CELT switch mid-stream; both are built now and have to match the reference packet for packet"""
     import opus_amd as oa
-    b = oa.EncoderBatch(2, channels=1, application=2049, Fs=24000)              # CELT below 48 kHz is not built: AUDIO 24 kHz at the default rate decides CELT-only
-    pk, lens, rng = b.encode(np.zeros((2, 480), np.int16) + 100, 480)
-    assert all(int(l) == oa.OPUS_UNIMPLEMENTED for l in lens)
+    rs = np.random.default_rng(1)
+    x = rs.normal(0, 3000, (12, 480)).astype(np.int16)
+    b = oa.EncoderBatch(1, channels=1, application=2049, Fs=24000)              # AUDIO 24 kHz at the default rate decides CELT-only
+    ref = RefOpusEnc(24000, 1, 2049)
+    for f in range(12):
+        pk, lens, rng = b.encode(x[f:f + 1], 480)
+        assert bytes(pk[0]) == ref.encode(x[f], 480)[0], f
     b.close()
-    b = oa.EncoderBatch(1, channels=1, application=2048, Fs=48000)              # a SILK -> CELT-only switch mid-stream needs the redundancy frame: not built
+    b = oa.EncoderBatch(1, channels=1, application=2048, Fs=48000)              # SILK -> CELT-only switch: redundancy frame
+    ref = RefOpusEnc(48000, 1, 2048, force_mode=1000, bitrate=20000)
     b.ctl(11002, 1000); b.ctl(4002, 20000)
-    x = (np.random.default_rng(1).normal(0, 3000, (1, 960))).astype(np.int16)
-    pk, lens, rng = b.encode(x, 960); assert int(lens[0]) > 0
-    b.ctl(11002, 1002)
-    pk, lens, rng = b.encode(x, 960); assert int(lens[0]) == oa.OPUS_UNIMPLEMENTED
+    y = rs.normal(0, 3000, (8, 960)).astype(np.int16)
+    for f in range(8):
+        if f == 4: b.ctl(11002, 1002); assert ref.R.opus_encoder_ctl(ref.enc, 11002, ctypes.c_int(1002)) == 0
+        pk, lens, rng = b.encode(y[f:f + 1], 960)
+        assert bytes(pk[0]) == ref.encode(y[f], 960)[0], f
     b.close()
     with pytest.raises(oa.OpusError): oa.EncoderBatch(1, channels=1, application=2048, Fs=44100)
 

@@ -32,6 +32,22 @@ def test_gpu_test_opus_api(): _run("gpu", "test_opus_api", 900)
 @pytest.mark.gpu
 def test_gpu_test_opus_padding(): _run("gpu", "test_opus_padding", 300)
 @pytest.mark.gpu
-def test_gpu_test_opus_decode(): _run("gpu", "test_opus_decode", 1500)
-@pytest.mark.gpu
-def test_gpu_test_opus_encode(): _run("gpu", "test_opus_encode", 2400)
+def test_gpu_test_opus_decode_and_encode():
+    """test_opus_decode in full and test_opus_encode with the reference's own TEST_OPUS_NOFUZZ knob (the settings fuzz alone is another ~20 minutes at one
+    wave per call; OPUS_AMD_LONG_TESTS=1 runs it).  The two programs run side by side: each is bound by the latency of single-wave launches (~1-2 ms per
+    call, tools/classic_latency.py), not by the GPU.  Measured on the MI355X: 6 min 45 s and 5 min 50 s (profiles/r02_b/ref_test_opus_*.log)."""
+    import threading
+    res = {}
+    def go(name, env):
+        try:
+            exe = os.path.join(ROOT, "oracle/_ref/reftests/gpu", name)
+            p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=3000 if LONG else 1500, env=dict(os.environ, SEED="20260922", **env))
+            res[name] = (p.returncode, p.stdout.decode(errors="replace")[-2000:])
+        except Exception as ex: res[name] = (-1, repr(ex))
+    if not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/gpu/test_opus_decode")):
+        if not os.path.isdir(hostemu.REF): pytest.skip("reference test binaries not built and /root/reference absent")
+        hostemu.build_reftests("gpu")
+    ts = [threading.Thread(target=go, args=("test_opus_decode", {})), threading.Thread(target=go, args=("test_opus_encode", {} if LONG else {"TEST_OPUS_NOFUZZ": "1"}))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for name, (rc, out) in res.items(): assert rc == 0, (name, out)
