@@ -11,7 +11,7 @@ import ctypes, os, subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libopus_amd.so")
+LIB_PATH = os.environ.get("OPUS_AMD_LIB") or os.path.join(_HERE, "libopus_amd.so")     # (OPUS_AMD_LIB: A/B experiments with variant builds)
 
 OPUS_OK, OPUS_BAD_ARG, OPUS_BUFFER_TOO_SMALL, OPUS_INTERNAL_ERROR = 0, -1, -2, -3
 OPUS_INVALID_PACKET, OPUS_UNIMPLEMENTED, OPUS_INVALID_STATE, OPUS_ALLOC_FAIL = -4, -5, -6, -7

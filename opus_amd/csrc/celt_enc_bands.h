@@ -25,36 +25,20 @@ WV_DEV i32 inner_prod_norm_shift_w(const WV_LDS i32 *x, const WV_LDS i32 *y, int
    return (i32)(wv_sum64(sum) >> 2 * (NORM_SHIFT - 14));
 }
 
-/* compute_mdcts (celt_encoder.c:511): per channel, B interleaved transforms; freq lands in A.s.X */
-WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks)
+WV_DEV i32 inner_prod_norm_shift_gw(const i32 *x, const WV_LDS i32 *y, int len)         /* whole wave, x in HBM */
 {
-   const int C = L->sh.C, CC = L->sh.CC, LM = L->sh.LM;
-   int B, N, shift;
-   if (shortBlocks) { B = shortBlocks; N = 120; shift = 3; }
-   else { B = 1; N = 120 << LM; shift = 3 - LM; }
-   for (int c = 0; c < CC; c++)
-      mdct_forward_blocks(gst->in_mem + c * OA_OVERLAP, L->BC.in[c], L->A.s.X + c * N * B, shift, B, L->aux);
-   if (CC == 2 && C == 1) {
-      WV_LDS i32 *out = L->A.s.X;
-      FOR_LANES(i, B * N) out[i] = add32(out[i] >> 1, out[B * N + i] >> 1);
-      wv_sync();
-   }
-   if (L->sh.upsample > 1) {           /* zero-stuffed input: restore the level below the input's Nyquist, nothing above it (celt_encoder.c:544-554) */
-      const int up = L->sh.upsample, bound = B * N / up;
-      for (int c = 0; c < C; c++) { WV_LDS i32 *out = L->A.s.X + c * B * N; FOR_LANES(i, B * N) out[i] = i < bound ? out[i] * up : 0; }
-      wv_sync();
-   }
+   i64 sum = 0;
+   FOR_LANES(i, len) sum += x[i] * (i64)y[i];
+   return (i32)(wv_sum64(sum) >> 2 * (NORM_SHIFT - 14));
 }
 
-/* compute_band_energies + amp2Log2: one lane per (band, channel) */
-WV_DEVN void band_energies_wave(WV_LDS FrameLds *L, WV_LDS i32 *bandLogE_out)
+/* compute_band_energies + amp2Log2 of the channel resident in W: one lane per band */
+WV_DEV void band_energies_channel(WV_LDS FrameLds *L, const WV_LDS i32 *W, int c, WV_LDS i32 *bandLogE_out)
 {
-   const int C = L->sh.C, LM = L->sh.LM, N = L->sh.N, end = L->sh.end, effEnd = L->sh.effEnd;
-   const WV_LDS i32 *X = L->A.s.X;
-   FOR_LANES(w, C * NBE) {
-      int c = w / NBE, i = w - c * NBE;
+   const int LM = L->sh.LM, end = L->sh.end, effEnd = L->sh.effEnd;
+   FOR_LANES(i, NBE) {
       if (i < effEnd) {
-         const WV_LDS i32 *x = &X[c * N + (ct_eBands[i] << LM)];
+         const WV_LDS i32 *x = &W[ct_eBands[i] << LM];
          int len = (ct_eBands[i + 1] - ct_eBands[i]) << LM;
          i32 mx = 0, mn = 0, sum = 0, E;
          for (int j = 0; j < len; j++) { mx = imax(mx, x[j]); mn = imin(mn, x[j]); }
@@ -68,14 +52,42 @@ WV_DEVN void band_energies_wave(WV_LDS FrameLds *L, WV_LDS i32 *bandLogE_out)
          bandLogE_out[i + c * NBE] = fx_log2_db(E) - shl32((i32)ct_eMeans[i], DB_SHIFT - 4) + GC(2.f);
       } else if (i < end) bandLogE_out[i + c * NBE] = -GC(14.f);
    }
-   wv_sync();
 }
 
-/* normalise_bands (bands.c:125), in place: freq -> X */
+/* compute_mdcts (celt_encoder.c:511) + compute_band_energies (bands.c:95) + amp2Log2: one channel at a time through the LDS work buffer W -- B interleaved
+ * transforms in place, the band energies while the channel is resident, then the channel goes out to the HBM spectrum g->X */
+WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks, WV_LDS i32 *bandLogE_out)
+{
+   const int C = L->sh.C, CC = L->sh.CC, LM = L->sh.LM;
+   CeltScratch *G = L->g;
+   WV_LDS i32 *W = L->BC.W;
+   int B, N, shift;
+   if (shortBlocks) { B = shortBlocks; N = 120; shift = 3; }
+   else { B = 1; N = 120 << LM; shift = 3 - LM; }
+   const int up = L->sh.upsample > 1 ? L->sh.upsample : 1, bound = B * N / up;
+   for (int c = 0; c < CC; c++) {
+      mdct_forward_blocks(gst->in_mem + c * OA_OVERLAP, G->in[c], W, shift, B, L->aux);
+      if (CC == 2 && C == 1) {                                   /* stereo input coded as mono: the downmix of the two spectra */
+         if (c == 0) { FOR_LANES(i, B * N) G->X[i] = W[i]; wv_sync(); continue; }
+         FOR_LANES(i, B * N) W[i] = add32(G->X[i] >> 1, W[i] >> 1);
+         wv_sync();
+      }
+      if (up > 1) {                    /* zero-stuffed input: restore the level below the input's Nyquist, nothing above it (celt_encoder.c:544-554) */
+         FOR_LANES(i, B * N) W[i] = i < bound ? W[i] * up : 0;
+         wv_sync();
+      }
+      const int cc = C == 1 ? 0 : c;
+      band_energies_channel(L, W, cc, bandLogE_out);
+      FOR_LANES(i, B * N) G->X[cc * B * N + i] = W[i];
+      wv_sync();
+   }
+}
+
+/* normalise_bands (bands.c:125), in place in the HBM spectrum: freq -> X */
 WV_DEVN void normalise_bands_wave(WV_LDS FrameLds *L)
 {
    const int C = L->sh.C, M = L->sh.M, N = L->sh.N, end = L->sh.effEnd;
-   WV_LDS i32 *X = L->A.s.X;
+   i32 *X = L->g->X;
    for (int c = 0; c < C; c++)
       for (int i = 0; i < end; i++) {
          i32 E = L->bandE[i + c * NBE];
@@ -87,6 +99,16 @@ WV_DEVN void normalise_bands_wave(WV_LDS FrameLds *L)
          for (int j = lo + wv_lane(); j < hi; j += WV_WIDTH)
             X[j + c * N] = pshr32(mult32_32_q31(g, shl32(X[j + c * N], shift)), 30 - NORM_SHIFT);
       }
+   wv_sync();
+}
+
+/* the normalised coded bins of both channels -> LDS (BC.xs) for the analyses that walk bands serially per lane */
+WV_DEV void stage_coded_bins_wave(WV_LDS FrameLds *L)
+{
+   const int C = L->sh.C, N = L->sh.N, n = L->sh.M * ct_eBands[L->sh.effEnd];
+   const i32 *X = L->g->X;
+   wv_sync();
+   for (int c = 0; c < C; c++) FOR_LANES(j, n) L->BC.xs[c][j] = X[c * N + j];
    wv_sync();
 }
 
@@ -270,13 +292,15 @@ WV_DEVN void tf_analysis_wave(WV_LDS FrameLds *L, int lambda)
    const i16 tf_estimate = (i16)sh->tf_estimate;
    WV_LDS i32 *metric = L->scr, *path0 = L->scr + 21, *path1 = L->scr + 42;
    WV_LDS i32 *tmpA = L->BC.tf;             /* 800 words: private per-band segments (folding memory not live yet) */
-   WV_LDS i32 *tmpB = L->BC.tf + 800;    /* second copy for the "-1" trial */
-   const WV_LDS i32 *X = L->A.s.X;
+   WV_LDS i32 *tmpB = L->BC.tf + OA_CODED_BINS;    /* second copy for the "-1" trial */
+   const i32 *X = L->g->X + tf_chan * N0;
    i16 bias = (i16)mult16_16_q14(QC16(.04f, 15), imax(-QC16(.25f, 14), QC16(.5f, 14) - tf_estimate));
+   wv_sync();
+   FOR_LANES(j, ct_eBands[len] << LM) tmpA[j] = X[j];            /* the trial buffer is laid out like the spectrum: one coalesced copy from HBM */
+   wv_sync();
    FOR_LANES(i, len) {
       int off = ct_eBands[i] << LM, N = (ct_eBands[i + 1] - ct_eBands[i]) << LM, narrow = (ct_eBands[i + 1] - ct_eBands[i]) == 1, best_level = 0;
       WV_LDS i32 *tmp = tmpA + off, *tmp_1 = tmpB + off;
-      for (int j = 0; j < N; j++) tmp[j] = X[tf_chan * N0 + off + j];
       i32 L1 = l1_metric_l(tmp, N, isTransient ? LM : 0, bias), best_L1 = L1;
       if (isTransient && !narrow) {
          for (int j = 0; j < N; j++) tmp_1[j] = tmp[j];
@@ -358,8 +382,8 @@ WV_DEVN void spreading_decision_wave(WV_LDS FrameLds *L, int update_hf)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int end = sh->effEnd, C = sh->C, M = sh->M, N0 = sh->N;
-   const WV_LDS i32 *X = L->A.s.X;
+   const int end = sh->effEnd, C = sh->C, M = sh->M, N0 = OA_CODED_BINS;
+   const WV_LDS i32 *X = L->BC.xs[0];       /* staged by stage_coded_bins_wave */
    WV_LDS i32 *cnt = L->scr;      /* [2*21][2]: tmp, hf contribution */
    if (M * (ct_eBands[end] - ct_eBands[end - 1]) <= 8) { wv_sync(); LANE0 st->spread_decision = 0; wv_sync(); return; }
    FOR_LANES(w, C * NBE) {
@@ -419,8 +443,8 @@ WV_DEVN void spreading_decision_wave(WV_LDS FrameLds *L, int update_hf)
 /* stereo_analysis (celt_encoder.c:957): two L1 sums by wave reduction, decision identical on every lane */
 WV_DEV int stereo_analysis_wave(WV_LDS FrameLds *L)
 {
-   const int LM = L->sh.LM, N0 = L->sh.N;
-   const WV_LDS i32 *X = L->A.s.X;
+   const int LM = L->sh.LM, N0 = OA_CODED_BINS;
+   const WV_LDS i32 *X = L->BC.xs[0];
    i32 sLR = 0, sMS = 0;
    FOR_LANES(j, ct_eBands[13] << LM) {
       i32 Lv = X[j] >> (NORM_SHIFT - 14), R = X[N0 + j] >> (NORM_SHIFT - 14), Mv = add32(Lv, R), S = sub32(Lv, R);
@@ -439,8 +463,8 @@ WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int end = sh->end, LM = sh->LM, C = sh->C, N0 = sh->N, intensity = st->intensity;
-   const WV_LDS i32 *X = L->A.s.X;
+   const int end = sh->end, LM = sh->LM, C = sh->C, N0 = OA_CODED_BINS, intensity = st->intensity;
+   const WV_LDS i32 *X = L->BC.xs[0];
    WV_LDS i32 *partial = L->scr;
    if (C == 2) {
       FOR_LANES(i, NBE) {

@@ -40,7 +40,7 @@ WV_DEV int oa_emit_packet_wave(const WV_LDS u8 *pk, u8 *out, int nbytes, int pad
 WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to, int out_cap) { return oa_emit_packet_wave(L->packet, out, nbytes, pad_to, out_cap); }
 
 /* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
- * constants of the prologue in L->sh, the int16 input staged in L->A.pcm16 and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
+ * constants of the prologue in L->sh, the int16 input staged in L->g->pcm16 (HBM) and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
  * HYB = the hybrid branches of the reference (start band 17: no pitch pre-filter, no tf_analysis, weak transients, its own VBR target, :2030-2470). */
 template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr)
 {
@@ -53,10 +53,10 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    /* ---- pre-emphasis (celt_encoder.c:557) is not materialised: pre_at() recomputes it from the int16 staging buffer ---- */
    PreSrc ps0, ps1;
    const int up = sh->upsample > 1 ? wv_uni(sh->upsample) : 1;
-   ps0.hist = gst->prefilter_mem; ps0.pcm = L->A.pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0]; ps0.up = up;
-   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->A.pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1]; ps1.up = up;
+   ps0.hist = gst->prefilter_mem; ps0.pcm = L->g->pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0]; ps0.up = up;
+   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->g->pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1]; ps1.up = up;
    wv_sync();
-   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = up > 1 ? 0 : mult16_32_q15(27853, shl32((i32)L->A.pcm16[CC * (N - 1) + c], SIG_SHIFT)); }   /* the last zero-stuffed sample is 0 */
+   LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = up > 1 ? 0 : mult16_32_q15(27853, shl32((i32)L->g->pcm16[CC * (N - 1) + c], SIG_SHIFT)); }   /* the last zero-stuffed sample is 0 */
    wv_sync();
 
    K_PHASE(2);
@@ -108,15 +108,13 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    K_PHASE(5);
    /* ---- MDCT + band energies ---- */
    if (sh->secondMdct) {
-      compute_mdcts_wave(L, gst, 0);
-      band_energies_wave(L, L->bandLogE2);
+      compute_mdcts_wave(L, gst, 0, L->bandLogE2);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       wv_sync();
    }
-   compute_mdcts_wave(L, gst, sh->shortBlocks);
+   compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE);
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
-   band_energies_wave(L, L->bandLogE);
-   K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->A.s.X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
+   K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->g->X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
    if (sh->lfe) {                    /* LFE: nothing but the first two bands carries energy (celt_encoder.c:2099-2107) */
       LANE0 {
          for (int c = 0; c < C; c++) for (int i = 2; i < end; i++) {
@@ -177,8 +175,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    if (sh->do_patch) {
       LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
       wv_sync();
-      compute_mdcts_wave(L, gst, sh->shortBlocks);
-      band_energies_wave(L, L->bandLogE);
+      compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
@@ -186,7 +183,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    store_in_mem_wave(L, gst);          /* last MDCT done: the overlap memory may now be replaced; BC is free from here */
    LANE0 { EC_BEGIN; if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); EC_END; }
    normalise_bands_wave(L);
-   K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->A.s.X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
+   K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->g->X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
 
    K_PHASE(7);
    /* ---- allocation analyses ---- */
@@ -234,6 +231,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    wv_sync();
    K_DUMP("tf_res", L->tf_res, 84); K_DUMP("oldBandE_c", L->oldBandE, 168); K_DUMP("error_c", L->error, 168); K_DUMPI("rng_tf", L->ec.rng); K_DUMPI("tell_tf", ec_tell_frac_lds(&L->ec));
    K_PHASE(10);
+   stage_coded_bins_wave(L);              /* BC is free between the coarse-energy rollback and the PVQ: the analyses below read the spectrum from LDS */
    if (sh->r[2]) {
       if (sh->lfe) { LANE0 { st->tapset_decision = 0; st->spread_decision = 2; } wv_sync(); }                                                  /* :2305 */
       else if (HYB) { LANE0 st->spread_decision = sh->complexity == 0 ? 0 : sh->isTransient ? 2 : 3; wv_sync(); }                                      /* :2309 SPREAD_NONE / NORMAL / AGGRESSIVE */
@@ -463,11 +461,12 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
    wv_sync();
    if (sh->do_stereo_fade) { stereo_fade_lanes(L, frame_size); wv_sync(); }
    {  /* celt_maxabs over the head and the overlap tail of the frame (celt_encoder.c:1970-1973), at the API rate */
-      const WV_LDS i16 *p = L->A.pcm16;
+      const WV_LDS i16 *p = L->BC.stage16;
+      i16 *gp = L->g->pcm16;
       const int Nf = frame_size, ov = overlap / (sh->upsample > 1 ? sh->upsample : 1);
       i32 a = 0, b = 0;
-      FOR_LANES(i, CC * (Nf - ov)) a = imax(a, iabs((i32)p[i]));
-      FOR_LANES(i, CC * ov) b = imax(b, iabs((i32)p[CC * (Nf - ov) + i]));
+      FOR_LANES(i, CC * (Nf - ov)) { a = imax(a, iabs((i32)p[i])); gp[i] = p[i]; }                        /* ... and out to the HBM staging the CELT front end reads */
+      FOR_LANES(i, CC * ov) { b = imax(b, iabs((i32)p[CC * (Nf - ov) + i])); gp[CC * (Nf - ov) + i] = p[CC * (Nf - ov) + i]; }
       a = wv_max(a); b = wv_max(b);
       LANE0 { sh->r[0] = a; sh->r[1] = b; }
    }

@@ -181,7 +181,7 @@ WV_DEVN void opus_layer_frame(WV_LDS FrameLds *L, const OaEncConfig *cfg, int fr
  * only the 3-operation chain (mem) is serial. */
 WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int channels)
 {
-   WV_LDS i16 *io = L->A.pcm16;
+   WV_LDS i16 *io = L->BC.stage16;
    FOR_LANES(i, len * channels) io[i] = pcm[i];
    wv_sync();
    int c = wv_lane();
@@ -213,7 +213,7 @@ WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int cha
 /* stereo_fade (:548): the cross-fade covers overlap = 120 * Fs / 48000 samples, the window is read with stride 48000 / Fs */
 WV_DEV void stereo_fade_lanes(WV_LDS FrameLds *L, int frame_size)
 {
-   WV_LDS i16 *io = L->A.pcm16;
+   WV_LDS i16 *io = L->BC.stage16;
    const int inc = L->sh.upsample > 1 ? L->sh.upsample : 1, overlap = OA_OVERLAP / inc;
    i16 g1 = (i16)(Q15ONE - L->sh.fade_g1), g2 = (i16)(Q15ONE - L->sh.fade_g2);
    FOR_LANES(i, frame_size) {
@@ -308,7 +308,7 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L, int hyb_bytes = 0)
 /* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
  * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
  * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
-struct PreSrc { const i32 *hist; const WV_LDS i16 *pcm; int CC, c; i32 mem0; int up; };
+struct PreSrc { const i32 *hist; const i16 *pcm; int CC, c; i32 mem0; int up; };
 WV_DEV i32 pre_at(const PreSrc &p, int j)
 {
    if (j < OA_MAX_PERIOD) return p.hist[j];

@@ -1,14 +1,18 @@
-/* celt_enc_lds.h — per-wavefront LDS working set of the CELT frame encoder (one wave = one stream-frame).
+/* celt_enc_lds.h — per-wavefront working set of the CELT frame encoder (one wave = one stream-frame).
  *
- * Two big phase-aliased regions:
- *   A  (7,680 B)  dc-rejected int16 PCM (the unfiltered pre-emphasised signal is recomputed from it on the fly)
- *                 -> from the MDCT on: spectrum freq/X[2][960]; the FFT runs in place in its channel's half
- *   BC (7,840 B)  tone/transient int16 buffers | pitch buffers | comb-filtered input in[2][960] (until the last MDCT)
- *                 | tf_analysis / coarse-energy rollback scratch | PVQ: folding memory norm[624] (+ norm2 for
- *                 dual stereo, or the theta-RDO save slots: the two are mutually exclusive) + band scratch
- * Not in LDS: the 2x1024-sample pitch history and the 2x120 overlap memory (read from the stream's HBM record where
- * needed, rewritten in place) and the theta-RDO byte journal (per-stream HBM scratch).
- * Total < 20,480 B/wave -> 8 waves per CU (160 KB LDS) = 2 per SIMD, the VGPR limit. */
+ * LDS holds what lane-0 serial code and the in-place transforms touch; the bulk arrays that only lane-parallel, coalesced passes touch live in a
+ * per-stream HBM scratch record (CeltScratch, L2/MALL-resident while the frame is in flight):
+ *   HBM  pcm16[2][960]   dc-rejected int16 input (the unfiltered pre-emphasised signal is recomputed from it on the fly)
+ *        in[2][960]      comb-filtered new input, read once by every MDCT of the frame
+ *        X[2][960]       spectrum: freq, normalised in place; the PVQ stages one band at a time into LDS
+ *        theta-RDO save slots of the second trial
+ *   LDS  one phase-aliased region BC (7,136 B): dc_reject staging | tone/transient int16 buffers | pitch buffers | MDCT work buffer of ONE channel
+ *        (FFT in place, band energies taken before the channel is written out) | tf_analysis trial buffers | coarse-energy rollback |
+ *        both channels' coded bins [2][800] for the spreading / stereo / trim analyses | PVQ: band staging + folding memory norm[624] (+ norm2 for
+ *        dual stereo) + band scratch
+ * Also not in LDS: the 2x1024-sample pitch history and the 2x120 overlap memory (read from the stream's HBM record where needed, rewritten in place)
+ * and the theta-RDO byte journal (the stream's still-unwritten output slot).
+ * Total < 12,800 B/wave (10 allocation granules of 1,280 B) -> 12 waves per CU (160 KB LDS) = 3 per SIMD, matched by __launch_bounds__(64, 3). */
 #ifndef OPUS_AMD_CELT_ENC_LDS_H
 #define OPUS_AMD_CELT_ENC_LDS_H
 
@@ -40,10 +44,16 @@ struct FrameShared {
    i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
 };
 
-struct PvqScratch {                  /* band scratch during the PVQ phase */
-   i32 lowband_scratch[176], iy[176 + 8], Y_save2[176], norm_save2[176];
-};
 #define OA_NORM_LEN 624              /* 8 * eBands[20]: folding memory never extends into the last band */
+#define OA_MAX_BAND 176              /* widest band: 8 * (eBands[21] - eBands[20]) */
+#define OA_CODED_BINS 800            /* 8 * eBands[21] */
+
+struct CeltScratch {                 /* per-stream HBM scratch of one frame in flight (nothing in it survives the frame) */
+   i16 pcm16[2 * OA_MAX_FRAME];
+   i32 in[2][OA_MAX_FRAME];
+   i32 X[2 * OA_MAX_FRAME];
+   i32 X_save2[OA_MAX_BAND], Y_save2[OA_MAX_BAND], norm_save2[OA_MAX_BAND];
+};
 
 struct FrameLds {
    EcCtx ec;
@@ -51,6 +61,7 @@ struct FrameLds {
    EcCtx ecsave[2];
    FrameShared sh;
    OaEncScalars st;
+   CeltScratch *g;                    /* this frame's HBM scratch */
    i32 bandE[2 * NBE], bandLogE[2 * NBE], bandLogE2[2 * NBE], error[2 * NBE];
    i32 oldBandE[2 * NBE], energyError[2 * NBE];
    i32 offsets[NBE], importance[NBE], spread_weight[NBE], tf_res[NBE], pulses[NBE], fine_quant[NBE], fine_priority[NBE], cap[NBE];
@@ -62,20 +73,22 @@ struct FrameLds {
 #endif
    u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* packet[0] = TOC, range coder buffer = packet+1 */
-   union {                            /* A: int16 input until the MDCT, then the spectrum */
-      i16 pcm16[2 * OA_MAX_FRAME];                                     /* dc-rejected input, interleaved */
-      struct { i32 X[2 * OA_MAX_FRAME]; } s;
-   } A;
    union {                            /* BC: phase scratch */
+      i16 stage16[2 * OA_MAX_FRAME];                                   /* dc_reject: the per-channel recursion runs here, the result goes to g->pcm16 */
       i16 x16[2][OA_MAX_FRAME + OA_OVERLAP + 8];                        /* tone detector / transient detector */
       struct { i16 pitch_buf[992 + 8]; i16 x_lp4[240 + 8]; i16 y_lp4[496 + 8]; union { i32 xcorr[488 + 8]; i32 yy_lookup[514 + 6]; } u; } p;
-      i32 in[2][OA_MAX_FRAME];                                         /* comb-filtered new input (the 120-sample head is in_mem in HBM) */
-      i32 tf[2 * 800];                                                 /* tf_analysis trial buffers */
+      i32 W[OA_MAX_FRAME];                                             /* MDCT of one channel, in place */
+      i32 tf[2 * OA_CODED_BINS];                                       /* tf_analysis trial buffers */
       u8 coarse_save[OA_MAX_PACKET + 4];                               /* two-pass coarse energy rollback */
+      i32 xs[2][OA_CODED_BINS];                                        /* normalised coded bins of both channels: spreading_decision / stereo_analysis / alloc_trim */
       struct {
          i32 norm[OA_NORM_LEN];
-         union { i32 norm2[OA_NORM_LEN]; struct { i32 X_save[176], Y_save[176], X_save2[176]; } r; } u;
-         PvqScratch pvq;
+         i32 Xb[OA_MAX_BAND];                                          /* the band being coded (channel 0 / the mid) */
+         union { i32 norm2[OA_NORM_LEN]; i32 Yb[OA_MAX_BAND]; } u;     /* dual stereo: second folding memory; otherwise the band of channel 1 (never both: after the switch at the intensity band norm2 is dead) */
+         i32 lowband_scratch[OA_MAX_BAND];
+#ifdef K_DUMP_ENABLED
+         i32 iy[OA_MAX_BAND + 8];                                      /* stage dumps of the test build only */
+#endif
       } q;
    } BC;
 };

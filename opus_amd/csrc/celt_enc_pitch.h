@@ -325,7 +325,7 @@ WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperio
 
 /* comb_filter (celt.c:238) out of place: y[i] from the *unfiltered* signal (PreSrc, index 0 = first new sample), so all
  * outputs are independent */
-WV_DEV void comb_filter_wave(WV_LDS i32 *y, const PreSrc &p, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
+WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
 {
    const i16 gains[3][3] = {
       {QC16(0.3066406250f, 15), QC16(0.2170410156f, 15), QC16(0.1296386719f, 15)},
@@ -362,7 +362,7 @@ WV_DEV void comb_filter_wave(WV_LDS i32 *y, const PreSrc &p, int T0, int T1, int
 #undef XA
 }
 
-/* run_prefilter (celt_encoder.c:1405).  Writes the comb-filtered new input to BC.in[c][0..N) (its 120-sample head stays
+/* run_prefilter (celt_encoder.c:1405).  Writes the comb-filtered new input to g->in[c][0..N) (HBM scratch) (its 120-sample head stays
  * in_mem in HBM until the last MDCT of the frame has consumed it: store_in_mem_wave); rewrites prefilter_mem in HBM. */
 WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSrc &ps0, const PreSrc &ps1, int enabled)
 {
@@ -370,6 +370,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
    WV_LDS OaEncScalars *st = &L->st;
    const int CC = sh->CC, N = sh->N, overlap = OA_OVERLAP, max_period = OA_MAX_PERIOD, min_period = OA_MIN_PERIOD;
    const int prefilter_tapset = st->tapset_decision;
+   CeltScratch *G = L->g;
    int pitch_index, pf_on, qg;
    i16 gain1, pf_threshold;
    i16 tone_freq = (i16)sh->tone_freq;
@@ -427,11 +428,11 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
    }
    wv_sync();                    /* the pitch buffers (aliased with in[]) are dead from here */
    for (int c = 0; c < CC; c++)
-      comb_filter_wave(L->BC.in[c], c ? ps1 : ps0, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
+      comb_filter_wave(G->in[c], c ? ps1 : ps0, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
    wv_sync();
    for (int c = 0; c < CC; c++) {
       i32 a = 0;
-      FOR_LANES(i, N) a += iabs(L->BC.in[c][i] >> 12);
+      FOR_LANES(i, N) a += iabs(G->in[c][i] >> 12);
       after[c] = wv_sum(a);
    }
    int cancel_pitch = 0;
@@ -446,11 +447,11 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       wv_sync();
       for (int c = 0; c < CC; c++) {
          const PreSrc &ps = c ? ps1 : ps0;
-         FOR_LANES(i, N) L->BC.in[c][i] = pre_at(ps, max_period + i);
+         FOR_LANES(i, N) G->in[c][i] = pre_at(ps, max_period + i);
       }
       wv_sync();
       for (int c = 0; c < CC; c++)
-         comb_filter_wave(L->BC.in[c], c ? ps1 : ps0, old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
+         comb_filter_wave(G->in[c], c ? ps1 : ps0, old_period, pitch_index, overlap, (i16)-old_gain, 0, old_tapset, prefilter_tapset, overlap);
       gain1 = 0; pf_on = 0; qg = 0;
    }
    wv_sync();
@@ -478,7 +479,8 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
 WV_DEV void store_in_mem_wave(WV_LDS FrameLds *L, OaEncState *gst)
 {
    const int CC = L->sh.CC, N = L->sh.N, overlap = OA_OVERLAP;
-   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) gst->in_mem[c * overlap + i] = L->BC.in[c][N - overlap + i]; }
+   const CeltScratch *G = L->g;
+   for (int c = 0; c < CC; c++) { FOR_LANES(i, overlap) gst->in_mem[c * overlap + i] = G->in[c][N - overlap + i]; }
    wv_sync();
 }
 #endif

@@ -411,7 +411,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
       cm = wv_or(m);
    }
 #ifdef K_DUMP_ENABLED
-   { WV_LDS i32 *iy = L->BC.q.pvq.iy; wv_sync(); for (int t = 0; t < NR; t++) if (lane + 64 * t < N) iy[lane + 64 * t] = q[t]; wv_sync(); K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K); }
+   { WV_LDS i32 *iy = L->BC.q.iy; wv_sync(); for (int t = 0; t < NR; t++) if (lane + 64 * t < N) iy[lane + 64 * t] = q[t]; wv_sync(); K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K); }
 #endif
    encode_pulses_regs(L, q, N, K);
    K_TOC(18);
@@ -850,10 +850,11 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
    shortBlocks = wv_uni(shortBlocks); spread = wv_uni(spread); dual_stereo = wv_uni(dual_stereo); intensity = wv_uni(intensity); total_bits = wv_uni(total_bits);
    balance = wv_uni(balance); codedBands = wv_uni(codedBands); complexity = wv_uni(complexity); disable_inv = wv_uni(disable_inv);
    const int start = wv_uni(L->sh.start), end = wv_uni(L->sh.end), LM = wv_uni(L->sh.LM), C = wv_uni(L->sh.C), Nfull = wv_uni(L->sh.N);
-   WV_LDS i32 *X_ = L->A.s.X, *Y_ = C == 2 ? L->A.s.X + Nfull : 0;
-   WV_LDS PvqScratch *P = &L->BC.q.pvq;
-   WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.u.norm2;     /* norm2 (dual stereo) aliases the theta-RDO slots: never both */
-   WV_LDS i32 *X_save = L->BC.q.u.r.X_save, *Y_save = L->BC.q.u.r.Y_save, *X_save2 = L->BC.q.u.r.X_save2;
+   CeltScratch *G = L->g;
+   const i32 *X_ = G->X, *Y_ = C == 2 ? G->X + Nfull : 0;           /* the spectrum stays in HBM; the band being coded is staged into Xb / Yb */
+   WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.u.norm2;
+   WV_LDS i32 *const X = L->BC.q.Xb, *const Yb = L->BC.q.u.Yb;
+   i32 *X_save2 = G->X_save2, *Y_save2 = G->Y_save2, *norm_save2 = G->norm_save2;
    WV_LDS u8 *collapse_masks = L->collapse_masks;
    const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
    i32 remaining_bits;
@@ -861,7 +862,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
    int norm_offset = M * ct_eBands[start];
    int theta_rdo = Y_ != 0 && !dual_stereo && complexity >= 8;
    int resynth = theta_rdo;
-   WV_LDS i32 *lowband_scratch = P->lowband_scratch;
+   WV_LDS i32 *lowband_scratch = L->BC.q.lowband_scratch;
    BandCfg cfg;
    u32 seed = (u32)wv_uni((i32)L->st.rng);
    i32x4 r;
@@ -870,12 +871,12 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
    for (int i = start; i < end; i++) {
       i32 tell, curr_balance;
       int b, N, effective_lowband = -1, tf_change = 0, last;
-      WV_LDS i32 *X, *Y;
+      WV_LDS i32 *Y;
       unsigned x_cm, y_cm;
       cfg.i = i;
       last = (i == end - 1);
-      X = X_ + M * ct_eBands[i];
-      Y = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
+      const i32 *Xg = X_ + M * ct_eBands[i], *Yg = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
+      Y = Y_ != 0 ? Yb : 0;
       N = M * ct_eBands[i + 1] - M * ct_eBands[i];
       wv_sync();
       tell = wv_uni(ec_tell_frac_lds(&L->ec));
@@ -909,6 +910,9 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
          dual_stereo = 0;
          if (resynth) { wv_sync(); FOR_LANES(j, M * ct_eBands[i] - norm_offset) norm[j] = half32(norm[j] + norm2[j]); wv_sync(); }
       }
+      /* stage the band: in dual stereo the two channels are coded one after the other through Xb (Yb's bytes hold norm2) */
+      FOR_LANES(j, N) { X[j] = Xg[j]; if (Yg != 0 && !dual_stereo) Yb[j] = Yg[j]; }
+      wv_sync();
       WV_LDS i32 *lb = effective_lowband != -1 ? norm + effective_lowband : 0;
       WV_LDS i32 *lb2 = effective_lowband != -1 ? norm2 + effective_lowband : 0;
       WV_LDS i32 *lbo = last ? 0 : norm + M * ct_eBands[i] - norm_offset;
@@ -916,7 +920,10 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       if (dual_stereo) {
          r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
          x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
+         wv_sync();
+         FOR_LANES(j, N) X[j] = Yg[j];
+         wv_sync();
+         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
          y_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       } else {
          if (Y != 0) {
@@ -930,24 +937,23 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                K_TIC();
                wv_sync();
                LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
-               FOR_LANES(j, N) { X_save[j] = X[j]; Y_save[j] = Y[j]; }
-               wv_sync();
+               wv_sync();                                                   /* (the untouched band is the spectrum in HBM: nothing to save) */
                cfg.theta_round = -1;
                K_TOC(21);
                r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
                cm2 = (unsigned)wv_uni(r[0]); rem1 = wv_uni(r[1]); seed1 = (u32)wv_uni(r[2]);
                K_TOC(24);
                wv_sync();
-               dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
+               dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_gw(Xg, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_gw(Yg, Y, N));
                LANE0 ec_cp_lds(&L->ecsave[1], &L->ec);
-               FOR_LANES(j, N) { X_save2[j] = X[j]; P->Y_save2[j] = Y[j]; if (!last) P->norm_save2[j] = lbo[j]; }
+               FOR_LANES(j, N) { X_save2[j] = X[j]; Y_save2[j] = Y[j]; if (!last) norm_save2[j] = lbo[j]; }
                const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
                WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
                const int save_bytes = nend_bytes - nstart_bytes;
                FOR_LANES(j, save_bytes) journal[j] = bytes_buf[j];         /* trial-1 byte journal -> per-stream HBM scratch */
                wv_sync();
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
-               FOR_LANES(j, N) { X[j] = X_save[j]; Y[j] = Y_save[j]; }
+               FOR_LANES(j, N) { X[j] = Xg[j]; Y[j] = Yg[j]; }
                wv_sync();
                cfg.theta_round = 1;
                K_TOC(21);
@@ -955,12 +961,12 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
                K_TOC(24);
                wv_sync();
-               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_w(X_save, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_w(Y_save, Y, N));
+               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_gw(Xg, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_gw(Yg, Y, N));
                if (dist0 >= dist1) {
                   x_cm = cm2; remaining_bits = rem1; seed = seed1;
                   wv_sync();
                   LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
-                  FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = P->Y_save2[j]; if (!last) lbo[j] = P->norm_save2[j]; }
+                  FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = Y_save2[j]; if (!last) lbo[j] = norm_save2[j]; }
                   FOR_LANES(j, save_bytes) bytes_buf[j] = journal[j];
                   wv_sync();
                }

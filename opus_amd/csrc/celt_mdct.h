@@ -142,11 +142,11 @@ WV_DEV void fft_forward(WV_LDS i32 *data, int idx, int nblk, WV_LDS int *remaini
 }
 
 /* Forward MDCTs of one channel: B transforms of N2 = (960>>shift) output bins each.  The channel's time signal is
- * [head | body]: the first `overlap` samples (last frame's filtered tail, in_mem) come from HBM, the rest from LDS;
+ * [head | body]: the first `overlap` samples (last frame's filtered tail, in_mem) come from the stream's HBM record, the rest (this frame's comb-filtered input) from the HBM scratch;
  * input block b starts at sample b*N2 (N2+overlap samples); output bin k of block b goes to out[b + k*B] (interleaved,
  * stride B).  The complex FFT runs IN PLACE in out[] (B*N2 words); the post-rotation gathers every result into
  * registers before the first scattered store.  aux: >= 2*8 ints. */
-WV_DEV void mdct_forward_blocks(const i32 *head, const WV_LDS i32 *body, WV_LDS i32 *out, int shift, int B, WV_LDS int *aux)
+template <class BodyPtr> WV_DEV void mdct_forward_blocks(const i32 *head, BodyPtr body, WV_LDS i32 *out, int shift, int B, WV_LDS int *aux)
 {
    const int N = 1920 >> shift, N2 = N >> 1, N4 = N >> 2, overlap = OA_OVERLAP;
    const int trig_off = shift == 0 ? 0 : (shift == 1 ? 960 : (shift == 2 ? 1440 : 1680));

@@ -32,19 +32,30 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #include <mutex>
 #include <vector>
 
+/* The encoder kernels are persistent: the launch fills the chip once (grid = resident waves, opusgpu host code), every wave pops stream indices from a
+ * device-side queue until it is empty.  Streams cost different amounts (transients, VBR), so the queue balances what a static blockIdx -> stream map
+ * cannot, and the bulk scratch of a frame (CeltScratch) belongs to the wave, not the stream: grid x 21 KB that stays in the XCD's L2 / the MALL instead
+ * of streams x 21 KB streaming through HBM. */
+WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (int)atomicAdd(queue, 1u); return wv_bcast(s, 0); }
+
 #ifndef OA_ENC_WAVES_PER_EU
-#define OA_ENC_WAVES_PER_EU 2
+#define OA_ENC_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
-oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
+oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
-   const int s = blockIdx.x;
-   if (s >= nstreams) return;
-   OaStream *gs = streams + s;
-   const int ch = gs->cfg.channels;
-   oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s);
+   for (;;) {
+      const int s = oa_queue_pop(queue);
+      if (s >= nstreams) break;
+      if (threadIdx.x == 0) L->g = scratch + blockIdx.x;
+      __syncthreads();
+      OaStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s);
+      __syncthreads();
+   }
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2)
@@ -58,19 +69,24 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
    oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
 }
 
-/* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream, SILK state staged in LDS */
+/* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
+ * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave */
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i16 *pcm_hp, i32 *lens, u32 *rngs, int nstreams)
+oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
-   const int s = blockIdx.x;
-   if (s >= nstreams) return;
-   OaShStream *gs = streams + s;
-   const int ch = gs->cfg.channels;
-   char *scr = (char *)pcm_hp + (size_t)s * SH_SCRATCH_BYTES(frame_size, ch);
-   oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
-         (SeRateScratch *)(scr + SH_SCRATCH_BYTES(frame_size, ch) - sizeof(SeRateScratch)), lens + s, rngs + s);
+   for (;;) {
+      const int s = oa_queue_pop(queue);
+      if (s >= nstreams) break;
+      OaShStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
+      char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
+      oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
+            (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s);
+      __syncthreads();
+   }
 }
 
 /* masking analysis of the surround multistream encoder: one wave per input channel (opus_surround.h) */
@@ -91,20 +107,24 @@ oa_pack_kernel(const u8 *out, int stride, const i32 *lens, const long long *offs
    const u8 *src = out + (size_t)s * stride; u8 *dst = packed + offs[s];
    for (int i = threadIdx.x; i < len; i += 64) dst[i] = src[i];
 }
-/* T consecutive frame-steps of every stream in one launch: the wave keeps its stream for T frames (pcm [T][S][frame*ch], out [T][S][stride], lens / rngs [T][S]) */
-extern "C" __global__ void __launch_bounds__(64, 2)
-oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams)
+/* T consecutive frame-steps of every stream in one launch: the wave keeps a stream for T frames (pcm [T][S][frame*ch], out [T][S][stride], lens / rngs [T][S]) */
+extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
+oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
-   const int s = blockIdx.x;
-   if (s >= nstreams) return;
-   OaStream *gs = streams + s;
-   const int ch = gs->cfg.channels;
-   for (int t = 0; t < T; t++) {
-      const size_t row = (size_t)t * nstreams + s;
-      oa_encode_frame(L, gs, pcm + row * frame_size * ch, frame_size, max_data_bytes, out + row * out_stride, out_stride, lens + row, rngs + row);
-      __syncthreads();
+   for (;;) {
+      const int s = oa_queue_pop(queue);
+      if (s >= nstreams) break;
+      OaStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      for (int t = 0; t < T; t++) {
+         const size_t row = (size_t)t * nstreams + s;
+         if (threadIdx.x == 0) L->g = scratch + blockIdx.x;
+         __syncthreads();
+         oa_encode_frame(L, gs, pcm + row * frame_size * ch, frame_size, max_data_bytes, out + row * out_stride, out_stride, lens + row, rngs + row);
+         __syncthreads();
+      }
    }
 }
 
@@ -133,7 +153,9 @@ struct OpusGpuEncBatch {
    opus_int32 Fs; int application;
    OaShStream *d_sh;
    std::vector<OaShStream> h_sh;
-   opus_int16 *d_pcm_hp; size_t hp_cap; /* per-stream scratch of the high-passed input (kind 1) */
+   char *d_scratch; size_t scratch_cap;  /* per-wave HBM scratch of the frames in flight (CeltScratch; kind 1: SH_SCRATCH_BYTES) */
+   unsigned *d_queue;                    /* the launch's stream queue (next unclaimed stream) */
+   int num_cu;
    int device;
    opus_int32 S;
    int channels;
@@ -178,7 +200,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
-      b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_pcm_hp = nullptr; b->hp_cap = 0;
+      b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -189,6 +211,8 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_streams, sizeof(OaStream) * (size_t)(kind ? 1 : nstreams)) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess &&
+                hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 (kind || hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess) &&
                 hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       if (!ok) { opusgpu_enc_batch_destroy(b); b = nullptr; err = OPUS_ALLOC_FAIL; }
@@ -204,7 +228,8 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->stream) (void)hipStreamSynchronize(b->stream);
    if (b->d_streams) (void)hipFree(b->d_streams);
    if (b->d_sh) (void)hipFree(b->d_sh);
-   if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
+   if (b->d_scratch) (void)hipFree(b->d_scratch);
+   if (b->d_queue) (void)hipFree(b->d_queue);
    if (b->d_pcm) (void)hipFree(b->d_pcm);
    if (b->d_out) (void)hipFree(b->d_out);
    if (b->d_lens) (void)hipFree(b->d_lens);
@@ -285,6 +310,23 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
 int opusgpu_enc_batch_reset(OpusGpuEncBatch *b) { return opusgpu_enc_batch_ctl(b, -1, OPUS_RESET_STATE, 0); }
 int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
 
+/* grid of a persistent encoder launch = the waves the chip holds at this kernel's register / LDS footprint (never more than there are streams); makes sure the
+ * per-wave scratch covers it and resets the stream queue on the launch's HIP stream */
+static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds_bytes, size_t scratch_per_wave, hipStream_t s, int *grid_out)
+{
+   int per_cu = 0;
+   HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds_bytes));
+   if (per_cu < 1) per_cu = 1;
+   long long grid = (long long)per_cu * (b->num_cu > 0 ? b->num_cu : 1);
+   static const int grid_env = getenv("OPUS_AMD_GRID") ? atoi(getenv("OPUS_AMD_GRID")) : 0;                 /* experiments only */
+   if (grid_env > 0) grid = grid_env;
+   if (grid > b->S) grid = b->S;
+   const size_t need = (size_t)grid * scratch_per_wave;
+   if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
+   HIPCHECK(hipMemsetAsync(b->d_queue, 0, sizeof(unsigned), s));
+   *grid_out = (int)grid;
+   return OPUS_OK;
+}
 int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
@@ -295,8 +337,6 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    if (b->kind) {
-      const size_t need = (size_t)b->S * SH_SCRATCH_BYTES(frame_size, b->channels);
-      if (need > b->hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->hp_cap = need; }
       /* a launch whose streams are all pinned to the SILK layer (RESTRICTED_SILK, or OPUS_SET_FORCE_MODE(SILK_ONLY) with >= 10 ms frames at <= wideband) never enters the
        * CELT arena and gets the smaller LDS footprint (one more wave per CU) */
       if (b->cfg_dirty) {
@@ -308,14 +348,19 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
          b->all_silk_pinned = pinned; b->cfg_dirty = false;
       }
       const int silk_only = b->all_silk_pinned && frame_size >= b->Fs / 100;
-      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)b->S), dim3(64), sh_lds_bytes(b->channels, silk_only), s,
-            b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i16 *)b->d_pcm_hp, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+      const size_t lds = sh_lds_bytes(b->channels, silk_only);
+      int grid = 0;
+      { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds, s,
+            b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, b->d_queue);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }
    static const size_t lds_pad = getenv("OPUS_AMD_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_LDS_PAD")) : 0;   /* occupancy experiments only */
-   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+   int grid = 0;
+   { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
+   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
+         b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, (CeltScratch *)b->d_scratch, b->d_queue);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -346,8 +391,10 @@ int opusgpu_encode_batch_dev_frames(OpusGpuEncBatch *b, const opus_int16 *d_pcm,
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    HIPCHECK(hipFuncSetAttribute((const void *)oa_encode_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-   hipLaunchKernelGGL(oa_encode_frames_kernel, dim3((unsigned)b->S), dim3(64), sizeof(FrameLds), s,
-         b->d_streams, (const i16 *)d_pcm, frame_size, T, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S);
+   int grid = 0;
+   { const int r = oa_persistent_grid(b, (const void *)oa_encode_frames_kernel, sizeof(FrameLds), sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
+   hipLaunchKernelGGL(oa_encode_frames_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds), s,
+         b->d_streams, (const i16 *)d_pcm, frame_size, T, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, (CeltScratch *)b->d_scratch, b->d_queue);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }

@@ -45,14 +45,15 @@ struct ShLds {
    OaShScalars st;
    OaShConfig cfg;
    MfLds mf;
+   CeltScratch *cs;                                      /* the stream's HBM scratch of the CELT passes (celt_enc_lds.h) */
    u8 packet[OA_MAX_PACKET + 4];
    SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
 #define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
 /* per-stream HBM scratch: the high-passed input of the frame, the faded CELT input of the frame (only written when a frame needs more than one CELT pass),
- * the 2.5 ms CELT prefill, then the rate-loop snapshots */
+ * the 2.5 ms CELT prefill, the CELT passes' bulk arrays (CeltScratch), then the rate-loop snapshots */
 #define SH_PCM_BYTES(frame_size, channels) (((size_t)(frame_size) * (channels) * 2 + 63) / 64 * 64)
-#define SH_SCRATCH_BYTES(frame_size, channels) (2 * SH_PCM_BYTES(frame_size, channels) + 512 + sizeof(SeRateScratch))
+#define SH_SCRATCH_BYTES(frame_size, channels) (2 * SH_PCM_BYTES(frame_size, channels) + 512 + sizeof(CeltScratch) + sizeof(SeRateScratch))
 #define SH_STAGE_SAMPLES 1920
 
 WV_DEV i32 sh_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int mode, int complexity, int loss)      /* compute_equiv_rate :780 */
@@ -360,6 +361,7 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
    const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
    FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
    FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = gs->celt.oldBandE[i]; F->energyError[i] = gs->celt.energyError[i]; }
+   if (wv_lane() == 0) F->g = L->cs;
    wv_sync();
 }
 WV_DEV void sh_leave_celt(WV_LDS ShLds *L, OaShStream *gs)
@@ -401,7 +403,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
 #define SH_CELT_DISABLE_PF(F) ((F)->st.pad0[0])
 #define SH_CELT_FORCE_INTRA(F) ((F)->st.pad0[1])
 
-/* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in F->A.pcm16).
+/* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in the HBM scratch F->g->pcm16).
  *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in L->packet (hybrid), or starting it (CELT-only frame)
  *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
 struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
@@ -412,11 +414,11 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    WV_LDS FrameShared *fs = &F->sh;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, up = 48000 / Fs;
    wv_sync();
-   if (src) { FOR_LANES(i, nsamp * CC) F->A.pcm16[i] = src[i]; }
+   if (src) { i16 *dst = F->g->pcm16; FOR_LANES(i, nsamp * CC) dst[i] = src[i]; }
    if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i]; }
    wv_sync();
    {  /* celt_maxabs over the head and the overlap tail of the input (celt_encoder.c:1970-1973), at the API rate */
-      const WV_LDS i16 *p = F->A.pcm16;
+      const i16 *p = F->g->pcm16;
       const int ov = OA_OVERLAP / up;
       i32 a = 0, b = 0;
       FOR_LANES(i, CC * (nsamp - ov)) a = imax(a, iabs((i32)p[i]));
@@ -449,8 +451,8 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    wv_sync();
 }
 
-/* gain_fade (:581) / stereo_fade (:548) on `n` frames of CC interleaved int16 in LDS; the cross-fade covers overlap = 120 * Fs / 48000 samples, window read with stride inc */
-WV_DEV void sh_gain_fade_lds(WV_LDS i16 *io, int n, int CC, i16 g1, i16 g2, int Fs)
+/* gain_fade (:581) / stereo_fade (:548) on `n` frames of CC interleaved int16 (LDS staging or HBM scratch); the cross-fade covers overlap = 120 * Fs / 48000 samples, window read with stride inc */
+template <class P16> WV_DEV void sh_gain_fade_lds(P16 io, int n, int CC, i16 g1, i16 g2, int Fs)
 {
    const int inc = 48000 / Fs, overlap = OA_OVERLAP / inc;
    FOR_LANES(i, n * CC) {
@@ -459,7 +461,7 @@ WV_DEV void sh_gain_fade_lds(WV_LDS i16 *io, int n, int CC, i16 g1, i16 g2, int 
       io[i] = (i16)mult16_16_q15(g, io[i]);
    }
 }
-WV_DEV void sh_stereo_fade_lds(WV_LDS i16 *io, int n, i16 g1_, i16 g2_, int Fs)
+template <class P16> WV_DEV void sh_stereo_fade_lds(P16 io, int n, i16 g1_, i16 g2_, int Fs)
 {
    const int inc = 48000 / Fs, overlap = OA_OVERLAP / inc;
    const i16 g1 = (i16)(Q15ONE - g1_), g2 = (i16)(Q15ONE - g2_);
@@ -670,7 +672,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    }
    /* pcm_buf = [delay tail | this frame] -> the CELT staging area (only when a CELT pass will read it), then the delay line moves on (:2304-2312) */
    if (need_celt) {
-      WV_LDS i16 *io = F->A.pcm16;
+      i16 *io = F->g->pcm16;
       FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
       wv_sync();
    }
@@ -686,7 +688,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
       }
    }
    if (need_celt) {
-      WV_LDS i16 *io = F->A.pcm16;
+      i16 *io = F->g->pcm16;
       if (sh->do_gain_fade) { sh_gain_fade_lds(io, frame_size, CC, (i16)sh->hb_g1, (i16)sh->hb_g2, Fs); wv_sync(); }
       if (sh->do_stereo_fade) { sh_stereo_fade_lds(io, frame_size, (i16)sh->fade_g1, (i16)sh->fade_g2, Fs); wv_sync(); }
       /* more than one CELT pass reads pcm_buf: keep it in the HBM scratch */
@@ -829,7 +831,7 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
    }
 }
 
-WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, i32 *len_out, u32 *rng_out)
+WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    SE_PHASE_START(&L->S);
@@ -843,7 +845,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       FOR_LANES(i, SE_STATE_WORDS(gs->cfg.channels)) d[i] = g[i];
    }
    wv_sync();
-   LANE0 sh->silk_in_lds = 1;
+   LANE0 { sh->silk_in_lds = 1; L->cs = cs; }
    SE_PHASE(&L->S, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));

@@ -55,8 +55,8 @@ extern "C" int emu_silk_encode(OaSilkEnc *st, int32_t *ctl, const int16_t *pcm, 
 }
 
 /* ---- the whole Opus-layer frame (opus_enc_sh.h) ---- */
-struct ShJob { SeRateScratch *G; ShLds *L; OaShStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int out_cap; int16_t *pcm_hp; int32_t *len; uint32_t *rng; };
-static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->G, j->len, j->rng); }
+struct ShJob { CeltScratch *cs; SeRateScratch *G; ShLds *L; OaShStream *gs; const int16_t *pcm; int frame_size, max_bytes; uint8_t *out; int out_cap; int16_t *pcm_hp; int32_t *len; uint32_t *rng; };
+static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->G, j->cs, j->len, j->rng); }
 extern "C" int emu_sh_stream_size() { return (int)sizeof(OaShStream); }
 extern "C" int emu_sh_lds_size() { return (int)sizeof(ShLds); }
 extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int application) { oa_sh_stream_init(st, Fs, channels, application); }
@@ -67,7 +67,8 @@ extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size
    memset(L, 0xA5, sizeof(ShLds));
    int16_t *hp = (int16_t *)malloc(2 * SH_PCM_BYTES(frame_size, 2) + 512);          /* high-passed frame | faded CELT input | 2.5 ms CELT prefill */
    SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
-   ShJob j = {G, L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
+   CeltScratch *cs = (CeltScratch *)malloc(sizeof(CeltScratch)); memset(cs, 0xA5, sizeof(CeltScratch));
+   ShJob j = {cs, G, L, st, pcm, frame_size, max_bytes, out, out_cap, hp, len, rng};
    emu_run_wave(shjob, &j);
-   free(hp); free(L); free(G);
+   free(hp); free(L); free(G); free(cs);
 }

@@ -13,6 +13,7 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
 typedef struct EmuStream_ *hipStream_t;
 typedef struct EmuEvent_ { std::chrono::steady_clock::time_point t; } *hipEvent_t;
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
@@ -53,6 +54,9 @@ static inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t s
 { for (size_t i = 0; i < h; i++) memmove((char *)d + i * dp, (const char *)s + i * sp, w); return hipSuccess; }
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return hipSuccess; }                                 /* a 2-CU, 2-waves-per-CU "chip": persistent launches get a grid of 4 */
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }                     /* fibers are cooperative: no race */
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent_; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
