@@ -241,12 +241,13 @@ def main():
         peak_meas = round(copy_bandwidth(dev), 1) if world == 1 else None
         def roof(r, Sn):
             ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
-            traffic = None
+            traffic = None; issue = None
             try:
-                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")))
-                traffic = int(pt["config_%d" % r["config_id"]]["hbm_bytes_per_frame"] * Sn)
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")))["config_%d" % r["config_id"]]
+                traffic = int(pt["hbm_bytes_per_frame"] * Sn)
+                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (PMC passes of this build)"}
             except Exception: pass
-            return {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
+            return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
                     "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),
                     "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"],
                     "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)"}

@@ -180,7 +180,8 @@ WV_DEVN void dynalloc_analysis_l0(WV_LDS FrameLds *L)
    const int vbr = sh->vbr, constrained_vbr = sh->constrained_vbr, effectiveBytes = sh->effectiveBytes;
    const WV_LDS i32 *bandLogE = L->bandLogE, *bandLogE2 = L->bandLogE2, *oldBandE = L->oldBandE;
    WV_LDS i32 *offsets = L->offsets, *importance = L->importance, *spread_weight = L->spread_weight;
-   WV_LDS i32 *follower = L->scr, *noise_floor = L->scr + 42, *bandLogE3 = L->scr + 63, *mask = L->scr + 84, *sig = L->scr + 105;
+   WV_LDS i32 *const big = L->BC.tf;      /* 126 words: more than scr holds; BC is idle between the last MDCT and tf_analysis */
+   WV_LDS i32 *follower = big, *noise_floor = big + 42, *bandLogE3 = big + 63, *mask = big + 84, *sig = big + 105;
    i32 tot_boost = 0, maxDepth = -GC(31.9f);
    for (int i = 0; i < NBE; i++) offsets[i] = 0;
    for (int i = 0; i < end; i++)

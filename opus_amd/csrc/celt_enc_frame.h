@@ -206,7 +206,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    FOR_LANES(w, C * NBE) {
       int c = w / NBE, i = w - c * NBE;
       if (i >= start && i < end && iabs(sub32(L->bandLogE[i + c * NBE], L->oldBandE[i + c * NBE])) < GC(2.f))
-         L->bandLogE[i + c * NBE] -= mult16_32_q15(QC16(0.25f, 15), L->energyError[i + c * NBE]);
+         L->bandLogE[i + c * NBE] -= mult16_32_q15(QC16(0.25f, 15), gst->energyError[i + c * NBE]);
    }
    wv_sync();
    K_PHASE(9);
@@ -361,7 +361,6 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, sh->codedBands));
       else st->lastCodedBands = sh->codedBands;
       k_quant_fine_energy(start, end, L->oldBandE, L->error, 0, L->fine_quant, EC_PASS, C);
-      for (int i = 0; i < NBE * CC; i++) L->energyError[i] = 0;
       EC_END;
    }
    wv_sync();
@@ -381,8 +380,6 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       const int nbCompressedBytes = sh->nbCompressedBytes, isTransient = sh->isTransient, silence = sh->silence;
       if (sh->anti_collapse_rsv > 0) k_ec_enc_bits(EC_PASS, st->consec_transient < 2, 1);
       k_quant_energy_finalise(start, end, L->oldBandE, L->error, L->fine_quant, L->fine_priority, nbCompressedBytes * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
-      for (int c = 0; c < C; c++)
-         for (int i = start; i < end; i++) L->energyError[i + c * NBE] = imax(-GC(0.5f), imin(GC(0.5f), L->error[i + c * NBE]));
       if (silence) for (int i = 0; i < C * NBE; i++) L->oldBandE[i] = -GC(28.f);
       st->prefilter_period = sh->pitch_index;
       st->prefilter_gain = (i16)sh->gain1;
@@ -421,7 +418,9 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
             if (bi < sh->start || bi >= sh->end) { l1 = l2 = -GC(28.f); }
             gst->oldLogE[i] = l1; gst->oldLogE2[i] = l2;
          }
-         gst->oldBandE[i] = L->oldBandE[i]; gst->energyError[i] = L->energyError[i];
+         gst->oldBandE[i] = L->oldBandE[i];
+         /* energyError (celt_encoder.c:2698-2741): cleared for the frame's CC channels, then the clamped residual of the coded bands; channels beyond CC keep theirs */
+         if (i < nb) { const int c = i / NBE, bi = i - c * NBE; gst->energyError[i] = c < sh->C && bi >= sh->start && bi < sh->end ? imax(-GC(0.5f), imin(GC(0.5f), L->error[i])) : 0; }
       }
    }
 }
@@ -503,7 +502,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       const i32 *g = (const i32 *)&gs->st.s;
       WV_LDS i32 *d = (WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->st.oldBandE[i]; L->energyError[i] = gs->st.energyError[i]; }
+      FOR_LANES(i, 2 * NBE) L->oldBandE[i] = gs->st.oldBandE[i];
    }
    wv_sync();
    const int CC = gs->cfg.channels;
@@ -546,7 +545,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
          staged += tmp_len - 1; tot_size += tmp_len;
       }
       if (err) result = err;
-      else { result = oa_multiframe_assemble_wave(&L->mf, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames); if (result < 0) result = -3; }
+      else { result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames); if (result < 0) result = -3; }
    }
    /* ---- store lengths + state (coalesced) ---- */
    {

@@ -12,7 +12,7 @@
  *        dual stereo) + band scratch
  * Also not in LDS: the 2x1024-sample pitch history and the 2x120 overlap memory (read from the stream's HBM record where needed, rewritten in place)
  * and the theta-RDO byte journal (the stream's still-unwritten output slot).
- * Total < 12,800 B/wave (10 allocation granules of 1,280 B) -> 12 waves per CU (160 KB LDS) = 3 per SIMD, matched by __launch_bounds__(64, 3). */
+ * Total = 10,240 B/wave (8 allocation granules of 1,280 B) -> 16 waves per CU (160 KB LDS) = 4 per SIMD, matched by __launch_bounds__(64, 4) (<= 128 VGPRs). */
 #ifndef OPUS_AMD_CELT_ENC_LDS_H
 #define OPUS_AMD_CELT_ENC_LDS_H
 
@@ -41,7 +41,7 @@ struct FrameShared {
    i32 Fs, call_bitrate, call_max_data_bytes, call_equiv_rate, cbr_bytes, nb_frames, enc_frame_size, repacketize_len, max_len_sum, is_silence, activity, no_pad;
    i32 use_dtx, nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize, lfe, energy_mask_on;        /* the tail of the stream record, staged */
    i32 surround_masking, surround_trim;   /* what the surround masks of the multistream layer contribute to the VBR target / the allocation trim (celt_encoder.c:2112-2186) */
-   i32 r[24];     /* small hand-off slots between lane-0 sections and parallel code */
+   i32 r[8];      /* small hand-off slots between lane-0 sections and parallel code */
 };
 
 #define OA_NORM_LEN 624              /* 8 * eBands[20]: folding memory never extends into the last band */
@@ -58,20 +58,27 @@ struct CeltScratch {                 /* per-stream HBM scratch of one frame in f
 struct FrameLds {
    EcCtx ec;
    MfLds mf;                          /* multi-frame packet assembly (opus_multiframe.h) */
-   EcCtx ecsave[2];
+   union {                            /* (anonymous unions: members whose lifetimes never overlap share their bytes, the names stay) */
+      EcCtx ecsave[2];                /* theta-RDO coder snapshots (PVQ phase) */
+      i32 aux[32];                    /* MDCT headroom/shift bookkeeping (MDCT phase) */
+   };
    FrameShared sh;
    OaEncScalars st;
    CeltScratch *g;                    /* this frame's HBM scratch */
-   i32 bandE[2 * NBE], bandLogE[2 * NBE], bandLogE2[2 * NBE], error[2 * NBE];
-   i32 oldBandE[2 * NBE], energyError[2 * NBE];
+   i32 bandE[2 * NBE], bandLogE[2 * NBE], oldBandE[2 * NBE];
+   union {
+      i32 bandLogE2[2 * NBE];         /* second-MDCT energies: last read by dynalloc_analysis */
+      i32 error[2 * NBE];             /* coarse-energy residual: first written by the coarse quantiser, after dynalloc_analysis */
+   };                                 /* (energyError is not staged: one coalesced read and one coalesced write of the HBM state) */
    i32 offsets[NBE], importance[NBE], spread_weight[NBE], tf_res[NBE], pulses[NBE], fine_quant[NBE], fine_priority[NBE], cap[NBE];
-   i32 surround_dynalloc[NBE];
-   i32 scr[6 * NBE];                  /* lane-0 scratch (allocation vectors, dynalloc followers, two-pass energies) */
-   i32 aux[32];                       /* MDCT headroom/shift bookkeeping, reductions hand-off */
+   union {
+      i32 surround_dynalloc[NBE];     /* surround masking boosts: last read by dynalloc_analysis */
+      u8 collapse_masks[2 * NBE + 6]; /* first written by the PVQ */
+   };
+   i32 scr[4 * NBE];                  /* lane-0 scratch while BC is fully occupied (tf metrics, spreading counts, allocation vectors); the larger users borrow BC */
 #ifdef OA_PHASE_TIMERS
    u32 prof[34], prof_t0;             /* shader-clock buckets of the profiling build, start of the open phase */
 #endif
-   u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* packet[0] = TOC, range coder buffer = packet+1 */
    union {                            /* BC: phase scratch */
       i16 stage16[2 * OA_MAX_FRAME];                                   /* dc_reject: the per-channel recursion runs here, the result goes to g->pcm16 */

@@ -39,7 +39,7 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (int)atomicAdd(queue, 1u); return wv_bcast(s, 0); }
 
 #ifndef OA_ENC_WAVES_PER_EU
-#define OA_ENC_WAVES_PER_EU 3
+#define OA_ENC_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
 oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)

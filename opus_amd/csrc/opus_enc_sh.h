@@ -360,7 +360,7 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
    WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
    const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
    FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
-   FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = gs->celt.oldBandE[i]; F->energyError[i] = gs->celt.energyError[i]; }
+   FOR_LANES(i, 2 * NBE) F->oldBandE[i] = gs->celt.oldBandE[i];
    if (wv_lane() == 0) F->g = L->cs;
    wv_sync();
 }
@@ -394,7 +394,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
       c->spread_decision = 2; c->delayedIntra = 1; c->tonal_average = 256;
       L->sh.silk_signalType = 0; L->sh.silk_offset = 0;                                  /* SILKInfo sits in the reset region too: the CELT passes after a reset see zeros until the next frame sets it */
    }
-   FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = 0; F->energyError[i] = 0; gs->celt.oldBandE[i] = 0; gs->celt.energyError[i] = 0; gs->celt.oldLogE[i] = gs->celt.oldLogE2[i] = -(28 << 24); }
+   FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = 0; gs->celt.oldBandE[i] = 0; gs->celt.energyError[i] = 0; gs->celt.oldLogE[i] = gs->celt.oldLogE2[i] = -(28 << 24); }
    FOR_LANES(i, 2 * OA_OVERLAP) gs->celt.in_mem[i] = 0;
    FOR_LANES(i, 2 * OA_MAX_PERIOD) gs->celt.prefilter_mem[i] = 0;
    wv_sync();
@@ -904,7 +904,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       wv_sync();
       if (err) result = err;
       else {
-         result = oa_multiframe_assemble_wave(&L->mf, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames);
+         result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames);
          if (result < 0) result = OA_ERR_INTERNAL;
       }
    }

@@ -13,12 +13,13 @@
 #define OA_MF_MAX_FRAMES 6
 #define OA_MF_HEADROOM 48            /* >= the largest header: 2 + 31 padding length bytes for 7.6 KB + 2 x 5 frame lengths */
 
-struct MfLds { i32 len[OA_MF_MAX_FRAMES]; i32 n, toc, total, hdr_len, err; u8 hdr[OA_MF_HEADROOM]; };
+struct MfLds { i32 len[OA_MF_MAX_FRAMES]; i32 n, toc, total, hdr_len, err; };
 
 WV_DEV int mf_put_length(WV_LDS u8 *dst, int n) { if (n < 252) { dst[0] = (u8)n; return 1; } dst[0] = (u8)(252 + (n & 3)); dst[1] = (u8)((n - (int)dst[0]) >> 2); return 2; }
 
-/* out[OA_MF_HEADROOM ...] holds M->n payloads of M->len[i] bytes back to back; result: the packet at out[0 .. return).  maxlen = repacketize_len, fill = pad to it. */
-WV_DEV int oa_multiframe_assemble_wave(WV_LDS MfLds *M, u8 *out, int maxlen, int fill)
+/* out[OA_MF_HEADROOM ...] holds M->n payloads of M->len[i] bytes back to back; result: the packet at out[0 .. return).  maxlen = repacketize_len, fill = pad to it.
+ * hdr: OA_MF_HEADROOM bytes of LDS for the header (the frame's packet buffer: every payload has left it by now). */
+WV_DEV int oa_multiframe_assemble_wave(WV_LDS MfLds *M, WV_LDS u8 *hdr, u8 *out, int maxlen, int fill)
 {
    LANE0 {
       const int n = M->n;
@@ -27,16 +28,16 @@ WV_DEV int oa_multiframe_assemble_wave(WV_LDS MfLds *M, u8 *out, int maxlen, int
       const u8 toc = (u8)(M->toc & 0xFC);
       int code3 = n > 2;
       if (!code3) {
-         M->hdr[h++] = (u8)(toc | (same ? 1 : 2));
-         if (!same) h += mf_put_length(M->hdr + h, M->len[0]);
+         hdr[h++] = (u8)(toc | (same ? 1 : 2));
+         if (!same) h += mf_put_length(hdr + h, M->len[0]);
          total = h + body;
          if (total > maxlen) err = 1;
          code3 = fill && total < maxlen;
       }
       if (code3 && !err) {
          h = 0;
-         M->hdr[h++] = (u8)(toc | 3);
-         M->hdr[h++] = (u8)(n | (same ? 0 : 0x80));
+         hdr[h++] = (u8)(toc | 3);
+         hdr[h++] = (u8)(n | (same ? 0 : 0x80));
          total = 2 + body;
          if (!same) for (int i = 0; i < n - 1; i++) total += M->len[i] < 252 ? 1 : 2;
          if (total > maxlen) err = 1;
@@ -44,12 +45,12 @@ WV_DEV int oa_multiframe_assemble_wave(WV_LDS MfLds *M, u8 *out, int maxlen, int
             const int pad = fill ? maxlen - total : 0;
             if (pad > 0) {
                const int full = (pad - 1) / 255;
-               M->hdr[1] |= 0x40;
-               for (int i = 0; i < full; i++) M->hdr[h++] = 255;
-               M->hdr[h++] = (u8)(pad - 255 * full - 1);
+               hdr[1] |= 0x40;
+               for (int i = 0; i < full; i++) hdr[h++] = 255;
+               hdr[h++] = (u8)(pad - 255 * full - 1);
                total = maxlen;
             }
-            if (!same) for (int i = 0; i < n - 1; i++) h += mf_put_length(M->hdr + h, M->len[i]);
+            if (!same) for (int i = 0; i < n - 1; i++) h += mf_put_length(hdr + h, M->len[i]);
          }
       }
       M->hdr_len = h; M->total = total; M->err = err; M->len[0] = body;          /* len[0] now carries the payload size for the copy below */
@@ -64,7 +65,7 @@ WV_DEV int oa_multiframe_assemble_wave(WV_LDS MfLds *M, u8 *out, int maxlen, int
       if (i < body) out[h + i] = v;
       wv_sync();
    }
-   FOR_LANES(i, h) out[i] = M->hdr[i];
+   FOR_LANES(i, h) out[i] = hdr[i];
    FOR_LANES(i, total - h - body) out[h + body + i] = 0;
    wv_sync();
    return total;

@@ -10,7 +10,9 @@ PHASES = ["dc_reject+prologue", "preemphasis", "tone_detect", "transient", "pref
           "  pf: pitch_downsample", "  pf: pitch_search", "  pf: remove_doubling", "  pf: before/comb/after", "  pf: history store", "  (pf nested)"]
 def main():
     so = os.path.join(ROOT, "opus_amd/libopus_amd_prof.so")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DOA_PHASE_TIMERS",
+    srcs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "opus_amd/csrc"))]
+    if not (os.path.exists(so) and (os.environ.get("OPUS_AMD_PROF_PREBUILT") == "1" or os.path.getmtime(so) >= max(os.path.getmtime(f) for f in srcs))):      # (prebuilt in the container: the GPU box's minutes are for measuring)
+      subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DOA_PHASE_TIMERS",
                            "-I" + os.path.join(ROOT, "opus_amd/csrc"), "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "opus_amd/csrc/opus_amd.hip"), "-o", so])
     import opus_amd, signals
     opus_amd.LIB_PATH = so
