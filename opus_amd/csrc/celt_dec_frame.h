@@ -295,13 +295,21 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
       bits -= anti_collapse_rsv;
       sh->intensity = 0; sh->dual_stereo = 0; sh->balance = 0;
-      const int codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, alloc_trim, &sh->intensity, &sh->dual_stereo, bits, &sh->balance,
-            L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 0, 0, 0);
-      k_unquant_fine_energy(start, end, L->oldBandE, L->fine_quant, EC_PASS, C);
       sh->silence = silence; sh->postfilter_pitch = postfilter_pitch; sh->postfilter_gain = postfilter_gain; sh->postfilter_tapset = postfilter_tapset;
       sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision;
-      sh->anti_collapse_rsv = anti_collapse_rsv; sh->codedBands = codedBands;
+      sh->anti_collapse_rsv = anti_collapse_rsv; sh->alloc_trim = alloc_trim; sh->r[4] = bits;
       sh->pvq_total_bits = len * (8 << BITRES) - anti_collapse_rsv;
+      ec_st(&L->ec, &ec_);
+   }
+   wv_sync();
+   {  /* bit allocation: the same wave routine as the encoder, reading the three side-information symbols (celt_alloc.h) */
+      const int coded = oa_allocate_bits_wave<false>(&L->ec, L->packet + 1, L->scr, sh->start, sh->end, L->offsets, L->cap, sh->alloc_trim, &sh->intensity, &sh->dual_stereo, sh->r[4], &sh->balance,
+            L->pulses, L->fine_quant, L->fine_priority, sh->C, sh->LM, 0, 0, sh->r + 6);
+      LANE0 sh->codedBands = coded;
+   }
+   LANE0 {
+      EcCtx ec_; ec_ld(&ec_, &L->ec); EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
+      k_unquant_fine_energy(sh->start, sh->end, L->oldBandE, L->fine_quant, EC_PASS, sh->C);
       ec_st(&L->ec, &ec_);
    }
    wv_sync();

@@ -3,6 +3,7 @@
  * index -> pulse vector map cwrsi (celt/cwrs.c:467). */
 #ifndef OPUS_AMD_CELT_DEC_SERIAL_H
 #define OPUS_AMD_CELT_DEC_SERIAL_H
+WV_DEV unsigned laplace_freq1(unsigned fs0, int decay) { return (32768u - 32u - fs0) * (u32)(16384 - decay) >> 15; }
 WV_DEV int k_laplace_decode(EC_ARGS, unsigned fs, int decay)
 {
    int val = 0;
@@ -35,7 +36,7 @@ WV_DEV void k_unquant_coarse_energy(int start, int end, WV_LDS i32 *oldEBands, i
    long long prev[2] = {0, 0};
    i16 coef, beta;
    if (intra) { coef = 0; beta = 4915; }
-   else { beta = k_beta_coef[LM]; coef = k_pred_coef[LM]; }
+   else { beta = k_inter_leak[LM]; coef = k_inter_pred[LM]; }
    i32 budget = e->storage * 8;
    for (int i = start; i < end; i++) {
       for (int c = 0; c < C; c++) {
@@ -45,7 +46,7 @@ WV_DEV void k_unquant_coarse_energy(int start, int end, WV_LDS i32 *oldEBands, i
             int pi = 2 * imin(i, 20);
             qi = k_laplace_decode(EC_PASS, prob_model[pi] << 7, prob_model[pi + 1] << 6);
          } else if (budget - tell >= 2) {
-            qi = k_ec_dec_icdf(EC_PASS, k_small_energy_icdf, 2);
+            qi = k_ec_dec_icdf(EC_PASS, k_tiny_energy_icdf, 2);
             qi = (qi >> 1) ^ -(qi & 1);
          } else if (budget - tell >= 1) qi = -k_ec_dec_bit_logp(EC_PASS, 1);
          else qi = -1;
@@ -75,7 +76,7 @@ WV_DEV void k_unquant_energy_finalise(int start, int end, WV_LDS i32 *oldEBands,
 {
    for (int prio = 0; prio < 2; prio++) {
       for (int i = start; i < end && bits_left >= C; i++) {
-         if (fine_quant[i] >= MAX_FINE_BITS || fine_priority[i] != prio) continue;
+         if (fine_quant[i] >= OA_MAX_FINE_BITS || fine_priority[i] != prio) continue;
          for (int c = 0; c < C; c++) {
             int q2 = k_ec_dec_bits(EC_PASS, 1);
             i32 offset = (shl32(q2, DB_SHIFT) - GC(.5f)) >> (fine_quant[i] + 1);

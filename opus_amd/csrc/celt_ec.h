@@ -81,6 +81,7 @@ WV_DEV u32 k_ec_tell_frac(EC_ARGS)
    l = (l << 3) + b;
    return nbits - l;
 }
+WV_DEV int ec_tell_lds(const WV_LDS EcCtx *e) { return e->nbits_total - ec_ilog(e->rng); }
 WV_DEV u32 ec_tell_frac_lds(const WV_LDS EcCtx *e)
 {
    const unsigned correction[8] = {35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535};

@@ -8,7 +8,8 @@
 #include "celt_ec.h"
 #include "celt_ecdec.h"
 #include "celt_enc_lds.h"
-#include "celt_enc_serial.h"
+#include "celt_alloc.h"
+#include "celt_enc_energy.h"
 #include "celt_mdct.h"
 #include "celt_enc_front.h"
 #include "celt_enc_pitch.h"

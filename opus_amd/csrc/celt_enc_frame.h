@@ -220,10 +220,9 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       K_DUMP("coarse_in", w, 4 * n);
    }
 #endif
+   coarse_energy_wave(L);                 /* both hypotheses at once on lanes 0 and 1 (celt_enc_energy.h) */
    LANE0 {
       EC_BEGIN;
-      k_quant_coarse_energy(L->scr, L->BC.coarse_save, start, end, sh->effEnd, L->bandLogE, L->oldBandE, sh->total_bits, L->error, EC_PASS,
-            C, LM, sh->nbAvailableBytes, sh->force_intra, &st->delayedIntra, sh->complexity >= 4, sh->loss_rate, sh->lfe);
       tf_encode_l0(L, EC_PASS);
       sh->r[2] = k_ec_tell(EC_PASS) + 4 <= sh->total_bits;
       EC_END;
@@ -356,13 +355,20 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
          K_DUMP("alloc_in", w, 4 * n);
       }
 #endif
-      sh->codedBands = k_compute_allocation(L->scr, start, end, L->offsets, L->cap, sh->alloc_trim, &st->intensity, &sh->dual_stereo, bits, &sh->balance,
-            L->pulses, L->fine_quant, L->fine_priority, C, LM, EC_PASS, 1, st->lastCodedBands, signalBandwidth);
-      if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, sh->codedBands));
-      else st->lastCodedBands = sh->codedBands;
-      k_quant_fine_energy(start, end, L->oldBandE, L->error, 0, L->fine_quant, EC_PASS, C);
+      sh->bits = bits; sh->signalBandwidth = signalBandwidth;
       EC_END;
    }
+   wv_sync();
+   {
+      const int coded = oa_allocate_bits_wave<true>(&L->ec, L->packet + 1, L->scr, start, end, L->offsets, L->cap, sh->alloc_trim, &st->intensity, &sh->dual_stereo, sh->bits, &sh->balance,
+            L->pulses, L->fine_quant, L->fine_priority, C, LM, st->lastCodedBands, sh->signalBandwidth, sh->r + 6);
+      LANE0 {
+         sh->codedBands = coded;
+         if (st->lastCodedBands) st->lastCodedBands = imin(st->lastCodedBands + 1, imax(st->lastCodedBands - 1, coded));
+         else st->lastCodedBands = coded;
+      }
+   }
+   fine_energy_wave(L);
    wv_sync();
    K_DUMPI("nbCompressedBytes", sh->nbCompressedBytes); K_DUMPI("codedBands", sh->codedBands); K_DUMPI("balance", sh->balance); K_DUMP("pulses", L->pulses, 84); K_DUMP("fine_quant", L->fine_quant, 84); K_DUMP("fine_priority", L->fine_priority, 84); K_DUMPI("rng_fine", L->ec.rng);
 
@@ -377,9 +383,14 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    /* ---- finalise (lane 0) ---- */
    LANE0 {
       EC_BEGIN;
-      const int nbCompressedBytes = sh->nbCompressedBytes, isTransient = sh->isTransient, silence = sh->silence;
       if (sh->anti_collapse_rsv > 0) k_ec_enc_bits(EC_PASS, st->consec_transient < 2, 1);
-      k_quant_energy_finalise(start, end, L->oldBandE, L->error, L->fine_quant, L->fine_priority, nbCompressedBytes * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
+      sh->r[5] = (i32)energy_finalise_emit_l0(L, EC_PASS, sh->nbCompressedBytes * 8 - k_ec_tell(EC_PASS));
+      EC_END;
+   }
+   energy_finalise_apply_wave(L, (u32)wv_uni(sh->r[5]));
+   LANE0 {
+      EC_BEGIN;
+      const int nbCompressedBytes = sh->nbCompressedBytes, isTransient = sh->isTransient, silence = sh->silence;
       if (silence) for (int i = 0; i < C * NBE; i++) L->oldBandE[i] = -GC(28.f);
       st->prefilter_period = sh->pitch_index;
       st->prefilter_gain = (i16)sh->gain1;

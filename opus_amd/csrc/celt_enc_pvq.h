@@ -15,6 +15,7 @@
 #define K_DUMP(tag, ptr, nbytes)
 #define K_DUMPI(tag, v)
 #endif
+#define LOG_MAX_PSEUDO 6
 #ifndef K_TIC
 #define K_TIC()
 #define K_TOC(bucket)
