@@ -311,17 +311,15 @@ WV_DEVN void se_nsq_del_dec_wave(WV_LDS OaSilkEncChannel *c, WV_LDS OaSilkNsqSta
          for (int j = 0; j < 16; j++) LPC_pred_Q14 = sk_mlawb(LPC_pred_Q14, w[j], ca[j]);
          LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
          i32 n_AR_Q14 = S >> 1;
-         {  /* warped all-pass ladder: stage j consumes the output of stage j - 1 (:392-413); orders 12 / 14 / 16 / 24 (control_codec.c complexity table) */
+         {  /* warped all-pass ladder: stage j consumes the output of stage j - 1 (:392-413); orders 12 / 14 / 16 / 20 / 24 (control_codec.c complexity table) */
             i32 in = sk_mlawb(Diff, sar[0], warp);
 #define SE_AR_STAGE(j) { const i32 nxt = (j) + 1 < 24 ? sar[(j) + 1 < 24 ? (j) + 1 : 23] : 0; const i32 out = sk_mlawb(sar[j], sub32(nxt, in), warp); sar[j] = in; n_AR_Q14 = sk_mlawb(n_AR_Q14, in, cs[j]); in = out; }
 #pragma unroll
             for (int j = 0; j < 12; j++) SE_AR_STAGE(j)
             if (S > 12) { SE_AR_STAGE(12) SE_AR_STAGE(13) }
             if (S > 14) { SE_AR_STAGE(14) SE_AR_STAGE(15) }
-            if (S > 16) {
-#pragma unroll
-               for (int j = 16; j < 24; j++) SE_AR_STAGE(j)
-            }
+            if (S > 16) { SE_AR_STAGE(16) SE_AR_STAGE(17) SE_AR_STAGE(18) SE_AR_STAGE(19) }
+            if (S > 20) { SE_AR_STAGE(20) SE_AR_STAGE(21) SE_AR_STAGE(22) SE_AR_STAGE(23) }                 /* (order 20 must leave taps 20..23 alone: they come back into play when the complexity rises) */
 #undef SE_AR_STAGE
          }
          n_AR_Q14 = shl32(n_AR_Q14, 1);

@@ -34,6 +34,32 @@ def test_every_declared_symbol_is_exported(lib):
     assert not extra, extra
 
 
+def _reference_exports():
+    """every OPUS_EXPORT function the reference's public headers declare (custom modes excluded: CUSTOM_MODES is not part of the build that is the oracle).
+    Parsed from /root/reference when it is there (and the committed list refreshed), else read from the committed list."""
+    fixture = os.path.join(ROOT, "tests/golden/opus_exports.txt")
+    inc = "/root/reference/include"
+    if os.path.isdir(inc):
+        names = []
+        for h in ["opus.h", "opus_multistream.h", "opus_projection.h", "opus_defines.h"]:
+            src = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, h)).read(), flags=re.S)
+            src = re.sub(r"^\s*#.*$", "", src, flags=re.M)                     # (the macro's own definition lines)
+            names += [(m.group(1), h) for m in re.finditer(r"OPUS_EXPORT\b[^;{]*?\b(\w+)\s*\(", src)]
+        text = "# OPUS_EXPORT functions of the reference's public headers, refreshed by tests/test_abi_symbols.py whenever /root/reference is present\n" + "".join("%s %s\n" % n for n in names)
+        if not os.path.exists(fixture) or open(fixture).read() != text: open(fixture, "w").write(text)
+    return [l.split()[0] for l in open(fixture) if l.strip() and not l.startswith("#")]
+
+
+def test_every_reference_export_is_exported(lib):
+    """the drop-in claim, symbol by symbol: nm -D of the product against the reference's own headers"""
+    dyn = subprocess.run(["nm", "-D", "--defined-only", opus_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in dyn.splitlines() if " T " in l}
+    ref = _reference_exports()
+    assert len(ref) >= 85
+    missing = [n for n in ref if n not in exported]
+    assert not missing, missing
+
+
 def test_sizes_and_strings(lib):
     assert lib.opus_encoder_get_size(1) == lib.opus_encoder_get_size(2) > lib.opusgpu_enc_state_size() > 0
     assert lib.opus_encoder_get_size(0) == 0 and lib.opus_encoder_get_size(3) == 0          # opus_encoder.c:194-202

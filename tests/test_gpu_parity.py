@@ -1,7 +1,7 @@
 """GPU (MI355X): the HIP path, called through the C ABI, must reproduce the reference bit for bit.
 Checkers: the plain-C oracle (oracle/libcelt_oracle.so) and, where it travelled with the snapshot, the compiled
 reference itself (oracle/_ref/libopus_ref_fx.so).  Bit-exact: packets, lengths, OPUS_GET_FINAL_RANGE."""
-import ctypes, numpy as np, pytest
+import ctypes, os, numpy as np, pytest
 import signals
 from reflib import oracle, ref_fx
 
@@ -143,3 +143,18 @@ def test_gpu_full_size_properties():
             assert np.all(lens[idx] == a[1]) and np.all(rng[idx] == a[2])
             for s in (k, k + 8 * 1000, k + 8 * 8191): assert pk[s] == a[0]
     b.close()
+
+
+def test_gpu_parity_soak_with_midstream_ctls():
+    """the parity gate of SURVEY 8d inside the suite: configs 2, 3 and 4, 256 streams x 1000 consecutive frames each, 64 distinct base signals (the rest are
+    shifted / scaled copies), bitrate / complexity / VBR / FEC / DTX / bandwidth / channel changes applied mid-stream to the batch and to every reference
+    encoder at the same frame (tools/parity_soak.py SCHEDULE): every packet, length and final range equal"""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools/parity_soak.py"), "--streams", "256", "--frames", "1000", "--bases", "64", "--ctl-schedule"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    rows = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(rows) == 3, out[-3000:]
+    for r in rows: assert r["mismatches"] == 0 and r["stream_frames_checked"] == 256000, r

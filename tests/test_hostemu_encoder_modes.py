@@ -87,3 +87,11 @@ def test_settings_fuzz():
                         force_channels=int(rng.choice([-1000, 1, 2])), max_bandwidth=int(rng.integers(1101, 1106)), signal=int(rng.choice([-1000, 3001, 3002])),
                         inband_fec=int(rng.integers(0, 3)), packet_loss=int(rng.integers(0, 30)), dtx=int(rng.integers(0, 2)), prediction_disabled=int(rng.integers(0, 2)))
     run(Fs, 2, 2049, frames, sched, seed=31)
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_complexity_steps_midstream(ch):
+    """every row of the SILK complexity table (silk/control_codec.c:307) entered and left mid-stream in hybrid frames: the noise-shaping order moves 12 -> 24 -> 20 -> 24 ...,
+    and the taps above the current order have to survive untouched until the order rises again (found by the parity soak's control schedule)"""
+    sched = {i * 4: dict(complexity=c) for i, c in enumerate([6, 10, 2, 8, 0, 7, 4, 10, 1, 6, 9])}
+    m = run(48000, ch, 2049, [960] * 46, sched, seed=5, bitrate=160000, force_mode=1001, bandwidth=1105)
+    assert set(m) == {"H"}, m

@@ -10,8 +10,14 @@ CONFIGS = {
     3: dict(name="config 3: SILK-only, VOIP 16 kHz mono WB, 20 ms, 24 kb/s, complexity 10", Fs=16000, ch=1, app=2048, ctl=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), sig="speech"),
     4: dict(name="config 4: hybrid, AUDIO 48 kHz stereo FB, 20 ms, VBR 128 kb/s, complexity 10", Fs=48000, ch=2, app=2049, ctl=((11002, 1001), (4008, 1105), (4002, 128000), (4010, 10)), sig="speech"),
 }
+# mid-stream control changes applied to every stream of the batch and to every reference encoder at the same frame: (frame, request, value)
+SCHEDULE = {
+    2: [(150, 4002, 96000), (300, 4010, 5), (450, 4006, 0), (600, 4006, 1), (600, 4020, 0), (750, 4002, 160000), (750, 4010, 10), (900, 4022, 1)],
+    3: [(150, 4002, 16000), (300, 4010, 4), (450, 4012, 1), (450, 4014, 15), (600, 4016, 1), (750, 4002, 32000), (900, 4010, 10)],
+    4: [(150, 4002, 96000), (300, 4010, 6), (450, 4008, 1104), (600, 4012, 1), (600, 4014, 10), (750, 4002, 160000), (750, 4008, 1105), (900, 4010, 10)],
+}
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--streams", type=int, default=256); ap.add_argument("--frames", type=int, default=1000); ap.add_argument("--configs", default="2,3,4"); ap.add_argument("--bases", type=int, default=32)
+    ap = argparse.ArgumentParser(); ap.add_argument("--ctl-schedule", action="store_true", help="apply SCHEDULE[config] while the streams run"); ap.add_argument("--streams", type=int, default=256); ap.add_argument("--frames", type=int, default=1000); ap.add_argument("--configs", default="2,3,4"); ap.add_argument("--bases", type=int, default=32)
     a = ap.parse_args()
     import opus_amd, signals
     from reflib import ref_fx
@@ -31,7 +37,10 @@ def main():
         b = opus_amd.EncoderBatch(S, channels=ch, application=c["app"], Fs=Fs)
         for req, v in c["ctl"]: b.ctl(req, v)
         gp = [[None] * T for _ in range(S)]; gr = np.zeros((S, T), np.uint32)
+        sched = SCHEDULE[cid] if a.ctl_schedule else []
         for f in range(T):
+            for (ff, req, v) in sched:
+                if ff == f: b.ctl(req, v)
             pcm = np.stack([sig[s][f * n:(f + 1) * n].reshape(-1) for s in range(S)])
             pk, lens, rng = b.encode(pcm, n)
             for s in range(S): gp[s][f] = pk[s] if int(lens[s]) > 0 else int(lens[s])
@@ -44,6 +53,8 @@ def main():
             for req, v in c["ctl"]: R.opus_encoder_ctl(enc, req, ctypes.c_int(v))
             o = np.zeros(1500, np.uint8); r = ctypes.c_uint32(0)
             for f in range(T):
+                for (ff, req, v) in sched:
+                    if ff == f: assert R.opus_encoder_ctl(enc, req, ctypes.c_int(v)) == 0
                 x = sig[s][f * n:(f + 1) * n]
                 l = R.opus_encode(enc, x.ctypes.data_as(ctypes.c_void_p), n, o.ctypes.data_as(ctypes.c_void_p), 1276)
                 R.opus_encoder_ctl(enc, 4031, ctypes.byref(r))
@@ -53,5 +64,5 @@ def main():
                     if first is None: first = [s, f, l, len(gp[s][f]) if isinstance(gp[s][f], bytes) else gp[s][f]]
             R.opus_encoder_destroy(enc)
         print(json.dumps({"parity_gate": c["name"], "streams": S, "frames_per_stream": T, "stream_frames_checked": S * T, "mismatches": bad, "first_mismatch": first,
-                          "mean_packet_bytes": nbytes / (S * T), "distinct_base_signals": U, "gpu_seconds_incl_host_copies": round(t_gpu, 1), "reference_seconds_one_core": round(time.time() - t0, 1)}), flush=True)
+                          "mean_packet_bytes": nbytes / (S * T), "distinct_base_signals": U, "ctl_changes": len(sched), "gpu_seconds_incl_host_copies": round(t_gpu, 1), "reference_seconds_one_core": round(time.time() - t0, 1)}), flush=True)
 if __name__ == "__main__": main()
