@@ -7,13 +7,12 @@
  *    opus_encode :266, opus_encoder_destroy :354, opus_encoder_ctl :367; error codes opus_defines.h:46-60).
  *    The OpusEncoder blob is flat host memory holding the complete canonical state (memcpy-able, no device
  *    handles: opus.h:108-109); every opus_encode() runs the frame on the GPU as a batch of one.
- *    Scope this round: OPUS_APPLICATION_RESTRICTED_LOWDELAY / RESTRICTED_CELT (CELT-only kernel, Fs = 48000, 2.5-20 ms) and
- *    OPUS_APPLICATION_VOIP / AUDIO / RESTRICTED_SILK (the SILK-capable kernel: SILK-only frames at Fs 8-48 kHz, 10-60 ms; hybrid and
- *    CELT-only frames at 48 kHz; mode / bandwidth / channel decisions as the reference's opus_encode_native, src/opus_encoder.c:1310-1700,
- *    or pinned with OPUS_SET_FORCE_MODE); VBR / constrained VBR / hard CBR (code-3 padding); OPUS_SET_DTX (SILK's own DTX and the generalised
- *    decision, OPUS_GET_IN_DTX) and OPUS_SET_INBAND_FEC + OPUS_SET_PACKET_LOSS_PERC (decide_fec, LBRR).  What is not built (mode or SILK-bandwidth
- *    switches that need a CELT redundancy frame, frames above 60 ms, CELT below 48 kHz) returns OPUS_UNIMPLEMENTED -- from the encode call,
- *    per stream, on the very frame where the decision arises (no packet is ever emitted without the redundancy it would need).
+ *    Scope: every application (RESTRICTED_LOWDELAY / RESTRICTED_CELT on the CELT-only kernel; VOIP / AUDIO / RESTRICTED_SILK on the SILK-capable kernel), every API
+ *    rate (8-48 kHz), 2.5-120 ms (calls above 20 ms become multi-frame packets, src/opus_encoder.c:1698-1838), mode / bandwidth / channel decisions as the reference's
+ *    opus_encode_native (src/opus_encoder.c:1310-1700) or pinned with OPUS_SET_FORCE_MODE, mode and SILK-bandwidth switches with their CELT redundancy frames and
+ *    SILK / CELT prefills, VBR / constrained VBR / hard CBR (code-3 padding), OPUS_SET_DTX (SILK's own DTX and the generalised decision, OPUS_GET_IN_DTX),
+ *    OPUS_SET_INBAND_FEC + OPUS_SET_PACKET_LOSS_PERC (decide_fec, LBRR), LFE / energy-mask / prediction / expert-frame-duration controls.  No legal argument set
+ *    returns OPUS_UNIMPLEMENTED.
  *
  * 2. The batch API (additive): S independent streams stepped together, one wavefront per
  *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.
@@ -158,7 +157,8 @@ OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
  * host memory with the complete state (memcpy-able).  Scope: CELT-only, SILK-only (NB/MB/WB, 10-60 ms) and hybrid packets, any frame count /
  * size the TOC allows, mono/stereo streams into mono/stereo output, mode transitions in every direction incl. the 5 ms CELT redundancy frames,
  * packet-loss concealment in every mode (data == NULL or len == 0: CELT pitch/noise PLC, SILK PLC + comfort noise, hybrid = both) and DTX frames.
- * decode_fec = 1 decodes the in-band FEC (LBRR) copy (src/opus_decoder.c:786-824), concealing where there is none.  Fs != 48000 returns OPUS_UNIMPLEMENTED. */
+ * decode_fec = 1 decodes the in-band FEC (LBRR) copy (src/opus_decoder.c:786-824), concealing where there is none.  Every API rate (8-48 kHz: CELT keeps every n-th de-emphasised
+ * sample, celt_decoder.c:361-404; SILK resamples to the API rate); OPUS_SET_GAIN; opus_decode24 / opus_decode_float as the fixed-point build converts them. */
 typedef struct OpusDecoder OpusDecoder;
 OPUS_AMD_EXPORT int opus_decoder_get_size(int channels);
 OPUS_AMD_EXPORT OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error);
@@ -217,10 +217,9 @@ OPUS_AMD_EXPORT opus_int32 opus_multistream_packet_unpad(unsigned char *data, op
 
 /* ================= multistream (reference/include/opus_multistream.h:203-726) =================
  * One multistream frame = its streams stepped together by the batch kernels (one launch per group: coupled, mono).  Same names,
- * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: every application (the elementary encoders are the CELT-only or the
- * SILK-capable stream records, with the scope stated above for each), frames <= 20 ms, mapping families 0, 2 (ambisonics) and 255, family 1
- * up to two channels; int16 entry points.  Family-1 surround (> 2 channels,
- * needs the masking analysis) and float / 24-bit entry points return OPUS_UNIMPLEMENTED. */
+ * arguments, layouts (mapping semantics :86-140) and error codes.  Scope: every application, frame sizes up to 120 ms, mapping families 0, 1 (surround: the
+ * masking analysis of src/opus_multistream_encoder.c:230 runs on the device, one wave per channel; LFE stream), 2 / 3 (ambisonics and projection, opus_projection.h)
+ * and 255; int16, 24-bit and float entry points (the latter two convert, as the reference's fixed-point build does). */
 typedef struct OpusMSEncoder OpusMSEncoder;
 typedef struct OpusMSDecoder OpusMSDecoder;
 OPUS_AMD_EXPORT opus_int32 opus_multistream_encoder_get_size(int streams, int coupled_streams);
