@@ -142,12 +142,34 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     out = torch.zeros((S, STRIDE), dtype=torch.uint8, device=dev)
     lens = torch.zeros((S,), dtype=torch.int32, device=dev)
     rng = torch.zeros((S,), dtype=torch.int32, device=dev)
-    b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
-    for req, v in cfg["ctls"]: b.ctl(req, v)
-    if cid == 5:                                               # per-stream rates of the 255-channel multistream layout (rate_allocation, src/opus_multistream_encoder.c:702): equal shares
-        pass
     stream = torch.cuda.current_stream(dev)
-    gather = gather_cls(S * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls) else None
+    gather = gather_cls(S * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls and cid != 5) else None
+    if cid == 5:
+        # B multistream encoders x 255 mono AUDIO streams, resident on the device (opusgpu_ms_enc_batch_*, opus_amd/csrc/opus_ms_batch.h): channel split, the 65,535 elementary
+        # encodes and the self-delimited packing are launches on one stream; `out` holds the B multistream packets
+        NS = 255; Bn = S // NS; S = Bn * NS
+        L = opus_amd.lib()
+        L.opusgpu_ms_enc_batch_create.restype = ctypes.c_void_p
+        L.opusgpu_ms_enc_batch_create.argtypes = [ctypes.c_int] * 6 + [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.opusgpu_ms_enc_batch_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.opusgpu_ms_encode_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.opusgpu_ms_enc_batch_destroy.argtypes = [ctypes.c_void_p]; L.opusgpu_ms_enc_batch_destroy.restype = None
+        err = ctypes.c_int()
+        msb = L.opusgpu_ms_enc_batch_create(Bn, Fs, NS, 255, NS, 0, bytes(range(NS)), cfg["app"], local, ctypes.byref(err))
+        if not msb: raise RuntimeError("opusgpu_ms_enc_batch_create failed: %d" % err.value)
+        assert L.opusgpu_ms_enc_batch_ctl(msb, 4002, NS * 64000) == 0 and L.opusgpu_ms_enc_batch_ctl(msb, 4010, 10) == 0
+        pcm = pcm[:, :S].reshape(T, Bn, NS, FR).permute(0, 1, 3, 2).contiguous()            # [T][B][frame][channels] interleaved, as opus_multistream_encode takes it
+        MS_STRIDE = 65536; MS_MAX = (NS - 1) * 1279 + 7662 + 3 * NS + 8
+        out = torch.zeros((Bn, MS_STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((Bn,), dtype=torch.int32, device=dev); rng = torch.zeros((Bn,), dtype=torch.int32, device=dev)
+        class _Ms:
+            def encode_dev(self, p, fr, o, stride, l, r, hip_stream=None):
+                rc = L.opusgpu_ms_encode_batch_dev(msb, p, fr, o, MS_STRIDE, MS_MAX, l, r, hip_stream)
+                if rc != 0: raise RuntimeError("opusgpu_ms_encode_batch_dev failed: %d" % rc)
+            def close(self): L.opusgpu_ms_enc_batch_destroy(msb)
+        b = _Ms()
+    else:
+        b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
+        for req, v in cfg["ctls"]: b.ctl(req, v)
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
@@ -171,14 +193,14 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     lens_h = lens.cpu().numpy()
     ok = bool((lens_h > 0).all())
-    mean_len = float(lens_h.mean())
+    mean_len = float(lens_h.mean()) / (255 if cid == 5 else 1)                               # config 5: per elementary stream (incl. its self-delimiting length byte)
     L = opus_amd.lib()
     L.opusgpu_enc_moved_state_bytes.restype = ctypes.c_int
     state_moved = L.opusgpu_enc_moved_state_bytes(cfg["app"], CH, 1 if cid == 4 else 0)          # state bytes read + written per frame-step
     alg = FR * CH * 2 + mean_len + 8 + state_moved
-    res = {"config_id": cid, "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"], "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
+    res = {"config_id": cid, "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
            "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved}
-    if frames_per_launch and world == 1:
+    if frames_per_launch and world == 1 and cid != 5:
         # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "T = 50 consecutive steps"
         Tn = min(frames_per_launch, T)
         outs = torch.zeros((Tn, S, STRIDE), dtype=torch.uint8, device=dev); lns = torch.zeros((Tn, S), dtype=torch.int32, device=dev); rgs = torch.zeros((Tn, S), dtype=torch.int32, device=dev)
@@ -189,7 +211,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         e1.record(stream); torch.cuda.synchronize(dev)
         if r == 0: res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1)}
     if with_cpu:
-        res["pcm0"] = pcm[:, 0, :].cpu().numpy().reshape(T, FR * CH)
+        res["pcm0"] = (pcm[:, 0, :, 0] if cid == 5 else pcm[:, 0, :]).cpu().numpy().reshape(T, FR * CH)
     b.close()
     del pcm, out
     torch.cuda.empty_cache()

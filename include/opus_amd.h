@@ -362,6 +362,23 @@ OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch(int device, opus_int32 n, 
 OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32 n, const opus_int16 *d_frames, const OpusGpuPitchIn *d_in, OpusGpuPitchOut *d_out,
       int Fs_kHz, int complexity, int nb_subfr, void *hip_stream);
 
+/* ================= device-resident batch of multistream encoders (BASELINE config 5) =================
+ * B encoders with one layout, i.e. B x opus_multistream_encoder_create(Fs, channels, streams, coupled_streams, mapping, application)
+ * (reference include/opus_multistream.h:260, src/opus_multistream_encoder.c:841-1060), stepped together with their B x streams elementary encoders resident in HBM:
+ * channel extraction, the elementary encodes and the self-delimited packing (RFC 6716 Appendix B) are launches on one HIP stream, no host round trip.
+ * mapping_family 0 / 255 (plain layouts) or 2 (ambisonics layouts: CELT-only elementary encoders); VBR; max_data_bytes large enough for every stream to be
+ * offered its own cap ((streams - 1) * 1279 + 7662 + 3 * streams + 8 for frames <= 20 ms), else OPUS_BUFFER_TOO_SMALL -- the classic opus_multistream_encode
+ * serves tight buffers, hard CBR and the surround family.  Packets are byte-identical to the reference's. */
+typedef struct OpusGpuMsEncBatch OpusGpuMsEncBatch;
+OPUS_AMD_EXPORT OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 nb_encoders, opus_int32 Fs, int channels, int mapping_family, int streams, int coupled_streams,
+      const unsigned char *mapping, int application, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_ms_enc_batch_destroy(OpusGpuMsEncBatch *b);
+OPUS_AMD_EXPORT int opusgpu_ms_enc_batch_ctl(OpusGpuMsEncBatch *b, int request, opus_int32 value);            /* SET requests, applied to all encoders */
+OPUS_AMD_EXPORT int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *b, const opus_int16 *d_pcm /* [B][frame_size][channels] */, int frame_size, unsigned char *d_out /* [B][out_stride] */,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens /* [B] */, opus_uint32 *d_final_range /* [B] */, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_ms_encode_batch(OpusGpuMsEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out, opus_int32 out_stride, opus_int32 max_data_bytes,
+      opus_int32 *lens, opus_uint32 *final_range);
+
 #ifdef __cplusplus
 }
 #endif

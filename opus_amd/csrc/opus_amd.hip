@@ -884,6 +884,7 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 }
 } /* extern "C" */
 #include "opus_ms_host.h"
+#include "opus_ms_batch.h"
 #include "opus_api_host.h"
 #include "opus_projection_host.h"
 #include "silk_batch.h"

@@ -1,0 +1,229 @@
+/* opus_ms_batch.h — a device-resident batch of B identical multistream encoders (BASELINE config 5: 257 encoders x 255 mono AUDIO streams).
+ *
+ * opus_multistream_encode (src/opus_multistream_encoder.c:841) is, per frame: rate allocation -> channel extraction -> one independent opus_encode per
+ * elementary stream -> the streams' packets concatenated, all but the last in the self-delimiting framing of RFC 6716 Appendix B (:1016-1060).  The classic
+ * entry points of opus_ms_host.h do that per encoder through host memory.  Here the B x N elementary streams ARE two ordinary encoder batches (the coupled
+ * streams, the mono streams) whose state never leaves HBM, and a frame-step of all B encoders is four launches on one HIP stream, no host round trip:
+ *   oa_ms_split_kernel   [B][frame][channels] interleaved PCM -> the two groups' per-stream inputs (one wave per (encoder, stream), coalesced)
+ *   the coupled group's and the mono group's encode kernels (persistent waves over B * nc and B * nm streams)
+ *   oa_ms_pack_kernel    one wave per encoder: every lane reads one stream's header and derives the Appendix-B length field, a wave scan turns the sizes into
+ *                        offsets, then the wave copies packet after packet; the encoder's final range is the XOR over its streams.
+ * The byte budget the reference hands to stream s depends on what streams 0..s-1 used (:1016-1026); when the caller's buffer is large enough for every stream
+ * to be offered the elementary encoder's own cap, the budgets are all the same and the streams are independent -- that is the case this batch serves (it checks
+ * it and answers OPUS_BUFFER_TOO_SMALL otherwise; tight buffers and hard CBR go through the classic entry points).  Mapping families without a per-frame
+ * analysis: 0 / 255 (none) and 2 (ambisonics: elementary encoders forced to CELT); surround (family 1 > 2 channels) needs its masking analysis per frame and
+ * stays with the classic path. */
+#ifndef OPUS_AMD_MS_BATCH_H
+#define OPUS_AMD_MS_BATCH_H
+
+/* one wave per (encoder b, stream s): s < nc -> interleaved stereo pair into pc, else mono into pm */
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_split_kernel(const i16 *pcm, int frame, int nch, const i32 *chan /* [2 * nc | nm] source channel of every elementary channel */, int nc, int nm, i16 *pc, i16 *pm)
+{
+   const int ns = nc + nm, b = (int)blockIdx.x / ns, s = (int)blockIdx.x - b * ns;
+   const i16 *src = pcm + (size_t)b * frame * nch;
+   if (s < nc) {
+      const int l = chan[2 * s], r = chan[2 * s + 1];
+      i16 *d = pc + ((size_t)b * nc + s) * frame * 2;
+      for (int i = threadIdx.x; i < frame; i += 64) { d[2 * i] = src[(size_t)i * nch + l]; d[2 * i + 1] = src[(size_t)i * nch + r]; }
+   } else {
+      const int c = chan[2 * nc + (s - nc)];
+      i16 *d = pm + ((size_t)b * nm + (s - nc)) * frame;
+      for (int i = threadIdx.x; i < frame; i += 64) d[i] = src[(size_t)i * nch + c];
+   }
+}
+
+/* bytes of an Opus packet's own header (RFC 6716 section 3.2: TOC, code-3 count byte, explicit lengths; packets of this encoder carry no padding in VBR) and the
+ * size of its last frame -- what Appendix B wants coded in addition */
+WV_DEV void oa_ms_header(const u8 *p, int len, int *hdr, int *last)
+{
+   const int code = p[0] & 3;
+   if (code == 0) { *hdr = 1; *last = len - 1; }
+   else if (code == 1) { *hdr = 1; *last = (len - 1) >> 1; }
+   else if (code == 2) { const int a = p[1], lb = a < 252 ? 1 : 2, n0 = a < 252 ? a : 4 * p[2] + a; *hdr = 1 + lb; *last = len - 1 - lb - n0; }
+   else {
+      const int n = p[1] & 0x3F, vbr = p[1] >> 7;
+      int at = 2, body = 0;
+      if (vbr) for (int i = 0; i < n - 1; i++) { const int a = p[at], two = a >= 252; body += two ? 4 * p[at + 1] + a : a; at += 1 + two; }
+      *hdr = at; *last = vbr ? len - at - body : (len - at) / n;
+   }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_pack_kernel(const u8 *pkc, const i32 *lc, const u32 *rc, int nc, const u8 *pkm, const i32 *lm, const u32 *rm, int nm, int stride,
+      u8 *out, int out_stride, int max_data_bytes, i32 *lens, u32 *rngs)
+{
+   const int b = blockIdx.x, ns = nc + nm, lane = threadIdx.x;
+   u8 *dst = out + (size_t)b * out_stride;
+   int at = 0, err = 0;
+   u32 rx = 0;
+   for (int s0 = 0; s0 < ns; s0 += 64) {
+      const int s = s0 + lane, mine = s < ns;
+      const u8 *p = 0; int len = 0, hdr = 0, last = 0, extra = 0;
+      if (mine) {
+         if (s < nc) { p = pkc + ((size_t)b * nc + s) * stride; len = lc[b * nc + s]; rx ^= rc[b * nc + s]; }
+         else { p = pkm + ((size_t)b * nm + (s - nc)) * stride; len = lm[b * nm + (s - nc)]; rx ^= rm[b * nm + (s - nc)]; }
+         if (len <= 0) err = len < 0 ? len : OPUS_INTERNAL_ERROR;
+         else { oa_ms_header(p, len, &hdr, &last); extra = s == ns - 1 ? 0 : (last < 252 ? 1 : 2); }
+      }
+      err = wv_min(err);
+      if (err) break;
+      const int total = mine ? len + extra : 0;
+      const int incl = wv_scan_incl(total), off = at + incl - total;
+      const int chunk = imin(64, ns - s0);
+      for (int k = 0; k < chunk; k++) {                                   /* packet after packet, all lanes on the bytes */
+         const unsigned long long pw = (unsigned long long)p;
+         const u8 *q = (const u8 *)(((unsigned long long)(u32)wv_bcast((i32)(pw >> 32), k) << 32) | (unsigned long long)(u32)wv_bcast((i32)(u32)pw, k));
+         const int ql = wv_bcast(len, k), qh = wv_bcast(hdr, k), qx = wv_bcast(extra, k), qlast = wv_bcast(last, k), qo = wv_bcast(off, k);
+         if (qo + ql + qx > max_data_bytes || qo + ql + qx > out_stride) { err = OPUS_BUFFER_TOO_SMALL; break; }
+         for (int i = lane; i < qh; i += 64) dst[qo + i] = q[i];
+         if (lane == 0 && qx) { if (qlast < 252) dst[qo + qh] = (u8)qlast; else { const int f = 252 + (qlast & 3); dst[qo + qh] = (u8)f; dst[qo + qh + 1] = (u8)((qlast - f) >> 2); } }
+         for (int i = lane; i < ql - qh; i += 64) dst[qo + qh + qx + i] = q[qh + i];
+      }
+      if (err) break;
+      at += wv_bcast(incl, 63);
+   }
+   for (int d = 1; d < 64; d <<= 1) rx ^= (u32)wv_shfl((i32)rx, lane ^ d);
+   if (lane == 0) { lens[b] = err ? err : at; rngs[b] = err ? 0 : rx; }
+}
+
+struct OpusGpuMsEncBatch {
+   int B, nch, ns, nc, nm, device, application, last_frame_size;
+   opus_int32 Fs;
+   OpusMSEncoder *proto;                 /* host-side prototype encoder: layout, controls, rate allocation (never encodes) */
+   OpusGpuEncBatch *bc, *bm;             /* the B * nc coupled and B * nm mono elementary encoders */
+   i32 *d_chan;
+   i16 *d_pc, *d_pm; size_t pc_cap, pm_cap;
+   u8 *d_pkc, *d_pkm; i32 *d_lc, *d_lm; u32 *d_rc, *d_rm; opus_int32 stride;
+   /* staging of the host-pointer entry */
+   i16 *d_pcm; size_t pcm_cap; u8 *d_out; size_t out_cap; i32 *d_lens; u32 *d_rng;
+};
+
+extern "C" {
+void opusgpu_ms_enc_batch_destroy(OpusGpuMsEncBatch *m)
+{
+   if (!m) return;
+   if (m->bc) opusgpu_enc_batch_destroy(m->bc);
+   if (m->bm) opusgpu_enc_batch_destroy(m->bm);
+   (void)hipSetDevice(m->device);
+   void *bufs[] = {m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
+   for (void *p : bufs) if (p) (void)hipFree(p);
+   free(m->proto);
+   delete m;
+}
+/* B encoders of opus_multistream_encoder_create(Fs, channels, streams, coupled_streams, mapping, application) (include/opus_multistream.h:260); mapping_family 0 / 255:
+ * plain layouts, 2: ambisonics (the caller passes the layout opus_multistream_surround_encoder_create would derive) */
+OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int channels, int mapping_family, int streams, int coupled_streams, const unsigned char *mapping,
+      int application, int device, int *error)
+{
+   int err = OPUS_OK;
+   OpusGpuMsEncBatch *m = nullptr;
+   if (B <= 0 || !mapping || (mapping_family != 0 && mapping_family != 255 && mapping_family != 2)) err = mapping_family == 1 || mapping_family == 3 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   OpusMSEncoder *proto = nullptr;
+   if (err == OPUS_OK) {
+      const opus_int32 sz = opus_multistream_encoder_get_size(streams, coupled_streams);
+      proto = sz > 0 ? (OpusMSEncoder *)malloc((size_t)sz) : nullptr;
+      if (!proto) err = sz > 0 ? OPUS_ALLOC_FAIL : OPUS_BAD_ARG;
+      else err = oa_ms_encoder_init_impl(proto, Fs, channels, streams, coupled_streams, mapping, application, mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE, -1);
+   }
+   if (err == OPUS_OK) {
+      m = new OpusGpuMsEncBatch();
+      memset(m, 0, sizeof(*m));
+      m->B = B; m->nch = channels; m->ns = streams; m->nc = coupled_streams; m->nm = streams - coupled_streams; m->device = device; m->application = application; m->Fs = Fs; m->proto = proto;
+      proto = nullptr;
+      if (m->nc) m->bc = opusgpu_enc_batch_create(B * m->nc, Fs, 2, application, device, &err);
+      if (err == OPUS_OK && m->nm) m->bm = opusgpu_enc_batch_create(B * m->nm, Fs, 1, application, device, &err);
+      std::vector<i32> chan((size_t)2 * m->nc + m->nm + 1);
+      for (int s = 0; s < m->nc; s++) { chan[2 * s] = oa_get_left(&m->proto->layout, s, -1); chan[2 * s + 1] = oa_get_right(&m->proto->layout, s, -1); }
+      for (int s = 0; s < m->nm; s++) chan[2 * m->nc + s] = oa_get_mono(&m->proto->layout, m->nc + s, -1);
+      const size_t nstr = (size_t)B * streams;
+      m->stride = (oa_enc_out_stride_needed(Fs, Fs / 25 * 3, 1276 * 6) + 15) & ~15;
+      if (err == OPUS_OK) {
+         const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void **)&m->d_chan, chan.size() * 4) == hipSuccess &&
+               hipMemcpy(m->d_chan, chan.data(), chan.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMalloc((void **)&m->d_pkc, (size_t)B * (m->nc ? m->nc : 1) * m->stride) == hipSuccess && hipMalloc((void **)&m->d_pkm, (size_t)B * (m->nm ? m->nm : 1) * m->stride) == hipSuccess &&
+               hipMalloc((void **)&m->d_lc, nstr * 4 + 4) == hipSuccess && hipMalloc((void **)&m->d_lm, nstr * 4 + 4) == hipSuccess &&
+               hipMalloc((void **)&m->d_rc, nstr * 4 + 4) == hipSuccess && hipMalloc((void **)&m->d_rm, nstr * 4 + 4) == hipSuccess &&
+               hipMalloc((void **)&m->d_lens, (size_t)B * 4) == hipSuccess && hipMalloc((void **)&m->d_rng, (size_t)B * 4) == hipSuccess;
+         if (!ok) err = OPUS_ALLOC_FAIL;
+      }
+      if (err == OPUS_OK && mapping_family == 2) {                        /* ambisonics: CELT-only elementary encoders (opus_multistream_encoder.c:986) */
+         if (m->bc) err = opusgpu_enc_batch_ctl(m->bc, -1, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY);
+         if (err == OPUS_OK && m->bm) err = opusgpu_enc_batch_ctl(m->bm, -1, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY);
+      }
+      if (err != OPUS_OK) { opusgpu_ms_enc_batch_destroy(m); m = nullptr; }
+   }
+   free(proto);
+   if (error) *error = err;
+   return m;
+}
+/* opus_multistream_encoder_ctl for all B encoders: OPUS_SET_BITRATE feeds the rate allocation, every other SET goes to every elementary encoder (:1245-1278) */
+int opusgpu_ms_enc_batch_ctl(OpusGpuMsEncBatch *m, int request, opus_int32 value)
+{
+   if (!m) return OPUS_BAD_ARG;
+   if (request & 1) return OPUS_BAD_ARG;                                  /* GETs: ask one encoder through the classic API */
+   const int r = opus_multistream_encoder_ctl(m->proto, request, value);
+   if (r != OPUS_OK) return r;
+   if (request == OPUS_SET_BITRATE_REQUEST) { m->last_frame_size = 0; return OPUS_OK; }
+   int e = OPUS_OK;
+   if (m->bc) e = opusgpu_enc_batch_ctl(m->bc, -1, request, value);
+   if (e == OPUS_OK && m->bm) e = opusgpu_enc_batch_ctl(m->bm, -1, request, value);
+   return e;
+}
+/* one frame of all B encoders, everything in HBM: d_pcm [B][frame_size][channels] int16 -> d_out [B][out_stride] packets, d_lens [B] (byte count or a negative
+ * OPUS_* code per encoder), d_final_range [B].  max_data_bytes as in opus_multistream_encode; see the header for the buffer-size condition. */
+int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
+      opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
+{
+   if (!m || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
+   const opus_int32 Fs = m->Fs;
+   if (oa_frame_size_select(m->application, frame_size, OPUS_FRAMESIZE_ARG, Fs) != frame_size) return OPUS_BAD_ARG;
+   const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;
+   const long long worst = (long long)(m->ns - 1) * (1276 * nf + 3) + OA_MS_FRAME_TMP + 3 * m->ns + 8;
+   opus_int32 vbr = 1;
+   (void)opus_multistream_encoder_ctl(m->proto, OPUS_GET_VBR_REQUEST, &vbr);
+   if (!vbr) return OPUS_UNIMPLEMENTED;                                   /* hard CBR chains the streams' budgets: classic entry points */
+   if (max_data_bytes < worst) return OPUS_BUFFER_TOO_SMALL;
+   HIPCHECK(hipSetDevice(m->device));
+   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : (m->bc ? m->bc->stream : m->bm->stream);
+   if (frame_size != m->last_frame_size) {                                /* per-stream rates depend on the frame rate (rate_allocation :702): refresh on change */
+      std::vector<opus_int32> rates((size_t)m->ns);
+      (void)oa_ms_rate_allocation(m->proto, rates.data(), frame_size);
+      for (int b = 0; b < m->B; b++) for (int k = 0; k < m->ns; k++) {
+         const int e = k < m->nc ? opusgpu_enc_batch_ctl(m->bc, b * m->nc + k, OPUS_SET_BITRATE_REQUEST, rates[k]) : opusgpu_enc_batch_ctl(m->bm, b * m->nm + (k - m->nc), OPUS_SET_BITRATE_REQUEST, rates[k]);
+         if (e != OPUS_OK) return e;
+      }
+      m->last_frame_size = frame_size;
+   }
+   const size_t need_c = (size_t)m->B * m->nc * frame_size * 2 * sizeof(i16), need_m = (size_t)m->B * m->nm * frame_size * sizeof(i16);
+   if (need_c > m->pc_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pc) (void)hipFree(m->d_pc); m->d_pc = nullptr; m->pc_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pc, need_c)); m->pc_cap = need_c; }
+   if (need_m > m->pm_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pm) (void)hipFree(m->d_pm); m->d_pm = nullptr; m->pm_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pm, need_m)); m->pm_cap = need_m; }
+   hipLaunchKernelGGL(oa_ms_split_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, (const i16 *)d_pcm, frame_size, m->nch, (const i32 *)m->d_chan, m->nc, m->nm, m->d_pc, m->d_pm);
+   HIPCHECK(hipGetLastError());
+   if (m->nc) { const int r = opusgpu_encode_batch_dev(m->bc, m->d_pc, frame_size, m->d_pkc, m->stride, 1276 * 6, m->d_lc, m->d_rc, s); if (r != OPUS_OK) return r; }
+   if (m->nm) { const int r = opusgpu_encode_batch_dev(m->bm, m->d_pm, frame_size, m->d_pkm, m->stride, 1276 * 6, m->d_lm, m->d_rm, s); if (r != OPUS_OK) return r; }
+   hipLaunchKernelGGL(oa_ms_pack_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
+         (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range);
+   HIPCHECK(hipGetLastError());
+   return OPUS_OK;
+}
+/* host-pointer convenience (tests): pcm [B][frame_size][channels], out [B][out_stride] */
+int opusgpu_ms_encode_batch(OpusGpuMsEncBatch *m, const opus_int16 *pcm, int frame_size, unsigned char *out, opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
+{
+   if (!m || !pcm || !out || !lens || !final_range || frame_size <= 0 || out_stride <= 0) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(m->device));
+   const size_t npcm = (size_t)m->B * frame_size * m->nch * sizeof(i16), nout = (size_t)m->B * out_stride;
+   if (npcm > m->pcm_cap) { if (m->d_pcm) (void)hipFree(m->d_pcm); m->d_pcm = nullptr; m->pcm_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pcm, npcm)); m->pcm_cap = npcm; }
+   if (nout > m->out_cap) { if (m->d_out) (void)hipFree(m->d_out); m->d_out = nullptr; m->out_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_out, nout)); m->out_cap = nout; }
+   HIPCHECK(hipMemcpy(m->d_pcm, pcm, npcm, hipMemcpyHostToDevice));
+   const int r = opusgpu_ms_encode_batch_dev(m, m->d_pcm, frame_size, m->d_out, out_stride, max_data_bytes, m->d_lens, m->d_rng, nullptr);
+   if (r != OPUS_OK) return r;
+   hipStream_t s = m->bc ? m->bc->stream : m->bm->stream;
+   HIPCHECK(hipStreamSynchronize(s));
+   HIPCHECK(hipMemcpy(out, m->d_out, nout, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(lens, m->d_lens, (size_t)m->B * 4, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(final_range, m->d_rng, (size_t)m->B * 4, hipMemcpyDeviceToHost));
+   return OPUS_OK;
+}
+}
+#endif

@@ -367,93 +367,6 @@ WV_DEV void sd_decode_parameters(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, int
 
 struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; WV_LDS SdCtrl *ctrl; i32 *cng_exc; /* this channel's CNG excitation buffer (HBM) */ };
 
-WV_DEV void sd_decode_core(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *xq, const SdScratch &S)               /* decode_core.c:38 */
-{
-   const WV_LDS OaSilkIndices *ix = &ch->indices;
-   const int L = ch->subfr_length, mem = ch->ltp_mem_length, P = ch->LPC_order;
-   const i32 offset_Q10 = k_silk_quant_offsets_Q10[(ix->signalType >> 1) * 2 + ix->quantOffsetType];
-   const int interp_flag = ix->NLSFInterpCoef_Q2 < 4;
-   i32 rand_seed = ix->Seed;
-   for (int i = 0; i < ch->frame_length; i++) {
-      rand_seed = sk_rand(rand_seed);
-      i32 e = shl32(S.pulses[i], 14);
-      if (e > 0) e -= 80 << 4; else if (e < 0) e += 80 << 4;
-      e += offset_Q10 << 4;
-      if (rand_seed < 0) e = -e;
-      ch->exc_Q14[i] = e;
-      rand_seed = add32(rand_seed, S.pulses[i]);
-   }
-   for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = ch->sLPC_Q14_buf[i];
-   const WV_LDS i32 *pexc = ch->exc_Q14;
-   WV_LDS i16 *pxq = xq;
-   int sLTP_buf_idx = mem, lag = 0;
-   for (int k = 0; k < ch->nb_subfr; k++) {
-      const WV_LDS i16 *A_Q12 = c->PredCoef_Q12[k >> 1];
-      WV_LDS i16 *B_Q14 = &c->LTPCoef_Q14[k * 5];
-      int signalType = ix->signalType;
-      const i32 Gain_Q10 = c->Gains_Q16[k] >> 6;
-      i32 inv_gain_Q31 = sk_inverse32_varQ(c->Gains_Q16[k], 47);
-      i32 gain_adj_Q16 = (i32)1 << 16;
-      if (c->Gains_Q16[k] != ch->prev_gain_Q16) {
-         gain_adj_Q16 = sk_div32_varQ(ch->prev_gain_Q16, c->Gains_Q16[k], 16);
-         for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = sk_mulww(gain_adj_Q16, S.sLPC_Q14[i]);
-      }
-      ch->prev_gain_Q16 = c->Gains_Q16[k];
-      if (ch->lossCnt && ch->prevSignalType == SD_TYPE_VOICED && ix->signalType != SD_TYPE_VOICED && k < 2) {
-         for (int i = 0; i < 5; i++) B_Q14[i] = 0;
-         B_Q14[2] = 4096;
-         signalType = SD_TYPE_VOICED;
-         c->pitchL[k] = ch->lagPrev;
-      }
-      if (signalType == SD_TYPE_VOICED) {
-         lag = c->pitchL[k];
-         if (k == 0 || (k == 2 && interp_flag)) {
-            const int start_idx = mem - lag - P - 2;
-            if (k == 2) for (int i = 0; i < 2 * L; i++) ch->outBuf[mem + i] = xq[i];
-            /* silk_LPC_analysis_filter(&sLTP[start_idx], &outBuf[start_idx + k*L], A_Q12, mem - start_idx, P) */
-            for (int n = 0; n < mem - start_idx; n++) {
-               i32 o = 0;
-               if (n >= P) {
-                  const WV_LDS i16 *in = &ch->outBuf[start_idx + k * L + n];
-                  i32 pred = 0;
-                  for (int j = 0; j < P; j++) pred = add32(pred, (i32)in[-1 - j] * A_Q12[j]);
-                  o = sk_sat16(sk_rround(sub32(shl32(in[0], 12), pred), 12));
-               }
-               S.sLTP[start_idx + n] = (i16)o;
-            }
-            if (k == 0) inv_gain_Q31 = shl32(sk_mulwb(inv_gain_Q31, c->LTP_scale_Q14), 2);
-            for (int i = 0; i < lag + 2; i++) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulwb(inv_gain_Q31, S.sLTP[mem - i - 1]);
-         } else if (gain_adj_Q16 != (i32)1 << 16) {
-            for (int i = 0; i < lag + 2; i++) S.sLTP_Q15[sLTP_buf_idx - i - 1] = sk_mulww(gain_adj_Q16, S.sLTP_Q15[sLTP_buf_idx - i - 1]);
-         }
-      }
-      const WV_LDS i32 *pres;
-      if (signalType == SD_TYPE_VOICED) {
-         for (int i = 0; i < L; i++) {
-            const WV_LDS i32 *pl = &S.sLTP_Q15[sLTP_buf_idx - lag + 2];
-            i32 LTP_pred_Q13 = 2;
-            for (int j = 0; j < 5; j++) LTP_pred_Q13 = sk_mlawb(LTP_pred_Q13, pl[-j], B_Q14[j]);
-            const i32 r = pexc[i] + shl32(LTP_pred_Q13, 1);
-            S.res_Q14[i] = r;
-            S.sLTP_Q15[sLTP_buf_idx] = shl32(r, 1);
-            sLTP_buf_idx++;
-         }
-         pres = 0;
-      } else pres = pexc;
-      for (int i = 0; i < L; i++) {
-         i32 LPC_pred_Q10 = P >> 1;
-         for (int j = 0; j < P; j++) LPC_pred_Q10 = sk_mlawb(LPC_pred_Q10, S.sLPC_Q14[16 + i - 1 - j], A_Q12[j]);
-         const i32 r = pres ? pres[i] : S.res_Q14[i];
-         const i32 v = sk_add_sat(r, sk_shl_sat(LPC_pred_Q10, 4));
-         S.sLPC_Q14[16 + i] = v;
-         pxq[i] = (i16)sk_sat16(sk_rround(sk_mulww(v, Gain_Q10), 8));
-      }
-      for (int i = 0; i < 16; i++) S.sLPC_Q14[i] = S.sLPC_Q14[L + i];
-      pexc += L; pxq += L;
-   }
-   for (int i = 0; i < 16; i++) ch->sLPC_Q14_buf[i] = S.sLPC_Q14[i];
-}
-
 WV_DEV void sd_reset(WV_LDS OaSilkChannel *ch)                                                                    /* init_decoder.c:43 (whole state) */
 {
    WV_LDS i32 *w = (WV_LDS i32 *)ch;
