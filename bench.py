@@ -266,7 +266,7 @@ def main():
             traffic = None; issue = None
             try:
                 pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")))["config_%d" % r["config_id"]]
-                traffic = int(pt["hbm_bytes_per_frame"] * Sn)
+                if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
                 issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (PMC passes of this build)"}
             except Exception: pass
             return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
