@@ -785,11 +785,14 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
          else if (decode_fec && (frame_size < packet_frame_size || packet_mode == 1002 || st->mode == 1002)) sh->count = -1;   /* no usable LBRR: conceal (src/opus_decoder.c:791-797) */
          else if (!decode_fec && count * packet_frame_size > frame_size) ret = OA_ERR_BUFFER_TOO_SMALL;
          else {
-            if (decode_fec) sh->r[5] = 1;
-            st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
             int endband = 21;
             switch (packet_bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
-            st->end = endband; st->start = 0;
+            if (decode_fec) {                       /* the leading samples are concealed with the PREVIOUS packet's parameters; the new ones apply from the LBRR frame on (src/opus_decoder.c:798-823) */
+               sh->r[5] = 1; sh->r[0] = packet_mode; sh->r[1] = packet_bandwidth; sh->r[2] = (toc & 0x4) ? 2 : 1; sh->r[3] = endband;
+            } else {
+               st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
+               st->end = endband; st->start = 0;
+            }
             sh->count = count; sh->packet_frame_size = packet_frame_size; sh->frame_bytes_off = offset;
          }
       }
@@ -800,6 +803,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
    const int count = wv_uni(sh->count), pfs = wv_uni(sh->packet_frame_size), CC = wv_uni(st->channels);
    int off = wv_uni(sh->frame_bytes_off), nb = 0;
    const int fec = wv_uni(sh->r[5]);
+   const int fec_mode = wv_uni(sh->r[0]), fec_bw = wv_uni(sh->r[1]), fec_ch = wv_uni(sh->r[2]), fec_end = wv_uni(sh->r[3]);     /* (the slots are reused by the frame functions below) */
    if (fec && ret >= 0) {
       /* in-band FEC (src/opus_decoder.c:798-824): conceal everything before the last packet_frame_size samples, then decode the LBRR copy of
        * the first frame in this packet into them */
@@ -810,6 +814,8 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
          nb += r;
       }
       if (ret >= 0) {
+         LANE0 { st->mode = fec_mode; st->bandwidth = fec_bw; st->frame_size = pfs; st->stream_channels = fec_ch; st->end = fec_end; st->start = 0; }
+         wv_sync();
          const int r = oa_decode_frame_wave(L, gs, data + off, wv_uni(sh->size[0]), pfs, pcm_out + (size_t)nb * CC, CC, 1);
          if (r < 0) ret = r; else nb = frame_size;
       }

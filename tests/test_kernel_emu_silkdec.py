@@ -148,6 +148,33 @@ def _run_fec(ch, frame, nframes, seed, lose, **ctl):
 def test_emu_inband_fec(ch, mode, bw, bitrate, frame):
     _run_fec(ch, frame, 26, seed=mode + bw + frame + ch, lose={3, 7, 8, 12, 16, 17, 18, 22}, force_mode=mode, bandwidth=bw, bitrate=bitrate)
 
+def test_emu_fec_packet_changes_parameters():
+    """the packet whose LBRR copy is used differs from the previous packet in bandwidth (hybrid SWB -> FB end band), stream channels and frame size, and the request is
+    longer than the packet: the leading samples are concealed with the PREVIOUS parameters, the packet's own apply from the LBRR frame on (src/opus_decoder.c:798-823)"""
+    ch = 2
+    sig = speechy(40, ch, 77, 960)
+    e = RefEnc(ch, application=2049, inband_fec=1, packet_loss=25, force_mode=1001, bandwidth=1104, bitrate=40000); r = RefDec(ch); k = EmuDec(ch)
+    req = dict(bandwidth=4008, force_channels=4022, bitrate=4002)
+    sched = {6: dict(bandwidth=1105), 12: dict(force_channels=1), 18: dict(bandwidth=1104, force_channels=2), 24: dict(bandwidth=1105, bitrate=56000)}
+    pos = 0; pk = []
+    for i in range(30):
+        if i in sched:
+            for kk, v in sched[i].items(): assert e.L.opus_encoder_ctl(e.st, req[kk], v) == 0
+        fr = 480 if 18 <= i < 24 else 960
+        pk.append((e.encode(np.ascontiguousarray(sig[pos:pos + fr]), fr)[0], fr)); pos += fr
+    lose = {5, 11, 17, 23}                         # each loss is followed by the first packet with the new parameters
+    used = 0
+    for i in range(30):
+        if i in lose:
+            want = pk[i][1]                        # the duration of the lost packet (as a jitter buffer would ask), with the NEXT packet's data and decode_fec = 1
+            a = r.decode(pk[i + 1][0], want, fec=1); b = k.decode(pk[i + 1][0], want, fec=1); used += 1
+        else:
+            a = r.decode(pk[i][0], pk[i][1]); b = k.decode(pk[i][0], pk[i][1])
+        assert a[0] == b[0], (i, a[0], b[0])
+        assert a[2] == b[2], (i, hex(a[2]), hex(b[2]))
+        assert np.array_equal(a[1], b[1]), (i, i in lose, np.nonzero(a[1] != b[1])[0][:6])
+    assert used == 4
+
 def test_emu_fec_request_on_celt_packets_conceals():
     """decode_fec on CELT-only packets (no LBRR exists) = concealment (src/opus_decoder.c:791-797)"""
     sig = speechy(10, 1, 3, 960)
