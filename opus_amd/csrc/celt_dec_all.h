@@ -3,7 +3,7 @@
 #ifndef OPUS_AMD_CELT_DEC_ALL_H
 #define OPUS_AMD_CELT_DEC_ALL_H
 #include "celt_dec_lds.h"
-#include "celt_dec_serial.h"
+#include "celt_dec_energy.h"
 #include "celt_dec_bands.h"
 #include "celt_dec_frame.h"
 #endif

@@ -5,15 +5,15 @@
 #ifndef OPUS_AMD_CELT_DEC_BANDS_H
 #define OPUS_AMD_CELT_DEC_BANDS_H
 
-/* alg_unquant: the pulse vector is decoded serially (cwrsi walks the index), everything after it is elementwise / in registers */
+/* alg_unquant: cwrsi walks the index with the wave holding one row of U(n,k) per step (celt_dec_energy.h), everything after it is elementwise / in registers */
 template <int NR> WV_DEV unsigned alg_unquant_regs(WV_LDS DecLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain)
 {
    const int lane = wv_lane();
    WV_LDS i32 *iy = L->BC.q.iy;
    const u32 ft = pvq_u(N, K) + pvq_u(N, K + 1);
    wv_sync();
-   LANE0 { EC_BEGIN; u32 idx = k_ec_dec_uint(EC_PASS, ft); i32 yy_ = k_cwrsi(N, K, idx, iy); L->sh.r[0] = yy_; EC_END; }
-   const i32 Ryy = wv_uni(L->sh.r[0]);
+   LANE0 { EC_BEGIN; L->sh.r[0] = (i32)k_ec_dec_uint(EC_PASS, ft); EC_END; }
+   const i32 Ryy = cwrsi_wave(N, K, (u32)wv_uni(L->sh.r[0]), iy);
    i32 v[NR], q[NR];
    for (int t = 0; t < NR; t++) q[t] = lane + 64 * t < N ? iy[lane + 64 * t] : 0;
    int k = celt_ilog2(Ryy) >> 1;

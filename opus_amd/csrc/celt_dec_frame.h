@@ -266,8 +266,8 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
             }
          }
       }
-      k_unquant_coarse_energy(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM);
-      k_tf_decode(start, end, isTransient, L->tf_res, LM, EC_PASS);
+      coarse_energy_read_l0(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM, L->scr);
+      tf_read_l0(start, end, isTransient, L->tf_res, LM, EC_PASS);
       tell = k_ec_tell(EC_PASS);
       int spread_decision = 2;
       if (tell + 4 <= total_bits) spread_decision = k_ec_dec_icdf(EC_PASS, k_spread_icdf, 5);
@@ -307,12 +307,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
             L->pulses, L->fine_quant, L->fine_priority, sh->C, sh->LM, 0, 0, sh->r + 6);
       LANE0 sh->codedBands = coded;
    }
-   LANE0 {
-      EcCtx ec_; ec_ld(&ec_, &L->ec); EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
-      k_unquant_fine_energy(sh->start, sh->end, L->oldBandE, L->fine_quant, EC_PASS, sh->C);
-      ec_st(&L->ec, &ec_);
-   }
-   wv_sync();
+   fine_energy_read_wave(&L->ec, L->packet + 1, L->scr, sh->r + 6, sh->start, sh->end, L->oldBandE, L->fine_quant, sh->C);
    /* X starts at zero (the reference's bands below start / above end are never written) */
    FOR_LANES(i, C * N) L->A.X[i] = 0;
    wv_sync();
@@ -321,11 +316,11 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
       EC_BEGIN;
       int anti_collapse_on = 0;
       if (sh->anti_collapse_rsv > 0) anti_collapse_on = k_ec_dec_bits(EC_PASS, 1);
-      k_unquant_energy_finalise(start, end, L->oldBandE, L->fine_quant, L->fine_priority, len * 8 - k_ec_tell(EC_PASS), EC_PASS, C);
+      sh->r[6] = (i32)energy_finalise_read_l0(start, end, L->fine_quant, L->fine_priority, len * 8 - k_ec_tell(EC_PASS), L->scr, EC_PASS, C);
       sh->anti_collapse_on = anti_collapse_on;
       EC_END;
    }
-   wv_sync();
+   energy_finalise_apply_dec_wave((u32)wv_uni(sh->r[6]), L->scr, L->oldBandE, L->fine_quant, C);
    if (sh->anti_collapse_on) anti_collapse_wave(L, LM, C, N, start, end);
    const int silence = wv_uni(sh->silence), isTransient = wv_uni(sh->isTransient);
    if (silence) { wv_sync(); FOR_LANES(i, C * NBE) L->oldBandE[i] = -GC(28.f); wv_sync(); }

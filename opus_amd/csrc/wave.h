@@ -12,7 +12,9 @@
 #include <stdint.h>
 
 #define WV_DEV  __device__ __forceinline__
+#ifndef WV_DEVN
 #define WV_DEVN __device__ __noinline__
+#endif
 #define WV_MEM  __device__ __forceinline__          /* member functions */
 #define WV_HD   __host__ __device__ inline          /* small pure helpers shared with host code */
 #define WV_LDS  __attribute__((address_space(3)))
