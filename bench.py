@@ -118,7 +118,7 @@ def copy_bandwidth(dev):
     e1.record(); torch.cuda.synchronize(dev)
     return 4 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=True, frames_per_launch=0):
+def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=True, frames_per_launch=0, decode=False):
     """times K frame-steps of BASELINE config `cid` on this rank; returns a result dict (rank-local figures; the caller reduces dt over ranks)"""
     import torch, torch.distributed as dist
     import opus_amd
@@ -210,7 +210,37 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r = L.opusgpu_encode_batch_dev_frames(b._b, pcm.data_ptr(), FR, Tn, outs.data_ptr(), STRIDE, 1276, lns.data_ptr(), rgs.data_ptr(), stream.cuda_stream)
         e1.record(stream); torch.cuda.synchronize(dev)
         if r == 0: res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1)}
-    if with_cpu:
+    if decode and cid != 5:
+        # the decoder on these very streams: a fresh encoder batch produces the T packets of every stream (untimed), a decoder batch then decodes them step by step
+        # with its state carried in HBM; timed like the encoder (HIP events per launch, barrier + synchronize around the K steps)
+        e2 = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
+        for req, v in cfg["ctls"]: e2.ctl(req, v)
+        pk = torch.zeros((T, S, STRIDE), dtype=torch.uint8, device=dev); pl = torch.zeros((T, S), dtype=torch.int32, device=dev)
+        for t in range(T): e2.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, pl[t].data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev); e2.close()
+        d = opus_amd.DecoderBatch(S, channels=CH, Fs=Fs, device=local)
+        dpcm = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((S,), dtype=torch.int32, device=dev)
+        for t in range(W): d.decode_dev(pk[t].data_ptr(), STRIDE, pl[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if world > 1: dist.barrier()
+        dev_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        t0 = time.perf_counter()
+        for k in range(K):
+            dev_ev[k][0].record(stream)
+            d.decode_dev(pk[W + k].data_ptr(), STRIDE, pl[W + k].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+            dev_ev[k][1].record(stream)
+        torch.cuda.synchronize(dev)
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize(dev)
+        res["dt"] = time.perf_counter() - t0
+        res["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
+        res["kernel"] = "oa_decode_kernel"
+        res["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool((drng.cpu().numpy() == rng.cpu().numpy()).all())      # every stream decoded FR samples and ends on the encoder's final range
+        L.opusgpu_dec_state_size.restype = ctypes.c_int
+        res["algorithmic_bytes_per_frame"] = round(FR * CH * 2 + mean_len + 8 + 2 * L.opusgpu_dec_state_size(), 1)
+        res["metric"] = "decoded frames/s (" + cfg["metric"].split("(", 1)[1]
+        d.close(); del pk, dpcm
+    if with_cpu and not decode:
         res["pcm0"] = (pcm[:, 0, :, 0] if cid == 5 else pcm[:, 0, :]).cpu().numpy().reshape(T, FR * CH)
     b.close()
     del pcm, out
@@ -226,6 +256,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="also time T consecutive frame-steps in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first, untimed) instead of the encoder")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the short config 3 / 4 legs")
     a = ap.parse_args()
     import torch, torch.distributed as dist
@@ -249,14 +280,14 @@ def main():
     S = a.streams or (257 * 255 if a.config == 5 else 65536)
     K, W = a.steps, a.warmup
     main_res = run_config(a.config, S, K, W, dev, local, rank, world, gather_cls=PacketGather, with_cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline),
-                          frames_per_launch=a.frames_per_launch)
+                          frames_per_launch=a.frames_per_launch, decode=a.decode)
     tt = torch.tensor([main_res["dt"]], dtype=torch.float64, device=dev)
     if world > 1:
         if backend != "nccl": tt = tt.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     extras = []
-    if world == 1 and a.config == 2 and not a.no_extra_configs:
+    if world == 1 and a.config == 2 and not a.no_extra_configs and not a.decode:
         for cid in (3, 4):
             extras.append(run_config(cid, S, max(3, K // 2), 2, dev, local, rank, world, with_cpu=not a.no_cpu_baseline))
     if rank == 0:
@@ -275,10 +306,10 @@ def main():
                     "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)"}
         frames = S * world * K
         res = {
-            "metric": CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
+            "metric": main_res["metric"] if a.decode else (CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"), "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-            "config": {"workload": CONFIGS[a.config]["name"] + ", bit-exact fixed-point", "baseline_config": a.config,
+            "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point", "baseline_config": a.config,
                        "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather of the compacted packets in the timed region" if world > 1 else "")},
             "roofline": roof(main_res, S),

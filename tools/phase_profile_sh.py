@@ -9,7 +9,7 @@ PH = ["load state", "silence+decide+highpass", "silk_Encode front (control, resa
 def main():
     so = os.path.join(ROOT, "opus_amd/libopus_amd_prof.so")
     hd = os.path.join(ROOT, "opus_amd/csrc")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(hd, f)) for f in os.listdir(hd)):
+    if not os.path.exists(so) or (os.environ.get("OPUS_AMD_PROF_PREBUILT") != "1" and os.path.getmtime(so) < max(os.path.getmtime(os.path.join(hd, f)) for f in os.listdir(hd))):
       subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DOA_PHASE_TIMERS",
                            "-I" + os.path.join(ROOT, "opus_amd/csrc"), "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "opus_amd/csrc/opus_amd.hip"), "-o", so])
     import opus_amd
