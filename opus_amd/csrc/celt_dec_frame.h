@@ -1,8 +1,8 @@
 /* celt_dec_frame.h — CELT frame decoder + Opus packet layer for CELT-only packets, one wavefront per stream.
  * Reference: src/opus.c:203/:224 (packet parse), src/opus_decoder.c:271/:716 (opus_decode_frame / _native, CELT-only branch),
  * celt/celt_decoder.c:1104 (celt_decode_with_ec), :413 (celt_synthesis), :318 (deemphasis), celt/mdct.c:268
- * (clt_mdct_backward), celt/celt.c:238 (comb_filter, in place = recursive).  Not built: PLC / FEC / DTX (len <= 1 frames,
- * data == NULL), SILK and hybrid packets, mode transitions -> OPUS_UNIMPLEMENTED per stream. */
+ * (clt_mdct_backward), celt/celt.c:238 (comb_filter, in place = recursive).  The Opus layer below (oa_decode_frame_wave, oa_conceal_wave, oa_decode_packet)
+ * covers every packet mode (SILK and hybrid through silk_dec*.h), mode transitions with redundancy frames, concealment / DTX / in-band FEC, and every API rate. */
 #ifndef OPUS_AMD_CELT_DEC_FRAME_H
 #define OPUS_AMD_CELT_DEC_FRAME_H
 

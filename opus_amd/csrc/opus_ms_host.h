@@ -2,9 +2,9 @@
  * src/opus_multistream_encoder.c, src/opus_multistream_decoder.c) on top of the batch kernels: the streams of one multistream
  * frame are independent CELT encodes / decodes, so ONE launch per group (coupled streams, mono streams) does a whole frame of up to
  * 255 channels.  Host code only orchestrates: layout, rate allocation, channel (de)interleaving, self-delimited packing.
- * Scope: every application (the CELT-only ones run the CELT kernel, VOIP / AUDIO / RESTRICTED_SILK the SILK-capable kernel with the mode decisions
- * that kernel builds), mapping families 0, 2, 255 and
- * family 1 up to two channels (the surround masking analysis of family 1 with > 2 channels is not built -> OPUS_UNIMPLEMENTED). */
+ * Scope: every application (the CELT-only ones run the CELT kernel, VOIP / AUDIO / RESTRICTED_SILK the SILK-capable kernel), mapping families 0, 1 (the surround
+ * masking analysis runs on the device, opus_surround*.h), 2 and 255; other families answer OPUS_UNIMPLEMENTED as the reference does.  A device-resident batch of
+ * encoders with the packing on the device: opus_ms_batch.h. */
 #ifndef OPUS_AMD_MS_HOST_H
 #define OPUS_AMD_MS_HOST_H
 #include <map>
