@@ -171,6 +171,61 @@ WV_DEV void find_best_pitch_l0(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int
    }
 }
 
+/* find_best_pitch on the wave.  The two things the serial form chains are separable: the running window energy is Syy0 + a prefix sum of (entering - leaving)
+ * squares -- exact integer adds, so a wave scan gives every lag its Syy at once (the reference's clamp max(1, .) only acts on an all-zero window: detected, and then
+ * the serial form runs instead) -- and the best-two selection, whose cross-multiplied comparisons round and are therefore order-dependent, is replayed in lag order on
+ * wave-uniform values fetched with v_readlane: no LDS traffic, the compares run on the scalar unit.  Lane l owns lags l * per .. l * per + per - 1. */
+WV_DEV void find_best_pitch_wave(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, int len, int max_pitch, int *best_pitch, int yshift, i32 maxcorr, WV_LDS i32 *hand)
+{
+   const int lane = wv_lane(), per = (max_pitch + WV_WIDTH - 1) / WV_WIDTH, xshift = celt_ilog2(maxcorr) - 14;
+   i32 e0 = 0;
+   FOR_LANES(j, len) e0 = add32(e0, mult16_16(y[j], y[j]) >> yshift);
+   const i32 Syy0 = add32(1, wv_sum(e0));
+   i32 S[8], nm[8], acc = 0, low = 1;
+#pragma unroll
+   for (int t = 0; t < 8; t++) {
+      const int i = lane * per + t;
+      S[t] = acc; nm[t] = -1;
+      if (t < per && i < max_pitch) {
+         acc += (mult16_16(y[i + len], y[i + len]) >> yshift) - (mult16_16(y[i], y[i]) >> yshift);
+         const i32 xc = xcorr[i];
+         if (xc > 0) { const i16 x16 = extract16(vshr32(xc, xshift)); nm[t] = (i16)mult16_16_q15(x16, x16); }
+      }
+   }
+   const i32 base = Syy0 + wv_scan_incl(acc) - acc;                /* window energy in front of this lane's first lag */
+#pragma unroll
+   for (int t = 0; t < 8; t++) S[t] += base;
+   /* the clamp would have acted iff some window energy (after lag i's update) falls below 1 */
+#pragma unroll
+   for (int t = 0; t < 8; t++) {
+      const int i = lane * per + t;
+      if (t < per && i < max_pitch) { const i32 nxt = S[t] + ((mult16_16(y[i + len], y[i + len]) >> yshift) - (mult16_16(y[i], y[i]) >> yshift)); low = imin(low, nxt); }
+   }
+   if (wv_min(low) < 1) {                                            /* digital silence inside the window: the clamped recurrence, as written in the reference */
+      LANE0 { int bp[2]; find_best_pitch_l0(xcorr, y, len, max_pitch, bp, yshift, maxcorr); hand[0] = bp[0]; hand[1] = bp[1]; }
+      best_pitch[0] = wv_uni(hand[0]); best_pitch[1] = wv_uni(hand[1]);
+      wv_sync();
+      return;
+   }
+   i32 num0 = -1, num1 = -1, den0 = 0, den1 = 0; int p0 = 0, p1 = 1;
+   for (int l = 0; l < WV_WIDTH && l * per < max_pitch; l++) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+         if (t < per && l * per + t < max_pitch) {
+            const i32 n = wv_bcast(nm[t], l);
+            if (n >= 0) {
+               const i32 sy = wv_bcast(S[t], l);
+               if (mult16_32_q15((i16)n, den1) > mult16_32_q15((i16)num1, sy)) {
+                  if (mult16_32_q15((i16)n, den0) > mult16_32_q15((i16)num0, sy)) { num1 = num0; den1 = den0; p1 = p0; num0 = n; den0 = sy; p0 = l * per + t; }
+                  else { num1 = n; den1 = sy; p1 = l * per + t; }
+               }
+            }
+         }
+      }
+   }
+   best_pitch[0] = p0; best_pitch[1] = p1;
+}
+
 /* pitch_search (pitch.c:307); returns the pitch lag in every lane */
 WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LDS i16 *x_lp4, WV_LDS i16 *y_lp4, WV_LDS i32 *xcorr, WV_LDS i32 *hand, int len, int max_pitch)
 {
@@ -197,13 +252,9 @@ WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LD
    }
    maxcorr = wv_max(maxcorr);
    wv_sync();
-   LANE0 {
-      int bp[2];
-      find_best_pitch_l0(xcorr, y_lp4, len >> 2, max_pitch >> 2, bp, 0, maxcorr);
-      hand[0] = bp[0]; hand[1] = bp[1];
-   }
-   wv_sync();
-   int bp0 = hand[0], bp1 = hand[1];
+   int bpa[2];
+   find_best_pitch_wave(xcorr, y_lp4, len >> 2, max_pitch >> 2, bpa, 0, maxcorr, hand);
+   const int bp0 = bpa[0], bp1 = bpa[1];
    wv_sync();
    /* finer search, 2x decimated, around the two candidates */
    maxcorr = 1;
@@ -218,9 +269,10 @@ WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LD
       maxcorr = imax(maxcorr, s);
    }
    wv_sync();
+   int bpb[2];
+   find_best_pitch_wave(xcorr, y, len >> 1, max_pitch >> 1, bpb, shift + 1, maxcorr, hand);
    LANE0 {
-      int bp[2] = {bp0, bp1};
-      find_best_pitch_l0(xcorr, y, len >> 1, max_pitch >> 1, bp, shift + 1, maxcorr);
+      const int bp[2] = {bpb[0], bpb[1]};
       int offset = 0;
       if (bp[0] > 0 && bp[0] < (max_pitch >> 1) - 1) {
          i32 a = xcorr[bp[0] - 1], b = xcorr[bp[0]], c = xcorr[bp[0] + 1];

@@ -156,6 +156,7 @@ struct OpusGpuEncBatch {
    char *d_scratch; size_t scratch_cap;  /* per-wave HBM scratch of the frames in flight (CeltScratch; kind 1: SH_SCRATCH_BYTES) */
    unsigned *d_queue;                    /* the launch's stream queue (next unclaimed stream) */
    int num_cu;
+   const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    int device;
    opus_int32 S;
    int channels;
@@ -200,7 +201,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
-      b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0;
+      b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -314,9 +315,12 @@ int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HI
  * per-wave scratch covers it and resets the stream queue on the launch's HIP stream */
 static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds_bytes, size_t scratch_per_wave, hipStream_t s, int *grid_out)
 {
-   int per_cu = 0;
-   HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds_bytes));
-   if (per_cu < 1) per_cu = 1;
+   int per_cu = b->occ_per_cu;
+   if (b->occ_kernel != kernel || b->occ_lds != lds_bytes) {
+      HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds_bytes));
+      if (per_cu < 1) per_cu = 1;
+      b->occ_kernel = kernel; b->occ_lds = lds_bytes; b->occ_per_cu = per_cu;
+   }
    long long grid = (long long)per_cu * (b->num_cu > 0 ? b->num_cu : 1);
    static const int grid_env = getenv("OPUS_AMD_GRID") ? atoi(getenv("OPUS_AMD_GRID")) : 0;                 /* experiments only */
    if (grid_env > 0) grid = grid_env;
