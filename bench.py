@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+CORPUS = "pool"          # --corpus reference: the reference's generate_music() tunes instead of this repo's music / noise-burst pool
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
@@ -30,10 +31,36 @@ CONFIGS = {
             app=2049, Fs=48000, ch=1, kernel="oa_sh_encode_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
 
-def synth(cfg, T, n_pool, rank):
+def reference_music(nsamp, seed):
+    """the reference's own test corpus: generate_music() of tests/test_opus_encode.c:57-85 (a byte-beat tune through two rounding one-pole filters, dithered with the
+    fast_rand() multiply-with-carry generator of tests/test_opus_common.h:56-62), restated here because the bench input must not come from oracle/; stereo int16
+    [nsamp, 2].  The 60 ms of leading silence are skipped (a bench step should not time digital silence)."""
+    Rz, Rw = (seed * 2654435761) & 0xffffffff or 1, (seed * 40503 + 12345) & 0xffffffff or 1
+    out = np.zeros((nsamp, 2), np.int16)
+    a1 = b1 = a2 = b2 = c1 = c2 = d1 = d2 = 0; j = 0
+    def asr(x, n): return x >> n                                                   # Python ints: arithmetic shift, unbounded (the C code stays within 32 bits)
+    for i in range(nsamp):
+        v1 = v2 = (((j * ((j >> 12) ^ ((j >> 10 | j >> 12) & 26 & j >> 7))) & 128) + 128) << 15
+        Rz = (36969 * (Rz & 65535) + (Rz >> 16)) & 0xffffffff; Rw = (18000 * (Rw & 65535) + (Rw >> 16)) & 0xffffffff; r = ((Rz << 16) + Rw) & 0xffffffff
+        v1 += (r & 65535) - (r >> 16)
+        Rz = (36969 * (Rz & 65535) + (Rz >> 16)) & 0xffffffff; Rw = (18000 * (Rw & 65535) + (Rw >> 16)) & 0xffffffff; r = ((Rz << 16) + Rw) & 0xffffffff
+        v2 += (r & 65535) - (r >> 16)
+        b1 = v1 - a1 + asr(b1 * 61 + 32, 6); a1 = v1
+        b2 = v2 - a2 + asr(b2 * 61 + 32, 6); a2 = v2
+        c1 = asr(30 * (c1 + b1 + d1) + 32, 6); d1 = b1
+        c2 = asr(30 * (c2 + b2 + d2) + 32, 6); d2 = b2
+        out[i, 0] = max(-32768, min(32767, asr(c1 + 128, 8))); out[i, 1] = max(-32768, min(32767, asr(c2 + 128, 8)))
+        if (i + 2880) % 6 == 0: j += 1
+    return out
+
+def synth(cfg, T, n_pool, rank, corpus="pool"):
     """pool of distinct signals [n_pool, (T+2)*frame*ch] int16 at the config's rate"""
     import signals
     Fs, ch, fr = cfg["Fs"], cfg["ch"], cfg["Fs"] // 50
+    if corpus == "reference" and Fs == 48000:
+        n_pool = min(n_pool, 16)                                                   # (a pure-Python recurrence: a few seconds for 16 tunes)
+        tunes = [reference_music((T + 2) * fr, 1000 * rank + p + 1) for p in range(n_pool)]
+        return np.stack([(t if ch == 2 else t[:, :1]).reshape(-1) for t in tunes])
     if Fs == 48000:
         return np.stack([(signals.music(T + 2, channels=ch, seed=1000 * rank + p) if p % 4 else signals.noise_bursts(T + 2, channels=ch, seed=1000 * rank + p)).reshape(-1) for p in range(n_pool)])
     rng = np.random.default_rng(77 + rank)
@@ -125,7 +152,8 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     cfg = CONFIGS[cid]
     Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; T = K + W
     P = 256
-    pool = synth(cfg, T, P, rank)
+    pool = synth(cfg, T, P, rank, corpus=CORPUS)
+    P = pool.shape[0]
     pool_d = torch.from_numpy(pool).to(dev)
     g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
     pid = torch.randint(0, P, (S,), generator=g).to(dev)
@@ -256,9 +284,12 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="also time T consecutive frame-steps in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus", default="pool", choices=["pool", "reference"], help="input signals: this repo's music / noise-burst pool (default) or the reference's generate_music() tunes (tests/test_opus_encode.c:57)")
     ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first, untimed) instead of the encoder")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the short config 3 / 4 legs")
     a = ap.parse_args()
+    global CORPUS
+    CORPUS = a.corpus
     import torch, torch.distributed as dist
     import opus_amd
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -308,7 +339,7 @@ def main():
         res = {
             "metric": main_res["metric"] if a.decode else (CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"), "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i32", "data": "synthetic" if a.corpus == "pool" else "synthetic (the reference's generate_music() tunes, tests/test_opus_encode.c:57)",
             "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point", "baseline_config": a.config,
                        "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather of the compacted packets in the timed region" if world > 1 else "")},
