@@ -129,8 +129,11 @@ WV_DEV unsigned dec_quant_band_n1_wave(WV_LDS DecLds *L, i32 &remaining_bits, WV
    return 1;
 }
 
+/* (as in the encoder: the body is inlined at its single depth-0 call site, deeper levels are out-of-line instantiations) */
+template <int DEPTH> WV_DEVN i32x4 dec_quant_partition_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, i32 gain, int fill);
 template <int DEPTH>
-WV_DEVN i32x4 dec_quant_partition_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+WV_DEV i32x4 dec_quant_partition_body(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
       int LM, i32 gain, int fill)
 {
    cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
@@ -225,6 +228,12 @@ WV_DEVN i32x4 dec_quant_partition_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remain
    return ret3(cm, remaining_bits, seed);
 }
 
+template <int DEPTH> WV_DEVN i32x4 dec_quant_partition_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, i32 gain, int fill)
+{
+   return dec_quant_partition_body<DEPTH>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
+}
+
 WV_DEVN i32x4 dec_quant_band_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
       WV_LDS i32 *lowband_out, i32 gain, WV_LDS i32 *lowband_scratch, int fill)
 {
@@ -263,7 +272,7 @@ WV_DEVN i32x4 dec_quant_band_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_b
    N_B0 = N_B;
    if (B0 > 1 && lowband) deinterleave_hadamard_wave(lowband, N_B >> recombine, B0 << recombine, longBlocks);
    {
-      const i32x4 r = dec_quant_partition_wave<0>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
+      const i32x4 r = dec_quant_partition_body<0>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
       cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
    }
    {
@@ -292,7 +301,7 @@ WV_DEVN i32x4 dec_quant_band_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_b
    return ret3(cm, remaining_bits, seed);
 }
 
-WV_DEVN i32x4 dec_quant_band_stereo_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B,
+WV_DEV i32x4 dec_quant_band_stereo_wave(WV_LDS DecLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B,
       WV_LDS i32 *lowband, int LM, WV_LDS i32 *lowband_out, WV_LDS i32 *lowband_scratch, int fill)
 {
    cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);

@@ -16,6 +16,9 @@
 #define K_DUMPI(tag, v)
 #endif
 #define LOG_MAX_PSEUDO 6
+#ifndef OA_PVQ_STEREO_FN            /* inlined into its three call sites: out of line (-DOA_PVQ_STEREO_FN=WV_DEVN) it saves and restores 13 VGPRs per call, 27 % of the frame's HBM traffic (profiles/r02_l) */
+#define OA_PVQ_STEREO_FN WV_DEV
+#endif
 #ifndef K_TIC
 #define K_TIC()
 #define K_TOC(bucket)
@@ -581,9 +584,12 @@ WV_DEV unsigned quant_band_n1_wave(WV_LDS FrameLds *L, const BandCfg &cfg, i32 &
    return 1;
 }
 
-/* quant_partition (bands.c:973).  Returns {collapse mask, remaining_bits, seed}. */
+/* quant_partition (bands.c:973).  Returns {collapse mask, remaining_bits, seed}.  The body is inlined where depth 0 starts (one call site, quant_band_wave); the deeper
+ * levels are out-of-line instantiations (each saves / restores the VGPRs it keeps SGPR spills in: a per-call cost worth paying only where the code would multiply). */
+template <int DEPTH> WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, i32 gain, int fill);
 template <int DEPTH>
-WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+WV_DEV i32x4 quant_partition_body(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
       int LM, i32 gain, int fill)
 {
    cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
@@ -678,6 +684,12 @@ WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remainin
    return ret3(cm, remaining_bits, seed);
 }
 
+template <int DEPTH> WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband,
+      int LM, i32 gain, int fill)
+{
+   return quant_partition_body<DEPTH>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
+}
+
 /* quant_band (bands.c:1248).  Returns {collapse mask, remaining_bits, seed}. */
 WV_DEVN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
       WV_LDS i32 *lowband_out, i32 gain, WV_LDS i32 *lowband_scratch, int fill)
@@ -724,7 +736,7 @@ WV_DEVN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bit
    }
    K_TOC(22);
    {
-      const i32x4 r = quant_partition_wave<0>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
+      const i32x4 r = quant_partition_body<0>(L, cfg, remaining_bits, seed, X, N, b, B, lowband, LM, gain, fill);
       cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
    }
    K_TOC(24);
@@ -756,7 +768,7 @@ WV_DEVN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bit
 }
 
 /* quant_band_stereo (bands.c:1387).  Returns {collapse mask, remaining_bits, seed}. */
-WV_DEVN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B,
+OA_PVQ_STEREO_FN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, WV_LDS i32 *Y, int N, int b, int B,
       WV_LDS i32 *lowband, int LM, WV_LDS i32 *lowband_out, WV_LDS i32 *lowband_scratch, int fill)
 {
    cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
