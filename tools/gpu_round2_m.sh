@@ -1,0 +1,17 @@
+cd $GRAFT_REPO_ROOT && O=gpurun_out/r02m && mkdir -p $O && export TMPDIR=/tmp
+B="python bench.py --no-cpu-baseline --no-extra-configs --steps 8"
+( $B ) > $O/bench_c2.log 2>&1
+( $B --decode ) > $O/bench_c2_decode.log 2>&1
+for f in $O/bench_*.log; do echo $f; grep -o '"value": [0-9.]*' $f | head -1; done
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_decoder.py tests/test_gpu_silkenc.py -x -q -k "not soak" ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-include-regex oa_encode -f csv -d /tmp/pmc_m_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs --streams 16384 > /dev/null 2>&1
+  find /tmp/pmc_m_$c -name '*counter_collection.csv' -exec cp {} $GRAFT_REPO_ROOT/$O/pmc_$c.csv \;
+done
+python3 - <<'PY'
+import csv,glob,os
+for f in sorted(glob.glob(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r02m/pmc_*.csv")):
+    v=[float(r["Counter_Value"]) for r in csv.DictReader(open(f))]
+    print(os.path.basename(f), sum(v)/len(v))
+PY
