@@ -16,6 +16,9 @@
 #define K_DUMPI(tag, v)
 #endif
 #define LOG_MAX_PSEUDO 6
+#ifndef OA_ALG_QUANT_FN             /* (A/B experiments: -DOA_ALG_QUANT_FN=WV_DEV inlines the 6 k-instruction quantiser into every partition level) */
+#define OA_ALG_QUANT_FN WV_DEVN
+#endif
 #ifndef OA_PVQ_STEREO_FN            /* inlined into its three call sites: out of line (-DOA_PVQ_STEREO_FN=WV_DEVN) it saves and restores 13 VGPRs per call, 27 % of the frame's HBM traffic (profiles/r02_l) */
 #define OA_PVQ_STEREO_FN WV_DEV
 #endif
@@ -432,7 +435,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
    K_TOC(19);
    return cm;
 }
-WV_DEVN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
+OA_ALG_QUANT_FN unsigned alg_quant_wave(WV_LDS FrameLds *L, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
 {
    N = wv_uni(N); K = wv_uni(K); spread = wv_uni(spread); B = wv_uni(B); gain = wv_uni(gain); resynth = wv_uni(resynth);
    if (N <= 64) return alg_quant_regs<1>(L, X, N, K, spread, B, gain, resynth);
