@@ -145,6 +145,33 @@ def test_gpu_full_size_properties():
     b.close()
 
 
+@pytest.mark.parametrize("name,Fs,ch,app,ctl", [
+    ("config 3", 16000, 1, 2048, ((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10))),
+    ("config 4", 48000, 2, 2049, ((11002, 1001), (4008, 1105), (4002, 128000), (4010, 10)))])
+def test_gpu_full_size_properties_silk_and_hybrid(name, Fs, ch, app, ctl):
+    """the SILK-capable kernel at BASELINE width: 65,536 streams of config 3 / config 4, 32 distinct signals tiled over them, three consecutive frames with the state
+    carried on the device; every replica must agree with the compiled reference encoder in length and final range, sampled replicas byte for byte"""
+    import capi
+    from test_kernel_emu_silkdec import speechy
+    oa = _oa()
+    S, U, n = 65536, 32, Fs // 50
+    b = oa.EncoderBatch(S, channels=ch, application=app, Fs=Fs)
+    for req, v in ctl: b.ctl(req, v)
+    step = 48000 // Fs
+    base = [np.ascontiguousarray(speechy(5, ch, 400 + k, 960)[::step]) for k in range(U)]
+    req_name = {11002: "force_mode", 4008: "bandwidth", 4002: "bitrate", 4010: "complexity"}
+    refs = [capi.Enc("ref", Fs, ch, app, **{req_name[r]: v for r, v in ctl}) for _ in range(U)]
+    for i in range(3):
+        fr = np.stack([base[k][i * n:(i + 1) * n].reshape(-1) for k in range(U)])
+        pk, lens, rng = b.encode(np.tile(fr, (S // U, 1)), n)
+        for k in range(U):
+            a = refs[k].encode(np.ascontiguousarray(base[k][i * n:(i + 1) * n]), n)
+            idx = np.arange(k, S, U)
+            assert np.all(lens[idx] == a[1]) and np.all(rng[idx] == a[2]), (name, i, k)
+            for s in (k, k + U * 1000, k + U * 2047): assert pk[s] == a[0], (name, i, k, s)
+    b.close()
+
+
 def test_gpu_parity_soak_with_midstream_ctls():
     """the parity gate of SURVEY 8d inside the suite: configs 2, 3 and 4, 256 streams x 1000 consecutive frames each, 64 distinct base signals (the rest are
     shifted / scaled copies), bitrate / complexity / VBR / FEC / DTX / bandwidth / channel changes applied mid-stream to the batch and to every reference
