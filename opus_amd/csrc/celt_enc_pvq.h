@@ -16,6 +16,9 @@
 #define K_DUMPI(tag, v)
 #endif
 #define LOG_MAX_PSEUDO 6
+#ifndef OA_QUANT_BAND_FN            /* inlined too (+0.9 %, -14 % traffic, profiles/r02_o); -DOA_QUANT_BAND_FN=WV_DEVN puts it back out of line */
+#define OA_QUANT_BAND_FN WV_DEV
+#endif
 #ifndef OA_ALG_QUANT_FN             /* (A/B experiments: -DOA_ALG_QUANT_FN=WV_DEV inlines the 6 k-instruction quantiser into every partition level) */
 #define OA_ALG_QUANT_FN WV_DEVN
 #endif
@@ -694,7 +697,7 @@ template <int DEPTH> WV_DEVN i32x4 quant_partition_wave(WV_LDS FrameLds *L, Band
 }
 
 /* quant_band (bands.c:1248).  Returns {collapse mask, remaining_bits, seed}. */
-WV_DEVN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
+OA_QUANT_BAND_FN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_bits, u32 seed, WV_LDS i32 *X, int N, int b, int B, WV_LDS i32 *lowband, int LM,
       WV_LDS i32 *lowband_out, i32 gain, WV_LDS i32 *lowband_scratch, int fill)
 {
    cfg = cfg_uni(cfg); remaining_bits = wv_uni(remaining_bits); seed = (u32)wv_uni((i32)seed); N = wv_uni(N); b = wv_uni(b); B = wv_uni(B);
