@@ -13,6 +13,9 @@ def load(which):
     if which == "ref":
         from reflib import ref_fx
         return ref_fx()
+    if which == "ref_fl":
+        from reflib import ref_fl
+        return ref_fl()
     if which == "emu":
         import hostemu
         return ctypes.CDLL(hostemu.build_emu_lib(), mode=ctypes.RTLD_LOCAL)

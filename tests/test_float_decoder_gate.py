@@ -1,0 +1,8 @@
+"""CPU: packets of this encoder (C ABI on the wave emulator) through the reference's float decoder (tests/float_gate_check.py)"""
+import pytest
+from reflib import ref_fx, ref_fl
+import float_gate_check as G
+pytestmark = pytest.mark.skipif(ref_fx() is None or ref_fl() is None, reason="oracle/_ref not built")
+
+@pytest.mark.parametrize("case", range(len(G.CASES)))
+def test_emu_packets_decode_with_float_reference(case): G.check("emu", *G.CASES[case])
