@@ -361,7 +361,6 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
    const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
    FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
    FOR_LANES(i, 2 * NBE) F->oldBandE[i] = gs->celt.oldBandE[i];
-   if (wv_lane() == 0) F->g = L->cs;
    wv_sync();
 }
 WV_DEV void sh_leave_celt(WV_LDS ShLds *L, OaShStream *gs)
@@ -403,7 +402,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
 #define SH_CELT_DISABLE_PF(F) ((F)->st.pad0[0])
 #define SH_CELT_FORCE_INTRA(F) ((F)->st.pad0[1])
 
-/* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in the HBM scratch F->g->pcm16).
+/* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in the HBM scratch L->cs->pcm16).
  *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in L->packet (hybrid), or starting it (CELT-only frame)
  *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
 struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
@@ -414,11 +413,13 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    WV_LDS FrameShared *fs = &F->sh;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, up = 48000 / Fs;
    wv_sync();
-   if (src) { i16 *dst = F->g->pcm16; FOR_LANES(i, nsamp * CC) dst[i] = src[i]; }
+   if (wv_lane() == 0) F->g = L->cs;               /* (the arena aliases the SILK working set: whatever SILK did since the last CELT pass may have overwritten the pointer) */
+   wv_sync();
+   if (src) { i16 *dst = L->cs->pcm16; FOR_LANES(i, nsamp * CC) dst[i] = src[i]; }
    if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i]; }
    wv_sync();
    {  /* celt_maxabs over the head and the overlap tail of the input (celt_encoder.c:1970-1973), at the API rate */
-      const i16 *p = F->g->pcm16;
+      const i16 *p = L->cs->pcm16;
       const int ov = OA_OVERLAP / up;
       i32 a = 0, b = 0;
       FOR_LANES(i, CC * (nsamp - ov)) a = imax(a, iabs((i32)p[i]));
@@ -511,7 +512,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
       sh->bits_target = imin(8 * (max_data_bytes - redundancy_bytes), bitrate_to_bits(sh->bitrate_bps, Fs, frame_size)) - 8;
       sh->curr_bandwidth = st->bandwidth;
       sh->redundant_rng = 0; sh->f_size = frame_size; sh->r[3] = 0;                  /* r[3]: the result is a bare TOC that is never padded (DTX) */
-      { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)(orig_max_data_bytes - 1)); ec_st(&L->ec, e); }
+      { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)imin(orig_max_data_bytes - 1, 1275)); ec_st(&L->ec, e); }   /* the reference's coder spans the caller's whole buffer (:1964); a frame never fills more than 1275 bytes of it, and what lies beyond only ever gets cleared by ec_enc_done -- which here would run past the LDS packet buffer */
       const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
       st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
       sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
@@ -672,7 +673,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    }
    /* pcm_buf = [delay tail | this frame] -> the CELT staging area (only when a CELT pass will read it), then the delay line moves on (:2304-2312) */
    if (need_celt) {
-      i16 *io = F->g->pcm16;
+      i16 *io = L->cs->pcm16;
       FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
       wv_sync();
    }
@@ -688,7 +689,7 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
       }
    }
    if (need_celt) {
-      i16 *io = F->g->pcm16;
+      i16 *io = L->cs->pcm16;
       if (sh->do_gain_fade) { sh_gain_fade_lds(io, frame_size, CC, (i16)sh->hb_g1, (i16)sh->hb_g2, Fs); wv_sync(); }
       if (sh->do_stereo_fade) { sh_stereo_fade_lds(io, frame_size, (i16)sh->fade_g1, (i16)sh->fade_g2, Fs); wv_sync(); }
       /* more than one CELT pass reads pcm_buf: keep it in the HBM scratch */

@@ -51,3 +51,41 @@ def test_gpu_test_opus_decode_and_encode():
     for t in ts: t.start()
     for t in ts: t.join()
     for name, (rc, out) in res.items(): assert rc == 0, (name, out)
+
+
+def _opus_demo_roundtrip(flavour, tmp_path, args, Fs, ch, seconds=1.0):
+    """the reference's opus_demo (src/opus_demo.c, unmodified) linked against this library and against the reference's own: same .bit file out of the encoder, same PCM
+    out of the decoder (opus_demo drives the 24-bit entry points and checks the final range of every packet itself)"""
+    import numpy as np
+    from test_kernel_emu_silkdec import speechy
+    for fl in (flavour, "ref"):
+        exe = os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")
+        if not os.path.exists(exe):
+            if not os.path.isdir(hostemu.REF): pytest.skip("opus_demo binaries not built and /root/reference absent")
+            hostemu.build_reftests(fl)
+    n = int(Fs * seconds)
+    sig = np.ascontiguousarray(speechy(n * (48000 // Fs) // 960 + 2, ch, 99, 960)[::48000 // Fs][:n]).astype("<i2")
+    pcm = tmp_path / "in.pcm"; sig.tofile(pcm)
+    outs = {}
+    for fl in (flavour, "ref"):
+        exe = os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")
+        bit = tmp_path / (fl + ".bit"); dec = tmp_path / (fl + ".dec")
+        p = subprocess.run([exe, "-e"] + list(args) + [str(pcm), str(bit)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+        p = subprocess.run([exe, "-d", str(Fs), str(ch), str(bit), str(dec)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+        outs[fl] = (bit.read_bytes(), dec.read_bytes())
+    assert len(outs["ref"][0]) > 1000
+    assert outs[flavour][0] == outs["ref"][0], "bitstreams differ"
+    assert outs[flavour][1] == outs["ref"][1], "decoded PCM differs"
+
+DEMO_CASES = [(["audio", "48000", "2", "64000"], 48000, 2), (["voip", "16000", "1", "20000", "-inbandfec", "-loss", "10"], 16000, 1),
+              (["restricted-lowdelay", "48000", "2", "96000", "-framesize", "10", "-cbr"], 48000, 2), (["audio", "24000", "1", "32000", "-framesize", "40"], 24000, 1)]
+
+@pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/ref/opus_demo")), reason="no reference tree")
+@pytest.mark.parametrize("case", range(len(DEMO_CASES)))
+def test_emu_opus_demo_roundtrip(case, tmp_path): _opus_demo_roundtrip("emu", tmp_path, *DEMO_CASES[case], seconds=0.6)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(DEMO_CASES)))
+def test_gpu_opus_demo_roundtrip(case, tmp_path): _opus_demo_roundtrip("gpu", tmp_path, *DEMO_CASES[case], seconds=2.0)
