@@ -89,3 +89,42 @@ def test_emu_opus_demo_roundtrip(case, tmp_path): _opus_demo_roundtrip("emu", tm
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", range(len(DEMO_CASES)))
 def test_gpu_opus_demo_roundtrip(case, tmp_path): _opus_demo_roundtrip("gpu", tmp_path, *DEMO_CASES[case], seconds=2.0)
+
+
+# opus_demo as encoder + decoder in one process (its own final-range check on every packet), with its built-in mode / bandwidth / frame-size schedules, random frame sizes,
+# random FEC, simulated loss, DTX, bitrate sweeps: the decoded PCM of the run linked against this library must equal the run linked against the reference's
+DEMO_MODES = [(48000, 2, ["audio", "48000", "2", "96000", "-hybrid48k_test"]), (48000, 2, ["audio", "48000", "2", "64000", "-celt_test"]),
+              (48000, 2, ["audio", "48000", "2", "128000", "-celt_hq_test"]), (24000, 1, ["audio", "24000", "1", "32000", "-hybrid24k_test"]),
+              (16000, 1, ["voip", "16000", "1", "20000", "-silk16k_test"]), (12000, 1, ["voip", "12000", "1", "16000", "-silk12k_test"]),
+              (8000, 1, ["voip", "8000", "1", "12000", "-silk8k_test"]), (48000, 2, ["audio", "48000", "2", "48000", "-random_framesize", "-random_fec", "-loss", "5"]),
+              (48000, 1, ["voip", "48000", "1", "24000", "-dtx", "-cvbr", "-framesize", "60"]),
+              (48000, 2, ["restricted-lowdelay", "48000", "2", "256000", "-framesize", "2.5", "-max_payload", "400"]),
+              (48000, 2, ["audio", "48000", "2", "32000", "-bandwidth", "SWB", "-forcemono", "-framesize", "80"]),
+              (48000, 2, ["audio", "48000", "2", "80000", "-sweep", "2000", "-sweep_max", "160000", "-framesize", "120"]),
+              (16000, 2, ["audio", "16000", "2", "40000", "-inbandfec", "-loss", "15", "-complexity", "5"])]
+
+def _opus_demo_codec(flavour, tmp_path, Fs, ch, args, seconds):
+    import numpy as np
+    from test_kernel_emu_silkdec import speechy
+    for fl in (flavour, "ref"):
+        if not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")):
+            if not os.path.isdir(hostemu.REF): pytest.skip("opus_demo binaries not built and /root/reference absent")
+            hostemu.build_reftests(fl)
+    n = int(Fs * seconds)
+    sig = np.ascontiguousarray(speechy(n * (48000 // Fs) // 960 + 2, ch, len(args), 960)[::48000 // Fs][:n]).astype("<i2")
+    pcm = tmp_path / "in.pcm"; sig.tofile(pcm)
+    outs = []
+    for fl in (flavour, "ref"):
+        o = tmp_path / (fl + ".pcm")
+        p = subprocess.run([os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")] + list(args) + [str(pcm), str(o)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, (fl, p.stdout.decode(errors="replace")[-1500:])
+        outs.append(o.read_bytes())
+    assert len(outs[1]) > 1000 and outs[0] == outs[1], "decoded PCM differs"
+
+@pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/ref/opus_demo")), reason="no reference tree")
+@pytest.mark.parametrize("case", range(len(DEMO_MODES)))
+def test_emu_opus_demo_schedules(case, tmp_path): _opus_demo_codec("emu", tmp_path, *DEMO_MODES[case], seconds=2.2)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(DEMO_MODES)))
+def test_gpu_opus_demo_schedules(case, tmp_path): _opus_demo_codec("gpu", tmp_path, *DEMO_MODES[case], seconds=3.0)
