@@ -30,7 +30,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 extern thread_local __attribute__((aligned(64))) char smem[];
 extern thread_local unsigned emu_block_x;
 struct EmuIdx { unsigned x, y, z; };
-static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)emu_cur->cur, 0, 0}; return i; }
+static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)(emu_cur->cur ^ emu_flip), 0, 0}; return i; }
 static inline EmuIdx emu_bidx() { EmuIdx i = {emu_block_x, 0, 0}; return i; }
 static inline void __syncthreads() { emu_rendezvous(); }
 #define threadIdx (emu_tidx())

@@ -1,6 +1,8 @@
 /* tests/emu/wave_emu.cpp — fiber scheduler of the CPU wave emulator (TEST INFRASTRUCTURE). */
 #include "wave_emu.h"
 thread_local EmuWave *emu_cur = nullptr;
+int emu_check_uni = getenv("OA_EMU_CHECK_UNI") && atoi(getenv("OA_EMU_CHECK_UNI"));
+int emu_flip = getenv("OA_EMU_REVERSE") && atoi(getenv("OA_EMU_REVERSE")) ? 63 : 0;
 
 __asm__(
    ".text\n.globl emu_switch\n.type emu_switch,@function\nemu_switch:\n"

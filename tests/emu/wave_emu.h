@@ -20,26 +20,32 @@ static inline void emu_die() { void *bt[32]; int n = backtrace(bt, 32); backtrac
 #define WV_TABLE static const
 #define WV_WIDTH 64
 
-struct EmuFiber { void *sp; char *stack; int done; long nsync; long nx; };
+struct EmuFiber { void *sp; char *stack; int done; long nsync; long nx; int uni_k; };
 struct EmuWave {
    EmuFiber f[64];
    void *main_sp;
    int cur;
    int64_t xch[2][64][4];
+   int32_t uni_val[1024]; int uni_n;   /* OA_EMU_CHECK_UNI: the values the first-scheduled fiber passed to wv_uni since the last rendezvous */
    unsigned char kind_ring[4096];      /* lane 0's op kind per rendezvous, to catch lanes meeting at different primitives */
    void (*entry)(void *);
    void *arg;
 };
 extern thread_local EmuWave *emu_cur;
+/* OA_EMU_REVERSE=1 runs the fibers in the order lane 63 .. lane 0 instead of 0 .. 63 (logical lane = fiber index ^ emu_flip).  Between two rendezvous a fiber sees the
+ * writes of the fibers scheduled before it and none of those after it; code that depends on that (a read of another lane's LDS write with no wv_sync in between) gives
+ * different results under the two orders, which is how such races -- invisible in either order alone, real on the lockstep hardware -- are found here. */
+extern int emu_flip, emu_check_uni;
 extern "C" void emu_switch(void **save_sp, void *new_sp);
 void emu_run_wave(void (*entry)(void *), void *arg);
 
-WV_DEV int wv_lane() { return emu_cur->cur; }
+WV_DEV int wv_lane() { return emu_cur->cur ^ emu_flip; }
 static inline void emu_rendezvous(int kind = 0)
 {
    EmuWave *w = emu_cur;
    int me = w->cur, nxt = (me + 1) & 63;
    w->f[me].nsync++;
+   if (me == 0) w->uni_n = w->f[0].uni_k;
    if (me == 0) w->kind_ring[w->f[0].nsync & 4095] = (unsigned char)kind;
    else if (w->kind_ring[w->f[me].nsync & 4095] != kind) {
       fprintf(stderr, "wave_emu: lane %d meets lane 0 at rendezvous %ld with a different primitive (%d vs %d): divergent control flow\n", me, w->f[me].nsync, kind, w->kind_ring[w->f[me].nsync & 4095]); emu_die();
@@ -47,6 +53,7 @@ static inline void emu_rendezvous(int kind = 0)
    if (w->f[nxt].done) { fprintf(stderr, "wave_emu: lane %d reached a collective but lane %d already exited (divergence)\n", me, nxt); abort(); }
    w->cur = nxt;
    emu_switch(&w->f[me].sp, w->f[nxt].sp);
+   w->f[me].uni_k = 0;
    int prv = (me + 63) & 63;
    long expect = w->f[me].nsync + (me == 0 ? 0 : 1);          /* the previous lane is parked at the next rendezvous */
    if (!(w->f[prv].nsync == expect || (w->f[prv].done && w->f[prv].nsync == w->f[me].nsync))) {
@@ -59,20 +66,37 @@ WV_DEV void wv_order() { emu_rendezvous(); }
 static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0))[4]
 {
    EmuWave *w = emu_cur;
-   int me = w->cur;
-   int p = (int)(w->f[me].nx++ & 1);
+   int fib = w->cur, me = fib ^ emu_flip;
+   int p = (int)(w->f[fib].nx++ & 1);
    w->xch[p][me][0] = a; w->xch[p][me][1] = b; w->xch[p][me][2] = c; w->xch[p][me][3] = d;
    emu_rendezvous(1);
    return w->xch[p];
 }
 WV_DEV int32_t wv_shfl(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src & 63][0]; }
 template <int Q> WV_DEV int32_t wv_lane_const(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[Q][0]; }
-template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[(emu_cur->cur & ~3) | J][0]; }
-WV_DEV int32_t wv_bcast(int32_t v, int src) { auto t = emu_xchg(v); return (int32_t)t[src][0]; }
-WV_DEV int32_t wv_uni(int32_t v) { return v; }
-WV_DEV int32_t wv_shift_down1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = emu_cur->cur; return me == 63 ? fill : (int32_t)t[me + 1][0]; }
-WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = emu_cur->cur; return me == 0 ? fill : (int32_t)t[me - 1][0]; }
-WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return emu_cur->cur == lane ? val : old; }
+template <int J> WV_DEV int32_t wv_quad_bcast(int32_t v) { auto t = emu_xchg(v); return (int32_t)t[(wv_lane() & ~3) | J][0]; }
+WV_DEV int32_t wv_bcast(int32_t v, int src)
+{
+   auto t = emu_xchg(v, src);
+   if (emu_check_uni && t[wv_lane()][1] != t[0][1]) { fprintf(stderr, "wave_emu: wv_bcast (v_readlane) with a lane index that is not uniform: lane %d asks for %d, lane 0 for %d\n", wv_lane(), src, (int)t[0][1]); emu_die(); }
+   if ((unsigned)src > 63u) { fprintf(stderr, "wave_emu: wv_bcast from lane %d\n", src); emu_die(); }
+   return (int32_t)t[src][0];
+}
+/* on the hardware: v_readfirstlane, i.e. the value of the first active lane in EVERY lane.  Here each lane keeps its own value, so a caller that passes a value that
+ * is not in fact uniform behaves differently on the GPU; OA_EMU_CHECK_UNI=1 compares, call by call between two rendezvous, every lane's argument with the one the
+ * first-scheduled lane passed (calls inside one-lane sections have nothing to be compared with and are skipped). */
+WV_DEV int32_t wv_uni(int32_t v)
+{
+   if (emu_check_uni) {
+      EmuWave *w = emu_cur; const int fib = w->cur, k = w->f[fib].uni_k++;
+      if (fib == 0) { if (k < 1024) w->uni_val[k] = v; }
+      else if (k < w->uni_n && k < 1024 && w->uni_val[k] != v) { fprintf(stderr, "wave_emu: wv_uni of a non-uniform value: lane %d passes %d, lane %d passed %d (call %d since the last rendezvous)\n", wv_lane(), v, emu_flip, w->uni_val[k], k); emu_die(); }
+   }
+   return v;
+}
+WV_DEV int32_t wv_shift_down1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = wv_lane(); return me == 63 ? fill : (int32_t)t[me + 1][0]; }
+WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = wv_lane(); return me == 0 ? fill : (int32_t)t[me - 1][0]; }
+WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return wv_lane() == lane ? val : old; }
 WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
 WV_DEV uint32_t wv_sumu(uint32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return s; }
 WV_DEV int64_t wv_sum64(int64_t v) { auto t = emu_xchg(v); uint64_t s = 0; for (int i = 0; i < 64; i++) s += (uint64_t)t[i][0]; return (int64_t)s; }
@@ -80,7 +104,7 @@ WV_DEV int32_t wv_max(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[
 WV_DEV int32_t wv_min(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[0][0]; for (int i = 1; i < 64; i++) if ((int32_t)t[i][0] < m) m = (int32_t)t[i][0]; return m; }
 WV_DEV uint32_t wv_or(uint32_t v) { auto t = emu_xchg(v); uint32_t m = 0; for (int i = 0; i < 64; i++) m |= (uint32_t)t[i][0]; return m; }
 WV_DEV uint64_t wv_ballot(int pred) { auto t = emu_xchg(pred != 0); uint64_t m = 0; for (int i = 0; i < 64; i++) m |= (uint64_t)(t[i][0] != 0) << i; return m; }
-WV_DEV int32_t wv_scan_incl(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; int me = emu_cur->cur; for (int i = 0; i <= me; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
+WV_DEV int32_t wv_scan_incl(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; int me = wv_lane(); for (int i = 0; i <= me; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
 WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nlanes)
 {
    /* same contract as the DPP version: maximal num/den by exact cross-multiplication among valid lanes, lowest lane wins ties */

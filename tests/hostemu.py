@@ -34,8 +34,11 @@ def build_reftests(flavour):
         if flavour == "ref" and name != "opus_demo": continue
         exe = os.path.join(out, name)
         s = [os.path.join(REF, x) for x in srcs]
+        extra = []
+        if name == "opus_demo":                # its rand() must not be shared with the ROCm runtime's threads: tests/emu/demo_rand.c
+            s.append(os.path.join(ROOT, "tests/emu/demo_rand.c")); extra = ["-Drand=oa_demo_rand", "-Dsrand=oa_demo_srand"]
         if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(x) for x in s): continue
-        subprocess.check_call(["gcc"] + REFTEST_FLAGS + s + ["-o", exe] + lib + ["-lm"])
+        subprocess.check_call(["gcc"] + REFTEST_FLAGS + extra + s + ["-o", exe] + lib + ["-lm"])
     return out
 
 if __name__ == "__main__":
