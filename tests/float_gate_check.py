@@ -1,7 +1,12 @@
 """tests/float_gate_check.py — the float-mode half of the parity gate of SURVEY 8d, as far as it applies to a bit-exact fixed-point encoder: every packet this
 encoder produces must decode with the reference's FLOAT decoder (the build users deploy) to the encoder's final range, and the float decoder's PCM must agree
 with the fixed-point decoder's within the noise floor opus_compare tolerates between conforming decoders (here: SNR >= 60 dB on 16-bit PCM, a far tighter bound
-than opus_compare's perceptual threshold).  `which` = "emu" | "gpu"."""
+than opus_compare's perceptual threshold).  `which` = "emu" | "gpu".
+
+compare_gate() is the decoder half, with the reference's own judge: every committed bitstream (tests/golden/bitstreams/*.bit, reference-encoded over the mode
+matrix of tests/test_opus_encode.c) is decoded by THIS decoder and by the reference's FLOAT decoder, at 48 kHz stereo and mono as tests/run_vectors.sh:77-132 does (plus
+three of the lower output rates its RATE argument selects), and the reference's opus_compare (src/opus_compare.c compiled in place -> oracle/_ref/opus_compare) must print its PASS verdict for each pair -- the
+conformance criterion of RFC 6716 section 6 applied to this decoder against the build users deploy."""
 import numpy as np
 import capi
 from test_kernel_emu_silkdec import speechy
@@ -28,3 +33,35 @@ def check(which, name, Fs, ch, app, ctl, frames=12):
     snr = 10 * np.log10((num + 1e-9) / (den + 1e-9))
     assert snr >= 60.0, (name, snr)
     return snr
+
+
+def compare_gate(which, tmp, names=None, rates=((48000, 2), (48000, 1), (24000, 2), (16000, 1), (8000, 1))):
+    import glob, os, re, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "oracle/_ref/opus_compare")
+    assert os.path.exists(tool), "oracle/_ref/opus_compare not built (make -C oracle ref)"
+    files = sorted(glob.glob(os.path.join(root, "tests/golden/bitstreams/*.bit")))
+    if names: files = [f for f in files if os.path.basename(f)[:-4] in names]
+    assert files
+    out = {}
+    for f in files:
+        data = open(f, "rb").read(); pk = []; p = 0
+        while p + 8 <= len(data):
+            ln, rng = struct.unpack(">II", data[p:p + 8]); p += 8
+            pk.append(data[p:p + ln]); p += ln
+        ref = capi.Dec("ref_fl", 48000, 2)                                   # the .dec side is always the reference's 48 kHz stereo output (opus_compare.c:232)
+        pb = os.path.join(str(tmp), "ref.dec"); np.concatenate([ref.decode(d, 5760)[1] for d in pk]).astype("<i2").tofile(pb)
+        refm = capi.Dec("ref_fl", 48000, 1)                                  # and the "m.dec" alternative run_vectors.sh accepts: the reference decoding to mono, as a stereo file
+        pm = os.path.join(str(tmp), "refm.dec"); np.repeat(np.concatenate([refm.decode(d, 5760)[1] for d in pk]), 2, axis=1).astype("<i2").tofile(pm)
+        for Fs, ch in rates:
+            ours = capi.Dec(which, Fs, ch)
+            pa = os.path.join(str(tmp), "ours.sw"); np.concatenate([ours.decode(d, Fs // 25 * 3)[1] for d in pk]).astype("<i2").tofile(pa)
+            best = None; txts = []
+            for dec in (pb, pm):
+                r = subprocess.run([tool] + (["-s"] if ch == 2 else []) + ["-r", str(Fs), dec, pa], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                txt = r.stdout.decode(errors="replace"); txts.append(txt[-200:])
+                m = re.search(r"quality metric: ([-0-9.]+) %", txt)
+                if r.returncode == 0 and "PASSES" in txt and m: best = max(best or 0.0, float(m.group(1)))
+            assert best is not None, (os.path.basename(f), Fs, ch, txts)
+            out[(os.path.basename(f)[:-4], Fs, ch)] = best
+    return out

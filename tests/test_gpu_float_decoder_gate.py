@@ -5,3 +5,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("case", range(len(G.CASES)))
 def test_gpu_packets_decode_with_float_reference(case): G.check("gpu", *G.CASES[case], frames=25)
+
+def test_gpu_decoder_passes_opus_compare_against_float_reference(tmp_path):
+    q = G.compare_gate("gpu", tmp_path)
+    assert len(q) == 65 and min(v for k, v in q.items() if k[1] == 48000) > 99.0, q
