@@ -154,117 +154,117 @@ WV_DEV int patch_transient_decision_l0(WV_LDS FrameLds *L)
    return mean_diff > GC(1.f);
 }
 
-WV_DEV i32 median_of_5(const WV_LDS i32 *x)
+/* ---- dynalloc_analysis (celt_encoder.c:1049) on the wave ----
+ * One lane per (band, channel): lane = 32 * channel + band.  Everything the reference chains along the bands is a recurrence of the form
+ *       f[i] = op(f[i-1] + step, g[i])            op = min or max, step a constant
+ * whose closed form is op over j of (g[j] + step * |i - j|): a prefix (suffix) scan in the (op, +) semiring.  The values are Q24 integers far from overflow, the
+ * operations are adds and compares only, so the scan -- five shuffle steps for 21 bands -- gives the recurrence's result exactly.  The spreading mask, the two
+ * energy followers (up 1.5 dB / band, down 2 dB / band below the last upward step), the median floors (neighbours fetched from LDS) and the stereo coupling are
+ * done that way; the boost loop's running total with its cap is an inclusive sum scan plus a ballot for the first band that hits the cap. */
+WV_DEV i32 oa_med3(i32 a, i32 b, i32 c) { return imax(imin(a, b), imin(imax(a, b), c)); }
+WV_DEV i32 oa_med5(i32 a, i32 b, i32 c, i32 d, i32 e)
 {
-   i32 t0, t1, t2 = x[2], t3, t4, t;
-   if (x[0] > x[1]) { t0 = x[1]; t1 = x[0]; } else { t0 = x[0]; t1 = x[1]; }
-   if (x[3] > x[4]) { t3 = x[4]; t4 = x[3]; } else { t3 = x[3]; t4 = x[4]; }
-   if (t0 > t3) { t = t0; t0 = t3; t3 = t; t = t1; t1 = t4; t4 = t; }
-   if (t2 > t1) return t1 < t3 ? imin(t2, t3) : imin(t4, t1);
-   return t2 < t3 ? imin(t1, t3) : imin(t2, t4);
+   /* median of five = median of (the larger of the two pair minima, the smaller of the two pair maxima, the odd one) */
+   const i32 lo1 = imin(a, b), hi1 = imax(a, b), lo2 = imin(d, e), hi2 = imax(d, e);
+   return oa_med3(imax(lo1, lo2), imin(hi1, hi2), c);
 }
-WV_DEV i32 median_of_3(const WV_LDS i32 *x)
+/* v[i] <- op over j <= i (UP) or j >= i (!UP) of v[j] + step * |i - j| inside each 32-lane half, sources limited to bands [lo, hi] */
+template <bool UP, bool MIN> WV_DEV i32 oa_band_scan(i32 v, int band, int lo, int hi, i32 step)
 {
-   i32 t0, t1, t2 = x[2];
-   if (x[0] > x[1]) { t0 = x[1]; t1 = x[0]; } else { t0 = x[0]; t1 = x[1]; }
-   if (t1 < t2) return t1;
-   if (t0 < t2) return t2;
-   return t0;
+   const int lane = wv_lane();
+#pragma unroll
+   for (int d = 1; d < 32; d <<= 1) {
+      const int src = UP ? band - d : band + d;
+      const i32 t = wv_shfl(v, (lane + (UP ? -d : d)) & 63) + d * step;
+      if (src >= lo && src <= hi && band >= lo && band <= hi) v = MIN ? imin(v, t) : imax(v, t);
+   }
+   return v;
 }
 
-/* lane 0: dynalloc_analysis (celt_encoder.c:1049) */
-WV_DEVN void dynalloc_analysis_l0(WV_LDS FrameLds *L)
+WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L)
 {
    WV_LDS FrameShared *sh = &L->sh;
-   const int start = sh->start, end = sh->end, C = sh->C, LM = sh->LM, lsb_depth = sh->lsb_depth, isTransient = sh->isTransient;
+   const int start = sh->start, end = sh->end, C = sh->C, LM = sh->LM, isTransient = sh->isTransient;
    const int vbr = sh->vbr, constrained_vbr = sh->constrained_vbr, effectiveBytes = sh->effectiveBytes;
-   const WV_LDS i32 *bandLogE = L->bandLogE, *bandLogE2 = L->bandLogE2, *oldBandE = L->oldBandE;
-   WV_LDS i32 *offsets = L->offsets, *importance = L->importance, *spread_weight = L->spread_weight;
-   WV_LDS i32 *const big = L->BC.tf;      /* 126 words: more than scr holds; BC is idle between the last MDCT and tf_analysis */
-   WV_LDS i32 *follower = big, *noise_floor = big + 42, *bandLogE3 = big + 63, *mask = big + 84, *sig = big + 105;
-   i32 tot_boost = 0, maxDepth = -GC(31.9f);
-   for (int i = 0; i < NBE; i++) offsets[i] = 0;
-   for (int i = 0; i < end; i++)
-      noise_floor[i] = GC(0.0625f) * ct_logN[i] + GC(.5f) + shl32(9 - lsb_depth, DB_SHIFT) - shl32(ct_eMeans[i], DB_SHIFT - 4)
-            + GC(.0062f) * (i + 5) * (i + 5);
-   for (int c = 0; c < C; c++) for (int i = 0; i < end; i++) maxDepth = imax(maxDepth, bandLogE[c * NBE + i] - noise_floor[i]);
-   {
-      for (int i = 0; i < end; i++) mask[i] = bandLogE[i] - noise_floor[i];
-      if (C == 2) for (int i = 0; i < end; i++) mask[i] = imax(mask[i], bandLogE[NBE + i] - noise_floor[i]);
-      for (int i = 0; i < end; i++) sig[i] = mask[i];
-      for (int i = 1; i < end; i++) mask[i] = imax(mask[i], mask[i - 1] - GC(2.f));
-      for (int i = end - 2; i >= 0; i--) mask[i] = imax(mask[i], mask[i + 1] - GC(3.f));
-      for (int i = 0; i < end; i++) {
-         i32 smr = sig[i] - imax(imax(0, maxDepth - GC(12.f)), mask[i]);
-         int shift = -pshr32(imax(-GC(5.f), imin(0, smr)), DB_SHIFT);
-         spread_weight[i] = 32 >> shift;
-      }
+   const int lane = wv_lane(), band = lane & 31, ch = lane >> 5;
+   const bool in_band = band < end, mine = in_band && ch < C, lead = in_band && ch == 0;      /* lead: the lane that owns the band's per-band results */
+   const int w = imin(ch, C - 1) * NBE + imin(band, NBE - 1);
+   WV_LDS i32 *const b3 = L->BC.tf;                /* 2 x 32 words: the (patched) long-window band energies, for the median neighbourhoods */
+   FOR_LANES(i, NBE) L->offsets[i] = 0;
+   const int ib = imin(band, NBE - 1);
+   const i32 noise_floor = GC(0.0625f) * ct_logN[ib] + GC(.5f) + shl32(9 - sh->lsb_depth, DB_SHIFT) - shl32(ct_eMeans[ib], DB_SHIFT - 4) + GC(.0062f) * (ib + 5) * (ib + 5);
+   const i32 E = L->bandLogE[w];
+   const i32 maxDepth = imax(-GC(31.9f), wv_max(mine ? E - noise_floor : -GC(31.9f)));
+   {  /* masking spread for the spreading decision's band weights: 2 dB / band upwards, 3 dB / band downwards */
+      i32 sig = L->bandLogE[ib] - noise_floor;
+      if (C == 2) sig = imax(sig, L->bandLogE[NBE + ib] - noise_floor);
+      i32 mask = oa_band_scan<true, false>(sig, band, 0, end - 1, -GC(2.f));
+      mask = oa_band_scan<false, false>(mask, band, 0, end - 1, -GC(3.f));
+      const i32 smr = sig - imax(imax(0, maxDepth - GC(12.f)), mask);
+      if (lead) L->spread_weight[band] = 32 >> -pshr32(imax(-GC(5.f), imin(0, smr)), DB_SHIFT);
    }
+   i32 tot_boost = 0;
    if (effectiveBytes >= (30 + 5 * LM) && !sh->lfe) {
-      int last = 0;
-      for (int c = 0; c < C; c++) {
-         i32 offset, tmp;
-         WV_LDS i32 *f;
-         for (int i = 0; i < end; i++) bandLogE3[i] = bandLogE2[c * NBE + i];
-         if (LM == 0) for (int i = 0; i < imin(8, end); i++) bandLogE3[i] = imax(bandLogE2[c * NBE + i], oldBandE[c * NBE + i]);
-         f = &follower[c * NBE];
-         f[0] = bandLogE3[0];
-         for (int i = 1; i < end; i++) {
-            if (bandLogE3[i] > bandLogE3[i - 1] + GC(.5f)) last = i;
-            f[i] = imin(f[i - 1] + GC(1.5f), bandLogE3[i]);
-         }
-         for (int i = last - 1; i >= 0; i--) f[i] = imin(f[i], imin(f[i + 1] + GC(2.f), bandLogE3[i]));
-         offset = GC(1.f);
-         for (int i = 2; i < end - 2; i++) f[i] = imax(f[i], median_of_5(&bandLogE3[i - 2]) - offset);
-         tmp = median_of_3(&bandLogE3[0]) - offset;
-         f[0] = imax(f[0], tmp); f[1] = imax(f[1], tmp);
-         tmp = median_of_3(&bandLogE3[end - 3]) - offset;
-         f[end - 2] = imax(f[end - 2], tmp); f[end - 1] = imax(f[end - 1], tmp);
-         for (int i = 0; i < end; i++) f[i] = imax(f[i], noise_floor[i]);
+      i32 e3 = L->bandLogE2[w];
+      if (LM == 0 && band < 8) e3 = imax(e3, L->oldBandE[w]);
+      b3[lane] = e3;
+      wv_sync();
+      /* the last band that steps up by more than half a dB over its lower neighbour; a channel without one inherits the previous channel's */
+      const u64 up = wv_ballot(mine && band >= 1 && e3 > b3[lane - (band >= 1)] + GC(.5f));
+      const u32 up0 = (u32)up, up1 = (u32)(up >> 32);
+      const int last0 = up0 ? 31 - __builtin_clz(up0) : 0, last1 = up1 ? 31 - __builtin_clz(up1) : last0;
+      const int last = ch ? last1 : last0;
+      i32 f = oa_band_scan<true, true>(e3, band, 0, end - 1, GC(1.5f));
+      f = oa_band_scan<false, true>(f, band, 0, last, GC(2.f));
+      if (mine) {
+         const int base = lane - band;
+         if (band >= 2 && band < end - 2) f = imax(f, oa_med5(b3[lane - 2], b3[lane - 1], e3, b3[lane + 1], b3[lane + 2]) - GC(1.f));
+         if (band < 2) f = imax(f, oa_med3(b3[base], b3[base + 1], b3[base + 2]) - GC(1.f));
+         if (band >= end - 2) f = imax(f, oa_med3(b3[base + end - 3], b3[base + end - 2], b3[base + end - 1]) - GC(1.f));
+         f = imax(f, noise_floor);
       }
+      /* from here on one value per band, on the channel-0 lane */
       if (C == 2) {
-         for (int i = start; i < end; i++) {
-            follower[NBE + i] = imax(follower[NBE + i], follower[i] - GC(4.f));
-            follower[i] = imax(follower[i], follower[NBE + i] - GC(4.f));
-            follower[i] = half32(imax(0, bandLogE[i] - follower[i]) + imax(0, bandLogE[NBE + i] - follower[NBE + i]));
-         }
-      } else for (int i = start; i < end; i++) follower[i] = imax(0, bandLogE[i] - follower[i]);
-      for (int i = start; i < end; i++) follower[i] = imax(follower[i], L->surround_dynalloc[i]);
-      for (int i = start; i < end; i++) importance[i] = pshr32(13 * fx_exp2_db(imin(follower[i], GC(4.f))), 16);
-      if ((!vbr || constrained_vbr) && !isTransient) for (int i = start; i < end; i++) follower[i] = half32(follower[i]);
-      for (int i = start; i < end; i++) {
-         if (i < 8) follower[i] *= 2;
-         if (i >= 12) follower[i] = half32(follower[i]);
-      }
+         i32 f1 = wv_shfl(f, band + 32);
+         f1 = imax(f1, f - GC(4.f));
+         f = imax(f, f1 - GC(4.f));
+         f = half32(imax(0, E - f) + imax(0, L->bandLogE[NBE + ib] - f1));
+      } else f = imax(0, E - f);
+      const bool coded = lead && band >= start;
+      f = imax(f, L->surround_dynalloc[ib]);
+      if (coded) L->importance[band] = pshr32(13 * fx_exp2_db(imin(f, GC(4.f))), 16);
+      if ((!vbr || constrained_vbr) && !isTransient) f = half32(f);
+      if (band < 8) f *= 2;
+      if (band >= 12) f = half32(f);
       if (sh->toneishness > QC32(.98f, 29)) {
-         int freq_bin = pshr32((i32)(i16)sh->tone_freq * QC16(120 / 3.14159265358979323846, 9), 13 + 9);
-         for (int i = start; i < end; i++) {
-            if (freq_bin >= ct_eBands[i] && freq_bin <= ct_eBands[i + 1]) follower[i] += GC(2.f);
-            if (freq_bin >= ct_eBands[i] - 1 && freq_bin <= ct_eBands[i + 1] + 1) follower[i] += GC(1.f);
-            if (freq_bin >= ct_eBands[i] - 2 && freq_bin <= ct_eBands[i + 1] + 2) follower[i] += GC(1.f);
-            if (freq_bin >= ct_eBands[i] - 3 && freq_bin <= ct_eBands[i + 1] + 3) follower[i] += GC(.5f);
-         }
-         if (freq_bin >= ct_eBands[end]) { follower[end - 1] += GC(2.f); follower[end - 2] += GC(1.f); }
+         const int freq_bin = pshr32((i32)(i16)sh->tone_freq * QC16(120 / 3.14159265358979323846, 9), 13 + 9);
+         const int lo = ct_eBands[ib], hi = ct_eBands[ib + 1];
+         if (freq_bin >= lo && freq_bin <= hi) f += GC(2.f);
+         if (freq_bin >= lo - 1 && freq_bin <= hi + 1) f += GC(1.f);
+         if (freq_bin >= lo - 2 && freq_bin <= hi + 2) f += GC(1.f);
+         if (freq_bin >= lo - 3 && freq_bin <= hi + 3) f += GC(.5f);
+         if (freq_bin >= ct_eBands[end]) { if (band == end - 1) f += GC(2.f); if (band == end - 2) f += GC(1.f); }
       }
-      if (effectiveBytes > 320) follower[0] += imin(GC(1.5f), GC(1e-3f) * (effectiveBytes - 320));
-      for (int i = start; i < end; i++) {
-         int width, boost, boost_bits;
-         follower[i] = imin(follower[i], GC(4));
-         follower[i] = follower[i] >> 8;
-         width = C * (ct_eBands[i + 1] - ct_eBands[i]) << LM;
-         if (width < 6) { boost = (int)(follower[i] >> (DB_SHIFT - 8)); boost_bits = boost * width << BITRES; }
-         else if (width > 48) { boost = (int)((follower[i] * 8) >> (DB_SHIFT - 8)); boost_bits = (boost * width << BITRES) / 8; }
-         else { boost = (int)((follower[i] * width / 6) >> (DB_SHIFT - 8)); boost_bits = boost * 6 << BITRES; }
-         if ((!vbr || (constrained_vbr && !isTransient)) && (tot_boost + boost_bits) >> BITRES >> 3 > 2 * effectiveBytes / 3) {
-            i32 cap = ((2 * effectiveBytes / 3) << BITRES << 3);
-            offsets[i] = cap - tot_boost;
-            tot_boost = cap;
-            break;
-         } else { offsets[i] = boost; tot_boost += boost_bits; }
-      }
-   } else for (int i = start; i < end; i++) importance[i] = 13;
-   sh->tot_boost = tot_boost;
-   sh->maxDepth = maxDepth;
+      if (effectiveBytes > 320 && band == 0) f += imin(GC(1.5f), GC(1e-3f) * (effectiveBytes - 320));
+      /* boosts, their cost, and the running total with its cap (CBR / constrained VBR: at most two thirds of the frame) */
+      f = imin(f, GC(4)) >> 8;
+      const int width = C * (ct_eBands[ib + 1] - ct_eBands[ib]) << LM;
+      int boost, boost_bits;
+      if (width < 6) { boost = (int)(f >> (DB_SHIFT - 8)); boost_bits = boost * width << BITRES; }
+      else if (width > 48) { boost = (int)((f * 8) >> (DB_SHIFT - 8)); boost_bits = (boost * width << BITRES) / 8; }
+      else { boost = (int)((f * width / 6) >> (DB_SHIFT - 8)); boost_bits = boost * 6 << BITRES; }
+      if (!coded) boost_bits = 0;
+      const i32 upto = wv_scan_incl(boost_bits);                                   /* lanes run in band order: channel-1 lanes add nothing */
+      const bool capped = !vbr || (constrained_vbr && !isTransient);
+      const u64 hit = wv_ballot(coded && capped && (upto >> BITRES >> 3) > 2 * effectiveBytes / 3);
+      const int stop = hit ? __builtin_ctzll(hit) : 64;                            /* the first band whose boost would pass the cap takes what is left */
+      const i32 cap = (2 * effectiveBytes / 3) << BITRES << 3;
+      if (coded && band < stop) L->offsets[band] = boost;
+      if (coded && band == stop) L->offsets[band] = cap - (upto - boost_bits);
+      tot_boost = hit ? cap : wv_bcast(upto, 31);
+   } else if (lead && band >= start) L->importance[band] = 13;
+   LANE0 { sh->tot_boost = tot_boost; sh->maxDepth = maxDepth; }
+   wv_sync();
 }
 
 /* tf_analysis (celt_encoder.c:663): L1 metrics = one lane per band on a private scratch copy (Haar transforms

@@ -189,9 +189,9 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    /* ---- allocation analyses ---- */
    LANE0 {
       sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && !HYB && sh->complexity >= 2 && !sh->lfe && sh->toneishness < QC32(.98f, 29);
-      dynalloc_analysis_l0(L);
    }
    wv_sync();
+   dynalloc_analysis_wave(L);
    K_DUMPI("maxDepth", sh->maxDepth); K_DUMPI("tot_boost", sh->tot_boost); K_DUMP("offsets", L->offsets, 84); K_DUMP("importance", L->importance, 84); K_DUMP("spread_weight", L->spread_weight, 84);
    K_PHASE(8);
    if (sh->enable_tf_analysis) tf_analysis_wave(L, imax(80, 20480 / sh->effectiveBytes + 2));
