@@ -112,55 +112,6 @@ WV_DEV void stage_coded_bins_wave(WV_LDS FrameLds *L)
    wv_sync();
 }
 
-/* lane 0: temporal VBR follower (celt_encoder.c:2196-2213) */
-WV_DEV void temporal_vbr_l0(WV_LDS FrameLds *L)
-{
-   const int C = L->sh.C, start = L->sh.start, end = L->sh.end, LM = L->sh.LM;
-   i32 follow = -QC32(10.0f, DB_SHIFT - 5), frame_avg = 0, offset = L->sh.shortBlocks ? half32(shl32(LM, DB_SHIFT - 5)) : 0;
-   for (int i = start; i < end; i++) {
-      follow = imax(follow - QC32(1.0f, DB_SHIFT - 5), (L->bandLogE[i] >> 5) - offset);
-      if (C == 2) follow = imax(follow, (L->bandLogE[i + NBE] >> 5) - offset);
-      frame_avg += follow;
-   }
-   frame_avg /= (end - start);
-   i32 tv = sub32(shl32(frame_avg, 5), L->st.spec_avg);
-   tv = imin(GC(3.f), imax(-GC(1.5f), tv));
-   L->st.spec_avg += mult16_32_q15(QC16(.02f, 15), tv);
-   L->sh.temporal_vbr = tv;
-}
-
-/* lane 0: patch_transient_decision (celt_encoder.c:473) */
-WV_DEV int patch_transient_decision_l0(WV_LDS FrameLds *L)
-{
-   const int C = L->sh.C, start = L->sh.start, end = L->sh.end;
-   const WV_LDS i32 *newE = L->bandLogE, *oldE = L->oldBandE;
-   WV_LDS i32 *spread_old = L->scr;
-   i32 mean_diff = 0;
-   if (C == 1) {
-      spread_old[start] = oldE[start];
-      for (int i = start + 1; i < end; i++) spread_old[i] = imax(spread_old[i - 1] - GC(1.0f), oldE[i]);
-   } else {
-      spread_old[start] = imax(oldE[start], oldE[start + NBE]);
-      for (int i = start + 1; i < end; i++) spread_old[i] = imax(spread_old[i - 1] - GC(1.0f), imax(oldE[i], oldE[i + NBE]));
-   }
-   for (int i = end - 2; i >= start; i--) spread_old[i] = imax(spread_old[i], spread_old[i + 1] - GC(1.0f));
-   for (int c = 0; c < C; c++)
-      for (int i = imax(2, start); i < end - 1; i++) {
-         i16 x1 = (i16)imax(0, newE[i + c * NBE]);
-         i16 x2 = (i16)imax(0, spread_old[i]);
-         mean_diff = add32(mean_diff, imax(0, sub32(x1, x2)));
-      }
-   mean_diff = mean_diff / (C * (end - 1 - imax(2, start)));
-   return mean_diff > GC(1.f);
-}
-
-/* ---- dynalloc_analysis (celt_encoder.c:1049) on the wave ----
- * One lane per (band, channel): lane = 32 * channel + band.  Everything the reference chains along the bands is a recurrence of the form
- *       f[i] = op(f[i-1] + step, g[i])            op = min or max, step a constant
- * whose closed form is op over j of (g[j] + step * |i - j|): a prefix (suffix) scan in the (op, +) semiring.  The values are Q24 integers far from overflow, the
- * operations are adds and compares only, so the scan -- five shuffle steps for 21 bands -- gives the recurrence's result exactly.  The spreading mask, the two
- * energy followers (up 1.5 dB / band, down 2 dB / band below the last upward step), the median floors (neighbours fetched from LDS) and the stereo coupling are
- * done that way; the boost loop's running total with its cap is an inclusive sum scan plus a ballot for the first band that hits the cap. */
 WV_DEV i32 oa_med3(i32 a, i32 b, i32 c) { return imax(imin(a, b), imin(imax(a, b), c)); }
 WV_DEV i32 oa_med5(i32 a, i32 b, i32 c, i32 d, i32 e)
 {
@@ -181,6 +132,52 @@ template <bool UP, bool MIN> WV_DEV i32 oa_band_scan(i32 v, int band, int lo, in
    return v;
 }
 
+/* temporal VBR follower (celt_encoder.c:2196-2213): the loudest channel's band energies followed downwards by at most 1 dB per band from a -10 dB start --
+ * a (max,+) prefix scan with the start value folded in as "a source one band below `start`" -- then the mean of the follower over the coded bands */
+WV_DEV void temporal_vbr_wave(WV_LDS FrameLds *L)
+{
+   const int C = L->sh.C, start = L->sh.start, end = L->sh.end, LM = L->sh.LM;
+   const int lane = wv_lane(), band = lane & 31, ib = imin(band, NBE - 1);
+   const i32 offset = L->sh.shortBlocks ? half32(shl32(LM, DB_SHIFT - 5)) : 0, one = QC32(1.0f, DB_SHIFT - 5);
+   i32 e = (L->bandLogE[ib] >> 5) - offset;
+   if (C == 2) e = imax(e, (L->bandLogE[ib + NBE] >> 5) - offset);
+   i32 follow = oa_band_scan<true, false>(e, band, start, end - 1, -one);
+   follow = imax(follow, -QC32(10.0f, DB_SHIFT - 5) - (band - start + 1) * one);
+   const i32 total = wv_sum(lane >= start && lane < end ? follow : 0);
+   LANE0 {
+      i32 tv = sub32(shl32(total / (end - start), 5), L->st.spec_avg);
+      tv = imin(GC(3.f), imax(-GC(1.5f), tv));
+      L->st.spec_avg += mult16_32_q15(QC16(.02f, 15), tv);
+      L->sh.temporal_vbr = tv;
+   }
+}
+
+/* patch_transient_decision (celt_encoder.c:473): last frame's energies (louder channel) spread 1 dB per band both ways -- two (max,+) scans -- against this
+ * frame's: a large mean increase means the transient detector missed an onset */
+WV_DEV int patch_transient_decision_wave(WV_LDS FrameLds *L)
+{
+   const int C = L->sh.C, start = L->sh.start, end = L->sh.end;
+   const int lane = wv_lane(), band = lane & 31, ch = lane >> 5, ib = imin(band, NBE - 1);
+   i32 old = L->oldBandE[ib];
+   if (C == 2) old = imax(old, L->oldBandE[ib + NBE]);
+   i32 spread = oa_band_scan<true, false>(old, band, start, end - 1, -GC(1.0f));
+   spread = oa_band_scan<false, false>(spread, band, start, end - 1, -GC(1.0f));
+   i32 diff = 0;
+   if (ch < C && band >= imax(2, start) && band < end - 1) {
+      const i16 x1 = (i16)imax(0, L->bandLogE[ib + ch * NBE]), x2 = (i16)imax(0, spread);
+      diff = imax(0, sub32(x1, x2));
+   }
+   const i32 mean_diff = wv_sum(diff) / (C * (end - 1 - imax(2, start)));
+   return mean_diff > GC(1.f);
+}
+
+/* ---- dynalloc_analysis (celt_encoder.c:1049) on the wave ----
+ * One lane per (band, channel): lane = 32 * channel + band.  Everything the reference chains along the bands is a recurrence of the form
+ *       f[i] = op(f[i-1] + step, g[i])            op = min or max, step a constant
+ * whose closed form is op over j of (g[j] + step * |i - j|): a prefix (suffix) scan in the (op, +) semiring.  The values are Q24 integers far from overflow, the
+ * operations are adds and compares only, so the scan -- five shuffle steps for 21 bands -- gives the recurrence's result exactly.  The spreading mask, the two
+ * energy followers (up 1.5 dB / band, down 2 dB / band below the last upward step), the median floors (neighbours fetched from LDS) and the stereo coupling are
+ * done that way; the boost loop's running total with its cap is an inclusive sum scan plus a ballot for the first band that hits the cap. */
 WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L)
 {
    WV_LDS FrameShared *sh = &L->sh;
@@ -267,88 +264,140 @@ WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L)
    wv_sync();
 }
 
-/* tf_analysis (celt_encoder.c:663): L1 metrics = one lane per band on a private scratch copy (Haar transforms
- * are done in place, tf_tmp holds the 800-bin copy + 560 for the "-1" trial); Viterbi on lane 0. */
-WV_DEV i32 l1_metric_l(const WV_LDS i32 *tmp, int N, int LM, i16 bias)
+/* ---- tf_analysis (celt_encoder.c:663) ----
+ * Metric: per band, the L1 norm of the (normalised) spectrum after 0 .. LM+1 levels of Haar mixing picks the time-frequency resolution the band likes best.
+ * The spectrum is cut into `units` of 2^LM bins (a band is 1 .. 22 units; 100 units in all): the butterflies of the levels below LM stay inside a unit, the one of
+ * level LM joins the even-th unit of a band with its neighbour.  One lane per unit does its butterflies and its |.| sum in the same pass -- the "-1" trial of a
+ * transient frame needs the sums only, so nothing is stored for it -- and one lane per band adds its units up and keeps the best level.
+ * Search: the two-state Viterbi over the bands is a chain of 2x2 (min,+) matrix products, so the running costs of every band come out of one prefix scan (exact:
+ * integer adds and minima); the decisions follow from the costs one band down, and the backtrace -- each band maps the state above it to its own -- is a suffix
+ * scan of those two-bit maps under composition.  Both tf_select hypotheses run side by side, one per half of the wave. */
+WV_TABLE u8 ct_unit2band[100] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 13, 13, 13, 13, 14, 14, 14, 14, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
+
+WV_DEV i32 tf_band_cost(WV_LDS const i32 *usum, int band_lo, int band_hi, int level_bias)
 {
    i32 L1 = 0;
-   for (int i = 0; i < N; i++) L1 += iabs(tmp[i] >> (NORM_SHIFT - 14));
-   return mac16_32_q15(L1, LM * bias, L1);
-}
-WV_DEV void haar1_l(WV_LDS i32 *X, int N0, int stride)        /* one lane, serial (bands.c:623) */
-{
-   N0 >>= 1;
-   for (int i = 0; i < stride; i++)
-      for (int j = 0; j < N0; j++) {
-         i32 t1 = mult32_32_q31(QC32(.70710678f, 31), X[stride * 2 * j + i]);
-         i32 t2 = mult32_32_q31(QC32(.70710678f, 31), X[stride * (2 * j + 1) + i]);
-         X[stride * 2 * j + i] = add32(t1, t2);
-         X[stride * (2 * j + 1) + i] = sub32(t1, t2);
-      }
+   for (int u = band_lo; u < band_hi; u++) L1 += usum[u];
+   return mac16_32_q15(L1, level_bias, L1);
 }
 WV_DEVN void tf_analysis_wave(WV_LDS FrameLds *L, int lambda)
 {
    WV_LDS FrameShared *sh = &L->sh;
-   const int len = sh->effEnd, isTransient = sh->isTransient, LM = sh->LM, N0 = sh->N, tf_chan = sh->tf_chan;
+   const int len = sh->effEnd, isTransient = sh->isTransient, LM = sh->LM, N0 = sh->N, tf_chan = sh->tf_chan, lane = wv_lane();
    const i16 tf_estimate = (i16)sh->tf_estimate;
-   WV_LDS i32 *metric = L->scr, *path0 = L->scr + 21, *path1 = L->scr + 42;
-   WV_LDS i32 *tmpA = L->BC.tf;             /* 800 words: private per-band segments (folding memory not live yet) */
-   WV_LDS i32 *tmpB = L->BC.tf + OA_CODED_BINS;    /* second copy for the "-1" trial */
+   WV_LDS i32 *metric = L->scr;
+   WV_LDS i32 *tmp = L->BC.tf;                       /* the spectrum being mixed, laid out like X */
+   WV_LDS i32 *usum = L->BC.tf + OA_CODED_BINS;      /* one |.| sum per unit */
    const i32 *X = L->g->X + tf_chan * N0;
-   i16 bias = (i16)mult16_16_q14(QC16(.04f, 15), imax(-QC16(.25f, 14), QC16(.5f, 14) - tf_estimate));
+   const i16 bias = (i16)mult16_16_q14(QC16(.04f, 15), imax(-QC16(.25f, 14), QC16(.5f, 14) - tf_estimate));
+   const int units = ct_eBands[len], U = 1 << LM, sh14 = NORM_SHIFT - 14;
    wv_sync();
-   FOR_LANES(j, ct_eBands[len] << LM) tmpA[j] = X[j];            /* the trial buffer is laid out like the spectrum: one coalesced copy from HBM */
+   FOR_LANES(j, units << LM) tmp[j] = X[j];
    wv_sync();
-   FOR_LANES(i, len) {
-      int off = ct_eBands[i] << LM, N = (ct_eBands[i + 1] - ct_eBands[i]) << LM, narrow = (ct_eBands[i + 1] - ct_eBands[i]) == 1, best_level = 0;
-      WV_LDS i32 *tmp = tmpA + off, *tmp_1 = tmpB + off;
-      i32 L1 = l1_metric_l(tmp, N, isTransient ? LM : 0, bias), best_L1 = L1;
-      if (isTransient && !narrow) {
-         for (int j = 0; j < N; j++) tmp_1[j] = tmp[j];
-         haar1_l(tmp_1, N >> LM, 1 << LM);
-         L1 = l1_metric_l(tmp_1, N, LM + 1, bias);
-         if (L1 < best_L1) { best_L1 = L1; best_level = -1; }
+   /* this lane's band (lanes >= len idle in the per-band steps) */
+   const int b = imin(lane, len - 1), b_lo = ct_eBands[b], b_hi = ct_eBands[b + 1], narrow = b_hi - b_lo == 1;
+   const int levels = LM + !(isTransient || narrow);
+   FOR_LANES(u, units) { i32 s = 0; for (int i = 0; i < U; i++) s += iabs(tmp[(u << LM) + i] >> sh14); usum[u] = s; }
+   wv_sync();
+   i32 best_L1 = tf_band_cost(usum, b_lo, b_hi, (isTransient ? LM : 0) * bias);
+   int best_level = 0;
+   wv_sync();
+   if (isTransient) {                                /* one level coarser in time than the short blocks: sums only */
+      FOR_LANES(u, units) {
+         const int bu = ct_unit2band[u], rel = u - ct_eBands[bu];
+         i32 s = 0;
+         if (!(rel & 1) && ct_eBands[bu + 1] - ct_eBands[bu] > 1)
+            for (int i = 0; i < U; i++) {
+               const i32 t1 = mult32_32_q31(QC32(.70710678f, 31), tmp[(u << LM) + i]), t2 = mult32_32_q31(QC32(.70710678f, 31), tmp[((u + 1) << LM) + i]);
+               s += iabs(add32(t1, t2) >> sh14) + iabs(sub32(t1, t2) >> sh14);
+            }
+         usum[u] = s;
       }
-      for (int k = 0; k < LM + !(isTransient || narrow); k++) {
-         int B = isTransient ? (LM - k - 1) : k + 1;
-         haar1_l(tmp, N >> k, 1 << k);
-         L1 = l1_metric_l(tmp, N, B, bias);
-         if (L1 < best_L1) { best_L1 = L1; best_level = k + 1; }
+      wv_sync();
+      const i32 L1 = tf_band_cost(usum, b_lo, b_hi, (LM + 1) * bias);
+      if (!narrow && L1 < best_L1) { best_L1 = L1; best_level = -1; }
+      wv_sync();
+   }
+   for (int k = 0; k < LM + !isTransient; k++) {
+      if (k < LM) {
+         const int stride = 1 << k;
+         FOR_LANES(u, units) {
+            WV_LDS i32 *x = tmp + (u << LM);
+            i32 s = 0;
+            for (int j = 0; j < U >> 1; j++) {
+               const int p = ((j >> k) << (k + 1)) | (j & (stride - 1));
+               const i32 t1 = mult32_32_q31(QC32(.70710678f, 31), x[p]), t2 = mult32_32_q31(QC32(.70710678f, 31), x[p + stride]);
+               const i32 a = add32(t1, t2), d = sub32(t1, t2);
+               x[p] = a; x[p + stride] = d;
+               s += iabs(a >> sh14) + iabs(d >> sh14);
+            }
+            usum[u] = s;
+         }
+      } else {
+         FOR_LANES(u, units) {
+            const int bu = ct_unit2band[u], rel = u - ct_eBands[bu];
+            i32 s = 0;
+            if (!(rel & 1) && ct_eBands[bu + 1] - ct_eBands[bu] > 1) {
+               WV_LDS i32 *x = tmp + (u << LM);
+               for (int i = 0; i < U; i++) {
+                  const i32 t1 = mult32_32_q31(QC32(.70710678f, 31), x[i]), t2 = mult32_32_q31(QC32(.70710678f, 31), x[U + i]);
+                  const i32 a = add32(t1, t2), d = sub32(t1, t2);
+                  x[i] = a; x[U + i] = d;
+                  s += iabs(a >> sh14) + iabs(d >> sh14);
+               }
+            }
+            usum[u] = s;
+         }
       }
+      wv_sync();
+      const i32 L1 = tf_band_cost(usum, b_lo, b_hi, (isTransient ? LM - k - 1 : k + 1) * bias);
+      if (k < levels && L1 < best_L1) { best_L1 = L1; best_level = k + 1; }
+      wv_sync();
+   }
+   {
       int m = isTransient ? 2 * best_level : -2 * best_level;
       if (narrow && (m == 0 || m == -2 * LM)) m -= 1;
-      metric[i] = m;
+      if (lane < len) metric[lane] = m;
    }
    wv_sync();
-   LANE0 {
-      const WV_LDS i32 *importance = L->importance;
-      WV_LDS i32 *tf_res = L->tf_res;
-      int cost0, cost1, selcost[2], tf_select = 0;
-      for (int sel = 0; sel < 2; sel++) {
-         cost0 = importance[0] * iabs(metric[0] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * sel + 0]);
-         cost1 = importance[0] * iabs(metric[0] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * sel + 1]) + (isTransient ? 0 : lambda);
-         for (int i = 1; i < len; i++) {
-            int curr0 = imin(cost0, cost1 + lambda), curr1 = imin(cost0 + lambda, cost1);
-            cost0 = curr0 + importance[i] * iabs(metric[i] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * sel + 0]);
-            cost1 = curr1 + importance[i] * iabs(metric[i] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * sel + 1]);
-         }
-         selcost[sel] = imin(cost0, cost1);
+   /* ---- the search: hypothesis tf_select = half of the wave, band = lane within the half ---- */
+   const int sel = lane >> 5, i = lane & 31, ib = imin(i, len - 1);
+   const signed char *row = k_tf_select_table[LM] + 4 * isTransient + 2 * sel;
+   const i32 d0 = L->importance[ib] * iabs(metric[ib] - 2 * row[0]), d1 = L->importance[ib] * iabs(metric[ib] - 2 * row[1]);
+   const i32 FAR = 1 << 28;
+   /* band i's step as a (min,+) matrix a[from][to]; band 0 is the start vector in row 0 */
+   i32 a00, a01, a10, a11;
+   if (i == 0) { a00 = d0; a01 = d1 + (isTransient ? 0 : lambda); a10 = FAR; a11 = FAR; }
+   else { a00 = d0; a01 = d1 + lambda; a10 = d0 + lambda; a11 = d1; }
+#pragma unroll
+   for (int d = 1; d < 32; d <<= 1) {
+      const int src = (lane - d) & 63;
+      const i32 b00 = wv_shfl(a00, src), b01 = wv_shfl(a01, src), b10 = wv_shfl(a10, src), b11 = wv_shfl(a11, src);
+      if (i >= d) {                                  /* (bands i-2d+1 .. i-d) x (bands i-d+1 .. i) */
+         const i32 n00 = imin(b00 + a00, b01 + a10), n01 = imin(b00 + a01, b01 + a11), n10 = imin(b10 + a00, b11 + a10), n11 = imin(b10 + a01, b11 + a11);
+         a00 = imin(n00, FAR); a01 = imin(n01, FAR); a10 = imin(n10, FAR); a11 = imin(n11, FAR);
       }
-      if (selcost[1] < selcost[0] && isTransient) tf_select = 1;
-      cost0 = importance[0] * iabs(metric[0] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * tf_select + 0]);
-      cost1 = importance[0] * iabs(metric[0] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * tf_select + 1]) + (isTransient ? 0 : lambda);
-      for (int i = 1; i < len; i++) {
-         int curr0, curr1, from0 = cost0, from1 = cost1 + lambda;
-         if (from0 < from1) { curr0 = from0; path0[i] = 0; } else { curr0 = from1; path0[i] = 1; }
-         from0 = cost0 + lambda; from1 = cost1;
-         if (from0 < from1) { curr1 = from0; path1[i] = 0; } else { curr1 = from1; path1[i] = 1; }
-         cost0 = curr0 + importance[i] * iabs(metric[i] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * tf_select + 0]);
-         cost1 = curr1 + importance[i] * iabs(metric[i] - 2 * k_tf_select_table[LM][4 * isTransient + 2 * tf_select + 1]);
-      }
-      tf_res[len - 1] = cost0 < cost1 ? 0 : 1;
-      for (int i = len - 2; i >= 0; i--) tf_res[i] = tf_res[i + 1] == 1 ? path1[i + 1] : path0[i + 1];
-      for (int i = len; i < sh->end; i++) tf_res[i] = tf_res[len - 1];
-      sh->tf_select = tf_select;
+   }
+   const i32 cost0 = a00, cost1 = a01;               /* the costs of ending band i in state 0 / 1 */
+   const i32 end0 = wv_shfl(cost0, (lane & 32) | (len - 1)), end1 = wv_shfl(cost1, (lane & 32) | (len - 1));
+   const i32 selcost = imin(end0, end1);
+   const int tf_select = isTransient && wv_bcast(selcost, 32) < wv_bcast(selcost, 0);
+   /* where state 0 / state 1 of band i came from, as a map "state of band i -> state of band i-1" in two bits; then k = the map of the band above */
+   const i32 p0 = wv_shfl(cost0, (lane - 1) & 63), p1 = wv_shfl(cost1, (lane - 1) & 63);
+   const int from = (p0 < p1 + lambda ? 0 : 1) | (p0 + lambda < p1 ? 0 : 2);
+   int up = wv_shfl(from, (lane + 1) & 63);
+   if (i >= len - 1) up = 2;                         /* identity above the last band */
+#pragma unroll
+   for (int d = 1; d < 32; d <<= 1) {
+      int far = wv_shfl(up, (lane + d) & 63);
+      if (i + d >= 32) far = 2;
+      up = ((up >> (far & 1)) & 1) | (((up >> ((far >> 1) & 1)) & 1) << 1);     /* up o far */
+   }
+   const int last_state = end0 < end1 ? 0 : 1, state = (up >> last_state) & 1;
+   if (sel == tf_select) {
+      if (i < len) L->tf_res[i] = state;
+      else if (i < sh->end) L->tf_res[i] = last_state;
+      if (lane == 32 * tf_select) sh->tf_select = tf_select;
    }
    wv_sync();
 }

@@ -162,14 +162,13 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       }
    }
    K_PHASE(6);
-   LANE0 {
-      EC_BEGIN;
-      if (!sh->lfe) temporal_vbr_l0(L); else sh->temporal_vbr = 0;
-      if (!sh->secondMdct) for (int i = 0; i < C * NBE; i++) L->bandLogE2[i] = L->bandLogE[i];
-      sh->do_patch = 0;
-      if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5 && !sh->lfe && !HYB)
-         sh->do_patch = patch_transient_decision_l0(L);
-      EC_END;
+   if (!sh->lfe) temporal_vbr_wave(L); else { LANE0 sh->temporal_vbr = 0; }
+   if (!sh->secondMdct) { FOR_LANES(i, C * NBE) L->bandLogE2[i] = L->bandLogE[i]; }
+   {
+      EC_BEGIN;                                                    /* every lane reads the coder's position; nothing is coded here */
+      const int may_patch = LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits && !sh->isTransient && sh->complexity >= 5 && !sh->lfe && !HYB;
+      const int do_patch = may_patch ? patch_transient_decision_wave(L) : 0;
+      LANE0 sh->do_patch = do_patch;
    }
    wv_sync();
    if (sh->do_patch) {
