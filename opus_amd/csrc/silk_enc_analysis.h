@@ -649,6 +649,158 @@ WV_DEV void se_ltp_scale_ctrl(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl,
    ctl->LTP_scale_Q14 = sk_ltpscales_table_q14[c->indices.LTP_scaleIndex];
 }
 
+/* ---- the same two stages on the wave ----
+ * silk_sum_sqr_shift: both passes are sums of individually shifted pair energies (mod 2^32) -> lanes over pairs + one reduction per pass. */
+WV_DEV void se_sum_sqr_shift_wave(i32 *energy, int *shift, const WV_LDS i16 *x, int len)
+{
+   int shft = 31 - sk_clz(len);
+   i32 nrg = len;
+   for (int pass = 0; pass < 2; pass++) {
+      if (pass) { shft = imax(0, shft + 3 - sk_clz(nrg)); nrg = 0; }
+      u32 part = 0;
+      FOR_LANES(p, (len + 1) >> 1) {
+         const int i = 2 * p;
+         u32 t = (u32)((i32)x[i] * x[i]);
+         if (i + 1 < len) t += (u32)((i32)x[i + 1] * x[i + 1]);
+         part += t >> shft;
+      }
+      nrg = (i32)((u32)nrg + wv_sumu(part));
+   }
+   *shift = shft; *energy = nrg;
+}
+/* silk_find_LTP_FIX: per sub-frame the 5x5 correlation matrix of the lagged residual and its 5 correlations with the target.  Every entry is a sum over the
+ * sub-frame of (optionally shifted) products -- order-free -- plus at most four boundary corrections chained along a diagonal: lanes over the samples, one
+ * reduction per first-row entry and per correlation, the corrections on wave-uniform values; the 30 normalising 64-bit divisions one per lane. */
+WV_DEV void se_find_ltp_wave(WV_LDS i32 *XX, WV_LDS i32 *xX, const WV_LDS i16 *r_ptr, const WV_LDS i32 *lag, int subfr_length, int nb_subfr)
+{
+   const int order = 5, L = subfr_length, lane = wv_lane();
+   for (int k = 0; k < nb_subfr; k++) {
+      const WV_LDS i16 *xm = r_ptr - (lag[k] + 5 / 2), *ptr1 = xm + order - 1;
+      i32 xx, nrg; int xx_shifts, rs;
+      se_sum_sqr_shift_wave(&xx, &xx_shifts, r_ptr, L + order);
+      se_sum_sqr_shift_wave(&nrg, &rs, xm, L + order - 1);
+      /* first column (= first row) of the matrix: lag lg against lag 0, over the sub-frame */
+      i32 col[5];
+      {
+         i32 e = nrg;
+         for (int i = 0; i < order - 1; i++) e -= sk_mulbb(xm[i], xm[i]) >> rs;
+         col[0] = e;
+         i32 part[4] = {0, 0, 0, 0};
+         FOR_LANES(i, L) {
+            const i32 a = ptr1[i];
+#pragma unroll
+            for (int lg = 1; lg < order; lg++) part[lg - 1] = add32(part[lg - 1], sk_mulbb(a, ptr1[i - lg]) >> rs);
+         }
+#pragma unroll
+         for (int lg = 1; lg < order; lg++) col[lg] = wv_sum(part[lg - 1]);
+      }
+      /* down each diagonal: drop the product leaving the window, add the one entering */
+      wv_sync();
+#pragma unroll
+      for (int lg = 0; lg < order; lg++) {
+         i32 e = col[lg];
+         if (lane == 0) { XX[lg * order] = e; XX[lg] = e; }
+         for (int j = 1; j < order - lg; j++) {
+            e = sub32(e, sk_mulbb(ptr1[L - j], ptr1[L - j - lg]) >> rs);
+            e = add32(e, sk_mulbb(ptr1[-j], ptr1[-j - lg]) >> rs);
+            if (lane == 0) { XX[(lg + j) * order + j] = e; XX[j * order + lg + j] = e; }
+         }
+      }
+      const int extra_shifts = xx_shifts - rs;
+      int xX_shifts = xx_shifts, XX_down = 0;
+      if (extra_shifts > 0) { XX_down = extra_shifts; nrg >>= extra_shifts; }
+      else if (extra_shifts < 0) { xX_shifts = rs; xx >>= -extra_shifts; }
+      i32 ipart[5] = {0, 0, 0, 0, 0};
+      FOR_LANES(i, L) {
+         const i32 t = r_ptr[i];
+#pragma unroll
+         for (int lg = 0; lg < order; lg++) ipart[lg] = add32(ipart[lg], sk_mulbb(ptr1[i - lg], t) >> xX_shifts);
+      }
+      i32 ip[5];
+#pragma unroll
+      for (int lg = 0; lg < order; lg++) ip[lg] = wv_sum(ipart[lg]);
+      wv_sync();
+      const i32 temp = imax(sk_mlawb(1, nrg, SE_FIX(0.03f, 16)), xx);
+      if (lane < 25) XX[lane] = (i32)(((i64)(XX[lane] >> XX_down) << 17) / temp);
+      if (lane >= 32 && lane < 37) { i32 v = ip[0]; for (int lg = 1; lg < order; lg++) if (lane - 32 == lg) v = ip[lg]; xX[lane - 32] = (i32)(((i64)v << 17) / temp); }
+      wv_sync();
+      r_ptr += subfr_length; XX += 25; xX += 5;
+   }
+}
+
+/* silk_quant_LTP_gains + silk_VQ_WMat_EC: one lane per codebook vector of all three codebooks at once (8 + 16 + 32 = 56 lanes).  Along the sub-frames each
+ * codebook carries its own gain budget; per sub-frame and codebook the winner is the LAST vector of minimal cost (the reference's `<=` scan): a wave minimum, then
+ * the top bit of a ballot.  A sub-frame in which some codebook has no admissible vector makes the reference fall back on a value left over from the previous
+ * search; that corner is left to the serial form. */
+WV_DEV void se_quant_ltp_gains_wave(WV_LDS i16 *B_Q14, WV_LDS i8 *cbk_index, WV_LDS i8 *periodicity_index, WV_LDS i32 *sum_log_gain_Q7, WV_LDS i32 *pred_gain_dB_Q7,
+      const WV_LDS i32 *XX_Q17, const WV_LDS i32 *xX_Q17, int subfr_len, int nb_subfr)
+{
+   const int lane = wv_lane(), v = imin(lane, 55), k = v < 8 ? 0 : v < 24 ? 1 : 2;
+   const u64 cb_mask[3] = {0xffull, 0xffff00ull, 0xffffffff000000ull};
+   const int cb_first[3] = {0, 8, 24};
+   const i32 gain_safety = SE_FIX(0.4, 7);
+   const i8 *row = &sk_ltp_vq_q7[v * 5];
+   const i32 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4], gain_v = se_ltp_vq_gain_q7[v], cl_v = se_ltp_gain_bits_q5[v];
+   i32 slg[3], rate[3] = {0, 0, 0}, res[3] = {0, 0, 0};
+   int idx[3][4], degenerate = 0;
+   slg[0] = slg[1] = slg[2] = *sum_log_gain_Q7;
+   const WV_LDS i32 *XX = XX_Q17, *xX = xX_Q17;
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      if (j >= nb_subfr) break;
+      const i32 my_slg = k == 0 ? slg[0] : k == 1 ? slg[1] : slg[2];
+      const i32 max_gain_Q7 = se_log2lin((SE_FIX(250.0f / 6.0, 7) - my_slg) + SE_FIX(7, 7)) - gain_safety;
+      const i32 n0 = -shl32(xX[0], 7), n1 = -shl32(xX[1], 7), n2 = -shl32(xX[2], 7), n3 = -shl32(xX[3], 7), n4 = -shl32(xX[4], 7);
+      const i32 penalty = shl32(imax(sub32(gain_v, max_gain_Q7), 0), 11);
+      i32 sum1_Q15 = SE_FIX(1.001, 15), sum2_Q24;
+      sum2_Q24 = n0 + XX[1] * r1; sum2_Q24 += XX[2] * r2; sum2_Q24 += XX[3] * r3; sum2_Q24 += XX[4] * r4;
+      sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[0] * r0; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, r0);
+      sum2_Q24 = n1 + XX[7] * r2; sum2_Q24 += XX[8] * r3; sum2_Q24 += XX[9] * r4;
+      sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[6] * r1; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, r1);
+      sum2_Q24 = n2 + XX[13] * r3; sum2_Q24 += XX[14] * r4;
+      sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[12] * r2; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, r2);
+      sum2_Q24 = n3 + XX[19] * r4;
+      sum2_Q24 = shl32(sum2_Q24, 1); sum2_Q24 += XX[18] * r3; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, r3);
+      sum2_Q24 = shl32(n4, 1); sum2_Q24 += XX[24] * r4; sum1_Q15 = sk_mlawb(sum1_Q15, sum2_Q24, r4);
+      const bool ok = lane < 56 && sum1_Q15 >= 0;
+      const i32 res_v = sum1_Q15 + penalty;
+      const i32 bits_tot_Q8 = ok ? se_add_lshift32(sk_mulbb(subfr_len, se_lin2log(ok ? res_v : 1) - (15 << 7)), cl_v, 3 - 1) : 2147483647;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+         const bool mine = ok && k == c;
+         const i32 best = wv_min(mine ? bits_tot_Q8 : 2147483647);
+         const u64 at = wv_ballot(mine && bits_tot_Q8 == best) & cb_mask[c];
+         if (!at) { degenerate = 1; idx[c][j] = 0; continue; }
+         const int win = 63 - __builtin_clzll(at);
+         idx[c][j] = win - cb_first[c];
+         res[c] = se_add_pos_sat(res[c], wv_bcast(res_v, win));
+         rate[c] = se_add_pos_sat(rate[c], best);
+         slg[c] = imax(0, slg[c] + se_lin2log(gain_safety + wv_bcast(gain_v, win)) - SE_FIX(7, 7));
+      }
+      XX += 25; xX += 5;
+   }
+   if (degenerate) {
+      LANE0 se_quant_ltp_gains_l0(B_Q14, cbk_index, periodicity_index, sum_log_gain_Q7, pred_gain_dB_Q7, XX_Q17, xX_Q17, subfr_len, nb_subfr);
+      wv_sync();
+      return;
+   }
+   int per = 0; i32 min_rate = 2147483647;
+#pragma unroll
+   for (int c = 0; c < 3; c++) if (rate[c] <= min_rate) { min_rate = rate[c]; per = c; }
+   const i32 best_slg = per == 0 ? slg[0] : per == 1 ? slg[1] : slg[2];
+   wv_sync();
+   if (lane < nb_subfr) { int w = idx[0][0]; for (int c = 0; c < 3; c++) for (int j = 0; j < 4; j++) if (c == per && j == lane) w = idx[c][j]; cbk_index[lane] = (i8)w; }
+   wv_sync();
+   FOR_LANES(t, nb_subfr * 5) { const int j = t / 5, e = t - 5 * j; B_Q14[t] = (i16)shl32(sk_ltp_vq_q7[(cb_first[per] + cbk_index[j]) * 5 + e], 7); }
+   LANE0 {
+      const i32 res_nrg_Q15 = nb_subfr == 2 ? res[2] >> 1 : res[2] >> 2;
+      *periodicity_index = (i8)per;
+      *sum_log_gain_Q7 = best_slg;
+      *pred_gain_dB_Q7 = sk_mulbb(-3, se_lin2log(res_nrg_Q15) - (15 << 7));
+   }
+   wv_sync();
+}
+
 /* every output sample is independent: lanes */
 WV_DEV void se_ltp_analysis_filter_wave(WV_LDS i16 *LTP_res, const WV_LDS i16 *x, const WV_LDS i16 *LTPCoef_Q14, const WV_LDS i32 *pitchL, const WV_LDS i32 *invGains_Q16, int subfr_length, int nb_subfr, int pre_length)
 {

@@ -188,7 +188,7 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *
 /* scratch of the LPC / NLSF stages (LDS) */
 struct SeLpcWork {
    i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8];
-   i16 NLSF_Q15[16], NLSF0_Q15[16], a_tmp_Q12[16], pW[16];
+   i16 NLSF_Q15[16], pW[16];
    i32 wk[66];
    union {                                                     /* one stage at a time: LTP correlations -> Burg -> A2NLSF grid -> interpolation residual -> NLSF quantiser -> residual energies */
       i32 XX[120];
@@ -285,13 +285,20 @@ WV_DEV void se_process_nlsfs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS i16 *PredCo
       for (int i = 0; i < order; i++) W->pW[i] = w[i];
    }
    se_nlsf_encode_wave(c->indices.NLSFIndices, W->NLSF_Q15, order, W->pW, NLSF_mu_Q20, c->NLSF_MSVQ_Survivors, c->indices.signalType, W);
-   LANE0 {
-      sd_nlsf2a_w(PredCoef_Q12 + 16, W->NLSF_Q15, order, W->wk);
-      if (doInterpolate) {
-         for (int i = 0; i < order; i++) W->NLSF0_Q15[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], c->indices.NLSFInterpCoef_Q2) >> 2));
-         sd_nlsf2a_w(PredCoef_Q12, W->NLSF0_Q15, order, W->wk);
-      } else for (int i = 0; i < order; i++) PredCoef_Q12[i] = PredCoef_Q12[16 + i];
+   /* the two conversions back to LPC (second half: the quantised NLSFs; first half: their interpolation with last frame's) side by side on lanes 0 and 1 */
+   wv_sync();
+   {
+      const int lane = wv_lane();
+      if (lane == 0) sd_nlsf2a_w(PredCoef_Q12 + 16, W->NLSF_Q15, order, W->wk);
+      if (lane == 1 && doInterpolate) {
+         i16 n0[16];
+         for (int i = 0; i < order; i++) n0[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], c->indices.NLSFInterpCoef_Q2) >> 2));
+         sd_nlsf2a_w(PredCoef_Q12, n0, order, W->stk);                          /* the quantiser's work area (same union) is free again */
+      }
    }
+   wv_sync();
+   if (!doInterpolate) { FOR_LANES(i, order) PredCoef_Q12[i] = PredCoef_Q12[16 + i]; }
+   wv_sync();
 }
 
 /* x = LPC_in_pre; LPC_res: i16[2 * 96] */
@@ -316,26 +323,38 @@ WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, c
    if (interp) se_a2nlsf_wave(W->NLSF_Q15, W->a_tmp_Q16, order, W->Y);
    SE_TICK(tk, 12);                                                              /* Burg (x2) + A2NLSF of the second half */
    if (interp) {
-      for (int k = 3; k >= 0; k--) {
-         LANE0 {
-            for (int i = 0; i < order; i++) W->NLSF0_Q15[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], k) >> 2));   /* silk_interpolate */
-            sd_nlsf2a_w(W->a_tmp_Q12, W->NLSF0_Q15, order, W->wk);
-         }
-         se_lpc_analysis_filter_wave(LPC_res, x, W->a_tmp_Q12, 2 * subfr_length, order);
-         LANE0 {
-            i32 res_nrg0, res_nrg1, res_nrg = W->r[0]; int rshift0, rshift1, res_nrg_Q = W->r[1], res_nrg_interp_Q, isInterpLower;
-            sd_sum_sqr_shift(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order);
-            sd_sum_sqr_shift(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order);
-            int shift = rshift0 - rshift1;
-            if (shift >= 0) { res_nrg1 >>= shift; res_nrg_interp_Q = -rshift0; } else { res_nrg0 >>= -shift; res_nrg_interp_Q = -rshift1; }
-            const i32 res_nrg_interp = add32(res_nrg0, res_nrg1);
-            shift = res_nrg_interp_Q - res_nrg_Q;
-            if (shift >= 0) isInterpLower = (res_nrg_interp >> shift) < res_nrg;
-            else if (-shift < 32) isInterpLower = res_nrg_interp < (res_nrg >> -shift);
-            else isInterpLower = 0;
-            if (isInterpLower) { W->r[0] = res_nrg_interp; W->r[1] = res_nrg_interp_Q; c->indices.NLSFInterpCoef_Q2 = (i8)k; }
-         }
+      /* the four interpolation candidates (k/4 of the way from last frame's NLSFs to this frame's second-half NLSFs): their NLSF -> LPC conversions are serial
+       * and independent, so they run side by side on lanes 0..3, each with its own work area behind the residual buffer; the residual energies of the
+       * candidates are then measured one after the other by the whole wave, and the reference's running comparison is replayed on uniform values */
+      WV_LDS i32 *pool = (WV_LDS i32 *)W->LPC_res + 96;                         /* LPC_res is i16[192]; the union holds 348 words */
+      WV_LDS i16 *cand_a = (WV_LDS i16 *)(pool + 3 * 66);                       /* 4 x 16 coefficients */
+      const int lane = wv_lane();
+      wv_sync();
+      if (lane < 4) {
+         i16 n[16];
+         for (int i = 0; i < order; i++) n[i] = (i16)(c->prev_NLSFq_Q15[i] + (sk_mulbb(W->NLSF_Q15[i] - c->prev_NLSFq_Q15[i], lane) >> 2));   /* silk_interpolate */
+         sd_nlsf2a_w(cand_a + 16 * lane, n, order, lane == 0 ? W->wk : pool + (lane - 1) * 66);
       }
+      wv_sync();
+      i32 res_nrg = W->r[0]; int res_nrg_Q = W->r[1], coef = 4;
+      for (int k = 3; k >= 0; k--) {
+         se_lpc_analysis_filter_wave(LPC_res, x, cand_a + 16 * k, 2 * subfr_length, order);
+         wv_sync();
+         i32 res_nrg0, res_nrg1; int rshift0, rshift1, res_nrg_interp_Q, isInterpLower;
+         se_sum_sqr_shift_wave(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order);
+         se_sum_sqr_shift_wave(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order);
+         int shift = rshift0 - rshift1;
+         if (shift >= 0) { res_nrg1 >>= shift; res_nrg_interp_Q = -rshift0; } else { res_nrg0 >>= -shift; res_nrg_interp_Q = -rshift1; }
+         const i32 res_nrg_interp = add32(res_nrg0, res_nrg1);
+         shift = res_nrg_interp_Q - res_nrg_Q;
+         if (shift >= 0) isInterpLower = (res_nrg_interp >> shift) < res_nrg;
+         else if (-shift < 32) isInterpLower = res_nrg_interp < (res_nrg >> -shift);
+         else isInterpLower = 0;
+         if (isInterpLower) { res_nrg = res_nrg_interp; res_nrg_Q = res_nrg_interp_Q; coef = k; }
+         wv_sync();
+      }
+      LANE0 { W->r[0] = res_nrg; W->r[1] = res_nrg_Q; c->indices.NLSFInterpCoef_Q2 = (i8)coef; }
+      wv_sync();
    }
    SE_TICK(tk, 13);                                                              /* interpolation search */
    if (c->indices.NLSFInterpCoef_Q2 == 4) se_a2nlsf_wave(W->NLSF_Q15, W->a_Q16, order, W->Y);
@@ -357,11 +376,10 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       }
    }
    if (c->indices.signalType == SE_TYPE_VOICED) {
-      LANE0 {
-         se_find_ltp_l0(XX + 20, XX, res_pitch, ctl->pitchL, sl, nb);
-         se_quant_ltp_gains_l0(ctl->LTPCoef_Q14, c->indices.LTPIndex, &c->indices.PERIndex, &c->sum_log_gain_Q7, &ctl->LTPredCodGain_Q7, XX + 20, XX, sl, nb);
-         se_ltp_scale_ctrl(c, ctl, condCoding);
-      }
+      wv_sync();
+      se_find_ltp_wave(XX + 20, XX, res_pitch, ctl->pitchL, sl, nb);
+      se_quant_ltp_gains_wave(ctl->LTPCoef_Q14, c->indices.LTPIndex, &c->indices.PERIndex, &c->sum_log_gain_Q7, &ctl->LTPredCodGain_Q7, XX + 20, XX, sl, nb);
+      LANE0 se_ltp_scale_ctrl(c, ctl, condCoding);
       se_ltp_analysis_filter_wave(LPC_in_pre, x - order, ctl->LTPCoef_Q14, ctl->pitchL, W->invGains_Q16, sl, nb, order);
    } else {
       for (int i = 0; i < nb; i++) {
