@@ -171,6 +171,24 @@ template <class PA> WV_DEV void se_limit_warped_coefs(PA coefs_Q24, int lambda_Q
 
 /* pitch_res = res_pitch_frame, x = x_frame; xw: i16[240] windowed signal, xx: i16[240], w32: i32[28] (auto-correlation, [26] = SNR hand-off) */
 /* stk: 100 words of lane-0 working arrays in LDS */
+/* silk_sum_sqr_shift (sum_sqr_shift.c:36) on the wave: both passes are sums of individually shifted pair energies (mod 2^32) -> lanes over pairs + one reduction per pass. */
+WV_DEV void se_sum_sqr_shift_wave(i32 *energy, int *shift, const WV_LDS i16 *x, int len)
+{
+   int shft = 31 - sk_clz(len);
+   i32 nrg = len;
+   for (int pass = 0; pass < 2; pass++) {
+      if (pass) { shft = imax(0, shft + 3 - sk_clz(nrg)); nrg = 0; }
+      u32 part = 0;
+      FOR_LANES(p, (len + 1) >> 1) {
+         const int i = 2 * p;
+         u32 t = (u32)((i32)x[i] * x[i]);
+         if (i + 1 < len) t += (u32)((i32)x[i + 1] * x[i + 1]);
+         part += t >> shft;
+      }
+      nrg = (i32)((u32)nrg + wv_sumu(part));
+   }
+   *shift = shft; *energy = nrg;
+}
 WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *pitch_res, const WV_LDS i16 *x, WV_LDS i16 *xw, WV_LDS i16 *xx, WV_LDS i32 *w32, WV_LDS i32 *stk)
 {
    const WV_LDS i16 *x_ptr = x - c->la_shape;
@@ -187,22 +205,20 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
       if (c->indices.signalType == SE_TYPE_VOICED) SNR_adj_dB_Q7 = sk_mlawb(SNR_adj_dB_Q7, SE_FIX(2.0f, 8), c->LTPCorr_Q15);
       else SNR_adj_dB_Q7 = sk_mlawb(SNR_adj_dB_Q7, sk_mlawb(SE_FIX(6.0, 9), -SE_FIX(0.4, 18), c->SNR_dB_Q7), SE_FIX(1.0, 14) - ctl->input_quality_Q14);
       if (c->indices.signalType == SE_TYPE_VOICED) c->indices.quantOffsetType = 0;
-      else {
-         const int nSamples = shl32(c->fs_kHz, 1), nSegs = sk_mulbb(5, c->nb_subfr) / 2;
-         i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
-         const WV_LDS i16 *p = pitch_res;
-         for (int k = 0; k < nSegs; k++) {
-            i32 nrg; int scale;
-            sd_sum_sqr_shift(&nrg, &scale, p, nSamples);
-            nrg += nSamples >> scale;
-            const i32 log_energy_Q7 = se_lin2log(nrg);
-            if (k > 0) energy_variation_Q7 += iabs(log_energy_Q7 - log_energy_prev_Q7);
-            log_energy_prev_Q7 = log_energy_Q7;
-            p += nSamples;
-         }
-         c->indices.quantOffsetType = energy_variation_Q7 > SE_FIX(0.6f, 7) * (nSegs - 1) ? 0 : 1;
-      }
       w32[26] = SNR_adj_dB_Q7;
+   }
+   if (c->indices.signalType != SE_TYPE_VOICED) {                                  /* sparseness: how much the 2 ms segment energies of the residual jump about */
+      const int nSamples = shl32(c->fs_kHz, 1), nSegs = sk_mulbb(5, c->nb_subfr) / 2;
+      i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
+      for (int k = 0; k < nSegs; k++) {
+         i32 nrg; int scale;
+         se_sum_sqr_shift_wave(&nrg, &scale, pitch_res + k * nSamples, nSamples);
+         nrg += nSamples >> scale;
+         const i32 log_energy_Q7 = se_lin2log(nrg);
+         if (k > 0) energy_variation_Q7 += iabs(log_energy_Q7 - log_energy_prev_Q7);
+         log_energy_prev_Q7 = log_energy_Q7;
+      }
+      LANE0 c->indices.quantOffsetType = energy_variation_Q7 > SE_FIX(0.6f, 7) * (nSegs - 1) ? 0 : 1;
    }
    i32 strength_Q16 = sk_mulwb(ctl->predGain_Q16, SE_FIX(1e-3f, 16));
    const i32 BWExp_Q16 = sk_div32_varQ(SE_FIX(0.94f, 16), sk_mlaww(SE_FIX(1.0, 16), strength_Q16, strength_Q16), 16);
@@ -649,25 +665,7 @@ WV_DEV void se_ltp_scale_ctrl(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl,
    ctl->LTP_scale_Q14 = sk_ltpscales_table_q14[c->indices.LTP_scaleIndex];
 }
 
-/* ---- the same two stages on the wave ----
- * silk_sum_sqr_shift: both passes are sums of individually shifted pair energies (mod 2^32) -> lanes over pairs + one reduction per pass. */
-WV_DEV void se_sum_sqr_shift_wave(i32 *energy, int *shift, const WV_LDS i16 *x, int len)
-{
-   int shft = 31 - sk_clz(len);
-   i32 nrg = len;
-   for (int pass = 0; pass < 2; pass++) {
-      if (pass) { shft = imax(0, shft + 3 - sk_clz(nrg)); nrg = 0; }
-      u32 part = 0;
-      FOR_LANES(p, (len + 1) >> 1) {
-         const int i = 2 * p;
-         u32 t = (u32)((i32)x[i] * x[i]);
-         if (i + 1 < len) t += (u32)((i32)x[i + 1] * x[i + 1]);
-         part += t >> shft;
-      }
-      nrg = (i32)((u32)nrg + wv_sumu(part));
-   }
-   *shift = shft; *energy = nrg;
-}
+/* ---- the same two stages on the wave ---- */
 /* silk_find_LTP_FIX: per sub-frame the 5x5 correlation matrix of the lagged residual and its 5 correlations with the target.  Every entry is a sum over the
  * sub-frame of (optionally shifted) products -- order-free -- plus at most four boundary corrections chained along a diagonal: lanes over the samples, one
  * reduction per first-row entry and per correlation, the corrections on wave-uniform values; the 30 normalising 64-bit divisions one per lane. */

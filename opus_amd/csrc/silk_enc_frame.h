@@ -191,18 +191,28 @@ WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LD
    }
 }
 
-/* ---- stereo ---- */
-WV_DEV i32 se_stereo_find_predictor(i32 *ratio_Q14, const WV_LDS i16 *x, const WV_LDS i16 *y, WV_LDS i32 *mid_res_amp_Q0, int length, int smooth_coef_Q16)
+/* ---- stereo ----
+ * silk_stereo_find_predictor (stereo_find_predictor.c:34) in two halves: the three sums over the frame (two energies with their two-pass scaling, one cross
+ * product whose terms are shifted one by one: all order-free) by the whole wave, the fixed-point tail on lane 0 */
+struct SeStereoSums { i32 nrgx, nrgy, corr; int scale; };
+WV_DEV SeStereoSums se_stereo_sums_wave(const WV_LDS i16 *x, const WV_LDS i16 *y, int length)
 {
-   int scale, scale1, scale2; i32 nrgx, nrgy;
-   sd_sum_sqr_shift(&nrgx, &scale1, x, length);
-   sd_sum_sqr_shift(&nrgy, &scale2, y, length);
-   scale = imax(scale1, scale2);
+   SeStereoSums r; int scale1, scale2;
+   se_sum_sqr_shift_wave(&r.nrgx, &scale1, x, length);
+   se_sum_sqr_shift_wave(&r.nrgy, &scale2, y, length);
+   int scale = imax(scale1, scale2);
    scale = scale + (scale & 1);
-   nrgy >>= scale - scale2; nrgx >>= scale - scale1;
-   nrgx = imax(nrgx, 1);
-   i32 corr = 0;
-   for (int i = 0; i < length; i++) corr = corr + (sk_mulbb(x[i], y[i]) >> scale);
+   r.nrgy >>= scale - scale2; r.nrgx >>= scale - scale1;
+   r.nrgx = imax(r.nrgx, 1);
+   i32 part = 0;
+   FOR_LANES(i, length) part = add32(part, sk_mulbb(x[i], y[i]) >> scale);
+   r.corr = wv_sum(part);
+   r.scale = scale;
+   return r;
+}
+WV_DEV i32 se_stereo_predictor_tail(i32 *ratio_Q14, SeStereoSums m, WV_LDS i32 *mid_res_amp_Q0, int smooth_coef_Q16)
+{
+   i32 nrgx = m.nrgx, nrgy = m.nrgy; const i32 corr = m.corr; int scale = m.scale;
    i32 pred_Q13 = sk_div32_varQ(corr, nrgx, 13);
    pred_Q13 = se_limit(pred_Q13, -(1 << 14), 1 << 14);
    const i32 pred2_Q10 = sk_mulwb(pred_Q13, pred_Q13);
@@ -239,79 +249,93 @@ WV_DEV void se_stereo_encode_pred(EC_ARGS, const WV_LDS i8 *ix)
    k_ec_enc_icdf(EC_PASS, 5 * ix[2] + ix[3 + 2], sk_stereo_pred_joint_icdf, 8);
    for (int n = 0; n < 2; n++) { k_ec_enc_icdf(EC_PASS, ix[n * 3 + 0], sk_uniform3_icdf, 8); k_ec_enc_icdf(EC_PASS, ix[n * 3 + 1], sk_uniform5_icdf, 8); }
 }
-/* x1 = &inputBuf0[2], x2 = &inputBuf1[2]; lane 0 */
-WV_DEV void se_stereo_lr_to_ms_l0(WV_LDS OaSilkEncStereo *state, WV_LDS i16 *x1, WV_LDS i16 *x2, WV_LDS i8 *ix, WV_LDS i8 *mid_only_flag, i32 *mid_side_rates_bps, i32 total_rate_bps,
+/* silk_stereo_LR_to_MS (stereo_LR_to_MS.c:35).  x1 = &inputBuf0[2], x2 = &inputBuf1[2].  Every per-sample pass (mid / side, the 3-tap low / high split, the
+ * predicted side signal with its 8 ms parameter ramp -- written in closed form: step n uses start + (n + 1) * delta, exact mod 2^32) and every sum over the frame
+ * runs on the whole wave; lane 0 keeps the decision logic in between.  mid_side_rates_bps -> hand[0..1]. */
+WV_DEV void se_stereo_lr_to_ms_wave(WV_LDS OaSilkEncStereo *state, WV_LDS i16 *x1, WV_LDS i16 *x2, WV_LDS i8 *ix, WV_LDS i8 *mid_only_flag, WV_LDS i32 *hand, i32 total_rate_bps,
       int prev_speech_act_Q8, int toMono, int fs_kHz, int frame_length, WV_LDS SeStereoLds *T)
 {
    WV_LDS i16 *mid = &x1[-2], *side = T->side;
-   i32 sum, diff, pred_Q13[2], LP_ratio_Q14, HP_ratio_Q14, width_Q14;
-   for (int n = 0; n < frame_length + 2; n++) {
-      sum = x1[n - 2] + (i32)x2[n - 2]; diff = x1[n - 2] - (i32)x2[n - 2];
+   wv_sync();
+   FOR_LANES(n, frame_length + 2) {
+      const i32 sum = x1[n - 2] + (i32)x2[n - 2], diff = x1[n - 2] - (i32)x2[n - 2];
       mid[n] = (i16)sk_rround(sum, 1); side[n] = (i16)sk_sat16(sk_rround(diff, 1));
    }
-   mid[0] = state->sMid[0]; mid[1] = state->sMid[1]; side[0] = state->sSide[0]; side[1] = state->sSide[1];
-   state->sMid[0] = mid[frame_length]; state->sMid[1] = mid[frame_length + 1]; state->sSide[0] = side[frame_length]; state->sSide[1] = side[frame_length + 1];
-   for (int n = 0; n < frame_length; n++) {
-      sum = sk_rround(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 2); T->LP_mid[n] = (i16)sum; T->HP_mid[n] = (i16)(mid[n + 1] - sum);
+   wv_sync();
+   LANE0 {
+      mid[0] = state->sMid[0]; mid[1] = state->sMid[1]; side[0] = state->sSide[0]; side[1] = state->sSide[1];
+      state->sMid[0] = mid[frame_length]; state->sMid[1] = mid[frame_length + 1]; state->sSide[0] = side[frame_length]; state->sSide[1] = side[frame_length + 1];
+   }
+   wv_sync();
+   FOR_LANES(n, frame_length) {
+      i32 sum = sk_rround(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 2); T->LP_mid[n] = (i16)sum; T->HP_mid[n] = (i16)(mid[n + 1] - sum);
       sum = sk_rround(add32(side[n] + (i32)side[n + 2], shl32(side[n + 1], 1)), 2); T->LP_side[n] = (i16)sum; T->HP_side[n] = (i16)(side[n + 1] - sum);
    }
-   const int is10msFrame = frame_length == 10 * fs_kHz;
-   i32 smooth_coef_Q16 = is10msFrame ? SE_FIX(0.01 / 2, 16) : SE_FIX(0.01, 16);
-   smooth_coef_Q16 = sk_mulwb(sk_mulbb(prev_speech_act_Q8, prev_speech_act_Q8), smooth_coef_Q16);
-   pred_Q13[0] = se_stereo_find_predictor(&LP_ratio_Q14, T->LP_mid, T->LP_side, &state->mid_side_amp_Q0[0], frame_length, smooth_coef_Q16);
-   pred_Q13[1] = se_stereo_find_predictor(&HP_ratio_Q14, T->HP_mid, T->HP_side, &state->mid_side_amp_Q0[2], frame_length, smooth_coef_Q16);
-   i32 frac_Q16 = sk_mlabb(HP_ratio_Q14, LP_ratio_Q14, 3);
-   frac_Q16 = imin(frac_Q16, SE_FIX(1, 16));
-   total_rate_bps -= is10msFrame ? 1200 : 600;
-   if (total_rate_bps < 1) total_rate_bps = 1;
-   const i32 min_mid_rate_bps = sk_mlabb(2000, fs_kHz, 600), frac_3_Q16 = 3 * frac_Q16;
-   mid_side_rates_bps[0] = sk_div32_varQ(total_rate_bps, SE_FIX(8 + 5, 16) + frac_3_Q16, 16 + 3);
-   if (mid_side_rates_bps[0] < min_mid_rate_bps) {
-      mid_side_rates_bps[0] = min_mid_rate_bps; mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0];
-      width_Q14 = sk_div32_varQ(shl32(mid_side_rates_bps[1], 1) - min_mid_rate_bps, sk_mulwb(SE_FIX(1, 16) + frac_3_Q16, min_mid_rate_bps), 14 + 2);
-      width_Q14 = se_limit(width_Q14, 0, SE_FIX(1, 14));
-   } else { mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0]; width_Q14 = SE_FIX(1, 14); }
-   state->smth_width_Q14 = (i16)sk_mlawb(state->smth_width_Q14, width_Q14 - state->smth_width_Q14, smooth_coef_Q16);
-   *mid_only_flag = 0;
-   if (toMono) { width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; se_stereo_quant_pred(pred_Q13, ix); }
-   else if (state->width_prev_Q14 == 0 && (8 * total_rate_bps < 13 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.05, 14))) {
-      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
-      se_stereo_quant_pred(pred_Q13, ix);
-      width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; mid_side_rates_bps[0] = total_rate_bps; mid_side_rates_bps[1] = 0; *mid_only_flag = 1;
-   } else if (state->width_prev_Q14 != 0 && (8 * total_rate_bps < 11 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.02, 14))) {
-      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
-      se_stereo_quant_pred(pred_Q13, ix);
-      width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0;
-   } else if (state->smth_width_Q14 > SE_FIX(0.95, 14)) { se_stereo_quant_pred(pred_Q13, ix); width_Q14 = SE_FIX(1, 14); }
-   else {
-      pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
-      se_stereo_quant_pred(pred_Q13, ix);
-      width_Q14 = state->smth_width_Q14;
+   wv_sync();
+   const SeStereoSums lp = se_stereo_sums_wave(T->LP_mid, T->LP_side, frame_length), hp = se_stereo_sums_wave(T->HP_mid, T->HP_side, frame_length);
+   LANE0 {
+      i32 pred_Q13[2], LP_ratio_Q14, HP_ratio_Q14, width_Q14, mid_side_rates_bps[2];
+      const int is10msFrame = frame_length == 10 * fs_kHz;
+      i32 smooth_coef_Q16 = is10msFrame ? SE_FIX(0.01 / 2, 16) : SE_FIX(0.01, 16);
+      smooth_coef_Q16 = sk_mulwb(sk_mulbb(prev_speech_act_Q8, prev_speech_act_Q8), smooth_coef_Q16);
+      pred_Q13[0] = se_stereo_predictor_tail(&LP_ratio_Q14, lp, &state->mid_side_amp_Q0[0], smooth_coef_Q16);
+      pred_Q13[1] = se_stereo_predictor_tail(&HP_ratio_Q14, hp, &state->mid_side_amp_Q0[2], smooth_coef_Q16);
+      i32 frac_Q16 = sk_mlabb(HP_ratio_Q14, LP_ratio_Q14, 3);
+      frac_Q16 = imin(frac_Q16, SE_FIX(1, 16));
+      total_rate_bps -= is10msFrame ? 1200 : 600;
+      if (total_rate_bps < 1) total_rate_bps = 1;
+      const i32 min_mid_rate_bps = sk_mlabb(2000, fs_kHz, 600), frac_3_Q16 = 3 * frac_Q16;
+      mid_side_rates_bps[0] = sk_div32_varQ(total_rate_bps, SE_FIX(8 + 5, 16) + frac_3_Q16, 16 + 3);
+      if (mid_side_rates_bps[0] < min_mid_rate_bps) {
+         mid_side_rates_bps[0] = min_mid_rate_bps; mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0];
+         width_Q14 = sk_div32_varQ(shl32(mid_side_rates_bps[1], 1) - min_mid_rate_bps, sk_mulwb(SE_FIX(1, 16) + frac_3_Q16, min_mid_rate_bps), 14 + 2);
+         width_Q14 = se_limit(width_Q14, 0, SE_FIX(1, 14));
+      } else { mid_side_rates_bps[1] = total_rate_bps - mid_side_rates_bps[0]; width_Q14 = SE_FIX(1, 14); }
+      state->smth_width_Q14 = (i16)sk_mlawb(state->smth_width_Q14, width_Q14 - state->smth_width_Q14, smooth_coef_Q16);
+      *mid_only_flag = 0;
+      if (toMono) { width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; se_stereo_quant_pred(pred_Q13, ix); }
+      else if (state->width_prev_Q14 == 0 && (8 * total_rate_bps < 13 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.05, 14))) {
+         pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+         se_stereo_quant_pred(pred_Q13, ix);
+         width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0; mid_side_rates_bps[0] = total_rate_bps; mid_side_rates_bps[1] = 0; *mid_only_flag = 1;
+      } else if (state->width_prev_Q14 != 0 && (8 * total_rate_bps < 11 * min_mid_rate_bps || sk_mulwb(frac_Q16, state->smth_width_Q14) < SE_FIX(0.02, 14))) {
+         pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+         se_stereo_quant_pred(pred_Q13, ix);
+         width_Q14 = 0; pred_Q13[0] = 0; pred_Q13[1] = 0;
+      } else if (state->smth_width_Q14 > SE_FIX(0.95, 14)) { se_stereo_quant_pred(pred_Q13, ix); width_Q14 = SE_FIX(1, 14); }
+      else {
+         pred_Q13[0] = sk_mulbb(state->smth_width_Q14, pred_Q13[0]) >> 14; pred_Q13[1] = sk_mulbb(state->smth_width_Q14, pred_Q13[1]) >> 14;
+         se_stereo_quant_pred(pred_Q13, ix);
+         width_Q14 = state->smth_width_Q14;
+      }
+      if (*mid_only_flag == 1) {
+         state->silent_side_len += frame_length - 8 * fs_kHz;
+         if (state->silent_side_len < 5 * fs_kHz) *mid_only_flag = 0; else state->silent_side_len = 10000;
+      } else state->silent_side_len = 0;
+      if (*mid_only_flag == 0 && mid_side_rates_bps[1] < 1) { mid_side_rates_bps[1] = 1; mid_side_rates_bps[0] = imax(1, total_rate_bps - mid_side_rates_bps[1]); }
+      const int denom_Q16 = ((i32)1 << 16) / (8 * fs_kHz);
+      hand[0] = mid_side_rates_bps[0]; hand[1] = mid_side_rates_bps[1];
+      hand[2] = -state->pred_prev_Q13[0]; hand[3] = -state->pred_prev_Q13[1]; hand[4] = shl32(state->width_prev_Q14, 10);
+      hand[5] = -sk_rround(sk_mulbb(pred_Q13[0] - state->pred_prev_Q13[0], denom_Q16), 16); hand[6] = -sk_rround(sk_mulbb(pred_Q13[1] - state->pred_prev_Q13[1], denom_Q16), 16);
+      hand[7] = shl32(sk_mulwb(width_Q14 - state->width_prev_Q14, denom_Q16), 10);
+      hand[8] = -pred_Q13[0]; hand[9] = -pred_Q13[1]; hand[10] = shl32(width_Q14, 10);
+      state->pred_prev_Q13[0] = (i16)pred_Q13[0]; state->pred_prev_Q13[1] = (i16)pred_Q13[1]; state->width_prev_Q14 = (i16)width_Q14;
    }
-   if (*mid_only_flag == 1) {
-      state->silent_side_len += frame_length - 8 * fs_kHz;
-      if (state->silent_side_len < 5 * fs_kHz) *mid_only_flag = 0; else state->silent_side_len = 10000;
-   } else state->silent_side_len = 0;
-   if (*mid_only_flag == 0 && mid_side_rates_bps[1] < 1) { mid_side_rates_bps[1] = 1; mid_side_rates_bps[0] = imax(1, total_rate_bps - mid_side_rates_bps[1]); }
-   i32 pred0_Q13 = -state->pred_prev_Q13[0], pred1_Q13 = -state->pred_prev_Q13[1], w_Q24 = shl32(state->width_prev_Q14, 10);
-   const int denom_Q16 = ((i32)1 << 16) / (8 * fs_kHz);
-   const i32 delta0_Q13 = -sk_rround(sk_mulbb(pred_Q13[0] - state->pred_prev_Q13[0], denom_Q16), 16), delta1_Q13 = -sk_rround(sk_mulbb(pred_Q13[1] - state->pred_prev_Q13[1], denom_Q16), 16);
-   const i32 deltaw_Q24 = shl32(sk_mulwb(width_Q14 - state->width_prev_Q14, denom_Q16), 10);
-   for (int n = 0; n < 8 * fs_kHz; n++) {
-      pred0_Q13 += delta0_Q13; pred1_Q13 += delta1_Q13; w_Q24 += deltaw_Q24;
-      sum = shl32(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 9);
-      sum = sk_mlawb(sk_mulwb(w_Q24, side[n + 1]), sum, pred0_Q13);
-      sum = sk_mlawb(sum, shl32((i32)mid[n + 1], 11), pred1_Q13);
-      x2[n - 1] = (i16)sk_sat16(sk_rround(sum, 8));
+   wv_sync();
+   {
+      const i32 p0s = hand[2], p1s = hand[3], ws = hand[4], d0 = hand[5], d1 = hand[6], dw = hand[7], p0e = hand[8], p1e = hand[9], we = hand[10];
+      const int ramp = 8 * fs_kHz;
+      FOR_LANES(n, frame_length) {
+         const i32 k = n + 1;
+         const i32 pred0_Q13 = n < ramp ? add32(p0s, (i32)((u32)k * (u32)d0)) : p0e, pred1_Q13 = n < ramp ? add32(p1s, (i32)((u32)k * (u32)d1)) : p1e;
+         const i32 w_Q24 = n < ramp ? add32(ws, (i32)((u32)k * (u32)dw)) : we;
+         i32 sum = shl32(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 9);
+         sum = sk_mlawb(sk_mulwb(w_Q24, side[n + 1]), sum, pred0_Q13);
+         sum = sk_mlawb(sum, shl32((i32)mid[n + 1], 11), pred1_Q13);
+         x2[n - 1] = (i16)sk_sat16(sk_rround(sum, 8));
+      }
    }
-   pred0_Q13 = -pred_Q13[0]; pred1_Q13 = -pred_Q13[1]; w_Q24 = shl32(width_Q14, 10);
-   for (int n = 8 * fs_kHz; n < frame_length; n++) {
-      sum = shl32(add32(mid[n] + (i32)mid[n + 2], shl32(mid[n + 1], 1)), 9);
-      sum = sk_mlawb(sk_mulwb(w_Q24, side[n + 1]), sum, pred0_Q13);
-      sum = sk_mlawb(sum, shl32((i32)mid[n + 1], 11), pred1_Q13);
-      x2[n - 1] = (i16)sk_sat16(sk_rround(sum, 8));
-   }
-   state->pred_prev_Q13[0] = (i16)pred_Q13[0]; state->pred_prev_Q13[1] = (i16)pred_Q13[1]; state->width_prev_Q14 = (i16)width_Q14;
+   wv_sync();
 }
 
 /* ---- stage taps of the emulator build (same word layout as the tapped reference shim of the tests) ---- */
@@ -665,11 +689,16 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
          if (c0->nFramesEncoded > 0) { const i32 bitsBalance = k_ec_tell(EC_PASS) - E->nBitsUsedLBRR - nBits * c0->nFramesEncoded; T -= (bitsBalance * 1000) / 500; }
          T = se_limit(T, ec->bitRate, 5000);
          S->r[4] = T;
+         ec_st(ecl, &ec_);
+      }
+      if (ec->nChannelsInternal == 2) {
+         se_stereo_lr_to_ms_wave(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], S->stk, S->r[4], c0->speech_activity_Q8,
+               ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
+      }
+      LANE0 {
+         EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
          if (ec->nChannelsInternal == 2) {
-            i32 ms[2];
-            se_stereo_lr_to_ms_l0(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], ms, T, c0->speech_activity_Q8,
-                  ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
-            S->r[5] = ms[0]; S->r[6] = ms[1];
+            S->r[5] = S->stk[0]; S->r[6] = S->stk[1];
             if (E->st.mid_only_flags[c0->nFramesEncoded] == 0) {
                if (E->prev_decode_only_middle == 1) {
                   c1->LastGainIndex = 0; c1->HarmShapeGain_smth_Q16 = 0; c1->Tilt_smth_Q16 = 0;
