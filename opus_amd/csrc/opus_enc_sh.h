@@ -412,6 +412,7 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
    WV_LDS FrameShared *fs = &F->sh;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, up = 48000 / Fs;
+   SE_CLK_BEGIN();                                  /* (profiling build: the pass is timed from a register, the SILK hand-off words are about to be overwritten) */
    wv_sync();
    if (wv_lane() == 0) F->g = L->cs;               /* (the arena aliases the SILK working set: whatever SILK did since the last CELT pass may have overwritten the pointer) */
    wv_sync();
@@ -444,12 +445,13 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    wv_sync();
    LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
    wv_sync();
-   if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
+   if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); SE_CLK_END(16); SE_PHASE_START(&L->S); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
    if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
    else celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask);
    wv_sync();
    LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = fs->ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
    wv_sync();
+   SE_CLK_END(16); SE_PHASE_START(&L->S);
 }
 
 /* gain_fade (:581) / stereo_fade (:548) on `n` frames of CC interleaved int16 (LDS staging or HBM scratch); the cross-fade covers overlap = 120 * Fs / 48000 samples, window read with stride inc */
