@@ -20,7 +20,7 @@ template <int NR> WV_DEV unsigned alg_unquant_regs(WV_LDS DecLds *L, WV_LDS i32 
    i32 t_ = vshr32(Ryy, 2 * (k - 7) - 15);
    i32 g = mult32_32_q31(fx_rsqrt_norm32(t_), gain);
    for (int t = 0; t < NR; t++) v[t] = vshr32(mult16_32_q15(q[t], g), k + 15 - NORM_SHIFT);
-   exp_rotation_regs(v, N, -1, B, K, spread);
+   exp_rotation_regs(v, X, N, -1, B, K, spread);                 /* X: the output slot, free as scratch until the store below */
    unsigned cm = 1;
    if (B > 1) {
       int N0 = (u32)N / (u32)B;

@@ -272,8 +272,55 @@ template <int NR> WV_DEV void rot_pass(i32 (&v)[NR], int nblk, int len, int d, i
       for (int t = 0; t < NR; t++) v[t] = (pos[t] >= d && pos[t] <= len - d - 1) ? ou[t] : hv[t];
    }
 }
-/* exp_rotation (vq.c:104) on the register-resident band */
-template <int NR> WV_DEV void exp_rotation_regs(i32 (&v)[NR], int len, int dir, int stride, int K, int spread)
+/* The same pass when it falls apart into several independent chains (one per block and residue mod d: 2 .. 40 of them): one LANE per chain.  The band goes
+ * through its own LDS slot T (dead between the load and the store of alg_quant), laid out as it is in memory, so the lanes of one step touch consecutive words;
+ * each lane runs the reference's two sweeps over its residue class -- the same class in both directions, so nothing is shared between lanes in between.  A pass
+ * of `steps` = len / d rounds costs steps x ~12 vector instructions for the whole band instead of 2 vector + 6 scalar instructions per ELEMENT. */
+template <int NR> WV_DEV void rot_pass_lds(i32 (&v)[NR], WV_LDS i32 *T, int nblk, int len, int d, i32 c_, i32 s_)
+{
+   const i32 c = (i16)c_, s = (i16)s_;
+   const int lane = wv_lane(), N = nblk * len, top = len - 2 * d - 1;
+   wv_sync();
+   for (int t = 0; t < NR; t++) if (lane + 64 * t < N) T[lane + 64 * t] = v[t];
+   wv_sync();
+   for (int ch = lane; ch < nblk * d; ch += WV_WIDTH) {
+      const int blk = (int)((u32)ch / (u32)d), r = ch - blk * d;
+      WV_LDS i32 *X = T + blk * len;
+      if (r < len - d) {                                     /* upwards: (X[i], X[i+d]) <- (c X[i] - s X[i+d], c X[i+d] + s X[i]), i = r, r + d, ... */
+         i32 x1 = X[r];
+         int i = r;
+         for (; i < len - d; i += d) {
+            const i32 x2 = X[i + d];
+            X[i] = (i32)(i16)(add32(sub32(mult16_16(c, x1), s * x2), 16384) >> 15);
+            x1 = (i32)(i16)(add32(add32(mult16_16(c, x2), s * x1), 16384) >> 15);
+         }
+         X[i] = x1;
+      }
+      if (top >= r) {                                        /* downwards from the highest i <= top of the same class */
+         int i = top - (int)((u32)(top - r) % (u32)d);
+         i32 y = X[i + d];
+         for (; i >= 0; i -= d) {
+            const i32 x1 = X[i];
+            X[i + d] = (i32)(i16)(add32(add32(mult16_16(c, y), s * x1), 16384) >> 15);
+            y = (i32)(i16)(add32(sub32(mult16_16(c, x1), s * y), 16384) >> 15);
+         }
+         X[i + d] = y;
+      }
+   }
+   wv_sync();
+   for (int t = 0; t < NR; t++) if (lane + 64 * t < N) v[t] = T[lane + 64 * t];
+   wv_sync();
+}
+#ifndef OA_ROT_LANE_CHAINS
+#define OA_ROT_LANE_CHAINS 4      /* from this many chains on, a pass runs one lane per chain; below, on the scalar unit */
+#endif
+template <int NR> WV_DEV void rot_pass_any(i32 (&v)[NR], WV_LDS i32 *T, int nblk, int len, int d, i32 c_, i32 s_)
+{
+   if (nblk * d >= OA_ROT_LANE_CHAINS) rot_pass_lds(v, T, nblk, len, d, c_, s_); else rot_pass(v, nblk, len, d, c_, s_);
+}
+
+/* exp_rotation (vq.c:104) on the register-resident band; T: the band's LDS slot, free as scratch */
+template <int NR> WV_DEV void exp_rotation_regs(i32 (&v)[NR], WV_LDS i32 *T, int len, int dir, int stride, int K, int spread)
 {
    int stride2 = 0;
    if (2 * K >= len || spread == 0) return;
@@ -289,11 +336,11 @@ template <int NR> WV_DEV void exp_rotation_regs(i32 (&v)[NR], int len, int dir, 
    for (int t = 0; t < NR; t++) v[t] = pshr32(v[t], NORM_SHIFT - 14);       /* norm_scaledown once (up/down between passes cancels exactly) */
    len = (u32)len / (u32)stride;
    if (dir < 0) {
-      if (stride2) rot_pass(v, stride, len, stride2, s, c);
-      rot_pass(v, stride, len, 1, c, s);
+      if (stride2) rot_pass_any(v, T, stride, len, stride2, s, c);
+      rot_pass_any(v, T, stride, len, 1, c, s);
    } else {
-      rot_pass(v, stride, len, 1, c, -s);
-      if (stride2) rot_pass(v, stride, len, stride2, s, -c);
+      rot_pass_any(v, T, stride, len, 1, c, -s);
+      if (stride2) rot_pass_any(v, T, stride, len, stride2, s, -c);
    }
    for (int t = 0; t < NR; t++) v[t] = shl32(v[t], NORM_SHIFT - 14);
 }
@@ -409,7 +456,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
    K_DUMP("pvqX", X, N * 4);
    K_TIC();
    for (int t = 0; t < NR; t++) v[t] = lane + 64 * t < N ? X[lane + 64 * t] : 0;
-   exp_rotation_regs(v, N, 1, B, K, spread);
+   exp_rotation_regs(v, X, N, 1, B, K, spread);
    K_TOC(16);
    i32 yy = op_pvq_search_regs(v, q, K, N);
    K_TOC(17);
@@ -430,7 +477,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
       i32 t_ = vshr32(yy, 2 * (k - 7) - 15);
       i32 g = mult32_32_q31(fx_rsqrt_norm32(t_), gain);
       for (int t = 0; t < NR; t++) v[t] = vshr32(mult16_32_q15(q[t], g), k + 15 - NORM_SHIFT);
-      exp_rotation_regs(v, N, -1, B, K, spread);
+      exp_rotation_regs(v, X, N, -1, B, K, spread);
       wv_sync();
       for (int t = 0; t < NR; t++) if (lane + 64 * t < N) X[lane + 64 * t] = v[t];
       wv_sync();
