@@ -16,6 +16,9 @@ def load(which):
     if which == "ref_fl":
         from reflib import ref_fl
         return ref_fl()
+    if which == "ref_fxa":
+        from reflib import ref_fxa
+        return ref_fxa()
     if which == "emu":
         import hostemu
         return ctypes.CDLL(hostemu.build_emu_lib(), mode=ctypes.RTLD_LOCAL)

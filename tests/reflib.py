@@ -24,6 +24,11 @@ def ref_fl():
     return _load("oracle/_ref/libopus_ref_fl.so")
 
 @functools.lru_cache(None)
+def ref_fxa():
+    """fixed-point arithmetic with the float API: analysis.c + mlp.c active (the oracle of the analysis row; today only the gap is measured, tools/analysis_gap.py)"""
+    return _load("oracle/_ref/libopus_ref_fxa.so")
+
+@functools.lru_cache(None)
 def ref_expose():
     ref_fx()
     return _load("oracle/_ref/libref_expose_fx.so")
