@@ -29,6 +29,12 @@ def ref_fxa():
     return _load("oracle/_ref/libopus_ref_fxa.so")
 
 @functools.lru_cache(None)
+def ref_expose_fxa():
+    """run_analysis of the compiled reference, frame by frame (oracle/ref_expose_fxa/x_analysis.c)"""
+    ref_fxa()
+    return _load("oracle/_ref/libref_expose_fxa.so")
+
+@functools.lru_cache(None)
 def ref_expose():
     ref_fx()
     return _load("oracle/_ref/libref_expose_fx.so")

@@ -1,8 +1,8 @@
 """Where the build this port is bit-exact to (FIXED_POINT + DISABLE_FLOAT_API) and the fixed-point build users get by default (float API on: src/analysis.c + mlp.c
 steer the encoder) agree and where they do not -- both sides are the compiled reference (oracle/_ref/libopus_ref_fx.so vs libopus_ref_fxa.so), tools/analysis_gap.py.
 The forced SILK-only (BASELINE config 3) and forced hybrid (config 4) encoders and an unforced VOIP encoder produce IDENTICAL packets with and without the analysis:
-for those the parity this repo proves against the no-float-API library is parity with the deployed fixed-point library as well.  CELT-coded frames at complexity >= 7
-(config 2, unforced AUDIO) differ: that is the row DESIGN.md section 8 lists next."""
+for those the parity this repo proves against the no-float-API library is parity with the deployed fixed-point library as well.  CELT-coded frames at complexity 10 (the
+FIXED_POINT build runs the analysis at complexity 10 only, src/opus_encoder.c:1249; config 2, unforced AUDIO) differ: that is the row DESIGN.md section 8 lists next."""
 import os, sys, pytest
 from reflib import ref_fx, ROOT
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -13,3 +13,35 @@ def test_which_configurations_the_analysis_changes():
     r = {c[0].split(":")[0].split(",")[0]: G.run(*c, frames=100) for c in G.CASES}
     for k in ("config 3", "config 4", "VOIP 16 kHz mono 20 kb/s"): assert r[k]["identical"] == r[k]["frames"], r[k]
     assert r["config 2"]["identical"] < r["config 2"]["frames"] and r["config 2"]["toc_differs"] == 0, r["config 2"]      # same decisions, different allocation tuning
+
+
+FIELDS = ["valid", "tonality", "tonality_slope", "noisiness", "activity", "music_prob", "music_prob_min", "music_prob_max", "bandwidth", "activity_probability", "max_pitch_ratio"]
+
+def _analyse(sig, Fs, ch, frames):
+    import ctypes, numpy as np
+    from reflib import ref_expose_fxa
+    X = ref_expose_fxa()
+    X.ref_analysis_state_size.restype = ctypes.c_int
+    X.ref_analysis_init.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int]; X.ref_analysis_init.restype = None
+    X.ref_analysis_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p]; X.ref_analysis_frame.restype = None
+    st = ctypes.create_string_buffer(X.ref_analysis_state_size())
+    X.ref_analysis_init(st, Fs, 2049)
+    n = Fs // 50; out = np.zeros((frames, 30), np.float32)
+    for f in range(frames):
+        x = np.ascontiguousarray(sig[f * n:(f + 1) * n], np.int16)
+        X.ref_analysis_frame(st, x.ctypes.data, n, ch, Fs, 16, out[f].ctypes.data)
+    return out
+
+def test_analysis_oracle_runs_frame_by_frame():
+    """the oracle the device analysis will be checked against (oracle/ref_expose_fxa): the compiled reference's run_analysis on the encoder's int16 input, one
+    AnalysisInfo per 20 ms frame.  Pinned here only as far as it can be without a device implementation: deterministic, valid after the first frames, and telling
+    this repo's music corpus from its speech corpus the way the encoder's mode decision needs it to."""
+    import numpy as np, signals
+    from test_kernel_emu_silkdec import speechy
+    m = _analyse(signals.music(60, seed=3), 48000, 2, 60); m2 = _analyse(signals.music(60, seed=3), 48000, 2, 60)
+    s = _analyse(speechy(60, 1, 5, 960)[::3], 16000, 1, 60)
+    assert np.array_equal(m, m2)
+    assert m[10:, 0].all() and s[10:, 0].all()                      # valid
+    assert 12 <= m[-1, 8] <= 20 and 12 <= s[-1, 8] <= 20             # detected bandwidth, in bands
+    assert np.isfinite(m).all() and np.isfinite(s).all()
+    assert m[20:, 5].mean() > s[20:, 5].mean()                      # music_prob: music above speech
