@@ -1,11 +1,13 @@
 /* silk_enc_analysis.h — SILK encoder analysis stages (row a20 of SURVEY §8): noise shaping, LTP and LPC analysis.
  *
- *   se_warped_autocorr_l0        silk_warped_autocorrelation_FIX_c   silk/fixed/warped_autocorrelation_FIX.c:40
+ *   se_warped_autocorr_wave      silk_warped_autocorrelation_FIX_c   silk/fixed/warped_autocorrelation_FIX.c:40 (systolic: lane = ladder stage)
  *   se_schur64 / se_k2a_Q16      silk_schur64 / silk_k2a_Q16         silk/fixed/schur64_FIX.c:36, k2a_Q16_FIX.c:36
  *   se_noise_shape_analysis      silk_noise_shape_analysis_FIX       silk/fixed/noise_shape_analysis_FIX.c:147 (warped_gain :38, limit_warped_coefs :59)
- *   se_burg_modified_l0          silk_burg_modified_c                silk/fixed/burg_modified_FIX.c:46
- *   se_find_ltp_l0               silk_find_LTP_FIX                   silk/fixed/find_LTP_FIX.c:36 (corrMatrix_FIX.c:40,:83)
- *   se_quant_ltp_gains_l0        silk_quant_LTP_gains, silk_VQ_WMat_EC_c   silk/quant_LTP_gains.c:35, silk/VQ_WMat_EC.c:35
+ *   se_burg_modified_wave        silk_burg_modified_c                silk/fixed/burg_modified_FIX.c:46
+ *   se_find_ltp_wave             silk_find_LTP_FIX                   silk/fixed/find_LTP_FIX.c:36 (corrMatrix_FIX.c:40,:83); XX: i32[nb*25], xX: i32[nb*5]
+ *   se_quant_ltp_gains_wave      silk_quant_LTP_gains, silk_VQ_WMat_EC_c   silk/quant_LTP_gains.c:35, silk/VQ_WMat_EC.c:35 (one lane per codebook vector; _l0: the serial form,
+ *                                                                    kept for the one corner the wave form hands back to it)
+ *   se_sum_sqr_shift_wave        silk_sum_sqr_shift                  silk/sum_sqr_shift.c:36
  *   se_ltp_scale_ctrl            silk_LTP_scale_ctrl_FIX             silk/fixed/LTP_scale_ctrl_FIX.c:36
  *   se_ltp_analysis_filter_wave  silk_LTP_analysis_filter_FIX        silk/fixed/LTP_analysis_filter_FIX.c:36
  *   se_residual_energy           silk_residual_energy_FIX            silk/fixed/residual_energy_FIX.c:37
@@ -533,63 +535,6 @@ WV_DEVN void se_burg_modified_wave(WV_LDS i32 *out, WV_LDS i32 *A_Q16, const WV_
          out[0] = sk_mlaww(nrg, sk_mulhi(SE_FIX(1e-5f, 32), C0), -tmp1);
       }
       out[1] = -rshifts;
-   }
-}
-
-/* ---- silk_find_LTP_FIX with silk_corrMatrix_FIX / silk_corrVector_FIX.  XX: i32[nb*25], xX: i32[nb*5] ---- */
-WV_DEV void se_find_ltp_l0(WV_LDS i32 *XX, WV_LDS i32 *xX, const WV_LDS i16 *r_ptr, const WV_LDS i32 *lag, int subfr_length, int nb_subfr)
-{
-   const int order = 5, L = subfr_length;
-   for (int k = 0; k < nb_subfr; k++) {
-      const WV_LDS i16 *lag_ptr = r_ptr - (lag[k] + 5 / 2);
-      i32 xx, nrg; int xx_shifts, XX_shifts, xX_shifts;
-      sd_sum_sqr_shift(&xx, &xx_shifts, r_ptr, L + order);
-      {  /* corrMatrix */
-         const WV_LDS i16 *xm = lag_ptr;
-         sd_sum_sqr_shift(&nrg, &XX_shifts, xm, L + order - 1);
-         const int rs = XX_shifts;
-         i32 energy = nrg;
-         for (int i = 0; i < order - 1; i++) energy -= sk_mulbb(xm[i], xm[i]) >> rs;
-         XX[0] = energy;
-         const WV_LDS i16 *ptr1 = &xm[order - 1];
-         for (int j = 1; j < order; j++) {
-            energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr1[L - j]) >> rs);
-            energy = add32(energy, sk_mulbb(ptr1[-j], ptr1[-j]) >> rs);
-            XX[j * order + j] = energy;
-         }
-         const WV_LDS i16 *ptr2 = &xm[order - 2];
-         for (int lg = 1; lg < order; lg++) {
-            energy = 0;
-            if (rs > 0) for (int i = 0; i < L; i++) energy += sk_mulbb(ptr1[i], ptr2[i]) >> rs;
-            else for (int i = 0; i < L; i++) energy = sk_mlabb(energy, ptr1[i], ptr2[i]);
-            XX[lg * order] = energy; XX[lg] = energy;
-            for (int j = 1; j < order - lg; j++) {
-               if (rs > 0) { energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr2[L - j]) >> rs); energy = add32(energy, sk_mulbb(ptr1[-j], ptr2[-j]) >> rs); }
-               else { energy = sub32(energy, sk_mulbb(ptr1[L - j], ptr2[L - j])); energy = sk_mlabb(energy, ptr1[-j], ptr2[-j]); }
-               XX[(lg + j) * order + j] = energy; XX[j * order + lg + j] = energy;
-            }
-            ptr2--;
-         }
-      }
-      const int extra_shifts = xx_shifts - XX_shifts;
-      if (extra_shifts > 0) { xX_shifts = xx_shifts; for (int i = 0; i < 25; i++) XX[i] >>= extra_shifts; nrg >>= extra_shifts; }
-      else if (extra_shifts < 0) { xX_shifts = XX_shifts; xx >>= -extra_shifts; }
-      else xX_shifts = xx_shifts;
-      {  /* corrVector */
-         const WV_LDS i16 *ptr1 = &lag_ptr[order - 1];
-         for (int lg = 0; lg < order; lg++) {
-            i32 ip = 0;
-            if (xX_shifts > 0) for (int i = 0; i < L; i++) ip = add32(ip, sk_mulbb(ptr1[i], r_ptr[i]) >> xX_shifts);
-            else for (int i = 0; i < L; i++) ip = sk_mlabb(ip, ptr1[i], r_ptr[i]);
-            xX[lg] = ip;
-            ptr1--;
-         }
-      }
-      i32 temp = sk_mlawb(1, nrg, SE_FIX(0.03f, 16));
-      temp = imax(temp, xx);
-      for (int i = 0; i < 25; i++) XX[i] = (i32)(((i64)XX[i] << 17) / temp);
-      for (int i = 0; i < 5; i++) xX[i] = (i32)(((i64)xX[i] << 17) / temp);
-      r_ptr += subfr_length; XX += 25; xX += 5;
    }
 }
 
