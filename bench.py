@@ -129,9 +129,19 @@ def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
                 allc = float(sum(pool.map(_cpu_worker, [(path, cfg, pcm0, all_cores_seconds, c) for c in cpus])))
         except Exception:
             allc = None
+    same = None                                                              # the library the GPU path is bit-exact to: fixed-point arithmetic, no float API (no analysis.c)
+    try:
+        fx = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so")
+        if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, pcm0, min(4.0, seconds), first))), 1)
+        try: os.sched_setaffinity(0, set(cpus))
+        except Exception: pass
+    except Exception:
+        same = None
     return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
             "sample": "stream 0 of the GPU batch (its %d frames copied back, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD" % (pcm0.shape[0], seconds),
-            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None}
+            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None,
+            "same_work_value": same, "same_work_note": "one pinned core of the reference's FIXED_POINT + DISABLE_FLOAT_API build: the arithmetic and the decisions the GPU reproduces bit for bit "
+                                                      "(`value` is the float build with SIMD dispatch and the tonality analysis, the fastest way to run the reference on this host)"}
 
 def copy_bandwidth(dev):
     """device-to-device copy, GB/s of traffic (read + write)"""
