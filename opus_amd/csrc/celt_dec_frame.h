@@ -786,7 +786,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
                sh->r[5] = 1; sh->r[0] = packet_mode; sh->r[1] = packet_bandwidth; sh->r[2] = (toc & 0x4) ? 2 : 1; sh->r[3] = endband;
             } else {
                st->mode = packet_mode; st->bandwidth = packet_bandwidth; st->frame_size = packet_frame_size; st->stream_channels = (toc & 0x4) ? 2 : 1;
-               st->end = endband; st->start = 0;
+               sh->r[3] = endband;                  /* applies from the first frame that carries data: a DTX frame is concealed with the band limit in force (:316, :538 `if (bandwidth)`) */
             }
             sh->count = count; sh->packet_frame_size = packet_frame_size; sh->frame_bytes_off = offset;
          }
@@ -809,9 +809,12 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
          nb += r;
       }
       if (ret >= 0) {
-         LANE0 { st->mode = fec_mode; st->bandwidth = fec_bw; st->frame_size = pfs; st->stream_channels = fec_ch; st->end = fec_end; st->start = 0; }
+         const int flen = wv_uni(sh->size[0]);
+         LANE0 { st->mode = fec_mode; st->bandwidth = fec_bw; st->frame_size = pfs; st->stream_channels = fec_ch; if (flen > 1) { st->end = fec_end; st->start = 0; } }
          wv_sync();
-         const int r = oa_decode_frame_wave(L, gs, data + off, wv_uni(sh->size[0]), pfs, pcm_out + (size_t)nb * CC, CC, 1);
+         /* a first frame without data (DTX) has no LBRR copy either: opus_decode_frame turns it into concealment in the previous mode, final range 0 (:316-322, :676) */
+         const int r = flen <= 1 ? oa_conceal_wave(L, gs, pfs, pcm_out + (size_t)nb * CC, CC)
+                                 : oa_decode_frame_wave(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC, 1);
          if (r < 0) ret = r; else nb = frame_size;
       }
    }
@@ -821,6 +824,8 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
       if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
          r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
       } else {
+         LANE0 { st->end = fec_end; st->start = 0; }                                   /* (fec_end: the packet's band limit, whichever branch stored it) */
+         wv_sync();
          r = oa_decode_frame_wave(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
       }
       if (r < 0) ret = r;

@@ -50,3 +50,23 @@ def test_hybrid_and_switches(Fs):
     _compare(_stream(2049, 2, 960, 8, bitrate=64000, force_mode=1001, bandwidth=1105), Fs, 2, lose=(5,))
     sched = {3: dict(force_mode=1002), 6: dict(force_mode=1000, bandwidth=1103), 9: dict(force_mode=1001, bandwidth=1104)}
     _compare(_stream(2049, 1, 960, 12, schedule=sched, bitrate=40000, force_mode=1001, bandwidth=1105, seed=7), Fs, 1)
+
+def test_toc_only_packets_change_nothing_but_the_frame_size():
+    """A one-byte packet (TOC only: what DTX sends) is concealed in the PREVIOUS mode with the band limit in force -- its own TOC's bandwidth does not apply, because
+    opus_decode_frame runs it with bandwidth = 0 (src/opus_decoder.c:316-366, :538) -- and as the FEC source of the previous loss it has no LBRR data either: the call
+    conceals and reports a final range of 0 (:676).  Both were found by replaying the decode calls of the reference's tests/test_opus_encode.c (fuzz section) against
+    the compiled reference decoder: hybrid SWB -> one-byte hybrid FB packet -> data again."""
+    def toc_only(config, stereo): return bytes([(config << 3) | (4 if stereo else 0)])
+    pk = _stream(2049, 2, 480, 10, bitrate=48000, force_mode=1001, bandwidth=1104, seed=11)          # hybrid SWB, 10 ms, stereo
+    fb = _stream(2049, 2, 480, 4, bitrate=64000, force_mode=1001, bandwidth=1105, seed=12)           # hybrid FB afterwards
+    seq = pk[:6] + [toc_only(14, True)] + fb[:2] + [toc_only(12, True), toc_only(31, True)] + pk[6:]
+    for Fs, ch in ((48000, 2), (16000, 1)): _compare(seq, Fs, ch)
+    sk = _stream(2048, 1, 960, 8, bitrate=20000, force_mode=1000, bandwidth=1103, inband_fec=1, packet_loss=20, seed=13)
+    a = capi.Dec("ref", 48000, 2); b = capi.Dec(WHICH, 48000, 2)
+    for i, p in enumerate(sk[:5]):
+        x = a.decode(p); y = b.decode(p); assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), i
+    for fec_src in (toc_only(9, False), sk[6]):                                                        # frame lost; the next packet (one-byte / real) as FEC source, then itself
+        x = a.decode(fec_src, 960, 1); y = b.decode(fec_src, 960, 1)
+        assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), (len(fec_src), hex(x[2]), hex(y[2]))
+        x = a.decode(fec_src); y = b.decode(fec_src)
+        assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), len(fec_src)
