@@ -743,7 +743,11 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
       } else oa_smooth_fade_wave(gs->trans, pcm, pcm, F2_5, CC, finc);
    }
    wv_sync();
-   LANE0 { st->rangeFinal ^= redundant_rng; st->prev_mode = mode; st->prev_redundancy = redundancy && !celt_to_silk; }
+   LANE0 {
+      if (len <= 1) st->rangeFinal = 0;               /* (a corrupt redundancy length leaves no payload: `len = 0`, src/opus_decoder.c:517, and the frame reports range 0, :676) */
+      else st->rangeFinal ^= redundant_rng;
+      st->prev_mode = mode; st->prev_redundancy = redundancy && !celt_to_silk;
+   }
    wv_sync();
    return audiosize;
 }

@@ -804,6 +804,16 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
    if (len < 0) return OPUS_BAD_ARG;
    if (len == 0) decode_fec = 0;
    const int cap = st->Fs / 25 * 3;                 /* 120 ms */
+   if (len == 0 && frame_size > cap) {              /* a loss longer than the longest packet: the reference conceals all of it, 20 ms or less at a time (src/opus_decoder.c:756-769) */
+      int total = 0;
+      while (total < frame_size) {
+         const int r = opus_decode(st, nullptr, 0, pcm + (size_t)total * st->s.s.channels, frame_size - total < cap ? frame_size - total : cap, 0);
+         if (r < 0) return r;
+         total += r;
+      }
+      st->s.s.last_packet_duration = total;
+      return total;
+   }
    if (frame_size > cap) frame_size = cap;
    std::lock_guard<std::mutex> lock(g_classic_dec_mu);
    const int ci = st->s.s.channels - 1, fi = oa_fs_index(st->Fs);

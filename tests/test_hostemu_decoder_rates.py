@@ -70,3 +70,26 @@ def test_toc_only_packets_change_nothing_but_the_frame_size():
         assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), (len(fec_src), hex(x[2]), hex(y[2]))
         x = a.decode(fec_src); y = b.decode(fec_src)
         assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), len(fec_src)
+
+CORRUPT_HYBRID = bytes.fromhex("6c87fd0b6fe495ccd17a395af820bba695c6bce5cdc3a41ba9247539fccc7bed043755c8bbc01d7efd96c9ce1b5710c04b8b2ea1b423a64b32360322db6b6b74b9d19a3907bf0fc640947fee09a726"
+                               "db869a898723eb640341b8c315149227aa38fa309ceab4b988139f6819bb1614344c49f0567a1b2dbac0c4751a0033")
+
+def test_corrupt_redundancy_length_and_losses_longer_than_a_packet():
+    """Two more finds of the decode-call replay (tools/replay_decode_trace.py) in the fuzz section of the reference's test_opus_encode: a hybrid packet whose (corrupted)
+    redundancy length leaves no payload decodes to a final range of 0 (src/opus_decoder.c:517 `len = 0`, :676), and a loss longer than the longest packet -- here
+    360 ms asked of a 16 kHz decoder in one call -- is concealed in full, 20 ms or less at a time (:756-769)."""
+    for Fs, ch in ((48000, 2), (16000, 1), (8000, 2)):
+        a = capi.Dec("ref", Fs, ch); b = capi.Dec(WHICH, Fs, ch)
+        for p in _stream(2049, 2, 960, 3, bitrate=40000, force_mode=1001, bandwidth=1104, seed=21) + [CORRUPT_HYBRID, CORRUPT_HYBRID]:
+            x = a.decode(p); y = b.decode(p)
+            assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), (Fs, ch, hex(x[2]), hex(y[2]))
+        assert x[2] == 0
+    a = capi.Dec("ref", 16000, 1); b = capi.Dec(WHICH, 16000, 1)
+    pk = _stream(2048, 1, 960, 6, bitrate=20000, force_mode=1000, bandwidth=1103, seed=22)
+    for p in pk[:4]: a.decode(p); b.decode(p)
+    x = a.decode(b"", 5760); y = b.decode(b"", 5760)
+    assert x[0] == y[0] == 5760 and np.array_equal(x[1], y[1])
+    assert a.get(4039) == b.get(4039) == 5760                       # OPUS_GET_LAST_PACKET_DURATION
+    for p in pk[4:]:
+        x = a.decode(p); y = b.decode(p)
+        assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1])
