@@ -814,7 +814,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
       }
       if (ret >= 0) {
          const int flen = wv_uni(sh->size[0]);
-         LANE0 { st->mode = fec_mode; st->bandwidth = fec_bw; st->frame_size = pfs; st->stream_channels = fec_ch; if (flen > 1) { st->end = fec_end; st->start = 0; } }
+         LANE0 { st->mode = fec_mode; st->bandwidth = fec_bw; st->frame_size = pfs; st->stream_channels = fec_ch; if (flen > 1) st->start = 0; }
          wv_sync();
          /* a first frame without data (DTX) has no LBRR copy either: opus_decode_frame turns it into concealment in the previous mode, final range 0 (:316-322, :676) */
          const int r = flen <= 1 ? oa_conceal_wave(L, gs, pfs, pcm_out + (size_t)nb * CC, CC)
@@ -828,7 +828,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
       if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
          r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
       } else {
-         LANE0 { st->end = fec_end; st->start = 0; }                                   /* (fec_end: the packet's band limit, whichever branch stored it) */
+         LANE0 { st->start = 0; }                        /* (the packet's band limit applies inside, after the transition fade sources are concealed with the old one: src/opus_decoder.c:388, :540, :547) */
          wv_sync();
          r = oa_decode_frame_wave(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
       }

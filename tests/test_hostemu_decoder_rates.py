@@ -93,3 +93,11 @@ def test_corrupt_redundancy_length_and_losses_longer_than_a_packet():
     for p in pk[4:]:
         x = a.decode(p); y = b.decode(p)
         assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1])
+
+def test_transition_fade_source_keeps_the_old_band_limit():
+    """hybrid fullband -> 2.5 ms narrowband CELT with no redundancy frame: the concealed fade source of the transition runs BEFORE the new packet's band limit is
+    applied (src/opus_decoder.c:388-393 and :540-544 come before :547), so it still has the old frame's bands 17..20.  Found by the decode-call replay of test_opus_decode."""
+    hyb = _stream(2049, 2, 960, 3, bitrate=64000, force_mode=1001, bandwidth=1105, seed=31)
+    nb = _stream(2051, 1, 120, 3, bitrate=32000, bandwidth=1101, seed=32)
+    swb = _stream(2049, 1, 480, 3, bitrate=40000, force_mode=1001, bandwidth=1104, seed=33)
+    for Fs, ch in ((48000, 2), (48000, 1), (24000, 2)): _compare(hyb + nb + swb + nb + hyb, Fs, ch)
