@@ -157,7 +157,7 @@ class EncoderBatch:
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         assert pcm.size == self.S * frame_size * self.channels
         nf = max(1, -(-frame_size * 50 // self.Fs)) if frame_size > self.Fs // 50 else 1       # calls above 20 ms may come back as multi-frame packets
-        stride = 1280 if nf == 1 else ((min(max_data_bytes, 1276 * nf) + 48 + 15) // 16) * 16
+        stride = max(1280, ((min(max_data_bytes, 1276 * 6) + 15) // 16) * 16) if nf == 1 else ((max_data_bytes + 48 + 15) // 16) * 16   # oa_enc_out_stride_needed
         out = np.zeros((self.S, stride), np.uint8); lens = np.zeros(self.S, np.int32); rng = np.zeros(self.S, np.uint32)
         r = self._L.opusgpu_encode_batch(self._b, pcm.ctypes.data, frame_size, out.ctypes.data, stride, max_data_bytes, lens.ctypes.data, rng.ctypes.data)
         if r != OPUS_OK: raise OpusError(r)

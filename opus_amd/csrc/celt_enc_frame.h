@@ -555,7 +555,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
          staged += tmp_len - 1; tot_size += tmp_len;
       }
       if (err) result = err;
-      else { result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames); if (result < 0) result = -3; }
+      else { result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames, out_cap); if (result < 0) result = -3; }
    }
    /* ---- store lengths + state (coalesced) ---- */
    {

@@ -134,13 +134,14 @@ oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T
 
 #include "opus_enc_host.h"
 /* frame sizes an encode call accepts: 2.5, 5, 10, 20, 40, 60, 80, 100, 120 ms at the API rate (frame_size_select :845; the SILK-only application starts at 10 ms) */
-/* bytes of the per-stream output slot a call needs: the packet itself, and for calls above 20 ms (repacketised multi-frame packets, src/opus_encoder.c:1698-1838)
- * the 48-byte staging head-room of oa_multiframe_* (opus_multiframe.h) */
+/* bytes of the per-stream output slot a call needs: the largest packet the call can return -- a coded frame never exceeds 1276 bytes, but a hard-CBR call is
+ * padded to its byte budget whatever the frame size, up to the 1276*6 the reference clamps max_data_bytes to -- and for calls above 20 ms (repacketised
+ * multi-frame packets, src/opus_encoder.c:1698-1838) the 48-byte staging head-room of oa_multiframe_* (opus_multiframe.h) */
 static opus_int32 oa_enc_out_stride_needed(opus_int32 Fs, int frame_size, opus_int32 max_data_bytes)
 {
    const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;
-   const opus_int32 cap = 1276 * nf, m = max_data_bytes < cap ? max_data_bytes : cap;
-   return nf > 1 ? m + 48 : m;
+   if (nf > 1) return max_data_bytes + 48;                                               /* repacketize_len = the caller's whole buffer with OPUS_BITRATE_MAX (:1757) */
+   return max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6;                         /* one frame: padded to min(max_data_bytes, 1276*6) (:1221, :1330, :2646) */
 }
 static int oa_enc_frame_size_code(opus_int32 Fs, int application, int frame_size)
 {
@@ -486,7 +487,7 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    OpusGpuEncBatch *b = *slot;
    b->application = application;
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   const opus_int32 stride = oa_enc_out_stride_needed(Fs, frame_size, max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6) + 8;
+   const opus_int32 stride = oa_enc_out_stride_needed(Fs, frame_size, max_data_bytes) + 8;
    std::vector<unsigned char> buf((size_t)(stride < 1288 ? 1288 : stride));
    opus_int32 len = 0; opus_uint32 rng = 0;
    void *blob = st->kind ? (void *)&st->sh : (void *)&st->s;

@@ -907,7 +907,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       wv_sync();
       if (err) result = err;
       else {
-         result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames);
+         result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames, out_cap);
          if (result < 0) result = OA_ERR_INTERNAL;
       }
    }

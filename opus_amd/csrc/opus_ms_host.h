@@ -237,6 +237,11 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    HIPCHECK(hipStreamSynchronize(b->stream));
    if (kind) HIPCHECK(hipMemcpy2D(b->d_sh, sizeof(OaShStream), &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), (size_t)n, hipMemcpyHostToDevice));
    else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].s, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
+   /* the batch is shared by every multistream encoder of this shape: what the host side of a launch derives from its mirror of the configuration (the frame sizes
+    * the application accepts, whether the launch can skip the CELT arena) must follow the records just uploaded, not the encoder the batch was created for */
+   b->application = application;
+   if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = states[i].sh.cfg; b->cfg_dirty = true; }
+   else for (int i = 0; i < n; i++) b->h_streams[i].cfg = states[i].s.cfg;
    int r = opusgpu_encode_batch(b, pcm, frame_size, out, stride, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
    if (kind) HIPCHECK(hipMemcpy2D(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), sizeof(OaShStream), (size_t)n, hipMemcpyDeviceToHost));
@@ -301,7 +306,7 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
       opus_int16 *d = pm.data() + (size_t)s * frame_size;
       for (int i = 0; i < frame_size; i++) d[i] = pcm[(size_t)i * nch + c];
    }
-   const opus_int32 stride = (oa_enc_out_stride_needed(Fs, frame_size, 1276 * 6) + 15) & ~15;     /* multi-frame calls stage their frames in the output slot */
+   const opus_int32 stride = (oa_enc_out_stride_needed(Fs, frame_size, OA_MS_FRAME_TMP) + 15) & ~15;     /* a stream is offered at most MS_FRAME_TMP bytes (:1024); multi-frame calls stage their frames in the output slot */
    std::vector<unsigned char> pk((size_t)ns * stride);
    std::vector<opus_int32> lens((size_t)ns);
    std::vector<opus_uint32> rngs((size_t)ns);
@@ -470,12 +475,10 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
    if ((lost || fec) && frame_size % (Fs / 400) != 0) return OPUS_BAD_ARG;
    if (!lost && len < 2 * ns - 1) return OPUS_INVALID_PACKET;
    /* opus_multistream_packet_validate (:149) + re-framing of every stream's self-delimited packet as a plain packet for the batch decoder */
-   const int stride = 1280 * 6 + 16;
-   std::vector<unsigned char> pk((size_t)ns * stride, 0);
-   std::vector<opus_int32> lens((size_t)ns);
+   std::vector<opus_int32> lens((size_t)ns), sub((size_t)ns);
    int samples = 0;
-   if (lost) { for (int s = 0; s < ns; s++) lens[s] = 0; }
-   else {
+   opus_int32 longest = 0;
+   if (!lost) {
       const unsigned char *p = data; opus_int32 left = len;
       for (int s = 0; s < ns; s++) {
          unsigned char toc; opus_int16 size[48]; opus_int32 packet_offset;
@@ -485,6 +488,20 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
          int tmp_samples = opus_packet_get_nb_samples(p, packet_offset, Fs);
          if (s != 0 && samples != tmp_samples) return OPUS_INVALID_PACKET;
          samples = tmp_samples;
+         sub[s] = packet_offset; if (packet_offset > longest) longest = packet_offset;
+         p += packet_offset; left -= packet_offset;
+      }
+   }
+   if (samples < 0) return samples;
+   if (samples > frame_size) return OPUS_BUFFER_TOO_SMALL;                             /* with or without FEC (opus_multistream_decoder.c:216-222) */
+   /* one slot per stream, wide enough for the largest sub-packet (a code-3 packet of many maximum-size frames runs to tens of KB; re-framing never grows one) */
+   const int stride = (int)((longest > 1275 ? longest : 1275) + 16 + 3) & ~3;
+   std::vector<unsigned char> pk((size_t)ns * stride, 0);
+   if (lost) { for (int s = 0; s < ns; s++) lens[s] = 0; }
+   else {
+      const unsigned char *p = data;
+      for (int s = 0; s < ns; s++) {
+         const opus_int32 packet_offset = sub[s];
          OpusRepacketizer rp;
          opus_repacketizer_init(&rp);
          int r = oa_repacketizer_cat_impl(&rp, p, packet_offset, s != ns - 1);
@@ -492,11 +509,9 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
          opus_int32 l = oa_repacketizer_out_range_impl(&rp, 0, rp.nb_frames, pk.data() + (size_t)s * stride, stride, 0, 0);
          if (l < 0) return l;
          lens[s] = l;
-         p += packet_offset; left -= packet_offset;
+         p += packet_offset;
       }
    }
-   if (samples < 0) return samples;
-   if (!fec && samples > frame_size) return OPUS_BUFFER_TOO_SMALL;
    std::lock_guard<std::mutex> lock(g_ms_mu);
    std::vector<opus_int16> oc((size_t)nc * frame_size * 2 + 2), om((size_t)nm * frame_size + 1);
    std::vector<opus_int32> nso((size_t)ns);
@@ -507,6 +522,11 @@ int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_i
    if (r != OPUS_OK) return r;
    int out_n = 0;
    for (int s = 0; s < ns; s++) { if (nso[s] <= 0) return nso[s] == 0 ? OPUS_INTERNAL_ERROR : nso[s]; out_n = nso[s]; }
+   /* OPUS_SET_GAIN reaches every elementary decoder (opus_multistream_decoder.c:427): applied to each stream's output as the classic opus_decode does */
+   for (int s = 0; s < ns; s++) if (st->streams[s].decode_gain) {
+      if (s < nc) oa_apply_decode_gain(oc.data() + (size_t)s * frame_size * 2, nso[s] * 2, st->streams[s].decode_gain);
+      else oa_apply_decode_gain(om.data() + (size_t)(s - nc) * frame_size, nso[s], st->streams[s].decode_gain);
+   }
    for (int s = 0; s < ns; s++) {
       if (s < nc) {
          const opus_int16 *b = oc.data() + (size_t)s * frame_size * 2;

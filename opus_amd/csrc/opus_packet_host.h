@@ -103,47 +103,46 @@ static int oa_frame_map(const unsigned char *pkt, opus_int32 len, bool framed, O
  * (un-padding in place).  Returns the packet size or OPUS_BUFFER_TOO_SMALL. */
 static opus_int32 oa_frames_emit(unsigned char toc, int n, const unsigned char *const *frame, const opus_int16 *size, unsigned char *out, opus_int32 maxlen, bool framed, bool fill)
 {
-   unsigned char hdr[2 + 40 + 2 * OA_MAX_FRAMES];        /* toc, count, <= 31 padding length bytes for a 7.6 KB packet, frame lengths */
-   int h = 0;
    bool same = true;
    opus_int32 body = 0;
    for (int i = 0; i < n; i++) { body += size[i]; same = same && size[i] == size[0]; }
    const int tail = framed ? oa_length_bytes(size[n - 1]) : 0;
    toc &= 0xFC;
-   opus_int32 total;
+   /* pass 1: the shape of the header (nothing is written yet: the padding length run is as long as the caller's maxlen makes it) */
+   opus_int32 h = 0, total = 0, pad = 0, full = 0;
    bool code3 = n > 2;
    if (!code3) {
-      hdr[h++] = (unsigned char)(toc | (n == 1 ? 0 : same ? 1 : 2));
-      if (n == 2 && !same) h += oa_put_length(size[0], hdr + h);
+      h = 1 + (n == 2 && !same ? oa_length_bytes(size[0]) : 0);
       total = h + tail + body;
       if (total > maxlen) return OPUS_BUFFER_TOO_SMALL;
       code3 = fill && total < maxlen;
    }
    if (code3) {
-      h = 0;
-      hdr[h++] = (unsigned char)(toc | 3);
-      hdr[h++] = (unsigned char)(n | (same ? 0 : 0x80));
-      total = 2 + tail + body;
-      if (!same) for (int i = 0; i < n - 1; i++) total += oa_length_bytes(size[i]);
+      h = 2;
+      if (!same) for (int i = 0; i < n - 1; i++) h += oa_length_bytes(size[i]);
+      total = h + tail + body;
       if (total > maxlen) return OPUS_BUFFER_TOO_SMALL;
-      const opus_int32 pad = fill ? maxlen - total : 0;
-      if (pad > 0) {                                                                              /* the length bytes of the padding count as padding */
-         const int full = (int)((pad - 1) / 255);
-         hdr[1] |= 0x40;
-         for (int i = 0; i < full; i++) hdr[h++] = 255;
-         hdr[h++] = (unsigned char)(pad - 255 * full - 1);
-         total = maxlen;
-      }
-      if (!same) for (int i = 0; i < n - 1; i++) h += oa_put_length(size[i], hdr + h);
+      pad = fill ? maxlen - total : 0;
+      if (pad > 0) { full = (pad - 1) / 255; h += full + 1; total = maxlen; }                     /* the length bytes of the padding count as padding */
    }
-   if (framed) h += oa_put_length(size[n - 1], hdr + h);
-   /* frames first when they may overlap the header area?  No: destinations never pass their sources (see above), so ascending order is safe,
-    * but the header must not clobber frame 0 before it moved — it cannot, frame 0 starts at >= h in any packet it came from, except when padding
-    * grows the header; callers that pad in place pass a copy. */
+   h += tail;
+   /* pass 2: frames first (destinations never pass their sources, so ascending order is safe; the header cannot clobber frame 0 before it moved
+    * because frame 0 starts at >= h in any packet it came from -- except when padding grows the header: callers that pad in place pass a copy),
+    * then the header straight into the packet */
    unsigned char *w = out + h;
    for (int i = 0; i < n; i++) { memmove(w, frame[i], (size_t)size[i]); w += size[i]; }
-   memcpy(out, hdr, (size_t)h);
-   if (fill) while (w < out + total) *w++ = 0;
+   unsigned char *q = out;
+   if (!code3) {
+      *q++ = (unsigned char)(toc | (n == 1 ? 0 : same ? 1 : 2));
+      if (n == 2 && !same) q += oa_put_length(size[0], q);
+   } else {
+      *q++ = (unsigned char)(toc | 3);
+      *q++ = (unsigned char)(n | (same ? 0 : 0x80) | (pad > 0 ? 0x40 : 0));
+      if (pad > 0) { memset(q, 255, (size_t)full); q += full; *q++ = (unsigned char)(pad - 255 * full - 1); }
+      if (!same) for (int i = 0; i < n - 1; i++) q += oa_put_length(size[i], q);
+   }
+   if (framed) q += oa_put_length(size[n - 1], q);
+   if (fill && w < out + total) memset(w, 0, (size_t)(out + total - w));
    return total;
 }
 
