@@ -11,6 +11,7 @@
 #include "celt_alloc.h"
 #include "celt_enc_energy.h"
 #include "celt_mdct.h"
+#include "opus_analysis.h"
 #include "celt_enc_front.h"
 #include "celt_enc_pitch.h"
 #include "celt_enc_bands.h"

@@ -178,7 +178,7 @@ WV_DEV int patch_transient_decision_wave(WV_LDS FrameLds *L)
  * operations are adds and compares only, so the scan -- five shuffle steps for 21 bands -- gives the recurrence's result exactly.  The spreading mask, the two
  * energy followers (up 1.5 dB / band, down 2 dB / band below the last upward step), the median floors (neighbours fetched from LDS) and the stereo coupling are
  * done that way; the boost loop's running total with its cap is an inclusive sum scan plus a ballot for the first band that hits the cap. */
-WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L)
+WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L, const OaAnalysisInfo *an)
 {
    WV_LDS FrameShared *sh = &L->sh;
    const int start = sh->start, end = sh->end, C = sh->C, LM = sh->LM, isTransient = sh->isTransient;
@@ -242,6 +242,7 @@ WV_DEVN void dynalloc_analysis_wave(WV_LDS FrameLds *L)
          if (freq_bin >= lo - 3 && freq_bin <= hi + 3) f += GC(.5f);
          if (freq_bin >= ct_eBands[end]) { if (band == end - 1) f += GC(2.f); if (band == end - 2) f += GC(1.f); }
       }
+      if (an->valid && band >= start && band < imin(AN_LEAK_BANDS, end)) f += GC(1.f / 64.f) * (i32)an->leak_boost[band];        /* the analysis' leakage boosts (:1226-1230) */
       if (effectiveBytes > 320 && band == 0) f += imin(GC(1.5f), GC(1e-3f) * (effectiveBytes - 320));
       /* boosts, their cost, and the running total with its cap (CBR / constrained VBR: at most two thirds of the frame) */
       f = imin(f, GC(4)) >> 8;
@@ -509,7 +510,7 @@ WV_DEV int stereo_analysis_wave(WV_LDS FrameLds *L)
 }
 
 /* alloc_trim_analysis (celt_encoder.c:865): band cross-correlations one lane per band, scalar tail on lane 0 */
-WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
+WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L, const OaAnalysisInfo *an)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -550,6 +551,7 @@ WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
       trim = (i16)(trim - imax(-QC16(2.f, 8), imin(QC16(2.f, 8), ((diff + QC32(1.f, DB_SHIFT - 5)) >> (DB_SHIFT - 13)) / 6)));
       trim = (i16)(trim - (sh->surround_trim >> (DB_SHIFT - 8)));
       trim = (i16)(trim - 2 * ((i16)sh->tf_estimate >> (14 - 8)));
+      if (an->valid) trim = (i16)an_trim_tonality_slope(trim, an);                               /* :935-939 */
       int trim_index = pshr32(trim, 8);
       sh->alloc_trim = imax(0, imin(10, trim_index));
    }
@@ -557,7 +559,7 @@ WV_DEVN void alloc_trim_analysis_wave(WV_LDS FrameLds *L)
 }
 
 /* lane 0: compute_vbr (celt_encoder.c:1605) */
-WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target)
+WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target, const OaAnalysisInfo *an)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -569,7 +571,7 @@ WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target)
    int coded_bands = st->lastCodedBands ? st->lastCodedBands : NBE;
    int coded_bins = ct_eBands[coded_bands] << LM;
    if (C == 2) coded_bins += ct_eBands[imin(intensity, coded_bands)] << LM;
-   target = base_target;
+   target = an_vbr_activity(base_target, coded_bins, an);                                            /* :1632: less for a frame the analysis calls inactive */
    if (C == 2) {
       int coded_stereo_bands = imin(intensity, coded_bands);
       int coded_stereo_dof = (ct_eBands[coded_stereo_bands] << LM) - coded_stereo_bands;
@@ -581,6 +583,7 @@ WV_DEV i32 compute_vbr_l0(WV_LDS FrameLds *L, i32 base_target)
    i16 tf_calibration = QC16(0.044f, 14);
    target += (i32)shl32(mult16_32_q15(tf_estimate - tf_calibration, target), 1);
    const int has_surround_mask = sh->energy_mask_on, lfe = sh->lfe;
+   if (an->valid && !lfe) target = an_vbr_tonality(target, coded_bins, sh->pitch_change, an);         /* :1658-1670: tonality boost */
    if (has_surround_mask && !lfe) {
       const i32 surround_target = target + (i32)(mult16_16((i16)(sh->surround_masking >> (DB_SHIFT - 10)), coded_bins << BITRES) >> 10);
       target = imax(target / 4, surround_target);

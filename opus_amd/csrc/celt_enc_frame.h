@@ -82,7 +82,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
          EC_BEGIN;
          int pitch_index = sh->pitch_index; i16 gain1 = (i16)sh->gain1;
          sh->pitch_change = 0;
-         if ((gain1 > QC16(.4f, 15) || (i16)st->prefilter_gain > QC16(.4f, 15)) && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period)) sh->pitch_change = 1;
+         if ((gain1 > QC16(.4f, 15) || (i16)st->prefilter_gain > QC16(.4f, 15)) && an_tonal_enough_for_prefilter(&gst->analysis) && (pitch_index > 1.26 * st->prefilter_period || pitch_index < .79 * st->prefilter_period)) sh->pitch_change = 1;
          if (sh->pf_on == 0) {
             if (!HYB && sh->tell + 16 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, 0, 1);
          } else {
@@ -190,7 +190,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       sh->enable_tf_analysis = sh->effectiveBytes >= 15 * C && !HYB && sh->complexity >= 2 && !sh->lfe && sh->toneishness < QC32(.98f, 29);
    }
    wv_sync();
-   dynalloc_analysis_wave(L);
+   dynalloc_analysis_wave(L, &gst->analysis);
    K_DUMPI("maxDepth", sh->maxDepth); K_DUMPI("tot_boost", sh->tot_boost); K_DUMP("offsets", L->offsets, 84); K_DUMP("importance", L->importance, 84); K_DUMP("spread_weight", L->spread_weight, 84);
    K_PHASE(8);
    if (sh->enable_tf_analysis) tf_analysis_wave(L, imax(80, 20480 / sh->effectiveBytes + 2));
@@ -284,7 +284,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    }
    if (sh->r[4]) {
       if (HYB || sh->lfe) { LANE0 { st->stereo_saving = 0; sh->alloc_trim = 5; } }             /* start > 0 || lfe (celt_encoder.c:2412) */
-      else alloc_trim_analysis_wave(L);
+      else alloc_trim_analysis_wave(L, &gst->analysis);
       LANE0 { EC_BEGIN; k_ec_enc_icdf(EC_PASS, sh->alloc_trim, k_trim_icdf, 7); EC_END; }
       wv_sync();
    }
@@ -305,7 +305,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
          nbCompressedBytes = imin(nbCompressedBytes, 1275 >> (3 - LM));
          base_target = HYB ? imax(0, vbr_rate - ((9 * C + 4) << BITRES)) : vbr_rate - ((40 * C + 20) << BITRES);
          if (sh->constrained_vbr) base_target += (st->vbr_offset >> lm_diff);
-         if (!HYB) target = compute_vbr_l0(L, base_target);
+         if (!HYB) target = compute_vbr_l0(L, base_target, &gst->analysis);
          else {                                                                                       /* :2463-2475 */
             target = base_target;
             if (sh->silk_offset < 100) target += 12 << BITRES >> (3 - LM);
@@ -344,6 +344,11 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
       bits -= anti_collapse_rsv;
       sh->anti_collapse_rsv = anti_collapse_rsv;
       int signalBandwidth = end - 1;
+      if (gst->analysis.valid) {                                                                       /* :2610-2624: no bits above what the analysis detected (and the rate deserves) */
+         const i32 er = sh->equiv_rate;
+         const int min_bandwidth = er < (i32)32000 * C ? 13 : er < (i32)48000 * C ? 16 : er < (i32)60000 * C ? 18 : er < (i32)80000 * C ? 19 : 20;
+         signalBandwidth = imax(gst->analysis.bandwidth, min_bandwidth);
+      }
       if (sh->lfe) signalBandwidth = 1;
 #ifdef K_DUMP_ENABLED
       {  /* tap_alloc */
@@ -459,8 +464,13 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
       if (wv_uni(sh->use_dtx)) {
          const i32 m = oa_maxabs_wave(pcm, frame_size * CC);
          if (m == 0) activity = 0;
+         else if (wv_uni(gs->an_info.valid)) {                                                      /* the analysis' activity probability; a loud enough noise frame counts as active (:1916-1924) */
+            activity = an_activity_prob_active(&gs->an_info);
+            if (!activity) activity = an_loud_noise_active(wv_uni(sh->peak_signal_energy), oa_frame_energy_wave(pcm, frame_size * CC, m));
+         }
          else { const i32 noise_energy = oa_frame_energy_wave(pcm, frame_size * CC, m); activity = (i64)wv_uni(sh->peak_signal_energy) < 316 * (i64)half32(noise_energy); }
       }
+      if (wv_lane() < (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)&gs->st.analysis)[wv_lane()] = ((const i32 *)&gs->an_info)[wv_lane()];   /* CELT_SET_ANALYSIS (:2418) */
       LANE0 { sh->activity = activity; opus_layer_frame(L, &gs->cfg, frame_size, orig_max_data_bytes); }
    }
    wv_sync();
@@ -503,7 +513,7 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
 }
 
 WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -520,11 +530,30 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       sh->Fs = gs->Fs ? gs->Fs : 48000; sh->use_dtx = gs->use_dtx; sh->nb_no_activity_ms_Q1 = gs->nb_no_activity_ms_Q1; sh->peak_signal_energy = gs->peak_signal_energy;
       sh->prev_framesize = gs->prev_framesize; sh->lfe = gs->cfg.lfe; sh->energy_mask_on = gs->energy_mask_on;
    }
-   if (wv_uni(sh->use_dtx)) {                                                            /* peak signal energy tracker (:1310-1320); only the DTX decision reads it */
-      const i32 m = oa_maxabs_wave(pcm, frame_size * CC);
-      if (m != 0) { const i32 en = oa_frame_energy_wave(pcm, frame_size * CC, m); LANE0 sh->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), sh->peak_signal_energy), en); }
+   const i32 sample_max = oa_maxabs_wave(pcm, frame_size * CC);
+   const int Fs = wv_uni(gs->Fs) ? wv_uni(gs->Fs) : 48000, float_api = !wv_uni(gs->analysis_off);
+   LANE0 {
+      sh->is_silence = sample_max == 0;                                                  /* is_digital_silence (:1246) */
+      if (gs->voice_ratio_seq != st->voice_ratio_seq) { st->voice_ratio = gs->voice_ratio; st->voice_ratio_seq = gs->voice_ratio_seq; }   /* OPUS_SET_VOICE_RATIO through a batch ctl */
    }
-   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes);
+   /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only); a call the reference turns away before
+    * that (:1231) leaves it alone */
+   if (!(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
+      if (float_api && wv_uni(gs->cfg.complexity) >= 10 && Fs >= 16000) {
+         LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
+         an_run_analysis_wave((WV_LDS AnLds *)&L->BC, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(gs->cfg.input_depth) ? wv_uni(gs->cfg.input_depth) : 16, wv_uni(gs->cfg.lsb_depth)),
+               (i32 *)L->g->X, &gs->an_info);
+      } else {
+         if (wv_uni(gs->an.initialized)) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }       /* tonality_analysis_reset (:1262) */
+         LANE0 { gs->an_info.valid = 0; gs->an_read_pos_bak = -1; }
+      }
+   }
+   wv_sync();
+   if (wv_uni(sh->use_dtx) && sample_max != 0 && (!wv_uni(gs->an_info.valid) || an_activity_prob_above(&gs->an_info))) {   /* peak signal energy tracker (:1310-1320); only the DTX decision reads it */
+      const i32 en = oa_frame_energy_wave(pcm, frame_size * CC, sample_max);
+      LANE0 sh->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), sh->peak_signal_energy), en);
+   }
+   LANE0 opus_layer_decide(L, &gs->cfg, frame_size, max_data_bytes, gs->signal_type, float_api, &gs->an_info);
    wv_sync();
    int result;
    if (sh->plc_frame) {
@@ -541,9 +570,12 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       int tot_size = 0, dtx_count = 0, err = 0, staged = 0;
       LANE0 L->mf.n = nb_frames;
       if (OA_MF_HEADROOM + imin(max_len_sum, 1276 * nb_frames) > out_cap) err = -2;
+      const int an_bak = wv_uni(gs->an_read_pos_bak);
+      if (an_bak != -1) { LANE0 { gs->an.read_pos = an_bak; gs->an.read_subframe = gs->an_read_subframe_bak; } }   /* the analysis is read one coded frame at a time (:1727-1735) */
       for (int i = 0; i < nb_frames && !err; i++) {
          int curr_max = imin(bitrate_to_bits(wv_uni(sh->call_bitrate), Fs, efs) / 8, max_len_sum / nb_frames);
          curr_max = imin(max_len_sum - tot_size, curr_max);
+         if (an_bak != -1) an_get_info_wave((WV_LDS AnLds *)&L->BC, &gs->an, &gs->an_info, efs, Fs);                 /* (:1796-1800) */
          const int tmp_len = oa_celt_frame_native(L, gs, pcm + (size_t)i * CC * efs, efs, curr_max, out + OA_MF_HEADROOM + staged);
          if (tmp_len < 0) { err = -3; break; }
          if (tmp_len == 1) dtx_count++;

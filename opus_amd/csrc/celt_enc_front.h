@@ -49,11 +49,11 @@ WV_DEV u8 gen_toc_celt(int framerate, int bandwidth, int channels)
 
 /* lane 0: the call-level decisions of opus_encode_native (src/opus_encoder.c:1325-1755) that are left when the application pins CELT-only
  * (RESTRICTED_LOWDELAY / RESTRICTED_CELT): rate, 'PLC' frames, channels, bandwidth, the split of calls above 20 ms into 20 ms frames. */
-WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int frame_size, int out_data_bytes)
+WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int frame_size, int out_data_bytes, int signal_type, int float_api, const OaAnalysisInfo *info)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
-   const int Fs = sh->Fs, voice_est = 48;
+   const int Fs = sh->Fs;
    int channels = cfg->channels;
    i32 max_data_bytes = imin(1276 * 6, out_data_bytes);
    st->rangeFinal = 0;
@@ -61,6 +61,14 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    sh->CC = channels; sh->upsample = 48000 / Fs; sh->raw_frame = 0;
    sh->lsb_depth = imin(cfg->input_depth ? cfg->input_depth : 16, cfg->lsb_depth);
    if (max_data_bytes == 1 && Fs == frame_size * 10) { sh->plc_frame = 2; sh->ret = -2; return; }           /* cannot code 100 ms in one byte: OPUS_BUFFER_TOO_SMALL (:1231) */
+   /* voice_ratio and the detected bandwidth from the analysis of the call (:1273-1308); without the float API voice_ratio is always -1 */
+   if (!sh->is_silence || !float_api) st->voice_ratio = -1;
+   int detected_bandwidth = 0;
+   if (info->valid) {
+      if (signal_type == OA_AUTO) st->voice_ratio = an_voice_ratio(info, st->prev_mode);
+      detected_bandwidth = an_detected_bandwidth(info->bandwidth);
+   }
+   const int voice_est = signal_type == 3001 /* OPUS_SIGNAL_VOICE */ ? 127 : signal_type == 3002 /* OPUS_SIGNAL_MUSIC */ ? 0 : st->voice_ratio >= 0 ? st->voice_ratio * 327 >> 8 : 48;   /* :1413-1425 */
    i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
    i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
    int frame_rate = Fs / frame_size;
@@ -124,6 +132,11 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
    if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
    if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
    if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
+   if (detected_bandwidth && cfg->user_bandwidth == OA_AUTO) {                                        /* use the detected bandwidth to reduce the encoded bandwidth (:1651-1674) */
+      const i32 sc = st->stream_channels;
+      const int min_detected_bandwidth = equiv_rate <= 18000 * sc ? OA_BW_NB : equiv_rate <= 24000 * sc ? OA_BW_MB : equiv_rate <= 30000 * sc ? OA_BW_WB : equiv_rate <= 44000 * sc ? OA_BW_SWB : OA_BW_FB;
+      st->bandwidth = imin(st->bandwidth, imax(detected_bandwidth, min_detected_bandwidth));
+   }
    if (st->bandwidth == OA_BW_MB) st->bandwidth = OA_BW_WB;
    if (cfg->lfe) st->bandwidth = OA_BW_NB;
    sh->curr_bandwidth = st->bandwidth;

@@ -448,6 +448,7 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       if (sh->loss_rate > 4) gain1 = (i16)(gain1 >> 1);
       if (sh->loss_rate > 8) gain1 = 0;
    } else { gain1 = 0; pitch_index = OA_MIN_PERIOD; }
+   if (gst->analysis.valid) gain1 = (i16)an_scale_pitch_gain(gain1, &gst->analysis);               /* :1494: less pre-filtering the more energy lies above the pitch range */
    const i16 old_gain = (i16)st->prefilter_gain;
    pf_threshold = QC16(.2f, 15);
    if (iabs(pitch_index - st->prefilter_period) * 10 > pitch_index) {

@@ -8,6 +8,7 @@
 #ifndef OPUS_AMD_CELT_FRAME_H
 #define OPUS_AMD_CELT_FRAME_H
 #include <stdint.h>
+#include "analysis_state.h"
 
 #define OA_NB_EBANDS 21
 #define OA_OVERLAP 120
@@ -41,7 +42,9 @@ struct OaEncScalars {
    int32_t prefilter_period, prefilter_gain, prefilter_tapset, consec_transient;
    int32_t preemph_memE[2];
    int32_t vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max, stereo_saving, intensity, spec_avg;
-   int32_t pad0[4];
+   int32_t pad0[2];             /* (the SILK-capable kernel parks CELT's disable_pf / force_intra here between its CELT passes) */
+   int32_t voice_ratio;         /* OpusEncoder.voice_ratio (src/opus_encoder.c:91): -1, the value of OPUS_SET_VOICE_RATIO, or what the analysis said (:1291); CELT-only kernel */
+   int32_t voice_ratio_seq;     /* last OaStream.voice_ratio_seq seen: a batch ctl hands its value over through the configuration */
 };
 /* ... and arrays */
 struct OaEncState {
@@ -49,18 +52,30 @@ struct OaEncState {
    int32_t oldBandE[2 * OA_NB_EBANDS], oldLogE[2 * OA_NB_EBANDS], oldLogE2[2 * OA_NB_EBANDS], energyError[2 * OA_NB_EBANDS];
    int32_t in_mem[2 * OA_OVERLAP];
    int32_t prefilter_mem[2 * OA_MAX_PERIOD];
+   OaAnalysisInfo analysis;     /* CELT_SET_ANALYSIS (celt_encoder.c:109,:3114): the analysis of the frame being coded; inside CELT's reset region */
 };
 
 struct OaStream {
    OaEncConfig cfg;
    OaEncState st;
    /* tail (added after the arrays so that the offsets above stay put) */
+   /* configuration, second part (host-owned like cfg: a batch ctl pushes OA_STREAM_CFG2_WORDS words from Fs on) */
    int32_t Fs;                  /* API rate: 48000 (0 = 48000), 24000, 16000, 12000, 8000 (CELT zero-stuffs up to 48 kHz, celt_encoder.c:255,:557) */
-   int32_t use_dtx, nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize, energy_mask_on;
-   int32_t signal_type, use_inband_fec, user_forced_mode, voice_ratio;   /* accepted and read back like the reference does; they do not change CELT-only coding */
-   int32_t tail_pad[5];
+   int32_t use_dtx, energy_mask_on;
+   int32_t signal_type;         /* OPUS_SET_SIGNAL: voice_est of the channel / bandwidth decisions (src/opus_encoder.c:1413) */
+   int32_t use_inband_fec, user_forced_mode;   /* accepted and read back like the reference does; they do not change CELT-only coding */
+   int32_t voice_ratio, voice_ratio_seq;       /* OPUS_SET_VOICE_RATIO: value and a count of the sets (the kernel adopts the value when the count moves) */
+   int32_t analysis_off;        /* private: 1 = behave like a reference built with DISABLE_FLOAT_API (no tonality analysis at complexity 10) */
+   int32_t cfg2_pad[3];
+   /* state */
+   int32_t nb_no_activity_ms_Q1, peak_signal_energy, prev_framesize;
+   int32_t an_read_pos_bak, an_read_subframe_bak;   /* the analysis' read position at the start of the call (multi-frame calls rewind to it, src/opus_encoder.c:1255,:1732), -1 = the analysis did not run */
+   int32_t tail_pad[3];
    int32_t energy_mask[2 * OA_NB_EBANDS];   /* surround masking of this stream (OPUS_SET_ENERGY_MASK; copied in by the multistream layer each frame) */
+   OaAnalysisInfo an_info;      /* the AnalysisInfo of the call (opus_encode_native's local, src/opus_encoder.c:1206) */
+   OaAnalysis an;               /* TonalityAnalysisState (src/opus_encoder.c:105) */
 };
+#define OA_STREAM_CFG2_WORDS 12
 
 
 /* ---- decoder: per-stream persistent state (reference OpusDecoder src/opus_decoder.c:65-94, CELT-only subset, and

@@ -42,7 +42,7 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #define OA_ENC_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
-oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)
+oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
@@ -53,7 +53,8 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, int frame_size, int max_data
       __syncthreads();
       OaStream *gs = streams + s;
       const int ch = gs->cfg.channels;
-      oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s);
+      oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
+            apcm ? apcm + (size_t)s * frame_size * ch : nullptr);
       __syncthreads();
    }
 }
@@ -72,7 +73,7 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
  * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave */
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue)
+oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -84,7 +85,8 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, int frame_size, int max
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
       oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
-            (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s);
+            (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
+            apcm ? apcm + (size_t)s * frame_size * ch : nullptr);
       __syncthreads();
    }
 }
@@ -168,6 +170,7 @@ struct OpusGpuEncBatch {
    int all_silk_pinned;
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
+   opus_int32 *d_apcm; size_t apcm_cap;  /* signal-domain copy of the input for the analysis (24-bit / float entry points) */
    unsigned char *d_out; size_t out_cap;
    opus_int32 *d_lens; opus_uint32 *d_rng;
 };
@@ -203,7 +206,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_pcm = nullptr; b->pcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
+      b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 (kind ? hipMalloc((void **)&b->d_sh, sizeof(OaShStream) * (size_t)nstreams) == hipSuccess &&
@@ -233,6 +236,7 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_scratch) (void)hipFree(b->d_scratch);
    if (b->d_queue) (void)hipFree(b->d_queue);
    if (b->d_pcm) (void)hipFree(b->d_pcm);
+   if (b->d_apcm) (void)hipFree(b->d_apcm);
    if (b->d_out) (void)hipFree(b->d_out);
    if (b->d_lens) (void)hipFree(b->d_lens);
    if (b->d_rng) (void)hipFree(b->d_rng);
@@ -259,7 +263,10 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    }
    /* one transfer for the whole range: full records on RESET, otherwise only the cfg prefix of every record (strided copy) */
    if (request == OPUS_RESET_STATE) HIPCHECK(hipMemcpy(b->d_streams + lo, &b->h_streams[lo], sizeof(OaStream) * (size_t)(hi - lo), hipMemcpyHostToDevice));
-   else HIPCHECK(hipMemcpy2D(&b->d_streams[lo].cfg, sizeof(OaStream), &b->h_streams[lo].cfg, sizeof(OaStream), sizeof(OaEncConfig), (size_t)(hi - lo), hipMemcpyHostToDevice));
+   else {
+      HIPCHECK(hipMemcpy2D(&b->d_streams[lo].cfg, sizeof(OaStream), &b->h_streams[lo].cfg, sizeof(OaStream), sizeof(OaEncConfig), (size_t)(hi - lo), hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy2D(&b->d_streams[lo].Fs, sizeof(OaStream), &b->h_streams[lo].Fs, sizeof(OaStream), sizeof(opus_int32) * OA_STREAM_CFG2_WORDS, (size_t)(hi - lo), hipMemcpyHostToDevice));   /* DTX, signal type, ... live behind the state */
+   }
    return OPUS_OK;
 }
 int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, opus_int32 *value)
@@ -332,7 +339,9 @@ static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds
    *grid_out = (int)grid;
    return OPUS_OK;
 }
-int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+/* d_apcm (may be NULL): the same samples in the encoder's signal domain (int32, Q12 below int16 full scale: src/opus_encoder.c FLOAT2SIG / INT24TOSIG), which the
+ * 24-bit and float entry points hand to the analysis instead of the rounded int16 samples (downmix_int24 :804, downmix_float :748) */
+int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
@@ -357,7 +366,7 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds, s,
-            b->d_sh, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, b->d_queue);
+            b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, b->d_queue);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }
@@ -365,9 +374,14 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, (CeltScratch *)b->d_scratch, b->d_queue);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, (CeltScratch *)b->d_scratch, b->d_queue);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
+}
+int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
+{
+   return opusgpu_encode_batch_dev_sig(b, d_pcm, nullptr, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, hip_stream);
 }
 int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed, opus_int32 n, void *hip_stream)
 {
@@ -422,7 +436,14 @@ int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fra
    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
    return OPUS_OK;
 }
+int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
 int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
+{
+   return opusgpu_encode_batch_sig(b, pcm, nullptr, frame_size, out, out_stride, max_data_bytes, lens, final_range);
+}
+int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, unsigned char *out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
 {
    if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
@@ -432,7 +453,11 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
    if (nout > b->out_cap) { if (b->d_out) (void)hipFree(b->d_out); HIPCHECK(hipMalloc((void **)&b->d_out, nout)); b->out_cap = nout; }
    HIPCHECK(hipMemcpyAsync(b->d_pcm, pcm, npcm, hipMemcpyHostToDevice, b->stream));
-   int r = opusgpu_encode_batch_dev(b, b->d_pcm, frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
+   if (apcm) {
+      if (2 * npcm > b->apcm_cap) { if (b->d_apcm) (void)hipFree(b->d_apcm); b->d_apcm = nullptr; b->apcm_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_apcm, 2 * npcm)); b->apcm_cap = 2 * npcm; }
+      HIPCHECK(hipMemcpyAsync(b->d_apcm, apcm, 2 * npcm, hipMemcpyHostToDevice, b->stream));
+   }
+   int r = opusgpu_encode_batch_dev_sig(b, b->d_pcm, apcm ? b->d_apcm : nullptr, frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
    if (r != OPUS_OK) return r;
    HIPCHECK(hipMemcpyAsync(out, b->d_out, nout, hipMemcpyDeviceToHost, b->stream));
    HIPCHECK(hipMemcpyAsync(lens, b->d_lens, sizeof(opus_int32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
@@ -470,7 +495,7 @@ OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, i
 void opus_encoder_destroy(OpusEncoder *st) { free(st); }
 /* one frame of one classic encoder: the record goes to the device, the kernel runs a batch of one, the record comes back.  depth = the sample depth
  * of the entry point (opus_encode 16, opus_encode24 / _float 24: the lsb_depth argument of opus_encode_native, src/opus_encoder.c:2667,:2722) */
-static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth)
+static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth, const opus_int32 *apcm = nullptr)
 {
    if (!st || st->magic != OA_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
    const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels, application = st->kind ? st->sh.cfg.application : st->s.cfg.application;
@@ -492,7 +517,7 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    opus_int32 len = 0; opus_uint32 rng = 0;
    void *blob = st->kind ? (void *)&st->sh : (void *)&st->s;
    int r = opusgpu_enc_batch_import_state(b, 0, blob);
-   if (r == OPUS_OK) r = opusgpu_encode_batch(b, pcm, frame_size, buf.data(), (opus_int32)buf.size(), max_data_bytes, &len, &rng);
+   if (r == OPUS_OK) r = opusgpu_encode_batch_sig(b, pcm, apcm, frame_size, buf.data(), (opus_int32)buf.size(), max_data_bytes, &len, &rng);
    if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, blob);
    if (r != OPUS_OK) return r;
    if (len > 0) memcpy(data, buf.data(), (size_t)(len < max_data_bytes ? len : max_data_bytes));
@@ -512,21 +537,30 @@ static inline opus_int16 oa_float2int16(float x)
    x = x < 32767.f ? x : 32767.f;
    return (opus_int16)lrintf(x);
 }
+static inline opus_int32 oa_float2sig(float x)
+{
+   x = x * ((opus_int32)32768 << 12);
+   x = x > -(65536 << 12) ? x : -(65536 << 12);
+   x = x < (65536 << 12) ? x : (65536 << 12);
+   return (opus_int32)lrintf(x);
+}
 opus_int32 opus_encode24(OpusEncoder *st, const opus_int32 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 {
    if (!st || st->magic != OA_MAGIC || !pcm || frame_size <= 0 || frame_size > 5760 * 2) return OPUS_BAD_ARG;
    const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels;
    std::vector<opus_int16> in((size_t)frame_size * channels);
-   for (size_t i = 0; i < in.size(); i++) in[i] = oa_sat16((pcm[i] + 128) >> 8);
-   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24);
+   std::vector<opus_int32> sig((size_t)frame_size * channels);                                 /* what the analysis sees: INT24TOSIG (downmix_int24, src/opus_encoder.c:804) */
+   for (size_t i = 0; i < in.size(); i++) { in[i] = oa_sat16((pcm[i] + 128) >> 8); sig[i] = (opus_int32)((opus_uint32)pcm[i] << 4); }
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
 }
 opus_int32 opus_encode_float(OpusEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 {
    if (!st || st->magic != OA_MAGIC || !pcm || frame_size <= 0 || frame_size > 5760 * 2) return OPUS_BAD_ARG;
    const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels;
    std::vector<opus_int16> in((size_t)frame_size * channels);
-   for (size_t i = 0; i < in.size(); i++) in[i] = oa_float2int16(pcm[i]);
-   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24);
+   std::vector<opus_int32> sig((size_t)frame_size * channels);                                 /* what the analysis sees: FLOAT2SIG (downmix_float :748, celt/float_cast.h:166) */
+   for (size_t i = 0; i < in.size(); i++) { in[i] = oa_float2int16(pcm[i]); sig[i] = oa_float2sig(pcm[i]); }
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
 }
 int opus_encoder_ctl(OpusEncoder *st, int request, ...)
 {

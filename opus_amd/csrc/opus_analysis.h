@@ -17,6 +17,8 @@
 #ifndef OPUS_AMD_OPUS_ANALYSIS_H
 #define OPUS_AMD_OPUS_ANALYSIS_H
 #include "analysis_tables.h"
+#include "analysis_state.h"
+#include <math.h>
 #ifdef __clang__
 #pragma clang fp contract(off)
 #endif
@@ -25,47 +27,11 @@
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
 #endif
 
-#define AN_NB_FRAMES 8
-#define AN_NB_TBANDS 18
-#define AN_BUF_SIZE 720               /* 30 ms at 24 kHz */
-#define AN_DETECT_SIZE 100
-#define AN_LEAK_BANDS 19
-#define AN_COUNT_MAX 10000
-#define AN_NB_TONAL_SKIP_BANDS 9
 /* celt/arch.h:100-105 (macros: the comparison decides, also for -0 and NaN) and the FIXED_POINT ABS16 (:227) */
 #define AN_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define AN_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define AN_ABS(x) ((x) < 0 ? (-(x)) : (x))
 
-/* AnalysisInfo (celt/celt.h:65-79) */
-struct OaAnalysisInfo {
-   i32 valid;
-   float tonality, tonality_slope, noisiness, activity, music_prob, music_prob_min, music_prob_max;
-   i32 bandwidth;
-   float activity_probability, max_pitch_ratio;
-   u8 leak_boost[AN_LEAK_BANDS];
-   u8 pad;
-};
-/* TonalityAnalysisState (src/analysis.h:49-85) from `angle` on: all zero = reset (tonality_analysis_reset :225) */
-struct OaAnalysis {
-   float angle[240], d_angle[240], d2_angle[240];
-   i32 inmem[AN_BUF_SIZE];
-   i32 mem_fill;
-   float prev_band_tonality[AN_NB_TBANDS];
-   float prev_tonality;
-   i32 prev_bandwidth;
-   float E[AN_NB_FRAMES][AN_NB_TBANDS], logE[AN_NB_FRAMES][AN_NB_TBANDS];
-   float lowE[AN_NB_TBANDS], highE[AN_NB_TBANDS], meanE[AN_NB_TBANDS + 1];
-   float mem[32], cmean[8], std[9];
-   float Etracker, lowECount;
-   i32 E_count, count, analysis_offset, write_pos, read_pos, read_subframe;
-   float hp_ener_accum;
-   i32 initialized;
-   float rnn_state[32];
-   i32 downmix_state[3];
-   i32 pad;
-   OaAnalysisInfo info[AN_DETECT_SIZE];
-};
 #define AN_SCRATCH_WORDS 480          /* per-wave HBM words the analysis borrows (the second half of a frame's decimated input, until the window has read the old one) */
 
 struct AnLds {
@@ -107,7 +73,7 @@ WV_DEV float an_tansig(float x)
    return AN_MAX(-1.f, AN_MIN(1.f, num));
 }
 WV_DEV float an_sigmoid(float x) { return .5f + .5f * an_tansig(.5f * x); }
-WV_DEV int an_float2int(float x) { return (int)__builtin_rintf(x); }                  /* lrintf: to nearest, ties to even */
+WV_DEV int an_float2int(float x) { return (int)rintf(x); }                  /* lrintf: to nearest, ties to even */
 
 /* downmix_and_resample (src/analysis.c:157) with the encoder's own arguments (c1 = 0, c2 = -2: all C <= 2 channels): `subframe` samples at 24 kHz, starting
  * `offset` samples (at 24 kHz) into the call's input, into y[] (HBM); input = the int16 samples of opus_encode (downmix_int, src/opus_encoder.c:780) or -- apcm --
@@ -298,10 +264,10 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       if (!count) { lowE = 1e10; highE = -1e10; }
       A->E[E_count][b] = E;
       W->t.t_noisy[b] = nE / (1e-15f + E);
-      W->t.t_loud[b] = (float)__builtin_sqrt(E + 1e-10f);
-      const float logE = (float)__builtin_log(E + 1e-10f);
+      W->t.t_loud[b] = (float)sqrt((double)(E + 1e-10f));
+      const float logE = (float)log((double)(E + 1e-10f));
       W->t.logE[b] = logE;
-      W->t.band_log2[b + 1] = .5f * 1.442695f * (float)__builtin_log(E + 1e-10f);
+      W->t.band_log2[b + 1] = .5f * 1.442695f * (float)log((double)(E + 1e-10f));
       A->logE[E_count][b] = logE;
       if (count == 0) highE = lowE = logE;
       if (highE > lowE + 7.5) { if (highE - logE > logE - lowE) highE -= .01f; else lowE += .01f; }
@@ -310,8 +276,8 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       A->lowE[b] = lowE; A->highE[b] = highE;
       W->t.t_relE[b] = (logE - lowE) / (1e-5f + (highE - lowE));
       float L1 = 0, L2 = 0;
-      for (int i = 0; i < AN_NB_FRAMES; i++) { const float Ei = i == E_count ? E : A->E[i][b]; L1 += (float)__builtin_sqrt(Ei); L2 += Ei; }
-      float stationarity = AN_MIN(0.99f, L1 / (float)__builtin_sqrt(1e-15 + AN_NB_FRAMES * L2));
+      for (int i = 0; i < AN_NB_FRAMES; i++) { const float Ei = i == E_count ? E : A->E[i][b]; L1 += (float)sqrt((double)(Ei)); L2 += Ei; }
+      float stationarity = AN_MIN(0.99f, L1 / (float)sqrt((double)(1e-15 + AN_NB_FRAMES * L2)));
       stationarity *= stationarity;
       stationarity *= stationarity;
       W->t.t_stat[b] = stationarity;
@@ -329,7 +295,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       float E = W->E0;
       for (int i = 1; i < 4; i++) E += W->s.binE[i];
       E = scale_ener * E;
-      W->t.band_log2[0] = .5f * 1.442695f * (float)__builtin_log(E + 1e-10f);
+      W->t.band_log2[0] = .5f * 1.442695f * (float)log((double)(E + 1e-10f));
    }
    wv_sync();
    {  /* spectral variability (:755-775): the 8 x 8 distances between the stored log spectra, one lane per pair */
@@ -380,14 +346,14 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       }
       float spec_variability = 0;
       for (int i = 0; i < AN_NB_FRAMES; i++) spec_variability += W->t.mindist[i];
-      spec_variability = (float)__builtin_sqrt(spec_variability / AN_NB_FRAMES / AN_NB_TBANDS);
+      spec_variability = (float)sqrt((double)(spec_variability / AN_NB_FRAMES / AN_NB_TBANDS));
       /* bandwidth detection (:776-853) */
       float bandwidth_mask = 0, maxE = 0, below_max_pitch = 0, above_max_pitch = 0;
       int bandwidth = 0;
       float noise_floor = 5.7e-4f / (1 << (imax(0, lsb_depth - 8)));
       noise_floor *= noise_floor;
       const int prev_bandwidth = A->prev_bandwidth;
-      int masked_last = 0, masked_at_bw[AN_NB_TBANDS + 1];
+      u32 masked = 0;                                             /* bit b: band b is masked (is_masked[], :810) */
       for (int b = 0; b < AN_NB_TBANDS; b++) {
          const float E = W->t.E2[b], Em = W->t.Em[b];
          const int band_start = an_tbands[b], band_end = an_tbands[b + 1];
@@ -395,10 +361,9 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
          if (band_start < 64) below_max_pitch += E; else above_max_pitch += E;
          /* "active" only if less than 90 dB below the peak band and above the PCM quantization noise floor; b+1 because the first CELT band isn't included in tbands[] */
          if (E * 1e9f > maxE && (Em > 3 * noise_floor * (band_end - band_start) || E > noise_floor * (band_end - band_start))) bandwidth = b + 1;
-         masked_at_bw[b] = E < (prev_bandwidth >= b + 1 ? .01f : .05f) * bandwidth_mask;
+         if (E < (prev_bandwidth >= b + 1 ? .01f : .05f) * bandwidth_mask) masked |= 1u << b;
          bandwidth_mask = AN_MAX(.05f * bandwidth_mask, E);        /* a simple follower with 13 dB/Bark slope for spreading function */
       }
-      masked_at_bw[AN_NB_TBANDS] = 0;
       if (Fs == 48000) {                                            /* the last two bands: only the energy above 12 kHz, from the decimator's high-pass branch */
          float E = W->hp_ener * (1.f / (60 * 60));
          const float noise_ratio = prev_bandwidth == 20 ? 10.f : 30.f;
@@ -408,15 +373,14 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
          A->meanE[AN_NB_TBANDS] = meanE;
          const float Em = AN_MAX(E, meanE);
          if (Em > 3 * noise_ratio * noise_floor * 160 || E > noise_ratio * noise_floor * 160) bandwidth = 20;
-         masked_at_bw[AN_NB_TBANDS] = E < (prev_bandwidth == 20 ? .01f : .05f) * bandwidth_mask;
+         if (E < (prev_bandwidth == 20 ? .01f : .05f) * bandwidth_mask) masked |= 1u << AN_NB_TBANDS;
       }
-      (void)masked_last;
       W->max_pitch_ratio = above_max_pitch > below_max_pitch ? below_max_pitch / above_max_pitch : 1;
       /* resampling aliasing can create a small amount of energy in the first band being cut: if the last band is masked, it is not included */
-      if (bandwidth == 20 && masked_at_bw[AN_NB_TBANDS]) bandwidth -= 2;
-      else if (bandwidth > 0 && bandwidth <= AN_NB_TBANDS && masked_at_bw[bandwidth - 1]) bandwidth--;
+      if (bandwidth == 20 && (masked >> AN_NB_TBANDS & 1)) bandwidth -= 2;
+      else if (bandwidth > 0 && bandwidth <= AN_NB_TBANDS && (masked >> (bandwidth - 1) & 1)) bandwidth--;
       if (count <= 2) bandwidth = 20;
-      frame_loudness = 20 * (float)__builtin_log10(frame_loudness);
+      frame_loudness = 20 * (float)log10((double)(frame_loudness));
       const float Etracker = AN_MAX(A->Etracker - .003f, frame_loudness);
       A->Etracker = Etracker;
       float lowECount = A->lowECount;
@@ -444,7 +408,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       if (count1 > 5) for (int i = 0; i < 9; i++) std[i] = (1 - alpha) * std[i] + alpha * features[i] * features[i];
       for (int i = 0; i < 4; i++) features[i] = BFCC[i] - W->t.midE[i];
       for (int i = 0; i < 8; i++) { mem[i + 24] = mem[i + 16]; mem[i + 16] = mem[i + 8]; mem[i + 8] = mem[i]; mem[i] = BFCC[i]; }
-      for (int i = 0; i < 9; i++) features[11 + i] = (float)__builtin_sqrt(std[i]) - an_std_feature_bias[i];
+      for (int i = 0; i < 9; i++) features[11 + i] = (float)sqrt((double)(std[i])) - an_std_feature_bias[i];
       features[18] = spec_variability - 0.78f;
       features[20] = frame_tonality - 0.154723f;
       features[21] = activity - 0.724643f;
@@ -458,7 +422,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
    if (lane < AN_NB_TBANDS + 1) {
       const int b = lane;
       const float boost = AN_MAX(0, W->t.leak_to[b] - W->t.band_log2[b]) + AN_MAX(0, W->t.band_log2[b] - (W->t.leak_from[b] + 2.5f));
-      info->leak_boost[b] = (u8)imin(255, (int)__builtin_floor(.5 + 64.f * boost));
+      info->leak_boost[b] = (u8)imin(255, (int)floor((double)(.5 + 64.f * boost)));
    }
    /* ---- the network (src/mlp.c): dense 25 -> 32 (tanh), GRU 32 -> 24, dense 24 -> 2 (sigmoid); one lane per neuron, inputs in order ---- */
    const float WEIGHTS_SCALE = 1.f / 128;
@@ -509,7 +473,6 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       info->music_prob = W->t.probs[0];
       info->tonality = W->frame_tonality; info->tonality_slope = W->tonality_slope; info->activity = W->activity; info->noisiness = W->frame_noisiness;
       info->bandwidth = W->bandwidth; info->max_pitch_ratio = W->max_pitch_ratio;
-      info->music_prob_min = A->info[wp].music_prob_min; info->music_prob_max = A->info[wp].music_prob_max;   /* (left as they were: tonality_get_info computes them on the copy it hands out) */
       info->valid = 1;
    }
 }
@@ -636,7 +599,7 @@ WV_DEV void an_run_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *pcm,
 WV_DEV int an_voice_ratio(const OaAnalysisInfo *a, int prev_mode)
 {
    const float prob = prev_mode == 0 ? a->music_prob : prev_mode == 1002 ? a->music_prob_max : a->music_prob_min;
-   return (int)__builtin_floor(.5 + 100 * (1 - prob));
+   return (int)floor((double)(.5 + 100 * (1 - prob)));
 }
 WV_DEV int an_detected_bandwidth(int analysis_bandwidth)
 {
@@ -646,6 +609,7 @@ WV_DEV int an_detected_bandwidth(int analysis_bandwidth)
 #define AN_PSEUDO_SNR_THRESHOLD 316.23f                         /* src/opus_encoder.c:68: 10^(25/10) */
 /* src/opus_encoder.c:1916-1923: is the frame active (for the generalised DTX)?  noise_energy is only consulted for a low activity probability */
 WV_DEV int an_activity_prob_active(const OaAnalysisInfo *a) { return a->activity_probability >= AN_DTX_ACTIVITY_THRESHOLD; }
+WV_DEV int an_activity_prob_above(const OaAnalysisInfo *a) { return a->activity_probability > AN_DTX_ACTIVITY_THRESHOLD; }     /* :1312 */
 WV_DEV int an_loud_noise_active(i32 peak_signal_energy, i32 noise_energy) { return peak_signal_energy < (AN_PSEUDO_SNR_THRESHOLD * noise_energy); }
 /* celt/celt_encoder.c:935-939 (alloc_trim_analysis): trim in Q8 */
 WV_DEV i32 an_trim_tonality_slope(i32 trim, const OaAnalysisInfo *a)
@@ -669,15 +633,6 @@ WV_DEV i32 an_vbr_tonality(i32 target, i32 coded_bins, int pitch_change, const O
    i32 tonal_target = target + (i32)((coded_bins << BITRES) * 1.2f * tonal);
    if (pitch_change) tonal_target += (i32)((coded_bins << BITRES) * .8f);
    return tonal_target;
-}
-/* celt/celt_encoder.c:44 hysteresis_decision on float thresholds (:2328-2336: spreading and tapset from the tonality) */
-WV_DEV int an_hysteresis_decision(float val, const float *thresholds, const float *hysteresis, int N, int prev)
-{
-   int i;
-   for (i = 0; i < N; i++) if (val < thresholds[i]) break;
-   if (i > prev && val < thresholds[prev] + hysteresis[prev]) i = prev;
-   if (i < prev && val > thresholds[prev - 1] - hysteresis[prev - 1]) i = prev;
-   return i;
 }
 #ifdef __clang__
 #pragma clang fp contract(fast)

@@ -9,6 +9,10 @@
 
 #define OPUS_SET_VOICE_RATIO_REQUEST 11018
 #define OPUS_GET_VOICE_RATIO_REQUEST 11019
+/* private to this library: 1 (default) = the encoder runs the tonality / music analysis at complexity 10 like a FIXED_POINT libopus with its float API (the default
+ * build); 0 = like one built with DISABLE_FLOAT_API.  The parity tests use it to compare against either build of the reference. */
+#define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
+#define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
 #define OPUS_SET_LFE_REQUEST 10024
 #define OPUS_SET_ENERGY_MASK_REQUEST 10026
 #define OPUS_GET_LOOKAHEAD_REQUEST 4027
@@ -32,6 +36,10 @@ static inline opus_int32 &oa_signal(OaStream *r) { return r->signal_type; }     
 static inline opus_int32 &oa_fec(OaStream *r) { return r->use_inband_fec; }          static inline opus_int32 &oa_fec(OaShStream *r) { return r->cfg.use_inband_fec; }
 static inline opus_int32 &oa_forced_mode(OaStream *r) { return r->user_forced_mode; } static inline opus_int32 &oa_forced_mode(OaShStream *r) { return r->cfg.user_forced_mode; }
 static inline opus_int32 &oa_voice_ratio(OaStream *r) { return r->voice_ratio; }     static inline opus_int32 &oa_voice_ratio(OaShStream *r) { return r->cfg.voice_ratio; }
+static inline opus_int32 &oa_voice_ratio_seq(OaStream *r) { return r->voice_ratio_seq; }   static inline opus_int32 &oa_voice_ratio_seq(OaShStream *r) { return r->cfg.voice_ratio_seq; }
+static inline opus_int32 &oa_voice_ratio_now(OaStream *r) { return r->st.s.voice_ratio; }  static inline opus_int32 &oa_voice_ratio_now(OaShStream *r) { return r->s.voice_ratio; }
+static inline opus_int32 &oa_voice_ratio_seen(OaStream *r) { return r->st.s.voice_ratio_seq; }  static inline opus_int32 &oa_voice_ratio_seen(OaShStream *r) { return r->s.voice_ratio_seq; }
+static inline opus_int32 &oa_analysis_off(OaStream *r) { return r->analysis_off; }   static inline opus_int32 &oa_analysis_off(OaShStream *r) { return r->cfg.analysis_off; }
 static inline opus_int32 &oa_mask_on(OaStream *r) { return r->energy_mask_on; }      static inline opus_int32 &oa_mask_on(OaShStream *r) { return r->cfg.energy_mask_on; }
 static inline opus_int32 oa_prev_framesize(const OaStream *r) { return r->prev_framesize; }   static inline opus_int32 oa_prev_framesize(const OaShStream *r) { return r->s.prev_framesize; }
 static inline opus_int32 oa_bandwidth(const OaStream *r) { return r->st.s.bandwidth; }        static inline opus_int32 oa_bandwidth(const OaShStream *r) { return r->s.bandwidth; }
@@ -39,13 +47,18 @@ static inline opus_uint32 oa_range(const OaStream *r) { return r->st.s.rangeFina
 static inline int oa_first(const OaStream *r) { return r->st.s.first; }                       static inline int oa_first(const OaShStream *r) { return r->s.first; }
 static inline opus_int32 oa_dtx_counter(const OaStream *r) { return r->nb_no_activity_ms_Q1; } static inline opus_int32 oa_dtx_counter(const OaShStream *r) { return r->s.nb_no_activity_ms_Q1; }
 
+/* process-wide default of the private float-analysis switch: OPUS_AMD_FLOAT_ANALYSIS=0 makes new encoders behave like a reference built with DISABLE_FLOAT_API
+ * (the suites that check against that build of the reference run under it); unset or anything else: like the default build */
+static int oa_default_analysis_off(void) { static const int off = getenv("OPUS_AMD_FLOAT_ANALYSIS") && !strcmp(getenv("OPUS_AMD_FLOAT_ANALYSIS"), "0"); return off; }
 /* ---- init / reset (opus_encoder_init :204-330, OPUS_RESET_STATE :3200-3232) ---- */
 static void oa_stream_reset_state(OaStream *st)
 {
    OaEncConfig cfg = st->cfg;
-   const opus_int32 Fs = st->Fs, dtx = st->use_dtx, sig = st->signal_type, fec = st->use_inband_fec, fm = st->user_forced_mode, vr = st->voice_ratio;
-   memset(st, 0, sizeof(*st));
-   st->cfg = cfg; st->Fs = Fs; st->use_dtx = dtx; st->signal_type = sig; st->use_inband_fec = fec; st->user_forced_mode = fm; st->voice_ratio = vr;
+   opus_int32 cfg2[OA_STREAM_CFG2_WORDS];
+   memcpy(cfg2, &st->Fs, sizeof(cfg2));
+   const opus_int32 vr = st->st.s.voice_ratio, vrs = st->st.s.voice_ratio_seq;       /* voice_ratio sits outside the reference's reset region (src/opus_encoder.c:91,:111) */
+   memset(st, 0, sizeof(*st));                                                       /* (this also is tonality_analysis_reset, :3210) */
+   st->cfg = cfg; memcpy(&st->Fs, cfg2, sizeof(cfg2)); st->st.s.voice_ratio = vr; st->st.s.voice_ratio_seq = vrs;
    st->st.s.stream_channels = cfg.channels; st->st.s.bandwidth = OPUS_BANDWIDTH_FULLBAND; st->st.s.first = 1; st->st.s.hybrid_stereo_width_Q14 = 1 << 14;
    st->st.s.spread_decision = 2; st->st.s.delayedIntra = 1; st->st.s.tonal_average = 256;
    for (int i = 0; i < 2 * OA_NB_EBANDS; i++) st->st.oldLogE[i] = st->st.oldLogE2[i] = -(28 << 24);
@@ -59,14 +72,16 @@ static int oa_init_stream(OaStream *st, opus_int32 Fs, int channels, int applica
    st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = OPUS_AUTO;
    st->cfg.user_bandwidth = OPUS_AUTO; st->cfg.max_bandwidth = OPUS_BANDWIDTH_FULLBAND; st->cfg.lsb_depth = 24; st->cfg.variable_duration = OPUS_FRAMESIZE_ARG;
    st->Fs = Fs; st->signal_type = OPUS_AUTO; st->user_forced_mode = OPUS_AUTO; st->voice_ratio = -1;
+   st->analysis_off = oa_default_analysis_off();
    oa_stream_reset_state(st);
+   st->st.s.voice_ratio = -1;
    return OPUS_OK;
 }
 static int sh_init_stream(OaShStream *st, opus_int32 Fs, int channels, int application)
 {
    if (!oa_fs_ok(Fs) || (channels != 1 && channels != 2) || !oa_app_is_sh(application)) return OPUS_BAD_ARG;
    oa_sh_stream_init(st, Fs, channels, application);
-   st->cfg.variable_duration = OPUS_FRAMESIZE_ARG; st->cfg.voice_ratio = -1;
+   st->cfg.variable_duration = OPUS_FRAMESIZE_ARG; st->cfg.voice_ratio = -1; st->s.voice_ratio = -1; st->cfg.analysis_off = oa_default_analysis_off();
    return OPUS_OK;
 }
 static void oa_reset_rec(OaStream *r) { oa_stream_reset_state(r); }
@@ -114,7 +129,10 @@ template <class R> static int oa_rec_set(R *r, int request, opus_int32 value)
    case OPUS_SET_PACKET_LOSS_PERC_REQUEST: if (value < 0 || value > 100) return OPUS_BAD_ARG; c->packet_loss_perc = value; return OPUS_OK;
    case OPUS_SET_INBAND_FEC_REQUEST: if (value < 0 || value > 2) return OPUS_BAD_ARG; oa_fec(r) = value; return OPUS_OK;
    case OPUS_SET_DTX_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; oa_use_dtx(r) = value; return OPUS_OK;
-   case OPUS_SET_VOICE_RATIO_REQUEST: if (value < -1 || value > 100) return OPUS_BAD_ARG; oa_voice_ratio(r) = value; return OPUS_OK;
+   case OPUS_SET_VOICE_RATIO_REQUEST:          /* the record's own copy changes at once (classic API: the record IS the state); a batch learns of it through the configuration */
+      if (value < -1 || value > 100) return OPUS_BAD_ARG;
+      oa_voice_ratio(r) = value; oa_voice_ratio_seq(r)++; oa_voice_ratio_now(r) = value; oa_voice_ratio_seen(r) = oa_voice_ratio_seq(r); return OPUS_OK;
+   case OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; oa_analysis_off(r) = !value; return OPUS_OK;
    case OPUS_SET_EXPERT_FRAME_DURATION_REQUEST: if (value < OPUS_FRAMESIZE_ARG || value > OPUS_FRAMESIZE_120_MS) return OPUS_BAD_ARG; c->variable_duration = value; return OPUS_OK;
    case OPUS_SET_PREDICTION_DISABLED_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->prediction_disabled = value; return OPUS_OK;
    case OPUS_SET_LFE_REQUEST: c->lfe = value; return OPUS_OK;
@@ -160,7 +178,8 @@ template <class R> static int oa_rec_get(R *r, int request, opus_int32 *value)
    case OPUS_GET_PACKET_LOSS_PERC_REQUEST: *value = c->packet_loss_perc; return OPUS_OK;
    case OPUS_GET_INBAND_FEC_REQUEST: *value = oa_fec(r); return OPUS_OK;
    case OPUS_GET_DTX_REQUEST: *value = oa_use_dtx(r); return OPUS_OK;
-   case OPUS_GET_VOICE_RATIO_REQUEST: *value = oa_voice_ratio(r); return OPUS_OK;
+   case OPUS_GET_VOICE_RATIO_REQUEST: *value = oa_voice_ratio_now(r); return OPUS_OK;
+   case OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST: *value = !oa_analysis_off(r); return OPUS_OK;
    case OPUS_GET_EXPERT_FRAME_DURATION_REQUEST: *value = c->variable_duration ? c->variable_duration : OPUS_FRAMESIZE_ARG; return OPUS_OK;
    case OPUS_GET_PREDICTION_DISABLED_REQUEST: *value = c->prediction_disabled; return OPUS_OK;
    case OPUS_GET_SAMPLE_RATE_REQUEST: *value = oa_fs(r); return OPUS_OK;

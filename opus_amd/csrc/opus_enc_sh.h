@@ -141,7 +141,7 @@ WV_DEV i32 sh_frame_energy_wave(const i16 *pcm, int len)
 }
 
 /* lane 0: opus_encode_native's decisions for the call (:1325-1696) */
-WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes)
+WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes, const OaAnalysisInfo *info)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st; const WV_LDS OaShConfig *cfg = &L->cfg;
    const int Fs = cfg->Fs, channels = cfg->channels;
@@ -151,6 +151,13 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    sh->redundancy = 0; sh->celt_to_silk = 0; sh->to_celt = 0; sh->prefill = 0; sh->nb_frames = 1; sh->enc_frame_size = frame_size;
    sh->lsb_depth = imin(cfg->input_depth ? cfg->input_depth : 16, cfg->lsb_depth);
    if (max_data_bytes == 1 && Fs == frame_size * 10) { sh->err = OA_ERR_BUFFER_TOO_SMALL; return; }
+   /* voice_ratio and the detected bandwidth from the analysis of the call (:1273-1308); without the float API voice_ratio is always -1 */
+   if (!sh->is_silence || cfg->analysis_off) st->voice_ratio = -1;
+   int detected_bandwidth = 0;
+   if (info->valid) {
+      if (cfg->signal_type == OA_AUTO) st->voice_ratio = an_voice_ratio(info, st->prev_mode);
+      detected_bandwidth = an_detected_bandwidth(info->bandwidth);
+   }
    const i32 user = cfg->user_bitrate_bps == OA_AUTO ? 60 * Fs / frame_size + Fs * channels : (cfg->user_bitrate_bps == OA_BITRATE_MAX ? 1500000 : cfg->user_bitrate_bps);
    i32 bitrate_bps = imin(user, bits_to_bitrate(max_data_bytes * 8, Fs, frame_size));
    int frame_rate = Fs / frame_size;
@@ -184,7 +191,8 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    i32 equiv_rate = sh_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
    int voice_est;
    if (cfg->signal_type == OA_SIGNAL_VOICE) voice_est = 127; else if (cfg->signal_type == OA_SIGNAL_MUSIC) voice_est = 0;
-   else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;                 /* voice_ratio is -1 without the float analysis (:1307) */
+   else if (st->voice_ratio >= 0) { voice_est = st->voice_ratio * 327 >> 8; if (cfg->application == OA_APP_AUDIO) voice_est = imin(voice_est, 115); }   /* for AUDIO, never more than 90% confident of having speech */
+   else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;
    if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
    else if (channels == 2) {
       i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
@@ -192,7 +200,7 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       st->stream_channels = equiv_rate > thr ? 2 : 1;
    } else st->stream_channels = channels;
    equiv_rate = sh_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, loss);
-   st->sm_useDTX = cfg->use_dtx && !sh->is_silence;                                               /* :1463: SILK's own DTX; digital silence takes the generalised one */
+   st->sm_useDTX = cfg->use_dtx && !(info->valid || sh->is_silence);                              /* :1461: SILK's own DTX only where the generalised one cannot be used */
    /* mode (:1466-1539) */
    if (cfg->application == OA_APP_RESTRICTED_SILK) st->mode = OA_MODE_SILK_ONLY;
    else if (cfg->user_forced_mode == OA_AUTO) {
@@ -244,6 +252,11 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    if (Fs <= 16000 && st->bandwidth > OA_BW_WB) st->bandwidth = OA_BW_WB;
    if (Fs <= 12000 && st->bandwidth > OA_BW_MB) st->bandwidth = OA_BW_MB;
    if (Fs <= 8000 && st->bandwidth > OA_BW_NB) st->bandwidth = OA_BW_NB;
+   if (detected_bandwidth && cfg->user_bandwidth == OA_AUTO) {                                    /* use the detected bandwidth to reduce the encoded bandwidth (:1651-1674); SILK / hybrid never below wideband */
+      const i32 sc = st->stream_channels; const int celt = st->mode == OA_MODE_CELT_ONLY;
+      const int min_detected_bandwidth = equiv_rate <= 18000 * sc && celt ? OA_BW_NB : equiv_rate <= 24000 * sc && celt ? OA_BW_MB : equiv_rate <= 30000 * sc ? OA_BW_WB : equiv_rate <= 44000 * sc ? OA_BW_SWB : OA_BW_FB;
+      st->bandwidth = imin(st->bandwidth, imax(detected_bandwidth, min_detected_bandwidth));
+   }
    {  /* decide_fec (:940): enough rate for the LBRR side stream at this bandwidth?  With > 5 % loss the bandwidth comes down until there is. */
       int fec = 0;
       if (cfg->use_inband_fec && loss != 0 && st->mode != OA_MODE_CELT_ONLY) {
@@ -380,6 +393,17 @@ WV_DEV void sh_reload_silk(WV_LDS ShLds *L, const OaShStream *gs)
    wv_sync();
    LANE0 L->sh.silk_in_lds = 1;
 }
+/* SILK state back to HBM (if it is in LDS): whoever borrows the arena next may overwrite it; sh_reload_silk brings it back */
+WV_DEV void sh_park_silk(WV_LDS ShLds *L, OaShStream *gs)
+{
+   wv_sync();
+   if (wv_uni(L->sh.silk_in_lds)) {
+      i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, SE_STATE_WORDS(L->cfg.channels)) g[i] = d[i];
+      wv_sync();
+      LANE0 L->sh.silk_in_lds = 0;
+   }
+}
 /* OPUS_RESET_STATE of the CELT encoder (celt_encoder.c:2972-2992) on the state in HBM + the scalars in the arena; configuration-like words survive */
 WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
 {
@@ -396,6 +420,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
    FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = 0; gs->celt.oldBandE[i] = 0; gs->celt.energyError[i] = 0; gs->celt.oldLogE[i] = gs->celt.oldLogE2[i] = -(28 << 24); }
    FOR_LANES(i, 2 * OA_OVERLAP) gs->celt.in_mem[i] = 0;
    FOR_LANES(i, 2 * OA_MAX_PERIOD) gs->celt.prefilter_mem[i] = 0;
+   FOR_LANES(i, (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)&gs->celt.analysis)[i] = 0;       /* the AnalysisInfo of CELT_SET_ANALYSIS sits in the reset region as well (celt_encoder.c:109) */
    wv_sync();
 }
 /* the persistent CELT_SET_PREDICTION state (celt_encoder.c:2893: disable_pf = value <= 1, force_intra = value == 0) lives in two spare scalar words */
@@ -492,11 +517,13 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    /* ---- activity (:1911-1930) ---- */
    {
       i32 noise_energy = 0;
-      const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;
-      if (!wv_uni(sh->f_silence) && celt_only) noise_energy = sh_frame_energy_wave(pcm, frame_size * CC);
+      const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY, an_valid = wv_uni(gs->an_info.valid);
+      const int an_active = an_valid ? an_activity_prob_active(&gs->an_info) : 0;
+      if (!wv_uni(sh->f_silence) && (an_valid ? !an_active : celt_only)) noise_energy = sh_frame_energy_wave(pcm, frame_size * CC);
       LANE0 {
          sh->activity = SE_VAD_NO_DECISION;
          if (sh->f_silence) sh->activity = 0;
+         else if (an_valid) sh->activity = an_active || an_loud_noise_active(st->peak_signal_energy, noise_energy);     /* the analysis' activity probability; loud noise counts as active (:1916-1924) */
          else if (celt_only) sh->activity = (i64)st->peak_signal_energy < 316 * (i64)half32(noise_energy);
       }
    }
@@ -732,6 +759,10 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    }
    const int redundancy = wv_uni(sh->f_redundancy), celt_to_silk = wv_uni(sh->f_celt_to_silk), redundancy_bytes = wv_uni(sh->redundancy_bytes);
    const int n2 = Fs / 200, n4 = Fs / 400;
+   if (redundancy || mode != OA_MODE_SILK_ONLY) {                                          /* CELT_SET_ANALYSIS (:2416-2419) */
+      if (wv_lane() < (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)&gs->celt.analysis)[wv_lane()] = ((const i32 *)&gs->an_info)[wv_lane()];
+      wv_sync();
+   }
    /* ---- 5 ms redundant CELT frame ahead of the SILK / hybrid audio (CELT -> SILK, :2427-2442) ---- */
    if (redundancy && celt_to_silk) {
       ShCeltCtl c; c.start = 0; c.vbr = 0; c.constrained_vbr = 0; c.nbytes = redundancy_bytes; c.raw = 1; c.cont = 0; c.bitrate = -1;
@@ -834,7 +865,8 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
    }
 }
 
-WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out)
+WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out,
+      const i32 *apcm = nullptr)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    SE_PHASE_START(&L->S);
@@ -844,22 +876,44 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       FOR_LANES(i, (int)(sizeof(OaShConfig) / 4)) d[i] = g[i];
       g = (const i32 *)&gs->s; d = (WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) d[i] = g[i];
-      g = (const i32 *)&gs->silk; d = (WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(gs->cfg.channels)) d[i] = g[i];
    }
    wv_sync();
-   LANE0 { sh->silk_in_lds = 1; L->cs = cs; }
-   SE_PHASE(&L->S, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   LANE0 {
+      L->cs = cs;
+      if (L->cfg.voice_ratio_seq != st->voice_ratio_seq) { st->voice_ratio = L->cfg.voice_ratio; st->voice_ratio_seq = L->cfg.voice_ratio_seq; }   /* OPUS_SET_VOICE_RATIO through a batch ctl */
+   }
+   /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only), in the arena the SILK state is about to
+    * be loaded into; a call the reference turns away before that (:1231) leaves it alone */
+   if (!(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
+      if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
+         LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
+         an_run_analysis_wave((WV_LDS AnLds *)&L->S, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
+               (i32 *)cs->X, &gs->an_info);
+      } else {
+         if (wv_uni(gs->an.initialized)) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }       /* tonality_analysis_reset (:1262) */
+         LANE0 { gs->an_info.valid = 0; gs->an_read_pos_bak = -1; }
+      }
+   }
+   wv_sync();
+   SE_PHASE_START(&L->S);                                                               /* (profiling build: the analysis borrowed the arena the phase clock lives in) */
+   {  /* the SILK encoder state (coalesced) */
+      const i32 *g = (const i32 *)&gs->silk; WV_LDS i32 *d = (WV_LDS i32 *)&L->S.st;
+      FOR_LANES(i, SE_STATE_WORDS(CC)) d[i] = g[i];
+   }
+   wv_sync();
+   LANE0 sh->silk_in_lds = 1;
+   SE_PHASE(&L->S, 0);
    i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
-   {  /* is_digital_silence (:1060, fixed point: all samples zero); peak signal energy tracker (:1310-1320) */
+   {  /* is_digital_silence (:1060, fixed point: all samples zero); peak signal energy tracker (:1310-1320: frames the analysis calls inactive do not feed it) */
       const i32 m = sh_maxabs_wave(pcm, frame_size * CC);
       i32 en = 0;
-      if (m != 0) en = sh_frame_energy_wave(pcm, frame_size * CC);
-      LANE0 { sh->sample_max = m; sh->is_silence = m == 0; if (m != 0) st->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), st->peak_signal_energy), en); }
+      const int track = m != 0 && (!wv_uni(gs->an_info.valid) || an_activity_prob_above(&gs->an_info));
+      if (track) en = sh_frame_energy_wave(pcm, frame_size * CC);
+      LANE0 { sh->sample_max = m; sh->is_silence = m == 0; if (track) st->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), st->peak_signal_energy), en); }
    }
    if (CC == 2 && L->cfg.force_channels != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
-   LANE0 sh_layer_decide(L, frame_size, max_data_bytes);
+   LANE0 sh_layer_decide(L, frame_size, max_data_bytes, &gs->an_info);
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
       const int n = sh_emit_packet(L->packet, out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);
@@ -881,8 +935,14 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       LANE0 { if (bak_to_mono) L->cfg.force_channels = 1; else st->prev_channels = st->stream_channels; L->mf.n = nb_frames; }
       int tot_size = 0, dtx_count = 0, err = 0, staged = 0;
       if (OA_MF_HEADROOM + imin(max_len_sum, 1276 * nb_frames) > out_cap) err = OA_ERR_BUFFER_TOO_SMALL;     /* staging + theta-RDO journal need the slot the host promised */
+      const int an_bak = wv_uni(gs->an_read_pos_bak);
+      if (an_bak != -1) { LANE0 { gs->an.read_pos = an_bak; gs->an.read_subframe = gs->an_read_subframe_bak; } }   /* the analysis is read one coded frame at a time (:1727-1735) */
       for (int i = 0; i < nb_frames && !err; i++) {
          const i16 *fp = pcm + (size_t)i * CC * enc_frame_size;
+         if (an_bak != -1) {                                                              /* (:1796-1800); the arena is borrowed: the SILK state goes back to HBM first */
+            sh_park_silk(L, gs);
+            an_get_info_wave((WV_LDS AnLds *)&L->S, &gs->an, &gs->an_info, enc_frame_size, Fs);
+         }
          const i32 fm = sh_maxabs_wave(fp, enc_frame_size * CC);
          int curr_max = imin(bitrate_to_bits(wv_uni(sh->bitrate_bps), Fs, enc_frame_size) / 8, max_len_sum / nb_frames);
          curr_max = imin(max_len_sum - tot_size, curr_max);

@@ -10,7 +10,12 @@
 struct OaShConfig {
    int32_t Fs, channels, application, user_bitrate_bps, use_vbr, vbr_constraint, complexity, force_channels;
    int32_t user_bandwidth, max_bandwidth, lsb_depth, disable_inv, packet_loss_perc, user_forced_mode, signal_type, use_inband_fec;
-   int32_t use_dtx, variable_duration, input_depth, lfe, prediction_disabled, voice_ratio, energy_mask_on, reserved[1];
+   int32_t use_dtx, variable_duration, input_depth, lfe, prediction_disabled;
+   int32_t voice_ratio;                                 /* OPUS_SET_VOICE_RATIO: the value last set ... */
+   int32_t energy_mask_on;
+   int32_t voice_ratio_seq;                             /* ... and a count of the sets (the kernel adopts the value when the count moves) */
+   int32_t analysis_off;                                /* private: 1 = behave like a reference built with DISABLE_FLOAT_API (no tonality analysis at complexity 10) */
+   int32_t reserved[7];
 };
 struct OaShScalars {
    int32_t stream_channels, bandwidth, auto_bandwidth, first, mode, prev_mode, prev_channels, prev_framesize;
@@ -24,6 +29,8 @@ struct OaShScalars {
    int32_t nb_no_activity_ms_Q1, sm_useDTX;             /* generalised DTX counter (decide_dtx_mode, src/opus_encoder.c:1115); silk_mode.useDTX of the last frame */
    int32_t peak_signal_energy;                          /* src/opus_encoder.c:1310-1320 (activity decision of CELT-only frames, :1926) */
    int32_t nonfinal_frame;                              /* inside a repacketised multi-frame packet (:1779) */
+   int32_t voice_ratio;                                 /* OpusEncoder.voice_ratio (:91): -1, the value of OPUS_SET_VOICE_RATIO, or what the analysis said (:1291) */
+   int32_t voice_ratio_seq;                             /* last cfg.voice_ratio_seq seen */
    int32_t pad0[2];
 };
 #define OA_SH_MAX_DELAY 480                              /* encoder_buffer = Fs / 100 samples per channel */
@@ -35,13 +42,17 @@ struct OaShStream {
    int16_t delay_buffer[2 * OA_SH_MAX_DELAY];            /* hybrid only */
    OaSilkLbrr lbrr;                                      /* in-band FEC only */
    int32_t energy_mask[2 * OA_NB_EBANDS];                /* surround masking (OPUS_SET_ENERGY_MASK; copied in by the multistream layer each frame) */
+   OaAnalysisInfo an_info;                               /* the AnalysisInfo of the call (opus_encode_native's local, src/opus_encoder.c:1206) */
+   int32_t an_read_pos_bak, an_read_subframe_bak;         /* the analysis' read position at the start of the call (multi-frame calls rewind to it, :1255,:1732), -1 = the analysis did not run */
+   OaAnalysis an;                                        /* TonalityAnalysisState (src/opus_encoder.c:105) */
 };
 /* opus_encoder_init (src/opus_encoder.c:204-330) */
 static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)
 {
    OaShConfig keep = st->cfg;
+   const int32_t vr = st->s.voice_ratio, vrs = st->s.voice_ratio_seq;            /* voice_ratio sits outside the reference's reset region (src/opus_encoder.c:91,:111) */
    char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
-   st->cfg = keep;
+   st->cfg = keep; st->s.voice_ratio = vr; st->s.voice_ratio_seq = vrs;
    st->cfg.Fs = Fs; st->cfg.channels = channels; st->cfg.application = application;
    st->s.stream_channels = channels; st->s.first = 1; st->s.mode = 1001; st->s.bandwidth = 1105;
    st->s.hybrid_stereo_width_Q14 = 1 << 14; st->s.prev_HB_gain = 32767;
@@ -56,5 +67,6 @@ static inline void oa_sh_stream_init(OaShStream *st, int32_t Fs, int channels, i
    st->cfg.user_bitrate_bps = -1000; st->cfg.use_vbr = 1; st->cfg.vbr_constraint = 1; st->cfg.complexity = 9; st->cfg.force_channels = -1000;
    st->cfg.user_bandwidth = -1000; st->cfg.max_bandwidth = 1105; st->cfg.lsb_depth = 24; st->cfg.user_forced_mode = -1000; st->cfg.signal_type = -1000;
    oa_sh_stream_reset(st, Fs, channels, application);
+   st->cfg.voice_ratio = -1; st->s.voice_ratio = -1;
 }
 #endif

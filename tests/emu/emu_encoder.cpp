@@ -28,6 +28,7 @@ extern "C" void emu_encode_batch(OaStream *streams, const int16_t *pcm, int S, i
       FrameLds *L = (FrameLds *)aligned_alloc(64, (sizeof(FrameLds) + 63) & ~63);
       memset(L, 0xA5, sizeof(FrameLds));          /* LDS is uninitialised on the GPU: make stale reads loud */
       CeltScratch *cs = (CeltScratch *)malloc(sizeof(CeltScratch)); memset(cs, 0xA5, sizeof(CeltScratch)); L->g = cs;
+      streams[s].analysis_off = 1;              /* this harness is checked against the restatement oracle / the reference built with DISABLE_FLOAT_API */
       Job j = {L, streams + s, pcm + (size_t)s * frame_size * streams[s].cfg.channels, frame_size, max_bytes, out + (size_t)s * stride, lens + s, rngs + s};
       emu_run_wave(job_entry, &j);
       free(L); free(cs);

@@ -59,7 +59,7 @@ struct ShJob { CeltScratch *cs; SeRateScratch *G; ShLds *L; OaShStream *gs; cons
 static void shjob(void *p) { ShJob *j = (ShJob *)p; oa_sh_encode_frame(j->L, j->gs, j->pcm, j->frame_size, j->max_bytes, j->out, j->out_cap, j->pcm_hp, j->G, j->cs, j->len, j->rng); }
 extern "C" int emu_sh_stream_size() { return (int)sizeof(OaShStream); }
 extern "C" int emu_sh_lds_size() { return (int)sizeof(ShLds); }
-extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int application) { oa_sh_stream_init(st, Fs, channels, application); }
+extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int application) { oa_sh_stream_init(st, Fs, channels, application); st->cfg.analysis_off = 1; }   /* this harness is checked against the reference built with DISABLE_FLOAT_API */
 extern "C" void emu_sh_set_cfg(OaShStream *st, int word, int value) { ((int32_t *)&st->cfg)[word] = value; }
 extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size, int max_bytes, uint8_t *out, int out_cap, int32_t *len, uint32_t *rng)
 {

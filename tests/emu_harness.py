@@ -27,6 +27,7 @@ def new_stream(E, channels, bitrate=-1000, complexity=9, application=2051, use_v
     s[st + 12] = 2      # spread_decision = SPREAD_NORMAL
     s[st + 13] = 1      # delayedIntra
     s[st + 14] = 256    # tonal_average
+    s[st + 34] = -1     # voice_ratio
     arr = st + 36
     s[arr + 42: arr + 42 + 84] = -(28 << 24)   # oldLogE, oldLogE2 = -28.0 (Q24)
     return s
