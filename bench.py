@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+NO_ANALYSIS = False      # --no-analysis
 CORPUS = "pool"          # --corpus reference: the reference's generate_music() tunes instead of this repo's music / noise-burst pool
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
@@ -131,7 +132,7 @@ def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
             allc = None
     same = None                                                              # the library the GPU path is bit-exact to: fixed-point arithmetic, no float API (no analysis.c)
     try:
-        fx = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so")
+        fx = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so" if NO_ANALYSIS else "oracle/_ref/libopus_ref_fxa.so")
         if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, pcm0, min(4.0, seconds), first))), 1)
         try: os.sched_setaffinity(0, set(cpus))
         except Exception: pass
@@ -140,8 +141,8 @@ def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
     return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
             "sample": "stream 0 of the GPU batch (its %d frames copied back, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD" % (pcm0.shape[0], seconds),
             "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None,
-            "same_work_value": same, "same_work_note": "one pinned core of the reference's FIXED_POINT + DISABLE_FLOAT_API build: the arithmetic and the decisions the GPU reproduces bit for bit "
-                                                      "(`value` is the float build with SIMD dispatch and the tonality analysis, the fastest way to run the reference on this host)"}
+            "same_work_value": same, "same_work_note": ("one pinned core of the reference's FIXED_POINT + DISABLE_FLOAT_API build" if NO_ANALYSIS else "one pinned core of the reference's FIXED_POINT build with the float API (fixed-point codec + the float tonality analysis)") +
+                              ": the arithmetic and the decisions the GPU reproduces bit for bit (`value` is the float build with SIMD dispatch, the fastest way to run the reference on this host)"}
 
 def copy_bandwidth(dev):
     """device-to-device copy, GB/s of traffic (read + write)"""
@@ -208,6 +209,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     else:
         b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
         for req, v in cfg["ctls"]: b.ctl(req, v)
+        b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)        # default: like the reference's default build (analysis.c + mlp.c at complexity 10)
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
@@ -235,9 +237,12 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     L = opus_amd.lib()
     L.opusgpu_enc_moved_state_bytes.restype = ctypes.c_int
     state_moved = L.opusgpu_enc_moved_state_bytes(cfg["app"], CH, 1 if cid == 4 else 0)          # state bytes read + written per frame-step
+    L.opusgpu_enc_analysis_moved_bytes.restype = ctypes.c_int
+    analysis_on = (not NO_ANALYSIS) and cid != 5 and Fs >= 16000 and cfg["app"] != opus_amd.OPUS_APPLICATION_RESTRICTED_SILK and any(req == 4010 and v >= 10 for req, v in cfg["ctls"])
+    if analysis_on: state_moved += L.opusgpu_enc_analysis_moved_bytes()                       # the tonality analysis' own state (phase history, 30 ms input window, band energies, info ring)
     alg = FR * CH * 2 + mean_len + 8 + state_moved
     res = {"config_id": cid, "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
-           "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved}
+           "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved, "float_analysis": bool(analysis_on)}
     if frames_per_launch and world == 1 and cid != 5:
         # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "T = 50 consecutive steps"
         Tn = min(frames_per_launch, T)
@@ -294,12 +299,13 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
     ap.add_argument("--frames-per-launch", type=int, default=0, help="also time T consecutive frame-steps in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-analysis", action="store_true", help="encode like a reference built with DISABLE_FLOAT_API: no tonality / music analysis at complexity 10 (the round-1/2 workload)")
     ap.add_argument("--corpus", default="pool", choices=["pool", "reference"], help="input signals: this repo's music / noise-burst pool (default) or the reference's generate_music() tunes (tests/test_opus_encode.c:57)")
     ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first, untimed) instead of the encoder")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the short config 3 / 4 legs")
     a = ap.parse_args()
-    global CORPUS
-    CORPUS = a.corpus
+    global CORPUS, NO_ANALYSIS
+    CORPUS = a.corpus; NO_ANALYSIS = a.no_analysis
     import torch, torch.distributed as dist
     import opus_amd
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))

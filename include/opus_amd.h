@@ -125,6 +125,18 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *p
 /* Same, with every buffer already resident in this device's HBM; asynchronous on `hip_stream` (NULL = the batch's stream). */
 OPUS_AMD_EXPORT int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
+/* Both again with a second view of the same input for the encoder's tonality / music analysis (src/analysis.c): apcm [S][frame_size*channels] int32 in the encoder's
+ * signal domain (2^12 per int16 LSB), what the reference's 24-bit and float entry points hand to run_analysis (downmix_int24 src/opus_encoder.c:804, downmix_float
+ * :748; opus_encode24 :2697 and opus_encode_float :2735 of this library call these).  NULL = derive it from pcm (downmix_int :780), i.e. the plain entry points above. */
+OPUS_AMD_EXPORT int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
+OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
+/* Private set / get requests of this library (opus_encoder_ctl, opusgpu_enc_batch_ctl, opus_multistream_encoder_ctl): OPUS_AMD_SET_FLOAT_ANALYSIS(1) (the default) = run the
+ * tonality / music analysis at complexity 10 like a FIXED_POINT libopus with its float API, the default build (src/opus_encoder.c:1249); (0) = like one built with
+ * DISABLE_FLOAT_API.  The process-wide default for new encoders can be set with the environment variable OPUS_AMD_FLOAT_ANALYSIS=0. */
+#define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
+#define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
 OPUS_AMD_EXPORT int opusgpu_enc_batch_sync(OpusGpuEncBatch *b);
 /* `steps` back-to-back frame-steps on device buffers ([steps][S][frame*channels] PCM), timed with HIP events on the
  * launch stream; returns elapsed milliseconds in *ms (kernel time only, inputs resident). */
@@ -138,6 +150,8 @@ OPUS_AMD_EXPORT int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_in
       opus_int32 n, void *hip_stream);
 /* state bytes one frame-step reads plus writes (roofline accounting): application, channels, hybrid frame? */
 OPUS_AMD_EXPORT int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid);
+/* ... and what the tonality analysis adds to that when it runs (complexity 10, API rate >= 16 kHz, float analysis on) */
+OPUS_AMD_EXPORT int opusgpu_enc_analysis_moved_bytes(void);
 /* memcpy contract: a stream's complete state as a flat blob (same layout as the classic OpusEncoder payload) */
 OPUS_AMD_EXPORT int opusgpu_enc_state_size(void);
 /* record size / LDS per wave of the SILK-capable encoder (batches created with OPUS_APPLICATION_VOIP / _AUDIO / _RESTRICTED_SILK; src/opus_encoder.c:76-146 + silk/fixed/structs_FIX.h:108) */

@@ -399,6 +399,14 @@ int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid)
    if (hybrid) n += 2 * (int)(sizeof(OaEncScalars) + sizeof(int32_t) * (4 * channels * OA_NB_EBANDS + channels * OA_OVERLAP + channels * OA_MAX_PERIOD)) + 2 * 2 * channels * OA_SH_MAX_DELAY;
    return n;
 }
+/* state bytes the tonality analysis of a 20 ms frame-step reads plus writes: the phase history of the 239 bins (read + written), the 30 ms input window (read; 20 ms of it
+ * rewritten), one row of the band-energy rings written and all eight read, the small feature / network state both ways, one info record written and the four
+ * fields of the ring that tonality_get_info walks read, the call's info handed to CELT */
+int opusgpu_enc_analysis_moved_bytes(void)
+{
+   return 2 * 3 * 240 * 4 + (AN_BUF_SIZE + 240 + 480) * 4 + (2 * AN_NB_FRAMES * AN_NB_TBANDS + 2 * AN_NB_TBANDS) * 4 + 2 * (3 * AN_NB_TBANDS + 1 + 32 + 8 + 9 + 24 + 16) * 4
+        + (int)sizeof(OaAnalysisInfo) * 4 + 4 * AN_DETECT_SIZE * 4;
+}
 int opusgpu_encode_batch_dev_frames(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, int T, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
       opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {

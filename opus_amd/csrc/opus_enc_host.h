@@ -11,8 +11,10 @@
 #define OPUS_GET_VOICE_RATIO_REQUEST 11019
 /* private to this library: 1 (default) = the encoder runs the tonality / music analysis at complexity 10 like a FIXED_POINT libopus with its float API (the default
  * build); 0 = like one built with DISABLE_FLOAT_API.  The parity tests use it to compare against either build of the reference. */
+#ifndef OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST
 #define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
 #define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
+#endif
 #define OPUS_SET_LFE_REQUEST 10024
 #define OPUS_SET_ENERGY_MASK_REQUEST 10026
 #define OPUS_GET_LOOKAHEAD_REQUEST 4027

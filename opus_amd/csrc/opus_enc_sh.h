@@ -891,7 +891,9 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
          an_run_analysis_wave((WV_LDS AnLds *)&L->S, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
                (i32 *)cs->X, &gs->an_info);
       } else {
-         if (wv_uni(gs->an.initialized)) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }       /* tonality_analysis_reset (:1262) */
+         const int was_initialized = wv_uni(gs->an.initialized);
+         wv_sync();                                                                       /* (every lane has read the flag before any lane clears it) */
+         if (was_initialized) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }                /* tonality_analysis_reset (:1262) */
          LANE0 { gs->an_info.valid = 0; gs->an_read_pos_bak = -1; }
       }
    }

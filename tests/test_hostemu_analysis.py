@@ -1,0 +1,127 @@
+"""CPU: the encoder WITH its tonality / music analysis (the library's default, complexity 10) against the compiled reference built the way a fixed-point libopus is by
+default -- FIXED_POINT with the float API, oracle/_ref/libopus_ref_fxa.so (src/analysis.c + src/mlp.c active) -- through the classic API on the wave emulator:
+packet bytes and final range call by call.  What the analysis steers is what is exercised: the allocation tuning of CELT-coded frames (config 2), the mode and
+bandwidth decisions of unforced AUDIO / VOIP encoders, the generalised DTX, calls of 2.5 ... 120 ms, the 24-bit and float entry points (which hand the analysis
+un-rounded samples), controls changed mid-stream (complexity in and out of 10: the analysis state is dropped, src/opus_encoder.c:1262).
+tests/test_gpu_analysis.py re-runs it on the MI355X against opus_amd/libopus_amd.so."""
+import ctypes, numpy as np, pytest
+import capi, signals
+from reflib import ref_fx, ref_fxa
+from test_hostemu_encoder_modes import sig_for
+pytestmark = pytest.mark.skipif(ref_fx() is None or ref_fxa() is None, reason="oracle/_ref not built")
+WHICH = "emu"
+FLOAT_ANALYSIS = 11900
+
+def pair(Fs, ch, app, **ctl):
+    ctl.setdefault("complexity", 10)
+    a = capi.Enc("ref_fxa", Fs, ch, app, **ctl); b = capi.Enc(WHICH, Fs, ch, app, **ctl)
+    b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    assert b.L.opus_encoder_ctl(b.st, FLOAT_ANALYSIS, 1) == 0
+    return a, b
+
+def run(Fs, ch, app, frames, schedule=None, seed=0, maxb=1276, sig=None, **ctl):
+    a, b = pair(Fs, ch, app, **ctl)
+    if sig is None: sig = sig_for(Fs, ch, sum(frames) + 16, seed)
+    pos = 0; modes = []
+    for i, fr in enumerate(frames):
+        if schedule and i in schedule:
+            for k, v in schedule[i].items():
+                if k == "reset":
+                    for e in (a, b): e.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int]; assert e.L.opus_encoder_ctl(e.st, 4028) == 0
+                else: ra = a.set(k, v); rb = b.set(k, v); assert ra == rb, (i, k, v, ra, rb)
+        pcm = sig[pos:pos + fr]; pos += fr
+        x = a.encode(pcm, fr, maxb); y = b.encode(pcm, fr, maxb)
+        modes.append("?" if x[1] <= 0 else "d" if x[1] <= 2 else "C" if x[0][0] & 0x80 else "H" if (x[0][0] & 0x60) == 0x60 else "S")
+        assert x[1] == y[1], (i, fr, "".join(modes), x[1], y[1])
+        assert x[2] == y[2], (i, fr, "".join(modes), hex(x[2]), hex(y[2]))
+        assert x[0] == y[0], (i, fr, "".join(modes), [k for k in range(len(x[0])) if x[0][k] != y[0][k]][:8])
+    return "".join(modes)
+
+def music(Fs, ch, nsamp, seed):
+    s = signals.music(nsamp * (48000 // Fs) // 960 + 2, seed=seed)[::48000 // Fs][:nsamp]
+    return np.ascontiguousarray(s if ch == 2 else s[:, :1])
+
+def test_the_analysis_changes_config_2():
+    """the reason this suite exists: with the analysis the packets of config 2 differ from the DISABLE_FLOAT_API build's in (nearly) every frame"""
+    Fs, ch = 48000, 2
+    s = music(Fs, ch, 960 * 40, 3)
+    a = capi.Enc("ref_fxa", Fs, ch, 2051, bitrate=128000, complexity=10); c = capi.Enc("ref", Fs, ch, 2051, bitrate=128000, complexity=10)
+    differ = sum(a.encode(s[i * 960:(i + 1) * 960], 960)[0] != c.encode(s[i * 960:(i + 1) * 960], 960)[0] for i in range(40))
+    assert differ > 30
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_config_2_with_analysis(ch):
+    run(48000, ch, 2051, [960] * 70, sig=music(48000, ch, 960 * 71, 3 + ch), bitrate=64000 * ch)
+    run(48000, ch, 2051, [960] * 40, seed=5, bitrate=48000 * ch)
+
+def test_lowdelay_rates_and_sizes():
+    run(48000, 2, 2051, [480] * 40 + [240] * 20 + [120] * 20 + [960] * 10, sig=music(48000, 2, 960 * 60, 7), bitrate=96000)
+    run(24000, 2, 2051, [480] * 50, sig=music(24000, 2, 480 * 52, 8), bitrate=64000)
+    run(16000, 1, 2051, [320] * 50, seed=9, bitrate=32000)
+    run(48000, 2, 2051, [1920, 2880, 960, 3840, 4800, 5760, 1920, 960, 2880], sig=music(48000, 2, 960 * 30, 10), bitrate=128000)
+    run(12000, 1, 2051, [240] * 10, seed=11, bitrate=24000)                     # below 16 kHz the analysis does not run (:1249)
+
+def test_audio_unforced_mode_decisions():
+    m = run(48000, 2, 2049, [960] * 120, sig=music(48000, 2, 960 * 121, 12), bitrate=64000)
+    assert "C" in m
+    m = run(48000, 1, 2049, [960] * 120, seed=13, bitrate=24000)                 # speech at a rate where the music probability decides SILK / hybrid / CELT
+    m = run(48000, 2, 2049, [960] * 60 + [1920] * 10 + [2880] * 6, seed=14, bitrate=40000)
+    m = run(16000, 1, 2048, [320] * 80, seed=15, bitrate=20000)
+    m = run(24000, 1, 2049, [480] * 80, sig=music(24000, 1, 480 * 81, 16), bitrate=32000)
+
+def test_speech_music_speech():
+    Fs, ch = 48000, 1
+    sp = sig_for(Fs, ch, 960 * 50, 17); mu = music(Fs, ch, 960 * 60, 18)
+    s = np.concatenate([sp, mu, sp])
+    m = run(Fs, ch, 2049, [960] * 155, sig=s, bitrate=32000)
+    assert len(set(m)) >= 2, m
+
+def test_forced_modes_and_hybrid():
+    run(48000, 2, 2049, [960] * 40, seed=19, bitrate=128000, force_mode=1001, bandwidth=1105)
+    run(48000, 1, 2049, [960] * 30, {10: dict(force_mode=1002), 20: dict(force_mode=1000)}, seed=20, bitrate=48000, force_mode=1001)
+    run(16000, 1, 2048, [320] * 30, seed=21, bitrate=24000, force_mode=1000, bandwidth=1103)
+
+def test_dtx_with_activity_probability():
+    Fs, ch = 48000, 1
+    s = sig_for(Fs, ch, 960 * 140, 22).copy()
+    s[960 * 30:960 * 70] = (s[960 * 30:960 * 70].astype(np.int32) // 512).astype(np.int16)      # near-silence: the activity probability drops, not digital silence
+    s[960 * 90:960 * 110] = 0
+    m = run(Fs, ch, 2049, [960] * 138, sig=s, bitrate=32000, dtx=1)
+    m2 = run(Fs, ch, 2051, [960] * 138, sig=s, bitrate=48000, dtx=1)
+    m3 = run(16000, ch, 2048, [320] * 138, sig=np.ascontiguousarray(s[::3]), bitrate=16000, dtx=1)
+    assert "d" in m + m2 + m3
+
+def test_cbr_and_constrained():
+    run(48000, 2, 2051, [960] * 30, sig=music(48000, 2, 960 * 31, 23), bitrate=96000, vbr=0)
+    run(48000, 2, 2049, [960] * 30, sig=music(48000, 2, 960 * 31, 24), bitrate=96000, vbr=1, vbr_constraint=0)
+    run(48000, 1, 2049, [960] * 30, seed=25, bitrate=20000, vbr=0)
+
+def test_controls_midstream():
+    sched = {10: dict(complexity=9), 20: dict(complexity=10), 30: dict(signal=3001), 40: dict(signal=-1000), 50: dict(reset=1), 60: dict(bandwidth=1103), 70: dict(bandwidth=-1000),
+             80: dict(signal=3002), 90: dict(max_bandwidth=1104, bitrate=24000)}
+    run(48000, 2, 2049, [960] * 100, sched, sig=music(48000, 2, 960 * 101, 26), bitrate=64000)
+    run(48000, 2, 2051, [960] * 100, sched, seed=27, bitrate=64000)
+
+def test_signal_type_steers_the_lowdelay_application():
+    """OPUS_SET_SIGNAL moves the stereo -> mono and bandwidth thresholds of RESTRICTED_LOWDELAY too (voice_est, src/opus_encoder.c:1413), analysis or not"""
+    for sig in (3001, 3002):
+        run(48000, 2, 2051, [960] * 12, seed=28, bitrate=18000, signal=sig, complexity=5)
+        run(48000, 2, 2051, [960] * 12, seed=28, bitrate=11000, signal=sig)
+
+def _encode_any(e, fn, arr, fr, ctype_ptr, maxb=1276):
+    out = (ctypes.c_ubyte * 1500)()
+    getattr(e.L, fn).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    n = getattr(e.L, fn)(e.st, arr.ctypes.data, fr, out, maxb)
+    return n, bytes(out[:max(n, 0)]), e.get(4031) & 0xffffffff
+
+def test_24_bit_and_float_entry_points_feed_the_analysis_unrounded_samples():
+    Fs, ch = 48000, 2
+    base = music(Fs, ch, 960 * 50, 29).astype(np.float64)
+    rng = np.random.default_rng(30)
+    fine = base + rng.uniform(-0.5, 0.5, base.shape)                                       # sub-LSB detail that the int16 path never sees
+    for fn, arr in (("opus_encode24", np.round(fine * 256).astype(np.int32)), ("opus_encode_float", (fine / 32768.0).astype(np.float32))):
+        for app, rate in ((2051, 96000), (2049, 48000)):
+            a, b = pair(Fs, ch, app, bitrate=rate)
+            for i in range(45):
+                x = _encode_any(a, fn, np.ascontiguousarray(arr[i * 960:(i + 1) * 960]), 960, None); y = _encode_any(b, fn, np.ascontiguousarray(arr[i * 960:(i + 1) * 960]), 960, None)
+                assert x == y, (fn, app, i, x[0], y[0])
