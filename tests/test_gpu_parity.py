@@ -175,13 +175,27 @@ def test_gpu_full_size_properties_silk_and_hybrid(name, Fs, ch, app, ctl):
 def test_gpu_parity_soak_with_midstream_ctls():
     """the parity gate of SURVEY 8d inside the suite: configs 2, 3 and 4, 256 streams x 1000 consecutive frames each, 64 distinct base signals (the rest are
     shifted / scaled copies), bitrate / complexity / VBR / FEC / DTX / bandwidth / channel changes applied mid-stream to the batch and to every reference
-    encoder at the same frame (tools/parity_soak.py SCHEDULE): every packet, length and final range equal"""
+    encoder at the same frame (tools/parity_soak.py SCHEDULE): every packet, length and final range equal.  Round 3: the encoder runs with its tonality / music analysis
+    (the default) and the reference is the build with the float API (libopus_ref_fxa.so), the fixed-point library as it is built by default."""
     import subprocess, sys, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools/parity_soak.py"), "--streams", "256", "--frames", "1000", "--bases", "64", "--ctl-schedule"],
+    p = subprocess.run([sys.executable, os.path.join(root, "tools/parity_soak.py"), "--streams", "256", "--frames", "1000", "--bases", "64", "--ctl-schedule", "--float-analysis"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0, out[-3000:]
     rows = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     assert len(rows) == 3, out[-3000:]
     for r in rows: assert r["mismatches"] == 0 and r["stream_frames_checked"] == 256000, r
+
+
+def test_gpu_parity_soak_without_the_float_api():
+    """the same gate for config 2 -- the configuration whose packets the analysis changes -- with the private switch off, against the reference built with
+    DISABLE_FLOAT_API: 256 streams x 400 frames with the control schedule's first two changes"""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools/parity_soak.py"), "--streams", "256", "--frames", "400", "--bases", "64", "--ctl-schedule", "--configs", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    rows = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(rows) == 1 and rows[0]["mismatches"] == 0 and rows[0]["stream_frames_checked"] == 256 * 400, out[-3000:]

@@ -18,11 +18,12 @@ SCHEDULE = {
 }
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--ctl-schedule", action="store_true", help="apply SCHEDULE[config] while the streams run"); ap.add_argument("--streams", type=int, default=256); ap.add_argument("--frames", type=int, default=1000); ap.add_argument("--configs", default="2,3,4"); ap.add_argument("--bases", type=int, default=32)
+    ap.add_argument("--float-analysis", action="store_true", help="the encoder with its tonality / music analysis (the library default) against the reference built WITH the float API (libopus_ref_fxa.so)")
     a = ap.parse_args()
     import opus_amd, signals
-    from reflib import ref_fx
+    from reflib import ref_fx, ref_fxa
     from silk_enc_bench import speech
-    R = ref_fx(); assert R is not None, "compiled reference (oracle/_ref) missing"
+    R = ref_fxa() if a.float_analysis else ref_fx(); assert R is not None, "compiled reference (oracle/_ref) missing"
     R.opus_encoder_create.restype = ctypes.c_void_p
     for cid in [int(x) for x in a.configs.split(",")]:
         c = CONFIGS[cid]; Fs, ch, n = c["Fs"], c["ch"], c["Fs"] // 50
@@ -36,6 +37,7 @@ def main():
         sig = [stream(s) for s in range(S)]
         b = opus_amd.EncoderBatch(S, channels=ch, application=c["app"], Fs=Fs)
         for req, v in c["ctl"]: b.ctl(req, v)
+        b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 1 if a.float_analysis else 0)
         gp = [[None] * T for _ in range(S)]; gr = np.zeros((S, T), np.uint32)
         sched = SCHEDULE[cid] if a.ctl_schedule else []
         for f in range(T):
@@ -64,5 +66,5 @@ def main():
                     if first is None: first = [s, f, l, len(gp[s][f]) if isinstance(gp[s][f], bytes) else gp[s][f]]
             R.opus_encoder_destroy(enc)
         print(json.dumps({"parity_gate": c["name"], "streams": S, "frames_per_stream": T, "stream_frames_checked": S * T, "mismatches": bad, "first_mismatch": first,
-                          "mean_packet_bytes": nbytes / (S * T), "distinct_base_signals": U, "ctl_changes": len(sched), "gpu_seconds_incl_host_copies": round(t_gpu, 1), "reference_seconds_one_core": round(time.time() - t0, 1)}), flush=True)
+                          "mean_packet_bytes": nbytes / (S * T), "reference_build": "FIXED_POINT + float API (analysis.c, mlp.c)" if a.float_analysis else "FIXED_POINT + DISABLE_FLOAT_API", "distinct_base_signals": U, "ctl_changes": len(sched), "gpu_seconds_incl_host_copies": round(t_gpu, 1), "reference_seconds_one_core": round(time.time() - t0, 1)}), flush=True)
 if __name__ == "__main__": main()
