@@ -125,3 +125,29 @@ def test_24_bit_and_float_entry_points_feed_the_analysis_unrounded_samples():
             for i in range(45):
                 x = _encode_any(a, fn, np.ascontiguousarray(arr[i * 960:(i + 1) * 960]), 960, None); y = _encode_any(b, fn, np.ascontiguousarray(arr[i * 960:(i + 1) * 960]), 960, None)
                 assert x == y, (fn, app, i, x[0], y[0])
+
+def test_multistream_with_analysis():
+    """every elementary encoder of a multistream encoder runs its own analysis on its own channels (opus_multistream_encoder.c:1027, c1 / c2 of the stream)"""
+    R, E = capi.load("ref_fxa"), capi.load(WHICH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    Fs, nch = 48000, 3
+    sig = np.concatenate([music(Fs, 2, 960 * 40, 31), sig_for(Fs, 1, 960 * 40, 32)], axis=1).astype(np.int16)
+    for app, rate in ((2049, 96000), (2051, 160000)):
+        out = []
+        for L in (R, E):
+            L.opus_multistream_encoder_create.restype = vp
+            L.opus_multistream_encoder_create.argtypes = [ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+            L.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ci]
+            L.opus_multistream_encoder_destroy.argtypes = [vp]; L.opus_multistream_encoder_destroy.restype = None
+            L.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]
+            err = ci()
+            e = L.opus_multistream_encoder_create(Fs, nch, 2, 1, bytes([0, 1, 2]), app, ctypes.byref(err)); assert e and err.value == 0
+            assert L.opus_multistream_encoder_ctl(e, 4010, 10) == 0 and L.opus_multistream_encoder_ctl(e, 4002, rate) == 0
+            if L is E: assert L.opus_multistream_encoder_ctl(e, FLOAT_ANALYSIS, 1) == 0
+            buf = (ctypes.c_ubyte * 4000)(); seq = []
+            for i in range(38):
+                p = np.ascontiguousarray(sig[i * 960:(i + 1) * 960])
+                n = L.opus_multistream_encode(e, p.ctypes.data, 960, buf, 4000); seq.append(bytes(buf[:max(n, 0)]) if n > 0 else n)
+            L.opus_multistream_encoder_destroy(e); out.append(seq)
+        bad = [i for i in range(38) if out[0][i] != out[1][i]]
+        assert not bad, (app, bad[:5])
