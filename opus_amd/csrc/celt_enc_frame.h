@@ -12,6 +12,7 @@
 /* profiling build only (-DOA_PHASE_TIMERS): per-phase shader-clock accounting, see opus_amd.hip */
 #ifndef K_PHASE
 #define K_PHASE(id)
+#define K_PHASE_BEGIN()
 #endif
 
 /* Final coalesced packet store.  nbytes at pk (pk[0] = TOC), or -- hard CBR (pad_to != 0) -- the same packet re-framed as a code-3 packet padded with zeros to exactly
@@ -517,6 +518,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
+   K_PHASE_BEGIN();
    /* ---- load persistent state (coalesced) ---- */
    {
       const i32 *g = (const i32 *)&gs->st.s;

@@ -7,8 +7,13 @@
 __device__ unsigned long long oa_phase_ticks[34];
 #define K_TIC() unsigned long long tic_ = clock64()
 #define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); L->prof[b] += (u32)(t_ - tic_); tic_ = t_; } } while (0)
-#define K_PHASE(id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); if ((id) > 0) L->prof[(id) - 1] = t_ - L->prof_t0; else for (int z_ = 0; z_ < 34; z_++) L->prof[z_] = 0; L->prof_t0 = t_; \
-      if ((id) == 15) for (int z_ = 0; z_ < 34; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
+/* K_PHASE_BEGIN at the top of the call; K_PHASE(0) closes what precedes the coded frame (state load, analysis, decisions: bucket 15), K_PHASE(id) closes phase id - 1 */
+#define K_PHASE_BEGIN() do { if (threadIdx.x == 0) { for (int z_ = 0; z_ < 34; z_++) L->prof[z_] = 0; L->prof_t0 = (u32)clock64(); } } while (0)
+#define K_PHASE(id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); L->prof[(id) > 0 ? (id) - 1 : 15] = t_ - L->prof_t0; L->prof_t0 = t_; \
+      if ((id) == 15) for (int z_ = 0; z_ < 31; z_++) atomicAdd(&oa_phase_ticks[z_], (unsigned long long)L->prof[z_]); } } while (0)
+/* the analysis has no FrameLds at hand: its sections go straight to the global totals (buckets 31..33) */
+#define AN_TIC() unsigned long long an_tic_ = clock64()
+#define AN_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - an_tic_); an_tic_ = t_; } } while (0)
 #endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"

@@ -32,6 +32,10 @@
 #define AN_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define AN_ABS(x) ((x) < 0 ? (-(x)) : (x))
 
+#ifndef AN_TIC          /* shader-clock section timers exist only in the -DOA_PHASE_TIMERS profiling build */
+#define AN_TIC()
+#define AN_TOC(bucket)
+#endif
 #define AN_SCRATCH_WORDS 480          /* per-wave HBM words the analysis borrows (the second half of a frame's decimated input, until the window has read the old one) */
 
 struct AnLds {
@@ -132,6 +136,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
 {
    const int lane = wv_lane();
    const int N = 480, N2 = 240;
+   AN_TIC();
    LANE0 { if (!A->initialized) { A->mem_fill = 240; A->initialized = 1; } }
    const int count = wv_uni(A->count);
    const float alpha = 1.f / imin(10, 1 + count), alphaE = 1.f / imin(25, 1 + count);
@@ -187,6 +192,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       wv_sync();
       return;
    }
+   AN_TOC(31);
    fft_forward(W->fft, 0, 1, W->aux);
    const int left = wv_uni(W->aux[0]);
    /* stage the small state of the feature / network tail */
@@ -248,6 +254,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; if (i >= 2 && i < N2 - 1) W->s.tonality[i] = sm[t]; }
    }
    wv_sync();
+   AN_TOC(32);
    const float scale_ener = (1.f / ((i32)1 << (15 + SIG_SHIFT))) * (1.f / ((i32)1 << (15 + SIG_SHIFT)));   /* SCALE_ENER (:414): the input is +/-2^15 shifted up by SIG_SHIFT */
    const int E_count = wv_uni(A->E_count);
    /* ---- the bands (:643-723): one lane per band, its bins in order ---- */
@@ -475,6 +482,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
       info->bandwidth = W->bandwidth; info->max_pitch_ratio = W->max_pitch_ratio;
       info->valid = 1;
    }
+   AN_TOC(33);
 }
 
 /* tonality_get_info (src/analysis.c:232): the info the encoder uses for a frame of `len` samples -- the stored one at the read position, with tonality and bandwidth

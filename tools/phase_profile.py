@@ -5,9 +5,9 @@ import ctypes, os, subprocess, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 PHASES = ["dc_reject+prologue", "preemphasis", "tone_detect", "transient", "prefilter(pitch+comb)", "mdct+bandE",
-          "tvbr/patch", "normalise+dynalloc", "tf_analysis", "coarse+tf_encode", "spread+dynalloc_sig+stereo+trim", "vbr+alloc+fine", "pvq", "finalise", "store", "(unused)", "  pvq: exp_rotation fwd", "  pvq: pulse search", "  pvq: mask+icwrs+ec_enc_uint", "  pvq: resynth (normalise+rotation)",
+          "tvbr/patch", "normalise+dynalloc", "tf_analysis", "coarse+tf_encode", "spread+dynalloc_sig+stereo+trim", "vbr+alloc+fine", "pvq", "finalise", "store", "state load + analysis + call decisions", "  pvq: exp_rotation fwd", "  pvq: pulse search", "  pvq: mask+icwrs+ec_enc_uint", "  pvq: resynth (normalise+rotation)",
           "  pvq: compute_theta", "  pvq: theta-RDO save/restore/dist", "  pvq: quant_band pre/post (haar, hadamard, lowband)", "  pvq: stereo_merge", "  (nested-call total, ignore)",
-          "  pf: pitch_downsample", "  pf: pitch_search", "  pf: remove_doubling", "  pf: before/comb/after", "  pf: history store", "  (pf nested)"]
+          "  pf: pitch_downsample", "  pf: pitch_search", "  pf: remove_doubling", "  pf: before/comb/after", "  pf: history store", "  (pf nested)", "  analysis: decimator + window", "  analysis: FFT + bins", "  analysis: bands + network"]
 def main():
     so = os.path.join(ROOT, "opus_amd/libopus_amd_prof.so")
     srcs = [os.path.join(ROOT, "opus_amd/csrc", f) for f in os.listdir(os.path.join(ROOT, "opus_amd/csrc"))]
@@ -27,8 +27,8 @@ def main():
         if i == 3: L.opusgpu_debug_phase_ticks(ticks, 1)
         b.encode(pcm, 960)
     L.opusgpu_debug_phase_ticks(ticks, 0)
-    t = np.array(list(ticks)[:31], dtype=np.float64)
-    tot = t[:15].sum()
+    t = np.array(list(ticks)[:34], dtype=np.float64)
+    tot = t[:16].sum()
     print("phase shares over %d frames (shader clock ticks per frame: %.0f)" % (5 * S, tot / (5 * S)))
     for n, v in zip(PHASES, t): print("  %-34s %6.2f %%  %9.0f ticks/frame" % (n, 100 * v / tot, v / (5 * S)))
 if __name__ == "__main__": main()
