@@ -36,6 +36,10 @@
 #define AN_TIC()
 #define AN_TOC(bucket)
 #endif
+#ifndef AN_FN           /* out of line: inlined into the kernels (-DAN_FN=WV_DEV) the analysis' live ranges push the frame's own code into more spills -- measured on the MI355X:
+                           1.316 M frames/s and 368 KB / frame of HBM traffic inlined against 1.371 M and 300 KB out of line (profiles/r03_c) */
+#define AN_FN WV_DEVN
+#endif
 #define AN_SCRATCH_WORDS 480          /* per-wave HBM words the analysis borrows (the second half of a frame's decimated input, until the window has read the old one) */
 
 struct AnLds {
@@ -132,7 +136,7 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
 
 /* tonality_analysis (src/analysis.c:445): up to 20 ms of input; when 30 ms at 24 kHz have accumulated, one analysis frame -> A->info[write_pos++].
  * gscratch: AN_SCRATCH_WORDS of per-wave HBM.  Every argument is wave-uniform. */
-WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *pcm, const i32 *apcm, int len, int offset, int C, int Fs, int lsb_depth, i32 *gscratch)
+AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *pcm, const i32 *apcm, int len, int offset, int C, int Fs, int lsb_depth, i32 *gscratch)
 {
    const int lane = wv_lane();
    const int N = 480, N2 = 240;
@@ -487,7 +491,7 @@ WV_DEVN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16
 
 /* tonality_get_info (src/analysis.c:232): the info the encoder uses for a frame of `len` samples -- the stored one at the read position, with tonality and bandwidth
  * widened over the neighbours and the music probability turned into switching thresholds over the look-ahead.  Lane 0 on an LDS copy of the ring's four fields. */
-WV_DEVN void an_get_info_wave(WV_LDS AnLds *W, OaAnalysis *A, OaAnalysisInfo *info_out, int len, int Fs)
+AN_FN void an_get_info_wave(WV_LDS AnLds *W, OaAnalysis *A, OaAnalysisInfo *info_out, int len, int Fs)
 {
    const int lane = wv_lane();
    wv_sync();

@@ -27,7 +27,7 @@ def build_reftests(flavour):
     or the product library (flavour 'gpu', rpath relative so that the binaries travel to the GPU box).  Outputs under oracle/_ref/reftests/."""
     out = os.path.join(ROOT, "oracle/_ref/reftests", flavour); os.makedirs(out, exist_ok=True)
     if flavour == "emu": lib = ["-L" + os.path.join(ROOT, "tests/emu"), "-lopus_amd_emu", "-Wl,-rpath," + os.path.join(ROOT, "tests/emu")]; build_emu_lib()
-    elif flavour == "ref": lib = ["-L" + os.path.join(ROOT, "oracle/_ref"), "-l:libopus_ref_fx.so", "-Wl,-rpath,$ORIGIN/../.."]          # the reference's own library: the comparison side of the opus_demo tests
+    elif flavour == "ref": lib = ["-L" + os.path.join(ROOT, "oracle/_ref"), "-l:libopus_ref_fxa.so", "-Wl,-rpath,$ORIGIN/../.."]         # the reference's own library (fixed-point, float API on: the default build): the comparison side of the opus_demo tests
     else: lib = ["-L" + os.path.join(ROOT, "opus_amd"), "-lopus_amd", "-Wl,-rpath,$ORIGIN/../../../../opus_amd"]
     if not os.path.isdir(REF): return out
     for name, srcs in REFTESTS.items():

@@ -8,13 +8,16 @@ import os, subprocess, pytest
 import hostemu
 ROOT = hostemu.ROOT
 LONG = os.environ.get("OPUS_AMD_LONG_TESTS") == "1"
+# these programs run the library the way a user gets it: the tonality / music analysis on (opus_demo's default complexity is 10), whatever the rest of the session uses;
+# the comparison side of the opus_demo tests is linked against the reference built with its float API (libopus_ref_fxa.so)
+ENV = dict(os.environ, OPUS_AMD_FLOAT_ANALYSIS="1")
 
 def _run(flavour, name, timeout, args=()):
     exe = os.path.join(ROOT, "oracle/_ref/reftests", flavour, name)
     if not os.path.exists(exe):
         if not os.path.isdir(hostemu.REF): pytest.skip("reference test binaries not built and /root/reference absent")
         hostemu.build_reftests(flavour)
-    p = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=dict(os.environ, SEED="20260922"))
+    p = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=dict(ENV, SEED="20260922"))
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
     return p.stdout.decode(errors="replace")
 
@@ -41,7 +44,7 @@ def test_gpu_test_opus_decode_and_encode():
     def go(name, env):
         try:
             exe = os.path.join(ROOT, "oracle/_ref/reftests/gpu", name)
-            p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=3000 if LONG else 1500, env=dict(os.environ, SEED="20260922", **env))
+            p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=3000 if LONG else 1500, env=dict(ENV, SEED="20260922", **env))
             res[name] = (p.returncode, p.stdout.decode(errors="replace")[-2000:])
         except Exception as ex: res[name] = (-1, repr(ex))
     if not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/gpu/test_opus_decode")):
@@ -70,9 +73,9 @@ def _opus_demo_roundtrip(flavour, tmp_path, args, Fs, ch, seconds=1.0):
     for fl in (flavour, "ref"):
         exe = os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")
         bit = tmp_path / (fl + ".bit"); dec = tmp_path / (fl + ".dec")
-        p = subprocess.run([exe, "-e"] + list(args) + [str(pcm), str(bit)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        p = subprocess.run([exe, "-e"] + list(args) + [str(pcm), str(bit)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=ENV)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
-        p = subprocess.run([exe, "-d", str(Fs), str(ch), str(bit), str(dec)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        p = subprocess.run([exe, "-d", str(Fs), str(ch), str(bit), str(dec)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=ENV)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
         outs[fl] = (bit.read_bytes(), dec.read_bytes())
     assert len(outs["ref"][0]) > 1000
@@ -116,7 +119,7 @@ def _opus_demo_codec(flavour, tmp_path, Fs, ch, args, seconds):
     outs = []
     for fl in (flavour, "ref"):
         o = tmp_path / (fl + ".pcm")
-        p = subprocess.run([os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")] + list(args) + [str(pcm), str(o)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        p = subprocess.run([os.path.join(ROOT, "oracle/_ref/reftests", fl, "opus_demo")] + list(args) + [str(pcm), str(o)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=ENV)
         assert p.returncode == 0, (fl, p.stdout.decode(errors="replace")[-1500:])
         outs.append(o.read_bytes())
     assert len(outs[1]) > 1000 and outs[0] == outs[1], "decoded PCM differs"
