@@ -111,7 +111,17 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
       WV_LDS i32 *p = lane == 0 ? W->fft : lane == 1 ? W->fft + 1 : W->hbuf;
       const int stride = lane == 2 ? 1 : 2;
       i32 s = A->downmix_state[lane];
-      for (int k = 0; k < len2; k++) {
+      int k = 0;
+      for (; k + 8 <= len2; k += 8) {                            /* eight samples per trip: the LDS reads of a trip are issued back to back, only the chain through s is serial */
+         i32 x[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) { x[u] = p[(k + u) * stride]; if (lane == 2) x[u] = neg32(x[u]); }
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const i32 X = mult16_32_q15(c, sub32(x[u], s)); const i32 o = add32(s, X); s = add32(x[u], X); x[u] = o; }
+#pragma unroll
+         for (int u = 0; u < 8; u++) p[(k + u) * stride] = x[u];
+      }
+      for (; k < len2; k++) {
          i32 in32 = p[k * stride];
          if (lane == 2) in32 = neg32(in32);
          const i32 X = mult16_32_q15(c, sub32(in32, s));

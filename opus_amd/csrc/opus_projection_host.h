@@ -84,7 +84,11 @@ static int oa_proj_encode(OpusProjectionEncoder *st, const opus_int16 *pcm16, co
          mixed[(size_t)i * C + r] = (opus_int16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v);
       }
    }
-   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, pcm16 ? 16 : 24);
+   /* the elementary encoders' analyses look at the caller's UN-mixed channels (opus_multistream_encode_native hands opus_encode_native the original pcm with the
+    * stream's channel indices, opus_multistream_encoder.c:1027), in the signal domain of the entry point (downmix_int / downmix_int24) */
+   std::vector<opus_int32> sig((size_t)frame_size * C);
+   for (size_t i = 0; i < sig.size(); i++) sig[i] = pcm16 ? (opus_int32)((opus_uint32)(opus_int32)pcm16[i] << 12) : (opus_int32)((opus_uint32)pcm24[i] << 4);
+   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, pcm16 ? 16 : 24, sig.data());
 }
 int opus_projection_encode(OpusProjectionEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 { return pcm ? oa_proj_encode(st, pcm, NULL, frame_size, data, max_data_bytes) : OPUS_BAD_ARG; }
@@ -102,7 +106,9 @@ int opus_projection_encode_float(OpusProjectionEncoder *st, const float *pcm, in
       for (int c = 0; c < C; c++) acc += m->data[m->rows * c + r] * pcm[(size_t)i * C + c];
       mixed[(size_t)i * C + r] = oa_float2int16((1 / 32768.f) * acc);
    }
-   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, 24);
+   std::vector<opus_int32> sig((size_t)frame_size * C);                                    /* (the analyses see the un-mixed input: downmix_float) */
+   for (size_t i = 0; i < sig.size(); i++) sig[i] = oa_float2sig(pcm[i]);
+   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, 24, sig.data());
 }
 void opus_projection_encoder_destroy(OpusProjectionEncoder *st) { free(st); }
 int opus_projection_encoder_ctl(OpusProjectionEncoder *st, int request, ...)

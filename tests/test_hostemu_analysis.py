@@ -151,3 +151,39 @@ def test_multistream_with_analysis():
             L.opus_multistream_encoder_destroy(e); out.append(seq)
         bad = [i for i in range(38) if out[0][i] != out[1][i]]
         assert not bad, (app, bad[:5])
+
+def test_multistream_float_and_projection_with_analysis():
+    """the float entry point of the multistream encoder hands every elementary analysis its channels un-rounded; a projection (ambisonics) encoder's analyses look at the
+    caller's un-mixed channels (opus_multistream_encoder.c:1027 passes the original pcm with the stream's channel indices)"""
+    R, E = capi.load("ref_fxa"), capi.load(WHICH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    Fs = 48000
+    rng = np.random.default_rng(41)
+    base = np.concatenate([music(Fs, 2, 960 * 30, 40), sig_for(Fs, 2, 960 * 30, 42)], axis=1).astype(np.float64)          # 4 channels
+    fine = ((base + rng.uniform(-0.5, 0.5, base.shape)) / 32768.0).astype(np.float32)
+    for kind in ("ms_float", "projection"):
+        out = []
+        for L in (R, E):
+            err = ci()
+            if kind == "ms_float":
+                L.opus_multistream_encoder_create.restype = vp
+                L.opus_multistream_encoder_create.argtypes = [ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+                e = L.opus_multistream_encoder_create(Fs, 4, 3, 1, bytes([0, 1, 2, 3]), 2049, ctypes.byref(err))
+                ctl, enc, destroy = L.opus_multistream_encoder_ctl, L.opus_multistream_encode_float, L.opus_multistream_encoder_destroy
+            else:
+                streams, coupled = ci(), ci()
+                L.opus_projection_ambisonics_encoder_create.restype = vp
+                L.opus_projection_ambisonics_encoder_create.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
+                e = L.opus_projection_ambisonics_encoder_create(Fs, 4, 3, ctypes.byref(streams), ctypes.byref(coupled), 2049, ctypes.byref(err))
+                ctl, enc, destroy = L.opus_projection_encoder_ctl, L.opus_projection_encode_float, L.opus_projection_encoder_destroy
+            assert e and err.value == 0, (kind, err.value)
+            ctl.argtypes = [vp, ci, ci]; enc.argtypes = [vp, vp, ci, vp, ci]; destroy.argtypes = [vp]; destroy.restype = None
+            assert ctl(e, 4010, 10) == 0 and ctl(e, 4002, 160000) == 0
+            if L is E: assert ctl(e, FLOAT_ANALYSIS, 1) == 0
+            buf = (ctypes.c_ubyte * 4000)(); seq = []
+            for i in range(28):
+                p = np.ascontiguousarray(fine[i * 960:(i + 1) * 960])
+                n = enc(e, p.ctypes.data, 960, buf, 4000); seq.append(bytes(buf[:max(n, 0)]) if n > 0 else n)
+            destroy(e); out.append(seq)
+        bad = [i for i in range(28) if out[0][i] != out[1][i]]
+        assert not bad, (kind, bad[:5], [type(x) for x in out[1][:3]])
