@@ -522,7 +522,7 @@ WV_DEV BandCfg cfg_uni(BandCfg c)
 WV_DEV i32 cache_row_load(int band, int LM)
 {
    const int off = ct_cache_index[(LM + 1) * OA_NB_EBANDS + band];
-   return (i32)ct_cache_bits[off + imin(wv_lane(), 40)];
+   return (i32)ct_cache_bits[imin(off + imin(wv_lane(), 40), (int)sizeof(ct_cache_bits) - 1)];      /* (the last rows are shorter than 41 entries: the lanes beyond a row's end read values nobody uses, but stay inside the table) */
 }
 WV_DEV int row_bits2pulses(i32 row, int bits)
 {

@@ -40,6 +40,27 @@ static int oa_validate_ambisonics(int nb_channels, int *nb_streams, int *nb_coup
    return 1;
 }
 
+/* n records of `width` bytes, `hpitch` apart in the host blob <-> the contiguous device array: packed through one host buffer so that the transfer itself is one plain
+ * contiguous hipMemcpy (a pitched copy from / to pageable host memory goes through the runtime's rectangle path; on the MI355X box a long series of such copies --
+ * the reference's regression tests with 255-stream encoders -- ended in a GPU memory fault inside one of the runtime's own copy kernels, which never happens with
+ * contiguous copies or with AMD_SERIALIZE_COPY=3) */
+static int oa_rows_upload(void *d, const void *h, size_t hpitch, size_t width, int n)
+{
+   if (n == 1) { HIPCHECK(hipMemcpy(d, h, width, hipMemcpyHostToDevice)); return OPUS_OK; }
+   std::vector<char> tmp(width * (size_t)n);
+   for (int i = 0; i < n; i++) memcpy(tmp.data() + (size_t)i * width, (const char *)h + (size_t)i * hpitch, width);
+   HIPCHECK(hipMemcpy(d, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+   return OPUS_OK;
+}
+static int oa_rows_download(void *h, size_t hpitch, const void *d, size_t width, int n)
+{
+   if (n == 1) { HIPCHECK(hipMemcpy(h, d, width, hipMemcpyDeviceToHost)); return OPUS_OK; }
+   std::vector<char> tmp(width * (size_t)n);
+   HIPCHECK(hipMemcpy(tmp.data(), d, tmp.size(), hipMemcpyDeviceToHost));
+   for (int i = 0; i < n; i++) memcpy((char *)h + (size_t)i * hpitch, tmp.data() + (size_t)i * width, width);
+   return OPUS_OK;
+}
+
 /* process-wide batches, one per (stream count, channels) */
 static std::mutex g_ms_mu;
 static std::map<long, OpusGpuEncBatch *> g_ms_enc;
@@ -235,8 +256,7 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   if (kind) HIPCHECK(hipMemcpy2D(b->d_sh, sizeof(OaShStream), &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), (size_t)n, hipMemcpyHostToDevice));
-   else HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaStream), &states[0].s, sizeof(OaMsRec), sizeof(OaStream), (size_t)n, hipMemcpyHostToDevice));
+   { const int ru = kind ? oa_rows_upload(b->d_sh, &states[0].sh, sizeof(OaMsRec), sizeof(OaShStream), n) : oa_rows_upload(b->d_streams, &states[0].s, sizeof(OaMsRec), sizeof(OaStream), n); if (ru != OPUS_OK) return ru; }
    /* the batch is shared by every multistream encoder of this shape: what the host side of a launch derives from its mirror of the configuration (the frame sizes
     * the application accepts, whether the launch can skip the CELT arena) must follow the records just uploaded, not the encoder the batch was created for */
    b->application = application;
@@ -244,9 +264,7 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = states[i].s.cfg;
    int r = opusgpu_encode_batch_sig(b, pcm, apcm, frame_size, out, stride, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
-   if (kind) HIPCHECK(hipMemcpy2D(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), sizeof(OaShStream), (size_t)n, hipMemcpyDeviceToHost));
-   else HIPCHECK(hipMemcpy2D(&states[0].s, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), sizeof(OaStream), (size_t)n, hipMemcpyDeviceToHost));
-   return OPUS_OK;
+   return kind ? oa_rows_download(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), n) : oa_rows_download(&states[0].s, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), n);
 }
 
 /* opus_multistream_encode_native, opus_multistream_encoder.c:841 (int16 samples; depth = 16 or 24: the lsb_depth of the entry point) */
@@ -471,11 +489,10 @@ static int oa_ms_decode_group(OpusDecoder *states, int n, int ch, const unsigned
    if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   HIPCHECK(hipMemcpy2D(b->d_streams, sizeof(OaDecStream), &states[0].s, sizeof(OpusDecoder), sizeof(OaDecStream), (size_t)n, hipMemcpyHostToDevice));
+   { const int ru = oa_rows_upload(b->d_streams, &states[0].s, sizeof(OpusDecoder), sizeof(OaDecStream), n); if (ru != OPUS_OK) return ru; }
    int r = opusgpu_decode_batch(b, pk, stride, lens, pcm, frame_size, ns_out, rngs);
    if (r != OPUS_OK) return r;
-   HIPCHECK(hipMemcpy2D(&states[0].s, sizeof(OpusDecoder), b->d_streams, sizeof(OaDecStream), sizeof(OaDecStream), (size_t)n, hipMemcpyDeviceToHost));
-   return OPUS_OK;
+   return oa_rows_download(&states[0].s, sizeof(OpusDecoder), b->d_streams, sizeof(OaDecStream), n);
 }
 /* opus_multistream_decode_native, opus_multistream_decoder.c:178 (int16 output) */
 int opus_multistream_decode(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec)
