@@ -343,9 +343,9 @@ def main():
             ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
             traffic = None; issue = None
             try:
-                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")))["config_%d" % r["config_id"]]
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json" if NO_ANALYSIS else "pmc_traffic_r03.json")))["config_%d" % r["config_id"]]
                 if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
-                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (rocprofv3 --pmc passes at build r02_final3; the builds after it moved lane-0 analysis stages onto the wave and were not re-counted)"}
+                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (rocprofv3 --pmc passes at build r02_final3, no analysis)" if NO_ANALYSIS else "profiles/pmc_traffic_r03.json (rocprofv3 --pmc passes at build r03_b, analysis on; configs 3 / 4: round-2 counters)"}
             except Exception: pass
             return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
                     "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),
@@ -356,7 +356,7 @@ def main():
             "metric": main_res["metric"] if a.decode else (CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"), "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic" if a.corpus == "pool" else "synthetic (the reference's generate_music() tunes, tests/test_opus_encode.c:57)",
-            "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point", "baseline_config": a.config,
+            "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point" + (" (with the tonality / music analysis of the float API, as the reference's default build)" if main_res.get("float_analysis") else " (no float API: like a reference built with DISABLE_FLOAT_API)"), "baseline_config": a.config, "float_analysis": bool(main_res.get("float_analysis")),
                        "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather of the compacted packets in the timed region" if world > 1 else "")},
             "roofline": roof(main_res, S),

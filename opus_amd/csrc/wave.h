@@ -115,8 +115,14 @@ WV_DEV uint64_t wv_ballot(int pred) { return __ballot(pred); }
 /* inclusive prefix sum over lanes */
 WV_DEV int32_t wv_scan_incl(int32_t v)
 {
-   int l = wv_lane();
-   for (int o = 1; o < 64; o <<= 1) { int32_t t = __shfl_up(v, o, 64); if (l >= o) v += t; }
+   /* on the DPP network like the reductions above: shifts by 1, 2, 4, 8 inside each row of 16 lanes (lanes without a source add 0), then the totals of the rows
+    * below are broadcast up (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six adds, no LDS crossbar */
+   v += WV_DPP(0, v, 0x111, 0xf);
+   v += WV_DPP(0, v, 0x112, 0xf);
+   v += WV_DPP(0, v, 0x114, 0xf);
+   v += WV_DPP(0, v, 0x118, 0xf);
+   v += WV_DPP(0, v, WV_DPP_BCAST15, 0xa);
+   v += WV_DPP(0, v, WV_DPP_BCAST31, 0xc);
    return v;
 }
 /* PVQ greedy-search arg-max: maximise num/den (den > 0, exact 16x16 cross products), lowest index wins ties.
