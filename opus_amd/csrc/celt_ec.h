@@ -10,20 +10,11 @@ struct EcCtx { u32 storage, end_offs, end_window; i32 nend_bits, nbits_total; u3
  * plus the byte stores into the LDS packet. */
 #define EC_ARGS EcCtx *e, WV_LDS u8 *buf
 #define EC_PASS e, buf
-#ifdef OA_EC_SCALAR       /* experiment: the coder state of a lane-0 section in scalar registers (v_readfirstlane after the LDS reads), so that its arithmetic runs on the scalar unit */
-#define EC_U(x) ((u32)wv_uni((i32)(x)))
-WV_DEV void ec_ld(EcCtx *d, const WV_LDS EcCtx *s)
-{
-   d->storage = EC_U(s->storage); d->end_offs = EC_U(s->end_offs); d->end_window = EC_U(s->end_window); d->nend_bits = wv_uni(s->nend_bits); d->nbits_total = wv_uni(s->nbits_total);
-   d->offs = EC_U(s->offs); d->rng = EC_U(s->rng); d->val = EC_U(s->val); d->ext = EC_U(s->ext); d->rem = wv_uni(s->rem); d->error = wv_uni(s->error);
-}
-#else
 WV_DEV void ec_ld(EcCtx *d, const WV_LDS EcCtx *s)
 {
    d->storage = s->storage; d->end_offs = s->end_offs; d->end_window = s->end_window; d->nend_bits = s->nend_bits; d->nbits_total = s->nbits_total;
    d->offs = s->offs; d->rng = s->rng; d->val = s->val; d->ext = s->ext; d->rem = s->rem; d->error = s->error;
 }
-#endif
 WV_DEV void ec_st(WV_LDS EcCtx *d, const EcCtx *s)
 {
    d->storage = s->storage; d->end_offs = s->end_offs; d->end_window = s->end_window; d->nend_bits = s->nend_bits; d->nbits_total = s->nbits_total;
