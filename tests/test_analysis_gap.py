@@ -1,8 +1,9 @@
-"""Where the build this port is bit-exact to (FIXED_POINT + DISABLE_FLOAT_API) and the fixed-point build users get by default (float API on: src/analysis.c + mlp.c
-steer the encoder) agree and where they do not -- both sides are the compiled reference (oracle/_ref/libopus_ref_fx.so vs libopus_ref_fxa.so), tools/analysis_gap.py.
-The forced SILK-only (BASELINE config 3) and forced hybrid (config 4) encoders and an unforced VOIP encoder produce IDENTICAL packets with and without the analysis:
-for those the parity this repo proves against the no-float-API library is parity with the deployed fixed-point library as well.  CELT-coded frames at complexity 10 (the
-FIXED_POINT build runs the analysis at complexity 10 only, src/opus_encoder.c:1249; config 2, unforced AUDIO) differ: that is the row DESIGN.md section 8 lists next."""
+"""Where the reference built with DISABLE_FLOAT_API (oracle/_ref/libopus_ref_fx.so, what the plain-C restatement follows) and the fixed-point build users get by
+default (float API on: src/analysis.c + mlp.c steer the encoder, libopus_ref_fxa.so) agree and where they do not -- both sides are the compiled reference,
+tools/analysis_gap.py.  The forced SILK-only (BASELINE config 3) and forced hybrid (config 4) encoders and an unforced VOIP encoder produce IDENTICAL packets with and
+without the analysis; CELT-coded frames at complexity 10 (the FIXED_POINT build runs the analysis at complexity 10 only, src/opus_encoder.c:1249; config 2, unforced
+AUDIO) differ.  The product runs the analysis on the device since round 3 (opus_amd/csrc/opus_analysis.h, tests/test_hostemu_analysis.py, tests/test_gpu_analysis.py);
+this file keeps the map of which configurations it matters for, and pins the frame-by-frame analysis oracle (oracle/ref_expose_fxa) those suites lean on."""
 import os, sys, pytest
 from reflib import ref_fx, ROOT
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -33,9 +34,9 @@ def _analyse(sig, Fs, ch, frames):
     return out
 
 def test_analysis_oracle_runs_frame_by_frame():
-    """the oracle the device analysis will be checked against (oracle/ref_expose_fxa): the compiled reference's run_analysis on the encoder's int16 input, one
-    AnalysisInfo per 20 ms frame.  Pinned here only as far as it can be without a device implementation: deterministic, valid after the first frames, and telling
-    this repo's music corpus from its speech corpus the way the encoder's mode decision needs it to."""
+    """the oracle the device analysis is checked against field by field (tests/test_kernel_emu_analysis.py): the compiled reference's run_analysis on the encoder's
+    int16 input, one AnalysisInfo per 20 ms frame.  Pinned here on its own: deterministic, valid after the first frames, and telling this repo's music corpus from
+    its speech corpus the way the encoder's mode decision needs it to."""
     import numpy as np, signals
     from test_kernel_emu_silkdec import speechy
     m = _analyse(signals.music(60, seed=3), 48000, 2, 60); m2 = _analyse(signals.music(60, seed=3), 48000, 2, 60)
