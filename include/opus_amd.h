@@ -152,6 +152,10 @@ OPUS_AMD_EXPORT int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_in
 OPUS_AMD_EXPORT int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid);
 /* ... and what the tonality analysis adds to that when it runs (complexity 10, API rate >= 16 kHz, float analysis on) */
 OPUS_AMD_EXPORT int opusgpu_enc_analysis_moved_bytes(void);
+/* the classic entry points under concurrent callers (include/opus.h:425-429 allows any number of threads on different states): calls that arrive while a launch is in
+ * flight share the next launch, one wave per call (opus_amd/csrc/opus_call_combiner.h; at most OPUS_AMD_CLASSIC_BATCH states per launch, default 256).
+ * out = {opus_encode* calls, launches that served them, opus_decode* calls, launches that served them} since the library was loaded */
+OPUS_AMD_EXPORT void opusgpu_classic_call_stats(long long out[4]);
 /* memcpy contract: a stream's complete state as a flat blob (same layout as the classic OpusEncoder payload) */
 OPUS_AMD_EXPORT int opusgpu_enc_state_size(void);
 /* record size / LDS per wave of the SILK-capable encoder (batches created with OPUS_APPLICATION_VOIP / _AUDIO / _RESTRICTED_SILK; src/opus_encoder.c:76-146 + silk/fixed/structs_FIX.h:108) */

@@ -36,6 +36,7 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #include <stdio.h>
 #include <mutex>
 #include <vector>
+#include "opus_call_combiner.h"
 
 /* The encoder kernels are persistent: the launch fills the chip once (grid = resident waves, opusgpu host code), every wave pops stream indices from a
  * device-side queue until it is empty.  Streams cost different amounts (transients, VBR), so the queue balances what a static blockIdx -> stream map
@@ -167,6 +168,7 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    int device;
    opus_int32 S;
+   opus_int32 n_act;                     /* streams a call processes: the first n_act records (== S except under the classic API's call combiner) */
    int channels;
    hipStream_t stream;
    OaStream *d_streams;
@@ -209,7 +211,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
@@ -337,7 +339,7 @@ static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds
    long long grid = (long long)per_cu * (b->num_cu > 0 ? b->num_cu : 1);
    static const int grid_env = getenv("OPUS_AMD_GRID") ? atoi(getenv("OPUS_AMD_GRID")) : 0;                 /* experiments only */
    if (grid_env > 0) grid = grid_env;
-   if (grid > b->S) grid = b->S;
+   if (grid > b->n_act) grid = b->n_act;
    const size_t need = (size_t)grid * scratch_per_wave;
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, sizeof(unsigned), s));
@@ -360,7 +362,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
        * CELT arena and gets the smaller LDS footprint (one more wave per CU) */
       if (b->cfg_dirty) {
          int pinned = 1;
-         for (opus_int32 i = 0; pinned && i < b->S; i++) {
+         for (opus_int32 i = 0; pinned && i < b->n_act; i++) {
             const OaShConfig &c = b->h_sh[i].cfg;
             pinned = c.application == OPUS_APPLICATION_RESTRICTED_SILK || (c.user_forced_mode == OPUS_MODE_SILK_ONLY && !c.lfe && (b->Fs <= 16000 || (c.user_bandwidth != OPUS_AUTO && c.user_bandwidth <= OPUS_BANDWIDTH_WIDEBAND) || c.max_bandwidth <= OPUS_BANDWIDTH_WIDEBAND));
          }
@@ -371,7 +373,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds, s,
-            b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, b->d_queue);
+            b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }
@@ -379,7 +381,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->S, (CeltScratch *)b->d_scratch, b->d_queue);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -462,7 +464,7 @@ int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const op
    if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
    { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    HIPCHECK(hipSetDevice(b->device));
-   size_t npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->S * out_stride;
+   size_t npcm = (size_t)b->n_act * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->n_act * out_stride;
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
    if (nout > b->out_cap) { if (b->d_out) (void)hipFree(b->d_out); HIPCHECK(hipMalloc((void **)&b->d_out, nout)); b->out_cap = nout; }
    HIPCHECK(hipMemcpyAsync(b->d_pcm, pcm, npcm, hipMemcpyHostToDevice, b->stream));
@@ -473,8 +475,8 @@ int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const op
    int r = opusgpu_encode_batch_dev_sig(b, b->d_pcm, apcm ? b->d_apcm : nullptr, frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
    if (r != OPUS_OK) return r;
    HIPCHECK(hipMemcpyAsync(out, b->d_out, nout, hipMemcpyDeviceToHost, b->stream));
-   HIPCHECK(hipMemcpyAsync(lens, b->d_lens, sizeof(opus_int32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
-   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipMemcpyAsync(lens, b->d_lens, sizeof(opus_int32) * (size_t)b->n_act, hipMemcpyDeviceToHost, b->stream));
+   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->n_act, hipMemcpyDeviceToHost, b->stream));
    HIPCHECK(hipStreamSynchronize(b->stream));
    return OPUS_OK;
 }
@@ -482,8 +484,24 @@ int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const op
 /* ---------------- classic libopus encoder API on top of a process-wide batch-of-one ---------------- */
 #define OA_MAGIC 0x4f41454eu /* "OAEN" */
 struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pad[2]; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
-static std::mutex g_classic_mu;
-static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][API rate][channels - 1] */
+static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][API rate][channels - 1]: created by the first call of that shape, used by one launch at a time */
+/* one classic call waiting for (or leading) a launch: opus_call_combiner.h */
+struct OaEncCall {
+   OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
+   int frame_size, application, channels; opus_int32 Fs, max_data_bytes;
+   int ret; bool done;
+   bool same_launch(const OaEncCall &o) const
+   {
+      return st != o.st && st->kind == o.st->kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
+          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr);
+   }
+};
+static OaCallCombiner<OaEncCall> g_enc_calls;
+static int oa_classic_cap()      /* states one launch of the classic API carries at most (the device arrays of a shape are sized for it once) */
+{
+   static const int cap = getenv("OPUS_AMD_CLASSIC_BATCH") && atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) > 0 ? atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) : 256;
+   return cap;
+}
 static int oa_fs_index(opus_int32 Fs) { return Fs == 8000 ? 0 : Fs == 12000 ? 1 : Fs == 16000 ? 2 : Fs == 24000 ? 3 : 4; }
 
 int opus_encoder_get_size(int channels) { if (channels < 1 || channels > 2) return 0; return (int)sizeof(OpusEncoder); }
@@ -506,7 +524,61 @@ OpusEncoder *opus_encoder_create(opus_int32 Fs, int channels, int application, i
    return st;
 }
 void opus_encoder_destroy(OpusEncoder *st) { free(st); }
-/* one frame of one classic encoder: the record goes to the device, the kernel runs a batch of one, the record comes back.  depth = the sample depth
+/* one launch for a group of classic calls of one shape: their records go to the first n slots of the shape's batch, the kernel runs n waves, the records come back */
+static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
+{
+   const OaEncCall &h = *g[0];
+   const int n = (int)g.size(), kind = (int)h.st->kind;
+   OpusGpuEncBatch **slot = &g_classic[kind][oa_fs_index(h.Fs)][h.channels - 1];
+   if (!*slot) {
+      int err;
+      *slot = opusgpu_enc_batch_create(oa_classic_cap(), h.Fs, h.channels, kind ? OPUS_APPLICATION_AUDIO : OPUS_APPLICATION_RESTRICTED_LOWDELAY, 0, &err);
+      if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   }
+   OpusGpuEncBatch *b = *slot;
+   b->application = h.application; b->n_act = n;
+   opus_int32 stride = oa_enc_out_stride_needed(h.Fs, h.frame_size, h.max_data_bytes) + 8;
+   if (stride < 1288) stride = 1288;
+   const size_t per = (size_t)h.frame_size * h.channels, rec = kind ? sizeof(OaShStream) : sizeof(OaStream);
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   const opus_int16 *pcm = h.pcm; const opus_int32 *apcm = h.apcm;
+   std::vector<opus_int16> pcm_all; std::vector<opus_int32> apcm_all; std::vector<char> recs;
+   if (n > 1) {                                                            /* inputs and records of the group side by side: one contiguous transfer each */
+      pcm_all.resize(per * n); recs.resize(rec * (size_t)n);
+      if (apcm) apcm_all.resize(per * n);
+      for (int i = 0; i < n; i++) {
+         memcpy(pcm_all.data() + per * i, g[i]->pcm, per * sizeof(opus_int16));
+         if (apcm) memcpy(apcm_all.data() + per * i, g[i]->apcm, per * sizeof(opus_int32));
+         memcpy(recs.data() + rec * i, kind ? (const void *)&g[i]->st->sh : (const void *)&g[i]->st->s, rec);
+      }
+      pcm = pcm_all.data(); if (apcm) apcm = apcm_all.data();
+   }
+   const void *rec_src = n > 1 ? (const void *)recs.data() : kind ? (const void *)&h.st->sh : (const void *)&h.st->s;
+   HIPCHECK(hipMemcpy(kind ? (void *)b->d_sh : (void *)b->d_streams, rec_src, rec * (size_t)n, hipMemcpyHostToDevice));
+   if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = g[i]->st->sh.cfg; b->cfg_dirty = true; }     /* the launch's host-side decisions follow the records it carries */
+   else for (int i = 0; i < n; i++) b->h_streams[i].cfg = g[i]->st->s.cfg;
+   std::vector<unsigned char> out((size_t)stride * n);
+   std::vector<opus_int32> lens((size_t)n); std::vector<opus_uint32> rng((size_t)n);
+   int r = opusgpu_encode_batch_sig(b, pcm, apcm, h.frame_size, out.data(), stride, h.max_data_bytes, lens.data(), rng.data());
+   if (r != OPUS_OK) return r;
+   if (n > 1) {
+      HIPCHECK(hipMemcpy(recs.data(), kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec * (size_t)n, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) memcpy(kind ? (void *)&g[i]->st->sh : (void *)&g[i]->st->s, recs.data() + rec * i, rec);
+   } else HIPCHECK(hipMemcpy(kind ? (void *)&h.st->sh : (void *)&h.st->s, kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec, hipMemcpyDeviceToHost));
+   for (int i = 0; i < n; i++) {
+      const opus_int32 len = lens[i];
+      if (len > 0) memcpy(g[i]->data, out.data() + (size_t)stride * i, (size_t)(len < h.max_data_bytes ? len : h.max_data_bytes));
+      g[i]->ret = len;
+   }
+   return OPUS_OK;
+}
+static void oa_classic_encode_group(std::vector<OaEncCall *> &g)
+{
+   const int r = oa_classic_encode_group_run(g);
+   if (r != OPUS_OK) for (OaEncCall *c : g) c->ret = r;
+}
+/* one frame of one classic encoder: the record goes to the device, the kernel runs one wave for it (and one for every other call waiting with it), the record comes back.  depth = the sample depth
  * of the entry point (opus_encode 16, opus_encode24 / _float 24: the lsb_depth argument of opus_encode_native, src/opus_encoder.c:2667,:2722) */
 static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth, const opus_int32 *apcm = nullptr)
 {
@@ -515,26 +587,11 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    const opus_int32 Fs = st->kind ? st->sh.cfg.Fs : st->s.Fs;
    const int frame_size = (int)oa_frame_size_select(application, analysis_frame_size, st->kind ? st->sh.cfg.variable_duration : st->s.cfg.variable_duration, Fs);
    if (frame_size <= 0 || max_data_bytes <= 0) return OPUS_BAD_ARG;
-   std::lock_guard<std::mutex> lock(g_classic_mu);
-   OpusGpuEncBatch **slot = &g_classic[st->kind][oa_fs_index(Fs)][channels - 1];
-   if (!*slot) {
-      int err;
-      *slot = opusgpu_enc_batch_create(1, Fs, channels, st->kind ? OPUS_APPLICATION_AUDIO : OPUS_APPLICATION_RESTRICTED_LOWDELAY, 0, &err);
-      if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
-   }
-   OpusGpuEncBatch *b = *slot;
-   b->application = application;
+   { const int fr = oa_enc_frame_size_code(Fs, application, frame_size); if (fr != OPUS_OK) return fr; }
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   const opus_int32 stride = oa_enc_out_stride_needed(Fs, frame_size, max_data_bytes) + 8;
-   std::vector<unsigned char> buf((size_t)(stride < 1288 ? 1288 : stride));
-   opus_int32 len = 0; opus_uint32 rng = 0;
-   void *blob = st->kind ? (void *)&st->sh : (void *)&st->s;
-   int r = opusgpu_enc_batch_import_state(b, 0, blob);
-   if (r == OPUS_OK) r = opusgpu_encode_batch_sig(b, pcm, apcm, frame_size, buf.data(), (opus_int32)buf.size(), max_data_bytes, &len, &rng);
-   if (r == OPUS_OK) r = opusgpu_enc_batch_export_state(b, 0, blob);
-   if (r != OPUS_OK) return r;
-   if (len > 0) memcpy(data, buf.data(), (size_t)(len < max_data_bytes ? len : max_data_bytes));
-   return len;
+   OaEncCall call = {st, pcm, apcm, data, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false};
+   g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_encode_group);
+   return call.ret;
 }
 opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 {
@@ -651,7 +708,7 @@ static int oa_dec_init_stream(OaDecStream *st, opus_int32 Fs, int channels)
    return OPUS_OK;
 }
 struct OpusGpuDecBatch {
-   int device; opus_int32 S; int channels; opus_int32 Fs; int decode_fec; hipStream_t stream;
+   int device; opus_int32 S; opus_int32 n_act /* as in the encoder batch */; int channels; opus_int32 Fs; int decode_fec; hipStream_t stream;
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
 };
@@ -691,7 +748,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuDecBatch();
-      b->device = device; b->S = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -748,9 +805,9 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    if (frame_size <= 0 || frame_size > 5760) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
-   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)b->S), dim3(64), sizeof(DecLds), s,
+   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)b->n_act), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-         (u32 *)d_final_range, (int)b->S, b->decode_fec);
+         (u32 *)d_final_range, (int)b->n_act, b->decode_fec);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -760,17 +817,17 @@ int opusgpu_decode_batch(OpusGpuDecBatch *b, const unsigned char *packets, opus_
    if (!b || !packets || !lens || !pcm || !nsamples || packet_stride <= 0) return OPUS_BAD_ARG;
    if (frame_size <= 0 || frame_size > 5760) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
-   size_t npkt = (size_t)b->S * packet_stride, npcm = (size_t)b->S * frame_size * b->channels * sizeof(opus_int16);
+   size_t npkt = (size_t)b->n_act * packet_stride, npcm = (size_t)b->n_act * frame_size * b->channels * sizeof(opus_int16);
    if (npkt > b->pkt_cap) { if (b->d_pkt) (void)hipFree(b->d_pkt); HIPCHECK(hipMalloc((void **)&b->d_pkt, npkt)); b->pkt_cap = npkt; }
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
    HIPCHECK(hipMemcpyAsync(b->d_pkt, packets, npkt, hipMemcpyHostToDevice, b->stream));
-   HIPCHECK(hipMemcpyAsync(b->d_lens, lens, sizeof(opus_int32) * (size_t)b->S, hipMemcpyHostToDevice, b->stream));
+   HIPCHECK(hipMemcpyAsync(b->d_lens, lens, sizeof(opus_int32) * (size_t)b->n_act, hipMemcpyHostToDevice, b->stream));
    HIPCHECK(hipMemsetAsync(b->d_pcm, 0, npcm, b->stream));
    int r = opusgpu_decode_batch_dev(b, b->d_pkt, packet_stride, b->d_lens, b->d_pcm, frame_size, b->d_ns, b->d_rng, nullptr);
    if (r != OPUS_OK) return r;
    HIPCHECK(hipMemcpyAsync(pcm, b->d_pcm, npcm, hipMemcpyDeviceToHost, b->stream));
-   HIPCHECK(hipMemcpyAsync(nsamples, b->d_ns, sizeof(opus_int32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
-   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->S, hipMemcpyDeviceToHost, b->stream));
+   HIPCHECK(hipMemcpyAsync(nsamples, b->d_ns, sizeof(opus_int32) * (size_t)b->n_act, hipMemcpyDeviceToHost, b->stream));
+   if (final_range) HIPCHECK(hipMemcpyAsync(final_range, b->d_rng, sizeof(opus_uint32) * (size_t)b->n_act, hipMemcpyDeviceToHost, b->stream));
    HIPCHECK(hipStreamSynchronize(b->stream));
    return OPUS_OK;
 }
@@ -793,14 +850,19 @@ int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, 
    return OPUS_OK;
 }
 
-/* ---- classic decoder API: flat host blob, batch of one per call (reference src/opus_decoder.c:121 get_size, :135 init, :186 create,
+/* ---- classic decoder API: flat host blob, one wave per call, concurrent calls share a launch (opus_call_combiner.h) (reference src/opus_decoder.c:121 get_size, :135 init, :186 create,
  *      :890 opus_decode, :1033 ctl, :1246 destroy) ---- */
 #define OA_DEC_MAGIC 0x4f414443u
 #define OPUS_SET_GAIN_REQUEST 4034
 #define OPUS_GET_GAIN_REQUEST 4045
 struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 decode_gain; opus_int32 pad[1]; OaDecStream s; };
-static std::mutex g_classic_dec_mu;
 static OpusGpuDecBatch *g_classic_dec[5][2];
+struct OaDecCall {
+   OpusDecoder *st; const unsigned char *data; opus_int32 len; opus_int16 *pcm; int frame_size, decode_fec;
+   int ret; bool done;
+   bool same_launch(const OaDecCall &o) const;
+};
+static OaCallCombiner<OaDecCall> g_dec_calls;
 int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
 int opus_decoder_init(OpusDecoder *st, opus_int32 Fs, int channels)
 {
@@ -843,6 +905,58 @@ static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
       pcm[i] = (opus_int16)(y > 32767 ? 32767 : y < -32767 ? -32767 : y);
    }
 }
+bool OaDecCall::same_launch(const OaDecCall &o) const
+{
+   return st != o.st && st->Fs == o.st->Fs && st->s.s.channels == o.st->s.s.channels && frame_size == o.frame_size && decode_fec == o.decode_fec;
+}
+/* one launch for a group of classic decode calls of one shape (rate, channels, output size, FEC flag): packets of any mode and length side by side, one wave each */
+static int oa_classic_decode_group_run(std::vector<OaDecCall *> &g)
+{
+   const OaDecCall &h = *g[0];
+   const int n = (int)g.size(), ch = h.st->s.s.channels, ci = ch - 1, fi = oa_fs_index(h.st->Fs);
+   if (!g_classic_dec[fi][ci]) {
+      int err;
+      g_classic_dec[fi][ci] = opusgpu_dec_batch_create(oa_classic_cap(), h.st->Fs, ch, 0, &err);
+      if (!g_classic_dec[fi][ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
+   }
+   OpusGpuDecBatch *b = g_classic_dec[fi][ci];
+   b->n_act = n; b->decode_fec = h.decode_fec;
+   opus_int32 stride = 8;
+   for (int i = 0; i < n; i++) if (g[i]->len + 8 > stride) stride = g[i]->len + 8;
+   std::vector<unsigned char> pkt((size_t)stride * n, 0);
+   std::vector<opus_int32> lens((size_t)n), ns((size_t)n); std::vector<opus_uint32> rng((size_t)n);
+   std::vector<char> recs(sizeof(OaDecStream) * (size_t)n);
+   for (int i = 0; i < n; i++) {
+      if (g[i]->len > 0) memcpy(pkt.data() + (size_t)stride * i, g[i]->data, (size_t)g[i]->len);
+      lens[i] = g[i]->len;
+      memcpy(recs.data() + sizeof(OaDecStream) * i, &g[i]->st->s, sizeof(OaDecStream));
+   }
+   const size_t per = (size_t)h.frame_size * ch;
+   std::vector<opus_int16> out(per * n);
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(b->d_streams, recs.data(), recs.size(), hipMemcpyHostToDevice));
+   int r = opusgpu_decode_batch(b, pkt.data(), stride, lens.data(), out.data(), h.frame_size, ns.data(), rng.data());
+   if (r != OPUS_OK) return r;
+   HIPCHECK(hipMemcpy(recs.data(), b->d_streams, recs.size(), hipMemcpyDeviceToHost));
+   for (int i = 0; i < n; i++) {
+      OpusDecoder *st = g[i]->st;
+      memcpy(&st->s, recs.data() + sizeof(OaDecStream) * i, sizeof(OaDecStream));
+      const opus_int32 m = ns[i];
+      if (m > 0) {
+         opus_int16 *o = out.data() + per * i;
+         if (st->decode_gain) oa_apply_decode_gain(o, m * ch, st->decode_gain);
+         memcpy(g[i]->pcm, o, (size_t)m * ch * sizeof(opus_int16));
+      }
+      g[i]->ret = m;
+   }
+   return OPUS_OK;
+}
+static void oa_classic_decode_group(std::vector<OaDecCall *> &g)
+{
+   const int r = oa_classic_decode_group_run(g);
+   if (r != OPUS_OK) for (OaDecCall *c : g) c->ret = r;
+}
 int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus_int16 *pcm, int frame_size, int decode_fec)
 {
    if (!st || st->magic != OA_DEC_MAGIC || !pcm) return OPUS_BAD_ARG;
@@ -863,25 +977,9 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
       return total;
    }
    if (frame_size > cap) frame_size = cap;
-   std::lock_guard<std::mutex> lock(g_classic_dec_mu);
-   const int ci = st->s.s.channels - 1, fi = oa_fs_index(st->Fs);
-   if (!g_classic_dec[fi][ci]) {
-      int err;
-      g_classic_dec[fi][ci] = opusgpu_dec_batch_create(1, st->Fs, st->s.s.channels, 0, &err);
-      if (!g_classic_dec[fi][ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
-   }
-   OpusGpuDecBatch *b = g_classic_dec[fi][ci];
-   std::vector<unsigned char> pkt((size_t)len + 8, 0);
-   if (len > 0) memcpy(pkt.data(), data, (size_t)len);
-   std::vector<opus_int16> out((size_t)frame_size * st->s.s.channels);
-   opus_int32 n = 0, l = len; opus_uint32 rng = 0;
-   int r = opusgpu_dec_batch_import_state(b, 0, &st->s);
-   b->decode_fec = decode_fec;
-   if (r == OPUS_OK) r = opusgpu_decode_batch(b, pkt.data(), (opus_int32)pkt.size(), &l, out.data(), frame_size, &n, &rng);
-   if (r == OPUS_OK) r = opusgpu_dec_batch_export_state(b, 0, &st->s);
-   if (r != OPUS_OK) return r;
-   if (n > 0) { if (st->decode_gain) oa_apply_decode_gain(out.data(), n * st->s.s.channels, st->decode_gain); memcpy(pcm, out.data(), (size_t)n * st->s.s.channels * sizeof(opus_int16)); }
-   return n;
+   OaDecCall call = {st, data, len, pcm, frame_size, decode_fec, OPUS_INTERNAL_ERROR, false};
+   g_dec_calls.submit(&call, oa_classic_cap(), oa_classic_decode_group);
+   return call.ret;
 }
 /* opus_decode24 / opus_decode_float (reference include/opus.h:541,:566; src/opus_decoder.c:947-1030, the int16-resolution build): the frame size is
  * first limited to what the packet holds (so the temporary is no larger than needed), then decode, then RES2INT24 = << 8 / RES2FLOAT = * 1/32768 */
@@ -913,6 +1011,13 @@ int opus_decode_float(OpusDecoder *st, const unsigned char *data, opus_int32 len
    const int ret = opus_decode(st, data, len, out.data(), frame_size, decode_fec);
    for (int i = 0; i < ret * st->s.s.channels; i++) pcm[i] = (1.f / 32768.f) * out[i];
    return ret;
+}
+/* how the classic entry points were served so far: {opus_encode* calls, launches they shared, opus_decode* calls, launches they shared} (opus_call_combiner.h) */
+void opusgpu_classic_call_stats(long long out[4])
+{
+   if (!out) return;
+   { std::lock_guard<std::mutex> l(g_enc_calls.mu); out[0] = g_enc_calls.calls; out[1] = g_enc_calls.launches; }
+   { std::lock_guard<std::mutex> l(g_dec_calls.mu); out[2] = g_dec_calls.calls; out[3] = g_dec_calls.launches; }
 }
 int opus_decoder_get_nb_samples(const OpusDecoder *dec, const unsigned char packet[], opus_int32 len) { return opus_packet_get_nb_samples(packet, len, dec->Fs); }
 int opus_decoder_ctl(OpusDecoder *st, int request, ...)
