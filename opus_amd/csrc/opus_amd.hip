@@ -488,19 +488,38 @@ static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][A
 /* one classic call waiting for (or leading) a launch: opus_call_combiner.h */
 struct OaEncCall {
    OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
-   int frame_size, application, channels; opus_int32 Fs, max_data_bytes;
+   int kind, frame_size, application, channels; opus_int32 Fs, max_data_bytes;
    int ret; bool done;
-   bool same_launch(const OaEncCall &o) const
+   const void *who() const { return st; }
+   bool same_shape(const OaEncCall &o) const
    {
-      return st != o.st && st->kind == o.st->kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
+      return kind == o.kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
           && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr);
    }
 };
 static OaCallCombiner<OaEncCall> g_enc_calls;
+/* page-locked staging for the state records of a launch's group (one launch at a time per combiner owns it): packed here, sent with one copy, received back, unpacked */
+struct OaPinned { char *p = nullptr; size_t cap = 0; };
+static OaPinned g_enc_pin, g_dec_pin;
+static char *oa_pinned(OaPinned &b, size_t n)
+{
+   if (n > b.cap) {
+      if (b.p) (void)hipHostFree(b.p);
+      b.p = nullptr; b.cap = 0;
+      if (hipHostMalloc((void **)&b.p, n, 0) != hipSuccess) { b.p = nullptr; return nullptr; }
+      b.cap = n;
+   }
+   return b.p;
+}
 static int oa_classic_cap()      /* states one launch of the classic API carries at most (the device arrays of a shape are sized for it once) */
 {
    static const int cap = getenv("OPUS_AMD_CLASSIC_BATCH") && atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) > 0 ? atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) : 256;
    return cap;
+}
+static int oa_classic_linger_us() /* how long the leader of a launch waits for the callers it expects (opus_call_combiner.h); 0 = never */
+{
+   static const int us = getenv("OPUS_AMD_CLASSIC_LINGER_US") ? atoi(getenv("OPUS_AMD_CLASSIC_LINGER_US")) : 200;
+   return us;
 }
 static int oa_fs_index(opus_int32 Fs) { return Fs == 8000 ? 0 : Fs == 12000 ? 1 : Fs == 16000 ? 2 : Fs == 24000 ? 3 : 4; }
 
@@ -528,7 +547,7 @@ void opus_encoder_destroy(OpusEncoder *st) { free(st); }
 static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
 {
    const OaEncCall &h = *g[0];
-   const int n = (int)g.size(), kind = (int)h.st->kind;
+   const int n = (int)g.size(), kind = h.kind;
    OpusGpuEncBatch **slot = &g_classic[kind][oa_fs_index(h.Fs)][h.channels - 1];
    if (!*slot) {
       int err;
@@ -543,18 +562,20 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    const opus_int16 *pcm = h.pcm; const opus_int32 *apcm = h.apcm;
-   std::vector<opus_int16> pcm_all; std::vector<opus_int32> apcm_all; std::vector<char> recs;
+   std::vector<opus_int16> pcm_all; std::vector<opus_int32> apcm_all; char *recs = nullptr;
    if (n > 1) {                                                            /* inputs and records of the group side by side: one contiguous transfer each */
-      pcm_all.resize(per * n); recs.resize(rec * (size_t)n);
+      pcm_all.resize(per * n);
+      recs = oa_pinned(g_enc_pin, rec * (size_t)oa_classic_cap());
+      if (!recs) return OPUS_ALLOC_FAIL;
       if (apcm) apcm_all.resize(per * n);
       for (int i = 0; i < n; i++) {
          memcpy(pcm_all.data() + per * i, g[i]->pcm, per * sizeof(opus_int16));
          if (apcm) memcpy(apcm_all.data() + per * i, g[i]->apcm, per * sizeof(opus_int32));
-         memcpy(recs.data() + rec * i, kind ? (const void *)&g[i]->st->sh : (const void *)&g[i]->st->s, rec);
+         memcpy(recs + rec * i, kind ? (const void *)&g[i]->st->sh : (const void *)&g[i]->st->s, rec);
       }
       pcm = pcm_all.data(); if (apcm) apcm = apcm_all.data();
    }
-   const void *rec_src = n > 1 ? (const void *)recs.data() : kind ? (const void *)&h.st->sh : (const void *)&h.st->s;
+   const void *rec_src = n > 1 ? (const void *)recs : kind ? (const void *)&h.st->sh : (const void *)&h.st->s;
    HIPCHECK(hipMemcpy(kind ? (void *)b->d_sh : (void *)b->d_streams, rec_src, rec * (size_t)n, hipMemcpyHostToDevice));
    if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = g[i]->st->sh.cfg; b->cfg_dirty = true; }     /* the launch's host-side decisions follow the records it carries */
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = g[i]->st->s.cfg;
@@ -563,8 +584,8 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    int r = opusgpu_encode_batch_sig(b, pcm, apcm, h.frame_size, out.data(), stride, h.max_data_bytes, lens.data(), rng.data());
    if (r != OPUS_OK) return r;
    if (n > 1) {
-      HIPCHECK(hipMemcpy(recs.data(), kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec * (size_t)n, hipMemcpyDeviceToHost));
-      for (int i = 0; i < n; i++) memcpy(kind ? (void *)&g[i]->st->sh : (void *)&g[i]->st->s, recs.data() + rec * i, rec);
+      HIPCHECK(hipMemcpy(recs, kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec * (size_t)n, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) memcpy(kind ? (void *)&g[i]->st->sh : (void *)&g[i]->st->s, recs + rec * i, rec);
    } else HIPCHECK(hipMemcpy(kind ? (void *)&h.st->sh : (void *)&h.st->s, kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec, hipMemcpyDeviceToHost));
    for (int i = 0; i < n; i++) {
       const opus_int32 len = lens[i];
@@ -589,8 +610,8 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    if (frame_size <= 0 || max_data_bytes <= 0) return OPUS_BAD_ARG;
    { const int fr = oa_enc_frame_size_code(Fs, application, frame_size); if (fr != OPUS_OK) return fr; }
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   OaEncCall call = {st, pcm, apcm, data, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false};
-   g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_encode_group);
+   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false};
+   g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_linger_us(), oa_classic_encode_group);
    return call.ret;
 }
 opus_int32 opus_encode(OpusEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
@@ -858,9 +879,10 @@ int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned char *d_packets, 
 struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 decode_gain; opus_int32 pad[1]; OaDecStream s; };
 static OpusGpuDecBatch *g_classic_dec[5][2];
 struct OaDecCall {
-   OpusDecoder *st; const unsigned char *data; opus_int32 len; opus_int16 *pcm; int frame_size, decode_fec;
+   OpusDecoder *st; const unsigned char *data; opus_int32 len; opus_int16 *pcm; int frame_size, decode_fec, channels; opus_int32 Fs;
    int ret; bool done;
-   bool same_launch(const OaDecCall &o) const;
+   const void *who() const { return st; }
+   bool same_shape(const OaDecCall &o) const { return Fs == o.Fs && channels == o.channels && frame_size == o.frame_size && decode_fec == o.decode_fec; }
 };
 static OaCallCombiner<OaDecCall> g_dec_calls;
 int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
@@ -905,10 +927,6 @@ static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
       pcm[i] = (opus_int16)(y > 32767 ? 32767 : y < -32767 ? -32767 : y);
    }
 }
-bool OaDecCall::same_launch(const OaDecCall &o) const
-{
-   return st != o.st && st->Fs == o.st->Fs && st->s.s.channels == o.st->s.s.channels && frame_size == o.frame_size && decode_fec == o.decode_fec;
-}
 /* one launch for a group of classic decode calls of one shape (rate, channels, output size, FEC flag): packets of any mode and length side by side, one wave each */
 static int oa_classic_decode_group_run(std::vector<OaDecCall *> &g)
 {
@@ -925,23 +943,25 @@ static int oa_classic_decode_group_run(std::vector<OaDecCall *> &g)
    for (int i = 0; i < n; i++) if (g[i]->len + 8 > stride) stride = g[i]->len + 8;
    std::vector<unsigned char> pkt((size_t)stride * n, 0);
    std::vector<opus_int32> lens((size_t)n), ns((size_t)n); std::vector<opus_uint32> rng((size_t)n);
-   std::vector<char> recs(sizeof(OaDecStream) * (size_t)n);
+   char *recs = oa_pinned(g_dec_pin, sizeof(OaDecStream) * (size_t)oa_classic_cap());
+   if (!recs) return OPUS_ALLOC_FAIL;
+   const size_t recs_bytes = sizeof(OaDecStream) * (size_t)n;
    for (int i = 0; i < n; i++) {
       if (g[i]->len > 0) memcpy(pkt.data() + (size_t)stride * i, g[i]->data, (size_t)g[i]->len);
       lens[i] = g[i]->len;
-      memcpy(recs.data() + sizeof(OaDecStream) * i, &g[i]->st->s, sizeof(OaDecStream));
+      memcpy(recs + sizeof(OaDecStream) * i, &g[i]->st->s, sizeof(OaDecStream));
    }
    const size_t per = (size_t)h.frame_size * ch;
    std::vector<opus_int16> out(per * n);
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   HIPCHECK(hipMemcpy(b->d_streams, recs.data(), recs.size(), hipMemcpyHostToDevice));
+   HIPCHECK(hipMemcpy(b->d_streams, recs, recs_bytes, hipMemcpyHostToDevice));
    int r = opusgpu_decode_batch(b, pkt.data(), stride, lens.data(), out.data(), h.frame_size, ns.data(), rng.data());
    if (r != OPUS_OK) return r;
-   HIPCHECK(hipMemcpy(recs.data(), b->d_streams, recs.size(), hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(recs, b->d_streams, recs_bytes, hipMemcpyDeviceToHost));
    for (int i = 0; i < n; i++) {
       OpusDecoder *st = g[i]->st;
-      memcpy(&st->s, recs.data() + sizeof(OaDecStream) * i, sizeof(OaDecStream));
+      memcpy(&st->s, recs + sizeof(OaDecStream) * i, sizeof(OaDecStream));
       const opus_int32 m = ns[i];
       if (m > 0) {
          opus_int16 *o = out.data() + per * i;
@@ -977,8 +997,8 @@ int opus_decode(OpusDecoder *st, const unsigned char *data, opus_int32 len, opus
       return total;
    }
    if (frame_size > cap) frame_size = cap;
-   OaDecCall call = {st, data, len, pcm, frame_size, decode_fec, OPUS_INTERNAL_ERROR, false};
-   g_dec_calls.submit(&call, oa_classic_cap(), oa_classic_decode_group);
+   OaDecCall call = {st, data, len, pcm, frame_size, decode_fec, st->s.s.channels, st->Fs, OPUS_INTERNAL_ERROR, false};
+   g_dec_calls.submit(&call, oa_classic_cap(), oa_classic_linger_us(), oa_classic_decode_group);
    return call.ret;
 }
 /* opus_decode24 / opus_decode_float (reference include/opus.h:541,:566; src/opus_decoder.c:947-1030, the int16-resolution build): the frame size is

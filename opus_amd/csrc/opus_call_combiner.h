@@ -3,32 +3,65 @@
  * opus_encode() / opus_decode() work on ONE caller-owned state per call (include/opus.h:266, :516) and the reference lets any number of threads call them at the same
  * time on different states (include/opus.h:425-429).  A launch costs the same few milliseconds for one wave as for a few thousand, so calls that arrive while a launch
  * is in flight are not queued behind it one by one: they wait together, and the first caller to find the device free leads ONE launch for every waiting call of the
- * same shape (same kernel, rate, channels, frame size, byte budget), each with its own state record, input and output slot.  There is no timer and no added latency
- * for a lone caller (its group is itself); under T concurrent callers the groups settle at about T/2..T calls per launch.  The order of calls on one state is the
- * caller's (a state is in at most one call at a time, as the API requires); results do not depend on the grouping because streams never interact. */
+ * same shape (same kernel, rate, channels, frame size, byte budget), each with its own state record, input and output slot.
+ *
+ * Left alone, T steady callers settle into two alternating groups of T/2 (one group's launch runs while the other group's threads collect their results and come
+ * back), and every caller waits for two launches per call.  The leader therefore lingers for the callers it has reason to expect: the states of its own shape that the
+ * last two launches served and that are not waiting yet -- until they arrive or `linger_us` (a small fraction of a launch) have passed.  A lone caller expects nobody
+ * and never waits; a caller that stops calling is expected for two more launches, then forgotten.  The order of calls on one state is the caller's (a state is in at
+ * most one call at a time, as the API requires); results do not depend on the grouping because streams never interact. */
 #ifndef OPUS_AMD_CALL_COMBINER_H
 #define OPUS_AMD_CALL_COMBINER_H
 #include <mutex>
 #include <condition_variable>
 #include <deque>
 #include <vector>
-/* Req needs: bool done; int ret; bool same_launch(const Req &) const */
+#include <algorithm>
+#include <chrono>
+/* Req needs: bool done; int ret; const void *who() const (the state the call works on; never dereferenced here) and bool same_shape(const Req &) const, which compares
+ * plain values only: the combiner keeps a COPY of the last launches' head requests, whose states may be gone by the time it looks at them */
 template <class Req> struct OaCallCombiner {
-   std::mutex mu; std::condition_variable cv; std::deque<Req *> pending; bool busy = false;
+   std::mutex mu; std::condition_variable cv, cv_lead; std::deque<Req *> pending; bool busy = false, lingering = false;
+   std::vector<const void *> served[2];                                    /* states of the last two launches, with the shape they were launched for */
+   Req shape[2]; bool shape_set[2] = {false, false};
    long long calls = 0, launches = 0;
-   template <class Run> void submit(Req *rq, int cap, Run run)
+   static bool joins(const Req &head, const Req &r) { return &r == &head || (r.who() != head.who() && head.same_shape(r)); }
+   size_t fits(const Req &head) const { size_t n = 0; for (const Req *r : pending) n += joins(head, *r); return n; }
+   size_t expected(const Req &head) const                                  /* distinct recent callers of head's shape (head's own state included) */
+   {
+      std::vector<const void *> ids;
+      for (int k = 0; k < 2; k++) if (shape_set[k] && head.same_shape(shape[k]))
+         ids.insert(ids.end(), served[k].begin(), served[k].end());
+      ids.push_back(head.who());
+      std::sort(ids.begin(), ids.end());
+      return (size_t)(std::unique(ids.begin(), ids.end()) - ids.begin());
+   }
+   template <class Run> void submit(Req *rq, int cap, int linger_us, Run run)
    {
       std::unique_lock<std::mutex> lk(mu);
       calls++;
       pending.push_back(rq);
+      if (lingering) cv_lead.notify_one();
       while (!rq->done) {
          if (busy) { cv.wait(lk); continue; }
          busy = true;                                                    /* this caller leads the next launch: the oldest waiting call and every call that fits it */
-         std::vector<Req *> grp;
          Req *head = pending.front();
-         for (auto it = pending.begin(); it != pending.end() && (int)grp.size() < cap;) {
-            if (*it == head || head->same_launch(**it)) { grp.push_back(*it); it = pending.erase(it); } else ++it;
+         if (linger_us > 0) {
+            const size_t want = std::min(expected(*head), (size_t)cap);
+            if (fits(*head) < want) {
+               const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us);
+               lingering = true;
+               while (fits(*head) < want) if (cv_lead.wait_until(lk, deadline) == std::cv_status::timeout) break;
+               lingering = false;
+            }
          }
+         std::vector<Req *> grp;
+         for (auto it = pending.begin(); it != pending.end() && (int)grp.size() < cap;) {
+            if (joins(*head, **it)) { grp.push_back(*it); it = pending.erase(it); } else ++it;
+         }
+         served[1].swap(served[0]); shape[1] = shape[0]; shape_set[1] = shape_set[0];
+         served[0].clear(); for (Req *g : grp) served[0].push_back(g->who());
+         shape[0] = *head; shape_set[0] = true;
          launches++;
          lk.unlock();
          try { run(grp); } catch (...) { for (Req *g : grp) g->ret = -7 /* OPUS_ALLOC_FAIL */; }

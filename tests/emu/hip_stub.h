@@ -46,6 +46,8 @@ static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSu
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); if (*p) memset(*p, 0xA5, n); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
