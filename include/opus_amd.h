@@ -152,6 +152,9 @@ OPUS_AMD_EXPORT int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_in
 OPUS_AMD_EXPORT int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid);
 /* ... and what the tonality analysis adds to that when it runs (complexity 10, API rate >= 16 kHz, float analysis on) */
 OPUS_AMD_EXPORT int opusgpu_enc_analysis_moved_bytes(void);
+/* surround_analysis (src/opus_multistream_encoder.c:230) as an operator: per-channel signal-to-mask ratios (Q24, [channels][21]) of `len` interleaved int16 samples of a
+ * 3..8-channel vorbis-order layout; mem[channels][120], preemph_mem[channels]: the analysis memory, updated */
+OPUS_AMD_EXPORT int opusgpu_surround_analysis(const opus_int16 *pcm, int len, int channels, opus_int32 Fs, opus_int32 *mem, opus_int32 *preemph_mem, opus_int32 *bandSMR);
 /* the classic entry points under concurrent callers (include/opus.h:425-429 allows any number of threads on different states): calls that arrive while a launch is in
  * flight share the next launch, one wave per call (opus_amd/csrc/opus_call_combiner.h; at most OPUS_AMD_CLASSIC_BATCH states per launch, default 256).
  * out = {opus_encode* calls, launches that served them, opus_decode* calls, launches that served them} since the library was loaded */

@@ -107,6 +107,14 @@ struct OpusMSDecoder {
 #define OA_MS_FRAME_TMP (6 * 1275 + 12)
 
 extern "C" {
+/* the masking analysis of the surround layouts on its own (surround_analysis, src/opus_multistream_encoder.c:230): len samples of `channels` (3..8, vorbis order)
+ * interleaved int16 at Fs; mem[channels][120] / preemph_mem[channels] = the analysis memory (in and out); bandSMR[channels][21] = per-channel signal-to-mask ratios, Q24 */
+int opusgpu_surround_analysis(const opus_int16 *pcm, int len, int channels, opus_int32 Fs, opus_int32 *mem, opus_int32 *preemph_mem, opus_int32 *bandSMR)
+{
+   if (!pcm || !mem || !preemph_mem || !bandSMR || channels < 3 || channels > 8 || len <= 0 || !oa_fs_ok(Fs)) return OPUS_BAD_ARG;
+   std::lock_guard<std::mutex> lock(g_ms_mu);
+   return oa_surround_analysis(pcm, len, channels, Fs, mem, preemph_mem, bandSMR);
+}
 opus_int32 opus_multistream_encoder_get_size(int nb_streams, int nb_coupled_streams)
 {
    if (nb_streams < 1 || nb_coupled_streams > nb_streams || nb_coupled_streams < 0) return 0;

@@ -17,15 +17,17 @@ static int oa_log2_q10(opus_int32 x)
    for (int k = 3; k >= 0; k--) f = (opus_int16)(C[k] + (((opus_int32)n * f) >> 15));
    return ((i - 13) << 10) + (f >> (14 - 10));
 }
-/* log2(2^a + 2^b) in Q24 (DB_SHIFT), piecewise linear in the difference, half-unit steps (logSum :193) */
+/* log2(2^a + 2^b) in Q24 (DB_SHIFT), piecewise linear in the difference, half-unit steps (logSum :193).  The reference's function is declared to return opus_val16
+ * -- 16 bits in the fixed-point build -- so what reaches the masks is the low half of the Q24 sum, sign-extended (gcc's modulo conversion); the elementary encoders'
+ * allocation follows from exactly that value, so it is kept bit for bit (found by tools/encode_trace_compare.py on the reference's surround_analysis_uninit regression) */
 static opus_int32 oa_logsum(opus_int32 a, opus_int32 b)
 {
    static const opus_int32 tab[17] = {8388608, 4907022, 2700528, 1425434, 733691, 372406, 187635, 94181, 47183, 0, 0, 0, 0, 0, 0, 0, 0};   /* GCONST(.5, .2924813, .1609640, ...) */
    const opus_int32 hi = a > b ? a : b, diff = a > b ? a - b : b - a;
-   if (!(diff < (8 << 24))) return hi;
+   if (!(diff < (8 << 24))) return (opus_int16)hi;
    const int low = diff >> 23;
    const opus_int32 frac = (diff - (low << 23)) >> 8;                                      /* VSHR32(., DB_SHIFT - 16): Q15 of a half unit */
-   return hi + tab[low] + (opus_int32)(((long long)(opus_int16)frac * (tab[low + 1] - tab[low])) >> 15);
+   return (opus_int16)(hi + tab[low] + (opus_int32)(((long long)(opus_int16)frac * (tab[low + 1] - tab[low])) >> 15));
 }
 /* bandLogE[channels][21] (the per-channel spread log energies) -> signal-to-mask ratios in place */
 static void oa_surround_couple(opus_int32 *bandLogE, int channels)
