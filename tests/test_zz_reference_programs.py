@@ -1,4 +1,4 @@
-"""The reference's own UNMODIFIED C test programs (tests/test_opus_api.c, test_opus_padding.c, test_opus_decode.c, test_opus_encode.c + opus_encode_regressions.c,
+"""The reference's own UNMODIFIED C test programs (tests/test_opus_api.c, test_opus_padding.c, test_opus_projection.c, test_opus_decode.c, test_opus_encode.c + opus_encode_regressions.c,
 src/opus_demo.c), compiled where they lie by tests/hostemu.py against this library's C ABI and run:
   * here (no GPU) against the emulated library tests/emu/libopus_amd_emu.so: the quick ones on every run; the long ones (tens of minutes on the CPU wave emulator)
     when OPUS_AMD_LONG_TESTS=1;
@@ -25,6 +25,8 @@ def _run(flavour, name, timeout, args=()):
 def test_emu_test_opus_api(): _run("emu", "test_opus_api", 1800)
 @pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_padding")), reason="no reference tree")
 def test_emu_test_opus_padding(): _run("emu", "test_opus_padding", 600)
+@pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_projection")), reason="no reference tree")
+def test_emu_test_opus_projection(): assert "All projection tests passed" in _run("emu", "test_opus_projection", 600)
 @pytest.mark.skipif(not LONG, reason="tens of minutes on the CPU wave emulator: OPUS_AMD_LONG_TESTS=1")
 def test_emu_test_opus_encode(): _run("emu", "test_opus_encode", 4 * 3600)
 @pytest.mark.skipif(not LONG, reason="tens of minutes on the CPU wave emulator: OPUS_AMD_LONG_TESTS=1")
@@ -34,6 +36,8 @@ def test_emu_test_opus_decode(): _run("emu", "test_opus_decode", 4 * 3600)
 def test_gpu_test_opus_api(): _run("gpu", "test_opus_api", 900)
 @pytest.mark.gpu
 def test_gpu_test_opus_padding(): _run("gpu", "test_opus_padding", 300)
+@pytest.mark.gpu
+def test_gpu_test_opus_projection(): assert "All projection tests passed" in _run("gpu", "test_opus_projection", 300)
 @pytest.mark.gpu
 def test_gpu_test_opus_decode_and_encode():
     """test_opus_decode in full and test_opus_encode with the reference's own TEST_OPUS_NOFUZZ knob (the settings fuzz alone is another ~20 minutes at one
