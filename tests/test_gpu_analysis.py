@@ -11,7 +11,8 @@ def _product_library(monkeypatch):
 
 from test_hostemu_analysis import (test_config_2_with_analysis, test_lowdelay_rates_and_sizes, test_audio_unforced_mode_decisions, test_speech_music_speech,
     test_forced_modes_and_hybrid, test_dtx_with_activity_probability, test_cbr_and_constrained, test_controls_midstream, test_signal_type_steers_the_lowdelay_application,
-    test_24_bit_and_float_entry_points_feed_the_analysis_unrounded_samples, test_multistream_with_analysis)
+    test_24_bit_and_float_entry_points_feed_the_analysis_unrounded_samples, test_multistream_with_analysis,
+    test_lowdelay_dtx_is_only_taken_on_analysed_or_silent_frames, test_lowdelay_dtx_sees_the_peak_tracked_before_it_was_switched_on)
 
 
 @pytest.mark.parametrize("name,Fs,ch,app,ctl", [

@@ -187,3 +187,43 @@ def test_multistream_float_and_projection_with_analysis():
             destroy(e); out.append(seq)
         bad = [i for i in range(28) if out[0][i] != out[1][i]]
         assert not bad, (kind, bad[:5], [type(x) for x in out[1][:3]])
+
+def _loud_then_quiet(Fs, ch, n_loud, n_quiet, seed, quiet=0.004, gaps=()):
+    x = music(Fs, ch, n_loud + n_quiet, seed).astype(np.float64)
+    rng = np.random.default_rng(seed)
+    x[n_loud:] = x[n_loud:] * quiet + (rng.integers(-3, 4, x[n_loud:].shape) if quiet > 0 else 0)
+    for a, b in gaps: x[a:b] = 0
+    return np.ascontiguousarray(x.astype(np.int16))
+
+def test_lowdelay_dtx_is_only_taken_on_analysed_or_silent_frames():
+    """the generalised DTX of a CELT-only encoder (src/opus_encoder.c:2565) is gated by SILK's DTX flag, which is on whenever the frame is neither analysed nor digitally
+    silent (:1461): below complexity 10 or below 16 kHz a quiet-but-not-silent passage after a loud one must NOT turn into one-byte packets, whatever its energy against
+    the tracked peak (found by the call-by-call comparison of the reference's fuzz_encoder_settings between the two libraries: tools/encode_trace_shim.c)"""
+    for Fs, ch, fr, ctl in ((12000, 2, 240, dict(complexity=4, vbr=0, bitrate=-1, lsb_depth=8)), (48000, 2, 960, dict(complexity=5, lsb_depth=8)), (16000, 1, 320, dict(complexity=9)),
+                            (48000, 1, 3840, dict(complexity=5, signal=3001, prediction_disabled=1))):
+        n = 60 * (fr if fr < 1000 else 960)
+        m = run(Fs, ch, 2051, [fr] * (n // fr), sig=_loud_then_quiet(Fs, ch, n // 3, n - n // 3, 31), dtx=1, **ctl)
+        assert "d" not in m, (Fs, m)
+    m = run(48000, 2, 2051, [960] * 40, sig=_loud_then_quiet(48000, 2, 960 * 10, 960 * 30, 32, quiet=0.0), complexity=5, dtx=1)       # digital silence does
+    assert "d" in m
+    # the same against the build without the float API (:1463: digital silence alone lets the generalised DTX run)
+    for Fs, ch, fr, cx in ((48000, 2, 960, 10), (12000, 1, 240, 3)):
+        a = capi.Enc("ref", Fs, ch, 2051, dtx=1, complexity=cx); b = capi.Enc(WHICH, Fs, ch, 2051, dtx=1, complexity=cx)
+        b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; assert b.L.opus_encoder_ctl(b.st, FLOAT_ANALYSIS, 0) == 0
+        sig = _loud_then_quiet(Fs, ch, 15 * fr, 45 * fr, 35); sig[40 * fr:] = 0
+        got = [(a.encode(sig[i * fr:(i + 1) * fr], fr), b.encode(sig[i * fr:(i + 1) * fr], fr)) for i in range(60)]
+        assert all(x == y for x, y in got), [i for i, (x, y) in enumerate(got) if x != y][:5]
+        assert all(x[1] > 2 for x, _ in got[:40]) and any(x[1] == 1 for x, _ in got[40:])
+
+def test_lowdelay_dtx_sees_the_peak_tracked_before_it_was_switched_on():
+    """the peak signal energy (:1310) follows the input whether or not DTX is on; switched on later, the loud-noise exemption of an analysed inactive frame (:1920) compares
+    against that history.  Multi-frame calls: the digital-silence flag is the call's (a silent 20 ms inside a sounding 80 ms call is not 'silent')"""
+    Fs, ch = 48000, 1
+    sig = sig_for(Fs, ch, 960 * 150, 22).copy()
+    sig[960 * 60:] = (sig[960 * 60:].astype(np.int32) // 512).astype(np.int16)                   # near-silence after a loud minute: the activity probability drops
+    m = run(Fs, ch, 2051, [960] * 148, {70: dict(dtx=1)}, sig=sig, bitrate=64000)
+    assert "d" in m[70:], m
+    gaps = sig.copy()
+    for k in range(25): gaps[960 * 50 + k * 3840:960 * 50 + k * 3840 + 1400] = 0
+    run(Fs, ch, 2051, [3840] * 36, {5: dict(dtx=1)}, sig=gaps, bitrate=96000)
+    run(Fs, ch, 2049, [2880] * 48, {5: dict(dtx=1)}, sig=gaps, bitrate=40000)
