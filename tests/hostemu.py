@@ -43,6 +43,14 @@ def build_reftests(flavour):
         subprocess.check_call(["gcc"] + REFTEST_FLAGS + extra + s + ["-o", exe] + lib + ["-lm"])
     return out
 
+def build_trace_shim():
+    """tools/encode_trace_shim.c -> oracle/_ref/enc_trace_shim.so (LD_PRELOAD logger of the encode calls an unmodified program makes; travels to the GPU box)"""
+    so = os.path.join(ROOT, "oracle/_ref/enc_trace_shim.so"); src = os.path.join(ROOT, "tools/encode_trace_shim.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", so, "-ldl"])
+    return so
+
 if __name__ == "__main__":
     import sys
     print(build_reftests(sys.argv[1] if len(sys.argv) > 1 else "emu"))
