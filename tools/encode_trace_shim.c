@@ -1,5 +1,5 @@
-/* tools/encode_trace_shim.c — DIAGNOSTIC (not product, not test): an LD_PRELOAD shim that logs every opus_encode / opus_encode_float / opus_multistream_encode /
- * opus_projection_encode call an unmodified program makes (frame size, byte budget, return value, FNV-1a hash of the packet) to $OPUS_TRACE_FILE and forwards to
+/* tools/encode_trace_shim.c — TEST INFRASTRUCTURE: an LD_PRELOAD shim that logs every opus_encode / opus_encode_float / opus_multistream_encode /
+ * opus_projection_encode call (and every opus_decode / opus_multistream_decode call) an unmodified program makes (frame size, byte budget, return value, FNV-1a hash of the packet) to $OPUS_TRACE_FILE and forwards to
  * whichever library the program is linked to.  The reference's tests/test_opus_encode.c is deterministic for a given seed, so two runs of it -- one linked to the
  * compiled reference, one to this library -- must leave identical logs: every packet of the mode matrix, the settings fuzz and the regression cases, byte for byte
  * (tools/encode_trace_compare.py).
@@ -45,6 +45,40 @@ WRAP(opus_multistream_encode_float, "Mf", float)
 WRAP(opus_multistream_encode24, "M24", int32_t)
 WRAP(opus_projection_encode, "P", int16_t)
 WRAP(opus_projection_encode_float, "Pf", float)
+/* with $OPUS_TRACE_DECODE set, the decode calls of the same run as well (the program decodes every packet it made, some of them after corrupting them): sample count and PCM hash.  The decoder's channel count
+ * is known for decoders the program created through the API; for the copies it makes with memcpy only the sample count is logged */
+static void *dec_st_[64]; static int dec_ch_[64], dec_n_;
+static int dec_channels(void *st) { for (int i = 0; i < 64; i++) if (dec_st_[i] == st) return dec_ch_[i]; return 0; }
+void *opus_decoder_create(int32_t Fs, int channels, int *error)
+{
+   static void *(*real)(int32_t, int, int *);
+   if (!real) real = dlsym(RTLD_NEXT, "opus_decoder_create");
+   void *st = real(Fs, channels, error);
+   dec_st_[dec_n_ % 64] = st; dec_ch_[dec_n_ % 64] = channels; dec_n_++;
+   return st;
+}
+void *opus_multistream_decoder_create(int32_t Fs, int channels, int streams, int coupled, const unsigned char *mapping, int *error)
+{
+   static void *(*real)(int32_t, int, int, int, const unsigned char *, int *);
+   if (!real) real = dlsym(RTLD_NEXT, "opus_multistream_decoder_create");
+   void *st = real(Fs, channels, streams, coupled, mapping, error);
+   dec_st_[dec_n_ % 64] = st; dec_ch_[dec_n_ % 64] = channels; dec_n_++;
+   return st;
+}
+#define WRAPD(name, tag) \
+int name(void *st, const unsigned char *data, int32_t len, int16_t *pcm, int frame_size, int fec) \
+{ \
+   static int (*real)(void *, const unsigned char *, int32_t, int16_t *, int, int); \
+   if (!real) real = dlsym(RTLD_NEXT, #name); \
+   init(); \
+   int r = real(st, data, len, pcm, frame_size, fec); \
+   static int on = -1; if (on < 0) on = getenv("OPUS_TRACE_DECODE") != NULL; \
+   const int ch = dec_channels(st); \
+   if (on) fprintf(logf_, "%ld %s len=%d fs=%d fec=%d ret=%d pcm=%08x\n", ncall++, tag, (int)len, frame_size, fec, r, r > 0 && ch ? fnv(pcm, (long)r * ch * 2) : 0); \
+   return r; \
+}
+WRAPD(opus_decode, "D")
+WRAPD(opus_multistream_decode, "MD")
 /* context lines (not numbered: the call index counts encode calls only): encoder creation, controls, destruction.  With $OPUS_TRACE_PCM_FROM=<n> [$OPUS_TRACE_PCM_TO=<m>] the int16 input of
  * every opus_encode call from encode call n on (to m) is appended to $OPUS_TRACE_PCM (for replaying a section elsewhere: tools/encode_trace_replay.py) */
 #include <stdarg.h>
