@@ -460,16 +460,18 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
    const int overlap = OA_OVERLAP, CC = sh->CC;
-   {  /* activity for the generalised DTX (:1911-1930): the CALL's digital silence (is_silence comes down from opus_encode_native, one flag for every frame of a
-       * multi-frame call), else the analysis' verdict; the energy-against-peak branch of CELT-only frames (:1926) only ever feeds a decision that is not taken
-       * (see below) and is skipped */
+   {  /* activity for the generalised DTX (:1911-1930): this frame's digital silence (in a multi-frame call every coded frame gets its own flag, :1800, and its own
+       * analysis record, :1796), else the analysis' verdict, else the frame's energy against the tracked peak.  sh->use_dtx: 0 = off, 1 = on, 2 = on but the decision
+       * is not taken in this call (oa_encode_frame) */
       int activity = 1;
-      if (wv_uni(sh->use_dtx)) {
-         if (wv_uni(sh->is_silence)) activity = 0;
+      if (wv_uni(sh->use_dtx) == 1) {
+         const i32 m = oa_maxabs_wave(pcm, frame_size * CC);
+         if (m == 0) activity = 0;
          else if (wv_uni(gs->an_info.valid)) {                                                      /* the analysis' activity probability; a loud enough noise frame counts as active (:1916-1924) */
             activity = an_activity_prob_active(&gs->an_info);
-            if (!activity) { const i32 m = oa_maxabs_wave(pcm, frame_size * CC); activity = an_loud_noise_active(wv_uni(sh->peak_signal_energy), oa_frame_energy_wave(pcm, frame_size * CC, m)); }
+            if (!activity) activity = an_loud_noise_active(wv_uni(sh->peak_signal_energy), oa_frame_energy_wave(pcm, frame_size * CC, m));
          }
+         else { const i32 noise_energy = oa_frame_energy_wave(pcm, frame_size * CC, m); activity = (i64)wv_uni(sh->peak_signal_energy) < 316 * (i64)half32(noise_energy); }
       }
       if (wv_lane() < (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)&gs->st.analysis)[wv_lane()] = ((const i32 *)&gs->an_info)[wv_lane()];   /* CELT_SET_ANALYSIS (:2418) */
       LANE0 { sh->activity = activity; opus_layer_frame(L, &gs->cfg, frame_size, orig_max_data_bytes); }
@@ -501,9 +503,9 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
    K_PHASE(14);
    LANE0 {   /* the generalised DTX decision (:2565-2576, decide_dtx_mode :1115): after 200 ms without activity the packet is the TOC alone, at most 400 ms in a row.  It is
               * taken only where SILK's own DTX is off (:2565) -- and silk_mode.useDTX = use_dtx && !(analysis valid || digital silence) (:1461; without the float API
-              * :1463, digital silence alone) whatever the mode: a CELT-only frame that is neither analysed nor silent never counts towards DTX */
+              * :1463, digital silence alone), whatever the mode, decided once per CALL: a CELT-only call that is neither analysed nor silent never counts towards DTX */
       if (sh->ret >= 0) {
-         if (sh->use_dtx && (gs->an_info.valid || sh->is_silence)) {
+         if (sh->use_dtx == 1) {
             int dtx = 0;
             if (!sh->activity) {
                sh->nb_no_activity_ms_Q1 += 2 * 1000 * frame_size / sh->Fs;
@@ -557,6 +559,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       }
    }
    wv_sync();
+   LANE0 sh->use_dtx = gs->use_dtx ? ((gs->an_info.valid || sh->is_silence) ? 1 : 2) : 0;          /* silk_mode.useDTX (:1461), with the call's analysis record and the call's silence flag */
    if (sample_max != 0 && (!wv_uni(gs->an_info.valid) || an_activity_prob_above(&gs->an_info))) {   /* peak signal energy tracker (:1310-1320): tracked whatever the DTX setting is now -- it can be switched on later */
       const i32 en = oa_frame_energy_wave(pcm, frame_size * CC, sample_max);
       LANE0 sh->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), sh->peak_signal_energy), en);

@@ -29,13 +29,16 @@
 
 WV_DEV i32 bits_to_bitrate(i32 bits, i32 Fs, i32 frame_size) { return bits * (6 * Fs / frame_size) / 6; }
 WV_DEV i32 bitrate_to_bits(i32 bitrate, i32 Fs, i32 frame_size) { return bitrate * 6 / (6 * Fs / frame_size); }
-WV_DEV i32 compute_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int celt_mode_known, int complexity)
+/* compute_equiv_rate (src/opus_encoder.c:1027) for an encoder whose mode can only be CELT-only: before the mode is "known" (the channel decision, :1432) the reference
+ * discounts half of SILK's loss penalty whatever the application (:1055) */
+WV_DEV i32 compute_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int celt_mode_known, int complexity, int loss)
 {
    i32 equiv = bitrate;
    if (frame_rate > 50) equiv -= (40 * channels + 20) * (frame_rate - 50);
    if (!vbr) equiv -= equiv / 12;
    equiv = equiv * (90 + complexity) / 100;
    if (celt_mode_known) { if (complexity < 5) equiv = equiv * 9 / 10; }
+   else equiv -= equiv * loss / (12 * loss + 20);
    return equiv;
 }
 WV_DEV u8 gen_toc_celt(int framerate, int bandwidth, int channels)
@@ -104,14 +107,14 @@ WV_DEVN void opus_layer_decide(WV_LDS FrameLds *L, const OaEncConfig *cfg, int f
       sh->call_max_data_bytes = imax(max_data_bytes, sh->ret);
       return;
    }
-   i32 equiv_rate = compute_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity);
+   i32 equiv_rate = compute_equiv_rate(bitrate_bps, channels, frame_rate, cfg->use_vbr, 0, cfg->complexity, cfg->packet_loss_perc);
    if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
    else if (channels == 2) {
       i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
       if (st->stream_channels == 2) thr -= 1000; else thr += 1000;
       st->stream_channels = (equiv_rate > thr) ? 2 : 1;
    } else st->stream_channels = channels;
-   equiv_rate = compute_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 1, cfg->complexity);
+   equiv_rate = compute_equiv_rate(bitrate_bps, st->stream_channels, frame_rate, cfg->use_vbr, 1, cfg->complexity, cfg->packet_loss_perc);
    {
       const i32 voice_bw[8] = {9000, 700, 9000, 700, 13500, 1000, 14000, 2000};
       const i32 music_bw[8] = {9000, 700, 9000, 700, 11000, 1000, 12000, 2000};

@@ -2,12 +2,12 @@
 final range call by call) with the product library opus_amd/libopus_amd.so in place of the emulated C ABI: mode switches with redundancy and prefills, multi-frame
 packets, API rates below 48 kHz in both directions, CBR padding, settings fuzz."""
 import pytest
-import test_hostemu_encoder_modes as M, test_hostemu_decoder_rates as D, test_hostemu_api_limits as A, test_hostemu_threads as T
+import test_hostemu_encoder_modes as M, test_hostemu_decoder_rates as D, test_hostemu_api_limits as A, test_hostemu_threads as T, test_hostemu_fuzz as Z
 pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _product_library(monkeypatch):
-    monkeypatch.setattr(M, "WHICH", "gpu"); monkeypatch.setattr(D, "WHICH", "gpu"); monkeypatch.setattr(A, "WHICH", "gpu"); monkeypatch.setattr(T, "WHICH", "gpu")
+    monkeypatch.setattr(M, "WHICH", "gpu"); monkeypatch.setattr(D, "WHICH", "gpu"); monkeypatch.setattr(A, "WHICH", "gpu"); monkeypatch.setattr(T, "WHICH", "gpu"); monkeypatch.setattr(Z, "WHICH", "gpu")
 
 from test_hostemu_encoder_modes import (test_silk_celt_switches_mono, test_hybrid_celt_switches_stereo, test_switches_10ms_and_short_frames, test_auto_mode_rate_sweep,
     test_silk_bandwidth_switch, test_long_frames_celt_and_hybrid, test_long_frames_silk, test_celt_below_48k, test_cbr_padding_and_tiny_buffers, test_settings_fuzz)
@@ -41,3 +41,9 @@ def test_concurrent_callers_share_launches_on_the_device():
     for k in range(0, nt, 7):
         r = capi.Enc("ref", 48000, 2, 2051, bitrate=128000, complexity=10)
         assert got[k] == [r.encode(xs[k][i * 960:(i + 1) * 960], 960) for i in range(nf)], k
+
+@pytest.mark.parametrize("block", range(4))
+def test_settings_fuzz_more_seeds_on_the_device(block):
+    """tests/test_hostemu_fuzz.py's fuzz, 60 seeds per block (the emulator runs 20 of them in the CPU suite): one encoder per seed through ten random setting changes, every
+    packet against the reference (even seeds: float API with the analysis; odd: without)"""
+    for seed in [248, 252, 300, 304, 306, 337, 346, 423][2 * block:2 * block + 2] + list(range(1000 + 60 * block, 1060 + 60 * block)): Z.fuzz(seed)
