@@ -42,8 +42,8 @@ def test_concurrent_callers_share_launches_on_the_device():
         r = capi.Enc("ref", 48000, 2, 2051, bitrate=128000, complexity=10)
         assert got[k] == [r.encode(xs[k][i * 960:(i + 1) * 960], 960) for i in range(nf)], k
 
-@pytest.mark.parametrize("block", range(4))
+@pytest.mark.parametrize("block", range(2))
 def test_settings_fuzz_more_seeds_on_the_device(block):
-    """tests/test_hostemu_fuzz.py's fuzz, 60 seeds per block (the emulator runs 20 of them in the CPU suite): one encoder per seed through ten random setting changes, every
-    packet against the reference (even seeds: float API with the analysis; odd: without)"""
-    for seed in [248, 252, 300, 304, 306, 337, 346, 423][2 * block:2 * block + 2] + list(range(1000 + 60 * block, 1060 + 60 * block)): Z.fuzz(seed)
+    """tests/test_hostemu_fuzz.py's fuzz, 34 seeds per block (the emulator runs 20 in the CPU suite; 248 seeds ran here once: profiles/r03_o): one encoder per seed through ten
+    random setting changes, every packet against the reference (even seeds: float API with the analysis; odd: without)"""
+    for seed in [248, 252, 300, 304, 306, 337, 346, 423][4 * block:4 * block + 4] + list(range(1000 + 30 * block, 1030 + 30 * block)): Z.fuzz(seed)
