@@ -665,7 +665,7 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
       opus_int32 *dst = st->kind ? st->sh.energy_mask : st->s.energy_mask;
       const int n = 21 * (st->kind ? st->sh.cfg.channels : st->s.cfg.channels);
       if (m) memcpy(dst, m, sizeof(opus_int32) * (size_t)n);
-      if (st->kind) st->sh.cfg.energy_mask_on = m != nullptr; else st->s.energy_mask_on = m != nullptr;
+      if (st->kind) { st->sh.cfg.energy_mask_on = m != nullptr; st->sh.s.celt_mask_cleared = 0; } else st->s.energy_mask_on = m != nullptr;
       ret = OPUS_OK;
    }
    else if (request == OPUS_SET_APPLICATION_REQUEST) {

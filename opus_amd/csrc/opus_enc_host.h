@@ -86,8 +86,9 @@ static int sh_init_stream(OaShStream *st, opus_int32 Fs, int channels, int appli
    st->cfg.variable_duration = OPUS_FRAMESIZE_ARG; st->cfg.voice_ratio = -1; st->s.voice_ratio = -1; st->cfg.analysis_off = oa_default_analysis_off();
    return OPUS_OK;
 }
-static void oa_reset_rec(OaStream *r) { oa_stream_reset_state(r); }
-static void oa_reset_rec(OaShStream *r) { oa_sh_stream_reset(r, r->cfg.Fs, r->cfg.channels, r->cfg.application); }
+/* (the energy mask pointers of both layers sit in the reference's reset regions, src/opus_encoder.c:127, celt/celt_encoder.c:123: OPUS_RESET_STATE drops the mask) */
+static void oa_reset_rec(OaStream *r) { oa_stream_reset_state(r); r->energy_mask_on = 0; }
+static void oa_reset_rec(OaShStream *r) { oa_sh_stream_reset(r, r->cfg.Fs, r->cfg.channels, r->cfg.application); r->cfg.energy_mask_on = 0; }
 
 /* frame_size_select (:827) */
 static opus_int32 oa_frame_size_select(int application, opus_int32 frame_size, int variable_duration, opus_int32 Fs)
@@ -104,6 +105,9 @@ static opus_int32 oa_frame_size_select(int application, opus_int32 frame_size, i
    return n;
 }
 
+/* the multi-frame path's sticky 'force_channels = 1' (OaShScalars.mono_forced_seq): a new OPUS_SET_FORCE_CHANNELS ends it; the CELT-only record never has one */
+static inline void oa_force_channels_set(OaStream *) {}             static inline void oa_force_channels_set(OaShStream *r) { r->cfg.force_channels_seq++; }
+static inline int oa_mono_forced(const OaStream *) { return 0; }      static inline int oa_mono_forced(const OaShStream *r) { return r->s.mono_forced_seq == r->cfg.force_channels_seq + 1; }
 /* ---- CTLs ---- */
 template <class R> static int oa_rec_set(R *r, int request, opus_int32 value)
 {
@@ -121,7 +125,7 @@ template <class R> static int oa_rec_set(R *r, int request, opus_int32 value)
    case OPUS_SET_COMPLEXITY_REQUEST: if (value < 0 || value > 10) return OPUS_BAD_ARG; c->complexity = value; return OPUS_OK;
    case OPUS_SET_VBR_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->use_vbr = value; return OPUS_OK;
    case OPUS_SET_VBR_CONSTRAINT_REQUEST: if (value < 0 || value > 1) return OPUS_BAD_ARG; c->vbr_constraint = value; return OPUS_OK;
-   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > c->channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->force_channels = value; return OPUS_OK;
+   case OPUS_SET_FORCE_CHANNELS_REQUEST: if ((value < 1 || value > c->channels) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->force_channels = value; oa_force_channels_set(r); return OPUS_OK;
    case OPUS_SET_BANDWIDTH_REQUEST: if ((value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) && value != OPUS_AUTO) return OPUS_BAD_ARG; c->user_bandwidth = value; return OPUS_OK;
    case OPUS_SET_MAX_BANDWIDTH_REQUEST: if (value < OPUS_BANDWIDTH_NARROWBAND || value > OPUS_BANDWIDTH_FULLBAND) return OPUS_BAD_ARG; c->max_bandwidth = value; return OPUS_OK;
    case OPUS_SET_LSB_DEPTH_REQUEST: if (value < 8 || value > 24) return OPUS_BAD_ARG; c->lsb_depth = value; return OPUS_OK;
@@ -171,7 +175,7 @@ template <class R> static int oa_rec_get(R *r, int request, opus_int32 *value)
    case OPUS_GET_COMPLEXITY_REQUEST: *value = c->complexity; return OPUS_OK;
    case OPUS_GET_VBR_REQUEST: *value = c->use_vbr; return OPUS_OK;
    case OPUS_GET_VBR_CONSTRAINT_REQUEST: *value = c->vbr_constraint; return OPUS_OK;
-   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = c->force_channels; return OPUS_OK;
+   case OPUS_GET_FORCE_CHANNELS_REQUEST: *value = oa_mono_forced(r) ? 1 : c->force_channels; return OPUS_OK;
    case OPUS_GET_BANDWIDTH_REQUEST: *value = oa_bandwidth(r); return OPUS_OK;
    case OPUS_GET_MAX_BANDWIDTH_REQUEST: *value = c->max_bandwidth; return OPUS_OK;
    case OPUS_GET_LSB_DEPTH_REQUEST: *value = c->lsb_depth; return OPUS_OK;

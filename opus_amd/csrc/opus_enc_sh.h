@@ -56,6 +56,8 @@ struct ShLds {
 #define SH_SCRATCH_BYTES(frame_size, channels) (2 * SH_PCM_BYTES(frame_size, channels) + 512 + sizeof(CeltScratch) + sizeof(SeRateScratch))
 #define SH_STAGE_SAMPLES 1920
 
+/* OPUS_SET_FORCE_CHANNELS as the encoder sees it: 1 while the multi-frame path's own 'force_channels = 1' (OaShScalars.mono_forced_seq) is in force */
+#define SH_FORCE_CHANNELS(cfg, st) ((st)->mono_forced_seq == (cfg)->force_channels_seq + 1 ? 1 : (cfg)->force_channels)
 WV_DEV i32 sh_equiv_rate(i32 bitrate, int channels, int frame_rate, int vbr, int mode, int complexity, int loss)      /* compute_equiv_rate :780 */
 {
    i32 equiv = bitrate;
@@ -193,7 +195,8 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
    if (cfg->signal_type == OA_SIGNAL_VOICE) voice_est = 127; else if (cfg->signal_type == OA_SIGNAL_MUSIC) voice_est = 0;
    else if (st->voice_ratio >= 0) { voice_est = st->voice_ratio * 327 >> 8; if (cfg->application == OA_APP_AUDIO) voice_est = imin(voice_est, 115); }   /* for AUDIO, never more than 90% confident of having speech */
    else if (cfg->application == OA_APP_VOIP) voice_est = 115; else voice_est = 48;
-   if (cfg->force_channels != OA_AUTO && channels == 2) st->stream_channels = cfg->force_channels;
+   const int force_channels = SH_FORCE_CHANNELS(cfg, st);
+   if (force_channels != OA_AUTO && channels == 2) st->stream_channels = force_channels;
    else if (channels == 2) {
       i32 thr = 17000 + ((voice_est * voice_est * (19000 - 17000)) >> 14);
       if (st->stream_channels == 2) thr -= 1000; else thr += 1000;
@@ -415,6 +418,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
       WV_LDS i32 *w = (WV_LDS i32 *)c; for (int i = 0; i < (int)(sizeof(OaEncScalars) / 4); i++) w[i] = 0;
       c->pad0[0] = dpf; c->pad0[1] = fi;
       c->spread_decision = 2; c->delayedIntra = 1; c->tonal_average = 256;
+      L->st.celt_mask_cleared = 1;                                                       /* ... and so does CELT's energy_mask pointer: no surround masking in CELT until the mask is set again */
       L->sh.silk_signalType = 0; L->sh.silk_offset = 0;                                  /* SILKInfo sits in the reset region too: the CELT passes after a reset see zeros until the next frame sets it */
    }
    FOR_LANES(i, 2 * NBE) { F->oldBandE[i] = 0; gs->celt.oldBandE[i] = 0; gs->celt.energyError[i] = 0; gs->celt.oldLogE[i] = gs->celt.oldLogE2[i] = -(28 << 24); }
@@ -465,7 +469,7 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
       fs->max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_max_data_bytes; fs->orig_max_data_bytes = ctl.raw ? ctl.nbytes + 1 : sh->f_orig_max_data_bytes; fs->pad_to = 0;
       fs->plc_frame = 0; fs->ret = 0; fs->skip_celt = 0; fs->toc = 0;
       fs->silk_signalType = sh->silk_signalType; fs->silk_offset = sh->silk_offset;
-      fs->do_stereo_fade = 0; fs->lfe = L->cfg.lfe; fs->energy_mask_on = L->cfg.energy_mask_on; fs->Fs = Fs;
+      fs->do_stereo_fade = 0; fs->lfe = L->cfg.lfe; fs->energy_mask_on = L->cfg.energy_mask_on && !st->celt_mask_cleared; fs->Fs = Fs;
    }
    wv_sync();
    LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
@@ -914,7 +918,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       if (track) en = sh_frame_energy_wave(pcm, frame_size * CC);
       LANE0 { sh->sample_max = m; sh->is_silence = m == 0; if (track) st->peak_signal_energy = imax(mult16_32_q15(QC16(0.999f, 15), st->peak_signal_energy), en); }
    }
-   if (CC == 2 && L->cfg.force_channels != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
+   if (CC == 2 && SH_FORCE_CHANNELS(&L->cfg, st) != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
    LANE0 sh_layer_decide(L, frame_size, max_data_bytes, &gs->an_info);
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
@@ -933,8 +937,8 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    } else {
       /* ---- several coded frames, one packet (:1757-1838) ---- */
       const int nb_frames = wv_uni(sh->nb_frames), enc_frame_size = wv_uni(sh->enc_frame_size), max_len_sum = wv_uni(sh->max_len_sum), repacketize_len = wv_uni(sh->repacketize_len);
-      const int bak_to_mono = wv_uni(st->sm_toMono), saved_force_channels = wv_uni(L->cfg.force_channels);
-      LANE0 { if (bak_to_mono) L->cfg.force_channels = 1; else st->prev_channels = st->stream_channels; L->mf.n = nb_frames; }
+      const int bak_to_mono = wv_uni(st->sm_toMono);
+      LANE0 { if (bak_to_mono) st->mono_forced_seq = L->cfg.force_channels_seq + 1; else st->prev_channels = st->stream_channels; L->mf.n = nb_frames; }   /* (:1764: force_channels = 1, for good) */
       int tot_size = 0, dtx_count = 0, err = 0, staged = 0;
       if (OA_MF_HEADROOM + imin(max_len_sum, 1276 * nb_frames) > out_cap) err = OA_ERR_BUFFER_TOO_SMALL;     /* staging + theta-RDO journal need the slot the host promised */
       const int an_bak = wv_uni(gs->an_read_pos_bak);
@@ -965,7 +969,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
          wv_sync();
          staged += tmp_len - 1; tot_size += tmp_len;
       }
-      LANE0 { st->sm_toMono = bak_to_mono; L->cfg.force_channels = saved_force_channels; }
+      LANE0 st->sm_toMono = bak_to_mono;
       wv_sync();
       if (err) result = err;
       else {

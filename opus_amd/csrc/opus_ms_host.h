@@ -317,7 +317,7 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
          opus_int32 *mask = kind ? rec->sh.energy_mask : rec->s.energy_mask;
          if (s < nc) { const int l = oa_get_left(&st->layout, s, -1), r = oa_get_right(&st->layout, s, -1); for (int i = 0; i < 21; i++) { mask[i] = bandSMR[21 * l + i]; mask[21 + i] = bandSMR[21 * r + i]; } }
          else { const int c = oa_get_mono(&st->layout, s, -1); for (int i = 0; i < 21; i++) mask[i] = bandSMR[21 * c + i]; }
-         if (kind) rec->sh.cfg.energy_mask_on = 1; else rec->s.energy_mask_on = 1;
+         if (kind) { rec->sh.cfg.energy_mask_on = 1; rec->sh.s.celt_mask_cleared = 0; } else rec->s.energy_mask_on = 1;
       }
    }
    /* channel de-interleave into the two groups */

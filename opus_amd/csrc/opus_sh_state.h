@@ -15,7 +15,8 @@ struct OaShConfig {
    int32_t energy_mask_on;
    int32_t voice_ratio_seq;                             /* ... and a count of the sets (the kernel adopts the value when the count moves) */
    int32_t analysis_off;                                /* private: 1 = behave like a reference built with DISABLE_FLOAT_API (no tonality analysis at complexity 10) */
-   int32_t reserved[7];
+   int32_t force_channels_seq;                          /* count of the OPUS_SET_FORCE_CHANNELS requests (see OaShScalars.mono_forced_seq) */
+   int32_t reserved[6];
 };
 struct OaShScalars {
    int32_t stream_channels, bandwidth, auto_bandwidth, first, mode, prev_mode, prev_channels, prev_framesize;
@@ -31,7 +32,11 @@ struct OaShScalars {
    int32_t nonfinal_frame;                              /* inside a repacketised multi-frame packet (:1779) */
    int32_t voice_ratio;                                 /* OpusEncoder.voice_ratio (:91): -1, the value of OPUS_SET_VOICE_RATIO, or what the analysis said (:1291) */
    int32_t voice_ratio_seq;                             /* last cfg.voice_ratio_seq seen */
-   int32_t pad0[2];
+   int32_t celt_mask_cleared;                           /* CELT's own energy_mask pointer sits in its reset region (celt/celt_encoder.c:123): a CELT reset inside a call (mode
+                                                         * transition, :2479) drops it until the next OPUS_SET_ENERGY_MASK, while the Opus layer's copy (SILK's rate offset) stays */
+   int32_t mono_forced_seq;                             /* a multi-frame call that starts during a stereo -> mono transition sets the encoder's force_channels to 1 and never puts it
+                                                         * back (src/opus_encoder.c:1764-1766): the stream stays mono until the application sets OPUS_SET_FORCE_CHANNELS again.  Kept
+                                                         * as state next to the configuration: in force while it equals cfg.force_channels_seq + 1 */
 };
 #define OA_SH_MAX_DELAY 480                              /* encoder_buffer = Fs / 100 samples per channel */
 struct OaShStream {
@@ -50,9 +55,9 @@ struct OaShStream {
 static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)
 {
    OaShConfig keep = st->cfg;
-   const int32_t vr = st->s.voice_ratio, vrs = st->s.voice_ratio_seq;            /* voice_ratio sits outside the reference's reset region (src/opus_encoder.c:91,:111) */
+   const int32_t vr = st->s.voice_ratio, vrs = st->s.voice_ratio_seq, mfs = st->s.mono_forced_seq;   /* voice_ratio and force_channels sit outside the reference's reset region (src/opus_encoder.c:91,:111) */
    char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
-   st->cfg = keep; st->s.voice_ratio = vr; st->s.voice_ratio_seq = vrs;
+   st->cfg = keep; st->s.voice_ratio = vr; st->s.voice_ratio_seq = vrs; st->s.mono_forced_seq = mfs;
    st->cfg.Fs = Fs; st->cfg.channels = channels; st->cfg.application = application;
    st->s.stream_channels = channels; st->s.first = 1; st->s.mode = 1001; st->s.bandwidth = 1105;
    st->s.hybrid_stereo_width_Q14 = 1 << 14; st->s.prev_HB_gain = 32767;

@@ -47,3 +47,6 @@ def test_settings_fuzz_more_seeds_on_the_device(block):
     """tests/test_hostemu_fuzz.py's fuzz, 34 seeds per block (the emulator runs 20 in the CPU suite; 248 seeds ran here once: profiles/r03_o): one encoder per seed through ten
     random setting changes, every packet against the reference (even seeds: float API with the analysis; odd: without)"""
     for seed in [248, 252, 300, 304, 306, 337, 346, 423][4 * block:4 * block + 4] + list(range(1000 + 30 * block, 1030 + 30 * block)): Z.fuzz(seed)
+
+def test_multistream_settings_fuzz_on_the_device():
+    for seed in [101, 197] + list(range(400, 430)): Z.fuzz_ms(seed)

@@ -61,3 +61,53 @@ def fuzz(seed, changes=10, hold_ms=500):
 # the loss term of the equivalent rate before the mode is known)
 @pytest.mark.parametrize("seed", list(range(12)) + [248, 252, 300, 304, 306, 337, 346, 423])
 def test_settings_fuzz_against_the_reference(seed): fuzz(seed)
+
+
+def fuzz_ms(seed, changes=6, hold_ms=300):
+    """the same for multistream encoders: a random layout (mapping family 0 / 1 / 2 / 255), rate and application, random settings through opus_multistream_encoder_ctl"""
+    rng = np.random.default_rng(5000 + seed)
+    family = int(rng.choice([0, 1, 1, 2, 255])); Fs = int(rng.choice([8000, 12000, 16000, 24000, 48000, 48000])); app = int(rng.choice([2048, 2049, 2049, 2051]))
+    nch = int(rng.choice({0: [1, 2], 1: [1, 2, 3, 4, 5, 6, 7, 8], 2: [1, 4, 6, 9, 11], 255: [1, 2, 3, 5, 7]}[family]))
+    analysis = seed % 2 == 0
+    R = capi._proto(capi.load("ref_fxa" if analysis else "ref")); E = capi._proto(capi.load(WHICH))
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    encs = []
+    for L in (R, E):
+        L.opus_multistream_surround_encoder_create.restype = vp
+        L.opus_multistream_surround_encoder_create.argtypes = [ctypes.c_int32, ci, ci, vp, vp, vp, ci, vp]
+        s, c, m, err = ci(), ci(), (ctypes.c_ubyte * 256)(), ci()
+        e = L.opus_multistream_surround_encoder_create(Fs, nch, family, ctypes.byref(s), ctypes.byref(c), m, app, ctypes.byref(err))
+        assert e and err.value == 0, (seed, family, nch, err.value)
+        L.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ctypes.c_int32]
+        L.opus_multistream_encoder_destroy.argtypes = [vp]; L.opus_multistream_encoder_destroy.restype = None
+        encs.append((L, e, (s.value, c.value, bytes(m[:nch]))))
+    assert encs[0][2] == encs[1][2]
+    def ctl(L, e, req, v): L.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]; return L.opus_multistream_encoder_ctl(e, req, v)
+    def rng_of(L, e):
+        v = ctypes.c_uint32(); L.opus_multistream_encoder_ctl.argtypes = [vp, ci, vp]; assert L.opus_multistream_encoder_ctl(e, 4031, ctypes.byref(v)) == 0; return v.value
+    assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
+    cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(min(nch, 4))]
+    sig = np.ascontiguousarray(np.stack([(cols[c % len(cols)] // (1 + c // len(cols))).astype(np.int16) for c in range(nch)], 1))
+    pos = 0; cap = 1500 * nch + 4000
+    bufs = [(ctypes.c_ubyte * cap)(), (ctypes.c_ubyte * cap)()]
+    for j in range(changes):
+        ms_x2 = int(rng.choice([5, 10, 20, 40, 40, 40, 80, 120, 160, 240])); fr = ms_x2 * Fs // 2000
+        sets = [(4002, int(rng.choice([16000 * nch, 32000 * nch, 64000 * nch, 96000, 510000, -1000, -1]))), (4006, int(rng.choice([0, 1, 1]))), (4020, int(rng.choice([0, 1, 1]))),
+                (4010, int(rng.choice([0, 3, 5, 8, 10, 10]))), (4016, int(rng.choice([0, 1]))), (4012, int(rng.choice([0, 0, 1]))), (4014, int(rng.choice([0, 2, 10]))),
+                (4036, int(rng.choice([8, 16, 24]))), (4024, int(rng.choice([-1000, -1000, 3001, 3002]))), (4004, int(rng.integers(1101, 1106)))]
+        for req, v in sets:
+            ra, rb = ctl(R, encs[0][1], req, v), ctl(E, encs[1][1], req, v); assert ra == rb, (seed, j, req, v, ra, rb)
+        maxb = int(rng.choice([cap, cap, 400 * encs[0][2][0], 60 * encs[0][2][0]]))
+        for i in range(max(2, hold_ms * Fs // 1000 // fr)):
+            x = np.ascontiguousarray(sig[pos:pos + fr]).reshape(-1); pos += fr
+            out = []
+            for (L, e, _), buf in zip(encs, bufs):
+                n = L.opus_multistream_encode(e, x.ctypes.data, fr, buf, maxb)
+                out.append((n, bytes(buf[:max(n, 0)]), rng_of(L, e) if n > 0 else None))
+            assert out[0] == out[1], (seed, (family, nch, Fs, app), j, i, fr, maxb, out[0][0], out[1][0], dict(sets), out[0][1][:120].hex(), out[1][1][:120].hex())
+    for L, e, _ in encs: L.opus_multistream_encoder_destroy(e)
+
+# seeds 101, 197: the two of a 400-seed sweep that differed when this test was written (CELT's own energy-mask pointer is dropped by a CELT reset inside a call; a multi-frame
+# call that starts during a stereo -> mono transition leaves force_channels at 1 for good)
+@pytest.mark.parametrize("seed", list(range(10)) + [101, 197])
+def test_multistream_settings_fuzz_against_the_reference(seed): fuzz_ms(seed)
