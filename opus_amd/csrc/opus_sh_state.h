@@ -55,9 +55,16 @@ struct OaShStream {
 static inline void oa_sh_stream_reset(OaShStream *st, int32_t Fs, int channels, int application)
 {
    OaShConfig keep = st->cfg;
-   const int32_t vr = st->s.voice_ratio, vrs = st->s.voice_ratio_seq, mfs = st->s.mono_forced_seq;   /* voice_ratio and force_channels sit outside the reference's reset region (src/opus_encoder.c:91,:111) */
+   const OaShScalars was = st->s;
    char *p = (char *)st; for (size_t i = 0; i < sizeof(*st); i++) p[i] = 0;
-   st->cfg = keep; st->s.voice_ratio = vr; st->s.voice_ratio_seq = vrs; st->s.mono_forced_seq = mfs;
+   st->cfg = keep;
+   /* what sits in front of OPUS_ENCODER_RESET_START in the reference's OpusEncoder (src/opus_encoder.c:76-111) survives OPUS_RESET_STATE: voice_ratio, force_channels, and
+    * the whole silk_mode control structure -- including what the last silk_Encode() left in it (allowBandwidthSwitch, inWBmodeWithoutVariableLP, stereoWidth_Q14, ...), which
+    * the Opus layer reads again before SILK next runs */
+   st->s.voice_ratio = was.voice_ratio; st->s.voice_ratio_seq = was.voice_ratio_seq; st->s.mono_forced_seq = was.mono_forced_seq;
+   st->s.sm_toMono = was.sm_toMono; st->s.sm_opusCanSwitch = was.sm_opusCanSwitch; st->s.sm_allowBandwidthSwitch = was.sm_allowBandwidthSwitch;
+   st->s.sm_inWBmodeWithoutVariableLP = was.sm_inWBmodeWithoutVariableLP; st->s.sm_stereoWidth_Q14 = was.sm_stereoWidth_Q14; st->s.sm_LBRR_coded = was.sm_LBRR_coded;
+   st->s.sm_switchReady = was.sm_switchReady; st->s.sm_useDTX = was.sm_useDTX;
    st->cfg.Fs = Fs; st->cfg.channels = channels; st->cfg.application = application;
    st->s.stream_channels = channels; st->s.first = 1; st->s.mode = 1001; st->s.bandwidth = 1105;
    st->s.hybrid_stereo_width_Q14 = 1 << 14; st->s.prev_HB_gain = 32767;

@@ -50,3 +50,6 @@ def test_settings_fuzz_more_seeds_on_the_device(block):
 
 def test_multistream_settings_fuzz_on_the_device():
     for seed in [101, 197] + list(range(400, 430)): Z.fuzz_ms(seed)
+
+def test_sparse_settings_fuzz_on_the_device():
+    for seed in [102, 134, 172] + list(range(600, 630)): Z.fuzz_sparse(seed)
