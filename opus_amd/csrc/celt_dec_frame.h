@@ -598,6 +598,15 @@ WV_DEV void oa_smooth_fade_wave(const i16 *in1, const i16 *in2, i16 *out, int ov
    }
 }
 
+/* the decoder gain on the concealed fade source of a mode transition (OaDecScalars.transition_gain_Q16): MULT16_32_P16 + SATURATE(., 32767) as at src/opus_decoder.c:700-712 */
+WV_DEV void oa_transition_gain_wave(const WV_LDS OaDecScalars *st, i16 *x, int n)
+{
+   const i32 gain = wv_uni(st->transition_gain_Q16);
+   if (!gain) return;
+   wv_sync();
+   FOR_LANES(i, n) { const i32 y = (i32)(((i64)x[i] * gain + 32768) >> 16); x[i] = (i16)(y > 32767 ? 32767 : y < -32767 ? -32767 : y); }
+   wv_sync();
+}
 /* One Opus frame with payload (opus_decode_frame, src/opus_decoder.c:271-714, data != NULL): SILK part, redundancy, CELT part, mode transitions.
  * `data` = the frame's bytes in HBM, len >= 2.  Returns the frame size or a negative OA_ERR_*. */
 WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0)
@@ -616,6 +625,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    if (transition && mode == 1002) {                                            /* SILK/hybrid -> CELT without redundancy: 5 ms of concealment in the old mode as the fade source (:388-393) */
       const int r = oa_conceal_wave(L, gs, imin(F5, audiosize), gs->trans, CC);
       if (r < 0) return r;
+      oa_transition_gain_wave(st, gs->trans, imin(F5, audiosize) * CC);
       LANE0 { st->mode = mode; st->start = 0; }
    }
 
@@ -640,7 +650,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
             k_ec_dec_init(&ec, buf, (u32)len);
             ec_st(&L->ec_silk, &ec);
             if (prev_mode == 1002) {                                            /* silk_ResetDecoder (silk/dec_API.c:91) */
-               sd_reset(&sdh->ch[0]); sd_reset(&sdh->ch[1]);
+               sd_reset(&sdh->ch[0], &gs->silk.cng_exc_buf_Q14[0][0]); sd_reset(&sdh->ch[1], &gs->silk.cng_exc_buf_Q14[1][0]);
                sdh->pred_prev_Q13[0] = sdh->pred_prev_Q13[1] = 0; sdh->sMid[0] = sdh->sMid[1] = sdh->sSide[0] = sdh->sSide[1] = 0;
                sdh->prev_decode_only_middle = 0;
             }
@@ -683,6 +693,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    if (transition && mode != 1002) {                                            /* CELT -> SILK/hybrid: 5 ms of CELT concealment as the fade source (:534-539) */
       const int r = oa_conceal_wave(L, gs, imin(F5, audiosize), gs->trans, CC);
       if (r < 0) return r;
+      oa_transition_gain_wave(st, gs->trans, imin(F5, audiosize) * CC);
       wv_sync();
       FOR_LANES(i, len + redundancy_bytes) L->packet[1 + i] = data[i];           /* (concealment does not touch the packet buffer; reloaded for clarity of state) */
       wv_sync();

@@ -93,7 +93,9 @@ struct OaDecScalars {
    int32_t preemph_memD[2];
    int32_t hist_head;
    int32_t Fs;                  /* API (output) rate: 48000 (0 = 48000), 24000, 16000, 12000, 8000 */
-   int32_t pad0[2];
+   int32_t transition_gain_Q16; /* OPUS_SET_GAIN as a Q16 multiplier, or 0: the concealed fade source of a mode transition comes out of a nested opus_decode_frame in the reference and
+                                 * carries the gain already when it is mixed in (src/opus_decoder.c:391,:537), before the frame as a whole gets it (:700) -- the host applies that one */
+   int32_t pad0[1];
 };
 /* ---- SILK decoder state (reference silk_decoder_state silk/structs.h:236-286, silk_decoder / stereo_dec_state silk/main.h, silk/structs.h:121-127),
  * flat: table pointers of the reference (NLSF codebook, iCDFs) are re-derived from fs_kHz / nb_subfr, the resampler is its nine configuration

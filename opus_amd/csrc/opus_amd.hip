@@ -907,8 +907,9 @@ OpusDecoder *opus_decoder_create(opus_int32 Fs, int channels, int *error)
 }
 void opus_decoder_destroy(OpusDecoder *st) { free(st); }
 /* OPUS_SET_GAIN (src/opus_decoder.c:700-712): gain = celt_exp2(6.48814081e-4 * decode_gain) in Q16-ish fixed point, applied with saturation */
-static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
+static opus_int32 oa_decode_gain_q16(int decode_gain)
 {
+   if (!decode_gain) return 0;
    /* celt_exp2(MULT16_16_P15(QCONST16(6.48814081e-4f, 25), decode_gain)) with the reference's fixed-point celt_exp2 (celt/mathops.h) */
    const opus_int32 x = ((opus_int32)21771 * (opus_int16)decode_gain + 16384) >> 15;   /* QCONST16(6.48814081e-4, 25) = 21771; result Q10 */
    opus_int32 gain;
@@ -922,6 +923,11 @@ static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
          gain = integer + 2 >= 0 ? f << (integer + 2) : f >> (-2 - integer);                 /* VSHR32(frac, -integer-2) */
       }
    }
+   return gain;
+}
+static void oa_apply_decode_gain(opus_int16 *pcm, int n, int decode_gain)
+{
+   const opus_int32 gain = oa_decode_gain_q16(decode_gain);
    for (int i = 0; i < n; i++) {
       const opus_int32 y = (opus_int32)(((long long)(opus_int16)pcm[i] * gain + 32768) >> 16);   /* MULT16_32_P16 */
       pcm[i] = (opus_int16)(y > 32767 ? 32767 : y < -32767 ? -32767 : y);
@@ -949,6 +955,7 @@ static int oa_classic_decode_group_run(std::vector<OaDecCall *> &g)
    for (int i = 0; i < n; i++) {
       if (g[i]->len > 0) memcpy(pkt.data() + (size_t)stride * i, g[i]->data, (size_t)g[i]->len);
       lens[i] = g[i]->len;
+      g[i]->st->s.s.transition_gain_Q16 = oa_decode_gain_q16(g[i]->st->decode_gain);
       memcpy(recs + sizeof(OaDecStream) * i, &g[i]->st->s, sizeof(OaDecStream));
    }
    const size_t per = (size_t)h.frame_size * ch;

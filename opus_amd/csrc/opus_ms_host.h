@@ -497,6 +497,7 @@ static int oa_ms_decode_group(OpusDecoder *states, int n, int ch, const unsigned
    if (!b) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
+   for (int i = 0; i < n; i++) states[i].s.s.transition_gain_Q16 = oa_decode_gain_q16(states[i].decode_gain);
    { const int ru = oa_rows_upload(b->d_streams, &states[0].s, sizeof(OpusDecoder), sizeof(OaDecStream), n); if (ru != OPUS_OK) return ru; }
    int r = opusgpu_decode_batch(b, pk, stride, lens, pcm, frame_size, ns_out, rngs);
    if (r != OPUS_OK) return r;

@@ -367,10 +367,13 @@ WV_DEV void sd_decode_parameters(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, int
 
 struct SdScratch { WV_LDS i32 *sLTP_Q15, *res_Q14, *sLPC_Q14; WV_LDS i16 *sLTP, *pulses, *tmp; WV_LDS SdCtrl *ctrl; i32 *cng_exc; /* this channel's CNG excitation buffer (HBM) */ };
 
-WV_DEV void sd_reset(WV_LDS OaSilkChannel *ch)                                                                    /* init_decoder.c:43 (whole state) */
+/* cng_exc: this channel's comfort-noise excitation buffer, which lives apart from the hot state (HBM) but belongs to the reference's decoder state all the same:
+ * the reset clears it with everything else (a stale one is drawn from by the next concealment) */
+WV_DEV void sd_reset(WV_LDS OaSilkChannel *ch, i32 *cng_exc)                                                      /* init_decoder.c:43 (whole state) */
 {
    WV_LDS i32 *w = (WV_LDS i32 *)ch;
    for (int i = 0; i < (int)(sizeof(OaSilkChannel) / 4); i++) w[i] = 0;
+   for (int i = 0; i < 320; i++) cng_exc[i] = 0;
    ch->first_frame_after_reset = 1;
    ch->prev_gain_Q16 = 65536;
    ch->cng_smth_Gain_Q16 = 0; ch->cng_rand_seed = 3176576;                                                  /* silk_CNG_Reset with LPC_order == 0 (CNG.c:58) */

@@ -116,7 +116,7 @@ WV_DEVN int silk_decode_wave(WV_LDS OaSilkDec *sd, i32 *cng_exc, const SdDecCont
       int ret = 0, decode_only_middle = 0;
       i32 MS_pred_Q13[2] = { 0, 0 };
       if (newPacketFlag) for (int n = 0; n < dc.nChannelsInternal; n++) cs[n].nFramesDecoded = 0;
-      if (dc.nChannelsInternal > sd->nChannelsInternal) sd_reset(&cs[1]);                                /* mono -> stereo: init the side channel (:186) */
+      if (dc.nChannelsInternal > sd->nChannelsInternal) sd_reset(&cs[1], cng_exc + 320);                                /* mono -> stereo: init the side channel (:186) */
       const int stereo_to_mono = dc.nChannelsInternal == 1 && sd->nChannelsInternal == 2 && dc.internalSampleRate == 1000 * cs[0].fs_kHz;
       if (cs[0].nFramesDecoded == 0) {
          for (int n = 0; n < dc.nChannelsInternal; n++) {

@@ -53,3 +53,6 @@ def test_multistream_settings_fuzz_on_the_device():
 
 def test_sparse_settings_fuzz_on_the_device():
     for seed in [102, 134, 172] + list(range(600, 630)): Z.fuzz_sparse(seed)
+
+def test_decoder_fuzz_on_the_device():
+    for seed in [6, 16, 39, 115, 143, 150, 182] + list(range(300, 330)): Z.fuzz_dec(seed)

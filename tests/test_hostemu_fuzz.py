@@ -149,3 +149,60 @@ def fuzz_sparse(seed, changes=14, hold_ms=350):
 # the last SILK frame before the reset left there: allowBandwidthSwitch & co.)
 @pytest.mark.parametrize("seed", list(range(8)) + [102, 134, 172])
 def test_sparse_settings_fuzz_against_the_reference(seed): fuzz_sparse(seed)
+
+
+def fuzz_dec(seed, changes=10, hold_ms=250):
+    """decoder fuzz: packets from the reference encoder under the sparse settings fuzz (every mode, bandwidth, frame size, FEC, DTX, multi-frame), decoded at a random output
+    rate and channel count by the reference decoder and this one, with random events in between: lost packets (concealment of a random legal length), FEC recovery from the
+    next packet, a frame_size argument larger than needed or too small, OPUS_RESET_STATE, a decoder gain, corrupted and truncated packets.  Sample count, PCM and final range
+    of every call must agree"""
+    rng = np.random.default_rng(13000 + seed)
+    Fs = int(rng.choice([8000, 12000, 16000, 24000, 48000, 48000])); ch = int(rng.choice([1, 2])); app = int(rng.choice([2048, 2049, 2049, 2051]))
+    e = capi.Enc("ref", Fs, ch, app)
+    outFs = int(rng.choice([8000, 12000, 16000, 24000, 48000, 48000])); outch = int(rng.choice([1, 2]))
+    a = capi.Dec("ref", outFs, outch); b = capi.Dec(WHICH, outFs, outch)
+    sig = _signal(rng, Fs, ch, Fs * (changes * hold_ms + 2500) // 1000); pos = 0
+    menu = dict(bitrate=[6000, 9000, 12000, 16000, 24000, 32000, 48000, 64000, 96000, 160000, -1000], force_channels=[-1000, 1, 2], vbr=[0, 1], complexity=[0, 3, 6, 10],
+                max_bandwidth=[1101, 1102, 1103, 1104, 1105], inband_fec=[0, 1, 2], packet_loss=[0, 5, 15, 40], dtx=[0, 1], force_mode=[-1000, -1000, 1000, 1001, 1002], signal=[-1000, 3001, 3002])
+    fr = Fs // 50; prev = None; k = 0
+    def both(pkt, n, fec=0):
+        x, y = a.decode(pkt, n, fec), b.decode(pkt, n, fec)
+        assert x[0] == y[0] and x[2] == y[2] and np.array_equal(x[1], y[1]), (seed, (Fs, ch, app, outFs, outch), k, len(pkt or b""), n, fec, x[0], y[0], x[2], y[2],
+                                                                                 None if x[0] != y[0] or x[0] <= 0 else np.argwhere(x[1] != y[1])[:3].tolist())
+    for j in range(changes):
+        for name, vals in menu.items():
+            if rng.random() < 0.35:
+                v = int(rng.choice(vals))
+                if name == "force_channels" and v > ch: v = ch
+                e.set(name, v)
+        if rng.random() < 0.6: fr = int(rng.choice([5, 10, 20, 40, 40, 80, 120, 160, 240])) * Fs // 2000
+        for i in range(max(3, hold_ms * Fs // 1000 // fr)):
+            pkt = e.encode(sig[pos:pos + fr], fr, int(rng.choice([1500, 1276, 120])))[0]; pos += fr; k += 1
+            if not pkt: continue
+            n = fr * outFs // Fs                                            # samples this packet holds at the output rate
+            ev = rng.random()
+            if ev < 0.10:                                                    # lost: conceal, then (sometimes) recover the lost frame from this packet's FEC data instead
+                if rng.random() < 0.5: both(b"", n)
+                else: both(pkt, n, fec=1)
+                both(pkt, n)
+            elif ev < 0.14: both(b"", int(rng.choice([outFs // 400, outFs // 100, outFs // 50, outFs * 3 // 50, outFs // 8]))); both(pkt, n)
+            elif ev < 0.18: both(pkt, n + int(rng.integers(1, 400)))        # room to spare
+            elif ev < 0.21: both(pkt, max(outFs // 400, n // 2)); both(pkt, n)   # too small (OPUS_BUFFER_TOO_SMALL) and again
+            elif ev < 0.24:
+                bad = bytearray(pkt)
+                for _ in range(int(rng.integers(1, 4))): bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+                both(bytes(bad), outFs * 3 // 25)
+            elif ev < 0.26 and len(pkt) > 3: both(pkt[:int(rng.integers(1, len(pkt)))], outFs * 3 // 25)
+            elif ev < 0.28:
+                for d in (a, b): d.L.opus_decoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int]; assert d.L.opus_decoder_ctl(d.st, 4028) == 0
+                both(pkt, n)
+            elif ev < 0.30:
+                g = int(rng.integers(-3000, 3000)); assert a.set("gain", g) == b.set("gain", g) == 0
+                both(pkt, n)
+            else: both(pkt, n)
+
+# seeds 6-182: some of the ~70 of a 200-seed sweep that differed when this test was written -- two causes: with OPUS_SET_GAIN the concealed fade source of a mode transition
+# carries the gain already when it is mixed in (it comes out of a nested opus_decode_frame), and the reset of the SILK decoder on a CELT -> SILK switch clears the
+# comfort-noise excitation buffer with the rest of the state (a stale one is drawn from by the next concealment)
+@pytest.mark.parametrize("seed", list(range(10)) + [16, 39, 115, 143, 150, 182])
+def test_decoder_fuzz_against_the_reference(seed): fuzz_dec(seed)
