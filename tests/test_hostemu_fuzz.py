@@ -206,3 +206,66 @@ def fuzz_dec(seed, changes=10, hold_ms=250):
 # comfort-noise excitation buffer with the rest of the state (a stale one is drawn from by the next concealment)
 @pytest.mark.parametrize("seed", list(range(10)) + [16, 39, 115, 143, 150, 182])
 def test_decoder_fuzz_against_the_reference(seed): fuzz_dec(seed)
+
+
+def fuzz_ms_dec(seed, nframes=40):
+    """multistream decoder fuzz: packets of a reference multistream encoder (random layout, settings changing along the way), decoded by both multistream decoders at a
+    random output rate with lost packets, FEC recovery, a decoder gain, resets, corrupted packets"""
+    rng = np.random.default_rng(17000 + seed)
+    family = int(rng.choice([0, 1, 1, 255])); Fs = int(rng.choice([8000, 16000, 24000, 48000, 48000])); app = int(rng.choice([2048, 2049, 2051]))
+    nch = int(rng.choice({0: [1, 2], 1: [2, 3, 4, 6, 8], 255: [1, 3, 5]}[family]))
+    R = capi._proto(capi.load("ref")); E = capi._proto(capi.load(WHICH)); vp, ci = ctypes.c_void_p, ctypes.c_int
+    R.opus_multistream_surround_encoder_create.restype = vp
+    R.opus_multistream_surround_encoder_create.argtypes = [ctypes.c_int32, ci, ci, vp, vp, vp, ci, vp]
+    s, c, m, err = ci(), ci(), (ctypes.c_ubyte * 256)(), ci()
+    enc = R.opus_multistream_surround_encoder_create(Fs, nch, family, ctypes.byref(s), ctypes.byref(c), m, app, ctypes.byref(err)); assert enc and err.value == 0
+    R.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ctypes.c_int32]
+    outFs = int(rng.choice([8000, 12000, 16000, 24000, 48000, 48000]))
+    decs = []
+    for L in (R, E):
+        L.opus_multistream_decoder_create.restype = vp
+        L.opus_multistream_decoder_create.argtypes = [ctypes.c_int32, ci, ci, ci, vp, vp]
+        d = L.opus_multistream_decoder_create(outFs, nch, s.value, c.value, m, ctypes.byref(err)); assert d and err.value == 0
+        L.opus_multistream_decode.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, vp, ci, ci]
+        L.opus_multistream_decoder_destroy.argtypes = [vp]; L.opus_multistream_decoder_destroy.restype = None
+        decs.append((L, d))
+    def ectl(req, v): R.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]; return R.opus_multistream_encoder_ctl(enc, req, v)
+    def both(pkt, n, fec=0, k=0):
+        out = []
+        for L, d in decs:
+            o = np.zeros((max(n, 1), nch), np.int16)
+            r = L.opus_multistream_decode(d, pkt if pkt else None, len(pkt) if pkt else 0, o.ctypes.data, n, fec)
+            v = ctypes.c_uint32(); L.opus_multistream_decoder_ctl.argtypes = [vp, ci, vp]; L.opus_multistream_decoder_ctl(d, 4031, ctypes.byref(v))
+            out.append((r, o[:max(r, 0)].tobytes(), v.value))
+        assert out[0] == out[1], (seed, (family, nch, Fs, app, outFs), k, len(pkt or b""), n, fec, out[0][0], out[1][0], out[0][2], out[1][2])
+    cols = [_signal(rng, Fs, 1, Fs * (nframes * 60 + 1500) // 1000) for _ in range(min(nch, 3))]
+    sig = np.ascontiguousarray(np.stack([(cols[q % len(cols)] // (1 + q // len(cols))).astype(np.int16) for q in range(nch)], 1)); pos = 0
+    buf = (ctypes.c_ubyte * (1500 * nch + 2000))(); fr = Fs // 50
+    for k in range(nframes):
+        if k % 8 == 0:
+            fr = int(rng.choice([10, 20, 40, 40, 80, 120])) * Fs // 2000
+            for req, vals in ((4002, [12000 * nch, 24000 * nch, 64000 * nch, -1000]), (4012, [0, 1]), (4014, [0, 10]), (4016, [0, 1]), (4010, [0, 5, 10]), (4004, [1101, 1103, 1105])): ectl(req, int(rng.choice(vals)))
+        x = np.ascontiguousarray(sig[pos:pos + fr]).reshape(-1); pos += fr
+        n = R.opus_multistream_encode(enc, x.ctypes.data, fr, buf, len(buf)); assert n > 0
+        pkt = bytes(buf[:n]); no = fr * outFs // Fs
+        ev = rng.random()
+        if ev < 0.12:
+            if rng.random() < 0.5: both(b"", no, 0, k)
+            else: both(pkt, no, 1, k)
+            both(pkt, no, 0, k)
+        elif ev < 0.16:
+            g = int(rng.integers(-2000, 2000))
+            for L, d in decs: L.opus_multistream_decoder_ctl.argtypes = [vp, ci, ci]; assert L.opus_multistream_decoder_ctl(d, 4034, g) == 0
+            both(pkt, no, 0, k)
+        elif ev < 0.19:
+            for L, d in decs: L.opus_multistream_decoder_ctl.argtypes = [vp, ci]; assert L.opus_multistream_decoder_ctl(d, 4028) == 0
+            both(pkt, no, 0, k)
+        elif ev < 0.23:
+            bad = bytearray(pkt); bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8)); both(bytes(bad), outFs * 3 // 25, 0, k)
+        elif ev < 0.27: both(pkt, no + int(rng.integers(1, 300)), 0, k)
+        else: both(pkt, no, 0, k)
+    R.opus_multistream_encoder_destroy.argtypes = [vp]; R.opus_multistream_encoder_destroy(enc)
+    for L, d in decs: L.opus_multistream_decoder_destroy(d)
+
+@pytest.mark.parametrize("seed", range(8))
+def test_multistream_decoder_fuzz_against_the_reference(seed): fuzz_ms_dec(seed)
