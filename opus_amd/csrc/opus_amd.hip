@@ -257,6 +257,19 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   if (request == OPUS_RESET_STATE) {
+      /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
+       * them into the mirror first (gathered on the device, one contiguous transfer) */
+      const size_t n = (size_t)(hi - lo), w = b->kind ? sizeof(OaShScalars) : sizeof(OaEncScalars), pitch = b->kind ? sizeof(OaShStream) : sizeof(OaStream);
+      const char *src = b->kind ? (const char *)&b->d_sh[lo].s : (const char *)&b->d_streams[lo].st.s;
+      char *d_tmp = nullptr; std::vector<char> h_tmp(n * w);
+      HIPCHECK(hipMalloc((void **)&d_tmp, n * w));
+      hipError_t e_ = hipMemcpy2D(d_tmp, w, src, pitch, w, n, hipMemcpyDeviceToDevice);
+      if (e_ == hipSuccess) e_ = hipMemcpy(h_tmp.data(), d_tmp, n * w, hipMemcpyDeviceToHost);
+      (void)hipFree(d_tmp);
+      if (e_ != hipSuccess) return OPUS_INTERNAL_ERROR;
+      for (size_t i = 0; i < n; i++) { if (b->kind) memcpy(&b->h_sh[lo + i].s, h_tmp.data() + i * w, w); else memcpy(&b->h_streams[lo + i].st.s, h_tmp.data() + i * w, w); }
+   }
    if (b->kind) {
       b->cfg_dirty = true;
       for (opus_int32 s = lo; s < hi; s++) { int r = sh_ctl_set(&b->h_sh[s], request, value); if (r != OPUS_OK) return r; }

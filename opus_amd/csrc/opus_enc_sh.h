@@ -923,7 +923,13 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
       const int n = sh_emit_packet(L->packet, out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);
-      LANE0 { *len_out = n; *rng_out = 0; gs->s.rangeFinal = 0; }
+      /* what opus_encode_native has updated by the time it emits a 'PLC frame' (:1345) stays updated: the voice ratio (:1273-1292), the peak signal energy (:1310-1320), the
+       * stereo-width memory (:1322), besides the analysis (in HBM already) */
+      LANE0 {
+         *len_out = n; *rng_out = 0; gs->s.rangeFinal = 0;
+         gs->s.voice_ratio = st->voice_ratio; gs->s.voice_ratio_seq = st->voice_ratio_seq; gs->s.peak_signal_energy = st->peak_signal_energy;
+         gs->s.wm_XX = st->wm_XX; gs->s.wm_XY = st->wm_XY; gs->s.wm_YY = st->wm_YY; gs->s.wm_smoothed_width = st->wm_smoothed_width; gs->s.wm_max_follower = st->wm_max_follower;
+      }
       return;
    }
    if (wv_uni(sh->prefill)) sh_silk_init_wave(L);                                      /* CELT -> SILK: the SILK encoder starts over (:1576-1581) */

@@ -56,3 +56,9 @@ def test_sparse_settings_fuzz_on_the_device():
 
 def test_decoder_fuzz_on_the_device():
     for seed in [6, 16, 39, 115, 143, 150, 182] + list(range(300, 330)): Z.fuzz_dec(seed)
+
+def test_batch_abi_fuzz_on_the_device():
+    for seed in [5, 118] + list(range(420, 440)): Z.fuzz_batch(seed)
+
+def test_multistream_decoder_fuzz_on_the_device():
+    for seed in range(200, 220): Z.fuzz_ms_dec(seed)
