@@ -70,7 +70,8 @@ WV_DEV void coarse_energy_wave(WV_LDS FrameLds *L)
    const i32 tell0 = k_ec_tell(&mine, L->packet + 1);
    int intra_only = sh->force_intra || (!two_pass && delayed > 2 * C * nbands && avail > nbands * C);
    if (tell0 + 3 > budget) { two_pass = 0; intra_only = 0; }
-   const i32 intra_bias = (i32)(((u32)budget * (u32)delayed * (u32)sh->loss_rate) / (u32)(C * 512));
+   /* (budget * delayedIntra * loss_rate) / (C * 512) in the reference's 32-bit signed arithmetic (quant_bands.c:279): the product wraps at high loss rates, and the division is signed */
+   const i32 intra_bias = (i32)((u32)budget * (u32)delayed * (u32)sh->loss_rate) / (C * 512);
    i32 max_decay = GC(16.f);
    if (nbands > 10) max_decay = shl32(imin(max_decay >> (DB_SHIFT - 3), avail), DB_SHIFT - 3);
    if (lfe) max_decay = GC(3.f);
