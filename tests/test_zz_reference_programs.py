@@ -64,7 +64,18 @@ def test_gpu_test_opus_decode_and_encode(tmp_path):
     """test_opus_decode in full and test_opus_encode in full with every packet checked against the reference's (see _traced).  The two programs run side by side: each is
     bound by the latency of single-wave launches (~1-2 ms per call, tools/classic_latency.py), not by the GPU.  Measured on the MI355X: test_opus_decode 6 min 45 s
     (profiles/r02_b), the traced test_opus_encode with its fuzz section ~9 min next to another process (208,835 encode calls at this seed; profiles/r03_m)."""
-    import threading
+    import threading, sys
+    import conftest
+    bg = conftest.BACKGROUND
+    if bg.get("test_opus_decode") is not None and bg.get("test_opus_encode") is not None:           # started with the session (tests/conftest.py): collect
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import enc_trace_digest
+        for name, out in (("test_opus_decode", "dec.out"), ("test_opus_encode", "enc.out")):
+            rc = bg[name].wait(timeout=1500)
+            assert rc == 0, (name, open(os.path.join(bg["dir"], out), "rb").read().decode(errors="replace")[-3000:])
+        bad = enc_trace_digest.check(os.path.join(bg["dir"], "enc_trace.log"), os.path.join(ROOT, "tests/golden/enc_trace_20260922.digest"))
+        assert bad is None, bad
+        return
     res = {}
     def dec():
         try:
