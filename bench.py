@@ -345,7 +345,7 @@ def main():
             try:
                 pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json" if NO_ANALYSIS else "pmc_traffic_r03.json")))["config_%d" % r["config_id"]]
                 if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
-                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (rocprofv3 --pmc passes at build r02_final3, no analysis)" if NO_ANALYSIS else "profiles/pmc_traffic_r03.json (rocprofv3 --pmc passes at build r03_b, analysis on; configs 3 / 4: round-2 counters)"}
+                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (rocprofv3 --pmc passes at build r02_final3, no analysis)" if NO_ANALYSIS else "profiles/pmc_traffic_r03.json (rocprofv3 --pmc passes of the final round-3 build, analysis on: profiles/r03_final; configs 3 / 4: round-2 counters)"}
             except Exception: pass
             return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
                     "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),

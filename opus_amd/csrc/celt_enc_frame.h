@@ -442,12 +442,32 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
 }
 
 /* celt_maxabs16 / compute_frame_energy (src/opus_encoder.c:1080) of n int16 samples in HBM: plain int32 sums, order-free */
-WV_DEV i32 oa_maxabs_wave(const i16 *pcm, int n) { i32 m = 0; FOR_LANES(i, n) m = imax(m, iabs((i32)pcm[i])); return wv_max(m); }
+/* (n is even and pcm 4-byte aligned -- frame sizes are multiples of 20 samples: two samples per load, eight loads in flight per lane) */
+WV_DEV i32 oa_maxabs_wave(const i16 *pcm, int n)
+{
+   const u32 *p = (const u32 *)pcm; const int n2 = n >> 1;
+   i32 m = 0;
+   for (int i0 = wv_lane(); i0 < n2; i0 += 8 * WV_WIDTH) {
+      u32 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const int i = i0 + k * WV_WIDTH; v[k] = i < n2 ? p[i] : 0u; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) m = imax(m, imax(iabs((i32)(i16)(v[k] & 0xffffu)), iabs((i32)(i16)(v[k] >> 16))));
+   }
+   return wv_max(m);
+}
 WV_DEV i32 oa_frame_energy_wave(const i16 *pcm, int len, i32 sample_max)
 {
    const int shift = imax(0, (celt_ilog2(1 + sample_max) << 1) + celt_ilog2(len) - 28);
+   const u32 *p = (const u32 *)pcm; const int n2 = len >> 1;
    i32 e = 0;
-   FOR_LANES(i, len) e += mult16_16(pcm[i], pcm[i]) >> shift;
+   for (int i0 = wv_lane(); i0 < n2; i0 += 8 * WV_WIDTH) {
+      u32 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const int i = i0 + k * WV_WIDTH; v[k] = i < n2 ? p[i] : 0u; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const i32 a = (i16)(v[k] & 0xffffu), b = (i16)(v[k] >> 16); e += (mult16_16(a, a) >> shift) + (mult16_16(b, b) >> shift); }
+   }
    e = wv_sum(e);
    e /= len;
    return shl32(e, shift);
