@@ -954,6 +954,15 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       } else b = 0;
       if (resynth && (M * ct_eBands[i] - N >= M * ct_eBands[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
          lowband_offset = i;
+      /* special_hybrid_folding (bands.c:1575, RFC 8251 section 9): enough of the first band's folding data is duplicated for the second band to fold from (nothing when
+       * start == 0).  It only matters to an encoder that resynthesises -- the theta RDO compares reconstructions -- and there it has to be redone before the second RDO
+       * attempt of that band, whose first attempt wrote its own reconstruction over the copy (:1869) */
+      const int hf_n1 = M * (ct_eBands[start + 1] - ct_eBands[start]), hf_n2 = M * (ct_eBands[start + 2] - ct_eBands[start + 1]);
+      if (resynth && i == start + 1) {
+         wv_sync();
+         FOR_LANES(j, hf_n2 - hf_n1) { norm[hf_n1 + j] = norm[2 * hf_n1 - hf_n2 + j]; if (dual_stereo) norm2[hf_n1 + j] = norm2[2 * hf_n1 - hf_n2 + j]; }
+         wv_sync();
+      }
       tf_change = wv_uni(tf_res[i]);
       cfg.tf_change = tf_change;
       if (last && !theta_rdo) lowband_scratch = 0;
@@ -1021,6 +1030,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
                FOR_LANES(j, N) { X[j] = Xg[j]; Y[j] = Yg[j]; }
                wv_sync();
+               if (i == start + 1) { FOR_LANES(j, hf_n2 - hf_n1) norm[hf_n1 + j] = norm[2 * hf_n1 - hf_n2 + j]; wv_sync(); }      /* (theta RDO runs without dual stereo) */
                cfg.theta_round = 1;
                K_TOC(21);
                r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);

@@ -322,11 +322,9 @@ def fuzz_batch(seed, S=5, changes=8, hold_ms=250):
 def test_batch_abi_settings_fuzz_against_the_reference(seed): fuzz_batch(seed)
 
 
-@pytest.mark.xfail(strict=False, reason="open: see the docstring")
-def test_open_mismatch_hybrid_stereo_60ms_cbr_fec_no_prediction():
-    """KNOWN OPEN MISMATCH (round 3, sparse fuzz seed 2169): a 48 kHz stereo AUDIO encoder, packet loss 40 %, in-band FEC, OPUS_SET_PREDICTION_DISABLED(1), hard CBR 96 kb/s,
-    60 ms calls (three hybrid frames per packet), complexity >= 8, after one 2.5 ms CELT frame at the start: in the ninth 60 ms packet 39 bytes of the SECOND frame's
-    CELT layer differ from the reference's (lengths, TOCs and the packet's final range agree; the packet decodes).  20 ms and 40 ms calls, complexity <= 7, mono, VBR,
-    no FEC, prediction enabled, or no leading 2.5 ms frame: identical.  Not understood yet (the band quantiser's theta RDO is the only stage that switches on at
-    complexity 8)."""
+def test_hybrid_stereo_theta_rdo_folds_the_second_band_like_the_reference():
+    """sparse fuzz seed 2169 (the last open case of round 3's campaign): a 48 kHz stereo AUDIO encoder, packet loss 40 %, in-band FEC, OPUS_SET_PREDICTION_DISABLED(1), hard
+    CBR 96 kb/s, 60 ms calls, complexity >= 8 -- little enough for CELT's four hybrid bands that partitions without pulses fold from the band below.  An encoder that
+    resynthesises (the theta RDO compares reconstructions) needs special_hybrid_folding (celt/bands.c:1575) like the decoder, and again before the second RDO attempt of
+    band start + 1; without it 39 bytes of one frame differed (same lengths, same final range of the packet, decodable)"""
     fuzz_sparse(2169)
