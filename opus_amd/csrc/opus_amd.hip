@@ -613,7 +613,10 @@ static void oa_classic_encode_group(std::vector<OaEncCall *> &g)
    if (r != OPUS_OK) for (OaEncCall *c : g) c->ret = r;
 }
 /* one frame of one classic encoder: the record goes to the device, the kernel runs one wave for it (and one for every other call waiting with it), the record comes back.  depth = the sample depth
- * of the entry point (opus_encode 16, opus_encode24 / _float 24: the lsb_depth argument of opus_encode_native, src/opus_encoder.c:2667,:2722) */
+ * of the entry point (the lsb_depth argument of opus_encode_native, src/opus_encoder.c:2667,:2722: 16 for every entry point of this build, see OA_MAX_ENCODING_DEPTH) */
+/* MAX_ENCODING_DEPTH of the build this library reproduces (FIXED_POINT without ENABLE_RES24, celt/arch.h:176): the 24-bit and float entry points convert to 16-bit samples and
+ * say so -- lsb_depth 16 reaches the codec and the analysis, whatever the caller's samples held (src/opus_encoder.c:2724,:2762; the analysis still sees the unrounded samples) */
+#define OA_MAX_ENCODING_DEPTH 16
 static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int analysis_frame_size, unsigned char *data, opus_int32 max_data_bytes, int depth, const opus_int32 *apcm = nullptr)
 {
    if (!st || st->magic != OA_MAGIC || !pcm || !data) return OPUS_BAD_ARG;
@@ -655,7 +658,7 @@ opus_int32 opus_encode24(OpusEncoder *st, const opus_int32 *pcm, int frame_size,
    std::vector<opus_int16> in((size_t)frame_size * channels);
    std::vector<opus_int32> sig((size_t)frame_size * channels);                                 /* what the analysis sees: INT24TOSIG (downmix_int24, src/opus_encoder.c:804) */
    for (size_t i = 0; i < in.size(); i++) { in[i] = oa_sat16((pcm[i] + 128) >> 8); sig[i] = (opus_int32)((opus_uint32)pcm[i] << 4); }
-   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, OA_MAX_ENCODING_DEPTH, sig.data());
 }
 opus_int32 opus_encode_float(OpusEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 {
@@ -664,7 +667,7 @@ opus_int32 opus_encode_float(OpusEncoder *st, const float *pcm, int frame_size, 
    std::vector<opus_int16> in((size_t)frame_size * channels);
    std::vector<opus_int32> sig((size_t)frame_size * channels);                                 /* what the analysis sees: FLOAT2SIG (downmix_float :748, celt/float_cast.h:166) */
    for (size_t i = 0; i < in.size(); i++) { in[i] = oa_float2int16(pcm[i]); sig[i] = oa_float2sig(pcm[i]); }
-   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
+   return oa_classic_encode(st, in.data(), frame_size, data, max_data_bytes, OA_MAX_ENCODING_DEPTH, sig.data());
 }
 int opus_encoder_ctl(OpusEncoder *st, int request, ...)
 {

@@ -87,7 +87,7 @@ int opus_multistream_encode24(OpusMSEncoder *st, const opus_int32 *pcm, int fram
    std::vector<opus_int16> in((size_t)frame_size * oa_ms_enc_channels(st));
    std::vector<opus_int32> sig(in.size());
    for (size_t i = 0; i < in.size(); i++) { in[i] = oa_sat16((pcm[i] + 128) >> 8); sig[i] = (opus_int32)((opus_uint32)pcm[i] << 4); }
-   return oa_ms_encode_native(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
+   return oa_ms_encode_native(st, in.data(), frame_size, data, max_data_bytes, OA_MAX_ENCODING_DEPTH, sig.data());
 }
 int opus_multistream_encode_float(OpusMSEncoder *st, const float *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 {
@@ -95,7 +95,7 @@ int opus_multistream_encode_float(OpusMSEncoder *st, const float *pcm, int frame
    std::vector<opus_int16> in((size_t)frame_size * oa_ms_enc_channels(st));
    std::vector<opus_int32> sig(in.size());
    for (size_t i = 0; i < in.size(); i++) { in[i] = oa_float2int16(pcm[i]); sig[i] = oa_float2sig(pcm[i]); }
-   return oa_ms_encode_native(st, in.data(), frame_size, data, max_data_bytes, 24, sig.data());
+   return oa_ms_encode_native(st, in.data(), frame_size, data, max_data_bytes, OA_MAX_ENCODING_DEPTH, sig.data());
 }
 int opus_multistream_decode24(OpusMSDecoder *st, const unsigned char *data, opus_int32 len, opus_int32 *pcm, int frame_size, int decode_fec)
 {

@@ -108,7 +108,7 @@ int opus_projection_encode_float(OpusProjectionEncoder *st, const float *pcm, in
    }
    std::vector<opus_int32> sig((size_t)frame_size * C);                                    /* (the analyses see the un-mixed input: downmix_float) */
    for (size_t i = 0; i < sig.size(); i++) sig[i] = oa_float2sig(pcm[i]);
-   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, 24, sig.data());
+   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, OA_MAX_ENCODING_DEPTH, sig.data());
 }
 void opus_projection_encoder_destroy(OpusProjectionEncoder *st) { free(st); }
 int opus_projection_encoder_ctl(OpusProjectionEncoder *st, int request, ...)

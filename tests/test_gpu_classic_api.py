@@ -62,3 +62,6 @@ def test_batch_abi_fuzz_on_the_device():
 
 def test_multistream_decoder_fuzz_on_the_device():
     for seed in range(200, 220): Z.fuzz_ms_dec(seed)
+
+def test_entry_point_fuzz_on_the_device():
+    for seed in [0, 3, 25, 26] + list(range(80, 96)): Z.fuzz_entry(seed)
