@@ -65,3 +65,6 @@ def test_multistream_decoder_fuzz_on_the_device():
 
 def test_entry_point_fuzz_on_the_device():
     for seed in [0, 3, 25, 26] + list(range(80, 96)): Z.fuzz_entry(seed)
+
+def test_projection_fuzz_on_the_device():
+    for seed in range(120, 130): Z.fuzz_proj(seed)

@@ -363,3 +363,52 @@ def fuzz_entry(seed, changes=8, hold_ms=300):
 # MAX_ENCODING_DEPTH, celt/arch.h:176 -- which moves the noise floor of the dynamic allocation by eight bits on quiet input)
 @pytest.mark.parametrize("seed", [0, 3, 4, 9, 13, 25, 26, 45])
 def test_entry_point_fuzz_against_the_reference(seed): fuzz_entry(seed)
+
+
+def fuzz_proj(seed, changes=5, hold_ms=200):
+    """projection (ambisonics with mixing matrices, mapping family 3) encoders and decoders of a random order under changing settings: packets, final ranges and decoded PCM"""
+    rng = np.random.default_rng(29000 + seed)
+    nch = int(rng.choice([4, 6, 9, 11, 16, 18])); Fs = int(rng.choice([16000, 24000, 48000, 48000])); app = int(rng.choice([2048, 2049, 2051]))
+    analysis = seed % 2 == 0
+    R = capi.load("ref_fxa" if analysis else "ref"); E = capi.load(WHICH); vp, ci = ctypes.c_void_p, ctypes.c_int
+    encs = []; decs = []
+    for L in (R, E):
+        L.opus_projection_ambisonics_encoder_create.restype = vp
+        L.opus_projection_ambisonics_encoder_create.argtypes = [ctypes.c_int32, ci, ci, vp, vp, ci, vp]
+        s, c, err = ci(), ci(), ci()
+        e = L.opus_projection_ambisonics_encoder_create(Fs, nch, 3, ctypes.byref(s), ctypes.byref(c), app, ctypes.byref(err)); assert e and err.value == 0, (seed, nch, err.value)
+        L.opus_projection_encode.argtypes = [vp, vp, ci, vp, ctypes.c_int32]
+        L.opus_projection_encoder_ctl.argtypes = [vp, ci, vp]
+        size = ctypes.c_int32(); assert L.opus_projection_encoder_ctl(e, 6003, ctypes.byref(size)) == 0
+        mat = (ctypes.c_ubyte * size.value)(); L.opus_projection_encoder_ctl.argtypes = [vp, ci, vp, ci]; assert L.opus_projection_encoder_ctl(e, 6005, mat, size.value) == 0
+        L.opus_projection_decoder_create.restype = vp; L.opus_projection_decoder_create.argtypes = [ctypes.c_int32, ci, ci, ci, vp, ctypes.c_int32, vp]
+        d = L.opus_projection_decoder_create(Fs, nch, s.value, c.value, mat, size.value, ctypes.byref(err)); assert d and err.value == 0
+        L.opus_projection_decode.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, vp, ci, ci]
+        encs.append((L, e, (s.value, c.value, bytes(mat)))); decs.append((L, d))
+    assert encs[0][2] == encs[1][2]
+    def ctl(L, e, req, v): L.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]; return L.opus_projection_encoder_ctl(e, req, v)
+    assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
+    cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(4)]
+    sig = np.ascontiguousarray(np.stack([(cols[q % 4] // (1 + q // 4)).astype(np.int16) for q in range(nch)], 1)); pos = 0
+    cap = 1500 * nch; bufs = [(ctypes.c_ubyte * cap)(), (ctypes.c_ubyte * cap)()]
+    for j in range(changes):
+        fr = int(rng.choice([10, 20, 40, 40, 80])) * Fs // 2000
+        for req, vals in ((4002, [16000 * nch, 48000 * nch, -1000, -1]), (4006, [0, 1]), (4010, [0, 5, 10]), (4020, [0, 1])):
+            v = int(rng.choice(vals)); ra, rb = ctl(R, encs[0][1], req, v), ctl(E, encs[1][1], req, v); assert ra == rb, (seed, j, req, v, ra, rb)
+        for i in range(max(2, hold_ms * Fs // 1000 // fr)):
+            x = np.ascontiguousarray(sig[pos:pos + fr]).reshape(-1); pos += fr
+            out = []
+            for (L, e, _), buf in zip(encs, bufs):
+                n = L.opus_projection_encode(e, x.ctypes.data, fr, buf, cap)
+                v = ctypes.c_uint32(); L.opus_projection_encoder_ctl.argtypes = [vp, ci, vp]; L.opus_projection_encoder_ctl(e, 4031, ctypes.byref(v))
+                out.append((n, bytes(buf[:max(n, 0)]), v.value))
+            assert out[0] == out[1], (seed, (nch, Fs, app), j, i, fr, out[0][0], out[1][0])
+            pcm = []
+            for L, d in decs:
+                o = np.zeros((fr, nch), np.int16); r = L.opus_projection_decode(d, out[0][1], out[0][0], o.ctypes.data, fr, 0); pcm.append((r, o.tobytes()))
+            assert pcm[0] == pcm[1], (seed, (nch, Fs, app), j, i, "decode", pcm[0][0], pcm[1][0])
+    for (L, e, _), (_, d) in zip(encs, decs):
+        L.opus_projection_encoder_destroy.argtypes = [vp]; L.opus_projection_encoder_destroy(e); L.opus_projection_decoder_destroy.argtypes = [vp]; L.opus_projection_decoder_destroy(d)
+
+@pytest.mark.parametrize("seed", range(6))
+def test_projection_fuzz_against_the_reference(seed): fuzz_proj(seed)
