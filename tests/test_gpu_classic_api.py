@@ -68,3 +68,6 @@ def test_entry_point_fuzz_on_the_device():
 
 def test_projection_fuzz_on_the_device():
     for seed in range(120, 130): Z.fuzz_proj(seed)
+
+def test_packet_toolkit_fuzz_with_the_product_library():
+    for seed in range(200, 210): Z.fuzz_packets(seed)

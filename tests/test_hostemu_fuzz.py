@@ -412,3 +412,70 @@ def fuzz_proj(seed, changes=5, hold_ms=200):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_projection_fuzz_against_the_reference(seed): fuzz_proj(seed)
+
+
+def fuzz_packets(seed, rounds=60):
+    """the packet toolkit and the repacketizer (src/opus.c, src/repacketizer.c: host code, rewritten from RFC 6716 in round 2) against the reference's: packets of every mode
+    and framing from the reference encoder -- whole, truncated, with bytes flipped, and random bytes -- through opus_packet_parse / _get_* / _has_lbrr, pad / unpad (single and
+    multistream), and the repacketizer (runs of compatible and incompatible packets, random output ranges and buffer sizes): return codes and bytes"""
+    rng = np.random.default_rng(33000 + seed)
+    R, E = capi.load("ref"), capi.load(WHICH); vp, ci = ctypes.c_void_p, ctypes.c_int
+    Fs = int(rng.choice([8000, 16000, 48000])); ch = int(rng.choice([1, 2])); app = int(rng.choice([2048, 2049, 2051]))
+    e = capi.Enc("ref", Fs, ch, app); sig = _signal(rng, Fs, ch, Fs * 30); pos = 0
+    pool = []
+    for k in range(rounds):
+        if k % 6 == 0:
+            for name, vals in (("bitrate", [8000, 24000, 64000, 200000]), ("vbr", [0, 1]), ("inband_fec", [0, 1]), ("packet_loss", [0, 20]), ("force_mode", [-1000, 1000, 1001, 1002]), ("dtx", [0, 1])): e.set(name, int(rng.choice(vals)))
+        fr = int(rng.choice([5, 10, 20, 40, 40, 80, 120, 240])) * Fs // 2000
+        p = e.encode(sig[pos:pos + fr], fr, int(rng.choice([1276, 300, 4000])))[0]; pos += fr
+        if p: pool.append(p)
+    def variants(p):
+        yield p
+        if len(p) > 2: yield p[:int(rng.integers(1, len(p)))]
+        b = bytearray(p); b[int(rng.integers(0, min(len(b), 4)))] ^= 1 << int(rng.integers(0, 8)); yield bytes(b)
+        yield bytes(rng.integers(0, 256, int(rng.integers(1, 40))).astype(np.uint8))
+    for L in (R, E):
+        L.opus_packet_parse.argtypes = [ctypes.c_char_p, ctypes.c_int32, vp, vp, vp, vp]
+        L.opus_packet_get_nb_frames.argtypes = [ctypes.c_char_p, ctypes.c_int32]; L.opus_packet_get_nb_samples.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
+        L.opus_packet_has_lbrr.argtypes = [ctypes.c_char_p, ctypes.c_int32]; L.opus_packet_get_bandwidth.argtypes = [ctypes.c_char_p]; L.opus_packet_get_nb_channels.argtypes = [ctypes.c_char_p]
+        L.opus_packet_get_samples_per_frame.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+        L.opus_packet_pad.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]; L.opus_packet_unpad.argtypes = [vp, ctypes.c_int32]
+        L.opus_multistream_packet_pad.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ci]; L.opus_multistream_packet_unpad.argtypes = [vp, ctypes.c_int32, ci]
+        L.opus_repacketizer_create.restype = vp; L.opus_repacketizer_cat.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32]; L.opus_repacketizer_init.argtypes = [vp]; L.opus_repacketizer_init.restype = vp
+        L.opus_repacketizer_out_range.argtypes = [vp, ci, ci, vp, ctypes.c_int32]; L.opus_repacketizer_out.argtypes = [vp, vp, ctypes.c_int32]; L.opus_repacketizer_get_nb_frames.argtypes = [vp]
+        L.opus_repacketizer_destroy.argtypes = [vp]
+    def info(L, p):
+        toc = ctypes.c_ubyte(); sizes = (ctypes.c_int16 * 48)(); frames = (vp * 48)(); off = ci()
+        buf = ctypes.create_string_buffer(p, len(p))
+        n = L.opus_packet_parse(buf, len(p), ctypes.byref(toc), frames, sizes, ctypes.byref(off))
+        base = ctypes.addressof(buf)
+        fr = [(frames[i] - base, sizes[i]) for i in range(max(n, 0))]
+        return (n, toc.value if n > 0 else 0, fr, off.value if n > 0 else 0, L.opus_packet_get_nb_frames(p, len(p)), L.opus_packet_get_nb_samples(p, len(p), 48000), L.opus_packet_has_lbrr(p, len(p)),
+                L.opus_packet_get_bandwidth(p), L.opus_packet_get_nb_channels(p), L.opus_packet_get_samples_per_frame(p, 16000))
+    for p in pool:
+        for q in variants(p):
+            a, b = info(R, q), info(E, q); assert a == b, (seed, "parse", q[:6].hex(), len(q), a[:2], b[:2])
+            if q is not p: continue                                       # pad / unpad only on well-formed packets: what the reference does with NON-ZERO padding bytes (it reads
+                                                                          # them as packet extensions, src/extensions.c, and rejects or re-generates them) is out of scope here (DESIGN section 7)
+            for new_len in (len(q), len(q) + 1, len(q) + 2, len(q) + int(rng.integers(3, 700)), max(1, len(q) - 1)):
+                out = []
+                for L in (R, E):
+                    buf = (ctypes.c_ubyte * (new_len + 8))(*q[:new_len + 8]); r = L.opus_packet_pad(buf, len(q), new_len)
+                    r2 = L.opus_packet_unpad(buf, new_len) if r == 0 else None
+                    out.append((r, bytes(buf[:new_len]) if r == 0 else None, r2, bytes(buf[:max(r2 or 0, 0)])))
+                assert out[0] == out[1], (seed, "pad", q[:4].hex(), len(q), new_len, out[0][0], out[1][0], out[0][2], out[1][2])
+    for _ in range(rounds):                                               # repacketizer: runs of packets
+        k = int(rng.integers(1, 6)); run = [pool[int(rng.integers(0, len(pool)))] for _ in range(k)]
+        if rng.random() < 0.6: run = [run[0]] * k if rng.random() < 0.3 else [p for p in pool if p[0] & 0xfc == run[0][0] & 0xfc][:k] or run
+        res = []; tight = int(rng.integers(1, 400))
+        for L in (R, E):
+            rp = L.opus_repacketizer_create(); rets = [L.opus_repacketizer_cat(rp, p, len(p)) for p in run]; nb = L.opus_repacketizer_get_nb_frames(rp)
+            outs = []
+            for (b0, e0, maxlen) in ((0, nb, 8000), (0, max(1, nb // 2), 8000), (nb // 2, nb, 60), (0, nb, tight), (1, 0, 100), (0, nb + 1, 100)):
+                buf = (ctypes.c_ubyte * 8000)(); r = L.opus_repacketizer_out_range(rp, b0, e0, buf, maxlen); outs.append((r, bytes(buf[:max(r, 0)])))
+            buf = (ctypes.c_ubyte * 8000)(); r = L.opus_repacketizer_out(rp, buf, 8000); outs.append((r, bytes(buf[:max(r, 0)])))
+            L.opus_repacketizer_destroy(rp); res.append((rets, nb, outs))
+        assert res[0] == res[1], (seed, "repacketizer", [p[:1].hex() for p in run], res[0][0], res[1][0], res[0][1], res[1][1], [o[0] for o in res[0][2]], [o[0] for o in res[1][2]])
+
+@pytest.mark.parametrize("seed", range(6))
+def test_packet_toolkit_fuzz_against_the_reference(seed): fuzz_packets(seed)
