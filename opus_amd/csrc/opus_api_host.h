@@ -30,7 +30,7 @@ void opus_pcm_soft_clip(float *pcm, int frame_size, int channels, float *softcli
       for (;;) {
          /* next sample outside [-1, 1] */
          int pos = curr;
-         if (any) while (pos < N && x[pos * C] <= 1.f && x[pos * C] >= -1.f) pos++; else pos = N;
+         if (any) while (pos < N && !(x[pos * C] > 1.f || x[pos * C] < -1.f)) pos++; else pos = N;      /* (the reference's predicate, src/opus.c:81: a NaN is not "outside" and passes through; the other form never got past one) */
          if (pos == N) { a = 0; break; }
          int peak = pos, start = pos, end = pos;
          float vmax = fabsf(x[pos * C]);

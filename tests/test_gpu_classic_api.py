@@ -71,3 +71,7 @@ def test_projection_fuzz_on_the_device():
 
 def test_packet_toolkit_fuzz_with_the_product_library():
     for seed in range(200, 210): Z.fuzz_packets(seed)
+
+@pytest.mark.timeout(300)
+def test_float_output_fuzz_with_the_product_library():
+    for seed in range(80, 90): Z.fuzz_float_out(seed)

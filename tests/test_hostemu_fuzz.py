@@ -10,7 +10,7 @@ import ctypes, numpy as np, pytest
 import capi, signals
 from reflib import ref_fx, ref_fxa
 from test_kernel_emu_silkdec import speechy
-pytestmark = pytest.mark.skipif(ref_fx() is None or ref_fxa() is None, reason="oracle/_ref not built")
+pytestmark = [pytest.mark.skipif(ref_fx() is None or ref_fxa() is None, reason="oracle/_ref not built"), pytest.mark.timeout(900)]   # (a hang is a finding too: opus_pcm_soft_clip on a NaN was one)
 WHICH = "emu"
 
 def _signal(rng, Fs, ch, nsamp):
@@ -479,3 +479,43 @@ def fuzz_packets(seed, rounds=60):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_packet_toolkit_fuzz_against_the_reference(seed): fuzz_packets(seed)
+
+
+def fuzz_float_out(seed):
+    """the float side of the decoder API: opus_decode_float / opus_decode24 (sample conversion of the fixed-point decoder's output) and opus_pcm_soft_clip (src/opus.c:39, float
+    arithmetic: compared bit for bit against the reference with the float API) on random and on clipping input, with the memory carried across calls"""
+    rng = np.random.default_rng(37000 + seed)
+    R, E = capi.load("ref_fxa"), capi.load(WHICH); vp, ci = ctypes.c_void_p, ctypes.c_int
+    for L in (R, E): L.opus_pcm_soft_clip.argtypes = [vp, ci, ci, vp]; L.opus_pcm_soft_clip.restype = None
+    for ch in (1, 2):
+        mem = [np.zeros(2, np.float32), np.zeros(2, np.float32)]
+        for k in range(30):
+            n = int(rng.choice([1, 7, 120, 480, 960]))
+            kind = int(rng.integers(0, 4))
+            x = (rng.standard_normal((n, ch)) * (0.3, 0.9, 1.5, 4.0)[kind]).astype(np.float32)
+            if kind == 3: x[rng.integers(0, n)] = np.float32(np.nan) if rng.random() < 0.3 else np.float32(3.0)
+            out = []
+            for i, L in enumerate((R, E)):
+                y = np.ascontiguousarray(x.copy()); L.opus_pcm_soft_clip(y.ctypes.data, n, ch, mem[i].ctypes.data); out.append((y.view(np.uint32).tobytes(), mem[i].view(np.uint32).tobytes()))
+            assert out[0] == out[1], (seed, "soft_clip", ch, k, n, kind)
+    Fs = int(rng.choice([16000, 48000])); ch = int(rng.choice([1, 2]))
+    e = capi.Enc("ref", Fs, ch, 2049, bitrate=32000 * ch); sig = _signal(rng, Fs, ch, Fs * 2)
+    outFs = int(rng.choice([8000, 24000, 48000])); outch = int(rng.choice([1, 2]))
+    decs = [(L, capi.Dec(w, outFs, outch)) for L, w in ((R, "ref_fxa"), (E, WHICH))]
+    for L, _ in decs:
+        L.opus_decode_float.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, vp, ci, ci]; L.opus_decode24.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, vp, ci, ci]
+    fr = Fs // 50; no = outFs // 50
+    for i in range(40):
+        pkt = e.encode(sig[i * fr:(i + 1) * fr], fr)[0]
+        if rng.random() < 0.1: pkt = b""
+        kind = int(rng.integers(0, 2)); res = []
+        for L, d in decs:
+            if kind == 0: o = np.zeros((no, outch), np.float32); r = L.opus_decode_float(d.st, pkt if pkt else None, len(pkt), o.ctypes.data, no, 0)
+            else: o = np.zeros((no, outch), np.int32); r = L.opus_decode24(d.st, pkt if pkt else None, len(pkt), o.ctypes.data, no, 0)
+            res.append((r, o.tobytes()))
+        assert res[0] == res[1], (seed, "decode", kind, i, res[0][0], res[1][0])
+
+# (when this test was written opus_pcm_soft_clip never returned on input holding a NaN: its scan for the next sample outside [-1, 1] stopped AT the NaN, the reference's
+# predicate walks past it)
+@pytest.mark.parametrize("seed", range(4))
+def test_float_output_fuzz_against_the_reference(seed): fuzz_float_out(seed)
