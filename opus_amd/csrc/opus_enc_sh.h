@@ -507,15 +507,15 @@ template <class P16> WV_DEV void sh_stereo_fade_lds(P16 io, int n, i16 g1_, i16 
    }
 }
 
-/* One coded frame: opus_encode_frame_native (:1855).  pcm = this frame's input, frame_size samples per channel; the packet ends up in L->packet, its length (before
- * CBR padding) is returned and st / the HBM state are updated.  pcm_hp / pcm_celt / pre = per-stream HBM scratch. */
-WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill,
-      SeRateScratch *G, u8 *journal)
+/* One coded frame: opus_encode_frame_native (:1855), in two halves around the SILK layer so that the split path (opus_sh_split.h) can run them in kernels of their own.
+ * pcm = this frame's input, frame_size samples per channel; the packet ends up in L->packet, its length (before CBR padding) is returned and st / the HBM state are
+ * updated.  pcm_hp / pcm_celt / pre = per-stream HBM scratch.
+ * sh_frame_front_wave: activity (:1911-1930), the frame's redundancy / budget words, coder start, high-pass into pcm_hp (:1969-2009) and, when SILK codes the frame, the
+ * SILK control block *scp (:2043-2189). */
+WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, i16 *pcm_hp, SeControl *scp)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, application = L->cfg.application;
-   const int delay_compensation = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, total_buffer = delay_compensation, encoder_buffer = Fs / 100;
    const int frame_rate = Fs / frame_size;
    frame_size = wv_uni(frame_size); orig_max_data_bytes = wv_uni(orig_max_data_bytes);
    /* ---- activity (:1911-1930) ---- */
@@ -577,9 +577,8 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    }
    SE_PHASE(&L->S, 1);
    const int mode = wv_uni(st->mode);
-   SeControl sc;
-   int silk_nBytes = 1;
    if (mode != OA_MODE_CELT_ONLY) {
+      SeControl &sc = *scp;
       /* ---- SILK (:2043-2261) ---- */
       {
          const int curr_bandwidth = sh->curr_bandwidth, redundancy = sh->f_redundancy, redundancy_bytes = sh->redundancy_bytes;
@@ -631,28 +630,22 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
          sc.toMono = st->sm_toMono; sc.opusCanSwitch = st->sm_opusCanSwitch; sc.reducedDependency = L->cfg.prediction_disabled;
          sc.internalSampleRate = 0; sc.allowBandwidthSwitch = 0; sc.inWBmodeWithoutVariableLP = 0; sc.stereoWidth_Q14 = 0; sc.switchReady = 0; sc.signalType = 0; sc.offset = 0;
       }
-      if (wv_uni(sh->f_prefill) && application != OA_APP_RESTRICTED_SILK) {
-         /* smooth onset for the SILK prefill (:2191-2209): fade the delay line in over 2.5 ms, silence before it, feed its 10 ms to SILK with nothing coded */
-         const int prefill_offset = CC * (encoder_buffer - delay_compensation - Fs / 400), n4 = Fs / 400;
-         WV_LDS i16 *stage = L->S.u.pcm_stage;
-         wv_sync();
-         FOR_LANES(i, n4 * CC) stage[i] = gs->delay_buffer[prefill_offset + i];
-         wv_sync();
-         sh_gain_fade_lds(stage, n4, CC, 0, Q15ONE, Fs);
-         wv_sync();
-         FOR_LANES(i, n4 * CC) gs->delay_buffer[prefill_offset + i] = stage[i];
-         FOR_LANES(i, prefill_offset) gs->delay_buffer[i] = 0;
-         wv_sync();
-         const int pr = silk_encode_wave(&L->S, &sc, gs->delay_buffer, encoder_buffer, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr, wv_uni(sh->f_prefill));
-         wv_sync();
-         if (pr) { LANE0 { gs->s.error = pr; } return OA_ERR_INTERNAL; }
-         sc.opusCanSwitch = 0;                                                              /* no second switch in the real call */
-      }
-      const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
-      wv_sync();
-      if (sret) { LANE0 { gs->s.error = sret; } return OA_ERR_INTERNAL; }
+   }
+}
+/* sh_frame_back_wave: everything after silk_Encode (:2211-2657): what the Opus layer reads back from *scp, the CELT passes, redundancy, TOC, DTX, the frame's length.
+ * silk_nBytes: what SILK returned (1 when it did not run) */
+WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs, application = L->cfg.application;
+   const int delay_compensation = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, total_buffer = delay_compensation, encoder_buffer = Fs / 100;
+   frame_size = wv_uni(frame_size); silk_nBytes = wv_uni(silk_nBytes);
+   const int frame_rate = Fs / frame_size;
+   const int mode = wv_uni(st->mode);
+   if (mode != OA_MODE_CELT_ONLY) {
+      const SeControl &sc = *scp;
       SE_PHASE(&L->S, 9);
-      silk_nBytes = wv_uni(L->S.r[0]);
       LANE0 {
          int curr_bandwidth = sh->curr_bandwidth;
          if (st->mode == OA_MODE_SILK_ONLY) { if (sc.internalSampleRate == 8000) curr_bandwidth = OA_BW_NB; else if (sc.internalSampleRate == 12000) curr_bandwidth = OA_BW_MB; else if (sc.internalSampleRate == 16000) curr_bandwidth = OA_BW_WB; }
@@ -852,6 +845,41 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
    }
    wv_sync();
    return wv_uni(sh->ret);
+}
+WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill,
+      SeRateScratch *G, u8 *journal)
+{
+   WV_LDS ShShared *sh = &L->sh;
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs, application = L->cfg.application;
+   const int delay_compensation = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, encoder_buffer = Fs / 100;
+   frame_size = wv_uni(frame_size);
+   SeControl sc;
+   int silk_nBytes = 1;
+   sh_frame_front_wave(L, gs, pcm, frame_size, orig_max_data_bytes, pcm_hp, &sc);
+   if (wv_uni(L->st.mode) != OA_MODE_CELT_ONLY) {
+      if (wv_uni(sh->f_prefill) && application != OA_APP_RESTRICTED_SILK) {
+         /* smooth onset for the SILK prefill (:2191-2209): fade the delay line in over 2.5 ms, silence before it, feed its 10 ms to SILK with nothing coded */
+         const int prefill_offset = CC * (encoder_buffer - delay_compensation - Fs / 400), n4 = Fs / 400;
+         WV_LDS i16 *stage = L->S.u.pcm_stage;
+         wv_sync();
+         FOR_LANES(i, n4 * CC) stage[i] = gs->delay_buffer[prefill_offset + i];
+         wv_sync();
+         sh_gain_fade_lds(stage, n4, CC, 0, Q15ONE, Fs);
+         wv_sync();
+         FOR_LANES(i, n4 * CC) gs->delay_buffer[prefill_offset + i] = stage[i];
+         FOR_LANES(i, prefill_offset) gs->delay_buffer[i] = 0;
+         wv_sync();
+         const int pr = silk_encode_wave(&L->S, &sc, gs->delay_buffer, encoder_buffer, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr, wv_uni(sh->f_prefill));
+         wv_sync();
+         if (pr) { LANE0 { gs->s.error = pr; } return OA_ERR_INTERNAL; }
+         sc.opusCanSwitch = 0;                                                              /* no second switch in the real call */
+      }
+      const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
+      wv_sync();
+      if (sret) { LANE0 { gs->s.error = sret; } return OA_ERR_INTERNAL; }
+      silk_nBytes = wv_uni(L->S.r[0]);
+   }
+   return sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, journal, &sc, silk_nBytes);
 }
 
 /* silk_InitEncoder (silk/enc_API.c:82) on the state staged in LDS: everything, both channels */

@@ -387,12 +387,15 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
 template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
-WV_DEVN void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
+/* silk_encode_frame_FIX in four pieces, so that the stages between the analysis and the bookkeeping (the noise-shaping quantiser and the entropy coder: the rate-control
+ * loop) can also run in a kernel of their own on a several-streams-per-wave layout (opus_sh_split.h); se_encode_frame_wave below strings them together for the one-kernel path.
+ *   se_frame_head_wave      :98-128   seed, variable low-pass, the frame into x_buf
+ *   se_frame_analysis_wave  :130-160  pitch, noise shaping, prediction coefficients, gains  -> ctl, c->indices
+ *   se_frame_quant_wave     :162-378  LBRR, the rate-control loop: NSQ -> indices -> pulses -> bits
+ *   se_frame_finish_wave    :380-389  x_buf shift, what the next frame conditions on */
+WV_DEV void se_frame_head_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
 {
-   WV_LDS SeEncCtrl *ctl = &S->ctl;
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
-   const int bits_margin = useCBR ? 5 : maxBits / 4;
-   const int NSQW = (int)(sizeof(OaSilkNsqState) / 4);
    SE_PHASE(S, 2);
    LANE0 {
       c->indices.Seed = (i8)(c->frameCounter++ & 3);
@@ -400,145 +403,159 @@ WV_DEVN void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel 
    }
    FOR_LANES(i, c->frame_length) x_frame[5 * c->fs_kHz + i] = c->inputBuf[1 + i];
    wv_sync();
-   if (!c->prefillFlag) {
-      WV_LDS SeAnaLds *A = &S->u.a;
-      WV_LDS i16 *res_pitch = A->res_pitch, *res_pitch_frame = res_pitch + c->ltp_mem_length;
-      se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->u.a.Wsig, A->u.a.xx, A->w32, A->A_Q12s, &A->u.a.pitch);
-      wv_sync();
-      SE_TAP(0);
-      SE_PHASE(S, 3);
-      se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->u.a.Wsig, A->u.a.xx, A->w32, S->stk);
-      wv_sync();
-      SE_TAP(1);
-      SE_PHASE(S, 4);
-      se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15]);
-      SE_TAP(2);
-      SE_PHASE(S, 5);
-      LANE0 se_process_gains_l0(c, ctl, condCoding);
-      SE_TAP(3);
-      SE_PHASE(S, 6);
-      WV_LDS SeQuantLds *Q = &S->u.q;
-      if (c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8)) {
-         /* silk_LBRR_encode_FIX (:392): the same frame once more with raised gains -- the noise-shaping quantiser runs on the live state, which comes
-          * back from its HBM snapshot afterwards; indices and pulses go to the stream's HBM store for the next packet */
-         const int fi = c->nFramesEncoded, chn = c->channelNb;
-         i32 TempGains_Q16[4];
-         for (int k = 0; k < 4; k++) TempGains_Q16[k] = ctl->Gains_Q16[k];
-         se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
-         LANE0 {
-            c->LBRR_flags[fi] = 1;
-            { WV_LDS i32 *d = (WV_LDS i32 *)&Q->ix_lbrr; const WV_LDS i32 *sr = (const WV_LDS i32 *)&c->indices; for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) d[k] = sr[k]; }
-            if (fi == 0 || c->LBRR_flags[fi - 1] == 0) {
-               c->LBRRprevLastGainIndex = c->LastGainIndex;
-               Q->ix_lbrr.GainsIndices[0] = (i8)imin(Q->ix_lbrr.GainsIndices[0] + c->LBRR_GainIncreases, 64 - 1);
-            }
-            i32 g[4]; i8 gi[4]; int prev = c->LBRRprevLastGainIndex;
-            for (int k = 0; k < 4; k++) gi[k] = Q->ix_lbrr.GainsIndices[k];
-            se_gains_dequant(g, gi, &prev, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
-            for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = g[k];
-            c->LBRRprevLastGainIndex = prev;
-         }
-         if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
-         else se_nsq_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
-         wv_sync();
-         FOR_LANES(i, c->frame_length) lb->pulses[chn][fi][i] = Q->pulses_lbrr[i];
-         { const WV_LDS i32 *src = (const WV_LDS i32 *)&Q->ix_lbrr; i32 *dst = (i32 *)&lb->indices[chn][fi]; FOR_LANES(i, (int)(sizeof(OaSilkEncIndices) / 4)) dst[i] = src[i]; }
-         se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
-         LANE0 { for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = TempGains_Q16[k]; }
-      }
-      const int maxIter = 6;
-      int gainMult_Q8 = SE_FIX(1, 8), found_lower = 0, found_upper = 0;
-      i32 gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr), gainsID_lower = -1, gainsID_upper = -1;
-      i32 nBits = 0, nBits_lower = 0, nBits_upper = 0, gainMult_lower = 0, gainMult_upper = 0;
-      int LastGainIndex_copy2 = 0;
-      int gain_lock[4] = {0, 0, 0, 0}; i16 best_gain_mult[4] = {0, 0, 0, 0}; int best_sum[4] = {0, 0, 0, 0};
-      ec_cp_lds(&Q->ec_copy, ecl);
+}
+WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, int condCoding)
+{
+   WV_LDS SeEncCtrl *ctl = &S->ctl;
+   WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+   WV_LDS SeAnaLds *A = &S->u.a;
+   WV_LDS i16 *res_pitch = A->res_pitch, *res_pitch_frame = res_pitch + c->ltp_mem_length;
+   se_find_pitch_lags_wave(c, ctl, res_pitch, x_frame - c->ltp_mem_length, A->u.a.Wsig, A->u.a.xx, A->w32, A->A_Q12s, &A->u.a.pitch);
+   wv_sync();
+   SE_TAP(0);
+   SE_PHASE(S, 3);
+   se_noise_shape_analysis_wave(c, ctl, res_pitch_frame, x_frame, A->u.a.Wsig, A->u.a.xx, A->w32, S->stk);
+   wv_sync();
+   SE_TAP(1);
+   SE_PHASE(S, 4);
+   se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15]);
+   SE_TAP(2);
+   SE_PHASE(S, 5);
+   LANE0 se_process_gains_l0(c, ctl, condCoding);
+   SE_TAP(3);
+   SE_PHASE(S, 6);
+}
+WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
+{
+   WV_LDS SeEncCtrl *ctl = &S->ctl;
+   WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+   const int bits_margin = useCBR ? 5 : maxBits / 4;
+   const int NSQW = (int)(sizeof(OaSilkNsqState) / 4);
+   WV_LDS SeQuantLds *Q = &S->u.q;
+   if (c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8)) {
+      /* silk_LBRR_encode_FIX (:392): the same frame once more with raised gains -- the noise-shaping quantiser runs on the live state, which comes
+       * back from its HBM snapshot afterwards; indices and pulses go to the stream's HBM store for the next packet */
+      const int fi = c->nFramesEncoded, chn = c->channelNb;
+      i32 TempGains_Q16[4];
+      for (int k = 0; k < 4; k++) TempGains_Q16[k] = ctl->Gains_Q16[k];
       se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
-      const int seed_copy = c->indices.Seed, ec_prevLagIndex_copy = c->ec_prevLagIndex, ec_prevSignalType_copy = c->ec_prevSignalType;
-      for (int iter = 0; ; iter++) {
-         if (gainsID == gainsID_lower) nBits = nBits_lower;
-         else if (gainsID == gainsID_upper) nBits = nBits_upper;
-         else {
-            if (iter > 0) {
-               wv_sync();
-               LANE0 { ec_cp_lds(ecl, &Q->ec_copy); c->indices.Seed = (i8)seed_copy; c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy; }
-               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
-            }
-            if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
-            else se_nsq_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+      LANE0 {
+         c->LBRR_flags[fi] = 1;
+         { WV_LDS i32 *d = (WV_LDS i32 *)&Q->ix_lbrr; const WV_LDS i32 *sr = (const WV_LDS i32 *)&c->indices; for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) d[k] = sr[k]; }
+         if (fi == 0 || c->LBRR_flags[fi - 1] == 0) {
+            c->LBRRprevLastGainIndex = c->LastGainIndex;
+            Q->ix_lbrr.GainsIndices[0] = (i8)imin(Q->ix_lbrr.GainsIndices[0] + c->LBRR_GainIncreases, 64 - 1);
+         }
+         i32 g[4]; i8 gi[4]; int prev = c->LBRRprevLastGainIndex;
+         for (int k = 0; k < 4; k++) gi[k] = Q->ix_lbrr.GainsIndices[k];
+         se_gains_dequant(g, gi, &prev, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
+         for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = g[k];
+         c->LBRRprevLastGainIndex = prev;
+      }
+      if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+      else se_nsq_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+      wv_sync();
+      FOR_LANES(i, c->frame_length) lb->pulses[chn][fi][i] = Q->pulses_lbrr[i];
+      { const WV_LDS i32 *src = (const WV_LDS i32 *)&Q->ix_lbrr; i32 *dst = (i32 *)&lb->indices[chn][fi]; FOR_LANES(i, (int)(sizeof(OaSilkEncIndices) / 4)) dst[i] = src[i]; }
+      se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
+      LANE0 { for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = TempGains_Q16[k]; }
+   }
+   const int maxIter = 6;
+   int gainMult_Q8 = SE_FIX(1, 8), found_lower = 0, found_upper = 0;
+   i32 gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr), gainsID_lower = -1, gainsID_upper = -1;
+   i32 nBits = 0, nBits_lower = 0, nBits_upper = 0, gainMult_lower = 0, gainMult_upper = 0;
+   int LastGainIndex_copy2 = 0;
+   int gain_lock[4] = {0, 0, 0, 0}; i16 best_gain_mult[4] = {0, 0, 0, 0}; int best_sum[4] = {0, 0, 0, 0};
+   ec_cp_lds(&Q->ec_copy, ecl);
+   se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+   const int seed_copy = c->indices.Seed, ec_prevLagIndex_copy = c->ec_prevLagIndex, ec_prevSignalType_copy = c->ec_prevSignalType;
+   for (int iter = 0; ; iter++) {
+      if (gainsID == gainsID_lower) nBits = nBits_lower;
+      else if (gainsID == gainsID_upper) nBits = nBits_upper;
+      else {
+         if (iter > 0) {
             wv_sync();
-            SE_TAP(4);
-            SE_PHASE(S, 7);
-            LANE0 {
-               if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
-               EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+            LANE0 { ec_cp_lds(ecl, &Q->ec_copy); c->indices.Seed = (i8)seed_copy; c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy; }
+            se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
+         }
+         if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+         else se_nsq_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+         wv_sync();
+         SE_TAP(4);
+         SE_PHASE(S, 7);
+         LANE0 {
+            if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
+            EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+            se_encode_indices(c, &c->indices, EC_PASS, condCoding);
+            se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
+            int nb = k_ec_tell(EC_PASS);
+            if (iter == maxIter && !found_lower && nb > maxBits) {
+               ec_ld(&ec_, &Q->ec_copy2);
+               c->LastGainIndex = ctl->lastGainIndexPrev;
+               for (int i = 0; i < c->nb_subfr; i++) c->indices.GainsIndices[i] = 4;
+               if (condCoding != SE_CODE_CONDITIONALLY) c->indices.GainsIndices[0] = (i8)ctl->lastGainIndexPrev;
+               c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
+               for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
                se_encode_indices(c, &c->indices, EC_PASS, condCoding);
                se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
-               int nb = k_ec_tell(EC_PASS);
-               if (iter == maxIter && !found_lower && nb > maxBits) {
-                  ec_ld(&ec_, &Q->ec_copy2);
-                  c->LastGainIndex = ctl->lastGainIndexPrev;
-                  for (int i = 0; i < c->nb_subfr; i++) c->indices.GainsIndices[i] = 4;
-                  if (condCoding != SE_CODE_CONDITIONALLY) c->indices.GainsIndices[0] = (i8)ctl->lastGainIndexPrev;
-                  c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
-                  for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
-                  se_encode_indices(c, &c->indices, EC_PASS, condCoding);
-                  se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
-                  nb = k_ec_tell(EC_PASS);
-               }
-               ec_st(ecl, &ec_);
-               S->r[1] = nb;
+               nb = k_ec_tell(EC_PASS);
             }
-            SE_PHASE(S, 8);
-            nBits = S->r[1];
-            if (useCBR == 0 && iter == 0 && nBits <= maxBits) break;
+            ec_st(ecl, &ec_);
+            S->r[1] = nb;
          }
-         if (iter == maxIter) {
-            if (found_lower && (gainsID == gainsID_lower || nBits > maxBits)) {
-               wv_sync();
-               LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = G->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
-               se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[1], NSQW);
-            }
-            break;
-         }
-         if (nBits > maxBits) {
-            if (found_lower == 0 && iter >= 2) { LANE0 ctl->Lambda_Q10 = ctl->Lambda_Q10 + (ctl->Lambda_Q10 >> 1); found_upper = 0; gainsID_upper = -1; }
-            else { found_upper = 1; nBits_upper = nBits; gainMult_upper = gainMult_Q8; gainsID_upper = gainsID; }
-         } else if (nBits < maxBits - bits_margin) {
-            found_lower = 1; nBits_lower = nBits; gainMult_lower = gainMult_Q8;
-            if (gainsID != gainsID_lower) {
-               gainsID_lower = gainsID;
-               wv_sync();
-               LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) G->ec_buf_copy[i] = buf[i]; }
-               se_copy_words_wave((i32 *)&G->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
-               LastGainIndex_copy2 = c->LastGainIndex;
-            }
-         } else break;
-         if (!found_lower && nBits > maxBits) {
-            for (int i = 0; i < c->nb_subfr; i++) {
-               int sum = 0;
-               for (int j = i * c->subfr_length; j < (i + 1) * c->subfr_length; j++) sum += iabs((i32)c->pulses[j]);
-               if (iter == 0 || (sum < best_sum[i] && !gain_lock[i])) { best_sum[i] = sum; best_gain_mult[i] = (i16)gainMult_Q8; } else gain_lock[i] = 1;
-            }
-         }
-         if ((found_lower & found_upper) == 0) {
-            if (nBits > maxBits) gainMult_Q8 = imin(1024, gainMult_Q8 * 3 / 2); else gainMult_Q8 = imax(64, gainMult_Q8 * 4 / 5);
-            gainMult_Q8 = (i16)gainMult_Q8;
-         } else {
-            gainMult_Q8 = gainMult_lower + ((gainMult_upper - gainMult_lower) * (maxBits - nBits_lower)) / (nBits_upper - nBits_lower);
-            gainMult_Q8 = (i16)gainMult_Q8;
-            if (gainMult_Q8 > gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2));
-            else if (gainMult_Q8 < gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2));
-         }
-         wv_sync();
-         LANE0 {
-            for (int i = 0; i < c->nb_subfr; i++) { const i16 tmp = gain_lock[i] ? best_gain_mult[i] : (i16)gainMult_Q8; ctl->Gains_Q16[i] = sk_shl_sat(sk_mulwb(ctl->GainsUnq_Q16[i], tmp), 8); }
-            c->LastGainIndex = ctl->lastGainIndexPrev;
-            se_gains_quant(c->indices.GainsIndices, ctl->Gains_Q16, &c->LastGainIndex, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
-         }
-         gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr);
+         SE_PHASE(S, 8);
+         nBits = S->r[1];
+         if (useCBR == 0 && iter == 0 && nBits <= maxBits) break;
       }
+      if (iter == maxIter) {
+         if (found_lower && (gainsID == gainsID_lower || nBits > maxBits)) {
+            wv_sync();
+            LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = G->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
+            se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[1], NSQW);
+         }
+         break;
+      }
+      if (nBits > maxBits) {
+         if (found_lower == 0 && iter >= 2) { LANE0 ctl->Lambda_Q10 = ctl->Lambda_Q10 + (ctl->Lambda_Q10 >> 1); found_upper = 0; gainsID_upper = -1; }
+         else { found_upper = 1; nBits_upper = nBits; gainMult_upper = gainMult_Q8; gainsID_upper = gainsID; }
+      } else if (nBits < maxBits - bits_margin) {
+         found_lower = 1; nBits_lower = nBits; gainMult_lower = gainMult_Q8;
+         if (gainsID != gainsID_lower) {
+            gainsID_lower = gainsID;
+            wv_sync();
+            LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) G->ec_buf_copy[i] = buf[i]; }
+            se_copy_words_wave((i32 *)&G->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
+            LastGainIndex_copy2 = c->LastGainIndex;
+         }
+      } else break;
+      if (!found_lower && nBits > maxBits) {
+         for (int i = 0; i < c->nb_subfr; i++) {
+            int sum = 0;
+            for (int j = i * c->subfr_length; j < (i + 1) * c->subfr_length; j++) sum += iabs((i32)c->pulses[j]);
+            if (iter == 0 || (sum < best_sum[i] && !gain_lock[i])) { best_sum[i] = sum; best_gain_mult[i] = (i16)gainMult_Q8; } else gain_lock[i] = 1;
+         }
+      }
+      if ((found_lower & found_upper) == 0) {
+         if (nBits > maxBits) gainMult_Q8 = imin(1024, gainMult_Q8 * 3 / 2); else gainMult_Q8 = imax(64, gainMult_Q8 * 4 / 5);
+         gainMult_Q8 = (i16)gainMult_Q8;
+      } else {
+         gainMult_Q8 = gainMult_lower + ((gainMult_upper - gainMult_lower) * (maxBits - nBits_lower)) / (nBits_upper - nBits_lower);
+         gainMult_Q8 = (i16)gainMult_Q8;
+         if (gainMult_Q8 > gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_lower + ((gainMult_upper - gainMult_lower) >> 2));
+         else if (gainMult_Q8 < gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2)) gainMult_Q8 = (i16)(gainMult_upper - ((gainMult_upper - gainMult_lower) >> 2));
+      }
+      wv_sync();
+      LANE0 {
+         for (int i = 0; i < c->nb_subfr; i++) { const i16 tmp = gain_lock[i] ? best_gain_mult[i] : (i16)gainMult_Q8; ctl->Gains_Q16[i] = sk_shl_sat(sk_mulwb(ctl->GainsUnq_Q16[i], tmp), 8); }
+         c->LastGainIndex = ctl->lastGainIndexPrev;
+         se_gains_quant(c->indices.GainsIndices, ctl->Gains_Q16, &c->LastGainIndex, condCoding == SE_CODE_CONDITIONALLY, c->nb_subfr);
+      }
+      gainsID = se_gains_ID(c->indices.GainsIndices, c->nb_subfr);
    }
+}
+WV_DEV void se_frame_finish_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, const WV_LDS EcCtx *ecl)
+{
+   const WV_LDS SeEncCtrl *ctl = &S->ctl;
    /* input buffer shift (:381): overlapping move through registers */
    {
       const int n = c->ltp_mem_length + 5 * c->fs_kHz, fl = c->frame_length;
@@ -552,6 +569,15 @@ WV_DEVN void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel 
       }
    }
 }
+WV_DEVN void se_encode_frame_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int condCoding, int maxBits, int useCBR, SeRateScratch *G, OaSilkLbrr *lb)
+{
+   se_frame_head_wave(S, c);
+   if (!c->prefillFlag) {
+      se_frame_analysis_wave(S, c, condCoding);
+      se_frame_quant_wave(S, c, ecl, buf, condCoding, maxBits, useCBR, G, lb);
+   }
+   se_frame_finish_wave(S, c, ecl);
+}
 
 /* ---- silk_Encode.  pcm: the Opus layer's int16 staging of this call's input (interleaved, nChannelsAPI), nSamplesIn per channel.
  * Returns 0 or a negative error; *nBytesOut through S->r[0].  One SILK frame per call for 10/20 ms payloads, 2-3 frames for 40/60 ms. ---- */
@@ -560,12 +586,13 @@ struct SePcmSrc {
    WV_MEM i32 operator[](int i) const { if (!mix) return p[i * stride + off]; const i32 s = (i32)p[2 * i] + p[2 * i + 1]; return (i16)sk_rround(s, 1); }
    WV_MEM SePcmSrc operator+(int k) const { SePcmSrc r = *this; r.p = p + k * (mix ? 2 : stride); return r; }
 };
-WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb, int prefillFlag = 0)
+/* silk_Encode in pieces (the one-kernel path strings them together in silk_encode_wave; the split path -- opus_sh_split.h -- runs the channel loop's quantiser in a kernel of its own) */
+struct SeCall { int transition, nBlocksOf10ms, tot_blocks, curr_block, tmp_payloadSize_ms, tmp_complexity, nSamplesToBufferMax; };
+/* enc_API.c:166-281: channel bookkeeping, the checks on the input length, the prefill reset, silk_control_encoder per channel */
+WV_DEV int se_call_prologue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int nSamplesIn, int prefillFlag, SeCall *k)
 {
-   prefillFlag = wv_uni(prefillFlag);
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
-   int nBytesOut = 0;
    LANE0 {
       if (ec->reducedDependency) for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].first_frame_after_reset = 1;
       for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].nFramesEncoded = 0;
@@ -578,14 +605,14 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
          if (E->nChannelsAPI == 2) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; }
       }
    }
-   const int transition = ec->payloadSize_ms != c0->PacketSize_ms || E->nChannelsInternal != ec->nChannelsInternal;
+   k->transition = ec->payloadSize_ms != c0->PacketSize_ms || E->nChannelsInternal != ec->nChannelsInternal;
    LANE0 { E->nChannelsAPI = ec->nChannelsAPI; E->nChannelsInternal = ec->nChannelsInternal; }
-   const int nBlocksOf10ms = (100 * nSamplesIn) / ec->API_sampleRate;
-   const int tot_blocks = nBlocksOf10ms > 1 ? nBlocksOf10ms >> 1 : 1;
-   int curr_block = 0;
-   int tmp_payloadSize_ms = 0, tmp_complexity = 0;
+   k->nBlocksOf10ms = (100 * nSamplesIn) / ec->API_sampleRate;
+   k->tot_blocks = k->nBlocksOf10ms > 1 ? k->nBlocksOf10ms >> 1 : 1;
+   k->curr_block = 0;
+   k->tmp_payloadSize_ms = 0; k->tmp_complexity = 0;
    if (prefillFlag) {
-      if (nBlocksOf10ms != 1) return -101;
+      if (k->nBlocksOf10ms != 1) return -101;
       LANE0 {
          i32 lp[5];
          if (prefillFlag == 2) { lp[0] = c0->lp_In_LP_State[0]; lp[1] = c0->lp_In_LP_State[1]; lp[2] = c0->lp_transition_frame_no; lp[3] = c0->lp_mode; lp[4] = c0->fs_kHz; }   /* saved_fs_kHz = the rate in use */
@@ -594,191 +621,242 @@ WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm,
             if (prefillFlag == 2) { E->ch[n].lp_In_LP_State[0] = lp[0]; E->ch[n].lp_In_LP_State[1] = lp[1]; E->ch[n].lp_transition_frame_no = lp[2]; E->ch[n].lp_mode = lp[3]; E->ch[n].lp_saved_fs_kHz = lp[4]; }
          }
       }
-      tmp_payloadSize_ms = ec->payloadSize_ms; ec->payloadSize_ms = 10;
-      tmp_complexity = ec->complexity; ec->complexity = 0;
+      k->tmp_payloadSize_ms = ec->payloadSize_ms; ec->payloadSize_ms = 10;
+      k->tmp_complexity = ec->complexity; ec->complexity = 0;
       LANE0 { for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].controlled_since_last_payload = 0; E->ch[n].prefillFlag = 1; } }
    } else {
-      if (nBlocksOf10ms * ec->API_sampleRate != 100 * nSamplesIn || nSamplesIn < 0) return -101;
+      if (k->nBlocksOf10ms * ec->API_sampleRate != 100 * nSamplesIn || nSamplesIn < 0) return -101;
       if (1000 * (i32)nSamplesIn > ec->payloadSize_ms * ec->API_sampleRate) return -101;
    }
+   const int transition = k->transition;
    LANE0 {
-      i32 mb = ec->maxBits, sr = ec->switchReady;
       for (int n = 0; n < ec->nChannelsInternal; n++) {
          const int force_fs_kHz = n == 1 ? c0->fs_kHz : 0;
          se_control_encoder(&E->ch[n], ec, E->allowBandwidthSwitch, n, force_fs_kHz, &S->rs, S->u.rs_tmp, S->tmp_rs);
          if (E->ch[n].first_frame_after_reset || transition) for (int i = 0; i < c0->nFramesPerPacket; i++) E->ch[n].LBRR_flags[i] = 0;
          E->ch[n].inDTX = E->ch[n].useDTX;
       }
-      S->r[2] = ec->maxBits; S->r[3] = ec->switchReady; (void)mb; (void)sr;
+      S->r[2] = ec->maxBits; S->r[3] = ec->switchReady;
    }
    ec->maxBits = S->r[2]; ec->switchReady = S->r[3];                           /* se_control_audio_bw may have changed them on lane 0 */
-   const int nSamplesToBufferMax = 10 * nBlocksOf10ms * c0->fs_kHz;
-   while (1) {
-      int nSamplesToBuffer = imin(c0->frame_length - c0->inputBufIx, nSamplesToBufferMax);
-      const int nSamplesFromInput = (nSamplesToBuffer * c0->API_fs_Hz) / (c0->fs_kHz * 1000);
-      {  /* resample this call's input to the internal rate, buffer it (enc_API.c:283-340) */
-         const int ix0 = c0->inputBufIx;
-         if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
-            const int ix1 = c1->inputBufIx;
-            LANE0 { if (E->nPrevChannelsInternal == 1 && c0->nFramesEncoded == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; } }
-            SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
-            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
-            se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], s1, nSamplesFromInput);
-            LANE0 { c0->inputBufIx += nSamplesToBuffer; c1->inputBufIx += imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz); }
-         } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
-            SePcmSrc sm = {pcm, 2, 0, 1};
-            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], sm, nSamplesFromInput);
-            if (E->nPrevChannelsInternal == 2 && c0->nFramesEncoded == 0) {
-               const int ix1 = c1->inputBufIx;
-               se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], sm, nSamplesFromInput);
-               FOR_LANES(n, c0->frame_length) c0->inputBuf[ix0 + n + 2] = (i16)((c0->inputBuf[ix0 + n + 2] + c1->inputBuf[ix1 + n + 2]) >> 1);
-            }
-            LANE0 c0->inputBufIx += nSamplesToBuffer;
-         } else {
-            SePcmSrc s0 = {pcm, 1, 0, 0};
-            se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
-            LANE0 c0->inputBufIx += nSamplesToBuffer;
-         }
-         LANE0 E->allowBandwidthSwitch = 0;
+   k->nSamplesToBufferMax = 10 * k->nBlocksOf10ms * c0->fs_kHz;
+   return 0;
+}
+/* :283-340: resample this call's input to the internal rate, buffer it */
+WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesFromInput, int nSamplesToBuffer, int nBlocksOf10ms)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   const int ix0 = c0->inputBufIx;
+   if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
+      const int ix1 = c1->inputBufIx;
+      LANE0 { if (E->nPrevChannelsInternal == 1 && c0->nFramesEncoded == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; } }
+      SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
+      se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], s1, nSamplesFromInput);
+      LANE0 { c0->inputBufIx += nSamplesToBuffer; c1->inputBufIx += imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz); }
+   } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
+      SePcmSrc sm = {pcm, 2, 0, 1};
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], sm, nSamplesFromInput);
+      if (E->nPrevChannelsInternal == 2 && c0->nFramesEncoded == 0) {
+         const int ix1 = c1->inputBufIx;
+         se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], sm, nSamplesFromInput);
+         FOR_LANES(n, c0->frame_length) c0->inputBuf[ix0 + n + 2] = (i16)((c0->inputBuf[ix0 + n + 2] + c1->inputBuf[ix1 + n + 2]) >> 1);
       }
-      pcm += nSamplesFromInput * ec->nChannelsAPI;
-      nSamplesIn -= nSamplesFromInput;
-      if (c0->inputBufIx < c0->frame_length) break;
-      /* ---- enough data: encode one frame ---- */
-      i32 MStargetRates_bps[2] = {0, 0}, TargetRate_bps;
-      if (c0->nFramesEncoded == 0 && !prefillFlag) {                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
-         int any = 0;
-         for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) any |= E->ch[n].LBRR_flags[i];
-         if (any) { WV_LDS i32 *d = (WV_LDS i32 *)&S->u.lbrr; const i32 *g = (const i32 *)lb; wv_sync(); FOR_LANES(i, (int)(sizeof(OaSilkLbrr) / 4)) d[i] = g[i]; wv_sync(); }
-      }
-      LANE0 {
-         EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
-         int curr_nBitsUsedLBRR = 0;
-         if (c0->nFramesEncoded == 0 && !prefillFlag) {
-            u8 iCDF[2] = {0, 0};
-            iCDF[0] = (u8)(256 - (256 >> ((c0->nFramesPerPacket + 1) * ec->nChannelsInternal)));
-            k_ec_enc_icdf(EC_PASS, 0, iCDF, 8);
-            curr_nBitsUsedLBRR = k_ec_tell(EC_PASS);
-            for (int n = 0; n < ec->nChannelsInternal; n++) {                        /* LBRR flags (enc_API.c:364-374) */
-               int sym = 0;
-               for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) sym |= E->ch[n].LBRR_flags[i] << i;
-               E->ch[n].LBRR_flag = sym > 0;
-               if (sym && E->ch[n].nFramesPerPacket > 1) k_ec_enc_icdf(EC_PASS, sym - 1, &sk_lbrr_flags_icdf[E->ch[n].nFramesPerPacket == 2 ? 0 : 3], 8);
-            }
-            for (int i = 0; i < c0->nFramesPerPacket; i++) for (int n = 0; n < ec->nChannelsInternal; n++) if (E->ch[n].LBRR_flags[i]) {      /* indices and excitation (:376-400) */
-               if (ec->nChannelsInternal == 2 && n == 0) {
-                  se_stereo_encode_pred(EC_PASS, &E->st.predIx[i][0][0]);
-                  if (c1->LBRR_flags[i] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[i], sk_stereo_only_code_mid_icdf, 8);
-               }
-               const int cc = i > 0 && E->ch[n].LBRR_flags[i - 1] ? SE_CODE_CONDITIONALLY : SE_CODE_INDEPENDENTLY;
-               se_encode_indices(&E->ch[n], &S->u.lbrr.indices[n][i], EC_PASS, cc);
-               se_encode_pulses(EC_PASS, S->u.lbrr.indices[n][i].signalType, S->u.lbrr.indices[n][i].quantOffsetType, S->u.lbrr.pulses[n][i], E->ch[n].frame_length, S->stk);
-            }
-            for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0;
-            curr_nBitsUsedLBRR = k_ec_tell(EC_PASS) - curr_nBitsUsedLBRR;
-         }
-         se_hp_variable_cutoff(c0);
-         i32 nBits = (ec->bitRate * ec->payloadSize_ms) / 1000;
-         if (!prefillFlag) {
-            if (curr_nBitsUsedLBRR < 10) E->nBitsUsedLBRR = 0; else if (E->nBitsUsedLBRR < 10) E->nBitsUsedLBRR = curr_nBitsUsedLBRR; else E->nBitsUsedLBRR = (E->nBitsUsedLBRR + curr_nBitsUsedLBRR) / 2;
-            nBits -= E->nBitsUsedLBRR;
-         }
-         nBits = nBits / c0->nFramesPerPacket;
-         i32 T = ec->payloadSize_ms == 10 ? sk_mulbb(nBits, 100) : sk_mulbb(nBits, 50);
-         T -= (E->nBitsExceeded * 1000) / 500;
-         if (c0->nFramesEncoded > 0) { const i32 bitsBalance = k_ec_tell(EC_PASS) - E->nBitsUsedLBRR - nBits * c0->nFramesEncoded; T -= (bitsBalance * 1000) / 500; }
-         T = se_limit(T, ec->bitRate, 5000);
-         S->r[4] = T;
-         ec_st(ecl, &ec_);
-      }
-      if (ec->nChannelsInternal == 2) {
-         se_stereo_lr_to_ms_wave(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], S->stk, S->r[4], c0->speech_activity_Q8,
-               ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
-      }
-      LANE0 {
-         EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
-         if (ec->nChannelsInternal == 2) {
-            S->r[5] = S->stk[0]; S->r[6] = S->stk[1];
-            if (E->st.mid_only_flags[c0->nFramesEncoded] == 0) {
-               if (E->prev_decode_only_middle == 1) {
-                  c1->LastGainIndex = 0; c1->HarmShapeGain_smth_Q16 = 0; c1->Tilt_smth_Q16 = 0;
-                  se_nsq_reset(&c1->nsq);
-                  for (int i = 0; i < 16; i++) c1->prev_NLSFq_Q15[i] = 0;
-                  c1->lp_In_LP_State[0] = c1->lp_In_LP_State[1] = 0;
-                  c1->prevLag = 100; c1->nsq.lagPrev = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->nsq.prev_gain_Q16 = 65536; c1->first_frame_after_reset = 1;
-               }
-               se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
-            } else c1->VAD_flags[c0->nFramesEncoded] = 0;
-            if (!prefillFlag) {
-               se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
-               if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
-            }
-         } else {
-            c0->inputBuf[0] = E->st.sMid[0]; c0->inputBuf[1] = E->st.sMid[1];
-            E->st.sMid[0] = c0->inputBuf[c0->frame_length]; E->st.sMid[1] = c0->inputBuf[c0->frame_length + 1];
-         }
-         se_vad_l0(c0, c0->inputBuf + 1, S->u.vadX, activity);
-         ec_st(ecl, &ec_);
-      }
-      TargetRate_bps = S->r[4]; MStargetRates_bps[0] = S->r[5]; MStargetRates_bps[1] = S->r[6];
-      for (int n = 0; n < ec->nChannelsInternal; n++) {
-         int maxBits = ec->maxBits;
-         if (tot_blocks == 2 && curr_block == 0) maxBits = maxBits * 3 / 5;
-         else if (tot_blocks == 3) { if (curr_block == 0) maxBits = maxBits * 2 / 5; else if (curr_block == 1) maxBits = maxBits * 3 / 4; }
-         int useCBR = ec->useCBR && curr_block == tot_blocks - 1;
-         i32 channelRate_bps;
-         if (ec->nChannelsInternal == 1) channelRate_bps = TargetRate_bps;
-         else { channelRate_bps = MStargetRates_bps[n]; if (n == 0 && MStargetRates_bps[1] > 0) { useCBR = 0; maxBits -= ec->maxBits / (tot_blocks * 2); } }
-         if (channelRate_bps > 0) {
-            LANE0 se_control_snr(&E->ch[n], channelRate_bps);
-            int condCoding;
-            if (c0->nFramesEncoded - n <= 0) condCoding = SE_CODE_INDEPENDENTLY;
-            else if (n > 0 && E->prev_decode_only_middle) condCoding = SE_CODE_INDEPENDENTLY_NO_LTP_SCALING;
-            else condCoding = SE_CODE_CONDITIONALLY;
-            se_encode_frame_wave(S, &E->ch[n], ecl, buf, condCoding, maxBits, useCBR, G, lb);
-            nBytesOut = S->r[0];
-         }
-         wv_sync();
-         LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
-      }
-      LANE0 {
-         E->prev_decode_only_middle = E->st.mid_only_flags[c0->nFramesEncoded - 1];
-         if (nBytesOut > 0 && c0->nFramesEncoded == c0->nFramesPerPacket) {
-            int flags = 0;
-            for (int n = 0; n < ec->nChannelsInternal; n++) {
-               for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) { flags <<= 1; flags |= E->ch[n].VAD_flags[i]; }
-               flags <<= 1; flags |= E->ch[n].LBRR_flag;
-            }
-            if (!prefillFlag) {
-               EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
-               k_ec_enc_patch_initial_bits(EC_PASS, flags, (c0->nFramesPerPacket + 1) * ec->nChannelsInternal);
-               ec_st(ecl, &ec_);
-            }
-            int nb = nBytesOut;
-            if (c0->inDTX && (ec->nChannelsInternal == 1 || c1->inDTX)) nb = 0;
-            E->nBitsExceeded += nb * 8;
-            E->nBitsExceeded -= (ec->bitRate * ec->payloadSize_ms) / 1000;
-            E->nBitsExceeded = se_limit(E->nBitsExceeded, 0, 10000);
-            const int thr = sk_mlawb(SE_FIX(0.05f, 8), SE_FIX((1 - 0.05f) / 5000, 16 + 8), E->timeSinceSwitchAllowed_ms);
-            if (c0->speech_activity_Q8 < thr) { E->allowBandwidthSwitch = 1; E->timeSinceSwitchAllowed_ms = 0; } else { E->allowBandwidthSwitch = 0; E->timeSinceSwitchAllowed_ms += ec->payloadSize_ms; }
-            S->r[0] = nb;
-         }
-      }
-      nBytesOut = S->r[0];
-      if (nSamplesIn == 0) break;
-      curr_block++;
+      LANE0 c0->inputBufIx += nSamplesToBuffer;
+   } else {
+      SePcmSrc s0 = {pcm, 1, 0, 0};
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
+      LANE0 c0->inputBufIx += nSamplesToBuffer;
    }
+   LANE0 E->allowBandwidthSwitch = 0;
+}
+/* :342-470, a full frame is buffered: the LBRR side stream of the previous packet at the head of a new one, variable high-pass, target rate, stereo L/R -> M/S,
+ * VAD.  Leaves TargetRate_bps in S->r[4], the mid / side rates in S->r[5], S->r[6]. */
+WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, OaSilkLbrr *lb, int activity, int prefillFlag)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   if (c0->nFramesEncoded == 0 && !prefillFlag) {                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
+      int any = 0;
+      for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) any |= E->ch[n].LBRR_flags[i];
+      if (any) { WV_LDS i32 *d = (WV_LDS i32 *)&S->u.lbrr; const i32 *g = (const i32 *)lb; wv_sync(); FOR_LANES(i, (int)(sizeof(OaSilkLbrr) / 4)) d[i] = g[i]; wv_sync(); }
+   }
+   LANE0 {
+      EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+      int curr_nBitsUsedLBRR = 0;
+      if (c0->nFramesEncoded == 0 && !prefillFlag) {
+         u8 iCDF[2] = {0, 0};
+         iCDF[0] = (u8)(256 - (256 >> ((c0->nFramesPerPacket + 1) * ec->nChannelsInternal)));
+         k_ec_enc_icdf(EC_PASS, 0, iCDF, 8);
+         curr_nBitsUsedLBRR = k_ec_tell(EC_PASS);
+         for (int n = 0; n < ec->nChannelsInternal; n++) {                        /* LBRR flags (enc_API.c:364-374) */
+            int sym = 0;
+            for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) sym |= E->ch[n].LBRR_flags[i] << i;
+            E->ch[n].LBRR_flag = sym > 0;
+            if (sym && E->ch[n].nFramesPerPacket > 1) k_ec_enc_icdf(EC_PASS, sym - 1, &sk_lbrr_flags_icdf[E->ch[n].nFramesPerPacket == 2 ? 0 : 3], 8);
+         }
+         for (int i = 0; i < c0->nFramesPerPacket; i++) for (int n = 0; n < ec->nChannelsInternal; n++) if (E->ch[n].LBRR_flags[i]) {      /* indices and excitation (:376-400) */
+            if (ec->nChannelsInternal == 2 && n == 0) {
+               se_stereo_encode_pred(EC_PASS, &E->st.predIx[i][0][0]);
+               if (c1->LBRR_flags[i] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[i], sk_stereo_only_code_mid_icdf, 8);
+            }
+            const int cc = i > 0 && E->ch[n].LBRR_flags[i - 1] ? SE_CODE_CONDITIONALLY : SE_CODE_INDEPENDENTLY;
+            se_encode_indices(&E->ch[n], &S->u.lbrr.indices[n][i], EC_PASS, cc);
+            se_encode_pulses(EC_PASS, S->u.lbrr.indices[n][i].signalType, S->u.lbrr.indices[n][i].quantOffsetType, S->u.lbrr.pulses[n][i], E->ch[n].frame_length, S->stk);
+         }
+         for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) E->ch[n].LBRR_flags[i] = 0;
+         curr_nBitsUsedLBRR = k_ec_tell(EC_PASS) - curr_nBitsUsedLBRR;
+      }
+      se_hp_variable_cutoff(c0);
+      i32 nBits = (ec->bitRate * ec->payloadSize_ms) / 1000;
+      if (!prefillFlag) {
+         if (curr_nBitsUsedLBRR < 10) E->nBitsUsedLBRR = 0; else if (E->nBitsUsedLBRR < 10) E->nBitsUsedLBRR = curr_nBitsUsedLBRR; else E->nBitsUsedLBRR = (E->nBitsUsedLBRR + curr_nBitsUsedLBRR) / 2;
+         nBits -= E->nBitsUsedLBRR;
+      }
+      nBits = nBits / c0->nFramesPerPacket;
+      i32 T = ec->payloadSize_ms == 10 ? sk_mulbb(nBits, 100) : sk_mulbb(nBits, 50);
+      T -= (E->nBitsExceeded * 1000) / 500;
+      if (c0->nFramesEncoded > 0) { const i32 bitsBalance = k_ec_tell(EC_PASS) - E->nBitsUsedLBRR - nBits * c0->nFramesEncoded; T -= (bitsBalance * 1000) / 500; }
+      T = se_limit(T, ec->bitRate, 5000);
+      S->r[4] = T;
+      ec_st(ecl, &ec_);
+   }
+   if (ec->nChannelsInternal == 2) {
+      se_stereo_lr_to_ms_wave(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], S->stk, S->r[4], c0->speech_activity_Q8,
+            ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
+   }
+   LANE0 {
+      EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+      if (ec->nChannelsInternal == 2) {
+         S->r[5] = S->stk[0]; S->r[6] = S->stk[1];
+         if (E->st.mid_only_flags[c0->nFramesEncoded] == 0) {
+            if (E->prev_decode_only_middle == 1) {
+               c1->LastGainIndex = 0; c1->HarmShapeGain_smth_Q16 = 0; c1->Tilt_smth_Q16 = 0;
+               se_nsq_reset(&c1->nsq);
+               for (int i = 0; i < 16; i++) c1->prev_NLSFq_Q15[i] = 0;
+               c1->lp_In_LP_State[0] = c1->lp_In_LP_State[1] = 0;
+               c1->prevLag = 100; c1->nsq.lagPrev = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->nsq.prev_gain_Q16 = 65536; c1->first_frame_after_reset = 1;
+            }
+            se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
+         } else c1->VAD_flags[c0->nFramesEncoded] = 0;
+         if (!prefillFlag) {
+            se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
+            if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
+         }
+      } else {
+         c0->inputBuf[0] = E->st.sMid[0]; c0->inputBuf[1] = E->st.sMid[1];
+         E->st.sMid[0] = c0->inputBuf[c0->frame_length]; E->st.sMid[1] = c0->inputBuf[c0->frame_length + 1];
+      }
+      se_vad_l0(c0, c0->inputBuf + 1, S->u.vadX, activity);
+      ec_st(ecl, &ec_);
+   }
+}
+/* :472-520, channel n of the frame: bit budget, rate-control mode, SNR target, conditional coding.  channelRate_bps <= 0: the channel is not coded */
+struct SeChanParams { int maxBits, useCBR, condCoding; i32 channelRate_bps; };
+WV_DEV SeChanParams se_call_channel_params(WV_LDS SilkEncLds *S, const SeControl *ec, int n, int tot_blocks, int curr_block)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
+   const i32 TargetRate_bps = S->r[4], MStargetRates_bps[2] = {S->r[5], S->r[6]};
+   SeChanParams p;
+   p.maxBits = ec->maxBits;
+   if (tot_blocks == 2 && curr_block == 0) p.maxBits = p.maxBits * 3 / 5;
+   else if (tot_blocks == 3) { if (curr_block == 0) p.maxBits = p.maxBits * 2 / 5; else if (curr_block == 1) p.maxBits = p.maxBits * 3 / 4; }
+   p.useCBR = ec->useCBR && curr_block == tot_blocks - 1;
+   if (ec->nChannelsInternal == 1) p.channelRate_bps = TargetRate_bps;
+   else { p.channelRate_bps = MStargetRates_bps[n]; if (n == 0 && MStargetRates_bps[1] > 0) { p.useCBR = 0; p.maxBits -= ec->maxBits / (tot_blocks * 2); } }
+   p.condCoding = SE_CODE_INDEPENDENTLY;
+   if (p.channelRate_bps > 0) {
+      LANE0 se_control_snr(&E->ch[n], p.channelRate_bps);
+      if (c0->nFramesEncoded - n <= 0) p.condCoding = SE_CODE_INDEPENDENTLY;
+      else if (n > 0 && E->prev_decode_only_middle) p.condCoding = SE_CODE_INDEPENDENTLY_NO_LTP_SCALING;
+      else p.condCoding = SE_CODE_CONDITIONALLY;
+   }
+   return p;
+}
+/* :522-560 after the channels of a frame, lane 0.  part 1: what does not depend on the coded bytes (mid-only memory, the packet's VAD / LBRR flag bits -> S->r[7], "every
+ * channel is in DTX" -> S->r[8], the bandwidth-switch timer); part 2: the flag bits patched into the first payload byte, the bit reservoir; 3 = both */
+WV_DEV void se_call_frame_tail_l0(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int nBytesOut, int prefillFlag, int part)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   if (part & 1) E->prev_decode_only_middle = E->st.mid_only_flags[c0->nFramesEncoded - 1];
+   if (nBytesOut > 0 && c0->nFramesEncoded == c0->nFramesPerPacket) {
+      if (part & 1) {
+         int flags = 0;
+         for (int n = 0; n < ec->nChannelsInternal; n++) {
+            for (int i = 0; i < E->ch[n].nFramesPerPacket; i++) { flags <<= 1; flags |= E->ch[n].VAD_flags[i]; }
+            flags <<= 1; flags |= E->ch[n].LBRR_flag;
+         }
+         S->r[7] = flags; S->r[8] = c0->inDTX && (ec->nChannelsInternal == 1 || c1->inDTX);
+         const int thr = sk_mlawb(SE_FIX(0.05f, 8), SE_FIX((1 - 0.05f) / 5000, 16 + 8), E->timeSinceSwitchAllowed_ms);
+         if (c0->speech_activity_Q8 < thr) { E->allowBandwidthSwitch = 1; E->timeSinceSwitchAllowed_ms = 0; } else { E->allowBandwidthSwitch = 0; E->timeSinceSwitchAllowed_ms += ec->payloadSize_ms; }
+      }
+      if (part & 2) {
+         if (!prefillFlag) {
+            EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
+            k_ec_enc_patch_initial_bits(EC_PASS, S->r[7], (c0->nFramesPerPacket + 1) * ec->nChannelsInternal);
+            ec_st(ecl, &ec_);
+         }
+         int nb = nBytesOut;
+         if (S->r[8]) nb = 0;
+         E->nBitsExceeded += nb * 8;
+         E->nBitsExceeded -= (ec->bitRate * ec->payloadSize_ms) / 1000;
+         E->nBitsExceeded = se_limit(E->nBitsExceeded, 0, 10000);
+         S->r[0] = nb;
+      }
+   }
+}
+/* :562-590 */
+WV_DEV void se_call_epilogue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int prefillFlag, const SeCall *k)
+{
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    LANE0 E->nPrevChannelsInternal = ec->nChannelsInternal;
    ec->allowBandwidthSwitch = E->allowBandwidthSwitch;
    ec->inWBmodeWithoutVariableLP = c0->fs_kHz == 16 && c0->lp_mode == 0;
    ec->internalSampleRate = sk_mulbb(c0->fs_kHz, 1000);
    ec->stereoWidth_Q14 = ec->toMono ? 0 : E->st.smth_width_Q14;
    if (prefillFlag) {
-      ec->payloadSize_ms = tmp_payloadSize_ms; ec->complexity = tmp_complexity;
+      ec->payloadSize_ms = k->tmp_payloadSize_ms; ec->complexity = k->tmp_complexity;
       LANE0 { for (int n = 0; n < ec->nChannelsInternal; n++) { E->ch[n].controlled_since_last_payload = 0; E->ch[n].prefillFlag = 0; } }
    }
    ec->signalType = c0->indices.signalType;
    ec->offset = se_quantization_offsets_q10[(c0->indices.signalType >> 1) * 2 + c0->indices.quantOffsetType];
+}
+WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb, int prefillFlag = 0)
+{
+   prefillFlag = wv_uni(prefillFlag);
+   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
+   int nBytesOut = 0;
+   SeCall k;
+   { const int r = se_call_prologue_wave(S, ec, nSamplesIn, prefillFlag, &k); if (r) return r; }
+   while (1) {
+      int nSamplesToBuffer = imin(c0->frame_length - c0->inputBufIx, k.nSamplesToBufferMax);
+      const int nSamplesFromInput = (nSamplesToBuffer * c0->API_fs_Hz) / (c0->fs_kHz * 1000);
+      se_call_buffer_wave(S, ec, pcm, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
+      pcm += nSamplesFromInput * ec->nChannelsAPI;
+      nSamplesIn -= nSamplesFromInput;
+      if (c0->inputBufIx < c0->frame_length) break;
+      /* ---- enough data: encode one frame ---- */
+      se_call_frame_head_wave(S, ec, ecl, buf, lb, activity, prefillFlag);
+      for (int n = 0; n < ec->nChannelsInternal; n++) {
+         const SeChanParams p = se_call_channel_params(S, ec, n, k.tot_blocks, k.curr_block);
+         if (p.channelRate_bps > 0) {
+            se_encode_frame_wave(S, &E->ch[n], ecl, buf, p.condCoding, p.maxBits, p.useCBR, G, lb);
+            nBytesOut = S->r[0];
+         }
+         wv_sync();
+         LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
+      }
+      LANE0 se_call_frame_tail_l0(S, ec, ecl, buf, nBytesOut, prefillFlag, 3);
+      nBytesOut = S->r[0];
+      if (nSamplesIn == 0) break;
+      k.curr_block++;
+   }
+   se_call_epilogue_wave(S, ec, prefillFlag, &k);
    S->r[0] = nBytesOut;
    return 0;
 }
