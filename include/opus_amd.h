@@ -167,6 +167,9 @@ OPUS_AMD_EXPORT int opusgpu_sh_kernel_lds_bytes(void);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_export_state(OpusGpuEncBatch *b, opus_int32 stream, void *blob);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const void *blob);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);
+/* Diagnostics of a SILK-capable batch (applications VOIP / AUDIO / RESTRICTED_SILK): calls that went through the three-kernel split path of the encoder (front / 16-streams-
+ * per-wave quantiser / back, opus_amd/csrc/opus_sh_split.h) and calls it handed to the one-kernel path since the batch was created.  Results never depend on the path. */
+OPUS_AMD_EXPORT int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_uint32 *declined);
 /* introspection for the roofline report */
 OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
 

@@ -10,6 +10,9 @@ struct EcCtx { u32 storage, end_offs, end_window; i32 nend_bits, nbits_total; u3
  * plus the byte stores into the LDS packet. */
 #define EC_ARGS EcCtx *e, WV_LDS u8 *buf
 #define EC_PASS e, buf
+/* the symbol coder itself is generic over where the bytes go (ECB: any pointer to u8): the SILK quantiser kernel codes 16 streams per wave, each lane into its own
+ * stream's buffer in HBM (opus_sh_split.h) */
+#define EC_ARGS_G EcCtx *e, ECB buf
 WV_DEV void ec_ld(EcCtx *d, const WV_LDS EcCtx *s)
 {
    d->storage = s->storage; d->end_offs = s->end_offs; d->end_window = s->end_window; d->nend_bits = s->nend_bits; d->nbits_total = s->nbits_total;
@@ -29,7 +32,7 @@ WV_DEV void ec_cp_lds(WV_LDS EcCtx *d, const WV_LDS EcCtx *s) { EcCtx t; ec_ld(&
 #define CODE_TOP 0x80000000u
 #define CODE_BOT (CODE_TOP >> SYM_BITS)
 
-WV_DEV int ec_put_front(EC_ARGS, unsigned v)
+template <class ECB> WV_DEV int ec_put_front(EC_ARGS_G, unsigned v)
 {
    if (e->offs + e->end_offs >= e->storage) return -1;
    buf[e->offs++] = (u8)v;
@@ -42,7 +45,7 @@ WV_DEV int ec_put_back(EC_ARGS, unsigned v)
    return 0;
 }
 /* carry propagation: entenc.c:86 */
-WV_DEV void ec_carry_out(EC_ARGS, int c)
+template <class ECB> WV_DEV void ec_carry_out(EC_ARGS_G, int c)
 {
    if (c != (int)SYM_MAX) {
       int carry = c >> SYM_BITS;
@@ -54,7 +57,7 @@ WV_DEV void ec_carry_out(EC_ARGS, int c)
       e->rem = c & SYM_MAX;
    } else e->ext++;
 }
-WV_DEV void ec_renorm(EC_ARGS)
+template <class ECB> WV_DEV void ec_renorm(EC_ARGS_G)
 {
    while (e->rng <= CODE_BOT) {
       ec_carry_out(EC_PASS, (int)(e->val >> CODE_SHIFT));
@@ -69,7 +72,7 @@ WV_DEV void k_ec_enc_init(EC_ARGS, u32 size)
    e->nbits_total = 33; e->offs = 0; e->rng = CODE_TOP; e->rem = -1; e->val = 0; e->ext = 0;
    e->storage = size; e->error = 0;
 }
-WV_DEV int k_ec_tell(const EcCtx *e, WV_LDS u8 *buf) { (void)buf; return e->nbits_total - ec_ilog(e->rng); }
+template <class ECB> WV_DEV int k_ec_tell(const EcCtx *e, ECB buf) { (void)buf; return e->nbits_total - ec_ilog(e->rng); }
 WV_DEV u32 k_ec_tell_frac(EC_ARGS)
 {
    const unsigned correction[8] = {35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535};
@@ -115,7 +118,7 @@ WV_DEV void k_ec_enc_bit_logp(EC_ARGS, int val, unsigned logp)
    e->rng = val ? s : r;
    ec_renorm(EC_PASS);
 }
-WV_DEV void k_ec_enc_icdf(EC_ARGS, int s, const u8 *icdf, unsigned ftb)
+template <class ECB> WV_DEV void k_ec_enc_icdf(EC_ARGS_G, int s, const u8 *icdf, unsigned ftb)
 {
    u32 r = e->rng >> ftb;
    if (s > 0) { e->val += e->rng - r * icdf[s - 1]; e->rng = r * (u32)(icdf[s - 1] - icdf[s]); }
@@ -144,7 +147,7 @@ WV_DEV void k_ec_enc_uint(EC_ARGS, u32 fl, u32 ft)
       k_ec_enc_bits(EC_PASS, fl & (((u32)1 << ftb) - 1U), ftb);
    } else k_ec_encode(EC_PASS, fl, fl + 1, ft + 1);
 }
-WV_DEV void k_ec_enc_patch_initial_bits(EC_ARGS, unsigned val, unsigned nbits)
+template <class ECB> WV_DEV void k_ec_enc_patch_initial_bits(EC_ARGS_G, unsigned val, unsigned nbits)
 {
    int shift = SYM_BITS - nbits;
    unsigned mask = ((1 << nbits) - 1) << shift;

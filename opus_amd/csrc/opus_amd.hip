@@ -77,22 +77,95 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 }
 
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
- * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave */
+ * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave.  list != NULL: the calls the split path's front kernel turned away (their analysis has run) */
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue)
+oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue,
+      const int *list, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   const int n = list ? (int)*list_count : nstreams;
    for (;;) {
-      const int s = oa_queue_pop(queue);
-      if (s >= nstreams) break;
+      int s = oa_queue_pop(queue);
+      if (s >= n) break;
+      if (list) s = list[s];
       OaShStream *gs = streams + s;
       const int ch = gs->cfg.channels;
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
       oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
             (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
-            apcm ? apcm + (size_t)s * frame_size * ch : nullptr);
+            apcm ? apcm + (size_t)s * frame_size * ch : nullptr, list != nullptr);
+      __syncthreads();
+   }
+}
+/* the split path (opus_sh_split.h).  counters: [0] front queue, [1] quantiser queue, [2] back queue, [3] queue of the one-kernel pass over the calls turned away, [4] their count */
+#ifndef OA_SH_FRONT_WAVES_PER_EU
+#define OA_SH_FRONT_WAVES_PER_EU 2
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
+oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   unsigned kept = 0, seen = 0;
+   for (;;) {
+      const int s = oa_queue_pop(counters);
+      if (s >= nstreams) break;
+      OaShStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      seen++;
+      oa_sh_front_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
+            apcm ? apcm + (size_t)s * frame_size * ch : nullptr, slow_list, counters + 4, s);
+      __syncthreads();
+      kept += conts[s].kind == SH_CONT_FAST;
+   }
+   if (threadIdx.x == 0 && seen) { atomicAdd(counters + 16, kept); atomicAdd(counters + 17, seen - kept); }     /* running totals of the batch (opusgpu_enc_batch_split_stats) */
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_sh_quant_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS SqLds *Q = (WV_LDS SqLds *)smem;
+   char *scr = scratch + (size_t)blockIdx.x * SQ_WAVE_SCRATCH_BYTES;
+   const int ntiles = (nstreams + 15) / 16;
+   for (;;) {
+      const int t = oa_queue_pop(counters + 1);
+      if (t >= ntiles) break;
+      sq_quant_tile_wave(Q, streams, conts, t * 16, nstreams, (i32 *)scr, (SqSnap *)(scr + SQ_TILE_WORDS * 4));
+      __syncthreads();
+   }
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   for (;;) {
+      const int s = oa_queue_pop(counters + 1);
+      if (s >= nstreams) break;
+      if (conts[s].kind == SH_CONT_FAST) oa_sh_quant0_frame(L, streams + s, conts + s, (SeRateScratch *)(scratch + (size_t)blockIdx.x * sizeof(SeRateScratch)));
+      __syncthreads();
+   }
+}
+#ifndef OA_SH_BACK_WAVES_PER_EU
+#define OA_SH_BACK_WAVES_PER_EU 2
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
+oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   for (;;) {
+      const int s = oa_queue_pop(counters + 2);
+      if (s >= nstreams) break;
+      if (conts[s].kind == SH_CONT_FAST) {
+         OaShStream *gs = streams + s;
+         const int ch = gs->cfg.channels;
+         char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
+         oa_sh_back_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)),
+               (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s);
+      }
       __syncthreads();
    }
 }
@@ -166,6 +239,9 @@ struct OpusGpuEncBatch {
    unsigned *d_queue;                    /* the launch's stream queue (next unclaimed stream) */
    int num_cu;
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
+   /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
+   ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
+   struct { const void *kernel; size_t lds; int per_cu; } occ[4];
    int device;
    opus_int32 S;
    opus_int32 n_act;                     /* streams a call processes: the first n_act records (== S except under the classic API's call combiner) */
@@ -213,6 +289,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -223,7 +300,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_streams, sizeof(OaStream) * (size_t)(kind ? 1 : nstreams)) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMalloc((void **)&b->d_queue, 64) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 128) == hipSuccess && hipMemset(b->d_queue, 0, 128) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 (kind || hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(OaStream) * (size_t)nstreams, hipMemcpyHostToDevice) == hipSuccess) &&
                 hipFuncSetAttribute((const void *)oa_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -242,6 +319,9 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_sh) (void)hipFree(b->d_sh);
    if (b->d_scratch) (void)hipFree(b->d_scratch);
    if (b->d_queue) (void)hipFree(b->d_queue);
+   if (b->d_cont) (void)hipFree(b->d_cont);
+   if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
+   if (b->d_slow_list) (void)hipFree(b->d_slow_list);
    if (b->d_pcm) (void)hipFree(b->d_pcm);
    if (b->d_apcm) (void)hipFree(b->d_apcm);
    if (b->d_out) (void)hipFree(b->d_out);
@@ -336,6 +416,17 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
    HIPCHECK(hipMemcpy(b->d_streams + stream, src, sizeof(OaStream), hipMemcpyHostToDevice));
    return OPUS_OK;
 }
+/* calls the split path's front kernel has kept / handed to the one-kernel path since the batch was created (diagnostics, tests) */
+int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_uint32 *declined)
+{
+   if (!b || !kept || !declined) return OPUS_BAD_ARG;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   unsigned v[2] = {0, 0};
+   HIPCHECK(hipMemcpy(v, b->d_queue + 16, sizeof v, hipMemcpyDeviceToHost));
+   *kept = v[0]; *declined = v[1];
+   return OPUS_OK;
+}
 int opusgpu_enc_batch_reset(OpusGpuEncBatch *b) { return opusgpu_enc_batch_ctl(b, -1, OPUS_RESET_STATE, 0); }
 int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
 
@@ -357,6 +448,57 @@ static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, sizeof(unsigned), s));
    *grid_out = (int)grid;
+   return OPUS_OK;
+}
+/* One encode call of a SILK-capable batch as the kernel pipeline of opus_sh_split.h, all on HIP stream s: front (every stream) -> quantiser (16 streams per wave) ->
+ * back (every stream the front kernel kept) -> the one-kernel path over the streams it turned away (no wave finds work there when there are none).  The launches are
+ * persistent: each grid is what the chip holds of its kernel, the per-wave scratch is shared between them (they run one after the other). */
+static int oa_sh_grid(OpusGpuEncBatch *b, int slot, const void *kernel, size_t lds, long long work_items, int *grid_out)
+{
+   if (b->occ[slot].kernel != kernel || b->occ[slot].lds != lds) {
+      int per_cu = 0;
+      HIPCHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds));
+      b->occ[slot].kernel = kernel; b->occ[slot].lds = lds; b->occ[slot].per_cu = per_cu < 1 ? 1 : per_cu;
+   }
+   long long grid = (long long)b->occ[slot].per_cu * (b->num_cu > 0 ? b->num_cu : 1);
+   if (grid > work_items) grid = work_items;
+   *grid_out = (int)(grid < 1 ? 1 : grid);
+   return OPUS_OK;
+}
+static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
+      opus_int32 *d_lens, opus_uint32 *d_final_range, hipStream_t s, size_t lds_front, int silk_only, int mode)
+{
+   const int n = (int)b->n_act, ch = b->channels;
+   if (!b->d_cont) {
+      HIPCHECK(hipMalloc((void **)&b->d_cont, sizeof(ShCont) * (size_t)b->S));
+      HIPCHECK(hipMalloc((void **)&b->d_slow_list, sizeof(int) * (size_t)b->S));
+   }
+   { const size_t need = SH_PCM_BYTES(frame_size, ch) * (size_t)b->S; if (need > b->pcm_hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->pcm_hp_cap = need; } }
+   const size_t lds_back = offsetof(ShLds, S) + (silk_only ? 256 : sizeof(FrameLds));
+   const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
+   const size_t lds_q = mode == 2 ? lds_front : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
+   int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0;
+   { int r = oa_sh_grid(b, 0, (const void *)oa_sh_front_kernel, lds_front, n, &g_front); if (r != OPUS_OK) return r; }
+   { int r = oa_sh_grid(b, 1, kq, lds_q, mode == 2 ? n : (n + 15) / 16, &g_quant); if (r != OPUS_OK) return r; }
+   { int r = oa_sh_grid(b, 2, (const void *)oa_sh_back_kernel, lds_back, n, &g_back); if (r != OPUS_OK) return r; }
+   { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_front, n, &g_slow); if (r != OPUS_OK) return r; }
+   size_t need = (size_t)g_front * sizeof(CeltScratch);
+   if ((size_t)g_quant * scr_q > need) need = (size_t)g_quant * scr_q;
+   if ((size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch);
+   if ((size_t)g_slow * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_slow * SH_SCRATCH_BYTES(frame_size, ch);
+   if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
+   HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
+   hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n);
+   if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
+   else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
+   hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
+         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue);
+   hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_front, s,
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
+         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4));
+   HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
 /* d_apcm (may be NULL): the same samples in the encoder's signal domain (int32, Q12 below int16 full scale: src/opus_encoder.c FLOAT2SIG / INT24TOSIG), which the
@@ -383,10 +525,13 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
       }
       const int silk_only = b->all_silk_pinned && frame_size >= b->Fs / 100;
       const size_t lds = sh_lds_bytes(b->channels, silk_only);
+      static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : 1;       /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser */
+      if (split_env && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_env);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds, s,
-            b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue);
+            b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue,
+            (const int *)nullptr, (const unsigned *)nullptr);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }

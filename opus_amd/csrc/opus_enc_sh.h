@@ -897,8 +897,10 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
    }
 }
 
-WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out,
-      const i32 *apcm = nullptr)
+/* The top of opus_encode_native (:1182-1696) for one call: configuration, Opus-layer scalars and SILK state HBM -> LDS, the tonality analysis of the call's input, digital
+ * silence / peak energy / stereo width, the call's decisions (sh_layer_decide).  analysed = 1: the analysis of this call's input has run already (the split path's front
+ * kernel ran this very function on the stream and then handed the call to the one-kernel path: the analysis state in HBM is the only thing it changed) */
+WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, CeltScratch *cs, const i32 *apcm, int analysed)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    SE_PHASE_START(&L->S);
@@ -917,7 +919,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    }
    /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only), in the arena the SILK state is about to
     * be loaded into; a call the reference turns away before that (:1231) leaves it alone */
-   if (!(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
+   if (!analysed && !(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
       if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
          LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
          an_run_analysis_wave((WV_LDS AnLds *)&L->S, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
@@ -938,7 +940,6 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    wv_sync();
    LANE0 sh->silk_in_lds = 1;
    SE_PHASE(&L->S, 0);
-   i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
    {  /* is_digital_silence (:1060, fixed point: all samples zero); peak signal energy tracker (:1310-1320: frames the analysis calls inactive do not feed it) */
       const i32 m = sh_maxabs_wave(pcm, frame_size * CC);
       i32 en = 0;
@@ -948,6 +949,14 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    }
    if (CC == 2 && SH_FORCE_CHANNELS(&L->cfg, st) != 1) sh_compute_stereo_width_wave(L, pcm, frame_size); else { LANE0 sh->stereo_width = 0; }
    LANE0 sh_layer_decide(L, frame_size, max_data_bytes, &gs->an_info);
+}
+WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out,
+      const i32 *apcm = nullptr, int analysed = 0)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, analysed);
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
       const int n = sh_emit_packet(L->packet, out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);

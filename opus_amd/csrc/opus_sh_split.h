@@ -1,0 +1,478 @@
+/* opus_sh_split.h — the SILK-capable Opus encoder as three kernels instead of one: what a call does before, inside and after SILK's rate-control loop.
+ *
+ * Why: inside one wave the noise-shaping quantiser (silk/NSQ_del_dec.c:114: a 320-step recurrence per stream whose only parallelism is its <= 4 survivors) and the
+ * entropy coder (silk/encode_indices.c:35, encode_pulses.c:60: one symbol after the other) keep 4 and 1 of the 64 lanes busy for 40-50 % of a frame, and their
+ * working set (rings, snapshots, 250 VGPRs) sets the occupancy of everything else.  Both are independent ACROSS streams, so they get a kernel whose wave holds 16
+ * streams: one quad per stream for the quantiser (lane = survivor: the layout of silk_nsq_dd.h), one lane per stream for the entropy coder and the rate-control
+ * decisions (silk/fixed/encode_frame_FIX.c:170-370), each lane coding into its own stream's buffer.
+ *
+ *   front kernel  (one wave per stream)   oa_sh_front_frame   opus_encode_native's decisions, analysis.c, high-pass, silk_Encode up to and including silk_process_gains_FIX for
+ *                                                             every coded channel (src/opus_encoder.c:1182-2189, silk/enc_API.c:150-470, encode_frame_FIX.c:98-160) -> ShCont
+ *   quant kernel  (16 streams per wave)   sq_quant_tile_wave  per coded channel: silk_NSQ_del_dec, silk_encode_indices, silk_encode_pulses inside the rate loop
+ *                                                             (encode_frame_FIX.c:162-378); NSQ state, gain indices, coder state and payload bytes back to HBM
+ *   back kernel   (one wave per stream)   oa_sh_back_frame    the flag bits of the SILK payload, the bit reservoir (enc_API.c:522-545), then opus_encode_frame_native from
+ *                                                             :2211: CELT layer of hybrid frames, redundancy, TOC, DTX, padding, the packet
+ *
+ * The front kernel takes the split only for calls it can prove simple from the call's own decisions: one coded frame of 10 or 20 ms with a SILK layer, no prefill, no
+ * SILK bandwidth switch in progress, no in-band FEC, the delayed-decision quantiser (complexity >= 2).  Every other call goes to the one-kernel path
+ * (oa_sh_encode_kernel) unchanged: the front kernel leaves a stream it turns away exactly as it found it, except for the tonality analysis of the call's input, which
+ * has then run (oa_sh_encode_frame(..., analysed = 1)).  Both paths share every stage function (silk_enc_frame.h, opus_enc_sh.h) and the stream record. */
+#ifndef OPUS_AMD_OPUS_SH_SPLIT_H
+#define OPUS_AMD_OPUS_SH_SPLIT_H
+
+enum { SH_CONT_SLOW = 0, SH_CONT_FAST = 1 };
+/* one coded channel of the frame, as the quantiser kernel needs it: the argument list of silk_NSQ_del_dec (OaNsqFrame / OaNsqCfg, silk_frame.h) + the rate loop's inputs */
+struct ShQuantCh {
+   OaNsqFrame fr;
+   OaNsqCfg cfg;
+   i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan;
+   OaSilkEncIndices indices;
+   i16 x16[SE_MAX_FRAME];
+};
+/* the call between the kernels */
+struct ShCont {
+   i32 kind, nq;                                         /* SH_CONT_*; coded channels (jobs) of the frame */
+   i32 silk_flags, silk_flag_bits, silk_dtx, pad0[3];    /* VAD / LBRR flag bits of the payload's first byte, their count, "every channel is in DTX" */
+   EcCtx ec;                                             /* front -> quant -> back */
+   SeControl sc;
+   ShShared sh;
+   OaShScalars st;
+   ShQuantCh q[2];
+   u8 packet[OA_MAX_PACKET + 4];
+};
+
+/* ---------------- front ---------------- */
+/* the wave hands the call to the one-kernel path: nothing of the stream record has been written (the analysis aside) */
+WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, int s)
+{
+   wv_sync();
+   if (wv_lane() == 0) { ct->kind = SH_CONT_SLOW; slow_list[atomicAdd(slow_count, 1u)] = s; }
+   wv_sync();
+}
+template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
+WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
+      int *slow_list, unsigned *slow_count, int s)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   WV_LDS SilkEncLds *S = &L->S;
+   WV_LDS OaSilkEnc *E = &S->st;
+   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
+   const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   {
+      const int simple = !wv_uni(sh->err) && !wv_uni(sh->plc_frame) && wv_uni(sh->nb_frames) == 1 && wv_uni(st->mode) != OA_MODE_CELT_ONLY && !wv_uni(sh->prefill) && !wv_uni(st->silk_bw_switch) &&
+                         !wv_uni(L->cfg.use_inband_fec) && wv_uni(L->cfg.complexity) >= 2 && (frame_size * 100 == Fs || frame_size * 50 == Fs);
+      if (!simple) { sh_front_decline(ct, slow_list, slow_count, s); return; }
+   }
+   LANE0 { sh->f_redundancy = sh->redundancy; sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_to_celt = sh->to_celt; sh->f_silence = sh->is_silence; st->nonfinal_frame = 0; }
+   SeControl sc;
+   sh_frame_front_wave(L, gs, pcm, frame_size, wv_uni(sh->max_data_bytes), pcm_hp, &sc);
+   /* ---- silk_Encode, one frame (silk_encode_wave's pieces in its order; the quantiser and the coder of each channel are what is left out) ---- */
+   SeCall k;
+   if (se_call_prologue_wave(S, &sc, frame_size, 0, &k)) { sh_front_decline(ct, slow_list, slow_count, s); return; }
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
+   {
+      int ok = k.tot_blocks == 1 && wv_uni(c0->inputBufIx) == 0 && wv_uni(c0->nFramesPerPacket) == 1;
+      for (int n = 0; n < sc.nChannelsInternal; n++) ok = ok && !wv_uni(E->ch[n].LBRR_enabled) && (wv_uni(E->ch[n].nStatesDelayedDecision) > 1 || wv_uni(E->ch[n].warping_Q16) > 0);
+      const int nSamplesToBuffer = imin(wv_uni(c0->frame_length) - wv_uni(c0->inputBufIx), k.nSamplesToBufferMax);
+      const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
+      ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
+      if (!ok) { sh_front_decline(ct, slow_list, slow_count, s); return; }
+      se_call_buffer_wave(S, &sc, pcm_hp, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
+   }
+   wv_sync();
+   se_call_frame_head_wave(S, &sc, &L->ec, L->packet + 1, &gs->lbrr, wv_uni(sh->activity), 0);
+   int nq = 0;
+   for (int n = 0; n < sc.nChannelsInternal; n++) {
+      const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
+      if (p.channelRate_bps > 0) {
+         WV_LDS OaSilkEncChannel *c = &E->ch[n];
+         se_frame_head_wave(S, c);
+         se_frame_analysis_wave(S, c, p.condCoding);
+         wv_sync();
+         {  /* the channel's job for the quantiser kernel */
+            ShQuantCh *q = &ct->q[nq];
+            const WV_LDS SeEncCtrl *ctl = &S->ctl;
+            const WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+            FOR_LANES(i, 32) q->fr.PredCoef_Q12[i] = ctl->PredCoef_Q12[i >> 4][i & 15];
+            FOR_LANES(i, 20) q->fr.LTPCoef_Q14[i] = ctl->LTPCoef_Q14[i];
+            FOR_LANES(i, 4 * 24) q->fr.AR_Q13[i] = ctl->AR_Q13[i];
+            FOR_LANES(i, 4) {
+               q->fr.HarmShapeGain_Q14[i] = ctl->HarmShapeGain_Q14[i]; q->fr.Tilt_Q14[i] = ctl->Tilt_Q14[i]; q->fr.LF_shp_Q14[i] = ctl->LF_shp_Q14[i];
+               q->fr.Gains_Q16[i] = ctl->Gains_Q16[i]; q->fr.pitchL[i] = ctl->pitchL[i]; q->GainsUnq_Q16[i] = ctl->GainsUnq_Q16[i];
+            }
+            FOR_LANES(i, c->frame_length) q->x16[i] = x_frame[i];
+            sh_copy_words((i32 *)&q->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
+            if (wv_lane() == 0) {
+               q->fr.signalType = c->indices.signalType; q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Seed = c->indices.Seed;
+               q->fr.Lambda_Q10 = ctl->Lambda_Q10; q->fr.LTP_scale_Q14 = ctl->LTP_scale_Q14;
+               q->cfg.fs_kHz = c->fs_kHz; q->cfg.nb_subfr = c->nb_subfr; q->cfg.predictLPCOrder = c->predictLPCOrder; q->cfg.shapingLPCOrder = c->shapingLPCOrder;
+               q->cfg.nStatesDelayedDecision = c->nStatesDelayedDecision; q->cfg.warping_Q16 = c->warping_Q16;
+               q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex; q->condCoding = p.condCoding; q->maxBits = p.maxBits; q->useCBR = p.useCBR;
+               q->ec_prevLagIndex = c->ec_prevLagIndex; q->ec_prevSignalType = c->ec_prevSignalType; q->chan = n;
+            }
+         }
+         wv_sync();
+         se_frame_finish_wave(S, c, &L->ec);
+         nq++;
+      }
+      wv_sync();
+      LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
+   }
+   LANE0 se_call_frame_tail_l0(S, &sc, &L->ec, L->packet + 1, 1, 0, 1);
+   se_call_epilogue_wave(S, &sc, 0, &k);
+   /* ---- the call so far -> HBM: the continuation record, the SILK state ---- */
+   wv_sync();
+   sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
+   sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
+   sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)L->packet, (OA_MAX_PACKET + 4) / 4);
+   sh_copy_words((i32 *)&gs->silk, (const WV_LDS i32 *)&S->st, SE_STATE_WORDS(CC));
+   if (wv_lane() == 0) {
+      ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
+      ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
+   }
+   wv_sync();
+}
+
+/* ---------------- back ---------------- */
+WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, i16 *pcm_hp /* the stream's slot: the front kernel's high-passed input */, i16 *pcm_celt, i16 *tmp_prefill, CeltScratch *cs, const ShCont *ct, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
+   sh_copy_words((WV_LDS i32 *)sh, (const i32 *)&ct->sh, (int)(sizeof(ShShared) / 4));
+   sh_copy_words((WV_LDS i32 *)st, (const i32 *)&ct->st, (int)(sizeof(OaShScalars) / 4));
+   sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
+   sh_copy_words((WV_LDS i32 *)L->packet, (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
+   wv_sync();
+   const SeControl sc = ct->sc;
+   LANE0 {
+      L->cs = cs; sh->silk_in_lds = 0;
+      /* what silk_Encode does once the channels are coded (enc_API.c:522-545): VAD / LBRR flags into the payload's first bits, the bit reservoir */
+      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+      const int nBytesOut = (k_ec_tell(EC_PASS) + 7) >> 3;
+      k_ec_enc_patch_initial_bits(EC_PASS, (unsigned)ct->silk_flags, (unsigned)ct->silk_flag_bits);
+      ec_st(&L->ec, e);
+      const int nb = ct->silk_dtx ? 0 : nBytesOut;
+      i32 ex = gs->silk.nBitsExceeded + nb * 8 - (sc.bitRate * sc.payloadSize_ms) / 1000;
+      gs->silk.nBitsExceeded = se_limit(ex, 0, 10000);
+      sh->r[5] = nb;
+   }
+   const int silk_nBytes = wv_uni(sh->r[5]);
+   const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes);
+   const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
+   const int result = ret < 0 ? ret : sh_emit_packet(L->packet, out, ret, pad_to, out_cap);
+   LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
+   sh_copy_words((i32 *)&gs->s, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
+   wv_sync();
+}
+
+/* ---------------- quantiser, reference form: one wave per stream on the one-kernel path's own stage function (se_frame_quant_wave).  OPUS_AMD_SH_SPLIT=2 selects it: the
+ * split's data flow can then be checked apart from the 16-streams-per-wave kernel below ---------------- */
+WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeRateScratch *G)
+{
+   WV_LDS SilkEncLds *S = &L->S;
+   WV_LDS OaSilkEnc *E = &S->st;
+   sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
+   wv_sync();
+   const int CC = L->cfg.channels;
+   sh_copy_words((WV_LDS i32 *)&S->st, (const i32 *)&gs->silk, SE_STATE_WORDS(CC));
+   sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
+   sh_copy_words((WV_LDS i32 *)L->packet, (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
+   wv_sync();
+   const int nq = wv_uni(ct->nq);
+   for (int j = 0; j < nq; j++) {
+      const ShQuantCh *q = &ct->q[j];
+      const int n = wv_uni(q->chan);
+      WV_LDS OaSilkEncChannel *c = &E->ch[n];
+      WV_LDS SeEncCtrl *ctl = &S->ctl;
+      wv_sync();
+      FOR_LANES(i, 32) ctl->PredCoef_Q12[i >> 4][i & 15] = q->fr.PredCoef_Q12[i];
+      FOR_LANES(i, 20) ctl->LTPCoef_Q14[i] = q->fr.LTPCoef_Q14[i];
+      FOR_LANES(i, 4 * 24) ctl->AR_Q13[i] = q->fr.AR_Q13[i];
+      FOR_LANES(i, 4) {
+         ctl->HarmShapeGain_Q14[i] = q->fr.HarmShapeGain_Q14[i]; ctl->Tilt_Q14[i] = q->fr.Tilt_Q14[i]; ctl->LF_shp_Q14[i] = q->fr.LF_shp_Q14[i];
+         ctl->Gains_Q16[i] = q->fr.Gains_Q16[i]; ctl->pitchL[i] = q->fr.pitchL[i]; ctl->GainsUnq_Q16[i] = q->GainsUnq_Q16[i];
+      }
+      FOR_LANES(i, c->frame_length) c->x_buf[c->ltp_mem_length + i] = q->x16[i];          /* (LDS copy only: the front kernel has moved x_buf on already) */
+      if (wv_lane() == 0) { ctl->Lambda_Q10 = q->fr.Lambda_Q10; ctl->LTP_scale_Q14 = q->fr.LTP_scale_Q14; ctl->lastGainIndexPrev = q->lastGainIndexPrev; }
+      wv_sync();
+      se_frame_quant_wave(S, c, &L->ec, L->packet + 1, wv_uni(q->condCoding), wv_uni(q->maxBits), wv_uni(q->useCBR), G, &gs->lbrr);
+      wv_sync();
+      OaSilkEncChannel *gc = &gs->silk.ch[n];
+      sh_copy_words((i32 *)&gc->nsq, (const WV_LDS i32 *)&c->nsq, (int)(sizeof(OaSilkNsqState) / 4));
+      sh_copy_words((i32 *)&gc->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
+      sh_copy_words((i32 *)gc->pulses, (const WV_LDS i32 *)c->pulses, SE_MAX_FRAME / 4);
+      if (wv_lane() == 0) { gc->LastGainIndex = c->LastGainIndex; gc->ec_prevLagIndex = c->ec_prevLagIndex; gc->ec_prevSignalType = c->ec_prevSignalType; }
+   }
+   wv_sync();
+   sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)L->packet, (OA_MAX_PACKET + 4) / 4);
+   wv_sync();
+}
+
+/* ---------------- quantiser: 16 streams per wave ---------------- */
+/* the rate-control loop's variables of one stream (silk/fixed/encode_frame_FIX.c:100-120): in LDS, so that the wave's registers belong to whichever stage is running */
+struct SqRate {
+   EcCtx ec, ec_copy, ec_copy2;
+   i32 iter, done, need, gainMult_Q8, found_lower, found_upper, gainsID, gainsID_lower, gainsID_upper, nBits, nBits_lower, nBits_upper, gainMult_lower, gainMult_upper, LastGainIndex_copy2;
+   i32 gain_lock[4], best_gain_mult[4], best_sum[4];
+   i32 seed_copy, ec_prevLagIndex_copy, ec_prevSignalType_copy;
+   i32 condCoding, maxBits, useCBR, lastGainIndexPrev, snap_now, fin, use_lower, chan;
+};
+struct SqStream {                                        /* a stream's slice of the wave's LDS */
+   OaNsqFrame fr;                                        /* live copy: the rate loop changes Gains_Q16, Lambda_Q10, Seed */
+   OaNsqCfg cfg;
+   OaSilkEncIndices ix;
+   i32 nb_subfr, predictLPCOrder, fs_kHz, ec_prevSignalType, ec_prevLagIndex;     /* what se_encode_indices reads of the channel (and the two words it updates) */
+   i32 LastGainIndex, GainsUnq_Q16[4];
+   SqRate rc;
+   i32 wk[40];
+   i8 pulses[SE_MAX_FRAME + 16];
+};
+struct SqLds { SqStream s[16]; };
+/* per-wave HBM scratch: the quantiser's tile (silk_frame.h layout: histories, whitened copies, scalars, delayed-decision rings) + per stream the "lower" snapshot of the rate loop */
+struct SqSnap { OaSilkNsqState nsq; u8 ec_buf_copy[OA_MAX_PACKET + 4]; };
+#define SQ_TILE_WORDS ((size_t)(OA_SILK_HIST_ROWS * 16 * 2 + OA_NSQ_S_ROWS * 16 + OA_SILK_HIST_ROWS * 16 + 5 * OA_SILK_DD * 64))      /* = oa_nsq_tile_words(16), silk_frame.h */
+#define SQ_WAVE_SCRATCH_BYTES (SQ_TILE_WORDS * 4 + 16 * sizeof(SqSnap))
+
+WV_DEV NsqMem sq_mem(i32 *tile, int t)
+{
+   NsqMem m; const int R = OA_SILK_HIST_ROWS, T = 16;
+   m.shp = tile + t; m.q15 = tile + R * T + t; m.scal = tile + 2 * R * T + t;
+   m.xq = (i16 *)(tile + 2 * R * T + OA_NSQ_S_ROWS * T) + t; m.wh = (i16 *)(tile + 2 * R * T + OA_NSQ_S_ROWS * T + R * T / 2) + t;
+   m.T = T; m.len = 2 * R; m.base = 0;
+   return m;
+}
+/* the channel's quantiser state, stream record -> tile column: the quad's four lanes take every fourth word */
+WV_DEV void sq_tile_load(const NsqMem &m, const OaSilkNsqState *g, int mem, int kk)
+{
+   const int T = m.T;
+   for (int i = kk; i < mem; i += 4) { m.shp[i * T] = g->sLTP_shp_Q14[i]; m.xq[i * T] = g->xq[i]; }
+   for (int i = kk; i < 16; i += 4) m.scal[(OA_NSQ_S_LPC + i) * T] = g->sLPC_Q14[i];
+   for (int i = kk; i < 24; i += 4) m.scal[(OA_NSQ_S_AR2 + i) * T] = g->sAR2_Q14[i];
+   if (kk == 0) { m.scal[OA_NSQ_S_LF_AR * T] = g->sLF_AR_shp_Q14; m.scal[OA_NSQ_S_DIFF * T] = g->sDiff_shp_Q14; m.scal[OA_NSQ_S_LAGPREV * T] = g->lagPrev; m.scal[OA_NSQ_S_PREVGAIN * T] = g->prev_gain_Q16; }
+}
+/* ... and back, as silk_NSQ_del_dec leaves silk_nsq_state (NSQ_del_dec.c:299-311: histories moved down by one frame, the frame itself still behind them) */
+WV_DEV void sq_tile_store(const NsqMem &m, OaSilkNsqState *g, int mem, int frame, int ltp_end, int kk)
+{
+   const int T = m.T;
+   for (int i = kk; i < mem; i += 4) { g->sLTP_shp_Q14[i] = m.shp[(frame + i) * T]; g->xq[i] = m.xq[(frame + i) * T]; }
+   for (int i = kk; i < frame; i += 4) { g->sLTP_shp_Q14[mem + i] = m.shp[(mem + i) * T]; g->xq[mem + i] = m.xq[(mem + i) * T]; }
+   for (int i = kk; i < 16; i += 4) g->sLPC_Q14[i] = m.scal[(OA_NSQ_S_LPC + i) * T];
+   for (int i = kk; i < 24; i += 4) g->sAR2_Q14[i] = m.scal[(OA_NSQ_S_AR2 + i) * T];
+   if (kk == 0) {
+      g->sLF_AR_shp_Q14 = m.scal[OA_NSQ_S_LF_AR * T]; g->sDiff_shp_Q14 = m.scal[OA_NSQ_S_DIFF * T]; g->lagPrev = m.scal[OA_NSQ_S_LAGPREV * T]; g->prev_gain_Q16 = m.scal[OA_NSQ_S_PREVGAIN * T];
+      g->sLTP_shp_buf_idx = mem + frame; g->sLTP_buf_idx = ltp_end; g->rewhite_flag = 0;
+   }
+}
+/* the same words between two records (the rate loop's "lower" snapshot back into the stream record) */
+WV_DEV void sq_state_copy(OaSilkNsqState *d, const OaSilkNsqState *g, int mem, int frame, int kk)
+{
+   for (int i = kk; i < mem + frame; i += 4) { d->sLTP_shp_Q14[i] = g->sLTP_shp_Q14[i]; d->xq[i] = g->xq[i]; }
+   for (int i = kk; i < 16; i += 4) d->sLPC_Q14[i] = g->sLPC_Q14[i];
+   for (int i = kk; i < 24; i += 4) d->sAR2_Q14[i] = g->sAR2_Q14[i];
+   if (kk == 0) {
+      d->sLF_AR_shp_Q14 = g->sLF_AR_shp_Q14; d->sDiff_shp_Q14 = g->sDiff_shp_Q14; d->lagPrev = g->lagPrev; d->prev_gain_Q16 = g->prev_gain_Q16;
+      d->sLTP_shp_buf_idx = g->sLTP_shp_buf_idx; d->sLTP_buf_idx = g->sLTP_buf_idx; d->rewhite_flag = g->rewhite_flag;
+   }
+}
+WV_DEV OaNsqCfg sq_cfg_ld(const WV_LDS OaNsqCfg *p) { OaNsqCfg c; c.fs_kHz = p->fs_kHz; c.nb_subfr = p->nb_subfr; c.predictLPCOrder = p->predictLPCOrder; c.shapingLPCOrder = p->shapingLPCOrder; c.nStatesDelayedDecision = p->nStatesDelayedDecision; c.warping_Q16 = p->warping_Q16; return c; }
+WV_DEV bool sq_cfg_eq(const OaNsqCfg &a, const OaNsqCfg &b)
+{ return a.fs_kHz == b.fs_kHz && a.nb_subfr == b.nb_subfr && a.predictLPCOrder == b.predictLPCOrder && a.shapingLPCOrder == b.shapingLPCOrder && a.nStatesDelayedDecision == b.nStatesDelayedDecision && a.warping_Q16 == b.warping_Q16; }
+
+/* job -> the stream's LDS slice (the quad's four lanes share the copy) and the start of the rate loop (:170-185), coder state from / to *ecg */
+WV_DEVN void sq_job_open(WV_LDS SqStream *me, const ShQuantCh *job, const EcCtx *ecg, int first_job, int kk)
+{
+   WV_LDS i32 *d = (WV_LDS i32 *)&me->fr; const i32 *g = (const i32 *)&job->fr;
+   for (int i = kk; i < (int)(sizeof(OaNsqFrame) / 4); i += 4) d[i] = g[i];
+   d = (WV_LDS i32 *)&me->cfg; g = (const i32 *)&job->cfg;
+   for (int i = kk; i < (int)(sizeof(OaNsqCfg) / 4); i += 4) d[i] = g[i];
+   d = (WV_LDS i32 *)&me->ix; g = (const i32 *)&job->indices;
+   for (int i = kk; i < (int)(sizeof(OaSilkEncIndices) / 4); i += 4) d[i] = g[i];
+   me->GainsUnq_Q16[kk] = job->GainsUnq_Q16[kk];
+   if (kk == 0) {
+      WV_LDS SqRate *r = &me->rc;
+      me->nb_subfr = job->cfg.nb_subfr; me->predictLPCOrder = job->cfg.predictLPCOrder; me->fs_kHz = job->cfg.fs_kHz;
+      me->ec_prevSignalType = job->ec_prevSignalType; me->ec_prevLagIndex = job->ec_prevLagIndex; me->LastGainIndex = job->LastGainIndex;
+      if (first_job) { WV_LDS i32 *e = (WV_LDS i32 *)&r->ec; const i32 *s = (const i32 *)ecg; for (int i = 0; i < (int)(sizeof(EcCtx) / 4); i++) e[i] = s[i]; }
+      ec_cp_lds(&r->ec_copy, &r->ec); ec_cp_lds(&r->ec_copy2, &r->ec);
+      r->iter = 0; r->done = 0; r->need = 0; r->gainMult_Q8 = SE_FIX(1, 8); r->found_lower = 0; r->found_upper = 0;
+      { i32 id = 0; for (int k = 0; k < job->cfg.nb_subfr; k++) id = add32(job->indices.GainsIndices[k], shl32(id, 8)); r->gainsID = id; }      /* silk_gains_ID (straight from the job: the slice's copy is still being written by the quad's other lanes) */
+      r->gainsID_lower = -1; r->gainsID_upper = -1; r->nBits = 0; r->nBits_lower = 0; r->nBits_upper = 0; r->gainMult_lower = 0; r->gainMult_upper = 0; r->LastGainIndex_copy2 = 0;
+      for (int i = 0; i < 4; i++) { r->gain_lock[i] = 0; r->best_gain_mult[i] = 0; r->best_sum[i] = 0; }
+      r->seed_copy = job->indices.Seed; r->ec_prevLagIndex_copy = job->ec_prevLagIndex; r->ec_prevSignalType_copy = job->ec_prevSignalType;
+      r->condCoding = job->condCoding; r->maxBits = job->maxBits; r->useCBR = job->useCBR; r->lastGainIndexPrev = job->lastGainIndexPrev; r->chan = job->chan;
+      r->snap_now = 0; r->fin = 0; r->use_lower = 0;
+   }
+}
+/* does this pass quantise?  (a gain set met before: its bit count is known, :186-191) */
+WV_DEV void sq_rate_pre(WV_LDS SqStream *me)
+{
+   WV_LDS SqRate *r = &me->rc;
+   r->need = 0;
+   if (r->gainsID == r->gainsID_lower) r->nBits = r->nBits_lower;
+   else if (r->gainsID == r->gainsID_upper) r->nBits = r->nBits_upper;
+   else {
+      if (r->iter > 0) { ec_cp_lds(&r->ec, &r->ec_copy); me->ix.Seed = (i8)r->seed_copy; me->ec_prevLagIndex = r->ec_prevLagIndex_copy; me->ec_prevSignalType = r->ec_prevSignalType_copy; }
+      me->fr.Seed = me->ix.Seed;
+      r->need = 1;
+   }
+}
+/* entropy coding of the pass and the loop's decisions (:214-366), one lane for the stream; buf: the stream's payload bytes in HBM */
+WV_DEVN void sq_rate_post(WV_LDS SqStream *me, u8 *buf, SqSnap *snap)
+{
+   WV_LDS SqRate *r = &me->rc;
+   const int maxIter = 6, iter = r->iter, maxBits = r->maxBits, condCoding = r->condCoding, nb_subfr = me->nb_subfr, subfr_length = 5 * me->fs_kHz, frame_length = nb_subfr * subfr_length;
+   const int bits_margin = r->useCBR ? 5 : maxBits / 4;
+   int brk = 0;
+   r->snap_now = 0; r->fin = 0; r->use_lower = 0;
+   if (r->need) {
+      if (iter == maxIter && !r->found_lower) ec_cp_lds(&r->ec_copy2, &r->ec);
+      EcCtx ec_; ec_ld(&ec_, &r->ec); EcCtx *e = &ec_;
+      se_encode_indices(me, &me->ix, e, buf, condCoding);
+      se_encode_pulses(e, buf, me->ix.signalType, me->ix.quantOffsetType, (WV_LDS i8 *)me->pulses, frame_length, (WV_LDS i32 *)me->wk);
+      int nb = k_ec_tell(e, buf);
+      if (iter == maxIter && !r->found_lower && nb > maxBits) {
+         ec_ld(&ec_, &r->ec_copy2);
+         me->LastGainIndex = r->lastGainIndexPrev;
+         for (int i = 0; i < nb_subfr; i++) me->ix.GainsIndices[i] = 4;
+         if (condCoding != SE_CODE_CONDITIONALLY) me->ix.GainsIndices[0] = (i8)r->lastGainIndexPrev;
+         me->ec_prevLagIndex = r->ec_prevLagIndex_copy; me->ec_prevSignalType = r->ec_prevSignalType_copy;
+         for (int i = 0; i < frame_length; i++) me->pulses[i] = 0;
+         se_encode_indices(me, &me->ix, e, buf, condCoding);
+         se_encode_pulses(e, buf, me->ix.signalType, me->ix.quantOffsetType, (WV_LDS i8 *)me->pulses, frame_length, (WV_LDS i32 *)me->wk);
+         nb = k_ec_tell(e, buf);
+      }
+      ec_st(&r->ec, &ec_);
+      r->nBits = nb;
+      if (r->useCBR == 0 && iter == 0 && nb <= maxBits) brk = 1;
+   }
+   const i32 nBits = r->nBits, gainsID = r->gainsID;
+   if (!brk) {
+      if (iter == maxIter) {
+         if (r->found_lower && (gainsID == r->gainsID_lower || nBits > maxBits)) {
+            ec_cp_lds(&r->ec, &r->ec_copy2); for (u32 i = 0; i < r->ec_copy2.offs; i++) buf[i] = snap->ec_buf_copy[i]; me->LastGainIndex = r->LastGainIndex_copy2;
+            r->use_lower = 1;
+         }
+         brk = 1;
+      } else {
+         if (nBits > maxBits) {
+            if (r->found_lower == 0 && iter >= 2) { me->fr.Lambda_Q10 = me->fr.Lambda_Q10 + (me->fr.Lambda_Q10 >> 1); r->found_upper = 0; r->gainsID_upper = -1; }
+            else { r->found_upper = 1; r->nBits_upper = nBits; r->gainMult_upper = r->gainMult_Q8; r->gainsID_upper = gainsID; }
+         } else if (nBits < maxBits - bits_margin) {
+            r->found_lower = 1; r->nBits_lower = nBits; r->gainMult_lower = r->gainMult_Q8;
+            if (gainsID != r->gainsID_lower) {
+               r->gainsID_lower = gainsID;
+               ec_cp_lds(&r->ec_copy2, &r->ec); for (u32 i = 0; i < r->ec.offs; i++) snap->ec_buf_copy[i] = buf[i];
+               r->LastGainIndex_copy2 = me->LastGainIndex;
+               r->snap_now = 1;
+            }
+         } else brk = 1;
+      }
+   }
+   if (brk) { r->done = 1; r->fin = 1; return; }
+   int gainMult_Q8 = r->gainMult_Q8;
+   if (!r->found_lower && nBits > maxBits) {
+      for (int i = 0; i < nb_subfr; i++) {
+         int sum = 0;
+         for (int t = i * subfr_length; t < (i + 1) * subfr_length; t++) sum += iabs((i32)me->pulses[t]);
+         if (iter == 0 || (sum < r->best_sum[i] && !r->gain_lock[i])) { r->best_sum[i] = sum; r->best_gain_mult[i] = (i16)gainMult_Q8; } else r->gain_lock[i] = 1;
+      }
+   }
+   if ((r->found_lower & r->found_upper) == 0) {
+      if (nBits > maxBits) gainMult_Q8 = imin(1024, gainMult_Q8 * 3 / 2); else gainMult_Q8 = imax(64, gainMult_Q8 * 4 / 5);
+      gainMult_Q8 = (i16)gainMult_Q8;
+   } else {
+      const i32 gl = r->gainMult_lower, gu = r->gainMult_upper;
+      gainMult_Q8 = gl + ((gu - gl) * (maxBits - r->nBits_lower)) / (r->nBits_upper - r->nBits_lower);
+      gainMult_Q8 = (i16)gainMult_Q8;
+      if (gainMult_Q8 > gl + ((gu - gl) >> 2)) gainMult_Q8 = (i16)(gl + ((gu - gl) >> 2));
+      else if (gainMult_Q8 < gu - ((gu - gl) >> 2)) gainMult_Q8 = (i16)(gu - ((gu - gl) >> 2));
+   }
+   r->gainMult_Q8 = gainMult_Q8;
+   for (int i = 0; i < nb_subfr; i++) { const i16 tmp = r->gain_lock[i] ? (i16)r->best_gain_mult[i] : (i16)gainMult_Q8; me->fr.Gains_Q16[i] = sk_shl_sat(sk_mulwb(me->GainsUnq_Q16[i], tmp), 8); }
+   me->LastGainIndex = r->lastGainIndexPrev;
+   se_gains_quant((WV_LDS i8 *)me->ix.GainsIndices, (WV_LDS i32 *)me->fr.Gains_Q16, (WV_LDS i32 *)&me->LastGainIndex, condCoding == SE_CODE_CONDITIONALLY, nb_subfr);
+   r->gainsID = se_gains_ID((const WV_LDS i8 *)me->ix.GainsIndices, nb_subfr);
+   r->iter = iter + 1;
+}
+/* one silk_NSQ_del_dec pass over the wave's 16 streams; `same`: this quad's stream takes part (its parameters are *sp == its own slice), the others keep the collectives in step */
+WV_DEVN void sq_nsq_pass(const OaNsqCfg cfg, NsqMem mown, i32 *ring, WV_LDS SqStream *sp, const i16 *x16, const OaSilkNsqState *gnsq, int same, int kk)
+{
+   if (same) sq_tile_load(mown, gnsq, 20 * cfg.fs_kHz, kk);                          /* every pass starts from the state the frame started from: the stream record is not written before the loop ends */
+   wv_sync();
+   switch (cfg.shapingLPCOrder) {
+   case 24: silk_nsq_dd_wave<24>(cfg, mown, ring, (const WV_LDS OaNsqFrame *)&sp->fr, x16, (WV_LDS i8 *)sp->pulses, (WV_LDS i8 *)&sp->ix.Seed, same != 0); break;
+   case 16: silk_nsq_dd_wave<16>(cfg, mown, ring, (const WV_LDS OaNsqFrame *)&sp->fr, x16, (WV_LDS i8 *)sp->pulses, (WV_LDS i8 *)&sp->ix.Seed, same != 0); break;
+   default: silk_nsq_dd_wave<0>(cfg, mown, ring, (const WV_LDS OaNsqFrame *)&sp->fr, x16, (WV_LDS i8 *)sp->pulses, (WV_LDS i8 *)&sp->ix.Seed, same != 0); break;
+   }
+   wv_sync();
+}
+/* the quad's part of a snapshot / of the end of the loop: quantiser state tile -> HBM, and what else the frame leaves in the channel record */
+WV_DEVN void sq_store(WV_LDS SqStream *me, const NsqMem mown, OaSilkEncChannel *gc, SqSnap *snap, int snap_q, int fin_q, int low_q, int kk)
+{
+   const int nb_subfr = me->nb_subfr, subfr_length = 5 * me->fs_kHz, frame_length = nb_subfr * subfr_length, ltp_mem = 20 * me->fs_kHz;
+   const int interp = me->ix.NLSFInterpCoef_Q2 == 4 ? 0 : 1, voiced = me->ix.signalType == SE_TYPE_VOICED;
+   const int k_r = voiced && interp && nb_subfr == 4 ? 2 : 0;                    /* the last subframe that re-whitened the LTP state (:205, :232) */
+   const int ltp_end = ltp_mem + (nb_subfr - k_r) * subfr_length;
+   if (snap_q) sq_tile_store(mown, &snap->nsq, ltp_mem, frame_length, ltp_end, kk);
+   if (fin_q) {
+      if (low_q) sq_state_copy(&gc->nsq, &snap->nsq, ltp_mem, frame_length, kk);
+      else sq_tile_store(mown, &gc->nsq, ltp_mem, frame_length, ltp_end, kk);
+      i32 *d = (i32 *)&gc->indices; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->ix;
+      for (int i = kk; i < (int)(sizeof(OaSilkEncIndices) / 4); i += 4) d[i] = g[i];
+      d = (i32 *)gc->pulses; g = (const WV_LDS i32 *)me->pulses;
+      for (int i = kk; i < (frame_length + (frame_length & 15 ? 16 : 0)) / 4; i += 4) d[i] = g[i];      /* (+ the zeros silk_encode_pulses pads a frame that is not a multiple of 16 with) */
+      if (kk == 0) { gc->LastGainIndex = me->LastGainIndex; gc->ec_prevLagIndex = me->ec_prevLagIndex; gc->ec_prevSignalType = me->ec_prevSignalType; }
+   }
+}
+
+WV_DEV void sq_quant_tile_wave(WV_LDS SqLds *Q, OaShStream *streams, ShCont *conts, int first, int nstreams, i32 *tile, SqSnap *snaps)
+{
+   const int lane = wv_lane(), kk = lane & 3, qd = lane >> 2;
+   const int sidx = first + qd < nstreams ? first + qd : first;
+   ShCont *ct = conts + sidx;
+   const bool valid = first + qd < nstreams && ct->kind == SH_CONT_FAST;
+   const int nq = valid ? ct->nq : 0;
+   WV_LDS SqStream *me = &Q->s[qd];
+   SqSnap *snap = snaps + qd;
+   i32 *ring = tile + (SQ_TILE_WORDS - 5 * OA_SILK_DD * 64);
+   const NsqMem mown = sq_mem(tile, qd);
+   u8 *buf = ct->packet + 1;
+   for (int j = 0; j < 2; j++) {
+      if (!wv_ballot(j < nq)) break;
+      const bool has = j < nq;
+      const ShQuantCh *job = &ct->q[has ? j : 0];
+      OaSilkEncChannel *gc = &streams[sidx].silk.ch[has ? job->chan : 0];
+      wv_sync();
+      if (has) sq_job_open(me, job, &ct->ec, j == 0, kk); else if (kk == 0) me->rc.done = 1;
+      wv_sync();
+      /* the rate-control loop of silk_encode_frame_FIX (:170-370), one lane (kk == 0) per stream; the loop itself is the wave's, a stream that has converged sits out */
+      for (;;) {
+         if (kk == 0 && !me->rc.done) sq_rate_pre(me);
+         wv_sync();
+         const int need_q = !me->rc.done && me->rc.need;
+         /* silk_NSQ_del_dec for the streams that need it: one pass per distinct configuration among them (almost always one) */
+         unsigned long long pend = wv_ballot(need_q);
+         while (pend) {
+            const int lead = (int)(__builtin_ctzll(pend) >> 2);
+            const OaNsqCfg cfg = sq_cfg_ld(&Q->s[lead].cfg);
+            const int same = need_q && sq_cfg_eq(sq_cfg_ld(&me->cfg), cfg);
+            const int src = same ? qd : lead;
+            sq_nsq_pass(cfg, mown, ring, &Q->s[src], conts[first + src].q[j].x16, &gc->nsq, same, kk);
+            pend &= ~wv_ballot(same);
+         }
+         if (kk == 0 && !me->rc.done) sq_rate_post(me, buf, snap);
+         wv_sync();
+         const int act = has && (me->rc.snap_now || me->rc.fin);
+         if (act) sq_store(me, mown, gc, snap, me->rc.snap_now, me->rc.fin, me->rc.use_lower, kk);
+         wv_sync();
+         if (kk == 0 && has) { me->rc.snap_now = 0; me->rc.fin = 0; }
+         wv_sync();
+         if (!wv_ballot(!me->rc.done)) break;
+      }
+   }
+   if (valid && nq > 0 && kk == 0) { i32 *d = (i32 *)&ct->ec; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->rc.ec; for (int i = 0; i < (int)(sizeof(EcCtx) / 4); i++) d[i] = g[i]; }
+   wv_sync();
+}
+#endif

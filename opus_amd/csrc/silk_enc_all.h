@@ -9,4 +9,6 @@
 #include "silk_enc_nsq.h"
 #include "silk_enc_frame.h"
 #include "opus_enc_sh.h"
+#include "silk_nsq_dd.h"
+#include "opus_sh_split.h"
 #endif

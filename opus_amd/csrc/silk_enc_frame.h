@@ -44,7 +44,8 @@ struct SilkEncLds {
 #define SE_STATE_WORDS(channels) ((int)((sizeof(OaSilkEnc) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0)) / 4))
 
 /* ---- silk_encode_indices; ix = the frame's own index set, or an LBRR one (encode_LBRR: the type offset is then always >= 2) ---- */
-WV_DEV void se_encode_indices(WV_LDS OaSilkEncChannel *c, const WV_LDS OaSilkEncIndices *ix, EC_ARGS, int condCoding)
+/* C: anything with nb_subfr, predictLPCOrder, fs_kHz, ec_prevSignalType, ec_prevLagIndex (the channel state, or the quantiser kernel's per-stream record) */
+template <class C, class IX, class ECB> WV_DEV void se_encode_indices(C c, IX ix, EC_ARGS_G, int condCoding)
 {
    const int typeOffset = 2 * ix->signalType + ix->quantOffsetType;
    if (typeOffset >= 2) k_ec_enc_icdf(EC_PASS, typeOffset - 2, sk_type_offset_vad_icdf, 8); else k_ec_enc_icdf(EC_PASS, typeOffset, sk_type_offset_no_vad_icdf, 8);
@@ -92,8 +93,8 @@ WV_TABLE uint8_t se_sign_icdf_pairs[84] = { 254, 0, 49, 0, 67, 0, 77, 0, 82, 0, 
 template <int LEN> WV_DEV int se_combine_and_check(int *out, const int *in, int max_pulses) { int over = 0;
 #pragma unroll
    for (int k = 0; k < LEN; k++) { const int s = in[2 * k] + in[2 * k + 1]; over |= s > max_pulses; out[k] = s; } return over; }
-WV_DEV void se_encode_split(EC_ARGS, int p_child1, int p, const u8 *tab) { if (p > 0) k_ec_enc_icdf(EC_PASS, p_child1, &tab[sk_shell_code_table_offsets[p]], 8); }
-WV_DEV void se_shell_encoder(EC_ARGS, const int *p0)
+template <class ECB> WV_DEV void se_encode_split(EC_ARGS_G, int p_child1, int p, const u8 *tab) { if (p > 0) k_ec_enc_icdf(EC_PASS, p_child1, &tab[sk_shell_code_table_offsets[p]], 8); }
+template <class ECB> WV_DEV void se_shell_encoder(EC_ARGS_G, const int *p0)
 {
    int p1[8], p2[4], p3[2], p4[1];
 #pragma unroll
@@ -120,7 +121,7 @@ WV_DEV void se_shell_encoder(EC_ARGS, const int *p0)
    se_encode_split(EC_PASS, p0[14], p1[7], sk_shell_code_table0);
 }
 /* wk: 40 words of LDS (per-block sums and shift counts: run-time indexed) */
-WV_DEV void se_encode_pulses(EC_ARGS, int signalType, int quantOffsetType, WV_LDS i8 *pulses, int frame_length, WV_LDS i32 *wk)
+template <class ECB> WV_DEV void se_encode_pulses(EC_ARGS_G, int signalType, int quantOffsetType, WV_LDS i8 *pulses, int frame_length, WV_LDS i32 *wk)
 {
    const int max_pulses_table[4] = {8, 10, 12, 16};
    int iter = frame_length >> 4;

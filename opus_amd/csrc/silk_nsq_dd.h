@@ -32,8 +32,10 @@ WV_DEV int dd_argmin4(i32 v0, i32 v1, i32 v2, i32 v3, int K)
 WV_DEV int dd_argmax4(i32 v0, i32 v1, i32 v2, i32 v3, int K)
 { int w = 0; i32 m = v0; if (K > 1 && v1 > m) { m = v1; w = 1; } if (K > 2 && v2 > m) { m = v2; w = 2; } if (K > 3 && v3 > m) { m = v3; w = 3; } return w; }
 
-/* One frame of 16 streams on one wave.  fr/x16/pulses/seed_out point at this quad's stream; `store` masks the tail tile. */
-template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, const OaNsqFrame *fr, const i16 *x16, i8 *pulses, i8 *seed_out, bool store)
+/* One frame of 16 streams on one wave.  fr/x16/pulses/seed_out point at this quad's stream (any address space: FR, PU are pointer types).  `store` = 0: this quad only
+ * keeps the wave's collectives in step (tail tile of the batch kernel; in the encoder's quantiser kernel -- opus_sh_split.h -- a stream that sits out this pass): it reads
+ * (its own tile column, someone else's parameters) and leaves no trace -- no pulse, no state word; only its lanes' private ring columns are written. */
+template <int SS, class FR, class PU> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32 *ring, FR fr, const i16 *x16, PU pulses, PU seed_out, bool store)
 {
    const int lane = wv_lane(), kk = lane & 3, qb = lane & ~3;
    const int T = m.T, L = 5 * cfg.fs_kHz, mem = 20 * cfg.fs_kHz, frame = cfg.nb_subfr * L, P = cfg.predictLPCOrder, S = SS ? SS : cfg.shapingLPCOrder;   /* SS != 0: shaping order known at compile time */
@@ -66,7 +68,7 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
    int shp_idx = mem, ltp_idx = mem, p = 0, subfr = 0;
    i32 prevGain_Q10 = 0;
    for (int k = 0; k < cfg.nb_subfr; k++) {
-      const i16 *A_Q12 = &fr->PredCoef_Q12[((k >> 1) | (1 - interp)) * 16];
+      const auto A_Q12 = &fr->PredCoef_Q12[((k >> 1) | (1 - interp)) * 16];
       i32 a[16], ar[24], b[5];
       for (int j = 0; j < 16; j++) a[j] = j < P ? shl32(A_Q12[j], 16) : 0;
       for (int j = 0; j < 24; j++) ar[j] = j < S ? shl32(fr->AR_Q13[k * 24 + j], 16) : 0;
@@ -90,8 +92,7 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
             const i32 sv = wv_shfl(DD_RING(ring, DD_SHAPE, pos, lane), src);
             if (do_rewhite && age < D) {
                if (store) pulses[k * L - 1 - age] = (i8)sk_rround(q, 10);
-               m.xq[nm_row(m, mem + k * L - 1 - age)] = (i16)sk_sat16(sk_rround(sk_mulww(xv, fr->Gains_Q16[1]), 14));
-               m.shp[nm_row(m, shp_idx - 1 - age)] = sv;
+               if (store) { m.xq[nm_row(m, mem + k * L - 1 - age)] = (i16)sk_sat16(sk_rround(sk_mulww(xv, fr->Gains_Q16[1]), 14)); m.shp[nm_row(m, shp_idx - 1 - age)] = sv; }
             }
          }
          if (do_rewhite) { if (kk != w) RD += DD_PENALTY; subfr = 0; }
@@ -100,7 +101,7 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
       if (do_rewhite) {
          /* re-whitening, the quad splitting the output range in four contiguous pieces (FIR: outputs are independent) */
          const int start = mem - lag - P - OA_SILK_LTP_ORDER / 2, n0 = start + P, cnt = mem - n0, per = (cnt + 3) >> 2;
-         if (kk == 0) for (int j = 0; j < P; j++) m.wh[(start + j) * T] = 0;
+         if (kk == 0 && store) for (int j = 0; j < P; j++) m.wh[(start + j) * T] = 0;
          i32 aw[16], w[16];
          const int lo = n0 + kk * per, hi = imin(mem, lo + per);
          for (int j = 0; j < 16; j++) { aw[j] = j < P ? A_Q12[j] : 0; w[j] = (j < P && lo < hi) ? m.xq[nm_row(m, k * L + lo - 1 - j)] : 0; }
@@ -108,7 +109,7 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
             const i32 x = m.xq[nm_row(m, k * L + n)];
             i32 pred = 0;
             for (int j = 0; j < 16; j++) pred = add32(pred, w[j] * aw[j]);
-            m.wh[n * T] = (i16)sk_sat16(sk_rround(sub32(shl32(x, 12), pred), 12));
+            if (store) m.wh[n * T] = (i16)sk_sat16(sk_rround(sub32(shl32(x, 12), pred), 12));
             for (int j = 15; j > 0; j--) w[j] = w[j - 1];
             w[0] = x;
          }
@@ -121,12 +122,12 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
       const i32 inv_gain_Q26 = sk_rround(inv_gain_Q31, 5);
       if (rewhite) {
          if (k == 0) inv_gain_Q31 = shl32(sk_mulwb(inv_gain_Q31, fr->LTP_scale_Q14), 2);
-         for (int i = ltp_idx - lag - OA_SILK_LTP_ORDER / 2 + kk; i < ltp_idx; i += 4) m.q15[i * T] = sk_mulwb(inv_gain_Q31, m.wh[i * T]);
+         if (store) for (int i = ltp_idx - lag - OA_SILK_LTP_ORDER / 2 + kk; i < ltp_idx; i += 4) m.q15[i * T] = sk_mulwb(inv_gain_Q31, m.wh[i * T]);
       }
       if (Gain_Q16 != prev_gain) {
          const i32 adj = sk_div32_varQ(prev_gain, Gain_Q16, 16);
-         for (int i = shp_idx - mem + kk; i < shp_idx; i += 4) { int r = nm_row(m, i); m.shp[r] = sk_mulww(adj, m.shp[r]); }
-         if (voiced && !rewhite)
+         if (store) for (int i = shp_idx - mem + kk; i < shp_idx; i += 4) { int r = nm_row(m, i); m.shp[r] = sk_mulww(adj, m.shp[r]); }
+         if (store && voiced && !rewhite)
             for (int i = ltp_idx - lag - OA_SILK_LTP_ORDER / 2 + kk; i < ltp_idx - D; i += 4) m.q15[i * T] = sk_mulww(adj, m.q15[i * T]);
          LF_AR = sk_mulww(adj, LF_AR);
          Diff = sk_mulww(adj, Diff);
@@ -248,10 +249,12 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
          const int wsrc = wv_shfl(mysrc, qb + winner);
          const i32 vQ = wv_shfl(rQ, wsrc), vXq = wv_shfl(rXq, wsrc), vPred = wv_shfl(rPred, wsrc), vShape = wv_shfl(rShape, wsrc);
          if (subfr > 0 || i >= D) {
-            if (store) pulses[k * L + i - D] = (i8)sk_rround(vQ, 10);
-            m.xq[nm_row(m, mem + k * L + i - D)] = (i16)sk_sat16(sk_rround(sk_mulww(vXq, i >= D ? Gain_Q10 : prevGain_Q10), 8));
-            m.shp[nm_row(m, shp_idx - D)] = vShape;
-            m.q15[(ltp_idx - D) * T] = vPred;
+            if (store) {
+               pulses[k * L + i - D] = (i8)sk_rround(vQ, 10);
+               m.xq[nm_row(m, mem + k * L + i - D)] = (i16)sk_sat16(sk_rround(sk_mulww(vXq, i >= D ? Gain_Q10 : prevGain_Q10), 8));
+               m.shp[nm_row(m, shp_idx - D)] = vShape;
+               m.q15[(ltp_idx - D) * T] = vPred;
+            }
             if (D == lag - OA_SILK_LTP_ORDER / 2 - 1) nPl = vPred;           /* the tap sample i+1 needs is the one just committed */
          }
          shp_idx++; ltp_idx++;
@@ -292,20 +295,20 @@ template <int SS> WV_DEV void silk_nsq_dd_wave(const OaNsqCfg cfg, NsqMem m, i32
          const i32 q = wv_shfl(DD_RING(ring, DD_Q, pos, lane), src), xv = wv_shfl(DD_RING(ring, DD_XQ, pos, lane), src);
          const i32 sv = wv_shfl(DD_RING(ring, DD_SHAPE, pos, lane), src);
          if (age < D) {
-            if (store) pulses[frame - 1 - age] = (i8)sk_rround(q, 10);
-            m.xq[nm_row(m, mem + frame - 1 - age)] = (i16)sk_sat16(sk_rround(sk_mulww(xv, Gain_Q10), 8));
-            m.shp[nm_row(m, shp_idx - 1 - age)] = sv;
+            if (store) { pulses[frame - 1 - age] = (i8)sk_rround(q, 10); m.xq[nm_row(m, mem + frame - 1 - age)] = (i16)sk_sat16(sk_rround(sk_mulww(xv, Gain_Q10), 8)); m.shp[nm_row(m, shp_idx - 1 - age)] = sv; }
          }
       }
       const i32 si = wv_shfl(SeedInitCur, from);
       if (store && kk == 0) *seed_out = (i8)si;
-      for (int j = 0; j < 16; j++) { const i32 v = wv_shfl(s[j], from); m.scal[(OA_NSQ_S_LPC + 15 - j) * T] = v; }
-      for (int j = 0; j < 24; j++) { const i32 v = wv_shfl(ar2[j], from); m.scal[(OA_NSQ_S_AR2 + j) * T] = v; }
+      for (int j = 0; j < 16; j++) { const i32 v = wv_shfl(s[j], from); if (store) m.scal[(OA_NSQ_S_LPC + 15 - j) * T] = v; }
+      for (int j = 0; j < 24; j++) { const i32 v = wv_shfl(ar2[j], from); if (store) m.scal[(OA_NSQ_S_AR2 + j) * T] = v; }
       const i32 lf = wv_shfl(LF_AR, from), df = wv_shfl(Diff, from);
-      m.scal[OA_NSQ_S_LF_AR * T] = lf;  m.scal[OA_NSQ_S_DIFF * T] = df;
-      m.scal[OA_NSQ_S_PREVGAIN * T] = prev_gain;
-      m.scal[OA_NSQ_S_LAGPREV * T] = fr->pitchL[cfg.nb_subfr - 1];
-      { int nb = m.base + frame; m.scal[OA_NSQ_S_BASE * T] = nb >= m.len ? nb - m.len : nb; }
+      if (store) {
+         m.scal[OA_NSQ_S_LF_AR * T] = lf;  m.scal[OA_NSQ_S_DIFF * T] = df;
+         m.scal[OA_NSQ_S_PREVGAIN * T] = prev_gain;
+         m.scal[OA_NSQ_S_LAGPREV * T] = fr->pitchL[cfg.nb_subfr - 1];
+         { int nb = m.base + frame; m.scal[OA_NSQ_S_BASE * T] = nb >= m.len ? nb - m.len : nb; }
+      }
    }
 }
 #endif

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""tools/split_check.py — the SILK-capable encoder's split path (front / quantiser / back kernels, opus_amd/csrc/opus_sh_split.h) against its one-kernel path:
+the same batches through OPUS_AMD_SH_SPLIT = 0, 1, 2 (one subprocess each: the switch is read once per process) must give identical packets, final ranges AND
+identical stream records, byte for byte.  usage: split_check.py [emu|gpu]      (child: split_check.py <lib> <mode> <out.pkl>)"""
+import os, sys, ctypes, pickle, subprocess, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+
+def speech(fs, secs, ch, seed):
+    rng = np.random.default_rng(seed); t = np.arange(int(fs * secs)) / fs; outs = []
+    for c in range(ch):
+        f0 = 120 + 30 * np.sin(2 * np.pi * 0.7 * t + c + seed) + 15 * c + (seed % 7) * 9
+        ph = 2 * np.pi * np.cumsum(f0) / fs
+        s = sum(np.sin(k * ph) / k for k in range(1, 25) if k * 220 < fs / 2) * (np.sin(2 * np.pi * 1.5 * t + 0.3 * c + seed) > -0.3) * 6000 + rng.normal(0, 60 + 400 * (t > secs * 0.7), len(t))
+        outs.append(s)
+    return np.clip(np.stack(outs, 1), -32768, 32767).astype(np.int16)
+
+CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value}, per-stream ctl overrides)
+    "config3":      (16000, 1, 2048, 37, 12, 20, {4002: 24000, 4010: 10, 11002: 1000, 11900: 0}, {}),
+    "config4":      (48000, 2, 2049, 19, 8, 20, {4002: 128000, 4010: 10, 11002: 1001, 11900: 0}, {}),
+    "voip_auto":    (16000, 1, 2048, 5, 10, 20, {4002: 16000, 4010: 10}, {}),
+    "cbr_12k":      (16000, 1, 2048, 6, 10, 20, {4002: 12000, 4010: 8, 4006: 0, 11002: 1000, 11900: 0}, {}),
+    "tight_cvbr":   (16000, 1, 2048, 6, 10, 20, {4002: 9000, 4010: 6, 11002: 1000, 11900: 0}, {}),
+    "10ms_nb_mb":   (48000, 1, 2049, 6, 14, 10, {4002: 14000, 4010: 5, 11002: 1000}, {1: {4008: 1101}, 2: {4008: 1102}, 3: {4010: 2}, 4: {4010: 0}}),
+    "audio_auto":   (48000, 2, 2049, 6, 14, 20, {4002: 40000, 4010: 10}, {1: {4002: 20000}, 2: {4002: 96000}, 3: {4012: 1, 4014: 10}, 4: {4016: 1}}),
+    "stereo_silk":  (24000, 2, 2048, 5, 10, 20, {4002: 30000, 4010: 9, 11002: 1000}, {1: {4022: 1}, 2: {4002: 14000}}),
+}
+
+def run_child(libpath, out):
+    L = ctypes.CDLL(libpath)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    L.opusgpu_enc_batch_create.restype = vp; L.opusgpu_enc_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.opusgpu_enc_batch_ctl.argtypes = [vp, i32, ctypes.c_int, i32]
+    L.opusgpu_encode_batch.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp]
+    L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]
+    L.opusgpu_enc_batch_split_stats.argtypes = [vp, vp, vp]
+    L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
+    res = {}
+    for name, (Fs, ch, app, n, frames, ms, ctl, per) in CASES.items():
+        err = ctypes.c_int()
+        b = L.opusgpu_enc_batch_create(n, Fs, ch, app, 0, ctypes.byref(err)); assert b, err.value
+        for k, v in ctl.items(): assert L.opusgpu_enc_batch_ctl(b, -1, k, v) == 0, (name, k, v)
+        for s, d in per.items():
+            for k, v in d.items(): assert L.opusgpu_enc_batch_ctl(b, s, k, v) == 0, (name, s, k, v)
+        fsz = Fs * ms // 1000
+        sig = [speech(Fs, frames * ms / 1000 + 0.1, ch, s) for s in range(n)]
+        pk = []
+        for f in range(frames):
+            pcm = np.stack([np.ascontiguousarray(sig[s][f * fsz:(f + 1) * fsz]).reshape(-1) for s in range(n)]).astype(np.int16)
+            if f == frames // 2: pcm[0] = 0                      # a frame of digital silence
+            o = np.zeros((n, 1500), np.uint8); lens = np.zeros(n, np.int32); rng = np.zeros(n, np.uint32)
+            r = L.opusgpu_encode_batch(b, pcm.ctypes.data, fsz, o.ctypes.data, 1500, 1275, lens.ctypes.data, rng.ctypes.data); assert r == 0, (name, r)
+            pk.append((lens.copy(), rng.copy(), [bytes(o[s, :max(lens[s], 0)]) for s in range(n)]))
+        sz = L.opusgpu_enc_sh_state_size(); blobs = []
+        for s in range(n):
+            bl = np.zeros(sz, np.uint8); assert L.opusgpu_enc_batch_export_state(b, s, bl.ctypes.data) == 0; blobs.append(bl)
+        k = ctypes.c_uint32(); d = ctypes.c_uint32(); L.opusgpu_enc_batch_split_stats(b, ctypes.byref(k), ctypes.byref(d))
+        L.opusgpu_enc_batch_destroy(b)
+        res[name] = (pk, blobs, (k.value, d.value))
+    pickle.dump(res, open(out, "wb"))
+
+def compare(which="emu", tmpdir="/tmp", verbose=True):
+    if which == "emu":
+        import hostemu; lib = hostemu.build_emu_lib()
+    else: lib = os.path.join(ROOT, "opus_amd/libopus_amd.so")
+    r = {}
+    for mode in "012":
+        out = os.path.join(tmpdir, "split_check_%s_%s_%d.pkl" % (which, mode, os.getpid()))
+        env = dict(os.environ, OPUS_AMD_SH_SPLIT=mode)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), lib, mode, out], env=env)
+        r[mode] = pickle.load(open(out, "rb")); os.unlink(out)
+    bad = []
+    for name in CASES:
+        a = r["0"][name]
+        assert a[2] == (0, 0), "the one-kernel run went through the split path?"
+        for mode in "12":
+            b = r[mode][name]
+            okp = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(a[0], b[0]))
+            nd = [int((x != y).sum()) for x, y in zip(a[1], b[1])]
+            if verbose: print("%-12s mode %s: packets %s, state bytes differing per stream %s, calls kept / handed back %s" % (name, mode, "equal" if okp else "DIFFER", nd, b[2]))
+            if not okp or any(nd): bad.append((name, mode))
+    return bad, {name: r["1"][name][2] for name in CASES}
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4: run_child(sys.argv[1], sys.argv[3])
+    else:
+        bad, stats = compare(sys.argv[1] if len(sys.argv) > 1 else "emu")
+        print("FAIL: %s" % bad if bad else "split path == one-kernel path on every case")
+        sys.exit(1 if bad else 0)
