@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 NO_ANALYSIS = False      # --no-analysis
-CORPUS = "pool"          # --corpus reference: the reference's generate_music() tunes instead of this repo's music / noise-burst pool
+CORPUS = "reference"     # 48 kHz configurations: the reference's generate_music() tunes (SURVEY.md 8d names them first); --corpus pool: this repo's music / noise-burst pool
+CPU_STREAMS = 64         # streams of the GPU batch the CPU legs (baseline, parity sample) run
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
@@ -32,25 +33,32 @@ CONFIGS = {
             app=2049, Fs=48000, ch=1, kernel="oa_sh_encode_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
 
-def reference_music(nsamp, seed):
+def reference_music(nsamp, seeds):
     """the reference's own test corpus: generate_music() of tests/test_opus_encode.c:57-85 (a byte-beat tune through two rounding one-pole filters, dithered with the
-    fast_rand() multiply-with-carry generator of tests/test_opus_common.h:56-62), restated here because the bench input must not come from oracle/; stereo int16
-    [nsamp, 2].  The 60 ms of leading silence are skipped (a bench step should not time digital silence)."""
-    Rz, Rw = (seed * 2654435761) & 0xffffffff or 1, (seed * 40503 + 12345) & 0xffffffff or 1
-    out = np.zeros((nsamp, 2), np.int16)
-    a1 = b1 = a2 = b2 = c1 = c2 = d1 = d2 = 0; j = 0
-    def asr(x, n): return x >> n                                                   # Python ints: arithmetic shift, unbounded (the C code stays within 32 bits)
+    fast_rand() multiply-with-carry generator of tests/test_opus_common.h:56-62), restated here because the bench input must not come from oracle/.  One tune per seed
+    (Rz = Rw = seed, as the test program seeds them), all tunes advanced together: the recurrence is serial in time but independent across tunes, so every step is one
+    numpy operation over the seed axis.  int16 [len(seeds), nsamp, 2].  The 60 ms of leading silence are skipped (a bench step should not time digital silence)."""
+    n = len(seeds)
+    Rz = np.array(seeds, np.uint64) & 0xffffffff; Rw = Rz.copy()
+    Rz[Rz == 0] = 1; Rw[Rw == 0] = 1
+    out = np.zeros((n, nsamp, 2), np.int16)
+    z = np.zeros(n, np.int64)
+    a1, b1, a2, b2, c1, c2, d1, d2 = (z.copy() for _ in range(8))
+    M = np.uint64(0xffffffff); m16 = np.uint64(65535); s16 = np.uint64(16)
+    def rnd():
+        nonlocal Rz, Rw
+        Rz = (np.uint64(36969) * (Rz & m16) + (Rz >> s16)) & M; Rw = (np.uint64(18000) * (Rw & m16) + (Rw >> s16)) & M
+        r = ((Rz << s16) + Rw) & M
+        return (r & m16).astype(np.int64) - (r >> s16).astype(np.int64)
+    j = 0
     for i in range(nsamp):
-        v1 = v2 = (((j * ((j >> 12) ^ ((j >> 10 | j >> 12) & 26 & j >> 7))) & 128) + 128) << 15
-        Rz = (36969 * (Rz & 65535) + (Rz >> 16)) & 0xffffffff; Rw = (18000 * (Rw & 65535) + (Rw >> 16)) & 0xffffffff; r = ((Rz << 16) + Rw) & 0xffffffff
-        v1 += (r & 65535) - (r >> 16)
-        Rz = (36969 * (Rz & 65535) + (Rz >> 16)) & 0xffffffff; Rw = (18000 * (Rw & 65535) + (Rw >> 16)) & 0xffffffff; r = ((Rz << 16) + Rw) & 0xffffffff
-        v2 += (r & 65535) - (r >> 16)
-        b1 = v1 - a1 + asr(b1 * 61 + 32, 6); a1 = v1
-        b2 = v2 - a2 + asr(b2 * 61 + 32, 6); a2 = v2
-        c1 = asr(30 * (c1 + b1 + d1) + 32, 6); d1 = b1
-        c2 = asr(30 * (c2 + b2 + d2) + 32, 6); d2 = b2
-        out[i, 0] = max(-32768, min(32767, asr(c1 + 128, 8))); out[i, 1] = max(-32768, min(32767, asr(c2 + 128, 8)))
+        v = (((j * ((j >> 12) ^ ((j >> 10 | j >> 12) & 26 & j >> 7))) & 128) + 128) << 15
+        v1 = v + rnd(); v2 = v + rnd()
+        b1 = v1 - a1 + ((b1 * 61 + 32) >> 6); a1 = v1
+        b2 = v2 - a2 + ((b2 * 61 + 32) >> 6); a2 = v2
+        c1 = (30 * (c1 + b1 + d1) + 32) >> 6; d1 = b1
+        c2 = (30 * (c2 + b2 + d2) + 32) >> 6; d2 = b2
+        out[:, i, 0] = np.clip((c1 + 128) >> 8, -32768, 32767); out[:, i, 1] = np.clip((c2 + 128) >> 8, -32768, 32767)
         if (i + 2880) % 6 == 0: j += 1
     return out
 
@@ -59,9 +67,8 @@ def synth(cfg, T, n_pool, rank, corpus="pool"):
     import signals
     Fs, ch, fr = cfg["Fs"], cfg["ch"], cfg["Fs"] // 50
     if corpus == "reference" and Fs == 48000:
-        n_pool = min(n_pool, 16)                                                   # (a pure-Python recurrence: a few seconds for 16 tunes)
-        tunes = [reference_music((T + 2) * fr, 1000 * rank + p + 1) for p in range(n_pool)]
-        return np.stack([(t if ch == 2 else t[:, :1]).reshape(-1) for t in tunes])
+        tunes = reference_music((T + 2) * fr, [42 + 100000 * rank + p for p in range(n_pool)])      # Rz = Rw = seed0 + stream, seed0 = 42 (one tune per pool slot)
+        return (tunes if ch == 2 else tunes[:, :, :1]).reshape(n_pool, -1)
     if Fs == 48000:
         return np.stack([(signals.music(T + 2, channels=ch, seed=1000 * rank + p) if p % 4 else signals.noise_bursts(T + 2, channels=ch, seed=1000 * rank + p)).reshape(-1) for p in range(n_pool)])
     rng = np.random.default_rng(77 + rank)
@@ -85,41 +92,63 @@ def host_info():
     except Exception: ncpu = os.cpu_count() or 1
     return model, ncpu
 
+def _ref_lib(path):
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    vp = ctypes.c_void_p
+    L.opus_encoder_create.restype = vp; L.opus_encoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.opus_encode.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int]
+    L.opus_encoder_ctl.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.opus_encoder_destroy.argtypes = [vp]; L.opus_encoder_destroy.restype = None
+    L.opus_decoder_create.restype = vp; L.opus_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.opus_decode.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int]
+    L.opus_decoder_destroy.argtypes = [vp]; L.opus_decoder_destroy.restype = None
+    return L
+
 def _cpu_worker(args):
-    """encode `frames` (list of int16 arrays) in a loop for `seconds` with the compiled reference; returns frames/s of this worker"""
-    path, cfg, pcm, seconds, pin = args
+    """One worker of a CPU leg.  kind "enc": pcm [n_streams, T, frame*ch] int16, every stream through a fresh encoder, its T frames in order; kind "dec": (packets
+    [T, n_streams, stride] uint8, lens [T, n_streams]) through a fresh decoder per stream.  The streams are cycled (fresh state each time) until `seconds` have passed;
+    returns frames/s of this worker."""
+    path, cfg, data, seconds, pin, kind = args
     if pin is not None:
         try: os.sched_setaffinity(0, {pin})
         except Exception: pass
-    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
-    L.opus_encoder_create.restype = ctypes.c_void_p
-    L.opus_encoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
-    L.opus_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-    L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L = _ref_lib(path)
     err = ctypes.c_int()
-    st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
-    for req, v in cfg["ctls"]: L.opus_encoder_ctl(st, req, v)
-    out = (ctypes.c_ubyte * 1500)()
-    fr = cfg["Fs"] // 50; nfr = pcm.shape[0]
-    base = pcm.ctypes.data; stride = pcm.strides[0]
-    n = 0; t0 = time.perf_counter()
-    while True:
-        for i in range(nfr): L.opus_encode(st, base + i * stride, fr, out, 1276)
-        n += nfr
-        if time.perf_counter() - t0 > seconds: break
+    fr = cfg["Fs"] // 50
+    n = 0; t0 = time.perf_counter(); done = False
+    if kind == "enc":
+        pcm = data; ns, T = pcm.shape[0], pcm.shape[1]
+        out = (ctypes.c_ubyte * 1500)()
+        while not done:
+            for s in range(ns):
+                st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
+                for req, v in cfg["ctls"]: L.opus_encoder_ctl(st, req, v)
+                base = pcm[s].ctypes.data; stride = pcm.strides[1]
+                for i in range(T): L.opus_encode(st, base + i * stride, fr, out, 1276)
+                L.opus_encoder_destroy(st); n += T
+                if time.perf_counter() - t0 > seconds: done = True; break
+    else:
+        pk, lens = data; T, ns = lens.shape
+        pcm = (ctypes.c_int16 * (fr * cfg["ch"]))()
+        while not done:
+            for s in range(ns):
+                st = L.opus_decoder_create(cfg["Fs"], cfg["ch"], ctypes.byref(err))
+                for i in range(T): L.opus_decode(st, pk[i, s].ctypes.data, int(lens[i, s]), pcm, fr, 0)
+                L.opus_decoder_destroy(st); n += T
+                if time.perf_counter() - t0 > seconds: done = True; break
     return n / (time.perf_counter() - t0)
 
-def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
-    """Reference libopus (default float build, RTCD/AVX2) on ONE pinned host core over the frames of stream 0 copied back from the GPU batch; then one
-    worker per host core for the all-cores figure."""
+def cpu_baseline(cfg, data, seconds=10.0, all_cores_seconds=4.0, kind="enc"):
+    """Reference libopus (default float build, RTCD/AVX2) on ONE pinned host core over a sample of the GPU batch copied back from the device: the first CPU_STREAMS
+    streams, every frame the GPU batch saw of them (warm-up + timed steps), a fresh codec state per stream exactly as the GPU batch starts them; then one worker per
+    host core for the all-cores figure."""
     path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fl.so")
     model, ncpu = host_info()
     if not os.path.exists(path):
         return {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libopus_ref_fl.so did not travel", "host_nproc": ncpu, "cpu_model": model}
-    pcm0 = np.ascontiguousarray(pcm0)
     try: cpus = sorted(os.sched_getaffinity(0)); first = cpus[0]
     except Exception: cpus = list(range(ncpu)); first = None
-    one = _cpu_worker((path, cfg, pcm0, seconds, first))
+    one = _cpu_worker((path, cfg, data, seconds, first, kind))
     try: os.sched_setaffinity(0, set(cpus))                                 # the single-core leg pinned this process: undo before spawning the pool
     except Exception: pass
     allc = None
@@ -127,22 +156,55 @@ def cpu_baseline(cfg, pcm0, seconds=10.0, all_cores_seconds=4.0):
         try:
             import multiprocessing as mp
             with mp.get_context("spawn").Pool(len(cpus)) as pool:            # (never fork a process that holds a HIP context)
-                allc = float(sum(pool.map(_cpu_worker, [(path, cfg, pcm0, all_cores_seconds, c) for c in cpus])))
+                allc = float(sum(pool.map(_cpu_worker, [(path, cfg, data, all_cores_seconds, c, kind) for c in cpus])))
         except Exception:
             allc = None
-    same = None                                                              # the library the GPU path is bit-exact to: fixed-point arithmetic, no float API (no analysis.c)
+    same = None                                                              # the library the GPU path is bit-exact to: fixed-point arithmetic (+ the float analysis unless --no-analysis)
     try:
         fx = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so" if NO_ANALYSIS else "oracle/_ref/libopus_ref_fxa.so")
-        if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, pcm0, min(4.0, seconds), first))), 1)
+        if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, data, min(4.0, seconds), first, kind))), 1)
         try: os.sched_setaffinity(0, set(cpus))
         except Exception: pass
     except Exception:
         same = None
+    if kind == "enc": ns, T = data.shape[0], data.shape[1]
+    else: T, ns = data[1].shape
     return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": "stream 0 of the GPU batch (its %d frames copied back, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD" % (pcm0.shape[0], seconds),
+            "sample": "streams 0..%d of the GPU batch, their %d frames each (%d distinct frames copied back from the device; a fresh %s per stream, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD"
+                      % (ns - 1, T, ns * T, "encoder" if kind == "enc" else "decoder", seconds),
             "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None,
             "same_work_value": same, "same_work_note": ("one pinned core of the reference's FIXED_POINT + DISABLE_FLOAT_API build" if NO_ANALYSIS else "one pinned core of the reference's FIXED_POINT build with the float API (fixed-point codec + the float tonality analysis)") +
                               ": the arithmetic and the decisions the GPU reproduces bit for bit (`value` is the float build with SIMD dispatch, the fastest way to run the reference on this host)"}
+
+def parity_sample(cfg, pcm, gpu_packets, gpu_lens, gpu_rng, gpu_dec=None):
+    """After the timed region: the first CPU_STREAMS streams once more through the compiled reference the GPU path is bit-exact to (libopus_ref_fxa.so: fixed point + float
+    API; libopus_ref_fx.so under --no-analysis) -- every frame in order, state carried -- and EVERY packet and final range of those streams compared with what the GPU
+    batch produced during the run (warm-up and timed steps).  gpu_dec = (pcm [T, ns, frame*ch], final ranges [T, ns]): the decoder leg's output, compared with the
+    reference decoder's on the same packets.  Returns {"ok", "streams", "frames", "mismatches"} or None when the checker did not travel."""
+    path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so" if NO_ANALYSIS else "oracle/_ref/libopus_ref_fxa.so")
+    if not os.path.exists(path): return None
+    L = _ref_lib(path)
+    L.opus_encoder_ctl.argtypes = None
+    err = ctypes.c_int(); fr = cfg["Fs"] // 50
+    ns, T = pcm.shape[0], pcm.shape[1]
+    out = (ctypes.c_ubyte * 1500)(); bad = 0; rv = ctypes.c_uint32()
+    dpcm = np.zeros(fr * cfg["ch"], np.int16)
+    for s in range(ns):
+        st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
+        for req, v in cfg["ctls"]: L.opus_encoder_ctl(ctypes.c_void_p(st), ctypes.c_int(req), ctypes.c_int(v))
+        dc = L.opus_decoder_create(cfg["Fs"], cfg["ch"], ctypes.byref(err)) if gpu_dec is not None else None
+        for t in range(T):
+            n = L.opus_encode(st, pcm[s, t].ctypes.data, fr, out, 1276)
+            L.opus_encoder_ctl(ctypes.c_void_p(st), ctypes.c_int(4031), ctypes.byref(rv))
+            ok = n == int(gpu_lens[t, s]) and rv.value == int(gpu_rng[t, s]) & 0xffffffff and bytes(out[:max(n, 0)]) == gpu_packets[t, s, :max(n, 0)].tobytes()
+            if ok and dc is not None:
+                m = L.opus_decode(dc, gpu_packets[t, s].ctypes.data, n, dpcm.ctypes.data, fr, 0)
+                ok = m == fr and np.array_equal(dpcm, gpu_dec[0][t, s])
+            bad += 0 if ok else 1
+        L.opus_encoder_destroy(st)
+        if dc is not None: L.opus_decoder_destroy(dc)
+    return {"ok": bad == 0, "streams": ns, "frames": ns * T, "mismatches": bad, "checker": os.path.basename(path),
+            "what": "packets + final ranges" + (" + decoded PCM" if gpu_dec is not None else "") + " of every frame of the sampled streams, GPU batch vs the compiled reference, after the timed region"}
 
 def copy_bandwidth(dev):
     """device-to-device copy, GB/s of traffic (read + write)"""
@@ -156,12 +218,14 @@ def copy_bandwidth(dev):
     e1.record(); torch.cuda.synchronize(dev)
     return 4 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=True, frames_per_launch=0, decode=False):
-    """times K frame-steps of BASELINE config `cid` on this rank; returns a result dict (rank-local figures; the caller reduces dt over ranks)"""
+def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=True, frames_per_launch=0, decode=False, gather_on=True):
+    """times K frame-steps of BASELINE config `cid` on this rank -- the encoder, then (decode=True) the decoder on the packets the encoder just produced; returns a list of
+    result dicts (rank-local figures; the caller reduces dt over ranks): [encode] or [encode, decode]"""
     import torch, torch.distributed as dist
     import opus_amd
     cfg = CONFIGS[cid]
-    Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; T = K + W
+    Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; TE = K + W
+    T = max(TE, frames_per_launch if (world == 1 and cid == 2) else 0)                      # frames of input per stream (the T-frames-per-launch leg wants T of them)
     P = 256
     pool = synth(cfg, T, P, rank, corpus=CORPUS)
     P = pool.shape[0]
@@ -178,11 +242,8 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         pcm[t] = x.round().clamp(-32768, 32767).to(torch.int16)
     del pool_d
     STRIDE = 1280
-    out = torch.zeros((S, STRIDE), dtype=torch.uint8, device=dev)
-    lens = torch.zeros((S,), dtype=torch.int32, device=dev)
-    rng = torch.zeros((S,), dtype=torch.int32, device=dev)
+    NC = min(CPU_STREAMS, S)
     stream = torch.cuda.current_stream(dev)
-    gather = gather_cls(S * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls and cid != 5) else None
     if cid == 5:
         # B multistream encoders x 255 mono AUDIO streams, resident on the device (opusgpu_ms_enc_batch_*, opus_amd/csrc/opus_ms_batch.h): channel split, the 65,535 elementary
         # encodes and the self-delimited packing are launches on one stream; `out` holds the B multistream packets
@@ -198,24 +259,30 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         if not msb: raise RuntimeError("opusgpu_ms_enc_batch_create failed: %d" % err.value)
         assert L.opusgpu_ms_enc_batch_ctl(msb, 4002, NS * 64000) == 0 and L.opusgpu_ms_enc_batch_ctl(msb, 4010, 10) == 0
         pcm = pcm[:, :S].reshape(T, Bn, NS, FR).permute(0, 1, 3, 2).contiguous()            # [T][B][frame][channels] interleaved, as opus_multistream_encode takes it
-        MS_STRIDE = 65536; MS_MAX = (NS - 1) * 1279 + 7662 + 3 * NS + 8
-        out = torch.zeros((Bn, MS_STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((Bn,), dtype=torch.int32, device=dev); rng = torch.zeros((Bn,), dtype=torch.int32, device=dev)
+        STRIDE = 65536; MS_MAX = (NS - 1) * 1279 + 7662 + 3 * NS + 8
+        NP = Bn                                                                              # packets per step
         class _Ms:
             def encode_dev(self, p, fr, o, stride, l, r, hip_stream=None):
-                rc = L.opusgpu_ms_encode_batch_dev(msb, p, fr, o, MS_STRIDE, MS_MAX, l, r, hip_stream)
+                rc = L.opusgpu_ms_encode_batch_dev(msb, p, fr, o, STRIDE, MS_MAX, l, r, hip_stream)
                 if rc != 0: raise RuntimeError("opusgpu_ms_encode_batch_dev failed: %d" % rc)
             def close(self): L.opusgpu_ms_enc_batch_destroy(msb)
         b = _Ms()
     else:
+        NP = S
         b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
         for req, v in cfg["ctls"]: b.ctl(req, v)
         b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)        # default: like the reference's default build (analysis.c + mlp.c at complexity 10)
+    # every step's packets stay on the device (the decoder leg and the parity sample read them): [TE][NP][STRIDE]
+    pk = torch.zeros((TE, NP, STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((TE, NP), dtype=torch.int32, device=dev); rng = torch.zeros((TE, NP), dtype=torch.int32, device=dev)
+    gather = gather_cls(NP * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls and gather_on) else None
 
     def step(t):
-        b.encode_dev(pcm[t].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
-        if gather is not None: gather.launch(lens, rng, out)       # the only exchange of the path: final gather of the packets (RCCL over xGMI)
+        b.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
 
-    for t in range(W): step(t)
+    for t in range(W):
+        step(t)
+        if gather is not None: gather.launch(lens[t], rng[t], pk[t])
+    if gather is not None: gather.flush()
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
@@ -223,15 +290,16 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     t0 = time.perf_counter()
     for k in range(K):
         ev[k][0].record(stream)
-        b.encode_dev(pcm[W + k].data_ptr(), FR, out.data_ptr(), STRIDE, lens.data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
+        step(W + k)
         ev[k][1].record(stream)
-        if gather is not None: gather.launch(lens, rng, out)
+        if gather is not None: gather.launch(lens[W + k], rng[W + k], pk[W + k])  # the only exchange of the path: final gather of the packets (RCCL over xGMI), on a side stream, behind the next step's encode
+    if gather is not None: gather.flush()                                          # ... and the last step's gather is inside the timed region too
     torch.cuda.synchronize(dev)
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
-    lens_h = lens.cpu().numpy()
+    lens_h = lens[W:].cpu().numpy()
     ok = bool((lens_h > 0).all())
     mean_len = float(lens_h.mean()) / (255 if cid == 5 else 1)                               # config 5: per elementary stream (incl. its self-delimiting length byte)
     L = opus_amd.lib()
@@ -241,54 +309,72 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     analysis_on = (not NO_ANALYSIS) and cid != 5 and Fs >= 16000 and cfg["app"] != opus_amd.OPUS_APPLICATION_RESTRICTED_SILK and any(req == 4010 and v >= 10 for req, v in cfg["ctls"])
     if analysis_on: state_moved += L.opusgpu_enc_analysis_moved_bytes()                       # the tonality analysis' own state (phase history, 30 ms input window, band energies, info ring)
     alg = FR * CH * 2 + mean_len + 8 + state_moved
-    res = {"config_id": cid, "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
-           "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved, "float_analysis": bool(analysis_on)}
-    if frames_per_launch and world == 1 and cid != 5:
-        # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "T = 50 consecutive steps"
+    res = {"config_id": cid, "leg": "encode", "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
+           "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved, "float_analysis": bool(analysis_on),
+           "gather": None if gather is None else gather.stats()}
+    results = [res]
+    # the CPU legs' sample: the first NC streams, every frame the batch saw of them
+    pcm_h = None
+    if with_cpu and cid != 5:
+        pcm_h = np.ascontiguousarray(pcm[:TE, :NC].permute(1, 0, 2).cpu().numpy())          # [NC][TE][FR*CH]
+        pk_h = pk[:, :NC].cpu().numpy(); lens_c = lens[:, :NC].cpu().numpy(); rng_c = rng[:, :NC].cpu().numpy()
+        res["pcm_sample"] = pcm_h
+        res["parity_sample"] = parity_sample(cfg, pcm_h, pk_h, lens_c, rng_c)
+    if frames_per_launch and world == 1 and cid == 2:
+        # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "report also T = 50 consecutive steps"; a fresh batch
         Tn = min(frames_per_launch, T)
+        b2 = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
+        for req, v in cfg["ctls"]: b2.ctl(req, v)
+        b2.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)
         outs = torch.zeros((Tn, S, STRIDE), dtype=torch.uint8, device=dev); lns = torch.zeros((Tn, S), dtype=torch.int32, device=dev); rgs = torch.zeros((Tn, S), dtype=torch.int32, device=dev)
         L.opusgpu_encode_batch_dev_frames.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        r = L.opusgpu_encode_batch_dev_frames(b._b, pcm.data_ptr(), FR, Tn, outs.data_ptr(), STRIDE, 1276, lns.data_ptr(), rgs.data_ptr(), stream.cuda_stream)
+        r = L.opusgpu_encode_batch_dev_frames(b2._b, pcm.data_ptr(), FR, Tn, outs.data_ptr(), STRIDE, 1276, lns.data_ptr(), rgs.data_ptr(), stream.cuda_stream)
         e1.record(stream); torch.cuda.synchronize(dev)
-        if r == 0: res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1)}
+        if r == 0:
+            same = bool(torch.equal(lns[:TE], lens)) and bool(torch.equal(rgs[:TE], rng))     # the T-frame launch reproduces the step-by-step run (lengths and final ranges of the frames both saw)
+            res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1), "equals_step_by_step": same}
+        b2.close(); del outs, lns, rgs
     if decode and cid != 5:
-        # the decoder on these very streams: a fresh encoder batch produces the T packets of every stream (untimed), a decoder batch then decodes them step by step
-        # with its state carried in HBM; timed like the encoder (HIP events per launch, barrier + synchronize around the K steps)
-        e2 = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
-        for req, v in cfg["ctls"]: e2.ctl(req, v)
-        pk = torch.zeros((T, S, STRIDE), dtype=torch.uint8, device=dev); pl = torch.zeros((T, S), dtype=torch.int32, device=dev)
-        for t in range(T): e2.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, pl[t].data_ptr(), rng.data_ptr(), hip_stream=stream.cuda_stream)
-        torch.cuda.synchronize(dev); e2.close()
+        # the decoder on these very packets: a decoder batch decodes them step by step with its state carried in HBM; timed like the encoder (HIP events per launch,
+        # barrier + synchronize around the K steps)
         d = opus_amd.DecoderBatch(S, channels=CH, Fs=Fs, device=local)
-        dpcm = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((S,), dtype=torch.int32, device=dev)
-        for t in range(W): d.decode_dev(pk[t].data_ptr(), STRIDE, pl[t].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+        dpcm = torch.zeros((TE, NC, FR * CH), dtype=torch.int16, device=dev)                 # (kept for the sampled streams only)
+        work = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((TE, S), dtype=torch.int32, device=dev)
+        def dstep(t):
+            d.decode_dev(pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), work.data_ptr(), FR, dns.data_ptr(), drng[t].data_ptr(), hip_stream=stream.cuda_stream)
+        for t in range(W): dstep(t); dpcm[t].copy_(work[:NC])
         torch.cuda.synchronize(dev)
         if world > 1: dist.barrier()
         dev_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         t0 = time.perf_counter()
         for k in range(K):
             dev_ev[k][0].record(stream)
-            d.decode_dev(pk[W + k].data_ptr(), STRIDE, pl[W + k].data_ptr(), dpcm.data_ptr(), FR, dns.data_ptr(), drng.data_ptr(), hip_stream=stream.cuda_stream)
+            dstep(W + k)
             dev_ev[k][1].record(stream)
+            dpcm[W + k].copy_(work[:NC])                                                     # (64 streams' output kept for the parity sample: 245 KB per step)
         torch.cuda.synchronize(dev)
         if world > 1: dist.barrier()
         torch.cuda.synchronize(dev)
-        res["dt"] = time.perf_counter() - t0
-        res["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
-        res["kernel"] = "oa_decode_kernel"
-        res["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool((drng.cpu().numpy() == rng.cpu().numpy()).all())      # every stream decoded FR samples and ends on the encoder's final range
+        r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None)
+        r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
+        r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
+        r2["kernel"] = "oa_decode_kernel"
+        r2["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool(torch.equal(drng, rng))      # every stream decoded FR samples and every frame ends on the encoder's final range
         L.opusgpu_dec_state_size.restype = ctypes.c_int
-        res["algorithmic_bytes_per_frame"] = round(FR * CH * 2 + mean_len + 8 + 2 * L.opusgpu_dec_state_size(), 1)
-        res["metric"] = "decoded frames/s (" + cfg["metric"].split("(", 1)[1]
-        d.close(); del pk, dpcm
-    if with_cpu and not decode:
-        res["pcm0"] = (pcm[:, 0, :, 0] if cid == 5 else pcm[:, 0, :]).cpu().numpy().reshape(T, FR * CH)
+        r2["algorithmic_bytes_per_frame"] = round(FR * CH * 2 + mean_len + 8 + 2 * L.opusgpu_dec_state_size(), 1)
+        r2["state_bytes_moved_per_frame"] = 2 * L.opusgpu_dec_state_size()
+        r2["metric"] = "decoded frames/s (" + cfg["metric"].split("(", 1)[1]
+        if pcm_h is not None:
+            r2["parity_sample"] = parity_sample(cfg, pcm_h, pk_h, lens_c, rng_c, gpu_dec=(dpcm.cpu().numpy(), None))
+            r2["dec_sample"] = (pk_h, lens_c)
+        d.close(); del dpcm, work
+        results.append(r2)
     b.close()
-    del pcm, out
+    del pcm, pk
     torch.cuda.empty_cache()
-    return res
+    return results
 
 def main():
     ap = argparse.ArgumentParser()
@@ -297,12 +383,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default 65,536; config 5: 257 x 255)")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="also time T consecutive frame-steps in one launch")
+    ap.add_argument("--frames-per-launch", type=int, default=-1, help="also time T consecutive frame-steps in one launch (config 2, N = 1; default 50 in the default run, 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-analysis", action="store_true", help="encode like a reference built with DISABLE_FLOAT_API: no tonality / music analysis at complexity 10 (the round-1/2 workload)")
-    ap.add_argument("--corpus", default="pool", choices=["pool", "reference"], help="input signals: this repo's music / noise-burst pool (default) or the reference's generate_music() tunes (tests/test_opus_encode.c:57)")
-    ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first, untimed) instead of the encoder")
-    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the short config 3 / 4 legs")
+    ap.add_argument("--corpus", default="reference", choices=["pool", "reference"], help="input signals of the 48 kHz configurations: the reference's generate_music() tunes (tests/test_opus_encode.c:57; default) or this repo's music / noise-burst pool")
+    ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first) and report IT as the main line")
+    ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the config 3 / 4 / 5 and decoder legs")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the final packet gather out (to time what it costs)")
     a = ap.parse_args()
     global CORPUS, NO_ANALYSIS
     CORPUS = a.corpus; NO_ANALYSIS = a.no_analysis
@@ -326,55 +413,83 @@ def main():
     from opus_amd.shard import PacketGather
     S = a.streams or (257 * 255 if a.config == 5 else 65536)
     K, W = a.steps, a.warmup
-    main_res = run_config(a.config, S, K, W, dev, local, rank, world, gather_cls=PacketGather, with_cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline),
-                          frames_per_launch=a.frames_per_launch, decode=a.decode)
+    full = world == 1 and a.config == 2 and not a.no_extra_configs and not a.decode       # the default N = 1 run: every BASELINE configuration + the decoder, one JSON line
+    fpl = a.frames_per_launch if a.frames_per_launch >= 0 else (50 if full else 0)
+    cpu_on = rank == 0 and world == 1 and not a.no_cpu_baseline
+    legs = run_config(a.config, S, K, W, dev, local, rank, world, gather_cls=PacketGather, with_cpu=cpu_on, frames_per_launch=fpl, decode=a.decode or full, gather_on=not a.no_gather)
+    main_res = legs[-1] if a.decode else legs[0]
     tt = torch.tensor([main_res["dt"]], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         if backend != "nccl": tt = tt.cpu()
+        mine = torch.tensor([float(rank), float(local), main_res["dt"] / K * 1e3, main_res["kernel_ms"]], dtype=torch.float64, device=tt.device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(x[0].item()), "device": int(x[1].item()), "ms_per_step": round(float(x[2].item()), 3), "kernel_ms": round(float(x[3].item()), 3)} for x in allr]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    extras = []
-    if world == 1 and a.config == 2 and not a.no_extra_configs and not a.decode:
+    extras = [l for l in legs if l is not main_res]
+    if full:
+        Kx = max(3, K // 2)
         for cid in (3, 4):
-            extras.append(run_config(cid, S, max(3, K // 2), 2, dev, local, rank, world, with_cpu=not a.no_cpu_baseline))
+            extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on, decode=True)
+        extras += run_config(5, 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=False)
     if rank == 0:
         peak_meas = round(copy_bandwidth(dev), 1) if world == 1 else None
+        built = opus_amd.lib().opusgpu_build_info().decode()
+        try: src_now = opus_amd.source_hash()
+        except Exception: src_now = None
         def roof(r, Sn):
             ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
-            traffic = None; issue = None
-            try:
-                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r02.json" if NO_ANALYSIS else "pmc_traffic_r03.json")))["config_%d" % r["config_id"]]
-                if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
-                issue = {"valu_busy_per_simd": pt["issue"]["valu_busy_per_simd"], "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"], "source": "profiles/pmc_traffic_r02.json (rocprofv3 --pmc passes at build r02_final3, no analysis)" if NO_ANALYSIS else "profiles/pmc_traffic_r03.json (rocprofv3 --pmc passes of the final round-3 build, analysis on: profiles/r03_final; configs 3 / 4: round-2 counters)"}
-            except Exception: pass
-            return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "peak_measured": peak_meas,
+            traffic = None; issue = None; tsrc = None
+            key = ("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]
+            for name in (["pmc_traffic_r02.json"] if NO_ANALYSIS else ["pmc_traffic_r04.json", "pmc_traffic_r03.json"]):
+                try:
+                    doc = json.load(open(os.path.join(ROOT, "profiles", name))); pt = doc[key]
+                    if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
+                    issue = {"valu_busy_per_simd": pt["issue"].get("valu_busy_per_simd"), "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"]}
+                    tsrc = "profiles/%s: %s" % (name, pt.get("source") or doc.get("source") or "rocprofv3 --pmc passes (separate runs, not this timed run)")
+                    break
+                except Exception: continue
+            return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc, "peak_measured": peak_meas,
                     "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),
                     "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"],
-                    "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)"}
-        frames = S * world * K
+                    "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d); kernel_ms = HIP events around one call's launches on the launch stream, inside the timed region"}
+        def cpu_leg(r, seconds, allc):
+            if r["leg"] == "decode" and "dec_sample" in r: return cpu_baseline(CONFIGS[r["config_id"]], r["dec_sample"], seconds=seconds, all_cores_seconds=allc, kind="dec")
+            if r["leg"] == "encode" and "pcm_sample" in r: return cpu_baseline(CONFIGS[r["config_id"]], r["pcm_sample"], seconds=seconds, all_cores_seconds=allc, kind="enc")
+            return None
+        frames = main_res["streams_per_gpu"] * world * K
         res = {
-            "metric": main_res["metric"] if a.decode else (CONFIGS[a.config]["metric"] if a.config != 2 else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"), "value": round(frames / dt, 1), "unit": "frames/s",
+            "metric": main_res["metric"] if (a.decode or a.config != 2) else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i32", "data": "synthetic" if a.corpus == "pool" else "synthetic (the reference's generate_music() tunes, tests/test_opus_encode.c:57)",
+            "vs_baseline": None, "dtype": "i32", "data": ("synthetic (the reference's generate_music() tunes, tests/test_opus_encode.c:57: 256 seeds, per-stream phase and gain)" if (a.corpus == "reference" and CONFIGS[a.config]["Fs"] == 48000) else "synthetic"),
             "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point" + (" (with the tonality / music analysis of the float API, as the reference's default build)" if main_res.get("float_analysis") else " (no float API: like a reference built with DISABLE_FLOAT_API)"), "baseline_config": a.config, "float_analysis": bool(main_res.get("float_analysis")),
-                       "streams_per_gpu": S, "frames_per_step": S * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
-                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, ", final RCCL gather of the compacted packets in the timed region" if world > 1 else "")},
-            "roofline": roof(main_res, S),
+                       "streams_per_gpu": main_res["streams_per_gpu"], "frames_per_step": main_res["streams_per_gpu"] * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
+                       "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),
+                       "lib_build": built, "lib_matches_sources": None if src_now is None else built == "OA_SRC_HASH=" + src_now,
+                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final RCCL gather of the compacted packets in the timed region (side stream, double-buffered)" if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
+            "roofline": roof(main_res, main_res["streams_per_gpu"]),
         }
-        if "frames_per_launch" in main_res: res["frames_per_launch"] = main_res["frames_per_launch"]
-        if "pcm0" in main_res:
-            res["cpu_baseline"] = cpu_baseline(CONFIGS[a.config], main_res["pcm0"])
-            if res["cpu_baseline"]["value"]: res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+        if per_rank is not None: res["ranks_seen"] = len(per_rank); res["per_rank"] = per_rank
+        if main_res.get("gather"): res["gather"] = main_res["gather"]
+        if "frames_per_launch" in legs[0]: res["frames_per_launch"] = legs[0]["frames_per_launch"]
+        c = cpu_leg(main_res, 10.0, 4.0) if cpu_on else None
+        if c:
+            res["cpu_baseline"] = c
+            if c["value"]: res["speedup_vs_cpu_1core"] = round(res["value"] / c["value"], 2)
         if extras:
             res["configs"] = {}
             for r in extras:
-                Kx = max(3, K // 2)
-                e = {"workload": r["workload"], "metric": r["metric"], "value": round(S * Kx / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
-                     "mean_packet_bytes": r["mean_packet_bytes"], "all_packets_valid": r["all_packets_valid"], "roofline": roof(r, S)}
-                if "pcm0" in r:
-                    e["cpu_baseline"] = cpu_baseline(CONFIGS[r["config_id"]], r["pcm0"], seconds=5.0, all_cores_seconds=0)
-                    if e["cpu_baseline"]["value"]: e["speedup_vs_cpu_1core"] = round(e["value"] / e["cpu_baseline"]["value"], 2)
-                res["configs"]["config_%d" % r["config_id"]] = e
+                Kx = K if r["config_id"] == a.config else max(3, K // 2)
+                e = {"workload": ("DECODE of the packets of: " if r["leg"] == "decode" else "") + r["workload"], "metric": r["metric"], "value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
+                     "streams_per_gpu": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "all_packets_valid": r["all_packets_valid"], "parity_sample_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
+                     "roofline": roof(r, r["streams_per_gpu"])}
+                c = cpu_leg(r, 3.0, 0) if cpu_on else None
+                if c:
+                    e["cpu_baseline"] = c
+                    if c["value"]: e["speedup_vs_cpu_1core"] = round(e["value"] / c["value"], 2)
+                res["configs"][("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]] = e
         print(json.dumps(res))
     if world > 1: dist.destroy_process_group()
 

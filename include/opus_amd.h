@@ -111,6 +111,9 @@ OPUS_AMD_EXPORT const char *opus_get_version_string(void);
 typedef struct OpusGpuEncBatch OpusGpuEncBatch;
 
 OPUS_AMD_EXPORT int opusgpu_device_count(void);
+/* "OA_SRC_HASH=<16 hex digits>": the hash of the source files this library was compiled from (opus_amd.build() / opus_amd.source_hash()), so that a run can state
+ * which sources its numbers belong to; "OA_SRC_HASH=unknown" for a build outside opus_amd.build() */
+OPUS_AMD_EXPORT const char *opusgpu_build_info(void);
 /* S streams with a common initial configuration on HIP device `device`. */
 OPUS_AMD_EXPORT OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, int channels, int application, int device, int *error);
 OPUS_AMD_EXPORT void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b);

@@ -30,12 +30,30 @@ OPUS_BANDWIDTH_NARROWBAND, OPUS_BANDWIDTH_MEDIUMBAND, OPUS_BANDWIDTH_WIDEBAND, O
 
 SOURCES = [os.path.join(_HERE, "csrc", "opus_amd.hip")]
 
+def source_hash():
+    """sha256 over the sources the library is compiled from (opus_amd/csrc/*, include/opus_amd.h, in name order), first 16 hex digits"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip"))) + [os.path.join(_ROOT, "include", "opus_amd.h")]
+    for p in files:
+        h.update(os.path.basename(p).encode()); h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+def built_source_hash(path=None):
+    """the source hash the built library carries (the string `OA_SRC_HASH=<hex>` compiled into it, opus_amd.hip: opusgpu_build_info); None when there is no library"""
+    path = path or LIB_PATH
+    if not os.path.exists(path): return None
+    data = open(path, "rb").read()
+    i = data.find(b"OA_SRC_HASH=")
+    return None if i < 0 else data[i + 12:i + 28].decode("ascii", "replace")
+
 def build(force=False, verbose=False):
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    hdrs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [os.path.join(_ROOT, "include", "opus_amd.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in hdrs):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  Skipped only when the library on disk was built from exactly these sources
+    (the hash it carries == the hash of the files; when the source tree is absent -- a box that received only the .so -- there is nothing to rebuild from)."""
+    want = source_hash()
+    if not force and built_source_hash() == want and not os.environ.get("OPUS_AMD_EXTRA_CFLAGS"):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-I" + os.path.join(_HERE, "csrc"),
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-DOA_SOURCE_HASH=\"%s\"" % want, "-I" + os.path.join(_HERE, "csrc"),
            "-I" + os.path.join(_ROOT, "include")] + os.environ.get("OPUS_AMD_EXTRA_CFLAGS", "").split() + SOURCES + ["-o", LIB_PATH]   # (extra flags: profiling experiments only)
     if verbose: print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -54,7 +72,7 @@ def lib():
         L.opus_encoder_init.argtypes = [vp, i32, ctypes.c_int, ctypes.c_int]
         L.opus_encode.restype = i32; L.opus_encode.argtypes = [vp, vp, ctypes.c_int, vp, i32]
         L.opus_encoder_destroy.argtypes = [vp]; L.opus_encoder_destroy.restype = None
-        L.opus_strerror.restype = ctypes.c_char_p; L.opus_get_version_string.restype = ctypes.c_char_p
+        L.opus_strerror.restype = ctypes.c_char_p; L.opus_get_version_string.restype = ctypes.c_char_p; L.opusgpu_build_info.restype = ctypes.c_char_p
         L.opusgpu_enc_batch_create.restype = vp; L.opusgpu_enc_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
         L.opusgpu_enc_batch_ctl.argtypes = [vp, i32, ctypes.c_int, i32]

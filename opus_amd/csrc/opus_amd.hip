@@ -261,6 +261,10 @@ struct OpusGpuEncBatch {
 extern "C" {
 
 int opusgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+#ifndef OA_SOURCE_HASH
+#define OA_SOURCE_HASH "unknown"
+#endif
+const char *opusgpu_build_info(void) { return "OA_SRC_HASH=" OA_SOURCE_HASH; }
 int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
 int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
 int opusgpu_sh_kernel_lds_bytes(void) { return (int)SH_LDS_BYTES(1); }

@@ -47,7 +47,7 @@ template <int SS, class FR, class PU> WV_DEV void silk_nsq_dd_wave(const OaNsqCf
    for (int j = 0; j < 24; j++) ar2[j] = m.scal[(OA_NSQ_S_AR2 + j) * T];
    i32 LF_AR = m.scal[OA_NSQ_S_LF_AR * T], Diff = m.scal[OA_NSQ_S_DIFF * T];
    i32 prev_gain = m.scal[OA_NSQ_S_PREVGAIN * T];
-   int lag = m.scal[OA_NSQ_S_LAGPREV * T];
+   int lag = store ? m.scal[OA_NSQ_S_LAGPREV * T] : 0;          /* a quad that sits out may never have had its tile column loaded: nothing read from it may become an address (lag does, through D and the history taps) */
    const int signalType = fr->signalType;
    const bool voiced = signalType == OA_SILK_TYPE_VOICED;
    const int offset_Q10 = k_silk_quant_offsets_Q10[(signalType >> 1) * 2 + fr->quantOffsetType];

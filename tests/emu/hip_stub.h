@@ -44,7 +44,10 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); if (*p) memset(*p, 0xA5, n); return *p ? hipSuccess : hipErrorUnknown; }
+/* device memory is uninitialised on the GPU: fill it with a loud pattern (OA_EMU_FILL=<byte>, default 0xA5 = large negative words; 0x5A = large positive words finds the
+ * garbage-as-index reads a negative pattern hides) */
+static inline int emu_fill_byte() { static const int v = getenv("OA_EMU_FILL") ? (int)strtol(getenv("OA_EMU_FILL"), nullptr, 0) : 0xA5; return v; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); if (*p) memset(*p, emu_fill_byte(), n); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
@@ -70,7 +73,7 @@ static inline void emu_launch(dim3 grid, std::function<void()> body)
 {
    for (unsigned b = 0; b < grid.x; b++) {
       emu_block_x = b;
-      memset(smem, 0xA5, 65536);                         /* LDS is uninitialised on the GPU: make stale reads loud */
+      memset(smem, emu_fill_byte(), 65536);                         /* LDS is uninitialised on the GPU: make stale reads loud */
       emu_run_wave(emu_launch_tramp, &body);
    }
 }
