@@ -33,11 +33,14 @@ CONFIGS = {
             app=2049, Fs=48000, ch=1, kernel="oa_sh_encode_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
 
-def reference_music(nsamp, seeds):
+def reference_music(nsamp, seeds, starts=None):
     """the reference's own test corpus: generate_music() of tests/test_opus_encode.c:57-85 (a byte-beat tune through two rounding one-pole filters, dithered with the
     fast_rand() multiply-with-carry generator of tests/test_opus_common.h:56-62), restated here because the bench input must not come from oracle/.  One tune per seed
     (Rz = Rw = seed, as the test program seeds them), all tunes advanced together: the recurrence is serial in time but independent across tunes, so every step is one
-    numpy operation over the seed axis.  int16 [len(seeds), nsamp, 2].  The 60 ms of leading silence are skipped (a bench step should not time digital silence)."""
+    numpy operation over the seed axis.  int16 [len(seeds), nsamp, 2].
+    starts[p] (default 2880: right after the 60 ms of leading silence, which a bench step should not time) = the sample of the 30 s piece tune p begins at: the melody counter
+    j is a function of the sample index alone (it steps at every i % 6 == 0 from 2880 on), so a tune can be entered anywhere -- filters and dither restart there (their memory
+    is a few dozen samples) -- and a pool of tunes covers the whole piece instead of its first quarter second.  starts = 2880 reproduces the C function bit for bit."""
     n = len(seeds)
     Rz = np.array(seeds, np.uint64) & 0xffffffff; Rw = Rz.copy()
     Rz[Rz == 0] = 1; Rw[Rw == 0] = 1
@@ -50,16 +53,17 @@ def reference_music(nsamp, seeds):
         Rz = (np.uint64(36969) * (Rz & m16) + (Rz >> s16)) & M; Rw = (np.uint64(18000) * (Rw & m16) + (Rw >> s16)) & M
         r = ((Rz << s16) + Rw) & M
         return (r & m16).astype(np.int64) - (r >> s16).astype(np.int64)
-    j = 0
-    for i in range(nsamp):
+    i0 = np.full(n, 2880, np.int64) if starts is None else np.asarray(starts, np.int64)
+    j = (i0 + 5) // 6 - 480                                                         # increments before sample i0: the multiples of 6 in [2880, i0)
+    for k in range(nsamp):
         v = (((j * ((j >> 12) ^ ((j >> 10 | j >> 12) & 26 & j >> 7))) & 128) + 128) << 15
         v1 = v + rnd(); v2 = v + rnd()
         b1 = v1 - a1 + ((b1 * 61 + 32) >> 6); a1 = v1
         b2 = v2 - a2 + ((b2 * 61 + 32) >> 6); a2 = v2
         c1 = (30 * (c1 + b1 + d1) + 32) >> 6; d1 = b1
         c2 = (30 * (c2 + b2 + d2) + 32) >> 6; d2 = b2
-        out[:, i, 0] = np.clip((c1 + 128) >> 8, -32768, 32767); out[:, i, 1] = np.clip((c2 + 128) >> 8, -32768, 32767)
-        if (i + 2880) % 6 == 0: j += 1
+        out[:, k, 0] = np.clip((c1 + 128) >> 8, -32768, 32767); out[:, k, 1] = np.clip((c2 + 128) >> 8, -32768, 32767)
+        j = j + ((i0 + k) % 6 == 0)
     return out
 
 def synth(cfg, T, n_pool, rank, corpus="pool"):
@@ -67,7 +71,9 @@ def synth(cfg, T, n_pool, rank, corpus="pool"):
     import signals
     Fs, ch, fr = cfg["Fs"], cfg["ch"], cfg["Fs"] // 50
     if corpus == "reference" and Fs == 48000:
-        tunes = reference_music((T + 2) * fr, [42 + 100000 * rank + p for p in range(n_pool)])      # Rz = Rw = seed0 + stream, seed0 = 42 (one tune per pool slot)
+        span = 30 * 48000 - 2880 - (T + 2) * fr                                                      # the piece is 30 s long in the reference's test (SAMPLES, tests/test_opus_encode.c:51)
+        tunes = reference_music((T + 2) * fr, [42 + 100000 * rank + p for p in range(n_pool)],      # Rz = Rw = seed0 + stream, seed0 = 42 (one tune per pool slot)
+                                starts=[2880 + (p * span) // n_pool for p in range(n_pool)])           # ... the pool's tunes enter the piece at evenly spread points
         return (tunes if ch == 2 else tunes[:, :, :1]).reshape(n_pool, -1)
     if Fs == 48000:
         return np.stack([(signals.music(T + 2, channels=ch, seed=1000 * rank + p) if p % 4 else signals.noise_bursts(T + 2, channels=ch, seed=1000 * rank + p)).reshape(-1) for p in range(n_pool)])
@@ -274,7 +280,9 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)        # default: like the reference's default build (analysis.c + mlp.c at complexity 10)
     # every step's packets stay on the device (the decoder leg and the parity sample read them): [TE][NP][STRIDE]
     pk = torch.zeros((TE, NP, STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((TE, NP), dtype=torch.int32, device=dev); rng = torch.zeros((TE, NP), dtype=torch.int32, device=dev)
-    gather = gather_cls(NP * world, STRIDE, dev, dst=0) if (world > 1 and gather_cls and gather_on) else None
+    # wire record of the final gather: capacity per stream from the bitrate bound (twice the nominal packet + 64: the aggregate of a shard stays far below it; an overflow is reported)
+    nominal = {2: 128000, 3: 24000, 4: 128000, 5: 255 * 64000}[cid] // 400
+    gather = gather_cls(NP * world, STRIDE, dev, dst=0, cap_per_stream=min(STRIDE, 2 * nominal + 64 * (255 if cid == 5 else 1))) if (world > 1 and gather_cls and gather_on) else None
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
@@ -333,7 +341,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r = L.opusgpu_encode_batch_dev_frames(b2._b, pcm.data_ptr(), FR, Tn, outs.data_ptr(), STRIDE, 1276, lns.data_ptr(), rgs.data_ptr(), stream.cuda_stream)
         e1.record(stream); torch.cuda.synchronize(dev)
         if r == 0:
-            same = bool(torch.equal(lns[:TE], lens)) and bool(torch.equal(rgs[:TE], rng))     # the T-frame launch reproduces the step-by-step run (lengths and final ranges of the frames both saw)
+            m = min(Tn, TE); same = bool(torch.equal(lns[:m], lens[:m])) and bool(torch.equal(rgs[:m], rng[:m]))     # the T-frame launch reproduces the step-by-step run (lengths and final ranges of the frames both saw)
             res["frames_per_launch"] = {"T": Tn, "ms_per_frame_step": round(e0.elapsed_time(e1) / Tn, 3), "frames_per_s": round(S * Tn / (e0.elapsed_time(e1) * 1e-3), 1), "equals_step_by_step": same}
         b2.close(); del outs, lns, rgs
     if decode and cid != 5:
@@ -433,7 +441,7 @@ def main():
         Kx = max(3, K // 2)
         for cid in (3, 4):
             extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on, decode=True)
-        extras += run_config(5, 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=False)
+        extras += run_config(5, (a.streams // 255) * 255 if a.streams else 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=False)
     if rank == 0:
         peak_meas = round(copy_bandwidth(dev), 1) if world == 1 else None
         built = opus_amd.lib().opusgpu_build_info().decode()
@@ -463,7 +471,7 @@ def main():
         res = {
             "metric": main_res["metric"] if (a.decode or a.config != 2) else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i32", "data": ("synthetic (the reference's generate_music() tunes, tests/test_opus_encode.c:57: 256 seeds, per-stream phase and gain)" if (a.corpus == "reference" and CONFIGS[a.config]["Fs"] == 48000) else "synthetic"),
+            "vs_baseline": None, "dtype": "i32", "data": ("synthetic (the reference's generate_music(), tests/test_opus_encode.c:57: 256 seeds entering the 30 s piece at evenly spread points, per-stream phase and gain)" if (a.corpus == "reference" and CONFIGS[a.config]["Fs"] == 48000) else "synthetic"),
             "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point" + (" (with the tonality / music analysis of the float API, as the reference's default build)" if main_res.get("float_analysis") else " (no float API: like a reference built with DISABLE_FLOAT_API)"), "baseline_config": a.config, "float_analysis": bool(main_res.get("float_analysis")),
                        "streams_per_gpu": main_res["streams_per_gpu"], "frames_per_step": main_res["streams_per_gpu"] * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),

@@ -151,6 +151,9 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_frames(OpusGpuEncBatch *b, const op
 /* final-gather compaction (opus_amd/shard.py): packet s = d_lens[s] bytes of its slot -> d_packed[d_offsets[s] ...]; d_offsets = exclusive prefix sum of the lengths (int64) */
 OPUS_AMD_EXPORT int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed,
       opus_int32 n, void *hip_stream);
+/* the same into a record of `capacity` bytes: bytes beyond it are dropped (the lengths travel with the record, so the receiver can tell) */
+OPUS_AMD_EXPORT int opusgpu_pack_packets_cap_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed,
+      opus_int32 n, long long capacity, void *hip_stream);
 /* state bytes one frame-step reads plus writes (roofline accounting): application, channels, hybrid frame? */
 OPUS_AMD_EXPORT int opusgpu_enc_moved_state_bytes(int application, int channels, int hybrid);
 /* ... and what the tonality analysis adds to that when it runs (complexity 10, API rate >= 16 kHz, float analysis on) */

@@ -83,6 +83,7 @@ def lib():
         L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, i32, vp]
         L.opusgpu_enc_batch_sync.argtypes = [vp]; L.opusgpu_enc_batch_reset.argtypes = [vp]
         L.opusgpu_pack_packets_dev.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+        L.opusgpu_pack_packets_cap_dev.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.c_longlong, vp]
         L.opusgpu_enc_moved_state_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         # decoder
         L.opus_decoder_create.restype = vp; L.opus_decoder_create.argtypes = [i32, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]

@@ -93,6 +93,8 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
       const int ch = gs->cfg.channels;
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
+      if (threadIdx.x == 0) L->silk_tail = 1;
+      __syncthreads();
       oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
             (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
             apcm ? apcm + (size_t)s * frame_size * ch : nullptr, list != nullptr);
@@ -101,7 +103,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 }
 /* the split path (opus_sh_split.h).  counters: [0] front queue, [1] quantiser queue, [2] back queue, [3] queue of the one-kernel pass over the calls turned away, [4] their count */
 #ifndef OA_SH_FRONT_WAVES_PER_EU
-#define OA_SH_FRONT_WAVES_PER_EU 2
+#define OA_SH_FRONT_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
 oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams)
@@ -149,7 +151,7 @@ oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scra
    }
 }
 #ifndef OA_SH_BACK_WAVES_PER_EU
-#define OA_SH_BACK_WAVES_PER_EU 2
+#define OA_SH_BACK_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
 oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters)
@@ -180,12 +182,14 @@ oa_surround_kernel(const i16 *pcm, int len, int channels, int Fs, i32 *mem, i32 
 
 /* final-gather compaction: packet s (lens[s] bytes of its out slot) -> packed[offs[s] ...], one wave per packet */
 extern "C" __global__ void __launch_bounds__(64)
-oa_pack_kernel(const u8 *out, int stride, const i32 *lens, const long long *offs, u8 *packed, int n)
+oa_pack_kernel(const u8 *out, int stride, const i32 *lens, const long long *offs, u8 *packed, int n, long long capacity)
 {
    const int s = blockIdx.x;
    if (s >= n) return;
-   const int len = lens[s];
-   const u8 *src = out + (size_t)s * stride; u8 *dst = packed + offs[s];
+   const long long o = offs[s];
+   long long len = lens[s];
+   if (o + len > capacity) len = capacity - o;            /* a fixed-size wire record: what does not fit is dropped (the receiver sees it from the lengths) */
+   const u8 *src = out + (size_t)s * stride; u8 *dst = packed + o;
    for (int i = threadIdx.x; i < len; i += 64) dst[i] = src[i];
 }
 /* T consecutive frame-steps of every stream in one launch: the wave keeps a stream for T frames (pcm [T][S][frame*ch], out [T][S][stride], lens / rngs [T][S]) */
@@ -471,7 +475,7 @@ static int oa_sh_grid(OpusGpuEncBatch *b, int slot, const void *kernel, size_t l
    return OPUS_OK;
 }
 static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
-      opus_int32 *d_lens, opus_uint32 *d_final_range, hipStream_t s, size_t lds_front, int silk_only, int mode)
+      opus_int32 *d_lens, opus_uint32 *d_final_range, hipStream_t s, size_t lds_full, int silk_only, int mode)
 {
    const int n = (int)b->n_act, ch = b->channels;
    if (!b->d_cont) {
@@ -479,14 +483,18 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
       HIPCHECK(hipMalloc((void **)&b->d_slow_list, sizeof(int) * (size_t)b->S));
    }
    { const size_t need = SH_PCM_BYTES(frame_size, ch) * (size_t)b->S; if (need > b->pcm_hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->pcm_hp_cap = need; } }
+   static const size_t lds_pad = getenv("OPUS_AMD_SH_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_SH_LDS_PAD")) : 0;   /* occupancy experiments only */
+   /* the front kernel holds the SILK state without the quantiser tails; the arena behind the head must also hold the tonality analysis' working set */
+   size_t lds_front = SH_FRONT_LDS_BYTES(ch) + lds_pad;
+   if (lds_front < offsetof(ShLds, S) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + sizeof(AnLds);
    const size_t lds_back = offsetof(ShLds, S) + (silk_only ? 256 : sizeof(FrameLds));
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
-   const size_t lds_q = mode == 2 ? lds_front : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
+   const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
    int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0;
    { int r = oa_sh_grid(b, 0, (const void *)oa_sh_front_kernel, lds_front, n, &g_front); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 1, kq, lds_q, mode == 2 ? n : (n + 15) / 16, &g_quant); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 2, (const void *)oa_sh_back_kernel, lds_back, n, &g_back); if (r != OPUS_OK) return r; }
-   { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_front, n, &g_slow); if (r != OPUS_OK) return r; }
+   { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_full, n, &g_slow); if (r != OPUS_OK) return r; }
    size_t need = (size_t)g_front * sizeof(CeltScratch);
    if ((size_t)g_quant * scr_q > need) need = (size_t)g_quant * scr_q;
    if ((size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch);
@@ -499,7 +507,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
          b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue);
-   hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_front, s,
+   hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
          (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4));
    HIPCHECK(hipGetLastError());
@@ -552,12 +560,16 @@ int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fr
 {
    return opusgpu_encode_batch_dev_sig(b, d_pcm, nullptr, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, hip_stream);
 }
-int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed, opus_int32 n, void *hip_stream)
+int opusgpu_pack_packets_cap_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed, opus_int32 n, long long capacity, void *hip_stream)
 {
-   if (!d_out || !d_lens || !d_offsets || !d_packed || n <= 0 || stride <= 0) return OPUS_BAD_ARG;
-   hipLaunchKernelGGL(oa_pack_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)hip_stream, (const u8 *)d_out, (int)stride, (const i32 *)d_lens, d_offsets, (u8 *)d_packed, (int)n);
+   if (!d_out || !d_lens || !d_offsets || !d_packed || n <= 0 || stride <= 0 || capacity < 0) return OPUS_BAD_ARG;
+   hipLaunchKernelGGL(oa_pack_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)hip_stream, (const u8 *)d_out, (int)stride, (const i32 *)d_lens, d_offsets, (u8 *)d_packed, (int)n, capacity);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
+}
+int opusgpu_pack_packets_dev(const unsigned char *d_out, opus_int32 stride, const opus_int32 *d_lens, const long long *d_offsets, unsigned char *d_packed, opus_int32 n, void *hip_stream)
+{
+   return opusgpu_pack_packets_cap_dev(d_out, stride, d_lens, d_offsets, d_packed, n, (long long)n * stride, hip_stream);
 }
 /* state bytes a frame-step reads plus writes (for the roofline's algorithmic traffic): the CELT-only record moves its scalars, the four energy arrays, the overlap and the
  * pitch history; the SILK-capable record moves configuration, scalars and the SILK state of the coded channels, plus -- hybrid -- the CELT state and the delay line */

@@ -46,10 +46,12 @@ struct ShLds {
    OaShConfig cfg;
    MfLds mf;
    CeltScratch *cs;                                      /* the stream's HBM scratch of the CELT passes (celt_enc_lds.h) */
+   i32 silk_tail, pad_;                                  /* 1: this kernel stages the quantiser tails of the SILK state (OaSilkEncTail) too; 0: the split path's front kernel (set by the kernel before the call opens) */
    u8 packet[OA_MAX_PACKET + 4];
    SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
-#define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
+#define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))
+#define SH_FRONT_LDS_BYTES(channels) (offsetof(ShLds, S) + SE_FRONT_LDS_BYTES(channels))
 /* per-stream HBM scratch: the high-passed input of the frame, the faded CELT input of the frame (only written when a frame needs more than one CELT pass),
  * the 2.5 ms CELT prefill, the CELT passes' bulk arrays (CeltScratch), then the rate-loop snapshots */
 #define SH_PCM_BYTES(frame_size, channels) (((size_t)(frame_size) * (channels) * 2 + 63) / 64 * 64)
@@ -368,8 +370,7 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
    const int CC = L->cfg.channels;
    wv_sync();
    if (wv_uni(L->sh.silk_in_lds)) {
-      i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, CC, wv_uni(L->silk_tail));
       wv_sync();
       LANE0 L->sh.silk_in_lds = 0;
    }
@@ -391,8 +392,7 @@ WV_DEV void sh_reload_silk(WV_LDS ShLds *L, const OaShStream *gs)
 {
    if (wv_uni(L->sh.silk_in_lds)) return;
    wv_sync();
-   const i32 *g = (const i32 *)&gs->silk; WV_LDS i32 *d = (WV_LDS i32 *)&L->S.st;
-   FOR_LANES(i, SE_STATE_WORDS(L->cfg.channels)) d[i] = g[i];
+   se_state_copy_wave((WV_LDS i32 *)&L->S.st, (const i32 *)&gs->silk, L->cfg.channels, wv_uni(L->silk_tail));
    wv_sync();
    LANE0 L->sh.silk_in_lds = 1;
 }
@@ -401,8 +401,7 @@ WV_DEV void sh_park_silk(WV_LDS ShLds *L, OaShStream *gs)
 {
    wv_sync();
    if (wv_uni(L->sh.silk_in_lds)) {
-      i32 *g = (i32 *)&gs->silk; const WV_LDS i32 *d = (const WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(L->cfg.channels)) g[i] = d[i];
+      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, L->cfg.channels, wv_uni(L->silk_tail));
       wv_sync();
       LANE0 L->sh.silk_in_lds = 0;
    }
@@ -888,7 +887,8 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
    const int CC = L->cfg.channels;
    wv_sync();
    WV_LDS i32 *w = (WV_LDS i32 *)&L->S.st;
-   FOR_LANES(i, SE_STATE_WORDS(CC)) w[i] = 0;
+   FOR_LANES(i, SE_STATE_LITE_WORDS(CC)) w[i] = 0;
+   if (wv_uni(L->silk_tail)) { const int o = (int)(offsetof(OaSilkEnc, tail) / 4); FOR_LANES(i, CC * SE_TAIL_WORDS) w[o + i] = 0; }
    wv_sync();
    LANE0 {
       WV_LDS OaSilkEnc *E = &L->S.st;
@@ -934,8 +934,7 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
    wv_sync();
    SE_PHASE_START(&L->S);                                                               /* (profiling build: the analysis borrowed the arena the phase clock lives in) */
    {  /* the SILK encoder state (coalesced) */
-      const i32 *g = (const i32 *)&gs->silk; WV_LDS i32 *d = (WV_LDS i32 *)&L->S.st;
-      FOR_LANES(i, SE_STATE_WORDS(CC)) d[i] = g[i];
+      se_state_copy_wave((WV_LDS i32 *)&L->S.st, (const i32 *)&gs->silk, CC, wv_uni(L->silk_tail));
    }
    wv_sync();
    LANE0 sh->silk_in_lds = 1;
@@ -1026,8 +1025,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       i32 *g = (i32 *)&gs->s; const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
       if (wv_uni(sh->silk_in_lds)) {
-         g = (i32 *)&gs->silk; d = (const WV_LDS i32 *)&L->S.st;
-         FOR_LANES(i, SE_STATE_WORDS(CC)) g[i] = d[i];
+         se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, CC, wv_uni(L->silk_tail));
       }
    }
    SE_PHASE(&L->S, 10);

@@ -85,10 +85,13 @@ static int oa_proj_encode(OpusProjectionEncoder *st, const opus_int16 *pcm16, co
       }
    }
    /* the elementary encoders' analyses look at the caller's UN-mixed channels (opus_multistream_encode_native hands opus_encode_native the original pcm with the
-    * stream's channel indices, opus_multistream_encoder.c:1027), in the signal domain of the entry point (downmix_int / downmix_int24) */
+    * stream's channel indices, opus_multistream_encoder.c:1027) through the entry point's downmix function.  opus_projection_encode24 passes downmix_int -- the int16
+    * reader -- and MAX_ENCODING_DEPTH for its int32 input (src/opus_projection_encoder.c:408-415): the analysis of the reference therefore reads the caller's buffer as
+    * int16 halves, sample k of the view = half k of the int32 array.  A drop-in shares that: the same halves, the same depth (16 in this FIXED_POINT build). */
    std::vector<opus_int32> sig((size_t)frame_size * C);
-   for (size_t i = 0; i < sig.size(); i++) sig[i] = pcm16 ? (opus_int32)((opus_uint32)(opus_int32)pcm16[i] << 12) : (opus_int32)((opus_uint32)pcm24[i] << 4);
-   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, pcm16 ? 16 : 24, sig.data());
+   const opus_int16 *v16 = pcm16 ? pcm16 : (const opus_int16 *)(const void *)pcm24;
+   for (size_t i = 0; i < sig.size(); i++) sig[i] = (opus_int32)((opus_uint32)(opus_int32)v16[i] << 12);
+   return oa_ms_encode_native(oa_proj_ms(st), mixed.data(), frame_size, data, max_data_bytes, pcm16 ? 16 : OA_MAX_ENCODING_DEPTH, sig.data());
 }
 int opus_projection_encode(OpusProjectionEncoder *st, const opus_int16 *pcm, int frame_size, unsigned char *data, opus_int32 max_data_bytes)
 { return pcm ? oa_proj_encode(st, pcm, NULL, frame_size, data, max_data_bytes) : OPUS_BAD_ARG; }

@@ -25,7 +25,7 @@ enum { SH_CONT_SLOW = 0, SH_CONT_FAST = 1 };
 struct ShQuantCh {
    OaNsqFrame fr;
    OaNsqCfg cfg;
-   i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan;
+   i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan, nsq_reset, pad_[3];
    OaSilkEncIndices indices;
    i16 x16[SE_MAX_FRAME];
 };
@@ -56,6 +56,8 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
    WV_LDS OaSilkEnc *E = &S->st;
+   LANE0 L->silk_tail = 0;                                                               /* the quantiser tails stay in HBM: they are the quantiser kernel's */
+   wv_sync();
    sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    {
@@ -109,6 +111,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
                q->cfg.nStatesDelayedDecision = c->nStatesDelayedDecision; q->cfg.warping_Q16 = c->warping_Q16;
                q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex; q->condCoding = p.condCoding; q->maxBits = p.maxBits; q->useCBR = p.useCBR;
                q->ec_prevLagIndex = c->ec_prevLagIndex; q->ec_prevSignalType = c->ec_prevSignalType; q->chan = n;
+               q->nsq_reset = c->nsq_reset_req; c->nsq_reset_req = 0;                          /* the quantiser kernel starts this channel's state over (se_nsq_apply_reset_wave on the one-kernel path) */
             }
          }
          wv_sync();
@@ -126,7 +129,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
    sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
    sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)L->packet, (OA_MAX_PACKET + 4) / 4);
-   sh_copy_words((i32 *)&gs->silk, (const WV_LDS i32 *)&S->st, SE_STATE_WORDS(CC));
+   se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&S->st, CC, 0);
    if (wv_lane() == 0) {
       ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
       ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
@@ -175,7 +178,7 @@ WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeR
    sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
    wv_sync();
    const int CC = L->cfg.channels;
-   sh_copy_words((WV_LDS i32 *)&S->st, (const i32 *)&gs->silk, SE_STATE_WORDS(CC));
+   se_state_copy_wave((WV_LDS i32 *)&S->st, (const i32 *)&gs->silk, CC, 1);
    sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
    sh_copy_words((WV_LDS i32 *)L->packet, (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
    wv_sync();
@@ -194,14 +197,13 @@ WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeR
          ctl->Gains_Q16[i] = q->fr.Gains_Q16[i]; ctl->pitchL[i] = q->fr.pitchL[i]; ctl->GainsUnq_Q16[i] = q->GainsUnq_Q16[i];
       }
       FOR_LANES(i, c->frame_length) c->x_buf[c->ltp_mem_length + i] = q->x16[i];          /* (LDS copy only: the front kernel has moved x_buf on already) */
-      if (wv_lane() == 0) { ctl->Lambda_Q10 = q->fr.Lambda_Q10; ctl->LTP_scale_Q14 = q->fr.LTP_scale_Q14; ctl->lastGainIndexPrev = q->lastGainIndexPrev; }
+      if (wv_lane() == 0) { ctl->Lambda_Q10 = q->fr.Lambda_Q10; ctl->LTP_scale_Q14 = q->fr.LTP_scale_Q14; ctl->lastGainIndexPrev = q->lastGainIndexPrev; c->nsq_reset_req = q->nsq_reset; }
       wv_sync();
       se_frame_quant_wave(S, c, &L->ec, L->packet + 1, wv_uni(q->condCoding), wv_uni(q->maxBits), wv_uni(q->useCBR), G, &gs->lbrr);
       wv_sync();
       OaSilkEncChannel *gc = &gs->silk.ch[n];
-      sh_copy_words((i32 *)&gc->nsq, (const WV_LDS i32 *)&c->nsq, (int)(sizeof(OaSilkNsqState) / 4));
+      sh_copy_words((i32 *)&gs->silk.tail[n], (const WV_LDS i32 *)&E->tail[n], SE_TAIL_WORDS);
       sh_copy_words((i32 *)&gc->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
-      sh_copy_words((i32 *)gc->pulses, (const WV_LDS i32 *)c->pulses, SE_MAX_FRAME / 4);
       if (wv_lane() == 0) { gc->LastGainIndex = c->LastGainIndex; gc->ec_prevLagIndex = c->ec_prevLagIndex; gc->ec_prevSignalType = c->ec_prevSignalType; }
    }
    wv_sync();
@@ -217,7 +219,7 @@ struct SqRate {
    i32 iter, done, need, gainMult_Q8, found_lower, found_upper, gainsID, gainsID_lower, gainsID_upper, nBits, nBits_lower, nBits_upper, gainMult_lower, gainMult_upper, LastGainIndex_copy2;
    i32 gain_lock[4], best_gain_mult[4], best_sum[4];
    i32 seed_copy, ec_prevLagIndex_copy, ec_prevSignalType_copy;
-   i32 condCoding, maxBits, useCBR, lastGainIndexPrev, snap_now, fin, use_lower, chan;
+   i32 condCoding, maxBits, useCBR, lastGainIndexPrev, snap_now, fin, use_lower, chan, nsq_reset;
 };
 struct SqStream {                                        /* a stream's slice of the wave's LDS */
    OaNsqFrame fr;                                        /* live copy: the rate loop changes Gains_Q16, Lambda_Q10, Seed */
@@ -244,9 +246,17 @@ WV_DEV NsqMem sq_mem(i32 *tile, int t)
    return m;
 }
 /* the channel's quantiser state, stream record -> tile column: the quad's four lanes take every fourth word */
-WV_DEV void sq_tile_load(const NsqMem &m, const OaSilkNsqState *g, int mem, int kk)
+/* reset: the state starts over instead (the front kernel's request, ShQuantCh.nsq_reset): all zero, lagPrev = 100, prev_gain_Q16 = 1.0 */
+WV_DEV void sq_tile_load(const NsqMem &m, const OaSilkNsqState *g, int mem, int kk, int reset)
 {
    const int T = m.T;
+   if (reset) {
+      for (int i = kk; i < mem; i += 4) { m.shp[i * T] = 0; m.xq[i * T] = 0; }
+      for (int i = kk; i < 16; i += 4) m.scal[(OA_NSQ_S_LPC + i) * T] = 0;
+      for (int i = kk; i < 24; i += 4) m.scal[(OA_NSQ_S_AR2 + i) * T] = 0;
+      if (kk == 0) { m.scal[OA_NSQ_S_LF_AR * T] = 0; m.scal[OA_NSQ_S_DIFF * T] = 0; m.scal[OA_NSQ_S_LAGPREV * T] = 100; m.scal[OA_NSQ_S_PREVGAIN * T] = 65536; }
+      return;
+   }
    for (int i = kk; i < mem; i += 4) { m.shp[i * T] = g->sLTP_shp_Q14[i]; m.xq[i * T] = g->xq[i]; }
    for (int i = kk; i < 16; i += 4) m.scal[(OA_NSQ_S_LPC + i) * T] = g->sLPC_Q14[i];
    for (int i = kk; i < 24; i += 4) m.scal[(OA_NSQ_S_AR2 + i) * T] = g->sAR2_Q14[i];
@@ -301,7 +311,7 @@ WV_DEVN void sq_job_open(WV_LDS SqStream *me, const ShQuantCh *job, const EcCtx 
       r->gainsID_lower = -1; r->gainsID_upper = -1; r->nBits = 0; r->nBits_lower = 0; r->nBits_upper = 0; r->gainMult_lower = 0; r->gainMult_upper = 0; r->LastGainIndex_copy2 = 0;
       for (int i = 0; i < 4; i++) { r->gain_lock[i] = 0; r->best_gain_mult[i] = 0; r->best_sum[i] = 0; }
       r->seed_copy = job->indices.Seed; r->ec_prevLagIndex_copy = job->ec_prevLagIndex; r->ec_prevSignalType_copy = job->ec_prevSignalType;
-      r->condCoding = job->condCoding; r->maxBits = job->maxBits; r->useCBR = job->useCBR; r->lastGainIndexPrev = job->lastGainIndexPrev; r->chan = job->chan;
+      r->condCoding = job->condCoding; r->maxBits = job->maxBits; r->useCBR = job->useCBR; r->lastGainIndexPrev = job->lastGainIndexPrev; r->chan = job->chan; r->nsq_reset = job->nsq_reset;
       r->snap_now = 0; r->fin = 0; r->use_lower = 0;
    }
 }
@@ -397,9 +407,9 @@ WV_DEVN void sq_rate_post(WV_LDS SqStream *me, u8 *buf, SqSnap *snap)
    r->iter = iter + 1;
 }
 /* one silk_NSQ_del_dec pass over the wave's 16 streams; `same`: this quad's stream takes part (its parameters are *sp == its own slice), the others keep the collectives in step */
-WV_DEVN void sq_nsq_pass(const OaNsqCfg cfg, NsqMem mown, i32 *ring, WV_LDS SqStream *sp, const i16 *x16, const OaSilkNsqState *gnsq, int same, int kk)
+WV_DEVN void sq_nsq_pass(const OaNsqCfg cfg, NsqMem mown, i32 *ring, WV_LDS SqStream *sp, const i16 *x16, const OaSilkNsqState *gnsq, int same, int kk, int reset)
 {
-   if (same) sq_tile_load(mown, gnsq, 20 * cfg.fs_kHz, kk);                          /* every pass starts from the state the frame started from: the stream record is not written before the loop ends */
+   if (same) sq_tile_load(mown, gnsq, 20 * cfg.fs_kHz, kk, reset);                          /* every pass starts from the state the frame started from: the stream record is not written before the loop ends */
    wv_sync();
    switch (cfg.shapingLPCOrder) {
    case 24: silk_nsq_dd_wave<24>(cfg, mown, ring, (const WV_LDS OaNsqFrame *)&sp->fr, x16, (WV_LDS i8 *)sp->pulses, (WV_LDS i8 *)&sp->ix.Seed, same != 0); break;
@@ -409,7 +419,7 @@ WV_DEVN void sq_nsq_pass(const OaNsqCfg cfg, NsqMem mown, i32 *ring, WV_LDS SqSt
    wv_sync();
 }
 /* the quad's part of a snapshot / of the end of the loop: quantiser state tile -> HBM, and what else the frame leaves in the channel record */
-WV_DEVN void sq_store(WV_LDS SqStream *me, const NsqMem mown, OaSilkEncChannel *gc, SqSnap *snap, int snap_q, int fin_q, int low_q, int kk)
+WV_DEVN void sq_store(WV_LDS SqStream *me, const NsqMem mown, OaSilkEncChannel *gc, OaSilkEncTail *gt, SqSnap *snap, int snap_q, int fin_q, int low_q, int kk)
 {
    const int nb_subfr = me->nb_subfr, subfr_length = 5 * me->fs_kHz, frame_length = nb_subfr * subfr_length, ltp_mem = 20 * me->fs_kHz;
    const int interp = me->ix.NLSFInterpCoef_Q2 == 4 ? 0 : 1, voiced = me->ix.signalType == SE_TYPE_VOICED;
@@ -417,11 +427,11 @@ WV_DEVN void sq_store(WV_LDS SqStream *me, const NsqMem mown, OaSilkEncChannel *
    const int ltp_end = ltp_mem + (nb_subfr - k_r) * subfr_length;
    if (snap_q) sq_tile_store(mown, &snap->nsq, ltp_mem, frame_length, ltp_end, kk);
    if (fin_q) {
-      if (low_q) sq_state_copy(&gc->nsq, &snap->nsq, ltp_mem, frame_length, kk);
-      else sq_tile_store(mown, &gc->nsq, ltp_mem, frame_length, ltp_end, kk);
+      if (low_q) sq_state_copy(&gt->nsq, &snap->nsq, ltp_mem, frame_length, kk);
+      else sq_tile_store(mown, &gt->nsq, ltp_mem, frame_length, ltp_end, kk);
       i32 *d = (i32 *)&gc->indices; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->ix;
       for (int i = kk; i < (int)(sizeof(OaSilkEncIndices) / 4); i += 4) d[i] = g[i];
-      d = (i32 *)gc->pulses; g = (const WV_LDS i32 *)me->pulses;
+      d = (i32 *)gt->pulses; g = (const WV_LDS i32 *)me->pulses;
       for (int i = kk; i < (frame_length + (frame_length & 15 ? 16 : 0)) / 4; i += 4) d[i] = g[i];      /* (+ the zeros silk_encode_pulses pads a frame that is not a multiple of 16 with) */
       if (kk == 0) { gc->LastGainIndex = me->LastGainIndex; gc->ec_prevLagIndex = me->ec_prevLagIndex; gc->ec_prevSignalType = me->ec_prevSignalType; }
    }
@@ -444,8 +454,10 @@ WV_DEV void sq_quant_tile_wave(WV_LDS SqLds *Q, OaShStream *streams, ShCont *con
       const bool has = j < nq;
       const ShQuantCh *job = &ct->q[has ? j : 0];
       OaSilkEncChannel *gc = &streams[sidx].silk.ch[has ? job->chan : 0];
+      OaSilkEncTail *gt = &streams[sidx].silk.tail[has ? job->chan : 0];
       wv_sync();
       if (has) sq_job_open(me, job, &ct->ec, j == 0, kk); else if (kk == 0) me->rc.done = 1;
+      if (has && job->nsq_reset) { i32 *z = (i32 *)&gt->nsq; for (int i = kk; i < (int)(sizeof(OaSilkNsqState) / 4); i += 4) z[i] = 0; }     /* the record too: the passes start from constants (sq_tile_load), the store at the end writes what a frame leaves */
       wv_sync();
       /* the rate-control loop of silk_encode_frame_FIX (:170-370), one lane (kk == 0) per stream; the loop itself is the wave's, a stream that has converged sits out */
       for (;;) {
@@ -459,13 +471,13 @@ WV_DEV void sq_quant_tile_wave(WV_LDS SqLds *Q, OaShStream *streams, ShCont *con
             const OaNsqCfg cfg = sq_cfg_ld(&Q->s[lead].cfg);
             const int same = need_q && sq_cfg_eq(sq_cfg_ld(&me->cfg), cfg);
             const int src = same ? qd : lead;
-            sq_nsq_pass(cfg, mown, ring, &Q->s[src], conts[first + src].q[j].x16, &gc->nsq, same, kk);
+            sq_nsq_pass(cfg, mown, ring, &Q->s[src], conts[first + src].q[j].x16, &gt->nsq, same, kk, me->rc.nsq_reset);
             pend &= ~wv_ballot(same);
          }
          if (kk == 0 && !me->rc.done) sq_rate_post(me, buf, snap);
          wv_sync();
          const int act = has && (me->rc.snap_now || me->rc.fin);
-         if (act) sq_store(me, mown, gc, snap, me->rc.snap_now, me->rc.fin, me->rc.use_lower, kk);
+         if (act) sq_store(me, mown, gc, gt, snap, me->rc.snap_now, me->rc.fin, me->rc.use_lower, kk);
          wv_sync();
          if (kk == 0 && has) { me->rc.snap_now = 0; me->rc.fin = 0; }
          wv_sync();

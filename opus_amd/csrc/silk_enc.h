@@ -193,7 +193,6 @@ WV_DEV void se_setup_resamplers(WV_LDS OaSilkEncChannel *c, int fs_kHz, WV_LDS S
    c->prev_API_fs_Hz = c->API_fs_Hz;
 }
 
-WV_DEV void se_nsq_reset(WV_LDS OaSilkNsqState *n) { WV_LDS i32 *w = (WV_LDS i32 *)n; for (int i = 0; i < (int)(sizeof(OaSilkNsqState) / 4); i++) w[i] = 0; }
 
 /* ---- silk_setup_fs (control_codec.c:198) ---- */
 WV_DEV void se_setup_fs(WV_LDS OaSilkEncChannel *c, int fs_kHz, int PacketSize_ms)
@@ -206,11 +205,11 @@ WV_DEV void se_setup_fs(WV_LDS OaSilkEncChannel *c, int fs_kHz, int PacketSize_m
    }
    if (c->fs_kHz != fs_kHz) {
       c->LastGainIndex = 0; c->HarmShapeGain_smth_Q16 = 0; c->Tilt_smth_Q16 = 0;
-      se_nsq_reset(&c->nsq);
+      c->nsq_reset_req = 1;                                                            /* (silk_nsq_state zeroed, lagPrev = 100, prev_gain_Q16 = 65536: applied by the quantiser stage, se_nsq_apply_reset_wave) */
       for (int i = 0; i < 16; i++) c->prev_NLSFq_Q15[i] = 0;
       c->lp_In_LP_State[0] = c->lp_In_LP_State[1] = 0;
       c->inputBufIx = 0; c->nFramesEncoded = 0; c->TargetRate_bps = 0;
-      c->prevLag = 100; c->first_frame_after_reset = 1; c->LastGainIndex = 10; c->nsq.lagPrev = 100; c->nsq.prev_gain_Q16 = 65536; c->prevSignalType = SE_TYPE_NO_VOICE;
+      c->prevLag = 100; c->first_frame_after_reset = 1; c->LastGainIndex = 10; c->prevSignalType = SE_TYPE_NO_VOICE;
       c->fs_kHz = fs_kHz;
       c->predictLPCOrder = (fs_kHz == 8 || fs_kHz == 12) ? 10 : 16;
       c->subfr_length = 5 * fs_kHz; c->frame_length = sk_mulbb(c->subfr_length, c->nb_subfr); c->ltp_mem_length = sk_mulbb(20, fs_kHz);

@@ -34,14 +34,35 @@ struct SeStereoLds { i16 side[322 + 6], LP_mid[320], HP_mid[320], LP_side[320], 
 struct SilkEncLds {
    SeEncCtrl ctl;
    SeRsLds rs;
-   i32 tmp_rs[99 + 1];
    i32 r[16];                                          /* lane-0 hand-off words */
-   i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM) */
+   i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM); the temporary resampler of a rate switch (se_setup_resamplers: 99 words) */
    union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; OaSilkLbrr lbrr; } u;
-   OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.ch[1] */
+   OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.tail[1], the split path's front kernel only up to st.ch[channels] */
 };
-#define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0))
-#define SE_STATE_WORDS(channels) ((int)((sizeof(OaSilkEnc) - ((channels) == 1 ? sizeof(OaSilkEncChannel) : 0)) / 4))
+#define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))
+#define SE_FRONT_LDS_BYTES(channels) (offsetof(SilkEncLds, st) + offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel))
+#define SE_STATE_LITE_WORDS(channels) ((int)((offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel)) / 4))
+#define SE_TAIL_WORDS ((int)(sizeof(OaSilkEncTail) / 4))
+#define SE_STATE_WORDS(channels) (SE_STATE_LITE_WORDS(channels) + (channels) * SE_TAIL_WORDS)       /* words a frame-step moves each way */
+/* the SILK state between the stream record and the wave's LDS (either direction): header + the channels in use, and their tails when the kernel holds them */
+template <class PD, class PS> WV_DEV void se_state_copy_wave(PD d, PS s, int channels, int with_tail)
+{
+   FOR_LANES(i, SE_STATE_LITE_WORDS(channels)) d[i] = s[i];
+   if (with_tail) { const int o = (int)(offsetof(OaSilkEnc, tail) / 4); FOR_LANES(i, channels * SE_TAIL_WORDS) d[o + i] = s[o + i]; }
+}
+WV_DEV WV_LDS OaSilkEncTail *se_tail(WV_LDS SilkEncLds *S, const WV_LDS OaSilkEncChannel *c) { return &S->st.tail[c == &S->st.ch[1] ? 1 : 0]; }
+/* the quantiser state starts over if someone asked for it since its last use (silk_setup_fs: control_codec.c:241-246; the side channel after mid-only frames: enc_API.c:449-456) */
+WV_DEV void se_nsq_apply_reset_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
+{
+   wv_sync();
+   if (wv_uni(c->nsq_reset_req)) {
+      WV_LDS OaSilkNsqState *n = &se_tail(S, c)->nsq; WV_LDS i32 *w = (WV_LDS i32 *)n;
+      FOR_LANES(i, (int)(sizeof(OaSilkNsqState) / 4)) w[i] = 0;
+      wv_sync();
+      LANE0 { n->lagPrev = 100; n->prev_gain_Q16 = 65536; c->nsq_reset_req = 0; }
+   }
+   wv_sync();
+}
 
 /* ---- silk_encode_indices; ix = the frame's own index set, or an LBRR one (encode_LBRR: the type offset is then always >= 2) ---- */
 /* C: anything with nb_subfr, predictLPCOrder, fs_kHz, ec_prevSignalType, ec_prevLagIndex (the channel state, or the quantiser kernel's per-stream record) */
@@ -341,7 +362,7 @@ WV_DEV void se_stereo_lr_to_ms_wave(WV_LDS OaSilkEncStereo *state, WV_LDS i16 *x
 
 /* ---- stage taps of the emulator build (same word layout as the tapped reference shim of the tests) ---- */
 #ifdef K_DUMP_ENABLED
-WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
+WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which, const WV_LDS i8 *tl_pulses = nullptr)
 {
    i32 w[330]; int n = 0;
    if (which == 0) {
@@ -377,13 +398,15 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which)
       K_DUMP("gains", w, 4 * n);
    } else {
       w[n++] = c->indices.Seed;
-      for (int i = 0; i < c->frame_length; i++) w[n++] = c->pulses[i];
+      for (int i = 0; i < c->frame_length; i++) w[n++] = tl_pulses[i];
       K_DUMP("nsq", w, 4 * n);
    }
 }
 #define SE_TAP(which) do { wv_sync(); if (wv_lane() == 0) se_tap(c, ctl, which); wv_sync(); } while (0)
+#define SE_TAP_Q(which, pulses) do { wv_sync(); if (wv_lane() == 0) se_tap(c, ctl, which, pulses); wv_sync(); } while (0)
 #else
 #define SE_TAP(which)
+#define SE_TAP_Q(which, pulses)
 #endif
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
@@ -433,13 +456,15 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
    const int bits_margin = useCBR ? 5 : maxBits / 4;
    const int NSQW = (int)(sizeof(OaSilkNsqState) / 4);
    WV_LDS SeQuantLds *Q = &S->u.q;
+   WV_LDS OaSilkEncTail *tl = se_tail(S, c);
+   se_nsq_apply_reset_wave(S, c);
    if (c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8)) {
       /* silk_LBRR_encode_FIX (:392): the same frame once more with raised gains -- the noise-shaping quantiser runs on the live state, which comes
        * back from its HBM snapshot afterwards; indices and pulses go to the stream's HBM store for the next packet */
       const int fi = c->nFramesEncoded, chn = c->channelNb;
       i32 TempGains_Q16[4];
       for (int k = 0; k < 4; k++) TempGains_Q16[k] = ctl->Gains_Q16[k];
-      se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+      se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&tl->nsq, NSQW);
       LANE0 {
          c->LBRR_flags[fi] = 1;
          { WV_LDS i32 *d = (WV_LDS i32 *)&Q->ix_lbrr; const WV_LDS i32 *sr = (const WV_LDS i32 *)&c->indices; for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) d[k] = sr[k]; }
@@ -453,12 +478,12 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
          for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = g[k];
          c->LBRRprevLastGainIndex = prev;
       }
-      if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
-      else se_nsq_wave(c, &c->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+      if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &tl->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
+      else se_nsq_wave(c, &tl->nsq, &Q->ix_lbrr, &Q->N, ctl, x_frame, Q->pulses_lbrr);
       wv_sync();
       FOR_LANES(i, c->frame_length) lb->pulses[chn][fi][i] = Q->pulses_lbrr[i];
       { const WV_LDS i32 *src = (const WV_LDS i32 *)&Q->ix_lbrr; i32 *dst = (i32 *)&lb->indices[chn][fi]; FOR_LANES(i, (int)(sizeof(OaSilkEncIndices) / 4)) dst[i] = src[i]; }
-      se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
+      se_copy_words_wave((WV_LDS i32 *)&tl->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
       LANE0 { for (int k = 0; k < c->nb_subfr; k++) ctl->Gains_Q16[k] = TempGains_Q16[k]; }
    }
    const int maxIter = 6;
@@ -468,7 +493,7 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
    int LastGainIndex_copy2 = 0;
    int gain_lock[4] = {0, 0, 0, 0}; i16 best_gain_mult[4] = {0, 0, 0, 0}; int best_sum[4] = {0, 0, 0, 0};
    ec_cp_lds(&Q->ec_copy, ecl);
-   se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&c->nsq, NSQW);
+   se_copy_words_wave((i32 *)&G->nsq_copy[0], (const WV_LDS i32 *)&tl->nsq, NSQW);
    const int seed_copy = c->indices.Seed, ec_prevLagIndex_copy = c->ec_prevLagIndex, ec_prevSignalType_copy = c->ec_prevSignalType;
    for (int iter = 0; ; iter++) {
       if (gainsID == gainsID_lower) nBits = nBits_lower;
@@ -477,18 +502,18 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
          if (iter > 0) {
             wv_sync();
             LANE0 { ec_cp_lds(ecl, &Q->ec_copy); c->indices.Seed = (i8)seed_copy; c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy; }
-            se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
+            se_copy_words_wave((WV_LDS i32 *)&tl->nsq, (const i32 *)&G->nsq_copy[0], NSQW);
          }
-         if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
-         else se_nsq_wave(c, &c->nsq, &c->indices, &Q->N, ctl, x_frame, c->pulses);
+         if (c->nStatesDelayedDecision > 1 || c->warping_Q16 > 0) se_nsq_del_dec_wave(c, &tl->nsq, &c->indices, &Q->N, ctl, x_frame, tl->pulses);
+         else se_nsq_wave(c, &tl->nsq, &c->indices, &Q->N, ctl, x_frame, tl->pulses);
          wv_sync();
-         SE_TAP(4);
+         SE_TAP_Q(4, tl->pulses);
          SE_PHASE(S, 7);
          LANE0 {
             if (iter == maxIter && !found_lower) ec_cp_lds(&Q->ec_copy2, ecl);
             EcCtx ec_; ec_ld(&ec_, ecl); EcCtx *e = &ec_;
             se_encode_indices(c, &c->indices, EC_PASS, condCoding);
-            se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
+            se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, tl->pulses, c->frame_length, S->stk);
             int nb = k_ec_tell(EC_PASS);
             if (iter == maxIter && !found_lower && nb > maxBits) {
                ec_ld(&ec_, &Q->ec_copy2);
@@ -496,9 +521,9 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
                for (int i = 0; i < c->nb_subfr; i++) c->indices.GainsIndices[i] = 4;
                if (condCoding != SE_CODE_CONDITIONALLY) c->indices.GainsIndices[0] = (i8)ctl->lastGainIndexPrev;
                c->ec_prevLagIndex = ec_prevLagIndex_copy; c->ec_prevSignalType = ec_prevSignalType_copy;
-               for (int i = 0; i < c->frame_length; i++) c->pulses[i] = 0;
+               for (int i = 0; i < c->frame_length; i++) tl->pulses[i] = 0;
                se_encode_indices(c, &c->indices, EC_PASS, condCoding);
-               se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, c->pulses, c->frame_length, S->stk);
+               se_encode_pulses(EC_PASS, c->indices.signalType, c->indices.quantOffsetType, tl->pulses, c->frame_length, S->stk);
                nb = k_ec_tell(EC_PASS);
             }
             ec_st(ecl, &ec_);
@@ -512,7 +537,7 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
          if (found_lower && (gainsID == gainsID_lower || nBits > maxBits)) {
             wv_sync();
             LANE0 { ec_cp_lds(ecl, &Q->ec_copy2); for (u32 i = 0; i < Q->ec_copy2.offs; i++) buf[i] = G->ec_buf_copy[i]; c->LastGainIndex = LastGainIndex_copy2; }
-            se_copy_words_wave((WV_LDS i32 *)&c->nsq, (const i32 *)&G->nsq_copy[1], NSQW);
+            se_copy_words_wave((WV_LDS i32 *)&tl->nsq, (const i32 *)&G->nsq_copy[1], NSQW);
          }
          break;
       }
@@ -525,14 +550,14 @@ WV_DEV void se_frame_quant_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c
             gainsID_lower = gainsID;
             wv_sync();
             LANE0 { ec_cp_lds(&Q->ec_copy2, ecl); for (u32 i = 0; i < ecl->offs; i++) G->ec_buf_copy[i] = buf[i]; }
-            se_copy_words_wave((i32 *)&G->nsq_copy[1], (const WV_LDS i32 *)&c->nsq, NSQW);
+            se_copy_words_wave((i32 *)&G->nsq_copy[1], (const WV_LDS i32 *)&tl->nsq, NSQW);
             LastGainIndex_copy2 = c->LastGainIndex;
          }
       } else break;
       if (!found_lower && nBits > maxBits) {
          for (int i = 0; i < c->nb_subfr; i++) {
             int sum = 0;
-            for (int j = i * c->subfr_length; j < (i + 1) * c->subfr_length; j++) sum += iabs((i32)c->pulses[j]);
+            for (int j = i * c->subfr_length; j < (i + 1) * c->subfr_length; j++) sum += iabs((i32)tl->pulses[j]);
             if (iter == 0 || (sum < best_sum[i] && !gain_lock[i])) { best_sum[i] = sum; best_gain_mult[i] = (i16)gainMult_Q8; } else gain_lock[i] = 1;
          }
       }
@@ -633,7 +658,7 @@ WV_DEV int se_call_prologue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int nSampl
    LANE0 {
       for (int n = 0; n < ec->nChannelsInternal; n++) {
          const int force_fs_kHz = n == 1 ? c0->fs_kHz : 0;
-         se_control_encoder(&E->ch[n], ec, E->allowBandwidthSwitch, n, force_fs_kHz, &S->rs, S->u.rs_tmp, S->tmp_rs);
+         se_control_encoder(&E->ch[n], ec, E->allowBandwidthSwitch, n, force_fs_kHz, &S->rs, S->u.rs_tmp, S->stk);
          if (E->ch[n].first_frame_after_reset || transition) for (int i = 0; i < c0->nFramesPerPacket; i++) E->ch[n].LBRR_flags[i] = 0;
          E->ch[n].inDTX = E->ch[n].useDTX;
       }
@@ -734,10 +759,10 @@ WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS 
          if (E->st.mid_only_flags[c0->nFramesEncoded] == 0) {
             if (E->prev_decode_only_middle == 1) {
                c1->LastGainIndex = 0; c1->HarmShapeGain_smth_Q16 = 0; c1->Tilt_smth_Q16 = 0;
-               se_nsq_reset(&c1->nsq);
+               c1->nsq_reset_req = 1;
                for (int i = 0; i < 16; i++) c1->prev_NLSFq_Q15[i] = 0;
                c1->lp_In_LP_State[0] = c1->lp_In_LP_State[1] = 0;
-               c1->prevLag = 100; c1->nsq.lagPrev = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->nsq.prev_gain_Q16 = 65536; c1->first_frame_after_reset = 1;
+               c1->prevLag = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->first_frame_after_reset = 1;
             }
             se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
          } else c1->VAD_flags[c0->nFramesEncoded] = 0;

@@ -39,13 +39,16 @@ struct OaSilkEncChannel {
    /* sShape + LTPCorr */
    int32_t LastGainIndex, HarmShapeGain_smth_Q16, Tilt_smth_Q16, LTPCorr_Q15;
    int32_t rs_cfg[9], rs_rows[90];
-   OaSilkNsqState nsq;
+   int32_t nsq_reset_req;                      /* the quantiser state (OaSilkEncTail) starts over before its next use: silk_setup_fs (control_codec.c:241) and the side channel's
+                                                * return after mid-only frames (enc_API.c:449) ask for it here, because the analysis kernel of the split path does not hold the tails */
    int16_t prev_NLSFq_Q15[16];
    int16_t inputBuf[SE_MAX_FRAME + 2];
    int16_t x_buf[SE_X_BUF_LEN];
    OaSilkEncIndices indices;
-   int8_t pulses[SE_MAX_FRAME];
 };
+/* what only the quantiser / entropy coder stage of a channel touches: behind both channels in the record, so that the stage in front of it (the split path's front kernel,
+ * opus_sh_split.h) stages {header, ch[0 .. C-1]} in LDS and nothing else */
+struct OaSilkEncTail { OaSilkNsqState nsq; int8_t pulses[SE_MAX_FRAME]; };
 
 struct OaSilkEncStereo {                       /* stereo_enc_state */
    int32_t pred_prev_Q13[2];
@@ -59,6 +62,7 @@ struct OaSilkEnc {                             /* silk_encoder */
    OaSilkEncStereo st;
    int32_t nBitsUsedLBRR, nBitsExceeded, nChannelsAPI, nChannelsInternal, nPrevChannelsInternal, timeSinceSwitchAllowed_ms, allowBandwidthSwitch, prev_decode_only_middle;
    OaSilkEncChannel ch[2];
+   OaSilkEncTail tail[2];
 };
 
 /* silk_EncControlStruct (silk/control.h:42-120): what the Opus layer hands to silk_Encode and reads back */

@@ -5,12 +5,14 @@ rank for its lifetime and a frame-step needs no data-path collective.  The only 
 (length, final range, payload) to the rank that owns the output — RCCL over xGMI when the tensors are on GPUs
 (torch.distributed backend "nccl"), gloo in the CPU tests.  Nothing here touches the codec itself.
 
-The payload travels compacted: every rank packs its packets back to back on the device (exclusive prefix sum of the lengths,
-one scatter — no dynamic shapes, so no host round trip for the packing itself), the fixed-size (length | final range) table
-is gathered with one collective, and the packed bytes follow with one point-to-point transfer per rank of exactly the bytes
-the packets hold (~320 B per 128 kb/s frame instead of the 1,280 B slot: 21 MB instead of 84 MB per rank per step at 65,536
-streams).  The byte count has to be known on the host to size that transfer; reading it is the one synchronisation point of
-a step, and it waits for nothing that the transfer would not have had to wait for (the encode of that step).
+The payload travels compacted and the step never waits for the host: every rank packs its packets back to back on the
+device (exclusive prefix sum of the lengths, one scatter) into a wire record of FIXED size -- [lengths | final ranges |
+packed bytes up to a capacity derived from the bitrate bound] -- so the transfer size is known without reading a byte
+count back.  One `gather` collective per step moves the records of all ranks to dst at once (RCCL: every peer over its
+own xGMI link in parallel), issued on a side stream behind an event recorded after the pack, into double-buffered
+records: the gather of step t runs while the encoder of step t+1 does, and a record is reused only after the gather
+that read it has completed (stream-side wait, no host synchronisation).  A step whose packets exceed the capacity is
+flagged in the record (`stats()["overflow"]`), never silently truncated into a valid-looking result.
 """
 import torch
 import torch.distributed as dist
@@ -37,18 +39,21 @@ def owner_of(stream, total_streams, world):
 
 
 def pack_packets(lens, out, packed):
-    """Packs out[s, :lens[s]] back to back into `packed` (capacity >= n * stride + 1 bytes, last byte = spill slot).  Device-side,
-    static shapes: bytes beyond a packet's length are scattered to the spill slot.  Returns the exclusive prefix sum of the lengths."""
+    """Packs out[s, :lens[s]] back to back into `packed` (last byte = spill slot).  Device-side, static shapes: bytes beyond a packet's
+    length -- and, when `packed` is smaller than n * stride + 1, bytes beyond its capacity -- are scattered to the spill slot.  Returns the
+    exclusive prefix sum of the lengths."""
     n, stride = out.shape
     l = lens.clamp(min=0).to(torch.int64)
     offs = torch.cumsum(l, 0) - l
-    if out.is_cuda:                                                     # one wave per packet, coalesced byte copies (opusgpu_pack_packets_dev, opus_amd.hip)
+    if out.is_cuda:                                                     # one wave per packet, coalesced byte copies (opusgpu_pack_packets_cap_dev, opus_amd.hip)
         from . import lib
-        r = lib().opusgpu_pack_packets_dev(out.data_ptr(), stride, lens.data_ptr(), offs.data_ptr(), packed.data_ptr(), n, torch.cuda.current_stream(out.device).cuda_stream)
-        if r != 0: raise RuntimeError("opusgpu_pack_packets_dev failed: %d" % r)
+        r = lib().opusgpu_pack_packets_cap_dev(out.data_ptr(), stride, lens.data_ptr(), offs.data_ptr(), packed.data_ptr(), n, packed.numel() - 1, torch.cuda.current_stream(out.device).cuda_stream)
+        if r != 0: raise RuntimeError("opusgpu_pack_packets_cap_dev failed: %d" % r)
         return offs
     col = torch.arange(stride, device=out.device, dtype=torch.int64)
-    idx = torch.where(col[None, :] < l[:, None], offs[:, None] + col[None, :], torch.full((), packed.numel() - 1, device=out.device, dtype=torch.int64))
+    spill = packed.numel() - 1
+    idx = offs[:, None] + col[None, :]
+    idx = torch.where((col[None, :] < l[:, None]) & (idx < spill), idx, torch.full((), spill, device=out.device, dtype=torch.int64))
     packed.scatter_(0, idx.reshape(-1), out.reshape(-1))
     return offs
 
@@ -64,67 +69,129 @@ def unpack_packets(lens, packed, stride):
 
 
 class PacketGather:
-    """Final gather of one frame-step's packets to `dst`.
+    """Final gather of a frame-step's packets to `dst`, pipelined behind the next step's encode.
 
     Every rank passes its shard's lens [s_r] int32, final_range [s_r] int32 and out [s_r, stride] uint8; ragged shards
-    (total % world != 0) are padded to the largest shard for the table collective and trimmed on `dst`.  Buffers are
-    allocated once and reused every step."""
+    (total % world != 0) are padded to the largest shard in the wire record and trimmed on `dst`.  `cap_per_stream`
+    (default: stride, which can never overflow) sizes the packed part of the record: smax * cap_per_stream bytes.
 
-    def __init__(self, total_streams, stride, device, dst=0, group=None):
-        self.total, self.stride, self.dst, self.group, self.device = total_streams, stride, dst, group, device
+        g.launch(lens, rng, out)   enqueue the exchange of one step (returns at once; at most `depth` steps in flight)
+        g.flush()                  make the current stream (host, for CPU tensors) wait for every exchange enqueued so far
+        g(lens, rng, out)          launch + flush + re-assembly on dst: (lens, final_range, out) of ALL streams, None elsewhere
+    """
+
+    def __init__(self, total_streams, stride, device, dst=0, group=None, cap_per_stream=None, depth=2):
+        self.total, self.stride, self.dst, self.group, self.device = total_streams, stride, dst, group, torch.device(device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi = shard_range(total_streams, self.rank, self.world)
         self.sizes = [shard_range(total_streams, r, self.world) for r in range(self.world)]
         self.smax = max(hi - lo for lo, hi in self.sizes)
-        n = self.hi - self.lo
-        # collectives on device tensors need a backend that moves them (nccl = RCCL); with gloo (tests) everything is staged through host memory
-        self.stage_cpu = dist.is_initialized() and dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
-        cdev = torch.device("cpu") if self.stage_cpu else device
+        self.cap = min(stride, int(cap_per_stream)) if cap_per_stream else stride
+        self.depth = depth
+        self.on_gpu = self.device.type == "cuda"
+        # collectives on device tensors need a backend that moves them (nccl = RCCL); with gloo (tests) the record is staged through pinned host memory
+        self.stage_cpu = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.on_gpu
+        self.meta_bytes = self.smax * 8
+        self.wire_bytes = self.meta_bytes + self.smax * self.cap + 8                                    # [lens int32 | final ranges int32 | packed bytes | spill slot + pad]
+        self.wire_bytes = (self.wire_bytes + 15) & ~15
+        self._wire = [torch.zeros(self.wire_bytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        cdev = torch.device("cpu") if self.stage_cpu else self.device
         self.cdev = cdev
-        self._meta = torch.zeros((self.smax, 2), dtype=torch.int32, device=cdev)
-        self._packed = torch.zeros(n * stride + 1, dtype=torch.uint8, device=device)
-        self._recv_meta = [torch.empty((self.smax, 2), dtype=torch.int32, device=cdev) for _ in range(self.world)] if (self.world > 1 and self.rank == dst) else None
-        self._recv_bytes = [torch.empty((hi - lo) * stride + 1, dtype=torch.uint8, device=cdev) for lo, hi in self.sizes] if (self.world > 1 and self.rank == dst) else None
-        self.last_bytes = 0
+        self._host = [torch.zeros(self.wire_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)] if self.stage_cpu else None
+        is_dst = self.world > 1 and self.rank == dst
+        self._recv = [[torch.zeros(self.wire_bytes, dtype=torch.uint8, device=cdev) for _ in range(self.world)] for _ in range(depth)] if is_dst else None
+        self._side = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self._packed_ev = [torch.cuda.Event() for _ in range(depth)] if self.on_gpu else None
+        self._done_ev = [None] * depth                                                                # GPU: event on the side stream after the gather of that slot
+        self._work = [None] * depth                                                                   # CPU / staged: the outstanding gloo work of that slot
+        self._staged = [False] * depth                                                                # staged: the device->host copy of that slot is enqueued, its gather is not
+        self.steps = 0
+        self.last_slot = None
+
+    # -- slot lifecycle --
+    def _issue_staged(self, slot):
+        if self._staged[slot]:
+            self._packed_ev[slot].synchronize()                                                       # the copy into pinned memory (long finished when this is called a step later)
+            self._work[slot] = dist.gather(self._host[slot], self._recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+            self._staged[slot] = False
+
+    def _retire(self, slot):
+        """the slot's previous exchange has completed before anything overwrites its record"""
+        if self.on_gpu and not self.stage_cpu:
+            if self._done_ev[slot] is not None: torch.cuda.current_stream(self.device).wait_event(self._done_ev[slot])
+        else:
+            if self.stage_cpu: self._issue_staged(slot)
+            if self._work[slot] is not None: self._work[slot].wait(); self._work[slot] = None
 
     def launch(self, lens, final_range, out):
-        """The exchange of one step (no re-assembly on dst): what bench.py puts inside the timed region.  Returns the per-rank byte counts on dst."""
+        """Enqueue the exchange of one step."""
         n = self.hi - self.lo
         if lens.shape[0] != n or out.shape != (n, self.stride):
             raise ValueError("shard shape mismatch")
         if self.world == 1:
             return None
-        pack_packets(lens, out, self._packed)
-        meta = torch.stack([lens, final_range], 1)
-        self._meta[:n].copy_(meta)
-        dist.gather(self._meta, self._recv_meta, dst=self.dst, group=self.group)
-        nbytes = int(lens.clamp(min=0).sum().item())                       # the one host read of the step
-        self.last_bytes = nbytes
-        if self.rank != self.dst:
-            if nbytes:
-                buf = self._packed[:nbytes]
-                dist.send(buf.cpu() if self.stage_cpu else buf, self.dst, group=self.group)
-            return None
-        counts = [int(self._recv_meta[r][:hi - lo, 0].clamp(min=0).sum().item()) for r, (lo, hi) in enumerate(self.sizes)]
-        for r in range(self.world):
-            if r == self.dst:
-                continue
-            if counts[r]:
-                dist.recv(self._recv_bytes[r][:counts[r]], r, group=self.group)
-        return counts
+        slot = self.steps % self.depth
+        self._retire(slot)
+        w = self._wire[slot]
+        meta = w[:self.meta_bytes].view(torch.int32).view(2, self.smax)
+        meta[0, :n].copy_(lens); meta[1, :n].copy_(final_range)
+        pack_packets(lens, out, w[self.meta_bytes:self.meta_bytes + self.smax * self.cap + 1])
+        if self.on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            ev = self._packed_ev[slot]
+            if self.stage_cpu:
+                ev0 = torch.cuda.Event(); ev0.record(cur)
+                self._side.wait_event(ev0)
+                with torch.cuda.stream(self._side):
+                    self._host[slot].copy_(w, non_blocking=True)
+                    ev.record(self._side)
+                self._staged[slot] = True
+                prev = (self.steps - 1) % self.depth                                                  # the host part of the PREVIOUS step's exchange runs now, under this step's encode
+                if self.steps > 0 and prev != slot: self._issue_staged(prev)
+            else:
+                ev.record(cur)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    work = dist.gather(w, self._recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+                    work.wait()                                                                       # stream-side: the side stream waits for RCCL, the host does not
+                    d = torch.cuda.Event(); d.record(self._side); self._done_ev[slot] = d
+        else:
+            self._work[slot] = dist.gather(w, self._recv[slot] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        self.last_slot = slot
+        self.steps += 1
+        return None
+
+    def flush(self):
+        if self.world == 1: return
+        for slot in range(self.depth): self._retire(slot)
+
+    def stats(self):
+        """figures of the exchange for the bench line (reads the overflow flags back: call it after the timed region)"""
+        over = False
+        if self.world > 1:
+            self.flush()
+            if self.on_gpu: torch.cuda.current_stream(self.device).synchronize()
+            n = self.hi - self.lo
+            for w in self._wire:
+                over = over or int(w[:self.meta_bytes].view(torch.int32).view(2, self.smax)[0, :n].clamp(min=0).sum().item()) > self.smax * self.cap
+        return {"steps": self.steps, "wire_bytes_per_rank_per_step": self.wire_bytes, "cap_bytes_per_stream": self.cap, "slot_bytes_per_stream": self.stride, "overflow": bool(over), "in_flight": self.depth,
+                "transport": "gloo, staged through pinned host memory (test hook)" if self.stage_cpu else ("RCCL gather on a side stream" if self.on_gpu else "gloo")}
 
     def __call__(self, lens, final_range, out):
         """Returns (lens, final_range, out) for ALL streams on dst (re-assembled [total, stride] slots), None elsewhere."""
         if self.world == 1:
             return lens, final_range, out
-        counts = self.launch(lens, final_range, out)
+        self.launch(lens, final_range, out)
+        self.flush()
         if self.rank != self.dst:
             return None
+        if self.on_gpu and not self.stage_cpu: torch.cuda.current_stream(self.device).synchronize()
         ls, rs, os_ = [], [], []
         for r, (lo, hi) in enumerate(self.sizes):
-            m = self._recv_meta[r][:hi - lo]
-            l = m[:, 0].contiguous(); ls.append(l); rs.append(m[:, 1].contiguous())
-            src = (self._packed.to(self.cdev) if self.stage_cpu else self._packed) if r == self.dst else self._recv_bytes[r]
-            os_.append(unpack_packets(l, src, self.stride))
+            w = self._recv[self.last_slot][r]
+            meta = w[:self.meta_bytes].view(torch.int32).view(2, self.smax)
+            l = meta[0, :hi - lo].contiguous(); ls.append(l); rs.append(meta[1, :hi - lo].contiguous())
+            if int(l.clamp(min=0).sum().item()) > self.smax * self.cap: raise OverflowError("rank %d's packets exceed the wire record's capacity (%d bytes per stream): raise cap_per_stream" % (r, self.cap))
+            os_.append(unpack_packets(l, w[self.meta_bytes:], self.stride))
         return torch.cat(ls), torch.cat(rs), torch.cat(os_)

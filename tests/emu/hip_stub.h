@@ -69,13 +69,18 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 
 static void emu_launch_tramp(void *p) { (*(std::function<void()> *)p)(); }
-static inline void emu_launch(dim3 grid, std::function<void()> body)
+/* lds = the launch's dynamic LDS size: on the GPU an access beyond it is dropped / reads zero without any fault, so the bytes behind it are watched here -- a kernel that
+ * writes there (a struct member outside the part of the layout the launch allocated) aborts the test instead of passing on the emulator and failing on the device */
+static inline void emu_launch(dim3 grid, size_t lds, const char *name, std::function<void()> body)
 {
+   const size_t guard = 8192;
    for (unsigned b = 0; b < grid.x; b++) {
       emu_block_x = b;
       memset(smem, emu_fill_byte(), 65536);                         /* LDS is uninitialised on the GPU: make stale reads loud */
+      if (lds + guard > 65536) memset(smem + 65536, emu_fill_byte(), lds + guard - 65536);
       emu_run_wave(emu_launch_tramp, &body);
+      for (size_t i = lds; i < lds + guard; i++) if ((unsigned char)smem[i] != (unsigned char)emu_fill_byte()) { fprintf(stderr, "wave_emu: kernel %s wrote LDS byte %zu, beyond its dynamic allocation of %zu bytes\n", name, i, lds); abort(); }
    }
 }
-#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu_launch((grid), [&]() { kern(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu_launch((grid), (size_t)(lds), #kern, [&]() { kern(__VA_ARGS__); })
 #endif

@@ -13,15 +13,43 @@ def _last_json(txt):
         if line.startswith("{"): return json.loads(line)
     raise AssertionError(txt[-2000:])
 
-def test_bench_two_ranks_one_gpu():
-    env = dict(os.environ, OPUS_AMD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "2048"]
+def _run_ranks(n, extra, backend):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend: env["OPUS_AMD_BENCH_BACKEND"] = backend
+    else: env.pop("OPUS_AMD_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + extra
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
-    r = _last_json(p.stdout.decode(errors="replace"))
-    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["value"] > 0
-    assert r["config"]["frames_per_step"] == 2 * 2048 and r["config"]["all_packets_valid"]
+    return _last_json(p.stdout.decode(errors="replace"))
+
+def _check_ranks(r, n, S, K):
+    assert r["n_gpus"] == n and r["steps"] == K and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["frames_per_step"] == n * S and r["config"]["all_packets_valid"]
+    assert r["ranks_seen"] == n and sorted(x["rank"] for x in r["per_rank"]) == list(range(n)) and all(x["ms_per_step"] > 0 for x in r["per_rank"])
+
+def test_bench_two_ranks_one_gpu():
+    """the N > 1 path end to end on one GPU (gloo stands in for RCCL), with and without the final gather: the gather of step t is issued on a side stream / from the host
+    while step t + 1 encodes, so it must not show in the step time beyond noise (two processes time-slice ONE GPU here, hence the generous bound)"""
+    S, K = 4096, 6
+    r = _run_ranks(2, ["--steps", str(K), "--warmup", "2", "--streams", str(S)], "gloo")
+    _check_ranks(r, 2, S, K)
+    g = r["gather"]
+    assert g["steps"] == K + 2 and not g["overflow"] and g["cap_bytes_per_stream"] < g["slot_bytes_per_stream"]
+    r0 = _run_ranks(2, ["--steps", str(K), "--warmup", "2", "--streams", str(S), "--no-gather"], "gloo")
+    _check_ranks(r0, 2, S, K)
+    assert "gather" not in r0
+    print("ms_per_step with the gather %.3f, without %.3f" % (r["ms_per_step"], r0["ms_per_step"]))
+    assert r["ms_per_step"] < 1.5 * r0["ms_per_step"] + 2.0
+
+def test_bench_two_ranks_rccl():
+    """two ranks, two GPUs, RCCL: only where the box has them (the driver's scaling run is the real measurement)"""
+    import torch
+    if torch.cuda.device_count() < 2: pytest.skip("one GPU on this box")
+    S, K = 8192, 4
+    r = _run_ranks(2, ["--steps", str(K), "--warmup", "2", "--streams", str(S)], None)
+    _check_ranks(r, 2, S, K)
+    assert sorted(x["device"] for x in r["per_rank"]) == [0, 1] and not r["gather"]["overflow"] and r["gather"]["transport"].startswith("RCCL")
 
 def test_bench_single_rank_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--streams", "4096", "--no-extra-configs", "--frames-per-launch", "3"],
@@ -32,4 +60,16 @@ def test_bench_single_rank_contract():
         assert k in r, k
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["peak_measured"] > 1000
     assert r["cpu_baseline"]["kind"] == "reference" and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["host_nproc"] >= 1
-    assert r["frames_per_launch"]["T"] == 3 and r["frames_per_launch"]["frames_per_s"] > 0
+    assert r["frames_per_launch"]["T"] == 3 and r["frames_per_launch"]["frames_per_s"] > 0 and r["frames_per_launch"]["equals_step_by_step"]
+    assert r["config"]["parity_sample_ok"] is True and r["config"]["parity_sample"]["frames"] == 64 * 4 and r["config"]["lib_matches_sources"] is True
+
+def test_bench_default_line_has_every_configuration():
+    """the default N = 1 line (what the driver records) at a reduced stream count: configs 3 / 4 / 5 and the decoder legs, each with value, roofline and parity sample"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--streams", "4096", "--frames-per-launch", "6"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    r = _last_json(p.stdout.decode(errors="replace"))
+    assert set(r["configs"]) == {"decode_2", "config_3", "decode_3", "config_4", "decode_4", "config_5"}
+    for k, e in r["configs"].items():
+        assert e["value"] > 0 and e["all_packets_valid"] and e["roofline"]["kernel_ms"] > 0, k
+        if k != "config_5": assert e["parity_sample_ok"] is True and e["cpu_baseline"]["value"] > 0, k

@@ -100,3 +100,24 @@ def test_projection_float_entry_points():
             n = L.opus_projection_encode_float(e, x.ctypes.data, frame, buf, 20000); pk.append(bytes(buf[:max(n, 0)]) if n > 0 else n)
         L.opus_projection_encoder_destroy(e); res.append(pk)
     assert res[0] == res[1]
+
+def test_projection_encode24_at_complexity_10():
+    """opus_projection_encode24 with the tonality analysis on (complexity 10): the reference hands its int32 input to the analysis through downmix_int -- the int16 reader --
+    and codes at MAX_ENCODING_DEPTH (src/opus_projection_encoder.c:408-415); a drop-in produces the same packets"""
+    R, E = capi.load("ref_fxa"), capi.load(WHICH)
+    nch, frame = 4, 960
+    sig = _signal(nch, frame * 10, 11).astype(np.int32) << 8               # 24-bit samples
+    sig[frame * 4:frame * 5] //= 4096                                        # a very quiet frame: the depth handed to CELT's dynalloc noise floor matters there
+    res = []
+    for L in (R, E):
+        e, err, s, c = _enc(L, 48000, nch, 2049); assert e and err == 0
+        L.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]
+        assert L.opus_projection_encoder_ctl(e, 4010, 10) == 0 and L.opus_projection_encoder_ctl(e, 4002, 4 * 48000) == 0
+        L.opus_projection_encode24.argtypes = [vp, vp, ci, vp, ci]
+        buf = (ctypes.c_ubyte * 20000)(); pk = []
+        for i in range(10):
+            x = np.ascontiguousarray(sig[i * frame:(i + 1) * frame])
+            n = L.opus_projection_encode24(e, x.ctypes.data, frame, buf, 20000); pk.append(bytes(buf[:max(n, 0)]) if n > 0 else n)
+        L.opus_projection_encoder_destroy(e); res.append(pk)
+    assert all(isinstance(p, bytes) and len(p) > 8 for p in res[0])
+    assert res[0] == res[1]

@@ -68,13 +68,13 @@ def _worker(rank, world, port, total, nframes, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [5, 4])          # ragged (3+2) and even shards
-def test_two_rank_gather_equals_unsharded(total):
+@pytest.mark.parametrize("total,world", [(5, 2), (4, 2), (7, 4)])          # ragged (3+2), even, and four ranks ragged (2+2+2+1)
+def test_gather_equals_unsharded(total, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     nframes = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, nframes, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, nframes, q)) for r in range(world)]
     for p in procs: p.start()
     got = q.get(timeout=240)
     for p in procs:
@@ -84,3 +84,70 @@ def test_two_rank_gather_equals_unsharded(total):
     for (gl, gr, go), (wl, wr, wo) in zip(got, want):
         assert (gl == wl.numpy()).all() and (gr == wr.numpy()).all() and (go == wo.numpy()).all()
         assert (gl > 2).all()
+
+
+def _synthetic_steps(lo, hi, nsteps, seed=5):
+    """deterministic pseudo-packets (any bytes will do for the transport): step t, global stream s -> length and payload derived from (t, s)"""
+    steps = []
+    for t in range(nsteps):
+        n = hi - lo
+        lens = torch.zeros(n, dtype=torch.int32); rng = torch.zeros(n, dtype=torch.int32); out = torch.zeros((n, STRIDE), dtype=torch.uint8)
+        for k in range(n):
+            s = lo + k
+            g = torch.Generator(); g.manual_seed(seed * 1000003 + t * 4099 + s)
+            ln = int(torch.randint(3, 700, (1,), generator=g))
+            lens[k] = ln; rng[k] = int(torch.randint(-2**31, 2**31 - 1, (1,), generator=g, dtype=torch.int64))
+            out[k, :ln] = torch.randint(0, 256, (ln,), generator=g, dtype=torch.uint8)
+        steps.append((lens, rng, out))
+    return steps
+
+
+def _pipeline_worker(rank, world, port, total, nsteps, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PacketGather(total, STRIDE, torch.device("cpu"), dst=0, cap_per_stream=cap, depth=2)
+        steps = _synthetic_steps(g.lo, g.hi, nsteps)
+        got = []
+        # two steps in flight: launch t and t + 1, then flush and read both records (what bench.py does, minus the encoder in between)
+        for t in range(0, nsteps, 2):
+            slots = []
+            for u in (t, t + 1):
+                if u < nsteps:
+                    g.launch(*steps[u]); slots.append(g.last_slot)
+            g.flush()
+            if rank == 0:
+                for slot in slots:
+                    ls, rs, os_ = [], [], []
+                    for r, (lo, hi) in enumerate(g.sizes):
+                        w = g._recv[slot][r]
+                        meta = w[:g.meta_bytes].view(torch.int32).view(2, g.smax)
+                        l = meta[0, :hi - lo].contiguous(); ls.append(l.clone()); rs.append(meta[1, :hi - lo].clone())
+                        from opus_amd.shard import unpack_packets
+                        os_.append(unpack_packets(l, w[g.meta_bytes:], STRIDE) if int(l.sum()) <= g.smax * g.cap else torch.zeros((hi - lo, STRIDE), dtype=torch.uint8))
+                    got.append((torch.cat(ls).numpy(), torch.cat(rs).numpy(), torch.cat(os_).numpy()))
+        st = g.stats()
+        if rank == 0: q.put((got, st))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cap,expect_overflow", [(None, False), (760, False), (200, True)])
+def test_pipelined_gather_two_steps_in_flight(cap, expect_overflow):
+    """launch / launch / flush with double-buffered fixed-size records; a capacity from a bitrate bound that holds (760 B per stream for lengths < 700) is exact, one
+    that does not (200) is reported as overflow instead of passing for a result"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    total, world, nsteps = 11, 3, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, total, nsteps, cap, q)) for r in range(world)]
+    for p in procs: p.start()
+    got, st = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert st["steps"] == nsteps and st["overflow"] == expect_overflow
+    want = _synthetic_steps(0, total, nsteps)
+    for (gl, gr, go), (wl, wr, wo) in zip(got, want):
+        assert (gl == wl.numpy()).all() and (gr == wr.numpy()).all()
+        if not expect_overflow: assert (go == wo.numpy()).all()

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=$1; shift
 O=gpurun_out/r04_$TAG; mkdir -p $O
 export TMPDIR=/tmp
-B="--steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs"
+B="--steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs $BENCH_EXTRA"
 for step in "$@"; do
 case $step in
 smoke) python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 ;;
@@ -13,13 +13,17 @@ split_check) timeout 900 python tools/split_check.py gpu > $O/split_check.log 2>
 silkenc) timeout 1200 python -m pytest tests/test_gpu_silkenc.py -x -q > $O/pytest_silkenc.log 2>&1 ;;
 classic) timeout 1200 python -m pytest tests/test_gpu_classic_api.py -x -q > $O/pytest_classic.log 2>&1 ;;
 bench2) timeout 300 python bench.py $B > $O/bench2.log 2>&1 ;;
-bench3) for m in 0 1; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 3 > $O/bench3_split$m.log 2>&1; done ;;
-bench4) for m in 0 1; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 4 > $O/bench4_split$m.log 2>&1; done ;;
+pool) for c in 2 3 4; do timeout 300 python bench.py $B --config $c --corpus pool > $O/bench${c}_pool.log 2>&1; done ;;
+bench3) for m in ${SPLIT_MODES:-0 1}; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 3 > $O/bench3_split$m.log 2>&1; done ;;
+bench4) for m in ${SPLIT_MODES:-0 1}; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 4 > $O/bench4_split$m.log 2>&1; done ;;
 bench5) timeout 300 python bench.py $B --config 5 > $O/bench5.log 2>&1 ;;
 decode) for c in 2 3 4; do timeout 300 python bench.py $B --config $c --decode > $O/decode$c.log 2>&1; done ;;
 bench_default) timeout 900 python bench.py > $O/bench_default.log 2>&1 ;;
 prof2|prof3|prof4) c=${step#prof}; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete ;;
 pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc$c > $O/pmc$c.log 2>&1 ;;
+exp_occ) for pad in 0 20000 60000; do OPUS_AMD_SH_LDS_PAD=$pad timeout 300 python bench.py $B --config 3 > $O/bench3_pad$pad.log 2>&1; done ;;
+exp_lib) for f in $EXP_LIBS; do for c in $EXP_CONFIGS; do OPUS_AMD_LIB=$PWD/opus_amd/$f timeout 300 python bench.py $B --config $c > $O/bench${c}_$f.log 2>&1; done; done ;;
+ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
 full) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1 ;;
 *) echo "unknown step $step" ;;
 esac
