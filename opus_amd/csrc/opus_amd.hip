@@ -487,7 +487,10 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    /* the front kernel holds the SILK state without the quantiser tails; the arena behind the head must also hold the tonality analysis' working set */
    size_t lds_front = SH_FRONT_LDS_BYTES(ch) + lds_pad;
    if (lds_front < offsetof(ShLds, S) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + sizeof(AnLds);
-   const size_t lds_back = offsetof(ShLds, S) + (silk_only ? 256 : sizeof(FrameLds));
+   /* the back kernel enters the CELT arena for hybrid frames AND for the redundant CELT frame that announces a SILK bandwidth switch (opus_encoder.c:2251-2260), which a
+    * stream pinned to SILK-only can still ask for: only RESTRICTED_SILK never does */
+   const size_t lds_back = offsetof(ShLds, S) + (b->application == OPUS_APPLICATION_RESTRICTED_SILK ? 256 : sizeof(FrameLds));
+   (void)silk_only;
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
    const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
    int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0;
@@ -869,6 +872,11 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
          }
       }
    }
+   else if (request == 10015 /* CELT_GET_MODE (celt/celt.h; the reference's multistream code asks its elementary encoders for it): an opaque handle here */) {
+      const void **p = va_arg(ap, const void **);
+      static const int oa_mode48000_960 = 0;
+      if (!p) ret = OPUS_BAD_ARG; else { *p = &oa_mode48000_960; ret = OPUS_OK; }
+   }
    else if (request & 1) { opus_int32 *p = va_arg(ap, opus_int32 *); ret = st->kind ? sh_ctl_get(&st->sh, request, p) : oa_ctl_get(&st->s, request, p); }   /* GET requests are odd */
    else { opus_int32 v = va_arg(ap, opus_int32); ret = st->kind ? sh_ctl_set(&st->sh, request, v) : oa_ctl_set(&st->s, request, v); }
    va_end(ap);
@@ -1244,8 +1252,11 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
    } break;
    case OPUS_SET_GAIN_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < -32768 || v > 32767) ret = OPUS_BAD_ARG; else st->decode_gain = v; } break;
    case OPUS_GET_GAIN_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->decode_gain; } break;
-   case OPUS_SET_COMPLEXITY_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 10) ret = OPUS_BAD_ARG; else st->pad[0] = v; } break;   /* decoder complexity only gates the DNN options (:1041) */
-   case OPUS_GET_COMPLEXITY_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->pad[0]; } break;
+   case OPUS_SET_COMPLEXITY_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 10) ret = OPUS_BAD_ARG; else st->pad[0] = (st->pad[0] & ~0xff) | v; } break;   /* decoder complexity only gates the DNN options (:1041) */
+   case OPUS_GET_COMPLEXITY_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->pad[0] & 0xff; } break;
+   /* OPUS_SET / GET_IGNORE_EXTENSIONS (:1199-1217): stored (bit 8 of the word the complexity lives in) and read back; this decoder never looks at the extensions in a packet's padding either way */
+   case 4058: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else st->pad[0] = (st->pad[0] & ~0x100) | (v << 8); } break;
+   case 4059: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = (st->pad[0] >> 8) & 1; } break;
    case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 v = va_arg(ap, opus_int32); if (v < 0 || v > 1) ret = OPUS_BAD_ARG; else st->s.s.disable_inv = v; } break;
    case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->s.s.disable_inv; } break;
    default: ret = OPUS_UNIMPLEMENTED;

@@ -92,7 +92,7 @@ typedef OpusEncoder OaMsRec;                 /* a complete classic encoder objec
 struct OpusMSEncoder {
    opus_uint32 magic; opus_int32 Fs, application, bitrate_bps, mapping_type, lfe_stream;
    OaLayout layout;
-   opus_int32 kind, pad;           /* kind 1: records are OaShStream */
+   opus_int32 kind, variable_duration;   /* kind 1: records are OaShStream; OPUS_SET_EXPERT_FRAME_DURATION of the multistream encoder itself (opus_multistream_encoder.c:483, :888) */
    OaMsRec streams[1];             /* nb_streams records: coupled streams first, then mono (flat, memcpy-able) */
 };
 static int oa_ms_rec_init(OaMsRec *r, int kind, opus_int32 Fs, int ch, int application) { (void)kind; return opus_encoder_init(r, Fs, ch, application); }
@@ -132,7 +132,7 @@ static int oa_ms_encoder_init_impl(OpusMSEncoder *st, opus_int32 Fs, int channel
    { OaMsRec *probe = new OaMsRec; r = oa_ms_rec_init(probe, kind, Fs, 2, application); delete probe; }
    if (r != OPUS_OK) return r;
    memset(st, 0, sizeof(OpusMSEncoder) - sizeof(OaMsRec));
-   st->kind = kind;
+   st->kind = kind; st->variable_duration = OPUS_FRAMESIZE_ARG;
    st->magic = OA_MS_MAGIC; st->Fs = Fs; st->application = application; st->bitrate_bps = OPUS_AUTO; st->mapping_type = mapping_type; st->lfe_stream = lfe_stream;
    st->layout.nb_channels = channels; st->layout.nb_streams = streams; st->layout.nb_coupled_streams = coupled_streams;
    for (int i = 0; i < channels; i++) st->layout.mapping[i] = mapping[i];
@@ -282,7 +282,7 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
    const opus_int32 Fs = st->Fs;
    const int ns = st->layout.nb_streams, nc = st->layout.nb_coupled_streams, nm = ns - nc, nch = st->layout.nb_channels;
    const int kind = st->kind;
-   const int frame_size = (int)oa_frame_size_select(st->application, analysis_frame_size, kind ? st->streams[0].sh.cfg.variable_duration : st->streams[0].s.cfg.variable_duration, Fs);
+   const int frame_size = st->variable_duration == 0 ? -1 : (int)oa_frame_size_select(st->application, analysis_frame_size, st->variable_duration, Fs);   /* (0 is no legal value: frame_size_select, opus_encoder.c:827-849) */
    if (frame_size <= 0) return OPUS_BAD_ARG;
    for (int s = 0; s < ns; s++) { if (kind) st->streams[s].sh.cfg.input_depth = depth; else st->streams[s].s.cfg.input_depth = depth; }
    const int vbr = kind ? st->streams[0].sh.cfg.use_vbr : st->streams[0].s.cfg.use_vbr;
@@ -431,14 +431,34 @@ static int oa_ms_encoder_ctl_va(OpusMSEncoder *st, int request, va_list ap)
       if (id < 0 || id >= ns || !value) { ret = OPUS_BAD_ARG; break; }
       *value = &st->streams[id];
    } break;
-   default:
-      if (request & 1) {           /* GET: answered by the first stream (opus_multistream_encoder.c:1196-1219) */
-         opus_int32 *value = va_arg(ap, opus_int32 *);
-         if (!value) ret = OPUS_BAD_ARG; else ret = oa_ms_rec_get(&st->streams[0], st->kind, request, value);
-      } else {                     /* SET: applied to every stream (:1245-1278) */
-         opus_int32 value = va_arg(ap, opus_int32);
-         for (int s = 0; s < ns; s++) { ret = oa_ms_rec_set(&st->streams[s], st->kind, request, value); if (ret != OPUS_OK) break; }
+   /* the requests the reference's switch knows (opus_multistream_encoder.c:1196-1330); everything else is OPUS_UNIMPLEMENTED there and here */
+   case OPUS_GET_LSB_DEPTH_REQUEST: case OPUS_GET_VBR_REQUEST: case OPUS_GET_APPLICATION_REQUEST: case OPUS_GET_BANDWIDTH_REQUEST: case OPUS_GET_COMPLEXITY_REQUEST:
+   case OPUS_GET_PACKET_LOSS_PERC_REQUEST: case OPUS_GET_DTX_REQUEST: case OPUS_GET_VOICE_RATIO_REQUEST: case OPUS_GET_VBR_CONSTRAINT_REQUEST: case OPUS_GET_SIGNAL_REQUEST:
+   case OPUS_GET_LOOKAHEAD_REQUEST: case OPUS_GET_SAMPLE_RATE_REQUEST: case OPUS_GET_INBAND_FEC_REQUEST: case OPUS_GET_FORCE_CHANNELS_REQUEST: case OPUS_GET_PREDICTION_DISABLED_REQUEST:
+   case OPUS_GET_PHASE_INVERSION_DISABLED_REQUEST: case 4057 /* OPUS_GET_QEXT: the elementary encoder answers (unimplemented without ENABLE_QEXT) */: case 11901 /* OPUS_AMD_GET_FLOAT_ANALYSIS (private) */: {
+      opus_int32 *value = va_arg(ap, opus_int32 *);              /* answered by the first stream (:1196-1219) */
+      ret = opus_encoder_ctl(&st->streams[0], request, value);
+   } break;
+   case OPUS_SET_LSB_DEPTH_REQUEST: case OPUS_SET_COMPLEXITY_REQUEST: case OPUS_SET_VBR_REQUEST: case OPUS_SET_VBR_CONSTRAINT_REQUEST: case OPUS_SET_MAX_BANDWIDTH_REQUEST:
+   case OPUS_SET_BANDWIDTH_REQUEST: case OPUS_SET_SIGNAL_REQUEST: case OPUS_SET_INBAND_FEC_REQUEST: case OPUS_SET_PACKET_LOSS_PERC_REQUEST: case OPUS_SET_DTX_REQUEST:
+   case OPUS_SET_FORCE_MODE_REQUEST: case OPUS_SET_FORCE_CHANNELS_REQUEST: case OPUS_SET_PREDICTION_DISABLED_REQUEST: case OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST:
+   case 4056 /* OPUS_SET_QEXT */: case 11900 /* OPUS_AMD_SET_FLOAT_ANALYSIS (private, include/opus_amd.h) */: {
+      const opus_int32 value = va_arg(ap, opus_int32);           /* applied to every stream, stopping at the first that refuses (:1245-1278) */
+      for (int s = 0; s < ns; s++) { ret = oa_ms_rec_set(&st->streams[s], st->kind, request, value); if (ret != OPUS_OK) break; }
+   } break;
+   case OPUS_SET_APPLICATION_REQUEST: {                          /* ... this one through the classic entry point: a change to / from RESTRICTED_LOWDELAY moves a stream to the other record type */
+      const opus_int32 value = va_arg(ap, opus_int32);
+      for (int s = 0; s < ns; s++) {
+         ret = opus_encoder_ctl(&st->streams[s], request, value);
+         if (ret != OPUS_OK) break;
+         if (s == st->lfe_stream) (void)opus_encoder_ctl(&st->streams[s], OPUS_SET_LFE_REQUEST, 1);      /* (a converted record starts from opus_encoder_init) */
       }
+      st->kind = (opus_int32)st->streams[0].kind;
+      if (ret == OPUS_OK) st->application = value;
+   } break;
+   case OPUS_SET_EXPERT_FRAME_DURATION_REQUEST: st->variable_duration = va_arg(ap, opus_int32); break;      /* stored as it comes (:1303-1307) */
+   case OPUS_GET_EXPERT_FRAME_DURATION_REQUEST: { opus_int32 *value = va_arg(ap, opus_int32 *); if (!value) ret = OPUS_BAD_ARG; else *value = st->variable_duration; } break;
+   default: ret = OPUS_UNIMPLEMENTED;
    }
    return ret;
 }
@@ -601,7 +621,7 @@ static int oa_ms_decoder_ctl_va(OpusMSDecoder *st, int request, va_list ap)
       *value = &st->streams[id];
    } break;
    case OPUS_SET_GAIN_REQUEST: { const opus_int32 v = va_arg(ap, opus_int32); for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = opus_decoder_ctl(&st->streams[s], request, v); } break;
-   case OPUS_GET_GAIN_REQUEST: case OPUS_GET_COMPLEXITY_REQUEST: case 4033: { opus_int32 *p = va_arg(ap, opus_int32 *); ret = opus_decoder_ctl(&st->streams[0], request, p); } break;
+   case OPUS_GET_GAIN_REQUEST: case OPUS_GET_COMPLEXITY_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); ret = opus_decoder_ctl(&st->streams[0], request, p); } break;   /* (OPUS_GET_PITCH is not in the multistream decoder's switch: opus_multistream_decoder.c:442-547) */
    case OPUS_SET_COMPLEXITY_REQUEST: { const opus_int32 v = va_arg(ap, opus_int32); for (int s = 0; s < ns && ret == OPUS_OK; s++) ret = opus_decoder_ctl(&st->streams[s], request, v); } break;
    case OPUS_GET_SAMPLE_RATE_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->Fs; } break;
    case OPUS_GET_BANDWIDTH_REQUEST: { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else *p = st->streams[0].s.s.bandwidth; } break;

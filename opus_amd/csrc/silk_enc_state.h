@@ -8,6 +8,7 @@
 #ifndef OPUS_AMD_SILK_ENC_STATE_H
 #define OPUS_AMD_SILK_ENC_STATE_H
 #include <stdint.h>
+#include <stddef.h>
 
 #define SE_MAX_FRAME 320
 #define SE_LA_SHAPE_MAX 80

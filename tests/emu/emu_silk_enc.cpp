@@ -7,6 +7,7 @@ extern "C" void emu_set_dump(dump_fn f) { g_dump = f; }
 #define K_DUMP(tag, ptr, nbytes) do { if (g_dump && wv_lane() == 0) g_dump(tag, (const void *)(ptr), nbytes); } while (0)
 #define K_DUMPI(tag, v) do { int32_t v__ = (int32_t)(v); if (g_dump && wv_lane() == 0) g_dump(tag, &v__, 4); } while (0)
 #define K_DUMP_ENABLED 1
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }   /* (opus_sh_split.h; fibers are cooperative) */
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
 #include "silk_enc_all.h"

@@ -113,6 +113,7 @@ def test_projection_encode24_at_complexity_10():
         e, err, s, c = _enc(L, 48000, nch, 2049); assert e and err == 0
         L.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]
         assert L.opus_projection_encoder_ctl(e, 4010, 10) == 0 and L.opus_projection_encoder_ctl(e, 4002, 4 * 48000) == 0
+        if L is E: assert L.opus_projection_encoder_ctl(e, 11900, 1) == 0                     # (the test process starts encoders with the analysis off: conftest.py)
         L.opus_projection_encode24.argtypes = [vp, vp, ci, vp, ci]
         buf = (ctypes.c_ubyte * 20000)(); pk = []
         for i in range(10):
