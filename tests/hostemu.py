@@ -41,6 +41,12 @@ def build_reftests(flavour):
             s.append(os.path.join(ROOT, "tests/emu/demo_rand.c")); extra = ["-Drand=oa_demo_rand", "-Dsrand=oa_demo_srand"]
         if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(x) for x in s): continue
         subprocess.check_call(["gcc"] + REFTEST_FLAGS + extra + s + ["-o", exe] + lib + ["-lm"])
+    if flavour != "ref":
+        # test_opus_api once more WITHOUT -DDISABLE_FLOAT_API: the library models the reference's default build (float API on), so the program's float-entry checks
+        # (opus_decode_float / opus_encode_float / multistream float paths) run too
+        exe = os.path.join(out, "test_opus_api_fl"); s = [os.path.join(REF, x) for x in REFTESTS["test_opus_api"]]
+        if not (os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(x) for x in s)):
+            subprocess.check_call(["gcc"] + [f for f in REFTEST_FLAGS if f != "-DDISABLE_FLOAT_API"] + s + ["-o", exe] + lib + ["-lm"])
     return out
 
 def build_trace_shim():

@@ -23,6 +23,8 @@ def _run(flavour, name, timeout, args=()):
 
 @pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_api")), reason="no reference tree")
 def test_emu_test_opus_api(): _run("emu", "test_opus_api", 1800)
+@pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_api_fl")), reason="no reference tree")
+def test_emu_test_opus_api_with_the_float_api(): _run("emu", "test_opus_api_fl", 1800)          # the same program compiled without -DDISABLE_FLOAT_API: its float-entry checks run
 @pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_padding")), reason="no reference tree")
 def test_emu_test_opus_padding(): _run("emu", "test_opus_padding", 600)
 @pytest.mark.skipif(not os.path.isdir(hostemu.REF) and not os.path.exists(os.path.join(ROOT, "oracle/_ref/reftests/emu/test_opus_projection")), reason="no reference tree")
@@ -34,6 +36,8 @@ def test_emu_test_opus_decode(): _run("emu", "test_opus_decode", 4 * 3600)
 
 @pytest.mark.gpu
 def test_gpu_test_opus_api(): _run("gpu", "test_opus_api", 900)
+@pytest.mark.gpu
+def test_gpu_test_opus_api_with_the_float_api(): _run("gpu", "test_opus_api_fl", 900)
 @pytest.mark.gpu
 def test_gpu_test_opus_padding(): _run("gpu", "test_opus_padding", 300)
 @pytest.mark.gpu

@@ -20,7 +20,8 @@ bench5) timeout 300 python bench.py $B --config 5 > $O/bench5.log 2>&1 ;;
 decode) for c in 2 3 4; do timeout 300 python bench.py $B --config $c --decode > $O/decode$c.log 2>&1; done ;;
 bench_default) timeout 900 python bench.py > $O/bench_default.log 2>&1 ;;
 prof2|prof3|prof4) c=${step#prof}; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete ;;
-pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc$c > $O/pmc$c.log 2>&1 ;;
+pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmc$c > $O/pmc$c.log 2>&1 ;;
+pmcd2|pmcd3|pmcd4) c=${step#pmcd}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmcd$c --decode > $O/pmcd$c.log 2>&1 ;;
 exp_occ) for pad in 0 20000 60000; do OPUS_AMD_SH_LDS_PAD=$pad timeout 300 python bench.py $B --config 3 > $O/bench3_pad$pad.log 2>&1; done ;;
 exp_lib) for f in $EXP_LIBS; do for c in $EXP_CONFIGS; do OPUS_AMD_LIB=$PWD/opus_amd/$f timeout 300 python bench.py $B --config $c > $O/bench${c}_$f.log 2>&1; done; done ;;
 ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
