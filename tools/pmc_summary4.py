@@ -5,6 +5,8 @@ kernels of one call: what bench.py quotes in roofline.traffic / roofline.issue. 
 import csv, collections, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
 FR = 16384; GiB = 1 << 30
+# resident waves per SIMD of each kernel (LDS / VGPR footprint: tools/kernel_resources.sh + the launch's dynamic LDS); front: 10 waves per CU mono, 9 stereo
+WPS = {"oa_encode_kernel": 4.0, "oa_sh_front_kernel": 2.5, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 1.75, "oa_sh_encode_kernel": 1.75}
 def table(d, f):
     """{kernel: {counter: mean value per dispatch}}, dispatch counts"""
     p = os.path.join(d, f); agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -26,7 +28,8 @@ for sub in sorted(os.listdir(root)):
     if not (os.path.isdir(d) and sub.startswith("pmc")): continue
     key = ("decode_%s" % sub[4:]) if sub.startswith("pmcd") else ("config_%s" % sub[3:])
     ins, busy, lanes, fe, wr = table(d, "pmc_sq_insts.csv"), table(d, "pmc_valu_busy.csv"), table(d, "pmc_lanes.csv"), table(d, "pmc_fetch.csv"), table(d, "pmc_write.csv")
-    kernels = sorted(ins)
+    kernels = sorted(k for k in ins if ("decode" in k) == key.startswith("decode"))     # (a decoder leg encodes its packets first: those launches are not its own)
+    ins = {k: ins[k] for k in kernels}; busy = {k: v for k, v in busy.items() if k in kernels}; lanes = {k: v for k, v in lanes.items() if k in kernels}
     per = {}
     tot = collections.Counter()
     for k in kernels:
@@ -45,7 +48,8 @@ for sub in sorted(os.listdir(root)):
                 "hbm_bytes_per_frame": (tot["fetch_bytes_per_frame"] + tot["write_bytes_per_frame"]) or None,
                 "issue": {"valu_insts_per_frame": tot["valu_insts_per_frame"], "salu_insts_per_frame": tot["salu_insts_per_frame"], "lds_insts_per_frame": tot["lds_insts_per_frame"],
                           "valu_active_fraction_of_wave_cycles": None if not wc else round(va / wc, 3),     # x resident waves per SIMD = VALU busy per SIMD
-                          "valu_busy_per_simd": None},
+                          "valu_busy_per_simd": None if not wc else round(va / sum(busy[k].get("SQ_WAVE_CYCLES", 0) / WPS.get(k, 2.0) for k in busy), 3),     # VALU-active cycles / SIMD-resident cycles (wave cycles / resident waves per SIMD), over the call's kernels
+                          "waves_per_simd": {k: WPS.get(k) for k in kernels}},
                 "lane_utilisation": {"active_lanes_per_valu_cycle": None if not ta else round(tl / ta, 1)},
                 "kernels": per}
 json.dump(doc, open(out, "w"), indent=1)
