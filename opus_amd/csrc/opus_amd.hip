@@ -80,7 +80,7 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
  * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave.  list != NULL: the calls the split path's front kernel turned away (their analysis has run) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue,
-      const int *list, const unsigned *list_count)
+      const int *list, const unsigned *list_count, int pkt_off)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -93,7 +93,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
       const int ch = gs->cfg.channels;
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
-      if (threadIdx.x == 0) L->silk_tail = 1;
+      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; }
       __syncthreads();
       oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
             (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
@@ -106,7 +106,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 #define OA_SH_FRONT_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
-oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams)
+oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -117,6 +117,8 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
       OaShStream *gs = streams + s;
       const int ch = gs->cfg.channels;
       seen++;
+      if (threadIdx.x == 0) L->packet_off = pkt_off;
+      __syncthreads();
       oa_sh_front_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
             apcm ? apcm + (size_t)s * frame_size * ch : nullptr, slow_list, counters + 4, s);
       __syncthreads();
@@ -139,13 +141,15 @@ oa_sh_quant_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scrat
    }
 }
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters)
+oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters, int pkt_off)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
    for (;;) {
       const int s = oa_queue_pop(counters + 1);
       if (s >= nstreams) break;
+      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; }
+      __syncthreads();
       if (conts[s].kind == SH_CONT_FAST) oa_sh_quant0_frame(L, streams + s, conts + s, (SeRateScratch *)(scratch + (size_t)blockIdx.x * sizeof(SeRateScratch)));
       __syncthreads();
    }
@@ -154,13 +158,15 @@ oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scra
 #define OA_SH_BACK_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
-oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters)
+oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters, int pkt_off)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
    for (;;) {
       const int s = oa_queue_pop(counters + 2);
       if (s >= nstreams) break;
+      if (threadIdx.x == 0) L->packet_off = pkt_off;
+      __syncthreads();
       if (conts[s].kind == SH_CONT_FAST) {
          OaShStream *gs = streams + s;
          const int ch = gs->cfg.channels;
@@ -485,11 +491,16 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    { const size_t need = SH_PCM_BYTES(frame_size, ch) * (size_t)b->S; if (need > b->pcm_hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->pcm_hp_cap = need; } }
    static const size_t lds_pad = getenv("OPUS_AMD_SH_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_SH_LDS_PAD")) : 0;   /* occupancy experiments only */
    /* the front kernel holds the SILK state without the quantiser tails; the arena behind the head must also hold the tonality analysis' working set */
+   /* every kernel's packet buffer sits behind the rest of its LDS (ShLds.packet_off): the full OA_MAX_PACKET + 4 bytes, or the front kernel's few header bytes */
+   auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
    size_t lds_front = SH_FRONT_LDS_BYTES(ch) + lds_pad;
    if (lds_front < offsetof(ShLds, S) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + sizeof(AnLds);
+   const int po_front = (int)al16(lds_front); lds_front = po_front + SH_FRONT_PKT_BYTES;
    /* the back kernel enters the CELT arena for hybrid frames AND for the redundant CELT frame that announces a SILK bandwidth switch (opus_encoder.c:2251-2260), which a
     * stream pinned to SILK-only can still ask for: only RESTRICTED_SILK never does */
-   const size_t lds_back = offsetof(ShLds, S) + (b->application == OPUS_APPLICATION_RESTRICTED_SILK ? 256 : sizeof(FrameLds));
+   size_t lds_back = offsetof(ShLds, S) + (b->application == OPUS_APPLICATION_RESTRICTED_SILK ? 256 : sizeof(FrameLds));
+   const int po_back = (int)al16(lds_back); lds_back = po_back + SH_PKT_BYTES;
+   const int po_full = (int)al16(lds_full); lds_full = po_full + SH_PKT_BYTES;
    (void)silk_only;
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
    const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
@@ -505,14 +516,14 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
-         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n);
-   if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front);
+   if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
-         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue);
+         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back);
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
-         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4));
+         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -539,14 +550,15 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
          b->all_silk_pinned = pinned; b->cfg_dirty = false;
       }
       const int silk_only = b->all_silk_pinned && frame_size >= b->Fs / 100;
-      const size_t lds = sh_lds_bytes(b->channels, silk_only);
+      const size_t lds = sh_lds_bytes(b->channels, silk_only);                                                 /* (without the packet buffer: it goes behind, ShLds.packet_off) */
+      const int po = (int)((lds + 15) & ~(size_t)15); const size_t lds_pk = (size_t)po + SH_PKT_BYTES;
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : 1;       /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser */
       if (split_env && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_env);
       int grid = 0;
-      { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
-      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds, s,
+      { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
+      hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds_pk, s,
             b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue,
-            (const int *)nullptr, (const unsigned *)nullptr);
+            (const int *)nullptr, (const unsigned *)nullptr, po);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }

@@ -8,7 +8,7 @@
  * rate (8-48 kHz), mono / stereo, 2.5-120 ms.  Mode switches in every direction (SILK / hybrid <-> CELT-only with the redundant frame on the right side of the
  * switch, SILK bandwidth switches), in-band FEC, both DTX flavours.
  *
- * LDS protocol: the packet being built lives in L->packet (ShLds); the SILK working set and the CELT frame arena alias each other in L->S, so a frame that needs
+ * LDS protocol: the packet being built lives in SH_PKT(L) (ShLds); the SILK working set and the CELT frame arena alias each other in L->S, so a frame that needs
  * the CELT coder first sends the SILK state back to HBM (sh_enter_celt) and the next frame of the same call brings it back (sh_reload_silk). */
 #ifndef OPUS_AMD_OPUS_ENC_SH_H
 #define OPUS_AMD_OPUS_ENC_SH_H
@@ -47,10 +47,14 @@ struct ShLds {
    MfLds mf;
    CeltScratch *cs;                                      /* the stream's HBM scratch of the CELT passes (celt_enc_lds.h) */
    i32 silk_tail, pad_;                                  /* 1: this kernel stages the quantiser tails of the SILK state (OaSilkEncTail) too; 0: the split path's front kernel (set by the kernel before the call opens) */
-   u8 packet[OA_MAX_PACKET + 4];
+   i32 packet_off, pad2_;                                /* the packet being built: SH_PKT(L), behind everything else the kernel allocates -- OA_MAX_PACKET + 4 bytes, except in the
+                                                          * split path's front kernel, which codes a few header symbols and gets SH_FRONT_PKT_BYTES (set by the kernel before the call opens) */
    SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
-#define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))
+#define SH_PKT(L) ((WV_LDS u8 *)(L) + (L)->packet_off)
+#define SH_PKT_BYTES (OA_MAX_PACKET + 4)
+#define SH_FRONT_PKT_BYTES 64
+#define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))                 /* without the packet: the kernels add it behind (packet_off) */
 #define SH_FRONT_LDS_BYTES(channels) (offsetof(ShLds, S) + SE_FRONT_LDS_BYTES(channels))
 /* per-stream HBM scratch: the high-passed input of the frame, the faded CELT input of the frame (only written when a frame needs more than one CELT pass),
  * the 2.5 ms CELT prefill, the CELT passes' bulk arrays (CeltScratch), then the rate-loop snapshots */
@@ -184,8 +188,8 @@ WV_DEVN void sh_layer_decide(WV_LDS ShLds *L, int frame_size, int out_data_bytes
       if (tocmode == OA_MODE_SILK_ONLY && bw > OA_BW_WB) bw = OA_BW_WB;
       else if (tocmode == OA_MODE_CELT_ONLY && bw == OA_BW_MB) bw = OA_BW_NB;
       else if (tocmode == OA_MODE_HYBRID && bw <= OA_BW_SWB) bw = OA_BW_SWB;
-      L->packet[0] = (u8)(sh_gen_toc(tocmode, frame_rate, bw, st->stream_channels) | packet_code);
-      if (packet_code == 3) L->packet[1] = (u8)num_multiframes;
+      SH_PKT(L)[0] = (u8)(sh_gen_toc(tocmode, frame_rate, bw, st->stream_channels) | packet_code);
+      if (packet_code == 3) SH_PKT(L)[1] = (u8)num_multiframes;
       sh->plc_frame = 1; sh->ret = packet_code <= 1 ? 1 : 2;
       sh->max_data_bytes = imax(max_data_bytes, sh->ret);
       return;
@@ -431,7 +435,7 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
 #define SH_CELT_FORCE_INTRA(F) ((F)->st.pad0[1])
 
 /* One celt_encode_with_ec (celt/celt_encoder.c:1726) on the arena: `src` = nsamp * CC int16 samples at the API rate in HBM (NULL: already staged in the HBM scratch L->cs->pcm16).
- *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in L->packet (hybrid), or starting it (CELT-only frame)
+ *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in SH_PKT(L) (hybrid), or starting it (CELT-only frame)
  *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
 struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
 WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal)
@@ -445,7 +449,7 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    if (wv_lane() == 0) F->g = L->cs;               /* (the arena aliases the SILK working set: whatever SILK did since the last CELT pass may have overwritten the pointer) */
    wv_sync();
    if (src) { i16 *dst = L->cs->pcm16; FOR_LANES(i, nsamp * CC) dst[i] = src[i]; }
-   if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)L->packet)[i]; }
+   if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)SH_PKT(L))[i]; }
    wv_sync();
    {  /* celt_maxabs over the head and the overlap tail of the input (celt_encoder.c:1970-1973), at the API rate */
       const i16 *p = L->cs->pcm16;
@@ -507,7 +511,7 @@ template <class P16> WV_DEV void sh_stereo_fade_lds(P16 io, int n, i16 g1_, i16 
 }
 
 /* One coded frame: opus_encode_frame_native (:1855), in two halves around the SILK layer so that the split path (opus_sh_split.h) can run them in kernels of their own.
- * pcm = this frame's input, frame_size samples per channel; the packet ends up in L->packet, its length (before CBR padding) is returned and st / the HBM state are
+ * pcm = this frame's input, frame_size samples per channel; the packet ends up in SH_PKT(L), its length (before CBR padding) is returned and st / the HBM state are
  * updated.  pcm_hp / pcm_celt / pre = per-stream HBM scratch.
  * sh_frame_front_wave: activity (:1911-1930), the frame's redundancy / budget words, coder start, high-pass into pcm_hp (:1969-2009) and, when SILK codes the frame, the
  * SILK control block *scp (:2043-2189). */
@@ -544,7 +548,7 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       sh->bits_target = imin(8 * (max_data_bytes - redundancy_bytes), bitrate_to_bits(sh->bitrate_bps, Fs, frame_size)) - 8;
       sh->curr_bandwidth = st->bandwidth;
       sh->redundant_rng = 0; sh->f_size = frame_size; sh->r[3] = 0;                  /* r[3]: the result is a bare TOC that is never padded (DTX) */
-      { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1; k_ec_enc_init(EC_PASS, (u32)imin(orig_max_data_bytes - 1, 1275)); ec_st(&L->ec, e); }   /* the reference's coder spans the caller's whole buffer (:1964); a frame never fills more than 1275 bytes of it, and what lies beyond only ever gets cleared by ec_enc_done -- which here would run past the LDS packet buffer */
+      { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = SH_PKT(L) + 1; k_ec_enc_init(EC_PASS, (u32)imin(orig_max_data_bytes - 1, 1275)); ec_st(&L->ec, e); }   /* the reference's coder spans the caller's whole buffer (:1964); a frame never fills more than 1275 bytes of it, and what lies beyond only ever gets cleared by ec_enc_done -- which here would run past the LDS packet buffer */
       const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
       st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
       sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
@@ -664,7 +668,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
          }
       }
       if (silk_nBytes == 0) {                                                             /* SILK DTX (:2242): the TOC alone, no bookkeeping */
-         LANE0 { st->rangeFinal = 0; L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, sh->curr_bandwidth, st->stream_channels); sh->r[3] = 1; }
+         LANE0 { st->rangeFinal = 0; SH_PKT(L)[0] = sh_gen_toc(st->mode, Fs / frame_size, sh->curr_bandwidth, st->stream_channels); sh->r[3] = 1; }
          wv_sync();
          return 1;
       }
@@ -722,7 +726,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
    }
    /* ---- redundancy signalling, end of the SILK layer (:2351-2414) ---- */
    LANE0 {
-      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = SH_PKT(L) + 1;
       int redundancy = sh->f_redundancy, redundancy_bytes = sh->redundancy_bytes;
       const int max_data_bytes = sh->f_max_data_bytes;
       if (st->mode != OA_MODE_CELT_ONLY && k_ec_tell(EC_PASS) + 17 + 20 * (st->mode == OA_MODE_HYBRID) <= 8 * (max_data_bytes - 1)) {
@@ -765,7 +769,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
       sh_celt_run(L, gs, pcm_celt, n2, c, journal);
       if (wv_uni(sh->celt_ret) < 0) return OA_ERR_INTERNAL;
       wv_sync();
-      FOR_LANES(i, redundancy_bytes) L->packet[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
+      FOR_LANES(i, redundancy_bytes) SH_PKT(L)[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
       LANE0 sh->redundant_rng = F->st.rangeFinal;
       sh_celt_reset_wave(L, gs);
    }
@@ -790,15 +794,15 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
             ran = 1;
             LANE0 sh->ret = cret;
             wv_sync();
-            FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)L->packet)[i] = ((const WV_LDS i32 *)F->packet)[i];    /* the frame's bytes return to the packet buffer */
+            FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)SH_PKT(L))[i] = ((const WV_LDS i32 *)F->packet)[i];    /* the frame's bytes return to the packet buffer */
             wv_sync();
             if (redundancy && celt_to_silk && hyb && wv_uni(sh->nb_compr_bytes) != cret) {      /* the redundant frame follows the bytes CELT really used (:2503-2507) */
                const int from = wv_uni(sh->nb_compr_bytes);
                for (int b0 = 0; b0 < redundancy_bytes; b0 += WV_WIDTH) {
                   const int i = b0 + wv_lane(); u8 v = 0;
-                  if (i < redundancy_bytes) v = L->packet[1 + from + i];
+                  if (i < redundancy_bytes) v = SH_PKT(L)[1 + from + i];
                   wv_sync();
-                  if (i < redundancy_bytes) L->packet[1 + cret + i] = v;
+                  if (i < redundancy_bytes) SH_PKT(L)[1 + cret + i] = v;
                   wv_sync();
                }
                LANE0 sh->nb_compr_bytes = cret + redundancy_bytes;
@@ -818,7 +822,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
       sh_celt_run(L, gs, pcm_celt + CC * (frame_size - n2), n2, c, journal);
       if (wv_uni(sh->celt_ret) < 0) return OA_ERR_INTERNAL;
       wv_sync();
-      FOR_LANES(i, redundancy_bytes) L->packet[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
+      FOR_LANES(i, redundancy_bytes) SH_PKT(L)[1 + sh->nb_compr_bytes + i] = F->packet[1 + i];
       LANE0 sh->redundant_rng = F->st.rangeFinal;
       wv_sync();
    }
@@ -826,7 +830,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
    /* ---- TOC, bookkeeping, DTX, busted budget (:2549-2601) ---- */
    LANE0 {
       const int curr_bandwidth = sh->curr_bandwidth;
-      L->packet[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
+      SH_PKT(L)[0] = sh_gen_toc(st->mode, Fs / frame_size, curr_bandwidth, st->stream_channels);
       st->rangeFinal ^= (u32)sh->redundant_rng;
       st->prev_mode = sh->f_to_celt ? OA_MODE_CELT_ONLY : st->mode;
       st->prev_channels = st->stream_channels; st->prev_framesize = frame_size; st->first = 0;
@@ -836,8 +840,8 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
          const int busted = (st->mode == OA_MODE_SILK_ONLY ? sh->r[7] : sh->r[4]) > (sh->f_max_data_bytes - 1) * 8;
          if (busted) {
             if (sh->f_max_data_bytes < 2) ret = OA_ERR_BUFFER_TOO_SMALL;
-            else { L->packet[1] = 0; ret = 1; st->rangeFinal = 0; }
-         } else if (st->mode == OA_MODE_SILK_ONLY && !sh->f_redundancy) while (ret > 2 && L->packet[ret] == 0) ret--;     /* trailing zeros are implied in SILK-only packets (:2590) */
+            else { SH_PKT(L)[1] = 0; ret = 1; st->rangeFinal = 0; }
+         } else if (st->mode == OA_MODE_SILK_ONLY && !sh->f_redundancy) while (ret > 2 && SH_PKT(L)[ret] == 0) ret--;     /* trailing zeros are implied in SILK-only packets (:2590) */
          if (ret >= 0) ret += 1 + sh->redundancy_bytes;
       }
       sh->ret = ret;
@@ -868,12 +872,12 @@ WV_DEVN int sh_encode_frame_native(WV_LDS ShLds *L, OaShStream *gs, const i16 *p
          FOR_LANES(i, n4 * CC) gs->delay_buffer[prefill_offset + i] = stage[i];
          FOR_LANES(i, prefill_offset) gs->delay_buffer[i] = 0;
          wv_sync();
-         const int pr = silk_encode_wave(&L->S, &sc, gs->delay_buffer, encoder_buffer, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr, wv_uni(sh->f_prefill));
+         const int pr = silk_encode_wave(&L->S, &sc, gs->delay_buffer, encoder_buffer, &L->ec, SH_PKT(L) + 1, sh->activity, G, &gs->lbrr, wv_uni(sh->f_prefill));
          wv_sync();
          if (pr) { LANE0 { gs->s.error = pr; } return OA_ERR_INTERNAL; }
          sc.opusCanSwitch = 0;                                                              /* no second switch in the real call */
       }
-      const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, L->packet + 1, sh->activity, G, &gs->lbrr);
+      const int sret = silk_encode_wave(&L->S, &sc, pcm_hp, frame_size, &L->ec, SH_PKT(L) + 1, sh->activity, G, &gs->lbrr);
       wv_sync();
       if (sret) { LANE0 { gs->s.error = sret; } return OA_ERR_INTERNAL; }
       silk_nBytes = wv_uni(L->S.r[0]);
@@ -958,7 +962,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }
    if (sh->plc_frame) {
-      const int n = sh_emit_packet(L->packet, out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);
+      const int n = sh_emit_packet(SH_PKT(L), out, sh->ret, L->cfg.use_vbr ? 0 : sh->max_data_bytes, out_cap);
       /* what opus_encode_native has updated by the time it emits a 'PLC frame' (:1345) stays updated: the voice ratio (:1273-1292), the peak signal energy (:1310-1320), the
        * stereo-width memory (:1322), besides the analysis (in HBM already) */
       LANE0 {
@@ -975,7 +979,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       const int ret = sh_encode_frame_native(L, gs, pcm, frame_size, wv_uni(sh->max_data_bytes), pcm_hp, pcm_celt, tmp_prefill, G, out);
       /* apply_padding (:2646): hard CBR pads every packet, except the bare TOC of a DTX frame, to the byte budget */
       const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
-      result = ret < 0 ? ret : sh_emit_packet(L->packet, out, ret, pad_to, out_cap);
+      result = ret < 0 ? ret : sh_emit_packet(SH_PKT(L), out, ret, pad_to, out_cap);
    } else {
       /* ---- several coded frames, one packet (:1757-1838) ---- */
       const int nb_frames = wv_uni(sh->nb_frames), enc_frame_size = wv_uni(sh->enc_frame_size), max_len_sum = wv_uni(sh->max_len_sum), repacketize_len = wv_uni(sh->repacketize_len);
@@ -1005,9 +1009,9 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
          if (tmp_len < 0) { err = OA_ERR_INTERNAL; break; }
          if (tmp_len == 1) dtx_count++;
          wv_sync();
-         if (i > 0 && ((wv_uni(L->mf.toc) ^ L->packet[0]) & 0xFC)) { err = OA_ERR_INTERNAL; break; }   /* opus_repacketizer_cat refuses frames of another configuration */
-         LANE0 { if (i == 0) L->mf.toc = L->packet[0]; L->mf.len[i] = tmp_len - 1; }
-         FOR_LANES(k, tmp_len - 1) out[OA_MF_HEADROOM + staged + k] = L->packet[1 + k];
+         if (i > 0 && ((wv_uni(L->mf.toc) ^ SH_PKT(L)[0]) & 0xFC)) { err = OA_ERR_INTERNAL; break; }   /* opus_repacketizer_cat refuses frames of another configuration */
+         LANE0 { if (i == 0) L->mf.toc = SH_PKT(L)[0]; L->mf.len[i] = tmp_len - 1; }
+         FOR_LANES(k, tmp_len - 1) out[OA_MF_HEADROOM + staged + k] = SH_PKT(L)[1 + k];
          wv_sync();
          staged += tmp_len - 1; tot_size += tmp_len;
       }
@@ -1015,7 +1019,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       wv_sync();
       if (err) result = err;
       else {
-         result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames, out_cap);
+         result = oa_multiframe_assemble_wave(&L->mf, SH_PKT(L), out, repacketize_len, !L->cfg.use_vbr && dtx_count != nb_frames, out_cap);
          if (result < 0) result = OA_ERR_INTERNAL;
       }
    }

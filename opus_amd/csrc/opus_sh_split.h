@@ -82,7 +82,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       se_call_buffer_wave(S, &sc, pcm_hp, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
    }
    wv_sync();
-   se_call_frame_head_wave(S, &sc, &L->ec, L->packet + 1, &gs->lbrr, wv_uni(sh->activity), 0);
+   se_call_frame_head_wave(S, &sc, &L->ec, SH_PKT(L) + 1, &gs->lbrr, wv_uni(sh->activity), 0);
    int nq = 0;
    for (int n = 0; n < sc.nChannelsInternal; n++) {
       const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
@@ -121,14 +121,14 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       wv_sync();
       LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
    }
-   LANE0 se_call_frame_tail_l0(S, &sc, &L->ec, L->packet + 1, 1, 0, 1);
+   LANE0 se_call_frame_tail_l0(S, &sc, &L->ec, SH_PKT(L) + 1, 1, 0, 1);
    se_call_epilogue_wave(S, &sc, 0, &k);
    /* ---- the call so far -> HBM: the continuation record, the SILK state ---- */
    wv_sync();
    sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
    sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
    sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)L->packet, (OA_MAX_PACKET + 4) / 4);
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most; the quantiser kernel's lanes code on from there, in HBM) */
    se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&S->st, CC, 0);
    if (wv_lane() == 0) {
       ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
@@ -145,13 +145,13 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
    sh_copy_words((WV_LDS i32 *)sh, (const i32 *)&ct->sh, (int)(sizeof(ShShared) / 4));
    sh_copy_words((WV_LDS i32 *)st, (const i32 *)&ct->st, (int)(sizeof(OaShScalars) / 4));
    sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((WV_LDS i32 *)L->packet, (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
+   sh_copy_words((WV_LDS i32 *)SH_PKT(L), (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
    wv_sync();
    const SeControl sc = ct->sc;
    LANE0 {
       L->cs = cs; sh->silk_in_lds = 0;
       /* what silk_Encode does once the channels are coded (enc_API.c:522-545): VAD / LBRR flags into the payload's first bits, the bit reservoir */
-      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = L->packet + 1;
+      EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = SH_PKT(L) + 1;
       const int nBytesOut = (k_ec_tell(EC_PASS) + 7) >> 3;
       k_ec_enc_patch_initial_bits(EC_PASS, (unsigned)ct->silk_flags, (unsigned)ct->silk_flag_bits);
       ec_st(&L->ec, e);
@@ -163,7 +163,7 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
    const int silk_nBytes = wv_uni(sh->r[5]);
    const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes);
    const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
-   const int result = ret < 0 ? ret : sh_emit_packet(L->packet, out, ret, pad_to, out_cap);
+   const int result = ret < 0 ? ret : sh_emit_packet(SH_PKT(L), out, ret, pad_to, out_cap);
    LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
    sh_copy_words((i32 *)&gs->s, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
    wv_sync();
@@ -180,7 +180,7 @@ WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeR
    const int CC = L->cfg.channels;
    se_state_copy_wave((WV_LDS i32 *)&S->st, (const i32 *)&gs->silk, CC, 1);
    sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((WV_LDS i32 *)L->packet, (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
+   sh_copy_words((WV_LDS i32 *)SH_PKT(L), (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
    wv_sync();
    const int nq = wv_uni(ct->nq);
    for (int j = 0; j < nq; j++) {
@@ -199,7 +199,7 @@ WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeR
       FOR_LANES(i, c->frame_length) c->x_buf[c->ltp_mem_length + i] = q->x16[i];          /* (LDS copy only: the front kernel has moved x_buf on already) */
       if (wv_lane() == 0) { ctl->Lambda_Q10 = q->fr.Lambda_Q10; ctl->LTP_scale_Q14 = q->fr.LTP_scale_Q14; ctl->lastGainIndexPrev = q->lastGainIndexPrev; c->nsq_reset_req = q->nsq_reset; }
       wv_sync();
-      se_frame_quant_wave(S, c, &L->ec, L->packet + 1, wv_uni(q->condCoding), wv_uni(q->maxBits), wv_uni(q->useCBR), G, &gs->lbrr);
+      se_frame_quant_wave(S, c, &L->ec, SH_PKT(L) + 1, wv_uni(q->condCoding), wv_uni(q->maxBits), wv_uni(q->useCBR), G, &gs->lbrr);
       wv_sync();
       OaSilkEncChannel *gc = &gs->silk.ch[n];
       sh_copy_words((i32 *)&gs->silk.tail[n], (const WV_LDS i32 *)&E->tail[n], SE_TAIL_WORDS);
@@ -208,7 +208,7 @@ WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeR
    }
    wv_sync();
    sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)L->packet, (OA_MAX_PACKET + 4) / 4);
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), (OA_MAX_PACKET + 4) / 4);
    wv_sync();
 }
 

@@ -64,8 +64,10 @@ extern "C" void emu_sh_stream_init(OaShStream *st, int Fs, int channels, int app
 extern "C" void emu_sh_set_cfg(OaShStream *st, int word, int value) { ((int32_t *)&st->cfg)[word] = value; }
 extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size, int max_bytes, uint8_t *out, int out_cap, int32_t *len, uint32_t *rng)
 {
-   ShLds *L = (ShLds *)aligned_alloc(64, (sizeof(ShLds) + 63) & ~63);
-   memset(L, 0xA5, sizeof(ShLds));
+   const size_t po = (sizeof(ShLds) + 15) & ~(size_t)15, tot = (po + SH_PKT_BYTES + 63) & ~(size_t)63;
+   ShLds *L = (ShLds *)aligned_alloc(64, tot);
+   memset(L, 0xA5, tot);
+   L->silk_tail = 1; L->packet_off = (i32)po;                                      /* what oa_sh_encode_kernel sets before a call: the tails are staged, the packet buffer sits behind the rest */
    int16_t *hp = (int16_t *)malloc(2 * SH_PCM_BYTES(frame_size, 2) + 512);          /* high-passed frame | faded CELT input | 2.5 ms CELT prefill */
    SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
    CeltScratch *cs = (CeltScratch *)malloc(sizeof(CeltScratch)); memset(cs, 0xA5, sizeof(CeltScratch));
