@@ -1,4 +1,4 @@
-/* opus_amd.h — C ABI of the MI355X-native batched Opus encode path (drop-in boundary).
+/* opus_amd.h — C ABI of the MI355X-native batched Opus encode / decode path (drop-in boundary).
  *
  * Two layers, both plain C (no torch / HIP types in the signatures):
  *
@@ -17,8 +17,9 @@
  * 2. The batch API (additive): S independent streams stepped together, one wavefront per
  *    (stream, frame); state lives in HBM between calls; import/export honours the memcpy contract.
  *
- * Results are bit-identical to the reference fixed-point build (FIXED_POINT, DISABLE_FLOAT_API): same packet
- * bytes and OPUS_GET_FINAL_RANGE. */
+ * Results are bit-identical to the reference's fixed-point build with its float API on (FIXED_POINT, the default otherwise: the fixed-point codec plus the tonality /
+ * music analysis of src/analysis.c at complexity 10; opus_encode_float / opus_encode24 / opus_decode_float / opus_decode24 present and converting as that build does):
+ * same packet bytes, same OPUS_GET_FINAL_RANGE, same decoded PCM.  OPUS_AMD_SET_FLOAT_ANALYSIS(0) gives the packets of a build with DISABLE_FLOAT_API instead. */
 #ifndef OPUS_AMD_H
 #define OPUS_AMD_H
 #include <stdint.h>
@@ -396,7 +397,8 @@ OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32
  * B encoders with one layout, i.e. B x opus_multistream_encoder_create(Fs, channels, streams, coupled_streams, mapping, application)
  * (reference include/opus_multistream.h:260, src/opus_multistream_encoder.c:841-1060), stepped together with their B x streams elementary encoders resident in HBM:
  * channel extraction, the elementary encodes and the self-delimited packing (RFC 6716 Appendix B) are launches on one HIP stream, no host round trip.
- * mapping_family 0 / 255 (plain layouts) or 2 (ambisonics layouts: CELT-only elementary encoders); VBR; max_data_bytes large enough for every stream to be
+ * mapping_family 0 / 255 (plain layouts), 2 (ambisonics layouts: CELT-only elementary encoders) or 3 (projection: the layout and mixing matrix of
+ * opus_projection_ambisonics_encoder_create, reference src/opus_projection_encoder.c:176, mixed on the device as src/mapping_matrix.c:148 does; `mapping` is ignored); VBR; max_data_bytes large enough for every stream to be
  * offered its own cap ((streams - 1) * 1279 + 7662 + 3 * streams + 8 for frames <= 20 ms), else OPUS_BUFFER_TOO_SMALL -- the classic opus_multistream_encode
  * serves tight buffers, hard CBR and the surround family.  Packets are byte-identical to the reference's. */
 typedef struct OpusGpuMsEncBatch OpusGpuMsEncBatch;
@@ -408,6 +410,20 @@ OPUS_AMD_EXPORT int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *b, const opus
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens /* [B] */, opus_uint32 *d_final_range /* [B] */, void *hip_stream);
 OPUS_AMD_EXPORT int opusgpu_ms_encode_batch(OpusGpuMsEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out, opus_int32 out_stride, opus_int32 max_data_bytes,
       opus_int32 *lens, opus_uint32 *final_range);
+/* ---- device-resident multistream / projection DECODER batches (opus_amd/csrc/opus_ms_dec_batch.h) ----
+ * B decoders of opus_multistream_decoder_create(Fs, channels, streams, coupled_streams, mapping) (reference include/opus_multistream.h:461, src/opus_multistream_decoder.c:178): a
+ * frame-step parses the B multistream packets, decodes the B x streams elementary packets and maps the decoded channels to the caller's interleaved output, all in HBM.
+ * d_data [B][stride] packets of d_lens [B] bytes (0 = lost), d_pcm [B][frame_size][channels] int16, d_nsamples [B] = samples per channel or a negative OPUS_* code. */
+typedef struct OpusGpuMsDecBatch OpusGpuMsDecBatch;
+OPUS_AMD_EXPORT OpusGpuMsDecBatch *opusgpu_ms_dec_batch_create(opus_int32 nb_decoders, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int device, int *error);
+/* ... of opus_projection_decoder_create (reference include/opus_projection.h:418, src/opus_projection_decoder.c:213): the same with the demixing matrix (src/mapping_matrix.c:257) applied on the device */
+OPUS_AMD_EXPORT OpusGpuMsDecBatch *opusgpu_projection_dec_batch_create(opus_int32 nb_decoders, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *demixing_matrix,
+      opus_int32 demixing_matrix_size, int device, int *error);
+OPUS_AMD_EXPORT void opusgpu_ms_dec_batch_destroy(OpusGpuMsDecBatch *b);
+OPUS_AMD_EXPORT int opusgpu_ms_decode_batch_dev(OpusGpuMsDecBatch *b, const unsigned char *d_data, opus_int32 stride, const opus_int32 *d_lens, opus_int16 *d_pcm, int frame_size,
+      opus_int32 *d_nsamples, opus_uint32 *d_final_range, void *hip_stream);
+OPUS_AMD_EXPORT int opusgpu_ms_decode_batch(OpusGpuMsDecBatch *b, const unsigned char *data, opus_int32 stride, const opus_int32 *lens, opus_int16 *pcm, int frame_size,
+      opus_int32 *nsamples, opus_uint32 *final_range);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
-"""opus_amd — MI355X-native batched Opus (CELT-only) encoder behind the libopus C ABI.
+"""opus_amd — MI355X-native batched Opus encoder and decoder (CELT, SILK, hybrid; multistream, projection) behind the libopus C ABI.
 
-Host side: a thin ctypes mirror of the reference's encoder interface (`opus_encoder_create / opus_encode /
-opus_encoder_ctl`, reference/include/opus.h:174-367) plus the additive batch API of include/opus_amd.h.
+Host side: a thin ctypes mirror of the reference's encoder / decoder interface (`opus_encoder_create / opus_encode /
+opus_encoder_ctl`, `opus_decoder_create / opus_decode`, reference/include/opus.h:174-520) plus the additive batch API of include/opus_amd.h.
 All compute happens in the hand-written HIP kernels of opus_amd/csrc (one wavefront per stream-frame);
 there is NO CPU fallback: if the shared library or a GPU is missing, construction raises.
 

@@ -1278,11 +1278,12 @@ int opus_decoder_ctl(OpusDecoder *st, int request, ...)
 }
 } /* extern "C" */
 #include "opus_ms_host.h"
-#include "opus_ms_batch.h"
 #include "opus_api_host.h"
 #include "opus_projection_host.h"
+#include "opus_ms_dec_batch.h"
+#include "opus_ms_batch.h"
 #include "silk_batch.h"
 extern "C" {
-const char *opus_get_version_string(void) { return "opus-amd 0.3 (gfx950, fixed-point bit-exact CELT encoder, full Opus decoder, SILK operator kernels)"; }
+const char *opus_get_version_string(void) { return "opus-amd 0.4 (gfx950; bit-exact fixed-point Opus encoder and decoder: CELT, SILK, hybrid, multistream, projection)"; }
 
 } /* extern "C" */

@@ -33,6 +33,24 @@ oa_ms_split_kernel(const i16 *pcm, int frame, int nch, const i32 *chan /* [2 * n
    }
 }
 
+/* the same split of the caller's UN-mixed channels into the analysis' signal domain (int32, INT16TOSIG = << 12): what the elementary encoders' tonality analysis looks at when
+ * a mixing matrix sits in front of them (opus_multistream_encoder.c:1027 hands opus_encode_native the original pcm with the stream's channel indices) */
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_split_sig_kernel(const i16 *pcm, int frame, int nch, const i32 *chan, int nc, int nm, i32 *pc, i32 *pm)
+{
+   const int ns = nc + nm, b = (int)blockIdx.x / ns, s = (int)blockIdx.x - b * ns;
+   const i16 *src = pcm + (size_t)b * frame * nch;
+   if (s < nc) {
+      const int l = chan[2 * s], r = chan[2 * s + 1];
+      i32 *d = pc + ((size_t)b * nc + s) * frame * 2;
+      for (int i = threadIdx.x; i < frame; i += 64) { d[2 * i] = shl32((i32)src[(size_t)i * nch + l], 12); d[2 * i + 1] = shl32((i32)src[(size_t)i * nch + r], 12); }
+   } else {
+      const int c = chan[2 * nc + (s - nc)];
+      i32 *d = pm + ((size_t)b * nm + (s - nc)) * frame;
+      for (int i = threadIdx.x; i < frame; i += 64) d[i] = shl32((i32)src[(size_t)i * nch + c], 12);
+   }
+}
+
 /* bytes of an Opus packet's own header (RFC 6716 section 3.2: TOC, code-3 count byte, explicit lengths; packets of this encoder carry no padding in VBR) and the
  * size of its last frame -- what Appendix B wants coded in addition */
 WV_DEV void oa_ms_header(const u8 *p, int len, int *hdr, int *last)
@@ -94,6 +112,7 @@ struct OpusGpuMsEncBatch {
    OpusGpuEncBatch *bc, *bm;             /* the B * nc coupled and B * nm mono elementary encoders */
    i32 *d_chan;
    i16 *d_pc, *d_pm; size_t pc_cap, pm_cap;
+   i16 *d_M, *d_mixed; size_t mixed_cap; i32 *d_apc, *d_apm; size_t apc_cap, apm_cap;      /* mapping family 3 (projection): the mixing matrix [C][C], the mixed input, the un-mixed channels for the analysis */
    u8 *d_pkc, *d_pkm; i32 *d_lc, *d_lm; u32 *d_rc, *d_rm; opus_int32 stride;
    /* staging of the host-pointer entry */
    i16 *d_pcm; size_t pcm_cap; u8 *d_out; size_t out_cap; i32 *d_lens; u32 *d_rng;
@@ -106,7 +125,7 @@ void opusgpu_ms_enc_batch_destroy(OpusGpuMsEncBatch *m)
    if (m->bc) opusgpu_enc_batch_destroy(m->bc);
    if (m->bm) opusgpu_enc_batch_destroy(m->bm);
    (void)hipSetDevice(m->device);
-   void *bufs[] = {m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
+   void *bufs[] = {m->d_M, m->d_mixed, m->d_apc, m->d_apm, m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
    for (void *p : bufs) if (p) (void)hipFree(p);
    free(m->proto);
    delete m;
@@ -118,13 +137,21 @@ OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int 
 {
    int err = OPUS_OK;
    OpusGpuMsEncBatch *m = nullptr;
-   if (B <= 0 || !mapping || (mapping_family != 0 && mapping_family != 255 && mapping_family != 2)) err = mapping_family == 1 || mapping_family == 3 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   if (B <= 0 || !mapping || (mapping_family != 0 && mapping_family != 255 && mapping_family != 2 && mapping_family != 3)) err = mapping_family == 1 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
+   int o1 = 0;
+   unsigned char ident[255];
+   if (err == OPUS_OK && mapping_family == 3) {                             /* projection: the layout opus_projection_ambisonics_encoder_init derives, identity mapping, mixing matrix of the order */
+      int ps = 0, pc = 0;
+      if (oa_proj_layout(channels, 3, &ps, &pc, &o1) != OPUS_OK || o1 < 2 || o1 > 6 || ps != streams || pc != coupled_streams || channels > OA_PROJ_MAXC) err = OPUS_BAD_ARG;
+      for (int i = 0; i < channels && i < 255; i++) ident[i] = (unsigned char)i;
+      mapping = ident;
+   }
    OpusMSEncoder *proto = nullptr;
    if (err == OPUS_OK) {
       const opus_int32 sz = opus_multistream_encoder_get_size(streams, coupled_streams);
       proto = sz > 0 ? (OpusMSEncoder *)malloc((size_t)sz) : nullptr;
       if (!proto) err = sz > 0 ? OPUS_ALLOC_FAIL : OPUS_BAD_ARG;
-      else err = oa_ms_encoder_init_impl(proto, Fs, channels, streams, coupled_streams, mapping, application, mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE, -1);
+      else err = oa_ms_encoder_init_impl(proto, Fs, channels, streams, coupled_streams, mapping, application, mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE, -1);      /* (family 3: opus_projection_ambisonics_encoder_init builds a PLAIN multistream encoder behind its matrix, opus_projection_encoder.c:224) */
    }
    if (err == OPUS_OK) {
       m = new OpusGpuMsEncBatch();
@@ -146,6 +173,12 @@ OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int 
                hipMalloc((void **)&m->d_rc, nstr * 4 + 4) == hipSuccess && hipMalloc((void **)&m->d_rm, nstr * 4 + 4) == hipSuccess &&
                hipMalloc((void **)&m->d_lens, (size_t)B * 4) == hipSuccess && hipMalloc((void **)&m->d_rng, (size_t)B * 4) == hipSuccess;
          if (!ok) err = OPUS_ALLOC_FAIL;
+      }
+      if (err == OPUS_OK && mapping_family == 3) {
+         const OaMatrixDesc *mix = &oa_pm_mixing[o1 - 2];
+         std::vector<i16> M((size_t)channels * channels);
+         for (int c = 0; c < channels; c++) for (int r = 0; r < channels; r++) M[(size_t)channels * c + r] = mix->data[mix->rows * c + r];
+         if (hipMalloc((void **)&m->d_M, M.size() * 2) != hipSuccess || hipMemcpy(m->d_M, M.data(), M.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = OPUS_ALLOC_FAIL;
       }
       if (err == OPUS_OK && mapping_family == 2) {                        /* ambisonics: CELT-only elementary encoders (opus_multistream_encoder.c:986) */
          if (m->bc) err = opusgpu_enc_batch_ctl(m->bc, -1, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY);
@@ -198,10 +231,20 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
    const size_t need_c = (size_t)m->B * m->nc * frame_size * 2 * sizeof(i16), need_m = (size_t)m->B * m->nm * frame_size * sizeof(i16);
    if (need_c > m->pc_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pc) (void)hipFree(m->d_pc); m->d_pc = nullptr; m->pc_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pc, need_c)); m->pc_cap = need_c; }
    if (need_m > m->pm_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pm) (void)hipFree(m->d_pm); m->d_pm = nullptr; m->pm_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pm, need_m)); m->pm_cap = need_m; }
-   hipLaunchKernelGGL(oa_ms_split_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, (const i16 *)d_pcm, frame_size, m->nch, (const i32 *)m->d_chan, m->nc, m->nm, m->d_pc, m->d_pm);
+   const i16 *src = (const i16 *)d_pcm;
+   if (m->d_M) {                                                           /* projection: mix on the device, and give the analyses the caller's un-mixed channels */
+      const size_t need_x = (size_t)m->B * frame_size * m->nch * sizeof(i16);
+      if (need_x > m->mixed_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_mixed) (void)hipFree(m->d_mixed); m->d_mixed = nullptr; m->mixed_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_mixed, need_x)); m->mixed_cap = need_x; }
+      if (2 * need_c > m->apc_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_apc) (void)hipFree(m->d_apc); m->d_apc = nullptr; m->apc_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_apc, 2 * need_c + 4)); m->apc_cap = 2 * need_c; }
+      if (2 * need_m > m->apm_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_apm) (void)hipFree(m->d_apm); m->d_apm = nullptr; m->apm_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_apm, 2 * need_m + 4)); m->apm_cap = 2 * need_m; }
+      hipLaunchKernelGGL(oa_proj_mix_kernel, dim3((unsigned)(((frame_size + 63) / 64) * m->B)), dim3(64), 0, s, (const i16 *)m->d_M, m->nch, (const i16 *)d_pcm, frame_size, m->d_mixed);
+      hipLaunchKernelGGL(oa_ms_split_sig_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, (const i16 *)d_pcm, frame_size, m->nch, (const i32 *)m->d_chan, m->nc, m->nm, m->d_apc, m->d_apm);
+      src = m->d_mixed;
+   }
+   hipLaunchKernelGGL(oa_ms_split_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, src, frame_size, m->nch, (const i32 *)m->d_chan, m->nc, m->nm, m->d_pc, m->d_pm);
    HIPCHECK(hipGetLastError());
-   if (m->nc) { const int r = opusgpu_encode_batch_dev(m->bc, m->d_pc, frame_size, m->d_pkc, m->stride, 1276 * 6, m->d_lc, m->d_rc, s); if (r != OPUS_OK) return r; }
-   if (m->nm) { const int r = opusgpu_encode_batch_dev(m->bm, m->d_pm, frame_size, m->d_pkm, m->stride, 1276 * 6, m->d_lm, m->d_rm, s); if (r != OPUS_OK) return r; }
+   if (m->nc) { const int r = opusgpu_encode_batch_dev_sig(m->bc, m->d_pc, m->d_M ? m->d_apc : nullptr, frame_size, m->d_pkc, m->stride, 1276 * 6, m->d_lc, m->d_rc, s); if (r != OPUS_OK) return r; }
+   if (m->nm) { const int r = opusgpu_encode_batch_dev_sig(m->bm, m->d_pm, m->d_M ? m->d_apm : nullptr, frame_size, m->d_pkm, m->stride, 1276 * 6, m->d_lm, m->d_rm, s); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_ms_pack_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
          (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range);
    HIPCHECK(hipGetLastError());

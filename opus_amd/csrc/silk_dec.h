@@ -632,8 +632,7 @@ WV_DEV void sd_cng(WV_LDS OaSilkChannel *ch, const WV_LDS SdCtrl *c, WV_LDS i16 
    } else for (int i = 0; i < ch->LPC_order; i++) ch->cng_synth_state[i] = 0;
 }
 
-/* ---- silk_decode_core, wave-wide (decode_core.c:38).  Same arithmetic as sd_decode_core above (kept as the readable serial statement of the
- * algorithm and used by nothing else), spread over the 64 lanes:
+/* ---- silk_decode_core, wave-wide (decode_core.c:38): the reference's sample loop spread over the 64 lanes:
  *   excitation    the dither seed is an affine recurrence s <- a*s + c + pulse[i]; affine maps compose associatively, so each lane composes its
  *                 5 samples, a 6-step scan over the lanes gives every lane its starting seed, and the lane replays its 5 samples
  *   re-whitening  an FIR: one output per lane

@@ -58,3 +58,110 @@ CASES = [
     dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000),    # VOIP 16 kHz (SILK elementary streams)
     dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=3),   # 40 ms calls (multi-frame elementary packets), a muted channel, permuted mapping
 ]
+
+# ---- projection (mapping family 3) encoder batch and the multistream / projection decoder batches ----
+def _proj_ref_enc(R, Fs, channels, app):
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    R.opus_projection_ambisonics_encoder_create.restype = vp
+    R.opus_projection_ambisonics_encoder_create.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
+    s, c, err = ci(), ci(), ci()
+    e = R.opus_projection_ambisonics_encoder_create(Fs, channels, 3, ctypes.byref(s), ctypes.byref(c), app, ctypes.byref(err)); assert e and err.value == 0
+    return e, s.value, c.value
+
+def check_projection(which, B=2, channels=9, application=2049, frames=4, frame=960, Fs=48000, bitrate=None, complexity=None, analysis=False):
+    """B projection encoders (device mixing in front of the multistream batch) against the reference's opus_projection_encode; then the packets through the projection DECODER
+    batch (device parse / decode / demix) against the reference's opus_projection_decode"""
+    L = capi.load(which); R = capi.load("ref_fxa" if analysis else "ref")
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    refs = [_proj_ref_enc(R, Fs, channels, application) for _ in range(B)]
+    streams, coupled = refs[0][1], refs[0][2]
+    L.opusgpu_ms_enc_batch_create.restype = vp
+    L.opusgpu_ms_enc_batch_create.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.c_char_p, ci, ci, ctypes.POINTER(ci)]
+    L.opusgpu_ms_enc_batch_destroy.argtypes = [vp]; L.opusgpu_ms_enc_batch_destroy.restype = None
+    L.opusgpu_ms_enc_batch_ctl.argtypes = [vp, ci, ci]
+    L.opusgpu_ms_encode_batch.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
+    err = ci()
+    m = L.opusgpu_ms_enc_batch_create(B, Fs, channels, 3, streams, coupled, bytes(range(channels)), application, 0, ctypes.byref(err)); assert m and err.value == 0, err.value
+    sets = ([(4002, bitrate)] if bitrate else []) + ([(4010, complexity)] if complexity is not None else [])
+    R.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]
+    for req, v in sets:
+        assert L.opusgpu_ms_enc_batch_ctl(m, req, v) == 0, (req, v)
+        for r in refs: assert R.opus_projection_encoder_ctl(r[0], req, v) == 0
+    assert L.opusgpu_ms_enc_batch_ctl(m, 11900, 1 if analysis else 0) == 0
+    # the decoder side: the demixing matrix from the reference encoder
+    R.opus_projection_encoder_ctl.argtypes = [vp, ci, vp]; sz = ctypes.c_int32(); assert R.opus_projection_encoder_ctl(refs[0][0], 6003, ctypes.byref(sz)) == 0
+    mat = (ctypes.c_ubyte * sz.value)(); R.opus_projection_encoder_ctl.argtypes = [vp, ci, vp, ci]; assert R.opus_projection_encoder_ctl(refs[0][0], 6005, mat, sz.value) == 0
+    R.opus_projection_decoder_create.restype = vp; R.opus_projection_decoder_create.argtypes = [ci, ci, ci, ci, vp, ci, ctypes.POINTER(ci)]
+    R.opus_projection_decode.argtypes = [vp, vp, ci, vp, ci, ci]
+    rdec = [R.opus_projection_decoder_create(Fs, channels, streams, coupled, mat, sz.value, ctypes.byref(err)) for _ in range(B)]; assert all(rdec) and err.value == 0
+    L.opusgpu_projection_dec_batch_create.restype = vp; L.opusgpu_projection_dec_batch_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, ci, ctypes.POINTER(ci)]
+    L.opusgpu_ms_decode_batch.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
+    L.opusgpu_ms_dec_batch_destroy.argtypes = [vp]; L.opusgpu_ms_dec_batch_destroy.restype = None
+    d = L.opusgpu_projection_dec_batch_create(B, Fs, channels, streams, coupled, mat, sz.value, 0, ctypes.byref(err)); assert d and err.value == 0, err.value
+    cap = (streams - 1) * 1279 + 7662 + 3 * streams + 8
+    sig = [np.stack([(speechy(frames * frame // 960 + 2, 1, 17 * b + c, 960)[:, 0] * (0.8 / (1 + c % 4))).astype(np.int16) for c in range(channels)], 1) for b in range(B)]
+    out = np.zeros((B, cap), np.uint8); lens = np.zeros(B, np.int32); rng = np.zeros(B, np.uint32)
+    o = np.zeros(cap, np.uint8); R.opus_projection_encode.argtypes = [vp, vp, ci, vp, ci]
+    pcm_out = np.zeros((B, frame, channels), np.int16); ns = np.zeros(B, np.int32); drng = np.zeros(B, np.uint32); ro = np.zeros((frame, channels), np.int16)
+    for f in range(frames):
+        pcm = np.ascontiguousarray(np.stack([x[f * frame:(f + 1) * frame] for x in sig]).astype(np.int16))
+        r = L.opusgpu_ms_encode_batch(m, pcm.ctypes.data, frame, out.ctypes.data, cap, cap, lens.ctypes.data, rng.ctypes.data); assert r == 0, r
+        for b in range(B):
+            n = R.opus_projection_encode(refs[b][0], pcm[b].ctypes.data, frame, o.ctypes.data, cap)
+            assert n == int(lens[b]) and bytes(out[b, :n]) == bytes(o[:n]), (f, b, n, int(lens[b]))
+        if f == 2: lens[0] = 0                                                         # a lost packet for decoder 0: every stream conceals
+        r = L.opusgpu_ms_decode_batch(d, out.ctypes.data, cap, lens.ctypes.data, pcm_out.ctypes.data, frame, ns.ctypes.data, drng.ctypes.data); assert r == 0, r
+        for b in range(B):
+            k = R.opus_projection_decode(rdec[b], out[b].ctypes.data if lens[b] else None, int(lens[b]), ro.ctypes.data, frame, 0)
+            assert k == int(ns[b]) == frame, (f, b, k, int(ns[b]))
+            assert np.array_equal(ro, pcm_out[b]), (f, b, int(np.abs(ro.astype(int) - pcm_out[b]).max()))
+    L.opusgpu_ms_enc_batch_destroy(m); L.opusgpu_ms_dec_batch_destroy(d)
+    R.opus_projection_encoder_destroy.argtypes = [vp]; R.opus_projection_decoder_destroy.argtypes = [vp]
+    for r in refs: R.opus_projection_encoder_destroy(r[0])
+    for r in rdec: R.opus_projection_decoder_destroy(r)
+
+def check_ms_decode(which, B, channels, streams, coupled, mapping, application, frames=4, frame=960, Fs=48000, bitrate=None, corrupt=False):
+    """packets of the reference's multistream encoder through the multistream DECODER batch against the reference's opus_multistream_decode: PCM, sample counts, final ranges;
+    corrupt: one decoder gets a truncated packet (the reference's error code, its streams untouched) and is then fed good packets again"""
+    L = capi.load(which); R = capi.load("ref")
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    R.opus_multistream_encoder_create.restype = vp; R.opus_multistream_encoder_create.argtypes = [ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    R.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ci]
+    R.opus_multistream_decoder_create.restype = vp; R.opus_multistream_decoder_create.argtypes = [ci, ci, ci, ci, ctypes.c_char_p, ctypes.POINTER(ci)]
+    R.opus_multistream_decode.argtypes = [vp, vp, ci, vp, ci, ci]
+    L.opusgpu_ms_dec_batch_create.restype = vp; L.opusgpu_ms_dec_batch_create.argtypes = [ci, ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    L.opusgpu_ms_decode_batch.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
+    L.opusgpu_ms_dec_batch_destroy.argtypes = [vp]; L.opusgpu_ms_dec_batch_destroy.restype = None
+    err = ci(); mp = bytes(mapping)
+    encs = [R.opus_multistream_encoder_create(Fs, channels, streams, coupled, mp, application, ctypes.byref(err)) for _ in range(B)]; assert all(encs)
+    decs = [R.opus_multistream_decoder_create(Fs, channels, streams, coupled, mp, ctypes.byref(err)) for _ in range(B)]; assert all(decs)
+    if bitrate:
+        R.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]
+        for e in encs: assert R.opus_multistream_encoder_ctl(e, 4002, bitrate) == 0
+    d = L.opusgpu_ms_dec_batch_create(B, Fs, channels, streams, coupled, mp, 0, ctypes.byref(err)); assert d and err.value == 0, err.value
+    nf = max(1, (frame * 50 + Fs - 1) // Fs); cap = (streams - 1) * (1276 * nf + 3) + 7662 + 3 * streams + 8
+    step = 48000 // Fs
+    sig = [np.ascontiguousarray(np.stack([speechy((frames * frame * step) // 960 + 2, 1, 41 * b + c, 960)[:, 0] for c in range(channels)], 1)[::step]) for b in range(B)]
+    data = np.zeros((B, cap), np.uint8); lens = np.zeros(B, np.int32)
+    pcm_out = np.zeros((B, frame, channels), np.int16); ns = np.zeros(B, np.int32); drng = np.zeros(B, np.uint32); ro = np.zeros((frame, channels), np.int16); fr = ctypes.c_uint32()
+    R.opus_multistream_decoder_ctl.argtypes = [vp, ci, vp]
+    for f in range(frames):
+        for b in range(B):
+            x = np.ascontiguousarray(sig[b][f * frame:(f + 1) * frame].astype(np.int16))
+            n = R.opus_multistream_encode(encs[b], x.ctypes.data, frame, data[b].ctypes.data, cap); assert n > 0
+            lens[b] = n
+        if corrupt and f == 1: lens[B - 1] = max(2 * streams - 1, lens[B - 1] // 2)       # truncated in the middle of a stream
+        r = L.opusgpu_ms_decode_batch(d, data.ctypes.data, cap, lens.ctypes.data, pcm_out.ctypes.data, frame, ns.ctypes.data, drng.ctypes.data); assert r == 0, r
+        for b in range(B):
+            k = R.opus_multistream_decode(decs[b], data[b].ctypes.data, int(lens[b]), ro.ctypes.data, frame, 0)
+            assert k == int(ns[b]), (f, b, k, int(ns[b]))
+            if k > 0:
+                R.opus_multistream_decoder_ctl(decs[b], 4031, ctypes.byref(fr))
+                assert np.array_equal(ro[:k], pcm_out[b, :k]) and fr.value == int(drng[b]), (f, b)
+    L.opusgpu_ms_dec_batch_destroy(d)
+
+DEC_CASES = [
+    dict(B=3, channels=6, streams=4, coupled=2, mapping=[0, 4, 1, 2, 3, 5], application=2049, bitrate=256000, corrupt=True),
+    dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=3),      # 40 ms multi-frame elementary packets, a muted channel
+    dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000),                 # SILK streams at 16 kHz
+]

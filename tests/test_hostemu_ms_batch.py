@@ -6,3 +6,10 @@ pytestmark = pytest.mark.skipif(ref_fx() is None, reason="oracle/_ref not built"
 
 @pytest.mark.parametrize("case", range(len(ms_batch_check.CASES)))
 def test_emu_ms_batch(case): ms_batch_check.check("emu", **ms_batch_check.CASES[case])
+
+@pytest.mark.parametrize("case", range(len(ms_batch_check.DEC_CASES)))
+def test_emu_ms_decode_batch(case): ms_batch_check.check_ms_decode("emu", **ms_batch_check.DEC_CASES[case])
+
+@pytest.mark.parametrize("channels,analysis", [(4, False), (9, False), (6, True)])
+def test_emu_projection_batches(channels, analysis):
+    ms_batch_check.check_projection("emu", B=2, channels=channels, bitrate=channels * 48000, complexity=10 if analysis else 5, analysis=analysis)
