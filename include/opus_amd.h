@@ -397,10 +397,11 @@ OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32
  * B encoders with one layout, i.e. B x opus_multistream_encoder_create(Fs, channels, streams, coupled_streams, mapping, application)
  * (reference include/opus_multistream.h:260, src/opus_multistream_encoder.c:841-1060), stepped together with their B x streams elementary encoders resident in HBM:
  * channel extraction, the elementary encodes and the self-delimited packing (RFC 6716 Appendix B) are launches on one HIP stream, no host round trip.
- * mapping_family 0 / 255 (plain layouts), 2 (ambisonics layouts: CELT-only elementary encoders) or 3 (projection: the layout and mixing matrix of
+ * mapping_family 0 / 255 (plain layouts), 1 (surround: the Vorbis layouts with their per-frame masking analysis, reference src/opus_multistream_encoder.c:230, on the
+ * device; pass the streams / coupled streams opus_multistream_surround_encoder_create reports), 2 (ambisonics layouts: CELT-only elementary encoders) or 3 (projection: the layout and mixing matrix of
  * opus_projection_ambisonics_encoder_create, reference src/opus_projection_encoder.c:176, mixed on the device as src/mapping_matrix.c:148 does; `mapping` is ignored); VBR; max_data_bytes large enough for every stream to be
  * offered its own cap ((streams - 1) * 1279 + 7662 + 3 * streams + 8 for frames <= 20 ms), else OPUS_BUFFER_TOO_SMALL -- the classic opus_multistream_encode
- * serves tight buffers, hard CBR and the surround family.  Packets are byte-identical to the reference's. */
+ * serves tight buffers and hard CBR.  Packets are byte-identical to the reference's. */
 typedef struct OpusGpuMsEncBatch OpusGpuMsEncBatch;
 OPUS_AMD_EXPORT OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 nb_encoders, opus_int32 Fs, int channels, int mapping_family, int streams, int coupled_streams,
       const unsigned char *mapping, int application, int device, int *error);

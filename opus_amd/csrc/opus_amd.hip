@@ -183,7 +183,10 @@ extern "C" __global__ void __launch_bounds__(64, 2)
 oa_surround_kernel(const i16 *pcm, int len, int channels, int Fs, i32 *mem, i32 *preemph_mem, i32 *bandLogE)
 {
    __shared__ SurroundLds lds;
-   oa_surround_channel_wave((WV_LDS SurroundLds *)&lds, pcm, len, channels, (int)blockIdx.x, Fs, mem, preemph_mem, bandLogE);
+   /* grid = encoders x channels (the classic entry point launches one encoder): encoder b's input, state and result rows */
+   const int b = (int)blockIdx.x / channels, c = (int)blockIdx.x - b * channels;
+   oa_surround_channel_wave((WV_LDS SurroundLds *)&lds, pcm + (size_t)b * len * channels, len, channels, c, Fs, mem + (size_t)b * channels * 120, preemph_mem + (size_t)b * channels,
+         bandLogE + (size_t)b * channels * 21);
 }
 
 /* final-gather compaction: packet s (lens[s] bytes of its out slot) -> packed[offs[s] ...], one wave per packet */

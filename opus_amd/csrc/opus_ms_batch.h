@@ -10,9 +10,9 @@
  *                        offsets, then the wave copies packet after packet; the encoder's final range is the XOR over its streams.
  * The byte budget the reference hands to stream s depends on what streams 0..s-1 used (:1016-1026); when the caller's buffer is large enough for every stream
  * to be offered the elementary encoder's own cap, the budgets are all the same and the streams are independent -- that is the case this batch serves (it checks
- * it and answers OPUS_BUFFER_TOO_SMALL otherwise; tight buffers and hard CBR go through the classic entry points).  Mapping families without a per-frame
- * analysis: 0 / 255 (none) and 2 (ambisonics: elementary encoders forced to CELT); surround (family 1 > 2 channels) needs its masking analysis per frame and
- * stays with the classic path. */
+ * it and answers OPUS_BUFFER_TOO_SMALL otherwise; tight buffers and hard CBR go through the classic entry points).  Mapping families: 0 / 255 (plain), 2 (ambisonics:
+ * elementary encoders forced to CELT), 3 (projection: the mixing matrix applied on the device, opus_ms_dec_batch.h) and 1 (surround: the masking analysis of every
+ * encoder and the energy masks of its streams are two more launches per frame, oa_surround_kernel + oa_ms_surround_mask_kernel). */
 #ifndef OPUS_AMD_MS_BATCH_H
 #define OPUS_AMD_MS_BATCH_H
 
@@ -48,6 +48,45 @@ oa_ms_split_sig_kernel(const i16 *pcm, int frame, int nch, const i32 *chan, int 
       const int c = chan[2 * nc + (s - nc)];
       i32 *d = pm + ((size_t)b * nm + (s - nc)) * frame;
       for (int i = threadIdx.x; i < frame; i += 64) d[i] = shl32((i32)src[(size_t)i * nch + c], 12);
+   }
+}
+
+/* surround (mapping family 1, > 2 channels): what couples the channels (opus_surround_host.h: oa_surround_couple, src/opus_multistream_encoder.c:310-376) and hands every
+ * elementary encoder its energy mask (:1005-1014), for all B encoders on the device.  One wave per encoder, lane = band: the per-channel log energies of oa_surround_kernel in
+ * E [B][channels][21] become signal-to-mask ratios in place and go straight into the stream records of the two groups. */
+WV_TABLE unsigned char oa_surround_pos_dev[9][8] = {{0}, {0}, {0}, {1, 2, 3}, {1, 3, 1, 3}, {1, 2, 3, 1, 3}, {1, 2, 3, 1, 3, 0}, {1, 2, 3, 1, 3, 2, 0}, {1, 2, 3, 1, 3, 1, 3, 0}};
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_surround_mask_kernel(i32 *E, int channels, const i32 *chan, int nc, int nm, OaShStream *shc, OaShStream *shm, OaStream *cc, OaStream *cm)
+{
+   const int b = blockIdx.x, i = threadIdx.x;
+   i32 *e = E + (size_t)b * channels * 21;
+   if (i < 21) {
+      i32 m0 = -(28 << 24), m2 = -(28 << 24);
+      for (int c = 0; c < channels; c++) {
+         const int p = oa_surround_pos_dev[channels][c]; const i32 v = e[21 * c + i];
+         if (p == 1) m0 = oa_logsum(m0, v);
+         else if (p == 3) m2 = oa_logsum(m2, v);
+         else if (p == 2) { m0 = oa_logsum(m0, v - (1 << 23)); m2 = oa_logsum(m2, v - (1 << 23)); }
+      }
+      const i32 m1 = m0 < m2 ? m0 : m2, off = oa_log2_q10(32768 / (channels - 1)) >> 1;
+      for (int c = 0; c < channels; c++) {
+         const int p = oa_surround_pos_dev[channels][c];
+         e[21 * c + i] = p != 0 ? e[21 * c + i] - ((p == 1 ? m0 : p == 2 ? m1 : m2) + off) : 0;
+      }
+      for (int s = 0; s < nc; s++) {
+         const int l = chan[2 * s], r = chan[2 * s + 1]; const size_t k = (size_t)b * nc + s;
+         i32 *mask = shc ? shc[k].energy_mask : cc[k].energy_mask;
+         mask[i] = e[21 * l + i]; mask[21 + i] = e[21 * r + i];
+      }
+      for (int s = 0; s < nm; s++) {
+         const int c = chan[2 * nc + s]; const size_t k = (size_t)b * nm + s;
+         i32 *mask = shm ? shm[k].energy_mask : cm[k].energy_mask;
+         mask[i] = e[21 * c + i];
+      }
+   }
+   if (i == 0) {
+      for (int s = 0; s < nc; s++) { const size_t k = (size_t)b * nc + s; if (shc) { shc[k].cfg.energy_mask_on = 1; shc[k].s.celt_mask_cleared = 0; } else cc[k].energy_mask_on = 1; }
+      for (int s = 0; s < nm; s++) { const size_t k = (size_t)b * nm + s; if (shm) { shm[k].cfg.energy_mask_on = 1; shm[k].s.celt_mask_cleared = 0; } else cm[k].energy_mask_on = 1; }
    }
 }
 
@@ -112,6 +151,7 @@ struct OpusGpuMsEncBatch {
    OpusGpuEncBatch *bc, *bm;             /* the B * nc coupled and B * nm mono elementary encoders */
    i32 *d_chan;
    i16 *d_pc, *d_pm; size_t pc_cap, pm_cap;
+   i32 *d_surround;                                                       /* surround: [B][channels][120] window memory | [B][channels] pre-emphasis memory | [B][channels][21] energies / ratios */
    i16 *d_M, *d_mixed; size_t mixed_cap; i32 *d_apc, *d_apm; size_t apc_cap, apm_cap;      /* mapping family 3 (projection): the mixing matrix [C][C], the mixed input, the un-mixed channels for the analysis */
    u8 *d_pkc, *d_pkm; i32 *d_lc, *d_lm; u32 *d_rc, *d_rm; opus_int32 stride;
    /* staging of the host-pointer entry */
@@ -125,7 +165,7 @@ void opusgpu_ms_enc_batch_destroy(OpusGpuMsEncBatch *m)
    if (m->bc) opusgpu_enc_batch_destroy(m->bc);
    if (m->bm) opusgpu_enc_batch_destroy(m->bm);
    (void)hipSetDevice(m->device);
-   void *bufs[] = {m->d_M, m->d_mixed, m->d_apc, m->d_apm, m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
+   void *bufs[] = {m->d_surround, m->d_M, m->d_mixed, m->d_apc, m->d_apm, m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
    for (void *p : bufs) if (p) (void)hipFree(p);
    free(m->proto);
    delete m;
@@ -137,9 +177,14 @@ OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int 
 {
    int err = OPUS_OK;
    OpusGpuMsEncBatch *m = nullptr;
-   if (B <= 0 || !mapping || (mapping_family != 0 && mapping_family != 255 && mapping_family != 2 && mapping_family != 3)) err = mapping_family == 1 ? OPUS_UNIMPLEMENTED : OPUS_BAD_ARG;
-   int o1 = 0;
+   if (B <= 0 || !mapping || (mapping_family != 0 && mapping_family != 255 && mapping_family != 1 && mapping_family != 2 && mapping_family != 3)) err = OPUS_BAD_ARG;
+   int o1 = 0, map_type = mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE, lfe = -1;
    unsigned char ident[255];
+   if (err == OPUS_OK && mapping_family == 1) {                             /* surround: the Vorbis layout opus_multistream_surround_encoder_create derives (the caller passes the same streams / coupled) */
+      int ps = 0, pc = 0;
+      if (oa_surround_layout(channels, 1, &ps, &pc, ident, &map_type, &lfe) != OPUS_OK || ps != streams || pc != coupled_streams) err = OPUS_BAD_ARG;
+      mapping = ident;
+   }
    if (err == OPUS_OK && mapping_family == 3) {                             /* projection: the layout opus_projection_ambisonics_encoder_init derives, identity mapping, mixing matrix of the order */
       int ps = 0, pc = 0;
       if (oa_proj_layout(channels, 3, &ps, &pc, &o1) != OPUS_OK || o1 < 2 || o1 > 6 || ps != streams || pc != coupled_streams || channels > OA_PROJ_MAXC) err = OPUS_BAD_ARG;
@@ -149,9 +194,9 @@ OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int 
    OpusMSEncoder *proto = nullptr;
    if (err == OPUS_OK) {
       const opus_int32 sz = opus_multistream_encoder_get_size(streams, coupled_streams);
-      proto = sz > 0 ? (OpusMSEncoder *)malloc((size_t)sz) : nullptr;
+      proto = sz > 0 ? (OpusMSEncoder *)malloc((size_t)sz + (map_type == OA_MAP_SURROUND ? (size_t)channels * (120 + 1) * sizeof(opus_int32) : 0)) : nullptr;      /* (a surround encoder carries its analysis memory behind the records: opus_multistream_surround_encoder_get_size) */
       if (!proto) err = sz > 0 ? OPUS_ALLOC_FAIL : OPUS_BAD_ARG;
-      else err = oa_ms_encoder_init_impl(proto, Fs, channels, streams, coupled_streams, mapping, application, mapping_family == 2 ? OA_MAP_AMBISONICS : OA_MAP_NONE, -1);      /* (family 3: opus_projection_ambisonics_encoder_init builds a PLAIN multistream encoder behind its matrix, opus_projection_encoder.c:224) */
+      else err = oa_ms_encoder_init_impl(proto, Fs, channels, streams, coupled_streams, mapping, application, map_type, lfe);      /* (family 3: opus_projection_ambisonics_encoder_init builds a PLAIN multistream encoder behind its matrix, opus_projection_encoder.c:224) */
    }
    if (err == OPUS_OK) {
       m = new OpusGpuMsEncBatch();
@@ -173,6 +218,11 @@ OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 B, opus_int32 Fs, int 
                hipMalloc((void **)&m->d_rc, nstr * 4 + 4) == hipSuccess && hipMalloc((void **)&m->d_rm, nstr * 4 + 4) == hipSuccess &&
                hipMalloc((void **)&m->d_lens, (size_t)B * 4) == hipSuccess && hipMalloc((void **)&m->d_rng, (size_t)B * 4) == hipSuccess;
          if (!ok) err = OPUS_ALLOC_FAIL;
+      }
+      if (err == OPUS_OK && lfe >= 0 && m->bm) for (int b = 0; b < B && err == OPUS_OK; b++) err = opusgpu_enc_batch_ctl(m->bm, b * m->nm + (lfe - m->nc), OPUS_SET_LFE_REQUEST, 1);      /* (:499) */
+      if (err == OPUS_OK && map_type == OA_MAP_SURROUND) {
+         const size_t nw = (size_t)B * channels * (120 + 1 + 21);
+         if (hipMalloc((void **)&m->d_surround, nw * 4) != hipSuccess || hipMemset(m->d_surround, 0, nw * 4) != hipSuccess) err = OPUS_ALLOC_FAIL;
       }
       if (err == OPUS_OK && mapping_family == 3) {
          const OaMatrixDesc *mix = &oa_pm_mixing[o1 - 2];
@@ -226,11 +276,27 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
          const int e = k < m->nc ? opusgpu_enc_batch_ctl(m->bc, b * m->nc + k, OPUS_SET_BITRATE_REQUEST, rates[k]) : opusgpu_enc_batch_ctl(m->bm, b * m->nm + (k - m->nc), OPUS_SET_BITRATE_REQUEST, rates[k]);
          if (e != OPUS_OK) return e;
       }
+      if (m->proto->mapping_type == OA_MAP_SURROUND) {                     /* what opus_multistream_encode_native sets on every elementary encoder of a surround layout (:965-985) */
+         opus_int32 equiv_rate = m->proto->bitrate_bps;
+         if (frame_size * 50 < Fs) equiv_rate -= 60 * (Fs / frame_size - 50) * m->nch;
+         const opus_int32 bw = equiv_rate > 10000 * m->nch ? OPUS_BANDWIDTH_FULLBAND : equiv_rate > 7000 * m->nch ? OPUS_BANDWIDTH_SUPERWIDEBAND : equiv_rate > 5000 * m->nch ? OPUS_BANDWIDTH_WIDEBAND : OPUS_BANDWIDTH_NARROWBAND;
+         int e = OPUS_OK;
+         if (m->bc) { e = opusgpu_enc_batch_ctl(m->bc, -1, OPUS_SET_BANDWIDTH_REQUEST, bw); if (e == OPUS_OK) e = opusgpu_enc_batch_ctl(m->bc, -1, OPUS_SET_FORCE_MODE_REQUEST, OPUS_MODE_CELT_ONLY); if (e == OPUS_OK) e = opusgpu_enc_batch_ctl(m->bc, -1, OPUS_SET_FORCE_CHANNELS_REQUEST, 2); }
+         if (e == OPUS_OK && m->bm) e = opusgpu_enc_batch_ctl(m->bm, -1, OPUS_SET_BANDWIDTH_REQUEST, bw);
+         if (e != OPUS_OK) return e;
+      }
       m->last_frame_size = frame_size;
    }
    const size_t need_c = (size_t)m->B * m->nc * frame_size * 2 * sizeof(i16), need_m = (size_t)m->B * m->nm * frame_size * sizeof(i16);
    if (need_c > m->pc_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pc) (void)hipFree(m->d_pc); m->d_pc = nullptr; m->pc_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pc, need_c)); m->pc_cap = need_c; }
    if (need_m > m->pm_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_pm) (void)hipFree(m->d_pm); m->d_pm = nullptr; m->pm_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_pm, need_m)); m->pm_cap = need_m; }
+   if (m->d_surround && m->application != OPUS_APPLICATION_RESTRICTED_SILK) {  /* surround_analysis (:230) of all B encoders, then the masks into the stream records */
+      i32 *mem = m->d_surround, *pre = mem + (size_t)m->B * m->nch * 120, *E = pre + (size_t)m->B * m->nch;
+      hipLaunchKernelGGL(oa_surround_kernel, dim3((unsigned)(m->B * m->nch)), dim3(64), 0, s, (const i16 *)d_pcm, frame_size, m->nch, (int)Fs, mem, pre, E);
+      hipLaunchKernelGGL(oa_ms_surround_mask_kernel, dim3((unsigned)m->B), dim3(64), 0, s, E, m->nch, (const i32 *)m->d_chan, m->nc, m->nm,
+            m->bc && m->bc->kind ? m->bc->d_sh : nullptr, m->bm && m->bm->kind ? m->bm->d_sh : nullptr, m->bc && !m->bc->kind ? m->bc->d_streams : nullptr, m->bm && !m->bm->kind ? m->bm->d_streams : nullptr);
+      HIPCHECK(hipGetLastError());
+   }
    const i16 *src = (const i16 *)d_pcm;
    if (m->d_M) {                                                           /* projection: mix on the device, and give the analyses the caller's un-mixed channels */
       const size_t need_x = (size_t)m->B * frame_size * m->nch * sizeof(i16);

@@ -7,9 +7,9 @@
 /* position of each channel of the vorbis layouts in the left-centre-right mix: 0 = not mixed (LFE), 1 = left, 2 = centre, 3 = right */
 static const unsigned char oa_surround_pos[9][8] = {{0}, {0}, {0}, {1, 2, 3}, {1, 3, 1, 3}, {1, 2, 3, 1, 3}, {1, 2, 3, 1, 3, 0}, {1, 2, 3, 1, 3, 2, 0}, {1, 2, 3, 1, 3, 1, 3, 0}};
 /* celt_log2 of the fixed-point build (celt/mathops.h:391): Q14 in, Q10 out, 4th-order polynomial on the mantissa */
-static int oa_log2_q10(opus_int32 x)
+WV_HD int oa_log2_q10(opus_int32 x)
 {
-   static const opus_int16 C[5] = {-6801 + (1 << (13 - 10)), 15746, -5217, 2545, -1401};
+   const opus_int16 C[5] = {-6801 + (1 << (13 - 10)), 15746, -5217, 2545, -1401};
    if (x == 0) return -32767;
    int i = 31; while (!(x >> i)) i--;
    const opus_int16 n = (opus_int16)((i - 15 > 0 ? x >> (i - 15) : x << (15 - i)) - 32768 - 16384);
@@ -20,9 +20,9 @@ static int oa_log2_q10(opus_int32 x)
 /* log2(2^a + 2^b) in Q24 (DB_SHIFT), piecewise linear in the difference, half-unit steps (logSum :193).  The reference's function is declared to return opus_val16
  * -- 16 bits in the fixed-point build -- so what reaches the masks is the low half of the Q24 sum, sign-extended (gcc's modulo conversion); the elementary encoders'
  * allocation follows from exactly that value, so it is kept bit for bit (found by tools/encode_trace_compare.py on the reference's surround_analysis_uninit regression) */
-static opus_int32 oa_logsum(opus_int32 a, opus_int32 b)
+WV_HD opus_int32 oa_logsum(opus_int32 a, opus_int32 b)
 {
-   static const opus_int32 tab[17] = {8388608, 4907022, 2700528, 1425434, 733691, 372406, 187635, 94181, 47183, 0, 0, 0, 0, 0, 0, 0, 0};   /* GCONST(.5, .2924813, .1609640, ...) */
+   const opus_int32 tab[17] = {8388608, 4907022, 2700528, 1425434, 733691, 372406, 187635, 94181, 47183, 0, 0, 0, 0, 0, 0, 0, 0};   /* GCONST(.5, .2924813, .1609640, ...) */
    const opus_int32 hi = a > b ? a : b, diff = a > b ? a - b : b - a;
    if (!(diff < (8 << 24))) return (opus_int16)hi;
    const int low = diff >> 23;

@@ -165,3 +165,37 @@ DEC_CASES = [
     dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=3),      # 40 ms multi-frame elementary packets, a muted channel
     dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000),                 # SILK streams at 16 kHz
 ]
+
+def check_surround(which, B, channels, application=2049, frames=4, frame=960, Fs=48000, bitrate=None):
+    """B surround encoders (mapping family 1: masking analysis + energy masks on the device) against the reference's opus_multistream_surround_encoder + opus_multistream_encode"""
+    L = capi.load(which); R = capi.load("ref")
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    R.opus_multistream_surround_encoder_create.restype = vp
+    R.opus_multistream_surround_encoder_create.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    R.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ci]
+    err, s, c = ci(), ci(), ci(); refs = []
+    for b in range(B):
+        mp = ctypes.create_string_buffer(8)
+        r = R.opus_multistream_surround_encoder_create(Fs, channels, 1, ctypes.byref(s), ctypes.byref(c), mp, application, ctypes.byref(err)); assert r and err.value == 0
+        refs.append(r)
+    streams, coupled = s.value, c.value
+    L.opusgpu_ms_enc_batch_create.restype = vp
+    L.opusgpu_ms_enc_batch_create.argtypes = [ci, ci, ci, ci, ci, ci, ctypes.c_char_p, ci, ci, ctypes.POINTER(ci)]
+    L.opusgpu_ms_enc_batch_destroy.argtypes = [vp]; L.opusgpu_ms_enc_batch_destroy.restype = None
+    L.opusgpu_ms_enc_batch_ctl.argtypes = [vp, ci, ci]
+    L.opusgpu_ms_encode_batch.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
+    m = L.opusgpu_ms_enc_batch_create(B, Fs, channels, 1, streams, coupled, mp.raw, application, 0, ctypes.byref(err)); assert m and err.value == 0, err.value
+    if bitrate:
+        assert L.opusgpu_ms_enc_batch_ctl(m, 4002, bitrate) == 0
+        R.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]
+        for r in refs: assert R.opus_multistream_encoder_ctl(r, 4002, bitrate) == 0
+    cap = (streams - 1) * 1279 + 7662 + 3 * streams + 8
+    sig = [np.stack([(speechy(frames * frame // 960 + 2, 1, 23 * b + ch, 960)[:, 0] * (0.9 / (1 + ch % 3))).astype(np.int16) for ch in range(channels)], 1) for b in range(B)]
+    out = np.zeros((B, cap), np.uint8); lens = np.zeros(B, np.int32); rng = np.zeros(B, np.uint32); o = np.zeros(cap, np.uint8)
+    for f in range(frames):
+        pcm = np.ascontiguousarray(np.stack([x[f * frame:(f + 1) * frame] for x in sig]).astype(np.int16))
+        r = L.opusgpu_ms_encode_batch(m, pcm.ctypes.data, frame, out.ctypes.data, cap, cap, lens.ctypes.data, rng.ctypes.data); assert r == 0, r
+        for b in range(B):
+            n = R.opus_multistream_encode(refs[b], pcm[b].ctypes.data, frame, o.ctypes.data, cap)
+            assert n == int(lens[b]) and bytes(out[b, :n]) == bytes(o[:n]), (f, b, n, int(lens[b]))
+    L.opusgpu_ms_enc_batch_destroy(m)

@@ -21,3 +21,6 @@ def test_gpu_ms_decode_batch_config5_width():
 def test_gpu_projection_batches(channels, analysis):
     """projection encoder batch (device mixing) and decoder batch (device demixing), orders 1-5 with and without the non-diegetic pair, against opus_projection_encode / _decode"""
     ms_batch_check.check_projection("gpu", B=3, channels=channels, bitrate=channels * 48000, complexity=10 if analysis else 5, analysis=analysis, frames=6)
+
+@pytest.mark.parametrize("channels", [3, 4, 5, 6, 7, 8])
+def test_gpu_surround_batch(channels): ms_batch_check.check_surround("gpu", B=3, channels=channels, bitrate=channels * 56000, frames=8)

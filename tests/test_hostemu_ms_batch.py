@@ -13,3 +13,6 @@ def test_emu_ms_decode_batch(case): ms_batch_check.check_ms_decode("emu", **ms_b
 @pytest.mark.parametrize("channels,analysis", [(4, False), (9, False), (6, True)])
 def test_emu_projection_batches(channels, analysis):
     ms_batch_check.check_projection("emu", B=2, channels=channels, bitrate=channels * 48000, complexity=10 if analysis else 5, analysis=analysis)
+
+@pytest.mark.parametrize("channels", [3, 6, 8])
+def test_emu_surround_batch(channels): ms_batch_check.check_surround("emu", B=2, channels=channels, bitrate=channels * 56000)
