@@ -24,6 +24,7 @@ pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmc$c
 pmcd2|pmcd3|pmcd4) c=${step#pmcd}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmcd$c --decode > $O/pmcd$c.log 2>&1 ;;
 exp_occ) for pad in 0 20000 60000; do OPUS_AMD_SH_LDS_PAD=$pad timeout 300 python bench.py $B --config 3 > $O/bench3_pad$pad.log 2>&1; done ;;
 exp_lib) for f in $EXP_LIBS; do for c in $EXP_CONFIGS; do OPUS_AMD_LIB=$PWD/opus_amd/$f timeout 300 python bench.py $B --config $c > $O/bench${c}_$f.log 2>&1; done; done ;;
+msbatch) timeout 1500 python -m pytest tests/test_gpu_ms_batch.py tests/test_gpu_float_decoder_gate.py -x -q -s > $O/pytest_ms_batch.log 2>&1 ;;
 ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
 full) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1 ;;
 *) echo "unknown step $step" ;;
