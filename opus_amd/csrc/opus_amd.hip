@@ -231,11 +231,13 @@ oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T
 /* bytes of the per-stream output slot a call needs: the largest packet the call can return -- a coded frame never exceeds 1276 bytes, but a hard-CBR call is
  * padded to its byte budget whatever the frame size, up to the 1276*6 the reference clamps max_data_bytes to -- and for calls above 20 ms (repacketised
  * multi-frame packets, src/opus_encoder.c:1698-1838) the 48-byte staging head-room of oa_multiframe_* (opus_multiframe.h) */
-static opus_int32 oa_enc_out_stride_needed(opus_int32 Fs, int frame_size, opus_int32 max_data_bytes)
+static opus_int32 oa_enc_out_stride_needed(opus_int32 Fs, int frame_size, opus_int32 max_data_bytes, int hard_cbr = 1)
 {
    const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;
-   if (nf > 1) return max_data_bytes + 48;                                               /* repacketize_len = the caller's whole buffer with OPUS_BITRATE_MAX (:1757) */
-   return max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6;                         /* one frame: padded to min(max_data_bytes, 1276*6) (:1221, :1330, :2646) */
+   const opus_int32 mdb = max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6;          /* the reference clamps the byte budget of ANY call to 1276 * 6 before it does anything else (:1221): nothing larger is ever written */
+   if (nf > 1) return mdb + 48;                                                          /* repacketize_len <= the clamped budget (:1757) + the staging head-room */
+   if (!hard_cbr) return mdb < 1276 ? mdb : 1276;                                        /* one VBR frame: TOC + at most 1275 bytes */
+   return mdb;                                                                           /* one frame of a hard-CBR stream: padded to min(max_data_bytes, 1276 * 6) (:1330, :2646) */
 }
 static int oa_enc_frame_size_code(opus_int32 Fs, int application, int frame_size)
 {
@@ -263,6 +265,7 @@ struct OpusGpuEncBatch {
    OaStream *d_streams;
    std::vector<OaStream> h_streams;     /* host mirror of the configuration (state is authoritative on device) */
    bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
+   int any_cbr;                         /* some stream of the mirror is hard CBR (-1: not derived since the mirror last changed): sizes the output slot a call needs */
    int all_silk_pinned;
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
@@ -304,7 +307,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
@@ -354,6 +357,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   b->any_cbr = -1;
    if (request == OPUS_RESET_STATE) {
       /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
        * them into the mirror first (gathered on the device, one contiguous transfer) */
@@ -421,7 +425,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
       if (src->cfg.channels != b->channels || src->cfg.Fs != b->Fs) return OPUS_BAD_ARG;
       HIPCHECK(hipSetDevice(b->device));
       HIPCHECK(hipStreamSynchronize(b->stream));
-      b->h_sh[stream] = *src; b->cfg_dirty = true;
+      b->h_sh[stream] = *src; b->cfg_dirty = true; b->any_cbr = -1;
       HIPCHECK(hipMemcpy(b->d_sh + stream, src, sizeof(OaShStream), hipMemcpyHostToDevice));
       return OPUS_OK;
    }
@@ -429,7 +433,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
    if (src->cfg.channels != b->channels) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   b->h_streams[stream] = *src;
+   b->h_streams[stream] = *src; b->any_cbr = -1;
    HIPCHECK(hipMemcpy(b->d_streams + stream, src, sizeof(OaStream), hipMemcpyHostToDevice));
    return OPUS_OK;
 }
@@ -530,6 +534,15 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
+static int oa_batch_any_cbr(OpusGpuEncBatch *b)
+{
+   if (b->any_cbr < 0) {
+      int any = 0;
+      for (opus_int32 i = 0; !any && i < b->n_act; i++) any = b->kind ? !b->h_sh[i].cfg.use_vbr : !b->h_streams[i].cfg.use_vbr;
+      b->any_cbr = any;
+   }
+   return b->any_cbr;
+}
 /* d_apcm (may be NULL): the same samples in the encoder's signal domain (int32, Q12 below int16 full scale: src/opus_encoder.c FLOAT2SIG / INT24TOSIG), which the
  * 24-bit and float entry points hand to the analysis instead of the rounded int16 samples (downmix_int24 :804, downmix_float :748) */
 int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out,
@@ -538,7 +551,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
    { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
-   if (out_stride < oa_enc_out_stride_needed(b->Fs, frame_size, max_data_bytes)) return OPUS_BUFFER_TOO_SMALL;
+   if (out_stride < oa_enc_out_stride_needed(b->Fs, frame_size, max_data_bytes, oa_batch_any_cbr(b))) return OPUS_BUFFER_TOO_SMALL;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
    if (b->kind) {
@@ -681,7 +694,7 @@ static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][A
 struct OaEncCall {
    OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
    int kind, frame_size, application, channels; opus_int32 Fs, max_data_bytes;
-   int ret; bool done;
+   int ret; bool done; size_t tid;
    const void *who() const { return st; }
    bool same_shape(const OaEncCall &o) const
    {
@@ -769,6 +782,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    }
    const void *rec_src = n > 1 ? (const void *)recs : kind ? (const void *)&h.st->sh : (const void *)&h.st->s;
    HIPCHECK(hipMemcpy(kind ? (void *)b->d_sh : (void *)b->d_streams, rec_src, rec * (size_t)n, hipMemcpyHostToDevice));
+   b->any_cbr = -1;
    if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = g[i]->st->sh.cfg; b->cfg_dirty = true; }     /* the launch's host-side decisions follow the records it carries */
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = g[i]->st->s.cfg;
    std::vector<unsigned char> out((size_t)stride * n);
@@ -1080,7 +1094,7 @@ struct OpusDecoder { opus_uint32 magic; opus_int32 Fs; opus_int32 decode_gain; o
 static OpusGpuDecBatch *g_classic_dec[5][2];
 struct OaDecCall {
    OpusDecoder *st; const unsigned char *data; opus_int32 len; opus_int16 *pcm; int frame_size, decode_fec, channels; opus_int32 Fs;
-   int ret; bool done;
+   int ret; bool done; size_t tid;
    const void *who() const { return st; }
    bool same_shape(const OaDecCall &o) const { return Fs == o.Fs && channels == o.channels && frame_size == o.frame_size && decode_fec == o.decode_fec; }
 };
