@@ -1,0 +1,17 @@
+"""The SILK-capable encoder's kernel pipeline (front / quantiser / back: opus_amd/csrc/opus_sh_split.h) against its one-kernel path on the CPU wave emulator: identical packets,
+final ranges AND stream records byte for byte over the case matrix of tools/split_check.py (configs 3 / 4, automatic modes, CBR, tight CVBR, 10 ms NB / MB with per-stream
+settings, stereo SILK, calls the front kernel hands back), in both quantiser forms.  The emulator also watches every launch's dynamic LDS (hip_stub.h) and runs the matrix a
+second time with positive garbage in "device" memory (OA_EMU_FILL=0x5A: an index read from an unloaded word faults here as it would on the GPU)."""
+import os, sys, pytest
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from reflib import ref_fx
+pytestmark = pytest.mark.skipif(ref_fx() is None, reason="oracle/_ref not built")
+
+@pytest.mark.parametrize("fill", ["0xA5", "0x5A"])
+def test_emu_split_path_equals_one_kernel_path(fill, monkeypatch, tmp_path):
+    import split_check
+    monkeypatch.setenv("OA_EMU_FILL", fill)
+    bad, stats = split_check.compare("emu", tmpdir=str(tmp_path), verbose=False)
+    assert not bad, bad
+    assert stats["config3"] == (444, 0) and stats["config4"] == (152, 0) and stats["audio_auto"][1] > 0          # (kept, handed back): the forced modes keep every call, the automatic ones hand some back

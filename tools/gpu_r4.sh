@@ -25,6 +25,8 @@ pmcd2|pmcd3|pmcd4) c=${step#pmcd}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/p
 exp_occ) for pad in 0 20000 60000; do OPUS_AMD_SH_LDS_PAD=$pad timeout 300 python bench.py $B --config 3 > $O/bench3_pad$pad.log 2>&1; done ;;
 exp_lib) for f in $EXP_LIBS; do for c in $EXP_CONFIGS; do OPUS_AMD_LIB=$PWD/opus_amd/$f timeout 300 python bench.py $B --config $c > $O/bench${c}_$f.log 2>&1; done; done ;;
 msbatch) timeout 1500 python -m pytest tests/test_gpu_ms_batch.py tests/test_gpu_float_decoder_gate.py -x -q -s > $O/pytest_ms_batch.log 2>&1 ;;
+latency) for m in 0 1; do OPUS_AMD_SH_SPLIT=$m timeout 600 python tools/classic_latency.py 200 > $O/classic_latency_split$m.log 2>&1; done; for c in 2 3 4; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --streams 1 --config $c > $O/bench${c}_one_stream.log 2>&1; done ;;
+soak) timeout 1500 python tools/parity_soak.py --float-analysis --streams ${SOAK_STREAMS:-512} --frames ${SOAK_FRAMES:-600} --configs 2,3,4 > $O/parity_soak_analysis.log 2>&1 ;;
 ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
 full) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1 ;;
 *) echo "unknown step $step" ;;
