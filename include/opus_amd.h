@@ -127,7 +127,7 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream,
  * out_stride must hold the largest packet the call can return, with m = min(max_data_bytes, 1276 * 6) (the reference clamps every call's budget to that, src/opus_encoder.c:1221):
  *   frames up to 20 ms, every stream VBR:        min(m, 1276)      (TOC + at most 1275 bytes)
  *   frames up to 20 ms, some stream hard CBR:     m                 (a CBR packet is padded to its budget, :2646)
- *   calls above 20 ms (multi-frame packets):     m + 48            (the repacketiser's staging head-room)
+ *   calls above 20 ms (multi-frame packets):     max_data_bytes + 48 (hard CBR / OPUS_BITRATE_MAX pad such a packet to the caller's whole buffer, :1757; + staging head-room)
  * else OPUS_BUFFER_TOO_SMALL.  1280 serves every VBR batch of 2.5-20 ms frames whatever max_data_bytes is. */
 OPUS_AMD_EXPORT int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);

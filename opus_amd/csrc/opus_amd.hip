@@ -234,8 +234,8 @@ oa_encode_frames_kernel(OaStream *streams, const i16 *pcm, int frame_size, int T
 static opus_int32 oa_enc_out_stride_needed(opus_int32 Fs, int frame_size, opus_int32 max_data_bytes, int hard_cbr = 1)
 {
    const int nf = frame_size > Fs / 50 ? (frame_size * 50 + Fs - 1) / Fs : 1;
-   const opus_int32 mdb = max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6;          /* the reference clamps the byte budget of ANY call to 1276 * 6 before it does anything else (:1221): nothing larger is ever written */
-   if (nf > 1) return mdb + 48;                                                          /* repacketize_len <= the clamped budget (:1757) + the staging head-room */
+   const opus_int32 mdb = max_data_bytes < 1276 * 6 ? max_data_bytes : 1276 * 6;          /* a single coded frame never gets more than 1276 * 6 bytes of budget (:1221) */
+   if (nf > 1) return max_data_bytes > 0x7fffffff - 64 ? 0x7fffffff - 16 : max_data_bytes + 48;   /* multi-frame packets: with hard CBR / OPUS_BITRATE_MAX the reference pads the repacketised packet to the caller's WHOLE buffer, beyond 1276 * 6 (:1757, :1823), + the staging head-room */
    if (!hard_cbr) return mdb < 1276 ? mdb : 1276;                                        /* one VBR frame: TOC + at most 1275 bytes */
    return mdb;                                                                           /* one frame of a hard-CBR stream: padded to min(max_data_bytes, 1276 * 6) (:1330, :2646) */
 }

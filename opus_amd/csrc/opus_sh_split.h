@@ -78,17 +78,31 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       const int nSamplesToBuffer = imin(wv_uni(c0->frame_length) - wv_uni(c0->inputBufIx), k.nSamplesToBufferMax);
       const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
       ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
+      if (sc.nChannelsInternal == 2) ok = ok && wv_uni(E->ch[1].inputBufIx) == 0;
       if (!ok) { sh_front_decline(ct, slow_list, slow_count, s); return; }
-      se_call_buffer_wave(S, &sc, pcm_hp, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
+      /* the channels' input buffers (OaSilkEnc.inbuf) are scratch in this kernel: every sample of them that a later stage reads is written by this call (the whole frame is
+       * buffered in one go, the two samples in front of it come from the stereo state), they live at the end of the phase union (se_inbuf<1>) from the resampler to the heads
+       * of the frames and go back to the record before the first analysis overwrites the union.  What this call does not write (a channel the call leaves alone) is brought
+       * in first, so that the record ends up as the one-kernel path leaves it */
+      for (int n = 0; n < CC; n++) sh_copy_words((WV_LDS i32 *)se_inbuf<1>(S, n), (const i32 *)gs->silk.inbuf[n], SE_INBUF_WORDS);
+      wv_sync();
+      se_call_buffer_wave<1>(S, &sc, pcm_hp, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
    }
    wv_sync();
-   se_call_frame_head_wave(S, &sc, &L->ec, SH_PKT(L) + 1, &gs->lbrr, wv_uni(sh->activity), 0);
+   se_call_frame_head_wave<1>(S, &sc, &L->ec, SH_PKT(L) + 1, &gs->lbrr, wv_uni(sh->activity), 0);
+   /* the head of every channel that is coded (seed, variable low-pass, the frame into x_buf: all of it the channel's own state) -- the last reader of the input buffers */
+   for (int n = 0; n < sc.nChannelsInternal; n++) {
+      const i32 rate = sc.nChannelsInternal == 1 ? wv_uni(S->r[4]) : wv_uni(S->r[5 + n]);
+      if (rate > 0) se_frame_head_wave<1>(S, &E->ch[n]);
+   }
+   wv_sync();
+   for (int n = 0; n < CC; n++) sh_copy_words((i32 *)gs->silk.inbuf[n], (const WV_LDS i32 *)se_inbuf<1>(S, n), SE_INBUF_WORDS);
+   wv_sync();
    int nq = 0;
    for (int n = 0; n < sc.nChannelsInternal; n++) {
       const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
       if (p.channelRate_bps > 0) {
          WV_LDS OaSilkEncChannel *c = &E->ch[n];
-         se_frame_head_wave(S, c);
          se_frame_analysis_wave(S, c, p.condCoding);
          wv_sync();
          {  /* the channel's job for the quantiser kernel */

@@ -43,12 +43,24 @@ struct SilkEncLds {
 #define SE_FRONT_LDS_BYTES(channels) (offsetof(SilkEncLds, st) + offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel))
 #define SE_STATE_LITE_WORDS(channels) ((int)((offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel)) / 4))
 #define SE_TAIL_WORDS ((int)(sizeof(OaSilkEncTail) / 4))
-#define SE_STATE_WORDS(channels) (SE_STATE_LITE_WORDS(channels) + (channels) * SE_TAIL_WORDS)       /* words a frame-step moves each way */
+#define SE_INBUF_WORDS ((int)(sizeof(int16_t) * (SE_MAX_FRAME + 2) / 4))
+#define SE_STATE_WORDS(channels) (SE_STATE_LITE_WORDS(channels) + (channels) * (SE_INBUF_WORDS + SE_TAIL_WORDS))       /* words a frame-step moves each way */
 /* the SILK state between the stream record and the wave's LDS (either direction): header + the channels in use, and their tails when the kernel holds them */
 template <class PD, class PS> WV_DEV void se_state_copy_wave(PD d, PS s, int channels, int with_tail)
 {
    FOR_LANES(i, SE_STATE_LITE_WORDS(channels)) d[i] = s[i];
-   if (with_tail) { const int o = (int)(offsetof(OaSilkEnc, tail) / 4); FOR_LANES(i, channels * SE_TAIL_WORDS) d[o + i] = s[o + i]; }
+   if (with_tail) {
+      const int o = (int)(offsetof(OaSilkEnc, tail) / 4), b = (int)(offsetof(OaSilkEnc, inbuf) / 4);
+      FOR_LANES(i, channels * SE_INBUF_WORDS) d[b + i] = s[b + i];
+      FOR_LANES(i, channels * SE_TAIL_WORDS) d[o + i] = s[o + i];
+   }
+}
+/* a channel's input buffer: in the staged state, or -- FRONT: the split path's front kernel, for which it is scratch between the resampler and the frame heads -- at the end of
+ * the phase union (behind everything the stages that run while it is live put there: the resampler ring, the stereo work arrays, the VAD scratch) */
+template <int FRONT> WV_DEV WV_LDS i16 *se_inbuf(WV_LDS SilkEncLds *S, int n)
+{
+   if (FRONT) return (WV_LDS i16 *)((WV_LDS char *)&S->u + sizeof(S->u) - (size_t)(2 - n) * sizeof(S->st.inbuf[0]));
+   return S->st.inbuf[n];
 }
 WV_DEV WV_LDS OaSilkEncTail *se_tail(WV_LDS SilkEncLds *S, const WV_LDS OaSilkEncChannel *c) { return &S->st.tail[c == &S->st.ch[1] ? 1 : 0]; }
 /* the quantiser state starts over if someone asked for it since its last use (silk_setup_fs: control_codec.c:241-246; the side channel after mid-only frames: enc_API.c:449-456) */
@@ -417,15 +429,16 @@ template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) 
  *   se_frame_analysis_wave  :130-160  pitch, noise shaping, prediction coefficients, gains  -> ctl, c->indices
  *   se_frame_quant_wave     :162-378  LBRR, the rate-control loop: NSQ -> indices -> pulses -> bits
  *   se_frame_finish_wave    :380-389  x_buf shift, what the next frame conditions on */
-WV_DEV void se_frame_head_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
+template <int FRONT = 0> WV_DEV void se_frame_head_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
 {
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+   WV_LDS i16 *inputBuf = se_inbuf<FRONT>(S, c == &S->st.ch[1] ? 1 : 0);
    SE_PHASE(S, 2);
    LANE0 {
       c->indices.Seed = (i8)(c->frameCounter++ & 3);
-      se_lp_variable_cutoff(c, c->inputBuf + 1, c->frame_length);
+      se_lp_variable_cutoff(c, inputBuf + 1, c->frame_length);
    }
-   FOR_LANES(i, c->frame_length) x_frame[5 * c->fs_kHz + i] = c->inputBuf[1 + i];
+   FOR_LANES(i, c->frame_length) x_frame[5 * c->fs_kHz + i] = inputBuf[1 + i];
    wv_sync();
 }
 WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, int condCoding)
@@ -669,40 +682,42 @@ WV_DEV int se_call_prologue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int nSampl
    return 0;
 }
 /* :283-340: resample this call's input to the internal rate, buffer it */
-WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesFromInput, int nSamplesToBuffer, int nBlocksOf10ms)
+template <int FRONT = 0> WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesFromInput, int nSamplesToBuffer, int nBlocksOf10ms)
 {
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   WV_LDS i16 *in0 = se_inbuf<FRONT>(S, 0), *in1 = se_inbuf<FRONT>(S, 1);
    const int ix0 = c0->inputBufIx;
    if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
       const int ix1 = c1->inputBufIx;
       LANE0 { if (E->nPrevChannelsInternal == 1 && c0->nFramesEncoded == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; } }
       SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
-      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
-      se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], s1, nSamplesFromInput);
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &in0[ix0 + 2], s0, nSamplesFromInput);
+      se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &in1[ix1 + 2], s1, nSamplesFromInput);
       LANE0 { c0->inputBufIx += nSamplesToBuffer; c1->inputBufIx += imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz); }
    } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
       SePcmSrc sm = {pcm, 2, 0, 1};
-      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], sm, nSamplesFromInput);
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &in0[ix0 + 2], sm, nSamplesFromInput);
       if (E->nPrevChannelsInternal == 2 && c0->nFramesEncoded == 0) {
          const int ix1 = c1->inputBufIx;
-         se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &c1->inputBuf[ix1 + 2], sm, nSamplesFromInput);
-         FOR_LANES(n, c0->frame_length) c0->inputBuf[ix0 + n + 2] = (i16)((c0->inputBuf[ix0 + n + 2] + c1->inputBuf[ix1 + n + 2]) >> 1);
+         se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &in1[ix1 + 2], sm, nSamplesFromInput);
+         FOR_LANES(n, c0->frame_length) in0[ix0 + n + 2] = (i16)((in0[ix0 + n + 2] + in1[ix1 + n + 2]) >> 1);
       }
       LANE0 c0->inputBufIx += nSamplesToBuffer;
    } else {
       SePcmSrc s0 = {pcm, 1, 0, 0};
-      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &c0->inputBuf[ix0 + 2], s0, nSamplesFromInput);
+      se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &in0[ix0 + 2], s0, nSamplesFromInput);
       LANE0 c0->inputBufIx += nSamplesToBuffer;
    }
    LANE0 E->allowBandwidthSwitch = 0;
 }
 /* :342-470, a full frame is buffered: the LBRR side stream of the previous packet at the head of a new one, variable high-pass, target rate, stereo L/R -> M/S,
  * VAD.  Leaves TargetRate_bps in S->r[4], the mid / side rates in S->r[5], S->r[6]. */
-WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, OaSilkLbrr *lb, int activity, int prefillFlag)
+template <int FRONT = 0> WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, OaSilkLbrr *lb, int activity, int prefillFlag)
 {
    WV_LDS OaSilkEnc *E = &S->st;
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
+   WV_LDS i16 *in0 = se_inbuf<FRONT>(S, 0), *in1 = se_inbuf<FRONT>(S, 1);
    if (c0->nFramesEncoded == 0 && !prefillFlag) {                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
       int any = 0;
       for (int n = 0; n < ec->nChannelsInternal; n++) for (int i = 0; i < 3; i++) any |= E->ch[n].LBRR_flags[i];
@@ -749,7 +764,7 @@ WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS 
       ec_st(ecl, &ec_);
    }
    if (ec->nChannelsInternal == 2) {
-      se_stereo_lr_to_ms_wave(&E->st, &c0->inputBuf[2], &c1->inputBuf[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], S->stk, S->r[4], c0->speech_activity_Q8,
+      se_stereo_lr_to_ms_wave(&E->st, &in0[2], &in1[2], &E->st.predIx[c0->nFramesEncoded][0][0], &E->st.mid_only_flags[c0->nFramesEncoded], S->stk, S->r[4], c0->speech_activity_Q8,
             ec->toMono, c0->fs_kHz, c0->frame_length, &S->u.s);
    }
    LANE0 {
@@ -764,17 +779,17 @@ WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS 
                c1->lp_In_LP_State[0] = c1->lp_In_LP_State[1] = 0;
                c1->prevLag = 100; c1->LastGainIndex = 10; c1->prevSignalType = SE_TYPE_NO_VOICE; c1->first_frame_after_reset = 1;
             }
-            se_vad_l0(c1, c1->inputBuf + 1, S->u.vadX, activity);
+            se_vad_l0(c1, in1 + 1, S->u.vadX, activity);
          } else c1->VAD_flags[c0->nFramesEncoded] = 0;
          if (!prefillFlag) {
             se_stereo_encode_pred(EC_PASS, &E->st.predIx[c0->nFramesEncoded][0][0]);
             if (c1->VAD_flags[c0->nFramesEncoded] == 0) k_ec_enc_icdf(EC_PASS, E->st.mid_only_flags[c0->nFramesEncoded], sk_stereo_only_code_mid_icdf, 8);
          }
       } else {
-         c0->inputBuf[0] = E->st.sMid[0]; c0->inputBuf[1] = E->st.sMid[1];
-         E->st.sMid[0] = c0->inputBuf[c0->frame_length]; E->st.sMid[1] = c0->inputBuf[c0->frame_length + 1];
+         in0[0] = E->st.sMid[0]; in0[1] = E->st.sMid[1];
+         E->st.sMid[0] = in0[c0->frame_length]; E->st.sMid[1] = in0[c0->frame_length + 1];
       }
-      se_vad_l0(c0, c0->inputBuf + 1, S->u.vadX, activity);
+      se_vad_l0(c0, in0 + 1, S->u.vadX, activity);
       ec_st(ecl, &ec_);
    }
 }

@@ -43,7 +43,6 @@ struct OaSilkEncChannel {
    int32_t nsq_reset_req;                      /* the quantiser state (OaSilkEncTail) starts over before its next use: silk_setup_fs (control_codec.c:241) and the side channel's
                                                 * return after mid-only frames (enc_API.c:449) ask for it here, because the analysis kernel of the split path does not hold the tails */
    int16_t prev_NLSFq_Q15[16];
-   int16_t inputBuf[SE_MAX_FRAME + 2];
    int16_t x_buf[SE_X_BUF_LEN];
    OaSilkEncIndices indices;
 };
@@ -63,6 +62,8 @@ struct OaSilkEnc {                             /* silk_encoder */
    OaSilkEncStereo st;
    int32_t nBitsUsedLBRR, nBitsExceeded, nChannelsAPI, nChannelsInternal, nPrevChannelsInternal, timeSinceSwitchAllowed_ms, allowBandwidthSwitch, prev_decode_only_middle;
    OaSilkEncChannel ch[2];
+   int16_t inbuf[2][SE_MAX_FRAME + 2];        /* silk_encoder_state.inputBuf of the two channels (silk/structs.h:176): the call's input at the internal rate, read only by the head of a frame (stereo L/R -> M/S, VAD,
+                                               * variable low-pass, the copy into x_buf) -- behind the channels, so that a kernel for which it is scratch (the split path's front kernel) does not stage it */
    OaSilkEncTail tail[2];
 };
 
