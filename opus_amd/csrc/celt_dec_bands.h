@@ -384,15 +384,15 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
    shortBlocks = wv_uni(shortBlocks); spread = wv_uni(spread); dual_stereo = wv_uni(dual_stereo); intensity = wv_uni(intensity); total_bits = wv_uni(total_bits);
    balance = wv_uni(balance); codedBands = wv_uni(codedBands); disable_inv = wv_uni(disable_inv);
    const int start = wv_uni(L->sh.start), end = wv_uni(L->sh.end), LM = wv_uni(L->sh.LM), C = wv_uni(L->sh.C), Nfull = wv_uni(L->sh.N);
-   WV_LDS i32 *X_ = L->A.X, *Y_ = C == 2 ? L->A.X + Nfull : 0;
+   i32 *Xg = L->Xg, *Yg = C == 2 ? L->Xg + Nfull : 0;                                  /* the spectrum in the wave's HBM scratch; a band is decoded in LDS (xb / yb) and copied out */
    WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.norm + OA_NORM_LEN;
    WV_LDS u8 *collapse_masks = L->collapse_masks;
    const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
    i32 remaining_bits;
    int M = 1 << LM, B = shortBlocks ? M : 1, lowband_offset = 0, update_lowband = 1;
    int norm_offset = M * ct_eBands[start];
-   /* decoder: the last band of X doubles as lowband scratch (bands.c:1642-1653) */
-   WV_LDS i32 *lowband_scratch = X_ + M * ct_eBands[OA_NB_EBANDS - 1];
+   /* (the reference borrows the last band of X as lowband scratch, bands.c:1642-1653, and stops using it when it decodes that band: a buffer of its own here) */
+   WV_LDS i32 *lowband_scratch = L->BC.q.lbs;
    BandCfg cfg;
    u32 seed = (u32)wv_uni((i32)L->st.rng);
    i32x4 r;
@@ -405,8 +405,8 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
       unsigned x_cm, y_cm;
       cfg.i = i;
       last = (i == end - 1);
-      X = X_ + M * ct_eBands[i];
-      Y = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
+      X = L->BC.q.xb;
+      Y = Yg != 0 ? L->BC.q.yb : 0;
       N = M * ct_eBands[i + 1] - M * ct_eBands[i];
       wv_sync();
       tell = wv_uni(ec_tell_frac_lds(&L->ec));
@@ -466,6 +466,7 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
          y_cm = x_cm;
       }
       wv_sync();
+      FOR_LANES(j, N) { Xg[M * ct_eBands[i] + j] = X[j]; if (Y != 0) Yg[M * ct_eBands[i] + j] = Y[j]; }       /* the finished band -> the spectrum */
       LANE0 { collapse_masks[i * C + 0] = (u8)x_cm; collapse_masks[i * C + C - 1] = (u8)y_cm; }
       balance += wv_uni(pulses[i]) + tell;
       update_lowband = b > (N << BITRES);
@@ -480,7 +481,7 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
  * noise is generated by lane 0; the renormalisation that follows is elementwise. */
 WV_DEVN void anti_collapse_wave(WV_LDS DecLds *L, int LM, int C, int size, int start, int end)
 {
-   WV_LDS i32 *X_ = L->A.X;
+   i32 *X_ = L->Xg;
    const WV_LDS i32 *logE = L->oldBandE, *prev1logE = L->oldLogE, *prev2logE = L->oldLogE2;
    u32 seed = (u32)wv_uni((i32)L->st.rng);
    for (int i = start; i < end; i++) {
@@ -504,8 +505,10 @@ WV_DEVN void anti_collapse_wave(WV_LDS DecLds *L, int LM, int C, int size, int s
          if (LM == 3) r = mult16_16_q14(23170, imin(23169, r));
          r = (i16)(imin(thresh, r)) >> 1;
          r = vshr32(mult16_16_q15(sqrt_1, r), shift + 14 - NORM_SHIFT);
-         WV_LDS i32 *X = X_ + c * size + (ct_eBands[i] << LM);
+         i32 *Xs = X_ + c * size + (ct_eBands[i] << LM);
+         WV_LDS i32 *X = L->BC.q.xb;                                       /* a band that needs filling goes through the staging buffer (PVQ phase memory: free by now) */
          const unsigned mask = (unsigned)wv_uni((i32)L->collapse_masks[i * C + c]);
+         if ((mask & ((1u << (1 << LM)) - 1)) != ((1u << (1 << LM)) - 1)) { wv_sync(); FOR_LANES(j, N0 << LM) X[j] = Xs[j]; }
          for (int k = 0; k < 1 << LM; k++) {
             if (!(mask & 1 << k)) {
                wv_sync();
@@ -514,14 +517,14 @@ WV_DEVN void anti_collapse_wave(WV_LDS DecLds *L, int LM, int C, int size, int s
                renormalize = 1;
             }
          }
-         if (renormalize) { wv_sync(); renormalise_vector_wave(X, N0 << LM, Q31ONE); }
+         if (renormalize) { wv_sync(); renormalise_vector_wave(X, N0 << LM, Q31ONE); wv_sync(); FOR_LANES(j, N0 << LM) Xs[j] = X[j]; }
       }
    }
    wv_sync();
 }
 
 /* denormalise_bands (bands.c:187), in place on one channel of X (downsample == 1): one lane per coefficient */
-WV_DEV void denormalise_bands_wave(WV_LDS i32 *XF, const WV_LDS i32 *bandLogE, WV_LDS i32 *gains /* 2*21 ints */, int start, int end, int M, int silence, int downsample = 1)
+WV_DEV void denormalise_bands_wave(i32 *XF, const WV_LDS i32 *bandLogE, WV_LDS i32 *gains /* 2*21 ints */, int start, int end, int M, int silence, int downsample = 1)
 {
    const int N = M * 120;
    int bound = M * ct_eBands[end];

@@ -17,11 +17,11 @@ WV_DEV int oa_dec_downsample(const WV_LDS OaDecScalars *st) { return 48000 / oa_
 #include "silk_nsq.h"          /* SILK fixed-point primitives */
 #include "silk_resampler.h"
 #include "silk_dec_api.h"      /* SILK decoder (lane-0 serial), shares this kernel's wave, range decoder and LDS */
-static_assert(sizeof(SilkLdsAll) <= sizeof(((DecLds *)0)->A) + sizeof(((DecLds *)0)->BC), "SILK scratch + staged state must fit the CELT decoder's phase regions");
+static_assert(offsetof(DecLds, A) == offsetof(DecLds, BC) + sizeof(((DecLds *)0)->BC) && sizeof(SilkLdsAll) <= sizeof(((DecLds *)0)->A) + sizeof(((DecLds *)0)->BC), "SILK scratch + staged state must fit the CELT decoder's phase regions");
 static_assert(OA_SILK_HOT_BYTES % 4 == 0 && sizeof(OaSilkChannel) % 4 == 0, "SILK state is copied as dwords");
 
 /* ---- inverse MDCT of one block (mdct.c:268): in = N2 bins at `stride` (LDS), out = N2 + overlap samples, TDAC into out[0..overlap) ---- */
-WV_DEVN void mdct_backward_wave(const WV_LDS i32 *in, WV_LDS i32 *out, int shift, int stride, WV_LDS int *aux)
+WV_DEVN void mdct_backward_wave(const i32 *in /* the wave's HBM scratch */, WV_LDS i32 *out, int shift, int stride, WV_LDS int *aux)
 {
    shift = wv_uni(shift); stride = wv_uni(stride);
    const int N = 1920 >> shift, N2 = N >> 1, N4 = N >> 2, overlap = OA_OVERLAP;
@@ -155,41 +155,38 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
    N = wv_uni(N); CC = wv_uni(CC);
    const int ds = oa_dec_downsample(st), Nd = N / ds;               /* API rates below 48 kHz keep every ds-th de-emphasised sample (celt_decoder.c:361-404) */
    wv_sync();
-   /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; int16 staged in region A ---- */
-   if (lane < CC) {
-      i32 m = st->preemph_memD[lane];
-      const WV_LDS i32 *x = L->BC.syn[lane];
-      WV_LDS i16 *y = L->A.pcm16;
-      for (int j0 = 0; j0 < N; j0 += 8) {                /* eight reads in flight per trip; only the (add, saturate, multiply) chain is serial */
-         i32 t[8];
-#pragma unroll
-         for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
-#pragma unroll
-         for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
-         if (ds == 1) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) y[(j0 + k) * CC + lane] = sig2word16(t[k]);
-         } else {
-            for (int k = 0; k < 8; k++) if ((j0 + k) % ds == 0) y[((j0 + k) / ds) * CC + lane] = sig2word16(t[k]);
-         }
-      }
-      st->preemph_memD[lane] = m;
-   }
-   wv_sync();
-   accum = wv_uni(accum);
-   if (ds != 1) {
-      if (accum) { FOR_LANES(i, Nd * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }
-      else FOR_LANES(i, Nd * CC) pcm_out[i] = L->A.pcm16[i];
-   }
-   else if (accum) { FOR_LANES(i, N * CC) { const i32 v = (i32)pcm_out[i] + (i32)L->A.pcm16[i]; pcm_out[i] = (i16)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); } }   /* ADD_RES, celt/arch.h:172 */
-   else FOR_LANES(i, N * CC) pcm_out[i] = L->A.pcm16[i];
-   /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) ---- */
+   /* ---- history ring <- the N post-filtered samples; overlap tail <- syn[N .. N+overlap) (before the de-emphasis below reuses syn's words) ---- */
    {
       const int head = wv_uni(st->hist_head);
       for (int c = 0; c < CC; c++) {
          FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = L->BC.syn[c][i];
          FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = L->BC.syn[c][N + i];
       }
+   }
+   wv_sync();
+   /* ---- deemphasis (celt_decoder.c:318): one-pole IIR with rounding -> one lane per channel; the int16 result goes back into the sample's own word of syn ---- */
+   if (lane < CC) {
+      i32 m = st->preemph_memD[lane];
+      WV_LDS i32 *x = L->BC.syn[lane];
+      for (int j0 = 0; j0 < N; j0 += 8) {                /* eight reads in flight per trip; only the (add, saturate, multiply) chain is serial */
+         i32 t[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) t[k] = x[j0 + k];
+#pragma unroll
+         for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
+#pragma unroll
+         for (int k = 0; k < 8; k++) x[j0 + k] = sig2word16(t[k]);
+      }
+      st->preemph_memD[lane] = m;
+   }
+   wv_sync();
+   accum = wv_uni(accum);
+   /* API rates below 48 kHz keep every ds-th de-emphasised sample (celt_decoder.c:361-404); interleave on the way out */
+   FOR_LANES(it, Nd * CC) {
+      const int i = it / CC, c = it - i * CC;
+      const i32 v = L->BC.syn[c][i * ds];
+      if (accum) { const i32 w = (i32)pcm_out[it] + v; pcm_out[it] = (i16)(w > 32767 ? 32767 : w < -32768 ? -32768 : w); }      /* ADD_RES, celt/arch.h:172 */
+      else pcm_out[it] = (i16)v;
    }
    wv_sync();
    LANE0 st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
@@ -200,7 +197,9 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
 
 /* ---- one CELT frame (celt_decoder.c:1104).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
 /* ec_cont: continue the range decoder parked in L->ec_silk (hybrid frames) instead of starting one; accum: add onto pcm_out (celt_decoder.c:1104 `dec`, `accum`) */
-WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int ec_cont = 0, int accum = 0)
+/* FAST: the instance of the CELT-only fast kernel (opus_amd.hip: oa_decode_fast_kernel): the concealment and the post-concealment fold are compiled out -- the kernel only takes
+ * packets that reach neither */
+template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int ec_cont = 0, int accum = 0)
 {
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
@@ -214,7 +213,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
    const int M = 1 << LM, N = M * 120;
    const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
-   if (len <= 1) {                                                /* lost / DTX frame: conceal (celt_decoder.c:1306) */
+   if (!FAST && len <= 1) {                                       /* lost / DTX frame: conceal (celt_decoder.c:1306) */
       celt_decode_lost_wave(L, gs, N, LM);
       celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
       return frame_size;
@@ -309,7 +308,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    }
    fine_energy_read_wave(&L->ec, L->packet + 1, L->scr, sh->r + 6, sh->start, sh->end, L->oldBandE, L->fine_quant, sh->C);
    /* X starts at zero (the reference's bands below start / above end are never written) */
-   FOR_LANES(i, C * N) L->A.X[i] = 0;
+   { i32 *Xz = L->Xg; FOR_LANES(i, C * N) Xz[i] = 0; }
    wv_sync();
    dec_quant_all_bands_wave(L, sh->shortBlocks, sh->spread, sh->dual_stereo, sh->intensity, sh->pvq_total_bits, sh->balance, sh->codedBands, st->disable_inv);
    LANE0 {
@@ -324,7 +323,7 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
    if (sh->anti_collapse_on) anti_collapse_wave(L, LM, C, N, start, end);
    const int silence = wv_uni(sh->silence), isTransient = wv_uni(sh->isTransient);
    if (silence) { wv_sync(); FOR_LANES(i, C * NBE) L->oldBandE[i] = -GC(28.f); wv_sync(); }
-   K_DUMP("dec_X", L->A.X, C * N * 4); K_DUMP("dec_oldBandE", L->oldBandE, 2 * NBE * 4);
+   K_DUMP("dec_X", L->Xg, C * N * 4); K_DUMP("dec_oldBandE", L->oldBandE, 2 * NBE * 4);
 
    /* ---- celt_synthesis (celt_decoder.c:413): denormalise in place, IMDCT per block into syn[c] (head = last frame's overlap tail) ---- */
    {
@@ -336,8 +335,8 @@ WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, i
          FOR_LANES(i, N) L->BC.syn[c][overlap + i] = 0;
       }
       wv_sync();
-      if (wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, CC);
-      WV_LDS i32 *freq = L->A.X;
+      if (!FAST && wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, CC);
+      i32 *freq = L->Xg;
       if (CC == 2 && C == 1) {
          denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
          FOR_LANES(i, N) freq[N + i] = freq[i];        /* the IMDCT consumes its input: keep a copy for the second channel */
@@ -523,7 +522,7 @@ WV_DEVN int oa_conceal_wave(WV_LDS DecLds *L, OaDecStream *gs, int frame_size, i
       i16 *pcm = pcm_out + (size_t)done * CC;
       if (mode != 1002) {
          /* SILK concealment (src/opus_decoder.c:404-497 with data == NULL): the decoder control of the last good frame persists */
-         WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->A;
+         WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->BC;
          wv_sync();
          FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];           /* SILK state -> LDS, coalesced */
          wv_sync();
@@ -609,8 +608,26 @@ WV_DEV void oa_transition_gain_wave(const WV_LDS OaDecScalars *st, i16 *x, int n
 }
 /* One Opus frame with payload (opus_decode_frame, src/opus_decoder.c:271-714, data != NULL): SILK part, redundancy, CELT part, mode transitions.
  * `data` = the frame's bytes in HBM, len >= 2.  Returns the frame size or a negative OA_ERR_*. */
-WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0)
+template <bool FAST = false> WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0)
 {
+   if (FAST) {                                                                  /* CELT-only steady state: opus_decode_frame with mode == prev_mode == CELT_ONLY (or a fresh decoder), no redundancy */
+      WV_LDS OaDecScalars *st = &L->st;
+      const int Fs = oa_dec_fs(st), F20 = Fs / 50;
+      const int bandwidth = wv_uni(st->bandwidth), mode = wv_uni(st->mode);
+      wv_sync();
+      FOR_LANES(i, len) L->packet[1 + i] = data[i];
+      wv_sync();
+      {
+         int endband = 21;
+         switch (bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
+         LANE0 { st->end = endband; st->start = 0; }
+      }
+      const int r = celt_decode_frame_wave<true>(L, gs, len, imin(F20, audiosize), pcm, 0, 0);
+      if (r < 0) return r;
+      LANE0 { st->rangeFinal = st->rng; st->prev_mode = mode; st->prev_redundancy = 0; }
+      wv_sync();
+      return audiosize;
+   }
    decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
@@ -634,7 +651,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
    wv_sync();
    if (mode != 1002) {
       /* ---- SILK part (:404-497) ---- */
-      WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->A;
+      WV_LDS SilkLdsAll *SL = (WV_LDS SilkLdsAll *)&L->BC;
       FOR_LANES(i, (int)(OA_SILK_HOT_BYTES / 4)) SL->hot[i] = ((const i32 *)&gs->silk)[i];              /* SILK state -> LDS, coalesced */
       wv_sync();
       {
@@ -764,7 +781,7 @@ WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *da
 }
 
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
-WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
+template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
 {
    decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
@@ -814,7 +831,7 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
    int off = wv_uni(sh->frame_bytes_off), nb = 0;
    const int fec = wv_uni(sh->r[5]);
    const int fec_mode = wv_uni(sh->r[0]), fec_bw = wv_uni(sh->r[1]), fec_ch = wv_uni(sh->r[2]), fec_end = wv_uni(sh->r[3]);     /* (the slots are reused by the frame functions below) */
-   if (fec && ret >= 0) {
+   if (!FAST && fec && ret >= 0) {
       /* in-band FEC (src/opus_decoder.c:798-824): conceal everything before the last packet_frame_size samples, then decode the LBRR copy of
        * the first frame in this packet into them */
       const int duration_copy = wv_uni(st->last_packet_duration);
@@ -836,18 +853,18 @@ WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, 
    for (int f = 0; f < count && ret >= 0 && !fec; f++) {
       const int flen = wv_uni(sh->size[f]);
       int r;
-      if (flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
+      if (!FAST && flen <= 1) {           /* DTX / lost frame inside a packet: opus_decode_frame with data = NULL, at most the TOC's frame size (:316-322) */
          r = oa_conceal_wave(L, gs, imin(frame_size - nb, pfs), pcm_out + (size_t)nb * CC, CC);
       } else {
          LANE0 { st->start = 0; }                        /* (the packet's band limit applies inside, after the transition fade sources are concealed with the old one: src/opus_decoder.c:388, :540, :547) */
          wv_sync();
-         r = oa_decode_frame_wave(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
+         r = oa_decode_frame_wave<FAST>(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
       }
       if (r < 0) ret = r;
       else nb += r;
       off += flen;
    }
-   if (count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
+   if (!FAST && count == -1 && ret >= 0) {       /* whole packet lost (opus_decoder.c:756-769) */
       while (nb < frame_size) {
          int r = oa_conceal_wave(L, gs, imin(frame_size - nb, wv_uni(st->frame_size)), pcm_out + (size_t)nb * CC, CC);   /* never more than the last TOC's frame size at a time (src/opus_decoder.c:316-322) */
          if (r < 0) { ret = r; break; }

@@ -1,10 +1,13 @@
-/* celt_dec_lds.h — per-wavefront LDS working set of the CELT frame decoder (one wave = one stream; the frames of a
- * multi-frame packet are decoded one after the other by the same wave).
- *   A  (7,680 B)  decoded normalised spectrum X[2][960] -> denormalised in place (freq) -> int16 PCM staging
- *   BC (8,640 B)  PVQ phase: folding memory norm[2][624] + pulse vector; synthesis phase: syn[2][960+120]
+/* celt_dec_lds.h — per-wavefront LDS working set of the decoder (one wave = one stream; the frames of a multi-frame packet are decoded one after the other by the same wave).
+ *   BC (8,640 B)  PVQ phase: folding memory norm[2][624], pulse vector, the band being decoded (X / Y staging + lowband scratch); synthesis phase: syn[2][960+120]
+ *   A  (7,680 B)  LAST: scratch of the concealment's pitch mode and, together with BC, the SILK decoder's arena (SilkLdsAll at &BC).  The CELT-only fast kernel
+ *                 (oa_decode_fast_kernel: packets whose decode touches neither) allocates LDS only up to here.
+ * The decoded spectrum X[2][960] itself (normalised, then denormalised in place = the IMDCT's input) lives in a per-wave HBM scratch (Xg): every pass over it is
+ * lane-parallel and coalesced (band copy-out, anti-collapse through the staging buffer, denormalise, the IMDCT's pre-rotation reads).
  * packet: the current frame's bytes (range decoder input). */
 #ifndef OPUS_AMD_CELT_DEC_LDS_H
 #define OPUS_AMD_CELT_DEC_LDS_H
+#include <stddef.h>
 struct DecShared {
    i32 CC, C, LM, M, N, start, end, effEnd, disable_inv, len, total_bits, silence, ret;
    i32 postfilter_pitch, postfilter_gain, postfilter_tapset, isTransient, shortBlocks, intra_ener, spread, alloc_trim, intensity, dual_stereo;
@@ -25,10 +28,13 @@ struct DecLds {
    i32 aux[32];
    u8 collapse_masks[2 * NBE + 6];
    u8 packet[OA_MAX_PACKET + 4];      /* frame bytes at packet + 1 (same convention as the encoder's EC macros) */
-   union { i32 X[2 * OA_MAX_FRAME]; i16 pcm16[2 * OA_MAX_FRAME]; } A;
+   i32 *Xg;                           /* the spectrum X[2][OA_MAX_FRAME] of the frame in flight: per-wave HBM scratch (set by the kernel) */
    union {
-      struct { i32 norm[2 * OA_NORM_LEN]; i32 iy[176 + 8]; } q;
+      struct { i32 norm[2 * OA_NORM_LEN]; i32 iy[176 + 8]; i32 xb[176], yb[176], lbs[176]; } q;      /* xb / yb: the band being decoded, copied out to Xg when it is done; lbs: quant_band's lowband scratch (the reference borrows the last band of X, bands.c:1642) */
       i32 syn[2][OA_MAX_FRAME + OA_OVERLAP];
    } BC;
+   union { i32 w[2 * OA_MAX_FRAME]; } A;
 };
+#define OA_DEC_FAST_LDS_BYTES (offsetof(DecLds, A))
+#define OA_DEC_SCRATCH_BYTES (2 * OA_MAX_FRAME * sizeof(i32))
 #endif

@@ -136,28 +136,36 @@ WV_DEVN void celt_decode_lost_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int
    wv_sync();
    if (curr_frame_type == 2) {
       const int end = wv_uni(st->end), effEnd = imax(start, imin(end, NBE));
-      if (wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, C);
       const i32 decay = loss_duration == 0 ? GC(1.5f) : GC(.5f);
       FOR_LANES(w, C * NBE) { int i = w % NBE; if (i >= start && i < end) L->oldBandE[w] = imax(L->backgroundLogE[w], L->oldBandE[w] - decay); }
-      FOR_LANES(i, C * N) L->A.X[i] = 0;
+      { i32 *Xz = L->Xg; FOR_LANES(i, C * N) Xz[i] = 0; }
       wv_sync();
       u32 seed = (u32)wv_uni((i32)st->rng);
       for (int c = 0; c < C; c++) {
          for (int i = start; i < effEnd; i++) {
             const int boffs = N * c + (ct_eBands[i] << LM), blen = (ct_eBands[i + 1] - ct_eBands[i]) << LM;
             wv_sync();
-            LANE0 { u32 s = seed; for (int j = 0; j < blen; j++) { s = lcg_rand(s); L->A.X[boffs + j] = shl32((i32)((i32)s >> 20), NORM_SHIFT - 14); } }
+            LANE0 { u32 s = seed; for (int j = 0; j < blen; j++) { s = lcg_rand(s); L->BC.q.xb[j] = shl32((i32)((i32)s >> 20), NORM_SHIFT - 14); } }
             for (int j = 0; j < blen; j++) seed = lcg_rand(seed);
-            renormalise_vector_wave(L->A.X + boffs, blen, Q31ONE);
+            renormalise_vector_wave(L->BC.q.xb, blen, Q31ONE);
+            wv_sync();
+            { i32 *Xo = L->Xg + boffs; FOR_LANES(j, blen) Xo[j] = L->BC.q.xb[j]; }
          }
       }
       wv_sync();
       LANE0 st->rng = seed;
       wv_sync();
+      /* (the noise bands went through the PVQ-phase staging buffer, which shares its bytes with syn: the head of the new frame is set up again now) */
+      for (int c = 0; c < C; c++) {
+         FOR_LANES(i, overlap) L->BC.syn[c][i] = gs->overlap_mem[c * overlap + i];
+         FOR_LANES(i, N) L->BC.syn[c][overlap + i] = 0;
+      }
+      wv_sync();
+      if (wv_uni(st->prefilter_and_fold)) prefilter_and_fold_wave(L, gs, C);
       /* celt_synthesis(X, out_syn, oldBandE, start, effEnd, C, C, isTransient = 0, LM, silence = 0) */
       for (int c = 0; c < C; c++) {
-         denormalise_bands_wave(L->A.X + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, 1 << LM, 0, oa_dec_downsample(&L->st));
-         mdct_backward_wave(L->A.X + c * N, L->BC.syn[c], 3 - LM, 1, L->aux);
+         denormalise_bands_wave(L->Xg + c * N, L->oldBandE + c * NBE, L->scr, start, effEnd, 1 << LM, 0, oa_dec_downsample(&L->st));
+         mdct_backward_wave(L->Xg + c * N, L->BC.syn[c], 3 - LM, 1, L->aux);
       }
       for (int c = 0; c < C; c++) { FOR_LANES(i, N) L->BC.syn[c][i] = saturate(L->BC.syn[c][i], SIG_SAT); }
       wv_sync();
@@ -179,7 +187,7 @@ WV_DEVN void celt_decode_lost_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int
       }
    } else {
       /* ---- pitch-based PLC ---- */
-      WV_LDS i16 *exc_ = (WV_LDS i16 *)L->A.X;               /* [1024 + 24] */
+      WV_LDS i16 *exc_ = (WV_LDS i16 *)L->A.w;               /* [1024 + 24] */
       WV_LDS i16 *exc = exc_ + PLC_LPC_ORDER;
       WV_LDS i16 *tmp16 = exc_ + 1056;                       /* [1024] windowed / scaled copy, FIR output */
       WV_LDS i32 *ac = (WV_LDS i32 *)(exc_ + 2112);          /* [25] + lpc32 [24] + lpc16 [24] */
@@ -189,7 +197,7 @@ WV_DEVN void celt_decode_lost_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int
       i16 fade = Q15ONE;
       if (first) {
          /* celt_plc_pitch_search: downsample both channels' 2048-sample history by 2, search lags 100..720 */
-         WV_LDS i16 *lp = (WV_LDS i16 *)L->A.X;                                  /* [1024] result */
+         WV_LDS i16 *lp = (WV_LDS i16 *)L->A.w;                                  /* [1024] result */
          WV_LDS i16 *raw = lp + 1024;                                            /* [1024] raw low-pass */
          WV_LDS i16 *x4 = raw + 1024, *y4 = x4 + 336;                            /* [332], [488] */
          WV_LDS i32 *xc = (WV_LDS i32 *)(y4 + 488);                              /* [310] */

@@ -65,15 +65,58 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
    }
 }
 
+/* The decoder: persistent waves fed from a queue, one packet of one stream at a time; the spectrum of the frame in flight lives in the wave's HBM scratch (celt_dec_lds.h).
+ * Two kernels on one HIP stream:
+ *   oa_decode_fast_kernel  packets whose decode is the CELT steady state and nothing else -- a CELT-only TOC with one coded frame, a stream whose last packet was CELT-only too
+ *                          (or that has not decoded anything yet), no FEC request, no pending fold of the concealment -- with the SILK decoder, the concealment and every
+ *                          transition compiled out (oa_decode_packet<true>): it needs neither the A arena nor their registers, so more waves fit; everything else goes to a
+ *                          device-side list
+ *   oa_decode_kernel       the general decoder over that list (list == NULL: over every stream) */
 extern "C" __global__ void __launch_bounds__(64, 2)
-oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec)
+oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
+      char *scratch, unsigned *queue, const int *list, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
-   const int s = blockIdx.x;
-   if (s >= nstreams) return;
-   if (lens[s] > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } return; }       /* a length beyond the stream's slot would read the neighbour's packet */
-   oa_decode_packet(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
+   const int n = list ? (int)*list_count : nstreams;
+   for (;;) {
+      int s = oa_queue_pop(queue);
+      if (s >= n) break;
+      if (list) s = list[s];
+      if (lens[s] > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } continue; }       /* a length beyond the stream's slot would read the neighbour's packet */
+      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      __syncthreads();
+      oa_decode_packet<false>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
+      __syncthreads();
+   }
+}
+#ifndef OA_DEC_FAST_WAVES_PER_EU
+#define OA_DEC_FAST_WAVES_PER_EU 3
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
+oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
+      char *scratch, unsigned *counters /* [0] this kernel's queue, [1] the general kernel's queue, [2] length of the list */, int *slow_list)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   for (;;) {
+      const int s = oa_queue_pop(counters);
+      if (s >= nstreams) break;
+      const int len = lens[s];
+      const OaDecStream *gs = streams + s;
+      int fast = 0;
+      if (!decode_fec && len >= 3 && len <= packet_stride && len <= 1276) {
+         const int toc = packets[(size_t)s * packet_stride];
+         const int prev = gs->s.prev_mode;
+         fast = (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && gs->s.prefilter_and_fold == 0;
+      }
+      fast = wv_uni(fast);
+      if (!fast) { if (threadIdx.x == 0) slow_list[atomicAdd(counters + 2, 1u)] = s; continue; }
+      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      __syncthreads();
+      oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
+      __syncthreads();
+   }
 }
 
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
@@ -949,12 +992,16 @@ struct OpusGpuDecBatch {
    int device; opus_int32 S; opus_int32 n_act /* as in the encoder batch */; int channels; opus_int32 Fs; int decode_fec; hipStream_t stream;
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
+   char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
+   unsigned *d_queue; int *d_slow;          /* [0] fast kernel's queue, [1] general kernel's queue, [2] length of the list of streams the fast kernel handed over */
+   int num_cu, occ_fast, occ_gen;
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
 /* decode_fec of the following calls (opus_decode's last argument, include/opus.h:516): 1 = decode the in-band FEC (LBRR) copy the packets carry for
  * the frame BEFORE them, concealing where there is none */
 int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec) { if (!b || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG; b->decode_fec = decode_fec; return OPUS_OK; }
 int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
+int opusgpu_dec_fast_kernel_lds_bytes(void) { return (int)OA_DEC_FAST_LDS_BYTES; }
 opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
 void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
 {
@@ -967,6 +1014,9 @@ void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
    if (b->d_lens) (void)hipFree(b->d_lens);
    if (b->d_ns) (void)hipFree(b->d_ns);
    if (b->d_rng) (void)hipFree(b->d_rng);
+   if (b->d_scratch) (void)hipFree(b->d_scratch);
+   if (b->d_queue) (void)hipFree(b->d_queue);
+   if (b->d_slow) (void)hipFree(b->d_slow);
    if (b->stream) (void)hipStreamDestroy(b->stream);
    delete b;
 }
@@ -988,13 +1038,19 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuDecBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
+      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, sizeof(int) * (size_t)nstreams) == hipSuccess &&
+                hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_gen, (const void *)oa_decode_kernel, 64, sizeof(DecLds)) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_fast, (const void *)oa_decode_fast_kernel, 64, OA_DEC_FAST_LDS_BYTES) == hipSuccess;
       for (opus_int32 s0 = 0; ok && s0 < nstreams; s0 += 256) {
          opus_int32 n = nstreams - s0 < 256 ? nstreams - s0 : 256;
          ok = hipMemcpy(b->d_streams + s0, init.data(), sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
@@ -1043,9 +1099,24 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    if (frame_size <= 0 || frame_size > 5760) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
-   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)b->n_act), dim3(64), sizeof(DecLds), s,
+   /* persistent launches: as many waves as the chip holds of each kernel (never more than there are streams), every wave with its own spectrum scratch; the fast kernel
+    * first, then the general one over the streams it handed over (its waves find an empty list when there are none) */
+   static const int fast_env = getenv("OPUS_AMD_DEC_FAST") ? atoi(getenv("OPUS_AMD_DEC_FAST")) : 1;                 /* 0: the general kernel for every packet (A/B, tests) */
+   const long long cu = b->num_cu > 0 ? b->num_cu : 1;
+   long long g_fast = (long long)(b->occ_fast < 1 ? 1 : b->occ_fast) * cu, g_gen = (long long)(b->occ_gen < 1 ? 1 : b->occ_gen) * cu;
+   if (g_fast > b->n_act) g_fast = b->n_act;
+   if (g_gen > b->n_act) g_gen = b->n_act;
+   const size_t need = (size_t)(g_fast > g_gen ? g_fast : g_gen) * OA_DEC_SCRATCH_BYTES;
+   if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
+   HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
+   const int use_fast = fast_env && !b->decode_fec;
+   if (use_fast)
+      hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
+            b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
+            (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue, b->d_slow);
+   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-         (u32 *)d_final_range, (int)b->n_act, b->decode_fec);
+         (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast ? (const int *)b->d_slow : (const int *)nullptr, (const unsigned *)(b->d_queue + 2));
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
