@@ -74,19 +74,21 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
  *   oa_decode_kernel       the general decoder over that list (list == NULL: over every stream) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
-      char *scratch, unsigned *queue, const int *list, const unsigned *list_count)
+      char *scratch, unsigned *queue, const int *taken /* NULL, or per stream: 1 = the fast kernel has decoded this packet */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
-   const int n = list ? (int)*list_count : nstreams;
    for (;;) {
-      int s = oa_queue_pop(queue);
-      if (s >= n) break;
-      if (list) s = list[s];
-      if (lens[s] > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } continue; }       /* a length beyond the stream's slot would read the neighbour's packet */
-      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
-      __syncthreads();
-      oa_decode_packet<false>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
+      const int s = oa_queue_pop(queue);
+      if (s >= nstreams) break;
+      const int skip = taken ? wv_uni(taken[s]) : 0;
+      const int len = lens[s];
+      if (!skip && len > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } }       /* a length beyond the stream's slot would read the neighbour's packet */
+      else if (!skip) {
+         if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+         __syncthreads();
+         oa_decode_packet<false>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
+      }
       __syncthreads();
    }
 }
@@ -94,27 +96,29 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 #define OA_DEC_FAST_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
-oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
-      char *scratch, unsigned *counters /* [0] this kernel's queue, [1] the general kernel's queue, [2] length of the list */, int *slow_list)
+oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,
+      char *scratch, unsigned *queue, int *taken /* out, per stream: 1 = decoded here, 0 = left to the general kernel */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
    for (;;) {
-      const int s = oa_queue_pop(counters);
+      const int s = oa_queue_pop(queue);
       if (s >= nstreams) break;
       const int len = lens[s];
       const OaDecStream *gs = streams + s;
       int fast = 0;
-      if (!decode_fec && len >= 3 && len <= packet_stride && len <= 1276) {
+      if (len >= 3 && len <= packet_stride && len <= 1276) {
          const int toc = packets[(size_t)s * packet_stride];
          const int prev = gs->s.prev_mode;
          fast = (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && gs->s.prefilter_and_fold == 0;
       }
       fast = wv_uni(fast);
-      if (!fast) { if (threadIdx.x == 0) slow_list[atomicAdd(counters + 2, 1u)] = s; continue; }
-      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
-      __syncthreads();
-      oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
+      if (threadIdx.x == 0) taken[s] = fast;
+      if (fast) {
+         if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+         __syncthreads();
+         oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
+      }
       __syncthreads();
    }
 }
@@ -993,7 +997,7 @@ struct OpusGpuDecBatch {
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
-   unsigned *d_queue; int *d_slow;          /* [0] fast kernel's queue, [1] general kernel's queue, [2] length of the list of streams the fast kernel handed over */
+   unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; d_slow [S]: 1 = the fast kernel has decoded the stream's packet */
    int num_cu, occ_fast, occ_gen;
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
@@ -1110,13 +1114,17 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    const int use_fast = fast_env && !b->decode_fec;
-   if (use_fast)
+   static const int dbg = getenv("OPUS_AMD_DEC_DEBUG") ? atoi(getenv("OPUS_AMD_DEC_DEBUG")) : 0;          /* bring-up only: 1 = the fast kernel alone, 2 = then the general kernel over every stream */
+   if (use_fast) {
       hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
             b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-            (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue, b->d_slow);
-   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
-         b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-         (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast ? (const int *)b->d_slow : (const int *)nullptr, (const unsigned *)(b->d_queue + 2));
+            (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, b->d_slow);
+   }
+   if (dbg != 1) {
+      hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
+            b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
+            (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast && dbg != 2 ? (const int *)b->d_slow : (const int *)nullptr);
+   }
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
