@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""tools/dec_fast_check.py — the decoder's CELT-only fast kernel (oa_decode_fast_kernel) in front of the general kernel against the general kernel alone: the same packet
+sequences through OPUS_AMD_DEC_FAST = 0 and 1 (one subprocess each: the switch is read once per process) must give identical PCM, sample counts, final ranges AND identical
+stream records, byte for byte.  The sequences mix what the fast kernel takes (CELT-only, one frame) with what it hands over (SILK / hybrid packets, multi-frame packets, lost
+packets and the frames after them), so that streams move between the kernels.  usage: dec_fast_check.py [emu|gpu]      (child: dec_fast_check.py <lib> <out.pkl>)"""
+import os, sys, ctypes, pickle, subprocess, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+
+CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, loss pattern period (0 = none))
+    "celt_stereo":   (48000, 2, 2051, {4002: 96000, 4010: 5}, 20, 14, 5),
+    "celt_mono_10":  (48000, 1, 2051, {4002: 48000, 4010: 5}, 10, 16, 0),
+    "celt_24k":      (24000, 2, 2051, {4002: 64000, 4010: 5}, 20, 10, 4),
+    "audio_auto":    (48000, 2, 2049, {4002: 32000, 4010: 5}, 20, 16, 6),          # SILK / hybrid / CELT packets as the encoder decides
+    "voip_16k":      (16000, 1, 2048, {4002: 20000, 4010: 5}, 20, 10, 0),
+    "celt_40ms":     (48000, 2, 2051, {4002: 96000, 4010: 5}, 40, 6, 0),            # multi-frame packets: general kernel
+}
+
+def make_packets(name):
+    from reflib import ref_fx
+    L = ref_fx(); Fs, ch, app, ctl, ms, frames, loss = CASES[name]
+    L.opus_encoder_create.restype = ctypes.c_void_p; L.opus_encoder_create.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
+    L.opus_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    n = Fs * ms // 1000; S = 5; out = (ctypes.c_ubyte * 4000)(); err = ctypes.c_int(); seqs = []
+    for s in range(S):
+        e = L.opus_encoder_create(Fs, ch, app, ctypes.byref(err))
+        for k, v in ctl.items(): L.opus_encoder_ctl(e, k, v)
+        if name == "audio_auto" and s % 2: L.opus_encoder_ctl(e, 4002, 96000)          # half the streams at a rate where the encoder picks CELT
+        rng = np.random.default_rng(100 * s + len(name)); t = np.arange(n * frames) / Fs
+        x = 6000 * np.sin(2 * np.pi * (180 + 40 * s) * t)[:, None] * (np.sin(2 * np.pi * 1.3 * t + s) > -0.2)[:, None] + rng.normal(0, 300, (n * frames, ch))
+        x = np.clip(x, -32768, 32767).astype(np.int16)
+        pk = []
+        for f in range(frames):
+            k = L.opus_encode(e, np.ascontiguousarray(x[f * n:(f + 1) * n]).ctypes.data, n, out, 1500); assert k > 0
+            pk.append(b"" if loss and (f + s) % loss == loss - 1 else bytes(out[:k]))
+        seqs.append(pk)
+    return seqs
+
+def run_child(libpath, outp):
+    import opus_amd
+    opus_amd.LIB_PATH = libpath
+    res = {}
+    for name, (Fs, ch, app, ctl, ms, frames, loss) in CASES.items():
+        seqs = make_packets(name); S = len(seqs); n = Fs * ms // 1000
+        b = opus_amd.DecoderBatch(S, channels=ch, Fs=Fs)
+        steps = []
+        for f in range(frames):
+            pcm, ns, rng = b.decode([seqs[s][f] for s in range(S)], n)
+            steps.append((pcm.copy(), ns.copy(), rng.copy()))
+        res[name] = (steps, [b.export_state(s) for s in range(S)]); b.close()
+    pickle.dump(res, open(outp, "wb"))
+
+def compare(which="emu", tmpdir="/tmp", verbose=True):
+    if which == "emu":
+        import hostemu; lib = hostemu.build_emu_lib()
+    else: lib = os.path.join(ROOT, "opus_amd/libopus_amd.so")
+    r = {}
+    for mode in "01":
+        outp = os.path.join(tmpdir, "dec_fast_%s_%s_%d.pkl" % (which, mode, os.getpid()))
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), lib, outp], env=dict(os.environ, OPUS_AMD_DEC_FAST=mode))
+        r[mode] = pickle.load(open(outp, "rb")); os.unlink(outp)
+    bad = []
+    for name in CASES:
+        a, b = r["0"][name], r["1"][name]
+        ok = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) for x, y in zip(a[0], b[0]))
+        nd = [sum(p != q for p, q in zip(x, y)) for x, y in zip(a[1], b[1])]
+        if verbose: print("%-13s output %s, state bytes differing per stream %s" % (name, "equal" if ok else "DIFFERS", nd))
+        if not ok or any(nd): bad.append(name)
+    return bad
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3: run_child(sys.argv[1], sys.argv[2])
+    else:
+        bad = compare(sys.argv[1] if len(sys.argv) > 1 else "emu")
+        print("FAIL: %s" % bad if bad else "fast + general kernels == general kernel alone on every case")
+        sys.exit(1 if bad else 0)

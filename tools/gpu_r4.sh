@@ -17,8 +17,8 @@ pool) for c in 2 3 4; do timeout 300 python bench.py $B --config $c --corpus poo
 bench3) for m in ${SPLIT_MODES:-0 1}; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 3 > $O/bench3_split$m.log 2>&1; done ;;
 bench4) for m in ${SPLIT_MODES:-0 1}; do OPUS_AMD_SH_SPLIT=$m timeout 300 python bench.py $B --config 4 > $O/bench4_split$m.log 2>&1; done ;;
 bench5) timeout 300 python bench.py $B --config 5 > $O/bench5.log 2>&1 ;;
-decode) for f in 0 1; do for c in 2 3 4; do OPUS_AMD_DEC_FAST=$f timeout 300 python bench.py $B --config $c --decode > $O/decode${c}_fast$f.log 2>&1; done; done ;;
-dectests) timeout 1500 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_silkdec.py tests/test_gpu_float_decoder_gate.py tests/test_gpu_ms_batch.py -x -q > $O/pytest_decoder.log 2>&1 ;;
+decode) for f in ${DEC_FAST_MODES:-0 1}; do for c in 2 3 4; do OPUS_AMD_DEC_FAST=$f timeout 120 python bench.py $B --config $c --decode > $O/decode${c}_fast$f.log 2>&1; done; done ;;
+dectests) timeout 400 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_silkdec.py tests/test_gpu_float_decoder_gate.py tests/test_gpu_ms_batch.py -x -q --timeout 90 > $O/pytest_decoder.log 2>&1 ;;
 bench_default) timeout 900 python bench.py > $O/bench_default.log 2>&1 ;;
 prof2|prof3|prof4) c=${step#prof}; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete ;;
 pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmc$c > $O/pmc$c.log 2>&1 ;;
@@ -29,7 +29,7 @@ msbatch) timeout 1500 python -m pytest tests/test_gpu_ms_batch.py tests/test_gpu
 latency) for m in 0 1; do OPUS_AMD_SH_SPLIT=$m timeout 600 python tools/classic_latency.py 200 > $O/classic_latency_split$m.log 2>&1; done; for c in 2 3 4; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --streams 1 --config $c > $O/bench${c}_one_stream.log 2>&1; done ;;
 soak) timeout 1500 python tools/parity_soak.py --float-analysis --streams ${SOAK_STREAMS:-512} --frames ${SOAK_FRAMES:-600} --configs 2,3,4 > $O/parity_soak_analysis.log 2>&1 ;;
 ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
-full) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1 ;;
+full) timeout 1200 python -m pytest tests -m gpu -x -q --timeout 600 > $O/pytest_gpu_full.log 2>&1 ;;
 *) echo "unknown step $step" ;;
 esac
 done
