@@ -25,12 +25,12 @@ CPU_STREAMS = 64         # streams of the GPU batch the CPU legs (baseline, pari
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
-    3: dict(name="SILK-only encode, VOIP, 16 kHz mono, 20 ms, wideband, VBR 24 kb/s, complexity 10", app=2048, Fs=16000, ch=1, kernel="oa_sh_encode_kernel",
+    3: dict(name="SILK-only encode, VOIP, 16 kHz mono, 20 ms, wideband, VBR 24 kb/s, complexity 10", app=2048, Fs=16000, ch=1, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded frames/s (SILK-only, 16 kHz mono, 20 ms, complexity 10)"),
-    4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_encode_kernel",
+    4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1001), (4008, 1105), (4006, 1), (4002, 128000), (4010, 10)), metric="encoded frames/s (hybrid, 48 kHz stereo, 20 ms, complexity 10)"),
     5: dict(name="multistream, 255 mono AUDIO streams per encoder (mapping family 255), 48 kHz, 20 ms, 64 kb/s per stream, complexity 10; 257 encoders = 65,535 elementary streams",
-            app=2049, Fs=48000, ch=1, kernel="oa_sh_encode_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
+            app=2049, Fs=48000, ch=1, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
 
 def reference_music(nsamp, seeds, starts=None):
@@ -368,7 +368,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None)
         r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
         r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
-        r2["kernel"] = "oa_decode_kernel"
+        r2["kernel"] = "oa_decode_fast_kernel + oa_decode_kernel (one call)"
         r2["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool(torch.equal(drng, rng))      # every stream decoded FR samples and every frame ends on the encoder's final range
         L.opusgpu_dec_state_size.restype = ctypes.c_int
         r2["algorithmic_bytes_per_frame"] = round(FR * CH * 2 + mean_len + 8 + 2 * L.opusgpu_dec_state_size(), 1)
