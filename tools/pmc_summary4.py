@@ -5,8 +5,8 @@ kernels of one call: what bench.py quotes in roofline.traffic / roofline.issue. 
 import csv, collections, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
 FR = 16384; GiB = 1 << 30
-# resident waves per SIMD of each kernel (LDS / VGPR footprint: tools/kernel_resources.sh + the launch's dynamic LDS); front: 10 waves per CU mono, 9 stereo
-WPS = {"oa_encode_kernel": 4.0, "oa_sh_front_kernel": 2.5, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 2.0, "oa_decode_fast_kernel": 3.0, "oa_sh_encode_kernel": 1.75}
+# resident waves per SIMD of each kernel (LDS / VGPR footprint: tools/kernel_resources.sh + the launch's dynamic LDS); front: 12 waves per CU mono, 10 stereo
+WPS = {"oa_encode_kernel": 4.0, "oa_sh_front_kernel": 3.0, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 2.0, "oa_decode_fast_kernel": 3.0, "oa_sh_encode_kernel": 1.75}
 def table(d, f):
     """{kernel: {counter: mean value per dispatch}}, dispatch counts"""
     p = os.path.join(d, f); agg = collections.defaultdict(lambda: collections.defaultdict(list))
