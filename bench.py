@@ -287,11 +287,21 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
 
+    gather_err = None
     for t in range(W):
         step(t)
-        if gather is not None: gather.launch(lens[t], rng[t], pk[t])
-    if gather is not None: gather.flush()
+        if gather is not None:
+            try: gather.launch(lens[t], rng[t], pk[t])
+            except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e); gather = None
+    if gather is not None:
+        try: gather.flush(); torch.cuda.synchronize(dev)
+        except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e); gather = None
     torch.cuda.synchronize(dev)
+    if world > 1 and gather_cls and gather_on:
+        # an exchange that failed during the warm-up on ANY rank is left out on every rank (and reported in the line: "gather": {"error": ...}) rather than taking the run down
+        okf = torch.tensor([0 if gather_err else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0: gather = None; gather_err = gather_err or "the exchange failed on another rank"
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -319,7 +329,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     alg = FR * CH * 2 + mean_len + 8 + state_moved
     res = {"config_id": cid, "leg": "encode", "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
            "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved, "float_analysis": bool(analysis_on),
-           "gather": None if gather is None else gather.stats()}
+           "gather": ({"error": gather_err, "in_timed_region": False} if gather_err else None) if gather is None else gather.stats()}
     results = [res]
     # the CPU legs' sample: the first NC streams, every frame the batch saw of them
     pcm_h = None
@@ -476,7 +486,7 @@ def main():
                        "streams_per_gpu": main_res["streams_per_gpu"], "frames_per_step": main_res["streams_per_gpu"] * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),
                        "lib_build": built, "lib_matches_sources": None if src_now is None else built == "OA_SRC_HASH=" + src_now,
-                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final RCCL gather of the compacted packets in the timed region (side stream, double-buffered)" if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
+                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else ", final RCCL gather of the compacted packets in the timed region (side stream, double-buffered)" if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
             "roofline": roof(main_res, main_res["streams_per_gpu"]),
         }
         if per_rank is not None: res["ranks_seen"] = len(per_rank); res["per_rank"] = per_rank
