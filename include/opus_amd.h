@@ -227,6 +227,7 @@ OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_import_state(OpusGpuDecBatch *b, opus_int32 stream, const void *blob);
 OPUS_AMD_EXPORT int opusgpu_dec_kernel_lds_bytes(void);
+OPUS_AMD_EXPORT int opusgpu_dec_fast_kernel_lds_bytes(void);     /* LDS of one wave of the CELT-only fast kernel (16 waves per CU at <= 10,240 B) */
 
 /* ================= packet toolkit (host-side; reference/include/opus.h:713-788 and :953-1167) =================
  * Same names, arguments and results as the reference (src/opus.c:203-399, src/opus_decoder.c:1252-1340, src/repacketizer.c).

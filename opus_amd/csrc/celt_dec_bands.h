@@ -385,14 +385,17 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
    balance = wv_uni(balance); codedBands = wv_uni(codedBands); disable_inv = wv_uni(disable_inv);
    const int start = wv_uni(L->sh.start), end = wv_uni(L->sh.end), LM = wv_uni(L->sh.LM), C = wv_uni(L->sh.C), Nfull = wv_uni(L->sh.N);
    i32 *Xg = L->Xg, *Yg = C == 2 ? L->Xg + Nfull : 0;                                  /* the spectrum in the wave's HBM scratch; a band is decoded in LDS (xb / yb) and copied out */
-   WV_LDS i32 *norm = L->BC.q.norm, *norm2 = L->BC.q.norm + OA_NORM_LEN;
+   /* the folding memory (bands.c:1600 `norm`, `norm2`) sits behind the spectrum in the wave's HBM scratch: a band's source is staged into `lbs` before the band is decoded (the staging copy
+    * doubles as quant_band's lowband scratch), its contribution leaves through `lbo` when it is done -- both lane-parallel and coalesced */
+   i32 *norm = L->Xg + 2 * OA_MAX_FRAME, *norm2 = norm + OA_NORM_LEN;
+   WV_LDS i32 *const lbs = L->BC.q.lbs, *const lbo_buf = L->BC.q.lbo;
    WV_LDS u8 *collapse_masks = L->collapse_masks;
    const WV_LDS i32 *pulses = L->pulses, *tf_res = L->tf_res;
    i32 remaining_bits;
    int M = 1 << LM, B = shortBlocks ? M : 1, lowband_offset = 0, update_lowband = 1;
    int norm_offset = M * ct_eBands[start];
    /* (the reference borrows the last band of X as lowband scratch, bands.c:1642-1653, and stops using it when it decodes that band: a buffer of its own here) */
-   WV_LDS i32 *lowband_scratch = L->BC.q.lbs;
+   WV_LDS i32 *lowband_scratch = lbs;
    BandCfg cfg;
    u32 seed = (u32)wv_uni((i32)L->st.rng);
    i32x4 r;
@@ -446,15 +449,23 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
          dual_stereo = 0;
          wv_sync(); FOR_LANES(j, M * ct_eBands[i] - norm_offset) norm[j] = half32(norm[j] + norm2[j]); wv_sync();
       }
-      WV_LDS i32 *lb = effective_lowband != -1 ? norm + effective_lowband : 0;
-      WV_LDS i32 *lb2 = effective_lowband != -1 ? norm2 + effective_lowband : 0;
-      WV_LDS i32 *lbo = last ? 0 : norm + M * ct_eBands[i] - norm_offset;
-      WV_LDS i32 *lbo2 = last ? 0 : norm2 + M * ct_eBands[i] - norm_offset;
+      WV_LDS i32 *const lb = effective_lowband != -1 ? lbs : 0;
+      WV_LDS i32 *const lbo = last ? 0 : lbo_buf;
+      const int out_at = M * ct_eBands[i] - norm_offset;
+      wv_sync();
+      if (lb) { FOR_LANES(j, N) lbs[j] = norm[effective_lowband + j]; }
+      wv_sync();
       if (dual_stereo) {
          r = dec_quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
          x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-         r = dec_quant_band_wave(L, cfg, remaining_bits, seed, Y, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
+         wv_sync();
+         if (lbo) { FOR_LANES(j, N) norm[out_at + j] = lbo_buf[j]; }
+         if (lb) { FOR_LANES(j, N) lbs[j] = norm2[effective_lowband + j]; }
+         wv_sync();
+         r = dec_quant_band_wave(L, cfg, remaining_bits, seed, Y, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, y_cm);
          y_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+         wv_sync();
+         if (lbo) { FOR_LANES(j, N) norm2[out_at + j] = lbo_buf[j]; }
       } else {
          if (Y != 0) {
             cfg.theta_round = 0;
@@ -464,6 +475,8 @@ WV_DEVN void dec_quant_all_bands_wave(WV_LDS DecLds *L, int shortBlocks, int spr
          }
          x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
          y_cm = x_cm;
+         wv_sync();
+         if (lbo) { FOR_LANES(j, N) norm[out_at + j] = lbo_buf[j]; }
       }
       wv_sync();
       FOR_LANES(j, N) { Xg[M * ct_eBands[i] + j] = X[j]; if (Y != 0) Yg[M * ct_eBands[i] + j] = Y[j]; }       /* the finished band -> the spectrum */

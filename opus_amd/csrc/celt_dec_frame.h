@@ -325,6 +325,81 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
    if (silence) { wv_sync(); FOR_LANES(i, C * NBE) L->oldBandE[i] = -GC(28.f); wv_sync(); }
    K_DUMP("dec_X", L->Xg, C * N * 4); K_DUMP("dec_oldBandE", L->oldBandE, 2 * NBE * 4);
 
+   if (FAST) {
+      /* ---- the fast kernel's tail: celt_synthesis (celt_decoder.c:413), the post-filter (:1536), the history / overlap update and the de-emphasis (:318) one CHANNEL at a time in
+       * syn[0] -- half the synthesis memory, which is what lets 16 waves share a CU; the price is the de-emphasis recursion running once per channel instead of on two lanes at once ---- */
+      int B, NB, shift;
+      if (isTransient) { B = M; NB = 120; shift = 3; }
+      else { B = 1; NB = 120 << LM; shift = 3 - LM; }
+      const int head = wv_uni(st->hist_head), ds = oa_dec_downsample(st), Nd = N / ds;
+      WV_LDS i32 *const syn = L->BC.syn[0];
+      i32 *freq = L->Xg;
+      accum = wv_uni(accum);
+      LANE0 { st->postfilter_period = imax(st->postfilter_period, OA_MIN_PERIOD); st->postfilter_period_old = imax(st->postfilter_period_old, OA_MIN_PERIOD); }
+      wv_sync();
+      if (CC == 2 && C == 1) {
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
+         FOR_LANES(i, N) freq[N + i] = freq[i];        /* the IMDCT consumes its input: keep a copy for the second channel */
+         wv_sync();
+      } else if (CC == 1 && C == 2) {
+         denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
+         denormalise_bands_wave(freq + N, L->oldBandE + NBE, L->scr, start, effEnd, M, silence, downsample);
+         FOR_LANES(i, N) freq[i] = add32(half32(freq[i]), half32(freq[N + i]));
+         wv_sync();
+      }
+      for (int c = 0; c < CC; c++) {
+         i32 *fc;
+         if (CC == 2 && C == 1) fc = c == 0 ? freq + N : freq;
+         else if (CC == 1 && C == 2) fc = freq;
+         else { fc = freq + c * N; denormalise_bands_wave(fc, L->oldBandE + c * NBE, L->scr, start, effEnd, M, silence, downsample); }
+         wv_sync();
+         FOR_LANES(i, overlap) syn[i] = gs->overlap_mem[c * overlap + i];
+         FOR_LANES(i, N) syn[overlap + i] = 0;
+         wv_sync();
+         for (int b = 0; b < B; b++) mdct_backward_wave(fc + b, syn + NB * b, shift, B, L->aux);
+         FOR_LANES(i, N) syn[i] = saturate(syn[i], SIG_SAT);
+         wv_sync();
+         K_DUMP("dec_syn", syn, N * 4);
+         const i32 *hist = gs->hist + c * OA_DEC_HISTORY;
+         comb_filter_inplace_wave(syn, hist, head, 0, st->postfilter_period_old, st->postfilter_period, 120, st->postfilter_gain_old, st->postfilter_gain,
+               st->postfilter_tapset_old, st->postfilter_tapset, overlap);
+         if (LM != 0)
+            comb_filter_inplace_wave(syn, hist, head, 120, st->postfilter_period, sh->postfilter_pitch, N - 120, st->postfilter_gain, sh->postfilter_gain,
+                  st->postfilter_tapset, sh->postfilter_tapset, overlap);
+         wv_sync();
+         FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = syn[i];
+         FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = syn[N + i];
+         wv_sync();
+         if (lane == 0) {
+            i32 m = st->preemph_memD[c];
+            for (int j0 = 0; j0 < N; j0 += 8) {
+               i32 t[8];
+#pragma unroll
+               for (int k = 0; k < 8; k++) t[k] = syn[j0 + k];
+#pragma unroll
+               for (int k = 0; k < 8; k++) { t[k] = saturate(t[k] + m, SIG_SAT); m = mult16_32_q15(27853, t[k]); }
+#pragma unroll
+               for (int k = 0; k < 8; k++) syn[j0 + k] = sig2word16(t[k]);
+            }
+            st->preemph_memD[c] = m;
+         }
+         wv_sync();
+         FOR_LANES(i, Nd) {
+            const i32 v = syn[i * ds];
+            const int it = i * CC + c;
+            if (accum) { const i32 w = (i32)pcm_out[it] + v; pcm_out[it] = (i16)(w > 32767 ? 32767 : w < -32768 ? -32768 : w); }
+            else pcm_out[it] = (i16)v;
+         }
+         wv_sync();
+      }
+      LANE0 {
+         st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
+         st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset;
+         st->postfilter_period = sh->postfilter_pitch; st->postfilter_gain = sh->postfilter_gain; st->postfilter_tapset = sh->postfilter_tapset;
+         if (LM != 0) { st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset; }
+      }
+      wv_sync();
+   } else {
    /* ---- celt_synthesis (celt_decoder.c:413): denormalise in place, IMDCT per block into syn[c] (head = last frame's overlap tail) ---- */
    {
       int B, NB, shift;
@@ -382,6 +457,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
       if (LM != 0) { st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset; }
    }
    wv_sync();
+   }
    if (C == 1) { FOR_LANES(i, NBE) L->oldBandE[NBE + i] = L->oldBandE[i]; wv_sync(); }
    {
       const i32 max_background_increase = imin(160, wv_uni(st->loss_duration) + M) * GC(0.001f);
@@ -395,7 +471,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
       }
    }
    wv_sync();
-   celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
+   if (!FAST) celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
    int ret = frame_size;
    LANE0 {
       st->rng = L->ec.rng;

@@ -1,9 +1,10 @@
 /* celt_dec_lds.h — per-wavefront LDS working set of the decoder (one wave = one stream; the frames of a multi-frame packet are decoded one after the other by the same wave).
- *   BC (8,640 B)  PVQ phase: folding memory norm[2][624], pulse vector, the band being decoded (X / Y staging + lowband scratch); synthesis phase: syn[2][960+120]
- *   A  (7,680 B)  LAST: scratch of the concealment's pitch mode and, together with BC, the SILK decoder's arena (SilkLdsAll at &BC).  The CELT-only fast kernel
- *                 (oa_decode_fast_kernel: packets whose decode touches neither) allocates LDS only up to here.
- * The decoded spectrum X[2][960] itself (normalised, then denormalised in place = the IMDCT's input) lives in a per-wave HBM scratch (Xg): every pass over it is
- * lane-parallel and coalesced (band copy-out, anti-collapse through the staging buffer, denormalise, the IMDCT's pre-rotation reads).
+ *   BC (8,640 B)  PVQ phase: pulse vector, the band being decoded (X / Y staging), its folding source and its contribution to the folding memory (3,552 B); synthesis phase: syn[2][960+120].
+ *                 The CELT-only fast kernel (oa_decode_fast_kernel) synthesises the channels one after the other in syn[0] and allocates LDS only up to the end of it (4,320 B of BC).
+ *   A  (7,680 B)  LAST: scratch of the concealment's pitch mode and, together with BC, the SILK decoder's arena (SilkLdsAll at &BC): the general kernel only.
+ * The decoded spectrum X[2][960] itself (normalised, then denormalised in place = the IMDCT's input) and the folding memory norm[2][624] live in a per-wave HBM scratch (Xg): every
+ * pass over them is lane-parallel and coalesced (band copy-out, folding source / contribution of a band, anti-collapse through the staging buffer, denormalise, the IMDCT's
+ * pre-rotation reads).
  * packet: the current frame's bytes (range decoder input). */
 #ifndef OPUS_AMD_CELT_DEC_LDS_H
 #define OPUS_AMD_CELT_DEC_LDS_H
@@ -30,11 +31,15 @@ struct DecLds {
    u8 packet[OA_MAX_PACKET + 4];      /* frame bytes at packet + 1 (same convention as the encoder's EC macros) */
    i32 *Xg;                           /* the spectrum X[2][OA_MAX_FRAME] of the frame in flight: per-wave HBM scratch (set by the kernel) */
    union {
-      struct { i32 norm[2 * OA_NORM_LEN]; i32 iy[176 + 8]; i32 xb[176], yb[176], lbs[176]; } q;      /* xb / yb: the band being decoded, copied out to Xg when it is done; lbs: quant_band's lowband scratch (the reference borrows the last band of X, bands.c:1642) */
-      i32 syn[2][OA_MAX_FRAME + OA_OVERLAP];
+      /* xb / yb: the band being decoded, copied out to Xg when it is done; lbs: the band's folding source, staged from the folding memory in the HBM scratch -- also quant_band's lowband
+       * scratch (the reference borrows the last band of X, bands.c:1642); lbo: the band's contribution to the folding memory (quant_band's lowband_out), copied out when it is complete */
+      struct { i32 iy[176 + 8]; i32 xb[176], yb[176], lbs[176], lbo[176]; } q;
+      i32 syn[2][OA_MAX_FRAME + OA_OVERLAP];     /* the fast kernel synthesises one channel at a time in syn[0] and allocates no further */
    } BC;
    union { i32 w[2 * OA_MAX_FRAME]; } A;
 };
-#define OA_DEC_FAST_LDS_BYTES (offsetof(DecLds, A))
-#define OA_DEC_SCRATCH_BYTES (2 * OA_MAX_FRAME * sizeof(i32))
+#define OA_DEC_FAST_LDS_BYTES (offsetof(DecLds, BC) + (OA_MAX_FRAME + OA_OVERLAP) * sizeof(i32))
+static_assert(sizeof(((DecLds *)0)->BC.q) <= (OA_MAX_FRAME + OA_OVERLAP) * sizeof(i32), "the PVQ phase fits the fast kernel's LDS");
+/* per resident wave in HBM: the spectrum X[2][OA_MAX_FRAME] of the frame in flight, then the folding memory norm[2][OA_NORM_LEN] (celt_dec_bands.h) */
+#define OA_DEC_SCRATCH_BYTES ((2 * OA_MAX_FRAME + 2 * OA_NORM_LEN) * sizeof(i32))
 #endif

@@ -69,9 +69,9 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
  * Two kernels on one HIP stream:
  *   oa_decode_fast_kernel  packets whose decode is the CELT steady state and nothing else -- a CELT-only TOC with one coded frame, a stream whose last packet was CELT-only too
  *                          (or that has not decoded anything yet), no FEC request, no pending fold of the concealment -- with the SILK decoder, the concealment and every
- *                          transition compiled out (oa_decode_packet<true>): it needs neither the A arena nor their registers, so more waves fit; everything else goes to a
- *                          device-side list
- *   oa_decode_kernel       the general decoder over that list (list == NULL: over every stream) */
+ *                          transition compiled out (oa_decode_packet<true>): it needs neither the A arena nor their registers and synthesises one channel at a time, so 16 waves
+ *                          share a CU; it marks the streams it decoded in `taken`
+ *   oa_decode_kernel       the general decoder over the streams not taken (taken == NULL: over every stream) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
       char *scratch, unsigned *queue, const int *taken /* NULL, or per stream: 1 = the fast kernel has decoded this packet */)
@@ -93,7 +93,7 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
    }
 }
 #ifndef OA_DEC_FAST_WAVES_PER_EU
-#define OA_DEC_FAST_WAVES_PER_EU 3
+#define OA_DEC_FAST_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,

@@ -53,7 +53,7 @@ extern "C" void emu_decode_batch(OaDecStream *streams, const uint8_t *data, int 
    for (int s = 0; s < S; s++) {
       DecLds *L = (DecLds *)aligned_alloc(64, (sizeof(DecLds) + 63) & ~63);
       memset(L, 0xA5, sizeof(DecLds));
-      static thread_local int32_t xg[2 * OA_MAX_FRAME];                           /* the wave's spectrum scratch (what the kernel points L->Xg at) */
+      static thread_local int32_t xg[OA_DEC_SCRATCH_BYTES / 4];                     /* the wave's spectrum + folding-memory scratch (what the kernel points L->Xg at) */
       memset(xg, 0xA5, sizeof xg); L->Xg = xg;
       DJob j = {L, streams + s, data + (size_t)s * stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, ns + s, rngs + s};
       emu_run_wave(djob_entry, &j);

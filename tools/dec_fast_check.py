@@ -14,15 +14,20 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "audio_auto":    (48000, 2, 2049, {4002: 32000, 4010: 5}, 20, 16, 6),          # SILK / hybrid / CELT packets as the encoder decides
     "voip_16k":      (16000, 1, 2048, {4002: 20000, 4010: 5}, 20, 10, 0),
     "celt_40ms":     (48000, 2, 2051, {4002: 96000, 4010: 5}, 40, 6, 0),            # multi-frame packets: general kernel
+    "celt_2_5ms":    (48000, 2, 2051, {4002: 128000, 4010: 5}, 2.5, 24, 7),         # LM = 0: one post-filter segment
+    "celt_5ms_12k":  (12000, 1, 2051, {4002: 24000, 4010: 5}, 5, 16, 0),            # downsampling by 4 on the way out
+    "mono_coded":    (48000, 2, 2051, {4002: 48000, 4010: 5, 4022: 1}, 20, 10, 4),  # mono packets into a stereo decoder: one spectrum, two syntheses
+    "stereo_to_mono": (48000, 2, 2051, {4002: 96000, 4010: 5}, 20, 10, 0, 1),       # stereo packets into a mono decoder: the spectra are mixed before the synthesis
 }
+def dec_channels(name): return CASES[name][7] if len(CASES[name]) > 7 else CASES[name][1]
 
 def make_packets(name):
     from reflib import ref_fx
-    L = ref_fx(); Fs, ch, app, ctl, ms, frames, loss = CASES[name]
+    L = ref_fx(); Fs, ch, app, ctl, ms, frames, loss = CASES[name][:7]
     L.opus_encoder_create.restype = ctypes.c_void_p; L.opus_encoder_create.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
     L.opus_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    n = Fs * ms // 1000; S = 5; out = (ctypes.c_ubyte * 4000)(); err = ctypes.c_int(); seqs = []
+    n = int(Fs * ms // 1000); S = 5; out = (ctypes.c_ubyte * 4000)(); err = ctypes.c_int(); seqs = []
     for s in range(S):
         e = L.opus_encoder_create(Fs, ch, app, ctypes.byref(err))
         for k, v in ctl.items(): L.opus_encoder_ctl(e, k, v)
@@ -41,9 +46,10 @@ def run_child(libpath, outp):
     import opus_amd
     opus_amd.LIB_PATH = libpath
     res = {}
-    for name, (Fs, ch, app, ctl, ms, frames, loss) in CASES.items():
-        seqs = make_packets(name); S = len(seqs); n = Fs * ms // 1000
-        b = opus_amd.DecoderBatch(S, channels=ch, Fs=Fs)
+    for name in CASES:
+        Fs, ch, app, ctl, ms, frames, loss = CASES[name][:7]
+        seqs = make_packets(name); S = len(seqs); n = int(Fs * ms // 1000)
+        b = opus_amd.DecoderBatch(S, channels=dec_channels(name), Fs=Fs)
         steps = []
         for f in range(frames):
             pcm, ns, rng = b.decode([seqs[s][f] for s in range(S)], n)
