@@ -25,6 +25,9 @@ __device__ unsigned long long oa_sh_phase_ticks[24];
 #define SE_TICK(tk_, id) do { if (threadIdx.x == 0) { const u32 t_ = (u32)clock64(); atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - (u32)*(tk_))); *(tk_) = (i32)t_; } } while (0)
 #define SE_CLK_BEGIN() const u32 clk0_ = (u32)clock64()
 #define SE_CLK_END(id) do { if (threadIdx.x == 0) atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)((u32)clock64() - clk0_)); } while (0)
+/* a clock of the function's own (a register): sub-marks that leave the parent phase's clock alone */
+#define SE_LTIC() u32 ltic_ = (u32)clock64()
+#define SE_LTOC(id) do { const u32 t_ = (u32)clock64(); if (threadIdx.x == 0) atomicAdd(&oa_sh_phase_ticks[id], (unsigned long long)(u32)(t_ - ltic_)); ltic_ = t_; } while (0)
 #endif
 #include "silk_enc_all.h"
 #include "opus_surround.h"

@@ -923,6 +923,7 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
    }
    /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only), in the arena the SILK state is about to
     * be loaded into; a call the reference turns away before that (:1231) leaves it alone */
+   SE_CLK_BEGIN();
    if (!analysed && !(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
       if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
          LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
@@ -936,6 +937,7 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
       }
    }
    wv_sync();
+   SE_CLK_END(23);
    SE_PHASE_START(&L->S);                                                               /* (profiling build: the analysis borrowed the arena the phase clock lives in) */
    {  /* the SILK encoder state (coalesced) */
       se_state_copy_wave((WV_LDS i32 *)&L->S.st, (const i32 *)&gs->silk, CC, wv_uni(L->silk_tail));

@@ -24,6 +24,8 @@
 #define SE_CLK_END(id)
 #define SE_PHASE_START(S_)
 #define SE_TICK(tk_, id)
+#define SE_LTIC()
+#define SE_LTOC(id)
 #endif
 #define SE_FIX(C, Q) ((i32)((C) * ((i64)1 << (Q)) + 0.5))          /* SILK_FIX_CONST (silk/SigProc_FIX.h:574): the literal keeps the reference's type */
 #define SE_TYPE_NO_VOICE 0
@@ -588,6 +590,7 @@ WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       WV_LDS i16 *A_Q12s, WV_LDS PitchLds *PL)
 {
    const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length, wl = c->pitch_LPC_win_length, la = c->la_pitch, order = c->pitchEstimationLPCOrder;
+   SE_LTIC();
    {
       const WV_LDS i16 *x_ptr = x + buf_len - wl;
       LANE0 { se_apply_sine_window(Wsig, x_ptr, 1, la); se_apply_sine_window(Wsig + wl - la, x_ptr + wl - la, 2, la); }
@@ -605,8 +608,10 @@ WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       wv_sync();
       LANE0 se_bwexpander(A_Q12s, order, SE_FIX(0.99f, 16));
    }
+   SE_LTOC(20);
    se_lpc_analysis_filter_wave(res, x, A_Q12s, buf_len, order);
    wv_sync();
+   SE_LTOC(21);
    if (c->indices.signalType != SE_TYPE_NO_VOICE && c->first_frame_after_reset == 0) {
       i32 thrhld_Q13 = SE_FIX(0.6, 13);
       thrhld_Q13 = sk_mlabb(thrhld_Q13, SE_FIX(-0.004, 13), order);

@@ -195,6 +195,7 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
 {
    const WV_LDS i16 *x_ptr = x - c->la_shape;
    const int order = c->shapingLPCOrder, swl = c->shapeWinLength;
+   SE_LTIC();
    LANE0 {
       i32 SNR_adj_dB_Q7 = c->SNR_dB_Q7;
       ctl->input_quality_Q14 = ((i32)c->input_quality_bands_Q15[0] + c->input_quality_bands_Q15[1]) >> 2;
@@ -222,6 +223,7 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
       }
       LANE0 c->indices.quantOffsetType = energy_variation_Q7 > SE_FIX(0.6f, 7) * (nSegs - 1) ? 0 : 1;
    }
+   SE_LTOC(17);
    i32 strength_Q16 = sk_mulwb(ctl->predGain_Q16, SE_FIX(1e-3f, 16));
    const i32 BWExp_Q16 = sk_div32_varQ(SE_FIX(0.94f, 16), sk_mlaww(SE_FIX(1.0, 16), strength_Q16, strength_Q16), 16);
    const int warping_Q16 = c->warping_Q16 > 0 ? sk_mlawb(c->warping_Q16, (i32)ctl->coding_quality_Q14, SE_FIX(0.01, 18)) : 0;
@@ -246,8 +248,10 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
       if (c->warping_Q16 > 0) scale = se_warped_autocorr_wave(w32, xw, warping_Q16, swl, order);
       else scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
       LANE0 w32[0] = add32(w32[0], imax(sk_mulwb(w32[0] >> 4, SE_FIX(3e-5f, 20)), 1));
+      SE_LTOC(18);
       const i32 nrg_w = se_schur64_wave(stk, w32, order);
       se_k2a_Q16_wave(stk + 24, stk, order);
+      SE_LTOC(19);
       LANE0 {
          WV_LDS i32 *auto_corr = w32, *refl_coef_Q16 = stk, *AR_Q24 = stk + 24;
          i32 nrg = nrg_w; (void)auto_corr; (void)refl_coef_Q16;
@@ -268,6 +272,7 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
             for (int i = 0; i < order; i++) ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER + i] = (i16)sk_sat16(sk_rround(AR_Q24[i], 11));
          } else se_lpc_fit(&ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER], AR_Q24, 13, 24, order);
       }
+      SE_LTOC(22);
    }
    LANE0 {
       const i32 SNR_adj_dB_Q7 = w32[26];

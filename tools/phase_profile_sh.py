@@ -5,7 +5,8 @@ import ctypes, os, subprocess, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 PH = ["load state", "silence+decide+highpass", "silk_Encode front (control, resample, VAD)", "find_pitch_lags", "noise_shape_analysis", "find_pred_coefs", "process_gains", "NSQ", "encode indices+pulses",
-      "silk_Encode tail", "finalise+store", "  pred: LTP corr + VQ + analysis filter", "  pred: Burg x2 + A2NLSF(2nd half)", "  pred: NLSF interpolation search", "  pred: final A2NLSF", "  pred: NLSF quantiser + NLSF2A", "CELT layer of a hybrid frame (+ store)"]
+      "silk_Encode tail", "finalise+store", "  pred: LTP corr + VQ + analysis filter", "  pred: Burg x2 + A2NLSF(2nd half)", "  pred: NLSF interpolation search", "  pred: final A2NLSF", "  pred: NLSF quantiser + NLSF2A", "CELT layer of a hybrid frame (+ store)",
+      "  shape: sparseness + control", "  shape: window + (warped) autocorrelation", "  shape: schur64 + k2a", "  pitch: window + autocorr + schur + k2a", "  pitch: LPC analysis filter", "  shape: lane-0 gain / bwexpand / limit_warped_coefs", "tonality analysis (own clock, not in the total)"]
 def main():
     so = os.path.join(ROOT, "opus_amd/libopus_amd_prof.so")
     hd = os.path.join(ROOT, "opus_amd/csrc")
@@ -29,7 +30,7 @@ def main():
         if i == 3: L.opusgpu_debug_sh_phase_ticks(ticks, 1)
         b.encode(pcm, n)
     L.opusgpu_debug_sh_phase_ticks(ticks, 0)
-    t = np.array(list(ticks)[:17], dtype=np.float64)
+    t = np.array(list(ticks)[:24], dtype=np.float64)
     t[5] += t[11:16].sum(); tot = t[:11].sum() + t[16]     # the sub-marks consume find_pred_coefs' clock: give the total back to the parent row
     print("oa_sh_encode_kernel, complexity %d: stage shares over %d frames (shader clock ticks per frame: %.0f)" % (cx, 5 * S, tot / (5 * S)))
     for n, v in zip(PH, t): print("  %-44s %6.2f %%  %9.0f ticks/frame" % (n, 100 * v / tot, v / (5 * S)))
