@@ -134,6 +134,93 @@ WV_DEV void se_k2a_Q16_wave(WV_LDS i32 *A_Q24, const WV_LDS i32 *rc_Q16, int ord
    if (lane < order) A_Q24[lane] = a;
    wv_sync();
 }
+/* ---- two sub-frames per pass (noise shaping analysis): lanes 0..31 work on sub-frame a, lanes 32..63 on sub-frame b.  order <= 24, so a chain / a correlation row fits one half. ---- */
+WV_DEV i32 wv_half_head(i32 v) { const i32 a = wv_lane_const<0>(v), b = wv_lane_const<32>(v); return wv_lane() < 32 ? a : b; }
+/* se_warped_autocorr_wave for two windowed sub-frames at once.  The window (sine slopes from wtab, silk/fixed/apply_sine_window_FIX.c:36 through se_sine_window_table) is applied as the
+ * samples are fetched, 64 per half at a time into a register per lane; the head lane of each half takes its next sample from there (v_readlane), the sample then travels down the
+ * chain beside the stage value (DPP), so the loop touches no memory.  Stages that have not started see zeros from above and stages that have finished are fed zero samples: no lane
+ * needs a predicate, a product with a sample outside [0, length) is zero.  Returns the lane's half's scale; corr_a / corr_b: LDS [order + 1]. */
+WV_DEV int se_warped_autocorr2_wave(WV_LDS i32 *corr_a, WV_LDS i32 *corr_b, const WV_LDS i16 *x_a, const WV_LDS i16 *x_b, const WV_LDS i32 *wtab, int slope_part, int flat_part,
+      int warping_Q16, int length, int order)
+{
+   const int lane = wv_lane(), l = lane & 31;
+   const bool head = l == 0, hb = lane >= 32;
+   i32 cur = 0, prev_stage_prev = 0, my = 0, xs = 0;
+   i64 acc = 0;
+   const int total = length + order;
+   for (int base = 0; base < total; base += 64) {
+      i32 in_a = 0, in_b = 0;
+      {
+         const int i = base + lane;
+         if (i < length) {
+            i32 va = x_a[i], vb = x_b[i];
+            if (i < slope_part) { const i32 w = wtab[i]; va = sk_mulwb(w, va); vb = sk_mulwb(w, vb); }
+            else if (i >= slope_part + flat_part) { const i32 w = wtab[i - flat_part]; va = sk_mulwb(w, va); vb = sk_mulwb(w, vb); }
+            in_a = shl32((i32)(i16)va, 13); in_b = shl32((i32)(i16)vb, 13);
+         }
+      }
+      const int nsteps = imin(64, total - base);
+      for (int j = 0; j < nsteps; j++) {
+         const i32 from_prev = wv_shift_up1(my, 0), x_prev = wv_shift_up1(xs, 0);
+         const i32 xa = wv_bcast(in_a, j), xb = wv_bcast(in_b, j);
+         const i32 x13 = head ? (hb ? xb : xa) : x_prev;
+         const i32 v = head ? x13 : add32(prev_stage_prev, sk_mulwb(sub32(cur, from_prev), warping_Q16));
+         prev_stage_prev = from_prev; cur = v; my = v; xs = x13;
+         acc += ((i64)v * (i64)x13) >> (2 * 13 - 10);
+      }
+   }
+   const i32 hi0 = wv_half_head((i32)(acc >> 32)), lo0 = wv_half_head((i32)acc);
+   int lsh = se_clz64((i64)(((u64)(u32)hi0 << 32) | (u32)lo0)) - 35;
+   lsh = se_limit(lsh, -12 - 10, 30 - 10);
+   wv_sync();
+   if (l <= order) (hb ? corr_b : corr_a)[l] = lsh >= 0 ? (i32)(acc << lsh) : (i32)(acc >> -lsh);
+   wv_sync();
+   return -(10 + lsh);
+}
+/* se_schur64_wave on both halves; a half whose recursion stops early (schur64_FIX.c:58) idles through the remaining orders.  Returns the lane's half's residual energy. */
+WV_DEV i32 se_schur64_wave2(WV_LDS i32 *rc_a, WV_LDS i32 *rc_b, const WV_LDS i32 *c_a, const WV_LDS i32 *c_b, int order)
+{
+   const int lane = wv_lane(), l = lane & 31;
+   const bool hb = lane >= 32;
+   const WV_LDS i32 *c = hb ? c_b : c_a;
+   WV_LDS i32 *rc = hb ? rc_b : rc_a;
+   const bool dead = c[0] <= 0;
+   i32 a = l < order ? c[l + 1] : 0, b = l <= order ? c[l] : 0;
+   wv_sync();
+   bool done = dead;
+   int kend = dead ? 0 : order;
+   for (int k = 0; k < order; k++) {
+      const i32 a0 = wv_half_head(a), b0 = wv_half_head(b);
+      const bool brk = !done && iabs(a0) >= b0, upd = !done && !brk;
+      const i32 rc_tmp_Q31 = sk_div32_varQ(upd ? -a0 : 0, upd ? b0 : 1, 31);
+      if (l == 0) { if (brk) rc[k] = a0 > 0 ? -SE_FIX(.99f, 16) : SE_FIX(.99f, 16); else if (upd) rc[k] = sk_rround(rc_tmp_Q31, 15); }
+      if (brk) { done = true; kend = k + 1; }
+      const i32 na = a + sk_mulhi(shl32(b, 1), rc_tmp_Q31), nb = b + sk_mulhi(shl32(a, 1), rc_tmp_Q31);
+      if (upd && l < order - k) { a = na; b = nb; }
+      const i32 down = wv_shift_down1(a, 0);
+      if (upd) a = down;
+   }
+   if (l >= kend && l < order) rc[l] = 0;
+   const i32 nrg = dead ? 0 : imax(1, wv_half_head(b));
+   wv_sync();
+   return nrg;
+}
+WV_DEV void se_k2a_Q16_wave2(WV_LDS i32 *A_a, WV_LDS i32 *A_b, const WV_LDS i32 *rc_a, const WV_LDS i32 *rc_b, int order)
+{
+   const int lane = wv_lane(), l = lane & 31;
+   const bool hb = lane >= 32;
+   const WV_LDS i32 *rcp = hb ? rc_b : rc_a;
+   i32 a = 0;
+   for (int k = 0; k < order; k++) {
+      const i32 rc = rcp[k];
+      const i32 other = wv_shfl(a, ((k - 1 - l) & 31) | (lane & 32));
+      if (l < k) a = sk_mlaww(a, other, rc);
+      if (l == k) a = -shl32(rc, 8);
+   }
+   wv_sync();
+   if (l < order) (hb ? A_b : A_a)[l] = a;
+   wv_sync();
+}
 template <class PA> WV_DEV i32 se_warped_gain(PA coefs_Q24, int lambda_Q16, int order)
 {
    lambda_Q16 = -lambda_Q16;
@@ -227,6 +314,48 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
    i32 strength_Q16 = sk_mulwb(ctl->predGain_Q16, SE_FIX(1e-3f, 16));
    const i32 BWExp_Q16 = sk_div32_varQ(SE_FIX(0.94f, 16), sk_mlaww(SE_FIX(1.0, 16), strength_Q16, strength_Q16), 16);
    const int warping_Q16 = c->warping_Q16 > 0 ? sk_mlawb(c->warping_Q16, (i32)ctl->coding_quality_Q14, SE_FIX(0.01, 18)) : 0;
+   if (c->warping_Q16 > 0) {
+      /* the warped path (complexity >= 4): the sub-frames are independent up to the gain smoothing below -> two per pass, one per half of the wave: the allpass ladder, the
+       * 64-bit Schur recursion, the step-up and the serial coefficient conditioning (lanes 0 and 32) all run for sub-frames 2p and 2p + 1 at once */
+      const int flat_part = c->fs_kHz * 3, slope_part = (swl - flat_part) >> 1;
+      WV_LDS i32 *wtab = (WV_LDS i32 *)xx;                                             /* the two window slopes, worked out once (lanes 0 and 1) */
+      WV_LDS i32 *const corr_b = (WV_LDS i32 *)xw, *const rc_b = corr_b + 32, *const AR_b = corr_b + 56;      /* the second half's rows: the windowed-signal buffer is free on this path */
+      const int lane = wv_lane(), l = lane & 31;
+      const bool hb = lane >= 32;
+      wv_sync();
+      if (lane < 2) se_sine_window_table(wtab + lane * slope_part, lane + 1, slope_part);
+      wv_sync();
+      for (int p = 0; p < c->nb_subfr; p += 2) {
+         const int scale = se_warped_autocorr2_wave(w32, corr_b, x_ptr, x_ptr + c->subfr_length, wtab, slope_part, flat_part, warping_Q16, swl, order);
+         x_ptr += 2 * c->subfr_length;
+         WV_LDS i32 *const corr = hb ? corr_b : w32;
+         if (l == 0) corr[0] = add32(corr[0], imax(sk_mulwb(corr[0] >> 4, SE_FIX(3e-5f, 20)), 1));
+         wv_sync();
+         SE_LTOC(18);
+         const i32 nrg_w = se_schur64_wave2(stk, rc_b, w32, corr_b, order);
+         se_k2a_Q16_wave2(stk + 24, AR_b, stk, rc_b, order);
+         SE_LTOC(19);
+         if (l == 0) {
+            const int k = p + (hb ? 1 : 0);
+            WV_LDS i32 *AR_Q24 = hb ? AR_b : stk + 24;
+            i32 nrg = nrg_w;
+            int Qnrg = -scale;
+            if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
+            const i32 tmp32 = se_sqrt_approx(nrg);
+            Qnrg >>= 1;
+            i32 g = sk_shl_sat(tmp32, 16 - Qnrg);
+            const i32 gain_mult_Q16 = se_warped_gain(AR_Q24, warping_Q16, order);
+            if (g < SE_FIX(0.25, 16)) g = sk_mulww(g, gain_mult_Q16);
+            else { g = sk_mulww(sk_rround(g, 1), gain_mult_Q16); g = g >= (2147483647 >> 1) ? 2147483647 : shl32(g, 1); }
+            ctl->Gains_Q16[k] = g;
+            se_bwexpander_32(AR_Q24, order, BWExp_Q16);
+            se_limit_warped_coefs(AR_Q24, warping_Q16, SE_FIX(3.999, 24), order);
+            for (int i = 0; i < order; i++) ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER + i] = (i16)sk_sat16(sk_rround(AR_Q24[i], 11));
+         }
+         wv_sync();
+         SE_LTOC(22);
+      }
+   } else
    for (int k = 0; k < c->nb_subfr; k++) {
       const int flat_part = c->fs_kHz * 3, slope_part = (swl - flat_part) >> 1;
       if (c->warping_Q16 > 0) {                                                        /* xx is free on the warped path: it holds the two window slopes, worked out once (lanes 0 and 1) */
