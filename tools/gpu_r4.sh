@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/gpu_r4.sh <tag> <step> [<step> ...] — the round-4 GPU passes, one parameterised script (output under gpurun_out/r04_<tag>/).
-# steps: split_check | silkenc | bench3 | bench4 | bench2 | bench_default | prof3 | prof4 | prof2 | pmc2 | pmc3 | pmc4 | full | smoke | decode | decfast | phases | bench34p
+# steps: split_check | silkenc | bench3 | bench4 | bench2 | bench_default | prof3 | prof4 | prof2 | pmc2 | pmc3 | pmc4 | full | smoke | decode | decfast | phases | bench34p | broad
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=$1; shift
 O=gpurun_out/r04_$TAG; mkdir -p $O
@@ -32,6 +32,7 @@ ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O
 decfast) timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --config 2 --decode > $O/decode2.log 2>&1; timeout 80 python tools/dec_fast_check.py gpu > $O/dec_fast_check.log 2>&1; timeout 100 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_dec_fast.py -x -q --timeout 60 > $O/pytest_decoder.log 2>&1 ;;
 phases) for m in 1 0; do for k in silk hybrid; do OPUS_AMD_PROF_PREBUILT=1 OPUS_AMD_SH_SPLIT=$m timeout 90 python tools/phase_profile_sh.py 16384 10 $k > $O/phases_${k}_split$m.txt 2>&1; done; done ;;
 bench34p) for c in 3 4; do timeout 200 python bench.py --steps 10 --warmup 3 --no-extra-configs --config $c > $O/bench${c}_parity.log 2>&1; done ;;
+broad) timeout ${BROAD_TIMEOUT:-190} python -m pytest tests -m gpu -q -n 6 --timeout 150 -k "not bench_ranks and not reference_programs" --durations=15 > $O/pytest_gpu_broad.log 2>&1 ;;
 full) timeout 1200 python -m pytest tests -m gpu -x -q --timeout 600 > $O/pytest_gpu_full.log 2>&1 ;;
 *) echo "unknown step $step" ;;
 esac
