@@ -143,7 +143,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
       const int ch = gs->cfg.channels;
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
-      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; }
+      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; L->S.st_off = (i32)offsetof(SilkEncLds, st); }
       __syncthreads();
       oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
             (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
@@ -153,7 +153,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 }
 /* the split path (opus_sh_split.h).  counters: [0] front queue, [1] quantiser queue, [2] back queue, [3] queue of the one-kernel pass over the calls turned away, [4] their count */
 #ifndef OA_SH_FRONT_WAVES_PER_EU
-#define OA_SH_FRONT_WAVES_PER_EU 3
+#define OA_SH_FRONT_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
 oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off)
@@ -167,7 +167,7 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
       OaShStream *gs = streams + s;
       const int ch = gs->cfg.channels;
       seen++;
-      if (threadIdx.x == 0) L->packet_off = pkt_off;
+      if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)SE_FRONT_ST_OFF; }
       __syncthreads();
       oa_sh_front_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
             apcm ? apcm + (size_t)s * frame_size * ch : nullptr, slow_list, counters + 4, s);
@@ -198,7 +198,7 @@ oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scra
    for (;;) {
       const int s = oa_queue_pop(counters + 1);
       if (s >= nstreams) break;
-      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; }
+      if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; L->S.st_off = (i32)offsetof(SilkEncLds, st); }
       __syncthreads();
       if (conts[s].kind == SH_CONT_FAST) oa_sh_quant0_frame(L, streams + s, conts + s, (SeRateScratch *)(scratch + (size_t)blockIdx.x * sizeof(SeRateScratch)));
       __syncthreads();
@@ -215,7 +215,7 @@ oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, 
    for (;;) {
       const int s = oa_queue_pop(counters + 2);
       if (s >= nstreams) break;
-      if (threadIdx.x == 0) L->packet_off = pkt_off;
+      if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)offsetof(SilkEncLds, st); }
       __syncthreads();
       if (conts[s].kind == SH_CONT_FAST) {
          OaShStream *gs = streams + s;
@@ -335,7 +335,7 @@ int opusgpu_enc_state_size(void) { return (int)sizeof(OaStream); }
 int opusgpu_enc_sh_state_size(void) { return (int)sizeof(OaShStream); }
 int opusgpu_sh_kernel_lds_bytes(void) { return (int)SH_LDS_BYTES(1); }
 /* dynamic LDS of one wave: the SILK working set, or -- when the batch can reach the CELT layer (48 kHz) -- at least the CELT frame arena that aliases it */
-static size_t sh_lds_bytes(int channels, int silk_only) { size_t n = SH_LDS_BYTES(channels); const size_t celt = offsetof(ShLds, S) + sizeof(FrameLds); if (!silk_only && celt > n) n = celt; return n; }
+static size_t sh_lds_bytes(int channels, int silk_only) { size_t n = SH_LDS_BYTES(channels); const size_t celt = SH_CELT_LDS_BYTES; if (!silk_only && celt > n) n = celt; return n; }
 int opusgpu_kernel_lds_bytes(void) { return (int)sizeof(FrameLds); }
 opus_int32 opusgpu_enc_batch_streams(const OpusGpuEncBatch *b) { return b ? b->S : 0; }
 
@@ -551,11 +551,11 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    /* every kernel's packet buffer sits behind the rest of its LDS (ShLds.packet_off): the full OA_MAX_PACKET + 4 bytes, or the front kernel's few header bytes */
    auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
    size_t lds_front = SH_FRONT_LDS_BYTES(ch) + lds_pad;
-   if (lds_front < offsetof(ShLds, S) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + sizeof(AnLds);
+   if (lds_front < offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds);
    const int po_front = (int)al16(lds_front); lds_front = po_front + SH_FRONT_PKT_BYTES;
    /* the back kernel enters the CELT arena for hybrid frames AND for the redundant CELT frame that announces a SILK bandwidth switch (opus_encoder.c:2251-2260), which a
     * stream pinned to SILK-only can still ask for: only RESTRICTED_SILK never does */
-   size_t lds_back = offsetof(ShLds, S) + (b->application == OPUS_APPLICATION_RESTRICTED_SILK ? 256 : sizeof(FrameLds));
+   size_t lds_back = b->application == OPUS_APPLICATION_RESTRICTED_SILK ? offsetof(ShLds, S) + 256 : SH_CELT_LDS_BYTES;
    const int po_back = (int)al16(lds_back); lds_back = po_back + SH_PKT_BYTES;
    const int po_full = (int)al16(lds_full); lds_full = po_full + SH_PKT_BYTES;
    (void)silk_only;

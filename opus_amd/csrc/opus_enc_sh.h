@@ -52,6 +52,10 @@ struct ShLds {
    SilkEncLds S;                                         /* LAST (its own last member is the SILK state): mono batches allocate SH_LDS_BYTES(1) */
 };
 #define SH_PKT(L) ((WV_LDS u8 *)(L) + (L)->packet_off)
+/* the CELT passes' arena (FrameLds) borrows the SILK encoder's LDS behind its 16-byte header */
+#define SH_F(L) ((WV_LDS FrameLds *)((WV_LDS char *)&(L)->S + 16))
+#define SH_CELT_LDS_BYTES (offsetof(ShLds, S) + 16 + sizeof(FrameLds))
+static_assert(sizeof(AnLds) <= SE_FRONT_U_BYTES && alignof(AnLds) <= 16 && (offsetof(ShLds, S) + offsetof(SilkEncLds, u)) % 16 == 0, "the tonality analysis works in the SILK encoder's phase union, in every kernel");
 #define SH_PKT_BYTES (OA_MAX_PACKET + 4)
 #define SH_FRONT_PKT_BYTES 64
 #define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))                 /* without the packet: the kernels add it behind (packet_off) */
@@ -374,11 +378,11 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
    const int CC = L->cfg.channels;
    wv_sync();
    if (wv_uni(L->sh.silk_in_lds)) {
-      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, CC, wv_uni(L->silk_tail));
+      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(&L->S), CC, wv_uni(L->silk_tail));
       wv_sync();
       LANE0 L->sh.silk_in_lds = 0;
    }
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameLds *F = SH_F(L);
    const i32 *g = (const i32 *)&gs->celt.s; WV_LDS i32 *d = (WV_LDS i32 *)&F->st;
    FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) d[i] = g[i];
    FOR_LANES(i, 2 * NBE) F->oldBandE[i] = gs->celt.oldBandE[i];
@@ -386,7 +390,7 @@ WV_DEV void sh_enter_celt(WV_LDS ShLds *L, OaShStream *gs)                      
 }
 WV_DEV void sh_leave_celt(WV_LDS ShLds *L, OaShStream *gs)
 {
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameLds *F = SH_F(L);
    wv_sync();
    i32 *g = (i32 *)&gs->celt.s; const WV_LDS i32 *d = (const WV_LDS i32 *)&F->st;
    FOR_LANES(i, (int)(sizeof(OaEncScalars) / 4)) g[i] = d[i];
@@ -396,7 +400,7 @@ WV_DEV void sh_reload_silk(WV_LDS ShLds *L, const OaShStream *gs)
 {
    if (wv_uni(L->sh.silk_in_lds)) return;
    wv_sync();
-   se_state_copy_wave((WV_LDS i32 *)&L->S.st, (const i32 *)&gs->silk, L->cfg.channels, wv_uni(L->silk_tail));
+   se_state_copy_wave((WV_LDS i32 *)se_st(&L->S), (const i32 *)&gs->silk, L->cfg.channels, wv_uni(L->silk_tail));
    wv_sync();
    LANE0 L->sh.silk_in_lds = 1;
 }
@@ -405,7 +409,7 @@ WV_DEV void sh_park_silk(WV_LDS ShLds *L, OaShStream *gs)
 {
    wv_sync();
    if (wv_uni(L->sh.silk_in_lds)) {
-      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, L->cfg.channels, wv_uni(L->silk_tail));
+      se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(&L->S), L->cfg.channels, wv_uni(L->silk_tail));
       wv_sync();
       LANE0 L->sh.silk_in_lds = 0;
    }
@@ -413,7 +417,7 @@ WV_DEV void sh_park_silk(WV_LDS ShLds *L, OaShStream *gs)
 /* OPUS_RESET_STATE of the CELT encoder (celt_encoder.c:2972-2992) on the state in HBM + the scalars in the arena; configuration-like words survive */
 WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
 {
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameLds *F = SH_F(L);
    wv_sync();
    LANE0 {
       WV_LDS OaEncScalars *c = &F->st;
@@ -441,7 +445,7 @@ struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitra
 WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameLds *F = SH_F(L);
    WV_LDS FrameShared *fs = &F->sh;
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, up = 48000 / Fs;
    SE_CLK_BEGIN();                                  /* (profiling build: the pass is timed from a register, the SILK hand-off words are about to be overwritten) */
@@ -549,7 +553,7 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       sh->curr_bandwidth = st->bandwidth;
       sh->redundant_rng = 0; sh->f_size = frame_size; sh->r[3] = 0;                  /* r[3]: the result is a bare TOC that is never padded (DTX) */
       { EcCtx e_; EcCtx *e = &e_; WV_LDS u8 *buf = SH_PKT(L) + 1; k_ec_enc_init(EC_PASS, (u32)imin(orig_max_data_bytes - 1, 1275)); ec_st(&L->ec, e); }   /* the reference's coder spans the caller's whole buffer (:1964); a frame never fills more than 1275 bytes of it, and what lies beyond only ever gets cleared by ec_enc_done -- which here would run past the LDS packet buffer */
-      const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : L->S.st.ch[0].variable_HP_smth1_Q15;
+      const i32 hp_freq_smth1 = st->mode == OA_MODE_CELT_ONLY ? shl32(se_lin2log(60), 8) : se_st(&L->S)->ch[0].variable_HP_smth1_Q15;
       st->variable_HP_smth2_Q15 = sk_mlawb(st->variable_HP_smth2_Q15, hp_freq_smth1 - st->variable_HP_smth2_Q15, SE_FIX(0.015f, 16));
       sh->cutoff_Hz = se_log2lin(st->variable_HP_smth2_Q15 >> 8);
       sh->use_hp_cutoff = application == OA_APP_VOIP;
@@ -640,7 +644,7 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
 WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   WV_LDS FrameLds *F = (WV_LDS FrameLds *)&L->S;
+   WV_LDS FrameLds *F = SH_F(L);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs, application = L->cfg.application;
    const int delay_compensation = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, total_buffer = delay_compensation, encoder_buffer = Fs / 100;
    frame_size = wv_uni(frame_size); silk_nBytes = wv_uni(silk_nBytes);
@@ -890,12 +894,12 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
 {
    const int CC = L->cfg.channels;
    wv_sync();
-   WV_LDS i32 *w = (WV_LDS i32 *)&L->S.st;
+   WV_LDS i32 *w = (WV_LDS i32 *)se_st(&L->S);
    FOR_LANES(i, SE_STATE_LITE_WORDS(CC)) w[i] = 0;
    if (wv_uni(L->silk_tail)) { const int o = (int)(offsetof(OaSilkEnc, tail) / 4); FOR_LANES(i, CC * SE_TAIL_WORDS) w[o + i] = 0; }
    wv_sync();
    LANE0 {
-      WV_LDS OaSilkEnc *E = &L->S.st;
+      WV_LDS OaSilkEnc *E = se_st(&L->S);
       se_init_channel(&E->ch[0]); if (CC == 2) se_init_channel(&E->ch[1]);
       E->nChannelsAPI = 1; E->nChannelsInternal = 1;
    }
@@ -921,13 +925,14 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
       L->cs = cs;
       if (L->cfg.voice_ratio_seq != st->voice_ratio_seq) { st->voice_ratio = L->cfg.voice_ratio; st->voice_ratio_seq = L->cfg.voice_ratio_seq; }   /* OPUS_SET_VOICE_RATIO through a batch ctl */
    }
-   /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only), in the arena the SILK state is about to
-    * be loaded into; a call the reference turns away before that (:1231) leaves it alone */
+   /* the tonality / music analysis of the call's input (:1247-1264; the FIXED_POINT build runs it at complexity 10 only), in the SILK encoder's phase union (nothing in it
+    * outlives a stage; the words in front of it -- among them where this kernel keeps the staged state, SilkEncLds.st_off -- stay); a call the reference turns away before
+    * that (:1231) leaves it alone */
    SE_CLK_BEGIN();
    if (!analysed && !(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
       if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
          LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
-         an_run_analysis_wave((WV_LDS AnLds *)&L->S, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
+         an_run_analysis_wave((WV_LDS AnLds *)&L->S.u, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
                (i32 *)cs->X, &gs->an_info);
       } else {
          const int was_initialized = wv_uni(gs->an.initialized);
@@ -940,7 +945,7 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
    SE_CLK_END(23);
    SE_PHASE_START(&L->S);                                                               /* (profiling build: the analysis borrowed the arena the phase clock lives in) */
    {  /* the SILK encoder state (coalesced) */
-      se_state_copy_wave((WV_LDS i32 *)&L->S.st, (const i32 *)&gs->silk, CC, wv_uni(L->silk_tail));
+      se_state_copy_wave((WV_LDS i32 *)se_st(&L->S), (const i32 *)&gs->silk, CC, wv_uni(L->silk_tail));
    }
    wv_sync();
    LANE0 sh->silk_in_lds = 1;
@@ -995,7 +1000,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
          const i16 *fp = pcm + (size_t)i * CC * enc_frame_size;
          if (an_bak != -1) {                                                              /* (:1796-1800); the arena is borrowed: the SILK state goes back to HBM first */
             sh_park_silk(L, gs);
-            an_get_info_wave((WV_LDS AnLds *)&L->S, &gs->an, &gs->an_info, enc_frame_size, Fs);
+            an_get_info_wave((WV_LDS AnLds *)&L->S.u, &gs->an, &gs->an_info, enc_frame_size, Fs);
          }
          const i32 fm = sh_maxabs_wave(fp, enc_frame_size * CC);
          int curr_max = imin(bitrate_to_bits(wv_uni(sh->bitrate_bps), Fs, enc_frame_size) / 8, max_len_sum / nb_frames);
@@ -1031,7 +1036,7 @@ WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       i32 *g = (i32 *)&gs->s; const WV_LDS i32 *d = (const WV_LDS i32 *)st;
       FOR_LANES(i, (int)(sizeof(OaShScalars) / 4)) g[i] = d[i];
       if (wv_uni(sh->silk_in_lds)) {
-         se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&L->S.st, CC, wv_uni(L->silk_tail));
+         se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(&L->S), CC, wv_uni(L->silk_tail));
       }
    }
    SE_PHASE(&L->S, 10);

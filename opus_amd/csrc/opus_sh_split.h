@@ -55,7 +55,9 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
-   WV_LDS OaSilkEnc *E = &S->st;
+   LANE0 { L->silk_tail = 0; S->st_off = (i32)SE_FRONT_ST_OFF; }          /* the quantiser tails stay in HBM: they are the quantiser kernel's; the state sits behind the analysis working set */
+   wv_sync();
+   WV_LDS OaSilkEnc *E = se_st(S);
    LANE0 L->silk_tail = 0;                                                               /* the quantiser tails stay in HBM: they are the quantiser kernel's */
    wv_sync();
    sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
@@ -143,7 +145,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
    sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
    sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most; the quantiser kernel's lanes code on from there, in HBM) */
-   se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)&S->st, CC, 0);
+   se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(S), CC, 0);
    if (wv_lane() == 0) {
       ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
       ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
@@ -188,11 +190,11 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
 WV_DEVN void oa_sh_quant0_frame(WV_LDS ShLds *L, OaShStream *gs, ShCont *ct, SeRateScratch *G)
 {
    WV_LDS SilkEncLds *S = &L->S;
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
    wv_sync();
    const int CC = L->cfg.channels;
-   se_state_copy_wave((WV_LDS i32 *)&S->st, (const i32 *)&gs->silk, CC, 1);
+   se_state_copy_wave((WV_LDS i32 *)se_st(S), (const i32 *)&gs->silk, CC, 1);
    sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
    sh_copy_words((WV_LDS i32 *)SH_PKT(L), (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
    wv_sync();

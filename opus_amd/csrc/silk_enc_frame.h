@@ -19,10 +19,13 @@ struct SeAnaLds {                                      /* analysis phases */
    i32 w32[32];
    i16 A_Q12s[16];
    union {
-      struct { i16 Wsig[384 + 8], xx[384 + 8]; PitchLds pitch; } a;     /* pitch analysis, noise shaping analysis */
+      /* pitch analysis, noise shaping analysis.  The windowed-signal buffers and the pitch estimator's working set take turns: find_pitch_lags is through with Wsig / xx (its
+       * autocorrelation) before the estimator runs -- its reflection coefficients sit in pitch.d_srch, behind both -- and the noise shaping analysis fills them again afterwards */
+      struct { union { struct { i16 Wsig[384 + 8], xx[384 + 8]; }; PitchLds pitch; }; } a;
       struct { i16 LPC_in_pre[4 * 16 + 320]; SeLpcWork W; } p;           /* prediction coefficients */
    } u;
 };
+static_assert(offsetof(PitchLds, d_srch) >= 2 * (384 + 8) * sizeof(i16), "find_pitch_lags keeps its reflection coefficients behind the windowed-signal buffers");
 struct SeQuantLds {                                    /* quantiser + rate loop */
    SeNsqLds N;
    EcCtx ec_copy, ec_copy2;
@@ -32,15 +35,25 @@ struct SeQuantLds {                                    /* quantiser + rate loop 
 struct SeRateScratch { OaSilkNsqState nsq_copy[2]; u8 ec_buf_copy[1280]; };
 struct SeStereoLds { i16 side[322 + 6], LP_mid[320], HP_mid[320], LP_side[320], HP_side[320]; };
 struct SilkEncLds {
+   i32 st_off, hdr_[3];                                /* where this kernel keeps the staged state: se_st(S).  offsetof(SilkEncLds, st) everywhere but in the split path's front kernel, which packs it
+                                                        * behind the part of the phase union its stages use (SE_FRONT_ST_OFF); set by the kernel before the call opens.  These 16 bytes are not part
+                                                        * of any arena that borrows the rest (the Opus layer's CELT passes: SH_F, opus_enc_sh.h) */
    SeEncCtrl ctl;
    SeRsLds rs;
    i32 r[16];                                          /* lane-0 hand-off words */
    i32 stk[104];                                       /* lane-0 working arrays (run-time indexed private arrays would live in scratch = HBM); the temporary resampler of a rate switch (se_setup_resamplers: 99 words) */
-   union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; OaSilkLbrr lbrr; } u;
+   alignas(16) union { SeAnaLds a; SeQuantLds q; SeStereoLds s; i16 vadX[448]; i16 rs_tmp[45 * 48 + 8]; i16 pcm_stage[1920 + 8]; i32 rs_ring[36 + 480 + 4]; OaSilkLbrr lbrr; } u;
    OaSilkEnc st;                                       /* persistent state, staged; LAST: a mono batch allocates LDS only up to st.tail[1], the split path's front kernel only up to st.ch[channels] */
 };
 #define SE_LDS_BYTES(channels) (sizeof(SilkEncLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))
-#define SE_FRONT_LDS_BYTES(channels) (offsetof(SilkEncLds, st) + offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel))
+/* the split path's front kernel (opus_sh_split.h) runs everything up to silk_process_gains: of the phase union it needs the analysis working set and the smaller members in front of it, not the
+ * quantiser's, so its copy of the state starts SE_FRONT_U_BYTES behind the union's start */
+#define SE_FRONT_U_BYTES ((sizeof(SeAnaLds) + 15) & ~(size_t)15)
+#define SE_FRONT_ST_OFF (offsetof(SilkEncLds, u) + SE_FRONT_U_BYTES)
+#define SE_FRONT_LDS_BYTES(channels) (SE_FRONT_ST_OFF + offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel))
+static_assert(sizeof(SeStereoLds) <= SE_FRONT_U_BYTES && sizeof(i16) * (45 * 48 + 8) <= SE_FRONT_U_BYTES && sizeof(i16) * (1920 + 8) + 2 * sizeof(int16_t) * (SE_MAX_FRAME + 2) <= SE_FRONT_U_BYTES &&
+              sizeof(OaSilkLbrr) <= SE_FRONT_U_BYTES && sizeof(i32) * (36 + 480 + 4) <= SE_FRONT_U_BYTES, "the front kernel's phase union holds every member its stages use (the input buffers sit at its end)");
+WV_DEV WV_LDS OaSilkEnc *se_st(WV_LDS SilkEncLds *S) { return (WV_LDS OaSilkEnc *)((WV_LDS char *)S + wv_uni(S->st_off)); }
 #define SE_STATE_LITE_WORDS(channels) ((int)((offsetof(OaSilkEnc, ch) + (size_t)(channels) * sizeof(OaSilkEncChannel)) / 4))
 #define SE_TAIL_WORDS ((int)(sizeof(OaSilkEncTail) / 4))
 #define SE_INBUF_WORDS ((int)(sizeof(int16_t) * (SE_MAX_FRAME + 2) / 4))
@@ -59,10 +72,10 @@ template <class PD, class PS> WV_DEV void se_state_copy_wave(PD d, PS s, int cha
  * the phase union (behind everything the stages that run while it is live put there: the resampler ring, the stereo work arrays, the VAD scratch) */
 template <int FRONT> WV_DEV WV_LDS i16 *se_inbuf(WV_LDS SilkEncLds *S, int n)
 {
-   if (FRONT) return (WV_LDS i16 *)((WV_LDS char *)&S->u + sizeof(S->u) - (size_t)(2 - n) * sizeof(S->st.inbuf[0]));
-   return S->st.inbuf[n];
+   if (FRONT) return (WV_LDS i16 *)((WV_LDS char *)se_st(S) - (size_t)(2 - n) * sizeof(S->st.inbuf[0]));
+   return se_st(S)->inbuf[n];
 }
-WV_DEV WV_LDS OaSilkEncTail *se_tail(WV_LDS SilkEncLds *S, const WV_LDS OaSilkEncChannel *c) { return &S->st.tail[c == &S->st.ch[1] ? 1 : 0]; }
+WV_DEV WV_LDS OaSilkEncTail *se_tail(WV_LDS SilkEncLds *S, const WV_LDS OaSilkEncChannel *c) { WV_LDS OaSilkEnc *E = se_st(S); return &E->tail[c == &E->ch[1] ? 1 : 0]; }
 /* the quantiser state starts over if someone asked for it since its last use (silk_setup_fs: control_codec.c:241-246; the side channel after mid-only frames: enc_API.c:449-456) */
 WV_DEV void se_nsq_apply_reset_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
 {
@@ -432,7 +445,7 @@ template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) 
 template <int FRONT = 0> WV_DEV void se_frame_head_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c)
 {
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
-   WV_LDS i16 *inputBuf = se_inbuf<FRONT>(S, c == &S->st.ch[1] ? 1 : 0);
+   WV_LDS i16 *inputBuf = se_inbuf<FRONT>(S, c == &se_st(S)->ch[1] ? 1 : 0);
    SE_PHASE(S, 2);
    LANE0 {
       c->indices.Seed = (i8)(c->frameCounter++ & 3);
@@ -630,7 +643,7 @@ struct SeCall { int transition, nBlocksOf10ms, tot_blocks, curr_block, tmp_paylo
 /* enc_API.c:166-281: channel bookkeeping, the checks on the input length, the prefill reset, silk_control_encoder per channel */
 WV_DEV int se_call_prologue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int nSamplesIn, int prefillFlag, SeCall *k)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    LANE0 {
       if (ec->reducedDependency) for (int n = 0; n < ec->nChannelsAPI; n++) E->ch[n].first_frame_after_reset = 1;
@@ -684,7 +697,7 @@ WV_DEV int se_call_prologue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int nSampl
 /* :283-340: resample this call's input to the internal rate, buffer it */
 template <int FRONT = 0> WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesFromInput, int nSamplesToBuffer, int nBlocksOf10ms)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    WV_LDS i16 *in0 = se_inbuf<FRONT>(S, 0), *in1 = se_inbuf<FRONT>(S, 1);
    const int ix0 = c0->inputBufIx;
@@ -715,7 +728,7 @@ template <int FRONT = 0> WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, S
  * VAD.  Leaves TargetRate_bps in S->r[4], the mid / side rates in S->r[5], S->r[6]. */
 template <int FRONT = 0> WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, OaSilkLbrr *lb, int activity, int prefillFlag)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    WV_LDS i16 *in0 = se_inbuf<FRONT>(S, 0), *in1 = se_inbuf<FRONT>(S, 1);
    if (c0->nFramesEncoded == 0 && !prefillFlag) {                              /* LBRR data of the previous packet: HBM store -> LDS (all lanes) before lane 0 codes it */
@@ -797,7 +810,7 @@ template <int FRONT = 0> WV_DEV void se_call_frame_head_wave(WV_LDS SilkEncLds *
 struct SeChanParams { int maxBits, useCBR, condCoding; i32 channelRate_bps; };
 WV_DEV SeChanParams se_call_channel_params(WV_LDS SilkEncLds *S, const SeControl *ec, int n, int tot_blocks, int curr_block)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    const i32 TargetRate_bps = S->r[4], MStargetRates_bps[2] = {S->r[5], S->r[6]};
    SeChanParams p;
@@ -820,7 +833,7 @@ WV_DEV SeChanParams se_call_channel_params(WV_LDS SilkEncLds *S, const SeControl
  * channel is in DTX" -> S->r[8], the bandwidth-switch timer); part 2: the flag bits patched into the first payload byte, the bit reservoir; 3 = both */
 WV_DEV void se_call_frame_tail_l0(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int nBytesOut, int prefillFlag, int part)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    if (part & 1) E->prev_decode_only_middle = E->st.mid_only_flags[c0->nFramesEncoded - 1];
    if (nBytesOut > 0 && c0->nFramesEncoded == c0->nFramesPerPacket) {
@@ -852,7 +865,7 @@ WV_DEV void se_call_frame_tail_l0(WV_LDS SilkEncLds *S, SeControl *ec, WV_LDS Ec
 /* :562-590 */
 WV_DEV void se_call_epilogue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int prefillFlag, const SeCall *k)
 {
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    LANE0 E->nPrevChannelsInternal = ec->nChannelsInternal;
    ec->allowBandwidthSwitch = E->allowBandwidthSwitch;
@@ -869,7 +882,7 @@ WV_DEV void se_call_epilogue_wave(WV_LDS SilkEncLds *S, SeControl *ec, int prefi
 WV_DEV int silk_encode_wave(WV_LDS SilkEncLds *S, SeControl *ec, const i16 *pcm, int nSamplesIn, WV_LDS EcCtx *ecl, WV_LDS u8 *buf, int activity, SeRateScratch *G, OaSilkLbrr *lb, int prefillFlag = 0)
 {
    prefillFlag = wv_uni(prefillFlag);
-   WV_LDS OaSilkEnc *E = &S->st;
+   WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    int nBytesOut = 0;
    SeCall k;

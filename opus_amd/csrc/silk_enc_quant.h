@@ -107,10 +107,11 @@ WV_DEV void se_insertion_sort_increasing(i32 *a, int *idx, int L, int K)
 }
 
 /* per-survivor working set of the NLSF trellis search, in LDS (run-time indexed private arrays would be scratch memory = HBM round trips) */
-struct SeNlsfLane {
-   i32 RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4], ind_sort[4];
-   i16 ec_ix[16], pred_Q8[16], res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
-   i8 ind[4][16], ti[16];
+struct SeNlsfLane {                                             /* one survivor's trellis (244 B: sixteen of them set the size of the prediction-coefficient phase) */
+   i32 RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4];
+   i16 res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
+   u8 ec_ix[16], pred_Q8[16];
+   i8 ind[4][16], ind_sort[4];
 };
 struct SeNlsfTabs { i32 out0[20], out1[20]; };
 WV_DEV void se_nlsf_out_tabs(WV_LDS SeNlsfTabs *T, int i /* 0..19 */, int quant_step_size_Q16)                 /* NLSF_del_dec_quant.c:66-87 */
@@ -120,7 +121,7 @@ WV_DEV void se_nlsf_out_tabs(WV_LDS SeNlsfTabs *T, int i /* 0..19 */, int quant_
    if (v > 0) { out0 = (i16)(out0 - adj); out1 = (i16)(out1 - adj); } else if (v == 0) out1 = (i16)(out1 - adj); else if (v == -1) out0 = (i16)(out0 + adj); else { out0 = (i16)(out0 + adj); out1 = (i16)(out1 + adj); }
    T->out0[i] = sk_mulbb(out0, quant_step_size_Q16) >> 16; T->out1[i] = sk_mulbb(out1, quant_step_size_Q16) >> 16;
 }
-WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *T, const u8 *ec_rates_Q5, i16 inv_quant_step_size_Q6, i32 mu_Q20, int order)
+WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, WV_LDS i8 *ti /* out: the winning path's indices [order] */, const WV_LDS SeNlsfTabs *T, const u8 *ec_rates_Q5, i16 inv_quant_step_size_Q6, i32 mu_Q20, int order)
 {
    const int NS = 4, AMP = 4, EXT = 10;
    int i, j, nStates, ind_tmp, ind_min_max, ind_max_min;
@@ -180,8 +181,8 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *
    ind_tmp = 0;
    i32 min_Q25 = 2147483647;
    for (j = 0; j < 2 * NS; j++) if (min_Q25 > w->RD_Q25[j]) { min_Q25 = w->RD_Q25[j]; ind_tmp = j; }
-   for (j = 0; j < order; j++) w->ti[j] = w->ind[ind_tmp & (NS - 1)][j];
-   w->ti[0] = (i8)(w->ti[0] + (ind_tmp >> 2));
+   for (j = 0; j < order; j++) ti[j] = w->ind[ind_tmp & (NS - 1)][j];
+   ti[0] = (i8)(ti[0] + (ind_tmp >> 2));
    return min_Q25;
 }
 
@@ -189,10 +190,9 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, const WV_LDS SeNlsfTabs *
 struct SeLpcWork {
    i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8];
    i16 NLSF_Q15[16], pW[16];
-   i32 wk[66];
    union {                                                     /* one stage at a time: LTP correlations -> Burg -> A2NLSF grid -> interpolation residual -> NLSF quantiser -> residual energies */
       i32 XX[120];
-      i32 stk[84 + 4 * 64 + 8];
+      struct { i32 stk[84 + 4 * 64 + 8]; i32 wk[66]; };        /* wk: lane 0's NLSF -> LPC conversions (interpolation search: behind the candidates' pool; after the quantiser: beside lane 1's, which borrows stk) */
       i32 Y[2 * 132];
       i16 LPC_res[2 * 96];
       struct { i32 err_Q24[32], RD_Q25[16], surv[16]; i8 tempIndices2[16 * 16]; SeNlsfTabs tabs; SeNlsfLane lane[16]; };
@@ -247,12 +247,12 @@ WV_DEVN void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, 
             w->ec_ix[i + 1] = ((entry >> 5) & 7) * 9; w->pred_Q8[i + 1] = cb.pred[i + ((entry >> 4) & 1) * (order - 1) + 1];
          }
       }
-      const i32 RD = se_nlsf_del_dec_quant(w, &W->tabs, ec_rates_Q5, inv_qstep_Q6, NLSF_mu_Q20, order);
+      for (int i = order; i < 16; i++) W->tempIndices2[s * 16 + i] = 0;
+      const i32 RD = se_nlsf_del_dec_quant(w, &W->tempIndices2[s * 16], &W->tabs, ec_rates_Q5, inv_qstep_Q6, NLSF_mu_Q20, order);
       const u8 *icdf = &cb.cb1_icdf[(signalType >> 1) * cb.nVectors];
       const int prob_Q8 = ind1 == 0 ? 256 - icdf[ind1] : icdf[ind1 - 1] - icdf[ind1];
       const int bits_q7 = (8 << 7) - se_lin2log(prob_Q8);
       W->RD_Q25[s] = sk_mlabb(RD, bits_q7, NLSF_mu_Q20 >> 2);
-      for (int i = 0; i < 16; i++) W->tempIndices2[s * 16 + i] = i < order ? w->ti[i] : 0;
    }
    LANE0 {
       int best = 0; i32 bv = W->RD_Q25[0];

@@ -18,7 +18,7 @@ static void ejob(void *p)
    EJob *j = (EJob *)p;
    SilkEncLds *S = j->S;
    const int lane = wv_lane();
-   { int32_t *d = (int32_t *)&S->st; const int32_t *g = (const int32_t *)j->gs; FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) d[i] = g[i]; }
+   { int32_t *d = (int32_t *)se_st(S); const int32_t *g = (const int32_t *)j->gs; FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) d[i] = g[i]; }
    wv_sync();
    SeControl c; memset(&c, 0, sizeof c);
    int32_t *w = (int32_t *)&c; for (int i = 0; i < 18; i++) w[i] = j->ctl[i];
@@ -38,7 +38,7 @@ static void ejob(void *p)
       for (int i = 0; i < j->out_cap; i++) j->out[i] = buf[i];
    }
    wv_sync();
-   { const int32_t *d = (const int32_t *)&S->st; int32_t *g = (int32_t *)j->gs; FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) g[i] = d[i]; }
+   { const int32_t *d = (const int32_t *)se_st(S); int32_t *g = (int32_t *)j->gs; FOR_LANES(i, (int)(sizeof(OaSilkEnc) / 4)) g[i] = d[i]; }
    (void)lane;
 }
 extern "C" int emu_silk_enc_size() { return (int)sizeof(OaSilkEnc); }
@@ -48,6 +48,7 @@ extern "C" int emu_silk_encode(OaSilkEnc *st, int32_t *ctl, const int16_t *pcm, 
 {
    SilkEncLds *S = (SilkEncLds *)aligned_alloc(64, (sizeof(SilkEncLds) + 63) & ~63);
    memset(S, 0xA5, sizeof(SilkEncLds));
+   S->st_off = (int32_t)offsetof(SilkEncLds, st);                                  /* (what the kernels set before a call) */
    SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
    EJob j = {G, S, st, ctl, pcm, nSamples, out, out_cap, res, activity, 0};
    emu_run_wave(ejob, &j);
@@ -67,7 +68,7 @@ extern "C" void emu_sh_encode(OaShStream *st, const int16_t *pcm, int frame_size
    const size_t po = (sizeof(ShLds) + 15) & ~(size_t)15, tot = (po + SH_PKT_BYTES + 63) & ~(size_t)63;
    ShLds *L = (ShLds *)aligned_alloc(64, tot);
    memset(L, 0xA5, tot);
-   L->silk_tail = 1; L->packet_off = (i32)po;                                      /* what oa_sh_encode_kernel sets before a call: the tails are staged, the packet buffer sits behind the rest */
+   L->silk_tail = 1; L->packet_off = (i32)po; L->S.st_off = (i32)offsetof(SilkEncLds, st);                                      /* what oa_sh_encode_kernel sets before a call: the tails are staged, the packet buffer sits behind the rest */
    int16_t *hp = (int16_t *)malloc(2 * SH_PCM_BYTES(frame_size, 2) + 512);          /* high-passed frame | faded CELT input | 2.5 ms CELT prefill */
    SeRateScratch *G = (SeRateScratch *)malloc(sizeof(SeRateScratch));
    CeltScratch *cs = (CeltScratch *)malloc(sizeof(CeltScratch)); memset(cs, 0xA5, sizeof(CeltScratch));
