@@ -55,7 +55,7 @@ struct ShLds {
 /* the CELT passes' arena (FrameLds) borrows the SILK encoder's LDS behind its 16-byte header */
 #define SH_F(L) ((WV_LDS FrameLds *)((WV_LDS char *)&(L)->S + 16))
 #define SH_CELT_LDS_BYTES (offsetof(ShLds, S) + 16 + sizeof(FrameLds))
-static_assert(sizeof(AnLds) <= SE_FRONT_U_BYTES && alignof(AnLds) <= 16 && (offsetof(ShLds, S) + offsetof(SilkEncLds, u)) % 16 == 0, "the tonality analysis works in the SILK encoder's phase union, in every kernel");
+static_assert(sizeof(AnLds) <= SE_FRONT_U_BYTES + offsetof(OaSilkEnc, ch) + sizeof(OaSilkEncChannel) /* (it runs before the state is staged: it may reach into where a mono stream's copy goes) */ && alignof(AnLds) <= 16 && (offsetof(ShLds, S) + offsetof(SilkEncLds, u)) % 16 == 0, "the tonality analysis works in the SILK encoder's phase union, in every kernel");
 #define SH_PKT_BYTES (OA_MAX_PACKET + 4)
 #define SH_FRONT_PKT_BYTES 64
 #define SH_LDS_BYTES(channels) (sizeof(ShLds) - ((channels) == 1 ? sizeof(OaSilkEncTail) : 0))                 /* without the packet: the kernels add it behind (packet_off) */

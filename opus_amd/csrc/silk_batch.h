@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void oa_silk_pitch_kernel(OaPitchCfg cfg, const
 {
    __shared__ PitchLds lds;
    const size_t s = blockIdx.x;
-   silk_pitch_analysis_wave(cfg, (WV_LDS PitchLds *)&lds, frames + s * (size_t)flen, in + s, out + s);
+   (void)silk_pitch_analysis_wave(cfg, (WV_LDS PitchLdsCore *)(WV_LDS PitchLds *)&lds, ((WV_LDS PitchLds *)&lds)->frame, frames + s * (size_t)flen, in + s, out + s);
 }
 
 extern "C" {

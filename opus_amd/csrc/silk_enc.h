@@ -587,7 +587,7 @@ struct SeEncCtrl {
 
 /* ---- silk_find_pitch_lags_FIX.  res: i16[la_pitch + frame + ltp_mem]; x = x_frame - ltp_mem; Wsig: i16[384] window scratch; xx: i16[384]; w32: i32[20] ---- */
 WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, WV_LDS i16 *res, const WV_LDS i16 *x, WV_LDS i16 *Wsig, WV_LDS i16 *xx, WV_LDS i32 *w32,
-      WV_LDS i16 *A_Q12s, WV_LDS PitchLds *PL)
+      WV_LDS i16 *A_Q12s, WV_LDS PitchLdsCore *PL)
 {
    const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length, wl = c->pitch_LPC_win_length, la = c->la_pitch, order = c->pitchEstimationLPCOrder;
    SE_LTIC();
@@ -623,8 +623,11 @@ WV_DEVN void se_find_pitch_lags_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       OaPitchIn pin; pin.prevLag = c->prevLag; pin.LTPCorr_Q15 = c->LTPCorr_Q15; pin.search_thres1_Q16 = c->pitchEstimationThreshold_Q16; pin.search_thres2_Q13 = thrhld_Q13;
       OaPitchOut po;
       wv_sync();
-      silk_pitch_analysis_wave(pc, PL, (const i16 *)res, &pin, &po);
+      /* the estimator works in place on the residual (its first step scales the frame down to two bits of headroom: silk_pitch_analysis_core's frame_scaled, :144-155);
+       * a residual it has scaled is worked out again for the stages behind it */
+      const int scaled = silk_pitch_analysis_wave(pc, PL, res, nullptr, &pin, &po);
       wv_sync();
+      if (scaled) { se_lpc_analysis_filter_wave(res, x, A_Q12s, buf_len, order); wv_sync(); }
       LANE0 {
          for (int k = 0; k < 4; k++) ctl->pitchL[k] = po.pitch[k];
          c->indices.lagIndex = po.lagIndex; c->indices.contourIndex = po.contourIndex; c->LTPCorr_Q15 = po.LTPCorr_Q15;

@@ -21,11 +21,11 @@ struct SeAnaLds {                                      /* analysis phases */
    union {
       /* pitch analysis, noise shaping analysis.  The windowed-signal buffers and the pitch estimator's working set take turns: find_pitch_lags is through with Wsig / xx (its
        * autocorrelation) before the estimator runs -- its reflection coefficients sit in pitch.d_srch, behind both -- and the noise shaping analysis fills them again afterwards */
-      struct { union { struct { i16 Wsig[384 + 8], xx[384 + 8]; }; PitchLds pitch; }; } a;
-      struct { i16 LPC_in_pre[4 * 16 + 320]; SeLpcWork W; } p;           /* prediction coefficients */
+      struct { union { struct { i16 Wsig[384 + 8], xx[384 + 8]; }; PitchLdsCore pitch; }; } a;
+      struct { SeLpcWork W; } p;                                         /* prediction coefficients */
    } u;
 };
-static_assert(offsetof(PitchLds, d_srch) >= 2 * (384 + 8) * sizeof(i16), "find_pitch_lags keeps its reflection coefficients behind the windowed-signal buffers");
+static_assert(offsetof(PitchLdsCore, d_srch) >= 2 * (384 + 8) * sizeof(i16), "find_pitch_lags keeps its reflection coefficients behind the windowed-signal buffers");
 struct SeQuantLds {                                    /* quantiser + rate loop */
    SeNsqLds N;
    EcCtx ec_copy, ec_copy2;
@@ -468,7 +468,7 @@ WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel
    wv_sync();
    SE_TAP(1);
    SE_PHASE(S, 4);
-   se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15]);
+   se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.W.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15]);
    SE_TAP(2);
    SE_PHASE(S, 5);
    LANE0 se_process_gains_l0(c, ctl, condCoding);

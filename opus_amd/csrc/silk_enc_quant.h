@@ -107,8 +107,8 @@ WV_DEV void se_insertion_sort_increasing(i32 *a, int *idx, int L, int K)
 }
 
 /* per-survivor working set of the NLSF trellis search, in LDS (run-time indexed private arrays would be scratch memory = HBM round trips) */
-struct SeNlsfLane {                                             /* one survivor's trellis (244 B: sixteen of them set the size of the prediction-coefficient phase) */
-   i32 RD_Q25[8], RD_min_Q25[4], RD_max_Q25[4];
+struct SeNlsfLane {                                             /* one survivor's trellis (212 B: sixteen of them set the size of the prediction-coefficient phase) */
+   i32 RD_Q25[8];
    i16 res_Q10[16], W_adj_Q5[16], prev_out_Q10[8];
    u8 ec_ix[16], pred_Q8[16];
    i8 ind[4][16], ind_sort[4];
@@ -157,22 +157,26 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, WV_LDS i8 *ti /* out: the
          nStates <<= 1;
          for (j = nStates; j < NS; j++) w->ind[j][i] = w->ind[j - nStates][i];
       } else {
-         for (j = 0; j < NS; j++) {
+         i32 RD_min_Q25[4], RD_max_Q25[4];                     /* (registers: every access below is statically indexed) */
+#pragma unroll
+         for (j = 0; j < 4; j++) {
             if (w->RD_Q25[j] > w->RD_Q25[j + NS]) {
-               w->RD_max_Q25[j] = w->RD_Q25[j]; w->RD_min_Q25[j] = w->RD_Q25[j + NS]; w->RD_Q25[j] = w->RD_min_Q25[j]; w->RD_Q25[j + NS] = w->RD_max_Q25[j];
+               RD_max_Q25[j] = w->RD_Q25[j]; RD_min_Q25[j] = w->RD_Q25[j + NS]; w->RD_Q25[j] = RD_min_Q25[j]; w->RD_Q25[j + NS] = RD_max_Q25[j];
                const i16 t = w->prev_out_Q10[j]; w->prev_out_Q10[j] = w->prev_out_Q10[j + NS]; w->prev_out_Q10[j + NS] = t;
-               w->ind_sort[j] = j + NS;
-            } else { w->RD_min_Q25[j] = w->RD_Q25[j]; w->RD_max_Q25[j] = w->RD_Q25[j + NS]; w->ind_sort[j] = j; }
+               w->ind_sort[j] = (i8)(j + NS);
+            } else { RD_min_Q25[j] = w->RD_Q25[j]; RD_max_Q25[j] = w->RD_Q25[j + NS]; w->ind_sort[j] = (i8)j; }
          }
          while (1) {
             i32 min_max = 2147483647, max_min = 0;
             ind_min_max = 0; ind_max_min = 0;
-            for (j = 0; j < NS; j++) { if (min_max > w->RD_max_Q25[j]) { min_max = w->RD_max_Q25[j]; ind_min_max = j; } if (max_min < w->RD_min_Q25[j]) { max_min = w->RD_min_Q25[j]; ind_max_min = j; } }
+#pragma unroll
+            for (j = 0; j < 4; j++) { if (min_max > RD_max_Q25[j]) { min_max = RD_max_Q25[j]; ind_min_max = j; } if (max_min < RD_min_Q25[j]) { max_min = RD_min_Q25[j]; ind_max_min = j; } }
             if (min_max >= max_min) break;
-            w->ind_sort[ind_max_min] = w->ind_sort[ind_min_max] ^ NS;
+            w->ind_sort[ind_max_min] = (i8)(w->ind_sort[ind_min_max] ^ NS);
             w->RD_Q25[ind_max_min] = w->RD_Q25[ind_min_max + NS];
             w->prev_out_Q10[ind_max_min] = w->prev_out_Q10[ind_min_max + NS];
-            w->RD_min_Q25[ind_max_min] = 0; w->RD_max_Q25[ind_min_max] = 2147483647;
+#pragma unroll
+            for (j = 0; j < 4; j++) { if (j == ind_max_min) RD_min_Q25[j] = 0; if (j == ind_min_max) RD_max_Q25[j] = 2147483647; }
             for (int q = 0; q < 16; q++) w->ind[ind_max_min][q] = w->ind[ind_min_max][q];
          }
          for (j = 0; j < NS; j++) w->ind[j][i] = (i8)(w->ind[j][i] + (w->ind_sort[j] >> 2));
@@ -190,11 +194,17 @@ WV_DEV i32 se_nlsf_del_dec_quant(WV_LDS SeNlsfLane *w, WV_LDS i8 *ti /* out: the
 struct SeLpcWork {
    i32 a_Q16[16], a_tmp_Q16[16], invGains_Q16[4], local_gains[4], r[8];
    i16 NLSF_Q15[16], pW[16];
-   union {                                                     /* one stage at a time: LTP correlations -> Burg -> A2NLSF grid -> interpolation residual -> NLSF quantiser -> residual energies */
-      i32 XX[120];
-      struct { i32 stk[84 + 4 * 64 + 8]; i32 wk[66]; };        /* wk: lane 0's NLSF -> LPC conversions (interpolation search: behind the candidates' pool; after the quantiser: beside lane 1's, which borrows stk) */
-      i32 Y[2 * 132];
-      i16 LPC_res[2 * 96];
+   union {
+      struct {
+         i16 LPC_in_pre[4 * 16 + 320];                         /* the gain-scaled (voiced: LTP-filtered) input of the LPC analysis, find_pred_coefs_FIX.c:45 */
+         union {                                               /* one stage at a time: LTP correlations -> Burg -> A2NLSF grid -> interpolation residual -> residual energies */
+            i32 XX[120];
+            struct { i32 stk[84 + 4 * 64 + 8]; i32 wk[66]; };  /* wk: lane 0's NLSF -> LPC conversions (interpolation search: behind the candidates' pool; after the quantiser: beside lane 1's, which borrows stk) */
+            i32 Y[2 * 132];
+            i16 LPC_res[2 * 96];
+         };
+      };
+      /* the NLSF quantiser (16 survivors, one lane each) borrows all of it: LPC_in_pre is worked out again for the residual energies behind it */
       struct { i32 err_Q24[32], RD_Q25[16], surv[16]; i8 tempIndices2[16 * 16]; SeNlsfTabs tabs; SeNlsfLane lane[16]; };
    };
 };
@@ -360,6 +370,20 @@ WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, c
    if (c->indices.NLSFInterpCoef_Q2 == 4) se_a2nlsf_wave(W->NLSF_Q15, W->a_Q16, order, W->Y);
 }
 
+/* LPC_in_pre (find_pred_coefs_FIX.c:82-101): voiced: the LTP residual of the input scaled by the inverse gains (silk_LTP_analysis_filter_FIX); otherwise the input scaled by them */
+WV_DEV void se_lpc_in_pre_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, const WV_LDS i16 *x)
+{
+   const int order = c->predictLPCOrder, nb = c->nb_subfr, sl = c->subfr_length;
+   wv_sync();
+   if (c->indices.signalType == SE_TYPE_VOICED) se_ltp_analysis_filter_wave(LPC_in_pre, x - order, ctl->LTPCoef_Q14, ctl->pitchL, W->invGains_Q16, sl, nb, order);
+   else {
+      for (int i = 0; i < nb; i++) {
+         const WV_LDS i16 *x_ptr = x - order + i * sl; WV_LDS i16 *o = LPC_in_pre + i * (sl + order); const i32 g = W->invGains_Q16[i];
+         FOR_LANES(j, sl + order) o[j] = (i16)sk_mulwb(g, x_ptr[j]);
+      }
+   }
+   wv_sync();
+}
 /* res_pitch = res_pitch_frame, x = x_frame.  LPC_in_pre: i16[4 * 16 + 320]; XX: i32[100 + 20]; LPC_res: i16[192] */
 WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
       WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
@@ -380,12 +404,9 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
       se_find_ltp_wave(XX + 20, XX, res_pitch, ctl->pitchL, sl, nb);
       se_quant_ltp_gains_wave(ctl->LTPCoef_Q14, c->indices.LTPIndex, &c->indices.PERIndex, &c->sum_log_gain_Q7, &ctl->LTPredCodGain_Q7, XX + 20, XX, sl, nb);
       LANE0 se_ltp_scale_ctrl(c, ctl, condCoding);
-      se_ltp_analysis_filter_wave(LPC_in_pre, x - order, ctl->LTPCoef_Q14, ctl->pitchL, W->invGains_Q16, sl, nb, order);
+      se_lpc_in_pre_wave(c, ctl, W, LPC_in_pre, x);
    } else {
-      for (int i = 0; i < nb; i++) {
-         const WV_LDS i16 *x_ptr = x - order + i * sl; WV_LDS i16 *o = LPC_in_pre + i * (sl + order); const i32 g = W->invGains_Q16[i];
-         FOR_LANES(j, sl + order) o[j] = (i16)sk_mulwb(g, x_ptr[j]);
-      }
+      se_lpc_in_pre_wave(c, ctl, W, LPC_in_pre, x);
       LANE0 { for (int i = 0; i < nb * 5; i++) ctl->LTPCoef_Q14[i] = 0; ctl->LTPredCodGain_Q7 = 0; c->sum_log_gain_Q7 = 0; ctl->LTP_scale_Q14 = 0; }
    }
    wv_sync();
@@ -400,6 +421,7 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
    SE_TICK(tk, 14);                                                              /* final A2NLSF */
    se_process_nlsfs_wave(c, &ctl->PredCoef_Q12[0][0], W);
    SE_TICK(tk, 15);                                                              /* NLSF quantiser + NLSF2A */
+   se_lpc_in_pre_wave(c, ctl, W, LPC_in_pre, x);                                 /* (the quantiser has worked in its bytes) */
    se_residual_energy_wave(ctl->ResNrg, ctl->ResNrgQ, LPC_in_pre, &ctl->PredCoef_Q12[0][0], W->local_gains, sl, nb, order, LPC_res);
    LANE0 { for (int i = 0; i < 16; i++) c->prev_NLSFq_Q15[i] = i < order ? W->NLSF_Q15[i] : (i16)0; }
 }

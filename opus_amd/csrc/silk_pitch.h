@@ -27,14 +27,15 @@ struct OaPitchCfg { i32 Fs_kHz, complexity, nb_subfr; };
 struct OaPitchIn  { i32 prevLag, LTPCorr_Q15, search_thres1_Q16, search_thres2_Q13; };
 struct OaPitchOut { i32 pitch[4]; i32 LTPCorr_Q15; i16 lagIndex; i8 contourIndex; i8 unvoiced; };
 
-struct PitchLds {
-   i16 frame[640 + 8], f8[320 + 8], f4[160 + 8];
+struct PitchLdsCore {
+   i16 f8[320 + 8], f4[160 + 8];
    i16 C[4 * PE_CSTRIDE_8K];
    i16 mark[160], conv1[160], d_comp[160];
    i32 d_srch[24];
    i32 xc[4][24], en[4][24];
    i32 sh[16];
 };
+struct PitchLds : PitchLdsCore { i16 frame[640 + 8]; };      /* with room for a copy of the input (the standalone kernel: its input is in HBM) */
 enum { PSH_LEN_SRCH = 0, PSH_LEN_COMP, PSH_LAG, PSH_CBIMAX, PSH_CCMAX, PSH_LAGNEW };
 
 WV_DEV i32 pe_dot(const WV_LDS i16 *a, const WV_LDS i16 *b, int n) { i32 s = 0; for (int i = 0; i < n; i++) s = add32(s, (i32)a[i] * (i32)b[i]); return s; }
@@ -79,7 +80,9 @@ WV_DEV void pe_down2_3_l0(WV_LDS i16 *out, const WV_LDS i16 *in, int inLen)
 }
 
 /* One frame on one wave.  frame: (20 + 5*nb_subfr) ms of int16 at Fs_kHz in HBM. */
-WV_DEV void silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLds *L, const i16 *frame_g, const OaPitchIn *pin, OaPitchOut *pout)
+/* fr: the wave's working copy of the input, scaled in place to two bits of headroom.  frame_g == nullptr: the input is in fr already (the encoder hands over its LDS residual buffer; the
+ * return value tells it whether the scaling has changed it).  Returns the down-scaling shift that was applied. */
+WV_DEV int silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLdsCore *L, WV_LDS i16 *fr, const i16 *frame_g, const OaPitchIn *pin, OaPitchOut *pout)
 {
    const int lane = wv_lane();
    const int Fs = cfg.Fs_kHz, cx = cfg.complexity, nb = cfg.nb_subfr;
@@ -92,20 +95,22 @@ WV_DEV void silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLds *L, c
    /* ---- input energy -> down-scaling to two bits of headroom (:144-155; silk/sum_sqr_shift.c:36: two passes of sum((x0^2+x1^2) >> shft)) ---- */
    int shft = 31 - sk_clz(flen);
    u32 part = 0;
-   for (int i = 2 * lane; i < flen; i += 2 * WV_WIDTH) { i32 a = frame_g[i], b = frame_g[i + 1]; L->frame[i] = (i16)a; L->frame[i + 1] = (i16)b; part += ((u32)(a * a) + (u32)(b * b)) >> shft; }
+   if (frame_g) { for (int i = 2 * lane; i < flen; i += 2 * WV_WIDTH) { fr[i] = frame_g[i]; fr[i + 1] = frame_g[i + 1]; } }
+   for (int i = 2 * lane; i < flen; i += 2 * WV_WIDTH) { i32 a = fr[i], b = fr[i + 1]; part += ((u32)(a * a) + (u32)(b * b)) >> shft; }
    i32 nrg = (i32)((u32)flen + wv_sumu(part));
    shft = imax(0, shft + 3 - sk_clz(nrg));
    wv_sync();
    part = 0;
-   for (int i = 2 * lane; i < flen; i += 2 * WV_WIDTH) { i32 a = L->frame[i], b = L->frame[i + 1]; part += ((u32)(a * a) + (u32)(b * b)) >> shft; }
+   for (int i = 2 * lane; i < flen; i += 2 * WV_WIDTH) { i32 a = fr[i], b = fr[i + 1]; part += ((u32)(a * a) + (u32)(b * b)) >> shft; }
    nrg = (i32)wv_sumu(part);
    int shift = shft + 3 - sk_clz(nrg);
-   if (shift > 0) { shift = (shift + 1) >> 1; for (int i = lane; i < flen; i += WV_WIDTH) L->frame[i] = (i16)(L->frame[i] >> shift); }
+   if (shift > 0) { shift = (shift + 1) >> 1; for (int i = lane; i < flen; i += WV_WIDTH) fr[i] = (i16)(fr[i] >> shift); }
+   const int applied_shift = shift > 0 ? shift : 0;
    wv_sync();
 
    /* ---- decimation to 8 kHz and 4 kHz (:157-182): serial recursions, lane 0 ---- */
-   if (Fs == 8) { for (int i = lane; i < len8; i += WV_WIDTH) L->f8[i] = L->frame[i]; }
-   else if (lane == 0) { if (Fs == 16) pe_down2_l0(L->f8, L->frame, flen); else pe_down2_3_l0(L->f8, L->frame, flen); }
+   if (Fs == 8) { for (int i = lane; i < len8; i += WV_WIDTH) L->f8[i] = fr[i]; }
+   else if (lane == 0) { if (Fs == 16) pe_down2_l0(L->f8, fr, flen); else pe_down2_3_l0(L->f8, fr, flen); }
    wv_sync();
    if (lane == 0) pe_down2_l0(L->f4, L->f8, len8);
    wv_sync();
@@ -259,11 +264,11 @@ WV_DEV void silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLds *L, c
             else { nb_cbk_search = 12; cbk_size = 12; Lag_CB = sk_cb_lags_stage3_10ms; Lag_range = sk_lag_range_stage3_10ms; }
             for (int it = lane; it < nb * 24; it += WV_WIDTH) {           /* correlations: lane = (subframe, lag offset) */
                const int k = it / 24, jj = it - k * 24, lo = Lag_range[2 * k], hi = Lag_range[2 * k + 1];
-               if (jj <= hi - lo) { const WV_LDS i16 *target = &L->frame[(sf_length << 2) + k * sf_length]; L->xc[k][jj] = pe_dot(target, target - start_lag - lo - jj, sf_length); }
+               if (jj <= hi - lo) { const WV_LDS i16 *target = &fr[(sf_length << 2) + k * sf_length]; L->xc[k][jj] = pe_dot(target, target - start_lag - lo - jj, sf_length); }
             }
             if (lane < nb) {                                             /* energies: the reference's saturating recursion, one lane per subframe */
                const int k = lane, lo = Lag_range[2 * k], hi = Lag_range[2 * k + 1];
-               const WV_LDS i16 *basis = &L->frame[(sf_length << 2) + k * sf_length] - (start_lag + lo);
+               const WV_LDS i16 *basis = &fr[(sf_length << 2) + k * sf_length] - (start_lag + lo);
                i32 e = pe_dot(basis, basis, sf_length);
                L->en[k][0] = e;
                for (int i = 1; i < hi - lo + 1; i++) {
@@ -273,7 +278,7 @@ WV_DEV void silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLds *L, c
                }
             }
             i32 etp = 0;
-            for (int i = lane; i < nb * sf_length; i += WV_WIDTH) { const i32 v = L->frame[20 * Fs + i]; etp = add32(etp, v * v); }
+            for (int i = lane; i < nb * sf_length; i += WV_WIDTH) { const i32 v = fr[20 * Fs + i]; etp = add32(etp, v * v); }
             const i32 energy_target = wv_sum(etp) + 1;
             wv_sync();
             const i32 contour_bias_Q15 = 1638 / lag;
@@ -303,5 +308,6 @@ WV_DEV void silk_pitch_analysis_wave(const OaPitchCfg cfg, WV_LDS PitchLds *L, c
       }
    }
    if (unvoiced && lane == 0) { for (int k = 0; k < 4; k++) pout->pitch[k] = 0; pout->LTPCorr_Q15 = 0; pout->lagIndex = 0; pout->contourIndex = 0; pout->unvoiced = 1; }
+   return applied_shift;
 }
 #endif

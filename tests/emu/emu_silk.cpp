@@ -74,7 +74,7 @@ extern "C" void emu_silk_resampler(const OaResamplerCfg *cfg, int32_t *state, in
 }
 
 struct PeJob { PitchLds lds; OaPitchCfg cfg; const int16_t *frame; const OaPitchIn *in; OaPitchOut *out; };
-static void pe_entry(void *arg) { PeJob *j = (PeJob *)arg; silk_pitch_analysis_wave(j->cfg, &j->lds, j->frame, j->in, j->out); }
+static void pe_entry(void *arg) { PeJob *j = (PeJob *)arg; (void)silk_pitch_analysis_wave(j->cfg, &j->lds, j->lds.frame, j->frame, j->in, j->out); }
 extern "C" void emu_silk_pitch(int n, const int16_t *frames, const OaPitchIn *in, OaPitchOut *out, int Fs_kHz, int complexity, int nb_subfr)
 {
    const int flen = (20 + 5 * nb_subfr) * Fs_kHz;
