@@ -358,6 +358,10 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         # the decoder on these very packets: a decoder batch decodes them step by step with its state carried in HBM; timed like the encoder (HIP events per launch,
         # barrier + synchronize around the K steps)
         d = opus_amd.DecoderBatch(S, channels=CH, Fs=Fs, device=local)
+        # configs 3 and 4 pin the encoder's mode (SILK-only / hybrid): a decoder batch for such a service knows it carries no CELT-only packets and skips the fast kernel's look at
+        # every stream (opusgpu_dec_batch_set_fast_kernel; the output is the same either way, the parity sample below checks it)
+        fast_kernel = cid == 2 or os.environ.get("OPUS_AMD_BENCH_DEC_FAST_LOOK") == "1"
+        if not fast_kernel: d.set_fast_kernel(False)
         dpcm = torch.zeros((TE, NC, FR * CH), dtype=torch.int16, device=dev)                 # (kept for the sampled streams only)
         work = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((TE, S), dtype=torch.int32, device=dev)
         def dstep(t):
@@ -378,7 +382,8 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None)
         r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
         r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
-        r2["kernel"] = "oa_decode_fast_kernel + oa_decode_kernel (one call)"
+        r2["kernel"] = "oa_decode_fast_kernel + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (the batch is told it carries no CELT-only packets: opusgpu_dec_batch_set_fast_kernel(b, 0))"
+        r2["dec_fast_kernel"] = bool(fast_kernel)
         r2["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool(torch.equal(drng, rng))      # every stream decoded FR samples and every frame ends on the encoder's final range
         L.opusgpu_dec_state_size.restype = ctypes.c_int
         r2["algorithmic_bytes_per_frame"] = round(FR * CH * 2 + mean_len + 8 + 2 * L.opusgpu_dec_state_size(), 1)
@@ -503,6 +508,7 @@ def main():
                 e = {"workload": ("DECODE of the packets of: " if r["leg"] == "decode" else "") + r["workload"], "metric": r["metric"], "value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
                      "streams_per_gpu": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "all_packets_valid": r["all_packets_valid"], "parity_sample_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
                      "roofline": roof(r, r["streams_per_gpu"])}
+                if "dec_fast_kernel" in r: e["dec_fast_kernel"] = r["dec_fast_kernel"]
                 c = cpu_leg(r, 3.0, 0) if cpu_on else None
                 if c:
                     e["cpu_baseline"] = c

@@ -222,6 +222,7 @@ OPUS_AMD_EXPORT int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned c
       opus_int16 *d_pcm, int frame_size, opus_int32 *d_nsamples, opus_uint32 *d_final_range, int steps, float *ms);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_sync(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec);   /* decode_fec of the following decode calls (include/opus.h:516) */
+OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fast_kernel(OpusGpuDecBatch *b, int enable);   /* 0: skip the CELT-only fast kernel (a batch without CELT-only packets saves its look at every stream); default 1; same output either way */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_reset(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);

@@ -1002,11 +1002,15 @@ struct OpusGpuDecBatch {
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
    unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; d_slow [S]: 1 = the fast kernel has decoded the stream's packet */
    int num_cu, occ_fast, occ_gen;
+   int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
 /* decode_fec of the following calls (opus_decode's last argument, include/opus.h:516): 1 = decode the in-band FEC (LBRR) copy the packets carry for
  * the frame BEFORE them, concealing where there is none */
 int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec) { if (!b || decode_fec < 0 || decode_fec > 1) return OPUS_BAD_ARG; b->decode_fec = decode_fec; return OPUS_OK; }
+/* 0: the following calls skip the CELT-only fast kernel and its look at every stream (a batch that knows it carries no CELT-only packets -- a SILK-only or hybrid service -- saves
+ * one launch and one queue pop per stream; any other batch only loses the fast kernel's occupancy); 1 (the default): fast kernel first, the general kernel takes the rest.  The output is the same either way. */
+int opusgpu_dec_batch_set_fast_kernel(OpusGpuDecBatch *b, int enable) { if (!b || enable < 0 || enable > 1) return OPUS_BAD_ARG; b->no_fast = !enable; return OPUS_OK; }
 int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
 int opusgpu_dec_fast_kernel_lds_bytes(void) { return (int)OA_DEC_FAST_LDS_BYTES; }
 opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
@@ -1045,7 +1049,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuDecBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
-      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0;
+      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
@@ -1116,7 +1120,7 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    const size_t need = (size_t)(g_fast > g_gen ? g_fast : g_gen) * OA_DEC_SCRATCH_BYTES;
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
-   const int use_fast = fast_env && !b->decode_fec;
+   const int use_fast = fast_env && !b->no_fast && !b->decode_fec;
    static const int dbg = getenv("OPUS_AMD_DEC_DEBUG") ? atoi(getenv("OPUS_AMD_DEC_DEBUG")) : 0;          /* bring-up only: 1 = the fast kernel alone, 2 = then the general kernel over every stream */
    if (use_fast) {
       hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
