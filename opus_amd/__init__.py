@@ -11,7 +11,8 @@ import ctypes, os, subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.environ.get("OPUS_AMD_LIB") or os.path.join(_HERE, "libopus_amd.so")     # (OPUS_AMD_LIB: A/B experiments with variant builds)
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libopus_amd.so")                               # what build() writes, always
+LIB_PATH = os.environ.get("OPUS_AMD_LIB") or PRODUCT_LIB_PATH                          # what lib() loads (OPUS_AMD_LIB / assignment: A/B experiments with variant builds, the emulated library of the CPU tests)
 
 OPUS_OK, OPUS_BAD_ARG, OPUS_BUFFER_TOO_SMALL, OPUS_INTERNAL_ERROR = 0, -1, -2, -3
 OPUS_INVALID_PACKET, OPUS_UNIMPLEMENTED, OPUS_INVALID_STATE, OPUS_ALLOC_FAIL = -4, -5, -6, -7
@@ -51,13 +52,13 @@ def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  Skipped only when the library on disk was built from exactly these sources
     (the hash it carries == the hash of the files; when the source tree is absent -- a box that received only the .so -- there is nothing to rebuild from)."""
     want = source_hash()
-    if not force and built_source_hash() == want and not os.environ.get("OPUS_AMD_EXTRA_CFLAGS"):
-        return LIB_PATH
+    if not force and built_source_hash(PRODUCT_LIB_PATH) == want and not os.environ.get("OPUS_AMD_EXTRA_CFLAGS"):
+        return PRODUCT_LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-DOA_SOURCE_HASH=\"%s\"" % want, "-I" + os.path.join(_HERE, "csrc"),
-           "-I" + os.path.join(_ROOT, "include")] + os.environ.get("OPUS_AMD_EXTRA_CFLAGS", "").split() + SOURCES + ["-o", LIB_PATH]   # (extra flags: profiling experiments only)
+           "-I" + os.path.join(_ROOT, "include")] + os.environ.get("OPUS_AMD_EXTRA_CFLAGS", "").split() + SOURCES + ["-o", PRODUCT_LIB_PATH]   # (extra flags: profiling experiments only)
     if verbose: print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return PRODUCT_LIB_PATH
 
 _lib = None
 def lib():
