@@ -62,14 +62,29 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    wv_sync();
    sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
+   const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;
    {
-      const int simple = !wv_uni(sh->err) && !wv_uni(sh->plc_frame) && wv_uni(sh->nb_frames) == 1 && wv_uni(st->mode) != OA_MODE_CELT_ONLY && !wv_uni(sh->prefill) && !wv_uni(st->silk_bw_switch) &&
-                         !wv_uni(L->cfg.use_inband_fec) && wv_uni(L->cfg.complexity) >= 2 && (frame_size * 100 == Fs || frame_size * 50 == Fs);
+      /* a CELT-only frame (the call's decision: opus_encoder.c:1413-1470) has no SILK layer at all: it skips the quantiser stage and is coded whole by the back kernel, at that
+       * kernel's occupancy instead of the one-kernel path's */
+      const int simple = !wv_uni(sh->err) && !wv_uni(sh->plc_frame) && wv_uni(sh->nb_frames) == 1 && !wv_uni(sh->prefill) && !wv_uni(st->silk_bw_switch) &&
+                         !wv_uni(L->cfg.use_inband_fec) && wv_uni(L->cfg.complexity) >= 2 && (celt_only || frame_size * 100 == Fs || frame_size * 50 == Fs);
       if (!simple) { sh_front_decline(ct, slow_list, slow_count, s); return; }
    }
    LANE0 { sh->f_redundancy = sh->redundancy; sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_to_celt = sh->to_celt; sh->f_silence = sh->is_silence; st->nonfinal_frame = 0; }
    SeControl sc;
+   if (celt_only) { i32 *z = (i32 *)&sc; for (int i = 0; i < (int)(sizeof(SeControl) / 4); i++) z[i] = 0; }         /* (sh_frame_front_wave leaves it alone for this mode; the record carries it) */
    sh_frame_front_wave(L, gs, pcm, frame_size, wv_uni(sh->max_data_bytes), pcm_hp, &sc);
+   if (celt_only) {
+      /* ---- the call so far -> HBM: the continuation record (no job for the quantiser kernel; the SILK state is as it was) ---- */
+      wv_sync();
+      sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
+      sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
+      sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
+      sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), SH_FRONT_PKT_BYTES / 4);
+      if (wv_lane() == 0) { ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = 0; ct->silk_flags = 0; ct->silk_dtx = 0; ct->silk_flag_bits = 0; }
+      wv_sync();
+      return;
+   }
    /* ---- silk_Encode, one frame (silk_encode_wave's pieces in its order; the quantiser and the coder of each channel are what is left out) ---- */
    SeCall k;
    if (se_call_prologue_wave(S, &sc, frame_size, 0, &k)) { sh_front_decline(ct, slow_list, slow_count, s); return; }
@@ -164,8 +179,9 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
    sh_copy_words((WV_LDS i32 *)SH_PKT(L), (const i32 *)ct->packet, (OA_MAX_PACKET + 4) / 4);
    wv_sync();
    const SeControl sc = ct->sc;
-   LANE0 {
-      L->cs = cs; sh->silk_in_lds = 0;
+   const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;                              /* no SILK layer: nothing for the flags and the reservoir to do, silk_nBytes as opus_encode_frame_native starts it */
+   LANE0 { L->cs = cs; sh->silk_in_lds = 0; sh->r[5] = 1; }
+   if (!celt_only) LANE0 {
       /* what silk_Encode does once the channels are coded (enc_API.c:522-545): VAD / LBRR flags into the payload's first bits, the bit reservoir */
       EcCtx e_; ec_ld(&e_, &L->ec); EcCtx *e = &e_; WV_LDS u8 *buf = SH_PKT(L) + 1;
       const int nBytesOut = (k_ec_tell(EC_PASS) + 7) >> 3;

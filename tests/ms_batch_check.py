@@ -57,6 +57,10 @@ CASES = [
     dict(B=2, channels=4, streams=3, coupled=1, mapping=[0, 1, 2, 3], application=2051, bitrate=200000, frame=480),         # restricted-lowdelay, 10 ms
     dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000),    # VOIP 16 kHz (SILK elementary streams)
     dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=3),   # 40 ms calls (multi-frame elementary packets), a muted channel, permuted mapping
+    # 64 elementary streams and more in one launch: the SILK-capable encoder's kernel pipeline against the reference
+    dict(B=2, channels=40, streams=40, coupled=0, mapping=list(range(40)), application=2049, bitrate=40 * 64000, frames=3),              # config-5 shape, 80 mono AUDIO streams: CELT-only frames, kept by the front kernel and coded by the back kernel
+    dict(B=2, channels=36, streams=36, coupled=0, mapping=list(range(36)), application=2048, Fs=16000, frame=320, bitrate=36 * 20000, frames=3),   # 72 VOIP streams at 16 kHz: SILK frames through front / quantiser / back
+    dict(B=2, channels=48, streams=32, coupled=16, mapping=list(range(48)), application=2049, bitrate=32 * 48000, frames=3),             # 64 streams, half of them coupled pairs: hybrid / SILK / CELT as the rate split decides
 ]
 
 # ---- projection (mapping family 3) encoder batch and the multistream / projection decoder batches ----

@@ -24,7 +24,16 @@ CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value
     "10ms_nb_mb":   (48000, 1, 2049, 6, 14, 10, {4002: 14000, 4010: 5, 11002: 1000}, {1: {4008: 1101}, 2: {4008: 1102}, 3: {4010: 2}, 4: {4010: 0}}),
     "audio_auto":   (48000, 2, 2049, 6, 14, 20, {4002: 40000, 4010: 10}, {1: {4002: 20000}, 2: {4002: 96000}, 3: {4012: 1, 4014: 10}, 4: {4016: 1}}),
     "stereo_silk":  (24000, 2, 2048, 5, 10, 20, {4002: 30000, 4010: 9, 11002: 1000}, {1: {4022: 1}, 2: {4002: 14000}}),
+    # CELT-only frames of the SILK-capable applications: kept by the front kernel since round 4's last day (no quantiser job, the back kernel codes them whole)
+    "audio_celt":   (48000, 2, 2049, 7, 12, 20, {4002: 96000, 4010: 10}, {1: {4002: 160000}, 2: {4006: 0}, 3: {4010: 5}, 4: {4022: 1}, 5: {4020: 0}, 6: {4008: 1104}}),
+    "celt_10ms":    (48000, 1, 2049, 6, 16, 10, {4002: 64000, 4010: 10}, {1: {4006: 0}, 2: {4046: 1}}),
+    "celt_5ms":     (48000, 2, 2049, 5, 20, 5, {4002: 96000, 4010: 8}, {}),
+    "celt_2_5ms":   (24000, 1, 2048, 5, 24, 2.5, {4002: 40000, 4010: 10}, {}),
+    "voip_celt":    (16000, 1, 2048, 5, 10, 20, {4002: 40000, 4010: 10, 11002: 1002}, {}),
+    # mode switches in both directions inside the run (redundancy frames, CELT prefill, SILK prefill -> those calls go to the one-kernel path, their neighbours stay): SCHEDULE below
+    "switching":    (48000, 2, 2049, 6, 18, 20, {4002: 24000, 4010: 10}, {1: {4022: 1}, 2: {4006: 0}}),
 }
+SCHEDULE = {"switching": {4: {4002: 96000}, 8: {4002: 20000}, 11: {11002: 1002}, 14: {11002: -1000, 4002: 32000}}}     # frame -> {ctl: value} for every stream
 
 def run_child(libpath, out):
     L = ctypes.CDLL(libpath)
@@ -42,12 +51,13 @@ def run_child(libpath, out):
         for k, v in ctl.items(): assert L.opusgpu_enc_batch_ctl(b, -1, k, v) == 0, (name, k, v)
         for s, d in per.items():
             for k, v in d.items(): assert L.opusgpu_enc_batch_ctl(b, s, k, v) == 0, (name, s, k, v)
-        fsz = Fs * ms // 1000
+        fsz = int(Fs * ms // 1000)
         sig = [speech(Fs, frames * ms / 1000 + 0.1, ch, s) for s in range(n)]
         pk = []
         for f in range(frames):
             pcm = np.stack([np.ascontiguousarray(sig[s][f * fsz:(f + 1) * fsz]).reshape(-1) for s in range(n)]).astype(np.int16)
             if f == frames // 2: pcm[0] = 0                      # a frame of digital silence
+            for k, v in SCHEDULE.get(name, {}).get(f, {}).items(): assert L.opusgpu_enc_batch_ctl(b, -1, k, v) == 0, (name, f, k, v)
             o = np.zeros((n, 1500), np.uint8); lens = np.zeros(n, np.int32); rng = np.zeros(n, np.uint32)
             r = L.opusgpu_encode_batch(b, pcm.ctypes.data, fsz, o.ctypes.data, 1500, 1275, lens.ctypes.data, rng.ctypes.data); assert r == 0, (name, r)
             pk.append((lens.copy(), rng.copy(), [bytes(o[s, :max(lens[s], 0)]) for s in range(n)]))
