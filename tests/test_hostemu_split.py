@@ -15,3 +15,14 @@ def test_emu_split_path_equals_one_kernel_path(fill, monkeypatch, tmp_path):
     bad, stats = split_check.compare("emu", tmpdir=str(tmp_path), verbose=False)
     assert not bad, bad
     assert stats["config3"] == (444, 0) and stats["config4"] == (152, 0) and stats["audio_auto"][1] > 0          # (kept, handed back): the forced modes keep every call, the automatic ones hand some back
+
+def test_emu_settings_fuzzers_through_the_pipeline():
+    """the settings fuzzers (encoder, sparse settings with resets, multistream layouts, batch ABI: tests/test_hostemu_fuzz.py) and the unforced-mode / long-frame cases of the mode and analysis suites once more with
+    OPUS_AMD_SH_SPLIT=1, which sends every 10 / 20 ms call of the SILK-capable applications through the front / quantiser / back kernels whatever the width of the launch: the
+    pipeline -- CELT-only frames kept by the front kernel, transitions, redundancy, declined calls -- against the compiled reference, not only against the one-kernel path"""
+    import subprocess
+    env = dict(os.environ, OPUS_AMD_SH_SPLIT="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu", "-k", "settings_fuzz or unforced_mode or long_frames",
+                        os.path.join(ROOT, "tests/test_hostemu_fuzz.py"), os.path.join(ROOT, "tests/test_hostemu_encoder_modes.py"), os.path.join(ROOT, "tests/test_hostemu_analysis.py")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT, timeout=3000)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
