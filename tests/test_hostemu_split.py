@@ -8,13 +8,18 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from reflib import ref_fx
 pytestmark = pytest.mark.skipif(ref_fx() is None, reason="oracle/_ref not built")
 
-@pytest.mark.parametrize("fill", ["0xA5", "0x5A"])
+LONG = os.environ.get("OPUS_AMD_LONG_TESTS") == "1"        # the default CPU suite: one garbage pattern, the cases that reach every kind of call; OPUS_AMD_LONG_TESTS=1: both patterns, the whole matrix, the wider fuzz
+QUICK = "config3,config4,audio_auto,audio_celt,switching,10ms_nb_mb"
+
+@pytest.mark.parametrize("fill", ["0xA5", "0x5A"] if LONG else ["0x5A"])
 def test_emu_split_path_equals_one_kernel_path(fill, monkeypatch, tmp_path):
     import split_check
     monkeypatch.setenv("OA_EMU_FILL", fill)
+    if not LONG: monkeypatch.setenv("SPLIT_CHECK_CASES", QUICK)
     bad, stats = split_check.compare("emu", tmpdir=str(tmp_path), verbose=False)
     assert not bad, bad
     assert stats["config3"] == (444, 0) and stats["config4"] == (152, 0) and stats["audio_auto"][1] > 0          # (kept, handed back): the forced modes keep every call, the automatic ones hand some back
+    assert stats["audio_celt"] == (84, 0) and stats["switching"][0] > 90                                        # CELT-only calls stay in the pipeline, and so do most calls around the mode switches
 
 def test_emu_settings_fuzzers_through_the_pipeline():
     """the settings fuzzers (encoder, sparse settings with resets, multistream layouts, batch ABI: tests/test_hostemu_fuzz.py) and the unforced-mode / long-frame cases of the mode and analysis suites once more with
@@ -22,7 +27,7 @@ def test_emu_settings_fuzzers_through_the_pipeline():
     pipeline -- CELT-only frames kept by the front kernel, transitions, redundancy, declined calls -- against the compiled reference, not only against the one-kernel path"""
     import subprocess
     env = dict(os.environ, OPUS_AMD_SH_SPLIT="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu", "-k", "settings_fuzz or unforced_mode or long_frames",
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu", "-k", "settings_fuzz or unforced_mode or long_frames" if LONG else "test_settings_fuzz or unforced_mode",
                         os.path.join(ROOT, "tests/test_hostemu_fuzz.py"), os.path.join(ROOT, "tests/test_hostemu_encoder_modes.py"), os.path.join(ROOT, "tests/test_hostemu_analysis.py")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT, timeout=3000)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]

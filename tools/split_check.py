@@ -35,6 +35,11 @@ CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value
 }
 SCHEDULE = {"switching": {4: {4002: 96000}, 8: {4002: 20000}, 11: {11002: 1002}, 14: {11002: -1000, 4002: 32000}}}     # frame -> {ctl: value} for every stream
 
+def selected_cases():
+    """SPLIT_CHECK_CASES=name,name,...: a subset (the default CPU suite runs the quick one: tests/test_hostemu_split.py)"""
+    want = os.environ.get("SPLIT_CHECK_CASES")
+    return CASES if not want else {k: v for k, v in CASES.items() if k in want.split(",")}
+
 def run_child(libpath, out):
     L = ctypes.CDLL(libpath)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
@@ -45,7 +50,7 @@ def run_child(libpath, out):
     L.opusgpu_enc_batch_split_stats.argtypes = [vp, vp, vp]
     L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
     res = {}
-    for name, (Fs, ch, app, n, frames, ms, ctl, per) in CASES.items():
+    for name, (Fs, ch, app, n, frames, ms, ctl, per) in selected_cases().items():
         err = ctypes.c_int()
         b = L.opusgpu_enc_batch_create(n, Fs, ch, app, 0, ctypes.byref(err)); assert b, err.value
         for k, v in ctl.items(): assert L.opusgpu_enc_batch_ctl(b, -1, k, v) == 0, (name, k, v)
@@ -80,7 +85,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
         subprocess.check_call([sys.executable, os.path.abspath(__file__), lib, mode, out], env=env)
         r[mode] = pickle.load(open(out, "rb")); os.unlink(out)
     bad = []
-    for name in CASES:
+    for name in selected_cases():
         a = r["0"][name]
         assert a[2] == (0, 0), "the one-kernel run went through the split path?"
         for mode in "12":
@@ -89,7 +94,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
             nd = [int((x != y).sum()) for x, y in zip(a[1], b[1])]
             if verbose: print("%-12s mode %s: packets %s, state bytes differing per stream %s, calls kept / handed back %s" % (name, mode, "equal" if okp else "DIFFER", nd, b[2]))
             if not okp or any(nd): bad.append((name, mode))
-    return bad, {name: r["1"][name][2] for name in CASES}
+    return bad, {name: r["1"][name][2] for name in selected_cases()}
 
 if __name__ == "__main__":
     if len(sys.argv) == 4: run_child(sys.argv[1], sys.argv[3])
