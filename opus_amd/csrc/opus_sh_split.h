@@ -58,8 +58,6 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    LANE0 { L->silk_tail = 0; S->st_off = (i32)SE_FRONT_ST_OFF; }          /* the quantiser tails stay in HBM: they are the quantiser kernel's; the state sits behind the analysis working set */
    wv_sync();
    WV_LDS OaSilkEnc *E = se_st(S);
-   LANE0 L->silk_tail = 0;                                                               /* the quantiser tails stay in HBM: they are the quantiser kernel's */
-   wv_sync();
    sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;

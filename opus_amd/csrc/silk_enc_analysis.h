@@ -1,6 +1,6 @@
 /* silk_enc_analysis.h — SILK encoder analysis stages (row a20 of SURVEY §8): noise shaping, LTP and LPC analysis.
  *
- *   se_warped_autocorr_wave      silk_warped_autocorrelation_FIX_c   silk/fixed/warped_autocorrelation_FIX.c:40 (systolic: lane = ladder stage)
+ *   se_warped_autocorr2_wave     silk_warped_autocorrelation_FIX_c   silk/fixed/warped_autocorrelation_FIX.c:40 (systolic: lane = ladder stage; two sub-frames per pass)
  *   se_schur64 / se_k2a_Q16      silk_schur64 / silk_k2a_Q16         silk/fixed/schur64_FIX.c:36, k2a_Q16_FIX.c:36
  *   se_noise_shape_analysis      silk_noise_shape_analysis_FIX       silk/fixed/noise_shape_analysis_FIX.c:147 (warped_gain :38, limit_warped_coefs :59)
  *   se_burg_modified_wave        silk_burg_modified_c                silk/fixed/burg_modified_FIX.c:46
@@ -42,33 +42,6 @@ template <class PO, class PI> WV_DEV void se_lpc_fit(PO a_QOUT, PI a_QIN, int QO
    else for (int k = 0; k < d; k++) a_QOUT[k] = (i16)sk_rround(a_QIN[k], QIN - QOUT);
 }
 
-/* silk_warped_autocorrelation_FIX_c as a systolic chain: lane i owns stage i of the warped allpass ladder and runs i samples behind lane 0, so one
- * wave step advances every stage (length + order steps instead of length x order).  in_{i}(n) = in_{i-1}(n-1) + SMLAWB(in_i(n-1) - in_{i-1}(n), w) is
- * exactly the reference's tmp1/tmp2 recursion; every corr[i] accumulates its 64-bit products in the reference's sample order.  QC = 10, QS = 13
- * (silk/fixed/main_FIX.h:49-50).  corr: [order + 2] in LDS, corr[order + 1] receives the scale. */
-WV_DEV int se_warped_autocorr_wave(WV_LDS i32 *corr, const WV_LDS i16 *input, int warping_Q16, int length, int order)
-{
-   const int lane = wv_lane();
-   i32 cur = 0, prev_stage_prev = 0, my = 0;
-   i64 acc = 0;
-   for (int t = 0; t < length + order; t++) {
-      const i32 from_prev = wv_shift_up1(my, 0);
-      const int m = t - lane;
-      if (lane <= order && m >= 0 && m < length) {
-         const i32 x13 = shl32((i32)input[m], 13);
-         const i32 v = lane == 0 ? x13 : add32(prev_stage_prev, sk_mulwb(sub32(cur, from_prev), warping_Q16));
-         prev_stage_prev = from_prev; cur = v; my = v;
-         acc += ((i64)v * (i64)x13) >> (2 * 13 - 10);
-      }
-   }
-   const i32 hi0 = wv_bcast((i32)(acc >> 32), 0), lo0 = wv_bcast((i32)acc, 0);
-   int lsh = se_clz64((i64)(((u64)(u32)hi0 << 32) | (u32)lo0)) - 35;
-   lsh = se_limit(lsh, -12 - 10, 30 - 10);
-   wv_sync();
-   if (lane <= order) corr[lane] = lsh >= 0 ? (i32)(acc << lsh) : (i32)(acc >> -lsh);
-   wv_sync();
-   return -(10 + lsh);
-}
 /* C: [order + 1][2] words of LDS */
 template <class PR, class PC> WV_DEV i32 se_schur64(PR rc_Q16, PC c, int order, WV_LDS i32 (*C)[2])
 {
@@ -136,7 +109,10 @@ WV_DEV void se_k2a_Q16_wave(WV_LDS i32 *A_Q24, const WV_LDS i32 *rc_Q16, int ord
 }
 /* ---- two sub-frames per pass (noise shaping analysis): lanes 0..31 work on sub-frame a, lanes 32..63 on sub-frame b.  order <= 24, so a chain / a correlation row fits one half. ---- */
 WV_DEV i32 wv_half_head(i32 v) { const i32 a = wv_lane_const<0>(v), b = wv_lane_const<32>(v); return wv_lane() < 32 ? a : b; }
-/* se_warped_autocorr_wave for two windowed sub-frames at once.  The window (sine slopes from wtab, silk/fixed/apply_sine_window_FIX.c:36 through se_sine_window_table) is applied as the
+/* silk_warped_autocorrelation_FIX_c (silk/fixed/warped_autocorrelation_FIX.c:40) as a systolic chain, two windowed sub-frames at once: lane i of a half owns stage i of the warped
+ * allpass ladder and runs i samples behind the half's head lane, so one wave step advances every stage (length + order steps instead of length x order).
+ * in_{i}(n) = in_{i-1}(n-1) + SMLAWB(in_i(n-1) - in_{i-1}(n), w) is exactly the reference's tmp1 / tmp2 recursion; every corr[i] accumulates its 64-bit products in the reference's
+ * sample order.  QC = 10, QS = 13 (silk/fixed/main_FIX.h:49-50).  The window (sine slopes from wtab, silk/fixed/apply_sine_window_FIX.c:36 through se_sine_window_table) is applied as the
  * samples are fetched, 64 per half at a time into a register per lane; the head lane of each half takes its next sample from there (v_readlane), the sample then travels down the
  * chain beside the stage value (DPP), so the loop touches no memory.  Stages that have not started see zeros from above and stages that have finished are fed zero samples: no lane
  * needs a predicate, a product with a sample outside [0, length) is zero.  Returns the lane's half's scale; corr_a / corr_b: LDS [order + 1]. */
@@ -356,50 +332,31 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
          SE_LTOC(22);
       }
    } else
-   for (int k = 0; k < c->nb_subfr; k++) {
+   for (int k = 0; k < c->nb_subfr; k++) {                                             /* no warping (complexity < 4): plain autocorrelation, one sub-frame at a time */
       const int flat_part = c->fs_kHz * 3, slope_part = (swl - flat_part) >> 1;
-      if (c->warping_Q16 > 0) {                                                        /* xx is free on the warped path: it holds the two window slopes, worked out once (lanes 0 and 1) */
-         WV_LDS i32 *wtab = (WV_LDS i32 *)xx;
-         if (k == 0) { if (wv_lane() < 2) se_sine_window_table(wtab + wv_lane() * slope_part, wv_lane() + 1, slope_part); wv_sync(); }
-         FOR_LANES(i, swl) {
-            i32 v = x_ptr[i];
-            if (i < slope_part) v = sk_mulwb(wtab[i], v); else if (i >= slope_part + flat_part) v = sk_mulwb(wtab[i - flat_part], v);
-            xw[i] = (i16)v;
-         }
-      } else LANE0 {
+      LANE0 {
          se_apply_sine_window(xw, x_ptr, 1, slope_part);
          for (int i = 0; i < flat_part; i++) xw[slope_part + i] = x_ptr[slope_part + i];
          se_apply_sine_window(xw + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
       }
       x_ptr += c->subfr_length;
-      int scale;
       wv_sync();
-      if (c->warping_Q16 > 0) scale = se_warped_autocorr_wave(w32, xw, warping_Q16, swl, order);
-      else scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
+      const int scale = se_autocorr_wave(w32, xw, swl, order + 1, xx);
       LANE0 w32[0] = add32(w32[0], imax(sk_mulwb(w32[0] >> 4, SE_FIX(3e-5f, 20)), 1));
       SE_LTOC(18);
       const i32 nrg_w = se_schur64_wave(stk, w32, order);
       se_k2a_Q16_wave(stk + 24, stk, order);
       SE_LTOC(19);
       LANE0 {
-         WV_LDS i32 *auto_corr = w32, *refl_coef_Q16 = stk, *AR_Q24 = stk + 24;
-         i32 nrg = nrg_w; (void)auto_corr; (void)refl_coef_Q16;
+         WV_LDS i32 *AR_Q24 = stk + 24;
+         i32 nrg = nrg_w;
          int Qnrg = -scale;
          if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
          const i32 tmp32 = se_sqrt_approx(nrg);
          Qnrg >>= 1;
-         i32 g = sk_shl_sat(tmp32, 16 - Qnrg);
-         if (c->warping_Q16 > 0) {
-            const i32 gain_mult_Q16 = se_warped_gain(AR_Q24, warping_Q16, order);
-            if (g < SE_FIX(0.25, 16)) g = sk_mulww(g, gain_mult_Q16);
-            else { g = sk_mulww(sk_rround(g, 1), gain_mult_Q16); g = g >= (2147483647 >> 1) ? 2147483647 : shl32(g, 1); }
-         }
-         ctl->Gains_Q16[k] = g;
+         ctl->Gains_Q16[k] = sk_shl_sat(tmp32, 16 - Qnrg);
          se_bwexpander_32(AR_Q24, order, BWExp_Q16);
-         if (c->warping_Q16 > 0) {
-            se_limit_warped_coefs(AR_Q24, warping_Q16, SE_FIX(3.999, 24), order);
-            for (int i = 0; i < order; i++) ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER + i] = (i16)sk_sat16(sk_rround(AR_Q24[i], 11));
-         } else se_lpc_fit(&ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER], AR_Q24, 13, 24, order);
+         se_lpc_fit(&ctl->AR_Q13[k * SE_MAX_SHAPE_ORDER], AR_Q24, 13, 24, order);
       }
       SE_LTOC(22);
    }
