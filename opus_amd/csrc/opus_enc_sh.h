@@ -896,7 +896,14 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
    wv_sync();
    WV_LDS i32 *w = (WV_LDS i32 *)se_st(&L->S);
    FOR_LANES(i, SE_STATE_LITE_WORDS(CC)) w[i] = 0;
-   if (wv_uni(L->silk_tail)) { const int o = (int)(offsetof(OaSilkEnc, tail) / 4); FOR_LANES(i, CC * SE_TAIL_WORDS) w[o + i] = 0; }
+   /* the channels' input buffers and the quantiser tails belong to the state silk_InitEncoder clears (silk_encoder_state.inputBuf, silk_nsq_state: silk/structs.h:176, :56): stale
+    * input would be read by the first mono frame after a stereo one (enc_API.c:318-326 averages frame_length samples of channel 1's buffer, of which its resampler -- still at the
+    * old internal rate when the rate switches with the channel count -- may have written fewer).  Only kernels that stage them run this (the pipeline's front kernel turns prefill calls away) */
+   if (wv_uni(L->silk_tail)) {
+      const int o = (int)(offsetof(OaSilkEnc, tail) / 4), b = (int)(offsetof(OaSilkEnc, inbuf) / 4);
+      FOR_LANES(i, CC * SE_TAIL_WORDS) w[o + i] = 0;
+      FOR_LANES(i, CC * SE_INBUF_WORDS) w[b + i] = 0;
+   }
    wv_sync();
    LANE0 {
       WV_LDS OaSilkEnc *E = se_st(&L->S);

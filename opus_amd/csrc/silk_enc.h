@@ -60,6 +60,7 @@ WV_DEV void se_init_channel(WV_LDS OaSilkEncChannel *c)
    for (int i = 0; i < (int)(sizeof(OaSilkEncChannel) / 4); i++) w[i] = 0;
    c->variable_HP_smth1_Q15 = shl32(se_lin2log(SE_FIX(60, 16)) - (16 << 7), 8);
    c->first_frame_after_reset = 1;
+   c->inbuf_reset_req = 1;
    for (int b = 0; b < 4; b++) c->vad_NoiseLevelBias[b] = imax(50 / (b + 1), 1);
    for (int b = 0; b < 4; b++) { c->vad_NL[b] = 100 * c->vad_NoiseLevelBias[b]; c->vad_inv_NL[b] = 2147483647 / c->vad_NL[b]; }
    c->vad_counter = 15;

@@ -700,6 +700,15 @@ template <int FRONT = 0> WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, S
    WV_LDS OaSilkEnc *E = se_st(S);
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0], *c1 = &E->ch[1];
    WV_LDS i16 *in0 = se_inbuf<FRONT>(S, 0), *in1 = se_inbuf<FRONT>(S, 1);
+   for (int n = 0; n < ec->nChannelsAPI; n++) {                                  /* a channel that silk_init_encoder has started over: its input buffer with it (inbuf_reset_req) */
+      if (wv_uni(E->ch[n].inbuf_reset_req)) {
+         WV_LDS i32 *z = (WV_LDS i32 *)(n ? in1 : in0);
+         wv_sync();
+         FOR_LANES(i, SE_INBUF_WORDS) z[i] = 0;
+         LANE0 E->ch[n].inbuf_reset_req = 0;
+      }
+   }
+   wv_sync();
    const int ix0 = c0->inputBufIx;
    if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 2) {
       const int ix1 = c1->inputBufIx;

@@ -42,6 +42,8 @@ struct OaSilkEncChannel {
    int32_t rs_cfg[9], rs_rows[90];
    int32_t nsq_reset_req;                      /* the quantiser state (OaSilkEncTail) starts over before its next use: silk_setup_fs (control_codec.c:241) and the side channel's
                                                 * return after mid-only frames (enc_API.c:449) ask for it here, because the analysis kernel of the split path does not hold the tails */
+   int32_t inbuf_reset_req;                    /* the channel's input buffer (OaSilkEnc.inbuf) is cleared before its next use: silk_init_encoder (init_encoder.c:46: the second channel's on a mono -> stereo
+                                                * switch, every channel's in a prefill call) clears it with the rest of the channel, and enc_API.c:318-326 can read samples of it that nothing has written since */
    int16_t prev_NLSFq_Q15[16];
    int16_t x_buf[SE_X_BUF_LEN];
    OaSilkEncIndices indices;
@@ -84,6 +86,7 @@ static inline void oa_silk_enc_channel_reset(OaSilkEncChannel *c)
    char *p = (char *)c; for (size_t i = 0; i < sizeof(*c); i++) p[i] = 0;
    c->variable_HP_smth1_Q15 = 193536;
    c->first_frame_after_reset = 1;
+   c->inbuf_reset_req = 1;
    for (int b = 0; b < 4; b++) { const int bias = 50 / (b + 1) > 1 ? 50 / (b + 1) : 1; c->vad_NoiseLevelBias[b] = bias; c->vad_NL[b] = 100 * bias; c->vad_inv_NL[b] = 2147483647 / (100 * bias); c->vad_NrgRatioSmth_Q8[b] = 100 * 256; }
    c->vad_counter = 15;
 }
