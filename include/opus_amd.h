@@ -146,6 +146,13 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_
  * DISABLE_FLOAT_API.  The process-wide default for new encoders can be set with the environment variable OPUS_AMD_FLOAT_ANALYSIS=0. */
 #define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
 #define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
+/* OPUS_AMD_SET_KERNEL_PIPELINE(v): how the following 10 / 20 ms calls of a SILK-capable encoder are launched -- a property of the launch, never of the packets (every value
+ * gives the same bytes).  -1 (the default) = the library chooses: the front / quantiser / back kernel pipeline (opus_sh_split.h) when the launch carries >= 64 streams, one
+ * kernel below that; 0 = always one kernel; 1 = always the pipeline; 2 = the pipeline with its one-wave-per-stream reference quantiser.  On a batch (opusgpu_enc_batch_ctl, any
+ * `stream`) it applies to the whole batch; on a classic encoder it applies to that encoder's calls (calls with different values are not combined into one launch); a
+ * multistream encoder passes it to its elementary encoders.  The process-wide default behind -1 can be set with the environment variable OPUS_AMD_SH_SPLIT=0|1|2. */
+#define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
+#define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
 OPUS_AMD_EXPORT int opusgpu_enc_batch_sync(OpusGpuEncBatch *b);
 /* `steps` back-to-back frame-steps on device buffers ([steps][S][frame*channels] PCM), timed with HIP events on the
  * launch stream; returns elapsed milliseconds in *ms (kernel time only, inputs resident). */

@@ -317,6 +317,7 @@ struct OpusGpuEncBatch {
    bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
    int any_cbr;                         /* some stream of the mirror is hard CBR (-1: not derived since the mirror last changed): sizes the output slot a call needs */
    int all_silk_pinned;
+   int pipeline;                        /* OPUS_AMD_SET_KERNEL_PIPELINE: -1 the library chooses, 0 one kernel, 1 / 2 the kernel pipeline (include/opus_amd.h) */
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
    opus_int32 *d_apcm; size_t apcm_cap;  /* signal-domain copy of the input for the analysis (24-bit / float entry points) */
@@ -357,7 +358,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
@@ -407,6 +408,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 2) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
    b->any_cbr = -1;
    if (request == OPUS_RESET_STATE) {
       /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
@@ -445,6 +447,7 @@ int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    if (!b || stream < 0 || stream >= b->S) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
+   if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { if (!value) return OPUS_BAD_ARG; *value = b->pipeline; return OPUS_OK; }
    if (b->kind) {
       OaShStream *t = new OaShStream(b->h_sh[stream]);
       hipError_t e_ = request == OPUS_GET_IN_DTX_REQUEST ? hipMemcpy(t, &b->d_sh[stream], sizeof(OaShStream), hipMemcpyDeviceToHost)      /* needs the SILK channel counters */
@@ -621,7 +624,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
       /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser; unset: the kernel pipeline when the launch is wide
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
-      const int split_mode = split_env >= 0 ? split_env : (b->n_act >= 64 ? 1 : 0);
+      const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 1 : 0);
       if (split_mode && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
@@ -741,18 +744,18 @@ int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const op
 
 /* ---------------- classic libopus encoder API on top of a process-wide batch-of-one ---------------- */
 #define OA_MAGIC 0x4f41454eu /* "OAEN" */
-struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pad[2]; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
+struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pipeline_p2 /* OPUS_AMD_SET_KERNEL_PIPELINE + 2; 0 = never set (-1) */; uint32_t pad; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
 static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][API rate][channels - 1]: created by the first call of that shape, used by one launch at a time */
 /* one classic call waiting for (or leading) a launch: opus_call_combiner.h */
 struct OaEncCall {
    OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
    int kind, frame_size, application, channels; opus_int32 Fs, max_data_bytes;
-   int ret; bool done; size_t tid;
+   int ret; bool done; size_t tid; int pipeline;
    const void *who() const { return st; }
    bool same_shape(const OaEncCall &o) const
    {
       return kind == o.kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
-          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr);
+          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr) && pipeline == o.pipeline;
    }
 };
 static OaCallCombiner<OaEncCall> g_enc_calls;
@@ -813,7 +816,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
       if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
    OpusGpuEncBatch *b = *slot;
-   b->application = h.application; b->n_act = n;
+   b->application = h.application; b->n_act = n; b->pipeline = h.pipeline;
    opus_int32 stride = oa_enc_out_stride_needed(h.Fs, h.frame_size, h.max_data_bytes) + 8;
    if (stride < 1288) stride = 1288;
    const size_t per = (size_t)h.frame_size * h.channels, rec = kind ? sizeof(OaShStream) : sizeof(OaStream);
@@ -872,7 +875,7 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    if (frame_size <= 0 || max_data_bytes <= 0) return OPUS_BAD_ARG;
    { const int fr = oa_enc_frame_size_code(Fs, application, frame_size); if (fr != OPUS_OK) return fr; }
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false};
+   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false, 0, st->pipeline_p2 ? (int)st->pipeline_p2 - 2 : -1};
    g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_linger_us(), oa_classic_encode_group);
    return call.ret;
 }
@@ -922,6 +925,8 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    va_start(ap, request);
    int ret;
    if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
+   else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 2) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
+   else if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else { *p = st->pipeline_p2 ? (opus_int32)st->pipeline_p2 - 2 : -1; ret = OPUS_OK; } }
    else if (request == OPUS_SET_ENERGY_MASK_REQUEST) {                                  /* internal (src/opus_private.h): multistream surround masking, 21 values per channel or NULL */
       const opus_int32 *m = va_arg(ap, const opus_int32 *);
       opus_int32 *dst = st->kind ? st->sh.energy_mask : st->s.energy_mask;
@@ -939,6 +944,7 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
          else {
             memcpy(o, st, sizeof(*o));
             ret = opus_encoder_init(st, o->kind ? o->sh.cfg.Fs : o->s.Fs, o->kind ? o->sh.cfg.channels : o->s.cfg.channels, v);
+            st->pipeline_p2 = o->pipeline_p2;
             static const int carry[] = {OPUS_SET_BITRATE_REQUEST, OPUS_SET_COMPLEXITY_REQUEST, OPUS_SET_VBR_REQUEST, OPUS_SET_VBR_CONSTRAINT_REQUEST, OPUS_SET_FORCE_CHANNELS_REQUEST,
                OPUS_SET_BANDWIDTH_REQUEST, OPUS_SET_MAX_BANDWIDTH_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST, OPUS_SET_FORCE_MODE_REQUEST, OPUS_SET_SIGNAL_REQUEST,
                OPUS_SET_PACKET_LOSS_PERC_REQUEST, OPUS_SET_INBAND_FEC_REQUEST, OPUS_SET_DTX_REQUEST, OPUS_SET_VOICE_RATIO_REQUEST, OPUS_SET_EXPERT_FRAME_DURATION_REQUEST, OPUS_SET_PREDICTION_DISABLED_REQUEST};

@@ -14,6 +14,8 @@
 #ifndef OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST
 #define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
 #define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
+#define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
+#define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
 #endif
 #define OPUS_SET_LFE_REQUEST 10024
 #define OPUS_SET_ENERGY_MASK_REQUEST 10026

@@ -90,6 +90,9 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    {
       int ok = k.tot_blocks == 1 && wv_uni(c0->inputBufIx) == 0 && wv_uni(c0->nFramesPerPacket) == 1;
       for (int n = 0; n < sc.nChannelsInternal; n++) ok = ok && !wv_uni(E->ch[n].LBRR_enabled) && (wv_uni(E->ch[n].nStatesDelayedDecision) > 1 || wv_uni(E->ch[n].warping_Q16) > 0);
+      /* the previous packet's LBRR side stream is still owed (enc_API.c:364-404 codes it at the head of this packet whatever the FEC setting is now -- the first frame after
+       * OPUS_SET_INBAND_FEC goes 1 -> 0): indices and pulses of up to three frames do not fit the front kernel's SH_FRONT_PKT_BYTES window, the one-kernel path codes this call */
+      for (int n = 0; n < sc.nChannelsInternal; n++) for (int i = 0; i < 3; i++) ok = ok && !wv_uni(E->ch[n].LBRR_flags[i]);
       const int nSamplesToBuffer = imin(wv_uni(c0->frame_length) - wv_uni(c0->inputBufIx), k.nSamplesToBufferMax);
       const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
       ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);

@@ -27,7 +27,11 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 #define __shared__ thread_local
 #define HIP_SYMBOL(x) x
 
-extern thread_local __attribute__((aligned(64))) char smem[];
+/* the launch's dynamic LDS: a window that ENDS at a PROT_NONE page (emu_lds_window), so that a load or a store beyond the launch's allocation faults here -- on the GPU the
+ * store is dropped and the load returns zero without any sign.  The kernels' own `extern __shared__ char smem[]` declarations resolve to this pointer-to-array. */
+extern thread_local char (*emu_smem_p)[];
+#define smem (*emu_smem_p)
+char *emu_lds_window(size_t lds, const char *kernel_name);      /* emu_host.cpp */
 extern thread_local unsigned emu_block_x;
 struct EmuIdx { unsigned x, y, z; };
 static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)(emu_cur->cur ^ emu_flip), 0, 0}; return i; }
@@ -69,18 +73,18 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 
 static void emu_launch_tramp(void *p) { (*(std::function<void()> *)p)(); }
-/* lds = the launch's dynamic LDS size: on the GPU an access beyond it is dropped / reads zero without any fault, so the bytes behind it are watched here -- a kernel that
- * writes there (a struct member outside the part of the layout the launch allocated) aborts the test instead of passing on the emulator and failing on the device */
+/* lds = the launch's dynamic LDS size: on the GPU an access beyond it is dropped / reads zero without any fault.  Here the window ends (to 16 bytes) at an inaccessible page:
+ * a kernel that reads or writes there (a struct member outside the part of the layout the launch allocated, a packet window too small for what is coded into it) dies with
+ * the kernel's name instead of passing on the emulator and failing -- or silently differing -- on the device */
 static inline void emu_launch(dim3 grid, size_t lds, const char *name, std::function<void()> body)
 {
-   const size_t guard = 8192;
    for (unsigned b = 0; b < grid.x; b++) {
       emu_block_x = b;
-      memset(smem, emu_fill_byte(), 65536);                         /* LDS is uninitialised on the GPU: make stale reads loud */
-      if (lds + guard > 65536) memset(smem + 65536, emu_fill_byte(), lds + guard - 65536);
+      char *w = emu_lds_window(lds, name);
+      memset(w, emu_fill_byte(), (lds + 15) & ~(size_t)15);         /* LDS is uninitialised on the GPU: make stale reads loud */
       emu_run_wave(emu_launch_tramp, &body);
-      for (size_t i = lds; i < lds + guard; i++) if ((unsigned char)smem[i] != (unsigned char)emu_fill_byte()) { fprintf(stderr, "wave_emu: kernel %s wrote LDS byte %zu, beyond its dynamic allocation of %zu bytes\n", name, i, lds); abort(); }
    }
+   emu_lds_window(0, nullptr);
 }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu_launch((grid), (size_t)(lds), #kern, [&]() { kern(__VA_ARGS__); })
 #endif

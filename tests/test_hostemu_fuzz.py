@@ -12,6 +12,7 @@ from reflib import ref_fx, ref_fxa
 from test_kernel_emu_silkdec import speechy
 pytestmark = [pytest.mark.skipif(ref_fx() is None or ref_fxa() is None, reason="oracle/_ref not built"), pytest.mark.timeout(900)]   # (a hang is a finding too: opus_pcm_soft_clip on a NaN was one)
 WHICH = "emu"
+PIPELINE = int(__import__("os").environ.get("OPUS_AMD_TEST_PIPELINE", "-1"))      # OPUS_AMD_SET_KERNEL_PIPELINE of every encoder under test (include/opus_amd.h): 1 = every 10 / 20 ms call through the front / quantiser / back kernels
 LONG = __import__("os").environ.get("OPUS_AMD_LONG_TESTS") == "1"      # the default CPU suite runs the seeds that once found something plus a fresh one or two; OPUS_AMD_LONG_TESTS=1 adds ranges
 
 def _signal(rng, Fs, ch, nsamp):
@@ -32,13 +33,14 @@ def _signal(rng, Fs, ch, nsamp):
     x = out[::48000 // Fs].astype(np.int16)
     return np.ascontiguousarray(x if ch == 2 else x[:, 0])
 
-def fuzz(seed, changes=10, hold_ms=500):
+def fuzz(seed, changes=10, hold_ms=500, pipeline=None):
     rng = np.random.default_rng(1000 + seed)
     Fs = int(rng.choice([8000, 12000, 16000, 24000, 48000])); ch = int(rng.choice([1, 2])); app = int(rng.choice([2048, 2049, 2051, 2051]))
     analysis = seed % 2 == 0
     a = capi.Enc("ref_fxa" if analysis else "ref", Fs, ch, app); b = capi.Enc(WHICH, Fs, ch, app)
     b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     assert b.L.opus_encoder_ctl(b.st, 11900, int(analysis)) == 0
+    assert b.L.opus_encoder_ctl(b.st, 11902, PIPELINE if pipeline is None else pipeline) == 0
     sig = _signal(rng, Fs, ch, Fs * (changes * hold_ms + 2000) // 1000); pos = 0
     hist = []
     for j in range(changes):
@@ -64,7 +66,7 @@ def fuzz(seed, changes=10, hold_ms=500):
 def test_settings_fuzz_against_the_reference(seed): fuzz(seed)
 
 
-def fuzz_ms(seed, changes=6, hold_ms=300):
+def fuzz_ms(seed, changes=6, hold_ms=300, pipeline=None):
     """the same for multistream encoders: a random layout (mapping family 0 / 1 / 2 / 255), rate and application, random settings through opus_multistream_encoder_ctl"""
     rng = np.random.default_rng(5000 + seed)
     family = int(rng.choice([0, 1, 1, 2, 255])); Fs = int(rng.choice([8000, 12000, 16000, 24000, 48000, 48000])); app = int(rng.choice([2048, 2049, 2049, 2051]))
@@ -87,6 +89,7 @@ def fuzz_ms(seed, changes=6, hold_ms=300):
     def rng_of(L, e):
         v = ctypes.c_uint32(); L.opus_multistream_encoder_ctl.argtypes = [vp, ci, vp]; assert L.opus_multistream_encoder_ctl(e, 4031, ctypes.byref(v)) == 0; return v.value
     assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
+    assert ctl(E, encs[1][1], 11902, PIPELINE if pipeline is None else pipeline) == 0
     cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(min(nch, 4))]
     sig = np.ascontiguousarray(np.stack([(cols[c % len(cols)] // (1 + c // len(cols))).astype(np.int16) for c in range(nch)], 1))
     pos = 0; cap = 1500 * nch + 4000
@@ -114,7 +117,7 @@ def fuzz_ms(seed, changes=6, hold_ms=300):
 def test_multistream_settings_fuzz_against_the_reference(seed): fuzz_ms(seed)
 
 
-def fuzz_sparse(seed, changes=14, hold_ms=350):
+def fuzz_sparse(seed, changes=14, hold_ms=350, pipeline=None):
     """a longer-lived variant: every change touches only a random subset of the settings (so that a setting, or a side effect the encoder left behind, survives many
     changes of the others), and the set includes the forced mode, the forced bandwidth and OPUS_RESET_STATE"""
     rng = np.random.default_rng(9000 + seed)
@@ -123,6 +126,7 @@ def fuzz_sparse(seed, changes=14, hold_ms=350):
     a = capi.Enc("ref_fxa" if analysis else "ref", Fs, ch, app); b = capi.Enc(WHICH, Fs, ch, app)
     b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     assert b.L.opus_encoder_ctl(b.st, 11900, int(analysis)) == 0
+    assert b.L.opus_encoder_ctl(b.st, 11902, PIPELINE if pipeline is None else pipeline) == 0
     sig = _signal(rng, Fs, ch, Fs * (changes * hold_ms + 2500) // 1000); pos = 0
     menu = dict(bitrate=[6000, 9000, 12000, 16000, 24000, 32000, 48000, 64000, 96000, 160000, 510000, -1000, -1], force_channels=[-1000, 1, 2], vbr=[0, 1], vbr_constraint=[0, 1],
                 complexity=list(range(11)), max_bandwidth=[1101, 1102, 1103, 1104, 1105], bandwidth=[-1000, -1000, 1101, 1102, 1103, 1104, 1105], signal=[-1000, 3001, 3002],
@@ -275,7 +279,7 @@ def fuzz_ms_dec(seed, nframes=40):
 def test_multistream_decoder_fuzz_against_the_reference(seed): fuzz_ms_dec(seed)
 
 
-def fuzz_batch(seed, S=5, changes=8, hold_ms=250):
+def fuzz_batch(seed, S=5, changes=8, hold_ms=250, pipeline=None):
     """the batch ABI under the same treatment: S streams of one shape stepped together, settings changed per stream (or for all streams at once) through
     opusgpu_enc_batch_ctl between calls, every stream compared with a reference encoder that was given the same history"""
     rng = np.random.default_rng(21000 + seed)
@@ -287,6 +291,7 @@ def fuzz_batch(seed, S=5, changes=8, hold_ms=250):
     L.opusgpu_encode_batch.argtypes = [vp, vp, ci, vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
     err = ci(); b = L.opusgpu_enc_batch_create(S, Fs, ch, app, 0, ctypes.byref(err)); assert b and err.value == 0
     assert L.opusgpu_enc_batch_ctl(b, -1, 11900, int(analysis)) == 0
+    assert L.opusgpu_enc_batch_ctl(b, -1, 11902, PIPELINE if pipeline is None else pipeline) == 0
     refs = [capi.Enc("ref_fxa" if analysis else "ref", Fs, ch, app) for _ in range(S)]
     sigs = [_signal(rng, Fs, ch, Fs * (changes * hold_ms + 2000) // 1000) for _ in range(S)]; pos = 0
     menu = dict(bitrate=[8000, 16000, 32000, 64000, 128000, -1000, -1], force_channels=[-1000, 1, 2], vbr=[0, 1], vbr_constraint=[0, 1], complexity=[0, 4, 8, 10, 10], max_bandwidth=[1101, 1103, 1104, 1105],
@@ -369,7 +374,7 @@ def fuzz_entry(seed, changes=8, hold_ms=300):
 def test_entry_point_fuzz_against_the_reference(seed): fuzz_entry(seed)
 
 
-def fuzz_proj(seed, changes=5, hold_ms=200):
+def fuzz_proj(seed, changes=5, hold_ms=200, pipeline=None):
     """projection (ambisonics with mixing matrices, mapping family 3) encoders and decoders of a random order under changing settings: packets, final ranges and decoded PCM"""
     rng = np.random.default_rng(29000 + seed)
     nch = int(rng.choice([4, 6, 9, 11, 16, 18])); Fs = int(rng.choice([16000, 24000, 48000, 48000])); app = int(rng.choice([2048, 2049, 2051]))
@@ -392,6 +397,7 @@ def fuzz_proj(seed, changes=5, hold_ms=200):
     assert encs[0][2] == encs[1][2]
     def ctl(L, e, req, v): L.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]; return L.opus_projection_encoder_ctl(e, req, v)
     assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
+    assert ctl(E, encs[1][1], 11902, PIPELINE if pipeline is None else pipeline) == 0
     cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(4)]
     sig = np.ascontiguousarray(np.stack([(cols[q % 4] // (1 + q // 4)).astype(np.int16) for q in range(nch)], 1)); pos = 0
     cap = 1500 * nch; bufs = [(ctypes.c_ubyte * cap)(), (ctypes.c_ubyte * cap)()]
@@ -523,3 +529,33 @@ def fuzz_float_out(seed):
 # predicate walks past it)
 @pytest.mark.parametrize("seed", range(4 if LONG else 2))
 def test_float_output_fuzz_against_the_reference(seed): fuzz_float_out(seed)
+
+
+# ---- the same fuzzers with every 10 / 20 ms call forced through the front / quantiser / back kernel pipeline (OPUS_AMD_SET_KERNEL_PIPELINE(1)), against the reference ----
+# sparse 7770080, batch 7770010: the round-4 review's finds -- the LBRR side stream of the packet before is owed at the head of the first packet after in-band FEC goes 1 -> 0
+# (enc_API.c:364-404), and the front kernel coded it into its 64-byte header window; the emulator's LDS watch (hip_stub.h: the window now ends at an inaccessible page, loads
+# included) aborts on the spot, on the GPU the stores were dropped and the packet differed from byte 64 on with the same final range
+@pytest.mark.parametrize("seed", [7770080] + ([7770000, 7770001] if LONG else []))
+def test_sparse_settings_fuzz_through_the_pipeline(seed): fuzz_sparse(seed, pipeline=1)
+
+@pytest.mark.parametrize("seed", [7770010] + ([7770000, 7770001] if LONG else []))
+def test_batch_abi_settings_fuzz_through_the_pipeline(seed): fuzz_batch(seed, pipeline=1)
+
+@pytest.mark.parametrize("seed", [1] + ([248, 300, 7770000] if LONG else []))
+def test_settings_fuzz_through_the_pipeline(seed): fuzz(seed, pipeline=1)
+
+@pytest.mark.parametrize("pipeline", [1, 2, 0])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_pending_lbrr_after_fec_is_switched_off(pipeline, ch):
+    """the deterministic case of the round-4 review (BASELINE config-3 shape): 16 kHz VOIP, SILK forced, complexity 10, 96 kb/s, in-band FEC with 20 % expected loss for ten
+    frames, then OPUS_SET_INBAND_FEC(0): frame 10 still carries frame 9's LBRR copy in front of its own payload (enc_API.c:364-404)"""
+    a = capi.Enc("ref", 16000, ch, 2048); b = capi.Enc(WHICH, 16000, ch, 2048)
+    b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    assert b.L.opus_encoder_ctl(b.st, 11900, 0) == 0 and b.L.opus_encoder_ctl(b.st, 11902, pipeline) == 0
+    g = ctypes.c_int32(); b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]; assert b.L.opus_encoder_ctl(b.st, 11903, ctypes.byref(g)) == 0 and g.value == pipeline
+    for k, v in dict(force_mode=1000, complexity=10, bitrate=96000 * ch, inband_fec=1, packet_loss=20).items(): assert a.set(k, v) == b.set(k, v) == 0
+    x = speechy(20, 2, 77, 960)[::3].astype(np.int16); x = np.ascontiguousarray(x if ch == 2 else x[:, 0])
+    for i in range(16):
+        if i == 10: assert a.set("inband_fec", 0) == b.set("inband_fec", 0) == 0
+        p, q = a.encode(x[i * 320:(i + 1) * 320], 320), b.encode(x[i * 320:(i + 1) * 320], 320)
+        assert p == q, (i, p[1], q[1], next((k for k in range(min(len(p[0]), len(q[0]))) if p[0][k] != q[0][k]), None))
