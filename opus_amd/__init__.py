@@ -27,6 +27,7 @@ OPUS_GET_FINAL_RANGE_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSI
 OPUS_SET_FORCE_MODE_REQUEST, OPUS_SET_SIGNAL_REQUEST, OPUS_SET_PACKET_LOSS_PERC_REQUEST, OPUS_SET_INBAND_FEC_REQUEST, OPUS_SET_DTX_REQUEST = 11002, 4024, 4014, 4012, 4016
 OPUS_MODE_SILK_ONLY, OPUS_MODE_HYBRID, OPUS_MODE_CELT_ONLY = 1000, 1001, 1002
 OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST = 11900, 11901     # private: 0 = encode like a reference built with DISABLE_FLOAT_API
+OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST, OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST = 11902, 11903       # private: -1 the library chooses, 0 one kernel, 1 / 2 the front / quantiser / back kernel pipeline (include/opus_amd.h)
 OPUS_BANDWIDTH_NARROWBAND, OPUS_BANDWIDTH_MEDIUMBAND, OPUS_BANDWIDTH_WIDEBAND, OPUS_BANDWIDTH_SUPERWIDEBAND, OPUS_BANDWIDTH_FULLBAND = 1101, 1102, 1103, 1104, 1105
 
 SOURCES = [os.path.join(_HERE, "csrc", "opus_amd.hip")]

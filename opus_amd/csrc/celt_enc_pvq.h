@@ -844,14 +844,18 @@ OA_PVQ_STEREO_FN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i
       mid = shl32((i32)wv_uni(th[1]), 16);
       side = shl32((i32)wv_uni(th[2]), 16);
    }
+   /* One quant_band site for every way through this function (the code object carried five inlined copies of it per copy of this function, fifteen in all, 216 KB of
+    * quant_all_bands: the hot loop of the frame did not fit the 64 KB instruction cache two CUs share): N == 2 codes one vector (the larger of mid and side, bands.c:1437-1476),
+    * everything else codes mid and side in the order of their budgets, the second one with what the first left over (:1479-1527). */
+   WV_LDS i32 *x2 = X, *y2 = Y;
+   int sign = 0, mid_first = 1, npass = 2;
+   i32 rebalance = 0;
    if (N == 2) {
-      int c, sign = 0;
-      WV_LDS i32 *x2, *y2;
       mbits = b;
       sbits = 0;
       if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
       mbits -= sbits;
-      c = itheta > 8192;
+      const int c = itheta > 8192;
       remaining_bits -= qalloc + sbits;
       x2 = c ? Y : X;
       y2 = c ? X : Y;
@@ -861,8 +865,26 @@ OA_PVQ_STEREO_FN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i
          LANE0 { EC_BEGIN; k_ec_enc_bits(EC_PASS, sign, 1); EC_END; }
       }
       sign = 1 - 2 * sign;
-      r = quant_band_wave(L, cfg, remaining_bits, seed, x2, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, orig_fill);
-      cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+      npass = 1;
+   } else {
+      mbits = imax(0, imin(b, (b - delta) / 2));
+      sbits = b - mbits;
+      remaining_bits -= qalloc;
+      rebalance = remaining_bits;
+      mid_first = mbits >= sbits;
+   }
+#pragma nounroll
+   for (int pass = 0; pass < npass; pass++) {
+      const int do_mid = (pass == 0) == (mid_first != 0);
+      if (pass == 1) {
+         if (mid_first) { rebalance = mbits - (rebalance - remaining_bits); if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES); }
+         else { rebalance = sbits - (rebalance - remaining_bits); if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES); }
+      }
+      r = quant_band_wave(L, cfg, remaining_bits, seed, N == 2 ? x2 : do_mid ? X : Y, N, do_mid ? mbits : sbits, B, do_mid ? lowband : (WV_LDS i32 *)0, LM,
+            do_mid ? lowband_out : (WV_LDS i32 *)0, do_mid ? Q31ONE : side, do_mid ? lowband_scratch : (WV_LDS i32 *)0, N == 2 ? orig_fill : do_mid ? fill : fill >> B);
+      cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+   }
+   if (N == 2) {
       wv_sync();
       LANE0 { y2[0] = -sign * x2[1]; y2[1] = sign * x2[0]; }
       wv_sync();
@@ -877,27 +899,6 @@ OA_PVQ_STEREO_FN i32x4 quant_band_stereo_wave(WV_LDS FrameLds *L, BandCfg cfg, i
             tmp = X[1]; X[1] = sub32(tmp, Y[1]); Y[1] = add32(tmp, Y[1]);
          }
          wv_sync();
-      }
-   } else {
-      i32 rebalance;
-      mbits = imax(0, imin(b, (b - delta) / 2));
-      sbits = b - mbits;
-      remaining_bits -= qalloc;
-      rebalance = remaining_bits;
-      if (mbits >= sbits) {
-         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
-         cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-         rebalance = mbits - (rebalance - remaining_bits);
-         if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
-         cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-      } else {
-         r = quant_band_wave(L, cfg, remaining_bits, seed, Y, N, sbits, B, 0, LM, 0, side, 0, fill >> B);
-         cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-         rebalance = sbits - (rebalance - remaining_bits);
-         if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, mbits, B, lowband, LM, lowband_out, Q31ONE, lowband_scratch, fill);
-         cm |= (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
       }
    }
    if (cfg.resynth) {
@@ -992,69 +993,77 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       WV_LDS i32 *lb2 = effective_lowband != -1 ? norm2 + effective_lowband : 0;
       WV_LDS i32 *lbo = last ? 0 : norm + M * ct_eBands[i] - norm_offset;
       WV_LDS i32 *lbo2 = last ? 0 : norm2 + M * ct_eBands[i] - norm_offset;
-      if (dual_stereo) {
-         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm);
-         x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-         wv_sync();
-         FOR_LANES(j, N) X[j] = Yg[j];
-         wv_sync();
-         r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b / 2, B, lb2, LM, lbo2, Q31ONE, lowband_scratch, y_cm);
-         y_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+      if (dual_stereo || Y == 0) {
+         /* one channel (mono), or the two of a dual-stereo band one after the other through Xb with half the budget each (bands.c:1831-1841) -- one quant_band site for both */
+         const int nc = dual_stereo ? 2 : 1;
+#pragma nounroll
+         for (int c = 0; c < nc; c++) {
+            if (c == 1) { wv_sync(); FOR_LANES(j, N) X[j] = Yg[j]; wv_sync(); }
+            r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, dual_stereo ? b / 2 : b, B, c ? lb2 : lb, LM, c ? lbo2 : lbo, Q31ONE, lowband_scratch,
+                  dual_stereo ? (c ? y_cm : x_cm) : (x_cm | y_cm));
+            if (c == 0) x_cm = (unsigned)wv_uni(r[0]); else y_cm = (unsigned)wv_uni(r[0]);
+            remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+         }
+         if (!dual_stereo) y_cm = x_cm;
       } else {
-         if (Y != 0) {
-            if (theta_rdo && i < intensity) {
-               i32 dist0, dist1, rem1;
-               u32 seed1;
-               unsigned cm, cm2;
-               i16 w[2];
-               compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
-               cm = x_cm | y_cm;
-               K_TIC();
-               wv_sync();
-               LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
-               wv_sync();                                                   /* (the untouched band is the spectrum in HBM: nothing to save) */
-               cfg.theta_round = -1;
-               K_TOC(21);
-               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
-               cm2 = (unsigned)wv_uni(r[0]); rem1 = wv_uni(r[1]); seed1 = (u32)wv_uni(r[2]);
-               K_TOC(24);
+         /* joint stereo; with the theta RDO (bands.c:1842-1912) the band is coded twice -- theta rounded down, then up -- and the trial with the smaller weighted distortion
+          * stays.  One quant_band_stereo site serves the two trials and the band without RDO (theta_round 0) */
+         const int rdo = theta_rdo && i < intensity;
+         i32 dist0 = 0, dist1, rem1 = 0;
+         u32 seed1 = 0;
+         unsigned cm2 = 0;
+         const unsigned cm = x_cm | y_cm;
+         const i32 rem0 = remaining_bits; const u32 seed0 = seed;             /* both trials start from the same budget and the same noise seed */
+         i16 w[2] = {0, 0};
+         int nstart_bytes = 0, save_bytes = 0;
+         WV_LDS u8 *bytes_buf = L->packet + 1;
+         if (rdo) {
+            compute_channel_weights(L->bandE[i], L->bandE[i + NBE], w);
+            K_TIC();
+            wv_sync();
+            LANE0 ec_cp_lds(&L->ecsave[0], &L->ec);
+            wv_sync();                                                   /* (the untouched band is the spectrum in HBM: nothing to save) */
+            K_TOC(21);
+         }
+#pragma nounroll
+         for (int tr = 0; tr < 1 + rdo; tr++) {
+            K_TIC();
+            if (tr == 1) {
                wv_sync();
                dist0 = mult16_32_q15(w[0], inner_prod_norm_shift_gw(Xg, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_gw(Yg, Y, N));
+               cm2 = x_cm; rem1 = remaining_bits; seed1 = seed;
                LANE0 ec_cp_lds(&L->ecsave[1], &L->ec);
                FOR_LANES(j, N) { X_save2[j] = X[j]; Y_save2[j] = Y[j]; if (!last) norm_save2[j] = lbo[j]; }
-               const int nstart_bytes = L->ecsave[0].offs, nend_bytes = L->ecsave[0].storage;
-               WV_LDS u8 *bytes_buf = L->packet + 1 + nstart_bytes;
-               const int save_bytes = nend_bytes - nstart_bytes;
+               nstart_bytes = L->ecsave[0].offs;
+               bytes_buf = L->packet + 1 + nstart_bytes;
+               save_bytes = (int)L->ecsave[0].storage - nstart_bytes;
                FOR_LANES(j, save_bytes) journal[j] = bytes_buf[j];         /* trial-1 byte journal -> per-stream HBM scratch */
                wv_sync();
                LANE0 ec_cp_lds(&L->ec, &L->ecsave[0]);
                FOR_LANES(j, N) { X[j] = Xg[j]; Y[j] = Yg[j]; }
                wv_sync();
                if (i == start + 1) { FOR_LANES(j, hf_n2 - hf_n1) norm[hf_n1 + j] = norm[2 * hf_n1 - hf_n2 + j]; wv_sync(); }      /* (theta RDO runs without dual stereo) */
-               cfg.theta_round = 1;
+               remaining_bits = rem0; seed = seed0;
                K_TOC(21);
-               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
-               x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
-               K_TOC(24);
-               wv_sync();
-               dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_gw(Xg, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_gw(Yg, Y, N));
-               if (dist0 >= dist1) {
-                  x_cm = cm2; remaining_bits = rem1; seed = seed1;
-                  wv_sync();
-                  LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
-                  FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = Y_save2[j]; if (!last) lbo[j] = norm_save2[j]; }
-                  FOR_LANES(j, save_bytes) bytes_buf[j] = journal[j];
-                  wv_sync();
-               }
-               K_TOC(21);
-            } else {
-               cfg.theta_round = 0;
-               r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, x_cm | y_cm);
-               x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
             }
-         } else {
-            r = quant_band_wave(L, cfg, remaining_bits, seed, X, N, b, B, lb, LM, lbo, Q31ONE, lowband_scratch, x_cm | y_cm);
+            cfg.theta_round = rdo ? 2 * tr - 1 : 0;
+            r = quant_band_stereo_wave(L, cfg, remaining_bits, seed, X, Y, N, b, B, lb, LM, lbo, lowband_scratch, cm);
             x_cm = (unsigned)wv_uni(r[0]); remaining_bits = wv_uni(r[1]); seed = (u32)wv_uni(r[2]);
+            K_TOC(24);
+         }
+         if (rdo) {
+            K_TIC();
+            wv_sync();
+            dist1 = mult16_32_q15(w[0], inner_prod_norm_shift_gw(Xg, X, N)) + mult16_32_q15(w[1], inner_prod_norm_shift_gw(Yg, Y, N));
+            if (dist0 >= dist1) {
+               x_cm = cm2; remaining_bits = rem1; seed = seed1;
+               wv_sync();
+               LANE0 ec_cp_lds(&L->ec, &L->ecsave[1]);
+               FOR_LANES(j, N) { X[j] = X_save2[j]; Y[j] = Y_save2[j]; if (!last) lbo[j] = norm_save2[j]; }
+               FOR_LANES(j, save_bytes) bytes_buf[j] = journal[j];
+               wv_sync();
+            }
+            K_TOC(21);
          }
          y_cm = x_cm;
       }

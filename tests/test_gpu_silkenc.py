@@ -5,6 +5,7 @@ import ctypes, numpy as np, pytest
 from reflib import ref_fx
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")]
+PIPELINE = -1     # OPUS_AMD_SET_KERNEL_PIPELINE of the batches under test (include/opus_amd.h): tests/test_gpu_pipeline.py runs this module's matrix again with 1 = front / quantiser / back kernels
 REQ = dict(bitrate=4002, vbr=4006, vbr_constraint=4020, complexity=4010, force_channels=4022, bandwidth=4008, max_bandwidth=4004, force_mode=11002, signal=4024, dtx=4016, fec=4012, loss=4014)
 
 def speech(fs, secs, ch, seed):
@@ -37,6 +38,7 @@ class RefOpusEnc:
 def check(S, frames, Fs=16000, ch=1, app=2048, ms=20, max_bytes=1276, shape=None, **ctl):
     import opus_amd as oa
     b = oa.EncoderBatch(S, channels=ch, application=app, Fs=Fs)
+    b.ctl(11902, PIPELINE)
     for k, v in ctl.items(): b.ctl(REQ[k], v)
     refs = [RefOpusEnc(Fs, ch, app, **ctl) for _ in range(S)]
     n = int(Fs * ms) // 1000
