@@ -10,6 +10,8 @@ for step in "$@"; do
 case $step in
 pipeline) timeout 1500 python -m pytest tests/test_gpu_pipeline.py -q -n 4 --timeout 900 > $O/pytest_pipeline.log 2>&1 ;;
 icache2|icache3|icache4) c=${step#icache}; for v in ${EXP_LIBS:-libopus_amd.so}; do (cd /tmp && rm -rf /tmp/ic_$c && OPUS_AMD_LIB=$OLDPWD/opus_amd/$v timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-include-regex "oa_" -f csv -d /tmp/ic_$c -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs --streams 16384 --config $c > /dev/null 2>&1; find /tmp/ic_$c -name '*counter_collection.csv' -exec cp {} $OLDPWD/$O/icache${c}_$v.csv \;); python tools/pmc_rows.py $O/icache${c}_$v.csv > $O/icache${c}_$v.log 2>&1; done ;;
+pcs2|pcs3|pcs4) c=${step#pcs}; M=${PCS_METHOD:-stochastic}; if [ $M = stochastic ]; then PU="--pc-sampling-unit cycles --pc-sampling-interval ${PCS_INTERVAL:-1048576}"; else PU="--pc-sampling-unit time --pc-sampling-interval ${PCS_INTERVAL:-100}"; fi
+  (cd /tmp && rm -rf /tmp/pcs_$c && ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1 timeout 200 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method $M $PU -f csv -d /tmp/pcs_$c -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs --streams ${PCS_STREAMS:-16384} --config $c > $OLDPWD/$O/pcs${c}_$M.log 2>&1; ls -laR /tmp/pcs_$c >> $OLDPWD/$O/pcs${c}_$M.log; for f in $(find /tmp/pcs_$c -name '*.csv'); do python $OLDPWD/tools/pcs_hist.py $f > $OLDPWD/$O/pcs${c}_${M}_$(basename $f).hist 2>&1; done) ;;
 phases2) OPUS_AMD_PROF_PREBUILT=1 timeout 200 python tools/phase_profile.py 16384 > $O/phases_config2.txt 2>&1 ;;
 smoke) python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 ;;
 split_check) timeout 900 python tools/split_check.py gpu > $O/split_check.log 2>&1 ;;
