@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 NO_ANALYSIS = False      # --no-analysis
 CORPUS = "reference"     # 48 kHz configurations: the reference's generate_music() tunes (SURVEY.md 8d names them first); --corpus pool: this repo's music / noise-burst pool
 CPU_STREAMS = 64         # streams of the GPU batch the CPU legs (baseline, parity sample) run
+GATHER = "rccl"          # --gather
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
@@ -42,29 +43,39 @@ def reference_music(nsamp, seeds, starts=None):
     j is a function of the sample index alone (it steps at every i % 6 == 0 from 2880 on), so a tune can be entered anywhere -- filters and dither restart there (their memory
     is a few dozen samples) -- and a pool of tunes covers the whole piece instead of its first quarter second.  starts = 2880 reproduces the C function bit for bit."""
     n = len(seeds)
-    Rz = np.array(seeds, np.uint64) & 0xffffffff; Rw = Rz.copy()
-    Rz[Rz == 0] = 1; Rw[Rw == 0] = 1
-    out = np.zeros((n, nsamp, 2), np.int16)
-    z = np.zeros(n, np.int64)
-    a1, b1, a2, b2, c1, c2, d1, d2 = (z.copy() for _ in range(8))
-    M = np.uint64(0xffffffff); m16 = np.uint64(65535); s16 = np.uint64(16)
-    def rnd():
-        nonlocal Rz, Rw
-        Rz = (np.uint64(36969) * (Rz & m16) + (Rz >> s16)) & M; Rw = (np.uint64(18000) * (Rw & m16) + (Rw >> s16)) & M
-        r = ((Rz << s16) + Rw) & M
-        return (r & m16).astype(np.int64) - (r >> s16).astype(np.int64)
+    z0 = np.array(seeds, np.uint64) & np.uint64(0xffffffff); z0[z0 == 0] = 1
     i0 = np.full(n, 2880, np.int64) if starts is None else np.asarray(starts, np.int64)
-    j = (i0 + 5) // 6 - 480                                                         # increments before sample i0: the multiples of 6 in [2880, i0)
-    for k in range(nsamp):
+    # fast_rand()'s two multiply-with-carry generators, all 2 * nsamp draws of every tune at once: z' = a (z & 65535) + (z >> 16) is z' = z * 65536^-1 mod (65536 a - 1)
+    # (z' * 65536 = z + (z & 65535)(65536 a - 1)), so draw t is z0 * 65536^-t mod m -- a table of powers, no loop over time
+    def mwc(a_):
+        m = a_ * 65536 - 1; binv = pow(65536, -1, m); C = 4096; Q = (2 * nsamp + C) // C + 1
+        def powers(base, cnt):
+            o = np.ones(cnt, np.uint64); k = 1
+            while k < cnt:
+                o[k:2 * k] = (o[:min(k, cnt - k)] * np.uint64(pow(base, k, m))) % np.uint64(m); k *= 2
+            return o
+        pw = ((powers(pow(binv, C, m), Q)[:, None] * powers(binv, C)[None, :]) % np.uint64(m)).reshape(-1)[1:2 * nsamp + 1]
+        return lambda zz: (zz[:, None] * pw[None, :]) % np.uint64(m)
+    draw_z, draw_w = mwc(36969), mwc(18000)
+    k = np.arange(nsamp, dtype=np.int64)
+    U = np.empty((nsamp, n, 2), np.int32)                                            # v - a, a = the previous v (0 before the first sample), of every tune
+    for p0 in range(0, n, 8):                                                        # (8 tunes at a time: the draw tables are [tunes, 2 * nsamp] uint64)
+        sl = slice(p0, min(n, p0 + 8))
+        r = ((draw_z(z0[sl]) << np.uint64(16)) + draw_w(z0[sl])) & np.uint64(0xffffffff)
+        dith = (r & np.uint64(65535)).astype(np.int64) - (r >> np.uint64(16)).astype(np.int64)              # [q, 2 * nsamp]: v1's and v2's dither, interleaved
+        j = ((i0[sl] + 5) // 6 - 480)[:, None] + ((i0[sl][:, None] + k[None, :] + 5) // 6 - ((i0[sl] + 5) // 6)[:, None])   # the melody counter at every sample (it steps after each i % 6 == 0)
         v = (((j * ((j >> 12) ^ ((j >> 10 | j >> 12) & 26 & j >> 7))) & 128) + 128) << 15
-        v1 = v + rnd(); v2 = v + rnd()
-        b1 = v1 - a1 + ((b1 * 61 + 32) >> 6); a1 = v1
-        b2 = v2 - a2 + ((b2 * 61 + 32) >> 6); a2 = v2
-        c1 = (30 * (c1 + b1 + d1) + 32) >> 6; d1 = b1
-        c2 = (30 * (c2 + b2 + d2) + 32) >> 6; d2 = b2
-        out[:, k, 0] = np.clip((c1 + 128) >> 8, -32768, 32767); out[:, k, 1] = np.clip((c2 + 128) >> 8, -32768, 32767)
-        j = j + ((i0 + k) % 6 == 0)
-    return out
+        vv = np.stack([v + dith[:, 0::2], v + dith[:, 1::2]], 2)                    # [q, nsamp, 2]
+        vv[:, 1:] -= vv[:, :-1].copy()
+        U[:, sl] = vv.transpose(1, 0, 2)
+    # the two rounding one-pole filters are the only serial part: one pass over time for all tunes and both channels
+    bb = np.zeros((n, 2), np.int64); cc = np.zeros((n, 2), np.int64); res = np.empty((nsamp, n, 2), np.int32)
+    for t in range(nsamp):
+        bn = U[t] + ((bb * 61 + 32) >> 6)
+        cc = (30 * (cc + bn + bb) + 32) >> 6
+        bb = bn
+        res[t] = cc
+    return np.clip((res.astype(np.int64) + 128) >> 8, -32768, 32767).astype(np.int16).transpose(1, 0, 2).copy()
 
 def synth(cfg, T, n_pool, rank, corpus="pool"):
     """pool of distinct signals [n_pool, (T+2)*frame*ch] int16 at the config's rate"""
@@ -111,50 +122,57 @@ def _ref_lib(path):
     return L
 
 def _cpu_worker(args):
-    """One worker of a CPU leg.  kind "enc": pcm [n_streams, T, frame*ch] int16, every stream through a fresh encoder, its T frames in order; kind "dec": (packets
-    [T, n_streams, stride] uint8, lens [T, n_streams]) through a fresh decoder per stream.  The streams are cycled (fresh state each time) until `seconds` have passed;
-    returns frames/s of this worker."""
-    path, cfg, data, seconds, pin, kind = args
+    """One worker of a CPU leg: ONE codec state, created and destroyed outside the clock, living through consecutive frames (>= 3,000 of them) -- the sample's
+    frames in order (stream 0's frames, then stream 1's, ...: the encoder meets the joins as it would meet any cut in its input), the whole sample again when it runs out, until
+    at least `min_frames` frames and `seconds` have passed.  kind "enc": pcm [n_streams, T, frame*ch] int16; kind "dec": (packets [T, n_streams, stride] uint8, lens [T, n_streams]).
+    Returns (frames/s of this worker, frames it processed)."""
+    path, cfg, data, seconds, pin, kind, min_frames = args
     if pin is not None:
         try: os.sched_setaffinity(0, {pin})
         except Exception: pass
     L = _ref_lib(path)
     err = ctypes.c_int()
     fr = cfg["Fs"] // 50
-    n = 0; t0 = time.perf_counter(); done = False
+    n = 0; done = False
     if kind == "enc":
         pcm = data; ns, T = pcm.shape[0], pcm.shape[1]
         out = (ctypes.c_ubyte * 1500)()
+        st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
+        for req, v in cfg["ctls"]: L.opus_encoder_ctl(st, req, v)
+        ptrs = [pcm[s_, i].ctypes.data for s_ in range(ns) for i in range(T)]
+        t0 = time.perf_counter()
         while not done:
-            for s in range(ns):
-                st = L.opus_encoder_create(cfg["Fs"], cfg["ch"], cfg["app"], ctypes.byref(err))
-                for req, v in cfg["ctls"]: L.opus_encoder_ctl(st, req, v)
-                base = pcm[s].ctypes.data; stride = pcm.strides[1]
-                for i in range(T): L.opus_encode(st, base + i * stride, fr, out, 1276)
-                L.opus_encoder_destroy(st); n += T
-                if time.perf_counter() - t0 > seconds: done = True; break
+            for p_ in ptrs: L.opus_encode(st, p_, fr, out, 1276)
+            n += len(ptrs)
+            done = n >= min_frames and time.perf_counter() - t0 > seconds
+        dt = time.perf_counter() - t0
+        L.opus_encoder_destroy(st)
     else:
         pk, lens = data; T, ns = lens.shape
         pcm = (ctypes.c_int16 * (fr * cfg["ch"]))()
+        st = L.opus_decoder_create(cfg["Fs"], cfg["ch"], ctypes.byref(err))
+        items = [(pk[i, s_].ctypes.data, int(lens[i, s_])) for s_ in range(ns) for i in range(T)]
+        t0 = time.perf_counter()
         while not done:
-            for s in range(ns):
-                st = L.opus_decoder_create(cfg["Fs"], cfg["ch"], ctypes.byref(err))
-                for i in range(T): L.opus_decode(st, pk[i, s].ctypes.data, int(lens[i, s]), pcm, fr, 0)
-                L.opus_decoder_destroy(st); n += T
-                if time.perf_counter() - t0 > seconds: done = True; break
-    return n / (time.perf_counter() - t0)
+            for p_, l_ in items: L.opus_decode(st, p_, l_, pcm, fr, 0)
+            n += len(items)
+            done = n >= min_frames and time.perf_counter() - t0 > seconds
+        dt = time.perf_counter() - t0
+        L.opus_decoder_destroy(st)
+    return n / dt, n
 
+CPU_MIN_FRAMES = 3000    # consecutive frames a CPU leg's codec state lives through at least (SURVEY.md 8d)
 def cpu_baseline(cfg, data, seconds=10.0, all_cores_seconds=4.0, kind="enc"):
     """Reference libopus (default float build, RTCD/AVX2) on ONE pinned host core over a sample of the GPU batch copied back from the device: the first CPU_STREAMS
-    streams, every frame the GPU batch saw of them (warm-up + timed steps), a fresh codec state per stream exactly as the GPU batch starts them; then one worker per
-    host core for the all-cores figure."""
+    streams, every frame the GPU batch saw of them, through ONE codec state that lives through >= CPU_MIN_FRAMES consecutive frames (create / destroy outside the clock);
+    then one worker per host core for the all-cores figure.  The strings that describe the legs are the same for every leg: NOTES (printed once, under "notes")."""
     path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fl.so")
     model, ncpu = host_info()
     if not os.path.exists(path):
-        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libopus_ref_fl.so did not travel", "host_nproc": ncpu, "cpu_model": model}
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref/libopus_ref_fl.so did not travel"}
     try: cpus = sorted(os.sched_getaffinity(0)); first = cpus[0]
     except Exception: cpus = list(range(ncpu)); first = None
-    one = _cpu_worker((path, cfg, data, seconds, first, kind))
+    one, nfr = _cpu_worker((path, cfg, data, seconds, first, kind, CPU_MIN_FRAMES))
     try: os.sched_setaffinity(0, set(cpus))                                 # the single-core leg pinned this process: undo before spawning the pool
     except Exception: pass
     allc = None
@@ -162,25 +180,22 @@ def cpu_baseline(cfg, data, seconds=10.0, all_cores_seconds=4.0, kind="enc"):
         try:
             import multiprocessing as mp
             with mp.get_context("spawn").Pool(len(cpus)) as pool:            # (never fork a process that holds a HIP context)
-                allc = float(sum(pool.map(_cpu_worker, [(path, cfg, data, all_cores_seconds, c, kind) for c in cpus])))
+                allc = float(sum(r[0] for r in pool.map(_cpu_worker, [(path, cfg, data, all_cores_seconds, c, kind, 0) for c in cpus])))
         except Exception:
             allc = None
     same = None                                                              # the library the GPU path is bit-exact to: fixed-point arithmetic (+ the float analysis unless --no-analysis)
     try:
         fx = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so" if NO_ANALYSIS else "oracle/_ref/libopus_ref_fxa.so")
-        if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, data, min(4.0, seconds), first, kind))), 1)
+        if os.path.exists(fx): same = round(float(_cpu_worker((fx, cfg, data, min(4.0, seconds), first, kind, CPU_MIN_FRAMES))[0]), 1)
         try: os.sched_setaffinity(0, set(cpus))
         except Exception: pass
     except Exception:
         same = None
     if kind == "enc": ns, T = data.shape[0], data.shape[1]
     else: T, ns = data[1].shape
-    return {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": "streams 0..%d of the GPU batch, their %d frames each (%d distinct frames copied back from the device; a fresh %s per stream, cycled), same settings, %.0f s, 1 thread pinned; libopus float build with RTCD"
-                      % (ns - 1, T, ns * T, "encoder" if kind == "enc" else "decoder", seconds),
-            "host_nproc": ncpu, "cpu_model": model, "all_cores_value": None if allc is None else round(allc, 1), "all_cores": len(cpus) if allc is not None else None,
-            "same_work_value": same, "same_work_note": ("one pinned core of the reference's FIXED_POINT + DISABLE_FLOAT_API build" if NO_ANALYSIS else "one pinned core of the reference's FIXED_POINT build with the float API (fixed-point codec + the float tonality analysis)") +
-                              ": the arithmetic and the decisions the GPU reproduces bit for bit (`value` is the float build with SIMD dispatch, the fastest way to run the reference on this host)"}
+    r = {"value": round(one, 1), "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "cpu_sample", "frames": int(nfr), "distinct_frames": int(ns * T), "same_work_value": same}
+    if allc is not None: r["all_cores_value"] = round(allc, 1); r["all_cores"] = len(cpus)
+    return r
 
 def parity_sample(cfg, pcm, gpu_packets, gpu_lens, gpu_rng, gpu_dec=None):
     """After the timed region: the first CPU_STREAMS streams once more through the compiled reference the GPU path is bit-exact to (libopus_ref_fxa.so: fixed point + float
@@ -211,6 +226,59 @@ def parity_sample(cfg, pcm, gpu_packets, gpu_lens, gpu_rng, gpu_dec=None):
         if dc is not None: L.opus_decoder_destroy(dc)
     return {"ok": bad == 0, "streams": ns, "frames": ns * T, "mismatches": bad, "checker": os.path.basename(path),
             "what": "packets + final ranges" + (" + decoded PCM" if gpu_dec is not None else "") + " of every frame of the sampled streams, GPU batch vs the compiled reference, after the timed region"}
+
+def _ref_ms_encoder(L, NS, app):
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.opus_multistream_encoder_create.restype = vp; L.opus_multistream_encoder_create.argtypes = [ctypes.c_int32, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    L.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ctypes.c_int32]
+    L.opus_multistream_encoder_destroy.argtypes = [vp]; L.opus_multistream_encoder_destroy.restype = None
+    err = ci()
+    st = L.opus_multistream_encoder_create(48000, NS, NS, 0, bytes(range(NS)), app, ctypes.byref(err))
+    if not st or err.value: raise RuntimeError("opus_multistream_encoder_create (reference): %d" % err.value)
+    L.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]
+    for req, v in ((4002, NS * 64000), (4010, 10)): assert L.opus_multistream_encoder_ctl(st, req, v) == 0
+    return st
+
+def parity_sample_ms(cfg, pcm, gpu_packets, gpu_lens, gpu_rng, NS, max_bytes):
+    """config 5 after the timed region: the first encoders of the batch once more through the compiled reference's opus_multistream_encode (255 mono streams, the same
+    settings), every frame in order, every multistream packet and final range (the XOR over the streams) compared.  pcm [T][nb][frame][NS] int16."""
+    path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fx.so" if NO_ANALYSIS else "oracle/_ref/libopus_ref_fxa.so")
+    if not os.path.exists(path): return None
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    T, nb = pcm.shape[0], pcm.shape[1]; fr = pcm.shape[2]
+    out = (ctypes.c_ubyte * (max_bytes + 16))(); bad = 0; rv = ctypes.c_uint32()
+    for b_ in range(nb):
+        st = _ref_ms_encoder(L, NS, cfg["app"])
+        for t in range(T):
+            x = np.ascontiguousarray(pcm[t, b_])
+            n = L.opus_multistream_encode(st, x.ctypes.data, fr, out, max_bytes)
+            L.opus_multistream_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]; L.opus_multistream_encoder_ctl(st, 4031, ctypes.byref(rv)); L.opus_multistream_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            ok = n == int(gpu_lens[t, b_]) and rv.value == int(gpu_rng[t, b_]) & 0xffffffff and bytes(out[:max(n, 0)]) == gpu_packets[t, b_, :max(n, 0)].tobytes()
+            bad += 0 if ok else 1
+        L.opus_multistream_encoder_destroy(st)
+    return {"ok": bad == 0, "streams": nb * NS, "frames": nb * NS * T, "mismatches": bad, "checker": os.path.basename(path)}
+
+def cpu_baseline_ms(cfg, pcm, NS, max_bytes, seconds=3.0):
+    """one pinned core of the reference (float build) running opus_multistream_encode on the first encoder's frames, cycled (one encoder object, created outside the clock);
+    elementary-stream frames/s"""
+    path = os.path.join(ROOT, "oracle/_ref/libopus_ref_fl.so")
+    if not os.path.exists(path): return None
+    try: cpus = sorted(os.sched_getaffinity(0)); os.sched_setaffinity(0, {cpus[0]})
+    except Exception: cpus = None
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    st = _ref_ms_encoder(L, NS, cfg["app"])
+    T, fr = pcm.shape[0], pcm.shape[1]
+    xs = [np.ascontiguousarray(pcm[t]) for t in range(T)]; out = (ctypes.c_ubyte * (max_bytes + 16))()
+    n = 0; t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for x in xs: L.opus_multistream_encode(st, x.ctypes.data, fr, out, max_bytes)
+        n += T
+    dt = time.perf_counter() - t0
+    L.opus_multistream_encoder_destroy(st)
+    if cpus:
+        try: os.sched_setaffinity(0, set(cpus))
+        except Exception: pass
+    return {"value": round(n * NS / dt, 1), "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "cpu_sample_ms", "frames": int(n * NS), "distinct_frames": int(T * NS)}
 
 def copy_bandwidth(dev):
     """device-to-device copy, GB/s of traffic (read + write)"""
@@ -264,6 +332,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         msb = L.opusgpu_ms_enc_batch_create(Bn, Fs, NS, 255, NS, 0, bytes(range(NS)), cfg["app"], local, ctypes.byref(err))
         if not msb: raise RuntimeError("opusgpu_ms_enc_batch_create failed: %d" % err.value)
         assert L.opusgpu_ms_enc_batch_ctl(msb, 4002, NS * 64000) == 0 and L.opusgpu_ms_enc_batch_ctl(msb, 4010, 10) == 0
+        assert L.opusgpu_ms_enc_batch_ctl(msb, opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1) == 0
         pcm = pcm[:, :S].reshape(T, Bn, NS, FR).permute(0, 1, 3, 2).contiguous()            # [T][B][frame][channels] interleaved, as opus_multistream_encode takes it
         STRIDE = 65536; MS_MAX = (NS - 1) * 1279 + 7662 + 3 * NS + 8
         NP = Bn                                                                              # packets per step
@@ -280,14 +349,15 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)        # default: like the reference's default build (analysis.c + mlp.c at complexity 10)
     # every step's packets stay on the device (the decoder leg and the parity sample read them): [TE][NP][STRIDE]
     pk = torch.zeros((TE, NP, STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((TE, NP), dtype=torch.int32, device=dev); rng = torch.zeros((TE, NP), dtype=torch.int32, device=dev)
-    # wire record of the final gather: capacity per stream from the bitrate bound (twice the nominal packet + 64: the aggregate of a shard stays far below it; an overflow is reported)
-    nominal = {2: 128000, 3: 24000, 4: 128000, 5: 255 * 64000}[cid] // 400
-    gather = gather_cls(NP * world, STRIDE, dev, dst=0, cap_per_stream=min(STRIDE, 2 * nominal + 64 * (255 if cid == 5 else 1))) if (world > 1 and gather_cls and gather_on) else None
+    # wire record of the final gather: its capacity per stream follows from the encoder settings (PacketGather.wire_capacity: the bitrate bound of these VBR streams; an overflow is reported)
+    gather = None; gather_err = None
+    if world > 1 and gather_cls and gather_on:
+        try: gather = gather_cls(NP * world, STRIDE, dev, dst=0, bitrate_bps={2: 128000, 3: 24000, 4: 128000, 5: 255 * 64000}[cid], frame_rate=50, cbr=False, sub_streams=255 if cid == 5 else 1, transport=GATHER)
+        except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e)
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
 
-    gather_err = None
     for t in range(W):
         step(t)
         if gather is not None:
@@ -324,7 +394,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     L.opusgpu_enc_moved_state_bytes.restype = ctypes.c_int
     state_moved = L.opusgpu_enc_moved_state_bytes(cfg["app"], CH, 1 if cid == 4 else 0)          # state bytes read + written per frame-step
     L.opusgpu_enc_analysis_moved_bytes.restype = ctypes.c_int
-    analysis_on = (not NO_ANALYSIS) and cid != 5 and Fs >= 16000 and cfg["app"] != opus_amd.OPUS_APPLICATION_RESTRICTED_SILK and any(req == 4010 and v >= 10 for req, v in cfg["ctls"])
+    analysis_on = (not NO_ANALYSIS) and Fs >= 16000 and cfg["app"] != opus_amd.OPUS_APPLICATION_RESTRICTED_SILK and any(req == 4010 and v >= 10 for req, v in cfg["ctls"])
     if analysis_on: state_moved += L.opusgpu_enc_analysis_moved_bytes()                       # the tonality analysis' own state (phase history, 30 ms input window, band energies, info ring)
     alg = FR * CH * 2 + mean_len + 8 + state_moved
     res = {"config_id": cid, "leg": "encode", "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
@@ -338,6 +408,11 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         pk_h = pk[:, :NC].cpu().numpy(); lens_c = lens[:, :NC].cpu().numpy(); rng_c = rng[:, :NC].cpu().numpy()
         res["pcm_sample"] = pcm_h
         res["parity_sample"] = parity_sample(cfg, pcm_h, pk_h, lens_c, rng_c)
+    if with_cpu and cid == 5:
+        nb = min(2, Bn)
+        ms_pcm = np.ascontiguousarray(pcm[:TE, :nb].cpu().numpy())                          # [TE][nb][FR][NS]
+        res["parity_sample"] = parity_sample_ms(cfg, ms_pcm, pk[:, :nb].cpu().numpy(), lens[:, :nb].cpu().numpy(), rng[:, :nb].cpu().numpy(), NS, MS_MAX)
+        res["ms_sample"] = (ms_pcm[:, 0], NS, MS_MAX)
     if frames_per_launch and world == 1 and cid == 2:
         # T consecutive frame-steps of every stream in ONE launch (the wave keeps its stream for T frames): SURVEY 8d "report also T = 50 consecutive steps"; a fresh batch
         Tn = min(frames_per_launch, T)
@@ -399,6 +474,67 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     torch.cuda.empty_cache()
     return results
 
+def steady_state_leg(cid, dev, local, K, S_full=65536, S1=1024, T1=500, with_cpu=True):
+    """Steady state next to the cold-start figure: S1 streams live through T1 CONSECUTIVE frames (10 s of audio each, state on the device) -- VBR reservoir,
+    prefilter and energy memories, the analysis' history all filled -- timed per step at the head and at the tail of the run; four of the streams checked against the compiled
+    reference over all T1 frames; then the S1 warmed-up states are fanned out over S_full streams (opusgpu_enc_batch_copy_states, 64 replicas each) and K more steps are timed
+    at full width on the frames that follow: the throughput of a batch that has been running for ten seconds."""
+    import torch, opus_amd
+    cfg = CONFIGS[cid]; Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; P = 32; STRIDE = 1280
+    T = T1 + K
+    pool = torch.from_numpy(synth(cfg, T, P, 4242, corpus=CORPUS)).to(dev)                  # [P][(T+2)*FR*CH]: P tunes entered at evenly spread points of the piece
+    g = torch.Generator(device="cpu"); g.manual_seed(99)
+    pid = torch.randint(0, P, (S1,), generator=g).to(dev); off = (torch.randint(0, FR, (S1,), generator=g) * CH).to(dev); gain = (0.5 + 0.5 * torch.rand((S1,), generator=g)).to(dev)
+    ar = torch.arange(FR * CH, device=dev)
+    def frames(t):
+        x = pool[pid[:, None], off[:, None] + t * FR * CH + ar[None, :]].to(torch.float32) * gain[:, None]
+        return x.round().clamp(-32768, 32767).to(torch.int16)
+    stream = torch.cuda.current_stream(dev)
+    def make(S):
+        b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
+        for req, v in cfg["ctls"]: b.ctl(req, v)
+        b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)
+        return b
+    b1 = make(S1)
+    pk = torch.zeros((T1, S1, STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((T1, S1), dtype=torch.int32, device=dev); rng = torch.zeros((T1, S1), dtype=torch.int32, device=dev)
+    keep = torch.zeros((T1, 4, FR * CH), dtype=torch.int16, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(T1)]
+    for t in range(T1):
+        x = frames(t); keep[t] = x[:4]
+        ev[t][0].record(stream)
+        b1.encode_dev(x.data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
+        ev[t][1].record(stream)
+    torch.cuda.synchronize(dev)
+    ms = np.array([a.elapsed_time(b_) for a, b_ in ev]); ln = lens.cpu().numpy()
+    out = {"streams": S1, "consecutive_frames": T1, "ms_per_step_first_25": round(float(ms[:25].mean()), 3), "ms_per_step_last_25": round(float(ms[-25:].mean()), 3),
+           "mean_packet_bytes_first_25": round(float(ln[:25].mean()), 1), "mean_packet_bytes_last_25": round(float(ln[-25:].mean()), 1), "all_packets_valid": bool((ln > 0).all())}
+    if with_cpu:
+        ps = parity_sample(cfg, np.ascontiguousarray(keep.permute(1, 0, 2).cpu().numpy()), pk[:, :4].cpu().numpy(), ln[:, :4], rng[:, :4].cpu().numpy())
+        out["parity_sample_ok"] = None if ps is None else ps["ok"]; out["parity_frames"] = None if ps is None else ps["frames"]
+    # fan the warmed-up states out and time K steps at full width on the frames that follow
+    R = S_full // S1
+    b2 = make(S_full)
+    for r in range(R): b2.copy_states_from(b1, S1, dst_first=r * S1)
+    pk2 = torch.zeros((S_full, STRIDE), dtype=torch.uint8, device=dev); l2 = torch.zeros((K, S_full), dtype=torch.int32, device=dev); r2 = torch.zeros((S_full,), dtype=torch.int32, device=dev)
+    xs = [frames(T1 + k).repeat(R, 1) for k in range(K)]
+    torch.cuda.synchronize(dev)
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev2[k][0].record(stream)
+        b2.encode_dev(xs[k].data_ptr(), FR, pk2.data_ptr(), STRIDE, l2[k].data_ptr(), r2.data_ptr(), hip_stream=stream.cuda_stream)
+        ev2[k][1].record(stream)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    l2h = l2.cpu().numpy()
+    out["full_width"] = {"streams": S_full, "steps": K, "value": round(S_full * K / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / K * 1e3, 3),
+                         "kernel_ms": round(float(np.mean([a.elapsed_time(b_) for a, b_ in ev2])), 3), "mean_packet_bytes": round(float(l2h.mean()), 1), "all_packets_valid": bool((l2h > 0).all()),
+                         "replicas_agree": bool((l2h.reshape(K, R, S1) == l2h.reshape(K, R, S1)[:, :1]).all())}
+    b1.close(); b2.close()
+    del pool, pk, pk2, xs
+    torch.cuda.empty_cache()
+    return out
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,10 +548,12 @@ def main():
     ap.add_argument("--corpus", default="reference", choices=["pool", "reference"], help="input signals of the 48 kHz configurations: the reference's generate_music() tunes (tests/test_opus_encode.c:57; default) or this repo's music / noise-burst pool")
     ap.add_argument("--decode", action="store_true", help="time the decoder on the packets of the chosen configuration (encoded first) and report IT as the main line")
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the config 3 / 4 / 5 and decoder legs")
+    ap.add_argument("--steady-state", type=int, default=-1, help="also run the steady-state leg of the main configuration: 1,024 streams through this many consecutive frames, then a full-width batch of the warmed-up states (default 500 in the default run, 0 = off)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the final packet gather out (to time what it costs)")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "p2p"], help="N > 1: transport of the final packet gather: one RCCL gather collective per step (default), or every rank copying its record into rank 0's buffer through an IPC mapping (no collective; independent of ProcessGroupNCCL)")
     a = ap.parse_args()
-    global CORPUS, NO_ANALYSIS
-    CORPUS = a.corpus; NO_ANALYSIS = a.no_analysis
+    global CORPUS, NO_ANALYSIS, GATHER
+    CORPUS = a.corpus; NO_ANALYSIS = a.no_analysis; GATHER = a.gather
     import torch, torch.distributed as dist
     import opus_amd
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -456,64 +594,86 @@ def main():
         Kx = max(3, K // 2)
         for cid in (3, 4):
             extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on, decode=True)
-        extras += run_config(5, (a.streams // 255) * 255 if a.streams else 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=False)
+        extras += run_config(5, (a.streams // 255) * 255 if a.streams else 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
+    steady = None
+    ss_frames = a.steady_state if a.steady_state >= 0 else (500 if full else 0)
+    if ss_frames and world == 1 and a.config != 5 and not a.decode:
+        steady = steady_state_leg(a.config, dev, local, K, S_full=S if S % 1024 == 0 and S >= 1024 else 65536, T1=ss_frames, with_cpu=cpu_on)
     if rank == 0:
         peak_meas = round(copy_bandwidth(dev), 1) if world == 1 else None
         built = opus_amd.lib().opusgpu_build_info().decode()
         try: src_now = opus_amd.source_hash()
         except Exception: src_now = None
+        traffic_docs = []
+        for name in (["pmc_traffic_r02.json"] if NO_ANALYSIS else ["pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json"]):
+            try: traffic_docs.append((name, json.load(open(os.path.join(ROOT, "profiles", name)))))
+            except Exception: continue
+        used_traffic = set()
         def roof(r, Sn):
             ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
-            traffic = None; issue = None; tsrc = None
+            traffic = None; issue = None
             key = ("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]
-            for name in (["pmc_traffic_r02.json"] if NO_ANALYSIS else ["pmc_traffic_r04.json", "pmc_traffic_r03.json"]):
+            for name, doc in traffic_docs:
                 try:
-                    doc = json.load(open(os.path.join(ROOT, "profiles", name))); pt = doc[key]
+                    pt = doc[key]
                     if pt.get("hbm_bytes_per_frame"): traffic = int(pt["hbm_bytes_per_frame"] * Sn)
-                    issue = {"valu_busy_per_simd": pt["issue"].get("valu_busy_per_simd"), "active_lanes_per_valu_cycle": pt["lane_utilisation"]["active_lanes_per_valu_cycle"]}
-                    tsrc = "profiles/%s: %s" % (name, pt.get("source") or doc.get("source") or "rocprofv3 --pmc passes (separate runs, not this timed run)")
+                    issue = {"valu_busy": pt["issue"].get("valu_busy_per_simd"), "lanes": pt["lane_utilisation"]["active_lanes_per_valu_cycle"]}
+                    used_traffic.add(name)
                     break
                 except Exception: continue
-            return {"bound": "hbm", "issue": issue, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc, "peak_measured": peak_meas,
-                    "frac_of_measured": None if not peak_meas else round(ach / peak_meas, 5), "kernel": r["kernel"], "kernel_ms": round(r["kernel_ms"], 3),
-                    "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"],
-                    "note": "latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d); kernel_ms = HIP events around one call's launches on the launch stream, inside the timed region"}
+            o = {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "kernel_ms": round(r["kernel_ms"], 3),
+                 "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"]}
+            if issue: o["issue"] = issue
+            return o
         def cpu_leg(r, seconds, allc):
             if r["leg"] == "decode" and "dec_sample" in r: return cpu_baseline(CONFIGS[r["config_id"]], r["dec_sample"], seconds=seconds, all_cores_seconds=allc, kind="dec")
             if r["leg"] == "encode" and "pcm_sample" in r: return cpu_baseline(CONFIGS[r["config_id"]], r["pcm_sample"], seconds=seconds, all_cores_seconds=allc, kind="enc")
+            if r["leg"] == "encode" and "ms_sample" in r: return cpu_baseline_ms(CONFIGS[r["config_id"]], *r["ms_sample"], seconds=seconds)
             return None
         frames = main_res["streams_per_gpu"] * world * K
+        model, ncpu = host_info()
         res = {
             "metric": main_res["metric"] if (a.decode or a.config != 2) else "encoded frames/s (48 kHz stereo, 20 ms, complexity 10)", "value": round(frames / dt, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i32", "data": ("synthetic (the reference's generate_music(), tests/test_opus_encode.c:57: 256 seeds entering the 30 s piece at evenly spread points, per-stream phase and gain)" if (a.corpus == "reference" and CONFIGS[a.config]["Fs"] == 48000) else "synthetic"),
-            "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point" + (" (with the tonality / music analysis of the float API, as the reference's default build)" if main_res.get("float_analysis") else " (no float API: like a reference built with DISABLE_FLOAT_API)"), "baseline_config": a.config, "float_analysis": bool(main_res.get("float_analysis")),
+            "vs_baseline": None, "dtype": "i32", "data": ("synthetic: the reference's generate_music() (tests/test_opus_encode.c:57), 256 seeds entering the 30 s piece at spread points" if (a.corpus == "reference" and CONFIGS[a.config]["Fs"] == 48000) else "synthetic"),
+            "config": {"workload": ("DECODE of the packets of: " if a.decode else "") + CONFIGS[a.config]["name"] + ", bit-exact fixed-point" + (" + float-API tonality analysis (the reference's default build)" if main_res.get("float_analysis") else " (DISABLE_FLOAT_API)"), "baseline_config": a.config, "float_analysis": bool(main_res.get("float_analysis")),
                        "streams_per_gpu": main_res["streams_per_gpu"], "frames_per_step": main_res["streams_per_gpu"] * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),
                        "lib_build": built, "lib_matches_sources": None if src_now is None else built == "OA_SRC_HASH=" + src_now,
-                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else ", final RCCL gather of the compacted packets in the timed region (side stream, double-buffered)" if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
-            "roofline": roof(main_res, main_res["streams_per_gpu"]),
+                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else (", final gather of the compacted packets in the timed region (%s; side stream, double-buffered)" % a.gather) if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
+            "roofline": dict(roof(main_res, main_res["streams_per_gpu"]), kernel=main_res["kernel"], peak_measured=peak_meas),
         }
         if per_rank is not None: res["ranks_seen"] = len(per_rank); res["per_rank"] = per_rank
         if main_res.get("gather"): res["gather"] = main_res["gather"]
         if "frames_per_launch" in legs[0]: res["frames_per_launch"] = legs[0]["frames_per_launch"]
+        if steady: res["steady_state"] = steady
         c = cpu_leg(main_res, 10.0, 4.0) if cpu_on else None
         if c:
+            c["host_nproc"] = ncpu; c["cpu_model"] = model
             res["cpu_baseline"] = c
             if c["value"]: res["speedup_vs_cpu_1core"] = round(res["value"] / c["value"], 2)
         if extras:
             res["configs"] = {}
             for r in extras:
                 Kx = K if r["config_id"] == a.config else max(3, K // 2)
-                e = {"workload": ("DECODE of the packets of: " if r["leg"] == "decode" else "") + r["workload"], "metric": r["metric"], "value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
-                     "streams_per_gpu": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "all_packets_valid": r["all_packets_valid"], "parity_sample_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
+                e = {"value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
+                     "streams": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "valid": r["all_packets_valid"], "parity_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
                      "roofline": roof(r, r["streams_per_gpu"])}
                 if "dec_fast_kernel" in r: e["dec_fast_kernel"] = r["dec_fast_kernel"]
                 c = cpu_leg(r, 3.0, 0) if cpu_on else None
                 if c:
-                    e["cpu_baseline"] = c
-                    if c["value"]: e["speedup_vs_cpu_1core"] = round(e["value"] / c["value"], 2)
+                    e["cpu"] = {k_: c[k_] for k_ in ("value", "same_work_value", "frames") if k_ in c}
+                    if c["value"]: e["x_cpu_1core"] = round(e["value"] / c["value"], 1)
                 res["configs"][("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]] = e
+        # what every leg has in common, said once (the per-leg entries stay short: the driver keeps the last 8 KB of this line)
+        res["notes"] = {
+            "legs": "configs.<config_N | decode_N>: BASELINE.json configuration N (2: CELT-only 48 kHz stereo 128 kb/s; 3: SILK-only VOIP 16 kHz mono 24 kb/s; 4: hybrid AUDIO 48 kHz stereo 128 kb/s; 5: 257 multistream encoders x 255 mono AUDIO streams at 64 kb/s) at 20 ms, complexity 10, 65,536 streams; decode_N = the decoder on config N's packets; value = frames/s (config_5: elementary-stream frames/s), unit frames/s",
+            "roofline": "achieved = algorithmic bytes per frame x streams / kernel_ms (HIP events around one call's launches on the launch stream, inside the timed region) in GB/s; frac = achieved / 8000 GB/s; traffic = counted HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE passes, separate runs: profiles/%s); issue = VALU busy per SIMD and active lanes per VALU cycle from the same passes; latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)" % (", ".join(sorted(used_traffic)) or "none on this box"),
+            "cpu_sample": "cpu_baseline / cpu: libopus (float build, RTCD) on ONE pinned core of this host: one codec state, created outside the clock, through >= %d consecutive frames -- streams 0..%d of the GPU batch, all their frames in order, cycled; same_work_value = the FIXED_POINT build%s the GPU path is bit-exact to; frames = frames timed" % (CPU_MIN_FRAMES, CPU_STREAMS - 1, "" if NO_ANALYSIS else " with the float API (tonality analysis)"),
+            "cpu_sample_ms": "config_5: one pinned core running the reference's opus_multistream_encode on encoder 0's frames (255 elementary frames per call), cycled",
+            "parity": "parity_ok / parity_sample: after the timed region, streams 0..%d (config_5: encoders 0..1 = 510 streams) once more through the compiled reference the GPU path is bit-exact to; every packet and final range (decode legs: + the PCM) of every frame the batch produced compared" % (CPU_STREAMS - 1),
+            "steady_state": "1,024 streams through 500 consecutive frames (state on the device), HIP-event ms per step at the head and the tail, 4 streams x 500 frames against the reference; full_width = the 1,024 warmed-up states fanned out over 65,536 streams, `steps` more frames: throughput of a batch ten seconds into its streams (value above: every stream's first frames from a cold start)",
+        }
         print(json.dumps(res))
     if world > 1: dist.destroy_process_group()
 

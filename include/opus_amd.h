@@ -141,6 +141,14 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int1
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
 OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
+/* Both once more with the reference's look-ahead (src/opus_encoder.c:1247, :2662-2690; run_analysis, src/analysis.c:954): every stream's row of pcm (and apcm) holds
+ * analysis_frame_size >= frame_size samples per channel -- the buffer opus_encode() is handed when OPUS_SET_EXPERT_FRAME_DURATION selects a frame shorter than it -- of
+ * which the first frame_size are coded; the tonality / music analysis sees the whole row (the classic entry points of this library call these).  analysis_frame_size ==
+ * frame_size is exactly opusgpu_encode_batch_sig / _dev_sig. */
+OPUS_AMD_EXPORT int opusgpu_encode_batch_lookahead(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, int analysis_frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
+OPUS_AMD_EXPORT int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size,
+      unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
 /* Private set / get requests of this library (opus_encoder_ctl, opusgpu_enc_batch_ctl, opus_multistream_encoder_ctl): OPUS_AMD_SET_FLOAT_ANALYSIS(1) (the default) = run the
  * tonality / music analysis at complexity 10 like a FIXED_POINT libopus with its float API, the default build (src/opus_encoder.c:1249); (0) = like one built with
  * DISABLE_FLOAT_API.  The process-wide default for new encoders can be set with the environment variable OPUS_AMD_FLOAT_ANALYSIS=0. */
@@ -153,6 +161,10 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_
  * multistream encoder passes it to its elementary encoders.  The process-wide default behind -1 can be set with the environment variable OPUS_AMD_SH_SPLIT=0|1|2. */
 #define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
 #define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
+/* n stream records -- configuration and state as they stand on the device -- from batch `src` (from stream src_first on) into batch `dst` (from dst_first on), device to
+ * device; both batches of one shape (application kind, rate, channels) on one device, the ranges inside them and, within one batch, disjoint.  The calls on both batches
+ * issued so far are waited for. */
+OPUS_AMD_EXPORT int opusgpu_enc_batch_copy_states(OpusGpuEncBatch *dst, opus_int32 dst_first, OpusGpuEncBatch *src, opus_int32 src_first, opus_int32 n);
 OPUS_AMD_EXPORT int opusgpu_enc_batch_sync(OpusGpuEncBatch *b);
 /* `steps` back-to-back frame-steps on device buffers ([steps][S][frame*channels] PCM), timed with HIP events on the
  * launch stream; returns elapsed milliseconds in *ms (kernel time only, inputs resident). */

@@ -84,6 +84,10 @@ def lib():
         L.opusgpu_time_encode_dev.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, i32, vp]
         L.opusgpu_enc_batch_sync.argtypes = [vp]; L.opusgpu_enc_batch_reset.argtypes = [vp]
+        if hasattr(L, "opusgpu_enc_batch_copy_states"): L.opusgpu_enc_batch_copy_states.argtypes = [vp, i32, vp, i32, i32]
+        if hasattr(L, "opusgpu_encode_batch_lookahead"):
+            L.opusgpu_encode_batch_lookahead.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, i32, i32, vp, vp]
+            L.opusgpu_encode_batch_lookahead_dev.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, i32, i32, vp, vp, vp]
         L.opusgpu_pack_packets_dev.argtypes = [vp, i32, vp, vp, vp, i32, vp]
         L.opusgpu_pack_packets_cap_dev.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.c_longlong, vp]
         L.opusgpu_enc_moved_state_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -201,6 +205,10 @@ class EncoderBatch:
     def import_state(self, stream, blob):
         if len(blob) != self.state_size: raise ValueError("state blob of %d bytes, this batch's records are %d bytes" % (len(blob), self.state_size))
         r = self._L.opusgpu_enc_batch_import_state(self._b, stream, blob)
+        if r != OPUS_OK: raise OpusError(r)
+    def copy_states_from(self, src, n, dst_first=0, src_first=0):
+        """n stream records (configuration + state) of batch `src` into this one, device to device (opusgpu_enc_batch_copy_states)"""
+        r = self._L.opusgpu_enc_batch_copy_states(self._b, dst_first, src._b, src_first, n)
         if r != OPUS_OK: raise OpusError(r)
     def reset(self):
         r = self._L.opusgpu_enc_batch_reset(self._b)

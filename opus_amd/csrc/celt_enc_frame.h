@@ -540,7 +540,7 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
 }
 
 WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr)
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr, int analysis_frame_size = 0 /* samples per channel pcm (and apcm) hold: >= frame_size, the caller's look-ahead (:2662-2690); 0 = frame_size */)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -569,7 +569,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
    if (!(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
       if (float_api && wv_uni(gs->cfg.complexity) >= 10 && Fs >= 16000) {
          LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
-         an_run_analysis_wave((WV_LDS AnLds *)&L->BC, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(gs->cfg.input_depth) ? wv_uni(gs->cfg.input_depth) : 16, wv_uni(gs->cfg.lsb_depth)),
+         an_run_analysis_wave((WV_LDS AnLds *)&L->BC, &gs->an, pcm, apcm, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, frame_size, CC, Fs, imin(wv_uni(gs->cfg.input_depth) ? wv_uni(gs->cfg.input_depth) : 16, wv_uni(gs->cfg.lsb_depth)),
                (i32 *)L->g->X, &gs->an_info);
       } else {
          const int was_initialized = wv_uni(gs->an.initialized);

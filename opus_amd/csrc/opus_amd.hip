@@ -51,7 +51,8 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #define OA_ENC_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
-oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue)
+oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
+      int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
@@ -62,8 +63,8 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
       __syncthreads();
       OaStream *gs = streams + s;
       const int ch = gs->cfg.channels;
-      oa_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
-            apcm ? apcm + (size_t)s * frame_size * ch : nullptr);
+      oa_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row);
       __syncthreads();
    }
 }
@@ -130,7 +131,7 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
  * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave.  list != NULL: the calls the split path's front kernel turned away (their analysis has run) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue,
-      const int *list, const unsigned *list_count, int pkt_off)
+      const int *list, const unsigned *list_count, int pkt_off, int pcm_row)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -145,9 +146,9 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
       char *tail = scr + SH_SCRATCH_BYTES(frame_size, ch);
       if (threadIdx.x == 0) { L->silk_tail = 1; L->packet_off = pkt_off; L->S.st_off = (i32)offsetof(SilkEncLds, st); }
       __syncthreads();
-      oa_sh_encode_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
+      oa_sh_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, (i16 *)scr,
             (SeRateScratch *)(tail - sizeof(SeRateScratch)), (CeltScratch *)(tail - sizeof(SeRateScratch) - sizeof(CeltScratch)), lens + s, rngs + s,
-            apcm ? apcm + (size_t)s * frame_size * ch : nullptr, list != nullptr);
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, list != nullptr, pcm_row);
       __syncthreads();
    }
 }
@@ -156,7 +157,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 #define OA_SH_FRONT_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
-oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off)
+oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pcm_row)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -169,8 +170,8 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
       seen++;
       if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)SE_FRONT_ST_OFF; }
       __syncthreads();
-      oa_sh_front_frame(L, gs, pcm + (size_t)s * frame_size * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
-            apcm ? apcm + (size_t)s * frame_size * ch : nullptr, slow_list, counters + 4, s);
+      oa_sh_front_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row);
       __syncthreads();
       kept += conts[s].kind == SH_CONT_FAST;
    }
@@ -490,6 +491,27 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
    HIPCHECK(hipMemcpy(b->d_streams + stream, src, sizeof(OaStream), hipMemcpyHostToDevice));
    return OPUS_OK;
 }
+/* n stream records (configuration AND state, as they stand on the device) from one batch into another of the same shape, device to device: a service that moves streams
+ * between batches, or fans a warmed-up stream out (bench.py's steady-state leg) -- what export_state + import_state do per stream through host memory */
+int opusgpu_enc_batch_copy_states(OpusGpuEncBatch *dst, opus_int32 dst_first, OpusGpuEncBatch *src, opus_int32 src_first, opus_int32 n)
+{
+   if (!dst || !src || n < 0 || dst_first < 0 || src_first < 0 || dst_first + n > dst->S || src_first + n > src->S) return OPUS_BAD_ARG;
+   if (dst->kind != src->kind || dst->channels != src->channels || dst->Fs != src->Fs || dst->device != src->device) return OPUS_BAD_ARG;
+   if (dst == src && dst_first < src_first + n && src_first < dst_first + n && n > 0) return OPUS_BAD_ARG;                     /* overlapping ranges of one batch */
+   HIPCHECK(hipSetDevice(dst->device));
+   HIPCHECK(hipStreamSynchronize(src->stream)); HIPCHECK(hipStreamSynchronize(dst->stream));
+   if (n == 0) return OPUS_OK;
+   if (dst->kind) {
+      HIPCHECK(hipMemcpy(dst->d_sh + dst_first, src->d_sh + src_first, sizeof(OaShStream) * (size_t)n, hipMemcpyDeviceToDevice));
+      for (opus_int32 i = 0; i < n; i++) dst->h_sh[dst_first + i] = src->h_sh[src_first + i];
+      dst->cfg_dirty = true;
+   } else {
+      HIPCHECK(hipMemcpy(dst->d_streams + dst_first, src->d_streams + src_first, sizeof(OaStream) * (size_t)n, hipMemcpyDeviceToDevice));
+      for (opus_int32 i = 0; i < n; i++) dst->h_streams[dst_first + i] = src->h_streams[src_first + i];
+   }
+   dst->any_cbr = -1;
+   return OPUS_OK;
+}
 /* calls the split path's front kernel has kept / handed to the one-kernel path since the batch was created (diagnostics, tests) */
 int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_uint32 *declined)
 {
@@ -541,7 +563,7 @@ static int oa_sh_grid(OpusGpuEncBatch *b, int slot, const void *kernel, size_t l
    return OPUS_OK;
 }
 static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out, opus_int32 out_stride, opus_int32 max_data_bytes,
-      opus_int32 *d_lens, opus_uint32 *d_final_range, hipStream_t s, size_t lds_full, int silk_only, int mode)
+      opus_int32 *d_lens, opus_uint32 *d_final_range, hipStream_t s, size_t lds_full, int silk_only, int mode, int pcm_row)
 {
    const int n = (int)b->n_act, ch = b->channels;
    if (!b->d_cont) {
@@ -576,14 +598,14 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
-         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front);
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
          b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back);
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
-         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full);
+         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -598,10 +620,22 @@ static int oa_batch_any_cbr(OpusGpuEncBatch *b)
 }
 /* d_apcm (may be NULL): the same samples in the encoder's signal domain (int32, Q12 below int16 full scale: src/opus_encoder.c FLOAT2SIG / INT24TOSIG), which the
  * 24-bit and float entry points hand to the analysis instead of the rounded int16 samples (downmix_int24 :804, downmix_float :748) */
+int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream);
 int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
+   return opusgpu_encode_batch_lookahead_dev(b, d_pcm, d_apcm, frame_size, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, hip_stream);
+}
+/* The same with the reference's look-ahead (src/opus_encoder.c:1247, :2662-2690; src/analysis.c:954): every stream's row of d_pcm (and d_apcm) holds analysis_frame_size >=
+ * frame_size samples per channel -- what opus_encode() is handed when OPUS_SET_EXPERT_FRAME_DURATION selects a frame shorter than the caller's buffer -- of which the first
+ * frame_size are coded; the tonality analysis runs over the whole row (the part it has not seen yet: OaAnalysis.analysis_offset carries that between calls) */
+int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
+{
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
+   if (analysis_frame_size < frame_size) return OPUS_BAD_ARG;
+   const int pcm_row = analysis_frame_size;
    { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
    if (out_stride < oa_enc_out_stride_needed(b->Fs, frame_size, max_data_bytes, oa_batch_any_cbr(b))) return OPUS_BUFFER_TOO_SMALL;
@@ -625,12 +659,12 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
       const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 1 : 0);
-      if (split_mode && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode);
+      if (split_mode && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds_pk, s,
             b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue,
-            (const int *)nullptr, (const unsigned *)nullptr, po);
+            (const int *)nullptr, (const unsigned *)nullptr, po, pcm_row);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }
@@ -638,7 +672,7 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -714,6 +748,8 @@ int opusgpu_time_encode_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int fra
 }
 int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, unsigned char *out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
+int opusgpu_encode_batch_lookahead(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, int analysis_frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range);
 int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
 {
@@ -722,10 +758,15 @@ int opusgpu_encode_batch(OpusGpuEncBatch *b, const opus_int16 *pcm, int frame_si
 int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, unsigned char *out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
 {
-   if (!b || !pcm || !out || !lens) return OPUS_BAD_ARG;
+   return opusgpu_encode_batch_lookahead(b, pcm, apcm, frame_size, frame_size, out, out_stride, max_data_bytes, lens, final_range);
+}
+int opusgpu_encode_batch_lookahead(OpusGpuEncBatch *b, const opus_int16 *pcm, const opus_int32 *apcm, int frame_size, int analysis_frame_size, unsigned char *out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *lens, opus_uint32 *final_range)
+{
+   if (!b || !pcm || !out || !lens || analysis_frame_size < frame_size) return OPUS_BAD_ARG;
    { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    HIPCHECK(hipSetDevice(b->device));
-   size_t npcm = (size_t)b->n_act * frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->n_act * out_stride;
+   size_t npcm = (size_t)b->n_act * analysis_frame_size * b->channels * sizeof(opus_int16), nout = (size_t)b->n_act * out_stride;
    if (npcm > b->pcm_cap) { if (b->d_pcm) (void)hipFree(b->d_pcm); HIPCHECK(hipMalloc((void **)&b->d_pcm, npcm)); b->pcm_cap = npcm; }
    if (nout > b->out_cap) { if (b->d_out) (void)hipFree(b->d_out); HIPCHECK(hipMalloc((void **)&b->d_out, nout)); b->out_cap = nout; }
    HIPCHECK(hipMemcpyAsync(b->d_pcm, pcm, npcm, hipMemcpyHostToDevice, b->stream));
@@ -733,7 +774,7 @@ int opusgpu_encode_batch_sig(OpusGpuEncBatch *b, const opus_int16 *pcm, const op
       if (2 * npcm > b->apcm_cap) { if (b->d_apcm) (void)hipFree(b->d_apcm); b->d_apcm = nullptr; b->apcm_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_apcm, 2 * npcm)); b->apcm_cap = 2 * npcm; }
       HIPCHECK(hipMemcpyAsync(b->d_apcm, apcm, 2 * npcm, hipMemcpyHostToDevice, b->stream));
    }
-   int r = opusgpu_encode_batch_dev_sig(b, b->d_pcm, apcm ? b->d_apcm : nullptr, frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
+   int r = opusgpu_encode_batch_lookahead_dev(b, b->d_pcm, apcm ? b->d_apcm : nullptr, frame_size, analysis_frame_size, b->d_out, out_stride, max_data_bytes, b->d_lens, b->d_rng, nullptr);
    if (r != OPUS_OK) return r;
    HIPCHECK(hipMemcpyAsync(out, b->d_out, nout, hipMemcpyDeviceToHost, b->stream));
    HIPCHECK(hipMemcpyAsync(lens, b->d_lens, sizeof(opus_int32) * (size_t)b->n_act, hipMemcpyDeviceToHost, b->stream));
@@ -750,12 +791,12 @@ static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][A
 struct OaEncCall {
    OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
    int kind, frame_size, application, channels; opus_int32 Fs, max_data_bytes;
-   int ret; bool done; size_t tid; int pipeline;
+   int ret; bool done; size_t tid; int pipeline; int analysis_frame_size;    /* samples per channel behind pcm (>= frame_size: OPUS_SET_EXPERT_FRAME_DURATION) */
    const void *who() const { return st; }
    bool same_shape(const OaEncCall &o) const
    {
       return kind == o.kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
-          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr) && pipeline == o.pipeline;
+          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr) && pipeline == o.pipeline && analysis_frame_size == o.analysis_frame_size;
    }
 };
 static OaCallCombiner<OaEncCall> g_enc_calls;
@@ -819,7 +860,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    b->application = h.application; b->n_act = n; b->pipeline = h.pipeline;
    opus_int32 stride = oa_enc_out_stride_needed(h.Fs, h.frame_size, h.max_data_bytes) + 8;
    if (stride < 1288) stride = 1288;
-   const size_t per = (size_t)h.frame_size * h.channels, rec = kind ? sizeof(OaShStream) : sizeof(OaStream);
+   const size_t per = (size_t)h.analysis_frame_size * h.channels, rec = kind ? sizeof(OaShStream) : sizeof(OaStream);
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    const opus_int16 *pcm = h.pcm; const opus_int32 *apcm = h.apcm;
@@ -843,7 +884,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = g[i]->st->s.cfg;
    std::vector<unsigned char> out((size_t)stride * n);
    std::vector<opus_int32> lens((size_t)n); std::vector<opus_uint32> rng((size_t)n);
-   int r = opusgpu_encode_batch_sig(b, pcm, apcm, h.frame_size, out.data(), stride, h.max_data_bytes, lens.data(), rng.data());
+   int r = opusgpu_encode_batch_lookahead(b, pcm, apcm, h.frame_size, h.analysis_frame_size, out.data(), stride, h.max_data_bytes, lens.data(), rng.data());
    if (r != OPUS_OK) return r;
    if (n > 1) {
       HIPCHECK(hipMemcpy(recs, kind ? (const void *)b->d_sh : (const void *)b->d_streams, rec * (size_t)n, hipMemcpyDeviceToHost));
@@ -872,10 +913,15 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
    const int channels = st->kind ? st->sh.cfg.channels : st->s.cfg.channels, application = st->kind ? st->sh.cfg.application : st->s.cfg.application;
    const opus_int32 Fs = st->kind ? st->sh.cfg.Fs : st->s.Fs;
    const int frame_size = (int)oa_frame_size_select(application, analysis_frame_size, st->kind ? st->sh.cfg.variable_duration : st->s.cfg.variable_duration, Fs);
-   if (frame_size <= 0 || max_data_bytes <= 0) return OPUS_BAD_ARG;
-   { const int fr = oa_enc_frame_size_code(Fs, application, frame_size); if (fr != OPUS_OK) return fr; }
+   /* opus_encode_native clears the final range before it looks at its arguments (src/opus_encoder.c:1223-1228); the int16 entry point hands it frame_size_select's -1 as it
+    * comes (:2659-2667), the 24-bit and float ones turn an illegal frame size away before that (:2713-2718, :2752-2757) */
+   const int fr_code = frame_size <= 0 ? OPUS_BAD_ARG : oa_enc_frame_size_code(Fs, application, frame_size);
+   if (fr_code != OPUS_OK || max_data_bytes <= 0) {
+      if (fr_code == OPUS_OK || apcm == nullptr) { if (st->kind) st->sh.s.rangeFinal = 0; else st->s.st.s.rangeFinal = 0; }
+      return fr_code != OPUS_OK ? fr_code : OPUS_BAD_ARG;
+   }
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false, 0, st->pipeline_p2 ? (int)st->pipeline_p2 - 2 : -1};
+   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false, 0, st->pipeline_p2 ? (int)st->pipeline_p2 - 2 : -1, analysis_frame_size > frame_size ? analysis_frame_size : frame_size};
    g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_linger_us(), oa_classic_encode_group);
    return call.ret;
 }

@@ -915,7 +915,7 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
 /* The top of opus_encode_native (:1182-1696) for one call: configuration, Opus-layer scalars and SILK state HBM -> LDS, the tonality analysis of the call's input, digital
  * silence / peak energy / stereo width, the call's decisions (sh_layer_decide).  analysed = 1: the analysis of this call's input has run already (the split path's front
  * kernel ran this very function on the stream and then handed the call to the one-kernel path: the analysis state in HBM is the only thing it changed) */
-WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, CeltScratch *cs, const i32 *apcm, int analysed)
+WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, CeltScratch *cs, const i32 *apcm, int analysed, int analysis_frame_size = 0 /* samples per channel behind pcm: the caller's look-ahead (src/opus_encoder.c:1247, :2662-2690); 0 = frame_size */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    SE_PHASE_START(&L->S);
@@ -939,7 +939,7 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
    if (!analysed && !(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
       if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
          LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
-         an_run_analysis_wave((WV_LDS AnLds *)&L->S.u, &gs->an, pcm, apcm, frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
+         an_run_analysis_wave((WV_LDS AnLds *)&L->S.u, &gs->an, pcm, apcm, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
                (i32 *)cs->X, &gs->an_info);
       } else {
          const int was_initialized = wv_uni(gs->an.initialized);
@@ -968,10 +968,10 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
    LANE0 sh_layer_decide(L, frame_size, max_data_bytes, &gs->an_info);
 }
 WV_DEV void oa_sh_encode_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, u8 *out, int out_cap, i16 *pcm_hp, SeRateScratch *G, CeltScratch *cs, i32 *len_out, u32 *rng_out,
-      const i32 *apcm = nullptr, int analysed = 0)
+      const i32 *apcm = nullptr, int analysed = 0, int analysis_frame_size = 0)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
-   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, analysed);
+   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, analysed, analysis_frame_size);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    i16 *pcm_celt = (i16 *)((char *)pcm_hp + SH_PCM_BYTES(frame_size, CC)), *tmp_prefill = (i16 *)((char *)pcm_hp + 2 * SH_PCM_BYTES(frame_size, CC));
    if (sh->err) { LANE0 { *len_out = sh->err; *rng_out = 0; gs->s.error = sh->err; } return; }

@@ -257,7 +257,8 @@ static opus_int32 oa_ms_rate_allocation(const OpusMSEncoder *st, opus_int32 *rat
 
 /* encode n streams of one group (all `ch`-channel) in one launch; states are loaded from / stored back to the flat blob */
 static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, int ch, int application, const opus_int16 *pcm, int frame_size, opus_int32 max_data_bytes,
-      unsigned char *out /* [n][stride] */, opus_int32 stride, opus_int32 *lens, opus_uint32 *rngs, const opus_int32 *apcm = nullptr /* signal-domain view for the analysis, or NULL */)
+      unsigned char *out /* [n][stride] */, opus_int32 stride, opus_int32 *lens, opus_uint32 *rngs, const opus_int32 *apcm = nullptr /* signal-domain view for the analysis, or NULL */,
+      int analysis_frame_size = 0 /* samples per channel of a stream's row of pcm / apcm (>= frame_size); 0 = frame_size */)
 {
    int err = OPUS_OK;
    OpusGpuEncBatch *b = oa_ms_enc_batch(n, ch, application, Fs, &err);
@@ -270,7 +271,7 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
    b->application = application; b->pipeline = states[0].pipeline_p2 ? (int)states[0].pipeline_p2 - 2 : -1;
    if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = states[i].sh.cfg; b->cfg_dirty = true; }
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = states[i].s.cfg;
-   int r = opusgpu_encode_batch_sig(b, pcm, apcm, frame_size, out, stride, max_data_bytes, lens, rngs);
+   int r = opusgpu_encode_batch_lookahead(b, pcm, apcm, frame_size, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, out, stride, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;
    return kind ? oa_rows_download(&states[0].sh, sizeof(OaMsRec), b->d_sh, sizeof(OaShStream), n) : oa_rows_download(&states[0].s, sizeof(OaMsRec), b->d_streams, sizeof(OaStream), n);
 }
@@ -320,31 +321,33 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
          if (kind) { rec->sh.cfg.energy_mask_on = 1; rec->sh.s.celt_mask_cleared = 0; } else rec->s.energy_mask_on = 1;
       }
    }
-   /* channel de-interleave into the two groups */
-   std::vector<opus_int16> pc((size_t)nc * frame_size * 2 + 2), pm((size_t)nm * frame_size + 1);
+   /* channel de-interleave into the two groups: the whole buffer the caller handed over (analysis_frame_size samples: the look-ahead the elementary encoders' analyses see,
+    * opus_multistream_encoder.c:1016-1040 passes pcm and analysis_frame_size on), of which the first frame_size samples are coded */
+   const int afs = analysis_frame_size > frame_size ? analysis_frame_size : frame_size;
+   std::vector<opus_int16> pc((size_t)nc * afs * 2 + 2), pm((size_t)nm * afs + 1);
    for (int s = 0; s < nc; s++) {
       int l = oa_get_left(&st->layout, s, -1), r = oa_get_right(&st->layout, s, -1);
-      opus_int16 *d = pc.data() + (size_t)s * frame_size * 2;
-      for (int i = 0; i < frame_size; i++) { d[2 * i] = pcm[(size_t)i * nch + l]; d[2 * i + 1] = pcm[(size_t)i * nch + r]; }
+      opus_int16 *d = pc.data() + (size_t)s * afs * 2;
+      for (int i = 0; i < afs; i++) { d[2 * i] = pcm[(size_t)i * nch + l]; d[2 * i + 1] = pcm[(size_t)i * nch + r]; }
    }
    for (int s = 0; s < nm; s++) {
       int c = oa_get_mono(&st->layout, nc + s, -1);
-      opus_int16 *d = pm.data() + (size_t)s * frame_size;
-      for (int i = 0; i < frame_size; i++) d[i] = pcm[(size_t)i * nch + c];
+      opus_int16 *d = pm.data() + (size_t)s * afs;
+      for (int i = 0; i < afs; i++) d[i] = pcm[(size_t)i * nch + c];
    }
    /* the 24-bit / float entry points: the same split of the signal-domain samples the elementary encoders' analyses see (downmix_int24 / downmix_float with the stream's c1, c2) */
    std::vector<opus_int32> ac, am;
    if (apcm) {
-      ac.resize((size_t)nc * frame_size * 2 + 2); am.resize((size_t)nm * frame_size + 1);
+      ac.resize((size_t)nc * afs * 2 + 2); am.resize((size_t)nm * afs + 1);
       for (int s = 0; s < nc; s++) {
          int l = oa_get_left(&st->layout, s, -1), r = oa_get_right(&st->layout, s, -1);
-         opus_int32 *d = ac.data() + (size_t)s * frame_size * 2;
-         for (int i = 0; i < frame_size; i++) { d[2 * i] = apcm[(size_t)i * nch + l]; d[2 * i + 1] = apcm[(size_t)i * nch + r]; }
+         opus_int32 *d = ac.data() + (size_t)s * afs * 2;
+         for (int i = 0; i < afs; i++) { d[2 * i] = apcm[(size_t)i * nch + l]; d[2 * i + 1] = apcm[(size_t)i * nch + r]; }
       }
       for (int s = 0; s < nm; s++) {
          int c = oa_get_mono(&st->layout, nc + s, -1);
-         opus_int32 *d = am.data() + (size_t)s * frame_size;
-         for (int i = 0; i < frame_size; i++) d[i] = apcm[(size_t)i * nch + c];
+         opus_int32 *d = am.data() + (size_t)s * afs;
+         for (int i = 0; i < afs; i++) d[i] = apcm[(size_t)i * nch + c];
       }
    }
    const opus_int32 *apc = apcm ? ac.data() : nullptr, *apm = apcm ? am.data() : nullptr;
@@ -362,8 +365,8 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
    opus_int32 tot_size = 0;
    unsigned char *out = data;
    if (parallel) {
-      if (nc) r = oa_ms_encode_group(st->streams, kind, Fs, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), stride, lens.data(), rngs.data(), apc);
-      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, kind, Fs, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, rngs.data() + nc, apm);
+      if (nc) r = oa_ms_encode_group(st->streams, kind, Fs, nc, 2, st->application, pc.data(), frame_size, 1276 * 6, pk.data(), stride, lens.data(), rngs.data(), apc, afs);
+      if (r == OPUS_OK && nm) r = oa_ms_encode_group(st->streams + nc, kind, Fs, nm, 1, st->application, pm.data(), frame_size, 1276 * 6, pk.data() + (size_t)nc * stride, stride, lens.data() + nc, rngs.data() + nc, apm, afs);
       if (r != OPUS_OK) return r;
    }
    for (int s = 0; s < ns; s++) {
@@ -378,8 +381,8 @@ static int oa_ms_encode_native(OpusMSEncoder *st, const opus_int16 *pcm, int ana
          if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
          if (!vbr && s == ns - 1) (void)oa_ms_rec_set(&st->streams[s], kind, OPUS_SET_BITRATE_REQUEST, curr_max * 8 * (6 * Fs / frame_size) / 6);
          if (curr_max <= 0) return OPUS_BUFFER_TOO_SMALL;
-         if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * frame_size * 2, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s], apc ? apc + (size_t)s * frame_size * 2 : nullptr);
-         else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * frame_size, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s], apm ? apm + (size_t)(s - nc) * frame_size : nullptr);
+         if (s < nc) r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 2, st->application, pc.data() + (size_t)s * afs * 2, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s], apc ? apc + (size_t)s * afs * 2 : nullptr, afs);
+         else r = oa_ms_encode_group(st->streams + s, kind, Fs, 1, 1, st->application, pm.data() + (size_t)(s - nc) * afs, frame_size, curr_max, pk.data() + (size_t)s * stride, stride, &lens[s], &rngs[s], apm ? apm + (size_t)(s - nc) * afs : nullptr, afs);
          if (r != OPUS_OK) return r;
       }
       if (lens[s] < 0) return lens[s];

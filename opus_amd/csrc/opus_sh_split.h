@@ -51,14 +51,14 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
 }
 template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
 WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
-      int *slow_list, unsigned *slow_count, int s)
+      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
    LANE0 { L->silk_tail = 0; S->st_off = (i32)SE_FRONT_ST_OFF; }          /* the quantiser tails stay in HBM: they are the quantiser kernel's; the state sits behind the analysis working set */
    wv_sync();
    WV_LDS OaSilkEnc *E = se_st(S);
-   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0);
+   sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0, analysis_frame_size);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;
    {

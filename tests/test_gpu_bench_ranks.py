@@ -42,6 +42,17 @@ def test_bench_two_ranks_one_gpu():
     print("ms_per_step with the gather %.3f, without %.3f" % (r["ms_per_step"], r0["ms_per_step"]))
     assert r["ms_per_step"] < 1.5 * r0["ms_per_step"] + 2.0
 
+@pytest.mark.parametrize("n,S", [(2, 4096), (8, 4096)])
+def test_bench_ranks_one_gpu_p2p_gather(n, S):
+    """the gather's second transport (--gather p2p: every rank copies its wire record into rank 0's double buffer through an IPC mapping, no collective, control traffic over
+    gloo) executed for real: n processes on GPU 0, IPC handles opened across them, device-to-device copies on side streams, the sticky overflow flag reduced over the ranks;
+    world size 8 at 8 x 4,096 streams is the shape of the driver's scaling run"""
+    K = 3
+    r = _run_ranks(n, ["--steps", str(K), "--warmup", "1", "--streams", str(S), "--gather", "p2p"], "gloo")
+    _check_ranks(r, n, S, K)
+    g = r["gather"]
+    assert g["steps"] == K + 1 and not g["overflow"] and g["transport"].startswith("p2p") and g["cap_bytes_per_stream"] == 2 * 320 + 64
+
 def test_bench_two_ranks_rccl():
     """two ranks, two GPUs, RCCL: only where the box has them (the driver's scaling run is the real measurement)"""
     import torch
@@ -65,11 +76,16 @@ def test_bench_single_rank_contract():
 
 def test_bench_default_line_has_every_configuration():
     """the default N = 1 line (what the driver records) at a reduced stream count: configs 3 / 4 / 5 and the decoder legs, each with value, roofline and parity sample"""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--streams", "4096", "--frames-per-launch", "6"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--streams", "4096", "--frames-per-launch", "6", "--steady-state", "40"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, cwd=ROOT)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
     r = _last_json(p.stdout.decode(errors="replace"))
     assert set(r["configs"]) == {"decode_2", "config_3", "decode_3", "config_4", "decode_4", "config_5"}
     for k, e in r["configs"].items():
-        assert e["value"] > 0 and e["all_packets_valid"] and e["roofline"]["kernel_ms"] > 0, k
-        if k != "config_5": assert e["parity_sample_ok"] is True and e["cpu_baseline"]["value"] > 0, k
+        assert e["value"] > 0 and e["valid"] and e["roofline"]["kernel_ms"] > 0, k
+        assert e["parity_ok"] is True and e["cpu"]["value"] > 0, k                       # every leg, config 5 included (opus_multistream_encode of the reference on two encoders)
+    ss = r["steady_state"]
+    assert ss["consecutive_frames"] == 40 and ss["parity_sample_ok"] is True and ss["parity_frames"] == 4 * 40 and ss["all_packets_valid"]
+    assert ss["full_width"]["value"] > 0 and ss["full_width"]["all_packets_valid"] and ss["full_width"]["replicas_agree"]
+    assert len(p.stdout.decode(errors="replace").strip().splitlines()[-1]) < 8000          # the driver keeps the last 8 KB of the line: every leg must be in it
+    assert all(k in r["notes"] for k in ("legs", "roofline", "cpu_sample", "parity", "steady_state"))

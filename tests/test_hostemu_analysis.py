@@ -227,3 +227,44 @@ def test_lowdelay_dtx_sees_the_peak_tracked_before_it_was_switched_on():
     for k in range(25): gaps[960 * 50 + k * 3840:960 * 50 + k * 3840 + 1400] = 0
     run(Fs, ch, 2051, [3840] * 36, {5: dict(dtx=1)}, sig=gaps, bitrate=96000)
     run(Fs, ch, 2049, [2880] * 48, {5: dict(dtx=1)}, sig=gaps, bitrate=40000)
+
+
+# ---- the caller's look-ahead: OPUS_SET_EXPERT_FRAME_DURATION shorter than the buffer handed to opus_encode (src/opus_encoder.c:1247, :2662-2690; run_analysis src/analysis.c:954) ----
+@pytest.mark.parametrize("Fs,ch,app,dur,buf_ms,ctl", [
+    (48000, 2, 2049, 5003, 20, dict(bitrate=96000, complexity=10)),                       # 10 ms frames out of 20 ms buffers, AUDIO (automatic mode)
+    (48000, 1, 2048, 5004, 60, dict(bitrate=24000, complexity=10)),                       # 20 ms out of 60 ms, VOIP
+    (48000, 2, 2051, 5002, 20, dict(bitrate=128000, complexity=10)),                      # 5 ms out of 20 ms, RESTRICTED_LOWDELAY (the CELT-only record)
+    (16000, 1, 2048, 5003, 40, dict(bitrate=20000, complexity=10, force_mode=1000)),      # SILK-only 10 ms out of 40 ms
+    (48000, 2, 2049, 5005, 120, dict(bitrate=64000, complexity=10))])                     # 40 ms (two coded frames) out of 120 ms: the analysis buffer's wrap-around guard (:964)
+def test_expert_frame_duration_with_a_longer_buffer_analyses_the_whole_buffer(Fs, ch, app, dur, buf_ms, ctl):
+    a, b = pair(Fs, ch, app)
+    for k, v in dict(ctl, expert_frame_duration=dur).items(): assert a.set(k, v) == b.set(k, v) == 0, k
+    fr = {5001: Fs // 400, 5002: Fs // 200, 5003: Fs // 100, 5004: Fs // 50, 5005: Fs // 25}[dur]; buf = Fs * buf_ms // 1000
+    x = signals.music(60, channels=ch, seed=31)[::48000 // Fs]; x = np.ascontiguousarray(x if ch == 2 else x.reshape(-1))
+    pos = 0
+    for i in range(40):
+        p, q = a.encode(x[pos:pos + buf], buf), b.encode(x[pos:pos + buf], buf)          # the buffer is `buf` samples long, the encoder codes its first `fr` (and analyses all of it)
+        assert p == q, (i, p[1], q[1])
+        pos += fr
+        if i == 20: assert a.set("expert_frame_duration", 5000) == b.set("expert_frame_duration", 5000) == 0; fr = buf   # back to OPUS_FRAMESIZE_ARG: the pending analysis offset is consumed
+
+def test_expert_frame_duration_look_ahead_through_the_multistream_and_float_entry_points():
+    import ctypes
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    R = capi._proto(capi.load("ref_fxa")); E = capi._proto(capi.load(WHICH))
+    encs = []
+    for L in (R, E):
+        L.opus_multistream_surround_encoder_create.restype = vp; L.opus_multistream_surround_encoder_create.argtypes = [ctypes.c_int32, ci, ci, vp, vp, vp, ci, vp]
+        s, c, m, err = ci(), ci(), (ctypes.c_ubyte * 256)(), ci()
+        e = L.opus_multistream_surround_encoder_create(48000, 3, 1, ctypes.byref(s), ctypes.byref(c), m, 2049, ctypes.byref(err)); assert e and err.value == 0
+        L.opus_multistream_encode_float.argtypes = [vp, vp, ci, vp, ctypes.c_int32]
+        L.opus_multistream_encoder_ctl.argtypes = [vp, ci, ci]
+        for req, v in ((4002, 160000), (4010, 10), (4040, 5003)): assert L.opus_multistream_encoder_ctl(e, req, v) == 0
+        if L is E: assert L.opus_multistream_encoder_ctl(e, FLOAT_ANALYSIS, 1) == 0
+        encs.append((L, e))
+    x = (signals.music(30, channels=2, seed=5).astype(np.float32) / 32768.0); x = np.ascontiguousarray(np.concatenate([x, x[:, :1] * 0.5], 1))
+    out = [(ctypes.c_ubyte * 4000)(), (ctypes.c_ubyte * 4000)()]
+    for i in range(30):
+        seg = np.ascontiguousarray(x[i * 480:i * 480 + 960])
+        n = [L.opus_multistream_encode_float(e, seg.ctypes.data, 960, o, 4000) for (L, e), o in zip(encs, out)]
+        assert n[0] == n[1] > 0 and bytes(out[0][:n[0]]) == bytes(out[1][:n[1]]), (i, n)

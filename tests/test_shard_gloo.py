@@ -151,3 +151,41 @@ def test_pipelined_gather_two_steps_in_flight(cap, expect_overflow):
     for (gl, gr, go), (wl, wr, wo) in zip(got, want):
         assert (gl == wl.numpy()).all() and (gr == wr.numpy()).all()
         if not expect_overflow: assert (go == wo.numpy()).all()
+
+
+def test_wire_capacity_rule():
+    """the capacity of the wire record comes from the encoder settings (PacketGather.wire_capacity): VBR twice the nominal packet + 64 B per elementary stream, hard CBR at
+    least the CBR packet, unknown / OPUS_BITRATE_MAX the whole slot"""
+    W = PacketGather.wire_capacity
+    assert W(1280, 128000) == 2 * 320 + 64 and W(1280, 24000) == 2 * 60 + 64
+    assert W(1280, 128000, cbr=True) >= 320 and W(1280, 510000, cbr=True) == 1275 + 3 and W(1280, 510000) == 1280
+    assert W(1280, -1) == 1280 and W(1280, -1000) == 1280 and W(1280, None) == 1280
+    assert W(65536, 255 * 64000, sub_streams=255) == 2 * 40800 + 64 * 255 if 2 * 40800 + 64 * 255 < 65536 else W(65536, 255 * 64000, sub_streams=255) == 65536
+    assert W(1280, 64000, frame_rate=100) == 2 * 80 + 64
+
+
+def _sticky_worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PacketGather(total, STRIDE, torch.device("cpu"), dst=0, bitrate_bps=16000, depth=2)          # capacity from the bitrate: 2 * 40 + 64 = 144 bytes per stream
+        n = g.hi - g.lo
+        for t in range(6):
+            big = t == 1 and rank == world - 1                                                            # ONE step of ONE rank exceeds it, four steps before the statistics are read
+            lens = torch.full((n,), 600 if big else 30, dtype=torch.int32)
+            g.launch(lens, torch.zeros(n, dtype=torch.int32), torch.zeros((n, STRIDE), dtype=torch.uint8))
+        q.put((rank, g.cap, g.stats()["overflow"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflow_flag_is_sticky_and_seen_by_every_rank():
+    """launch()-only use (the bench's timed region): a step over capacity that has long rotated out of the double buffer, on a rank other than dst, is still reported -- by every rank"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); world = 3
+    procs = [ctx.Process(target=_sticky_worker, args=(r, world, port, 10, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    assert [r[1] for r in res] == [144] * world and all(r[2] for r in res), res
