@@ -433,9 +433,9 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         # the decoder on these very packets: a decoder batch decodes them step by step with its state carried in HBM; timed like the encoder (HIP events per launch,
         # barrier + synchronize around the K steps)
         d = opus_amd.DecoderBatch(S, channels=CH, Fs=Fs, device=local)
-        # configs 3 and 4 pin the encoder's mode (SILK-only / hybrid): a decoder batch for such a service knows it carries no CELT-only packets and skips the fast kernel's look at
-        # every stream (opusgpu_dec_batch_set_fast_kernel; the output is the same either way, the parity sample below checks it)
-        fast_kernel = cid == 2 or os.environ.get("OPUS_AMD_BENCH_DEC_FAST_LOOK") == "1"
+        # the default call: oa_decode_look_kernel sorts the packets (one lane per stream), the CELT-only fast kernel and the general kernel each take their list -- whatever the
+        # batch carries (configs 3 and 4 carry no CELT-only packet: their look finds the fast list empty).  OPUS_AMD_BENCH_DEC_NO_LOOK=1: opusgpu_dec_batch_set_fast_kernel(b, 0), A/B only
+        fast_kernel = os.environ.get("OPUS_AMD_BENCH_DEC_NO_LOOK") != "1"
         if not fast_kernel: d.set_fast_kernel(False)
         dpcm = torch.zeros((TE, NC, FR * CH), dtype=torch.int16, device=dev)                 # (kept for the sampled streams only)
         work = torch.zeros((S, FR * CH), dtype=torch.int16, device=dev); dns = torch.zeros((S,), dtype=torch.int32, device=dev); drng = torch.zeros((TE, S), dtype=torch.int32, device=dev)
@@ -457,7 +457,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None)
         r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
         r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
-        r2["kernel"] = "oa_decode_fast_kernel + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (the batch is told it carries no CELT-only packets: opusgpu_dec_batch_set_fast_kernel(b, 0))"
+        r2["kernel"] = "oa_decode_look_kernel + oa_decode_fast_kernel + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (opusgpu_dec_batch_set_fast_kernel(b, 0))"
         r2["dec_fast_kernel"] = bool(fast_kernel)
         r2["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool(torch.equal(drng, rng))      # every stream decoded FR samples and every frame ends on the encoder's final range
         L.opusgpu_dec_state_size.restype = ctypes.c_int
@@ -658,8 +658,8 @@ def main():
                 Kx = K if r["config_id"] == a.config else max(3, K // 2)
                 e = {"value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
                      "streams": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "valid": r["all_packets_valid"], "parity_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
-                     "roofline": roof(r, r["streams_per_gpu"])}
-                if "dec_fast_kernel" in r: e["dec_fast_kernel"] = r["dec_fast_kernel"]
+                     "roofline": {k_: v_ for k_, v_ in roof(r, r["streams_per_gpu"]).items() if k_ not in ("bound", "peak", "unit")}}
+                if "dec_fast_kernel" in r and not r["dec_fast_kernel"]: e["dec_fast_kernel"] = False
                 c = cpu_leg(r, 3.0, 0) if cpu_on else None
                 if c:
                     e["cpu"] = {k_: c[k_] for k_ in ("value", "same_work_value", "frames") if k_ in c}

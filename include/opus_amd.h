@@ -437,10 +437,17 @@ OPUS_AMD_EXPORT int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *b, const opus
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens /* [B] */, opus_uint32 *d_final_range /* [B] */, void *hip_stream);
 OPUS_AMD_EXPORT int opusgpu_ms_encode_batch(OpusGpuMsEncBatch *b, const opus_int16 *pcm, int frame_size, unsigned char *out, opus_int32 out_stride, opus_int32 max_data_bytes,
       opus_int32 *lens, opus_uint32 *final_range);
+/* ORDERING (every batch object of this header): the *_dev entry points enqueue their launches on the HIP stream they are given (or the batch's own) and return; a batch
+ * owns per-call device state besides the streams' records -- the work queues of its persistent waves, the lists of the decoder's look, the spectrum scratch, the
+ * continuation records of the encoder's kernel pipeline -- so the calls on ONE batch must be ordered on ONE stream (or by events the caller records): two calls of one batch
+ * in flight on different streams are undefined.  Calls on different batches are independent. */
 /* ---- device-resident multistream / projection DECODER batches (opus_amd/csrc/opus_ms_dec_batch.h) ----
  * B decoders of opus_multistream_decoder_create(Fs, channels, streams, coupled_streams, mapping) (reference include/opus_multistream.h:461, src/opus_multistream_decoder.c:178): a
  * frame-step parses the B multistream packets, decodes the B x streams elementary packets and maps the decoded channels to the caller's interleaved output, all in HBM.
- * d_data [B][stride] packets of d_lens [B] bytes (0 = lost), d_pcm [B][frame_size][channels] int16, d_nsamples [B] = samples per channel or a negative OPUS_* code. */
+ * d_data [B][stride] packets of d_lens [B] bytes (0 = lost), d_pcm [B][frame_size][channels] int16, d_nsamples [B] = samples per channel or a negative OPUS_* code.
+ * Limit of this batch: an elementary packet (one stream's share of a multistream packet, without its self-delimiting length field) may have at most 7,696 bytes -- six
+ * coded frames of 1,275 bytes with their header: everything a 120 ms packet of this library's or the reference's encoder can hold; a packet repacketized beyond that is
+ * answered OPUS_BAD_ARG for the WHOLE multistream packet, with every elementary decoder left as it was (the classic opus_multistream_decode has no such limit). */
 typedef struct OpusGpuMsDecBatch OpusGpuMsDecBatch;
 OPUS_AMD_EXPORT OpusGpuMsDecBatch *opusgpu_ms_dec_batch_create(opus_int32 nb_decoders, opus_int32 Fs, int channels, int streams, int coupled_streams, const unsigned char *mapping, int device, int *error);
 /* ... of opus_projection_decoder_create (reference include/opus_projection.h:418, src/opus_projection_decoder.c:213): the same with the demixing matrix (src/mapping_matrix.c:257) applied on the device */

@@ -36,7 +36,9 @@ def source_hash():
     """sha256 over the sources the library is compiled from (opus_amd/csrc/*, include/opus_amd.h, in name order), first 16 hex digits"""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".hip"))) + [os.path.join(_ROOT, "include", "opus_amd.h")]
+    csrc = os.path.join(_HERE, "csrc")
+    if not os.path.isdir(csrc): return None                                                                # a box that received only the .so: nothing to hash, nothing to rebuild from
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))) + [os.path.join(_ROOT, "include", "opus_amd.h")]
     for p in files:
         h.update(os.path.basename(p).encode()); h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
@@ -53,6 +55,9 @@ def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  Skipped only when the library on disk was built from exactly these sources
     (the hash it carries == the hash of the files; when the source tree is absent -- a box that received only the .so -- there is nothing to rebuild from)."""
     want = source_hash()
+    if want is None:
+        if os.path.exists(PRODUCT_LIB_PATH): return PRODUCT_LIB_PATH
+        raise RuntimeError("opus_amd: neither the sources (opus_amd/csrc) nor a built %s are here" % PRODUCT_LIB_PATH)
     if not force and built_source_hash(PRODUCT_LIB_PATH) == want and not os.environ.get("OPUS_AMD_EXTRA_CFLAGS"):
         return PRODUCT_LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-fvisibility=hidden", "-DOA_SOURCE_HASH=\"%s\"" % want, "-I" + os.path.join(_HERE, "csrc"),
@@ -74,7 +79,8 @@ def lib():
         L.opus_encoder_init.argtypes = [vp, i32, ctypes.c_int, ctypes.c_int]
         L.opus_encode.restype = i32; L.opus_encode.argtypes = [vp, vp, ctypes.c_int, vp, i32]
         L.opus_encoder_destroy.argtypes = [vp]; L.opus_encoder_destroy.restype = None
-        L.opus_strerror.restype = ctypes.c_char_p; L.opus_get_version_string.restype = ctypes.c_char_p; L.opusgpu_build_info.restype = ctypes.c_char_p
+        L.opus_strerror.restype = ctypes.c_char_p; L.opus_get_version_string.restype = ctypes.c_char_p
+        if hasattr(L, "opusgpu_build_info"): L.opusgpu_build_info.restype = ctypes.c_char_p           # (variant / older libraries through OPUS_AMD_LIB may lack the newer entry points: guarded)
         L.opusgpu_enc_batch_create.restype = vp; L.opusgpu_enc_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
         L.opusgpu_enc_batch_ctl.argtypes = [vp, i32, ctypes.c_int, i32]
@@ -89,7 +95,7 @@ def lib():
             L.opusgpu_encode_batch_lookahead.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, i32, i32, vp, vp]
             L.opusgpu_encode_batch_lookahead_dev.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, i32, i32, vp, vp, vp]
         L.opusgpu_pack_packets_dev.argtypes = [vp, i32, vp, vp, vp, i32, vp]
-        L.opusgpu_pack_packets_cap_dev.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.c_longlong, vp]
+        if hasattr(L, "opusgpu_pack_packets_cap_dev"): L.opusgpu_pack_packets_cap_dev.argtypes = [vp, i32, vp, vp, vp, i32, ctypes.c_longlong, vp]
         L.opusgpu_enc_moved_state_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         # decoder
         L.opus_decoder_create.restype = vp; L.opus_decoder_create.argtypes = [i32, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]

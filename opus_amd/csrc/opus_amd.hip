@@ -78,17 +78,18 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
  *   oa_decode_kernel       the general decoder over the streams not taken (taken == NULL: over every stream) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams, int decode_fec,
-      char *scratch, unsigned *queue, const int *taken /* NULL, or per stream: 1 = the fast kernel has decoded this packet */)
+      char *scratch, unsigned *queue, const int *list /* NULL: every stream; else the streams oa_decode_look_kernel left to this kernel */, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   const int n = list ? (int)*list_count : nstreams;
    for (;;) {
-      const int s = oa_queue_pop(queue);
-      if (s >= nstreams) break;
-      const int skip = taken ? wv_uni(taken[s]) : 0;
+      int s = oa_queue_pop(queue);
+      if (s >= n) break;
+      if (list) s = wv_uni(list[s]);
       const int len = lens[s];
-      if (!skip && len > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } }       /* a length beyond the stream's slot would read the neighbour's packet */
-      else if (!skip) {
+      if (len > packet_stride) { if (threadIdx.x == 0) { nsamples[s] = OPUS_BAD_ARG; rngs[s] = 0; } }       /* a length beyond the stream's slot would read the neighbour's packet */
+      else {
          if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
          __syncthreads();
          oa_decode_packet<false>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, decode_fec);
@@ -101,30 +102,45 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,
-      char *scratch, unsigned *queue, int *taken /* out, per stream: 1 = decoded here, 0 = left to the general kernel */)
+      char *scratch, unsigned *queue, const int *list /* the streams oa_decode_look_kernel found in the CELT steady state */, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   (void)nstreams;
+   const int n = (int)*list_count;
    for (;;) {
-      const int s = oa_queue_pop(queue);
-      if (s >= nstreams) break;
-      const int len = lens[s];
-      const OaDecStream *gs = streams + s;
-      int fast = 0;
-      if (len >= 3 && len <= packet_stride && len <= 1276) {
-         const int toc = packets[(size_t)s * packet_stride];
-         const int prev = gs->s.prev_mode;
-         fast = (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && gs->s.prefilter_and_fold == 0;
-      }
-      fast = wv_uni(fast);
-      if (threadIdx.x == 0) taken[s] = fast;
-      if (fast) {
-         if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
-         __syncthreads();
-         oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, len, frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
-      }
+      const int i = oa_queue_pop(queue);
+      if (i >= n) break;
+      const int s = wv_uni(list[i]);
+      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      __syncthreads();
+      oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
       __syncthreads();
    }
+}
+/* The look that sorts a call's packets between the two decoder kernels, one LANE per stream (64 streams per wave, one ballot and one atomic per list and wave): a packet goes
+ * to the fast kernel when its decode is the CELT steady state and nothing else -- a CELT-only TOC with one coded frame that fits a frame's slot, a stream whose last packet was
+ * CELT-only too (or that has not decoded anything yet), no pending fold of the concealment.  A batch of SILK or hybrid packets pays 1,024 waves of a dozen instructions for
+ * it, not a queue pop and a header read per stream by the fast kernel's waves.  counters: [0] number of fast streams, [1] number of the others. */
+extern "C" __global__ void __launch_bounds__(64)
+oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int nstreams, int *fast_list, int *slow_list, unsigned *counters)
+{
+   const int lane = (int)threadIdx.x, s = (int)blockIdx.x * 64 + lane;
+   int fast = 0;
+   if (s < nstreams) {
+      const int len = lens[s];
+      if (len >= 3 && len <= packet_stride && len <= 1276) {
+         const int toc = packets[(size_t)s * packet_stride];
+         const int prev = streams[s].s.prev_mode;
+         fast = (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && streams[s].s.prefilter_and_fold == 0;
+      }
+   }
+   const unsigned long long mf = wv_ballot(fast), ms = wv_ballot(s < nstreams && !fast), below = lane ? (~0ull >> (64 - lane)) : 0ull;
+   int bf = 0, bs = 0;
+   if (lane == 0) { bf = mf ? (int)atomicAdd(counters, (unsigned)__builtin_popcountll(mf)) : 0; bs = ms ? (int)atomicAdd(counters + 1, (unsigned)__builtin_popcountll(ms)) : 0; }
+   bf = wv_bcast(bf, 0); bs = wv_bcast(bs, 0);
+   if (fast) fast_list[bf + __builtin_popcountll(mf & below)] = s;
+   else if (s < nstreams) slow_list[bs + __builtin_popcountll(ms & below)] = s;
 }
 
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
@@ -1052,7 +1068,7 @@ struct OpusGpuDecBatch {
    OaDecStream *d_streams;
    unsigned char *d_pkt; size_t pkt_cap; opus_int16 *d_pcm; size_t pcm_cap; opus_int32 *d_lens, *d_ns; opus_uint32 *d_rng;
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
-   unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; d_slow [S]: 1 = the fast kernel has decoded the stream's packet */
+   unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; [2] / [3] the lengths of the two lists; d_slow [2][S]: the streams oa_decode_look_kernel sent to the fast kernel, then those it left to the general one */
    int num_cu, occ_fast, occ_gen;
    int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
 };
@@ -1108,7 +1124,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, sizeof(int) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 2 * sizeof(int) * (size_t)nstreams) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
@@ -1173,17 +1189,17 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    const int use_fast = fast_env && !b->no_fast && !b->decode_fec;
-   static const int dbg = getenv("OPUS_AMD_DEC_DEBUG") ? atoi(getenv("OPUS_AMD_DEC_DEBUG")) : 0;          /* bring-up only: 1 = the fast kernel alone, 2 = then the general kernel over every stream */
+   /* d_queue: [0] the fast kernel's queue, [1] the general kernel's, [2] / [3] the lengths of their lists; d_slow: [S] the fast list, [S] the general kernel's list */
    if (use_fast) {
+      hipLaunchKernelGGL(oa_decode_look_kernel, dim3((unsigned)((b->n_act + 63) / 64)), dim3(64), 0, s,
+            (const OaDecStream *)b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (int)b->n_act, b->d_slow, b->d_slow + b->S, b->d_queue + 2);
       hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
             b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-            (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, b->d_slow);
+            (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, (const int *)b->d_slow, (const unsigned *)(b->d_queue + 2));
    }
-   if (dbg != 1) {
-      hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
-            b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-            (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast && dbg != 2 ? (const int *)b->d_slow : (const int *)nullptr);
-   }
+   hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
+         b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
+         (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast ? (const int *)(b->d_slow + b->S) : (const int *)nullptr, (const unsigned *)(b->d_queue + 3));
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }

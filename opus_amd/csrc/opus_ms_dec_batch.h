@@ -84,7 +84,7 @@ WV_DEV int oa_msd_parse_one(const u8 *p, int left, int framed, OaMsdDesc *d, int
 
 /* status[b]: samples per channel the packet holds at the decoder's rate (> 0), 0 for a lost packet (len 0: every stream conceals), or a negative OPUS_* code */
 extern "C" __global__ void __launch_bounds__(64)
-oa_msd_parse_kernel(const u8 *data, int stride, const i32 *lens, int ns, int Fs, int frame_size, OaMsdDesc *desc, i32 *status)
+oa_msd_parse_kernel(const u8 *data, int stride, const i32 *lens, int ns, int Fs, int frame_size, OaMsdDesc *desc, i32 *status, int slot /* bytes an elementary packet may have in this batch */)
 {
    const int b = blockIdx.x;
    if (threadIdx.x != 0) return;
@@ -106,6 +106,9 @@ oa_msd_parse_kernel(const u8 *data, int stride, const i32 *lens, int ns, int Fs,
       d[s].off = at;
       at += used;
    }
+   /* an elementary packet beyond the batch's slot (a limit of this library: include/opus_amd.h) turns the WHOLE multistream packet away here, before any elementary decoder
+    * has moved -- not its own stream alone after its siblings have decoded theirs */
+   for (int s = 0; s < ns; s++) if (d[s].out_len > slot) { status[b] = OPUS_BAD_ARG; return; }
    status[b] = samples > frame_size ? OPUS_BUFFER_TOO_SMALL : samples;
 }
 /* lens of a turned-away packet's streams: beyond the slot, so that oa_decode_kernel answers OPUS_BAD_ARG without touching the stream */
@@ -291,7 +294,7 @@ int opusgpu_ms_decode_batch_dev(OpusGpuMsDecBatch *m, const unsigned char *d_dat
       if (need_t > m->tmp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (m->d_tmp) (void)hipFree(m->d_tmp); m->d_tmp = nullptr; m->tmp_cap = 0; HIPCHECK(hipMalloc((void **)&m->d_tmp, need_t)); m->tmp_cap = need_t; }
       merged = m->d_tmp;
    }
-   hipLaunchKernelGGL(oa_msd_parse_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)d_data, (int)stride, (const i32 *)d_lens, m->ns, (int)m->Fs, frame_size, m->d_desc, m->d_status);
+   hipLaunchKernelGGL(oa_msd_parse_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)d_data, (int)stride, (const i32 *)d_lens, m->ns, (int)m->Fs, frame_size, m->d_desc, m->d_status, (int)m->slot);
    hipLaunchKernelGGL(oa_msd_scatter_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, (const u8 *)d_data, (int)stride, (const OaMsdDesc *)m->d_desc, (const i32 *)m->d_status, m->ns, m->nc,
          m->d_pkc, m->d_lc, m->d_pkm, m->d_lm, (int)m->slot);
    HIPCHECK(hipGetLastError());

@@ -203,3 +203,40 @@ def check_surround(which, B, channels, application=2049, frames=4, frame=960, Fs
             n = R.opus_multistream_encode(refs[b], pcm[b].ctypes.data, frame, o.ctypes.data, cap)
             assert n == int(lens[b]) and bytes(out[b, :n]) == bytes(o[:n]), (f, b, n, int(lens[b]))
     L.opusgpu_ms_enc_batch_destroy(m)
+
+def check_ms_decode_slot_limit(which):
+    """an elementary packet beyond the decoder batch's 7,696-byte slot (seven 2.5 ms frames of 1,275 bytes, code 3) in the FIRST stream of a two-stream packet: the whole
+    multistream packet is answered OPUS_BAD_ARG and neither elementary decoder has moved -- the good packets that follow decode exactly as they do in a batch that never saw it"""
+    L = capi.load(which); R = capi.load("ref"); vp, ci = ctypes.c_void_p, ctypes.c_int
+    R.opus_multistream_encoder_create.restype = vp; R.opus_multistream_encoder_create.argtypes = [ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    R.opus_multistream_encode.argtypes = [vp, vp, ci, vp, ci]
+    L.opusgpu_ms_dec_batch_create.restype = vp; L.opusgpu_ms_dec_batch_create.argtypes = [ci, ci, ci, ci, ci, ctypes.c_char_p, ci, ctypes.POINTER(ci)]
+    L.opusgpu_ms_decode_batch.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
+    L.opusgpu_ms_dec_batch_destroy.argtypes = [vp]; L.opusgpu_ms_dec_batch_destroy.restype = None
+    err = ci(); mp = bytes([0, 1])
+    enc = R.opus_multistream_encoder_create(48000, 2, 2, 0, mp, 2051, ctypes.byref(err)); assert enc
+    cap = 12000; frame = 960
+    sig = np.stack([speechy(8, 1, 7 + c, 960)[:, 0] for c in range(2)], 1).astype(np.int16)
+    good = []
+    for f in range(5):
+        buf = np.zeros(cap, np.uint8); x = np.ascontiguousarray(sig[f * frame:(f + 1) * frame])
+        n = R.opus_multistream_encode(enc, x.ctypes.data, frame, buf.ctypes.data, cap); assert n > 0
+        good.append((buf, n))
+    rs = np.random.default_rng(3)
+    toc = 0x80 | (0 << 3) | 3                                                    # CELT-only NB 2.5 ms, code 3 (mono)
+    s0 = bytes([toc, 7, 252 + (1275 - 252) % 4, (1275 - (252 + (1275 - 252) % 4)) // 4]) + rs.integers(0, 256, 7 * 1275, dtype=np.uint8).tobytes()   # self-delimited: CBR, 7 frames of 1,275 bytes
+    s1 = bytes([toc, 7]) + rs.integers(0, 256, 7 * 20, dtype=np.uint8).tobytes()
+    bad = np.zeros(cap, np.uint8); bad[:len(s0) + len(s1)] = np.frombuffer(s0 + s1, np.uint8)
+    def run(with_bad):
+        d = L.opusgpu_ms_dec_batch_create(1, 48000, 2, 2, 0, mp, 0, ctypes.byref(err)); assert d and err.value == 0
+        outs = []
+        seq = [(good[0], False), (good[1], False)] + ([((bad, len(s0) + len(s1)), True)] if with_bad else []) + [(good[2], False), (good[3], False), (good[4], False)]
+        for (buf, n), isbad in seq:
+            pcm = np.zeros((1, frame, 2), np.int16); ns = np.zeros(1, np.int32); rg = np.zeros(1, np.uint32); lens = np.array([n], np.int32)
+            r = L.opusgpu_ms_decode_batch(d, np.ascontiguousarray(buf).ctypes.data, cap, lens.ctypes.data, pcm.ctypes.data, frame, ns.ctypes.data, rg.ctypes.data); assert r == 0, r
+            if isbad: assert int(ns[0]) == -1, int(ns[0])                       # OPUS_BAD_ARG for the whole packet
+            else: outs.append((int(ns[0]), pcm.tobytes(), int(rg[0])))
+        L.opusgpu_ms_dec_batch_destroy(d)
+        return outs
+    a, b = run(False), run(True)
+    assert a == b and all(o[0] == frame for o in a)

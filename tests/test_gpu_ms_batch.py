@@ -24,3 +24,5 @@ def test_gpu_projection_batches(channels, analysis):
 
 @pytest.mark.parametrize("channels", [3, 4, 5, 6, 7, 8])
 def test_gpu_surround_batch(channels): ms_batch_check.check_surround("gpu", B=3, channels=channels, bitrate=channels * 56000, frames=8)
+
+def test_gpu_ms_decode_batch_turns_an_over_long_elementary_packet_away_whole(): ms_batch_check.check_ms_decode_slot_limit("gpu")

@@ -16,3 +16,5 @@ def test_emu_projection_batches(channels, analysis):
 
 @pytest.mark.parametrize("channels", [3, 6, 8])
 def test_emu_surround_batch(channels): ms_batch_check.check_surround("emu", B=2, channels=channels, bitrate=channels * 56000)
+
+def test_emu_ms_decode_batch_turns_an_over_long_elementary_packet_away_whole(): ms_batch_check.check_ms_decode_slot_limit("emu")
