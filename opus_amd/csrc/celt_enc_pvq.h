@@ -181,7 +181,7 @@ WV_DEV i32 stereo_itheta_wave(const WV_LDS i32 *X, const WV_LDS i32 *Y, int ster
          Emid = mac16_16(Emid, m, m);
          Eside = mac16_16(Eside, s, s);
       }
-      Emid = wv_sum(Emid); Eside = wv_sum(Eside);
+      Emid = wv_sum_n(Emid, N); Eside = wv_sum_n(Eside, N);
    } else {
       Emid = inner_prod_norm_shift_w(X, X, N);
       Eside = inner_prod_norm_shift_w(Y, Y, N);
@@ -352,7 +352,8 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
    const int lane = wv_lane();
    i64 e2 = 0;
    for (int t = 0; t < NR; t++) e2 += x[t] * (i64)x[t];
-   int shift = (celt_ilog2(1 + (i32)(wv_sum64(e2) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
+   const int nl = NR == 1 ? N : 64;                                        /* lanes that carry coefficients (the others hold zeros): short bands reduce inside their row */
+   int shift = (celt_ilog2(1 + (i32)(wv_sum64_n(e2, nl) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
    shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
    bool vld[NR]; i32 sg[NR], y[NR];
    i32 xsum = 0;
@@ -364,7 +365,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
    i32 xy = 0; i16 yy = 0;
    int pulsesLeft = K;
    if (K > (N >> 1)) {
-      i32 sum = wv_sum(xsum);
+      i32 sum = wv_sum_n(xsum, nl);
       if (sum <= K) {
          for (int t = 0; t < NR; t++) x[t] = 0;
          if (lane == 0) x[0] = QC16(1.f, 14);
@@ -376,9 +377,9 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
          q[t] = mult16_16_q15(x[t], rcp);
          yyp = mac16_16(yyp, q[t], q[t]); xyp = mac16_16(xyp, x[t], q[t]); y[t] = 2 * q[t]; qs += q[t];
       }
-      yy = (i16)wv_sum(yyp);
-      xy = wv_sum(xyp);
-      pulsesLeft -= wv_sum(qs);
+      yy = (i16)wv_sum_n(yyp, nl);
+      xy = wv_sum_n(xyp, nl);
+      pulsesLeft -= wv_sum_n(qs, nl);
    }
    if (pulsesLeft > N + 3) {
       i16 tmp = (i16)pulsesLeft;
@@ -388,7 +389,6 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
       if (lane == 0) q[0] += pulsesLeft;
       pulsesLeft = 0;
    }
-   const int nl = NR == 1 ? N : 64;
    for (int i = 0; i < pulsesLeft; i++) {
       int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
       yy = add16(yy, 1);
@@ -404,7 +404,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
          }
       }
       int owner, slot = 0;
-      if (NR == 1) owner = wv_argmax_ratio_packed(bn, bd, vld[0], nl);
+      if (NR == 1) owner = wv_argmax_ratio_fast(bn, bd, vld[0], nl);
       else {
          /* global index order is (slot, lane): find the maximal ratio first, then the lowest slot that attains it, then the lowest lane */
          const int any = wv_argmax_ratio_packed(bn, bd, vld[0], 64);
@@ -444,7 +444,7 @@ template <int NR> WV_DEV void encode_pulses_regs(WV_LDS FrameLds *L, const i32 (
       } else if (j == N - 1) idx += yv[t] < 0;
       above += tot[t];
    }
-   idx = wv_sumu(idx);
+   idx = (u32)wv_sum_n((i32)idx, NR == 1 ? N : 64);
    LANE0 { EC_BEGIN; k_ec_enc_uint(EC_PASS, idx, pvq_u(N, K) + pvq_u(N, K + 1)); EC_END; }
 }
 
@@ -495,7 +495,7 @@ WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
 {
    i32 e = 0;
    FOR_LANES(i, N) { i32 v = pshr32(X[i], NORM_SHIFT - 14); e = add32(e, (i32)((u32)v * (u32)v)); }
-   i32 E = add32(EPSILON, wv_sum(e));
+   i32 E = add32(EPSILON, wv_sum_n(e, N));
    int k = celt_ilog2(E) >> 1;
    i32 t = vshr32(E, 2 * (k - 7));
    i16 g = (i16)mult32_32_q31(fx_rsqrt_norm(t), gain);

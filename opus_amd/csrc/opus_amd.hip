@@ -52,13 +52,17 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
 oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
-      int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */)
+      int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
+      int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
+      const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
    for (;;) {
-      const int s = oa_queue_pop(queue);
-      if (s >= nstreams) break;
+      const int i_ = oa_queue_pop(queue);
+      if (i_ >= nstreams) break;
+      const int s = first + i_ * stride;
+      if (budget) { max_data_bytes = wv_uni(budget[s]); if (max_data_bytes <= 0) continue; }
       if (threadIdx.x == 0) L->g = scratch + blockIdx.x;
       __syncthreads();
       OaStream *gs = streams + s;
@@ -147,7 +151,7 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
  * the per-frame HBM scratch (scratch_bytes per wave) belongs to the wave.  list != NULL: the calls the split path's front kernel turned away (their analysis has run) */
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int nstreams, unsigned *queue,
-      const int *list, const unsigned *list_count, int pkt_off, int pcm_row)
+      const int *list, const unsigned *list_count, int pkt_off, int pcm_row, int first, int stride, const i32 *budget /* as in oa_encode_kernel */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -155,7 +159,8 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
    for (;;) {
       int s = oa_queue_pop(queue);
       if (s >= n) break;
-      if (list) s = list[s];
+      if (list) s = list[s]; else s = first + s * stride;
+      if (budget) { max_data_bytes = wv_uni(budget[s]); if (max_data_bytes <= 0) continue; }
       OaShStream *gs = streams + s;
       const int ch = gs->cfg.channels;
       char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
@@ -621,7 +626,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
          b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back);
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
-         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row);
+         (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row, 0, 1, (const i32 *)nullptr);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -646,11 +651,27 @@ int opusgpu_encode_batch_dev_sig(OpusGpuEncBatch *b, const opus_int16 *d_pcm, co
 /* The same with the reference's look-ahead (src/opus_encoder.c:1247, :2662-2690; src/analysis.c:954): every stream's row of d_pcm (and d_apcm) holds analysis_frame_size >=
  * frame_size samples per channel -- what opus_encode() is handed when OPUS_SET_EXPERT_FRAME_DURATION selects a frame shorter than the caller's buffer -- of which the first
  * frame_size are coded; the tonality analysis runs over the whole row (the part it has not seen yet: OaAnalysis.analysis_offset carries that between calls) */
+static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream, int first, int stride, opus_int32 count, const opus_int32 *d_budget);
 int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size, unsigned char *d_out,
       opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream)
 {
+   if (!b) return OPUS_BAD_ARG;
+   return oa_encode_launch(b, d_pcm, d_apcm, frame_size, analysis_frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, hip_stream, 0, 1, b->n_act, nullptr);
+}
+/* the launch itself.  first / stride / count: the call's streams are the records first, first + stride, ... (count of them; inputs, outputs and d_budget are indexed by the
+ * RECORD, as always); d_budget: per record, this call's max_data_bytes for it (<= 0: the stream sits the call out) -- both for the multistream batch's chained byte budgets
+ * (opus_ms_batch.h), which step through the streams of all encoders in order; such a call takes the one-kernel path */
+static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const opus_int32 *d_apcm, int frame_size, int analysis_frame_size, unsigned char *d_out,
+      opus_int32 out_stride, opus_int32 max_data_bytes, opus_int32 *d_lens, opus_uint32 *d_final_range, void *hip_stream, int first, int stride, opus_int32 count, const opus_int32 *d_budget)
+{
    if (!b || !d_pcm || !d_out || !d_lens || !d_final_range) return OPUS_BAD_ARG;
    if (analysis_frame_size < frame_size) return OPUS_BAD_ARG;
+   const bool subset = first != 0 || stride != 1 || count != b->n_act || d_budget != nullptr;
+   if (count <= 0 || stride < 1 || first < 0 || (long long)first + (long long)(count - 1) * stride >= b->S) return OPUS_BAD_ARG;
+   const opus_int32 n_act_saved = b->n_act;
+   struct Restore { OpusGpuEncBatch *b; opus_int32 n; ~Restore() { b->n_act = n; } } restore_{b, n_act_saved};
+   b->n_act = count;                                                        /* (the grid and the kernels' stream count follow the call's streams) */
    const int pcm_row = analysis_frame_size;
    { const int fr = oa_enc_frame_size_code(b->Fs, b->application, frame_size); if (fr != OPUS_OK) return fr; }
    if (max_data_bytes <= 0) return OPUS_BAD_ARG;
@@ -660,7 +681,8 @@ int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_p
    if (b->kind) {
       /* a launch whose streams are all pinned to the SILK layer (RESTRICTED_SILK, or OPUS_SET_FORCE_MODE(SILK_ONLY) with >= 10 ms frames at <= wideband) never enters the
        * CELT arena and gets the smaller LDS footprint (one more wave per CU) */
-      if (b->cfg_dirty) {
+      if (subset) { b->all_silk_pinned = 0; b->cfg_dirty = true; }
+      else if (b->cfg_dirty) {
          int pinned = 1;
          for (opus_int32 i = 0; pinned && i < b->n_act; i++) {
             const OaShConfig &c = b->h_sh[i].cfg;
@@ -675,12 +697,12 @@ int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_p
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
       const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 1 : 0);
-      if (split_mode && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
+      if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds_pk, s,
             b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, b->d_queue,
-            (const int *)nullptr, (const unsigned *)nullptr, po, pcm_row);
+            (const int *)nullptr, (const unsigned *)nullptr, po, pcm_row, first, stride, (const i32 *)d_budget);
       HIPCHECK(hipGetLastError());
       return OPUS_OK;
    }
@@ -688,7 +710,7 @@ int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const opus_int16 *d_p
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }

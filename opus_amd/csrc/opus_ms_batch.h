@@ -9,8 +9,11 @@
  *   oa_ms_pack_kernel    one wave per encoder: every lane reads one stream's header and derives the Appendix-B length field, a wave scan turns the sizes into
  *                        offsets, then the wave copies packet after packet; the encoder's final range is the XOR over its streams.
  * The byte budget the reference hands to stream s depends on what streams 0..s-1 used (:1016-1026); when the caller's buffer is large enough for every stream
- * to be offered the elementary encoder's own cap, the budgets are all the same and the streams are independent -- that is the case this batch serves (it checks
- * it and answers OPUS_BUFFER_TOO_SMALL otherwise; tight buffers and hard CBR go through the classic entry points).  Mapping families: 0 / 255 (plain), 2 (ambisonics:
+ * to be offered the elementary encoder's own cap, the budgets are all the same and the streams are independent: two encode launches.  A tighter buffer chains them:
+ * the call then steps through the streams in order -- oa_ms_budget_kernel (one lane per encoder) turns what the streams before took into stream k's budget, an
+ * encode launch codes stream k of all B encoders with it (oa_encode_launch: a strided subset of the batch with a per-record budget) -- 2 x streams launches, still
+ * without a host round trip, packets and error codes those of opus_multistream_encode.  Hard CBR (the last stream's rate follows from the bytes left and its packet
+ * is padded to them, :1027, :1048) is answered OPUS_UNIMPLEMENTED here and served by the classic entry points.  Mapping families: 0 / 255 (plain), 2 (ambisonics:
  * elementary encoders forced to CELT), 3 (projection: the mixing matrix applied on the device, opus_ms_dec_batch.h) and 1 (surround: the masking analysis of every
  * encoder and the energy masks of its streams are two more launches per frame, oa_surround_kernel + oa_ms_surround_mask_kernel). */
 #ifndef OPUS_AMD_MS_BATCH_H
@@ -106,12 +109,45 @@ WV_DEV void oa_ms_header(const u8 *p, int len, int *hdr, int *last)
    }
 }
 
+/* The chained byte budgets of opus_multistream_encode_native (src/opus_multistream_encoder.c:1016-1027) for all B encoders, one LANE per encoder: before stream s is coded,
+ * what stream s - 1 took (its packet plus the Appendix-B length field it will carry) joins the encoder's running total, and stream s's byte budget follows from what is
+ * left -- two bytes kept back for each stream still to come (one for the last), one more each at 100 ms, the elementary encoder's own cap, the length field of this stream.
+ * An encoder whose stream failed, or whose budget ran out, stops there like the reference's loop does: its later streams get budget 0 and sit the remaining calls out. */
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_budget_kernel(int s, int ns, int nc, int B, int Fs, int frame_size, int max_data_bytes, const u8 *pkc, const i32 *lc, const u8 *pkm, const i32 *lm, int stride,
+      i32 *tot, i32 *err, i32 *budget_c, i32 *budget_m)
+{
+   const int b = (int)blockIdx.x * 64 + (int)threadIdx.x, nm = ns - nc;
+   if (b >= B) return;
+   i32 t = s == 0 ? 0 : tot[b], e = s == 0 ? 0 : err[b];
+   if (s > 0 && !e) {
+      const int q = s - 1;
+      const u8 *p = q < nc ? pkc + ((size_t)b * nc + q) * stride : pkm + ((size_t)b * nm + (q - nc)) * stride;
+      const int len = q < nc ? lc[b * nc + q] : lm[b * nm + (q - nc)];
+      if (len <= 0) e = len < 0 ? len : OPUS_INTERNAL_ERROR;
+      else { int hdr, last; oa_ms_header(p, len, &hdr, &last); t += len + (last < 252 ? 1 : 2); }
+   }
+   i32 bud = 0;
+   if (!e) {
+      i32 curr_max = max_data_bytes - t;
+      const int resv = 2 * (ns - s - 1) - 1;
+      curr_max -= resv > 0 ? resv : 0;
+      if (Fs / frame_size == 10) curr_max -= ns - s - 1;
+      if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
+      if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
+      if (curr_max <= 0) e = OPUS_BUFFER_TOO_SMALL; else bud = curr_max;
+   }
+   tot[b] = t; err[b] = e;
+   if (s < nc) budget_c[b * nc + s] = bud; else budget_m[b * nm + (s - nc)] = bud;
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 oa_ms_pack_kernel(const u8 *pkc, const i32 *lc, const u32 *rc, int nc, const u8 *pkm, const i32 *lm, const u32 *rm, int nm, int stride,
-      u8 *out, int out_stride, int max_data_bytes, i32 *lens, u32 *rngs)
+      u8 *out, int out_stride, int max_data_bytes, i32 *lens, u32 *rngs, const i32 *err_in /* NULL, or per encoder: the error its chained-budget loop stopped on */)
 {
    const int b = blockIdx.x, ns = nc + nm, lane = threadIdx.x;
    u8 *dst = out + (size_t)b * out_stride;
+   if (err_in && err_in[b]) { if (lane == 0) { lens[b] = err_in[b]; rngs[b] = 0; } return; }
    int at = 0, err = 0;
    u32 rx = 0;
    for (int s0 = 0; s0 < ns; s0 += 64) {
@@ -154,6 +190,7 @@ struct OpusGpuMsEncBatch {
    i32 *d_surround;                                                       /* surround: [B][channels][120] window memory | [B][channels] pre-emphasis memory | [B][channels][21] energies / ratios */
    i16 *d_M, *d_mixed; size_t mixed_cap; i32 *d_apc, *d_apm; size_t apc_cap, apm_cap;      /* mapping family 3 (projection): the mixing matrix [C][C], the mixed input, the un-mixed channels for the analysis */
    u8 *d_pkc, *d_pkm; i32 *d_lc, *d_lm; u32 *d_rc, *d_rm; opus_int32 stride;
+   i32 *d_budget_c, *d_budget_m, *d_tot, *d_err;                          /* chained byte budgets (tight buffers): per elementary stream, per encoder */
    /* staging of the host-pointer entry */
    i16 *d_pcm; size_t pcm_cap; u8 *d_out; size_t out_cap; i32 *d_lens; u32 *d_rng;
 };
@@ -165,7 +202,7 @@ void opusgpu_ms_enc_batch_destroy(OpusGpuMsEncBatch *m)
    if (m->bc) opusgpu_enc_batch_destroy(m->bc);
    if (m->bm) opusgpu_enc_batch_destroy(m->bm);
    (void)hipSetDevice(m->device);
-   void *bufs[] = {m->d_surround, m->d_M, m->d_mixed, m->d_apc, m->d_apm, m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng};
+   void *bufs[] = {m->d_surround, m->d_M, m->d_mixed, m->d_apc, m->d_apm, m->d_chan, m->d_pc, m->d_pm, m->d_pkc, m->d_pkm, m->d_lc, m->d_lm, m->d_rc, m->d_rm, m->d_pcm, m->d_out, m->d_lens, m->d_rng, m->d_budget_c, m->d_budget_m, m->d_tot, m->d_err};
    for (void *p : bufs) if (p) (void)hipFree(p);
    free(m->proto);
    delete m;
@@ -265,9 +302,17 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
    const long long worst = (long long)(m->ns - 1) * (1276 * nf + 3) + OA_MS_FRAME_TMP + 3 * m->ns + 8;
    opus_int32 vbr = 1;
    (void)opus_multistream_encoder_ctl(m->proto, OPUS_GET_VBR_REQUEST, &vbr);
-   if (!vbr) return OPUS_UNIMPLEMENTED;                                   /* hard CBR chains the streams' budgets: classic entry points */
-   if (max_data_bytes < worst) return OPUS_BUFFER_TOO_SMALL;
+   if (!vbr) return OPUS_UNIMPLEMENTED;                                   /* hard CBR: the last stream's rate follows from the bytes left and its packet is padded to them (:1027, :1048): classic entry points */
+   opus_int32 smallest_packet = m->ns * 2 - 1;
+   if (Fs / frame_size == 10) smallest_packet += m->ns;
+   if (max_data_bytes < smallest_packet) return OPUS_BUFFER_TOO_SMALL;      /* (:898-906) */
+   const bool chained = max_data_bytes < worst;                           /* some stream's budget may bind: the streams are stepped in order, each with the bytes its predecessors left (:1016-1027) */
    HIPCHECK(hipSetDevice(m->device));
+   if (chained && !m->d_tot) {
+      const size_t nstr = (size_t)m->B * m->ns;
+      if (hipMalloc((void **)&m->d_budget_c, nstr * 4 + 4) != hipSuccess || hipMalloc((void **)&m->d_budget_m, nstr * 4 + 4) != hipSuccess ||
+          hipMalloc((void **)&m->d_tot, (size_t)m->B * 4) != hipSuccess || hipMalloc((void **)&m->d_err, (size_t)m->B * 4) != hipSuccess) return OPUS_ALLOC_FAIL;
+   }
    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : (m->bc ? m->bc->stream : m->bm->stream);
    if (frame_size != m->last_frame_size) {                                /* per-stream rates depend on the frame rate (rate_allocation :702): refresh on change */
       std::vector<opus_int32> rates((size_t)m->ns);
@@ -309,10 +354,25 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
    }
    hipLaunchKernelGGL(oa_ms_split_kernel, dim3((unsigned)(m->B * m->ns)), dim3(64), 0, s, src, frame_size, m->nch, (const i32 *)m->d_chan, m->nc, m->nm, m->d_pc, m->d_pm);
    HIPCHECK(hipGetLastError());
-   if (m->nc) { const int r = opusgpu_encode_batch_dev_sig(m->bc, m->d_pc, m->d_M ? m->d_apc : nullptr, frame_size, m->d_pkc, m->stride, 1276 * 6, m->d_lc, m->d_rc, s); if (r != OPUS_OK) return r; }
-   if (m->nm) { const int r = opusgpu_encode_batch_dev_sig(m->bm, m->d_pm, m->d_M ? m->d_apm : nullptr, frame_size, m->d_pkm, m->stride, 1276 * 6, m->d_lm, m->d_rm, s); if (r != OPUS_OK) return r; }
+   if (!chained) {
+      if (m->nc) { const int r = opusgpu_encode_batch_dev_sig(m->bc, m->d_pc, m->d_M ? m->d_apc : nullptr, frame_size, m->d_pkc, m->stride, 1276 * 6, m->d_lc, m->d_rc, s); if (r != OPUS_OK) return r; }
+      if (m->nm) { const int r = opusgpu_encode_batch_dev_sig(m->bm, m->d_pm, m->d_M ? m->d_apm : nullptr, frame_size, m->d_pkm, m->stride, 1276 * 6, m->d_lm, m->d_rm, s); if (r != OPUS_OK) return r; }
+   } else {
+      /* stream after stream, all B encoders at once: the budget kernel (one lane per encoder) turns what the streams before took into this stream's byte budget, then
+       * the B records of stream k -- every nc-th of the coupled batch, or every nm-th of the mono batch -- are coded with it.  2 x streams launches instead of 2: what
+       * a caller with a tight buffer pays for staying on the device */
+      for (int k = 0; k < m->ns; k++) {
+         hipLaunchKernelGGL(oa_ms_budget_kernel, dim3((unsigned)((m->B + 63) / 64)), dim3(64), 0, s, k, m->ns, m->nc, m->B, (int)Fs, frame_size, (int)max_data_bytes,
+               (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (int)m->stride, m->d_tot, m->d_err, m->d_budget_c, m->d_budget_m);
+         const int r = k < m->nc
+            ? oa_encode_launch(m->bc, m->d_pc, m->d_M ? m->d_apc : nullptr, frame_size, frame_size, m->d_pkc, m->stride, OA_MS_FRAME_TMP, m->d_lc, m->d_rc, s, k, m->nc, m->B, m->d_budget_c)
+            : oa_encode_launch(m->bm, m->d_pm, m->d_M ? m->d_apm : nullptr, frame_size, frame_size, m->d_pkm, m->stride, OA_MS_FRAME_TMP, m->d_lm, m->d_rm, s, k - m->nc, m->nm, m->B, m->d_budget_m);
+         if (r != OPUS_OK) return r;
+      }
+   }
    hipLaunchKernelGGL(oa_ms_pack_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
-         (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range);
+         (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range,
+         (const i32 *)(chained ? m->d_err : nullptr));
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }

@@ -5,7 +5,9 @@ import ctypes, numpy as np
 import capi
 from test_kernel_emu_silkdec import speechy
 
-def check(which, B, channels, streams, coupled, mapping, application, family=255, frames=4, frame=960, Fs=48000, bitrate=None, ctl=()):
+def check(which, B, channels, streams, coupled, mapping, application, family=255, frames=4, frame=960, Fs=48000, bitrate=None, ctl=(), max_bytes=None):
+    """max_bytes: the caller's buffer (a list: one value per frame, cycled) -- below the size at which every stream is offered the elementary encoder's own cap the reference
+    chains the streams' byte budgets (opus_multistream_encoder.c:1016-1027) and so does the batch; error codes (a buffer too small for the packet) must agree as well"""
     L = capi.load(which); R = capi.load("ref")
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.opusgpu_ms_enc_batch_create.restype = vp
@@ -40,12 +42,14 @@ def check(which, B, channels, streams, coupled, mapping, application, family=255
     for f in range(frames):
         pcm = np.ascontiguousarray(np.stack([x[f * frame:(f + 1) * frame] for x in sig]).astype(np.int16))
         assert pcm.shape == (B, frame, channels)
-        r = L.opusgpu_ms_encode_batch(m, pcm.ctypes.data, frame, out.ctypes.data, cap, cap, lens.ctypes.data, rng.ctypes.data)
-        assert r == 0, r
+        mb = cap if max_bytes is None else int(max_bytes[f % len(max_bytes)])
+        r = L.opusgpu_ms_encode_batch(m, pcm.ctypes.data, frame, out.ctypes.data, cap, mb, lens.ctypes.data, rng.ctypes.data)
         for b in range(B):
-            n = R.opus_multistream_encode(refs[b], pcm[b].ctypes.data, frame, o.ctypes.data, cap)
+            n = R.opus_multistream_encode(refs[b], pcm[b].ctypes.data, frame, o.ctypes.data, mb)
+            if r != 0: assert n == r, (f, b, n, r); continue                    # the whole call turned away (a buffer below the smallest packet): the reference says the same for every encoder
             fr = ctypes.c_uint32(); R.opus_multistream_encoder_ctl.argtypes = [vp, ci, vp]; R.opus_multistream_encoder_ctl(refs[b], 4031, ctypes.byref(fr))
-            assert n == int(lens[b]), (f, b, n, int(lens[b]))
+            assert n == int(lens[b]), (f, b, mb, n, int(lens[b]))
+            if n <= 0: continue
             assert bytes(out[b, :n]) == bytes(o[:n]), (f, b, [k for k in range(n) if out[b, k] != o[k]][:6])
             assert fr.value == int(rng[b]), (f, b)
     L.opusgpu_ms_enc_batch_destroy(m)
@@ -61,6 +65,16 @@ CASES = [
     dict(B=2, channels=40, streams=40, coupled=0, mapping=list(range(40)), application=2049, bitrate=40 * 64000, frames=3),              # config-5 shape, 80 mono AUDIO streams: CELT-only frames, kept by the front kernel and coded by the back kernel
     dict(B=2, channels=36, streams=36, coupled=0, mapping=list(range(36)), application=2048, Fs=16000, frame=320, bitrate=36 * 20000, frames=3),   # 72 VOIP streams at 16 kHz: SILK frames through front / quantiser / back
     dict(B=2, channels=48, streams=32, coupled=16, mapping=list(range(48)), application=2049, bitrate=32 * 48000, frames=3),             # 64 streams, half of them coupled pairs: hybrid / SILK / CELT as the rate split decides
+]
+
+# tight buffers: the streams' byte budgets chain (each stream is offered what its predecessors left)
+TIGHT_CASES = [
+    dict(B=3, channels=6, streams=4, coupled=2, mapping=[0, 1, 2, 3, 4, 5], application=2049, bitrate=256000, frames=8, max_bytes=[700, 400, 2000, 260, 120, 60, 9000, 30]),
+    dict(B=2, channels=5, streams=5, coupled=0, mapping=[0, 1, 2, 3, 4], application=2049, bitrate=5 * 64000, frames=6, max_bytes=[500, 300, 200, 100, 40, 9]),       # ... down to the smallest legal packet (2 * streams - 1 bytes)
+    dict(B=2, channels=4, streams=3, coupled=1, mapping=[0, 1, 2, 3], application=2051, bitrate=200000, frame=480, frames=6, max_bytes=[300, 150, 80, 1000, 20, 8]),
+    dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000, frames=6, max_bytes=[120, 60, 30, 200, 10, 4]),
+    dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=4, max_bytes=[900, 500, 250, 2500]),    # multi-frame elementary packets
+    dict(B=2, channels=4, streams=4, coupled=0, mapping=[0, 1, 2, 3], application=2049, bitrate=4 * 96000, frame=4800, frames=3, max_bytes=[3000, 1200, 7]),         # 100 ms: one more byte kept back per stream
 ]
 
 # ---- projection (mapping family 3) encoder batch and the multistream / projection decoder batches ----

@@ -26,3 +26,6 @@ def test_gpu_projection_batches(channels, analysis):
 def test_gpu_surround_batch(channels): ms_batch_check.check_surround("gpu", B=3, channels=channels, bitrate=channels * 56000, frames=8)
 
 def test_gpu_ms_decode_batch_turns_an_over_long_elementary_packet_away_whole(): ms_batch_check.check_ms_decode_slot_limit("gpu")
+
+@pytest.mark.parametrize("case", range(len(ms_batch_check.TIGHT_CASES)))
+def test_gpu_ms_batch_chained_byte_budgets(case): ms_batch_check.check("gpu", **ms_batch_check.TIGHT_CASES[case])

@@ -18,3 +18,6 @@ def test_emu_projection_batches(channels, analysis):
 def test_emu_surround_batch(channels): ms_batch_check.check_surround("emu", B=2, channels=channels, bitrate=channels * 56000)
 
 def test_emu_ms_decode_batch_turns_an_over_long_elementary_packet_away_whole(): ms_batch_check.check_ms_decode_slot_limit("emu")
+
+@pytest.mark.parametrize("case", range(len(ms_batch_check.TIGHT_CASES)))
+def test_emu_ms_batch_chained_byte_budgets(case): ms_batch_check.check("emu", **ms_batch_check.TIGHT_CASES[case])
