@@ -22,14 +22,14 @@ WV_DEV i32 inner_prod_norm_shift_w(const WV_LDS i32 *x, const WV_LDS i32 *y, int
 {
    i64 sum = 0;
    FOR_LANES(i, len) sum += x[i] * (i64)y[i];
-   return (i32)(wv_sum64_n(sum, len) >> 2 * (NORM_SHIFT - 14));
+   return (i32)(wv_sum64(sum) >> 2 * (NORM_SHIFT - 14));
 }
 
 WV_DEV i32 inner_prod_norm_shift_gw(const i32 *x, const WV_LDS i32 *y, int len)         /* whole wave, x in HBM */
 {
    i64 sum = 0;
    FOR_LANES(i, len) sum += x[i] * (i64)y[i];
-   return (i32)(wv_sum64_n(sum, len) >> 2 * (NORM_SHIFT - 14));
+   return (i32)(wv_sum64(sum) >> 2 * (NORM_SHIFT - 14));
 }
 
 /* compute_band_energies + amp2Log2 of the channel resident in W: one lane per band */

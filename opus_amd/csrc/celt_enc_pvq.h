@@ -181,7 +181,7 @@ WV_DEV i32 stereo_itheta_wave(const WV_LDS i32 *X, const WV_LDS i32 *Y, int ster
          Emid = mac16_16(Emid, m, m);
          Eside = mac16_16(Eside, s, s);
       }
-      Emid = wv_sum_n(Emid, N); Eside = wv_sum_n(Eside, N);
+      Emid = wv_sum(Emid); Eside = wv_sum(Eside);
    } else {
       Emid = inner_prod_norm_shift_w(X, X, N);
       Eside = inner_prod_norm_shift_w(Y, Y, N);
@@ -352,8 +352,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
    const int lane = wv_lane();
    i64 e2 = 0;
    for (int t = 0; t < NR; t++) e2 += x[t] * (i64)x[t];
-   const int nl = NR == 1 ? N : 64;                                        /* lanes that carry coefficients (the others hold zeros): short bands reduce inside their row */
-   int shift = (celt_ilog2(1 + (i32)(wv_sum64_n(e2, nl) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
+   int shift = (celt_ilog2(1 + (i32)(wv_sum64(e2) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
    shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
    bool vld[NR]; i32 sg[NR], y[NR];
    i32 xsum = 0;
@@ -365,7 +364,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
    i32 xy = 0; i16 yy = 0;
    int pulsesLeft = K;
    if (K > (N >> 1)) {
-      i32 sum = wv_sum_n(xsum, nl);
+      i32 sum = wv_sum(xsum);
       if (sum <= K) {
          for (int t = 0; t < NR; t++) x[t] = 0;
          if (lane == 0) x[0] = QC16(1.f, 14);
@@ -377,9 +376,9 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
          q[t] = mult16_16_q15(x[t], rcp);
          yyp = mac16_16(yyp, q[t], q[t]); xyp = mac16_16(xyp, x[t], q[t]); y[t] = 2 * q[t]; qs += q[t];
       }
-      yy = (i16)wv_sum_n(yyp, nl);
-      xy = wv_sum_n(xyp, nl);
-      pulsesLeft -= wv_sum_n(qs, nl);
+      yy = (i16)wv_sum(yyp);
+      xy = wv_sum(xyp);
+      pulsesLeft -= wv_sum(qs);
    }
    if (pulsesLeft > N + 3) {
       i16 tmp = (i16)pulsesLeft;
@@ -389,6 +388,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
       if (lane == 0) q[0] += pulsesLeft;
       pulsesLeft = 0;
    }
+   const int nl = NR == 1 ? N : 64;
    for (int i = 0; i < pulsesLeft; i++) {
       int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
       yy = add16(yy, 1);
@@ -404,7 +404,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
          }
       }
       int owner, slot = 0;
-      if (NR == 1) owner = wv_argmax_ratio_fast(bn, bd, vld[0], nl);
+      if (NR == 1) owner = wv_argmax_ratio_packed(bn, bd, vld[0], nl);
       else {
          /* global index order is (slot, lane): find the maximal ratio first, then the lowest slot that attains it, then the lowest lane */
          const int any = wv_argmax_ratio_packed(bn, bd, vld[0], 64);
@@ -428,7 +428,7 @@ template <int NR> WV_DEV i32 op_pvq_search_regs(i32 (&x)[NR], i32 (&q)[NR], int 
 
 /* encode_pulses (cwrs.c:444-465): index = (y[n-1]<0) + sum_j U(n-j, k_{j+1}) + [y_j<0] U(n-j, k_j+1), k_j = sum_{i>=j}|y_i|.
  * Suffix sums of |y| come from a wave scan per register; every table read is then independent (issued back to back). */
-template <int NR> WV_DEV void encode_pulses_regs(WV_LDS FrameLds *L, const i32 (&yv)[NR], int N, int K)
+template <int NR> WV_DEV void encode_pulses_regs(WV_LDS FrameLds *L, const i32 (&yv)[NR], int N, int K, u32 ft /* V(N, K) = U(N, K) + U(N, K + 1): loaded by the caller before the search, out of the way of this stage's own table round trip */)
 {
    const int lane = wv_lane();
    i32 a[NR], incl[NR], tot[NR];
@@ -444,8 +444,8 @@ template <int NR> WV_DEV void encode_pulses_regs(WV_LDS FrameLds *L, const i32 (
       } else if (j == N - 1) idx += yv[t] < 0;
       above += tot[t];
    }
-   idx = (u32)wv_sum_n((i32)idx, NR == 1 ? N : 64);
-   LANE0 { EC_BEGIN; k_ec_enc_uint(EC_PASS, idx, pvq_u(N, K) + pvq_u(N, K + 1)); EC_END; }
+   idx = wv_sumu(idx);
+   LANE0 { EC_BEGIN; k_ec_enc_uint(EC_PASS, idx, ft); EC_END; }
 }
 
 /* alg_quant (vq.c:552): load the band once, rotate / search / index / resynthesise in registers, store once */
@@ -455,6 +455,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
    i32 v[NR], q[NR];
    K_DUMP("pvqX", X, N * 4);
    K_TIC();
+   const u32 ft = pvq_u(N, K) + pvq_u(N, K + 1);                            /* (uniform addresses: in flight while the band is rotated and searched) */
    for (int t = 0; t < NR; t++) v[t] = lane + 64 * t < N ? X[lane + 64 * t] : 0;
    exp_rotation_regs(v, X, N, 1, B, K, spread);
    K_TOC(16);
@@ -470,7 +471,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
 #ifdef K_DUMP_ENABLED
    { WV_LDS i32 *iy = L->BC.q.iy; wv_sync(); for (int t = 0; t < NR; t++) if (lane + 64 * t < N) iy[lane + 64 * t] = q[t]; wv_sync(); K_DUMP("iy", iy, N * 4); K_DUMPI("pvqK", K); }
 #endif
-   encode_pulses_regs(L, q, N, K);
+   encode_pulses_regs(L, q, N, K, ft);
    K_TOC(18);
    if (resynth) {
       int k = celt_ilog2(yy) >> 1;
@@ -495,7 +496,7 @@ WV_DEV void renormalise_vector_wave(WV_LDS i32 *X, int N, i32 gain)
 {
    i32 e = 0;
    FOR_LANES(i, N) { i32 v = pshr32(X[i], NORM_SHIFT - 14); e = add32(e, (i32)((u32)v * (u32)v)); }
-   i32 E = add32(EPSILON, wv_sum_n(e, N));
+   i32 E = add32(EPSILON, wv_sum(e));
    int k = celt_ilog2(E) >> 1;
    i32 t = vshr32(E, 2 * (k - 7));
    i16 g = (i16)mult32_32_q31(fx_rsqrt_norm(t), gain);
@@ -519,10 +520,27 @@ WV_DEV BandCfg cfg_uni(BandCfg c)
 
 /* one row of the pulse cache (rate.h:48-66 get_pulses/bits2pulses/pulses2bits): cache[0..40] for (LM, band) held one entry per
  * lane, so the bisection and every later lookup are v_readlane's instead of dependent byte loads from memory */
+/* The five rows a band's partitions can ask for (LM + 1 = 0 .. 4: every split halves the band) are staged in LDS once per band -- L->scr is free during the PVQ -- by
+ * quant_all_bands: ONE global-memory round trip per band (all five rows in flight together) instead of two dependent ones (index, then row) per partition call, of which a
+ * frame has some three hundred.  The wave is latency-bound here: its time is the sum of its round trips. */
+#define PVQ_ROW_STRIDE 64
+WV_DEV void cache_rows_stage(WV_LDS FrameLds *L, int band)
+{
+   WV_LDS u8 *rows = (WV_LDS u8 *)L->scr;
+   wv_sync();
+   for (int t = wv_lane(); t < 5 * PVQ_ROW_STRIDE; t += WV_WIDTH) {
+      const int d = t / PVQ_ROW_STRIDE, e = t - d * PVQ_ROW_STRIDE;
+      const int off = ct_cache_index[d * OA_NB_EBANDS + band];
+      rows[t] = ct_cache_bits[imax(0, imin(off + imin(e, 40), (int)sizeof(ct_cache_bits) - 1))];   /* (the last rows are shorter than 41 entries: the lanes beyond a row's end read values nobody uses, but stay inside the table) */
+   }
+   wv_sync();
+}
+WV_DEV i32 cache_row_lds(WV_LDS FrameLds *L, int LM) { return (i32)((const WV_LDS u8 *)L->scr)[(LM + 1) * PVQ_ROW_STRIDE + imin(wv_lane(), 40)]; }
+/* (the decoder's partitions -- celt_dec_bands.h -- read their row from the table: its LDS layout has no such slot) */
 WV_DEV i32 cache_row_load(int band, int LM)
 {
    const int off = ct_cache_index[(LM + 1) * OA_NB_EBANDS + band];
-   return (i32)ct_cache_bits[imin(off + imin(wv_lane(), 40), (int)sizeof(ct_cache_bits) - 1)];      /* (the last rows are shorter than 41 entries: the lanes beyond a row's end read values nobody uses, but stay inside the table) */
+   return (i32)ct_cache_bits[imin(off + imin(wv_lane(), 40), (int)sizeof(ct_cache_bits) - 1)];
 }
 WV_DEV int row_bits2pulses(i32 row, int bits)
 {
@@ -650,7 +668,7 @@ WV_DEV i32x4 quant_partition_body(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining
    int B0 = B;
    const int i = cfg.i, spread = cfg.spread;
    unsigned cm = 0;
-   const i32 row = cache_row_load(i, LM);
+   const i32 row = cache_row_lds(L, LM);
    bool split = LM != -1 && b > wv_bcast(row, wv_bcast(row, 0)) + 12 && N > 2;
    if constexpr (DEPTH < 4) {
       if (split) {
@@ -941,6 +959,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       WV_LDS i32 *Y;
       unsigned x_cm, y_cm;
       cfg.i = i;
+      cache_rows_stage(L, i);
       last = (i == end - 1);
       const i32 *Xg = X_ + M * ct_eBands[i], *Yg = Y_ != 0 ? Y_ + M * ct_eBands[i] : 0;
       Y = Y_ != 0 ? Yb : 0;

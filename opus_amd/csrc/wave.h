@@ -81,32 +81,11 @@ WV_DEV int32_t wv_sum(int32_t v)
    return __builtin_amdgcn_readlane(v, 63);
 }
 WV_DEV uint32_t wv_sumu(uint32_t v) { return (uint32_t)wv_sum((int32_t)v); }
-/* the same when only the first nlanes (uniform) lanes carry anything (the lanes behind them up to the end of their row of 16 hold zero): a band of <= 16 coefficients -- most
- * of the PVQ's partitions -- is summed inside its row and the two cross-row stages are skipped */
-WV_DEV int32_t wv_sum_n(int32_t v, int nlanes)
-{
-   v += WV_DPP(0, v, WV_DPP_QP_1032, 0xf);
-   v += WV_DPP(0, v, WV_DPP_QP_2301, 0xf);
-   v += WV_DPP(0, v, WV_DPP_ROW_ROR4, 0xf);
-   v += WV_DPP(0, v, WV_DPP_ROW_ROR8, 0xf);
-   if (nlanes <= 16) return __builtin_amdgcn_readlane(v, 0);
-   v += WV_DPP(0, v, WV_DPP_BCAST15, 0xa);
-   if (nlanes <= 32) return __builtin_amdgcn_readlane(v, 31);
-   v += WV_DPP(0, v, WV_DPP_BCAST31, 0xc);
-   return __builtin_amdgcn_readlane(v, 63);
-}
 WV_DEV int64_t wv_sum64(int64_t v)
 {
    /* two independent 32-bit lanes of work; carries are rebuilt exactly by summing 16-bit quarters */
    uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
    uint32_t a = wv_sumu(lo & 0xffff), b = wv_sumu(lo >> 16), c = wv_sumu(hi & 0xffff), d = wv_sumu(hi >> 16);
-   uint64_t r = (uint64_t)a + ((uint64_t)b << 16) + ((uint64_t)c << 32) + ((uint64_t)d << 48);
-   return (int64_t)r;
-}
-WV_DEV int64_t wv_sum64_n(int64_t v, int nlanes)
-{
-   uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
-   uint32_t a = (uint32_t)wv_sum_n((int32_t)(lo & 0xffff), nlanes), b = (uint32_t)wv_sum_n((int32_t)(lo >> 16), nlanes), c = (uint32_t)wv_sum_n((int32_t)(hi & 0xffff), nlanes), d = (uint32_t)wv_sum_n((int32_t)(hi >> 16), nlanes);
    uint64_t r = (uint64_t)a + ((uint64_t)b << 16) + ((uint64_t)c << 32) + ((uint64_t)d << 48);
    return (int64_t)r;
 }
@@ -189,31 +168,5 @@ WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nl
    }
    const bool hit = valid && (mine >> 16) * (best & 0xffffu) == (best >> 16) * (mine & 0xffffu);
    return (int)__builtin_ctzll(__ballot(hit));
-}
-/* The same decision, found cheaply: the ratios as floats (v_rcp_f32 + one multiply: relative error below 2^-21), their wave maximum on the DPP network with v_max_f32 (one
- * instruction per stage), and every lane within 2^-18 of it a candidate -- the exact maxima are all among them whatever the rounding did.  One candidate (the rule: two
- * different ratios of 15-bit operands that close are rare, exact ties rarer) is the winner; several go through the exact cross-multiplying tree above, restricted to the
- * candidates, which also breaks ties towards the lowest lane.  The result never depends on a float comparison. */
-WV_DEV int wv_argmax_ratio_fast(uint32_t num, uint32_t den, bool valid, int nlanes)
-{
-   float r = valid ? (float)num * __builtin_amdgcn_rcpf((float)den) : -1.0f, m = r, t;
-#define WV_MAXF_STEP(ctrl, rmask) do { t = __builtin_bit_cast(float, WV_DPP(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), ctrl, rmask)); m = __builtin_fmaxf(m, t); } while (0)
-   WV_MAXF_STEP(WV_DPP_QP_1032, 0xf);
-   WV_MAXF_STEP(WV_DPP_QP_2301, 0xf);
-   WV_MAXF_STEP(WV_DPP_ROW_ROR4, 0xf);
-   WV_MAXF_STEP(WV_DPP_ROW_ROR8, 0xf);
-   int mi;
-   if (nlanes <= 16) mi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0);
-   else {
-      WV_MAXF_STEP(WV_DPP_BCAST15, 0xa);
-      if (nlanes <= 32) mi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31);
-      else { WV_MAXF_STEP(WV_DPP_BCAST31, 0xc); mi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63); }
-   }
-#undef WV_MAXF_STEP
-   const float thr = __builtin_bit_cast(float, mi) * 0.99999619f;                     /* 1 - 2^-18 */
-   const bool cand = valid && r >= thr;
-   const unsigned long long c = __ballot(cand);
-   if (__builtin_popcountll(c) == 1) return (int)__builtin_ctzll(c);
-   return wv_argmax_ratio_packed(num, den, cand, nlanes);
 }
 #endif

@@ -100,8 +100,6 @@ WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return wv_lane
 WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
 WV_DEV uint32_t wv_sumu(uint32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return s; }
 WV_DEV int64_t wv_sum64(int64_t v) { auto t = emu_xchg(v); uint64_t s = 0; for (int i = 0; i < 64; i++) s += (uint64_t)t[i][0]; return (int64_t)s; }
-WV_DEV int32_t wv_sum_n(int32_t v, int nlanes) { (void)nlanes; return wv_sum(v); }
-WV_DEV int64_t wv_sum64_n(int64_t v, int nlanes) { (void)nlanes; return wv_sum64(v); }
 WV_DEV int32_t wv_max(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[0][0]; for (int i = 1; i < 64; i++) if ((int32_t)t[i][0] > m) m = (int32_t)t[i][0]; return m; }
 WV_DEV int32_t wv_min(int32_t v) { auto t = emu_xchg(v); int32_t m = (int32_t)t[0][0]; for (int i = 1; i < 64; i++) if ((int32_t)t[i][0] < m) m = (int32_t)t[i][0]; return m; }
 WV_DEV uint32_t wv_or(uint32_t v) { auto t = emu_xchg(v); uint32_t m = 0; for (int i = 0; i < 64; i++) m |= (uint32_t)t[i][0]; return m; }
@@ -119,7 +117,6 @@ WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nl
    }
    return best;
 }
-WV_DEV int wv_argmax_ratio_fast(uint32_t num, uint32_t den, bool valid, int nlanes) { return wv_argmax_ratio_packed(num, den, valid, nlanes); }   /* same contract (wave.h finds it through a float pre-filter) */
 WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
 {
    auto t = emu_xchg(num, den, idx);
