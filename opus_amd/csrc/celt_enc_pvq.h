@@ -108,7 +108,7 @@ WV_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)
    const i16 exp2_table8[8] = {16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048};
    int qn, qb, N2 = 2 * N - 1;
    if (stereo && N == 2) N2--;
-   qb = (b + N2 * offset) / N2;
+   qb = fx_sdiv24(b + N2 * offset, N2);
    qb = imin(b - pulse_cap - (4 << BITRES), qb);
    qb = imin(8 << BITRES, qb);
    if (qb < (1 << BITRES >> 1)) qn = 1;
@@ -334,7 +334,7 @@ template <int NR> WV_DEV void exp_rotation_regs(i32 (&v)[NR], WV_LDS i32 *T, int
       while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
    }
    for (int t = 0; t < NR; t++) v[t] = pshr32(v[t], NORM_SHIFT - 14);       /* norm_scaledown once (up/down between passes cancels exactly) */
-   len = (u32)len / (u32)stride;
+   len = fx_div_pow2(len, stride);                                          /* stride = the band's block count: a power of two */
    if (dir < 0) {
       if (stride2) rot_pass_any(v, T, stride, len, stride2, s, c);
       rot_pass_any(v, T, stride, len, 1, c, s);
@@ -463,7 +463,7 @@ template <int NR> WV_DEV unsigned alg_quant_regs(WV_LDS FrameLds *L, WV_LDS i32 
    K_TOC(17);
    unsigned cm = 1;
    if (B > 1) {
-      int N0 = (u32)N / (u32)B;
+      int N0 = fx_div_pow2(N, B);
       u32 m = 0;
       for (int t = 0; t < NR; t++) if (q[t] != 0) m |= 1u << ((u32)(lane + 64 * t) / (u32)N0);
       cm = wv_or(m);
@@ -576,7 +576,7 @@ WV_DEVN i32x8 compute_theta_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_
       if (!stereo || cfg.theta_round == 0) {
          itheta = (itheta * (i32)qn + 8192) >> 14;
          if (!stereo && cfg.avoid_split_noise && itheta > 0 && itheta < qn) {
-            int unquantized = (u32)((i32)itheta * 16384) / (u32)qn;
+            int unquantized = (int)fx_udiv24((u32)((i32)itheta * 16384), (u32)qn);
             imid = bitexact_cos((i16)unquantized);
             iside = bitexact_cos((i16)(16384 - unquantized));
             delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
@@ -584,7 +584,8 @@ WV_DEVN i32x8 compute_theta_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_
             else if (delta < -b) itheta = 0;
          }
       } else {
-         int bias = itheta > 8192 ? 32767 / qn : -32767 / qn;
+         const int q32767 = (int)fx_udiv24(32767u, (u32)qn);
+         int bias = itheta > 8192 ? q32767 : -q32767;
          int down = imin(qn - 1, imax(0, (itheta * (i32)qn + bias) >> 14));
          itheta = cfg.theta_round < 0 ? down : down + 1;
       }
@@ -603,7 +604,7 @@ WV_DEVN i32x8 compute_theta_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 remaining_
          }
          EC_END;
       }
-      itheta = (u32)((i32)itheta * 16384) / (u32)qn;
+      itheta = (int)fx_udiv24((u32)((i32)itheta * 16384), (u32)qn);
       if (stereo) {
          if (itheta == 0) intensity_stereo_wave(L, X, Y, i, N);
          else stereo_split_wave(X, Y, N);
@@ -773,7 +774,7 @@ OA_QUANT_BAND_FN i32x4 quant_band_wave(WV_LDS FrameLds *L, BandCfg cfg, i32 rema
    unsigned cm = 0;
    int tf_change = cfg.tf_change;
    longBlocks = B0 == 1;
-   N_B = (u32)N_B / (u32)B;
+   N_B = fx_div_pow2(N_B, B);                                               /* (B: 1, 2, 4, 8 or 16 blocks) */
    if (N == 1) { cm = quant_band_n1_wave(L, cfg, remaining_bits, X, 0, lowband_out); return ret3(cm, remaining_bits, seed); }
    K_TIC();
    if (tf_change > 0) recombine = tf_change;
@@ -969,7 +970,7 @@ WV_DEVN void quant_all_bands_wave(WV_LDS FrameLds *L, int shortBlocks, int sprea
       if (i != start) balance -= tell;
       remaining_bits = total_bits - tell - 1;
       if (i <= codedBands - 1) {
-         curr_balance = balance / imin(3, codedBands - i);
+         curr_balance = fx_sdiv24(balance, imin(3, codedBands - i));
          b = imax(0, imin(16383, imin(remaining_bits + 1, wv_uni(pulses[i]) + curr_balance)));
       } else b = 0;
       if (resynth && (M * ct_eBands[i] - N >= M * ct_eBands[start] || i == start + 1) && (update_lowband || lowband_offset == 0))

@@ -83,6 +83,20 @@ WV_DEV i16 sig2word16(i32 x) { x = pshr32(x, SIG_SHIFT); x = imax(x, -32768); x 
 WV_DEV int ec_ilog(u32 v) { return v ? 32 - __builtin_clz(v) : 0; }
 WV_DEV int celt_ilog2(i32 x) { return ec_ilog((u32)x) - 1; }                    /* mathops.h:352 */
 WV_DEV int celt_zlog2(i32 x) { return x <= 0 ? 0 : celt_ilog2(x); }
+/* n / d for operands whose QUOTIENT stays below 2^20 (n < 2^24, d >= 1): the float estimate n * rcp(d) is within a quarter of the true quotient (v_rcp_f32 is good to 1 ulp,
+ * n and d are exact as floats), so its truncation is the quotient or one off either way and one remainder test settles it -- exact, and a third shorter a dependent chain
+ * than the 32-bit division sequence (reciprocal, Newton step, two corrections) the compiler emits.  The PVQ's control arithmetic (compute_qn, the theta grid, band
+ * budgets) divides small numbers by small numbers several times per partition, on a wave that is latency-bound. */
+WV_DEV u32 fx_udiv24(u32 n, u32 d)
+{
+   u32 q = (u32)((float)n * wv_rcpf((float)d));
+   const i32 r = (i32)(n - q * d);
+   if (r < 0) q--; else if ((u32)r >= d) q++;
+   return q;
+}
+WV_DEV i32 fx_sdiv24(i32 n, i32 d) { const u32 q = fx_udiv24((u32)(n < 0 ? -n : n), (u32)d); return n < 0 ? -(i32)q : (i32)q; }     /* d > 0; truncates towards zero like C */
+/* x / b for b a power of two (block counts) */
+WV_DEV int fx_div_pow2(int x, int b) { return (int)((u32)x >> (ec_ilog((u32)b) - 1)); }
 
 
 /* isqrt32: exact floor(sqrt(v)), celt/mathops.c:45 */

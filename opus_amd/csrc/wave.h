@@ -22,6 +22,7 @@
 #define WV_WIDTH 64
 
 WV_DEV int wv_lane() { return (int)threadIdx.x; }
+WV_DEV float wv_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }           /* v_rcp_f32: 1 ulp */
 /* Ordering of memory traffic between the lanes of the wave (block == wave).  A wavefront executes its LDS and its vector-memory instructions in issue order
  * and all its lanes share one L1, so a later access by any lane observes an earlier write by any other lane without waiting for anything: a wavefront-scope
  * fence (wv_order: a compiler barrier, no s_waitcnt) is all the ordering a one-wave workgroup needs, for LDS and for the per-wave HBM scratch alike.

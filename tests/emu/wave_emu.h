@@ -97,6 +97,7 @@ WV_DEV int32_t wv_uni(int32_t v)
 WV_DEV int32_t wv_shift_down1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = wv_lane(); return me == 63 ? fill : (int32_t)t[me + 1][0]; }
 WV_DEV int32_t wv_shift_up1(int32_t v, int32_t fill) { auto t = emu_xchg(v); int me = wv_lane(); return me == 0 ? fill : (int32_t)t[me - 1][0]; }
 WV_DEV int32_t wv_writelane(int32_t val, int lane, int32_t old) { return wv_lane() == lane ? val : old; }
+WV_DEV float wv_rcpf(float x) { return 1.0f / x; }
 WV_DEV int32_t wv_sum(int32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return (int32_t)s; }
 WV_DEV uint32_t wv_sumu(uint32_t v) { auto t = emu_xchg(v); uint32_t s = 0; for (int i = 0; i < 64; i++) s += (uint32_t)t[i][0]; return s; }
 WV_DEV int64_t wv_sum64(int64_t v) { auto t = emu_xchg(v); uint64_t s = 0; for (int i = 0; i < 64; i++) s += (uint64_t)t[i][0]; return (int64_t)s; }
