@@ -178,7 +178,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 #define OA_SH_FRONT_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
-oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pcm_row)
+oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pcm_row, int pred_split)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -192,11 +192,30 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
       if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)SE_FRONT_ST_OFF; }
       __syncthreads();
       oa_sh_front_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
-            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row);
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row, pred_split);
       __syncthreads();
       kept += conts[s].kind == SH_CONT_FAST;
+      if (pred_split && threadIdx.x == 0 && conts[s].kind == SH_CONT_FAST && conts[s].nq > 0) slow_list[nstreams + atomicAdd(counters + 6, 1u)] = s;      /* the pred kernel's work list: the streams with a SILK job (behind the list of the calls turned away) */
    }
    if (threadIdx.x == 0 && seen) { atomicAdd(counters + 16, kept); atomicAdd(counters + 17, seen - kept); }     /* running totals of the batch (opusgpu_enc_batch_split_stats) */
+}
+/* pipeline mode 3: the prediction stage of every coded channel the front kernel kept (oa_sh_pred_frame, opus_sh_split.h), persistent, 8 waves per SIMD */
+#ifndef OA_SH_PRED_WAVES_PER_EU
+#define OA_SH_PRED_WAVES_PER_EU 8
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_SH_PRED_WAVES_PER_EU)
+oa_sh_pred_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS PredLds *P = (WV_LDS PredLds *)smem;
+   const int n = (int)*list_count;                                       /* streams with a SILK job: none in a batch of CELT-only frames, whose launch of this kernel then costs a few microseconds */
+   for (;;) {
+      const int i = oa_queue_pop(queue);
+      if (i >= n) break;
+      const int s = wv_uni(list[i]);
+      oa_sh_pred_frame(P, streams + s, conts + s);
+      __syncthreads();
+   }
 }
 extern "C" __global__ void __launch_bounds__(64, 2)
 oa_sh_quant_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters)
@@ -328,7 +347,7 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
-   struct { const void *kernel; size_t lds; int per_cu; } occ[4];
+   struct { const void *kernel; size_t lds; int per_cu; } occ[5];
    int device;
    opus_int32 S;
    opus_int32 n_act;                     /* streams a call processes: the first n_act records (== S except under the classic API's call combiner) */
@@ -430,7 +449,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
-   if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 2) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
+   if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 3) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
    b->any_cbr = -1;
    if (request == OPUS_RESET_STATE) {
       /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
@@ -589,7 +608,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    const int n = (int)b->n_act, ch = b->channels;
    if (!b->d_cont) {
       HIPCHECK(hipMalloc((void **)&b->d_cont, sizeof(ShCont) * (size_t)b->S));
-      HIPCHECK(hipMalloc((void **)&b->d_slow_list, sizeof(int) * (size_t)b->S));
+      HIPCHECK(hipMalloc((void **)&b->d_slow_list, 2 * sizeof(int) * (size_t)b->S));         /* [S] the calls the front kernel turned away | [S] the pred kernel's work list */
    }
    { const size_t need = SH_PCM_BYTES(frame_size, ch) * (size_t)b->S; if (need > b->pcm_hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->pcm_hp_cap = need; } }
    static const size_t lds_pad = getenv("OPUS_AMD_SH_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_SH_LDS_PAD")) : 0;   /* occupancy experiments only */
@@ -607,11 +626,13 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    (void)silk_only;
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
    const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
-   int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0;
+   const int pred_split = mode == 3;                                    /* front -> pred -> quantiser -> back */
+   int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0, g_pred = 0;
    { int r = oa_sh_grid(b, 0, (const void *)oa_sh_front_kernel, lds_front, n, &g_front); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 1, kq, lds_q, mode == 2 ? n : (n + 15) / 16, &g_quant); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 2, (const void *)oa_sh_back_kernel, lds_back, n, &g_back); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_full, n, &g_slow); if (r != OPUS_OK) return r; }
+   if (pred_split) { int r = oa_sh_grid(b, 4, (const void *)oa_sh_pred_kernel, sizeof(PredLds), n, &g_pred); if (r != OPUS_OK) return r; }
    size_t need = (size_t)g_front * sizeof(CeltScratch);
    if ((size_t)g_quant * scr_q > need) need = (size_t)g_quant * scr_q;
    if ((size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch);
@@ -619,7 +640,8 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
-         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row);
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, pred_split);
+   if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
@@ -696,7 +718,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser; unset: the kernel pipeline when the launch is wide
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
-      const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 1 : 0);
+      const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 3 : 0);
       if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
@@ -1009,7 +1031,7 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    va_start(ap, request);
    int ret;
    if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
-   else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 2) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
+   else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 3) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
    else if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else { *p = st->pipeline_p2 ? (opus_int32)st->pipeline_p2 - 2 : -1; ret = OPUS_OK; } }
    else if (request == OPUS_SET_ENERGY_MASK_REQUEST) {                                  /* internal (src/opus_private.h): multistream surround masking, 21 values per channel or NULL */
       const opus_int32 *m = va_arg(ap, const opus_int32 *);

@@ -915,6 +915,23 @@ WV_DEV void sh_silk_init_wave(WV_LDS ShLds *L)
 /* The top of opus_encode_native (:1182-1696) for one call: configuration, Opus-layer scalars and SILK state HBM -> LDS, the tonality analysis of the call's input, digital
  * silence / peak energy / stereo width, the call's decisions (sh_layer_decide).  analysed = 1: the analysis of this call's input has run already (the split path's front
  * kernel ran this very function on the stream and then handed the call to the one-kernel path: the analysis state in HBM is the only thing it changed) */
+/* the tonality / music analysis of a call's input (src/opus_encoder.c:1247-1264; the FIXED_POINT build runs it at complexity 10 only); a call the reference turns away before
+ * that (:1231) leaves it alone.  A: 6 KB of LDS (AnLds); gscratch: 1,920 words of the wave's HBM scratch.  (As a kernel of its own ahead of the front kernel -- 64 VGPRs, 25 waves
+ * per CU -- it took the 1.9 ms it saved there: profiles/r05_o; it stays part of the call's opening.) */
+WV_DEV void sh_call_analysis_wave(WV_LDS AnLds *A, OaShStream *gs, int analysis_off, int complexity, int application, int input_depth, int lsb_depth, int CC, int Fs,
+      const i16 *pcm, const i32 *apcm, int frame_size, int analysis_frame_size, int max_data_bytes, i32 *gscratch)
+{
+   if (imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10) return;
+   if (!analysis_off && complexity >= 10 && Fs >= 16000 && application != OA_APP_RESTRICTED_SILK) {
+      LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
+      an_run_analysis_wave(A, &gs->an, pcm, apcm, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, frame_size, CC, Fs, imin(input_depth ? input_depth : 16, lsb_depth), gscratch, &gs->an_info);
+   } else {
+      const int was_initialized = wv_uni(gs->an.initialized);
+      wv_sync();                                                                       /* (every lane has read the flag before any lane clears it) */
+      if (was_initialized) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }                /* tonality_analysis_reset (:1262) */
+      LANE0 { gs->an_info.valid = 0; gs->an_read_pos_bak = -1; }
+   }
+}
 WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, CeltScratch *cs, const i32 *apcm, int analysed, int analysis_frame_size = 0 /* samples per channel behind pcm: the caller's look-ahead (src/opus_encoder.c:1247, :2662-2690); 0 = frame_size */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
@@ -936,18 +953,8 @@ WV_DEV void sh_call_open_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, i
     * outlives a stage; the words in front of it -- among them where this kernel keeps the staged state, SilkEncLds.st_off -- stay); a call the reference turns away before
     * that (:1231) leaves it alone */
    SE_CLK_BEGIN();
-   if (!analysed && !(imin(1276 * 6, max_data_bytes) == 1 && Fs == frame_size * 10)) {
-      if (!wv_uni(L->cfg.analysis_off) && wv_uni(L->cfg.complexity) >= 10 && Fs >= 16000 && wv_uni(L->cfg.application) != OA_APP_RESTRICTED_SILK) {
-         LANE0 { gs->an_read_pos_bak = gs->an.read_pos; gs->an_read_subframe_bak = gs->an.read_subframe; }
-         an_run_analysis_wave((WV_LDS AnLds *)&L->S.u, &gs->an, pcm, apcm, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, frame_size, CC, Fs, imin(wv_uni(L->cfg.input_depth) ? wv_uni(L->cfg.input_depth) : 16, wv_uni(L->cfg.lsb_depth)),
-               (i32 *)cs->X, &gs->an_info);
-      } else {
-         const int was_initialized = wv_uni(gs->an.initialized);
-         wv_sync();                                                                       /* (every lane has read the flag before any lane clears it) */
-         if (was_initialized) { i32 *z = (i32 *)&gs->an; FOR_LANES(i, (int)(sizeof(OaAnalysis) / 4)) z[i] = 0; }                /* tonality_analysis_reset (:1262) */
-         LANE0 { gs->an_info.valid = 0; gs->an_read_pos_bak = -1; }
-      }
-   }
+   if (!analysed) sh_call_analysis_wave((WV_LDS AnLds *)&L->S.u, gs, wv_uni(L->cfg.analysis_off), wv_uni(L->cfg.complexity), wv_uni(L->cfg.application), wv_uni(L->cfg.input_depth), wv_uni(L->cfg.lsb_depth), CC, Fs,
+         pcm, apcm, frame_size, analysis_frame_size, max_data_bytes, (i32 *)cs->X);
    wv_sync();
    SE_CLK_END(23);
    SE_PHASE_START(&L->S);                                                               /* (profiling build: the analysis borrowed the arena the phase clock lives in) */

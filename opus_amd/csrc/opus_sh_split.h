@@ -38,6 +38,7 @@ struct ShCont {
    ShShared sh;
    OaShScalars st;
    ShQuantCh q[2];
+   ShPredIn p[2];                                        /* front -> pred (pipeline mode 3): the prediction stage's input, per coded channel */
    u8 packet[OA_MAX_PACKET + 4];
 };
 
@@ -51,7 +52,7 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
 }
 template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
 WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
-      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0)
+      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame) */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
@@ -121,7 +122,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
       if (p.channelRate_bps > 0) {
          WV_LDS OaSilkEncChannel *c = &E->ch[n];
-         se_frame_analysis_wave(S, c, p.condCoding);
+         se_frame_analysis_wave(S, c, p.condCoding, pred_split ? &ct->p[nq] : (ShPredIn *)nullptr);
          wv_sync();
          {  /* the channel's job for the quantiser kernel */
             ShQuantCh *q = &ct->q[nq];
@@ -167,6 +168,63 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
    }
    wv_sync();
+}
+
+/* ---------------- pred (pipeline mode 3) ---------------- */
+/* The prediction stage of a coded channel -- silk_find_LPC_FIX (two Burg recursions, the NLSF interpolation search), silk_process_NLSFs (the 16-survivor trellis quantiser,
+ * NLSF -> LPC), silk_residual_energy_FIX, silk_process_gains_FIX: find_pred_coefs_FIX.c:115-144, encode_frame_FIX.c:157 -- as a kernel of its own between the front kernel
+ * and the quantiser.  The stage is 43 % of the front kernel's time (profiles/r04_s), a chain of short dependent steps: the wave is latency-bound, so what it needs is
+ * company on its SIMD -- and this stage alone fits 64 VGPRs and 3.5 KB of LDS: 32 waves per CU instead of the front kernel's 16 (mono) / 12 (stereo).  Same stage functions,
+ * templated on the channel type (SePredChan: the dozen fields of OaSilkEncChannel they read); inputs from the call's continuation record (ShPredIn), results into the
+ * quantiser's job (ShQuantCh) and the one piece of stream state the stage owns (prev_NLSFq_Q15). */
+struct SePredChan {
+   i32 predictLPCOrder, nb_subfr, subfr_length, useInterpolatedNLSFs, first_frame_after_reset, speech_activity_Q8, NLSF_MSVQ_Survivors, SNR_dB_Q7, input_tilt_Q15, nStatesDelayedDecision, LastGainIndex, pad_;
+   i16 prev_NLSFq_Q15[16];
+   OaSilkEncIndices indices;
+};
+struct PredLds { SePredChan c; SeEncCtrl ctl; SeLpcWork W; i32 tk[4]; };
+WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct)
+{
+   if (wv_uni(ct->kind) != SH_CONT_FAST) return;
+   const int nq = wv_uni(ct->nq);
+   for (int j = 0; j < nq; j++) {
+      const ShPredIn *in = &ct->p[j]; ShQuantCh *q = &ct->q[j];
+      WV_LDS SePredChan *c = &P->c; WV_LDS SeEncCtrl *ctl = &P->ctl; WV_LDS SeLpcWork *W = &P->W;
+      wv_sync();
+      const int order = wv_uni(in->predictLPCOrder), nb = wv_uni(in->nb_subfr), sl = wv_uni(in->subfr_length);
+      FOR_LANES(i, nb * (sl + order)) W->LPC_in_pre[i] = in->LPC_in_pre[i];
+      FOR_LANES(i, 16) c->prev_NLSFq_Q15[i] = in->prev_NLSFq_Q15[i];
+      FOR_LANES(i, 4) { W->local_gains[i] = in->local_gains[i]; ctl->Gains_Q16[i] = q->fr.Gains_Q16[i]; }
+      sh_copy_words((WV_LDS i32 *)&c->indices, (const i32 *)&q->indices, (int)(sizeof(OaSilkEncIndices) / 4));
+      if (wv_lane() == 0) {
+         c->predictLPCOrder = order; c->nb_subfr = nb; c->subfr_length = sl; c->useInterpolatedNLSFs = in->useInterpolatedNLSFs; c->first_frame_after_reset = in->first_frame_after_reset;
+         c->speech_activity_Q8 = in->speech_activity_Q8; c->NLSF_MSVQ_Survivors = in->NLSF_MSVQ_Survivors; c->SNR_dB_Q7 = in->SNR_dB_Q7; c->input_tilt_Q15 = in->input_tilt_Q15;
+         c->nStatesDelayedDecision = in->nStatesDelayedDecision; c->LastGainIndex = q->LastGainIndex;
+         ctl->LTPredCodGain_Q7 = in->LTPredCodGain_Q7; ctl->coding_quality_Q14 = in->coding_quality_Q14; ctl->input_quality_Q14 = in->input_quality_Q14;
+      }
+      wv_sync();
+      se_find_lpc_wave(c, W, W->LPC_in_pre, wv_uni(in->minInvGain_Q30), W->LPC_res, P->tk);
+      se_process_nlsfs_wave(c, &ctl->PredCoef_Q12[0][0], W);
+      wv_sync();
+      FOR_LANES(i, nb * (sl + order)) W->LPC_in_pre[i] = in->LPC_in_pre[i];          /* (the quantiser has worked in its bytes) */
+      wv_sync();
+      se_residual_energy_wave(ctl->ResNrg, ctl->ResNrgQ, W->LPC_in_pre, &ctl->PredCoef_Q12[0][0], W->local_gains, sl, nb, order, W->LPC_res);
+      LANE0 se_process_gains_l0(c, ctl, wv_uni(q->condCoding));
+      wv_sync();
+      /* results: the quantiser's job, the stream's NLSF memory */
+      FOR_LANES(i, 32) q->fr.PredCoef_Q12[i] = ctl->PredCoef_Q12[i >> 4][i & 15];
+      FOR_LANES(i, 4) { q->fr.Gains_Q16[i] = ctl->Gains_Q16[i]; q->GainsUnq_Q16[i] = ctl->GainsUnq_Q16[i]; }
+      sh_copy_words((i32 *)&q->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
+      { i16 *pn = gs->silk.ch[wv_uni(q->chan)].prev_NLSFq_Q15; FOR_LANES(i, 16) pn[i] = i < order ? W->NLSF_Q15[i] : (i16)0; }
+      if (wv_lane() == 0) {
+         q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Lambda_Q10 = ctl->Lambda_Q10;
+         q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex;
+         /* what silk_Encode reports of the first channel's frame to the Opus layer (enc_API.c:557-562; the hybrid CELT layer reads it as SILKInfo): the quantisation offset
+          * follows the quantOffsetType silk_process_gains_FIX has just decided -- the front kernel's epilogue wrote it from the value before */
+         if (q->chan == 0) ct->sc.offset = se_quantization_offsets_q10[(c->indices.signalType >> 1) * 2 + c->indices.quantOffsetType];
+      }
+      wv_sync();
+   }
 }
 
 /* ---------------- back ---------------- */

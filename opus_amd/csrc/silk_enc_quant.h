@@ -276,7 +276,8 @@ WV_DEVN void se_nlsf_encode_wave(WV_LDS i8 *NLSFIndices, WV_LDS i16 *pNLSF_Q15, 
 }
 
 /* PredCoef_Q12: LDS [2][16]; pNLSF_Q15 = W->NLSF_Q15 (quantised on return) */
-WV_DEV void se_process_nlsfs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS i16 *PredCoef_Q12, WV_LDS SeLpcWork *W)
+/* CH: OaSilkEncChannel, or the few fields of it the prediction stage needs (SePredChan: the pred kernel of the split path, opus_sh_split.h) */
+template <class CH> WV_DEV void se_process_nlsfs_wave(WV_LDS CH *c, WV_LDS i16 *PredCoef_Q12, WV_LDS SeLpcWork *W)
 {
    const int order = c->predictLPCOrder;
    int NLSF_mu_Q20 = sk_mlawb(SE_FIX(0.003, 20), SE_FIX(-0.001, 28), c->speech_activity_Q8);
@@ -312,7 +313,7 @@ WV_DEV void se_process_nlsfs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS i16 *PredCo
 }
 
 /* x = LPC_in_pre; LPC_res: i16[2 * 96] */
-WV_DEVN void se_find_lpc_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
+template <class CH> WV_DEVN void se_find_lpc_wave(WV_LDS CH *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
 {
    const int order = c->predictLPCOrder, subfr_length = c->subfr_length + order;
    const int interp = c->useInterpolatedNLSFs && !c->first_frame_after_reset && c->nb_subfr == 4;
@@ -385,8 +386,18 @@ WV_DEV void se_lpc_in_pre_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl
    wv_sync();
 }
 /* res_pitch = res_pitch_frame, x = x_frame.  LPC_in_pre: i16[4 * 16 + 320]; XX: i32[100 + 20]; LPC_res: i16[192] */
+/* what the prediction stage of the split path's pred kernel starts from (opus_sh_split.h): the outcome of this function's first half -- the LPC analysis' input and its
+ * gain bound -- and the few fields of the channel and its control block the second half and silk_process_gains_FIX read */
+struct ShPredIn {
+   i32 minInvGain_Q30, local_gains[4], LTPredCodGain_Q7, coding_quality_Q14, input_quality_Q14;
+   i32 predictLPCOrder, nb_subfr, subfr_length, useInterpolatedNLSFs, first_frame_after_reset, speech_activity_Q8, NLSF_MSVQ_Survivors, SNR_dB_Q7, input_tilt_Q15, nStatesDelayedDecision;
+   i16 prev_NLSFq_Q15[16];
+   i16 LPC_in_pre[4 * 16 + 320];
+};
+/* pj != NULL (the split path's front kernel): stop after the LPC analysis' input has been worked out (find_pred_coefs_FIX.c:45-101) and hand it, with the gain bound of :103-113,
+ * to the pred kernel, which runs silk_find_LPC_FIX, silk_process_NLSFs, silk_residual_energy_FIX (:115-144) and silk_process_gains_FIX at twice this kernel's occupancy */
 WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
-      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
+      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk, ShPredIn *pj = nullptr)
 {
    const int order = c->predictLPCOrder, nb = c->nb_subfr, sl = c->subfr_length;
    LANE0 {
@@ -416,6 +427,20 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
    else {
       minInvGain_Q30 = se_log2lin(sk_mlawb(16 << 7, (i32)ctl->LTPredCodGain_Q7, SE_FIX(1.0 / 3, 16)));
       minInvGain_Q30 = sk_div32_varQ(minInvGain_Q30, sk_mulww(SE_FIX(1e4f, 0), sk_mlawb(SE_FIX(0.25, 18), SE_FIX(0.75, 18), ctl->coding_quality_Q14)), 14);
+   }
+   if (pj) {
+      wv_sync();
+      FOR_LANES(i, nb * (sl + order)) pj->LPC_in_pre[i] = LPC_in_pre[i];
+      FOR_LANES(i, 16) pj->prev_NLSFq_Q15[i] = c->prev_NLSFq_Q15[i];
+      FOR_LANES(i, 4) pj->local_gains[i] = W->local_gains[i];
+      if (wv_lane() == 0) {
+         pj->minInvGain_Q30 = minInvGain_Q30; pj->LTPredCodGain_Q7 = ctl->LTPredCodGain_Q7; pj->coding_quality_Q14 = ctl->coding_quality_Q14; pj->input_quality_Q14 = ctl->input_quality_Q14;
+         pj->predictLPCOrder = order; pj->nb_subfr = nb; pj->subfr_length = sl; pj->useInterpolatedNLSFs = c->useInterpolatedNLSFs; pj->first_frame_after_reset = c->first_frame_after_reset;
+         pj->speech_activity_Q8 = c->speech_activity_Q8; pj->NLSF_MSVQ_Survivors = c->NLSF_MSVQ_Survivors; pj->SNR_dB_Q7 = c->SNR_dB_Q7; pj->input_tilt_Q15 = c->input_tilt_Q15;
+         pj->nStatesDelayedDecision = c->nStatesDelayedDecision;
+      }
+      wv_sync();
+      return;
    }
    se_find_lpc_wave(c, W, LPC_in_pre, minInvGain_Q30, LPC_res, tk);
    SE_TICK(tk, 14);                                                              /* final A2NLSF */
@@ -464,7 +489,7 @@ WV_DEV void se_gains_dequant(i32 *gain_Q16, const i8 *ind, int *prev_ind_p, int 
 }
 WV_DEV i32 se_gains_ID(const WV_LDS i8 *ind, int nb_subfr) { i32 id = 0; for (int k = 0; k < nb_subfr; k++) id = add32(ind[k], shl32(id, 8)); return id; }
 
-WV_DEV void se_process_gains_l0(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int condCoding)
+template <class CH> WV_DEV void se_process_gains_l0(WV_LDS CH *c, WV_LDS SeEncCtrl *ctl, int condCoding)
 {
    if (c->indices.signalType == SE_TYPE_VOICED) {
       const i32 s_Q16 = -se_sigm_Q15(sk_rround(ctl->LTPredCodGain_Q7 - SE_FIX(12.0, 7), 4));

@@ -33,9 +33,15 @@ def main():
     ap.add_argument("--fuzzers", default="fuzz,fuzz_sparse,fuzz_batch")
     ap.add_argument("--first", type=int, default=8800000); ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--pipeline", type=int, default=-1); ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--rerun-failures-of", default=None, help="a previous sweep's log: run exactly the jobs it logged as FAIL")
     ap.add_argument("--which", default="emu"); ap.add_argument("--log", default=None); ap.add_argument("--timeout", type=int, default=1800)
     a = ap.parse_args()
-    jobs = [(fz, a.first + i, a.which, a.pipeline, a.timeout) for i in range(a.count) for fz in a.fuzzers.split(",")]
+    if a.rerun_failures_of:
+        # the (fuzzer, seed) pairs a previous sweep logged as FAIL (jobs that died while the sources were being edited under a running sweep, or real finds since fixed), once more
+        pairs = sorted({(l.split()[1], int(l.split()[2])) for l in open(a.rerun_failures_of) if l.startswith("FAIL ")})
+        jobs = [(fz, seed, a.which, a.pipeline, a.timeout) for fz, seed in pairs]
+    else:
+        jobs = [(fz, a.first + i, a.which, a.pipeline, a.timeout) for i in range(a.count) for fz in a.fuzzers.split(",")]
     log = open(a.log, "a") if a.log else None
     def say(s):
         print(s, flush=True)

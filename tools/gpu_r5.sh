@@ -25,6 +25,14 @@ bench5) timeout 300 python bench.py $B --config 5 > $O/bench5.log 2>&1 ;;
 decode) for f in ${DEC_FAST_MODES:-0 1}; do for c in 2 3 4; do OPUS_AMD_DEC_FAST=$f timeout 120 python bench.py $B --config $c --decode > $O/decode${c}_fast$f.log 2>&1; done; done ;;
 dectests) timeout 400 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_silkdec.py tests/test_gpu_float_decoder_gate.py tests/test_gpu_ms_batch.py -x -q --timeout 90 > $O/pytest_decoder.log 2>&1 ;;
 bench_default) timeout 900 python bench.py > $O/bench_default.log 2>&1 ;;
+final) # the round's closing measurement, on the build that is in the tree: rocprofv3 kernel stats of every bench leg (configs 2-5, the three decoder legs), the five counter passes
+  # of each, condensed into profiles-ready files under $O (copy to profiles/r05_final + profiles/pmc_traffic_r05.json)
+  for c in 2 3 4 5; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete; done
+  for c in 2 3 4; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config $c --decode > $OLDPWD/$O/profd$c.log 2>&1); find $O/profd$c -name '*kernel_trace*' -delete; find $O/profd$c -name '*agent_info*' -delete; done
+  for c in 2 3 4 5; do timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmc$c --steady-state 0 > $O/pmc$c.log 2>&1; done
+  for c in 2 3 4; do timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmcd$c --steady-state 0 --decode > $O/pmcd$c.log 2>&1; done
+  python tools/pmc_summary4.py $O/pmc $O/pmc_traffic_r05.json > $O/pmc_summary.log 2>&1
+  bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1 ;;
 prof2|prof3|prof4) c=${step#prof}; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete ;;
 pmc2|pmc3|pmc4) c=${step#pmc}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmc$c > $O/pmc$c.log 2>&1 ;;
 pmcd2|pmcd3|pmcd4) c=${step#pmcd}; timeout 900 bash tools/gpu_pmc.sh $c $O/pmc/pmcd$c --decode > $O/pmcd$c.log 2>&1 ;;

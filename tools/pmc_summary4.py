@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""tools/pmc_summary4.py <dir with config dirs from tools/gpu_pmc.sh> <out.json> — condense the rocprofv3 counter passes of round 4 (one directory per bench leg: pmc2,
+"""tools/pmc_summary4.py <dir with config dirs from tools/gpu_pmc.sh> <out.json> — condense the rocprofv3 counter passes (rounds 4 and 5) (one directory per bench leg: pmc2,
 pmc3, pmc4, pmcd2 ...; separate passes per counter group; FETCH_SIZE / WRITE_SIZE with their calibration runs next to them) into per-frame figures, per kernel and summed over the
 kernels of one call: what bench.py quotes in roofline.traffic / roofline.issue.  16,384 frames per launch."""
 import csv, collections, json, os, sys
 root, out = sys.argv[1], sys.argv[2]
 FR = 16384; GiB = 1 << 30
 # resident waves per SIMD of each kernel (LDS / VGPR footprint: tools/kernel_resources.sh + the launch's dynamic LDS); front: 12 waves per CU mono, 10 stereo
-WPS = {"oa_encode_kernel": 4.0, "oa_sh_front_kernel": 3.0, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 2.0, "oa_decode_fast_kernel": 3.0, "oa_sh_encode_kernel": 1.75}
+WPS = {"oa_encode_kernel": 4.0, "oa_sh_front_kernel": 4.0, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 2.0, "oa_decode_fast_kernel": 4.0, "oa_sh_encode_kernel": 1.75,
+       "oa_decode_look_kernel": 8.0, "oa_ms_split_kernel": 8.0, "oa_ms_pack_kernel": 8.0}      # (round 5: the front kernel holds 16 waves per CU mono, 12 stereo -- config 4 below)
+WPS_BY_LEG = {"config_4": {"oa_sh_front_kernel": 3.0}}
 def table(d, f):
     """{kernel: {counter: mean value per dispatch}}, dispatch counts"""
     p = os.path.join(d, f); agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -48,8 +50,8 @@ for sub in sorted(os.listdir(root)):
                 "hbm_bytes_per_frame": (tot["fetch_bytes_per_frame"] + tot["write_bytes_per_frame"]) or None,
                 "issue": {"valu_insts_per_frame": tot["valu_insts_per_frame"], "salu_insts_per_frame": tot["salu_insts_per_frame"], "lds_insts_per_frame": tot["lds_insts_per_frame"],
                           "valu_active_fraction_of_wave_cycles": None if not wc else round(va / wc, 3),     # x resident waves per SIMD = VALU busy per SIMD
-                          "valu_busy_per_simd": None if not wc else round(va / sum(busy[k].get("SQ_WAVE_CYCLES", 0) / WPS.get(k, 2.0) for k in busy), 3),     # VALU-active cycles / SIMD-resident cycles (wave cycles / resident waves per SIMD), over the call's kernels
-                          "waves_per_simd": {k: WPS.get(k) for k in kernels}},
+                          "valu_busy_per_simd": None if not wc else round(va / sum(busy[k].get("SQ_WAVE_CYCLES", 0) / WPS_BY_LEG.get(key, {}).get(k, WPS.get(k, 2.0)) for k in busy), 3),     # VALU-active cycles / SIMD-resident cycles (wave cycles / resident waves per SIMD), over the call's kernels
+                          "waves_per_simd": {k: WPS_BY_LEG.get(key, {}).get(k, WPS.get(k)) for k in kernels}},
                 "lane_utilisation": {"active_lanes_per_valu_cycle": None if not ta else round(tl / ta, 1)},
                 "kernels": per}
 json.dump(doc, open(out, "w"), indent=1)
