@@ -426,11 +426,11 @@ OPUS_AMD_EXPORT int opusgpu_silk_pitch_analysis_batch_dev(int device, opus_int32
  * channel extraction, the elementary encodes and the self-delimited packing (RFC 6716 Appendix B) are launches on one HIP stream, no host round trip.
  * mapping_family 0 / 255 (plain layouts), 1 (surround: the Vorbis layouts with their per-frame masking analysis, reference src/opus_multistream_encoder.c:230, on the
  * device; pass the streams / coupled streams opus_multistream_surround_encoder_create reports), 2 (ambisonics layouts: CELT-only elementary encoders) or 3 (projection: the layout and mixing matrix of
- * opus_projection_ambisonics_encoder_create, reference src/opus_projection_encoder.c:176, mixed on the device as src/mapping_matrix.c:148 does; `mapping` is ignored); VBR (hard CBR: OPUS_UNIMPLEMENTED -- the
- * classic opus_multistream_encode serves it).  max_data_bytes as in opus_multistream_encode: when it is large enough for every stream to be offered its own cap
+ * opus_projection_ambisonics_encoder_create, reference src/opus_projection_encoder.c:176, mixed on the device as src/mapping_matrix.c:148 does; `mapping` is ignored).  max_data_bytes as in opus_multistream_encode: when it is large enough for every stream to be offered its own cap
  * ((streams - 1) * 1279 + 7662 + 3 * streams + 8 for frames <= 20 ms) the streams are independent and a frame-step is two encode launches; a tighter buffer chains the
  * streams' byte budgets as the reference does (src/opus_multistream_encoder.c:1016-1027) and the call steps through the streams in order on the device (2 x streams
- * launches).  Packets, lengths and per-encoder error codes are the reference's in both cases. */
+ * launches).  Hard CBR (OPUS_SET_VBR(0)) always takes the chained form: the packet is the bitrate's size, the last stream's rate follows from the bytes the others left and its
+ * packet is padded out to them (:918-927, :1027, :1048).  Packets, lengths and per-encoder error codes are the reference's in every case. */
 typedef struct OpusGpuMsEncBatch OpusGpuMsEncBatch;
 OPUS_AMD_EXPORT OpusGpuMsEncBatch *opusgpu_ms_enc_batch_create(opus_int32 nb_encoders, opus_int32 Fs, int channels, int mapping_family, int streams, int coupled_streams,
       const unsigned char *mapping, int application, int device, int *error);

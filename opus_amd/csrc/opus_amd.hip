@@ -195,7 +195,10 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
             apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row, pred_split);
       __syncthreads();
       kept += conts[s].kind == SH_CONT_FAST;
-      if (pred_split && threadIdx.x == 0 && conts[s].kind == SH_CONT_FAST && conts[s].nq > 0) slow_list[nstreams + atomicAdd(counters + 6, 1u)] = s;      /* the pred kernel's work list: the streams with a SILK job (behind the list of the calls turned away) */
+      if (pred_split && threadIdx.x == 0 && conts[s].kind == SH_CONT_FAST && conts[s].nq > 0) {      /* the pred kernel's work list: one item (stream * 2 + job) per coded channel, behind the list of the calls turned away */
+         const int nq = conts[s].nq; const unsigned at = atomicAdd(counters + 6, (unsigned)nq);
+         for (int j = 0; j < nq; j++) slow_list[nstreams + at + j] = 2 * s + j;
+      }
    }
    if (threadIdx.x == 0 && seen) { atomicAdd(counters + 16, kept); atomicAdd(counters + 17, seen - kept); }     /* running totals of the batch (opusgpu_enc_batch_split_stats) */
 }
@@ -208,12 +211,26 @@ oa_sh_pred_kernel(OaShStream *streams, ShCont *conts, const int *list, const uns
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS PredLds *P = (WV_LDS PredLds *)smem;
-   const int n = (int)*list_count;                                       /* streams with a SILK job: none in a batch of CELT-only frames, whose launch of this kernel then costs a few microseconds */
+   const int n = (int)*list_count;                                       /* coded channels with a SILK job: none in a batch of CELT-only frames, whose launch of this kernel then costs a few microseconds */
    for (;;) {
       const int i = oa_queue_pop(queue);
       if (i >= n) break;
-      const int s = wv_uni(list[i]);
-      oa_sh_pred_frame(P, streams + s, conts + s);
+      const int it = wv_uni(list[i]);
+      oa_sh_pred_frame(P, streams + (it >> 1), conts + (it >> 1), it & 1);
+      __syncthreads();
+   }
+}
+/* pipeline mode 4: the same stage with one LANE per coded channel, PL_STREAMS channels per wave (oa_sh_predl_tile, silk_enc_predl.h) */
+extern "C" __global__ void __launch_bounds__(64, 2)
+oa_sh_predl_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS PlLane *P = (WV_LDS PlLane *)smem;
+   const int n = (int)*list_count, ntiles = (n + PL_STREAMS - 1) / PL_STREAMS;
+   for (;;) {
+      const int t = oa_queue_pop(queue);
+      if (t >= ntiles) break;
+      oa_sh_predl_tile(P, streams, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
       __syncthreads();
    }
 }
@@ -449,7 +466,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
-   if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 3) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
+   if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 4) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
    b->any_cbr = -1;
    if (request == OPUS_RESET_STATE) {
       /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
@@ -608,7 +625,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    const int n = (int)b->n_act, ch = b->channels;
    if (!b->d_cont) {
       HIPCHECK(hipMalloc((void **)&b->d_cont, sizeof(ShCont) * (size_t)b->S));
-      HIPCHECK(hipMalloc((void **)&b->d_slow_list, 2 * sizeof(int) * (size_t)b->S));         /* [S] the calls the front kernel turned away | [S] the pred kernel's work list */
+      HIPCHECK(hipMalloc((void **)&b->d_slow_list, 3 * sizeof(int) * (size_t)b->S));         /* [S] the calls the front kernel turned away | [2 S] the pred kernel's work list (coded channels) */
    }
    { const size_t need = SH_PCM_BYTES(frame_size, ch) * (size_t)b->S; if (need > b->pcm_hp_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp); b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_pcm_hp, need)); b->pcm_hp_cap = need; } }
    static const size_t lds_pad = getenv("OPUS_AMD_SH_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_SH_LDS_PAD")) : 0;   /* occupancy experiments only */
@@ -626,13 +643,15 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    (void)silk_only;
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
    const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
-   const int pred_split = mode == 3;                                    /* front -> pred -> quantiser -> back */
+   const int pred_split = mode >= 3;                                    /* front -> pred -> quantiser -> back (3: one wave per coded channel, 4: one lane) */
+   const void *kp = mode == 4 ? (const void *)oa_sh_predl_kernel : (const void *)oa_sh_pred_kernel;
+   const size_t lds_p = mode == 4 ? sizeof(PlLane) * PL_STREAMS : sizeof(PredLds);
    int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0, g_pred = 0;
    { int r = oa_sh_grid(b, 0, (const void *)oa_sh_front_kernel, lds_front, n, &g_front); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 1, kq, lds_q, mode == 2 ? n : (n + 15) / 16, &g_quant); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 2, (const void *)oa_sh_back_kernel, lds_back, n, &g_back); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_full, n, &g_slow); if (r != OPUS_OK) return r; }
-   if (pred_split) { int r = oa_sh_grid(b, 4, (const void *)oa_sh_pred_kernel, sizeof(PredLds), n, &g_pred); if (r != OPUS_OK) return r; }
+   if (pred_split) { int r = oa_sh_grid(b, 4, kp, lds_p, mode == 4 ? (n * ch + PL_STREAMS - 1) / PL_STREAMS : n * ch, &g_pred); if (r != OPUS_OK) return r; }
    size_t need = (size_t)g_front * sizeof(CeltScratch);
    if ((size_t)g_quant * scr_q > need) need = (size_t)g_quant * scr_q;
    if ((size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch);
@@ -641,7 +660,8 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, pred_split);
-   if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
+   if (mode == 4) hipLaunchKernelGGL(oa_sh_predl_kernel, dim3((unsigned)g_pred), dim3(64), lds_p, s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
+   else if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), lds_p, s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
@@ -1031,7 +1051,7 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    va_start(ap, request);
    int ret;
    if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
-   else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 3) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
+   else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 4) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
    else if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else { *p = st->pipeline_p2 ? (opus_int32)st->pipeline_p2 - 2 : -1; ret = OPUS_OK; } }
    else if (request == OPUS_SET_ENERGY_MASK_REQUEST) {                                  /* internal (src/opus_private.h): multistream surround masking, 21 values per channel or NULL */
       const opus_int32 *m = va_arg(ap, const opus_int32 *);

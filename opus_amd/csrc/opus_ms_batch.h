@@ -12,8 +12,9 @@
  * to be offered the elementary encoder's own cap, the budgets are all the same and the streams are independent: two encode launches.  A tighter buffer chains them:
  * the call then steps through the streams in order -- oa_ms_budget_kernel (one lane per encoder) turns what the streams before took into stream k's budget, an
  * encode launch codes stream k of all B encoders with it (oa_encode_launch: a strided subset of the batch with a per-record budget) -- 2 x streams launches, still
- * without a host round trip, packets and error codes those of opus_multistream_encode.  Hard CBR (the last stream's rate follows from the bytes left and its packet
- * is padded to them, :1027, :1048) is answered OPUS_UNIMPLEMENTED here and served by the classic entry points.  Mapping families: 0 / 255 (plain), 2 (ambisonics:
+ * without a host round trip, packets and error codes those of opus_multistream_encode.  Hard CBR always chains: the packet is the bitrate's size (:918-927), the budget
+ * kernel sets the last stream's bitrate from the bytes left (:1027), and the assembly goes through the general packet form (oa_ms_pack_cbr_kernel: padded elementary packets
+ * lose their padding, the last one is padded out, :1032-1048).  Mapping families: 0 / 255 (plain), 2 (ambisonics:
  * elementary encoders forced to CELT), 3 (projection: the mixing matrix applied on the device, opus_ms_dec_batch.h) and 1 (surround: the masking analysis of every
  * encoder and the energy masks of its streams are two more launches per frame, oa_surround_kernel + oa_ms_surround_mask_kernel). */
 #ifndef OPUS_AMD_MS_BATCH_H
@@ -109,13 +110,106 @@ WV_DEV void oa_ms_header(const u8 *p, int len, int *hdr, int *last)
    }
 }
 
+/* The general form, for hard CBR: there an elementary packet may come padded (opus_encode_native pads to the CBR size, src/opus_encoder.c:2533-2544) and the multistream layer's
+ * repacketizer (cat + out_range_impl, opus_multistream_encoder.c:1032-1048) drops that padding, writes the smallest header that carries the frames, and pads the LAST stream's
+ * packet out to the bytes left.  oa_ms_plan = the frames of an elementary packet (the encoder emits at most six), oa_ms_shape = the header the repacketizer gives them
+ * (opus_packet_host.h: oa_frame_map / oa_frames_emit are the host forms of the same rules). */
+struct OaMsPlan { int toc, n, same, body, off0, size[6]; };
+WV_DEV int oa_ms_plan(const u8 *p, int len, OaMsPlan *m)
+{
+   if (len < 1) return OPUS_INTERNAL_ERROR;
+   const int code = p[0] & 3;
+   int n = 1, vbr = 0, at = 1, pad = 0, sz[6] = {0, 0, 0, 0, 0, 0};
+   if (code == 1) n = 2;
+   else if (code == 2) {
+      n = 2; vbr = 1;
+      if (len < 2) return OPUS_INTERNAL_ERROR;
+      const int a = p[1]; at = 2; sz[0] = a;
+      if (a >= 252) { if (len < 3) return OPUS_INTERNAL_ERROR; sz[0] = 4 * p[2] + a; at = 3; }
+   } else if (code == 3) {
+      if (len < 2) return OPUS_INTERNAL_ERROR;
+      const int v = p[1]; at = 2; n = v & 0x3F; vbr = v >> 7;
+      if (n < 1 || n > 6) return OPUS_INTERNAL_ERROR;
+      if (v & 0x40) { int b; do { if (at >= len) return OPUS_INTERNAL_ERROR; b = p[at++]; pad += b == 255 ? 254 : b; } while (b == 255); }
+      if (vbr) {
+#pragma unroll
+         for (int i = 0; i < 5; i++) if (i < n - 1) {
+            if (at >= len) return OPUS_INTERNAL_ERROR;
+            const int a = p[at++]; int s = a;
+            if (a >= 252) { if (at >= len) return OPUS_INTERNAL_ERROR; s = 4 * p[at++] + a; }
+            sz[i] = s;
+         }
+      }
+   }
+   int rest = len - at - pad;
+   if (rest < 0) return OPUS_INTERNAL_ERROR;
+   if (vbr) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) if (i < n - 1) rest -= sz[i];
+      if (rest < 0) return OPUS_INTERNAL_ERROR;
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (i == n - 1) sz[i] = rest;
+   } else {
+      if (rest % n) return OPUS_INTERNAL_ERROR;
+      const int each = rest / n;
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (i < n) sz[i] = each;
+   }
+   int body = 0, same = 1;
+#pragma unroll
+   for (int i = 0; i < 6; i++) { m->size[i] = sz[i]; if (i < n) { body += sz[i]; same = same && sz[i] == sz[0]; } }
+   m->toc = p[0]; m->n = n; m->same = same; m->body = body; m->off0 = at;
+   return n;
+}
+struct OaMsShape { int code3, h, total, pad, full; };      /* h: header bytes incl. padding length bytes and the Appendix-B length field; total: the packet */
+WV_DEV int oa_ms_lenbytes(int v) { return v < 252 ? 1 : 2; }
+WV_DEV int oa_ms_last_size(const OaMsPlan *m) { int v = 0; for (int i = 0; i < 6; i++) if (i == m->n - 1) v = m->size[i]; return v; }
+WV_DEV int oa_ms_shape(const OaMsPlan *m, int maxlen, int framed, int fill, OaMsShape *o)
+{
+   const int n = m->n, tail = framed ? oa_ms_lenbytes(oa_ms_last_size(m)) : 0;
+   int h = 0, total = 0, pad = 0, full = 0, code3 = n > 2;
+   if (!code3) {
+      h = 1 + (n == 2 && !m->same ? oa_ms_lenbytes(m->size[0]) : 0);
+      total = h + tail + m->body;
+      if (total > maxlen) return OPUS_BUFFER_TOO_SMALL;
+      code3 = fill && total < maxlen;
+   }
+   if (code3) {
+      h = 2;
+      if (!m->same) for (int i = 0; i < 5; i++) if (i < n - 1) h += oa_ms_lenbytes(m->size[i]);
+      total = h + tail + m->body;
+      if (total > maxlen) return OPUS_BUFFER_TOO_SMALL;
+      pad = fill ? maxlen - total : 0;
+      if (pad > 0) { full = (pad - 1) / 255; h += full + 1; total = maxlen; }
+   }
+   o->code3 = code3; o->h = h + tail; o->total = total; o->pad = pad; o->full = full;
+   return OPUS_OK;
+}
+WV_DEV int oa_ms_put_length(int v, u8 *d) { if (v < 252) { d[0] = (u8)v; return 1; } d[0] = (u8)(252 + (v & 3)); d[1] = (u8)((v - d[0]) >> 2); return 2; }
+WV_DEV void oa_ms_put_header(const OaMsPlan *m, const OaMsShape *o, int framed, u8 *q)
+{
+   const int n = m->n, toc = m->toc & 0xFC;
+   if (!o->code3) {
+      *q++ = (u8)(toc | (n == 1 ? 0 : m->same ? 1 : 2));
+      if (n == 2 && !m->same) q += oa_ms_put_length(m->size[0], q);
+   } else {
+      *q++ = (u8)(toc | 3);
+      *q++ = (u8)(n | (m->same ? 0 : 0x80) | (o->pad > 0 ? 0x40 : 0));
+      if (o->pad > 0) { for (int i = 0; i < o->full; i++) *q++ = 255; *q++ = (u8)(o->pad - 255 * o->full - 1); }
+      if (!m->same) for (int i = 0; i < 5; i++) if (i < n - 1) q += oa_ms_put_length(m->size[i], q);
+   }
+   if (framed) q += oa_ms_put_length(oa_ms_last_size(m), q);
+}
+
 /* The chained byte budgets of opus_multistream_encode_native (src/opus_multistream_encoder.c:1016-1027) for all B encoders, one LANE per encoder: before stream s is coded,
  * what stream s - 1 took (its packet plus the Appendix-B length field it will carry) joins the encoder's running total, and stream s's byte budget follows from what is
  * left -- two bytes kept back for each stream still to come (one for the last), one more each at 100 ms, the elementary encoder's own cap, the length field of this stream.
  * An encoder whose stream failed, or whose budget ran out, stops there like the reference's loop does: its later streams get budget 0 and sit the remaining calls out. */
 extern "C" __global__ void __launch_bounds__(64)
 oa_ms_budget_kernel(int s, int ns, int nc, int B, int Fs, int frame_size, int max_data_bytes, const u8 *pkc, const i32 *lc, const u8 *pkm, const i32 *lm, int stride,
-      i32 *tot, i32 *err, i32 *budget_c, i32 *budget_m)
+      i32 *tot, i32 *err, i32 *budget_c, i32 *budget_m,
+      int cbr /* hard CBR: the general packet form above, and the last stream's bitrate follows from the bytes left (:1027) */, char *last_rate /* &record[0].cfg.user_bitrate_bps of the
+      last stream's batch */, long long rate_pitch /* bytes between the last streams of consecutive encoders */, long long rate_first /* bytes to encoder 0's */, int last_channels)
 {
    const int b = (int)blockIdx.x * 64 + (int)threadIdx.x, nm = ns - nc;
    if (b >= B) return;
@@ -125,7 +219,8 @@ oa_ms_budget_kernel(int s, int ns, int nc, int B, int Fs, int frame_size, int ma
       const u8 *p = q < nc ? pkc + ((size_t)b * nc + q) * stride : pkm + ((size_t)b * nm + (q - nc)) * stride;
       const int len = q < nc ? lc[b * nc + q] : lm[b * nm + (q - nc)];
       if (len <= 0) e = len < 0 ? len : OPUS_INTERNAL_ERROR;
-      else { int hdr, last; oa_ms_header(p, len, &hdr, &last); t += len + (last < 252 ? 1 : 2); }
+      else if (!cbr) { int hdr, last; oa_ms_header(p, len, &hdr, &last); t += len + (last < 252 ? 1 : 2); }
+      else { OaMsPlan pl; OaMsShape sh; int r = oa_ms_plan(p, len, &pl); if (r > 0) r = oa_ms_shape(&pl, max_data_bytes - t, 1, 0, &sh); if (r < 0) e = r; else t += sh.total; }
    }
    i32 bud = 0;
    if (!e) {
@@ -135,6 +230,10 @@ oa_ms_budget_kernel(int s, int ns, int nc, int B, int Fs, int frame_size, int ma
       if (Fs / frame_size == 10) curr_max -= ns - s - 1;
       if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
       if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
+      if (cbr && s == ns - 1) {                                           /* OPUS_SET_BITRATE(bits_to_bitrate(curr_max * 8, Fs, frame_size)) on the last elementary encoder (opus_encoder.c ctl: <= 0 is refused, then 500 .. 750000 per channel) */
+         i32 v = curr_max * 8 * (6 * Fs / frame_size) / 6;
+         if (v > 0) { v = v <= 500 ? 500 : v > 750000 * last_channels ? 750000 * last_channels : v; *(i32 *)(last_rate + rate_first + (long long)b * rate_pitch) = v; }
+      }
       if (curr_max <= 0) e = OPUS_BUFFER_TOO_SMALL; else bud = curr_max;
    }
    tot[b] = t; err[b] = e;
@@ -175,6 +274,54 @@ oa_ms_pack_kernel(const u8 *pkc, const i32 *lc, const u32 *rc, int nc, const u8 
       }
       if (err) break;
       at += wv_bcast(incl, 63);
+   }
+   for (int d = 1; d < 64; d <<= 1) rx ^= (u32)wv_shfl((i32)rx, lane ^ d);
+   if (lane == 0) { lens[b] = err ? err : at; rngs[b] = err ? 0 : rx; }
+}
+
+/* the same assembly for hard CBR, through the general packet form: every lane plans its stream's packet (frames, the repacketizer's header), a wave scan places them, the last
+ * stream's packet is padded out to max_data_bytes; the owner lane writes its header, the wave copies the frames (contiguous in an elementary packet) and zeroes the padding */
+extern "C" __global__ void __launch_bounds__(64)
+oa_ms_pack_cbr_kernel(const u8 *pkc, const i32 *lc, const u32 *rc, int nc, const u8 *pkm, const i32 *lm, const u32 *rm, int nm, int stride,
+      u8 *out, int out_stride, int max_data_bytes, i32 *lens, u32 *rngs, const i32 *err_in)
+{
+   const int b = blockIdx.x, ns = nc + nm, lane = threadIdx.x;
+   u8 *dst = out + (size_t)b * out_stride;
+   if (err_in && err_in[b]) { if (lane == 0) { lens[b] = err_in[b]; rngs[b] = 0; } return; }
+   int at = 0, err = 0;
+   u32 rx = 0;
+   for (int s0 = 0; s0 < ns; s0 += 64) {
+      const int s = s0 + lane, mine = s < ns, is_last = s == ns - 1;
+      const u8 *p = 0; int len = 0, e = 0;
+      OaMsPlan pl; OaMsShape sh; pl.n = 1; pl.body = 0; pl.off0 = 0; sh.total = 0; sh.h = 0;
+      if (mine) {
+         if (s < nc) { p = pkc + ((size_t)b * nc + s) * stride; len = lc[b * nc + s]; rx ^= rc[b * nc + s]; }
+         else { p = pkm + ((size_t)b * nm + (s - nc)) * stride; len = lm[b * nm + (s - nc)]; rx ^= rm[b * nm + (s - nc)]; }
+         if (len <= 0) e = len < 0 ? len : OPUS_INTERNAL_ERROR;
+         else { const int r = oa_ms_plan(p, len, &pl); if (r < 0) e = r; else if (!is_last) e = oa_ms_shape(&pl, 1 << 30, 1, 0, &sh); }
+      }
+      err = wv_min(e);
+      if (err) break;
+      const int total0 = mine && !is_last ? sh.total : 0;
+      const int incl = wv_scan_incl(total0);
+      int off = at + incl - total0;
+      if (mine && is_last) { e = oa_ms_shape(&pl, max_data_bytes - off, 0, 1, &sh); }
+      err = wv_min(e);
+      if (err) break;
+      const int total = mine ? sh.total : 0;
+      if (mine && (off + total > max_data_bytes || off + total > out_stride)) e = OPUS_BUFFER_TOO_SMALL;
+      err = wv_min(e);
+      if (err) break;
+      if (mine) oa_ms_put_header(&pl, &sh, !is_last, dst + off);
+      const int chunk = imin(64, ns - s0);
+      for (int k = 0; k < chunk; k++) {                                   /* packet after packet, all lanes on the bytes */
+         const unsigned long long pw = (unsigned long long)p;
+         const u8 *q = (const u8 *)(((unsigned long long)(u32)wv_bcast((i32)(pw >> 32), k) << 32) | (unsigned long long)(u32)wv_bcast((i32)(u32)pw, k));
+         const int qo = wv_bcast(off, k) + wv_bcast(sh.h, k), qf = wv_bcast(pl.off0, k), qb = wv_bcast(pl.body, k), qt = wv_bcast(off, k) + wv_bcast(total, k);
+         for (int i = lane; i < qb; i += 64) dst[qo + i] = q[qf + i];
+         for (int i = qo + qb + lane; i < qt; i += 64) dst[i] = 0;
+      }
+      at += wv_bcast(wv_scan_incl(total), 63);
    }
    for (int d = 1; d < 64; d <<= 1) rx ^= (u32)wv_shfl((i32)rx, lane ^ d);
    if (lane == 0) { lens[b] = err ? err : at; rngs[b] = err ? 0 : rx; }
@@ -302,11 +449,20 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
    const long long worst = (long long)(m->ns - 1) * (1276 * nf + 3) + OA_MS_FRAME_TMP + 3 * m->ns + 8;
    opus_int32 vbr = 1;
    (void)opus_multistream_encoder_ctl(m->proto, OPUS_GET_VBR_REQUEST, &vbr);
-   if (!vbr) return OPUS_UNIMPLEMENTED;                                   /* hard CBR: the last stream's rate follows from the bytes left and its packet is padded to them (:1027, :1048): classic entry points */
    opus_int32 smallest_packet = m->ns * 2 - 1;
    if (Fs / frame_size == 10) smallest_packet += m->ns;
    if (max_data_bytes < smallest_packet) return OPUS_BUFFER_TOO_SMALL;      /* (:898-906) */
-   const bool chained = max_data_bytes < worst;                           /* some stream's budget may bind: the streams are stepped in order, each with the bytes its predecessors left (:1016-1027) */
+   if (!vbr) {                                                            /* hard CBR: the packet is the bitrate's size (:918-927), the last stream takes -- and is padded to -- what the others leave (:1027, :1048) */
+      std::vector<opus_int32> rates((size_t)m->ns);
+      const opus_int32 rate_sum = oa_ms_rate_allocation(m->proto, rates.data(), frame_size);
+      if (m->proto->bitrate_bps == OPUS_AUTO) { const opus_int32 c = (rate_sum * 6 / (6 * Fs / frame_size) + 4) / 8; if (c < max_data_bytes) max_data_bytes = c; }
+      else if (m->proto->bitrate_bps != OPUS_BITRATE_MAX) {
+         opus_int32 c = (m->proto->bitrate_bps * 6 / (6 * Fs / frame_size) + 4) / 8;
+         if (c < smallest_packet) c = smallest_packet;
+         if (c < max_data_bytes) max_data_bytes = c;
+      }
+   }
+   const bool chained = !vbr || max_data_bytes < worst;                   /* some stream's budget may bind: the streams are stepped in order, each with the bytes its predecessors left (:1016-1027) */
    HIPCHECK(hipSetDevice(m->device));
    if (chained && !m->d_tot) {
       const size_t nstr = (size_t)m->B * m->ns;
@@ -361,16 +517,24 @@ int opusgpu_ms_encode_batch_dev(OpusGpuMsEncBatch *m, const opus_int16 *d_pcm, i
       /* stream after stream, all B encoders at once: the budget kernel (one lane per encoder) turns what the streams before took into this stream's byte budget, then
        * the B records of stream k -- every nc-th of the coupled batch, or every nm-th of the mono batch -- are coded with it.  2 x streams launches instead of 2: what
        * a caller with a tight buffer pays for staying on the device */
+      /* hard CBR: where the last stream's user bitrate lives on the device (the budget kernel sets it per encoder) */
+      OpusGpuEncBatch *lb = m->nm ? m->bm : m->bc;
+      const int lper = m->nm ? m->nm : m->nc;
+      char *last_rate = lb->kind ? (char *)&lb->d_sh[0].cfg.user_bitrate_bps : (char *)&lb->d_streams[0].cfg.user_bitrate_bps;
+      const long long rec = lb->kind ? (long long)sizeof(OaShStream) : (long long)sizeof(OaStream);
       for (int k = 0; k < m->ns; k++) {
          hipLaunchKernelGGL(oa_ms_budget_kernel, dim3((unsigned)((m->B + 63) / 64)), dim3(64), 0, s, k, m->ns, m->nc, m->B, (int)Fs, frame_size, (int)max_data_bytes,
-               (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (int)m->stride, m->d_tot, m->d_err, m->d_budget_c, m->d_budget_m);
+               (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (int)m->stride, m->d_tot, m->d_err, m->d_budget_c, m->d_budget_m,
+               vbr ? 0 : 1, last_rate, rec * lper, rec * (lper - 1), lb->channels);
          const int r = k < m->nc
             ? oa_encode_launch(m->bc, m->d_pc, m->d_M ? m->d_apc : nullptr, frame_size, frame_size, m->d_pkc, m->stride, OA_MS_FRAME_TMP, m->d_lc, m->d_rc, s, k, m->nc, m->B, m->d_budget_c)
             : oa_encode_launch(m->bm, m->d_pm, m->d_M ? m->d_apm : nullptr, frame_size, frame_size, m->d_pkm, m->stride, OA_MS_FRAME_TMP, m->d_lm, m->d_rm, s, k - m->nc, m->nm, m->B, m->d_budget_m);
          if (r != OPUS_OK) return r;
       }
    }
-   hipLaunchKernelGGL(oa_ms_pack_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
+   if (!vbr) hipLaunchKernelGGL(oa_ms_pack_cbr_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
+         (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range, (const i32 *)m->d_err);
+   else hipLaunchKernelGGL(oa_ms_pack_kernel, dim3((unsigned)m->B), dim3(64), 0, s, (const u8 *)m->d_pkc, (const i32 *)m->d_lc, (const u32 *)m->d_rc, m->nc,
          (const u8 *)m->d_pkm, (const i32 *)m->d_lm, (const u32 *)m->d_rm, m->nm, (int)m->stride, (u8 *)d_out, (int)out_stride, (int)max_data_bytes, (i32 *)d_lens, (u32 *)d_final_range,
          (const i32 *)(chained ? m->d_err : nullptr));
    HIPCHECK(hipGetLastError());

@@ -183,11 +183,10 @@ struct SePredChan {
    OaSilkEncIndices indices;
 };
 struct PredLds { SePredChan c; SeEncCtrl ctl; SeLpcWork W; i32 tk[4]; };
-WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct)
+WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int j /* the coded channel (job) of the frame: one work item each */)
 {
-   if (wv_uni(ct->kind) != SH_CONT_FAST) return;
-   const int nq = wv_uni(ct->nq);
-   for (int j = 0; j < nq; j++) {
+   if (wv_uni(ct->kind) != SH_CONT_FAST || j >= wv_uni(ct->nq)) return;
+   {
       const ShPredIn *in = &ct->p[j]; ShQuantCh *q = &ct->q[j];
       WV_LDS SePredChan *c = &P->c; WV_LDS SeEncCtrl *ctl = &P->ctl; WV_LDS SeLpcWork *W = &P->W;
       wv_sync();
@@ -225,6 +224,51 @@ WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct)
       }
       wv_sync();
    }
+}
+
+/* ---------------- pred, one lane per coded channel (pipeline mode 4): silk_enc_predl.h ----------------
+ * A tile = up to PL_STREAMS work items (item = stream * 2 + job) of the pred work list.  The wave stages the items' inputs together (the LPC analysis' input of every item:
+ * coalesced rows), lane t then runs the whole stage of item t (pl_pred_lane), and the wave stores the results where oa_sh_pred_frame does. */
+WV_DEVN void oa_sh_predl_tile(WV_LDS PlLane *P, OaShStream *streams, ShCont *conts, const int *list, int base, int cnt)
+{
+   const int lane = wv_lane();
+   wv_sync();
+   for (int t = 0; t < cnt; t++) {                                          /* the rows: all lanes on one item's samples */
+      const int it = wv_uni(list[base + t]);
+      const ShPredIn *in = &conts[it >> 1].p[it & 1];
+      const int nw = (wv_uni(in->nb_subfr) * (wv_uni(in->subfr_length) + wv_uni(in->predictLPCOrder)) + 1) >> 1;
+      const i32 *src = (const i32 *)in->LPC_in_pre; WV_LDS i32 *dst = (WV_LDS i32 *)P[t].x;
+      FOR_LANES(i, nw) dst[i] = src[i];
+   }
+   if (lane < cnt) {
+      const int it = list[base + lane];
+      ShCont *ct = &conts[it >> 1]; const ShPredIn *in = &ct->p[it & 1]; const ShQuantCh *q = &ct->q[it & 1];
+      WV_LDS PlLane *c = &P[lane];
+      c->minInvGain_Q30 = in->minInvGain_Q30; c->LTPredCodGain_Q7 = in->LTPredCodGain_Q7; c->coding_quality_Q14 = in->coding_quality_Q14; c->input_quality_Q14 = in->input_quality_Q14;
+      c->predictLPCOrder = in->predictLPCOrder; c->nb_subfr = in->nb_subfr; c->subfr_length = in->subfr_length; c->useInterpolatedNLSFs = in->useInterpolatedNLSFs;
+      c->first_frame_after_reset = in->first_frame_after_reset; c->speech_activity_Q8 = in->speech_activity_Q8; c->NLSF_MSVQ_Survivors = in->NLSF_MSVQ_Survivors;
+      c->SNR_dB_Q7 = in->SNR_dB_Q7; c->input_tilt_Q15 = in->input_tilt_Q15; c->nStatesDelayedDecision = in->nStatesDelayedDecision;
+      c->LastGainIndex = q->LastGainIndex; c->condCoding = q->condCoding;
+      for (int i = 0; i < 4; i++) { c->local_gains[i] = in->local_gains[i]; c->Gains_Q16[i] = q->fr.Gains_Q16[i]; }
+      for (int i = 0; i < 16; i++) c->prev_NLSFq_Q15[i] = in->prev_NLSFq_Q15[i];
+      { const i32 *s = (const i32 *)&q->indices; WV_LDS i32 *d = (WV_LDS i32 *)&c->indices; for (int i = 0; i < (int)(sizeof(OaSilkEncIndices) / 4); i++) d[i] = s[i]; }
+   }
+   wv_sync();
+   if (lane < cnt) {
+      WV_LDS PlLane *c = &P[lane];
+      pl_pred_lane(c);
+      const int it = list[base + lane];
+      ShCont *ct = &conts[it >> 1]; ShQuantCh *q = &ct->q[it & 1];
+      const int order = c->predictLPCOrder;
+      for (int i = 0; i < 32; i++) q->fr.PredCoef_Q12[i] = c->PredCoef_Q12[i >> 4][i & 15];
+      for (int i = 0; i < 4; i++) { q->fr.Gains_Q16[i] = c->Gains_Q16[i]; q->GainsUnq_Q16[i] = c->GainsUnq_Q16[i]; }
+      { i32 *d = (i32 *)&q->indices; const WV_LDS i32 *s = (const WV_LDS i32 *)&c->indices; for (int i = 0; i < (int)(sizeof(OaSilkEncIndices) / 4); i++) d[i] = s[i]; }
+      { i16 *pn = streams[it >> 1].silk.ch[q->chan].prev_NLSFq_Q15; for (int i = 0; i < 16; i++) pn[i] = i < order ? c->NLSF_Q15[i] : (i16)0; }
+      q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Lambda_Q10 = c->Lambda_Q10;
+      q->lastGainIndexPrev = c->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex;
+      if (q->chan == 0) ct->sc.offset = se_quantization_offsets_q10[(c->indices.signalType >> 1) * 2 + c->indices.quantOffsetType];      /* (as in oa_sh_pred_frame) */
+   }
+   wv_sync();
 }
 
 /* ---------------- back ---------------- */

@@ -6,6 +6,7 @@
 #include "silk_enc.h"
 #include "silk_enc_analysis.h"
 #include "silk_enc_quant.h"
+#include "silk_enc_predl.h"
 #include "silk_enc_nsq.h"
 #include "silk_enc_frame.h"
 #include "opus_enc_sh.h"

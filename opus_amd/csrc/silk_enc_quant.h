@@ -489,7 +489,7 @@ WV_DEV void se_gains_dequant(i32 *gain_Q16, const i8 *ind, int *prev_ind_p, int 
 }
 WV_DEV i32 se_gains_ID(const WV_LDS i8 *ind, int nb_subfr) { i32 id = 0; for (int k = 0; k < nb_subfr; k++) id = add32(ind[k], shl32(id, 8)); return id; }
 
-template <class CH> WV_DEV void se_process_gains_l0(WV_LDS CH *c, WV_LDS SeEncCtrl *ctl, int condCoding)
+template <class CH, class CT> WV_DEV void se_process_gains_l0(WV_LDS CH *c, WV_LDS CT *ctl, int condCoding)
 {
    if (c->indices.signalType == SE_TYPE_VOICED) {
       const i32 s_Q16 = -se_sigm_Q15(sk_rround(ctl->LTPredCodGain_Q7 - SE_FIX(12.0, 7), 4));

@@ -77,6 +77,20 @@ TIGHT_CASES = [
     dict(B=2, channels=4, streams=4, coupled=0, mapping=[0, 1, 2, 3], application=2049, bitrate=4 * 96000, frame=4800, frames=3, max_bytes=[3000, 1200, 7]),         # 100 ms: one more byte kept back per stream
 ]
 
+# hard CBR (OPUS_SET_VBR(0) on the multistream encoder): the packet is the bitrate's size, the last stream takes what the others leave and is padded out to it, padded elementary
+# packets lose their padding on the way (opus_multistream_encoder.c:918-927, :1027, :1032-1048)
+CBR_CASES = [
+    dict(B=3, channels=6, streams=4, coupled=2, mapping=[0, 1, 2, 3, 4, 5], application=2049, bitrate=256000, frames=6, ctl=[(4006, 0)], max_bytes=[4000, 700, 400, 4000, 120, 30]),
+    dict(B=2, channels=5, streams=5, coupled=0, mapping=[0, 1, 2, 3, 4], application=2049, bitrate=5 * 64000, frames=5, ctl=[(4006, 0)]),                        # the caller's buffer never binds: the bitrate does
+    dict(B=2, channels=4, streams=3, coupled=1, mapping=[0, 1, 2, 3], application=2051, bitrate=200000, frame=480, frames=6, ctl=[(4006, 0)], max_bytes=[1000, 150, 80, 1000, 20, 8]),
+    dict(B=2, channels=3, streams=2, coupled=1, mapping=[0, 1, 2], application=2048, Fs=16000, frame=320, bitrate=60000, frames=6, ctl=[(4006, 0)], max_bytes=[400, 60, 30, 200, 10, 4]),   # SILK elementary streams
+    dict(B=2, channels=5, streams=3, coupled=1, mapping=[2, 0, 1, 255, 3], application=2049, bitrate=180000, frame=1920, frames=4, ctl=[(4006, 0)], max_bytes=[4000, 500, 250, 2500]),      # multi-frame elementary packets
+    dict(B=2, channels=4, streams=4, coupled=0, mapping=[0, 1, 2, 3], application=2049, frames=4, ctl=[(4006, 0)]),                                                   # OPUS_AUTO: the streams' allocated rates set the size
+    dict(B=2, channels=3, streams=3, coupled=0, mapping=[0, 1, 2], application=2049, bitrate=-1, frames=3, ctl=[(4006, 0)], max_bytes=[3000, 900, 200]),                # OPUS_BITRATE_MAX: only the buffer bounds it
+    dict(B=2, channels=4, streams=4, coupled=0, mapping=[0, 1, 2, 3], application=2048, Fs=16000, frame=320, bitrate=4 * 9000, frames=8, ctl=[(4006, 0), (4016, 1)]),  # DTX under CBR: one- and two-byte elementary packets, padded
+    dict(B=2, channels=4, streams=4, coupled=0, mapping=[0, 1, 2, 3], application=2049, bitrate=4 * 96000, frame=4800, frames=3, ctl=[(4006, 0)], max_bytes=[6000, 1200, 7]),   # 100 ms
+]
+
 # ---- projection (mapping family 3) encoder batch and the multistream / projection decoder batches ----
 def _proj_ref_enc(R, Fs, channels, app):
     vp, ci = ctypes.c_void_p, ctypes.c_int

@@ -29,3 +29,6 @@ def test_gpu_ms_decode_batch_turns_an_over_long_elementary_packet_away_whole(): 
 
 @pytest.mark.parametrize("case", range(len(ms_batch_check.TIGHT_CASES)))
 def test_gpu_ms_batch_chained_byte_budgets(case): ms_batch_check.check("gpu", **ms_batch_check.TIGHT_CASES[case])
+
+@pytest.mark.parametrize("case", range(len(ms_batch_check.CBR_CASES)))
+def test_gpu_ms_batch_hard_cbr(case): ms_batch_check.check("gpu", **ms_batch_check.CBR_CASES[case])

@@ -79,7 +79,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
         import hostemu; lib = hostemu.build_emu_lib()
     else: lib = os.path.join(ROOT, "opus_amd/libopus_amd.so")
     r = {}
-    for mode in "0123":
+    for mode in "01234":
         out = os.path.join(tmpdir, "split_check_%s_%s_%d.pkl" % (which, mode, os.getpid()))
         env = dict(os.environ, OPUS_AMD_SH_SPLIT=mode)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), lib, mode, out], env=env)
@@ -88,7 +88,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
     for name in selected_cases():
         a = r["0"][name]
         assert a[2] == (0, 0), "the one-kernel run went through the split path?"
-        for mode in "123":
+        for mode in "1234":
             b = r[mode][name]
             okp = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(a[0], b[0]))
             nd = [int((x != y).sum()) for x, y in zip(a[1], b[1])]
