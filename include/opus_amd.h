@@ -155,11 +155,13 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const
 #define OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST 11900
 #define OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST 11901
 /* OPUS_AMD_SET_KERNEL_PIPELINE(v): how the following 10 / 20 ms calls of a SILK-capable encoder are launched -- a property of the launch, never of the packets (every value
- * gives the same bytes).  -1 (the default) = the library chooses: the front / pred / quantiser / back kernel pipeline (opus_sh_split.h; value 3) when the launch carries >= 64 streams, one
+ * gives the same bytes).  -1 (the default) = the library chooses: the front / pred / quantiser / back kernel pipeline (opus_sh_split.h; value 4) when the launch carries >= 64 streams, one
  * kernel below that; 0 = always one kernel; 1 = always the front / quantiser / back pipeline; 2 = the same with its one-wave-per-stream reference quantiser; 3 = front / pred / quantiser / back (the
- * prediction stage -- LPC, NLSF, residual energies, gains -- as a kernel of its own at twice the front kernel's occupancy).  On a batch (opusgpu_enc_batch_ctl, any
+ * prediction stage -- LPC, NLSF, residual energies, gains -- as a kernel of its own at twice the front kernel's occupancy); 4 = the same with the prediction stage cut into
+ * lane kernels for its serial parts (Burg's recursion, A2NLSF, NLSF2A, the NLSF trellises: one lane per coded channel, silk_enc_predl.h) and wave kernels for its passes over
+ * the signal.  On a batch (opusgpu_enc_batch_ctl, any
  * `stream`) it applies to the whole batch; on a classic encoder it applies to that encoder's calls (calls with different values are not combined into one launch); a
- * multistream encoder passes it to its elementary encoders.  The process-wide default behind -1 can be set with the environment variable OPUS_AMD_SH_SPLIT=0|1|2. */
+ * multistream encoder passes it to its elementary encoders.  The process-wide default behind -1 can be set with the environment variable OPUS_AMD_SH_SPLIT=0..4. */
 #define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
 #define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
 /* n stream records -- configuration and state as they stand on the device -- from batch `src` (from stream src_first on) into batch `dst` (from dst_first on), device to

@@ -207,30 +207,55 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
 #define OA_SH_PRED_WAVES_PER_EU 8
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_PRED_WAVES_PER_EU)
-oa_sh_pred_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+oa_sh_pred_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue, int tail /* mode 4: the stage's last part only */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS PredLds *P = (WV_LDS PredLds *)smem;
    const int n = (int)*list_count;                                       /* coded channels with a SILK job: none in a batch of CELT-only frames, whose launch of this kernel then costs a few microseconds */
+   if (tail) {                                                           /* short uniform items: a static split (65,536 pops of one counter would cost more than the items, profiles/r05_r) */
+      for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) { const int it = wv_uni(list[i]); oa_sh_pred_frame(P, streams + (it >> 1), conts + (it >> 1), it & 1, 1); __syncthreads(); }
+      return;
+   }
    for (;;) {
       const int i = oa_queue_pop(queue);
       if (i >= n) break;
       const int it = wv_uni(list[i]);
-      oa_sh_pred_frame(P, streams + (it >> 1), conts + (it >> 1), it & 1);
+      oa_sh_pred_frame(P, streams + (it >> 1), conts + (it >> 1), it & 1, 0);
       __syncthreads();
    }
 }
-/* pipeline mode 4: the same stage with one LANE per coded channel, PL_STREAMS channels per wave (oa_sh_predl_tile, silk_enc_predl.h) */
-extern "C" __global__ void __launch_bounds__(64, 2)
-oa_sh_predl_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+/* pipeline mode 4: the stage's serial parts on lanes, its passes over the signal on waves (silk_enc_predl.h, opus_sh_split.h) -- four launches over the same work list */
+extern "C" __global__ void __launch_bounds__(64, 1)
+oa_sh_preda_kernel(ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
-   WV_LDS PlLane *P = (WV_LDS PlLane *)smem;
    const int n = (int)*list_count, ntiles = (n + PL_STREAMS - 1) / PL_STREAMS;
-   for (;;) {
-      const int t = oa_queue_pop(queue);
-      if (t >= ntiles) break;
-      oa_sh_predl_tile(P, streams, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
+   (void)queue;
+   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+      oa_sh_preda_tile((WV_LDS i32 *)smem, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
+      __syncthreads();
+   }
+}
+extern "C" __global__ void __launch_bounds__(64, OA_SH_PRED_WAVES_PER_EU)
+oa_sh_predc_kernel(ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   const int n = (int)*list_count;
+   (void)queue;
+   for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {           /* (short uniform items: a static split, as in the stage's tail) */
+      const int it = wv_uni(list[i]);
+      oa_sh_predc_frame((WV_LDS PredLds *)smem, conts + (it >> 1), it & 1);
+      __syncthreads();
+   }
+}
+extern "C" __global__ void __launch_bounds__(64, 1)
+oa_sh_predb_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   const int n = (int)*list_count, ntiles = (n + PL_STREAMS - 1) / PL_STREAMS;
+   (void)queue;
+   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+      oa_sh_predb_tile((WV_LDS PlBLane *)smem, (WV_LDS SeNlsfTabs *)(smem + sizeof(PlBLane) * PL_STREAMS), streams, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
       __syncthreads();
    }
 }
@@ -266,12 +291,13 @@ oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scra
 #define OA_SH_BACK_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
-oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters, int pkt_off)
+oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters, int pkt_off,
+      int chunk /* streams per pop of the queue: 1, or several where the frames are all light (a batch pinned to SILK-only: 65,536 pops of one counter take longer than their frames) */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
-   for (;;) {
-      const int s = oa_queue_pop(counters + 2);
+   for (int s = 0, end = 0;; s++) {
+      if (s >= end) { int b0 = 0; if (wv_lane() == 0) b0 = (int)atomicAdd(counters + 2, (unsigned)chunk); s = wv_bcast(b0, 0); end = s + chunk; }
       if (s >= nstreams) break;
       if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)offsetof(SilkEncLds, st); }
       __syncthreads();
@@ -364,7 +390,7 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
-   struct { const void *kernel; size_t lds; int per_cu; } occ[5];
+   struct { const void *kernel; size_t lds; int per_cu; } occ[8];
    int device;
    opus_int32 S;
    opus_int32 n_act;                     /* streams a call processes: the first n_act records (== S except under the classic API's call combiner) */
@@ -375,7 +401,7 @@ struct OpusGpuEncBatch {
    bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
    int any_cbr;                         /* some stream of the mirror is hard CBR (-1: not derived since the mirror last changed): sizes the output slot a call needs */
    int all_silk_pinned;
-   int pipeline;                        /* OPUS_AMD_SET_KERNEL_PIPELINE: -1 the library chooses, 0 one kernel, 1 / 2 the kernel pipeline (include/opus_amd.h) */
+   int pipeline;                        /* OPUS_AMD_SET_KERNEL_PIPELINE: -1 the library chooses, 0 one kernel, 1 .. 4 the kernel pipeline (include/opus_amd.h) */
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
    opus_int32 *d_apcm; size_t apcm_cap;  /* signal-domain copy of the input for the analysis (24-bit / float entry points) */
@@ -640,18 +666,23 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    size_t lds_back = b->application == OPUS_APPLICATION_RESTRICTED_SILK ? offsetof(ShLds, S) + 256 : SH_CELT_LDS_BYTES;
    const int po_back = (int)al16(lds_back); lds_back = po_back + SH_PKT_BYTES;
    const int po_full = (int)al16(lds_full); lds_full = po_full + SH_PKT_BYTES;
-   (void)silk_only;
    const void *kq = mode == 2 ? (const void *)oa_sh_quant0_kernel : (const void *)oa_sh_quant_kernel;
    const size_t lds_q = mode == 2 ? lds_full : sizeof(SqLds), scr_q = mode == 2 ? sizeof(SeRateScratch) : SQ_WAVE_SCRATCH_BYTES;
-   const int pred_split = mode >= 3;                                    /* front -> pred -> quantiser -> back (3: one wave per coded channel, 4: one lane) */
-   const void *kp = mode == 4 ? (const void *)oa_sh_predl_kernel : (const void *)oa_sh_pred_kernel;
-   const size_t lds_p = mode == 4 ? sizeof(PlLane) * PL_STREAMS : sizeof(PredLds);
+   const int pred_split = mode >= 3;                                    /* front -> pred -> quantiser -> back (3: one wave per coded channel; 4: the stage cut into lane and wave kernels) */
+   const size_t lds_pa = (size_t)PL_A_WORDS * 4 * PL_STREAMS, lds_pb = sizeof(PlBLane) * PL_STREAMS + 2 * sizeof(SeNlsfTabs);
    int g_front = 0, g_quant = 0, g_back = 0, g_slow = 0, g_pred = 0;
    { int r = oa_sh_grid(b, 0, (const void *)oa_sh_front_kernel, lds_front, n, &g_front); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 1, kq, lds_q, mode == 2 ? n : (n + 15) / 16, &g_quant); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 2, (const void *)oa_sh_back_kernel, lds_back, n, &g_back); if (r != OPUS_OK) return r; }
    { int r = oa_sh_grid(b, 3, (const void *)oa_sh_encode_kernel, lds_full, n, &g_slow); if (r != OPUS_OK) return r; }
-   if (pred_split) { int r = oa_sh_grid(b, 4, kp, lds_p, mode == 4 ? (n * ch + PL_STREAMS - 1) / PL_STREAMS : n * ch, &g_pred); if (r != OPUS_OK) return r; }
+   int g_pa = 0, g_pb = 0, g_pc = 0;
+   if (pred_split) { int r = oa_sh_grid(b, 4, (const void *)oa_sh_pred_kernel, sizeof(PredLds), n * ch, &g_pred); if (r != OPUS_OK) return r; }
+   if (mode == 4) {
+      const long long tiles = ((long long)n * ch + PL_STREAMS - 1) / PL_STREAMS;
+      int r = oa_sh_grid(b, 5, (const void *)oa_sh_preda_kernel, lds_pa, tiles, &g_pa); if (r != OPUS_OK) return r;
+      r = oa_sh_grid(b, 6, (const void *)oa_sh_predb_kernel, lds_pb, tiles, &g_pb); if (r != OPUS_OK) return r;
+      r = oa_sh_grid(b, 7, (const void *)oa_sh_predc_kernel, sizeof(PredLds), n * ch, &g_pc); if (r != OPUS_OK) return r;
+   }
    size_t need = (size_t)g_front * sizeof(CeltScratch);
    if ((size_t)g_quant * scr_q > need) need = (size_t)g_quant * scr_q;
    if ((size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_back * SH_SCRATCH_BYTES(frame_size, ch);
@@ -659,13 +690,18 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
-         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, pred_split);
-   if (mode == 4) hipLaunchKernelGGL(oa_sh_predl_kernel, dim3((unsigned)g_pred), dim3(64), lds_p, s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
-   else if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), lds_p, s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5);
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split);
+   if (mode == 4) {
+      const int *pl = (const int *)(b->d_slow_list + n); const unsigned *pc = (const unsigned *)(b->d_queue + 6);
+      hipLaunchKernelGGL(oa_sh_preda_kernel, dim3((unsigned)g_pa), dim3(64), lds_pa, s, b->d_cont, pl, pc, b->d_queue + 7);
+      hipLaunchKernelGGL(oa_sh_predc_kernel, dim3((unsigned)g_pc), dim3(64), sizeof(PredLds), s, b->d_cont, pl, pc, b->d_queue + 8);
+      hipLaunchKernelGGL(oa_sh_predb_kernel, dim3((unsigned)g_pb), dim3(64), lds_pb, s, b->d_sh, b->d_cont, pl, pc, b->d_queue + 9);
+   }
+   if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5, mode == 4 ? 1 : 0);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
-         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back);
+         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1);
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
          (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row, 0, 1, (const i32 *)nullptr);
@@ -735,10 +771,10 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       const int silk_only = b->all_silk_pinned && frame_size >= b->Fs / 100;
       const size_t lds = sh_lds_bytes(b->channels, silk_only);                                                 /* (without the packet buffer: it goes behind, ShLds.packet_off) */
       const int po = (int)((lds + 15) & ~(size_t)15); const size_t lds_pk = (size_t)po + SH_PKT_BYTES;
-      /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser; unset: the kernel pipeline when the launch is wide
+      /* 0: one kernel; 1: front / quantiser / back kernels; 2: the same with the one-wave-per-stream reference quantiser; 3 / 4: with the pred stage as kernel(s) of its own; unset: the kernel pipeline (4) when the launch is wide
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
-      const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 3 : 0);
+      const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 4 : 0);
       if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }

@@ -38,7 +38,8 @@ struct ShCont {
    ShShared sh;
    OaShScalars st;
    ShQuantCh q[2];
-   ShPredIn p[2];                                        /* front -> pred (pipeline mode 3): the prediction stage's input, per coded channel */
+   ShPredIn p[2];                                        /* front -> pred (pipeline modes 3 / 4): the prediction stage's input, per coded channel */
+   ShPredMid m[2];                                       /* between the pred stage's kernels (mode 4) */
    u8 packet[OA_MAX_PACKET + 4];
 };
 
@@ -52,7 +53,7 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
 }
 template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
 WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
-      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame) */)
+      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame); 2: the pred lane / wave kernels' (mode 4), which want the Burg correlations too */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
@@ -122,7 +123,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
       if (p.channelRate_bps > 0) {
          WV_LDS OaSilkEncChannel *c = &E->ch[n];
-         se_frame_analysis_wave(S, c, p.condCoding, pred_split ? &ct->p[nq] : (ShPredIn *)nullptr);
+         se_frame_analysis_wave(S, c, p.condCoding, pred_split ? &ct->p[nq] : (ShPredIn *)nullptr, pred_split == 2);
          wv_sync();
          {  /* the channel's job for the quantiser kernel */
             ShQuantCh *q = &ct->q[nq];
@@ -183,7 +184,8 @@ struct SePredChan {
    OaSilkEncIndices indices;
 };
 struct PredLds { SePredChan c; SeEncCtrl ctl; SeLpcWork W; i32 tk[4]; };
-WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int j /* the coded channel (job) of the frame: one work item each */)
+WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int j /* the coded channel (job) of the frame: one work item each */,
+      int tail /* mode 4: the LPC analysis and the NLSF quantiser have run in the lane kernels -- residual energies and gains only */)
 {
    if (wv_uni(ct->kind) != SH_CONT_FAST || j >= wv_uni(ct->nq)) return;
    {
@@ -202,10 +204,12 @@ WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int
          ctl->LTPredCodGain_Q7 = in->LTPredCodGain_Q7; ctl->coding_quality_Q14 = in->coding_quality_Q14; ctl->input_quality_Q14 = in->input_quality_Q14;
       }
       wv_sync();
-      se_find_lpc_wave(c, W, W->LPC_in_pre, wv_uni(in->minInvGain_Q30), W->LPC_res, P->tk);
-      se_process_nlsfs_wave(c, &ctl->PredCoef_Q12[0][0], W);
-      wv_sync();
-      FOR_LANES(i, nb * (sl + order)) W->LPC_in_pre[i] = in->LPC_in_pre[i];          /* (the quantiser has worked in its bytes) */
+      if (!tail) {
+         se_find_lpc_wave(c, W, W->LPC_in_pre, wv_uni(in->minInvGain_Q30), W->LPC_res, P->tk);
+         se_process_nlsfs_wave(c, &ctl->PredCoef_Q12[0][0], W);
+         wv_sync();
+         FOR_LANES(i, nb * (sl + order)) W->LPC_in_pre[i] = in->LPC_in_pre[i];          /* (the quantiser has worked in its bytes) */
+      } else { FOR_LANES(i, 32) ctl->PredCoef_Q12[i >> 4][i & 15] = q->fr.PredCoef_Q12[i]; }
       wv_sync();
       se_residual_energy_wave(ctl->ResNrg, ctl->ResNrgQ, W->LPC_in_pre, &ctl->PredCoef_Q12[0][0], W->local_gains, sl, nb, order, W->LPC_res);
       LANE0 se_process_gains_l0(c, ctl, wv_uni(q->condCoding));
@@ -214,7 +218,7 @@ WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int
       FOR_LANES(i, 32) q->fr.PredCoef_Q12[i] = ctl->PredCoef_Q12[i >> 4][i & 15];
       FOR_LANES(i, 4) { q->fr.Gains_Q16[i] = ctl->Gains_Q16[i]; q->GainsUnq_Q16[i] = ctl->GainsUnq_Q16[i]; }
       sh_copy_words((i32 *)&q->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
-      { i16 *pn = gs->silk.ch[wv_uni(q->chan)].prev_NLSFq_Q15; FOR_LANES(i, 16) pn[i] = i < order ? W->NLSF_Q15[i] : (i16)0; }
+      if (!tail) { i16 *pn = gs->silk.ch[wv_uni(q->chan)].prev_NLSFq_Q15; FOR_LANES(i, 16) pn[i] = i < order ? W->NLSF_Q15[i] : (i16)0; }
       if (wv_lane() == 0) {
          q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Lambda_Q10 = ctl->Lambda_Q10;
          q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex;
@@ -226,47 +230,51 @@ WV_DEVN void oa_sh_pred_frame(WV_LDS PredLds *P, OaShStream *gs, ShCont *ct, int
    }
 }
 
-/* ---------------- pred, one lane per coded channel (pipeline mode 4): silk_enc_predl.h ----------------
- * A tile = up to PL_STREAMS work items (item = stream * 2 + job) of the pred work list.  The wave stages the items' inputs together (the LPC analysis' input of every item:
- * coalesced rows), lane t then runs the whole stage of item t (pl_pred_lane), and the wave stores the results where oa_sh_pred_frame does. */
-WV_DEVN void oa_sh_predl_tile(WV_LDS PlLane *P, OaShStream *streams, ShCont *conts, const int *list, int base, int cnt)
+/* ---------------- pred, pipeline mode 4: lane kernels for the serial parts, wave kernels for the passes over the signal (silk_enc_predl.h) ----------------
+ * A work item = a coded channel (item = stream * 2 + job) of the pred work list; the lane kernels take PL_STREAMS of them per wave. */
+WV_DEVN void oa_sh_preda_tile(WV_LDS i32 *F, ShCont *conts, const int *list, int base, int cnt)
+{
+   const int lane = wv_lane();
+   if (lane < cnt) { const int it = list[base + lane]; ShCont *ct = &conts[it >> 1]; pl_stage_a(F + lane * PL_A_WORDS, &ct->p[it & 1], &ct->m[it & 1]); }
+}
+/* the interpolation choice (find_LPC_FIX.c:88-138): one wave per coded channel on the first half frame */
+WV_DEVN void oa_sh_predc_frame(WV_LDS PredLds *P, ShCont *ct, int j)
+{
+   const ShPredIn *in = &ct->p[j]; ShPredMid *md = &ct->m[j];
+   WV_LDS SeLpcWork *W = &P->W;
+   const int order = wv_uni(in->predictLPCOrder), subfr_length = wv_uni(in->subfr_length) + order;
+   int coef = 4;
+   wv_sync();
+   if (wv_uni(md->interp)) {
+      WV_LDS i16 *cand_a = (WV_LDS i16 *)W->a_Q16;                             /* 4 x 16 coefficients in a_Q16 | a_tmp_Q16 */
+      FOR_LANES(i, subfr_length) ((WV_LDS i32 *)W->LPC_in_pre)[i] = ((const i32 *)in->LPC_in_pre)[i];      /* 2 * subfr_length samples */
+      FOR_LANES(i, 32) ((WV_LDS i32 *)cand_a)[i] = ((const i32 *)md->cand_a)[i];
+      wv_sync();
+      i32 res_nrg = wv_uni(md->res_nrg); int res_nrg_Q = wv_uni(md->res_nrg_Q);
+      coef = se_interp_search_wave(W->LPC_in_pre, cand_a, W->LPC_res, subfr_length, order, &res_nrg, &res_nrg_Q);
+   }
+   FOR_LANES(i, 16) md->NLSF_Q15[i] = coef == 4 ? md->NLSF_full[i] : md->NLSF_half[i];
+   if (wv_lane() == 0) md->coef = coef;
+   wv_sync();
+}
+WV_DEVN void oa_sh_predb_tile(WV_LDS PlBLane *B, WV_LDS SeNlsfTabs *T /* [2]: order 16, order 10 */, OaShStream *streams, ShCont *conts, const int *list, int base, int cnt)
 {
    const int lane = wv_lane();
    wv_sync();
-   for (int t = 0; t < cnt; t++) {                                          /* the rows: all lanes on one item's samples */
-      const int it = wv_uni(list[base + t]);
-      const ShPredIn *in = &conts[it >> 1].p[it & 1];
-      const int nw = (wv_uni(in->nb_subfr) * (wv_uni(in->subfr_length) + wv_uni(in->predictLPCOrder)) + 1) >> 1;
-      const i32 *src = (const i32 *)in->LPC_in_pre; WV_LDS i32 *dst = (WV_LDS i32 *)P[t].x;
-      FOR_LANES(i, nw) dst[i] = src[i];
-   }
-   if (lane < cnt) {
-      const int it = list[base + lane];
-      ShCont *ct = &conts[it >> 1]; const ShPredIn *in = &ct->p[it & 1]; const ShQuantCh *q = &ct->q[it & 1];
-      WV_LDS PlLane *c = &P[lane];
-      c->minInvGain_Q30 = in->minInvGain_Q30; c->LTPredCodGain_Q7 = in->LTPredCodGain_Q7; c->coding_quality_Q14 = in->coding_quality_Q14; c->input_quality_Q14 = in->input_quality_Q14;
-      c->predictLPCOrder = in->predictLPCOrder; c->nb_subfr = in->nb_subfr; c->subfr_length = in->subfr_length; c->useInterpolatedNLSFs = in->useInterpolatedNLSFs;
-      c->first_frame_after_reset = in->first_frame_after_reset; c->speech_activity_Q8 = in->speech_activity_Q8; c->NLSF_MSVQ_Survivors = in->NLSF_MSVQ_Survivors;
-      c->SNR_dB_Q7 = in->SNR_dB_Q7; c->input_tilt_Q15 = in->input_tilt_Q15; c->nStatesDelayedDecision = in->nStatesDelayedDecision;
-      c->LastGainIndex = q->LastGainIndex; c->condCoding = q->condCoding;
-      for (int i = 0; i < 4; i++) { c->local_gains[i] = in->local_gains[i]; c->Gains_Q16[i] = q->fr.Gains_Q16[i]; }
-      for (int i = 0; i < 16; i++) c->prev_NLSFq_Q15[i] = in->prev_NLSFq_Q15[i];
-      { const i32 *s = (const i32 *)&q->indices; WV_LDS i32 *d = (WV_LDS i32 *)&c->indices; for (int i = 0; i < (int)(sizeof(OaSilkEncIndices) / 4); i++) d[i] = s[i]; }
-   }
+   FOR_LANES(i, 40) se_nlsf_out_tabs(&T[i >= 20], i >= 20 ? i - 20 : i, i >= 20 ? SK_NLSF_NB_MB_QSTEP_Q16 : SK_NLSF_WB_QSTEP_Q16);
    wv_sync();
    if (lane < cnt) {
-      WV_LDS PlLane *c = &P[lane];
-      pl_pred_lane(c);
       const int it = list[base + lane];
-      ShCont *ct = &conts[it >> 1]; ShQuantCh *q = &ct->q[it & 1];
-      const int order = c->predictLPCOrder;
+      ShCont *ct = &conts[it >> 1]; const ShPredIn *in = &ct->p[it & 1]; const ShPredMid *md = &ct->m[it & 1]; ShQuantCh *q = &ct->q[it & 1];
+      WV_LDS PlBLane *c = &B[lane];
+      const int order = in->predictLPCOrder, ic = md->coef;
+      for (int i = 0; i < 16; i++) { c->NLSF_Q15[i] = md->NLSF_Q15[i]; c->prev[i] = in->prev_NLSFq_Q15[i]; }
+      for (int i = 0; i < 17; i++) c->ind[i] = q->indices.NLSFIndices[i];
+      pl_stage_b(c, in, ic, q->indices.signalType, &T[order == 16 ? 0 : 1]);
       for (int i = 0; i < 32; i++) q->fr.PredCoef_Q12[i] = c->PredCoef_Q12[i >> 4][i & 15];
-      for (int i = 0; i < 4; i++) { q->fr.Gains_Q16[i] = c->Gains_Q16[i]; q->GainsUnq_Q16[i] = c->GainsUnq_Q16[i]; }
-      { i32 *d = (i32 *)&q->indices; const WV_LDS i32 *s = (const WV_LDS i32 *)&c->indices; for (int i = 0; i < (int)(sizeof(OaSilkEncIndices) / 4); i++) d[i] = s[i]; }
+      for (int i = 0; i < 17; i++) q->indices.NLSFIndices[i] = c->ind[i];
+      q->indices.NLSFInterpCoef_Q2 = (i8)ic;
       { i16 *pn = streams[it >> 1].silk.ch[q->chan].prev_NLSFq_Q15; for (int i = 0; i < 16; i++) pn[i] = i < order ? c->NLSF_Q15[i] : (i16)0; }
-      q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Lambda_Q10 = c->Lambda_Q10;
-      q->lastGainIndexPrev = c->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex;
-      if (q->chan == 0) ct->sc.offset = se_quantization_offsets_q10[(c->indices.signalType >> 1) * 2 + c->indices.quantOffsetType];      /* (as in oa_sh_pred_frame) */
    }
    wv_sync();
 }

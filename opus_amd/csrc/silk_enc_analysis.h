@@ -398,28 +398,18 @@ WV_DEVN void se_noise_shape_analysis_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeE
 
 /* ---- silk_burg_modified_c.  QA 25, N_BITS_HEAD_ROOM 3, MIN_RSHIFTS -16, MAX_RSHIFTS 7 ---- */
 WV_DEV i64 se_inner_prod16(const WV_LDS i16 *a, const WV_LDS i16 *b, int len) { i64 s = 0; for (int i = 0; i < len; i++) s += (i32)a[i] * (i32)b[i]; return s; }
-/* stk: 84 words of LDS for the five working rows */
-template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q, PA A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D, WV_LDS i32 *stk)
+/* The order recursion reads, of every subframe, only its first and its last 16 samples: the accessors below let it run on the whole signal (head(s, i) = sample i of subframe
+ * s, tail(s, m) = its m-th sample from the end, m >= 1) or on those edges alone (pipeline mode 4: the correlations over the whole signal come from the front kernel,
+ * se_burg_corr_wave, and a lane of the pred lane kernel runs the recursion of its channel on 32 samples per subframe) */
+struct SeBurgXFull { const WV_LDS i16 *x; int L; WV_MEM i32 head(int s, int i) const { return x[s * L + i]; } WV_MEM i32 tail(int s, int m) const { return x[s * L + L - m]; } };
+struct SeBurgXEdges { const WV_LDS i16 *e; WV_MEM i32 head(int s, int i) const { return e[s * 32 + i]; } WV_MEM i32 tail(int s, int m) const { return e[s * 32 + 32 - m]; } };
+/* stk: 84 words of LDS for the five working rows; C_first_row (stk[0..15]) holds the first row of the correlation matrix on entry */
+template <class PA, class XA> WV_DEV void se_burg_rec_l0(i32 *res_nrg, int *res_nrg_Q, PA A_Q16, const XA xa, i32 C0, int rshifts, i32 minInvGain_Q30, int nb_subfr, int D, WV_LDS i32 *stk)
 {
    const int QA = 25;
    WV_LDS i32 *C_first_row = stk, *C_last_row = stk + 16, *Af_QA = stk + 32, *CAf = stk + 48, *CAb = stk + 66;
-   int k, n, s, lz, rshifts, reached_max_gain;
-   i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
-   const i64 C0_64 = se_inner_prod16(x, x, subfr_length * nb_subfr);
-   lz = se_clz64(C0_64);
-   rshifts = 32 + 1 + 3 - lz;
-   if (rshifts > 32 - QA) rshifts = 32 - QA;
-   if (rshifts < -16) rshifts = -16;
-   if (rshifts > 0) C0 = (i32)(C0_64 >> rshifts); else C0 = shl32((i32)C0_64, -rshifts);
-   CAb[0] = CAf[0] = C0 + sk_mulhi(SE_FIX(1e-5f, 32), C0) + 1;
-   for (k = 0; k < 16; k++) C_first_row[k] = 0;
-   for (s = 0; s < nb_subfr; s++) {
-      const WV_LDS i16 *x_ptr = x + s * subfr_length;
-      for (n = 1; n < D + 1; n++) {
-         const i64 ip = se_inner_prod16(x_ptr, x_ptr + n, subfr_length - n);
-         if (rshifts > 0) C_first_row[n - 1] += (i32)(ip >> rshifts); else C_first_row[n - 1] = add32(C_first_row[n - 1], shl32((i32)ip, -rshifts));
-      }
-   }
+   int k, n, s, lz, reached_max_gain;
+   i32 num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
    for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
    CAb[0] = CAf[0] = C0 + sk_mulhi(SE_FIX(1e-5f, 32), C0) + 1;
    invGain_Q30 = (i32)1 << 30;
@@ -427,35 +417,33 @@ template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q
    for (n = 0; n < D; n++) {
       if (rshifts > -2) {
          for (s = 0; s < nb_subfr; s++) {
-            const WV_LDS i16 *x_ptr = x + s * subfr_length;
-            x1 = -shl32((i32)x_ptr[n], 16 - rshifts); x2 = -shl32((i32)x_ptr[subfr_length - n - 1], 16 - rshifts);
-            tmp1 = shl32((i32)x_ptr[n], QA - 16); tmp2 = shl32((i32)x_ptr[subfr_length - n - 1], QA - 16);
+            x1 = -shl32(xa.head(s, n), 16 - rshifts); x2 = -shl32(xa.tail(s, n + 1), 16 - rshifts);
+            tmp1 = shl32(xa.head(s, n), QA - 16); tmp2 = shl32(xa.tail(s, n + 1), QA - 16);
             for (k = 0; k < n; k++) {
-               C_first_row[k] = sk_mlawb(C_first_row[k], x1, x_ptr[n - k - 1]);
-               C_last_row[k] = sk_mlawb(C_last_row[k], x2, x_ptr[subfr_length - n + k]);
+               C_first_row[k] = sk_mlawb(C_first_row[k], x1, xa.head(s, n - k - 1));
+               C_last_row[k] = sk_mlawb(C_last_row[k], x2, xa.tail(s, n - k));
                Atmp_QA = Af_QA[k];
-               tmp1 = sk_mlawb(tmp1, Atmp_QA, x_ptr[n - k - 1]);
-               tmp2 = sk_mlawb(tmp2, Atmp_QA, x_ptr[subfr_length - n + k]);
+               tmp1 = sk_mlawb(tmp1, Atmp_QA, xa.head(s, n - k - 1));
+               tmp2 = sk_mlawb(tmp2, Atmp_QA, xa.tail(s, n - k));
             }
             tmp1 = shl32(-tmp1, 32 - QA - rshifts); tmp2 = shl32(-tmp2, 32 - QA - rshifts);
-            for (k = 0; k <= n; k++) { CAf[k] = sk_mlawb(CAf[k], tmp1, x_ptr[n - k]); CAb[k] = sk_mlawb(CAb[k], tmp2, x_ptr[subfr_length - n + k - 1]); }
+            for (k = 0; k <= n; k++) { CAf[k] = sk_mlawb(CAf[k], tmp1, xa.head(s, n - k)); CAb[k] = sk_mlawb(CAb[k], tmp2, xa.tail(s, n - k + 1)); }
          }
       } else {
          for (s = 0; s < nb_subfr; s++) {
-            const WV_LDS i16 *x_ptr = x + s * subfr_length;
-            x1 = -shl32((i32)x_ptr[n], -rshifts); x2 = -shl32((i32)x_ptr[subfr_length - n - 1], -rshifts);
-            tmp1 = shl32((i32)x_ptr[n], 17); tmp2 = shl32((i32)x_ptr[subfr_length - n - 1], 17);
+            x1 = -shl32(xa.head(s, n), -rshifts); x2 = -shl32(xa.tail(s, n + 1), -rshifts);
+            tmp1 = shl32(xa.head(s, n), 17); tmp2 = shl32(xa.tail(s, n + 1), 17);
             for (k = 0; k < n; k++) {
-               C_first_row[k] = add32(C_first_row[k], (i32)((u32)x1 * (u32)(i32)x_ptr[n - k - 1]));
-               C_last_row[k] = add32(C_last_row[k], (i32)((u32)x2 * (u32)(i32)x_ptr[subfr_length - n + k]));
+               C_first_row[k] = add32(C_first_row[k], (i32)((u32)x1 * (u32)(i32)xa.head(s, n - k - 1)));
+               C_last_row[k] = add32(C_last_row[k], (i32)((u32)x2 * (u32)(i32)xa.tail(s, n - k)));
                Atmp1 = sk_rround(Af_QA[k], QA - 17);
-               tmp1 = add32(tmp1, (i32)((u32)(i32)x_ptr[n - k - 1] * (u32)Atmp1));
-               tmp2 = add32(tmp2, (i32)((u32)(i32)x_ptr[subfr_length - n + k] * (u32)Atmp1));
+               tmp1 = add32(tmp1, (i32)((u32)(i32)xa.head(s, n - k - 1) * (u32)Atmp1));
+               tmp2 = add32(tmp2, (i32)((u32)(i32)xa.tail(s, n - k) * (u32)Atmp1));
             }
             tmp1 = neg32(tmp1); tmp2 = neg32(tmp2);
             for (k = 0; k <= n; k++) {
-               CAf[k] = sk_mlaww(CAf[k], tmp1, shl32((i32)x_ptr[n - k], -rshifts - 1));
-               CAb[k] = sk_mlaww(CAb[k], tmp2, shl32((i32)x_ptr[subfr_length - n + k - 1], -rshifts - 1));
+               CAf[k] = sk_mlaww(CAf[k], tmp1, shl32((i32)xa.head(s, n - k), -rshifts - 1));
+               CAb[k] = sk_mlaww(CAb[k], tmp2, shl32((i32)xa.tail(s, n - k + 1), -rshifts - 1));
             }
          }
       }
@@ -499,8 +487,7 @@ template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q
    if (reached_max_gain) {
       for (k = 0; k < D; k++) A_Q16[k] = -sk_rround(Af_QA[k], QA - 16);
       for (s = 0; s < nb_subfr; s++) {
-         const WV_LDS i16 *x_ptr = x + s * subfr_length;
-         const i64 ip = se_inner_prod16(x_ptr, x_ptr, D);
+         i64 ip = 0; for (k = 0; k < D; k++) ip += xa.head(s, k) * xa.head(s, k);
          if (rshifts > 0) C0 -= (i32)(ip >> rshifts); else C0 = sub32(C0, shl32((i32)ip, -rshifts));
       }
       *res_nrg = shl32(sk_mulhi(invGain_Q30, C0), 2);
@@ -516,6 +503,28 @@ template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q
       *res_nrg = sk_mlaww(nrg, sk_mulhi(SE_FIX(1e-5f, 32), C0), -tmp1);
       *res_nrg_Q = -rshifts;
    }
+}
+
+/* silk_burg_modified_c, serial: the correlations over the whole signal, then the recursion */
+template <class PA> WV_DEV void se_burg_modified_l0(i32 *res_nrg, int *res_nrg_Q, PA A_Q16, const WV_LDS i16 *x, i32 minInvGain_Q30, int subfr_length, int nb_subfr, int D, WV_LDS i32 *stk)
+{
+   const int QA = 25;
+   WV_LDS i32 *C_first_row = stk;
+   const i64 C0_64 = se_inner_prod16(x, x, subfr_length * nb_subfr);
+   int rshifts = 32 + 1 + 3 - se_clz64(C0_64);
+   if (rshifts > 32 - QA) rshifts = 32 - QA;
+   if (rshifts < -16) rshifts = -16;
+   const i32 C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
+   for (int k = 0; k < 16; k++) C_first_row[k] = 0;
+   for (int s = 0; s < nb_subfr; s++) {
+      const WV_LDS i16 *x_ptr = x + s * subfr_length;
+      for (int n = 1; n < D + 1; n++) {
+         const i64 ip = se_inner_prod16(x_ptr, x_ptr + n, subfr_length - n);
+         if (rshifts > 0) C_first_row[n - 1] += (i32)(ip >> rshifts); else C_first_row[n - 1] = add32(C_first_row[n - 1], shl32((i32)ip, -rshifts));
+      }
+   }
+   const SeBurgXFull xa = {x, subfr_length};
+   se_burg_rec_l0(res_nrg, res_nrg_Q, A_Q16, xa, C0, rshifts, minInvGain_Q30, nb_subfr, D, stk);
 }
 
 /* silk_burg_modified_c on the whole wave.  Every inner loop of the reference is a sum of individually rounded terms added with wrap-around, so the terms are
@@ -627,6 +636,32 @@ WV_DEVN void se_burg_modified_wave(WV_LDS i32 *out, WV_LDS i32 *A_Q16, const WV_
       }
       out[1] = -rshifts;
    }
+}
+
+/* The part of silk_burg_modified_c that reads the whole signal -- its energy and the first row of the correlation matrix (burg_modified_FIX.c:73-98) -- on the wave, for a
+ * recursion that runs elsewhere (se_burg_rec_l0 on the signal's edges: pipeline mode 4).  T: 64 words of LDS. */
+struct SeBurgCorr { i32 C0, rshifts, first_row[16]; };
+WV_DEV void se_burg_corr_wave(SeBurgCorr *out /* global */, const WV_LDS i16 *x, int subfr_length, int nb_subfr, int D, WV_LDS i32 *T)
+{
+   const int QA = 25;
+   const int lane = wv_lane(), s = lane >> 4, k = lane & 15;
+   const bool sact = s < nb_subfr;
+   const WV_LDS i16 *xs = x + (sact ? s : 0) * subfr_length;
+   i64 part = 0;
+   FOR_LANES(i, subfr_length * nb_subfr) part += (i32)x[i] * (i32)x[i];
+   const i64 C0_64 = wv_sum64(part);
+   int rshifts = 32 + 1 + 3 - se_clz64(C0_64);
+   if (rshifts > 32 - QA) rshifts = 32 - QA;
+   if (rshifts < -16) rshifts = -16;
+   const i32 C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
+   i32 term = 0;
+   if (sact && k < D) { const i64 ip = se_inner_prod16(xs, xs + k + 1, subfr_length - k - 1); term = rshifts > 0 ? (i32)(ip >> rshifts) : shl32((i32)ip, -rshifts); }
+   wv_sync();
+   T[lane] = term;
+   wv_sync();
+   if (lane < 16) { i32 v = 0; for (int q = 0; q < nb_subfr; q++) v = add32(v, T[q * 16 + lane]); out->first_row[lane] = lane < D ? v : 0; }
+   if (lane == 0) { out->C0 = C0; out->rshifts = rshifts; }
+   wv_sync();
 }
 
 /* ---- silk_quant_LTP_gains + silk_VQ_WMat_EC_c ---- */

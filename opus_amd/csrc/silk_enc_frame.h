@@ -454,7 +454,7 @@ template <int FRONT = 0> WV_DEV void se_frame_head_wave(WV_LDS SilkEncLds *S, WV
    FOR_LANES(i, c->frame_length) x_frame[5 * c->fs_kHz + i] = inputBuf[1 + i];
    wv_sync();
 }
-WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, int condCoding, ShPredIn *pj = nullptr /* the split path with its pred kernel: stop where that kernel takes over */)
+WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel *c, int condCoding, ShPredIn *pj = nullptr /* the split path with its pred kernel: stop where that kernel takes over */, int pj_corr = 0)
 {
    WV_LDS SeEncCtrl *ctl = &S->ctl;
    WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
@@ -468,7 +468,7 @@ WV_DEV void se_frame_analysis_wave(WV_LDS SilkEncLds *S, WV_LDS OaSilkEncChannel
    wv_sync();
    SE_TAP(1);
    SE_PHASE(S, 4);
-   se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.W.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15], pj);
+   se_find_pred_coefs_wave(c, ctl, res_pitch_frame, x_frame, condCoding, &A->u.p.W, A->u.p.W.LPC_in_pre, A->u.p.W.XX, A->u.p.W.LPC_res, &S->r[15], pj, pj_corr);
    SE_TAP(2);
    SE_PHASE(S, 5);
    if (pj) return;

@@ -312,6 +312,33 @@ template <class CH> WV_DEV void se_process_nlsfs_wave(WV_LDS CH *c, WV_LDS i16 *
    wv_sync();
 }
 
+/* the interpolation search of silk_find_LPC_FIX (find_LPC_FIX.c:88-138) once the four candidates' LPC coefficients (cand_a[k][16], k/4 of the way from last frame's NLSFs
+ * to this frame's second-half NLSFs) are there: the residual energies of the first half frame, measured one candidate after the other by the whole wave, and the reference's
+ * running comparison replayed on uniform values.  *res_nrg / *res_nrg_Q: in = the full-frame analysis' energy less the second half's; out = the winner's.  Returns the
+ * interpolation index (4: none) */
+WV_DEV int se_interp_search_wave(const WV_LDS i16 *x, const WV_LDS i16 *cand_a, WV_LDS i16 *LPC_res, int subfr_length /* incl. the order */, int order, i32 *res_nrg_io, int *res_nrg_Q_io)
+{
+   i32 res_nrg = *res_nrg_io; int res_nrg_Q = *res_nrg_Q_io, coef = 4;
+   for (int k = 3; k >= 0; k--) {
+      se_lpc_analysis_filter_wave(LPC_res, x, cand_a + 16 * k, 2 * subfr_length, order);
+      wv_sync();
+      i32 res_nrg0, res_nrg1; int rshift0, rshift1, res_nrg_interp_Q, isInterpLower;
+      se_sum_sqr_shift_wave(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order);
+      se_sum_sqr_shift_wave(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order);
+      int shift = rshift0 - rshift1;
+      if (shift >= 0) { res_nrg1 >>= shift; res_nrg_interp_Q = -rshift0; } else { res_nrg0 >>= -shift; res_nrg_interp_Q = -rshift1; }
+      const i32 res_nrg_interp = add32(res_nrg0, res_nrg1);
+      shift = res_nrg_interp_Q - res_nrg_Q;
+      if (shift >= 0) isInterpLower = (res_nrg_interp >> shift) < res_nrg;
+      else if (-shift < 32) isInterpLower = res_nrg_interp < (res_nrg >> -shift);
+      else isInterpLower = 0;
+      if (isInterpLower) { res_nrg = res_nrg_interp; res_nrg_Q = res_nrg_interp_Q; coef = k; }
+      wv_sync();
+   }
+   *res_nrg_io = res_nrg; *res_nrg_Q_io = res_nrg_Q;
+   return coef;
+}
+
 /* x = LPC_in_pre; LPC_res: i16[2 * 96] */
 template <class CH> WV_DEVN void se_find_lpc_wave(WV_LDS CH *c, WV_LDS SeLpcWork *W, const WV_LDS i16 *x, i32 minInvGain_Q30, WV_LDS i16 *LPC_res, WV_LDS i32 *tk)
 {
@@ -347,23 +374,8 @@ template <class CH> WV_DEVN void se_find_lpc_wave(WV_LDS CH *c, WV_LDS SeLpcWork
          sd_nlsf2a_w(cand_a + 16 * lane, n, order, lane == 0 ? W->wk : pool + (lane - 1) * 66);
       }
       wv_sync();
-      i32 res_nrg = W->r[0]; int res_nrg_Q = W->r[1], coef = 4;
-      for (int k = 3; k >= 0; k--) {
-         se_lpc_analysis_filter_wave(LPC_res, x, cand_a + 16 * k, 2 * subfr_length, order);
-         wv_sync();
-         i32 res_nrg0, res_nrg1; int rshift0, rshift1, res_nrg_interp_Q, isInterpLower;
-         se_sum_sqr_shift_wave(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order);
-         se_sum_sqr_shift_wave(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order);
-         int shift = rshift0 - rshift1;
-         if (shift >= 0) { res_nrg1 >>= shift; res_nrg_interp_Q = -rshift0; } else { res_nrg0 >>= -shift; res_nrg_interp_Q = -rshift1; }
-         const i32 res_nrg_interp = add32(res_nrg0, res_nrg1);
-         shift = res_nrg_interp_Q - res_nrg_Q;
-         if (shift >= 0) isInterpLower = (res_nrg_interp >> shift) < res_nrg;
-         else if (-shift < 32) isInterpLower = res_nrg_interp < (res_nrg >> -shift);
-         else isInterpLower = 0;
-         if (isInterpLower) { res_nrg = res_nrg_interp; res_nrg_Q = res_nrg_interp_Q; coef = k; }
-         wv_sync();
-      }
+      i32 res_nrg = W->r[0]; int res_nrg_Q = W->r[1];
+      const int coef = se_interp_search_wave(x, cand_a, LPC_res, subfr_length, order, &res_nrg, &res_nrg_Q);
       LANE0 { W->r[0] = res_nrg; W->r[1] = res_nrg_Q; c->indices.NLSFInterpCoef_Q2 = (i8)coef; }
       wv_sync();
    }
@@ -393,11 +405,12 @@ struct ShPredIn {
    i32 predictLPCOrder, nb_subfr, subfr_length, useInterpolatedNLSFs, first_frame_after_reset, speech_activity_Q8, NLSF_MSVQ_Survivors, SNR_dB_Q7, input_tilt_Q15, nStatesDelayedDecision;
    i16 prev_NLSFq_Q15[16];
    i16 LPC_in_pre[4 * 16 + 320];
+   SeBurgCorr bc[2];                   /* pipeline mode 4: the correlations of the two Burg analyses (whole frame; last two subframes), worked out where the signal is in LDS */
 };
 /* pj != NULL (the split path's front kernel): stop after the LPC analysis' input has been worked out (find_pred_coefs_FIX.c:45-101) and hand it, with the gain bound of :103-113,
  * to the pred kernel, which runs silk_find_LPC_FIX, silk_process_NLSFs, silk_residual_energy_FIX (:115-144) and silk_process_gains_FIX at twice this kernel's occupancy */
 WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, const WV_LDS i16 *res_pitch, const WV_LDS i16 *x, int condCoding,
-      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk, ShPredIn *pj = nullptr)
+      WV_LDS SeLpcWork *W, WV_LDS i16 *LPC_in_pre, WV_LDS i32 *XX, WV_LDS i16 *LPC_res, WV_LDS i32 *tk, ShPredIn *pj = nullptr, int pj_corr = 0 /* export the Burg correlations too */)
 {
    const int order = c->predictLPCOrder, nb = c->nb_subfr, sl = c->subfr_length;
    LANE0 {
@@ -440,6 +453,10 @@ WV_DEVN void se_find_pred_coefs_wave(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtr
          pj->nStatesDelayedDecision = c->nStatesDelayedDecision;
       }
       wv_sync();
+      if (pj_corr) {
+         se_burg_corr_wave(&pj->bc[0], LPC_in_pre, sl + order, nb, order, W->stk);
+         if (c->useInterpolatedNLSFs && !c->first_frame_after_reset && nb == 4) se_burg_corr_wave(&pj->bc[1], LPC_in_pre + 2 * (sl + order), sl + order, 2, order, W->stk);
+      }
       return;
    }
    se_find_lpc_wave(c, W, LPC_in_pre, minInvGain_Q30, LPC_res, tk);

@@ -42,7 +42,7 @@ char *emu_lds_window(size_t lds, const char *kernel_name)
    emu_smem_p = (char (*)[])w;
    return w;
 }
-thread_local unsigned emu_block_x = 0;
+thread_local unsigned emu_block_x = 0, emu_grid_x = 1;
 #define OPUS_AMD_WAVE_H            /* wave_emu.h is the wave vocabulary here */
 #define OPUS_AMD_EMU_HOST 1
 #include "../../opus_amd/csrc/opus_amd.hip"

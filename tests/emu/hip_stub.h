@@ -32,13 +32,15 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 extern thread_local char (*emu_smem_p)[];
 #define smem (*emu_smem_p)
 char *emu_lds_window(size_t lds, const char *kernel_name);      /* emu_host.cpp */
-extern thread_local unsigned emu_block_x;
+extern thread_local unsigned emu_block_x, emu_grid_x;
 struct EmuIdx { unsigned x, y, z; };
 static inline EmuIdx emu_tidx() { EmuIdx i = {(unsigned)(emu_cur->cur ^ emu_flip), 0, 0}; return i; }
 static inline EmuIdx emu_bidx() { EmuIdx i = {emu_block_x, 0, 0}; return i; }
 static inline void __syncthreads() { emu_rendezvous(); }
 #define threadIdx (emu_tidx())
 #define blockIdx (emu_bidx())
+static inline EmuIdx emu_gdim() { EmuIdx i = {emu_grid_x, 1, 1}; return i; }
+#define gridDim (emu_gdim())
 
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -78,6 +80,7 @@ static void emu_launch_tramp(void *p) { (*(std::function<void()> *)p)(); }
  * the kernel's name instead of passing on the emulator and failing -- or silently differing -- on the device */
 static inline void emu_launch(dim3 grid, size_t lds, const char *name, std::function<void()> body)
 {
+   emu_grid_x = grid.x;
    for (unsigned b = 0; b < grid.x; b++) {
       emu_block_x = b;
       char *w = emu_lds_window(lds, name);

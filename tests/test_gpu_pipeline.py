@@ -1,6 +1,6 @@
 """MI355X: the settings matrix and the settings fuzzers ONCE MORE with every 10 / 20 ms call of the SILK-capable encoder forced through the kernel
-pipeline (OPUS_AMD_SET_KERNEL_PIPELINE(3): front / pred / quantiser / back, opus_amd/csrc/opus_sh_split.h -- the path a >= 64-stream launch, i.e. the bench, takes by itself --
-and (1): the same without the pred kernel), against the compiled reference:
+pipeline (OPUS_AMD_SET_KERNEL_PIPELINE(4): front / pred lane + wave kernels / quantiser / back, opus_amd/csrc/opus_sh_split.h -- the path a >= 64-stream launch, i.e. the bench,
+takes by itself --, (3): the pred stage as one wave-per-channel kernel, and (1): the pipeline without a pred stage of its own), against the compiled reference:
 tests/test_gpu_silkenc.py's matrix (SILK, hybrid, CELT-only and automatic modes, complexities, hard CBR, tight buffers, DTX, in-band FEC), the encoder / sparse / batch-ABI /
 multistream fuzzers of tests/test_hostemu_fuzz.py, the pinned seeds and the deterministic case of the round-4 review (the LBRR side stream owed after FEC goes 1 -> 0).
 The small launches of the other GPU test files take the one-kernel path; here the same cases meet the reference through the pipeline."""
@@ -8,7 +8,7 @@ import pytest
 import test_gpu_silkenc as G, test_hostemu_fuzz as Z
 pytestmark = pytest.mark.gpu
 
-@pytest.fixture(autouse=True, params=[3, 1], ids=["front-pred-quant-back", "front-quant-back"])
+@pytest.fixture(autouse=True, params=[4, 3, 1], ids=["front-pred(lanes)-quant-back", "front-pred-quant-back", "front-quant-back"])
 def _through_the_pipeline(request, monkeypatch):
     monkeypatch.setattr(G, "PIPELINE", request.param); monkeypatch.setattr(Z, "WHICH", "gpu"); monkeypatch.setattr(Z, "PIPELINE", request.param)
 
@@ -33,7 +33,7 @@ def test_pipeline_is_a_per_batch_switch():
     import ctypes, numpy as np, opus_amd as oa
     L = oa.lib(); L.opusgpu_enc_batch_split_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     out = []
-    for mode in (0, 3):
+    for mode in (0, 4):
         b = oa.EncoderBatch(6, channels=1, application=2048, Fs=16000); b.ctl(11902, mode); assert b.get(11903, 0) == mode
         for k, v in dict(force_mode=1000, bitrate=24000, complexity=10).items(): b.ctl(G.REQ[k], v)
         sig = [G.speech(16000, 0.4, 1, 50 + s) for s in range(6)]

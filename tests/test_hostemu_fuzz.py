@@ -537,20 +537,23 @@ def fuzz_float_out(seed):
 def test_float_output_fuzz_against_the_reference(seed): fuzz_float_out(seed)
 
 
-# ---- the same fuzzers with every 10 / 20 ms call forced through the front / pred / quantiser / back kernel pipeline (OPUS_AMD_SET_KERNEL_PIPELINE(3)), against the reference ----
+# ---- the same fuzzers with every 10 / 20 ms call forced through the front / pred / quantiser / back kernel pipeline (OPUS_AMD_SET_KERNEL_PIPELINE(4): the pred stage as lane + wave kernels), against the reference ----
 # sparse 7770080, batch 7770010: the round-4 review's finds -- the LBRR side stream of the packet before is owed at the head of the first packet after in-band FEC goes 1 -> 0
 # (enc_API.c:364-404), and the front kernel coded it into its 64-byte header window; the emulator's LDS watch (hip_stub.h: the window now ends at an inaccessible page, loads
 # included) aborts on the spot, on the GPU the stores were dropped and the packet differed from byte 64 on with the same final range
 @pytest.mark.parametrize("seed", [7770080, 3000003] + ([7770000, 7770001, 3000007] if LONG else []))       # (3000003, 3000007: with OPUS_SET_EXPERT_FRAME_DURATION changes)
-def test_sparse_settings_fuzz_through_the_pipeline(seed): fuzz_sparse(seed, pipeline=3)
+def test_sparse_settings_fuzz_through_the_pipeline(seed): fuzz_sparse(seed, pipeline=4)
 
 @pytest.mark.parametrize("seed", [7770010] + ([7770000, 7770001] if LONG else []))
-def test_batch_abi_settings_fuzz_through_the_pipeline(seed): fuzz_batch(seed, pipeline=3)
+def test_batch_abi_settings_fuzz_through_the_pipeline(seed): fuzz_batch(seed, pipeline=4)
 
 @pytest.mark.parametrize("seed", [1] + ([248, 300, 7770000] if LONG else []))
-def test_settings_fuzz_through_the_pipeline(seed): fuzz(seed, pipeline=3)
+def test_settings_fuzz_through_the_pipeline(seed): fuzz(seed, pipeline=4)
 
-@pytest.mark.parametrize("pipeline", [3, 1, 2, 0])
+@pytest.mark.parametrize("seed", [7770080] + ([1, 3000003] if LONG else []))
+def test_sparse_settings_fuzz_through_the_one_wave_pred_kernel(seed): fuzz_sparse(seed, pipeline=3)
+
+@pytest.mark.parametrize("pipeline", [4, 3, 1, 2, 0])
 @pytest.mark.parametrize("ch", [1, 2])
 def test_pending_lbrr_after_fec_is_switched_off(pipeline, ch):
     """the deterministic case of the round-4 review (BASELINE config-3 shape): 16 kHz VOIP, SILK forced, complexity 10, 96 kb/s, in-band FEC with 20 % expected loss for ten
