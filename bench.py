@@ -26,12 +26,12 @@ GATHER = "rccl"          # --gather
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
-    3: dict(name="SILK-only encode, VOIP, 16 kHz mono, 20 ms, wideband, VBR 24 kb/s, complexity 10", app=2048, Fs=16000, ch=1, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
+    3: dict(name="SILK-only encode, VOIP, 16 kHz mono, 20 ms, wideband, VBR 24 kb/s, complexity 10", app=2048, Fs=16000, ch=1, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded frames/s (SILK-only, 16 kHz mono, 20 ms, complexity 10)"),
-    4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
+    4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1001), (4008, 1105), (4006, 1), (4002, 128000), (4010, 10)), metric="encoded frames/s (hybrid, 48 kHz stereo, 20 ms, complexity 10)"),
     5: dict(name="multistream, 255 mono AUDIO streams per encoder (mapping family 255), 48 kHz, 20 ms, 64 kb/s per stream, complexity 10; 257 encoders = 65,535 elementary streams",
-            app=2049, Fs=48000, ch=1, kernel="oa_sh_front_kernel + oa_sh_quant_kernel + oa_sh_back_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
+            app=2049, Fs=48000, ch=1, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
 
 def reference_music(nsamp, seeds, starts=None):
