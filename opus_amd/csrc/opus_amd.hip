@@ -173,7 +173,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
       __syncthreads();
    }
 }
-/* the split path (opus_sh_split.h).  counters: [0] front queue, [1] quantiser queue, [2] back queue, [3] queue of the one-kernel pass over the calls turned away, [4] their count */
+/* the split path (opus_sh_split.h).  counters: [0] front queue, [1] quantiser queue, [2] back queue, [3] queue of the one-kernel pass over the calls turned away, [4] their count, [5] queue of the one-wave pred kernel (value 3), [6] count of the pred work list */
 #ifndef OA_SH_FRONT_WAVES_PER_EU
 #define OA_SH_FRONT_WAVES_PER_EU 4
 #endif
@@ -226,22 +226,20 @@ oa_sh_pred_kernel(OaShStream *streams, ShCont *conts, const int *list, const uns
 }
 /* pipeline mode 4: the stage's serial parts on lanes, its passes over the signal on waves (silk_enc_predl.h, opus_sh_split.h) -- four launches over the same work list */
 extern "C" __global__ void __launch_bounds__(64, 1)
-oa_sh_preda_kernel(ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+oa_sh_preda_kernel(ShCont *conts, const int *list, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    const int n = (int)*list_count, ntiles = (n + PL_STREAMS - 1) / PL_STREAMS;
-   (void)queue;
    for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
       oa_sh_preda_tile((WV_LDS i32 *)smem, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
       __syncthreads();
    }
 }
 extern "C" __global__ void __launch_bounds__(64, OA_SH_PRED_WAVES_PER_EU)
-oa_sh_predc_kernel(ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+oa_sh_predc_kernel(ShCont *conts, const int *list, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    const int n = (int)*list_count;
-   (void)queue;
    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {           /* (short uniform items: a static split, as in the stage's tail) */
       const int it = wv_uni(list[i]);
       oa_sh_predc_frame((WV_LDS PredLds *)smem, conts + (it >> 1), it & 1);
@@ -249,11 +247,10 @@ oa_sh_predc_kernel(ShCont *conts, const int *list, const unsigned *list_count, u
    }
 }
 extern "C" __global__ void __launch_bounds__(64, 1)
-oa_sh_predb_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count, unsigned *queue)
+oa_sh_predb_kernel(OaShStream *streams, ShCont *conts, const int *list, const unsigned *list_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    const int n = (int)*list_count, ntiles = (n + PL_STREAMS - 1) / PL_STREAMS;
-   (void)queue;
    for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
       oa_sh_predb_tile((WV_LDS PlBLane *)smem, (WV_LDS SeNlsfTabs *)(smem + sizeof(PlBLane) * PL_STREAMS), streams, conts, list, t * PL_STREAMS, imin(PL_STREAMS, n - t * PL_STREAMS));
       __syncthreads();
@@ -693,9 +690,9 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split);
    if (mode == 4) {
       const int *pl = (const int *)(b->d_slow_list + n); const unsigned *pc = (const unsigned *)(b->d_queue + 6);
-      hipLaunchKernelGGL(oa_sh_preda_kernel, dim3((unsigned)g_pa), dim3(64), lds_pa, s, b->d_cont, pl, pc, b->d_queue + 7);
-      hipLaunchKernelGGL(oa_sh_predc_kernel, dim3((unsigned)g_pc), dim3(64), sizeof(PredLds), s, b->d_cont, pl, pc, b->d_queue + 8);
-      hipLaunchKernelGGL(oa_sh_predb_kernel, dim3((unsigned)g_pb), dim3(64), lds_pb, s, b->d_sh, b->d_cont, pl, pc, b->d_queue + 9);
+      hipLaunchKernelGGL(oa_sh_preda_kernel, dim3((unsigned)g_pa), dim3(64), lds_pa, s, b->d_cont, pl, pc);
+      hipLaunchKernelGGL(oa_sh_predc_kernel, dim3((unsigned)g_pc), dim3(64), sizeof(PredLds), s, b->d_cont, pl, pc);
+      hipLaunchKernelGGL(oa_sh_predb_kernel, dim3((unsigned)g_pb), dim3(64), lds_pb, s, b->d_sh, b->d_cont, pl, pc);
    }
    if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5, mode == 4 ? 1 : 0);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);

@@ -1,4 +1,5 @@
-/* opus_sh_split.h — the SILK-capable Opus encoder as three kernels instead of one: what a call does before, inside and after SILK's rate-control loop.
+/* opus_sh_split.h — the SILK-capable Opus encoder as a pipeline of kernels instead of one: what a call does before, inside and after SILK's rate-control loop, and (pipeline
+ * values 3 / 4) the prediction stage in front of that loop as a stage of its own.
  *
  * Why: inside one wave the noise-shaping quantiser (silk/NSQ_del_dec.c:114: a 320-step recurrence per stream whose only parallelism is its <= 4 survivors) and the
  * entropy coder (silk/encode_indices.c:35, encode_pulses.c:60: one symbol after the other) keep 4 and 1 of the 64 lanes busy for 40-50 % of a frame, and their
@@ -7,7 +8,11 @@
  * decisions (silk/fixed/encode_frame_FIX.c:170-370), each lane coding into its own stream's buffer.
  *
  *   front kernel  (one wave per stream)   oa_sh_front_frame   opus_encode_native's decisions, analysis.c, high-pass, silk_Encode up to and including silk_process_gains_FIX for
- *                                                             every coded channel (src/opus_encoder.c:1182-2189, silk/enc_API.c:150-470, encode_frame_FIX.c:98-160) -> ShCont
+ *                                                             every coded channel (src/opus_encoder.c:1182-2189, silk/enc_API.c:150-470, encode_frame_FIX.c:98-160) -> ShCont;
+ *                                                             values 3 / 4: only up to the LPC analysis' input (find_pred_coefs_FIX.c:101) -> ShCont.p
+ *   pred stage    (values 3 / 4)          oa_sh_pred_frame    silk_find_LPC_FIX, silk_process_NLSFs, silk_residual_energy_FIX, silk_process_gains_FIX per coded channel: one wave
+ *                                         oa_sh_preda_tile .. per channel (3), or lane kernels for the serial chains + wave kernels for the passes over the signal (4: the
+ *                                                             default of a wide launch; silk_enc_predl.h)
  *   quant kernel  (16 streams per wave)   sq_quant_tile_wave  per coded channel: silk_NSQ_del_dec, silk_encode_indices, silk_encode_pulses inside the rate loop
  *                                                             (encode_frame_FIX.c:162-378); NSQ state, gain indices, coder state and payload bytes back to HBM
  *   back kernel   (one wave per stream)   oa_sh_back_frame    the flag bits of the SILK payload, the bit reservoir (enc_API.c:522-545), then opus_encode_frame_native from

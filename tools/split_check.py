@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/split_check.py — the SILK-capable encoder's split path (front / quantiser / back kernels, opus_amd/csrc/opus_sh_split.h) against its one-kernel path:
-the same batches through OPUS_AMD_SH_SPLIT = 0, 1, 2 (one subprocess each: the switch is read once per process) must give identical packets, final ranges AND
+the same batches through OPUS_AMD_SH_SPLIT = 0 .. 4 (one subprocess each: the process-wide default of OPUS_AMD_SET_KERNEL_PIPELINE) must give identical packets, final ranges AND
 identical stream records, byte for byte.  usage: split_check.py [emu|gpu]      (child: split_check.py <lib> <mode> <out.pkl>)"""
 import os, sys, ctypes, pickle, subprocess, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
