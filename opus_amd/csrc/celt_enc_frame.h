@@ -43,7 +43,7 @@ WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to,
 /* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
  * constants of the prologue in L->sh, the int16 input staged in L->g->pcm16 (HBM) and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
  * HYB = the hybrid branches of the reference (start band 17: no pitch pre-filter, no tf_analysis, weak transients, its own VBR target, :2030-2470). */
-template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr)
+template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -68,7 +68,7 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
    LANE0 { sh->isTransient = 0; sh->shortBlocks = 0; sh->tf_estimate = 0; sh->tf_chan = 0; sh->weak_transient = 0; sh->transient_got_disabled = 0; }
    wv_sync();
    K_PHASE(3);
-   if (sh->complexity >= 1 && !sh->lfe) transient_analysis_wave(L, ps0, ps1, HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2);
+   if (sh->complexity >= 1 && !sh->lfe) transient_analysis_wave(L, ps0, ps1, HYB && sh->effectiveBytes < 15 && sh->silk_signalType != 2, tr_pre);
    wv_sync();
    K_DUMPI("isTransient", sh->isTransient); K_DUMPI("tf_estimate", (i16)sh->tf_estimate); K_DUMPI("tf_chan", sh->tf_chan);
    LANE0 sh->toneishness = imin(sh->toneishness, QC32(1.f, 29) - shl32((i16)sh->tf_estimate, 15));
@@ -475,7 +475,7 @@ WV_DEV i32 oa_frame_energy_wave(const i16 *pcm, int len, i32 sample_max)
 
 /* One coded frame of a CELT-only application: opus_encode_frame_native (src/opus_encoder.c:1855) with mode == MODE_CELT_ONLY and no delay compensation.
  * The packet ends up in L->packet; returns its length before CBR padding (1 = DTX / bare TOC), or a negative OPUS_* code. */
-WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal)
+WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal, const i32 *tr_pre = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -519,7 +519,7 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
       LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; st->rangeFinal = 0; sh->ret = 2; }
       wv_sync();
-   } else celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask);
+   } else celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask, tr_pre);
    K_PHASE(14);
    LANE0 {   /* the generalised DTX decision (:2565-2576, decide_dtx_mode :1115): after 200 ms without activity the packet is the TOC alone, at most 400 ms in a row.  It is
               * taken only where SILK's own DTX is off (:2565) -- and silk_mode.useDTX = use_dtx && !(analysis valid || digital silence) (:1461; without the float API
@@ -540,7 +540,8 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
 }
 
 WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
-      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr, int analysis_frame_size = 0 /* samples per channel pcm (and apcm) hold: >= frame_size, the caller's look-ahead (:2662-2690); 0 = frame_size */)
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr, int analysis_frame_size = 0 /* samples per channel pcm (and apcm) hold: >= frame_size, the caller's look-ahead (:2662-2690); 0 = frame_size */,
+      const i32 *tr_pre = nullptr /* the transient pre-pass's record of this stream for this call's frame (celt_enc_front.h: ct_transient_tile), or NULL */)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -591,7 +592,7 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       result = sh->plc_frame == 2 ? wv_uni(sh->ret) : emit_packet_wave(L, out, sh->ret, gs->cfg.use_vbr ? 0 : sh->call_max_data_bytes, out_cap);
       LANE0 st->rangeFinal = 0;
    } else if (wv_uni(sh->nb_frames) == 1) {
-      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out);
+      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out, tr_pre);
       const int pad_to = (!gs->cfg.use_vbr && ret > 0 && !wv_uni(sh->no_pad)) ? wv_uni(sh->call_max_data_bytes) : 0;      /* apply_padding (:2646) */
       result = ret < 0 ? ret : emit_packet_wave(L, out, ret, pad_to, out_cap);
    } else {

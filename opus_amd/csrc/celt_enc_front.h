@@ -419,7 +419,8 @@ WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc
 
 /* transient_analysis (celt_encoder.c:267): the HP filter and the forward/backward masking followers are
  * recursions with rounding -> one lane per channel runs them; ranges/normalisation use wave reductions. */
-WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int allow_weak_transients)
+WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc &p1, int allow_weak_transients, const i32 *tr_pre = nullptr /* the channels' unmask values from
+      ct_transient_tile (below), or NULL */)
 {
    const u8 inv_table[128] = {
       255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18, 17, 16, 16, 15, 15, 14, 13, 13, 12, 12,
@@ -429,6 +430,10 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
    const int C = L->sh.CC, len = L->sh.N + OA_OVERLAP, len2 = len / 2, lane = wv_lane();
    const int forward_shift = allow_weak_transients ? 5 : 4;
    const int j0 = OA_MAX_PERIOD - OA_OVERLAP;      /* in[c][i] == pre[c][1024 - overlap + i] */
+   i32 unmask_c = 0;
+   const bool have_pre = tr_pre != nullptr && !allow_weak_transients && !wv_uni(L->sh.do_stereo_fade) && p0.up <= 1 && wv_uni(tr_pre[2]) == len;   /* (worked out from the frame this call codes, unfaded, 48 kHz) */
+   if (have_pre) { if (lane < C) unmask_c = tr_pre[lane]; }
+   else {
    i32 mx = 0;
    FOR_LANES(i, len) { mx = imax(mx, iabs(pre_at(p0, j0 + i))); if (C == 2) mx = imax(mx, iabs(pre_at(p1, j0 + i))); }
    mx = wv_max(mx);                       /* celt_maxabs32 over both channels (|INT32_MIN| cannot occur: SIG range) */
@@ -469,7 +474,6 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
       }
    }
    wv_sync();
-   i32 unmask_c = 0;
    if (lane < C) {
       WV_LDS i16 *tmp = L->BC.x16[lane];
       i32 mean = 0, mem0 = 0, norm;
@@ -506,6 +510,7 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
       }
       unmask_c = 64 * unmask * 4 / (6 * (len2 - 17));
    }
+   }
    i32 u0 = wv_bcast(unmask_c, 0), u1 = wv_bcast(unmask_c, 1);
    i32 mask_metric = 0; int tf_chan = L->sh.tf_chan;
    if (u0 > mask_metric) { tf_chan = 0; mask_metric = u0; }
@@ -517,5 +522,117 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
    i16 tf_estimate = (i16)fx_sqrt(imax(0, shl32(mult16_16(QC16(0.0069, 14), imin(163, tf_max)), 14) - QC32(0.139, 28)));
    wv_sync();
    LANE0 { L->sh.isTransient = is_transient; L->sh.weak_transient = weak; L->sh.tf_estimate = tf_estimate; L->sh.tf_chan = tf_chan; }
+}
+
+/* The serial part of transient_analysis with one LANE per (stream, channel) -- 64 of them per wave, ahead of the CELT-only encode kernel of a wide launch (oa_celt_transient_kernel):
+ * the high-pass and the two masking followers are recursions with rounding over 1,080 / 540 samples that keep two lanes of a stream's wave busy for 4.4 % of a config-2 frame.
+ * A lane regenerates its channel's input on the fly -- dc_reject (src/opus_encoder.c:479, from the state as it stands before the call), pre-emphasis (celt_encoder.c:557), the
+ * overlap from the stream's history -- twice (range, then filter) instead of storing it; the followers' array lives in the tile's HBM scratch as [sample][lane] (coalesced).  The result, the
+ * channel's unmask value, is used by transient_analysis_wave when the frame turns out to be coded the plain way (no stereo fade, 48 kHz, the reference's forward_shift 4);
+ * tone override, tf_estimate and tf_chan stay there. */
+struct CtTrGen {                                                 /* regenerates in[i] = pre[c][1024 - 120 + i], i = 0 .. N + 119, eight at a time (the block's loads in flight together) */
+   const i32 *hist; const i16 *pcm; int CC; i32 dc_mem, dc_mem0, pre_mem0, prev; int dc_shift;
+   WV_MEM void rewind() { dc_mem = dc_mem0; prev = 0; }
+   WV_MEM void block(int i0, i32 *v)                              /* v[0..7] = in[i0 .. i0 + 7]; i0 a multiple of 8 (so is the overlap: a block is all history or all new input) */
+   {
+      if (i0 < OA_OVERLAP) {
+#pragma unroll
+         for (int j = 0; j < 8; j++) v[j] = hist[OA_MAX_PERIOD - OA_OVERLAP + i0 + j];
+         return;
+      }
+      const int k0 = i0 - OA_OVERLAP;
+      i32 raw[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) raw[j] = pcm[CC * (k0 + j)];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const i32 x = shl32(saturate(raw[j], (1 << 16) - 1), 14), y = x - dc_mem;
+         dc_mem = dc_mem + pshr32(y, dc_shift);
+         const i32 s = shl32((i32)(i16)saturate(pshr32(y, 14), 32767), SIG_SHIFT);
+         const i32 m = k0 + j == 0 ? pre_mem0 : mult16_32_q15(27853, prev);
+         prev = s;
+         v[j] = s - m;
+      }
+   }
+};
+WV_DEVN void ct_transient_tile(const OaStream *streams, const i16 *pcm, int pcm_row, int N, int CC, int first, int stride, int n_items, int base, i16 *scr /* [N + 120][64] */, i32 *tr /* [stream][4] */)
+{
+   const u8 inv_table[128] = {
+      255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18, 17, 16, 16, 15, 15, 14, 13, 13, 12, 12,
+      12, 12, 11, 11, 11, 10, 10, 10, 9, 9, 9, 9, 9, 9, 8, 8, 8, 8, 8, 7, 7, 7, 7, 7, 7, 6, 6, 6, 6, 6, 6, 6,
+      6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+      4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2};
+   const int lane = wv_lane(), it = base + lane, itc = it < n_items ? it : n_items - 1;            /* (lanes past the end shadow the last item and write nothing: every lane meets the shuffle below) */
+   const int si = CC == 2 ? itc >> 1 : itc, c = CC == 2 ? itc & 1 : 0, s = first + si * stride;
+   const OaStream *gs = streams + s;
+   const int len = N + OA_OVERLAP, len2 = len / 2, Fs = gs->Fs ? gs->Fs : 48000;             /* len is a multiple of 8, len2 of 4 (N = 120 .. 960) */
+   CtTrGen g;
+   g.hist = gs->st.prefilter_mem + c * OA_MAX_PERIOD; g.pcm = pcm + (size_t)s * pcm_row * CC + c; g.CC = CC;
+   g.dc_mem0 = gs->st.s.hp_mem[2 * c]; g.pre_mem0 = gs->st.s.preemph_memE[c]; g.dc_shift = celt_ilog2(Fs / (3 * 4));
+   i16 *col = scr + lane;
+   /* pass 1: the range of the input over both channels (celt_maxabs32, :281) */
+   i32 mx = 0;
+   g.rewind();
+   for (int i0 = 0; i0 < len; i0 += 8) {
+      i32 v[8]; g.block(i0, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) mx = imax(mx, iabs(v[j]));
+   }
+   if (CC == 2) mx = imax(mx, wv_shfl(mx, lane ^ 1));
+   const int in_shift = imax(0, celt_ilog2(1 + mx) - 14);
+   /* pass 2: high-pass (:298-320), its range */
+   i32 mem0 = 0, mem1 = 0, m = 0;
+   g.rewind();
+   for (int i0 = 0; i0 < len; i0 += 8) {
+      i32 v[8]; g.block(i0, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const i32 x = (i16)(v[j] >> in_shift), y = add32(mem0, x);
+         mem0 = mem1 + y - shl32(x, 1);
+         mem1 = x - (y >> 1);
+         const i32 t = i0 + j < 12 ? 0 : sround16(y, 2);
+         col[(size_t)(i0 + j) * 64] = (i16)t;
+         m = imax(m, iabs(t));
+      }
+   }
+   const int sh = 14 - celt_ilog2(imax(1, m));
+   /* pass 3: pair energies, forward follower (:340-362): four pairs per trip, their eight loads ahead of the four stores */
+   i32 mean = 0; mem0 = 0;
+   for (int i0 = 0; i0 < len2; i0 += 4) {
+      i32 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = col[(size_t)(2 * i0 + j) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         i32 a = t[2 * j], b = t[2 * j + 1];
+         if (sh != 0) { a = shl16(a, sh); b = shl16(b, sh); }
+         const i32 x2 = pshr32(mult16_16(a, a) + mult16_16(b, b), 4);
+         mean += pshr32(x2, 12);
+         mem0 = mem0 + pshr32(x2 - mem0, 4);
+         t[j] = pshr32(mem0, 12);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) col[(size_t)(i0 + j) * 64] = (i16)t[j];
+   }
+   /* pass 4: backward follower (:364-380) */
+   i16 maxE = 0; mem0 = 0;
+   for (int i0 = len2 - 4; i0 >= 0; i0 -= 4) {
+      i32 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) t[j] = shl32((i32)col[(size_t)(i0 + j) * 64], 4);
+#pragma unroll
+      for (int j = 3; j >= 0; j--) { mem0 = mem0 + pshr32(t[j] - mem0, 3); t[j] = (i16)pshr32(mem0, 4); maxE = (i16)imax(maxE, t[j]); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) col[(size_t)(i0 + j) * 64] = (i16)t[j];
+   }
+   mean = mult16_16(fx_sqrt(mean), fx_sqrt(mult16_16(maxE, len2 >> 1)));
+   const i32 norm = shl32((i32)len2, 6 + 14) / add32(EPSILON, mean >> 1);
+   i32 unmask = 0;
+#pragma unroll 8
+   for (int i = 12; i < len2 - 5; i += 4) unmask += inv_table[imax(0, imin(127, mult16_32_q15(col[(size_t)i * 64] + EPSILON, norm)))];
+   if (it < n_items) {
+      tr[4 * s + c] = 64 * unmask * 4 / (6 * (len2 - 17));
+      if (c == 0) tr[4 * s + 2] = Fs == 48000 ? len : 0;          /* what the values are good for: this frame length at 48 kHz */
+   }
 }
 #endif

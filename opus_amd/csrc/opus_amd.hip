@@ -54,7 +54,8 @@ extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
 oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
       int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
       int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
-      const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */)
+      const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */,
+      const i32 *tr /* NULL, or [record][4]: the unmask values oa_celt_transient_kernel worked out for this call's frames */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
@@ -68,9 +69,17 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
       OaStream *gs = streams + s;
       const int ch = gs->cfg.channels;
       oa_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
-            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row);
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row, tr ? tr + 4 * (size_t)s : nullptr);
       __syncthreads();
    }
+}
+/* ahead of oa_encode_kernel in a wide launch of 48 kHz frames up to 20 ms: the serial part of every stream's transient analysis, one lane per (stream, channel) (celt_enc_front.h) */
+extern "C" __global__ void __launch_bounds__(64)
+oa_celt_transient_kernel(const OaStream *streams, const i16 *pcm, int pcm_row, int frame_size, int channels, int first, int stride, int n_items, i16 *scratch, i32 *tr)
+{
+   const int ntiles = (n_items + 63) / 64;
+   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x)
+      ct_transient_tile(streams, pcm, pcm_row, frame_size, channels, first, stride, n_items, t * 64, scratch + (size_t)blockIdx.x * (OA_MAX_FRAME + OA_OVERLAP) * 64, tr);
 }
 
 /* The decoder: persistent waves fed from a queue, one packet of one stream at a time; the spectrum of the frame in flight lives in the wave's HBM scratch (celt_dec_lds.h).
@@ -387,6 +396,7 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
+   i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
    struct { const void *kernel; size_t lds; int per_cu; } occ[8];
    int device;
    opus_int32 S;
@@ -441,7 +451,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ);
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -474,6 +484,8 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_cont) (void)hipFree(b->d_cont);
    if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_slow_list) (void)hipFree(b->d_slow_list);
+   if (b->d_tr) (void)hipFree(b->d_tr);
+   if (b->d_tr_scratch) (void)hipFree(b->d_tr_scratch);
    if (b->d_pcm) (void)hipFree(b->d_pcm);
    if (b->d_apcm) (void)hipFree(b->d_apcm);
    if (b->d_out) (void)hipFree(b->d_out);
@@ -782,10 +794,22 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       return OPUS_OK;
    }
    static const size_t lds_pad = getenv("OPUS_AMD_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_LDS_PAD")) : 0;   /* occupancy experiments only */
+   /* a wide launch of 48 kHz frames up to 20 ms: the transient analysis' recursions first, one lane per (stream, channel) (oa_celt_transient_kernel); OPUS_AMD_TR_PRE=0 keeps them in the encode kernel */
+   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
+   const i32 *d_tr = nullptr;
+   if (tr_env && b->Fs == 48000 && frame_size <= OA_MAX_FRAME && (b->n_act >= 64 || tr_env == 2 /* tests: whatever the width */)) {
+      const int items = (int)b->n_act * b->channels, tiles = (items + 63) / 64;
+      const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
+      const size_t need = (size_t)g * (OA_MAX_FRAME + OA_OVERLAP) * 64 * sizeof(i16);
+      if (!b->d_tr) { HIPCHECK(hipMalloc((void **)&b->d_tr, (size_t)b->S * 4 * sizeof(i32))); HIPCHECK(hipMemsetAsync(b->d_tr, 0, (size_t)b->S * 4 * sizeof(i32), s)); }
+      if (need > b->tr_scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_tr_scratch) (void)hipFree(b->d_tr_scratch); b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_tr_scratch, need)); b->tr_scratch_cap = need; }
+      hipLaunchKernelGGL(oa_celt_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaStream *)b->d_streams, (const i16 *)d_pcm, pcm_row, frame_size, b->channels, first, stride, items, b->d_tr_scratch, b->d_tr);
+      d_tr = b->d_tr;
+   }
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr);
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
