@@ -530,9 +530,26 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
  * overlap from the stream's history -- twice (range, then filter) instead of storing it; the followers' array lives in the tile's HBM scratch as [sample][lane] (coalesced).  The result, the
  * channel's unmask value, is used by transient_analysis_wave when the frame turns out to be coded the plain way (no stereo fade, 48 kHz, the reference's forward_shift 4);
  * tone override, tf_estimate and tf_chan stay there. */
-struct CtTrGen {                                                 /* regenerates in[i] = pre[c][1024 - 120 + i], i = 0 .. N + 119, eight at a time (the block's loads in flight together) */
-   const i32 *hist; const i16 *pcm; int CC; i32 dc_mem, dc_mem0, pre_mem0, prev; int dc_shift;
-   WV_MEM void rewind() { dc_mem = dc_mem0; prev = 0; }
+/* the int16 signal celt_encode_with_ec is handed, eight samples of one channel at a time: dc_reject of the caller's PCM (the CELT-only applications, src/opus_encoder.c:479) */
+struct CtSrcDc {
+   const i16 *pcm; int CC; i32 mem, mem0; int shift;
+   WV_MEM void rewind() { mem = mem0; }
+   WV_MEM void block(int k0, i32 *v)
+   {
+      i32 raw[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) raw[j] = pcm[CC * (k0 + j)];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const i32 x = shl32(saturate(raw[j], (1 << 16) - 1), 14), y = x - mem;
+         mem = mem + pshr32(y, shift);
+         v[j] = (i16)saturate(pshr32(y, 14), 32767);
+      }
+   }
+};
+template <class SRC> struct CtTrGen {                            /* regenerates in[i] = pre[c][1024 - 120 + i], i = 0 .. N + 119, eight at a time (the block's loads in flight together) */
+   const i32 *hist; SRC src; i32 pre_mem0, prev;
+   WV_MEM void rewind() { src.rewind(); prev = 0; }
    WV_MEM void block(int i0, i32 *v)                              /* v[0..7] = in[i0 .. i0 + 7]; i0 a multiple of 8 (so is the overlap: a block is all history or all new input) */
    {
       if (i0 < OA_OVERLAP) {
@@ -541,35 +558,25 @@ struct CtTrGen {                                                 /* regenerates 
          return;
       }
       const int k0 = i0 - OA_OVERLAP;
-      i32 raw[8];
+      src.block(k0, v);
 #pragma unroll
-      for (int j = 0; j < 8; j++) raw[j] = pcm[CC * (k0 + j)];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-         const i32 x = shl32(saturate(raw[j], (1 << 16) - 1), 14), y = x - dc_mem;
-         dc_mem = dc_mem + pshr32(y, dc_shift);
-         const i32 s = shl32((i32)(i16)saturate(pshr32(y, 14), 32767), SIG_SHIFT);
+      for (int j = 0; j < 8; j++) {                               /* celt_preemphasis at 48 kHz (celt_encoder.c:557) */
+         const i32 s = shl32(v[j], SIG_SHIFT);
          const i32 m = k0 + j == 0 ? pre_mem0 : mult16_32_q15(27853, prev);
          prev = s;
          v[j] = s - m;
       }
    }
 };
-WV_DEVN void ct_transient_tile(const OaStream *streams, const i16 *pcm, int pcm_row, int N, int CC, int first, int stride, int n_items, int base, i16 *scr /* [N + 120][64] */, i32 *tr /* [stream][4] */)
+/* one lane = one channel; returns the channel's unmask value.  Every lane of the wave calls it (the two channels of a stream sit on neighbouring lanes and meet in one shuffle) */
+template <class SRC> WV_DEV i32 ct_transient_lane(CtTrGen<SRC> &g, int N, int CC, i16 *col /* [N + 120] at stride 64 */)
 {
    const u8 inv_table[128] = {
       255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18, 17, 16, 16, 15, 15, 14, 13, 13, 12, 12,
       12, 12, 11, 11, 11, 10, 10, 10, 9, 9, 9, 9, 9, 9, 8, 8, 8, 8, 8, 7, 7, 7, 7, 7, 7, 6, 6, 6, 6, 6, 6, 6,
       6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
       4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2};
-   const int lane = wv_lane(), it = base + lane, itc = it < n_items ? it : n_items - 1;            /* (lanes past the end shadow the last item and write nothing: every lane meets the shuffle below) */
-   const int si = CC == 2 ? itc >> 1 : itc, c = CC == 2 ? itc & 1 : 0, s = first + si * stride;
-   const OaStream *gs = streams + s;
-   const int len = N + OA_OVERLAP, len2 = len / 2, Fs = gs->Fs ? gs->Fs : 48000;             /* len is a multiple of 8, len2 of 4 (N = 120 .. 960) */
-   CtTrGen g;
-   g.hist = gs->st.prefilter_mem + c * OA_MAX_PERIOD; g.pcm = pcm + (size_t)s * pcm_row * CC + c; g.CC = CC;
-   g.dc_mem0 = gs->st.s.hp_mem[2 * c]; g.pre_mem0 = gs->st.s.preemph_memE[c]; g.dc_shift = celt_ilog2(Fs / (3 * 4));
-   i16 *col = scr + lane;
+   const int len = N + OA_OVERLAP, len2 = len / 2;                /* len is a multiple of 8, len2 of 4 (N = 120 .. 960) */
    /* pass 1: the range of the input over both channels (celt_maxabs32, :281) */
    i32 mx = 0;
    g.rewind();
@@ -578,7 +585,7 @@ WV_DEVN void ct_transient_tile(const OaStream *streams, const i16 *pcm, int pcm_
 #pragma unroll
       for (int j = 0; j < 8; j++) mx = imax(mx, iabs(v[j]));
    }
-   if (CC == 2) mx = imax(mx, wv_shfl(mx, lane ^ 1));
+   if (CC == 2) mx = imax(mx, wv_shfl(mx, wv_lane() ^ 1));
    const int in_shift = imax(0, celt_ilog2(1 + mx) - 14);
    /* pass 2: high-pass (:298-320), its range */
    i32 mem0 = 0, mem1 = 0, m = 0;
@@ -630,9 +637,22 @@ WV_DEVN void ct_transient_tile(const OaStream *streams, const i16 *pcm, int pcm_
    i32 unmask = 0;
 #pragma unroll 8
    for (int i = 12; i < len2 - 5; i += 4) unmask += inv_table[imax(0, imin(127, mult16_32_q15(col[(size_t)i * 64] + EPSILON, norm)))];
+   return 64 * unmask * 4 / (6 * (len2 - 17));
+}
+/* the CELT-only applications: tr [stream][4] = the two channels' values, the frame length they are good for (48 kHz), - */
+WV_DEVN void ct_transient_tile(const OaStream *streams, const i16 *pcm, int pcm_row, int N, int CC, int first, int stride, int n_items, int base, i16 *scr /* [N + 120][64] */, i32 *tr)
+{
+   const int lane = wv_lane(), it = base + lane, itc = it < n_items ? it : n_items - 1;            /* (lanes past the end shadow the last item and write nothing: every lane meets the shuffle) */
+   const int si = CC == 2 ? itc >> 1 : itc, c = CC == 2 ? itc & 1 : 0, s = first + si * stride;
+   const OaStream *gs = streams + s;
+   const int Fs = gs->Fs ? gs->Fs : 48000;
+   CtTrGen<CtSrcDc> g;
+   g.hist = gs->st.prefilter_mem + c * OA_MAX_PERIOD; g.pre_mem0 = gs->st.s.preemph_memE[c];
+   g.src.pcm = pcm + (size_t)s * pcm_row * CC + c; g.src.CC = CC; g.src.mem0 = gs->st.s.hp_mem[2 * c]; g.src.shift = celt_ilog2(Fs / (3 * 4));
+   const i32 u = ct_transient_lane(g, N, CC, scr + lane);
    if (it < n_items) {
-      tr[4 * s + c] = 64 * unmask * 4 / (6 * (len2 - 17));
-      if (c == 0) tr[4 * s + 2] = Fs == 48000 ? len : 0;          /* what the values are good for: this frame length at 48 kHz */
+      tr[4 * s + c] = u;
+      if (c == 0) tr[4 * s + 2] = Fs == 48000 ? N + OA_OVERLAP : 0;
    }
 }
 #endif

@@ -293,12 +293,21 @@ oa_sh_quant0_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scra
       __syncthreads();
    }
 }
+/* ahead of the back kernel in a 48 kHz launch: the serial part of the CELT layer's transient analysis, one lane per (stream, channel) (opus_sh_split.h: oa_sh_transient_tile) */
+extern "C" __global__ void __launch_bounds__(64)
+oa_sh_transient_kernel(const OaShStream *streams, const ShCont *conts, const char *pcm_hp_all, int frame_size, int channels, int n_items, i16 *scratch, i32 *tr)
+{
+   const int ntiles = (n_items + 63) / 64;
+   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x)
+      oa_sh_transient_tile(streams, conts, pcm_hp_all, frame_size, channels, n_items, t * 64, scratch + (size_t)blockIdx.x * (OA_MAX_FRAME + OA_OVERLAP) * 64, tr);
+}
 #ifndef OA_SH_BACK_WAVES_PER_EU
 #define OA_SH_BACK_WAVES_PER_EU 3
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
 oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters, int pkt_off,
-      int chunk /* streams per pop of the queue: 1, or several where the frames are all light (a batch pinned to SILK-only: 65,536 pops of one counter take longer than their frames) */)
+      int chunk /* streams per pop of the queue: 1, or several where the frames are all light (a batch pinned to SILK-only: 65,536 pops of one counter take longer than their frames) */,
+      const i32 *tr /* NULL, or [stream][12]: the transient pre-pass's records (oa_sh_transient_kernel) */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -312,7 +321,7 @@ oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, 
          const int ch = gs->cfg.channels;
          char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
          oa_sh_back_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)),
-               (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s);
+               (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s, tr ? tr + 12 * (size_t)s : nullptr);
       }
       __syncthreads();
    }
@@ -709,8 +718,20 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5, mode == 4 ? 1 : 0);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
+   /* the CELT layer's transient recursions on lanes first (48 kHz, AUDIO / VOIP: frames with a CELT layer); OPUS_AMD_TR_PRE=0 keeps them in the back kernel */
+   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
+   const i32 *d_tr = nullptr;
+   if (tr_env && b->Fs == 48000 && b->application != OPUS_APPLICATION_RESTRICTED_SILK && !silk_only) {
+      const int items = n * ch, tiles = (items + 63) / 64;
+      const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
+      const size_t need_tr = (size_t)g * (OA_MAX_FRAME + OA_OVERLAP) * 64 * sizeof(i16);
+      if (!b->d_tr) { HIPCHECK(hipMalloc((void **)&b->d_tr, (size_t)b->S * 12 * sizeof(i32))); HIPCHECK(hipMemsetAsync(b->d_tr, 0, (size_t)b->S * 12 * sizeof(i32), s)); }
+      if (need_tr > b->tr_scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_tr_scratch) (void)hipFree(b->d_tr_scratch); b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_tr_scratch, need_tr)); b->tr_scratch_cap = need_tr; }
+      hipLaunchKernelGGL(oa_sh_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaShStream *)b->d_sh, (const ShCont *)b->d_cont, (const char *)b->d_pcm_hp, frame_size, ch, items, b->d_tr_scratch, b->d_tr);
+      d_tr = b->d_tr;
+   }
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
-         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1);
+         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1, d_tr);
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
          (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row, 0, 1, (const i32 *)nullptr);

@@ -442,7 +442,8 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
  *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in SH_PKT(L) (hybrid), or starting it (CELT-only frame)
  *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
 struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
-WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal)
+WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal, const i32 *tr = nullptr /* the transient pre-pass's record of the
+      stream (opus_sh_split.h: oa_sh_transient_tile), for the frame's own pass on the input this function finds staged */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS FrameLds *F = SH_F(L);
@@ -482,8 +483,14 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
    wv_sync();
    if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); SE_CLK_END(16); SE_PHASE_START(&L->S); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
-   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
-   else celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask);
+   /* the pre-pass worked from the gains it expected this function's caller to apply to the input: its values hold if those are the ones that were applied */
+   const i32 *tp = nullptr;
+   if (tr && !ctl.raw && !src) {
+      const int dg = wv_uni(sh->do_gain_fade), ds = wv_uni(sh->do_stereo_fade);
+      if (wv_uni(tr[3]) == dg && (!dg || (wv_uni(tr[4]) == wv_uni(sh->hb_g1) && wv_uni(tr[5]) == wv_uni(sh->hb_g2))) && wv_uni(tr[6]) == ds && (!ds || (wv_uni(tr[7]) == wv_uni(sh->fade_g1) && wv_uni(tr[8]) == wv_uni(sh->fade_g2)))) tp = tr;
+   }
+   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask, tp);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
+   else celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask, tp);
    wv_sync();
    LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = fs->ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
    wv_sync();
@@ -641,7 +648,7 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
 }
 /* sh_frame_back_wave: everything after silk_Encode (:2211-2657): what the Opus layer reads back from *scp, the CELT passes, redundancy, TOC, DTX, the frame's length.
  * silk_nBytes: what SILK returned (1 when it did not run) */
-WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes)
+WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes, const i32 *tr = nullptr)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS FrameLds *F = SH_F(L);
@@ -791,7 +798,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
       int ran = 0;
       if (wv_uni(sh->r[7]) <= 8 * wv_uni(sh->nb_compr_bytes)) {                            /* otherwise the budget is gone already and the frame ends up a "PLC frame" (:2487) */
          const int reload = wv_uni(sh->f_redundancy) || celt_prefill;
-         sh_celt_run(L, gs, reload ? pcm_celt : (const i16 *)0, frame_size, c, journal);
+         sh_celt_run(L, gs, reload ? pcm_celt : (const i16 *)0, frame_size, c, journal, tr);
          const int cret = wv_uni(sh->celt_ret);
          if (cret != -1000 && cret < 0) return OA_ERR_INTERNAL;
          if (cret >= 0) {

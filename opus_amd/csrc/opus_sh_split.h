@@ -284,8 +284,81 @@ WV_DEVN void oa_sh_predb_tile(WV_LDS PlBLane *B, WV_LDS SeNlsfTabs *T /* [2]: or
    wv_sync();
 }
 
+/* ---------------- the CELT layer's transient analysis as a lane pre-pass (celt_enc_front.h: ct_transient_lane), ahead of the back kernel ----------------
+ * The back kernel hands celt_encode_with_ec [delay line | this frame's high-passed input] after the hybrid gain fade and the stereo width fade (opus_encoder.c:2304-2349); a lane
+ * regenerates its channel of that signal from the stream record and the front kernel's output, with the gains it works out the way sh_frame_back_wave will -- and records them:
+ * sh_celt_run uses the lane's value only when the gains that were applied are those (tr [stream][12]: 0 / 1 the channels' values, 2 the frame length they are good for or 0,
+ * 3 .. 8 do_gain_fade, hb_g1, hb_g2, do_stereo_fade, fade_g1, fade_g2). */
+struct CtSrcSh {
+   const i16 *delay, *hp; int CC, c, total_buffer, overlap, inc, do_gain, do_stereo; i32 hb_g1, hb_g2, sg1, sg2;
+   WV_MEM void rewind() {}
+   WV_MEM i32 gain_at(int n, i32 g1, i32 g2) const
+   {
+      if (n >= overlap) return g2;
+      i16 w = ct_window[n * inc]; w = (i16)mult16_16_q15(w, w);
+      return (i16)(mac16_16(mult16_16(w, g2), Q15ONE - w, g1) >> 15);
+   }
+   WV_MEM void block(int k0, i32 *v)
+   {
+      i32 a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const int n = k0 + j;
+         const i16 *p = n < total_buffer ? delay + n * CC : hp + (n - total_buffer) * CC;
+         a[j] = p[c]; b[j] = do_stereo ? p[c ^ 1] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const int n = k0 + j;
+         if (do_gain) { const i32 g = gain_at(n, hb_g1, hb_g2); a[j] = (i16)mult16_16_q15(g, a[j]); b[j] = (i16)mult16_16_q15(g, b[j]); }
+         if (do_stereo) {
+            const i32 g = gain_at(n, sg1, sg2);
+            i32 diff = half32((c == 0 ? a[j] : b[j]) - (c == 0 ? b[j] : a[j]));
+            diff = mult16_16_q15(g, diff);
+            a[j] = c == 0 ? (i16)(a[j] - diff) : (i16)(a[j] + diff);
+         }
+         v[j] = a[j];
+      }
+   }
+};
+WV_DEVN void oa_sh_transient_tile(const OaShStream *streams, const ShCont *conts, const char *pcm_hp_all, int N, int CC, int n_items, int base, i16 *scr, i32 *tr)
+{
+   const int lane = wv_lane(), it = base + lane, itc = it < n_items ? it : n_items - 1;
+   const int s = CC == 2 ? itc >> 1 : itc, c = CC == 2 ? itc & 1 : 0;
+   const OaShStream *gs = streams + s; const ShCont *ct = conts + s;
+   const int Fs = gs->cfg.Fs, application = gs->cfg.application, mode = ct->st.mode;
+   const int total_buffer = application == OA_APP_RESTRICTED_SILK ? 0 : Fs / 250, encoder_buffer = Fs / 100;
+   /* the gains, as sh_frame_back_wave will work them out (opus_encoder.c:2264-2349) */
+   const i32 HB_gain = mode != OA_MODE_CELT_ONLY ? ct->sh.HB_gain : Q15ONE;
+   i32 sw = mode != OA_MODE_CELT_ONLY ? ct->sc.stereoWidth_Q14 : ct->st.sm_stereoWidth_Q14;
+   if (mode != OA_MODE_HYBRID || ct->st.stream_channels == 1) {
+      const i32 er = ct->sh.equiv_rate;
+      sw = er > 32000 ? 16384 : er < 16000 ? 0 : 16384 - 2048 * (i32)(32000 - er) / (er - 14000);
+   }
+   const int do_gain = (ct->st.prev_HB_gain < Q15ONE || HB_gain < Q15ONE) && application != OA_APP_RESTRICTED_SILK;
+   int do_stereo = 0; i32 fg1 = 0, fg2 = 0;
+   if (!gs->cfg.energy_mask_on && CC == 2 && (ct->st.hybrid_stereo_width_Q14 < (1 << 14) || sw < (1 << 14))) {
+      const i16 g1 = (i16)ct->st.hybrid_stereo_width_Q14, g2 = (i16)sw;
+      do_stereo = application != OA_APP_RESTRICTED_SILK; fg1 = g1 == 16384 ? Q15ONE : shl16(g1, 1); fg2 = g2 == 16384 ? Q15ONE : shl16(g2, 1);
+   }
+   CtTrGen<CtSrcSh> g;
+   g.hist = gs->celt.prefilter_mem + c * OA_MAX_PERIOD; g.pre_mem0 = gs->celt.s.preemph_memE[c];
+   g.src.delay = gs->delay_buffer + (encoder_buffer - total_buffer) * CC; g.src.hp = (const i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(N, CC));
+   g.src.CC = CC; g.src.c = c; g.src.total_buffer = total_buffer; g.src.inc = 48000 / Fs; g.src.overlap = OA_OVERLAP / g.src.inc;
+   g.src.do_gain = do_gain; g.src.do_stereo = do_stereo; g.src.hb_g1 = (i16)ct->st.prev_HB_gain; g.src.hb_g2 = (i16)HB_gain; g.src.sg1 = (i16)(Q15ONE - fg1); g.src.sg2 = (i16)(Q15ONE - fg2);
+   const i32 u = ct_transient_lane(g, N, CC, scr + lane);
+   if (it < n_items) {
+      i32 *r = tr + 12 * (size_t)s;
+      r[c] = u;
+      if (c == 0) {
+         r[2] = ct->kind == SH_CONT_FAST && mode != OA_MODE_SILK_ONLY && Fs == 48000 ? N + OA_OVERLAP : 0;
+         r[3] = do_gain; r[4] = ct->st.prev_HB_gain; r[5] = HB_gain; r[6] = do_stereo; r[7] = fg1; r[8] = fg2;
+      }
+   }
+}
+
 /* ---------------- back ---------------- */
-WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, i16 *pcm_hp /* the stream's slot: the front kernel's high-passed input */, i16 *pcm_celt, i16 *tmp_prefill, CeltScratch *cs, const ShCont *ct, i32 *len_out, u32 *rng_out)
+WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, i16 *pcm_hp /* the stream's slot: the front kernel's high-passed input */, i16 *pcm_celt, i16 *tmp_prefill, CeltScratch *cs, const ShCont *ct, i32 *len_out, u32 *rng_out, const i32 *tr = nullptr /* the transient pre-pass's record of the stream */)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
@@ -309,7 +382,7 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
       sh->r[5] = nb;
    }
    const int silk_nBytes = wv_uni(sh->r[5]);
-   const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes);
+   const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes, tr);
    const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
    const int result = ret < 0 ? ret : sh_emit_packet(SH_PKT(L), out, ret, pad_to, out_cap);
    LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
