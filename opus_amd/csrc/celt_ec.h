@@ -38,7 +38,7 @@ template <class ECB> WV_DEV int ec_put_front(EC_ARGS_G, unsigned v)
    buf[e->offs++] = (u8)v;
    return 0;
 }
-WV_DEV int ec_put_back(EC_ARGS, unsigned v)
+template <class ECB> WV_DEV int ec_put_back(EC_ARGS_G, unsigned v)
 {
    if (e->offs + e->end_offs >= e->storage) return -1;
    buf[e->storage - ++(e->end_offs)] = (u8)v;
@@ -96,7 +96,7 @@ WV_DEV u32 ec_tell_frac_lds(const WV_LDS EcCtx *e)
    l = (l << 3) + b;
    return nbits - l;
 }
-WV_DEV void k_ec_encode(EC_ARGS, unsigned fl, unsigned fh, unsigned ft)
+template <class ECB> WV_DEV void k_ec_encode(EC_ARGS_G, unsigned fl, unsigned fh, unsigned ft)
 {
    u32 r = e->rng / ft;
    if (fl > 0) { e->val += e->rng - r * (ft - fl); e->rng = r * (fh - fl); }
@@ -110,7 +110,7 @@ WV_DEV void k_ec_encode_bin(EC_ARGS, unsigned fl, unsigned fh, unsigned bits)
    else e->rng -= r * ((1U << bits) - fh);
    ec_renorm(EC_PASS);
 }
-WV_DEV void k_ec_enc_bit_logp(EC_ARGS, int val, unsigned logp)
+template <class ECB> WV_DEV void k_ec_enc_bit_logp(EC_ARGS_G, int val, unsigned logp)
 {
    u32 r = e->rng, l = e->val, s = r >> logp;
    r -= s;
@@ -125,7 +125,7 @@ template <class ECB> WV_DEV void k_ec_enc_icdf(EC_ARGS_G, int s, const u8 *icdf,
    else e->rng -= r * icdf[s];
    ec_renorm(EC_PASS);
 }
-WV_DEV void k_ec_enc_bits(EC_ARGS, u32 fl, unsigned bits)
+template <class ECB> WV_DEV void k_ec_enc_bits(EC_ARGS_G, u32 fl, unsigned bits)
 {
    u32 window = e->end_window;
    int used = e->nend_bits;
@@ -136,7 +136,7 @@ WV_DEV void k_ec_enc_bits(EC_ARGS, u32 fl, unsigned bits)
    used += bits;
    e->end_window = window; e->nend_bits = used; e->nbits_total += bits;
 }
-WV_DEV void k_ec_enc_uint(EC_ARGS, u32 fl, u32 ft)
+template <class ECB> WV_DEV void k_ec_enc_uint(EC_ARGS_G, u32 fl, u32 ft)
 {
    ft--;
    int ftb = ec_ilog(ft);

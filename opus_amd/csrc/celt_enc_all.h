@@ -16,5 +16,6 @@
 #include "celt_enc_pitch.h"
 #include "celt_enc_bands.h"
 #include "celt_enc_pvq.h"
+#include "celt_enc_pvq4.h"
 #include "celt_enc_frame.h"
 #endif

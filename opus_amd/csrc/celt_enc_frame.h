@@ -43,7 +43,21 @@ WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to,
 /* celt_encode_with_ec from the pre-emphasis on (celt/celt_encoder.c:1990-2830).  Expects the CELT scalars in L->st, oldBandE / energyError in LDS, the frame
  * constants of the prologue in L->sh, the int16 input staged in L->g->pcm16 (HBM) and the range coder in L->ec (fresh, or -- HYB -- continuing after the SILK layer).
  * HYB = the hybrid branches of the reference (start band 17: no pitch pre-filter, no tf_analysis, weak transients, its own VBR target, :2030-2470). */
-template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */)
+/* The frame can be CUT between the fine energy and the PVQ (the kernel pipeline of the CELT-only applications, opus_amd.hip): celt_encode_core<..>(.., cut) parks the wave's
+ * LDS image and the normalised spectrum in the stream's continuation record and returns OA_CUT; oa_celt_pvq_kernel codes the bands of four such streams per wave
+ * (celt_enc_pvq4.h); the back kernel reloads the image and runs the *_tail functions below.  cut == NULL: the whole frame here, as ever. */
+#define OA_CUT (-1000)
+template <bool HYB> WV_DEV void celt_encode_core_tail(WV_LDS FrameLds *L, OaEncState *gst);
+WV_DEV void celt_cut_dump(WV_LDS FrameLds *L, CeltCont *cut)
+{
+   const int C = L->sh.C, N = L->sh.N, nb = L->sh.M * ct_eBands[L->sh.end];
+   wv_sync();
+   FOR_LANES(i, (int)(offsetof(FrameLds, BC) / 4)) cut->image[i] = ((const WV_LDS i32 *)L)[i];
+   for (int c = 0; c < C; c++) { const i32 *X = L->g->X + c * N; FOR_LANES(j, nb) cut->X[c][j] = X[j]; }
+   LANE0 cut->state = 1;
+}
+template <bool HYB> WV_DEV int celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */,
+      CeltCont *cut = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -379,10 +393,20 @@ template <bool HYB> WV_DEV void celt_encode_core(WV_LDS FrameLds *L, OaEncState 
 
    K_PHASE(12);
    /* ---- PVQ residual ---- */
+   if (cut && !HYB && LM >= 2) { celt_cut_dump(L, cut); return OA_CUT; }        /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
          sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv,
          journal /* the stream's still-unwritten output slot doubles as the theta-RDO byte journal */);
    K_DUMPI("rng_pvq", L->ec.rng); K_DUMP("collapse", L->collapse_masks, 42);
+   celt_encode_core_tail<HYB>(L, gst);
+   return 0;
+}
+/* celt_encode_with_ec after quant_all_bands (celt_encoder.c:2680-2830) */
+template <bool HYB> WV_DEV void celt_encode_core_tail(WV_LDS FrameLds *L, OaEncState *gst)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
+   const int CC = sh->CC, C = sh->C, start = sh->start, end = sh->end;
 
    K_PHASE(13);
    /* ---- finalise (lane 0) ---- */
@@ -475,7 +499,8 @@ WV_DEV i32 oa_frame_energy_wave(const i16 *pcm, int len, i32 sample_max)
 
 /* One coded frame of a CELT-only application: opus_encode_frame_native (src/opus_encoder.c:1855) with mode == MODE_CELT_ONLY and no delay compensation.
  * The packet ends up in L->packet; returns its length before CBR padding (1 = DTX / bare TOC), or a negative OPUS_* code. */
-WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal, const i32 *tr_pre = nullptr)
+WV_DEV int oa_celt_frame_tail(WV_LDS FrameLds *L, int frame_size);
+WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal, const i32 *tr_pre = nullptr, CeltCont *cut = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -519,7 +544,14 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
       LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; st->rangeFinal = 0; sh->ret = 2; }
       wv_sync();
-   } else celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask, tr_pre);
+   } else if (celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask, tr_pre, cut) == OA_CUT) return OA_CUT;
+   return oa_celt_frame_tail(L, frame_size);
+}
+/* opus_encode_frame_native after celt_encode_with_ec */
+WV_DEV int oa_celt_frame_tail(WV_LDS FrameLds *L, int frame_size)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
    K_PHASE(14);
    LANE0 {   /* the generalised DTX decision (:2565-2576, decide_dtx_mode :1115): after 200 ms without activity the packet is the TOC alone, at most 400 ms in a row.  It is
               * taken only where SILK's own DTX is off (:2565) -- and silk_mode.useDTX = use_dtx && !(analysis valid || digital silence) (:1461; without the float API
@@ -539,9 +571,13 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
    return wv_uni(sh->ret);
 }
 
-WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
       u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr, int analysis_frame_size = 0 /* samples per channel pcm (and apcm) hold: >= frame_size, the caller's look-ahead (:2662-2690); 0 = frame_size */,
-      const i32 *tr_pre = nullptr /* the transient pre-pass's record of this stream for this call's frame (celt_enc_front.h: ct_transient_tile), or NULL */)
+      const i32 *tr_pre = nullptr /* the transient pre-pass's record of this stream for this call's frame (celt_enc_front.h: ct_transient_tile), or NULL */,
+      CeltCont *cut = nullptr /* the stream's continuation record: a single-frame call of 10 / 20 ms stops before the PVQ (see OA_CUT above) and returns 1 */);
+WV_DEV void oa_encode_frame_tail(WV_LDS FrameLds *L, OaStream *gs, int result, i32 *len_out, u32 *rng_out);
+WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+      u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm, int analysis_frame_size, const i32 *tr_pre, CeltCont *cut)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -592,7 +628,8 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       result = sh->plc_frame == 2 ? wv_uni(sh->ret) : emit_packet_wave(L, out, sh->ret, gs->cfg.use_vbr ? 0 : sh->call_max_data_bytes, out_cap);
       LANE0 st->rangeFinal = 0;
    } else if (wv_uni(sh->nb_frames) == 1) {
-      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out, tr_pre);
+      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out, tr_pre, cut);
+      if (ret == OA_CUT) return 1;
       const int pad_to = (!gs->cfg.use_vbr && ret > 0 && !wv_uni(sh->no_pad)) ? wv_uni(sh->call_max_data_bytes) : 0;      /* apply_padding (:2646) */
       result = ret < 0 ? ret : emit_packet_wave(L, out, ret, pad_to, out_cap);
    } else {
@@ -621,6 +658,23 @@ WV_DEV void oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, in
       if (err) result = err;
       else { result = oa_multiframe_assemble_wave(&L->mf, L->packet, out, repacketize_len, !gs->cfg.use_vbr && dtx_count != nb_frames, out_cap); if (result < 0) result = -3; }
    }
+   oa_encode_frame_tail(L, gs, result, len_out, rng_out);
+   return 0;
+}
+/* what the back kernel of the pipeline runs on a frame that was cut: the rest of celt_encode_with_ec, of opus_encode_frame_native and of opus_encode_native */
+WV_DEV void oa_encode_frame_back(WV_LDS FrameLds *L, OaStream *gs, int frame_size, u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   celt_encode_core_tail<false>(L, &gs->st);
+   const int ret = oa_celt_frame_tail(L, frame_size);
+   const int pad_to = (!gs->cfg.use_vbr && ret > 0 && !wv_uni(sh->no_pad)) ? wv_uni(sh->call_max_data_bytes) : 0;      /* apply_padding (:2646) */
+   const int result = ret < 0 ? ret : emit_packet_wave(L, out, ret, pad_to, out_cap);
+   oa_encode_frame_tail(L, gs, result, len_out, rng_out);
+}
+WV_DEV void oa_encode_frame_tail(WV_LDS FrameLds *L, OaStream *gs, int result, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS FrameShared *sh = &L->sh;
+   WV_LDS OaEncScalars *st = &L->st;
    /* ---- store lengths + state (coalesced) ---- */
    {
       LANE0 {

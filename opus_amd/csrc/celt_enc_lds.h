@@ -99,4 +99,16 @@ struct FrameLds {
       } q;
    } BC;
 };
+#include <stddef.h>
+/* what the front kernel hands over and the back kernel takes up again (one record per stream, HBM) */
+struct alignas(16) CeltCont {
+   i32 state;                                  /* 0: the front kernel finished the call itself; 1: cut before the PVQ */
+   i32 pad_[3];
+   i32 image[(offsetof(FrameLds, BC) + 3) / 4];   /* the front wave's LDS up to the phase scratch: coder, frame constants, band arrays, packet */
+   i32 X[2][OA_CODED_BINS];                    /* the normalised spectrum, coded bins of each channel */
+   i32 norm[2][OA_NORM_LEN];                   /* folding memory (norm, norm2) */
+   i32 norm_alt[2][OA_MAX_BAND];               /* the two theta-RDO trials' folding output of the band in flight */
+   u8 alt[OA_MAX_PACKET + 4];                  /* the second theta-RDO trial codes into this buffer */
+};
+
 #endif

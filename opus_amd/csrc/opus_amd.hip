@@ -55,7 +55,9 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
       int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
       int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
       const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */,
-      const i32 *tr /* NULL, or [record][4]: the unmask values oa_celt_transient_kernel worked out for this call's frames */)
+      const i32 *tr /* NULL, or [record][4]: the unmask values oa_celt_transient_kernel worked out for this call's frames */,
+      CeltCont *conts /* NULL, or [record]: the kernel pipeline -- a single-frame call of 10 / 20 ms stops before the PVQ, its stream goes on the list (queue[1] counts) for oa_celt_pvq_kernel / oa_celt_back_kernel */,
+      int *cut_list)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
@@ -68,8 +70,52 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
       __syncthreads();
       OaStream *gs = streams + s;
       const int ch = gs->cfg.channels;
-      oa_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
-            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row, tr ? tr + 4 * (size_t)s : nullptr);
+      const int cut = oa_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row, tr ? tr + 4 * (size_t)s : nullptr, conts ? conts + s : nullptr);
+      if (cut) { if (threadIdx.x == 0) cut_list[atomicAdd(queue + 1, 1u)] = s; }
+      __syncthreads();
+   }
+}
+/* the PVQ of the frames the encode kernel cut: four streams per wave, one 16-lane group each (celt_enc_pvq4.h) */
+#ifndef OA_PVQ4_WAVES_PER_EU
+#define OA_PVQ4_WAVES_PER_EU 3
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_PVQ4_WAVES_PER_EU)
+oa_celt_pvq_kernel(CeltCont *conts, const int *cut_list, unsigned *queue)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS P4Lds *L4 = (WV_LDS P4Lds *)smem;
+   const int n = (int)wv_uni((i32)queue[1]);
+   for (;;) {
+      int base = 0;
+      if (wv_lane() == 0) base = (int)atomicAdd(queue + 2, 4u);
+      base = wv_bcast(base, 0);
+      if (base >= n) break;
+      const int k = base + wg_id();
+      p4_quant_all_bands(L4, k < n ? conts + cut_list[k] : (CeltCont *)0);
+      __syncthreads();
+   }
+}
+/* ... and the rest of their call: one wave per stream again, the front wave's LDS reloaded from the continuation record */
+extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
+oa_celt_back_kernel(OaStream *streams, CeltCont *conts, const int *cut_list, unsigned *queue, int frame_size, u8 *out, int out_stride, i32 *lens, u32 *rngs, CeltScratch *scratch)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
+   const int n = (int)wv_uni((i32)queue[1]);
+   for (;;) {
+      int k = 0;
+      if (wv_lane() == 0) k = (int)atomicAdd(queue + 3, 1u);
+      k = wv_bcast(k, 0);
+      if (k >= n) break;
+      const int s = wv_uni(cut_list[k]);
+      CeltCont *c = conts + s;
+      __syncthreads();
+      FOR_LANES(i, (int)(offsetof(FrameLds, BC) / 4)) ((WV_LDS i32 *)L)[i] = c->image[i];
+      __syncthreads();
+      if (threadIdx.x == 0) L->g = scratch + blockIdx.x;
+      __syncthreads();
+      oa_encode_frame_back(L, streams + s, frame_size, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s);
       __syncthreads();
    }
 }
@@ -405,6 +451,7 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
+   CeltCont *d_ccont; int *d_cut_list; int celt_pipe_last /* streams of the last pipelined call, 0 = the last call was not pipelined */;                                       /* CELT-only batches, kernel pipeline: per-stream continuation records, the list of the streams whose call was cut before the PVQ */
    i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
    struct { const void *kernel; size_t lds; int per_cu; } occ[8];
    int device;
@@ -460,7 +507,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0;
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -490,6 +537,8 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_sh) (void)hipFree(b->d_sh);
    if (b->d_scratch) (void)hipFree(b->d_scratch);
    if (b->d_queue) (void)hipFree(b->d_queue);
+   if (b->d_ccont) (void)hipFree(b->d_ccont);
+   if (b->d_cut_list) (void)hipFree(b->d_cut_list);
    if (b->d_cont) (void)hipFree(b->d_cont);
    if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_slow_list) (void)hipFree(b->d_slow_list);
@@ -620,6 +669,12 @@ int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_ui
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    unsigned v[2] = {0, 0};
+   if (!b->kind) {      /* a CELT-only batch: the LAST call -- the streams it cut before the PVQ (oa_celt_pvq_kernel coded their bands), and those the encode kernel kept whole */
+      if (!b->d_ccont || !b->celt_pipe_last) { *kept = 0; *declined = 0; return OPUS_OK; }
+      HIPCHECK(hipMemcpy(v, b->d_queue + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+      *kept = v[0]; *declined = (opus_uint32)b->celt_pipe_last - v[0];
+      return OPUS_OK;
+   }
    HIPCHECK(hipMemcpy(v, b->d_queue + 16, sizeof v, hipMemcpyDeviceToHost));
    *kept = v[0]; *declined = v[1];
    return OPUS_OK;
@@ -827,11 +882,33 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       hipLaunchKernelGGL(oa_celt_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaStream *)b->d_streams, (const i16 *)d_pcm, pcm_row, frame_size, b->channels, first, stride, items, b->d_tr_scratch, b->d_tr);
       d_tr = b->d_tr;
    }
+   /* the kernel pipeline of the CELT-only applications (OPUS_AMD_SET_KERNEL_PIPELINE: -1 = wide launches, 0 = never, >= 1 = always; process default OPUS_AMD_CELT_PIPE): 10 / 20 ms
+    * calls stop before the PVQ (oa_encode_kernel with continuation records), oa_celt_pvq_kernel codes the bands of four streams per wave, oa_celt_back_kernel finishes the calls */
+   static const int pipe_env = getenv("OPUS_AMD_CELT_PIPE") ? atoi(getenv("OPUS_AMD_CELT_PIPE")) : -1;
+   const int pipe_mode = b->pipeline >= 0 ? b->pipeline : pipe_env;
+   const bool pipe = (pipe_mode < 0 ? b->n_act >= 64 : pipe_mode > 0) && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
+   if (pipe && !b->d_ccont) {
+      HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
+      HIPCHECK(hipMalloc((void **)&b->d_cut_list, sizeof(int) * (size_t)b->S));
+   }
+   b->celt_pipe_last = pipe ? (int)b->n_act : 0;
    int grid = 0;
    { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
+   if (pipe) HIPCHECK(hipMemsetAsync(b->d_queue, 0, 4 * sizeof(unsigned), s));
    hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
-         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr);
+         b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
+         pipe ? b->d_ccont : (CeltCont *)nullptr, b->d_cut_list);
    HIPCHECK(hipGetLastError());
+   if (pipe) {
+      int g_pvq = 0, g_back = 0;
+      { const int r = oa_sh_grid(b, 6, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)b->n_act + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
+      { const int r = oa_sh_grid(b, 7, (const void *)oa_celt_back_kernel, offsetof(FrameLds, BC), b->n_act, &g_back); if (r != OPUS_OK) return r; }
+      if (g_back > grid) g_back = grid;                                   /* (the per-wave scratch was sized for the encode kernel's grid) */
+      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)b->d_cut_list, b->d_queue);
+      hipLaunchKernelGGL(oa_celt_back_kernel, dim3((unsigned)g_back), dim3(64), offsetof(FrameLds, BC), s, b->d_streams, b->d_ccont, (const int *)b->d_cut_list, b->d_queue, frame_size, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range,
+            (CeltScratch *)b->d_scratch);
+      HIPCHECK(hipGetLastError());
+   }
    return OPUS_OK;
 }
 int opusgpu_encode_batch_dev(OpusGpuEncBatch *b, const opus_int16 *d_pcm, int frame_size, unsigned char *d_out,

@@ -170,4 +170,70 @@ WV_DEV int wv_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid, int nl
    const bool hit = valid && (mine >> 16) * (best & 0xffffu) == (best >> 16) * (mine & 0xffffu);
    return (int)__builtin_ctzll(__ballot(hit));
 }
+/* ---- 16-lane groups: four independent streams share one wave (celt_enc_pvq4.h).  A group is one DPP row, so its reductions are the row part of the wave trees above
+ * (every lane of the row ends with the row's result: no v_readlane), and groups may sit in different branches: the collectives below only touch lanes of the caller's own
+ * row, which a group enters and leaves together.  Values that are "uniform" per stream live in VGPRs here (one copy per lane of the row). ---- */
+#define WG_WIDTH 16
+WV_DEV int wg_lane() { return (int)threadIdx.x & 15; }
+WV_DEV int wg_id() { return (int)threadIdx.x >> 4; }
+WV_DEV void wg_sync() { wv_order(); }          /* one wave: the LDS pipeline is in order, a compiler fence is all the ordering there is to ask for */
+WV_DEV bool wv_any(int pred) { return __ballot(pred) != 0; }      /* WAVE-level vote (every lane must call it) */
+WV_DEV int32_t wg_sum(int32_t v)
+{
+   v += WV_DPP(0, v, WV_DPP_QP_1032, 0xf);
+   v += WV_DPP(0, v, WV_DPP_QP_2301, 0xf);
+   v += WV_DPP(0, v, WV_DPP_ROW_ROR4, 0xf);
+   v += WV_DPP(0, v, WV_DPP_ROW_ROR8, 0xf);
+   return v;
+}
+WV_DEV uint32_t wg_sumu(uint32_t v) { return (uint32_t)wg_sum((int32_t)v); }
+WV_DEV int64_t wg_sum64(int64_t v)
+{
+   uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+   uint32_t a = wg_sumu(lo & 0xffff), b = wg_sumu(lo >> 16), c = wg_sumu(hi & 0xffff), d = wg_sumu(hi >> 16);
+   return (int64_t)((uint64_t)a + ((uint64_t)b << 16) + ((uint64_t)c << 32) + ((uint64_t)d << 48));
+}
+WV_DEV int32_t wg_max(int32_t v)
+{
+   int32_t t;
+   t = WV_DPP(v, v, WV_DPP_QP_1032, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_QP_2301, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_ROW_ROR4, 0xf); v = t > v ? t : v;
+   t = WV_DPP(v, v, WV_DPP_ROW_ROR8, 0xf); v = t > v ? t : v;
+   return v;
+}
+WV_DEV uint32_t wg_or(uint32_t v)
+{
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_QP_1032, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_QP_2301, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_ROW_ROR4, 0xf);
+   v |= (uint32_t)WV_DPP(0, (int)v, WV_DPP_ROW_ROR8, 0xf);
+   return v;
+}
+/* inclusive prefix sum inside the row (row_shr:1/2/4/8, lanes without a source add 0) */
+WV_DEV int32_t wg_scan_incl(int32_t v)
+{
+   v += WV_DPP(0, v, 0x111, 0xf);
+   v += WV_DPP(0, v, 0x112, 0xf);
+   v += WV_DPP(0, v, 0x114, 0xf);
+   v += WV_DPP(0, v, 0x118, 0xf);
+   return v;
+}
+/* value of lane src (0..15, the same in all lanes of the group, free to differ between groups) of the caller's group: ds_bpermute_b32, the LDS crossbar without memory */
+WV_DEV int32_t wg_bcast(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 48u) | (unsigned)src) << 2), v); }
+WV_DEV uint32_t wg_ballot(int pred) { return (uint32_t)(__ballot(pred) >> (threadIdx.x & 48u)) & 0xffffu; }
+/* the packed-ratio arg-max of wv_argmax_ratio_packed inside a group: returns the winning lane (0..15) */
+WV_DEV int wg_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid)
+{
+   uint32_t pk = den << 16 | num;
+   const uint32_t mine = pk;
+   WV_ARGMAXP_STEP(WV_DPP_QP_1032, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_QP_2301, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_ROW_ROR4, 0xf);
+   WV_ARGMAXP_STEP(WV_DPP_ROW_ROR8, 0xf);
+   /* the row tree is not a total order on ties (equal ratios with different (num, den) may leave different representatives in different lanes), but every lane holds A
+    * maximal ratio, and the hit test is by cross-multiplication: the set of hits is the set of maximal lanes whichever representative a lane holds */
+   const bool hit = valid && (mine >> 16) * (pk & 0xffffu) == (pk >> 16) * (mine & 0xffffu);
+   return (int)__builtin_ctz(wg_ballot(hit) | 0x10000u);
+}
 #endif

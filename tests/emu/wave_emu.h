@@ -20,12 +20,13 @@ static inline void emu_die() { void *bt[32]; int n = backtrace(bt, 32); backtrac
 #define WV_TABLE static const
 #define WV_WIDTH 64
 
-struct EmuFiber { void *sp; char *stack; int done; long nsync; long nx; int uni_k; };
+struct EmuFiber { void *sp; char *stack; int done; long nsync; long nx; int uni_k; long gsync; long gnx; };
 struct EmuWave {
    EmuFiber f[64];
    void *main_sp;
    int cur;
    int64_t xch[2][64][4];
+   int64_t gxch[2][64][4];             /* the 16-lane group collectives' own exchange tables (groups run between two wave rendezvous independently of each other) */
    int32_t uni_val[1024]; int uni_n;   /* OA_EMU_CHECK_UNI: the values the first-scheduled fiber passed to wv_uni since the last rendezvous */
    unsigned char kind_ring[4096];      /* lane 0's op kind per rendezvous, to catch lanes meeting at different primitives */
    void (*entry)(void *);
@@ -56,7 +57,8 @@ static inline void emu_rendezvous(int kind = 0)
    w->f[me].uni_k = 0;
    int prv = (me + 63) & 63;
    long expect = w->f[me].nsync + (me == 0 ? 0 : 1);          /* the previous lane is parked at the next rendezvous */
-   if (!(w->f[prv].nsync == expect || (w->f[prv].done && w->f[prv].nsync == w->f[me].nsync))) {
+   const bool in_group_op = (prv >> 4) == (me >> 4) && w->f[prv].nsync == w->f[me].nsync && w->f[prv].gsync == w->f[me].gsync + 1;   /* the previous lane woke this one from a group collective (wg_*) it reached after this rendezvous */
+   if (!(w->f[prv].nsync == expect || in_group_op || (w->f[prv].done && w->f[prv].nsync == w->f[me].nsync))) {
       fprintf(stderr, "wave_emu: divergent collectives: lane %d at %ld, lane %d at %ld\n", me, w->f[me].nsync, prv, w->f[prv].nsync); abort();
    }
 }
@@ -128,5 +130,61 @@ WV_DEV void wv_argmax_ratio(int32_t &num, int32_t &den, int32_t &idx)
       if (lhs > rhs || (lhs == rhs && i2 < bi)) { bn = n2; bd = d2; bi = i2; }
    }
    num = bn; den = bd; idx = bi;
+}
+/* ---- 16-lane groups (wave.h: wg_*): a rendezvous of the caller's 16 lanes only.  The fibers of a group cycle among themselves; the other groups of the wave run when this
+ * group's lanes reach the next WAVE rendezvous.  So four groups can sit in different branches of the kernel (on the GPU: EXEC masks), each with its own collectives. ---- */
+#define WG_WIDTH 16
+WV_DEV int wg_lane() { return (emu_cur->cur ^ emu_flip) & 15; }
+WV_DEV int wg_id() { return (emu_cur->cur ^ emu_flip) >> 4; }
+static inline void emu_grendezvous()
+{
+   EmuWave *w = emu_cur;
+   const int me = w->cur, nxt = (me & ~15) | ((me + 1) & 15), prv = (me & ~15) | ((me + 15) & 15);
+   w->f[me].gsync++;
+   if (w->f[nxt].done) { fprintf(stderr, "wave_emu: lane %d reached a group collective but lane %d of its group already exited\n", me, nxt); emu_die(); }
+   w->cur = nxt;
+   emu_switch(&w->f[me].sp, w->f[nxt].sp);
+   /* who woke this lane: the previous lane of the group, parked at the group's next collective, or -- no further group collective -- at the next wave rendezvous, or gone */
+   const bool ok = (me & 15) == 0 ? (w->f[prv].gsync == w->f[me].gsync && w->f[prv].nsync == w->f[me].nsync)
+                 : ((w->f[prv].gsync == w->f[me].gsync + 1 && w->f[prv].nsync == w->f[me].nsync) || (w->f[prv].gsync == w->f[me].gsync && (w->f[prv].nsync == w->f[me].nsync + 1 || w->f[prv].done)));
+   if (!ok) {
+      fprintf(stderr, "wave_emu: divergent group collectives: lane %d at %ld (wave %ld), lane %d at %ld (wave %ld)\n", me, w->f[me].gsync, w->f[me].nsync, prv, w->f[prv].gsync, w->f[prv].nsync); emu_die();
+   }
+}
+static inline int64_t (*emu_gxchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0))[4]
+{
+   EmuWave *w = emu_cur;
+   const int fib = w->cur, me = fib ^ emu_flip;
+   const int p = (int)(w->f[fib].gnx++ & 1);
+   w->gxch[p][me][0] = a; w->gxch[p][me][1] = b; w->gxch[p][me][2] = c; w->gxch[p][me][3] = d;
+   emu_grendezvous();
+   return w->gxch[p];
+}
+WV_DEV void wg_sync() { emu_grendezvous(); }
+WV_DEV bool wv_any(int pred) { auto t = emu_xchg(pred != 0); for (int i = 0; i < 64; i++) if (t[i][0]) return true; return false; }
+#define EMU_GBASE ((emu_cur->cur ^ emu_flip) & 48)
+WV_DEV int32_t wg_sum(int32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE; uint32_t s = 0; for (int i = 0; i < 16; i++) s += (uint32_t)t[g + i][0]; return (int32_t)s; }
+WV_DEV uint32_t wg_sumu(uint32_t v) { return (uint32_t)wg_sum((int32_t)v); }
+WV_DEV int64_t wg_sum64(int64_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE; uint64_t s = 0; for (int i = 0; i < 16; i++) s += (uint64_t)t[g + i][0]; return (int64_t)s; }
+WV_DEV int32_t wg_max(int32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE; int32_t m = (int32_t)t[g][0]; for (int i = 1; i < 16; i++) if ((int32_t)t[g + i][0] > m) m = (int32_t)t[g + i][0]; return m; }
+WV_DEV uint32_t wg_or(uint32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE; uint32_t m = 0; for (int i = 0; i < 16; i++) m |= (uint32_t)t[g + i][0]; return m; }
+WV_DEV int32_t wg_scan_incl(int32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE, me = wg_lane(); uint32_t s = 0; for (int i = 0; i <= me; i++) s += (uint32_t)t[g + i][0]; return (int32_t)s; }
+WV_DEV int32_t wg_bcast(int32_t v, int src)
+{
+   auto t = emu_gxchg(v, src); const int g = EMU_GBASE;
+   if ((unsigned)src > 15u) { fprintf(stderr, "wave_emu: wg_bcast from lane %d of the group\n", src); emu_die(); }
+   if (emu_check_uni && t[g + wg_lane()][1] != t[g][1]) { fprintf(stderr, "wave_emu: wg_bcast with a lane index that is not uniform in the group: lane %d asks for %d, the group's lane 0 for %d\n", wv_lane(), src, (int)t[g][1]); emu_die(); }
+   return (int32_t)t[g + src][0];
+}
+WV_DEV uint32_t wg_ballot(int pred) { auto t = emu_gxchg(pred != 0); const int g = EMU_GBASE; uint32_t m = 0; for (int i = 0; i < 16; i++) m |= (uint32_t)(t[g + i][0] != 0) << i; return m; }
+WV_DEV int wg_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid)
+{
+   auto t = emu_gxchg(num, den, valid ? 1 : 0); const int g = EMU_GBASE;
+   int best = -1;
+   for (int i = 0; i < 16; i++) {
+      if (!t[g + i][2]) continue;
+      if (best < 0 || (uint64_t)t[g + best][1] * (uint64_t)t[g + i][0] > (uint64_t)t[g + i][1] * (uint64_t)t[g + best][0]) best = i;
+   }
+   return best < 0 ? 16 : best;
 }
 #endif
