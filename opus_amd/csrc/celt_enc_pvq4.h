@@ -535,7 +535,7 @@ WV_DEV P4Theta p4_compute_theta(WV_LDS P4Group *G, u8 *ecbuf, const P4Cfg &cfg, 
       iside = bitexact_cos((i16)(16384 - itheta));
       delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
    }
-   P4_TOC(20);
+   P4_TOC(stereo ? 31 : 20);
    P4Theta r = {inv, imid, iside, delta, itheta, qalloc, b, fill};
    return r;
 }
@@ -547,6 +547,7 @@ struct P4Tree { int act; int xo, N, b, B, LM, lb, fill; i32 gain; int depth, don
 WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4Cfg &cfg, P4Tree &tr)
 {
    tr.depth = 0; tr.done = !tr.act; tr.cm = 0;
+   P4_TIC();
    while (wv_any(!tr.done)) {
       /* down through the split nodes to the next leaf */
       for (;;) {
@@ -585,6 +586,7 @@ WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4
          }
       }
       /* the leaf */
+      P4_TOC(25);
       unsigned cm = 0;
       if (!tr.done) {
          const WV_LDS u8 *row = L4->rows + (tr.LM + 1) * 64;
@@ -599,6 +601,7 @@ WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4
             curr_bits = p4_pulses2bits(row, q);
             tr.remaining_bits -= curr_bits;
          }
+         P4_TOC(26);
          if (q != 0) cm = p4_alg_quant(G, ecbuf, X, N, k_get_pulses(q), cfg.spread, B, tr.gain, cfg.resynth);
          else if (cfg.resynth) {
             const unsigned cm_mask = (unsigned)(1UL << B) - 1;
@@ -624,6 +627,7 @@ WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4
          }
       }
       /* back up: finished nodes hand their mask to the parent; the first parent with a child to go sends the group down again */
+      P4_TOC(30);
       if (!tr.done) {
          for (;;) {
             if (tr.depth == 0) { tr.done = 1; tr.cm = cm; break; }
@@ -655,6 +659,7 @@ WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4
             tr.depth--;
          }
       }
+      P4_TOC(27);
    }
 }
 
@@ -771,6 +776,7 @@ WV_DEV void p4_quant_all_bands(WV_LDS P4Lds *L4, CeltCont *cont)
    cfg.intensity = intensity; cfg.spread = spread; cfg.disable_inv = disable_inv; cfg.resynth = resynth; cfg.theta_round = 0; cfg.avoid_split_noise = B > 1; cfg.i = 0; cfg.tf_change = 0;
    for (int i = i_lo; i < i_hi; i++) {
       const int N = M * ct_eBands[i + 1] - M * ct_eBands[i];          /* wave-uniform */
+      P4_TIC();
       p4_rows_stage(L4, i);
       const int act = active && i >= start && i < end;
       const int last = i == end - 1;
@@ -821,6 +827,7 @@ WV_DEV void p4_quant_all_bands(WV_LDS P4Lds *L4, CeltCont *cont)
       i32 *const lbo = last ? (i32 *)0 : norm + M * ct_eBands[i] - norm_offset, *const lbo2 = last ? (i32 *)0 : norm2 + M * ct_eBands[i] - norm_offset;
       const i32 rem0 = remaining_bits; const u32 seed0 = seed;
       const unsigned cm_in = x_cm | y_cm;
+      P4_TOC(0);
       i32 dist0 = 0, rem1 = 0, w0 = 0, w1 = 0;
       u32 seed1 = 0;
       unsigned cm2 = 0;

@@ -15,6 +15,17 @@ __device__ unsigned long long oa_phase_ticks[34];
 #define AN_TIC() unsigned long long an_tic_ = clock64()
 #define AN_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - an_tic_); an_tic_ = t_; } } while (0)
 #endif
+#ifdef OA_PHASE_TIMERS
+/* the four-streams-per-wave PVQ kernel: a section's wave time (the first active lane adds the ticks) and its lane time (ticks x active lanes: how full the wave was),
+ * accumulated per wave in LDS (ds_add), added to the global totals when the wave is done with its four streams */
+__device__ unsigned long long oa_p4_ticks[32], oa_p4_lanes[32];
+__shared__ unsigned int oa_p4_prof[64];
+#define P4_TIC() unsigned long long p4tic_ = clock64()
+#define P4_TOC(b) do { const unsigned long long t_ = clock64(); const int me_ = (int)threadIdx.x; const unsigned n_ = (unsigned)__popcll(__ballot(1)); if (me_ == __builtin_amdgcn_readfirstlane(me_)) { \
+      atomicAdd(&oa_p4_prof[b], (unsigned)(t_ - p4tic_)); atomicAdd(&oa_p4_prof[32 + (b)], (unsigned)(t_ - p4tic_) * n_ >> 6); } p4tic_ = t_; } while (0)
+#define P4_PROF_BEGIN() do { oa_p4_prof[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define P4_PROF_END() do { __syncthreads(); if (threadIdx.x < 32) { atomicAdd(&oa_p4_ticks[threadIdx.x], (unsigned long long)oa_p4_prof[threadIdx.x]); atomicAdd(&oa_p4_lanes[threadIdx.x], (unsigned long long)oa_p4_prof[32 + threadIdx.x]); } __syncthreads(); } while (0)
+#endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
 #ifdef OA_PHASE_TIMERS
@@ -92,7 +103,13 @@ oa_celt_pvq_kernel(CeltCont *conts, const int *cut_list, unsigned *queue)
       base = wv_bcast(base, 0);
       if (base >= n) break;
       const int k = base + wg_id();
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_BEGIN();
+#endif
       p4_quant_all_bands(L4, k < n ? conts + cut_list[k] : (CeltCont *)0);
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_END();
+#endif
       __syncthreads();
    }
 }
@@ -1270,6 +1287,14 @@ OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset
    HIPCHECK(hipDeviceSynchronize());
    HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 34));
    if (reset) { unsigned long long z[34] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
+   return OPUS_OK;
+}
+OPUS_AMD_EXPORT int opusgpu_debug_p4_ticks(unsigned long long *ticks, unsigned long long *lanes, int reset)
+{
+   HIPCHECK(hipDeviceSynchronize());
+   HIPCHECK(hipMemcpyFromSymbol(ticks, HIP_SYMBOL(oa_p4_ticks), sizeof(unsigned long long) * 32));
+   HIPCHECK(hipMemcpyFromSymbol(lanes, HIP_SYMBOL(oa_p4_lanes), sizeof(unsigned long long) * 32));
+   if (reset) { unsigned long long z[32] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_p4_ticks), z, sizeof(z))); HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_p4_lanes), z, sizeof(z))); }
    return OPUS_OK;
 }
 #endif
