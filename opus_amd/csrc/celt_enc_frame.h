@@ -56,7 +56,7 @@ WV_DEV void celt_cut_dump(WV_LDS FrameLds *L, CeltCont *cut)
    for (int c = 0; c < C; c++) { const i32 *X = L->g->X + c * N; FOR_LANES(j, nb) cut->X[c][j] = X[j]; }
    LANE0 cut->state = 1;
 }
-template <bool HYB> WV_DEV int celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */,
+template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */,
       CeltCont *cut = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
@@ -394,12 +394,15 @@ template <bool HYB> WV_DEV int celt_encode_core(WV_LDS FrameLds *L, OaEncState *
    K_PHASE(12);
    /* ---- PVQ residual ---- */
    if (cut && !HYB && LM >= 2) { celt_cut_dump(L, cut); return OA_CUT; }        /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
+   if constexpr (NOPVQ) return 0;                                               /* (the pipeline's front kernel: its calls are single frames of 10 / 20 ms, every frame that gets here is cut) */
+   else {
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,
          sh->nbCompressedBytes * (8 << BITRES) - sh->anti_collapse_rsv, sh->balance, sh->codedBands, sh->complexity, sh->disable_inv,
          journal /* the stream's still-unwritten output slot doubles as the theta-RDO byte journal */);
    K_DUMPI("rng_pvq", L->ec.rng); K_DUMP("collapse", L->collapse_masks, 42);
    celt_encode_core_tail<HYB>(L, gst);
    return 0;
+   }
 }
 /* celt_encode_with_ec after quant_all_bands (celt_encoder.c:2680-2830) */
 template <bool HYB> WV_DEV void celt_encode_core_tail(WV_LDS FrameLds *L, OaEncState *gst)
@@ -500,7 +503,7 @@ WV_DEV i32 oa_frame_energy_wave(const i16 *pcm, int len, i32 sample_max)
 /* One coded frame of a CELT-only application: opus_encode_frame_native (src/opus_encoder.c:1855) with mode == MODE_CELT_ONLY and no delay compensation.
  * The packet ends up in L->packet; returns its length before CBR padding (1 = DTX / bare TOC), or a negative OPUS_* code. */
 WV_DEV int oa_celt_frame_tail(WV_LDS FrameLds *L, int frame_size);
-WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal, const i32 *tr_pre = nullptr, CeltCont *cut = nullptr)
+template <bool NOPVQ = false> WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int orig_max_data_bytes, u8 *journal, const i32 *tr_pre = nullptr, CeltCont *cut = nullptr)
 {
    WV_LDS FrameShared *sh = &L->sh;
    WV_LDS OaEncScalars *st = &L->st;
@@ -544,7 +547,7 @@ WV_DEV int oa_celt_frame_native(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm
       /* budget already busted: emit TOC + "PLC" byte (opus_encoder.c:2581-2591) */
       LANE0 { L->packet[0] = (u8)sh->toc; L->packet[1] = 0; st->rangeFinal = 0; sh->ret = 2; }
       wv_sync();
-   } else if (celt_encode_core<false>(L, &gs->st, journal, gs->energy_mask, tr_pre, cut) == OA_CUT) return OA_CUT;
+   } else if (celt_encode_core<false, NOPVQ>(L, &gs->st, journal, gs->energy_mask, tr_pre, cut) == OA_CUT) return OA_CUT;
    return oa_celt_frame_tail(L, frame_size);
 }
 /* opus_encode_frame_native after celt_encode_with_ec */
@@ -571,12 +574,12 @@ WV_DEV int oa_celt_frame_tail(WV_LDS FrameLds *L, int frame_size)
    return wv_uni(sh->ret);
 }
 
-WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+template <bool NOPVQ = false> WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
       u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm = nullptr, int analysis_frame_size = 0 /* samples per channel pcm (and apcm) hold: >= frame_size, the caller's look-ahead (:2662-2690); 0 = frame_size */,
       const i32 *tr_pre = nullptr /* the transient pre-pass's record of this stream for this call's frame (celt_enc_front.h: ct_transient_tile), or NULL */,
       CeltCont *cut = nullptr /* the stream's continuation record: a single-frame call of 10 / 20 ms stops before the PVQ (see OA_CUT above) and returns 1 */);
 WV_DEV void oa_encode_frame_tail(WV_LDS FrameLds *L, OaStream *gs, int result, i32 *len_out, u32 *rng_out);
-WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
+template <bool NOPVQ> WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int frame_size, int max_data_bytes,
       u8 *out, int out_cap, i32 *len_out, u32 *rng_out, const i32 *apcm, int analysis_frame_size, const i32 *tr_pre, CeltCont *cut)
 {
    WV_LDS FrameShared *sh = &L->sh;
@@ -628,11 +631,12 @@ WV_DEV int oa_encode_frame(WV_LDS FrameLds *L, OaStream *gs, const i16 *pcm, int
       result = sh->plc_frame == 2 ? wv_uni(sh->ret) : emit_packet_wave(L, out, sh->ret, gs->cfg.use_vbr ? 0 : sh->call_max_data_bytes, out_cap);
       LANE0 st->rangeFinal = 0;
    } else if (wv_uni(sh->nb_frames) == 1) {
-      const int ret = oa_celt_frame_native(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out, tr_pre, cut);
+      const int ret = oa_celt_frame_native<NOPVQ>(L, gs, pcm, frame_size, wv_uni(sh->call_max_data_bytes), out, tr_pre, cut);
       if (ret == OA_CUT) return 1;
       const int pad_to = (!gs->cfg.use_vbr && ret > 0 && !wv_uni(sh->no_pad)) ? wv_uni(sh->call_max_data_bytes) : 0;      /* apply_padding (:2646) */
       result = ret < 0 ? ret : emit_packet_wave(L, out, ret, pad_to, out_cap);
-   } else {
+   } else if constexpr (NOPVQ) result = -3;                /* (never: a call of the pipeline's front kernel is one frame) */
+   else {
       /* ---- 40-120 ms: 20 ms frames staged in the output slot, then framed as one packet (:1757-1838, opus_multiframe.h) ---- */
       const int nb_frames = wv_uni(sh->nb_frames), efs = wv_uni(sh->enc_frame_size), max_len_sum = wv_uni(sh->max_len_sum), repacketize_len = wv_uni(sh->repacketize_len);
       const int Fs = wv_uni(sh->Fs);

@@ -186,6 +186,8 @@ WV_DEV void p4_renormalise_vector(WV_LDS i32 *X, int N, i32 gain)
 /* ---- exp_rotation (vq.c:104) in place on the band in LDS (already scaled down to Q14): one lane per independent chain (block, residue mod d) ---- */
 WV_DEV void p4_rot_pass(WV_LDS i32 *T, int nblk, int len, int d, i32 c_, i32 s_)
 {
+   /* (fetching eight steps' operands ahead of the chain -- what a sweep reads ahead of itself is untouched data -- was tried: 16 more live registers at the 168 the kernel
+    * is held to, more scratch, config 2 1.86 -> 1.79 M frames/s, profiles/r06_d; the kernel is VALU-issue-bound, not LDS-latency-bound: profiles/r06_e) */
    const i32 c = (i16)c_, s = (i16)s_;
    const int top = len - 2 * d - 1;
    wg_sync();
@@ -239,30 +241,119 @@ WV_DEV void p4_exp_rotation_q14(WV_LDS i32 *T, int len, int dir, int stride, int
    }
 }
 
+/* The same rotation on a leaf of at most 16 coefficients held one per lane (v; pos = the lane's place in its block, out of range for lanes beyond the leaf).  Only the chain
+ * itself is serial: x1' = (A + s x1) >> 15 with A from the not-yet-touched neighbour, handed from lane to lane by a DPP row shift; every other product is elementwise
+ * (the scheme of celt_enc_pvq.h: rot_pass, there on the scalar unit).  A step is ~8 instructions without an LDS round trip. */
+template <int D> WV_DEV i32 p4_rot_pass_reg(i32 v, int pos, int len, i32 c_, i32 s_)
+{
+   const i32 c = (i16)c_, s = (i16)s_;
+   if (len - D > 0) {            /* upwards: (X[i], X[i+D]) <- (c X[i] - s X[i+D], c X[i+D] + s X[i]), i = 0 .. len-D-1 */
+      const i32 xs = wg_shl<D>(v);
+      const i32 A = add32(mult16_16(c, xs), 16384), Bv = mult16_16(s, xs);
+      i32 x1 = v;
+      const int nsteps = (len - 1) / D;                                  /* ceil((len - D) / D) */
+      for (int m = 0; m < nsteps; m++) {
+         const i32 t = wg_shr<D>((i32)(i16)(add32(A, s * x1) >> 15));
+         if (pos >= (m + 1) * D && pos < (m + 2) * D) x1 = t;
+      }
+      v = pos < len - D ? (i32)(i16)(add32(sub32(mult16_16(c, x1), Bv), 16384) >> 15) : x1;
+   }
+   const int top = len - 2 * D - 1;
+   if (top >= 0) {               /* downwards from i = len-2D-1, same butterfly: the chain carries the new X[i] down as the X[i+D] of step i-D */
+      const i32 Cv = add32(mult16_16(c, v), 16384), Sv = mult16_16(s, v);
+      i32 y = wg_shl<D>(v), h = v;
+      const int nsteps = top / D + 1;
+      for (int m = 0; m < nsteps; m++) {
+         const i32 yn = (i32)(i16)(sub32(Cv, s * y) >> 15);
+         const i32 t = wg_shl<D>(yn);
+         if (pos < D && pos <= top - m * D && pos > top - (m + 1) * D) h = yn;
+         if (pos <= top - (m + 1) * D && pos > top - (m + 2) * D) y = t;
+      }
+      const i32 ou = wg_shr<D>((i32)(i16)(add32(add32(mult16_16(c, y), Sv), 16384) >> 15));
+      v = (pos >= D && pos <= len - D - 1) ? ou : h;
+   }
+   return v;
+}
+struct P4Rot { int on, len, stride2; i32 c, s; };
+WV_DEV P4Rot p4_rot_setup(int len, int stride, int K, int spread)
+{
+   P4Rot r; r.on = p4_rot_applies(len, K, spread); r.len = len; r.stride2 = 0; r.c = 0; r.s = 0;
+   if (r.on) {
+      const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
+      const i16 gain = (i16)fx_div(mult16_16(Q15ONE, len), (i32)(len + factor * K));
+      const i16 theta = (i16)(mult16_16_q15(gain, gain) >> 1);
+      r.c = fx_cos_norm(theta);
+      r.s = fx_cos_norm(sub16(Q15ONE, theta));
+      if (len >= 8 * stride) {
+         r.stride2 = 1;
+         while ((r.stride2 * r.stride2 + r.stride2) * stride + (stride >> 2) < len) r.stride2++;
+      }
+      r.len = fx_div_pow2(len, stride);
+   }
+   return r;
+}
+/* v in Q14 (scaled down by the caller); T: the leaf's LDS words, the way round for a stride the row shifts are not instantiated for */
+WV_DEV i32 p4_rot_pass_any(i32 v, WV_LDS i32 *T, int N, int pos, int nblk, int len, int d, i32 c, i32 s)
+{
+   if (d == 1) return p4_rot_pass_reg<1>(v, pos, len, c, s);
+   if (d == 2) return p4_rot_pass_reg<2>(v, pos, len, c, s);
+   if (d == 3) return p4_rot_pass_reg<3>(v, pos, len, c, s);
+   if (d == 4) return p4_rot_pass_reg<4>(v, pos, len, c, s);
+   wg_sync();
+   if (wg_lane() < N) T[wg_lane()] = v;
+   p4_rot_pass(T, nblk, len, d, c, s);
+   v = wg_lane() < N ? T[wg_lane()] : 0;
+   wg_sync();
+   return v;
+}
+WV_DEV i32 p4_exp_rotation_reg(i32 v, WV_LDS i32 *T, int N, const P4Rot &r, int dir, int stride)
+{
+   const int gl = wg_lane();
+   const int pos = gl < N ? gl - (int)fx_udiv24((u32)gl, (u32)r.len) * r.len : 1 << 20;
+   v = pshr32(v, NORM_SHIFT - 14);
+   if (dir < 0) {
+      if (r.stride2) v = p4_rot_pass_any(v, T, N, pos, stride, r.len, r.stride2, r.s, r.c);
+      v = p4_rot_pass_any(v, T, N, pos, stride, r.len, 1, r.c, r.s);
+   } else {
+      v = p4_rot_pass_any(v, T, N, pos, stride, r.len, 1, r.c, -r.s);
+      if (r.stride2) v = p4_rot_pass_any(v, T, N, pos, stride, r.len, r.stride2, r.s, -r.c);
+   }
+   return shl32(v, NORM_SHIFT - 14);
+}
+
 /* ---- alg_quant (vq.c:552) of the leaf X[0 .. N) in the group's LDS.  The leaf is searched in registers when it fits one per lane (N <= 16: most leaves), else word by word
  * from LDS.  During the search a word of X holds |x| (15 bits) | sign << 15 | 2 * pulses << 16. ---- */
 WV_DEV unsigned p4_alg_quant(WV_LDS P4Group *G, u8 *ecbuf, WV_LDS i32 *X, int N, int K, int spread, int B, i32 gain, int resynth)
 {
    const int gl = wg_lane();
    const u32 ft = pvq_u(N, K) + pvq_u(N, K + 1);
+   const int reg = N <= WG_WIDTH;
    const int rot = p4_rot_applies(N, K, spread);
+#ifdef P4_STAT
+   if (gl == 0) fprintf(stderr, "P4LEAF N %d K %d B %d spread %d rot %d\n", N, K, B, spread, rot);
+#endif
    P4_TIC();
    wg_sync();
-   if (rot) {
+   if (rot && !reg) {
       FOR_GL(j, N) X[j] = pshr32(X[j], NORM_SHIFT - 14);
       p4_exp_rotation_q14(X, N, 1, B, K, spread);
       FOR_GL(j, N) X[j] = shl32(X[j], NORM_SHIFT - 14);
       wg_sync();
+      P4_TOC(2);
    }
-   P4_TOC(16);
    /* op_pvq_search (vq.c:205) */
-   const int reg = N <= WG_WIDTH;
    i32 yy_out;
    unsigned cm = 1;
    u32 idx = 0;
    if (reg) {
+      /* the leaf lives in registers from here to its last store: rotation, search, index, resynthesis */
       const bool vld = gl < N;
       i32 xv0 = vld ? X[gl] : 0;
+      P4_TOC(1);
+      const P4Rot rr = p4_rot_setup(N, B, K, spread);
+      P4_TOC(3);
+      if (rot) xv0 = p4_exp_rotation_reg(xv0, X, N, rr, 1, B);
+      P4_TOC(16);
       i64 e2 = xv0 * (i64)xv0;
       int shift = (celt_ilog2(1 + (i32)(wg_sum64(e2) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
       shift = imax(0, shift + (NORM_SHIFT - 14) - 14);
@@ -317,11 +408,14 @@ WV_DEV unsigned p4_alg_quant(WV_LDS P4Group *G, u8 *ecbuf, WV_LDS i32 *X, int N,
          int k = celt_ilog2(yy_out) >> 1;
          i32 t_ = vshr32(yy_out, 2 * (k - 7) - 15);
          i32 g = mult32_32_q31(fx_rsqrt_norm32(t_), gain);
+         i32 v = vld ? vshr32(mult16_32_q15(q, g), k + 15 - NORM_SHIFT) : 0;
+         if (rot) v = p4_exp_rotation_reg(v, X, N, rr, -1, B);
          wg_sync();
-         if (vld) { const i32 v = vshr32(mult16_32_q15(q, g), k + 15 - NORM_SHIFT); X[gl] = rot ? pshr32(v, NORM_SHIFT - 14) : v; }
+         if (vld) X[gl] = v;
          wg_sync();
       }
    } else {
+      P4_TOC(16);
       i64 e2 = 0;
       FOR_GL(j, N) e2 += X[j] * (i64)X[j];
       int shift = (celt_ilog2(1 + (i32)(wg_sum64(e2) >> 2 * (NORM_SHIFT - 14))) + 1) / 2;
@@ -417,7 +511,7 @@ WV_DEV unsigned p4_alg_quant(WV_LDS P4Group *G, u8 *ecbuf, WV_LDS i32 *X, int N,
          wg_sync();
       }
    }
-   if (resynth && rot) {
+   if (resynth && rot && !reg) {
       p4_exp_rotation_q14(X, N, -1, B, K, spread);
       FOR_GL(j, N) X[j] = shl32(X[j], NORM_SHIFT - 14);
       wg_sync();

@@ -61,8 +61,7 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #ifndef OA_ENC_WAVES_PER_EU
 #define OA_ENC_WAVES_PER_EU 4
 #endif
-extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU)
-oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
+template <bool NOPVQ> WV_DEV void oa_encode_kernel_body(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
       int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
       int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
       const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */,
@@ -81,12 +80,22 @@ oa_encode_kernel(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_s
       __syncthreads();
       OaStream *gs = streams + s;
       const int ch = gs->cfg.channels;
-      const int cut = oa_encode_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
+      const int cut = oa_encode_frame<NOPVQ>(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
             apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row, tr ? tr + 4 * (size_t)s : nullptr, conts ? conts + s : nullptr);
       if (cut) { if (threadIdx.x == 0) cut_list[atomicAdd(queue + 1, 1u)] = s; }
       __syncthreads();
    }
 }
+#define OA_ENC_KERNEL_PARAMS OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue, \
+      int pcm_row, int first, int stride, const i32 *budget, const i32 *tr, CeltCont *conts, int *cut_list
+#define OA_ENC_KERNEL_ARGS streams, pcm, apcm, frame_size, max_data_bytes, out, out_stride, lens, rngs, nstreams, scratch, queue, pcm_row, first, stride, budget, tr, conts, cut_list
+extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU) oa_encode_kernel(OA_ENC_KERNEL_PARAMS) { oa_encode_kernel_body<false>(OA_ENC_KERNEL_ARGS); }
+/* the pipeline's front kernel: oa_encode_kernel on single-frame calls of 10 / 20 ms with continuation records -- every frame that reaches the PVQ is cut there, so the PVQ
+ * (and the multi-frame loop) are not in its code */
+#ifndef OA_FRONT_WAVES_PER_EU
+#define OA_FRONT_WAVES_PER_EU 4
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_FRONT_WAVES_PER_EU) oa_celt_front_kernel(OA_ENC_KERNEL_PARAMS) { oa_encode_kernel_body<true>(OA_ENC_KERNEL_ARGS); }
 /* the PVQ of the frames the encode kernel cut: four streams per wave, one 16-lane group each (celt_enc_pvq4.h) */
 #ifndef OA_PVQ4_WAVES_PER_EU
 #define OA_PVQ4_WAVES_PER_EU 3
@@ -726,7 +735,11 @@ static int oa_sh_grid(OpusGpuEncBatch *b, int slot, const void *kernel, size_t l
 {
    if (b->occ[slot].kernel != kernel || b->occ[slot].lds != lds) {
       int per_cu = 0;
+#ifdef OA_PHASE_TIMERS
+      HIPCHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));      /* (the profiling build's kernels carry static LDS counters) */
+#else
       HIPCHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
       HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds));
       b->occ[slot].kernel = kernel; b->occ[slot].lds = lds; b->occ[slot].per_cu = per_cu < 1 ? 1 : per_cu;
    }
@@ -910,11 +923,15 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
    }
    b->celt_pipe_last = pipe ? (int)b->n_act : 0;
    int grid = 0;
-   { const int r = oa_persistent_grid(b, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
-   if (pipe) HIPCHECK(hipMemsetAsync(b->d_queue, 0, 4 * sizeof(unsigned), s));
-   hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
+   { const int r = oa_persistent_grid(b, pipe ? (const void *)oa_celt_front_kernel : (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
+   if (pipe) {
+      HIPCHECK(hipMemsetAsync(b->d_queue, 0, 4 * sizeof(unsigned), s));
+      hipLaunchKernelGGL(oa_celt_front_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
+            b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
+            b->d_ccont, b->d_cut_list);
+   } else hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
          b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
-         pipe ? b->d_ccont : (CeltCont *)nullptr, b->d_cut_list);
+         (CeltCont *)nullptr, (int *)nullptr);
    HIPCHECK(hipGetLastError());
    if (pipe) {
       int g_pvq = 0, g_back = 0;

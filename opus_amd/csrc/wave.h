@@ -219,6 +219,9 @@ WV_DEV int32_t wg_scan_incl(int32_t v)
    v += WV_DPP(0, v, 0x118, 0xf);
    return v;
 }
+/* lane i of the group receives v of lane i + D (wg_shl) / i - D (wg_shr) of the same group, 0 where there is none: DPP row_shl / row_shr, one instruction */
+template <int D> WV_DEV int32_t wg_shl(int32_t v) { return WV_DPP(0, v, 0x100 + D, 0xf); }
+template <int D> WV_DEV int32_t wg_shr(int32_t v) { return WV_DPP(0, v, 0x110 + D, 0xf); }
 /* value of lane src (0..15, the same in all lanes of the group, free to differ between groups) of the caller's group: ds_bpermute_b32, the LDS crossbar without memory */
 WV_DEV int32_t wg_bcast(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 48u) | (unsigned)src) << 2), v); }
 WV_DEV uint32_t wg_ballot(int pred) { return (uint32_t)(__ballot(pred) >> (threadIdx.x & 48u)) & 0xffffu; }

@@ -176,6 +176,8 @@ WV_DEV int32_t wg_bcast(int32_t v, int src)
    if (emu_check_uni && t[g + wg_lane()][1] != t[g][1]) { fprintf(stderr, "wave_emu: wg_bcast with a lane index that is not uniform in the group: lane %d asks for %d, the group's lane 0 for %d\n", wv_lane(), src, (int)t[g][1]); emu_die(); }
    return (int32_t)t[g + src][0];
 }
+template <int D> WV_DEV int32_t wg_shl(int32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE, me = wg_lane(); return me + D < 16 ? (int32_t)t[g + me + D][0] : 0; }
+template <int D> WV_DEV int32_t wg_shr(int32_t v) { auto t = emu_gxchg(v); const int g = EMU_GBASE, me = wg_lane(); return me - D >= 0 ? (int32_t)t[g + me - D][0] : 0; }
 WV_DEV uint32_t wg_ballot(int pred) { auto t = emu_gxchg(pred != 0); const int g = EMU_GBASE; uint32_t m = 0; for (int i = 0; i < 16; i++) m |= (uint32_t)(t[g + i][0] != 0) << i; return m; }
 WV_DEV int wg_argmax_ratio_packed(uint32_t num, uint32_t den, bool valid)
 {

@@ -5,7 +5,7 @@ Profiling aid only; the product library has no timers.   usage: phase_profile_p4
 import ctypes, os, subprocess, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-NAMES = {0: "band begin (rows, budget, folding masks)", 16: "leaf: exp_rotation fwd", 17: "leaf: pulse search", 18: "leaf: mask + icwrs + ec_enc_uint", 19: "leaf: resynthesis (+ rotation back)",
+NAMES = {1: "leaf: entry (reg path: load)", 2: "leaf: LDS-path rotation fwd", 3: "leaf: reg-path rotation set-up", 0: "band begin (rows, budget, folding masks)", 16: "leaf: exp_rotation fwd", 17: "leaf: pulse search", 18: "leaf: mask + icwrs + ec_enc_uint", 19: "leaf: resynthesis (+ rotation back)",
          20: "compute_theta (partition splits)", 31: "compute_theta (stereo, band level)", 21: "trial set-up: staging, RDO switch / decision", 22: "quant_band pre / post (haar, hadamard, lowband out)",
          23: "stereo_merge", 24: "(tree total, nested)", 25: "tree: way down incl. theta (nested)", 26: "tree: leaf budget (bits2pulses ..)", 30: "tree: leaf incl. alg_quant (nested)", 27: "tree: way up"}
 def main():
@@ -31,7 +31,7 @@ def main():
     L.opusgpu_debug_p4_ticks(ticks, lanes, 0)
     t = np.array(list(ticks), dtype=np.float64); l = np.array(list(lanes), dtype=np.float64)
     frames = 5 * S
-    excl = [0, 16, 17, 18, 19, 20, 31, 21, 22, 23, 26, 27]
+    excl = [0, 1, 2, 3, 16, 17, 18, 19, 20, 31, 21, 22, 23, 26, 27]
     print("PVQ kernel sections over %d frames (%s signals); ticks per FRAME = wave ticks / 4 streams" % (frames, "identical" if same else "mixed"))
     for k in sorted(NAMES, key=lambda k: (k not in excl, k)):
         if t[k] == 0: continue
