@@ -204,6 +204,9 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_reset(OpusGpuEncBatch *b);
 /* Diagnostics of a SILK-capable batch (applications VOIP / AUDIO / RESTRICTED_SILK): calls that went through the three-kernel split path of the encoder (front / 16-streams-
  * per-wave quantiser / back, opus_amd/csrc/opus_sh_split.h) and calls it handed to the one-kernel path since the batch was created.  Results never depend on the path. */
 OPUS_AMD_EXPORT int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_uint32 *declined);
+/* *streams = how many streams of the batch's LAST call had the PVQ of their CELT frame coded by the four-streams-per-wave stage (oa_celt_pvq_kernel: celt_enc_pvq4.h) --
+ * 10 / 20 ms calls of a launch that runs as a kernel pipeline (OPUS_AMD_SET_KERNEL_PIPELINE); 0 when the call ran as one kernel.  Waits for the batch's stream.  Test / bench aid. */
+OPUS_AMD_EXPORT int opusgpu_enc_batch_pvq_stage_stats(OpusGpuEncBatch *b, opus_uint32 *streams);
 /* introspection for the roofline report */
 OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
 

@@ -393,7 +393,7 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
 
    K_PHASE(12);
    /* ---- PVQ residual ---- */
-   if (cut && !HYB && LM >= 2) { celt_cut_dump(L, cut); return OA_CUT; }        /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
+   if (cut && LM >= 2) { celt_cut_dump(L, cut); return OA_CUT; }                /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
    if constexpr (NOPVQ) return 0;                                               /* (the pipeline's front kernel: its calls are single frames of 10 / 20 ms, every frame that gets here is cut) */
    else {
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,

@@ -379,7 +379,9 @@ oa_sh_transient_kernel(const OaShStream *streams, const ShCont *conts, const cha
 extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
 oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *pcm_hp_all, char *scratch, const ShCont *conts, i32 *lens, u32 *rngs, int nstreams, unsigned *counters, int pkt_off,
       int chunk /* streams per pop of the queue: 1, or several where the frames are all light (a batch pinned to SILK-only: 65,536 pops of one counter take longer than their frames) */,
-      const i32 *tr /* NULL, or [stream][12]: the transient pre-pass's records (oa_sh_transient_kernel) */)
+      const i32 *tr /* NULL, or [stream][12]: the transient pre-pass's records (oa_sh_transient_kernel) */,
+      CeltCont *cconts /* NULL, or [stream]: the CELT layer's PVQ as a stage of its own -- a frame with one CELT pass stops before its PVQ, its stream goes on cut_list (cutq[1] counts) */,
+      ShBackHdr *hdrs, int *cut_list, unsigned *cutq)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -392,9 +394,32 @@ oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, 
          OaShStream *gs = streams + s;
          const int ch = gs->cfg.channels;
          char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
-         oa_sh_back_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)),
-               (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s, tr ? tr + 12 * (size_t)s : nullptr);
+         const int cut = oa_sh_back_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)),
+               (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s, tr ? tr + 12 * (size_t)s : nullptr,
+               cconts ? cconts + s : (CeltCont *)0, cconts ? hdrs + s : (ShBackHdr *)0);
+         if (cut) { if (threadIdx.x == 0) cut_list[atomicAdd(cutq + 1, 1u)] = s; }
       }
+      __syncthreads();
+   }
+}
+/* the rest of the calls the back kernel cut before their PVQ (oa_celt_pvq_kernel in between) */
+extern "C" __global__ void __launch_bounds__(64, OA_SH_BACK_WAVES_PER_EU)
+oa_sh_back2_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, char *scratch, i32 *lens, u32 *rngs, int pkt_off, const CeltCont *cconts, const ShBackHdr *hdrs, const int *cut_list, unsigned *cutq)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   const int n = (int)wv_uni((i32)cutq[1]);
+   for (;;) {
+      int k = 0;
+      if (wv_lane() == 0) k = (int)atomicAdd(cutq + 3, 1u);
+      k = wv_bcast(k, 0);
+      if (k >= n) break;
+      const int s = wv_uni(cut_list[k]);
+      OaShStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      char *scr = scratch + (size_t)blockIdx.x * SH_SCRATCH_BYTES(frame_size, ch);
+      __syncthreads();
+      oa_sh_back2_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), hdrs + s, cconts + s, pkt_off, lens + s, rngs + s);
       __syncthreads();
    }
 }
@@ -477,6 +502,8 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
+   int pvq4_last;                                                           /* the last call launched oa_celt_pvq_kernel */
+   ShBackHdr *d_back_hdr;                                                   /* SILK-capable batches: the back kernel's LDS header of the calls cut before their CELT pass's PVQ */
    CeltCont *d_ccont; int *d_cut_list; int celt_pipe_last /* streams of the last pipelined call, 0 = the last call was not pipelined */;                                       /* CELT-only batches, kernel pipeline: per-stream continuation records, the list of the streams whose call was cut before the PVQ */
    i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
    struct { const void *kernel; size_t lds; int per_cu; } occ[8];
@@ -533,7 +560,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0;
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -565,6 +592,7 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_queue) (void)hipFree(b->d_queue);
    if (b->d_ccont) (void)hipFree(b->d_ccont);
    if (b->d_cut_list) (void)hipFree(b->d_cut_list);
+   if (b->d_back_hdr) (void)hipFree(b->d_back_hdr);
    if (b->d_cont) (void)hipFree(b->d_cont);
    if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_slow_list) (void)hipFree(b->d_slow_list);
@@ -705,6 +733,18 @@ int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_ui
    *kept = v[0]; *declined = v[1];
    return OPUS_OK;
 }
+int opusgpu_enc_batch_pvq_stage_stats(OpusGpuEncBatch *b, opus_uint32 *streams)
+{
+   if (!b || !streams) return OPUS_BAD_ARG;
+   *streams = 0;
+   if (!b->d_ccont || !b->pvq4_last) return OPUS_OK;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipStreamSynchronize(b->stream));
+   unsigned v = 0;
+   HIPCHECK(hipMemcpy(&v, b->d_queue + (b->kind ? 25 : 1), sizeof v, hipMemcpyDeviceToHost));
+   *streams = v;
+   return OPUS_OK;
+}
 int opusgpu_enc_batch_reset(OpusGpuEncBatch *b) { return opusgpu_enc_batch_ctl(b, -1, OPUS_RESET_STATE, 0); }
 int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
 
@@ -815,8 +855,29 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
       hipLaunchKernelGGL(oa_sh_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaShStream *)b->d_sh, (const ShCont *)b->d_cont, (const char *)b->d_pcm_hp, frame_size, ch, items, b->d_tr_scratch, b->d_tr);
       d_tr = b->d_tr;
    }
+   /* the CELT layer's PVQ as a stage of its own (celt_enc_pvq4.h: four streams per wave) wherever the launch can carry CELT frames; OPUS_AMD_SH_PVQ4=0: inside the back kernel */
+   static const int pvq4_env = getenv("OPUS_AMD_SH_PVQ4") ? atoi(getenv("OPUS_AMD_SH_PVQ4")) : 1;
+   const bool pvq4 = pvq4_env && !silk_only && b->application != OPUS_APPLICATION_RESTRICTED_SILK;
+   unsigned *cutq = b->d_queue + 24;
+   b->pvq4_last = pvq4;
+   if (pvq4) {
+      if (!b->d_ccont) {
+         HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
+         HIPCHECK(hipMalloc((void **)&b->d_cut_list, sizeof(int) * (size_t)b->S));
+         HIPCHECK(hipMalloc((void **)&b->d_back_hdr, sizeof(ShBackHdr) * (size_t)b->S));
+      }
+      HIPCHECK(hipMemsetAsync(cutq, 0, 4 * sizeof(unsigned), s));
+   }
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
-         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1, d_tr);
+         b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1, d_tr,
+         pvq4 ? b->d_ccont : (CeltCont *)nullptr, b->d_back_hdr, b->d_cut_list, cutq);
+   if (pvq4) {
+      int g_pvq = 0;
+      { const int r = oa_sh_grid(b, 6, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)n + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
+      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)b->d_cut_list, cutq);
+      hipLaunchKernelGGL(oa_sh_back2_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s, b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, po_back,
+            (const CeltCont *)b->d_ccont, (const ShBackHdr *)b->d_back_hdr, (const int *)b->d_cut_list, cutq);
+   }
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
          (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row, 0, 1, (const i32 *)nullptr);
@@ -890,6 +951,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
        * enough for it to pay -- a handful of streams (the classic API's lone caller: profiles/r04_j) finish sooner in one launch than in four */
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
       const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 4 : 0);
+      b->pvq4_last = 0;
       if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
@@ -921,7 +983,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
       HIPCHECK(hipMalloc((void **)&b->d_cut_list, sizeof(int) * (size_t)b->S));
    }
-   b->celt_pipe_last = pipe ? (int)b->n_act : 0;
+   b->celt_pipe_last = pipe ? (int)b->n_act : 0; b->pvq4_last = pipe;
    int grid = 0;
    { const int r = oa_persistent_grid(b, pipe ? (const void *)oa_celt_front_kernel : (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    if (pipe) {

@@ -442,8 +442,18 @@ WV_DEV void sh_celt_reset_wave(WV_LDS ShLds *L, OaShStream *gs)
  *   raw = 0: the CELT layer of the frame being built, continuing the coder in L->ec on the bytes in SH_PKT(L) (hybrid), or starting it (CELT-only frame)
  *   raw = 1: a self-contained redundancy / prefill frame of `nbytes` bytes; its bytes end up at F->packet + 1, its return value in L->sh.celt_ret */
 struct ShCeltCtl { int start, vbr, constrained_vbr, nbytes, raw, cont; i32 bitrate; };     /* raw: own nbytes-byte buffer; cont: continue the frame's coder after the SILK layer */
-WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal, const i32 *tr = nullptr /* the transient pre-pass's record of the
-      stream (opus_sh_split.h: oa_sh_transient_tile), for the frame's own pass on the input this function finds staged */)
+/* what follows celt_encode_with_ec in a pass: its return value and the coder's position, for the caller */
+WV_DEV void sh_celt_run_tail(WV_LDS ShLds *L)
+{
+   WV_LDS ShShared *sh = &L->sh;
+   WV_LDS FrameLds *F = SH_F(L);
+   wv_sync();
+   LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = F->sh.ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
+   wv_sync();
+}
+/* cut: the stream's continuation record -- the pass stops before the PVQ (celt_enc_frame.h: OA_CUT, returned) and goes on in oa_celt_pvq_kernel / oa_sh_back2_kernel */
+WV_DEVN int sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsamp, const ShCeltCtl ctl, u8 *journal, const i32 *tr = nullptr /* the transient pre-pass's record of the
+      stream (opus_sh_split.h: oa_sh_transient_tile), for the frame's own pass on the input this function finds staged */, CeltCont *cut = nullptr)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS FrameLds *F = SH_F(L);
@@ -482,19 +492,20 @@ WV_DEVN void sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int ns
    wv_sync();
    LANE0 celt_prologue(F, ctl.cont ? sh->nb_compr_bytes : 0);
    wv_sync();
-   if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); SE_CLK_END(16); SE_PHASE_START(&L->S); return; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
+   if (fs->skip_celt) { LANE0 sh->celt_ret = -1000; wv_sync(); SE_CLK_END(16); SE_PHASE_START(&L->S); return 0; }                /* budget already gone: the caller emits the "PLC" byte (:2487) */
    /* the pre-pass worked from the gains it expected this function's caller to apply to the input: its values hold if those are the ones that were applied */
    const i32 *tp = nullptr;
    if (tr && !ctl.raw && !src) {
       const int dg = wv_uni(sh->do_gain_fade), ds = wv_uni(sh->do_stereo_fade);
       if (wv_uni(tr[3]) == dg && (!dg || (wv_uni(tr[4]) == wv_uni(sh->hb_g1) && wv_uni(tr[5]) == wv_uni(sh->hb_g2))) && wv_uni(tr[6]) == ds && (!ds || (wv_uni(tr[7]) == wv_uni(sh->fade_g1) && wv_uni(tr[8]) == wv_uni(sh->fade_g2)))) tp = tr;
    }
-   if (ctl.start != 0) celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask, tp);                    /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
-   else celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask, tp);
-   wv_sync();
-   LANE0 { EcCtx t; ec_ld(&t, &F->ec); sh->celt_ret = fs->ret; sh->r[4] = k_ec_tell(&t, F->packet + 1); }
-   wv_sync();
+   int r;
+   if (ctl.start != 0) r = celt_encode_core<true>(F, &gs->celt, journal, gs->energy_mask, tp, cut);           /* "hybrid" inside CELT = start band above 0 (celt_encoder.c:1809) */
+   else r = celt_encode_core<false>(F, &gs->celt, journal, gs->energy_mask, tp, cut);
+   if (r == OA_CUT) { SE_CLK_END(16); return OA_CUT; }
+   sh_celt_run_tail(L);
    SE_CLK_END(16); SE_PHASE_START(&L->S);
+   return 0;
 }
 
 /* gain_fade (:581) / stereo_fade (:548) on `n` frames of CC interleaved int16 (LDS staging or HBM scratch); the cross-fade covers overlap = 120 * Fs / 48000 samples, window read with stride inc */
@@ -648,7 +659,11 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
 }
 /* sh_frame_back_wave: everything after silk_Encode (:2211-2657): what the Opus layer reads back from *scp, the CELT passes, redundancy, TOC, DTX, the frame's length.
  * silk_nBytes: what SILK returned (1 when it did not run) */
-WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes, const i32 *tr = nullptr)
+/* cut / resume: the kernel pipeline's cut of the frame's own CELT pass before its PVQ (sh_celt_run).  With a continuation record the function returns OA_CUT there (only a
+ * frame with no other CELT pass is cut: no redundancy frame, no prefill -- those read the per-wave copy of the input); resume = 1 is the other half, entered with the
+ * wave's LDS as the first half left it (oa_sh_back2_frame) and the PVQ coded: everything from celt_encode_with_ec's finalisation on. */
+WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i16 *pcm_hp, i16 *pcm_celt, i16 *tmp_prefill, u8 *journal, const SeControl *scp, int silk_nBytes, const i32 *tr = nullptr,
+      CeltCont *cut = nullptr, const int resume = 0)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS FrameLds *F = SH_F(L);
@@ -657,7 +672,8 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
    frame_size = wv_uni(frame_size); silk_nBytes = wv_uni(silk_nBytes);
    const int frame_rate = Fs / frame_size;
    const int mode = wv_uni(st->mode);
-   if (mode != OA_MODE_CELT_ONLY) {
+   if (resume) {}
+   else if (mode != OA_MODE_CELT_ONLY) {
       const SeControl &sc = *scp;
       SE_PHASE(&L->S, 9);
       LANE0 {
@@ -688,6 +704,7 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
    /* ---- CELT control, delay line, fades (:2264-2349) ---- */
    const int need_celt = mode != OA_MODE_SILK_ONLY || wv_uni(sh->f_redundancy);
    const int celt_prefill = mode != OA_MODE_SILK_ONLY && mode != wv_uni(st->prev_mode) && wv_uni(st->prev_mode) > 0;
+   if (!resume) {
    if (celt_prefill) {                                                                    /* tmp_prefill: the 2.5 ms ahead of the delay-compensated input (:2298-2302) */
       const int n4 = Fs / 400;
       FOR_LANES(i, n4 * CC) tmp_prefill[i] = gs->delay_buffer[(encoder_buffer - total_buffer - n4) * CC + i];
@@ -768,14 +785,16 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
       ec_st(&L->ec, e);
       sh->f_redundancy = redundancy; sh->redundancy_bytes = redundancy_bytes;
    }
+   }   /* !resume */
    const int redundancy = wv_uni(sh->f_redundancy), celt_to_silk = wv_uni(sh->f_celt_to_silk), redundancy_bytes = wv_uni(sh->redundancy_bytes);
    const int n2 = Fs / 200, n4 = Fs / 400;
-   if (redundancy || mode != OA_MODE_SILK_ONLY) {                                          /* CELT_SET_ANALYSIS (:2416-2419) */
+   if (resume) {}
+   else if (redundancy || mode != OA_MODE_SILK_ONLY) {                                          /* CELT_SET_ANALYSIS (:2416-2419) */
       if (wv_lane() < (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)&gs->celt.analysis)[wv_lane()] = ((const i32 *)&gs->an_info)[wv_lane()];
       wv_sync();
    }
    /* ---- 5 ms redundant CELT frame ahead of the SILK / hybrid audio (CELT -> SILK, :2427-2442) ---- */
-   if (redundancy && celt_to_silk) {
+   if (!resume && redundancy && celt_to_silk) {
       ShCeltCtl c; c.start = 0; c.vbr = 0; c.constrained_vbr = 0; c.nbytes = redundancy_bytes; c.raw = 1; c.cont = 0; c.bitrate = -1;
       sh_celt_run(L, gs, pcm_celt, n2, c, journal);
       if (wv_uni(sh->celt_ret) < 0) return OA_ERR_INTERNAL;
@@ -789,16 +808,17 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
       const int hyb = mode == OA_MODE_HYBRID;
       ShCeltCtl c; c.start = hyb ? 17 : 0; c.vbr = L->cfg.use_vbr; c.constrained_vbr = hyb ? 0 : L->cfg.vbr_constraint; c.nbytes = 0; c.raw = 0; c.cont = hyb; c.bitrate = -1;
       if (L->cfg.use_vbr) { const i32 cb = hyb ? sh->bitrate_bps - sh->silk_bitRate : sh->bitrate_bps; if (cb > 500) c.bitrate = imin(cb, 750000 * CC); }    /* OPUS_SET_BITRATE rejects <= 500 and keeps OPUS_BITRATE_MAX */
-      if (celt_prefill) {                                                                 /* mode change: restart CELT on the 2.5 ms before the frame, then no inter-frame prediction (:2478-2486) */
+      if (!resume && celt_prefill) {                                                      /* mode change: restart CELT on the 2.5 ms before the frame, then no inter-frame prediction (:2478-2486) */
          sh_celt_reset_wave(L, gs);
          ShCeltCtl p = c; p.raw = 1; p.nbytes = 2; p.cont = 0;
          sh_celt_run(L, gs, tmp_prefill, n4, p, journal);
          LANE0 { SH_CELT_DISABLE_PF(F) = 1; SH_CELT_FORCE_INTRA(F) = 1; }
       }
       int ran = 0;
-      if (wv_uni(sh->r[7]) <= 8 * wv_uni(sh->nb_compr_bytes)) {                            /* otherwise the budget is gone already and the frame ends up a "PLC frame" (:2487) */
+      if (resume || wv_uni(sh->r[7]) <= 8 * wv_uni(sh->nb_compr_bytes)) {                  /* otherwise the budget is gone already and the frame ends up a "PLC frame" (:2487) */
          const int reload = wv_uni(sh->f_redundancy) || celt_prefill;
-         sh_celt_run(L, gs, reload ? pcm_celt : (const i16 *)0, frame_size, c, journal, tr);
+         if (resume) { if (hyb) celt_encode_core_tail<true>(F, &gs->celt); else celt_encode_core_tail<false>(F, &gs->celt); sh_celt_run_tail(L); }
+         else if (sh_celt_run(L, gs, reload ? pcm_celt : (const i16 *)0, frame_size, c, journal, tr, reload ? (CeltCont *)0 : cut) == OA_CUT) return OA_CUT;
          const int cret = wv_uni(sh->celt_ret);
          if (cret != -1000 && cret < 0) return OA_ERR_INTERNAL;
          if (cret >= 0) {

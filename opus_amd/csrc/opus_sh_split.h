@@ -358,7 +358,33 @@ WV_DEVN void oa_sh_transient_tile(const OaShStream *streams, const ShCont *conts
 }
 
 /* ---------------- back ---------------- */
-WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, i16 *pcm_hp /* the stream's slot: the front kernel's high-passed input */, i16 *pcm_celt, i16 *tmp_prefill, CeltScratch *cs, const ShCont *ct, i32 *len_out, u32 *rng_out, const i32 *tr = nullptr /* the transient pre-pass's record of the stream */)
+/* The CELT layer's PVQ as a stage of its own (celt_enc_pvq4.h: four streams per wave): the back kernel stops a frame before the PVQ of its CELT pass (a hybrid or CELT-only frame
+ * with that one pass), parks the wave's LDS -- this header in the stream's ShBackHdr, the CELT arena in its CeltCont -- and returns 1; oa_celt_pvq_kernel codes the bands;
+ * oa_sh_back2_frame reloads the LDS and finishes the call. */
+#define SH_BACK_HDR_WORDS ((int)((offsetof(ShLds, S) + 16 + 3) / 4))
+struct ShBackHdr { i32 w[SH_BACK_HDR_WORDS]; };
+WV_DEV void oa_sh_back_finish(WV_LDS ShLds *L, OaShStream *gs, int ret, u8 *out, int out_cap, i32 *len_out, u32 *rng_out)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
+   const int result = ret < 0 ? ret : sh_emit_packet(SH_PKT(L), out, ret, pad_to, out_cap);
+   LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
+   sh_copy_words((i32 *)&gs->s, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
+   wv_sync();
+}
+WV_DEVN void oa_sh_back2_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, CeltScratch *cs, const ShBackHdr *hdr, const CeltCont *cc, int pkt_off, i32 *len_out, u32 *rng_out)
+{
+   wv_sync();
+   sh_copy_words((WV_LDS i32 *)L, hdr->w, SH_BACK_HDR_WORDS);
+   sh_copy_words((WV_LDS i32 *)SH_F(L), cc->image, (int)(offsetof(FrameLds, BC) / 4));
+   wv_sync();
+   LANE0 { L->cs = cs; L->packet_off = pkt_off; SH_F(L)->g = cs; }
+   wv_sync();
+   const int ret = sh_frame_back_wave(L, gs, frame_size, (i16 *)0, (i16 *)0, (i16 *)0, out, (const SeControl *)0, 1, (const i32 *)0, (CeltCont *)0, 1);
+   oa_sh_back_finish(L, gs, ret, out, out_cap, len_out, rng_out);
+}
+WV_DEVN int oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u8 *out, int out_cap, i16 *pcm_hp /* the stream's slot: the front kernel's high-passed input */, i16 *pcm_celt, i16 *tmp_prefill, CeltScratch *cs, const ShCont *ct, i32 *len_out, u32 *rng_out, const i32 *tr = nullptr /* the transient pre-pass's record of the stream */,
+      CeltCont *cut = nullptr, ShBackHdr *hdr = nullptr)
 {
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
@@ -382,12 +408,10 @@ WV_DEVN void oa_sh_back_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, u
       sh->r[5] = nb;
    }
    const int silk_nBytes = wv_uni(sh->r[5]);
-   const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes, tr);
-   const int pad_to = (!L->cfg.use_vbr && ret > 0 && !wv_uni(sh->r[3])) ? wv_uni(sh->max_data_bytes) : 0;
-   const int result = ret < 0 ? ret : sh_emit_packet(SH_PKT(L), out, ret, pad_to, out_cap);
-   LANE0 { *len_out = result; *rng_out = result < 0 ? 0 : st->rangeFinal; }
-   sh_copy_words((i32 *)&gs->s, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
-   wv_sync();
+   const int ret = sh_frame_back_wave(L, gs, frame_size, pcm_hp, pcm_celt, tmp_prefill, out, &sc, silk_nBytes, tr, cut);
+   if (ret == OA_CUT) { wv_sync(); sh_copy_words(hdr->w, (const WV_LDS i32 *)L, SH_BACK_HDR_WORDS); wv_sync(); return 1; }
+   oa_sh_back_finish(L, gs, ret, out, out_cap, len_out, rng_out);
+   return 0;
 }
 
 /* ---------------- quantiser, reference form: one wave per stream on the one-kernel path's own stage function (se_frame_quant_wave).  OPUS_AMD_SH_SPLIT=2 selects it: the

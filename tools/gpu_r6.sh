@@ -16,6 +16,7 @@ phases2) OPUS_AMD_PROF_PREBUILT=1 timeout 200 python tools/phase_profile.py 1638
 celtpipe) timeout 600 python tests/celt_pipe_check.py gpu > $O/celt_pipe_check.log 2>&1 ;;
 bench2ab) for m in 1 0; do OPUS_AMD_CELT_PIPE=$m timeout 300 python bench.py $B > $O/bench2_pipe$m.log 2>&1; done ;;
 p4phases) OPUS_AMD_PROF_PREBUILT=1 timeout 200 python tools/phase_profile_p4.py 16384 > $O/p4_phases_mixed.txt 2>&1; OPUS_AMD_PROF_PREBUILT=1 timeout 200 python tools/phase_profile_p4.py 16384 same > $O/p4_phases_same.txt 2>&1 ;;
+bench45ab) for c in 4 5; do for m in 1 0; do OPUS_AMD_SH_PVQ4=$m timeout 300 python bench.py $B --config $c > $O/bench${c}_pvq4_$m.log 2>&1; done; done ;;
 smoke) python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 ;;
 split_check) timeout 900 python tools/split_check.py gpu > $O/split_check.log 2>&1 ;;
 silkenc) timeout 1200 python -m pytest tests/test_gpu_silkenc.py -x -q > $O/pytest_silkenc.log 2>&1 ;;

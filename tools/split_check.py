@@ -47,7 +47,7 @@ def run_child(libpath, out):
     L.opusgpu_enc_batch_ctl.argtypes = [vp, i32, ctypes.c_int, i32]
     L.opusgpu_encode_batch.argtypes = [vp, vp, ctypes.c_int, vp, i32, i32, vp, vp]
     L.opusgpu_enc_batch_export_state.argtypes = [vp, i32, vp]
-    L.opusgpu_enc_batch_split_stats.argtypes = [vp, vp, vp]
+    L.opusgpu_enc_batch_split_stats.argtypes = [vp, vp, vp]; L.opusgpu_enc_batch_pvq_stage_stats.argtypes = [vp, vp]
     L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
     res = {}
     for name, (Fs, ch, app, n, frames, ms, ctl, per) in selected_cases().items():
@@ -58,20 +58,21 @@ def run_child(libpath, out):
             for k, v in d.items(): assert L.opusgpu_enc_batch_ctl(b, s, k, v) == 0, (name, s, k, v)
         fsz = int(Fs * ms // 1000)
         sig = [speech(Fs, frames * ms / 1000 + 0.1, ch, s) for s in range(n)]
-        pk = []
+        pk = []; pvq_calls = 0
         for f in range(frames):
             pcm = np.stack([np.ascontiguousarray(sig[s][f * fsz:(f + 1) * fsz]).reshape(-1) for s in range(n)]).astype(np.int16)
             if f == frames // 2: pcm[0] = 0                      # a frame of digital silence
             for k, v in SCHEDULE.get(name, {}).get(f, {}).items(): assert L.opusgpu_enc_batch_ctl(b, -1, k, v) == 0, (name, f, k, v)
             o = np.zeros((n, 1500), np.uint8); lens = np.zeros(n, np.int32); rng = np.zeros(n, np.uint32)
             r = L.opusgpu_encode_batch(b, pcm.ctypes.data, fsz, o.ctypes.data, 1500, 1275, lens.ctypes.data, rng.ctypes.data); assert r == 0, (name, r)
+            pv = ctypes.c_uint32(); L.opusgpu_enc_batch_pvq_stage_stats(b, ctypes.byref(pv)); pvq_calls += pv.value
             pk.append((lens.copy(), rng.copy(), [bytes(o[s, :max(lens[s], 0)]) for s in range(n)]))
         sz = L.opusgpu_enc_sh_state_size(); blobs = []
         for s in range(n):
             bl = np.zeros(sz, np.uint8); assert L.opusgpu_enc_batch_export_state(b, s, bl.ctypes.data) == 0; blobs.append(bl)
         k = ctypes.c_uint32(); d = ctypes.c_uint32(); L.opusgpu_enc_batch_split_stats(b, ctypes.byref(k), ctypes.byref(d))
         L.opusgpu_enc_batch_destroy(b)
-        res[name] = (pk, blobs, (k.value, d.value))
+        res[name] = (pk, blobs, (k.value, d.value), pvq_calls)
     pickle.dump(res, open(out, "wb"))
 
 def compare(which="emu", tmpdir="/tmp", verbose=True):
@@ -92,7 +93,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
             b = r[mode][name]
             okp = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(a[0], b[0]))
             nd = [int((x != y).sum()) for x, y in zip(a[1], b[1])]
-            if verbose: print("%-12s mode %s: packets %s, state bytes differing per stream %s, calls kept / handed back %s" % (name, mode, "equal" if okp else "DIFFER", nd, b[2]))
+            if verbose: print("%-12s mode %s: packets %s, state bytes differing per stream %s, calls kept / handed back %s, CELT frames through the PVQ stage %d" % (name, mode, "equal" if okp else "DIFFER", nd, b[2], b[3]))
             if not okp or any(nd): bad.append((name, mode))
     return bad, {name: r["1"][name][2] for name in selected_cases()}
 
