@@ -103,7 +103,8 @@ struct FrameLds {
 /* what the front kernel hands over and the back kernel takes up again (one record per stream, HBM) */
 struct alignas(16) CeltCont {
    i32 state;                                  /* 0: the front kernel finished the call itself; 1: cut before the PVQ */
-   i32 pad_[3];
+   i32 sort_key;                               /* what the PVQ kernel's order is sorted by (opus_amd.hip: oa_cut_key) */
+   i32 pad_[2];
    i32 image[(offsetof(FrameLds, BC) + 3) / 4];   /* the front wave's LDS up to the phase scratch: coder, frame constants, band arrays, packet */
    i32 X[2][OA_CODED_BINS];                    /* the normalised spectrum, coded bins of each channel */
    i32 norm[2][OA_NORM_LEN];                   /* folding memory (norm, norm2) */

@@ -61,13 +61,15 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #ifndef OA_ENC_WAVES_PER_EU
 #define OA_ENC_WAVES_PER_EU 4
 #endif
+#define OA_SORT_KEYS 128          /* the order the PVQ kernel takes the cut frames in: see oa_celt_sort_kernel */
+WV_DEV int oa_cut_key(const WV_LDS FrameLds *F) { return (F->sh.shortBlocks ? 64 : 0) | (F->sh.dual_stereo ? 32 : 0) | imin(31, F->sh.nbCompressedBytes >> 4); }
 template <bool NOPVQ> WV_DEV void oa_encode_kernel_body(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
       int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
       int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
       const i32 *budget /* NULL, or per stream record: this call's max_data_bytes for it, <= 0 = the stream sits this call out (opus_ms_batch.h: chained byte budgets) */,
       const i32 *tr /* NULL, or [record][4]: the unmask values oa_celt_transient_kernel worked out for this call's frames */,
       CeltCont *conts /* NULL, or [record]: the kernel pipeline -- a single-frame call of 10 / 20 ms stops before the PVQ, its stream goes on the list (queue[1] counts) for oa_celt_pvq_kernel / oa_celt_back_kernel */,
-      int *cut_list)
+      int *cut_list, unsigned *srt /* the key counts of the PVQ kernel's order (oa_celt_sort_kernel) */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS FrameLds *L = (WV_LDS FrameLds *)smem;
@@ -82,13 +84,13 @@ template <bool NOPVQ> WV_DEV void oa_encode_kernel_body(OaStream *streams, const
       const int ch = gs->cfg.channels;
       const int cut = oa_encode_frame<NOPVQ>(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, out + (size_t)s * out_stride, out_stride, lens + s, rngs + s,
             apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, pcm_row, tr ? tr + 4 * (size_t)s : nullptr, conts ? conts + s : nullptr);
-      if (cut) { if (threadIdx.x == 0) cut_list[atomicAdd(queue + 1, 1u)] = s; }
+      if (cut) { if (threadIdx.x == 0) { const int key = oa_cut_key(L); conts[s].sort_key = key; atomicAdd(srt + key, 1u); cut_list[atomicAdd(queue + 1, 1u)] = s; } }
       __syncthreads();
    }
 }
 #define OA_ENC_KERNEL_PARAMS OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue, \
-      int pcm_row, int first, int stride, const i32 *budget, const i32 *tr, CeltCont *conts, int *cut_list
-#define OA_ENC_KERNEL_ARGS streams, pcm, apcm, frame_size, max_data_bytes, out, out_stride, lens, rngs, nstreams, scratch, queue, pcm_row, first, stride, budget, tr, conts, cut_list
+      int pcm_row, int first, int stride, const i32 *budget, const i32 *tr, CeltCont *conts, int *cut_list, unsigned *srt
+#define OA_ENC_KERNEL_ARGS streams, pcm, apcm, frame_size, max_data_bytes, out, out_stride, lens, rngs, nstreams, scratch, queue, pcm_row, first, stride, budget, tr, conts, cut_list, srt
 extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU) oa_encode_kernel(OA_ENC_KERNEL_PARAMS) { oa_encode_kernel_body<false>(OA_ENC_KERNEL_ARGS); }
 /* the pipeline's front kernel: oa_encode_kernel on single-frame calls of 10 / 20 ms with continuation records -- every frame that reaches the PVQ is cut there, so the PVQ
  * (and the multi-frame loop) are not in its code */
@@ -96,6 +98,24 @@ extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU) oa_encode_
 #define OA_FRONT_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_FRONT_WAVES_PER_EU) oa_celt_front_kernel(OA_ENC_KERNEL_PARAMS) { oa_encode_kernel_body<true>(OA_ENC_KERNEL_ARGS); }
+/* The four streams of a PVQ wave go through their bands side by side: the more alike their band trees, the fewer instructions the wave spends on branches only some of them
+ * take.  The frames that were cut are therefore handed to the PVQ kernel sorted by what shapes the tree -- block switching, dual stereo, the frame's byte budget -- with a
+ * counting sort: the kernel that cuts a frame counts its key (srt[key]), oa_celt_sort_kernel places every list entry behind the keys below it (srt[128 + key] fills). */
+extern "C" __global__ void __launch_bounds__(64)
+oa_celt_sort_kernel(const CeltCont *conts, const int *cut_list, int *order, const unsigned *queue, unsigned *srt)
+{
+   const int n = (int)queue[1], lane = (int)threadIdx.x;
+   /* exclusive prefix of the 128 key counts, two per lane */
+   const i32 c0 = (i32)srt[2 * lane], c1 = (i32)srt[2 * lane + 1];
+   const i32 incl = wv_scan_incl(c0 + c1), base0 = incl - c0 - c1, base1 = base0 + c0;
+   for (int k0 = (int)blockIdx.x * 64; k0 < n; k0 += (int)gridDim.x * 64) {
+      const int k = k0 + lane;
+      int s = 0, key = 0;
+      if (k < n) { s = cut_list[k]; key = conts[s].sort_key; }
+      const i32 b0 = wv_shfl(base0, key >> 1), b1 = wv_shfl(base1, key >> 1);          /* (from the lane that owns the key pair) */
+      if (k < n) order[(key & 1 ? b1 : b0) + (int)atomicAdd(srt + OA_SORT_KEYS + key, 1u)] = s;
+   }
+}
 /* the PVQ of the frames the encode kernel cut: four streams per wave, one 16-lane group each (celt_enc_pvq4.h) */
 #ifndef OA_PVQ4_WAVES_PER_EU
 #define OA_PVQ4_WAVES_PER_EU 3
@@ -381,7 +401,7 @@ oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, 
       int chunk /* streams per pop of the queue: 1, or several where the frames are all light (a batch pinned to SILK-only: 65,536 pops of one counter take longer than their frames) */,
       const i32 *tr /* NULL, or [stream][12]: the transient pre-pass's records (oa_sh_transient_kernel) */,
       CeltCont *cconts /* NULL, or [stream]: the CELT layer's PVQ as a stage of its own -- a frame with one CELT pass stops before its PVQ, its stream goes on cut_list (cutq[1] counts) */,
-      ShBackHdr *hdrs, int *cut_list, unsigned *cutq)
+      ShBackHdr *hdrs, int *cut_list, unsigned *cutq, unsigned *srt)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -397,7 +417,7 @@ oa_sh_back_kernel(OaShStream *streams, int frame_size, u8 *out, int out_stride, 
          const int cut = oa_sh_back_frame(L, gs, frame_size, out + (size_t)s * out_stride, out_stride, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)),
                (i16 *)(scr + SH_PCM_BYTES(frame_size, ch)), (i16 *)(scr + 2 * SH_PCM_BYTES(frame_size, ch)), (CeltScratch *)(scr + 2 * SH_PCM_BYTES(frame_size, ch) + 512), conts + s, lens + s, rngs + s, tr ? tr + 12 * (size_t)s : nullptr,
                cconts ? cconts + s : (CeltCont *)0, cconts ? hdrs + s : (ShBackHdr *)0);
-         if (cut) { if (threadIdx.x == 0) cut_list[atomicAdd(cutq + 1, 1u)] = s; }
+         if (cut) { if (threadIdx.x == 0) { const int key = oa_cut_key(SH_F(L)); cconts[s].sort_key = key; atomicAdd(srt + key, 1u); cut_list[atomicAdd(cutq + 1, 1u)] = s; } }
       }
       __syncthreads();
    }
@@ -504,6 +524,7 @@ struct OpusGpuEncBatch {
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
    int pvq4_last;                                                           /* the last call launched oa_celt_pvq_kernel */
    ShBackHdr *d_back_hdr;                                                   /* SILK-capable batches: the back kernel's LDS header of the calls cut before their CELT pass's PVQ */
+   unsigned *d_srt;                                                         /* [128] key counts, [128] fill counters of the PVQ kernel's sorted order */
    CeltCont *d_ccont; int *d_cut_list; int celt_pipe_last /* streams of the last pipelined call, 0 = the last call was not pipelined */;                                       /* CELT-only batches, kernel pipeline: per-stream continuation records, the list of the streams whose call was cut before the PVQ */
    i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
    struct { const void *kernel; size_t lds; int per_cu; } occ[8];
@@ -560,7 +581,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0;
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0; b->d_srt = nullptr;
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -593,6 +614,7 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_ccont) (void)hipFree(b->d_ccont);
    if (b->d_cut_list) (void)hipFree(b->d_cut_list);
    if (b->d_back_hdr) (void)hipFree(b->d_back_hdr);
+   if (b->d_srt) (void)hipFree(b->d_srt);
    if (b->d_cont) (void)hipFree(b->d_cont);
    if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_slow_list) (void)hipFree(b->d_slow_list);
@@ -863,18 +885,21 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (pvq4) {
       if (!b->d_ccont) {
          HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
-         HIPCHECK(hipMalloc((void **)&b->d_cut_list, sizeof(int) * (size_t)b->S));
+         HIPCHECK(hipMalloc((void **)&b->d_cut_list, 2 * sizeof(int) * (size_t)b->S));
          HIPCHECK(hipMalloc((void **)&b->d_back_hdr, sizeof(ShBackHdr) * (size_t)b->S));
+         HIPCHECK(hipMalloc((void **)&b->d_srt, 2 * OA_SORT_KEYS * sizeof(unsigned)));
       }
       HIPCHECK(hipMemsetAsync(cutq, 0, 4 * sizeof(unsigned), s));
+      HIPCHECK(hipMemsetAsync(b->d_srt, 0, 2 * OA_SORT_KEYS * sizeof(unsigned), s));
    }
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
          b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1, d_tr,
-         pvq4 ? b->d_ccont : (CeltCont *)nullptr, b->d_back_hdr, b->d_cut_list, cutq);
+         pvq4 ? b->d_ccont : (CeltCont *)nullptr, b->d_back_hdr, b->d_cut_list, cutq, b->d_srt);
    if (pvq4) {
       int g_pvq = 0;
       { const int r = oa_sh_grid(b, 6, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)n + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
-      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)b->d_cut_list, cutq);
+      { const int gs_ = (n + 63) / 64; hipLaunchKernelGGL(oa_celt_sort_kernel, dim3((unsigned)(gs_ < 1024 ? gs_ : 1024)), dim3(64), 0, s, (const CeltCont *)b->d_ccont, (const int *)b->d_cut_list, b->d_cut_list + b->S, (const unsigned *)cutq, b->d_srt); }
+      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)(b->d_cut_list + b->S), cutq);
       hipLaunchKernelGGL(oa_sh_back2_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s, b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, po_back,
             (const CeltCont *)b->d_ccont, (const ShBackHdr *)b->d_back_hdr, (const int *)b->d_cut_list, cutq);
    }
@@ -981,26 +1006,29 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
    const bool pipe = (pipe_mode < 0 ? b->n_act >= 64 : pipe_mode > 0) && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
    if (pipe && !b->d_ccont) {
       HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
-      HIPCHECK(hipMalloc((void **)&b->d_cut_list, sizeof(int) * (size_t)b->S));
+      HIPCHECK(hipMalloc((void **)&b->d_cut_list, 2 * sizeof(int) * (size_t)b->S));                 /* [S] the streams that were cut, in the order they were; [S] sorted for the PVQ kernel */
+      HIPCHECK(hipMalloc((void **)&b->d_srt, 2 * OA_SORT_KEYS * sizeof(unsigned)));
    }
    b->celt_pipe_last = pipe ? (int)b->n_act : 0; b->pvq4_last = pipe;
    int grid = 0;
    { const int r = oa_persistent_grid(b, pipe ? (const void *)oa_celt_front_kernel : (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, sizeof(CeltScratch), s, &grid); if (r != OPUS_OK) return r; }
    if (pipe) {
       HIPCHECK(hipMemsetAsync(b->d_queue, 0, 4 * sizeof(unsigned), s));
+      HIPCHECK(hipMemsetAsync(b->d_srt, 0, 2 * OA_SORT_KEYS * sizeof(unsigned), s));
       hipLaunchKernelGGL(oa_celt_front_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
             b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
-            b->d_ccont, b->d_cut_list);
+            b->d_ccont, b->d_cut_list, b->d_srt);
    } else hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
          b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
-         (CeltCont *)nullptr, (int *)nullptr);
+         (CeltCont *)nullptr, (int *)nullptr, (unsigned *)nullptr);
    HIPCHECK(hipGetLastError());
    if (pipe) {
       int g_pvq = 0, g_back = 0;
       { const int r = oa_sh_grid(b, 6, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)b->n_act + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
       { const int r = oa_sh_grid(b, 7, (const void *)oa_celt_back_kernel, offsetof(FrameLds, BC), b->n_act, &g_back); if (r != OPUS_OK) return r; }
       if (g_back > grid) g_back = grid;                                   /* (the per-wave scratch was sized for the encode kernel's grid) */
-      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)b->d_cut_list, b->d_queue);
+      { const int gs_ = (int)((b->n_act + 63) / 64); hipLaunchKernelGGL(oa_celt_sort_kernel, dim3((unsigned)(gs_ < 1024 ? gs_ : 1024)), dim3(64), 0, s, (const CeltCont *)b->d_ccont, (const int *)b->d_cut_list, b->d_cut_list + b->S, (const unsigned *)b->d_queue, b->d_srt); }
+      hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)(b->d_cut_list + b->S), b->d_queue);
       hipLaunchKernelGGL(oa_celt_back_kernel, dim3((unsigned)g_back), dim3(64), offsetof(FrameLds, BC), s, b->d_streams, b->d_ccont, (const int *)b->d_cut_list, b->d_queue, frame_size, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range,
             (CeltScratch *)b->d_scratch);
       HIPCHECK(hipGetLastError());
