@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 NO_ANALYSIS = False      # --no-analysis
 CORPUS = "reference"     # 48 kHz configurations: the reference's generate_music() tunes (SURVEY.md 8d names them first); --corpus pool: this repo's music / noise-burst pool
 CPU_STREAMS = 64         # streams of the GPU batch the CPU legs (baseline, parity sample) run
-GATHER = "rccl"          # --gather
+GATHER = "auto"          # --gather
 CONFIGS = {
     2: dict(name="CELT-only encode, restricted-lowdelay, 48 kHz stereo, 20 ms, CVBR 128 kb/s, complexity 10", app=2051, Fs=48000, ch=2, kernel="oa_encode_kernel",
             ctls=((4002, 128000), (4010, 10)), metric="encoded frames/s (48 kHz stereo, 20 ms, complexity 10)"),
@@ -347,31 +347,37 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         b = opus_amd.EncoderBatch(S, channels=CH, application=cfg["app"], Fs=Fs, device=local)
         for req, v in cfg["ctls"]: b.ctl(req, v)
         b.ctl(opus_amd.OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, 0 if NO_ANALYSIS else 1)        # default: like the reference's default build (analysis.c + mlp.c at complexity 10)
+        try: b.ctl(opus_amd.OPUS_AMD_SET_KERNEL_TIMING_REQUEST, 1)                         # HIP events between the launches of every call (a few event records per step): the last step's per-kernel times go into the line
+        except Exception: pass
     # every step's packets stay on the device (the decoder leg and the parity sample read them): [TE][NP][STRIDE]
     pk = torch.zeros((TE, NP, STRIDE), dtype=torch.uint8, device=dev); lens = torch.zeros((TE, NP), dtype=torch.int32, device=dev); rng = torch.zeros((TE, NP), dtype=torch.int32, device=dev)
     # wire record of the final gather: its capacity per stream follows from the encoder settings (PacketGather.wire_capacity: the bitrate bound of these VBR streams; an overflow is reported)
-    gather = None; gather_err = None
-    if world > 1 and gather_cls and gather_on:
-        try: gather = gather_cls(NP * world, STRIDE, dev, dst=0, bitrate_bps={2: 128000, 3: 24000, 4: 128000, 5: 255 * 64000}[cid], frame_rate=50, cbr=False, sub_streams=255 if cid == 5 else 1, transport=GATHER)
-        except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e)
+    gather = None; gather_err = None; gather_fallback = None
 
     def step(t):
         b.encode_dev(pcm[t].data_ptr(), FR, pk[t].data_ptr(), STRIDE, lens[t].data_ptr(), rng[t].data_ptr(), hip_stream=stream.cuda_stream)
 
-    for t in range(W):
-        step(t)
-        if gather is not None:
-            try: gather.launch(lens[t], rng[t], pk[t])
-            except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e); gather = None
-    if gather is not None:
-        try: gather.flush(); torch.cuda.synchronize(dev)
-        except Exception as e: gather_err = "%s: %s" % (type(e).__name__, e); gather = None
+    for t in range(W): step(t)
     torch.cuda.synchronize(dev)
     if world > 1 and gather_cls and gather_on:
-        # an exchange that failed during the warm-up on ANY rank is left out on every rank (and reported in the line: "gather": {"error": ...}) rather than taking the run down
-        okf = torch.tensor([0 if gather_err else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        if int(okf.item()) == 0: gather = None; gather_err = gather_err or "the exchange failed on another rank"
+        # The exchange is warmed up on the warm-up steps' packets, one transport after the other ("auto": the RCCL gather first, then the point-to-point copies): a transport
+        # that fails on ANY rank (all-reduced verdict: every rank takes the same decision) is replaced by the next one, so that the exchange north_star asks for is inside the
+        # timed region whenever one of them works; the line says which one ran and why an earlier one did not.  Only when every transport fails is the exchange left out
+        # (reported: "gather": {"error": ...}) rather than taking the run down.
+        for tr in (["rccl", "p2p"] if GATHER == "auto" else [GATHER]):
+            g = None; err = None
+            try:
+                if tr == "rccl" and os.environ.get("OPUS_AMD_BENCH_FAIL_RCCL") == "1": raise RuntimeError("forced failure of the RCCL gather (test hook OPUS_AMD_BENCH_FAIL_RCCL)")
+                g = gather_cls(NP * world, STRIDE, dev, dst=0, bitrate_bps={2: 128000, 3: 24000, 4: 128000, 5: 255 * 64000}[cid], frame_rate=50, cbr=False, sub_streams=255 if cid == 5 else 1, transport=tr)
+                for t in range(W): g.launch(lens[t], rng[t], pk[t])
+                g.flush(); torch.cuda.synchronize(dev)
+            except Exception as e: err = "%s: %s" % (type(e).__name__, e)
+            okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 1: gather = g; gather_err = None; break
+            err = err or "the exchange failed on another rank"
+            gather_fallback = ((gather_fallback + "; ") if gather_fallback else "") + "%s: %s" % (tr, err)
+            gather_err = gather_fallback
     if world > 1: dist.barrier()
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -387,6 +393,10 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    kernels_ms = {}
+    if hasattr(b, "kernel_times"):
+        try: kernels_ms = {k_: round(v_, 3) for k_, v_ in b.kernel_times().items()}           # the LAST timed step's launches, HIP events on the launch stream inside the library
+        except Exception: kernels_ms = {}
     lens_h = lens[W:].cpu().numpy()
     ok = bool((lens_h > 0).all())
     mean_len = float(lens_h.mean()) / (255 if cid == 5 else 1)                               # config 5: per elementary stream (incl. its self-delimiting length byte)
@@ -399,7 +409,8 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     alg = FR * CH * 2 + mean_len + 8 + state_moved
     res = {"config_id": cid, "leg": "encode", "workload": cfg["name"], "metric": cfg["metric"], "kernel": cfg["kernel"] + (" (+ oa_ms_split_kernel, oa_ms_pack_kernel)" if cid == 5 else ""), "streams_per_gpu": S, "dt": dt, "kernel_ms": kern_ms,
            "mean_packet_bytes": round(mean_len, 1), "all_packets_valid": ok, "algorithmic_bytes_per_frame": round(alg, 1), "state_bytes_moved_per_frame": state_moved, "float_analysis": bool(analysis_on),
-           "gather": ({"error": gather_err, "in_timed_region": False} if gather_err else None) if gather is None else gather.stats()}
+           "kernels_ms": kernels_ms,
+           "gather": ({"error": gather_err, "in_timed_region": False} if gather_err else None) if gather is None else dict(gather.stats(), in_timed_region=True, **({"fallback_from": gather_fallback} if gather_fallback else {}))}
     results = [res]
     # the CPU legs' sample: the first NC streams, every frame the batch saw of them
     pcm_h = None
@@ -550,7 +561,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="N = 1 default run: skip the config 3 / 4 / 5 and decoder legs")
     ap.add_argument("--steady-state", type=int, default=-1, help="also run the steady-state leg of the main configuration: 1,024 streams through this many consecutive frames, then a full-width batch of the warmed-up states (default 500 in the default run, 0 = off)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the final packet gather out (to time what it costs)")
-    ap.add_argument("--gather", default="rccl", choices=["rccl", "p2p"], help="N > 1: transport of the final packet gather: one RCCL gather collective per step (default), or every rank copying its record into rank 0's buffer through an IPC mapping (no collective; independent of ProcessGroupNCCL)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "p2p"], help="N > 1: auto (default) = the RCCL gather, and when its warm-up fails on any rank the point-to-point copies instead, so that the exchange is in the timed region either way; rccl = one RCCL gather collective per step; p2p = every rank copying its record into rank 0's buffer through an IPC mapping (no collective; independent of ProcessGroupNCCL)")
     a = ap.parse_args()
     global CORPUS, NO_ANALYSIS, GATHER
     CORPUS = a.corpus; NO_ANALYSIS = a.no_analysis; GATHER = a.gather
@@ -605,7 +616,7 @@ def main():
         try: src_now = opus_amd.source_hash()
         except Exception: src_now = None
         traffic_docs = []
-        for name in (["pmc_traffic_r02.json"] if NO_ANALYSIS else ["pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json"]):
+        for name in (["pmc_traffic_r02.json"] if NO_ANALYSIS else ["pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json"]):
             try: traffic_docs.append((name, json.load(open(os.path.join(ROOT, "profiles", name)))))
             except Exception: continue
         used_traffic = set()
@@ -624,6 +635,11 @@ def main():
             o = {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "kernel_ms": round(r["kernel_ms"], 3),
                  "algorithmic_bytes_per_frame": r["algorithmic_bytes_per_frame"]}
             if issue: o["issue"] = issue
+            km = r.get("kernels_ms") or {}
+            if km:
+                dk = max(km, key=km.get)
+                o["kernels_ms"] = km
+                o["dominant"] = {"kernel": dk, "ms": km[dk], "achieved": round(Sn * r["algorithmic_bytes_per_frame"] / (km[dk] * 1e-3) / 1e9, 2), "frac": round(Sn * r["algorithmic_bytes_per_frame"] / (km[dk] * 1e-3) / 1e9 / 8000.0, 5)}
             return o
         def cpu_leg(r, seconds, allc):
             if r["leg"] == "decode" and "dec_sample" in r: return cpu_baseline(CONFIGS[r["config_id"]], r["dec_sample"], seconds=seconds, all_cores_seconds=allc, kind="dec")
@@ -640,8 +656,8 @@ def main():
                        "streams_per_gpu": main_res["streams_per_gpu"], "frames_per_step": main_res["streams_per_gpu"] * world, "mean_packet_bytes": main_res["mean_packet_bytes"], "all_packets_valid": main_res["all_packets_valid"],
                        "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),
                        "lib_build": built, "lib_matches_sources": None if src_now is None else built == "OA_SRC_HASH=" + src_now,
-                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else (", final gather of the compacted packets in the timed region (%s; side stream, double-buffered)" % a.gather) if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
-            "roofline": dict(roof(main_res, main_res["streams_per_gpu"]), kernel=main_res["kernel"], peak_measured=peak_meas),
+                       "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else (", final gather of the compacted packets in the timed region (%s; side stream, double-buffered)" % ((main_res.get("gather") or {}).get("transport") or a.gather)) if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
+            "roofline": (lambda ro_: dict(ro_, kernel=(ro_["dominant"]["kernel"] + " (the dominant kernel of the call: roofline.dominant; achieved / frac above are the WHOLE call's: " + " + ".join(ro_["kernels_ms"]) + ")") if ro_.get("dominant") else main_res["kernel"], peak_measured=peak_meas))(roof(main_res, main_res["streams_per_gpu"])),
         }
         if per_rank is not None: res["ranks_seen"] = len(per_rank); res["per_rank"] = per_rank
         if main_res.get("gather"): res["gather"] = main_res["gather"]

@@ -162,6 +162,9 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const
  * the signal.  On a batch (opusgpu_enc_batch_ctl, any
  * `stream`) it applies to the whole batch; on a classic encoder it applies to that encoder's calls (calls with different values are not combined into one launch); a
  * multistream encoder passes it to its elementary encoders.  The process-wide default behind -1 can be set with the environment variable OPUS_AMD_SH_SPLIT=0..4. */
+/* OPUS_AMD_SET_KERNEL_TIMING(1) on a batch: HIP events on the launch stream around every kernel of the following calls; opusgpu_enc_batch_kernel_times returns the last call's
+ * kernel names (comma separated, in launch order) and durations in ms (bench.py's per-kernel figures; no effect on the packets). */
+#define OPUS_AMD_SET_KERNEL_TIMING_REQUEST 11904
 #define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
 #define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
 /* n stream records -- configuration and state as they stand on the device -- from batch `src` (from stream src_first on) into batch `dst` (from dst_first on), device to
@@ -207,6 +210,8 @@ OPUS_AMD_EXPORT int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint3
 /* *streams = how many streams of the batch's LAST call had the PVQ of their CELT frame coded by the four-streams-per-wave stage (oa_celt_pvq_kernel: celt_enc_pvq4.h) --
  * 10 / 20 ms calls of a launch that runs as a kernel pipeline (OPUS_AMD_SET_KERNEL_PIPELINE); 0 when the call ran as one kernel.  Waits for the batch's stream.  Test / bench aid. */
 OPUS_AMD_EXPORT int opusgpu_enc_batch_pvq_stage_stats(OpusGpuEncBatch *b, opus_uint32 *streams);
+/* returns the number of kernels of the batch's last call (<= max_kernels), 0 without OPUS_AMD_SET_KERNEL_TIMING(1); waits for that call */
+OPUS_AMD_EXPORT int opusgpu_enc_batch_kernel_times(OpusGpuEncBatch *b, char *names, int names_cap, float *ms, int max_kernels);
 /* introspection for the roofline report */
 OPUS_AMD_EXPORT int opusgpu_kernel_lds_bytes(void);
 

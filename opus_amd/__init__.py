@@ -26,6 +26,7 @@ OPUS_SET_VBR_CONSTRAINT_REQUEST, OPUS_SET_FORCE_CHANNELS_REQUEST, OPUS_RESET_STA
 OPUS_GET_FINAL_RANGE_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST = 4031, 4036, 4046
 OPUS_SET_FORCE_MODE_REQUEST, OPUS_SET_SIGNAL_REQUEST, OPUS_SET_PACKET_LOSS_PERC_REQUEST, OPUS_SET_INBAND_FEC_REQUEST, OPUS_SET_DTX_REQUEST = 11002, 4024, 4014, 4012, 4016
 OPUS_MODE_SILK_ONLY, OPUS_MODE_HYBRID, OPUS_MODE_CELT_ONLY = 1000, 1001, 1002
+OPUS_AMD_SET_KERNEL_TIMING_REQUEST = 11904       # HIP events around every kernel of a batch's calls (EncoderBatch.kernel_times)
 OPUS_AMD_SET_FLOAT_ANALYSIS_REQUEST, OPUS_AMD_GET_FLOAT_ANALYSIS_REQUEST = 11900, 11901     # private: 0 = encode like a reference built with DISABLE_FLOAT_API
 OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST, OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST = 11902, 11903       # private: -1 the library chooses, 0 one kernel, 1 / 2 the front / quantiser / back kernel pipeline (include/opus_amd.h)
 OPUS_BANDWIDTH_NARROWBAND, OPUS_BANDWIDTH_MEDIUMBAND, OPUS_BANDWIDTH_WIDEBAND, OPUS_BANDWIDTH_SUPERWIDEBAND, OPUS_BANDWIDTH_FULLBAND = 1101, 1102, 1103, 1104, 1105
@@ -203,6 +204,17 @@ class EncoderBatch:
         r = self._L.opusgpu_time_encode_dev(self._b, d_pcm_ptr, frame_size, d_out_ptr, out_stride, max_data_bytes, d_lens_ptr, d_rng_ptr, steps, ctypes.byref(ms))
         if r != OPUS_OK: raise OpusError(r)
         return ms.value
+    def kernel_times(self):
+        """{kernel name: ms} of the batch's last call, in launch order (after ctl(OPUS_AMD_SET_KERNEL_TIMING_REQUEST, 1)); {} when the library predates the entry"""
+        L = lib()
+        if not hasattr(L, "opusgpu_enc_batch_kernel_times"): return {}
+        L.opusgpu_enc_batch_kernel_times.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+        names = ctypes.create_string_buffer(1024); ms = (ctypes.c_float * 20)()
+        n = L.opusgpu_enc_batch_kernel_times(self._b, names, 1024, ms, 20)
+        if n <= 0: return {}
+        out = {}
+        for k, v in zip(names.value.decode().split(","), list(ms)[:n]): out[k] = out.get(k, 0.0) + float(v)
+        return out
     def export_state(self, stream):
         buf = ctypes.create_string_buffer(self.state_size)
         r = self._L.opusgpu_enc_batch_export_state(self._b, stream, buf)

@@ -522,12 +522,13 @@ struct OpusGpuEncBatch {
    const void *occ_kernel; size_t occ_lds; int occ_per_cu;   /* last occupancy query (it is a host-side call per launch otherwise) */
    /* the split path of the SILK-capable encoder (opus_sh_split.h): per-stream continuation records, per-stream high-passed input, the calls handed to the one-kernel path */
    ShCont *d_cont; char *d_pcm_hp; size_t pcm_hp_cap; int *d_slow_list;
+   int timing; int n_stamps; hipEvent_t stamp_ev[20]; const char *stamp_name[20];   /* OPUS_AMD_SET_KERNEL_TIMING: HIP events between the launches of the last call (opusgpu_enc_batch_kernel_times) */
    int pvq4_last;                                                           /* the last call launched oa_celt_pvq_kernel */
    ShBackHdr *d_back_hdr;                                                   /* SILK-capable batches: the back kernel's LDS header of the calls cut before their CELT pass's PVQ */
    unsigned *d_srt;                                                         /* [128] key counts, [128] fill counters of the PVQ kernel's sorted order */
    CeltCont *d_ccont; int *d_cut_list; int celt_pipe_last /* streams of the last pipelined call, 0 = the last call was not pipelined */;                                       /* CELT-only batches, kernel pipeline: per-stream continuation records, the list of the streams whose call was cut before the PVQ */
    i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
-   struct { const void *kernel; size_t lds; int per_cu; } occ[8];
+   struct { const void *kernel; size_t lds; int per_cu; } occ[12];
    int device;
    opus_int32 S;
    opus_int32 n_act;                     /* streams a call processes: the first n_act records (== S except under the classic API's call combiner) */
@@ -581,7 +582,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuEncBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
-      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0; b->d_srt = nullptr;
+      b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0; b->d_srt = nullptr; b->timing = 0; b->n_stamps = 0; memset(b->stamp_ev, 0, sizeof b->stamp_ev);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
       if (kind) b->h_sh.assign(nstreams, *shproto); else b->h_streams.assign(nstreams, proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
@@ -615,6 +616,7 @@ void opusgpu_enc_batch_destroy(OpusGpuEncBatch *b)
    if (b->d_cut_list) (void)hipFree(b->d_cut_list);
    if (b->d_back_hdr) (void)hipFree(b->d_back_hdr);
    if (b->d_srt) (void)hipFree(b->d_srt);
+   for (int i = 0; i < 20; i++) if (b->stamp_ev[i]) (void)hipEventDestroy(b->stamp_ev[i]);
    if (b->d_cont) (void)hipFree(b->d_cont);
    if (b->d_pcm_hp) (void)hipFree(b->d_pcm_hp);
    if (b->d_slow_list) (void)hipFree(b->d_slow_list);
@@ -635,6 +637,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   if (request == OPUS_AMD_SET_KERNEL_TIMING_REQUEST) { b->timing = value != 0; b->n_stamps = 0; return OPUS_OK; }      /* the launch's, not a stream's */
    if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 4) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
    b->any_cbr = -1;
    if (request == OPUS_RESET_STATE) {
@@ -703,6 +706,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
    if (b->kind) {
       const OaShStream *src = (const OaShStream *)blob;
       if (src->cfg.channels != b->channels || src->cfg.Fs != b->Fs) return OPUS_BAD_ARG;
+      if ((src->cfg.application == OPUS_APPLICATION_RESTRICTED_SILK) != (b->application == OPUS_APPLICATION_RESTRICTED_SILK)) return OPUS_BAD_ARG;      /* (as in opusgpu_enc_batch_copy_states) */
       HIPCHECK(hipSetDevice(b->device));
       HIPCHECK(hipStreamSynchronize(b->stream));
       b->h_sh[stream] = *src; b->cfg_dirty = true; b->any_cbr = -1;
@@ -723,6 +727,8 @@ int opusgpu_enc_batch_copy_states(OpusGpuEncBatch *dst, opus_int32 dst_first, Op
 {
    if (!dst || !src || n < 0 || dst_first < 0 || src_first < 0 || dst_first + n > dst->S || src_first + n > src->S) return OPUS_BAD_ARG;
    if (dst->kind != src->kind || dst->channels != src->channels || dst->Fs != src->Fs || dst->device != src->device) return OPUS_BAD_ARG;
+   /* a RESTRICTED_SILK batch launches its back kernel without the CELT arena (oa_sh_encode_split: lds_back): records of the other SILK-capable applications do not go there, nor its own elsewhere */
+   if (dst->kind && (dst->application == OPUS_APPLICATION_RESTRICTED_SILK) != (src->application == OPUS_APPLICATION_RESTRICTED_SILK)) return OPUS_BAD_ARG;
    if (dst == src && dst_first < src_first + n && src_first < dst_first + n && n > 0) return OPUS_BAD_ARG;                     /* overlapping ranges of one batch */
    HIPCHECK(hipSetDevice(dst->device));
    HIPCHECK(hipStreamSynchronize(src->stream)); HIPCHECK(hipStreamSynchronize(dst->stream));
@@ -755,6 +761,25 @@ int opusgpu_enc_batch_split_stats(OpusGpuEncBatch *b, opus_uint32 *kept, opus_ui
    *kept = v[0]; *declined = v[1];
    return OPUS_OK;
 }
+int opusgpu_enc_batch_kernel_times(OpusGpuEncBatch *b, char *names, int names_cap, float *ms, int max_kernels)
+{
+   if (!b || !names || !ms || names_cap < 1 || max_kernels < 0) return OPUS_BAD_ARG;
+   names[0] = 0;
+   if (b->n_stamps < 2) return 0;
+   HIPCHECK(hipSetDevice(b->device));
+   HIPCHECK(hipEventSynchronize(b->stamp_ev[b->n_stamps - 1]));
+   int n = 0; size_t used = 0;
+   for (int i = 1; i < b->n_stamps && n < max_kernels; i++) {
+      float t = 0;
+      HIPCHECK(hipEventElapsedTime(&t, b->stamp_ev[i - 1], b->stamp_ev[i]));
+      const size_t l = strlen(b->stamp_name[i]);
+      if (used + l + 2 > (size_t)names_cap) break;
+      if (n) names[used++] = ',';
+      memcpy(names + used, b->stamp_name[i], l); used += l; names[used] = 0;
+      ms[n++] = t;
+   }
+   return n;
+}
 int opusgpu_enc_batch_pvq_stage_stats(OpusGpuEncBatch *b, opus_uint32 *streams)
 {
    if (!b || !streams) return OPUS_BAD_ARG;
@@ -770,6 +795,16 @@ int opusgpu_enc_batch_pvq_stage_stats(OpusGpuEncBatch *b, opus_uint32 *streams)
 int opusgpu_enc_batch_reset(OpusGpuEncBatch *b) { return opusgpu_enc_batch_ctl(b, -1, OPUS_RESET_STATE, 0); }
 int opusgpu_enc_batch_sync(OpusGpuEncBatch *b) { if (!b) return OPUS_BAD_ARG; HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream)); return OPUS_OK; }
 
+/* OPUS_AMD_SET_KERNEL_TIMING(1): an event on the launch stream before the call's first launch and after each of its launches; opusgpu_enc_batch_kernel_times reads the last call's */
+static void oa_stamp(OpusGpuEncBatch *b, hipStream_t s, const char *name)
+{
+   if (!b->timing || b->n_stamps >= 20) return;
+   const int i = b->n_stamps++;
+   if (!b->stamp_ev[i] && hipEventCreate(&b->stamp_ev[i]) != hipSuccess) { b->stamp_ev[i] = nullptr; b->n_stamps = i; return; }
+   b->stamp_name[i] = name;
+   (void)hipEventRecord(b->stamp_ev[i], s);
+}
+static void oa_stamp_begin(OpusGpuEncBatch *b, hipStream_t s) { b->n_stamps = 0; oa_stamp(b, s, "begin"); }
 /* grid of a persistent encoder launch = the waves the chip holds at this kernel's register / LDS footprint (never more than there are streams); makes sure the
  * per-wave scratch covers it and resets the stream queue on the launch's HIP stream */
 static int oa_persistent_grid(OpusGpuEncBatch *b, const void *kernel, size_t lds_bytes, size_t scratch_per_wave, hipStream_t s, int *grid_out)
@@ -854,17 +889,21 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if ((size_t)g_slow * SH_SCRATCH_BYTES(frame_size, ch) > need) need = (size_t)g_slow * SH_SCRATCH_BYTES(frame_size, ch);
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
+   oa_stamp_begin(b, s);
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split);
+   oa_stamp(b, s, "oa_sh_front_kernel");
    if (mode == 4) {
       const int *pl = (const int *)(b->d_slow_list + n); const unsigned *pc = (const unsigned *)(b->d_queue + 6);
       hipLaunchKernelGGL(oa_sh_preda_kernel, dim3((unsigned)g_pa), dim3(64), lds_pa, s, b->d_cont, pl, pc);
       hipLaunchKernelGGL(oa_sh_predc_kernel, dim3((unsigned)g_pc), dim3(64), sizeof(PredLds), s, b->d_cont, pl, pc);
       hipLaunchKernelGGL(oa_sh_predb_kernel, dim3((unsigned)g_pb), dim3(64), lds_pb, s, b->d_sh, b->d_cont, pl, pc);
+      oa_stamp(b, s, "oa_sh_preda_kernel+oa_sh_predc_kernel+oa_sh_predb_kernel");
    }
    if (pred_split) hipLaunchKernelGGL(oa_sh_pred_kernel, dim3((unsigned)g_pred), dim3(64), sizeof(PredLds), s, b->d_sh, b->d_cont, (const int *)(b->d_slow_list + n), (const unsigned *)(b->d_queue + 6), b->d_queue + 5, mode == 4 ? 1 : 0);
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
+   oa_stamp(b, s, pred_split ? "oa_sh_pred_kernel+oa_sh_quant_kernel" : "oa_sh_quant_kernel");
    /* the CELT layer's transient recursions on lanes first (48 kHz, AUDIO / VOIP: frames with a CELT layer); OPUS_AMD_TR_PRE=0 keeps them in the back kernel */
    static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
    const i32 *d_tr = nullptr;
@@ -875,6 +914,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
       if (!b->d_tr) { HIPCHECK(hipMalloc((void **)&b->d_tr, (size_t)b->S * 12 * sizeof(i32))); HIPCHECK(hipMemsetAsync(b->d_tr, 0, (size_t)b->S * 12 * sizeof(i32), s)); }
       if (need_tr > b->tr_scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_tr_scratch) (void)hipFree(b->d_tr_scratch); b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_tr_scratch, need_tr)); b->tr_scratch_cap = need_tr; }
       hipLaunchKernelGGL(oa_sh_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaShStream *)b->d_sh, (const ShCont *)b->d_cont, (const char *)b->d_pcm_hp, frame_size, ch, items, b->d_tr_scratch, b->d_tr);
+      oa_stamp(b, s, "oa_sh_transient_kernel");
       d_tr = b->d_tr;
    }
    /* the CELT layer's PVQ as a stage of its own (celt_enc_pvq4.h: four streams per wave) wherever the launch can carry CELT frames; OPUS_AMD_SH_PVQ4=0: inside the back kernel */
@@ -895,17 +935,22 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    hipLaunchKernelGGL(oa_sh_back_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s,
          b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_pcm_hp, b->d_scratch, (const ShCont *)b->d_cont, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue, po_back, silk_only ? 8 : 1, d_tr,
          pvq4 ? b->d_ccont : (CeltCont *)nullptr, b->d_back_hdr, b->d_cut_list, cutq, b->d_srt);
+   oa_stamp(b, s, "oa_sh_back_kernel");
    if (pvq4) {
       int g_pvq = 0;
-      { const int r = oa_sh_grid(b, 6, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)n + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
+      { const int r = oa_sh_grid(b, 8, (const void *)oa_celt_pvq_kernel, sizeof(P4Lds), ((long long)n + 3) / 4, &g_pvq); if (r != OPUS_OK) return r; }
       { const int gs_ = (n + 63) / 64; hipLaunchKernelGGL(oa_celt_sort_kernel, dim3((unsigned)(gs_ < 1024 ? gs_ : 1024)), dim3(64), 0, s, (const CeltCont *)b->d_ccont, (const int *)b->d_cut_list, b->d_cut_list + b->S, (const unsigned *)cutq, b->d_srt); }
+      oa_stamp(b, s, "oa_celt_sort_kernel");
       hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)(b->d_cut_list + b->S), cutq);
+      oa_stamp(b, s, "oa_celt_pvq_kernel");
       hipLaunchKernelGGL(oa_sh_back2_kernel, dim3((unsigned)g_back), dim3(64), lds_back, s, b->d_sh, frame_size, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, po_back,
             (const CeltCont *)b->d_ccont, (const ShBackHdr *)b->d_back_hdr, (const int *)b->d_cut_list, cutq);
+      oa_stamp(b, s, "oa_sh_back2_kernel");
    }
    hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)g_slow), dim3(64), lds_full, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, b->d_scratch, (i32 *)d_lens, (u32 *)d_final_range, n, b->d_queue + 3,
          (const int *)b->d_slow_list, (const unsigned *)(b->d_queue + 4), po_full, pcm_row, 0, 1, (const i32 *)nullptr);
+   oa_stamp(b, s, "oa_sh_encode_kernel(declined calls)");
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }
@@ -990,6 +1035,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
    /* a wide launch of 48 kHz frames up to 20 ms: the transient analysis' recursions first, one lane per (stream, channel) (oa_celt_transient_kernel); OPUS_AMD_TR_PRE=0 keeps them in the encode kernel */
    static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
    const i32 *d_tr = nullptr;
+   oa_stamp_begin(b, s);
    if (tr_env && b->Fs == 48000 && frame_size <= OA_MAX_FRAME && (b->n_act >= 64 || tr_env == 2 /* tests: whatever the width */)) {
       const int items = (int)b->n_act * b->channels, tiles = (items + 63) / 64;
       const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
@@ -997,6 +1043,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       if (!b->d_tr) { HIPCHECK(hipMalloc((void **)&b->d_tr, (size_t)b->S * 4 * sizeof(i32))); HIPCHECK(hipMemsetAsync(b->d_tr, 0, (size_t)b->S * 4 * sizeof(i32), s)); }
       if (need > b->tr_scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_tr_scratch) (void)hipFree(b->d_tr_scratch); b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_tr_scratch, need)); b->tr_scratch_cap = need; }
       hipLaunchKernelGGL(oa_celt_transient_kernel, dim3((unsigned)g), dim3(64), 0, s, (const OaStream *)b->d_streams, (const i16 *)d_pcm, pcm_row, frame_size, b->channels, first, stride, items, b->d_tr_scratch, b->d_tr);
+      oa_stamp(b, s, "oa_celt_transient_kernel");
       d_tr = b->d_tr;
    }
    /* the kernel pipeline of the CELT-only applications (OPUS_AMD_SET_KERNEL_PIPELINE: -1 = wide launches, 0 = never, >= 1 = always; process default OPUS_AMD_CELT_PIPE): 10 / 20 ms
@@ -1021,6 +1068,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
    } else hipLaunchKernelGGL(oa_encode_kernel, dim3((unsigned)grid), dim3(64), sizeof(FrameLds) + lds_pad, s,
          b->d_streams, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range, (int)b->n_act, (CeltScratch *)b->d_scratch, b->d_queue, pcm_row, first, stride, (const i32 *)d_budget, d_tr,
          (CeltCont *)nullptr, (int *)nullptr, (unsigned *)nullptr);
+   oa_stamp(b, s, pipe ? "oa_celt_front_kernel" : "oa_encode_kernel");
    HIPCHECK(hipGetLastError());
    if (pipe) {
       int g_pvq = 0, g_back = 0;
@@ -1028,9 +1076,12 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       { const int r = oa_sh_grid(b, 7, (const void *)oa_celt_back_kernel, offsetof(FrameLds, BC), b->n_act, &g_back); if (r != OPUS_OK) return r; }
       if (g_back > grid) g_back = grid;                                   /* (the per-wave scratch was sized for the encode kernel's grid) */
       { const int gs_ = (int)((b->n_act + 63) / 64); hipLaunchKernelGGL(oa_celt_sort_kernel, dim3((unsigned)(gs_ < 1024 ? gs_ : 1024)), dim3(64), 0, s, (const CeltCont *)b->d_ccont, (const int *)b->d_cut_list, b->d_cut_list + b->S, (const unsigned *)b->d_queue, b->d_srt); }
+      oa_stamp(b, s, "oa_celt_sort_kernel");
       hipLaunchKernelGGL(oa_celt_pvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_ccont, (const int *)(b->d_cut_list + b->S), b->d_queue);
+      oa_stamp(b, s, "oa_celt_pvq_kernel");
       hipLaunchKernelGGL(oa_celt_back_kernel, dim3((unsigned)g_back), dim3(64), offsetof(FrameLds, BC), s, b->d_streams, b->d_ccont, (const int *)b->d_cut_list, b->d_queue, frame_size, (u8 *)d_out, (int)out_stride, (i32 *)d_lens, (u32 *)d_final_range,
             (CeltScratch *)b->d_scratch);
+      oa_stamp(b, s, "oa_celt_back_kernel");
       HIPCHECK(hipGetLastError());
    }
    return OPUS_OK;

@@ -137,7 +137,10 @@ class PacketGather:
         """dst shares the IPC handles of its receive buffers; every rank maps the [depth] views of ITS slot in them.  Control traffic (the handles, the completion barrier of
         flush) goes over a gloo group of its own, so that nothing of this transport touches ProcessGroupNCCL."""
         from torch.multiprocessing.reductions import reduce_tensor
-        self._ctl = dist.new_group(backend="gloo") if dist.get_backend(self.group) != "gloo" else self.group
+        # (the control group spans the ranks of `group`, not the world: new_group is a collective over the ranks it names; and dst reads _recv only after flush()'s barrier --
+        # a peer overwrites its slot `depth` steps later without asking)
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+        self._ctl = dist.new_group(ranks=ranks, backend="gloo") if dist.get_backend(self.group) != "gloo" else self.group
         box = [[reduce_tensor(self._recv[d][r]) for r in range(self.world)] for d in range(self.depth)] if self.rank == self.dst else None
         got = [box]
         dist.broadcast_object_list(got, src=self.dst, group=self._ctl)

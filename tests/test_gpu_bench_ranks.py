@@ -53,6 +53,21 @@ def test_bench_ranks_one_gpu_p2p_gather(n, S):
     g = r["gather"]
     assert g["steps"] == K + 1 and not g["overflow"] and g["transport"].startswith("p2p") and g["cap_bytes_per_stream"] == 2 * 320 + 64
 
+def test_bench_ranks_gather_falls_back_to_p2p_when_the_collective_fails():
+    """--gather auto (the default): the RCCL gather's warm-up fails on every rank (test hook) -> all ranks switch to the point-to-point transport, the exchange stays inside
+    the timed region and the line says so; 8 ranks on the one GPU = the shape of the driver's scaling run"""
+    S, K = 4096, 3
+    env_was = os.environ.get("OPUS_AMD_BENCH_FAIL_RCCL")
+    os.environ["OPUS_AMD_BENCH_FAIL_RCCL"] = "1"
+    try: r = _run_ranks(8, ["--steps", str(K), "--warmup", "1", "--streams", str(S)], "gloo")
+    finally:
+        if env_was is None: os.environ.pop("OPUS_AMD_BENCH_FAIL_RCCL", None)
+        else: os.environ["OPUS_AMD_BENCH_FAIL_RCCL"] = env_was
+    _check_ranks(r, 8, S, K)
+    g = r["gather"]
+    assert g["in_timed_region"] and g["transport"].startswith("p2p") and "rccl" in g["fallback_from"] and g["steps"] == K + 1 and not g["overflow"]
+    assert "p2p" in r["config"]["parallelism"]
+
 def test_bench_two_ranks_rccl():
     """two ranks, two GPUs, RCCL: only where the box has them (the driver's scaling run is the real measurement)"""
     import torch

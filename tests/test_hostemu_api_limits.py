@@ -182,3 +182,23 @@ def test_ms_decode_sub_packet_longer_than_six_frames():
         out.append((r, pcm.tobytes()))
         L.opus_multistream_decoder_destroy(d)
     assert out[0][0] == 5760 and out[0] == out[1]
+
+def test_copy_and_import_of_stream_records_between_restricted_silk_and_other_applications_is_refused():
+    """a RESTRICTED_SILK batch launches its back kernel without the CELT arena: records of VOIP / AUDIO batches (same kind, rate, channels) must not get there by
+    opusgpu_enc_batch_copy_states or opusgpu_enc_batch_import_state, nor the other way round; like with like still works"""
+    L = capi.load(WHICH)
+    L.opusgpu_enc_batch_create.restype = vp; L.opusgpu_enc_batch_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ci, ci, ci, ctypes.POINTER(ci)]
+    L.opusgpu_enc_batch_copy_states.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32]
+    L.opusgpu_enc_batch_export_state.argtypes = [vp, ctypes.c_int32, vp]; L.opusgpu_enc_batch_import_state.argtypes = [vp, ctypes.c_int32, vp]
+    L.opusgpu_enc_batch_destroy.argtypes = [vp]; L.opusgpu_enc_batch_destroy.restype = None
+    err = ci()
+    voip = L.opusgpu_enc_batch_create(2, 16000, 1, 2048, 0, ctypes.byref(err)); rs = L.opusgpu_enc_batch_create(2, 16000, 1, 2052, 0, ctypes.byref(err)); rs2 = L.opusgpu_enc_batch_create(2, 16000, 1, 2052, 0, ctypes.byref(err))
+    assert voip and rs and rs2
+    assert L.opusgpu_enc_batch_copy_states(rs, 0, voip, 0, 2) == -1 and L.opusgpu_enc_batch_copy_states(voip, 0, rs, 0, 2) == -1
+    assert L.opusgpu_enc_batch_copy_states(rs2, 0, rs, 0, 2) == 0
+    blob = (ctypes.c_ubyte * L.opusgpu_enc_sh_state_size())()
+    assert L.opusgpu_enc_batch_export_state(voip, 0, blob) == 0
+    assert L.opusgpu_enc_batch_import_state(rs, 1, blob) == -1 and L.opusgpu_enc_batch_import_state(voip, 1, blob) == 0
+    assert L.opusgpu_enc_batch_export_state(rs, 0, blob) == 0
+    assert L.opusgpu_enc_batch_import_state(voip, 1, blob) == -1 and L.opusgpu_enc_batch_import_state(rs2, 1, blob) == 0
+    for b in (voip, rs, rs2): L.opusgpu_enc_batch_destroy(b)
