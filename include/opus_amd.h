@@ -165,6 +165,16 @@ OPUS_AMD_EXPORT int opusgpu_encode_batch_lookahead_dev(OpusGpuEncBatch *b, const
 /* OPUS_AMD_SET_KERNEL_TIMING(1) on a batch: HIP events on the launch stream around every kernel of the following calls; opusgpu_enc_batch_kernel_times returns the last call's
  * kernel names (comma separated, in launch order) and durations in ms (bench.py's per-kernel figures; no effect on the packets). */
 #define OPUS_AMD_SET_KERNEL_TIMING_REQUEST 11904
+/* Two more launch properties (never the packets'), same scope rules as OPUS_AMD_SET_KERNEL_PIPELINE; -1 = the library chooses (the default), 0 = off, 1 = on:
+ *   OPUS_AMD_SET_TRANSIENT_PREPASS(v)  the serial recursions of CELT's transient analysis as a lane pre-pass ahead of the kernel that applies them (celt_enc_front.h:
+ *                                       ct_transient_lane); -1: on for 48 kHz launches of >= 64 streams (CELT-only applications) / of the kernel pipeline (the others)
+ *   OPUS_AMD_SET_PVQ_STAGE(v)          the PVQ of 10 / 20 ms CELT frames as a kernel of its own with four streams per wave (celt_enc_pvq4.h: oa_celt_pvq_kernel); -1: on
+ *                                       wherever the call runs as a kernel pipeline.  For a CELT-only application the pipeline IS this stage: 0 keeps the call in one kernel
+ * The process-wide defaults behind -1 can be set with OPUS_AMD_TR_PRE=0|1|2 and OPUS_AMD_CELT_PIPE=0|1 / OPUS_AMD_SH_PVQ4=0|1 (experiments). */
+#define OPUS_AMD_SET_TRANSIENT_PREPASS_REQUEST 11906
+#define OPUS_AMD_GET_TRANSIENT_PREPASS_REQUEST 11907
+#define OPUS_AMD_SET_PVQ_STAGE_REQUEST 11908
+#define OPUS_AMD_GET_PVQ_STAGE_REQUEST 11909
 #define OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST 11902
 #define OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST 11903
 /* n stream records -- configuration and state as they stand on the device -- from batch `src` (from stream src_first on) into batch `dst` (from dst_first on), device to

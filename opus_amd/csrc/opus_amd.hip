@@ -539,6 +539,7 @@ struct OpusGpuEncBatch {
    bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
    int any_cbr;                         /* some stream of the mirror is hard CBR (-1: not derived since the mirror last changed): sizes the output slot a call needs */
    int all_silk_pinned;
+   int tr_pre, pvq_stage;               /* OPUS_AMD_SET_TRANSIENT_PREPASS, OPUS_AMD_SET_PVQ_STAGE: -1 the library chooses, 0 off, 1 on (include/opus_amd.h) */
    int pipeline;                        /* OPUS_AMD_SET_KERNEL_PIPELINE: -1 the library chooses, 0 one kernel, 1 .. 4 the kernel pipeline (include/opus_amd.h) */
    /* staging for the host-pointer entry */
    opus_int16 *d_pcm; size_t pcm_cap;
@@ -580,7 +581,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1; b->tr_pre = -1; b->pvq_stage = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0; b->d_srt = nullptr; b->timing = 0; b->n_stamps = 0; memset(b->stamp_ev, 0, sizeof b->stamp_ev);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
@@ -637,6 +638,8 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    opus_int32 lo = stream < 0 ? 0 : stream, hi = stream < 0 ? b->S : stream + 1;
+   if (request == OPUS_AMD_SET_TRANSIENT_PREPASS_REQUEST) { if (value < -1 || value > 1) return OPUS_BAD_ARG; b->tr_pre = value; return OPUS_OK; }     /* the launch's, not a stream's */
+   if (request == OPUS_AMD_SET_PVQ_STAGE_REQUEST) { if (value < -1 || value > 1) return OPUS_BAD_ARG; b->pvq_stage = value; return OPUS_OK; }
    if (request == OPUS_AMD_SET_KERNEL_TIMING_REQUEST) { b->timing = value != 0; b->n_stamps = 0; return OPUS_OK; }      /* the launch's, not a stream's */
    if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 4) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
    b->any_cbr = -1;
@@ -678,6 +681,8 @@ int opusgpu_enc_batch_get(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
    if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { if (!value) return OPUS_BAD_ARG; *value = b->pipeline; return OPUS_OK; }
+   if (request == OPUS_AMD_GET_TRANSIENT_PREPASS_REQUEST) { if (!value) return OPUS_BAD_ARG; *value = b->tr_pre; return OPUS_OK; }
+   if (request == OPUS_AMD_GET_PVQ_STAGE_REQUEST) { if (!value) return OPUS_BAD_ARG; *value = b->pvq_stage; return OPUS_OK; }
    if (b->kind) {
       OaShStream *t = new OaShStream(b->h_sh[stream]);
       hipError_t e_ = request == OPUS_GET_IN_DTX_REQUEST ? hipMemcpy(t, &b->d_sh[stream], sizeof(OaShStream), hipMemcpyDeviceToHost)      /* needs the SILK channel counters */
@@ -905,9 +910,10 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    oa_stamp(b, s, pred_split ? "oa_sh_pred_kernel+oa_sh_quant_kernel" : "oa_sh_quant_kernel");
    /* the CELT layer's transient recursions on lanes first (48 kHz, AUDIO / VOIP: frames with a CELT layer); OPUS_AMD_TR_PRE=0 keeps them in the back kernel */
-   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
+   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;               /* (process default behind OPUS_AMD_SET_TRANSIENT_PREPASS(-1)) */
+   const int tr_on = b->tr_pre >= 0 ? b->tr_pre : tr_env;
    const i32 *d_tr = nullptr;
-   if (tr_env && b->Fs == 48000 && b->application != OPUS_APPLICATION_RESTRICTED_SILK && !silk_only) {
+   if (tr_on && b->Fs == 48000 && b->application != OPUS_APPLICATION_RESTRICTED_SILK && !silk_only) {
       const int items = n * ch, tiles = (items + 63) / 64;
       const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
       const size_t need_tr = (size_t)g * (OA_MAX_FRAME + OA_OVERLAP) * 64 * sizeof(i16);
@@ -918,8 +924,8 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
       d_tr = b->d_tr;
    }
    /* the CELT layer's PVQ as a stage of its own (celt_enc_pvq4.h: four streams per wave) wherever the launch can carry CELT frames; OPUS_AMD_SH_PVQ4=0: inside the back kernel */
-   static const int pvq4_env = getenv("OPUS_AMD_SH_PVQ4") ? atoi(getenv("OPUS_AMD_SH_PVQ4")) : 1;
-   const bool pvq4 = pvq4_env && !silk_only && b->application != OPUS_APPLICATION_RESTRICTED_SILK;
+   static const int pvq4_env = getenv("OPUS_AMD_SH_PVQ4") ? atoi(getenv("OPUS_AMD_SH_PVQ4")) : 1;          /* (process default behind OPUS_AMD_SET_PVQ_STAGE(-1)) */
+   const bool pvq4 = (b->pvq_stage >= 0 ? b->pvq_stage : pvq4_env) && !silk_only && b->application != OPUS_APPLICATION_RESTRICTED_SILK;
    unsigned *cutq = b->d_queue + 24;
    b->pvq4_last = pvq4;
    if (pvq4) {
@@ -1033,10 +1039,10 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
    }
    static const size_t lds_pad = getenv("OPUS_AMD_LDS_PAD") ? (size_t)atoi(getenv("OPUS_AMD_LDS_PAD")) : 0;   /* occupancy experiments only */
    /* a wide launch of 48 kHz frames up to 20 ms: the transient analysis' recursions first, one lane per (stream, channel) (oa_celt_transient_kernel); OPUS_AMD_TR_PRE=0 keeps them in the encode kernel */
-   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;
+   static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;               /* (process default behind OPUS_AMD_SET_TRANSIENT_PREPASS(-1): 0 never, 1 wide launches, 2 always) */
    const i32 *d_tr = nullptr;
    oa_stamp_begin(b, s);
-   if (tr_env && b->Fs == 48000 && frame_size <= OA_MAX_FRAME && (b->n_act >= 64 || tr_env == 2 /* tests: whatever the width */)) {
+   if ((b->tr_pre >= 0 ? b->tr_pre : tr_env) && b->Fs == 48000 && frame_size <= OA_MAX_FRAME && (b->n_act >= 64 || b->tr_pre == 1 || (b->tr_pre < 0 && tr_env == 2))) {
       const int items = (int)b->n_act * b->channels, tiles = (items + 63) / 64;
       const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
       const size_t need = (size_t)g * (OA_MAX_FRAME + OA_OVERLAP) * 64 * sizeof(i16);
@@ -1050,7 +1056,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
     * calls stop before the PVQ (oa_encode_kernel with continuation records), oa_celt_pvq_kernel codes the bands of four streams per wave, oa_celt_back_kernel finishes the calls */
    static const int pipe_env = getenv("OPUS_AMD_CELT_PIPE") ? atoi(getenv("OPUS_AMD_CELT_PIPE")) : -1;
    const int pipe_mode = b->pipeline >= 0 ? b->pipeline : pipe_env;
-   const bool pipe = (pipe_mode < 0 ? b->n_act >= 64 : pipe_mode > 0) && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
+   const bool pipe = (pipe_mode < 0 ? b->n_act >= 64 : pipe_mode > 0) && b->pvq_stage != 0 && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
    if (pipe && !b->d_ccont) {
       HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
       HIPCHECK(hipMalloc((void **)&b->d_cut_list, 2 * sizeof(int) * (size_t)b->S));                 /* [S] the streams that were cut, in the order they were; [S] sorted for the PVQ kernel */
@@ -1195,18 +1201,18 @@ int opusgpu_encode_batch_lookahead(OpusGpuEncBatch *b, const opus_int16 *pcm, co
 
 /* ---------------- classic libopus encoder API on top of a process-wide batch-of-one ---------------- */
 #define OA_MAGIC 0x4f41454eu /* "OAEN" */
-struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pipeline_p2 /* OPUS_AMD_SET_KERNEL_PIPELINE + 2; 0 = never set (-1) */; uint32_t pad; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
+struct OpusEncoder { uint32_t magic; uint32_t kind; uint32_t pipeline_p2 /* OPUS_AMD_SET_KERNEL_PIPELINE + 2; 0 = never set (-1) */; uint32_t launch_opts /* bits 0-1: OPUS_AMD_SET_TRANSIENT_PREPASS + 2, bits 2-3: OPUS_AMD_SET_PVQ_STAGE + 2; 0 = never set (-1) */; union { OaStream s; OaShStream sh; }; };   /* flat, no device handles: memcpy-able (include/opus.h:108) */
 static OpusGpuEncBatch *g_classic[2][5][2];                   /* [record kind][API rate][channels - 1]: created by the first call of that shape, used by one launch at a time */
 /* one classic call waiting for (or leading) a launch: opus_call_combiner.h */
 struct OaEncCall {
    OpusEncoder *st; const opus_int16 *pcm; const opus_int32 *apcm; unsigned char *data;
    int kind, frame_size, application, channels; opus_int32 Fs, max_data_bytes;
-   int ret; bool done; size_t tid; int pipeline; int analysis_frame_size;    /* samples per channel behind pcm (>= frame_size: OPUS_SET_EXPERT_FRAME_DURATION) */
+   int ret; bool done; size_t tid; int pipeline; unsigned launch_opts; int analysis_frame_size;    /* samples per channel behind pcm (>= frame_size: OPUS_SET_EXPERT_FRAME_DURATION) */
    const void *who() const { return st; }
    bool same_shape(const OaEncCall &o) const
    {
       return kind == o.kind && Fs == o.Fs && channels == o.channels && application == o.application && frame_size == o.frame_size
-          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr) && pipeline == o.pipeline && analysis_frame_size == o.analysis_frame_size;
+          && max_data_bytes == o.max_data_bytes && (apcm != nullptr) == (o.apcm != nullptr) && pipeline == o.pipeline && launch_opts == o.launch_opts && analysis_frame_size == o.analysis_frame_size;
    }
 };
 static OaCallCombiner<OaEncCall> g_enc_calls;
@@ -1267,7 +1273,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
       if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
    OpusGpuEncBatch *b = *slot;
-   b->application = h.application; b->n_act = n; b->pipeline = h.pipeline;
+   b->application = h.application; b->n_act = n; b->pipeline = h.pipeline; b->tr_pre = (h.launch_opts & 3) ? (int)(h.launch_opts & 3) - 2 : -1; b->pvq_stage = ((h.launch_opts >> 2) & 3) ? (int)((h.launch_opts >> 2) & 3) - 2 : -1;
    opus_int32 stride = oa_enc_out_stride_needed(h.Fs, h.frame_size, h.max_data_bytes) + 8;
    if (stride < 1288) stride = 1288;
    const size_t per = (size_t)h.analysis_frame_size * h.channels, rec = kind ? sizeof(OaShStream) : sizeof(OaStream);
@@ -1331,7 +1337,7 @@ static opus_int32 oa_classic_encode(OpusEncoder *st, const opus_int16 *pcm, int 
       return fr_code != OPUS_OK ? fr_code : OPUS_BAD_ARG;
    }
    if (st->kind) st->sh.cfg.input_depth = depth; else st->s.cfg.input_depth = depth;
-   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false, 0, st->pipeline_p2 ? (int)st->pipeline_p2 - 2 : -1, analysis_frame_size > frame_size ? analysis_frame_size : frame_size};
+   OaEncCall call = {st, pcm, apcm, data, (int)st->kind, frame_size, application, channels, Fs, max_data_bytes, OPUS_INTERNAL_ERROR, false, 0, st->pipeline_p2 ? (int)st->pipeline_p2 - 2 : -1, (unsigned)st->launch_opts, analysis_frame_size > frame_size ? analysis_frame_size : frame_size};
    g_enc_calls.submit(&call, oa_classic_cap(), oa_classic_linger_us(), oa_classic_encode_group);
    return call.ret;
 }
@@ -1383,6 +1389,14 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
    if (request == OPUS_RESET_STATE) ret = st->kind ? sh_ctl_set(&st->sh, request, 0) : oa_ctl_set(&st->s, request, 0);
    else if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { const opus_int32 v = va_arg(ap, opus_int32); if (v < -1 || v > 4) ret = OPUS_BAD_ARG; else { st->pipeline_p2 = (uint32_t)(v + 2); ret = OPUS_OK; } }
    else if (request == OPUS_AMD_GET_KERNEL_PIPELINE_REQUEST) { opus_int32 *p = va_arg(ap, opus_int32 *); if (!p) ret = OPUS_BAD_ARG; else { *p = st->pipeline_p2 ? (opus_int32)st->pipeline_p2 - 2 : -1; ret = OPUS_OK; } }
+   else if (request == OPUS_AMD_SET_TRANSIENT_PREPASS_REQUEST || request == OPUS_AMD_SET_PVQ_STAGE_REQUEST) {
+      const opus_int32 v = va_arg(ap, opus_int32); const int sh_ = request == OPUS_AMD_SET_PVQ_STAGE_REQUEST ? 2 : 0;
+      if (v < -1 || v > 1) ret = OPUS_BAD_ARG; else { st->launch_opts = (st->launch_opts & ~(3u << sh_)) | ((uint32_t)(v + 2) << sh_); ret = OPUS_OK; }
+   }
+   else if (request == OPUS_AMD_GET_TRANSIENT_PREPASS_REQUEST || request == OPUS_AMD_GET_PVQ_STAGE_REQUEST) {
+      opus_int32 *p = va_arg(ap, opus_int32 *); const int sh_ = request == OPUS_AMD_GET_PVQ_STAGE_REQUEST ? 2 : 0;
+      if (!p) ret = OPUS_BAD_ARG; else { const uint32_t f = (st->launch_opts >> sh_) & 3; *p = f ? (opus_int32)f - 2 : -1; ret = OPUS_OK; }
+   }
    else if (request == OPUS_SET_ENERGY_MASK_REQUEST) {                                  /* internal (src/opus_private.h): multistream surround masking, 21 values per channel or NULL */
       const opus_int32 *m = va_arg(ap, const opus_int32 *);
       opus_int32 *dst = st->kind ? st->sh.energy_mask : st->s.energy_mask;
@@ -1400,7 +1414,7 @@ int opus_encoder_ctl(OpusEncoder *st, int request, ...)
          else {
             memcpy(o, st, sizeof(*o));
             ret = opus_encoder_init(st, o->kind ? o->sh.cfg.Fs : o->s.Fs, o->kind ? o->sh.cfg.channels : o->s.cfg.channels, v);
-            st->pipeline_p2 = o->pipeline_p2;
+            st->pipeline_p2 = o->pipeline_p2; st->launch_opts = o->launch_opts;
             static const int carry[] = {OPUS_SET_BITRATE_REQUEST, OPUS_SET_COMPLEXITY_REQUEST, OPUS_SET_VBR_REQUEST, OPUS_SET_VBR_CONSTRAINT_REQUEST, OPUS_SET_FORCE_CHANNELS_REQUEST,
                OPUS_SET_BANDWIDTH_REQUEST, OPUS_SET_MAX_BANDWIDTH_REQUEST, OPUS_SET_LSB_DEPTH_REQUEST, OPUS_SET_PHASE_INVERSION_DISABLED_REQUEST, OPUS_SET_FORCE_MODE_REQUEST, OPUS_SET_SIGNAL_REQUEST,
                OPUS_SET_PACKET_LOSS_PERC_REQUEST, OPUS_SET_INBAND_FEC_REQUEST, OPUS_SET_DTX_REQUEST, OPUS_SET_VOICE_RATIO_REQUEST, OPUS_SET_EXPERT_FRAME_DURATION_REQUEST, OPUS_SET_PREDICTION_DISABLED_REQUEST};

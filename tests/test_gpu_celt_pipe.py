@@ -21,11 +21,11 @@ def _celt_seeds(lo, n):
     return out
 
 def test_settings_fuzz_celt_only_through_the_pipeline(monkeypatch):
-    monkeypatch.setattr(Z, "WHICH", "gpu"); monkeypatch.setattr(Z, "PIPELINE", 1)
+    monkeypatch.setattr(Z, "WHICH", "gpu"); monkeypatch.setattr(Z, "PIPELINE", 1); monkeypatch.setattr(Z, "TRPRE", 1)      # ... and the transient pre-pass for these narrow launches too
     for seed in _celt_seeds(3000, 24): Z.fuzz(seed)
 
 def test_batch_abi_fuzz_through_the_celt_pipeline(monkeypatch):
-    monkeypatch.setattr(Z, "WHICH", "gpu"); monkeypatch.setattr(Z, "PIPELINE", 1)
+    monkeypatch.setattr(Z, "WHICH", "gpu"); monkeypatch.setattr(Z, "PIPELINE", 1); monkeypatch.setattr(Z, "TRPRE", 1)
     for seed in range(3100, 3124): Z.fuzz_batch(seed)
 
 def test_pipeline_and_one_kernel_agree_on_a_wide_batch():

@@ -12,6 +12,7 @@ from reflib import ref_fx, ref_fxa
 from test_kernel_emu_silkdec import speechy
 pytestmark = [pytest.mark.skipif(ref_fx() is None or ref_fxa() is None, reason="oracle/_ref not built"), pytest.mark.timeout(900)]   # (a hang is a finding too: opus_pcm_soft_clip on a NaN was one)
 WHICH = "emu"
+TRPRE = int(__import__("os").environ.get("OPUS_AMD_TEST_TRPRE", "-1"))            # OPUS_AMD_SET_TRANSIENT_PREPASS of every encoder under test: 1 = the transient analysis' lane pre-pass also for the narrow launches of these tests
 PIPELINE = int(__import__("os").environ.get("OPUS_AMD_TEST_PIPELINE", "-1"))      # OPUS_AMD_SET_KERNEL_PIPELINE of every encoder under test (include/opus_amd.h): 1 = every 10 / 20 ms call through the front / quantiser / back kernels
 LONG = __import__("os").environ.get("OPUS_AMD_LONG_TESTS") == "1"      # the default CPU suite runs the seeds that once found something plus a fresh one or two; OPUS_AMD_LONG_TESTS=1 adds ranges
 
@@ -41,6 +42,7 @@ def fuzz(seed, changes=10, hold_ms=500, pipeline=None):
     b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     assert b.L.opus_encoder_ctl(b.st, 11900, int(analysis)) == 0
     assert b.L.opus_encoder_ctl(b.st, 11902, PIPELINE if pipeline is None else pipeline) == 0
+    assert b.L.opus_encoder_ctl(b.st, 11906, TRPRE) == 0
     sig = _signal(rng, Fs, ch, Fs * (changes * hold_ms + 2000) // 1000); pos = 0
     hist = []
     for j in range(changes):
@@ -90,6 +92,7 @@ def fuzz_ms(seed, changes=6, hold_ms=300, pipeline=None):
         v = ctypes.c_uint32(); L.opus_multistream_encoder_ctl.argtypes = [vp, ci, vp]; assert L.opus_multistream_encoder_ctl(e, 4031, ctypes.byref(v)) == 0; return v.value
     assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
     assert ctl(E, encs[1][1], 11902, PIPELINE if pipeline is None else pipeline) == 0
+    assert ctl(E, encs[1][1], 11906, TRPRE) == 0
     cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(min(nch, 4))]
     sig = np.ascontiguousarray(np.stack([(cols[c % len(cols)] // (1 + c // len(cols))).astype(np.int16) for c in range(nch)], 1))
     pos = 0; cap = 1500 * nch + 4000
@@ -127,6 +130,7 @@ def fuzz_sparse(seed, changes=14, hold_ms=350, pipeline=None):
     b.L.opus_encoder_ctl.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     assert b.L.opus_encoder_ctl(b.st, 11900, int(analysis)) == 0
     assert b.L.opus_encoder_ctl(b.st, 11902, PIPELINE if pipeline is None else pipeline) == 0
+    assert b.L.opus_encoder_ctl(b.st, 11906, TRPRE) == 0
     sig = _signal(rng, Fs, ch, Fs * (changes * hold_ms + 2500) // 1000); pos = 0
     menu = dict(bitrate=[6000, 9000, 12000, 16000, 24000, 32000, 48000, 64000, 96000, 160000, 510000, -1000, -1], force_channels=[-1000, 1, 2], vbr=[0, 1], vbr_constraint=[0, 1],
                 complexity=list(range(11)), max_bandwidth=[1101, 1102, 1103, 1104, 1105], bandwidth=[-1000, -1000, 1101, 1102, 1103, 1104, 1105], signal=[-1000, 3001, 3002],
@@ -298,6 +302,7 @@ def fuzz_batch(seed, S=5, changes=8, hold_ms=250, pipeline=None):
     err = ci(); b = L.opusgpu_enc_batch_create(S, Fs, ch, app, 0, ctypes.byref(err)); assert b and err.value == 0
     assert L.opusgpu_enc_batch_ctl(b, -1, 11900, int(analysis)) == 0
     assert L.opusgpu_enc_batch_ctl(b, -1, 11902, PIPELINE if pipeline is None else pipeline) == 0
+    assert L.opusgpu_enc_batch_ctl(b, -1, 11906, TRPRE) == 0
     refs = [capi.Enc("ref_fxa" if analysis else "ref", Fs, ch, app) for _ in range(S)]
     sigs = [_signal(rng, Fs, ch, Fs * (changes * hold_ms + 2000) // 1000) for _ in range(S)]; pos = 0
     menu = dict(bitrate=[8000, 16000, 32000, 64000, 128000, -1000, -1], force_channels=[-1000, 1, 2], vbr=[0, 1], vbr_constraint=[0, 1], complexity=[0, 4, 8, 10, 10], max_bandwidth=[1101, 1103, 1104, 1105],
@@ -404,6 +409,7 @@ def fuzz_proj(seed, changes=5, hold_ms=200, pipeline=None):
     def ctl(L, e, req, v): L.opus_projection_encoder_ctl.argtypes = [vp, ci, ci]; return L.opus_projection_encoder_ctl(e, req, v)
     assert ctl(E, encs[1][1], 11900, int(analysis)) == 0
     assert ctl(E, encs[1][1], 11902, PIPELINE if pipeline is None else pipeline) == 0
+    assert ctl(E, encs[1][1], 11906, TRPRE) == 0
     cols = [_signal(rng, Fs, 1, Fs * (changes * hold_ms + 1500) // 1000) for _ in range(4)]
     sig = np.ascontiguousarray(np.stack([(cols[q % 4] // (1 + q // 4)).astype(np.int16) for q in range(nch)], 1)); pos = 0
     cap = 1500 * nch; bufs = [(ctypes.c_ubyte * cap)(), (ctypes.c_ubyte * cap)()]

@@ -19,7 +19,7 @@ getattr(t, %r)(%d)
 
 def run(job):
     fz, seed, which, pipeline, timeout = job
-    env = dict(os.environ, OPUS_AMD_TEST_PIPELINE=str(pipeline))
+    env = dict(os.environ, OPUS_AMD_TEST_PIPELINE=str(pipeline), OPUS_AMD_TEST_TRPRE=os.environ.get("OPUS_AMD_TEST_TRPRE", "-1"))
     t0 = time.time()
     try:
         p = subprocess.run([sys.executable, "-c", JOB % (os.path.join(ROOT, "tests"), which, fz, seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT, timeout=timeout)
