@@ -30,9 +30,16 @@ CONFIGS = {
             ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded frames/s (SILK-only, 16 kHz mono, 20 ms, complexity 10)"),
     4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1001), (4008, 1105), (4006, 1), (4002, 128000), (4010, 10)), metric="encoded frames/s (hybrid, 48 kHz stereo, 20 ms, complexity 10)"),
+    # what a VoIP deployment of config 3 also runs (not BASELINE.json rows; "extra" legs of the default line): in-band FEC at 10 % expected loss, and 60 ms packets
+    31: dict(name="config 3 + OPUS_SET_INBAND_FEC(1), OPUS_SET_PACKET_LOSS_PERC(10)", app=2048, Fs=16000, ch=1, kernel="the SILK-capable pipeline / one-kernel path (LBRR)", key="config_3_fec",
+             ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10), (4012, 1), (4014, 10)), metric="encoded frames/s (SILK-only + in-band FEC, 16 kHz mono, 20 ms, complexity 10)"),
+    32: dict(name="config 3 in 60 ms packets (three SILK frames per call)", app=2048, Fs=16000, ch=1, frame_ms=60, kernel="oa_sh_encode_kernel (one-kernel path: multi-frame packets)", key="config_3_60ms",
+             ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded 60 ms packets/s (SILK-only, 16 kHz mono, complexity 10); x 3 = 20 ms frames/s"),
     5: dict(name="multistream, 255 mono AUDIO streams per encoder (mapping family 255), 48 kHz, 20 ms, 64 kb/s per stream, complexity 10; 257 encoders = 65,535 elementary streams",
             app=2049, Fs=48000, ch=1, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
 }
+
+def frame_of(cfg): return cfg["Fs"] * cfg.get("frame_ms", 20) // 1000          # samples per channel of one call
 
 def reference_music(nsamp, seeds, starts=None):
     """the reference's own test corpus: generate_music() of tests/test_opus_encode.c:57-85 (a byte-beat tune through two rounding one-pole filters, dithered with the
@@ -80,7 +87,7 @@ def reference_music(nsamp, seeds, starts=None):
 def synth(cfg, T, n_pool, rank, corpus="pool"):
     """pool of distinct signals [n_pool, (T+2)*frame*ch] int16 at the config's rate"""
     import signals
-    Fs, ch, fr = cfg["Fs"], cfg["ch"], cfg["Fs"] // 50
+    Fs, ch, fr = cfg["Fs"], cfg["ch"], frame_of(cfg)
     if corpus == "reference" and Fs == 48000:
         span = 30 * 48000 - 2880 - (T + 2) * fr                                                      # the piece is 30 s long in the reference's test (SAMPLES, tests/test_opus_encode.c:51)
         tunes = reference_music((T + 2) * fr, [42 + 100000 * rank + p for p in range(n_pool)],      # SURVEY.md 8d: Rz = Rw = seed0 + stream, seed0 = 42 (one tune per pool slot)
@@ -132,7 +139,7 @@ def _cpu_worker(args):
         except Exception: pass
     L = _ref_lib(path)
     err = ctypes.c_int()
-    fr = cfg["Fs"] // 50
+    fr = frame_of(cfg)
     n = 0; done = False
     if kind == "enc":
         pcm = data; ns, T = pcm.shape[0], pcm.shape[1]
@@ -206,7 +213,7 @@ def parity_sample(cfg, pcm, gpu_packets, gpu_lens, gpu_rng, gpu_dec=None):
     if not os.path.exists(path): return None
     L = _ref_lib(path)
     L.opus_encoder_ctl.argtypes = None
-    err = ctypes.c_int(); fr = cfg["Fs"] // 50
+    err = ctypes.c_int(); fr = frame_of(cfg)
     ns, T = pcm.shape[0], pcm.shape[1]
     out = (ctypes.c_ubyte * 1500)(); bad = 0; rv = ctypes.c_uint32()
     dpcm = np.zeros(fr * cfg["ch"], np.int16)
@@ -298,7 +305,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
     import torch, torch.distributed as dist
     import opus_amd
     cfg = CONFIGS[cid]
-    Fs, CH = cfg["Fs"], cfg["ch"]; FR = Fs // 50; TE = K + W
+    Fs, CH = cfg["Fs"], cfg["ch"]; FR = frame_of(cfg); TE = K + W
     T = max(TE, frames_per_launch if (world == 1 and cid == 2) else 0)                      # frames of input per stream (the T-frames-per-launch leg wants T of them)
     P = 256
     pool = synth(cfg, T, P, rank, corpus=CORPUS)
@@ -605,6 +612,8 @@ def main():
         Kx = max(3, K // 2)
         for cid in (3, 4):
             extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on, decode=True)
+        for cid in (31, 32):
+            extras += run_config(cid, S if cid == 31 else max(64, S // 4), Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
         extras += run_config(5, (a.streams // 255) * 255 if a.streams else 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
     steady = None
     ss_frames = a.steady_state if a.steady_state >= 0 else (500 if full else 0)
@@ -680,7 +689,8 @@ def main():
                 if c:
                     e["cpu"] = {k_: c[k_] for k_ in ("value", "same_work_value", "frames") if k_ in c}
                     if c["value"]: e["x_cpu_1core"] = round(e["value"] / c["value"], 1)
-                res["configs"][("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]] = e
+                if CONFIGS[r["config_id"]].get("frame_ms", 20) != 20: e["frames_20ms_per_s"] = round(e["value"] * CONFIGS[r["config_id"]]["frame_ms"] / 20, 1)
+                res["configs"][CONFIGS[r["config_id"]].get("key") or (("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"])] = e
         # what every leg has in common, said once (the per-leg entries stay short: the driver keeps the last 8 KB of this line)
         res["notes"] = {
             "legs": "configs.<config_N | decode_N>: BASELINE.json configuration N (2: CELT-only 48 kHz stereo 128 kb/s; 3: SILK-only VOIP 16 kHz mono 24 kb/s; 4: hybrid AUDIO 48 kHz stereo 128 kb/s; 5: 257 multistream encoders x 255 mono AUDIO streams at 64 kb/s) at 20 ms, complexity 10, 65,536 streams; decode_N = the decoder on config N's packets; value = frames/s (config_5: elementary-stream frames/s), unit frames/s",

@@ -925,7 +925,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    }
    /* the CELT layer's PVQ as a stage of its own (celt_enc_pvq4.h: four streams per wave) wherever the launch can carry CELT frames; OPUS_AMD_SH_PVQ4=0: inside the back kernel */
    static const int pvq4_env = getenv("OPUS_AMD_SH_PVQ4") ? atoi(getenv("OPUS_AMD_SH_PVQ4")) : 1;          /* (process default behind OPUS_AMD_SET_PVQ_STAGE(-1)) */
-   const bool pvq4 = (b->pvq_stage >= 0 ? b->pvq_stage : pvq4_env) && !silk_only && b->application != OPUS_APPLICATION_RESTRICTED_SILK;
+   const bool pvq4 = (b->pvq_stage >= 0 ? b->pvq_stage : (pvq4_env && (pvq4_env > 1 || n > (long long)b->occ[2].per_cu * (b->num_cu > 0 ? b->num_cu : 1)))) /* -1: where the back kernel needs more than one round of the chip (profiles/r06_j) */ && !silk_only && b->application != OPUS_APPLICATION_RESTRICTED_SILK;
    unsigned *cutq = b->d_queue + 24;
    b->pvq4_last = pvq4;
    if (pvq4) {
@@ -1056,7 +1056,11 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
     * calls stop before the PVQ (oa_encode_kernel with continuation records), oa_celt_pvq_kernel codes the bands of four streams per wave, oa_celt_back_kernel finishes the calls */
    static const int pipe_env = getenv("OPUS_AMD_CELT_PIPE") ? atoi(getenv("OPUS_AMD_CELT_PIPE")) : -1;
    const int pipe_mode = b->pipeline >= 0 ? b->pipeline : pipe_env;
-   const bool pipe = (pipe_mode < 0 ? b->n_act >= 64 : pipe_mode > 0) && b->pvq_stage != 0 && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
+   /* -1: the pipeline when the one-kernel path would need more than one round of the chip (its waves = the streams it holds at once): below that a lone frame's serial
+    * chain is the call's latency, and one wave per stream walks it faster than the three-kernel relay (profiles/r06_j: 4,096 streams 4.6 vs 5.2 ms, 16,384 13.9 vs 11.0 ms) */
+   long long one_round = 0;
+   { int g1 = 0; const int r = oa_sh_grid(b, 9, (const void *)oa_encode_kernel, sizeof(FrameLds) + lds_pad, 1LL << 40, &g1); if (r != OPUS_OK) return r; one_round = g1; }
+   const bool pipe = (pipe_mode < 0 ? b->n_act > one_round : pipe_mode > 0) && b->pvq_stage != 0 && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs);
    if (pipe && !b->d_ccont) {
       HIPCHECK(hipMalloc((void **)&b->d_ccont, sizeof(CeltCont) * (size_t)b->S));
       HIPCHECK(hipMalloc((void **)&b->d_cut_list, 2 * sizeof(int) * (size_t)b->S));                 /* [S] the streams that were cut, in the order they were; [S] sorted for the PVQ kernel */
