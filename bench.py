@@ -322,7 +322,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         x = pool_d[pid[:, None], idx].to(torch.float32) * gain[:, None]
         pcm[t] = x.round().clamp(-32768, 32767).to(torch.int16)
     del pool_d
-    STRIDE = 1280
+    STRIDE = 1280 if cfg.get("frame_ms", 20) == 20 else 1344          # (a multi-frame call's slot: max_data_bytes + the staging head-room of the device-side assembly)
     NC = min(CPU_STREAMS, S)
     stream = torch.cuda.current_stream(dev)
     if cid == 5:
