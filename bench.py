@@ -472,7 +472,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         torch.cuda.synchronize(dev)
         if world > 1: dist.barrier()
         torch.cuda.synchronize(dev)
-        r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None)
+        r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None); r2.pop("kernels_ms", None)
         r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
         r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
         r2["kernel"] = "oa_decode_look_kernel + oa_decode_fast_kernel + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (opusgpu_dec_batch_set_fast_kernel(b, 0))"
@@ -629,7 +629,7 @@ def main():
             try: traffic_docs.append((name, json.load(open(os.path.join(ROOT, "profiles", name)))))
             except Exception: continue
         used_traffic = set()
-        def roof(r, Sn):
+        def roof(r, Sn, short=False):
             ach = Sn * r["algorithmic_bytes_per_frame"] / (r["kernel_ms"] * 1e-3) / 1e9
             traffic = None; issue = None
             key = ("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"]
@@ -647,7 +647,8 @@ def main():
             km = r.get("kernels_ms") or {}
             if km:
                 dk = max(km, key=km.get)
-                o["kernels_ms"] = km
+                if not short: o["kernels_ms"] = km
+                else: o["kernels_ms"] = {k_.replace("oa_", "").replace("_kernel", ""): v_ for k_, v_ in km.items() if v_ >= 0.1}          # (the extra legs: short names, launches above 0.1 ms)
                 o["dominant"] = {"kernel": dk, "ms": km[dk], "achieved": round(Sn * r["algorithmic_bytes_per_frame"] / (km[dk] * 1e-3) / 1e9, 2), "frac": round(Sn * r["algorithmic_bytes_per_frame"] / (km[dk] * 1e-3) / 1e9 / 8000.0, 5)}
             return o
         def cpu_leg(r, seconds, allc):
@@ -666,7 +667,7 @@ def main():
                        "parity_sample_ok": None if not main_res.get("parity_sample") else main_res["parity_sample"]["ok"], "parity_sample": main_res.get("parity_sample"),
                        "lib_build": built, "lib_matches_sources": None if src_now is None else built == "OA_SRC_HASH=" + src_now,
                        "parallelism": "streams sharded over %d GPU(s), no data-path collective%s" % (world, (", final gather FAILED in the warm-up and was left out (see \"gather\")" if (main_res.get("gather") or {}).get("error") else (", final gather of the compacted packets in the timed region (%s; side stream, double-buffered)" % ((main_res.get("gather") or {}).get("transport") or a.gather)) if not a.no_gather else ", final gather switched off (--no-gather)") if world > 1 else "")},
-            "roofline": (lambda ro_: dict(ro_, kernel=(ro_["dominant"]["kernel"] + " (the dominant kernel of the call: roofline.dominant; achieved / frac above are the WHOLE call's: " + " + ".join(ro_["kernels_ms"]) + ")") if ro_.get("dominant") else main_res["kernel"], peak_measured=peak_meas))(roof(main_res, main_res["streams_per_gpu"])),
+            "roofline": (lambda ro_: dict(ro_, kernel=(ro_["dominant"]["kernel"] + " (dominant, see roofline.dominant; achieved / frac are the whole call's, all of kernels_ms)") if ro_.get("dominant") else main_res["kernel"], peak_measured=peak_meas))(roof(main_res, main_res["streams_per_gpu"])),
         }
         if per_rank is not None: res["ranks_seen"] = len(per_rank); res["per_rank"] = per_rank
         if main_res.get("gather"): res["gather"] = main_res["gather"]
@@ -683,7 +684,7 @@ def main():
                 Kx = K if r["config_id"] == a.config else max(3, K // 2)
                 e = {"value": round(r["streams_per_gpu"] * Kx / r["dt"], 1), "ms_per_step": round(r["dt"] / Kx * 1e3, 3), "steps": Kx,
                      "streams": r["streams_per_gpu"], "mean_packet_bytes": r["mean_packet_bytes"], "valid": r["all_packets_valid"], "parity_ok": None if not r.get("parity_sample") else r["parity_sample"]["ok"],
-                     "roofline": {k_: v_ for k_, v_ in roof(r, r["streams_per_gpu"]).items() if k_ not in ("bound", "peak", "unit")}}
+                     "roofline": {k_: v_ for k_, v_ in roof(r, r["streams_per_gpu"], short=True).items() if k_ not in ("bound", "peak", "unit")}}
                 if "dec_fast_kernel" in r and not r["dec_fast_kernel"]: e["dec_fast_kernel"] = False
                 c = cpu_leg(r, 3.0, 0) if cpu_on else None
                 if c:
@@ -693,12 +694,11 @@ def main():
                 res["configs"][CONFIGS[r["config_id"]].get("key") or (("decode_%d" if r["leg"] == "decode" else "config_%d") % r["config_id"])] = e
         # what every leg has in common, said once (the per-leg entries stay short: the driver keeps the last 8 KB of this line)
         res["notes"] = {
-            "legs": "configs.<config_N | decode_N>: BASELINE.json configuration N (2: CELT-only 48 kHz stereo 128 kb/s; 3: SILK-only VOIP 16 kHz mono 24 kb/s; 4: hybrid AUDIO 48 kHz stereo 128 kb/s; 5: 257 multistream encoders x 255 mono AUDIO streams at 64 kb/s) at 20 ms, complexity 10, 65,536 streams; decode_N = the decoder on config N's packets; value = frames/s (config_5: elementary-stream frames/s), unit frames/s",
-            "roofline": "achieved = algorithmic bytes per frame x streams / kernel_ms (HIP events around one call's launches on the launch stream, inside the timed region) in GB/s; frac = achieved / 8000 GB/s; traffic = counted HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE passes, separate runs: profiles/%s); issue = VALU busy per SIMD and active lanes per VALU cycle from the same passes; latency/issue-bound integer codec path: the HBM fraction is small by construction (SURVEY.md 8d)" % (", ".join(sorted(used_traffic)) or "none on this box"),
-            "cpu_sample": "cpu_baseline / cpu: libopus (float build, RTCD) on ONE pinned core of this host: one codec state, created outside the clock, through >= %d consecutive frames -- streams 0..%d of the GPU batch, all their frames in order, cycled; same_work_value = the FIXED_POINT build%s the GPU path is bit-exact to; frames = frames timed" % (CPU_MIN_FRAMES, CPU_STREAMS - 1, "" if NO_ANALYSIS else " with the float API (tonality analysis)"),
-            "cpu_sample_ms": "config_5: one pinned core running the reference's opus_multistream_encode on encoder 0's frames (255 elementary frames per call), cycled",
-            "parity": "parity_ok / parity_sample: after the timed region, streams 0..%d (config_5: encoders 0..1 = 510 streams) once more through the compiled reference the GPU path is bit-exact to; every packet and final range (decode legs: + the PCM) of every frame the batch produced compared" % (CPU_STREAMS - 1),
-            "steady_state": "1,024 streams through 500 consecutive frames (state on the device), HIP-event ms per step at the head and the tail, 4 streams x 500 frames against the reference; full_width = the 1,024 warmed-up states fanned out over 65,536 streams, `steps` more frames: throughput of a batch ten seconds into its streams (value above: every stream's first frames from a cold start)",
+            "legs": "configs.<config_N|decode_N>: BASELINE.json configuration N at 20 ms, complexity 10, 65,536 streams (decode_N: the decoder on its packets; config_5: elementary-stream frames/s; config_3_fec / config_3_60ms: config 3 with in-band FEC at 10 % loss / in 60 ms packets, calls/s); DESIGN.md 5 has the definitions",
+            "roofline": "achieved = algorithmic bytes per frame x streams / kernel_ms (HIP events on the launch stream around one call, in the timed region), frac = / 8000 GB/s; kernels_ms / dominant: HIP events between the call's launches inside the library (last timed step); traffic / issue: rocprofv3 counter passes, profiles/%s" % (", ".join(sorted(used_traffic)) or "none on this box"),
+            "cpu": "cpu_baseline / cpu: libopus float + RTCD on ONE pinned core, one codec state through >= %d consecutive frames of streams 0..%d (config_5: opus_multistream_encode on encoder 0); same_work_value = the fixed-point build the GPU path is bit-exact to" % (CPU_MIN_FRAMES, CPU_STREAMS - 1),
+            "parity": "parity_ok / parity_sample: after the timed region streams 0..%d (config_5: 510 streams) once more through the compiled reference: every packet and final range (decode legs: + PCM) equal" % (CPU_STREAMS - 1),
+            "steady_state": "1,024 streams x 500 consecutive frames on the device (4 x 500 checked against the reference), then fanned out over 65,536 streams and timed",
         }
         print(json.dumps(res))
     if world > 1: dist.destroy_process_group()
