@@ -99,7 +99,7 @@ def test_bench_default_line_has_every_configuration():
     for k, e in r["configs"].items():
         assert e["value"] > 0 and e["valid"] and e["roofline"]["kernel_ms"] > 0, k
         assert e["parity_ok"] is True and e["cpu"]["value"] > 0, k                       # every leg, config 5 included (opus_multistream_encode of the reference on two encoders)
-    assert r["roofline"]["dominant"]["kernel"] == "oa_celt_pvq_kernel" and set(r["roofline"]["kernels_ms"]) >= {"oa_celt_front_kernel", "oa_celt_pvq_kernel", "oa_celt_back_kernel"}      # HIP events between the launches, inside the library
+    assert r["roofline"]["dominant"]["kernel"] in ("oa_encode_kernel", "oa_celt_pvq_kernel") and r["roofline"]["dominant"]["ms"] > 0      # HIP events between the launches, inside the library (4,096 streams fit one round of the chip: one kernel)
     ss = r["steady_state"]
     assert ss["consecutive_frames"] == 40 and ss["parity_sample_ok"] is True and ss["parity_frames"] == 4 * 40 and ss["all_packets_valid"]
     assert ss["full_width"]["value"] > 0 and ss["full_width"]["all_packets_valid"] and ss["full_width"]["replicas_agree"]
