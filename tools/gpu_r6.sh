@@ -29,7 +29,8 @@ bench5) timeout 300 python bench.py $B --config 5 > $O/bench5.log 2>&1 ;;
 decode) for f in ${DEC_FAST_MODES:-0 1}; do for c in 2 3 4; do OPUS_AMD_DEC_FAST=$f timeout 120 python bench.py $B --config $c --decode > $O/decode${c}_fast$f.log 2>&1; done; done ;;
 dectests) timeout 400 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_silkdec.py tests/test_gpu_float_decoder_gate.py tests/test_gpu_ms_batch.py -x -q --timeout 90 > $O/pytest_decoder.log 2>&1 ;;
 bench_default) timeout 900 python bench.py > $O/bench_default.log 2>&1 ;;
-final) # the round's closing measurement, on the build that is in the tree: rocprofv3 kernel stats of every bench leg (configs 2-5, the three decoder legs), the five counter passes
+final) timeout 1500 python bench.py > $O/bench_default.log 2>&1   # the driver's line first, in the SAME call as the profiles below (profiles/INDEX.md states the delta between the two)
+  # the round's closing measurement, on the build that is in the tree: rocprofv3 kernel stats of every bench leg (configs 2-5, the three decoder legs), the five counter passes
   # of each, condensed into profiles-ready files under $O (copy to profiles/r06_final + profiles/pmc_traffic_r06.json)
   for c in 2 3 4 5; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/prof$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config $c > $OLDPWD/$O/prof$c.log 2>&1); find $O/prof$c -name '*kernel_trace*' -delete; find $O/prof$c -name '*agent_info*' -delete; done
   for c in 2 3 4; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config $c --decode > $OLDPWD/$O/profd$c.log 2>&1); find $O/profd$c -name '*kernel_trace*' -delete; find $O/profd$c -name '*agent_info*' -delete; done
