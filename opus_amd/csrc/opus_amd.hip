@@ -1233,6 +1233,13 @@ static char *oa_pinned(OaPinned &b, size_t n)
    }
    return b.p;
 }
+/* the device the classic entry points (opus_encode, opus_decode, the multistream and projection calls) run on: OPUS_AMD_DEVICE=<index>, default 0.  The batch ABI takes
+ * its device as an argument; a process that serves N GPUs through the classic API runs one process per GPU */
+static int oa_classic_device()
+{
+   static const int dev = getenv("OPUS_AMD_DEVICE") && atoi(getenv("OPUS_AMD_DEVICE")) > 0 ? atoi(getenv("OPUS_AMD_DEVICE")) : 0;
+   return dev;
+}
 static int oa_classic_cap()      /* states one launch of the classic API carries at most (the device arrays of a shape are sized for it once) */
 {
    static const int cap = getenv("OPUS_AMD_CLASSIC_BATCH") && atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) > 0 ? atoi(getenv("OPUS_AMD_CLASSIC_BATCH")) : 256;
@@ -1273,7 +1280,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    OpusGpuEncBatch **slot = &g_classic[kind][oa_fs_index(h.Fs)][h.channels - 1];
    if (!*slot) {
       int err;
-      *slot = opusgpu_enc_batch_create(oa_classic_cap(), h.Fs, h.channels, kind ? OPUS_APPLICATION_AUDIO : OPUS_APPLICATION_RESTRICTED_LOWDELAY, 0, &err);
+      *slot = opusgpu_enc_batch_create(oa_classic_cap(), h.Fs, h.channels, kind ? OPUS_APPLICATION_AUDIO : OPUS_APPLICATION_RESTRICTED_LOWDELAY, oa_classic_device(), &err);
       if (!*slot) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
    OpusGpuEncBatch *b = *slot;
@@ -1731,7 +1738,7 @@ static int oa_classic_decode_group_run(std::vector<OaDecCall *> &g)
    const int n = (int)g.size(), ch = h.st->s.s.channels, ci = ch - 1, fi = oa_fs_index(h.st->Fs);
    if (!g_classic_dec[fi][ci]) {
       int err;
-      g_classic_dec[fi][ci] = opusgpu_dec_batch_create(oa_classic_cap(), h.st->Fs, ch, 0, &err);
+      g_classic_dec[fi][ci] = opusgpu_dec_batch_create(oa_classic_cap(), h.st->Fs, ch, oa_classic_device(), &err);
       if (!g_classic_dec[fi][ci]) return err == OPUS_OK ? OPUS_INTERNAL_ERROR : err;
    }
    OpusGpuDecBatch *b = g_classic_dec[fi][ci];

@@ -70,7 +70,7 @@ static OpusGpuEncBatch *oa_ms_enc_batch(int n, int channels, int application, op
    long key = (((long)n * 4 + channels) * 64 + Fs / 1000) * 2 + oa_app_is_sh(application);
    auto it = g_ms_enc.find(key);
    if (it != g_ms_enc.end()) return it->second;
-   OpusGpuEncBatch *b = opusgpu_enc_batch_create(n, Fs, channels, application, 0, err);
+   OpusGpuEncBatch *b = opusgpu_enc_batch_create(n, Fs, channels, application, oa_classic_device(), err);
    if (b) g_ms_enc[key] = b;
    return b;
 }
@@ -79,7 +79,7 @@ static OpusGpuDecBatch *oa_ms_dec_batch(int n, int channels, opus_int32 Fs, int 
    long key = ((long)n * 4 + channels) * 64 + Fs / 1000;
    auto it = g_ms_dec.find(key);
    if (it != g_ms_dec.end()) return it->second;
-   OpusGpuDecBatch *b = opusgpu_dec_batch_create(n, Fs, channels, 0, err);
+   OpusGpuDecBatch *b = opusgpu_dec_batch_create(n, Fs, channels, oa_classic_device(), err);
    if (b) g_ms_dec[key] = b;
    return b;
 }
