@@ -279,7 +279,7 @@ oa_sh_encode_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fr
 #define OA_SH_FRONT_WAVES_PER_EU 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
-oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pcm_row, int pred_split)
+oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, char *pcm_hp_all, CeltScratch *scratch, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pcm_row, int pred_split, int pkt_window /* bytes of packet buffer behind pkt_off: SH_FRONT_PKT_BYTES, or SH_PKT_BYTES when the batch has in-band FEC on */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
@@ -293,7 +293,7 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
       if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)SE_FRONT_ST_OFF; }
       __syncthreads();
       oa_sh_front_frame(L, gs, pcm + (size_t)s * pcm_row * ch, frame_size, max_data_bytes, (i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), scratch + blockIdx.x, conts + s,
-            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row, pred_split);
+            apcm ? apcm + (size_t)s * pcm_row * ch : nullptr, slow_list, counters + 4, s, pcm_row, pred_split, pkt_window);
       __syncthreads();
       kept += conts[s].kind == SH_CONT_FAST;
       if (pred_split && threadIdx.x == 0 && conts[s].kind == SH_CONT_FAST && conts[s].nq > 0) {      /* the pred kernel's work list: one item (stream * 2 + job) per coded channel, behind the list of the calls turned away */
@@ -537,6 +537,7 @@ struct OpusGpuEncBatch {
    OaStream *d_streams;
    std::vector<OaStream> h_streams;     /* host mirror of the configuration (state is authoritative on device) */
    bool cfg_dirty;                      /* the host mirror changed since all_silk_pinned was derived */
+   int any_fec;                         /* some stream of the mirror has in-band FEC on (-1: not derived since the mirror last changed): sizes the front kernel's packet window */
    int any_cbr;                         /* some stream of the mirror is hard CBR (-1: not derived since the mirror last changed): sizes the output slot a call needs */
    int all_silk_pinned;
    int tr_pre, pvq_stage;               /* OPUS_AMD_SET_TRANSIENT_PREPASS, OPUS_AMD_SET_PVQ_STAGE: -1 the library chooses, 0 off, 1 on (include/opus_amd.h) */
@@ -581,7 +582,7 @@ OpusGpuEncBatch *opusgpu_enc_batch_create(opus_int32 nstreams, opus_int32 Fs, in
    }
    if (err == OPUS_OK) {
       b = new OpusGpuEncBatch();
-      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->pipeline = -1; b->tr_pre = -1; b->pvq_stage = -1;
+      b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->cfg_dirty = true; b->all_silk_pinned = 0; b->any_cbr = -1; b->any_fec = -1; b->pipeline = -1; b->tr_pre = -1; b->pvq_stage = -1;
       b->kind = kind; b->Fs = Fs; b->application = application; b->d_sh = nullptr; b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->num_cu = 0; b->occ_kernel = nullptr; b->occ_lds = 0; b->occ_per_cu = 0;
       b->d_cont = nullptr; b->d_pcm_hp = nullptr; b->pcm_hp_cap = 0; b->d_slow_list = nullptr; memset(b->occ, 0, sizeof b->occ); b->d_tr = nullptr; b->d_tr_scratch = nullptr; b->tr_scratch_cap = 0; b->d_ccont = nullptr; b->d_cut_list = nullptr; b->celt_pipe_last = 0; b->d_back_hdr = nullptr; b->pvq4_last = 0; b->d_srt = nullptr; b->timing = 0; b->n_stamps = 0; memset(b->stamp_ev, 0, sizeof b->stamp_ev);
       b->d_pcm = nullptr; b->pcm_cap = 0; b->d_apcm = nullptr; b->apcm_cap = 0; b->d_out = nullptr; b->out_cap = 0; b->d_lens = nullptr; b->d_rng = nullptr; b->d_streams = nullptr; b->stream = nullptr;
@@ -642,7 +643,7 @@ int opusgpu_enc_batch_ctl(OpusGpuEncBatch *b, opus_int32 stream, int request, op
    if (request == OPUS_AMD_SET_PVQ_STAGE_REQUEST) { if (value < -1 || value > 1) return OPUS_BAD_ARG; b->pvq_stage = value; return OPUS_OK; }
    if (request == OPUS_AMD_SET_KERNEL_TIMING_REQUEST) { b->timing = value != 0; b->n_stamps = 0; return OPUS_OK; }      /* the launch's, not a stream's */
    if (request == OPUS_AMD_SET_KERNEL_PIPELINE_REQUEST) { if (value < -1 || value > 4) return OPUS_BAD_ARG; b->pipeline = value; return OPUS_OK; }   /* the launch's, not a stream's */
-   b->any_cbr = -1;
+   b->any_cbr = -1; b->any_fec = -1;
    if (request == OPUS_RESET_STATE) {
       /* what the reference keeps across a reset (voice_ratio, the sticky force_channels, SILK's control structure) lives in the scalars, and those are the device's: bring
        * them into the mirror first (gathered on the device, one contiguous transfer) */
@@ -714,7 +715,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
       if ((src->cfg.application == OPUS_APPLICATION_RESTRICTED_SILK) != (b->application == OPUS_APPLICATION_RESTRICTED_SILK)) return OPUS_BAD_ARG;      /* (as in opusgpu_enc_batch_copy_states) */
       HIPCHECK(hipSetDevice(b->device));
       HIPCHECK(hipStreamSynchronize(b->stream));
-      b->h_sh[stream] = *src; b->cfg_dirty = true; b->any_cbr = -1;
+      b->h_sh[stream] = *src; b->cfg_dirty = true; b->any_cbr = -1; b->any_fec = -1;
       HIPCHECK(hipMemcpy(b->d_sh + stream, src, sizeof(OaShStream), hipMemcpyHostToDevice));
       return OPUS_OK;
    }
@@ -722,7 +723,7 @@ int opusgpu_enc_batch_import_state(OpusGpuEncBatch *b, opus_int32 stream, const 
    if (src->cfg.channels != b->channels) return OPUS_BAD_ARG;
    HIPCHECK(hipSetDevice(b->device));
    HIPCHECK(hipStreamSynchronize(b->stream));
-   b->h_streams[stream] = *src; b->any_cbr = -1;
+   b->h_streams[stream] = *src; b->any_cbr = -1; b->any_fec = -1;
    HIPCHECK(hipMemcpy(b->d_streams + stream, src, sizeof(OaStream), hipMemcpyHostToDevice));
    return OPUS_OK;
 }
@@ -746,7 +747,7 @@ int opusgpu_enc_batch_copy_states(OpusGpuEncBatch *dst, opus_int32 dst_first, Op
       HIPCHECK(hipMemcpy(dst->d_streams + dst_first, src->d_streams + src_first, sizeof(OaStream) * (size_t)n, hipMemcpyDeviceToDevice));
       for (opus_int32 i = 0; i < n; i++) dst->h_streams[dst_first + i] = src->h_streams[src_first + i];
    }
-   dst->any_cbr = -1;
+   dst->any_cbr = -1; dst->any_fec = -1;
    return OPUS_OK;
 }
 /* calls the split path's front kernel has kept / handed to the one-kernel path since the batch was created (diagnostics, tests) */
@@ -865,7 +866,10 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
    size_t lds_front = SH_FRONT_LDS_BYTES(ch) + lds_pad;
    if (lds_front < offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds);
-   const int po_front = (int)al16(lds_front); lds_front = po_front + SH_FRONT_PKT_BYTES;
+   /* a batch with in-band FEC on somewhere: the front kernel codes the previous packet's LBRR side stream at the head of the packet, which can be most of a packet: full window */
+   if (b->any_fec < 0) { int f = 0; for (opus_int32 i = 0; !f && i < b->S; i++) f = b->h_sh[i].cfg.use_inband_fec != 0; b->any_fec = f; }
+   const int pkt_window = b->any_fec && mode != 2 /* (the one-wave-per-stream reference quantiser of value 2 has no LBRR pass: those calls stay on the one-kernel path) */ ? (int)SH_PKT_BYTES : (int)SH_FRONT_PKT_BYTES;
+   const int po_front = (int)al16(lds_front); lds_front = po_front + pkt_window;
    /* the back kernel enters the CELT arena for hybrid frames AND for the redundant CELT frame that announces a SILK bandwidth switch (opus_encoder.c:2251-2260), which a
     * stream pinned to SILK-only can still ask for: only RESTRICTED_SILK never does */
    size_t lds_back = b->application == OPUS_APPLICATION_RESTRICTED_SILK ? offsetof(ShLds, S) + 256 : SH_CELT_LDS_BYTES;
@@ -896,7 +900,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    oa_stamp_begin(b, s);
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
-         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split);
+         b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split, pkt_window);
    oa_stamp(b, s, "oa_sh_front_kernel");
    if (mode == 4) {
       const int *pl = (const int *)(b->d_slow_list + n); const unsigned *pc = (const unsigned *)(b->d_queue + 6);
@@ -1306,7 +1310,7 @@ static int oa_classic_encode_group_run(std::vector<OaEncCall *> &g)
    }
    const void *rec_src = n > 1 ? (const void *)recs : kind ? (const void *)&h.st->sh : (const void *)&h.st->s;
    HIPCHECK(hipMemcpy(kind ? (void *)b->d_sh : (void *)b->d_streams, rec_src, rec * (size_t)n, hipMemcpyHostToDevice));
-   b->any_cbr = -1;
+   b->any_cbr = -1; b->any_fec = -1;
    if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = g[i]->st->sh.cfg; b->cfg_dirty = true; }     /* the launch's host-side decisions follow the records it carries */
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = g[i]->st->s.cfg;
    std::vector<unsigned char> out((size_t)stride * n);

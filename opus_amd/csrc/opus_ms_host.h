@@ -270,7 +270,7 @@ static int oa_ms_encode_group(OaMsRec *states, int kind, opus_int32 Fs, int n, i
     * the application accepts, whether the launch can skip the CELT arena) must follow the records just uploaded, not the encoder the batch was created for */
    b->application = application; b->pipeline = states[0].pipeline_p2 ? (int)states[0].pipeline_p2 - 2 : -1;
    b->tr_pre = (states[0].launch_opts & 3) ? (int)(states[0].launch_opts & 3) - 2 : -1; b->pvq_stage = ((states[0].launch_opts >> 2) & 3) ? (int)((states[0].launch_opts >> 2) & 3) - 2 : -1;
-   if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = states[i].sh.cfg; b->cfg_dirty = true; }
+   if (kind) { for (int i = 0; i < n; i++) b->h_sh[i].cfg = states[i].sh.cfg; b->cfg_dirty = true; b->any_fec = -1; }
    else for (int i = 0; i < n; i++) b->h_streams[i].cfg = states[i].s.cfg;
    int r = opusgpu_encode_batch_lookahead(b, pcm, apcm, frame_size, analysis_frame_size > frame_size ? analysis_frame_size : frame_size, out, stride, max_data_bytes, lens, rngs);
    if (r != OPUS_OK) return r;

@@ -30,7 +30,8 @@ enum { SH_CONT_SLOW = 0, SH_CONT_FAST = 1 };
 struct ShQuantCh {
    OaNsqFrame fr;
    OaNsqCfg cfg;
-   i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan, nsq_reset, pad_[3];
+   i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan, nsq_reset;
+   i32 lbrr_on, LBRR_GainIncreases, pad_;              /* in-band FEC: this frame gets a second, coarser quantisation for the NEXT packet's side stream (silk_LBRR_encode_FIX) */
    OaSilkEncIndices indices;
    i16 x16[SE_MAX_FRAME];
 };
@@ -58,8 +59,10 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
 }
 template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
 WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
-      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame); 2: the pred lane / wave kernels' (mode 4), which want the Burg correlations too */)
+      int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame); 2: the pred lane / wave kernels' (mode 4), which want the Burg correlations too */,
+      int pkt_window = SH_FRONT_PKT_BYTES /* bytes of packet buffer this launch gave the wave: SH_FRONT_PKT_BYTES (a few header symbols), or SH_PKT_BYTES -- a launch with in-band FEC in its batch: the previous packet's LBRR side stream is coded at the head of this one (enc_API.c:364-404) */)
 {
+   const int fec_ok = pkt_window >= (int)SH_PKT_BYTES;
    WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
    WV_LDS SilkEncLds *S = &L->S;
    LANE0 { L->silk_tail = 0; S->st_off = (i32)SE_FRONT_ST_OFF; }          /* the quantiser tails stay in HBM: they are the quantiser kernel's; the state sits behind the analysis working set */
@@ -72,7 +75,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       /* a CELT-only frame (the call's decision: opus_encoder.c:1413-1470) has no SILK layer at all: it skips the quantiser stage and is coded whole by the back kernel, at that
        * kernel's occupancy instead of the one-kernel path's */
       const int simple = !wv_uni(sh->err) && !wv_uni(sh->plc_frame) && wv_uni(sh->nb_frames) == 1 && !wv_uni(sh->prefill) && !wv_uni(st->silk_bw_switch) &&
-                         !wv_uni(L->cfg.use_inband_fec) && wv_uni(L->cfg.complexity) >= 2 && (celt_only || frame_size * 100 == Fs || frame_size * 50 == Fs);
+                         (fec_ok || !wv_uni(L->cfg.use_inband_fec)) && wv_uni(L->cfg.complexity) >= 2 && (celt_only || frame_size * 100 == Fs || frame_size * 50 == Fs);
       if (!simple) { sh_front_decline(ct, slow_list, slow_count, s); return; }
    }
    LANE0 { sh->f_redundancy = sh->redundancy; sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_to_celt = sh->to_celt; sh->f_silence = sh->is_silence; st->nonfinal_frame = 0; }
@@ -96,10 +99,10 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    {
       int ok = k.tot_blocks == 1 && wv_uni(c0->inputBufIx) == 0 && wv_uni(c0->nFramesPerPacket) == 1;
-      for (int n = 0; n < sc.nChannelsInternal; n++) ok = ok && !wv_uni(E->ch[n].LBRR_enabled) && (wv_uni(E->ch[n].nStatesDelayedDecision) > 1 || wv_uni(E->ch[n].warping_Q16) > 0);
+      for (int n = 0; n < sc.nChannelsInternal; n++) ok = ok && (fec_ok || !wv_uni(E->ch[n].LBRR_enabled)) && (wv_uni(E->ch[n].nStatesDelayedDecision) > 1 || wv_uni(E->ch[n].warping_Q16) > 0);
       /* the previous packet's LBRR side stream is still owed (enc_API.c:364-404 codes it at the head of this packet whatever the FEC setting is now -- the first frame after
        * OPUS_SET_INBAND_FEC goes 1 -> 0): indices and pulses of up to three frames do not fit the front kernel's SH_FRONT_PKT_BYTES window, the one-kernel path codes this call */
-      for (int n = 0; n < sc.nChannelsInternal; n++) for (int i = 0; i < 3; i++) ok = ok && !wv_uni(E->ch[n].LBRR_flags[i]);
+      if (!fec_ok) for (int n = 0; n < sc.nChannelsInternal; n++) for (int i = 0; i < 3; i++) ok = ok && !wv_uni(E->ch[n].LBRR_flags[i]);
       const int nSamplesToBuffer = imin(wv_uni(c0->frame_length) - wv_uni(c0->inputBufIx), k.nSamplesToBufferMax);
       const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
       ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
@@ -151,6 +154,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
                q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex; q->condCoding = p.condCoding; q->maxBits = p.maxBits; q->useCBR = p.useCBR;
                q->ec_prevLagIndex = c->ec_prevLagIndex; q->ec_prevSignalType = c->ec_prevSignalType; q->chan = n;
                q->nsq_reset = c->nsq_reset_req; c->nsq_reset_req = 0;                          /* the quantiser kernel starts this channel's state over (se_nsq_apply_reset_wave on the one-kernel path) */
+               q->lbrr_on = c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8); q->LBRR_GainIncreases = c->LBRR_GainIncreases;      /* (encode_frame_FIX.c:392-398; the frame is the packet's only one: nFramesEncoded == 0) */
             }
          }
          wv_sync();
@@ -167,7 +171,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
    sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
    sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most; the quantiser kernel's lanes code on from there, in HBM) */
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), fec_ok ? (int)((wv_uni((i32)L->ec.offs) + 11) / 4) : SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most -- with in-band FEC: + the side stream; the quantiser kernel's lanes code on from there, in HBM) */
    se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(S), CC, 0);
    if (wv_lane() == 0) {
       ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
@@ -651,6 +655,39 @@ WV_DEVN void sq_rate_post(WV_LDS SqStream *me, u8 *buf, SqSnap *snap)
    r->gainsID = se_gains_ID((const WV_LDS i8 *)me->ix.GainsIndices, nb_subfr);
    r->iter = iter + 1;
 }
+/* the LBRR pass of a stream (lane kk == 0): the frame's indices with the first gain index raised, the gains those indices stand for; the stream's own gains and indices wait in wk */
+WV_DEV void sq_lbrr_pre(WV_LDS SqStream *me, const ShQuantCh *job)
+{
+   WV_LDS i32 *wk = (WV_LDS i32 *)me->wk; const WV_LDS i32 *ixw = (const WV_LDS i32 *)&me->ix;
+   for (int k = 0; k < 4; k++) wk[k] = me->fr.Gains_Q16[k];
+   for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) wk[4 + k] = ixw[k];
+   /* first frame of the packet (the only one here): LBRRprevLastGainIndex = LastGainIndex, the first index raised (:404-410) */
+   int prev = me->LastGainIndex;
+   me->ix.GainsIndices[0] = (i8)imin(me->ix.GainsIndices[0] + job->LBRR_GainIncreases, 64 - 1);
+   i32 g[4]; i8 gi[4];
+   for (int k = 0; k < 4; k++) gi[k] = me->ix.GainsIndices[k];
+   se_gains_dequant(g, gi, &prev, me->rc.condCoding == SE_CODE_CONDITIONALLY, me->nb_subfr);
+   for (int k = 0; k < me->nb_subfr; k++) me->fr.Gains_Q16[k] = g[k];
+   wk[4 + (int)(sizeof(OaSilkEncIndices) / 4)] = prev;
+   me->fr.Seed = me->ix.Seed;
+}
+/* ... and after the pass (the quad's four lanes): pulses and indices into the side-stream store, the flag and the gain predictor into the channel record, the stream's own values back */
+WV_DEV void sq_lbrr_post(WV_LDS SqStream *me, const ShQuantCh *job, OaSilkLbrr *lb, OaSilkEncChannel *gc, int kk)
+{
+   const int frame_length = me->nb_subfr * 5 * me->fs_kHz, chn = job->chan, NIX = (int)(sizeof(OaSilkEncIndices) / 4);
+   { i32 *d = (i32 *)lb->pulses[chn][0]; const WV_LDS i32 *g = (const WV_LDS i32 *)me->pulses; for (int i = kk; i < frame_length / 4; i += 4) d[i] = g[i]; }
+   { i32 *d = (i32 *)&lb->indices[chn][0]; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->ix; for (int i = kk; i < NIX; i += 4) d[i] = g[i]; }
+}
+WV_DEV void sq_lbrr_restore(WV_LDS SqStream *me, OaSilkEncChannel *gc, int kk)
+{
+   const int NIX = (int)(sizeof(OaSilkEncIndices) / 4);
+   if (kk == 0) {
+      WV_LDS i32 *wk = (WV_LDS i32 *)me->wk; WV_LDS i32 *ixw = (WV_LDS i32 *)&me->ix;
+      gc->LBRR_flags[0] = 1; gc->LBRRprevLastGainIndex = wk[4 + NIX];
+      for (int k = 0; k < 4; k++) me->fr.Gains_Q16[k] = wk[k];
+      for (int k = 0; k < NIX; k++) ixw[k] = wk[4 + k];
+   }
+}
 /* one silk_NSQ_del_dec pass over the wave's 16 streams; `same`: this quad's stream takes part (its parameters are *sp == its own slice), the others keep the collectives in step */
 WV_DEVN void sq_nsq_pass(const OaNsqCfg cfg, NsqMem mown, i32 *ring, WV_LDS SqStream *sp, const i16 *x16, const OaSilkNsqState *gnsq, int same, int kk, int reset)
 {
@@ -704,6 +741,26 @@ WV_DEV void sq_quant_tile_wave(WV_LDS SqLds *Q, OaShStream *streams, ShCont *con
       if (has) sq_job_open(me, job, &ct->ec, j == 0, kk); else if (kk == 0) me->rc.done = 1;
       if (has && job->nsq_reset) { i32 *z = (i32 *)&gt->nsq; for (int i = kk; i < (int)(sizeof(OaSilkNsqState) / 4); i += 4) z[i] = 0; }     /* the record too: the passes start from constants (sq_tile_load), the store at the end writes what a frame leaves */
       wv_sync();
+      /* silk_LBRR_encode_FIX (encode_frame_FIX.c:172, :392-455) ahead of the rate loop: the same frame once more with raised gains, from the same quantiser state (every pass
+       * loads it from the record, nothing is written back); indices and pulses go to the stream's side-stream store for the next packet */
+      const int lb_on = has && job->lbrr_on;
+      if (wv_ballot(lb_on)) {
+         if (kk == 0 && lb_on) sq_lbrr_pre(me, job);
+         wv_sync();
+         unsigned long long pend = wv_ballot(lb_on);
+         while (pend) {
+            const int lead = (int)(__builtin_ctzll(pend) >> 2);
+            const OaNsqCfg cfg = sq_cfg_ld(&Q->s[lead].cfg);
+            const int same = lb_on && sq_cfg_eq(sq_cfg_ld(&me->cfg), cfg);
+            const int src = same ? qd : lead;
+            sq_nsq_pass(cfg, mown, ring, &Q->s[src], conts[first + src].q[j].x16, &gt->nsq, same, kk, me->rc.nsq_reset);
+            pend &= ~wv_ballot(same);
+         }
+         if (lb_on) sq_lbrr_post(me, job, &streams[sidx].lbrr, gc, kk);
+         wv_sync();
+         if (lb_on) sq_lbrr_restore(me, gc, kk);
+         wv_sync();
+      }
       /* the rate-control loop of silk_encode_frame_FIX (:170-370), one lane (kk == 0) per stream; the loop itself is the wave's, a stream that has converged sits out */
       for (;;) {
          if (kk == 0 && !me->rc.done) sq_rate_pre(me);

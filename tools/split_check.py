@@ -18,6 +18,9 @@ def speech(fs, secs, ch, seed):
 CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value}, per-stream ctl overrides)
     "config3":      (16000, 1, 2048, 37, 12, 20, {4002: 24000, 4010: 10, 11002: 1000, 11900: 0}, {}),
     "config4":      (48000, 2, 2049, 19, 8, 20, {4002: 128000, 4010: 10, 11002: 1001, 11900: 0}, {}),
+    "config3_fec":  (16000, 1, 2048, 9, 12, 20, {4002: 24000, 4010: 10, 11002: 1000, 11900: 0, 4012: 1, 4014: 10}, {1: {4014: 25}, 2: {4002: 40000}, 3: {4010: 5}}),      # in-band FEC through the pipeline (round 6): the LBRR pass in the quantiser kernel, the side stream at the head of the next packet
+    "stereo_fec":   (48000, 2, 2049, 6, 12, 20, {4002: 36000, 4010: 10, 4012: 1, 4014: 15}, {1: {4002: 20000}, 2: {4012: 2}, 3: {4006: 0}}),
+    "fec_10ms":     (16000, 1, 2048, 5, 16, 10, {4002: 20000, 4010: 8, 11002: 1000, 4012: 1, 4014: 20}, {}),
     "voip_auto":    (16000, 1, 2048, 5, 10, 20, {4002: 16000, 4010: 10}, {}),
     "cbr_12k":      (16000, 1, 2048, 6, 10, 20, {4002: 12000, 4010: 8, 4006: 0, 11002: 1000, 11900: 0}, {}),
     "tight_cvbr":   (16000, 1, 2048, 6, 10, 20, {4002: 9000, 4010: 6, 11002: 1000, 11900: 0}, {}),
@@ -33,7 +36,7 @@ CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value
     # mode switches in both directions inside the run (redundancy frames, CELT prefill, SILK prefill -> those calls go to the one-kernel path, their neighbours stay): SCHEDULE below
     "switching":    (48000, 2, 2049, 6, 18, 20, {4002: 24000, 4010: 10}, {1: {4022: 1}, 2: {4006: 0}}),
 }
-SCHEDULE = {"switching": {4: {4002: 96000}, 8: {4002: 20000}, 11: {11002: 1002}, 14: {11002: -1000, 4002: 32000}}}     # frame -> {ctl: value} for every stream
+SCHEDULE = {"config3_fec": {6: {4012: 0}, 9: {4012: 1}}, "switching": {4: {4002: 96000}, 8: {4002: 20000}, 11: {11002: 1002}, 14: {11002: -1000, 4002: 32000}}}     # frame -> {ctl: value} for every stream
 
 def selected_cases():
     """SPLIT_CHECK_CASES=name,name,...: a subset (the default CPU suite runs the quick one: tests/test_hostemu_split.py)"""
