@@ -31,7 +31,7 @@ struct ShQuantCh {
    OaNsqFrame fr;
    OaNsqCfg cfg;
    i32 GainsUnq_Q16[4], lastGainIndexPrev, LastGainIndex, condCoding, maxBits, useCBR, ec_prevLagIndex, ec_prevSignalType, chan, nsq_reset;
-   i32 lbrr_on, LBRR_GainIncreases, pad_;              /* in-band FEC: this frame gets a second, coarser quantisation for the NEXT packet's side stream (silk_LBRR_encode_FIX) */
+   i32 lbrr_on, LBRR_GainIncreases, lbrr_fi, lbrr_prev_flag, LBRRprevLastGainIndex, pad_[3];      /* in-band FEC: this frame (number lbrr_fi of its packet) gets a second, coarser quantisation for the NEXT packet's side stream (silk_LBRR_encode_FIX) */
    OaSilkEncIndices indices;
    i16 x16[SE_MAX_FRAME];
 };
@@ -41,6 +41,7 @@ struct ShCont {
    i32 silk_flags, silk_flag_bits, silk_dtx, pad0[3];    /* VAD / LBRR flag bits of the payload's first byte, their count, "every channel is in DTX" */
    EcCtx ec;                                             /* front -> quant -> back */
    SeControl sc;
+   SeCall k; i32 blk_from_input, blk_to_buffer;          /* a 40 / 60 ms SILK packet: silk_Encode's loop variables between the blocks (one front -> pred -> quant relay per 20 ms frame) */
    ShShared sh;
    OaShScalars st;
    ShQuantCh q[2];
@@ -58,6 +59,91 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
    wv_sync();
 }
 template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
+/* One block of silk_Encode's loop (enc_API.c:283-560) in the front kernels: the block's input into the channels' buffers, the head of the frame, every coded channel up to its
+ * quantiser job, the call's continuation record.  The first block of a call comes here from oa_sh_front_frame, the later ones of a 40 / 60 ms SILK packet from
+ * oa_sh_front_cont_frame, after the quantiser kernel has coded the block before. */
+WV_DEV void sh_front_silk_block(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm_blk, ShCont *ct, SeControl &sc, const SeCall &k, int nSamplesFromInput, int nSamplesToBuffer, int last, int pred_split, int fec_ok)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   WV_LDS SilkEncLds *S = &L->S;
+   WV_LDS OaSilkEnc *E = se_st(S);
+   WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
+   const int CC = L->cfg.channels;
+   {
+      /* the channels' input buffers (OaSilkEnc.inbuf) are scratch in this kernel: every sample of them that a later stage reads is written by this call (the whole frame is
+       * buffered in one go, the two samples in front of it come from the stereo state), they live at the end of the phase union (se_inbuf<1>) from the resampler to the heads
+       * of the frames and go back to the record before the first analysis overwrites the union.  What this call does not write (a channel the call leaves alone) is brought
+       * in first, so that the record ends up as the one-kernel path leaves it */
+   for (int n = 0; n < CC; n++) sh_copy_words((WV_LDS i32 *)se_inbuf<1>(S, n), (const i32 *)gs->silk.inbuf[n], SE_INBUF_WORDS);
+   wv_sync();
+   se_call_buffer_wave<1>(S, &sc, pcm_blk, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
+   }
+   wv_sync();
+   se_call_frame_head_wave<1>(S, &sc, &L->ec, SH_PKT(L) + 1, &gs->lbrr, wv_uni(sh->activity), 0);
+   /* the head of every channel that is coded (seed, variable low-pass, the frame into x_buf: all of it the channel's own state) -- the last reader of the input buffers */
+   for (int n = 0; n < sc.nChannelsInternal; n++) {
+      const i32 rate = sc.nChannelsInternal == 1 ? wv_uni(S->r[4]) : wv_uni(S->r[5 + n]);
+      if (rate > 0) se_frame_head_wave<1>(S, &E->ch[n]);
+   }
+   wv_sync();
+   for (int n = 0; n < CC; n++) sh_copy_words((i32 *)gs->silk.inbuf[n], (const WV_LDS i32 *)se_inbuf<1>(S, n), SE_INBUF_WORDS);
+   wv_sync();
+   int nq = 0;
+   for (int n = 0; n < sc.nChannelsInternal; n++) {
+      const SeChanParams p = se_call_channel_params(S, &sc, n, k.tot_blocks, k.curr_block);
+      if (p.channelRate_bps > 0) {
+         WV_LDS OaSilkEncChannel *c = &E->ch[n];
+         se_frame_analysis_wave(S, c, p.condCoding, pred_split ? &ct->p[nq] : (ShPredIn *)nullptr, pred_split == 2);
+         wv_sync();
+         {  /* the channel's job for the quantiser kernel */
+            ShQuantCh *q = &ct->q[nq];
+            const WV_LDS SeEncCtrl *ctl = &S->ctl;
+            const WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
+            FOR_LANES(i, 32) q->fr.PredCoef_Q12[i] = ctl->PredCoef_Q12[i >> 4][i & 15];
+            FOR_LANES(i, 20) q->fr.LTPCoef_Q14[i] = ctl->LTPCoef_Q14[i];
+            FOR_LANES(i, 4 * 24) q->fr.AR_Q13[i] = ctl->AR_Q13[i];
+            FOR_LANES(i, 4) {
+               q->fr.HarmShapeGain_Q14[i] = ctl->HarmShapeGain_Q14[i]; q->fr.Tilt_Q14[i] = ctl->Tilt_Q14[i]; q->fr.LF_shp_Q14[i] = ctl->LF_shp_Q14[i];
+               q->fr.Gains_Q16[i] = ctl->Gains_Q16[i]; q->fr.pitchL[i] = ctl->pitchL[i]; q->GainsUnq_Q16[i] = ctl->GainsUnq_Q16[i];
+            }
+            FOR_LANES(i, c->frame_length) q->x16[i] = x_frame[i];
+            sh_copy_words((i32 *)&q->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
+            if (wv_lane() == 0) {
+               q->fr.signalType = c->indices.signalType; q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Seed = c->indices.Seed;
+               q->fr.Lambda_Q10 = ctl->Lambda_Q10; q->fr.LTP_scale_Q14 = ctl->LTP_scale_Q14;
+               q->cfg.fs_kHz = c->fs_kHz; q->cfg.nb_subfr = c->nb_subfr; q->cfg.predictLPCOrder = c->predictLPCOrder; q->cfg.shapingLPCOrder = c->shapingLPCOrder;
+               q->cfg.nStatesDelayedDecision = c->nStatesDelayedDecision; q->cfg.warping_Q16 = c->warping_Q16;
+               q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex; q->condCoding = p.condCoding; q->maxBits = p.maxBits; q->useCBR = p.useCBR;
+               q->ec_prevLagIndex = c->ec_prevLagIndex; q->ec_prevSignalType = c->ec_prevSignalType; q->chan = n;
+               q->nsq_reset = c->nsq_reset_req; c->nsq_reset_req = 0;                          /* the quantiser kernel starts this channel's state over (se_nsq_apply_reset_wave on the one-kernel path) */
+               q->lbrr_on = c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8); q->LBRR_GainIncreases = c->LBRR_GainIncreases;      /* (encode_frame_FIX.c:392-410) */
+               q->lbrr_fi = c->nFramesEncoded; q->lbrr_prev_flag = c->nFramesEncoded > 0 ? c->LBRR_flags[c->nFramesEncoded - 1] : 0; q->LBRRprevLastGainIndex = c->LBRRprevLastGainIndex;
+            }
+         }
+         wv_sync();
+         se_frame_finish_wave(S, c, &L->ec);
+         nq++;
+      }
+      wv_sync();
+      LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
+   }
+   LANE0 se_call_frame_tail_l0(S, &sc, &L->ec, SH_PKT(L) + 1, 1, 0, 1);
+   if (last) se_call_epilogue_wave(S, &sc, 0, &k);
+   /* ---- the call so far -> HBM: the continuation record, the SILK state ---- */
+   wv_sync();
+   sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
+   sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
+   sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
+   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), fec_ok ? (int)((wv_uni((i32)L->ec.offs) + 11) / 4) : SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most -- with in-band FEC: + the side stream; the quantiser kernel's lanes code on from there, in HBM) */
+   se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(S), CC, 0);
+   if (wv_lane() == 0) {
+      ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq; ct->k = k; ct->k.curr_block = k.curr_block + 1; ct->blk_from_input = nSamplesFromInput; ct->blk_to_buffer = nSamplesToBuffer;
+      ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
+   }
+   wv_sync();
+}
+
+
 WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, int frame_size, int max_data_bytes, i16 *pcm_hp, CeltScratch *cs, ShCont *ct, const i32 *apcm,
       int *slow_list, unsigned *slow_count, int s, int analysis_frame_size = 0, int pred_split = 0 /* 1: the prediction stage is the pred kernel's (oa_sh_pred_frame); 2: the pred lane / wave kernels' (mode 4), which want the Burg correlations too */,
       int pkt_window = SH_FRONT_PKT_BYTES /* bytes of packet buffer this launch gave the wave: SH_FRONT_PKT_BYTES (a few header symbols), or SH_PKT_BYTES -- a launch with in-band FEC in its batch: the previous packet's LBRR side stream is coded at the head of this one (enc_API.c:364-404) */)
@@ -107,77 +193,10 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
       ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
       if (sc.nChannelsInternal == 2) ok = ok && wv_uni(E->ch[1].inputBufIx) == 0;
+      const int last = k.tot_blocks == 1;
       if (!ok) { sh_front_decline(ct, slow_list, slow_count, s); return; }
-      /* the channels' input buffers (OaSilkEnc.inbuf) are scratch in this kernel: every sample of them that a later stage reads is written by this call (the whole frame is
-       * buffered in one go, the two samples in front of it come from the stereo state), they live at the end of the phase union (se_inbuf<1>) from the resampler to the heads
-       * of the frames and go back to the record before the first analysis overwrites the union.  What this call does not write (a channel the call leaves alone) is brought
-       * in first, so that the record ends up as the one-kernel path leaves it */
-      for (int n = 0; n < CC; n++) sh_copy_words((WV_LDS i32 *)se_inbuf<1>(S, n), (const i32 *)gs->silk.inbuf[n], SE_INBUF_WORDS);
-      wv_sync();
-      se_call_buffer_wave<1>(S, &sc, pcm_hp, nSamplesFromInput, nSamplesToBuffer, k.nBlocksOf10ms);
+      sh_front_silk_block(L, gs, pcm_hp, ct, sc, k, nSamplesFromInput, nSamplesToBuffer, last, pred_split, fec_ok);
    }
-   wv_sync();
-   se_call_frame_head_wave<1>(S, &sc, &L->ec, SH_PKT(L) + 1, &gs->lbrr, wv_uni(sh->activity), 0);
-   /* the head of every channel that is coded (seed, variable low-pass, the frame into x_buf: all of it the channel's own state) -- the last reader of the input buffers */
-   for (int n = 0; n < sc.nChannelsInternal; n++) {
-      const i32 rate = sc.nChannelsInternal == 1 ? wv_uni(S->r[4]) : wv_uni(S->r[5 + n]);
-      if (rate > 0) se_frame_head_wave<1>(S, &E->ch[n]);
-   }
-   wv_sync();
-   for (int n = 0; n < CC; n++) sh_copy_words((i32 *)gs->silk.inbuf[n], (const WV_LDS i32 *)se_inbuf<1>(S, n), SE_INBUF_WORDS);
-   wv_sync();
-   int nq = 0;
-   for (int n = 0; n < sc.nChannelsInternal; n++) {
-      const SeChanParams p = se_call_channel_params(S, &sc, n, 1, 0);
-      if (p.channelRate_bps > 0) {
-         WV_LDS OaSilkEncChannel *c = &E->ch[n];
-         se_frame_analysis_wave(S, c, p.condCoding, pred_split ? &ct->p[nq] : (ShPredIn *)nullptr, pred_split == 2);
-         wv_sync();
-         {  /* the channel's job for the quantiser kernel */
-            ShQuantCh *q = &ct->q[nq];
-            const WV_LDS SeEncCtrl *ctl = &S->ctl;
-            const WV_LDS i16 *x_frame = c->x_buf + c->ltp_mem_length;
-            FOR_LANES(i, 32) q->fr.PredCoef_Q12[i] = ctl->PredCoef_Q12[i >> 4][i & 15];
-            FOR_LANES(i, 20) q->fr.LTPCoef_Q14[i] = ctl->LTPCoef_Q14[i];
-            FOR_LANES(i, 4 * 24) q->fr.AR_Q13[i] = ctl->AR_Q13[i];
-            FOR_LANES(i, 4) {
-               q->fr.HarmShapeGain_Q14[i] = ctl->HarmShapeGain_Q14[i]; q->fr.Tilt_Q14[i] = ctl->Tilt_Q14[i]; q->fr.LF_shp_Q14[i] = ctl->LF_shp_Q14[i];
-               q->fr.Gains_Q16[i] = ctl->Gains_Q16[i]; q->fr.pitchL[i] = ctl->pitchL[i]; q->GainsUnq_Q16[i] = ctl->GainsUnq_Q16[i];
-            }
-            FOR_LANES(i, c->frame_length) q->x16[i] = x_frame[i];
-            sh_copy_words((i32 *)&q->indices, (const WV_LDS i32 *)&c->indices, (int)(sizeof(OaSilkEncIndices) / 4));
-            if (wv_lane() == 0) {
-               q->fr.signalType = c->indices.signalType; q->fr.quantOffsetType = c->indices.quantOffsetType; q->fr.NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2; q->fr.Seed = c->indices.Seed;
-               q->fr.Lambda_Q10 = ctl->Lambda_Q10; q->fr.LTP_scale_Q14 = ctl->LTP_scale_Q14;
-               q->cfg.fs_kHz = c->fs_kHz; q->cfg.nb_subfr = c->nb_subfr; q->cfg.predictLPCOrder = c->predictLPCOrder; q->cfg.shapingLPCOrder = c->shapingLPCOrder;
-               q->cfg.nStatesDelayedDecision = c->nStatesDelayedDecision; q->cfg.warping_Q16 = c->warping_Q16;
-               q->lastGainIndexPrev = ctl->lastGainIndexPrev; q->LastGainIndex = c->LastGainIndex; q->condCoding = p.condCoding; q->maxBits = p.maxBits; q->useCBR = p.useCBR;
-               q->ec_prevLagIndex = c->ec_prevLagIndex; q->ec_prevSignalType = c->ec_prevSignalType; q->chan = n;
-               q->nsq_reset = c->nsq_reset_req; c->nsq_reset_req = 0;                          /* the quantiser kernel starts this channel's state over (se_nsq_apply_reset_wave on the one-kernel path) */
-               q->lbrr_on = c->LBRR_enabled && c->speech_activity_Q8 > SE_FIX(0.3f, 8); q->LBRR_GainIncreases = c->LBRR_GainIncreases;      /* (encode_frame_FIX.c:392-398; the frame is the packet's only one: nFramesEncoded == 0) */
-            }
-         }
-         wv_sync();
-         se_frame_finish_wave(S, c, &L->ec);
-         nq++;
-      }
-      wv_sync();
-      LANE0 { E->ch[n].controlled_since_last_payload = 0; E->ch[n].inputBufIx = 0; E->ch[n].nFramesEncoded++; }
-   }
-   LANE0 se_call_frame_tail_l0(S, &sc, &L->ec, SH_PKT(L) + 1, 1, 0, 1);
-   se_call_epilogue_wave(S, &sc, 0, &k);
-   /* ---- the call so far -> HBM: the continuation record, the SILK state ---- */
-   wv_sync();
-   sh_copy_words((i32 *)&ct->sh, (const WV_LDS i32 *)sh, (int)(sizeof(ShShared) / 4));
-   sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
-   sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
-   sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), fec_ok ? (int)((wv_uni((i32)L->ec.offs) + 11) / 4) : SH_FRONT_PKT_BYTES / 4);        /* (the header symbols: a handful of bytes at most -- with in-band FEC: + the side stream; the quantiser kernel's lanes code on from there, in HBM) */
-   se_state_copy_wave((i32 *)&gs->silk, (const WV_LDS i32 *)se_st(S), CC, 0);
-   if (wv_lane() == 0) {
-      ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = nq;
-      ct->silk_flags = S->r[7]; ct->silk_dtx = S->r[8]; ct->silk_flag_bits = (c0->nFramesPerPacket + 1) * sc.nChannelsInternal;
-   }
-   wv_sync();
 }
 
 /* ---------------- pred (pipeline mode 3) ---------------- */
