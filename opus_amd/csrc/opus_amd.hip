@@ -303,6 +303,28 @@ oa_sh_front_kernel(OaShStream *streams, const i16 *pcm, const i32 *apcm, int fra
    }
    if (threadIdx.x == 0 && seen) { atomicAdd(counters + 16, kept); atomicAdd(counters + 17, seen - kept); }     /* running totals of the batch (opusgpu_enc_batch_split_stats) */
 }
+/* a 40 / 60 ms SILK packet's second / third frame (oa_sh_front_cont_frame): every stream of the launch the front kernel kept, after the quantiser kernel coded the frame before */
+extern "C" __global__ void __launch_bounds__(64, OA_SH_FRONT_WAVES_PER_EU)
+oa_sh_frontc_kernel(OaShStream *streams, int frame_size, char *pcm_hp_all, ShCont *conts, int *slow_list, unsigned *counters, int nstreams, int pkt_off, int pred_split, int block)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS ShLds *L = (WV_LDS ShLds *)smem;
+   for (;;) {
+      const int s = oa_queue_pop(counters);
+      if (s >= nstreams) break;
+      if (wv_uni(conts[s].kind) != SH_CONT_FAST || wv_uni(conts[s].k.tot_blocks) <= block || wv_uni(conts[s].k.curr_block) != block) continue;
+      OaShStream *gs = streams + s;
+      const int ch = gs->cfg.channels;
+      if (threadIdx.x == 0) { L->packet_off = pkt_off; L->S.st_off = (i32)SE_FRONT_ST_OFF; }
+      __syncthreads();
+      oa_sh_front_cont_frame(L, gs, frame_size, (const i16 *)(pcm_hp_all + (size_t)s * SH_PCM_BYTES(frame_size, ch)), conts + s, block, pred_split);
+      __syncthreads();
+      if (pred_split && threadIdx.x == 0 && conts[s].nq > 0) {
+         const int nq = conts[s].nq; const unsigned at = atomicAdd(counters + 6, (unsigned)nq);
+         for (int j = 0; j < nq; j++) slow_list[nstreams + at + j] = 2 * s + j;
+      }
+   }
+}
 /* pipeline mode 3: the prediction stage of every coded channel the front kernel kept (oa_sh_pred_frame, opus_sh_split.h), persistent, 8 waves per SIMD */
 #ifndef OA_SH_PRED_WAVES_PER_EU
 #define OA_SH_PRED_WAVES_PER_EU 8
@@ -868,7 +890,7 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (lds_front < offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds)) lds_front = offsetof(ShLds, S) + offsetof(SilkEncLds, u) + sizeof(AnLds);
    /* a batch with in-band FEC on somewhere: the front kernel codes the previous packet's LBRR side stream at the head of the packet, which can be most of a packet: full window */
    if (b->any_fec < 0) { int f = 0; for (opus_int32 i = 0; !f && i < b->S; i++) f = b->h_sh[i].cfg.use_inband_fec != 0; b->any_fec = f; }
-   const int pkt_window = b->any_fec && mode != 2 /* (the one-wave-per-stream reference quantiser of value 2 has no LBRR pass: those calls stay on the one-kernel path) */ ? (int)SH_PKT_BYTES : (int)SH_FRONT_PKT_BYTES;
+   const int pkt_window = (b->any_fec || frame_size * 50 > b->Fs) && mode != 2 /* (the one-wave-per-stream reference quantiser of value 2 has no LBRR pass: those calls stay on the one-kernel path) */ ? (int)SH_PKT_BYTES : (int)SH_FRONT_PKT_BYTES;
    const int po_front = (int)al16(lds_front); lds_front = po_front + pkt_window;
    /* the back kernel enters the CELT arena for hybrid frames AND for the redundant CELT frame that announces a SILK bandwidth switch (opus_encoder.c:2251-2260), which a
     * stream pinned to SILK-only can still ask for: only RESTRICTED_SILK never does */
@@ -902,6 +924,15 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    hipLaunchKernelGGL(oa_sh_front_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s,
          b->d_sh, (const i16 *)d_pcm, (const i32 *)d_apcm, frame_size, (int)max_data_bytes, b->d_pcm_hp, (CeltScratch *)b->d_scratch, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, pcm_row, mode == 4 ? 2 : pred_split, pkt_window);
    oa_stamp(b, s, "oa_sh_front_kernel");
+   /* a 40 / 60 ms call: the SILK-only packets among its streams code two / three 20 ms frames on one coder -- the pred / quantiser stages run once per frame, with
+    * oa_sh_frontc_kernel (the next frame's analysis) in between; every other stream of such a launch was handed to the one-kernel path by the front kernel */
+   const int nblk = frame_size * 50 > b->Fs ? frame_size * 50 / b->Fs : 1;
+   for (int blk = 0; blk < nblk; blk++) {
+   if (blk > 0) {
+      HIPCHECK(hipMemsetAsync(b->d_queue, 0, 2 * sizeof(unsigned), s)); HIPCHECK(hipMemsetAsync(b->d_queue + 5, 0, 2 * sizeof(unsigned), s));
+      hipLaunchKernelGGL(oa_sh_frontc_kernel, dim3((unsigned)g_front), dim3(64), lds_front, s, b->d_sh, frame_size, b->d_pcm_hp, b->d_cont, b->d_slow_list, b->d_queue, n, po_front, mode == 4 ? 2 : pred_split, blk);
+      oa_stamp(b, s, "oa_sh_frontc_kernel");
+   }
    if (mode == 4) {
       const int *pl = (const int *)(b->d_slow_list + n); const unsigned *pc = (const unsigned *)(b->d_queue + 6);
       hipLaunchKernelGGL(oa_sh_preda_kernel, dim3((unsigned)g_pa), dim3(64), lds_pa, s, b->d_cont, pl, pc);
@@ -913,11 +944,12 @@ static int oa_sh_encode_split(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const
    if (mode == 2) hipLaunchKernelGGL(oa_sh_quant0_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue, po_full);
    else hipLaunchKernelGGL(oa_sh_quant_kernel, dim3((unsigned)g_quant), dim3(64), lds_q, s, b->d_sh, b->d_cont, n, b->d_scratch, b->d_queue);
    oa_stamp(b, s, pred_split ? "oa_sh_pred_kernel+oa_sh_quant_kernel" : "oa_sh_quant_kernel");
+   }
    /* the CELT layer's transient recursions on lanes first (48 kHz, AUDIO / VOIP: frames with a CELT layer); OPUS_AMD_TR_PRE=0 keeps them in the back kernel */
    static const int tr_env = getenv("OPUS_AMD_TR_PRE") ? atoi(getenv("OPUS_AMD_TR_PRE")) : 1;               /* (process default behind OPUS_AMD_SET_TRANSIENT_PREPASS(-1)) */
    const int tr_on = b->tr_pre >= 0 ? b->tr_pre : tr_env;
    const i32 *d_tr = nullptr;
-   if (tr_on && b->Fs == 48000 && b->application != OPUS_APPLICATION_RESTRICTED_SILK && !silk_only) {
+   if (tr_on && b->Fs == 48000 && b->application != OPUS_APPLICATION_RESTRICTED_SILK && !silk_only && nblk == 1 /* (a 40 / 60 ms launch keeps SILK-only packets only: no CELT layer to prepare) */) {
       const int items = n * ch, tiles = (items + 63) / 64;
       const int g = tiles < 8 * (b->num_cu > 0 ? b->num_cu : 1) ? tiles : 8 * (b->num_cu > 0 ? b->num_cu : 1);
       const size_t need_tr = (size_t)g * (OA_MAX_FRAME + OA_OVERLAP) * 64 * sizeof(i16);
@@ -1032,7 +1064,7 @@ static int oa_encode_launch(OpusGpuEncBatch *b, const opus_int16 *d_pcm, const o
       static const int split_env = getenv("OPUS_AMD_SH_SPLIT") ? atoi(getenv("OPUS_AMD_SH_SPLIT")) : -1;
       const int split_mode = b->pipeline >= 0 ? b->pipeline : split_env >= 0 ? split_env : (b->n_act >= 64 ? 4 : 0);
       b->pvq4_last = 0;
-      if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs)) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
+      if (split_mode && !subset && (frame_size * 100 == b->Fs || frame_size * 50 == b->Fs || (split_mode != 2 && (frame_size * 25 == b->Fs || frame_size * 50 == 3 * b->Fs)))) return oa_sh_encode_split(b, d_pcm, d_apcm, frame_size, d_out, out_stride, max_data_bytes, d_lens, d_final_range, s, lds, silk_only, split_mode, pcm_row);
       int grid = 0;
       { const int r = oa_persistent_grid(b, (const void *)oa_sh_encode_kernel, lds_pk, SH_SCRATCH_BYTES(frame_size, b->channels), s, &grid); if (r != OPUS_OK) return r; }
       hipLaunchKernelGGL(oa_sh_encode_kernel, dim3((unsigned)grid), dim3(64), lds_pk, s,

@@ -157,11 +157,14 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    sh_call_open_wave(L, gs, pcm, frame_size, max_data_bytes, cs, apcm, 0, analysis_frame_size);
    const int CC = L->cfg.channels, Fs = L->cfg.Fs;
    const int celt_only = wv_uni(st->mode) == OA_MODE_CELT_ONLY;
+   /* a SILK-only call of 40 / 60 ms is ONE Opus frame whose SILK layer codes two / three 20 ms frames on one coder (nFramesPerPacket, enc_API.c:283-560): the pipeline runs its
+    * front -> pred -> quantiser relay once per frame (oa_sh_front_cont_frame takes the later ones) -- with the full packet window, which later frames code into */
+   const int silk_multi = fec_ok && wv_uni(st->mode) == OA_MODE_SILK_ONLY && (frame_size * 25 == Fs || frame_size * 50 == 3 * Fs);
    {
       /* a CELT-only frame (the call's decision: opus_encoder.c:1413-1470) has no SILK layer at all: it skips the quantiser stage and is coded whole by the back kernel, at that
        * kernel's occupancy instead of the one-kernel path's */
       const int simple = !wv_uni(sh->err) && !wv_uni(sh->plc_frame) && wv_uni(sh->nb_frames) == 1 && !wv_uni(sh->prefill) && !wv_uni(st->silk_bw_switch) &&
-                         (fec_ok || !wv_uni(L->cfg.use_inband_fec)) && wv_uni(L->cfg.complexity) >= 2 && (celt_only || frame_size * 100 == Fs || frame_size * 50 == Fs);
+                         (fec_ok || !wv_uni(L->cfg.use_inband_fec)) && wv_uni(L->cfg.complexity) >= 2 && (celt_only || frame_size * 100 == Fs || frame_size * 50 == Fs || silk_multi);
       if (!simple) { sh_front_decline(ct, slow_list, slow_count, s); return; }
    }
    LANE0 { sh->f_redundancy = sh->redundancy; sh->f_celt_to_silk = sh->celt_to_silk; sh->f_prefill = sh->prefill; sh->f_to_celt = sh->to_celt; sh->f_silence = sh->is_silence; st->nonfinal_frame = 0; }
@@ -175,7 +178,7 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
       sh_copy_words((i32 *)&ct->st, (const WV_LDS i32 *)st, (int)(sizeof(OaShScalars) / 4));
       sh_copy_words((i32 *)&ct->ec, (const WV_LDS i32 *)&L->ec, (int)(sizeof(EcCtx) / 4));
       sh_copy_words((i32 *)ct->packet, (const WV_LDS i32 *)SH_PKT(L), SH_FRONT_PKT_BYTES / 4);
-      if (wv_lane() == 0) { ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = 0; ct->silk_flags = 0; ct->silk_dtx = 0; ct->silk_flag_bits = 0; }
+      if (wv_lane() == 0) { ct->sc = sc; ct->kind = SH_CONT_FAST; ct->nq = 0; ct->silk_flags = 0; ct->silk_dtx = 0; ct->silk_flag_bits = 0; ct->k.tot_blocks = 1; ct->k.curr_block = 1; }
       wv_sync();
       return;
    }
@@ -184,19 +187,45 @@ WV_DEVN void oa_sh_front_frame(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm, 
    if (se_call_prologue_wave(S, &sc, frame_size, 0, &k)) { sh_front_decline(ct, slow_list, slow_count, s); return; }
    WV_LDS OaSilkEncChannel *c0 = &E->ch[0];
    {
-      int ok = k.tot_blocks == 1 && wv_uni(c0->inputBufIx) == 0 && wv_uni(c0->nFramesPerPacket) == 1;
+      const int nblk = silk_multi ? frame_size * 50 / Fs : 1;
+      int ok = k.tot_blocks == nblk && wv_uni(c0->inputBufIx) == 0 && wv_uni(c0->nFramesPerPacket) == nblk;
       for (int n = 0; n < sc.nChannelsInternal; n++) ok = ok && (fec_ok || !wv_uni(E->ch[n].LBRR_enabled)) && (wv_uni(E->ch[n].nStatesDelayedDecision) > 1 || wv_uni(E->ch[n].warping_Q16) > 0);
       /* the previous packet's LBRR side stream is still owed (enc_API.c:364-404 codes it at the head of this packet whatever the FEC setting is now -- the first frame after
        * OPUS_SET_INBAND_FEC goes 1 -> 0): indices and pulses of up to three frames do not fit the front kernel's SH_FRONT_PKT_BYTES window, the one-kernel path codes this call */
       if (!fec_ok) for (int n = 0; n < sc.nChannelsInternal; n++) for (int i = 0; i < 3; i++) ok = ok && !wv_uni(E->ch[n].LBRR_flags[i]);
       const int nSamplesToBuffer = imin(wv_uni(c0->frame_length) - wv_uni(c0->inputBufIx), k.nSamplesToBufferMax);
       const int nSamplesFromInput = (nSamplesToBuffer * wv_uni(c0->API_fs_Hz)) / (wv_uni(c0->fs_kHz) * 1000);
-      ok = ok && nSamplesFromInput == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
+      ok = ok && nSamplesFromInput * nblk == frame_size && nSamplesToBuffer == wv_uni(c0->frame_length);
       if (sc.nChannelsInternal == 2) ok = ok && wv_uni(E->ch[1].inputBufIx) == 0;
-      const int last = k.tot_blocks == 1;
+      const int last = k.tot_blocks == 1;                                          /* (a 40 / 60 ms SILK packet: the first of its frames; the call's input starts at pcm_hp) */
       if (!ok) { sh_front_decline(ct, slow_list, slow_count, s); return; }
       sh_front_silk_block(L, gs, pcm_hp, ct, sc, k, nSamplesFromInput, nSamplesToBuffer, last, pred_split, fec_ok);
    }
+}
+
+/* the later 20 ms frames of a 40 / 60 ms SILK packet: the wave takes the call up again from the continuation record (Opus-layer scalars, coder, loop variables) and the stream
+ * record (the SILK state as the front and quantiser kernels of the frame before left it), and runs the next block.  The packet bytes written so far come into the LDS window:
+ * the frame's header symbols continue the coder where the quantiser kernel left it. */
+WV_DEVN void oa_sh_front_cont_frame(WV_LDS ShLds *L, OaShStream *gs, int frame_size, const i16 *pcm_hp, ShCont *ct, int block, int pred_split)
+{
+   WV_LDS ShShared *sh = &L->sh; WV_LDS OaShScalars *st = &L->st;
+   WV_LDS SilkEncLds *S = &L->S;
+   LANE0 { L->silk_tail = 0; S->st_off = (i32)SE_FRONT_ST_OFF; }
+   wv_sync();
+   sh_copy_words((WV_LDS i32 *)&L->cfg, (const i32 *)&gs->cfg, (int)(sizeof(OaShConfig) / 4));
+   sh_copy_words((WV_LDS i32 *)sh, (const i32 *)&ct->sh, (int)(sizeof(ShShared) / 4));
+   sh_copy_words((WV_LDS i32 *)st, (const i32 *)&ct->st, (int)(sizeof(OaShScalars) / 4));
+   sh_copy_words((WV_LDS i32 *)&L->ec, (const i32 *)&ct->ec, (int)(sizeof(EcCtx) / 4));
+   wv_sync();
+   const int CC = L->cfg.channels;
+   se_state_copy_wave((WV_LDS i32 *)se_st(S), (const i32 *)&gs->silk, CC, 0);
+   sh_copy_words((WV_LDS i32 *)SH_PKT(L), (const i32 *)ct->packet, (int)((wv_uni((i32)L->ec.offs) + 8) / 4));
+   wv_sync();
+   SeControl sc = ct->sc;
+   SeCall k = ct->k;
+   const int nSamplesFromInput = wv_uni(ct->blk_from_input), nSamplesToBuffer = wv_uni(ct->blk_to_buffer);
+   (void)frame_size;
+   sh_front_silk_block(L, gs, pcm_hp + (size_t)block * nSamplesFromInput * sc.nChannelsAPI, ct, sc, k, nSamplesFromInput, nSamplesToBuffer, k.curr_block == k.tot_blocks - 1, pred_split, 1);
 }
 
 /* ---------------- pred (pipeline mode 3) ---------------- */
@@ -680,9 +709,12 @@ WV_DEV void sq_lbrr_pre(WV_LDS SqStream *me, const ShQuantCh *job)
    WV_LDS i32 *wk = (WV_LDS i32 *)me->wk; const WV_LDS i32 *ixw = (const WV_LDS i32 *)&me->ix;
    for (int k = 0; k < 4; k++) wk[k] = me->fr.Gains_Q16[k];
    for (int k = 0; k < (int)(sizeof(OaSilkEncIndices) / 4); k++) wk[4 + k] = ixw[k];
-   /* first frame of the packet (the only one here): LBRRprevLastGainIndex = LastGainIndex, the first index raised (:404-410) */
-   int prev = me->LastGainIndex;
-   me->ix.GainsIndices[0] = (i8)imin(me->ix.GainsIndices[0] + job->LBRR_GainIncreases, 64 - 1);
+   /* first frame of the packet, or no LBRR frame before this one: LBRRprevLastGainIndex = LastGainIndex, the first index raised (:404-410) */
+   int prev = job->LBRRprevLastGainIndex;
+   if (job->lbrr_fi == 0 || job->lbrr_prev_flag == 0) {
+      prev = me->LastGainIndex;
+      me->ix.GainsIndices[0] = (i8)imin(me->ix.GainsIndices[0] + job->LBRR_GainIncreases, 64 - 1);
+   }
    i32 g[4]; i8 gi[4];
    for (int k = 0; k < 4; k++) gi[k] = me->ix.GainsIndices[k];
    se_gains_dequant(g, gi, &prev, me->rc.condCoding == SE_CODE_CONDITIONALLY, me->nb_subfr);
@@ -693,16 +725,16 @@ WV_DEV void sq_lbrr_pre(WV_LDS SqStream *me, const ShQuantCh *job)
 /* ... and after the pass (the quad's four lanes): pulses and indices into the side-stream store, the flag and the gain predictor into the channel record, the stream's own values back */
 WV_DEV void sq_lbrr_post(WV_LDS SqStream *me, const ShQuantCh *job, OaSilkLbrr *lb, OaSilkEncChannel *gc, int kk)
 {
-   const int frame_length = me->nb_subfr * 5 * me->fs_kHz, chn = job->chan, NIX = (int)(sizeof(OaSilkEncIndices) / 4);
-   { i32 *d = (i32 *)lb->pulses[chn][0]; const WV_LDS i32 *g = (const WV_LDS i32 *)me->pulses; for (int i = kk; i < frame_length / 4; i += 4) d[i] = g[i]; }
-   { i32 *d = (i32 *)&lb->indices[chn][0]; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->ix; for (int i = kk; i < NIX; i += 4) d[i] = g[i]; }
+   const int frame_length = me->nb_subfr * 5 * me->fs_kHz, chn = job->chan, fi = job->lbrr_fi, NIX = (int)(sizeof(OaSilkEncIndices) / 4);
+   { i32 *d = (i32 *)lb->pulses[chn][fi]; const WV_LDS i32 *g = (const WV_LDS i32 *)me->pulses; for (int i = kk; i < frame_length / 4; i += 4) d[i] = g[i]; }
+   { i32 *d = (i32 *)&lb->indices[chn][fi]; const WV_LDS i32 *g = (const WV_LDS i32 *)&me->ix; for (int i = kk; i < NIX; i += 4) d[i] = g[i]; }
 }
-WV_DEV void sq_lbrr_restore(WV_LDS SqStream *me, OaSilkEncChannel *gc, int kk)
+WV_DEV void sq_lbrr_restore(WV_LDS SqStream *me, const ShQuantCh *job, OaSilkEncChannel *gc, int kk)
 {
    const int NIX = (int)(sizeof(OaSilkEncIndices) / 4);
    if (kk == 0) {
       WV_LDS i32 *wk = (WV_LDS i32 *)me->wk; WV_LDS i32 *ixw = (WV_LDS i32 *)&me->ix;
-      gc->LBRR_flags[0] = 1; gc->LBRRprevLastGainIndex = wk[4 + NIX];
+      gc->LBRR_flags[job->lbrr_fi] = 1; gc->LBRRprevLastGainIndex = wk[4 + NIX];
       for (int k = 0; k < 4; k++) me->fr.Gains_Q16[k] = wk[k];
       for (int k = 0; k < NIX; k++) ixw[k] = wk[4 + k];
    }
@@ -777,7 +809,7 @@ WV_DEV void sq_quant_tile_wave(WV_LDS SqLds *Q, OaShStream *streams, ShCont *con
          }
          if (lb_on) sq_lbrr_post(me, job, &streams[sidx].lbrr, gc, kk);
          wv_sync();
-         if (lb_on) sq_lbrr_restore(me, gc, kk);
+         if (lb_on) sq_lbrr_restore(me, job, gc, kk);
          wv_sync();
       }
       /* the rate-control loop of silk_encode_frame_FIX (:170-370), one lane (kk == 0) per stream; the loop itself is the wave's, a stream that has converged sits out */

@@ -21,6 +21,10 @@ CASES = {   # name: (Fs, channels, application, streams, frames, ms, {ctl: value
     "config3_fec":  (16000, 1, 2048, 9, 12, 20, {4002: 24000, 4010: 10, 11002: 1000, 11900: 0, 4012: 1, 4014: 10}, {1: {4014: 25}, 2: {4002: 40000}, 3: {4010: 5}}),      # in-band FEC through the pipeline (round 6): the LBRR pass in the quantiser kernel, the side stream at the head of the next packet
     "stereo_fec":   (48000, 2, 2049, 6, 12, 20, {4002: 36000, 4010: 10, 4012: 1, 4014: 15}, {1: {4002: 20000}, 2: {4012: 2}, 3: {4006: 0}}),
     "fec_10ms":     (16000, 1, 2048, 5, 16, 10, {4002: 20000, 4010: 8, 11002: 1000, 4012: 1, 4014: 20}, {}),
+    "silk_60ms":    (16000, 1, 2048, 7, 8, 60, {4002: 24000, 4010: 10, 11002: 1000, 11900: 0}, {1: {4002: 14000}, 2: {4006: 0}, 3: {4010: 4}, 4: {4016: 1}}),      # 40 / 60 ms SILK packets through the pipeline (round 6): the front -> pred -> quantiser relay once per 20 ms frame
+    "silk_40ms_fec": (16000, 1, 2048, 6, 10, 40, {4002: 28000, 4010: 10, 11002: 1000, 4012: 1, 4014: 15}, {1: {4014: 30}, 2: {4002: 16000}}),
+    "stereo_60ms":  (24000, 2, 2048, 5, 6, 60, {4002: 30000, 4010: 9, 11002: 1000, 4008: 1103}, {1: {4012: 1, 4014: 10}, 2: {4002: 18000}}),
+    "audio_40ms":   (48000, 2, 2049, 5, 8, 40, {4002: 24000, 4010: 10}, {1: {4002: 64000}, 2: {11002: 1000, 4008: 1103}}),
     "voip_auto":    (16000, 1, 2048, 5, 10, 20, {4002: 16000, 4010: 10}, {}),
     "cbr_12k":      (16000, 1, 2048, 6, 10, 20, {4002: 12000, 4010: 8, 4006: 0, 11002: 1000, 11900: 0}, {}),
     "tight_cvbr":   (16000, 1, 2048, 6, 10, 20, {4002: 9000, 4010: 6, 11002: 1000, 11900: 0}, {}),
