@@ -31,9 +31,9 @@ CONFIGS = {
     4: dict(name="hybrid encode, AUDIO, 48 kHz stereo, 20 ms, fullband, VBR 128 kb/s, complexity 10", app=2049, Fs=48000, ch=2, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel (one call)",
             ctls=((11002, 1001), (4008, 1105), (4006, 1), (4002, 128000), (4010, 10)), metric="encoded frames/s (hybrid, 48 kHz stereo, 20 ms, complexity 10)"),
     # what a VoIP deployment of config 3 also runs (not BASELINE.json rows; "extra" legs of the default line): in-band FEC at 10 % expected loss, and 60 ms packets
-    31: dict(name="config 3 + OPUS_SET_INBAND_FEC(1), OPUS_SET_PACKET_LOSS_PERC(10)", app=2048, Fs=16000, ch=1, kernel="the SILK-capable pipeline / one-kernel path (LBRR)", key="config_3_fec",
+    31: dict(name="config 3 + OPUS_SET_INBAND_FEC(1), OPUS_SET_PACKET_LOSS_PERC(10)", app=2048, Fs=16000, ch=1, kernel="the SILK-capable pipeline (the LBRR pass in the quantiser kernel)", key="config_3_fec",
              ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10), (4012, 1), (4014, 10)), metric="encoded frames/s (SILK-only + in-band FEC, 16 kHz mono, 20 ms, complexity 10)"),
-    32: dict(name="config 3 in 60 ms packets (three SILK frames per call)", app=2048, Fs=16000, ch=1, frame_ms=60, kernel="oa_sh_encode_kernel (one-kernel path: multi-frame packets)", key="config_3_60ms",
+    32: dict(name="config 3 in 60 ms packets (three SILK frames per call)", app=2048, Fs=16000, ch=1, frame_ms=60, kernel="the SILK-capable pipeline, its front -> pred -> quantiser relay once per 20 ms frame", key="config_3_60ms",
              ctls=((11002, 1000), (4008, 1103), (4002, 24000), (4010, 10)), metric="encoded 60 ms packets/s (SILK-only, 16 kHz mono, complexity 10); x 3 = 20 ms frames/s"),
     5: dict(name="multistream, 255 mono AUDIO streams per encoder (mapping family 255), 48 kHz, 20 ms, 64 kb/s per stream, complexity 10; 257 encoders = 65,535 elementary streams",
             app=2049, Fs=48000, ch=1, kernel="oa_sh_front_kernel + the pred stage's four kernels + oa_sh_quant_kernel + oa_sh_back_kernel", ctls=((4002, 64000), (4010, 10)), metric="encoded elementary-stream frames/s (255-channel multistream, 48 kHz, 20 ms, complexity 10)"),
