@@ -36,6 +36,8 @@ def check(which, name, Fs, ch, app, ctl, frames=12):
     return snr
 
 
+HAND_PICKED = ["auto_switching_stereo", "celt_fb_20ms_stereo", "celt_fb_60ms_stereo", "celt_nb_5ms_mono", "celt_wb_2p5ms_mono", "hybrid_fb_10ms_stereo", "hybrid_fb_20ms_cbr", "hybrid_swb_20ms_mono",
+               "silk_mb_40ms_mono", "silk_nb_20ms_mono", "silk_wb_10ms_fec", "silk_wb_20ms_dtx", "silk_wb_60ms_stereo"]
 def compare_gate(which, tmp, names=None, rates=((48000, 2), (48000, 1), (24000, 2), (16000, 1), (8000, 1))):
     import glob, os, re, struct, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

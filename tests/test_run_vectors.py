@@ -13,8 +13,10 @@ def _go(which, Fs, ch, files=FILES):
     npk, bad, _ = run_vectors_gpu.run(files, Fs, ch, which)
     assert npk > 100 and bad == 0, (npk, bad)
 
-def test_emu_vectors_48k_stereo(): _go("emu", 48000, 2)
-def test_emu_vectors_16k_mono(): _go("emu", 16000, 1, FILES[::3])
+HAND = [f for f in FILES if not os.path.basename(f).startswith("mx_")]      # the 13 hand-picked files; mx_*: the 3 x 13 rows of the Encode+Decode matrix of tests/test_opus_encode.c:420-512 (tools/gen_bit_vectors.py)
+def test_emu_vectors_48k_stereo(): _go("emu", 48000, 2, HAND)
+def test_emu_vectors_16k_mono(): _go("emu", 16000, 1, HAND[::3])
+def test_emu_vectors_reference_matrix(): _go("emu", 48000, 2, [f for f in FILES if os.path.basename(f).startswith("mx_")])
 @pytest.mark.gpu
 @pytest.mark.parametrize("Fs,ch", [(48000, 2), (48000, 1), (24000, 2), (16000, 1), (8000, 2)])
 def test_gpu_vectors(Fs, ch): _go("gpu", Fs, ch)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/gen_bit_vectors.py — config 1 stand-in vectors: the RFC 8251 test vectors are not on this box (no network), so this script produces `.bit` files in
 opus_demo's framing (src/opus_demo.c:1102-1112: per packet a 4-byte big-endian length, the 4-byte big-endian encoder final range, the payload) with the COMPILED
-REFERENCE ENCODER over the mode matrix of tests/test_opus_encode.c:330-512 (modes x bandwidths x frame sizes, mono / stereo, VBR / CBR, in-band FEC, DTX).  Runs where
+REFERENCE ENCODER over the mode matrix of tests/test_opus_encode.c:330-512 (modes x bandwidths x frame sizes, mono / stereo, VBR / CBR, in-band FEC, DTX: 13 hand-picked files, and -- round 6, `mx_*` -- the 3 x 13 rows of that test's own tables).  Runs where
 oracle/_ref/libopus_ref_fx.so exists; the small files it writes to tests/golden/bitstreams/ are committed (they travel to the GPU box) together with this generator.
 When real vectors are supplied, tools/run_vectors_gpu.py takes their directory instead."""
 import os, struct, sys, zlib, numpy as np
@@ -26,12 +26,25 @@ MATRIX = [  # name, application, channels, frame (samples @48k), ctls
     ("celt_fb_60ms_stereo", 2051, 2, 2880, dict(bitrate=96000)),
     ("auto_switching_stereo", 2049, 2, 960, dict(bitrate=24000)),
 ]
+# the Encode+Decode matrix of tests/test_opus_encode.c:420-512 itself: rc = 0 VBR + in-band FEC, 1 constrained VBR, 2 hard CBR; the 13 (mode, rate, frame) rows of its tables;
+# bandwidth, complexity, DTX and loss percentage -- drawn at random there -- walk through their ranges deterministically here; force_channels by rate as there
+REF_MODES = [0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2]
+REF_RATES = [6000, 12000, 48000, 16000, 32000, 48000, 64000, 512000, 13000, 24000, 48000, 64000, 96000]
+REF_FRAME = [960 * 2, 960, 480, 960, 960, 960, 480, 960 * 3, 960 * 3, 960, 480, 240, 120]
+for rc in range(3):
+    for j in range(13):
+        mode = REF_MODES[j]
+        bw = (1101 + (j + rc) % 3) if mode == 0 else (1104 + (j + rc) % 2) if mode == 1 else (1101 + (2 * j + rc) % 5)
+        if bw == 1102 and mode == 2: bw = 1101                                   # (CELT has no mediumband)
+        MATRIX.append(("mx_rc%d_%s_%d_%d" % (rc, ("silk", "hybrid", "celt")[mode], REF_RATES[j], REF_FRAME[j]), 2049, 2, REF_FRAME[j],
+                       dict(vbr=int(rc < 2), vbr_constraint=int(rc == 1), inband_fec=int(rc == 0), force_mode=1000 + mode, dtx=(j + rc) & 1, bitrate=REF_RATES[j] + (7919 * (j + 3 * rc)) % REF_RATES[j],
+                            force_channels=2 if REF_RATES[j] >= 64000 else 1, complexity=(3 * j + 5 * rc) % 11, packet_loss=(5 * j + rc) % 15, bandwidth=bw)))
 SWITCH = {"auto_switching_stereo": {10: dict(bitrate=96000), 20: dict(bitrate=16000, force_mode=1000), 30: dict(force_mode=1002), 40: dict(force_mode=1001, bandwidth=1105, bitrate=64000)}}
 
 def main(outdir=os.path.join(ROOT, "tests/golden/bitstreams"), seconds=1.0):
     os.makedirs(outdir, exist_ok=True)
     for name, app, ch, fr, ctl in MATRIX:
-        n = max(8, int(seconds * 48000 / fr))
+        n = max(8, int((0.3 if name.startswith("mx_") else seconds) * 48000 / fr))
         sig = speechy(n * fr // 960 + 2, ch, zlib.crc32(name.encode()) % 97, 960) if app != 2051 else signals.music(n * fr // 960 + 2, 960, ch, zlib.crc32(name.encode()) % 97)
         e = capi.Enc("ref", 48000, ch, app, **ctl)
         with open(os.path.join(outdir, name + ".bit"), "wb") as f:
