@@ -613,7 +613,7 @@ def main():
         for cid in (3, 4):
             extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on, decode=True)
         for cid in (31, 32):
-            extras += run_config(cid, S if cid == 31 else max(64, S // 4), Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
+            extras += run_config(cid, S, Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
         extras += run_config(5, (a.streams // 255) * 255 if a.streams else 257 * 255, Kx, 2, dev, local, rank, world, with_cpu=cpu_on)
     steady = None
     ss_frames = a.steady_state if a.steady_state >= 0 else (500 if full else 0)

@@ -263,6 +263,8 @@ OPUS_AMD_EXPORT int opusgpu_time_decode_dev(OpusGpuDecBatch *b, const unsigned c
 OPUS_AMD_EXPORT int opusgpu_dec_batch_sync(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec);   /* decode_fec of the following decode calls (include/opus.h:516) */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fast_kernel(OpusGpuDecBatch *b, int enable);   /* 0: skip the CELT-only fast kernel (a batch without CELT-only packets saves its look at every stream); default 1; same output either way */
+OPUS_AMD_EXPORT int opusgpu_dec_batch_set_lane_kernel(OpusGpuDecBatch *b, int enable);   /* 0: skip oa_sdec_lane_kernel (the SILK steady state, one lane per stream: silk/dec_API.c:142 silk_Decode for 64 streams per wave); default 1; same output either way */
+OPUS_AMD_EXPORT int opusgpu_dec_batch_lane_stats(OpusGpuDecBatch *b, opus_uint32 *taken, opus_uint32 *handed_on);   /* the last call: packets oa_sdec_lane_kernel was given / of those, handed on to the general kernel (a redundant CELT frame behind the SILK data, src/opus_decoder.c:499-526) */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_reset(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);

@@ -105,6 +105,8 @@ def lib():
         L.opusgpu_dec_batch_create.restype = vp; L.opusgpu_dec_batch_create.argtypes = [i32, i32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.opusgpu_dec_batch_destroy.argtypes = [vp]
         if hasattr(L, "opusgpu_dec_batch_set_fast_kernel"): L.opusgpu_dec_batch_set_fast_kernel.argtypes = [vp, ctypes.c_int]
+        if hasattr(L, "opusgpu_dec_batch_set_lane_kernel"): L.opusgpu_dec_batch_set_lane_kernel.argtypes = [vp, ctypes.c_int]
+        if hasattr(L, "opusgpu_dec_batch_lane_stats"): L.opusgpu_dec_batch_lane_stats.argtypes = [vp, vp, vp]
         L.opusgpu_decode_batch.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp]
         L.opusgpu_decode_batch_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, vp]
         L.opusgpu_time_decode_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
@@ -286,6 +288,16 @@ class DecoderBatch:
     def set_fast_kernel(self, enable):
         """False: the following calls skip the CELT-only fast kernel (for batches that carry no CELT-only packets); the output is the same either way"""
         r = self._L.opusgpu_dec_batch_set_fast_kernel(self._b, 1 if enable else 0)
+        if r != OPUS_OK: raise OpusError(r)
+    def lane_stats(self):
+        """(packets of the last call given to the lane = stream SILK kernel, of those handed on to the general kernel)"""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        r = self._L.opusgpu_dec_batch_lane_stats(self._b, ctypes.byref(a), ctypes.byref(b))
+        if r != OPUS_OK: raise OpusError(r)
+        return a.value, b.value
+    def set_lane_kernel(self, enable):
+        """False: the following calls skip the lane = stream SILK kernel (oa_sdec_lane_kernel); the output is the same either way"""
+        r = self._L.opusgpu_dec_batch_set_lane_kernel(self._b, 1 if enable else 0)
         if r != OPUS_OK: raise OpusError(r)
     def decode_dev(self, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream=None):
         r = self._L.opusgpu_decode_batch_dev(self._b, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream)

@@ -1,11 +1,12 @@
 /* celt_ecdec.h — range decoder on the register-resident EcCtx (lane-0 serial code), mirror of celt_ec.h.
- * Semantics: celt/entdec.c:91-266.  The frame's bytes sit in LDS (L->packet + 1), loaded once, coalesced. */
+ * Semantics: celt/entdec.c:91-266.  The frame's bytes sit in LDS (L->packet + 1), loaded once, coalesced -- or, for the lane = stream SILK decoder
+ * (silk_dec_lane.h), in the stream's packet slot in HBM: like the encoder's symbol coder the functions are generic over the byte pointer (ECB). */
 #ifndef OPUS_AMD_CELT_ECDEC_H
 #define OPUS_AMD_CELT_ECDEC_H
 #define DEC_CODE_EXTRA 7
-WV_DEV int ecd_read_front(EC_ARGS) { return e->offs < e->storage ? buf[e->offs++] : 0; }
-WV_DEV int ecd_read_back(EC_ARGS) { return e->end_offs < e->storage ? buf[e->storage - ++(e->end_offs)] : 0; }
-WV_DEV void ecd_normalize(EC_ARGS)
+template <class ECB> WV_DEV int ecd_read_front(EC_ARGS_G) { return e->offs < e->storage ? buf[e->offs++] : 0; }
+template <class ECB> WV_DEV int ecd_read_back(EC_ARGS_G) { return e->end_offs < e->storage ? buf[e->storage - ++(e->end_offs)] : 0; }
+template <class ECB> WV_DEV void ecd_normalize(EC_ARGS_G)
 {
    while (e->rng <= CODE_BOT) {
       int sym;
@@ -17,7 +18,7 @@ WV_DEV void ecd_normalize(EC_ARGS)
       e->val = ((e->val << SYM_BITS) + (SYM_MAX & ~sym)) & (CODE_TOP - 1);
    }
 }
-WV_DEV void k_ec_dec_init(EC_ARGS, u32 storage)
+template <class ECB> WV_DEV void k_ec_dec_init(EC_ARGS_G, u32 storage)
 {
    e->storage = storage; e->end_offs = 0; e->end_window = 0; e->nend_bits = 0;
    e->nbits_total = 32 + 1 - ((32 - DEC_CODE_EXTRA) / SYM_BITS) * SYM_BITS;
@@ -28,26 +29,26 @@ WV_DEV void k_ec_dec_init(EC_ARGS, u32 storage)
    e->error = 0; e->ext = 0;
    ecd_normalize(EC_PASS);
 }
-WV_DEV unsigned k_ec_decode(EC_ARGS, unsigned ft)
+template <class ECB> WV_DEV unsigned k_ec_decode(EC_ARGS_G, unsigned ft)
 {
    e->ext = e->rng / ft;
    unsigned s = (unsigned)(e->val / e->ext);
    return ft - (s + 1 < ft ? s + 1 : ft);
 }
-WV_DEV unsigned k_ec_decode_bin(EC_ARGS, unsigned bits)
+template <class ECB> WV_DEV unsigned k_ec_decode_bin(EC_ARGS_G, unsigned bits)
 {
    e->ext = e->rng >> bits;
    unsigned s = (unsigned)(e->val / e->ext);
    return (1U << bits) - (s + 1U < (1U << bits) ? s + 1U : (1U << bits));
 }
-WV_DEV void k_ec_dec_update(EC_ARGS, unsigned fl, unsigned fh, unsigned ft)
+template <class ECB> WV_DEV void k_ec_dec_update(EC_ARGS_G, unsigned fl, unsigned fh, unsigned ft)
 {
    u32 s = e->ext * (ft - fh);
    e->val -= s;
    e->rng = fl > 0 ? e->ext * (fh - fl) : e->rng - s;
    ecd_normalize(EC_PASS);
 }
-WV_DEV int k_ec_dec_bit_logp(EC_ARGS, unsigned logp)
+template <class ECB> WV_DEV int k_ec_dec_bit_logp(EC_ARGS_G, unsigned logp)
 {
    u32 r = e->rng, v = e->val, s = r >> logp;
    int ret = v < s;
@@ -56,7 +57,7 @@ WV_DEV int k_ec_dec_bit_logp(EC_ARGS, unsigned logp)
    ecd_normalize(EC_PASS);
    return ret;
 }
-WV_DEV int k_ec_dec_icdf(EC_ARGS, const u8 *icdf, unsigned ftb)
+template <class ECB> WV_DEV int k_ec_dec_icdf(EC_ARGS_G, const u8 *icdf, unsigned ftb)
 {
    u32 s = e->rng, v = e->val, r = s >> ftb, t;
    int ret = -1;
@@ -66,7 +67,7 @@ WV_DEV int k_ec_dec_icdf(EC_ARGS, const u8 *icdf, unsigned ftb)
    ecd_normalize(EC_PASS);
    return ret;
 }
-WV_DEV u32 k_ec_dec_bits(EC_ARGS, unsigned bits)
+template <class ECB> WV_DEV u32 k_ec_dec_bits(EC_ARGS_G, unsigned bits)
 {
    u32 window = e->end_window;
    int available = e->nend_bits;
@@ -79,7 +80,7 @@ WV_DEV u32 k_ec_dec_bits(EC_ARGS, unsigned bits)
    e->end_window = window; e->nend_bits = available; e->nbits_total += bits;
    return ret;
 }
-WV_DEV u32 k_ec_dec_uint(EC_ARGS, u32 ft_)
+template <class ECB> WV_DEV u32 k_ec_dec_uint(EC_ARGS_G, u32 ft_)
 {
    unsigned ft, s;
    int ftb;

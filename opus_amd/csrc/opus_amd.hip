@@ -28,6 +28,7 @@ __shared__ unsigned int oa_p4_prof[64];
 #endif
 #include "celt_enc_all.h"
 #include "celt_dec_all.h"
+#include "silk_dec_lane.h"
 #ifdef OA_PHASE_TIMERS
 /* SILK-capable kernel: shader-clock ticks between SE_PHASE marks (lane 0), summed over all waves */
 __device__ unsigned long long oa_sh_phase_ticks[24];
@@ -223,29 +224,66 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
       __syncthreads();
    }
 }
-/* The look that sorts a call's packets between the two decoder kernels, one LANE per stream (64 streams per wave, one ballot and one atomic per list and wave): a packet goes
- * to the fast kernel when its decode is the CELT steady state and nothing else -- a CELT-only TOC with one coded frame that fits a frame's slot, a stream whose last packet was
- * CELT-only too (or that has not decoded anything yet), no pending fold of the concealment.  A batch of SILK or hybrid packets pays 1,024 waves of a dozen instructions for
- * it, not a queue pop and a header read per stream by the fast kernel's waves.  counters: [0] number of fast streams, [1] number of the others. */
+/* The look that sorts a call's packets between the decoder's kernels, one LANE per stream (64 streams per wave, one ballot and one atomic per list and wave):
+ *   fast list   the CELT steady state and nothing else -- a CELT-only TOC with one coded frame that fits a frame's slot, a stream whose last packet was CELT-only too (or that
+ *               has not decoded anything yet), no pending fold of the concealment
+ *   lane list   (lane_list != NULL) the SILK steady state -- a SILK-only TOC with one coded frame, the stream's last packet SILK-only too, the internal rate and the channel
+ *               count of last time (so that silk_decoder_set_fs and the resampler set-up have nothing to do), API channels = coded channels, nothing lost last time:
+ *               oa_sdec_lane_kernel, 64 streams per wave (silk_dec_lane.h)
+ *   slow list   everything else: the general kernel
+ * counters: [0] number of fast streams, [1] number of the others, [2] number of lane streams. */
 extern "C" __global__ void __launch_bounds__(64)
-oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int nstreams, int *fast_list, int *slow_list, unsigned *counters)
+oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int nstreams, int frame_size, int *fast_list, int *slow_list, int *lane_list, unsigned *counters)
 {
    const int lane = (int)threadIdx.x, s = (int)blockIdx.x * 64 + lane;
-   int fast = 0;
+   int fast = 0, ln = 0;
    if (s < nstreams) {
       const int len = lens[s];
       if (len >= 3 && len <= packet_stride && len <= 1276) {
          const int toc = packets[(size_t)s * packet_stride];
-         const int prev = streams[s].s.prev_mode;
-         fast = (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && streams[s].s.prefilter_and_fold == 0;
+         const OaDecStream *g = streams + s;
+         const int prev = g->s.prev_mode;
+         fast = fast_list && (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && g->s.prefilter_and_fold == 0;
+         if (lane_list && !(toc & 0x80) && (toc & 0x60) != 0x60 && (toc & 3) == 0 && prev == 1000) {
+            const int Fs = g->s.Fs ? g->s.Fs : 48000, nch = (toc & 0x4) ? 2 : 1, bw = 1101 + ((toc >> 5) & 0x3);
+            const int rate = bw == 1101 ? 8000 : bw == 1102 ? 12000 : 16000;
+            ln = oa_samples_per_frame(toc, Fs) <= frame_size && nch == g->s.channels && g->silk.nChannelsInternal == nch && g->silk.nChannelsAPI == nch && g->silk.lastChannelsInternal == nch &&
+                 g->silk.lastInternalRate == rate;
+            for (int n = 0; n < nch && ln; n++) ln = g->silk.ch[n].fs_kHz * 1000 == rate && g->silk.ch[n].fs_API_hz == Fs && g->silk.ch[n].lossCnt == 0 && g->silk.ch[n].rs_cfg[5] * 1000 == rate;
+         }
       }
    }
-   const unsigned long long mf = wv_ballot(fast), ms = wv_ballot(s < nstreams && !fast), below = lane ? (~0ull >> (64 - lane)) : 0ull;
-   int bf = 0, bs = 0;
-   if (lane == 0) { bf = mf ? (int)atomicAdd(counters, (unsigned)__builtin_popcountll(mf)) : 0; bs = ms ? (int)atomicAdd(counters + 1, (unsigned)__builtin_popcountll(ms)) : 0; }
-   bf = wv_bcast(bf, 0); bs = wv_bcast(bs, 0);
+   const int slow = s < nstreams && !fast && !ln;
+   const unsigned long long mf = wv_ballot(fast), ms = wv_ballot(slow), ml = wv_ballot(ln), below = lane ? (~0ull >> (64 - lane)) : 0ull;
+   int bf = 0, bs = 0, bl = 0;
+   if (lane == 0) {
+      bf = mf ? (int)atomicAdd(counters, (unsigned)__builtin_popcountll(mf)) : 0; bs = ms ? (int)atomicAdd(counters + 1, (unsigned)__builtin_popcountll(ms)) : 0;
+      bl = ml ? (int)atomicAdd(counters + 2, (unsigned)__builtin_popcountll(ml)) : 0;
+   }
+   bf = wv_bcast(bf, 0); bs = wv_bcast(bs, 0); bl = wv_bcast(bl, 0);
    if (fast) fast_list[bf + __builtin_popcountll(mf & below)] = s;
-   else if (s < nstreams) slow_list[bs + __builtin_popcountll(ms & below)] = s;
+   else if (ln) lane_list[bl + __builtin_popcountll(ml & below)] = s;
+   else if (slow) slow_list[bs + __builtin_popcountll(ms & below)] = s;
+}
+/* The SILK steady state, one lane per stream (silk_dec_lane.h): tiles of 64 entries of the look's lane list, a static split over the grid; a lane whose packet turns out to
+ * carry a redundant CELT frame appends its stream to the general kernel's list (which is launched behind this kernel on the same HIP stream).
+ * work: SL_WORK_BYTES per block. */
+extern "C" __global__ void __launch_bounds__(64, 1)
+oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, char *work,
+      const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   const int n = (int)*list_count, ntiles = (n + SL_STREAMS - 1) / SL_STREAMS, lane = (int)threadIdx.x;
+   for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+      const int i = t * SL_STREAMS + lane;
+      if (i < n) {
+         const int s = list[i];
+         if (!oa_sdec_lane_packet(streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, work + (size_t)blockIdx.x * SL_WORK_BYTES,
+                                  (WV_LDS ResamplerLds *)smem, lane))
+            { slow_list[atomicAdd(slow_count, 1u)] = s; atomicAdd(rejected, 1u); }
+      }
+      __syncthreads();
+   }
 }
 
 /* the SILK-capable encoder (applications VOIP / AUDIO / RESTRICTED_SILK): one wave per stream at a time, SILK state staged in LDS; persistent like oa_encode_kernel,
@@ -1533,6 +1571,8 @@ struct OpusGpuDecBatch {
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
    unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; [2] / [3] the lengths of the two lists; d_slow [2][S]: the streams oa_decode_look_kernel sent to the fast kernel, then those it left to the general one */
    int num_cu, occ_fast, occ_gen;
+   char *d_lane_work; size_t lane_work_cap;  /* oa_sdec_lane_kernel's work rows, SL_WORK_BYTES per block of its grid */
+   int no_lane;                             /* opusgpu_dec_batch_set_lane_kernel(b, 0): SILK-only packets go to the general kernel too */
    int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
@@ -1542,6 +1582,17 @@ int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec) { if (!b || de
 /* 0: the following calls skip the CELT-only fast kernel and its look at every stream (a batch that knows it carries no CELT-only packets -- a SILK-only or hybrid service -- saves
  * one launch and one queue pop per stream; any other batch only loses the fast kernel's occupancy); 1 (the default): fast kernel first, the general kernel takes the rest.  The output is the same either way. */
 int opusgpu_dec_batch_set_fast_kernel(OpusGpuDecBatch *b, int enable) { if (!b || enable < 0 || enable > 1) return OPUS_BAD_ARG; b->no_fast = !enable; return OPUS_OK; }
+/* the last call's split (after a sync): packets the look gave to oa_sdec_lane_kernel, and how many of those it handed on to the general kernel (a redundant CELT frame) */
+int opusgpu_dec_batch_lane_stats(OpusGpuDecBatch *b, opus_uint32 *taken, opus_uint32 *handed_on)
+{
+   if (!b || !taken || !handed_on) return OPUS_BAD_ARG;
+   unsigned q[2] = { 0, 0 };
+   HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(q, b->d_queue + 4, sizeof(q), hipMemcpyDeviceToHost));
+   *taken = q[0]; *handed_on = q[1];
+   return OPUS_OK;
+}
+int opusgpu_dec_batch_set_lane_kernel(OpusGpuDecBatch *b, int enable) { if (!b || enable < 0 || enable > 1) return OPUS_BAD_ARG; b->no_lane = !enable; return OPUS_OK; }
 int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
 int opusgpu_dec_fast_kernel_lds_bytes(void) { return (int)OA_DEC_FAST_LDS_BYTES; }
 opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
@@ -1559,6 +1610,7 @@ void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
    if (b->d_scratch) (void)hipFree(b->d_scratch);
    if (b->d_queue) (void)hipFree(b->d_queue);
    if (b->d_slow) (void)hipFree(b->d_slow);
+   if (b->d_lane_work) (void)hipFree(b->d_lane_work);
    if (b->stream) (void)hipStreamDestroy(b->stream);
    delete b;
 }
@@ -1580,14 +1632,14 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuDecBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
-      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0;
+      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0; b->d_lane_work = nullptr; b->lane_work_cap = 0; b->no_lane = 0;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 2 * sizeof(int) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 3 * sizeof(int) * (size_t)nstreams) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
@@ -1644,6 +1696,7 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    /* persistent launches: as many waves as the chip holds of each kernel (never more than there are streams), every wave with its own spectrum scratch; the fast kernel
     * first, then the general one over the streams it handed over (its waves find an empty list when there are none) */
    static const int fast_env = getenv("OPUS_AMD_DEC_FAST") ? atoi(getenv("OPUS_AMD_DEC_FAST")) : 1;                 /* 0: the general kernel for every packet (A/B, tests) */
+   static const int lane_env = getenv("OPUS_AMD_DEC_LANE") ? atoi(getenv("OPUS_AMD_DEC_LANE")) : 1;                 /* 0: no lane = stream SILK kernel */
    const long long cu = b->num_cu > 0 ? b->num_cu : 1;
    long long g_fast = (long long)(b->occ_fast < 1 ? 1 : b->occ_fast) * cu, g_gen = (long long)(b->occ_gen < 1 ? 1 : b->occ_gen) * cu;
    if (g_fast > b->n_act) g_fast = b->n_act;
@@ -1652,17 +1705,31 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    if (need > b->scratch_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_scratch) (void)hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_scratch, need)); b->scratch_cap = need; }
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    const int use_fast = fast_env && !b->no_fast && !b->decode_fec;
-   /* d_queue: [0] the fast kernel's queue, [1] the general kernel's, [2] / [3] the lengths of their lists; d_slow: [S] the fast list, [S] the general kernel's list */
-   if (use_fast) {
+   const int use_lane = fast_env && lane_env && !b->no_lane && !b->decode_fec, use_look = use_fast || use_lane;
+   long long g_lane = 0;
+   if (use_lane) {                                                    /* one block per tile of 64 streams, four per CU at most (one wave per SIMD: the kernel's register budget) */
+      g_lane = ((long long)b->n_act + SL_STREAMS - 1) / SL_STREAMS;
+      if (g_lane > 4 * cu) g_lane = 4 * cu;
+      const size_t lneed = (size_t)g_lane * SL_WORK_BYTES;
+      if (lneed > b->lane_work_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_lane_work) (void)hipFree(b->d_lane_work); b->d_lane_work = nullptr; b->lane_work_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_lane_work, lneed)); b->lane_work_cap = lneed; }
+   }
+   /* d_queue: [0] the fast kernel's queue, [1] the general kernel's, [2] / [3] / [4] the lengths of the fast, general and lane lists; d_slow: [S] the fast list, [S] the
+    * general kernel's list, [S] the lane kernel's list */
+   if (use_look) {
       hipLaunchKernelGGL(oa_decode_look_kernel, dim3((unsigned)((b->n_act + 63) / 64)), dim3(64), 0, s,
-            (const OaDecStream *)b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (int)b->n_act, b->d_slow, b->d_slow + b->S, b->d_queue + 2);
-      hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
+            (const OaDecStream *)b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (int)b->n_act, frame_size, use_fast ? b->d_slow : (int *)nullptr, b->d_slow + b->S,
+            use_lane ? b->d_slow + 2 * (size_t)b->S : (int *)nullptr, b->d_queue + 2);
+      if (use_lane)
+         hipLaunchKernelGGL(oa_sdec_lane_kernel, dim3((unsigned)g_lane), dim3(64), sizeof(ResamplerLds), s,
+               b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, b->d_lane_work,
+               (const int *)(b->d_slow + 2 * (size_t)b->S), (const unsigned *)(b->d_queue + 4), b->d_slow + b->S, b->d_queue + 3, b->d_queue + 5);
+      if (use_fast) hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
             b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
             (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, (const int *)b->d_slow, (const unsigned *)(b->d_queue + 2));
    }
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-         (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_fast ? (const int *)(b->d_slow + b->S) : (const int *)nullptr, (const unsigned *)(b->d_queue + 3));
+         (u32 *)d_final_range, (int)b->n_act, b->decode_fec, b->d_scratch, b->d_queue + 1, use_look ? (const int *)(b->d_slow + b->S) : (const int *)nullptr, (const unsigned *)(b->d_queue + 3));
    HIPCHECK(hipGetLastError());
    return OPUS_OK;
 }

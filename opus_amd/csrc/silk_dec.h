@@ -54,9 +54,9 @@ WV_DEV const u8 *sd_pitch_contour_icdf(int fs_kHz, int nb_subfr)
 { return fs_kHz == 8 ? (nb_subfr == 4 ? sk_pitch_contour_nb_icdf : sk_pitch_contour_10ms_nb_icdf) : (nb_subfr == 4 ? sk_pitch_contour_icdf : sk_pitch_contour_10ms_icdf); }
 WV_DEV const u8 *sd_pitch_low_bits_icdf(int fs_kHz) { return fs_kHz == 16 ? sk_uniform8_icdf : fs_kHz == 12 ? sk_uniform6_icdf : sk_uniform4_icdf; }
 
-WV_DEV void sd_decode_indices(EC_ARGS, WV_LDS OaSilkChannel *ch, int FrameIndex, int decode_LBRR, int condCoding)
+template <class ECB, class CH> WV_DEV void sd_decode_indices(EC_ARGS_G, CH ch, int FrameIndex, int decode_LBRR, int condCoding)
 {
-   WV_LDS OaSilkIndices *ix = &ch->indices;
+   auto ix = &ch->indices;
    int Ix;
    if (decode_LBRR || ch->VAD_flags[FrameIndex]) Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_vad_icdf, 8) + 2;
    else Ix = k_ec_dec_icdf(EC_PASS, sk_type_offset_no_vad_icdf, 8);
@@ -96,31 +96,31 @@ WV_DEV void sd_decode_indices(EC_ARGS, WV_LDS OaSilkChannel *ch, int FrameIndex,
    ix->Seed = (i8)k_ec_dec_icdf(EC_PASS, sk_uniform4_icdf, 8);
 }
 
-WV_DEV void sd_split(WV_LDS i16 *c1, WV_LDS i16 *c2, EC_ARGS, int p, const u8 *table)                 /* shell_coder.c:63 */
+template <class P1, class ECB> WV_DEV void sd_split(P1 c1, P1 c2, EC_ARGS_G, int p, const u8 *table)                 /* shell_coder.c:63 */
 {
    if (p > 0) { c1[0] = (i16)k_ec_dec_icdf(EC_PASS, &table[sk_shell_code_table_offsets[p]], 8); c2[0] = (i16)(p - c1[0]); }
    else { c1[0] = 0; c2[0] = 0; }
 }
-WV_DEV void sd_shell_decoder(WV_LDS i16 *p0, EC_ARGS, int pulses4, WV_LDS i16 *tmp)                   /* shell_coder.c:118; tmp: 14 words */
+template <class PU, class ECB, class PT> WV_DEV void sd_shell_decoder(PU p0, EC_ARGS_G, int pulses4, PT tmp)                   /* shell_coder.c:118; tmp: 14 words */
 {
-   WV_LDS i16 *p3 = tmp, *p2 = tmp + 2, *p1 = tmp + 6;
-   sd_split(&p3[0], &p3[1], EC_PASS, pulses4, sk_shell_code_table3);
-   sd_split(&p2[0], &p2[1], EC_PASS, p3[0], sk_shell_code_table2);
-   sd_split(&p1[0], &p1[1], EC_PASS, p2[0], sk_shell_code_table1);
-   sd_split(&p0[0], &p0[1], EC_PASS, p1[0], sk_shell_code_table0);
-   sd_split(&p0[2], &p0[3], EC_PASS, p1[1], sk_shell_code_table0);
-   sd_split(&p1[2], &p1[3], EC_PASS, p2[1], sk_shell_code_table1);
-   sd_split(&p0[4], &p0[5], EC_PASS, p1[2], sk_shell_code_table0);
-   sd_split(&p0[6], &p0[7], EC_PASS, p1[3], sk_shell_code_table0);
-   sd_split(&p2[2], &p2[3], EC_PASS, p3[1], sk_shell_code_table2);
-   sd_split(&p1[4], &p1[5], EC_PASS, p2[2], sk_shell_code_table1);
-   sd_split(&p0[8], &p0[9], EC_PASS, p1[4], sk_shell_code_table0);
-   sd_split(&p0[10], &p0[11], EC_PASS, p1[5], sk_shell_code_table0);
-   sd_split(&p1[6], &p1[7], EC_PASS, p2[3], sk_shell_code_table1);
-   sd_split(&p0[12], &p0[13], EC_PASS, p1[6], sk_shell_code_table0);
-   sd_split(&p0[14], &p0[15], EC_PASS, p1[7], sk_shell_code_table0);
+   PT p3 = tmp, p2 = tmp + 2, p1 = tmp + 6;
+   sd_split(p3 + 0, p3 + 1, EC_PASS, pulses4, sk_shell_code_table3);
+   sd_split(p2 + 0, p2 + 1, EC_PASS, p3[0], sk_shell_code_table2);
+   sd_split(p1 + 0, p1 + 1, EC_PASS, p2[0], sk_shell_code_table1);
+   sd_split(p0 + 0, p0 + 1, EC_PASS, p1[0], sk_shell_code_table0);
+   sd_split(p0 + 2, p0 + 3, EC_PASS, p1[1], sk_shell_code_table0);
+   sd_split(p1 + 2, p1 + 3, EC_PASS, p2[1], sk_shell_code_table1);
+   sd_split(p0 + 4, p0 + 5, EC_PASS, p1[2], sk_shell_code_table0);
+   sd_split(p0 + 6, p0 + 7, EC_PASS, p1[3], sk_shell_code_table0);
+   sd_split(p2 + 2, p2 + 3, EC_PASS, p3[1], sk_shell_code_table2);
+   sd_split(p1 + 4, p1 + 5, EC_PASS, p2[2], sk_shell_code_table1);
+   sd_split(p0 + 8, p0 + 9, EC_PASS, p1[4], sk_shell_code_table0);
+   sd_split(p0 + 10, p0 + 11, EC_PASS, p1[5], sk_shell_code_table0);
+   sd_split(p1 + 6, p1 + 7, EC_PASS, p2[3], sk_shell_code_table1);
+   sd_split(p0 + 12, p0 + 13, EC_PASS, p1[6], sk_shell_code_table0);
+   sd_split(p0 + 14, p0 + 15, EC_PASS, p1[7], sk_shell_code_table0);
 }
-WV_DEV void sd_decode_pulses(EC_ARGS, WV_LDS i16 *pulses, int signalType, int quantOffsetType, int frame_length, WV_LDS i16 *tmp)
+template <class ECB, class PU, class PT> WV_DEV void sd_decode_pulses(EC_ARGS_G, PU pulses, int signalType, int quantOffsetType, int frame_length, PT tmp)
 {
    i32 sum_pulses[20], nLshifts[20];
    const int RateLevelIndex = k_ec_dec_icdf(EC_PASS, &sk_rate_levels_icdf[(signalType >> 1) * 9], 8);
@@ -133,7 +133,7 @@ WV_DEV void sd_decode_pulses(EC_ARGS, WV_LDS i16 *pulses, int signalType, int qu
       while (sum_pulses[i] == 17) { nLshifts[i]++; sum_pulses[i] = k_ec_dec_icdf(EC_PASS, &sk_pulses_per_block_icdf[9 * 18] + (nLshifts[i] == 10), 8); }
    }
    for (int i = 0; i < iter; i++) {
-      if (sum_pulses[i] > 0) sd_shell_decoder(&pulses[i * 16], EC_PASS, sum_pulses[i], tmp);
+      if (sum_pulses[i] > 0) sd_shell_decoder(pulses + i * 16, EC_PASS, sum_pulses[i], tmp);
       else for (int k = 0; k < 16; k++) pulses[i * 16 + k] = 0;
    }
    for (int i = 0; i < iter; i++) {
@@ -174,7 +174,7 @@ template <class PA> WV_DEV void sd_bwexpander_32(PA ar, int d, i32 chirp_Q16)   
    for (int i = 0; i < d - 1; i++) { ar[i] = sk_mulww(chirp_Q16, ar[i]); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
    ar[d - 1] = sk_mulww(chirp_Q16, ar[d - 1]);
 }
-WV_DEV void sd_bwexpander(WV_LDS i16 *ar, int d, i32 chirp_Q16)                                              /* bwexpander.c:35 */
+template <class PA> WV_DEV void sd_bwexpander(PA ar, int d, i32 chirp_Q16)                                              /* bwexpander.c:35 */
 {
    const i32 cm1 = chirp_Q16 - 65536;
    for (int i = 0; i < d - 1; i++) { ar[i] = (i16)sk_rround(chirp_Q16 * ar[i], 16); chirp_Q16 += sk_rround(chirp_Q16 * cm1, 16); }
@@ -298,7 +298,7 @@ WV_DEV void sd_nlsf_stabilize(i16 *NLSF, const i16 *NDeltaMin, int L)           
    NLSF[L - 1] = (i16)imin(NLSF[L - 1], (1 << 15) - NDeltaMin[L]);
    for (int i = L - 2; i >= 0; i--) NLSF[i] = (i16)imin(NLSF[i], NLSF[i + 1] - NDeltaMin[i + 1]);
 }
-WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const WV_LDS i8 *NLSFIndices, const SdNlsfCb &cb)                      /* NLSF_decode.c:62 */
+template <class PI> WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, PI NLSFIndices, const SdNlsfCb &cb)                      /* NLSF_decode.c:62 */
 {
    i32 ec_ix[16], pred_Q8[16]; i32 res_Q10[16];
    sd_nlsf_unpack(ec_ix, pred_Q8, cb, NLSFIndices[0]);
@@ -318,7 +318,7 @@ WV_DEV void sd_nlsf_decode(i16 *pNLSF_Q15, const WV_LDS i8 *NLSFIndices, const S
    }
    sd_nlsf_stabilize(pNLSF_Q15, cb.deltamin, cb.order);
 }
-WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, WV_LDS i32 *pitch_lags, int Fs_kHz, int nb_subfr)     /* decode_pitch.c:38 */
+template <class PL> WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, PL pitch_lags, int Fs_kHz, int nb_subfr)     /* decode_pitch.c:38 */
 {
    const i8 *cb; int cbk_size;
    if (Fs_kHz == 8) { if (nb_subfr == 4) { cb = sk_cb_lags_stage2; cbk_size = 11; } else { cb = sk_cb_lags_stage2_10ms; cbk_size = 3; } }
@@ -327,9 +327,9 @@ WV_DEV void sd_decode_pitch(int lagIndex, int contourIndex, WV_LDS i32 *pitch_la
    for (int k = 0; k < nb_subfr; k++) { int p = lag + cb[k * cbk_size + contourIndex]; pitch_lags[k] = p < min_lag ? min_lag : p > max_lag ? max_lag : p; }
 }
 
-WV_DEV void sd_decode_parameters(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, int condCoding)                              /* decode_parameters.c:35 */
+template <class CH, class CT> WV_DEV void sd_decode_parameters(CH ch, CT c, int condCoding)                              /* decode_parameters.c:35 */
 {
-   WV_LDS OaSilkIndices *ix = &ch->indices;
+   auto ix = &ch->indices;
    /* gains (gain_quant.c:100): OFFSET = 2090, INV_SCALE_Q16 = 1907825 */
    for (int k = 0; k < ch->nb_subfr; k++) {
       int prev = ch->LastGainIndex;
@@ -402,7 +402,7 @@ WV_DEV int sd_set_fs(WV_LDS OaSilkChannel *ch, int fs_kHz, i32 fs_API_Hz)
 
 
 /* ---- packet loss concealment and comfort noise (silk/PLC.c, silk/CNG.c) ---- */
-WV_DEV void sd_sum_sqr_shift(i32 *energy, int *shift, const WV_LDS i16 *x, int len)                         /* sum_sqr_shift.c:36 */
+template <class PX> WV_DEV void sd_sum_sqr_shift(i32 *energy, int *shift, PX x, int len)                         /* sum_sqr_shift.c:36 */
 {
    int shft = 31 - sk_clz(len);
    i32 nrg = len;
@@ -424,9 +424,9 @@ WV_DEV i32 sd_sqrt_approx(i32 x)                                                
    y >>= lz >> 1;
    return sk_mlawb(y, y, sk_mulbb(213, frac_Q7));
 }
-WV_DEV void sd_plc_reset(WV_LDS OaSilkChannel *ch)                                                                 /* PLC.c:65 */
+template <class CH> WV_DEV void sd_plc_reset(CH ch)                                                                 /* PLC.c:65 */
 { ch->plc_pitchL_Q8 = shl32(ch->frame_length, 7); ch->plc_prevGain_Q16[0] = ch->plc_prevGain_Q16[1] = 65536; ch->plc_subfr_length = 20; ch->plc_nb_subfr = 2; }
-WV_DEV void sd_plc_update(WV_LDS OaSilkChannel *ch, const WV_LDS SdCtrl *c)                                               /* PLC.c:107 */
+template <class CH, class CT> WV_DEV void sd_plc_update(CH ch, CT c)                                               /* PLC.c:107 */
 {
    ch->prevSignalType = ch->indices.signalType;
    i32 LTP_Gain_Q14 = 0;
@@ -549,7 +549,7 @@ WV_DEV void sd_plc(WV_LDS OaSilkChannel *ch, WV_LDS SdCtrl *c, WV_LDS i16 *frame
    if (lost) { sd_plc_conceal(ch, c, frame, S); ch->lossCnt++; }
    else sd_plc_update(ch, c);
 }
-WV_DEV void sd_plc_glue_frames(WV_LDS OaSilkChannel *ch, WV_LDS i16 *frame, int length)                            /* PLC.c:441 */
+template <class CH, class PF> WV_DEV void sd_plc_glue_frames(CH ch, PF frame, int length)                            /* PLC.c:441 */
 {
    if (ch->lossCnt) {
       i32 en; int sh; sd_sum_sqr_shift(&en, &sh, frame, length); ch->plc_conc_energy = en; ch->plc_conc_energy_shift = sh;
@@ -578,7 +578,7 @@ WV_DEV void sd_plc_glue_frames(WV_LDS OaSilkChannel *ch, WV_LDS i16 *frame, int 
       ch->plc_last_frame_lost = 0;
    }
 }
-WV_DEV void sd_cng_reset(WV_LDS OaSilkChannel *ch)                                                                 /* CNG.c:58 */
+template <class CH> WV_DEV void sd_cng_reset(CH ch)                                                                 /* CNG.c:58 */
 {
    const i32 step = 32767 / (ch->LPC_order + 1);
    i32 acc = 0;
@@ -784,7 +784,7 @@ WV_DEV void sd_decode_frame_back(WV_LDS OaSilkChannel *ch, WV_LDS i16 *pOut, int
    ch->lagPrev = ctrl->pitchL[ch->nb_subfr - 1];
 }
 
-WV_DEV void sd_stereo_decode_pred(EC_ARGS, i32 *pred_Q13)                                                   /* stereo_decode_pred.c:35 */
+template <class ECB> WV_DEV void sd_stereo_decode_pred(EC_ARGS_G, i32 *pred_Q13)                                                   /* stereo_decode_pred.c:35 */
 {
    int ixs[2][3];
    int n = k_ec_dec_icdf(EC_PASS, sk_stereo_pred_joint_icdf, 8);
@@ -798,7 +798,7 @@ WV_DEV void sd_stereo_decode_pred(EC_ARGS, i32 *pred_Q13)                       
    }
    pred_Q13[0] -= pred_Q13[1];
 }
-WV_DEV void sd_stereo_ms_to_lr(WV_LDS OaSilkDec *sd, WV_LDS i16 *x1, WV_LDS i16 *x2, const i32 *pred_Q13, int fs_kHz, int frame_length)   /* stereo_MS_to_LR.c:35 */
+template <class SD, class PX> WV_DEV void sd_stereo_ms_to_lr(SD sd, PX x1, PX x2, const i32 *pred_Q13, int fs_kHz, int frame_length)   /* stereo_MS_to_LR.c:35 */
 {
    for (int i = 0; i < 2; i++) { x1[i] = sd->sMid[i]; x2[i] = sd->sSide[i]; sd->sMid[i] = x1[frame_length + i]; sd->sSide[i] = x2[frame_length + i]; }
    i32 pred0 = sd->pred_prev_Q13[0], pred1 = sd->pred_prev_Q13[1];

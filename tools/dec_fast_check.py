@@ -18,7 +18,19 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "celt_5ms_12k":  (12000, 1, 2051, {4002: 24000, 4010: 5}, 5, 16, 0),            # downsampling by 4 on the way out
     "mono_coded":    (48000, 2, 2051, {4002: 48000, 4010: 5, 4022: 1}, 20, 10, 4),  # mono packets into a stereo decoder: one spectrum, two syntheses
     "stereo_to_mono": (48000, 2, 2051, {4002: 96000, 4010: 5}, 20, 10, 0, 1),       # stereo packets into a mono decoder: the spectra are mixed before the synthesis
+    # the SILK steady state: oa_sdec_lane_kernel (one lane per stream) takes these after each stream's first packet, and after a loss the general kernel has them back for a packet
+    "silk_wb_20":    (16000, 1, 2048, {11002: 1000, 4002: 24000, 4010: 5}, 20, 12, 0),
+    "silk_stereo":   (48000, 2, 2048, {11002: 1000, 4002: 40000, 4010: 5}, 20, 14, 6),            # mid/side, side frames that come and go, 16 -> 48 kHz on the way out
+    "silk_nb_10":    (8000, 1, 2048, {11002: 1000, 4008: 1101, 4002: 12000, 4010: 5}, 10, 16, 0),
+    "silk_mb_60":    (12000, 1, 2048, {11002: 1000, 4008: 1102, 4002: 16000, 4010: 5}, 60, 6, 0),  # three SILK frames per packet
+    "silk_fec":      (16000, 1, 2048, {11002: 1000, 4002: 28000, 4010: 5, 4012: 1, 4014: 20}, 20, 14, 5),   # packets that carry LBRR data (skipped: no FEC request)
+    "silk_24k_st40": (24000, 2, 2048, {11002: 1000, 4002: 36000, 4010: 5}, 40, 8, 0),
+    "silk_cbr":      (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5, 4006: 0}, 20, 10, 0),    # padded packets (code 3): the general kernel
+    "silk_dtx":      (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5, 4016: 1}, 20, 30, 0, 1, "quiet"),
+    "silk_mono_in_stereo": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 8, 0, 2),     # mono packets into a stereo decoder: not the lane kernel's
+    "silk_bw_switch": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 16, 0, 1, "bw"),   # the bandwidth changes in mid-stream: the general kernel re-initialises, then the lanes again
 }
+if os.environ.get("DEC_FAST_CASES"): CASES = {k: v for k, v in CASES.items() if any(x in k for x in os.environ["DEC_FAST_CASES"].split(","))}
 def dec_channels(name): return CASES[name][7] if len(CASES[name]) > 7 else CASES[name][1]
 
 def make_packets(name):
@@ -34,9 +46,12 @@ def make_packets(name):
         if name == "audio_auto" and s % 2: L.opus_encoder_ctl(e, 4002, 96000)          # half the streams at a rate where the encoder picks CELT
         rng = np.random.default_rng(100 * s + len(name)); t = np.arange(n * frames) / Fs
         x = 6000 * np.sin(2 * np.pi * (180 + 40 * s) * t)[:, None] * (np.sin(2 * np.pi * 1.3 * t + s) > -0.2)[:, None] + rng.normal(0, 300, (n * frames, ch))
+        kind = CASES[name][8] if len(CASES[name]) > 8 else ""
+        if kind == "quiet": x[n * 6:n * 22] = x[n * 6:n * 22] * 0.0005                    # a long silence: DTX frames (one-byte packets)
         x = np.clip(x, -32768, 32767).astype(np.int16)
         pk = []
         for f in range(frames):
+            if kind == "bw" and f in (5, 10): L.opus_encoder_ctl(e, 4008, 1101 if f == 5 else 1103)
             k = L.opus_encode(e, np.ascontiguousarray(x[f * n:(f + 1) * n]).ctypes.data, n, out, 1500); assert k > 0
             pk.append(b"" if loss and (f + s) % loss == loss - 1 else bytes(out[:k]))
         seqs.append(pk)
@@ -50,11 +65,13 @@ def run_child(libpath, outp):
         Fs, ch, app, ctl, ms, frames, loss = CASES[name][:7]
         seqs = make_packets(name); S = len(seqs); n = int(Fs * ms // 1000)
         b = opus_amd.DecoderBatch(S, channels=dec_channels(name), Fs=Fs)
-        steps = []
+        steps = []; lane = [0, 0]
         for f in range(frames):
             pcm, ns, rng = b.decode([seqs[s][f] for s in range(S)], n)
             steps.append((pcm.copy(), ns.copy(), rng.copy()))
-        res[name] = (steps, [b.export_state(s) for s in range(S)]); b.close()
+            if hasattr(b, "lane_stats") and os.environ.get("OPUS_AMD_DEC_FAST", "1") != "0":
+                t, h = b.lane_stats(); lane[0] += t; lane[1] += h
+        res[name] = (steps, [b.export_state(s) for s in range(S)], lane); b.close()
     pickle.dump(res, open(outp, "wb"))
 
 def compare(which="emu", tmpdir="/tmp", verbose=True):
@@ -71,7 +88,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
         a, b = r["0"][name], r["1"][name]
         ok = all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) for x, y in zip(a[0], b[0]))
         nd = [sum(p != q for p, q in zip(x, y)) for x, y in zip(a[1], b[1])]
-        if verbose: print("%-13s output %s, state bytes differing per stream %s" % (name, "equal" if ok else "DIFFERS", nd))
+        if verbose: print("%-13s output %s, state bytes differing per stream %s; lane kernel took %d packets, handed on %d" % (name, "equal" if ok else "DIFFERS", nd, b[2][0], b[2][1]))
         if not ok or any(nd): bad.append(name)
     return bad
 
