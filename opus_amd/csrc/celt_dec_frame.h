@@ -957,4 +957,38 @@ template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDe
    }
    LANE0 { *nsamples_out = ret; *rng_out = st->rangeFinal; }
 }
+/* The CELT layer of a hybrid packet whose SILK layer oa_sdec_lane_kernel has decoded (silk_dec_lane.h): what oa_decode_packet + oa_decode_frame_wave do for a hybrid frame in
+ * the steady state (mode == prev_mode == hybrid, one coded frame, no redundancy: src/opus_decoder.c:540-690) from the point where the SILK audio is in pcm_out and the
+ * range decoder stands behind the redundancy flag (*cont): bands 17.. of the CELT-only fast kernel's frame function, accumulated onto the SILK audio. */
+WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, const EcCtx *cont)
+{
+   WV_LDS OaDecScalars *st = &L->st;
+   {
+      const i32 *g = (const i32 *)&gs->s;
+      WV_LDS i32 *d = (WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaDecScalars) / 4)) d[i] = g[i];
+      FOR_LANES(i, 2 * NBE) { L->oldBandE[i] = gs->oldBandE[i]; L->oldLogE[i] = gs->oldLogE[i]; L->oldLogE2[i] = gs->oldLogE2[i]; L->backgroundLogE[i] = gs->backgroundLogE[i]; }
+   }
+   wv_sync();
+   const int toc = wv_uni((int)data[0]), Fs = oa_dec_fs(st);
+   const int pfs = (toc & 0x08) ? Fs / 50 : Fs / 100, bw = (toc & 0x10) ? 1105 : 1104, flen = len - 1;
+   LANE0 {
+      st->mode = 1001; st->bandwidth = bw; st->frame_size = pfs; st->stream_channels = (toc & 0x4) ? 2 : 1;
+      st->start = 17; st->end = bw == 1104 ? 19 : 21;
+      EcCtx ec = *cont;
+      ec_st(&L->ec_silk, &ec);
+   }
+   FOR_LANES(i, flen) L->packet[1 + i] = data[1 + i];
+   wv_sync();
+   const int r = celt_decode_frame_wave<true>(L, gs, flen, pfs, pcm_out, 1, 1);
+   if (r >= 0) { LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1001; st->prev_redundancy = 0; st->last_packet_duration = pfs; } }
+   wv_sync();
+   {
+      i32 *g = (i32 *)&gs->s;
+      const WV_LDS i32 *d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaDecScalars) / 4)) g[i] = d[i];
+      FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
+   }
+   LANE0 { *nsamples_out = r < 0 ? r : pfs; *rng_out = st->rangeFinal; }
+}
 #endif

@@ -224,12 +224,32 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
       __syncthreads();
    }
 }
+/* The CELT layer of the hybrid packets whose SILK layer oa_sdec_lane_kernel has decoded: the fast kernel's frame function from band 17 on top of the SILK audio
+ * (celt_dec_frame.h: oa_decode_hybrid_tail), persistent waves over the list the lane kernel built */
+extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
+oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs,
+      char *scratch, unsigned *queue, const int *list, const unsigned *list_count, const EcCtx *hyb_ec)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   const int n = (int)*list_count;
+   for (;;) {
+      const int i = oa_queue_pop(queue);
+      if (i >= n) break;
+      const int s = wv_uni(list[i]);
+      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      __syncthreads();
+      oa_decode_hybrid_tail(L, streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s);
+      __syncthreads();
+   }
+}
 /* The look that sorts a call's packets between the decoder's kernels, one LANE per stream (64 streams per wave, one ballot and one atomic per list and wave):
  *   fast list   the CELT steady state and nothing else -- a CELT-only TOC with one coded frame that fits a frame's slot, a stream whose last packet was CELT-only too (or that
  *               has not decoded anything yet), no pending fold of the concealment
  *   lane list   (lane_list != NULL) the SILK steady state -- a SILK-only TOC with one coded frame, the stream's last packet SILK-only too, the internal rate and the channel
  *               count of last time (so that silk_decoder_set_fs and the resampler set-up have nothing to do), API channels = coded channels, nothing lost last time:
- *               oa_sdec_lane_kernel, 64 streams per wave (silk_dec_lane.h)
+ *               oa_sdec_lane_kernel, 64 streams per wave (silk_dec_lane.h) -- and the hybrid steady state (a hybrid TOC with one coded frame after a hybrid packet, no
+ *               pending fold of the concealment): the same kernel for the SILK layer, then oa_decode_hyb_kernel for the CELT layer
  *   slow list   everything else: the general kernel
  * counters: [0] number of fast streams, [1] number of the others, [2] number of lane streams. */
 extern "C" __global__ void __launch_bounds__(64)
@@ -244,9 +264,10 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
          const OaDecStream *g = streams + s;
          const int prev = g->s.prev_mode;
          fast = fast_list && (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && g->s.prefilter_and_fold == 0;
-         if (lane_list && !(toc & 0x80) && (toc & 0x60) != 0x60 && (toc & 3) == 0 && prev == 1000) {
+         const int hyb = (toc & 0x60) == 0x60;
+         if (lane_list && !(toc & 0x80) && (toc & 3) == 0 && (hyb ? prev == 1001 && g->s.prefilter_and_fold == 0 : prev == 1000)) {
             const int Fs = g->s.Fs ? g->s.Fs : 48000, nch = (toc & 0x4) ? 2 : 1, bw = 1101 + ((toc >> 5) & 0x3);
-            const int rate = bw == 1101 ? 8000 : bw == 1102 ? 12000 : 16000;
+            const int rate = hyb ? 16000 : bw == 1101 ? 8000 : bw == 1102 ? 12000 : 16000;
             ln = oa_samples_per_frame(toc, Fs) <= frame_size && nch == g->s.channels && g->silk.nChannelsInternal == nch && g->silk.nChannelsAPI == nch && g->silk.lastChannelsInternal == nch &&
                  g->silk.lastInternalRate == rate;
             for (int n = 0; n < nch && ln; n++) ln = g->silk.ch[n].fs_kHz * 1000 == rate && g->silk.ch[n].fs_API_hz == Fs && g->silk.ch[n].lossCnt == 0 && g->silk.ch[n].rs_cfg[5] * 1000 == rate;
@@ -270,7 +291,7 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
  * work: SL_WORK_BYTES per block. */
 extern "C" __global__ void __launch_bounds__(64, 1)
 oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, char *work,
-      const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected)
+      const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected, int *hyb_list, unsigned *hyb_count, EcCtx *hyb_ec)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    const int n = (int)*list_count, ntiles = (n + SL_STREAMS - 1) / SL_STREAMS, lane = (int)threadIdx.x;
@@ -278,9 +299,10 @@ oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, 
       const int i = t * SL_STREAMS + lane;
       if (i < n) {
          const int s = list[i];
-         if (!oa_sdec_lane_packet(streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, work + (size_t)blockIdx.x * SL_WORK_BYTES,
-                                  (WV_LDS ResamplerLds *)smem, lane))
-            { slow_list[atomicAdd(slow_count, 1u)] = s; atomicAdd(rejected, 1u); }
+         const int r = oa_sdec_lane_packet(streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s,
+                                           work + (size_t)blockIdx.x * SL_WORK_BYTES, (WV_LDS ResamplerLds *)smem, lane);
+         if (r == 0) { slow_list[atomicAdd(slow_count, 1u)] = s; atomicAdd(rejected, 1u); }
+         else if (r == 2) hyb_list[atomicAdd(hyb_count, 1u)] = s;
       }
       __syncthreads();
    }
@@ -1571,7 +1593,8 @@ struct OpusGpuDecBatch {
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
    unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; [2] / [3] the lengths of the two lists; d_slow [2][S]: the streams oa_decode_look_kernel sent to the fast kernel, then those it left to the general one */
    int num_cu, occ_fast, occ_gen;
-   char *d_lane_work; size_t lane_work_cap;  /* oa_sdec_lane_kernel's work rows, SL_WORK_BYTES per block of its grid */
+   char *d_lane_work; size_t lane_work_cap; EcCtx *d_hyb_ec;   /* [S] the range decoders of the hybrid packets between the lane kernel and oa_decode_hyb_kernel */
+    /* oa_sdec_lane_kernel's work rows, SL_WORK_BYTES per block of its grid */
    int no_lane;                             /* opusgpu_dec_batch_set_lane_kernel(b, 0): SILK-only packets go to the general kernel too */
    int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
 };
@@ -1611,6 +1634,7 @@ void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
    if (b->d_queue) (void)hipFree(b->d_queue);
    if (b->d_slow) (void)hipFree(b->d_slow);
    if (b->d_lane_work) (void)hipFree(b->d_lane_work);
+   if (b->d_hyb_ec) (void)hipFree(b->d_hyb_ec);
    if (b->stream) (void)hipStreamDestroy(b->stream);
    delete b;
 }
@@ -1632,17 +1656,18 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuDecBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
-      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0; b->d_lane_work = nullptr; b->lane_work_cap = 0; b->no_lane = 0;
+      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0; b->d_lane_work = nullptr; b->lane_work_cap = 0; b->no_lane = 0; b->d_hyb_ec = nullptr;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 3 * sizeof(int) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 4 * sizeof(int) * (size_t)nstreams) == hipSuccess && hipMalloc((void **)&b->d_hyb_ec, sizeof(EcCtx) * (size_t)nstreams) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_hyb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_gen, (const void *)oa_decode_kernel, 64, sizeof(DecLds)) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_fast, (const void *)oa_decode_fast_kernel, 64, OA_DEC_FAST_LDS_BYTES) == hipSuccess;
       for (opus_int32 s0 = 0; ok && s0 < nstreams; s0 += 256) {
@@ -1722,10 +1747,15 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
       if (use_lane)
          hipLaunchKernelGGL(oa_sdec_lane_kernel, dim3((unsigned)g_lane), dim3(64), sizeof(ResamplerLds), s,
                b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, b->d_lane_work,
-               (const int *)(b->d_slow + 2 * (size_t)b->S), (const unsigned *)(b->d_queue + 4), b->d_slow + b->S, b->d_queue + 3, b->d_queue + 5);
+               (const int *)(b->d_slow + 2 * (size_t)b->S), (const unsigned *)(b->d_queue + 4), b->d_slow + b->S, b->d_queue + 3, b->d_queue + 5,
+               b->d_slow + 3 * (size_t)b->S, b->d_queue + 6, b->d_hyb_ec);
       if (use_fast) hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
             b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
             (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, (const int *)b->d_slow, (const unsigned *)(b->d_queue + 2));
+      if (use_lane)                                                   /* (d_queue [6] the hybrid list's length, [7] the kernel's queue; an empty list costs the launch) */
+         hipLaunchKernelGGL(oa_decode_hyb_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
+               b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range,
+               b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const EcCtx *)b->d_hyb_ec);
    }
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,

@@ -86,8 +86,9 @@ WV_DEV void sl_load_channel(SlCh *d, const OaSilkChannel *g, LnI16 outBuf)
    for (int i = 0; i < 6; i++) d->plc_LTPCoef_Q14[i] = g->plc_LTPCoef_Q14[i];
    d->indices = g->indices;
    d->cng_loaded = 0;
-   const i32 *ob = (const i32 *)g->outBuf;                          /* the history the long-term predictor reads: ltp_mem_length samples, as dwords */
-   for (int i = 0; i < (d->ltp_mem_length >> 1); i++) { const i32 w = ob[i]; outBuf[2 * i] = (i16)(w & 0xFFFF); outBuf[2 * i + 1] = (i16)(w >> 16); }
+   const i32 *ob = (const i32 *)g->outBuf;                          /* the history the long-term predictor reads (ltp_mem_length samples) and the half frame behind it that
+                                                                     * decode_core.c:141 parks there (so that the record comes back byte for byte), as dwords */
+   for (int i = 0; i < ((d->ltp_mem_length + 10 * d->fs_kHz) >> 1); i++) { const i32 w = ob[i]; outBuf[2 * i] = (i16)(w & 0xFFFF); outBuf[2 * i + 1] = (i16)(w >> 16); }
 }
 WV_DEV void sl_store_channel(OaSilkChannel *g, const SlCh *d, LnI16 outBuf, LnI32 exc, LnI32 cng, i32 *cng_exc)
 {
@@ -108,7 +109,7 @@ WV_DEV void sl_store_channel(OaSilkChannel *g, const SlCh *d, LnI16 outBuf, LnI3
    for (int i = 0; i < 6; i++) g->plc_LTPCoef_Q14[i] = d->plc_LTPCoef_Q14[i];
    g->indices = d->indices;
    i32 *ob = (i32 *)g->outBuf;
-   for (int i = 0; i < (d->ltp_mem_length >> 1); i++) ob[i] = (i32)(((u32)outBuf[2 * i] & 0xFFFFu) | ((u32)outBuf[2 * i + 1] << 16));
+   for (int i = 0; i < ((d->ltp_mem_length + 10 * d->fs_kHz) >> 1); i++) ob[i] = (i32)(((u32)outBuf[2 * i] & 0xFFFFu) | ((u32)outBuf[2 * i + 1] << 16));
    for (int i = 0; i < d->frame_length; i++) g->exc_Q14[i] = exc[i];
    if (d->cng_loaded) for (int i = 0; i < 320; i++) cng_exc[i] = cng[i];
 }
@@ -254,14 +255,17 @@ template <class CH> WV_DEV void sl_decode_frame_back(CH ch, SdCtrl *c, LnI16 pOu
 }
 
 /* One packet of one stream on this lane.  Returns 1 when the stream record has been updated (and *nsamples_out / *rng_out written), 0 when the packet has to go to the
- * general kernel (a redundant CELT frame follows the SILK data): nothing but the PCM slot has been written then.
+ * general kernel (a redundant CELT frame follows the SILK data): nothing but the PCM slot has been written then.  A HYBRID packet (the look sends those whose stream's last
+ * packet was hybrid too): the SILK layer is decoded and committed here, the range decoder -- behind the redundancy flag, src/opus_decoder.c:503 -- is parked in *hyb_ec, and
+ * the return value 2 asks for oa_decode_hyb_kernel (the CELT layer on top of this lane's PCM; it writes the scalars, the sample count and the final range).
  * work: this lane's base in the tile's work area (the tile's base + lane, see SL_WORK_BYTES); ring: the tile's resampler ring in LDS. */
-WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, char *tile_work, WV_LDS ResamplerLds *ring, const int lane)
+WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, EcCtx *hyb_ec, char *tile_work, WV_LDS ResamplerLds *ring, const int lane)
 {
    const int CC = gs->s.channels, Fs = gs->s.Fs ? gs->s.Fs : 48000;
    const int toc = data[0];
    const int nch = (toc & 0x4) ? 2 : 1;
-   const int bandwidth = 1101 + ((toc >> 5) & 0x3);
+   const int hybrid = (toc & 0x60) == 0x60;
+   const int bandwidth = hybrid ? ((toc & 0x10) ? 1105 : 1104) : 1101 + ((toc >> 5) & 0x3);
    const int audiosize = oa_samples_per_frame(toc, Fs);
    const int internalRate = bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000, fs_kHz = internalRate / 1000;
    const int payload_ms = imax(10, 1000 * audiosize / Fs);
@@ -371,13 +375,15 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    } while (decoded < audiosize);
 
    /* a SILK-only packet with 17 bits to spare carries a redundant CELT frame (src/opus_decoder.c:499-526): the general kernel's business */
-   if (k_ec_tell(e, buf) + 17 <= 8 * flen) return 0;
+   if (hybrid) { if (k_ec_tell(e, buf) + 17 + 20 <= 8 * flen && k_ec_dec_bit_logp(e, buf, 12)) return 0; }
+   else if (k_ec_tell(e, buf) + 17 <= 8 * flen) return 0;
 
    /* ---- commit ---- */
    for (int n = 0; n < nch; n++) sl_store_channel(&gs->silk.ch[n], &cs[n], outBuf[n], exc[n], cng[n], &gs->silk.cng_exc_buf_Q14[n][0]);
    gs->silk.pred_prev_Q13[0] = sd.pred_prev_Q13[0]; gs->silk.pred_prev_Q13[1] = sd.pred_prev_Q13[1];
    gs->silk.sMid[0] = sd.sMid[0]; gs->silk.sMid[1] = sd.sMid[1]; gs->silk.sSide[0] = sd.sSide[0]; gs->silk.sSide[1] = sd.sSide[1];
    gs->silk.prev_decode_only_middle = sd.prev_decode_only_middle;
+   if (hybrid) { *hyb_ec = *e; return 2; }
    gs->s.mode = 1000; gs->s.bandwidth = bandwidth; gs->s.frame_size = audiosize; gs->s.stream_channels = nch;
    gs->s.start = 17; gs->s.end = bandwidth == 1101 ? 13 : 17;                    /* what opus_decode_frame leaves behind for a SILK-only frame (celt_dec_frame.h: oa_decode_frame_wave) */
    gs->s.rangeFinal = e->rng; gs->s.prev_mode = 1000; gs->s.prev_redundancy = 0; gs->s.last_packet_duration = decoded;

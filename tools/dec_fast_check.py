@@ -20,14 +20,20 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "stereo_to_mono": (48000, 2, 2051, {4002: 96000, 4010: 5}, 20, 10, 0, 1),       # stereo packets into a mono decoder: the spectra are mixed before the synthesis
     # the SILK steady state: oa_sdec_lane_kernel (one lane per stream) takes these after each stream's first packet, and after a loss the general kernel has them back for a packet
     "silk_wb_20":    (16000, 1, 2048, {11002: 1000, 4002: 24000, 4010: 5}, 20, 12, 0),
-    "silk_stereo":   (48000, 2, 2048, {11002: 1000, 4002: 40000, 4010: 5}, 20, 14, 6),            # mid/side, side frames that come and go, 16 -> 48 kHz on the way out
+    "silk_stereo":   (48000, 2, 2048, {11002: 1000, 4004: 1103, 4002: 40000, 4010: 5}, 20, 14, 6),            # mid/side, side frames that come and go, 16 -> 48 kHz on the way out
     "silk_nb_10":    (8000, 1, 2048, {11002: 1000, 4008: 1101, 4002: 12000, 4010: 5}, 10, 16, 0),
     "silk_mb_60":    (12000, 1, 2048, {11002: 1000, 4008: 1102, 4002: 16000, 4010: 5}, 60, 6, 0),  # three SILK frames per packet
     "silk_fec":      (16000, 1, 2048, {11002: 1000, 4002: 28000, 4010: 5, 4012: 1, 4014: 20}, 20, 14, 5),   # packets that carry LBRR data (skipped: no FEC request)
-    "silk_24k_st40": (24000, 2, 2048, {11002: 1000, 4002: 36000, 4010: 5}, 40, 8, 0),
+    "silk_24k_st40": (24000, 2, 2048, {11002: 1000, 4004: 1102, 4002: 36000, 4010: 5}, 40, 8, 0),
     "silk_cbr":      (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5, 4006: 0}, 20, 10, 0),    # padded packets (code 3): the general kernel
     "silk_dtx":      (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5, 4016: 1}, 20, 30, 0, 1, "quiet"),
     "silk_mono_in_stereo": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 8, 0, 2),     # mono packets into a stereo decoder: not the lane kernel's
+    "silk_celt_switch": (16000, 1, 2049, {11002: 1000, 4002: 24000, 4010: 5}, 20, 20, 0, 1, "mode"),  # SILK-only <-> CELT-only every five frames: the last SILK packet before a switch carries a redundant CELT frame -- the lane hands it on
+    # the hybrid steady state: the SILK layer on the lane kernel, the CELT layer (bands 17..) by oa_decode_hyb_kernel
+    "hyb_stereo":    (48000, 2, 2049, {11002: 1001, 4002: 48000, 4010: 5}, 20, 14, 6),
+    "hyb_mono_10":   (48000, 1, 2048, {11002: 1001, 4004: 1104, 4002: 32000, 4010: 5}, 10, 16, 0),           # super-wideband: bands 17..18
+    "hyb_24k_out":   (48000, 2, 2049, {11002: 1001, 4002: 64000, 4010: 5}, 20, 10, 0, 2, "", 24000),         # decoded at 24 kHz: the SILK layer resampled 16 -> 24, the CELT layer decimated
+    "hyb_celt_switch": (48000, 2, 2049, {11002: 1001, 4002: 48000, 4010: 5}, 20, 20, 0, 2, "hmode"),           # hybrid <-> CELT-only: redundant frames, transitions
     "silk_bw_switch": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 16, 0, 1, "bw"),   # the bandwidth changes in mid-stream: the general kernel re-initialises, then the lanes again
 }
 if os.environ.get("DEC_FAST_CASES"): CASES = {k: v for k, v in CASES.items() if any(x in k for x in os.environ["DEC_FAST_CASES"].split(","))}
@@ -51,6 +57,8 @@ def make_packets(name):
         x = np.clip(x, -32768, 32767).astype(np.int16)
         pk = []
         for f in range(frames):
+            if kind == "hmode" and f and f % 5 == 0: L.opus_encoder_ctl(e, 11002, 1002 if (f // 5) % 2 else 1001)
+            if kind == "mode" and f and f % 5 == 0: L.opus_encoder_ctl(e, 11002, 1002 if (f // 5) % 2 else 1000)
             if kind == "bw" and f in (5, 10): L.opus_encoder_ctl(e, 4008, 1101 if f == 5 else 1103)
             k = L.opus_encode(e, np.ascontiguousarray(x[f * n:(f + 1) * n]).ctypes.data, n, out, 1500); assert k > 0
             pk.append(b"" if loss and (f + s) % loss == loss - 1 else bytes(out[:k]))
@@ -63,7 +71,9 @@ def run_child(libpath, outp):
     res = {}
     for name in CASES:
         Fs, ch, app, ctl, ms, frames, loss = CASES[name][:7]
-        seqs = make_packets(name); S = len(seqs); n = int(Fs * ms // 1000)
+        seqs = make_packets(name); S = len(seqs)
+        if len(CASES[name]) > 9: Fs = CASES[name][9]
+        n = int(Fs * ms // 1000)
         b = opus_amd.DecoderBatch(S, channels=dec_channels(name), Fs=Fs)
         steps = []; lane = [0, 0]
         for f in range(frames):

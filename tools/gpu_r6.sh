@@ -47,6 +47,11 @@ msbatch) timeout 1500 python -m pytest tests/test_gpu_ms_batch.py tests/test_gpu
 latency) for m in 0 1; do OPUS_AMD_SH_SPLIT=$m timeout 600 python tools/classic_latency.py 200 > $O/classic_latency_split$m.log 2>&1; done; for c in 2 3 4; do timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --streams 1 --config $c > $O/bench${c}_one_stream.log 2>&1; done ;;
 soak) timeout 1500 python tools/parity_soak.py --float-analysis --streams ${SOAK_STREAMS:-512} --frames ${SOAK_FRAMES:-600} --configs 2,3,4 > $O/parity_soak_analysis.log 2>&1 ;;
 ranks) timeout 1800 python -m pytest tests/test_gpu_bench_ranks.py -x -q -s > $O/pytest_bench_ranks.log 2>&1 ;;
+declane) timeout 300 python tools/dec_fast_check.py gpu > $O/dec_fast_check.log 2>&1; for c in 3 4 2; do timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --config $c --decode > $O/decode$c.log 2>&1; done
+  for m in 0 1; do OPUS_AMD_DEC_LANE=$m timeout 200 python bench.py --steps 8 --warmup 2 --no-extra-configs --no-cpu-baseline --config 3 --decode > $O/decode3_lane$m.log 2>&1; done
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd3 -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config 3 --decode > $OLDPWD/$O/profd3.log 2>&1); find $O/profd3 -name '*kernel_trace*' -delete; find $O/profd3 -name '*agent_info*' -delete
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd4 -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config 4 --decode > $OLDPWD/$O/profd4.log 2>&1); find $O/profd4 -name '*kernel_trace*' -delete; find $O/profd4 -name '*agent_info*' -delete
+  timeout 600 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_dec_fast.py -x -q --timeout 300 > $O/pytest_decoder.log 2>&1 ;;
 decfast) timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --config 2 --decode > $O/decode2.log 2>&1; timeout 80 python tools/dec_fast_check.py gpu > $O/dec_fast_check.log 2>&1; timeout 100 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_dec_fast.py -x -q --timeout 60 > $O/pytest_decoder.log 2>&1 ;;
 phases) for m in 1 0; do for k in silk hybrid; do OPUS_AMD_PROF_PREBUILT=1 OPUS_AMD_SH_SPLIT=$m timeout 90 python tools/phase_profile_sh.py 16384 10 $k > $O/phases_${k}_split$m.txt 2>&1; done; done ;;
 bench34p) for c in 3 4; do timeout 200 python bench.py --steps 10 --warmup 3 --no-extra-configs --config $c > $O/bench${c}_parity.log 2>&1; done ;;
