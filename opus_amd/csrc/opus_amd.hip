@@ -288,22 +288,41 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
 }
 /* The SILK steady state, one lane per stream (silk_dec_lane.h): tiles of 64 entries of the look's lane list, a static split over the grid; a lane whose packet turns out to
  * carry a redundant CELT frame appends its stream to the general kernel's list (which is launched behind this kernel on the same HIP stream).
+ * tile_width: the lanes of a wave that take a stream.  The lane code is a chain of dependent steps (a symbol of the range decoder, a sample of a recursive filter): a wave
+ * alone on its SIMD waits out every latency, so a call with too few streams to give every SIMD two full waves runs half-filled waves, two per SIMD, instead.
  * work: SL_WORK_BYTES per block. */
-extern "C" __global__ void __launch_bounds__(64, 1)
-oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, char *work,
+#ifndef OA_SDEC_WAVES_PER_EU
+#define OA_SDEC_WAVES_PER_EU 2
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_SDEC_WAVES_PER_EU)
+oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, char *work, int tile_width,
       const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected, int *hyb_list, unsigned *hyb_count, EcCtx *hyb_ec)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
-   const int n = (int)*list_count, ntiles = (n + SL_STREAMS - 1) / SL_STREAMS, lane = (int)threadIdx.x;
+   const int n = (int)*list_count, ntiles = (n + tile_width - 1) / tile_width, lane = (int)threadIdx.x;
+   sl_tabs_fill((WV_LDS SlTabs *)(smem + sizeof(ResamplerLds)), lane);
+   __syncthreads();
    for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
-      const int i = t * SL_STREAMS + lane;
+      const int i = lane < tile_width ? t * tile_width + lane : n;
+      const int s = i < n ? list[i] : -1, len_s = s >= 0 ? lens[s] : 0;
+      WV_LDS u8 *win = (WV_LDS u8 *)(smem + sizeof(ResamplerLds) + sizeof(SlTabs));
+      for (int k = 0; k < tile_width; k++) {                           /* the packets' heads -> LDS, a stream at a time, every lane a byte of it */
+         const int sk = wv_shfl(s, k), nb = imin(wv_shfl(len_s, k) - 1, SL_WIN);
+         if (sk >= 0) { const u8 *src = packets + (size_t)sk * packet_stride + 1; for (int j = lane; j < nb; j += 64) win[k * SL_WIN_STRIDE + j] = src[j]; }
+      }
+      __syncthreads();
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_BEGIN();
+#endif
       if (i < n) {
-         const int s = list[i];
-         const int r = oa_sdec_lane_packet(streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s,
-                                           work + (size_t)blockIdx.x * SL_WORK_BYTES, (WV_LDS ResamplerLds *)smem, lane);
+         const int r = oa_sdec_lane_packet(streams + s, packets + (size_t)s * packet_stride, len_s, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s,
+                                           work + (size_t)blockIdx.x * SL_WORK_BYTES, (WV_LDS ResamplerLds *)smem, (const WV_LDS SlTabs *)(smem + sizeof(ResamplerLds)), win, lane);
          if (r == 0) { slow_list[atomicAdd(slow_count, 1u)] = s; atomicAdd(rejected, 1u); }
          else if (r == 2) hyb_list[atomicAdd(hyb_count, 1u)] = s;
       }
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_END();
+#endif
       __syncthreads();
    }
 }
@@ -1731,10 +1750,13 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
    HIPCHECK(hipMemsetAsync(b->d_queue, 0, 64, s));
    const int use_fast = fast_env && !b->no_fast && !b->decode_fec;
    const int use_lane = fast_env && lane_env && !b->no_lane && !b->decode_fec, use_look = use_fast || use_lane;
-   long long g_lane = 0;
-   if (use_lane) {                                                    /* one block per tile of 64 streams, four per CU at most (one wave per SIMD: the kernel's register budget) */
-      g_lane = ((long long)b->n_act + SL_STREAMS - 1) / SL_STREAMS;
-      if (g_lane > 4 * cu) g_lane = 4 * cu;
+   long long g_lane = 0; int lane_tw = SL_STREAMS;
+   if (use_lane) {                                                    /* one block per tile, as many as the chip holds at most */
+      static const int tw_env = getenv("OPUS_AMD_SDEC_TILE") ? atoi(getenv("OPUS_AMD_SDEC_TILE")) : 0;           /* 16 / 32 / 64: fixed tile width (experiments) */
+      const long long slots = (long long)OA_SDEC_WAVES_PER_EU * 4 * cu;
+      lane_tw = tw_env >= 1 && tw_env <= SL_STREAMS ? tw_env : (long long)b->n_act >= 4 * cu * SL_STREAMS ? SL_STREAMS : 32;   /* (full waves as soon as every SIMD has one: measured, profiles/r06_r) */
+      g_lane = ((long long)b->n_act + lane_tw - 1) / lane_tw;
+      if (g_lane > slots) g_lane = slots;
       const size_t lneed = (size_t)g_lane * SL_WORK_BYTES;
       if (lneed > b->lane_work_cap) { HIPCHECK(hipStreamSynchronize(s)); if (b->d_lane_work) (void)hipFree(b->d_lane_work); b->d_lane_work = nullptr; b->lane_work_cap = 0; HIPCHECK(hipMalloc((void **)&b->d_lane_work, lneed)); b->lane_work_cap = lneed; }
    }
@@ -1745,8 +1767,8 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
             (const OaDecStream *)b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (int)b->n_act, frame_size, use_fast ? b->d_slow : (int *)nullptr, b->d_slow + b->S,
             use_lane ? b->d_slow + 2 * (size_t)b->S : (int *)nullptr, b->d_queue + 2);
       if (use_lane)
-         hipLaunchKernelGGL(oa_sdec_lane_kernel, dim3((unsigned)g_lane), dim3(64), sizeof(ResamplerLds), s,
-               b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, b->d_lane_work,
+         hipLaunchKernelGGL(oa_sdec_lane_kernel, dim3((unsigned)g_lane), dim3(64), sizeof(ResamplerLds) + sizeof(SlTabs) + SL_STREAMS * SL_WIN_STRIDE, s,
+               b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, b->d_lane_work, lane_tw,
                (const int *)(b->d_slow + 2 * (size_t)b->S), (const unsigned *)(b->d_queue + 4), b->d_slow + b->S, b->d_queue + 3, b->d_queue + 5,
                b->d_slow + 3 * (size_t)b->S, b->d_queue + 6, b->d_hyb_ec);
       if (use_fast) hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,

@@ -25,6 +25,10 @@
 #include "silk_dec_api.h"
 
 #define SL_STREAMS 64
+#ifndef P4_TIC            /* (section timers of the -DOA_PHASE_TIMERS build, tools/phase_profile_sdec.py; nothing in the product) */
+#define P4_TIC()
+#define P4_TOC(bucket)
+#endif
 
 /* a lane's array in a work area: ST = 64 rows interleaved over the wave's lanes, ST = 1 contiguous */
 template <class T, int ST> struct LnArr {
@@ -62,9 +66,140 @@ struct SlCh {
    i32 cng_synth_state[16], cng_smth_Gain_Q16, cng_rand_seed, cng_fs_kHz;
    i16 prevNLSF_Q15[16], plc_LTPCoef_Q14[6], plc_prevLPC_Q12[16], cng_smth_NLSF_Q15[16];
    OaSilkIndices indices;
+   i32 exc_valid;                                                  /* this packet has decoded a frame of this channel: its excitation rows go back at the commit (a side channel that was not coded keeps its old one) */
    i32 cng_loaded;                                                 /* the comfort-noise excitation buffer has been copied into its work rows (and goes back at the commit) */
 };
 struct SlDec { i32 pred_prev_Q13[2]; i16 sMid[2], sSide[2]; i32 prev_decode_only_middle; };
+
+
+/* n elements from src to dst, eight loads in flight before the first store: a lane's copy loop is otherwise one memory round trip per element (the compiler cannot tell the
+ * rows apart and keeps every load behind the store before it; with one wave per SIMD nothing else hides that latency) */
+template <class D, class S> WV_DEV void sl_copy(D dst, S src, int n)
+{
+   int i = 0;
+   for (; i + 8 <= n; i += 8) {
+      i32 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = src[i + k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) dst[i + k] = t[k];
+   }
+   for (; i < n; i++) dst[i] = src[i];
+}
+
+/* The head of every lane's packet in LDS (the tile's waves fill it together, one coalesced row per stream): the range decoder takes a byte every few symbols, and a wave of 64
+ * decoders waits for the slowest lane at EVERY symbol -- with the bytes in HBM nearly every symbol of the wave paid a memory round trip for some lane's renormalisation.
+ * 33 dwords per lane: the lanes' windows start in different banks.  Bytes beyond the window (long packets) come from HBM as before. */
+#define SL_WIN 128
+#define SL_WIN_STRIDE 132
+struct SlPkt {
+   const u8 *g; const WV_LDS u8 *w;
+   WV_MEM int operator[](u32 i) const { return i < SL_WIN ? (int)w[i] : (int)g[i]; }
+};
+/* the pulse coder's tables in LDS, each padded so that a four-entry look-ahead never leaves it (sl_dec_icdf): silk/tables_pulses_per_block.c:34-263 */
+struct SlTabs { u8 ppb[180 + 4]; u8 rate[18 + 2]; u8 shell[4][152]; u8 shell_pad[4]; u8 sign[42 + 2]; u8 offs[17 + 3]; };
+WV_DEV void sl_tabs_fill(WV_LDS SlTabs *T, int lane)
+{
+   for (int i = lane; i < 184; i += SL_STREAMS) T->ppb[i] = i < 180 ? sk_pulses_per_block_icdf[i] : (u8)0;
+   for (int i = lane; i < 20; i += SL_STREAMS) { T->rate[i] = i < 18 ? sk_rate_levels_icdf[i] : (u8)0; T->offs[i] = i < 17 ? sk_shell_code_table_offsets[i] : (u8)0; }
+   for (int i = lane; i < 152; i += SL_STREAMS) { T->shell[0][i] = sk_shell_code_table0[i]; T->shell[1][i] = sk_shell_code_table1[i]; T->shell[2][i] = sk_shell_code_table2[i]; T->shell[3][i] = sk_shell_code_table3[i]; }
+   for (int i = lane; i < 44; i += SL_STREAMS) T->sign[i] = i < 42 ? sk_sign_icdf[i] : (u8)0;
+   if (lane < 4) T->shell_pad[lane] = 0;
+}
+/* ec_dec_icdf (celt/entdec.c:181, ftb = 8) on a table in LDS, four entries per look: the scan is a chain of dependent reads otherwise, as long as the slowest lane's symbol */
+template <class ECB> WV_DEV int sl_dec_icdf(EcCtx *e, ECB buf, const WV_LDS u8 *icdf)
+{
+   u32 s = e->rng, t;
+   const u32 v = e->val, r = s >> 8;
+   int ret = 0;
+   for (;; ret += 4) {
+      const u32 c0 = icdf[ret], c1 = icdf[ret + 1], c2 = icdf[ret + 2], c3 = icdf[ret + 3];
+      t = s; s = r * c0; if (v >= s) break;
+      t = s; s = r * c1; if (v >= s) { ret += 1; break; }
+      t = s; s = r * c2; if (v >= s) { ret += 2; break; }
+      t = s; s = r * c3; if (v >= s) { ret += 3; break; }
+   }
+   e->val = v - s;
+   e->rng = t - s;
+   ecd_normalize(e, buf);
+   return ret;
+}
+/* silk_decode_pulses (silk/decode_pulses.c:37) as one lane runs it: a shell block's sixteen counts are built in registers (silk/shell_coder.c:118) and written once; the sign
+ * pass (silk/code_signs.c:74) reads a block's sixteen values with one wait, not sixteen */
+/* (silk_shell_code_table_offsets[p] = p (p + 1) / 2 - 1 for p >= 1: arithmetic, not a look-up in front of the look-up) */
+#define SL_SPLIT(a, b, p, tb) do { if ((p) > 0) { a = sl_dec_icdf(e, buf, &T->shell[tb][(((p) * ((p) + 1)) >> 1) - 1]); b = (p) - a; } else { a = 0; b = 0; } } while (0)
+template <class ECB> WV_DEV void sl_decode_pulses(EcCtx *e, ECB buf, LnI16 pulses, int signalType, int quantOffsetType, int frame_length, const WV_LDS SlTabs *T)
+{
+   i32 sum_pulses[20], nLshifts[20];
+   const int RateLevelIndex = sl_dec_icdf(e, buf, &T->rate[(signalType >> 1) * 9]);
+   int iter = frame_length >> 4;
+   if (iter * 16 < frame_length) iter++;                                                              /* 10 ms at 12 kHz */
+   for (int i = 0; i < iter; i++) {
+      int nl = 0, sp = sl_dec_icdf(e, buf, &T->ppb[RateLevelIndex * 18]);
+      while (sp == 17) { nl++; sp = sl_dec_icdf(e, buf, &T->ppb[9 * 18 + (nl == 10)]); }
+      nLshifts[i] = nl; sum_pulses[i] = sp;
+   }
+   for (int i = 0; i < iter; i++) {
+      i32 q[16];
+      const int p4 = sum_pulses[i];
+      if (p4 > 0) {
+         int a3, b3, a2, b2, c2, d2, p1[8];
+         SL_SPLIT(a3, b3, p4, 3);
+         SL_SPLIT(a2, b2, a3, 2);
+         SL_SPLIT(p1[0], p1[1], a2, 1);
+         SL_SPLIT(q[0], q[1], p1[0], 0);
+         SL_SPLIT(q[2], q[3], p1[1], 0);
+         SL_SPLIT(p1[2], p1[3], b2, 1);
+         SL_SPLIT(q[4], q[5], p1[2], 0);
+         SL_SPLIT(q[6], q[7], p1[3], 0);
+         SL_SPLIT(c2, d2, b3, 2);
+         SL_SPLIT(p1[4], p1[5], c2, 1);
+         SL_SPLIT(q[8], q[9], p1[4], 0);
+         SL_SPLIT(q[10], q[11], p1[5], 0);
+         SL_SPLIT(p1[6], p1[7], d2, 1);
+         SL_SPLIT(q[12], q[13], p1[6], 0);
+         SL_SPLIT(q[14], q[15], p1[7], 0);
+      } else {
+#pragma unroll
+         for (int k = 0; k < 16; k++) q[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) pulses[i * 16 + k] = (i16)q[k];
+   }
+   for (int i = 0; i < iter; i++) {
+      if (nLshifts[i] > 0) {
+         const int nLS = nLshifts[i];
+         for (int k = 0; k < 16; k++) {
+            int abs_q = pulses[i * 16 + k];
+            for (int j = 0; j < nLS; j++) abs_q = (abs_q << 1) + k_ec_dec_icdf(e, buf, sk_lsb_icdf, 8);
+            pulses[i * 16 + k] = (i16)abs_q;
+         }
+         sum_pulses[i] |= nLS << 5;
+      }
+   }
+   const WV_LDS u8 *icdf_ptr = &T->sign[7 * (quantOffsetType + (signalType << 1))];
+   const int nblk = (frame_length + 8) >> 4;
+   for (int i = 0; i < nblk; i++) {
+      const int p = sum_pulses[i];
+      if (p > 0) {
+         const u32 c0 = icdf_ptr[imin(p & 0x1F, 6)];
+         i32 q[16];
+#pragma unroll
+         for (int k = 0; k < 16; k++) q[k] = pulses[i * 16 + k];
+#pragma unroll
+         for (int k = 0; k < 16; k++) {
+            if (q[k] > 0) {                                                                          /* ec_dec_icdf on the two-entry table { c0, 0 } */
+               const u32 rr = e->rng >> 8, s1 = rr * c0;
+               if (e->val >= s1) { e->val -= s1; e->rng -= s1; q[k] = -q[k]; } else e->rng = s1;
+               ecd_normalize(e, buf);
+            }
+         }
+#pragma unroll
+         for (int k = 0; k < 16; k++) pulses[i * 16 + k] = (i16)q[k];
+      }
+   }
+}
+#undef SL_SPLIT
 
 WV_DEV void sl_load_channel(SlCh *d, const OaSilkChannel *g, LnI16 outBuf)
 {
@@ -76,7 +211,7 @@ WV_DEV void sl_load_channel(SlCh *d, const OaSilkChannel *g, LnI16 outBuf)
    d->ec_prevSignalType = g->ec_prevSignalType; d->ec_prevLagIndex = g->ec_prevLagIndex;
    for (int i = 0; i < 3; i++) { d->VAD_flags[i] = g->VAD_flags[i]; d->LBRR_flags[i] = g->LBRR_flags[i]; }
    d->LBRR_flag = g->LBRR_flag; d->lossCnt = g->lossCnt; d->prevSignalType = g->prevSignalType;
-   for (int i = 0; i < 90; i++) d->rs_rows[i] = g->rs_rows[i];
+   sl_copy(d->rs_rows, g->rs_rows, 90);
    d->plc_pitchL_Q8 = g->plc_pitchL_Q8; d->plc_last_frame_lost = g->plc_last_frame_lost; d->plc_conc_energy = g->plc_conc_energy; d->plc_conc_energy_shift = g->plc_conc_energy_shift;
    d->plc_prevGain_Q16[0] = g->plc_prevGain_Q16[0]; d->plc_prevGain_Q16[1] = g->plc_prevGain_Q16[1]; d->plc_fs_kHz = g->plc_fs_kHz; d->plc_nb_subfr = g->plc_nb_subfr;
    d->plc_subfr_length = g->plc_subfr_length; d->plc_prevLTP_scale_Q14 = g->plc_prevLTP_scale_Q14;
@@ -85,10 +220,17 @@ WV_DEV void sl_load_channel(SlCh *d, const OaSilkChannel *g, LnI16 outBuf)
    for (int i = 0; i < 16; i++) { d->prevNLSF_Q15[i] = g->prevNLSF_Q15[i]; d->plc_prevLPC_Q12[i] = g->plc_prevLPC_Q12[i]; d->cng_smth_NLSF_Q15[i] = g->cng_smth_NLSF_Q15[i]; }
    for (int i = 0; i < 6; i++) d->plc_LTPCoef_Q14[i] = g->plc_LTPCoef_Q14[i];
    d->indices = g->indices;
-   d->cng_loaded = 0;
+   d->cng_loaded = 0; d->exc_valid = 0;
    const i32 *ob = (const i32 *)g->outBuf;                          /* the history the long-term predictor reads (ltp_mem_length samples) and the half frame behind it that
                                                                      * decode_core.c:141 parks there (so that the record comes back byte for byte), as dwords */
-   for (int i = 0; i < ((d->ltp_mem_length + 10 * d->fs_kHz) >> 1); i++) { const i32 w = ob[i]; outBuf[2 * i] = (i16)(w & 0xFFFF); outBuf[2 * i + 1] = (i16)(w >> 16); }
+   const int nw = (d->ltp_mem_length + 10 * d->fs_kHz) >> 1;
+   for (int i = 0; i < nw; i += 8) {
+      i32 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = i + k < nw ? ob[i + k] : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (i + k < nw) { outBuf[2 * (i + k)] = (i16)(t[k] & 0xFFFF); outBuf[2 * (i + k) + 1] = (i16)(t[k] >> 16); }
+   }
 }
 WV_DEV void sl_store_channel(OaSilkChannel *g, const SlCh *d, LnI16 outBuf, LnI32 exc, LnI32 cng, i32 *cng_exc)
 {
@@ -99,7 +241,7 @@ WV_DEV void sl_store_channel(OaSilkChannel *g, const SlCh *d, LnI16 outBuf, LnI3
    g->ec_prevSignalType = d->ec_prevSignalType; g->ec_prevLagIndex = d->ec_prevLagIndex;
    for (int i = 0; i < 3; i++) { g->VAD_flags[i] = d->VAD_flags[i]; g->LBRR_flags[i] = d->LBRR_flags[i]; }
    g->LBRR_flag = d->LBRR_flag; g->lossCnt = d->lossCnt; g->prevSignalType = d->prevSignalType;
-   for (int i = 0; i < 90; i++) g->rs_rows[i] = d->rs_rows[i];
+   sl_copy(g->rs_rows, d->rs_rows, 90);
    g->plc_pitchL_Q8 = d->plc_pitchL_Q8; g->plc_last_frame_lost = d->plc_last_frame_lost; g->plc_conc_energy = d->plc_conc_energy; g->plc_conc_energy_shift = d->plc_conc_energy_shift;
    g->plc_prevGain_Q16[0] = d->plc_prevGain_Q16[0]; g->plc_prevGain_Q16[1] = d->plc_prevGain_Q16[1]; g->plc_fs_kHz = d->plc_fs_kHz; g->plc_nb_subfr = d->plc_nb_subfr;
    g->plc_subfr_length = d->plc_subfr_length; g->plc_prevLTP_scale_Q14 = d->plc_prevLTP_scale_Q14;
@@ -109,9 +251,16 @@ WV_DEV void sl_store_channel(OaSilkChannel *g, const SlCh *d, LnI16 outBuf, LnI3
    for (int i = 0; i < 6; i++) g->plc_LTPCoef_Q14[i] = d->plc_LTPCoef_Q14[i];
    g->indices = d->indices;
    i32 *ob = (i32 *)g->outBuf;
-   for (int i = 0; i < ((d->ltp_mem_length + 10 * d->fs_kHz) >> 1); i++) ob[i] = (i32)(((u32)outBuf[2 * i] & 0xFFFFu) | ((u32)outBuf[2 * i + 1] << 16));
-   for (int i = 0; i < d->frame_length; i++) g->exc_Q14[i] = exc[i];
-   if (d->cng_loaded) for (int i = 0; i < 320; i++) cng_exc[i] = cng[i];
+   const int nw = (d->ltp_mem_length + 10 * d->fs_kHz) >> 1;
+   for (int i = 0; i < nw; i += 8) {
+      i32 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = i + k < nw ? (i32)(((u32)outBuf[2 * (i + k)] & 0xFFFFu) | ((u32)outBuf[2 * (i + k) + 1] << 16)) : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (i + k < nw) ob[i + k] = t[k];
+   }
+   if (d->exc_valid) sl_copy(g->exc_Q14, exc, d->frame_length);
+   if (d->cng_loaded) sl_copy(cng_exc, cng, 320);
 }
 
 /* silk_decode_core (silk/decode_core.c:38) as one lane runs it.  The long-term predictor's state needs only the last lag + 2 whitened samples (:147-160 use sLTP[mem - i - 1],
@@ -126,15 +275,22 @@ template <class CH> WV_DEV void sl_decode_core(CH ch, SdCtrl *c, LnI16 xq, LnI16
    const int interp_flag = ix->NLSFInterpCoef_Q2 < 4;
    {
       i32 seed = ix->Seed;
-      for (int i = 0; i < FL; i++) {
-         seed = sk_rand(seed);
-         const i32 q = pulses[i];
-         i32 e = shl32(q, 14);
-         if (e > 0) e -= 80 << 4; else if (e < 0) e += 80 << 4;
-         e += offset_Q10 << 4;
-         if (seed < 0) e = -e;
-         exc[i] = e;
-         seed = add32(seed, q);
+      for (int i0 = 0; i0 < FL; i0 += 8) {                                     /* (frame lengths are multiples of 8) */
+         i32 q[8];
+#pragma unroll
+         for (int k = 0; k < 8; k++) q[k] = pulses[i0 + k];
+#pragma unroll
+         for (int k = 0; k < 8; k++) {
+            seed = sk_rand(seed);
+            i32 e = shl32(q[k], 14);
+            if (e > 0) e -= 80 << 4; else if (e < 0) e += 80 << 4;
+            e += offset_Q10 << 4;
+            if (seed < 0) e = -e;
+            seed = add32(seed, q[k]);
+            q[k] = e;
+         }
+#pragma unroll
+         for (int k = 0; k < 8; k++) exc[i0 + k] = q[k];
       }
    }
    i32 w[20];                                                                 /* w[0..15]: the synthesis outputs of lags 16..1 (oldest first), w[16..19]: the four being made */
@@ -163,7 +319,7 @@ template <class CH> WV_DEV void sl_decode_core(CH ch, SdCtrl *c, LnI16 xq, LnI16
       if (voiced) {
          lag = c->pitchL[k];
          if (k == 0 || (k == 2 && interp_flag)) {
-            if (k == 2) for (int i = 0; i < 2 * L; i++) outBuf[mem + i] = xq[i];
+            if (k == 2) sl_copy(outBuf + mem, xq, 2 * L);
             if (k == 0) inv_gain_Q31 = shl32(sk_mulwb(inv_gain_Q31, c->LTP_scale_Q14), 2);
             const int top = mem - 1 + k * L;                                   /* newest sample of the history */
             i32 h[20];                                                       /* h[j] = history sample top - i0 - j */
@@ -177,14 +333,16 @@ template <class CH> WV_DEV void sl_decode_core(CH ch, SdCtrl *c, LnI16 xq, LnI16
 #pragma unroll
                   for (int j = 16; j < 20; j++) { const int p = top - i0 - j; h[j] = p >= 0 ? (i32)outBuf[p] : 0; }
                }
+               i32 o4[4];
 #pragma unroll
                for (int u = 0; u < 4; u++) {
                   i32 pred = 0;
 #pragma unroll
                   for (int j = 0; j < 16; j++) pred = add32(pred, h[u + 1 + j] * A[j]);
-                  const i32 o = sk_sat16(sk_rround(sub32(shl32(h[u], 12), pred), 12));
-                  if (i0 + u < lag + 2) lt[sLTP_buf_idx - (i0 + u) - 1] = sk_mulwb(inv_gain_Q31, o);
+                  o4[u] = sk_mulwb(inv_gain_Q31, sk_sat16(sk_rround(sub32(shl32(h[u], 12), pred), 12)));
                }
+#pragma unroll
+               for (int u = 0; u < 4; u++) if (i0 + u < lag + 2) lt[sLTP_buf_idx - (i0 + u) - 1] = o4[u];
             }
          } else if (gain_adj_Q16 != (i32)1 << 16) {
             for (int i = 0; i < lag + 2; i++) lt[sLTP_buf_idx - i - 1] = sk_mulww(gain_adj_Q16, lt[sLTP_buf_idx - i - 1]);
@@ -194,25 +352,29 @@ template <class CH> WV_DEV void sl_decode_core(CH ch, SdCtrl *c, LnI16 xq, LnI16
          t0 = pl[-1]; t1 = pl[-2]; t2 = pl[-3]; t3 = pl[-4];
       }
       for (int i0 = 0; i0 < L; i0 += 4) {
+         i32 r4[4], tn4[4], l4[4], x4[4];                                      /* this pass's reads first (the long-term taps lie at least 14 samples back), its writes last */
+#pragma unroll
+         for (int u = 0; u < 4; u++) { r4[u] = pexc[i0 + u]; tn4[u] = voiced ? pl[i0 + u] : 0; }
 #pragma unroll
          for (int u = 0; u < 4; u++) {
-            const int i = i0 + u;
-            i32 r = pexc[i];
+            i32 r = r4[u];
             if (voiced) {
-               const i32 tn = pl[i];
+               const i32 tn = tn4[u];
                i32 p = 2;
                p = sk_mlawb(p, tn, b0); p = sk_mlawb(p, t0, b1); p = sk_mlawb(p, t1, b2); p = sk_mlawb(p, t2, b3); p = sk_mlawb(p, t3, b4);
                t3 = t2; t2 = t1; t1 = t0; t0 = tn;
                r = r + shl32(p, 1);
-               lt[sLTP_buf_idx + i] = shl32(r, 1);
+               l4[u] = shl32(r, 1);
             }
             i32 pred = P >> 1;
 #pragma unroll
             for (int j = 0; j < 16; j++) pred = sk_mlawb(pred, w[16 + u - 1 - j], A[j]);
             const i32 v = sk_add_sat(r, sk_shl_sat(pred, 4));
             w[16 + u] = v;
-            pxq[i] = (i16)sk_sat16(sk_rround(sk_mulww(v, Gain_Q10), 8));
+            x4[u] = sk_sat16(sk_rround(sk_mulww(v, Gain_Q10), 8));
          }
+#pragma unroll
+         for (int u = 0; u < 4; u++) { if (voiced) lt[sLTP_buf_idx + i0 + u] = l4[u]; pxq[i0 + u] = (i16)x4[u]; }
 #pragma unroll
          for (int j = 0; j < 16; j++) w[j] = w[j + 4];
       }
@@ -228,8 +390,8 @@ template <class CH> WV_DEV void sl_decode_core(CH ch, SdCtrl *c, LnI16 xq, LnI16
 template <class CH> WV_DEV void sl_decode_frame_back(CH ch, SdCtrl *c, LnI16 pOut, LnI16 outBuf, LnI32 exc, LnI32 cng, const i32 *cng_exc)
 {
    const int L = ch->frame_length, mv = ch->ltp_mem_length - L;
-   for (int i = 0; i < mv; i++) outBuf[i] = outBuf[L + i];
-   for (int i = 0; i < L; i++) outBuf[mv + i] = pOut[i];
+   sl_copy(outBuf, outBuf + L, mv);
+   sl_copy(outBuf + mv, pOut, L);
    if (ch->fs_kHz != ch->plc_fs_kHz) { sd_plc_reset(ch); ch->plc_fs_kHz = ch->fs_kHz; }
    sd_plc_update(ch, c);
    ch->lossCnt = 0;
@@ -240,10 +402,20 @@ template <class CH> WV_DEV void sl_decode_frame_back(CH ch, SdCtrl *c, LnI16 pOu
       for (int i = 0; i < ch->LPC_order; i++) ch->cng_smth_NLSF_Q15[i] = (i16)(ch->cng_smth_NLSF_Q15[i] + sk_mulwb((i32)ch->prevNLSF_Q15[i] - (i32)ch->cng_smth_NLSF_Q15[i], 16348));
       i32 max_Gain_Q16 = 0; int subfr = 0;
       for (int i = 0; i < ch->nb_subfr; i++) if (c->Gains_Q16[i] > max_Gain_Q16) { max_Gain_Q16 = c->Gains_Q16[i]; subfr = i; }
-      if (!ch->cng_loaded) { for (int i = 0; i < 320; i++) cng[i] = cng_exc[i]; ch->cng_loaded = 1; }
+      if (!ch->cng_loaded) { sl_copy(cng, cng_exc, 320); ch->cng_loaded = 1; }
       const int SL = ch->subfr_length;
-      for (int i = (ch->nb_subfr - 1) * SL - 1; i >= 0; i--) cng[SL + i] = cng[i];
-      for (int i = 0; i < SL; i++) cng[i] = exc[subfr * SL + i];
+      {                                                                        /* memmove up by one subframe, from the top, eight at a time */
+         int i = (ch->nb_subfr - 1) * SL;
+         for (; i >= 8; i -= 8) {
+            i32 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = cng[i - 8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cng[SL + i - 8 + k] = t[k];
+         }
+         for (i--; i >= 0; i--) cng[SL + i] = cng[i];
+      }
+      sl_copy(cng, exc + subfr * SL, SL);
       for (int i = 0; i < ch->nb_subfr; i++) {
          ch->cng_smth_Gain_Q16 += sk_mulwb(c->Gains_Q16[i] - ch->cng_smth_Gain_Q16, 4634);
          if (sk_mulww(ch->cng_smth_Gain_Q16, 46396) > c->Gains_Q16[i]) ch->cng_smth_Gain_Q16 = c->Gains_Q16[i];
@@ -259,7 +431,7 @@ template <class CH> WV_DEV void sl_decode_frame_back(CH ch, SdCtrl *c, LnI16 pOu
  * packet was hybrid too): the SILK layer is decoded and committed here, the range decoder -- behind the redundancy flag, src/opus_decoder.c:503 -- is parked in *hyb_ec, and
  * the return value 2 asks for oa_decode_hyb_kernel (the CELT layer on top of this lane's PCM; it writes the scalars, the sample count and the final range).
  * work: this lane's base in the tile's work area (the tile's base + lane, see SL_WORK_BYTES); ring: the tile's resampler ring in LDS. */
-WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, EcCtx *hyb_ec, char *tile_work, WV_LDS ResamplerLds *ring, const int lane)
+WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, EcCtx *hyb_ec, char *tile_work, WV_LDS ResamplerLds *ring, const WV_LDS SlTabs *tabs, const WV_LDS u8 *win, const int lane)
 {
    const int CC = gs->s.channels, Fs = gs->s.Fs ? gs->s.Fs : 48000;
    const int toc = data[0];
@@ -269,7 +441,8 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    const int audiosize = oa_samples_per_frame(toc, Fs);
    const int internalRate = bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000, fs_kHz = internalRate / 1000;
    const int payload_ms = imax(10, 1000 * audiosize / Fs);
-   const u8 *buf = data + 1; const int flen = len - 1;
+   SlPkt buf; buf.g = data + 1; buf.w = win + lane * SL_WIN_STRIDE;
+   const int flen = len - 1;
 
    i16 *r16 = (i16 *)tile_work + lane;
    i32 *r32 = (i32 *)(tile_work + (size_t)SL_ROWS16 * SL_STREAMS * 2) + lane;
@@ -279,6 +452,7 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    exc[0].p = r32; exc[1].p = r32 + 320 * SL_STREAMS; cng[0].p = r32 + 640 * SL_STREAMS; cng[1].p = r32 + 960 * SL_STREAMS;
 
    SlCh cs[2]; SlDec sd; SdCtrl ctrl;
+   P4_TIC();
    for (int n = 0; n < nch; n++) sl_load_channel(&cs[n], &gs->silk.ch[n], outBuf[n]);
    sd.pred_prev_Q13[0] = gs->silk.pred_prev_Q13[0]; sd.pred_prev_Q13[1] = gs->silk.pred_prev_Q13[1];
    sd.sMid[0] = gs->silk.sMid[0]; sd.sMid[1] = gs->silk.sMid[1]; sd.sSide[0] = gs->silk.sSide[0]; sd.sSide[1] = gs->silk.sSide[1];
@@ -290,7 +464,7 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    }
    EcCtx ec_; EcCtx *e = &ec_;
    k_ec_dec_init(e, buf, (u32)flen);
-   i16 tmp[16];
+   P4_TOC(0);
 
    int decoded = 0;
    do {
@@ -330,7 +504,7 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
                   }
                   const int condCoding = (i > 0 && cs[n].LBRR_flags[i - 1]) ? SD_CODE_CONDITIONALLY : SD_CODE_INDEPENDENTLY;
                   sd_decode_indices(e, buf, &cs[n], i, 1, condCoding);
-                  sd_decode_pulses(e, buf, pulses, cs[n].indices.signalType, cs[n].indices.quantOffsetType, cs[n].frame_length, tmp);
+                  sl_decode_pulses(e, buf, pulses, cs[n].indices.signalType, cs[n].indices.quantOffsetType, cs[n].frame_length, tabs);
                }
             }
          }
@@ -354,22 +528,30 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
             if (FrameIndex <= 0) condCoding = SD_CODE_INDEPENDENTLY;
             else if (n > 0 && sd.prev_decode_only_middle) condCoding = SD_CODE_INDEPENDENTLY_NO_LTP_SCALING;
             else condCoding = SD_CODE_CONDITIONALLY;
-            ctrl.LTP_scale_Q14 = 0;
+            ctrl.LTP_scale_Q14 = 0; ch->exc_valid = 1;
+            P4_TOC(1);
             sd_decode_indices(e, buf, ch, ch->nFramesDecoded, 0, condCoding);
-            sd_decode_pulses(e, buf, pulses, ch->indices.signalType, ch->indices.quantOffsetType, ch->frame_length, tmp);
+            P4_TOC(2);
+            sl_decode_pulses(e, buf, pulses, ch->indices.signalType, ch->indices.quantOffsetType, ch->frame_length, tabs);
+            P4_TOC(3);
             sd_decode_parameters(ch, &ctrl, condCoding);
+            P4_TOC(4);
             sl_decode_core(ch, &ctrl, xq[n] + 2, pulses, exc[n], outBuf[n], lt);
+            P4_TOC(5);
             sl_decode_frame_back(ch, &ctrl, xq[n] + 2, outBuf[n], exc[n], cng[n], &gs->silk.cng_exc_buf_Q14[n][0]);
+            P4_TOC(6);
          } else for (int i = 0; i < nDec; i++) xq[n][2 + i] = 0;
          ch->nFramesDecoded++;
       }
       if (CC == 2 && nch == 2) sd_stereo_ms_to_lr(&sd, xq[0], xq[1], MS_pred_Q13, cs[0].fs_kHz, nDec);
       else for (int i = 0; i < 2; i++) { xq[0][i] = sd.sMid[i]; sd.sMid[i] = xq[0][nDec + i]; }
       const int nOut = (nDec * Fs) / (cs[0].fs_kHz * 1000);
+      P4_TOC(1);
       for (int n = 0; n < nch; n++) {
          SlPcmOut out; out.p = pcm_out + (size_t)decoded * CC + n; out.st = CC;
          silk_resampler_lane(rc, ring, cs[n].rs_rows, 1, xq[n] + 1, nDec, out, lane);
       }
+      P4_TOC(7);
       sd.prev_decode_only_middle = decode_only_middle;
       decoded += nOut;
    } while (decoded < audiosize);
@@ -379,10 +561,12 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    else if (k_ec_tell(e, buf) + 17 <= 8 * flen) return 0;
 
    /* ---- commit ---- */
+   P4_TOC(1);
    for (int n = 0; n < nch; n++) sl_store_channel(&gs->silk.ch[n], &cs[n], outBuf[n], exc[n], cng[n], &gs->silk.cng_exc_buf_Q14[n][0]);
    gs->silk.pred_prev_Q13[0] = sd.pred_prev_Q13[0]; gs->silk.pred_prev_Q13[1] = sd.pred_prev_Q13[1];
    gs->silk.sMid[0] = sd.sMid[0]; gs->silk.sMid[1] = sd.sMid[1]; gs->silk.sSide[0] = sd.sSide[0]; gs->silk.sSide[1] = sd.sSide[1];
    gs->silk.prev_decode_only_middle = sd.prev_decode_only_middle;
+   P4_TOC(8);
    if (hybrid) { *hyb_ec = *e; return 2; }
    gs->s.mode = 1000; gs->s.bandwidth = bandwidth; gs->s.frame_size = audiosize; gs->s.stream_channels = nch;
    gs->s.start = 17; gs->s.end = bandwidth == 1101 ? 13 : 17;                    /* what opus_decode_frame leaves behind for a SILK-only frame (celt_dec_frame.h: oa_decode_frame_wave) */

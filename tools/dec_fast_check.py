@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/dec_fast_check.py — the decoder's CELT-only fast kernel (oa_decode_fast_kernel) in front of the general kernel against the general kernel alone: the same packet
+"""tools/dec_fast_check.py — the decoder's steady-state kernels (oa_decode_fast_kernel: CELT-only; oa_sdec_lane_kernel: SILK-only and the SILK layer of hybrid packets, one lane
+per stream; oa_decode_hyb_kernel: the hybrid packets' CELT layer) in front of the general kernel against the general kernel alone: the same packet
 sequences through OPUS_AMD_DEC_FAST = 0 and 1 (one subprocess each: the switch is read once per process) must give identical PCM, sample counts, final ranges AND identical
 stream records, byte for byte.  The sequences mix what the fast kernel takes (CELT-only, one frame) with what it hands over (SILK / hybrid packets, multi-frame packets, lost
 packets and the frames after them), so that streams move between the kernels.  usage: dec_fast_check.py [emu|gpu]      (child: dec_fast_check.py <lib> <out.pkl>)"""
@@ -34,6 +35,9 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "hyb_mono_10":   (48000, 1, 2048, {11002: 1001, 4004: 1104, 4002: 32000, 4010: 5}, 10, 16, 0),           # super-wideband: bands 17..18
     "hyb_24k_out":   (48000, 2, 2049, {11002: 1001, 4002: 64000, 4010: 5}, 20, 10, 0, 2, "", 24000),         # decoded at 24 kHz: the SILK layer resampled 16 -> 24, the CELT layer decimated
     "hyb_celt_switch": (48000, 2, 2049, {11002: 1001, 4002: 48000, 4010: 5}, 20, 20, 0, 2, "hmode"),           # hybrid <-> CELT-only: redundant frames, transitions
+    "silk_down_12k": (16000, 1, 2048, {11002: 1000, 4002: 24000, 4010: 5}, 20, 12, 5, 1, "", 12000),          # decoded below the internal rate: the resampler's AR2 + FIR path on the lanes
+    "silk_st_down_8k": (16000, 2, 2048, {11002: 1000, 4002: 36000, 4010: 5}, 40, 8, 0, 2, "", 8000),
+    "silk_nb_up_24k": (8000, 1, 2048, {11002: 1000, 4002: 12000, 4010: 5}, 60, 6, 0, 1, "", 24000),
     "silk_bw_switch": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 16, 0, 1, "bw"),   # the bandwidth changes in mid-stream: the general kernel re-initialises, then the lanes again
 }
 if os.environ.get("DEC_FAST_CASES"): CASES = {k: v for k, v in CASES.items() if any(x in k for x in os.environ["DEC_FAST_CASES"].split(","))}
@@ -84,7 +88,7 @@ def run_child(libpath, outp):
         res[name] = (steps, [b.export_state(s) for s in range(S)], lane); b.close()
     pickle.dump(res, open(outp, "wb"))
 
-def compare(which="emu", tmpdir="/tmp", verbose=True):
+def compare(which="emu", tmpdir="/tmp", verbose=True, with_stats=False):
     if which == "emu":
         import hostemu; lib = hostemu.build_emu_lib()
     else: lib = os.path.join(ROOT, "opus_amd/libopus_amd.so")
@@ -100,7 +104,7 @@ def compare(which="emu", tmpdir="/tmp", verbose=True):
         nd = [sum(p != q for p, q in zip(x, y)) for x, y in zip(a[1], b[1])]
         if verbose: print("%-13s output %s, state bytes differing per stream %s; lane kernel took %d packets, handed on %d" % (name, "equal" if ok else "DIFFERS", nd, b[2][0], b[2][1]))
         if not ok or any(nd): bad.append(name)
-    return bad
+    return (bad, {name: r["1"][name][2] for name in CASES}) if with_stats else bad
 
 if __name__ == "__main__":
     if len(sys.argv) == 3: run_child(sys.argv[1], sys.argv[2])
