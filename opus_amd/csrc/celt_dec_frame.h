@@ -220,6 +220,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
    }
    const int effEnd = imin(end, NBE);
    wv_sync();
+   P4_TIC();
    LANE0 {
       EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
       sh->CC = CC; sh->C = C; sh->LM = LM; sh->M = M; sh->N = N; sh->start = start; sh->end = end; sh->effEnd = effEnd; sh->len = len;
@@ -301,6 +302,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
       ec_st(&L->ec, &ec_);
    }
    wv_sync();
+   if (FAST) P4_TOC(10);
    {  /* bit allocation: the same wave routine as the encoder, reading the three side-information symbols (celt_alloc.h) */
       const int coded = oa_allocate_bits_wave<false>(&L->ec, L->packet + 1, L->scr, sh->start, sh->end, L->offsets, L->cap, sh->alloc_trim, &sh->intensity, &sh->dual_stereo, sh->r[4], &sh->balance,
             L->pulses, L->fine_quant, L->fine_priority, sh->C, sh->LM, 0, 0, sh->r + 6);
@@ -310,7 +312,9 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
    /* X starts at zero (the reference's bands below start / above end are never written) */
    { i32 *Xz = L->Xg; FOR_LANES(i, C * N) Xz[i] = 0; }
    wv_sync();
+   if (FAST) P4_TOC(11);
    dec_quant_all_bands_wave(L, sh->shortBlocks, sh->spread, sh->dual_stereo, sh->intensity, sh->pvq_total_bits, sh->balance, sh->codedBands, st->disable_inv);
+   if (FAST) P4_TOC(12);
    LANE0 {
       EC_BEGIN;
       int anti_collapse_on = 0;
@@ -337,6 +341,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
       accum = wv_uni(accum);
       LANE0 { st->postfilter_period = imax(st->postfilter_period, OA_MIN_PERIOD); st->postfilter_period_old = imax(st->postfilter_period_old, OA_MIN_PERIOD); }
       wv_sync();
+      P4_TOC(13);
       if (CC == 2 && C == 1) {
          denormalise_bands_wave(freq, L->oldBandE, L->scr, start, effEnd, M, silence, downsample);
          FOR_LANES(i, N) freq[N + i] = freq[i];        /* the IMDCT consumes its input: keep a copy for the second channel */
@@ -356,9 +361,11 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
          FOR_LANES(i, overlap) syn[i] = gs->overlap_mem[c * overlap + i];
          FOR_LANES(i, N) syn[overlap + i] = 0;
          wv_sync();
+         P4_TOC(14);
          for (int b = 0; b < B; b++) mdct_backward_wave(fc + b, syn + NB * b, shift, B, L->aux);
          FOR_LANES(i, N) syn[i] = saturate(syn[i], SIG_SAT);
          wv_sync();
+         P4_TOC(15);
          K_DUMP("dec_syn", syn, N * 4);
          const i32 *hist = gs->hist + c * OA_DEC_HISTORY;
          comb_filter_inplace_wave(syn, hist, head, 0, st->postfilter_period_old, st->postfilter_period, 120, st->postfilter_gain_old, st->postfilter_gain,
@@ -370,6 +377,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
          FOR_LANES(i, N) gs->hist[c * OA_DEC_HISTORY + ((head + i) & (OA_DEC_HISTORY - 1))] = syn[i];
          FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = syn[N + i];
          wv_sync();
+         P4_TOC(16);
          if (lane == 0) {
             i32 m = st->preemph_memD[c];
             for (int j0 = 0; j0 < N; j0 += 8) {
@@ -384,6 +392,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
             st->preemph_memD[c] = m;
          }
          wv_sync();
+         P4_TOC(17);
          FOR_LANES(i, Nd) {
             const i32 v = syn[i * ds];
             const int it = i * CC + c;
@@ -391,6 +400,7 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
             else pcm_out[it] = (i16)v;
          }
          wv_sync();
+         P4_TOC(18);
       }
       LANE0 {
          st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);

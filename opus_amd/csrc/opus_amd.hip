@@ -206,6 +206,11 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 #ifndef OA_DEC_FAST_WAVES_PER_EU
 #define OA_DEC_FAST_WAVES_PER_EU 4
 #endif
+#ifdef OA_PHASE_TIMERS
+#define OA_DEC_FAST_DYN_LDS_MAX (159 * 1024)          /* (the timers' static LDS words come on top) */
+#else
+#define OA_DEC_FAST_DYN_LDS_MAX (160 * 1024)
+#endif
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,
       char *scratch, unsigned *queue, const int *list /* the streams oa_decode_look_kernel found in the CELT steady state */, const unsigned *list_count)
@@ -220,7 +225,13 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
       const int s = wv_uni(list[i]);
       if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
       __syncthreads();
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_BEGIN();
+#endif
       oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_END();
+#endif
       __syncthreads();
    }
 }
@@ -1685,8 +1696,8 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 4 * sizeof(int) * (size_t)nstreams) == hipSuccess && hipMalloc((void **)&b->d_hyb_ec, sizeof(EcCtx) * (size_t)nstreams) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                hipFuncSetAttribute((const void *)oa_decode_hyb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OA_DEC_FAST_DYN_LDS_MAX) == hipSuccess &&
+                hipFuncSetAttribute((const void *)oa_decode_hyb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OA_DEC_FAST_DYN_LDS_MAX) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_gen, (const void *)oa_decode_kernel, 64, sizeof(DecLds)) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_fast, (const void *)oa_decode_fast_kernel, 64, OA_DEC_FAST_LDS_BYTES) == hipSuccess;
       for (opus_int32 s0 = 0; ok && s0 < nstreams; s0 += 256) {
