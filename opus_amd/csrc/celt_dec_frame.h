@@ -512,7 +512,7 @@ WV_DEV int oa_parse_size(const u8 *data, i32 len, i32 *size)
    else { *size = 4 * data[1] + data[0]; return 2; }
 }
 /* opus_packet_parse_impl (opus.c:224, not self-delimited); lane 0.  Fills sh->size[], returns count or < 0; *payload_offset */
-WV_DEV int oa_packet_parse(const u8 *data, i32 len, WV_LDS i32 *size, int *payload_offset)
+template <class SZ> WV_DEV int oa_packet_parse(const u8 *data, i32 len, SZ size, int *payload_offset)
 {
    int i, bytes, count, framesize;
    u8 ch, toc;
@@ -967,10 +967,12 @@ template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDe
    }
    LANE0 { *nsamples_out = ret; *rng_out = st->rangeFinal; }
 }
+/* between oa_sdec_lane_kernel and oa_decode_hyb_kernel, per stream: the range decoder behind the SILK layer and the redundancy flag, and where the coded frame lies in the packet */
+struct OaHybCont { EcCtx ec; i32 off, flen; };
 /* The CELT layer of a hybrid packet whose SILK layer oa_sdec_lane_kernel has decoded (silk_dec_lane.h): what oa_decode_packet + oa_decode_frame_wave do for a hybrid frame in
  * the steady state (mode == prev_mode == hybrid, one coded frame, no redundancy: src/opus_decoder.c:540-690) from the point where the SILK audio is in pcm_out and the
  * range decoder stands behind the redundancy flag (*cont): bands 17.. of the CELT-only fast kernel's frame function, accumulated onto the SILK audio. */
-WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, const EcCtx *cont)
+WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, const OaHybCont *cont)
 {
    WV_LDS OaDecScalars *st = &L->st;
    {
@@ -981,14 +983,14 @@ WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *d
    }
    wv_sync();
    const int toc = wv_uni((int)data[0]), Fs = oa_dec_fs(st);
-   const int pfs = (toc & 0x08) ? Fs / 50 : Fs / 100, bw = (toc & 0x10) ? 1105 : 1104, flen = len - 1;
+   const int pfs = (toc & 0x08) ? Fs / 50 : Fs / 100, bw = (toc & 0x10) ? 1105 : 1104, flen = wv_uni(cont->flen), off = wv_uni(cont->off);
    LANE0 {
       st->mode = 1001; st->bandwidth = bw; st->frame_size = pfs; st->stream_channels = (toc & 0x4) ? 2 : 1;
       st->start = 17; st->end = bw == 1104 ? 19 : 21;
-      EcCtx ec = *cont;
+      EcCtx ec = cont->ec;
       ec_st(&L->ec_silk, &ec);
    }
-   FOR_LANES(i, flen) L->packet[1 + i] = data[1 + i];
+   FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
    wv_sync();
    const int r = celt_decode_frame_wave<true>(L, gs, flen, pfs, pcm_out, 1, 1);
    if (r >= 0) { LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1001; st->prev_redundancy = 0; st->last_packet_duration = pfs; } }

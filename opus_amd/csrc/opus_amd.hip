@@ -239,7 +239,7 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
  * (celt_dec_frame.h: oa_decode_hybrid_tail), persistent waves over the list the lane kernel built */
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs,
-      char *scratch, unsigned *queue, const int *list, const unsigned *list_count, const EcCtx *hyb_ec)
+      char *scratch, unsigned *queue, const int *list, const unsigned *list_count, const OaHybCont *hyb_ec)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
@@ -250,7 +250,7 @@ oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride,
       const int s = wv_uni(list[i]);
       if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
       __syncthreads();
-      oa_decode_hybrid_tail(L, streams + s, packets + (size_t)s * packet_stride, lens[s], pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s);
+      oa_decode_hybrid_tail(L, streams + s, packets + (size_t)s * packet_stride, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s);
       __syncthreads();
    }
 }
@@ -258,7 +258,7 @@ oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride,
  *   fast list   the CELT steady state and nothing else -- a CELT-only TOC with one coded frame that fits a frame's slot, a stream whose last packet was CELT-only too (or that
  *               has not decoded anything yet), no pending fold of the concealment
  *   lane list   (lane_list != NULL) the SILK steady state -- a SILK-only TOC with one coded frame, the stream's last packet SILK-only too, the internal rate and the channel
- *               count of last time (so that silk_decoder_set_fs and the resampler set-up have nothing to do), API channels = coded channels, nothing lost last time:
+ *               count of last time (so that silk_decoder_set_fs and the resampler set-up have nothing to do), API channels = coded channels or a mono packet into a stereo decoder, nothing lost last time:
  *               oa_sdec_lane_kernel, 64 streams per wave (silk_dec_lane.h) -- and the hybrid steady state (a hybrid TOC with one coded frame after a hybrid packet, no
  *               pending fold of the concealment): the same kernel for the SILK layer, then oa_decode_hyb_kernel for the CELT layer
  *   slow list   everything else: the general kernel
@@ -276,10 +276,11 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
          const int prev = g->s.prev_mode;
          fast = fast_list && (toc & 0x80) && (toc & 3) == 0 && (prev == 0 || prev == 1002) && g->s.prefilter_and_fold == 0;
          const int hyb = (toc & 0x60) == 0x60;
-         if (lane_list && !(toc & 0x80) && (toc & 3) == 0 && (hyb ? prev == 1001 && g->s.prefilter_and_fold == 0 : prev == 1000)) {
+         const int one = (toc & 3) == 0 || ((toc & 3) == 3 && (packets[(size_t)s * packet_stride + 1] & 0x3F) == 1);           /* one coded frame: code 0, or code 3 with M = 1 (a padded packet) */
+         if (lane_list && !(toc & 0x80) && one && (hyb ? prev == 1001 && g->s.prefilter_and_fold == 0 : prev == 1000)) {
             const int Fs = g->s.Fs ? g->s.Fs : 48000, nch = (toc & 0x4) ? 2 : 1, bw = 1101 + ((toc >> 5) & 0x3);
             const int rate = hyb ? 16000 : bw == 1101 ? 8000 : bw == 1102 ? 12000 : 16000;
-            ln = oa_samples_per_frame(toc, Fs) <= frame_size && nch == g->s.channels && g->silk.nChannelsInternal == nch && g->silk.nChannelsAPI == nch && g->silk.lastChannelsInternal == nch &&
+            ln = oa_samples_per_frame(toc, Fs) <= frame_size && (nch == g->s.channels || nch == 1) && g->silk.nChannelsInternal == nch && g->silk.nChannelsAPI == g->s.channels && g->silk.lastChannelsInternal == nch &&
                  g->silk.lastInternalRate == rate;
             for (int n = 0; n < nch && ln; n++) ln = g->silk.ch[n].fs_kHz * 1000 == rate && g->silk.ch[n].fs_API_hz == Fs && g->silk.ch[n].lossCnt == 0 && g->silk.ch[n].rs_cfg[5] * 1000 == rate;
          }
@@ -307,7 +308,7 @@ oa_decode_look_kernel(const OaDecStream *streams, const u8 *packets, int packet_
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_SDEC_WAVES_PER_EU)
 oa_sdec_lane_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, char *work, int tile_width,
-      const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected, int *hyb_list, unsigned *hyb_count, EcCtx *hyb_ec)
+      const int *list, const unsigned *list_count, int *slow_list, unsigned *slow_count, unsigned *rejected, int *hyb_list, unsigned *hyb_count, OaHybCont *hyb_ec)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    const int n = (int)*list_count, ntiles = (n + tile_width - 1) / tile_width, lane = (int)threadIdx.x;
@@ -1623,7 +1624,7 @@ struct OpusGpuDecBatch {
    char *d_scratch; size_t scratch_cap;     /* per resident wave: the spectrum of the frame in flight (OA_DEC_SCRATCH_BYTES) */
    unsigned *d_queue; int *d_slow;          /* d_queue [0] fast kernel's queue, [1] general kernel's queue; [2] / [3] the lengths of the two lists; d_slow [2][S]: the streams oa_decode_look_kernel sent to the fast kernel, then those it left to the general one */
    int num_cu, occ_fast, occ_gen;
-   char *d_lane_work; size_t lane_work_cap; EcCtx *d_hyb_ec;   /* [S] the range decoders of the hybrid packets between the lane kernel and oa_decode_hyb_kernel */
+   char *d_lane_work; size_t lane_work_cap; OaHybCont *d_hyb_ec;   /* [S] the range decoders of the hybrid packets between the lane kernel and oa_decode_hyb_kernel */
     /* oa_sdec_lane_kernel's work rows, SL_WORK_BYTES per block of its grid */
    int no_lane;                             /* opusgpu_dec_batch_set_lane_kernel(b, 0): SILK-only packets go to the general kernel too */
    int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
@@ -1693,7 +1694,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipMalloc((void **)&b->d_lens, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_ns, sizeof(opus_int32) * (size_t)nstreams) == hipSuccess &&
                 hipMalloc((void **)&b->d_rng, sizeof(opus_uint32) * (size_t)nstreams) == hipSuccess &&
-                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 4 * sizeof(int) * (size_t)nstreams) == hipSuccess && hipMalloc((void **)&b->d_hyb_ec, sizeof(EcCtx) * (size_t)nstreams) == hipSuccess &&
+                hipMalloc((void **)&b->d_queue, 64) == hipSuccess && hipMalloc((void **)&b->d_slow, 4 * sizeof(int) * (size_t)nstreams) == hipSuccess && hipMalloc((void **)&b->d_hyb_ec, sizeof(OaHybCont) * (size_t)nstreams) == hipSuccess &&
                 hipDeviceGetAttribute(&b->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OA_DEC_FAST_DYN_LDS_MAX) == hipSuccess &&
@@ -1788,7 +1789,7 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
       if (use_lane)                                                   /* (d_queue [6] the hybrid list's length, [7] the kernel's queue; an empty list costs the launch) */
          hipLaunchKernelGGL(oa_decode_hyb_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
                b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range,
-               b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const EcCtx *)b->d_hyb_ec);
+               b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const OaHybCont *)b->d_hyb_ec);
    }
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,

@@ -93,8 +93,8 @@ template <class D, class S> WV_DEV void sl_copy(D dst, S src, int n)
 #define SL_WIN 128
 #define SL_WIN_STRIDE 132
 struct SlPkt {
-   const u8 *g; const WV_LDS u8 *w;
-   WV_MEM int operator[](u32 i) const { return i < SL_WIN ? (int)w[i] : (int)g[i]; }
+   const u8 *g; const WV_LDS u8 *w; u32 sh;                            /* the window holds the packet from its second byte on; the coded frame starts sh bytes into it */
+   WV_MEM int operator[](u32 i) const { return i + sh < SL_WIN ? (int)w[i + sh] : (int)g[i]; }
 };
 /* the pulse coder's tables in LDS, each padded so that a four-entry look-ahead never leaves it (sl_dec_icdf): silk/tables_pulses_per_block.c:34-263 */
 struct SlTabs { u8 ppb[180 + 4]; u8 rate[18 + 2]; u8 shell[4][152]; u8 shell_pad[4]; u8 sign[42 + 2]; u8 offs[17 + 3]; };
@@ -431,7 +431,7 @@ template <class CH> WV_DEV void sl_decode_frame_back(CH ch, SdCtrl *c, LnI16 pOu
  * packet was hybrid too): the SILK layer is decoded and committed here, the range decoder -- behind the redundancy flag, src/opus_decoder.c:503 -- is parked in *hyb_ec, and
  * the return value 2 asks for oa_decode_hyb_kernel (the CELT layer on top of this lane's PCM; it writes the scalars, the sample count and the final range).
  * work: this lane's base in the tile's work area (the tile's base + lane, see SL_WORK_BYTES); ring: the tile's resampler ring in LDS. */
-WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, EcCtx *hyb_ec, char *tile_work, WV_LDS ResamplerLds *ring, const WV_LDS SlTabs *tabs, const WV_LDS u8 *win, const int lane)
+WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, OaHybCont *hyb, char *tile_work, WV_LDS ResamplerLds *ring, const WV_LDS SlTabs *tabs, const WV_LDS u8 *win, const int lane)
 {
    const int CC = gs->s.channels, Fs = gs->s.Fs ? gs->s.Fs : 48000;
    const int toc = data[0];
@@ -441,8 +441,13 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    const int audiosize = oa_samples_per_frame(toc, Fs);
    const int internalRate = bandwidth == 1101 ? 8000 : bandwidth == 1102 ? 12000 : 16000, fs_kHz = internalRate / 1000;
    const int payload_ms = imax(10, 1000 * audiosize / Fs);
-   SlPkt buf; buf.g = data + 1; buf.w = win + lane * SL_WIN_STRIDE;
-   const int flen = len - 1;
+   int off = 1, flen = len - 1;
+   if (toc & 3) {                                                   /* a code-3 packet with one frame (what a CBR encoder's padding makes of a packet): opus_packet_parse_impl, src/opus.c:224 */
+      i32 size[48];
+      if (oa_packet_parse(data, len, size, &off) != 1 || size[0] <= 1) return 0;
+      flen = size[0];
+   }
+   SlPkt buf; buf.g = data + off; buf.w = win + lane * SL_WIN_STRIDE; buf.sh = (u32)(off - 1);
 
    i16 *r16 = (i16 *)tile_work + lane;
    i32 *r32 = (i32 *)(tile_work + (size_t)SL_ROWS16 * SL_STREAMS * 2) + lane;
@@ -551,6 +556,16 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
          SlPcmOut out; out.p = pcm_out + (size_t)decoded * CC + n; out.st = CC;
          silk_resampler_lane(rc, ring, cs[n].rs_rows, 1, xq[n] + 1, nDec, out, lane);
       }
+      if (CC == 2 && nch == 1) {                                    /* a mono packet into a stereo decoder: both channels get the one signal (silk/dec_API.c:401) */
+         i16 *pp = pcm_out + (size_t)decoded * 2;
+         for (int i0 = 0; i0 < nOut; i0 += 8) {
+            i32 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = i0 + k < nOut ? pp[2 * (i0 + k)] : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (i0 + k < nOut) pp[2 * (i0 + k) + 1] = (i16)t[k];
+         }
+      }
       P4_TOC(7);
       sd.prev_decode_only_middle = decode_only_middle;
       decoded += nOut;
@@ -567,7 +582,7 @@ WV_DEVN int oa_sdec_lane_packet(OaDecStream *gs, const u8 *data, int len, i16 *p
    gs->silk.sMid[0] = sd.sMid[0]; gs->silk.sMid[1] = sd.sMid[1]; gs->silk.sSide[0] = sd.sSide[0]; gs->silk.sSide[1] = sd.sSide[1];
    gs->silk.prev_decode_only_middle = sd.prev_decode_only_middle;
    P4_TOC(8);
-   if (hybrid) { *hyb_ec = *e; return 2; }
+   if (hybrid) { hyb->ec = *e; hyb->off = off; hyb->flen = flen; return 2; }
    gs->s.mode = 1000; gs->s.bandwidth = bandwidth; gs->s.frame_size = audiosize; gs->s.stream_channels = nch;
    gs->s.start = 17; gs->s.end = bandwidth == 1101 ? 13 : 17;                    /* what opus_decode_frame leaves behind for a SILK-only frame (celt_dec_frame.h: oa_decode_frame_wave) */
    gs->s.rangeFinal = e->rng; gs->s.prev_mode = 1000; gs->s.prev_redundancy = 0; gs->s.last_packet_duration = decoded;

@@ -38,6 +38,7 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "silk_down_12k": (16000, 1, 2048, {11002: 1000, 4002: 24000, 4010: 5}, 20, 12, 5, 1, "", 12000),          # decoded below the internal rate: the resampler's AR2 + FIR path on the lanes
     "silk_st_down_8k": (16000, 2, 2048, {11002: 1000, 4002: 36000, 4010: 5}, 40, 8, 0, 2, "", 8000),
     "silk_nb_up_24k": (8000, 1, 2048, {11002: 1000, 4002: 12000, 4010: 5}, 60, 6, 0, 1, "", 24000),
+    "hyb_cbr_mono_in_stereo": (48000, 1, 2049, {11002: 1001, 4002: 32000, 4010: 5, 4006: 0}, 20, 10, 0, 2),   # padded hybrid packets (code 3, one frame), mono into a stereo decoder
     "silk_bw_switch": (16000, 1, 2048, {11002: 1000, 4002: 20000, 4010: 5}, 20, 16, 0, 1, "bw"),   # the bandwidth changes in mid-stream: the general kernel re-initialises, then the lanes again
 }
 if os.environ.get("DEC_FAST_CASES"): CASES = {k: v for k, v in CASES.items() if any(x in k for x in os.environ["DEC_FAST_CASES"].split(","))}
