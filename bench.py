@@ -475,7 +475,7 @@ def run_config(cid, S, K, W, dev, local, rank, world, gather_cls=None, with_cpu=
         r2 = dict(res); r2.pop("pcm_sample", None); r2.pop("frames_per_launch", None); r2.pop("kernels_ms", None)
         r2["leg"] = "decode"; r2["dt"] = time.perf_counter() - t0
         r2["kernel_ms"] = float(np.mean([a.elapsed_time(b_) for a, b_ in dev_ev]))
-        r2["kernel"] = "oa_decode_look_kernel + oa_sdec_lane_kernel (SILK steady state, lane = stream) + oa_decode_fast_kernel / oa_decode_hyb_kernel (CELT) + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (opusgpu_dec_batch_set_fast_kernel(b, 0))"
+        r2["kernel"] = "oa_decode_look_kernel + oa_sdec_lane_kernel (SILK steady state, lane = stream) + oa_decode_fast_kernel / oa_decode_hyb_kernel (CELT frames up to their bands) + oa_celt_dpvq_kernel (the bands, four streams per wave) + oa_celt_dback_kernel (synthesis) + oa_decode_kernel (one call)" if fast_kernel else "oa_decode_kernel (opusgpu_dec_batch_set_fast_kernel(b, 0))"
         r2["dec_fast_kernel"] = bool(fast_kernel)
         r2["all_packets_valid"] = bool((dns.cpu().numpy() == FR).all()) and bool(torch.equal(drng, rng))      # every stream decoded FR samples and every frame ends on the encoder's final range
         L.opusgpu_dec_state_size.restype = ctypes.c_int

@@ -265,6 +265,8 @@ OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fec(OpusGpuDecBatch *b, int decode_fec
 OPUS_AMD_EXPORT int opusgpu_dec_batch_set_fast_kernel(OpusGpuDecBatch *b, int enable);   /* 0: skip the CELT-only fast kernel (a batch without CELT-only packets saves its look at every stream); default 1; same output either way */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_set_lane_kernel(OpusGpuDecBatch *b, int enable);   /* 0: skip oa_sdec_lane_kernel (the SILK steady state, one lane per stream: silk/dec_API.c:142 silk_Decode for 64 streams per wave); default 1; same output either way */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_lane_stats(OpusGpuDecBatch *b, opus_uint32 *taken, opus_uint32 *handed_on);   /* the last call: packets oa_sdec_lane_kernel was given / of those, handed on to the general kernel (a redundant CELT frame behind the SILK data, src/opus_decoder.c:499-526) */
+OPUS_AMD_EXPORT int opusgpu_dec_batch_set_pvq_stage(OpusGpuDecBatch *b, int mode);   /* the band decoding (celt/bands.c:1589 quant_all_bands, encode = 0) of steady-state CELT-only / hybrid packets of one 10 / 20 ms frame as oa_celt_dpvq_kernel, four streams per wave: -1 (default) wide calls, 0 never, 1 always; same output either way */
+OPUS_AMD_EXPORT int opusgpu_dec_batch_pvq_stats(OpusGpuDecBatch *b, opus_uint32 *frames);   /* the last call: frames whose bands oa_celt_dpvq_kernel decoded */
 OPUS_AMD_EXPORT int opusgpu_dec_batch_reset(OpusGpuDecBatch *b);
 OPUS_AMD_EXPORT int opusgpu_dec_state_size(void);
 OPUS_AMD_EXPORT int opusgpu_dec_batch_export_state(OpusGpuDecBatch *b, opus_int32 stream, void *blob);

@@ -107,6 +107,7 @@ def lib():
         if hasattr(L, "opusgpu_dec_batch_set_fast_kernel"): L.opusgpu_dec_batch_set_fast_kernel.argtypes = [vp, ctypes.c_int]
         if hasattr(L, "opusgpu_dec_batch_set_lane_kernel"): L.opusgpu_dec_batch_set_lane_kernel.argtypes = [vp, ctypes.c_int]
         if hasattr(L, "opusgpu_dec_batch_lane_stats"): L.opusgpu_dec_batch_lane_stats.argtypes = [vp, vp, vp]
+        if hasattr(L, "opusgpu_dec_batch_set_pvq_stage"): L.opusgpu_dec_batch_set_pvq_stage.argtypes = [vp, ctypes.c_int]; L.opusgpu_dec_batch_pvq_stats.argtypes = [vp, vp]
         L.opusgpu_decode_batch.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp]
         L.opusgpu_decode_batch_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, vp]
         L.opusgpu_time_decode_dev.argtypes = [vp, vp, i32, vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
@@ -299,6 +300,16 @@ class DecoderBatch:
         """False: the following calls skip the lane = stream SILK kernel (oa_sdec_lane_kernel); the output is the same either way"""
         r = self._L.opusgpu_dec_batch_set_lane_kernel(self._b, 1 if enable else 0)
         if r != OPUS_OK: raise OpusError(r)
+    def set_pvq_stage(self, mode):
+        """-1: wide calls (the default), 0: never, 1: always -- the bands of steady-state CELT frames on oa_celt_dpvq_kernel (four streams per wave); the output is the same either way"""
+        r = self._L.opusgpu_dec_batch_set_pvq_stage(self._b, int(mode))
+        if r != OPUS_OK: raise OpusError(r)
+    def pvq_stats(self):
+        """frames of the last call whose bands oa_celt_dpvq_kernel decoded"""
+        a = ctypes.c_uint32()
+        r = self._L.opusgpu_dec_batch_pvq_stats(self._b, ctypes.byref(a))
+        if r != OPUS_OK: raise OpusError(r)
+        return a.value
     def decode_dev(self, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream=None):
         r = self._L.opusgpu_decode_batch_dev(self._b, d_pkt_ptr, stride, d_lens_ptr, d_pcm_ptr, frame_size, d_ns_ptr, d_rng_ptr, hip_stream)
         if r != OPUS_OK: raise OpusError(r)

@@ -5,5 +5,6 @@
 #include "celt_dec_lds.h"
 #include "celt_dec_energy.h"
 #include "celt_dec_bands.h"
+#include "celt_dec_pvq4.h"
 #include "celt_dec_frame.h"
 #endif

@@ -195,126 +195,20 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
 
 #include "celt_dec_plc.h"
 
-/* ---- one CELT frame (celt_decoder.c:1104).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
-/* ec_cont: continue the range decoder parked in L->ec_silk (hybrid frames) instead of starting one; accum: add onto pcm_out (celt_decoder.c:1104 `dec`, `accum`) */
-/* FAST: the instance of the CELT-only fast kernel (opus_amd.hip: oa_decode_fast_kernel): the concealment and the post-concealment fold are compiled out -- the kernel only takes
- * packets that reach neither */
-template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int ec_cont = 0, int accum = 0)
+/* the frame from behind its bands to the end (celt_decoder.c:1476-1640): anti-collapse, energy finalisation, synthesis, post-filter, state update, de-emphasis.  Called by
+ * celt_decode_frame_wave where the bands were decoded in place, and by the back kernel of the decoder's kernel pipeline (oa_celt_dback_kernel) on the reloaded LDS image:
+ * everything it needs of the frame is in L->sh / L->st. */
+template <bool FAST> WV_DEV int celt_decode_frame_tail(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int accum)
 {
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
    const int overlap = OA_OVERLAP;
    const int lane = wv_lane();
    len = wv_uni(len); frame_size = wv_uni(frame_size);
-   const int downsample = oa_dec_downsample(st);                        /* frame_size is in API-rate samples; the codec runs at 48 kHz (celt_decoder.c:1185) */
-   int LM;
-   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size * downsample) break;
-   if (LM > 3) return OA_ERR_BAD_ARG;
-   if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
-   const int M = 1 << LM, N = M * 120;
-   const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
-   if (!FAST && len <= 1) {                                       /* lost / DTX frame: conceal (celt_decoder.c:1306) */
-      celt_decode_lost_wave(L, gs, N, LM);
-      celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
-      return frame_size;
-   }
-   const int effEnd = imin(end, NBE);
-   wv_sync();
+   const int downsample = oa_dec_downsample(st);
+   const int LM = wv_uni(sh->LM), M = 1 << LM, N = M * 120;
+   const int CC = wv_uni(sh->CC), C = wv_uni(sh->C), start = wv_uni(sh->start), end = wv_uni(sh->end), effEnd = wv_uni(sh->effEnd);
    P4_TIC();
-   LANE0 {
-      EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
-      sh->CC = CC; sh->C = C; sh->LM = LM; sh->M = M; sh->N = N; sh->start = start; sh->end = end; sh->effEnd = effEnd; sh->len = len;
-      if (st->loss_duration == 0) st->skip_plc = 0;
-      if (ec_cont) { ec_ld(e, &L->ec_silk); e->storage = (u32)len; } else k_ec_dec_init(EC_PASS, len);
-      if (C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[i] = imax(L->oldBandE[i], L->oldBandE[NBE + i]);
-      i32 total_bits = len * 8, tell = k_ec_tell(EC_PASS);
-      int silence;
-      if (tell >= total_bits) silence = 1;
-      else if (tell == 1) silence = k_ec_dec_bit_logp(EC_PASS, 15);
-      else silence = 0;
-      if (silence) { tell = len * 8; e->nbits_total += tell - k_ec_tell(EC_PASS); }
-      int postfilter_gain = 0, postfilter_pitch = 0, postfilter_tapset = 0;
-      if (start == 0 && tell + 16 <= total_bits) {
-         if (k_ec_dec_bit_logp(EC_PASS, 1)) {
-            int qg, octave = k_ec_dec_uint(EC_PASS, 6);
-            postfilter_pitch = (16 << octave) + k_ec_dec_bits(EC_PASS, 4 + octave) - 1;
-            qg = k_ec_dec_bits(EC_PASS, 3);
-            if (k_ec_tell(EC_PASS) + 2 <= total_bits) postfilter_tapset = k_ec_dec_icdf(EC_PASS, k_tapset_icdf, 2);
-            postfilter_gain = (i16)(QC16(.09375f, 15) * (qg + 1));
-         }
-         tell = k_ec_tell(EC_PASS);
-      }
-      int isTransient = 0;
-      if (LM > 0 && tell + 3 <= total_bits) { isTransient = k_ec_dec_bit_logp(EC_PASS, 3); tell = k_ec_tell(EC_PASS); }
-      const int shortBlocks = isTransient ? M : 0;
-      const int intra_ener = tell + 3 <= total_bits ? k_ec_dec_bit_logp(EC_PASS, 3) : 0;
-      if (!intra_ener && st->loss_duration != 0) {          /* energy prediction safety after a loss (celt_decoder.c:1387) */
-         for (int c = 0; c < 2; c++) {
-            i32 safety = 0;
-            int missing = imin(10, st->loss_duration >> LM);
-            if (LM == 0) safety = GC(1.5f);
-            else if (LM == 1) safety = GC(.5f);
-            for (int i = start; i < end; i++) {
-               i32 E0 = L->oldBandE[c * NBE + i], E1 = L->oldLogE[c * NBE + i], E2 = L->oldLogE2[c * NBE + i];
-               if (E0 < imax(E1, E2)) {
-                  i32 slope = imax(E1 - E0, half32(E2 - E0));
-                  slope = imin(slope, GC(2.f));
-                  E0 -= imax(0, (1 + missing) * slope);
-                  E0 = imax(-GC(20.f), E0);
-               } else E0 = imin(imin(E0, E1), E2);
-               L->oldBandE[c * NBE + i] = E0 - safety;
-            }
-         }
-      }
-      coarse_energy_read_l0(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM, L->scr);
-      tf_read_l0(start, end, isTransient, L->tf_res, LM, EC_PASS);
-      tell = k_ec_tell(EC_PASS);
-      int spread_decision = 2;
-      if (tell + 4 <= total_bits) spread_decision = k_ec_dec_icdf(EC_PASS, k_spread_icdf, 5);
-      k_init_caps(L->cap, LM, C);
-      int dynalloc_logp = 6;
-      total_bits <<= BITRES;
-      tell = k_ec_tell_frac(EC_PASS);
-      for (int i = start; i < end; i++) {
-         int width = C * (ct_eBands[i + 1] - ct_eBands[i]) << LM;
-         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
-         int dynalloc_loop_logp = dynalloc_logp, boost = 0;
-         while (tell + (dynalloc_loop_logp << BITRES) < total_bits && boost < L->cap[i]) {
-            int flag = k_ec_dec_bit_logp(EC_PASS, dynalloc_loop_logp);
-            tell = k_ec_tell_frac(EC_PASS);
-            if (!flag) break;
-            boost += quanta;
-            total_bits -= quanta;
-            dynalloc_loop_logp = 1;
-         }
-         L->offsets[i] = boost;
-         if (boost > 0) dynalloc_logp = imax(2, dynalloc_logp - 1);
-      }
-      const int alloc_trim = tell + (6 << BITRES) <= total_bits ? k_ec_dec_icdf(EC_PASS, k_trim_icdf, 7) : 5;
-      i32 bits = (((i32)len * 8) << BITRES) - (i32)k_ec_tell_frac(EC_PASS) - 1;
-      const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
-      bits -= anti_collapse_rsv;
-      sh->intensity = 0; sh->dual_stereo = 0; sh->balance = 0;
-      sh->silence = silence; sh->postfilter_pitch = postfilter_pitch; sh->postfilter_gain = postfilter_gain; sh->postfilter_tapset = postfilter_tapset;
-      sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision;
-      sh->anti_collapse_rsv = anti_collapse_rsv; sh->alloc_trim = alloc_trim; sh->r[4] = bits;
-      sh->pvq_total_bits = len * (8 << BITRES) - anti_collapse_rsv;
-      ec_st(&L->ec, &ec_);
-   }
-   wv_sync();
-   if (FAST) P4_TOC(10);
-   {  /* bit allocation: the same wave routine as the encoder, reading the three side-information symbols (celt_alloc.h) */
-      const int coded = oa_allocate_bits_wave<false>(&L->ec, L->packet + 1, L->scr, sh->start, sh->end, L->offsets, L->cap, sh->alloc_trim, &sh->intensity, &sh->dual_stereo, sh->r[4], &sh->balance,
-            L->pulses, L->fine_quant, L->fine_priority, sh->C, sh->LM, 0, 0, sh->r + 6);
-      LANE0 sh->codedBands = coded;
-   }
-   fine_energy_read_wave(&L->ec, L->packet + 1, L->scr, sh->r + 6, sh->start, sh->end, L->oldBandE, L->fine_quant, sh->C);
-   /* X starts at zero (the reference's bands below start / above end are never written) */
-   { i32 *Xz = L->Xg; FOR_LANES(i, C * N) Xz[i] = 0; }
-   wv_sync();
-   if (FAST) P4_TOC(11);
-   dec_quant_all_bands_wave(L, sh->shortBlocks, sh->spread, sh->dual_stereo, sh->intensity, sh->pvq_total_bits, sh->balance, sh->codedBands, st->disable_inv);
-   if (FAST) P4_TOC(12);
    LANE0 {
       EC_BEGIN;
       int anti_collapse_on = 0;
@@ -493,6 +387,130 @@ template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L
    wv_sync();
    ret = wv_uni(sh->r[1]);
    return ret;
+}
+
+/* ---- one CELT frame (celt_decoder.c:1104).  The frame's bytes are at L->packet + 1.  Returns the frame size or < 0. ---- */
+/* ec_cont: continue the range decoder parked in L->ec_silk (hybrid frames) instead of starting one; accum: add onto pcm_out (celt_decoder.c:1104 `dec`, `accum`) */
+/* FAST: the instance of the CELT-only fast kernel (opus_amd.hip: oa_decode_fast_kernel): the concealment and the post-concealment fold are compiled out -- the kernel only takes
+ * packets that reach neither */
+template <bool FAST = false> WV_DEVN int celt_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int ec_cont = 0, int accum = 0, int cut = 0 /* FAST: stop in front of the bands of a 10 / 20 ms frame and return OA_DEC_CUT (the kernel pipeline, celt_dec_pvq4.h) */)
+{
+   WV_LDS DecShared *sh = &L->sh;
+   WV_LDS OaDecScalars *st = &L->st;
+   const int overlap = OA_OVERLAP;
+   const int lane = wv_lane();
+   len = wv_uni(len); frame_size = wv_uni(frame_size);
+   const int downsample = oa_dec_downsample(st);                        /* frame_size is in API-rate samples; the codec runs at 48 kHz (celt_decoder.c:1185) */
+   int LM;
+   for (LM = 0; LM <= 3; LM++) if (120 << LM == frame_size * downsample) break;
+   if (LM > 3) return OA_ERR_BAD_ARG;
+   if (len < 0 || len > 1275) return OA_ERR_BAD_ARG;
+   const int M = 1 << LM, N = M * 120;
+   const int CC = wv_uni(st->channels), C = wv_uni(st->stream_channels), start = wv_uni(st->start), end = wv_uni(st->end);
+   if (!FAST && len <= 1) {                                       /* lost / DTX frame: conceal (celt_decoder.c:1306) */
+      celt_decode_lost_wave(L, gs, N, LM);
+      celt_emit_frame_wave(L, gs, N, CC, pcm_out, accum);
+      return frame_size;
+   }
+   const int effEnd = imin(end, NBE);
+   wv_sync();
+   P4_TIC();
+   LANE0 {
+      EcCtx ec_; EcCtx *e = &ec_; WV_LDS u8 *buf = L->packet + 1;
+      sh->CC = CC; sh->C = C; sh->LM = LM; sh->M = M; sh->N = N; sh->start = start; sh->end = end; sh->effEnd = effEnd; sh->len = len;
+      if (st->loss_duration == 0) st->skip_plc = 0;
+      if (ec_cont) { ec_ld(e, &L->ec_silk); e->storage = (u32)len; } else k_ec_dec_init(EC_PASS, len);
+      if (C == 1) for (int i = 0; i < NBE; i++) L->oldBandE[i] = imax(L->oldBandE[i], L->oldBandE[NBE + i]);
+      i32 total_bits = len * 8, tell = k_ec_tell(EC_PASS);
+      int silence;
+      if (tell >= total_bits) silence = 1;
+      else if (tell == 1) silence = k_ec_dec_bit_logp(EC_PASS, 15);
+      else silence = 0;
+      if (silence) { tell = len * 8; e->nbits_total += tell - k_ec_tell(EC_PASS); }
+      int postfilter_gain = 0, postfilter_pitch = 0, postfilter_tapset = 0;
+      if (start == 0 && tell + 16 <= total_bits) {
+         if (k_ec_dec_bit_logp(EC_PASS, 1)) {
+            int qg, octave = k_ec_dec_uint(EC_PASS, 6);
+            postfilter_pitch = (16 << octave) + k_ec_dec_bits(EC_PASS, 4 + octave) - 1;
+            qg = k_ec_dec_bits(EC_PASS, 3);
+            if (k_ec_tell(EC_PASS) + 2 <= total_bits) postfilter_tapset = k_ec_dec_icdf(EC_PASS, k_tapset_icdf, 2);
+            postfilter_gain = (i16)(QC16(.09375f, 15) * (qg + 1));
+         }
+         tell = k_ec_tell(EC_PASS);
+      }
+      int isTransient = 0;
+      if (LM > 0 && tell + 3 <= total_bits) { isTransient = k_ec_dec_bit_logp(EC_PASS, 3); tell = k_ec_tell(EC_PASS); }
+      const int shortBlocks = isTransient ? M : 0;
+      const int intra_ener = tell + 3 <= total_bits ? k_ec_dec_bit_logp(EC_PASS, 3) : 0;
+      if (!intra_ener && st->loss_duration != 0) {          /* energy prediction safety after a loss (celt_decoder.c:1387) */
+         for (int c = 0; c < 2; c++) {
+            i32 safety = 0;
+            int missing = imin(10, st->loss_duration >> LM);
+            if (LM == 0) safety = GC(1.5f);
+            else if (LM == 1) safety = GC(.5f);
+            for (int i = start; i < end; i++) {
+               i32 E0 = L->oldBandE[c * NBE + i], E1 = L->oldLogE[c * NBE + i], E2 = L->oldLogE2[c * NBE + i];
+               if (E0 < imax(E1, E2)) {
+                  i32 slope = imax(E1 - E0, half32(E2 - E0));
+                  slope = imin(slope, GC(2.f));
+                  E0 -= imax(0, (1 + missing) * slope);
+                  E0 = imax(-GC(20.f), E0);
+               } else E0 = imin(imin(E0, E1), E2);
+               L->oldBandE[c * NBE + i] = E0 - safety;
+            }
+         }
+      }
+      coarse_energy_read_l0(start, end, L->oldBandE, intra_ener, EC_PASS, C, LM, L->scr);
+      tf_read_l0(start, end, isTransient, L->tf_res, LM, EC_PASS);
+      tell = k_ec_tell(EC_PASS);
+      int spread_decision = 2;
+      if (tell + 4 <= total_bits) spread_decision = k_ec_dec_icdf(EC_PASS, k_spread_icdf, 5);
+      k_init_caps(L->cap, LM, C);
+      int dynalloc_logp = 6;
+      total_bits <<= BITRES;
+      tell = k_ec_tell_frac(EC_PASS);
+      for (int i = start; i < end; i++) {
+         int width = C * (ct_eBands[i + 1] - ct_eBands[i]) << LM;
+         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
+         int dynalloc_loop_logp = dynalloc_logp, boost = 0;
+         while (tell + (dynalloc_loop_logp << BITRES) < total_bits && boost < L->cap[i]) {
+            int flag = k_ec_dec_bit_logp(EC_PASS, dynalloc_loop_logp);
+            tell = k_ec_tell_frac(EC_PASS);
+            if (!flag) break;
+            boost += quanta;
+            total_bits -= quanta;
+            dynalloc_loop_logp = 1;
+         }
+         L->offsets[i] = boost;
+         if (boost > 0) dynalloc_logp = imax(2, dynalloc_logp - 1);
+      }
+      const int alloc_trim = tell + (6 << BITRES) <= total_bits ? k_ec_dec_icdf(EC_PASS, k_trim_icdf, 7) : 5;
+      i32 bits = (((i32)len * 8) << BITRES) - (i32)k_ec_tell_frac(EC_PASS) - 1;
+      const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
+      bits -= anti_collapse_rsv;
+      sh->intensity = 0; sh->dual_stereo = 0; sh->balance = 0;
+      sh->silence = silence; sh->postfilter_pitch = postfilter_pitch; sh->postfilter_gain = postfilter_gain; sh->postfilter_tapset = postfilter_tapset;
+      sh->isTransient = isTransient; sh->shortBlocks = shortBlocks; sh->spread = spread_decision;
+      sh->anti_collapse_rsv = anti_collapse_rsv; sh->alloc_trim = alloc_trim; sh->r[4] = bits;
+      sh->pvq_total_bits = len * (8 << BITRES) - anti_collapse_rsv;
+      ec_st(&L->ec, &ec_);
+   }
+   wv_sync();
+   if (FAST) P4_TOC(10);
+   {  /* bit allocation: the same wave routine as the encoder, reading the three side-information symbols (celt_alloc.h) */
+      const int coded = oa_allocate_bits_wave<false>(&L->ec, L->packet + 1, L->scr, sh->start, sh->end, L->offsets, L->cap, sh->alloc_trim, &sh->intensity, &sh->dual_stereo, sh->r[4], &sh->balance,
+            L->pulses, L->fine_quant, L->fine_priority, sh->C, sh->LM, 0, 0, sh->r + 6);
+      LANE0 sh->codedBands = coded;
+   }
+   fine_energy_read_wave(&L->ec, L->packet + 1, L->scr, sh->r + 6, sh->start, sh->end, L->oldBandE, L->fine_quant, sh->C);
+   /* X starts at zero (the reference's bands below start / above end are never written) */
+   { i32 *Xz = L->Xg; FOR_LANES(i, C * N) Xz[i] = 0; }
+   wv_sync();
+   if (FAST) P4_TOC(11);
+   if (FAST && wv_uni(cut) && LM >= 2) return OA_DEC_CUT;
+   dec_quant_all_bands_wave(L, sh->shortBlocks, sh->spread, sh->dual_stereo, sh->intensity, sh->pvq_total_bits, sh->balance, sh->codedBands, st->disable_inv);
+   if (FAST) P4_TOC(12);
+   return celt_decode_frame_tail<FAST>(L, gs, len, frame_size, pcm_out, accum);
 }
 
 /* ---- Opus packet layer: opus_decode_native (opus_decoder.c:716) for CELT-only packets ---- */
@@ -694,7 +712,7 @@ WV_DEV void oa_transition_gain_wave(const WV_LDS OaDecScalars *st, i16 *x, int n
 }
 /* One Opus frame with payload (opus_decode_frame, src/opus_decoder.c:271-714, data != NULL): SILK part, redundancy, CELT part, mode transitions.
  * `data` = the frame's bytes in HBM, len >= 2.  Returns the frame size or a negative OA_ERR_*. */
-template <bool FAST = false> WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0)
+template <bool FAST = false> WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int audiosize, i16 *pcm, int CC, int decode_fec = 0, int cut = 0)
 {
    if (FAST) {                                                                  /* CELT-only steady state: opus_decode_frame with mode == prev_mode == CELT_ONLY (or a fresh decoder), no redundancy */
       WV_LDS OaDecScalars *st = &L->st;
@@ -708,8 +726,8 @@ template <bool FAST = false> WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, 
          switch (bandwidth) { case 1101: endband = 13; break; case 1102: case 1103: endband = 17; break; case 1104: endband = 19; break; default: endband = 21; }
          LANE0 { st->end = endband; st->start = 0; }
       }
-      const int r = celt_decode_frame_wave<true>(L, gs, len, imin(F20, audiosize), pcm, 0, 0);
-      if (r < 0) return r;
+      const int r = celt_decode_frame_wave<true>(L, gs, len, imin(F20, audiosize), pcm, 0, 0, cut);
+      if (r < 0) return r;                                                      /* (OA_DEC_CUT too: oa_decode_packet_back finishes the frame) */
       LANE0 { st->rangeFinal = st->rng; st->prev_mode = mode; st->prev_redundancy = 0; }
       wv_sync();
       return audiosize;
@@ -867,7 +885,10 @@ template <bool FAST = false> WV_DEVN int oa_decode_frame_wave(WV_LDS DecLds *L, 
 }
 
 /* one packet of one stream: returns samples per channel (written to pcm_out, interleaved) or a negative OPUS_* code */
-template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0)
+/* cont (FAST only): the stream's continuation record -- a packet of one 10 / 20 ms frame stops in front of its bands, the wave's LDS image goes to the record and the
+ * function returns 1 (the frame is finished by oa_celt_dpvq_kernel and oa_celt_dback_kernel: oa_decode_packet_back); otherwise 0 */
+template <bool FAST = false> WV_DEV int oa_decode_packet(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, int len, int frame_size, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int decode_fec = 0,
+      CeltDecCont *cont = 0)
 {
    decode_fec = wv_uni(decode_fec);
    WV_LDS DecShared *sh = &L->sh;
@@ -944,7 +965,7 @@ template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDe
       } else {
          LANE0 { st->start = 0; }                        /* (the packet's band limit applies inside, after the transition fade sources are concealed with the old one: src/opus_decoder.c:388, :540, :547) */
          wv_sync();
-         r = oa_decode_frame_wave<FAST>(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC);
+         r = oa_decode_frame_wave<FAST>(L, gs, data + off, flen, pfs, pcm_out + (size_t)nb * CC, CC, 0, FAST && cont != 0 && count == 1);
       }
       if (r < 0) ret = r;
       else nb += r;
@@ -957,6 +978,12 @@ template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDe
          nb += r;
       }
    }
+   if (FAST && ret == OA_DEC_CUT) {                 /* the frame stops here: everything the rest of it needs is in the wave's LDS up to the phase scratch */
+      wv_sync();
+      FOR_LANES(i, (int)(offsetof(DecLds, BC) / 4)) cont->image[i] = ((const WV_LDS i32 *)L)[i];
+      wv_sync();
+      return 1;
+   }
    if (ret >= 0) { ret = nb; LANE0 st->last_packet_duration = nb; wv_sync(); }
    /* ---- store state ---- */
    {
@@ -966,13 +993,36 @@ template <bool FAST = false> WV_DEV void oa_decode_packet(WV_LDS DecLds *L, OaDe
       FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
    }
    LANE0 { *nsamples_out = ret; *rng_out = st->rangeFinal; }
+   return 0;
+}
+/* The rest of a packet whose frame was stopped in front of its bands (oa_decode_packet<true> / oa_decode_hybrid_tail with a continuation record) once oa_celt_dpvq_kernel has
+ * decoded them: the LDS image back, the frame from behind the bands (celt_decode_frame_tail), then what oa_decode_frame_wave and oa_decode_packet do after a CELT-only frame
+ * in the steady state -- or oa_decode_hybrid_tail after the CELT layer of a hybrid one (accumulated onto the SILK audio) -- : final range, mode memory, duration, state store. */
+WV_DEV void oa_decode_packet_back(WV_LDS DecLds *L, OaDecStream *gs, const CeltDecCont *cont, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
+{
+   wv_sync();
+   FOR_LANES(i, (int)(offsetof(DecLds, BC) / 4)) ((WV_LDS i32 *)L)[i] = cont->image[i];
+   wv_sync();
+   WV_LDS OaDecScalars *st = &L->st;
+   const int mode = wv_uni(st->mode), pfs = wv_uni(st->frame_size), len = wv_uni(L->sh.len);
+   const int r = celt_decode_frame_tail<true>(L, gs, len, pfs, pcm_out, mode == 1001);
+   if (r >= 0) { LANE0 { st->rangeFinal = st->rng; st->prev_mode = mode; st->prev_redundancy = 0; st->last_packet_duration = pfs; } }
+   wv_sync();
+   {
+      i32 *g = (i32 *)&gs->s;
+      const WV_LDS i32 *d = (const WV_LDS i32 *)st;
+      FOR_LANES(i, (int)(sizeof(OaDecScalars) / 4)) g[i] = d[i];
+      FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
+   }
+   LANE0 { *nsamples_out = r < 0 ? r : pfs; *rng_out = st->rangeFinal; }
 }
 /* between oa_sdec_lane_kernel and oa_decode_hyb_kernel, per stream: the range decoder behind the SILK layer and the redundancy flag, and where the coded frame lies in the packet */
 struct OaHybCont { EcCtx ec; i32 off, flen; };
 /* The CELT layer of a hybrid packet whose SILK layer oa_sdec_lane_kernel has decoded (silk_dec_lane.h): what oa_decode_packet + oa_decode_frame_wave do for a hybrid frame in
  * the steady state (mode == prev_mode == hybrid, one coded frame, no redundancy: src/opus_decoder.c:540-690) from the point where the SILK audio is in pcm_out and the
  * range decoder stands behind the redundancy flag (*cont): bands 17.. of the CELT-only fast kernel's frame function, accumulated onto the SILK audio. */
-WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, const OaHybCont *cont)
+/* dcont: as in oa_decode_packet -- the frame stops in front of its bands, returns 1 */
+WV_DEV int oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *data, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, const OaHybCont *cont, CeltDecCont *dcont = 0)
 {
    WV_LDS OaDecScalars *st = &L->st;
    {
@@ -992,7 +1042,13 @@ WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *d
    }
    FOR_LANES(i, flen) L->packet[1 + i] = data[off + i];
    wv_sync();
-   const int r = celt_decode_frame_wave<true>(L, gs, flen, pfs, pcm_out, 1, 1);
+   const int r = celt_decode_frame_wave<true>(L, gs, flen, pfs, pcm_out, 1, 1, dcont != 0);
+   if (r == OA_DEC_CUT) {
+      wv_sync();
+      FOR_LANES(i, (int)(offsetof(DecLds, BC) / 4)) dcont->image[i] = ((const WV_LDS i32 *)L)[i];
+      wv_sync();
+      return 1;
+   }
    if (r >= 0) { LANE0 { st->rangeFinal = st->rng; st->prev_mode = 1001; st->prev_redundancy = 0; st->last_packet_duration = pfs; } }
    wv_sync();
    {
@@ -1002,5 +1058,6 @@ WV_DEV void oa_decode_hybrid_tail(WV_LDS DecLds *L, OaDecStream *gs, const u8 *d
       FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
    }
    LANE0 { *nsamples_out = r < 0 ? r : pfs; *rng_out = st->rangeFinal; }
+   return 0;
 }
 #endif

@@ -760,7 +760,7 @@ WV_DEV void p4_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, u8 *ecbuf, const P4
 /* quant_band (bands.c:1248) around the tree: what is done to the band before (p4_qb_pre) and after (p4_qb_post) quant_partition */
 struct P4Qb { int N0, recombine, time_divide, B0, N_B0, longBlocks, B; };
 
-WV_DEV void p4_qb_pre(WV_LDS P4Group *G, P4Tree &tr, P4Qb &qb, int tf_change, int nmax)
+WV_DEV void p4_qb_pre(WV_LDS P4Group *G, P4Tree &tr, P4Qb &qb, int tf_change, int nmax, int do_x = 1 /* 0: the decoder -- the band has no content yet, only the folding source is transformed */)
 {
    WV_LDS i32 *X = G->Xb + tr.xo;
    WV_LDS i32 *lowband = tr.lb >= 0 ? G->lbs + tr.lb : (WV_LDS i32 *)0;
@@ -770,14 +770,14 @@ WV_DEV void p4_qb_pre(WV_LDS P4Group *G, P4Tree &tr, P4Qb &qb, int tf_change, in
    P4_TIC();
    if (tf_change > 0) qb.recombine = tf_change;
    for (int k = 0; k < qb.recombine; k++) {
-      p4_haar1(X, N >> k, 1 << k);
+      if (do_x) p4_haar1(X, N >> k, 1 << k);
       if (lowband) p4_haar1(lowband, N >> k, 1 << k);
       fill = k_bit_interleave_table[fill & 0xF] | k_bit_interleave_table[fill >> 4] << 2;
    }
    B >>= qb.recombine;
    N_B <<= qb.recombine;
    while ((N_B & 1) == 0 && tf_change < 0) {
-      p4_haar1(X, N_B, B);
+      if (do_x) p4_haar1(X, N_B, B);
       if (lowband) p4_haar1(lowband, N_B, B);
       fill |= fill << B;
       B <<= 1;
@@ -787,7 +787,7 @@ WV_DEV void p4_qb_pre(WV_LDS P4Group *G, P4Tree &tr, P4Qb &qb, int tf_change, in
    }
    qb.B0 = B; qb.N_B0 = N_B;
    if (B > 1) {
-      p4_deinterleave_hadamard(X, N_B >> qb.recombine, B << qb.recombine, qb.longBlocks, nmax);
+      if (do_x) p4_deinterleave_hadamard(X, N_B >> qb.recombine, B << qb.recombine, qb.longBlocks, nmax);
       if (lowband) p4_deinterleave_hadamard(lowband, N_B >> qb.recombine, B << qb.recombine, qb.longBlocks, nmax);
    }
    tr.B = B; tr.fill = fill;

@@ -213,22 +213,25 @@ oa_decode_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, con
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, int frame_size, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,
-      char *scratch, unsigned *queue, const int *list /* the streams oa_decode_look_kernel found in the CELT steady state */, const unsigned *list_count)
+      char *scratch, unsigned *queue, const int *list /* the streams oa_decode_look_kernel found in the CELT steady state */, const unsigned *list_count,
+      CeltDecCont *conts /* NULL, or [stream]: the kernel pipeline -- a packet of one 10 / 20 ms frame stops in front of its bands, its stream goes on the list of its frame size
+                          * (cut_list [2][nstreams]: 20 ms, 10 ms; cut_count[2]) for oa_celt_dpvq_kernel / oa_celt_dback_kernel; the spectrum of every packet then lives in the stream's record */,
+      int *cut_list, unsigned *cut_count)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
-   (void)nstreams;
    const int n = (int)*list_count;
    for (;;) {
       const int i = oa_queue_pop(queue);
       if (i >= n) break;
       const int s = wv_uni(list[i]);
-      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      if (threadIdx.x == 0) L->Xg = conts ? conts[s].xg : (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
       __syncthreads();
 #ifdef OA_PHASE_TIMERS
       P4_PROF_BEGIN();
 #endif
-      oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0);
+      const int cut = oa_decode_packet<true>(L, streams + s, packets + (size_t)s * packet_stride, lens[s], frame_size, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, 0, conts ? conts + s : (CeltDecCont *)0);
+      if (cut) { if (threadIdx.x == 0) { const int w = L->sh.LM == 3 ? 0 : 1; cut_list[(size_t)w * nstreams + atomicAdd(cut_count + w, 1u)] = s; } }
 #ifdef OA_PHASE_TIMERS
       P4_PROF_END();
 #endif
@@ -239,7 +242,8 @@ oa_decode_fast_kernel(OaDecStream *streams, const u8 *packets, int packet_stride
  * (celt_dec_frame.h: oa_decode_hybrid_tail), persistent waves over the list the lane kernel built */
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
 oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride, const i32 *lens, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs,
-      char *scratch, unsigned *queue, const int *list, const unsigned *list_count, const OaHybCont *hyb_ec)
+      char *scratch, unsigned *queue, const int *list, const unsigned *list_count, const OaHybCont *hyb_ec,
+      CeltDecCont *conts /* as in oa_decode_fast_kernel */, int *cut_list, unsigned *cut_count, int nstreams)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
@@ -248,9 +252,54 @@ oa_decode_hyb_kernel(OaDecStream *streams, const u8 *packets, int packet_stride,
       const int i = oa_queue_pop(queue);
       if (i >= n) break;
       const int s = wv_uni(list[i]);
-      if (threadIdx.x == 0) L->Xg = (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
+      if (threadIdx.x == 0) L->Xg = conts ? conts[s].xg : (i32 *)(scratch + (size_t)blockIdx.x * OA_DEC_SCRATCH_BYTES);
       __syncthreads();
-      oa_decode_hybrid_tail(L, streams + s, packets + (size_t)s * packet_stride, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s);
+      const int cut = oa_decode_hybrid_tail(L, streams + s, packets + (size_t)s * packet_stride, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, hyb_ec + s, conts ? conts + s : (CeltDecCont *)0);
+      if (cut) { if (threadIdx.x == 0) { const int w = L->sh.LM == 3 ? 0 : 1; cut_list[(size_t)w * nstreams + atomicAdd(cut_count + w, 1u)] = s; } }
+      __syncthreads();
+   }
+}
+/* The bands of the frames the two kernels above stopped: four streams per wave, one 16-lane group each (celt_dec_pvq4.h); a wave takes four entries of ONE list (the bands of
+ * a wave go in lockstep, their sizes depend on the frame size).  queue: the tile counter. */
+#ifndef OA_DPVQ4_WAVES_PER_EU
+#define OA_DPVQ4_WAVES_PER_EU 3
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_DPVQ4_WAVES_PER_EU)
+oa_celt_dpvq_kernel(CeltDecCont *conts, const int *cut_list, const unsigned *cut_count, unsigned *queue, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS P4Lds *L4 = (WV_LDS P4Lds *)smem;
+   const int n0 = (int)wv_uni((i32)cut_count[0]), n1 = (int)wv_uni((i32)cut_count[1]);
+   const int t0 = (n0 + 3) >> 2, t1 = (n1 + 3) >> 2;
+   for (;;) {
+      int t = 0;
+      if (wv_lane() == 0) t = (int)atomicAdd(queue, 1u);
+      t = wv_bcast(t, 0);
+      if (t >= t0 + t1) break;
+      const int w = t >= t0, k = (w ? t - t0 : t) * 4 + wg_id(), n = w ? n1 : n0;
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_BEGIN();
+#endif
+      p4d_quant_all_bands(L4, k < n ? conts + cut_list[(size_t)w * nstreams + k] : (CeltDecCont *)0);
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_END();
+#endif
+      __syncthreads();
+   }
+}
+/* ... and the rest of their packets: one wave per stream again, the front wave's LDS reloaded from the continuation record (celt_dec_frame.h: oa_decode_packet_back) */
+extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
+oa_celt_dback_kernel(OaDecStream *streams, const CeltDecCont *conts, const int *cut_list, const unsigned *cut_count, unsigned *queue, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams)
+{
+   extern __shared__ __attribute__((aligned(16))) char smem[];
+   WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
+   const int n0 = (int)wv_uni((i32)cut_count[0]), n1 = (int)wv_uni((i32)cut_count[1]);
+   for (;;) {
+      const int k = oa_queue_pop(queue);
+      if (k >= n0 + n1) break;
+      const int s = wv_uni(k < n0 ? cut_list[k] : cut_list[(size_t)nstreams + (k - n0)]);
+      __syncthreads();
+      oa_decode_packet_back(L, streams + s, conts + s, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s);
       __syncthreads();
    }
 }
@@ -1628,6 +1677,9 @@ struct OpusGpuDecBatch {
     /* oa_sdec_lane_kernel's work rows, SL_WORK_BYTES per block of its grid */
    int no_lane;                             /* opusgpu_dec_batch_set_lane_kernel(b, 0): SILK-only packets go to the general kernel too */
    int no_fast;                             /* opusgpu_dec_batch_set_fast_kernel(b, 0): every packet goes to the general kernel */
+   int pvq_stage;                           /* opusgpu_dec_batch_set_pvq_stage: -1 wide launches (the default), 0 never, 1 always -- the bands of the steady-state CELT frames by oa_celt_dpvq_kernel, four streams per wave */
+   CeltDecCont *d_dcont; int *d_cut;        /* [S] continuation records of the decoder's kernel pipeline; [2][S] the streams the front kernels stopped, by frame size (20 ms, 10 ms) */
+   int occ_dpvq;
 };
 int opusgpu_dec_state_size(void) { return (int)sizeof(OaDecStream); }
 /* decode_fec of the following calls (opus_decode's last argument, include/opus.h:516): 1 = decode the in-band FEC (LBRR) copy the packets carry for
@@ -1647,6 +1699,19 @@ int opusgpu_dec_batch_lane_stats(OpusGpuDecBatch *b, opus_uint32 *taken, opus_ui
    return OPUS_OK;
 }
 int opusgpu_dec_batch_set_lane_kernel(OpusGpuDecBatch *b, int enable) { if (!b || enable < 0 || enable > 1) return OPUS_BAD_ARG; b->no_lane = !enable; return OPUS_OK; }
+/* the band decoding (quant_all_bands) of the CELT-only and hybrid steady-state packets of one 10 / 20 ms frame as a kernel of its own with four streams per wave
+ * (oa_celt_dpvq_kernel, celt_dec_pvq4.h) between the kernels that decode the rest of those frames: -1 (the default) when the call is wider than one round of the fast kernel's
+ * waves, 0 never, 1 always.  The output is the same either way.  The last call's count: opusgpu_dec_batch_pvq_stats. */
+int opusgpu_dec_batch_set_pvq_stage(OpusGpuDecBatch *b, int mode) { if (!b || mode < -1 || mode > 1) return OPUS_BAD_ARG; b->pvq_stage = mode; return OPUS_OK; }
+int opusgpu_dec_batch_pvq_stats(OpusGpuDecBatch *b, opus_uint32 *frames)
+{
+   if (!b || !frames) return OPUS_BAD_ARG;
+   unsigned q[2] = { 0, 0 };
+   HIPCHECK(hipSetDevice(b->device)); HIPCHECK(hipStreamSynchronize(b->stream));
+   HIPCHECK(hipMemcpy(q, b->d_queue + 8, sizeof(q), hipMemcpyDeviceToHost));
+   *frames = q[0] + q[1];
+   return OPUS_OK;
+}
 int opusgpu_dec_kernel_lds_bytes(void) { return (int)sizeof(DecLds); }
 int opusgpu_dec_fast_kernel_lds_bytes(void) { return (int)OA_DEC_FAST_LDS_BYTES; }
 opus_int32 opusgpu_dec_batch_streams(const OpusGpuDecBatch *b) { return b ? b->S : 0; }
@@ -1666,6 +1731,8 @@ void opusgpu_dec_batch_destroy(OpusGpuDecBatch *b)
    if (b->d_slow) (void)hipFree(b->d_slow);
    if (b->d_lane_work) (void)hipFree(b->d_lane_work);
    if (b->d_hyb_ec) (void)hipFree(b->d_hyb_ec);
+   if (b->d_dcont) (void)hipFree(b->d_dcont);
+   if (b->d_cut) (void)hipFree(b->d_cut);
    if (b->stream) (void)hipStreamDestroy(b->stream);
    delete b;
 }
@@ -1687,7 +1754,7 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
       b = new OpusGpuDecBatch();
       b->device = device; b->S = nstreams; b->n_act = nstreams; b->channels = channels; b->Fs = Fs; b->decode_fec = 0; b->stream = nullptr; b->d_streams = nullptr;
       b->d_pkt = nullptr; b->pkt_cap = 0; b->d_pcm = nullptr; b->pcm_cap = 0; b->d_lens = nullptr; b->d_ns = nullptr; b->d_rng = nullptr;
-      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0; b->d_lane_work = nullptr; b->lane_work_cap = 0; b->no_lane = 0; b->d_hyb_ec = nullptr;
+      b->d_scratch = nullptr; b->scratch_cap = 0; b->d_queue = nullptr; b->d_slow = nullptr; b->num_cu = 0; b->occ_fast = 0; b->occ_gen = 0; b->no_fast = 0; b->d_lane_work = nullptr; b->lane_work_cap = 0; b->no_lane = 0; b->d_hyb_ec = nullptr; b->pvq_stage = -1; b->d_dcont = nullptr; b->d_cut = nullptr; b->occ_dpvq = 0;
       std::vector<OaDecStream> init((size_t)(nstreams < 256 ? nstreams : 256), *proto);
       bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreate(&b->stream) == hipSuccess &&
                 hipMalloc((void **)&b->d_streams, sizeof(OaDecStream) * (size_t)nstreams) == hipSuccess &&
@@ -1700,7 +1767,8 @@ OpusGpuDecBatch *opusgpu_dec_batch_create(opus_int32 nstreams, opus_int32 Fs, in
                 hipFuncSetAttribute((const void *)oa_decode_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OA_DEC_FAST_DYN_LDS_MAX) == hipSuccess &&
                 hipFuncSetAttribute((const void *)oa_decode_hyb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OA_DEC_FAST_DYN_LDS_MAX) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_gen, (const void *)oa_decode_kernel, 64, sizeof(DecLds)) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_fast, (const void *)oa_decode_fast_kernel, 64, OA_DEC_FAST_LDS_BYTES) == hipSuccess;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_fast, (const void *)oa_decode_fast_kernel, 64, OA_DEC_FAST_LDS_BYTES) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->occ_dpvq, (const void *)oa_celt_dpvq_kernel, 64, sizeof(P4Lds)) == hipSuccess;
       for (opus_int32 s0 = 0; ok && s0 < nstreams; s0 += 256) {
          opus_int32 n = nstreams - s0 < 256 ? nstreams - s0 : 256;
          ok = hipMemcpy(b->d_streams + s0, init.data(), sizeof(OaDecStream) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
@@ -1783,13 +1851,32 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
                b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, b->d_lane_work, lane_tw,
                (const int *)(b->d_slow + 2 * (size_t)b->S), (const unsigned *)(b->d_queue + 4), b->d_slow + b->S, b->d_queue + 3, b->d_queue + 5,
                b->d_slow + 3 * (size_t)b->S, b->d_queue + 6, b->d_hyb_ec);
+      /* the kernel pipeline of the steady-state CELT frames (opusgpu_dec_batch_set_pvq_stage; process default OPUS_AMD_DEC_PVQ4): the two kernels below stop a packet of one
+       * 10 / 20 ms frame in front of its bands, oa_celt_dpvq_kernel decodes the bands of four streams per wave, oa_celt_dback_kernel finishes the packets.
+       * d_queue [8] / [9] the lengths of the 20 ms / 10 ms lists, [10] the PVQ kernel's tile counter, [11] the back kernel's queue */
+      static const int pvq_env = getenv("OPUS_AMD_DEC_PVQ4") ? atoi(getenv("OPUS_AMD_DEC_PVQ4")) : -1;
+      const int pvq_mode = b->pvq_stage >= 0 ? b->pvq_stage : pvq_env;
+      const bool dpipe = (use_fast || use_lane) && (pvq_mode < 0 ? (long long)b->n_act > g_fast : pvq_mode > 0);
+      if (dpipe && !b->d_dcont) {
+         HIPCHECK(hipMalloc((void **)&b->d_dcont, sizeof(CeltDecCont) * (size_t)b->S));
+         HIPCHECK(hipMalloc((void **)&b->d_cut, 2 * sizeof(int) * (size_t)b->S));
+      }
+      CeltDecCont *const dc = dpipe ? b->d_dcont : (CeltDecCont *)nullptr;
       if (use_fast) hipLaunchKernelGGL(oa_decode_fast_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
             b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,
-            (u32 *)d_final_range, (int)b->n_act, b->d_scratch, b->d_queue, (const int *)b->d_slow, (const unsigned *)(b->d_queue + 2));
+            (u32 *)d_final_range, (int)b->S, b->d_scratch, b->d_queue, (const int *)b->d_slow, (const unsigned *)(b->d_queue + 2), dc, b->d_cut, b->d_queue + 8);
       if (use_lane)                                                   /* (d_queue [6] the hybrid list's length, [7] the kernel's queue; an empty list costs the launch) */
          hipLaunchKernelGGL(oa_decode_hyb_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
                b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range,
-               b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const OaHybCont *)b->d_hyb_ec);
+               b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const OaHybCont *)b->d_hyb_ec, dc, b->d_cut, b->d_queue + 8, (int)b->S);
+      if (dpipe) {
+         long long g_pvq = (long long)(b->occ_dpvq < 1 ? 1 : b->occ_dpvq) * cu;
+         const long long tiles = ((long long)b->n_act + 3) / 4 + 1;
+         if (g_pvq > tiles) g_pvq = tiles;
+         hipLaunchKernelGGL(oa_celt_dpvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), b->d_queue + 10, (int)b->S);
+         hipLaunchKernelGGL(oa_celt_dback_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
+               b->d_streams, (const CeltDecCont *)b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), b->d_queue + 11, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, (int)b->S);
+      }
    }
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,
          b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, frame_size, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples,

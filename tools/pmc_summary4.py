@@ -7,7 +7,7 @@ root, out = sys.argv[1], sys.argv[2]
 FR = 16384; GiB = 1 << 30
 # resident waves per SIMD of each kernel (LDS / VGPR footprint: tools/kernel_resources.sh + the launch's dynamic LDS); front: 12 waves per CU mono, 10 stereo
 WPS = {"oa_encode_kernel": 4.0, "oa_celt_front_kernel": 4.0, "oa_celt_pvq_kernel": 3.0, "oa_celt_back_kernel": 4.0, "oa_sh_back2_kernel": 3.0, "oa_celt_sort_kernel": 8.0, "oa_sh_front_kernel": 4.0, "oa_sh_quant_kernel": 2.0, "oa_sh_back_kernel": 3.0, "oa_decode_kernel": 2.0, "oa_decode_fast_kernel": 4.0, "oa_sh_encode_kernel": 1.75,
-       "oa_decode_look_kernel": 8.0, "oa_ms_split_kernel": 8.0, "oa_ms_pack_kernel": 8.0,
+       "oa_decode_look_kernel": 8.0, "oa_decode_hyb_kernel": 4.0, "oa_celt_dpvq_kernel": 3.0, "oa_celt_dback_kernel": 4.0, "oa_sdec_lane_kernel": 2.0, "oa_ms_split_kernel": 8.0, "oa_ms_pack_kernel": 8.0,
        "oa_sh_pred_kernel": 8.0, "oa_sh_predc_kernel": 8.0, "oa_sh_preda_kernel": 1.0, "oa_sh_predb_kernel": 1.0, "oa_celt_transient_kernel": 2.0, "oa_sh_transient_kernel": 2.0}      # (round 5: the front kernel holds 16 waves per CU mono, 12 stereo -- config 4 below)
 WPS_BY_LEG = {"config_4": {"oa_sh_front_kernel": 3.0}}
 def table(d, f):
