@@ -556,11 +556,11 @@ WV_DEV void denormalise_bands_wave(i32 *XF, const WV_LDS i32 *bandLogE, WV_LDS i
       }
    }
    wv_sync();
+   const int lm = ec_ilog((u32)M) - 1;
    FOR_LANES(j, N) {
       i32 v = 0;
       if (j >= M * ct_eBands[start] && j < bound) {
-         int bnd = start;
-         while (j >= M * ct_eBands[bnd + 1]) bnd++;
+         const int bnd = ct_band_of[j >> lm];
          v = pshr32(mult32_32_q31(shl32(XF[j], 30 - NORM_SHIFT), gains[bnd]), gains[NBE + bnd]);
       }
       XF[j] = v;

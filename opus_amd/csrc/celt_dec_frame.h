@@ -198,7 +198,9 @@ WV_DEVN void celt_emit_frame_wave(WV_LDS DecLds *L, OaDecStream *gs, int N, int 
 /* the frame from behind its bands to the end (celt_decoder.c:1476-1640): anti-collapse, energy finalisation, synthesis, post-filter, state update, de-emphasis.  Called by
  * celt_decode_frame_wave where the bands were decoded in place, and by the back kernel of the decoder's kernel pipeline (oa_celt_dback_kernel) on the reloaded LDS image:
  * everything it needs of the frame is in L->sh / L->st. */
-template <bool FAST> WV_DEV int celt_decode_frame_tail(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int accum)
+/* hdr (FAST only; NULL, or two words of the stream's continuation record): the de-emphasis and the PCM store are left to oa_celt_deemph_kernel (one lane per stream): every
+ * channel's post-filtered samples go where its spectrum was (the IMDCT has consumed it), hdr[0] = N, hdr[1] = accum | 2 * (channel 0 sits in the second half) */
+template <bool FAST> WV_DEV int celt_decode_frame_tail(WV_LDS DecLds *L, OaDecStream *gs, int len, int frame_size, i16 *pcm_out, int accum, i32 *hdr = 0)
 {
    WV_LDS DecShared *sh = &L->sh;
    WV_LDS OaDecScalars *st = &L->st;
@@ -272,6 +274,11 @@ template <bool FAST> WV_DEV int celt_decode_frame_tail(WV_LDS DecLds *L, OaDecSt
          FOR_LANES(i, overlap) gs->overlap_mem[c * overlap + i] = syn[N + i];
          wv_sync();
          P4_TOC(16);
+         if (hdr) {
+            FOR_LANES(i, N) fc[i] = syn[i];
+            wv_sync();
+            continue;
+         }
          if (lane == 0) {
             i32 m = st->preemph_memD[c];
             for (int j0 = 0; j0 < N; j0 += 8) {
@@ -296,6 +303,7 @@ template <bool FAST> WV_DEV int celt_decode_frame_tail(WV_LDS DecLds *L, OaDecSt
          wv_sync();
          P4_TOC(18);
       }
+      if (hdr) { LANE0 { hdr[0] = N; hdr[1] = (accum ? 1 : 0) | (CC == 2 && C == 1 ? 2 : 0); } }
       LANE0 {
          st->hist_head = (st->hist_head + N) & (OA_DEC_HISTORY - 1);
          st->postfilter_period_old = st->postfilter_period; st->postfilter_gain_old = st->postfilter_gain; st->postfilter_tapset_old = st->postfilter_tapset;
@@ -998,14 +1006,15 @@ template <bool FAST = false> WV_DEV int oa_decode_packet(WV_LDS DecLds *L, OaDec
 /* The rest of a packet whose frame was stopped in front of its bands (oa_decode_packet<true> / oa_decode_hybrid_tail with a continuation record) once oa_celt_dpvq_kernel has
  * decoded them: the LDS image back, the frame from behind the bands (celt_decode_frame_tail), then what oa_decode_frame_wave and oa_decode_packet do after a CELT-only frame
  * in the steady state -- or oa_decode_hybrid_tail after the CELT layer of a hybrid one (accumulated onto the SILK audio) -- : final range, mode memory, duration, state store. */
-WV_DEV void oa_decode_packet_back(WV_LDS DecLds *L, OaDecStream *gs, const CeltDecCont *cont, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out)
+WV_DEV void oa_decode_packet_back(WV_LDS DecLds *L, OaDecStream *gs, CeltDecCont *cont, i16 *pcm_out, i32 *nsamples_out, u32 *rng_out, int defer_deemph)
 {
    wv_sync();
    FOR_LANES(i, (int)(offsetof(DecLds, BC) / 4)) ((WV_LDS i32 *)L)[i] = cont->image[i];
    wv_sync();
    WV_LDS OaDecScalars *st = &L->st;
    const int mode = wv_uni(st->mode), pfs = wv_uni(st->frame_size), len = wv_uni(L->sh.len);
-   const int r = celt_decode_frame_tail<true>(L, gs, len, pfs, pcm_out, mode == 1001);
+   if (defer_deemph) { LANE0 { cont->hdr[0] = 0; } }                      /* (a frame that fails leaves nothing for the de-emphasis pass) */
+   const int r = celt_decode_frame_tail<true>(L, gs, len, pfs, pcm_out, mode == 1001, defer_deemph ? cont->hdr : (i32 *)0);
    if (r >= 0) { LANE0 { st->rangeFinal = st->rng; st->prev_mode = mode; st->prev_redundancy = 0; st->last_packet_duration = pfs; } }
    wv_sync();
    {
@@ -1015,6 +1024,66 @@ WV_DEV void oa_decode_packet_back(WV_LDS DecLds *L, OaDecStream *gs, const CeltD
       FOR_LANES(i, 2 * NBE) { gs->oldBandE[i] = L->oldBandE[i]; gs->oldLogE[i] = L->oldLogE[i]; gs->oldLogE2[i] = L->oldLogE2[i]; gs->backgroundLogE[i] = L->backgroundLogE[i]; }
    }
    LANE0 { *nsamples_out = r < 0 ? r : pfs; *rng_out = st->rangeFinal; }
+}
+/* The de-emphasis (celt_decoder.c:318: y[n] = sat(x[n] + m), m = 0.85 y[n] rounded -- a chain no scan reproduces) and the PCM store of the frames oa_celt_dback_kernel
+ * synthesised, ONE LANE PER STREAM: the one-wave-per-stream kernels walk this recursion on one lane per channel while 62 lanes wait; here 64 streams share the instruction.
+ * A lane reads its stream's samples sixteen at a time per channel (one 64-byte line), walks the chains of its channels side by side, and writes interleaved int16 PCM
+ * (API rates below 48 kHz keep every ds-th sample; hybrid frames add onto the SILK audio: celt/arch.h:172 ADD_RES). */
+struct alignas(16) OaQuad { i32 x, y, z, w; };
+WV_DEV void oa_deemph_lane(OaDecStream *gs, const CeltDecCont *cont, i16 *pcm_out)
+{
+   const int N = cont->hdr[0], flags = cont->hdr[1];
+   if (N <= 0) return;
+   const int CC = gs->s.channels, Fs = gs->s.Fs ? gs->s.Fs : 48000, ds = 48000 / Fs, accum = flags & 1;
+   const i32 *x0 = cont->xg + ((flags & 2) ? N : 0), *x1 = cont->xg + ((flags & 2) ? 0 : N);
+   i32 m0 = gs->s.preemph_memD[0], m1 = gs->s.preemph_memD[1];
+   const bool packed = CC == 2 && ds == 1 && ((size_t)pcm_out & 15) == 0;        /* (the batch's own and torch's buffers are; a caller's device pointer need not be) */
+   for (int j0 = 0; j0 < N; j0 += 16) {
+      i32 a[16], b[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const OaQuad v = *(const OaQuad *)(x0 + j0 + 4 * q); a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+      if (CC == 2) {
+#pragma unroll
+         for (int q = 0; q < 4; q++) { const OaQuad v = *(const OaQuad *)(x1 + j0 + 4 * q); b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) { a[k] = saturate(a[k] + m0, SIG_SAT); m0 = mult16_32_q15(27853, a[k]); a[k] = sig2word16(a[k]); }
+      if (CC == 2) {
+#pragma unroll
+         for (int k = 0; k < 16; k++) { b[k] = saturate(b[k] + m1, SIG_SAT); m1 = mult16_32_q15(27853, b[k]); b[k] = sig2word16(b[k]); }
+      }
+      if (packed) {
+         u32 *o = (u32 *)(pcm_out + 2 * j0);
+#pragma unroll
+         for (int q = 0; q < 4; q++) {
+            OaQuad w;
+            if (accum) {                                      /* onto the SILK audio that is there (ADD_RES, celt/arch.h:172) */
+               const OaQuad old = *(const OaQuad *)(o + 4 * q);
+#define OA_AS(o_, k_) { const i32 l_ = (i32)(i16)(o_) + a[k_], r_ = ((o_) >> 16) + b[k_]; a[k_] = l_ > 32767 ? 32767 : l_ < -32768 ? -32768 : l_; b[k_] = r_ > 32767 ? 32767 : r_ < -32768 ? -32768 : r_; }
+               OA_AS(old.x, 4 * q) OA_AS(old.y, 4 * q + 1) OA_AS(old.z, 4 * q + 2) OA_AS(old.w, 4 * q + 3)
+#undef OA_AS
+            }
+#define OA_PK(k_) (i32)(((u32)a[k_] & 0xffffu) | ((u32)b[k_] << 16))
+            w.x = OA_PK(4 * q); w.y = OA_PK(4 * q + 1); w.z = OA_PK(4 * q + 2); w.w = OA_PK(4 * q + 3);
+#undef OA_PK
+            *(OaQuad *)(o + 4 * q) = w;
+         }
+      } else {
+#pragma unroll
+         for (int k = 0; k < 16; k++) {
+            const int i = j0 + k;
+            if (ds == 1 || (u32)i % (u32)ds == 0) {
+               const int it = (int)((u32)i / (u32)ds) * CC;
+               if (accum) {
+                  i32 w = (i32)pcm_out[it] + a[k]; pcm_out[it] = (i16)(w > 32767 ? 32767 : w < -32768 ? -32768 : w);
+                  if (CC == 2) { w = (i32)pcm_out[it + 1] + b[k]; pcm_out[it + 1] = (i16)(w > 32767 ? 32767 : w < -32768 ? -32768 : w); }
+               } else { pcm_out[it] = (i16)a[k]; if (CC == 2) pcm_out[it + 1] = (i16)b[k]; }
+            }
+         }
+      }
+   }
+   gs->s.preemph_memD[0] = m0;
+   if (CC == 2) gs->s.preemph_memD[1] = m1;
 }
 /* between oa_sdec_lane_kernel and oa_decode_hyb_kernel, per stream: the range decoder behind the SILK layer and the redundancy flag, and where the coded frame lies in the packet */
 struct OaHybCont { EcCtx ec; i32 off, flen; };

@@ -13,8 +13,9 @@
 
 /* what oa_decode_fast_kernel / oa_decode_hyb_kernel hand over when they stop a frame in front of its bands, and oa_celt_dback_kernel takes up again (one record per stream, HBM) */
 struct alignas(16) CeltDecCont {
+   i32 hdr[4];                                       /* from oa_celt_dback_kernel to oa_celt_deemph_kernel: [0] samples per channel of the frame (0: nothing to do), [1] flags (celt_dec_frame.h: celt_decode_frame_tail) */
    i32 image[(offsetof(DecLds, BC) + 3) / 4];        /* the front wave's LDS up to the phase scratch: coder, frame constants, band arrays, the frame's bytes */
-   i32 xg[2 * OA_MAX_FRAME + 2 * OA_NORM_LEN];       /* the spectrum X[2][N] of the frame in flight, then the folding memory norm[2][OA_NORM_LEN] (the layout of the per-wave scratch, celt_dec_lds.h) */
+   alignas(16) i32 xg[2 * OA_MAX_FRAME + 2 * OA_NORM_LEN];       /* the spectrum X[2][N] of the frame in flight, then the folding memory norm[2][OA_NORM_LEN] (the layout of the per-wave scratch, celt_dec_lds.h) */
 };
 #define OA_DEC_CUT (-1000)                           /* celt_decode_frame_wave: stopped in front of the bands (never leaves the kernels) */
 
@@ -23,30 +24,43 @@ struct alignas(16) CeltDecCont {
 
 /* cwrsi (cwrs.c:467) on a group: index -> y[0 .. N) (plain integers, one per word of y), returns sum y^2.  N, K, idx are group-uniform.  At dimension n with k pulses left
  * and running index i: the sign is negative iff i >= U(n, k + 1); the pulses that remain AFTER this position are the largest k' <= k with U(n, k') <= i.  U(n, .) is
- * non-decreasing and a position rarely takes more than a few pulses, so the sixteen lanes test k, k - 1, ..., k - 15 at once and the first hit is the answer; the next
- * sixteen only when none of them fits. */
-WV_DEV i32 p4d_cwrsi(int N, int K, u32 idx, WV_LDS i32 *y)
+ * non-decreasing and a position rarely takes more than a few pulses, so the sixteen lanes hold a WINDOW of the row -- lane l: U(n, ka + 1 - l), anchored at the pulse count ka
+ * the walk had one position earlier -- and the first lane at or below the current k whose entry fits is the answer.  Anchoring the window one position back is what takes the
+ * table read off the chain: the window of dimension n - 1 is requested when the walk arrives at dimension n (k only shrinks, by the d pulses this position takes: the next
+ * position finds its U(n - 1, k + 1) in lane d and its candidates behind it).  Only a position that takes 15 pulses or more reads the table on the spot.
+ * W0: the first window, U(N, K + 1 - lane) (0 where K + 1 - lane < 0), requested by the caller ahead of the index symbol. */
+WV_DEV u32 p4d_cwrsi_window(int n, int ka) { const int c = ka + 1 - wg_lane(); return c >= 0 ? pvq_u(n, c) : 0u; }
+WV_DEV i32 p4d_cwrsi(int N, int K, u32 idx, WV_LDS i32 *y, u32 W0)
 {
    const int gl = wg_lane();
-   int k = K;
-   u32 i = idx;
+   int k = K, ka = K;
+   u32 i = idx, W = W0;
    i32 yy = 0;
    for (int n = N; n > 2; n--) {
-      const u32 above = pvq_u(n, k + 1);
+      const u32 Wn = n - 1 > 2 ? p4d_cwrsi_window(n - 1, k) : 0u;                 /* in flight while this position is searched */
+      const int d0 = ka - k;                                                      /* lane d0 holds U(n, k + 1), the lanes behind it U(n, k), U(n, k - 1), ... */
+      const u32 above = d0 < WG_WIDTH ? (u32)wg_bcast((i32)W, d0) : pvq_u(n, k + 1);
       const int neg = i >= above;
       if (neg) i -= above;
       int kk = 0; u32 below = 0;
-      for (int base = k; ; base -= WG_WIDTH) {
-         const int cand = base - gl;
-         const u32 u = cand >= 0 ? pvq_u(n, cand) : 0u;
-         const u32 m = wg_ballot(cand >= 0 && u <= i);
-         if (m) { const int f = __builtin_ctz(m); kk = base - f; below = (u32)wg_bcast((i32)u, f); break; }
+      const u32 m = wg_ballot(gl > d0 && ka + 1 - gl >= 0 && W <= i);
+      if (m) { const int f = __builtin_ctz(m); kk = ka + 1 - f; below = (u32)wg_bcast((i32)W, f); }
+      else {
+#ifdef P4_STAT
+         if (gl == 0) fprintf(stderr, "P4D cwrsi: table read on the spot, n %d k %d ka %d\n", n, k, ka);
+#endif
+         for (int base = imin(k, ka + 1 - WG_WIDTH); ; base -= WG_WIDTH) {
+            const int cand = base - gl;
+            const u32 u = cand >= 0 ? pvq_u(n, cand) : 0u;
+            const u32 m2 = wg_ballot(cand >= 0 && u <= i);
+            if (m2) { const int f = __builtin_ctz(m2); kk = base - f; below = (u32)wg_bcast((i32)u, f); break; }
+         }
       }
       i -= below;
       const int v = neg ? kk - k : k - kk;
       if (gl == 0) y[N - n] = v;
       yy += v * v;
-      k = kk;
+      ka = k; k = kk; W = Wn;
    }
    if (N >= 2) {                                                                  /* dimensions 2 and 1 in closed form: U(2, k) = 2k - 1 (k > 0) */
       const u32 p = 2 * (u32)k + 1;
@@ -69,9 +83,13 @@ WV_DEV unsigned p4d_alg_unquant(WV_LDS P4Group *G, const u8 *ecbuf, WV_LDS i32 *
    const int gl = wg_lane();
    const u32 ft = pvq_u(N, K) + pvq_u(N, K + 1);
    i32 idx = 0;
+   const u32 W0 = N > 2 ? p4d_cwrsi_window(N, K) : 0u;
+   P4_TIC();
    GLANE0 { P4D_EC_BEGIN; idx = (i32)k_ec_dec_uint(EC_PASS, ft); P4D_EC_END; }
    idx = wg_bcast(idx, 0);
-   const i32 Ryy = p4d_cwrsi(N, K, (u32)idx, X);
+   P4_TOC(5);
+   const i32 Ryy = p4d_cwrsi(N, K, (u32)idx, X, W0);
+   P4_TOC(6);
    const int k = celt_ilog2(Ryy) >> 1;
    const i32 t_ = vshr32(Ryy, 2 * (k - 7) - 15);
    const i32 g = mult32_32_q31(fx_rsqrt_norm32(t_), gain);
@@ -102,6 +120,7 @@ WV_DEV unsigned p4d_alg_unquant(WV_LDS P4Group *G, const u8 *ecbuf, WV_LDS i32 *
          wg_sync();
       }
    }
+   P4_TOC(7);
    return cm;
 }
 
@@ -110,6 +129,7 @@ WV_DEV P4Theta p4d_compute_theta(WV_LDS P4Group *G, const u8 *ecbuf, const P4Cfg
 {
    int qn, itheta = 0, delta, imid, iside, qalloc, pulse_cap, offset, inv = 0;
    const int i = cfg.i, intensity = cfg.intensity;
+   P4_TIC();
    pulse_cap = ct_logN[i] + LM * (1 << BITRES);
    offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
    qn = p4_compute_qn(N, b, offset, pulse_cap, stereo);
@@ -169,6 +189,7 @@ WV_DEV P4Theta p4d_compute_theta(WV_LDS P4Group *G, const u8 *ecbuf, const P4Cfg
       iside = bitexact_cos((i16)(16384 - itheta));
       delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
    }
+   P4_TOC(stereo ? 1 : 3);
    P4Theta r = {inv, imid, iside, delta, itheta, qalloc, b, fill};
    return r;
 }
@@ -178,6 +199,7 @@ WV_DEV P4Theta p4d_compute_theta(WV_LDS P4Group *G, const u8 *ecbuf, const P4Cfg
 WV_DEV void p4d_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, const u8 *ecbuf, const P4Cfg &cfg, P4Tree &tr)
 {
    tr.depth = 0; tr.done = !tr.act; tr.cm = 0;
+   P4_TIC();
    while (wv_any(!tr.done)) {
       for (;;) {
          int split = 0;
@@ -213,6 +235,7 @@ WV_DEV void p4d_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, const u8 *ecbuf, c
             tr.depth++;
          }
       }
+      P4_TOC(2);
       unsigned cm = 0;
       if (!tr.done) {
          const WV_LDS u8 *row = L4->rows + (tr.LM + 1) * 64;
@@ -227,6 +250,7 @@ WV_DEV void p4d_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, const u8 *ecbuf, c
             curr_bits = p4_pulses2bits(row, q);
             tr.remaining_bits -= curr_bits;
          }
+         P4_TOC(4);
          if (q != 0) cm = p4d_alg_unquant(G, ecbuf, X, N, k_get_pulses(q), cfg.spread, B, tr.gain);
          else {
             const unsigned cm_mask = (unsigned)(1UL << B) - 1;
@@ -249,6 +273,7 @@ WV_DEV void p4d_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, const u8 *ecbuf, c
             }
          }
       }
+      P4_TOC(8);
       if (!tr.done) {
          for (;;) {
             if (tr.depth == 0) { tr.done = 1; tr.cm = cm; break; }
@@ -280,6 +305,7 @@ WV_DEV void p4d_tree_run(WV_LDS P4Lds *L4, WV_LDS P4Group *G, const u8 *ecbuf, c
             tr.depth--;
          }
       }
+      P4_TOC(9);
    }
 }
 
@@ -316,6 +342,7 @@ WV_DEV void p4d_quant_all_bands(WV_LDS P4Lds *L4, CeltDecCont *cont)
    cfg.intensity = intensity; cfg.spread = spread; cfg.disable_inv = disable_inv; cfg.resynth = 1; cfg.theta_round = 0; cfg.avoid_split_noise = B > 1; cfg.i = 0; cfg.tf_change = 0;
    for (int i = i_lo; i < i_hi; i++) {
       const int N = M * ct_eBands[i + 1] - M * ct_eBands[i];          /* wave-uniform */
+      P4_TIC();
       p4_rows_stage(L4, i);
       const int act = active && i >= start && i < end;
       const int last = i == end - 1;
@@ -365,6 +392,7 @@ WV_DEV void p4d_quant_all_bands(WV_LDS P4Lds *L4, CeltDecCont *cont)
       const unsigned cm_in = x_cm | y_cm;
       int mbits = 0, sbits = 0, itheta = 0, inv = 0, mid_first = 1, fill_j = 0;
       i32 mid = 0, side = 0, rebalance = 0;
+      P4_TOC(0);
       if (act) {
          wg_sync();
          if (effective_lowband != -1) { FOR_GL(j, N) G->lbs[j] = norm[effective_lowband + j]; }
@@ -409,7 +437,9 @@ WV_DEV void p4d_quant_all_bands(WV_LDS P4Lds *L4, CeltDecCont *cont)
             p4_qb_pre(G, tr, qb, tf_change, N, 0);
          }
          const int xo = tr.xo;
+         P4_TIC();
          p4d_tree_run(L4, G, pkt, cfg, tr);
+         P4_TOC(24);
          if (s_act) {
             const unsigned cm = p4_qb_post(G, tr, qb, xo, 1, lb_out, N);
             remaining_bits = tr.remaining_bits; seed = tr.seed;
@@ -418,6 +448,8 @@ WV_DEV void p4d_quant_all_bands(WV_LDS P4Lds *L4, CeltDecCont *cont)
             else { x_cm = cm; y_cm = cm; }
          }
       }
+      {
+      P4_TIC();
       if (act) {
          if (joint) {
             p4_stereo_merge(G->Xb, G->Yb, mid, N);
@@ -430,6 +462,8 @@ WV_DEV void p4d_quant_all_bands(WV_LDS P4Lds *L4, CeltDecCont *cont)
          balance += G->pulses[i] + tell;
          update_lowband = b > (N << BITRES);
          cfg.avoid_split_noise = 0;
+      }
+      P4_TOC(20);
       }
    }
    if (active) {

@@ -289,7 +289,8 @@ oa_celt_dpvq_kernel(CeltDecCont *conts, const int *cut_list, const unsigned *cut
 }
 /* ... and the rest of their packets: one wave per stream again, the front wave's LDS reloaded from the continuation record (celt_dec_frame.h: oa_decode_packet_back) */
 extern "C" __global__ void __launch_bounds__(64, OA_DEC_FAST_WAVES_PER_EU)
-oa_celt_dback_kernel(OaDecStream *streams, const CeltDecCont *conts, const int *cut_list, const unsigned *cut_count, unsigned *queue, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams)
+oa_celt_dback_kernel(OaDecStream *streams, CeltDecCont *conts, const int *cut_list, const unsigned *cut_count, unsigned *queue, i16 *pcm, int pcm_stride, i32 *nsamples, u32 *rngs, int nstreams,
+      int defer_deemph /* the de-emphasis and the PCM store are oa_celt_deemph_kernel's */)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
    WV_LDS DecLds *L = (WV_LDS DecLds *)smem;
@@ -299,8 +300,24 @@ oa_celt_dback_kernel(OaDecStream *streams, const CeltDecCont *conts, const int *
       if (k >= n0 + n1) break;
       const int s = wv_uni(k < n0 ? cut_list[k] : cut_list[(size_t)nstreams + (k - n0)]);
       __syncthreads();
-      oa_decode_packet_back(L, streams + s, conts + s, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s);
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_BEGIN();
+#endif
+      oa_decode_packet_back(L, streams + s, conts + s, pcm + (size_t)s * pcm_stride, nsamples + s, rngs + s, defer_deemph);
+#ifdef OA_PHASE_TIMERS
+      P4_PROF_END();
+#endif
       __syncthreads();
+   }
+}
+/* ... whose de-emphasis recursion and PCM store run one lane per stream (celt_dec_frame.h: oa_deemph_lane) */
+extern "C" __global__ void __launch_bounds__(64)
+oa_celt_deemph_kernel(OaDecStream *streams, const CeltDecCont *conts, const int *cut_list, const unsigned *cut_count, i16 *pcm, int pcm_stride, int nstreams)
+{
+   const int n0 = (int)cut_count[0], n1 = (int)cut_count[1];
+   for (int k = (int)blockIdx.x * 64 + (int)threadIdx.x; k < n0 + n1; k += (int)gridDim.x * 64) {
+      const int s = k < n0 ? cut_list[k] : cut_list[(size_t)nstreams + (k - n0)];
+      oa_deemph_lane(streams + s, conts + s, pcm + (size_t)s * pcm_stride);
    }
 }
 /* The look that sorts a call's packets between the decoder's kernels, one LANE per stream (64 streams per wave, one ballot and one atomic per list and wave):
@@ -1869,13 +1886,17 @@ int opusgpu_decode_batch_dev(OpusGpuDecBatch *b, const unsigned char *d_packets,
          hipLaunchKernelGGL(oa_decode_hyb_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
                b->d_streams, (const u8 *)d_packets, (int)packet_stride, (const i32 *)d_lens, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range,
                b->d_scratch, b->d_queue + 7, (const int *)(b->d_slow + 3 * (size_t)b->S), (const unsigned *)(b->d_queue + 6), (const OaHybCont *)b->d_hyb_ec, dc, b->d_cut, b->d_queue + 8, (int)b->S);
+      static const int deemph_lane = getenv("OPUS_AMD_DEC_DEEMPH_LANE") ? atoi(getenv("OPUS_AMD_DEC_DEEMPH_LANE")) : 1;      /* 0: the de-emphasis stays in the back kernel (A/B) */
       if (dpipe) {
          long long g_pvq = (long long)(b->occ_dpvq < 1 ? 1 : b->occ_dpvq) * cu;
          const long long tiles = ((long long)b->n_act + 3) / 4 + 1;
          if (g_pvq > tiles) g_pvq = tiles;
          hipLaunchKernelGGL(oa_celt_dpvq_kernel, dim3((unsigned)g_pvq), dim3(64), sizeof(P4Lds), s, b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), b->d_queue + 10, (int)b->S);
          hipLaunchKernelGGL(oa_celt_dback_kernel, dim3((unsigned)g_fast), dim3(64), OA_DEC_FAST_LDS_BYTES, s,
-               b->d_streams, (const CeltDecCont *)b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), b->d_queue + 11, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, (int)b->S);
+               b->d_streams, b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), b->d_queue + 11, (i16 *)d_pcm, frame_size * b->channels, (i32 *)d_nsamples, (u32 *)d_final_range, (int)b->S, deemph_lane);
+         if (deemph_lane)
+            hipLaunchKernelGGL(oa_celt_deemph_kernel, dim3((unsigned)((b->n_act + 63) / 64)), dim3(64), 0, s,
+                  b->d_streams, (const CeltDecCont *)b->d_dcont, (const int *)b->d_cut, (const unsigned *)(b->d_queue + 8), (i16 *)d_pcm, frame_size * b->channels, (int)b->S);
       }
    }
    hipLaunchKernelGGL(oa_decode_kernel, dim3((unsigned)g_gen), dim3(64), sizeof(DecLds), s,

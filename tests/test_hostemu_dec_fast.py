@@ -60,3 +60,42 @@ def test_emu_fast_kernel_switch_per_batch():
             a.close(); b.close()
     finally:
         opus_amd.LIB_PATH, opus_amd._lib = saved                  # (this process's other tests -- and opus_amd.build() -- see the product library again)
+
+PVQ_CASES = ("celt_stereo", "celt_mono_10", "hyb_stereo", "hyb_mono_10", "mono_coded", "stereo_to_mono", "audio_auto")
+
+def pvq_stage_switch(lib, cases=PVQ_CASES):
+    """opusgpu_dec_batch_set_pvq_stage(b, 1) == (b, 0), in one process: the bands of the steady-state CELT frames on oa_celt_dpvq_kernel (four streams per wave,
+    opus_amd/csrc/celt_dec_pvq4.h) against the one-wave-per-stream band decoder -- PCM, sample counts, final ranges and stream records"""
+    import numpy as np, opus_amd, dec_fast_check, importlib
+    saved = (opus_amd.LIB_PATH, opus_amd._lib)
+    opus_amd.LIB_PATH = lib; opus_amd._lib = None
+    try:
+        os.environ.pop("DEC_FAST_CASES", None); importlib.reload(dec_fast_check)
+        for name in cases:
+            Fs, ch, app, ctl, ms, frames, loss = dec_fast_check.CASES[name][:7]
+            seqs = dec_fast_check.make_packets(name); S = len(seqs)
+            if len(dec_fast_check.CASES[name]) > 9: Fs = dec_fast_check.CASES[name][9]
+            n = int(Fs * ms // 1000); dch = dec_fast_check.dec_channels(name)
+            a = opus_amd.DecoderBatch(S, channels=dch, Fs=Fs); b = opus_amd.DecoderBatch(S, channels=dch, Fs=Fs); a.set_pvq_stage(1); b.set_pvq_stage(0)
+            took = 0
+            for f in range(frames):
+                pk = [seqs[s][f] for s in range(S)]
+                x, y = a.decode(pk, n), b.decode(pk, n)
+                assert all(np.array_equal(p, q) for p, q in zip(x, y)), (name, f)
+                took += a.pvq_stats(); assert b.pvq_stats() == 0
+            assert took > 0 and all(a.export_state(s) == b.export_state(s) for s in range(S)), name
+            a.close(); b.close()
+    finally:
+        opus_amd.LIB_PATH, opus_amd._lib = saved
+
+def test_emu_pvq_stage_switch_per_batch():
+    import hostemu
+    pvq_stage_switch(hostemu.build_emu_lib())
+
+def test_emu_fast_decoder_with_the_pvq_stage_forced_equals_general_decoder(tmp_path, monkeypatch):
+    """the whole check of the first test once more with OPUS_AMD_DEC_PVQ4=1 (the process default the narrow test batches would otherwise never reach)"""
+    monkeypatch.setenv("OPUS_AMD_DEC_PVQ4", "1")
+    monkeypatch.setenv("DEC_FAST_CASES", "celt_,hyb_,mono_coded,stereo_to_mono,audio_auto,silk_celt_switch" if LONG else "celt_stereo,celt_24k,celt_5ms_12k,hyb_stereo,hyb_24k_out,hyb_celt_switch,mono_coded,stereo_to_mono")
+    import importlib, dec_fast_check
+    importlib.reload(dec_fast_check)
+    assert not dec_fast_check.compare("emu", tmpdir=str(tmp_path), verbose=False)

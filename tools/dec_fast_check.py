@@ -19,6 +19,8 @@ CASES = {   # name: (Fs, channels, application, encoder ctls, frame ms, frames, 
     "celt_5ms_12k":  (12000, 1, 2051, {4002: 24000, 4010: 5}, 5, 16, 0),            # downsampling by 4 on the way out
     "mono_coded":    (48000, 2, 2051, {4002: 48000, 4010: 5, 4022: 1}, 20, 10, 4),  # mono packets into a stereo decoder: one spectrum, two syntheses
     "stereo_to_mono": (48000, 2, 2051, {4002: 96000, 4010: 5}, 20, 10, 0, 1),       # stereo packets into a mono decoder: the spectra are mixed before the synthesis
+    "celt_510k":     (48000, 2, 2051, {4002: 510000, 4010: 5}, 20, 8, 0),           # the highest rate: leaves with more pulses than a 16-entry window of U(n, k) holds (celt_dec_pvq4.h: p4d_cwrsi's table reads on the spot)
+    "celt_mono_256k_10": (48000, 1, 2051, {4002: 256000, 4010: 5}, 10, 12, 5),
     # the SILK steady state: oa_sdec_lane_kernel (one lane per stream) takes these after each stream's first packet, and after a loss the general kernel has them back for a packet
     "silk_wb_20":    (16000, 1, 2048, {11002: 1000, 4002: 24000, 4010: 5}, 20, 12, 0),
     "silk_stereo":   (48000, 2, 2048, {11002: 1000, 4004: 1103, 4002: 40000, 4010: 5}, 20, 14, 6),            # mid/side, side frames that come and go, 16 -> 48 kHz on the way out

@@ -57,6 +57,8 @@ gpufuzz) OPUS_AMD_TEST_TRPRE=1 timeout 2400 python tools/fuzz_sweep.py --which g
 dpvq) OPUS_AMD_DEC_PVQ4=1 timeout 500 python tools/dec_fast_check.py gpu > $O/dec_fast_check_pvq4.log 2>&1
   for m in 0 1; do for c in ${DPVQ_CONFIGS:-2 4}; do OPUS_AMD_DEC_PVQ4=$m timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --no-cpu-baseline --steady-state 0 --config $c --decode > $O/decode${c}_pvq4_$m.log 2>&1; done; done
   for c in ${DPVQ_CONFIGS:-2 4}; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd$c -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config $c --decode > $OLDPWD/$O/profd$c.log 2>&1); find $O/profd$c -name '*kernel_trace*' -delete; find $O/profd$c -name '*agent_info*' -delete; done ;;
+dpvqprof) OPUS_AMD_PROF_PREBUILT=1 timeout 300 python tools/phase_profile_dpvq.py 16384 > $O/phases_dpvq_config2.txt 2>&1 ;;
+deemph) for m in 0 1; do for c in ${DPVQ_CONFIGS:-2 4}; do OPUS_AMD_DEC_DEEMPH_LANE=$m timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --no-cpu-baseline --steady-state 0 --config $c --decode > $O/decode${c}_deemph_$m.log 2>&1; done; done ;;
 decfast) timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --config 2 --decode > $O/decode2.log 2>&1; timeout 80 python tools/dec_fast_check.py gpu > $O/dec_fast_check.log 2>&1; timeout 100 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_dec_fast.py -x -q --timeout 60 > $O/pytest_decoder.log 2>&1 ;;
 phases) for m in 1 0; do for k in silk hybrid; do OPUS_AMD_PROF_PREBUILT=1 OPUS_AMD_SH_SPLIT=$m timeout 90 python tools/phase_profile_sh.py 16384 10 $k > $O/phases_${k}_split$m.txt 2>&1; done; done ;;
 bench34p) for c in 3 4; do timeout 200 python bench.py --steps 10 --warmup 3 --no-extra-configs --config $c > $O/bench${c}_parity.log 2>&1; done ;;
