@@ -29,7 +29,12 @@ struct alignas(16) CeltDecCont {
  * table read off the chain: the window of dimension n - 1 is requested when the walk arrives at dimension n (k only shrinks, by the d pulses this position takes: the next
  * position finds its U(n - 1, k + 1) in lane d and its candidates behind it).  Only a position that takes 15 pulses or more reads the table on the spot.
  * W0: the first window, U(N, K + 1 - lane) (0 where K + 1 - lane < 0), requested by the caller ahead of the index symbol. */
-WV_DEV u32 p4d_cwrsi_window(int n, int ka) { const int c = ka + 1 - wg_lane(); return c >= 0 ? pvq_u(n, c) : 0u; }
+WV_DEV u32 p4d_cwrsi_window(int n, int ka)                    /* lane l: U(n, ka + 1 - l); no such entry (ka + 1 - l < 0): all ones, which no index reaches */
+{
+   const int c = ka + 1 - wg_lane();
+   const u32 u = pvq_u(n, imax(c, 0));
+   return c >= 0 ? u : 0xffffffffu;
+}
 WV_DEV i32 p4d_cwrsi(int N, int K, u32 idx, WV_LDS i32 *y, u32 W0)
 {
    const int gl = wg_lane();
@@ -37,18 +42,20 @@ WV_DEV i32 p4d_cwrsi(int N, int K, u32 idx, WV_LDS i32 *y, u32 W0)
    u32 i = idx, W = W0;
    i32 yy = 0;
    for (int n = N; n > 2; n--) {
-      const u32 Wn = n - 1 > 2 ? p4d_cwrsi_window(n - 1, k) : 0u;                 /* in flight while this position is searched */
+      const u32 Wn = p4d_cwrsi_window(n - 1, k);                                  /* in flight while this position is searched (dimension 2 is in the table too; its window goes unused) */
       const int d0 = ka - k;                                                      /* lane d0 holds U(n, k + 1), the lanes behind it U(n, k), U(n, k - 1), ... */
-      const u32 above = d0 < WG_WIDTH ? (u32)wg_bcast((i32)W, d0) : pvq_u(n, k + 1);
+      u32 above = (u32)wg_bcast((i32)W, imin(d0, WG_WIDTH - 1));
+      if (d0 >= WG_WIDTH) above = pvq_u(n, k + 1);
       const int neg = i >= above;
-      if (neg) i -= above;
-      int kk = 0; u32 below = 0;
-      const u32 m = wg_ballot(gl > d0 && ka + 1 - gl >= 0 && W <= i);
+      i -= neg ? above : 0u;
+      int kk; u32 below;
+      const u32 m = wg_ballot(W <= i) & (0xfffeu << imin(d0, WG_WIDTH)) & 0xffffu;    /* (the lanes behind lane d0; d0 >= 16: none) */
       if (m) { const int f = __builtin_ctz(m); kk = ka + 1 - f; below = (u32)wg_bcast((i32)W, f); }
       else {
 #ifdef P4_STAT
          if (gl == 0) fprintf(stderr, "P4D cwrsi: table read on the spot, n %d k %d ka %d\n", n, k, ka);
 #endif
+         kk = 0; below = 0;
          for (int base = imin(k, ka + 1 - WG_WIDTH); ; base -= WG_WIDTH) {
             const int cand = base - gl;
             const u32 u = cand >= 0 ? pvq_u(n, cand) : 0u;
@@ -58,8 +65,8 @@ WV_DEV i32 p4d_cwrsi(int N, int K, u32 idx, WV_LDS i32 *y, u32 W0)
       }
       i -= below;
       const int v = neg ? kk - k : k - kk;
-      if (gl == 0) y[N - n] = v;
-      yy += v * v;
+      y[N - n] = v;                                                               /* (every lane of the group the same word) */
+      yy = mac16_16(yy, v, v);
       ka = k; k = kk; W = Wn;
    }
    if (N >= 2) {                                                                  /* dimensions 2 and 1 in closed form: U(2, k) = 2k - 1 (k > 0) */
@@ -83,7 +90,7 @@ WV_DEV unsigned p4d_alg_unquant(WV_LDS P4Group *G, const u8 *ecbuf, WV_LDS i32 *
    const int gl = wg_lane();
    const u32 ft = pvq_u(N, K) + pvq_u(N, K + 1);
    i32 idx = 0;
-   const u32 W0 = N > 2 ? p4d_cwrsi_window(N, K) : 0u;
+   const u32 W0 = p4d_cwrsi_window(N, K);
    P4_TIC();
    GLANE0 { P4D_EC_BEGIN; idx = (i32)k_ec_dec_uint(EC_PASS, ft); P4D_EC_END; }
    idx = wg_bcast(idx, 0);
