@@ -264,6 +264,7 @@ class OpusDecoder:
     def __del__(self):
         if getattr(self, "_st", None): self._L.opus_decoder_destroy(self._st); self._st = None
 
+DEC_PVQ_STAGE_DEFAULT = None      # tests: opusgpu_dec_batch_set_pvq_stage of every DecoderBatch created from here on (None: the library's default, wide calls only)
 class DecoderBatch:
     """S independent streams decoded together on one GPU (include/opus_amd.h batch decoder API)."""
     def __init__(self, nstreams, channels=2, Fs=48000, device=0):
@@ -272,6 +273,7 @@ class DecoderBatch:
         self._b = self._L.opusgpu_dec_batch_create(nstreams, Fs, channels, device, ctypes.byref(err))
         if not self._b: raise OpusError(err.value)
         self.S, self.channels, self.device = nstreams, channels, device
+        if DEC_PVQ_STAGE_DEFAULT is not None: self.set_pvq_stage(DEC_PVQ_STAGE_DEFAULT)
     def decode(self, packets, frame_size=960):
         """packets: list of S bytes objects (b"" or None = lost packet: conceal frame_size samples).  Returns (pcm int16 [S, frame_size, channels],
         nsamples [S], final ranges [S])."""

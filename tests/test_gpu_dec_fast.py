@@ -18,3 +18,9 @@ def test_gpu_fast_decoder_with_the_pvq_stage_forced_equals_general_decoder(tmp_p
 def test_gpu_pvq_stage_switch_per_batch():
     import test_hostemu_dec_fast as t
     t.pvq_stage_switch(os.path.join(ROOT, "opus_amd/libopus_amd.so"))
+
+def test_gpu_pvq_stage_vs_reference():
+    from reflib import ref_fx
+    if ref_fx() is None: pytest.skip("compiled reference did not travel")
+    import test_hostemu_dec_fast as t
+    t.pvq_stage_vs_reference(os.path.join(ROOT, "opus_amd/libopus_amd.so"))

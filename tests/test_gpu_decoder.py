@@ -248,3 +248,30 @@ def test_gpu_dec_classic_loss_api_vs_reference():
             na = r.L.opus_decode(r.st, pkt, len(pkt), pa.ctypes.data, 960, 0); nb = L.opus_decode(d._st, pkt, len(pkt), pb.ctypes.data, 960, 0)
         assert na == nb == 960 and np.array_equal(pa, pb), (i, na, nb)
     assert L.opus_decode(d._st, None, 0, pb.ctypes.data, 961, 0) == r.L.opus_decode(r.st, None, 0, pa.ctypes.data, 961, 0) == -1
+
+
+# ---- the same comparisons with the decoder's PVQ stage forced (oa_celt_dpvq_kernel: the bands of four streams per wave, opus_amd/csrc/celt_dec_pvq4.h; wide calls take it by
+# default, these few-stream batches only through opusgpu_dec_batch_set_pvq_stage(b, 1)) ----
+@pytest.fixture
+def pvq_forced():
+    oa = _oa(); old = oa.DEC_PVQ_STAGE_DEFAULT; oa.DEC_PVQ_STAGE_DEFAULT = 1
+    yield
+    oa.DEC_PVQ_STAGE_DEFAULT = old
+
+def test_gpu_dec_pvq_stage_config2_vs_oracle(pvq_forced):
+    _check(32, 40, 2, 2, 960, dict(bitrate=128000, complexity=10))
+
+@pytest.mark.skipif(ref_fx() is None, reason="compiled reference did not travel")
+def test_gpu_dec_pvq_stage_config2_vs_reference(pvq_forced):
+    _check(12, 30, 2, 2, 960, dict(bitrate=128000, complexity=10), checker="ref")
+
+@pytest.mark.parametrize("enc_ch,dec_ch,bitrate,complexity,frame", [
+    (2, 2, 64000, 10, 960), (2, 2, 24000, 10, 960), (2, 2, 510000, 10, 960), (1, 1, 64000, 10, 960), (1, 1, 12000, 5, 960), (1, 1, 256000, 10, 480),
+    (2, 2, 128000, 10, 480), (2, 2, 8000, 10, 960), (1, 2, 48000, 10, 960), (2, 1, 96000, 10, 960)])
+def test_gpu_dec_pvq_stage_rates_sizes(pvq_forced, enc_ch, dec_ch, bitrate, complexity, frame):
+    _check(6, min(16 * 960 // frame, 40), enc_ch, dec_ch, frame, dict(bitrate=bitrate, complexity=complexity))
+
+@pytest.mark.parametrize("channels,bitrate,frame,pattern", [(2, 96000, 960, "burst"), (2, 64000, 480, "random"), (1, 64000, 480, "start")])
+def test_gpu_dec_pvq_stage_packet_loss(pvq_forced, channels, bitrate, frame, pattern):
+    """streams leave the pipeline for the general kernel on a loss (and for the frame after it) and come back"""
+    test_gpu_dec_packet_loss(channels, bitrate, frame, pattern)

@@ -99,3 +99,35 @@ def test_emu_fast_decoder_with_the_pvq_stage_forced_equals_general_decoder(tmp_p
     import importlib, dec_fast_check
     importlib.reload(dec_fast_check)
     assert not dec_fast_check.compare("emu", tmpdir=str(tmp_path), verbose=False)
+
+def pvq_stage_vs_reference(lib, cases=("celt_stereo", "celt_mono_10", "celt_510k", "celt_24k", "hyb_stereo", "mono_coded")):
+    """the PVQ stage forced, against the COMPILED REFERENCE decoder (oracle/_ref), packet by packet: PCM, sample counts, final ranges -- lost packets included (the stream leaves
+    the pipeline for the general kernel and comes back)"""
+    import numpy as np, opus_amd, dec_fast_check, importlib, capi
+    saved = (opus_amd.LIB_PATH, opus_amd._lib)
+    opus_amd.LIB_PATH = lib; opus_amd._lib = None
+    try:
+        os.environ.pop("DEC_FAST_CASES", None); importlib.reload(dec_fast_check)
+        for name in cases:
+            Fs, ch, app, ctl, ms, frames, loss = dec_fast_check.CASES[name][:7]
+            seqs = dec_fast_check.make_packets(name); S = len(seqs)
+            if len(dec_fast_check.CASES[name]) > 9: Fs = dec_fast_check.CASES[name][9]
+            n = int(Fs * ms // 1000); dch = dec_fast_check.dec_channels(name)
+            a = opus_amd.DecoderBatch(S, channels=dch, Fs=Fs); a.set_pvq_stage(1)
+            refs = [capi.Dec("ref", Fs, dch) for _ in range(S)]
+            took = 0
+            for f in range(frames):
+                pk = [seqs[s][f] for s in range(S)]
+                pcm, ns, rng = a.decode(pk, n); took += a.pvq_stats()
+                for s in range(S):
+                    x = refs[s].decode(pk[s], n)
+                    assert x[0] == int(ns[s]) == n and (x[2] == int(rng[s]) or not pk[s]), (name, f, s, x[0], int(ns[s]), hex(x[2]), hex(int(rng[s])))
+                    assert np.array_equal(x[1], pcm[s, :n]), (name, f, s, np.nonzero(x[1] != pcm[s, :n])[0][:6])
+            assert took > 0, name
+            a.close()
+    finally:
+        opus_amd.LIB_PATH, opus_amd._lib = saved
+
+def test_emu_pvq_stage_vs_reference():
+    import hostemu
+    pvq_stage_vs_reference(hostemu.build_emu_lib())
