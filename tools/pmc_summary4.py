@@ -10,6 +10,8 @@ WPS = {"oa_encode_kernel": 4.0, "oa_celt_front_kernel": 4.0, "oa_celt_pvq_kernel
        "oa_decode_look_kernel": 8.0, "oa_decode_hyb_kernel": 4.0, "oa_celt_dpvq_kernel": 3.0, "oa_celt_dback_kernel": 4.0, "oa_sdec_lane_kernel": 2.0, "oa_ms_split_kernel": 8.0, "oa_ms_pack_kernel": 8.0,
        "oa_sh_pred_kernel": 8.0, "oa_sh_predc_kernel": 8.0, "oa_sh_preda_kernel": 1.0, "oa_sh_predb_kernel": 1.0, "oa_celt_transient_kernel": 2.0, "oa_sh_transient_kernel": 2.0}      # (round 5: the front kernel holds 16 waves per CU mono, 12 stereo -- config 4 below)
 WPS_BY_LEG = {"config_4": {"oa_sh_front_kernel": 3.0}}
+DEC_KERNELS = {"oa_sdec_lane_kernel", "oa_celt_dpvq_kernel", "oa_celt_dback_kernel", "oa_celt_deemph_kernel"}
+def is_dec(k): return "decode" in k or k in DEC_KERNELS
 def table(d, f):
     """{kernel: {counter: mean value per dispatch}}, dispatch counts"""
     p = os.path.join(d, f); agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -31,7 +33,7 @@ for sub in sorted(os.listdir(root)):
     if not (os.path.isdir(d) and sub.startswith("pmc")): continue
     key = ("decode_%s" % sub[4:]) if sub.startswith("pmcd") else ("config_%s" % sub[3:])
     ins, busy, lanes, fe, wr = table(d, "pmc_sq_insts.csv"), table(d, "pmc_valu_busy.csv"), table(d, "pmc_lanes.csv"), table(d, "pmc_fetch.csv"), table(d, "pmc_write.csv")
-    kernels = sorted(k for k in ins if ("decode" in k) == key.startswith("decode"))     # (a decoder leg encodes its packets first: those launches are not its own)
+    kernels = sorted(k for k in ins if is_dec(k) == key.startswith("decode"))     # (a decoder leg encodes its packets first: those launches are not its own)
     ins = {k: ins[k] for k in kernels}; busy = {k: v for k, v in busy.items() if k in kernels}; lanes = {k: v for k, v in lanes.items() if k in kernels}
     per = {}
     tot = collections.Counter()
