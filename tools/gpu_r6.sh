@@ -52,7 +52,7 @@ declane) timeout 300 python tools/dec_fast_check.py gpu > $O/dec_fast_check.log 
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd3 -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config 3 --decode > $OLDPWD/$O/profd3.log 2>&1); find $O/profd3 -name '*kernel_trace*' -delete; find $O/profd3 -name '*agent_info*' -delete
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$O/profd4 -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --steady-state 0 --config 4 --decode > $OLDPWD/$O/profd4.log 2>&1); find $O/profd4 -name '*kernel_trace*' -delete; find $O/profd4 -name '*agent_info*' -delete
   timeout 600 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_dec_fast.py -x -q --timeout 300 > $O/pytest_decoder.log 2>&1 ;;
-gpufuzz) OPUS_AMD_TEST_TRPRE=1 timeout 2400 python tools/fuzz_sweep.py --which gpu --fuzzers fuzz_dec,fuzz_ms_dec --first ${FUZZ_FIRST:-9990000} --count ${FUZZ_DEC_COUNT:-1500} --pipeline 4 --workers 8 --log $O/fuzz_gpu_decoders.log > /dev/null 2>&1
+gpufuzz) OPUS_AMD_DEC_PVQ4=${FUZZ_DEC_PVQ4:-1} OPUS_AMD_TEST_TRPRE=1 timeout 2400 python tools/fuzz_sweep.py --which gpu --fuzzers fuzz_dec,fuzz_ms_dec --first ${FUZZ_FIRST:-9990000} --count ${FUZZ_DEC_COUNT:-1500} --pipeline 4 --workers 8 --log $O/fuzz_gpu_decoders.log > /dev/null 2>&1
   OPUS_AMD_TEST_TRPRE=1 timeout 3000 python tools/fuzz_sweep.py --which gpu --fuzzers fuzz,fuzz_sparse,fuzz_batch --first ${FUZZ_FIRST:-9990000} --count ${FUZZ_ENC_COUNT:-800} --pipeline 4 --workers 8 --log $O/fuzz_gpu_encoders_pipeline4.log > /dev/null 2>&1 ;;
 dpvq) OPUS_AMD_DEC_PVQ4=1 timeout 500 python tools/dec_fast_check.py gpu > $O/dec_fast_check_pvq4.log 2>&1
   for m in 0 1; do for c in ${DPVQ_CONFIGS:-2 4}; do OPUS_AMD_DEC_PVQ4=$m timeout 220 python bench.py --steps 8 --warmup 2 --no-extra-configs --no-cpu-baseline --steady-state 0 --config $c --decode > $O/decode${c}_pvq4_$m.log 2>&1; done; done
