@@ -65,11 +65,12 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
    const int N = sh->N, LM = sh->LM, M = sh->M, start = sh->start, end = sh->end;
 
    K_PHASE(1);
-   /* ---- pre-emphasis (celt_encoder.c:557) is not materialised: pre_at() recomputes it from the int16 staging buffer ---- */
+   /* ---- pre-emphasis (celt_encoder.c:557): the new samples once, into the spectrum scratch (free until the first MDCT); pre_at() reads history and new samples alike ---- */
    PreSrc ps0, ps1;
    const int up = sh->upsample > 1 ? wv_uni(sh->upsample) : 1;
-   ps0.hist = gst->prefilter_mem; ps0.pcm = L->g->pcm16; ps0.CC = CC; ps0.c = 0; ps0.mem0 = st->preemph_memE[0]; ps0.up = up;
-   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.pcm = L->g->pcm16; ps1.CC = CC; ps1.c = 1; ps1.mem0 = st->preemph_memE[1]; ps1.up = up;
+   pre_stage_wave(L->g->X, L->g->pcm16, CC, N, st->preemph_memE[0], st->preemph_memE[1], up);
+   ps0.hist = gst->prefilter_mem; ps0.xnew = L->g->X;
+   ps1.hist = gst->prefilter_mem + OA_MAX_PERIOD; ps1.xnew = L->g->X + N;
    wv_sync();
    LANE0 { for (int c = 0; c < CC; c++) st->preemph_memE[c] = up > 1 ? 0 : mult16_32_q15(27853, shl32((i32)L->g->pcm16[CC * (N - 1) + c], SIG_SHIFT)); }   /* the last zero-stuffed sample is 0 */
    wv_sync();

@@ -321,23 +321,41 @@ WV_DEVN void celt_prologue(WV_LDS FrameLds *L, int hyb_bytes = 0)
    EC_END;
 }
 
-/* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input):
- * history comes straight from the stream's HBM state, new samples are recomputed from the int16 staging buffer
- * (x<<12 - .85*prev<<12, celt_encoder.c:557), so no 16 KB copy has to live in LDS. */
-struct PreSrc { const i32 *hist; const i16 *pcm; int CC, c; i32 mem0; int up; };
+/* The unfiltered pre-emphasised signal of one channel, indexed like the reference's pre[c][] (history then new input): the history comes straight from the stream's
+ * HBM state, the new samples (x<<12 - .85*prev<<12, celt_encoder.c:557) are worked out once per frame into the frame's spectrum scratch, which nothing else uses before
+ * the first MDCT (pre_stage_wave) -- so no 16 KB copy has to live in LDS, and a sample is ONE load without control flow (the compiler keeps many of them in flight). */
+struct PreSrc { const i32 *hist; const i32 *xnew; };
 WV_DEV i32 pre_at(const PreSrc &p, int j)
 {
-   if (j < OA_MAX_PERIOD) return p.hist[j];
-   int i = j - OA_MAX_PERIOD;
-   if (p.up > 1) {                     /* API rate below 48 kHz: sample i of the zero-stuffed signal is pcm[i / up] when up divides i, else 0 (celt_encoder.c:583-612) */
-      const int q = i / p.up, r = i - q * p.up;
-      const i32 x = r == 0 ? shl32((i32)p.pcm[p.CC * q + p.c], SIG_SHIFT) : 0;
-      const i32 m = i == 0 ? p.mem0 : (r == 1 ? mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * q + p.c], SIG_SHIFT)) : 0);
+   const i32 *b = j < OA_MAX_PERIOD ? p.hist : p.xnew - OA_MAX_PERIOD;
+   return b[j];
+}
+WV_DEV i32 pre_calc(const i16 *pcm, int CC, int c, i32 mem0, int up, int i)
+{
+   if (up > 1) {                       /* API rate below 48 kHz: sample i of the zero-stuffed signal is pcm[i / up] when up divides i, else 0 (celt_encoder.c:583-612) */
+      const int q = i / up, r = i - q * up;
+      const i32 x = r == 0 ? shl32((i32)pcm[CC * q + c], SIG_SHIFT) : 0;
+      const i32 m = i == 0 ? mem0 : (r == 1 ? mult16_32_q15(27853, shl32((i32)pcm[CC * q + c], SIG_SHIFT)) : 0);
       return x - m;
    }
-   i32 x = shl32((i32)p.pcm[p.CC * i + p.c], SIG_SHIFT);
-   i32 m = i == 0 ? p.mem0 : mult16_32_q15(27853, shl32((i32)p.pcm[p.CC * (i - 1) + p.c], SIG_SHIFT));
+   i32 x = shl32((i32)pcm[CC * i + c], SIG_SHIFT);
+   i32 m = i == 0 ? mem0 : mult16_32_q15(27853, shl32((i32)pcm[CC * (i - 1) + c], SIG_SHIFT));
    return x - m;
+}
+/* the frame's N new pre-emphasised samples of every channel -> xnew[c * N + i] */
+WV_DEV void pre_stage_wave(i32 *xnew, const i16 *pcm, int CC, int N, i32 mem0, i32 mem1, int up)
+{
+   if (CC == 2 && up == 1) {           /* both channels of a sample in one word */
+      const u32 *pw = (const u32 *)pcm;
+      FOR_LANES(i, N) {
+         const u32 cur = pw[i], prv = pw[i > 0 ? i - 1 : 0];
+         const i32 m0 = i == 0 ? mem0 : mult16_32_q15(27853, shl32((i32)(i16)prv, SIG_SHIFT)), m1 = i == 0 ? mem1 : mult16_32_q15(27853, shl32((i32)prv >> 16, SIG_SHIFT));
+         xnew[i] = shl32((i32)(i16)cur, SIG_SHIFT) - m0;
+         xnew[N + i] = shl32((i32)cur >> 16, SIG_SHIFT) - m1;
+      }
+   } else {
+      for (int c = 0; c < CC; c++) { FOR_LANES(i, N) xnew[c * N + i] = pre_calc(pcm, CC, c, c ? mem1 : mem0, up, i); }
+   }
 }
 
 /* tone detector (celt_encoder.c:1272-1403).  x16 built in parallel, correlations by wave reductions
@@ -431,7 +449,7 @@ WV_DEVN void transient_analysis_wave(WV_LDS FrameLds *L, const PreSrc &p0, const
    const int forward_shift = allow_weak_transients ? 5 : 4;
    const int j0 = OA_MAX_PERIOD - OA_OVERLAP;      /* in[c][i] == pre[c][1024 - overlap + i] */
    i32 unmask_c = 0;
-   const bool have_pre = tr_pre != nullptr && !allow_weak_transients && !wv_uni(L->sh.do_stereo_fade) && p0.up <= 1 && wv_uni(tr_pre[2]) == len;   /* (worked out from the frame this call codes, unfaded, 48 kHz) */
+   const bool have_pre = tr_pre != nullptr && !allow_weak_transients && !wv_uni(L->sh.do_stereo_fade) && wv_uni(L->sh.upsample) <= 1 && wv_uni(tr_pre[2]) == len;   /* (worked out from the frame this call codes, unfaded, 48 kHz) */
    if (have_pre) { if (lane < C) unmask_c = tr_pre[lane]; }
    else {
    i32 mx = 0;

@@ -70,21 +70,35 @@ template <class Src>
 WV_DEVN void pitch_downsample_src(WV_LDS i16 *x_lp, WV_LDS i16 *xx, const Src &p0, const Src &p1, int len, int C)
 {
    i32 maxabs = 0;
-   FOR_LANES(i, 2 * len) { maxabs = imax(maxabs, iabs(src_at(p0, i))); if (C == 2) maxabs = imax(maxabs, iabs(src_at(p1, i))); }
+   for (int i0 = wv_lane(); i0 < 2 * len; i0 += 8 * WV_WIDTH) {      /* (eight loads per channel in flight; a clamped index repeats a sample, which a maximum does not see) */
+      i32 a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) { const int i = imin(i0 + t * WV_WIDTH, 2 * len - 1); a[t] = src_at(p0, i); b[t] = C == 2 ? src_at(p1, i) : 0; }
+#pragma unroll
+      for (int t = 0; t < 8; t++) maxabs = imax(maxabs, imax(iabs(a[t]), iabs(b[t])));
+   }
    maxabs = wv_max(maxabs);
    if (maxabs < 1) maxabs = 1;
    int shift = celt_ilog2(maxabs) - 10;
    if (shift < 0) shift = 0;
    if (C == 2) shift++;
-   FOR_LANES(i, len) {
-      i16 v;
-      if (i == 0) v = (i16)((src_at(p0, 1) >> (shift + 2)) + (src_at(p0, 0) >> (shift + 1)));
-      else v = (i16)((src_at(p0, 2 * i - 1) >> (shift + 2)) + (src_at(p0, 2 * i + 1) >> (shift + 2)) + (src_at(p0, 2 * i) >> (shift + 1)));
-      if (C == 2) {
-         if (i == 0) v = (i16)(v + (src_at(p1, 1) >> (shift + 2)) + (src_at(p1, 0) >> (shift + 1)));
-         else v = (i16)(v + (src_at(p1, 2 * i - 1) >> (shift + 2)) + (src_at(p1, 2 * i + 1) >> (shift + 2)) + (src_at(p1, 2 * i) >> (shift + 1)));
+   for (int i0 = wv_lane(); i0 < len; i0 += 4 * WV_WIDTH) {
+      i32 a[4][3], b[4][3];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+         const int i = imin(i0 + t * WV_WIDTH, len - 1);
+#pragma unroll
+         for (int k = 0; k < 3; k++) { const int j = imax(2 * i - 1 + k, 0); a[t][k] = src_at(p0, j); b[t][k] = C == 2 ? src_at(p1, j) : 0; }
       }
-      x_lp[i] = v;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+         const int i = i0 + t * WV_WIDTH;
+         if (i < len) {
+            i16 v = (i16)((i == 0 ? 0 : a[t][0] >> (shift + 2)) + (a[t][2] >> (shift + 2)) + (a[t][1] >> (shift + 1)));
+            if (C == 2) v = (i16)(v + (i == 0 ? 0 : b[t][0] >> (shift + 2)) + (b[t][2] >> (shift + 2)) + (b[t][1] >> (shift + 1)));
+            x_lp[i] = v;
+         }
+      }
    }
    wv_sync();
    /* _celt_autocorr(x_lp, ac, NULL, 0, 4, len) */
@@ -208,10 +222,14 @@ WV_DEV void find_best_pitch_wave(const WV_LDS i32 *xcorr, const WV_LDS i16 *y, i
       return;
    }
    i32 num0 = -1, num1 = -1, den0 = 0, den1 = 0; int p0 = 0, p1 = 1;
-   for (int l = 0; l < WV_WIDTH && l * per < max_pitch; l++) {
+   i32 anyc = nm[0];
+#pragma unroll
+   for (int t = 1; t < 8; t++) anyc = imax(anyc, nm[t]);
+   for (u64 todo = wv_ballot(anyc >= 0); todo; todo &= todo - 1) {   /* lanes that hold a candidate, in lag order (the fine search has ten of them among 489 lags) */
+      const int l = (int)__builtin_ctzll(todo);
 #pragma unroll
       for (int t = 0; t < 8; t++) {
-         if (t < per && l * per + t < max_pitch) {
+         if (t < per) {                                               /* (lags past max_pitch carry nm = -1) */
             const i32 n = wv_bcast(nm[t], l);
             if (n >= 0) {
                const i32 sy = wv_bcast(S[t], l);
@@ -242,13 +260,31 @@ WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LD
       shift *= 2;
       wv_sync();
    } else shift = 0;
-   /* coarse search, 4x decimated: one lag per lane */
+   /* coarse search, 4x decimated: four consecutive lags per lane.  The lane's window of y slides through registers (two samples per LDS word, one new word per two taps),
+    * x is a broadcast read: a quarter of the LDS reads of a lag-per-lane loop and four independent accumulators (mod-2^32 sums: any order) */
    i32 maxcorr = 1;
-   FOR_LANES(i, max_pitch >> 2) {
-      i32 s = 0;
-      for (int j = 0; j < len >> 2; j++) s = mac16_16(s, x_lp4[j], y_lp4[i + j]);
-      xcorr[i] = s;
-      maxcorr = imax(maxcorr, s);
+   {
+      const int nl = max_pitch >> 2, n4 = len >> 2, i0 = 4 * wv_lane();
+      if (i0 < nl) {
+         const WV_LDS u32 *xp = (const WV_LDS u32 *)x_lp4, *yp = (const WV_LDS u32 *)(y_lp4 + i0);
+         i32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+         const u32 q0 = yp[0], q1 = yp[1];
+         i32 w0 = (i16)q0, w1 = (i32)q0 >> 16, w2 = (i16)q1, w3 = (i32)q1 >> 16;
+         for (int j = 0; j + 1 < n4; j += 2) {
+            const u32 xx = xp[j >> 1], q2 = yp[(j >> 1) + 2];
+            const i32 xa = (i16)xx, xb = (i32)xx >> 16, w4 = (i16)q2, w5 = (i32)q2 >> 16;
+            s0 = mac16_16(mac16_16(s0, xa, w0), xb, w1);
+            s1 = mac16_16(mac16_16(s1, xa, w1), xb, w2);
+            s2 = mac16_16(mac16_16(s2, xa, w2), xb, w3);
+            s3 = mac16_16(mac16_16(s3, xa, w3), xb, w4);
+            w0 = w2; w1 = w3; w2 = w4; w3 = w5;
+         }
+         if (n4 & 1) { const i32 xa = x_lp4[n4 - 1]; s0 = mac16_16(s0, xa, w0); s1 = mac16_16(s1, xa, w1); s2 = mac16_16(s2, xa, w2); s3 = mac16_16(s3, xa, w3); }
+         xcorr[i0] = s0; maxcorr = imax(maxcorr, s0);
+         if (i0 + 1 < nl) { xcorr[i0 + 1] = s1; maxcorr = imax(maxcorr, s1); }
+         if (i0 + 2 < nl) { xcorr[i0 + 2] = s2; maxcorr = imax(maxcorr, s2); }
+         if (i0 + 3 < nl) { xcorr[i0 + 3] = s3; maxcorr = imax(maxcorr, s3); }
+      }
    }
    maxcorr = wv_max(maxcorr);
    wv_sync();
@@ -260,13 +296,19 @@ WV_DEVN int pitch_search_bufs(const WV_LDS i16 *x_lp, const WV_LDS i16 *y, WV_LD
    maxcorr = 1;
    FOR_LANES(i, max_pitch >> 1) xcorr[i] = 0;
    wv_sync();
-   for (int i = 0; i < max_pitch >> 1; i++) {
-      if (iabs(i - 2 * bp0) > 2 && iabs(i - 2 * bp1) > 2) continue;
-      i32 s = 0;
-      FOR_LANES(j, len >> 1) s += mult16_16(x_lp[j], y[i + j]) >> shift;
-      s = wv_sum(s);
-      LANE0 xcorr[i] = imax(-1, s);
-      maxcorr = imax(maxcorr, s);
+   for (int r = 0; r < 2; r++) {                                     /* the five lags around each candidate side by side: one read of x per five products */
+      const int c2 = 2 * (r ? bp1 : bp0), lo = imax(0, c2 - 2), hi = imin((max_pitch >> 1) - 1, c2 + 2);
+      i32 s[5] = {0, 0, 0, 0, 0};
+      FOR_LANES(j, len >> 1) {
+         const i32 xv = x_lp[j];
+#pragma unroll
+         for (int d = 0; d < 5; d++) s[d] += mult16_16(xv, y[lo + d + j]) >> shift;       /* (lags past hi read on inside the buffer; their sums are dropped) */
+      }
+#pragma unroll
+      for (int d = 0; d < 5; d++) {
+         const i32 sd = wv_sum(s[d]);
+         if (lo + d <= hi) { LANE0 xcorr[lo + d] = imax(-1, sd); maxcorr = imax(maxcorr, sd); }
+      }
    }
    wv_sync();
    int bpb[2];
@@ -376,15 +418,21 @@ WV_DEVN i16 remove_doubling_wave(WV_LDS FrameLds *L, int maxperiod, int minperio
 }
 
 /* comb_filter (celt.c:238) out of place: y[i] from the *unfiltered* signal (PreSrc, index 0 = first new sample), so all
- * outputs are independent */
-WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap)
+ * outputs are independent.  sums (or NULL): [0] += sum |x[i] >> 12| of the input, [1] += sum |y[i] >> 12| of the output -- run_prefilter's before / after measures
+ * (celt_encoder.c:1520-1540) taken while the samples are in registers. */
+WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16 g0, i16 g1, int tapset0, int tapset1, int overlap, i32 *sums = nullptr)
 {
    const i16 gains[3][3] = {
       {QC16(0.3066406250f, 15), QC16(0.2170410156f, 15), QC16(0.1296386719f, 15)},
       {QC16(0.4638671875f, 15), QC16(0.2680664062f, 15), QC16(0.f, 15)},
       {QC16(0.7998046875f, 15), QC16(0.1000976562f, 15), QC16(0.f, 15)}};
 #define XA(k) pre_at(p, OA_MAX_PERIOD + (k))
-   if (g0 == 0 && g1 == 0) { FOR_LANES(i, N) y[i] = XA(i); return; }
+   i32 sb = 0, sa = 0;
+   if (g0 == 0 && g1 == 0) {
+      FOR_LANES(i, N) { const i32 v = XA(i); y[i] = v; sb += iabs(v >> 12); }
+      if (sums) { sb = wv_sum(sb); sums[0] += sb; sums[1] += sb; }
+      return;
+   }
    T0 = imax(T0, OA_MIN_PERIOD);
    T1 = imax(T1, OA_MIN_PERIOD);
    i16 g00 = (i16)mult_coef_taps(g0, gains[tapset0][0]), g01 = (i16)mult_coef_taps(g0, gains[tapset0][1]), g02 = (i16)mult_coef_taps(g0, gains[tapset0][2]);
@@ -392,9 +440,10 @@ WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16
    if (g0 == g1 && T0 == T1 && tapset0 == tapset1) overlap = 0;
    FOR_LANES(i, N) {
       i32 v;
+      const i32 x0 = XA(i);
       if (i < overlap) {
          i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
-         v = XA(i);
+         v = x0;
          v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), XA(i - T0)));
          v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(XA(i - T0 + 1), XA(i - T0 - 1))));
          v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(XA(i - T0 + 2), XA(i - T0 - 2))));
@@ -403,14 +452,17 @@ WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16
          v = add32(v, mult_coef_32(mult_coef(f, g12), add32(XA(i - T1 + 2), XA(i - T1 - 2))));
          v = saturate(sub32(v, 3), SIG_SAT);
       } else if (g1 == 0) {
-         v = XA(i);
+         v = x0;
       } else {
-         v = add32(add32(add32(XA(i), mult_coef_32(g10, XA(i - T1))), mult_coef_32(g11, add32(XA(i - T1 + 1), XA(i - T1 - 1)))),
-               mult_coef_32(g12, add32(XA(i - T1 + 2), XA(i - T1 - 2))));
+         /* (tap sets 1 and 2 have no outer taps: g12 == 0 contributes mult_coef_32(0, .) == 0 -- two loads less) */
+         const i32 outer = g12 != 0 ? mult_coef_32(g12, add32(XA(i - T1 + 2), XA(i - T1 - 2))) : 0;
+         v = add32(add32(add32(x0, mult_coef_32(g10, XA(i - T1))), mult_coef_32(g11, add32(XA(i - T1 + 1), XA(i - T1 - 1)))), outer);
          v = saturate(sub32(v, 1), SIG_SAT);
       }
       y[i] = v;
+      sb += iabs(x0 >> 12); sa += iabs(v >> 12);
    }
+   if (sums) { sums[0] += wv_sum(sb); sums[1] += wv_sum(sa); }
 #undef XA
 }
 
@@ -471,22 +523,12 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
    const int old_period = imax(st->prefilter_period, OA_MIN_PERIOD), old_tapset = st->prefilter_tapset;
    i32 before[2] = {0, 0}, after[2] = {0, 0};
    K_TIC();
-   wv_sync();
+   wv_sync();                    /* the pitch buffers (aliased with in[]) are dead from here */
    /* (the head in[c][0..overlap) is in_mem, last frame's *filtered* tail, celt_encoder.c:1546: it stays in HBM) */
    for (int c = 0; c < CC; c++) {
-      const PreSrc &ps = c ? ps1 : ps0;
-      i32 b = 0;
-      FOR_LANES(i, N) b += iabs(pre_at(ps, max_period + i) >> 12);
-      before[c] = wv_sum(b);
-   }
-   wv_sync();                    /* the pitch buffers (aliased with in[]) are dead from here */
-   for (int c = 0; c < CC; c++)
-      comb_filter_wave(G->in[c], c ? ps1 : ps0, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap);
-   wv_sync();
-   for (int c = 0; c < CC; c++) {
-      i32 a = 0;
-      FOR_LANES(i, N) a += iabs(G->in[c][i] >> 12);
-      after[c] = wv_sum(a);
+      i32 sums[2] = {0, 0};
+      comb_filter_wave(G->in[c], c ? ps1 : ps0, old_period, pitch_index, N, (i16)-old_gain, (i16)-gain1, old_tapset, prefilter_tapset, overlap, sums);
+      before[c] = sums[0]; after[c] = sums[1];
    }
    int cancel_pitch = 0;
    if (CC == 2) {
