@@ -32,31 +32,56 @@ WV_DEV i32 inner_prod_norm_shift_gw(const i32 *x, const WV_LDS i32 *y, int len) 
    return (i32)(wv_sum64(sum) >> 2 * (NORM_SHIFT - 14));
 }
 
-/* compute_band_energies + amp2Log2 of the channel resident in W: one lane per band */
+/* compute_band_energies + amp2Log2 of the channel resident in W.  A band is cut into chunks of two base coefficients (2 << LM bins): 54 chunks, one lane each, so the
+ * widest band (22 base coefficients) is eleven lanes' work instead of one lane's 176 bins twice over.  The band's range is the maximum of its chunks' ranges, its
+ * energy sum the (mod-2^32, order-free) sum of the chunks' sums; the first lane of a band finishes it.  Partials in L->scr [64]. */
+WV_TABLE u8 k_be_band[54] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 13, 13, 14, 14, 15, 15, 15, 16, 16, 16, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18,
+   19, 19, 19, 19, 19, 19, 19, 19, 19, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
+WV_TABLE u8 k_be_first[22] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21, 24, 28, 34, 43, 54};
 WV_DEV void band_energies_channel(WV_LDS FrameLds *L, const WV_LDS i32 *W, int c, WV_LDS i32 *bandLogE_out)
 {
-   const int LM = L->sh.LM, end = L->sh.end, effEnd = L->sh.effEnd;
-   FOR_LANES(i, NBE) {
-      if (i < effEnd) {
-         const WV_LDS i32 *x = &W[ct_eBands[i] << LM];
-         int len = (ct_eBands[i + 1] - ct_eBands[i]) << LM;
-         i32 mx = 0, mn = 0, sum = 0, E;
-         for (int j = 0; j < len; j++) { mx = imax(mx, x[j]); mn = imin(mn, x[j]); }
-         i32 maxval = imax(mx, neg32(mn));
-         if (maxval > 0) {
-            int shift = imax(0, 30 - celt_ilog2(maxval + (maxval >> 14) + 1) - ((((ct_logN[i] + 7) >> BITRES) + LM + 1) >> 1));
-            for (int j = 0; j < len; j++) { i32 v = shl32(x[j], shift); sum = add32(sum, mult32_32_q31(v, v)); }
-            E = imax(maxval, pshr32(fx_sqrt32(sum >> 1), shift));
-         } else E = EPSILON;
-         L->bandE[i + c * NBE] = E;
-         bandLogE_out[i + c * NBE] = fx_log2_db(E) - shl32((i32)ct_eMeans[i], DB_SHIFT - 4) + GC(2.f);
-      } else if (i < end) bandLogE_out[i + c * NBE] = -GC(14.f);
+   const int LM = L->sh.LM, end = L->sh.end, effEnd = L->sh.effEnd, lane = wv_lane();
+   WV_LDS i32 *part = L->scr;
+   int b = NBE, first = 0, last = 0, n = 0;
+   const WV_LDS i32 *x = W;
+   if (lane < 54) {
+      b = k_be_band[lane]; first = k_be_first[b]; last = k_be_first[b + 1];
+      const int k = lane - first, w = ct_eBands[b + 1] - ct_eBands[b];
+      x = &W[(ct_eBands[b] + 2 * k) << LM];
+      n = b < effEnd ? imin(2, w - 2 * k) << LM : 0;
    }
+   i32 mx = 0, mn = 0;
+   for (int j = 0; j < n; j++) { mx = imax(mx, x[j]); mn = imin(mn, x[j]); }
+   part[lane] = imax(mx, neg32(mn));
+   wv_sync();
+   i32 maxval = 0, sum = 0; int shift = 0;
+   for (int t = first; t < last; t++) maxval = imax(maxval, part[t]);
+   if (maxval > 0) {
+      shift = imax(0, 30 - celt_ilog2(maxval + (maxval >> 14) + 1) - ((((ct_logN[b] + 7) >> BITRES) + LM + 1) >> 1));
+      for (int j = 0; j < n; j++) { i32 v = shl32(x[j], shift); sum = add32(sum, mult32_32_q31(v, v)); }
+   }
+   wv_sync();
+   part[lane] = sum;
+   wv_sync();
+   if (lane < 54 && lane == first && b < effEnd) {
+      i32 E;
+      if (maxval > 0) {
+         i32 tot = 0;
+         for (int t = first; t < last; t++) tot = add32(tot, part[t]);
+         E = imax(maxval, pshr32(fx_sqrt32(tot >> 1), shift));
+      } else E = EPSILON;
+      L->bandE[b + c * NBE] = E;
+      bandLogE_out[b + c * NBE] = fx_log2_db(E) - shl32((i32)ct_eMeans[b], DB_SHIFT - 4) + GC(2.f);
+   }
+   FOR_LANES(i, NBE) { if (i >= effEnd && i < end) bandLogE_out[i + c * NBE] = -GC(14.f); }
+   wv_sync();
 }
 
 /* compute_mdcts (celt_encoder.c:511) + compute_band_energies (bands.c:95) + amp2Log2: one channel at a time through the LDS work buffer W -- B interleaved
  * transforms in place, the band energies while the channel is resident, then the channel goes out to the HBM spectrum g->X */
-WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks, WV_LDS i32 *bandLogE_out)
+/* normalise: the channel leaves LDS normalised (normalise_bands, bands.c:125, with the energies just taken) -- the spectrum is then written once instead of written,
+ * read and written again; the caller passes 0 when the energies can still change before the normalisation (LFE) or the transform is not the frame's last word */
+WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks, WV_LDS i32 *bandLogE_out, int normalise = 0)
 {
    const int C = L->sh.C, CC = L->sh.CC, LM = L->sh.LM;
    CeltScratch *G = L->g;
@@ -65,8 +90,10 @@ WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int s
    if (shortBlocks) { B = shortBlocks; N = 120; shift = 3; }
    else { B = 1; N = 120 << LM; shift = 3 - LM; }
    const int up = L->sh.upsample > 1 ? L->sh.upsample : 1, bound = B * N / up;
+   AN_TIC();
    for (int c = 0; c < CC; c++) {
       mdct_forward_blocks(gst->in_mem + c * OA_OVERLAP, G->in[c], W, shift, B, L->aux);
+      AN_TOC(19);
       if (CC == 2 && C == 1) {                                   /* stereo input coded as mono: the downmix of the two spectra */
          if (c == 0) { FOR_LANES(i, B * N) G->X[i] = W[i]; wv_sync(); continue; }
          FOR_LANES(i, B * N) W[i] = add32(G->X[i] >> 1, W[i] >> 1);
@@ -78,8 +105,26 @@ WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int s
       }
       const int cc = C == 1 ? 0 : c;
       band_energies_channel(L, W, cc, bandLogE_out);
-      FOR_LANES(i, B * N) G->X[cc * B * N + i] = W[i];
+      AN_TOC(20);
+      if (normalise) {
+         const int effEnd = L->sh.effEnd, nb = ct_eBands[effEnd] << LM;
+         FOR_LANES(i, NBE) {                                       /* (band_energies_channel ends on a barrier) */
+            if (i < effEnd) {
+               i32 E = L->bandE[i + cc * NBE];
+               if (E < 10) E += EPSILON;
+               const int sh = 30 - celt_zlog2(E);
+               L->scr[i] = fx_rcp_norm32(shl32(E, sh)); L->scr[NBE + i] = sh;
+            }
+         }
+         wv_sync();
+         FOR_LANES(i, B * N) {
+            i32 v = W[i];
+            if (i < nb) { const int bnd = ct_band_of[i >> LM]; v = pshr32(mult32_32_q31(L->scr[bnd], shl32(v, L->scr[NBE + bnd])), 30 - NORM_SHIFT); }
+            G->X[cc * B * N + i] = v;
+         }
+      } else { FOR_LANES(i, B * N) G->X[cc * B * N + i] = W[i]; }
       wv_sync();
+      AN_TOC(21);
    }
 }
 

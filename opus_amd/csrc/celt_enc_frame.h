@@ -128,7 +128,12 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       wv_sync();
    }
-   compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE);
+#ifdef K_DUMP_ENABLED
+   const int fuse_norm = 0;                                           /* (the stage dumps of the test build show the spectrum before and after normalise_bands) */
+#else
+   const int fuse_norm = !sh->lfe;                                    /* (LFE changes the energies first: normalise_bands_wave below) */
+#endif
+   compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm);
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->g->X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
    if (sh->lfe) {                    /* LFE: nothing but the first two bands carries energy (celt_encoder.c:2099-2107) */
@@ -190,14 +195,14 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
    if (sh->do_patch) {
       LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
       wv_sync();
-      compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE);
+      compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
    }
    store_in_mem_wave(L, gst);          /* last MDCT done: the overlap memory may now be replaced; BC is free from here */
    LANE0 { EC_BEGIN; if (LM > 0 && k_ec_tell(EC_PASS) + 3 <= sh->total_bits) k_ec_enc_bit_logp(EC_PASS, sh->isTransient, 3); EC_END; }
-   normalise_bands_wave(L);
+   if (!fuse_norm) normalise_bands_wave(L);
    K_DUMPI("isTransient2", sh->isTransient); K_DUMP("bandLogE2", L->bandLogE2, 42 * 4); for (int c = 0; c < C; c++) K_DUMP("X", L->g->X + c * N, M * ct_eBands[sh->effEnd] * 4); K_DUMPI("temporal_vbr", sh->temporal_vbr);
 
    K_PHASE(7);
@@ -379,6 +384,7 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
       EC_END;
    }
    wv_sync();
+   AN_TIC();
    {
       const int coded = oa_allocate_bits_wave<true>(&L->ec, L->packet + 1, L->scr, start, end, L->offsets, L->cap, sh->alloc_trim, &st->intensity, &sh->dual_stereo, sh->bits, &sh->balance,
             L->pulses, L->fine_quant, L->fine_priority, C, LM, st->lastCodedBands, sh->signalBandwidth, sh->r + 6);
@@ -388,8 +394,10 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
          else st->lastCodedBands = coded;
       }
    }
+   AN_TOC(22);
    fine_energy_wave(L);
    wv_sync();
+   AN_TOC(23);
    K_DUMPI("nbCompressedBytes", sh->nbCompressedBytes); K_DUMPI("codedBands", sh->codedBands); K_DUMPI("balance", sh->balance); K_DUMP("pulses", L->pulses, 84); K_DUMP("fine_quant", L->fine_quant, 84); K_DUMP("fine_priority", L->fine_priority, 84); K_DUMPI("rng_fine", L->ec.rng);
 
    K_PHASE(12);

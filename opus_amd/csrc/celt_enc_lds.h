@@ -22,6 +22,10 @@
 #define K_TIC()
 #define K_TOC(bucket)
 #endif
+#ifndef AN_TIC           /* ... and so do the sections that add straight to the global totals */
+#define AN_TIC()
+#define AN_TOC(bucket)
+#endif
 
 struct FrameShared {
    /* frame constants derived by the Opus layer / CELT prologue */

@@ -4,7 +4,7 @@
 #ifdef OA_PHASE_TIMERS
 /* profiling variant: shader-clock ticks per encoder phase, accumulated per wave in LDS (lane 0) and added to the
  * global totals once per frame */
-__device__ unsigned long long oa_phase_ticks[34];
+__device__ unsigned long long oa_phase_ticks[50];
 #define K_TIC() unsigned long long tic_ = clock64()
 #define K_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); L->prof[b] += (u32)(t_ - tic_); tic_ = t_; } } while (0)
 /* K_PHASE_BEGIN at the top of the call; K_PHASE(0) closes what precedes the coded frame (state load, analysis, decisions: bucket 15), K_PHASE(id) closes phase id - 1 */
@@ -14,6 +14,9 @@ __device__ unsigned long long oa_phase_ticks[34];
 /* the analysis has no FrameLds at hand: its sections go straight to the global totals (buckets 31..33) */
 #define AN_TIC() unsigned long long an_tic_ = clock64()
 #define AN_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - an_tic_); an_tic_ = t_; } } while (0)
+/* ... and a second clock for the finer sections inside those (buckets 34..49) */
+#define AN2_TIC() unsigned long long an2_tic_ = clock64()
+#define AN2_TOC(b) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&oa_phase_ticks[b], t_ - an2_tic_); an2_tic_ = t_; } } while (0)
 #endif
 #ifdef OA_PHASE_TIMERS
 /* the four-streams-per-wave PVQ kernel: a section's wave time (the first active lane adds the ticks) and its lane time (ticks x active lanes: how full the wave was),
@@ -1661,8 +1664,8 @@ OPUS_AMD_EXPORT int opusgpu_debug_sh_phase_ticks(unsigned long long *out, int re
 OPUS_AMD_EXPORT int opusgpu_debug_phase_ticks(unsigned long long *out, int reset)
 {
    HIPCHECK(hipDeviceSynchronize());
-   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 34));
-   if (reset) { unsigned long long z[34] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
+   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(oa_phase_ticks), sizeof(unsigned long long) * 50));
+   if (reset) { unsigned long long z[50] = {0}; HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(oa_phase_ticks), z, sizeof(z))); }
    return OPUS_OK;
 }
 OPUS_AMD_EXPORT int opusgpu_debug_p4_ticks(unsigned long long *ticks, unsigned long long *lanes, int reset)

@@ -36,6 +36,10 @@
 #define AN_TIC()
 #define AN_TOC(bucket)
 #endif
+#ifndef AN2_TIC
+#define AN2_TIC()
+#define AN2_TOC(bucket)
+#endif
 #ifndef AN_FN           /* out of line: inlined into the kernels (-DAN_FN=WV_DEV) the analysis' live ranges push the frame's own code into more spills -- measured on the MI355X:
                            1.316 M frames/s and 368 KB / frame of HBM traffic inlined against 1.371 M and 300 KB out of line (profiles/r03_c) */
 #define AN_FN WV_DEVN
@@ -93,6 +97,7 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
    if (subframe == 0) return 0;
    if (Fs == 48000) { subframe *= 2; offset *= 2; }
    else if (Fs == 16000) { subframe = subframe * 2 / 3; offset = offset * 2 / 3; }
+   AN2_TIC();
    FOR_LANES(j, subframe) {
       i32 v;
       if (apcm) { v = apcm[(size_t)(j + offset) * C]; if (C == 2) v = add32(v, apcm[(size_t)(j + offset) * C + 1]); }
@@ -103,6 +108,7 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
       else for (int m = 0; m < 3; m++) { const int p = 3 * j + m; W->fft[p] = v; if (p & 1) W->hbuf[p >> 1] = v; }   /* "Don't do this at home!" (:190): x3 by repetition, then 2:1 */
    }
    wv_sync();
+   AN2_TOC(34);
    if (Fs == 24000) return 0;
    const int len2 = (Fs == 48000 ? subframe : 3 * subframe) / 2;
    const int lane = wv_lane();
@@ -131,6 +137,7 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
       A->downmix_state[lane] = s;
    }
    wv_sync();
+   AN2_TOC(35);
    i64 ener = 0;
    FOR_LANES(k, len2) {
       const i32 e = W->fft[2 * k];
@@ -141,6 +148,7 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
    ener = wv_sum64(ener) >> (2 * SIG_SHIFT);
    if (ener > 2147483647) ener = 2147483647;
    wv_sync();
+   AN2_TOC(36);
    return Fs == 48000 ? (i32)ener : 0;
 }
 
@@ -168,6 +176,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
    /* the rest of the input goes through the decimator now (its state carries on from the first part) and waits in HBM until the window has read inmem */
    const int remaining = len - (AN_BUF_SIZE - mem_fill);
    const i32 e2 = an_downmix_resample_wave(W, A, pcm, apcm, gscratch, remaining, offset + AN_BUF_SIZE - mem_fill, C, Fs);
+   AN2_TIC();
    const int wp = wv_uni(A->write_pos);
    OaAnalysisInfo *info = &A->info[wp];
    i32 mx = 0;
@@ -179,6 +188,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       A->write_pos = wp + 1 >= AN_DETECT_SIZE ? wp + 1 - AN_DETECT_SIZE : wp + 1;
       A->mem_fill = 240 + remaining;
    }
+   AN2_TOC(37);
    {  /* window (:523-530) + the bit-reversed, scaled load of opus_fft_c (celt/kiss_fft.c:615) */
       const int16_t *bitrev = ct_fft_bitrev + ct_fft_bitrev_off[0];
       const int scale = ct_fft_misc[1];
@@ -192,6 +202,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       }
       if (lane == 0) W->aux[0] = ct_fft_misc[2] - 1;           /* the down-shift budget of opus_fft_c: scale_shift - 1 */
    }
+   AN2_TOC(38);
    {  /* OPUS_MOVE(inmem, inmem + 720 - 240, 240) and the second part behind it: every lane reads what it moves before anyone writes */
       i32 keep[4];
       for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; keep[t] = i < 240 ? A->inmem[AN_BUF_SIZE - 240 + i] : 0; }
@@ -206,8 +217,10 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       wv_sync();
       return;
    }
+   AN2_TOC(39);
    AN_TOC(31);
    fft_forward(W->fft, 0, 1, W->aux);
+   AN2_TOC(40);
    const int left = wv_uni(W->aux[0]);
    /* stage the small state of the feature / network tail */
    if (lane < 32) W->mem[lane] = A->mem[lane];
@@ -249,6 +262,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
             r_binE[t] = a.r * (float)a.r + b.r * (float)b.r + a.i * (float)a.i + b.i * (float)b.i;
          }
       }
+      AN2_TOC(41);
       wv_sync();                                               /* the spectrum is dead: its bytes now hold the per-bin results */
       for (int t = 0; t < 4; t++) {
          const int i = lane + t * WV_WIDTH;
@@ -268,6 +282,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; if (i >= 2 && i < N2 - 1) W->s.tonality[i] = sm[t]; }
    }
    wv_sync();
+   AN2_TOC(42);
    AN_TOC(32);
    const float scale_ener = (1.f / ((i32)1 << (15 + SIG_SHIFT))) * (1.f / ((i32)1 << (15 + SIG_SHIFT)));   /* SCALE_ENER (:414): the input is +/-2^15 shifted up by SIG_SHIFT */
    const int E_count = wv_uni(A->E_count);
@@ -319,6 +334,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       W->t.band_log2[0] = .5f * 1.442695f * (float)log((double)(E + 1e-10f));
    }
    wv_sync();
+   AN2_TOC(43);
    {  /* spectral variability (:755-775): the 8 x 8 distances between the stored log spectra, one lane per pair */
       const int i = lane >> 3, j = lane & 7;
       float dist = 0;
@@ -338,6 +354,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       if (lane >= 8 && lane < 16) { const int c = lane - 8; float sum = 0; for (int b = 0; b < 16; b++) sum += an_dct_table[c * 16 + b] * W->t.logE[b]; W->t.BFCC[c] = sum; }
       if (lane >= 16 && lane < 24) { const int c = lane - 16; float sum = 0; for (int b = 0; b < 16; b++) sum += an_dct_table[c * 16 + b] * .5f * (A->highE[b] + A->lowE[b]); W->t.midE[c] = sum; }
    }
+   AN2_TOC(44);
    /* ---- what chains across the bands: lane 0 ---- */
    LANE0 {
       float frame_tonality = 0, max_frame_tonality = 0, frame_noisiness = 0, frame_stationarity = 0, relativeE = 0, frame_loudness = 0, slope = 0;
@@ -439,6 +456,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       W->frame_tonality = frame_tonality; W->tonality_slope = slope; W->activity = activity; W->frame_noisiness = frame_noisiness; W->bandwidth = bandwidth;
       A->prev_bandwidth = bandwidth;
    }
+   AN2_TOC(45);
    /* leak_boost (:744-753), one lane per band, straight into the info record */
    if (lane < AN_NB_TBANDS + 1) {
       const int b = lane;
@@ -496,6 +514,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
       info->bandwidth = W->bandwidth; info->max_pitch_ratio = W->max_pitch_ratio;
       info->valid = 1;
    }
+   AN2_TOC(46);
    AN_TOC(33);
 }
 
@@ -504,6 +523,7 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
 AN_FN void an_get_info_wave(WV_LDS AnLds *W, OaAnalysis *A, OaAnalysisInfo *info_out, int len, int Fs)
 {
    const int lane = wv_lane();
+   AN2_TIC();
    wv_sync();
    FOR_LANES(i, AN_DETECT_SIZE) {
       W->ring.tonality[i] = A->info[i].tonality; W->ring.music_prob[i] = A->info[i].music_prob;
@@ -526,6 +546,7 @@ AN_FN void an_get_info_wave(WV_LDS AnLds *W, OaAnalysis *A, OaAnalysisInfo *info
    const int pos0 = pos;
    if (lane < (int)(sizeof(OaAnalysisInfo) / 4)) ((i32 *)info_out)[lane] = ((const i32 *)&A->info[pos0])[lane];
    wv_sync();
+   AN2_TOC(47);
    if (!wv_uni(A->info[pos0].valid)) return;
    LANE0 {
       const WV_LDS float *ton = W->ring.tonality, *mp = W->ring.music_prob, *ap = W->ring.activity_probability;
@@ -597,6 +618,7 @@ AN_FN void an_get_info_wave(WV_LDS AnLds *W, OaAnalysis *A, OaAnalysisInfo *info
       info_out->music_prob_min = prob_min;
       info_out->music_prob_max = prob_max;
    }
+   AN2_TOC(48);
 }
 
 /* run_analysis (src/analysis.c:954): the call's input through tonality_analysis in 20 ms steps, then the info for the call's first coded frame */
