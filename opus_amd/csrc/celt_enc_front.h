@@ -15,7 +15,7 @@
 /* lane-0 serial section, fenced on both sides: other lanes neither race ahead of its inputs nor read its
  * outputs early (on the GPU the fences are LDS waits; the CPU emulator needs them for fiber ordering) */
 #ifndef LANE0
-#define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
+#define LANE0 for (int l0_ = (wv_sync(), wv_prio_serial(), 1); l0_; l0_ = (wv_prio_normal(), wv_sync(), 0)) if (wv_lane() == 0)
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
 #endif
 

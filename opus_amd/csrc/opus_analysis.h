@@ -23,7 +23,7 @@
 #pragma clang fp contract(off)
 #endif
 #ifndef LANE0
-#define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
+#define LANE0 for (int l0_ = (wv_sync(), wv_prio_serial(), 1); l0_; l0_ = (wv_prio_normal(), wv_sync(), 0)) if (wv_lane() == 0)
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
 #endif
 
@@ -91,27 +91,40 @@ WV_DEV int an_float2int(float x) { return (int)rintf(x); }                  /* l
  * `offset` samples (at 24 kHz) into the call's input, into y[] (HBM); input = the int16 samples of opus_encode (downmix_int, src/opus_encoder.c:780) or -- apcm --
  * the samples of the 24-bit / float entry points already in the signal domain (downmix_int24 :804, downmix_float :748).  Returns the high-pass energy (48 kHz only).
  * silk_resampler_down2_hp (:114): out[k] = (ap0(x[2k]) + ap1(x[2k+1])) / 2, hp[k] = ap0(x[2k]) + ap1'(-x[2k+1]); each first-order all-pass section rounds at every
- * step, so it is a serial recursion -- but the three are independent of each other: lanes 0, 1, 2. */
-WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *pcm, const i32 *apcm, i32 *y, int subframe, int offset, int C, int Fs)
+ * step, so it is a serial recursion -- but the three are independent of each other: lanes 0, 1, 2.
+ * mirror: the output also stays in LDS, W->hbuf [0, subframe at 24 kHz), for a caller that reads it back at once. */
+WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *pcm, const i32 *apcm, i32 *y, int subframe, int offset, int C, int Fs, bool mirror = false)
 {
    if (subframe == 0) return 0;
    if (Fs == 48000) { subframe *= 2; offset *= 2; }
    else if (Fs == 16000) { subframe = subframe * 2 / 3; offset = offset * 2 / 3; }
    AN2_TIC();
-   FOR_LANES(j, subframe) {
-      i32 v;
-      if (apcm) { v = apcm[(size_t)(j + offset) * C]; if (C == 2) v = add32(v, apcm[(size_t)(j + offset) * C + 1]); }
-      else { v = shl32((i32)pcm[(size_t)(j + offset) * C], SIG_SHIFT); if (C == 2) v = add32(v, shl32((i32)pcm[(size_t)(j + offset) * C + 1], SIG_SHIFT)); }
-      if (C == 2) v = half32(v);
-      if (Fs == 48000) { W->fft[j] = v; if (j & 1) W->hbuf[j >> 1] = v; }
-      else if (Fs == 24000) y[j] = v;
-      else for (int m = 0; m < 3; m++) { const int p = 3 * j + m; W->fft[p] = v; if (p & 1) W->hbuf[p >> 1] = v; }   /* "Don't do this at home!" (:190): x3 by repetition, then 2:1 */
+   for (int j0 = 0; j0 < subframe; j0 += 8 * WV_WIDTH) {         /* eight trips' samples are asked for together: a trip is a round trip to HBM (the input's first touch) */
+      i32 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const size_t at = (size_t)(imin(j0 + u * WV_WIDTH + wv_lane(), subframe - 1) + offset) * C;
+         if (apcm) { a[u] = apcm[at]; b[u] = C == 2 ? apcm[at + 1] : 0; }
+         else { a[u] = shl32((i32)pcm[at], SIG_SHIFT); b[u] = C == 2 ? shl32((i32)pcm[at + 1], SIG_SHIFT) : 0; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int j = j0 + u * WV_WIDTH + wv_lane();
+         if (j < subframe) {
+            i32 v = a[u];
+            if (C == 2) v = half32(add32(v, b[u]));
+            if (Fs == 48000) { W->fft[j] = v; if (j & 1) W->hbuf[j >> 1] = v; }
+            else if (Fs == 24000) { y[j] = v; if (mirror) W->hbuf[j] = v; }
+            else for (int m = 0; m < 3; m++) { const int p = 3 * j + m; W->fft[p] = v; if (p & 1) W->hbuf[p >> 1] = v; }   /* "Don't do this at home!" (:190): x3 by repetition, then 2:1 */
+         }
+      }
    }
    wv_sync();
    AN2_TOC(34);
    if (Fs == 24000) return 0;
    const int len2 = (Fs == 48000 ? subframe : 3 * subframe) / 2;
    const int lane = wv_lane();
+   wv_prio_serial();
    if (lane < 3) {
       const i32 c = lane == 0 ? 19904 /* QCONST16(0.6074371f, 15) */ : 4936 /* QCONST16(0.15063f, 15) */;
       WV_LDS i32 *p = lane == 0 ? W->fft : lane == 1 ? W->fft + 1 : W->hbuf;
@@ -136,13 +149,15 @@ WV_DEV i32 an_downmix_resample_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *p
       }
       A->downmix_state[lane] = s;
    }
+   wv_prio_normal();
    wv_sync();
    AN2_TOC(35);
    i64 ener = 0;
    FOR_LANES(k, len2) {
-      const i32 e = W->fft[2 * k];
-      y[k] = half32(add32(e, W->fft[2 * k + 1]));
+      const i32 e = W->fft[2 * k], o = half32(add32(e, W->fft[2 * k + 1]));
+      y[k] = o;
       const i32 hp = add32(e, W->hbuf[k]);
+      if (mirror) W->hbuf[k] = o;                               /* (this lane has just read the word) */
       ener += ((i64)hp * (i64)hp) >> 8;                         /* (len2 can be up to 480, so we shift by 8 to make it fit) */
    }
    ener = wv_sum64(ener) >> (2 * SIG_SHIFT);
@@ -159,57 +174,66 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
    const int lane = wv_lane();
    const int N = 480, N2 = 240;
    AN_TIC();
-   LANE0 { if (!A->initialized) { A->mem_fill = 240; A->initialized = 1; } }
-   const int count = wv_uni(A->count);
+   int mem_fill = wv_uni(A->mem_fill);
+   const int count = wv_uni(A->count), wp = wv_uni(A->write_pos);
+   const float hp_acc = A->hp_ener_accum;                     /* (the call's small state is asked for together, ahead of the decimator) */
+   if (!wv_uni(A->initialized)) { mem_fill = 240; if (lane == 0) { A->mem_fill = 240; A->initialized = 1; } }
    const float alpha = 1.f / imin(10, 1 + count), alphaE = 1.f / imin(25, 1 + count);
    float alphaE2 = 1.f / imin(100, 1 + count);                 /* noise floor related decay for bandwidth detection: -2.2 dB/second */
    if (count <= 1) alphaE2 = 1;
    if (Fs == 48000) { len /= 2; offset /= 2; }                 /* len and offset are now at 24 kHz */
    else if (Fs == 16000) { len = 3 * len / 2; offset = 3 * offset / 2; }
-   const int mem_fill = wv_uni(A->mem_fill);
    const int n1 = imin(len, AN_BUF_SIZE - mem_fill);
-   const i32 e1 = an_downmix_resample_wave(W, A, pcm, apcm, A->inmem + mem_fill, n1, offset, C, Fs);
+   const i32 e1 = an_downmix_resample_wave(W, A, pcm, apcm, A->inmem + mem_fill, n1, offset, C, Fs, true);
    if (mem_fill + len < AN_BUF_SIZE) {                         /* not enough to update the analysis */
-      LANE0 { A->hp_ener_accum += (float)e1; A->mem_fill = mem_fill + len; }
+      LANE0 { A->hp_ener_accum = hp_acc + (float)e1; A->mem_fill = mem_fill + len; }
       return;
    }
    /* the rest of the input goes through the decimator now (its state carries on from the first part) and waits in HBM until the window has read inmem */
    const int remaining = len - (AN_BUF_SIZE - mem_fill);
    const i32 e2 = an_downmix_resample_wave(W, A, pcm, apcm, gscratch, remaining, offset + AN_BUF_SIZE - mem_fill, C, Fs);
    AN2_TIC();
-   const int wp = wv_uni(A->write_pos);
    OaAnalysisInfo *info = &A->info[wp];
-   i32 mx = 0;
-   FOR_LANES(i, AN_BUF_SIZE) mx = imax(mx, iabs(A->inmem[i]));
-   const int is_silence = wv_max(mx) == 0;                     /* is_digital_silence32 (:418) */
-   LANE0 {
-      W->hp_ener = A->hp_ener_accum + (float)e1;
+   /* with nothing left over (the frame sizes of a stream that does not change them) the new part [mem_fill, 720) is still in LDS where the decimator put it: the window,
+    * the silence check and the move read it there instead of waiting for it to come back from HBM */
+   const bool fast = remaining == 0;
+#define AN_IN(idx) ((fast && (idx) >= mem_fill) ? W->hbuf[(idx) - mem_fill] : A->inmem[(idx)])
+   if (lane == 0) {
+      W->hp_ener = hp_acc + (float)e1;
       A->hp_ener_accum = (float)e2;
       A->write_pos = wp + 1 >= AN_DETECT_SIZE ? wp + 1 - AN_DETECT_SIZE : wp + 1;
       A->mem_fill = 240 + remaining;
    }
    AN2_TOC(37);
-   {  /* window (:523-530) + the bit-reversed, scaled load of opus_fft_c (celt/kiss_fft.c:615) */
+   i32 mx = 0;
+   {  /* window (:523-530) + the bit-reversed, scaled load of opus_fft_c (celt/kiss_fft.c:615); its four reads per point cover all of inmem: is_digital_silence32 (:418) */
       const int16_t *bitrev = ct_fft_bitrev + ct_fft_bitrev_off[0];
       const int scale = ct_fft_misc[1];
-      FOR_LANES(i, N2) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+         const int i = imin(lane + t * WV_WIDTH, N2 - 1);       /* (the last trip's spare lanes redo point 239: same values to the same words) */
          const float w = an_window[i];
-         const i32 ar = (i32)(w * A->inmem[i]), ai = (i32)(w * A->inmem[N2 + i]);
-         const i32 br = (i32)(w * A->inmem[N - i - 1]), bi = (i32)(w * A->inmem[N + N2 - i - 1]);
+         const i32 x0 = AN_IN(i), x1 = AN_IN(N2 + i), x2 = AN_IN(N - i - 1), x3 = AN_IN(N + N2 - i - 1);
+         mx = imax(imax(mx, iabs(x0)), imax(iabs(x1), imax(iabs(x2), iabs(x3))));
+         const i32 ar = (i32)(w * x0), ai = (i32)(w * x1);
+         const i32 br = (i32)(w * x2), bi = (i32)(w * x3);
          const int ra = bitrev[i], rb = bitrev[N - i - 1];
          W->fft[2 * ra] = SMUL2(ar, scale); W->fft[2 * ra + 1] = SMUL2(ai, scale);
          W->fft[2 * rb] = SMUL2(br, scale); W->fft[2 * rb + 1] = SMUL2(bi, scale);
       }
       if (lane == 0) W->aux[0] = ct_fft_misc[2] - 1;           /* the down-shift budget of opus_fft_c: scale_shift - 1 */
    }
+   const int is_silence = wv_max(mx) == 0;
    AN2_TOC(38);
-   {  /* OPUS_MOVE(inmem, inmem + 720 - 240, 240) and the second part behind it: every lane reads what it moves before anyone writes */
+   {  /* OPUS_MOVE(inmem, inmem + 720 - 240, 240) and the second part behind it (what is read, [480, 720), and what is written, [0, 240), do not meet; the second part
+       * lands on what was read, so there every lane reads what it moves before anyone writes) */
       i32 keep[4];
-      for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; keep[t] = i < 240 ? A->inmem[AN_BUF_SIZE - 240 + i] : 0; }
-      wv_sync();
+      for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; keep[t] = i < 240 ? AN_IN(AN_BUF_SIZE - 240 + i) : 0; }
+      if (!fast) wv_sync();
       for (int t = 0; t < 4; t++) { const int i = lane + t * WV_WIDTH; if (i < 240) A->inmem[i] = keep[t]; }
       FOR_LANES(i, remaining) A->inmem[240 + i] = gscratch[i];
    }
+#undef AN_IN
    wv_sync();
    if (is_silence) {                                           /* on silence, copy the previous analysis (:537) */
       const int prev_pos = wp + 1 - 2 < 0 ? wp + 1 - 2 + AN_DETECT_SIZE : wp + 1 - 2;

@@ -7,7 +7,7 @@
 #define OPUS_AMD_MULTIFRAME_H
 
 #ifndef LANE0
-#define LANE0 for (int l0_ = (wv_sync(), 1); l0_; l0_ = (wv_sync(), 0)) if (wv_lane() == 0)
+#define LANE0 for (int l0_ = (wv_sync(), wv_prio_serial(), 1); l0_; l0_ = (wv_prio_normal(), wv_sync(), 0)) if (wv_lane() == 0)
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
 #endif
 #define OA_MF_MAX_FRAMES 6

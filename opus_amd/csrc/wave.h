@@ -36,6 +36,16 @@ WV_DEV void wv_sync() { wv_order(); }
 WV_DEV void wv_sync() { __syncthreads(); }
 #endif
 
+/* the wave's issue priority (s_setprio 0..3): a section in which one lane walks a dependent chain raises it, so that the chain's next instruction does not queue
+ * behind the other waves' parallel work (which fills the slots the chain leaves anyway) */
+#ifdef OA_SERIAL_PRIO
+WV_DEV void wv_prio_serial() { __builtin_amdgcn_s_setprio(OA_SERIAL_PRIO); }
+WV_DEV void wv_prio_normal() { __builtin_amdgcn_s_setprio(0); }
+#else
+WV_DEV void wv_prio_serial() {}
+WV_DEV void wv_prio_normal() {}
+#endif
+
 WV_DEV int32_t wv_shfl(int32_t v, int src) { return __shfl(v, src, 64); }
 /* src must be wave-uniform */
 WV_DEV int32_t wv_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }

@@ -64,6 +64,8 @@ static inline void emu_rendezvous(int kind = 0)
 }
 WV_DEV void wv_sync() { emu_rendezvous(); }
 WV_DEV void wv_order() { emu_rendezvous(); }
+WV_DEV void wv_prio_serial() {}
+WV_DEV void wv_prio_normal() {}
 /* publish (a,b,c,d) for this lane, rendezvous, return this op's table [64][4] */
 static inline int64_t (*emu_xchg(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0))[4]
 {
