@@ -65,8 +65,21 @@ WV_DEV int oa_queue_pop(unsigned *queue) { int s = 0; if (wv_lane() == 0) s = (i
 #ifndef OA_ENC_WAVES_PER_EU
 #define OA_ENC_WAVES_PER_EU 4
 #endif
-#define OA_SORT_KEYS 128          /* the order the PVQ kernel takes the cut frames in: see oa_celt_sort_kernel */
-WV_DEV int oa_cut_key(const WV_LDS FrameLds *F) { return (F->sh.shortBlocks ? 64 : 0) | (F->sh.dual_stereo ? 32 : 0) | imin(31, F->sh.nbCompressedBytes >> 4); }
+#ifndef OA_KEY_BYTES_SHIFT
+#define OA_KEY_BYTES_SHIFT 4      /* the byte budget in steps of 16 */
+#endif
+#ifndef OA_KEY_TRIM_BITS
+#define OA_KEY_TRIM_BITS 0
+#endif
+#define OA_KEY_BYTES_N (512 >> OA_KEY_BYTES_SHIFT)
+#define OA_SORT_KEYS (16 * (1 << OA_KEY_TRIM_BITS) * OA_KEY_BYTES_N)          /* the order the PVQ kernel takes the cut frames in: see oa_celt_sort_kernel */
+WV_DEV int oa_cut_key(const WV_LDS FrameLds *F)
+{
+   int k = (F->sh.shortBlocks ? 2 : 0) | (F->sh.dual_stereo ? 1 : 0);
+   k = k * 4 + (F->st.spread_decision & 3);
+   if (OA_KEY_TRIM_BITS) k = (k << OA_KEY_TRIM_BITS) + (imin(11, imax(0, F->sh.alloc_trim)) >> (4 - OA_KEY_TRIM_BITS));
+   return k * OA_KEY_BYTES_N + imin(OA_KEY_BYTES_N - 1, F->sh.nbCompressedBytes >> OA_KEY_BYTES_SHIFT);
+}
 template <bool NOPVQ> WV_DEV void oa_encode_kernel_body(OaStream *streams, const i16 *pcm, const i32 *apcm, int frame_size, int max_data_bytes, u8 *out, int out_stride, i32 *lens, u32 *rngs, int nstreams, CeltScratch *scratch, unsigned *queue,
       int pcm_row /* samples per channel of a stream's row of pcm / apcm: frame_size, or more when the caller hands the analysis a look-ahead */,
       int first, int stride /* the call's streams: first, first + stride, ... (nstreams of them; 0, 1: the first nstreams records) */,
@@ -103,21 +116,30 @@ extern "C" __global__ void __launch_bounds__(64, OA_ENC_WAVES_PER_EU) oa_encode_
 #endif
 extern "C" __global__ void __launch_bounds__(64, OA_FRONT_WAVES_PER_EU) oa_celt_front_kernel(OA_ENC_KERNEL_PARAMS) { oa_encode_kernel_body<true>(OA_ENC_KERNEL_ARGS); }
 /* The four streams of a PVQ wave go through their bands side by side: the more alike their band trees, the fewer instructions the wave spends on branches only some of them
- * take.  The frames that were cut are therefore handed to the PVQ kernel sorted by what shapes the tree -- block switching, dual stereo, the frame's byte budget -- with a
- * counting sort: the kernel that cuts a frame counts its key (srt[key]), oa_celt_sort_kernel places every list entry behind the keys below it (srt[128 + key] fills). */
+ * take.  The frames that were cut are therefore handed to the PVQ kernel sorted by what shapes the tree -- block switching, dual stereo, the spreading decision (which
+ * leaves are rotated), the frame's byte budget -- with a counting sort: the kernel that cuts a frame counts its key (srt[key]), oa_celt_sort_kernel places every list
+ * entry behind the keys below it (srt[OA_SORT_KEYS + key] fills). */
 extern "C" __global__ void __launch_bounds__(64)
 oa_celt_sort_kernel(const CeltCont *conts, const int *cut_list, int *order, const unsigned *queue, unsigned *srt)
 {
    const int n = (int)queue[1], lane = (int)threadIdx.x;
-   /* exclusive prefix of the 128 key counts, two per lane */
-   const i32 c0 = (i32)srt[2 * lane], c1 = (i32)srt[2 * lane + 1];
-   const i32 incl = wv_scan_incl(c0 + c1), base0 = incl - c0 - c1, base1 = base0 + c0;
+   /* exclusive prefix of the key counts, OA_SORT_KEYS / 64 consecutive keys per lane */
+   __shared__ i32 base[OA_SORT_KEYS];
+   {
+      const int per = OA_SORT_KEYS / 64;
+      i32 c[per], sum = 0;
+#pragma unroll
+      for (int u = 0; u < per; u++) { c[u] = (i32)srt[per * lane + u]; sum += c[u]; }
+      i32 run = wv_scan_incl(sum) - sum;
+#pragma unroll
+      for (int u = 0; u < per; u++) { base[per * lane + u] = run; run += c[u]; }
+      __syncthreads();
+   }
    for (int k0 = (int)blockIdx.x * 64; k0 < n; k0 += (int)gridDim.x * 64) {
       const int k = k0 + lane;
       int s = 0, key = 0;
       if (k < n) { s = cut_list[k]; key = conts[s].sort_key; }
-      const i32 b0 = wv_shfl(base0, key >> 1), b1 = wv_shfl(base1, key >> 1);          /* (from the lane that owns the key pair) */
-      if (k < n) order[(key & 1 ? b1 : b0) + (int)atomicAdd(srt + OA_SORT_KEYS + key, 1u)] = s;
+      if (k < n) order[base[key] + (int)atomicAdd(srt + OA_SORT_KEYS + key, 1u)] = s;
    }
 }
 /* the PVQ of the frames the encode kernel cut: four streams per wave, one 16-lane group each (celt_enc_pvq4.h) */
@@ -539,7 +561,10 @@ oa_sh_predb_kernel(OaShStream *streams, ShCont *conts, const int *list, const un
       __syncthreads();
    }
 }
-extern "C" __global__ void __launch_bounds__(64, 2)
+#ifndef OA_SH_QUANT_WAVES_PER_EU
+#define OA_SH_QUANT_WAVES_PER_EU 2
+#endif
+extern "C" __global__ void __launch_bounds__(64, OA_SH_QUANT_WAVES_PER_EU)
 oa_sh_quant_kernel(OaShStream *streams, ShCont *conts, int nstreams, char *scratch, unsigned *counters)
 {
    extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -707,7 +732,7 @@ struct OpusGpuEncBatch {
    int timing; int n_stamps; hipEvent_t stamp_ev[20]; const char *stamp_name[20];   /* OPUS_AMD_SET_KERNEL_TIMING: HIP events between the launches of the last call (opusgpu_enc_batch_kernel_times) */
    int pvq4_last;                                                           /* the last call launched oa_celt_pvq_kernel */
    ShBackHdr *d_back_hdr;                                                   /* SILK-capable batches: the back kernel's LDS header of the calls cut before their CELT pass's PVQ */
-   unsigned *d_srt;                                                         /* [128] key counts, [128] fill counters of the PVQ kernel's sorted order */
+   unsigned *d_srt;                                                         /* [OA_SORT_KEYS] key counts, [OA_SORT_KEYS] fill counters of the PVQ kernel's sorted order */
    CeltCont *d_ccont; int *d_cut_list; int celt_pipe_last /* streams of the last pipelined call, 0 = the last call was not pipelined */;                                       /* CELT-only batches, kernel pipeline: per-stream continuation records, the list of the streams whose call was cut before the PVQ */
    i32 *d_tr; i16 *d_tr_scratch; size_t tr_scratch_cap;                      /* CELT-only batches: the transient pre-pass's records [S][4] and its per-wave scratch */
    struct { const void *kernel; size_t lds; int per_cu; } occ[12];
