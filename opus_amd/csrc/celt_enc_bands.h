@@ -80,8 +80,9 @@ WV_DEV void band_energies_channel(WV_LDS FrameLds *L, const WV_LDS i32 *W, int c
 /* compute_mdcts (celt_encoder.c:511) + compute_band_energies (bands.c:95) + amp2Log2: one channel at a time through the LDS work buffer W -- B interleaved
  * transforms in place, the band energies while the channel is resident, then the channel goes out to the HBM spectrum g->X */
 /* normalise: the channel leaves LDS normalised (normalise_bands, bands.c:125, with the energies just taken) -- the spectrum is then written once instead of written,
- * read and written again; the caller passes 0 when the energies can still change before the normalisation (LFE) or the transform is not the frame's last word */
-WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks, WV_LDS i32 *bandLogE_out, int normalise = 0)
+ * read and written again; the caller passes 0 when the energies can still change before the normalisation (LFE) or the transform is not the frame's last word.
+ * xcut (with normalise): the frame will be cut in front of its bands -- the coded bins also go to the continuation record's X[2][OA_CODED_BINS] from the same registers */
+WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int shortBlocks, WV_LDS i32 *bandLogE_out, int normalise = 0, i32 *xcut = nullptr)
 {
    const int C = L->sh.C, CC = L->sh.CC, LM = L->sh.LM;
    CeltScratch *G = L->g;
@@ -121,6 +122,7 @@ WV_DEVN void compute_mdcts_wave(WV_LDS FrameLds *L, const OaEncState *gst, int s
             i32 v = W[i];
             if (i < nb) { const int bnd = ct_band_of[i >> LM]; v = pshr32(mult32_32_q31(L->scr[bnd], shl32(v, L->scr[NBE + bnd])), 30 - NORM_SHIFT); }
             G->X[cc * B * N + i] = v;
+            if (xcut && i < nb) xcut[cc * OA_CODED_BINS + i] = v;
          }
       } else { FOR_LANES(i, B * N) G->X[cc * B * N + i] = W[i]; }
       wv_sync();

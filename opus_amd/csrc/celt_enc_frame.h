@@ -48,12 +48,12 @@ WV_DEV int emit_packet_wave(WV_LDS FrameLds *L, u8 *out, int nbytes, int pad_to,
  * (celt_enc_pvq4.h); the back kernel reloads the image and runs the *_tail functions below.  cut == NULL: the whole frame here, as ever. */
 #define OA_CUT (-1000)
 template <bool HYB> WV_DEV void celt_encode_core_tail(WV_LDS FrameLds *L, OaEncState *gst);
-WV_DEV void celt_cut_dump(WV_LDS FrameLds *L, CeltCont *cut)
+WV_DEV void celt_cut_dump(WV_LDS FrameLds *L, CeltCont *cut, int x_stored /* the spectrum is in the record already (compute_mdcts_wave's xcut) */)
 {
    const int C = L->sh.C, N = L->sh.N, nb = L->sh.M * ct_eBands[L->sh.end];
    wv_sync();
    FOR_LANES(i, (int)(offsetof(FrameLds, BC) / 4)) cut->image[i] = ((const WV_LDS i32 *)L)[i];
-   for (int c = 0; c < C; c++) { const i32 *X = L->g->X + c * N; FOR_LANES(j, nb) cut->X[c][j] = X[j]; }
+   if (!x_stored) for (int c = 0; c < C; c++) { const i32 *X = L->g->X + c * N; FOR_LANES(j, nb) cut->X[c][j] = X[j]; }
    LANE0 cut->state = 1;
 }
 template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS FrameLds *L, OaEncState *gst, u8 *journal, const i32 *energy_mask = nullptr, const i32 *tr_pre = nullptr /* ct_transient_tile's record of the stream, or NULL */,
@@ -133,7 +133,8 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
 #else
    const int fuse_norm = !sh->lfe;                                    /* (LFE changes the energies first: normalise_bands_wave below) */
 #endif
-   compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm);
+   i32 *const xcut = fuse_norm && cut && LM >= 2 && sh->effEnd == end ? &cut->X[0][0] : nullptr;      /* (the record's rows hold the bins below eBands[end]; the normalisation covers those below eBands[effEnd]) */
+   compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm, xcut);
    if (CC == 2 && C == 1) { LANE0 sh->tf_chan = 0; }
    K_DUMPI("shortBlocks", sh->shortBlocks); K_DUMP("freq", L->g->X, C * N * 4); K_DUMP("bandE", L->bandE, 42 * 4); K_DUMP("bandLogE", L->bandLogE, 42 * 4);
    if (sh->lfe) {                    /* LFE: nothing but the first two bands carries energy (celt_encoder.c:2099-2107) */
@@ -195,7 +196,7 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
    if (sh->do_patch) {
       LANE0 { sh->isTransient = 1; sh->shortBlocks = M; }
       wv_sync();
-      compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm);
+      compute_mdcts_wave(L, gst, sh->shortBlocks, L->bandLogE, fuse_norm, xcut);
       FOR_LANES(w, C * NBE) { int c = w / NBE, i = w - c * NBE; if (i < end) L->bandLogE2[c * NBE + i] += half32(shl32(LM, DB_SHIFT)); }
       LANE0 sh->tf_estimate = QC16(.2f, 14);
       wv_sync();
@@ -402,7 +403,7 @@ template <bool HYB, bool NOPVQ = false> WV_DEV int celt_encode_core(WV_LDS Frame
 
    K_PHASE(12);
    /* ---- PVQ residual ---- */
-   if (cut && LM >= 2) { celt_cut_dump(L, cut); return OA_CUT; }                /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
+   if (cut && LM >= 2) { celt_cut_dump(L, cut, xcut != nullptr); return OA_CUT; }                /* (frames under 10 ms have bands of one and two coefficients: the four-streams-per-wave stage does not take those) */
    if constexpr (NOPVQ) return 0;                                               /* (the pipeline's front kernel: its calls are single frames of 10 / 20 ms, every frame that gets here is cut) */
    else {
    quant_all_bands_wave(L, sh->shortBlocks, st->spread_decision, sh->dual_stereo, st->intensity,

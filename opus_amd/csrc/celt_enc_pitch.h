@@ -429,7 +429,13 @@ WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16
 #define XA(k) pre_at(p, OA_MAX_PERIOD + (k))
    i32 sb = 0, sa = 0;
    if (g0 == 0 && g1 == 0) {
-      FOR_LANES(i, N) { const i32 v = XA(i); y[i] = v; sb += iabs(v >> 12); }
+      for (int i0 = wv_lane(); i0 < N; i0 += 8 * WV_WIDTH) {
+         i32 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) v[u] = XA(imin(i0 + u * WV_WIDTH, N - 1));
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int i = i0 + u * WV_WIDTH; if (i < N) { y[i] = v[u]; sb += iabs(v[u] >> 12); } }
+      }
       if (sums) { sb = wv_sum(sb); sums[0] += sb; sums[1] += sb; }
       return;
    }
@@ -438,29 +444,38 @@ WV_DEV void comb_filter_wave(i32 *y, const PreSrc &p, int T0, int T1, int N, i16
    i16 g00 = (i16)mult_coef_taps(g0, gains[tapset0][0]), g01 = (i16)mult_coef_taps(g0, gains[tapset0][1]), g02 = (i16)mult_coef_taps(g0, gains[tapset0][2]);
    i16 g10 = (i16)mult_coef_taps(g1, gains[tapset1][0]), g11 = (i16)mult_coef_taps(g1, gains[tapset1][1]), g12 = (i16)mult_coef_taps(g1, gains[tapset1][2]);
    if (g0 == g1 && T0 == T1 && tapset0 == tapset1) overlap = 0;
-   FOR_LANES(i, N) {
-      i32 v;
-      const i32 x0 = XA(i);
-      if (i < overlap) {
-         i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
-         v = x0;
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), XA(i - T0)));
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(XA(i - T0 + 1), XA(i - T0 - 1))));
-         v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(XA(i - T0 + 2), XA(i - T0 - 2))));
-         v = add32(v, mult_coef_32(mult_coef(f, g10), XA(i - T1)));
-         v = add32(v, mult_coef_32(mult_coef(f, g11), add32(XA(i - T1 + 1), XA(i - T1 - 1))));
-         v = add32(v, mult_coef_32(mult_coef(f, g12), add32(XA(i - T1 + 2), XA(i - T1 - 2))));
-         v = saturate(sub32(v, 3), SIG_SAT);
-      } else if (g1 == 0) {
-         v = x0;
-      } else {
-         /* (tap sets 1 and 2 have no outer taps: g12 == 0 contributes mult_coef_32(0, .) == 0 -- two loads less) */
-         const i32 outer = g12 != 0 ? mult_coef_32(g12, add32(XA(i - T1 + 2), XA(i - T1 - 2))) : 0;
-         v = add32(add32(add32(x0, mult_coef_32(g10, XA(i - T1))), mult_coef_32(g11, add32(XA(i - T1 + 1), XA(i - T1 - 1)))), outer);
-         v = saturate(sub32(v, 1), SIG_SAT);
+   const bool outer_on = g12 != 0;                               /* (tap sets 1 and 2 have no outer taps: g12 == 0 contributes mult_coef_32(0, .) == 0 -- two loads less) */
+   for (int i0 = wv_lane(); i0 < N; i0 += 4 * WV_WIDTH) {        /* four trips' taps are asked for together (a trip is a round trip to the scratch), then the arithmetic, then the stores */
+      i32 x0[4], c0[4], c1[4], c2[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const int i = imin(i0 + u * WV_WIDTH, N - 1);            /* (the clamped sample of a ragged last batch is loaded again and not stored) */
+         x0[u] = XA(i); c0[u] = XA(i - T1); c1[u] = add32(XA(i - T1 + 1), XA(i - T1 - 1));
+         c2[u] = outer_on ? add32(XA(i - T1 + 2), XA(i - T1 - 2)) : 0;
       }
-      y[i] = v;
-      sb += iabs(x0 >> 12); sa += iabs(v >> 12);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const int i = i0 + u * WV_WIDTH;
+         if (i < N) {
+            i32 v = x0[u];
+            if (i < overlap) {
+               i16 f = (i16)mult_coef(ct_window[i], ct_window[i]);
+               v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g00), XA(i - T0)));
+               v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g01), add32(XA(i - T0 + 1), XA(i - T0 - 1))));
+               v = add32(v, mult_coef_32(mult_coef((Q15ONE - f), g02), add32(XA(i - T0 + 2), XA(i - T0 - 2))));
+               v = add32(v, mult_coef_32(mult_coef(f, g10), c0[u]));
+               v = add32(v, mult_coef_32(mult_coef(f, g11), c1[u]));
+               v = add32(v, mult_coef_32(mult_coef(f, g12), c2[u]));
+               v = saturate(sub32(v, 3), SIG_SAT);
+            } else if (g1 != 0) {
+               const i32 outer = outer_on ? mult_coef_32(g12, c2[u]) : 0;
+               v = add32(add32(add32(v, mult_coef_32(g10, c0[u])), mult_coef_32(g11, c1[u])), outer);
+               v = saturate(sub32(v, 1), SIG_SAT);
+            }
+            y[i] = v;
+            sb += iabs(x0[u] >> 12); sa += iabs(v >> 12);
+         }
+      }
    }
    if (sums) { sums[0] += wv_sum(sb); sums[1] += wv_sum(sa); }
 #undef XA
@@ -542,7 +557,13 @@ WV_DEVN void run_prefilter_wave(WV_LDS FrameLds *L, OaEncState *gst, const PreSr
       wv_sync();
       for (int c = 0; c < CC; c++) {
          const PreSrc &ps = c ? ps1 : ps0;
-         FOR_LANES(i, N) G->in[c][i] = pre_at(ps, max_period + i);
+         for (int i0 = wv_lane(); i0 < N; i0 += 8 * WV_WIDTH) {
+            i32 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = pre_at(ps, max_period + imin(i0 + u * WV_WIDTH, N - 1));
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * WV_WIDTH; if (i < N) G->in[c][i] = v[u]; }
+         }
       }
       wv_sync();
       for (int c = 0; c < CC; c++)

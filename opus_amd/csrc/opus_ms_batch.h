@@ -230,6 +230,12 @@ oa_ms_budget_kernel(int s, int ns, int nc, int B, int Fs, int frame_size, int ma
       if (Fs / frame_size == 10) curr_max -= ns - s - 1;
       if (curr_max > OA_MS_FRAME_TMP) curr_max = OA_MS_FRAME_TMP;
       if (s != ns - 1) curr_max -= curr_max > 253 ? 2 : 1;
+      /* INVARIANT (hard CBR): the override below exists in the DEVICE record only -- the host mirror of the last stream (h_sh / h_streams) keeps the rate the surround
+       * allocation gave it.  That is sound because (1) every hard-CBR frame writes the value again before the last stream's kernels read it, (2) any ctl on the batch
+       * uploads the mirror over the record, after which (1) applies again, and (3) the reference leaves the same trace: its OPUS_SET_BITRATE on the last encoder is
+       * overwritten by the next frame's rate allocation (opus_multistream_encoder.c:1005-1030).  Between frames the two copies therefore differ: opusgpu_enc_batch_get answers configuration
+       * requests from the mirror (the allocated rate), export_state / copy_states move the device record (the overridden one, what OPUS_GET_BITRATE on the reference's last
+       * encoder reports between frames); no frame reads either before (1) has written it again. */
       if (cbr && s == ns - 1) {                                           /* OPUS_SET_BITRATE(bits_to_bitrate(curr_max * 8, Fs, frame_size)) on the last elementary encoder (opus_encoder.c ctl: <= 0 is refused, then 500 .. 750000 per channel) */
          i32 v = curr_max * 8 * (6 * Fs / frame_size) / 6;
          if (v > 0) { v = v <= 500 ? 500 : v > 750000 * last_channels ? 750000 * last_channels : v; *(i32 *)(last_rate + rate_first + (long long)b * rate_pitch) = v; }
