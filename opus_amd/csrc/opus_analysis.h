@@ -361,9 +361,12 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
    AN2_TOC(43);
    {  /* spectral variability (:755-775): the 8 x 8 distances between the stored log spectra, one lane per pair */
       const int i = lane >> 3, j = lane & 7;
-      float dist = 0;
+      float dist = 0, gi[AN_NB_TBANDS], gj[AN_NB_TBANDS];
+#pragma unroll
+      for (int k = 0; k < AN_NB_TBANDS; k++) { gi[k] = A->logE[i][k]; gj[k] = A->logE[j][k]; }      /* (the 36 stored values of the pair are asked for together; the sum keeps the reference's order) */
+#pragma unroll
       for (int k = 0; k < AN_NB_TBANDS; k++) {
-         const float li = i == E_count ? W->t.logE[k] : A->logE[i][k], lj = j == E_count ? W->t.logE[k] : A->logE[j][k];
+         const float li = i == E_count ? W->t.logE[k] : gi[k], lj = j == E_count ? W->t.logE[k] : gj[k];
          const float tmp = li - lj;
          dist += tmp * tmp;
       }
@@ -375,8 +378,15 @@ AN_FN void an_tonality_analysis_wave(WV_LDS AnLds *W, OaAnalysis *A, const i16 *
          W->t.mindist[lane] = mindist;
       }
       /* the cepstral sums (:861-875): BFCC on lanes 8..15, midE on lanes 16..23 */
-      if (lane >= 8 && lane < 16) { const int c = lane - 8; float sum = 0; for (int b = 0; b < 16; b++) sum += an_dct_table[c * 16 + b] * W->t.logE[b]; W->t.BFCC[c] = sum; }
-      if (lane >= 16 && lane < 24) { const int c = lane - 16; float sum = 0; for (int b = 0; b < 16; b++) sum += an_dct_table[c * 16 + b] * .5f * (A->highE[b] + A->lowE[b]); W->t.midE[c] = sum; }
+      if (lane >= 8 && lane < 24) {                               /* (one body for both: the table row and the band values in flight together) */
+         const int c = lane & 7; const bool mid = lane >= 16;
+         float tb[16], hv[16], lv[16], sum = 0;
+#pragma unroll
+         for (int b = 0; b < 16; b++) { tb[b] = an_dct_table[c * 16 + b]; hv[b] = A->highE[b]; lv[b] = A->lowE[b]; }
+#pragma unroll
+         for (int b = 0; b < 16; b++) sum += mid ? tb[b] * .5f * (hv[b] + lv[b]) : tb[b] * W->t.logE[b];
+         if (mid) W->t.midE[c] = sum; else W->t.BFCC[c] = sum;
+      }
    }
    AN2_TOC(44);
    /* ---- what chains across the bands: lane 0 ---- */
