@@ -155,7 +155,14 @@ WV_DEV void stage_coded_bins_wave(WV_LDS FrameLds *L)
    const int C = L->sh.C, N = L->sh.N, n = L->sh.M * ct_eBands[L->sh.effEnd];
    const i32 *X = L->g->X;
    wv_sync();
-   for (int c = 0; c < C; c++) FOR_LANES(j, n) L->BC.xs[c][j] = X[c * N + j];
+   for (int c = 0; c < C; c++)
+      for (int j0 = wv_lane(); j0 < n; j0 += 7 * WV_WIDTH) {       /* seven trips' bins in flight (800 bins: two batches) */
+         i32 v[7];
+#pragma unroll
+         for (int u = 0; u < 7; u++) v[u] = X[c * N + imin(j0 + u * WV_WIDTH, n - 1)];
+#pragma unroll
+         for (int u = 0; u < 7; u++) { const int j = j0 + u * WV_WIDTH; if (j < n) L->BC.xs[c][j] = v[u]; }
+      }
    wv_sync();
 }
 
@@ -340,7 +347,16 @@ WV_DEVN void tf_analysis_wave(WV_LDS FrameLds *L, int lambda)
    const i16 bias = (i16)mult16_16_q14(QC16(.04f, 15), imax(-QC16(.25f, 14), QC16(.5f, 14) - tf_estimate));
    const int units = ct_eBands[len], U = 1 << LM, sh14 = NORM_SHIFT - 14;
    wv_sync();
-   FOR_LANES(j, units << LM) tmp[j] = X[j];
+   {  /* seven trips' bins in flight */
+      const int n = units << LM;
+      for (int j0 = lane; j0 < n; j0 += 7 * WV_WIDTH) {
+         i32 v[7];
+#pragma unroll
+         for (int u = 0; u < 7; u++) v[u] = X[imin(j0 + u * WV_WIDTH, n - 1)];
+#pragma unroll
+         for (int u = 0; u < 7; u++) { const int j = j0 + u * WV_WIDTH; if (j < n) tmp[j] = v[u]; }
+      }
+   }
    wv_sync();
    /* this lane's band (lanes >= len idle in the per-band steps) */
    const int b = imin(lane, len - 1), b_lo = ct_eBands[b], b_hi = ct_eBands[b + 1], narrow = b_hi - b_lo == 1;

@@ -198,7 +198,18 @@ WV_DEVN void opus_layer_frame(WV_LDS FrameLds *L, const OaEncConfig *cfg, int fr
 WV_DEV void dc_reject_lanes(WV_LDS FrameLds *L, const i16 *pcm, int len, int channels)
 {
    WV_LDS i16 *io = L->BC.stage16;
-   FOR_LANES(i, len * channels) io[i] = pcm[i];
+   {  /* two samples per word, eight trips' words in flight (the caller's frames start on word boundaries: oa_maxabs_wave reads them the same way) */
+      const int n = len * channels, nw = n >> 1;
+      const u32 *pw = (const u32 *)pcm; WV_LDS u32 *iw = (WV_LDS u32 *)io;
+      for (int i0 = wv_lane(); i0 < nw; i0 += 8 * WV_WIDTH) {
+         u32 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) v[u] = pw[imin(i0 + u * WV_WIDTH, nw - 1)];
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int i = i0 + u * WV_WIDTH; if (i < nw) iw[i] = v[u]; }
+      }
+      if ((n & 1) && wv_lane() == 0) io[n - 1] = pcm[n - 1];
+   }
    wv_sync();
    int c = wv_lane();
    if (c < channels) {
@@ -347,11 +358,19 @@ WV_DEV void pre_stage_wave(i32 *xnew, const i16 *pcm, int CC, int N, i32 mem0, i
 {
    if (CC == 2 && up == 1) {           /* both channels of a sample in one word */
       const u32 *pw = (const u32 *)pcm;
-      FOR_LANES(i, N) {
-         const u32 cur = pw[i], prv = pw[i > 0 ? i - 1 : 0];
-         const i32 m0 = i == 0 ? mem0 : mult16_32_q15(27853, shl32((i32)(i16)prv, SIG_SHIFT)), m1 = i == 0 ? mem1 : mult16_32_q15(27853, shl32((i32)prv >> 16, SIG_SHIFT));
-         xnew[i] = shl32((i32)(i16)cur, SIG_SHIFT) - m0;
-         xnew[N + i] = shl32((i32)cur >> 16, SIG_SHIFT) - m1;
+      for (int i0 = wv_lane(); i0 < N; i0 += 4 * WV_WIDTH) {        /* four trips' samples in flight, then the stores */
+         u32 cur[4], prv[4];
+#pragma unroll
+         for (int u = 0; u < 4; u++) { const int i = imin(i0 + u * WV_WIDTH, N - 1); cur[u] = pw[i]; prv[u] = pw[i > 0 ? i - 1 : 0]; }
+#pragma unroll
+         for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * WV_WIDTH;
+            if (i < N) {
+               const i32 m0 = i == 0 ? mem0 : mult16_32_q15(27853, shl32((i32)(i16)prv[u], SIG_SHIFT)), m1 = i == 0 ? mem1 : mult16_32_q15(27853, shl32((i32)prv[u] >> 16, SIG_SHIFT));
+               xnew[i] = shl32((i32)(i16)cur[u], SIG_SHIFT) - m0;
+               xnew[N + i] = shl32((i32)cur[u] >> 16, SIG_SHIFT) - m1;
+            }
+         }
       }
    } else {
       for (int c = 0; c < CC; c++) { FOR_LANES(i, N) xnew[c * N + i] = pre_calc(pcm, CC, c, c ? mem1 : mem0, up, i); }
@@ -408,11 +427,19 @@ WV_DEVN void tone_detect_wave(WV_LDS FrameLds *L, const PreSrc &p0, const PreSrc
    WV_LDS i16 *x = L->BC.x16[0];
    const int j0 = OA_MAX_PERIOD - OA_OVERLAP;      /* in[c][i] == pre[c][1024 - overlap + i] */
    i32 ac0 = 0;
-   FOR_LANES(i, N) {
-      i32 a0 = pre_at(p0, j0 + i);
-      i16 v = CC == 2 ? (i16)pshr32(add32(a0 >> 1, pre_at(p1, j0 + i) >> 1), SIG_SHIFT + 2) : (i16)pshr32(a0, SIG_SHIFT + 2);
-      x[i] = v;
-      ac0 += mult16_16(v, v) >> 10;
+   for (int i0 = wv_lane(); i0 < N; i0 += 6 * WV_WIDTH) {           /* six trips' samples in flight (N = 1,080 at 20 ms: three batches) */
+      i32 a0[6], a1[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) { const int i = imin(i0 + u * WV_WIDTH, N - 1); a0[u] = pre_at(p0, j0 + i); a1[u] = CC == 2 ? pre_at(p1, j0 + i) : 0; }
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+         const int i = i0 + u * WV_WIDTH;
+         if (i < N) {
+            i16 v = CC == 2 ? (i16)pshr32(add32(a0[u] >> 1, a1[u] >> 1), SIG_SHIFT + 2) : (i16)pshr32(a0[u], SIG_SHIFT + 2);
+            x[i] = v;
+            ac0 += mult16_16(v, v) >> 10;
+         }
+      }
    }
    ac0 = add32(N, wv_sum(ac0));
    int shift = 5 - (28 - celt_ilog2(ac0)) / 2;

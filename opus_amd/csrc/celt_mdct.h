@@ -185,17 +185,20 @@ template <class BodyPtr> WV_DEV void mdct_forward_blocks(const i32 *head, BodyPt
       const int x0 = b * N2;
       WV_LDS i32 *f2 = fbuf + 2 * b * N4;
       i32 maxval = 1;
-      for (int i0 = lane; i0 < N4; i0 += 2 * WV_WIDTH) {        /* two points per trip: the loads of both ahead of the arithmetic of either */
-         i32 re[2], im[2]; int t0[2], t1[2], rv[2];
+      for (int i0 = lane; i0 < N4; i0 += 4 * WV_WIDTH) {        /* four points per trip (a long block's 240 in one): the loads of all ahead of the arithmetic of any */
+         i32 re[4], im[4]; int t0[4], t1[4], rv[4];
 #pragma unroll
-         for (int u = 0; u < 2; u++) {
-            const int i = imin(i0 + u * WV_WIDTH, N4 - 1);       /* (the clamped point of a ragged last trip is computed twice and stored once) */
-            const int p1 = x0 + (overlap >> 1) + 2 * i, p2 = x0 + N2 - 1 + (overlap >> 1) - 2 * i;
-            re[u] = XIN(p2); im[u] = XIN(p1);
-            t0[u] = trig[i]; t1[u] = trig[N4 + i]; rv[u] = bitrev[i];
+         for (int u = 0; u < 4; u++) {
+            re[u] = im[u] = 0; t0[u] = t1[u] = rv[u] = 0;
+            if (i0 - lane + u * WV_WIDTH < N4) {                  /* (wave-uniform: a short block's 30 points are one trip) */
+               const int i = imin(i0 + u * WV_WIDTH, N4 - 1);    /* (the clamped point of a ragged trip is loaded again and not stored) */
+               const int p1 = x0 + (overlap >> 1) + 2 * i, p2 = x0 + N2 - 1 + (overlap >> 1) - 2 * i;
+               re[u] = XIN(p2); im[u] = XIN(p1);
+               t0[u] = trig[i]; t1[u] = trig[N4 + i]; rv[u] = bitrev[i];
+            }
          }
 #pragma unroll
-         for (int u = 0; u < 2; u++) {
+         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * WV_WIDTH;
             if (i < N4) {
                const int p1 = x0 + (overlap >> 1) + 2 * i, p2 = x0 + N2 - 1 + (overlap >> 1) - 2 * i;
