@@ -18,6 +18,18 @@
 #define LANE0 for (int l0_ = (wv_sync(), wv_prio_serial(), 1); l0_; l0_ = (wv_prio_normal(), wv_sync(), 0)) if (wv_lane() == 0)
 #define FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += WV_WIDTH)
 #endif
+/* d[0 .. n) = s[0 .. n), lane-strided, eight trips' loads in flight before the first store: a trip of a plain lane loop over HBM is a round trip (the store of one trip
+ * keeps the next trip's load behind it), and a wave has four or five of those per stage to hide -- measured on the front kernels (profiles/r06_aq, r06_ar) */
+template <class PD, class PS> WV_DEV void wv_copy_batched(PD d, PS s, int n)
+{
+   for (int i0 = wv_lane(); i0 < n; i0 += 8 * WV_WIDTH) {
+      decltype(+s[0]) v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = s[i0 + u * WV_WIDTH < n ? i0 + u * WV_WIDTH : n - 1];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * WV_WIDTH; if (i < n) d[i] = v[u]; }
+   }
+}
 
 #define OA_AUTO (-1000)
 #define OA_BITRATE_MAX (-1)

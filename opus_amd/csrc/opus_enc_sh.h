@@ -136,6 +136,7 @@ WV_DEV void sh_compute_stereo_width_wave(WV_LDS ShLds *L, const i16 *pcm, int fr
 /* celt_maxabs16 of n int16 samples in HBM */
 WV_DEV i32 sh_maxabs_wave(const i16 *pcm, int n)
 {
+   if (!((size_t)pcm & 3) && !(n & 1)) return oa_maxabs_wave(pcm, n);      /* (two samples per word, eight trips in flight) */
    i32 m = 0;
    FOR_LANES(i, n) m = imax(m, iabs((i32)pcm[i]));
    return wv_max(m);
@@ -145,6 +146,7 @@ WV_DEV i32 sh_frame_energy_wave(const i16 *pcm, int len)
 {
    const i32 sample_max = sh_maxabs_wave(pcm, len);
    const int shift = imax(0, (celt_ilog2(1 + sample_max) << 1) + celt_ilog2(len) - 28);
+   if (!((size_t)pcm & 3) && !(len & 1)) return oa_frame_energy_wave(pcm, len, sample_max);
    i32 e = 0;
    FOR_LANES(i, len) e += mult16_16(pcm[i], pcm[i]) >> shift;
    e = wv_sum(e);
@@ -592,6 +594,14 @@ WV_DEV void sh_frame_front_wave(WV_LDS ShLds *L, OaShStream *gs, const i16 *pcm,
       for (int i0 = 0; i0 < frame_size; i0 += chunk) {
          const int n = imin(chunk, frame_size - i0);
          wv_sync();
+         if (!(((size_t)pcm | (size_t)pcm_hp) & 3) && !((i0 * CC | n * CC) & 1)) {           /* by words, eight trips in flight */
+            wv_copy_batched((WV_LDS u32 *)stage, (const u32 *)(pcm + i0 * CC), n * CC >> 1);
+            wv_sync();
+            sh_highpass_chunk(L, stage, n, CC, B_Q28, A_Q28);
+            wv_sync();
+            wv_copy_batched((u32 *)(pcm_hp + i0 * CC), (const WV_LDS u32 *)stage, n * CC >> 1);
+            continue;
+         }
          FOR_LANES(i, n * CC) stage[i] = pcm[i0 * CC + i];
          wv_sync();
          sh_highpass_chunk(L, stage, n, CC, B_Q28, A_Q28);

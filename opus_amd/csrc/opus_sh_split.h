@@ -58,7 +58,7 @@ WV_DEV void sh_front_decline(ShCont *ct, int *slow_list, unsigned *slow_count, i
    if (wv_lane() == 0) { ct->kind = SH_CONT_SLOW; slow_list[atomicAdd(slow_count, 1u)] = s; }
    wv_sync();
 }
-template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { FOR_LANES(i, n) d[i] = s[i]; }
+template <class PD, class PS> WV_DEV void sh_copy_words(PD d, PS s, int n) { wv_copy_batched(d, s, n); }
 /* One block of silk_Encode's loop (enc_API.c:283-560) in the front kernels: the block's input into the channels' buffers, the head of the frame, every coded channel up to its
  * quantiser job, the call's continuation record.  The first block of a call comes here from oa_sh_front_frame, the later ones of a 40 / 60 ms SILK packet from
  * oa_sh_front_cont_frame, after the quantiser kernel has coded the block before. */

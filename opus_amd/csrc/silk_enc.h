@@ -118,7 +118,13 @@ template <class InP> WV_DEV void se_resample_wave(WV_LDS i32 *cfgw, WV_LDS i32 *
    const int nd = c.inputDelay, lane = wv_lane();
    wv_sync();
    if (c.resampler_function == OA_RS_FN_COPY) {
-      FOR_LANES(k, inLen) out[k] = k < nd ? (i16)rows[OA_RS_ROW_DELAY + k] : (i16)in[k - nd];
+      for (int k0 = wv_lane(); k0 < inLen; k0 += 8 * WV_WIDTH) {                       /* (eight trips' input samples in flight) */
+         i16 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int k = imin(k0 + u * WV_WIDTH, inLen - 1); v[u] = k < nd ? (i16)rows[OA_RS_ROW_DELAY + k] : (i16)in[k - nd]; }
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int k = k0 + u * WV_WIDTH; if (k < inLen) out[k] = v[u]; }
+      }
       wv_sync();
       FOR_LANES(j, nd) rows[OA_RS_ROW_DELAY + j] = in[inLen - nd + j];
       wv_sync();
@@ -135,7 +141,13 @@ template <class InP> WV_DEV void se_resample_wave(WV_LDS i32 *cfgw, WV_LDS i32 *
       const int len = seg == 0 ? c.Fs_in_kHz : inLen - c.Fs_in_kHz;
       for (int done = 0; done < len;) {
          const int nIn = imin(len - done, c.batchSize);
-         FOR_LANES(k, nIn) { const int q = pos + k; Rb[ord + k] = q < nd ? rows[OA_RS_ROW_DELAY + q] : (i32)in[q - nd]; }
+         for (int k0 = wv_lane(); k0 < nIn; k0 += 8 * WV_WIDTH) {                     /* (eight trips' input samples in flight) */
+            i32 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int q = pos + imin(k0 + u * WV_WIDTH, nIn - 1); v[u] = q < nd ? rows[OA_RS_ROW_DELAY + q] : (i32)in[q - nd]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int k = k0 + u * WV_WIDTH; if (k < nIn) Rb[ord + k] = v[u]; }
+         }
          wv_sync();
          if (lane == 0) {                                                            /* silk_resampler_private_AR2 (resampler_private_AR2.c:36) */
             WV_LDS i32 *x = Rb + ord;

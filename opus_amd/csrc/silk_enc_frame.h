@@ -61,11 +61,11 @@ WV_DEV WV_LDS OaSilkEnc *se_st(WV_LDS SilkEncLds *S) { return (WV_LDS OaSilkEnc 
 /* the SILK state between the stream record and the wave's LDS (either direction): header + the channels in use, and their tails when the kernel holds them */
 template <class PD, class PS> WV_DEV void se_state_copy_wave(PD d, PS s, int channels, int with_tail)
 {
-   FOR_LANES(i, SE_STATE_LITE_WORDS(channels)) d[i] = s[i];
+   wv_copy_batched(d, s, SE_STATE_LITE_WORDS(channels));
    if (with_tail) {
       const int o = (int)(offsetof(OaSilkEnc, tail) / 4), b = (int)(offsetof(OaSilkEnc, inbuf) / 4);
-      FOR_LANES(i, channels * SE_INBUF_WORDS) d[b + i] = s[b + i];
-      FOR_LANES(i, channels * SE_TAIL_WORDS) d[o + i] = s[o + i];
+      wv_copy_batched(d + b, s + b, channels * SE_INBUF_WORDS);
+      wv_copy_batched(d + o, s + o, channels * SE_TAIL_WORDS);
    }
 }
 /* a channel's input buffer: in the staged state, or -- FRONT: the split path's front kernel, for which it is scratch between the resampler and the frame heads -- at the end of
@@ -435,7 +435,7 @@ WV_DEV void se_tap(WV_LDS OaSilkEncChannel *c, WV_LDS SeEncCtrl *ctl, int which,
 #endif
 
 /* ---- silk_encode_frame_FIX.  ec / packet buffer: the caller's (L->ec, buf) in LDS; returns nBytesOut through S->r[0] ---- */
-template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); FOR_LANES(i, n) d[i] = s[i]; wv_sync(); }
+template <class PD, class PS> WV_DEV void se_copy_words_wave(PD d, PS s, int n) { wv_sync(); wv_copy_batched(d, s, n); wv_sync(); }
 /* silk_encode_frame_FIX in four pieces, so that the stages between the analysis and the bookkeeping (the noise-shaping quantiser and the entropy coder: the rate-control
  * loop) can also run in a kernel of their own on a several-streams-per-wave layout (opus_sh_split.h); se_encode_frame_wave below strings them together for the one-kernel path.
  *   se_frame_head_wave      :98-128   seed, variable low-pass, the frame into x_buf
