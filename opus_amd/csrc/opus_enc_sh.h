@@ -465,16 +465,20 @@ WV_DEVN int sh_celt_run(WV_LDS ShLds *L, OaShStream *gs, const i16 *src, int nsa
    wv_sync();
    if (wv_lane() == 0) F->g = L->cs;               /* (the arena aliases the SILK working set: whatever SILK did since the last CELT pass may have overwritten the pointer) */
    wv_sync();
-   if (src) { i16 *dst = L->cs->pcm16; FOR_LANES(i, nsamp * CC) dst[i] = src[i]; }
+   if (src) { i16 *dst = L->cs->pcm16; const int n = nsamp * CC; if (!((size_t)src & 3) && !(n & 1)) wv_copy_batched((u32 *)dst, (const u32 *)src, n >> 1); else wv_copy_batched(dst, src, n); }
    if (!ctl.raw) { FOR_LANES(i, (OA_MAX_PACKET + 4) / 4) ((WV_LDS i32 *)F->packet)[i] = ((const WV_LDS i32 *)SH_PKT(L))[i]; }
    wv_sync();
    {  /* celt_maxabs over the head and the overlap tail of the input (celt_encoder.c:1970-1973), at the API rate */
       const i16 *p = L->cs->pcm16;
       const int ov = OA_OVERLAP / up;
       i32 a = 0, b = 0;
-      FOR_LANES(i, CC * (nsamp - ov)) a = imax(a, iabs((i32)p[i]));
-      FOR_LANES(i, CC * ov) b = imax(b, iabs((i32)p[CC * (nsamp - ov) + i]));
+      const int na = CC * (nsamp - ov), nb = CC * ov;
+      if (!((na | nb) & 1)) { a = na ? oa_maxabs_wave(p, na) : 0; b = oa_maxabs_wave(p + na, nb); }           /* (by words, eight trips in flight; pcm16 starts on a word) */
+      else {
+      FOR_LANES(i, na) a = imax(a, iabs((i32)p[i]));
+      FOR_LANES(i, nb) b = imax(b, iabs((i32)p[na + i]));
       a = wv_max(a); b = wv_max(b);
+      }
       LANE0 { fs->r[0] = a; fs->r[1] = b; }
    }
    LANE0 {
@@ -741,17 +745,30 @@ WV_DEV int sh_frame_back_wave(WV_LDS ShLds *L, OaShStream *gs, int frame_size, i
    /* pcm_buf = [delay tail | this frame] -> the CELT staging area (only when a CELT pass will read it), then the delay line moves on (:2304-2312) */
    if (need_celt) {
       i16 *io = L->cs->pcm16;
-      FOR_LANES(i, frame_size * CC) { const int n = i / CC, c = i - n * CC; io[i] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
+      for (int i0 = wv_lane(); i0 < frame_size * CC; i0 += 8 * WV_WIDTH) {                 /* (eight trips' samples in flight) */
+         i16 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int i = imin(i0 + u * WV_WIDTH, frame_size * CC - 1), n = i / CC, c = i - n * CC; v[u] = n < total_buffer ? gs->delay_buffer[(encoder_buffer - total_buffer + n) * CC + c] : pcm_hp[(n - total_buffer) * CC + c]; }
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int i = i0 + u * WV_WIDTH; if (i < frame_size * CC) io[i] = v[u]; }
+      }
       wv_sync();
    }
    if (application != OA_APP_RESTRICTED_SILK) {
-      /* new delay line = the last encoder_buffer samples of [old line | this frame]; ascending in place through registers, one 64-lane trip at a time */
-      for (int b0 = 0; b0 < encoder_buffer * CC; b0 += WV_WIDTH) {
-         const int i = b0 + wv_lane(), j = i + frame_size * CC;
-         i16 v = 0;
-         if (i < encoder_buffer * CC) v = j < encoder_buffer * CC ? gs->delay_buffer[j] : pcm_hp[j - encoder_buffer * CC];
+      /* new delay line = the last encoder_buffer samples of [old line | this frame]; ascending in place through registers, eight 64-lane trips at a time: a batch reads
+       * [b0 + F, b0 + F + 512) before it writes [b0, b0 + 512), and no later batch reads below b0 + 512 + F -- nothing is read after it was written */
+      const int EB = encoder_buffer * CC, F = frame_size * CC;
+      for (int b0 = 0; b0 < EB; b0 += 8 * WV_WIDTH) {
+         i16 v[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = b0 + u * WV_WIDTH + wv_lane(), j = i + F;
+            v[u] = 0;
+            if (i < EB) v[u] = j < EB ? gs->delay_buffer[j] : pcm_hp[j - EB];
+         }
          wv_sync();
-         if (i < encoder_buffer * CC) gs->delay_buffer[i] = v;
+#pragma unroll
+         for (int u = 0; u < 8; u++) { const int i = b0 + u * WV_WIDTH + wv_lane(); if (i < EB) gs->delay_buffer[i] = v[u]; }
          wv_sync();
       }
    }
