@@ -189,6 +189,87 @@ template <class InP> WV_DEV void se_resample_wave(WV_LDS i32 *cfgw, WV_LDS i32 *
    FOR_LANES(j, nd) rows[OA_RS_ROW_DELAY + j] = in[inLen - nd + j];
    wv_sync();
 }
+/* The two channels of a stereo input side by side (same rates, the down-FIR method): what se_resample_wave does per channel, with the second-order recursion -- the serial
+ * part, 960 steps per channel at 48 kHz -- on lane 0 for channel 0 and lane 1 for channel 1 at the same time, and the FIR of both channels in one lane loop.  Rb0 / Rb1:
+ * i32[36 + 480 + 4] each.  Returns 0 when the pair does not qualify (the caller runs the channels one after the other). */
+template <class InP> WV_DEV int se_resample2_wave(WV_LDS i32 *cfgw0, WV_LDS i32 *rows0, WV_LDS i32 *cfgw1, WV_LDS i32 *rows1, WV_LDS i32 *Rb0, WV_LDS i32 *Rb1,
+      WV_LDS i16 *out0, WV_LDS i16 *out1, InP in0, InP in1, int inLen)
+{
+   const OaResamplerCfg c = se_rs_cfg(cfgw0);
+   {
+      int same = c.resampler_function == OA_RS_FN_DOWN_FIR;
+      for (int i = 0; i < 9; i++) same &= cfgw0[i] == cfgw1[i];
+      if (!wv_uni(same)) return 0;
+   }
+   const int nd = c.inputDelay, lane = wv_lane(), ord = c.FIR_Order;
+   wv_sync();
+   const i16 *C = rs_coefs(c.coefs_id), *F = C + 2;
+   const i32 C0 = C[0], C1 = C[1], inv = c.invRatio_Q16;
+   WV_LDS i32 *const rows_l = lane == 1 ? rows1 : rows0;                             /* (lanes 0 and 1 carry a channel's recursion state) */
+   WV_LDS i32 *const Rb_l = lane == 1 ? Rb1 : Rb0;
+   i32 iir0 = rows_l[OA_RS_ROW_IIR], iir1 = rows_l[OA_RS_ROW_IIR + 1];
+   FOR_LANES(j, ord) { Rb0[j] = rows0[OA_RS_ROW_FIR + j]; Rb1[j] = rows1[OA_RS_ROW_FIR + j]; }
+   int pos = 0, no = 0;
+   for (int seg = 0; seg < 2; seg++) {
+      const int len = seg == 0 ? c.Fs_in_kHz : inLen - c.Fs_in_kHz;
+      for (int done = 0; done < len;) {
+         const int nIn = imin(len - done, c.batchSize);
+         for (int k0 = wv_lane(); k0 < nIn; k0 += 4 * WV_WIDTH) {                     /* (four trips' input samples of both channels in flight) */
+            i32 v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+               const int q = pos + imin(k0 + u * WV_WIDTH, nIn - 1);
+               v0[u] = q < nd ? rows0[OA_RS_ROW_DELAY + q] : (i32)in0[q - nd];
+               v1[u] = q < nd ? rows1[OA_RS_ROW_DELAY + q] : (i32)in1[q - nd];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * WV_WIDTH; if (k < nIn) { Rb0[ord + k] = v0[u]; Rb1[ord + k] = v1[u]; } }
+         }
+         wv_sync();
+         if (lane < 2) {                                                             /* silk_resampler_private_AR2 (resampler_private_AR2.c:36), a channel per lane */
+            WV_LDS i32 *x = Rb_l + ord;
+            int k = 0;
+            for (; k + 4 <= nIn; k += 4) {
+               const i32 s0 = x[k], s1 = x[k + 1], s2 = x[k + 2], s3 = x[k + 3];
+               i32 o;
+               o = iir0 + shl32(s0, 8); x[k] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s1, 8); x[k + 1] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s2, 8); x[k + 2] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+               o = iir0 + shl32(s3, 8); x[k + 3] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1);
+            }
+            for (; k < nIn; k++) { i32 o = iir0 + shl32(x[k], 8); x[k] = o; o = shl32(o, 2); iir0 = sk_mlawb(iir1, o, C0); iir1 = sk_mulwb(o, C1); }
+         }
+         wv_sync();
+         const int nOut = (int)((((i64)nIn << 16) + inv - 1) / inv);                   /* index_Q16 = 0, inv, 2 inv, ... < nIn << 16 */
+         FOR_LANES(jj, 2 * nOut) {
+            const int ch = jj >= nOut, j = ch ? jj - nOut : jj;
+            const WV_LDS i32 *Rb = ch ? Rb1 : Rb0;
+            const i32 idx = j * inv; const int b = idx >> 16;
+            i32 a;
+            if (ord == 18) {                                                          /* resampler_private_down_FIR.c:56-86 */
+               const int ph = sk_mulwb(idx & 0xFFFF, c.FIR_Fracs);
+               const i16 *c0 = &F[9 * ph], *c1 = &F[9 * (c.FIR_Fracs - 1 - ph)];
+               a = sk_mulwb(Rb[b], c0[0]);
+               for (int t = 1; t < 9; t++) a = sk_mlawb(a, Rb[b + t], c0[t]);
+               for (int t = 0; t < 9; t++) a = sk_mlawb(a, Rb[b + 17 - t], c1[t]);
+            } else {                                                                  /* :88-141, symmetric 24 / 36 taps */
+               a = sk_mulwb(Rb[b] + Rb[b + ord - 1], F[0]);
+               for (int t = 1; t < ord / 2; t++) a = sk_mlawb(a, Rb[b + t] + Rb[b + ord - 1 - t], F[t]);
+            }
+            (ch ? out1 : out0)[no + j] = (i16)sk_sat16(sk_rround(a, 6));
+         }
+         wv_sync();
+         { const i32 t0 = lane < ord ? Rb0[nIn + lane] : 0, t1 = lane < ord ? Rb1[nIn + lane] : 0; wv_sync(); if (lane < ord) { Rb0[lane] = t0; Rb1[lane] = t1; } wv_sync(); }   /* the tails become the heads of the next batch */
+         no += nOut; pos += nIn; done += nIn;
+      }
+   }
+   if (lane < 2) { rows_l[OA_RS_ROW_IIR] = iir0; rows_l[OA_RS_ROW_IIR + 1] = iir1; }
+   wv_sync();
+   FOR_LANES(j, ord) { rows0[OA_RS_ROW_FIR + j] = Rb0[j]; rows1[OA_RS_ROW_FIR + j] = Rb1[j]; }
+   FOR_LANES(j, nd) { rows0[OA_RS_ROW_DELAY + j] = in0[inLen - nd + j]; rows1[OA_RS_ROW_DELAY + j] = in1[inLen - nd + j]; }
+   wv_sync();
+   return 1;
+}
 
 /* ---- silk_setup_resamplers (control_codec.c:134): on a change of internal rate the buffered signal is carried over by resampling it up to the API
  * rate and down again.  tmp: i16[(2 * 20 + 5) * 48] scratch ---- */

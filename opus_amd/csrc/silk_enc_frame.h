@@ -715,8 +715,14 @@ template <int FRONT = 0> WV_DEV void se_call_buffer_wave(WV_LDS SilkEncLds *S, S
       const int ix1 = c1->inputBufIx;
       LANE0 { if (E->nPrevChannelsInternal == 1 && c0->nFramesEncoded == 0) { for (int i = 0; i < 9; i++) c1->rs_cfg[i] = c0->rs_cfg[i]; for (int i = 0; i < 90; i++) c1->rs_rows[i] = c0->rs_rows[i]; } }
       SePcmSrc s0 = {pcm, 2, 0, 0}, s1 = {pcm, 2, 1, 0};
+      /* both channels at once where the kernel's phase union has room for a second ring in front of the input buffers (the split path's front kernel: they sit at its end) */
+      int both = 0;
+      if (FRONT && sizeof(i32) * 2 * (36 + 480 + 4) + 2 * sizeof(int16_t) * (SE_MAX_FRAME + 2) <= SE_FRONT_U_BYTES)
+         both = se_resample2_wave(c0->rs_cfg, c0->rs_rows, c1->rs_cfg, c1->rs_rows, S->u.rs_ring, S->u.rs_ring + (36 + 480 + 4), &in0[ix0 + 2], &in1[ix1 + 2], s0, s1, nSamplesFromInput);
+      if (!both) {
       se_resample_wave(c0->rs_cfg, c0->rs_rows, &S->rs, S->u.rs_ring, &in0[ix0 + 2], s0, nSamplesFromInput);
       se_resample_wave(c1->rs_cfg, c1->rs_rows, &S->rs, S->u.rs_ring, &in1[ix1 + 2], s1, nSamplesFromInput);
+      }
       LANE0 { c0->inputBufIx += nSamplesToBuffer; c1->inputBufIx += imin(c1->frame_length - c1->inputBufIx, 10 * nBlocksOf10ms * c1->fs_kHz); }
    } else if (ec->nChannelsAPI == 2 && ec->nChannelsInternal == 1) {
       SePcmSrc sm = {pcm, 2, 0, 1};
