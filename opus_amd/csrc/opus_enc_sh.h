@@ -317,7 +317,23 @@ WV_DEV void sh_highpass_chunk(WV_LDS ShLds *L, WV_LDS i16 *io, int len, int chan
       if (L->sh.use_hp_cutoff) {
          const i32 A0_L = (-A_Q28[0]) & 0x3FFF, A0_U = (-A_Q28[0]) >> 14, A1_L = (-A_Q28[1]) & 0x3FFF, A1_U = (-A_Q28[1]) >> 14;
          i32 S0 = L->st.hp_mem[2 * c], S1 = L->st.hp_mem[2 * c + 1];
-         for (int k = 0; k < len; k++) {
+         int k = 0;
+         for (; k + 8 <= len; k += 8) {                  /* eight samples per trip: the LDS reads of a trip are issued back to back, only the chain through S0 / S1 is serial */
+            i32 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = io[(k + u) * channels + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+               const i32 inval = x[u];
+               const i32 out32_Q14 = shl32(sk_mlawb(S0, B_Q28[0], inval), 2);
+               S0 = S1 + sk_rround(sk_mulwb(out32_Q14, A0_L), 14); S0 = sk_mlawb(S0, out32_Q14, A0_U); S0 = sk_mlawb(S0, B_Q28[1], inval);
+               S1 = sk_rround(sk_mulwb(out32_Q14, A1_L), 14); S1 = sk_mlawb(S1, out32_Q14, A1_U); S1 = sk_mlawb(S1, B_Q28[2], inval);
+               x[u] = sk_sat16((out32_Q14 + (1 << 14) - 1) >> 14);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) io[(k + u) * channels + c] = (i16)x[u];
+         }
+         for (; k < len; k++) {
             const i32 inval = io[k * channels + c];
             const i32 out32_Q14 = shl32(sk_mlawb(S0, B_Q28[0], inval), 2);
             S0 = S1 + sk_rround(sk_mulwb(out32_Q14, A0_L), 14); S0 = sk_mlawb(S0, out32_Q14, A0_U); S0 = sk_mlawb(S0, B_Q28[1], inval);
@@ -328,7 +344,17 @@ WV_DEV void sh_highpass_chunk(WV_LDS ShLds *L, WV_LDS i16 *io, int len, int chan
       } else {
          const int shift = celt_ilog2(L->cfg.Fs / (3 * 4));
          i32 mem = L->st.hp_mem[2 * c];
-         for (int k = 0; k < len; k++) {
+         int k = 0;
+         for (; k + 8 <= len; k += 8) {
+            i32 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = shl32(saturate((i32)io[(k + u) * channels + c], (1 << 16) - 1), 14);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const i32 y = x[u] - mem; mem = mem + pshr32(y, shift); x[u] = saturate(pshr32(y, 14), 32767); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) io[(k + u) * channels + c] = (i16)x[u];
+         }
+         for (; k < len; k++) {
             const i32 x = shl32(saturate((i32)io[k * channels + c], (1 << 16) - 1), 14), y = x - mem;
             mem = mem + pshr32(y, shift);
             io[k * channels + c] = (i16)saturate(pshr32(y, 14), 32767);

@@ -373,7 +373,26 @@ WV_DEV void se_ana_filt_bank_1(const WV_LDS i16 *in, WV_LDS i32 *S, WV_LDS i16 *
 {
    const int N2 = N >> 1;
    i32 S0 = S[0], S1 = S[1];
-   for (int k = 0; k < N2; k++) {
+   int k = 0;
+   /* eight output pairs per trip: the sixteen LDS reads of a trip are issued back to back, then the two all-pass chains, then the stores (in place the low band lands on
+    * words the trip has already read, the high band on a region of its own: silk_VAD_GetSA_Q8's X_offset layout) */
+   for (; k + 8 <= N2; k += 8) {
+      i32 e[8], o[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { e[u] = shl32((i32)in[2 * (k + u)], 10); o[u] = shl32((i32)in[2 * (k + u) + 1], 10); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         i32 Y = sub32(e[u], S0), X = sk_mlawb(Y, Y, -24290);
+         const i32 out_1 = add32(S0, X); S0 = add32(e[u], X);
+         Y = sub32(o[u], S1); X = sk_mulwb(Y, 5394 << 1);
+         const i32 out_2 = add32(S1, X); S1 = add32(o[u], X);
+         e[u] = sk_sat16(sk_rround(add32(out_2, out_1), 11));
+         o[u] = sk_sat16(sk_rround(sub32(out_2, out_1), 11));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { outL[k + u] = (i16)e[u]; outH[k + u] = (i16)o[u]; }
+   }
+   for (; k < N2; k++) {
       i32 in32 = shl32((i32)in[2 * k], 10), Y = sub32(in32, S0), X = sk_mlawb(Y, Y, -24290);
       const i32 out_1 = add32(S0, X); S0 = add32(in32, X);
       in32 = shl32((i32)in[2 * k + 1], 10); Y = sub32(in32, S1); X = sk_mulwb(Y, 5394 << 1);
